@@ -1,0 +1,60 @@
+/*
+ * myslam_c.h -- C wrapper of the libmyslam-compatible host layer (rgbd_visualodometry_amd/host),
+ * so that Python (bench.py, tests) can drive the same FrontEnd::AddFrame loop that the
+ * reference's app/run_vo.cpp:89-117 drives.  One myslam_system = Camera + FrontEnd + Backend +
+ * its own MapManager, i.e. one independent RGB-D stream.
+ */
+#ifndef MYSLAM_C_H
+#define MYSLAM_C_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct myslam_system myslam_system;
+
+typedef struct myslam_options {
+    int32_t width, height;
+    float fx, fy, cx, cy, depth_scale;      /* camera.* keys of config/default.yaml */
+    int32_t number_of_features;             /* 500  */
+    float scale_factor;                     /* 1.2  */
+    int32_t level_pyramid;                  /* 8    */
+    float match_ratio;                      /* 2.0  */
+    int32_t max_num_lost;                   /* 10   */
+    int32_t min_inliers;                    /* 10   */
+    double keyframe_rotation, keyframe_translation;   /* 0.05, 0.05 */
+    int32_t enable_local_optimization;      /* 1    */
+    float chi2_th;                          /* 1    */
+    int32_t ransac_iterations;              /* 100 (frontend.cpp:240) */
+    int32_t max_frames_in_flight;           /* look-ahead ORB batch (1 = none) */
+    int32_t map_capacity;
+    int32_t device;
+    int32_t verbose;
+} myslam_options;
+
+typedef struct myslam_stats {
+    int32_t frames, keyframes, lost, state;         /* state: 0 INITIALIZING, 1 TRACKING, 2 LOST */
+    int32_t last_keypoints, last_candidates, last_matches, last_ransac_inliers, last_lm_inliers;
+    int32_t map_points;
+    int32_t ba_runs, ba_poses, ba_fixed, ba_points, ba_edges, ba_outliers;
+    double ba_ms;
+} myslam_stats;
+
+int myslam_default_options(myslam_options* o);
+/* yaml_path may be NULL; keys present in the file override `o` defaults, explicit `o` wins when yaml is NULL */
+int myslam_system_create(const myslam_options* o, const char* yaml_path, myslam_system** out);
+void myslam_system_destroy(myslam_system* s);
+/* Register the next n frames (host or device memory) and run batched ORB on them (look-ahead). */
+int myslam_prefetch(myslam_system* s, int n, const double* stamps, const void* const* bgr, const void* const* depth,
+                    int bgr_stride, int depth_stride, int on_device);
+/* AddFrame on the next prefetched frame, or on an explicit host/device frame if none is queued.
+ * tracked = return value of FrontEnd::AddFrame; T_wc = GetPose().inverse() as written by run_vo.cpp:116. */
+int myslam_add_frame(myslam_system* s, double stamp, const void* bgr, const void* depth, int bgr_stride, int depth_stride,
+                     int on_device, int* tracked, double T_wc[12]);
+int myslam_add_prefetched(myslam_system* s, int* tracked, double T_wc[12]);
+int myslam_get_stats(myslam_system* s, myslam_stats* st);
+const char* myslam_last_error(void);
+const char* myslam_backend_name(void);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,208 @@
+/*
+ * vo_hip.h -- C-ABI of the MI355X-native RGB-D visual-odometry hot path.
+ *
+ * This is the drop-in boundary.  The reference (BowenBZ/RGBD_VisualOdometry) has no
+ * FFI of its own: its hot path is private methods of myslam::FrontEnd / Backend that
+ * call OpenCV 3.1 / g2o directly.  The entry points below are cut exactly at those
+ * third-party seams; every one names the reference call site it replaces.
+ *
+ *   vo_orb_detect_describe  <- cv::ORB::detectAndCompute          src/frontend.cpp:35-37,:153
+ *   vo_match_active_map     <- Frame::IsCouldObserveMappoint loop  src/frontend.cpp:171-184, src/frame.cpp:70-91
+ *                              + cv::FlannBasedMatcher::match      src/frontend.cpp:33,:187-211
+ *   vo_pnp_ransac           <- cv::solvePnPRansac                  src/frontend.cpp:238-254
+ *   vo_pose_refine_lm       <- g2o pose-only LM (2 x 10 iters)     src/frontend.cpp:257-329, include/myslam/g2o_types.h:47-108
+ *   vo_track_frame          <- FrontEnd::TrackingHandler :102-108  (coarse + fine pass fused, one host sync)
+ *   vo_local_ba             <- Backend::Optimize                   src/backend.cpp:19-195, include/myslam/g2o_types.h:111-179
+ *   vo_frame_upload         <- Frame::CreateFrame deep copy        src/frame.cpp:18-31
+ *   vo_map_upsert/_set_active <- MapManager + trackingMap_         src/mapmanager.cpp:14-38, src/frontend.cpp:159-166
+ *
+ * Conventions: plain C, plain pointers and sizes.  Every function returns 0 (VO_OK) or a
+ * negative vo_status; nothing throws across the boundary.  The caller owns all host
+ * buffers; the context owns all device memory and one HIP stream.  One context per GPU
+ * stream of frames; a context is not thread-safe (single caller thread, like AddFrame).
+ * Poses are T_c_w (world -> camera) as 12 doubles: R row-major (9) then t (3).
+ *
+ * Two libraries export exactly these symbols: the product (libvo_hip.so, HIP/gfx950) and the
+ * CPU oracle used only by tests / the CPU baseline (oracle/_build/liboracle_vo.so).
+ */
+#ifndef VO_HIP_H
+#define VO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vo_ctx vo_ctx;
+
+typedef enum vo_status {
+    VO_OK = 0,
+    VO_E_INVALID = -1,      /* bad argument / out-of-range slot or index          */
+    VO_E_NOMEM = -2,        /* host or device allocation failed                    */
+    VO_E_DEVICE = -3,       /* HIP runtime error (no device, launch failure, ...)  */
+    VO_E_OVERFLOW = -4,     /* an internal fixed-capacity list overflowed          */
+    VO_E_STATE = -5,        /* call sequence error (e.g. match before ORB)         */
+    VO_E_UNSUPPORTED = -6
+} vo_status;
+
+/* Construction parameters.  Defaults mirror config/default.yaml:10-29 and the OpenCV-3.1
+ * cv::ORB defaults the reference relies on (edgeThreshold 31, patchSize 31, FAST 20). */
+typedef struct vo_params {
+    int32_t width, height;          /* level-0 image size                                  */
+    float fx, fy, cx, cy;           /* pinhole intrinsics, stored as float (camera.cpp:29-32) */
+    float depth_scale;              /* raw depth units per metre (5000)                    */
+    int32_t n_features;             /* number_of_features                                  */
+    float scale_factor;             /* 1.2                                                 */
+    int32_t n_levels;               /* 8                                                   */
+    int32_t fast_threshold;         /* 20                                                  */
+    int32_t edge_threshold;         /* 31                                                  */
+    int32_t max_frames;             /* frame slots (frames in flight for batched ORB), >=1 */
+    int32_t map_capacity;           /* device map capacity in points                        */
+    int32_t max_hypotheses;         /* RANSAC hypothesis capacity (>= n_hyp ever passed)    */
+    int32_t reserved[8];
+} vo_params;
+
+/* cv::KeyPoint's seven fields + the raw depth sample of Frame::GetDepth. */
+typedef struct vo_keypoint {
+    float x, y;             /* level-0 pixel coordinates (level coords * 1.2^octave)   */
+    float size;             /* 31 * 1.2^octave                                         */
+    float angle;            /* degrees [0,360)                                         */
+    float response;         /* Harris response                                         */
+    int32_t octave;         /* pyramid level                                           */
+    int32_t class_id;       /* -1                                                      */
+    int32_t depth_raw;      /* src/frame.cpp:43-67: raw u16 at (round x, round y) or the
+                               first non-zero of its 4 neighbours; 0 = no depth         */
+} vo_keypoint;
+
+typedef struct vo_match {
+    int32_t map_index;      /* device-map slot of the query map point                  */
+    int32_t kp_index;       /* index of the matched keypoint in the frame slot         */
+    int32_t distance;       /* Hamming distance 0..256                                 */
+    int32_t flags;          /* VO_MATCH_* bits, filled by vo_track_frame               */
+} vo_match;
+
+#define VO_MATCH_RANSAC_INLIER 1   /* in cv::solvePnPRansac's inlier list (frontend.cpp:242)   */
+#define VO_MATCH_LM_INLIER     2   /* chi2 <= 1 after the second LM round (frontend.cpp:317-329) */
+
+#define VO_MAP_FLAG_OUTLIER 1      /* Mappoint::outlier_ */
+
+typedef struct vo_track_params {
+    float match_ratio;          /* match_ratio 2.0 (default.yaml:21)            */
+    float match_floor;          /* 30.0 (frontend.cpp:196)                      */
+    int32_t n_hyp;              /* RANSAC iterations cap, 100 (frontend.cpp:240) */
+    float reproj_px;            /* 4.0                                          */
+    float confidence;           /* 0.99                                         */
+    uint64_t seed;              /* hypothesis sampler seed                       */
+    double huber_delta;         /* sqrt(7.815) (frontend.cpp:282)               */
+    double chi2_cut;            /* 1.0 (frontend.cpp:300,:322)                  */
+    int32_t it_robust, it_plain;/* 10, 10 (frontend.cpp:291,:310)               */
+    int32_t passes;             /* 2 = coarse + fine (frontend.cpp:102-108)     */
+    int32_t reserved[5];
+} vo_track_params;
+
+typedef struct vo_track_result {
+    double T_cw[12];            /* refined pose                                               */
+    int32_t n_candidates;       /* map points that passed the frustum/view-angle filter       */
+    int32_t n_matches;          /* pairs that passed the distance gate                        */
+    int32_t n_ransac_inliers;   /* numInliers_ (frontend.cpp:242)                              */
+    int32_t n_lm_inliers;       /* |pnpMatchedMptSet_|                                         */
+    int32_t min_distance;       /* min_dis (frontend.cpp:190-195), -1 if no match              */
+    int32_t ransac_iters;       /* hypotheses actually consumed by the adaptive stop           */
+    int32_t best_hypothesis;    /* index of the winning hypothesis, -1 if none                  */
+    int32_t lm_iters;           /* LM outer iterations executed (both rounds)                   */
+    int32_t status;             /* VO_OK or VO_E_OVERFLOW raised inside the device pipeline     */
+    int32_t reserved[7];
+} vo_track_result;
+
+/* Local bundle adjustment problem (flattened covisibility graph, built by the host). */
+typedef struct vo_ba_problem {
+    int32_t n_poses;            /* free poses first, then fixed ones */
+    int32_t n_free;
+    int32_t n_points;
+    int32_t n_edges;
+    const double* poses;        /* n_poses x 12 */
+    const double* points;       /* n_points x 3 */
+    const int32_t* edge_pose;   /* n_edges */
+    const int32_t* edge_point;  /* n_edges */
+    const float* edge_uv;       /* n_edges x 2, observed pixel (Point2f) */
+    double huber_delta;         /* sqrt(7.815) backend.cpp:83 */
+    double chi2_th;             /* chi2_th backend.h:24 */
+    int32_t it_robust, it_plain;/* 10, 10 backend.cpp:141,:159 */
+} vo_ba_problem;
+
+typedef struct vo_ba_result {
+    double* poses;              /* n_free x 12, caller allocated */
+    double* points;             /* n_points x 3, caller allocated */
+    uint8_t* edge_flags;        /* n_edges: bit0 culled after round 1 (backend.cpp:147-152),
+                                   bit1 chi2 > th after round 2 at level 0 (:165-170)        */
+    double chi2_initial, chi2_final;
+    int32_t lm_iters;
+    int32_t reserved[3];
+} vo_ba_result;
+
+/* ---- lifetime ---------------------------------------------------------------------- */
+int vo_ctx_create(const vo_params* p, int device, vo_ctx** out);
+void vo_ctx_destroy(vo_ctx* ctx);
+const char* vo_strerror(int status);
+const char* vo_backend_name(void);          /* "hip-gfx950" or "cpu-oracle" */
+int vo_default_params(vo_params* p);        /* fills default.yaml + TUM fr1 values */
+int vo_default_track_params(vo_track_params* tp);
+
+/* ---- frames ------------------------------------------------------------------------ */
+/* Copy a BGR8 + depth16 frame from host memory into frame slot `slot` (strides in bytes). */
+int vo_frame_upload(vo_ctx* ctx, int slot, const uint8_t* bgr, int bgr_stride,
+                    const uint16_t* depth, int depth_stride);
+/* Use frames already resident in device memory (no copy; pointers must stay valid until the
+ * slot is rebound).  For the CPU oracle these are ordinary host pointers. */
+int vo_frame_bind_device(vo_ctx* ctx, int slot, const void* d_bgr, int bgr_stride,
+                         const void* d_depth, int depth_stride);
+
+/* ---- ORB --------------------------------------------------------------------------- */
+/* Detect + describe on slots [slot0, slot0+nslots) in one batched launch chain (asynchronous
+ * on the context's stream; results stay on the device). */
+int vo_orb_detect_describe(vo_ctx* ctx, int slot0, int nslots);
+/* Download slot results: up to `cap` keypoints and cap x 32 descriptor bytes. */
+int vo_orb_fetch(vo_ctx* ctx, int slot, vo_keypoint* kps, uint8_t* desc, int cap, int* n_out);
+/* Debug/parity taps: pyramid level image (gray u8, tightly packed w*h) and its size. */
+int vo_orb_level_size(vo_ctx* ctx, int level, int* w, int* h, int* quota);
+int vo_orb_fetch_level(vo_ctx* ctx, int slot, int level, uint8_t* gray_out);
+
+/* ---- map ---------------------------------------------------------------------------- */
+/* Insert or overwrite map points at device-map slots idx[i] (0 <= idx < map_capacity). */
+int vo_map_upsert(vo_ctx* ctx, const int32_t* idx, const double* xyz, const double* normal,
+                  const uint8_t* desc, const uint8_t* flags, int n);
+/* Define the tracking map: the ordered list of device-map slots matched against. */
+int vo_map_set_active(vo_ctx* ctx, const int32_t* idx, int n);
+
+/* ---- per-stage entry points (parity tests, and callers that want the seams) ---------- */
+int vo_match_active_map(vo_ctx* ctx, int slot, const double T_cw[12], float ratio, float floor_dist,
+                        vo_match* out, int cap, int* n_out, int* n_candidates, int* min_distance);
+/* Replace the context's current correspondence set by an explicit one (3-D points as the
+ * float32 the reference casts to at frontend.cpp:228, pixels as Point2f). */
+int vo_matches_set(vo_ctx* ctx, const float* xyz, const float* uv, int n);
+int vo_pnp_ransac(vo_ctx* ctx, int n_hyp, float reproj_px, float confidence, uint64_t seed,
+                  double T_cw_inout[12], int32_t* inliers, int cap, int* n_inliers,
+                  int32_t* hyp_counts /* optional, n_hyp entries */, int* iters_used, int* best_hyp);
+int vo_pose_refine_lm(vo_ctx* ctx, double T_cw_inout[12], double huber_delta, double chi2_cut,
+                      int it_robust, int it_plain, uint8_t* inlier_mask /* one per RANSAC inlier */,
+                      int cap, int* n_edges, int* lm_iters);
+
+/* ---- fused per-frame tracking ------------------------------------------------------- */
+int vo_track_frame(vo_ctx* ctx, int slot, const double T_cw_prior[12], const vo_track_params* tp,
+                   vo_track_result* res, vo_match* matches, int cap);
+
+/* ---- local bundle adjustment --------------------------------------------------------- */
+int vo_local_ba(vo_ctx* ctx, const vo_ba_problem* in, vo_ba_result* out);
+
+/* ---- plumbing ------------------------------------------------------------------------- */
+int vo_sync(vo_ctx* ctx);
+/* Per-kernel accumulated device time measured with HIP events on the context's stream
+ * (enabled by vo_profile_enable).  names/ms/calls are caller arrays of `cap` entries. */
+int vo_profile_enable(vo_ctx* ctx, int on);
+int vo_profile_read(vo_ctx* ctx, char (*names)[48], double* ms, int64_t* calls, int cap, int* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VO_HIP_H */

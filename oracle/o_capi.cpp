@@ -1,0 +1,259 @@
+// ORACLE -- test infrastructure, NOT the product (see o_math.h header).
+// o_capi.cpp: the C-ABI of include/vo_hip.h implemented on the CPU by the restatement above.
+// Built into oracle/_build/liboracle_vo.so; loaded only by tests/, smoke() and bench.py's
+// cpu_baseline leg.  Same symbols as the HIP product library so that the same host code
+// (rgbd_visualodometry_amd/host) and the same tests drive either side of the boundary.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../include/vo_hip.h"
+#include "o_orb.h"
+#include "o_track.h"
+
+using namespace orc;
+
+struct vo_ctx {
+    vo_params p;
+    OrbPlan plan;
+    Cam cam;
+    struct Slot {
+        std::vector<uint8_t> bgr; std::vector<uint16_t> depth;     // owned copies (upload)
+        const uint8_t* bgr_p = nullptr; const uint16_t* depth_p = nullptr; int bstride = 0, dstride = 0;
+        std::vector<vo_keypoint> kps; std::vector<uint8_t> desc; std::vector<OrbLevelDebug> dbg; bool has_orb = false;
+    };
+    std::vector<Slot> slots;
+    MapStore map;
+    Corr corr; std::vector<vo_match> last_matches;
+    std::vector<int32_t> ransac_inliers;
+};
+
+extern "C" {
+
+const char* vo_backend_name(void) { return "cpu-oracle"; }
+
+const char* vo_strerror(int s) {
+    switch (s) {
+        case VO_OK: return "ok"; case VO_E_INVALID: return "invalid argument"; case VO_E_NOMEM: return "out of memory";
+        case VO_E_DEVICE: return "device error"; case VO_E_OVERFLOW: return "capacity overflow"; case VO_E_STATE: return "bad call sequence";
+        case VO_E_UNSUPPORTED: return "unsupported"; default: return "unknown";
+    }
+}
+
+int vo_default_params(vo_params* p) {
+    if (!p) return VO_E_INVALID;
+    std::memset(p, 0, sizeof(*p));
+    p->width = 640; p->height = 480; p->fx = 517.3f; p->fy = 516.5f; p->cx = 318.6f; p->cy = 255.3f; p->depth_scale = 5000.f;
+    p->n_features = 500; p->scale_factor = 1.2f; p->n_levels = 8; p->fast_threshold = 20; p->edge_threshold = 31;
+    p->max_frames = 1; p->map_capacity = 1 << 18; p->max_hypotheses = 2048;
+    return VO_OK;
+}
+
+int vo_default_track_params(vo_track_params* t) {
+    if (!t) return VO_E_INVALID;
+    std::memset(t, 0, sizeof(*t));
+    t->match_ratio = 2.0f; t->match_floor = 30.0f; t->n_hyp = 100; t->reproj_px = 4.0f; t->confidence = 0.99f; t->seed = 0x5eed5eedull;
+    t->huber_delta = std::sqrt(7.815); t->chi2_cut = 1.0; t->it_robust = 10; t->it_plain = 10; t->passes = 2;
+    return VO_OK;
+}
+
+int vo_ctx_create(const vo_params* p, int, vo_ctx** out) {
+    if (!p || !out || p->width < 64 || p->height < 64 || p->n_levels < 1 || p->n_levels > 16 || p->max_frames < 1 ||
+        p->n_features < 1 || !(p->scale_factor > 1.0f) || p->map_capacity < 1) return VO_E_INVALID;
+    vo_ctx* c = new (std::nothrow) vo_ctx();
+    if (!c) return VO_E_NOMEM;
+    c->p = *p;
+    orb_build_plan(*p, c->plan);
+    c->cam = {(double)p->fx, (double)p->fy, (double)p->cx, (double)p->cy, p->width, p->height};
+    c->slots.resize(p->max_frames);
+    c->map.pos.assign((size_t)3 * p->map_capacity, 0.0); c->map.nrm.assign((size_t)3 * p->map_capacity, 0.0);
+    c->map.desc.assign((size_t)32 * p->map_capacity, 0); c->map.flags.assign(p->map_capacity, 0);
+    *out = c;
+    return VO_OK;
+}
+void vo_ctx_destroy(vo_ctx* c) { delete c; }
+
+int vo_frame_upload(vo_ctx* c, int slot, const uint8_t* bgr, int bs, const uint16_t* depth, int ds) {
+    if (!c || slot < 0 || slot >= (int)c->slots.size() || !bgr || !depth || bs < 3 * c->p.width || ds < 2 * c->p.width) return VO_E_INVALID;
+    auto& s = c->slots[slot];
+    int W = c->p.width, H = c->p.height;
+    s.bgr.resize((size_t)3 * W * H); s.depth.resize((size_t)W * H);
+    for (int y = 0; y < H; ++y) {
+        std::memcpy(&s.bgr[(size_t)3 * W * y], bgr + (size_t)bs * y, 3 * W);
+        std::memcpy(&s.depth[(size_t)W * y], (const uint8_t*)depth + (size_t)ds * y, 2 * W);
+    }
+    s.bgr_p = s.bgr.data(); s.depth_p = s.depth.data(); s.bstride = 3 * W; s.dstride = 2 * W; s.has_orb = false;
+    return VO_OK;
+}
+
+int vo_frame_bind_device(vo_ctx* c, int slot, const void* b, int bs, const void* d, int ds) {
+    if (!c || slot < 0 || slot >= (int)c->slots.size() || !b || !d || bs < 3 * c->p.width || ds < 2 * c->p.width) return VO_E_INVALID;
+    auto& s = c->slots[slot];
+    s.bgr_p = (const uint8_t*)b; s.depth_p = (const uint16_t*)d; s.bstride = bs; s.dstride = ds; s.has_orb = false;
+    return VO_OK;
+}
+
+int vo_orb_detect_describe(vo_ctx* c, int slot0, int n) {
+    if (!c || slot0 < 0 || n < 1 || slot0 + n > (int)c->slots.size()) return VO_E_INVALID;
+    for (int i = slot0; i < slot0 + n; ++i) {
+        auto& s = c->slots[i];
+        if (!s.bgr_p) return VO_E_STATE;
+        orb_detect_describe(c->plan, s.bgr_p, s.bstride, s.depth_p, s.dstride, s.kps, s.desc, &s.dbg);
+        s.has_orb = true;
+    }
+    return VO_OK;
+}
+
+int vo_orb_fetch(vo_ctx* c, int slot, vo_keypoint* kps, uint8_t* desc, int cap, int* n_out) {
+    if (!c || slot < 0 || slot >= (int)c->slots.size() || !n_out) return VO_E_INVALID;
+    auto& s = c->slots[slot];
+    if (!s.has_orb) return VO_E_STATE;
+    int n = std::min<int>(cap, (int)s.kps.size());
+    if (kps) std::memcpy(kps, s.kps.data(), sizeof(vo_keypoint) * n);
+    if (desc) std::memcpy(desc, s.desc.data(), (size_t)32 * n);
+    *n_out = (int)s.kps.size();
+    return VO_OK;
+}
+
+int vo_orb_level_size(vo_ctx* c, int l, int* w, int* h, int* quota) {
+    if (!c || l < 0 || l >= c->plan.nlevels) return VO_E_INVALID;
+    if (w) *w = c->plan.lw[l];
+    if (h) *h = c->plan.lh[l];
+    if (quota) *quota = c->plan.quota[l];
+    return VO_OK;
+}
+
+int vo_orb_fetch_level(vo_ctx* c, int slot, int l, uint8_t* out) {
+    if (!c || slot < 0 || slot >= (int)c->slots.size() || l < 0 || l >= c->plan.nlevels || !out) return VO_E_INVALID;
+    auto& s = c->slots[slot];
+    if (!s.has_orb) return VO_E_STATE;
+    std::memcpy(out, s.dbg[l].gray.data(), s.dbg[l].gray.size());
+    return VO_OK;
+}
+
+int vo_map_upsert(vo_ctx* c, const int32_t* idx, const double* xyz, const double* nrm, const uint8_t* desc, const uint8_t* flags, int n) {
+    if (!c || n < 0 || (n && !idx)) return VO_E_INVALID;
+    for (int i = 0; i < n; ++i) if (idx[i] < 0 || idx[i] >= c->p.map_capacity) return VO_E_INVALID;
+    for (int i = 0; i < n; ++i) {
+        size_t k = idx[i];
+        if (xyz) std::memcpy(&c->map.pos[3 * k], xyz + 3 * (size_t)i, 24);
+        if (nrm) std::memcpy(&c->map.nrm[3 * k], nrm + 3 * (size_t)i, 24);
+        if (desc) std::memcpy(&c->map.desc[32 * k], desc + 32 * (size_t)i, 32);
+        if (flags) c->map.flags[k] = flags[i];
+    }
+    return VO_OK;
+}
+
+int vo_map_set_active(vo_ctx* c, const int32_t* idx, int n) {
+    if (!c || n < 0 || (n && !idx)) return VO_E_INVALID;
+    for (int i = 0; i < n; ++i) if (idx[i] < 0 || idx[i] >= c->p.map_capacity) return VO_E_INVALID;
+    c->map.active.assign(idx, idx + n);
+    return VO_OK;
+}
+
+static void corr_from_matches(vo_ctx* c, int slot) {
+    auto& s = c->slots[slot];
+    c->corr.n = (int)c->last_matches.size();
+    c->corr.xyz.resize((size_t)3 * c->corr.n); c->corr.uv.resize((size_t)2 * c->corr.n);
+    for (int i = 0; i < c->corr.n; ++i) {
+        const vo_match& m = c->last_matches[i];
+        for (int a = 0; a < 3; ++a) c->corr.xyz[3 * i + a] = (float)c->map.pos[3 * (size_t)m.map_index + a];   // frontend.cpp:228
+        c->corr.uv[2 * i] = s.kps[m.kp_index].x; c->corr.uv[2 * i + 1] = s.kps[m.kp_index].y;                  // frontend.cpp:229
+    }
+}
+
+int vo_match_active_map(vo_ctx* c, int slot, const double T[12], float ratio, float floor_dist, vo_match* out, int cap,
+                        int* n_out, int* n_cand, int* min_distance) {
+    if (!c || slot < 0 || slot >= (int)c->slots.size() || !T) return VO_E_INVALID;
+    auto& s = c->slots[slot];
+    if (!s.has_orb) return VO_E_STATE;
+    int nc = 0, md = -1;
+    match_active(c->cam, c->map, SE3::from12(T), s.desc.data(), (int)s.kps.size(), ratio, floor_dist, c->last_matches, nc, md);
+    corr_from_matches(c, slot);
+    c->ransac_inliers.clear();
+    if (out) std::memcpy(out, c->last_matches.data(), sizeof(vo_match) * std::min<int>(cap, (int)c->last_matches.size()));
+    if (n_out) *n_out = (int)c->last_matches.size();
+    if (n_cand) *n_cand = nc;
+    if (min_distance) *min_distance = md;
+    return VO_OK;
+}
+
+int vo_matches_set(vo_ctx* c, const float* xyz, const float* uv, int n) {
+    if (!c || n < 0 || (n && (!xyz || !uv))) return VO_E_INVALID;
+    c->corr.n = n; c->corr.xyz.assign(xyz, xyz + 3 * (size_t)n); c->corr.uv.assign(uv, uv + 2 * (size_t)n);
+    c->last_matches.clear(); c->ransac_inliers.clear();
+    return VO_OK;
+}
+
+int vo_pnp_ransac(vo_ctx* c, int n_hyp, float reproj_px, float conf, uint64_t seed, double T[12], int32_t* inl, int cap,
+                  int* n_inl, int32_t* hyp_counts, int* iters_used, int* best_hyp) {
+    if (!c || !T || n_hyp < 1 || n_hyp > c->p.max_hypotheses) return VO_E_INVALID;
+    RansacOut r;
+    pnp_ransac(c->cam, c->corr, n_hyp, reproj_px, conf, seed, SE3::from12(T), r);
+    r.T.to12(T);
+    c->ransac_inliers = r.inliers;
+    if (inl) std::memcpy(inl, r.inliers.data(), 4 * std::min<size_t>(cap, r.inliers.size()));
+    if (n_inl) *n_inl = (int)r.inliers.size();
+    if (hyp_counts) std::memcpy(hyp_counts, r.hyp_counts.data(), 4 * (size_t)n_hyp);
+    if (iters_used) *iters_used = r.iters_used;
+    if (best_hyp) *best_hyp = r.best;
+    return VO_OK;
+}
+
+int vo_pose_refine_lm(vo_ctx* c, double T[12], double delta, double cut, int it_r, int it_p, uint8_t* mask, int cap,
+                      int* n_edges, int* lm_iters) {
+    if (!c || !T) return VO_E_INVALID;
+    LmOut o;
+    pose_lm(c->cam, c->corr, c->ransac_inliers, SE3::from12(T), delta, cut, it_r, it_p, o);
+    o.T.to12(T);
+    if (mask) std::memcpy(mask, o.inlier_mask.data(), std::min<size_t>(cap, o.inlier_mask.size()));
+    if (n_edges) *n_edges = (int)o.inlier_mask.size();
+    if (lm_iters) *lm_iters = o.iters;
+    return VO_OK;
+}
+
+int vo_track_frame(vo_ctx* c, int slot, const double T0[12], const vo_track_params* tp, vo_track_result* res,
+                   vo_match* matches, int cap) {
+    if (!c || !T0 || !tp || !res || slot < 0 || slot >= (int)c->slots.size() || tp->passes < 1) return VO_E_INVALID;
+    if (!c->slots[slot].has_orb) return VO_E_STATE;
+    std::memset(res, 0, sizeof(*res));
+    double T[12];
+    std::memcpy(T, T0, sizeof(T));
+    for (int pass = 0; pass < tp->passes; ++pass) {           // coarse, fine (frontend.cpp:100-108)
+        int nm = 0, nc = 0, md = -1, ni = 0, iu = 0, bh = -1, ne = 0, li = 0;
+        int rc = vo_match_active_map(c, slot, T, tp->match_ratio, tp->match_floor, nullptr, 0, &nm, &nc, &md);
+        if (rc) return rc;
+        rc = vo_pnp_ransac(c, tp->n_hyp, tp->reproj_px, tp->confidence, tp->seed + (uint64_t)pass, T, nullptr, 0, &ni, nullptr, &iu, &bh);
+        if (rc) return rc;
+        std::vector<uint8_t> mask(std::max(ni, 1));
+        rc = vo_pose_refine_lm(c, T, tp->huber_delta, tp->chi2_cut, tp->it_robust, tp->it_plain, mask.data(), ni, &ne, &li);
+        if (rc) return rc;
+        for (auto& m : c->last_matches) m.flags = 0;
+        int nlm = 0;
+        for (int i = 0; i < ni; ++i) {
+            c->last_matches[c->ransac_inliers[i]].flags |= VO_MATCH_RANSAC_INLIER;
+            if (mask[i]) { c->last_matches[c->ransac_inliers[i]].flags |= VO_MATCH_LM_INLIER; ++nlm; }
+        }
+        res->n_candidates = nc; res->n_matches = nm; res->n_ransac_inliers = ni; res->n_lm_inliers = nlm;
+        res->min_distance = md; res->ransac_iters = iu; res->best_hypothesis = bh; res->lm_iters += li;
+    }
+    std::memcpy(res->T_cw, T, sizeof(T));
+    if (matches) std::memcpy(matches, c->last_matches.data(), sizeof(vo_match) * std::min<size_t>(cap, c->last_matches.size()));
+    if ((int)c->last_matches.size() > cap && matches) res->status = VO_E_OVERFLOW;
+    return VO_OK;
+}
+
+int vo_local_ba(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
+    if (!c || !in || !out || !out->poses || !out->points || !out->edge_flags) return VO_E_INVALID;
+    return local_ba(c->cam, *in, *out);
+}
+
+int vo_sync(vo_ctx*) { return VO_OK; }
+int vo_profile_enable(vo_ctx*, int) { return VO_OK; }
+int vo_profile_read(vo_ctx*, char (*)[48], double*, int64_t*, int, int* n) { if (n) *n = 0; return VO_OK; }
+
+}  // extern "C"

@@ -1,0 +1,338 @@
+"""ctypes binding of the C-ABI in include/vo_hip.h.
+
+The product library is ``rgbd_visualodometry_amd/csrc/libvo_hip.so`` (HIP, gfx950).  There is
+no CPU fallback: ``load()`` raises if that library is missing.  Tests and bench.py's
+``cpu_baseline`` leg load the oracle (``oracle/_build/liboracle_vo.so``) through the very same
+binding by passing its path explicitly -- both libraries export identical symbols.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+HIP_LIB = os.path.join(HERE, "csrc", "libvo_hip.so")
+ORACLE_LIB = os.path.join(ROOT, "oracle", "_build", "liboracle_vo.so")
+SYNTH_LIB = os.path.join(HERE, "synth", "libvo_synth.so")
+
+
+class VoParams(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("fx", C.c_float), ("fy", C.c_float),
+                ("cx", C.c_float), ("cy", C.c_float), ("depth_scale", C.c_float), ("n_features", C.c_int32),
+                ("scale_factor", C.c_float), ("n_levels", C.c_int32), ("fast_threshold", C.c_int32),
+                ("edge_threshold", C.c_int32), ("max_frames", C.c_int32), ("map_capacity", C.c_int32),
+                ("max_hypotheses", C.c_int32), ("reserved", C.c_int32 * 8)]
+
+
+class VoTrackParams(C.Structure):
+    _fields_ = [("match_ratio", C.c_float), ("match_floor", C.c_float), ("n_hyp", C.c_int32),
+                ("reproj_px", C.c_float), ("confidence", C.c_float), ("seed", C.c_uint64),
+                ("huber_delta", C.c_double), ("chi2_cut", C.c_double), ("it_robust", C.c_int32),
+                ("it_plain", C.c_int32), ("passes", C.c_int32), ("reserved", C.c_int32 * 5)]
+
+
+class VoTrackResult(C.Structure):
+    _fields_ = [("T_cw", C.c_double * 12), ("n_candidates", C.c_int32), ("n_matches", C.c_int32),
+                ("n_ransac_inliers", C.c_int32), ("n_lm_inliers", C.c_int32), ("min_distance", C.c_int32),
+                ("ransac_iters", C.c_int32), ("best_hypothesis", C.c_int32), ("lm_iters", C.c_int32),
+                ("status", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+class VoBaProblem(C.Structure):
+    _fields_ = [("n_poses", C.c_int32), ("n_free", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32),
+                ("poses", C.c_void_p), ("points", C.c_void_p), ("edge_pose", C.c_void_p), ("edge_point", C.c_void_p),
+                ("edge_uv", C.c_void_p), ("huber_delta", C.c_double), ("chi2_th", C.c_double),
+                ("it_robust", C.c_int32), ("it_plain", C.c_int32)]
+
+
+class VoBaResult(C.Structure):
+    _fields_ = [("poses", C.c_void_p), ("points", C.c_void_p), ("edge_flags", C.c_void_p),
+                ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lm_iters", C.c_int32),
+                ("reserved", C.c_int32 * 3)]
+
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                           ("octave", "<i4"), ("class_id", "<i4"), ("depth_raw", "<i4")])
+MATCH_DTYPE = np.dtype([("map_index", "<i4"), ("kp_index", "<i4"), ("distance", "<i4"), ("flags", "<i4")])
+
+# every symbol include/vo_hip.h declares
+SYMBOLS = ["vo_ctx_create", "vo_ctx_destroy", "vo_strerror", "vo_backend_name", "vo_default_params",
+           "vo_default_track_params", "vo_frame_upload", "vo_frame_bind_device", "vo_orb_detect_describe",
+           "vo_orb_fetch", "vo_orb_level_size", "vo_orb_fetch_level", "vo_map_upsert", "vo_map_set_active",
+           "vo_match_active_map", "vo_matches_set", "vo_pnp_ransac", "vo_pose_refine_lm", "vo_track_frame",
+           "vo_local_ba", "vo_sync", "vo_profile_enable", "vo_profile_read"]
+
+
+class VoError(RuntimeError):
+    pass
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class VoLib:
+    """A loaded implementation of the C-ABI (HIP product or CPU oracle)."""
+
+    def __init__(self, path: str):
+        if not os.path.exists(path):
+            raise VoError("C-ABI library not found: %s (build it: python -c 'import __graft_entry__ as g; g.build()')" % path)
+        self.path = path
+        self.lib = C.CDLL(path, mode=C.RTLD_LOCAL)
+        L = self.lib
+        for s in SYMBOLS:
+            getattr(L, s)  # raises AttributeError if a declared symbol is missing
+        L.vo_strerror.restype = C.c_char_p
+        L.vo_backend_name.restype = C.c_char_p
+        L.vo_ctx_destroy.restype = None
+        for name in SYMBOLS:
+            if name not in ("vo_strerror", "vo_backend_name", "vo_ctx_destroy"):
+                getattr(L, name).restype = C.c_int
+        L.vo_ctx_create.argtypes = [C.POINTER(VoParams), C.c_int, C.POINTER(C.c_void_p)]
+        L.vo_ctx_destroy.argtypes = [C.c_void_p]
+        L.vo_frame_upload.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.vo_frame_bind_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.vo_orb_detect_describe.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.vo_orb_fetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.vo_orb_level_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.vo_orb_fetch_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.vo_map_upsert.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int]
+        L.vo_map_set_active.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.vo_match_active_map.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_int,
+                                          C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.vo_matches_set.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.vo_pnp_ransac.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int,
+                                    C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.vo_pose_refine_lm.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                        C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.vo_track_frame.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(VoTrackParams), C.POINTER(VoTrackResult),
+                                     C.c_void_p, C.c_int]
+        L.vo_local_ba.argtypes = [C.c_void_p, C.POINTER(VoBaProblem), C.POINTER(VoBaResult)]
+        L.vo_sync.argtypes = [C.c_void_p]
+        L.vo_profile_enable.argtypes = [C.c_void_p, C.c_int]
+        L.vo_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+
+    @property
+    def backend(self) -> str:
+        return self.lib.vo_backend_name().decode()
+
+    def check(self, rc: int, what: str = ""):
+        if rc != 0:
+            raise VoError("%s failed: %s (%d)" % (what or "vo call", self.lib.vo_strerror(rc).decode(), rc))
+
+    def default_params(self, **kw) -> VoParams:
+        p = VoParams()
+        self.check(self.lib.vo_default_params(C.byref(p)))
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+
+    def default_track_params(self, **kw) -> VoTrackParams:
+        t = VoTrackParams()
+        self.check(self.lib.vo_default_track_params(C.byref(t)))
+        for k, v in kw.items():
+            setattr(t, k, v)
+        return t
+
+    def context(self, params: VoParams, device: int = 0) -> "VoContext":
+        return VoContext(self, params, device)
+
+
+class VoContext:
+    def __init__(self, lib: VoLib, params: VoParams, device: int = 0):
+        self.L = lib
+        self.params = params
+        self.h = C.c_void_p()
+        lib.check(lib.lib.vo_ctx_create(C.byref(params), device, C.byref(self.h)), "vo_ctx_create")
+        self._keep = {}
+
+    def close(self):
+        if self.h:
+            self.L.lib.vo_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # frames ---------------------------------------------------------------------------
+    def upload(self, slot: int, bgr: np.ndarray, depth: np.ndarray):
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        depth = np.ascontiguousarray(depth, dtype=np.uint16)
+        self.L.check(self.L.lib.vo_frame_upload(self.h, slot, _ptr(bgr), bgr.strides[0], _ptr(depth), depth.strides[0]), "vo_frame_upload")
+
+    def bind_device(self, slot: int, bgr_ptr: int, bgr_stride: int, depth_ptr: int, depth_stride: int):
+        self.L.check(self.L.lib.vo_frame_bind_device(self.h, slot, C.c_void_p(bgr_ptr), bgr_stride, C.c_void_p(depth_ptr), depth_stride), "vo_frame_bind_device")
+
+    # ORB ------------------------------------------------------------------------------
+    def orb(self, slot0: int = 0, nslots: int = 1):
+        self.L.check(self.L.lib.vo_orb_detect_describe(self.h, slot0, nslots), "vo_orb_detect_describe")
+
+    def orb_fetch(self, slot: int = 0, cap: Optional[int] = None):
+        cap = cap or 4 * self.params.n_features + 64
+        kps = np.zeros(cap, dtype=KEYPOINT_DTYPE)
+        desc = np.zeros((cap, 32), dtype=np.uint8)
+        n = C.c_int()
+        self.L.check(self.L.lib.vo_orb_fetch(self.h, slot, _ptr(kps), _ptr(desc), cap, C.byref(n)), "vo_orb_fetch")
+        k = min(n.value, cap)
+        return kps[:k].copy(), desc[:k].copy()
+
+    def level_size(self, level: int):
+        w, h, q = C.c_int(), C.c_int(), C.c_int()
+        self.L.check(self.L.lib.vo_orb_level_size(self.h, level, C.byref(w), C.byref(h), C.byref(q)))
+        return w.value, h.value, q.value
+
+    def fetch_level(self, slot: int, level: int) -> np.ndarray:
+        w, h, _ = self.level_size(level)
+        out = np.zeros((h, w), dtype=np.uint8)
+        self.L.check(self.L.lib.vo_orb_fetch_level(self.h, slot, level, _ptr(out)), "vo_orb_fetch_level")
+        return out
+
+    # map ------------------------------------------------------------------------------
+    def map_upsert(self, idx, xyz=None, normal=None, desc=None, flags=None):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        xyz = None if xyz is None else np.ascontiguousarray(xyz, dtype=np.float64)
+        normal = None if normal is None else np.ascontiguousarray(normal, dtype=np.float64)
+        desc = None if desc is None else np.ascontiguousarray(desc, dtype=np.uint8)
+        flags = None if flags is None else np.ascontiguousarray(flags, dtype=np.uint8)
+        self.L.check(self.L.lib.vo_map_upsert(self.h, _ptr(idx), _ptr(xyz), _ptr(normal), _ptr(desc), _ptr(flags), len(idx)), "vo_map_upsert")
+
+    def map_set_active(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        self.L.check(self.L.lib.vo_map_set_active(self.h, _ptr(idx), len(idx)), "vo_map_set_active")
+
+    # stages ---------------------------------------------------------------------------
+    def match(self, slot, T_cw, ratio=2.0, floor_dist=30.0, cap=None):
+        cap = cap or max(1024, self.params.map_capacity)
+        T = np.ascontiguousarray(T_cw, dtype=np.float64).reshape(12)
+        out = np.zeros(cap, dtype=MATCH_DTYPE)
+        n, nc, md = C.c_int(), C.c_int(), C.c_int()
+        self.L.check(self.L.lib.vo_match_active_map(self.h, slot, _ptr(T), ratio, floor_dist, _ptr(out), cap, C.byref(n), C.byref(nc), C.byref(md)), "vo_match_active_map")
+        return out[:min(n.value, cap)].copy(), nc.value, md.value
+
+    def matches_set(self, xyz, uv):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        uv = np.ascontiguousarray(uv, dtype=np.float32)
+        self.L.check(self.L.lib.vo_matches_set(self.h, _ptr(xyz), _ptr(uv), len(xyz)), "vo_matches_set")
+
+    def pnp_ransac(self, T_cw, n_hyp=100, reproj_px=4.0, confidence=0.99, seed=1, cap=65536):
+        T = np.array(T_cw, dtype=np.float64).reshape(12).copy()
+        inl = np.zeros(cap, dtype=np.int32)
+        counts = np.zeros(n_hyp, dtype=np.int32)
+        n, it, best = C.c_int(), C.c_int(), C.c_int()
+        self.L.check(self.L.lib.vo_pnp_ransac(self.h, n_hyp, reproj_px, confidence, seed, _ptr(T), _ptr(inl), cap, C.byref(n), _ptr(counts), C.byref(it), C.byref(best)), "vo_pnp_ransac")
+        return T, inl[:min(n.value, cap)].copy(), counts, it.value, best.value
+
+    def pose_lm(self, T_cw, huber_delta=7.815 ** 0.5, chi2_cut=1.0, it_robust=10, it_plain=10, cap=65536):
+        T = np.array(T_cw, dtype=np.float64).reshape(12).copy()
+        mask = np.zeros(cap, dtype=np.uint8)
+        n, it = C.c_int(), C.c_int()
+        self.L.check(self.L.lib.vo_pose_refine_lm(self.h, _ptr(T), huber_delta, chi2_cut, it_robust, it_plain, _ptr(mask), cap, C.byref(n), C.byref(it)), "vo_pose_refine_lm")
+        return T, mask[:min(n.value, cap)].copy(), it.value
+
+    def track(self, slot, T_prior, tp: VoTrackParams, cap=None):
+        cap = cap or max(1024, self.params.map_capacity)
+        T = np.ascontiguousarray(T_prior, dtype=np.float64).reshape(12)
+        res = VoTrackResult()
+        m = np.zeros(cap, dtype=MATCH_DTYPE)
+        self.L.check(self.L.lib.vo_track_frame(self.h, slot, _ptr(T), C.byref(tp), C.byref(res), _ptr(m), cap), "vo_track_frame")
+        return res, m[:min(res.n_matches, cap)].copy()
+
+    def local_ba(self, poses, n_free, points, edge_pose, edge_point, edge_uv, huber_delta=7.815 ** 0.5, chi2_th=1.0,
+                 it_robust=10, it_plain=10):
+        poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 12)
+        points = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        ep = np.ascontiguousarray(edge_pose, dtype=np.int32)
+        el = np.ascontiguousarray(edge_point, dtype=np.int32)
+        uv = np.ascontiguousarray(edge_uv, dtype=np.float32).reshape(-1, 2)
+        prob = VoBaProblem(len(poses), n_free, len(points), len(ep), _ptr(poses).value, _ptr(points).value, _ptr(ep).value,
+                           _ptr(el).value, _ptr(uv).value, huber_delta, chi2_th, it_robust, it_plain)
+        po = np.zeros((max(n_free, 1), 12)); pt = np.zeros((max(len(points), 1), 3)); fl = np.zeros(max(len(ep), 1), dtype=np.uint8)
+        res = VoBaResult(_ptr(po).value, _ptr(pt).value, _ptr(fl).value)
+        self.L.check(self.L.lib.vo_local_ba(self.h, C.byref(prob), C.byref(res)), "vo_local_ba")
+        return po[:n_free], pt[:len(points)], fl[:len(ep)], res
+
+    def sync(self):
+        self.L.check(self.L.lib.vo_sync(self.h), "vo_sync")
+
+    def profile_enable(self, on=True):
+        self.L.check(self.L.lib.vo_profile_enable(self.h, int(on)))
+
+    def profile_read(self, cap=64):
+        names = (C.c_char * 48 * cap)()
+        ms = np.zeros(cap); calls = np.zeros(cap, dtype=np.int64)
+        n = C.c_int()
+        self.L.check(self.L.lib.vo_profile_read(self.h, C.cast(names, C.c_void_p), _ptr(ms), _ptr(calls), cap, C.byref(n)))
+        return {names[i].value.decode(): (float(ms[i]), int(calls[i])) for i in range(n.value)}
+
+
+_cache = {}
+
+
+def load(path: Optional[str] = None) -> VoLib:
+    """Load the HIP product library (default) or an explicit implementation of the C-ABI."""
+    path = path or HIP_LIB
+    if path not in _cache:
+        _cache[path] = VoLib(path)
+    return _cache[path]
+
+
+# --------------------------------------------------------------------------------------- #
+# synthetic stream generator binding
+# --------------------------------------------------------------------------------------- #
+class SynthParams(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
+                ("cy", C.c_float), ("depth_scale", C.c_float), ("seed", C.c_uint64), ("noise_sigma", C.c_float),
+                ("depth_noise_rel", C.c_float), ("invalid_frac", C.c_float), ("supersample", C.c_int32),
+                ("fps", C.c_double), ("speed", C.c_double)]
+
+
+class Synth:
+    def __init__(self, path: str = SYNTH_LIB):
+        if not os.path.exists(path):
+            raise VoError("synthetic generator library not found: %s" % path)
+        self.lib = C.CDLL(path)
+        self.lib.synth_render_range.argtypes = [C.POINTER(SynthParams), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+
+    def params(self, **kw) -> SynthParams:
+        p = SynthParams()
+        self.lib.synth_default_params(C.byref(p))
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+
+    def render(self, p: SynthParams, i0: int, n: int, threads: Optional[int] = None):
+        threads = threads or min(16, os.cpu_count() or 1)
+        bgr = np.empty((n, p.height, p.width, 3), dtype=np.uint8)
+        depth = np.empty((n, p.height, p.width), dtype=np.uint16)
+        T = np.empty((n, 12)); ts = np.empty(n)
+        rc = self.lib.synth_render_range(C.byref(p), i0, n, _ptr(bgr), _ptr(depth), _ptr(T), _ptr(ts), threads)
+        if rc:
+            raise VoError("synth_render_range failed")
+        return bgr, depth, T, ts
+
+
+def pose12_to_tum(T_wc: np.ndarray):
+    """12-double pose (R row-major, t) -> (tx,ty,tz,qx,qy,qz,qw)."""
+    R = np.asarray(T_wc[:9]).reshape(3, 3)
+    t = np.asarray(T_wc[9:12])
+    tr = np.trace(R)
+    if tr > 0:
+        s = np.sqrt(tr + 1.0) * 2
+        q = [(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s]
+    elif R[0, 0] > R[1, 1] and R[0, 0] > R[2, 2]:
+        s = np.sqrt(1.0 + R[0, 0] - R[1, 1] - R[2, 2]) * 2
+        q = [0.25 * s, (R[0, 1] + R[1, 0]) / s, (R[0, 2] + R[2, 0]) / s, (R[2, 1] - R[1, 2]) / s]
+    elif R[1, 1] > R[2, 2]:
+        s = np.sqrt(1.0 + R[1, 1] - R[0, 0] - R[2, 2]) * 2
+        q = [(R[0, 1] + R[1, 0]) / s, 0.25 * s, (R[1, 2] + R[2, 1]) / s, (R[0, 2] - R[2, 0]) / s]
+    else:
+        s = np.sqrt(1.0 + R[2, 2] - R[0, 0] - R[1, 1]) * 2
+        q = [(R[0, 2] + R[2, 0]) / s, (R[1, 2] + R[2, 1]) / s, 0.25 * s, (R[1, 0] - R[0, 1]) / s]
+    return [float(t[0]), float(t[1]), float(t[2])] + [float(v) for v in q]

@@ -1,0 +1,50 @@
+// frame.h -- one RGB-D frame and, once promoted, a keyframe with its observations and
+// covisibility links (reference include/myslam/frame.h:23-92, src/frame.cpp:18-171).
+#ifndef MYSLAM_FRAME_H
+#define MYSLAM_FRAME_H
+#include "myslam/camera.h"
+#include "myslam/common_include.h"
+#include "myslam/mappoint.h"
+
+namespace myslam {
+class Frame {
+public:
+    typedef std::shared_ptr<Frame> Ptr;
+    typedef std::unordered_map<size_t, int> CovisibleKeyframeIdToWeight;
+
+    double      timestamp_;
+    Camera::Ptr camera_;
+    Mat         color_, depth_;     // 8UC3 BGR, 16UC1 depth
+
+    // Host images are deep-copied (frame.cpp:28-29); device-resident images are referenced.
+    static Frame::Ptr CreateFrame(const double timestamp, const Camera::Ptr camera, const Mat color, const Mat depth);
+
+    size_t GetId() const { return id_; }
+    SE3 GetPose() { std::unique_lock<std::mutex> lck(poseMutex_); return T_c_w_; }
+    void SetPose(const SE3 pose) { std::unique_lock<std::mutex> lck(poseMutex_); T_c_w_ = pose; }
+    double GetDepth(const KeyPoint& kp);                  // metres, -1 if none (frame.cpp:43-67)
+    Vector3d GetCamCenter() const { return T_c_w_.inverse().translation(); }
+    bool IsCouldObserveMappoint(const Mappoint::Ptr& mpt);
+    void AddObservedMappoint(const size_t mappointId, const Point2f pixelPos);
+    void RemoveObservedMappoint(const size_t mappointId);
+    std::unordered_set<size_t> GetObservedMappointIds() { std::unique_lock<std::mutex> lck(observationMutex_); return observedMappointIds_; }
+    bool IsObservedMappoint(const size_t id) { std::unique_lock<std::mutex> lck(observationMutex_); return observedMappointIds_.count(id) != 0; }
+    void UpdateCovisibleKeyframeWeight(const size_t id, const int weight);
+    std::unordered_set<size_t> GetCovisibleKeyframes() { std::unique_lock<std::mutex> lck(observationMutex_); return activeCovisibleKeyframes_; }
+
+    int slot_ = -1;                 // vo_ctx frame slot holding this frame's ORB results (-1: none)
+    bool orb_done_ = false;
+
+private:
+    static size_t factoryId_;
+    size_t id_;
+    std::mutex poseMutex_;
+    SE3 T_c_w_;
+    std::mutex observationMutex_;
+    std::unordered_set<size_t> observedMappointIds_;
+    CovisibleKeyframeIdToWeight allCovisibleKeyframeIdToWeight_;
+    std::unordered_set<size_t> activeCovisibleKeyframes_;    // >= 15 shared map points
+    Frame(const size_t id, const double timestamp, const Camera::Ptr camera, const Mat color, const Mat depth);
+};
+}  // namespace myslam
+#endif

@@ -1,0 +1,82 @@
+// frontend.h -- tracking front-end (reference include/myslam/frontend.h:32-112,
+// src/frontend.cpp).  Same public surface (AddFrame / SetViewer / SetBackend / GetState); the
+// ORB, matching, PnP-RANSAC and pose-refinement numerics run behind the C-ABI of vo_hip.h.
+#ifndef MYSLAM_FRONTEND_H
+#define MYSLAM_FRONTEND_H
+#include "myslam/backend.h"
+#include "myslam/common_include.h"
+#include "myslam/frame.h"
+#include "myslam/mappoint.h"
+#include "myslam/util.h"
+#include "myslam/viewer.h"
+
+namespace myslam {
+class FrontEnd {
+public:
+    typedef std::shared_ptr<FrontEnd> Ptr;
+    enum VOState { INITIALIZING = 0, TRACKING, LOST };
+
+    FrontEnd();                         // parameters from Config (frontend.cpp:29-43); owns a vo_ctx on device 0
+    explicit FrontEnd(int device, int width = 640, int height = 480, int max_frames = 1);
+    ~FrontEnd();
+
+    bool AddFrame(const Frame::Ptr frame);
+    void SetViewer(const Viewer::Ptr viewer) { viewer_ = viewer; }
+    void SetBackend(const Backend::Ptr backend) { backend_ = backend; if (backend_) backend_->SetContext(ctx_); }
+    VOState GetState() const { return state_; }
+
+    // Look-ahead: upload (or bind) and run batched ORB for upcoming frames of this stream.
+    // Frames of one stream depend on each other only from matching onwards, so detection and
+    // description of up to max_frames future frames run as one batched launch chain.
+    int PrefetchFrames(const std::vector<Frame::Ptr>& frames);
+
+    vo_ctx* GetContext() const { return ctx_; }
+    struct Stats { int frames = 0, keyframes = 0, lost = 0; int last_candidates = 0, last_matches = 0, last_ransac = 0, last_lm = 0, last_keypoints = 0; };
+    const Stats& GetStats() const { return stats_; }
+    bool verbose_ = false;
+
+private:
+    Viewer::Ptr  viewer_;
+    Backend::Ptr backend_;
+    VOState      state_;
+    int          accuLostFrameNums_;
+    Frame::Ptr   keyframeRef_, framePrev_, frameCurr_;
+    std::unordered_map<size_t, Mappoint::Ptr> trackingMap_;
+    Frame::Ptr   keyframeForTrackingMap_;
+    bool         trackingMapChanged_ = true;
+
+    vo_ctx*                 ctx_ = nullptr;
+    vo_params               params_;
+    vo_track_params         trackParams_;
+    std::vector<KeyPoint>   keypointsCurr_;
+    std::vector<Descriptor> descriptorsCurr_;
+    std::vector<Mappoint::Ptr> activeList_;                 // device tracking map, in matching order
+    std::unordered_map<int, Mappoint::Ptr> slotToMappoint_;
+    std::unordered_map<Mappoint::Ptr, KeyPoint> flannMatchedMptKptMap_;
+    KeyPointSet flannMatchedKptSet_;
+    std::unordered_set<Mappoint::Ptr> pnpMatchedMptSet_;
+    KeyPointSet pnpMatchedKptSet_;
+    std::vector<Mappoint::Ptr> newMappoints_;
+    int   numInliers_ = 0;
+    float minDisRatio_; int maxLostFrames_, minInliers_; double keyFrameMinRot_, keyFrameMinTrans_;
+    int   nextSlot_ = 0;
+    uint64_t frameCounter_ = 0;
+    Stats stats_;
+    std::vector<vo_keypoint> kpBuf_; std::vector<uint8_t> descBuf_; std::vector<vo_match> matchBuf_;
+
+    void Init(int device, int width, int height, int max_frames);
+    void InitializationHandler();
+    bool TrackingHandler();
+    void LostHandler();
+    void ExtractKeyPointsAndComputeDescriptors();
+    void MatchAndEstimatePose();            // MatchKeyPointsInTrackingMap + EstimatePosePnP, coarse and fine
+    void RefreshTrackingMap();
+    void FlushDirtyMappoints();
+    bool IsGoodEstimation();
+    bool IsKeyframe();
+    void AddCurrentKeyframeObservations();
+    void CreateNewMappoints();
+    void TriangulateMappointsInTrackingMap();
+};
+}  // namespace myslam
+#endif

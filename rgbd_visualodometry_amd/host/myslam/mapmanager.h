@@ -1,0 +1,42 @@
+// mapmanager.h -- owner of all keyframes and map points (reference include/myslam/mapmanager.h:23-62,
+// src/mapmanager.cpp:14-38).  GetInstance() returns the map bound to the calling thread's VO
+// system (one process may drive several independent streams); without a binding it is the
+// process-wide singleton of the reference.
+#ifndef MYSLAM_MAPMANAGER_H
+#define MYSLAM_MAPMANAGER_H
+#include "myslam/common_include.h"
+#include "myslam/frame.h"
+#include "myslam/mappoint.h"
+
+namespace myslam {
+class MapManager {
+public:
+    typedef std::shared_ptr<MapManager> Ptr;
+    typedef std::unordered_map<size_t, Mappoint::Ptr> MappointIdToPtr;
+    typedef std::unordered_map<size_t, Frame::Ptr> KeyframeIdToPtr;
+
+    static MapManager& GetInstance();
+    static void BindToThread(MapManager* m);       // nullptr -> process-wide singleton
+
+    void InsertKeyframe(const Frame::Ptr& frame) { std::unique_lock<std::mutex> lck(dataMutex_); keyframesDict_[frame->GetId()] = frame; }
+    Frame::Ptr GetKeyframe(const size_t id) { std::unique_lock<std::mutex> lck(dataMutex_); auto it = keyframesDict_.find(id); return it == keyframesDict_.end() ? nullptr : it->second; }
+    KeyframeIdToPtr GetAllKeyframes() { std::unique_lock<std::mutex> lck(dataMutex_); return keyframesDict_; }
+    void InsertMappoint(const Mappoint::Ptr& map_point);
+    Mappoint::Ptr GetMappoint(const size_t id) { std::unique_lock<std::mutex> lck(dataMutex_); auto it = mappointsDict_.find(id); return it == mappointsDict_.end() ? nullptr : it->second; }
+    MappointIdToPtr GetAllMappoints() { std::unique_lock<std::mutex> lck(dataMutex_); return mappointsDict_; }
+    MappointIdToPtr GetMappointsAroundKeyframe(const Frame::Ptr& keyframe);
+
+    size_t MappointCount() { std::unique_lock<std::mutex> lck(dataMutex_); return mappointsDict_.size(); }
+    // map points whose host state is newer than the device copy (drained by the front-end)
+    std::vector<Mappoint::Ptr> TakeDirtyMappoints();
+    void MarkDirty(const Mappoint::Ptr& mp);
+
+private:
+    std::mutex dataMutex_;
+    MappointIdToPtr mappointsDict_;
+    KeyframeIdToPtr keyframesDict_;
+    int nextSlot_ = 0;
+    std::vector<Mappoint::Ptr> dirty_;
+};
+}  // namespace myslam
+#endif

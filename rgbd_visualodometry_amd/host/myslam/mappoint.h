@@ -1,0 +1,43 @@
+// mappoint.h -- 3-D landmark (reference include/myslam/mappoint.h:36-84, src/mappoint.cpp:17-49).
+#ifndef MYSLAM_MAPPOINT_H
+#define MYSLAM_MAPPOINT_H
+#include "myslam/common_include.h"
+
+namespace myslam {
+class Mappoint {
+public:
+    typedef std::shared_ptr<Mappoint> Ptr;
+    typedef std::unordered_map<size_t, Point2f> ObservedByKeyframeIdtoPixelPos;
+
+    Descriptor  descriptor_;        // 256-bit rBRIEF descriptor used for matching
+    bool        triangulated_;      // refined by the front-end's triangulation
+    bool        optimized_;         // touched by the back-end
+    bool        outlier_;           // no observation left / rejected
+
+    static Mappoint::Ptr CreateMappoint(const Vector3d position, const Descriptor& descriptor);
+
+    Vector3d GetPosition() { std::unique_lock<std::mutex> lock(posMutex_); return pos_; }
+    void SetPosition(const Vector3d pos) { std::unique_lock<std::mutex> lock(posMutex_); pos_ = pos; dirty_ = true; }
+    size_t GetId() const { return id_; }
+    Vector3d GetNormDirection() { std::unique_lock<std::mutex> lock(observationMutex_); return norm_; }
+
+    void AddObservedByKeyframe(const size_t keyframeId, const Point2f posInPixel, const Vector3d cameraCenter);
+    void RemoveObservedByKeyframe(const size_t keyframeId);
+    ObservedByKeyframeIdtoPixelPos GetObservedByKeyframesMap() { std::unique_lock<std::mutex> lock(observationMutex_); return observedByKeyframeMap_; }
+
+    // device-map bookkeeping (slot in the vo_ctx map, set by MapManager::InsertMappoint)
+    int  slot_ = -1;
+    bool dirty_ = true;             // host copy newer than the device copy
+
+private:
+    static size_t factoryId_;
+    size_t id_;
+    Vector3d norm_;
+    std::mutex posMutex_;
+    Vector3d pos_;
+    std::mutex observationMutex_;
+    ObservedByKeyframeIdtoPixelPos observedByKeyframeMap_;
+    Mappoint(const size_t id, const Vector3d position, const Descriptor& descriptor);
+};
+}  // namespace myslam
+#endif

@@ -1,0 +1,76 @@
+// frame.cpp -- reference src/frame.cpp:18-171.
+#include "myslam/frame.h"
+
+#include "myslam/mapmanager.h"
+
+namespace myslam {
+size_t Frame::factoryId_ = 0;
+
+Frame::Ptr Frame::CreateFrame(const double timestamp, const Camera::Ptr camera, const Mat color, const Mat depth) {
+    return Frame::Ptr(new Frame(++factoryId_, timestamp, camera, color.clone(3), depth.clone(2)));
+}
+
+Frame::Frame(const size_t id, const double timestamp, const Camera::Ptr camera, const Mat color, const Mat depth)
+    : timestamp_(timestamp), camera_(camera), color_(color), depth_(depth), id_(id), T_c_w_(SE3()) {}
+
+// The raw sample (with the 4-neighbour fallback of frame.cpp:52-63) is taken on the device next to the
+// keypoint (vo_keypoint::depth_raw); only the metric conversion is left.
+double Frame::GetDepth(const KeyPoint& kp) {
+    if (kp.depth_raw != 0) return double(kp.depth_raw) / camera_->GetDepthScale();
+    return -1.0;
+}
+
+bool Frame::IsCouldObserveMappoint(const Mappoint::Ptr& mpt) {
+    Vector3d posInCam = camera_->World2Camera(mpt->GetPosition(), T_c_w_);
+    if (posInCam[2] < 0) return false;
+    Vector2d px = camera_->Camera2Pixel(posInCam);
+    if (px.x < 0 || px.x >= color_.cols || px.y < 0 || px.y >= color_.rows) return false;
+    Vector3d direction = (mpt->GetPosition() - GetCamCenter()).normalized();
+    double angle = std::acos(direction.dot(mpt->GetNormDirection()));
+    return !(angle > M_PI / 6);
+}
+
+void Frame::AddObservedMappoint(const size_t mappointId, const Point2f pixelPos) {
+    std::unique_lock<std::mutex> lck(observationMutex_);
+    assert(!observedMappointIds_.count(mappointId));
+    observedMappointIds_.insert(mappointId);
+    auto mappoint = MapManager::GetInstance().GetMappoint(mappointId);
+    assert(mappoint != nullptr);
+    mappoint->AddObservedByKeyframe(id_, pixelPos, GetCamCenter());
+    for (auto& idToPixel : mappoint->GetObservedByKeyframesMap()) {
+        const size_t other = idToPixel.first;
+        if (other == id_) continue;
+        auto otherKF = MapManager::GetInstance().GetKeyframe(other);
+        assert(otherKF != nullptr);
+        int w = ++allCovisibleKeyframeIdToWeight_[other];
+        if (w >= 15) activeCovisibleKeyframes_.insert(other);
+        otherKF->UpdateCovisibleKeyframeWeight(id_, w);
+    }
+}
+
+void Frame::RemoveObservedMappoint(const size_t mappointId) {
+    std::unique_lock<std::mutex> lck(observationMutex_);
+    assert(observedMappointIds_.count(mappointId));
+    observedMappointIds_.erase(mappointId);
+    auto mappoint = MapManager::GetInstance().GetMappoint(mappointId);
+    assert(mappoint != nullptr);
+    mappoint->RemoveObservedByKeyframe(id_);
+    for (auto& idToPixel : mappoint->GetObservedByKeyframesMap()) {
+        const size_t other = idToPixel.first;
+        if (other == id_) continue;
+        auto otherKF = MapManager::GetInstance().GetKeyframe(other);
+        assert(otherKF != nullptr);
+        int w = --allCovisibleKeyframeIdToWeight_[other];
+        if (w == 0) allCovisibleKeyframeIdToWeight_.erase(other);
+        else if (w < 15) activeCovisibleKeyframes_.erase(other);
+        otherKF->UpdateCovisibleKeyframeWeight(id_, w);
+    }
+}
+
+void Frame::UpdateCovisibleKeyframeWeight(const size_t id, const int weight) {
+    std::unique_lock<std::mutex> lck(observationMutex_);
+    if (weight == 0) { allCovisibleKeyframeIdToWeight_.erase(id); activeCovisibleKeyframes_.erase(id); }
+    else if (weight >= 15) { allCovisibleKeyframeIdToWeight_[id] = weight; activeCovisibleKeyframes_.insert(id); }
+    else { allCovisibleKeyframeIdToWeight_[id] = weight; activeCovisibleKeyframes_.erase(id); }
+}
+}  // namespace myslam

@@ -1,0 +1,274 @@
+// frontend.cpp -- tracking front-end behind the reference's FrontEnd surface
+// (reference src/frontend.cpp:29-506).  State machine, keyframe policy and map bookkeeping stay
+// on the host; ORB, matching, PnP-RANSAC and pose refinement run through the C-ABI (vo_hip.h).
+#include "myslam/frontend.h"
+
+#include <algorithm>
+#include <stdexcept>
+
+#include "myslam/config.h"
+#include "myslam/mapmanager.h"
+
+namespace myslam {
+
+static void vo_check(int rc, const char* what) {
+    if (rc != VO_OK) throw std::runtime_error(std::string(what) + " failed: " + vo_strerror(rc));
+}
+
+template <typename T>
+static T cfg_or(const std::string& key, T dflt) { return Config::has(key) ? Config::get<T>(key) : dflt; }
+
+FrontEnd::FrontEnd() { Init(cfg_or<int>("device", 0), cfg_or<int>("image.width", 640), cfg_or<int>("image.height", 480), cfg_or<int>("max_frames_in_flight", 1)); }
+FrontEnd::FrontEnd(int device, int width, int height, int max_frames) { Init(device, width, height, max_frames); }
+
+void FrontEnd::Init(int device, int width, int height, int max_frames) {
+    state_ = INITIALIZING;
+    accuLostFrameNums_ = 0;                                           // (uninitialised in the reference, frontend.h:59)
+    vo_default_params(&params_);
+    params_.width = width; params_.height = height;
+    params_.fx = cfg_or<float>("camera.fx", params_.fx); params_.fy = cfg_or<float>("camera.fy", params_.fy);
+    params_.cx = cfg_or<float>("camera.cx", params_.cx); params_.cy = cfg_or<float>("camera.cy", params_.cy);
+    params_.depth_scale = cfg_or<float>("camera.depth_scale", params_.depth_scale);
+    params_.n_features = cfg_or<int>("number_of_features", params_.n_features);            // frontend.cpp:35
+    params_.scale_factor = (float)cfg_or<double>("scale_factor", params_.scale_factor);    // :36
+    params_.n_levels = cfg_or<int>("level_pyramid", params_.n_levels);                     // :37
+    params_.max_frames = std::max(1, max_frames);
+    params_.map_capacity = cfg_or<int>("map_capacity", 1 << 20);
+    vo_default_track_params(&trackParams_);
+    trackParams_.match_ratio = minDisRatio_ = cfg_or<float>("match_ratio", 2.0f);          // :38
+    maxLostFrames_ = (int)cfg_or<float>("max_num_lost", 10.f);                             // :39
+    minInliers_ = cfg_or<int>("min_inliers", 10);                                          // :40
+    keyFrameMinRot_ = cfg_or<double>("keyframe_rotation", 0.05);                           // :41
+    keyFrameMinTrans_ = cfg_or<double>("keyframe_translation", 0.05);                      // :42
+    trackParams_.n_hyp = cfg_or<int>("ransac_iterations", 100);                            // :240
+    params_.max_hypotheses = std::max(params_.max_hypotheses, trackParams_.n_hyp);
+    vo_check(vo_ctx_create(&params_, device, &ctx_), "vo_ctx_create");
+    if (backend_) backend_->SetContext(ctx_);
+}
+
+FrontEnd::~FrontEnd() { if (ctx_) vo_ctx_destroy(ctx_); }
+
+bool FrontEnd::AddFrame(const Frame::Ptr frame) {
+    if (verbose_) std::cout << "Frontend status: " << (state_ == INITIALIZING ? "Initializing" : state_ == TRACKING ? "Tracking" : "Lost") << std::endl;
+    frameCurr_ = frame;
+    ++stats_.frames;
+    switch (state_) {
+        case INITIALIZING: InitializationHandler(); break;
+        case TRACKING: if (!TrackingHandler()) return false; break;
+        case LOST: LostHandler(); return false;
+    }
+    if (viewer_) { viewer_->setCurrentFrame(frameCurr_, flannMatchedKptSet_); viewer_->updateDrawingObjects(); }
+    return true;
+}
+
+void FrontEnd::InitializationHandler() {
+    ExtractKeyPointsAndComputeDescriptors();
+    MapManager::GetInstance().InsertKeyframe(frameCurr_);       // the first frame is a keyframe
+    ++stats_.keyframes;
+    CreateNewMappoints();                                        // one frame suffices: depth is measured
+    state_ = TRACKING;
+    framePrev_ = frameCurr_;
+    keyframeRef_ = frameCurr_;
+}
+
+bool FrontEnd::TrackingHandler() {
+    frameCurr_->SetPose(framePrev_->GetPose());                  // prior = pose of the last keyframe (frontend.cpp:96)
+    ExtractKeyPointsAndComputeDescriptors();
+    MatchAndEstimatePose();                                      // coarse + fine (frontend.cpp:100-108)
+
+    if (!IsGoodEstimation()) {
+        accuLostFrameNums_++;
+        state_ = (++accuLostFrameNums_ > maxLostFrames_) ? LOST : TRACKING;      // double increment kept (:113-114)
+        ++stats_.lost;
+        return false;
+    }
+    accuLostFrameNums_ = 0;
+    if (!IsKeyframe()) return true;
+
+    MapManager::GetInstance().InsertKeyframe(frameCurr_);
+    ++stats_.keyframes;
+    AddCurrentKeyframeObservations();
+    CreateNewMappoints();
+    TriangulateMappointsInTrackingMap();
+    if (backend_) backend_->OptimizeCovisibleGraphOfKeyframe(frameCurr_);
+    framePrev_ = frameCurr_;
+    keyframeRef_ = frameCurr_;
+    return true;
+}
+
+void FrontEnd::LostHandler() { if (verbose_) std::cout << "Tracking is lost" << std::endl; }
+
+int FrontEnd::PrefetchFrames(const std::vector<Frame::Ptr>& frames) {
+    const int n = std::min<int>((int)frames.size(), params_.max_frames);
+    if (n <= 0) return 0;
+    for (int i = 0; i < n; ++i) {
+        const Frame::Ptr& f = frames[i];
+        if (f->color_.cols != params_.width || f->color_.rows != params_.height) throw std::runtime_error("frame size differs from the context's");
+        if (f->color_.on_device) vo_check(vo_frame_bind_device(ctx_, i, f->color_.data, f->color_.stride, f->depth_.data, f->depth_.stride), "vo_frame_bind_device");
+        else vo_check(vo_frame_upload(ctx_, i, (const uint8_t*)f->color_.data, f->color_.stride, (const uint16_t*)f->depth_.data, f->depth_.stride), "vo_frame_upload");
+        f->slot_ = i; f->orb_done_ = false;
+    }
+    vo_check(vo_orb_detect_describe(ctx_, 0, n), "vo_orb_detect_describe");
+    for (int i = 0; i < n; ++i) frames[i]->orb_done_ = true;
+    nextSlot_ = 0;
+    return n;
+}
+
+void FrontEnd::ExtractKeyPointsAndComputeDescriptors() {
+    Frame::Ptr f = frameCurr_;
+    if (!f->orb_done_) {
+        std::vector<Frame::Ptr> one{f};
+        PrefetchFrames(one);
+    }
+    const int cap = 2 * params_.n_features + 64;
+    kpBuf_.resize(cap); descBuf_.resize((size_t)32 * cap);
+    int n = 0;
+    vo_check(vo_orb_fetch(ctx_, f->slot_, kpBuf_.data(), descBuf_.data(), cap, &n), "vo_orb_fetch");
+    n = std::min(n, cap);
+    keypointsCurr_.resize(n); descriptorsCurr_.resize(n);
+    for (int i = 0; i < n; ++i) {
+        const vo_keypoint& k = kpBuf_[i];
+        KeyPoint& o = keypointsCurr_[i];
+        o.pt = Point2f(k.x, k.y); o.size = k.size; o.angle = k.angle; o.response = k.response; o.octave = k.octave; o.class_id = k.class_id;
+        o.index = i; o.depth_raw = k.depth_raw;
+        std::memcpy(descriptorsCurr_[i].data(), &descBuf_[(size_t)32 * i], 32);
+    }
+    stats_.last_keypoints = n;
+}
+
+void FrontEnd::RefreshTrackingMap() {
+    bool changed = false;
+    if (keyframeForTrackingMap_ != keyframeRef_) {                                  // frontend.cpp:159-162
+        keyframeForTrackingMap_ = keyframeRef_;
+        trackingMap_ = MapManager::GetInstance().GetMappointsAroundKeyframe(keyframeRef_);
+        changed = true;
+    }
+    if (trackingMap_.size() < 100) {                                                // frontend.cpp:163-166
+        trackingMap_ = MapManager::GetInstance().GetAllMappoints();
+        changed = true;
+    }
+    if (!changed) return;
+    activeList_.clear();
+    for (auto& kv : trackingMap_) activeList_.push_back(kv.second);
+    std::sort(activeList_.begin(), activeList_.end(), [](const Mappoint::Ptr& a, const Mappoint::Ptr& b) { return a->GetId() < b->GetId(); });
+    std::vector<int32_t> slots(activeList_.size());
+    slotToMappoint_.clear();
+    for (size_t i = 0; i < activeList_.size(); ++i) { slots[i] = activeList_[i]->slot_; slotToMappoint_[slots[i]] = activeList_[i]; }
+    vo_check(vo_map_set_active(ctx_, slots.data(), (int)slots.size()), "vo_map_set_active");
+}
+
+void FrontEnd::FlushDirtyMappoints() {
+    std::vector<int32_t> idx; std::vector<double> xyz, nrm; std::vector<uint8_t> desc, flags;
+    for (auto& mp : activeList_) {
+        if (!mp->dirty_) continue;
+        mp->dirty_ = false;
+        idx.push_back(mp->slot_);
+        Vector3d p = mp->GetPosition(), n = mp->GetNormDirection();
+        for (int a = 0; a < 3; ++a) { xyz.push_back(p[a]); nrm.push_back(n[a]); }
+        desc.insert(desc.end(), mp->descriptor_.begin(), mp->descriptor_.end());
+        flags.push_back(mp->outlier_ ? VO_MAP_FLAG_OUTLIER : 0);
+    }
+    if (!idx.empty()) vo_check(vo_map_upsert(ctx_, idx.data(), xyz.data(), nrm.data(), desc.data(), flags.data(), (int)idx.size()), "vo_map_upsert");
+}
+
+void FrontEnd::MatchAndEstimatePose() {
+    RefreshTrackingMap();
+    FlushDirtyMappoints();
+    double prior[12];
+    frameCurr_->GetPose().to12(prior);
+    vo_track_result res;
+    const int cap = (int)activeList_.size() + 1;
+    matchBuf_.resize(cap);
+    trackParams_.seed = 0x5eed5eedull + 2 * frameCounter_++;
+    vo_check(vo_track_frame(ctx_, frameCurr_->slot_, prior, &trackParams_, &res, matchBuf_.data(), cap), "vo_track_frame");
+    if (res.status != VO_OK) throw std::runtime_error(std::string("device pipeline: ") + vo_strerror(res.status));
+
+    flannMatchedMptKptMap_.clear(); flannMatchedKptSet_.clear();
+    pnpMatchedMptSet_.clear(); pnpMatchedKptSet_.clear();
+    for (int i = 0; i < res.n_matches; ++i) {
+        const vo_match& m = matchBuf_[i];
+        const Mappoint::Ptr& mp = slotToMappoint_[m.map_index];
+        const KeyPoint& kp = keypointsCurr_[m.kp_index];
+        flannMatchedMptKptMap_[mp] = kp;                                            // frontend.cpp:208-209
+        flannMatchedKptSet_.insert(kp);
+        if (m.flags & VO_MATCH_LM_INLIER) { pnpMatchedMptSet_.insert(mp); pnpMatchedKptSet_.insert(kp); }   // :326-328
+    }
+    numInliers_ = res.n_ransac_inliers;                                             // frontend.cpp:242
+    frameCurr_->SetPose(SE3::from12(res.T_cw));                                     // frontend.cpp:312
+    stats_.last_candidates = res.n_candidates; stats_.last_matches = res.n_matches;
+    stats_.last_ransac = res.n_ransac_inliers; stats_.last_lm = res.n_lm_inliers;
+    if (verbose_)
+        std::cout << "  tracking map " << trackingMap_.size() << ", candidates " << res.n_candidates << ", matches " << res.n_matches
+                  << ", PnP inliers " << res.n_ransac_inliers << ", LM inliers " << res.n_lm_inliers << std::endl;
+}
+
+bool FrontEnd::IsGoodEstimation() {
+    if (numInliers_ < minInliers_) return false;                                    // frontend.cpp:337-341
+    SE3 T_r_c = framePrev_->GetPose() * frameCurr_->GetPose().inverse();
+    Vector6d d = T_r_c.log();
+    double n2 = 0;
+    for (double v : d) n2 += v * v;
+    return !(std::sqrt(n2) > 5.0);                                                  // frontend.cpp:345
+}
+
+bool FrontEnd::IsKeyframe() {
+    SE3 T_r_c = framePrev_->GetPose() * frameCurr_->GetPose().inverse();
+    Vector6d d = T_r_c.log();
+    const double trans = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    const double rot = std::sqrt(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+    return rot > keyFrameMinRot_ || trans > keyFrameMinTrans_;                      // frontend.cpp:359
+}
+
+void FrontEnd::AddCurrentKeyframeObservations() {
+    // reference iterates an unordered_set (frontend.cpp:366-370); match order here, for determinism
+    std::vector<Mappoint::Ptr> ordered(pnpMatchedMptSet_.begin(), pnpMatchedMptSet_.end());
+    std::sort(ordered.begin(), ordered.end(), [](const Mappoint::Ptr& a, const Mappoint::Ptr& b) { return a->GetId() < b->GetId(); });
+    for (auto& mp : ordered) frameCurr_->AddObservedMappoint(mp->GetId(), flannMatchedMptKptMap_[mp].pt);
+}
+
+void FrontEnd::CreateNewMappoints() {
+    newMappoints_.clear();
+    for (size_t idx = 0; idx < keypointsCurr_.size(); ++idx) {
+        const KeyPoint& kp = keypointsCurr_[idx];
+        if (pnpMatchedKptSet_.count(kp)) continue;                                  // already explained by the map
+        double depth = frameCurr_->GetDepth(kp);
+        if (depth < 0) continue;
+        Vector3d pos = frameCurr_->camera_->Pixel2World(kp, frameCurr_->GetPose(), depth);
+        Mappoint::Ptr mpt = Mappoint::CreateMappoint(pos, descriptorsCurr_[idx]);
+        MapManager::GetInstance().InsertMappoint(mpt);
+        if (mpt->slot_ >= params_.map_capacity) throw std::runtime_error("device map capacity exceeded (raise map_capacity)");
+        frameCurr_->AddObservedMappoint(mpt->GetId(), kp.pt);
+        newMappoints_.push_back(mpt);
+    }
+    if (verbose_) std::cout << "Created new mappoints: " << newMappoints_.size() << std::endl;
+}
+
+void FrontEnd::TriangulateMappointsInTrackingMap() {
+    int triangulatedCnt = 0;
+    for (auto& mp : activeList_) {                                                  // trackingMap_ in id order
+        if (mp->outlier_ || mp->triangulated_ || mp->optimized_ || !pnpMatchedMptSet_.count(mp)) continue;
+        std::vector<SE3> poses; std::vector<Vec3> points;
+        auto obs = mp->GetObservedByKeyframesMap();
+        std::vector<size_t> ids;
+        for (auto& kv : obs) ids.push_back(kv.first);
+        std::sort(ids.begin(), ids.end());
+        for (size_t id : ids) {
+            auto kf = MapManager::GetInstance().GetKeyframe(id);
+            if (kf == nullptr) continue;
+            poses.push_back(kf->GetPose());
+            points.push_back(kf->camera_->Pixel2Camera(obs[id]));
+        }
+        if (poses.size() >= 2) {
+            Vec3 pworld = Vec3::Zero();
+            if (Triangulation(poses, points, pworld) && pworld[2] > 0) {
+                mp->SetPosition(pworld);
+                mp->triangulated_ = true;
+                triangulatedCnt++;
+                break;                                                              // frontend.cpp:501
+            }
+        }
+    }
+    if (verbose_) std::cout << "  Triangulate active mappoints size: " << triangulatedCnt << std::endl;
+}
+
+}  // namespace myslam

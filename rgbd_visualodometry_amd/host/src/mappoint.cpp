@@ -1,0 +1,28 @@
+// mappoint.cpp -- reference src/mappoint.cpp:17-49, include/myslam/mappoint.h:59-64.
+#include "myslam/mappoint.h"
+
+namespace myslam {
+size_t Mappoint::factoryId_ = 0;
+
+Mappoint::Ptr Mappoint::CreateMappoint(const Vector3d position, const Descriptor& descriptor) {
+    return Mappoint::Ptr(new Mappoint(++factoryId_, position, descriptor));
+}
+
+Mappoint::Mappoint(const size_t id, const Vector3d position, const Descriptor& descriptor)
+    : descriptor_(descriptor), triangulated_(false), optimized_(false), outlier_(false), id_(id), norm_(Vector3d::Zero()), pos_(position) {}
+
+void Mappoint::AddObservedByKeyframe(const size_t keyframeId, const Point2f posInPixel, const Vector3d cameraCenter) {
+    std::unique_lock<std::mutex> lock(observationMutex_);
+    assert(!observedByKeyframeMap_.count(keyframeId));
+    observedByKeyframeMap_[keyframeId] = posInPixel;
+    norm_ = (norm_ + (pos_ - cameraCenter).normalized()).normalized();      // running mean viewing direction
+    dirty_ = true;
+}
+
+void Mappoint::RemoveObservedByKeyframe(const size_t keyframeId) {
+    std::unique_lock<std::mutex> lock(observationMutex_);
+    assert(observedByKeyframeMap_.count(keyframeId));
+    observedByKeyframeMap_.erase(keyframeId);
+    if (observedByKeyframeMap_.empty()) { outlier_ = true; dirty_ = true; }  // no observation left
+}
+}  // namespace myslam

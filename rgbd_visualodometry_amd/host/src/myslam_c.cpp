@@ -1,0 +1,134 @@
+// myslam_c.cpp -- C wrapper of the host layer (see include/myslam_c.h).
+#include "myslam_c.h"
+
+#include <deque>
+#include <exception>
+
+#include "myslam/backend.h"
+#include "myslam/config.h"
+#include "myslam/frontend.h"
+#include "myslam/mapmanager.h"
+
+using namespace myslam;
+
+struct myslam_system {
+    MapManager map;
+    Camera::Ptr camera;
+    FrontEnd::Ptr frontend;
+    Backend::Ptr backend;
+    std::deque<Frame::Ptr> queue;
+    myslam_options opt;
+};
+
+namespace {
+thread_local std::string g_err;
+template <typename F>
+int guarded(myslam_system* s, F&& f) {
+    try { if (s) MapManager::BindToThread(&s->map); f(); MapManager::BindToThread(nullptr); return 0; }
+    catch (const std::exception& e) { g_err = e.what(); MapManager::BindToThread(nullptr); return -1; }
+}
+Frame::Ptr make_frame(myslam_system* s, double stamp, const void* bgr, const void* depth, int bs, int ds, int on_device) {
+    Image c, d;
+    c.data = bgr; c.rows = s->opt.height; c.cols = s->opt.width; c.stride = bs; c.on_device = on_device != 0;
+    d.data = depth; d.rows = s->opt.height; d.cols = s->opt.width; d.stride = ds; d.on_device = on_device != 0;
+    return Frame::CreateFrame(stamp, s->camera, c, d);
+}
+void out_pose(const Frame::Ptr& f, double T_wc[12]) { if (T_wc) f->GetPose().inverse().to12(T_wc); }
+}  // namespace
+
+extern "C" {
+
+const char* myslam_last_error(void) { return g_err.c_str(); }
+const char* myslam_backend_name(void) { return vo_backend_name(); }
+
+int myslam_default_options(myslam_options* o) {
+    if (!o) return -1;
+    std::memset(o, 0, sizeof(*o));
+    o->width = 640; o->height = 480; o->fx = 517.3f; o->fy = 516.5f; o->cx = 318.6f; o->cy = 255.3f; o->depth_scale = 5000.f;
+    o->number_of_features = 500; o->scale_factor = 1.2f; o->level_pyramid = 8; o->match_ratio = 2.0f; o->max_num_lost = 10;
+    o->min_inliers = 10; o->keyframe_rotation = 0.05; o->keyframe_translation = 0.05; o->enable_local_optimization = 1; o->chi2_th = 1.f;
+    o->ransac_iterations = 100; o->max_frames_in_flight = 1; o->map_capacity = 1 << 20; o->device = 0; o->verbose = 0;
+    return 0;
+}
+
+int myslam_system_create(const myslam_options* o, const char* yaml, myslam_system** out) {
+    if (!o || !out) return -1;
+    myslam_system* s = nullptr;
+    int rc = guarded(nullptr, [&]() {
+        s = new myslam_system();
+        s->opt = *o;
+        auto S = [](auto v) { return std::to_string(v); };
+        Config::set("camera.fx", S(o->fx)); Config::set("camera.fy", S(o->fy)); Config::set("camera.cx", S(o->cx)); Config::set("camera.cy", S(o->cy));
+        Config::set("camera.depth_scale", S(o->depth_scale)); Config::set("number_of_features", S(o->number_of_features));
+        Config::set("scale_factor", S(o->scale_factor)); Config::set("level_pyramid", S(o->level_pyramid)); Config::set("match_ratio", S(o->match_ratio));
+        Config::set("max_num_lost", S(o->max_num_lost)); Config::set("min_inliers", S(o->min_inliers));
+        Config::set("keyframe_rotation", S(o->keyframe_rotation)); Config::set("keyframe_translation", S(o->keyframe_translation));
+        Config::set("enable_local_optimization", S(o->enable_local_optimization)); Config::set("chi2_th", S(o->chi2_th));
+        Config::set("ransac_iterations", S(o->ransac_iterations)); Config::set("map_capacity", S(o->map_capacity));
+        if (yaml) Config::setParameterFile(yaml);
+        MapManager::BindToThread(&s->map);
+        s->camera = Camera::Ptr(new Camera);
+        s->frontend = FrontEnd::Ptr(new FrontEnd(o->device, o->width, o->height, o->max_frames_in_flight));
+        s->frontend->verbose_ = o->verbose != 0;
+        if (Config::get<int>("enable_local_optimization")) { s->backend = Backend::Ptr(new Backend(s->camera)); s->frontend->SetBackend(s->backend); }
+    });
+    if (rc) { delete s; return rc; }
+    *out = s;
+    return 0;
+}
+
+void myslam_system_destroy(myslam_system* s) {
+    if (!s) return;
+    MapManager::BindToThread(&s->map);
+    s->queue.clear(); s->frontend.reset(); s->backend.reset();
+    MapManager::BindToThread(nullptr);
+    delete s;
+}
+
+int myslam_prefetch(myslam_system* s, int n, const double* stamps, const void* const* bgr, const void* const* depth, int bs, int ds, int on_device) {
+    if (!s || n < 1 || !bgr || !depth) return -1;
+    return guarded(s, [&]() {
+        if (!s->queue.empty()) throw std::runtime_error("previous prefetched frames not consumed yet");
+        std::vector<Frame::Ptr> fr;
+        for (int i = 0; i < n; ++i) fr.push_back(make_frame(s, stamps ? stamps[i] : 0.0, bgr[i], depth[i], bs, ds, on_device));
+        int done = s->frontend->PrefetchFrames(fr);
+        for (int i = 0; i < done; ++i) s->queue.push_back(fr[i]);
+    });
+}
+
+int myslam_add_prefetched(myslam_system* s, int* tracked, double T_wc[12]) {
+    if (!s) return -1;
+    return guarded(s, [&]() {
+        if (s->queue.empty()) throw std::runtime_error("no prefetched frame queued");
+        Frame::Ptr f = s->queue.front(); s->queue.pop_front();
+        bool ok = s->frontend->AddFrame(f);
+        if (tracked) *tracked = ok ? 1 : 0;
+        out_pose(f, T_wc);
+    });
+}
+
+int myslam_add_frame(myslam_system* s, double stamp, const void* bgr, const void* depth, int bs, int ds, int on_device, int* tracked, double T_wc[12]) {
+    if (!s || !bgr || !depth) return -1;
+    return guarded(s, [&]() {
+        Frame::Ptr f = make_frame(s, stamp, bgr, depth, bs, ds, on_device);
+        bool ok = s->frontend->AddFrame(f);
+        if (tracked) *tracked = ok ? 1 : 0;
+        out_pose(f, T_wc);
+    });
+}
+
+int myslam_get_stats(myslam_system* s, myslam_stats* st) {
+    if (!s || !st) return -1;
+    std::memset(st, 0, sizeof(*st));
+    const auto& f = s->frontend->GetStats();
+    st->frames = f.frames; st->keyframes = f.keyframes; st->lost = f.lost; st->state = (int)s->frontend->GetState();
+    st->last_keypoints = f.last_keypoints; st->last_candidates = f.last_candidates; st->last_matches = f.last_matches;
+    st->last_ransac_inliers = f.last_ransac; st->last_lm_inliers = f.last_lm; st->map_points = (int)s->map.MappointCount();
+    if (s->backend) {
+        const auto& b = s->backend->GetStats();
+        st->ba_runs = b.runs; st->ba_poses = b.poses; st->ba_fixed = b.fixed; st->ba_points = b.points; st->ba_edges = b.edges; st->ba_outliers = b.outliers; st->ba_ms = b.ms;
+    }
+    return 0;
+}
+
+}  // extern "C"
