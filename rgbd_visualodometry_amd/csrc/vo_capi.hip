@@ -1,0 +1,554 @@
+// vo_capi.hip -- context management and the extern "C" entry points of include/vo_hip.h for the
+// HIP (gfx950) implementation.  No CPU fallback exists in this library: without a usable HIP
+// device vo_ctx_create returns VO_E_DEVICE.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "vo_internal.h"
+
+int vo_orb_upload_constants();
+
+static inline short sat_short(long v) { return (short)std::min(32767L, std::max(-32768L, v)); }
+static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// Host-side plan: level sizes, quotas and the fixed-point tables (cv::ORB / cv::resize semantics,
+// see SURVEY.md 8a-1).  Computed once per context; the kernels only read it.
+static int build_plan(const vo_params& p, DevPlan& P, std::vector<int>& tab, std::vector<short>& tabs) {
+    memset(&P, 0, sizeof(P));
+    P.W = p.width; P.H = p.height; P.L = p.n_levels; P.nfeat = p.n_features; P.fast_thr = p.fast_threshold; P.edge = p.edge_threshold;
+    P.fx = p.fx; P.fy = p.fy; P.cx = p.cx; P.cy = p.cy;
+    const double sf = (double)p.scale_factor;
+    unsigned off = 0;
+    for (int l = 0; l < P.L; ++l) {
+        P.scale[l] = (float)std::pow(sf, (double)l);
+        P.lw[l] = (int)lrintf((float)P.W / P.scale[l]);
+        P.lh[l] = (int)lrintf((float)P.H / P.scale[l]);
+        if (P.lw[l] < 2 * P.edge + 1 || P.lh[l] < 2 * P.edge + 1 || P.lw[l] > 4095 || P.lh[l] > 4095) return VO_E_INVALID;
+        P.pitch[l] = align_up(P.lw[l], 64);
+        P.loff[l] = off;
+        off += (unsigned)P.pitch[l] * (unsigned)P.lh[l];
+        off = (off + 255u) & ~255u;
+    }
+    P.pyr_stride = off;
+    float factor = (float)(1.0 / sf);
+    float per = P.nfeat * (1 - factor) / (1 - (float)std::pow((double)factor, (double)P.L));
+    int sum = 0;
+    for (int l = 0; l < P.L - 1; ++l) { P.quota[l] = (int)lrintf(per); sum += P.quota[l]; per *= factor; }
+    P.quota[P.L - 1] = std::max(P.nfeat - sum, 0);
+    int maxq = 1;
+    for (int l = 0; l < P.L; ++l) {
+        P.qprefix[l + 1] = P.qprefix[l] + P.quota[l];
+        P.ccap[l] = std::max(4096, P.lw[l] * P.lh[l] / 8);
+        P.cprefix[l + 1] = P.cprefix[l] + P.ccap[l];
+        P.tiles_x[l] = (P.lw[l] - 2 * P.edge + 63) / 64;
+        const int tiles_y = (P.lh[l] - 2 * P.edge + 15) / 16;
+        P.tile_prefix[l + 1] = P.tile_prefix[l] + P.tiles_x[l] * tiles_y;
+        maxq = std::max(maxq, P.quota[l]);
+    }
+    P.sel_cap = 1;
+    while (P.sel_cap < 4 * maxq) P.sel_cap <<= 1;
+    if ((size_t)P.sel_cap * 12 + 2048 > 160 * 1024) return VO_E_INVALID;
+    // bilinear tables
+    tab.clear(); tabs.clear();
+    for (int l = 1; l < P.L; ++l) {
+        const int sw = P.lw[l - 1], sh = P.lh[l - 1], dw = P.lw[l], dh = P.lh[l];
+        const double sx_ = (double)sw / dw, sy_ = (double)sh / dh;
+        P.tabx[l] = (int)tab.size();
+        for (int dx = 0; dx < dw; ++dx) {
+            float fx = (float)((dx + 0.5) * sx_ - 0.5);
+            int sx = (int)std::floor(fx);
+            fx -= sx;
+            if (sx < 0) { fx = 0; sx = 0; }
+            if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+            tab.push_back(sx);
+            tabs.push_back(sat_short(lrintf((1.f - fx) * 2048.f))); tabs.push_back(sat_short(lrintf(fx * 2048.f)));
+        }
+        P.taby[l] = (int)tab.size();
+        for (int dy = 0; dy < dh; ++dy) {
+            float fy = (float)((dy + 0.5) * sy_ - 0.5);
+            int sy = (int)std::floor(fy);
+            fy -= sy;
+            tab.push_back(sy);
+            tabs.push_back(sat_short(lrintf((1.f - fy) * 2048.f))); tabs.push_back(sat_short(lrintf(fy * 2048.f)));
+        }
+    }
+    const int hp = 15;
+    const int vmax = (int)std::floor(hp * std::sqrt(2.0) / 2 + 1), vmin = (int)std::ceil(hp * std::sqrt(2.0) / 2);
+    for (int v = 0; v <= vmax; ++v) P.umax[v] = (int)lrint(std::sqrt((double)hp * hp - v * v));
+    for (int v = hp, v0 = 0; v >= vmin; --v) {
+        while (P.umax[v0] == P.umax[v0 + 1]) ++v0;
+        P.umax[v] = v0;
+        ++v0;
+    }
+    double g[7], gs = 0;
+    for (int i = 0; i < 7; ++i) { double x = i - 3; g[i] = (double)(float)std::exp(-0.5 / 4.0 * x * x); gs += g[i]; }
+    for (int i = 0; i < 7; ++i) P.gk[i] = (int)lrintf((float)(g[i] / gs) * 256.f);
+    return VO_OK;
+}
+
+void* vo_stage(vo_ctx* c, size_t bytes) {
+    if (bytes <= c->h_stage_bytes) return c->h_stage;
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    c->h_stage = nullptr; c->h_stage_bytes = 0;
+    size_t want = std::max<size_t>(bytes, 1 << 20);
+    if (hipHostMalloc(&c->h_stage, want, hipHostMallocDefault) != hipSuccess) { c->h_stage = nullptr; return nullptr; }
+    c->h_stage_bytes = want;
+    return c->h_stage;
+}
+
+int vo_scratch(vo_ctx* c, size_t bytes) {
+    if (bytes <= c->d_ba_bytes) return VO_OK;
+    if (c->d_ba) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->d_ba); }
+    c->d_ba = nullptr; c->d_ba_bytes = 0;
+    const size_t want = bytes + bytes / 2 + (1 << 20);
+    if (hipMalloc(&c->d_ba, want) != hipSuccess) return VO_E_NOMEM;
+    c->d_ba_bytes = want;
+    return VO_OK;
+}
+
+void vo_prof_begin(vo_ctx* c, const char* name) {
+    ProfRec r; r.name = name;
+    auto get = [&]() { hipEvent_t e; if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
+    r.a = get(); r.b = get();
+    (void)hipEventRecord(r.a, c->stream);
+    c->prof.push_back(r);
+}
+void vo_prof_end(vo_ctx* c) { (void)hipEventRecord(c->prof.back().b, c->stream); }
+
+static void prof_collect(vo_ctx* c) {
+    if (c->prof.empty()) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& r : c->prof) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        size_t i = 0;
+        for (; i < c->prof_names.size(); ++i) if (c->prof_names[i] == r.name) break;
+        if (i == c->prof_names.size()) { c->prof_names.push_back(r.name); c->prof_ms.push_back(0); c->prof_calls.push_back(0); }
+        c->prof_ms[i] += ms; c->prof_calls[i] += 1;
+        c->ev_pool.push_back(r.a); c->ev_pool.push_back(r.b);
+    }
+    c->prof.clear();
+}
+
+template <typename T>
+static int dev_alloc(T** p, size_t count) {
+    *p = nullptr;
+    if (hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return VO_E_NOMEM;
+    return VO_OK;
+}
+#define ALLOC(ptr, count) do { int rc_ = dev_alloc(&(ptr), (count)); if (rc_) { vo_ctx_destroy(c); return rc_; } } while (0)
+
+extern "C" {
+
+const char* vo_backend_name(void) { return "hip-gfx950"; }
+
+const char* vo_strerror(int s) {
+    switch (s) {
+        case VO_OK: return "ok"; case VO_E_INVALID: return "invalid argument"; case VO_E_NOMEM: return "out of memory";
+        case VO_E_DEVICE: return "device error"; case VO_E_OVERFLOW: return "capacity overflow"; case VO_E_STATE: return "bad call sequence";
+        case VO_E_UNSUPPORTED: return "unsupported"; default: return "unknown";
+    }
+}
+
+int vo_default_params(vo_params* p) {
+    if (!p) return VO_E_INVALID;
+    memset(p, 0, sizeof(*p));
+    p->width = 640; p->height = 480; p->fx = 517.3f; p->fy = 516.5f; p->cx = 318.6f; p->cy = 255.3f; p->depth_scale = 5000.f;
+    p->n_features = 500; p->scale_factor = 1.2f; p->n_levels = 8; p->fast_threshold = 20; p->edge_threshold = 31;
+    p->max_frames = 1; p->map_capacity = 1 << 18; p->max_hypotheses = 2048;
+    return VO_OK;
+}
+
+int vo_default_track_params(vo_track_params* t) {
+    if (!t) return VO_E_INVALID;
+    memset(t, 0, sizeof(*t));
+    t->match_ratio = 2.0f; t->match_floor = 30.0f; t->n_hyp = 100; t->reproj_px = 4.0f; t->confidence = 0.99f; t->seed = 0x5eed5eedull;
+    t->huber_delta = std::sqrt(7.815); t->chi2_cut = 1.0; t->it_robust = 10; t->it_plain = 10; t->passes = 2;
+    return VO_OK;
+}
+
+void vo_ctx_destroy(vo_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto p : c->own_bgr) if (p) (void)hipFree(p);
+    for (auto p : c->own_depth) if (p) (void)hipFree(p);
+    void* ptrs[] = {c->d_slots, c->d_pyr, c->d_tab, c->d_tabs, c->d_cand, c->d_cand_cnt, c->d_sel, c->d_sel_key, c->d_sel_cnt, c->d_kps,
+                    c->d_desc, c->d_nkp, c->d_status, c->d_map_pos, c->d_map_nrm, c->d_map_desc, c->d_map_flags, c->d_active, c->d_best,
+                    c->d_matches, c->d_corr_xyz, c->d_corr_uv, c->d_hyp_pose, c->d_hyp_cnt, c->d_inliers, c->d_lm_mask, c->d_track, c->d_ba};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (c->h_track) (void)hipHostFree(c->h_track);
+    if (c->h_matches) (void)hipHostFree(c->h_matches);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    for (auto& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int vo_ctx_create(const vo_params* p, int device, vo_ctx** out) {
+    if (!p || !out || p->width < 64 || p->height < 64 || p->n_levels < 1 || p->n_levels > VO_MAX_LEVELS || p->max_frames < 1 ||
+        p->n_features < 1 || !(p->scale_factor > 1.0f) || p->map_capacity < 1 || p->max_hypotheses < 1) return VO_E_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        fprintf(stderr, "[vo_hip] no usable HIP device (requested %d of %d): the HIP path has no CPU fallback\n", device, ndev);
+        return VO_E_DEVICE;
+    }
+    HIP_TRY(hipSetDevice(device));
+    vo_ctx* c = new (std::nothrow) vo_ctx();
+    if (!c) return VO_E_NOMEM;
+    c->p = *p; c->device = device; c->stream = nullptr; c->prof_on = false; c->corr_external = false;
+    c->d_slots = nullptr; c->d_pyr = nullptr; c->d_tab = nullptr; c->d_tabs = nullptr; c->d_cand = nullptr; c->d_cand_cnt = nullptr;
+    c->d_sel = nullptr; c->d_sel_key = nullptr; c->d_sel_cnt = nullptr; c->d_kps = nullptr; c->d_desc = nullptr; c->d_nkp = nullptr; c->d_status = nullptr;
+    c->d_map_pos = nullptr; c->d_map_nrm = nullptr; c->d_map_desc = nullptr; c->d_map_flags = nullptr; c->d_active = nullptr; c->n_active = 0; c->active_cap = 0;
+    c->d_best = nullptr; c->d_matches = nullptr; c->d_corr_xyz = nullptr; c->d_corr_uv = nullptr; c->corr_cap = 0; c->d_hyp_pose = nullptr; c->d_hyp_cnt = nullptr;
+    c->d_inliers = nullptr; c->d_lm_mask = nullptr; c->d_track = nullptr; c->h_track = nullptr; c->h_matches = nullptr; c->h_matches_cap = 0;
+    c->h_stage = nullptr; c->h_stage_bytes = 0; c->d_ba = nullptr; c->d_ba_bytes = 0;
+    std::vector<int> tab; std::vector<short> tabs;
+    int rc = build_plan(*p, c->plan, tab, tabs);
+    if (rc) { delete c; return rc; }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return VO_E_DEVICE; }
+    rc = vo_orb_upload_constants();
+    if (rc) { vo_ctx_destroy(c); return rc; }
+    const DevPlan& P = c->plan;
+    const int F = p->max_frames;
+    c->own_bgr.assign(F, nullptr); c->own_depth.assign(F, nullptr);
+    c->h_slots.assign(F, SlotDesc{nullptr, nullptr, 0, 0}); c->slot_bound.assign(F, 0); c->slot_orb.assign(F, 0);
+    ALLOC(c->d_slots, (size_t)F);
+    ALLOC(c->d_pyr, (size_t)F * P.pyr_stride);
+    ALLOC(c->d_tab, tab.size()); ALLOC(c->d_tabs, tabs.size());
+    ALLOC(c->d_cand, (size_t)F * P.cprefix[P.L]); ALLOC(c->d_cand_cnt, (size_t)F * VO_MAX_LEVELS);
+    ALLOC(c->d_sel, (size_t)F * P.nfeat); ALLOC(c->d_sel_key, (size_t)F * P.nfeat); ALLOC(c->d_sel_cnt, (size_t)F * VO_MAX_LEVELS);
+    ALLOC(c->d_kps, (size_t)F * P.nfeat); ALLOC(c->d_desc, (size_t)F * P.nfeat * 32); ALLOC(c->d_nkp, (size_t)F);
+    ALLOC(c->d_status, 1);
+    const size_t M = (size_t)p->map_capacity;
+    ALLOC(c->d_map_pos, 3 * M); ALLOC(c->d_map_nrm, 3 * M); ALLOC(c->d_map_desc, 8 * M); ALLOC(c->d_map_flags, M);
+    c->active_cap = p->map_capacity; c->corr_cap = p->map_capacity;
+    ALLOC(c->d_active, M); ALLOC(c->d_best, M); ALLOC(c->d_matches, M); ALLOC(c->d_corr_xyz, 3 * M); ALLOC(c->d_corr_uv, 2 * M);
+    ALLOC(c->d_hyp_pose, (size_t)12 * p->max_hypotheses); ALLOC(c->d_hyp_cnt, (size_t)p->max_hypotheses);
+    ALLOC(c->d_inliers, M); ALLOC(c->d_lm_mask, M); ALLOC(c->d_track, 1);
+    if (hipHostMalloc((void**)&c->h_track, sizeof(TrackDev), hipHostMallocDefault) != hipSuccess) { vo_ctx_destroy(c); return VO_E_NOMEM; }
+    hipStream_t st = c->stream;
+    HIP_TRY(hipMemcpyAsync(c->d_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(c->d_tabs, tabs.data(), tabs.size() * sizeof(short), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(int), st));
+    HIP_TRY(hipMemsetAsync(c->d_nkp, 0, sizeof(int) * F, st));
+    HIP_TRY(hipMemsetAsync(c->d_sel_cnt, 0, sizeof(int) * F * VO_MAX_LEVELS, st));
+    HIP_TRY(hipMemsetAsync(c->d_map_flags, 0, M, st));
+    HIP_TRY(hipMemsetAsync(c->d_track, 0, sizeof(TrackDev), st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *out = c;
+    return VO_OK;
+}
+
+static int push_slot(vo_ctx* c, int slot) {
+    SlotDesc* stage = (SlotDesc*)vo_stage(c, sizeof(SlotDesc));
+    if (!stage) return VO_E_NOMEM;
+    // the staging buffer is shared: make sure an earlier async copy out of it has completed
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *stage = c->h_slots[slot];
+    HIP_TRY(hipMemcpyAsync(c->d_slots + slot, stage, sizeof(SlotDesc), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return VO_OK;
+}
+
+int vo_frame_upload(vo_ctx* c, int slot, const uint8_t* bgr, int bs, const uint16_t* depth, int ds) {
+    if (!c || slot < 0 || slot >= c->p.max_frames || !bgr || !depth || bs < 3 * c->p.width || ds < 2 * c->p.width) return VO_E_INVALID;
+    HIP_TRY(hipSetDevice(c->device));
+    const int W = c->p.width, H = c->p.height;
+    const int bp = align_up(3 * W, 256), dp = align_up(2 * W, 256);
+    if (!c->own_bgr[slot]) { if (hipMalloc((void**)&c->own_bgr[slot], (size_t)bp * H) != hipSuccess) return VO_E_NOMEM; }
+    if (!c->own_depth[slot]) { if (hipMalloc((void**)&c->own_depth[slot], (size_t)dp * H) != hipSuccess) return VO_E_NOMEM; }
+    HIP_TRY(hipMemcpy2DAsync(c->own_bgr[slot], bp, bgr, bs, 3 * (size_t)W, H, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpy2DAsync(c->own_depth[slot], dp, depth, ds, 2 * (size_t)W, H, hipMemcpyHostToDevice, c->stream));
+    c->h_slots[slot] = SlotDesc{c->own_bgr[slot], c->own_depth[slot], bp, dp};
+    c->slot_bound[slot] = 1; c->slot_orb[slot] = 0;
+    return push_slot(c, slot);     // also waits for the pageable host copies: caller may reuse its buffers
+}
+
+int vo_frame_bind_device(vo_ctx* c, int slot, const void* b, int bs, const void* d, int ds) {
+    if (!c || slot < 0 || slot >= c->p.max_frames || !b || !d || bs < 3 * c->p.width || ds < 2 * c->p.width) return VO_E_INVALID;
+    HIP_TRY(hipSetDevice(c->device));
+    c->h_slots[slot] = SlotDesc{(const uint8_t*)b, (const uint8_t*)d, bs, ds};
+    c->slot_bound[slot] = 1; c->slot_orb[slot] = 0;
+    return push_slot(c, slot);
+}
+
+int vo_orb_detect_describe(vo_ctx* c, int slot0, int n) {
+    if (!c || slot0 < 0 || n < 1 || slot0 + n > c->p.max_frames) return VO_E_INVALID;
+    for (int i = slot0; i < slot0 + n; ++i) if (!c->slot_bound[i]) return VO_E_STATE;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = vo_orb_launch(c, slot0, n);
+    if (rc) return rc;
+    for (int i = slot0; i < slot0 + n; ++i) c->slot_orb[i] = 1;
+    return VO_OK;
+}
+
+static int read_status(vo_ctx* c) {
+    int* st = (int*)vo_stage(c, 64);
+    if (!st) return VO_E_NOMEM;
+    HIP_TRY(hipMemcpyAsync(st, c->d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return *st;
+}
+
+int vo_orb_fetch(vo_ctx* c, int slot, vo_keypoint* kps, uint8_t* desc, int cap, int* n_out) {
+    if (!c || slot < 0 || slot >= c->p.max_frames || !n_out || cap < 0) return VO_E_INVALID;
+    if (!c->slot_orb[slot]) return VO_E_STATE;
+    HIP_TRY(hipSetDevice(c->device));
+    const int N = c->p.n_features;
+    const size_t need = 64 + (size_t)N * (sizeof(vo_keypoint) + 32);
+    uint8_t* st = (uint8_t*)vo_stage(c, need);
+    if (!st) return VO_E_NOMEM;
+    int* hn = (int*)st; int* hs = hn + 1;
+    vo_keypoint* hk = (vo_keypoint*)(st + 64);
+    uint8_t* hd = st + 64 + (size_t)N * sizeof(vo_keypoint);
+    const int take = std::min(cap, N);
+    HIP_TRY(hipMemcpyAsync(hn, c->d_nkp + slot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(hs, c->d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (take > 0 && kps) HIP_TRY(hipMemcpyAsync(hk, c->d_kps + (size_t)slot * N, sizeof(vo_keypoint) * take, hipMemcpyDeviceToHost, c->stream));
+    if (take > 0 && desc) HIP_TRY(hipMemcpyAsync(hd, c->d_desc + (size_t)slot * N * 32, (size_t)32 * take, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (*hs != VO_OK) return *hs;
+    const int n = *hn, k = std::min(n, take);
+    if (kps) memcpy(kps, hk, sizeof(vo_keypoint) * k);
+    if (desc) memcpy(desc, hd, (size_t)32 * k);
+    *n_out = n;
+    return VO_OK;
+}
+
+int vo_orb_level_size(vo_ctx* c, int l, int* w, int* h, int* quota) {
+    if (!c || l < 0 || l >= c->plan.L) return VO_E_INVALID;
+    if (w) *w = c->plan.lw[l];
+    if (h) *h = c->plan.lh[l];
+    if (quota) *quota = c->plan.quota[l];
+    return VO_OK;
+}
+
+int vo_orb_fetch_level(vo_ctx* c, int slot, int l, uint8_t* out) {
+    if (!c || slot < 0 || slot >= c->p.max_frames || l < 0 || l >= c->plan.L || !out) return VO_E_INVALID;
+    if (!c->slot_orb[slot]) return VO_E_STATE;
+    HIP_TRY(hipSetDevice(c->device));
+    const DevPlan& P = c->plan;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy2D(out, P.lw[l], c->d_pyr + (size_t)slot * P.pyr_stride + P.loff[l], P.pitch[l], P.lw[l], P.lh[l], hipMemcpyDeviceToHost));
+    return VO_OK;
+}
+
+int vo_map_upsert(vo_ctx* c, const int32_t* idx, const double* xyz, const double* nrm, const uint8_t* desc, const uint8_t* flags, int n) {
+    if (!c || n < 0 || (n && !idx)) return VO_E_INVALID;
+    for (int i = 0; i < n; ++i) if (idx[i] < 0 || idx[i] >= c->p.map_capacity) return VO_E_INVALID;
+    if (n == 0) return VO_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    // pack -> one pinned staging buffer -> one H2D copy -> scatter kernel
+    const size_t N = (size_t)n;
+    const size_t o_idx = 0, o_xyz = (4 * N + 255) & ~(size_t)255, o_nrm = o_xyz + ((24 * N + 255) & ~(size_t)255),
+                 o_desc = o_nrm + ((24 * N + 255) & ~(size_t)255), o_flags = o_desc + ((32 * N + 255) & ~(size_t)255),
+                 total = o_flags + ((N + 255) & ~(size_t)255);
+    uint8_t* h = (uint8_t*)vo_stage(c, total);
+    if (!h) return VO_E_NOMEM;
+    int rc = vo_scratch(c, total);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(st));                      // staging buffer may still feed an earlier copy
+    memcpy(h + o_idx, idx, 4 * N);
+    if (xyz) memcpy(h + o_xyz, xyz, 24 * N);
+    if (nrm) memcpy(h + o_nrm, nrm, 24 * N);
+    if (desc) memcpy(h + o_desc, desc, 32 * N);
+    if (flags) memcpy(h + o_flags, flags, N);
+    uint8_t* d = (uint8_t*)c->d_ba;
+    HIP_TRY(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, st));
+    rc = vo_map_scatter_launch(c, n, (const int32_t*)(d + o_idx), xyz ? (const double*)(d + o_xyz) : nullptr, nrm ? (const double*)(d + o_nrm) : nullptr,
+                               desc ? (const uint32_t*)(d + o_desc) : nullptr, flags ? d + o_flags : nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(st));
+    return VO_OK;
+}
+
+int vo_map_set_active(vo_ctx* c, const int32_t* idx, int n) {
+    if (!c || n < 0 || (n && !idx) || n > c->active_cap) return VO_E_INVALID;
+    for (int i = 0; i < n; ++i) if (idx[i] < 0 || idx[i] >= c->p.map_capacity) return VO_E_INVALID;
+    HIP_TRY(hipSetDevice(c->device));
+    if (n) HIP_TRY(hipMemcpyAsync(c->d_active, idx, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->n_active = n;
+    return VO_OK;
+}
+
+static int upload_pose(vo_ctx* c, const double T[12], bool reset) {
+    // whole header is rewritten: counters start from zero for a new frame
+    TrackDev* h = c->h_track;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (reset) memset(h, 0, sizeof(*h));
+    memcpy(h->T, T, sizeof(double) * 12);
+    memcpy(h->T_ransac, T, sizeof(double) * 12);
+    HIP_TRY(hipMemcpyAsync(c->d_track, h, sizeof(TrackDev), hipMemcpyHostToDevice, c->stream));
+    return VO_OK;
+}
+
+static int download_track(vo_ctx* c) {
+    HIP_TRY(hipMemcpyAsync(c->h_track, c->d_track, sizeof(TrackDev), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return VO_OK;
+}
+
+static int ensure_match_stage(vo_ctx* c, int n) {
+    if (n <= c->h_matches_cap) return VO_OK;
+    if (c->h_matches) (void)hipHostFree(c->h_matches);
+    c->h_matches = nullptr; c->h_matches_cap = 0;
+    const int want = std::max(n, 4096);
+    if (hipHostMalloc((void**)&c->h_matches, sizeof(vo_match) * (size_t)want, hipHostMallocDefault) != hipSuccess) return VO_E_NOMEM;
+    c->h_matches_cap = want;
+    return VO_OK;
+}
+
+int vo_match_active_map(vo_ctx* c, int slot, const double T[12], float ratio, float floor_dist, vo_match* out, int cap,
+                        int* n_out, int* n_cand, int* min_distance) {
+    if (!c || slot < 0 || slot >= c->p.max_frames || !T || cap < 0) return VO_E_INVALID;
+    if (!c->slot_orb[slot]) return VO_E_STATE;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = upload_pose(c, T, true);
+    if (rc) return rc;
+    rc = vo_track_match_launch(c, slot, ratio, floor_dist);
+    if (rc) return rc;
+    const int take = std::min(cap, c->n_active);
+    rc = ensure_match_stage(c, take);
+    if (rc) return rc;
+    if (take > 0 && out) HIP_TRY(hipMemcpyAsync(c->h_matches, c->d_matches, sizeof(vo_match) * take, hipMemcpyDeviceToHost, c->stream));
+    rc = download_track(c);
+    if (rc) return rc;
+    const TrackDev& t = *c->h_track;
+    if (out) memcpy(out, c->h_matches, sizeof(vo_match) * std::min(take, t.n_match));
+    if (n_out) *n_out = t.n_match;
+    if (n_cand) *n_cand = t.n_cand;
+    if (min_distance) *min_distance = t.min_dist;
+    return t.status;
+}
+
+int vo_matches_set(vo_ctx* c, const float* xyz, const float* uv, int n) {
+    if (!c || n < 0 || (n && (!xyz || !uv))) return VO_E_INVALID;
+    HIP_TRY(hipSetDevice(c->device));
+    return vo_corr_from_host(c, xyz, uv, n);
+}
+
+int vo_pnp_ransac(vo_ctx* c, int n_hyp, float reproj_px, float conf, uint64_t seed, double T[12], int32_t* inl, int cap,
+                  int* n_inl, int32_t* hyp_counts, int* iters_used, int* best_hyp) {
+    if (!c || !T || n_hyp < 1 || n_hyp > c->p.max_hypotheses || cap < 0) return VO_E_INVALID;
+    HIP_TRY(hipSetDevice(c->device));
+    // keep n_match of the current correspondence set; only the pose is replaced
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int rc = download_track(c);
+    if (rc) return rc;
+    memcpy(c->h_track->T, T, sizeof(double) * 12);
+    HIP_TRY(hipMemcpyAsync(c->d_track, c->h_track, sizeof(TrackDev), hipMemcpyHostToDevice, c->stream));
+    rc = vo_track_ransac_launch(c, n_hyp, reproj_px, conf, seed);
+    if (rc) return rc;
+    rc = download_track(c);
+    if (rc) return rc;
+    const TrackDev t = *c->h_track;
+    memcpy(T, t.T, sizeof(double) * 12);
+    const int take = std::min(cap, t.n_inl);
+    if (take > 0 && inl) HIP_TRY(hipMemcpy(inl, c->d_inliers, sizeof(int32_t) * take, hipMemcpyDeviceToHost));
+    if (hyp_counts) HIP_TRY(hipMemcpy(hyp_counts, c->d_hyp_cnt, sizeof(int32_t) * n_hyp, hipMemcpyDeviceToHost));
+    if (n_inl) *n_inl = t.n_inl;
+    if (iters_used) *iters_used = t.iters_used;
+    if (best_hyp) *best_hyp = t.best_hyp;
+    return VO_OK;
+}
+
+int vo_pose_refine_lm(vo_ctx* c, double T[12], double delta, double cut, int it_r, int it_p, uint8_t* mask, int cap,
+                      int* n_edges, int* lm_iters) {
+    if (!c || !T || cap < 0) return VO_E_INVALID;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = download_track(c);
+    if (rc) return rc;
+    memcpy(c->h_track->T, T, sizeof(double) * 12);
+    c->h_track->lm_iters = 0;
+    HIP_TRY(hipMemcpyAsync(c->d_track, c->h_track, sizeof(TrackDev), hipMemcpyHostToDevice, c->stream));
+    rc = vo_track_lm_launch(c, delta, cut, it_r, it_p);
+    if (rc) return rc;
+    rc = download_track(c);
+    if (rc) return rc;
+    const TrackDev t = *c->h_track;
+    memcpy(T, t.T, sizeof(double) * 12);
+    const int take = std::min(cap, t.n_inl);
+    if (take > 0 && mask) {
+        std::vector<uint8_t> tmp(take);
+        HIP_TRY(hipMemcpy(tmp.data(), c->d_lm_mask, take, hipMemcpyDeviceToHost));
+        for (int i = 0; i < take; ++i) mask[i] = tmp[i] & 1;
+    }
+    if (n_edges) *n_edges = t.n_inl;
+    if (lm_iters) *lm_iters = t.lm_iters;
+    return VO_OK;
+}
+
+int vo_track_frame(vo_ctx* c, int slot, const double T0[12], const vo_track_params* tp, vo_track_result* res,
+                   vo_match* matches, int cap) {
+    if (!c || !T0 || !tp || !res || slot < 0 || slot >= c->p.max_frames || tp->passes < 1 || cap < 0 ||
+        tp->n_hyp < 1 || tp->n_hyp > c->p.max_hypotheses) return VO_E_INVALID;
+    if (!c->slot_orb[slot]) return VO_E_STATE;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = upload_pose(c, T0, true);
+    if (rc) return rc;
+    for (int pass = 0; pass < tp->passes; ++pass) {           // coarse, fine (frontend.cpp:100-108)
+        if ((rc = vo_track_match_launch(c, slot, tp->match_ratio, tp->match_floor))) return rc;
+        if ((rc = vo_track_ransac_launch(c, tp->n_hyp, tp->reproj_px, tp->confidence, tp->seed + (uint64_t)pass))) return rc;
+        if ((rc = vo_track_lm_launch(c, tp->huber_delta, tp->chi2_cut, tp->it_robust, tp->it_plain))) return rc;
+    }
+    if ((rc = vo_track_flags_launch(c))) return rc;
+    const int take = std::min(cap, c->n_active);
+    if ((rc = ensure_match_stage(c, take))) return rc;
+    if (take > 0 && matches) HIP_TRY(hipMemcpyAsync(c->h_matches, c->d_matches, sizeof(vo_match) * take, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = download_track(c))) return rc;
+    const TrackDev& t = *c->h_track;
+    memset(res, 0, sizeof(*res));
+    memcpy(res->T_cw, t.T, sizeof(double) * 12);
+    res->n_candidates = t.n_cand; res->n_matches = t.n_match; res->n_ransac_inliers = t.n_inl; res->n_lm_inliers = t.n_lm_inl;
+    res->min_distance = t.min_dist; res->ransac_iters = t.iters_used; res->best_hypothesis = t.best_hyp; res->lm_iters = t.lm_iters;
+    res->status = t.status;
+    if (t.n_match > cap && matches) res->status = VO_E_OVERFLOW;
+    if (matches) memcpy(matches, c->h_matches, sizeof(vo_match) * std::min(take, t.n_match));
+    return VO_OK;
+}
+
+int vo_local_ba(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
+    if (!c || !in || !out || !out->poses || !out->points || !out->edge_flags) return VO_E_INVALID;
+    if (in->n_free < 0 || in->n_free > in->n_poses || in->n_points < 0 || in->n_edges < 0) return VO_E_INVALID;
+    for (int e = 0; e < in->n_edges; ++e)
+        if (in->edge_pose[e] < 0 || in->edge_pose[e] >= in->n_poses || in->edge_point[e] < 0 || in->edge_point[e] >= in->n_points) return VO_E_INVALID;
+    HIP_TRY(hipSetDevice(c->device));
+    return vo_ba_run(c, in, out);
+}
+
+int vo_sync(vo_ctx* c) {
+    if (!c) return VO_E_INVALID;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return read_status(c);
+}
+
+int vo_profile_enable(vo_ctx* c, int on) {
+    if (!c) return VO_E_INVALID;
+    prof_collect(c);
+    c->prof_on = on != 0;
+    if (on) { c->prof_names.clear(); c->prof_ms.clear(); c->prof_calls.clear(); }
+    return VO_OK;
+}
+
+int vo_profile_read(vo_ctx* c, char (*names)[48], double* ms, int64_t* calls, int cap, int* n) {
+    if (!c || !n) return VO_E_INVALID;
+    prof_collect(c);
+    const int k = std::min<int>(cap, (int)c->prof_names.size());
+    for (int i = 0; i < k; ++i) {
+        if (names) { strncpy(names[i], c->prof_names[i].c_str(), 47); names[i][47] = 0; }
+        if (ms) ms[i] = c->prof_ms[i];
+        if (calls) calls[i] = c->prof_calls[i];
+    }
+    *n = k;
+    return VO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,100 @@
+// vo_internal.h -- internal declarations of the HIP implementation of include/vo_hip.h.
+// Target: gfx950 (MI355X, CDNA4) only: 64-wide wavefronts, 160 KiB LDS per CU, 256 CUs.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "vo_hip.h"
+
+#define VO_MAX_LEVELS 16
+#define VO_WAVE 64
+
+// Everything a kernel needs to know about the pyramid / detector geometry; passed by value.
+struct DevPlan {
+    int W, H, L, nfeat, fast_thr, edge;
+    int lw[VO_MAX_LEVELS], lh[VO_MAX_LEVELS], pitch[VO_MAX_LEVELS];
+    int quota[VO_MAX_LEVELS], qprefix[VO_MAX_LEVELS + 1];       // selected-keypoint quota per level and its prefix sum
+    int ccap[VO_MAX_LEVELS], cprefix[VO_MAX_LEVELS + 1];        // FAST candidate capacity per level and prefix
+    unsigned loff[VO_MAX_LEVELS];                               // byte offset of each level inside a slot's pyramid slab
+    float scale[VO_MAX_LEVELS];
+    int tiles_x[VO_MAX_LEVELS], tile_prefix[VO_MAX_LEVELS + 1]; // FAST tiling (64x16 tiles), blockIdx.x -> (level, tile)
+    int tabx[VO_MAX_LEVELS], taby[VO_MAX_LEVELS];               // offsets into the resize tables
+    int umax[16];
+    int gk[7];
+    int sel_cap;                                                // power-of-two sort capacity of the select kernel
+    unsigned pyr_stride;                                        // bytes per slot in the pyramid slab
+    float fx, fy, cx, cy;
+};
+
+struct SlotDesc {               // where a slot's input frame lives (device memory)
+    const uint8_t* bgr; const uint8_t* depth; int bgr_stride, depth_stride;
+};
+
+struct ProfRec { const char* name; hipEvent_t a, b; };
+
+// Device-resident result header of the tracking chain (one per context).
+struct TrackDev {
+    int n_cand, n_match, min_dist, pad0;
+    int n_inl, best_hyp, iters_used, best_cnt;
+    int lm_iters, n_lm_inl, status, pad1;
+    double T[12];               // current pose estimate (in/out through the chain)
+    double T_ransac[12];
+};
+
+struct vo_ctx {
+    vo_params p;
+    DevPlan plan;
+    int device;
+    hipStream_t stream;
+    // frames
+    std::vector<uint8_t*> own_bgr, own_depth;       // per slot (allocated lazily on upload)
+    SlotDesc* d_slots; std::vector<SlotDesc> h_slots;
+    std::vector<char> slot_bound, slot_orb;
+    // pyramid + ORB work buffers
+    uint8_t* d_pyr;
+    int* d_tab; short* d_tabs;                      // resize tables: int offsets, short weights
+    uint32_t* d_cand; int* d_cand_cnt;              // [slot][cprefix[L]] packed candidates, [slot][L] counts
+    uint32_t* d_sel; long long* d_sel_key; int* d_sel_cnt;   // [slot][nfeat] selected (x|y<<12), keys, [slot][L] counts
+    vo_keypoint* d_kps; uint8_t* d_desc; int* d_nkp;         // [slot][nfeat], [slot][nfeat*32], [slot]
+    int* d_status;                                  // sticky overflow flag
+    // map
+    double* d_map_pos; double* d_map_nrm; uint32_t* d_map_desc; uint8_t* d_map_flags;
+    int32_t* d_active; int n_active; int active_cap;
+    // tracking chain
+    unsigned long long* d_best;                     // per active query: (dist<<32)|kp
+    vo_match* d_matches; float* d_corr_xyz; float* d_corr_uv; int corr_cap;
+    double* d_hyp_pose; int* d_hyp_cnt;             // [max_hyp][12], [max_hyp]
+    int32_t* d_inliers; uint8_t* d_lm_mask;
+    TrackDev* d_track; TrackDev* h_track;           // h_track pinned
+    vo_match* h_matches;                            // pinned staging
+    int h_matches_cap;
+    void* h_stage; size_t h_stage_bytes;            // pinned general staging
+    bool corr_external;
+    // BA scratch
+    void* d_ba; size_t d_ba_bytes;
+    // profiling
+    bool prof_on; std::vector<ProfRec> prof; std::vector<hipEvent_t> ev_pool;
+    std::vector<std::string> prof_names; std::vector<double> prof_ms; std::vector<int64_t> prof_calls;
+};
+
+// profiling helpers (vo_capi.hip)
+void vo_prof_begin(vo_ctx* c, const char* name);
+void vo_prof_end(vo_ctx* c);
+struct ProfScope { vo_ctx* c; ProfScope(vo_ctx* c_, const char* n) : c(c_) { if (c->prof_on) vo_prof_begin(c, n); } ~ProfScope() { if (c->prof_on) vo_prof_end(c); } };
+void* vo_stage(vo_ctx* c, size_t bytes);           // pinned host staging buffer of at least `bytes`
+int vo_scratch(vo_ctx* c, size_t bytes);           // grow the device scratch slab c->d_ba to at least `bytes`
+int vo_map_scatter_launch(vo_ctx* c, int n, const int32_t* d_idx, const double* d_xyz, const double* d_nrm, const uint32_t* d_desc, const uint8_t* d_flags);
+
+// stage launchers
+int vo_orb_launch(vo_ctx* c, int slot0, int nslots);                                        // vo_orb.hip
+int vo_track_match_launch(vo_ctx* c, int slot, float ratio, float floor_dist);              // vo_track.hip
+int vo_track_ransac_launch(vo_ctx* c, int n_hyp, float reproj_px, float conf, uint64_t seed);
+int vo_track_lm_launch(vo_ctx* c, double delta, double cut, int it_r, int it_p);
+int vo_track_flags_launch(vo_ctx* c);
+int vo_corr_from_host(vo_ctx* c, const float* xyz, const float* uv, int n);
+int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out);                       // vo_ba.hip
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "[vo_hip] %s -> %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return VO_E_DEVICE; } } while (0)

@@ -1,0 +1,413 @@
+// vo_orb.hip -- ORB detect + describe on gfx950, replacing cv::ORB::detectAndCompute behind
+// FrontEnd::ExtractKeyPointsAndComputeDescriptors (reference src/frontend.cpp:150-154; detector
+// parameters :35-37).  All kernels are batched over frame slots (blockIdx.z = slot) so that the
+// look-ahead batch of a stream -- or many streams -- runs as one launch chain:
+//
+//   k_gray      BGR8 -> gray8 level 0            HBM-bound, 16-B per lane stores
+//   k_resize    level l from level l-1           11-bit fixed-point bilinear (cv::resize 8u semantics)
+//   k_fast_nms  FAST-9/16 score + 3x3 NMS        one 64x16 tile per workgroup, gray tile + halo in LDS,
+//                                                scores never leave LDS; survivors appended to a list
+//   k_select    retain-best by FAST then Harris  one workgroup per (level, slot): LDS histogram cut,
+//                                                exact integer Harris, LDS bitonic sort
+//   k_describe  IC angle + 7x7 blur + rBRIEF     one wavefront per keypoint: 43x43 patch staged in LDS,
+//                                                256 tests packed with 4 x __ballot (64 lanes)
+//
+// Integer pipeline end to end: bit-exact against oracle/o_orb.cpp by construction.
+#include <cfloat>
+#include <climits>
+#include <cstdio>
+
+#include "vo_brief_pattern.h"
+#include "vo_internal.h"
+
+__constant__ int8_t c_pattern[256 * 4];
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gray(DevPlan P, const SlotDesc* __restrict__ slots, uint8_t* __restrict__ pyr, int slot0) {
+    const int slot = slot0 + blockIdx.z, y = blockIdx.y;
+    const int g = blockIdx.x * 256 + threadIdx.x;      // group of 4 pixels
+    const int x = g * 4;
+    if (x >= P.W) return;
+    const SlotDesc sd = slots[slot];
+    const uint8_t* row = sd.bgr + (size_t)y * sd.bgr_stride + 3 * (size_t)x;
+    uint8_t* out = pyr + (size_t)slot * P.pyr_stride + P.loff[0] + (size_t)y * P.pitch[0] + x;
+    uint8_t px[12];
+    const int n = min(4, P.W - x);
+    if (n == 4 && ((uintptr_t)row & 3) == 0) {
+        const uint32_t* r32 = (const uint32_t*)row;
+        uint32_t a = r32[0], b = r32[1], c = r32[2];
+        *(uint32_t*)&px[0] = a; *(uint32_t*)&px[4] = b; *(uint32_t*)&px[8] = c;
+    } else {
+        for (int i = 0; i < 3 * n; ++i) px[i] = row[i];
+    }
+    uint32_t packed = 0;
+    for (int i = 0; i < n; ++i) {
+        uint32_t v = (px[3 * i] * 1868u + px[3 * i + 1] * 9617u + px[3 * i + 2] * 4899u + 8192u) >> 14;
+        packed |= v << (8 * i);
+    }
+    if (n == 4) *(uint32_t*)out = packed;
+    else for (int i = 0; i < n; ++i) out[i] = (uint8_t)(packed >> (8 * i));
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize(DevPlan P, int l, uint8_t* __restrict__ pyr, const int* __restrict__ tab,
+                                                const short* __restrict__ tabs, int slot0) {
+    const int slot = slot0 + blockIdx.z;
+    const int dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y * 4 + threadIdx.y;
+    const int dw = P.lw[l], dh = P.lh[l], sw = P.lw[l - 1], sh = P.lh[l - 1];
+    if (dx >= dw || dy >= dh) return;
+    const uint8_t* src = pyr + (size_t)slot * P.pyr_stride + P.loff[l - 1];
+    uint8_t* dst = pyr + (size_t)slot * P.pyr_stride + P.loff[l];
+    const int sp = P.pitch[l - 1];
+    const int sx = tab[P.tabx[l] + dx], sy = tab[P.taby[l] + dy];
+    const int a0 = tabs[2 * (P.tabx[l] + dx)], a1 = tabs[2 * (P.tabx[l] + dx) + 1];
+    const int b0 = tabs[2 * (P.taby[l] + dy)], b1 = tabs[2 * (P.taby[l] + dy) + 1];
+    const int sx1 = min(sx + 1, sw - 1);
+    const int r0 = min(max(sy, 0), sh - 1), r1 = min(max(sy + 1, 0), sh - 1);
+    const uint8_t* S0 = src + (size_t)r0 * sp;
+    const uint8_t* S1 = src + (size_t)r1 * sp;
+    const int h0 = S0[sx] * a0 + S0[sx1] * a1;
+    const int h1 = S1[sx] * a0 + S1[sx1] * a1;
+    int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+    dst[(size_t)dy * P.pitch[l] + dx] = (uint8_t)min(255, max(0, v));
+}
+
+// ------------------------------------------------------------------------------------------
+// FAST-9/16 corner score: the largest threshold for which the pixel is still a corner =
+// max over the 16 arcs of 9 contiguous ring pixels of min(+diff) or min(-diff), minus 1.
+#define TW 64
+#define TH 16
+#define GP (TW + 8)          // gray tile pitch (halo 4)
+#define SP (TW + 2)          // score tile pitch (halo 1)
+
+__device__ __forceinline__ int fast_score_lds(const uint8_t* g, int idx) {
+    // ring offsets in a GP-pitch tile, same order as the oracle's RING table
+    const int off[16] = {3 * GP, 3 * GP + 1, 2 * GP + 2, GP + 3, 3, -GP + 3, -2 * GP + 2, -3 * GP + 1,
+                         -3 * GP, -3 * GP - 1, -2 * GP - 2, -GP - 3, -3, GP - 3, 2 * GP - 2, 3 * GP - 1};
+    const int p = g[idx];
+    int d[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d[i] = (int)g[idx + off[i]] - p;
+    int mn2[16], mx2[16], mn4[16], mx4[16], mn8[16], mx8[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { mn2[i] = min(d[i], d[(i + 1) & 15]); mx2[i] = max(d[i], d[(i + 1) & 15]); }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { mn4[i] = min(mn2[i], mn2[(i + 2) & 15]); mx4[i] = max(mx2[i], mx2[(i + 2) & 15]); }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { mn8[i] = min(mn4[i], mn4[(i + 4) & 15]); mx8[i] = max(mx4[i], mx4[(i + 4) & 15]); }
+    int best = -256;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        int mn9 = min(mn8[i], d[(i + 8) & 15]), mx9 = max(mx8[i], d[(i + 8) & 15]);
+        best = max(best, max(mn9, -mx9));
+    }
+    return best - 1;
+}
+
+__global__ __launch_bounds__(256) void k_fast_nms(DevPlan P, const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand,
+                                                  int* __restrict__ cand_cnt, int* __restrict__ status, int slot0) {
+    __shared__ uint8_t s_gray[GP * (TH + 8)];
+    __shared__ uint8_t s_score[SP * (TH + 2)];
+    const int slot = slot0 + blockIdx.z;
+    int l = 0;
+    while (l + 1 < P.L && (int)blockIdx.x >= P.tile_prefix[l + 1]) ++l;
+    const int t = blockIdx.x - P.tile_prefix[l];
+    const int w = P.lw[l], h = P.lh[l], pitch = P.pitch[l];
+    const int x0 = P.edge + (t % P.tiles_x[l]) * TW, y0 = P.edge + (t / P.tiles_x[l]) * TH;
+    const uint8_t* img = pyr + (size_t)slot * P.pyr_stride + P.loff[l];
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    // gray tile with halo 4 (coordinates clamped; clamped positions never produce a score)
+    for (int i = tid; i < GP * (TH + 8); i += 256) {
+        int gx = x0 - 4 + i % GP, gy = y0 - 4 + i / GP;
+        gx = min(max(gx, 0), w - 1); gy = min(max(gy, 0), h - 1);
+        s_gray[i] = img[(size_t)gy * pitch + gx];
+    }
+    __syncthreads();
+    // scores on the tile + halo 1
+    for (int i = tid; i < SP * (TH + 2); i += 256) {
+        const int sx = i % SP, sy = i / SP;
+        const int x = x0 - 1 + sx, y = y0 - 1 + sy;
+        int sc = 0;
+        if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) {
+            const int gi = (sy + 3) * GP + sx + 3;
+            const int p = s_gray[gi], thr = P.fast_thr;
+            // every 9-arc contains one pixel of each opposite pair: cheap reject
+            const bool c0 = abs((int)s_gray[gi + 3 * GP] - p) > thr || abs((int)s_gray[gi - 3 * GP] - p) > thr;
+            const bool c1 = abs((int)s_gray[gi + 3] - p) > thr || abs((int)s_gray[gi - 3] - p) > thr;
+            if (c0 && c1) {
+                int s = fast_score_lds(s_gray, gi);
+                if (s >= thr) sc = min(s, 255);
+            }
+        }
+        s_score[i] = (uint8_t)sc;
+    }
+    __syncthreads();
+    // 3x3 non-max suppression (strict), border filter, append survivors
+    for (int k = 0; k < TH / 4; ++k) {
+        const int ty = threadIdx.y + 4 * k, tx = threadIdx.x;
+        const int x = x0 + tx, y = y0 + ty;
+        if (x >= w - P.edge || y >= h - P.edge) continue;
+        const uint8_t* q = &s_score[(ty + 1) * SP + tx + 1];
+        const int s = q[0];
+        if (s == 0) continue;
+        if (s > q[-1] && s > q[1] && s > q[-SP - 1] && s > q[-SP] && s > q[-SP + 1] && s > q[SP - 1] && s > q[SP] && s > q[SP + 1]) {
+            int pos = atomicAdd(&cand_cnt[slot * VO_MAX_LEVELS + l], 1);
+            if (pos < P.ccap[l]) cand[(size_t)slot * P.cprefix[P.L] + P.cprefix[l] + pos] = ((uint32_t)s << 24) | ((uint32_t)y << 12) | (uint32_t)x;
+            else *status = VO_E_OVERFLOW;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long harris_key_dev(const uint8_t* img, int pitch, int x, int y) {
+    long long a = 0, b = 0, c = 0;
+    for (int dy = -3; dy <= 3; ++dy) {
+        const uint8_t* r0 = img + (size_t)(y + dy - 1) * pitch + x;
+        const uint8_t* r1 = r0 + pitch;
+        const uint8_t* r2 = r1 + pitch;
+#pragma unroll
+        for (int dx = -3; dx <= 3; ++dx) {
+            const int ix = ((int)r1[dx + 1] - (int)r1[dx - 1]) * 2 + ((int)r0[dx + 1] - (int)r0[dx - 1]) + ((int)r2[dx + 1] - (int)r2[dx - 1]);
+            const int iy = ((int)r2[dx] - (int)r0[dx]) * 2 + ((int)r2[dx - 1] - (int)r0[dx - 1]) + ((int)r2[dx + 1] - (int)r0[dx + 1]);
+            a += ix * ix; b += iy * iy; c += ix * iy;
+        }
+    }
+    return 25 * (a * b - c * c) - (a + b) * (a + b);
+}
+
+__device__ __forceinline__ bool sel_before(long long ka, uint32_t ia, long long kb, uint32_t ib) {
+    return ka > kb || (ka == kb && ia < ib);
+}
+
+// one workgroup per (level, slot)
+__global__ __launch_bounds__(1024) void k_select(DevPlan P, const uint8_t* __restrict__ pyr, const uint32_t* __restrict__ cand,
+                                                 const int* __restrict__ cand_cnt, uint32_t* __restrict__ sel, long long* __restrict__ sel_key,
+                                                 int* __restrict__ sel_cnt, int slot0) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    long long* s_key = (long long*)smem;                            // [sel_cap]
+    uint32_t* s_idx = (uint32_t*)(smem + (size_t)P.sel_cap * 8);    // [sel_cap]  packed (y<<12|x) doubles as the tie-break index y*4096+x
+    int* s_hist = (int*)(smem + (size_t)P.sel_cap * 12);            // [256] + misc
+    int* s_misc = s_hist + 256;
+    const int l = blockIdx.x, slot = slot0 + blockIdx.y, tid = threadIdx.x;
+    const int n = min(cand_cnt[slot * VO_MAX_LEVELS + l], P.ccap[l]);
+    const int quota = P.quota[l];
+    const uint32_t* cl = cand + (size_t)slot * P.cprefix[P.L] + P.cprefix[l];
+    const uint8_t* img = pyr + (size_t)slot * P.pyr_stride + P.loff[l];
+    const int pitch = P.pitch[l];
+    if (tid < 256) s_hist[tid] = 0;
+    if (tid == 0) { s_misc[0] = 0; s_misc[1] = 0; }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) atomicAdd(&s_hist[cl[i] >> 24], 1);
+    __syncthreads();
+    if (tid == 0) {
+        int thr = 0;
+        if (n > 2 * quota) {
+            int acc = 0, s = 255;
+            for (; s >= 0; --s) { acc += s_hist[s]; if (acc >= 2 * quota) break; }
+            thr = s;
+            if (acc > 4 * quota) thr = s + 1;
+        }
+        s_misc[1] = thr;
+    }
+    __syncthreads();
+    const int thr = s_misc[1];
+    for (int i = tid; i < n; i += 1024) {
+        const uint32_t c = cl[i];
+        if ((int)(c >> 24) >= thr) {
+            const int pos = atomicAdd(&s_misc[0], 1);
+            if (pos < P.sel_cap) {
+                const int x = c & 0xFFF, y = (c >> 12) & 0xFFF;
+                s_key[pos] = harris_key_dev(img, pitch, x, y);
+                s_idx[pos] = c & 0xFFFFFF;
+            }
+        }
+    }
+    __syncthreads();
+    const int kept = min(s_misc[0], P.sel_cap);
+    int m = 1;
+    while (m < kept) m <<= 1;
+    for (int i = kept + tid; i < m; i += 1024) { s_key[i] = LLONG_MIN; s_idx[i] = 0xFFFFFFFFu; }
+    __syncthreads();
+    for (int k = 2; k <= m; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < m; i += 1024) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const long long ka = s_key[i], kb = s_key[p];
+                    const uint32_t ia = s_idx[i], ib = s_idx[p];
+                    const bool up = (i & k) == 0;          // ascending position = "before" order
+                    const bool swap = up ? sel_before(kb, ib, ka, ia) : sel_before(ka, ia, kb, ib);
+                    if (swap) { s_key[i] = kb; s_key[p] = ka; s_idx[i] = ib; s_idx[p] = ia; }
+                }
+            }
+            __syncthreads();
+        }
+    const int out_n = min(kept, quota);
+    for (int i = tid; i < out_n; i += 1024) {
+        sel[(size_t)slot * P.nfeat + P.qprefix[l] + i] = s_idx[i];
+        sel_key[(size_t)slot * P.nfeat + P.qprefix[l] + i] = s_key[i];
+    }
+    if (tid == 0) sel_cnt[slot * VO_MAX_LEVELS + l] = out_n;
+}
+
+// ------------------------------------------------------------------------------------------
+#define PR 21                 // raw patch radius (18 for the rotated BRIEF footprint + 3 for the blur)
+#define PW (2 * PR + 1)       // 43
+#define PP 44                 // raw patch pitch
+#define BR 18
+#define BW (2 * BR + 1)       // 37
+#define WAVE_LDS (PW * PP + PW * BW * 2 + BW * BW + 7)
+
+__device__ __forceinline__ float fast_atan2_deg_dev(float y, float x) {
+    const float k = 57.29577951308232f;
+    const float p1 = 0.9997878412794807f * k, p3 = -0.3258083974640975f * k, p5 = 0.1555786518463281f * k, p7 = -0.04432655554792128f * k;
+    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+    if (ax >= ay) { c = ay / (ax + 2.220446e-16f); c2 = c * c; a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    else { c = ax / (ay + 2.220446e-16f); c2 = c * c; a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// one wavefront per keypoint, 4 per workgroup
+__global__ __launch_bounds__(256) void k_describe(DevPlan P, const SlotDesc* __restrict__ slots, const uint8_t* __restrict__ pyr,
+                                                  const uint32_t* __restrict__ sel, const long long* __restrict__ sel_key,
+                                                  const int* __restrict__ sel_cnt, vo_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
+                                                  int* __restrict__ nkp, int slot0) {
+    __shared__ __align__(8) uint8_t s_all[4][(WAVE_LDS + 7) & ~7];
+    const int slot = slot0 + blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + wave;
+    uint8_t* raw = s_all[wave];
+    uint16_t* hb = (uint16_t*)(raw + PW * PP);
+    uint8_t* blur = raw + PW * PP + PW * BW * 2;
+    // which level / rank is keypoint slot g, and where does it land in the compact output?
+    int l = 0, base = 0, total = 0;
+    for (int i = 0; i < P.L; ++i) total += sel_cnt[slot * VO_MAX_LEVELS + i];
+    bool active = g < P.nfeat;
+    if (active) {
+        while (l + 1 < P.L && g >= P.qprefix[l + 1]) { base += sel_cnt[slot * VO_MAX_LEVELS + l]; ++l; }
+        active = (g - P.qprefix[l]) < sel_cnt[slot * VO_MAX_LEVELS + l];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) nkp[slot] = total;
+    int x = 0, y = 0;
+    const int pitch = P.pitch[l];
+    const uint8_t* img = pyr + (size_t)slot * P.pyr_stride + P.loff[l];
+    if (active) {
+        const uint32_t c = sel[(size_t)slot * P.nfeat + g];
+        x = c & 0xFFF; y = (c >> 12) & 0xFFF;
+        for (int i = lane; i < PW * PW; i += 64) {
+            const int r = i / PW, cc = i - r * PW;
+            raw[r * PP + cc] = img[(size_t)(y - PR + r) * pitch + (x - PR + cc)];
+        }
+    }
+    __syncthreads();
+    int m10 = 0, m01 = 0;
+    if (active) {
+        // intensity centroid over the radius-15 disc
+        for (int i = lane; i < 31 * 31; i += 64) {
+            const int v = i / 31 - 15, u = i % 31 - 15;
+            if (abs(u) <= P.umax[abs(v)]) { const int I = raw[(PR + v) * PP + PR + u]; m10 += u * I; m01 += v * I; }
+        }
+        // horizontal 7-tap pass (u16 is enough: 255 * sum(gk) < 65536)
+        for (int i = lane; i < PW * BW; i += 64) {
+            const int r = i / BW, cc = i - r * BW;
+            const uint8_t* q = &raw[r * PP + cc];
+            int s = 0;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) s += P.gk[k] * q[k];
+            hb[i] = (uint16_t)s;
+        }
+    }
+    m10 = wave_sum_i32(m10); m01 = wave_sum_i32(m01);
+    __syncthreads();
+    if (active) {
+        for (int i = lane; i < BW * BW; i += 64) {
+            const int r = i / BW, cc = i - r * BW;
+            int s = 0;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) s += P.gk[k] * hb[(r + k) * BW + cc];
+            blur[i] = (uint8_t)min(255, (s + (1 << 15)) >> 16);
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    double cs = 1.0, sn = 0.0;
+    if (m10 != 0 || m01 != 0) {
+        const double nrm = sqrt((double)m10 * (double)m10 + (double)m01 * (double)m01);
+        cs = (double)m10 / nrm; sn = (double)m01 / nrm;
+    }
+    const int out = base + (g - P.qprefix[l]);
+    uint64_t bits[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int8_t* q = &c_pattern[(r * 64 + lane) * 4];
+        const int x1 = __double2int_rn((double)q[0] * cs - (double)q[1] * sn), y1 = __double2int_rn((double)q[0] * sn + (double)q[1] * cs);
+        const int x2 = __double2int_rn((double)q[2] * cs - (double)q[3] * sn), y2 = __double2int_rn((double)q[2] * sn + (double)q[3] * cs);
+        const bool b = blur[(BR + y1) * BW + BR + x1] < blur[(BR + y2) * BW + BR + x2];
+        bits[r] = __ballot(b);
+    }
+    if (lane == 0) {
+        uint64_t* d = (uint64_t*)(desc + ((size_t)slot * P.nfeat + out) * 32);
+        d[0] = bits[0]; d[1] = bits[1]; d[2] = bits[2]; d[3] = bits[3];
+        vo_keypoint kp;
+        kp.x = (float)x * P.scale[l];
+        kp.y = (float)y * P.scale[l];
+        kp.size = 31.f * P.scale[l];
+        kp.angle = fast_atan2_deg_dev((float)m01, (float)m10);
+        kp.response = (float)((double)sel_key[(size_t)slot * P.nfeat + g] * (1.0 / (25.0 * 7140.0 * 7140.0 * 7140.0 * 7140.0)));
+        kp.octave = l; kp.class_id = -1;
+        // Frame::GetDepth (reference src/frame.cpp:43-67), bounds-checked
+        const SlotDesc sd = slots[slot];
+        const int px = __float2int_rn(kp.x), py = __float2int_rn(kp.y);
+        const int nx[5] = {0, -1, 0, 1, 0}, ny[5] = {0, 0, -1, 0, 1};
+        int dr = 0;
+        for (int i = 0; i < 5 && dr == 0; ++i) {
+            const int xx = px + nx[i], yy = py + ny[i];
+            if (xx >= 0 && yy >= 0 && xx < P.W && yy < P.H) dr = *(const uint16_t*)(sd.depth + (size_t)yy * sd.depth_stride + 2 * (size_t)xx);
+        }
+        kp.depth_raw = dr;
+        kps[(size_t)slot * P.nfeat + out] = kp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+int vo_orb_upload_constants() {
+    static bool done = false;
+    if (done) return VO_OK;
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), VO_BRIEF_PATTERN, sizeof(c_pattern)));
+    done = true;
+    return VO_OK;
+}
+
+int vo_orb_launch(vo_ctx* c, int slot0, int n) {
+    const DevPlan& P = c->plan;
+    hipStream_t st = c->stream;
+    HIP_TRY(hipMemsetAsync(c->d_cand_cnt + (size_t)slot0 * VO_MAX_LEVELS, 0, sizeof(int) * VO_MAX_LEVELS * n, st));
+    { ProfScope ps(c, "k_gray");
+      dim3 g(((P.W + 3) / 4 + 255) / 256, P.H, n);
+      hipLaunchKernelGGL(k_gray, g, dim3(256), 0, st, P, c->d_slots, c->d_pyr, slot0); }
+    for (int l = 1; l < P.L; ++l) {
+        ProfScope ps(c, "k_resize");
+        dim3 g((P.lw[l] + 63) / 64, (P.lh[l] + 3) / 4, n);
+        hipLaunchKernelGGL(k_resize, g, dim3(64, 4), 0, st, P, l, c->d_pyr, c->d_tab, c->d_tabs, slot0);
+    }
+    { ProfScope ps(c, "k_fast_nms");
+      dim3 g(P.tile_prefix[P.L], 1, n);
+      hipLaunchKernelGGL(k_fast_nms, g, dim3(64, 4), 0, st, P, c->d_pyr, c->d_cand, c->d_cand_cnt, c->d_status, slot0); }
+    { ProfScope ps(c, "k_select");
+      size_t lds = (size_t)P.sel_cap * 12 + 4 * 260;
+      dim3 g(P.L, n);
+      hipLaunchKernelGGL(k_select, g, dim3(1024), lds, st, P, c->d_pyr, c->d_cand, c->d_cand_cnt, c->d_sel, c->d_sel_key, c->d_sel_cnt, slot0); }
+    { ProfScope ps(c, "k_describe");
+      dim3 g((P.nfeat + 3) / 4, n);
+      hipLaunchKernelGGL(k_describe, g, dim3(256), 0, st, P, c->d_slots, c->d_pyr, c->d_sel, c->d_sel_key, c->d_sel_cnt, c->d_kps, c->d_desc, c->d_nkp, slot0); }
+    HIP_TRY(hipGetLastError());
+    return VO_OK;
+}

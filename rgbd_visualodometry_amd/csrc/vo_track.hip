@@ -1,0 +1,682 @@
+// vo_track.hip -- per-frame tracking chain on gfx950:
+//
+//   k_match         frustum/view-angle filter (reference src/frame.cpp:70-91, loop src/frontend.cpp:171-184)
+//                   fused with an exact brute-force Hamming 1-NN of every active map point against the
+//                   frame's descriptors (replaces cv::FlannBasedMatcher+LSH, src/frontend.cpp:33,:187).
+//                   256 queries x 256 train descriptors per workgroup; the train tile sits in LDS and is
+//                   read as wave-wide broadcasts (2 x ds_read_b128 per descriptor); 8 x v_bcnt per pair;
+//                   cross-tile argmin by one 64-bit atomicMin((dist<<32)|index).
+//   k_match_gate    min distance, gate max(min*ratio, 30) (src/frontend.cpp:190-211), ORDER-PRESERVING
+//                   compaction (ballot + popcount prefix) and gather of the float32 3-D/2-D pairs (:225-230)
+//   k_ransac_hyp    one lane per hypothesis: counter-based 4-sample, Grunert P3P, 4th point disambiguates
+//   k_ransac_score  one wavefront per hypothesis: reprojection test of all pairs, __ballot + popcount
+//   k_ransac_select sequential adaptive-stop scan (solvePnPRansac semantics, src/frontend.cpp:238-241),
+//                   inlier list of the winner (order-preserving)
+//   k_pose_lm       whole 2 x 10-iteration Levenberg-Marquardt with Huber kernel in ONE workgroup
+//                   (g2o semantics, src/frontend.cpp:257-329; Jacobian include/myslam/g2o_types.h:86-100)
+//
+// The chain never returns to the host between stages: counts live in TrackDev, grids are sized
+// by capacity and trimmed on the device.  All double arithmetic mirrors oracle/o_track.cpp
+// operation by operation (file is compiled with -ffp-contract=off).
+#include <cfloat>
+#include <cstdio>
+#include <cstring>
+
+#include "vo_internal.h"
+
+struct CamD { double fx, fy, cx, cy; int W, H; };
+
+// ------------------------------------------------------------------------------------------
+// small double-precision helpers (same operation order as oracle/o_math.h)
+// ------------------------------------------------------------------------------------------
+struct D3 { double x, y, z; };
+__device__ __forceinline__ D3 mk(double a, double b, double c) { D3 r; r.x = a; r.y = b; r.z = c; return r; }
+__device__ __forceinline__ D3 sub(D3 a, D3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ D3 scl(double s, D3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ double dot3(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ D3 cross3(D3 a, D3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ D3 nrm3(D3 a) { double n = sqrt(dot3(a, a)); return mk(a.x / n, a.y / n, a.z / n); }
+__device__ __forceinline__ D3 rot(const double* R, D3 v) {
+    return mk(R[0] * v.x + R[1] * v.y + R[2] * v.z, R[3] * v.x + R[4] * v.y + R[5] * v.z, R[6] * v.x + R[7] * v.y + R[8] * v.z);
+}
+__device__ __forceinline__ D3 xform(const double* T, D3 p) { D3 r = rot(T, p); return mk(r.x + T[9], r.y + T[10], r.z + T[11]); }
+__device__ __forceinline__ double comp(D3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+// ------------------------------------------------------------------------------------------
+// K10 + K11
+// ------------------------------------------------------------------------------------------
+#define MQ 256
+#define MT 256
+__global__ __launch_bounds__(256) void k_match(CamD cam, const TrackDev* __restrict__ tr, const double* __restrict__ map_pos,
+                                               const double* __restrict__ map_nrm, const uint32_t* __restrict__ map_desc,
+                                               const uint8_t* __restrict__ map_flags, const int32_t* __restrict__ active, int n_active,
+                                               const uint32_t* __restrict__ fdesc, const int* __restrict__ nkp_p,
+                                               unsigned long long* __restrict__ best) {
+    __shared__ uint4 s_train[MT * 2];
+    const int nkp = *nkp_p;
+    const int t0 = blockIdx.y * MT;
+    if (t0 >= nkp) return;
+    const int nt = min(MT, nkp - t0);
+    const uint4* src = (const uint4*)(fdesc + (size_t)t0 * 8);
+    for (int i = threadIdx.x; i < nt * 2; i += 256) s_train[i] = src[i];
+    __syncthreads();
+    const int q = blockIdx.x * MQ + threadIdx.x;
+    if (q >= n_active) return;
+    const int mi = active[q];
+    if (map_flags[mi] & VO_MAP_FLAG_OUTLIER) return;
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = tr->T[i];
+    const D3 pw = mk(map_pos[3 * (size_t)mi], map_pos[3 * (size_t)mi + 1], map_pos[3 * (size_t)mi + 2]);
+    const D3 pc = xform(T, pw);
+    if (!(pc.z > 0)) return;
+    const double u = cam.fx * pc.x / pc.z + cam.cx, v = cam.fy * pc.y / pc.z + cam.cy;
+    if (u < 0 || u >= cam.W || v < 0 || v >= cam.H) return;
+    // camera centre C = -R^T t
+    const D3 C = mk(-(T[0] * T[9] + T[3] * T[10] + T[6] * T[11]), -(T[1] * T[9] + T[4] * T[10] + T[7] * T[11]), -(T[2] * T[9] + T[5] * T[10] + T[8] * T[11]));
+    const D3 dir = nrm3(sub(pw, C));
+    const double dd = dir.x * map_nrm[3 * (size_t)mi] + dir.y * map_nrm[3 * (size_t)mi + 1] + dir.z * map_nrm[3 * (size_t)mi + 2];
+    if (dd < 0.8660254037844387) return;
+    const uint4* qd = (const uint4*)(map_desc + (size_t)mi * 8);
+    const uint4 qa = qd[0], qb = qd[1];
+    int bd = 1 << 30, bi = 0;
+    for (int t = 0; t < nt; ++t) {
+        const uint4 a = s_train[2 * t], b = s_train[2 * t + 1];
+        const int h = __popc(qa.x ^ a.x) + __popc(qa.y ^ a.y) + __popc(qa.z ^ a.z) + __popc(qa.w ^ a.w) +
+                      __popc(qb.x ^ b.x) + __popc(qb.y ^ b.y) + __popc(qb.z ^ b.z) + __popc(qb.w ^ b.w);
+        if (h < bd) { bd = h; bi = t; }
+    }
+    atomicMin(&best[q], ((unsigned long long)bd << 32) | (unsigned)(t0 + bi));
+}
+
+__device__ __forceinline__ int block_excl_scan_flag(bool flag, int* s_w, int& total) {
+    // order-preserving position of `flag` lanes inside a 1024-thread workgroup
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(flag);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_w[wave] = __popcll(m);
+    __syncthreads();
+    int off = 0, tot = 0;
+    for (int i = 0; i < 16; ++i) { int c = s_w[i]; if (i < wave) off += c; tot += c; }
+    __syncthreads();
+    total = tot;
+    return off + before;
+}
+
+__global__ __launch_bounds__(1024) void k_match_gate(TrackDev* __restrict__ tr, const unsigned long long* __restrict__ best,
+                                                     const int32_t* __restrict__ active, int n_active, const double* __restrict__ map_pos,
+                                                     const vo_keypoint* __restrict__ kps, float ratio, float floor_dist,
+                                                     vo_match* __restrict__ matches, float* __restrict__ cxyz, float* __restrict__ cuv, int cap) {
+    __shared__ int s_w[16];
+    __shared__ int s_min, s_cnt;
+    if (threadIdx.x == 0) { s_min = 1 << 30; s_cnt = 0; }
+    __syncthreads();
+    int mn = 1 << 30, cnt = 0;
+    for (int q = threadIdx.x; q < n_active; q += 1024) {
+        const unsigned long long b = best[q];
+        if (b != ~0ull) { mn = min(mn, (int)(b >> 32)); ++cnt; }
+    }
+    atomicMin(&s_min, mn); atomicAdd(&s_cnt, cnt);
+    __syncthreads();
+    const int gmin = s_min, ncand = s_cnt;
+    const float max_dis = fmaxf((float)gmin * ratio, floor_dist);
+    int outn = 0;
+    for (int base = 0; base < n_active; base += 1024) {
+        const int q = base + threadIdx.x;
+        unsigned long long b = ~0ull;
+        if (q < n_active) b = best[q];
+        const bool keep = (b != ~0ull) && ((float)(int)(b >> 32) <= max_dis);
+        int tot;
+        const int pos = outn + block_excl_scan_flag(keep, s_w, tot);
+        if (keep && pos < cap) {
+            const int mi = active[q], kp = (int)(b & 0xFFFFFFFFu);
+            vo_match m; m.map_index = mi; m.kp_index = kp; m.distance = (int)(b >> 32); m.flags = 0;
+            matches[pos] = m;
+            cxyz[3 * pos] = (float)map_pos[3 * (size_t)mi]; cxyz[3 * pos + 1] = (float)map_pos[3 * (size_t)mi + 1]; cxyz[3 * pos + 2] = (float)map_pos[3 * (size_t)mi + 2];
+            cuv[2 * pos] = kps[kp].x; cuv[2 * pos + 1] = kps[kp].y;
+        }
+        outn += tot;
+    }
+    if (threadIdx.x == 0) {
+        tr->n_cand = ncand; tr->n_match = min(outn, cap); tr->min_dist = ncand ? gmin : -1;
+        if (outn > cap) tr->status = VO_E_OVERFLOW;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// quartic / P3P / sampler (mirrors oracle/o_track.cpp)
+// ------------------------------------------------------------------------------------------
+__device__ int solve_quartic_dev(double a4, double a3, double a2, double a1, double a0, double roots[4]) {
+    if (!(fabs(a4) > 1e-300)) return 0;
+    const double b3 = a3 / a4, b2 = a2 / a4, b1 = a1 / a4, b0 = a0 / a4;
+    const double p = b2 - 3.0 * b3 * b3 / 8.0;
+    const double q = b1 - b2 * b3 / 2.0 + b3 * b3 * b3 / 8.0;
+    const double r = b0 - b1 * b3 / 4.0 + b2 * b3 * b3 / 16.0 - 3.0 * b3 * b3 * b3 * b3 / 256.0;
+    double ys[4]; int n = 0;
+    const double qtol = 1e-13 * (1.0 + fabs(p) * sqrt(fabs(p)) + fabs(r));
+    if (fabs(q) <= qtol) {
+        double disc = p * p - 4.0 * r;
+        if (disc < 0) return 0;
+        double sd = sqrt(disc);
+        double z0 = (-p + sd) / 2.0, z1 = (-p - sd) / 2.0;
+        if (z0 >= 0) { double y = sqrt(z0); ys[n++] = y; ys[n++] = -y; }
+        if (z1 >= 0) { double y = sqrt(z1); ys[n++] = y; ys[n++] = -y; }
+    } else {
+        const double c2 = 8.0 * p, c1 = 2.0 * p * p - 8.0 * r, c0 = -q * q;
+        double lo = 0.0, hi = 1.0;
+        int guard = 0;
+        while (!((((8.0 * hi + c2) * hi + c1) * hi + c0) > 0.0) && guard < 600) { hi *= 2.0; ++guard; }
+        if (guard >= 600) return 0;
+        for (int it = 0; it < 64; ++it) {
+            double mid = 0.5 * (lo + hi);
+            if ((((8.0 * mid + c2) * mid + c1) * mid + c0) > 0.0) hi = mid; else lo = mid;
+        }
+        double m = 0.5 * (lo + hi);
+        for (int it = 0; it < 4; ++it) {
+            double gd = (24.0 * m + 2.0 * c2) * m + c1;
+            if (gd == 0.0) break;
+            double mn = m - (((8.0 * m + c2) * m + c1) * m + c0) / gd;
+            if (mn > 0.0) m = mn;
+        }
+        if (!(m > 0.0)) return 0;
+        const double s = sqrt(2.0 * m), h = q / (2.0 * s), base = p / 2.0 + m;
+        double d1 = s * s - 4.0 * (base + h);
+        if (d1 >= 0) { double sd = sqrt(d1); ys[n++] = (s + sd) / 2.0; ys[n++] = (s - sd) / 2.0; }
+        double d2 = s * s - 4.0 * (base - h);
+        if (d2 >= 0) { double sd = sqrt(d2); ys[n++] = (-s + sd) / 2.0; ys[n++] = (-s - sd) / 2.0; }
+    }
+    for (int i = 0; i < 4; ++i) {
+        if (i >= n) break;
+        double x = ys[i] - b3 / 4.0;
+        for (int it = 0; it < 2; ++it) {
+            double f = (((x + b3) * x + b2) * x + b1) * x + b0;
+            double fd = ((4.0 * x + 3.0 * b3) * x + 2.0 * b2) * x + b1;
+            if (fd != 0.0) x -= f / fd;
+        }
+        roots[i] = x;
+    }
+    return n;
+}
+
+__device__ __forceinline__ void frame_of_dev(D3 A, D3 B, D3 Cc, D3 e[3]) {
+    e[0] = nrm3(sub(B, A));
+    e[2] = nrm3(cross3(e[0], sub(Cc, A)));
+    e[1] = cross3(e[2], e[0]);
+}
+
+// returns number of solutions; poses as 12 doubles each
+__device__ int p3p_grunert_dev(const D3 P[3], const D3 f[3], double Rt[4][12]) {
+    const D3 d12 = sub(P[1], P[2]), d02 = sub(P[0], P[2]), d01 = sub(P[0], P[1]);
+    const double a2 = dot3(d12, d12), b2 = dot3(d02, d02), c2 = dot3(d01, d01);
+    if (!(a2 > 1e-18 && b2 > 1e-18 && c2 > 1e-18)) return 0;
+    const double ca = dot3(f[1], f[2]), cb = dot3(f[0], f[2]), cg = dot3(f[0], f[1]);
+    const double q = (a2 - c2) / b2, ac = (a2 + c2) / b2;
+    const double A4 = (q - 1.0) * (q - 1.0) - 4.0 * c2 / b2 * ca * ca;
+    const double A3 = 4.0 * (q * (1.0 - q) * cb - (1.0 - ac) * ca * cg + 2.0 * c2 / b2 * ca * ca * cb);
+    const double A2 = 2.0 * (q * q - 1.0 + 2.0 * q * q * cb * cb + 2.0 * ((b2 - c2) / b2) * ca * ca -
+                             4.0 * ac * ca * cb * cg + 2.0 * ((b2 - a2) / b2) * cg * cg);
+    const double A1 = 4.0 * (-q * (1.0 + q) * cb + 2.0 * a2 / b2 * cg * cg * cb - (1.0 - ac) * ca * cg);
+    const double A0 = (1.0 + q) * (1.0 + q) - 4.0 * a2 / b2 * cg * cg;
+    double vs[4];
+    const int nr = solve_quartic_dev(A4, A3, A2, A1, A0, vs);
+    int ns = 0;
+    D3 ep[3];
+    frame_of_dev(P[0], P[1], P[2], ep);
+    for (int i = 0; i < 4; ++i) {
+        if (i >= nr) break;
+        const double v = vs[i];
+        if (!(v > 0.0)) continue;
+        const double den = 2.0 * (cg - v * ca);
+        if (fabs(den) < 1e-12) continue;
+        const double u = ((q - 1.0) * v * v - 2.0 * q * cb * v + 1.0 + q) / den;
+        if (!(u > 0.0)) continue;
+        const double s1sq = b2 / (1.0 + v * v - 2.0 * v * cb);
+        if (!(s1sq > 0.0)) continue;
+        const double s1 = sqrt(s1sq), s2 = u * s1, s3 = v * s1;
+        const D3 Q0 = scl(s1, f[0]), Q1 = scl(s2, f[1]), Q2 = scl(s3, f[2]);
+        D3 eq[3];
+        frame_of_dev(Q0, Q1, Q2, eq);
+        double* o = Rt[ns];
+        for (int r_ = 0; r_ < 3; ++r_)
+            for (int c_ = 0; c_ < 3; ++c_)
+                o[3 * r_ + c_] = comp(eq[0], r_) * comp(ep[0], c_) + comp(eq[1], r_) * comp(ep[1], c_) + comp(eq[2], r_) * comp(ep[2], c_);
+        const D3 rp = rot(o, P[0]);
+        o[9] = Q0.x - rp.x; o[10] = Q0.y - rp.y; o[11] = Q0.z - rp.z;
+        if (!(isfinite(o[9]) && isfinite(o[10]) && isfinite(o[11]))) continue;
+        ++ns;
+    }
+    return ns;
+}
+
+__device__ __forceinline__ uint64_t mix64_dev(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint64_t rng_draw_dev(uint64_t seed, uint64_t hyp, uint64_t j) { return mix64_dev(seed ^ mix64_dev(hyp * 0x100000001B3ull + j)); }
+
+__device__ void sample4_dev(uint64_t seed, int hyp, int n, int idx[4]) {
+    uint64_t j = 0;
+    for (int k = 0; k < 4; ++k) {
+        for (;;) {
+            int c = (int)(rng_draw_dev(seed, (uint64_t)hyp, j++) % (uint64_t)n);
+            bool dup = false;
+            for (int i = 0; i < k; ++i) dup |= (idx[i] == c);
+            if (!dup) { idx[k] = c; break; }
+            if (j > 64) {
+                for (c = 0; c < n; ++c) { dup = false; for (int i = 0; i < k; ++i) dup |= (idx[i] == c); if (!dup) break; }
+                idx[k] = c; break;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ bool reproj_ok_dev(const CamD& cam, const double* T, const float* X, const float* z, double thr2) {
+    const D3 pc = xform(T, mk((double)X[0], (double)X[1], (double)X[2]));
+    if (!(pc.z > 0)) return false;
+    const double du = cam.fx * pc.x / pc.z + cam.cx - (double)z[0], dv = cam.fy * pc.y / pc.z + cam.cy - (double)z[1];
+    return du * du + dv * dv <= thr2;
+}
+
+__global__ __launch_bounds__(64) void k_ransac_hyp(CamD cam, const TrackDev* __restrict__ tr, const float* __restrict__ cxyz,
+                                                   const float* __restrict__ cuv, int n_hyp, uint64_t seed, double* __restrict__ hyp_pose,
+                                                   int* __restrict__ hyp_cnt) {
+    const int h = blockIdx.x * 64 + threadIdx.x;
+    if (h >= n_hyp) return;
+    const int n = tr->n_match;
+    if (n < 4) { hyp_cnt[h] = -1; return; }
+    int id[4];
+    sample4_dev(seed, h, n, id);
+    D3 P[3], f[3];
+    for (int k = 0; k < 3; ++k) {
+        P[k] = mk((double)cxyz[3 * id[k]], (double)cxyz[3 * id[k] + 1], (double)cxyz[3 * id[k] + 2]);
+        f[k] = nrm3(mk(((double)cuv[2 * id[k]] - cam.cx) / cam.fx, ((double)cuv[2 * id[k] + 1] - cam.cy) / cam.fy, 1.0));
+    }
+    double Rt[4][12];
+    const int ns = p3p_grunert_dev(P, f, Rt);
+    int bi = -1;
+    double be = DBL_MAX;
+    for (int s = 0; s < 4; ++s) {
+        if (s >= ns) break;
+        const D3 pc = xform(Rt[s], mk((double)cxyz[3 * id[3]], (double)cxyz[3 * id[3] + 1], (double)cxyz[3 * id[3] + 2]));
+        if (!(pc.z > 0)) continue;
+        const double du = cam.fx * pc.x / pc.z + cam.cx - (double)cuv[2 * id[3]], dv = cam.fy * pc.y / pc.z + cam.cy - (double)cuv[2 * id[3] + 1];
+        const double e = du * du + dv * dv;
+        if (e < be) { be = e; bi = s; }
+    }
+    if (bi < 0) { hyp_cnt[h] = -1; return; }
+    for (int i = 0; i < 12; ++i) hyp_pose[(size_t)12 * h + i] = Rt[bi][i];
+    hyp_cnt[h] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_ransac_score(CamD cam, const TrackDev* __restrict__ tr, const float* __restrict__ cxyz,
+                                                      const float* __restrict__ cuv, int n_hyp, double thr2, const double* __restrict__ hyp_pose,
+                                                      int* __restrict__ hyp_cnt) {
+    const int h = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (h >= n_hyp) return;
+    if (hyp_cnt[h] < 0) return;
+    const int n = tr->n_match;
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = hyp_pose[(size_t)12 * h + i];
+    int cnt = 0;
+    for (int k = lane; k < n; k += 64) cnt += reproj_ok_dev(cam, T, &cxyz[3 * k], &cuv[2 * k], thr2) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (lane == 0) hyp_cnt[h] = cnt;
+}
+
+__device__ __forceinline__ int ransac_update_iters_dev(double conf, int n_pts, int n_inl, int max_iters) {
+    const double w = (double)n_inl / (double)n_pts;
+    const double qf = 1.0 - w * w * w * w, target = 1.0 - conf;
+    if (!(qf > 0.0)) return 0;
+    double acc = 1.0; int k = 0;
+    while (acc > target && k < max_iters) { acc *= qf; ++k; }
+    return k;
+}
+
+__global__ __launch_bounds__(1024) void k_ransac_select(CamD cam, TrackDev* __restrict__ tr, const float* __restrict__ cxyz,
+                                                        const float* __restrict__ cuv, int n_hyp, double thr2, double conf,
+                                                        const double* __restrict__ hyp_pose, const int* __restrict__ hyp_cnt,
+                                                        int32_t* __restrict__ inliers) {
+    __shared__ int s_w[16];
+    __shared__ int s_best;
+    const int n = tr->n_match;
+    if (threadIdx.x == 0) {
+        int best = -1, best_cnt = 3, niters = n_hyp, h = 0;
+        if (n >= 4) {
+            for (; h < niters; ++h) {
+                const int cnt = hyp_cnt[h];
+                if (cnt > best_cnt) { best_cnt = cnt; best = h; niters = min(niters, ransac_update_iters_dev(conf, n, cnt, niters)); }
+            }
+        }
+        s_best = best;
+        tr->best_hyp = best; tr->iters_used = h; tr->best_cnt = best >= 0 ? best_cnt : 0;
+        if (best >= 0) for (int i = 0; i < 12; ++i) tr->T[i] = hyp_pose[(size_t)12 * best + i];
+        for (int i = 0; i < 12; ++i) tr->T_ransac[i] = tr->T[i];
+    }
+    __syncthreads();
+    const int best = s_best;
+    if (best < 0) { if (threadIdx.x == 0) tr->n_inl = 0; return; }
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = hyp_pose[(size_t)12 * best + i];
+    int outn = 0;
+    for (int base = 0; base < n; base += 1024) {
+        const int k = base + threadIdx.x;
+        const bool ok = (k < n) && reproj_ok_dev(cam, T, &cxyz[3 * k], &cuv[2 * k], thr2);
+        int tot;
+        const int pos = outn + block_excl_scan_flag(ok, s_w, tot);
+        if (ok) inliers[pos] = k;
+        outn += tot;
+    }
+    if (threadIdx.x == 0) tr->n_inl = outn;
+}
+
+// ------------------------------------------------------------------------------------------
+// K14 pose-only LM in one workgroup
+// ------------------------------------------------------------------------------------------
+#define LM_T 256
+#define LM_NV 28            // 21 (upper H) + 6 (b) + 1 (chi)
+
+__device__ __forceinline__ void so3_exp_dev(const double w[3], double R[9]) {
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = sqrt(th2);
+    double A, B;
+    if (th < 1e-8) { A = 1.0 - th2 / 6.0; B = 0.5 - th2 / 24.0; }
+    else { A = sin(th) / th; B = (1.0 - cos(th)) / th2; }
+    const double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+    double W2[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += W[3 * i + k] * W[3 * k + j]; W2[3 * i + j] = s; }
+    for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0 ? 1.0 : 0.0) + A * W[i] + B * W2[i];
+}
+
+// Tn = exp(d) * T   (tangent = [translation, rotation], g2o_types.h:56-60)
+__device__ void se3_exp_mul_dev(const double d[6], const double* T, double* Tn) {
+    const double w[3] = {d[3], d[4], d[5]};
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = sqrt(th2);
+    double B, C;
+    if (th < 1e-8) { B = 0.5 - th2 / 24.0; C = 1.0 / 6.0 - th2 / 120.0; }
+    else { B = (1.0 - cos(th)) / th2; C = (th - sin(th)) / (th2 * th); }
+    const double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+    double W2[9], V[9], R[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += W[3 * i + k] * W[3 * k + j]; W2[3 * i + j] = s; }
+    for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0 ? 1.0 : 0.0) + B * W[i] + C * W2[i];
+    so3_exp_dev(w, R);
+    const double tx = V[0] * d[0] + V[1] * d[1] + V[2] * d[2], ty = V[3] * d[0] + V[4] * d[1] + V[5] * d[2], tz = V[6] * d[0] + V[7] * d[1] + V[8] * d[2];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += R[3 * i + k] * T[3 * k + j]; Tn[3 * i + j] = s; }
+    Tn[9] = R[0] * T[9] + R[1] * T[10] + R[2] * T[11] + tx;
+    Tn[10] = R[3] * T[9] + R[4] * T[10] + R[5] * T[11] + ty;
+    Tn[11] = R[6] * T[9] + R[7] * T[10] + R[8] * T[11] + tz;
+}
+
+__device__ __forceinline__ bool chol6_dev(double* A, double* b) {
+    for (int j = 0; j < 6; ++j) {
+        double d = A[j * 6 + j];
+        for (int k = 0; k < j; ++k) d -= A[j * 6 + k] * A[j * 6 + k];
+        if (!(d > 0.0)) return false;
+        d = sqrt(d);
+        A[j * 6 + j] = d;
+        for (int i = j + 1; i < 6; ++i) { double s = A[i * 6 + j]; for (int k = 0; k < j; ++k) s -= A[i * 6 + k] * A[j * 6 + k]; A[i * 6 + j] = s / d; }
+    }
+    for (int i = 0; i < 6; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= A[i * 6 + k] * b[k]; b[i] = s / A[i * 6 + i]; }
+    for (int i = 5; i >= 0; --i) { double s = b[i]; for (int k = i + 1; k < 6; ++k) s -= A[k * 6 + i] * b[k]; b[i] = s / A[i * 6 + i]; }
+    return true;
+}
+
+template <int NV>
+__device__ __forceinline__ void block_reduce_dev(double* v, double* s_part, double* s_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double x = v[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+        v[i] = x;
+    }
+    if (lane == 0) for (int i = 0; i < NV; ++i) s_part[wave * NV + i] = v[i];
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double s = 0;
+        for (int w = 0; w < LM_T / 64; ++w) s += s_part[w * NV + threadIdx.x];
+        s_out[threadIdx.x] = s;
+    }
+    __syncthreads();
+    for (int i = 0; i < NV; ++i) v[i] = s_out[i];
+    __syncthreads();
+}
+
+__device__ __forceinline__ void edge_err_dev(const CamD& cam, const double* T, const float* X, const float* z, double e[2], D3& pc) {
+    pc = xform(T, mk((double)X[0], (double)X[1], (double)X[2]));
+    e[0] = (double)z[0] - (cam.fx * pc.x / pc.z + cam.cx);
+    e[1] = (double)z[1] - (cam.fy * pc.y / pc.z + cam.cy);
+}
+
+__device__ double lm_chi_dev(const CamD& cam, const float* cxyz, const float* cuv, const int32_t* edges, const uint8_t* mask, int n,
+                             int round, const double* T, bool robust, double delta, double* s_part, double* s_out) {
+    double v[1] = {0.0};
+    for (int i = threadIdx.x; i < n; i += LM_T) {
+        if (round == 1 && !(mask[i] & 2)) continue;
+        const int k = edges[i];
+        double e[2]; D3 pc;
+        edge_err_dev(cam, T, &cxyz[3 * k], &cuv[2 * k], e, pc);
+        const double e2 = e[0] * e[0] + e[1] * e[1];
+        if (robust && e2 > delta * delta) v[0] += 2.0 * sqrt(e2) * delta - delta * delta; else v[0] += e2;
+    }
+    block_reduce_dev<1>(v, s_part, s_out);
+    return v[0];
+}
+
+// round 0: robust on all edges; round 1: plain on edges with mask bit1
+__device__ int lm_optimize_dev(const CamD& cam, const float* cxyz, const float* cuv, const int32_t* edges, const uint8_t* mask, int n,
+                               int round, double* T, double delta, int max_it, double* s_part, double* s_out) {
+    const bool robust = round == 0;
+    double lambda = 0, ni = 2;
+    int it = 0;
+    for (; it < max_it; ++it) {
+        double v[LM_NV];
+#pragma unroll
+        for (int i = 0; i < LM_NV; ++i) v[i] = 0;
+        for (int i = threadIdx.x; i < n; i += LM_T) {
+            if (round == 1 && !(mask[i] & 2)) continue;
+            const int k = edges[i];
+            double e[2]; D3 pc;
+            edge_err_dev(cam, T, &cxyz[3 * k], &cuv[2 * k], e, pc);
+            const double e2 = e[0] * e[0] + e[1] * e[1];
+            double r1 = 1.0;
+            if (robust && e2 > delta * delta) { const double se = sqrt(e2); v[27] += 2.0 * se * delta - delta * delta; r1 = delta / se; } else v[27] += e2;
+            const double X = pc.x, Y = pc.y, Zi = 1.0 / (pc.z + 1e-18), Zi2 = Zi * Zi, fx = cam.fx, fy = cam.fy;
+            const double J0[6] = {-fx * Zi, 0, fx * X * Zi2, fx * X * Y * Zi2, -fx - fx * X * X * Zi2, fx * Y * Zi};
+            const double J1[6] = {0, -fy * Zi, fy * Y * Zi2, fy + fy * Y * Y * Zi2, -fy * X * Y * Zi2, -fy * X * Zi};
+            int c = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                v[21 + a] -= r1 * (J0[a] * e[0] + J1[a] * e[1]);
+#pragma unroll
+                for (int b = a; b < 6; ++b) v[c++] += r1 * (J0[a] * J0[b] + J1[a] * J1[b]);
+            }
+        }
+        block_reduce_dev<LM_NV>(v, s_part, s_out);
+        double H[36], bvec[6];
+        { int c = 0; for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) { H[a * 6 + b] = v[c]; H[b * 6 + a] = v[c]; ++c; } }
+        for (int a = 0; a < 6; ++a) bvec[a] = v[21 + a];
+        double cur = v[27];
+        if (it == 0) {
+            double md = 0;
+            for (int i = 0; i < 6; ++i) md = fmax(md, fabs(H[i * 7]));
+            lambda = 1e-5 * md; ni = 2;
+        }
+        double rho = 0; int qmax = 0;
+        do {
+            double A[36], x[6], Tn[12];
+            for (int i = 0; i < 36; ++i) A[i] = H[i];
+            for (int i = 0; i < 6; ++i) { A[i * 7] += lambda; x[i] = bvec[i]; }
+            const bool ok = chol6_dev(A, x);
+            double tmp = DBL_MAX;
+            if (ok) se3_exp_mul_dev(x, T, Tn);
+            else for (int i = 0; i < 12; ++i) Tn[i] = T[i];
+            // every thread takes the same branch (ok derives from block-uniform data), so the barrier inside is safe
+            const double chi_n = lm_chi_dev(cam, cxyz, cuv, edges, mask, n, round, Tn, robust, delta, s_part, s_out);
+            if (ok) tmp = chi_n;
+            rho = cur - tmp;
+            double scale = 1e-3;
+            if (ok) for (int i = 0; i < 6; ++i) scale += x[i] * (lambda * x[i] + bvec[i]);
+            rho /= scale;
+            if (rho > 0 && isfinite(tmp)) {
+                double a = 1.0 - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
+                a = fmin(a, 2.0 / 3.0);
+                lambda *= fmax(1.0 / 3.0, a); ni = 2; cur = tmp;
+                for (int i = 0; i < 12; ++i) T[i] = Tn[i];
+            } else { lambda *= ni; ni *= 2; }
+            ++qmax;
+        } while (rho < 0 && qmax < 10);
+        if (qmax == 10 || rho == 0) { ++it; break; }
+    }
+    return it;
+}
+
+__global__ __launch_bounds__(LM_T) void k_pose_lm(CamD cam, TrackDev* __restrict__ tr, const float* __restrict__ cxyz,
+                                                  const float* __restrict__ cuv, const int32_t* __restrict__ edges, uint8_t* __restrict__ mask,
+                                                  double delta, double cut, int it_r, int it_p) {
+    __shared__ double s_part[(LM_T / 64) * LM_NV];
+    __shared__ double s_out[LM_NV];
+    __shared__ int s_cnt;
+    const int n = tr->n_inl;
+    double T[12];
+    for (int i = 0; i < 12; ++i) T[i] = tr->T[i];
+    if (threadIdx.x == 0) s_cnt = 0;
+    int iters = 0;
+    int n_act = n;
+    if (n_act > 0) iters += lm_optimize_dev(cam, cxyz, cuv, edges, mask, n, 0, T, delta, it_r, s_part, s_out);
+    // edges whose chi2 exceeds the cut leave the second round (frontend.cpp:294-306)
+    int loc = 0;
+    for (int i = threadIdx.x; i < n; i += LM_T) {
+        const int k = edges[i];
+        double e[2]; D3 pc;
+        edge_err_dev(cam, T, &cxyz[3 * k], &cuv[2 * k], e, pc);
+        const bool keep = !(e[0] * e[0] + e[1] * e[1] > cut);
+        mask[i] = keep ? 2 : 0;
+        loc += keep ? 1 : 0;
+    }
+    atomicAdd(&s_cnt, loc);
+    __threadfence_block();
+    __syncthreads();
+    n_act = s_cnt;
+    __syncthreads();
+    if (n_act > 0) iters += lm_optimize_dev(cam, cxyz, cuv, edges, mask, n, 1, T, delta, it_p, s_part, s_out);
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    loc = 0;
+    for (int i = threadIdx.x; i < n; i += LM_T) {
+        const int k = edges[i];
+        double e[2]; D3 pc;
+        edge_err_dev(cam, T, &cxyz[3 * k], &cuv[2 * k], e, pc);
+        const bool in = !(e[0] * e[0] + e[1] * e[1] > cut);
+        mask[i] = (mask[i] & 2) | (in ? 1 : 0);
+        loc += in ? 1 : 0;
+    }
+    atomicAdd(&s_cnt, loc);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < 12; ++i) tr->T[i] = T[i];
+        tr->lm_iters += iters; tr->n_lm_inl = s_cnt;
+    }
+}
+
+__global__ void k_track_flags(const TrackDev* __restrict__ tr, const int32_t* __restrict__ inliers, const uint8_t* __restrict__ mask,
+                              vo_match* __restrict__ matches) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= tr->n_inl) return;
+    matches[inliers[i]].flags = VO_MATCH_RANSAC_INLIER | ((mask[i] & 1) ? VO_MATCH_LM_INLIER : 0);
+}
+
+__global__ void k_set_nmatch(TrackDev* tr, int n) { tr->n_match = n; tr->n_inl = 0; }
+
+// device-map update: scatter packed host records to their slots (vo_map_upsert)
+__global__ void k_map_scatter(int n, const int32_t* __restrict__ idx, const double* __restrict__ xyz, const double* __restrict__ nrm,
+                              const uint32_t* __restrict__ desc, const uint8_t* __restrict__ flags, double* __restrict__ mpos,
+                              double* __restrict__ mnrm, uint32_t* __restrict__ mdesc, uint8_t* __restrict__ mflags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t k = (size_t)idx[i];
+    if (xyz) { mpos[3 * k] = xyz[3 * (size_t)i]; mpos[3 * k + 1] = xyz[3 * (size_t)i + 1]; mpos[3 * k + 2] = xyz[3 * (size_t)i + 2]; }
+    if (nrm) { mnrm[3 * k] = nrm[3 * (size_t)i]; mnrm[3 * k + 1] = nrm[3 * (size_t)i + 1]; mnrm[3 * k + 2] = nrm[3 * (size_t)i + 2]; }
+    if (desc) for (int w = 0; w < 8; ++w) mdesc[8 * k + w] = desc[8 * (size_t)i + w];
+    if (flags) mflags[k] = flags[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------
+static CamD cam_of(const vo_ctx* c) { CamD k; k.fx = c->p.fx; k.fy = c->p.fy; k.cx = c->p.cx; k.cy = c->p.cy; k.W = c->p.width; k.H = c->p.height; return k; }
+
+int vo_track_match_launch(vo_ctx* c, int slot, float ratio, float floor_dist) {
+    hipStream_t st = c->stream;
+    const int na = c->n_active;
+    c->corr_external = false;
+    if (na > 0) HIP_TRY(hipMemsetAsync(c->d_best, 0xFF, sizeof(unsigned long long) * na, st));
+    if (na > 0) {
+        ProfScope ps(c, "k_match");
+        dim3 g((na + MQ - 1) / MQ, (c->p.n_features + MT - 1) / MT);
+        hipLaunchKernelGGL(k_match, g, dim3(256), 0, st, cam_of(c), c->d_track, c->d_map_pos, c->d_map_nrm, c->d_map_desc, c->d_map_flags,
+                           c->d_active, na, (const uint32_t*)(c->d_desc + (size_t)slot * c->p.n_features * 32), c->d_nkp + slot, c->d_best);
+    }
+    { ProfScope ps(c, "k_match_gate");
+      hipLaunchKernelGGL(k_match_gate, dim3(1), dim3(1024), 0, st, c->d_track, c->d_best, c->d_active, na, c->d_map_pos,
+                         c->d_kps + (size_t)slot * c->p.n_features, ratio, floor_dist, c->d_matches, c->d_corr_xyz, c->d_corr_uv, c->corr_cap); }
+    HIP_TRY(hipGetLastError());
+    return VO_OK;
+}
+
+int vo_corr_from_host(vo_ctx* c, const float* xyz, const float* uv, int n) {
+    if (n > c->corr_cap) return VO_E_OVERFLOW;
+    hipStream_t st = c->stream;
+    if (n > 0) {
+        float* stage = (float*)vo_stage(c, sizeof(float) * 5 * (size_t)n);
+        if (!stage) return VO_E_NOMEM;
+        memcpy(stage, xyz, sizeof(float) * 3 * (size_t)n);
+        memcpy(stage + 3 * (size_t)n, uv, sizeof(float) * 2 * (size_t)n);
+        HIP_TRY(hipMemcpyAsync(c->d_corr_xyz, stage, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(c->d_corr_uv, stage + 3 * (size_t)n, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, st));
+    }
+    hipLaunchKernelGGL(k_set_nmatch, dim3(1), dim3(1), 0, st, c->d_track, n);
+    HIP_TRY(hipStreamSynchronize(st));      // staging buffer is reused by later calls
+    c->corr_external = true;
+    return VO_OK;
+}
+
+int vo_track_ransac_launch(vo_ctx* c, int n_hyp, float reproj_px, float conf, uint64_t seed) {
+    hipStream_t st = c->stream;
+    const CamD cam = cam_of(c);
+    const double thr2 = (double)reproj_px * (double)reproj_px;
+    { ProfScope ps(c, "k_ransac_hyp");
+      hipLaunchKernelGGL(k_ransac_hyp, dim3((n_hyp + 63) / 64), dim3(64), 0, st, cam, c->d_track, c->d_corr_xyz, c->d_corr_uv, n_hyp, seed, c->d_hyp_pose, c->d_hyp_cnt); }
+    { ProfScope ps(c, "k_ransac_score");
+      hipLaunchKernelGGL(k_ransac_score, dim3((n_hyp + 3) / 4), dim3(256), 0, st, cam, c->d_track, c->d_corr_xyz, c->d_corr_uv, n_hyp, thr2, c->d_hyp_pose, c->d_hyp_cnt); }
+    { ProfScope ps(c, "k_ransac_select");
+      hipLaunchKernelGGL(k_ransac_select, dim3(1), dim3(1024), 0, st, cam, c->d_track, c->d_corr_xyz, c->d_corr_uv, n_hyp, thr2, (double)conf, c->d_hyp_pose, c->d_hyp_cnt, c->d_inliers); }
+    HIP_TRY(hipGetLastError());
+    return VO_OK;
+}
+
+int vo_track_lm_launch(vo_ctx* c, double delta, double cut, int it_r, int it_p) {
+    ProfScope ps(c, "k_pose_lm");
+    hipLaunchKernelGGL(k_pose_lm, dim3(1), dim3(LM_T), 0, c->stream, cam_of(c), c->d_track, c->d_corr_xyz, c->d_corr_uv, c->d_inliers, c->d_lm_mask, delta, cut, it_r, it_p);
+    HIP_TRY(hipGetLastError());
+    return VO_OK;
+}
+
+int vo_map_scatter_launch(vo_ctx* c, int n, const int32_t* d_idx, const double* d_xyz, const double* d_nrm, const uint32_t* d_desc, const uint8_t* d_flags) {
+    hipLaunchKernelGGL(k_map_scatter, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, d_idx, d_xyz, d_nrm, d_desc, d_flags,
+                       c->d_map_pos, c->d_map_nrm, c->d_map_desc, c->d_map_flags);
+    HIP_TRY(hipGetLastError());
+    return VO_OK;
+}
+
+int vo_track_flags_launch(vo_ctx* c) {
+    ProfScope ps(c, "k_track_flags");
+    const int cap = c->corr_cap;
+    hipLaunchKernelGGL(k_track_flags, dim3((cap + 255) / 256), dim3(256), 0, c->stream, c->d_track, c->d_inliers, c->d_lm_mask, c->d_matches);
+    HIP_TRY(hipGetLastError());
+    return VO_OK;
+}

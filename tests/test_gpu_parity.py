@@ -1,0 +1,204 @@
+"""GPU parity: every stage of the HIP path (through the C-ABI) against the CPU oracle on identical
+seeded inputs.  Integer / index / byte results must be bit-exact; the LM / BA results (block
+reductions, f64 atomics: different summation order) agree to the tolerance written in each test."""
+import numpy as np
+import pytest
+
+from rgbd_visualodometry_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+IDENT = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], dtype=np.float64)
+
+
+def inv12(T):
+    R = T[:9].reshape(3, 3)
+    t = T[9:]
+    return np.concatenate([R.T.ravel(), -R.T @ t])
+
+
+@pytest.fixture(scope="module")
+def frames():
+    syn = capi.Synth()
+    sp = syn.params(seed=11)
+    bgr, depth, Twc, ts = syn.render(sp, 0, 10, threads=8)
+    return bgr, depth, Twc, ts
+
+
+@pytest.fixture(scope="module")
+def libs():
+    return capi.load(capi.HIP_LIB), capi.load(capi.ORACLE_LIB)
+
+
+def make_ctx(L, **kw):
+    p = L.default_params(**kw)
+    return L.context(p), p
+
+
+def seed_map(ctx, p, kps, desc, T_wc):
+    ok = kps["depth_raw"] > 0
+    z = kps["depth_raw"][ok] / 5000.0
+    pc = np.stack([(kps["x"][ok] - p.cx) * z / p.fx, (kps["y"][ok] - p.cy) * z / p.fy, z], 1)
+    R, t = T_wc[:9].reshape(3, 3), T_wc[9:]
+    pw = pc @ R.T + t
+    nrm = pw - t
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    idx = np.arange(len(pw), dtype=np.int32)
+    ctx.map_upsert(idx, pw, nrm, desc[ok], np.zeros(len(pw), np.uint8))
+    ctx.map_set_active(idx)
+    return len(pw)
+
+
+@pytest.mark.parametrize("nfeat", [500, 2000])
+def test_orb_bit_exact(frames, libs, nfeat):
+    bgr, depth, _, _ = frames
+    H, O = libs
+    assert H.backend == "hip-gfx950" and O.backend == "cpu-oracle"
+    ch, _ = make_ctx(H, n_features=nfeat, max_frames=3)
+    co, _ = make_ctx(O, n_features=nfeat, max_frames=3)
+    for s, f in enumerate((0, 4, 9)):
+        ch.upload(s, bgr[f], depth[f])
+        co.upload(s, bgr[f], depth[f])
+    ch.orb(0, 3)            # one batched launch chain for the three slots
+    co.orb(0, 3)
+    for s in range(3):
+        for l in range(8):
+            assert np.array_equal(ch.fetch_level(s, l), co.fetch_level(s, l)), "pyramid level %d of slot %d differs" % (l, s)
+        kh, dh = ch.orb_fetch(s)
+        ko, do = co.orb_fetch(s)
+        assert len(kh) == len(ko) == nfeat
+        for field in ("x", "y", "size", "octave", "class_id", "depth_raw"):
+            assert np.array_equal(kh[field], ko[field]), "keypoint field %s differs (slot %d)" % (field, s)
+        assert np.array_equal(dh, do), "descriptors differ (slot %d): %d rows" % (s, int((dh != do).any(axis=1).sum()))
+        np.testing.assert_allclose(kh["angle"], ko["angle"], atol=2e-3)         # float polynomial, degrees
+        np.testing.assert_allclose(kh["response"], ko["response"], rtol=1e-5)
+
+
+def test_match_bit_exact(frames, libs):
+    bgr, depth, Twc, _ = frames
+    out = []
+    for L in libs:
+        ctx, p = make_ctx(L, n_features=1000, max_frames=2, map_capacity=8192)
+        ctx.upload(0, bgr[0], depth[0]); ctx.upload(1, bgr[6], depth[6])
+        ctx.orb(0, 2)
+        k0, d0 = ctx.orb_fetch(0)
+        seed_map(ctx, p, k0, d0, Twc[0])
+        m, ncand, mind = ctx.match(1, inv12(Twc[1]), 2.0, 30.0)
+        out.append((m, ncand, mind))
+    (mh, ch, dh), (mo, co, do) = out
+    assert ch == co and dh == do and len(mh) == len(mo) > 100
+    for f in ("map_index", "kp_index", "distance"):
+        assert np.array_equal(mh[f], mo[f]), "match field %s differs" % f
+
+
+def synth_corr(rng, n, outlier_frac, p, noise=0.3):
+    X = rng.uniform(-2, 2, size=(n, 3)) + np.array([0, 0, 4.5])
+    w = rng.normal(size=3) * 0.05
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    R = np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+    t = rng.normal(size=3) * 0.1
+    pc = X @ R.T + t
+    uv = np.stack([p.fx * pc[:, 0] / pc[:, 2] + p.cx, p.fy * pc[:, 1] / pc[:, 2] + p.cy], 1) + rng.normal(size=(n, 2)) * noise
+    bad = rng.uniform(size=n) < outlier_frac
+    uv[bad] = rng.uniform([0, 0], [640, 480], size=(int(bad.sum()), 2))
+    return X.astype(np.float32), uv.astype(np.float32), np.concatenate([R.ravel(), t])
+
+
+@pytest.mark.parametrize("n,n_hyp,outl", [(300, 100, 0.3), (2000, 256, 0.5), (40, 64, 0.1), (5, 16, 0.0)])
+def test_ransac_counts_bit_exact_and_lm_close(libs, n, n_hyp, outl):
+    rng = np.random.default_rng(n)
+    out = []
+    for L in libs:
+        ctx, p = make_ctx(L, map_capacity=4096)
+        X, uv, Tgt = synth_corr(np.random.default_rng(n), n, outl, p)
+        ctx.matches_set(X, uv)
+        T, inl, counts, iters, best = ctx.pnp_ransac(IDENT, n_hyp=n_hyp, seed=77)
+        T2, mask, lm_it = ctx.pose_lm(T)
+        out.append((T, inl, counts, iters, best, T2, mask, Tgt))
+    h, o = out
+    assert np.array_equal(h[2], o[2]), "per-hypothesis inlier counts differ: %d of %d" % (int((h[2] != o[2]).sum()), n_hyp)
+    assert h[3] == o[3] and h[4] == o[4]
+    assert np.array_equal(h[1], o[1])
+    np.testing.assert_allclose(h[0], o[0], atol=1e-12)      # same hypothesis, same arithmetic
+    np.testing.assert_allclose(h[5], o[5], atol=1e-9)       # LM: summation order differs
+    assert np.array_equal(h[6], o[6])
+    if n >= 40:
+        assert np.abs(o[5] - o[7]).max() < 0.02             # and both found the true pose
+
+
+def test_track_frame_matches_oracle(frames, libs):
+    bgr, depth, Twc, _ = frames
+    out = []
+    for L in libs:
+        ctx, p = make_ctx(L, n_features=2000, max_frames=2, map_capacity=8192)
+        ctx.upload(0, bgr[0], depth[0]); ctx.upload(1, bgr[8], depth[8])
+        ctx.orb(0, 2)
+        k0, d0 = ctx.orb_fetch(0)
+        seed_map(ctx, p, k0, d0, Twc[0])
+        res, m = ctx.track(1, inv12(Twc[0]), L.default_track_params(n_hyp=128))
+        out.append((res, m))
+    (rh, mh), (ro, mo) = out
+    for f in ("n_candidates", "n_matches", "n_ransac_inliers", "n_lm_inliers", "min_distance", "ransac_iters", "best_hypothesis"):
+        assert getattr(rh, f) == getattr(ro, f), f
+    assert rh.status == 0
+    for f in ("map_index", "kp_index", "distance", "flags"):
+        assert np.array_equal(mh[f], mo[f]), f
+    np.testing.assert_allclose(np.array(rh.T_cw), np.array(ro.T_cw), atol=1e-9)
+    assert np.abs(np.array(ro.T_cw) - inv12(Twc[8])).max() < 0.02
+
+
+def test_local_ba_matches_oracle(libs):
+    rng = np.random.default_rng(5)
+    nP, nX, nfree = 6, 400, 4
+
+    def expso3(w):
+        th = np.linalg.norm(w)
+        K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+
+    H, O = libs
+    p = O.default_params()
+    poses = []
+    for j in range(nP):
+        R = expso3(rng.normal(size=3) * 0.1)
+        c = rng.normal(size=3) * 0.5
+        poses.append(np.concatenate([R.ravel(), -R @ c]))
+    poses = np.array(poses)
+    X = rng.uniform(-2, 2, size=(nX, 3)) + np.array([0, 0, 5.0])
+    ep, el, uv = [], [], []
+    for k in range(nX):
+        for j in range(nP):
+            if rng.uniform() < 0.7:
+                R, t = poses[j][:9].reshape(3, 3), poses[j][9:]
+                pc = R @ X[k] + t
+                o = rng.normal(size=2) * 0.3 + (rng.uniform(size=2) < 0.02) * 15.0
+                ep.append(j); el.append(k); uv.append([p.fx * pc[0] / pc[2] + p.cx + o[0], p.fy * pc[1] / pc[2] + p.cy + o[1]])
+    poses0 = poses.copy()
+    for j in range(nfree):
+        poses0[j][:9] = (expso3(rng.normal(size=3) * 0.01) @ poses[j][:9].reshape(3, 3)).ravel()
+        poses0[j][9:] += rng.normal(size=3) * 0.02
+    X0 = X + rng.normal(size=X.shape) * 0.05
+    res = []
+    for L in (H, O):
+        ctx, _ = make_ctx(L, map_capacity=1024)
+        res.append(ctx.local_ba(poses0, nfree, X0, ep, el, np.array(uv, dtype=np.float32)))
+    (ph, xh, fh, rh), (po, xo, fo, ro) = res
+    assert rh.lm_iters == ro.lm_iters
+    assert np.array_equal(fh, fo)
+    np.testing.assert_allclose(ph, po, atol=1e-8)
+    np.testing.assert_allclose(xh, xo, atol=1e-7)
+    assert ro.chi2_final < 0.01 * ro.chi2_initial
+    assert np.abs(po - poses[:nfree]).max() < 0.01
+
+
+def test_hip_rejects_bad_arguments(libs):
+    H, _ = libs
+    p = H.default_params(width=32)
+    with pytest.raises(capi.VoError):
+        H.context(p)
+    ctx, _ = make_ctx(H)
+    with pytest.raises(capi.VoError):
+        ctx.orb(0, 1)                       # no frame bound yet -> VO_E_STATE
+    with pytest.raises(capi.VoError):
+        ctx.map_set_active(np.array([1 << 30], dtype=np.int32))
