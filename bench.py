@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""bench.py -- VO frames/sec on synthetic 640x480 RGB-D streams (BASELINE.json metric).
+
+One "step" = one frame through FrontEnd::AddFrame (ORB detect+describe, map match, P3P-RANSAC,
+pose LM, keyframe work incl. local BA) on the HIP path.  Workload at N=1 is BASELINE.json
+configs[1]: a single synthetic 640x480 stream, 2000 ORB features, default.yaml parameters
+otherwise.  For N>1 every rank tracks its own independent stream (configs[3]): weak scaling,
+no data-path collective (frames of one stream are sequentially dependent).
+
+Inputs are rendered on the host before the timed region and are resident in HBM (torch tensors)
+when it starts.  ORB of up to --lookahead future frames of the stream runs as one batched launch
+chain (detection does not depend on earlier poses); matching/PnP/LM/BA run frame by frame.
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel, live HIP-event
+timing on the kernel's own stream) and `cpu_baseline` (the CPU oracle port, timed on rank 0 at
+N=1 on a bounded sample of the same frames).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def level_sizes(W, H, L=8, sf=1.2):
+    out = []
+    for l in range(L):
+        s = np.float32(np.float64(np.float32(sf)) ** l)
+        out.append((int(np.rint(np.float32(W) / s)), int(np.rint(np.float32(H) / s))))
+    return out
+
+
+def algorithmic_bytes(W, H, N, M, K, n_hyp, passes=2):
+    """Per-frame algorithmic bytes by kernel (SURVEY.md 8d decomposition)."""
+    lv = level_sizes(W, H)
+    P = sum(w * h for w, h in lv)
+    b = {
+        "k_gray": 3 * W * H + W * H,                              # BGR in, level 0 out
+        "k_resize": sum(lv[l - 1][0] * lv[l - 1][1] + lv[l][0] * lv[l][1] for l in range(1, len(lv))),
+        "k_fast_nms": P,                                          # every pyramid pixel read once
+        "k_select": 81 * 2 * N + 8 * 2 * N,                       # 9x9 Harris windows of the 2N survivors + list traffic
+        "k_describe": (43 * 43) * N + 2 * W * H * 0 + 48 * N,     # one 43x43 patch per keypoint, kp+descriptor out
+        "k_match": passes * (32 * M + 32 * N + 8 * M),
+        "k_match_gate": passes * (8 * M + 36 * K),
+        "k_ransac_hyp": passes * (20 * 4 * n_hyp + 96 * n_hyp),
+        "k_ransac_score": passes * (20 * K + 4 * n_hyp),
+        "k_ransac_select": passes * (20 * K + 4 * K),
+        "k_pose_lm": passes * (20 * K),
+        "depth": 2 * W * H * 0 + 2 * 5 * N,                       # depth samples at keypoints
+    }
+    total_survey = 5 * W * H + 4 * P + 2003 * N + 48 * N + (32 * M + 32 * N + 8 * M) + (20 * K + 4 * n_hyp)
+    return b, total_survey, P
+
+
+def run_stream(system_mod, lib_path, frames, stamps, opts, lookahead, device_ptrs=None, pose_out=None):
+    """Drive one VoSystem over the given frames; returns elapsed seconds (caller syncs)."""
+    s = system_mod.VoSystem(lib_path, **opts)
+    return s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--features", type=int, default=2000)
+    ap.add_argument("--lookahead", type=int, default=32, help="frames per batched ORB launch chain")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-ba", action="store_true", help="disable local BA (enable_local_optimization: 0)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=150, help="bounded CPU-baseline sample (frames)")
+    ap.add_argument("--profile-frames", type=int, default=64)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from rgbd_visualodometry_amd import capi, system, evaluate as ev
+
+    W, H, N = 640, 480, args.features
+    K, Wm = args.steps, args.warmup
+    total = K + Wm
+    syn = capi.Synth()
+    sp = syn.params(seed=args.seed + rank)
+    threads = max(1, (os.cpu_count() or 8) // max(1, world))
+    t0 = time.time()
+    bgr, depth, Twc, stamps = syn.render(sp, 0, total, threads=min(32, threads))
+    t_render = time.time() - t0
+    d_bgr = torch.from_numpy(bgr).cuda(local_rank)          # inputs resident in HBM
+    d_depth = torch.from_numpy(depth.view(np.int16)).cuda(local_rank)
+    torch.cuda.synchronize()
+    fb, fd = W * H * 3, W * H * 2
+    bptr = [d_bgr.data_ptr() + i * fb for i in range(total)]
+    dptr = [d_depth.data_ptr() + i * fd for i in range(total)]
+
+    opts = dict(width=W, height=H, number_of_features=N, max_frames_in_flight=args.lookahead, device=local_rank,
+                enable_local_optimization=0 if args.no_ba else 1, map_capacity=1 << 20)
+    sysm = system.VoSystem(system.HOST_LIB, **opts)
+    assert sysm.backend == "hip-gfx950", sysm.backend
+
+    est = {}
+
+    def drive(i0, i1):
+        i = i0
+        while i < i1:
+            n = min(args.lookahead, i1 - i)
+            sysm.prefetch(stamps[i:i + n], bptr[i:i + n], dptr[i:i + n], 3 * W, 2 * W, True)
+            for j in range(n):
+                ok, T = sysm.add_prefetched()
+                est[stamps[i + j]] = T
+            i += n
+
+    drive(0, Wm)                                            # warmup (also initialises the map)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    drive(Wm, total)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    st = sysm.stats()
+
+    # accuracy of the timed run (every rank checks its own stream; rank 0 reports)
+    gt = {stamps[i]: capi.pose12_to_tum(Twc[i]) for i in range(total)}
+    est_t = {k: capi.pose12_to_tum(v) for k, v in est.items()}
+    ate_gpu = ev.ate(gt, est_t)["rmse"]
+
+    out = None
+    if rank == 0:
+        fps = world * K / elapsed
+        # ---- roofline of the dominant kernel: live HIP-event timing on the context's stream -------
+        prof_sys = system.VoSystem(system.HOST_LIB, **opts)
+        L = capi.load(capi.HIP_LIB)
+        import ctypes as C
+        h = C.c_void_p(prof_sys.context_handle())
+        pf = min(args.profile_frames, total)
+        # first pass without events to build the map, second profiled
+        n0 = min(args.lookahead, pf)
+        prof_sys.prefetch(stamps[:n0], bptr[:n0], dptr[:n0], 3 * W, 2 * W, True)
+        for _ in range(n0):
+            prof_sys.add_prefetched()
+        L.check(L.lib.vo_profile_enable(h, 1))
+        i = n0
+        frames_prof = 0
+        while i < pf:
+            n = min(args.lookahead, pf - i)
+            prof_sys.prefetch(stamps[i:i + n], bptr[i:i + n], dptr[i:i + n], 3 * W, 2 * W, True)
+            for _ in range(n):
+                prof_sys.add_prefetched()
+            i += n
+            frames_prof += n
+        names = (C.c_char * 48 * 64)()
+        ms = np.zeros(64)
+        calls = np.zeros(64, dtype=np.int64)
+        nn = C.c_int()
+        L.check(L.lib.vo_profile_read(h, C.cast(names, C.c_void_p), ms.ctypes.data, calls.ctypes.data, 64, C.byref(nn)))
+        pst = prof_sys.stats()
+        kern = {names[j].value.decode(): (float(ms[j]), int(calls[j])) for j in range(nn.value)}
+        M = max(1, pst["last_candidates"]); Kc = max(1, pst["last_matches"])
+        per_frame, b_survey, P = algorithmic_bytes(W, H, N, M, Kc, 100)
+        roof = None
+        table = {}
+        if kern and frames_prof > 0:
+            for name, (tms, c) in kern.items():
+                if name not in per_frame or c == 0:
+                    continue
+                passes_per_frame = {"k_resize": 7}.get(name, 1)
+                # bytes one launch moves = per-frame bytes x frames per launch / launches per frame
+                launches = c
+                bytes_total = per_frame[name] * frames_prof
+                avg_ms = tms / launches
+                table[name] = {"total_ms": round(tms, 4), "launches": launches, "avg_us": round(avg_ms * 1e3, 3),
+                               "alg_bytes_per_launch": int(bytes_total / launches),
+                               "GBps": round(bytes_total / launches / (avg_ms * 1e-3) / 1e9, 2) if avg_ms > 0 else None}
+            dom = max(table, key=lambda k: table[k]["total_ms"]) if table else None
+            if dom:
+                roof = {"bound": "hbm", "kernel": dom, "achieved": table[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(table[dom]["GBps"] / HBM_PEAK_GBS, 5), "traffic": None,
+                        "avg_launch_us": table[dom]["avg_us"], "alg_bytes_per_launch": table[dom]["alg_bytes_per_launch"],
+                        "kernels": table}
+        # ---- CPU baseline: the oracle port on host cores, bounded sample ---------------------------
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            nf = min(args.cpu_frames, total)
+            o = system.VoSystem(system.ORACLE_LIB, **{**opts, "max_frames_in_flight": 1})
+            est_c = {}
+            tc = time.perf_counter()
+            for i in range(nf):
+                ok, T = o.add_frame(stamps[i], bgr[i], depth[i])
+                est_c[stamps[i]] = capi.pose12_to_tum(T)
+            tc = time.perf_counter() - tc
+            gt_c = {stamps[i]: gt[stamps[i]] for i in range(nf)}
+            est_g = {stamps[i]: est_t[stamps[i]] for i in range(nf)}
+            cpu = {"value": round(nf / tc, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+                   "sample": "first %d frames of the same synthetic stream, single thread, oracle/_build/liboracle_vo.so" % nf,
+                   "ate_rmse_m": round(ev.ate(gt_c, est_c)["rmse"], 5), "gpu_ate_rmse_m_same_frames": round(ev.ate(gt_c, est_g)["rmse"], 5),
+                   "host_cpus": os.cpu_count()}
+        out = {
+            "metric": "VO frames/sec (640x480 RGB-D)", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/f64", "data": "synthetic",
+            "config": {"workload": "synthetic 640x480 RGB-D stream per GPU, %d ORB features, default.yaml tracking parameters" % N,
+                       "streams_per_gpu": 1, "lookahead_frames": args.lookahead, "local_ba": not args.no_ba, "ransac_hypotheses": 100},
+            "ate_rmse_m": round(ate_gpu, 5), "keyframes": st["keyframes"], "lost": st["lost"], "map_points": st["map_points"],
+            "alg_bytes_per_frame_survey": b_survey, "hbm_frac_whole_frame": round(b_survey * (fps / world) / (HBM_PEAK_GBS * 1e9), 6),
+            "render_s": round(t_render, 2),
+            "host_stage_ms": {k: round(st[k], 2) for k in ("ms_extract", "ms_track", "ms_keyframe", "ms_backend")},
+            "ba": {k: st[k] for k in ("ba_runs", "ba_poses", "ba_fixed", "ba_points", "ba_edges", "ba_outliers")},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

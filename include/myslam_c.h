@@ -37,6 +37,7 @@ typedef struct myslam_stats {
     int32_t map_points;
     int32_t ba_runs, ba_poses, ba_fixed, ba_points, ba_edges, ba_outliers;
     double ba_ms;
+    double ms_extract, ms_track, ms_keyframe, ms_backend;   /* accumulated host wall time per stage */
 } myslam_stats;
 
 int myslam_default_options(myslam_options* o);
@@ -52,6 +53,8 @@ int myslam_add_frame(myslam_system* s, double stamp, const void* bgr, const void
                      int on_device, int* tracked, double T_wc[12]);
 int myslam_add_prefetched(myslam_system* s, int* tracked, double T_wc[12]);
 int myslam_get_stats(myslam_system* s, myslam_stats* st);
+/* The vo_ctx (include/vo_hip.h) the system's FrontEnd owns, for profiling taps (vo_profile_*). */
+void* myslam_get_context(myslam_system* s);
 const char* myslam_last_error(void);
 const char* myslam_backend_name(void);
 #ifdef __cplusplus

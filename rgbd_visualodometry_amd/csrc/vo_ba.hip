@@ -25,14 +25,18 @@
 
 struct BaCam { double fx, fy, cx, cy; };
 
+struct BaBlock { int j1, j2, start, count; };      // one 6x6 block of the reduced system and its pair list
+
 struct BaDev {
-    int n_poses, n_free, n_points, n_edges, D;
+    int n_poses, n_free, n_points, n_edges, D, n_blocks;
     double* poses; double* pts; double* poses_n; double* pts_n;
     const int32_t* e_pose; const int32_t* e_pt; const float* e_uv; uint8_t* active; uint8_t* flags;
-    const int32_t* pt_start; const int32_t* pt_edges;
+    const int32_t* pt_start; const int32_t* pt_edges;       // CSR point -> edges
+    const int32_t* ps_start; const int32_t* ps_edges;       // CSR free pose -> edges
+    const BaBlock* blocks; const int2* pairs;               // (e1, e2) pairs sharing a point, grouped by (pose(e1) <= pose(e2))
     double* Hpp; double* bp; double* Hll; double* bl; double* W;
     double* S; double* bs; double* Hinv; double* dl;
-    double* scal;       // [0] chi cur  [1] chi trial  [2] scale  [3] ok  [4] maxdiag (as u64 bits)
+    double* scal;       // [0] chi cur  [1] chi trial  [2] scale  [3] ok  [4] maxdiag (as u64 bits) [5] chi report [6] chi final
 };
 
 __device__ __forceinline__ void ba_err(const BaCam& cam, const double* T, const double* p, const float* uv, double r[2], double pc[3]) {
@@ -43,32 +47,99 @@ __device__ __forceinline__ void ba_err(const BaCam& cam, const double* T, const 
     r[1] = (double)uv[1] - (cam.fy * pc[1] / pc[2] + cam.cy);
 }
 
-__global__ void k_ba_linearize(BaCam cam, BaDev B, int robust, double delta) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= B.n_edges || !B.active[e]) return;
-    const int j = B.e_pose[e], k = B.e_pt[e];
-    const double* T = B.poses + 12 * (size_t)j;
-    double r[2], pc[3];
-    ba_err(cam, T, B.pts + 3 * (size_t)k, B.e_uv + 2 * (size_t)e, r, pc);
+// residual, Huber weight and both Jacobians of one edge (g2o_types.h:143-167)
+__device__ __forceinline__ void ba_edge(const BaCam& cam, const double* T, const double* p, const float* uv, int robust, double delta,
+                                        double r[2], double& w, double& rho0, double Jp[2][6], double Jl[2][3]) {
+    double pc[3];
+    ba_err(cam, T, p, uv, r, pc);
     const double e2 = r[0] * r[0] + r[1] * r[1];
-    double w = 1.0, rho0 = e2;
+    w = 1.0; rho0 = e2;
     if (robust && e2 > delta * delta) { const double se = sqrt(e2); rho0 = 2.0 * se * delta - delta * delta; w = delta / se; }
-    atomicAdd(&B.scal[0], rho0);
     const double X = pc[0], Y = pc[1], Zi = 1.0 / (pc[2] + 1e-18), Zi2 = Zi * Zi, fx = cam.fx, fy = cam.fy;
-    const double Jp[2][6] = {{-fx * Zi, 0, fx * X * Zi2, fx * X * Y * Zi2, -fx - fx * X * X * Zi2, fx * Y * Zi},
-                             {0, -fy * Zi, fy * Y * Zi2, fy + fy * Y * Y * Zi2, -fy * X * Y * Zi2, -fy * X * Zi}};
-    double Jl[2][3];
-    for (int a = 0; a < 2; ++a) for (int c = 0; c < 3; ++c) Jl[a][c] = Jp[a][0] * T[c] + Jp[a][1] * T[3 + c] + Jp[a][2] * T[6 + c];
-    for (int a = 0; a < 3; ++a) {
-        atomicAdd(&B.bl[3 * (size_t)k + a], -w * (Jl[0][a] * r[0] + Jl[1][a] * r[1]));
-        for (int c = 0; c < 3; ++c) atomicAdd(&B.Hll[9 * (size_t)k + 3 * a + c], w * (Jl[0][a] * Jl[0][c] + Jl[1][a] * Jl[1][c]));
+    Jp[0][0] = -fx * Zi; Jp[0][1] = 0; Jp[0][2] = fx * X * Zi2; Jp[0][3] = fx * X * Y * Zi2; Jp[0][4] = -fx - fx * X * X * Zi2; Jp[0][5] = fx * Y * Zi;
+    Jp[1][0] = 0; Jp[1][1] = -fy * Zi; Jp[1][2] = fy * Y * Zi2; Jp[1][3] = fy + fy * Y * Y * Zi2; Jp[1][4] = -fy * X * Y * Zi2; Jp[1][5] = -fy * X * Zi;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Jl[a][c] = Jp[a][0] * T[c] + Jp[a][1] * T[3 + c] + Jp[a][2] * T[6 + c];
+}
+
+template <int NV>
+__device__ __forceinline__ void ba_block_reduce(double* v, double* s_part) {      // 256 threads; result valid in thread 0
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double x = v[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+        v[i] = x;
     }
-    if (j < B.n_free) {
-        for (int a = 0; a < 6; ++a) {
-            atomicAdd(&B.bp[6 * j + a], -w * (Jp[0][a] * r[0] + Jp[1][a] * r[1]));
-            for (int c = 0; c < 6; ++c) atomicAdd(&B.Hpp[36 * (size_t)j + 6 * a + c], w * (Jp[0][a] * Jp[0][c] + Jp[1][a] * Jp[1][c]));
-            for (int c = 0; c < 3; ++c) B.W[18 * (size_t)e + 3 * a + c] = w * (Jp[0][a] * Jl[0][c] + Jp[1][a] * Jl[1][c]);
+    __syncthreads();
+    if (lane == 0) for (int i = 0; i < NV; ++i) s_part[wave * NV + i] = v[i];
+    __syncthreads();
+    if (threadIdx.x == 0) for (int i = 0; i < NV; ++i) v[i] = s_part[i] + s_part[NV + i] + s_part[2 * NV + i] + s_part[3 * NV + i];
+}
+
+// one lane per point: H_ll, b_l (no atomics), W_e of its free-pose edges, robust chi2
+__global__ __launch_bounds__(256) void k_ba_lin_points(BaCam cam, BaDev B, int robust, double delta) {
+    __shared__ double s_part[4];
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    double chi[1] = {0.0};
+    if (k < B.n_points) {
+        double H[6] = {0, 0, 0, 0, 0, 0}, b3[3] = {0, 0, 0};
+        const double* p = B.pts + 3 * (size_t)k;
+        for (int q = B.pt_start[k]; q < B.pt_start[k + 1]; ++q) {
+            const int e = B.pt_edges[q];
+            if (!B.active[e]) continue;
+            const int j = B.e_pose[e];
+            double r[2], w, rho0, Jp[2][6], Jl[2][3];
+            ba_edge(cam, B.poses + 12 * (size_t)j, p, B.e_uv + 2 * (size_t)e, robust, delta, r, w, rho0, Jp, Jl);
+            chi[0] += rho0;
+            b3[0] -= w * (Jl[0][0] * r[0] + Jl[1][0] * r[1]); b3[1] -= w * (Jl[0][1] * r[0] + Jl[1][1] * r[1]); b3[2] -= w * (Jl[0][2] * r[0] + Jl[1][2] * r[1]);
+            H[0] += w * (Jl[0][0] * Jl[0][0] + Jl[1][0] * Jl[1][0]); H[1] += w * (Jl[0][0] * Jl[0][1] + Jl[1][0] * Jl[1][1]); H[2] += w * (Jl[0][0] * Jl[0][2] + Jl[1][0] * Jl[1][2]);
+            H[3] += w * (Jl[0][1] * Jl[0][1] + Jl[1][1] * Jl[1][1]); H[4] += w * (Jl[0][1] * Jl[0][2] + Jl[1][1] * Jl[1][2]); H[5] += w * (Jl[0][2] * Jl[0][2] + Jl[1][2] * Jl[1][2]);
+            if (j < B.n_free) {
+                double* We = B.W + 18 * (size_t)e;
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) We[3 * a + c] = w * (Jp[0][a] * Jl[0][c] + Jp[1][a] * Jl[1][c]);
+            }
         }
+        double* Ho = B.Hll + 9 * (size_t)k;
+        Ho[0] = H[0]; Ho[1] = H[1]; Ho[2] = H[2]; Ho[3] = H[1]; Ho[4] = H[3]; Ho[5] = H[4]; Ho[6] = H[2]; Ho[7] = H[4]; Ho[8] = H[5];
+        B.bl[3 * (size_t)k] = b3[0]; B.bl[3 * (size_t)k + 1] = b3[1]; B.bl[3 * (size_t)k + 2] = b3[2];
+    }
+    ba_block_reduce<1>(chi, s_part);
+    if (threadIdx.x == 0 && chi[0] != 0.0) atomicAdd(&B.scal[0], chi[0]);
+}
+
+// one workgroup per free pose: H_pp (6x6) and b_p by a block reduction over the pose's edges
+__global__ __launch_bounds__(256) void k_ba_lin_poses(BaCam cam, BaDev B, int robust, double delta) {
+    __shared__ double s_part[4 * 27];
+    const int j = blockIdx.x;
+    const double* T = B.poses + 12 * (size_t)j;
+    double v[27];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) v[i] = 0;
+    for (int q = B.ps_start[j] + threadIdx.x; q < B.ps_start[j + 1]; q += 256) {
+        const int e = B.ps_edges[q];
+        if (!B.active[e]) continue;
+        double r[2], w, rho0, Jp[2][6], Jl[2][3];
+        ba_edge(cam, T, B.pts + 3 * (size_t)B.e_pt[e], B.e_uv + 2 * (size_t)e, robust, delta, r, w, rho0, Jp, Jl);
+        int c = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            v[21 + a] -= w * (Jp[0][a] * r[0] + Jp[1][a] * r[1]);
+#pragma unroll
+            for (int b = a; b < 6; ++b) v[c++] += w * (Jp[0][a] * Jp[0][b] + Jp[1][a] * Jp[1][b]);
+        }
+    }
+    ba_block_reduce<27>(v, s_part);
+    if (threadIdx.x == 0) {
+        int c = 0;
+        for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) { B.Hpp[36 * (size_t)j + 6 * a + b] = v[c]; B.Hpp[36 * (size_t)j + 6 * b + a] = v[c]; ++c; }
+        for (int a = 0; a < 6; ++a) B.bp[6 * j + a] = v[21 + a];
     }
 }
 
@@ -78,104 +149,160 @@ __global__ void k_ba_maxdiag(BaDev B) {
     if (i < B.D) v = fabs(B.Hpp[36 * (size_t)(i / 6) + 7 * (i % 6)]);
     else if (i < B.D + 3 * B.n_points) { const int k = (i - B.D) / 3, a = (i - B.D) % 3; v = fabs(B.Hll[9 * (size_t)k + 4 * a]); }
     else return;
-    atomicMax((unsigned long long*)&B.scal[4], (unsigned long long)__double_as_longlong(v));   // v >= 0: bit order == value order
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax((unsigned long long*)&B.scal[4], (unsigned long long)__double_as_longlong(v));   // v >= 0: bit order == value order
 }
 
+// S = blockdiag(H_pp) + lambda I, b_s = b_p, and (H_ll + lambda I)^-1 per point
 __global__ void k_ba_init_S(BaDev B, double lambda) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B.D * B.D) return;
-    const int r = i / B.D, c = i % B.D;
-    double v = 0;
-    if (r / 6 == c / 6) v = B.Hpp[36 * (size_t)(r / 6) + 6 * (r % 6) + (c % 6)];
-    if (r == c) { v += lambda; B.bs[r] = B.bp[r]; }
-    B.S[i] = v;
-}
-
-__global__ void k_ba_schur(BaDev B, double lambda) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= B.n_points) return;
-    double a[9];
-    for (int i = 0; i < 9; ++i) a[i] = B.Hll[9 * (size_t)k + i];
-    a[0] += lambda; a[4] += lambda; a[8] += lambda;
-    const double det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]);
-    double h[9];
-    if (!(fabs(det) > 0)) { for (int i = 0; i < 9; ++i) { h[i] = 0; B.Hinv[9 * (size_t)k + i] = 0; } return; }
-    const double id = 1.0 / det;
-    h[0] = (a[4] * a[8] - a[5] * a[7]) * id; h[1] = (a[2] * a[7] - a[1] * a[8]) * id; h[2] = (a[1] * a[5] - a[2] * a[4]) * id;
-    h[3] = (a[5] * a[6] - a[3] * a[8]) * id; h[4] = (a[0] * a[8] - a[2] * a[6]) * id; h[5] = (a[2] * a[3] - a[0] * a[5]) * id;
-    h[6] = (a[3] * a[7] - a[4] * a[6]) * id; h[7] = (a[1] * a[6] - a[0] * a[7]) * id; h[8] = (a[0] * a[4] - a[1] * a[3]) * id;
-    for (int i = 0; i < 9; ++i) B.Hinv[9 * (size_t)k + i] = h[i];
-    const double bl0 = B.bl[3 * (size_t)k], bl1 = B.bl[3 * (size_t)k + 1], bl2 = B.bl[3 * (size_t)k + 2];
-    for (int p1 = B.pt_start[k]; p1 < B.pt_start[k + 1]; ++p1) {
-        const int e1 = B.pt_edges[p1], j1 = B.e_pose[e1];
-        if (!B.active[e1] || j1 >= B.n_free) continue;
-        const double* W1 = B.W + 18 * (size_t)e1;
-        double WH[18];
-        for (int r = 0; r < 6; ++r) for (int c = 0; c < 3; ++c) WH[3 * r + c] = W1[3 * r] * h[c] + W1[3 * r + 1] * h[3 + c] + W1[3 * r + 2] * h[6 + c];
-        for (int r = 0; r < 6; ++r) atomicAdd(&B.bs[6 * j1 + r], -(WH[3 * r] * bl0 + WH[3 * r + 1] * bl1 + WH[3 * r + 2] * bl2));
-        for (int p2 = B.pt_start[k]; p2 < B.pt_start[k + 1]; ++p2) {
-            const int e2 = B.pt_edges[p2], j2 = B.e_pose[e2];
-            if (!B.active[e2] || j2 >= B.n_free) continue;
-            const double* W2 = B.W + 18 * (size_t)e2;
-            for (int r = 0; r < 6; ++r)
-                for (int c = 0; c < 6; ++c)
-                    atomicAdd(&B.S[(size_t)(6 * j1 + r) * B.D + 6 * j2 + c], -(WH[3 * r] * W2[3 * c] + WH[3 * r + 1] * W2[3 * c + 1] + WH[3 * r + 2] * W2[3 * c + 2]));
+    if (i < B.D * B.D) {
+        const int r = i / B.D, c = i % B.D;
+        double v = 0;
+        if (r / 6 == c / 6) v = B.Hpp[36 * (size_t)(r / 6) + 6 * (r % 6) + (c % 6)];
+        if (r == c) v += lambda;
+        B.S[i] = v;
+    }
+    if (i < B.n_points) {
+        const int k = i;
+        double a[9];
+        for (int q = 0; q < 9; ++q) a[q] = B.Hll[9 * (size_t)k + q];
+        a[0] += lambda; a[4] += lambda; a[8] += lambda;
+        const double det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]);
+        double* h = B.Hinv + 9 * (size_t)k;
+        if (!(fabs(det) > 0)) { for (int q = 0; q < 9; ++q) h[q] = 0; }
+        else {
+            const double id = 1.0 / det;
+            h[0] = (a[4] * a[8] - a[5] * a[7]) * id; h[1] = (a[2] * a[7] - a[1] * a[8]) * id; h[2] = (a[1] * a[5] - a[2] * a[4]) * id;
+            h[3] = (a[5] * a[6] - a[3] * a[8]) * id; h[4] = (a[0] * a[8] - a[2] * a[6]) * id; h[5] = (a[2] * a[3] - a[0] * a[5]) * id;
+            h[6] = (a[3] * a[7] - a[4] * a[6]) * id; h[7] = (a[1] * a[6] - a[0] * a[7]) * id; h[8] = (a[0] * a[4] - a[1] * a[3]) * id;
         }
     }
 }
 
-// in-place Cholesky + solve, one workgroup; result in bs, ok flag in scal[3]
-__global__ __launch_bounds__(256) void k_ba_chol(BaDev B) {
+// Schur complement, one workgroup per 6x6 block (j1 <= j2) of the reduced system:
+//   S[j1][j2] -= sum over points seen by both poses of W_e1 (H_ll+lambda)^-1 W_e2^T       (no atomics)
+__global__ __launch_bounds__(256) void k_ba_schur_blocks(BaDev B) {
+    __shared__ double s_part[4 * 36];
+    const BaBlock blk = B.blocks[blockIdx.x];
+    double v[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) v[i] = 0;
+    for (int q = blk.start + threadIdx.x; q < blk.start + blk.count; q += 256) {
+        const int2 pr = B.pairs[q];
+        if (!B.active[pr.x] || !B.active[pr.y]) continue;
+        const double* h = B.Hinv + 9 * (size_t)B.e_pt[pr.x];
+        const double* W1 = B.W + 18 * (size_t)pr.x;
+        const double* W2 = B.W + 18 * (size_t)pr.y;
+        double w2[18];
+#pragma unroll
+        for (int i = 0; i < 18; ++i) w2[i] = W2[i];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const double y0 = W1[3 * r] * h[0] + W1[3 * r + 1] * h[3] + W1[3 * r + 2] * h[6];
+            const double y1 = W1[3 * r] * h[1] + W1[3 * r + 1] * h[4] + W1[3 * r + 2] * h[7];
+            const double y2 = W1[3 * r] * h[2] + W1[3 * r + 1] * h[5] + W1[3 * r + 2] * h[8];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v[6 * r + c] += y0 * w2[3 * c] + y1 * w2[3 * c + 1] + y2 * w2[3 * c + 2];
+        }
+    }
+    ba_block_reduce<36>(v, s_part);
+    if (threadIdx.x == 0) {
+        for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < 6; ++c) {
+                B.S[(size_t)(6 * blk.j1 + r) * B.D + 6 * blk.j2 + c] -= v[6 * r + c];
+                if (blk.j1 != blk.j2) B.S[(size_t)(6 * blk.j2 + c) * B.D + 6 * blk.j1 + r] -= v[6 * r + c];
+            }
+    }
+}
+
+// b_s[j] = b_p[j] - sum over the pose's edges of W_e (H_ll+lambda)^-1 b_l
+__global__ __launch_bounds__(256) void k_ba_bs(BaDev B) {
+    __shared__ double s_part[4 * 6];
+    const int j = blockIdx.x;
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    for (int q = B.ps_start[j] + threadIdx.x; q < B.ps_start[j + 1]; q += 256) {
+        const int e = B.ps_edges[q];
+        if (!B.active[e]) continue;
+        const int k = B.e_pt[e];
+        const double* h = B.Hinv + 9 * (size_t)k;
+        const double b0 = B.bl[3 * (size_t)k], b1 = B.bl[3 * (size_t)k + 1], b2 = B.bl[3 * (size_t)k + 2];
+        const double g0 = h[0] * b0 + h[1] * b1 + h[2] * b2, g1 = h[3] * b0 + h[4] * b1 + h[5] * b2, g2 = h[6] * b0 + h[7] * b1 + h[8] * b2;
+        const double* We = B.W + 18 * (size_t)e;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) v[r] += We[3 * r] * g0 + We[3 * r + 1] * g1 + We[3 * r + 2] * g2;
+    }
+    ba_block_reduce<6>(v, s_part);
+    if (threadIdx.x == 0) for (int r = 0; r < 6; ++r) B.bs[6 * j + r] = B.bp[6 * j + r] - v[r];
+}
+
+// dense Cholesky + solve of the reduced system in one 1024-thread workgroup (right-looking, trailing
+// update spread over all lanes); result in bs, ok flag in scal[3].  Only the lower triangle is used.
+__global__ __launch_bounds__(1024) void k_ba_chol(BaDev B) {
     const int D = B.D, tid = threadIdx.x;
     double* A = B.S; double* b = B.bs;
     __shared__ int s_ok;
+    __shared__ double s_col[1024];
     if (tid == 0) s_ok = 1;
     __syncthreads();
     for (int j = 0; j < D; ++j) {
-        if (tid == 0) {
-            double d = A[(size_t)j * D + j];
-            for (int k = 0; k < j; ++k) d -= A[(size_t)j * D + k] * A[(size_t)j * D + k];
-            if (!(d > 0.0)) s_ok = 0; else A[(size_t)j * D + j] = sqrt(d);
-        }
+        if (tid == 0) { const double d = A[(size_t)j * D + j]; if (!(d > 0.0)) s_ok = 0; else A[(size_t)j * D + j] = sqrt(d); }
         __syncthreads();
         if (!s_ok) break;
-        const double d = A[(size_t)j * D + j];
-        for (int i = j + 1 + tid; i < D; i += 256) {
-            double s = A[(size_t)i * D + j];
-            for (int k = 0; k < j; ++k) s -= A[(size_t)i * D + k] * A[(size_t)j * D + k];
-            A[(size_t)i * D + j] = s / d;
+        const double dj = A[(size_t)j * D + j];
+        for (int i = j + 1 + tid; i < D; i += 1024) { const double l = A[(size_t)i * D + j] / dj; A[(size_t)i * D + j] = l; if (i - j - 1 < 1024) s_col[i - j - 1] = l; }
+        __syncthreads();
+        const int m = D - j - 1;                      // trailing (m x m) lower triangle -= l l^T
+        if (m <= 1024) {
+            for (int t = tid; t < m * m; t += 1024) { const int r = t / m, c = t - r * m; if (c <= r) A[(size_t)(j + 1 + r) * D + j + 1 + c] -= s_col[r] * s_col[c]; }
+        } else {
+            for (int t = tid; t < m * m; t += 1024) { const int r = t / m, c = t - r * m; if (c <= r) A[(size_t)(j + 1 + r) * D + j + 1 + c] -= A[(size_t)(j + 1 + r) * D + j] * A[(size_t)(j + 1 + c) * D + j]; }
         }
         __syncthreads();
     }
-    if (tid == 0) {
-        if (s_ok) {
-            for (int i = 0; i < D; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= A[(size_t)i * D + k] * b[k]; b[i] = s / A[(size_t)i * D + i]; }
-            for (int i = D - 1; i >= 0; --i) { double s = b[i]; for (int k = i + 1; k < D; ++k) s -= A[(size_t)k * D + i] * b[k]; b[i] = s / A[(size_t)i * D + i]; }
+    if (s_ok) {
+        // forward / backward substitution, one column at a time (axpy form)
+        for (int j = 0; j < D; ++j) {
+            if (tid == 0) b[j] /= A[(size_t)j * D + j];
+            __syncthreads();
+            const double bj = b[j];
+            for (int i = j + 1 + tid; i < D; i += 1024) b[i] -= A[(size_t)i * D + j] * bj;
+            __syncthreads();
         }
-        B.scal[3] = s_ok ? 1.0 : 0.0;
+        for (int j = D - 1; j >= 0; --j) {
+            if (tid == 0) b[j] /= A[(size_t)j * D + j];
+            __syncthreads();
+            const double bj = b[j];
+            for (int i = tid; i < j; i += 1024) b[i] -= A[(size_t)j * D + i] * bj;
+            __syncthreads();
+        }
     }
+    if (tid == 0) B.scal[3] = s_ok ? 1.0 : 0.0;
 }
 
 __global__ void k_ba_backsub(BaDev B, double lambda) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= B.n_points) return;
-    if (B.scal[3] == 0.0) return;
-    double rhs[3] = {B.bl[3 * (size_t)k], B.bl[3 * (size_t)k + 1], B.bl[3 * (size_t)k + 2]};
-    for (int p1 = B.pt_start[k]; p1 < B.pt_start[k + 1]; ++p1) {
-        const int e1 = B.pt_edges[p1], j1 = B.e_pose[e1];
-        if (!B.active[e1] || j1 >= B.n_free) continue;
-        const double* W1 = B.W + 18 * (size_t)e1;
-        for (int c = 0; c < 3; ++c) for (int r = 0; r < 6; ++r) rhs[c] -= W1[3 * r + c] * B.bs[6 * j1 + r];
-    }
-    const double* h = B.Hinv + 9 * (size_t)k;
     double sc = 0;
-    for (int a = 0; a < 3; ++a) {
-        const double d = h[3 * a] * rhs[0] + h[3 * a + 1] * rhs[1] + h[3 * a + 2] * rhs[2];
-        B.dl[3 * (size_t)k + a] = d;
-        B.pts_n[3 * (size_t)k + a] = B.pts[3 * (size_t)k + a] + d;
-        sc += d * (lambda * d + B.bl[3 * (size_t)k + a]);
+    if (k < B.n_points && B.scal[3] != 0.0) {
+        double rhs[3] = {B.bl[3 * (size_t)k], B.bl[3 * (size_t)k + 1], B.bl[3 * (size_t)k + 2]};
+        for (int p1 = B.pt_start[k]; p1 < B.pt_start[k + 1]; ++p1) {
+            const int e1 = B.pt_edges[p1], j1 = B.e_pose[e1];
+            if (!B.active[e1] || j1 >= B.n_free) continue;
+            const double* W1 = B.W + 18 * (size_t)e1;
+            for (int c = 0; c < 3; ++c) for (int r = 0; r < 6; ++r) rhs[c] -= W1[3 * r + c] * B.bs[6 * j1 + r];
+        }
+        const double* h = B.Hinv + 9 * (size_t)k;
+        for (int a = 0; a < 3; ++a) {
+            const double d = h[3 * a] * rhs[0] + h[3 * a + 1] * rhs[1] + h[3 * a + 2] * rhs[2];
+            B.dl[3 * (size_t)k + a] = d;
+            B.pts_n[3 * (size_t)k + a] = B.pts[3 * (size_t)k + a] + d;
+            sc += d * (lambda * d + B.bl[3 * (size_t)k + a]);
+        }
     }
-    atomicAdd(&B.scal[2], sc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sc += __shfl_xor(sc, o, 64);
+    if ((threadIdx.x & 63) == 0 && sc != 0.0) atomicAdd(&B.scal[2], sc);
 }
 
 __global__ void k_ba_pose(BaDev B, double lambda) {
@@ -204,7 +331,7 @@ __global__ void k_ba_pose(BaDev B, double lambda) {
     atomicAdd(&B.scal[2], sc);
 }
 
-// which: 0 -> current state into scal[0]-free slot scal[5]; 1 -> trial state into scal[1]
+// chi2 of the current (trial = 0 -> scal[5]) or trial (-> scal[1]) state
 __global__ void k_ba_chi(BaCam cam, BaDev B, int trial, int robust, double delta) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     double v = 0;
@@ -248,6 +375,42 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     for (int k = 0; k < nx; ++k) pt_start[k + 1] += pt_start[k];
     { std::vector<int32_t> fill(pt_start.begin(), pt_start.end() - 1);
       for (int e = 0; e < ne; ++e) pt_edges[fill[in->edge_point[e]]++] = e; }
+    // CSR free pose -> edges, and the (e1, e2) pair lists of every 6x6 block of the reduced system
+    std::vector<int32_t> ps_start(nf + 1, 0), ps_edges;
+    for (int e = 0; e < ne; ++e) if (in->edge_pose[e] < nf) ps_start[in->edge_pose[e] + 1]++;
+    for (int j = 0; j < nf; ++j) ps_start[j + 1] += ps_start[j];
+    ps_edges.resize(ps_start[nf]);
+    { std::vector<int32_t> fill(ps_start.begin(), ps_start.end() - 1);
+      for (int e = 0; e < ne; ++e) if (in->edge_pose[e] < nf) ps_edges[fill[in->edge_pose[e]]++] = e; }
+    std::vector<int32_t> blk_cnt((size_t)nf * nf, 0);
+    for (int k = 0; k < nx; ++k)
+        for (int a = pt_start[k]; a < pt_start[k + 1]; ++a) {
+            const int j1 = in->edge_pose[pt_edges[a]];
+            if (j1 >= nf) continue;
+            for (int b2 = pt_start[k]; b2 < pt_start[k + 1]; ++b2) { const int j2 = in->edge_pose[pt_edges[b2]]; if (j2 < nf && j1 <= j2 && (j1 < j2 || a == b2)) blk_cnt[(size_t)j1 * nf + j2]++; }
+        }
+    std::vector<BaBlock> blocks;
+    std::vector<int32_t> blk_off((size_t)nf * nf, -1);
+    int npairs = 0;
+    for (int j1 = 0; j1 < nf; ++j1) for (int j2 = j1; j2 < nf; ++j2) {
+        const int cnt = blk_cnt[(size_t)j1 * nf + j2];
+        if (!cnt) continue;
+        blk_off[(size_t)j1 * nf + j2] = npairs;
+        blocks.push_back(BaBlock{j1, j2, npairs, cnt});
+        npairs += cnt;
+    }
+    std::vector<int2> pairs((size_t)std::max(npairs, 1));
+    { std::vector<int32_t> fill = blk_off;
+      for (int k = 0; k < nx; ++k)
+          for (int a = pt_start[k]; a < pt_start[k + 1]; ++a) {
+              const int e1 = pt_edges[a], j1 = in->edge_pose[e1];
+              if (j1 >= nf) continue;
+              for (int b2 = pt_start[k]; b2 < pt_start[k + 1]; ++b2) {
+                  const int e2 = pt_edges[b2], j2 = in->edge_pose[e2];
+                  if (j2 < nf && j1 <= j2 && (j1 < j2 || a == b2)) pairs[fill[(size_t)j1 * nf + j2]++] = make_int2(e1, e2);
+              }
+          } }
+    const int nblk = (int)blocks.size();
 
     // carve the scratch slab
     size_t off = 0;
@@ -255,15 +418,16 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     const size_t o_poses = carve(96 * (size_t)np), o_pts = carve(24 * (size_t)nx), o_poses_n = carve(96 * (size_t)np), o_pts_n = carve(24 * (size_t)nx);
     const size_t o_epose = carve(4 * (size_t)ne), o_ept = carve(4 * (size_t)ne), o_euv = carve(8 * (size_t)ne), o_act = carve(ne), o_flags = carve(ne);
     const size_t o_ps = carve(4 * (size_t)(nx + 1)), o_pe = carve(4 * (size_t)ne);
-    const size_t o_lin = off;      // zeroed before every linearisation: Hpp bp Hll bl scal
+    const size_t o_qs = carve(4 * (size_t)(nf + 1)), o_qe = carve(4 * (size_t)std::max<size_t>(ps_edges.size(), 1));
+    const size_t o_blk = carve(sizeof(BaBlock) * (size_t)std::max(nblk, 1)), o_pairs = carve(sizeof(int2) * pairs.size());
     const size_t o_Hpp = carve(288 * (size_t)nf), o_bp = carve(8 * (size_t)D), o_Hll = carve(72 * (size_t)nx), o_bl = carve(24 * (size_t)nx), o_scal = carve(64);
-    const size_t lin_bytes = off - o_lin;
     const size_t o_W = carve(144 * (size_t)ne), o_S = carve(8 * (size_t)D * D), o_bs = carve(8 * (size_t)D), o_Hinv = carve(72 * (size_t)nx), o_dl = carve(24 * (size_t)nx);
     int rc = vo_scratch(c, off);
     if (rc) return rc;
     uint8_t* base = (uint8_t*)c->d_ba;
     BaDev B;
-    B.n_poses = np; B.n_free = nf; B.n_points = nx; B.n_edges = ne; B.D = D;
+    B.n_poses = np; B.n_free = nf; B.n_points = nx; B.n_edges = ne; B.D = D; B.n_blocks = nblk;
+    B.ps_start = (const int32_t*)(base + o_qs); B.ps_edges = (const int32_t*)(base + o_qe); B.blocks = (const BaBlock*)(base + o_blk); B.pairs = (const int2*)(base + o_pairs);
     B.poses = (double*)(base + o_poses); B.pts = (double*)(base + o_pts); B.poses_n = (double*)(base + o_poses_n); B.pts_n = (double*)(base + o_pts_n);
     B.e_pose = (const int32_t*)(base + o_epose); B.e_pt = (const int32_t*)(base + o_ept); B.e_uv = (const float*)(base + o_euv);
     B.active = base + o_act; B.flags = base + o_flags; B.pt_start = (const int32_t*)(base + o_ps); B.pt_edges = (const int32_t*)(base + o_pe);
@@ -278,6 +442,10 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     HIP_TRY(hipMemcpyAsync(base + o_euv, in->edge_uv, 8 * (size_t)ne, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(base + o_ps, pt_start.data(), 4 * (size_t)(nx + 1), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(base + o_pe, pt_edges.data(), 4 * (size_t)ne, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(base + o_qs, ps_start.data(), 4 * (size_t)(nf + 1), hipMemcpyHostToDevice, st));
+    if (!ps_edges.empty()) HIP_TRY(hipMemcpyAsync(base + o_qe, ps_edges.data(), 4 * ps_edges.size(), hipMemcpyHostToDevice, st));
+    if (nblk) HIP_TRY(hipMemcpyAsync(base + o_blk, blocks.data(), sizeof(BaBlock) * (size_t)nblk, hipMemcpyHostToDevice, st));
+    if (npairs) HIP_TRY(hipMemcpyAsync(base + o_pairs, pairs.data(), sizeof(int2) * (size_t)npairs, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(base + o_act, 1, ne, st));
     HIP_TRY(hipMemsetAsync(base + o_flags, 0, ne, st));
     HIP_TRY(hipStreamSynchronize(st));       // pageable sources
@@ -293,8 +461,9 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     auto optimize = [&](int robust, int max_it, int& iters) -> int {
         double lambda = 0, ni = 2;
         for (int it = 0; it < max_it; ++it) {
-            HIP_TRY(hipMemsetAsync(base + o_lin, 0, lin_bytes, st));
-            { ProfScope ps(c, "k_ba_linearize"); hipLaunchKernelGGL(k_ba_linearize, gE, blk, 0, st, cam, B, robust, in->huber_delta); }
+            HIP_TRY(hipMemsetAsync(B.scal, 0, 64, st));     // H/b buffers are fully overwritten (no atomics)
+            { ProfScope ps(c, "k_ba_lin_points"); hipLaunchKernelGGL(k_ba_lin_points, gP, blk, 0, st, cam, B, robust, in->huber_delta); }
+            { ProfScope ps(c, "k_ba_lin_poses"); hipLaunchKernelGGL(k_ba_lin_poses, dim3(nf), blk, 0, st, cam, B, robust, in->huber_delta); }
             if (it == 0) hipLaunchKernelGGL(k_ba_maxdiag, dim3((D + 3 * nx + 255) / 256), blk, 0, st, B);
             if ((rc = read_scal())) return rc;
             double cur = h_scal[0];
@@ -302,9 +471,10 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
             double rho = 0; int qmax = 0;
             do {
                 HIP_TRY(hipMemsetAsync(B.scal + 1, 0, 24, st));        // trial chi, scale, ok
-                hipLaunchKernelGGL(k_ba_init_S, dim3((D * D + 255) / 256), blk, 0, st, B, lambda);
-                { ProfScope ps(c, "k_ba_schur"); hipLaunchKernelGGL(k_ba_schur, gP, blk, 0, st, B, lambda); }
-                { ProfScope ps(c, "k_ba_chol"); hipLaunchKernelGGL(k_ba_chol, dim3(1), blk, 0, st, B); }
+                hipLaunchKernelGGL(k_ba_init_S, dim3((std::max(D * D, nx) + 255) / 256), blk, 0, st, B, lambda);
+                if (nblk) { ProfScope ps(c, "k_ba_schur_blocks"); hipLaunchKernelGGL(k_ba_schur_blocks, dim3(nblk), blk, 0, st, B); }
+                hipLaunchKernelGGL(k_ba_bs, dim3(nf), blk, 0, st, B);
+                { ProfScope ps(c, "k_ba_chol"); hipLaunchKernelGGL(k_ba_chol, dim3(1), dim3(1024), 0, st, B); }
                 hipLaunchKernelGGL(k_ba_backsub, gP, blk, 0, st, B, lambda);
                 hipLaunchKernelGGL(k_ba_pose, gJ, blk, 0, st, B, lambda);
                 hipLaunchKernelGGL(k_ba_chi, gE, blk, 0, st, cam, B, 1, robust, in->huber_delta);

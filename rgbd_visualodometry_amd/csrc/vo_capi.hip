@@ -183,6 +183,8 @@ void vo_ctx_destroy(vo_ctx* c) {
     if (c->h_track) (void)hipHostFree(c->h_track);
     if (c->h_matches) (void)hipHostFree(c->h_matches);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_slots_pinned) (void)hipHostFree(c->h_slots_pinned);
+    if (c->slots_ev) (void)hipEventDestroy(c->slots_ev);
     for (auto& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -207,6 +209,7 @@ int vo_ctx_create(const vo_params* p, int device, vo_ctx** out) {
     c->d_best = nullptr; c->d_matches = nullptr; c->d_corr_xyz = nullptr; c->d_corr_uv = nullptr; c->corr_cap = 0; c->d_hyp_pose = nullptr; c->d_hyp_cnt = nullptr;
     c->d_inliers = nullptr; c->d_lm_mask = nullptr; c->d_track = nullptr; c->h_track = nullptr; c->h_matches = nullptr; c->h_matches_cap = 0;
     c->h_stage = nullptr; c->h_stage_bytes = 0; c->d_ba = nullptr; c->d_ba_bytes = 0;
+    c->h_slots_pinned = nullptr; c->slots_ev = nullptr; c->slots_dirty = false; c->slots_pending = false;
     std::vector<int> tab; std::vector<short> tabs;
     int rc = build_plan(*p, c->plan, tab, tabs);
     if (rc) { delete c; return rc; }
@@ -218,6 +221,9 @@ int vo_ctx_create(const vo_params* p, int device, vo_ctx** out) {
     c->own_bgr.assign(F, nullptr); c->own_depth.assign(F, nullptr);
     c->h_slots.assign(F, SlotDesc{nullptr, nullptr, 0, 0}); c->slot_bound.assign(F, 0); c->slot_orb.assign(F, 0);
     ALLOC(c->d_slots, (size_t)F);
+    if (hipHostMalloc((void**)&c->h_slots_pinned, sizeof(SlotDesc) * F, hipHostMallocDefault) != hipSuccess) { vo_ctx_destroy(c); return VO_E_NOMEM; }
+    memset(c->h_slots_pinned, 0, sizeof(SlotDesc) * F);
+    if (hipEventCreateWithFlags(&c->slots_ev, hipEventDisableTiming) != hipSuccess) { vo_ctx_destroy(c); return VO_E_DEVICE; }
     ALLOC(c->d_pyr, (size_t)F * P.pyr_stride);
     ALLOC(c->d_tab, tab.size()); ALLOC(c->d_tabs, tabs.size());
     ALLOC(c->d_cand, (size_t)F * P.cprefix[P.L]); ALLOC(c->d_cand_cnt, (size_t)F * VO_MAX_LEVELS);
@@ -244,14 +250,18 @@ int vo_ctx_create(const vo_params* p, int device, vo_ctx** out) {
     return VO_OK;
 }
 
-static int push_slot(vo_ctx* c, int slot) {
-    SlotDesc* stage = (SlotDesc*)vo_stage(c, sizeof(SlotDesc));
-    if (!stage) return VO_E_NOMEM;
-    // the staging buffer is shared: make sure an earlier async copy out of it has completed
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    *stage = c->h_slots[slot];
-    HIP_TRY(hipMemcpyAsync(c->d_slots + slot, stage, sizeof(SlotDesc), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+// Slot descriptors are mirrored in pinned memory and pushed lazily, once, in front of the next ORB launch.
+static int mark_slot(vo_ctx* c, int slot) {
+    if (c->slots_pending) { HIP_TRY(hipEventSynchronize(c->slots_ev)); c->slots_pending = false; }
+    c->h_slots_pinned[slot] = c->h_slots[slot];
+    c->slots_dirty = true;
+    return VO_OK;
+}
+static int push_slots(vo_ctx* c) {
+    if (!c->slots_dirty) return VO_OK;
+    HIP_TRY(hipMemcpyAsync(c->d_slots, c->h_slots_pinned, sizeof(SlotDesc) * c->p.max_frames, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->slots_ev, c->stream));
+    c->slots_dirty = false; c->slots_pending = true;
     return VO_OK;
 }
 
@@ -266,7 +276,8 @@ int vo_frame_upload(vo_ctx* c, int slot, const uint8_t* bgr, int bs, const uint1
     HIP_TRY(hipMemcpy2DAsync(c->own_depth[slot], dp, depth, ds, 2 * (size_t)W, H, hipMemcpyHostToDevice, c->stream));
     c->h_slots[slot] = SlotDesc{c->own_bgr[slot], c->own_depth[slot], bp, dp};
     c->slot_bound[slot] = 1; c->slot_orb[slot] = 0;
-    return push_slot(c, slot);     // also waits for the pageable host copies: caller may reuse its buffers
+    HIP_TRY(hipStreamSynchronize(c->stream));     // pageable host copies done: caller may reuse its buffers
+    return mark_slot(c, slot);
 }
 
 int vo_frame_bind_device(vo_ctx* c, int slot, const void* b, int bs, const void* d, int ds) {
@@ -274,14 +285,16 @@ int vo_frame_bind_device(vo_ctx* c, int slot, const void* b, int bs, const void*
     HIP_TRY(hipSetDevice(c->device));
     c->h_slots[slot] = SlotDesc{(const uint8_t*)b, (const uint8_t*)d, bs, ds};
     c->slot_bound[slot] = 1; c->slot_orb[slot] = 0;
-    return push_slot(c, slot);
+    return mark_slot(c, slot);
 }
 
 int vo_orb_detect_describe(vo_ctx* c, int slot0, int n) {
     if (!c || slot0 < 0 || n < 1 || slot0 + n > c->p.max_frames) return VO_E_INVALID;
     for (int i = slot0; i < slot0 + n; ++i) if (!c->slot_bound[i]) return VO_E_STATE;
     HIP_TRY(hipSetDevice(c->device));
-    int rc = vo_orb_launch(c, slot0, n);
+    int rc = push_slots(c);
+    if (rc) return rc;
+    rc = vo_orb_launch(c, slot0, n);
     if (rc) return rc;
     for (int i = slot0; i < slot0 + n; ++i) c->slot_orb[i] = 1;
     return VO_OK;

@@ -52,6 +52,7 @@ struct vo_ctx {
     // frames
     std::vector<uint8_t*> own_bgr, own_depth;       // per slot (allocated lazily on upload)
     SlotDesc* d_slots; std::vector<SlotDesc> h_slots;
+    SlotDesc* h_slots_pinned; hipEvent_t slots_ev; bool slots_dirty, slots_pending;
     std::vector<char> slot_bound, slot_orb;
     // pyramid + ORB work buffers
     uint8_t* d_pyr;

@@ -4,12 +4,21 @@
 #include "myslam/frontend.h"
 
 #include <algorithm>
+#include <chrono>
 #include <stdexcept>
 
 #include "myslam/config.h"
 #include "myslam/mapmanager.h"
 
 namespace myslam {
+
+namespace {
+struct StageTimer {
+    double& acc; std::chrono::steady_clock::time_point t0;
+    explicit StageTimer(double& a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+    ~StageTimer() { acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+}  // namespace
 
 static void vo_check(int rc, const char* what) {
     if (rc != VO_OK) throw std::runtime_error(std::string(what) + " failed: " + vo_strerror(rc));
@@ -73,8 +82,8 @@ void FrontEnd::InitializationHandler() {
 
 bool FrontEnd::TrackingHandler() {
     frameCurr_->SetPose(framePrev_->GetPose());                  // prior = pose of the last keyframe (frontend.cpp:96)
-    ExtractKeyPointsAndComputeDescriptors();
-    MatchAndEstimatePose();                                      // coarse + fine (frontend.cpp:100-108)
+    { StageTimer t(stats_.ms_extract); ExtractKeyPointsAndComputeDescriptors(); }
+    { StageTimer t(stats_.ms_track); MatchAndEstimatePose(); }   // coarse + fine (frontend.cpp:100-108)
 
     if (!IsGoodEstimation()) {
         accuLostFrameNums_++;
@@ -85,12 +94,15 @@ bool FrontEnd::TrackingHandler() {
     accuLostFrameNums_ = 0;
     if (!IsKeyframe()) return true;
 
-    MapManager::GetInstance().InsertKeyframe(frameCurr_);
-    ++stats_.keyframes;
-    AddCurrentKeyframeObservations();
-    CreateNewMappoints();
-    TriangulateMappointsInTrackingMap();
-    if (backend_) backend_->OptimizeCovisibleGraphOfKeyframe(frameCurr_);
+    {
+        StageTimer t(stats_.ms_keyframe);
+        MapManager::GetInstance().InsertKeyframe(frameCurr_);
+        ++stats_.keyframes;
+        AddCurrentKeyframeObservations();
+        CreateNewMappoints();
+        TriangulateMappointsInTrackingMap();
+    }
+    if (backend_) { StageTimer t(stats_.ms_backend); backend_->OptimizeCovisibleGraphOfKeyframe(frameCurr_); }
     framePrev_ = frameCurr_;
     keyframeRef_ = frameCurr_;
     return true;

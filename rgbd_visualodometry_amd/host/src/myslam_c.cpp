@@ -117,12 +117,15 @@ int myslam_add_frame(myslam_system* s, double stamp, const void* bgr, const void
     });
 }
 
+void* myslam_get_context(myslam_system* s) { return s ? (void*)s->frontend->GetContext() : nullptr; }
+
 int myslam_get_stats(myslam_system* s, myslam_stats* st) {
     if (!s || !st) return -1;
     std::memset(st, 0, sizeof(*st));
     const auto& f = s->frontend->GetStats();
     st->frames = f.frames; st->keyframes = f.keyframes; st->lost = f.lost; st->state = (int)s->frontend->GetState();
     st->last_keypoints = f.last_keypoints; st->last_candidates = f.last_candidates; st->last_matches = f.last_matches;
+    st->ms_extract = f.ms_extract; st->ms_track = f.ms_track; st->ms_keyframe = f.ms_keyframe; st->ms_backend = f.ms_backend;
     st->last_ransac_inliers = f.last_ransac; st->last_lm_inliers = f.last_lm; st->map_points = (int)s->map.MappointCount();
     if (s->backend) {
         const auto& b = s->backend->GetStats();

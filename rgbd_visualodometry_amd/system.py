@@ -34,14 +34,15 @@ class Stats(C.Structure):
                 ("last_keypoints", C.c_int32), ("last_candidates", C.c_int32), ("last_matches", C.c_int32),
                 ("last_ransac_inliers", C.c_int32), ("last_lm_inliers", C.c_int32), ("map_points", C.c_int32),
                 ("ba_runs", C.c_int32), ("ba_poses", C.c_int32), ("ba_fixed", C.c_int32), ("ba_points", C.c_int32),
-                ("ba_edges", C.c_int32), ("ba_outliers", C.c_int32), ("ba_ms", C.c_double)]
+                ("ba_edges", C.c_int32), ("ba_outliers", C.c_int32), ("ba_ms", C.c_double),
+                ("ms_extract", C.c_double), ("ms_track", C.c_double), ("ms_keyframe", C.c_double), ("ms_backend", C.c_double)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 SYMBOLS = ["myslam_default_options", "myslam_system_create", "myslam_system_destroy", "myslam_prefetch",
-           "myslam_add_frame", "myslam_add_prefetched", "myslam_get_stats", "myslam_last_error", "myslam_backend_name"]
+           "myslam_add_frame", "myslam_add_prefetched", "myslam_get_stats", "myslam_get_context", "myslam_last_error", "myslam_backend_name"]
 
 _libs = {}
 
@@ -62,6 +63,8 @@ def _load(path: str):
         lib.myslam_add_frame.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p]
         lib.myslam_add_prefetched.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
         lib.myslam_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        lib.myslam_get_context.argtypes = [C.c_void_p]
+        lib.myslam_get_context.restype = C.c_void_p
         _libs[path] = lib
     return _libs[path]
 
@@ -127,6 +130,9 @@ class VoSystem:
         T = np.zeros(12)
         self._check(self.lib.myslam_add_prefetched(self.h, C.byref(ok), T.ctypes.data), "myslam_add_prefetched")
         return bool(ok.value), T
+
+    def context_handle(self) -> int:
+        return self.lib.myslam_get_context(self.h)
 
     def stats(self) -> dict:
         st = Stats()
