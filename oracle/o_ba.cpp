@@ -82,7 +82,7 @@ struct BA {
                 for (int k = 0; k < np; ++k) for (int a = 0; a < 3; ++a) md = std::max(md, std::fabs(Hll[9 * (size_t)k + 4 * a]));
                 lambda = 1e-5 * md; ni = 2;
             }
-            double rho = 0; int qmax = 0;
+            double rho = 0; int qmax = 0; bool converged = false;
             do {
                 // Schur complement on the points
                 std::vector<double> S = Hpp, bs = bp, Hinv((size_t)9 * np), dl((size_t)3 * np);
@@ -145,10 +145,14 @@ struct BA {
                     double a = 1.0 - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
                     a = std::min(a, 2.0 / 3.0);
                     lambda *= std::max(1.0 / 3.0, a); ni = 2; cur = tmp; pose.swap(Pn); pt.swap(Xn);
+                    double mx = 0;
+                    for (int i = 0; i < D; ++i) mx = std::max(mx, std::fabs(dp[i]));
+                    for (int i = 0; i < 3 * np; ++i) mx = std::max(mx, std::fabs(dl[i]));
+                    converged = mx < 1e-10;
                 } else { lambda *= ni; ni *= 2; }
                 ++qmax;
             } while (rho < 0 && qmax < 10);
-            if (qmax == 10 || rho == 0) { ++it; break; }
+            if (qmax == 10 || rho == 0 || converged) { ++it; break; }
         }
         return it;
     }

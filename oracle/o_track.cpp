@@ -193,11 +193,13 @@ int ransac_update_iters(double conf, int n_pts, int n_inl, int max_iters) {
     return k;
 }
 
+// inlier test without divisions: |fx X + (cx-u) Z, fy Y + (cy-v) Z|^2 <= thr^2 Z^2  (same predicate as
+// |proj - z|^2 <= thr^2 for Z > 0; written so that CPU and GPU evaluate identical operations)
 static inline bool reproj_ok(const Cam& cam, const M3& R, V3 t, const float* X, const float* z, double thr2) {
     V3 pc = R * V3(X[0], X[1], X[2]) + t;
     if (!(pc.z > 0)) return false;
-    double du = cam.fx * pc.x / pc.z + cam.cx - (double)z[0], dv = cam.fy * pc.y / pc.z + cam.cy - (double)z[1];
-    return du * du + dv * dv <= thr2;
+    double du = cam.fx * pc.x + (cam.cx - (double)z[0]) * pc.z, dv = cam.fy * pc.y + (cam.cy - (double)z[1]) * pc.z;
+    return du * du + dv * dv <= thr2 * (pc.z * pc.z);
 }
 
 void pnp_ransac(const Cam& cam, const Corr& c, int n_hyp, float reproj_px, float conf, uint64_t seed,
@@ -298,7 +300,7 @@ static int lm_optimize(const Cam& cam, const Corr& c, const std::vector<int32_t>
             for (int i = 0; i < 6; ++i) md = std::max(md, std::fabs(H[i * 7]));
             lambda = 1e-5 * md; ni = 2;
         }
-        double rho = 0; int qmax = 0;
+        double rho = 0; int qmax = 0; bool converged = false;
         do {
             double A[36], x[6];
             for (int i = 0; i < 36; ++i) A[i] = H[i];
@@ -315,10 +317,13 @@ static int lm_optimize(const Cam& cam, const Corr& c, const std::vector<int32_t>
                 double a = 1.0 - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
                 a = std::min(a, 2.0 / 3.0);
                 lambda *= std::max(1.0 / 3.0, a); ni = 2; cur = tmp; T = Tn;
+                double mx = 0;
+                for (int i = 0; i < 6; ++i) mx = std::max(mx, std::fabs(x[i]));
+                converged = mx < 1e-10;                     // accepted step below 1e-10: later iterations cannot move the pose
             } else { lambda *= ni; ni *= 2; }
             ++qmax;
         } while (rho < 0 && qmax < 10);
-        if (qmax == 10 || rho == 0) { ++it; break; }
+        if (qmax == 10 || rho == 0 || converged) { ++it; break; }
     }
     return it;
 }

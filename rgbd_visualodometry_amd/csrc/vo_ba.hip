@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "vo_internal.h"
+#include "vo_reduce.h"
 
 struct BaCam { double fx, fy, cx, cy; };
 
@@ -50,6 +51,7 @@ __device__ __forceinline__ void ba_err(const BaCam& cam, const double* T, const 
 // residual, Huber weight and both Jacobians of one edge (g2o_types.h:143-167)
 __device__ __forceinline__ void ba_edge(const BaCam& cam, const double* T, const double* p, const float* uv, int robust, double delta,
                                         double r[2], double& w, double& rho0, double Jp[2][6], double Jl[2][3]) {
+#pragma clang fp contract(fast)
     double pc[3];
     ba_err(cam, T, p, uv, r, pc);
     const double e2 = r[0] * r[0] + r[1] * r[1];
@@ -68,16 +70,17 @@ template <int NV>
 __device__ __forceinline__ void ba_block_reduce(double* v, double* s_part) {      // 256 threads; result valid in thread 0
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        double x = v[i];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-        v[i] = x;
-    }
+    for (int i = 0; i < NV; ++i) v[i] = vo_wave_sum_f64(v[i]);
     __syncthreads();
     if (lane == 0) for (int i = 0; i < NV; ++i) s_part[wave * NV + i] = v[i];
     __syncthreads();
     if (threadIdx.x == 0) for (int i = 0; i < NV; ++i) v[i] = s_part[i] + s_part[NV + i] + s_part[2 * NV + i] + s_part[3 * NV + i];
+}
+
+template <int NV>
+__device__ __forceinline__ void ba_wave_reduce(double* v) {      // 64 threads; result valid in every lane
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = vo_wave_sum_f64(v[i]);
 }
 
 // one lane per point: H_ll, b_l (no atomics), W_e of its free-pose edges, robust chi2
@@ -161,7 +164,7 @@ __global__ void k_ba_init_S(BaDev B, double lambda) {
         const int r = i / B.D, c = i % B.D;
         double v = 0;
         if (r / 6 == c / 6) v = B.Hpp[36 * (size_t)(r / 6) + 6 * (r % 6) + (c % 6)];
-        if (r == c) v += lambda;
+        if (r == c) { v += lambda; B.bs[r] = B.bp[r]; }
         B.S[i] = v;
     }
     if (i < B.n_points) {
@@ -181,23 +184,28 @@ __global__ void k_ba_init_S(BaDev B, double lambda) {
     }
 }
 
-// Schur complement, one workgroup per 6x6 block (j1 <= j2) of the reduced system:
+// Schur complement, one wavefront per 6x6 block (j1 <= j2) of the reduced system:
 //   S[j1][j2] -= sum over points seen by both poses of W_e1 (H_ll+lambda)^-1 W_e2^T       (no atomics)
+// Diagonal blocks also produce b_s[j] = b_p[j] - sum W_e (H_ll+lambda)^-1 b_l.
 __global__ __launch_bounds__(256) void k_ba_schur_blocks(BaDev B) {
-    __shared__ double s_part[4 * 36];
+    __shared__ double s_part[4 * 42];
+    __shared__ double s_tot[42];
     const BaBlock blk = B.blocks[blockIdx.x];
-    double v[36];
+    const bool diag = blk.j1 == blk.j2;
+    double v[42];
 #pragma unroll
-    for (int i = 0; i < 36; ++i) v[i] = 0;
+    for (int i = 0; i < 42; ++i) v[i] = 0;
     for (int q = blk.start + threadIdx.x; q < blk.start + blk.count; q += 256) {
         const int2 pr = B.pairs[q];
         if (!B.active[pr.x] || !B.active[pr.y]) continue;
-        const double* h = B.Hinv + 9 * (size_t)B.e_pt[pr.x];
+        const int k = B.e_pt[pr.x];
+        const double* h = B.Hinv + 9 * (size_t)k;
         const double* W1 = B.W + 18 * (size_t)pr.x;
         const double* W2 = B.W + 18 * (size_t)pr.y;
         double w2[18];
 #pragma unroll
         for (int i = 0; i < 18; ++i) w2[i] = W2[i];
+        const double b0 = B.bl[3 * (size_t)k], b1 = B.bl[3 * (size_t)k + 1], b2 = B.bl[3 * (size_t)k + 2];
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             const double y0 = W1[3 * r] * h[0] + W1[3 * r + 1] * h[3] + W1[3 * r + 2] * h[6];
@@ -205,36 +213,107 @@ __global__ __launch_bounds__(256) void k_ba_schur_blocks(BaDev B) {
             const double y2 = W1[3 * r] * h[2] + W1[3 * r + 1] * h[5] + W1[3 * r + 2] * h[8];
 #pragma unroll
             for (int c = 0; c < 6; ++c) v[6 * r + c] += y0 * w2[3 * c] + y1 * w2[3 * c + 1] + y2 * w2[3 * c + 2];
+            if (diag) v[36 + r] += y0 * b0 + y1 * b1 + y2 * b2;
         }
     }
-    ba_block_reduce<36>(v, s_part);
-    if (threadIdx.x == 0) {
-        for (int r = 0; r < 6; ++r)
-            for (int c = 0; c < 6; ++c) {
-                B.S[(size_t)(6 * blk.j1 + r) * B.D + 6 * blk.j2 + c] -= v[6 * r + c];
-                if (blk.j1 != blk.j2) B.S[(size_t)(6 * blk.j2 + c) * B.D + 6 * blk.j1 + r] -= v[6 * r + c];
-            }
+    ba_wave_reduce<42>(v);
+    if ((threadIdx.x & 63) == 0) for (int i = 0; i < 42; ++i) s_part[(threadIdx.x >> 6) * 42 + i] = v[i];
+    __syncthreads();
+    if (threadIdx.x < 42) s_tot[threadIdx.x] = s_part[threadIdx.x] + s_part[42 + threadIdx.x] + s_part[84 + threadIdx.x] + s_part[126 + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < 36) {
+        const int r = threadIdx.x / 6, c = threadIdx.x % 6;
+        const double val = s_tot[threadIdx.x];
+        B.S[(size_t)(6 * blk.j1 + r) * B.D + 6 * blk.j2 + c] -= val;
+        if (!diag) B.S[(size_t)(6 * blk.j2 + c) * B.D + 6 * blk.j1 + r] -= val;
+    } else if (diag && threadIdx.x < 42) {
+        B.bs[6 * blk.j1 + threadIdx.x - 36] -= s_tot[threadIdx.x];
     }
 }
 
-// b_s[j] = b_p[j] - sum over the pose's edges of W_e (H_ll+lambda)^-1 b_l
-__global__ __launch_bounds__(256) void k_ba_bs(BaDev B) {
-    __shared__ double s_part[4 * 6];
-    const int j = blockIdx.x;
-    double v[6] = {0, 0, 0, 0, 0, 0};
-    for (int q = B.ps_start[j] + threadIdx.x; q < B.ps_start[j + 1]; q += 256) {
-        const int e = B.ps_edges[q];
-        if (!B.active[e]) continue;
-        const int k = B.e_pt[e];
-        const double* h = B.Hinv + 9 * (size_t)k;
-        const double b0 = B.bl[3 * (size_t)k], b1 = B.bl[3 * (size_t)k + 1], b2 = B.bl[3 * (size_t)k + 2];
-        const double g0 = h[0] * b0 + h[1] * b1 + h[2] * b2, g1 = h[3] * b0 + h[4] * b1 + h[5] * b2, g2 = h[6] * b0 + h[7] * b1 + h[8] * b2;
-        const double* We = B.W + 18 * (size_t)e;
+// Dense Cholesky + solve of the reduced system, whole lower triangle resident in LDS (D <= 140),
+// blocked by pose (6-column panels): diagonal 6x6 factor, panel solve (one lane per row), rank-6
+// trailing update spread over 1024 lanes.  3 barriers per panel instead of 3 per column.
+__global__ __launch_bounds__(1024) void k_ba_chol_lds(BaDev B) {
+    extern __shared__ double s_L[];
+    const int D = B.D, ld = D | 1, tid = threadIdx.x, np = D / 6;
+    double* s_b = s_L + (size_t)ld * D;
+    __shared__ int s_ok;
+    if (tid == 0) s_ok = 1;
+    for (int i = tid; i < D * D; i += 1024) { const int r = i / D, c = i - r * D; if (c <= r) s_L[r * ld + c] = B.S[i]; }
+    for (int i = tid; i < D; i += 1024) s_b[i] = B.bs[i];
+    __syncthreads();
+    for (int p = 0; p < np; ++p) {
+        const int j0 = 6 * p;
+        if (tid == 0) {
+            for (int j = 0; j < 6 && s_ok; ++j) {
+                double d = s_L[(j0 + j) * ld + j0 + j];
+                for (int k = 0; k < j; ++k) d -= s_L[(j0 + j) * ld + j0 + k] * s_L[(j0 + j) * ld + j0 + k];
+                if (!(d > 0.0)) { s_ok = 0; break; }
+                d = sqrt(d);
+                s_L[(j0 + j) * ld + j0 + j] = d;
+                const double inv = 1.0 / d;
+                for (int i = j + 1; i < 6; ++i) {
+                    double sum = s_L[(j0 + i) * ld + j0 + j];
+                    for (int k = 0; k < j; ++k) sum -= s_L[(j0 + i) * ld + j0 + k] * s_L[(j0 + j) * ld + j0 + k];
+                    s_L[(j0 + i) * ld + j0 + j] = sum * inv;
+                }
+            }
+        }
+        __syncthreads();
+        if (!s_ok) break;
+        const int m = D - j0 - 6;                       // rows below the panel
+        for (int r = tid; r < m; r += 1024) {
+            double* row = s_L + (size_t)(j0 + 6 + r) * ld + j0;
+            double x[6];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) v[r] += We[3 * r] * g0 + We[3 * r + 1] * g1 + We[3 * r + 2] * g2;
+            for (int c = 0; c < 6; ++c) {
+                double sum = row[c];
+#pragma unroll
+                for (int k = 0; k < c; ++k) sum -= x[k] * s_L[(j0 + c) * ld + j0 + k];
+                x[c] = sum / s_L[(j0 + c) * ld + j0 + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) row[c] = x[c];
+        }
+        __syncthreads();
+        for (int t = tid; t < m * m; t += 1024) {
+            const int r = t / m, c = t - r * m;
+            if (c > r) continue;
+            const double* a = s_L + (size_t)(j0 + 6 + r) * ld + j0;
+            const double* b = s_L + (size_t)(j0 + 6 + c) * ld + j0;
+            s_L[(size_t)(j0 + 6 + r) * ld + j0 + 6 + c] -= a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+        }
+        __syncthreads();
     }
-    ba_block_reduce<6>(v, s_part);
-    if (threadIdx.x == 0) for (int r = 0; r < 6; ++r) B.bs[6 * j + r] = B.bp[6 * j + r] - v[r];
+    if (s_ok) {
+        for (int p = 0; p < np; ++p) {                  // L y = b
+            const int j0 = 6 * p;
+            if (tid == 0)
+                for (int j = 0; j < 6; ++j) { double sum = s_b[j0 + j]; for (int k = 0; k < j; ++k) sum -= s_L[(j0 + j) * ld + j0 + k] * s_b[j0 + k]; s_b[j0 + j] = sum / s_L[(j0 + j) * ld + j0 + j]; }
+            __syncthreads();
+            for (int r = j0 + 6 + tid; r < D; r += 1024) {
+                const double* a = s_L + (size_t)r * ld + j0;
+                s_b[r] -= a[0] * s_b[j0] + a[1] * s_b[j0 + 1] + a[2] * s_b[j0 + 2] + a[3] * s_b[j0 + 3] + a[4] * s_b[j0 + 4] + a[5] * s_b[j0 + 5];
+            }
+            __syncthreads();
+        }
+        for (int p = np - 1; p >= 0; --p) {             // L^T x = y
+            const int j0 = 6 * p;
+            if (tid == 0)
+                for (int j = 5; j >= 0; --j) { double sum = s_b[j0 + j]; for (int k = j + 1; k < 6; ++k) sum -= s_L[(j0 + k) * ld + j0 + j] * s_b[j0 + k]; s_b[j0 + j] = sum / s_L[(j0 + j) * ld + j0 + j]; }
+            __syncthreads();
+            for (int r = tid; r < j0; r += 1024) {
+                double sum = 0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) sum += s_L[(size_t)(j0 + k) * ld + r] * s_b[j0 + k];
+                s_b[r] -= sum;
+            }
+            __syncthreads();
+        }
+        for (int i = tid; i < D; i += 1024) B.bs[i] = s_b[i];
+    }
+    if (tid == 0) B.scal[3] = s_ok ? 1.0 : 0.0;
 }
 
 // dense Cholesky + solve of the reduced system in one 1024-thread workgroup (right-looking, trailing
@@ -283,7 +362,7 @@ __global__ __launch_bounds__(1024) void k_ba_chol(BaDev B) {
 
 __global__ void k_ba_backsub(BaDev B, double lambda) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    double sc = 0;
+    double sc = 0, mx = 0;
     if (k < B.n_points && B.scal[3] != 0.0) {
         double rhs[3] = {B.bl[3 * (size_t)k], B.bl[3 * (size_t)k + 1], B.bl[3 * (size_t)k + 2]};
         for (int p1 = B.pt_start[k]; p1 < B.pt_start[k + 1]; ++p1) {
@@ -298,11 +377,13 @@ __global__ void k_ba_backsub(BaDev B, double lambda) {
             B.dl[3 * (size_t)k + a] = d;
             B.pts_n[3 * (size_t)k + a] = B.pts[3 * (size_t)k + a] + d;
             sc += d * (lambda * d + B.bl[3 * (size_t)k + a]);
+            mx = fmax(mx, fabs(d));
         }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sc += __shfl_xor(sc, o, 64);
+    for (int o = 32; o > 0; o >>= 1) { sc += __shfl_xor(sc, o, 64); mx = fmax(mx, __shfl_xor(mx, o, 64)); }
     if ((threadIdx.x & 63) == 0 && sc != 0.0) atomicAdd(&B.scal[2], sc);
+    if ((threadIdx.x & 63) == 0 && mx != 0.0) atomicMax((unsigned long long*)&B.scal[7], (unsigned long long)__double_as_longlong(mx));
 }
 
 __global__ void k_ba_pose(BaDev B, double lambda) {
@@ -326,9 +407,10 @@ __global__ void k_ba_pose(BaDev B, double lambda) {
     Tn[9] = R[0] * T[9] + R[1] * T[10] + R[2] * T[11] + tx;
     Tn[10] = R[3] * T[9] + R[4] * T[10] + R[5] * T[11] + ty;
     Tn[11] = R[6] * T[9] + R[7] * T[10] + R[8] * T[11] + tz;
-    double sc = 0;
-    for (int a = 0; a < 6; ++a) sc += d[a] * (lambda * d[a] + B.bp[6 * j + a]);
+    double sc = 0, mx = 0;
+    for (int a = 0; a < 6; ++a) { sc += d[a] * (lambda * d[a] + B.bp[6 * j + a]); mx = fmax(mx, fabs(d[a])); }
     atomicAdd(&B.scal[2], sc);
+    atomicMax((unsigned long long*)&B.scal[7], (unsigned long long)__double_as_longlong(mx));
 }
 
 // chi2 of the current (trial = 0 -> scal[5]) or trial (-> scal[1]) state
@@ -361,6 +443,7 @@ __global__ void k_ba_cull(BaCam cam, BaDev B, int stage, double th) {
 
 int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     hipStream_t st = c->stream;
+    { static bool attr = false; if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)); attr = true; } }
     const int np = in->n_poses, nf = in->n_free, nx = in->n_points, ne = in->n_edges, D = 6 * nf;
     out->lm_iters = 0; out->chi2_initial = 0; out->chi2_final = 0;
     if (ne == 0 || nf == 0 || nx == 0) {
@@ -468,13 +551,15 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
             if ((rc = read_scal())) return rc;
             double cur = h_scal[0];
             if (it == 0) { double md; memcpy(&md, &h_scal[4], 8); lambda = 1e-5 * md; ni = 2; }
-            double rho = 0; int qmax = 0;
+            double rho = 0; int qmax = 0; bool converged = false;
             do {
                 HIP_TRY(hipMemsetAsync(B.scal + 1, 0, 24, st));        // trial chi, scale, ok
+                HIP_TRY(hipMemsetAsync(B.scal + 7, 0, 8, st));         // max |step|
                 hipLaunchKernelGGL(k_ba_init_S, dim3((std::max(D * D, nx) + 255) / 256), blk, 0, st, B, lambda);
                 if (nblk) { ProfScope ps(c, "k_ba_schur_blocks"); hipLaunchKernelGGL(k_ba_schur_blocks, dim3(nblk), blk, 0, st, B); }
-                hipLaunchKernelGGL(k_ba_bs, dim3(nf), blk, 0, st, B);
-                { ProfScope ps(c, "k_ba_chol"); hipLaunchKernelGGL(k_ba_chol, dim3(1), dim3(1024), 0, st, B); }
+                { ProfScope ps(c, "k_ba_chol");
+                  if (D <= 138) hipLaunchKernelGGL(k_ba_chol_lds, dim3(1), dim3(1024), sizeof(double) * ((size_t)(D | 1) * D + D), st, B);
+                  else hipLaunchKernelGGL(k_ba_chol, dim3(1), dim3(1024), 0, st, B); }
                 hipLaunchKernelGGL(k_ba_backsub, gP, blk, 0, st, B, lambda);
                 hipLaunchKernelGGL(k_ba_pose, gJ, blk, 0, st, B, lambda);
                 hipLaunchKernelGGL(k_ba_chi, gE, blk, 0, st, cam, B, 1, robust, in->huber_delta);
@@ -488,11 +573,13 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
                     a = std::min(a, 2.0 / 3.0);
                     lambda *= std::max(1.0 / 3.0, a); ni = 2; cur = tmp;
                     std::swap(B.poses, B.poses_n); std::swap(B.pts, B.pts_n);
+                    double mx; memcpy(&mx, &h_scal[7], 8);
+                    converged = mx < 1e-10;
                 } else { lambda *= ni; ni *= 2; }
                 ++qmax;
             } while (rho < 0 && qmax < 10);
             ++iters;
-            if (qmax == 10 || rho == 0) break;
+            if (qmax == 10 || rho == 0 || converged) break;
         }
         return VO_OK;
     };

@@ -5,11 +5,13 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <new>
 
 #include "vo_internal.h"
 
 int vo_orb_upload_constants();
+int vo_track_set_attrs();
 
 static inline short sat_short(long v) { return (short)std::min(32767L, std::max(-32768L, v)); }
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
@@ -177,7 +179,7 @@ void vo_ctx_destroy(vo_ctx* c) {
     for (auto p : c->own_bgr) if (p) (void)hipFree(p);
     for (auto p : c->own_depth) if (p) (void)hipFree(p);
     void* ptrs[] = {c->d_slots, c->d_pyr, c->d_tab, c->d_tabs, c->d_cand, c->d_cand_cnt, c->d_sel, c->d_sel_key, c->d_sel_cnt, c->d_kps,
-                    c->d_desc, c->d_nkp, c->d_status, c->d_map_pos, c->d_map_nrm, c->d_map_desc, c->d_map_flags, c->d_active, c->d_best,
+                    c->d_desc, c->d_nkp, c->d_status, c->d_map_pos, c->d_map_nrm, c->d_map_desc, c->d_map_flags, c->d_active, c->d_best, c->d_mcand,
                     c->d_matches, c->d_corr_xyz, c->d_corr_uv, c->d_hyp_pose, c->d_hyp_cnt, c->d_inliers, c->d_lm_mask, c->d_track, c->d_ba};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->h_track) (void)hipHostFree(c->h_track);
@@ -206,7 +208,7 @@ int vo_ctx_create(const vo_params* p, int device, vo_ctx** out) {
     c->d_slots = nullptr; c->d_pyr = nullptr; c->d_tab = nullptr; c->d_tabs = nullptr; c->d_cand = nullptr; c->d_cand_cnt = nullptr;
     c->d_sel = nullptr; c->d_sel_key = nullptr; c->d_sel_cnt = nullptr; c->d_kps = nullptr; c->d_desc = nullptr; c->d_nkp = nullptr; c->d_status = nullptr;
     c->d_map_pos = nullptr; c->d_map_nrm = nullptr; c->d_map_desc = nullptr; c->d_map_flags = nullptr; c->d_active = nullptr; c->n_active = 0; c->active_cap = 0;
-    c->d_best = nullptr; c->d_matches = nullptr; c->d_corr_xyz = nullptr; c->d_corr_uv = nullptr; c->corr_cap = 0; c->d_hyp_pose = nullptr; c->d_hyp_cnt = nullptr;
+    c->d_best = nullptr; c->d_mcand = nullptr; c->d_matches = nullptr; c->d_corr_xyz = nullptr; c->d_corr_uv = nullptr; c->corr_cap = 0; c->d_hyp_pose = nullptr; c->d_hyp_cnt = nullptr;
     c->d_inliers = nullptr; c->d_lm_mask = nullptr; c->d_track = nullptr; c->h_track = nullptr; c->h_matches = nullptr; c->h_matches_cap = 0;
     c->h_stage = nullptr; c->h_stage_bytes = 0; c->d_ba = nullptr; c->d_ba_bytes = 0;
     c->h_slots_pinned = nullptr; c->slots_ev = nullptr; c->slots_dirty = false; c->slots_pending = false;
@@ -215,6 +217,8 @@ int vo_ctx_create(const vo_params* p, int device, vo_ctx** out) {
     if (rc) { delete c; return rc; }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return VO_E_DEVICE; }
     rc = vo_orb_upload_constants();
+    if (rc) { vo_ctx_destroy(c); return rc; }
+    rc = vo_track_set_attrs();
     if (rc) { vo_ctx_destroy(c); return rc; }
     const DevPlan& P = c->plan;
     const int F = p->max_frames;
@@ -233,7 +237,7 @@ int vo_ctx_create(const vo_params* p, int device, vo_ctx** out) {
     const size_t M = (size_t)p->map_capacity;
     ALLOC(c->d_map_pos, 3 * M); ALLOC(c->d_map_nrm, 3 * M); ALLOC(c->d_map_desc, 8 * M); ALLOC(c->d_map_flags, M);
     c->active_cap = p->map_capacity; c->corr_cap = p->map_capacity;
-    ALLOC(c->d_active, M); ALLOC(c->d_best, M); ALLOC(c->d_matches, M); ALLOC(c->d_corr_xyz, 3 * M); ALLOC(c->d_corr_uv, 2 * M);
+    ALLOC(c->d_active, M); ALLOC(c->d_best, M); ALLOC(c->d_mcand, M); ALLOC(c->d_matches, M); ALLOC(c->d_corr_xyz, 3 * M); ALLOC(c->d_corr_uv, 2 * M);
     ALLOC(c->d_hyp_pose, (size_t)12 * p->max_hypotheses); ALLOC(c->d_hyp_cnt, (size_t)p->max_hypotheses);
     ALLOC(c->d_inliers, M); ALLOC(c->d_lm_mask, M); ALLOC(c->d_track, 1);
     if (hipHostMalloc((void**)&c->h_track, sizeof(TrackDev), hipHostMallocDefault) != hipSuccess) { vo_ctx_destroy(c); return VO_E_NOMEM; }
@@ -498,30 +502,41 @@ int vo_pose_refine_lm(vo_ctx* c, double T[12], double delta, double cut, int it_
     return VO_OK;
 }
 
+static double g_tt[6]; static long g_tn;
+static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 int vo_track_frame(vo_ctx* c, int slot, const double T0[12], const vo_track_params* tp, vo_track_result* res,
                    vo_match* matches, int cap) {
+    const bool trace = getenv("VO_TRACE") != nullptr;
+    double t0 = trace ? now_us() : 0;
     if (!c || !T0 || !tp || !res || slot < 0 || slot >= c->p.max_frames || tp->passes < 1 || cap < 0 ||
         tp->n_hyp < 1 || tp->n_hyp > c->p.max_hypotheses) return VO_E_INVALID;
     if (!c->slot_orb[slot]) return VO_E_STATE;
     HIP_TRY(hipSetDevice(c->device));
     int rc = upload_pose(c, T0, true);
     if (rc) return rc;
+    double t1 = trace ? now_us() : 0;
     for (int pass = 0; pass < tp->passes; ++pass) {           // coarse, fine (frontend.cpp:100-108)
         if ((rc = vo_track_match_launch(c, slot, tp->match_ratio, tp->match_floor))) return rc;
         if ((rc = vo_track_ransac_launch(c, tp->n_hyp, tp->reproj_px, tp->confidence, tp->seed + (uint64_t)pass))) return rc;
         if ((rc = vo_track_lm_launch(c, tp->huber_delta, tp->chi2_cut, tp->it_robust, tp->it_plain))) return rc;
     }
     if ((rc = vo_track_flags_launch(c))) return rc;
+    double t2 = trace ? now_us() : 0;
     const int take = std::min(cap, c->n_active);
     if ((rc = ensure_match_stage(c, take))) return rc;
     if (take > 0 && matches) HIP_TRY(hipMemcpyAsync(c->h_matches, c->d_matches, sizeof(vo_match) * take, hipMemcpyDeviceToHost, c->stream));
     if ((rc = download_track(c))) return rc;
+    if (trace) { double t3 = now_us(); g_tt[0] += t1 - t0; g_tt[1] += t2 - t1; g_tt[2] += t3 - t2; if (++g_tn % 100 == 0) fprintf(stderr, "[vo_trace] track_frame avg us: upload %.1f launch %.1f wait+d2h %.1f\n", g_tt[0] / g_tn, g_tt[1] / g_tn, g_tt[2] / g_tn); }
     const TrackDev& t = *c->h_track;
     memset(res, 0, sizeof(*res));
     memcpy(res->T_cw, t.T, sizeof(double) * 12);
     res->n_candidates = t.n_cand; res->n_matches = t.n_match; res->n_ransac_inliers = t.n_inl; res->n_lm_inliers = t.n_lm_inl;
     res->min_distance = t.min_dist; res->ransac_iters = t.iters_used; res->best_hypothesis = t.best_hyp; res->lm_iters = t.lm_iters;
     res->status = t.status;
+#ifdef VO_LM_STAMPS
+    for (int i = 0; i < 6; ++i) res->reserved[i] = (int32_t)(t.dbg[i] >> (i < 2 || i == 4 ? 4 : 0));
+#endif
     if (t.n_match > cap && matches) res->status = VO_E_OVERFLOW;
     if (matches) memcpy(matches, c->h_matches, sizeof(vo_match) * std::min(take, t.n_match));
     return VO_OK;

@@ -42,6 +42,7 @@ struct TrackDev {
     int lm_iters, n_lm_inl, status, pad1;
     double T[12];               // current pose estimate (in/out through the chain)
     double T_ransac[12];
+    long long dbg[8];           // diagnostic stamps (only written by -DVO_LM_STAMPS builds)
 };
 
 struct vo_ctx {
@@ -66,6 +67,7 @@ struct vo_ctx {
     int32_t* d_active; int n_active; int active_cap;
     // tracking chain
     unsigned long long* d_best;                     // per active query: (dist<<32)|kp
+    int32_t* d_mcand;                               // visible candidates (indices into the active list), unordered
     vo_match* d_matches; float* d_corr_xyz; float* d_corr_uv; int corr_cap;
     double* d_hyp_pose; int* d_hyp_cnt;             // [max_hyp][12], [max_hyp]
     int32_t* d_inliers; uint8_t* d_lm_mask;

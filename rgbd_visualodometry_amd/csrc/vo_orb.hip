@@ -382,6 +382,7 @@ int vo_orb_upload_constants() {
     static bool done = false;
     if (done) return VO_OK;
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), VO_BRIEF_PATTERN, sizeof(c_pattern)));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
     done = true;
     return VO_OK;
 }

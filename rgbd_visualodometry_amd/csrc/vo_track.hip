@@ -23,6 +23,7 @@
 #include <cstring>
 
 #include "vo_internal.h"
+#include "vo_reduce.h"
 
 struct CamD { double fx, fy, cx, cy; int W, H; };
 
@@ -45,23 +46,17 @@ __device__ __forceinline__ double comp(D3 a, int i) { return i == 0 ? a.x : (i =
 // ------------------------------------------------------------------------------------------
 // K10 + K11
 // ------------------------------------------------------------------------------------------
-#define MQ 256
-#define MT 256
-__global__ __launch_bounds__(256) void k_match(CamD cam, const TrackDev* __restrict__ tr, const double* __restrict__ map_pos,
-                                               const double* __restrict__ map_nrm, const uint32_t* __restrict__ map_desc,
-                                               const uint8_t* __restrict__ map_flags, const int32_t* __restrict__ active, int n_active,
-                                               const uint32_t* __restrict__ fdesc, const int* __restrict__ nkp_p,
-                                               unsigned long long* __restrict__ best) {
-    __shared__ uint4 s_train[MT * 2];
-    const int nkp = *nkp_p;
-    const int t0 = blockIdx.y * MT;
-    if (t0 >= nkp) return;
-    const int nt = min(MT, nkp - t0);
-    const uint4* src = (const uint4*)(fdesc + (size_t)t0 * 8);
-    for (int i = threadIdx.x; i < nt * 2; i += 256) s_train[i] = src[i];
-    __syncthreads();
-    const int q = blockIdx.x * MQ + threadIdx.x;
+#define MQ 64
+#define MT 64
+// visibility filter: every active map point gets best[q] = ~0; visible ones are appended to the
+// (unordered) candidate list -- order is restored later because results are indexed by q.
+__global__ __launch_bounds__(256) void k_frustum(CamD cam, TrackDev* __restrict__ tr, const double* __restrict__ map_pos,
+                                                 const double* __restrict__ map_nrm, const uint8_t* __restrict__ map_flags,
+                                                 const int32_t* __restrict__ active, int n_active, unsigned long long* __restrict__ best,
+                                                 int32_t* __restrict__ cand) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= n_active) return;
+    best[q] = ~0ull;
     const int mi = active[q];
     if (map_flags[mi] & VO_MAP_FLAG_OUTLIER) return;
     double T[12];
@@ -77,7 +72,27 @@ __global__ __launch_bounds__(256) void k_match(CamD cam, const TrackDev* __restr
     const D3 dir = nrm3(sub(pw, C));
     const double dd = dir.x * map_nrm[3 * (size_t)mi] + dir.y * map_nrm[3 * (size_t)mi + 1] + dir.z * map_nrm[3 * (size_t)mi + 2];
     if (dd < 0.8660254037844387) return;
-    const uint4* qd = (const uint4*)(map_desc + (size_t)mi * 8);
+    cand[atomicAdd(&tr->n_cand, 1)] = q;
+}
+
+// 64 candidates x 64 frame descriptors per wavefront; the train tile sits in LDS and every lane reads
+// the same descriptor (broadcast), 8 x (v_xor, v_bcnt) per pair; cross-tile argmin by 64-bit atomicMin.
+__global__ __launch_bounds__(64) void k_match(const TrackDev* __restrict__ tr, const uint32_t* __restrict__ map_desc,
+                                              const int32_t* __restrict__ active, const int32_t* __restrict__ cand,
+                                              const uint32_t* __restrict__ fdesc, const int* __restrict__ nkp_p,
+                                              unsigned long long* __restrict__ best) {
+    __shared__ uint4 s_train[MT * 2];
+    const int nkp = *nkp_p, ncand = tr->n_cand;
+    const int t0 = blockIdx.y * MT;
+    if (t0 >= nkp || (int)blockIdx.x * MQ >= ncand) return;
+    const int nt = min(MT, nkp - t0);
+    const uint4* src = (const uint4*)(fdesc + (size_t)t0 * 8);
+    for (int i = threadIdx.x; i < nt * 2; i += 64) s_train[i] = src[i];
+    __syncthreads();
+    const int ci = blockIdx.x * MQ + threadIdx.x;
+    if (ci >= ncand) return;
+    const int q = cand[ci];
+    const uint4* qd = (const uint4*)(map_desc + (size_t)active[q] * 8);
     const uint4 qa = qd[0], qb = qd[1];
     int bd = 1 << 30, bi = 0;
     for (int t = 0; t < nt; ++t) {
@@ -103,43 +118,70 @@ __device__ __forceinline__ int block_excl_scan_flag(bool flag, int* s_w, int& to
     return off + before;
 }
 
+// Distance gate + ORDER-PRESERVING compaction.  The (dist, kp) results of all active points are first
+// staged in LDS with coalesced loads (packed to 32 bit); then every thread owns one contiguous
+// segment of the active list, so the output order is the list order with a single block scan.
+#define GATE_LDS_MAX 36864          // entries (144 KiB)
 __global__ __launch_bounds__(1024) void k_match_gate(TrackDev* __restrict__ tr, const unsigned long long* __restrict__ best,
                                                      const int32_t* __restrict__ active, int n_active, const double* __restrict__ map_pos,
                                                      const vo_keypoint* __restrict__ kps, float ratio, float floor_dist,
-                                                     vo_match* __restrict__ matches, float* __restrict__ cxyz, float* __restrict__ cuv, int cap) {
+                                                     vo_match* __restrict__ matches, float* __restrict__ cxyz, float* __restrict__ cuv, int cap,
+                                                     int use_lds) {
+    extern __shared__ uint32_t s_pk[];
     __shared__ int s_w[16];
-    __shared__ int s_min, s_cnt;
-    if (threadIdx.x == 0) { s_min = 1 << 30; s_cnt = 0; }
-    __syncthreads();
-    int mn = 1 << 30, cnt = 0;
-    for (int q = threadIdx.x; q < n_active; q += 1024) {
-        const unsigned long long b = best[q];
-        if (b != ~0ull) { mn = min(mn, (int)(b >> 32)); ++cnt; }
-    }
-    atomicMin(&s_min, mn); atomicAdd(&s_cnt, cnt);
-    __syncthreads();
-    const int gmin = s_min, ncand = s_cnt;
-    const float max_dis = fmaxf((float)gmin * ratio, floor_dist);
-    int outn = 0;
-    for (int base = 0; base < n_active; base += 1024) {
-        const int q = base + threadIdx.x;
-        unsigned long long b = ~0ull;
-        if (q < n_active) b = best[q];
-        const bool keep = (b != ~0ull) && ((float)(int)(b >> 32) <= max_dis);
-        int tot;
-        const int pos = outn + block_excl_scan_flag(keep, s_w, tot);
-        if (keep && pos < cap) {
-            const int mi = active[q], kp = (int)(b & 0xFFFFFFFFu);
-            vo_match m; m.map_index = mi; m.kp_index = kp; m.distance = (int)(b >> 32); m.flags = 0;
-            matches[pos] = m;
-            cxyz[3 * pos] = (float)map_pos[3 * (size_t)mi]; cxyz[3 * pos + 1] = (float)map_pos[3 * (size_t)mi + 1]; cxyz[3 * pos + 2] = (float)map_pos[3 * (size_t)mi + 2];
-            cuv[2 * pos] = kps[kp].x; cuv[2 * pos + 1] = kps[kp].y;
+    __shared__ int s_min;
+    if (threadIdx.x == 0) s_min = 1 << 30;
+    int mn = 1 << 30;
+    if (use_lds) {
+        for (int q = threadIdx.x; q < n_active; q += 1024) {
+            const unsigned long long b = best[q];
+            uint32_t pk = 0xFFFFFFFFu;
+            if (b != ~0ull) { const int d = (int)(b >> 32); mn = min(mn, d); pk = ((uint32_t)d << 22) | (uint32_t)(b & 0x3FFFFFu); }
+            s_pk[q] = pk;
         }
-        outn += tot;
+    } else {
+        for (int q = threadIdx.x; q < n_active; q += 1024) { const unsigned long long b = best[q]; if (b != ~0ull) mn = min(mn, (int)(b >> 32)); }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mn = min(mn, __shfl_xor(mn, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMin(&s_min, mn);
+    __syncthreads();
+    const int gmin = s_min;
+    const float max_dis = fmaxf((float)gmin * ratio, floor_dist);
+    const int seg = (n_active + 1023) / 1024;
+    const int q0 = min(n_active, (int)threadIdx.x * seg), q1 = min(n_active, q0 + seg);
+    auto fetch = [&](int q, int& d, int& kp) -> bool {
+        if (use_lds) { const uint32_t pk = s_pk[q]; if (pk == 0xFFFFFFFFu) return false; d = (int)(pk >> 22); kp = (int)(pk & 0x3FFFFFu); return true; }
+        const unsigned long long b = best[q]; if (b == ~0ull) return false; d = (int)(b >> 32); kp = (int)(b & 0xFFFFFFFFu); return true;
+    };
+    int keep = 0;
+    for (int q = q0; q < q1; ++q) { int d, kp; if (fetch(q, d, kp) && (float)d <= max_dis) ++keep; }
+    int incl = keep;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int off = 0, total = 0;
+    for (int i = 0; i < 16; ++i) { const int c = s_w[i]; if (i < wave) off += c; total += c; }
+    int pos = off + incl - keep;
+    for (int q = q0; q < q1; ++q) {
+        int d, kp;
+        if (fetch(q, d, kp) && (float)d <= max_dis) {
+            if (pos < cap) {
+                const int mi = active[q];
+                vo_match m; m.map_index = mi; m.kp_index = kp; m.distance = d; m.flags = 0;
+                matches[pos] = m;
+                cxyz[3 * pos] = (float)map_pos[3 * (size_t)mi]; cxyz[3 * pos + 1] = (float)map_pos[3 * (size_t)mi + 1]; cxyz[3 * pos + 2] = (float)map_pos[3 * (size_t)mi + 2];
+                cuv[2 * pos] = kps[kp].x; cuv[2 * pos + 1] = kps[kp].y;
+            }
+            ++pos;
+        }
     }
     if (threadIdx.x == 0) {
-        tr->n_cand = ncand; tr->n_match = min(outn, cap); tr->min_dist = ncand ? gmin : -1;
-        if (outn > cap) tr->status = VO_E_OVERFLOW;
+        tr->n_match = min(total, cap); tr->min_dist = tr->n_cand ? gmin : -1;
+        if (total > cap) tr->status = VO_E_OVERFLOW;
     }
 }
 
@@ -275,8 +317,8 @@ __device__ void sample4_dev(uint64_t seed, int hyp, int n, int idx[4]) {
 __device__ __forceinline__ bool reproj_ok_dev(const CamD& cam, const double* T, const float* X, const float* z, double thr2) {
     const D3 pc = xform(T, mk((double)X[0], (double)X[1], (double)X[2]));
     if (!(pc.z > 0)) return false;
-    const double du = cam.fx * pc.x / pc.z + cam.cx - (double)z[0], dv = cam.fy * pc.y / pc.z + cam.cy - (double)z[1];
-    return du * du + dv * dv <= thr2;
+    const double du = cam.fx * pc.x + (cam.cx - (double)z[0]) * pc.z, dv = cam.fy * pc.y + (cam.cy - (double)z[1]) * pc.z;
+    return du * du + dv * dv <= thr2 * (pc.z * pc.z);
 }
 
 __global__ __launch_bounds__(64) void k_ransac_hyp(CamD cam, const TrackDev* __restrict__ tr, const float* __restrict__ cxyz,
@@ -313,18 +355,22 @@ __global__ __launch_bounds__(64) void k_ransac_hyp(CamD cam, const TrackDev* __r
 __global__ __launch_bounds__(256) void k_ransac_score(CamD cam, const TrackDev* __restrict__ tr, const float* __restrict__ cxyz,
                                                       const float* __restrict__ cuv, int n_hyp, double thr2, const double* __restrict__ hyp_pose,
                                                       int* __restrict__ hyp_cnt) {
-    const int h = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (h >= n_hyp) return;
+    __shared__ int s_cnt;
+    const int h = blockIdx.x;
     if (hyp_cnt[h] < 0) return;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
     const int n = tr->n_match;
     double T[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = hyp_pose[(size_t)12 * h + i];
     int cnt = 0;
-    for (int k = lane; k < n; k += 64) cnt += reproj_ok_dev(cam, T, &cxyz[3 * k], &cuv[2 * k], thr2) ? 1 : 0;
+    for (int k = threadIdx.x; k < n; k += 256) cnt += reproj_ok_dev(cam, T, &cxyz[3 * k], &cuv[2 * k], thr2) ? 1 : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-    if (lane == 0) hyp_cnt[h] = cnt;
+    if ((threadIdx.x & 63) == 0) atomicAdd(&s_cnt, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0) hyp_cnt[h] = s_cnt;
 }
 
 __device__ __forceinline__ int ransac_update_iters_dev(double conf, int n_pts, int n_inl, int max_iters) {
@@ -377,14 +423,22 @@ __global__ __launch_bounds__(1024) void k_ransac_select(CamD cam, TrackDev* __re
 // ------------------------------------------------------------------------------------------
 // K14 pose-only LM in one workgroup
 // ------------------------------------------------------------------------------------------
+#ifdef VO_LM_STAMPS
+__device__ long long g_dbg[8];
+#endif
 #define LM_T 256
+#define LM_W (LM_T / 64)
 #define LM_NV 28            // 21 (upper H) + 6 (b) + 1 (chi)
+#define LM_LDS_MAX 6144     // inlier correspondences staged in LDS (20 B each)
 
 __device__ __forceinline__ void so3_exp_dev(const double w[3], double R[9]) {
+#pragma clang fp contract(fast)
     const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = sqrt(th2);
     double A, B;
-    if (th < 1e-8) { A = 1.0 - th2 / 6.0; B = 0.5 - th2 / 24.0; }
-    else { A = sin(th) / th; B = (1.0 - cos(th)) / th2; }
+    if (th2 < 0.0625) {     // |theta| < 0.25: Taylor to theta^14 (error < 1e-19), avoids the sin/cos call chains
+        A = 1.0 - th2 / 6.0 * (1.0 - th2 / 20.0 * (1.0 - th2 / 42.0 * (1.0 - th2 / 72.0 * (1.0 - th2 / 110.0 * (1.0 - th2 / 156.0 * (1.0 - th2 / 210.0))))));
+        B = 0.5 * (1.0 - th2 / 12.0 * (1.0 - th2 / 30.0 * (1.0 - th2 / 56.0 * (1.0 - th2 / 90.0 * (1.0 - th2 / 132.0 * (1.0 - th2 / 182.0 * (1.0 - th2 / 240.0)))))));
+    } else { A = sin(th) / th; B = (1.0 - cos(th)) / th2; }
     const double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
     double W2[9];
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += W[3 * i + k] * W[3 * k + j]; W2[3 * i + j] = s; }
@@ -393,11 +447,14 @@ __device__ __forceinline__ void so3_exp_dev(const double w[3], double R[9]) {
 
 // Tn = exp(d) * T   (tangent = [translation, rotation], g2o_types.h:56-60)
 __device__ void se3_exp_mul_dev(const double d[6], const double* T, double* Tn) {
+#pragma clang fp contract(fast)
     const double w[3] = {d[3], d[4], d[5]};
     const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = sqrt(th2);
     double B, C;
-    if (th < 1e-8) { B = 0.5 - th2 / 24.0; C = 1.0 / 6.0 - th2 / 120.0; }
-    else { B = (1.0 - cos(th)) / th2; C = (th - sin(th)) / (th2 * th); }
+    if (th2 < 0.0625) {
+        B = 0.5 * (1.0 - th2 / 12.0 * (1.0 - th2 / 30.0 * (1.0 - th2 / 56.0 * (1.0 - th2 / 90.0 * (1.0 - th2 / 132.0 * (1.0 - th2 / 182.0 * (1.0 - th2 / 240.0)))))));
+        C = 1.0 / 6.0 * (1.0 - th2 / 20.0 * (1.0 - th2 / 42.0 * (1.0 - th2 / 72.0 * (1.0 - th2 / 110.0 * (1.0 - th2 / 156.0 * (1.0 - th2 / 210.0 * (1.0 - th2 / 272.0)))))));
+    } else { B = (1.0 - cos(th)) / th2; C = (th - sin(th)) / (th2 * th); }
     const double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
     double W2[9], V[9], R[9];
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += W[3 * i + k] * W[3 * k + j]; W2[3 * i + j] = s; }
@@ -410,114 +467,126 @@ __device__ void se3_exp_mul_dev(const double d[6], const double* T, double* Tn) 
     Tn[11] = R[6] * T[9] + R[7] * T[10] + R[8] * T[11] + tz;
 }
 
+// 6x6 Cholesky solve; one reciprocal per pivot instead of a division per element
 __device__ __forceinline__ bool chol6_dev(double* A, double* b) {
+#pragma clang fp contract(fast)
+    double inv[6];
+#pragma unroll
     for (int j = 0; j < 6; ++j) {
         double d = A[j * 6 + j];
+#pragma unroll
         for (int k = 0; k < j; ++k) d -= A[j * 6 + k] * A[j * 6 + k];
         if (!(d > 0.0)) return false;
-        d = sqrt(d);
-        A[j * 6 + j] = d;
-        for (int i = j + 1; i < 6; ++i) { double s = A[i * 6 + j]; for (int k = 0; k < j; ++k) s -= A[i * 6 + k] * A[j * 6 + k]; A[i * 6 + j] = s / d; }
+        inv[j] = 1.0 / sqrt(d);
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) { double s = A[i * 6 + j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= A[i * 6 + k] * A[j * 6 + k];
+            A[i * 6 + j] = s * inv[j]; }
     }
-    for (int i = 0; i < 6; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= A[i * 6 + k] * b[k]; b[i] = s / A[i * 6 + i]; }
-    for (int i = 5; i >= 0; --i) { double s = b[i]; for (int k = i + 1; k < 6; ++k) s -= A[k * 6 + i] * b[k]; b[i] = s / A[i * 6 + i]; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { double s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= A[i * 6 + k] * b[k];
+        b[i] = s * inv[i]; }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) { double s = b[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) s -= A[k * 6 + i] * b[k];
+        b[i] = s * inv[i]; }
     return true;
 }
 
-template <int NV>
-__device__ __forceinline__ void block_reduce_dev(double* v, double* s_part, double* s_out) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// One pass over the active edges at pose T: robust chi2, H (upper triangle) and b, reduced over the
+// whole 1024-thread workgroup and broadcast to every thread (v[0..20] H, v[21..26] b, v[27] chi).
+__device__ void lm_pass_dev(const CamD& cam, const float* cxyz, const float* cuv, const int32_t* edges,
+                            const uint8_t* mask, int n, int round, const double* T, double delta, double* v,
+                            double* s_part, double* s_out) {
+#pragma clang fp contract(fast)
+    const bool robust = round == 0;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        double x = v[i];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-        v[i] = x;
-    }
-    if (lane == 0) for (int i = 0; i < NV; ++i) s_part[wave * NV + i] = v[i];
-    __syncthreads();
-    if (threadIdx.x < NV) {
-        double s = 0;
-        for (int w = 0; w < LM_T / 64; ++w) s += s_part[w * NV + threadIdx.x];
-        s_out[threadIdx.x] = s;
-    }
-    __syncthreads();
-    for (int i = 0; i < NV; ++i) v[i] = s_out[i];
-    __syncthreads();
-}
-
-__device__ __forceinline__ void edge_err_dev(const CamD& cam, const double* T, const float* X, const float* z, double e[2], D3& pc) {
-    pc = xform(T, mk((double)X[0], (double)X[1], (double)X[2]));
-    e[0] = (double)z[0] - (cam.fx * pc.x / pc.z + cam.cx);
-    e[1] = (double)z[1] - (cam.fy * pc.y / pc.z + cam.cy);
-}
-
-__device__ double lm_chi_dev(const CamD& cam, const float* cxyz, const float* cuv, const int32_t* edges, const uint8_t* mask, int n,
-                             int round, const double* T, bool robust, double delta, double* s_part, double* s_out) {
-    double v[1] = {0.0};
+    for (int i = 0; i < LM_NV; ++i) v[i] = 0;
     for (int i = threadIdx.x; i < n; i += LM_T) {
         if (round == 1 && !(mask[i] & 2)) continue;
-        const int k = edges[i];
-        double e[2]; D3 pc;
-        edge_err_dev(cam, T, &cxyz[3 * k], &cuv[2 * k], e, pc);
-        const double e2 = e[0] * e[0] + e[1] * e[1];
-        if (robust && e2 > delta * delta) v[0] += 2.0 * sqrt(e2) * delta - delta * delta; else v[0] += e2;
+        const int k = edges ? edges[i] : i;            // edges == nullptr: correspondences already gathered (LDS)
+        const D3 pc = xform(T, mk((double)cxyz[3 * k], (double)cxyz[3 * k + 1], (double)cxyz[3 * k + 2]));
+        const double Zi = 1.0 / (pc.z + 1e-18), Zi2 = Zi * Zi, X = pc.x, Y = pc.y, fx = cam.fx, fy = cam.fy;
+        const double e0 = (double)cuv[2 * k] - (fx * X * Zi + cam.cx), e1 = (double)cuv[2 * k + 1] - (fy * Y * Zi + cam.cy);   // g2o_types.h:83
+        const double e2 = e0 * e0 + e1 * e1;
+        double r1 = 1.0;
+        if (robust && e2 > delta * delta) { const double se = sqrt(e2); v[27] += 2.0 * se * delta - delta * delta; r1 = delta / se; } else v[27] += e2;
+        const double J0[6] = {-fx * Zi, 0, fx * X * Zi2, fx * X * Y * Zi2, -fx - fx * X * X * Zi2, fx * Y * Zi};                 // g2o_types.h:97-99
+        const double J1[6] = {0, -fy * Zi, fy * Y * Zi2, fy + fy * Y * Y * Zi2, -fy * X * Y * Zi2, -fy * X * Zi};
+        int c = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            v[21 + a] -= r1 * (J0[a] * e0 + J1[a] * e1);
+#pragma unroll
+            for (int b = a; b < 6; ++b) v[c++] += r1 * (J0[a] * J0[b] + J1[a] * J1[b]);
+        }
     }
-    block_reduce_dev<1>(v, s_part, s_out);
-    return v[0];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < LM_NV; ++i) v[i] = vo_wave_sum_f64(v[i]);
+    __syncthreads();                                   // previous readers of s_out are done
+    if (lane == 0) for (int i = 0; i < LM_NV; ++i) s_part[wave * LM_NV + i] = v[i];
+    __syncthreads();
+    if (threadIdx.x < LM_NV) {
+        double sum = 0;
+#pragma unroll
+        for (int w = 0; w < LM_W; ++w) sum += s_part[w * LM_NV + threadIdx.x];
+        s_out[threadIdx.x] = sum;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < LM_NV; ++i) v[i] = s_out[i];
 }
 
-// round 0: robust on all edges; round 1: plain on edges with mask bit1
+// g2o Levenberg-Marquardt (lambda/rho policy of OptimizationAlgorithmLevenberg).  The trial pass also
+// linearises at the trial pose, so an accepted step needs no second pass (same numbers g2o recomputes).
 __device__ int lm_optimize_dev(const CamD& cam, const float* cxyz, const float* cuv, const int32_t* edges, const uint8_t* mask, int n,
                                int round, double* T, double delta, int max_it, double* s_part, double* s_out) {
-    const bool robust = round == 0;
-    double lambda = 0, ni = 2;
+    double cur_v[LM_NV], tr_v[LM_NV];
+#ifdef VO_LM_STAMPS
+    long long t_pass = 0, t_serial = 0, n_pass = 1, t0 = clock64();
+#endif
+    lm_pass_dev(cam, cxyz, cuv, edges, mask, n, round, T, delta, cur_v, s_part, s_out);
+#ifdef VO_LM_STAMPS
+    t_pass += clock64() - t0;
+#endif
+    double lambda, ni = 2;
+    {
+        const int dg[6] = {0, 6, 11, 15, 18, 20};
+        double md = 0;
+        for (int i = 0; i < 6; ++i) md = fmax(md, fabs(cur_v[dg[i]]));
+        lambda = 1e-5 * md;
+    }
     int it = 0;
     for (; it < max_it; ++it) {
-        double v[LM_NV];
-#pragma unroll
-        for (int i = 0; i < LM_NV; ++i) v[i] = 0;
-        for (int i = threadIdx.x; i < n; i += LM_T) {
-            if (round == 1 && !(mask[i] & 2)) continue;
-            const int k = edges[i];
-            double e[2]; D3 pc;
-            edge_err_dev(cam, T, &cxyz[3 * k], &cuv[2 * k], e, pc);
-            const double e2 = e[0] * e[0] + e[1] * e[1];
-            double r1 = 1.0;
-            if (robust && e2 > delta * delta) { const double se = sqrt(e2); v[27] += 2.0 * se * delta - delta * delta; r1 = delta / se; } else v[27] += e2;
-            const double X = pc.x, Y = pc.y, Zi = 1.0 / (pc.z + 1e-18), Zi2 = Zi * Zi, fx = cam.fx, fy = cam.fy;
-            const double J0[6] = {-fx * Zi, 0, fx * X * Zi2, fx * X * Y * Zi2, -fx - fx * X * X * Zi2, fx * Y * Zi};
-            const double J1[6] = {0, -fy * Zi, fy * Y * Zi2, fy + fy * Y * Y * Zi2, -fy * X * Y * Zi2, -fy * X * Zi};
-            int c = 0;
-#pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                v[21 + a] -= r1 * (J0[a] * e[0] + J1[a] * e[1]);
-#pragma unroll
-                for (int b = a; b < 6; ++b) v[c++] += r1 * (J0[a] * J0[b] + J1[a] * J1[b]);
-            }
-        }
-        block_reduce_dev<LM_NV>(v, s_part, s_out);
         double H[36], bvec[6];
-        { int c = 0; for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) { H[a * 6 + b] = v[c]; H[b * 6 + a] = v[c]; ++c; } }
-        for (int a = 0; a < 6; ++a) bvec[a] = v[21 + a];
-        double cur = v[27];
-        if (it == 0) {
-            double md = 0;
-            for (int i = 0; i < 6; ++i) md = fmax(md, fabs(H[i * 7]));
-            lambda = 1e-5 * md; ni = 2;
-        }
-        double rho = 0; int qmax = 0;
+        { int c = 0; for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) { H[a * 6 + b] = cur_v[c]; H[b * 6 + a] = cur_v[c]; ++c; } }
+        for (int a = 0; a < 6; ++a) bvec[a] = cur_v[21 + a];
+        double cur = cur_v[27];
+        double rho = 0; int qmax = 0; bool converged = false;
         do {
             double A[36], x[6], Tn[12];
+#ifdef VO_LM_STAMPS
+            long long t1 = clock64();
+#endif
             for (int i = 0; i < 36; ++i) A[i] = H[i];
             for (int i = 0; i < 6; ++i) { A[i * 7] += lambda; x[i] = bvec[i]; }
             const bool ok = chol6_dev(A, x);
-            double tmp = DBL_MAX;
             if (ok) se3_exp_mul_dev(x, T, Tn);
             else for (int i = 0; i < 12; ++i) Tn[i] = T[i];
-            // every thread takes the same branch (ok derives from block-uniform data), so the barrier inside is safe
-            const double chi_n = lm_chi_dev(cam, cxyz, cuv, edges, mask, n, round, Tn, robust, delta, s_part, s_out);
-            if (ok) tmp = chi_n;
+#ifdef VO_LM_STAMPS
+            long long t2 = clock64(); t_serial += t2 - t1;
+#endif
+            // block-uniform control flow: every thread holds the same H, b, lambda
+            lm_pass_dev(cam, cxyz, cuv, edges, mask, n, round, Tn, delta, tr_v, s_part, s_out);
+#ifdef VO_LM_STAMPS
+            t_pass += clock64() - t2; ++n_pass;
+#endif
+            const double tmp = ok ? tr_v[27] : DBL_MAX;
             rho = cur - tmp;
             double scale = 1e-3;
             if (ok) for (int i = 0; i < 6; ++i) scale += x[i] * (lambda * x[i] + bvec[i]);
@@ -527,59 +596,80 @@ __device__ int lm_optimize_dev(const CamD& cam, const float* cxyz, const float* 
                 a = fmin(a, 2.0 / 3.0);
                 lambda *= fmax(1.0 / 3.0, a); ni = 2; cur = tmp;
                 for (int i = 0; i < 12; ++i) T[i] = Tn[i];
+                for (int i = 0; i < LM_NV; ++i) cur_v[i] = tr_v[i];
+                double mx = 0;
+                for (int i = 0; i < 6; ++i) mx = fmax(mx, fabs(x[i]));
+                converged = mx < 1e-10;
             } else { lambda *= ni; ni *= 2; }
             ++qmax;
         } while (rho < 0 && qmax < 10);
-        if (qmax == 10 || rho == 0) { ++it; break; }
+        if (qmax == 10 || rho == 0 || converged) { ++it; break; }
     }
+#ifdef VO_LM_STAMPS
+    if (threadIdx.x == 0) { g_dbg[0] += t_pass; g_dbg[1] += t_serial; g_dbg[2] += n_pass; g_dbg[3] += it; }
+#endif
     return it;
 }
 
-__global__ __launch_bounds__(LM_T) void k_pose_lm(CamD cam, TrackDev* __restrict__ tr, const float* __restrict__ cxyz,
-                                                  const float* __restrict__ cuv, const int32_t* __restrict__ edges, uint8_t* __restrict__ mask,
+__device__ __forceinline__ double edge_chi2_dev(const CamD& cam, const double* T, const float* X, const float* z) {
+    const D3 pc = xform(T, mk((double)X[0], (double)X[1], (double)X[2]));
+    const double Zi = 1.0 / (pc.z + 1e-18);
+    const double e0 = (double)z[0] - (cam.fx * pc.x * Zi + cam.cx), e1 = (double)z[1] - (cam.fy * pc.y * Zi + cam.cy);
+    return e0 * e0 + e1 * e1;
+}
+
+__global__ __launch_bounds__(LM_T) void k_pose_lm(CamD cam, TrackDev* __restrict__ tr, const float* cxyz,
+                                                  const float* cuv, const int32_t* edges, uint8_t* __restrict__ mask,
                                                   double delta, double cut, int it_r, int it_p) {
-    __shared__ double s_part[(LM_T / 64) * LM_NV];
+#ifdef VO_LM_STAMPS
+    const long long t_kernel0 = clock64();
+#endif
+    extern __shared__ float s_corr[];                  // gathered inlier correspondences: n x 3 then n x 2 floats
+    __shared__ double s_part[LM_W * LM_NV];
     __shared__ double s_out[LM_NV];
-    __shared__ int s_cnt;
+    __shared__ int s_cnt[2];
     const int n = tr->n_inl;
     double T[12];
     for (int i = 0; i < 12; ++i) T[i] = tr->T[i];
-    if (threadIdx.x == 0) s_cnt = 0;
+    if (threadIdx.x == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
+    if (n <= LM_LDS_MAX) {
+        for (int i = threadIdx.x; i < n; i += LM_T) {
+            const int k = edges[i];
+            s_corr[3 * i] = cxyz[3 * k]; s_corr[3 * i + 1] = cxyz[3 * k + 1]; s_corr[3 * i + 2] = cxyz[3 * k + 2];
+            s_corr[3 * n + 2 * i] = cuv[2 * k]; s_corr[3 * n + 2 * i + 1] = cuv[2 * k + 1];
+        }
+        cxyz = s_corr; cuv = s_corr + 3 * n; edges = nullptr;
+    }
+    __syncthreads();
     int iters = 0;
-    int n_act = n;
-    if (n_act > 0) iters += lm_optimize_dev(cam, cxyz, cuv, edges, mask, n, 0, T, delta, it_r, s_part, s_out);
+    if (n > 0) iters += lm_optimize_dev(cam, cxyz, cuv, edges, mask, n, 0, T, delta, it_r, s_part, s_out);
     // edges whose chi2 exceeds the cut leave the second round (frontend.cpp:294-306)
     int loc = 0;
     for (int i = threadIdx.x; i < n; i += LM_T) {
-        const int k = edges[i];
-        double e[2]; D3 pc;
-        edge_err_dev(cam, T, &cxyz[3 * k], &cuv[2 * k], e, pc);
-        const bool keep = !(e[0] * e[0] + e[1] * e[1] > cut);
+        const int k = edges ? edges[i] : i;
+        const bool keep = !(edge_chi2_dev(cam, T, &cxyz[3 * k], &cuv[2 * k]) > cut);
         mask[i] = keep ? 2 : 0;
         loc += keep ? 1 : 0;
     }
-    atomicAdd(&s_cnt, loc);
-    __threadfence_block();
+    if (loc) atomicAdd(&s_cnt[0], loc);
     __syncthreads();
-    n_act = s_cnt;
-    __syncthreads();
-    if (n_act > 0) iters += lm_optimize_dev(cam, cxyz, cuv, edges, mask, n, 1, T, delta, it_p, s_part, s_out);
-    if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
+    if (s_cnt[0] > 0) iters += lm_optimize_dev(cam, cxyz, cuv, edges, mask, n, 1, T, delta, it_p, s_part, s_out);
     loc = 0;
     for (int i = threadIdx.x; i < n; i += LM_T) {
-        const int k = edges[i];
-        double e[2]; D3 pc;
-        edge_err_dev(cam, T, &cxyz[3 * k], &cuv[2 * k], e, pc);
-        const bool in = !(e[0] * e[0] + e[1] * e[1] > cut);
+        const int k = edges ? edges[i] : i;
+        const bool in = !(edge_chi2_dev(cam, T, &cxyz[3 * k], &cuv[2 * k]) > cut);
         mask[i] = (mask[i] & 2) | (in ? 1 : 0);
         loc += in ? 1 : 0;
     }
-    atomicAdd(&s_cnt, loc);
+    if (loc) atomicAdd(&s_cnt[1], loc);
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int i = 0; i < 12; ++i) tr->T[i] = T[i];
-        tr->lm_iters += iters; tr->n_lm_inl = s_cnt;
+        tr->lm_iters += iters; tr->n_lm_inl = s_cnt[1];
+#ifdef VO_LM_STAMPS
+        for (int i = 0; i < 4; ++i) { tr->dbg[i] = g_dbg[i]; g_dbg[i] = 0; }
+        tr->dbg[4] = clock64() - t_kernel0; tr->dbg[5] = n;
+#endif
     }
 }
 
@@ -608,22 +698,32 @@ __global__ void k_map_scatter(int n, const int32_t* __restrict__ idx, const doub
 // ------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------
+int vo_track_set_attrs() {
+    HIP_TRY(hipFuncSetAttribute((const void*)k_match_gate, hipFuncAttributeMaxDynamicSharedMemorySize, GATE_LDS_MAX * 4));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_pose_lm, hipFuncAttributeMaxDynamicSharedMemorySize, LM_LDS_MAX * 20));
+    return VO_OK;
+}
+
 static CamD cam_of(const vo_ctx* c) { CamD k; k.fx = c->p.fx; k.fy = c->p.fy; k.cx = c->p.cx; k.cy = c->p.cy; k.W = c->p.width; k.H = c->p.height; return k; }
 
 int vo_track_match_launch(vo_ctx* c, int slot, float ratio, float floor_dist) {
     hipStream_t st = c->stream;
     const int na = c->n_active;
     c->corr_external = false;
-    if (na > 0) HIP_TRY(hipMemsetAsync(c->d_best, 0xFF, sizeof(unsigned long long) * na, st));
+    HIP_TRY(hipMemsetAsync(&c->d_track->n_cand, 0, sizeof(int), st));
     if (na > 0) {
+        { ProfScope ps(c, "k_frustum");
+          hipLaunchKernelGGL(k_frustum, dim3((na + 255) / 256), dim3(256), 0, st, cam_of(c), c->d_track, c->d_map_pos, c->d_map_nrm, c->d_map_flags,
+                             c->d_active, na, c->d_best, c->d_mcand); }
         ProfScope ps(c, "k_match");
         dim3 g((na + MQ - 1) / MQ, (c->p.n_features + MT - 1) / MT);
-        hipLaunchKernelGGL(k_match, g, dim3(256), 0, st, cam_of(c), c->d_track, c->d_map_pos, c->d_map_nrm, c->d_map_desc, c->d_map_flags,
-                           c->d_active, na, (const uint32_t*)(c->d_desc + (size_t)slot * c->p.n_features * 32), c->d_nkp + slot, c->d_best);
+        hipLaunchKernelGGL(k_match, g, dim3(64), 0, st, c->d_track, c->d_map_desc, c->d_active, c->d_mcand,
+                           (const uint32_t*)(c->d_desc + (size_t)slot * c->p.n_features * 32), c->d_nkp + slot, c->d_best);
     }
     { ProfScope ps(c, "k_match_gate");
-      hipLaunchKernelGGL(k_match_gate, dim3(1), dim3(1024), 0, st, c->d_track, c->d_best, c->d_active, na, c->d_map_pos,
-                         c->d_kps + (size_t)slot * c->p.n_features, ratio, floor_dist, c->d_matches, c->d_corr_xyz, c->d_corr_uv, c->corr_cap); }
+      const int use_lds = na <= GATE_LDS_MAX ? 1 : 0;
+      hipLaunchKernelGGL(k_match_gate, dim3(1), dim3(1024), use_lds ? sizeof(uint32_t) * (size_t)na : 0, st, c->d_track, c->d_best, c->d_active, na, c->d_map_pos,
+                         c->d_kps + (size_t)slot * c->p.n_features, ratio, floor_dist, c->d_matches, c->d_corr_xyz, c->d_corr_uv, c->corr_cap, use_lds); }
     HIP_TRY(hipGetLastError());
     return VO_OK;
 }
@@ -652,7 +752,7 @@ int vo_track_ransac_launch(vo_ctx* c, int n_hyp, float reproj_px, float conf, ui
     { ProfScope ps(c, "k_ransac_hyp");
       hipLaunchKernelGGL(k_ransac_hyp, dim3((n_hyp + 63) / 64), dim3(64), 0, st, cam, c->d_track, c->d_corr_xyz, c->d_corr_uv, n_hyp, seed, c->d_hyp_pose, c->d_hyp_cnt); }
     { ProfScope ps(c, "k_ransac_score");
-      hipLaunchKernelGGL(k_ransac_score, dim3((n_hyp + 3) / 4), dim3(256), 0, st, cam, c->d_track, c->d_corr_xyz, c->d_corr_uv, n_hyp, thr2, c->d_hyp_pose, c->d_hyp_cnt); }
+      hipLaunchKernelGGL(k_ransac_score, dim3(n_hyp), dim3(256), 0, st, cam, c->d_track, c->d_corr_xyz, c->d_corr_uv, n_hyp, thr2, c->d_hyp_pose, c->d_hyp_cnt); }
     { ProfScope ps(c, "k_ransac_select");
       hipLaunchKernelGGL(k_ransac_select, dim3(1), dim3(1024), 0, st, cam, c->d_track, c->d_corr_xyz, c->d_corr_uv, n_hyp, thr2, (double)conf, c->d_hyp_pose, c->d_hyp_cnt, c->d_inliers); }
     HIP_TRY(hipGetLastError());
@@ -661,7 +761,7 @@ int vo_track_ransac_launch(vo_ctx* c, int n_hyp, float reproj_px, float conf, ui
 
 int vo_track_lm_launch(vo_ctx* c, double delta, double cut, int it_r, int it_p) {
     ProfScope ps(c, "k_pose_lm");
-    hipLaunchKernelGGL(k_pose_lm, dim3(1), dim3(LM_T), 0, c->stream, cam_of(c), c->d_track, c->d_corr_xyz, c->d_corr_uv, c->d_inliers, c->d_lm_mask, delta, cut, it_r, it_p);
+    hipLaunchKernelGGL(k_pose_lm, dim3(1), dim3(LM_T), LM_LDS_MAX * 20, c->stream, cam_of(c), c->d_track, c->d_corr_xyz, c->d_corr_uv, c->d_inliers, c->d_lm_mask, delta, cut, it_r, it_p);
     HIP_TRY(hipGetLastError());
     return VO_OK;
 }

@@ -18,7 +18,7 @@ public:
     void SetContext(vo_ctx* ctx) { ctx_ = ctx; }
     void Stop() {}
     void OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr);
-    struct Stats { int runs = 0, poses = 0, fixed = 0, points = 0, edges = 0, outliers = 0; double ms = 0; };
+    struct Stats { int runs = 0, poses = 0, fixed = 0, points = 0, edges = 0, outliers = 0; double ms = 0, ms_build = 0, ms_solve = 0; };
     const Stats& GetStats() const { return stats_; }
 private:
     Camera::Ptr camera_;

@@ -52,10 +52,13 @@ private:
     std::vector<KeyPoint>   keypointsCurr_;
     std::vector<Descriptor> descriptorsCurr_;
     std::vector<Mappoint::Ptr> activeList_;                 // device tracking map, in matching order
-    std::unordered_map<int, Mappoint::Ptr> slotToMappoint_;
-    std::unordered_map<Mappoint::Ptr, KeyPoint> flannMatchedMptKptMap_;
+    std::vector<int> activeIndexOfSlot_;
+    std::vector<Mappoint*> slotToMappoint_;                 // device-map slot -> map point of the active list
+    // flannMatchedMptKptMap_ of the reference (frontend.h:73) as parallel arrays in match order
+    std::vector<Mappoint::Ptr> flannMatchedMpt_; std::vector<int> flannMatchedKp_; std::vector<char> flannMatchedLm_;
     KeyPointSet flannMatchedKptSet_;
-    std::unordered_set<Mappoint::Ptr> pnpMatchedMptSet_;
+    std::vector<Mappoint::Ptr> pnpMatchedMpt_;              // pnpMatchedMptSet_ (frontend.h:76), id order
+    std::vector<int> pnpMatchedMptKp_;
     KeyPointSet pnpMatchedKptSet_;
     std::vector<Mappoint::Ptr> newMappoints_;
     int   numInliers_ = 0;

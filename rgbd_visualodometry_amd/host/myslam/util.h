@@ -9,12 +9,13 @@ namespace myslam {
 bool Triangulation(const std::vector<SE3>& poses, const std::vector<Vec3>& points, Vec3& pt_world);
 // symmetric eigen-decomposition (Jacobi), ascending eigenvalues; V columns = eigenvectors
 void SymmetricEigen4(const double A[16], double evals[4], double V[16]);
-struct KeyPointSet {            // identity set of keypoints of the current frame (reference: hashed cv::KeyPoint)
-    std::unordered_set<int> idx;
-    size_t count(const KeyPoint& k) const { return idx.count(k.index); }
-    void insert(const KeyPoint& k) { idx.insert(k.index); }
-    void clear() { idx.clear(); }
-    size_t size() const { return idx.size(); }
+struct KeyPointSet {            // identity set of keypoints of the current frame (reference: hashed cv::KeyPoint), flat bitmap
+    std::vector<char> hit; size_t n = 0;
+    size_t count(const KeyPoint& k) const { return (size_t)k.index < hit.size() && hit[k.index] ? 1 : 0; }
+    void insert(const KeyPoint& k) { if ((size_t)k.index >= hit.size()) hit.resize(k.index + 1, 0); if (!hit[k.index]) { hit[k.index] = 1; ++n; } }
+    void clear() { hit.assign(hit.size(), 0); n = 0; }
+    void reset(size_t cap) { hit.assign(cap, 0); n = 0; }
+    size_t size() const { return n; }
 };
 }  // namespace myslam
 #endif

@@ -87,7 +87,10 @@ void Backend::Optimize() {
     vo_ba_result res;
     std::memset(&res, 0, sizeof(res));
     res.poses = posesOut.data(); res.points = ptsOut.data(); res.edge_flags = flags.data();
+    auto t1 = std::chrono::steady_clock::now();
     int rc = vo_local_ba(ctx_, &prob, &res);
+    auto t2 = std::chrono::steady_clock::now();
+    stats_.ms_build += std::chrono::duration<double, std::milli>(t1 - t0).count(); stats_.ms_solve += std::chrono::duration<double, std::milli>(t2 - t1).count();
     if (rc != VO_OK) throw std::runtime_error(std::string("vo_local_ba failed: ") + vo_strerror(rc));
 
     int outlierCnt = 0;

@@ -164,8 +164,11 @@ void FrontEnd::RefreshTrackingMap() {
     for (auto& kv : trackingMap_) activeList_.push_back(kv.second);
     std::sort(activeList_.begin(), activeList_.end(), [](const Mappoint::Ptr& a, const Mappoint::Ptr& b) { return a->GetId() < b->GetId(); });
     std::vector<int32_t> slots(activeList_.size());
-    slotToMappoint_.clear();
-    for (size_t i = 0; i < activeList_.size(); ++i) { slots[i] = activeList_[i]->slot_; slotToMappoint_[slots[i]] = activeList_[i]; }
+    int maxSlot = -1;
+    for (auto& mp : activeList_) maxSlot = std::max(maxSlot, mp->slot_);
+    slotToMappoint_.assign((size_t)maxSlot + 1, nullptr);
+    activeIndexOfSlot_.assign((size_t)maxSlot + 1, -1);
+    for (size_t i = 0; i < activeList_.size(); ++i) { slots[i] = activeList_[i]->slot_; slotToMappoint_[slots[i]] = activeList_[i].get(); activeIndexOfSlot_[slots[i]] = (int)i; }
     vo_check(vo_map_set_active(ctx_, slots.data(), (int)slots.size()), "vo_map_set_active");
 }
 
@@ -195,15 +198,17 @@ void FrontEnd::MatchAndEstimatePose() {
     vo_check(vo_track_frame(ctx_, frameCurr_->slot_, prior, &trackParams_, &res, matchBuf_.data(), cap), "vo_track_frame");
     if (res.status != VO_OK) throw std::runtime_error(std::string("device pipeline: ") + vo_strerror(res.status));
 
-    flannMatchedMptKptMap_.clear(); flannMatchedKptSet_.clear();
-    pnpMatchedMptSet_.clear(); pnpMatchedKptSet_.clear();
+    flannMatchedMpt_.clear(); flannMatchedKp_.clear(); flannMatchedLm_.clear();
+    flannMatchedKptSet_.reset(keypointsCurr_.size()); pnpMatchedKptSet_.reset(keypointsCurr_.size());
+    pnpMatchedMpt_.clear(); pnpMatchedMptKp_.clear();
     for (int i = 0; i < res.n_matches; ++i) {
         const vo_match& m = matchBuf_[i];
-        const Mappoint::Ptr& mp = slotToMappoint_[m.map_index];
+        const Mappoint::Ptr& mp = activeList_[activeIndexOfSlot_[m.map_index]];
         const KeyPoint& kp = keypointsCurr_[m.kp_index];
-        flannMatchedMptKptMap_[mp] = kp;                                            // frontend.cpp:208-209
+        flannMatchedMpt_.push_back(mp); flannMatchedKp_.push_back(m.kp_index);              // frontend.cpp:208-209
+        flannMatchedLm_.push_back((m.flags & VO_MATCH_LM_INLIER) ? 1 : 0);
         flannMatchedKptSet_.insert(kp);
-        if (m.flags & VO_MATCH_LM_INLIER) { pnpMatchedMptSet_.insert(mp); pnpMatchedKptSet_.insert(kp); }   // :326-328
+        if (m.flags & VO_MATCH_LM_INLIER) { pnpMatchedMpt_.push_back(mp); pnpMatchedMptKp_.push_back(m.kp_index); pnpMatchedKptSet_.insert(kp); }   // :326-328
     }
     numInliers_ = res.n_ransac_inliers;                                             // frontend.cpp:242
     frameCurr_->SetPose(SE3::from12(res.T_cw));                                     // frontend.cpp:312
@@ -232,10 +237,9 @@ bool FrontEnd::IsKeyframe() {
 }
 
 void FrontEnd::AddCurrentKeyframeObservations() {
-    // reference iterates an unordered_set (frontend.cpp:366-370); match order here, for determinism
-    std::vector<Mappoint::Ptr> ordered(pnpMatchedMptSet_.begin(), pnpMatchedMptSet_.end());
-    std::sort(ordered.begin(), ordered.end(), [](const Mappoint::Ptr& a, const Mappoint::Ptr& b) { return a->GetId() < b->GetId(); });
-    for (auto& mp : ordered) frameCurr_->AddObservedMappoint(mp->GetId(), flannMatchedMptKptMap_[mp].pt);
+    // reference iterates an unordered_set (frontend.cpp:366-370); active-list (= id) order here, for determinism
+    for (size_t i = 0; i < pnpMatchedMpt_.size(); ++i)
+        frameCurr_->AddObservedMappoint(pnpMatchedMpt_[i]->GetId(), keypointsCurr_[pnpMatchedMptKp_[i]].pt);
 }
 
 void FrontEnd::CreateNewMappoints() {
@@ -257,8 +261,8 @@ void FrontEnd::CreateNewMappoints() {
 
 void FrontEnd::TriangulateMappointsInTrackingMap() {
     int triangulatedCnt = 0;
-    for (auto& mp : activeList_) {                                                  // trackingMap_ in id order
-        if (mp->outlier_ || mp->triangulated_ || mp->optimized_ || !pnpMatchedMptSet_.count(mp)) continue;
+    for (auto& mp : pnpMatchedMpt_) {                                               // trackingMap_ ∩ pnpMatchedMptSet_, id order
+        if (mp->outlier_ || mp->triangulated_ || mp->optimized_) continue;
         std::vector<SE3> poses; std::vector<Vec3> points;
         auto obs = mp->GetObservedByKeyframesMap();
         std::vector<size_t> ids;

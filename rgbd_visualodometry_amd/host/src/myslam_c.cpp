@@ -1,6 +1,8 @@
 // myslam_c.cpp -- C wrapper of the host layer (see include/myslam_c.h).
 #include "myslam_c.h"
 
+#include <cstdio>
+#include <cstdlib>
 #include <deque>
 #include <exception>
 
@@ -130,6 +132,7 @@ int myslam_get_stats(myslam_system* s, myslam_stats* st) {
     if (s->backend) {
         const auto& b = s->backend->GetStats();
         st->ba_runs = b.runs; st->ba_poses = b.poses; st->ba_fixed = b.fixed; st->ba_points = b.points; st->ba_edges = b.edges; st->ba_outliers = b.outliers; st->ba_ms = b.ms;
+        if (getenv("VO_TRACE")) fprintf(stderr, "[vo_trace] BA runs %d build %.2f ms solve %.2f ms total %.2f ms\n", b.runs, b.ms_build, b.ms_solve, b.ms);
     }
     return 0;
 }
