@@ -59,12 +59,6 @@ def algorithmic_bytes(W, H, N, M, K, n_hyp, passes=2):
     return b, total_survey, P
 
 
-def run_stream(system_mod, lib_path, frames, stamps, opts, lookahead, device_ptrs=None, pose_out=None):
-    """Drive one VoSystem over the given frames; returns elapsed seconds (caller syncs)."""
-    s = system_mod.VoSystem(lib_path, **opts)
-    return s
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,26 +73,19 @@ def main():
     ap.add_argument("--profile-frames", type=int, default=64)
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
+    from rgbd_visualodometry_amd import capi, system, shard, evaluate as ev
+    rank, local_rank, world = shard.env_rank_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    from rgbd_visualodometry_amd import capi, system, evaluate as ev
+    grp = shard.Group("nccl", device=torch.device("cuda", local_rank))     # RCCL; only barrier + MAX(time) cross ranks
 
     W, H, N = 640, 480, args.features
     K, Wm = args.steps, args.warmup
     total = K + Wm
     syn = capi.Synth()
-    sp = syn.params(seed=args.seed + rank)
+    sp = syn.params(seed=shard.stream_seed(args.seed, rank))
     threads = max(1, (os.cpu_count() or 8) // max(1, world))
     t0 = time.time()
     bgr, depth, Twc, stamps = syn.render(sp, 0, total, threads=min(32, threads))
@@ -129,20 +116,14 @@ def main():
 
     drive(0, Wm)                                            # warmup (also initialises the map)
     torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    grp.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     drive(Wm, total)
     torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    grp.barrier()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = grp.max_scalar(time.perf_counter() - t0)
     st = sysm.stats()
 
     # accuracy of the timed run (every rank checks its own stream; rank 0 reports)
@@ -152,7 +133,7 @@ def main():
 
     out = None
     if rank == 0:
-        fps = world * K / elapsed
+        fps = shard.aggregate_fps(K, world, elapsed)
         # ---- roofline of the dominant kernel: live HIP-event timing on the context's stream -------
         prof_sys = system.VoSystem(system.HOST_LIB, **opts)
         L = capi.load(capi.HIP_LIB)
@@ -234,9 +215,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    grp.close()
 
 
 if __name__ == "__main__":

