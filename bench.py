@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--lookahead", type=int, default=32, help="frames per batched ORB launch chain")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-ba", action="store_true", help="disable local BA (enable_local_optimization: 0)")
+    ap.add_argument("--ba-lag", type=int, default=0, help="0: BA synchronous in AddFrame; L>0: overlapped, merged L frames later (deterministic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=150, help="bounded CPU-baseline sample (frames)")
     ap.add_argument("--profile-frames", type=int, default=64)
@@ -98,7 +99,7 @@ def main():
     dptr = [d_depth.data_ptr() + i * fd for i in range(total)]
 
     opts = dict(width=W, height=H, number_of_features=N, max_frames_in_flight=args.lookahead, device=local_rank,
-                enable_local_optimization=0 if args.no_ba else 1, map_capacity=1 << 20)
+                enable_local_optimization=0 if args.no_ba else 1, backend_lag_frames=args.ba_lag, map_capacity=1 << 20)
     sysm = system.VoSystem(system.HOST_LIB, **opts)
     assert sysm.backend == "hip-gfx950", sysm.backend
 
@@ -197,7 +198,7 @@ def main():
             tc = time.perf_counter() - tc
             gt_c = {stamps[i]: gt[stamps[i]] for i in range(nf)}
             est_g = {stamps[i]: est_t[stamps[i]] for i in range(nf)}
-            cpu = {"value": round(nf / tc, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+            cpu = {"value": round(nf / tc, 3), "unit": "frames/s", "cores": 1 if (args.ba_lag == 0 or args.no_ba) else 2, "kind": "port",
                    "sample": "first %d frames of the same synthetic stream, single thread, oracle/_build/liboracle_vo.so" % nf,
                    "ate_rmse_m": round(ev.ate(gt_c, est_c)["rmse"], 5), "gpu_ate_rmse_m_same_frames": round(ev.ate(gt_c, est_g)["rmse"], 5),
                    "host_cpus": os.cpu_count()}
@@ -206,7 +207,7 @@ def main():
             "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/f64", "data": "synthetic",
             "config": {"workload": "synthetic 640x480 RGB-D stream per GPU, %d ORB features, default.yaml tracking parameters" % N,
-                       "streams_per_gpu": 1, "lookahead_frames": args.lookahead, "local_ba": not args.no_ba, "ransac_hypotheses": 100},
+                       "streams_per_gpu": 1, "lookahead_frames": args.lookahead, "local_ba": (False if args.no_ba else ("synchronous" if args.ba_lag == 0 else "overlapped, merged %d frames later" % args.ba_lag)), "ransac_hypotheses": 100},
             "ate_rmse_m": round(ate_gpu, 5), "keyframes": st["keyframes"], "lost": st["lost"], "map_points": st["map_points"],
             "alg_bytes_per_frame_survey": b_survey, "hbm_frac_whole_frame": round(b_survey * (fps / world) / (HBM_PEAK_GBS * 1e9), 6),
             "render_s": round(t_render, 2),

@@ -25,6 +25,8 @@ typedef struct myslam_options {
     int32_t enable_local_optimization;      /* 1    */
     float chi2_th;                          /* 1    */
     int32_t ransac_iterations;              /* 100 (frontend.cpp:240) */
+    int32_t backend_lag_frames;             /* 0: BA solved + merged inside AddFrame; L>0: solved on a worker thread,
+                                               merged deterministically L frames later (or at the next keyframe) */
     int32_t max_frames_in_flight;           /* look-ahead ORB batch (1 = none) */
     int32_t map_capacity;
     int32_t device;

@@ -145,13 +145,15 @@ struct BA {
                     double a = 1.0 - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
                     a = std::min(a, 2.0 / 3.0);
                     lambda *= std::max(1.0 / 3.0, a); ni = 2; cur = tmp; pose.swap(Pn); pt.swap(Xn);
+                } else { lambda *= ni; ni *= 2; }
+                if (ok) {
                     double mx = 0;
                     for (int i = 0; i < D; ++i) mx = std::max(mx, std::fabs(dp[i]));
                     for (int i = 0; i < 3 * np; ++i) mx = std::max(mx, std::fabs(dl[i]));
                     converged = mx < 1e-10;
-                } else { lambda *= ni; ni *= 2; }
+                }
                 ++qmax;
-            } while (rho < 0 && qmax < 10);
+            } while (rho < 0 && qmax < 10 && !converged);
             if (qmax == 10 || rho == 0 || converged) { ++it; break; }
         }
         return it;

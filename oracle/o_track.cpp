@@ -317,12 +317,14 @@ static int lm_optimize(const Cam& cam, const Corr& c, const std::vector<int32_t>
                 double a = 1.0 - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
                 a = std::min(a, 2.0 / 3.0);
                 lambda *= std::max(1.0 / 3.0, a); ni = 2; cur = tmp; T = Tn;
-                double mx = 0;
-                for (int i = 0; i < 6; ++i) mx = std::max(mx, std::fabs(x[i]));
-                converged = mx < 1e-10;                     // accepted step below 1e-10: later iterations cannot move the pose
             } else { lambda *= ni; ni *= 2; }
+            if (ok) {                                       // a step below 1e-10 (taken or not) ends the optimisation:
+                double mx = 0;                              // later iterations / retries cannot move the pose any further
+                for (int i = 0; i < 6; ++i) mx = std::max(mx, std::fabs(x[i]));
+                converged = mx < 1e-10;
+            }
             ++qmax;
-        } while (rho < 0 && qmax < 10);
+        } while (rho < 0 && qmax < 10 && !converged);
         if (qmax == 10 || rho == 0 || converged) { ++it; break; }
     }
     return it;

@@ -573,11 +573,10 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
                     a = std::min(a, 2.0 / 3.0);
                     lambda *= std::max(1.0 / 3.0, a); ni = 2; cur = tmp;
                     std::swap(B.poses, B.poses_n); std::swap(B.pts, B.pts_n);
-                    double mx; memcpy(&mx, &h_scal[7], 8);
-                    converged = mx < 1e-10;
                 } else { lambda *= ni; ni *= 2; }
+                if (ok) { double mx; memcpy(&mx, &h_scal[7], 8); converged = mx < 1e-10; }
                 ++qmax;
-            } while (rho < 0 && qmax < 10);
+            } while (rho < 0 && qmax < 10 && !converged);
             ++iters;
             if (qmax == 10 || rho == 0 || converged) break;
         }

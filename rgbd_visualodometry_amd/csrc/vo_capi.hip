@@ -186,6 +186,7 @@ void vo_ctx_destroy(vo_ctx* c) {
     if (c->h_matches) (void)hipHostFree(c->h_matches);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_slots_pinned) (void)hipHostFree(c->h_slots_pinned);
+    if (c->h_orb_cache) (void)hipHostFree(c->h_orb_cache);
     if (c->slots_ev) (void)hipEventDestroy(c->slots_ev);
     for (auto& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -211,6 +212,7 @@ int vo_ctx_create(const vo_params* p, int device, vo_ctx** out) {
     c->d_best = nullptr; c->d_mcand = nullptr; c->d_matches = nullptr; c->d_corr_xyz = nullptr; c->d_corr_uv = nullptr; c->corr_cap = 0; c->d_hyp_pose = nullptr; c->d_hyp_cnt = nullptr;
     c->d_inliers = nullptr; c->d_lm_mask = nullptr; c->d_track = nullptr; c->h_track = nullptr; c->h_matches = nullptr; c->h_matches_cap = 0;
     c->h_stage = nullptr; c->h_stage_bytes = 0; c->d_ba = nullptr; c->d_ba_bytes = 0;
+    c->h_orb_cache = nullptr; c->orb_cache_valid = false; c->orb_batch0 = 0; c->orb_batchn = 0;
     c->h_slots_pinned = nullptr; c->slots_ev = nullptr; c->slots_dirty = false; c->slots_pending = false;
     std::vector<int> tab; std::vector<short> tabs;
     int rc = build_plan(*p, c->plan, tab, tabs);
@@ -301,6 +303,7 @@ int vo_orb_detect_describe(vo_ctx* c, int slot0, int n) {
     rc = vo_orb_launch(c, slot0, n);
     if (rc) return rc;
     for (int i = slot0; i < slot0 + n; ++i) c->slot_orb[i] = 1;
+    c->orb_cache_valid = false; c->orb_batch0 = slot0; c->orb_batchn = n;
     return VO_OK;
 }
 
@@ -312,27 +315,34 @@ static int read_status(vo_ctx* c) {
     return *st;
 }
 
+// Results of the whole last ORB batch come down in ONE set of D2H copies into a pinned cache; the
+// per-slot fetches of a look-ahead batch are then plain host memcpys.
 int vo_orb_fetch(vo_ctx* c, int slot, vo_keypoint* kps, uint8_t* desc, int cap, int* n_out) {
     if (!c || slot < 0 || slot >= c->p.max_frames || !n_out || cap < 0) return VO_E_INVALID;
     if (!c->slot_orb[slot]) return VO_E_STATE;
     HIP_TRY(hipSetDevice(c->device));
-    const int N = c->p.n_features;
-    const size_t need = 64 + (size_t)N * (sizeof(vo_keypoint) + 32);
-    uint8_t* st = (uint8_t*)vo_stage(c, need);
-    if (!st) return VO_E_NOMEM;
-    int* hn = (int*)st; int* hs = hn + 1;
-    vo_keypoint* hk = (vo_keypoint*)(st + 64);
-    uint8_t* hd = st + 64 + (size_t)N * sizeof(vo_keypoint);
-    const int take = std::min(cap, N);
-    HIP_TRY(hipMemcpyAsync(hn, c->d_nkp + slot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(hs, c->d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    if (take > 0 && kps) HIP_TRY(hipMemcpyAsync(hk, c->d_kps + (size_t)slot * N, sizeof(vo_keypoint) * take, hipMemcpyDeviceToHost, c->stream));
-    if (take > 0 && desc) HIP_TRY(hipMemcpyAsync(hd, c->d_desc + (size_t)slot * N * 32, (size_t)32 * take, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (*hs != VO_OK) return *hs;
-    const int n = *hn, k = std::min(n, take);
-    if (kps) memcpy(kps, hk, sizeof(vo_keypoint) * k);
-    if (desc) memcpy(desc, hd, (size_t)32 * k);
+    const int N = c->p.n_features, F = c->p.max_frames;
+    const size_t o_n = 0, o_st = 4 * (size_t)F, o_k = (o_st + 64 + 255) & ~(size_t)255, o_d = o_k + sizeof(vo_keypoint) * (size_t)F * N;
+    if (!c->h_orb_cache) {
+        if (hipHostMalloc((void**)&c->h_orb_cache, o_d + (size_t)32 * F * N, hipHostMallocDefault) != hipSuccess) return VO_E_NOMEM;
+    }
+    const bool in_batch = slot >= c->orb_batch0 && slot < c->orb_batch0 + c->orb_batchn;
+    if (!c->orb_cache_valid || !in_batch) {
+        const int s0 = in_batch ? c->orb_batch0 : slot, sn = in_batch ? c->orb_batchn : 1;
+        uint8_t* h = c->h_orb_cache;
+        HIP_TRY(hipMemcpyAsync(h + o_n + 4 * (size_t)s0, c->d_nkp + s0, sizeof(int) * sn, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(h + o_st, c->d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(h + o_k + sizeof(vo_keypoint) * (size_t)s0 * N, c->d_kps + (size_t)s0 * N, sizeof(vo_keypoint) * (size_t)sn * N, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(h + o_d + (size_t)32 * s0 * N, c->d_desc + (size_t)s0 * N * 32, (size_t)32 * sn * N, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (in_batch) c->orb_cache_valid = true;
+    }
+    const uint8_t* h = c->h_orb_cache;
+    const int st = *(const int*)(h + o_st);
+    if (st != VO_OK) return st;
+    const int n = ((const int*)(h + o_n))[slot], k = std::min(n, std::min(cap, N));
+    if (kps) memcpy(kps, h + o_k + sizeof(vo_keypoint) * (size_t)slot * N, sizeof(vo_keypoint) * k);
+    if (desc) memcpy(desc, h + o_d + (size_t)32 * slot * N, (size_t)32 * k);
     *n_out = n;
     return VO_OK;
 }
@@ -485,7 +495,7 @@ int vo_pose_refine_lm(vo_ctx* c, double T[12], double delta, double cut, int it_
     memcpy(c->h_track->T, T, sizeof(double) * 12);
     c->h_track->lm_iters = 0;
     HIP_TRY(hipMemcpyAsync(c->d_track, c->h_track, sizeof(TrackDev), hipMemcpyHostToDevice, c->stream));
-    rc = vo_track_lm_launch(c, delta, cut, it_r, it_p);
+    rc = vo_track_lm_launch(c, delta, cut, it_r, it_p, false);
     if (rc) return rc;
     rc = download_track(c);
     if (rc) return rc;
@@ -519,9 +529,8 @@ int vo_track_frame(vo_ctx* c, int slot, const double T0[12], const vo_track_para
     for (int pass = 0; pass < tp->passes; ++pass) {           // coarse, fine (frontend.cpp:100-108)
         if ((rc = vo_track_match_launch(c, slot, tp->match_ratio, tp->match_floor))) return rc;
         if ((rc = vo_track_ransac_launch(c, tp->n_hyp, tp->reproj_px, tp->confidence, tp->seed + (uint64_t)pass))) return rc;
-        if ((rc = vo_track_lm_launch(c, tp->huber_delta, tp->chi2_cut, tp->it_robust, tp->it_plain))) return rc;
+        if ((rc = vo_track_lm_launch(c, tp->huber_delta, tp->chi2_cut, tp->it_robust, tp->it_plain, pass == tp->passes - 1))) return rc;
     }
-    if ((rc = vo_track_flags_launch(c))) return rc;
     double t2 = trace ? now_us() : 0;
     const int take = std::min(cap, c->n_active);
     if ((rc = ensure_match_stage(c, take))) return rc;
@@ -535,7 +544,8 @@ int vo_track_frame(vo_ctx* c, int slot, const double T0[12], const vo_track_para
     res->min_distance = t.min_dist; res->ransac_iters = t.iters_used; res->best_hypothesis = t.best_hyp; res->lm_iters = t.lm_iters;
     res->status = t.status;
 #ifdef VO_LM_STAMPS
-    for (int i = 0; i < 6; ++i) res->reserved[i] = (int32_t)(t.dbg[i] >> (i < 2 || i == 4 ? 4 : 0));
+    for (int i = 0; i < 7; ++i) res->reserved[i] = (int32_t)(t.dbg[i == 6 ? 7 : i] >> ((i == 2 || i == 3) ? 0 : 4));
+    res->n_lm_inliers = (int32_t)(t.dbg[6] >> 4);
 #endif
     if (t.n_match > cap && matches) res->status = VO_E_OVERFLOW;
     if (matches) memcpy(matches, c->h_matches, sizeof(vo_match) * std::min(take, t.n_match));

@@ -75,6 +75,7 @@ struct vo_ctx {
     vo_match* h_matches;                            // pinned staging
     int h_matches_cap;
     void* h_stage; size_t h_stage_bytes;            // pinned general staging
+    uint8_t* h_orb_cache; bool orb_cache_valid; int orb_batch0, orb_batchn;   // pinned copy of the last ORB batch's results
     bool corr_external;
     // BA scratch
     void* d_ba; size_t d_ba_bytes;
@@ -95,7 +96,7 @@ int vo_map_scatter_launch(vo_ctx* c, int n, const int32_t* d_idx, const double* 
 int vo_orb_launch(vo_ctx* c, int slot0, int nslots);                                        // vo_orb.hip
 int vo_track_match_launch(vo_ctx* c, int slot, float ratio, float floor_dist);              // vo_track.hip
 int vo_track_ransac_launch(vo_ctx* c, int n_hyp, float reproj_px, float conf, uint64_t seed);
-int vo_track_lm_launch(vo_ctx* c, double delta, double cut, int it_r, int it_p);
+int vo_track_lm_launch(vo_ctx* c, double delta, double cut, int it_r, int it_p, bool write_flags);
 int vo_track_flags_launch(vo_ctx* c);
 int vo_corr_from_host(vo_ctx* c, const float* xyz, const float* uv, int n);
 int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out);                       // vo_ba.hip

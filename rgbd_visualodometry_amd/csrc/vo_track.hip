@@ -25,6 +25,10 @@
 #include "vo_internal.h"
 #include "vo_reduce.h"
 
+#ifdef VO_LM_STAMPS
+__device__ long long g_dbg[8];
+#endif
+
 struct CamD { double fx, fy, cx, cy; int W, H; };
 
 // ------------------------------------------------------------------------------------------
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(256) void k_frustum(CamD cam, TrackDev* __restrict_
     const D3 dir = nrm3(sub(pw, C));
     const double dd = dir.x * map_nrm[3 * (size_t)mi] + dir.y * map_nrm[3 * (size_t)mi + 1] + dir.z * map_nrm[3 * (size_t)mi + 2];
     if (dd < 0.8660254037844387) return;
-    cand[atomicAdd(&tr->n_cand, 1)] = q;
+    cand[atomicAdd(&tr->pad0, 1)] = q;          // pad0 = live candidate counter (reset by k_match_gate)
 }
 
 // 64 candidates x 64 frame descriptors per wavefront; the train tile sits in LDS and every lane reads
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(64) void k_match(const TrackDev* __restrict__ tr, c
                                               const uint32_t* __restrict__ fdesc, const int* __restrict__ nkp_p,
                                               unsigned long long* __restrict__ best) {
     __shared__ uint4 s_train[MT * 2];
-    const int nkp = *nkp_p, ncand = tr->n_cand;
+    const int nkp = *nkp_p, ncand = tr->pad0;
     const int t0 = blockIdx.y * MT;
     if (t0 >= nkp || (int)blockIdx.x * MQ >= ncand) return;
     const int nt = min(MT, nkp - t0);
@@ -180,7 +184,9 @@ __global__ __launch_bounds__(1024) void k_match_gate(TrackDev* __restrict__ tr, 
         }
     }
     if (threadIdx.x == 0) {
-        tr->n_match = min(total, cap); tr->min_dist = tr->n_cand ? gmin : -1;
+        const int ncand = tr->pad0;
+        tr->n_cand = ncand; tr->pad0 = 0;                 // counter ready for the next pass
+        tr->n_match = min(total, cap); tr->min_dist = ncand ? gmin : -1;
         if (total > cap) tr->status = VO_E_OVERFLOW;
     }
 }
@@ -423,9 +429,6 @@ __global__ __launch_bounds__(1024) void k_ransac_select(CamD cam, TrackDev* __re
 // ------------------------------------------------------------------------------------------
 // K14 pose-only LM in one workgroup
 // ------------------------------------------------------------------------------------------
-#ifdef VO_LM_STAMPS
-__device__ long long g_dbg[8];
-#endif
 #define LM_T 256
 #define LM_W (LM_T / 64)
 #define LM_NV 28            // 21 (upper H) + 6 (b) + 1 (chi)
@@ -504,30 +507,51 @@ __device__ void lm_pass_dev(const CamD& cam, const float* cxyz, const float* cuv
                             double* s_part, double* s_out) {
 #pragma clang fp contract(fast)
     const bool robust = round == 0;
+#ifdef VO_LM_STAMPS
+    const long long ts0 = clock64();
+#endif
 #pragma unroll
     for (int i = 0; i < LM_NV; ++i) v[i] = 0;
+    // Per edge: the weighted outer products of a = [J0, e0] and b = [J1, e1] give H, J^T e and chi2 at once;
+    // J0[1] = J1[0] = 0 (g2o_types.h:97-99) removes a third of the products.
+    double g[6] = {0, 0, 0, 0, 0, 0};
     for (int i = threadIdx.x; i < n; i += LM_T) {
         if (round == 1 && !(mask[i] & 2)) continue;
         const int k = edges ? edges[i] : i;            // edges == nullptr: correspondences already gathered (LDS)
         const D3 pc = xform(T, mk((double)cxyz[3 * k], (double)cxyz[3 * k + 1], (double)cxyz[3 * k + 2]));
-        const double Zi = 1.0 / (pc.z + 1e-18), Zi2 = Zi * Zi, X = pc.x, Y = pc.y, fx = cam.fx, fy = cam.fy;
-        const double e0 = (double)cuv[2 * k] - (fx * X * Zi + cam.cx), e1 = (double)cuv[2 * k + 1] - (fy * Y * Zi + cam.cy);   // g2o_types.h:83
+        const double zz = pc.z + 1e-18;
+        const double Zi = 1.0 / zz;                    // correctly rounded: the gain ratio near convergence is sensitive to chi2 noise
+        const double fx = cam.fx, fy = cam.fy, xz = pc.x * Zi, yz = pc.y * Zi;
+        const double e0 = (double)cuv[2 * k] - (fx * xz + cam.cx), e1 = (double)cuv[2 * k + 1] - (fy * yz + cam.cy);   // g2o_types.h:83
         const double e2 = e0 * e0 + e1 * e1;
         double r1 = 1.0;
         if (robust && e2 > delta * delta) { const double se = sqrt(e2); v[27] += 2.0 * se * delta - delta * delta; r1 = delta / se; } else v[27] += e2;
-        const double J0[6] = {-fx * Zi, 0, fx * X * Zi2, fx * X * Y * Zi2, -fx - fx * X * X * Zi2, fx * Y * Zi};                 // g2o_types.h:97-99
-        const double J1[6] = {0, -fy * Zi, fy * Y * Zi2, fy + fy * Y * Y * Zi2, -fy * X * Y * Zi2, -fy * X * Zi};
-        int c = 0;
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-            v[21 + a] -= r1 * (J0[a] * e0 + J1[a] * e1);
-#pragma unroll
-            for (int b = a; b < 6; ++b) v[c++] += r1 * (J0[a] * J0[b] + J1[a] * J1[b]);
-        }
+        const double fxz = fx * Zi, fyz = fy * Zi;
+        // J0 = [-fx/Z, 0, fx X/Z^2, fx XY/Z^2, -fx - fx X^2/Z^2, fx Y/Z],  J1 = [0, -fy/Z, fy Y/Z^2, fy + fy Y^2/Z^2, -fy XY/Z^2, -fy X/Z]
+        const double a0 = -fxz, a2 = fxz * xz, a3 = a2 * pc.y, a4 = -fx - a2 * pc.x, a5 = fxz * pc.y;
+        const double b1 = -fyz, b2 = fyz * yz, b3 = fy + b2 * pc.y, b4 = -b2 * pc.x, b5 = -fyz * pc.x;
+        const double wa0 = r1 * a0, wa2 = r1 * a2, wa3 = r1 * a3, wa4 = r1 * a4, wa5 = r1 * a5;
+        const double wb1 = r1 * b1, wb2 = r1 * b2, wb3 = r1 * b3, wb4 = r1 * b4, wb5 = r1 * b5;
+        // upper triangle, row-major: (0,0..5) (1,1..5) (2,2..5) (3,3..5) (4,4..5) (5,5)
+        v[0] += wa0 * a0; v[2] += wa0 * a2; v[3] += wa0 * a3; v[4] += wa0 * a4; v[5] += wa0 * a5;
+        v[6] += wb1 * b1; v[7] += wb1 * b2; v[8] += wb1 * b3; v[9] += wb1 * b4; v[10] += wb1 * b5;
+        v[11] += wa2 * a2 + wb2 * b2; v[12] += wa2 * a3 + wb2 * b3; v[13] += wa2 * a4 + wb2 * b4; v[14] += wa2 * a5 + wb2 * b5;
+        v[15] += wa3 * a3 + wb3 * b3; v[16] += wa3 * a4 + wb3 * b4; v[17] += wa3 * a5 + wb3 * b5;
+        v[18] += wa4 * a4 + wb4 * b4; v[19] += wa4 * a5 + wb4 * b5;
+        v[20] += wa5 * a5 + wb5 * b5;
+        g[0] += wa0 * e0; g[1] += wb1 * e1; g[2] += wa2 * e0 + wb2 * e1; g[3] += wa3 * e0 + wb3 * e1; g[4] += wa4 * e0 + wb4 * e1; g[5] += wa5 * e0 + wb5 * e1;
     }
+#pragma unroll
+    for (int a_ = 0; a_ < 6; ++a_) v[21 + a_] = -g[a_];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#ifdef VO_LM_STAMPS
+    const long long ts1 = clock64();
+#endif
 #pragma unroll
     for (int i = 0; i < LM_NV; ++i) v[i] = vo_wave_sum_f64(v[i]);
+#ifdef VO_LM_STAMPS
+    const long long ts2 = clock64();
+#endif
     __syncthreads();                                   // previous readers of s_out are done
     if (lane == 0) for (int i = 0; i < LM_NV; ++i) s_part[wave * LM_NV + i] = v[i];
     __syncthreads();
@@ -540,6 +564,9 @@ __device__ void lm_pass_dev(const CamD& cam, const float* cxyz, const float* cuv
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < LM_NV; ++i) v[i] = s_out[i];
+#ifdef VO_LM_STAMPS
+    if (threadIdx.x == 0) { g_dbg[4] += ts1 - ts0; g_dbg[5] += ts2 - ts1; g_dbg[6] += clock64() - ts2; }
+#endif
 }
 
 // g2o Levenberg-Marquardt (lambda/rho policy of OptimizationAlgorithmLevenberg).  The trial pass also
@@ -597,12 +624,14 @@ __device__ int lm_optimize_dev(const CamD& cam, const float* cxyz, const float* 
                 lambda *= fmax(1.0 / 3.0, a); ni = 2; cur = tmp;
                 for (int i = 0; i < 12; ++i) T[i] = Tn[i];
                 for (int i = 0; i < LM_NV; ++i) cur_v[i] = tr_v[i];
+            } else { lambda *= ni; ni *= 2; }
+            if (ok) {
                 double mx = 0;
                 for (int i = 0; i < 6; ++i) mx = fmax(mx, fabs(x[i]));
                 converged = mx < 1e-10;
-            } else { lambda *= ni; ni *= 2; }
+            }
             ++qmax;
-        } while (rho < 0 && qmax < 10);
+        } while (rho < 0 && qmax < 10 && !converged);
         if (qmax == 10 || rho == 0 || converged) { ++it; break; }
     }
 #ifdef VO_LM_STAMPS
@@ -620,7 +649,8 @@ __device__ __forceinline__ double edge_chi2_dev(const CamD& cam, const double* T
 
 __global__ __launch_bounds__(LM_T) void k_pose_lm(CamD cam, TrackDev* __restrict__ tr, const float* cxyz,
                                                   const float* cuv, const int32_t* edges, uint8_t* __restrict__ mask,
-                                                  double delta, double cut, int it_r, int it_p) {
+                                                  double delta, double cut, int it_r, int it_p, vo_match* __restrict__ matches) {
+    const int32_t* edges_g = edges;
 #ifdef VO_LM_STAMPS
     const long long t_kernel0 = clock64();
 #endif
@@ -659,6 +689,7 @@ __global__ __launch_bounds__(LM_T) void k_pose_lm(CamD cam, TrackDev* __restrict
         const int k = edges ? edges[i] : i;
         const bool in = !(edge_chi2_dev(cam, T, &cxyz[3 * k], &cuv[2 * k]) > cut);
         mask[i] = (mask[i] & 2) | (in ? 1 : 0);
+        if (matches) matches[edges_g[i]].flags = VO_MATCH_RANSAC_INLIER | (in ? VO_MATCH_LM_INLIER : 0);     // frontend.cpp:242,:317-329
         loc += in ? 1 : 0;
     }
     if (loc) atomicAdd(&s_cnt[1], loc);
@@ -667,8 +698,8 @@ __global__ __launch_bounds__(LM_T) void k_pose_lm(CamD cam, TrackDev* __restrict
         for (int i = 0; i < 12; ++i) tr->T[i] = T[i];
         tr->lm_iters += iters; tr->n_lm_inl = s_cnt[1];
 #ifdef VO_LM_STAMPS
-        for (int i = 0; i < 4; ++i) { tr->dbg[i] = g_dbg[i]; g_dbg[i] = 0; }
-        tr->dbg[4] = clock64() - t_kernel0; tr->dbg[5] = n;
+        for (int i = 0; i < 7; ++i) { tr->dbg[i] = g_dbg[i]; g_dbg[i] = 0; }
+        tr->dbg[7] = clock64() - t_kernel0;
 #endif
     }
 }
@@ -710,7 +741,6 @@ int vo_track_match_launch(vo_ctx* c, int slot, float ratio, float floor_dist) {
     hipStream_t st = c->stream;
     const int na = c->n_active;
     c->corr_external = false;
-    HIP_TRY(hipMemsetAsync(&c->d_track->n_cand, 0, sizeof(int), st));
     if (na > 0) {
         { ProfScope ps(c, "k_frustum");
           hipLaunchKernelGGL(k_frustum, dim3((na + 255) / 256), dim3(256), 0, st, cam_of(c), c->d_track, c->d_map_pos, c->d_map_nrm, c->d_map_flags,
@@ -759,9 +789,9 @@ int vo_track_ransac_launch(vo_ctx* c, int n_hyp, float reproj_px, float conf, ui
     return VO_OK;
 }
 
-int vo_track_lm_launch(vo_ctx* c, double delta, double cut, int it_r, int it_p) {
+int vo_track_lm_launch(vo_ctx* c, double delta, double cut, int it_r, int it_p, bool write_flags) {
     ProfScope ps(c, "k_pose_lm");
-    hipLaunchKernelGGL(k_pose_lm, dim3(1), dim3(LM_T), LM_LDS_MAX * 20, c->stream, cam_of(c), c->d_track, c->d_corr_xyz, c->d_corr_uv, c->d_inliers, c->d_lm_mask, delta, cut, it_r, it_p);
+    hipLaunchKernelGGL(k_pose_lm, dim3(1), dim3(LM_T), LM_LDS_MAX * 20, c->stream, cam_of(c), c->d_track, c->d_corr_xyz, c->d_corr_uv, c->d_inliers, c->d_lm_mask, delta, cut, it_r, it_p, write_flags ? c->d_matches : nullptr);
     HIP_TRY(hipGetLastError());
     return VO_OK;
 }

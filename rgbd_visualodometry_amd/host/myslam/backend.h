@@ -1,10 +1,17 @@
 // backend.h -- local bundle adjustment over the covisibility graph of a new keyframe
-// (reference include/myslam/backend.h:21-37, src/backend.cpp:19-195).  The graph is flattened
-// on the host and solved by vo_local_ba on the GPU.  By default the optimisation runs
-// synchronously inside OptimizeCovisibleGraphOfKeyframe (deterministic; removes the
-// tracker/back-end data race of the reference).
+// (reference include/myslam/backend.h:21-37, src/backend.cpp:19-195).  The graph is flattened on the
+// caller's thread and solved by vo_local_ba on the GPU.
+//
+// Scheduling.  The reference solves on a worker thread and writes results back whenever it finishes
+// (racing with the tracker).  Here the solve may also overlap tracking (own worker
+// thread, own vo_ctx / HIP stream), but the result is merged at a DETERMINISTIC point: on the
+// tracker thread, `lag` frames after the keyframe (or at the next keyframe, whichever comes first).
+// lag = 0 (default) solves and merges synchronously inside OptimizeCovisibleGraphOfKeyframe.
 #ifndef MYSLAM_BACKEND_H
 #define MYSLAM_BACKEND_H
+#include <condition_variable>
+#include <thread>
+
 #include "myslam/camera.h"
 #include "myslam/common_include.h"
 #include "myslam/frame.h"
@@ -15,18 +22,37 @@ class Backend {
 public:
     typedef std::shared_ptr<Backend> Ptr;
     Backend(const Camera::Ptr camera);
-    void SetContext(vo_ctx* ctx) { ctx_ = ctx; }
-    void Stop() {}
+    ~Backend();
+    void SetContext(vo_ctx* ctx, int device);        // tracker's context (used when lag == 0)
+    void SetLag(int frames) { lag_ = frames < 0 ? 0 : frames; }
+    void Stop();                                     // finish the pending job, join the worker
     void OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr);
-    struct Stats { int runs = 0, poses = 0, fixed = 0, points = 0, edges = 0, outliers = 0; double ms = 0, ms_build = 0, ms_solve = 0; };
+    // tracker thread, once per frame before tracking: merge a finished/overdue job
+    void Poll(size_t frameIndex);
+    struct Stats { int runs = 0, poses = 0, fixed = 0, points = 0, edges = 0, outliers = 0; double ms = 0, ms_build = 0, ms_solve = 0, ms_wait = 0; };
     const Stats& GetStats() const { return stats_; }
 private:
+    struct Job {
+        std::vector<Frame::Ptr> poseFrames; int nFree = 0;
+        std::vector<Mappoint::Ptr> points;
+        std::vector<int32_t> edgePose, edgePoint; std::vector<float> edgeUv;
+        std::vector<double> poses, pts, posesOut, ptsOut; std::vector<uint8_t> flags;
+        size_t frameIndex = 0; int rc = 0; double solveMs = 0; bool done = false;
+    };
     Camera::Ptr camera_;
-    Frame::Ptr keyframeCurr_;
     float chi2Threshold_;
-    vo_ctx* ctx_ = nullptr;
+    vo_ctx* ctx_ = nullptr;         // tracker context
+    vo_ctx* ctxOwn_ = nullptr;      // worker's own context (lag > 0)
+    int device_ = 0, lag_ = 0;
+    size_t frameIndex_ = 0;
+    std::unique_ptr<Job> job_;
+    std::thread worker_; std::mutex mu_; std::condition_variable cv_; bool quit_ = false, hasWork_ = false;
     Stats stats_;
-    void Optimize();
+    void Build(Job& j, const Frame::Ptr& kf);
+    void Solve(Job& j, vo_ctx* ctx);
+    void Apply(Job& j);
+    void Finish();                  // wait for the pending job and merge it
+    void WorkerLoop();
 };
 }  // namespace myslam
 #endif

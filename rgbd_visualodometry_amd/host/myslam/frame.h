@@ -30,6 +30,8 @@ public:
     std::unordered_set<size_t> GetObservedMappointIds() { std::unique_lock<std::mutex> lck(observationMutex_); return observedMappointIds_; }
     bool IsObservedMappoint(const size_t id) { std::unique_lock<std::mutex> lck(observationMutex_); return observedMappointIds_.count(id) != 0; }
     void UpdateCovisibleKeyframeWeight(const size_t id, const int weight);
+    // insertion-ordered view for deterministic single-threaded iteration (entries may be stale: check IsObservedMappoint)
+    const std::vector<size_t>& ObservedOrder() const { return observedOrder_; }
     std::unordered_set<size_t> GetCovisibleKeyframes() { std::unique_lock<std::mutex> lck(observationMutex_); return activeCovisibleKeyframes_; }
 
     int slot_ = -1;                 // vo_ctx frame slot holding this frame's ORB results (-1: none)
@@ -42,6 +44,7 @@ private:
     SE3 T_c_w_;
     std::mutex observationMutex_;
     std::unordered_set<size_t> observedMappointIds_;
+    std::vector<size_t> observedOrder_;
     CovisibleKeyframeIdToWeight allCovisibleKeyframeIdToWeight_;
     std::unordered_set<size_t> activeCovisibleKeyframes_;    // >= 15 shared map points
     Frame(const size_t id, const double timestamp, const Camera::Ptr camera, const Mat color, const Mat depth);

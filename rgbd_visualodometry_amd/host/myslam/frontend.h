@@ -22,7 +22,7 @@ public:
 
     bool AddFrame(const Frame::Ptr frame);
     void SetViewer(const Viewer::Ptr viewer) { viewer_ = viewer; }
-    void SetBackend(const Backend::Ptr backend) { backend_ = backend; if (backend_) backend_->SetContext(ctx_); }
+    void SetBackend(const Backend::Ptr backend) { backend_ = backend; if (backend_) backend_->SetContext(ctx_, device_); }
     VOState GetState() const { return state_; }
 
     // Look-ahead: upload (or bind) and run batched ORB for upcoming frames of this stream.
@@ -47,13 +47,13 @@ private:
     bool         trackingMapChanged_ = true;
 
     vo_ctx*                 ctx_ = nullptr;
+    int                     device_ = 0;
     vo_params               params_;
     vo_track_params         trackParams_;
     std::vector<KeyPoint>   keypointsCurr_;
     std::vector<Descriptor> descriptorsCurr_;
     std::vector<Mappoint::Ptr> activeList_;                 // device tracking map, in matching order
     std::vector<int> activeIndexOfSlot_;
-    std::vector<Mappoint*> slotToMappoint_;                 // device-map slot -> map point of the active list
     // flannMatchedMptKptMap_ of the reference (frontend.h:73) as parallel arrays in match order
     std::vector<Mappoint::Ptr> flannMatchedMpt_; std::vector<int> flannMatchedKp_; std::vector<char> flannMatchedLm_;
     KeyPointSet flannMatchedKptSet_;
@@ -67,6 +67,7 @@ private:
     uint64_t frameCounter_ = 0;
     Stats stats_;
     std::vector<vo_keypoint> kpBuf_; std::vector<uint8_t> descBuf_; std::vector<vo_match> matchBuf_;
+    std::vector<int32_t> upIdx_; std::vector<double> upXyz_, upNrm_; std::vector<uint8_t> upDesc_, upFlags_;
 
     void Init(int device, int width, int height, int max_frames);
     void InitializationHandler();

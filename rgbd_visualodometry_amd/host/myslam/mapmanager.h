@@ -26,17 +26,23 @@ public:
     MappointIdToPtr GetAllMappoints() { std::unique_lock<std::mutex> lck(dataMutex_); return mappointsDict_; }
     MappointIdToPtr GetMappointsAroundKeyframe(const Frame::Ptr& keyframe);
 
+    Mappoint* FindMappoint(const size_t id) { auto it = mappointsDict_.find(id); return it == mappointsDict_.end() ? nullptr : it->second.get(); }   // no lock, no copy
     size_t MappointCount() { std::unique_lock<std::mutex> lck(dataMutex_); return mappointsDict_.size(); }
-    // map points whose host state is newer than the device copy (drained by the front-end)
-    std::vector<Mappoint::Ptr> TakeDirtyMappoints();
-    void MarkDirty(const Mappoint::Ptr& mp);
+    // map points whose host state is newer than the device copy (drained by the front-end once per frame)
+    void NoteDirty(Mappoint* mp) { dirty_.push_back(mp); }
+    std::vector<Mappoint*> TakeDirty() { std::vector<Mappoint*> d; d.swap(dirty_); return d; }
+    // all map points in insertion (= id) order, and the de-duplicated local map of a keyframe as vectors
+    const std::vector<Mappoint::Ptr>& AllMappointsOrdered() const { return order_; }
+    std::vector<Mappoint::Ptr> CollectMappointsAroundKeyframe(const Frame::Ptr& keyframe);
 
 private:
     std::mutex dataMutex_;
     MappointIdToPtr mappointsDict_;
     KeyframeIdToPtr keyframesDict_;
     int nextSlot_ = 0;
-    std::vector<Mappoint::Ptr> dirty_;
+    std::vector<Mappoint*> dirty_;
+    std::vector<Mappoint::Ptr> order_;
+    uint64_t stamp_ = 0;
 };
 }  // namespace myslam
 #endif

@@ -17,17 +17,20 @@ public:
     static Mappoint::Ptr CreateMappoint(const Vector3d position, const Descriptor& descriptor);
 
     Vector3d GetPosition() { std::unique_lock<std::mutex> lock(posMutex_); return pos_; }
-    void SetPosition(const Vector3d pos) { std::unique_lock<std::mutex> lock(posMutex_); pos_ = pos; dirty_ = true; }
+    void SetPosition(const Vector3d pos) { { std::unique_lock<std::mutex> lock(posMutex_); pos_ = pos; } MarkDirty(); }
     size_t GetId() const { return id_; }
     Vector3d GetNormDirection() { std::unique_lock<std::mutex> lock(observationMutex_); return norm_; }
 
     void AddObservedByKeyframe(const size_t keyframeId, const Point2f posInPixel, const Vector3d cameraCenter);
     void RemoveObservedByKeyframe(const size_t keyframeId);
+    const ObservedByKeyframeIdtoPixelPos& ObservationsNoCopy() const { return observedByKeyframeMap_; }   // single-threaded callers only
     ObservedByKeyframeIdtoPixelPos GetObservedByKeyframesMap() { std::unique_lock<std::mutex> lock(observationMutex_); return observedByKeyframeMap_; }
 
     // device-map bookkeeping (slot in the vo_ctx map, set by MapManager::InsertMappoint)
     int  slot_ = -1;
-    bool dirty_ = true;             // host copy newer than the device copy
+    bool dirty_ = false;            // host copy newer than the device copy (queued in MapManager's dirty list)
+    uint64_t visitStamp_ = 0;       // scratch for de-duplicated traversals
+    void MarkDirty();
 
 private:
     static size_t factoryId_;

@@ -1,5 +1,5 @@
-// backend.cpp -- local BA over the covisibility graph (reference src/backend.cpp:19-195).  The
-// graph is flattened into the vo_ba_problem arrays; the LM/Schur numerics run in vo_local_ba.
+// backend.cpp -- local BA over the covisibility graph (reference src/backend.cpp:19-195).  The graph is
+// flattened into the vo_ba_problem arrays; the LM/Schur numerics run in vo_local_ba.
 #include "myslam/backend.h"
 
 #include <algorithm>
@@ -10,105 +10,157 @@
 
 namespace myslam {
 
+static double ms_since(std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+
 Backend::Backend(const Camera::Ptr camera) : camera_(camera) {
     chi2Threshold_ = Config::has("chi2_th") ? Config::get<float>("chi2_th") : 1.0f;       // backend.h:24
+    if (Config::has("backend_lag_frames")) lag_ = std::max(0, Config::get<int>("backend_lag_frames"));
+}
+
+Backend::~Backend() { Stop(); if (ctxOwn_) vo_ctx_destroy(ctxOwn_); }
+
+void Backend::SetContext(vo_ctx* ctx, int device) { ctx_ = ctx; device_ = device; }
+
+void Backend::Stop() {
+    if (job_) Finish();
+    if (worker_.joinable()) {
+        { std::unique_lock<std::mutex> lk(mu_); quit_ = true; }
+        cv_.notify_all();
+        worker_.join();
+    }
+}
+
+void Backend::WorkerLoop() {
+    for (;;) {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return quit_ || hasWork_; });
+        if (quit_) return;
+        hasWork_ = false;
+        Job* j = job_.get();
+        lk.unlock();
+        Solve(*j, ctxOwn_);
+        lk.lock();
+        j->done = true;
+        cv_.notify_all();
+    }
+}
+
+void Backend::Poll(size_t frameIndex) {
+    frameIndex_ = frameIndex;
+    if (job_ && frameIndex >= job_->frameIndex + (size_t)lag_) Finish();
+}
+
+void Backend::Finish() {
+    auto t0 = std::chrono::steady_clock::now();
+    if (lag_ > 0) { std::unique_lock<std::mutex> lk(mu_); cv_.wait(lk, [&] { return job_->done; }); }
+    stats_.ms_wait += ms_since(t0);
+    std::unique_ptr<Job> j = std::move(job_);
+    if (j->rc != VO_OK) throw std::runtime_error(std::string("vo_local_ba failed: ") + vo_strerror(j->rc));
+    Apply(*j);
 }
 
 void Backend::OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr) {
-    keyframeCurr_ = keyframeCurr;
-    Optimize();
-}
-
-void Backend::Optimize() {
     if (!ctx_) throw std::runtime_error("Backend has no compute context (FrontEnd::SetBackend binds it)");
     auto t0 = std::chrono::steady_clock::now();
-    MapManager& map = MapManager::GetInstance();
+    if (job_) Finish();                              // the previous result is merged before a new graph is cut
+    std::unique_ptr<Job> j(new Job);
+    j->frameIndex = frameIndex_;
+    Build(*j, keyframeCurr);
+    stats_.ms_build += ms_since(t0);
+    if (j->edgePose.empty() || j->nFree == 0) return;
+    job_ = std::move(j);
+    if (lag_ == 0) { Solve(*job_, ctx_); job_->done = true; Finish(); }
+    else {
+        if (!ctxOwn_) {                              // small private context: BA needs scratch + a stream only
+            vo_params p; vo_default_params(&p);
+            p.fx = camera_->GetFx(); p.fy = camera_->GetFy(); p.cx = camera_->GetCx(); p.cy = camera_->GetCy();
+            p.n_features = 64; p.max_frames = 1; p.map_capacity = 64; p.max_hypotheses = 1;
+            int rc = vo_ctx_create(&p, device_, &ctxOwn_);
+            if (rc != VO_OK) throw std::runtime_error(std::string("vo_ctx_create (backend) failed: ") + vo_strerror(rc));
+        }
+        if (!worker_.joinable()) worker_ = std::thread(&Backend::WorkerLoop, this);
+        { std::unique_lock<std::mutex> lk(mu_); hasWork_ = true; }
+        cv_.notify_all();
+    }
+    stats_.ms += ms_since(t0);
+}
 
-    // free poses: covisible keyframes + the current one (backend.cpp:36-59), id order
-    auto covis = keyframeCurr_->GetCovisibleKeyframes();
-    covis.insert(keyframeCurr_->GetId());
+// Flatten: free poses = covisible keyframes + current (backend.cpp:36-59); points = non-outlier map points
+// they observe (:62-81); one edge per observation, observers outside the free set are fixed (:88-135).
+void Backend::Build(Job& j, const Frame::Ptr& kf) {
+    MapManager& map = MapManager::GetInstance();
+    auto covis = kf->GetCovisibleKeyframes();
+    covis.insert(kf->GetId());
     std::vector<size_t> freeIds(covis.begin(), covis.end());
     std::sort(freeIds.begin(), freeIds.end());
-    std::vector<Frame::Ptr> poseFrames;
     std::unordered_map<size_t, int> poseIndex;
-    std::vector<Mappoint::Ptr> points;
-    std::unordered_map<size_t, int> pointIndex;
     for (size_t id : freeIds) {
-        auto kf = map.GetKeyframe(id);
-        if (kf == nullptr) continue;
-        poseIndex[id] = (int)poseFrames.size();
-        poseFrames.push_back(kf);
+        auto f = map.GetKeyframe(id);
+        if (f == nullptr) continue;
+        poseIndex[id] = (int)j.poseFrames.size();
+        j.poseFrames.push_back(f);
     }
-    const int nFree = (int)poseFrames.size();
-    // points: every non-outlier map point observed by a free keyframe (backend.cpp:62-81)
-    for (int j = 0; j < nFree; ++j) {
-        auto obs = poseFrames[j]->GetObservedMappointIds();
-        std::vector<size_t> ids(obs.begin(), obs.end());
-        std::sort(ids.begin(), ids.end());
-        for (size_t mpId : ids) {
-            if (pointIndex.count(mpId)) continue;
+    j.nFree = (int)j.poseFrames.size();
+    std::unordered_map<size_t, int> pointIndex;
+    for (int p = 0; p < j.nFree; ++p) {
+        Frame& f = *j.poseFrames[p];
+        for (size_t mpId : f.ObservedOrder()) {          // insertion order: deterministic without sorting
+            if (pointIndex.count(mpId) || !f.IsObservedMappoint(mpId)) continue;
             auto mp = map.GetMappoint(mpId);
             if (mp == nullptr || mp->outlier_) continue;
-            pointIndex[mpId] = (int)points.size();
-            points.push_back(mp);
+            pointIndex[mpId] = (int)j.points.size();
+            j.points.push_back(mp);
         }
     }
-    // edges: every observation of those points; observers outside the free set are fixed (backend.cpp:88-135)
-    std::vector<int32_t> edgePose, edgePoint; std::vector<float> edgeUv;
-    std::vector<std::pair<Frame::Ptr, Mappoint::Ptr>> edgeOwner;
-    for (size_t k = 0; k < points.size(); ++k) {
-        auto obs = points[k]->GetObservedByKeyframesMap();
-        std::vector<size_t> kfIds;
-        for (auto& kv : obs) kfIds.push_back(kv.first);
-        std::sort(kfIds.begin(), kfIds.end());
-        for (size_t kfId : kfIds) {
-            auto kf = map.GetKeyframe(kfId);
-            if (kf == nullptr) continue;
-            auto it = poseIndex.find(kfId);
+    std::vector<std::pair<size_t, Point2f>> obs;
+    for (size_t k = 0; k < j.points.size(); ++k) {
+        obs.assign(j.points[k]->ObservationsNoCopy().begin(), j.points[k]->ObservationsNoCopy().end());
+        std::sort(obs.begin(), obs.end(), [](const std::pair<size_t, Point2f>& a, const std::pair<size_t, Point2f>& b) { return a.first < b.first; });
+        for (auto& o : obs) {
+            auto it = poseIndex.find(o.first);
             int pj;
             if (it != poseIndex.end()) pj = it->second;
-            else { pj = (int)poseFrames.size(); poseIndex[kfId] = pj; poseFrames.push_back(kf); }
-            edgePose.push_back(pj); edgePoint.push_back((int)k);
-            edgeUv.push_back(obs[kfId].x); edgeUv.push_back(obs[kfId].y);
-            edgeOwner.emplace_back(kf, points[k]);
+            else {
+                auto f = map.GetKeyframe(o.first);
+                if (f == nullptr) continue;
+                pj = (int)j.poseFrames.size(); poseIndex[o.first] = pj; j.poseFrames.push_back(f);
+            }
+            j.edgePose.push_back(pj); j.edgePoint.push_back((int)k);
+            j.edgeUv.push_back(o.second.x); j.edgeUv.push_back(o.second.y);
         }
     }
-    if (edgePose.empty() || nFree == 0) return;
+    j.poses.resize(12 * j.poseFrames.size()); j.pts.resize(3 * j.points.size());
+    for (size_t p = 0; p < j.poseFrames.size(); ++p) j.poseFrames[p]->GetPose().to12(&j.poses[12 * p]);
+    for (size_t k = 0; k < j.points.size(); ++k) { Vector3d x = j.points[k]->GetPosition(); j.pts[3 * k] = x[0]; j.pts[3 * k + 1] = x[1]; j.pts[3 * k + 2] = x[2]; }
+    j.posesOut.resize(12 * (size_t)std::max(j.nFree, 1)); j.ptsOut.resize(3 * std::max<size_t>(j.points.size(), 1)); j.flags.resize(std::max<size_t>(j.edgePose.size(), 1));
+}
 
-    std::vector<double> poses(12 * poseFrames.size()), pts(3 * points.size());
-    for (size_t j = 0; j < poseFrames.size(); ++j) poseFrames[j]->GetPose().to12(&poses[12 * j]);
-    for (size_t k = 0; k < points.size(); ++k) { Vector3d p = points[k]->GetPosition(); pts[3 * k] = p[0]; pts[3 * k + 1] = p[1]; pts[3 * k + 2] = p[2]; }
+void Backend::Solve(Job& j, vo_ctx* ctx) {
+    auto t0 = std::chrono::steady_clock::now();
     vo_ba_problem prob;
-    prob.n_poses = (int)poseFrames.size(); prob.n_free = nFree; prob.n_points = (int)points.size(); prob.n_edges = (int)edgePose.size();
-    prob.poses = poses.data(); prob.points = pts.data(); prob.edge_pose = edgePose.data(); prob.edge_point = edgePoint.data(); prob.edge_uv = edgeUv.data();
-    prob.huber_delta = std::sqrt(7.815); prob.chi2_th = chi2Threshold_; prob.it_robust = 10; prob.it_plain = 10;
-    std::vector<double> posesOut(12 * (size_t)nFree), ptsOut(3 * points.size());
-    std::vector<uint8_t> flags(edgePose.size());
+    prob.n_poses = (int)j.poseFrames.size(); prob.n_free = j.nFree; prob.n_points = (int)j.points.size(); prob.n_edges = (int)j.edgePose.size();
+    prob.poses = j.poses.data(); prob.points = j.pts.data(); prob.edge_pose = j.edgePose.data(); prob.edge_point = j.edgePoint.data(); prob.edge_uv = j.edgeUv.data();
+    prob.huber_delta = std::sqrt(7.815); prob.chi2_th = chi2Threshold_; prob.it_robust = 10; prob.it_plain = 10;      // backend.cpp:83,141,159
     vo_ba_result res;
     std::memset(&res, 0, sizeof(res));
-    res.poses = posesOut.data(); res.points = ptsOut.data(); res.edge_flags = flags.data();
-    auto t1 = std::chrono::steady_clock::now();
-    int rc = vo_local_ba(ctx_, &prob, &res);
-    auto t2 = std::chrono::steady_clock::now();
-    stats_.ms_build += std::chrono::duration<double, std::milli>(t1 - t0).count(); stats_.ms_solve += std::chrono::duration<double, std::milli>(t2 - t1).count();
-    if (rc != VO_OK) throw std::runtime_error(std::string("vo_local_ba failed: ") + vo_strerror(rc));
+    res.poses = j.posesOut.data(); res.points = j.ptsOut.data(); res.edge_flags = j.flags.data();
+    j.rc = vo_local_ba(ctx, &prob, &res);
+    j.solveMs = ms_since(t0);
+}
 
+void Backend::Apply(Job& j) {
     int outlierCnt = 0;
-    for (size_t e = 0; e < flags.size(); ++e) {                                 // backend.cpp:144-172
-        if (flags[e] & 3) {
-            auto& kf = edgeOwner[e].first; auto& mp = edgeOwner[e].second;
-            if (kf->IsObservedMappoint(mp->GetId())) kf->RemoveObservedMappoint(mp->GetId());
-            ++outlierCnt;
-        }
-        edgeOwner[e].second->optimized_ = true;
+    for (size_t e = 0; e < j.edgePose.size(); ++e) {                          // backend.cpp:144-172
+        Frame& f = *j.poseFrames[j.edgePose[e]];
+        Mappoint& mp = *j.points[j.edgePoint[e]];
+        if (j.flags[e] & 3) { if (f.IsObservedMappoint(mp.GetId())) f.RemoveObservedMappoint(mp.GetId()); ++outlierCnt; }
+        mp.optimized_ = true;
     }
-    for (int j = 0; j < nFree; ++j) poseFrames[j]->SetPose(SE3::from12(&posesOut[12 * (size_t)j]));     // backend.cpp:183-187
-    for (size_t k = 0; k < points.size(); ++k)                                                           // backend.cpp:188-194
-        if (!points[k]->outlier_) points[k]->SetPosition(Vector3d(ptsOut[3 * k], ptsOut[3 * k + 1], ptsOut[3 * k + 2]));
-
-    stats_.runs++; stats_.poses = nFree; stats_.fixed = (int)poseFrames.size() - nFree; stats_.points = (int)points.size();
-    stats_.edges = (int)edgePose.size(); stats_.outliers = outlierCnt;
-    stats_.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (int p = 0; p < j.nFree; ++p) j.poseFrames[p]->SetPose(SE3::from12(&j.posesOut[12 * (size_t)p]));       // backend.cpp:183-187
+    for (size_t k = 0; k < j.points.size(); ++k)                                                                 // backend.cpp:188-194
+        if (!j.points[k]->outlier_) j.points[k]->SetPosition(Vector3d(j.ptsOut[3 * k], j.ptsOut[3 * k + 1], j.ptsOut[3 * k + 2]));
+    stats_.runs++; stats_.poses = j.nFree; stats_.fixed = (int)j.poseFrames.size() - j.nFree; stats_.points = (int)j.points.size();
+    stats_.edges = (int)j.edgePose.size(); stats_.outliers = outlierCnt; stats_.ms_solve += j.solveMs;
 }
 
 }  // namespace myslam

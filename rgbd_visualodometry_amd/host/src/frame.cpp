@@ -34,6 +34,7 @@ void Frame::AddObservedMappoint(const size_t mappointId, const Point2f pixelPos)
     std::unique_lock<std::mutex> lck(observationMutex_);
     assert(!observedMappointIds_.count(mappointId));
     observedMappointIds_.insert(mappointId);
+    observedOrder_.push_back(mappointId);
     auto mappoint = MapManager::GetInstance().GetMappoint(mappointId);
     assert(mappoint != nullptr);
     mappoint->AddObservedByKeyframe(id_, pixelPos, GetCamCenter());

@@ -32,6 +32,7 @@ FrontEnd::FrontEnd(int device, int width, int height, int max_frames) { Init(dev
 
 void FrontEnd::Init(int device, int width, int height, int max_frames) {
     state_ = INITIALIZING;
+    device_ = device;
     accuLostFrameNums_ = 0;                                           // (uninitialised in the reference, frontend.h:59)
     vo_default_params(&params_);
     params_.width = width; params_.height = height;
@@ -52,7 +53,7 @@ void FrontEnd::Init(int device, int width, int height, int max_frames) {
     trackParams_.n_hyp = cfg_or<int>("ransac_iterations", 100);                            // :240
     params_.max_hypotheses = std::max(params_.max_hypotheses, trackParams_.n_hyp);
     vo_check(vo_ctx_create(&params_, device, &ctx_), "vo_ctx_create");
-    if (backend_) backend_->SetContext(ctx_);
+    if (backend_) backend_->SetContext(ctx_, device_);
 }
 
 FrontEnd::~FrontEnd() { if (ctx_) vo_ctx_destroy(ctx_); }
@@ -61,6 +62,7 @@ bool FrontEnd::AddFrame(const Frame::Ptr frame) {
     if (verbose_) std::cout << "Frontend status: " << (state_ == INITIALIZING ? "Initializing" : state_ == TRACKING ? "Tracking" : "Lost") << std::endl;
     frameCurr_ = frame;
     ++stats_.frames;
+    if (backend_) { StageTimer t(stats_.ms_backend); backend_->Poll((size_t)stats_.frames); }   // deterministic merge point of an overlapped BA
     switch (state_) {
         case INITIALIZING: InitializationHandler(); break;
         case TRACKING: if (!TrackingHandler()) return false; break;
@@ -152,38 +154,37 @@ void FrontEnd::RefreshTrackingMap() {
     bool changed = false;
     if (keyframeForTrackingMap_ != keyframeRef_) {                                  // frontend.cpp:159-162
         keyframeForTrackingMap_ = keyframeRef_;
-        trackingMap_ = MapManager::GetInstance().GetMappointsAroundKeyframe(keyframeRef_);
+        activeList_ = MapManager::GetInstance().CollectMappointsAroundKeyframe(keyframeRef_);
         changed = true;
     }
-    if (trackingMap_.size() < 100) {                                                // frontend.cpp:163-166
-        trackingMap_ = MapManager::GetInstance().GetAllMappoints();
+    if (activeList_.size() < 100) {                                                 // frontend.cpp:163-166
+        activeList_ = MapManager::GetInstance().AllMappointsOrdered();
         changed = true;
     }
     if (!changed) return;
-    activeList_.clear();
-    for (auto& kv : trackingMap_) activeList_.push_back(kv.second);
-    std::sort(activeList_.begin(), activeList_.end(), [](const Mappoint::Ptr& a, const Mappoint::Ptr& b) { return a->GetId() < b->GetId(); });
     std::vector<int32_t> slots(activeList_.size());
     int maxSlot = -1;
     for (auto& mp : activeList_) maxSlot = std::max(maxSlot, mp->slot_);
-    slotToMappoint_.assign((size_t)maxSlot + 1, nullptr);
     activeIndexOfSlot_.assign((size_t)maxSlot + 1, -1);
-    for (size_t i = 0; i < activeList_.size(); ++i) { slots[i] = activeList_[i]->slot_; slotToMappoint_[slots[i]] = activeList_[i].get(); activeIndexOfSlot_[slots[i]] = (int)i; }
+    for (size_t i = 0; i < activeList_.size(); ++i) { slots[i] = activeList_[i]->slot_; activeIndexOfSlot_[slots[i]] = (int)i; }
     vo_check(vo_map_set_active(ctx_, slots.data(), (int)slots.size()), "vo_map_set_active");
 }
 
 void FrontEnd::FlushDirtyMappoints() {
-    std::vector<int32_t> idx; std::vector<double> xyz, nrm; std::vector<uint8_t> desc, flags;
-    for (auto& mp : activeList_) {
-        if (!mp->dirty_) continue;
+    std::vector<Mappoint*> dirty = MapManager::GetInstance().TakeDirty();
+    if (dirty.empty()) return;
+    const size_t n = dirty.size();
+    upIdx_.resize(n); upXyz_.resize(3 * n); upNrm_.resize(3 * n); upDesc_.resize(32 * n); upFlags_.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+        Mappoint* mp = dirty[i];
         mp->dirty_ = false;
-        idx.push_back(mp->slot_);
-        Vector3d p = mp->GetPosition(), n = mp->GetNormDirection();
-        for (int a = 0; a < 3; ++a) { xyz.push_back(p[a]); nrm.push_back(n[a]); }
-        desc.insert(desc.end(), mp->descriptor_.begin(), mp->descriptor_.end());
-        flags.push_back(mp->outlier_ ? VO_MAP_FLAG_OUTLIER : 0);
+        upIdx_[i] = mp->slot_;
+        Vector3d p = mp->GetPosition(), nr = mp->GetNormDirection();
+        for (int a = 0; a < 3; ++a) { upXyz_[3 * i + a] = p[a]; upNrm_[3 * i + a] = nr[a]; }
+        std::memcpy(&upDesc_[32 * i], mp->descriptor_.data(), 32);
+        upFlags_[i] = mp->outlier_ ? VO_MAP_FLAG_OUTLIER : 0;
     }
-    if (!idx.empty()) vo_check(vo_map_upsert(ctx_, idx.data(), xyz.data(), nrm.data(), desc.data(), flags.data(), (int)idx.size()), "vo_map_upsert");
+    vo_check(vo_map_upsert(ctx_, upIdx_.data(), upXyz_.data(), upNrm_.data(), upDesc_.data(), upFlags_.data(), (int)n), "vo_map_upsert");
 }
 
 void FrontEnd::MatchAndEstimatePose() {
@@ -193,7 +194,7 @@ void FrontEnd::MatchAndEstimatePose() {
     frameCurr_->GetPose().to12(prior);
     vo_track_result res;
     const int cap = (int)activeList_.size() + 1;
-    matchBuf_.resize(cap);
+    if ((int)matchBuf_.size() < cap) matchBuf_.resize(cap);
     trackParams_.seed = 0x5eed5eedull + 2 * frameCounter_++;
     vo_check(vo_track_frame(ctx_, frameCurr_->slot_, prior, &trackParams_, &res, matchBuf_.data(), cap), "vo_track_frame");
     if (res.status != VO_OK) throw std::runtime_error(std::string("device pipeline: ") + vo_strerror(res.status));
@@ -215,7 +216,7 @@ void FrontEnd::MatchAndEstimatePose() {
     stats_.last_candidates = res.n_candidates; stats_.last_matches = res.n_matches;
     stats_.last_ransac = res.n_ransac_inliers; stats_.last_lm = res.n_lm_inliers;
     if (verbose_)
-        std::cout << "  tracking map " << trackingMap_.size() << ", candidates " << res.n_candidates << ", matches " << res.n_matches
+        std::cout << "  tracking map " << activeList_.size() << ", candidates " << res.n_candidates << ", matches " << res.n_matches
                   << ", PnP inliers " << res.n_ransac_inliers << ", LM inliers " << res.n_lm_inliers << std::endl;
 }
 

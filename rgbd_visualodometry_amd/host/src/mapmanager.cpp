@@ -1,6 +1,8 @@
 // mapmanager.cpp -- reference src/mapmanager.cpp:14-38, include/myslam/mapmanager.h:23-58.
 #include "myslam/mapmanager.h"
 
+#include <algorithm>
+
 namespace myslam {
 namespace { thread_local MapManager* t_bound = nullptr; }
 
@@ -13,7 +15,7 @@ void MapManager::BindToThread(MapManager* m) { t_bound = m; }
 
 void MapManager::InsertMappoint(const Mappoint::Ptr& mp) {
     std::unique_lock<std::mutex> lck(dataMutex_);
-    if (mp->slot_ < 0) mp->slot_ = nextSlot_++;
+    if (mp->slot_ < 0) { mp->slot_ = nextSlot_++; order_.push_back(mp); mp->dirty_ = true; dirty_.push_back(mp.get()); }
     mappointsDict_[mp->GetId()] = mp;
 }
 
@@ -34,6 +36,29 @@ MapManager::MappointIdToPtr MapManager::GetMappointsAroundKeyframe(const Frame::
     return local;
 }
 
-std::vector<Mappoint::Ptr> MapManager::TakeDirtyMappoints() { std::unique_lock<std::mutex> lck(dataMutex_); std::vector<Mappoint::Ptr> d; d.swap(dirty_); return d; }
-void MapManager::MarkDirty(const Mappoint::Ptr& mp) { std::unique_lock<std::mutex> lck(dataMutex_); dirty_.push_back(mp); }
+// Same set as GetMappointsAroundKeyframe (mapmanager.cpp:14-38) as a vector: keyframes in id order, each
+// keyframe's observations in insertion order, de-duplicated with a visit stamp (no hash-map copies).
+std::vector<Mappoint::Ptr> MapManager::CollectMappointsAroundKeyframe(const Frame::Ptr& keyframe) {
+    std::unique_lock<std::mutex> lck(dataMutex_);
+    auto ids = keyframe->GetCovisibleKeyframes();
+    ids.insert(keyframe->GetId());
+    std::vector<size_t> kfs(ids.begin(), ids.end());
+    std::sort(kfs.begin(), kfs.end());
+    std::vector<Mappoint::Ptr> out;
+    const uint64_t stamp = ++stamp_;
+    for (size_t kfId : kfs) {
+        auto kf = keyframesDict_.find(kfId);
+        assert(kf != keyframesDict_.end());
+        Frame& f = *kf->second;
+        for (size_t mpId : f.ObservedOrder()) {
+            auto it = mappointsDict_.find(mpId);
+            if (it == mappointsDict_.end()) continue;
+            Mappoint& mp = *it->second;
+            if (mp.visitStamp_ == stamp || mp.outlier_ || !f.IsObservedMappoint(mpId)) continue;
+            mp.visitStamp_ = stamp;
+            out.push_back(it->second);
+        }
+    }
+    return out;
+}
 }  // namespace myslam

@@ -1,6 +1,8 @@
 // mappoint.cpp -- reference src/mappoint.cpp:17-49, include/myslam/mappoint.h:59-64.
 #include "myslam/mappoint.h"
 
+#include "myslam/mapmanager.h"
+
 namespace myslam {
 size_t Mappoint::factoryId_ = 0;
 
@@ -16,13 +18,20 @@ void Mappoint::AddObservedByKeyframe(const size_t keyframeId, const Point2f posI
     assert(!observedByKeyframeMap_.count(keyframeId));
     observedByKeyframeMap_[keyframeId] = posInPixel;
     norm_ = (norm_ + (pos_ - cameraCenter).normalized()).normalized();      // running mean viewing direction
-    dirty_ = true;
+    lock.unlock();
+    MarkDirty();
 }
 
 void Mappoint::RemoveObservedByKeyframe(const size_t keyframeId) {
     std::unique_lock<std::mutex> lock(observationMutex_);
     assert(observedByKeyframeMap_.count(keyframeId));
     observedByKeyframeMap_.erase(keyframeId);
-    if (observedByKeyframeMap_.empty()) { outlier_ = true; dirty_ = true; }  // no observation left
+    if (observedByKeyframeMap_.empty()) { outlier_ = true; lock.unlock(); MarkDirty(); }  // no observation left
+}
+
+void Mappoint::MarkDirty() {
+    if (dirty_ || slot_ < 0) return;            // not yet inserted: InsertMappoint queues it
+    dirty_ = true;
+    MapManager::GetInstance().NoteDirty(this);
 }
 }  // namespace myslam

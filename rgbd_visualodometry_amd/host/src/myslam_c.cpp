@@ -49,7 +49,7 @@ int myslam_default_options(myslam_options* o) {
     o->width = 640; o->height = 480; o->fx = 517.3f; o->fy = 516.5f; o->cx = 318.6f; o->cy = 255.3f; o->depth_scale = 5000.f;
     o->number_of_features = 500; o->scale_factor = 1.2f; o->level_pyramid = 8; o->match_ratio = 2.0f; o->max_num_lost = 10;
     o->min_inliers = 10; o->keyframe_rotation = 0.05; o->keyframe_translation = 0.05; o->enable_local_optimization = 1; o->chi2_th = 1.f;
-    o->ransac_iterations = 100; o->max_frames_in_flight = 1; o->map_capacity = 1 << 20; o->device = 0; o->verbose = 0;
+    o->ransac_iterations = 100; o->backend_lag_frames = 0; o->max_frames_in_flight = 1; o->map_capacity = 1 << 20; o->device = 0; o->verbose = 0;
     return 0;
 }
 
@@ -72,7 +72,7 @@ int myslam_system_create(const myslam_options* o, const char* yaml, myslam_syste
         s->camera = Camera::Ptr(new Camera);
         s->frontend = FrontEnd::Ptr(new FrontEnd(o->device, o->width, o->height, o->max_frames_in_flight));
         s->frontend->verbose_ = o->verbose != 0;
-        if (Config::get<int>("enable_local_optimization")) { s->backend = Backend::Ptr(new Backend(s->camera)); s->frontend->SetBackend(s->backend); }
+        if (Config::get<int>("enable_local_optimization")) { s->backend = Backend::Ptr(new Backend(s->camera)); s->backend->SetLag(o->backend_lag_frames); s->frontend->SetBackend(s->backend); }
     });
     if (rc) { delete s; return rc; }
     *out = s;
@@ -82,6 +82,7 @@ int myslam_system_create(const myslam_options* o, const char* yaml, myslam_syste
 void myslam_system_destroy(myslam_system* s) {
     if (!s) return;
     MapManager::BindToThread(&s->map);
+    if (s->backend) { try { s->backend->Stop(); } catch (...) {} }
     s->queue.clear(); s->frontend.reset(); s->backend.reset();
     MapManager::BindToThread(nullptr);
     delete s;
@@ -132,7 +133,7 @@ int myslam_get_stats(myslam_system* s, myslam_stats* st) {
     if (s->backend) {
         const auto& b = s->backend->GetStats();
         st->ba_runs = b.runs; st->ba_poses = b.poses; st->ba_fixed = b.fixed; st->ba_points = b.points; st->ba_edges = b.edges; st->ba_outliers = b.outliers; st->ba_ms = b.ms;
-        if (getenv("VO_TRACE")) fprintf(stderr, "[vo_trace] BA runs %d build %.2f ms solve %.2f ms total %.2f ms\n", b.runs, b.ms_build, b.ms_solve, b.ms);
+        if (getenv("VO_TRACE")) fprintf(stderr, "[vo_trace] BA runs %d build %.2f ms solve %.2f ms wait %.2f ms\n", b.runs, b.ms_build, b.ms_solve, b.ms_wait);
     }
     return 0;
 }

@@ -1,5 +1,5 @@
 import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, time
+import numpy as np
 from rgbd_visualodometry_amd import capi
 syn = capi.Synth(); sp = syn.params(seed=0)
 bgr, depth, Twc, ts = syn.render(sp, 0, 10)
@@ -17,4 +17,4 @@ tp = L.default_track_params(passes=1)
 for rep in range(3):
     res, m = ctx.track(1, inv12(Twc[0]), tp)
     r = list(res.reserved)
-    print("n_inl", r[5], "lm_iters", res.lm_iters, "passes", r[2], "it", r[3], "pass cycles", r[0]*16, "serial cycles", r[1]*16, "kernel cycles", r[4]*16)
+    print("n_inl", res.n_ransac_inliers, "lm_iters", res.lm_iters, "passes", r[2], "| pass", r[0]*16, "serial", r[1]*16, "| loop", r[4]*16, "wave-reduce", r[5]*16, "lds+barriers", res.n_lm_inliers*16, "| kernel", r[6]*16)
