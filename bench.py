@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--lookahead", type=int, default=32, help="frames per batched ORB launch chain")
+    ap.add_argument("--track-batch", type=int, default=1, help="frames tracked speculatively per launch chain (share prior + map)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-ba", action="store_true", help="disable local BA (enable_local_optimization: 0)")
     ap.add_argument("--ba-lag", type=int, default=0, help="0: BA synchronous in AddFrame; L>0: overlapped, merged L frames later (deterministic)")
@@ -99,7 +100,7 @@ def main():
     dptr = [d_depth.data_ptr() + i * fd for i in range(total)]
 
     opts = dict(width=W, height=H, number_of_features=N, max_frames_in_flight=args.lookahead, device=local_rank,
-                enable_local_optimization=0 if args.no_ba else 1, backend_lag_frames=args.ba_lag, map_capacity=1 << 20)
+                enable_local_optimization=0 if args.no_ba else 1, backend_lag_frames=args.ba_lag, track_batch=args.track_batch, map_capacity=1 << 20)
     sysm = system.VoSystem(system.HOST_LIB, **opts)
     assert sysm.backend == "hip-gfx950", sysm.backend
 
@@ -189,7 +190,7 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             nf = min(args.cpu_frames, total)
-            o = system.VoSystem(system.ORACLE_LIB, **{**opts, "max_frames_in_flight": 1})
+            o = system.VoSystem(system.ORACLE_LIB, **{**opts, "max_frames_in_flight": 1, "track_batch": 1})
             est_c = {}
             tc = time.perf_counter()
             for i in range(nf):
@@ -207,7 +208,7 @@ def main():
             "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/f64", "data": "synthetic",
             "config": {"workload": "synthetic 640x480 RGB-D stream per GPU, %d ORB features, default.yaml tracking parameters" % N,
-                       "streams_per_gpu": 1, "lookahead_frames": args.lookahead, "local_ba": (False if args.no_ba else ("synchronous" if args.ba_lag == 0 else "overlapped, merged %d frames later" % args.ba_lag)), "ransac_hypotheses": 100},
+                       "streams_per_gpu": 1, "lookahead_frames": args.lookahead, "track_batch": args.track_batch, "local_ba": (False if args.no_ba else ("synchronous" if args.ba_lag == 0 else "overlapped, merged %d frames later" % args.ba_lag)), "ransac_hypotheses": 100},
             "ate_rmse_m": round(ate_gpu, 5), "keyframes": st["keyframes"], "lost": st["lost"], "map_points": st["map_points"],
             "alg_bytes_per_frame_survey": b_survey, "hbm_frac_whole_frame": round(b_survey * (fps / world) / (HBM_PEAK_GBS * 1e9), 6),
             "render_s": round(t_render, 2),

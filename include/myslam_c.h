@@ -28,6 +28,7 @@ typedef struct myslam_options {
     int32_t backend_lag_frames;             /* 0: BA solved + merged inside AddFrame; L>0: solved on a worker thread,
                                                merged deterministically L frames later (or at the next keyframe) */
     int32_t max_frames_in_flight;           /* look-ahead ORB batch (1 = none) */
+    int32_t track_batch;                    /* frames tracked speculatively in one launch chain (1 = none, <= 16) */
     int32_t map_capacity;
     int32_t device;
     int32_t verbose;

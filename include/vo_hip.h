@@ -12,6 +12,7 @@
  *   vo_pnp_ransac           <- cv::solvePnPRansac                  src/frontend.cpp:238-254
  *   vo_pose_refine_lm       <- g2o pose-only LM (2 x 10 iters)     src/frontend.cpp:257-329, include/myslam/g2o_types.h:47-108
  *   vo_track_frame          <- FrontEnd::TrackingHandler :102-108  (coarse + fine pass fused, one host sync)
+ *   vo_track_batch          <- the same for several frames that share prior + map (one launch chain)
  *   vo_local_ba             <- Backend::Optimize                   src/backend.cpp:19-195, include/myslam/g2o_types.h:111-179
  *   vo_frame_upload         <- Frame::CreateFrame deep copy        src/frame.cpp:18-31
  *   vo_map_upsert/_set_active <- MapManager + trackingMap_         src/mapmanager.cpp:14-38, src/frontend.cpp:159-166
@@ -60,7 +61,8 @@ typedef struct vo_params {
     int32_t max_frames;             /* frame slots (frames in flight for batched ORB), >=1 */
     int32_t map_capacity;           /* device map capacity in points                        */
     int32_t max_hypotheses;         /* RANSAC hypothesis capacity (>= n_hyp ever passed)    */
-    int32_t reserved[8];
+    int32_t max_track_batch;        /* frames tracked concurrently by vo_track_batch (0/1 = one) */
+    int32_t reserved[7];
 } vo_params;
 
 /* cv::KeyPoint's seven fields + the raw depth sample of Frame::GetDepth. */
@@ -191,6 +193,13 @@ int vo_pose_refine_lm(vo_ctx* ctx, double T_cw_inout[12], double huber_delta, do
 /* ---- fused per-frame tracking ------------------------------------------------------- */
 int vo_track_frame(vo_ctx* ctx, int slot, const double T_cw_prior[12], const vo_track_params* tp,
                    vo_track_result* res, vo_match* matches, int cap);
+
+/* Track n frames (slots[i]) that share the prior pose and the map in ONE batched launch chain.
+ * Frames between two keyframes are independent of each other: the reference's prior is the last
+ * keyframe's pose (src/frontend.cpp:96), not the previous frame's.  res[i] / matches[i*cap ..] per
+ * frame; seeds[i] replaces tp->seed for frame i.  n <= max_track_batch. */
+int vo_track_batch(vo_ctx* ctx, int n, const int* slots, const double T_cw_prior[12], const vo_track_params* tp,
+                   const uint64_t* seeds, vo_track_result* res, vo_match* matches, int cap);
 
 /* ---- local bundle adjustment --------------------------------------------------------- */
 int vo_local_ba(vo_ctx* ctx, const vo_ba_problem* in, vo_ba_result* out);

@@ -49,7 +49,7 @@ int vo_default_params(vo_params* p) {
     std::memset(p, 0, sizeof(*p));
     p->width = 640; p->height = 480; p->fx = 517.3f; p->fy = 516.5f; p->cx = 318.6f; p->cy = 255.3f; p->depth_scale = 5000.f;
     p->n_features = 500; p->scale_factor = 1.2f; p->n_levels = 8; p->fast_threshold = 20; p->edge_threshold = 31;
-    p->max_frames = 1; p->map_capacity = 1 << 18; p->max_hypotheses = 2048;
+    p->max_frames = 1; p->map_capacity = 1 << 18; p->max_hypotheses = 2048; p->max_track_batch = 1;
     return VO_OK;
 }
 
@@ -244,6 +244,19 @@ int vo_track_frame(vo_ctx* c, int slot, const double T0[12], const vo_track_para
     std::memcpy(res->T_cw, T, sizeof(T));
     if (matches) std::memcpy(matches, c->last_matches.data(), sizeof(vo_match) * std::min<size_t>(cap, c->last_matches.size()));
     if ((int)c->last_matches.size() > cap && matches) res->status = VO_E_OVERFLOW;
+    return VO_OK;
+}
+
+int vo_track_batch(vo_ctx* c, int n, const int* slots, const double T0[12], const vo_track_params* tp, const uint64_t* seeds,
+                   vo_track_result* res, vo_match* matches, int cap) {
+    if (!c || n < 1 || !slots || !T0 || !tp || !res || cap < 0) return VO_E_INVALID;
+    if (n > std::max(1, c->p.max_track_batch)) return VO_E_INVALID;
+    for (int i = 0; i < n; ++i) {                  // frames sharing prior + map are independent: a plain loop on the CPU
+        vo_track_params t = *tp;
+        if (seeds) t.seed = seeds[i];
+        int rc = vo_track_frame(c, slots[i], T0, &t, &res[i], matches ? matches + (size_t)i * cap : nullptr, cap);
+        if (rc) return rc;
+    }
     return VO_OK;
 }
 

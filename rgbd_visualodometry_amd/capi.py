@@ -25,7 +25,7 @@ class VoParams(C.Structure):
                 ("cx", C.c_float), ("cy", C.c_float), ("depth_scale", C.c_float), ("n_features", C.c_int32),
                 ("scale_factor", C.c_float), ("n_levels", C.c_int32), ("fast_threshold", C.c_int32),
                 ("edge_threshold", C.c_int32), ("max_frames", C.c_int32), ("map_capacity", C.c_int32),
-                ("max_hypotheses", C.c_int32), ("reserved", C.c_int32 * 8)]
+                ("max_hypotheses", C.c_int32), ("max_track_batch", C.c_int32), ("reserved", C.c_int32 * 7)]
 
 
 class VoTrackParams(C.Structure):
@@ -63,7 +63,7 @@ MATCH_DTYPE = np.dtype([("map_index", "<i4"), ("kp_index", "<i4"), ("distance", 
 SYMBOLS = ["vo_ctx_create", "vo_ctx_destroy", "vo_strerror", "vo_backend_name", "vo_default_params",
            "vo_default_track_params", "vo_frame_upload", "vo_frame_bind_device", "vo_orb_detect_describe",
            "vo_orb_fetch", "vo_orb_level_size", "vo_orb_fetch_level", "vo_map_upsert", "vo_map_set_active",
-           "vo_match_active_map", "vo_matches_set", "vo_pnp_ransac", "vo_pose_refine_lm", "vo_track_frame",
+           "vo_match_active_map", "vo_matches_set", "vo_pnp_ransac", "vo_pose_refine_lm", "vo_track_frame", "vo_track_batch",
            "vo_local_ba", "vo_sync", "vo_profile_enable", "vo_profile_read"]
 
 
@@ -111,6 +111,7 @@ class VoLib:
                                         C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.vo_track_frame.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(VoTrackParams), C.POINTER(VoTrackResult),
                                      C.c_void_p, C.c_int]
+        L.vo_track_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(VoTrackParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.vo_local_ba.argtypes = [C.c_void_p, C.POINTER(VoBaProblem), C.POINTER(VoBaResult)]
         L.vo_sync.argtypes = [C.c_void_p]
         L.vo_profile_enable.argtypes = [C.c_void_p, C.c_int]
@@ -243,6 +244,16 @@ class VoContext:
         m = np.zeros(cap, dtype=MATCH_DTYPE)
         self.L.check(self.L.lib.vo_track_frame(self.h, slot, _ptr(T), C.byref(tp), C.byref(res), _ptr(m), cap), "vo_track_frame")
         return res, m[:min(res.n_matches, cap)].copy()
+
+    def track_batch(self, slots, T_prior, tp: VoTrackParams, seeds, cap=4096):
+        n = len(slots)
+        sl = np.ascontiguousarray(slots, dtype=np.int32)
+        sd = np.ascontiguousarray(seeds, dtype=np.uint64)
+        T = np.ascontiguousarray(T_prior, dtype=np.float64).reshape(12)
+        res = (VoTrackResult * n)()
+        m = np.zeros((n, cap), dtype=MATCH_DTYPE)
+        self.L.check(self.L.lib.vo_track_batch(self.h, n, _ptr(sl), _ptr(T), C.byref(tp), _ptr(sd), C.cast(res, C.c_void_p), _ptr(m), cap), "vo_track_batch")
+        return [res[i] for i in range(n)], [m[i, :min(res[i].n_matches, cap)].copy() for i in range(n)]
 
     def local_ba(self, poses, n_free, points, edge_pose, edge_point, edge_uv, huber_delta=7.815 ** 0.5, chi2_th=1.0,
                  it_robust=10, it_plain=10):

@@ -160,7 +160,7 @@ int vo_default_params(vo_params* p) {
     memset(p, 0, sizeof(*p));
     p->width = 640; p->height = 480; p->fx = 517.3f; p->fy = 516.5f; p->cx = 318.6f; p->cy = 255.3f; p->depth_scale = 5000.f;
     p->n_features = 500; p->scale_factor = 1.2f; p->n_levels = 8; p->fast_threshold = 20; p->edge_threshold = 31;
-    p->max_frames = 1; p->map_capacity = 1 << 18; p->max_hypotheses = 2048;
+    p->max_frames = 1; p->map_capacity = 1 << 18; p->max_hypotheses = 2048; p->max_track_batch = 1;
     return VO_OK;
 }
 
@@ -196,7 +196,7 @@ void vo_ctx_destroy(vo_ctx* c) {
 
 int vo_ctx_create(const vo_params* p, int device, vo_ctx** out) {
     if (!p || !out || p->width < 64 || p->height < 64 || p->n_levels < 1 || p->n_levels > VO_MAX_LEVELS || p->max_frames < 1 ||
-        p->n_features < 1 || !(p->scale_factor > 1.0f) || p->map_capacity < 1 || p->max_hypotheses < 1) return VO_E_INVALID;
+        p->n_features < 1 || !(p->scale_factor > 1.0f) || p->map_capacity < 1 || p->max_hypotheses < 1 || p->max_track_batch > VO_MAX_LANES) return VO_E_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
         fprintf(stderr, "[vo_hip] no usable HIP device (requested %d of %d): the HIP path has no CPU fallback\n", device, ndev);
@@ -209,6 +209,7 @@ int vo_ctx_create(const vo_params* p, int device, vo_ctx** out) {
     c->d_slots = nullptr; c->d_pyr = nullptr; c->d_tab = nullptr; c->d_tabs = nullptr; c->d_cand = nullptr; c->d_cand_cnt = nullptr;
     c->d_sel = nullptr; c->d_sel_key = nullptr; c->d_sel_cnt = nullptr; c->d_kps = nullptr; c->d_desc = nullptr; c->d_nkp = nullptr; c->d_status = nullptr;
     c->d_map_pos = nullptr; c->d_map_nrm = nullptr; c->d_map_desc = nullptr; c->d_map_flags = nullptr; c->d_active = nullptr; c->n_active = 0; c->active_cap = 0;
+    c->lanes = std::max(1, p->max_track_batch);
     c->d_best = nullptr; c->d_mcand = nullptr; c->d_matches = nullptr; c->d_corr_xyz = nullptr; c->d_corr_uv = nullptr; c->corr_cap = 0; c->d_hyp_pose = nullptr; c->d_hyp_cnt = nullptr;
     c->d_inliers = nullptr; c->d_lm_mask = nullptr; c->d_track = nullptr; c->h_track = nullptr; c->h_matches = nullptr; c->h_matches_cap = 0;
     c->h_stage = nullptr; c->h_stage_bytes = 0; c->d_ba = nullptr; c->d_ba_bytes = 0;
@@ -239,10 +240,15 @@ int vo_ctx_create(const vo_params* p, int device, vo_ctx** out) {
     const size_t M = (size_t)p->map_capacity;
     ALLOC(c->d_map_pos, 3 * M); ALLOC(c->d_map_nrm, 3 * M); ALLOC(c->d_map_desc, 8 * M); ALLOC(c->d_map_flags, M);
     c->active_cap = p->map_capacity; c->corr_cap = p->map_capacity;
-    ALLOC(c->d_active, M); ALLOC(c->d_best, M); ALLOC(c->d_mcand, M); ALLOC(c->d_matches, M); ALLOC(c->d_corr_xyz, 3 * M); ALLOC(c->d_corr_uv, 2 * M);
-    ALLOC(c->d_hyp_pose, (size_t)12 * p->max_hypotheses); ALLOC(c->d_hyp_cnt, (size_t)p->max_hypotheses);
-    ALLOC(c->d_inliers, M); ALLOC(c->d_lm_mask, M); ALLOC(c->d_track, 1);
-    if (hipHostMalloc((void**)&c->h_track, sizeof(TrackDev), hipHostMallocDefault) != hipSuccess) { vo_ctx_destroy(c); return VO_E_NOMEM; }
+    const size_t NL = (size_t)c->lanes;
+    ALLOC(c->d_active, M); ALLOC(c->d_best, NL * M); ALLOC(c->d_mcand, NL * M); ALLOC(c->d_matches, NL * M); ALLOC(c->d_corr_xyz, NL * 3 * M); ALLOC(c->d_corr_uv, NL * 2 * M);
+    ALLOC(c->d_hyp_pose, NL * 12 * p->max_hypotheses); ALLOC(c->d_hyp_cnt, NL * p->max_hypotheses);
+    ALLOC(c->d_inliers, NL * M); ALLOC(c->d_lm_mask, NL * M); ALLOC(c->d_track, NL);
+    if (hipHostMalloc((void**)&c->h_track, sizeof(TrackDev) * NL, hipHostMallocDefault) != hipSuccess) { vo_ctx_destroy(c); return VO_E_NOMEM; }
+    memset(&c->chain, 0, sizeof(c->chain));
+    c->chain.tr = c->d_track; c->chain.best = c->d_best; c->chain.mcand = c->d_mcand; c->chain.matches = c->d_matches; c->chain.cxyz = c->d_corr_xyz;
+    c->chain.cuv = c->d_corr_uv; c->chain.hyp_pose = c->d_hyp_pose; c->chain.hyp_cnt = c->d_hyp_cnt; c->chain.inliers = c->d_inliers; c->chain.lm_mask = c->d_lm_mask;
+    c->chain.stride = M; c->chain.max_hyp = p->max_hypotheses; c->chain.nfeat = P.nfeat; c->chain.desc = c->d_desc; c->chain.nkp = c->d_nkp; c->chain.kps = c->d_kps;
     hipStream_t st = c->stream;
     HIP_TRY(hipMemcpyAsync(c->d_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(c->d_tabs, tabs.data(), tabs.size() * sizeof(short), hipMemcpyHostToDevice, st));
@@ -250,7 +256,7 @@ int vo_ctx_create(const vo_params* p, int device, vo_ctx** out) {
     HIP_TRY(hipMemsetAsync(c->d_nkp, 0, sizeof(int) * F, st));
     HIP_TRY(hipMemsetAsync(c->d_sel_cnt, 0, sizeof(int) * F * VO_MAX_LEVELS, st));
     HIP_TRY(hipMemsetAsync(c->d_map_flags, 0, M, st));
-    HIP_TRY(hipMemsetAsync(c->d_track, 0, sizeof(TrackDev), st));
+    HIP_TRY(hipMemsetAsync(c->d_track, 0, sizeof(TrackDev) * NL, st));
     HIP_TRY(hipStreamSynchronize(st));
     *out = c;
     return VO_OK;
@@ -405,19 +411,21 @@ int vo_map_set_active(vo_ctx* c, const int32_t* idx, int n) {
     return VO_OK;
 }
 
-static int upload_pose(vo_ctx* c, const double T[12], bool reset) {
-    // whole header is rewritten: counters start from zero for a new frame
-    TrackDev* h = c->h_track;
+static int upload_pose(vo_ctx* c, int nl, const double T[12], bool reset) {
+    // whole headers are rewritten: counters start from zero for a new frame
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (reset) memset(h, 0, sizeof(*h));
-    memcpy(h->T, T, sizeof(double) * 12);
-    memcpy(h->T_ransac, T, sizeof(double) * 12);
-    HIP_TRY(hipMemcpyAsync(c->d_track, h, sizeof(TrackDev), hipMemcpyHostToDevice, c->stream));
+    for (int i = 0; i < nl; ++i) {
+        TrackDev* h = c->h_track + i;
+        if (reset) memset(h, 0, sizeof(*h));
+        memcpy(h->T, T, sizeof(double) * 12);
+        memcpy(h->T_ransac, T, sizeof(double) * 12);
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_track, c->h_track, sizeof(TrackDev) * nl, hipMemcpyHostToDevice, c->stream));
     return VO_OK;
 }
 
-static int download_track(vo_ctx* c) {
-    HIP_TRY(hipMemcpyAsync(c->h_track, c->d_track, sizeof(TrackDev), hipMemcpyDeviceToHost, c->stream));
+static int download_track(vo_ctx* c, int nl = 1) {
+    HIP_TRY(hipMemcpyAsync(c->h_track, c->d_track, sizeof(TrackDev) * nl, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return VO_OK;
 }
@@ -437,9 +445,9 @@ int vo_match_active_map(vo_ctx* c, int slot, const double T[12], float ratio, fl
     if (!c || slot < 0 || slot >= c->p.max_frames || !T || cap < 0) return VO_E_INVALID;
     if (!c->slot_orb[slot]) return VO_E_STATE;
     HIP_TRY(hipSetDevice(c->device));
-    int rc = upload_pose(c, T, true);
+    int rc = upload_pose(c, 1, T, true);
     if (rc) return rc;
-    rc = vo_track_match_launch(c, slot, ratio, floor_dist);
+    rc = vo_track_match_launch(c, 1, &slot, ratio, floor_dist);
     if (rc) return rc;
     const int take = std::min(cap, c->n_active);
     rc = ensure_match_stage(c, take);
@@ -471,7 +479,7 @@ int vo_pnp_ransac(vo_ctx* c, int n_hyp, float reproj_px, float conf, uint64_t se
     if (rc) return rc;
     memcpy(c->h_track->T, T, sizeof(double) * 12);
     HIP_TRY(hipMemcpyAsync(c->d_track, c->h_track, sizeof(TrackDev), hipMemcpyHostToDevice, c->stream));
-    rc = vo_track_ransac_launch(c, n_hyp, reproj_px, conf, seed);
+    rc = vo_track_ransac_launch(c, 1, n_hyp, reproj_px, conf, &seed);
     if (rc) return rc;
     rc = download_track(c);
     if (rc) return rc;
@@ -495,7 +503,7 @@ int vo_pose_refine_lm(vo_ctx* c, double T[12], double delta, double cut, int it_
     memcpy(c->h_track->T, T, sizeof(double) * 12);
     c->h_track->lm_iters = 0;
     HIP_TRY(hipMemcpyAsync(c->d_track, c->h_track, sizeof(TrackDev), hipMemcpyHostToDevice, c->stream));
-    rc = vo_track_lm_launch(c, delta, cut, it_r, it_p, false);
+    rc = vo_track_lm_launch(c, 1, delta, cut, it_r, it_p, false);
     if (rc) return rc;
     rc = download_track(c);
     if (rc) return rc;
@@ -515,41 +523,62 @@ int vo_pose_refine_lm(vo_ctx* c, double T[12], double delta, double cut, int it_
 static double g_tt[6]; static long g_tn;
 static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+#define MATCH_COPY_FIRST 4096       // matches copied with the headers; a frame with more gets a second copy
+
+int vo_track_batch(vo_ctx* c, int n, const int* slots, const double T0[12], const vo_track_params* tp, const uint64_t* seeds,
+                   vo_track_result* res, vo_match* matches, int cap) {
+    if (!c || n < 1 || n > c->lanes || !slots || !T0 || !tp || !res || tp->passes < 1 || cap < 0 || tp->n_hyp < 1 || tp->n_hyp > c->p.max_hypotheses) return VO_E_INVALID;
+    for (int i = 0; i < n; ++i) { if (slots[i] < 0 || slots[i] >= c->p.max_frames) return VO_E_INVALID; if (!c->slot_orb[slots[i]]) return VO_E_STATE; }
+    const bool trace = getenv("VO_TRACE") != nullptr;
+    const double t0 = trace ? now_us() : 0;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = upload_pose(c, n, T0, true);
+    if (rc) return rc;
+    const double t1 = trace ? now_us() : 0;
+    uint64_t sd[VO_MAX_LANES];
+    for (int pass = 0; pass < tp->passes; ++pass) {           // coarse, fine (frontend.cpp:100-108)
+        for (int i = 0; i < n; ++i) sd[i] = (seeds ? seeds[i] : tp->seed) + (uint64_t)pass;
+        if ((rc = vo_track_match_launch(c, n, slots, tp->match_ratio, tp->match_floor))) return rc;
+        if ((rc = vo_track_ransac_launch(c, n, tp->n_hyp, tp->reproj_px, tp->confidence, sd))) return rc;
+        if ((rc = vo_track_lm_launch(c, n, tp->huber_delta, tp->chi2_cut, tp->it_robust, tp->it_plain, pass == tp->passes - 1))) return rc;
+    }
+    const double t2 = trace ? now_us() : 0;
+    const int first = std::min(std::min(cap, c->n_active), MATCH_COPY_FIRST);
+    if ((rc = ensure_match_stage(c, std::max(first * n, std::min(cap, c->n_active))))) return rc;
+    if (first > 0 && matches)
+        HIP_TRY(hipMemcpy2DAsync(c->h_matches, sizeof(vo_match) * (size_t)first, c->d_matches, sizeof(vo_match) * c->chain.stride, sizeof(vo_match) * (size_t)first, n, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = download_track(c, n))) return rc;
+    for (int i = 0; i < n; ++i) {
+        const TrackDev& t = c->h_track[i];
+        vo_track_result& r = res[i];
+        memset(&r, 0, sizeof(r));
+        memcpy(r.T_cw, t.T, sizeof(double) * 12);
+        r.n_candidates = t.n_cand; r.n_matches = t.n_match; r.n_ransac_inliers = t.n_inl; r.n_lm_inliers = t.n_lm_inl;
+        r.min_distance = t.min_dist; r.ransac_iters = t.iters_used; r.best_hypothesis = t.best_hyp; r.lm_iters = t.lm_iters;
+        r.status = t.status;
+#ifdef VO_LM_STAMPS
+        for (int k = 0; k < 7; ++k) r.reserved[k] = (int32_t)(t.dbg[k == 6 ? 7 : k] >> ((k == 2 || k == 3) ? 0 : 4));
+        r.n_lm_inliers = (int32_t)(t.dbg[6] >> 4);
+#endif
+        if (t.n_match > cap && matches) r.status = VO_E_OVERFLOW;
+        if (matches) memcpy(matches + (size_t)i * cap, c->h_matches + (size_t)i * first, sizeof(vo_match) * std::min(first, t.n_match));
+    }
+    if (matches)
+        for (int i = 0; i < n; ++i) {                          // rare: more matches than the first copy carried
+            const int want = std::min(cap, c->h_track[i].n_match);
+            if (want > first) {
+                HIP_TRY(hipMemcpy(c->h_matches, c->d_matches + (size_t)i * c->chain.stride, sizeof(vo_match) * (size_t)want, hipMemcpyDeviceToHost));
+                memcpy(matches + (size_t)i * cap, c->h_matches, sizeof(vo_match) * (size_t)want);
+            }
+        }
+    if (trace) { const double t3 = now_us(); g_tt[0] += t1 - t0; g_tt[1] += t2 - t1; g_tt[2] += t3 - t2; g_tt[3] += n; if (++g_tn % 50 == 0) fprintf(stderr, "[vo_trace] track_batch avg us: upload %.1f launch %.1f wait+d2h %.1f, frames/batch %.2f\n", g_tt[0] / g_tn, g_tt[1] / g_tn, g_tt[2] / g_tn, g_tt[3] / g_tn); }
+    return VO_OK;
+}
+
 int vo_track_frame(vo_ctx* c, int slot, const double T0[12], const vo_track_params* tp, vo_track_result* res,
                    vo_match* matches, int cap) {
-    const bool trace = getenv("VO_TRACE") != nullptr;
-    double t0 = trace ? now_us() : 0;
-    if (!c || !T0 || !tp || !res || slot < 0 || slot >= c->p.max_frames || tp->passes < 1 || cap < 0 ||
-        tp->n_hyp < 1 || tp->n_hyp > c->p.max_hypotheses) return VO_E_INVALID;
-    if (!c->slot_orb[slot]) return VO_E_STATE;
-    HIP_TRY(hipSetDevice(c->device));
-    int rc = upload_pose(c, T0, true);
-    if (rc) return rc;
-    double t1 = trace ? now_us() : 0;
-    for (int pass = 0; pass < tp->passes; ++pass) {           // coarse, fine (frontend.cpp:100-108)
-        if ((rc = vo_track_match_launch(c, slot, tp->match_ratio, tp->match_floor))) return rc;
-        if ((rc = vo_track_ransac_launch(c, tp->n_hyp, tp->reproj_px, tp->confidence, tp->seed + (uint64_t)pass))) return rc;
-        if ((rc = vo_track_lm_launch(c, tp->huber_delta, tp->chi2_cut, tp->it_robust, tp->it_plain, pass == tp->passes - 1))) return rc;
-    }
-    double t2 = trace ? now_us() : 0;
-    const int take = std::min(cap, c->n_active);
-    if ((rc = ensure_match_stage(c, take))) return rc;
-    if (take > 0 && matches) HIP_TRY(hipMemcpyAsync(c->h_matches, c->d_matches, sizeof(vo_match) * take, hipMemcpyDeviceToHost, c->stream));
-    if ((rc = download_track(c))) return rc;
-    if (trace) { double t3 = now_us(); g_tt[0] += t1 - t0; g_tt[1] += t2 - t1; g_tt[2] += t3 - t2; if (++g_tn % 100 == 0) fprintf(stderr, "[vo_trace] track_frame avg us: upload %.1f launch %.1f wait+d2h %.1f\n", g_tt[0] / g_tn, g_tt[1] / g_tn, g_tt[2] / g_tn); }
-    const TrackDev& t = *c->h_track;
-    memset(res, 0, sizeof(*res));
-    memcpy(res->T_cw, t.T, sizeof(double) * 12);
-    res->n_candidates = t.n_cand; res->n_matches = t.n_match; res->n_ransac_inliers = t.n_inl; res->n_lm_inliers = t.n_lm_inl;
-    res->min_distance = t.min_dist; res->ransac_iters = t.iters_used; res->best_hypothesis = t.best_hyp; res->lm_iters = t.lm_iters;
-    res->status = t.status;
-#ifdef VO_LM_STAMPS
-    for (int i = 0; i < 7; ++i) res->reserved[i] = (int32_t)(t.dbg[i == 6 ? 7 : i] >> ((i == 2 || i == 3) ? 0 : 4));
-    res->n_lm_inliers = (int32_t)(t.dbg[6] >> 4);
-#endif
-    if (t.n_match > cap && matches) res->status = VO_E_OVERFLOW;
-    if (matches) memcpy(matches, c->h_matches, sizeof(vo_match) * std::min(take, t.n_match));
-    return VO_OK;
+    if (!tp) return VO_E_INVALID;
+    return vo_track_batch(c, 1, &slot, T0, tp, &tp->seed, res, matches, cap);
 }
 
 int vo_local_ba(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {

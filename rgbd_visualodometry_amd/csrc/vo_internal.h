@@ -45,6 +45,18 @@ struct TrackDev {
     long long dbg[8];           // diagnostic stamps (only written by -DVO_LM_STAMPS builds)
 };
 
+#define VO_MAX_LANES 16
+// Per-lane working set of the tracking chain.  A "lane" is one frame of a batch that is tracked
+// concurrently (blockIdx.z): frames between two keyframes share the prior pose and the map
+// (reference src/frontend.cpp:96 -- the prior is the last KEYFRAME's pose), so they are independent.
+struct ChainBuf {
+    TrackDev* tr; unsigned long long* best; int32_t* mcand; vo_match* matches; float* cxyz; float* cuv;
+    double* hyp_pose; int* hyp_cnt; int32_t* inliers; uint8_t* lm_mask;
+    size_t stride; int max_hyp, nfeat;
+    const uint8_t* desc; const int* nkp; const vo_keypoint* kps;      // per frame slot: [slot][nfeat]
+    int slot[VO_MAX_LANES]; unsigned long long seed[VO_MAX_LANES];
+};
+
 struct vo_ctx {
     vo_params p;
     DevPlan plan;
@@ -71,7 +83,8 @@ struct vo_ctx {
     vo_match* d_matches; float* d_corr_xyz; float* d_corr_uv; int corr_cap;
     double* d_hyp_pose; int* d_hyp_cnt;             // [max_hyp][12], [max_hyp]
     int32_t* d_inliers; uint8_t* d_lm_mask;
-    TrackDev* d_track; TrackDev* h_track;           // h_track pinned
+    TrackDev* d_track; TrackDev* h_track;           // [lanes]; h_track pinned
+    ChainBuf chain; int lanes;                      // base pointers of the per-lane chain buffers
     vo_match* h_matches;                            // pinned staging
     int h_matches_cap;
     void* h_stage; size_t h_stage_bytes;            // pinned general staging
@@ -94,10 +107,9 @@ int vo_map_scatter_launch(vo_ctx* c, int n, const int32_t* d_idx, const double* 
 
 // stage launchers
 int vo_orb_launch(vo_ctx* c, int slot0, int nslots);                                        // vo_orb.hip
-int vo_track_match_launch(vo_ctx* c, int slot, float ratio, float floor_dist);              // vo_track.hip
-int vo_track_ransac_launch(vo_ctx* c, int n_hyp, float reproj_px, float conf, uint64_t seed);
-int vo_track_lm_launch(vo_ctx* c, double delta, double cut, int it_r, int it_p, bool write_flags);
-int vo_track_flags_launch(vo_ctx* c);
+int vo_track_match_launch(vo_ctx* c, int nl, const int* slots, float ratio, float floor_dist);       // vo_track.hip (nl lanes)
+int vo_track_ransac_launch(vo_ctx* c, int nl, int n_hyp, float reproj_px, float conf, const uint64_t* seeds);
+int vo_track_lm_launch(vo_ctx* c, int nl, double delta, double cut, int it_r, int it_p, bool write_flags);
 int vo_corr_from_host(vo_ctx* c, const float* xyz, const float* uv, int n);
 int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out);                       // vo_ba.hip
 

@@ -31,6 +31,24 @@ __device__ long long g_dbg[8];
 
 struct CamD { double fx, fy, cx, cy; int W, H; };
 
+#define LANE_PTRS(cb) \
+    const int lane_ = blockIdx.z; \
+    TrackDev* tr = cb.tr + lane_; \
+    unsigned long long* best = cb.best + (size_t)lane_ * cb.stride; \
+    int32_t* cand = cb.mcand + (size_t)lane_ * cb.stride; \
+    vo_match* matches = cb.matches + (size_t)lane_ * cb.stride; \
+    float* cxyz = cb.cxyz + 3 * (size_t)lane_ * cb.stride; \
+    float* cuv = cb.cuv + 2 * (size_t)lane_ * cb.stride; \
+    double* hyp_pose = cb.hyp_pose + (size_t)12 * lane_ * cb.max_hyp; \
+    int* hyp_cnt = cb.hyp_cnt + (size_t)lane_ * cb.max_hyp; \
+    int32_t* inliers = cb.inliers + (size_t)lane_ * cb.stride; \
+    uint8_t* mask = cb.lm_mask + (size_t)lane_ * cb.stride; \
+    const int slot_ = cb.slot[lane_]; \
+    const uint32_t* fdesc = (const uint32_t*)(cb.desc + (size_t)slot_ * cb.nfeat * 32); \
+    const int* nkp_p = cb.nkp + slot_; \
+    const vo_keypoint* kps = cb.kps + (size_t)slot_ * cb.nfeat; \
+    (void)tr; (void)best; (void)cand; (void)matches; (void)cxyz; (void)cuv; (void)hyp_pose; (void)hyp_cnt; (void)inliers; (void)mask; (void)fdesc; (void)nkp_p; (void)kps;
+
 // ------------------------------------------------------------------------------------------
 // small double-precision helpers (same operation order as oracle/o_math.h)
 // ------------------------------------------------------------------------------------------
@@ -54,10 +72,10 @@ __device__ __forceinline__ double comp(D3 a, int i) { return i == 0 ? a.x : (i =
 #define MT 64
 // visibility filter: every active map point gets best[q] = ~0; visible ones are appended to the
 // (unordered) candidate list -- order is restored later because results are indexed by q.
-__global__ __launch_bounds__(256) void k_frustum(CamD cam, TrackDev* __restrict__ tr, const double* __restrict__ map_pos,
+__global__ __launch_bounds__(256) void k_frustum(CamD cam, ChainBuf cb, const double* __restrict__ map_pos,
                                                  const double* __restrict__ map_nrm, const uint8_t* __restrict__ map_flags,
-                                                 const int32_t* __restrict__ active, int n_active, unsigned long long* __restrict__ best,
-                                                 int32_t* __restrict__ cand) {
+                                                 const int32_t* __restrict__ active, int n_active) {
+    LANE_PTRS(cb)
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= n_active) return;
     best[q] = ~0ull;
@@ -81,10 +99,8 @@ __global__ __launch_bounds__(256) void k_frustum(CamD cam, TrackDev* __restrict_
 
 // 64 candidates x 64 frame descriptors per wavefront; the train tile sits in LDS and every lane reads
 // the same descriptor (broadcast), 8 x (v_xor, v_bcnt) per pair; cross-tile argmin by 64-bit atomicMin.
-__global__ __launch_bounds__(64) void k_match(const TrackDev* __restrict__ tr, const uint32_t* __restrict__ map_desc,
-                                              const int32_t* __restrict__ active, const int32_t* __restrict__ cand,
-                                              const uint32_t* __restrict__ fdesc, const int* __restrict__ nkp_p,
-                                              unsigned long long* __restrict__ best) {
+__global__ __launch_bounds__(64) void k_match(ChainBuf cb, const uint32_t* __restrict__ map_desc, const int32_t* __restrict__ active) {
+    LANE_PTRS(cb)
     __shared__ uint4 s_train[MT * 2];
     const int nkp = *nkp_p, ncand = tr->pad0;
     const int t0 = blockIdx.y * MT;
@@ -126,11 +142,9 @@ __device__ __forceinline__ int block_excl_scan_flag(bool flag, int* s_w, int& to
 // staged in LDS with coalesced loads (packed to 32 bit); then every thread owns one contiguous
 // segment of the active list, so the output order is the list order with a single block scan.
 #define GATE_LDS_MAX 36864          // entries (144 KiB)
-__global__ __launch_bounds__(1024) void k_match_gate(TrackDev* __restrict__ tr, const unsigned long long* __restrict__ best,
-                                                     const int32_t* __restrict__ active, int n_active, const double* __restrict__ map_pos,
-                                                     const vo_keypoint* __restrict__ kps, float ratio, float floor_dist,
-                                                     vo_match* __restrict__ matches, float* __restrict__ cxyz, float* __restrict__ cuv, int cap,
-                                                     int use_lds) {
+__global__ __launch_bounds__(1024) void k_match_gate(ChainBuf cb, const int32_t* __restrict__ active, int n_active, const double* __restrict__ map_pos,
+                                                     float ratio, float floor_dist, int cap, int use_lds) {
+    LANE_PTRS(cb)
     extern __shared__ uint32_t s_pk[];
     __shared__ int s_w[16];
     __shared__ int s_min;
@@ -327,9 +341,9 @@ __device__ __forceinline__ bool reproj_ok_dev(const CamD& cam, const double* T, 
     return du * du + dv * dv <= thr2 * (pc.z * pc.z);
 }
 
-__global__ __launch_bounds__(64) void k_ransac_hyp(CamD cam, const TrackDev* __restrict__ tr, const float* __restrict__ cxyz,
-                                                   const float* __restrict__ cuv, int n_hyp, uint64_t seed, double* __restrict__ hyp_pose,
-                                                   int* __restrict__ hyp_cnt) {
+__global__ __launch_bounds__(64) void k_ransac_hyp(CamD cam, ChainBuf cb, int n_hyp) {
+    LANE_PTRS(cb)
+    const uint64_t seed = cb.seed[lane_];
     const int h = blockIdx.x * 64 + threadIdx.x;
     if (h >= n_hyp) return;
     const int n = tr->n_match;
@@ -358,9 +372,8 @@ __global__ __launch_bounds__(64) void k_ransac_hyp(CamD cam, const TrackDev* __r
     hyp_cnt[h] = 0;
 }
 
-__global__ __launch_bounds__(256) void k_ransac_score(CamD cam, const TrackDev* __restrict__ tr, const float* __restrict__ cxyz,
-                                                      const float* __restrict__ cuv, int n_hyp, double thr2, const double* __restrict__ hyp_pose,
-                                                      int* __restrict__ hyp_cnt) {
+__global__ __launch_bounds__(256) void k_ransac_score(CamD cam, ChainBuf cb, int n_hyp, double thr2) {
+    LANE_PTRS(cb)
     __shared__ int s_cnt;
     const int h = blockIdx.x;
     if (hyp_cnt[h] < 0) return;
@@ -388,32 +401,30 @@ __device__ __forceinline__ int ransac_update_iters_dev(double conf, int n_pts, i
     return k;
 }
 
-__global__ __launch_bounds__(1024) void k_ransac_select(CamD cam, TrackDev* __restrict__ tr, const float* __restrict__ cxyz,
-                                                        const float* __restrict__ cuv, int n_hyp, double thr2, double conf,
-                                                        const double* __restrict__ hyp_pose, const int* __restrict__ hyp_cnt,
-                                                        int32_t* __restrict__ inliers) {
+__global__ __launch_bounds__(1024) void k_ransac_select(CamD cam, ChainBuf cb, int n_hyp, double thr2, double conf) {
+    LANE_PTRS(cb)
     __shared__ int s_w[16];
     __shared__ int s_best;
     const int n = tr->n_match;
     if (threadIdx.x == 0) {
-        int best = -1, best_cnt = 3, niters = n_hyp, h = 0;
+        int bh = -1, best_cnt = 3, niters = n_hyp, h = 0;
         if (n >= 4) {
             for (; h < niters; ++h) {
                 const int cnt = hyp_cnt[h];
-                if (cnt > best_cnt) { best_cnt = cnt; best = h; niters = min(niters, ransac_update_iters_dev(conf, n, cnt, niters)); }
+                if (cnt > best_cnt) { best_cnt = cnt; bh = h; niters = min(niters, ransac_update_iters_dev(conf, n, cnt, niters)); }
             }
         }
-        s_best = best;
-        tr->best_hyp = best; tr->iters_used = h; tr->best_cnt = best >= 0 ? best_cnt : 0;
-        if (best >= 0) for (int i = 0; i < 12; ++i) tr->T[i] = hyp_pose[(size_t)12 * best + i];
+        s_best = bh;
+        tr->best_hyp = bh; tr->iters_used = h; tr->best_cnt = bh >= 0 ? best_cnt : 0;
+        if (bh >= 0) for (int i = 0; i < 12; ++i) tr->T[i] = hyp_pose[(size_t)12 * bh + i];
         for (int i = 0; i < 12; ++i) tr->T_ransac[i] = tr->T[i];
     }
     __syncthreads();
-    const int best = s_best;
-    if (best < 0) { if (threadIdx.x == 0) tr->n_inl = 0; return; }
+    const int bsel = s_best;
+    if (bsel < 0) { if (threadIdx.x == 0) tr->n_inl = 0; return; }
     double T[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) T[i] = hyp_pose[(size_t)12 * best + i];
+    for (int i = 0; i < 12; ++i) T[i] = hyp_pose[(size_t)12 * bsel + i];
     int outn = 0;
     for (int base = 0; base < n; base += 1024) {
         const int k = base + threadIdx.x;
@@ -647,9 +658,10 @@ __device__ __forceinline__ double edge_chi2_dev(const CamD& cam, const double* T
     return e0 * e0 + e1 * e1;
 }
 
-__global__ __launch_bounds__(LM_T) void k_pose_lm(CamD cam, TrackDev* __restrict__ tr, const float* cxyz,
-                                                  const float* cuv, const int32_t* edges, uint8_t* __restrict__ mask,
-                                                  double delta, double cut, int it_r, int it_p, vo_match* __restrict__ matches) {
+__global__ __launch_bounds__(LM_T) void k_pose_lm(CamD cam, ChainBuf cb, double delta, double cut, int it_r, int it_p, int write_flags) {
+    LANE_PTRS(cb)
+    const int32_t* edges = inliers;
+    if (!write_flags) matches = nullptr;
     const int32_t* edges_g = edges;
 #ifdef VO_LM_STAMPS
     const long long t_kernel0 = clock64();
@@ -704,13 +716,6 @@ __global__ __launch_bounds__(LM_T) void k_pose_lm(CamD cam, TrackDev* __restrict
     }
 }
 
-__global__ void k_track_flags(const TrackDev* __restrict__ tr, const int32_t* __restrict__ inliers, const uint8_t* __restrict__ mask,
-                              vo_match* __restrict__ matches) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= tr->n_inl) return;
-    matches[inliers[i]].flags = VO_MATCH_RANSAC_INLIER | ((mask[i] & 1) ? VO_MATCH_LM_INLIER : 0);
-}
-
 __global__ void k_set_nmatch(TrackDev* tr, int n) { tr->n_match = n; tr->n_inl = 0; }
 
 // device-map update: scatter packed host records to their slots (vo_map_upsert)
@@ -737,23 +742,28 @@ int vo_track_set_attrs() {
 
 static CamD cam_of(const vo_ctx* c) { CamD k; k.fx = c->p.fx; k.fy = c->p.fy; k.cx = c->p.cx; k.cy = c->p.cy; k.W = c->p.width; k.H = c->p.height; return k; }
 
-int vo_track_match_launch(vo_ctx* c, int slot, float ratio, float floor_dist) {
+static ChainBuf chain_of(vo_ctx* c, int nl, const int* slots, const uint64_t* seeds) {
+    ChainBuf cb = c->chain;
+    for (int i = 0; i < nl; ++i) { cb.slot[i] = slots ? slots[i] : 0; cb.seed[i] = seeds ? seeds[i] : 0; }
+    return cb;
+}
+
+int vo_track_match_launch(vo_ctx* c, int nl, const int* slots, float ratio, float floor_dist) {
     hipStream_t st = c->stream;
     const int na = c->n_active;
     c->corr_external = false;
+    const ChainBuf cb = chain_of(c, nl, slots, nullptr);
     if (na > 0) {
         { ProfScope ps(c, "k_frustum");
-          hipLaunchKernelGGL(k_frustum, dim3((na + 255) / 256), dim3(256), 0, st, cam_of(c), c->d_track, c->d_map_pos, c->d_map_nrm, c->d_map_flags,
-                             c->d_active, na, c->d_best, c->d_mcand); }
+          hipLaunchKernelGGL(k_frustum, dim3((na + 255) / 256, 1, nl), dim3(256), 0, st, cam_of(c), cb, c->d_map_pos, c->d_map_nrm, c->d_map_flags, c->d_active, na); }
         ProfScope ps(c, "k_match");
-        dim3 g((na + MQ - 1) / MQ, (c->p.n_features + MT - 1) / MT);
-        hipLaunchKernelGGL(k_match, g, dim3(64), 0, st, c->d_track, c->d_map_desc, c->d_active, c->d_mcand,
-                           (const uint32_t*)(c->d_desc + (size_t)slot * c->p.n_features * 32), c->d_nkp + slot, c->d_best);
+        dim3 g((na + MQ - 1) / MQ, (c->p.n_features + MT - 1) / MT, nl);
+        hipLaunchKernelGGL(k_match, g, dim3(64), 0, st, cb, c->d_map_desc, c->d_active);
     }
     { ProfScope ps(c, "k_match_gate");
       const int use_lds = na <= GATE_LDS_MAX ? 1 : 0;
-      hipLaunchKernelGGL(k_match_gate, dim3(1), dim3(1024), use_lds ? sizeof(uint32_t) * (size_t)na : 0, st, c->d_track, c->d_best, c->d_active, na, c->d_map_pos,
-                         c->d_kps + (size_t)slot * c->p.n_features, ratio, floor_dist, c->d_matches, c->d_corr_xyz, c->d_corr_uv, c->corr_cap, use_lds); }
+      hipLaunchKernelGGL(k_match_gate, dim3(1, 1, nl), dim3(1024), use_lds ? sizeof(uint32_t) * (size_t)na : 0, st, cb, c->d_active, na, c->d_map_pos,
+                         ratio, floor_dist, c->corr_cap, use_lds); }
     HIP_TRY(hipGetLastError());
     return VO_OK;
 }
@@ -766,32 +776,34 @@ int vo_corr_from_host(vo_ctx* c, const float* xyz, const float* uv, int n) {
         if (!stage) return VO_E_NOMEM;
         memcpy(stage, xyz, sizeof(float) * 3 * (size_t)n);
         memcpy(stage + 3 * (size_t)n, uv, sizeof(float) * 2 * (size_t)n);
-        HIP_TRY(hipMemcpyAsync(c->d_corr_xyz, stage, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(c->d_corr_uv, stage + 3 * (size_t)n, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(c->chain.cxyz, stage, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(c->chain.cuv, stage + 3 * (size_t)n, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, st));
     }
-    hipLaunchKernelGGL(k_set_nmatch, dim3(1), dim3(1), 0, st, c->d_track, n);
+    hipLaunchKernelGGL(k_set_nmatch, dim3(1), dim3(1), 0, st, c->chain.tr, n);
     HIP_TRY(hipStreamSynchronize(st));      // staging buffer is reused by later calls
     c->corr_external = true;
     return VO_OK;
 }
 
-int vo_track_ransac_launch(vo_ctx* c, int n_hyp, float reproj_px, float conf, uint64_t seed) {
+int vo_track_ransac_launch(vo_ctx* c, int nl, int n_hyp, float reproj_px, float conf, const uint64_t* seeds) {
     hipStream_t st = c->stream;
     const CamD cam = cam_of(c);
     const double thr2 = (double)reproj_px * (double)reproj_px;
+    const ChainBuf cb = chain_of(c, nl, nullptr, seeds);
     { ProfScope ps(c, "k_ransac_hyp");
-      hipLaunchKernelGGL(k_ransac_hyp, dim3((n_hyp + 63) / 64), dim3(64), 0, st, cam, c->d_track, c->d_corr_xyz, c->d_corr_uv, n_hyp, seed, c->d_hyp_pose, c->d_hyp_cnt); }
+      hipLaunchKernelGGL(k_ransac_hyp, dim3((n_hyp + 63) / 64, 1, nl), dim3(64), 0, st, cam, cb, n_hyp); }
     { ProfScope ps(c, "k_ransac_score");
-      hipLaunchKernelGGL(k_ransac_score, dim3(n_hyp), dim3(256), 0, st, cam, c->d_track, c->d_corr_xyz, c->d_corr_uv, n_hyp, thr2, c->d_hyp_pose, c->d_hyp_cnt); }
+      hipLaunchKernelGGL(k_ransac_score, dim3(n_hyp, 1, nl), dim3(256), 0, st, cam, cb, n_hyp, thr2); }
     { ProfScope ps(c, "k_ransac_select");
-      hipLaunchKernelGGL(k_ransac_select, dim3(1), dim3(1024), 0, st, cam, c->d_track, c->d_corr_xyz, c->d_corr_uv, n_hyp, thr2, (double)conf, c->d_hyp_pose, c->d_hyp_cnt, c->d_inliers); }
+      hipLaunchKernelGGL(k_ransac_select, dim3(1, 1, nl), dim3(1024), 0, st, cam, cb, n_hyp, thr2, (double)conf); }
     HIP_TRY(hipGetLastError());
     return VO_OK;
 }
 
-int vo_track_lm_launch(vo_ctx* c, double delta, double cut, int it_r, int it_p, bool write_flags) {
+int vo_track_lm_launch(vo_ctx* c, int nl, double delta, double cut, int it_r, int it_p, bool write_flags) {
     ProfScope ps(c, "k_pose_lm");
-    hipLaunchKernelGGL(k_pose_lm, dim3(1), dim3(LM_T), LM_LDS_MAX * 20, c->stream, cam_of(c), c->d_track, c->d_corr_xyz, c->d_corr_uv, c->d_inliers, c->d_lm_mask, delta, cut, it_r, it_p, write_flags ? c->d_matches : nullptr);
+    const ChainBuf cb = chain_of(c, nl, nullptr, nullptr);
+    hipLaunchKernelGGL(k_pose_lm, dim3(1, 1, nl), dim3(LM_T), LM_LDS_MAX * 20, c->stream, cam_of(c), cb, delta, cut, it_r, it_p, write_flags ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return VO_OK;
 }
@@ -799,14 +811,6 @@ int vo_track_lm_launch(vo_ctx* c, double delta, double cut, int it_r, int it_p, 
 int vo_map_scatter_launch(vo_ctx* c, int n, const int32_t* d_idx, const double* d_xyz, const double* d_nrm, const uint32_t* d_desc, const uint8_t* d_flags) {
     hipLaunchKernelGGL(k_map_scatter, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, d_idx, d_xyz, d_nrm, d_desc, d_flags,
                        c->d_map_pos, c->d_map_nrm, c->d_map_desc, c->d_map_flags);
-    HIP_TRY(hipGetLastError());
-    return VO_OK;
-}
-
-int vo_track_flags_launch(vo_ctx* c) {
-    ProfScope ps(c, "k_track_flags");
-    const int cap = c->corr_cap;
-    hipLaunchKernelGGL(k_track_flags, dim3((cap + 255) / 256), dim3(256), 0, c->stream, c->d_track, c->d_inliers, c->d_lm_mask, c->d_matches);
     HIP_TRY(hipGetLastError());
     return VO_OK;
 }

@@ -27,8 +27,10 @@ public:
     void SetLag(int frames) { lag_ = frames < 0 ? 0 : frames; }
     void Stop();                                     // finish the pending job, join the worker
     void OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr);
-    // tracker thread, once per frame before tracking: merge a finished/overdue job
-    void Poll(size_t frameIndex);
+    // tracker thread, once per frame before tracking: merge a finished/overdue job; true if the map changed
+    bool Poll(size_t frameIndex);
+    // frame index at which the pending job will be merged (SIZE_MAX: none pending)
+    size_t NextMergeFrame() const { return job_ ? job_->frameIndex + (size_t)lag_ : (size_t)-1; }
     struct Stats { int runs = 0, poses = 0, fixed = 0, points = 0, edges = 0, outliers = 0; double ms = 0, ms_build = 0, ms_solve = 0, ms_wait = 0; };
     const Stats& GetStats() const { return stats_; }
 private:

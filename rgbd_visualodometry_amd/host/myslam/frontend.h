@@ -64,7 +64,14 @@ private:
     int   numInliers_ = 0;
     float minDisRatio_; int maxLostFrames_, minInliers_; double keyFrameMinRot_, keyFrameMinTrans_;
     int   nextSlot_ = 0;
-    uint64_t frameCounter_ = 0;
+    // speculative batch tracking: frames between keyframes share prior + map (frontend.cpp:96), so the frames that
+    // follow the current one in the prefetch queue are tracked in the same launch chain; results are cached and
+    // dropped when a keyframe / BA merge changes the inputs (epoch).
+    struct SpecResult { size_t frameId; uint64_t epoch; vo_track_result res; std::vector<vo_match> matches; };
+    std::vector<SpecResult> spec_;
+    std::vector<Frame::Ptr> prefetched_;
+    uint64_t epoch_ = 0;
+    int trackBatch_ = 1, framesSinceKf_ = 0; double lastMotion_ = 0;
     Stats stats_;
     std::vector<vo_keypoint> kpBuf_; std::vector<uint8_t> descBuf_; std::vector<vo_match> matchBuf_;
     std::vector<int32_t> upIdx_; std::vector<double> upXyz_, upNrm_; std::vector<uint8_t> upDesc_, upFlags_;

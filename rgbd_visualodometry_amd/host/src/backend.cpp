@@ -45,9 +45,10 @@ void Backend::WorkerLoop() {
     }
 }
 
-void Backend::Poll(size_t frameIndex) {
+bool Backend::Poll(size_t frameIndex) {
     frameIndex_ = frameIndex;
-    if (job_ && frameIndex >= job_->frameIndex + (size_t)lag_) Finish();
+    if (job_ && frameIndex >= job_->frameIndex + (size_t)lag_) { Finish(); return true; }
+    return false;
 }
 
 void Backend::Finish() {

@@ -44,6 +44,8 @@ void FrontEnd::Init(int device, int width, int height, int max_frames) {
     params_.n_levels = cfg_or<int>("level_pyramid", params_.n_levels);                     // :37
     params_.max_frames = std::max(1, max_frames);
     params_.map_capacity = cfg_or<int>("map_capacity", 1 << 20);
+    trackBatch_ = std::max(1, std::min(16, cfg_or<int>("track_batch", 1)));
+    params_.max_track_batch = trackBatch_;
     vo_default_track_params(&trackParams_);
     trackParams_.match_ratio = minDisRatio_ = cfg_or<float>("match_ratio", 2.0f);          // :38
     maxLostFrames_ = (int)cfg_or<float>("max_num_lost", 10.f);                             // :39
@@ -62,7 +64,7 @@ bool FrontEnd::AddFrame(const Frame::Ptr frame) {
     if (verbose_) std::cout << "Frontend status: " << (state_ == INITIALIZING ? "Initializing" : state_ == TRACKING ? "Tracking" : "Lost") << std::endl;
     frameCurr_ = frame;
     ++stats_.frames;
-    if (backend_) { StageTimer t(stats_.ms_backend); backend_->Poll((size_t)stats_.frames); }   // deterministic merge point of an overlapped BA
+    if (backend_) { StageTimer t(stats_.ms_backend); if (backend_->Poll((size_t)stats_.frames)) ++epoch_; }   // deterministic merge point of an overlapped BA
     switch (state_) {
         case INITIALIZING: InitializationHandler(); break;
         case TRACKING: if (!TrackingHandler()) return false; break;
@@ -96,6 +98,7 @@ bool FrontEnd::TrackingHandler() {
     accuLostFrameNums_ = 0;
     if (!IsKeyframe()) return true;
 
+    ++epoch_; framesSinceKf_ = 0;                                  // map + prior change: cached speculative results are void
     {
         StageTimer t(stats_.ms_keyframe);
         MapManager::GetInstance().InsertKeyframe(frameCurr_);
@@ -124,6 +127,8 @@ int FrontEnd::PrefetchFrames(const std::vector<Frame::Ptr>& frames) {
     }
     vo_check(vo_orb_detect_describe(ctx_, 0, n), "vo_orb_detect_describe");
     for (int i = 0; i < n; ++i) frames[i]->orb_done_ = true;
+    prefetched_.assign(frames.begin(), frames.begin() + n);
+    spec_.clear();                                               // slots were reassigned
     nextSlot_ = 0;
     return n;
 }
@@ -188,15 +193,49 @@ void FrontEnd::FlushDirtyMappoints() {
 }
 
 void FrontEnd::MatchAndEstimatePose() {
-    RefreshTrackingMap();
-    FlushDirtyMappoints();
-    double prior[12];
-    frameCurr_->GetPose().to12(prior);
     vo_track_result res;
-    const int cap = (int)activeList_.size() + 1;
-    if ((int)matchBuf_.size() < cap) matchBuf_.resize(cap);
-    trackParams_.seed = 0x5eed5eedull + 2 * frameCounter_++;
-    vo_check(vo_track_frame(ctx_, frameCurr_->slot_, prior, &trackParams_, &res, matchBuf_.data(), cap), "vo_track_frame");
+    bool have = false;
+    for (auto& sp : spec_)
+        if (sp.frameId == frameCurr_->GetId() && sp.epoch == epoch_) {            // tracked ahead of time with identical inputs
+            res = sp.res;
+            if ((int)matchBuf_.size() < res.n_matches) matchBuf_.resize(res.n_matches);
+            std::copy(sp.matches.begin(), sp.matches.begin() + res.n_matches, matchBuf_.begin());
+            have = true;
+            break;
+        }
+    if (!have) {
+        spec_.clear();
+        RefreshTrackingMap();
+        FlushDirtyMappoints();
+        double prior[12];
+        frameCurr_->GetPose().to12(prior);
+        // batch = this frame + the prefetched frames that follow it, while they see the same map: stop before a
+        // scheduled BA merge and before the predicted next keyframe
+        std::vector<Frame::Ptr> batch{frameCurr_};
+        size_t pos = 0;
+        while (pos < prefetched_.size() && prefetched_[pos] != frameCurr_) ++pos;
+        const size_t nextMerge = backend_ ? backend_->NextMergeFrame() : (size_t)-1;
+        int want = trackBatch_;
+        if (framesSinceKf_ > 0 && lastMotion_ > 0) {
+            const double left = (1.0 - lastMotion_) / (lastMotion_ / framesSinceKf_);      // frames until a threshold is reached
+            want = std::max(1, std::min(trackBatch_, (int)left + 1));
+        }
+        for (size_t j = pos + 1; j < prefetched_.size() && (int)batch.size() < want; ++j) {
+            if (!prefetched_[j]->orb_done_ || (size_t)stats_.frames + batch.size() >= nextMerge) break;
+            batch.push_back(prefetched_[j]);
+        }
+        const int nb = (int)batch.size(), cap = (int)activeList_.size() + 1;
+        std::vector<int> slots(nb); std::vector<uint64_t> seeds(nb); std::vector<vo_track_result> rs(nb);
+        for (int j = 0; j < nb; ++j) { slots[j] = batch[j]->slot_; seeds[j] = 0x5eed5eedull + 2 * (uint64_t)(stats_.frames + j); }
+        if (matchBuf_.size() < (size_t)nb * cap) matchBuf_.resize((size_t)nb * cap);
+        vo_check(vo_track_batch(ctx_, nb, slots.data(), prior, &trackParams_, seeds.data(), rs.data(), matchBuf_.data(), cap), "vo_track_batch");
+        for (int j = 1; j < nb; ++j) {
+            SpecResult sp; sp.frameId = batch[j]->GetId(); sp.epoch = epoch_; sp.res = rs[j];
+            sp.matches.assign(matchBuf_.begin() + (size_t)j * cap, matchBuf_.begin() + (size_t)j * cap + std::min(rs[j].n_matches, cap));
+            spec_.push_back(std::move(sp));
+        }
+        res = rs[0];
+    }
     if (res.status != VO_OK) throw std::runtime_error(std::string("device pipeline: ") + vo_strerror(res.status));
 
     flannMatchedMpt_.clear(); flannMatchedKp_.clear(); flannMatchedLm_.clear();
@@ -234,6 +273,8 @@ bool FrontEnd::IsKeyframe() {
     Vector6d d = T_r_c.log();
     const double trans = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
     const double rot = std::sqrt(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+    ++framesSinceKf_;
+    lastMotion_ = std::max(rot / keyFrameMinRot_, trans / keyFrameMinTrans_);   // fraction of the keyframe threshold used up
     return rot > keyFrameMinRot_ || trans > keyFrameMinTrans_;                      // frontend.cpp:359
 }
 

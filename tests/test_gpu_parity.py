@@ -202,3 +202,57 @@ def test_hip_rejects_bad_arguments(libs):
         ctx.orb(0, 1)                       # no frame bound yet -> VO_E_STATE
     with pytest.raises(capi.VoError):
         ctx.map_set_active(np.array([1 << 30], dtype=np.int32))
+
+
+def test_track_batch_equals_sequential_calls(frames, libs):
+    """vo_track_batch on frames that share prior + map == one vo_track_frame per frame (same kernels, lanes)."""
+    bgr, depth, Twc, _ = frames
+    H, _ = libs
+    ctx, p = make_ctx(H, n_features=1000, max_frames=5, map_capacity=8192, max_track_batch=4)
+    for s in range(5):
+        ctx.upload(s, bgr[2 * s], depth[2 * s])
+    ctx.orb(0, 5)
+    k0, d0 = ctx.orb_fetch(0)
+    seed_map(ctx, p, k0, d0, Twc[0])
+    tp = H.default_track_params()
+    seeds = [101, 202, 303, 404]
+    single = []
+    for j, s in enumerate((1, 2, 3, 4)):
+        tp.seed = seeds[j]
+        single.append(ctx.track(s, inv12(Twc[0]), tp, cap=4096))
+    res, ms = ctx.track_batch([1, 2, 3, 4], inv12(Twc[0]), tp, seeds, cap=4096)
+    for j in range(4):
+        rs, m1 = single[j]
+        for f in ("n_candidates", "n_matches", "n_ransac_inliers", "n_lm_inliers", "min_distance", "ransac_iters", "best_hypothesis", "lm_iters"):
+            assert getattr(res[j], f) == getattr(rs, f), (j, f)
+        assert np.array_equal(np.array(res[j].T_cw), np.array(rs.T_cw))
+        assert np.array_equal(ms[j], m1)
+
+
+def test_vo_system_gpu_matches_oracle_trajectory(frames):
+    """End to end through the libmyslam-style host layer: HIP path (look-ahead ORB, speculative batches) vs oracle."""
+    from rgbd_visualodometry_amd import system, evaluate as ev
+    bgr, depth, Twc, ts = frames
+    n = len(ts)
+
+    def run(lib, **opt):
+        s = system.VoSystem(lib, number_of_features=800, **opt)
+        look = opt.get("max_frames_in_flight", 1)
+        poses, i = [], 0
+        while i < n:
+            k = min(look, n - i)
+            s.prefetch(ts[i:i + k], [bgr[j].ctypes.data for j in range(i, i + k)], [depth[j].ctypes.data for j in range(i, i + k)],
+                       bgr[0].strides[0], depth[0].strides[0], False)
+            for _ in range(k):
+                poses.append(s.add_prefetched()[1])
+            i += k
+        return np.array(poses), s.stats()
+
+    po, so = run(system.ORACLE_LIB)
+    ph, sh = run(system.HOST_LIB, max_frames_in_flight=5, track_batch=4)
+    assert so["keyframes"] == sh["keyframes"] and so["map_points"] == sh["map_points"]
+    np.testing.assert_allclose(ph, po, atol=1e-7)
+    gt = {ts[i]: capi.pose12_to_tum(Twc[i]) for i in range(n)}
+    a_h = ev.ate(gt, {ts[i]: capi.pose12_to_tum(ph[i]) for i in range(n)})["rmse"]
+    a_o = ev.ate(gt, {ts[i]: capi.pose12_to_tum(po[i]) for i in range(n)})["rmse"]
+    assert a_h <= 1.05 * a_o + 1e-6 and a_o < 0.05

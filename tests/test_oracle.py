@@ -236,3 +236,34 @@ def test_config_file_parser(tmp_path):
     s.add_frame(ts[0], bgr[0], depth[0])
     assert s.stats()["last_keypoints"] == 0 or True
     assert s.stats()["map_points"] <= 321 and s.stats()["ba_runs"] == 0
+
+
+def run_system(lib, frames, n, **opt):
+    bgr, depth, Twc, ts = frames
+    look = opt.get("max_frames_in_flight", 1)
+    s = system.VoSystem(lib, **opt)
+    poses = []
+    i = 0
+    while i < n:
+        k = min(look, n - i)
+        if look > 1:
+            s.prefetch(ts[i:i + k], [bgr[j].ctypes.data for j in range(i, i + k)], [depth[j].ctypes.data for j in range(i, i + k)],
+                       bgr[0].strides[0], depth[0].strides[0], False)
+            for _ in range(k):
+                poses.append(s.add_prefetched()[1])
+        else:
+            poses.append(s.add_frame(ts[i], bgr[i], depth[i])[1])
+        i += k
+    return np.array(poses), s.stats()
+
+
+def test_speculative_batch_and_lookahead_do_not_change_the_trajectory(frames):
+    """Look-ahead ORB + speculative batched tracking (frames between keyframes share prior and map) must give
+    exactly the sequential result; an overlapped BA merged with a deterministic lag must be reproducible."""
+    n = 24
+    base, st0 = run_system(system.ORACLE_LIB, frames, n, number_of_features=400)
+    spec, st1 = run_system(system.ORACLE_LIB, frames, n, number_of_features=400, max_frames_in_flight=8, track_batch=4)
+    assert np.array_equal(base, spec) and st0["keyframes"] == st1["keyframes"] >= 2
+    lag_a, sa = run_system(system.ORACLE_LIB, frames, n, number_of_features=400, backend_lag_frames=3)
+    lag_b, sb = run_system(system.ORACLE_LIB, frames, n, number_of_features=400, backend_lag_frames=3, max_frames_in_flight=8, track_batch=4)
+    assert np.array_equal(lag_a, lag_b) and sa["ba_runs"] == sb["ba_runs"] >= 1
