@@ -66,10 +66,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--lookahead", type=int, default=32, help="frames per batched ORB launch chain")
-    ap.add_argument("--track-batch", type=int, default=1, help="frames tracked speculatively per launch chain (share prior + map)")
+    ap.add_argument("--track-batch", type=int, default=8, help="frames tracked speculatively per launch chain (share prior + map)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-ba", action="store_true", help="disable local BA (enable_local_optimization: 0)")
-    ap.add_argument("--ba-lag", type=int, default=0, help="0: BA synchronous in AddFrame; L>0: overlapped, merged L frames later (deterministic)")
+    ap.add_argument("--ba-lag", type=int, default=8, help="0: BA synchronous in AddFrame; L>0: overlapped, merged L frames later (deterministic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=150, help="bounded CPU-baseline sample (frames)")
     ap.add_argument("--profile-frames", type=int, default=64)

@@ -316,46 +316,91 @@ __global__ __launch_bounds__(1024) void k_ba_chol_lds(BaDev B) {
     if (tid == 0) B.scal[3] = s_ok ? 1.0 : 0.0;
 }
 
-// dense Cholesky + solve of the reduced system in one 1024-thread workgroup (right-looking, trailing
-// update spread over all lanes); result in bs, ok flag in scal[3].  Only the lower triangle is used.
+// Dense Cholesky + solve for any D: the matrix stays in global memory (L2 resident), only the current
+// 6-column panel (one pose block) is staged in LDS.  Per panel: 6x6 diagonal factor (lane 0), panel solve
+// (one lane per row), rank-6 trailing update of the lower triangle spread over 1024 lanes.
 __global__ __launch_bounds__(1024) void k_ba_chol(BaDev B) {
-    const int D = B.D, tid = threadIdx.x;
-    double* A = B.S; double* b = B.bs;
+    extern __shared__ double s_P[];                 // [D][6] current panel, then the right-hand side [D]
+    const int D = B.D, tid = threadIdx.x, np = D / 6;
+    double* A = B.S;
+    double* s_b = s_P + (size_t)6 * D;
+    __shared__ double s_dg[36];
     __shared__ int s_ok;
-    __shared__ double s_col[1024];
     if (tid == 0) s_ok = 1;
+    for (int i = tid; i < D; i += 1024) s_b[i] = B.bs[i];
     __syncthreads();
-    for (int j = 0; j < D; ++j) {
-        if (tid == 0) { const double d = A[(size_t)j * D + j]; if (!(d > 0.0)) s_ok = 0; else A[(size_t)j * D + j] = sqrt(d); }
+    for (int p = 0; p < np; ++p) {
+        const int j0 = 6 * p;
+        if (tid == 0) {
+            double d6[36];
+            for (int r = 0; r < 6; ++r) for (int c = 0; c <= r; ++c) d6[6 * r + c] = A[(size_t)(j0 + r) * D + j0 + c];
+            for (int j = 0; j < 6; ++j) {
+                double d = d6[7 * j];
+                for (int k = 0; k < j; ++k) d -= d6[6 * j + k] * d6[6 * j + k];
+                if (!(d > 0.0)) { s_ok = 0; break; }
+                d = sqrt(d);
+                d6[7 * j] = d;
+                const double inv = 1.0 / d;
+                for (int i = j + 1; i < 6; ++i) {
+                    double sum = d6[6 * i + j];
+                    for (int k = 0; k < j; ++k) sum -= d6[6 * i + k] * d6[6 * j + k];
+                    d6[6 * i + j] = sum * inv;
+                }
+            }
+            for (int r = 0; r < 6; ++r) for (int c = 0; c <= r; ++c) { s_dg[6 * r + c] = d6[6 * r + c]; A[(size_t)(j0 + r) * D + j0 + c] = d6[6 * r + c]; }
+        }
         __syncthreads();
         if (!s_ok) break;
-        const double dj = A[(size_t)j * D + j];
-        for (int i = j + 1 + tid; i < D; i += 1024) { const double l = A[(size_t)i * D + j] / dj; A[(size_t)i * D + j] = l; if (i - j - 1 < 1024) s_col[i - j - 1] = l; }
+        const int m = D - j0 - 6;
+        for (int r = tid; r < m; r += 1024) {
+            double* row = A + (size_t)(j0 + 6 + r) * D + j0;
+            double x[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                double sum = row[c];
+#pragma unroll
+                for (int k = 0; k < c; ++k) sum -= x[k] * s_dg[6 * c + k];
+                x[c] = sum / s_dg[7 * c];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) { row[c] = x[c]; s_P[6 * r + c] = x[c]; }
+        }
         __syncthreads();
-        const int m = D - j - 1;                      // trailing (m x m) lower triangle -= l l^T
-        if (m <= 1024) {
-            for (int t = tid; t < m * m; t += 1024) { const int r = t / m, c = t - r * m; if (c <= r) A[(size_t)(j + 1 + r) * D + j + 1 + c] -= s_col[r] * s_col[c]; }
-        } else {
-            for (int t = tid; t < m * m; t += 1024) { const int r = t / m, c = t - r * m; if (c <= r) A[(size_t)(j + 1 + r) * D + j + 1 + c] -= A[(size_t)(j + 1 + r) * D + j] * A[(size_t)(j + 1 + c) * D + j]; }
+        for (int t = tid; t < m * m; t += 1024) {
+            const int r = t / m, c = t - r * m;
+            if (c > r) continue;
+            const double* a = s_P + 6 * r;
+            const double* b = s_P + 6 * c;
+            A[(size_t)(j0 + 6 + r) * D + j0 + 6 + c] -= a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
         }
         __syncthreads();
     }
     if (s_ok) {
-        // forward / backward substitution, one column at a time (axpy form)
-        for (int j = 0; j < D; ++j) {
-            if (tid == 0) b[j] /= A[(size_t)j * D + j];
+        for (int p = 0; p < np; ++p) {                  // L y = b
+            const int j0 = 6 * p;
+            if (tid == 0)
+                for (int j = 0; j < 6; ++j) { double sum = s_b[j0 + j]; for (int k = 0; k < j; ++k) sum -= A[(size_t)(j0 + j) * D + j0 + k] * s_b[j0 + k]; s_b[j0 + j] = sum / A[(size_t)(j0 + j) * D + j0 + j]; }
             __syncthreads();
-            const double bj = b[j];
-            for (int i = j + 1 + tid; i < D; i += 1024) b[i] -= A[(size_t)i * D + j] * bj;
-            __syncthreads();
-        }
-        for (int j = D - 1; j >= 0; --j) {
-            if (tid == 0) b[j] /= A[(size_t)j * D + j];
-            __syncthreads();
-            const double bj = b[j];
-            for (int i = tid; i < j; i += 1024) b[i] -= A[(size_t)j * D + i] * bj;
+            for (int r = j0 + 6 + tid; r < D; r += 1024) {
+                const double* a = A + (size_t)r * D + j0;
+                s_b[r] -= a[0] * s_b[j0] + a[1] * s_b[j0 + 1] + a[2] * s_b[j0 + 2] + a[3] * s_b[j0 + 3] + a[4] * s_b[j0 + 4] + a[5] * s_b[j0 + 5];
+            }
             __syncthreads();
         }
+        for (int p = np - 1; p >= 0; --p) {             // L^T x = y
+            const int j0 = 6 * p;
+            if (tid == 0)
+                for (int j = 5; j >= 0; --j) { double sum = s_b[j0 + j]; for (int k = j + 1; k < 6; ++k) sum -= A[(size_t)(j0 + k) * D + j0 + j] * s_b[j0 + k]; s_b[j0 + j] = sum / A[(size_t)(j0 + j) * D + j0 + j]; }
+            __syncthreads();
+            for (int r = tid; r < j0; r += 1024) {
+                double sum = 0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) sum += A[(size_t)(j0 + k) * D + r] * s_b[j0 + k];
+                s_b[r] -= sum;
+            }
+            __syncthreads();
+        }
+        for (int i = tid; i < D; i += 1024) B.bs[i] = s_b[i];
     }
     if (tid == 0) B.scal[3] = s_ok ? 1.0 : 0.0;
 }
@@ -443,8 +488,10 @@ __global__ void k_ba_cull(BaCam cam, BaDev B, int stage, double th) {
 
 int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     hipStream_t st = c->stream;
-    { static bool attr = false; if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)); attr = true; } }
+    { static bool attr = false; if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)); attr = true; } }
     const int np = in->n_poses, nf = in->n_free, nx = in->n_points, ne = in->n_edges, D = 6 * nf;
+    if ((size_t)7 * D * sizeof(double) > 158 * 1024) return VO_E_UNSUPPORTED;      // > 481 free poses
     out->lm_iters = 0; out->chi2_initial = 0; out->chi2_final = 0;
     if (ne == 0 || nf == 0 || nx == 0) {
         memcpy(out->poses, in->poses, sizeof(double) * 12 * (size_t)nf);
@@ -559,7 +606,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
                 if (nblk) { ProfScope ps(c, "k_ba_schur_blocks"); hipLaunchKernelGGL(k_ba_schur_blocks, dim3(nblk), blk, 0, st, B); }
                 { ProfScope ps(c, "k_ba_chol");
                   if (D <= 138) hipLaunchKernelGGL(k_ba_chol_lds, dim3(1), dim3(1024), sizeof(double) * ((size_t)(D | 1) * D + D), st, B);
-                  else hipLaunchKernelGGL(k_ba_chol, dim3(1), dim3(1024), 0, st, B); }
+                  else hipLaunchKernelGGL(k_ba_chol, dim3(1), dim3(1024), sizeof(double) * (size_t)7 * D, st, B); }
                 hipLaunchKernelGGL(k_ba_backsub, gP, blk, 0, st, B, lambda);
                 hipLaunchKernelGGL(k_ba_pose, gJ, blk, 0, st, B, lambda);
                 hipLaunchKernelGGL(k_ba_chi, gE, blk, 0, st, cam, B, 1, robust, in->huber_delta);

@@ -47,6 +47,7 @@ private:
     vo_ctx* ctxOwn_ = nullptr;      // worker's own context (lag > 0)
     int device_ = 0, lag_ = 0;
     size_t frameIndex_ = 0;
+    uint64_t buildStamp_ = 0;
     std::unique_ptr<Job> job_;
     std::thread worker_; std::mutex mu_; std::condition_variable cv_; bool quit_ = false, hasWork_ = false;
     Stats stats_;

@@ -35,6 +35,7 @@ public:
     std::unordered_set<size_t> GetCovisibleKeyframes() { std::unique_lock<std::mutex> lck(observationMutex_); return activeCovisibleKeyframes_; }
 
     int slot_ = -1;                 // vo_ctx frame slot holding this frame's ORB results (-1: none)
+    uint64_t baStamp_ = 0; int baIndex_ = -1;    // scratch of Backend::Build
     bool orb_done_ = false;
 
 private:

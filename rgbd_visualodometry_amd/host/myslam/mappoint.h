@@ -4,10 +4,12 @@
 #include "myslam/common_include.h"
 
 namespace myslam {
+class Frame;
 class Mappoint {
 public:
     typedef std::shared_ptr<Mappoint> Ptr;
     typedef std::unordered_map<size_t, Point2f> ObservedByKeyframeIdtoPixelPos;
+    struct Observation { size_t keyframeId; Point2f pixel; Frame* keyframe; };
 
     Descriptor  descriptor_;        // 256-bit rBRIEF descriptor used for matching
     bool        triangulated_;      // refined by the front-end's triangulation
@@ -21,7 +23,8 @@ public:
     size_t GetId() const { return id_; }
     Vector3d GetNormDirection() { std::unique_lock<std::mutex> lock(observationMutex_); return norm_; }
 
-    void AddObservedByKeyframe(const size_t keyframeId, const Point2f posInPixel, const Vector3d cameraCenter);
+    void AddObservedByKeyframe(const size_t keyframeId, const Point2f posInPixel, const Vector3d cameraCenter, Frame* keyframe = nullptr);
+    const std::vector<Observation>& ObservationList() const { return obsList_; }     // insertion (= keyframe id) order; single-threaded callers
     void RemoveObservedByKeyframe(const size_t keyframeId);
     const ObservedByKeyframeIdtoPixelPos& ObservationsNoCopy() const { return observedByKeyframeMap_; }   // single-threaded callers only
     ObservedByKeyframeIdtoPixelPos GetObservedByKeyframesMap() { std::unique_lock<std::mutex> lock(observationMutex_); return observedByKeyframeMap_; }
@@ -30,6 +33,7 @@ public:
     int  slot_ = -1;
     bool dirty_ = false;            // host copy newer than the device copy (queued in MapManager's dirty list)
     uint64_t visitStamp_ = 0;       // scratch for de-duplicated traversals
+    uint64_t baStamp_ = 0; int baIndex_ = -1;    // scratch of Backend::Build
     void MarkDirty();
 
 private:
@@ -40,6 +44,7 @@ private:
     Vector3d pos_;
     std::mutex observationMutex_;
     ObservedByKeyframeIdtoPixelPos observedByKeyframeMap_;
+    std::vector<Observation> obsList_;
     Mappoint(const size_t id, const Vector3d position, const Descriptor& descriptor);
 };
 }  // namespace myslam

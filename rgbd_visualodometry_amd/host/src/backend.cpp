@@ -90,44 +90,39 @@ void Backend::OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr) {
 // they observe (:62-81); one edge per observation, observers outside the free set are fixed (:88-135).
 void Backend::Build(Job& j, const Frame::Ptr& kf) {
     MapManager& map = MapManager::GetInstance();
+    const uint64_t stamp = ++buildStamp_;            // index scratch lives in the frames / map points: no hash maps
     auto covis = kf->GetCovisibleKeyframes();
     covis.insert(kf->GetId());
     std::vector<size_t> freeIds(covis.begin(), covis.end());
     std::sort(freeIds.begin(), freeIds.end());
-    std::unordered_map<size_t, int> poseIndex;
     for (size_t id : freeIds) {
         auto f = map.GetKeyframe(id);
         if (f == nullptr) continue;
-        poseIndex[id] = (int)j.poseFrames.size();
+        f->baStamp_ = stamp; f->baIndex_ = (int)j.poseFrames.size();
         j.poseFrames.push_back(f);
     }
     j.nFree = (int)j.poseFrames.size();
-    std::unordered_map<size_t, int> pointIndex;
     for (int p = 0; p < j.nFree; ++p) {
         Frame& f = *j.poseFrames[p];
         for (size_t mpId : f.ObservedOrder()) {          // insertion order: deterministic without sorting
-            if (pointIndex.count(mpId) || !f.IsObservedMappoint(mpId)) continue;
-            auto mp = map.GetMappoint(mpId);
-            if (mp == nullptr || mp->outlier_) continue;
-            pointIndex[mpId] = (int)j.points.size();
-            j.points.push_back(mp);
+            Mappoint* mp = map.FindMappoint(mpId);
+            if (mp == nullptr || mp->baStamp_ == stamp || mp->outlier_ || !f.IsObservedMappoint(mpId)) continue;
+            mp->baStamp_ = stamp; mp->baIndex_ = (int)j.points.size();
+            j.points.push_back(map.GetMappoint(mpId));
         }
     }
-    std::vector<std::pair<size_t, Point2f>> obs;
     for (size_t k = 0; k < j.points.size(); ++k) {
-        obs.assign(j.points[k]->ObservationsNoCopy().begin(), j.points[k]->ObservationsNoCopy().end());
-        std::sort(obs.begin(), obs.end(), [](const std::pair<size_t, Point2f>& a, const std::pair<size_t, Point2f>& b) { return a.first < b.first; });
-        for (auto& o : obs) {
-            auto it = poseIndex.find(o.first);
-            int pj;
-            if (it != poseIndex.end()) pj = it->second;
-            else {
-                auto f = map.GetKeyframe(o.first);
-                if (f == nullptr) continue;
-                pj = (int)j.poseFrames.size(); poseIndex[o.first] = pj; j.poseFrames.push_back(f);
+        for (const Mappoint::Observation& o : j.points[k]->ObservationList()) {     // keyframe-id order
+            Frame* f = o.keyframe;
+            if (f == nullptr) continue;
+            if (f->baStamp_ != stamp) {                                             // observer outside the free set: fixed pose
+                auto fp = map.GetKeyframe(o.keyframeId);
+                if (fp == nullptr) continue;
+                f->baStamp_ = stamp; f->baIndex_ = (int)j.poseFrames.size();
+                j.poseFrames.push_back(fp);
             }
-            j.edgePose.push_back(pj); j.edgePoint.push_back((int)k);
-            j.edgeUv.push_back(o.second.x); j.edgeUv.push_back(o.second.y);
+            j.edgePose.push_back(f->baIndex_); j.edgePoint.push_back((int)k);
+            j.edgeUv.push_back(o.pixel.x); j.edgeUv.push_back(o.pixel.y);
         }
     }
     j.poses.resize(12 * j.poseFrames.size()); j.pts.resize(3 * j.points.size());

@@ -37,7 +37,7 @@ void Frame::AddObservedMappoint(const size_t mappointId, const Point2f pixelPos)
     observedOrder_.push_back(mappointId);
     auto mappoint = MapManager::GetInstance().GetMappoint(mappointId);
     assert(mappoint != nullptr);
-    mappoint->AddObservedByKeyframe(id_, pixelPos, GetCamCenter());
+    mappoint->AddObservedByKeyframe(id_, pixelPos, GetCamCenter(), this);
     for (auto& idToPixel : mappoint->GetObservedByKeyframesMap()) {
         const size_t other = idToPixel.first;
         if (other == id_) continue;

@@ -13,10 +13,11 @@ Mappoint::Ptr Mappoint::CreateMappoint(const Vector3d position, const Descriptor
 Mappoint::Mappoint(const size_t id, const Vector3d position, const Descriptor& descriptor)
     : descriptor_(descriptor), triangulated_(false), optimized_(false), outlier_(false), id_(id), norm_(Vector3d::Zero()), pos_(position) {}
 
-void Mappoint::AddObservedByKeyframe(const size_t keyframeId, const Point2f posInPixel, const Vector3d cameraCenter) {
+void Mappoint::AddObservedByKeyframe(const size_t keyframeId, const Point2f posInPixel, const Vector3d cameraCenter, Frame* keyframe) {
     std::unique_lock<std::mutex> lock(observationMutex_);
     assert(!observedByKeyframeMap_.count(keyframeId));
     observedByKeyframeMap_[keyframeId] = posInPixel;
+    obsList_.push_back(Observation{keyframeId, posInPixel, keyframe});
     norm_ = (norm_ + (pos_ - cameraCenter).normalized()).normalized();      // running mean viewing direction
     lock.unlock();
     MarkDirty();
@@ -26,6 +27,7 @@ void Mappoint::RemoveObservedByKeyframe(const size_t keyframeId) {
     std::unique_lock<std::mutex> lock(observationMutex_);
     assert(observedByKeyframeMap_.count(keyframeId));
     observedByKeyframeMap_.erase(keyframeId);
+    for (size_t i = 0; i < obsList_.size(); ++i) if (obsList_[i].keyframeId == keyframeId) { obsList_.erase(obsList_.begin() + i); break; }
     if (observedByKeyframeMap_.empty()) { outlier_ = true; lock.unlock(); MarkDirty(); }  // no observation left
 }
 

@@ -148,9 +148,9 @@ def test_track_frame_matches_oracle(frames, libs):
     assert np.abs(np.array(ro.T_cw) - inv12(Twc[8])).max() < 0.02
 
 
-def test_local_ba_matches_oracle(libs):
+@pytest.mark.parametrize("nP,nX,nfree", [(6, 400, 4), (34, 500, 30)])       # 30 free poses: D = 180 > LDS-resident limit
+def test_local_ba_matches_oracle(libs, nP, nX, nfree):
     rng = np.random.default_rng(5)
-    nP, nX, nfree = 6, 400, 4
 
     def expso3(w):
         th = np.linalg.norm(w)
@@ -184,10 +184,12 @@ def test_local_ba_matches_oracle(libs):
         ctx, _ = make_ctx(L, map_capacity=1024)
         res.append(ctx.local_ba(poses0, nfree, X0, ep, el, np.array(uv, dtype=np.float32)))
     (ph, xh, fh, rh), (po, xo, fo, ro) = res
-    assert rh.lm_iters == ro.lm_iters
+    # the gain-ratio test near convergence is noise-limited: one LM iteration more or less is legitimate
+    assert abs(rh.lm_iters - ro.lm_iters) <= (0 if nfree < 10 else 2)
     assert np.array_equal(fh, fo)
-    np.testing.assert_allclose(ph, po, atol=1e-8)
-    np.testing.assert_allclose(xh, xo, atol=1e-7)
+    tol = 1e-8 if nfree < 10 else 1e-6
+    np.testing.assert_allclose(ph, po, atol=tol)
+    np.testing.assert_allclose(xh, xo, atol=10 * tol)
     assert ro.chi2_final < 0.01 * ro.chi2_initial
     assert np.abs(po - poses[:nfree]).max() < 0.01
 
