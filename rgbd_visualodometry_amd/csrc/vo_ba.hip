@@ -19,6 +19,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
+#include <cstdlib>
 #include <vector>
 
 #include "vo_internal.h"
@@ -231,32 +233,33 @@ __global__ __launch_bounds__(256) void k_ba_schur_blocks(BaDev B) {
     }
 }
 
-// Dense Cholesky + solve of the reduced system, whole lower triangle resident in LDS (D <= 140),
+// Dense Cholesky + solve of the reduced system, packed lower triangle resident in LDS (D <= 198),
 // blocked by pose (6-column panels): diagonal 6x6 factor, panel solve (one lane per row), rank-6
 // trailing update spread over 1024 lanes.  3 barriers per panel instead of 3 per column.
+#define TRI(r, c) ((size_t)(r) * ((r) + 1) / 2 + (c))      // packed lower triangle
 __global__ __launch_bounds__(1024) void k_ba_chol_lds(BaDev B) {
     extern __shared__ double s_L[];
-    const int D = B.D, ld = D | 1, tid = threadIdx.x, np = D / 6;
-    double* s_b = s_L + (size_t)ld * D;
+    const int D = B.D, tid = threadIdx.x, np = D / 6;
+    double* s_b = s_L + TRI(D, 0);
     __shared__ int s_ok;
     if (tid == 0) s_ok = 1;
-    for (int i = tid; i < D * D; i += 1024) { const int r = i / D, c = i - r * D; if (c <= r) s_L[r * ld + c] = B.S[i]; }
+    for (int i = tid; i < D * D; i += 1024) { const int r = i / D, c = i - r * D; if (c <= r) s_L[TRI(r, c)] = B.S[i]; }
     for (int i = tid; i < D; i += 1024) s_b[i] = B.bs[i];
     __syncthreads();
     for (int p = 0; p < np; ++p) {
         const int j0 = 6 * p;
         if (tid == 0) {
             for (int j = 0; j < 6 && s_ok; ++j) {
-                double d = s_L[(j0 + j) * ld + j0 + j];
-                for (int k = 0; k < j; ++k) d -= s_L[(j0 + j) * ld + j0 + k] * s_L[(j0 + j) * ld + j0 + k];
+                double d = s_L[TRI(j0 + j, j0 + j)];
+                for (int k = 0; k < j; ++k) d -= s_L[TRI(j0 + j, j0 + k)] * s_L[TRI(j0 + j, j0 + k)];
                 if (!(d > 0.0)) { s_ok = 0; break; }
                 d = sqrt(d);
-                s_L[(j0 + j) * ld + j0 + j] = d;
+                s_L[TRI(j0 + j, j0 + j)] = d;
                 const double inv = 1.0 / d;
                 for (int i = j + 1; i < 6; ++i) {
-                    double sum = s_L[(j0 + i) * ld + j0 + j];
-                    for (int k = 0; k < j; ++k) sum -= s_L[(j0 + i) * ld + j0 + k] * s_L[(j0 + j) * ld + j0 + k];
-                    s_L[(j0 + i) * ld + j0 + j] = sum * inv;
+                    double sum = s_L[TRI(j0 + i, j0 + j)];
+                    for (int k = 0; k < j; ++k) sum -= s_L[TRI(j0 + i, j0 + k)] * s_L[TRI(j0 + j, j0 + k)];
+                    s_L[TRI(j0 + i, j0 + j)] = sum * inv;
                 }
             }
         }
@@ -264,14 +267,14 @@ __global__ __launch_bounds__(1024) void k_ba_chol_lds(BaDev B) {
         if (!s_ok) break;
         const int m = D - j0 - 6;                       // rows below the panel
         for (int r = tid; r < m; r += 1024) {
-            double* row = s_L + (size_t)(j0 + 6 + r) * ld + j0;
+            double* row = s_L + TRI(j0 + 6 + r, j0);
             double x[6];
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
                 double sum = row[c];
 #pragma unroll
-                for (int k = 0; k < c; ++k) sum -= x[k] * s_L[(j0 + c) * ld + j0 + k];
-                x[c] = sum / s_L[(j0 + c) * ld + j0 + c];
+                for (int k = 0; k < c; ++k) sum -= x[k] * s_L[TRI(j0 + c, j0 + k)];
+                x[c] = sum / s_L[TRI(j0 + c, j0 + c)];
             }
 #pragma unroll
             for (int c = 0; c < 6; ++c) row[c] = x[c];
@@ -280,9 +283,9 @@ __global__ __launch_bounds__(1024) void k_ba_chol_lds(BaDev B) {
         for (int t = tid; t < m * m; t += 1024) {
             const int r = t / m, c = t - r * m;
             if (c > r) continue;
-            const double* a = s_L + (size_t)(j0 + 6 + r) * ld + j0;
-            const double* b = s_L + (size_t)(j0 + 6 + c) * ld + j0;
-            s_L[(size_t)(j0 + 6 + r) * ld + j0 + 6 + c] -= a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+            const double* a = s_L + TRI(j0 + 6 + r, j0);
+            const double* b = s_L + TRI(j0 + 6 + c, j0);
+            s_L[TRI(j0 + 6 + r, j0 + 6 + c)] -= a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
         }
         __syncthreads();
     }
@@ -290,10 +293,10 @@ __global__ __launch_bounds__(1024) void k_ba_chol_lds(BaDev B) {
         for (int p = 0; p < np; ++p) {                  // L y = b
             const int j0 = 6 * p;
             if (tid == 0)
-                for (int j = 0; j < 6; ++j) { double sum = s_b[j0 + j]; for (int k = 0; k < j; ++k) sum -= s_L[(j0 + j) * ld + j0 + k] * s_b[j0 + k]; s_b[j0 + j] = sum / s_L[(j0 + j) * ld + j0 + j]; }
+                for (int j = 0; j < 6; ++j) { double sum = s_b[j0 + j]; for (int k = 0; k < j; ++k) sum -= s_L[TRI(j0 + j, j0 + k)] * s_b[j0 + k]; s_b[j0 + j] = sum / s_L[TRI(j0 + j, j0 + j)]; }
             __syncthreads();
             for (int r = j0 + 6 + tid; r < D; r += 1024) {
-                const double* a = s_L + (size_t)r * ld + j0;
+                const double* a = s_L + TRI(r, j0);
                 s_b[r] -= a[0] * s_b[j0] + a[1] * s_b[j0 + 1] + a[2] * s_b[j0 + 2] + a[3] * s_b[j0 + 3] + a[4] * s_b[j0 + 4] + a[5] * s_b[j0 + 5];
             }
             __syncthreads();
@@ -301,12 +304,12 @@ __global__ __launch_bounds__(1024) void k_ba_chol_lds(BaDev B) {
         for (int p = np - 1; p >= 0; --p) {             // L^T x = y
             const int j0 = 6 * p;
             if (tid == 0)
-                for (int j = 5; j >= 0; --j) { double sum = s_b[j0 + j]; for (int k = j + 1; k < 6; ++k) sum -= s_L[(j0 + k) * ld + j0 + j] * s_b[j0 + k]; s_b[j0 + j] = sum / s_L[(j0 + j) * ld + j0 + j]; }
+                for (int j = 5; j >= 0; --j) { double sum = s_b[j0 + j]; for (int k = j + 1; k < 6; ++k) sum -= s_L[TRI(j0 + k, j0 + j)] * s_b[j0 + k]; s_b[j0 + j] = sum / s_L[TRI(j0 + j, j0 + j)]; }
             __syncthreads();
             for (int r = tid; r < j0; r += 1024) {
                 double sum = 0;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) sum += s_L[(size_t)(j0 + k) * ld + r] * s_b[j0 + k];
+                for (int k = 0; k < 6; ++k) sum += s_L[TRI(j0 + k, r)] * s_b[j0 + k];
                 s_b[r] -= sum;
             }
             __syncthreads();
@@ -366,12 +369,26 @@ __global__ __launch_bounds__(1024) void k_ba_chol(BaDev B) {
             for (int c = 0; c < 6; ++c) { row[c] = x[c]; s_P[6 * r + c] = x[c]; }
         }
         __syncthreads();
-        for (int t = tid; t < m * m; t += 1024) {
-            const int r = t / m, c = t - r * m;
-            if (c > r) continue;
-            const double* a = s_P + 6 * r;
-            const double* b = s_P + 6 * c;
-            A[(size_t)(j0 + 6 + r) * D + j0 + 6 + c] -= a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+        for (int t0 = tid; t0 < m * m; t0 += 4 * 1024) {   // 4 independent read-modify-writes in flight per lane
+            double* ptr[4]; double upd[4], old[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + u * 1024;
+                ptr[u] = nullptr;
+                if (t < m * m) {
+                    const int r = t / m, c = t - r * m;
+                    if (c <= r) {
+                        const double* a = s_P + 6 * r;
+                        const double* b = s_P + 6 * c;
+                        ptr[u] = &A[(size_t)(j0 + 6 + r) * D + j0 + 6 + c];
+                        upd[u] = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (ptr[u]) old[u] = *ptr[u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (ptr[u]) *ptr[u] = old[u] - upd[u];
         }
         __syncthreads();
     }
@@ -499,6 +516,9 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
         memset(out->edge_flags, 0, ne);
         return VO_OK;
     }
+    const bool trace = getenv("VO_TRACE") != nullptr;
+    auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tt0 = tnow();
     // CSR point -> edges
     std::vector<int32_t> pt_start(nx + 1, 0), pt_edges(ne);
     for (int e = 0; e < ne; ++e) pt_start[in->edge_point[e] + 1]++;
@@ -580,6 +600,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     HIP_TRY(hipMemsetAsync(base + o_flags, 0, ne, st));
     HIP_TRY(hipStreamSynchronize(st));       // pageable sources
 
+    const double tt1 = tnow();
     double* h_scal = (double*)vo_stage(c, 64);
     if (!h_scal) return VO_E_NOMEM;
     const dim3 blk(256), gE((ne + 255) / 256), gP((nx + 255) / 256), gJ((np + 255) / 256);
@@ -605,7 +626,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
                 hipLaunchKernelGGL(k_ba_init_S, dim3((std::max(D * D, nx) + 255) / 256), blk, 0, st, B, lambda);
                 if (nblk) { ProfScope ps(c, "k_ba_schur_blocks"); hipLaunchKernelGGL(k_ba_schur_blocks, dim3(nblk), blk, 0, st, B); }
                 { ProfScope ps(c, "k_ba_chol");
-                  if (D <= 138) hipLaunchKernelGGL(k_ba_chol_lds, dim3(1), dim3(1024), sizeof(double) * ((size_t)(D | 1) * D + D), st, B);
+                  if (D <= 198) hipLaunchKernelGGL(k_ba_chol_lds, dim3(1), dim3(1024), sizeof(double) * ((size_t)D * (D + 1) / 2 + D), st, B);
                   else hipLaunchKernelGGL(k_ba_chol, dim3(1), dim3(1024), sizeof(double) * (size_t)7 * D, st, B); }
                 hipLaunchKernelGGL(k_ba_backsub, gP, blk, 0, st, B, lambda);
                 hipLaunchKernelGGL(k_ba_pose, gJ, blk, 0, st, B, lambda);
@@ -645,10 +666,12 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     if ((rc = read_scal())) return rc;
     out->chi2_final = h_scal[6];
     out->lm_iters = iters;
+    const double tt2 = tnow();
     HIP_TRY(hipMemcpyAsync(out->poses, B.poses, 96 * (size_t)nf, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(out->points, B.pts, 24 * (size_t)nx, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(out->edge_flags, B.flags, ne, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
+    if (trace) { static double a0 = 0, a1 = 0, a2 = 0; static int n = 0; a0 += tt1 - tt0; a1 += tt2 - tt1; a2 += tnow() - tt2; if (++n % 10 == 0) fprintf(stderr, "[vo_trace] vo_ba_run avg ms: prep+upload %.2f optimise %.2f download %.2f (D=%d edges=%d pairs=%d)\n", a0 / n, a1 / n, a2 / n, D, ne, npairs); }
     return VO_OK;
 }
