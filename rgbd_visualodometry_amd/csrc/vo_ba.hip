@@ -30,9 +30,18 @@ struct BaCam { double fx, fy, cx, cy; };
 
 struct BaBlock { int j1, j2, start, count; };      // one 6x6 block of the reduced system and its pair list
 
+// Device-resident Levenberg-Marquardt state: the accept/reject decision, the lambda policy and the
+// iteration bookkeeping run in a one-lane kernel (k_ba_control) so that several LM steps can be enqueued
+// back to back; the host only polls `finished` once per chunk of steps.
+struct BaCtl {
+    double lambda, ni, cur;
+    int it, qmax, max_it, need_lin, first, finished, buf, iters_done, steps, pad;
+};
+
 struct BaDev {
     int n_poses, n_free, n_points, n_edges, D, n_blocks;
-    double* poses; double* pts; double* poses_n; double* pts_n;
+    BaCtl* ctl;
+    double* posesA; double* ptsA; double* posesB; double* ptsB;      // double-buffered state, ctl->buf selects the current one
     const int32_t* e_pose; const int32_t* e_pt; const float* e_uv; uint8_t* active; uint8_t* flags;
     const int32_t* pt_start; const int32_t* pt_edges;       // CSR point -> edges
     const int32_t* ps_start; const int32_t* ps_edges;       // CSR free pose -> edges
@@ -41,6 +50,12 @@ struct BaDev {
     double* S; double* bs; double* Hinv; double* dl;
     double* scal;       // [0] chi cur  [1] chi trial  [2] scale  [3] ok  [4] maxdiag (as u64 bits) [5] chi report [6] chi final
 };
+
+#define BA_STATE(B) \
+    const int buf_ = B.ctl->buf; \
+    double* const poses_c = buf_ ? B.posesB : B.posesA; double* const pts_c = buf_ ? B.ptsB : B.ptsA; \
+    double* const poses_t = buf_ ? B.posesA : B.posesB; double* const pts_t = buf_ ? B.ptsA : B.ptsB; \
+    (void)poses_c; (void)pts_c; (void)poses_t; (void)pts_t;
 
 __device__ __forceinline__ void ba_err(const BaCam& cam, const double* T, const double* p, const float* uv, double r[2], double pc[3]) {
     pc[0] = T[0] * p[0] + T[1] * p[1] + T[2] * p[2] + T[9];
@@ -85,53 +100,66 @@ __device__ __forceinline__ void ba_wave_reduce(double* v) {      // 64 threads; 
     for (int i = 0; i < NV; ++i) v[i] = vo_wave_sum_f64(v[i]);
 }
 
-// one lane per point: H_ll, b_l (no atomics), W_e of its free-pose edges, robust chi2
+// one lane per EDGE: H_ll, b_l through f64 atomics (a point has only a handful of edges: no contention),
+// W_e of free-pose edges, robust chi2.  H_ll / b_l are zeroed by k_ba_prelin.
 __global__ __launch_bounds__(256) void k_ba_lin_points(BaCam cam, BaDev B, int robust, double delta) {
+    if (B.ctl->finished || !B.ctl->need_lin) return;
+    BA_STATE(B)
     __shared__ double s_part[4];
-    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int e = blockIdx.x * 256 + threadIdx.x;
     double chi[1] = {0.0};
-    if (k < B.n_points) {
-        double H[6] = {0, 0, 0, 0, 0, 0}, b3[3] = {0, 0, 0};
-        const double* p = B.pts + 3 * (size_t)k;
-        for (int q = B.pt_start[k]; q < B.pt_start[k + 1]; ++q) {
-            const int e = B.pt_edges[q];
-            if (!B.active[e]) continue;
-            const int j = B.e_pose[e];
-            double r[2], w, rho0, Jp[2][6], Jl[2][3];
-            ba_edge(cam, B.poses + 12 * (size_t)j, p, B.e_uv + 2 * (size_t)e, robust, delta, r, w, rho0, Jp, Jl);
-            chi[0] += rho0;
-            b3[0] -= w * (Jl[0][0] * r[0] + Jl[1][0] * r[1]); b3[1] -= w * (Jl[0][1] * r[0] + Jl[1][1] * r[1]); b3[2] -= w * (Jl[0][2] * r[0] + Jl[1][2] * r[1]);
-            H[0] += w * (Jl[0][0] * Jl[0][0] + Jl[1][0] * Jl[1][0]); H[1] += w * (Jl[0][0] * Jl[0][1] + Jl[1][0] * Jl[1][1]); H[2] += w * (Jl[0][0] * Jl[0][2] + Jl[1][0] * Jl[1][2]);
-            H[3] += w * (Jl[0][1] * Jl[0][1] + Jl[1][1] * Jl[1][1]); H[4] += w * (Jl[0][1] * Jl[0][2] + Jl[1][1] * Jl[1][2]); H[5] += w * (Jl[0][2] * Jl[0][2] + Jl[1][2] * Jl[1][2]);
-            if (j < B.n_free) {
-                double* We = B.W + 18 * (size_t)e;
-#pragma unroll
-                for (int a = 0; a < 6; ++a)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) We[3 * a + c] = w * (Jp[0][a] * Jl[0][c] + Jp[1][a] * Jl[1][c]);
-            }
-        }
+    if (e < B.n_edges && B.active[e]) {
+        const int j = B.e_pose[e], k = B.e_pt[e];
+        double r[2], w, rho0, Jp[2][6], Jl[2][3];
+        ba_edge(cam, poses_c + 12 * (size_t)j, pts_c + 3 * (size_t)k, B.e_uv + 2 * (size_t)e, robust, delta, r, w, rho0, Jp, Jl);
+        chi[0] = rho0;
         double* Ho = B.Hll + 9 * (size_t)k;
-        Ho[0] = H[0]; Ho[1] = H[1]; Ho[2] = H[2]; Ho[3] = H[1]; Ho[4] = H[3]; Ho[5] = H[4]; Ho[6] = H[2]; Ho[7] = H[4]; Ho[8] = H[5];
-        B.bl[3 * (size_t)k] = b3[0]; B.bl[3 * (size_t)k + 1] = b3[1]; B.bl[3 * (size_t)k + 2] = b3[2];
+        double* bo = B.bl + 3 * (size_t)k;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicAdd(&bo[a], -w * (Jl[0][a] * r[0] + Jl[1][a] * r[1]));
+#pragma unroll
+            for (int c = 0; c < 3; ++c) atomicAdd(&Ho[3 * a + c], w * (Jl[0][a] * Jl[0][c] + Jl[1][a] * Jl[1][c]));
+        }
+        if (j < B.n_free) {
+            double* We = B.W + 18 * (size_t)e;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) We[3 * a + c] = w * (Jp[0][a] * Jl[0][c] + Jp[1][a] * Jl[1][c]);
+        }
     }
     ba_block_reduce<1>(chi, s_part);
     if (threadIdx.x == 0 && chi[0] != 0.0) atomicAdd(&B.scal[0], chi[0]);
 }
 
-// one workgroup per free pose: H_pp (6x6) and b_p by a block reduction over the pose's edges
+// zero the accumulators of a linearisation (H_ll, b_l, H_pp, b_p)
+__global__ void k_ba_prelin(BaDev B) {
+    if (B.ctl->finished || !B.ctl->need_lin) return;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 9 * (size_t)B.n_points) B.Hll[i] = 0;
+    if (i < 3 * (size_t)B.n_points) B.bl[i] = 0;
+    if (i < 36 * (size_t)B.n_free) B.Hpp[i] = 0;
+    if (i < (size_t)B.D) B.bp[i] = 0;
+}
+
+// PSPLIT workgroups per free pose: H_pp (6x6) and b_p by block reductions over slices of the pose's edges,
+// combined with 27 f64 atomics per workgroup
+#define PSPLIT 4
 __global__ __launch_bounds__(256) void k_ba_lin_poses(BaCam cam, BaDev B, int robust, double delta) {
+    if (B.ctl->finished || !B.ctl->need_lin) return;
+    BA_STATE(B)
     __shared__ double s_part[4 * 27];
-    const int j = blockIdx.x;
-    const double* T = B.poses + 12 * (size_t)j;
+    const int j = blockIdx.x / PSPLIT, part = blockIdx.x % PSPLIT;
+    const double* T = poses_c + 12 * (size_t)j;
     double v[27];
 #pragma unroll
     for (int i = 0; i < 27; ++i) v[i] = 0;
-    for (int q = B.ps_start[j] + threadIdx.x; q < B.ps_start[j + 1]; q += 256) {
+    for (int q = B.ps_start[j] + part * 256 + threadIdx.x; q < B.ps_start[j + 1]; q += 256 * PSPLIT) {
         const int e = B.ps_edges[q];
         if (!B.active[e]) continue;
         double r[2], w, rho0, Jp[2][6], Jl[2][3];
-        ba_edge(cam, T, B.pts + 3 * (size_t)B.e_pt[e], B.e_uv + 2 * (size_t)e, robust, delta, r, w, rho0, Jp, Jl);
+        ba_edge(cam, T, pts_c + 3 * (size_t)B.e_pt[e], B.e_uv + 2 * (size_t)e, robust, delta, r, w, rho0, Jp, Jl);
         int c = 0;
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
@@ -143,12 +171,13 @@ __global__ __launch_bounds__(256) void k_ba_lin_poses(BaCam cam, BaDev B, int ro
     ba_block_reduce<27>(v, s_part);
     if (threadIdx.x == 0) {
         int c = 0;
-        for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) { B.Hpp[36 * (size_t)j + 6 * a + b] = v[c]; B.Hpp[36 * (size_t)j + 6 * b + a] = v[c]; ++c; }
-        for (int a = 0; a < 6; ++a) B.bp[6 * j + a] = v[21 + a];
+        for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) { atomicAdd(&B.Hpp[36 * (size_t)j + 6 * a + b], v[c]); if (a != b) atomicAdd(&B.Hpp[36 * (size_t)j + 6 * b + a], v[c]); ++c; }
+        for (int a = 0; a < 6; ++a) atomicAdd(&B.bp[6 * j + a], v[21 + a]);
     }
 }
 
 __global__ void k_ba_maxdiag(BaDev B) {
+    if (B.ctl->finished || !B.ctl->need_lin || !B.ctl->first) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     double v = 0;
     if (i < B.D) v = fabs(B.Hpp[36 * (size_t)(i / 6) + 7 * (i % 6)]);
@@ -160,7 +189,9 @@ __global__ void k_ba_maxdiag(BaDev B) {
 }
 
 // S = blockdiag(H_pp) + lambda I, b_s = b_p, and (H_ll + lambda I)^-1 per point
-__global__ void k_ba_init_S(BaDev B, double lambda) {
+__global__ void k_ba_init_S(BaDev B) {
+    if (B.ctl->finished) return;
+    const double lambda = B.ctl->lambda;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < B.D * B.D) {
         const int r = i / B.D, c = i % B.D;
@@ -190,6 +221,7 @@ __global__ void k_ba_init_S(BaDev B, double lambda) {
 //   S[j1][j2] -= sum over points seen by both poses of W_e1 (H_ll+lambda)^-1 W_e2^T       (no atomics)
 // Diagonal blocks also produce b_s[j] = b_p[j] - sum W_e (H_ll+lambda)^-1 b_l.
 __global__ __launch_bounds__(256) void k_ba_schur_blocks(BaDev B) {
+    if (B.ctl->finished) return;
     __shared__ double s_part[4 * 42];
     __shared__ double s_tot[42];
     const BaBlock blk = B.blocks[blockIdx.x];
@@ -226,10 +258,10 @@ __global__ __launch_bounds__(256) void k_ba_schur_blocks(BaDev B) {
     if (threadIdx.x < 36) {
         const int r = threadIdx.x / 6, c = threadIdx.x % 6;
         const double val = s_tot[threadIdx.x];
-        B.S[(size_t)(6 * blk.j1 + r) * B.D + 6 * blk.j2 + c] -= val;
-        if (!diag) B.S[(size_t)(6 * blk.j2 + c) * B.D + 6 * blk.j1 + r] -= val;
+        atomicAdd(&B.S[(size_t)(6 * blk.j1 + r) * B.D + 6 * blk.j2 + c], -val);        // a block may be split over several workgroups
+        if (!diag) atomicAdd(&B.S[(size_t)(6 * blk.j2 + c) * B.D + 6 * blk.j1 + r], -val);
     } else if (diag && threadIdx.x < 42) {
-        B.bs[6 * blk.j1 + threadIdx.x - 36] -= s_tot[threadIdx.x];
+        atomicAdd(&B.bs[6 * blk.j1 + threadIdx.x - 36], -s_tot[threadIdx.x]);
     }
 }
 
@@ -238,6 +270,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_blocks(BaDev B) {
 // trailing update spread over 1024 lanes.  3 barriers per panel instead of 3 per column.
 #define TRI(r, c) ((size_t)(r) * ((r) + 1) / 2 + (c))      // packed lower triangle
 __global__ __launch_bounds__(1024) void k_ba_chol_lds(BaDev B) {
+    if (B.ctl->finished) return;
     extern __shared__ double s_L[];
     const int D = B.D, tid = threadIdx.x, np = D / 6;
     double* s_b = s_L + TRI(D, 0);
@@ -323,6 +356,7 @@ __global__ __launch_bounds__(1024) void k_ba_chol_lds(BaDev B) {
 // 6-column panel (one pose block) is staged in LDS.  Per panel: 6x6 diagonal factor (lane 0), panel solve
 // (one lane per row), rank-6 trailing update of the lower triangle spread over 1024 lanes.
 __global__ __launch_bounds__(1024) void k_ba_chol(BaDev B) {
+    if (B.ctl->finished) return;
     extern __shared__ double s_P[];                 // [D][6] current panel, then the right-hand side [D]
     const int D = B.D, tid = threadIdx.x, np = D / 6;
     double* A = B.S;
@@ -422,7 +456,10 @@ __global__ __launch_bounds__(1024) void k_ba_chol(BaDev B) {
     if (tid == 0) B.scal[3] = s_ok ? 1.0 : 0.0;
 }
 
-__global__ void k_ba_backsub(BaDev B, double lambda) {
+__global__ void k_ba_backsub(BaDev B) {
+    if (B.ctl->finished) return;
+    const double lambda = B.ctl->lambda;
+    BA_STATE(B)
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     double sc = 0, mx = 0;
     if (k < B.n_points && B.scal[3] != 0.0) {
@@ -437,7 +474,7 @@ __global__ void k_ba_backsub(BaDev B, double lambda) {
         for (int a = 0; a < 3; ++a) {
             const double d = h[3 * a] * rhs[0] + h[3 * a + 1] * rhs[1] + h[3 * a + 2] * rhs[2];
             B.dl[3 * (size_t)k + a] = d;
-            B.pts_n[3 * (size_t)k + a] = B.pts[3 * (size_t)k + a] + d;
+            pts_t[3 * (size_t)k + a] = pts_c[3 * (size_t)k + a] + d;
             sc += d * (lambda * d + B.bl[3 * (size_t)k + a]);
             mx = fmax(mx, fabs(d));
         }
@@ -448,11 +485,14 @@ __global__ void k_ba_backsub(BaDev B, double lambda) {
     if ((threadIdx.x & 63) == 0 && mx != 0.0) atomicMax((unsigned long long*)&B.scal[7], (unsigned long long)__double_as_longlong(mx));
 }
 
-__global__ void k_ba_pose(BaDev B, double lambda) {
+__global__ void k_ba_pose(BaDev B) {
+    if (B.ctl->finished) return;
+    const double lambda = B.ctl->lambda;
+    BA_STATE(B)
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= B.n_poses) return;
-    const double* T = B.poses + 12 * (size_t)j;
-    double* Tn = B.poses_n + 12 * (size_t)j;
+    const double* T = poses_c + 12 * (size_t)j;
+    double* Tn = poses_t + 12 * (size_t)j;
     if (j >= B.n_free || B.scal[3] == 0.0) { for (int i = 0; i < 12; ++i) Tn[i] = T[i]; return; }
     const double* d = B.bs + 6 * j;
     const double w[3] = {d[3], d[4], d[5]};
@@ -476,12 +516,14 @@ __global__ void k_ba_pose(BaDev B, double lambda) {
 }
 
 // chi2 of the current (trial = 0 -> scal[5]) or trial (-> scal[1]) state
-__global__ void k_ba_chi(BaCam cam, BaDev B, int trial, int robust, double delta) {
+__global__ void k_ba_chi(BaCam cam, BaDev B, int trial, int robust, double delta, int guard) {
+    if (guard && B.ctl->finished) return;
+    BA_STATE(B)
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     double v = 0;
     if (e < B.n_edges && B.active[e]) {
-        const double* P = (trial ? B.poses_n : B.poses) + 12 * (size_t)B.e_pose[e];
-        const double* X = (trial ? B.pts_n : B.pts) + 3 * (size_t)B.e_pt[e];
+        const double* P = (trial ? poses_t : poses_c) + 12 * (size_t)B.e_pose[e];
+        const double* X = (trial ? pts_t : pts_c) + 3 * (size_t)B.e_pt[e];
         double r[2], pc[3];
         ba_err(cam, P, X, B.e_uv + 2 * (size_t)e, r, pc);
         const double e2 = r[0] * r[0] + r[1] * r[1];
@@ -492,12 +534,50 @@ __global__ void k_ba_chi(BaCam cam, BaDev B, int trial, int robust, double delta
     if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(&B.scal[trial ? 1 : 5], v);
 }
 
+// one lane, before every trial: take over the freshly linearised chi2 / initial lambda, clear the trial sums
+__global__ void k_ba_prestep(BaDev B) {
+    BaCtl* c = B.ctl;
+    if (c->finished) return;
+    if (c->need_lin) {
+        c->cur = B.scal[0];
+        if (c->first) { c->lambda = 1e-5 * __longlong_as_double((long long)*(unsigned long long*)&B.scal[4]); c->ni = 2; c->first = 0; }
+        c->need_lin = 0;
+    }
+    B.scal[1] = 0; B.scal[2] = 0; B.scal[3] = 0; B.scal[7] = 0;
+}
+
+// one lane, after every trial: g2o's gain-ratio test and lambda policy (OptimizationAlgorithmLevenberg::solve)
+__global__ void k_ba_control(BaDev B) {
+    BaCtl* c = B.ctl;
+    if (c->finished) return;
+    const bool ok = B.scal[3] != 0.0;
+    const double tmp = ok ? B.scal[1] : DBL_MAX;
+    const double scale = (ok ? B.scal[2] : 0.0) + 1e-3;
+    const double rho = (c->cur - tmp) / scale;
+    bool converged = false;
+    if (rho > 0 && isfinite(tmp)) {
+        double a = 1.0 - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
+        a = fmin(a, 2.0 / 3.0);
+        c->lambda *= fmax(1.0 / 3.0, a); c->ni = 2; c->cur = tmp;
+        c->buf ^= 1; c->need_lin = 1;                   // trial state becomes the current state
+        B.scal[0] = 0; B.scal[4] = 0;
+    } else { c->lambda *= c->ni; c->ni *= 2; }
+    if (ok) converged = __longlong_as_double((long long)*(unsigned long long*)&B.scal[7]) < 1e-10;
+    c->qmax += 1; c->steps += 1;
+    if (!(rho < 0 && c->qmax < 10 && !converged)) {     // this LM iteration is over
+        c->iters_done += 1;
+        if (c->qmax == 10 || rho == 0 || converged || c->it + 1 >= c->max_it) c->finished = 1;
+        c->it += 1; c->qmax = 0;
+    }
+}
+
 // stage 0: cull after the robust round (bit0, deactivate); stage 1: flag level-0 outliers (bit1)
 __global__ void k_ba_cull(BaCam cam, BaDev B, int stage, double th) {
+    BA_STATE(B)
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= B.n_edges) return;
     double r[2], pc[3];
-    ba_err(cam, B.poses + 12 * (size_t)B.e_pose[e], B.pts + 3 * (size_t)B.e_pt[e], B.e_uv + 2 * (size_t)e, r, pc);
+    ba_err(cam, poses_c + 12 * (size_t)B.e_pose[e], pts_c + 3 * (size_t)B.e_pt[e], B.e_uv + 2 * (size_t)e, r, pc);
     const double c2 = r[0] * r[0] + r[1] * r[1];
     if (stage == 0) { if (c2 > th) { B.flags[e] = 1; B.active[e] = 0; } else B.flags[e] = 0; }
     else if (B.active[e]) { if (c2 > th) B.flags[e] |= 2; else atomicAdd(&B.scal[6], c2); }
@@ -546,7 +626,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
         const int cnt = blk_cnt[(size_t)j1 * nf + j2];
         if (!cnt) continue;
         blk_off[(size_t)j1 * nf + j2] = npairs;
-        blocks.push_back(BaBlock{j1, j2, npairs, cnt});
+        for (int o = 0; o < cnt; o += 512) blocks.push_back(BaBlock{j1, j2, npairs + o, std::min(512, cnt - o)});   // <= 2 pairs per lane
         npairs += cnt;
     }
     std::vector<int2> pairs((size_t)std::max(npairs, 1));
@@ -571,6 +651,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     const size_t o_qs = carve(4 * (size_t)(nf + 1)), o_qe = carve(4 * (size_t)std::max<size_t>(ps_edges.size(), 1));
     const size_t o_blk = carve(sizeof(BaBlock) * (size_t)std::max(nblk, 1)), o_pairs = carve(sizeof(int2) * pairs.size());
     const size_t o_Hpp = carve(288 * (size_t)nf), o_bp = carve(8 * (size_t)D), o_Hll = carve(72 * (size_t)nx), o_bl = carve(24 * (size_t)nx), o_scal = carve(64);
+    const size_t o_ctl = carve(sizeof(BaCtl));
     const size_t o_W = carve(144 * (size_t)ne), o_S = carve(8 * (size_t)D * D), o_bs = carve(8 * (size_t)D), o_Hinv = carve(72 * (size_t)nx), o_dl = carve(24 * (size_t)nx);
     int rc = vo_scratch(c, off);
     if (rc) return rc;
@@ -578,7 +659,8 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     BaDev B;
     B.n_poses = np; B.n_free = nf; B.n_points = nx; B.n_edges = ne; B.D = D; B.n_blocks = nblk;
     B.ps_start = (const int32_t*)(base + o_qs); B.ps_edges = (const int32_t*)(base + o_qe); B.blocks = (const BaBlock*)(base + o_blk); B.pairs = (const int2*)(base + o_pairs);
-    B.poses = (double*)(base + o_poses); B.pts = (double*)(base + o_pts); B.poses_n = (double*)(base + o_poses_n); B.pts_n = (double*)(base + o_pts_n);
+    B.posesA = (double*)(base + o_poses); B.ptsA = (double*)(base + o_pts); B.posesB = (double*)(base + o_poses_n); B.ptsB = (double*)(base + o_pts_n);
+    B.ctl = (BaCtl*)(base + o_ctl);
     B.e_pose = (const int32_t*)(base + o_epose); B.e_pt = (const int32_t*)(base + o_ept); B.e_uv = (const float*)(base + o_euv);
     B.active = base + o_act; B.flags = base + o_flags; B.pt_start = (const int32_t*)(base + o_ps); B.pt_edges = (const int32_t*)(base + o_pe);
     B.Hpp = (double*)(base + o_Hpp); B.bp = (double*)(base + o_bp); B.Hll = (double*)(base + o_Hll); B.bl = (double*)(base + o_bl); B.scal = (double*)(base + o_scal);
@@ -601,7 +683,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     HIP_TRY(hipStreamSynchronize(st));       // pageable sources
 
     const double tt1 = tnow();
-    double* h_scal = (double*)vo_stage(c, 64);
+    double* h_scal = (double*)vo_stage(c, 256);
     if (!h_scal) return VO_E_NOMEM;
     const dim3 blk(256), gE((ne + 255) / 256), gP((nx + 255) / 256), gJ((np + 255) / 256);
     auto read_scal = [&]() -> int {
@@ -609,51 +691,55 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
         HIP_TRY(hipStreamSynchronize(st));
         return VO_OK;
     };
+    BaCtl* h_ctl = (BaCtl*)((uint8_t*)h_scal + 64);
+    int cur_buf = 0;
+    const int CHUNK = 6;                                    // LM steps enqueued between two host polls
     auto optimize = [&](int robust, int max_it, int& iters) -> int {
-        double lambda = 0, ni = 2;
-        for (int it = 0; it < max_it; ++it) {
-            HIP_TRY(hipMemsetAsync(B.scal, 0, 64, st));     // H/b buffers are fully overwritten (no atomics)
-            { ProfScope ps(c, "k_ba_lin_points"); hipLaunchKernelGGL(k_ba_lin_points, gP, blk, 0, st, cam, B, robust, in->huber_delta); }
-            { ProfScope ps(c, "k_ba_lin_poses"); hipLaunchKernelGGL(k_ba_lin_poses, dim3(nf), blk, 0, st, cam, B, robust, in->huber_delta); }
-            if (it == 0) hipLaunchKernelGGL(k_ba_maxdiag, dim3((D + 3 * nx + 255) / 256), blk, 0, st, B);
-            if ((rc = read_scal())) return rc;
-            double cur = h_scal[0];
-            if (it == 0) { double md; memcpy(&md, &h_scal[4], 8); lambda = 1e-5 * md; ni = 2; }
-            double rho = 0; int qmax = 0; bool converged = false;
-            do {
-                HIP_TRY(hipMemsetAsync(B.scal + 1, 0, 24, st));        // trial chi, scale, ok
-                HIP_TRY(hipMemsetAsync(B.scal + 7, 0, 8, st));         // max |step|
-                hipLaunchKernelGGL(k_ba_init_S, dim3((std::max(D * D, nx) + 255) / 256), blk, 0, st, B, lambda);
+        if (max_it <= 0) return VO_OK;
+        HIP_TRY(hipStreamSynchronize(st));
+        memset(h_ctl, 0, sizeof(BaCtl));
+        h_ctl->max_it = max_it; h_ctl->need_lin = 1; h_ctl->first = 1; h_ctl->buf = cur_buf; h_ctl->ni = 2;
+        HIP_TRY(hipMemcpyAsync(B.ctl, h_ctl, sizeof(BaCtl), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(B.scal, 0, 64, st));
+        for (int guard_steps = 0, chunk = max_it; guard_steps < max_it * 10 + CHUNK; guard_steps += chunk, chunk = 2) {
+            for (int sidx = 0; sidx < chunk; ++sidx) {
+                hipLaunchKernelGGL(k_ba_prelin, dim3((unsigned)((std::max<size_t>(9 * (size_t)nx, 36 * (size_t)nf) + 255) / 256)), blk, 0, st, B);
+                { ProfScope ps(c, "k_ba_lin_points"); hipLaunchKernelGGL(k_ba_lin_points, gE, blk, 0, st, cam, B, robust, in->huber_delta); }
+                { ProfScope ps(c, "k_ba_lin_poses"); hipLaunchKernelGGL(k_ba_lin_poses, dim3(nf * PSPLIT), blk, 0, st, cam, B, robust, in->huber_delta); }
+                hipLaunchKernelGGL(k_ba_maxdiag, dim3((D + 3 * nx + 255) / 256), blk, 0, st, B);
+                hipLaunchKernelGGL(k_ba_prestep, dim3(1), dim3(1), 0, st, B);
+                hipLaunchKernelGGL(k_ba_init_S, dim3((std::max(D * D, nx) + 255) / 256), blk, 0, st, B);
                 if (nblk) { ProfScope ps(c, "k_ba_schur_blocks"); hipLaunchKernelGGL(k_ba_schur_blocks, dim3(nblk), blk, 0, st, B); }
                 { ProfScope ps(c, "k_ba_chol");
                   if (D <= 198) hipLaunchKernelGGL(k_ba_chol_lds, dim3(1), dim3(1024), sizeof(double) * ((size_t)D * (D + 1) / 2 + D), st, B);
                   else hipLaunchKernelGGL(k_ba_chol, dim3(1), dim3(1024), sizeof(double) * (size_t)7 * D, st, B); }
-                hipLaunchKernelGGL(k_ba_backsub, gP, blk, 0, st, B, lambda);
-                hipLaunchKernelGGL(k_ba_pose, gJ, blk, 0, st, B, lambda);
-                hipLaunchKernelGGL(k_ba_chi, gE, blk, 0, st, cam, B, 1, robust, in->huber_delta);
-                if ((rc = read_scal())) return rc;
-                const bool ok = h_scal[3] != 0.0;
-                const double tmp = ok ? h_scal[1] : DBL_MAX;
-                const double scale = (ok ? h_scal[2] : 0.0) + 1e-3;
-                rho = (cur - tmp) / scale;
-                if (rho > 0 && std::isfinite(tmp)) {
-                    double a = 1.0 - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
-                    a = std::min(a, 2.0 / 3.0);
-                    lambda *= std::max(1.0 / 3.0, a); ni = 2; cur = tmp;
-                    std::swap(B.poses, B.poses_n); std::swap(B.pts, B.pts_n);
-                } else { lambda *= ni; ni *= 2; }
-                if (ok) { double mx; memcpy(&mx, &h_scal[7], 8); converged = mx < 1e-10; }
-                ++qmax;
-            } while (rho < 0 && qmax < 10 && !converged);
-            ++iters;
-            if (qmax == 10 || rho == 0 || converged) break;
+                hipLaunchKernelGGL(k_ba_backsub, gP, blk, 0, st, B);
+                hipLaunchKernelGGL(k_ba_pose, gJ, blk, 0, st, B);
+                hipLaunchKernelGGL(k_ba_chi, gE, blk, 0, st, cam, B, 1, robust, in->huber_delta, 1);
+                hipLaunchKernelGGL(k_ba_control, dim3(1), dim3(1), 0, st, B);
+            }
+            HIP_TRY(hipMemcpyAsync(h_ctl, B.ctl, sizeof(BaCtl), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (h_ctl->finished) break;
         }
+        if (!h_ctl->finished) return VO_E_DEVICE;
+        iters += h_ctl->iters_done;
+        cur_buf = h_ctl->buf;
+        return VO_OK;
+    };
+    // kernels outside the LM loop read the current buffer index from the control block
+    auto set_ctl_idle = [&]() -> int {
+        HIP_TRY(hipStreamSynchronize(st));
+        memset(h_ctl, 0, sizeof(BaCtl));
+        h_ctl->buf = cur_buf;
+        HIP_TRY(hipMemcpyAsync(B.ctl, h_ctl, sizeof(BaCtl), hipMemcpyHostToDevice, st));
         return VO_OK;
     };
 
     // initial plain chi2 (reporting only)
+    if ((rc = set_ctl_idle())) return rc;
     HIP_TRY(hipMemsetAsync(B.scal, 0, 64, st));
-    hipLaunchKernelGGL(k_ba_chi, gE, blk, 0, st, cam, B, 0, 0, in->huber_delta);
+    hipLaunchKernelGGL(k_ba_chi, gE, blk, 0, st, cam, B, 0, 0, in->huber_delta, 0);
     if ((rc = read_scal())) return rc;
     out->chi2_initial = h_scal[5];
 
@@ -667,8 +753,8 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     out->chi2_final = h_scal[6];
     out->lm_iters = iters;
     const double tt2 = tnow();
-    HIP_TRY(hipMemcpyAsync(out->poses, B.poses, 96 * (size_t)nf, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(out->points, B.pts, 24 * (size_t)nx, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out->poses, cur_buf ? B.posesB : B.posesA, 96 * (size_t)nf, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out->points, cur_buf ? B.ptsB : B.ptsA, 24 * (size_t)nx, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(out->edge_flags, B.flags, ne, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
