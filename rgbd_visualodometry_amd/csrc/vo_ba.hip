@@ -269,15 +269,25 @@ __global__ __launch_bounds__(256) void k_ba_schur_blocks(BaDev B) {
 // blocked by pose (6-column panels): diagonal 6x6 factor, panel solve (one lane per row), rank-6
 // trailing update spread over 1024 lanes.  3 barriers per panel instead of 3 per column.
 #define TRI(r, c) ((size_t)(r) * ((r) + 1) / 2 + (c))      // packed lower triangle
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+// Cholesky + solve with the packed lower triangle of [S b; b^T .] resident in LDS (D <= 198).
+//  * the right-hand side rides along as row D of the augmented matrix, so the forward substitution
+//    falls out of the factorisation (L_aug's last row is y = L^-1 b);
+//  * per 6-column panel (one pose): 6x6 diagonal factor, panel solve (one lane per row), and the
+//    rank-6 trailing update S22 -= L21 L21^T as 16x16 tiles on the f64 matrix cores
+//    (v_mfma_f64_16x16x4_f64, K = 6 padded to 8): the dense J^T J-style contraction of the BA solve;
+//  * backward substitution by panels with pre-inverted pivots.
 __global__ __launch_bounds__(1024) void k_ba_chol_lds(BaDev B) {
     if (B.ctl->finished) return;
     extern __shared__ double s_L[];
-    const int D = B.D, tid = threadIdx.x, np = D / 6;
-    double* s_b = s_L + TRI(D, 0);
+    const int D = B.D, DA = D + 1, tid = threadIdx.x, np = D / 6, lane = tid & 63, wave = tid >> 6;
+    double* s_b = s_L + TRI(DA, 0);                 // x / y vector [D]
+    double* s_inv = s_b + D;                        // 1 / L[j][j]
     __shared__ int s_ok;
     if (tid == 0) s_ok = 1;
     for (int i = tid; i < D * D; i += 1024) { const int r = i / D, c = i - r * D; if (c <= r) s_L[TRI(r, c)] = B.S[i]; }
-    for (int i = tid; i < D; i += 1024) s_b[i] = B.bs[i];
+    for (int i = tid; i < D; i += 1024) s_L[TRI(D, i)] = B.bs[i];
+    if (tid == 0) s_L[TRI(D, D)] = 0.0;
     __syncthreads();
     for (int p = 0; p < np; ++p) {
         const int j0 = 6 * p;
@@ -289,6 +299,7 @@ __global__ __launch_bounds__(1024) void k_ba_chol_lds(BaDev B) {
                 d = sqrt(d);
                 s_L[TRI(j0 + j, j0 + j)] = d;
                 const double inv = 1.0 / d;
+                s_inv[j0 + j] = inv;
                 for (int i = j + 1; i < 6; ++i) {
                     double sum = s_L[TRI(j0 + i, j0 + j)];
                     for (int k = 0; k < j; ++k) sum -= s_L[TRI(j0 + i, j0 + k)] * s_L[TRI(j0 + j, j0 + k)];
@@ -298,46 +309,52 @@ __global__ __launch_bounds__(1024) void k_ba_chol_lds(BaDev B) {
         }
         __syncthreads();
         if (!s_ok) break;
-        const int m = D - j0 - 6;                       // rows below the panel
+        const int base = j0 + 6, m = DA - base;         // rows below the panel, incl. the rhs row
         for (int r = tid; r < m; r += 1024) {
-            double* row = s_L + TRI(j0 + 6 + r, j0);
+            double* row = s_L + TRI(base + r, j0);
             double x[6];
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
                 double sum = row[c];
 #pragma unroll
                 for (int k = 0; k < c; ++k) sum -= x[k] * s_L[TRI(j0 + c, j0 + k)];
-                x[c] = sum / s_L[TRI(j0 + c, j0 + c)];
+                x[c] = sum * s_inv[j0 + c];
             }
 #pragma unroll
             for (int c = 0; c < 6; ++c) row[c] = x[c];
         }
         __syncthreads();
-        for (int t = tid; t < m * m; t += 1024) {
-            const int r = t / m, c = t - r * m;
-            if (c > r) continue;
-            const double* a = s_L + TRI(j0 + 6 + r, j0);
-            const double* b = s_L + TRI(j0 + 6 + c, j0);
-            s_L[TRI(j0 + 6 + r, j0 + 6 + c)] -= a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+        // trailing update on the matrix cores: tile (tr, tc), tc <= tr, 16x16 each; A[i][k] = L21[16 tr + i][k],
+        // B[k][j] = L21[16 tc + j][k]; lane l holds A[l&15][l>>4], B[l>>4][l&15]; D: col = l&15, row = (l>>4) + 4 reg
+        const int T = (m + 15) >> 4, ntile = T * (T + 1) / 2;
+        for (int t = wave; t < ntile; t += 16) {
+            int tr = 0;
+            while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
+            const int tc = t - tr * (tr + 1) / 2;
+            const int ra = 16 * tr + (lane & 15), rb = 16 * tc + (lane & 15), kq = lane >> 4;
+            const double a0 = ra < m ? s_L[TRI(base + ra, j0 + kq)] : 0.0;
+            const double b0 = rb < m ? s_L[TRI(base + rb, j0 + kq)] : 0.0;
+            const double a1 = (ra < m && kq < 2) ? s_L[TRI(base + ra, j0 + 4 + kq)] : 0.0;
+            const double b1 = (rb < m && kq < 2) ? s_L[TRI(base + rb, j0 + 4 + kq)] : 0.0;
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+            const int col = 16 * tc + (lane & 15);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = 16 * tr + (lane >> 4) + 4 * q;
+                if (row < m && col <= row) s_L[TRI(base + row, base + col)] -= acc[q];
+            }
         }
         __syncthreads();
     }
     if (s_ok) {
-        for (int p = 0; p < np; ++p) {                  // L y = b
-            const int j0 = 6 * p;
-            if (tid == 0)
-                for (int j = 0; j < 6; ++j) { double sum = s_b[j0 + j]; for (int k = 0; k < j; ++k) sum -= s_L[TRI(j0 + j, j0 + k)] * s_b[j0 + k]; s_b[j0 + j] = sum / s_L[TRI(j0 + j, j0 + j)]; }
-            __syncthreads();
-            for (int r = j0 + 6 + tid; r < D; r += 1024) {
-                const double* a = s_L + TRI(r, j0);
-                s_b[r] -= a[0] * s_b[j0] + a[1] * s_b[j0 + 1] + a[2] * s_b[j0 + 2] + a[3] * s_b[j0 + 3] + a[4] * s_b[j0 + 4] + a[5] * s_b[j0 + 5];
-            }
-            __syncthreads();
-        }
+        for (int i = tid; i < D; i += 1024) s_b[i] = s_L[TRI(D, i)];     // y = L^-1 b (last row of the augmented factor)
+        __syncthreads();
         for (int p = np - 1; p >= 0; --p) {             // L^T x = y
             const int j0 = 6 * p;
             if (tid == 0)
-                for (int j = 5; j >= 0; --j) { double sum = s_b[j0 + j]; for (int k = j + 1; k < 6; ++k) sum -= s_L[TRI(j0 + k, j0 + j)] * s_b[j0 + k]; s_b[j0 + j] = sum / s_L[TRI(j0 + j, j0 + j)]; }
+                for (int j = 5; j >= 0; --j) { double sum = s_b[j0 + j]; for (int k = j + 1; k < 6; ++k) sum -= s_L[TRI(j0 + k, j0 + j)] * s_b[j0 + k]; s_b[j0 + j] = sum * s_inv[j0 + j]; }
             __syncthreads();
             for (int r = tid; r < j0; r += 1024) {
                 double sum = 0;
@@ -711,7 +728,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
                 hipLaunchKernelGGL(k_ba_init_S, dim3((std::max(D * D, nx) + 255) / 256), blk, 0, st, B);
                 if (nblk) { ProfScope ps(c, "k_ba_schur_blocks"); hipLaunchKernelGGL(k_ba_schur_blocks, dim3(nblk), blk, 0, st, B); }
                 { ProfScope ps(c, "k_ba_chol");
-                  if (D <= 198) hipLaunchKernelGGL(k_ba_chol_lds, dim3(1), dim3(1024), sizeof(double) * ((size_t)D * (D + 1) / 2 + D), st, B);
+                  if (D <= 192) hipLaunchKernelGGL(k_ba_chol_lds, dim3(1), dim3(1024), sizeof(double) * ((size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D), st, B);
                   else hipLaunchKernelGGL(k_ba_chol, dim3(1), dim3(1024), sizeof(double) * (size_t)7 * D, st, B); }
                 hipLaunchKernelGGL(k_ba_backsub, gP, blk, 0, st, B);
                 hipLaunchKernelGGL(k_ba_pose, gJ, blk, 0, st, B);

@@ -20,6 +20,8 @@ public:
 
     Vector3d GetPosition() { std::unique_lock<std::mutex> lock(posMutex_); return pos_; }
     void SetPosition(const Vector3d pos) { { std::unique_lock<std::mutex> lock(posMutex_); pos_ = pos; } MarkDirty(); }
+    // position already mirrored on the device by the caller (bulk upsert): no dirty marking
+    void SetPositionSynced(const Vector3d pos) { std::unique_lock<std::mutex> lock(posMutex_); pos_ = pos; }
     size_t GetId() const { return id_; }
     Vector3d GetNormDirection() { std::unique_lock<std::mutex> lock(observationMutex_); return norm_; }
 

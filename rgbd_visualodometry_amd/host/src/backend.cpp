@@ -153,8 +153,20 @@ void Backend::Apply(Job& j) {
         mp.optimized_ = true;
     }
     for (int p = 0; p < j.nFree; ++p) j.poseFrames[p]->SetPose(SE3::from12(&j.posesOut[12 * (size_t)p]));       // backend.cpp:183-187
-    for (size_t k = 0; k < j.points.size(); ++k)                                                                 // backend.cpp:188-194
-        if (!j.points[k]->outlier_) j.points[k]->SetPosition(Vector3d(j.ptsOut[3 * k], j.ptsOut[3 * k + 1], j.ptsOut[3 * k + 2]));
+    // backend.cpp:188-194.  The optimised positions are already one flat array: they go to the tracker's device map
+    // in a single vo_map_upsert (positions only) instead of through the per-point dirty list.
+    std::vector<int32_t> slots; std::vector<double> xyz;
+    slots.reserve(j.points.size()); xyz.reserve(3 * j.points.size());
+    for (size_t k = 0; k < j.points.size(); ++k) {
+        Mappoint& mp = *j.points[k];
+        if (mp.outlier_) continue;
+        mp.SetPositionSynced(Vector3d(j.ptsOut[3 * k], j.ptsOut[3 * k + 1], j.ptsOut[3 * k + 2]));
+        slots.push_back(mp.slot_); xyz.push_back(j.ptsOut[3 * k]); xyz.push_back(j.ptsOut[3 * k + 1]); xyz.push_back(j.ptsOut[3 * k + 2]);
+    }
+    if (!slots.empty()) {
+        int rc = vo_map_upsert(ctx_, slots.data(), xyz.data(), nullptr, nullptr, nullptr, (int)slots.size());
+        if (rc != VO_OK) throw std::runtime_error(std::string("vo_map_upsert (BA merge) failed: ") + vo_strerror(rc));
+    }
     stats_.runs++; stats_.poses = j.nFree; stats_.fixed = (int)j.poseFrames.size() - j.nFree; stats_.points = (int)j.points.size();
     stats_.edges = (int)j.edgePose.size(); stats_.outliers = outlierCnt; stats_.ms_solve += j.solveMs;
 }

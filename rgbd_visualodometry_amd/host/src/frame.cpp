@@ -38,10 +38,10 @@ void Frame::AddObservedMappoint(const size_t mappointId, const Point2f pixelPos)
     auto mappoint = MapManager::GetInstance().GetMappoint(mappointId);
     assert(mappoint != nullptr);
     mappoint->AddObservedByKeyframe(id_, pixelPos, GetCamCenter(), this);
-    for (auto& idToPixel : mappoint->GetObservedByKeyframesMap()) {
-        const size_t other = idToPixel.first;
+    for (const Mappoint::Observation& o : mappoint->ObservationList()) {     // no copy of the observation map
+        const size_t other = o.keyframeId;
         if (other == id_) continue;
-        auto otherKF = MapManager::GetInstance().GetKeyframe(other);
+        Frame* otherKF = o.keyframe;
         assert(otherKF != nullptr);
         int w = ++allCovisibleKeyframeIdToWeight_[other];
         if (w >= 15) activeCovisibleKeyframes_.insert(other);

@@ -205,8 +205,8 @@ void FrontEnd::MatchAndEstimatePose() {
         }
     if (!have) {
         spec_.clear();
-        RefreshTrackingMap();
-        FlushDirtyMappoints();
+        { StageTimer t(stats_.ms_refresh); RefreshTrackingMap(); }
+        { StageTimer t(stats_.ms_flush); FlushDirtyMappoints(); }
         double prior[12];
         frameCurr_->GetPose().to12(prior);
         // batch = this frame + the prefetched frames that follow it, while they see the same map: stop before a

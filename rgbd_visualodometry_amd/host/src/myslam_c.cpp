@@ -129,6 +129,7 @@ int myslam_get_stats(myslam_system* s, myslam_stats* st) {
     st->frames = f.frames; st->keyframes = f.keyframes; st->lost = f.lost; st->state = (int)s->frontend->GetState();
     st->last_keypoints = f.last_keypoints; st->last_candidates = f.last_candidates; st->last_matches = f.last_matches;
     st->ms_extract = f.ms_extract; st->ms_track = f.ms_track; st->ms_keyframe = f.ms_keyframe; st->ms_backend = f.ms_backend;
+    if (getenv("VO_TRACE")) fprintf(stderr, "[vo_trace] frontend ms: extract %.1f track %.1f (refresh %.1f flush %.1f) keyframe %.1f backend %.1f\n", f.ms_extract, f.ms_track, f.ms_refresh, f.ms_flush, f.ms_keyframe, f.ms_backend);
     st->last_ransac_inliers = f.last_ransac; st->last_lm_inliers = f.last_lm; st->map_points = (int)s->map.MappointCount();
     if (s->backend) {
         const auto& b = s->backend->GetStats();
