@@ -270,58 +270,72 @@ __global__ __launch_bounds__(256) void k_ba_schur_blocks(BaDev B) {
 // trailing update spread over 1024 lanes.  3 barriers per panel instead of 3 per column.
 #define TRI(r, c) ((size_t)(r) * ((r) + 1) / 2 + (c))      // packed lower triangle
 typedef double f64x4 __attribute__((ext_vector_type(4)));
-// Cholesky + solve with the packed lower triangle of [S b; b^T .] resident in LDS (D <= 198).
-//  * the right-hand side rides along as row D of the augmented matrix, so the forward substitution
-//    falls out of the factorisation (L_aug's last row is y = L^-1 b);
-//  * per 6-column panel (one pose): 6x6 diagonal factor, panel solve (one lane per row), and the
-//    rank-6 trailing update S22 -= L21 L21^T as 16x16 tiles on the f64 matrix cores
-//    (v_mfma_f64_16x16x4_f64, K = 6 padded to 8): the dense J^T J-style contraction of the BA solve;
+
+// Cholesky + solve of the reduced system in one 1024-lane workgroup.
+//  * the right-hand side rides along as row D of the augmented matrix [S b; b^T .], so the forward substitution
+//    falls out of the factorisation (the last row of the augmented factor is y = L^-1 b);
+//  * per 6-column panel (one pose): 6x6 diagonal factor, panel solve (one lane per row), and the rank-6 trailing
+//    update S22 -= L21 L21^T as 16x16 tiles on the f64 matrix cores (v_mfma_f64_16x16x4_f64, K = 6 padded to 8):
+//    the dense J^T J-style contraction of the BA solve;
 //  * backward substitution by panels with pre-inverted pivots.
-__global__ __launch_bounds__(1024) void k_ba_chol_lds(BaDev B) {
+// INLDS: packed lower triangle resident in LDS (D <= 192).  Otherwise the matrix stays in global memory
+// (L2 resident) and only the rhs row, the current panel and the pivots live in LDS (any D).
+template <bool INLDS>
+__global__ __launch_bounds__(1024) void k_ba_chol_t(BaDev B) {
     if (B.ctl->finished) return;
-    extern __shared__ double s_L[];
+    extern __shared__ double s_mem[];
     const int D = B.D, DA = D + 1, tid = threadIdx.x, np = D / 6, lane = tid & 63, wave = tid >> 6;
-    double* s_b = s_L + TRI(DA, 0);                 // x / y vector [D]
-    double* s_inv = s_b + D;                        // 1 / L[j][j]
+    double* const A = B.S;
+    // LDS carve: INLDS: [tri(DA)] [x D] [inv D]          else: [aug DA] [panel 6*DA] [x D] [inv D]
+    double* const s_L = s_mem;
+    double* const s_aug = s_mem;
+    double* const s_P = s_mem + DA;
+    double* const s_b = INLDS ? s_mem + TRI(DA, 0) : s_mem + DA + (size_t)6 * DA;
+    double* const s_inv = s_b + D;
+    auto at = [&](int r, int c) -> double& { if (INLDS) return s_L[TRI(r, c)]; return r == D ? s_aug[c] : A[(size_t)r * D + c]; };
     __shared__ int s_ok;
     if (tid == 0) s_ok = 1;
-    for (int i = tid; i < D * D; i += 1024) { const int r = i / D, c = i - r * D; if (c <= r) s_L[TRI(r, c)] = B.S[i]; }
-    for (int i = tid; i < D; i += 1024) s_L[TRI(D, i)] = B.bs[i];
-    if (tid == 0) s_L[TRI(D, D)] = 0.0;
+    if (INLDS) { for (int i = tid; i < D * D; i += 1024) { const int r = i / D, c = i - r * D; if (c <= r) s_L[TRI(r, c)] = A[i]; } }
+    for (int i = tid; i < D; i += 1024) at(D, i) = B.bs[i];
+    if (tid == 0) at(D, D) = 0.0;
     __syncthreads();
     for (int p = 0; p < np; ++p) {
         const int j0 = 6 * p;
         if (tid == 0) {
-            for (int j = 0; j < 6 && s_ok; ++j) {
-                double d = s_L[TRI(j0 + j, j0 + j)];
-                for (int k = 0; k < j; ++k) d -= s_L[TRI(j0 + j, j0 + k)] * s_L[TRI(j0 + j, j0 + k)];
+            double d6[36];
+            for (int r = 0; r < 6; ++r) for (int c = 0; c <= r; ++c) d6[6 * r + c] = at(j0 + r, j0 + c);
+            for (int j = 0; j < 6; ++j) {
+                double d = d6[7 * j];
+                for (int k = 0; k < j; ++k) d -= d6[6 * j + k] * d6[6 * j + k];
                 if (!(d > 0.0)) { s_ok = 0; break; }
                 d = sqrt(d);
-                s_L[TRI(j0 + j, j0 + j)] = d;
+                d6[7 * j] = d;
                 const double inv = 1.0 / d;
                 s_inv[j0 + j] = inv;
                 for (int i = j + 1; i < 6; ++i) {
-                    double sum = s_L[TRI(j0 + i, j0 + j)];
-                    for (int k = 0; k < j; ++k) sum -= s_L[TRI(j0 + i, j0 + k)] * s_L[TRI(j0 + j, j0 + k)];
-                    s_L[TRI(j0 + i, j0 + j)] = sum * inv;
+                    double sum = d6[6 * i + j];
+                    for (int k = 0; k < j; ++k) sum -= d6[6 * i + k] * d6[6 * j + k];
+                    d6[6 * i + j] = sum * inv;
                 }
             }
+            for (int r = 0; r < 6; ++r) for (int c = 0; c <= r; ++c) at(j0 + r, j0 + c) = d6[6 * r + c];
         }
         __syncthreads();
         if (!s_ok) break;
         const int base = j0 + 6, m = DA - base;         // rows below the panel, incl. the rhs row
+        double dg[15];                                  // strict lower part of the diagonal block, broadcast reads
+        { int q = 0; for (int r = 1; r < 6; ++r) for (int c = 0; c < r; ++c) dg[q++] = at(j0 + r, j0 + c); }
         for (int r = tid; r < m; r += 1024) {
-            double* row = s_L + TRI(base + r, j0);
             double x[6];
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
-                double sum = row[c];
+                double sum = at(base + r, j0 + c);
 #pragma unroll
-                for (int k = 0; k < c; ++k) sum -= x[k] * s_L[TRI(j0 + c, j0 + k)];
+                for (int k = 0; k < c; ++k) sum -= x[k] * dg[c * (c - 1) / 2 + k];
                 x[c] = sum * s_inv[j0 + c];
             }
 #pragma unroll
-            for (int c = 0; c < 6; ++c) row[c] = x[c];
+            for (int c = 0; c < 6; ++c) { at(base + r, j0 + c) = x[c]; if (!INLDS) s_P[6 * r + c] = x[c]; }
         }
         __syncthreads();
         // trailing update on the matrix cores: tile (tr, tc), tc <= tr, 16x16 each; A[i][k] = L21[16 tr + i][k],
@@ -332,10 +346,11 @@ __global__ __launch_bounds__(1024) void k_ba_chol_lds(BaDev B) {
             while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
             const int tc = t - tr * (tr + 1) / 2;
             const int ra = 16 * tr + (lane & 15), rb = 16 * tc + (lane & 15), kq = lane >> 4;
-            const double a0 = ra < m ? s_L[TRI(base + ra, j0 + kq)] : 0.0;
-            const double b0 = rb < m ? s_L[TRI(base + rb, j0 + kq)] : 0.0;
-            const double a1 = (ra < m && kq < 2) ? s_L[TRI(base + ra, j0 + 4 + kq)] : 0.0;
-            const double b1 = (rb < m && kq < 2) ? s_L[TRI(base + rb, j0 + 4 + kq)] : 0.0;
+            auto pan = [&](int r, int k) -> double { return INLDS ? s_L[TRI(base + r, j0 + k)] : s_P[6 * r + k]; };
+            const double a0 = ra < m ? pan(ra, kq) : 0.0;
+            const double b0 = rb < m ? pan(rb, kq) : 0.0;
+            const double a1 = (ra < m && kq < 2) ? pan(ra, 4 + kq) : 0.0;
+            const double b1 = (rb < m && kq < 2) ? pan(rb, 4 + kq) : 0.0;
             f64x4 acc = {0.0, 0.0, 0.0, 0.0};
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
@@ -343,127 +358,23 @@ __global__ __launch_bounds__(1024) void k_ba_chol_lds(BaDev B) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int row = 16 * tr + (lane >> 4) + 4 * q;
-                if (row < m && col <= row) s_L[TRI(base + row, base + col)] -= acc[q];
+                if (row < m && col <= row) at(base + row, base + col) -= acc[q];
             }
         }
         __syncthreads();
     }
     if (s_ok) {
-        for (int i = tid; i < D; i += 1024) s_b[i] = s_L[TRI(D, i)];     // y = L^-1 b (last row of the augmented factor)
+        for (int i = tid; i < D; i += 1024) s_b[i] = at(D, i);          // y = L^-1 b (last row of the augmented factor)
         __syncthreads();
         for (int p = np - 1; p >= 0; --p) {             // L^T x = y
             const int j0 = 6 * p;
             if (tid == 0)
-                for (int j = 5; j >= 0; --j) { double sum = s_b[j0 + j]; for (int k = j + 1; k < 6; ++k) sum -= s_L[TRI(j0 + k, j0 + j)] * s_b[j0 + k]; s_b[j0 + j] = sum * s_inv[j0 + j]; }
+                for (int j = 5; j >= 0; --j) { double sum = s_b[j0 + j]; for (int k = j + 1; k < 6; ++k) sum -= at(j0 + k, j0 + j) * s_b[j0 + k]; s_b[j0 + j] = sum * s_inv[j0 + j]; }
             __syncthreads();
             for (int r = tid; r < j0; r += 1024) {
                 double sum = 0;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) sum += s_L[TRI(j0 + k, r)] * s_b[j0 + k];
-                s_b[r] -= sum;
-            }
-            __syncthreads();
-        }
-        for (int i = tid; i < D; i += 1024) B.bs[i] = s_b[i];
-    }
-    if (tid == 0) B.scal[3] = s_ok ? 1.0 : 0.0;
-}
-
-// Dense Cholesky + solve for any D: the matrix stays in global memory (L2 resident), only the current
-// 6-column panel (one pose block) is staged in LDS.  Per panel: 6x6 diagonal factor (lane 0), panel solve
-// (one lane per row), rank-6 trailing update of the lower triangle spread over 1024 lanes.
-__global__ __launch_bounds__(1024) void k_ba_chol(BaDev B) {
-    if (B.ctl->finished) return;
-    extern __shared__ double s_P[];                 // [D][6] current panel, then the right-hand side [D]
-    const int D = B.D, tid = threadIdx.x, np = D / 6;
-    double* A = B.S;
-    double* s_b = s_P + (size_t)6 * D;
-    __shared__ double s_dg[36];
-    __shared__ int s_ok;
-    if (tid == 0) s_ok = 1;
-    for (int i = tid; i < D; i += 1024) s_b[i] = B.bs[i];
-    __syncthreads();
-    for (int p = 0; p < np; ++p) {
-        const int j0 = 6 * p;
-        if (tid == 0) {
-            double d6[36];
-            for (int r = 0; r < 6; ++r) for (int c = 0; c <= r; ++c) d6[6 * r + c] = A[(size_t)(j0 + r) * D + j0 + c];
-            for (int j = 0; j < 6; ++j) {
-                double d = d6[7 * j];
-                for (int k = 0; k < j; ++k) d -= d6[6 * j + k] * d6[6 * j + k];
-                if (!(d > 0.0)) { s_ok = 0; break; }
-                d = sqrt(d);
-                d6[7 * j] = d;
-                const double inv = 1.0 / d;
-                for (int i = j + 1; i < 6; ++i) {
-                    double sum = d6[6 * i + j];
-                    for (int k = 0; k < j; ++k) sum -= d6[6 * i + k] * d6[6 * j + k];
-                    d6[6 * i + j] = sum * inv;
-                }
-            }
-            for (int r = 0; r < 6; ++r) for (int c = 0; c <= r; ++c) { s_dg[6 * r + c] = d6[6 * r + c]; A[(size_t)(j0 + r) * D + j0 + c] = d6[6 * r + c]; }
-        }
-        __syncthreads();
-        if (!s_ok) break;
-        const int m = D - j0 - 6;
-        for (int r = tid; r < m; r += 1024) {
-            double* row = A + (size_t)(j0 + 6 + r) * D + j0;
-            double x[6];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                double sum = row[c];
-#pragma unroll
-                for (int k = 0; k < c; ++k) sum -= x[k] * s_dg[6 * c + k];
-                x[c] = sum / s_dg[7 * c];
-            }
-#pragma unroll
-            for (int c = 0; c < 6; ++c) { row[c] = x[c]; s_P[6 * r + c] = x[c]; }
-        }
-        __syncthreads();
-        for (int t0 = tid; t0 < m * m; t0 += 4 * 1024) {   // 4 independent read-modify-writes in flight per lane
-            double* ptr[4]; double upd[4], old[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int t = t0 + u * 1024;
-                ptr[u] = nullptr;
-                if (t < m * m) {
-                    const int r = t / m, c = t - r * m;
-                    if (c <= r) {
-                        const double* a = s_P + 6 * r;
-                        const double* b = s_P + 6 * c;
-                        ptr[u] = &A[(size_t)(j0 + 6 + r) * D + j0 + 6 + c];
-                        upd[u] = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) if (ptr[u]) old[u] = *ptr[u];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) if (ptr[u]) *ptr[u] = old[u] - upd[u];
-        }
-        __syncthreads();
-    }
-    if (s_ok) {
-        for (int p = 0; p < np; ++p) {                  // L y = b
-            const int j0 = 6 * p;
-            if (tid == 0)
-                for (int j = 0; j < 6; ++j) { double sum = s_b[j0 + j]; for (int k = 0; k < j; ++k) sum -= A[(size_t)(j0 + j) * D + j0 + k] * s_b[j0 + k]; s_b[j0 + j] = sum / A[(size_t)(j0 + j) * D + j0 + j]; }
-            __syncthreads();
-            for (int r = j0 + 6 + tid; r < D; r += 1024) {
-                const double* a = A + (size_t)r * D + j0;
-                s_b[r] -= a[0] * s_b[j0] + a[1] * s_b[j0 + 1] + a[2] * s_b[j0 + 2] + a[3] * s_b[j0 + 3] + a[4] * s_b[j0 + 4] + a[5] * s_b[j0 + 5];
-            }
-            __syncthreads();
-        }
-        for (int p = np - 1; p >= 0; --p) {             // L^T x = y
-            const int j0 = 6 * p;
-            if (tid == 0)
-                for (int j = 5; j >= 0; --j) { double sum = s_b[j0 + j]; for (int k = j + 1; k < 6; ++k) sum -= A[(size_t)(j0 + k) * D + j0 + j] * s_b[j0 + k]; s_b[j0 + j] = sum / A[(size_t)(j0 + j) * D + j0 + j]; }
-            __syncthreads();
-            for (int r = tid; r < j0; r += 1024) {
-                double sum = 0;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) sum += A[(size_t)(j0 + k) * D + r] * s_b[j0 + k];
+                for (int k = 0; k < 6; ++k) sum += at(j0 + k, r) * s_b[j0 + k];
                 s_b[r] -= sum;
             }
             __syncthreads();
@@ -602,10 +513,10 @@ __global__ void k_ba_cull(BaCam cam, BaDev B, int stage, double th) {
 
 int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     hipStream_t st = c->stream;
-    { static bool attr = false; if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-      HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)); attr = true; } }
+    { static bool attr = false; if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)); attr = true; } }
     const int np = in->n_poses, nf = in->n_free, nx = in->n_points, ne = in->n_edges, D = 6 * nf;
-    if ((size_t)7 * D * sizeof(double) > 158 * 1024) return VO_E_UNSUPPORTED;      // > 481 free poses
+    if (((size_t)7 * (D + 1) + 2 * (size_t)D) * sizeof(double) > 158 * 1024) return VO_E_UNSUPPORTED;      // > ~370 free poses
     out->lm_iters = 0; out->chi2_initial = 0; out->chi2_final = 0;
     if (ne == 0 || nf == 0 || nx == 0) {
         memcpy(out->poses, in->poses, sizeof(double) * 12 * (size_t)nf);
@@ -728,11 +639,11 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
                 hipLaunchKernelGGL(k_ba_init_S, dim3((std::max(D * D, nx) + 255) / 256), blk, 0, st, B);
                 if (nblk) { ProfScope ps(c, "k_ba_schur_blocks"); hipLaunchKernelGGL(k_ba_schur_blocks, dim3(nblk), blk, 0, st, B); }
                 { ProfScope ps(c, "k_ba_chol");
-                  if (D <= 192) hipLaunchKernelGGL(k_ba_chol_lds, dim3(1), dim3(1024), sizeof(double) * ((size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D), st, B);
-                  else hipLaunchKernelGGL(k_ba_chol, dim3(1), dim3(1024), sizeof(double) * (size_t)7 * D, st, B); }
-                hipLaunchKernelGGL(k_ba_backsub, gP, blk, 0, st, B);
+                  if (D <= 192) hipLaunchKernelGGL(k_ba_chol_t<true>, dim3(1), dim3(1024), sizeof(double) * ((size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D), st, B);
+                  else hipLaunchKernelGGL(k_ba_chol_t<false>, dim3(1), dim3(1024), sizeof(double) * ((size_t)7 * (D + 1) + 2 * (size_t)D), st, B); }
+                { ProfScope ps(c, "k_ba_backsub"); hipLaunchKernelGGL(k_ba_backsub, gP, blk, 0, st, B); }
                 hipLaunchKernelGGL(k_ba_pose, gJ, blk, 0, st, B);
-                hipLaunchKernelGGL(k_ba_chi, gE, blk, 0, st, cam, B, 1, robust, in->huber_delta, 1);
+                { ProfScope ps(c, "k_ba_chi"); hipLaunchKernelGGL(k_ba_chi, gE, blk, 0, st, cam, B, 1, robust, in->huber_delta, 1); }
                 hipLaunchKernelGGL(k_ba_control, dim3(1), dim3(1), 0, st, B);
             }
             HIP_TRY(hipMemcpyAsync(h_ctl, B.ctl, sizeof(BaCtl), hipMemcpyDeviceToHost, st));

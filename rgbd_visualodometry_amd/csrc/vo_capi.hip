@@ -111,6 +111,14 @@ int vo_scratch(vo_ctx* c, size_t bytes) {
     return VO_OK;
 }
 
+// Profiling is process-wide: a VO system owns several contexts (tracker + overlapped back-end), and the
+// per-kernel table has to cover all of them.  Contexts register themselves; reads merge every context.
+#include <mutex>
+static std::mutex g_prof_mu;
+static std::vector<vo_ctx*> g_ctxs;
+static bool g_prof_on = false;
+static std::vector<std::string> g_prof_names; static std::vector<double> g_prof_ms; static std::vector<int64_t> g_prof_calls;
+
 void vo_prof_begin(vo_ctx* c, const char* name) {
     ProfRec r; r.name = name;
     auto get = [&]() { hipEvent_t e; if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
@@ -120,16 +128,17 @@ void vo_prof_begin(vo_ctx* c, const char* name) {
 }
 void vo_prof_end(vo_ctx* c) { (void)hipEventRecord(c->prof.back().b, c->stream); }
 
-static void prof_collect(vo_ctx* c) {
+static void prof_collect(vo_ctx* c) {      // caller holds g_prof_mu
     if (c->prof.empty()) return;
+    (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto& r : c->prof) {
         float ms = 0;
         (void)hipEventElapsedTime(&ms, r.a, r.b);
         size_t i = 0;
-        for (; i < c->prof_names.size(); ++i) if (c->prof_names[i] == r.name) break;
-        if (i == c->prof_names.size()) { c->prof_names.push_back(r.name); c->prof_ms.push_back(0); c->prof_calls.push_back(0); }
-        c->prof_ms[i] += ms; c->prof_calls[i] += 1;
+        for (; i < g_prof_names.size(); ++i) if (g_prof_names[i] == r.name) break;
+        if (i == g_prof_names.size()) { g_prof_names.push_back(r.name); g_prof_ms.push_back(0); g_prof_calls.push_back(0); }
+        g_prof_ms[i] += ms; g_prof_calls[i] += 1;
         c->ev_pool.push_back(r.a); c->ev_pool.push_back(r.b);
     }
     c->prof.clear();
@@ -174,6 +183,7 @@ int vo_default_track_params(vo_track_params* t) {
 
 void vo_ctx_destroy(vo_ctx* c) {
     if (!c) return;
+    { std::unique_lock<std::mutex> lk(g_prof_mu); prof_collect(c); for (size_t i = 0; i < g_ctxs.size(); ++i) if (g_ctxs[i] == c) { g_ctxs.erase(g_ctxs.begin() + i); break; } }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto p : c->own_bgr) if (p) (void)hipFree(p);
@@ -258,6 +268,7 @@ int vo_ctx_create(const vo_params* p, int device, vo_ctx** out) {
     HIP_TRY(hipMemsetAsync(c->d_map_flags, 0, M, st));
     HIP_TRY(hipMemsetAsync(c->d_track, 0, sizeof(TrackDev) * NL, st));
     HIP_TRY(hipStreamSynchronize(st));
+    { std::unique_lock<std::mutex> lk(g_prof_mu); g_ctxs.push_back(c); c->prof_on = g_prof_on; }
     *out = c;
     return VO_OK;
 }
@@ -599,20 +610,22 @@ int vo_sync(vo_ctx* c) {
 
 int vo_profile_enable(vo_ctx* c, int on) {
     if (!c) return VO_E_INVALID;
-    prof_collect(c);
-    c->prof_on = on != 0;
-    if (on) { c->prof_names.clear(); c->prof_ms.clear(); c->prof_calls.clear(); }
+    std::unique_lock<std::mutex> lk(g_prof_mu);
+    for (vo_ctx* x : g_ctxs) { prof_collect(x); x->prof_on = on != 0; }
+    g_prof_on = on != 0;
+    if (on) { g_prof_names.clear(); g_prof_ms.clear(); g_prof_calls.clear(); }
     return VO_OK;
 }
 
 int vo_profile_read(vo_ctx* c, char (*names)[48], double* ms, int64_t* calls, int cap, int* n) {
     if (!c || !n) return VO_E_INVALID;
-    prof_collect(c);
-    const int k = std::min<int>(cap, (int)c->prof_names.size());
+    std::unique_lock<std::mutex> lk(g_prof_mu);
+    for (vo_ctx* x : g_ctxs) prof_collect(x);
+    const int k = std::min<int>(cap, (int)g_prof_names.size());
     for (int i = 0; i < k; ++i) {
-        if (names) { strncpy(names[i], c->prof_names[i].c_str(), 47); names[i][47] = 0; }
-        if (ms) ms[i] = c->prof_ms[i];
-        if (calls) calls[i] = c->prof_calls[i];
+        if (names) { strncpy(names[i], g_prof_names[i].c_str(), 47); names[i][47] = 0; }
+        if (ms) ms[i] = g_prof_ms[i];
+        if (calls) calls[i] = g_prof_calls[i];
     }
     *n = k;
     return VO_OK;

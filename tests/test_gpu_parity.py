@@ -148,7 +148,7 @@ def test_track_frame_matches_oracle(frames, libs):
     assert np.abs(np.array(ro.T_cw) - inv12(Twc[8])).max() < 0.02
 
 
-@pytest.mark.parametrize("nP,nX,nfree", [(6, 400, 4), (34, 500, 30)])       # 30 free poses: D = 180 > LDS-resident limit
+@pytest.mark.parametrize("nP,nX,nfree", [(6, 400, 4), (34, 500, 30), (40, 500, 36)])   # 36 free poses: D = 216 > LDS-resident limit (192)
 def test_local_ba_matches_oracle(libs, nP, nX, nfree):
     rng = np.random.default_rng(5)
 
