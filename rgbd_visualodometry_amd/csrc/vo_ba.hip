@@ -35,7 +35,7 @@ struct BaBlock { int j1, j2, start, count; };      // one 6x6 block of the reduc
 // back to back; the host only polls `finished` once per chunk of steps.
 struct BaCtl {
     double lambda, ni, cur;
-    int it, qmax, max_it, need_lin, first, finished, buf, iters_done, steps, pad;
+    int it, qmax, max_it, need_lin, first, finished, buf, iters_done, steps, arrived;
 };
 
 struct BaDev {
@@ -100,57 +100,46 @@ __device__ __forceinline__ void ba_wave_reduce(double* v) {      // 64 threads; 
     for (int i = 0; i < NV; ++i) v[i] = vo_wave_sum_f64(v[i]);
 }
 
-// one lane per EDGE: H_ll, b_l through f64 atomics (a point has only a handful of edges: no contention),
-// W_e of free-pose edges, robust chi2.  H_ll / b_l are zeroed by k_ba_prelin.
-__global__ __launch_bounds__(256) void k_ba_lin_points(BaCam cam, BaDev B, int robust, double delta) {
-    if (B.ctl->finished || !B.ctl->need_lin) return;
-    BA_STATE(B)
-    __shared__ double s_part[4];
-    const int e = blockIdx.x * 256 + threadIdx.x;
+// Linearisation, one launch: blocks [0, gp) own 256 points each (H_ll, b_l, W_e, chi2: no atomics, no zeroing),
+// blocks [gp, gp + PSPLIT n_free) reduce slices of a free pose's edges into H_pp / b_p (27 f64 atomics per block;
+// H_pp / b_p are zeroed by the step that accepted the state, see k_ba_chi_control).
+#define PSPLIT 4
+__device__ __forceinline__ void ba_lin_points_body(const BaCam& cam, const BaDev& B, int robust, double delta, int blk,
+                                                   const double* poses_c, const double* pts_c, double* s_part) {
+    const int k = blk * 256 + threadIdx.x;
     double chi[1] = {0.0};
-    if (e < B.n_edges && B.active[e]) {
-        const int j = B.e_pose[e], k = B.e_pt[e];
-        double r[2], w, rho0, Jp[2][6], Jl[2][3];
-        ba_edge(cam, poses_c + 12 * (size_t)j, pts_c + 3 * (size_t)k, B.e_uv + 2 * (size_t)e, robust, delta, r, w, rho0, Jp, Jl);
-        chi[0] = rho0;
+    if (k < B.n_points) {
+        double H[6] = {0, 0, 0, 0, 0, 0}, b3[3] = {0, 0, 0};
+        const double* p = pts_c + 3 * (size_t)k;
+        for (int q = B.pt_start[k]; q < B.pt_start[k + 1]; ++q) {
+            const int e = B.pt_edges[q];
+            if (!B.active[e]) continue;
+            const int j = B.e_pose[e];
+            double r[2], w, rho0, Jp[2][6], Jl[2][3];
+            ba_edge(cam, poses_c + 12 * (size_t)j, p, B.e_uv + 2 * (size_t)e, robust, delta, r, w, rho0, Jp, Jl);
+            chi[0] += rho0;
+            b3[0] -= w * (Jl[0][0] * r[0] + Jl[1][0] * r[1]); b3[1] -= w * (Jl[0][1] * r[0] + Jl[1][1] * r[1]); b3[2] -= w * (Jl[0][2] * r[0] + Jl[1][2] * r[1]);
+            H[0] += w * (Jl[0][0] * Jl[0][0] + Jl[1][0] * Jl[1][0]); H[1] += w * (Jl[0][0] * Jl[0][1] + Jl[1][0] * Jl[1][1]); H[2] += w * (Jl[0][0] * Jl[0][2] + Jl[1][0] * Jl[1][2]);
+            H[3] += w * (Jl[0][1] * Jl[0][1] + Jl[1][1] * Jl[1][1]); H[4] += w * (Jl[0][1] * Jl[0][2] + Jl[1][1] * Jl[1][2]); H[5] += w * (Jl[0][2] * Jl[0][2] + Jl[1][2] * Jl[1][2]);
+            if (j < B.n_free) {
+                double* We = B.W + 18 * (size_t)e;
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) We[3 * a + c] = w * (Jp[0][a] * Jl[0][c] + Jp[1][a] * Jl[1][c]);
+            }
+        }
         double* Ho = B.Hll + 9 * (size_t)k;
-        double* bo = B.bl + 3 * (size_t)k;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            atomicAdd(&bo[a], -w * (Jl[0][a] * r[0] + Jl[1][a] * r[1]));
-#pragma unroll
-            for (int c = 0; c < 3; ++c) atomicAdd(&Ho[3 * a + c], w * (Jl[0][a] * Jl[0][c] + Jl[1][a] * Jl[1][c]));
-        }
-        if (j < B.n_free) {
-            double* We = B.W + 18 * (size_t)e;
-#pragma unroll
-            for (int a = 0; a < 6; ++a)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) We[3 * a + c] = w * (Jp[0][a] * Jl[0][c] + Jp[1][a] * Jl[1][c]);
-        }
+        Ho[0] = H[0]; Ho[1] = H[1]; Ho[2] = H[2]; Ho[3] = H[1]; Ho[4] = H[3]; Ho[5] = H[4]; Ho[6] = H[2]; Ho[7] = H[4]; Ho[8] = H[5];
+        B.bl[3 * (size_t)k] = b3[0]; B.bl[3 * (size_t)k + 1] = b3[1]; B.bl[3 * (size_t)k + 2] = b3[2];
     }
     ba_block_reduce<1>(chi, s_part);
     if (threadIdx.x == 0 && chi[0] != 0.0) atomicAdd(&B.scal[0], chi[0]);
 }
 
-// zero the accumulators of a linearisation (H_ll, b_l, H_pp, b_p)
-__global__ void k_ba_prelin(BaDev B) {
-    if (B.ctl->finished || !B.ctl->need_lin) return;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 9 * (size_t)B.n_points) B.Hll[i] = 0;
-    if (i < 3 * (size_t)B.n_points) B.bl[i] = 0;
-    if (i < 36 * (size_t)B.n_free) B.Hpp[i] = 0;
-    if (i < (size_t)B.D) B.bp[i] = 0;
-}
-
-// PSPLIT workgroups per free pose: H_pp (6x6) and b_p by block reductions over slices of the pose's edges,
-// combined with 27 f64 atomics per workgroup
-#define PSPLIT 4
-__global__ __launch_bounds__(256) void k_ba_lin_poses(BaCam cam, BaDev B, int robust, double delta) {
-    if (B.ctl->finished || !B.ctl->need_lin) return;
-    BA_STATE(B)
-    __shared__ double s_part[4 * 27];
-    const int j = blockIdx.x / PSPLIT, part = blockIdx.x % PSPLIT;
+__device__ __forceinline__ void ba_lin_poses_body(const BaCam& cam, const BaDev& B, int robust, double delta, int blk,
+                                                  const double* poses_c, const double* pts_c, double* s_part) {
+    const int j = blk / PSPLIT, part = blk % PSPLIT;
     const double* T = poses_c + 12 * (size_t)j;
     double v[27];
 #pragma unroll
@@ -176,6 +165,14 @@ __global__ __launch_bounds__(256) void k_ba_lin_poses(BaCam cam, BaDev B, int ro
     }
 }
 
+__global__ __launch_bounds__(256) void k_ba_lin(BaCam cam, BaDev B, int robust, double delta, int gp) {
+    if (B.ctl->finished || !B.ctl->need_lin) return;
+    BA_STATE(B)
+    __shared__ double s_part[4 * 27];
+    if ((int)blockIdx.x < gp) ba_lin_points_body(cam, B, robust, delta, blockIdx.x, poses_c, pts_c, s_part);
+    else ba_lin_poses_body(cam, B, robust, delta, blockIdx.x - gp, poses_c, pts_c, s_part);
+}
+
 __global__ void k_ba_maxdiag(BaDev B) {
     if (B.ctl->finished || !B.ctl->need_lin || !B.ctl->first) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -191,7 +188,9 @@ __global__ void k_ba_maxdiag(BaDev B) {
 // S = blockdiag(H_pp) + lambda I, b_s = b_p, and (H_ll + lambda I)^-1 per point
 __global__ void k_ba_init_S(BaDev B) {
     if (B.ctl->finished) return;
-    const double lambda = B.ctl->lambda;
+    // first step of a round: lambda = 1e-5 * max diag(H) (g2o computeLambdaInit); the control block is updated later in
+    // this step by the Cholesky kernel's prologue, so every lane derives the same value here
+    const double lambda = (B.ctl->need_lin && B.ctl->first) ? 1e-5 * B.scal[4] : B.ctl->lambda;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < B.D * B.D) {
         const int r = i / B.D, c = i % B.D;
@@ -294,7 +293,16 @@ __global__ __launch_bounds__(1024) void k_ba_chol_t(BaDev B) {
     double* const s_inv = s_b + D;
     auto at = [&](int r, int c) -> double& { if (INLDS) return s_L[TRI(r, c)]; return r == D ? s_aug[c] : A[(size_t)r * D + c]; };
     __shared__ int s_ok;
-    if (tid == 0) s_ok = 1;
+    if (tid == 0) {
+        s_ok = 1;
+        BaCtl* c = B.ctl;                               // take over the fresh linearisation, clear the trial sums
+        if (c->need_lin) {
+            c->cur = B.scal[0];
+            if (c->first) { c->lambda = 1e-5 * B.scal[4]; c->ni = 2; c->first = 0; }
+            c->need_lin = 0;
+        }
+        B.scal[1] = 0; B.scal[2] = 0; B.scal[7] = 0;
+    }
     if (INLDS) { for (int i = tid; i < D * D; i += 1024) { const int r = i / D, c = i - r * D; if (c <= r) s_L[TRI(r, c)] = A[i]; } }
     for (int i = tid; i < D; i += 1024) at(D, i) = B.bs[i];
     if (tid == 0) at(D, D) = 0.0;
@@ -384,11 +392,8 @@ __global__ __launch_bounds__(1024) void k_ba_chol_t(BaDev B) {
     if (tid == 0) B.scal[3] = s_ok ? 1.0 : 0.0;
 }
 
-__global__ void k_ba_backsub(BaDev B) {
-    if (B.ctl->finished) return;
-    const double lambda = B.ctl->lambda;
-    BA_STATE(B)
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void ba_backsub_body(const BaDev& B, double lambda, int blk, const double* pts_c, double* pts_t) {
+    const int k = blk * blockDim.x + threadIdx.x;
     double sc = 0, mx = 0;
     if (k < B.n_points && B.scal[3] != 0.0) {
         double rhs[3] = {B.bl[3 * (size_t)k], B.bl[3 * (size_t)k + 1], B.bl[3 * (size_t)k + 2]};
@@ -413,11 +418,8 @@ __global__ void k_ba_backsub(BaDev B) {
     if ((threadIdx.x & 63) == 0 && mx != 0.0) atomicMax((unsigned long long*)&B.scal[7], (unsigned long long)__double_as_longlong(mx));
 }
 
-__global__ void k_ba_pose(BaDev B) {
-    if (B.ctl->finished) return;
-    const double lambda = B.ctl->lambda;
-    BA_STATE(B)
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void ba_pose_body(const BaDev& B, double lambda, int blk, const double* poses_c, double* poses_t) {
+    const int j = blk * blockDim.x + threadIdx.x;
     if (j >= B.n_poses) return;
     const double* T = poses_c + 12 * (size_t)j;
     double* Tn = poses_t + 12 * (size_t)j;
@@ -443,6 +445,15 @@ __global__ void k_ba_pose(BaDev B) {
     atomicMax((unsigned long long*)&B.scal[7], (unsigned long long)__double_as_longlong(mx));
 }
 
+// trial state: new points (blocks [0, gp)) and new poses (blocks [gp, ...)), gain-ratio terms, max |step|
+__global__ void k_ba_update(BaDev B, int gp) {
+    if (B.ctl->finished) return;
+    const double lambda = B.ctl->lambda;
+    BA_STATE(B)
+    if ((int)blockIdx.x < gp) ba_backsub_body(B, lambda, blockIdx.x, pts_c, pts_t);
+    else ba_pose_body(B, lambda, blockIdx.x - gp, poses_c, poses_t);
+}
+
 // chi2 of the current (trial = 0 -> scal[5]) or trial (-> scal[1]) state
 __global__ void k_ba_chi(BaCam cam, BaDev B, int trial, int robust, double delta, int guard) {
     if (guard && B.ctl->finished) return;
@@ -462,40 +473,64 @@ __global__ void k_ba_chi(BaCam cam, BaDev B, int trial, int robust, double delta
     if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(&B.scal[trial ? 1 : 5], v);
 }
 
-// one lane, before every trial: take over the freshly linearised chi2 / initial lambda, clear the trial sums
-__global__ void k_ba_prestep(BaDev B) {
-    BaCtl* c = B.ctl;
-    if (c->finished) return;
-    if (c->need_lin) {
-        c->cur = B.scal[0];
-        if (c->first) { c->lambda = 1e-5 * __longlong_as_double((long long)*(unsigned long long*)&B.scal[4]); c->ni = 2; c->first = 0; }
-        c->need_lin = 0;
+// Robust chi2 of the trial state; the LAST workgroup to finish runs g2o's gain-ratio test and lambda policy
+// (OptimizationAlgorithmLevenberg::solve) on the control block and, when the step is accepted, clears
+// H_pp / b_p for the next linearisation.  Partial sums reach L2 through f64 atomics; the arrival counter is
+// taken after a device-scope fence (threadfence reduction).
+__global__ __launch_bounds__(256) void k_ba_chi_control(BaCam cam, BaDev B, int robust, double delta) {
+    if (B.ctl->finished) return;
+    BA_STATE(B)
+    __shared__ int s_last;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    double v = 0;
+    if (e < B.n_edges && B.active[e]) {
+        double r[2], pc[3];
+        ba_err(cam, poses_t + 12 * (size_t)B.e_pose[e], pts_t + 3 * (size_t)B.e_pt[e], B.e_uv + 2 * (size_t)e, r, pc);
+        const double e2 = r[0] * r[0] + r[1] * r[1];
+        v = (robust && e2 > delta * delta) ? 2.0 * sqrt(e2) * delta - delta * delta : e2;
     }
-    B.scal[1] = 0; B.scal[2] = 0; B.scal[3] = 0; B.scal[7] = 0;
-}
-
-// one lane, after every trial: g2o's gain-ratio test and lambda policy (OptimizationAlgorithmLevenberg::solve)
-__global__ void k_ba_control(BaDev B) {
-    BaCtl* c = B.ctl;
-    if (c->finished) return;
-    const bool ok = B.scal[3] != 0.0;
-    const double tmp = ok ? B.scal[1] : DBL_MAX;
-    const double scale = (ok ? B.scal[2] : 0.0) + 1e-3;
-    const double rho = (c->cur - tmp) / scale;
-    bool converged = false;
-    if (rho > 0 && isfinite(tmp)) {
-        double a = 1.0 - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
-        a = fmin(a, 2.0 / 3.0);
-        c->lambda *= fmax(1.0 / 3.0, a); c->ni = 2; c->cur = tmp;
-        c->buf ^= 1; c->need_lin = 1;                   // trial state becomes the current state
-        B.scal[0] = 0; B.scal[4] = 0;
-    } else { c->lambda *= c->ni; c->ni *= 2; }
-    if (ok) converged = __longlong_as_double((long long)*(unsigned long long*)&B.scal[7]) < 1e-10;
-    c->qmax += 1; c->steps += 1;
-    if (!(rho < 0 && c->qmax < 10 && !converged)) {     // this LM iteration is over
-        c->iters_done += 1;
-        if (c->qmax == 10 || rho == 0 || converged || c->it + 1 >= c->max_it) c->finished = 1;
-        c->it += 1; c->qmax = 0;
+    v = vo_wave_sum_f64(v);
+    if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(&B.scal[1], v);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd(&B.ctl->arrived, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __shared__ int s_accept;
+    if (threadIdx.x == 0) {
+        __threadfence();
+        BaCtl* c = B.ctl;
+        c->arrived = 0;
+        const double s1 = atomicAdd(&B.scal[1], 0.0), s2 = atomicAdd(&B.scal[2], 0.0), s3 = atomicAdd(&B.scal[3], 0.0);
+        const unsigned long long s7 = atomicAdd((unsigned long long*)&B.scal[7], 0ull);
+        const bool ok = s3 != 0.0;
+        const double tmp = ok ? s1 : DBL_MAX;
+        const double scale = (ok ? s2 : 0.0) + 1e-3;
+        const double rho = (c->cur - tmp) / scale;
+        bool converged = false;
+        int accept = 0;
+        if (rho > 0 && isfinite(tmp)) {
+            double a = 1.0 - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
+            a = fmin(a, 2.0 / 3.0);
+            c->lambda *= fmax(1.0 / 3.0, a); c->ni = 2; c->cur = tmp;
+            c->buf ^= 1; c->need_lin = 1; accept = 1;       // trial state becomes the current state
+            B.scal[0] = 0; B.scal[4] = 0;
+        } else { c->lambda *= c->ni; c->ni *= 2; }
+        if (ok) converged = __longlong_as_double((long long)s7) < 1e-10;
+        c->qmax += 1; c->steps += 1;
+        if (!(rho < 0 && c->qmax < 10 && !converged)) {     // this LM iteration is over
+            c->iters_done += 1;
+            if (c->qmax == 10 || rho == 0 || converged || c->it + 1 >= c->max_it) c->finished = 1;
+            c->it += 1; c->qmax = 0;
+        }
+        s_accept = accept;
+    }
+    __syncthreads();
+    if (s_accept) {
+        for (int i = threadIdx.x; i < 36 * B.n_free; i += 256) B.Hpp[i] = 0;
+        for (int i = threadIdx.x; i < B.D; i += 256) B.bp[i] = 0;
     }
 }
 
@@ -629,22 +664,19 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
         h_ctl->max_it = max_it; h_ctl->need_lin = 1; h_ctl->first = 1; h_ctl->buf = cur_buf; h_ctl->ni = 2;
         HIP_TRY(hipMemcpyAsync(B.ctl, h_ctl, sizeof(BaCtl), hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemsetAsync(B.scal, 0, 64, st));
+        HIP_TRY(hipMemsetAsync(B.Hpp, 0, sizeof(double) * 36 * (size_t)nf, st));
+        HIP_TRY(hipMemsetAsync(B.bp, 0, sizeof(double) * (size_t)D, st));
         for (int guard_steps = 0, chunk = max_it; guard_steps < max_it * 10 + CHUNK; guard_steps += chunk, chunk = 2) {
             for (int sidx = 0; sidx < chunk; ++sidx) {
-                hipLaunchKernelGGL(k_ba_prelin, dim3((unsigned)((std::max<size_t>(9 * (size_t)nx, 36 * (size_t)nf) + 255) / 256)), blk, 0, st, B);
-                { ProfScope ps(c, "k_ba_lin_points"); hipLaunchKernelGGL(k_ba_lin_points, gE, blk, 0, st, cam, B, robust, in->huber_delta); }
-                { ProfScope ps(c, "k_ba_lin_poses"); hipLaunchKernelGGL(k_ba_lin_poses, dim3(nf * PSPLIT), blk, 0, st, cam, B, robust, in->huber_delta); }
-                hipLaunchKernelGGL(k_ba_maxdiag, dim3((D + 3 * nx + 255) / 256), blk, 0, st, B);
-                hipLaunchKernelGGL(k_ba_prestep, dim3(1), dim3(1), 0, st, B);
-                hipLaunchKernelGGL(k_ba_init_S, dim3((std::max(D * D, nx) + 255) / 256), blk, 0, st, B);
+                { ProfScope ps(c, "k_ba_lin"); hipLaunchKernelGGL(k_ba_lin, dim3(gP.x + nf * PSPLIT), blk, 0, st, cam, B, robust, in->huber_delta, (int)gP.x); }
+                if (guard_steps == 0 && sidx == 0) hipLaunchKernelGGL(k_ba_maxdiag, dim3((D + 3 * nx + 255) / 256), blk, 0, st, B);
+                { ProfScope ps(c, "k_ba_init_S"); hipLaunchKernelGGL(k_ba_init_S, dim3((std::max(D * D, nx) + 255) / 256), blk, 0, st, B); }
                 if (nblk) { ProfScope ps(c, "k_ba_schur_blocks"); hipLaunchKernelGGL(k_ba_schur_blocks, dim3(nblk), blk, 0, st, B); }
                 { ProfScope ps(c, "k_ba_chol");
                   if (D <= 192) hipLaunchKernelGGL(k_ba_chol_t<true>, dim3(1), dim3(1024), sizeof(double) * ((size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D), st, B);
                   else hipLaunchKernelGGL(k_ba_chol_t<false>, dim3(1), dim3(1024), sizeof(double) * ((size_t)7 * (D + 1) + 2 * (size_t)D), st, B); }
-                { ProfScope ps(c, "k_ba_backsub"); hipLaunchKernelGGL(k_ba_backsub, gP, blk, 0, st, B); }
-                hipLaunchKernelGGL(k_ba_pose, gJ, blk, 0, st, B);
-                { ProfScope ps(c, "k_ba_chi"); hipLaunchKernelGGL(k_ba_chi, gE, blk, 0, st, cam, B, 1, robust, in->huber_delta, 1); }
-                hipLaunchKernelGGL(k_ba_control, dim3(1), dim3(1), 0, st, B);
+                { ProfScope ps(c, "k_ba_update"); hipLaunchKernelGGL(k_ba_update, dim3(gP.x + gJ.x), blk, 0, st, B, (int)gP.x); }
+                { ProfScope ps(c, "k_ba_chi_control"); hipLaunchKernelGGL(k_ba_chi_control, gE, blk, 0, st, cam, B, robust, in->huber_delta); }
             }
             HIP_TRY(hipMemcpyAsync(h_ctl, B.ctl, sizeof(BaCtl), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));

@@ -34,7 +34,9 @@ Pose pose_at(const synth_params& p, int frame) {
     auto ph = [&](int k) { return 6.283185307179586 * (double)((mix(h + k) >> 11) & 0xFFFFF) / 1048576.0; };
     Pose P;
     P.t[0] = 0.40 * std::sin(0.50 * t + ph(0)); P.t[1] = 0.25 * std::sin(0.37 * t + ph(1)); P.t[2] = 0.30 * std::sin(0.29 * t + ph(2));
-    double yaw = 0.35 * std::sin(0.23 * t + ph(3)), pitch = 0.20 * std::sin(0.31 * t + ph(4)), roll = 0.10 * std::sin(0.41 * t + ph(5));
+    // slow continuous turn (0.25 deg/frame at 30 Hz: the camera sweeps all four walls in 1440 frames, so old keyframes
+    // drop out of the covisible set instead of the whole run staying inside one local map) plus small oscillations
+    double yaw = 0.1309 * t + 0.15 * std::sin(0.23 * t + ph(3)), pitch = 0.15 * std::sin(0.31 * t + ph(4)), roll = 0.08 * std::sin(0.41 * t + ph(5));
     rot_xyz(pitch, yaw, roll, P.R);
     return P;
 }
