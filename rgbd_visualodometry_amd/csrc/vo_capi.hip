@@ -48,6 +48,8 @@ static int build_plan(const vo_params& p, DevPlan& P, std::vector<int>& tab, std
         P.tiles_x[l] = (P.lw[l] - 2 * P.edge + 63) / 64;
         const int tiles_y = (P.lh[l] - 2 * P.edge + 15) / 16;
         P.tile_prefix[l + 1] = P.tile_prefix[l] + P.tiles_x[l] * tiles_y;
+        P.btiles_x[l] = (P.lw[l] + 63) / 64;
+        P.btile_prefix[l + 1] = P.btile_prefix[l] + P.btiles_x[l] * ((P.lh[l] + 15) / 16);
         maxq = std::max(maxq, P.quota[l]);
     }
     P.sel_cap = 1;
@@ -188,7 +190,7 @@ void vo_ctx_destroy(vo_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto p : c->own_bgr) if (p) (void)hipFree(p);
     for (auto p : c->own_depth) if (p) (void)hipFree(p);
-    void* ptrs[] = {c->d_slots, c->d_pyr, c->d_tab, c->d_tabs, c->d_cand, c->d_cand_cnt, c->d_sel, c->d_sel_key, c->d_sel_cnt, c->d_kps,
+    void* ptrs[] = {c->d_slots, c->d_pyr, c->d_blur, c->d_tab, c->d_tabs, c->d_cand, c->d_cand_cnt, c->d_sel, c->d_sel_key, c->d_sel_cnt, c->d_kps,
                     c->d_desc, c->d_nkp, c->d_status, c->d_map_pos, c->d_map_nrm, c->d_map_desc, c->d_map_flags, c->d_active, c->d_best, c->d_mcand,
                     c->d_matches, c->d_corr_xyz, c->d_corr_uv, c->d_hyp_pose, c->d_hyp_cnt, c->d_inliers, c->d_lm_mask, c->d_track, c->d_ba};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -216,7 +218,7 @@ int vo_ctx_create(const vo_params* p, int device, vo_ctx** out) {
     vo_ctx* c = new (std::nothrow) vo_ctx();
     if (!c) return VO_E_NOMEM;
     c->p = *p; c->device = device; c->stream = nullptr; c->prof_on = false; c->corr_external = false;
-    c->d_slots = nullptr; c->d_pyr = nullptr; c->d_tab = nullptr; c->d_tabs = nullptr; c->d_cand = nullptr; c->d_cand_cnt = nullptr;
+    c->d_slots = nullptr; c->d_pyr = nullptr; c->d_blur = nullptr; c->d_tab = nullptr; c->d_tabs = nullptr; c->d_cand = nullptr; c->d_cand_cnt = nullptr;
     c->d_sel = nullptr; c->d_sel_key = nullptr; c->d_sel_cnt = nullptr; c->d_kps = nullptr; c->d_desc = nullptr; c->d_nkp = nullptr; c->d_status = nullptr;
     c->d_map_pos = nullptr; c->d_map_nrm = nullptr; c->d_map_desc = nullptr; c->d_map_flags = nullptr; c->d_active = nullptr; c->n_active = 0; c->active_cap = 0;
     c->lanes = std::max(1, p->max_track_batch);
@@ -242,6 +244,7 @@ int vo_ctx_create(const vo_params* p, int device, vo_ctx** out) {
     memset(c->h_slots_pinned, 0, sizeof(SlotDesc) * F);
     if (hipEventCreateWithFlags(&c->slots_ev, hipEventDisableTiming) != hipSuccess) { vo_ctx_destroy(c); return VO_E_DEVICE; }
     ALLOC(c->d_pyr, (size_t)F * P.pyr_stride);
+    ALLOC(c->d_blur, (size_t)F * P.pyr_stride);
     ALLOC(c->d_tab, tab.size()); ALLOC(c->d_tabs, tabs.size());
     ALLOC(c->d_cand, (size_t)F * P.cprefix[P.L]); ALLOC(c->d_cand_cnt, (size_t)F * VO_MAX_LEVELS);
     ALLOC(c->d_sel, (size_t)F * P.nfeat); ALLOC(c->d_sel_key, (size_t)F * P.nfeat); ALLOC(c->d_sel_cnt, (size_t)F * VO_MAX_LEVELS);

@@ -21,6 +21,7 @@ struct DevPlan {
     unsigned loff[VO_MAX_LEVELS];                               // byte offset of each level inside a slot's pyramid slab
     float scale[VO_MAX_LEVELS];
     int tiles_x[VO_MAX_LEVELS], tile_prefix[VO_MAX_LEVELS + 1]; // FAST tiling (64x16 tiles), blockIdx.x -> (level, tile)
+    int btiles_x[VO_MAX_LEVELS], btile_prefix[VO_MAX_LEVELS + 1]; // blur tiling (64x16 tiles over the whole level)
     int tabx[VO_MAX_LEVELS], taby[VO_MAX_LEVELS];               // offsets into the resize tables
     int umax[16];
     int gk[7];
@@ -68,7 +69,7 @@ struct vo_ctx {
     SlotDesc* h_slots_pinned; hipEvent_t slots_ev; bool slots_dirty, slots_pending;
     std::vector<char> slot_bound, slot_orb;
     // pyramid + ORB work buffers
-    uint8_t* d_pyr;
+    uint8_t* d_pyr; uint8_t* d_blur;                // gray pyramid and its 7x7 sigma-2 blurred copy, same layout
     int* d_tab; short* d_tabs;                      // resize tables: int offsets, short weights
     uint32_t* d_cand; int* d_cand_cnt;              // [slot][cprefix[L]] packed candidates, [slot][L] counts
     uint32_t* d_sel; long long* d_sel_key; int* d_sel_cnt;   // [slot][nfeat] selected (x|y<<12), keys, [slot][L] counts

@@ -20,6 +20,10 @@
 #include "vo_brief_pattern.h"
 #include "vo_internal.h"
 
+#ifndef FAST_VARIANT
+#define FAST_VARIANT 0
+#endif
+
 __constant__ int8_t c_pattern[256 * 4];
 
 // ------------------------------------------------------------------------------------------
@@ -120,41 +124,82 @@ __global__ __launch_bounds__(256) void k_fast_nms(DevPlan P, const uint8_t* __re
     for (int i = tid; i < GP * (TH + 8); i += 256) {
         int gx = x0 - 4 + i % GP, gy = y0 - 4 + i / GP;
         gx = min(max(gx, 0), w - 1); gy = min(max(gy, 0), h - 1);
+#if FAST_VARIANT == 3
+        s_gray[i] = (uint8_t)(gx * 7 + gy * 13);
+#else
         s_gray[i] = img[(size_t)gy * pitch + gx];
+#endif
     }
     __syncthreads();
-    // scores on the tile + halo 1
+    // scores on the tile + halo 1, in two phases so that the expensive arc evaluation runs on a dense list:
+    // (A) every position: cheap reject (a 9-arc always contains one pixel of each opposite pair) -> LDS work list,
+    // (B) lanes walk the list and evaluate the full corner score.  Without the split, one candidate per
+    //     wavefront makes all 64 lanes wait for the ~250-instruction score at every position.
+    __shared__ uint16_t s_list[SP * (TH + 2)];
+    __shared__ int s_nlist;
+    if (tid == 0) s_nlist = 0;
+    __syncthreads();
+    const int thr = P.fast_thr;
     for (int i = tid; i < SP * (TH + 2); i += 256) {
         const int sx = i % SP, sy = i / SP;
         const int x = x0 - 1 + sx, y = y0 - 1 + sy;
-        int sc = 0;
+        s_score[i] = 0;
         if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) {
             const int gi = (sy + 3) * GP + sx + 3;
-            const int p = s_gray[gi], thr = P.fast_thr;
-            // every 9-arc contains one pixel of each opposite pair: cheap reject
+            const int p = s_gray[gi];
             const bool c0 = abs((int)s_gray[gi + 3 * GP] - p) > thr || abs((int)s_gray[gi - 3 * GP] - p) > thr;
             const bool c1 = abs((int)s_gray[gi + 3] - p) > thr || abs((int)s_gray[gi - 3] - p) > thr;
-            if (c0 && c1) {
-                int s = fast_score_lds(s_gray, gi);
-                if (s >= thr) sc = min(s, 255);
-            }
+            if (c0 && c1) s_list[atomicAdd(&s_nlist, 1)] = (uint16_t)i;
         }
-        s_score[i] = (uint8_t)sc;
     }
     __syncthreads();
-    // 3x3 non-max suppression (strict), border filter, append survivors
+    const int nlist = s_nlist;
+#if FAST_VARIANT == 2
+    for (int q = tid; q < 0; q += 256) {
+#else
+    for (int q = tid; q < nlist; q += 256) {
+#endif
+        const int i = s_list[q];
+        const int sx = i % SP, sy = i / SP;
+        const int sc = fast_score_lds(s_gray, (sy + 3) * GP + sx + 3);
+        if (sc >= thr) s_score[i] = (uint8_t)min(sc, 255);
+    }
+    __syncthreads();
+    // 3x3 non-max suppression (strict), border filter; survivors are gathered in LDS and appended with ONE
+    // global atomic per workgroup (a per-survivor atomic on the shared (slot, level) counter serialises at L2:
+    // it was 80 % of this kernel's time)
+    __shared__ uint32_t s_surv[TW * TH / 2];
+    __shared__ int s_nsurv, s_base;
+    if (tid == 0) s_nsurv = 0;
+    __syncthreads();
     for (int k = 0; k < TH / 4; ++k) {
         const int ty = threadIdx.y + 4 * k, tx = threadIdx.x;
         const int x = x0 + tx, y = y0 + ty;
         if (x >= w - P.edge || y >= h - P.edge) continue;
         const uint8_t* q = &s_score[(ty + 1) * SP + tx + 1];
-        const int s = q[0];
-        if (s == 0) continue;
-        if (s > q[-1] && s > q[1] && s > q[-SP - 1] && s > q[-SP] && s > q[-SP + 1] && s > q[SP - 1] && s > q[SP] && s > q[SP + 1]) {
-            int pos = atomicAdd(&cand_cnt[slot * VO_MAX_LEVELS + l], 1);
-            if (pos < P.ccap[l]) cand[(size_t)slot * P.cprefix[P.L] + P.cprefix[l] + pos] = ((uint32_t)s << 24) | ((uint32_t)y << 12) | (uint32_t)x;
-            else *status = VO_E_OVERFLOW;
+        const int sc = q[0];
+        if (sc == 0) continue;
+        if (sc > q[-1] && sc > q[1] && sc > q[-SP - 1] && sc > q[-SP] && sc > q[-SP + 1] && sc > q[SP - 1] && sc > q[SP] && sc > q[SP + 1]) {
+            const int pos = atomicAdd(&s_nsurv, 1);      // strict 3x3 maxima: at most every other pixel -> fits TW*TH/2
+            s_surv[pos] = ((uint32_t)sc << 24) | ((uint32_t)y << 12) | (uint32_t)x;
         }
+    }
+    __syncthreads();
+    const int ns = s_nsurv;
+    if (ns == 0) return;
+    if (tid == 0) {
+#if FAST_VARIANT == 1
+        s_base = 0; (void)cand_cnt;
+#else
+        s_base = atomicAdd(&cand_cnt[slot * VO_MAX_LEVELS + l], ns);
+#endif
+    }
+    __syncthreads();
+    const int base = s_base;
+    for (int i = tid; i < ns; i += 256) {
+        const int pos = base + i;
+        if (pos < P.ccap[l]) cand[(size_t)slot * P.cprefix[P.L] + P.cprefix[l] + pos] = s_surv[i];
+        else *status = VO_E_OVERFLOW;
     }
 }
 
@@ -251,12 +296,54 @@ __global__ __launch_bounds__(1024) void k_select(DevPlan P, const uint8_t* __res
 }
 
 // ------------------------------------------------------------------------------------------
-#define PR 21                 // raw patch radius (18 for the rotated BRIEF footprint + 3 for the blur)
-#define PW (2 * PR + 1)       // 43
-#define PP 44                 // raw patch pitch
-#define BR 18
-#define BW (2 * BR + 1)       // 37
-#define WAVE_LDS (PW * PP + PW * BW * 2 + BW * BW + 7)
+// 7x7 sigma-2 Gaussian blur of every pyramid level in 8-bit fixed point (cv::GaussianBlur semantics for 8-bit images:
+// integer kernel round(k*256), row pass in int, column pass (sum + 2^15) >> 16), BORDER_REFLECT_101.  Separable in
+// LDS: 64x16 output tile, (64+6)x(16+6) input halo, u16 intermediate.  Streaming kernel: reads P, writes P.
+#define BTW 64
+#define BTH 16
+__global__ __launch_bounds__(256) void k_blur(DevPlan P, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, int slot0) {
+    __shared__ uint8_t s_in[(BTH + 6) * (BTW + 8)];
+    __shared__ uint16_t s_h[(BTH + 6) * BTW];
+    const int slot = slot0 + blockIdx.z;
+    int l = 0;
+    while (l + 1 < P.L && (int)blockIdx.x >= P.btile_prefix[l + 1]) ++l;
+    const int t = blockIdx.x - P.btile_prefix[l];
+    const int w = P.lw[l], h = P.lh[l], pitch = P.pitch[l];
+    const int x0 = (t % P.btiles_x[l]) * BTW, y0 = (t / P.btiles_x[l]) * BTH;
+    const uint8_t* img = pyr + (size_t)slot * P.pyr_stride + P.loff[l];
+    uint8_t* out = blur + (size_t)slot * P.pyr_stride + P.loff[l];
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
+    // halo tile, reflect-101 at the image border
+    for (int r = ty; r < BTH + 6; r += 4) {
+        int gy = y0 - 3 + r;
+        gy = gy < 0 ? -gy : (gy >= h ? 2 * h - 2 - gy : gy);
+        gy = min(max(gy, 0), h - 1);
+        for (int c = tx; c < BTW + 6; c += 64) {
+            int gx = x0 - 3 + c;
+            gx = gx < 0 ? -gx : (gx >= w ? 2 * w - 2 - gx : gx);
+            gx = min(max(gx, 0), w - 1);
+            s_in[r * (BTW + 8) + c] = img[(size_t)gy * pitch + gx];
+        }
+    }
+    __syncthreads();
+    for (int r = ty; r < BTH + 6; r += 4) {
+        const uint8_t* q = &s_in[r * (BTW + 8) + tx];
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) s += P.gk[k] * q[k];
+        s_h[r * BTW + tx] = (uint16_t)s;
+    }
+    __syncthreads();
+    (void)tid;
+    for (int r = ty; r < BTH; r += 4) {
+        const int x = x0 + tx, y = y0 + r;
+        if (x >= w || y >= h) continue;
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) s += P.gk[k] * s_h[(r + k) * BTW + tx];
+        out[(size_t)y * pitch + x] = (uint8_t)min(255, (s + (1 << 15)) >> 16);
+    }
+}
 
 __device__ __forceinline__ float fast_atan2_deg_dev(float y, float x) {
     const float k = 57.29577951308232f;
@@ -275,82 +362,52 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
     return v;
 }
 
-// one wavefront per keypoint, 4 per workgroup
+// One wavefront per keypoint, 4 per workgroup, no LDS: intensity-centroid moments over the radius-15 disc straight
+// from the level image (two 31-pixel rows per wave instruction), then the 256 steered tests read the blurred level
+// (8 samples per lane) and are packed with 4 x __ballot.
 __global__ __launch_bounds__(256) void k_describe(DevPlan P, const SlotDesc* __restrict__ slots, const uint8_t* __restrict__ pyr,
-                                                  const uint32_t* __restrict__ sel, const long long* __restrict__ sel_key,
-                                                  const int* __restrict__ sel_cnt, vo_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
-                                                  int* __restrict__ nkp, int slot0) {
-    __shared__ __align__(8) uint8_t s_all[4][(WAVE_LDS + 7) & ~7];
+                                                  const uint8_t* __restrict__ blurp, const uint32_t* __restrict__ sel,
+                                                  const long long* __restrict__ sel_key, const int* __restrict__ sel_cnt,
+                                                  vo_keypoint* __restrict__ kps, uint8_t* __restrict__ desc, int* __restrict__ nkp, int slot0) {
     const int slot = slot0 + blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = blockIdx.x * 4 + wave;
-    uint8_t* raw = s_all[wave];
-    uint16_t* hb = (uint16_t*)(raw + PW * PP);
-    uint8_t* blur = raw + PW * PP + PW * BW * 2;
-    // which level / rank is keypoint slot g, and where does it land in the compact output?
     int l = 0, base = 0, total = 0;
     for (int i = 0; i < P.L; ++i) total += sel_cnt[slot * VO_MAX_LEVELS + i];
-    bool active = g < P.nfeat;
-    if (active) {
-        while (l + 1 < P.L && g >= P.qprefix[l + 1]) { base += sel_cnt[slot * VO_MAX_LEVELS + l]; ++l; }
-        active = (g - P.qprefix[l]) < sel_cnt[slot * VO_MAX_LEVELS + l];
-    }
     if (blockIdx.x == 0 && threadIdx.x == 0) nkp[slot] = total;
-    int x = 0, y = 0;
+    if (g >= P.nfeat) return;
+    while (l + 1 < P.L && g >= P.qprefix[l + 1]) { base += sel_cnt[slot * VO_MAX_LEVELS + l]; ++l; }
+    if ((g - P.qprefix[l]) >= sel_cnt[slot * VO_MAX_LEVELS + l]) return;
     const int pitch = P.pitch[l];
     const uint8_t* img = pyr + (size_t)slot * P.pyr_stride + P.loff[l];
-    if (active) {
-        const uint32_t c = sel[(size_t)slot * P.nfeat + g];
-        x = c & 0xFFF; y = (c >> 12) & 0xFFF;
-        for (int i = lane; i < PW * PW; i += 64) {
-            const int r = i / PW, cc = i - r * PW;
-            raw[r * PP + cc] = img[(size_t)(y - PR + r) * pitch + (x - PR + cc)];
-        }
-    }
-    __syncthreads();
+    const uint8_t* blur = blurp + (size_t)slot * P.pyr_stride + P.loff[l];
+    const uint32_t c = sel[(size_t)slot * P.nfeat + g];
+    const int x = c & 0xFFF, y = (c >> 12) & 0xFFF;
+    // intensity centroid: lanes 0..30 take row v, lanes 32..62 row v+1
     int m10 = 0, m01 = 0;
-    if (active) {
-        // intensity centroid over the radius-15 disc
-        for (int i = lane; i < 31 * 31; i += 64) {
-            const int v = i / 31 - 15, u = i % 31 - 15;
-            if (abs(u) <= P.umax[abs(v)]) { const int I = raw[(PR + v) * PP + PR + u]; m10 += u * I; m01 += v * I; }
-        }
-        // horizontal 7-tap pass (u16 is enough: 255 * sum(gk) < 65536)
-        for (int i = lane; i < PW * BW; i += 64) {
-            const int r = i / BW, cc = i - r * BW;
-            const uint8_t* q = &raw[r * PP + cc];
-            int s = 0;
-#pragma unroll
-            for (int k = 0; k < 7; ++k) s += P.gk[k] * q[k];
-            hb[i] = (uint16_t)s;
+    const int u = (lane & 31) - 15, half = lane >> 5;
+    for (int v0 = -15; v0 <= 15; v0 += 2) {
+        const int v = v0 + half;
+        if ((lane & 31) < 31 && v <= 15 && abs(u) <= P.umax[abs(v)]) {
+            const int I = img[(size_t)(y + v) * pitch + x + u];
+            m10 += u * I; m01 += v * I;
         }
     }
     m10 = wave_sum_i32(m10); m01 = wave_sum_i32(m01);
-    __syncthreads();
-    if (active) {
-        for (int i = lane; i < BW * BW; i += 64) {
-            const int r = i / BW, cc = i - r * BW;
-            int s = 0;
-#pragma unroll
-            for (int k = 0; k < 7; ++k) s += P.gk[k] * hb[(r + k) * BW + cc];
-            blur[i] = (uint8_t)min(255, (s + (1 << 15)) >> 16);
-        }
-    }
-    __syncthreads();
-    if (!active) return;
     double cs = 1.0, sn = 0.0;
     if (m10 != 0 || m01 != 0) {
         const double nrm = sqrt((double)m10 * (double)m10 + (double)m01 * (double)m01);
         cs = (double)m10 / nrm; sn = (double)m01 / nrm;
     }
     const int out = base + (g - P.qprefix[l]);
+    const uint8_t* ctr = blur + (size_t)y * pitch + x;
     uint64_t bits[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int8_t* q = &c_pattern[(r * 64 + lane) * 4];
         const int x1 = __double2int_rn((double)q[0] * cs - (double)q[1] * sn), y1 = __double2int_rn((double)q[0] * sn + (double)q[1] * cs);
         const int x2 = __double2int_rn((double)q[2] * cs - (double)q[3] * sn), y2 = __double2int_rn((double)q[2] * sn + (double)q[3] * cs);
-        const bool b = blur[(BR + y1) * BW + BR + x1] < blur[(BR + y2) * BW + BR + x2];
+        const bool b = ctr[y1 * pitch + x1] < ctr[y2 * pitch + x2];
         bits[r] = __ballot(b);
     }
     if (lane == 0) {
@@ -406,9 +463,11 @@ int vo_orb_launch(vo_ctx* c, int slot0, int n) {
       size_t lds = (size_t)P.sel_cap * 12 + 4 * 260;
       dim3 g(P.L, n);
       hipLaunchKernelGGL(k_select, g, dim3(1024), lds, st, P, c->d_pyr, c->d_cand, c->d_cand_cnt, c->d_sel, c->d_sel_key, c->d_sel_cnt, slot0); }
+    { ProfScope ps(c, "k_blur");
+      hipLaunchKernelGGL(k_blur, dim3(P.btile_prefix[P.L], 1, n), dim3(64, 4), 0, st, P, c->d_pyr, c->d_blur, slot0); }
     { ProfScope ps(c, "k_describe");
       dim3 g((P.nfeat + 3) / 4, n);
-      hipLaunchKernelGGL(k_describe, g, dim3(256), 0, st, P, c->d_slots, c->d_pyr, c->d_sel, c->d_sel_key, c->d_sel_cnt, c->d_kps, c->d_desc, c->d_nkp, slot0); }
+      hipLaunchKernelGGL(k_describe, g, dim3(256), 0, st, P, c->d_slots, c->d_pyr, c->d_blur, c->d_sel, c->d_sel_key, c->d_sel_cnt, c->d_kps, c->d_desc, c->d_nkp, slot0); }
     HIP_TRY(hipGetLastError());
     return VO_OK;
 }
