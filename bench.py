@@ -193,6 +193,14 @@ def main():
                         "frac": round(t["TFLOPps"] / F64_MFMA_PEAK_TFLOPS, 6), "traffic": None}
             else:
                 roof = {"bound": "hbm", "kernel": dom, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+            # HBM traffic of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run inside
+            # this process); null when no measurement for this kernel is on file
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+                roof["traffic"] = pmc["kernels"][dom]["hbm_bytes_per_launch_corrected"]
+                roof["traffic_source"] = "profiles/r01_pmc_hbm_traffic.json (FETCH_SIZE, WRITE_SIZE: separate --pmc passes, (2*FETCH+WRITE)*1024)"
+            except Exception:
+                pass
             roof.update({"avg_launch_us": t["avg_us"], "launches": t["launches"],
                          "note": "single 640x480 stream: the chain is latency bound (small dependent kernels); see `kernels` for the streaming ORB kernels",
                          "kernels": table})
