@@ -47,7 +47,8 @@ def algorithmic_bytes(W, H, N, M, K, n_hyp, passes=2):
         "k_resize": sum(lv[l - 1][0] * lv[l - 1][1] + lv[l][0] * lv[l][1] for l in range(1, len(lv))),
         "k_fast_nms": P,                                          # every pyramid pixel read once
         "k_select": 81 * 2 * N + 8 * 2 * N,                       # 9x9 Harris windows of the 2N survivors + list traffic
-        "k_describe": (43 * 43) * N + 2 * W * H * 0 + 48 * N,     # one 43x43 patch per keypoint, kp+descriptor out
+        "k_blur": 2 * P,                                          # level pyramid in, blurred pyramid out
+        "k_describe": (709 + 512) * N + 32 * N + 64 * N,          # IC disc (709 px) + 512 BRIEF samples, kp in/out + descriptor
         "k_match": passes * (32 * M + 32 * N + 8 * M),
         "k_match_gate": passes * (8 * M + 36 * K),
         "k_ransac_hyp": passes * (20 * 4 * n_hyp + 96 * n_hyp),

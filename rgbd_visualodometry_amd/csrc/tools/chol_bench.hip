@@ -1,0 +1,142 @@
+// chol_bench.hip -- developer tool (not part of the product library): runs the reduced-system Cholesky kernels of
+// vo_ba.hip on random SPD systems, checks the solution against a host Cholesky and times them with HIP events.
+//   build:  make tools        run on the GPU box:  rgbd_visualodometry_amd/csrc/build/chol_bench
+// build with -DCH_STAMPS for the per-phase clock stamps (they perturb the timing: every stamp drains the LDS queue)
+#include "../vo_ba.hip"
+
+#include <random>
+
+// context helpers of vo_capi.hip that vo_ba_run references; the tool never calls vo_ba_run
+void vo_prof_begin(vo_ctx*, const char*) {}
+void vo_prof_end(vo_ctx*) {}
+void* vo_stage(vo_ctx*, size_t) { return nullptr; }
+int vo_scratch(vo_ctx*, size_t) { return VO_E_DEVICE; }
+
+static void host_solve(int D, std::vector<double> S, std::vector<double> b, std::vector<double>& x) {
+    for (int j = 0; j < D; ++j) {
+        double d = S[j * D + j];
+        for (int k = 0; k < j; ++k) d -= S[j * D + k] * S[j * D + k];
+        d = std::sqrt(d); S[j * D + j] = d;
+        for (int i = j + 1; i < D; ++i) { double s = S[i * D + j]; for (int k = 0; k < j; ++k) s -= S[i * D + k] * S[j * D + k]; S[i * D + j] = s / d; }
+    }
+    for (int i = 0; i < D; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= S[i * D + k] * b[k]; b[i] = s / S[i * D + i]; }
+    for (int i = D - 1; i >= 0; --i) { double s = b[i]; for (int k = i + 1; k < D; ++k) s -= S[k * D + i] * b[k]; b[i] = s / S[i * D + i]; }
+    x = b;
+}
+
+__global__ void k_dpp_probe(double* out) {
+    const int lane = threadIdx.x;
+    double v = 100.0 + lane;
+    double m = 2.0;
+    asm volatile("s_nop 4");
+    const double b = ch_bcast<3>(v);
+    double acc = 1000.0;
+    double vv = ch_mul_for_dpp(v, 1.0);
+    ch_fnma_bcast<5>(acc, vv, m);                 // 1000 - v[lane 5 of row] * 2
+    out[lane] = b; out[64 + lane] = acc;
+}
+
+__global__ void k_lat_probe(double* out, double seed) {
+    double x = seed + threadIdx.x, y = 1.0000001, z = 0.5;
+    long long t0 = clock64();
+#pragma unroll
+    for (int i = 0; i < 256; ++i) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(x) : "v"(y), "v"(z));
+    long long t1 = clock64();
+#pragma unroll
+    for (int i = 0; i < 128; ++i) asm volatile("v_mul_f64 %0, %0, %1\n\ts_nop 1\n\tv_fmac_f64_dpp %0, -%0, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(y), "v"(z));
+    long long t2 = clock64();
+#pragma unroll
+    for (int i = 0; i < 64; ++i) asm volatile("v_rsq_f64 %0, %0" : "+v"(x));
+    long long t3 = clock64();
+    double a0 = x, a1 = x + 1, a2 = x + 2, a3 = x + 3;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) asm volatile("v_fma_f64 %0, %0, %4, %5\n\tv_fma_f64 %1, %1, %4, %5\n\tv_fma_f64 %2, %2, %4, %5\n\tv_fma_f64 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(y), "v"(z));
+    long long t4 = clock64();
+#pragma unroll
+    for (int i = 0; i < 128; ++i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(reinterpret_cast<int&>(y)) : "v"(i));
+    long long t5 = clock64();
+    if (threadIdx.x == 0) { out[0] = (t1 - t0) / 256.0; out[1] = (t2 - t1) / 128.0; out[2] = (t3 - t2) / 64.0; out[3] = (t4 - t3) / 256.0; out[4] = (t5 - t4) / 128.0; }
+    out[8 + threadIdx.x] = x + a0 + a1 + a2 + a3 + y;
+}
+
+__global__ void k_rsq_probe(const double* x, double* y, int n) {
+#pragma clang fp contract(fast)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double d = x[i];
+    const double y0 = __builtin_amdgcn_rsq(d);
+    const double e = 1.0 - (d * y0) * y0;
+    const double y1 = y0 + y0 * (0.5 * e);                                  // one Newton step
+    const double yc = y0 + y0 * (e * (0.5 + 0.375 * e));                    // one cubic (Halley-like) step
+    y[i] = y0; y[n + i] = y1; y[2 * n + i] = yc; { double yy, qq; ba_rsqrt_parts(d, yy, qq); y[3 * n + i] = yy + yy * qq; }
+}
+
+int main() {
+    { double* d; hipMalloc(&d, 128 * 8); hipLaunchKernelGGL(k_lat_probe, dim3(1), dim3(64), 0, 0, d, 1.0); double h[8]; hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+      printf("latency probe (clocks): dependent v_fma_f64 %.1f | mul+nop+fmac_dpp pair %.1f | dependent v_rsq_f64 %.1f | independent v_fma_f64 %.1f | dependent v_cndmask_b32 %.1f\n", h[0], h[1], h[2], h[3], h[4]); hipFree(d); }
+    { const int n = 1 << 16; std::vector<double> hx(n), hy(4 * n); std::mt19937_64 rg(7); std::uniform_real_distribution<double> ud(-30.0, 30.0);
+      for (auto& v : hx) v = std::exp2(ud(rg));
+      double *dx, *dy; hipMalloc(&dx, n * 8); hipMalloc(&dy, 4 * n * 8); hipMemcpy(dx, hx.data(), n * 8, hipMemcpyHostToDevice);
+      hipLaunchKernelGGL(k_rsq_probe, dim3(n / 256), dim3(256), 0, 0, dx, dy, n); hipMemcpy(hy.data(), dy, 4 * n * 8, hipMemcpyDeviceToHost);
+      const char* nm[4] = {"v_rsq_f64", "+1 newton", "+1 cubic", "ba_rsqrt_parts"};
+      for (int v = 0; v < 4; ++v) { long double mx = 0; for (int i = 0; i < n; ++i) { long double ex = 1.0L / sqrtl((long double)hx[i]); long double er = fabsl((long double)hy[v * n + i] - ex) / ex; if (er > mx) mx = er; }
+          printf("rsq probe %-20s max rel err %.3Le (2^%.1Lf)\n", nm[v], mx, log2l(mx)); }
+      hipFree(dx); hipFree(dy); }
+
+    { double* d; hipMalloc(&d, 128 * 8); hipLaunchKernelGGL(k_dpp_probe, dim3(1), dim3(64), 0, 0, d); double h[128]; hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+      printf("bcast<3>: "); for (int i = 0; i < 64; i += 5) printf("[%d]=%.0f ", i, h[i]); printf("\nfnma<5>: "); for (int i = 0; i < 64; i += 5) printf("[%d]=%.0f ", i, h[64 + i]); printf("\n"); hipFree(d); }
+
+    const int sizes[] = {6, 24, 30, 60, 120, 168, 186, 192};
+    hipFuncSetAttribute((const void*)k_ba_chol_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+    hipFuncSetAttribute((const void*)k_ba_chol16, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+    hipStream_t st; hipStreamCreate(&st);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    int bad = 0;
+    for (int D : sizes) {
+        std::mt19937_64 rng(1234 + D);
+        std::normal_distribution<double> nd(0.0, 1.0);
+        std::vector<double> M((size_t)D * D), S((size_t)D * D), b(D), x;
+        for (auto& v : M) v = nd(rng);
+        for (int i = 0; i < D; ++i) for (int j = 0; j < D; ++j) { double s = 0; for (int k = 0; k < D; ++k) s += M[i * D + k] * M[j * D + k]; S[i * D + j] = s * 1e3 + (i == j ? 1e3 * D : 0.0); }
+        for (auto& v : b) v = nd(rng) * 1e2;
+        host_solve(D, S, b, x);
+        BaDev B; memset(&B, 0, sizeof(B));
+        B.D = D;
+        double* d_b0;
+        hipMalloc(&B.S, sizeof(double) * D * D); hipMalloc(&B.bs, sizeof(double) * D); hipMalloc(&d_b0, sizeof(double) * D);
+        hipMalloc(&B.scal, 64); hipMalloc(&B.dl, 128); hipMemset(B.dl, 0, 128); hipMalloc(&B.ctl, sizeof(BaCtl));
+        hipMemset(B.scal, 0, 64); hipMemset(B.ctl, 0, sizeof(BaCtl));
+        hipMemcpy(B.S, S.data(), sizeof(double) * D * D, hipMemcpyHostToDevice);
+        hipMemcpy(d_b0, b.data(), sizeof(double) * D, hipMemcpyHostToDevice);
+        for (int variant = 0; variant < 2; ++variant) {
+            float tot = 0; const int reps = 50;
+            for (int it = 0; it < reps + 5; ++it) {
+                hipMemcpyAsync(B.bs, d_b0, sizeof(double) * D, hipMemcpyDeviceToDevice, st);
+                hipEventRecord(e0, st);
+                if (variant == 0) hipLaunchKernelGGL(k_ba_chol_t<true>, dim3(1), dim3(1024), sizeof(double) * ((size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D), st, B);
+                else hipLaunchKernelGGL(k_ba_chol16, dim3(1), dim3(CH_THREADS), sizeof(double) * (CH_NB * CH_NB + (size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D), st, B);
+                hipEventRecord(e1, st);
+                hipStreamSynchronize(st);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                if (it >= 5) tot += ms;
+            }
+            std::vector<double> got(D); double ok;
+            hipMemcpy(got.data(), B.bs, sizeof(double) * D, hipMemcpyDeviceToHost);
+            hipMemcpy(&ok, B.scal + 3, 8, hipMemcpyDeviceToHost);
+            double err = 0, ref = 0;
+            for (int i = 0; i < D; ++i) { err = std::max(err, std::fabs(got[i] - x[i])); ref = std::max(ref, std::fabs(x[i])); }
+            printf("D %3d  %-12s  %8.2f us  ok %.0f  max|dx|/max|x| %.3e%s\n", D, variant ? "k_ba_chol16" : "k_ba_chol_t", 1e3 * tot / reps, ok, err / ref,
+                   (ok == 1.0 && err / ref < 1e-10) ? "" : "   <-- MISMATCH");
+            if (!(ok == 1.0 && err / ref < 1e-10)) ++bad;
+#ifdef CH_STAMPS
+            if (variant == 1) { double tt[12]; hipMemcpy(tt, B.dl, 96, hipMemcpyDeviceToHost);
+                printf("        clocks: load+block0 %.0f | solve+barrier %.0f | wave0: tile00 %.0f, load rows %.0f, factor %.0f, barrier wait %.0f | bwd: loads %.0f, push+chain %.0f, barrier %.0f, head/tail %.0f+%.0f\n",
+                       tt[0], tt[1], tt[5], tt[6], tt[7], tt[2], tt[4], tt[8], tt[9], tt[3], tt[10]); }
+#endif
+        }
+        hipFree(B.S); hipFree(B.bs); hipFree(d_b0); hipFree(B.scal); hipFree(B.ctl);
+    }
+    hipError_t e = hipGetLastError();
+    printf("last error: %s, mismatches: %d\n", hipGetErrorString(e), bad);
+    return bad != 0;
+}

@@ -392,6 +392,371 @@ __global__ __launch_bounds__(1024) void k_ba_chol_t(BaDev B) {
     if (tid == 0) B.scal[3] = s_ok ? 1.0 : 0.0;
 }
 
+// ---- k_ba_chol16: the D <= 192 Cholesky + solve, 16-column panels ---------------------------------------------
+// Same augmented-matrix scheme as k_ba_chol_t, re-blocked so that the dependent chain is short:
+//  * panel = 16 columns = one DPP row.  The diagonal block is factored by ONE wave entirely in registers: lane r
+//    (0..15) keeps row r; the pivot and the multipliers of column j reach the other lanes through the DP-ALU DPP
+//    row broadcast (v_mov_b64_dpp / v_fmac_f64_dpp row_newbcast:j), i.e. ONE instruction per rank-1 term, no
+//    LDS and no SGPR hop; the pivot uses v_rsq_f64 + 2 Newton steps (1/sqrt(d) directly, sqrt(d) = d * rsqrt(d))
+//    instead of an IEEE sqrt followed by an IEEE divide;
+//  * panel solve: one lane per row below the block, the factored block arrives as software-pipelined LDS broadcasts;
+//  * trailing update: 16x16 tiles, K = 16 -> 4 x v_mfma_f64_16x16x4_f64 per tile, spread over the waves;
+//  * backward substitution: wave 0 solves the 16x16 triangle in registers (DPP again), the other waves push x_p
+//    into the rows above -- one barrier per panel.
+#define CH_NB 16
+#define TRI32(r, c) ((int)(r) * ((int)(r) + 1) / 2 + (int)(c))   // packed lower triangle, 32-bit index math (< 2^15 entries)
+#define CH_THREADS 512
+__device__ __forceinline__ double ba_readlane(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// 1/sqrt(d) = y (1 + q):  y = v_rsq_f64 (2^-24), q = e (1/2 + 3/8 e), e = 1 - d y^2 -- one cubic step, 2^-52.7
+// (tools/chol_bench.hip probes both)
+__device__ __forceinline__ void ba_rsqrt_parts(double d, double& y, double& q) {
+#pragma clang fp contract(fast)
+    y = __builtin_amdgcn_rsq(d);
+    const double e = 1.0 - (d * y) * y;
+    q = e * (0.5 + 0.375 * e);
+}
+// DP-ALU DPP helpers.  A VGPR written by a VALU op needs 2 wait states before a DPP op reads it; the compiler cannot
+// see inside the asm, so the producers below carry the s_nop themselves.
+template <int K> __device__ __forceinline__ double ch_bcast(double v) {           // value of lane K of each 16-lane row
+    double r;
+    asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=&v"(r) : "v"(v), "n"(K));
+    return r;
+}
+__device__ __forceinline__ double ch_mul_for_dpp(double a, double b) {             // a * b, safe to feed a DPP read next
+    double r;
+    asm("v_mul_f64 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double ch_fma_for_dpp(double a, double b, double c) {      // a * b + c, safe to feed a DPP read next
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+template <int K> __device__ __forceinline__ double ch_mul_bcast(double bsrc, double m) {       // bsrc[lane K] * m
+    double acc = 0.0;
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(m), "n"(K));
+    return acc;
+}
+template <int K> __device__ __forceinline__ void ch_fnma_bcast(double& acc, double bsrc, double m) {   // acc -= bsrc[lane K] * m
+    asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(m), "n"(K));
+}
+template <int J, int K> struct ChRank1 {
+    static __device__ __forceinline__ void run(double (&a)[CH_NB], double l) { ch_fnma_bcast<K>(a[K], l, l); ChRank1<J, K + 1>::run(a, l); }
+};
+template <int J> struct ChRank1<J, CH_NB> { static __device__ __forceinline__ void run(double (&)[CH_NB], double) {} };
+template <int J> struct ChCol {                                 // column J of the in-register block factorisation
+    // No divergent branch may sit between the DPP ops (an EXEC write needs 5 wait states before the next DPP and the
+    // broadcast source lanes must be active): selects only, and the pivot inverse goes to LDS from every lane alike.
+    static __device__ __forceinline__ void run(double (&a)[CH_NB], double* s_pinv, bool& ok, int r) {
+        const double d = ch_bcast<J>(a[J]);
+        ok = ok && (d > 0.0);
+        double y, q;
+        ba_rsqrt_parts(d, y, q);
+        const double l0 = (r >= J ? a[J] : 0.0) * y;            // off the dependent chain (parallel to e, q)
+        const double l = ch_fma_for_dpp(l0, q, l0);             // a * rsqrt(d); lane J: d * rsqrt(d) = sqrt(d)
+        s_pinv[J] = fma(y, q, y);
+        a[J] = l;
+        ChRank1<J, J + 1>::run(a, l);
+        ChCol<J + 1>::run(a, s_pinv, ok, r);
+    }
+};
+template <> struct ChCol<CH_NB> { static __device__ __forceinline__ void run(double (&)[CH_NB], double*, bool&, int) {} };
+__device__ __forceinline__ void ch_exec_settle(double& v) { asm("s_nop 4" : "+v"(v)); }   // EXEC write -> DPP: 5 wait states
+template <int K> struct ChBack {                                // step K of the in-register back substitution
+    static __device__ __forceinline__ void run(const double (&col)[CH_NB], double& y, double inv, double& xf, int r) {
+        const double xv = ch_mul_for_dpp(y, inv);
+        xf = r == K ? xv : xf;
+        ch_fnma_bcast<K>(y, xv, col[K]);                        // col[K] = 0 for lanes >= K
+        ChBack<K - 1>::run(col, y, inv, xf, r);
+    }
+};
+template <> struct ChBack<-1> { static __device__ __forceinline__ void run(const double (&)[CH_NB], double&, double, double&, int) {} };
+template <int K> struct ChFwd {                                 // step K of the in-register forward substitution (rhs row only)
+    static __device__ __forceinline__ void run(const double (&Lr)[CH_NB], double& bc, double inv, double& yf, int r) {
+        const double yv = ch_mul_for_dpp(bc, inv);
+        yf = r == K ? yv : yf;
+        ch_fnma_bcast<K>(bc, yv, Lr[K]);                        // Lr[K] = 0 for lanes <= K
+        ChFwd<K + 1>::run(Lr, bc, inv, yf, r);
+    }
+};
+template <> struct ChFwd<CH_NB> { static __device__ __forceinline__ void run(const double (&)[CH_NB], double&, double, double&, int) {} };
+
+template <int K> struct ChPush {                               // y -= sum_k x[lane k] * Lx[k]: x_p pushed into the panel above, in registers
+    static __device__ __forceinline__ void run(const double (&Lx)[CH_NB], double& y, double x) { ch_fnma_bcast<K>(y, x, Lx[K]); ChPush<K + 1>::run(Lx, y, x); }
+};
+template <> struct ChPush<CH_NB> { static __device__ __forceinline__ void run(const double (&)[CH_NB], double&, double) {} };
+
+template <int K, int C> struct ChSolveRow {                     // x[C] -= L[C][K] * x[K], L[C][K] = lane C's Lk[K]
+    static __device__ __forceinline__ void run(double (&x)[CH_NB], const double (&Lk)[CH_NB]) { ch_fnma_bcast<C>(x[C], Lk[K], x[K]); ChSolveRow<K, C + 1>::run(x, Lk); }
+};
+template <int K> struct ChSolveRow<K, CH_NB> { static __device__ __forceinline__ void run(double (&)[CH_NB], const double (&)[CH_NB]) {} };
+template <int K> struct ChSolve {                               // panel solve of one matrix row per lane, the block row k in lanes 0..15 of each DPP row
+    static __device__ __forceinline__ void run(double (&x)[CH_NB], const double (&Lk)[CH_NB]) {
+        x[K] = ch_mul_bcast<K>(Lk[K], x[K]);                    // diagonal slot of the block copy holds 1 / L[K][K]
+        ChSolveRow<K, K + 1>::run(x, Lk);
+        ChSolve<K + 1>::run(x, Lk);
+    }
+};
+template <> struct ChSolve<CH_NB> { static __device__ __forceinline__ void run(double (&)[CH_NB], const double (&)[CH_NB]) {} };
+
+// One wave factors the 16x16 block at (j0, j0) of the packed triangle s_L in registers and leaves: the block's L in
+// s_L, its transposed copy (1/L[k][k] on the diagonal) in s_dg, the pivot inverses in s_inv.  Returns false on a
+// non-positive pivot.  `a` arrives loaded (row r16 of the block in every 16-lane DPP row, identity padding).
+__device__ __forceinline__ bool ch_factor_block(double (&a)[CH_NB], double* s_L, double* s_dg, double* s_inv, double* s_pinv, int j0, int nb, int lane) {
+    const int r16 = lane & 15;
+    bool ok = true;
+    ch_exec_settle(a[0]);
+    ChCol<0>::run(a, s_pinv, ok, r16);
+    const double myinv = s_pinv[r16];
+    if (lane < CH_NB) {                                         // transposed copy: column k of the block is contiguous
+#pragma unroll
+        for (int c = 0; c < CH_NB; ++c) s_dg[c * CH_NB + lane] = c < lane ? a[c] : (c == lane ? myinv : 0.0);
+    }
+    if (lane < nb) {
+        double* wrow = s_L + TRI32(j0 + lane, j0);
+#pragma unroll
+        for (int c = 0; c < CH_NB; ++c) if (c <= lane) wrow[c] = a[c];
+        s_inv[j0 + lane] = myinv;
+    }
+    return ok;
+}
+
+__global__ __launch_bounds__(CH_THREADS) void k_ba_chol16(BaDev B) {
+    if (B.ctl->finished) return;
+    extern __shared__ double s_mem[];
+    const int D = B.D, DA = D + 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15;
+    const double* const A = B.S;
+    double* const s_dg = s_mem;                                 // [16][16] factored diagonal block, transposed, 1/L[k][k] on the diagonal
+    double* const s_L = s_mem + CH_NB * CH_NB;                  // packed lower triangle of [S b; b^T 0]
+    double* const s_b = s_L + TRI32(DA, 0);                       // y, then x
+    double* const s_inv = s_b + D;                              // 1 / L[j][j]
+    __shared__ int s_ok;
+    __shared__ double s_pinv[CH_NB];                            // 1 / pivot of the block being factored
+#ifdef CH_STAMPS
+    long long t_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tl_ = clock64();
+#define CH_STAMP(i) { const long long n_ = clock64(); t_[i] += n_ - tl_; tl_ = n_; }
+#else
+#define CH_STAMP(i)
+#endif
+    if (tid == 0) {
+        s_ok = 1;
+        BaCtl* c = B.ctl;                               // take over the fresh linearisation, clear the trial sums
+        if (c->need_lin) {
+            c->cur = B.scal[0];
+            if (c->first) { c->lambda = 1e-5 * B.scal[4]; c->ni = 2; c->first = 0; }
+            c->need_lin = 0;
+        }
+        B.scal[1] = 0; B.scal[2] = 0; B.scal[7] = 0;
+    }
+    // ---- load.  Wave 0 takes the first diagonal block straight from global memory into registers and factors it
+    // while the other waves bring the rest of the lower triangle (rows >= 16) and the rhs row into LDS.
+    if (wave == 0) {
+        const int nb = min(CH_NB, D);
+        double a[CH_NB];
+        // loads are unconditional (clamped in range) and masked afterwards: a predicated load becomes a branch with
+        // its own wait, 16 of them in a row serialise the memory latency
+        const bool mine = r16 < nb;
+        const double* row = A + (size_t)(mine ? r16 : 0) * D;
+#pragma unroll
+        for (int c = 0; c < CH_NB; ++c) a[c] = row[min(c, nb - 1)];
+#pragma unroll
+        for (int c = 0; c < CH_NB; ++c) a[c] = (mine && c <= r16) ? a[c] : (c == r16 ? 1.0 : 0.0);
+        if (!ch_factor_block(a, s_L, s_dg, s_inv, s_pinv, 0, nb, lane) && lane == 0) s_ok = 0;
+    } else {
+        // two columns per lane (rows are 16-byte aligned: D is even), 12 rows in flight per wave
+#pragma unroll 12
+        for (int r = CH_NB + wave - 1; r < D; r += CH_THREADS / 64 - 1) {
+            const double2* src = reinterpret_cast<const double2*>(A + (size_t)r * D);
+            double* dst = s_L + TRI32(r, 0);
+            const int c0 = 2 * lane, c1 = 2 * lane + 128, last = (D >> 1) - 1;
+            const double2 v0 = src[min(lane, last)], v1 = src[min(lane + 64, last)];        // unconditional, clamped to the row
+            if (c0 <= r) dst[c0] = v0.x;
+            if (c0 + 1 <= r) dst[c0 + 1] = v0.y;
+            if (c1 <= r) dst[c1] = v1.x;
+            if (c1 + 1 <= r) dst[c1 + 1] = v1.y;
+        }
+        for (int i = tid - 64; i < D; i += CH_THREADS - 64) s_L[TRI32(D, i)] = B.bs[i];
+        if (tid == 64) s_L[TRI32(D, D)] = 0.0;
+    }
+    __syncthreads();
+    CH_STAMP(0)
+    // one 16x16 tile of the trailing update S22 -= L21 L21^T on the f64 matrix cores (K = 16: 4 MFMAs).  Lane l holds
+    // A[l&15][l>>4], B[l>>4][l&15]; D: col = l&15, row = (l>>4) + 4 reg.  Rows past the end are clamped (their
+    // products land in entries that are never written back).
+    auto tile = [&](int tr, int tc, int base, int j0, int m) {
+        const int ra = min(16 * tr + r16, m - 1), rb = min(16 * tc + r16, m - 1), kq = lane >> 4;
+        const double* pa = s_L + TRI32(base + ra, j0) + kq;
+        const double* pb = s_L + TRI32(base + rb, j0) + kq;
+        const double a0 = pa[0], a1 = pa[4], a2 = pa[8], a3 = pa[12], b0 = pb[0], b1 = pb[4], b2 = pb[8], b3 = pb[12];
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, acc, 0, 0, 0);
+        const int col = 16 * tc + r16;
+        double* pc[4]; double cv[4]; bool st[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rw = 16 * tr + (lane >> 4) + 4 * q;
+            st[q] = rw < m && col <= rw;
+            pc[q] = s_L + TRI32(base + min(rw, m - 1), base + min(col, min(rw, m - 1)));   // clamped: the load is unconditional
+            cv[q] = *pc[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (st[q]) *pc[q] = cv[q] - acc[q];
+    };
+    for (int j0 = 0; j0 < D; j0 += CH_NB) {
+        const int nb = min(CH_NB, D - j0);
+        if (!s_ok) break;
+        const int base = j0 + nb, m = DA - base;                // rows below the panel, incl. the rhs row
+        if (nb == CH_NB) {                                      // ---- panel solve, one lane per row
+            if (wave * 64 < m) {
+                // right-looking within the row: x[c] -= L[c][k] x[k] as soon as x[k] is final.  Lane r16 of every DPP
+                // row keeps column r16 of the transposed block copy (16 LDS reads per lane in total), L[c][k] reaches
+                // the FMA as the row broadcast of lane c: one v_fmac_f64_dpp per term, no LDS broadcast traffic.
+                // Every lane of the wave stays active (DPP sources); rows past the end are clamped and not stored.
+                double* prow = s_L + TRI32(base + min(tid, m - 1), j0);
+                double x[CH_NB], Lk[CH_NB];
+#pragma unroll
+                for (int k = 0; k < CH_NB; ++k) Lk[k] = s_dg[k * CH_NB + r16];
+#pragma unroll
+                for (int c = 0; c < CH_NB; ++c) x[c] = prow[c];
+                ch_exec_settle(x[0]);
+                ChSolve<0>::run(x, Lk);
+                if (tid < m) {
+#pragma unroll
+                    for (int c = 0; c < CH_NB; ++c) prow[c] = x[c];
+                }
+            }
+        } else if (wave == 0) {
+            // partial panel = the last one: only the rhs row is left below it.  Lane c keeps b_c and row c of the
+            // block; y_k travels by DPP broadcast.
+            double* prow = s_L + TRI32(D, j0);
+            double Lr[CH_NB];
+#pragma unroll
+            for (int k = 0; k < CH_NB; ++k) Lr[k] = s_dg[k * CH_NB + r16];
+#pragma unroll
+            for (int k = 0; k < CH_NB; ++k) Lr[k] = k < r16 ? Lr[k] : 0.0;
+            double bc = prow[min(r16, nb - 1)], yf = 0.0;
+            bc = r16 < nb ? bc : 0.0;
+            const double inv = s_dg[r16 * CH_NB + r16];
+            ch_exec_settle(bc);
+            ChFwd<0>::run(Lr, bc, inv, yf, r16);
+            if (lane < nb) prow[lane] = yf;
+        }
+        __syncthreads();
+        CH_STAMP(1)
+        if (base >= D) break;                                   // only the rhs row was left: nothing to update
+        // ---- trailing update with look-ahead: wave 0 updates the tile holding the next diagonal block and factors it
+        // while the other waves update the rest of the trailing matrix.
+        const int T = (m + 15) >> 4, ntile = T * (T + 1) / 2;
+        if (wave == 0) {
+            tile(0, 0, base, j0, m);
+            CH_STAMP(5)
+            const int nb2 = min(CH_NB, D - base);
+            double a[CH_NB];
+            const bool mine = r16 < nb2;
+            const int rl = mine ? r16 : 0;
+            const double* row = s_L + TRI32(base + rl, base);
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) a[c] = row[min(c, rl)];
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) a[c] = (mine && c <= r16) ? a[c] : (c == r16 ? 1.0 : 0.0);
+            CH_STAMP(6)
+            if (!ch_factor_block(a, s_L, s_dg, s_inv, s_pinv, base, nb2, lane) && lane == 0) s_ok = 0;
+            CH_STAMP(7)
+        } else {
+            int tr = 0, tc = wave;                              // tiles 1.. in (tr, tc <= tr) order, 7 waves
+            while (tc > tr) { tc -= tr + 1; ++tr; }
+            for (int t = wave; t < ntile; t += CH_THREADS / 64 - 1) {
+                tile(tr, tc, base, j0, m);
+                tc += CH_THREADS / 64 - 1;
+                while (tc > tr) { tc -= tr + 1; ++tr; }
+            }
+        }
+        __syncthreads();
+        CH_STAMP(2)
+    }
+    CH_STAMP(3)
+    if (s_ok) {
+        for (int i = tid; i < D; i += CH_THREADS) s_b[i] = s_L[TRI32(D, i)];    // y = L^-1 b (last row of the augmented factor)
+        __syncthreads();
+        // ---- L^T x = y, panel by panel from the bottom.  Wave 0 owns the dependent chain: it solves the 16x16 triangle
+        // in registers, pushes x_p into the panel above by DPP (no LDS round trip) and goes on; the other waves push x_p
+        // into the rows further up.  One barrier per panel.
+        const int np = (D + CH_NB - 1) / CH_NB;
+        double xf = 0.0;                                        // wave 0, lane k (of every DPP row): x[j0 + k]
+        if (wave == 0) {
+            const int j0 = CH_NB * (np - 1), nb = D - j0;
+            double col[CH_NB];                                  // lane j: L[j0+k][j0+j], k > j
+#pragma unroll
+            for (int k = 0; k < CH_NB; ++k) col[k] = s_L[TRI32(j0 + min(max(k, r16), nb - 1), j0 + min(r16, nb - 1))];
+#pragma unroll
+            for (int k = 0; k < CH_NB; ++k) col[k] = (r16 < nb && k < nb && k > r16) ? col[k] : 0.0;
+            double y = s_b[j0 + min(r16, nb - 1)];
+            double inv = s_inv[j0 + min(r16, nb - 1)];
+            y = r16 < nb ? y : 0.0; inv = r16 < nb ? inv : 0.0;
+            ch_exec_settle(y);
+            ChBack<CH_NB - 1>::run(col, y, inv, xf, r16);
+            if (lane < nb) s_b[j0 + lane] = xf;
+        }
+        __syncthreads();
+        for (int p = np - 1; p >= 1; --p) {
+            const int j0 = CH_NB * p, nb = min(CH_NB, D - j0), jn = j0 - CH_NB;
+            if (wave == 0) {
+                double Lx[CH_NB], col[CH_NB];
+#pragma unroll
+                for (int k = 0; k < CH_NB; ++k) Lx[k] = s_L[TRI32(j0 + min(k, nb - 1), jn) + r16];
+#pragma unroll
+                for (int k = 0; k < CH_NB; ++k) col[k] = s_L[TRI32(jn + k, jn) + min(r16, k)];      // uniform row base + lane offset, masked below
+#pragma unroll
+                for (int k = 0; k < CH_NB; ++k) { Lx[k] = k < nb ? Lx[k] : 0.0; col[k] = k > r16 ? col[k] : 0.0; }
+                double y = s_b[jn + r16];
+                const double inv = s_inv[jn + r16];
+                CH_STAMP(4)
+                const double xp = ch_mul_for_dpp(xf, 1.0);
+                ch_exec_settle(y);
+                ChPush<0>::run(Lx, y, xp);
+                xf = 0.0;
+                ChBack<CH_NB - 1>::run(col, y, inv, xf, r16);
+                if (lane < CH_NB) s_b[jn + lane] = xf;
+                CH_STAMP(8)
+            } else {
+                const int r = tid - 64;
+                if (r < jn) {
+#pragma clang fp contract(fast)
+                    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+                    if (nb == CH_NB) {
+#pragma unroll
+                        for (int k = 0; k < CH_NB; k += 4) {
+                            s0 += s_L[TRI32(j0 + k, r)] * s_b[j0 + k];
+                            s1 += s_L[TRI32(j0 + k + 1, r)] * s_b[j0 + k + 1];
+                            s2 += s_L[TRI32(j0 + k + 2, r)] * s_b[j0 + k + 2];
+                            s3 += s_L[TRI32(j0 + k + 3, r)] * s_b[j0 + k + 3];
+                        }
+                    } else {
+                        for (int k = 0; k + 1 < nb; k += 2) {   // nb is even
+                            s0 += s_L[TRI32(j0 + k, r)] * s_b[j0 + k];
+                            s1 += s_L[TRI32(j0 + k + 1, r)] * s_b[j0 + k + 1];
+                        }
+                    }
+                    s_b[r] -= (s0 + s1) + (s2 + s3);
+                }
+            }
+            __syncthreads();
+            CH_STAMP(9)
+        }
+        for (int i = tid; i < D; i += CH_THREADS) B.bs[i] = s_b[i];
+    }
+    if (tid == 0) B.scal[3] = s_ok ? 1.0 : 0.0;
+#ifdef CH_STAMPS
+    CH_STAMP(10)
+    if (tid == 0) for (int i = 0; i < 12; ++i) B.dl[i] = (double)t_[i];
+#endif
+}
+
 __device__ __forceinline__ void ba_backsub_body(const BaDev& B, double lambda, int blk, const double* pts_c, double* pts_t) {
     const int k = blk * blockDim.x + threadIdx.x;
     double sc = 0, mx = 0;
@@ -549,7 +914,8 @@ __global__ void k_ba_cull(BaCam cam, BaDev B, int stage, double th) {
 int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     hipStream_t st = c->stream;
     { static bool attr = false; if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-      HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)); attr = true; } }
+      HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol16, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)); attr = true; } }
     const int np = in->n_poses, nf = in->n_free, nx = in->n_points, ne = in->n_edges, D = 6 * nf;
     if (((size_t)7 * (D + 1) + 2 * (size_t)D) * sizeof(double) > 158 * 1024) return VO_E_UNSUPPORTED;      // > ~370 free poses
     out->lm_iters = 0; out->chi2_initial = 0; out->chi2_final = 0;
@@ -673,7 +1039,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
                 { ProfScope ps(c, "k_ba_init_S"); hipLaunchKernelGGL(k_ba_init_S, dim3((std::max(D * D, nx) + 255) / 256), blk, 0, st, B); }
                 if (nblk) { ProfScope ps(c, "k_ba_schur_blocks"); hipLaunchKernelGGL(k_ba_schur_blocks, dim3(nblk), blk, 0, st, B); }
                 { ProfScope ps(c, "k_ba_chol");
-                  if (D <= 192) hipLaunchKernelGGL(k_ba_chol_t<true>, dim3(1), dim3(1024), sizeof(double) * ((size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D), st, B);
+                  if (D <= 192) hipLaunchKernelGGL(k_ba_chol16, dim3(1), dim3(CH_THREADS), sizeof(double) * (CH_NB * CH_NB + (size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D), st, B);
                   else hipLaunchKernelGGL(k_ba_chol_t<false>, dim3(1), dim3(1024), sizeof(double) * ((size_t)7 * (D + 1) + 2 * (size_t)D), st, B); }
                 { ProfScope ps(c, "k_ba_update"); hipLaunchKernelGGL(k_ba_update, dim3(gP.x + gJ.x), blk, 0, st, B, (int)gP.x); }
                 { ProfScope ps(c, "k_ba_chi_control"); hipLaunchKernelGGL(k_ba_chi_control, gE, blk, 0, st, cam, B, robust, in->huber_delta); }
