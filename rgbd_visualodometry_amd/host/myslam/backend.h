@@ -35,8 +35,8 @@ public:
     const Stats& GetStats() const { return stats_; }
 private:
     struct Job {
-        std::vector<Frame::Ptr> poseFrames; int nFree = 0;
-        std::vector<Mappoint::Ptr> points;
+        std::vector<Frame*> poseFrames; int nFree = 0;          // keyframes and map points are never removed from the map:
+        std::vector<Mappoint*> points;                          // plain pointers stay valid for the job's lifetime
         std::vector<int32_t> edgePose, edgePoint; std::vector<float> edgeUv;
         std::vector<double> poses, pts, posesOut, ptsOut; std::vector<uint8_t> flags;
         size_t frameIndex = 0; int rc = 0; double solveMs = 0; bool done = false;
@@ -48,6 +48,7 @@ private:
     int device_ = 0, lag_ = 0;
     size_t frameIndex_ = 0;
     uint64_t buildStamp_ = 0;
+    size_t lastEdges_ = 0, lastPoints_ = 0;          // reserve hints for the next graph
     std::unique_ptr<Job> job_;
     std::thread worker_; std::mutex mu_; std::condition_variable cv_; bool quit_ = false, hasWork_ = false;
     Stats stats_;

@@ -26,12 +26,28 @@ public:
     Vector3d GetCamCenter() const { return T_c_w_.inverse().translation(); }
     bool IsCouldObserveMappoint(const Mappoint::Ptr& mpt);
     void AddObservedMappoint(const size_t mappointId, const Point2f pixelPos);
+    void AddObservedMappoint(Mappoint* mappoint, const Point2f pixelPos);      // same, without the id lookup
     void RemoveObservedMappoint(const size_t mappointId);
-    std::unordered_set<size_t> GetObservedMappointIds() { std::unique_lock<std::mutex> lck(observationMutex_); return observedMappointIds_; }
-    bool IsObservedMappoint(const size_t id) { std::unique_lock<std::mutex> lck(observationMutex_); return observedMappointIds_.count(id) != 0; }
+    // The observation set of the reference (frame.h:82, an unordered_set of ids) is stored as one flat, insertion-
+    // ordered list: iteration is deterministic and hash-free; a removed observation stays as a dead entry.
+    struct ObservedEntry { size_t id; Mappoint* mappoint; bool alive; };
+    const std::vector<ObservedEntry>& Observed() const { return observed_; }
+    std::unordered_set<size_t> GetObservedMappointIds() {
+        std::unique_lock<std::mutex> lck(observationMutex_);
+        std::unordered_set<size_t> ids;
+        for (const ObservedEntry& e : observed_) if (e.alive) ids.insert(e.id);
+        return ids;
+    }
+    bool IsObservedMappoint(const size_t id) {
+        std::unique_lock<std::mutex> lck(observationMutex_);
+        for (size_t i = observed_.size(); i-- > 0;) if (observed_[i].id == id) return observed_[i].alive;
+        return false;
+    }
     void UpdateCovisibleKeyframeWeight(const size_t id, const int weight);
-    // insertion-ordered view for deterministic single-threaded iteration (entries may be stale: check IsObservedMappoint)
-    const std::vector<size_t>& ObservedOrder() const { return observedOrder_; }
+    // Between Begin and End the covisibility weights raised by AddObservedMappoint are counted per partner keyframe
+    // and written once (same final weights and active sets as one update per observation).
+    void BeginCovisibilityBatch() { covisBatch_ = true; }
+    void EndCovisibilityBatch();
     std::unordered_set<size_t> GetCovisibleKeyframes() { std::unique_lock<std::mutex> lck(observationMutex_); return activeCovisibleKeyframes_; }
 
     int slot_ = -1;                 // vo_ctx frame slot holding this frame's ORB results (-1: none)
@@ -44,8 +60,9 @@ private:
     std::mutex poseMutex_;
     SE3 T_c_w_;
     std::mutex observationMutex_;
-    std::unordered_set<size_t> observedMappointIds_;
-    std::vector<size_t> observedOrder_;
+    std::vector<ObservedEntry> observed_;
+    bool covisBatch_ = false; int covisAcc_ = 0;            // batch state (this frame) / pending count (partner frame)
+    std::vector<Frame*> covisTouched_;
     CovisibleKeyframeIdToWeight allCovisibleKeyframeIdToWeight_;
     std::unordered_set<size_t> activeCovisibleKeyframes_;    // >= 15 shared map points
     Frame(const size_t id, const double timestamp, const Camera::Ptr camera, const Mat color, const Mat depth);

@@ -52,12 +52,12 @@ private:
     vo_track_params         trackParams_;
     std::vector<KeyPoint>   keypointsCurr_;
     std::vector<Descriptor> descriptorsCurr_;
-    std::vector<Mappoint::Ptr> activeList_;                 // device tracking map, in matching order
+    std::vector<Mappoint*> activeList_;                     // device tracking map, in matching order (owned by the MapManager)
     std::vector<int> activeIndexOfSlot_;
     // flannMatchedMptKptMap_ of the reference (frontend.h:73) as parallel arrays in match order
-    std::vector<Mappoint::Ptr> flannMatchedMpt_; std::vector<int> flannMatchedKp_; std::vector<char> flannMatchedLm_;
+    std::vector<Mappoint*> flannMatchedMpt_; std::vector<int> flannMatchedKp_; std::vector<char> flannMatchedLm_;
     KeyPointSet flannMatchedKptSet_;
-    std::vector<Mappoint::Ptr> pnpMatchedMpt_;              // pnpMatchedMptSet_ (frontend.h:76), id order
+    std::vector<Mappoint*> pnpMatchedMpt_;                  // pnpMatchedMptSet_ (frontend.h:76), id order
     std::vector<int> pnpMatchedMptKp_;
     KeyPointSet pnpMatchedKptSet_;
     std::vector<Mappoint::Ptr> newMappoints_;
@@ -74,6 +74,12 @@ private:
     int trackBatch_ = 1, framesSinceKf_ = 0; double lastMotion_ = 0;
     Stats stats_;
     std::vector<vo_keypoint> kpBuf_; std::vector<uint8_t> descBuf_; std::vector<vo_match> matchBuf_;
+    // The per-frame containers above (keypointsCurr_, flann*/pnp* lists) are only read on keyframes and by the viewer:
+    // they are materialised on demand from the raw device results of the current frame.
+    int nKeypointsCurr_ = 0; bool keypointsBuilt_ = false;
+    const vo_match* curMatches_ = nullptr; int nCurMatches_ = 0; bool matchListsBuilt_ = false;
+    void EnsureKeypoints();
+    void EnsureMatchLists();
     std::vector<int32_t> upIdx_; std::vector<double> upXyz_, upNrm_; std::vector<uint8_t> upDesc_, upFlags_;
 
     void Init(int device, int width, int height, int max_frames);

@@ -33,7 +33,7 @@ public:
     std::vector<Mappoint*> TakeDirty() { std::vector<Mappoint*> d; d.swap(dirty_); return d; }
     // all map points in insertion (= id) order, and the de-duplicated local map of a keyframe as vectors
     const std::vector<Mappoint::Ptr>& AllMappointsOrdered() const { return order_; }
-    std::vector<Mappoint::Ptr> CollectMappointsAroundKeyframe(const Frame::Ptr& keyframe);
+    std::vector<Mappoint*> CollectMappointsAroundKeyframe(const Frame::Ptr& keyframe);
 
 private:
     std::mutex dataMutex_;

@@ -28,8 +28,13 @@ public:
     void AddObservedByKeyframe(const size_t keyframeId, const Point2f posInPixel, const Vector3d cameraCenter, Frame* keyframe = nullptr);
     const std::vector<Observation>& ObservationList() const { return obsList_; }     // insertion (= keyframe id) order; single-threaded callers
     void RemoveObservedByKeyframe(const size_t keyframeId);
-    const ObservedByKeyframeIdtoPixelPos& ObservationsNoCopy() const { return observedByKeyframeMap_; }   // single-threaded callers only
-    ObservedByKeyframeIdtoPixelPos GetObservedByKeyframesMap() { std::unique_lock<std::mutex> lock(observationMutex_); return observedByKeyframeMap_; }
+    // the reference's container (mappoint.h:71), assembled on request: the flat observation list is the storage
+    ObservedByKeyframeIdtoPixelPos GetObservedByKeyframesMap() {
+        std::unique_lock<std::mutex> lock(observationMutex_);
+        ObservedByKeyframeIdtoPixelPos m;
+        for (const Observation& o : obsList_) m[o.keyframeId] = o.pixel;
+        return m;
+    }
 
     // device-map bookkeeping (slot in the vo_ctx map, set by MapManager::InsertMappoint)
     int  slot_ = -1;
@@ -45,7 +50,6 @@ private:
     std::mutex posMutex_;
     Vector3d pos_;
     std::mutex observationMutex_;
-    ObservedByKeyframeIdtoPixelPos observedByKeyframeMap_;
     std::vector<Observation> obsList_;
     Mappoint(const size_t id, const Vector3d position, const Descriptor& descriptor);
 };

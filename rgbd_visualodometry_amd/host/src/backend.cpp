@@ -7,6 +7,7 @@
 #include <stdexcept>
 
 #include "myslam/config.h"
+#include "myslam/util.h"
 
 namespace myslam {
 
@@ -89,6 +90,7 @@ void Backend::OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr) {
 // Flatten: free poses = covisible keyframes + current (backend.cpp:36-59); points = non-outlier map points
 // they observe (:62-81); one edge per observation, observers outside the free set are fixed (:88-135).
 void Backend::Build(Job& j, const Frame::Ptr& kf) {
+    VO_SCOPE("ba.build");
     MapManager& map = MapManager::GetInstance();
     const uint64_t stamp = ++buildStamp_;            // index scratch lives in the frames / map points: no hash maps
     auto covis = kf->GetCovisibleKeyframes();
@@ -99,32 +101,33 @@ void Backend::Build(Job& j, const Frame::Ptr& kf) {
         auto f = map.GetKeyframe(id);
         if (f == nullptr) continue;
         f->baStamp_ = stamp; f->baIndex_ = (int)j.poseFrames.size();
-        j.poseFrames.push_back(f);
+        j.poseFrames.push_back(f.get());
     }
     j.nFree = (int)j.poseFrames.size();
+    j.points.reserve(lastPoints_ + lastPoints_ / 4 + 1024);
     for (int p = 0; p < j.nFree; ++p) {
-        Frame& f = *j.poseFrames[p];
-        for (size_t mpId : f.ObservedOrder()) {          // insertion order: deterministic without sorting
-            Mappoint* mp = map.FindMappoint(mpId);
-            if (mp == nullptr || mp->baStamp_ == stamp || mp->outlier_ || !f.IsObservedMappoint(mpId)) continue;
+        for (const Frame::ObservedEntry& e : j.poseFrames[p]->Observed()) {        // insertion order: deterministic without sorting
+            Mappoint* mp = e.mappoint;
+            if (!e.alive || mp->baStamp_ == stamp || mp->outlier_) continue;
             mp->baStamp_ = stamp; mp->baIndex_ = (int)j.points.size();
-            j.points.push_back(map.GetMappoint(mpId));
+            j.points.push_back(mp);
         }
     }
+    const size_t hint = lastEdges_ + lastEdges_ / 4 + 4096;
+    j.edgePose.reserve(hint); j.edgePoint.reserve(hint); j.edgeUv.reserve(2 * hint);
     for (size_t k = 0; k < j.points.size(); ++k) {
         for (const Mappoint::Observation& o : j.points[k]->ObservationList()) {     // keyframe-id order
             Frame* f = o.keyframe;
             if (f == nullptr) continue;
             if (f->baStamp_ != stamp) {                                             // observer outside the free set: fixed pose
-                auto fp = map.GetKeyframe(o.keyframeId);
-                if (fp == nullptr) continue;
                 f->baStamp_ = stamp; f->baIndex_ = (int)j.poseFrames.size();
-                j.poseFrames.push_back(fp);
+                j.poseFrames.push_back(f);
             }
             j.edgePose.push_back(f->baIndex_); j.edgePoint.push_back((int)k);
             j.edgeUv.push_back(o.pixel.x); j.edgeUv.push_back(o.pixel.y);
         }
     }
+    lastEdges_ = j.edgePose.size(); lastPoints_ = j.points.size();
     j.poses.resize(12 * j.poseFrames.size()); j.pts.resize(3 * j.points.size());
     for (size_t p = 0; p < j.poseFrames.size(); ++p) j.poseFrames[p]->GetPose().to12(&j.poses[12 * p]);
     for (size_t k = 0; k < j.points.size(); ++k) { Vector3d x = j.points[k]->GetPosition(); j.pts[3 * k] = x[0]; j.pts[3 * k + 1] = x[1]; j.pts[3 * k + 2] = x[2]; }
@@ -145,13 +148,16 @@ void Backend::Solve(Job& j, vo_ctx* ctx) {
 }
 
 void Backend::Apply(Job& j) {
+    VO_SCOPE("ba.apply");
     int outlierCnt = 0;
     for (size_t e = 0; e < j.edgePose.size(); ++e) {                          // backend.cpp:144-172
+        if (!(j.flags[e] & 3)) continue;
         Frame& f = *j.poseFrames[j.edgePose[e]];
         Mappoint& mp = *j.points[j.edgePoint[e]];
-        if (j.flags[e] & 3) { if (f.IsObservedMappoint(mp.GetId())) f.RemoveObservedMappoint(mp.GetId()); ++outlierCnt; }
-        mp.optimized_ = true;
+        if (f.IsObservedMappoint(mp.GetId())) f.RemoveObservedMappoint(mp.GetId());
+        ++outlierCnt;
     }
+    for (Mappoint* mp : j.points) mp->optimized_ = true;                      // every point of the graph has at least one edge
     for (int p = 0; p < j.nFree; ++p) j.poseFrames[p]->SetPose(SE3::from12(&j.posesOut[12 * (size_t)p]));       // backend.cpp:183-187
     // backend.cpp:188-194.  The optimised positions are already one flat array: they go to the tracker's device map
     // in a single vo_map_upsert (positions only) instead of through the per-point dirty list.

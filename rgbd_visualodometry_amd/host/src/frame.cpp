@@ -31,35 +31,50 @@ bool Frame::IsCouldObserveMappoint(const Mappoint::Ptr& mpt) {
 }
 
 void Frame::AddObservedMappoint(const size_t mappointId, const Point2f pixelPos) {
-    std::unique_lock<std::mutex> lck(observationMutex_);
-    assert(!observedMappointIds_.count(mappointId));
-    observedMappointIds_.insert(mappointId);
-    observedOrder_.push_back(mappointId);
     auto mappoint = MapManager::GetInstance().GetMappoint(mappointId);
     assert(mappoint != nullptr);
+    AddObservedMappoint(mappoint.get(), pixelPos);
+}
+
+void Frame::AddObservedMappoint(Mappoint* mappoint, const Point2f pixelPos) {
+    std::unique_lock<std::mutex> lck(observationMutex_);
+    observed_.push_back(ObservedEntry{mappoint->GetId(), mappoint, true});
     mappoint->AddObservedByKeyframe(id_, pixelPos, GetCamCenter(), this);
     for (const Mappoint::Observation& o : mappoint->ObservationList()) {     // no copy of the observation map
-        const size_t other = o.keyframeId;
-        if (other == id_) continue;
         Frame* otherKF = o.keyframe;
+        if (otherKF == this) continue;
         assert(otherKF != nullptr);
-        int w = ++allCovisibleKeyframeIdToWeight_[other];
-        if (w >= 15) activeCovisibleKeyframes_.insert(other);
+        if (covisBatch_) { if (otherKF->covisAcc_++ == 0) covisTouched_.push_back(otherKF); continue; }
+        int w = ++allCovisibleKeyframeIdToWeight_[o.keyframeId];
+        if (w >= 15) activeCovisibleKeyframes_.insert(o.keyframeId);
         otherKF->UpdateCovisibleKeyframeWeight(id_, w);
     }
 }
 
+void Frame::EndCovisibilityBatch() {
+    std::unique_lock<std::mutex> lck(observationMutex_);
+    covisBatch_ = false;
+    for (Frame* otherKF : covisTouched_) {
+        const int w = (allCovisibleKeyframeIdToWeight_[otherKF->id_] += otherKF->covisAcc_);
+        otherKF->covisAcc_ = 0;
+        if (w >= 15) activeCovisibleKeyframes_.insert(otherKF->id_);
+        otherKF->UpdateCovisibleKeyframeWeight(id_, w);
+    }
+    covisTouched_.clear();
+}
+
 void Frame::RemoveObservedMappoint(const size_t mappointId) {
     std::unique_lock<std::mutex> lck(observationMutex_);
-    assert(observedMappointIds_.count(mappointId));
-    observedMappointIds_.erase(mappointId);
-    auto mappoint = MapManager::GetInstance().GetMappoint(mappointId);
+    Mappoint* mappoint = nullptr;
+    for (size_t i = observed_.size(); i-- > 0;)
+        if (observed_[i].id == mappointId && observed_[i].alive) { observed_[i].alive = false; mappoint = observed_[i].mappoint; break; }
     assert(mappoint != nullptr);
+    if (mappoint == nullptr) return;
     mappoint->RemoveObservedByKeyframe(id_);
-    for (auto& idToPixel : mappoint->GetObservedByKeyframesMap()) {
-        const size_t other = idToPixel.first;
+    for (const Mappoint::Observation& o : mappoint->ObservationList()) {
+        const size_t other = o.keyframeId;
         if (other == id_) continue;
-        auto otherKF = MapManager::GetInstance().GetKeyframe(other);
+        Frame* otherKF = o.keyframe;
         assert(otherKF != nullptr);
         int w = --allCovisibleKeyframeIdToWeight_[other];
         if (w == 0) allCovisibleKeyframeIdToWeight_.erase(other);

@@ -9,6 +9,7 @@
 
 #include "myslam/config.h"
 #include "myslam/mapmanager.h"
+#include "myslam/util.h"
 
 namespace myslam {
 
@@ -70,12 +71,13 @@ bool FrontEnd::AddFrame(const Frame::Ptr frame) {
         case TRACKING: if (!TrackingHandler()) return false; break;
         case LOST: LostHandler(); return false;
     }
-    if (viewer_) { viewer_->setCurrentFrame(frameCurr_, flannMatchedKptSet_); viewer_->updateDrawingObjects(); }
+    if (viewer_) { EnsureMatchLists(); viewer_->setCurrentFrame(frameCurr_, flannMatchedKptSet_); viewer_->updateDrawingObjects(); }
     return true;
 }
 
 void FrontEnd::InitializationHandler() {
     ExtractKeyPointsAndComputeDescriptors();
+    EnsureMatchLists();                                          // no matches yet: empty lists sized for this frame
     MapManager::GetInstance().InsertKeyframe(frameCurr_);       // the first frame is a keyframe
     ++stats_.keyframes;
     CreateNewMappoints();                                        // one frame suffices: depth is measured
@@ -101,11 +103,12 @@ bool FrontEnd::TrackingHandler() {
     ++epoch_; framesSinceKf_ = 0;                                  // map + prior change: cached speculative results are void
     {
         StageTimer t(stats_.ms_keyframe);
-        MapManager::GetInstance().InsertKeyframe(frameCurr_);
+        { VO_SCOPE("kf.lists"); EnsureMatchLists(); }
+        { VO_SCOPE("kf.insert"); MapManager::GetInstance().InsertKeyframe(frameCurr_); }
         ++stats_.keyframes;
-        AddCurrentKeyframeObservations();
-        CreateNewMappoints();
-        TriangulateMappointsInTrackingMap();
+        { VO_SCOPE("kf.add_observations"); AddCurrentKeyframeObservations(); }
+        { VO_SCOPE("kf.create_mappoints"); CreateNewMappoints(); }
+        { VO_SCOPE("kf.triangulate"); TriangulateMappointsInTrackingMap(); }
     }
     if (backend_) { StageTimer t(stats_.ms_backend); backend_->OptimizeCovisibleGraphOfKeyframe(frameCurr_); }
     framePrev_ = frameCurr_;
@@ -134,6 +137,7 @@ int FrontEnd::PrefetchFrames(const std::vector<Frame::Ptr>& frames) {
 }
 
 void FrontEnd::ExtractKeyPointsAndComputeDescriptors() {
+    VO_SCOPE("fe.fetch_keypoints");
     Frame::Ptr f = frameCurr_;
     if (!f->orb_done_) {
         std::vector<Frame::Ptr> one{f};
@@ -143,7 +147,14 @@ void FrontEnd::ExtractKeyPointsAndComputeDescriptors() {
     kpBuf_.resize(cap); descBuf_.resize((size_t)32 * cap);
     int n = 0;
     vo_check(vo_orb_fetch(ctx_, f->slot_, kpBuf_.data(), descBuf_.data(), cap, &n), "vo_orb_fetch");
-    n = std::min(n, cap);
+    nKeypointsCurr_ = std::min(n, cap);
+    keypointsBuilt_ = false; matchListsBuilt_ = false; curMatches_ = nullptr; nCurMatches_ = 0;
+    stats_.last_keypoints = nKeypointsCurr_;
+}
+
+void FrontEnd::EnsureKeypoints() {
+    if (keypointsBuilt_) return;
+    const int n = nKeypointsCurr_;
     keypointsCurr_.resize(n); descriptorsCurr_.resize(n);
     for (int i = 0; i < n; ++i) {
         const vo_keypoint& k = kpBuf_[i];
@@ -152,7 +163,26 @@ void FrontEnd::ExtractKeyPointsAndComputeDescriptors() {
         o.index = i; o.depth_raw = k.depth_raw;
         std::memcpy(descriptorsCurr_[i].data(), &descBuf_[(size_t)32 * i], 32);
     }
-    stats_.last_keypoints = n;
+    keypointsBuilt_ = true;
+}
+
+// flannMatchedMptKptMap_ / pnpMatchedMptSet_ / pnpMatchedKptSet_ of the reference (frontend.cpp:208-209, :326-328)
+void FrontEnd::EnsureMatchLists() {
+    if (matchListsBuilt_) return;
+    EnsureKeypoints();
+    flannMatchedMpt_.clear(); flannMatchedKp_.clear(); flannMatchedLm_.clear();
+    flannMatchedKptSet_.reset(keypointsCurr_.size()); pnpMatchedKptSet_.reset(keypointsCurr_.size());
+    pnpMatchedMpt_.clear(); pnpMatchedMptKp_.clear();
+    for (int i = 0; i < nCurMatches_; ++i) {
+        const vo_match& m = curMatches_[i];
+        Mappoint* mp = activeList_[activeIndexOfSlot_[m.map_index]];
+        const KeyPoint& kp = keypointsCurr_[m.kp_index];
+        flannMatchedMpt_.push_back(mp); flannMatchedKp_.push_back(m.kp_index);
+        flannMatchedLm_.push_back((m.flags & VO_MATCH_LM_INLIER) ? 1 : 0);
+        flannMatchedKptSet_.insert(kp);
+        if (m.flags & VO_MATCH_LM_INLIER) { pnpMatchedMpt_.push_back(mp); pnpMatchedMptKp_.push_back(m.kp_index); pnpMatchedKptSet_.insert(kp); }
+    }
+    matchListsBuilt_ = true;
 }
 
 void FrontEnd::RefreshTrackingMap() {
@@ -163,7 +193,9 @@ void FrontEnd::RefreshTrackingMap() {
         changed = true;
     }
     if (activeList_.size() < 100) {                                                 // frontend.cpp:163-166
-        activeList_ = MapManager::GetInstance().AllMappointsOrdered();
+        const auto& all = MapManager::GetInstance().AllMappointsOrdered();
+        activeList_.resize(all.size());
+        for (size_t i = 0; i < all.size(); ++i) activeList_[i] = all[i].get();
         changed = true;
     }
     if (!changed) return;
@@ -198,8 +230,7 @@ void FrontEnd::MatchAndEstimatePose() {
     for (auto& sp : spec_)
         if (sp.frameId == frameCurr_->GetId() && sp.epoch == epoch_) {            // tracked ahead of time with identical inputs
             res = sp.res;
-            if ((int)matchBuf_.size() < res.n_matches) matchBuf_.resize(res.n_matches);
-            std::copy(sp.matches.begin(), sp.matches.begin() + res.n_matches, matchBuf_.begin());
+            curMatches_ = sp.matches.data(); nCurMatches_ = (int)sp.matches.size();  // alive until the next batch call
             have = true;
             break;
         }
@@ -228,28 +259,18 @@ void FrontEnd::MatchAndEstimatePose() {
         std::vector<int> slots(nb); std::vector<uint64_t> seeds(nb); std::vector<vo_track_result> rs(nb);
         for (int j = 0; j < nb; ++j) { slots[j] = batch[j]->slot_; seeds[j] = 0x5eed5eedull + 2 * (uint64_t)(stats_.frames + j); }
         if (matchBuf_.size() < (size_t)nb * cap) matchBuf_.resize((size_t)nb * cap);
-        vo_check(vo_track_batch(ctx_, nb, slots.data(), prior, &trackParams_, seeds.data(), rs.data(), matchBuf_.data(), cap), "vo_track_batch");
+        { VO_SCOPE("fe.vo_track_batch"); vo_check(vo_track_batch(ctx_, nb, slots.data(), prior, &trackParams_, seeds.data(), rs.data(), matchBuf_.data(), cap), "vo_track_batch"); }
+        VO_SCOPE("fe.spec_store");
         for (int j = 1; j < nb; ++j) {
             SpecResult sp; sp.frameId = batch[j]->GetId(); sp.epoch = epoch_; sp.res = rs[j];
             sp.matches.assign(matchBuf_.begin() + (size_t)j * cap, matchBuf_.begin() + (size_t)j * cap + std::min(rs[j].n_matches, cap));
             spec_.push_back(std::move(sp));
         }
         res = rs[0];
+        curMatches_ = matchBuf_.data(); nCurMatches_ = std::min(res.n_matches, cap);
     }
     if (res.status != VO_OK) throw std::runtime_error(std::string("device pipeline: ") + vo_strerror(res.status));
-
-    flannMatchedMpt_.clear(); flannMatchedKp_.clear(); flannMatchedLm_.clear();
-    flannMatchedKptSet_.reset(keypointsCurr_.size()); pnpMatchedKptSet_.reset(keypointsCurr_.size());
-    pnpMatchedMpt_.clear(); pnpMatchedMptKp_.clear();
-    for (int i = 0; i < res.n_matches; ++i) {
-        const vo_match& m = matchBuf_[i];
-        const Mappoint::Ptr& mp = activeList_[activeIndexOfSlot_[m.map_index]];
-        const KeyPoint& kp = keypointsCurr_[m.kp_index];
-        flannMatchedMpt_.push_back(mp); flannMatchedKp_.push_back(m.kp_index);              // frontend.cpp:208-209
-        flannMatchedLm_.push_back((m.flags & VO_MATCH_LM_INLIER) ? 1 : 0);
-        flannMatchedKptSet_.insert(kp);
-        if (m.flags & VO_MATCH_LM_INLIER) { pnpMatchedMpt_.push_back(mp); pnpMatchedMptKp_.push_back(m.kp_index); pnpMatchedKptSet_.insert(kp); }   // :326-328
-    }
+    matchListsBuilt_ = false;
     numInliers_ = res.n_ransac_inliers;                                             // frontend.cpp:242
     frameCurr_->SetPose(SE3::from12(res.T_cw));                                     // frontend.cpp:312
     stats_.last_candidates = res.n_candidates; stats_.last_matches = res.n_matches;
@@ -280,8 +301,10 @@ bool FrontEnd::IsKeyframe() {
 
 void FrontEnd::AddCurrentKeyframeObservations() {
     // reference iterates an unordered_set (frontend.cpp:366-370); active-list (= id) order here, for determinism
+    frameCurr_->BeginCovisibilityBatch();
     for (size_t i = 0; i < pnpMatchedMpt_.size(); ++i)
-        frameCurr_->AddObservedMappoint(pnpMatchedMpt_[i]->GetId(), keypointsCurr_[pnpMatchedMptKp_[i]].pt);
+        frameCurr_->AddObservedMappoint(pnpMatchedMpt_[i], keypointsCurr_[pnpMatchedMptKp_[i]].pt);
+    frameCurr_->EndCovisibilityBatch();
 }
 
 void FrontEnd::CreateNewMappoints() {
@@ -295,7 +318,7 @@ void FrontEnd::CreateNewMappoints() {
         Mappoint::Ptr mpt = Mappoint::CreateMappoint(pos, descriptorsCurr_[idx]);
         MapManager::GetInstance().InsertMappoint(mpt);
         if (mpt->slot_ >= params_.map_capacity) throw std::runtime_error("device map capacity exceeded (raise map_capacity)");
-        frameCurr_->AddObservedMappoint(mpt->GetId(), kp.pt);
+        frameCurr_->AddObservedMappoint(mpt.get(), kp.pt);
         newMappoints_.push_back(mpt);
     }
     if (verbose_) std::cout << "Created new mappoints: " << newMappoints_.size() << std::endl;
@@ -303,18 +326,13 @@ void FrontEnd::CreateNewMappoints() {
 
 void FrontEnd::TriangulateMappointsInTrackingMap() {
     int triangulatedCnt = 0;
-    for (auto& mp : pnpMatchedMpt_) {                                               // trackingMap_ ∩ pnpMatchedMptSet_, id order
+    for (Mappoint* mp : pnpMatchedMpt_) {                                           // trackingMap_ ∩ pnpMatchedMptSet_, id order
         if (mp->outlier_ || mp->triangulated_ || mp->optimized_) continue;
         std::vector<SE3> poses; std::vector<Vec3> points;
-        auto obs = mp->GetObservedByKeyframesMap();
-        std::vector<size_t> ids;
-        for (auto& kv : obs) ids.push_back(kv.first);
-        std::sort(ids.begin(), ids.end());
-        for (size_t id : ids) {
-            auto kf = MapManager::GetInstance().GetKeyframe(id);
-            if (kf == nullptr) continue;
-            poses.push_back(kf->GetPose());
-            points.push_back(kf->camera_->Pixel2Camera(obs[id]));
+        for (const Mappoint::Observation& o : mp->ObservationList()) {              // keyframe-id order
+            if (o.keyframe == nullptr) continue;
+            poses.push_back(o.keyframe->GetPose());
+            points.push_back(o.keyframe->camera_->Pixel2Camera(o.pixel));
         }
         if (poses.size() >= 2) {
             Vec3 pworld = Vec3::Zero();

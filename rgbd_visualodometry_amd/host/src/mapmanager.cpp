@@ -38,25 +38,22 @@ MapManager::MappointIdToPtr MapManager::GetMappointsAroundKeyframe(const Frame::
 
 // Same set as GetMappointsAroundKeyframe (mapmanager.cpp:14-38) as a vector: keyframes in id order, each
 // keyframe's observations in insertion order, de-duplicated with a visit stamp (no hash-map copies).
-std::vector<Mappoint::Ptr> MapManager::CollectMappointsAroundKeyframe(const Frame::Ptr& keyframe) {
+std::vector<Mappoint*> MapManager::CollectMappointsAroundKeyframe(const Frame::Ptr& keyframe) {
     std::unique_lock<std::mutex> lck(dataMutex_);
     auto ids = keyframe->GetCovisibleKeyframes();
     ids.insert(keyframe->GetId());
     std::vector<size_t> kfs(ids.begin(), ids.end());
     std::sort(kfs.begin(), kfs.end());
-    std::vector<Mappoint::Ptr> out;
+    std::vector<Mappoint*> out;
     const uint64_t stamp = ++stamp_;
     for (size_t kfId : kfs) {
         auto kf = keyframesDict_.find(kfId);
         assert(kf != keyframesDict_.end());
-        Frame& f = *kf->second;
-        for (size_t mpId : f.ObservedOrder()) {
-            auto it = mappointsDict_.find(mpId);
-            if (it == mappointsDict_.end()) continue;
-            Mappoint& mp = *it->second;
-            if (mp.visitStamp_ == stamp || mp.outlier_ || !f.IsObservedMappoint(mpId)) continue;
+        for (const Frame::ObservedEntry& e : kf->second->Observed()) {
+            Mappoint& mp = *e.mappoint;
+            if (!e.alive || mp.visitStamp_ == stamp || mp.outlier_) continue;
             mp.visitStamp_ = stamp;
-            out.push_back(it->second);
+            out.push_back(&mp);
         }
     }
     return out;

@@ -15,8 +15,6 @@ Mappoint::Mappoint(const size_t id, const Vector3d position, const Descriptor& d
 
 void Mappoint::AddObservedByKeyframe(const size_t keyframeId, const Point2f posInPixel, const Vector3d cameraCenter, Frame* keyframe) {
     std::unique_lock<std::mutex> lock(observationMutex_);
-    assert(!observedByKeyframeMap_.count(keyframeId));
-    observedByKeyframeMap_[keyframeId] = posInPixel;
     obsList_.push_back(Observation{keyframeId, posInPixel, keyframe});
     norm_ = (norm_ + (pos_ - cameraCenter).normalized()).normalized();      // running mean viewing direction
     lock.unlock();
@@ -25,10 +23,8 @@ void Mappoint::AddObservedByKeyframe(const size_t keyframeId, const Point2f posI
 
 void Mappoint::RemoveObservedByKeyframe(const size_t keyframeId) {
     std::unique_lock<std::mutex> lock(observationMutex_);
-    assert(observedByKeyframeMap_.count(keyframeId));
-    observedByKeyframeMap_.erase(keyframeId);
     for (size_t i = 0; i < obsList_.size(); ++i) if (obsList_[i].keyframeId == keyframeId) { obsList_.erase(obsList_.begin() + i); break; }
-    if (observedByKeyframeMap_.empty()) { outlier_ = true; lock.unlock(); MarkDirty(); }  // no observation left
+    if (obsList_.empty()) { outlier_ = true; lock.unlock(); MarkDirty(); }  // no observation left
 }
 
 void Mappoint::MarkDirty() {

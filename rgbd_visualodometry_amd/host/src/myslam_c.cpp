@@ -1,5 +1,6 @@
 // myslam_c.cpp -- C wrapper of the host layer (see include/myslam_c.h).
 #include "myslam_c.h"
+#include "myslam/util.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -90,6 +91,7 @@ void myslam_system_destroy(myslam_system* s) {
 
 int myslam_prefetch(myslam_system* s, int n, const double* stamps, const void* const* bgr, const void* const* depth, int bs, int ds, int on_device) {
     if (!s || n < 1 || !bgr || !depth) return -1;
+    VO_SCOPE("c.prefetch");
     return guarded(s, [&]() {
         if (!s->queue.empty()) throw std::runtime_error("previous prefetched frames not consumed yet");
         std::vector<Frame::Ptr> fr;
@@ -101,6 +103,7 @@ int myslam_prefetch(myslam_system* s, int n, const double* stamps, const void* c
 
 int myslam_add_prefetched(myslam_system* s, int* tracked, double T_wc[12]) {
     if (!s) return -1;
+    VO_SCOPE("c.add_prefetched");
     return guarded(s, [&]() {
         if (s->queue.empty()) throw std::runtime_error("no prefetched frame queued");
         Frame::Ptr f = s->queue.front(); s->queue.pop_front();
@@ -136,6 +139,7 @@ int myslam_get_stats(myslam_system* s, myslam_stats* st) {
         st->ba_runs = b.runs; st->ba_poses = b.poses; st->ba_fixed = b.fixed; st->ba_points = b.points; st->ba_edges = b.edges; st->ba_outliers = b.outliers; st->ba_ms = b.ms;
         if (getenv("VO_TRACE")) fprintf(stderr, "[vo_trace] BA runs %d build %.2f ms solve %.2f ms wait %.2f ms\n", b.runs, b.ms_build, b.ms_solve, b.ms_wait);
     }
+    if (myslam::TraceScope::on()) myslam::TraceScope::dump();
     return 0;
 }
 

@@ -2,6 +2,11 @@
 // Jacobi eigen-decomposition of A^T A here: singular values = sqrt(eigenvalues)).
 #include "myslam/util.h"
 
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
 namespace myslam {
 
 void SymmetricEigen4(const double A[16], double ev[4], double V[16]) {
@@ -47,5 +52,23 @@ bool Triangulation(const std::vector<SE3>& poses, const std::vector<Vec3>& point
     pt_world = Vec3(V[0] / w, V[4] / w, V[8] / w);
     const double s4 = std::sqrt(std::max(ev[0], 0.0)), s3 = std::sqrt(std::max(ev[1], 0.0));
     return s4 / s3 < 1e-2;
+}
+
+namespace {
+struct TraceRow { const char* name; double ms; long calls; };
+std::mutex g_trace_mu;
+std::vector<TraceRow> g_trace_rows;
+}  // namespace
+
+bool TraceScope::on() { static const bool v = getenv("VO_TRACE") != nullptr; return v; }
+void TraceScope::add(const char* name, double ms) {
+    std::lock_guard<std::mutex> lk(g_trace_mu);
+    for (auto& r : g_trace_rows) if (r.name == name || !strcmp(r.name, name)) { r.ms += ms; ++r.calls; return; }
+    g_trace_rows.push_back({name, ms, 1});
+}
+void TraceScope::dump() {
+    std::lock_guard<std::mutex> lk(g_trace_mu);
+    for (auto& r : g_trace_rows) fprintf(stderr, "[vo_trace] scope %-28s %9.2f ms  %7ld calls  %8.2f us/call\n", r.name, r.ms, r.calls, 1e3 * r.ms / r.calls);
+    g_trace_rows.clear();
 }
 }  // namespace myslam
