@@ -36,6 +36,16 @@ __global__ void k_dpp_probe(double* out) {
     out[lane] = b; out[64 + lane] = acc;
 }
 
+__global__ void k_reduce32_probe(double* out) {
+    const int lane = threadIdx.x;
+    double v[32], r[8];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = (double)((lane * 37 + i * 101) % 1009) + 0.25 * i;
+    vo_wave_reduce32(v, r);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) out[k * 64 + lane] = r[k];
+}
+
 __global__ void k_lat_probe(double* out, double seed) {
     double x = seed + threadIdx.x, y = 1.0000001, z = 0.5;
     long long t0 = clock64();
@@ -72,6 +82,14 @@ __global__ void k_rsq_probe(const double* x, double* y, int n) {
 }
 
 int main() {
+    { double* d; hipMalloc(&d, 512 * 8); hipLaunchKernelGGL(k_reduce32_probe, dim3(1), dim3(64), 0, 0, d); std::vector<double> h(512); hipMemcpy(h.data(), d, 512 * 8, hipMemcpyDeviceToHost);
+      int bad = 0;
+      for (int k = 0; k < 8; ++k) for (int lane = 0; lane < 64; ++lane) {
+          const int i = 4 * k + VO_R32_SLOT(lane >> 4);
+          double ex = 0; for (int l = 0; l < 64; ++l) ex += (double)((l * 37 + i * 101) % 1009) + 0.25 * i;
+          if (h[k * 64 + lane] != ex) { if (bad < 4) printf("reduce32 probe: out[%d] lane %d = %.2f, expected %.2f\n", k, lane, h[k * 64 + lane], ex); ++bad; }
+      }
+      printf("reduce32 probe: %d mismatches\n", bad); hipFree(d); }
     { double* d; hipMalloc(&d, 128 * 8); hipLaunchKernelGGL(k_lat_probe, dim3(1), dim3(64), 0, 0, d, 1.0); double h[8]; hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
       printf("latency probe (clocks): dependent v_fma_f64 %.1f | mul+nop+fmac_dpp pair %.1f | dependent v_rsq_f64 %.1f | independent v_fma_f64 %.1f | dependent v_cndmask_b32 %.1f\n", h[0], h[1], h[2], h[3], h[4]); hipFree(d); }
     { const int n = 1 << 16; std::vector<double> hx(n), hy(4 * n); std::mt19937_64 rg(7); std::uniform_real_distribution<double> ud(-30.0, 30.0);

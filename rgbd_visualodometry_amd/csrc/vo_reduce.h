@@ -24,3 +24,48 @@ __device__ __forceinline__ double vo_wave_sum_f64(double x) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), 63), hi = __builtin_amdgcn_readlane(__double2hiint(x), 63);
     return __hiloint2double(hi, lo);
 }
+
+// ---- 32 values at once -------------------------------------------------------------------------------------------
+// Reducing k values one by one costs k x 6 butterfly steps.  With 32 values per lane the first two steps can halve the
+// register count instead: v_permlane32_swap / v_permlane16_swap (gfx950) exchange lane halves / odd-even 16-lane rows of
+// TWO registers, so one add folds a pair of values and each survivor keeps a different value per half / row.  After
+// 16 + 8 adds there are 8 registers holding 4 values each (one per DPP row); 4 rotate-and-add steps inside the rows
+// finish: 56 adds instead of 192.
+__device__ __forceinline__ void vo_swap_halves_f64(double& a, double& b) {     // a lanes 32..63 <-> b lanes 0..31
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]); b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ void vo_swap_rows_f64(double& a, double& b) {       // a rows 1, 3 <-> b rows 0, 2
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]); b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// Index of the value that DPP row `row` (lane >> 4) of out[k] holds after vo_wave_reduce32: 4 k + VO_R32_SLOT(row).
+#define VO_R32_SLOT(row) ((((row) & 1) << 1) | ((row) >> 1))
+// v[0..31]: per-lane partials.  out[k], k = 0..7: every lane of row r holds the wavefront sum of v[4 k + VO_R32_SLOT(r)].
+__device__ __forceinline__ void vo_wave_reduce32(double (&v)[32], double (&out)[8]) {
+    double p[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { double a = v[2 * i], b = v[2 * i + 1]; vo_swap_halves_f64(a, b); p[i] = a + b; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { double a = p[2 * k], b = p[2 * k + 1]; vo_swap_rows_f64(a, b); out[k] = a + b; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        double x = out[k];
+        x += vo_dpp_mov_f64<0x128, 0xF>(x);     // row_ror:8
+        x += vo_dpp_mov_f64<0x124, 0xF>(x);     // row_ror:4
+        x += vo_dpp_mov_f64<0x122, 0xF>(x);     // row_ror:2
+        x += vo_dpp_mov_f64<0x121, 0xF>(x);     // row_ror:1
+        out[k] = x;
+    }
+}
+
+// 1 / sqrt(d): v_rsq_f64 (2^-24) + one cubic correction e (1/2 + 3/8 e), e = 1 - d y^2 -> 2^-52.7 relative error,
+// 6 dependent operations instead of the ~25 of an IEEE sqrt followed by an IEEE divide.
+__device__ __forceinline__ double vo_rsqrt_f64(double d) {
+#pragma clang fp contract(fast)
+    const double y = __builtin_amdgcn_rsq(d);
+    const double e = 1.0 - (d * y) * y;
+    return y + y * (e * (0.5 + 0.375 * e));
+}

@@ -440,7 +440,7 @@ __global__ __launch_bounds__(1024) void k_ransac_select(CamD cam, ChainBuf cb, i
 // ------------------------------------------------------------------------------------------
 // K14 pose-only LM in one workgroup
 // ------------------------------------------------------------------------------------------
-#define LM_T 256
+#define LM_T 512
 #define LM_W (LM_T / 64)
 #define LM_NV 28            // 21 (upper H) + 6 (b) + 1 (chi)
 #define LM_LDS_MAX 6144     // inlier correspondences staged in LDS (20 B each)
@@ -450,8 +450,9 @@ __device__ __forceinline__ void so3_exp_dev(const double w[3], double R[9]) {
     const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = sqrt(th2);
     double A, B;
     if (th2 < 0.0625) {     // |theta| < 0.25: Taylor to theta^14 (error < 1e-19), avoids the sin/cos call chains
-        A = 1.0 - th2 / 6.0 * (1.0 - th2 / 20.0 * (1.0 - th2 / 42.0 * (1.0 - th2 / 72.0 * (1.0 - th2 / 110.0 * (1.0 - th2 / 156.0 * (1.0 - th2 / 210.0))))));
-        B = 0.5 * (1.0 - th2 / 12.0 * (1.0 - th2 / 30.0 * (1.0 - th2 / 56.0 * (1.0 - th2 / 90.0 * (1.0 - th2 / 132.0 * (1.0 - th2 / 182.0 * (1.0 - th2 / 240.0)))))));
+        // reciprocal constants: a division by a literal is still a full IEEE divide (~10 dependent operations) on the GPU
+        A = 1.0 - th2 * (1.0 / 6.0) * (1.0 - th2 * (1.0 / 20.0) * (1.0 - th2 * (1.0 / 42.0) * (1.0 - th2 * (1.0 / 72.0) * (1.0 - th2 * (1.0 / 110.0) * (1.0 - th2 * (1.0 / 156.0) * (1.0 - th2 * (1.0 / 210.0)))))));
+        B = 0.5 * (1.0 - th2 * (1.0 / 12.0) * (1.0 - th2 * (1.0 / 30.0) * (1.0 - th2 * (1.0 / 56.0) * (1.0 - th2 * (1.0 / 90.0) * (1.0 - th2 * (1.0 / 132.0) * (1.0 - th2 * (1.0 / 182.0) * (1.0 - th2 * (1.0 / 240.0))))))));
     } else { A = sin(th) / th; B = (1.0 - cos(th)) / th2; }
     const double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
     double W2[9];
@@ -466,8 +467,8 @@ __device__ void se3_exp_mul_dev(const double d[6], const double* T, double* Tn) 
     const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = sqrt(th2);
     double B, C;
     if (th2 < 0.0625) {
-        B = 0.5 * (1.0 - th2 / 12.0 * (1.0 - th2 / 30.0 * (1.0 - th2 / 56.0 * (1.0 - th2 / 90.0 * (1.0 - th2 / 132.0 * (1.0 - th2 / 182.0 * (1.0 - th2 / 240.0)))))));
-        C = 1.0 / 6.0 * (1.0 - th2 / 20.0 * (1.0 - th2 / 42.0 * (1.0 - th2 / 72.0 * (1.0 - th2 / 110.0 * (1.0 - th2 / 156.0 * (1.0 - th2 / 210.0 * (1.0 - th2 / 272.0)))))));
+        B = 0.5 * (1.0 - th2 * (1.0 / 12.0) * (1.0 - th2 * (1.0 / 30.0) * (1.0 - th2 * (1.0 / 56.0) * (1.0 - th2 * (1.0 / 90.0) * (1.0 - th2 * (1.0 / 132.0) * (1.0 - th2 * (1.0 / 182.0) * (1.0 - th2 * (1.0 / 240.0))))))));
+        C = 1.0 / 6.0 * (1.0 - th2 * (1.0 / 20.0) * (1.0 - th2 * (1.0 / 42.0) * (1.0 - th2 * (1.0 / 72.0) * (1.0 - th2 * (1.0 / 110.0) * (1.0 - th2 * (1.0 / 156.0) * (1.0 - th2 * (1.0 / 210.0) * (1.0 - th2 * (1.0 / 272.0))))))));
     } else { B = (1.0 - cos(th)) / th2; C = (th - sin(th)) / (th2 * th); }
     const double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
     double W2[9], V[9], R[9];
@@ -491,7 +492,7 @@ __device__ __forceinline__ bool chol6_dev(double* A, double* b) {
 #pragma unroll
         for (int k = 0; k < j; ++k) d -= A[j * 6 + k] * A[j * 6 + k];
         if (!(d > 0.0)) return false;
-        inv[j] = 1.0 / sqrt(d);
+        inv[j] = vo_rsqrt_f64(d);
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) { double s = A[i * 6 + j];
 #pragma unroll
@@ -511,18 +512,19 @@ __device__ __forceinline__ bool chol6_dev(double* A, double* b) {
     return true;
 }
 
-// One pass over the active edges at pose T: robust chi2, H (upper triangle) and b, reduced over the
-// whole 1024-thread workgroup and broadcast to every thread (v[0..20] H, v[21..26] b, v[27] chi).
+// One pass over the active edges at pose T: robust chi2, H (upper triangle) and b, reduced over the whole
+// workgroup into the LDS buffer `tot` ([0..20] H, [21..26] b, [27] chi) that every thread reads afterwards.
 __device__ void lm_pass_dev(const CamD& cam, const float* cxyz, const float* cuv, const int32_t* edges,
-                            const uint8_t* mask, int n, int round, const double* T, double delta, double* v,
-                            double* s_part, double* s_out) {
+                            const uint8_t* mask, int n, int round, const double* T, double delta,
+                            double* s_part, double* tot, int& phase) {
 #pragma clang fp contract(fast)
     const bool robust = round == 0;
 #ifdef VO_LM_STAMPS
     const long long ts0 = clock64();
 #endif
+    double a32[32];                                    // [0..20] H upper triangle, [21..26] b, [27] chi2, [28..31] padding of the reduction
 #pragma unroll
-    for (int i = 0; i < LM_NV; ++i) v[i] = 0;
+    for (int i = 0; i < 32; ++i) a32[i] = 0;
     // Per edge: the weighted outer products of a = [J0, e0] and b = [J1, e1] give H, J^T e and chi2 at once;
     // J0[1] = J1[0] = 0 (g2o_types.h:97-99) removes a third of the products.
     double g[6] = {0, 0, 0, 0, 0, 0};
@@ -536,7 +538,7 @@ __device__ void lm_pass_dev(const CamD& cam, const float* cxyz, const float* cuv
         const double e0 = (double)cuv[2 * k] - (fx * xz + cam.cx), e1 = (double)cuv[2 * k + 1] - (fy * yz + cam.cy);   // g2o_types.h:83
         const double e2 = e0 * e0 + e1 * e1;
         double r1 = 1.0;
-        if (robust && e2 > delta * delta) { const double se = sqrt(e2); v[27] += 2.0 * se * delta - delta * delta; r1 = delta / se; } else v[27] += e2;
+        if (robust && e2 > delta * delta) { const double se = sqrt(e2); a32[27] += 2.0 * se * delta - delta * delta; r1 = delta / se; } else a32[27] += e2;
         const double fxz = fx * Zi, fyz = fy * Zi;
         // J0 = [-fx/Z, 0, fx X/Z^2, fx XY/Z^2, -fx - fx X^2/Z^2, fx Y/Z],  J1 = [0, -fy/Z, fy Y/Z^2, fy + fy Y^2/Z^2, -fy XY/Z^2, -fy X/Z]
         const double a0 = -fxz, a2 = fxz * xz, a3 = a2 * pc.y, a4 = -fx - a2 * pc.x, a5 = fxz * pc.y;
@@ -544,37 +546,42 @@ __device__ void lm_pass_dev(const CamD& cam, const float* cxyz, const float* cuv
         const double wa0 = r1 * a0, wa2 = r1 * a2, wa3 = r1 * a3, wa4 = r1 * a4, wa5 = r1 * a5;
         const double wb1 = r1 * b1, wb2 = r1 * b2, wb3 = r1 * b3, wb4 = r1 * b4, wb5 = r1 * b5;
         // upper triangle, row-major: (0,0..5) (1,1..5) (2,2..5) (3,3..5) (4,4..5) (5,5)
-        v[0] += wa0 * a0; v[2] += wa0 * a2; v[3] += wa0 * a3; v[4] += wa0 * a4; v[5] += wa0 * a5;
-        v[6] += wb1 * b1; v[7] += wb1 * b2; v[8] += wb1 * b3; v[9] += wb1 * b4; v[10] += wb1 * b5;
-        v[11] += wa2 * a2 + wb2 * b2; v[12] += wa2 * a3 + wb2 * b3; v[13] += wa2 * a4 + wb2 * b4; v[14] += wa2 * a5 + wb2 * b5;
-        v[15] += wa3 * a3 + wb3 * b3; v[16] += wa3 * a4 + wb3 * b4; v[17] += wa3 * a5 + wb3 * b5;
-        v[18] += wa4 * a4 + wb4 * b4; v[19] += wa4 * a5 + wb4 * b5;
-        v[20] += wa5 * a5 + wb5 * b5;
+        a32[0] += wa0 * a0; a32[2] += wa0 * a2; a32[3] += wa0 * a3; a32[4] += wa0 * a4; a32[5] += wa0 * a5;
+        a32[6] += wb1 * b1; a32[7] += wb1 * b2; a32[8] += wb1 * b3; a32[9] += wb1 * b4; a32[10] += wb1 * b5;
+        a32[11] += wa2 * a2 + wb2 * b2; a32[12] += wa2 * a3 + wb2 * b3; a32[13] += wa2 * a4 + wb2 * b4; a32[14] += wa2 * a5 + wb2 * b5;
+        a32[15] += wa3 * a3 + wb3 * b3; a32[16] += wa3 * a4 + wb3 * b4; a32[17] += wa3 * a5 + wb3 * b5;
+        a32[18] += wa4 * a4 + wb4 * b4; a32[19] += wa4 * a5 + wb4 * b5;
+        a32[20] += wa5 * a5 + wb5 * b5;
         g[0] += wa0 * e0; g[1] += wb1 * e1; g[2] += wa2 * e0 + wb2 * e1; g[3] += wa3 * e0 + wb3 * e1; g[4] += wa4 * e0 + wb4 * e1; g[5] += wa5 * e0 + wb5 * e1;
     }
 #pragma unroll
-    for (int a_ = 0; a_ < 6; ++a_) v[21 + a_] = -g[a_];
+    for (int a_ = 0; a_ < 6; ++a_) a32[21 + a_] = -g[a_];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #ifdef VO_LM_STAMPS
     const long long ts1 = clock64();
 #endif
-#pragma unroll
-    for (int i = 0; i < LM_NV; ++i) v[i] = vo_wave_sum_f64(v[i]);
+    double r8[8];
+    vo_wave_reduce32(a32, r8);                         // row r of r8[k]: wavefront sum of a32[4 k + VO_R32_SLOT(r)]
 #ifdef VO_LM_STAMPS
     const long long ts2 = clock64();
 #endif
-    __syncthreads();                                   // previous readers of s_out are done
-    if (lane == 0) for (int i = 0; i < LM_NV; ++i) s_part[wave * LM_NV + i] = v[i];
+    // cross-wave: partials and totals are double buffered by `phase`, so two barriers per pass are enough (a buffer
+    // is rewritten two passes later, after every reader has crossed two barriers)
+    double* part = s_part + phase * (LM_W * 32);
+    if ((lane & 15) == 0) {
+        const int slot = VO_R32_SLOT(lane >> 4);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) part[wave * 32 + 4 * k + slot] = r8[k];
+    }
     __syncthreads();
     if (threadIdx.x < LM_NV) {
         double sum = 0;
 #pragma unroll
-        for (int w = 0; w < LM_W; ++w) sum += s_part[w * LM_NV + threadIdx.x];
-        s_out[threadIdx.x] = sum;
+        for (int w = 0; w < LM_W; ++w) sum += part[w * 32 + threadIdx.x];
+        tot[threadIdx.x] = sum;
     }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < LM_NV; ++i) v[i] = s_out[i];
+    __syncthreads();                                   // tot[0..27] (LDS) is now valid for every thread
+    phase ^= 1;
 #ifdef VO_LM_STAMPS
     if (threadIdx.x == 0) { g_dbg[4] += ts1 - ts0; g_dbg[5] += ts2 - ts1; g_dbg[6] += clock64() - ts2; }
 #endif
@@ -583,12 +590,14 @@ __device__ void lm_pass_dev(const CamD& cam, const float* cxyz, const float* cuv
 // g2o Levenberg-Marquardt (lambda/rho policy of OptimizationAlgorithmLevenberg).  The trial pass also
 // linearises at the trial pose, so an accepted step needs no second pass (same numbers g2o recomputes).
 __device__ int lm_optimize_dev(const CamD& cam, const float* cxyz, const float* cuv, const int32_t* edges, const uint8_t* mask, int n,
-                               int round, double* T, double delta, int max_it, double* s_part, double* s_out) {
-    double cur_v[LM_NV], tr_v[LM_NV];
+                               int round, double* T, double delta, int max_it, double* s_part, double* s_tot, int& phase) {
+    // The current linearisation and the trial one live in two LDS buffers (s_tot + 32 cur, s_tot + 32 (cur ^ 1)): an
+    // accepted step flips `cur`, nothing is copied and no thread keeps 2 x 28 doubles in registers across a pass.
+    int cur = 0;
 #ifdef VO_LM_STAMPS
     long long t_pass = 0, t_serial = 0, n_pass = 1, t0 = clock64();
 #endif
-    lm_pass_dev(cam, cxyz, cuv, edges, mask, n, round, T, delta, cur_v, s_part, s_out);
+    lm_pass_dev(cam, cxyz, cuv, edges, mask, n, round, T, delta, s_part, s_tot, phase);
 #ifdef VO_LM_STAMPS
     t_pass += clock64() - t0;
 #endif
@@ -596,15 +605,16 @@ __device__ int lm_optimize_dev(const CamD& cam, const float* cxyz, const float* 
     {
         const int dg[6] = {0, 6, 11, 15, 18, 20};
         double md = 0;
-        for (int i = 0; i < 6; ++i) md = fmax(md, fabs(cur_v[dg[i]]));
+        for (int i = 0; i < 6; ++i) md = fmax(md, fabs(s_tot[dg[i]]));
         lambda = 1e-5 * md;
     }
     int it = 0;
     for (; it < max_it; ++it) {
+        const double* cv = s_tot + 32 * cur;
         double H[36], bvec[6];
-        { int c = 0; for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) { H[a * 6 + b] = cur_v[c]; H[b * 6 + a] = cur_v[c]; ++c; } }
-        for (int a = 0; a < 6; ++a) bvec[a] = cur_v[21 + a];
-        double cur = cur_v[27];
+        { int c = 0; for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) { const double h = cv[c]; H[a * 6 + b] = h; H[b * 6 + a] = h; ++c; } }
+        for (int a = 0; a < 6; ++a) bvec[a] = cv[21 + a];
+        double chi_cur = cv[27];
         double rho = 0; int qmax = 0; bool converged = false;
         do {
             double A[36], x[6], Tn[12];
@@ -620,21 +630,22 @@ __device__ int lm_optimize_dev(const CamD& cam, const float* cxyz, const float* 
             long long t2 = clock64(); t_serial += t2 - t1;
 #endif
             // block-uniform control flow: every thread holds the same H, b, lambda
-            lm_pass_dev(cam, cxyz, cuv, edges, mask, n, round, Tn, delta, tr_v, s_part, s_out);
+            const double* tv = s_tot + 32 * (cur ^ 1);
+            lm_pass_dev(cam, cxyz, cuv, edges, mask, n, round, Tn, delta, s_part, s_tot + 32 * (cur ^ 1), phase);
 #ifdef VO_LM_STAMPS
             t_pass += clock64() - t2; ++n_pass;
 #endif
-            const double tmp = ok ? tr_v[27] : DBL_MAX;
-            rho = cur - tmp;
+            const double tmp = ok ? tv[27] : DBL_MAX;
+            rho = chi_cur - tmp;
             double scale = 1e-3;
             if (ok) for (int i = 0; i < 6; ++i) scale += x[i] * (lambda * x[i] + bvec[i]);
             rho /= scale;
             if (rho > 0 && isfinite(tmp)) {
                 double a = 1.0 - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
                 a = fmin(a, 2.0 / 3.0);
-                lambda *= fmax(1.0 / 3.0, a); ni = 2; cur = tmp;
+                lambda *= fmax(1.0 / 3.0, a); ni = 2; chi_cur = tmp;
                 for (int i = 0; i < 12; ++i) T[i] = Tn[i];
-                for (int i = 0; i < LM_NV; ++i) cur_v[i] = tr_v[i];
+                cur ^= 1;                                  // the trial linearisation becomes the current one
             } else { lambda *= ni; ni *= 2; }
             if (ok) {
                 double mx = 0;
@@ -667,8 +678,9 @@ __global__ __launch_bounds__(LM_T) void k_pose_lm(CamD cam, ChainBuf cb, double 
     const long long t_kernel0 = clock64();
 #endif
     extern __shared__ float s_corr[];                  // gathered inlier correspondences: n x 3 then n x 2 floats
-    __shared__ double s_part[LM_W * LM_NV];
-    __shared__ double s_out[LM_NV];
+    __shared__ double s_part[2 * LM_W * 32];
+    __shared__ double s_out[2 * 32];
+    int phase = 0;
     __shared__ int s_cnt[2];
     const int n = tr->n_inl;
     double T[12];
@@ -684,7 +696,7 @@ __global__ __launch_bounds__(LM_T) void k_pose_lm(CamD cam, ChainBuf cb, double 
     }
     __syncthreads();
     int iters = 0;
-    if (n > 0) iters += lm_optimize_dev(cam, cxyz, cuv, edges, mask, n, 0, T, delta, it_r, s_part, s_out);
+    if (n > 0) iters += lm_optimize_dev(cam, cxyz, cuv, edges, mask, n, 0, T, delta, it_r, s_part, s_out, phase);
     // edges whose chi2 exceeds the cut leave the second round (frontend.cpp:294-306)
     int loc = 0;
     for (int i = threadIdx.x; i < n; i += LM_T) {
@@ -695,7 +707,7 @@ __global__ __launch_bounds__(LM_T) void k_pose_lm(CamD cam, ChainBuf cb, double 
     }
     if (loc) atomicAdd(&s_cnt[0], loc);
     __syncthreads();
-    if (s_cnt[0] > 0) iters += lm_optimize_dev(cam, cxyz, cuv, edges, mask, n, 1, T, delta, it_p, s_part, s_out);
+    if (s_cnt[0] > 0) iters += lm_optimize_dev(cam, cxyz, cuv, edges, mask, n, 1, T, delta, it_p, s_part, s_out, phase);
     loc = 0;
     for (int i = threadIdx.x; i < n; i += LM_T) {
         const int k = edges ? edges[i] : i;
