@@ -250,7 +250,7 @@ int vo_ctx_create(const vo_params* p, int device, vo_ctx** out) {
     ALLOC(c->d_sel, (size_t)F * P.nfeat); ALLOC(c->d_sel_key, (size_t)F * P.nfeat); ALLOC(c->d_sel_cnt, (size_t)F * VO_MAX_LEVELS);
     ALLOC(c->d_kps, (size_t)F * P.nfeat); ALLOC(c->d_desc, (size_t)F * P.nfeat * 32); ALLOC(c->d_nkp, (size_t)F);
     ALLOC(c->d_status, 1);
-    const size_t M = (size_t)p->map_capacity;
+    const size_t M = ((size_t)p->map_capacity + 3) & ~(size_t)3;      // per-lane buffers stay 16-byte aligned (k_match_gate loads uint4)
     ALLOC(c->d_map_pos, 3 * M); ALLOC(c->d_map_nrm, 3 * M); ALLOC(c->d_map_desc, 8 * M); ALLOC(c->d_map_flags, M);
     c->active_cap = p->map_capacity; c->corr_cap = p->map_capacity;
     const size_t NL = (size_t)c->lanes;

@@ -51,7 +51,7 @@ struct TrackDev {
 // concurrently (blockIdx.z): frames between two keyframes share the prior pose and the map
 // (reference src/frontend.cpp:96 -- the prior is the last KEYFRAME's pose), so they are independent.
 struct ChainBuf {
-    TrackDev* tr; unsigned long long* best; int32_t* mcand; vo_match* matches; float* cxyz; float* cuv;
+    TrackDev* tr; uint32_t* best; int32_t* mcand; vo_match* matches; float* cxyz; float* cuv;
     double* hyp_pose; int* hyp_cnt; int32_t* inliers; uint8_t* lm_mask;
     size_t stride; int max_hyp, nfeat;
     const uint8_t* desc; const int* nkp; const vo_keypoint* kps;      // per frame slot: [slot][nfeat]
@@ -79,7 +79,7 @@ struct vo_ctx {
     double* d_map_pos; double* d_map_nrm; uint32_t* d_map_desc; uint8_t* d_map_flags;
     int32_t* d_active; int n_active; int active_cap;
     // tracking chain
-    unsigned long long* d_best;                     // per active query: (dist<<32)|kp
+    uint32_t* d_best;                               // per active query: (dist << 22) | kp, 0xFFFFFFFF = not a candidate
     int32_t* d_mcand;                               // visible candidates (indices into the active list), unordered
     vo_match* d_matches; float* d_corr_xyz; float* d_corr_uv; int corr_cap;
     double* d_hyp_pose; int* d_hyp_cnt;             // [max_hyp][12], [max_hyp]

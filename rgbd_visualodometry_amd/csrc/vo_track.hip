@@ -27,6 +27,7 @@
 
 #ifdef VO_LM_STAMPS
 __device__ long long g_dbg[8];
+__device__ long long g_dbg2[8];
 #endif
 
 struct CamD { double fx, fy, cx, cy; int W, H; };
@@ -34,7 +35,7 @@ struct CamD { double fx, fy, cx, cy; int W, H; };
 #define LANE_PTRS(cb) \
     const int lane_ = blockIdx.z; \
     TrackDev* tr = cb.tr + lane_; \
-    unsigned long long* best = cb.best + (size_t)lane_ * cb.stride; \
+    uint32_t* best = cb.best + (size_t)lane_ * cb.stride; \
     int32_t* cand = cb.mcand + (size_t)lane_ * cb.stride; \
     vo_match* matches = cb.matches + (size_t)lane_ * cb.stride; \
     float* cxyz = cb.cxyz + 3 * (size_t)lane_ * cb.stride; \
@@ -70,6 +71,8 @@ __device__ __forceinline__ double comp(D3 a, int i) { return i == 0 ? a.x : (i =
 // ------------------------------------------------------------------------------------------
 #define MQ 64
 #define MT 64
+#define MATCH_NONE 0xFFFFFFFFu      // best[q] = (distance << 22) | keypoint index: one 32-bit atomicMin keeps the first minimum
+#define MATCH_GRID_X 512            // candidate tiles per grid row (32768 candidates); more are taken in a stride loop
 // visibility filter: every active map point gets best[q] = ~0; visible ones are appended to the
 // (unordered) candidate list -- order is restored later because results are indexed by q.
 __global__ __launch_bounds__(256) void k_frustum(CamD cam, ChainBuf cb, const double* __restrict__ map_pos,
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(256) void k_frustum(CamD cam, ChainBuf cb, const do
     LANE_PTRS(cb)
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= n_active) return;
-    best[q] = ~0ull;
+    best[q] = MATCH_NONE;
     const int mi = active[q];
     if (map_flags[mi] & VO_MAP_FLAG_OUTLIER) return;
     double T[12];
@@ -104,24 +107,28 @@ __global__ __launch_bounds__(64) void k_match(ChainBuf cb, const uint32_t* __res
     __shared__ uint4 s_train[MT * 2];
     const int nkp = *nkp_p, ncand = tr->pad0;
     const int t0 = blockIdx.y * MT;
+    // the candidate count is only known on the device: the grid has a fixed number of candidate tiles per keypoint
+    // tile (instead of one per 64 ACTIVE points, most of which would exit at once) and strides over the rest
     if (t0 >= nkp || (int)blockIdx.x * MQ >= ncand) return;
     const int nt = min(MT, nkp - t0);
     const uint4* src = (const uint4*)(fdesc + (size_t)t0 * 8);
     for (int i = threadIdx.x; i < nt * 2; i += 64) s_train[i] = src[i];
     __syncthreads();
-    const int ci = blockIdx.x * MQ + threadIdx.x;
-    if (ci >= ncand) return;
-    const int q = cand[ci];
-    const uint4* qd = (const uint4*)(map_desc + (size_t)active[q] * 8);
-    const uint4 qa = qd[0], qb = qd[1];
-    int bd = 1 << 30, bi = 0;
-    for (int t = 0; t < nt; ++t) {
-        const uint4 a = s_train[2 * t], b = s_train[2 * t + 1];
-        const int h = __popc(qa.x ^ a.x) + __popc(qa.y ^ a.y) + __popc(qa.z ^ a.z) + __popc(qa.w ^ a.w) +
-                      __popc(qb.x ^ b.x) + __popc(qb.y ^ b.y) + __popc(qb.z ^ b.z) + __popc(qb.w ^ b.w);
-        if (h < bd) { bd = h; bi = t; }
+    for (int c0 = blockIdx.x * MQ; c0 < ncand; c0 += gridDim.x * MQ) {
+        const int ci = c0 + threadIdx.x;
+        if (ci >= ncand) break;
+        const int q = cand[ci];
+        const uint4* qd = (const uint4*)(map_desc + (size_t)active[q] * 8);
+        const uint4 qa = qd[0], qb = qd[1];
+        int bd = 1 << 30, bi = 0;
+        for (int t = 0; t < nt; ++t) {
+            const uint4 a = s_train[2 * t], b = s_train[2 * t + 1];
+            const int h = __popc(qa.x ^ a.x) + __popc(qa.y ^ a.y) + __popc(qa.z ^ a.z) + __popc(qa.w ^ a.w) +
+                          __popc(qb.x ^ b.x) + __popc(qb.y ^ b.y) + __popc(qb.z ^ b.z) + __popc(qb.w ^ b.w);
+            if (h < bd) { bd = h; bi = t; }
+        }
+        atomicMin(&best[q], ((uint32_t)bd << 22) | (uint32_t)(t0 + bi));
     }
-    atomicMin(&best[q], ((unsigned long long)bd << 32) | (unsigned)(t0 + bi));
 }
 
 __device__ __forceinline__ int block_excl_scan_flag(bool flag, int* s_w, int& total) {
@@ -149,32 +156,50 @@ __global__ __launch_bounds__(1024) void k_match_gate(ChainBuf cb, const int32_t*
     __shared__ int s_w[16];
     __shared__ int s_min;
     if (threadIdx.x == 0) s_min = 1 << 30;
-    int mn = 1 << 30;
+#ifdef VO_LM_STAMPS
+    long long gt_[6]; int gi_ = 0; gt_[gi_++] = clock64();
+#define GATE_STAMP() gt_[gi_++] = clock64();
+#else
+#define GATE_STAMP()
+#endif
+    uint32_t mn = MATCH_NONE;                               // distance sits in the top bits: min over the packed words
     if (use_lds) {
-        for (int q = threadIdx.x; q < n_active; q += 1024) {
-            const unsigned long long b = best[q];
-            uint32_t pk = 0xFFFFFFFFu;
-            if (b != ~0ull) { const int d = (int)(b >> 32); mn = min(mn, d); pk = ((uint32_t)d << 22) | (uint32_t)(b & 0x3FFFFFu); }
-            s_pk[q] = pk;
+        const uint4* b4 = reinterpret_cast<const uint4*>(best);     // 4 results per load (lane buffers are 16-byte aligned)
+        uint4* s4 = reinterpret_cast<uint4*>(s_pk);
+        const int n4 = (n_active + 3) >> 2;
+#pragma unroll 4
+        for (int i = threadIdx.x; i < n4; i += 1024) {
+            uint4 v = b4[i];
+            const int q = 4 * i;
+            if (q + 1 >= n_active) v.y = MATCH_NONE;
+            if (q + 2 >= n_active) v.z = MATCH_NONE;
+            if (q + 3 >= n_active) v.w = MATCH_NONE;
+            mn = min(min(mn, v.x), min(v.y, min(v.z, v.w)));
+            s4[i] = v;
         }
     } else {
-        for (int q = threadIdx.x; q < n_active; q += 1024) { const unsigned long long b = best[q]; if (b != ~0ull) mn = min(mn, (int)(b >> 32)); }
+        for (int q = threadIdx.x; q < n_active; q += 1024) mn = min(mn, best[q]);
     }
     __syncthreads();
+    GATE_STAMP()
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mn = min(mn, __shfl_xor(mn, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMin(&s_min, mn);
+    for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMin(&s_min, mn == MATCH_NONE ? (1 << 30) : (int)(mn >> 22));
     __syncthreads();
     const int gmin = s_min;
     const float max_dis = fmaxf((float)gmin * ratio, floor_dist);
     const int seg = (n_active + 1023) / 1024;
     const int q0 = min(n_active, (int)threadIdx.x * seg), q1 = min(n_active, q0 + seg);
     auto fetch = [&](int q, int& d, int& kp) -> bool {
-        if (use_lds) { const uint32_t pk = s_pk[q]; if (pk == 0xFFFFFFFFu) return false; d = (int)(pk >> 22); kp = (int)(pk & 0x3FFFFFu); return true; }
-        const unsigned long long b = best[q]; if (b == ~0ull) return false; d = (int)(b >> 32); kp = (int)(b & 0xFFFFFFFFu); return true;
+        const uint32_t pk = use_lds ? s_pk[q] : best[q];
+        if (pk == MATCH_NONE) return false;
+        d = (int)(pk >> 22); kp = (int)(pk & 0x3FFFFFu);
+        return true;
     };
+    GATE_STAMP()
     int keep = 0;
     for (int q = q0; q < q1; ++q) { int d, kp; if (fetch(q, d, kp) && (float)d <= max_dis) ++keep; }
+    GATE_STAMP()
     int incl = keep;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -184,24 +209,38 @@ __global__ __launch_bounds__(1024) void k_match_gate(ChainBuf cb, const int32_t*
     int off = 0, total = 0;
     for (int i = 0; i < 16; ++i) { const int c = s_w[i]; if (i < wave) off += c; total += c; }
     int pos = off + incl - keep;
+    GATE_STAMP()
+    // The kept queries go, in list order, to a compact index list (the candidate buffer is free again); k_match_emit
+    // writes the records by position with many workgroups, so the dependent gathers (active -> map position,
+    // keypoint) of different matches overlap instead of queueing up inside one thread's segment.
     for (int q = q0; q < q1; ++q) {
         int d, kp;
-        if (fetch(q, d, kp) && (float)d <= max_dis) {
-            if (pos < cap) {
-                const int mi = active[q];
-                vo_match m; m.map_index = mi; m.kp_index = kp; m.distance = d; m.flags = 0;
-                matches[pos] = m;
-                cxyz[3 * pos] = (float)map_pos[3 * (size_t)mi]; cxyz[3 * pos + 1] = (float)map_pos[3 * (size_t)mi + 1]; cxyz[3 * pos + 2] = (float)map_pos[3 * (size_t)mi + 2];
-                cuv[2 * pos] = kps[kp].x; cuv[2 * pos + 1] = kps[kp].y;
-            }
-            ++pos;
-        }
+        if (fetch(q, d, kp) && (float)d <= max_dis) { if (pos < cap) cand[pos] = q; ++pos; }
     }
+#ifdef VO_LM_STAMPS
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.z == 0) { GATE_STAMP() printf("[gate] n_active %d ncand %d | stage %lld min %lld count %lld scan %lld write %lld clocks\n", n_active, tr->pad0, gt_[1] - gt_[0], gt_[2] - gt_[1], gt_[3] - gt_[2], gt_[4] - gt_[3], gt_[5] - gt_[4]); }
+#endif
     if (threadIdx.x == 0) {
         const int ncand = tr->pad0;
         tr->n_cand = ncand; tr->pad0 = 0;                 // counter ready for the next pass
         tr->n_match = min(total, cap); tr->min_dist = ncand ? gmin : -1;
         if (total > cap) tr->status = VO_E_OVERFLOW;
+    }
+}
+
+// match records + float32 correspondence pairs of the kept queries (list written by k_match_gate), by output position
+__global__ __launch_bounds__(256) void k_match_emit(ChainBuf cb, const int32_t* __restrict__ active, const double* __restrict__ map_pos) {
+    LANE_PTRS(cb)
+    const int nout = tr->n_match;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < nout; p += gridDim.x * 256) {
+        const int q = cand[p];
+        const uint32_t pk = best[q];
+        const int d = (int)(pk >> 22), kp = (int)(pk & 0x3FFFFFu), mi = active[q];
+        vo_match m; m.map_index = mi; m.kp_index = kp; m.distance = d; m.flags = 0;
+        matches[p] = m;
+        cxyz[3 * p] = (float)map_pos[3 * (size_t)mi]; cxyz[3 * p + 1] = (float)map_pos[3 * (size_t)mi + 1]; cxyz[3 * p + 2] = (float)map_pos[3 * (size_t)mi + 2];
+        cuv[2 * p] = kps[kp].x; cuv[2 * p + 1] = kps[kp].y;
     }
 }
 
@@ -769,13 +808,14 @@ int vo_track_match_launch(vo_ctx* c, int nl, const int* slots, float ratio, floa
         { ProfScope ps(c, "k_frustum");
           hipLaunchKernelGGL(k_frustum, dim3((na + 255) / 256, 1, nl), dim3(256), 0, st, cam_of(c), cb, c->d_map_pos, c->d_map_nrm, c->d_map_flags, c->d_active, na); }
         ProfScope ps(c, "k_match");
-        dim3 g((na + MQ - 1) / MQ, (c->p.n_features + MT - 1) / MT, nl);
+        dim3 g(std::min((na + MQ - 1) / MQ, MATCH_GRID_X), (c->p.n_features + MT - 1) / MT, nl);
         hipLaunchKernelGGL(k_match, g, dim3(64), 0, st, cb, c->d_map_desc, c->d_active);
     }
     { ProfScope ps(c, "k_match_gate");
       const int use_lds = na <= GATE_LDS_MAX ? 1 : 0;
-      hipLaunchKernelGGL(k_match_gate, dim3(1, 1, nl), dim3(1024), use_lds ? sizeof(uint32_t) * (size_t)na : 0, st, cb, c->d_active, na, c->d_map_pos,
-                         ratio, floor_dist, c->corr_cap, use_lds); }
+      hipLaunchKernelGGL(k_match_gate, dim3(1, 1, nl), dim3(1024), use_lds ? sizeof(uint32_t) * (((size_t)na + 3) & ~(size_t)3) : 0, st, cb, c->d_active, na, c->d_map_pos,
+                         ratio, floor_dist, c->corr_cap, use_lds);
+      if (na > 0) hipLaunchKernelGGL(k_match_emit, dim3(32, 1, nl), dim3(256), 0, st, cb, c->d_active, c->d_map_pos); }
     HIP_TRY(hipGetLastError());
     return VO_OK;
 }
