@@ -48,6 +48,7 @@ struct BaDev {
     const BaBlock* blocks; const int2* pairs;               // (e1, e2) pairs sharing a point, grouped by (pose(e1) <= pose(e2))
     double* Hpp; double* bp; double* Hll; double* bl; double* W;
     double* S; double* bs; double* Hinv; double* dl;
+    double* partU; double* partC; int nU;   // per-workgroup partial sums (no same-address atomics): update {gain term, max step} x nU, trial chi2 x grid of k_ba_chi_control
     double* scal;       // [0] chi cur  [1] chi trial  [2] scale  [3] ok  [4] maxdiag (as u64 bits) [5] chi report [6] chi final
 };
 
@@ -100,18 +101,26 @@ __device__ __forceinline__ void ba_wave_reduce(double* v) {      // 64 threads; 
     for (int i = 0; i < NV; ++i) v[i] = vo_wave_sum_f64(v[i]);
 }
 
-// Linearisation, one launch: blocks [0, gp) own 256 points each (H_ll, b_l, W_e, chi2: no atomics, no zeroing),
+// Linearisation, one launch: blocks [0, gp) own 64 points each, 4 lanes per point (H_ll, b_l, W_e, chi2: no atomics, no zeroing),
 // blocks [gp, gp + PSPLIT n_free) reduce slices of a free pose's edges into H_pp / b_p (27 f64 atomics per block;
 // H_pp / b_p are zeroed by the step that accepted the state, see k_ba_chi_control).
 #define PSPLIT 4
+// Four lanes share a point (a quad): each takes every fourth edge, the quad sums H_ll / b_l with two DPP quad
+// permutes.  A point seen by all ~30 keyframes of the window no longer makes one lane walk 30 edges in a row.
+__device__ __forceinline__ double ba_quad_sum(double x) {
+    x += vo_dpp_mov_f64<0xB1, 0xF>(x);      // quad_perm [1,0,3,2]
+    x += vo_dpp_mov_f64<0x4E, 0xF>(x);      // quad_perm [2,3,0,1]
+    return x;
+}
 __device__ __forceinline__ void ba_lin_points_body(const BaCam& cam, const BaDev& B, int robust, double delta, int blk,
                                                    const double* poses_c, const double* pts_c, double* s_part) {
-    const int k = blk * 256 + threadIdx.x;
+    const int k = blk * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
     double chi[1] = {0.0};
+    double H[6] = {0, 0, 0, 0, 0, 0}, b3[3] = {0, 0, 0};
     if (k < B.n_points) {
-        double H[6] = {0, 0, 0, 0, 0, 0}, b3[3] = {0, 0, 0};
         const double* p = pts_c + 3 * (size_t)k;
-        for (int q = B.pt_start[k]; q < B.pt_start[k + 1]; ++q) {
+        const int q1 = B.pt_start[k + 1];
+        for (int q = B.pt_start[k] + sub; q < q1; q += 4) {
             const int e = B.pt_edges[q];
             if (!B.active[e]) continue;
             const int j = B.e_pose[e];
@@ -129,6 +138,12 @@ __device__ __forceinline__ void ba_lin_points_body(const BaCam& cam, const BaDev
                     for (int c = 0; c < 3; ++c) We[3 * a + c] = w * (Jp[0][a] * Jl[0][c] + Jp[1][a] * Jl[1][c]);
             }
         }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) H[i] = ba_quad_sum(H[i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) b3[i] = ba_quad_sum(b3[i]);
+    if (k < B.n_points && sub == 0) {
         double* Ho = B.Hll + 9 * (size_t)k;
         Ho[0] = H[0]; Ho[1] = H[1]; Ho[2] = H[2]; Ho[3] = H[1]; Ho[4] = H[3]; Ho[5] = H[4]; Ho[6] = H[2]; Ho[7] = H[4]; Ho[8] = H[5];
         B.bl[3 * (size_t)k] = b3[0]; B.bl[3 * (size_t)k + 1] = b3[1]; B.bl[3 * (size_t)k + 2] = b3[2];
@@ -157,18 +172,38 @@ __device__ __forceinline__ void ba_lin_poses_body(const BaCam& cam, const BaDev&
             for (int b = a; b < 6; ++b) v[c++] += w * (Jp[0][a] * Jp[0][b] + Jp[1][a] * Jp[1][b]);
         }
     }
-    ba_block_reduce<27>(v, s_part);
-    if (threadIdx.x == 0) {
-        int c = 0;
-        for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) { atomicAdd(&B.Hpp[36 * (size_t)j + 6 * a + b], v[c]); if (a != b) atomicAdd(&B.Hpp[36 * (size_t)j + 6 * b + a], v[c]); ++c; }
-        for (int a = 0; a < 6; ++a) atomicAdd(&B.bp[6 * j + a], v[21 + a]);
+    // 27 sums over the 256 threads: transposed 32-value wave reduction, then the 4 wave partials through LDS
+    {
+        double v32[32], r8[8];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) v32[i] = i < 27 ? v[i] : 0.0;
+        vo_wave_reduce32(v32, r8);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        __syncthreads();
+        if ((lane & 15) == 0) {
+            const int slot = VO_R32_SLOT(lane >> 4);
+#pragma unroll
+            for (int k8 = 0; k8 < 7; ++k8) s_part[wave * 32 + 4 * k8 + slot] = r8[k8];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 27) {
+        const int i = threadIdx.x;
+        const double t = s_part[i] + s_part[32 + i] + s_part[64 + i] + s_part[96 + i];
+        if (i < 21) {
+            int a = 0, rem = i;
+            while (rem >= 6 - a) { rem -= 6 - a; ++a; }        // upper-triangle index -> (a, b)
+            const int b = a + rem;
+            atomicAdd(&B.Hpp[36 * (size_t)j + 6 * a + b], t);
+            if (a != b) atomicAdd(&B.Hpp[36 * (size_t)j + 6 * b + a], t);
+        } else atomicAdd(&B.bp[6 * j + (i - 21)], t);
     }
 }
 
 __global__ __launch_bounds__(256) void k_ba_lin(BaCam cam, BaDev B, int robust, double delta, int gp) {
     if (B.ctl->finished || !B.ctl->need_lin) return;
     BA_STATE(B)
-    __shared__ double s_part[4 * 27];
+    __shared__ double s_part[4 * 32];
     if ((int)blockIdx.x < gp) ba_lin_points_body(cam, B, robust, delta, blockIdx.x, poses_c, pts_c, s_part);
     else ba_lin_poses_body(cam, B, robust, delta, blockIdx.x - gp, poses_c, pts_c, s_part);
 }
@@ -249,8 +284,21 @@ __global__ __launch_bounds__(256) void k_ba_schur_blocks(BaDev B) {
             if (diag) v[36 + r] += y0 * b0 + y1 * b1 + y2 * b2;
         }
     }
-    ba_wave_reduce<42>(v);
-    if ((threadIdx.x & 63) == 0) for (int i = 0; i < 42; ++i) s_part[(threadIdx.x >> 6) * 42 + i] = v[i];
+    {   // 42 sums: two transposed 32-value wave reductions (v[0..31], v[32..41] + padding), wave partials through LDS
+        double lo[32], hi[32], r0[8], r1[8];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { lo[i] = v[i]; hi[i] = i < 10 ? v[32 + i] : 0.0; }
+        vo_wave_reduce32(lo, r0);
+        vo_wave_reduce32(hi, r1);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if ((lane & 15) == 0) {
+            const int slot = VO_R32_SLOT(lane >> 4);
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) s_part[wave * 42 + 4 * k8 + slot] = r0[k8];
+#pragma unroll
+            for (int k8 = 0; k8 < 3; ++k8) if (4 * k8 + slot < 10) s_part[wave * 42 + 32 + 4 * k8 + slot] = r1[k8];
+        }
+    }
     __syncthreads();
     if (threadIdx.x < 42) s_tot[threadIdx.x] = s_part[threadIdx.x] + s_part[42 + threadIdx.x] + s_part[84 + threadIdx.x] + s_part[126 + threadIdx.x];
     __syncthreads();
@@ -758,16 +806,23 @@ __global__ __launch_bounds__(CH_THREADS) void k_ba_chol16(BaDev B) {
 }
 
 __device__ __forceinline__ void ba_backsub_body(const BaDev& B, double lambda, int blk, const double* pts_c, double* pts_t) {
-    const int k = blk * blockDim.x + threadIdx.x;
+    const int k = blk * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;       // 4 lanes per point, as in the linearisation
     double sc = 0, mx = 0;
-    if (k < B.n_points && B.scal[3] != 0.0) {
-        double rhs[3] = {B.bl[3 * (size_t)k], B.bl[3 * (size_t)k + 1], B.bl[3 * (size_t)k + 2]};
-        for (int p1 = B.pt_start[k]; p1 < B.pt_start[k + 1]; ++p1) {
+    const bool live = k < B.n_points && B.scal[3] != 0.0;
+    double rhs[3] = {0, 0, 0};
+    if (live) {
+        if (sub == 0) { rhs[0] = B.bl[3 * (size_t)k]; rhs[1] = B.bl[3 * (size_t)k + 1]; rhs[2] = B.bl[3 * (size_t)k + 2]; }
+        const int q1 = B.pt_start[k + 1];
+        for (int p1 = B.pt_start[k] + sub; p1 < q1; p1 += 4) {
             const int e1 = B.pt_edges[p1], j1 = B.e_pose[e1];
             if (!B.active[e1] || j1 >= B.n_free) continue;
             const double* W1 = B.W + 18 * (size_t)e1;
             for (int c = 0; c < 3; ++c) for (int r = 0; r < 6; ++r) rhs[c] -= W1[3 * r + c] * B.bs[6 * j1 + r];
         }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rhs[c] = ba_quad_sum(rhs[c]);
+    if (live && sub == 0) {
         const double* h = B.Hinv + 9 * (size_t)k;
         for (int a = 0; a < 3; ++a) {
             const double d = h[3 * a] * rhs[0] + h[3 * a + 1] * rhs[1] + h[3 * a + 2] * rhs[2];
@@ -779,8 +834,15 @@ __device__ __forceinline__ void ba_backsub_body(const BaDev& B, double lambda, i
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { sc += __shfl_xor(sc, o, 64); mx = fmax(mx, __shfl_xor(mx, o, 64)); }
-    if ((threadIdx.x & 63) == 0 && sc != 0.0) atomicAdd(&B.scal[2], sc);
-    if ((threadIdx.x & 63) == 0 && mx != 0.0) atomicMax((unsigned long long*)&B.scal[7], (unsigned long long)__double_as_longlong(mx));
+    // one partial per workgroup, summed by the last workgroup of k_ba_chi_control: hundreds of f64 atomics on ONE
+    // address serialise in L2 and used to outlast the kernel body
+    __shared__ double s_u[8];
+    if ((threadIdx.x & 63) == 0) { s_u[threadIdx.x >> 6] = sc; s_u[4 + (threadIdx.x >> 6)] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        B.partU[2 * blk] = (s_u[0] + s_u[1]) + (s_u[2] + s_u[3]);
+        B.partU[2 * blk + 1] = fmax(fmax(s_u[4], s_u[5]), fmax(s_u[6], s_u[7]));
+    }
 }
 
 __device__ __forceinline__ void ba_pose_body(const BaDev& B, double lambda, int blk, const double* poses_c, double* poses_t) {
@@ -855,21 +917,36 @@ __global__ __launch_bounds__(256) void k_ba_chi_control(BaCam cam, BaDev B, int 
         v = (robust && e2 > delta * delta) ? 2.0 * sqrt(e2) * delta - delta * delta : e2;
     }
     v = vo_wave_sum_f64(v);
-    if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(&B.scal[1], v);
+    __shared__ double s_w[12];
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x == 0) {
+        B.partC[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);       // one partial per workgroup, no same-address atomics
         __threadfence();
         s_last = atomicAdd(&B.ctl->arrived, 1) == (int)gridDim.x - 1;
     }
     __syncthreads();
     if (!s_last) return;
     __shared__ int s_accept;
-    if (threadIdx.x == 0) {
+    {   // the last workgroup sums the partials of this kernel (trial chi2) and of k_ba_update (gain term, max step)
         __threadfence();
+        const volatile double* pc = B.partC; const volatile double* pu = B.partU;
+        double a = 0, b = 0, m = 0;
+        for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) a += pc[i];
+        for (int i = threadIdx.x; i < B.nU; i += 256) { b += pu[2 * i]; m = fmax(m, pu[2 * i + 1]); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); m = fmax(m, __shfl_xor(m, o, 64)); }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; s_w[w] = a; s_w[4 + w] = b; s_w[8 + w] = m; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
         BaCtl* c = B.ctl;
         c->arrived = 0;
-        const double s1 = atomicAdd(&B.scal[1], 0.0), s2 = atomicAdd(&B.scal[2], 0.0), s3 = atomicAdd(&B.scal[3], 0.0);
-        const unsigned long long s7 = atomicAdd((unsigned long long*)&B.scal[7], 0ull);
+        const double s1 = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+        const double s2 = atomicAdd(&B.scal[2], 0.0) + ((s_w[4] + s_w[5]) + (s_w[6] + s_w[7])), s3 = atomicAdd(&B.scal[3], 0.0);
+        const double m7 = fmax(__longlong_as_double((long long)atomicAdd((unsigned long long*)&B.scal[7], 0ull)), fmax(fmax(s_w[8], s_w[9]), fmax(s_w[10], s_w[11])));
+        const unsigned long long s7 = (unsigned long long)__double_as_longlong(m7);
         const bool ok = s3 != 0.0;
         const double tmp = ok ? s1 : DBL_MAX;
         const double scale = (ok ? s2 : 0.0) + 1e-3;
@@ -981,6 +1058,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     const size_t o_blk = carve(sizeof(BaBlock) * (size_t)std::max(nblk, 1)), o_pairs = carve(sizeof(int2) * pairs.size());
     const size_t o_Hpp = carve(288 * (size_t)nf), o_bp = carve(8 * (size_t)D), o_Hll = carve(72 * (size_t)nx), o_bl = carve(24 * (size_t)nx), o_scal = carve(64);
     const size_t o_ctl = carve(sizeof(BaCtl));
+    const size_t o_partU = carve(16 * ((size_t)(nx + 63) / 64 + 1)), o_partC = carve(8 * ((size_t)(ne + 255) / 256 + 1));
     const size_t o_W = carve(144 * (size_t)ne), o_S = carve(8 * (size_t)D * D), o_bs = carve(8 * (size_t)D), o_Hinv = carve(72 * (size_t)nx), o_dl = carve(24 * (size_t)nx);
     int rc = vo_scratch(c, off);
     if (rc) return rc;
@@ -990,6 +1068,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     B.ps_start = (const int32_t*)(base + o_qs); B.ps_edges = (const int32_t*)(base + o_qe); B.blocks = (const BaBlock*)(base + o_blk); B.pairs = (const int2*)(base + o_pairs);
     B.posesA = (double*)(base + o_poses); B.ptsA = (double*)(base + o_pts); B.posesB = (double*)(base + o_poses_n); B.ptsB = (double*)(base + o_pts_n);
     B.ctl = (BaCtl*)(base + o_ctl);
+    B.partU = (double*)(base + o_partU); B.partC = (double*)(base + o_partC); B.nU = (nx + 63) / 64;
     B.e_pose = (const int32_t*)(base + o_epose); B.e_pt = (const int32_t*)(base + o_ept); B.e_uv = (const float*)(base + o_euv);
     B.active = base + o_act; B.flags = base + o_flags; B.pt_start = (const int32_t*)(base + o_ps); B.pt_edges = (const int32_t*)(base + o_pe);
     B.Hpp = (double*)(base + o_Hpp); B.bp = (double*)(base + o_bp); B.Hll = (double*)(base + o_Hll); B.bl = (double*)(base + o_bl); B.scal = (double*)(base + o_scal);
@@ -1014,7 +1093,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     const double tt1 = tnow();
     double* h_scal = (double*)vo_stage(c, 256);
     if (!h_scal) return VO_E_NOMEM;
-    const dim3 blk(256), gE((ne + 255) / 256), gP((nx + 255) / 256), gJ((np + 255) / 256);
+    const dim3 blk(256), gE((ne + 255) / 256), gP((nx + 255) / 256), gP4((nx + 63) / 64), gJ((np + 255) / 256);
     auto read_scal = [&]() -> int {
         HIP_TRY(hipMemcpyAsync(h_scal, B.scal, 64, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -1034,14 +1113,14 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
         HIP_TRY(hipMemsetAsync(B.bp, 0, sizeof(double) * (size_t)D, st));
         for (int guard_steps = 0, chunk = max_it; guard_steps < max_it * 10 + CHUNK; guard_steps += chunk, chunk = 2) {
             for (int sidx = 0; sidx < chunk; ++sidx) {
-                { ProfScope ps(c, "k_ba_lin"); hipLaunchKernelGGL(k_ba_lin, dim3(gP.x + nf * PSPLIT), blk, 0, st, cam, B, robust, in->huber_delta, (int)gP.x); }
+                { ProfScope ps(c, "k_ba_lin"); hipLaunchKernelGGL(k_ba_lin, dim3(gP4.x + nf * PSPLIT), blk, 0, st, cam, B, robust, in->huber_delta, (int)gP4.x); }
                 if (guard_steps == 0 && sidx == 0) hipLaunchKernelGGL(k_ba_maxdiag, dim3((D + 3 * nx + 255) / 256), blk, 0, st, B);
                 { ProfScope ps(c, "k_ba_init_S"); hipLaunchKernelGGL(k_ba_init_S, dim3((std::max(D * D, nx) + 255) / 256), blk, 0, st, B); }
                 if (nblk) { ProfScope ps(c, "k_ba_schur_blocks"); hipLaunchKernelGGL(k_ba_schur_blocks, dim3(nblk), blk, 0, st, B); }
                 { ProfScope ps(c, "k_ba_chol");
                   if (D <= 192) hipLaunchKernelGGL(k_ba_chol16, dim3(1), dim3(CH_THREADS), sizeof(double) * (CH_NB * CH_NB + (size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D), st, B);
                   else hipLaunchKernelGGL(k_ba_chol_t<false>, dim3(1), dim3(1024), sizeof(double) * ((size_t)7 * (D + 1) + 2 * (size_t)D), st, B); }
-                { ProfScope ps(c, "k_ba_update"); hipLaunchKernelGGL(k_ba_update, dim3(gP.x + gJ.x), blk, 0, st, B, (int)gP.x); }
+                { ProfScope ps(c, "k_ba_update"); hipLaunchKernelGGL(k_ba_update, dim3(gP4.x + gJ.x), blk, 0, st, B, (int)gP4.x); }
                 { ProfScope ps(c, "k_ba_chi_control"); hipLaunchKernelGGL(k_ba_chi_control, gE, blk, 0, st, cam, B, robust, in->huber_delta); }
             }
             HIP_TRY(hipMemcpyAsync(h_ctl, B.ctl, sizeof(BaCtl), hipMemcpyDeviceToHost, st));

@@ -49,6 +49,7 @@ private:
     size_t frameIndex_ = 0;
     uint64_t buildStamp_ = 0;
     size_t lastEdges_ = 0, lastPoints_ = 0;          // reserve hints for the next graph
+    std::vector<int32_t> applySlots_; std::vector<double> applyXyz_;      // merge scratch
     std::unique_ptr<Job> job_;
     std::thread worker_; std::mutex mu_; std::condition_variable cv_; bool quit_ = false, hasWork_ = false;
     Stats stats_;

@@ -22,6 +22,9 @@ public:
     void SetPosition(const Vector3d pos) { { std::unique_lock<std::mutex> lock(posMutex_); pos_ = pos; } MarkDirty(); }
     // position already mirrored on the device by the caller (bulk upsert): no dirty marking
     void SetPositionSynced(const Vector3d pos) { std::unique_lock<std::mutex> lock(posMutex_); pos_ = pos; }
+    // Bulk paths of the map-owning thread (BA graph cut / merge touch every point of the local map): no lock per point.
+    const Vector3d& PositionUnlocked() const { return pos_; }
+    void SetPositionSyncedUnlocked(const Vector3d& pos) { pos_ = pos; }
     size_t GetId() const { return id_; }
     Vector3d GetNormDirection() { std::unique_lock<std::mutex> lock(observationMutex_); return norm_; }
 

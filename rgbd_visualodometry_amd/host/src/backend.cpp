@@ -130,7 +130,7 @@ void Backend::Build(Job& j, const Frame::Ptr& kf) {
     lastEdges_ = j.edgePose.size(); lastPoints_ = j.points.size();
     j.poses.resize(12 * j.poseFrames.size()); j.pts.resize(3 * j.points.size());
     for (size_t p = 0; p < j.poseFrames.size(); ++p) j.poseFrames[p]->GetPose().to12(&j.poses[12 * p]);
-    for (size_t k = 0; k < j.points.size(); ++k) { Vector3d x = j.points[k]->GetPosition(); j.pts[3 * k] = x[0]; j.pts[3 * k + 1] = x[1]; j.pts[3 * k + 2] = x[2]; }
+    for (size_t k = 0; k < j.points.size(); ++k) { const Vector3d& x = j.points[k]->PositionUnlocked(); j.pts[3 * k] = x[0]; j.pts[3 * k + 1] = x[1]; j.pts[3 * k + 2] = x[2]; }
     j.posesOut.resize(12 * (size_t)std::max(j.nFree, 1)); j.ptsOut.resize(3 * std::max<size_t>(j.points.size(), 1)); j.flags.resize(std::max<size_t>(j.edgePose.size(), 1));
 }
 
@@ -150,27 +150,36 @@ void Backend::Solve(Job& j, vo_ctx* ctx) {
 void Backend::Apply(Job& j) {
     VO_SCOPE("ba.apply");
     int outlierCnt = 0;
-    for (size_t e = 0; e < j.edgePose.size(); ++e) {                          // backend.cpp:144-172
+    const size_t ne = j.edgePose.size();
+    for (size_t e = 0; e < ne; ++e) {                                         // backend.cpp:144-172
+        if (!j.flags[e]) {                                                    // flagged edges are rare: skip clean runs 8 at a time
+            uint64_t w;
+            while (e + 8 <= ne && (std::memcpy(&w, &j.flags[e], 8), w == 0)) e += 8;
+            if (e >= ne || !j.flags[e]) continue;
+        }
         if (!(j.flags[e] & 3)) continue;
         Frame& f = *j.poseFrames[j.edgePose[e]];
         Mappoint& mp = *j.points[j.edgePoint[e]];
         if (f.IsObservedMappoint(mp.GetId())) f.RemoveObservedMappoint(mp.GetId());
         ++outlierCnt;
     }
-    for (Mappoint* mp : j.points) mp->optimized_ = true;                      // every point of the graph has at least one edge
     for (int p = 0; p < j.nFree; ++p) j.poseFrames[p]->SetPose(SE3::from12(&j.posesOut[12 * (size_t)p]));       // backend.cpp:183-187
     // backend.cpp:188-194.  The optimised positions are already one flat array: they go to the tracker's device map
     // in a single vo_map_upsert (positions only) instead of through the per-point dirty list.
-    std::vector<int32_t> slots; std::vector<double> xyz;
-    slots.reserve(j.points.size()); xyz.reserve(3 * j.points.size());
-    for (size_t k = 0; k < j.points.size(); ++k) {
+    const size_t np = j.points.size();
+    applySlots_.resize(np); applyXyz_.resize(3 * np);
+    size_t m = 0;
+    for (size_t k = 0; k < np; ++k) {
         Mappoint& mp = *j.points[k];
+        mp.optimized_ = true;                                                 // every point of the graph has at least one edge
         if (mp.outlier_) continue;
-        mp.SetPositionSynced(Vector3d(j.ptsOut[3 * k], j.ptsOut[3 * k + 1], j.ptsOut[3 * k + 2]));
-        slots.push_back(mp.slot_); xyz.push_back(j.ptsOut[3 * k]); xyz.push_back(j.ptsOut[3 * k + 1]); xyz.push_back(j.ptsOut[3 * k + 2]);
+        const double* x = &j.ptsOut[3 * k];
+        mp.SetPositionSyncedUnlocked(Vector3d(x[0], x[1], x[2]));
+        applySlots_[m] = mp.slot_; applyXyz_[3 * m] = x[0]; applyXyz_[3 * m + 1] = x[1]; applyXyz_[3 * m + 2] = x[2];
+        ++m;
     }
-    if (!slots.empty()) {
-        int rc = vo_map_upsert(ctx_, slots.data(), xyz.data(), nullptr, nullptr, nullptr, (int)slots.size());
+    if (m) {
+        int rc = vo_map_upsert(ctx_, applySlots_.data(), applyXyz_.data(), nullptr, nullptr, nullptr, (int)m);
         if (rc != VO_OK) throw std::runtime_error(std::string("vo_map_upsert (BA merge) failed: ") + vo_strerror(rc));
     }
     stats_.runs++; stats_.poses = j.nFree; stats_.fixed = (int)j.poseFrames.size() - j.nFree; stats_.points = (int)j.points.size();
