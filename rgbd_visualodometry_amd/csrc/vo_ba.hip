@@ -21,6 +21,8 @@
 #include <cstring>
 #include <chrono>
 #include <cstdlib>
+#include <functional>
+#include <thread>
 #include <vector>
 
 #include "vo_internal.h"
@@ -1018,35 +1020,60 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     ps_edges.resize(ps_start[nf]);
     { std::vector<int32_t> fill(ps_start.begin(), ps_start.end() - 1);
       for (int e = 0; e < ne; ++e) if (in->edge_pose[e] < nf) ps_edges[fill[in->edge_pose[e]]++] = e; }
-    std::vector<int32_t> blk_cnt((size_t)nf * nf, 0);
-    for (int k = 0; k < nx; ++k)
-        for (int a = pt_start[k]; a < pt_start[k + 1]; ++a) {
-            const int j1 = in->edge_pose[pt_edges[a]];
-            if (j1 >= nf) continue;
-            for (int b2 = pt_start[k]; b2 < pt_start[k + 1]; ++b2) { const int j2 = in->edge_pose[pt_edges[b2]]; if (j2 < nf && j1 <= j2 && (j1 < j2 || a == b2)) blk_cnt[(size_t)j1 * nf + j2]++; }
+    const double tp1 = tnow();
+    // Pair lists of the 6x6 blocks (j1 <= j2) of the reduced system, grouped by block with the points in ascending
+    // order inside a block.  Host threads split the point range: count per (thread, block), prefix over blocks and
+    // threads, then every thread writes its pairs straight into pinned memory -- same lists for any thread count.
+    // Two edges of one point to the same pose never pair up.
+    const int NT = ne > 20000 ? 4 : 1;
+    std::vector<std::vector<int32_t>> cnt_t(NT, std::vector<int32_t>((size_t)nf * nf, 0));
+    auto k_lo = [&](int t) { return (int)((long long)nx * t / NT); };
+    auto enumerate = [&](int t, int2* out, std::vector<int32_t>* fill) {
+        std::vector<int32_t>& cnt = cnt_t[t];
+        int32_t fe[64], fj[64]; std::vector<int32_t> fev, fjv;
+        for (int k = k_lo(t); k < k_lo(t + 1); ++k) {
+            const int deg = pt_start[k + 1] - pt_start[k];
+            int32_t* pe = fe; int32_t* pj = fj;
+            if (deg > 64) { fev.resize(deg); fjv.resize(deg); pe = fev.data(); pj = fjv.data(); }
+            int m = 0;
+            for (int a = pt_start[k]; a < pt_start[k + 1]; ++a) { const int e = pt_edges[a], j = in->edge_pose[e]; if (j < nf) { pe[m] = e; pj[m] = j; ++m; } }
+            for (int a = 0; a < m; ++a) {
+                const int ja = pj[a], ea = pe[a];
+                if (out) out[(*fill)[(size_t)ja * nf + ja]++] = make_int2(ea, ea); else cnt[(size_t)ja * nf + ja]++;
+                for (int b2 = a + 1; b2 < m; ++b2) {
+                    const int jb = pj[b2];
+                    if (ja == jb) continue;
+                    const size_t bid = ja < jb ? (size_t)ja * nf + jb : (size_t)jb * nf + ja;
+                    if (out) out[(*fill)[bid]++] = ja < jb ? make_int2(ea, pe[b2]) : make_int2(pe[b2], ea); else cnt[bid]++;
+                }
+            }
         }
+    };
+    auto run_threads = [&](const std::function<void(int)>& fn) {
+        std::vector<std::thread> th;
+        for (int t = 1; t < NT; ++t) th.emplace_back(fn, t);
+        fn(0);
+        for (auto& x : th) x.join();
+    };
+    run_threads([&](int t) { enumerate(t, nullptr, nullptr); });
     std::vector<BaBlock> blocks;
-    std::vector<int32_t> blk_off((size_t)nf * nf, -1);
+    std::vector<std::vector<int32_t>> off_t(NT, std::vector<int32_t>((size_t)nf * nf, 0));
     int npairs = 0;
     for (int j1 = 0; j1 < nf; ++j1) for (int j2 = j1; j2 < nf; ++j2) {
-        const int cnt = blk_cnt[(size_t)j1 * nf + j2];
+        const size_t bid = (size_t)j1 * nf + j2;
+        int cnt = 0;
+        for (int t = 0; t < NT; ++t) { off_t[t][bid] = npairs + cnt; cnt += cnt_t[t][bid]; }
         if (!cnt) continue;
-        blk_off[(size_t)j1 * nf + j2] = npairs;
         for (int o = 0; o < cnt; o += 512) blocks.push_back(BaBlock{j1, j2, npairs + o, std::min(512, cnt - o)});   // <= 2 pairs per lane
         npairs += cnt;
     }
-    std::vector<int2> pairs((size_t)std::max(npairs, 1));
-    { std::vector<int32_t> fill = blk_off;
-      for (int k = 0; k < nx; ++k)
-          for (int a = pt_start[k]; a < pt_start[k + 1]; ++a) {
-              const int e1 = pt_edges[a], j1 = in->edge_pose[e1];
-              if (j1 >= nf) continue;
-              for (int b2 = pt_start[k]; b2 < pt_start[k + 1]; ++b2) {
-                  const int e2 = pt_edges[b2], j2 = in->edge_pose[e2];
-                  if (j2 < nf && j1 <= j2 && (j1 < j2 || a == b2)) pairs[fill[(size_t)j1 * nf + j2]++] = make_int2(e1, e2);
-              }
-          } }
+    // pairs are written straight into pinned memory (after the 512-byte mailbox used for scal / ctl read-backs)
+    uint8_t* h_pin = (uint8_t*)vo_stage(c, 512 + sizeof(int2) * (size_t)std::max(npairs, 1));
+    if (!h_pin) return VO_E_NOMEM;
+    int2* pairs = (int2*)(h_pin + 512);
+    run_threads([&](int t) { enumerate(t, pairs, &off_t[t]); });
     const int nblk = (int)blocks.size();
+    const double tp2 = tnow();
 
     // carve the scratch slab
     size_t off = 0;
@@ -1055,7 +1082,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     const size_t o_epose = carve(4 * (size_t)ne), o_ept = carve(4 * (size_t)ne), o_euv = carve(8 * (size_t)ne), o_act = carve(ne), o_flags = carve(ne);
     const size_t o_ps = carve(4 * (size_t)(nx + 1)), o_pe = carve(4 * (size_t)ne);
     const size_t o_qs = carve(4 * (size_t)(nf + 1)), o_qe = carve(4 * (size_t)std::max<size_t>(ps_edges.size(), 1));
-    const size_t o_blk = carve(sizeof(BaBlock) * (size_t)std::max(nblk, 1)), o_pairs = carve(sizeof(int2) * pairs.size());
+    const size_t o_blk = carve(sizeof(BaBlock) * (size_t)std::max(nblk, 1)), o_pairs = carve(sizeof(int2) * (size_t)std::max(npairs, 1));
     const size_t o_Hpp = carve(288 * (size_t)nf), o_bp = carve(8 * (size_t)D), o_Hll = carve(72 * (size_t)nx), o_bl = carve(24 * (size_t)nx), o_scal = carve(64);
     const size_t o_ctl = carve(sizeof(BaCtl));
     const size_t o_partU = carve(16 * ((size_t)(nx + 63) / 64 + 1)), o_partC = carve(8 * ((size_t)(ne + 255) / 256 + 1));
@@ -1085,9 +1112,10 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     HIP_TRY(hipMemcpyAsync(base + o_qs, ps_start.data(), 4 * (size_t)(nf + 1), hipMemcpyHostToDevice, st));
     if (!ps_edges.empty()) HIP_TRY(hipMemcpyAsync(base + o_qe, ps_edges.data(), 4 * ps_edges.size(), hipMemcpyHostToDevice, st));
     if (nblk) HIP_TRY(hipMemcpyAsync(base + o_blk, blocks.data(), sizeof(BaBlock) * (size_t)nblk, hipMemcpyHostToDevice, st));
-    if (npairs) HIP_TRY(hipMemcpyAsync(base + o_pairs, pairs.data(), sizeof(int2) * (size_t)npairs, hipMemcpyHostToDevice, st));
+    if (npairs) HIP_TRY(hipMemcpyAsync(base + o_pairs, pairs, sizeof(int2) * (size_t)npairs, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(base + o_act, 1, ne, st));
     HIP_TRY(hipMemsetAsync(base + o_flags, 0, ne, st));
+    const double tp3 = tnow();
     HIP_TRY(hipStreamSynchronize(st));       // pageable sources
 
     const double tt1 = tnow();
@@ -1163,6 +1191,6 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     HIP_TRY(hipMemcpyAsync(out->edge_flags, B.flags, ne, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
-    if (trace) { static double a0 = 0, a1 = 0, a2 = 0; static int n = 0; a0 += tt1 - tt0; a1 += tt2 - tt1; a2 += tnow() - tt2; if (++n % 10 == 0) fprintf(stderr, "[vo_trace] vo_ba_run avg ms: prep+upload %.2f optimise %.2f download %.2f (D=%d edges=%d pairs=%d)\n", a0 / n, a1 / n, a2 / n, D, ne, npairs); }
+    if (trace) { static double a0 = 0, a1 = 0, a2 = 0; static int n = 0; a0 += tt1 - tt0; a1 += tt2 - tt1; a2 += tnow() - tt2; if (++n % 10 == 0) fprintf(stderr, "[vo_trace] vo_ba_run avg ms: prep+upload %.2f optimise %.2f download %.2f (D=%d edges=%d pairs=%d) | last prep: csr %.2f pairs %.2f enqueue %.2f sync %.2f\n", a0 / n, a1 / n, a2 / n, D, ne, npairs, tp1 - tt0, tp2 - tp1, tp3 - tp2, tt1 - tp3); }
     return VO_OK;
 }

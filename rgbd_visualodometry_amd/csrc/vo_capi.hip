@@ -97,7 +97,7 @@ void* vo_stage(vo_ctx* c, size_t bytes) {
     if (bytes <= c->h_stage_bytes) return c->h_stage;
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     c->h_stage = nullptr; c->h_stage_bytes = 0;
-    size_t want = std::max<size_t>(bytes, 1 << 20);
+    size_t want = std::max<size_t>(bytes + bytes / 2, 1 << 20);     // grows with the map: leave headroom, pinned allocations are slow
     if (hipHostMalloc(&c->h_stage, want, hipHostMallocDefault) != hipSuccess) { c->h_stage = nullptr; return nullptr; }
     c->h_stage_bytes = want;
     return c->h_stage;

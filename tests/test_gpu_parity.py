@@ -148,8 +148,11 @@ def test_track_frame_matches_oracle(frames, libs):
     assert np.abs(np.array(ro.T_cw) - inv12(Twc[8])).max() < 0.02
 
 
-@pytest.mark.parametrize("nP,nX,nfree", [(6, 400, 4), (34, 500, 30), (40, 500, 36)])   # 36 free poses: D = 216 > LDS-resident limit (192)
-def test_local_ba_matches_oracle(libs, nP, nX, nfree):
+# D = 6 nfree: 24 (one 16-column panel + partial), 96 (full panels only), 180 (partial last panel), 192 (LDS-resident limit),
+# 216 (> limit: matrix in L2); 1300 points -> > 20000 edges (threaded pair-list build); shuffle: edges not sorted by point
+@pytest.mark.parametrize("nP,nX,nfree,shuffle", [(6, 400, 4, False), (18, 300, 16, False), (34, 500, 30, False), (34, 300, 32, True),
+                                                  (40, 500, 36, False), (34, 1300, 30, False)])
+def test_local_ba_matches_oracle(libs, nP, nX, nfree, shuffle):
     rng = np.random.default_rng(5)
 
     def expso3(w):
@@ -179,6 +182,9 @@ def test_local_ba_matches_oracle(libs, nP, nX, nfree):
         poses0[j][:9] = (expso3(rng.normal(size=3) * 0.01) @ poses[j][:9].reshape(3, 3)).ravel()
         poses0[j][9:] += rng.normal(size=3) * 0.02
     X0 = X + rng.normal(size=X.shape) * 0.05
+    if shuffle:
+        perm = rng.permutation(len(ep))
+        ep = [ep[i] for i in perm]; el = [el[i] for i in perm]; uv = [uv[i] for i in perm]
     res = []
     for L in (H, O):
         ctx, _ = make_ctx(L, map_capacity=1024)
