@@ -48,7 +48,7 @@ static int build_plan(const vo_params& p, DevPlan& P, std::vector<int>& tab, std
         P.tiles_x[l] = (P.lw[l] - 2 * P.edge + 63) / 64;
         const int tiles_y = (P.lh[l] - 2 * P.edge + 15) / 16;
         P.tile_prefix[l + 1] = P.tile_prefix[l] + P.tiles_x[l] * tiles_y;
-        P.btiles_x[l] = (P.lw[l] + 63) / 64;
+        P.btiles_x[l] = (P.lw[l] + 127) / 128;
         P.btile_prefix[l + 1] = P.btile_prefix[l] + P.btiles_x[l] * ((P.lh[l] + 15) / 16);
         maxq = std::max(maxq, P.quota[l]);
     }

@@ -27,30 +27,36 @@
 __constant__ int8_t c_pattern[256 * 4];
 
 // ------------------------------------------------------------------------------------------
+// 16 pixels per lane: 3 x 16-byte loads of BGR, one 16-byte store of gray (the row pitches are multiples of 16 for the
+// common widths; otherwise the byte path below).  The image is flattened over (row, 16-pixel group), so every
+// workgroup streams 256 x 48 B regardless of the image width.
+__device__ __forceinline__ uint32_t gray4(uint32_t w0, uint32_t w1, uint32_t w2) {      // 12 bytes BGRBGRBGRBGR -> 4 gray bytes
+    const uint32_t b0 = w0 & 255, g0 = (w0 >> 8) & 255, r0 = (w0 >> 16) & 255, b1 = w0 >> 24;
+    const uint32_t g1 = w1 & 255, r1 = (w1 >> 8) & 255, b2 = (w1 >> 16) & 255, g2 = w1 >> 24;
+    const uint32_t r2 = w2 & 255, b3 = (w2 >> 8) & 255, g3 = (w2 >> 16) & 255, r3 = w2 >> 24;
+    const uint32_t v0 = (b0 * 1868u + g0 * 9617u + r0 * 4899u + 8192u) >> 14, v1 = (b1 * 1868u + g1 * 9617u + r1 * 4899u + 8192u) >> 14;
+    const uint32_t v2 = (b2 * 1868u + g2 * 9617u + r2 * 4899u + 8192u) >> 14, v3 = (b3 * 1868u + g3 * 9617u + r3 * 4899u + 8192u) >> 14;
+    return v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
+}
 __global__ __launch_bounds__(256) void k_gray(DevPlan P, const SlotDesc* __restrict__ slots, uint8_t* __restrict__ pyr, int slot0) {
-    const int slot = slot0 + blockIdx.z, y = blockIdx.y;
-    const int g = blockIdx.x * 256 + threadIdx.x;      // group of 4 pixels
-    const int x = g * 4;
-    if (x >= P.W) return;
+    const int slot = slot0 + blockIdx.z;
+    const int gpr = (P.W + 15) >> 4;                   // 16-pixel groups per row
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= gpr * P.H) return;
+    const int y = id / gpr, x = (id - y * gpr) * 16;
     const SlotDesc sd = slots[slot];
     const uint8_t* row = sd.bgr + (size_t)y * sd.bgr_stride + 3 * (size_t)x;
     uint8_t* out = pyr + (size_t)slot * P.pyr_stride + P.loff[0] + (size_t)y * P.pitch[0] + x;
-    uint8_t px[12];
-    const int n = min(4, P.W - x);
-    if (n == 4 && ((uintptr_t)row & 3) == 0) {
-        const uint32_t* r32 = (const uint32_t*)row;
-        uint32_t a = r32[0], b = r32[1], c = r32[2];
-        *(uint32_t*)&px[0] = a; *(uint32_t*)&px[4] = b; *(uint32_t*)&px[8] = c;
+    if (x + 16 <= P.W && (((uintptr_t)row | (uintptr_t)out) & 15) == 0) {
+        const uint4* r4 = (const uint4*)row;
+        const uint4 a = r4[0], b = r4[1], c = r4[2];
+        uint4 o;
+        o.x = gray4(a.x, a.y, a.z); o.y = gray4(a.w, b.x, b.y); o.z = gray4(b.z, b.w, c.x); o.w = gray4(c.y, c.z, c.w);
+        *(uint4*)out = o;
     } else {
-        for (int i = 0; i < 3 * n; ++i) px[i] = row[i];
+        const int n = min(16, P.W - x);
+        for (int i = 0; i < n; ++i) out[i] = (uint8_t)((row[3 * i] * 1868u + row[3 * i + 1] * 9617u + row[3 * i + 2] * 4899u + 8192u) >> 14);
     }
-    uint32_t packed = 0;
-    for (int i = 0; i < n; ++i) {
-        uint32_t v = (px[3 * i] * 1868u + px[3 * i + 1] * 9617u + px[3 * i + 2] * 4899u + 8192u) >> 14;
-        packed |= v << (8 * i);
-    }
-    if (n == 4) *(uint32_t*)out = packed;
-    else for (int i = 0; i < n; ++i) out[i] = (uint8_t)(packed >> (8 * i));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -110,7 +116,7 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t* g, int idx) {
 
 __global__ __launch_bounds__(256) void k_fast_nms(DevPlan P, const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand,
                                                   int* __restrict__ cand_cnt, int* __restrict__ status, int slot0) {
-    __shared__ uint8_t s_gray[GP * (TH + 8)];
+    __shared__ __align__(4) uint8_t s_gray[GP * (TH + 8)];
     __shared__ uint8_t s_score[SP * (TH + 2)];
     const int slot = slot0 + blockIdx.z;
     int l = 0;
@@ -120,15 +126,22 @@ __global__ __launch_bounds__(256) void k_fast_nms(DevPlan P, const uint8_t* __re
     const int x0 = P.edge + (t % P.tiles_x[l]) * TW, y0 = P.edge + (t / P.tiles_x[l]) * TH;
     const uint8_t* img = pyr + (size_t)slot * P.pyr_stride + P.loff[l];
     const int tid = threadIdx.y * 64 + threadIdx.x;
-    // gray tile with halo 4 (coordinates clamped; clamped positions never produce a score)
-    for (int i = tid; i < GP * (TH + 8); i += 256) {
-        int gx = x0 - 4 + i % GP, gy = y0 - 4 + i / GP;
-        gx = min(max(gx, 0), w - 1); gy = min(max(gy, 0), h - 1);
-#if FAST_VARIANT == 3
-        s_gray[i] = (uint8_t)(gx * 7 + gy * 13);
-#else
-        s_gray[i] = img[(size_t)gy * pitch + gx];
-#endif
+    // gray tile with halo 4 (coordinates clamped; clamped positions never produce a score): one dword per lane and
+    // step; tile columns start at edge + 64 k - 4, i.e. not dword aligned -- gfx950 global loads take any alignment
+    struct __attribute__((packed)) U32u { uint32_t v; };
+    for (int i = tid; i < (GP / 4) * (TH + 8); i += 256) {
+        const int d = i % (GP / 4), r = i / (GP / 4);
+        const int gx0 = x0 - 4 + 4 * d;
+        const int gy = min(max(y0 - 4 + r, 0), h - 1);
+        const uint8_t* rowp = img + (size_t)gy * pitch;
+        uint32_t v;
+        if (gx0 >= 0 && gx0 + 3 < w) v = reinterpret_cast<const U32u*>(rowp + gx0)->v;
+        else {
+            v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) v |= (uint32_t)rowp[min(max(gx0 + b, 0), w - 1)] << (8 * b);
+        }
+        reinterpret_cast<uint32_t*>(s_gray)[r * (GP / 4) + d] = v;
     }
     __syncthreads();
     // scores on the tile + halo 1, in two phases so that the expensive arc evaluation runs on a dense list:
@@ -298,12 +311,14 @@ __global__ __launch_bounds__(1024) void k_select(DevPlan P, const uint8_t* __res
 // ------------------------------------------------------------------------------------------
 // 7x7 sigma-2 Gaussian blur of every pyramid level in 8-bit fixed point (cv::GaussianBlur semantics for 8-bit images:
 // integer kernel round(k*256), row pass in int, column pass (sum + 2^15) >> 16), BORDER_REFLECT_101.  Separable in
-// LDS: 64x16 output tile, (64+6)x(16+6) input halo, u16 intermediate.  Streaming kernel: reads P, writes P.
-#define BTW 64
+// LDS: 128x16 output tile, (128+8)x(16+6) input halo, u16 intermediate.  Streaming kernel: reads P, writes P.
+#define BTW 128
 #define BTH 16
+#define BSTR (BTW + 16)                                 // s_in row stride in bytes: 4 halo bytes left, 4+ right, 16-byte multiple
 __global__ __launch_bounds__(256) void k_blur(DevPlan P, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, int slot0) {
-    __shared__ uint8_t s_in[(BTH + 6) * (BTW + 8)];
-    __shared__ uint16_t s_h[(BTH + 6) * BTW];
+    // 4 pixels per lane in every phase: dword loads/stores to HBM and LDS (rows and level offsets are 64-byte aligned)
+    __shared__ uint32_t s_in[(BTH + 6) * BSTR / 4];
+    __shared__ uint32_t s_h[(BTH + 6) * BTW / 2];      // u16 row sums, two per dword
     const int slot = slot0 + blockIdx.z;
     int l = 0;
     while (l + 1 < P.L && (int)blockIdx.x >= P.btile_prefix[l + 1]) ++l;
@@ -312,36 +327,62 @@ __global__ __launch_bounds__(256) void k_blur(DevPlan P, const uint8_t* __restri
     const int x0 = (t % P.btiles_x[l]) * BTW, y0 = (t / P.btiles_x[l]) * BTH;
     const uint8_t* img = pyr + (size_t)slot * P.pyr_stride + P.loff[l];
     uint8_t* out = blur + (size_t)slot * P.pyr_stride + P.loff[l];
-    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
-    // halo tile, reflect-101 at the image border
-    for (int r = ty; r < BTH + 6; r += 4) {
+    const int tx = threadIdx.x, ty = threadIdx.y;      // 32 x 8
+    // halo tile: image columns x0-4 .. x0+BTW+3 as (BTW+8)/4 dwords per row, reflect-101 at the image border
+    for (int r = ty; r < BTH + 6; r += 8) {
         int gy = y0 - 3 + r;
         gy = gy < 0 ? -gy : (gy >= h ? 2 * h - 2 - gy : gy);
         gy = min(max(gy, 0), h - 1);
-        for (int c = tx; c < BTW + 6; c += 64) {
-            int gx = x0 - 3 + c;
-            gx = gx < 0 ? -gx : (gx >= w ? 2 * w - 2 - gx : gx);
-            gx = min(max(gx, 0), w - 1);
-            s_in[r * (BTW + 8) + c] = img[(size_t)gy * pitch + gx];
+        const uint8_t* rowp = img + (size_t)gy * pitch;
+        for (int d = tx; d < (BTW + 8) / 4; d += 32) {
+            const int gx0 = x0 - 4 + 4 * d;
+            uint32_t v;
+            if (gx0 >= 0 && gx0 + 3 < w) v = *(const uint32_t*)(rowp + gx0);
+            else {
+                v = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int gx = gx0 + i;
+                    gx = gx < 0 ? -gx : (gx >= w ? 2 * w - 2 - gx : gx);
+                    gx = min(max(gx, 0), w - 1);
+                    v |= (uint32_t)rowp[gx] << (8 * i);
+                }
+            }
+            s_in[r * (BSTR / 4) + d] = v;
         }
     }
     __syncthreads();
-    for (int r = ty; r < BTH + 6; r += 4) {
-        const uint8_t* q = &s_in[r * (BTW + 8) + tx];
-        int s = 0;
+    const int g0 = P.gk[0], g1 = P.gk[1], g2 = P.gk[2], g3 = P.gk[3];      // symmetric 7-tap kernel
+    for (int r = ty; r < BTH + 6; r += 8) {
+        const uint32_t* q = &s_in[r * (BSTR / 4) + tx];
+        const uint32_t a = q[0], b = q[1], c = q[2];   // bytes x-4 .. x+7 of this lane's 4 outputs x .. x+3
+        int px[12];
 #pragma unroll
-        for (int k = 0; k < 7; ++k) s += P.gk[k] * q[k];
-        s_h[r * BTW + tx] = (uint16_t)s;
+        for (int i = 0; i < 4; ++i) { px[i] = (a >> (8 * i)) & 255; px[4 + i] = (b >> (8 * i)) & 255; px[8 + i] = (c >> (8 * i)) & 255; }
+        int sum[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            sum[i] = g3 * px[i + 4] + g2 * (px[i + 3] + px[i + 5]) + g1 * (px[i + 2] + px[i + 6]) + g0 * (px[i + 1] + px[i + 7]);
+        s_h[r * (BTW / 2) + 2 * tx] = (uint32_t)sum[0] | ((uint32_t)sum[1] << 16);
+        s_h[r * (BTW / 2) + 2 * tx + 1] = (uint32_t)sum[2] | ((uint32_t)sum[3] << 16);
     }
     __syncthreads();
-    (void)tid;
-    for (int r = ty; r < BTH; r += 4) {
-        const int x = x0 + tx, y = y0 + r;
+    for (int r = ty; r < BTH; r += 8) {
+        const int x = x0 + 4 * tx, y = y0 + r;
         if (x >= w || y >= h) continue;
-        int s = 0;
+        int acc[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int k = 0; k < 7; ++k) s += P.gk[k] * s_h[(r + k) * BTW + tx];
-        out[(size_t)y * pitch + x] = (uint8_t)min(255, (s + (1 << 15)) >> 16);
+        for (int k = 0; k < 7; ++k) {
+            const uint32_t lo = s_h[(r + k) * (BTW / 2) + 2 * tx], hi = s_h[(r + k) * (BTW / 2) + 2 * tx + 1];
+            const int gk = P.gk[k];
+            acc[0] += gk * (int)(lo & 0xFFFF); acc[1] += gk * (int)(lo >> 16); acc[2] += gk * (int)(hi & 0xFFFF); acc[3] += gk * (int)(hi >> 16);
+        }
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o |= (uint32_t)min(255, (acc[i] + (1 << 15)) >> 16) << (8 * i);
+        uint8_t* op = out + (size_t)y * pitch + x;
+        if (x + 3 < w) *(uint32_t*)op = o;
+        else for (int i = 0; x + i < w; ++i) op[i] = (uint8_t)(o >> (8 * i));
     }
 }
 
@@ -449,7 +490,7 @@ int vo_orb_launch(vo_ctx* c, int slot0, int n) {
     hipStream_t st = c->stream;
     HIP_TRY(hipMemsetAsync(c->d_cand_cnt + (size_t)slot0 * VO_MAX_LEVELS, 0, sizeof(int) * VO_MAX_LEVELS * n, st));
     { ProfScope ps(c, "k_gray");
-      dim3 g(((P.W + 3) / 4 + 255) / 256, P.H, n);
+      dim3 g((((P.W + 15) / 16) * P.H + 255) / 256, 1, n);
       hipLaunchKernelGGL(k_gray, g, dim3(256), 0, st, P, c->d_slots, c->d_pyr, slot0); }
     for (int l = 1; l < P.L; ++l) {
         ProfScope ps(c, "k_resize");
@@ -464,7 +505,7 @@ int vo_orb_launch(vo_ctx* c, int slot0, int n) {
       dim3 g(P.L, n);
       hipLaunchKernelGGL(k_select, g, dim3(1024), lds, st, P, c->d_pyr, c->d_cand, c->d_cand_cnt, c->d_sel, c->d_sel_key, c->d_sel_cnt, slot0); }
     { ProfScope ps(c, "k_blur");
-      hipLaunchKernelGGL(k_blur, dim3(P.btile_prefix[P.L], 1, n), dim3(64, 4), 0, st, P, c->d_pyr, c->d_blur, slot0); }
+      hipLaunchKernelGGL(k_blur, dim3(P.btile_prefix[P.L], 1, n), dim3(32, 8), 0, st, P, c->d_pyr, c->d_blur, slot0); }
     { ProfScope ps(c, "k_describe");
       dim3 g((P.nfeat + 3) / 4, n);
       hipLaunchKernelGGL(k_describe, g, dim3(256), 0, st, P, c->d_slots, c->d_pyr, c->d_blur, c->d_sel, c->d_sel_key, c->d_sel_cnt, c->d_kps, c->d_desc, c->d_nkp, slot0); }
