@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-ba", action="store_true", help="disable local BA (enable_local_optimization: 0)")
     ap.add_argument("--ba-lag", type=int, default=8, help="0: BA synchronous in AddFrame; L>0: overlapped, merged L frames later (deterministic)")
+    ap.add_argument("--hyps", type=int, default=100, help="PnP-RANSAC hypotheses per pass (default.yaml: 100; BASELINE config 3: 2048)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=150, help="bounded CPU-baseline sample (frames)")
     args = ap.parse_args()
@@ -101,7 +102,7 @@ def main():
     dptr = [d_depth.data_ptr() + i * fd for i in range(total)]
 
     opts = dict(width=W, height=H, number_of_features=N, max_frames_in_flight=args.lookahead, device=local_rank,
-                enable_local_optimization=0 if args.no_ba else 1, backend_lag_frames=args.ba_lag, track_batch=args.track_batch, map_capacity=1 << 20)
+                enable_local_optimization=0 if args.no_ba else 1, backend_lag_frames=args.ba_lag, track_batch=args.track_batch, map_capacity=1 << 20, ransac_iterations=args.hyps)
     sysm = system.VoSystem(system.HOST_LIB, **opts)
     assert sysm.backend == "hip-gfx950", sysm.backend
 
@@ -164,7 +165,7 @@ def main():
         kern = {names[j].value.decode(): (float(ms[j]), int(calls[j])) for j in range(nn.value)}
         frames_prof = total
         M = max(1, pst["last_candidates"]); Kc = max(1, pst["last_matches"])
-        per_frame, b_survey, P = algorithmic_bytes(W, H, N, M, Kc, 100)
+        per_frame, b_survey, P = algorithmic_bytes(W, H, N, M, Kc, args.hyps)
         table = {}
         for name, (tms, c) in kern.items():
             if c == 0:
@@ -227,7 +228,7 @@ def main():
             "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/f64", "data": "synthetic",
             "config": {"workload": "synthetic 640x480 RGB-D stream per GPU, %d ORB features, default.yaml tracking parameters" % N,
-                       "streams_per_gpu": 1, "lookahead_frames": args.lookahead, "track_batch": args.track_batch, "local_ba": (False if args.no_ba else ("synchronous" if args.ba_lag == 0 else "overlapped, merged %d frames later" % args.ba_lag)), "ransac_hypotheses": 100},
+                       "streams_per_gpu": 1, "lookahead_frames": args.lookahead, "track_batch": args.track_batch, "local_ba": (False if args.no_ba else ("synchronous" if args.ba_lag == 0 else "overlapped, merged %d frames later" % args.ba_lag)), "ransac_hypotheses": args.hyps},
             "ate_rmse_m": round(ate_gpu, 5), "keyframes": st["keyframes"], "lost": st["lost"], "map_points": st["map_points"],
             "alg_bytes_per_frame_survey": b_survey, "hbm_frac_whole_frame": round(b_survey * (fps / world) / (HBM_PEAK_GBS * 1e9), 6),
             "render_s": round(t_render, 2),
