@@ -4,17 +4,17 @@
 // residual/Jacobians (include/myslam/g2o_types.h:143-167), Huber delta sqrt(7.815), Levenberg-
 // Marquardt with g2o's lambda/rho policy, 10 robust iterations + chi2 cull + 10 plain ones.
 //
-//   k_ba_linearize  one lane per edge: r, J_pose (2x6), J_point (2x3) = J_pose[:,0:3] R, Huber weight;
-//                   H_pp / b_p / H_ll / b_l accumulated with f64 global atomics, W_e = w J_p^T J_l stored
-//   k_ba_schur      one lane per point: (H_ll + lambda I)^-1, S -= W_i Hinv W_j^T, b_s -= W_i Hinv b_l
-//   k_ba_chol       dense Cholesky of the reduced 6K x 6K system in one workgroup
-//   k_ba_backsub    one lane per point: dl = Hinv (b_l - sum W^T dp), trial point, gain-ratio terms
-//   k_ba_pose       one lane per free pose: trial pose exp(dp) * T, gain-ratio terms
-//   k_ba_chi        robust chi2 of the trial state
-// The LM accept/reject decision is a handful of scalars: it is taken on the host after one small
-// D2H copy per trial (BA runs once per keyframe, not per frame).  The reduced system is dense and
-// tiny at default.yaml scale (6K <= ~100); config 5 of BASELINE.json (window 20, 1.6e5 points) is
-// where S would be rebuilt as an MFMA contraction -- not needed for correctness here.
+//   k_ba_lin          4 lanes per point: r, J_pose (2x6), J_point (2x3) = J_pose[:,0:3] R, Huber weight, H_ll / b_l / W_e
+//                     (no atomics); 4 workgroups per free pose: H_pp / b_p
+//   k_ba_init_S       S = blockdiag(H_pp) + lambda I, b_s = b_p, (H_ll + lambda I)^-1 per point
+//   k_ba_schur_blocks one workgroup per <= 512-pair slice of a 6x6 block: S -= W_e1 Hinv W_e2^T, b_s -= W_e Hinv b_l
+//   k_ba_chol16       dense Cholesky + solve of the reduced 6K x 6K system in one workgroup (16-column DPP panels,
+//                     f64 MFMA trailing update); k_ba_chol_t<false> for 6K > 192
+//   k_ba_update       trial points (back-substitution) and trial poses exp(dp) * T, gain-ratio terms
+//   k_ba_chi_control  robust chi2 of the trial state; the last workgroup runs the LM accept / lambda policy
+// The LM state (lambda, current chi2, iteration counters, which of the two state buffers is current) lives in a
+// device-resident control block, so a whole round of LM steps is enqueued back to back and the host polls
+// `finished` once per chunk.
 #include <cfloat>
 #include <cmath>
 #include <cstdio>

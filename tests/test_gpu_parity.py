@@ -148,6 +148,37 @@ def test_track_frame_matches_oracle(frames, libs):
     assert np.abs(np.array(ro.T_cw) - inv12(Twc[8])).max() < 0.02
 
 
+def test_config5_sizes_orb_and_tracking_match_oracle(libs):
+    """BASELINE.json config 5 sizes: 1280x960 frames (fr1 intrinsics x2), 8000 features, 2048 RANSAC hypotheses.
+    ORB stays bit-exact, the tracking chain gives the same integer results and the same pose."""
+    syn = capi.Synth()
+    sp = syn.params(seed=5, width=1280, height=960, fx=2 * 517.3, fy=2 * 516.5, cx=2 * 318.6, cy=2 * 255.3)
+    bgr, depth, Twc, _ = syn.render(sp, 0, 6, threads=8)
+    out = []
+    for L in libs:
+        ctx, p = make_ctx(L, width=1280, height=960, fx=sp.fx, fy=sp.fy, cx=sp.cx, cy=sp.cy, n_features=8000, max_frames=2,
+                          map_capacity=16384, max_hypotheses=2048)
+        ctx.upload(0, bgr[0], depth[0]); ctx.upload(1, bgr[5], depth[5])
+        ctx.orb(0, 2)
+        k0, d0 = ctx.orb_fetch(0)
+        k1, d1 = ctx.orb_fetch(1)
+        seed_map(ctx, p, k0, d0, Twc[0])
+        res, m = ctx.track(1, inv12(Twc[0]), L.default_track_params(n_hyp=2048))
+        out.append((k0, d0, k1, d1, res, m))
+    (k0h, d0h, k1h, d1h, rh, mh), (k0o, d0o, k1o, d1o, ro, mo) = out
+    assert len(k0h) == len(k0o) == 8000
+    for kh, ko, dh, do in ((k0h, k0o, d0h, d0o), (k1h, k1o, d1h, d1o)):
+        for field in ("x", "y", "size", "octave", "class_id", "depth_raw"):
+            assert np.array_equal(kh[field], ko[field]), field
+        assert np.array_equal(dh, do)
+    for f in ("n_candidates", "n_matches", "n_ransac_inliers", "n_lm_inliers", "min_distance", "ransac_iters", "best_hypothesis"):
+        assert getattr(rh, f) == getattr(ro, f), f
+    assert rh.status == 0 and rh.n_ransac_inliers > 1000
+    for f in ("map_index", "kp_index", "distance", "flags"):
+        assert np.array_equal(mh[f], mo[f]), f
+    np.testing.assert_allclose(np.array(rh.T_cw), np.array(ro.T_cw), atol=1e-9)
+
+
 # D = 6 nfree: 24 (one 16-column panel + partial), 96 (full panels only), 180 (partial last panel), 192 (LDS-resident limit),
 # 216 (> limit: matrix in L2); 1300 points -> > 20000 edges (threaded pair-list build); shuffle: edges not sorted by point
 @pytest.mark.parametrize("nP,nX,nfree,shuffle", [(6, 400, 4, False), (18, 300, 16, False), (34, 500, 30, False), (34, 300, 32, True),
