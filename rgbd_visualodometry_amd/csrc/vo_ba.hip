@@ -48,6 +48,7 @@ struct BaDev {
     const int32_t* pt_start; const int32_t* pt_edges;       // CSR point -> edges
     const int32_t* ps_start; const int32_t* ps_edges;       // CSR free pose -> edges
     const BaBlock* blocks; const int2* pairs;               // (e1, e2) pairs sharing a point, grouped by (pose(e1) <= pose(e2))
+    const int* n_slices;                                     // device-built pair lists: number of valid entries of `blocks` (nullptr: n_blocks)
     double* Hpp; double* bp; double* Hll; double* bl; double* W;
     double* S; double* bs; double* Hinv; double* dl;
     double* partU; double* partC; int nU;   // per-workgroup partial sums (no same-address atomics): update {gain term, max step} x nU, trial chi2 x grid of k_ba_chi_control
@@ -260,6 +261,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_blocks(BaDev B) {
     if (B.ctl->finished) return;
     __shared__ double s_part[4 * 42];
     __shared__ double s_tot[42];
+    if (B.n_slices && (int)blockIdx.x >= *B.n_slices) return;
     const BaBlock blk = B.blocks[blockIdx.x];
     const bool diag = blk.j1 == blk.j2;
     double v[42];
@@ -311,6 +313,81 @@ __global__ __launch_bounds__(256) void k_ba_schur_blocks(BaDev B) {
         if (!diag) atomicAdd(&B.S[(size_t)(6 * blk.j2 + c) * B.D + 6 * blk.j1 + r], -val);
     } else if (diag && threadIdx.x < 42) {
         atomicAdd(&B.bs[6 * blk.j1 + threadIdx.x - 36], -s_tot[threadIdx.x]);
+    }
+}
+
+// ---- pair lists of the reduced system, built on the device ---------------------------------------------------------
+// Block (j1 <= j2) needs the pairs (e1, e2) of edges of poses j1 / j2 that see the same point.  With the edges sorted
+// by point, the per-pose edge lists (ps_edges) are sorted by point too, so a block's list is the intersection of two
+// sorted lists: the workgroup keeps the point ids of pose j2 in LDS and binary-searches the points of pose j1.  Three
+// launches (count, scan + slice table, ordered fill) replace a host enumeration of ~4 pairs per edge and the upload
+// of the lists; the order inside a block (ascending point) is the host builder's, so the sums are the same.
+#define PAIR_LDS_CAP 8192
+struct BaPairPlan { const int32_t* ps_start; const int32_t* ps_edges; const int32_t* ps_pt; int nf; int* cnt; int* off; int* n_slices; int* n_pairs; BaBlock* blocks; int2* pairs; };
+
+__device__ __forceinline__ void ba_block_of(int b, int nf, int& j1, int& j2) {     // b-th (j1 <= j2) pair in row-major order
+    j1 = 0;
+    while (b >= nf - j1) { b -= nf - j1; ++j1; }
+    j2 = j1 + b;
+}
+__device__ __forceinline__ int ba_find_sorted(const int* s_pts, int n, int key) {  // index of key in the sorted list, -1 if absent
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_pts[mid] < key) lo = mid + 1; else hi = mid; }
+    return (lo < n && s_pts[lo] == key) ? lo : -1;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_ba_pairs(BaPairPlan Q) {
+    extern __shared__ int s_pts[];
+    __shared__ int s_w[16];
+    int j1, j2;
+    ba_block_of(blockIdx.x, Q.nf, j1, j2);
+    const int a0 = Q.ps_start[j1], n1 = Q.ps_start[j1 + 1] - a0, b0 = Q.ps_start[j2], n2 = Q.ps_start[j2 + 1] - b0;
+    if (!FILL && j1 == j2) { if (threadIdx.x == 0) Q.cnt[blockIdx.x] = n1; return; }
+    if (FILL && Q.cnt[blockIdx.x] == 0) return;
+    const int base = FILL ? Q.off[blockIdx.x] : 0;
+    if (FILL && j1 == j2) {
+        for (int q = threadIdx.x; q < n1; q += 256) { const int e = Q.ps_edges[a0 + q]; Q.pairs[base + q] = make_int2(e, e); }
+        return;
+    }
+    for (int i = threadIdx.x; i < n2; i += 256) s_pts[i] = Q.ps_pt[b0 + i];
+    __syncthreads();
+    int run = 0;
+    for (int c0 = 0; c0 < n1; c0 += 256) {
+        const int q = c0 + threadIdx.x;
+        const int hit = q < n1 ? ba_find_sorted(s_pts, n2, Q.ps_pt[a0 + q]) : -1;
+        // order-preserving position of the hits inside this chunk of 256
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const unsigned long long m = __ballot(hit >= 0);
+        if (lane == 0) s_w[wave] = __popcll(m);
+        __syncthreads();
+        int before = __popcll(m & ((1ull << lane) - 1ull)), tot = 0;
+        for (int w = 0; w < 4; ++w) { if (w < wave) before += s_w[w]; tot += s_w[w]; }
+        if (FILL && hit >= 0) Q.pairs[base + run + before] = make_int2(Q.ps_edges[a0 + q], Q.ps_edges[b0 + hit]);
+        run += tot;
+        __syncthreads();
+    }
+    if (!FILL && threadIdx.x == 0) Q.cnt[blockIdx.x] = run;
+}
+
+// one workgroup: offsets of the blocks' lists, the table of <= 512-pair slices, totals
+__global__ __launch_bounds__(1024) void k_ba_pairs_scan(BaPairPlan Q, int nb) {
+    __shared__ int s_c[2112], s_s[2112];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < nb; i += 1024) { const int c = Q.cnt[i]; s_c[i] = c; s_s[i] = (c + 511) >> 9; }
+    __syncthreads();
+    if (tid == 0) {                                  // nb <= 2080 entries: a serial scan is a few microseconds
+        int a = 0, b = 0;
+        for (int i = 0; i < nb; ++i) { const int c = s_c[i], sl = s_s[i]; s_c[i] = a; s_s[i] = b; a += c; b += sl; }
+        *Q.n_pairs = a; *Q.n_slices = b;
+    }
+    __syncthreads();
+    for (int i = tid; i < nb; i += 1024) {
+        const int c = Q.cnt[i], o = s_c[i];
+        Q.off[i] = o;
+        int j1, j2;
+        ba_block_of(i, Q.nf, j1, j2);
+        for (int k = 0, sl = s_s[i]; k < c; k += 512, ++sl) Q.blocks[sl] = BaBlock{j1, j2, o + k, min(512, c - k)};
     }
 }
 
@@ -1021,58 +1098,79 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     { std::vector<int32_t> fill(ps_start.begin(), ps_start.end() - 1);
       for (int e = 0; e < ne; ++e) if (in->edge_pose[e] < nf) ps_edges[fill[in->edge_pose[e]]++] = e; }
     const double tp1 = tnow();
-    // Pair lists of the 6x6 blocks (j1 <= j2) of the reduced system, grouped by block with the points in ascending
-    // order inside a block.  Host threads split the point range: count per (thread, block), prefix over blocks and
-    // threads, then every thread writes its pairs straight into pinned memory -- same lists for any thread count.
-    // Two edges of one point to the same pose never pair up.
-    const int NT = ne > 20000 ? 4 : 1;
-    std::vector<std::vector<int32_t>> cnt_t(NT, std::vector<int32_t>((size_t)nf * nf, 0));
-    auto k_lo = [&](int t) { return (int)((long long)nx * t / NT); };
-    auto enumerate = [&](int t, int2* out, std::vector<int32_t>* fill) {
-        std::vector<int32_t>& cnt = cnt_t[t];
-        int32_t fe[64], fj[64]; std::vector<int32_t> fev, fjv;
-        for (int k = k_lo(t); k < k_lo(t + 1); ++k) {
-            const int deg = pt_start[k + 1] - pt_start[k];
-            int32_t* pe = fe; int32_t* pj = fj;
-            if (deg > 64) { fev.resize(deg); fjv.resize(deg); pe = fev.data(); pj = fjv.data(); }
-            int m = 0;
-            for (int a = pt_start[k]; a < pt_start[k + 1]; ++a) { const int e = pt_edges[a], j = in->edge_pose[e]; if (j < nf) { pe[m] = e; pj[m] = j; ++m; } }
-            for (int a = 0; a < m; ++a) {
-                const int ja = pj[a], ea = pe[a];
-                if (out) out[(*fill)[(size_t)ja * nf + ja]++] = make_int2(ea, ea); else cnt[(size_t)ja * nf + ja]++;
-                for (int b2 = a + 1; b2 < m; ++b2) {
-                    const int jb = pj[b2];
-                    if (ja == jb) continue;
-                    const size_t bid = ja < jb ? (size_t)ja * nf + jb : (size_t)jb * nf + ja;
-                    if (out) out[(*fill)[bid]++] = ja < jb ? make_int2(ea, pe[b2]) : make_int2(pe[b2], ea); else cnt[bid]++;
+    // Device-built pair lists (k_ba_pairs) need the edges sorted by point (the per-pose lists are then sorted by point
+    // and a block's list is a sorted intersection) and the longest per-pose list in LDS; otherwise the host builds them.
+    bool dev_pairs = nf <= 64;
+    for (int e = 1; e < ne && dev_pairs; ++e) if (in->edge_point[e] < in->edge_point[e - 1]) dev_pairs = false;
+    int max_len = 0;
+    for (int j = 0; j < nf; ++j) max_len = std::max(max_len, ps_start[j + 1] - ps_start[j]);
+    if (max_len > PAIR_LDS_CAP) dev_pairs = false;
+    if (getenv("VO_BA_HOST_PAIRS")) dev_pairs = false;
+    std::vector<BaBlock> blocks;
+    int npairs = 0;
+    int2* pairs = nullptr;
+    std::vector<int32_t> ps_pt;
+    int nb_all = 0, slices_ub = 0;
+    if (dev_pairs) {
+        ps_pt.resize(std::max<size_t>(ps_edges.size(), 1));
+        for (size_t q = 0; q < ps_edges.size(); ++q) ps_pt[q] = in->edge_point[ps_edges[q]];
+        nb_all = nf * (nf + 1) / 2;
+        for (int j1 = 0; j1 < nf; ++j1) for (int j2 = j1; j2 < nf; ++j2) {
+            const int m = std::min(ps_start[j1 + 1] - ps_start[j1], ps_start[j2 + 1] - ps_start[j2]);
+            npairs += m; slices_ub += (m + 511) / 512;         // upper bounds: the device writes the real counts
+        }
+    } else {
+        // Pair lists of the 6x6 blocks (j1 <= j2) of the reduced system, grouped by block with the points in ascending
+        // order inside a block.  Host threads split the point range: count per (thread, block), prefix over blocks and
+        // threads, then every thread writes its pairs straight into pinned memory -- same lists for any thread count.
+        // Two edges of one point to the same pose never pair up.
+        const int NT = ne > 20000 ? 4 : 1;
+        std::vector<std::vector<int32_t>> cnt_t(NT, std::vector<int32_t>((size_t)nf * nf, 0));
+        auto k_lo = [&](int t) { return (int)((long long)nx * t / NT); };
+        auto enumerate = [&](int t, int2* out, std::vector<int32_t>* fill) {
+            std::vector<int32_t>& cnt = cnt_t[t];
+            int32_t fe[64], fj[64]; std::vector<int32_t> fev, fjv;
+            for (int k = k_lo(t); k < k_lo(t + 1); ++k) {
+                const int deg = pt_start[k + 1] - pt_start[k];
+                int32_t* pe = fe; int32_t* pj = fj;
+                if (deg > 64) { fev.resize(deg); fjv.resize(deg); pe = fev.data(); pj = fjv.data(); }
+                int m = 0;
+                for (int a = pt_start[k]; a < pt_start[k + 1]; ++a) { const int e = pt_edges[a], j = in->edge_pose[e]; if (j < nf) { pe[m] = e; pj[m] = j; ++m; } }
+                for (int a = 0; a < m; ++a) {
+                    const int ja = pj[a], ea = pe[a];
+                    if (out) out[(*fill)[(size_t)ja * nf + ja]++] = make_int2(ea, ea); else cnt[(size_t)ja * nf + ja]++;
+                    for (int b2 = a + 1; b2 < m; ++b2) {
+                        const int jb = pj[b2];
+                        if (ja == jb) continue;
+                        const size_t bid = ja < jb ? (size_t)ja * nf + jb : (size_t)jb * nf + ja;
+                        if (out) out[(*fill)[bid]++] = ja < jb ? make_int2(ea, pe[b2]) : make_int2(pe[b2], ea); else cnt[bid]++;
+                    }
                 }
             }
+        };
+        auto run_threads = [&](const std::function<void(int)>& fn) {
+            std::vector<std::thread> th;
+            for (int t = 1; t < NT; ++t) th.emplace_back(fn, t);
+            fn(0);
+            for (auto& x : th) x.join();
+        };
+        run_threads([&](int t) { enumerate(t, nullptr, nullptr); });
+        std::vector<std::vector<int32_t>> off_t(NT, std::vector<int32_t>((size_t)nf * nf, 0));
+        for (int j1 = 0; j1 < nf; ++j1) for (int j2 = j1; j2 < nf; ++j2) {
+            const size_t bid = (size_t)j1 * nf + j2;
+            int cnt = 0;
+            for (int t = 0; t < NT; ++t) { off_t[t][bid] = npairs + cnt; cnt += cnt_t[t][bid]; }
+            if (!cnt) continue;
+            for (int o = 0; o < cnt; o += 512) blocks.push_back(BaBlock{j1, j2, npairs + o, std::min(512, cnt - o)});   // <= 2 pairs per lane
+            npairs += cnt;
         }
-    };
-    auto run_threads = [&](const std::function<void(int)>& fn) {
-        std::vector<std::thread> th;
-        for (int t = 1; t < NT; ++t) th.emplace_back(fn, t);
-        fn(0);
-        for (auto& x : th) x.join();
-    };
-    run_threads([&](int t) { enumerate(t, nullptr, nullptr); });
-    std::vector<BaBlock> blocks;
-    std::vector<std::vector<int32_t>> off_t(NT, std::vector<int32_t>((size_t)nf * nf, 0));
-    int npairs = 0;
-    for (int j1 = 0; j1 < nf; ++j1) for (int j2 = j1; j2 < nf; ++j2) {
-        const size_t bid = (size_t)j1 * nf + j2;
-        int cnt = 0;
-        for (int t = 0; t < NT; ++t) { off_t[t][bid] = npairs + cnt; cnt += cnt_t[t][bid]; }
-        if (!cnt) continue;
-        for (int o = 0; o < cnt; o += 512) blocks.push_back(BaBlock{j1, j2, npairs + o, std::min(512, cnt - o)});   // <= 2 pairs per lane
-        npairs += cnt;
+        // pairs are written straight into pinned memory (after the 512-byte mailbox used for scal / ctl read-backs)
+        uint8_t* h_pin = (uint8_t*)vo_stage(c, 512 + sizeof(int2) * (size_t)std::max(npairs, 1));
+        if (!h_pin) return VO_E_NOMEM;
+        pairs = (int2*)(h_pin + 512);
+        run_threads([&](int t) { enumerate(t, pairs, &off_t[t]); });
     }
-    // pairs are written straight into pinned memory (after the 512-byte mailbox used for scal / ctl read-backs)
-    uint8_t* h_pin = (uint8_t*)vo_stage(c, 512 + sizeof(int2) * (size_t)std::max(npairs, 1));
-    if (!h_pin) return VO_E_NOMEM;
-    int2* pairs = (int2*)(h_pin + 512);
-    run_threads([&](int t) { enumerate(t, pairs, &off_t[t]); });
-    const int nblk = (int)blocks.size();
+    const int nblk = dev_pairs ? slices_ub : (int)blocks.size();
     const double tp2 = tnow();
 
     // carve the scratch slab
@@ -1083,6 +1181,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     const size_t o_ps = carve(4 * (size_t)(nx + 1)), o_pe = carve(4 * (size_t)ne);
     const size_t o_qs = carve(4 * (size_t)(nf + 1)), o_qe = carve(4 * (size_t)std::max<size_t>(ps_edges.size(), 1));
     const size_t o_blk = carve(sizeof(BaBlock) * (size_t)std::max(nblk, 1)), o_pairs = carve(sizeof(int2) * (size_t)std::max(npairs, 1));
+    const size_t o_pspt = carve(4 * ps_pt.size() + 4), o_pcnt = carve(4 * (size_t)std::max(nb_all, 1)), o_poff = carve(4 * (size_t)std::max(nb_all, 1)), o_pn = carve(16);
     const size_t o_Hpp = carve(288 * (size_t)nf), o_bp = carve(8 * (size_t)D), o_Hll = carve(72 * (size_t)nx), o_bl = carve(24 * (size_t)nx), o_scal = carve(64);
     const size_t o_ctl = carve(sizeof(BaCtl));
     const size_t o_partU = carve(16 * ((size_t)(nx + 63) / 64 + 1)), o_partC = carve(8 * ((size_t)(ne + 255) / 256 + 1));
@@ -1092,6 +1191,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     uint8_t* base = (uint8_t*)c->d_ba;
     BaDev B;
     B.n_poses = np; B.n_free = nf; B.n_points = nx; B.n_edges = ne; B.D = D; B.n_blocks = nblk;
+    B.n_slices = dev_pairs ? (const int*)(base + o_pn) : nullptr;
     B.ps_start = (const int32_t*)(base + o_qs); B.ps_edges = (const int32_t*)(base + o_qe); B.blocks = (const BaBlock*)(base + o_blk); B.pairs = (const int2*)(base + o_pairs);
     B.posesA = (double*)(base + o_poses); B.ptsA = (double*)(base + o_pts); B.posesB = (double*)(base + o_poses_n); B.ptsB = (double*)(base + o_pts_n);
     B.ctl = (BaCtl*)(base + o_ctl);
@@ -1111,8 +1211,21 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     HIP_TRY(hipMemcpyAsync(base + o_pe, pt_edges.data(), 4 * (size_t)ne, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(base + o_qs, ps_start.data(), 4 * (size_t)(nf + 1), hipMemcpyHostToDevice, st));
     if (!ps_edges.empty()) HIP_TRY(hipMemcpyAsync(base + o_qe, ps_edges.data(), 4 * ps_edges.size(), hipMemcpyHostToDevice, st));
-    if (nblk) HIP_TRY(hipMemcpyAsync(base + o_blk, blocks.data(), sizeof(BaBlock) * (size_t)nblk, hipMemcpyHostToDevice, st));
-    if (npairs) HIP_TRY(hipMemcpyAsync(base + o_pairs, pairs, sizeof(int2) * (size_t)npairs, hipMemcpyHostToDevice, st));
+    if (dev_pairs) {
+        if (!ps_edges.empty()) HIP_TRY(hipMemcpyAsync(base + o_pspt, ps_pt.data(), 4 * ps_edges.size(), hipMemcpyHostToDevice, st));
+        BaPairPlan Q;
+        Q.ps_start = B.ps_start; Q.ps_edges = B.ps_edges; Q.ps_pt = (const int32_t*)(base + o_pspt); Q.nf = nf;
+        Q.cnt = (int*)(base + o_pcnt); Q.off = (int*)(base + o_poff); Q.n_slices = (int*)(base + o_pn); Q.n_pairs = (int*)(base + o_pn) + 1;
+        Q.blocks = (BaBlock*)(base + o_blk); Q.pairs = (int2*)(base + o_pairs);
+        if (nb_all) {
+            hipLaunchKernelGGL(k_ba_pairs<false>, dim3(nb_all), dim3(256), 4 * (size_t)std::max(max_len, 1), st, Q);
+            hipLaunchKernelGGL(k_ba_pairs_scan, dim3(1), dim3(1024), 0, st, Q, nb_all);
+            hipLaunchKernelGGL(k_ba_pairs<true>, dim3(nb_all), dim3(256), 4 * (size_t)std::max(max_len, 1), st, Q);
+        }
+    } else {
+        if (nblk) HIP_TRY(hipMemcpyAsync(base + o_blk, blocks.data(), sizeof(BaBlock) * (size_t)nblk, hipMemcpyHostToDevice, st));
+        if (npairs) HIP_TRY(hipMemcpyAsync(base + o_pairs, pairs, sizeof(int2) * (size_t)npairs, hipMemcpyHostToDevice, st));
+    }
     HIP_TRY(hipMemsetAsync(base + o_act, 1, ne, st));
     HIP_TRY(hipMemsetAsync(base + o_flags, 0, ne, st));
     const double tp3 = tnow();
