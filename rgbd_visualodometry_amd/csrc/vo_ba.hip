@@ -1086,10 +1086,12 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     const double tt0 = tnow();
     // CSR point -> edges
     std::vector<int32_t> pt_start(nx + 1, 0), pt_edges(ne);
-    for (int e = 0; e < ne; ++e) pt_start[in->edge_point[e] + 1]++;
+    bool sorted_by_point = true;
+    for (int e = 0; e < ne; ++e) { pt_start[in->edge_point[e] + 1]++; if (e && in->edge_point[e] < in->edge_point[e - 1]) sorted_by_point = false; }
     for (int k = 0; k < nx; ++k) pt_start[k + 1] += pt_start[k];
-    { std::vector<int32_t> fill(pt_start.begin(), pt_start.end() - 1);
-      for (int e = 0; e < ne; ++e) pt_edges[fill[in->edge_point[e]]++] = e; }
+    if (sorted_by_point) for (int e = 0; e < ne; ++e) pt_edges[e] = e;        // the graph cut of Backend::Build emits edges point by point
+    else { std::vector<int32_t> fill(pt_start.begin(), pt_start.end() - 1);
+           for (int e = 0; e < ne; ++e) pt_edges[fill[in->edge_point[e]]++] = e; }
     // CSR free pose -> edges, and the (e1, e2) pair lists of every 6x6 block of the reduced system
     std::vector<int32_t> ps_start(nf + 1, 0), ps_edges;
     for (int e = 0; e < ne; ++e) if (in->edge_pose[e] < nf) ps_start[in->edge_pose[e] + 1]++;
@@ -1100,8 +1102,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     const double tp1 = tnow();
     // Device-built pair lists (k_ba_pairs) need the edges sorted by point (the per-pose lists are then sorted by point
     // and a block's list is a sorted intersection) and the longest per-pose list in LDS; otherwise the host builds them.
-    bool dev_pairs = nf <= 64;
-    for (int e = 1; e < ne && dev_pairs; ++e) if (in->edge_point[e] < in->edge_point[e - 1]) dev_pairs = false;
+    bool dev_pairs = nf <= 64 && sorted_by_point;
     int max_len = 0;
     for (int j = 0; j < nf; ++j) max_len = std::max(max_len, ps_start[j + 1] - ps_start[j]);
     if (max_len > PAIR_LDS_CAP) dev_pairs = false;

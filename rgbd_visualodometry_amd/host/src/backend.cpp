@@ -104,6 +104,7 @@ void Backend::Build(Job& j, const Frame::Ptr& kf) {
         j.poseFrames.push_back(f.get());
     }
     j.nFree = (int)j.poseFrames.size();
+    { VO_SCOPE("ba.build.points");
     j.points.reserve(lastPoints_ + lastPoints_ / 4 + 1024);
     for (int p = 0; p < j.nFree; ++p) {
         for (const Frame::ObservedEntry& e : j.poseFrames[p]->Observed()) {        // insertion order: deterministic without sorting
@@ -113,21 +114,35 @@ void Backend::Build(Job& j, const Frame::Ptr& kf) {
             j.points.push_back(mp);
         }
     }
-    const size_t hint = lastEdges_ + lastEdges_ / 4 + 4096;
-    j.edgePose.reserve(hint); j.edgePoint.reserve(hint); j.edgeUv.reserve(2 * hint);
-    for (size_t k = 0; k < j.points.size(); ++k) {
-        for (const Mappoint::Observation& o : j.points[k]->ObservationList()) {     // keyframe-id order
+    }
+    { VO_SCOPE("ba.build.edges");
+    // edges are written through raw pointers into arrays sized from the previous graph (grown geometrically when short)
+    size_t cap = lastEdges_ + lastEdges_ / 4 + 4096, ne = 0;
+    j.edgePose.resize(cap); j.edgePoint.resize(cap); j.edgeUv.resize(2 * cap);
+    int32_t* ep = j.edgePose.data(); int32_t* el = j.edgePoint.data(); float* uv = j.edgeUv.data();
+    const size_t npts = j.points.size();
+    for (size_t k = 0; k < npts; ++k) {
+        const std::vector<Mappoint::Observation>& obs = j.points[k]->ObservationList();     // keyframe-id order
+        if (ne + obs.size() > cap) {
+            cap = 2 * (ne + obs.size());
+            j.edgePose.resize(cap); j.edgePoint.resize(cap); j.edgeUv.resize(2 * cap);
+            ep = j.edgePose.data(); el = j.edgePoint.data(); uv = j.edgeUv.data();
+        }
+        for (const Mappoint::Observation& o : obs) {
             Frame* f = o.keyframe;
             if (f == nullptr) continue;
             if (f->baStamp_ != stamp) {                                             // observer outside the free set: fixed pose
                 f->baStamp_ = stamp; f->baIndex_ = (int)j.poseFrames.size();
                 j.poseFrames.push_back(f);
             }
-            j.edgePose.push_back(f->baIndex_); j.edgePoint.push_back((int)k);
-            j.edgeUv.push_back(o.pixel.x); j.edgeUv.push_back(o.pixel.y);
+            ep[ne] = f->baIndex_; el[ne] = (int32_t)k; uv[2 * ne] = o.pixel.x; uv[2 * ne + 1] = o.pixel.y;
+            ++ne;
         }
     }
+    j.edgePose.resize(ne); j.edgePoint.resize(ne); j.edgeUv.resize(2 * ne);
     lastEdges_ = j.edgePose.size(); lastPoints_ = j.points.size();
+    }
+    VO_SCOPE("ba.build.copy");
     j.poses.resize(12 * j.poseFrames.size()); j.pts.resize(3 * j.points.size());
     for (size_t p = 0; p < j.poseFrames.size(); ++p) j.poseFrames[p]->GetPose().to12(&j.poses[12 * p]);
     for (size_t k = 0; k < j.points.size(); ++k) { const Vector3d& x = j.points[k]->PositionUnlocked(); j.pts[3 * k] = x[0]; j.pts[3 * k + 1] = x[1]; j.pts[3 * k + 2] = x[2]; }
@@ -166,6 +181,7 @@ void Backend::Apply(Job& j) {
     for (int p = 0; p < j.nFree; ++p) j.poseFrames[p]->SetPose(SE3::from12(&j.posesOut[12 * (size_t)p]));       // backend.cpp:183-187
     // backend.cpp:188-194.  The optimised positions are already one flat array: they go to the tracker's device map
     // in a single vo_map_upsert (positions only) instead of through the per-point dirty list.
+    VO_SCOPE("ba.apply.points");
     const size_t np = j.points.size();
     applySlots_.resize(np); applyXyz_.resize(3 * np);
     size_t m = 0;
