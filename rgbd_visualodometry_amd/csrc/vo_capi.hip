@@ -537,7 +537,7 @@ int vo_pose_refine_lm(vo_ctx* c, double T[12], double delta, double cut, int it_
 static double g_tt[6]; static long g_tn;
 static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-#define MATCH_COPY_FIRST 4096       // matches copied with the headers; a frame with more gets a second copy
+#define MATCH_COPY_FIRST 4096       // floor of the per-lane match copy that travels with the headers; a frame with more gets a second copy
 
 int vo_track_batch(vo_ctx* c, int n, const int* slots, const double T0[12], const vo_track_params* tp, const uint64_t* seeds,
                    vo_track_result* res, vo_match* matches, int cap) {
@@ -557,11 +557,17 @@ int vo_track_batch(vo_ctx* c, int n, const int* slots, const double T0[12], cons
         if ((rc = vo_track_lm_launch(c, n, tp->huber_delta, tp->chi2_cut, tp->it_robust, tp->it_plain, pass == tp->passes - 1))) return rc;
     }
     const double t2 = trace ? now_us() : 0;
-    const int first = std::min(std::min(cap, c->n_active), MATCH_COPY_FIRST);
+    // the copy is sized from the largest match count seen recently (+25 %): consecutive frames see the same map, and a
+    // synchronous second copy per lane costs more than the extra bytes
+    const int first = std::min(std::min(cap, c->n_active), std::max(MATCH_COPY_FIRST, c->match_hint + c->match_hint / 4));
     if ((rc = ensure_match_stage(c, std::max(first * n, std::min(cap, c->n_active))))) return rc;
     if (first > 0 && matches)
         HIP_TRY(hipMemcpy2DAsync(c->h_matches, sizeof(vo_match) * (size_t)first, c->d_matches, sizeof(vo_match) * c->chain.stride, sizeof(vo_match) * (size_t)first, n, hipMemcpyDeviceToHost, c->stream));
     if ((rc = download_track(c, n))) return rc;
+    const double t2b = trace ? now_us() : 0;
+    int seen = 0;
+    for (int i = 0; i < n; ++i) seen = std::max(seen, c->h_track[i].n_match);
+    c->match_hint = std::max(seen, c->match_hint - c->match_hint / 16);      // slow decay
     for (int i = 0; i < n; ++i) {
         const TrackDev& t = c->h_track[i];
         vo_track_result& r = res[i];
@@ -585,7 +591,7 @@ int vo_track_batch(vo_ctx* c, int n, const int* slots, const double T0[12], cons
                 memcpy(matches + (size_t)i * cap, c->h_matches, sizeof(vo_match) * (size_t)want);
             }
         }
-    if (trace) { const double t3 = now_us(); g_tt[0] += t1 - t0; g_tt[1] += t2 - t1; g_tt[2] += t3 - t2; g_tt[3] += n; if (++g_tn % 50 == 0) fprintf(stderr, "[vo_trace] track_batch avg us: upload %.1f launch %.1f wait+d2h %.1f, frames/batch %.2f\n", g_tt[0] / g_tn, g_tt[1] / g_tn, g_tt[2] / g_tn, g_tt[3] / g_tn); }
+    if (trace) { const double t3 = now_us(); g_tt[0] += t1 - t0; g_tt[1] += t2 - t1; g_tt[2] += t2b - t2; g_tt[4] += t3 - t2b; g_tt[3] += n; if (++g_tn % 50 == 0) fprintf(stderr, "[vo_trace] track_batch avg us: upload %.1f launch %.1f wait+d2h %.1f host copy-out %.1f, frames/batch %.2f\n", g_tt[0] / g_tn, g_tt[1] / g_tn, g_tt[2] / g_tn, g_tt[4] / g_tn, g_tt[3] / g_tn); }
     return VO_OK;
 }
 
