@@ -20,9 +20,6 @@
 #include "vo_brief_pattern.h"
 #include "vo_internal.h"
 
-#ifndef FAST_VARIANT
-#define FAST_VARIANT 0
-#endif
 
 __constant__ int8_t c_pattern[256 * 4];
 
@@ -167,11 +164,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(DevPlan P, const uint8_t* __re
     }
     __syncthreads();
     const int nlist = s_nlist;
-#if FAST_VARIANT == 2
-    for (int q = tid; q < 0; q += 256) {
-#else
     for (int q = tid; q < nlist; q += 256) {
-#endif
         const int i = s_list[q];
         const int sx = i % SP, sy = i / SP;
         const int sc = fast_score_lds(s_gray, (sy + 3) * GP + sx + 3);
@@ -201,11 +194,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(DevPlan P, const uint8_t* __re
     const int ns = s_nsurv;
     if (ns == 0) return;
     if (tid == 0) {
-#if FAST_VARIANT == 1
-        s_base = 0; (void)cand_cnt;
-#else
         s_base = atomicAdd(&cand_cnt[slot * VO_MAX_LEVELS + l], ns);
-#endif
     }
     __syncthreads();
     const int base = s_base;
