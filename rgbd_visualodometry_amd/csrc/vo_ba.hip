@@ -1112,6 +1112,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     int2* pairs = nullptr;
     std::vector<int32_t> ps_pt;
     int nb_all = 0, slices_ub = 0;
+    int* h_counts = nullptr;
     if (dev_pairs) {
         ps_pt.resize(std::max<size_t>(ps_edges.size(), 1));
         for (size_t q = 0; q < ps_edges.size(); ++q) ps_pt[q] = in->edge_point[ps_edges[q]];
@@ -1223,6 +1224,11 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
             hipLaunchKernelGGL(k_ba_pairs_scan, dim3(1), dim3(1024), 0, st, Q, nb_all);
             hipLaunchKernelGGL(k_ba_pairs<true>, dim3(nb_all), dim3(256), 4 * (size_t)std::max(max_len, 1), st, Q);
         }
+        // the real slice / pair counts come back with the synchronisation below (it waits for the uploads anyway), so the
+        // Schur kernel is launched on the exact grid instead of the upper bound
+        if (!(h_counts = (int*)vo_stage(c, 512))) return VO_E_NOMEM;
+        h_counts[0] = 0; h_counts[1] = 0;
+        HIP_TRY(hipMemcpyAsync(h_counts, base + o_pn, 8, hipMemcpyDeviceToHost, st));
     } else {
         if (nblk) HIP_TRY(hipMemcpyAsync(base + o_blk, blocks.data(), sizeof(BaBlock) * (size_t)nblk, hipMemcpyHostToDevice, st));
         if (npairs) HIP_TRY(hipMemcpyAsync(base + o_pairs, pairs, sizeof(int2) * (size_t)npairs, hipMemcpyHostToDevice, st));
@@ -1231,6 +1237,8 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     HIP_TRY(hipMemsetAsync(base + o_flags, 0, ne, st));
     const double tp3 = tnow();
     HIP_TRY(hipStreamSynchronize(st));       // pageable sources
+    int nblk_launch = nblk;
+    if (dev_pairs && h_counts) { nblk_launch = std::min(nblk, h_counts[0]); npairs = h_counts[1]; }
 
     const double tt1 = tnow();
     double* h_scal = (double*)vo_stage(c, 256);
@@ -1258,7 +1266,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
                 { ProfScope ps(c, "k_ba_lin"); hipLaunchKernelGGL(k_ba_lin, dim3(gP4.x + nf * PSPLIT), blk, 0, st, cam, B, robust, in->huber_delta, (int)gP4.x); }
                 if (guard_steps == 0 && sidx == 0) hipLaunchKernelGGL(k_ba_maxdiag, dim3((D + 3 * nx + 255) / 256), blk, 0, st, B);
                 { ProfScope ps(c, "k_ba_init_S"); hipLaunchKernelGGL(k_ba_init_S, dim3((std::max(D * D, nx) + 255) / 256), blk, 0, st, B); }
-                if (nblk) { ProfScope ps(c, "k_ba_schur_blocks"); hipLaunchKernelGGL(k_ba_schur_blocks, dim3(nblk), blk, 0, st, B); }
+                if (nblk_launch) { ProfScope ps(c, "k_ba_schur_blocks"); hipLaunchKernelGGL(k_ba_schur_blocks, dim3(nblk_launch), blk, 0, st, B); }
                 { ProfScope ps(c, "k_ba_chol");
                   if (D <= 192) hipLaunchKernelGGL(k_ba_chol16, dim3(1), dim3(CH_THREADS), sizeof(double) * (CH_NB * CH_NB + (size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D), st, B);
                   else hipLaunchKernelGGL(k_ba_chol_t<false>, dim3(1), dim3(1024), sizeof(double) * ((size_t)7 * (D + 1) + 2 * (size_t)D), st, B); }
