@@ -295,3 +295,33 @@ def test_vo_system_gpu_matches_oracle_trajectory(frames):
     a_h = ev.ate(gt, {ts[i]: capi.pose12_to_tum(ph[i]) for i in range(n)})["rmse"]
     a_o = ev.ate(gt, {ts[i]: capi.pose12_to_tum(po[i]) for i in range(n)})["rmse"]
     assert a_h <= 1.05 * a_o + 1e-6 and a_o < 0.05
+
+
+def test_vo_system_config5_sizes_gpu_matches_oracle():
+    """BASELINE config-5 sizes end to end (1280x960, 8000 features, 2048 hypotheses, local BA on): the HIP path with look-ahead
+    ORB, speculative batches and an overlapped BA reproduces the oracle trajectory of the same schedule."""
+    from rgbd_visualodometry_amd import system
+    syn = capi.Synth()
+    sp = syn.params(seed=9, width=1280, height=960, fx=2 * 517.3, fy=2 * 516.5, cx=2 * 318.6, cy=2 * 255.3)
+    n = 10
+    bgr, depth, Twc, ts = syn.render(sp, 0, n, threads=8)
+
+    def run(lib, **opt):
+        s = system.VoSystem(lib, width=1280, height=960, fx=sp.fx, fy=sp.fy, cx=sp.cx, cy=sp.cy, number_of_features=8000,
+                            ransac_iterations=2048, backend_lag_frames=2, map_capacity=1 << 17, **opt)
+        look = opt.get("max_frames_in_flight", 1)
+        poses, i = [], 0
+        while i < n:
+            k = min(look, n - i)
+            s.prefetch(ts[i:i + k], [bgr[j].ctypes.data for j in range(i, i + k)], [depth[j].ctypes.data for j in range(i, i + k)],
+                       bgr[0].strides[0], depth[0].strides[0], False)
+            for _ in range(k):
+                poses.append(s.add_prefetched()[1])
+            i += k
+        return np.array(poses), s.stats()
+
+    po, so = run(system.ORACLE_LIB)
+    ph, sh = run(system.HOST_LIB, max_frames_in_flight=5, track_batch=4)
+    assert so["keyframes"] == sh["keyframes"] >= 2 and so["map_points"] == sh["map_points"] and so["lost"] == sh["lost"] == 0
+    assert so["ba_runs"] == sh["ba_runs"] >= 1 and so["ba_edges"] == sh["ba_edges"]
+    np.testing.assert_allclose(ph, po, atol=1e-6)
