@@ -190,6 +190,12 @@ int vo_pose_refine_lm(vo_ctx* ctx, double T_cw_inout[12], double huber_delta, do
                       int it_robust, int it_plain, uint8_t* inlier_mask /* one per RANSAC inlier */,
                       int cap, int* n_edges, int* lm_iters);
 
+/* Matches of one lane of the LAST vo_track_batch / vo_track_frame call (lane 0 for vo_track_frame), for callers that
+ * passed matches = NULL there and only need the records of some frames (the host layer: keyframes only -- the
+ * reference reads flannMatchedMptKptMap_ / pnpMatchedMptSet_ only when a keyframe is inserted, frontend.cpp:366-406).
+ * Valid until the next tracking call on the context. */
+int vo_track_fetch_matches(vo_ctx* ctx, int lane, vo_match* matches, int cap, int* n_out);
+
 /* ---- fused per-frame tracking ------------------------------------------------------- */
 int vo_track_frame(vo_ctx* ctx, int slot, const double T_cw_prior[12], const vo_track_params* tp,
                    vo_track_result* res, vo_match* matches, int cap);

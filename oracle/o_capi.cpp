@@ -29,6 +29,7 @@ struct vo_ctx {
     std::vector<Slot> slots;
     MapStore map;
     Corr corr; std::vector<vo_match> last_matches;
+    std::vector<std::vector<vo_match>> lane_matches;           // per lane of the last vo_track_batch (vo_track_fetch_matches)
     std::vector<int32_t> ransac_inliers;
 };
 
@@ -244,6 +245,7 @@ int vo_track_frame(vo_ctx* c, int slot, const double T0[12], const vo_track_para
     std::memcpy(res->T_cw, T, sizeof(T));
     if (matches) std::memcpy(matches, c->last_matches.data(), sizeof(vo_match) * std::min<size_t>(cap, c->last_matches.size()));
     if ((int)c->last_matches.size() > cap && matches) res->status = VO_E_OVERFLOW;
+    c->lane_matches.assign(1, c->last_matches);
     return VO_OK;
 }
 
@@ -251,12 +253,23 @@ int vo_track_batch(vo_ctx* c, int n, const int* slots, const double T0[12], cons
                    vo_track_result* res, vo_match* matches, int cap) {
     if (!c || n < 1 || !slots || !T0 || !tp || !res || cap < 0) return VO_E_INVALID;
     if (n > std::max(1, c->p.max_track_batch)) return VO_E_INVALID;
+    std::vector<std::vector<vo_match>> lanes(n);
     for (int i = 0; i < n; ++i) {                  // frames sharing prior + map are independent: a plain loop on the CPU
         vo_track_params t = *tp;
         if (seeds) t.seed = seeds[i];
         int rc = vo_track_frame(c, slots[i], T0, &t, &res[i], matches ? matches + (size_t)i * cap : nullptr, cap);
         if (rc) return rc;
+        lanes[i] = c->last_matches;
     }
+    c->lane_matches.swap(lanes);
+    return VO_OK;
+}
+
+int vo_track_fetch_matches(vo_ctx* c, int lane, vo_match* matches, int cap, int* n_out) {
+    if (!c || lane < 0 || lane >= (int)c->lane_matches.size() || !matches || cap < 0 || !n_out) return VO_E_INVALID;
+    const int n = (int)std::min<size_t>((size_t)cap, c->lane_matches[lane].size());
+    std::memcpy(matches, c->lane_matches[lane].data(), sizeof(vo_match) * (size_t)n);
+    *n_out = n;
     return VO_OK;
 }
 

@@ -63,7 +63,7 @@ MATCH_DTYPE = np.dtype([("map_index", "<i4"), ("kp_index", "<i4"), ("distance", 
 SYMBOLS = ["vo_ctx_create", "vo_ctx_destroy", "vo_strerror", "vo_backend_name", "vo_default_params",
            "vo_default_track_params", "vo_frame_upload", "vo_frame_bind_device", "vo_orb_detect_describe",
            "vo_orb_fetch", "vo_orb_level_size", "vo_orb_fetch_level", "vo_map_upsert", "vo_map_set_active",
-           "vo_match_active_map", "vo_matches_set", "vo_pnp_ransac", "vo_pose_refine_lm", "vo_track_frame", "vo_track_batch",
+           "vo_match_active_map", "vo_matches_set", "vo_pnp_ransac", "vo_pose_refine_lm", "vo_track_frame", "vo_track_batch", "vo_track_fetch_matches",
            "vo_local_ba", "vo_sync", "vo_profile_enable", "vo_profile_read"]
 
 
@@ -112,6 +112,7 @@ class VoLib:
         L.vo_track_frame.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(VoTrackParams), C.POINTER(VoTrackResult),
                                      C.c_void_p, C.c_int]
         L.vo_track_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(VoTrackParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.vo_track_fetch_matches.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.vo_local_ba.argtypes = [C.c_void_p, C.POINTER(VoBaProblem), C.POINTER(VoBaResult)]
         L.vo_sync.argtypes = [C.c_void_p]
         L.vo_profile_enable.argtypes = [C.c_void_p, C.c_int]
@@ -254,6 +255,22 @@ class VoContext:
         m = np.zeros((n, cap), dtype=MATCH_DTYPE)
         self.L.check(self.L.lib.vo_track_batch(self.h, n, _ptr(sl), _ptr(T), C.byref(tp), _ptr(sd), C.cast(res, C.c_void_p), _ptr(m), cap), "vo_track_batch")
         return [res[i] for i in range(n)], [m[i, :min(res[i].n_matches, cap)].copy() for i in range(n)]
+
+    def track_batch_deferred(self, slots, T_prior, tp: VoTrackParams, seeds, cap=4096):
+        """vo_track_batch without the match copy, then vo_track_fetch_matches per lane (what the host layer does on keyframes)."""
+        n = len(slots)
+        sl = np.ascontiguousarray(slots, dtype=np.int32)
+        sd = np.ascontiguousarray(seeds, dtype=np.uint64)
+        T = np.ascontiguousarray(T_prior, dtype=np.float64).reshape(12)
+        res = (VoTrackResult * n)()
+        self.L.check(self.L.lib.vo_track_batch(self.h, n, _ptr(sl), _ptr(T), C.byref(tp), _ptr(sd), C.cast(res, C.c_void_p), None, cap), "vo_track_batch")
+        out = []
+        for lane in range(n):
+            m = np.zeros(cap, dtype=MATCH_DTYPE)
+            got = C.c_int()
+            self.L.check(self.L.lib.vo_track_fetch_matches(self.h, lane, _ptr(m), cap, C.byref(got)), "vo_track_fetch_matches")
+            out.append(m[:got.value].copy())
+        return [res[i] for i in range(n)], out
 
     def local_ba(self, poses, n_free, points, edge_pose, edge_point, edge_uv, huber_delta=7.815 ** 0.5, chi2_th=1.0,
                  it_robust=10, it_plain=10):

@@ -346,6 +346,8 @@ int vo_orb_fetch(vo_ctx* c, int slot, vo_keypoint* kps, uint8_t* desc, int cap, 
     if (!c->h_orb_cache) {
         if (hipHostMalloc((void**)&c->h_orb_cache, o_d + (size_t)32 * F * N, hipHostMallocDefault) != hipSuccess) return VO_E_NOMEM;
     }
+    // The results of the whole ORB batch come down together on the first fetch of any of its slots (pinned cache): the
+    // copy rides behind the ORB launch chain, off the per-keyframe path; later fetches are host memcpys.
     const bool in_batch = slot >= c->orb_batch0 && slot < c->orb_batch0 + c->orb_batchn;
     if (!c->orb_cache_valid || !in_batch) {
         const int s0 = in_batch ? c->orb_batch0 : slot, sn = in_batch ? c->orb_batchn : 1;
@@ -564,6 +566,7 @@ int vo_track_batch(vo_ctx* c, int n, const int* slots, const double T0[12], cons
     if (first > 0 && matches)
         HIP_TRY(hipMemcpy2DAsync(c->h_matches, sizeof(vo_match) * (size_t)first, c->d_matches, sizeof(vo_match) * c->chain.stride, sizeof(vo_match) * (size_t)first, n, hipMemcpyDeviceToHost, c->stream));
     if ((rc = download_track(c, n))) return rc;
+    c->last_track_lanes = n;
     const double t2b = trace ? now_us() : 0;
     int seen = 0;
     for (int i = 0; i < n; ++i) seen = std::max(seen, c->h_track[i].n_match);
@@ -592,6 +595,21 @@ int vo_track_batch(vo_ctx* c, int n, const int* slots, const double T0[12], cons
             }
         }
     if (trace) { const double t3 = now_us(); g_tt[0] += t1 - t0; g_tt[1] += t2 - t1; g_tt[2] += t2b - t2; g_tt[4] += t3 - t2b; g_tt[3] += n; if (++g_tn % 50 == 0) fprintf(stderr, "[vo_trace] track_batch avg us: upload %.1f launch %.1f wait+d2h %.1f host copy-out %.1f, frames/batch %.2f\n", g_tt[0] / g_tn, g_tt[1] / g_tn, g_tt[2] / g_tn, g_tt[4] / g_tn, g_tt[3] / g_tn); }
+    return VO_OK;
+}
+
+int vo_track_fetch_matches(vo_ctx* c, int lane, vo_match* matches, int cap, int* n_out) {
+    if (!c || lane < 0 || lane >= c->last_track_lanes || !matches || cap < 0 || !n_out) return VO_E_INVALID;
+    HIP_TRY(hipSetDevice(c->device));
+    const int n = std::min(cap, c->h_track[lane].n_match);
+    int rc = ensure_match_stage(c, std::max(n, 1));
+    if (rc) return rc;
+    if (n > 0) {
+        HIP_TRY(hipMemcpyAsync(c->h_matches, c->d_matches + (size_t)lane * c->chain.stride, sizeof(vo_match) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        memcpy(matches, c->h_matches, sizeof(vo_match) * (size_t)n);
+    }
+    *n_out = n;
     return VO_OK;
 }
 

@@ -79,6 +79,7 @@ struct vo_ctx {
     double* d_map_pos; double* d_map_nrm; uint32_t* d_map_desc; uint8_t* d_map_flags;
     int32_t* d_active; int n_active; int active_cap;
     // tracking chain
+    int last_track_lanes = 0;                       // lanes of the last vo_track_batch (vo_track_fetch_matches)
     int match_hint = 0;                             // largest recent match count (sizes the result copy of vo_track_batch)
     uint32_t* d_best;                               // per active query: (dist << 22) | kp, 0xFFFFFFFF = not a candidate
     int32_t* d_mcand;                               // visible candidates (indices into the active list), unordered

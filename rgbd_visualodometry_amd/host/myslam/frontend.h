@@ -67,7 +67,7 @@ private:
     // speculative batch tracking: frames between keyframes share prior + map (frontend.cpp:96), so the frames that
     // follow the current one in the prefetch queue are tracked in the same launch chain; results are cached and
     // dropped when a keyframe / BA merge changes the inputs (epoch).
-    struct SpecResult { size_t frameId; uint64_t epoch; vo_track_result res; std::vector<vo_match> matches; };
+    struct SpecResult { size_t frameId; uint64_t epoch; vo_track_result res; int lane; };    // matches stay on the device (lane buffers)
     std::vector<SpecResult> spec_;
     std::vector<Frame::Ptr> prefetched_;
     uint64_t epoch_ = 0;
@@ -77,7 +77,7 @@ private:
     // The per-frame containers above (keypointsCurr_, flann*/pnp* lists) are only read on keyframes and by the viewer:
     // they are materialised on demand from the raw device results of the current frame.
     int nKeypointsCurr_ = 0; bool keypointsBuilt_ = false;
-    const vo_match* curMatches_ = nullptr; int nCurMatches_ = 0; bool matchListsBuilt_ = false;
+    int curLane_ = -1, nCurMatches_ = 0; bool matchesFetched_ = false, matchListsBuilt_ = false;    // lane of the last batch holding this frame's matches
     void EnsureKeypoints();
     void EnsureMatchLists();
     std::vector<int32_t> upIdx_; std::vector<double> upXyz_, upNrm_; std::vector<uint8_t> upDesc_, upFlags_;

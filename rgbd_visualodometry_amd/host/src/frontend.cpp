@@ -144,16 +144,19 @@ void FrontEnd::ExtractKeyPointsAndComputeDescriptors() {
         PrefetchFrames(one);
     }
     const int cap = 2 * params_.n_features + 64;
-    kpBuf_.resize(cap); descBuf_.resize((size_t)32 * cap);
     int n = 0;
-    vo_check(vo_orb_fetch(ctx_, f->slot_, kpBuf_.data(), descBuf_.data(), cap, &n), "vo_orb_fetch");
+    vo_check(vo_orb_fetch(ctx_, f->slot_, nullptr, nullptr, cap, &n), "vo_orb_fetch");      // count only; records on demand
     nKeypointsCurr_ = std::min(n, cap);
-    keypointsBuilt_ = false; matchListsBuilt_ = false; curMatches_ = nullptr; nCurMatches_ = 0;
+    keypointsBuilt_ = false; matchListsBuilt_ = false; matchesFetched_ = false; curLane_ = -1; nCurMatches_ = 0;
     stats_.last_keypoints = nKeypointsCurr_;
 }
 
 void FrontEnd::EnsureKeypoints() {
     if (keypointsBuilt_) return;
+    const int cap = 2 * params_.n_features + 64;
+    kpBuf_.resize(cap); descBuf_.resize((size_t)32 * cap);
+    int nf = 0;
+    vo_check(vo_orb_fetch(ctx_, frameCurr_->slot_, kpBuf_.data(), descBuf_.data(), cap, &nf), "vo_orb_fetch");
     const int n = nKeypointsCurr_;
     keypointsCurr_.resize(n); descriptorsCurr_.resize(n);
     for (int i = 0; i < n; ++i) {
@@ -170,11 +173,18 @@ void FrontEnd::EnsureKeypoints() {
 void FrontEnd::EnsureMatchLists() {
     if (matchListsBuilt_) return;
     EnsureKeypoints();
+    if (!matchesFetched_ && curLane_ >= 0 && nCurMatches_ > 0) {        // the records of this frame are still in its lane's device buffer
+        if ((int)matchBuf_.size() < nCurMatches_) matchBuf_.resize(nCurMatches_);
+        int got = 0;
+        vo_check(vo_track_fetch_matches(ctx_, curLane_, matchBuf_.data(), nCurMatches_, &got), "vo_track_fetch_matches");
+        nCurMatches_ = got;
+    }
+    matchesFetched_ = true;
     flannMatchedMpt_.clear(); flannMatchedKp_.clear(); flannMatchedLm_.clear();
     flannMatchedKptSet_.reset(keypointsCurr_.size()); pnpMatchedKptSet_.reset(keypointsCurr_.size());
     pnpMatchedMpt_.clear(); pnpMatchedMptKp_.clear();
     for (int i = 0; i < nCurMatches_; ++i) {
-        const vo_match& m = curMatches_[i];
+        const vo_match& m = matchBuf_[i];
         Mappoint* mp = activeList_[activeIndexOfSlot_[m.map_index]];
         const KeyPoint& kp = keypointsCurr_[m.kp_index];
         flannMatchedMpt_.push_back(mp); flannMatchedKp_.push_back(m.kp_index);
@@ -230,7 +240,7 @@ void FrontEnd::MatchAndEstimatePose() {
     for (auto& sp : spec_)
         if (sp.frameId == frameCurr_->GetId() && sp.epoch == epoch_) {            // tracked ahead of time with identical inputs
             res = sp.res;
-            curMatches_ = sp.matches.data(); nCurMatches_ = (int)sp.matches.size();  // alive until the next batch call
+            curLane_ = sp.lane;                                                   // lane buffers live until the next batch call
             have = true;
             break;
         }
@@ -258,19 +268,18 @@ void FrontEnd::MatchAndEstimatePose() {
         const int nb = (int)batch.size(), cap = (int)activeList_.size() + 1;
         std::vector<int> slots(nb); std::vector<uint64_t> seeds(nb); std::vector<vo_track_result> rs(nb);
         for (int j = 0; j < nb; ++j) { slots[j] = batch[j]->slot_; seeds[j] = 0x5eed5eedull + 2 * (uint64_t)(stats_.frames + j); }
-        if (matchBuf_.size() < (size_t)nb * cap) matchBuf_.resize((size_t)nb * cap);
-        { VO_SCOPE("fe.vo_track_batch"); vo_check(vo_track_batch(ctx_, nb, slots.data(), prior, &trackParams_, seeds.data(), rs.data(), matchBuf_.data(), cap), "vo_track_batch"); }
-        VO_SCOPE("fe.spec_store");
+        // match records are not copied back here: only keyframes (and the viewer) read them, through vo_track_fetch_matches
+        { VO_SCOPE("fe.vo_track_batch"); vo_check(vo_track_batch(ctx_, nb, slots.data(), prior, &trackParams_, seeds.data(), rs.data(), nullptr, cap), "vo_track_batch"); }
         for (int j = 1; j < nb; ++j) {
-            SpecResult sp; sp.frameId = batch[j]->GetId(); sp.epoch = epoch_; sp.res = rs[j];
-            sp.matches.assign(matchBuf_.begin() + (size_t)j * cap, matchBuf_.begin() + (size_t)j * cap + std::min(rs[j].n_matches, cap));
-            spec_.push_back(std::move(sp));
+            SpecResult sp; sp.frameId = batch[j]->GetId(); sp.epoch = epoch_; sp.res = rs[j]; sp.lane = j;
+            spec_.push_back(sp);
         }
         res = rs[0];
-        curMatches_ = matchBuf_.data(); nCurMatches_ = std::min(res.n_matches, cap);
+        curLane_ = 0;
     }
     if (res.status != VO_OK) throw std::runtime_error(std::string("device pipeline: ") + vo_strerror(res.status));
-    matchListsBuilt_ = false;
+    matchListsBuilt_ = false; matchesFetched_ = false;
+    nCurMatches_ = std::min(res.n_matches, (int)activeList_.size() + 1);
     numInliers_ = res.n_ransac_inliers;                                             // frontend.cpp:242
     frameCurr_->SetPose(SE3::from12(res.T_cw));                                     // frontend.cpp:312
     stats_.last_candidates = res.n_candidates; stats_.last_matches = res.n_matches;

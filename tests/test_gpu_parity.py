@@ -266,6 +266,10 @@ def test_track_batch_equals_sequential_calls(frames, libs):
             assert getattr(res[j], f) == getattr(rs, f), (j, f)
         assert np.array_equal(np.array(res[j].T_cw), np.array(rs.T_cw))
         assert np.array_equal(ms[j], m1)
+    # the deferred form (no match copy in the batch call, per-lane fetch afterwards) returns the same records
+    res2, ms2 = ctx.track_batch_deferred([1, 2, 3, 4], inv12(Twc[0]), tp, seeds, cap=4096)
+    for j in range(4):
+        assert np.array_equal(np.array(res2[j].T_cw), np.array(res[j].T_cw)) and np.array_equal(ms2[j], ms[j])
 
 
 def test_vo_system_gpu_matches_oracle_trajectory(frames):
