@@ -1254,7 +1254,8 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     const int CHUNK = 6;                                    // LM steps enqueued between two host polls
     auto optimize = [&](int robust, int max_it, int& iters) -> int {
         if (max_it <= 0) return VO_OK;
-        HIP_TRY(hipStreamSynchronize(st));
+        // no synchronisation here: the stream was drained by the previous read-back of h_ctl (or by the upload), so the
+        // pinned control block is free to be rewritten
         memset(h_ctl, 0, sizeof(BaCtl));
         h_ctl->max_it = max_it; h_ctl->need_lin = 1; h_ctl->first = 1; h_ctl->buf = cur_buf; h_ctl->ni = 2;
         HIP_TRY(hipMemcpyAsync(B.ctl, h_ctl, sizeof(BaCtl), hipMemcpyHostToDevice, st));
@@ -1283,20 +1284,20 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
         return VO_OK;
     };
     // kernels outside the LM loop read the current buffer index from the control block
-    auto set_ctl_idle = [&]() -> int {
-        HIP_TRY(hipStreamSynchronize(st));
-        memset(h_ctl, 0, sizeof(BaCtl));
-        h_ctl->buf = cur_buf;
-        HIP_TRY(hipMemcpyAsync(B.ctl, h_ctl, sizeof(BaCtl), hipMemcpyHostToDevice, st));
+    auto set_ctl_idle = [&]() -> int {                     // called right after the upload synchronisation: stream idle
+        BaCtl* h_idle = (BaCtl*)((uint8_t*)h_scal + 128);   // its own pinned slot: h_ctl is rewritten before this copy has run
+        memset(h_idle, 0, sizeof(BaCtl));
+        h_idle->buf = cur_buf;
+        HIP_TRY(hipMemcpyAsync(B.ctl, h_idle, sizeof(BaCtl), hipMemcpyHostToDevice, st));
         return VO_OK;
     };
 
-    // initial plain chi2 (reporting only)
+    // initial plain chi2 (reporting only): its read-back rides on the next synchronisation
     if ((rc = set_ctl_idle())) return rc;
     HIP_TRY(hipMemsetAsync(B.scal, 0, 64, st));
     hipLaunchKernelGGL(k_ba_chi, gE, blk, 0, st, cam, B, 0, 0, in->huber_delta, 0);
-    if ((rc = read_scal())) return rc;
-    out->chi2_initial = h_scal[5];
+    double* h_chi0 = h_scal + 24;                           // pinned mailbox, beyond scal (8 doubles) and ctl
+    HIP_TRY(hipMemcpyAsync(h_chi0, B.scal + 5, sizeof(double), hipMemcpyDeviceToHost, st));
 
     int iters = 0;
     if ((rc = optimize(1, in->it_robust, iters))) return rc;                       // backend.cpp:140-141
@@ -1304,15 +1305,16 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     if ((rc = optimize(0, in->it_plain, iters))) return rc;                        // backend.cpp:158-159
     HIP_TRY(hipMemsetAsync(B.scal, 0, 64, st));
     hipLaunchKernelGGL(k_ba_cull, gE, blk, 0, st, cam, B, 1, in->chi2_th);         // backend.cpp:162-172
-    if ((rc = read_scal())) return rc;
-    out->chi2_final = h_scal[6];
     out->lm_iters = iters;
     const double tt2 = tnow();
+    HIP_TRY(hipMemcpyAsync(h_scal, B.scal, 64, hipMemcpyDeviceToHost, st));     // one synchronisation for chi2 and the results
     HIP_TRY(hipMemcpyAsync(out->poses, cur_buf ? B.posesB : B.posesA, 96 * (size_t)nf, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(out->points, cur_buf ? B.ptsB : B.ptsA, 24 * (size_t)nx, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(out->edge_flags, B.flags, ne, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
+    out->chi2_final = h_scal[6];
+    out->chi2_initial = *h_chi0;
     if (trace) { static double a0 = 0, a1 = 0, a2 = 0; static int n = 0; a0 += tt1 - tt0; a1 += tt2 - tt1; a2 += tnow() - tt2; if (++n % 10 == 0) fprintf(stderr, "[vo_trace] vo_ba_run avg ms: prep+upload %.2f optimise %.2f download %.2f (D=%d edges=%d pairs=%d) | last prep: csr %.2f pairs %.2f enqueue %.2f sync %.2f\n", a0 / n, a1 / n, a2 / n, D, ne, npairs, tp1 - tt0, tp2 - tp1, tp3 - tp2, tt1 - tp3); }
     return VO_OK;
 }
