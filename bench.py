@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--no-ba", action="store_true", help="disable local BA (enable_local_optimization: 0)")
     ap.add_argument("--ba-lag", type=int, default=8, help="0: BA synchronous in AddFrame; L>0: overlapped, merged L frames later (deterministic)")
     ap.add_argument("--hyps", type=int, default=100, help="PnP-RANSAC hypotheses per pass (default.yaml: 100; BASELINE config 3: 2048)")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the driver's runs) | gloo (rehearsal of the multi-rank path)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses device 0 (needs --dist-backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=150, help="bounded CPU-baseline sample (frames)")
     args = ap.parse_args()
@@ -82,8 +84,10 @@ def main():
     rank, local_rank, world = shard.env_rank_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    grp = shard.Group("nccl", device=torch.device("cuda", local_rank))     # RCCL; only barrier + MAX(time) cross ranks
+    grp = shard.Group(args.dist_backend, device=torch.device("cuda", local_rank))     # RCCL; only barrier + MAX(time) cross ranks
 
     W, H, N = 640, 480, args.features
     K, Wm = args.steps, args.warmup

@@ -36,6 +36,12 @@ __global__ void k_dpp_probe(double* out) {
     out[lane] = b; out[64 + lane] = acc;
 }
 
+__global__ void k_spin(long long clocks, int* sink) {
+    const long long t0 = clock64();
+    while (clock64() - t0 < clocks) { }
+    if (clocks < 0) *sink = 1;
+}
+
 __global__ void k_reduce32_probe(double* out) {
     const int lane = threadIdx.x;
     double v[32], r[8];
@@ -82,6 +88,21 @@ __global__ void k_rsq_probe(const double* x, double* y, int n) {
 }
 
 int main() {
+    {   // do small kernels on different streams overlap?  N streams x 20 spin kernels of ~50 us (1 workgroup of 256 threads each)
+        int* sink; hipMalloc(&sink, 4);
+        for (int ns : {1, 2, 4, 8, 16}) {
+            std::vector<hipStream_t> sts(ns);
+            for (auto& x : sts) hipStreamCreateWithFlags(&x, hipStreamNonBlocking);
+            hipDeviceSynchronize();
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int it = 0; it < 20; ++it) for (int i = 0; i < ns; ++i) hipLaunchKernelGGL(k_spin, dim3(1), dim3(256), 0, sts[i], 120000LL, sink);
+            hipDeviceSynchronize();
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            printf("concurrency probe: %2d streams x 20 kernels of ~50 us: %.0f us wall (serial would be %.0f)\n", ns, us, 50.0 * 20 * ns);
+            for (auto& x : sts) hipStreamDestroy(x);
+        }
+        hipFree(sink);
+    }
     { double* d; hipMalloc(&d, 512 * 8); hipLaunchKernelGGL(k_reduce32_probe, dim3(1), dim3(64), 0, 0, d); std::vector<double> h(512); hipMemcpy(h.data(), d, 512 * 8, hipMemcpyDeviceToHost);
       int bad = 0;
       for (int k = 0; k < 8; ++k) for (int lane = 0; lane < 64; ++lane) {

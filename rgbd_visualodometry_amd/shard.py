@@ -28,7 +28,7 @@ class Group:
     def __init__(self, backend: Optional[str] = None, device=None):
         self.rank, self.local_rank, self.world = env_rank_world()
         self.dist = None
-        self.device = device
+        self.device = device if backend == "nccl" else None      # gloo reduces host tensors
         if self.world > 1:
             import torch.distributed as dist
             self.dist = dist
