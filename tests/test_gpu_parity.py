@@ -329,3 +329,31 @@ def test_vo_system_config5_sizes_gpu_matches_oracle():
     assert so["keyframes"] == sh["keyframes"] >= 2 and so["map_points"] == sh["map_points"] and so["lost"] == sh["lost"] == 0
     assert so["ba_runs"] == sh["ba_runs"] >= 1 and so["ba_edges"] == sh["ba_edges"]
     np.testing.assert_allclose(ph, po, atol=1e-6)
+
+
+def test_degenerate_frames_behave_like_the_oracle(frames, libs):
+    """Edge cases of the chain: a textureless frame (no FAST corner survives), an empty tracking map, a tracking map the
+    frame cannot see -- same counts and status on both sides, no fault."""
+    bgr, depth, Twc, _ = frames
+    flat = np.full_like(bgr[0], 127)
+    out = []
+    for L in libs:
+        ctx, p = make_ctx(L, n_features=500, max_frames=3, map_capacity=4096)
+        ctx.upload(0, flat, depth[0]); ctx.upload(1, bgr[0], depth[0]); ctx.upload(2, bgr[3], depth[3])
+        ctx.orb(0, 3)
+        kf, df = ctx.orb_fetch(0)
+        k1, d1 = ctx.orb_fetch(1)
+        tp = L.default_track_params(n_hyp=64)
+        r_empty, m_empty = ctx.track(2, inv12(Twc[0]), tp)                    # nothing in the map yet
+        seed_map(ctx, p, k1, d1, Twc[0])
+        r_flat, m_flat = ctx.track(0, inv12(Twc[0]), tp)                      # map, but a frame without keypoints
+        away = inv12(Twc[0]).copy(); away[:9] = np.array([-1, 0, 0, 0, 1, 0, 0, 0, -1.0])     # looking the other way
+        r_away, m_away = ctx.track(2, away, tp)
+        out.append((len(kf), r_empty, len(m_empty), r_flat, len(m_flat), r_away, len(m_away)))
+    h, o = out
+    assert h[0] == o[0] == 0
+    for a, b in ((h[1], o[1]), (h[3], o[3]), (h[5], o[5])):
+        for f in ("status", "n_candidates", "n_matches", "n_ransac_inliers", "n_lm_inliers"):
+            assert getattr(a, f) == getattr(b, f), f
+    assert h[2] == o[2] == 0 and h[4] == o[4] == 0 and h[6] == o[6]
+    assert h[1].n_ransac_inliers == 0 and h[3].n_ransac_inliers == 0
