@@ -1083,6 +1083,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     }
     const bool trace = getenv("VO_TRACE") != nullptr;
     auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    HIP_TRY(hipStreamSynchronize(st));                      // the pinned staging buffer may still feed an earlier vo_map_upsert
     const double tt0 = tnow();
     // CSR point -> edges
     std::vector<int32_t> pt_start(nx + 1, 0), pt_edges(ne);

@@ -95,7 +95,7 @@ static int build_plan(const vo_params& p, DevPlan& P, std::vector<int>& tab, std
 
 void* vo_stage(vo_ctx* c, size_t bytes) {
     if (bytes <= c->h_stage_bytes) return c->h_stage;
-    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_stage) { (void)hipStreamSynchronize(c->stream); (void)hipHostFree(c->h_stage); }     // an async copy may still read it
     c->h_stage = nullptr; c->h_stage_bytes = 0;
     size_t want = std::max<size_t>(bytes + bytes / 2, 1 << 20);     // grows with the map: leave headroom, pinned allocations are slow
     if (hipHostMalloc(&c->h_stage, want, hipHostMallocDefault) != hipSuccess) { c->h_stage = nullptr; return nullptr; }
@@ -413,7 +413,8 @@ int vo_map_upsert(vo_ctx* c, const int32_t* idx, const double* xyz, const double
     rc = vo_map_scatter_launch(c, n, (const int32_t*)(d + o_idx), xyz ? (const double*)(d + o_xyz) : nullptr, nrm ? (const double*)(d + o_nrm) : nullptr,
                                desc ? (const uint32_t*)(d + o_desc) : nullptr, flags ? d + o_flags : nullptr);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(st));
+    // no wait here: the copy and the scatter are ordered before any later work on this stream, and the next user of the
+    // staging buffer (this function, vo_ba_run, vo_corr_from_host) drains the stream before touching it
     return VO_OK;
 }
 

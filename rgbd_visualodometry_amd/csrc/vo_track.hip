@@ -826,6 +826,7 @@ int vo_corr_from_host(vo_ctx* c, const float* xyz, const float* uv, int n) {
     if (n > 0) {
         float* stage = (float*)vo_stage(c, sizeof(float) * 5 * (size_t)n);
         if (!stage) return VO_E_NOMEM;
+        HIP_TRY(hipStreamSynchronize(st));                  // the staging buffer may still feed an earlier vo_map_upsert
         memcpy(stage, xyz, sizeof(float) * 3 * (size_t)n);
         memcpy(stage + 3 * (size_t)n, uv, sizeof(float) * 2 * (size_t)n);
         HIP_TRY(hipMemcpyAsync(c->chain.cxyz, stage, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
