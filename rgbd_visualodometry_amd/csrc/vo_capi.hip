@@ -20,6 +20,7 @@ static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 // see SURVEY.md 8a-1).  Computed once per context; the kernels only read it.
 static int build_plan(const vo_params& p, DevPlan& P, std::vector<int>& tab, std::vector<short>& tabs) {
     memset(&P, 0, sizeof(P));
+    P.xcd_map = getenv("VO_NO_XCD_MAP") ? 0 : 1;
     P.W = p.width; P.H = p.height; P.L = p.n_levels; P.nfeat = p.n_features; P.fast_thr = p.fast_threshold; P.edge = p.edge_threshold;
     P.fx = p.fx; P.fy = p.fy; P.cx = p.cx; P.cy = p.cy;
     const double sf = (double)p.scale_factor;

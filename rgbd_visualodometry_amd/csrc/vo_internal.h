@@ -21,6 +21,7 @@ struct DevPlan {
     unsigned loff[VO_MAX_LEVELS];                               // byte offset of each level inside a slot's pyramid slab
     float scale[VO_MAX_LEVELS];
     int tiles_x[VO_MAX_LEVELS], tile_prefix[VO_MAX_LEVELS + 1]; // FAST tiling (64x16 tiles), blockIdx.x -> (level, tile)
+    int xcd_map;                                                // 1: XCD-aware tile order in the tiled ORB kernels (VO_NO_XCD_MAP=1 turns it off for A/B runs)
     int btiles_x[VO_MAX_LEVELS], btile_prefix[VO_MAX_LEVELS + 1]; // blur tiling (128x16 tiles over the whole level)
     int tabx[VO_MAX_LEVELS], taby[VO_MAX_LEVELS];               // offsets into the resize tables
     int umax[16];

@@ -116,9 +116,11 @@ __global__ __launch_bounds__(256) void k_fast_nms(DevPlan P, const uint8_t* __re
     __shared__ __align__(4) uint8_t s_gray[GP * (TH + 8)];
     __shared__ uint8_t s_score[SP * (TH + 2)];
     const int slot = slot0 + blockIdx.z;
+    const int per_xcd = gridDim.x >> 3, tile = P.xcd_map ? (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;      // XCD-aware order, see k_blur
+    if (tile >= P.tile_prefix[P.L]) return;
     int l = 0;
-    while (l + 1 < P.L && (int)blockIdx.x >= P.tile_prefix[l + 1]) ++l;
-    const int t = blockIdx.x - P.tile_prefix[l];
+    while (l + 1 < P.L && tile >= P.tile_prefix[l + 1]) ++l;
+    const int t = tile - P.tile_prefix[l];
     const int w = P.lw[l], h = P.lh[l], pitch = P.pitch[l];
     const int x0 = P.edge + (t % P.tiles_x[l]) * TW, y0 = P.edge + (t / P.tiles_x[l]) * TH;
     const uint8_t* img = pyr + (size_t)slot * P.pyr_stride + P.loff[l];
@@ -309,9 +311,13 @@ __global__ __launch_bounds__(256) void k_blur(DevPlan P, const uint8_t* __restri
     __shared__ uint32_t s_in[(BTH + 6) * BSTR / 4];
     __shared__ uint32_t s_h[(BTH + 6) * BTW / 2];      // u16 row sums, two per dword
     const int slot = slot0 + blockIdx.z;
+    // XCD-aware tile order: workgroups go round-robin over the 8 XCDs (each with its own L2), so workgroup b works on
+    // tile (b % 8) * (tiles / 8) + b / 8 -- neighbouring tiles, which share halo rows, meet in the same L2
+    const int per_xcd = gridDim.x >> 3, tile = P.xcd_map ? (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+    if (tile >= P.btile_prefix[P.L]) return;
     int l = 0;
-    while (l + 1 < P.L && (int)blockIdx.x >= P.btile_prefix[l + 1]) ++l;
-    const int t = blockIdx.x - P.btile_prefix[l];
+    while (l + 1 < P.L && tile >= P.btile_prefix[l + 1]) ++l;
+    const int t = tile - P.btile_prefix[l];
     const int w = P.lw[l], h = P.lh[l], pitch = P.pitch[l];
     const int x0 = (t % P.btiles_x[l]) * BTW, y0 = (t / P.btiles_x[l]) * BTH;
     const uint8_t* img = pyr + (size_t)slot * P.pyr_stride + P.loff[l];
@@ -487,14 +493,14 @@ int vo_orb_launch(vo_ctx* c, int slot0, int n) {
         hipLaunchKernelGGL(k_resize, g, dim3(64, 4), 0, st, P, l, c->d_pyr, c->d_tab, c->d_tabs, slot0);
     }
     { ProfScope ps(c, "k_fast_nms");
-      dim3 g(P.tile_prefix[P.L], 1, n);
+      dim3 g(8 * ((P.tile_prefix[P.L] + 7) / 8), 1, n);
       hipLaunchKernelGGL(k_fast_nms, g, dim3(64, 4), 0, st, P, c->d_pyr, c->d_cand, c->d_cand_cnt, c->d_status, slot0); }
     { ProfScope ps(c, "k_select");
       size_t lds = (size_t)P.sel_cap * 12 + 4 * 260;
       dim3 g(P.L, n);
       hipLaunchKernelGGL(k_select, g, dim3(1024), lds, st, P, c->d_pyr, c->d_cand, c->d_cand_cnt, c->d_sel, c->d_sel_key, c->d_sel_cnt, slot0); }
     { ProfScope ps(c, "k_blur");
-      hipLaunchKernelGGL(k_blur, dim3(P.btile_prefix[P.L], 1, n), dim3(32, 8), 0, st, P, c->d_pyr, c->d_blur, slot0); }
+      hipLaunchKernelGGL(k_blur, dim3(8 * ((P.btile_prefix[P.L] + 7) / 8), 1, n), dim3(32, 8), 0, st, P, c->d_pyr, c->d_blur, slot0); }
     { ProfScope ps(c, "k_describe");
       dim3 g((P.nfeat + 3) / 4, n);
       hipLaunchKernelGGL(k_describe, g, dim3(256), 0, st, P, c->d_slots, c->d_pyr, c->d_blur, c->d_sel, c->d_sel_key, c->d_sel_cnt, c->d_kps, c->d_desc, c->d_nkp, slot0); }
