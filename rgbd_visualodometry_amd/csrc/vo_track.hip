@@ -555,7 +555,7 @@ __device__ __forceinline__ bool chol6_dev(double* A, double* b) {
 // workgroup into the LDS buffer `tot` ([0..20] H, [21..26] b, [27] chi) that every thread reads afterwards.
 __device__ void lm_pass_dev(const CamD& cam, const float* cxyz, const float* cuv, const int32_t* edges,
                             const uint8_t* mask, int n, int round, const double* T, double delta,
-                            double* s_part, double* tot, int& phase) {
+                            double* s_part, double* tot, int& phase, const uint16_t* idx, int nidx) {
 #pragma clang fp contract(fast)
     const bool robust = round == 0;
 #ifdef VO_LM_STAMPS
@@ -567,9 +567,16 @@ __device__ void lm_pass_dev(const CamD& cam, const float* cxyz, const float* cuv
     // Per edge: the weighted outer products of a = [J0, e0] and b = [J1, e1] give H, J^T e and chi2 at once;
     // J0[1] = J1[0] = 0 (g2o_types.h:97-99) removes a third of the products.
     double g[6] = {0, 0, 0, 0, 0, 0};
-    for (int i = threadIdx.x; i < n; i += LM_T) {
-        if (round == 1 && !(mask[i] & 2)) continue;
-        const int k = edges ? edges[i] : i;            // edges == nullptr: correspondences already gathered (LDS)
+    // second round with the correspondences in LDS: the surviving edges come as a compact index list, so every lane has
+    // work (a masked loop leaves more than half of the lanes idle in every iteration)
+    const int cnt = idx ? nidx : n;
+    for (int i = threadIdx.x; i < cnt; i += LM_T) {
+        int k;
+        if (idx) k = idx[i];
+        else {
+            if (round == 1 && !(mask[i] & 2)) continue;
+            k = edges ? edges[i] : i;                  // edges == nullptr: correspondences already gathered (LDS)
+        }
         const D3 pc = xform(T, mk((double)cxyz[3 * k], (double)cxyz[3 * k + 1], (double)cxyz[3 * k + 2]));
         const double zz = pc.z + 1e-18;
         const double Zi = 1.0 / zz;                    // correctly rounded: the gain ratio near convergence is sensitive to chi2 noise
@@ -629,14 +636,15 @@ __device__ void lm_pass_dev(const CamD& cam, const float* cxyz, const float* cuv
 // g2o Levenberg-Marquardt (lambda/rho policy of OptimizationAlgorithmLevenberg).  The trial pass also
 // linearises at the trial pose, so an accepted step needs no second pass (same numbers g2o recomputes).
 __device__ int lm_optimize_dev(const CamD& cam, const float* cxyz, const float* cuv, const int32_t* edges, const uint8_t* mask, int n,
-                               int round, double* T, double delta, int max_it, double* s_part, double* s_tot, int& phase) {
+                               int round, double* T, double delta, int max_it, double* s_part, double* s_tot, int& phase,
+                               const uint16_t* idx = nullptr, int nidx = 0) {
     // The current linearisation and the trial one live in two LDS buffers (s_tot + 32 cur, s_tot + 32 (cur ^ 1)): an
     // accepted step flips `cur`, nothing is copied and no thread keeps 2 x 28 doubles in registers across a pass.
     int cur = 0;
 #ifdef VO_LM_STAMPS
     long long t_pass = 0, t_serial = 0, n_pass = 1, t0 = clock64();
 #endif
-    lm_pass_dev(cam, cxyz, cuv, edges, mask, n, round, T, delta, s_part, s_tot, phase);
+    lm_pass_dev(cam, cxyz, cuv, edges, mask, n, round, T, delta, s_part, s_tot, phase, idx, nidx);
 #ifdef VO_LM_STAMPS
     t_pass += clock64() - t0;
 #endif
@@ -670,7 +678,7 @@ __device__ int lm_optimize_dev(const CamD& cam, const float* cxyz, const float* 
 #endif
             // block-uniform control flow: every thread holds the same H, b, lambda
             const double* tv = s_tot + 32 * (cur ^ 1);
-            lm_pass_dev(cam, cxyz, cuv, edges, mask, n, round, Tn, delta, s_part, s_tot + 32 * (cur ^ 1), phase);
+            lm_pass_dev(cam, cxyz, cuv, edges, mask, n, round, Tn, delta, s_part, s_tot + 32 * (cur ^ 1), phase, idx, nidx);
 #ifdef VO_LM_STAMPS
             t_pass += clock64() - t2; ++n_pass;
 #endif
@@ -738,15 +746,35 @@ __global__ __launch_bounds__(LM_T) void k_pose_lm(CamD cam, ChainBuf cb, double 
     if (n > 0) iters += lm_optimize_dev(cam, cxyz, cuv, edges, mask, n, 0, T, delta, it_r, s_part, s_out, phase);
     // edges whose chi2 exceeds the cut leave the second round (frontend.cpp:294-306)
     int loc = 0;
-    for (int i = threadIdx.x; i < n; i += LM_T) {
-        const int k = edges ? edges[i] : i;
-        const bool keep = !(edge_chi2_dev(cam, T, &cxyz[3 * k], &cuv[2 * k]) > cut);
-        mask[i] = keep ? 2 : 0;
-        loc += keep ? 1 : 0;
+    __shared__ uint16_t s_keep[LM_LDS_MAX];            // LDS path: ordered list of the surviving edges
+    __shared__ int s_wk[LM_W];
+    const bool lds_path = edges == nullptr;
+    int run = 0;
+    for (int base = 0; base < n; base += LM_T) {
+        const int i = base + threadIdx.x;
+        bool keep = false;
+        if (i < n) {
+            const int k = edges ? edges[i] : i;
+            keep = !(edge_chi2_dev(cam, T, &cxyz[3 * k], &cuv[2 * k]) > cut);
+            mask[i] = keep ? 2 : 0;
+            loc += keep ? 1 : 0;
+        }
+        if (lds_path) {                                // block-uniform
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            const unsigned long long m = __ballot(keep);
+            if (lane == 0) s_wk[wave] = __popcll(m);
+            __syncthreads();
+            int before = __popcll(m & ((1ull << lane) - 1ull)), tot = 0;
+#pragma unroll
+            for (int w = 0; w < LM_W; ++w) { const int cw = s_wk[w]; if (w < wave) before += cw; tot += cw; }
+            if (keep) s_keep[run + before] = (uint16_t)i;
+            run += tot;
+            __syncthreads();
+        }
     }
     if (loc) atomicAdd(&s_cnt[0], loc);
     __syncthreads();
-    if (s_cnt[0] > 0) iters += lm_optimize_dev(cam, cxyz, cuv, edges, mask, n, 1, T, delta, it_p, s_part, s_out, phase);
+    if (s_cnt[0] > 0) iters += lm_optimize_dev(cam, cxyz, cuv, edges, mask, n, 1, T, delta, it_p, s_part, s_out, phase, lds_path ? s_keep : nullptr, run);
     loc = 0;
     for (int i = threadIdx.x; i < n; i += LM_T) {
         const int k = edges ? edges[i] : i;
