@@ -125,9 +125,10 @@ int main() {
     { double* d; hipMalloc(&d, 128 * 8); hipLaunchKernelGGL(k_dpp_probe, dim3(1), dim3(64), 0, 0, d); double h[128]; hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
       printf("bcast<3>: "); for (int i = 0; i < 64; i += 5) printf("[%d]=%.0f ", i, h[i]); printf("\nfnma<5>: "); for (int i = 0; i < 64; i += 5) printf("[%d]=%.0f ", i, h[64 + i]); printf("\n"); hipFree(d); }
 
-    const int sizes[] = {6, 24, 30, 60, 120, 168, 186, 192};
-    hipFuncSetAttribute((const void*)k_ba_chol_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+    const int sizes[] = {6, 24, 30, 60, 120, 168, 186, 192, 198, 216, 240, 300, 366};
     hipFuncSetAttribute((const void*)k_ba_chol16, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+    hipFuncSetAttribute((const void*)k_ba_chol16g, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+
     hipStream_t st; hipStreamCreate(&st);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     int bad = 0;
@@ -141,19 +142,21 @@ int main() {
         host_solve(D, S, b, x);
         BaDev B; memset(&B, 0, sizeof(B));
         B.D = D;
-        double* d_b0;
+        double* d_b0; double* d_S0;
         hipMalloc(&B.S, sizeof(double) * D * D); hipMalloc(&B.bs, sizeof(double) * D); hipMalloc(&d_b0, sizeof(double) * D);
         hipMalloc(&B.scal, 64); hipMalloc(&B.dl, 128); hipMemset(B.dl, 0, 128); hipMalloc(&B.ctl, sizeof(BaCtl));
         hipMemset(B.scal, 0, 64); hipMemset(B.ctl, 0, sizeof(BaCtl));
-        hipMemcpy(B.S, S.data(), sizeof(double) * D * D, hipMemcpyHostToDevice);
+        hipMalloc(&d_S0, sizeof(double) * D * D);
+        hipMemcpy(d_S0, S.data(), sizeof(double) * D * D, hipMemcpyHostToDevice);
         hipMemcpy(d_b0, b.data(), sizeof(double) * D, hipMemcpyHostToDevice);
-        for (int variant = 0; variant < 2; ++variant) {
+        for (int variant = 1; variant < 2; ++variant) {
             float tot = 0; const int reps = 50;
             for (int it = 0; it < reps + 5; ++it) {
                 hipMemcpyAsync(B.bs, d_b0, sizeof(double) * D, hipMemcpyDeviceToDevice, st);
+                hipMemcpyAsync(B.S, d_S0, sizeof(double) * D * D, hipMemcpyDeviceToDevice, st);      // the global-resident kernels factor S in place
                 hipEventRecord(e0, st);
-                if (variant == 0) hipLaunchKernelGGL(k_ba_chol_t<true>, dim3(1), dim3(1024), sizeof(double) * ((size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D), st, B);
-                else hipLaunchKernelGGL(k_ba_chol16, dim3(1), dim3(CH_THREADS), sizeof(double) * (CH_NB * CH_NB + (size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D), st, B);
+                if (D <= 192) hipLaunchKernelGGL(k_ba_chol16, dim3(1), dim3(CH_THREADS), sizeof(double) * (CH_NB * CH_NB + (size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D), st, B);
+                else hipLaunchKernelGGL(k_ba_chol16g, dim3(1), dim3(CH_THREADS), sizeof(double) * (CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D), st, B);
                 hipEventRecord(e1, st);
                 hipStreamSynchronize(st);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -164,7 +167,7 @@ int main() {
             hipMemcpy(&ok, B.scal + 3, 8, hipMemcpyDeviceToHost);
             double err = 0, ref = 0;
             for (int i = 0; i < D; ++i) { err = std::max(err, std::fabs(got[i] - x[i])); ref = std::max(ref, std::fabs(x[i])); }
-            printf("D %3d  %-12s  %8.2f us  ok %.0f  max|dx|/max|x| %.3e%s\n", D, variant ? "k_ba_chol16" : "k_ba_chol_t", 1e3 * tot / reps, ok, err / ref,
+            printf("D %3d  %-13s  %8.2f us  ok %.0f  max|dx|/max|x| %.3e%s\n", D, variant ? (D <= 192 ? "k_ba_chol16" : "k_ba_chol16g") : "k_ba_chol_t", 1e3 * tot / reps, ok, err / ref,
                    (ok == 1.0 && err / ref < 1e-10) ? "" : "   <-- MISMATCH");
             if (!(ok == 1.0 && err / ref < 1e-10)) ++bad;
 #ifdef CH_STAMPS
@@ -173,7 +176,7 @@ int main() {
                        tt[0], tt[1], tt[5], tt[6], tt[7], tt[2], tt[4], tt[8], tt[9], tt[3], tt[10]); }
 #endif
         }
-        hipFree(B.S); hipFree(B.bs); hipFree(d_b0); hipFree(B.scal); hipFree(B.ctl);
+        hipFree(d_S0); hipFree(B.S); hipFree(B.bs); hipFree(d_b0); hipFree(B.scal); hipFree(B.ctl);
     }
     hipError_t e = hipGetLastError();
     printf("last error: %s, mismatches: %d\n", hipGetErrorString(e), bad);

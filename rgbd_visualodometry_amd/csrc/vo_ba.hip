@@ -9,7 +9,7 @@
 //   k_ba_init_S       S = blockdiag(H_pp) + lambda I, b_s = b_p, (H_ll + lambda I)^-1 per point
 //   k_ba_schur_blocks one workgroup per <= 512-pair slice of a 6x6 block: S -= W_e1 Hinv W_e2^T, b_s -= W_e Hinv b_l
 //   k_ba_chol16       dense Cholesky + solve of the reduced 6K x 6K system in one workgroup (16-column DPP panels,
-//                     f64 MFMA trailing update); k_ba_chol_t<false> for 6K > 192
+//                     f64 MFMA trailing update); k_ba_chol16g (matrix in L2, panel in LDS) for 6K > 192
 //   k_ba_update       trial points (back-substitution) and trial poses exp(dp) * T, gain-ratio terms
 //   k_ba_chi_control  robust chi2 of the trial state; the last workgroup runs the LM accept / lambda policy
 // The LM state (lambda, current chi2, iteration counters, which of the two state buffers is current) lives in a
@@ -391,136 +391,11 @@ __global__ __launch_bounds__(1024) void k_ba_pairs_scan(BaPairPlan Q, int nb) {
     }
 }
 
-// Dense Cholesky + solve of the reduced system, packed lower triangle resident in LDS (D <= 198),
-// blocked by pose (6-column panels): diagonal 6x6 factor, panel solve (one lane per row), rank-6
-// trailing update spread over 1024 lanes.  3 barriers per panel instead of 3 per column.
-#define TRI(r, c) ((size_t)(r) * ((r) + 1) / 2 + (c))      // packed lower triangle
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-// Cholesky + solve of the reduced system in one 1024-lane workgroup.
-//  * the right-hand side rides along as row D of the augmented matrix [S b; b^T .], so the forward substitution
-//    falls out of the factorisation (the last row of the augmented factor is y = L^-1 b);
-//  * per 6-column panel (one pose): 6x6 diagonal factor, panel solve (one lane per row), and the rank-6 trailing
-//    update S22 -= L21 L21^T as 16x16 tiles on the f64 matrix cores (v_mfma_f64_16x16x4_f64, K = 6 padded to 8):
-//    the dense J^T J-style contraction of the BA solve;
-//  * backward substitution by panels with pre-inverted pivots.
-// INLDS: packed lower triangle resident in LDS (D <= 192).  Otherwise the matrix stays in global memory
-// (L2 resident) and only the rhs row, the current panel and the pivots live in LDS (any D).
-template <bool INLDS>
-__global__ __launch_bounds__(1024) void k_ba_chol_t(BaDev B) {
-    if (B.ctl->finished) return;
-    extern __shared__ double s_mem[];
-    const int D = B.D, DA = D + 1, tid = threadIdx.x, np = D / 6, lane = tid & 63, wave = tid >> 6;
-    double* const A = B.S;
-    // LDS carve: INLDS: [tri(DA)] [x D] [inv D]          else: [aug DA] [panel 6*DA] [x D] [inv D]
-    double* const s_L = s_mem;
-    double* const s_aug = s_mem;
-    double* const s_P = s_mem + DA;
-    double* const s_b = INLDS ? s_mem + TRI(DA, 0) : s_mem + DA + (size_t)6 * DA;
-    double* const s_inv = s_b + D;
-    auto at = [&](int r, int c) -> double& { if (INLDS) return s_L[TRI(r, c)]; return r == D ? s_aug[c] : A[(size_t)r * D + c]; };
-    __shared__ int s_ok;
-    if (tid == 0) {
-        s_ok = 1;
-        BaCtl* c = B.ctl;                               // take over the fresh linearisation, clear the trial sums
-        if (c->need_lin) {
-            c->cur = B.scal[0];
-            if (c->first) { c->lambda = 1e-5 * B.scal[4]; c->ni = 2; c->first = 0; }
-            c->need_lin = 0;
-        }
-        B.scal[1] = 0; B.scal[2] = 0; B.scal[7] = 0;
-    }
-    if (INLDS) { for (int i = tid; i < D * D; i += 1024) { const int r = i / D, c = i - r * D; if (c <= r) s_L[TRI(r, c)] = A[i]; } }
-    for (int i = tid; i < D; i += 1024) at(D, i) = B.bs[i];
-    if (tid == 0) at(D, D) = 0.0;
-    __syncthreads();
-    for (int p = 0; p < np; ++p) {
-        const int j0 = 6 * p;
-        if (tid == 0) {
-            double d6[36];
-            for (int r = 0; r < 6; ++r) for (int c = 0; c <= r; ++c) d6[6 * r + c] = at(j0 + r, j0 + c);
-            for (int j = 0; j < 6; ++j) {
-                double d = d6[7 * j];
-                for (int k = 0; k < j; ++k) d -= d6[6 * j + k] * d6[6 * j + k];
-                if (!(d > 0.0)) { s_ok = 0; break; }
-                d = sqrt(d);
-                d6[7 * j] = d;
-                const double inv = 1.0 / d;
-                s_inv[j0 + j] = inv;
-                for (int i = j + 1; i < 6; ++i) {
-                    double sum = d6[6 * i + j];
-                    for (int k = 0; k < j; ++k) sum -= d6[6 * i + k] * d6[6 * j + k];
-                    d6[6 * i + j] = sum * inv;
-                }
-            }
-            for (int r = 0; r < 6; ++r) for (int c = 0; c <= r; ++c) at(j0 + r, j0 + c) = d6[6 * r + c];
-        }
-        __syncthreads();
-        if (!s_ok) break;
-        const int base = j0 + 6, m = DA - base;         // rows below the panel, incl. the rhs row
-        double dg[15];                                  // strict lower part of the diagonal block, broadcast reads
-        { int q = 0; for (int r = 1; r < 6; ++r) for (int c = 0; c < r; ++c) dg[q++] = at(j0 + r, j0 + c); }
-        for (int r = tid; r < m; r += 1024) {
-            double x[6];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                double sum = at(base + r, j0 + c);
-#pragma unroll
-                for (int k = 0; k < c; ++k) sum -= x[k] * dg[c * (c - 1) / 2 + k];
-                x[c] = sum * s_inv[j0 + c];
-            }
-#pragma unroll
-            for (int c = 0; c < 6; ++c) { at(base + r, j0 + c) = x[c]; if (!INLDS) s_P[6 * r + c] = x[c]; }
-        }
-        __syncthreads();
-        // trailing update on the matrix cores: tile (tr, tc), tc <= tr, 16x16 each; A[i][k] = L21[16 tr + i][k],
-        // B[k][j] = L21[16 tc + j][k]; lane l holds A[l&15][l>>4], B[l>>4][l&15]; D: col = l&15, row = (l>>4) + 4 reg
-        const int T = (m + 15) >> 4, ntile = T * (T + 1) / 2;
-        for (int t = wave; t < ntile; t += 16) {
-            int tr = 0;
-            while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
-            const int tc = t - tr * (tr + 1) / 2;
-            const int ra = 16 * tr + (lane & 15), rb = 16 * tc + (lane & 15), kq = lane >> 4;
-            auto pan = [&](int r, int k) -> double { return INLDS ? s_L[TRI(base + r, j0 + k)] : s_P[6 * r + k]; };
-            const double a0 = ra < m ? pan(ra, kq) : 0.0;
-            const double b0 = rb < m ? pan(rb, kq) : 0.0;
-            const double a1 = (ra < m && kq < 2) ? pan(ra, 4 + kq) : 0.0;
-            const double b1 = (rb < m && kq < 2) ? pan(rb, 4 + kq) : 0.0;
-            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
-            const int col = 16 * tc + (lane & 15);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int row = 16 * tr + (lane >> 4) + 4 * q;
-                if (row < m && col <= row) at(base + row, base + col) -= acc[q];
-            }
-        }
-        __syncthreads();
-    }
-    if (s_ok) {
-        for (int i = tid; i < D; i += 1024) s_b[i] = at(D, i);          // y = L^-1 b (last row of the augmented factor)
-        __syncthreads();
-        for (int p = np - 1; p >= 0; --p) {             // L^T x = y
-            const int j0 = 6 * p;
-            if (tid == 0)
-                for (int j = 5; j >= 0; --j) { double sum = s_b[j0 + j]; for (int k = j + 1; k < 6; ++k) sum -= at(j0 + k, j0 + j) * s_b[j0 + k]; s_b[j0 + j] = sum * s_inv[j0 + j]; }
-            __syncthreads();
-            for (int r = tid; r < j0; r += 1024) {
-                double sum = 0;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) sum += at(j0 + k, r) * s_b[j0 + k];
-                s_b[r] -= sum;
-            }
-            __syncthreads();
-        }
-        for (int i = tid; i < D; i += 1024) B.bs[i] = s_b[i];
-    }
-    if (tid == 0) B.scal[3] = s_ok ? 1.0 : 0.0;
-}
-
 // ---- k_ba_chol16: the D <= 192 Cholesky + solve, 16-column panels ---------------------------------------------
-// Same augmented-matrix scheme as k_ba_chol_t, re-blocked so that the dependent chain is short:
+// The right-hand side rides along as row D of the augmented matrix [S b; b^T .], so the forward substitution falls out
+// of the factorisation (the last row of the augmented factor is y = L^-1 b).  Blocked so that the dependent chain is short:
 //  * panel = 16 columns = one DPP row.  The diagonal block is factored by ONE wave entirely in registers: lane r
 //    (0..15) keeps row r; the pivot and the multipliers of column j reach the other lanes through the DP-ALU DPP
 //    row broadcast (v_mov_b64_dpp / v_fmac_f64_dpp row_newbcast:j), i.e. ONE instruction per rank-1 term, no
@@ -884,6 +759,194 @@ __global__ __launch_bounds__(CH_THREADS) void k_ba_chol16(BaDev B) {
 #endif
 }
 
+// ---- k_ba_chol16g: the same 16-column scheme for D > 192, where the packed triangle no longer fits in LDS -----------
+// The matrix stays in global memory (S is rebuilt every step, so its lower triangle is overwritten by L in place; at
+// these sizes it sits in L2), LDS holds the solved panel (DA x 16, the MFMA operands of the trailing update), the
+// augmented rhs row, y / x and the pivots.  (A volatile pointer would make every access system-coherent, i.e. miss
+// every cache: 5x slower.  Workgroup-scope coherence needs nothing beyond the barriers: one CU, one L1.)
+#define CHG_TB 8
+__global__ __launch_bounds__(CH_THREADS) void k_ba_chol16g(BaDev B) {
+    if (B.ctl->finished) return;
+    extern __shared__ double s_mem[];
+    const int D = B.D, DA = D + 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15;
+    double* const S = B.S;              // plain accesses: the waves of one workgroup share the CU's L1, barriers order them
+    double* const s_dg = s_mem;                                 // [16][16] factored diagonal block, transposed, 1/L[k][k] on the diagonal
+    double* const s_P = s_mem + CH_NB * CH_NB;                  // [DA][16] solved panel rows (row index relative to `base`)
+    double* const s_aug = s_P + (size_t)DA * CH_NB;             // [DA] rhs row of the augmented matrix
+    double* const s_b = s_aug + DA;                             // y, then x
+    double* const s_inv = s_b + D;                              // 1 / L[j][j]
+    __shared__ int s_ok;
+    __shared__ double s_pinv[CH_NB];
+    if (tid == 0) {
+        s_ok = 1;
+        BaCtl* c = B.ctl;                               // take over the fresh linearisation, clear the trial sums
+        if (c->need_lin) {
+            c->cur = B.scal[0];
+            if (c->first) { c->lambda = 1e-5 * B.scal[4]; c->ni = 2; c->first = 0; }
+            c->need_lin = 0;
+        }
+        B.scal[1] = 0; B.scal[2] = 0; B.scal[7] = 0;
+    }
+    for (int i = tid; i < D; i += CH_THREADS) s_aug[i] = B.bs[i];
+    if (tid == 0) s_aug[D] = 0.0;
+    __syncthreads();
+    for (int j0 = 0; j0 < D; j0 += CH_NB) {
+        const int nb = min(CH_NB, D - j0);
+        const int base = j0 + nb, m = DA - base;                // rows below the panel, incl. the rhs row (local row m - 1)
+        // rows of the panel solve are fetched before the barrier: they do not depend on the block factor
+        double x[CH_NB];
+        const bool solver = nb == CH_NB && wave * 64 < m;
+        if (solver) {
+            const int rl = min(tid, m - 1), r = base + rl;
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) x[c] = r < D ? S[(size_t)r * D + j0 + c] : s_aug[j0 + c];
+        }
+        if (wave == 0) {                                        // ---- diagonal block, in registers
+            double a[CH_NB];
+            const bool mine = r16 < nb;
+            const double* row = S + (size_t)(j0 + (mine ? r16 : 0)) * D + j0;
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) a[c] = row[min(c, nb - 1)];
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) a[c] = (mine && c <= r16) ? a[c] : (c == r16 ? 1.0 : 0.0);
+            bool ok = true;
+            ch_exec_settle(a[0]);
+            ChCol<0>::run(a, s_pinv, ok, r16);
+            const double myinv = s_pinv[r16];
+            if (lane < CH_NB) {
+#pragma unroll
+                for (int c = 0; c < CH_NB; ++c) s_dg[c * CH_NB + lane] = c < lane ? a[c] : (c == lane ? myinv : 0.0);
+            }
+            if (lane < nb) {
+                double* wrow = S + (size_t)(j0 + lane) * D + j0;
+#pragma unroll
+                for (int c = 0; c < CH_NB; ++c) if (c <= lane) wrow[c] = a[c];
+                s_inv[j0 + lane] = myinv;
+            }
+            if (!ok && lane == 0) s_ok = 0;
+        }
+        __syncthreads();
+        if (!s_ok) break;
+        if (nb == CH_NB) {                                      // ---- panel solve, one lane per row
+            if (solver) {
+                double Lk[CH_NB];
+#pragma unroll
+                for (int k = 0; k < CH_NB; ++k) Lk[k] = s_dg[k * CH_NB + r16];
+                ch_exec_settle(x[0]);
+                ChSolve<0>::run(x, Lk);
+                if (tid < m) {
+                    const int r = base + tid;
+#pragma unroll
+                    for (int c = 0; c < CH_NB; ++c) {
+                        s_P[tid * CH_NB + c] = x[c];
+                        if (r < D) S[(size_t)r * D + j0 + c] = x[c]; else s_aug[j0 + c] = x[c];
+                    }
+                }
+            }
+        } else if (wave == 0) {                                 // partial last panel: only the rhs row is below it
+            double Lr[CH_NB];
+#pragma unroll
+            for (int k = 0; k < CH_NB; ++k) Lr[k] = s_dg[k * CH_NB + r16];
+#pragma unroll
+            for (int k = 0; k < CH_NB; ++k) Lr[k] = k < r16 ? Lr[k] : 0.0;
+            double bc = s_aug[j0 + min(r16, nb - 1)], yf = 0.0;
+            bc = r16 < nb ? bc : 0.0;
+            const double inv = s_dg[r16 * CH_NB + r16];
+            ch_exec_settle(bc);
+            ChFwd<0>::run(Lr, bc, inv, yf, r16);
+            if (lane < nb) s_aug[j0 + lane] = yf;
+        }
+        __syncthreads();
+        if (base >= D) break;
+        // ---- trailing update S22 -= L21 L21^T: 16x16 tiles, operands from the LDS panel, C read-modify-written in L2
+        // (rhs row: in s_aug).  Lane l holds A[l&15][l>>4], B[l>>4][l&15]; D: col = l&15, row = (l>>4) + 4 reg.
+        // A wave takes its tiles in groups of CHG_TB: all C loads of the group are issued first (independent L2 round
+        // trips in flight together), then the MFMAs, then the stores.
+        const int T = (m + 15) >> 4, ntile = T * (T + 1) / 2;
+        int tr = 0, tc = wave;
+        while (tc > tr) { tc -= tr + 1; ++tr; }
+        for (int t0 = wave; t0 < ntile; t0 += CHG_TB * (CH_THREADS / 64)) {
+            double cv[CHG_TB][4];
+            int trs[CHG_TB], tcs[CHG_TB];
+#pragma unroll
+            for (int g = 0; g < CHG_TB; ++g) {
+                trs[g] = tr; tcs[g] = tc;
+                const bool live = t0 + g * (CH_THREADS / 64) < ntile;
+                const int col = 16 * tc + r16;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int rwq = 16 * tr + (lane >> 4) + 4 * q;
+                    const int rc = min(rwq, m - 1), cc = min(col, rc);
+                    // both sources are read (clamped addresses) and the VALUE is selected: a select between an LDS and a
+                    // global pointer does not survive instruction selection
+                    const int rg = live ? min(rc, m - 2) : 0, cg = live ? min(cc, rg) : 0;
+                    const double vg = S[(size_t)(base + rg) * D + base + cg], va = s_aug[base + cc];
+                    cv[g][q] = rc == m - 1 ? va : vg;
+                }
+                tc += CH_THREADS / 64;
+                while (tc > tr) { tc -= tr + 1; ++tr; }
+            }
+#pragma unroll
+            for (int g = 0; g < CHG_TB; ++g) {
+                if (t0 + g * (CH_THREADS / 64) >= ntile) break;
+                const int trg = trs[g], tcg = tcs[g];
+                const int ra = min(16 * trg + r16, m - 1), rb = min(16 * tcg + r16, m - 1), kq = lane >> 4;
+                const int col = 16 * tcg + r16;
+                const double* pa = s_P + ra * CH_NB + kq;
+                const double* pb = s_P + rb * CH_NB + kq;
+                const double a0 = pa[0], a1 = pa[4], a2 = pa[8], a3 = pa[12], b0 = pb[0], b1 = pb[4], b2 = pb[8], b3 = pb[12];
+                f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, acc, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int rwq = 16 * trg + (lane >> 4) + 4 * q;
+                    if (!(rwq < m && col <= rwq)) continue;
+                    const double v = cv[g][q] - acc[q];
+                    if (rwq == m - 1) s_aug[base + col] = v; else S[(size_t)(base + rwq) * D + base + col] = v;
+                }
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (s_ok) {
+        for (int i = tid; i < D; i += CH_THREADS) s_b[i] = s_aug[i];          // y = L^-1 b
+        __syncthreads();
+        const int np = (D + CH_NB - 1) / CH_NB;
+        for (int p = np - 1; p >= 0; --p) {                     // L^T x = y, panel by panel from the bottom
+            const int j0 = CH_NB * p, nb = min(CH_NB, D - j0);
+            if (wave == 0) {
+                double col[CH_NB];                              // lane j: L[j0+k][j0+j], k > j
+#pragma unroll
+                for (int k = 0; k < CH_NB; ++k) col[k] = S[(size_t)(j0 + min(max(k, r16), nb - 1)) * D + j0 + min(r16, nb - 1)];
+#pragma unroll
+                for (int k = 0; k < CH_NB; ++k) col[k] = (r16 < nb && k < nb && k > r16) ? col[k] : 0.0;
+                double y = s_b[j0 + min(r16, nb - 1)], inv = s_inv[j0 + min(r16, nb - 1)];
+                y = r16 < nb ? y : 0.0; inv = r16 < nb ? inv : 0.0;
+                double xf = 0.0;
+                ch_exec_settle(y);
+                ChBack<CH_NB - 1>::run(col, y, inv, xf, r16);
+                if (lane < nb) s_b[j0 + lane] = xf;
+            }
+            __syncthreads();
+            for (int r = tid; r < j0; r += CH_THREADS) {        // rows above: L[j0+k][r] is contiguous in r
+                double s0 = 0, s1 = 0;
+                for (int k = 0; k + 1 < nb; k += 2) {           // nb is even
+                    s0 += S[(size_t)(j0 + k) * D + r] * s_b[j0 + k];
+                    s1 += S[(size_t)(j0 + k + 1) * D + r] * s_b[j0 + k + 1];
+                }
+                s_b[r] -= s0 + s1;
+            }
+            __syncthreads();
+        }
+        for (int i = tid; i < D; i += CH_THREADS) B.bs[i] = s_b[i];
+    }
+    if (tid == 0) B.scal[3] = s_ok ? 1.0 : 0.0;
+}
+
 __device__ __forceinline__ void ba_backsub_body(const BaDev& B, double lambda, int blk, const double* pts_c, double* pts_t) {
     const int k = blk * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;       // 4 lanes per point, as in the linearisation
     double sc = 0, mx = 0;
@@ -1069,11 +1132,10 @@ __global__ void k_ba_cull(BaCam cam, BaDev B, int stage, double th) {
 
 int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     hipStream_t st = c->stream;
-    { static bool attr = false; if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-      HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-      HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol16, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)); attr = true; } }
+    { static bool attr = false; if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol16, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol16g, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)); attr = true; } }
     const int np = in->n_poses, nf = in->n_free, nx = in->n_points, ne = in->n_edges, D = 6 * nf;
-    if (((size_t)7 * (D + 1) + 2 * (size_t)D) * sizeof(double) > 158 * 1024) return VO_E_UNSUPPORTED;      // > ~370 free poses
+    if ((CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D) * sizeof(double) > 158 * 1024) return VO_E_UNSUPPORTED;     // D > ~1060 (176 free poses)
     out->lm_iters = 0; out->chi2_initial = 0; out->chi2_final = 0;
     if (ne == 0 || nf == 0 || nx == 0) {
         memcpy(out->poses, in->poses, sizeof(double) * 12 * (size_t)nf);
@@ -1271,7 +1333,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
                 if (nblk_launch) { ProfScope ps(c, "k_ba_schur_blocks"); hipLaunchKernelGGL(k_ba_schur_blocks, dim3(nblk_launch), blk, 0, st, B); }
                 { ProfScope ps(c, "k_ba_chol");
                   if (D <= 192) hipLaunchKernelGGL(k_ba_chol16, dim3(1), dim3(CH_THREADS), sizeof(double) * (CH_NB * CH_NB + (size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D), st, B);
-                  else hipLaunchKernelGGL(k_ba_chol_t<false>, dim3(1), dim3(1024), sizeof(double) * ((size_t)7 * (D + 1) + 2 * (size_t)D), st, B); }
+                  else hipLaunchKernelGGL(k_ba_chol16g, dim3(1), dim3(CH_THREADS), sizeof(double) * (CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D), st, B); }
                 { ProfScope ps(c, "k_ba_update"); hipLaunchKernelGGL(k_ba_update, dim3(gP4.x + gJ.x), blk, 0, st, B, (int)gP4.x); }
                 { ProfScope ps(c, "k_ba_chi_control"); hipLaunchKernelGGL(k_ba_chi_control, gE, blk, 0, st, cam, B, robust, in->huber_delta); }
             }
