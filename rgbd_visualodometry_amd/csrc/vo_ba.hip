@@ -475,6 +475,22 @@ template <int K> struct ChBack {                                // step K of the
     }
 };
 template <> struct ChBack<-1> { static __device__ __forceinline__ void run(const double (&)[CH_NB], double&, double, double&, int) {} };
+// Back substitution on pre-scaled residuals z_j = y_j / L[j][j]: x_k = z_k when its turn comes and
+// z_j -= (L[k][j] / L[j][j]) x_k, so one dependent v_fmac_f64_dpp per step (no multiply, no select on the chain).
+template <int K> struct ChBackZ {
+    static __device__ __forceinline__ void run(const double (&colS)[CH_NB], double& z) {
+        asm("s_nop 1\n\tv_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(z) : "v"(colS[K]), "n"(K));   // colS[K] = 0 for lanes >= K
+        ChBackZ<K - 1>::run(colS, z);
+    }
+};
+template <> struct ChBackZ<0> { static __device__ __forceinline__ void run(const double (&)[CH_NB], double&) {} };   // step 0 would only touch lanes < 0
+template <int K> struct ChPush2 {                               // two accumulators: acc_(K&1) -= x[lane K] * Lx[K]
+    static __device__ __forceinline__ void run(const double (&Lx)[CH_NB], double& a0, double& a1, double x) {
+        ch_fnma_bcast<K>((K & 1) ? a1 : a0, x, Lx[K]);
+        ChPush2<K + 1>::run(Lx, a0, a1, x);
+    }
+};
+template <> struct ChPush2<CH_NB> { static __device__ __forceinline__ void run(const double (&)[CH_NB], double&, double&, double) {} };
 template <int K> struct ChFwd {                                 // step K of the in-register forward substitution (rhs row only)
     static __device__ __forceinline__ void run(const double (&Lr)[CH_NB], double& bc, double inv, double& yf, int r) {
         const double yv = ch_mul_for_dpp(bc, inv);
@@ -690,40 +706,56 @@ __global__ __launch_bounds__(CH_THREADS) void k_ba_chol16(BaDev B) {
         // into the rows further up.  One barrier per panel.
         const int np = (D + CH_NB - 1) / CH_NB;
         double xf = 0.0;                                        // wave 0, lane k (of every DPP row): x[j0 + k]
+        double Lx[CH_NB], colS[CH_NB], inv = 0.0;               // wave 0: operands of the NEXT panel up, loaded one panel ahead
+        auto load_panel = [&](int jt, int jb, int nbb) {        // target panel jt (full), pushed from panel jb of width nbb
+#pragma unroll
+            for (int k = 0; k < CH_NB; ++k) Lx[k] = s_L[TRI32(jb + min(k, nbb - 1), jt) + r16];
+#pragma unroll
+            for (int k = 0; k < CH_NB; ++k) colS[k] = s_L[TRI32(jt + k, jt) + min(r16, k)];      // uniform row base + lane offset
+            inv = s_inv[jt + r16];
+        };
+        auto mask_panel = [&](int nbb) {
+#pragma unroll
+            for (int k = 0; k < CH_NB; ++k) { Lx[k] = k < nbb ? Lx[k] : 0.0; colS[k] = k > r16 ? colS[k] * inv : 0.0; }
+        };
         if (wave == 0) {
             const int j0 = CH_NB * (np - 1), nb = D - j0;
-            double col[CH_NB];                                  // lane j: L[j0+k][j0+j], k > j
+            double col[CH_NB];                                  // lane j: L[j0+k][j0+j] / L[j][j], k > j
 #pragma unroll
             for (int k = 0; k < CH_NB; ++k) col[k] = s_L[TRI32(j0 + min(max(k, r16), nb - 1), j0 + min(r16, nb - 1))];
-#pragma unroll
-            for (int k = 0; k < CH_NB; ++k) col[k] = (r16 < nb && k < nb && k > r16) ? col[k] : 0.0;
             double y = s_b[j0 + min(r16, nb - 1)];
-            double inv = s_inv[j0 + min(r16, nb - 1)];
-            y = r16 < nb ? y : 0.0; inv = r16 < nb ? inv : 0.0;
-            ch_exec_settle(y);
-            ChBack<CH_NB - 1>::run(col, y, inv, xf, r16);
+            double iv = s_inv[j0 + min(r16, nb - 1)];
+            y = r16 < nb ? y : 0.0; iv = r16 < nb ? iv : 0.0;
+#pragma unroll
+            for (int k = 0; k < CH_NB; ++k) col[k] = (r16 < nb && k < nb && k > r16) ? col[k] * iv : 0.0;
+            if (np > 1) load_panel(j0 - CH_NB, j0, nb);          // in flight during the chain
+            double z = y * iv;
+            ch_exec_settle(z);
+            ChBackZ<CH_NB - 1>::run(col, z);
+            xf = z;
             if (lane < nb) s_b[j0 + lane] = xf;
+            if (np > 1) mask_panel(nb);
         }
         __syncthreads();
         for (int p = np - 1; p >= 1; --p) {
             const int j0 = CH_NB * p, nb = min(CH_NB, D - j0), jn = j0 - CH_NB;
             if (wave == 0) {
-                double Lx[CH_NB], col[CH_NB];
-#pragma unroll
-                for (int k = 0; k < CH_NB; ++k) Lx[k] = s_L[TRI32(j0 + min(k, nb - 1), jn) + r16];
-#pragma unroll
-                for (int k = 0; k < CH_NB; ++k) col[k] = s_L[TRI32(jn + k, jn) + min(r16, k)];      // uniform row base + lane offset, masked below
-#pragma unroll
-                for (int k = 0; k < CH_NB; ++k) { Lx[k] = k < nb ? Lx[k] : 0.0; col[k] = k > r16 ? col[k] : 0.0; }
                 double y = s_b[jn + r16];
-                const double inv = s_inv[jn + r16];
+                double cLx[CH_NB], cS[CH_NB];
+                const double cinv = inv;
+#pragma unroll
+                for (int k = 0; k < CH_NB; ++k) { cLx[k] = Lx[k]; cS[k] = colS[k]; }
+                if (p > 1) load_panel(jn - CH_NB, jn, CH_NB);   // next panel's operands: in flight during push + chain
                 CH_STAMP(4)
                 const double xp = ch_mul_for_dpp(xf, 1.0);
-                ch_exec_settle(y);
-                ChPush<0>::run(Lx, y, xp);
-                xf = 0.0;
-                ChBack<CH_NB - 1>::run(col, y, inv, xf, r16);
+                double a0 = 0.0, a1 = 0.0;
+                ch_exec_settle(a0);
+                ChPush2<0>::run(cLx, a0, a1, xp);
+                double z = (y + (a0 + a1)) * cinv;
+                ChBackZ<CH_NB - 1>::run(cS, z);
+                xf = z;
                 if (lane < CH_NB) s_b[jn + lane] = xf;
+                if (p > 1) mask_panel(CH_NB);
                 CH_STAMP(8)
             } else {
                 const int r = tid - 64;
