@@ -411,7 +411,7 @@ __global__ __launch_bounds__(64) void k_ransac_hyp(CamD cam, ChainBuf cb, int n_
     hyp_cnt[h] = 0;
 }
 
-__global__ __launch_bounds__(256) void k_ransac_score(CamD cam, ChainBuf cb, int n_hyp, double thr2) {
+__global__ __launch_bounds__(1024) void k_ransac_score(CamD cam, ChainBuf cb, int n_hyp, double thr2) {
     LANE_PTRS(cb)
     __shared__ int s_cnt;
     const int h = blockIdx.x;
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void k_ransac_score(CamD cam, ChainBuf cb, int
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = hyp_pose[(size_t)12 * h + i];
     int cnt = 0;
-    for (int k = threadIdx.x; k < n; k += 256) cnt += reproj_ok_dev(cam, T, &cxyz[3 * k], &cuv[2 * k], thr2) ? 1 : 0;
+    for (int k = threadIdx.x; k < n; k += 1024) cnt += reproj_ok_dev(cam, T, &cxyz[3 * k], &cuv[2 * k], thr2) ? 1 : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
     if ((threadIdx.x & 63) == 0) atomicAdd(&s_cnt, cnt);
@@ -874,7 +874,7 @@ int vo_track_ransac_launch(vo_ctx* c, int nl, int n_hyp, float reproj_px, float 
     { ProfScope ps(c, "k_ransac_hyp");
       hipLaunchKernelGGL(k_ransac_hyp, dim3((n_hyp + 63) / 64, 1, nl), dim3(64), 0, st, cam, cb, n_hyp); }
     { ProfScope ps(c, "k_ransac_score");
-      hipLaunchKernelGGL(k_ransac_score, dim3(n_hyp, 1, nl), dim3(256), 0, st, cam, cb, n_hyp, thr2); }
+      hipLaunchKernelGGL(k_ransac_score, dim3(n_hyp, 1, nl), dim3(1024), 0, st, cam, cb, n_hyp, thr2); }
     { ProfScope ps(c, "k_ransac_select");
       hipLaunchKernelGGL(k_ransac_select, dim3(1, 1, nl), dim3(1024), 0, st, cam, cb, n_hyp, thr2, (double)conf); }
     HIP_TRY(hipGetLastError());
