@@ -62,7 +62,9 @@ typedef struct vo_params {
     int32_t map_capacity;           /* device map capacity in points                        */
     int32_t max_hypotheses;         /* RANSAC hypothesis capacity (>= n_hyp ever passed)    */
     int32_t max_track_batch;        /* frames tracked concurrently by vo_track_batch (0/1 = one) */
-    int32_t reserved[7];
+    int32_t stream_priority;        /* 0 = default; 1 = the context's HIP stream is created with the highest priority (the
+                                       back-end's context: local BA is the latency-critical chain beside tracking) */
+    int32_t reserved[6];
 } vo_params;
 
 /* cv::KeyPoint's seven fields + the raw depth sample of Frame::GetDepth. */

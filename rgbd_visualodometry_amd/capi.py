@@ -25,7 +25,7 @@ class VoParams(C.Structure):
                 ("cx", C.c_float), ("cy", C.c_float), ("depth_scale", C.c_float), ("n_features", C.c_int32),
                 ("scale_factor", C.c_float), ("n_levels", C.c_int32), ("fast_threshold", C.c_int32),
                 ("edge_threshold", C.c_int32), ("max_frames", C.c_int32), ("map_capacity", C.c_int32),
-                ("max_hypotheses", C.c_int32), ("max_track_batch", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("max_hypotheses", C.c_int32), ("max_track_batch", C.c_int32), ("stream_priority", C.c_int32), ("reserved", C.c_int32 * 6)]
 
 
 class VoTrackParams(C.Structure):

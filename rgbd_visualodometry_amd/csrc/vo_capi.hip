@@ -231,7 +231,13 @@ int vo_ctx_create(const vo_params* p, int device, vo_ctx** out) {
     std::vector<int> tab; std::vector<short> tabs;
     int rc = build_plan(*p, c->plan, tab, tabs);
     if (rc) { delete c; return rc; }
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return VO_E_DEVICE; }
+    {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // numerically lower = higher priority
+        const hipError_t se = p->stream_priority > 0 ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi)
+                                                     : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (se != hipSuccess) { delete c; return VO_E_DEVICE; }
+    }
     rc = vo_orb_upload_constants();
     if (rc) { vo_ctx_destroy(c); return rc; }
     rc = vo_track_set_attrs();

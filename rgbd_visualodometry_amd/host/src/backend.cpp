@@ -77,6 +77,7 @@ void Backend::OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr) {
             vo_params p; vo_default_params(&p);
             p.fx = camera_->GetFx(); p.fy = camera_->GetFy(); p.cx = camera_->GetCx(); p.cy = camera_->GetCy();
             p.n_features = 64; p.max_frames = 1; p.map_capacity = 64; p.max_hypotheses = 1;
+            p.stream_priority = 1;                      // BA is the latency-critical chain beside tracking
             int rc = vo_ctx_create(&p, device_, &ctxOwn_);
             if (rc != VO_OK) throw std::runtime_error(std::string("vo_ctx_create (backend) failed: ") + vo_strerror(rc));
         }
