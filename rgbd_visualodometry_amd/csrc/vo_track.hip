@@ -120,14 +120,26 @@ __global__ __launch_bounds__(64) void k_match(ChainBuf cb, const uint32_t* __res
         const int q = cand[ci];
         const uint4* qd = (const uint4*)(map_desc + (size_t)active[q] * 8);
         const uint4 qa = qd[0], qb = qd[1];
-        int bd = 1 << 30, bi = 0;
+        // distance and tile-local index travel as one key (dist << 6 | t): a single v_min keeps the first minimum;
+        // the eight popcounts are chained through v_bcnt's accumulate operand (two pairs in flight hide the chain)
+        uint32_t bk = 0xFFFFFFFFu;
+#pragma unroll 2
         for (int t = 0; t < nt; ++t) {
             const uint4 a = s_train[2 * t], b = s_train[2 * t + 1];
-            const int h = __popc(qa.x ^ a.x) + __popc(qa.y ^ a.y) + __popc(qa.z ^ a.z) + __popc(qa.w ^ a.w) +
-                          __popc(qb.x ^ b.x) + __popc(qb.y ^ b.y) + __popc(qb.z ^ b.z) + __popc(qb.w ^ b.w);
-            if (h < bd) { bd = h; bi = t; }
+            uint32_t h;
+            asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(h) : "v"(qa.x ^ a.x), "v"((uint32_t)t));      // seeds the sum with t
+            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h) : "v"(qa.y ^ a.y));
+            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h) : "v"(qa.z ^ a.z));
+            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h) : "v"(qa.w ^ a.w));
+            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h) : "v"(qb.x ^ b.x));
+            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h) : "v"(qb.y ^ b.y));
+            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h) : "v"(qb.z ^ b.z));
+            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h) : "v"(qb.w ^ b.w));
+            // h = dist + t  ->  key = (dist << 6) | t = ((h - t) << 6) + t = (h << 6) - 63 t
+            bk = min(bk, (h << 6) - 63u * (uint32_t)t);
         }
-        atomicMin(&best[q], ((uint32_t)bd << 22) | (uint32_t)(t0 + bi));
+        const uint32_t bd = bk >> 6, bi = bk & 63u;
+        atomicMin(&best[q], (bd << 22) | (uint32_t)(t0 + (int)bi));
     }
 }
 
