@@ -589,9 +589,18 @@ __device__ void lm_pass_dev(const CamD& cam, const float* cxyz, const float* cuv
             if (round == 1 && !(mask[i] & 2)) continue;
             k = edges ? edges[i] : i;                  // edges == nullptr: correspondences already gathered (LDS)
         }
-        const D3 pc = xform(T, mk((double)cxyz[3 * k], (double)cxyz[3 * k + 1], (double)cxyz[3 * k + 2]));
+        // R p + t with fused multiply-adds (the shared xform() helper is compiled without contraction for the kernels whose
+        // integer decisions must match the oracle bit for bit; here only the tolerance-checked LM sums depend on it)
+        const double px = (double)cxyz[3 * k], py = (double)cxyz[3 * k + 1], pz = (double)cxyz[3 * k + 2];
+        D3 pc;
+        pc.x = fma(T[0], px, fma(T[1], py, fma(T[2], pz, T[9])));
+        pc.y = fma(T[3], px, fma(T[4], py, fma(T[5], pz, T[10])));
+        pc.z = fma(T[6], px, fma(T[7], py, fma(T[8], pz, T[11])));
         const double zz = pc.z + 1e-18;
-        const double Zi = 1.0 / zz;                    // correctly rounded: the gain ratio near convergence is sensitive to chi2 noise
+        // 1 / z: v_rcp_f64 (2^-26) + two Newton steps, ~1 ulp; the IEEE sequence (div_scale / fmas / fixup) is twice as long
+        double Zi = __builtin_amdgcn_rcp(zz);
+        Zi = fma(fma(-zz, Zi, 1.0), Zi, Zi);
+        Zi = fma(fma(-zz, Zi, 1.0), Zi, Zi);
         const double fx = cam.fx, fy = cam.fy, xz = pc.x * Zi, yz = pc.y * Zi;
         const double e0 = (double)cuv[2 * k] - (fx * xz + cam.cx), e1 = (double)cuv[2 * k + 1] - (fy * yz + cam.cy);   // g2o_types.h:83
         const double e2 = e0 * e0 + e1 * e1;
