@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the driver's runs) | gloo (rehearsal of the multi-rank path)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses device 0 (needs --dist-backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=150, help="bounded CPU-baseline sample (frames)")
+    ap.add_argument("--cpu-frames", type=int, default=330, help="bounded CPU-baseline sample (frames; ~14 s of CPU work at the default)")
     args = ap.parse_args()
 
     import torch
