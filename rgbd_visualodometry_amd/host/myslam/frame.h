@@ -20,10 +20,10 @@ public:
     static Frame::Ptr CreateFrame(const double timestamp, const Camera::Ptr camera, const Mat color, const Mat depth);
 
     size_t GetId() const { return id_; }
-    SE3 GetPose() { std::unique_lock<std::mutex> lck(poseMutex_); return T_c_w_; }
-    void SetPose(const SE3 pose) { std::unique_lock<std::mutex> lck(poseMutex_); T_c_w_ = pose; }
+    SE3 GetPose() { std::unique_lock<std::mutex> lck(poseLock_); return pose_cw_; }
+    void SetPose(const SE3 pose) { std::unique_lock<std::mutex> lck(poseLock_); pose_cw_ = pose; }
     double GetDepth(const KeyPoint& kp);                  // metres, -1 if none (frame.cpp:43-67)
-    Vector3d GetCamCenter() const { return T_c_w_.inverse().translation(); }
+    Vector3d GetCamCenter() const { return pose_cw_.inverse().translation(); }
     bool IsCouldObserveMappoint(const Mappoint::Ptr& mpt);
     void AddObservedMappoint(const size_t mappointId, const Point2f pixelPos);
     void AddObservedMappoint(Mappoint* mappoint, const Point2f pixelPos);      // same, without the id lookup
@@ -33,13 +33,13 @@ public:
     struct ObservedEntry { size_t id; Mappoint* mappoint; bool alive; };
     const std::vector<ObservedEntry>& Observed() const { return observed_; }
     std::unordered_set<size_t> GetObservedMappointIds() {
-        std::unique_lock<std::mutex> lck(observationMutex_);
+        std::unique_lock<std::mutex> lck(obsLock_);
         std::unordered_set<size_t> ids;
         for (const ObservedEntry& e : observed_) if (e.alive) ids.insert(e.id);
         return ids;
     }
     bool IsObservedMappoint(const size_t id) {
-        std::unique_lock<std::mutex> lck(observationMutex_);
+        std::unique_lock<std::mutex> lck(obsLock_);
         for (size_t i = observed_.size(); i-- > 0;) if (observed_[i].id == id) return observed_[i].alive;
         return false;
     }
@@ -48,23 +48,36 @@ public:
     // and written once (same final weights and active sets as one update per observation).
     void BeginCovisibilityBatch() { covisBatch_ = true; }
     void EndCovisibilityBatch();
-    std::unordered_set<size_t> GetCovisibleKeyframes() { std::unique_lock<std::mutex> lck(observationMutex_); return activeCovisibleKeyframes_; }
+    std::unordered_set<size_t> GetCovisibleKeyframes() { std::unique_lock<std::mutex> lck(obsLock_); return covis_.strong; }
 
     int slot_ = -1;                 // vo_ctx frame slot holding this frame's ORB results (-1: none)
     uint64_t baStamp_ = 0; int baIndex_ = -1;    // scratch of Backend::Build
     bool orb_done_ = false;
 
 private:
-    static size_t factoryId_;
+    // Covisibility ledger: shared-point counts per partner keyframe; a partner is "covisible" (returned by
+    // GetCovisibleKeyframes) exactly while its count is >= kCovisibleMin.  One routine keeps both containers in step.
+    static constexpr int kCovisibleMin = 15;
+    struct CovisLedger {
+        CovisibleKeyframeIdToWeight count;
+        std::unordered_set<size_t> strong;
+        int add(size_t kf, int delta) { return set(kf, count[kf] + delta); }
+        int set(size_t kf, int w) {
+            if (w <= 0) { count.erase(kf); strong.erase(kf); return 0; }
+            count[kf] = w;
+            if (w >= kCovisibleMin) strong.insert(kf); else strong.erase(kf);
+            return w;
+        }
+    };
+    static size_t nextId_;
     size_t id_;
-    std::mutex poseMutex_;
-    SE3 T_c_w_;
-    std::mutex observationMutex_;
+    std::mutex poseLock_;
+    SE3 pose_cw_;                                           // world -> camera
+    std::mutex obsLock_;
     std::vector<ObservedEntry> observed_;
-    bool covisBatch_ = false; int covisAcc_ = 0;            // batch state (this frame) / pending count (partner frame)
+    CovisLedger covis_;
+    bool covisBatch_ = false; int covisPending_ = 0;        // batch state (this frame) / pending count (partner frame)
     std::vector<Frame*> covisTouched_;
-    CovisibleKeyframeIdToWeight allCovisibleKeyframeIdToWeight_;
-    std::unordered_set<size_t> activeCovisibleKeyframes_;    // >= 15 shared map points
     Frame(const size_t id, const double timestamp, const Camera::Ptr camera, const Mat color, const Mat depth);
 };
 }  // namespace myslam

@@ -18,16 +18,16 @@ public:
     static MapManager& GetInstance();
     static void BindToThread(MapManager* m);       // nullptr -> process-wide singleton
 
-    void InsertKeyframe(const Frame::Ptr& frame) { std::unique_lock<std::mutex> lck(dataMutex_); keyframesDict_[frame->GetId()] = frame; }
-    Frame::Ptr GetKeyframe(const size_t id) { std::unique_lock<std::mutex> lck(dataMutex_); auto it = keyframesDict_.find(id); return it == keyframesDict_.end() ? nullptr : it->second; }
-    KeyframeIdToPtr GetAllKeyframes() { std::unique_lock<std::mutex> lck(dataMutex_); return keyframesDict_; }
+    void InsertKeyframe(const Frame::Ptr& frame) { std::unique_lock<std::mutex> lck(tableLock_); keyframesById_[frame->GetId()] = frame; }
+    Frame::Ptr GetKeyframe(const size_t id) { std::unique_lock<std::mutex> lck(tableLock_); auto it = keyframesById_.find(id); return it == keyframesById_.end() ? nullptr : it->second; }
+    KeyframeIdToPtr GetAllKeyframes() { std::unique_lock<std::mutex> lck(tableLock_); return keyframesById_; }
     void InsertMappoint(const Mappoint::Ptr& map_point);
-    Mappoint::Ptr GetMappoint(const size_t id) { std::unique_lock<std::mutex> lck(dataMutex_); auto it = mappointsDict_.find(id); return it == mappointsDict_.end() ? nullptr : it->second; }
-    MappointIdToPtr GetAllMappoints() { std::unique_lock<std::mutex> lck(dataMutex_); return mappointsDict_; }
+    Mappoint::Ptr GetMappoint(const size_t id) { std::unique_lock<std::mutex> lck(tableLock_); auto it = pointsById_.find(id); return it == pointsById_.end() ? nullptr : it->second; }
+    MappointIdToPtr GetAllMappoints() { std::unique_lock<std::mutex> lck(tableLock_); return pointsById_; }
     MappointIdToPtr GetMappointsAroundKeyframe(const Frame::Ptr& keyframe);
 
-    Mappoint* FindMappoint(const size_t id) { auto it = mappointsDict_.find(id); return it == mappointsDict_.end() ? nullptr : it->second.get(); }   // no lock, no copy
-    size_t MappointCount() { std::unique_lock<std::mutex> lck(dataMutex_); return mappointsDict_.size(); }
+    Mappoint* FindMappoint(const size_t id) { auto it = pointsById_.find(id); return it == pointsById_.end() ? nullptr : it->second.get(); }   // no lock, no copy
+    size_t MappointCount() { std::unique_lock<std::mutex> lck(tableLock_); return pointsById_.size(); }
     // map points whose host state is newer than the device copy (drained by the front-end once per frame)
     void NoteDirty(Mappoint* mp) { dirty_.push_back(mp); }
     std::vector<Mappoint*> TakeDirty() { std::vector<Mappoint*> d; d.swap(dirty_); return d; }
@@ -36,9 +36,9 @@ public:
     std::vector<Mappoint*> CollectMappointsAroundKeyframe(const Frame::Ptr& keyframe);
 
 private:
-    std::mutex dataMutex_;
-    MappointIdToPtr mappointsDict_;
-    KeyframeIdToPtr keyframesDict_;
+    std::mutex tableLock_;
+    MappointIdToPtr pointsById_;
+    KeyframeIdToPtr keyframesById_;
     int nextSlot_ = 0;
     std::vector<Mappoint*> dirty_;
     std::vector<Mappoint::Ptr> order_;

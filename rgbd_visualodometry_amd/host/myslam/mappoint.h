@@ -18,22 +18,22 @@ public:
 
     static Mappoint::Ptr CreateMappoint(const Vector3d position, const Descriptor& descriptor);
 
-    Vector3d GetPosition() { std::unique_lock<std::mutex> lock(posMutex_); return pos_; }
-    void SetPosition(const Vector3d pos) { { std::unique_lock<std::mutex> lock(posMutex_); pos_ = pos; } MarkDirty(); }
+    Vector3d GetPosition() { std::unique_lock<std::mutex> lock(posLock_); return pos_; }
+    void SetPosition(const Vector3d pos) { { std::unique_lock<std::mutex> lock(posLock_); pos_ = pos; } MarkDirty(); }
     // position already mirrored on the device by the caller (bulk upsert): no dirty marking
-    void SetPositionSynced(const Vector3d pos) { std::unique_lock<std::mutex> lock(posMutex_); pos_ = pos; }
+    void SetPositionSynced(const Vector3d pos) { std::unique_lock<std::mutex> lock(posLock_); pos_ = pos; }
     // Bulk paths of the map-owning thread (BA graph cut / merge touch every point of the local map): no lock per point.
     const Vector3d& PositionUnlocked() const { return pos_; }
     void SetPositionSyncedUnlocked(const Vector3d& pos) { pos_ = pos; }
     size_t GetId() const { return id_; }
-    Vector3d GetNormDirection() { std::unique_lock<std::mutex> lock(observationMutex_); return norm_; }
+    Vector3d GetNormDirection() { std::unique_lock<std::mutex> lock(obsLock_); return norm_; }
 
     void AddObservedByKeyframe(const size_t keyframeId, const Point2f posInPixel, const Vector3d cameraCenter, Frame* keyframe = nullptr);
     const std::vector<Observation>& ObservationList() const { return obsList_; }     // insertion (= keyframe id) order; single-threaded callers
     void RemoveObservedByKeyframe(const size_t keyframeId);
     // the reference's container (mappoint.h:71), assembled on request: the flat observation list is the storage
     ObservedByKeyframeIdtoPixelPos GetObservedByKeyframesMap() {
-        std::unique_lock<std::mutex> lock(observationMutex_);
+        std::unique_lock<std::mutex> lock(obsLock_);
         ObservedByKeyframeIdtoPixelPos m;
         for (const Observation& o : obsList_) m[o.keyframeId] = o.pixel;
         return m;
@@ -47,12 +47,12 @@ public:
     void MarkDirty();
 
 private:
-    static size_t factoryId_;
+    static size_t nextId_;
     size_t id_;
     Vector3d norm_;
-    std::mutex posMutex_;
+    std::mutex posLock_;
     Vector3d pos_;
-    std::mutex observationMutex_;
+    std::mutex obsLock_;
     std::vector<Observation> obsList_;
     Mappoint(const size_t id, const Vector3d position, const Descriptor& descriptor);
 };

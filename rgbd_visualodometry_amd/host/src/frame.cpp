@@ -4,14 +4,14 @@
 #include "myslam/mapmanager.h"
 
 namespace myslam {
-size_t Frame::factoryId_ = 0;
+size_t Frame::nextId_ = 0;
 
 Frame::Ptr Frame::CreateFrame(const double timestamp, const Camera::Ptr camera, const Mat color, const Mat depth) {
-    return Frame::Ptr(new Frame(++factoryId_, timestamp, camera, color.clone(3), depth.clone(2)));
+    return Frame::Ptr(new Frame(++nextId_, timestamp, camera, color.clone(3), depth.clone(2)));
 }
 
 Frame::Frame(const size_t id, const double timestamp, const Camera::Ptr camera, const Mat color, const Mat depth)
-    : timestamp_(timestamp), camera_(camera), color_(color), depth_(depth), id_(id), T_c_w_(SE3()) {}
+    : timestamp_(timestamp), camera_(camera), color_(color), depth_(depth), id_(id), pose_cw_(SE3()) {}
 
 // The raw sample (with the 4-neighbour fallback of frame.cpp:52-63) is taken on the device next to the
 // keypoint (vo_keypoint::depth_raw); only the metric conversion is left.
@@ -21,7 +21,7 @@ double Frame::GetDepth(const KeyPoint& kp) {
 }
 
 bool Frame::IsCouldObserveMappoint(const Mappoint::Ptr& mpt) {
-    Vector3d posInCam = camera_->World2Camera(mpt->GetPosition(), T_c_w_);
+    Vector3d posInCam = camera_->World2Camera(mpt->GetPosition(), pose_cw_);
     if (posInCam[2] < 0) return false;
     Vector2d px = camera_->Camera2Pixel(posInCam);
     if (px.x < 0 || px.x >= color_.cols || px.y < 0 || px.y >= color_.rows) return false;
@@ -37,56 +37,53 @@ void Frame::AddObservedMappoint(const size_t mappointId, const Point2f pixelPos)
 }
 
 void Frame::AddObservedMappoint(Mappoint* mappoint, const Point2f pixelPos) {
-    std::unique_lock<std::mutex> lck(observationMutex_);
+    std::unique_lock<std::mutex> guard(obsLock_);
     observed_.push_back(ObservedEntry{mappoint->GetId(), mappoint, true});
     mappoint->AddObservedByKeyframe(id_, pixelPos, GetCamCenter(), this);
-    for (const Mappoint::Observation& o : mappoint->ObservationList()) {     // no copy of the observation map
-        Frame* otherKF = o.keyframe;
-        if (otherKF == this) continue;
-        assert(otherKF != nullptr);
-        if (covisBatch_) { if (otherKF->covisAcc_++ == 0) covisTouched_.push_back(otherKF); continue; }
-        int w = ++allCovisibleKeyframeIdToWeight_[o.keyframeId];
-        if (w >= 15) activeCovisibleKeyframes_.insert(o.keyframeId);
-        otherKF->UpdateCovisibleKeyframeWeight(id_, w);
+    // every other keyframe that already sees this point gains one shared point with this frame (frame.cpp:104-119)
+    for (const Mappoint::Observation& seenBy : mappoint->ObservationList()) {
+        Frame* partner = seenBy.keyframe;
+        if (partner == this) continue;
+        assert(partner != nullptr);
+        if (covisBatch_) {                                  // counted now, written once in EndCovisibilityBatch
+            if (partner->covisPending_++ == 0) covisTouched_.push_back(partner);
+            continue;
+        }
+        partner->UpdateCovisibleKeyframeWeight(id_, covis_.add(seenBy.keyframeId, +1));
     }
 }
 
 void Frame::EndCovisibilityBatch() {
-    std::unique_lock<std::mutex> lck(observationMutex_);
+    std::unique_lock<std::mutex> guard(obsLock_);
     covisBatch_ = false;
-    for (Frame* otherKF : covisTouched_) {
-        const int w = (allCovisibleKeyframeIdToWeight_[otherKF->id_] += otherKF->covisAcc_);
-        otherKF->covisAcc_ = 0;
-        if (w >= 15) activeCovisibleKeyframes_.insert(otherKF->id_);
-        otherKF->UpdateCovisibleKeyframeWeight(id_, w);
+    for (Frame* partner : covisTouched_) {
+        const int gained = partner->covisPending_;
+        partner->covisPending_ = 0;
+        partner->UpdateCovisibleKeyframeWeight(id_, covis_.add(partner->id_, gained));
     }
     covisTouched_.clear();
 }
 
 void Frame::RemoveObservedMappoint(const size_t mappointId) {
-    std::unique_lock<std::mutex> lck(observationMutex_);
+    std::unique_lock<std::mutex> guard(obsLock_);
     Mappoint* mappoint = nullptr;
     for (size_t i = observed_.size(); i-- > 0;)
         if (observed_[i].id == mappointId && observed_[i].alive) { observed_[i].alive = false; mappoint = observed_[i].mappoint; break; }
     assert(mappoint != nullptr);
     if (mappoint == nullptr) return;
     mappoint->RemoveObservedByKeyframe(id_);
-    for (const Mappoint::Observation& o : mappoint->ObservationList()) {
-        const size_t other = o.keyframeId;
-        if (other == id_) continue;
-        Frame* otherKF = o.keyframe;
-        assert(otherKF != nullptr);
-        int w = --allCovisibleKeyframeIdToWeight_[other];
-        if (w == 0) allCovisibleKeyframeIdToWeight_.erase(other);
-        else if (w < 15) activeCovisibleKeyframes_.erase(other);
-        otherKF->UpdateCovisibleKeyframeWeight(id_, w);
+    // the remaining observers lose one shared point with this frame (frame.cpp:133-150)
+    for (const Mappoint::Observation& seenBy : mappoint->ObservationList()) {
+        Frame* partner = seenBy.keyframe;
+        if (partner == this) continue;
+        assert(partner != nullptr);
+        partner->UpdateCovisibleKeyframeWeight(id_, covis_.add(seenBy.keyframeId, -1));
     }
 }
 
+// the partner's side of a ledger update: it records the weight this frame computed (frame.cpp:157-171)
 void Frame::UpdateCovisibleKeyframeWeight(const size_t id, const int weight) {
-    std::unique_lock<std::mutex> lck(observationMutex_);
-    if (weight == 0) { allCovisibleKeyframeIdToWeight_.erase(id); activeCovisibleKeyframes_.erase(id); }
-    else if (weight >= 15) { allCovisibleKeyframeIdToWeight_[id] = weight; activeCovisibleKeyframes_.insert(id); }
-    else { allCovisibleKeyframeIdToWeight_[id] = weight; activeCovisibleKeyframes_.erase(id); }
+    std::unique_lock<std::mutex> guard(obsLock_);
+    covis_.set(id, weight);
 }
 }  // namespace myslam

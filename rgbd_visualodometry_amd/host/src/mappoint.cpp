@@ -4,17 +4,17 @@
 #include "myslam/mapmanager.h"
 
 namespace myslam {
-size_t Mappoint::factoryId_ = 0;
+size_t Mappoint::nextId_ = 0;
 
 Mappoint::Ptr Mappoint::CreateMappoint(const Vector3d position, const Descriptor& descriptor) {
-    return Mappoint::Ptr(new Mappoint(++factoryId_, position, descriptor));
+    return Mappoint::Ptr(new Mappoint(++nextId_, position, descriptor));
 }
 
 Mappoint::Mappoint(const size_t id, const Vector3d position, const Descriptor& descriptor)
     : descriptor_(descriptor), triangulated_(false), optimized_(false), outlier_(false), id_(id), norm_(Vector3d::Zero()), pos_(position) {}
 
 void Mappoint::AddObservedByKeyframe(const size_t keyframeId, const Point2f posInPixel, const Vector3d cameraCenter, Frame* keyframe) {
-    std::unique_lock<std::mutex> lock(observationMutex_);
+    std::unique_lock<std::mutex> lock(obsLock_);
     obsList_.push_back(Observation{keyframeId, posInPixel, keyframe});
     norm_ = (norm_ + (pos_ - cameraCenter).normalized()).normalized();      // running mean viewing direction
     lock.unlock();
@@ -22,7 +22,7 @@ void Mappoint::AddObservedByKeyframe(const size_t keyframeId, const Point2f posI
 }
 
 void Mappoint::RemoveObservedByKeyframe(const size_t keyframeId) {
-    std::unique_lock<std::mutex> lock(observationMutex_);
+    std::unique_lock<std::mutex> lock(obsLock_);
     for (size_t i = 0; i < obsList_.size(); ++i) if (obsList_[i].keyframeId == keyframeId) { obsList_.erase(obsList_.begin() + i); break; }
     if (obsList_.empty()) { outlier_ = true; lock.unlock(); MarkDirty(); }  // no observation left
 }
