@@ -3,9 +3,15 @@
 // reads <dataset_dir>/associate.txt, decodes the PNG pairs, feeds FrontEnd::AddFrame and writes the TUM
 // trajectory "timestamp tx ty tz qx qy qz qw" to output_file.  No OpenCV / Boost: PNG over zlib, wall-clock
 // timing of AddFrame only (the region the reference times, :104-109).
+// Optional keys (beyond the reference's default.yaml): lookahead_frames (default 1) decodes that many frame pairs ahead on
+// decode_threads host threads -- the next chunk is decoded while the current one is tracked -- and hands each chunk to
+// FrontEnd::PrefetchFrames (batched ORB); track_batch and backend_lag_frames are read by FrontEnd / Backend.  The
+// trajectory does not depend on any of them.
 #include <chrono>
 #include <fstream>
+#include <future>
 #include <iostream>
+#include <thread>
 
 #include "myslam/backend.h"
 #include "myslam/config.h"
@@ -34,34 +40,66 @@ int main(int argc, char** argv) {
         myslam::DecodedImage color0, depth0;
         if (!myslam::ReadColorBGR(datasetDir + "/" + entries[0].rgbFile, color0)) { std::cout << "Frame missing" << std::endl; return 1; }
         myslam::Camera::Ptr camera(new myslam::Camera);
-        myslam::FrontEnd::Ptr frontend(new myslam::FrontEnd(myslam::Config::has("device") ? myslam::Config::get<int>("device") : 0, color0.width, color0.height, 1));
+        const int lookahead = std::max(1, myslam::Config::has("lookahead_frames") ? myslam::Config::get<int>("lookahead_frames") : 1);
+        const int decodeThreads = std::max(1, myslam::Config::has("decode_threads") ? myslam::Config::get<int>("decode_threads")
+                                                                                    : (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency())));
+        myslam::FrontEnd::Ptr frontend(new myslam::FrontEnd(myslam::Config::has("device") ? myslam::Config::get<int>("device") : 0, color0.width, color0.height, lookahead));
         myslam::Backend::Ptr backend;
         if (myslam::Config::get<int>("enable_local_optimization")) {
             std::cout << "Enable local optimization" << std::endl;
             backend = myslam::Backend::Ptr(new myslam::Backend(camera));
             frontend->SetBackend(backend);
         }
-        std::cout << "Finish initialization! (compute backend: " << vo_backend_name() << ")\n\n" << std::endl;
+        std::cout << "Finish initialization! (compute backend: " << vo_backend_name() << ", lookahead " << lookahead << ")\n\n" << std::endl;
+
+        // one chunk = up to `lookahead` decoded frame pairs; ok[i] false marks the first missing / undecodable frame
+        struct Chunk { size_t first = 0; std::vector<myslam::DecodedImage> color, depth; std::vector<char> ok; };
+        auto decodeChunk = [&](size_t first) {
+            Chunk ch;
+            ch.first = first;
+            const size_t n = std::min<size_t>(lookahead, entries.size() - first);
+            ch.color.resize(n); ch.depth.resize(n); ch.ok.assign(n, 0);
+            auto work = [&](size_t t0) {
+                for (size_t j = t0; j < n; j += (size_t)decodeThreads)
+                    ch.ok[j] = myslam::ReadColorBGR(datasetDir + "/" + entries[first + j].rgbFile, ch.color[j]) &&
+                               myslam::ReadDepth16(datasetDir + "/" + entries[first + j].depthFile, ch.depth[j]);
+            };
+            std::vector<std::thread> pool;
+            for (int t = 1; t < decodeThreads && (size_t)t < n; ++t) pool.emplace_back(work, (size_t)t);
+            work(0);
+            for (auto& th : pool) th.join();
+            return ch;
+        };
+
         double totalMs = 0; size_t timed = 0;
-        for (size_t i = 0; i < entries.size(); ++i) {
-            myslam::DecodedImage color, depth;
-            if (!myslam::ReadColorBGR(datasetDir + "/" + entries[i].rgbFile, color) || !myslam::ReadDepth16(datasetDir + "/" + entries[i].depthFile, depth)) {
-                std::cout << "Frame missing" << std::endl;
-                break;
+        bool stop = false;
+        std::future<Chunk> next = std::async(std::launch::async, decodeChunk, (size_t)0);
+        for (size_t first = 0; first < entries.size() && !stop; first += (size_t)lookahead) {
+            Chunk ch = next.get();
+            if (first + (size_t)lookahead < entries.size()) next = std::async(std::launch::async, decodeChunk, first + (size_t)lookahead);
+            std::vector<myslam::Frame::Ptr> frames;
+            for (size_t j = 0; j < ch.ok.size(); ++j) {
+                if (!ch.ok[j]) { std::cout << "Frame missing" << std::endl; stop = true; break; }
+                myslam::Image c, d;
+                c.data = ch.color[j].data.data(); c.rows = ch.color[j].height; c.cols = ch.color[j].width; c.stride = 3 * ch.color[j].width;
+                d.data = ch.depth[j].data.data(); d.rows = ch.depth[j].height; d.cols = ch.depth[j].width; d.stride = 2 * ch.depth[j].width;
+                frames.push_back(myslam::Frame::CreateFrame(entries[first + j].rgbTime, camera, c, d));
             }
-            myslam::Image c, d;
-            c.data = color.data.data(); c.rows = color.height; c.cols = color.width; c.stride = 3 * color.width;
-            d.data = depth.data.data(); d.rows = depth.height; d.cols = depth.width; d.stride = 2 * depth.width;
-            myslam::Frame::Ptr pFrame = myslam::Frame::CreateFrame(entries[i].rgbTime, camera, c, d);
             auto t0 = std::chrono::steady_clock::now();
-            frontend->AddFrame(pFrame);
-            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            totalMs += ms; ++timed;
-            if (frontend->GetState() == myslam::FrontEnd::LOST) { std::cout << "VO lost" << std::endl; break; }
-            char stamp[64];
-            snprintf(stamp, sizeof(stamp), "%f", pFrame->timestamp_);          // std::to_string(double) formatting (run_vo.cpp:116)
-            myslam::WritePoseLine(fout, stamp, pFrame->GetPose().inverse());
+            if (lookahead > 1 && !frames.empty()) frontend->PrefetchFrames(frames);        // one batched ORB launch chain for the chunk
+            totalMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            for (auto& pFrame : frames) {
+                t0 = std::chrono::steady_clock::now();
+                frontend->AddFrame(pFrame);
+                totalMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                ++timed;
+                if (frontend->GetState() == myslam::FrontEnd::LOST) { std::cout << "VO lost" << std::endl; stop = true; break; }
+                char stamp[64];
+                snprintf(stamp, sizeof(stamp), "%f", pFrame->timestamp_);          // std::to_string(double) formatting (run_vo.cpp:116)
+                myslam::WritePoseLine(fout, stamp, pFrame->GetPose().inverse());
+            }
         }
+        if (next.valid()) next.wait();
         if (backend) backend->Stop();
         if (timed) std::cout << "Frames: " << timed << ", mean AddFrame time (ms): " << totalMs / timed << std::endl;
     } catch (const std::exception& e) {

@@ -43,6 +43,16 @@ def test_png_roundtrip_through_the_driver_decoder(tum_dir, tmp_path):
     check(traj, root)
 
 
+def test_lookahead_decode_mode_gives_the_same_trajectory(tum_dir, tmp_path):
+    """lookahead_frames / decode_threads / track_batch only change how the driver schedules work."""
+    root, _, _ = tum_dir
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    a, _ = run_driver(ORACLE_BIN, root, str(tmp_path / "a"), number_of_features=400)
+    b, log = run_driver(ORACLE_BIN, root, str(tmp_path / "b"), number_of_features=400, lookahead_frames=5, decode_threads=3, track_batch=4)
+    assert "lookahead 5" in log
+    assert sorted(a) == sorted(b) and all(a[k] == b[k] for k in a)
+
+
 def test_missing_associate_file(tmp_path):
     cfg = tmp_path / "cfg.yaml"
     dataset.write_config(str(cfg), str(tmp_path / "nowhere"), str(tmp_path / "o.txt"))
@@ -61,3 +71,6 @@ def test_run_vo_on_gpu_matches_oracle_driver(tum_dir, tmp_path):
     pa = np.array([[float(v) for v in a[k]] for k in sorted(a)])
     pb = np.array([[float(v) for v in b[k]] for k in sorted(b)])
     np.testing.assert_allclose(pa, pb, atol=2e-5)           # text output has 6 significant digits
+    (tmp_path / "l").mkdir()
+    c, log = run_driver(HIP_BIN, root, str(tmp_path / "l"), number_of_features=800, lookahead_frames=8, decode_threads=4, track_batch=4)
+    assert "lookahead 8" in log and sorted(c) == sorted(a) and all(c[k] == a[k] for k in a)
