@@ -214,7 +214,7 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             nf = min(args.cpu_frames, total)
-            o = system.VoSystem(system.ORACLE_LIB, **{**opts, "max_frames_in_flight": 1, "track_batch": 1})
+            o = system.VoSystem(ORACLE_LIB, **{**opts, "max_frames_in_flight": 1, "track_batch": 1})
             est_c = {}
             tc = time.perf_counter()
             for i in range(nf):

@@ -56,9 +56,39 @@ int myslam_add_frame(myslam_system* s, double stamp, const void* bgr, const void
                      int on_device, int* tracked, double T_wc[12]);
 int myslam_add_prefetched(myslam_system* s, int* tracked, double T_wc[12]);
 int myslam_get_stats(myslam_system* s, myslam_stats* st);
+/* Wait for a pending (overlapped) local BA and merge it now: end of a sequence, or of a timed region (Backend::Flush). */
+int myslam_flush(myslam_system* s);
 /* The vo_ctx (include/vo_hip.h) the system's FrontEnd owns, for profiling taps (vo_profile_*). */
 void* myslam_get_context(myslam_system* s);
 const char* myslam_last_error(void);
+
+/* ---- taps for parity tests: the host-layer logic checked against an independent model (tests/ref_model.py) ----------
+ * None of these is on the product path.  A "scenario" is a map built by hand on a myslam_system that tracks no frames:
+ * keyframes with given poses, map points with given positions, observations added and removed one by one through the
+ * same Frame / Mappoint / MapManager / Backend methods that FrontEnd::AddFrame uses. */
+/* Triangulation (reference include/myslam/util.h:16-34): n views, T_cw n x 12, pts n x 3 on the normalised plane. */
+int myslam_triangulate(int n, const double* T_cw, const double* pts, double out_xyz[3], int* ok);
+/* Sophus conventions the keyframe policy relies on (reference src/frontend.cpp:343-358): tangent = [translation, rotation]. */
+int myslam_se3_log(const double T[12], double out6[6]);
+int myslam_se3_exp(const double d6[6], double T_out[12]);
+/* FrontEnd::IsGoodEstimation / IsKeyframe on explicit poses (reference src/frontend.cpp:334-364): bit0 good, bit1 keyframe. */
+int myslam_keyframe_policy(myslam_system* s, const double T_ref_cw[12], const double T_cur_cw[12], int num_inliers, int* flags);
+int myslam_scn_add_keyframe(myslam_system* s, const double T_cw[12], int64_t* id_out);
+int myslam_scn_add_mappoint(myslam_system* s, const double xyz[3], int64_t* id_out);
+int myslam_scn_observe(myslam_system* s, int64_t keyframe_id, int64_t mappoint_id, float u, float v);       /* Frame::AddObservedMappoint   src/frame.cpp:93-120  */
+int myslam_scn_unobserve(myslam_system* s, int64_t keyframe_id, int64_t mappoint_id);                       /* Frame::RemoveObservedMappoint src/frame.cpp:122-152 */
+/* allCovisibleKeyframeIdToWeight_ / activeCovisibleKeyframes_ of a keyframe (reference include/myslam/frame.h:94-95), id order */
+int myslam_scn_covisibility(myslam_system* s, int64_t keyframe_id, int64_t* ids, int32_t* weights, uint8_t* active, int cap, int* n);
+/* MapManager::GetMappointsAroundKeyframe (reference src/mapmanager.cpp:14-38), in the host layer's matching order */
+int myslam_scn_local_map(myslam_system* s, int64_t keyframe_id, int64_t* mappoint_ids, int cap, int* n);
+/* The graph Backend::Optimize builds for a keyframe (reference src/backend.cpp:36-135): pose ids (free first), points, edges */
+int myslam_scn_ba_graph(myslam_system* s, int64_t keyframe_id, int64_t* pose_ids, int cap_poses, int* n_poses, int* n_free,
+                        int64_t* point_ids, int cap_points, int* n_points, int32_t* edge_pose, int32_t* edge_point, float* edge_uv, int cap_edges, int* n_edges);
+/* map point state: outlier flag, number of observing keyframes, position, mean viewing direction */
+int myslam_scn_mappoint(myslam_system* s, int64_t mappoint_id, int* outlier, int* n_obs, double xyz[3], double normal[3]);
+/* Run the local BA of a keyframe synchronously and merge it (Backend::Optimize incl. write-back, src/backend.cpp:19-195). */
+int myslam_scn_run_ba(myslam_system* s, int64_t keyframe_id);
+int myslam_scn_keyframe_pose(myslam_system* s, int64_t keyframe_id, double T_cw[12]);
 const char* myslam_backend_name(void);
 #ifdef __cplusplus
 }

@@ -171,6 +171,8 @@ int vo_orb_fetch(vo_ctx* ctx, int slot, vo_keypoint* kps, uint8_t* desc, int cap
 /* Debug/parity taps: pyramid level image (gray u8, tightly packed w*h) and its size. */
 int vo_orb_level_size(vo_ctx* ctx, int level, int* w, int* h, int* quota);
 int vo_orb_fetch_level(vo_ctx* ctx, int slot, int level, uint8_t* gray_out);
+/* The 7x7 sigma-2 blurred copy of that level (the image the rBRIEF tests read), same packing. */
+int vo_orb_fetch_blur_level(vo_ctx* ctx, int slot, int level, uint8_t* blur_out);
 
 /* ---- map ---------------------------------------------------------------------------- */
 /* Insert or overwrite map points at device-map slots idx[i] (0 <= idx < map_capacity). */

@@ -136,6 +136,14 @@ int vo_orb_fetch_level(vo_ctx* c, int slot, int l, uint8_t* out) {
     return VO_OK;
 }
 
+int vo_orb_fetch_blur_level(vo_ctx* c, int slot, int l, uint8_t* out) {
+    if (!c || slot < 0 || slot >= (int)c->slots.size() || l < 0 || l >= c->plan.nlevels || !out) return VO_E_INVALID;
+    auto& s = c->slots[slot];
+    if (!s.has_orb) return VO_E_STATE;
+    std::memcpy(out, s.dbg[l].blurred.data(), s.dbg[l].blurred.size());
+    return VO_OK;
+}
+
 int vo_map_upsert(vo_ctx* c, const int32_t* idx, const double* xyz, const double* nrm, const uint8_t* desc, const uint8_t* flags, int n) {
     if (!c || n < 0 || (n && !idx)) return VO_E_INVALID;
     for (int i = 0; i < n; ++i) if (idx[i] < 0 || idx[i] >= c->p.map_capacity) return VO_E_INVALID;

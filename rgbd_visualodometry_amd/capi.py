@@ -1,9 +1,8 @@
 """ctypes binding of the C-ABI in include/vo_hip.h.
 
 The product library is ``rgbd_visualodometry_amd/csrc/libvo_hip.so`` (HIP, gfx950).  There is
-no CPU fallback: ``load()`` raises if that library is missing.  Tests and bench.py's
-``cpu_baseline`` leg load the oracle (``oracle/_build/liboracle_vo.so``) through the very same
-binding by passing its path explicitly -- both libraries export identical symbols.
+no CPU fallback: ``load()`` raises if that library is missing.  ``load(path)`` binds any other
+implementation of the same C-ABI (the test suite passes its CPU checker's path).
 """
 from __future__ import annotations
 
@@ -16,7 +15,6 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 HIP_LIB = os.path.join(HERE, "csrc", "libvo_hip.so")
-ORACLE_LIB = os.path.join(ROOT, "oracle", "_build", "liboracle_vo.so")
 SYNTH_LIB = os.path.join(HERE, "synth", "libvo_synth.so")
 
 
@@ -62,7 +60,7 @@ MATCH_DTYPE = np.dtype([("map_index", "<i4"), ("kp_index", "<i4"), ("distance", 
 # every symbol include/vo_hip.h declares
 SYMBOLS = ["vo_ctx_create", "vo_ctx_destroy", "vo_strerror", "vo_backend_name", "vo_default_params",
            "vo_default_track_params", "vo_frame_upload", "vo_frame_bind_device", "vo_orb_detect_describe",
-           "vo_orb_fetch", "vo_orb_level_size", "vo_orb_fetch_level", "vo_map_upsert", "vo_map_set_active",
+           "vo_orb_fetch", "vo_orb_level_size", "vo_orb_fetch_level", "vo_orb_fetch_blur_level", "vo_map_upsert", "vo_map_set_active",
            "vo_match_active_map", "vo_matches_set", "vo_pnp_ransac", "vo_pose_refine_lm", "vo_track_frame", "vo_track_batch", "vo_track_fetch_matches",
            "vo_local_ba", "vo_sync", "vo_profile_enable", "vo_profile_read"]
 
@@ -100,6 +98,7 @@ class VoLib:
         L.vo_orb_fetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.vo_orb_level_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.vo_orb_fetch_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.vo_orb_fetch_blur_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.vo_map_upsert.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int]
         L.vo_map_set_active.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.vo_match_active_map.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_int,
@@ -194,6 +193,12 @@ class VoContext:
         w, h, _ = self.level_size(level)
         out = np.zeros((h, w), dtype=np.uint8)
         self.L.check(self.L.lib.vo_orb_fetch_level(self.h, slot, level, _ptr(out)), "vo_orb_fetch_level")
+        return out
+
+    def fetch_blur_level(self, slot: int, level: int) -> np.ndarray:
+        w, h, _ = self.level_size(level)
+        out = np.zeros((h, w), dtype=np.uint8)
+        self.L.check(self.L.lib.vo_orb_fetch_blur_level(self.h, slot, level, _ptr(out)), "vo_orb_fetch_blur_level")
         return out
 
     # map ------------------------------------------------------------------------------

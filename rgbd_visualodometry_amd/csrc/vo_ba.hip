@@ -1162,10 +1162,15 @@ __global__ void k_ba_cull(BaCam cam, BaDev B, int stage, double th) {
     else if (B.active[e]) { if (c2 > th) B.flags[e] |= 2; else atomicAdd(&B.scal[6], c2); }
 }
 
+// per-device function attributes (vo_ctx_create calls this with the context's device current)
+int vo_ba_set_attrs() {
+    HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol16, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol16g, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+    return VO_OK;
+}
+
 int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     hipStream_t st = c->stream;
-    { static bool attr = false; if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol16, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-      HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol16g, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)); attr = true; } }
     const int np = in->n_poses, nf = in->n_free, nx = in->n_points, ne = in->n_edges, D = 6 * nf;
     if ((CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D) * sizeof(double) > 158 * 1024) return VO_E_UNSUPPORTED;     // D > ~1060 (176 free poses)
     out->lm_iters = 0; out->chi2_initial = 0; out->chi2_final = 0;

@@ -12,6 +12,7 @@
 
 int vo_orb_upload_constants();
 int vo_track_set_attrs();
+int vo_ba_set_attrs();
 
 static inline short sat_short(long v) { return (short)std::min(32767L, std::max(-32768L, v)); }
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
@@ -122,20 +123,35 @@ static std::vector<vo_ctx*> g_ctxs;
 static bool g_prof_on = false;
 static std::vector<std::string> g_prof_names; static std::vector<double> g_prof_ms; static std::vector<int64_t> g_prof_calls;
 
-void vo_prof_begin(vo_ctx* c, const char* name) {
+// Records are appended by the context's owning thread (under the context's prof_mu) and drained by whichever thread
+// reads the table; a record whose end event has not been recorded yet stays in the list.
+int vo_prof_begin(vo_ctx* c, const char* name) {
+    std::unique_lock<std::mutex> lk(c->prof_mu);
     ProfRec r; r.name = name;
     auto get = [&]() { hipEvent_t e; if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
     r.a = get(); r.b = get();
     (void)hipEventRecord(r.a, c->stream);
     c->prof.push_back(r);
+    c->prof_open = r;
+    return (int)(++c->prof_ticket & 0x3FFFFFFF);
 }
-void vo_prof_end(vo_ctx* c) { (void)hipEventRecord(c->prof.back().b, c->stream); }
+void vo_prof_end(vo_ctx* c, int ticket) {
+    std::unique_lock<std::mutex> lk(c->prof_mu);
+    if (ticket != (int)(c->prof_ticket & 0x3FFFFFFF)) return;      // not the innermost open record any more (cannot happen: scopes do not nest)
+    (void)hipEventRecord(c->prof_open.b, c->stream);
+    c->prof_closed = c->prof_ticket;
+}
 
 static void prof_collect(vo_ctx* c) {      // caller holds g_prof_mu
+    std::unique_lock<std::mutex> lk(c->prof_mu);
     if (c->prof.empty()) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    for (auto& r : c->prof) {
+    const bool open_tail = c->prof_closed != c->prof_ticket;       // the newest record still waits for its end event
+    const size_t n = c->prof.size() - (open_tail ? 1 : 0);
+    if (n == 0) return;
+    (void)hipEventSynchronize(c->prof[n - 1].b);
+    for (size_t k = 0; k < n; ++k) {
+        const ProfRec& r = c->prof[k];
         float ms = 0;
         (void)hipEventElapsedTime(&ms, r.a, r.b);
         size_t i = 0;
@@ -144,7 +160,7 @@ static void prof_collect(vo_ctx* c) {      // caller holds g_prof_mu
         g_prof_ms[i] += ms; g_prof_calls[i] += 1;
         c->ev_pool.push_back(r.a); c->ev_pool.push_back(r.b);
     }
-    c->prof.clear();
+    c->prof.erase(c->prof.begin(), c->prof.begin() + n);
 }
 
 template <typename T>
@@ -218,7 +234,7 @@ int vo_ctx_create(const vo_params* p, int device, vo_ctx** out) {
     HIP_TRY(hipSetDevice(device));
     vo_ctx* c = new (std::nothrow) vo_ctx();
     if (!c) return VO_E_NOMEM;
-    c->p = *p; c->device = device; c->stream = nullptr; c->prof_on = false; c->corr_external = false;
+    c->p = *p; c->device = device; c->stream = nullptr; c->prof_on.store(false); c->corr_external = false;
     c->d_slots = nullptr; c->d_pyr = nullptr; c->d_blur = nullptr; c->d_tab = nullptr; c->d_tabs = nullptr; c->d_cand = nullptr; c->d_cand_cnt = nullptr;
     c->d_sel = nullptr; c->d_sel_key = nullptr; c->d_sel_cnt = nullptr; c->d_kps = nullptr; c->d_desc = nullptr; c->d_nkp = nullptr; c->d_status = nullptr;
     c->d_map_pos = nullptr; c->d_map_nrm = nullptr; c->d_map_desc = nullptr; c->d_map_flags = nullptr; c->d_active = nullptr; c->n_active = 0; c->active_cap = 0;
@@ -241,6 +257,8 @@ int vo_ctx_create(const vo_params* p, int device, vo_ctx** out) {
     rc = vo_orb_upload_constants();
     if (rc) { vo_ctx_destroy(c); return rc; }
     rc = vo_track_set_attrs();
+    if (rc) { vo_ctx_destroy(c); return rc; }
+    rc = vo_ba_set_attrs();
     if (rc) { vo_ctx_destroy(c); return rc; }
     const DevPlan& P = c->plan;
     const int F = p->max_frames;
@@ -278,7 +296,7 @@ int vo_ctx_create(const vo_params* p, int device, vo_ctx** out) {
     HIP_TRY(hipMemsetAsync(c->d_map_flags, 0, M, st));
     HIP_TRY(hipMemsetAsync(c->d_track, 0, sizeof(TrackDev) * NL, st));
     HIP_TRY(hipStreamSynchronize(st));
-    { std::unique_lock<std::mutex> lk(g_prof_mu); g_ctxs.push_back(c); c->prof_on = g_prof_on; }
+    { std::unique_lock<std::mutex> lk(g_prof_mu); g_ctxs.push_back(c); c->prof_on.store(g_prof_on); }
     *out = c;
     return VO_OK;
 }
@@ -391,6 +409,16 @@ int vo_orb_fetch_level(vo_ctx* c, int slot, int l, uint8_t* out) {
     const DevPlan& P = c->plan;
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy2D(out, P.lw[l], c->d_pyr + (size_t)slot * P.pyr_stride + P.loff[l], P.pitch[l], P.lw[l], P.lh[l], hipMemcpyDeviceToHost));
+    return VO_OK;
+}
+
+int vo_orb_fetch_blur_level(vo_ctx* c, int slot, int l, uint8_t* out) {
+    if (!c || slot < 0 || slot >= c->p.max_frames || l < 0 || l >= c->plan.L || !out) return VO_E_INVALID;
+    if (!c->slot_orb[slot]) return VO_E_STATE;
+    HIP_TRY(hipSetDevice(c->device));
+    const DevPlan& P = c->plan;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy2D(out, P.lw[l], c->d_blur + (size_t)slot * P.pyr_stride + P.loff[l], P.pitch[l], P.lw[l], P.lh[l], hipMemcpyDeviceToHost));
     return VO_OK;
 }
 
@@ -646,7 +674,7 @@ int vo_sync(vo_ctx* c) {
 int vo_profile_enable(vo_ctx* c, int on) {
     if (!c) return VO_E_INVALID;
     std::unique_lock<std::mutex> lk(g_prof_mu);
-    for (vo_ctx* x : g_ctxs) { prof_collect(x); x->prof_on = on != 0; }
+    for (vo_ctx* x : g_ctxs) { prof_collect(x); x->prof_on.store(on != 0); }
     g_prof_on = on != 0;
     if (on) { g_prof_names.clear(); g_prof_ms.clear(); g_prof_calls.clear(); }
     return VO_OK;

@@ -3,7 +3,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -97,14 +99,15 @@ struct vo_ctx {
     // BA scratch
     void* d_ba; size_t d_ba_bytes;
     // profiling
-    bool prof_on; std::vector<ProfRec> prof; std::vector<hipEvent_t> ev_pool;
-    std::vector<std::string> prof_names; std::vector<double> prof_ms; std::vector<int64_t> prof_calls;
+    std::atomic<bool> prof_on; std::mutex prof_mu; std::vector<ProfRec> prof; std::vector<hipEvent_t> ev_pool;      // prof / ev_pool: under prof_mu
+    ProfRec prof_open; uint64_t prof_ticket = 0, prof_closed = 0;
 };
 
 // profiling helpers (vo_capi.hip)
-void vo_prof_begin(vo_ctx* c, const char* name);
-void vo_prof_end(vo_ctx* c);
-struct ProfScope { vo_ctx* c; ProfScope(vo_ctx* c_, const char* n) : c(c_) { if (c->prof_on) vo_prof_begin(c, n); } ~ProfScope() { if (c->prof_on) vo_prof_end(c); } };
+int vo_prof_begin(vo_ctx* c, const char* name);     // returns a ticket for vo_prof_end (-1: not recorded)
+void vo_prof_end(vo_ctx* c, int ticket);
+// the flag is latched at construction: a toggle from another thread between begin and end cannot unbalance the records
+struct ProfScope { vo_ctx* c; int idx; ProfScope(vo_ctx* c_, const char* n) : c(c_), idx(c_->prof_on.load(std::memory_order_relaxed) ? vo_prof_begin(c_, n) : -1) {} ~ProfScope() { if (idx >= 0) vo_prof_end(c, idx); } };
 void* vo_stage(vo_ctx* c, size_t bytes);           // pinned host staging buffer of at least `bytes`
 int vo_scratch(vo_ctx* c, size_t bytes);           // grow the device scratch slab c->d_ba to at least `bytes`
 int vo_map_scatter_launch(vo_ctx* c, int n, const int32_t* d_idx, const double* d_xyz, const double* d_nrm, const uint32_t* d_desc, const uint8_t* d_flags);

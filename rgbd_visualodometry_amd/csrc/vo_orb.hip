@@ -21,7 +21,9 @@
 #include "vo_internal.h"
 
 
-__constant__ int8_t c_pattern[256 * 4];
+// rBRIEF test pattern: statically initialised, so every device of the process gets its copy with the code object
+// (a run-time upload guarded by a process-wide flag left the second GPU of a process with zeros)
+__constant__ int8_t c_pattern[256][4] = VO_BRIEF_PATTERN_INIT;
 
 // ------------------------------------------------------------------------------------------
 // 16 pixels per lane: 3 x 16-byte loads of BGR, one 16-byte store of gray (the row pitches are multiples of 16 for the
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(256) void k_describe(DevPlan P, const SlotDesc* __r
     uint64_t bits[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int8_t* q = &c_pattern[(r * 64 + lane) * 4];
+        const int8_t* q = c_pattern[r * 64 + lane];
         const int x1 = __double2int_rn((double)q[0] * cs - (double)q[1] * sn), y1 = __double2int_rn((double)q[0] * sn + (double)q[1] * cs);
         const int x2 = __double2int_rn((double)q[2] * cs - (double)q[3] * sn), y2 = __double2int_rn((double)q[2] * sn + (double)q[3] * cs);
         const bool b = ctr[y1 * pitch + x1] < ctr[y2 * pitch + x2];
@@ -471,12 +473,9 @@ __global__ __launch_bounds__(256) void k_describe(DevPlan P, const SlotDesc* __r
 }
 
 // ------------------------------------------------------------------------------------------
+// per-device function attributes: called from vo_ctx_create with the context's device current (cheap, idempotent)
 int vo_orb_upload_constants() {
-    static bool done = false;
-    if (done) return VO_OK;
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), VO_BRIEF_PATTERN, sizeof(c_pattern)));
     HIP_TRY(hipFuncSetAttribute((const void*)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
-    done = true;
     return VO_OK;
 }
 

@@ -24,15 +24,19 @@ public:
     Backend(const Camera::Ptr camera);
     ~Backend();
     void SetContext(vo_ctx* ctx, int device);        // tracker's context (used when lag == 0)
-    void SetLag(int frames) { lag_ = frames < 0 ? 0 : frames; }
+    void SetLag(int frames) { lag_ = frames < 0 ? 0 : frames; if (ctx_ && lag_ > 0) EnsureWorker(); }
     void Stop();                                     // finish the pending job, join the worker
+    void Flush() { if (job_) Finish(); }             // wait for the pending job and merge it now (end of a sequence / of a timed region)
     void OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr);
     // tracker thread, once per frame before tracking: merge a finished/overdue job; true if the map changed
     bool Poll(size_t frameIndex);
     // frame index at which the pending job will be merged (SIZE_MAX: none pending)
     size_t NextMergeFrame() const { return job_ ? job_->frameIndex + (size_t)lag_ : (size_t)-1; }
-    struct Stats { int runs = 0, poses = 0, fixed = 0, points = 0, edges = 0, outliers = 0; double ms = 0, ms_build = 0, ms_solve = 0, ms_wait = 0; };
+    struct Stats { int runs = 0, poses = 0, fixed = 0, points = 0, edges = 0, outliers = 0, failed = 0, capped = 0; double ms = 0, ms_build = 0, ms_solve = 0, ms_wait = 0; };
     const Stats& GetStats() const { return stats_; }
+    // the flattened graph of a keyframe, for inspection (parity tests): what Solve would be handed
+    struct GraphView { std::vector<size_t> poseIds; int nFree = 0; std::vector<size_t> pointIds; std::vector<int32_t> edgePose, edgePoint; std::vector<float> edgeUv; };
+    GraphView DescribeGraph(const Frame::Ptr& keyframe);
 private:
     struct Job {
         std::vector<Frame*> poseFrames; int nFree = 0;          // keyframes and map points are never removed from the map:
@@ -58,6 +62,8 @@ private:
     void Apply(Job& j);
     void Finish();                  // wait for the pending job and merge it
     void WorkerLoop();
+    void EnsureWorker();            // the worker's context, stream and thread exist before the first keyframe (no one-time setup inside a timed run)
+    int maxFree_ = 160;             // free-pose cap of one solve: the Cholesky of the reduced system is LDS resident (vo_local_ba: D = 6 n_free <= ~1050)
 };
 }  // namespace myslam
 #endif

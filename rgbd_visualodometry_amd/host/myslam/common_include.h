@@ -7,6 +7,7 @@
 #define MYSLAM_COMMON_INCLUDE_H
 
 #include <array>
+#include <atomic>
 #include <cassert>
 #include <cmath>
 #include <cstdint>

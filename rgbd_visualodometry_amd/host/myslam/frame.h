@@ -49,6 +49,7 @@ public:
     void BeginCovisibilityBatch() { covisBatch_ = true; }
     void EndCovisibilityBatch();
     std::unordered_set<size_t> GetCovisibleKeyframes() { std::unique_lock<std::mutex> lck(obsLock_); return covis_.strong; }
+    CovisibleKeyframeIdToWeight GetCovisibleKeyframeWeights() { std::unique_lock<std::mutex> lck(obsLock_); return covis_.count; }     // allCovisibleKeyframeIdToWeight_ (frame.h:94)
 
     int slot_ = -1;                 // vo_ctx frame slot holding this frame's ORB results (-1: none)
     uint64_t baStamp_ = 0; int baIndex_ = -1;    // scratch of Backend::Build
@@ -69,7 +70,7 @@ private:
             return w;
         }
     };
-    static size_t nextId_;
+    static std::atomic<size_t> nextId_;
     size_t id_;
     std::mutex poseLock_;
     SE3 pose_cw_;                                           // world -> camera

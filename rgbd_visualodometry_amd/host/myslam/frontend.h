@@ -24,6 +24,8 @@ public:
     void SetViewer(const Viewer::Ptr viewer) { viewer_ = viewer; }
     void SetBackend(const Backend::Ptr backend) { backend_ = backend; if (backend_) backend_->SetContext(ctx_, device_); }
     VOState GetState() const { return state_; }
+    // the two per-frame decisions on explicit inputs (parity tests): bit0 IsGoodEstimation, bit1 IsKeyframe
+    int PolicyFlags(const SE3& T_ref_cw, const SE3& T_cur_cw, int numInliers);
 
     // Look-ahead: upload (or bind) and run batched ORB for upcoming frames of this stream.
     // Frames of one stream depend on each other only from matching onwards, so detection and

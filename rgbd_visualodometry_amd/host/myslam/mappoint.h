@@ -47,7 +47,7 @@ public:
     void MarkDirty();
 
 private:
-    static size_t nextId_;
+    static std::atomic<size_t> nextId_;
     size_t id_;
     Vector3d norm_;
     std::mutex posLock_;

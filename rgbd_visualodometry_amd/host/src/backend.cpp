@@ -16,11 +16,24 @@ static double ms_since(std::chrono::steady_clock::time_point t0) { return std::c
 Backend::Backend(const Camera::Ptr camera) : camera_(camera) {
     chi2Threshold_ = Config::has("chi2_th") ? Config::get<float>("chi2_th") : 1.0f;       // backend.h:24
     if (Config::has("backend_lag_frames")) lag_ = std::max(0, Config::get<int>("backend_lag_frames"));
+    if (Config::has("ba_max_free_keyframes")) maxFree_ = std::max(1, Config::get<int>("ba_max_free_keyframes"));
 }
 
 Backend::~Backend() { Stop(); if (ctxOwn_) vo_ctx_destroy(ctxOwn_); }
 
-void Backend::SetContext(vo_ctx* ctx, int device) { ctx_ = ctx; device_ = device; }
+void Backend::SetContext(vo_ctx* ctx, int device) { ctx_ = ctx; device_ = device; if (ctx_ && lag_ > 0) EnsureWorker(); }
+
+void Backend::EnsureWorker() {
+    if (!ctxOwn_) {                                  // small private context: BA needs scratch + a stream only
+        vo_params p; vo_default_params(&p);
+        p.fx = camera_->GetFx(); p.fy = camera_->GetFy(); p.cx = camera_->GetCx(); p.cy = camera_->GetCy();
+        p.n_features = 64; p.max_frames = 1; p.map_capacity = 64; p.max_hypotheses = 1;
+        p.stream_priority = 1;                          // BA is the latency-critical chain beside tracking
+        int rc = vo_ctx_create(&p, device_, &ctxOwn_);
+        if (rc != VO_OK) throw std::runtime_error(std::string("vo_ctx_create (backend) failed: ") + vo_strerror(rc));
+    }
+    if (!worker_.joinable()) worker_ = std::thread(&Backend::WorkerLoop, this);
+}
 
 void Backend::Stop() {
     if (job_) Finish();
@@ -57,7 +70,10 @@ void Backend::Finish() {
     if (lag_ > 0) { std::unique_lock<std::mutex> lk(mu_); cv_.wait(lk, [&] { return job_->done; }); }
     stats_.ms_wait += ms_since(t0);
     std::unique_ptr<Job> j = std::move(job_);
-    if (j->rc != VO_OK) throw std::runtime_error(std::string("vo_local_ba failed: ") + vo_strerror(j->rc));
+    if (j->rc != VO_OK) {                            // a failed solve must not end the stream: the map keeps its un-optimised state
+        if (stats_.failed++ == 0) std::cerr << "[myslam] vo_local_ba failed (" << vo_strerror(j->rc) << "): this local BA is skipped, tracking continues" << std::endl;
+        return;
+    }
     Apply(*j);
 }
 
@@ -73,15 +89,7 @@ void Backend::OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr) {
     job_ = std::move(j);
     if (lag_ == 0) { Solve(*job_, ctx_); job_->done = true; Finish(); }
     else {
-        if (!ctxOwn_) {                              // small private context: BA needs scratch + a stream only
-            vo_params p; vo_default_params(&p);
-            p.fx = camera_->GetFx(); p.fy = camera_->GetFy(); p.cx = camera_->GetCx(); p.cy = camera_->GetCy();
-            p.n_features = 64; p.max_frames = 1; p.map_capacity = 64; p.max_hypotheses = 1;
-            p.stream_priority = 1;                      // BA is the latency-critical chain beside tracking
-            int rc = vo_ctx_create(&p, device_, &ctxOwn_);
-            if (rc != VO_OK) throw std::runtime_error(std::string("vo_ctx_create (backend) failed: ") + vo_strerror(rc));
-        }
-        if (!worker_.joinable()) worker_ = std::thread(&Backend::WorkerLoop, this);
+        EnsureWorker();
         { std::unique_lock<std::mutex> lk(mu_); hasWork_ = true; }
         cv_.notify_all();
     }
@@ -95,8 +103,14 @@ void Backend::Build(Job& j, const Frame::Ptr& kf) {
     MapManager& map = MapManager::GetInstance();
     const uint64_t stamp = ++buildStamp_;            // index scratch lives in the frames / map points: no hash maps
     auto covis = kf->GetCovisibleKeyframes();
-    covis.insert(kf->GetId());
     std::vector<size_t> freeIds(covis.begin(), covis.end());
+    if ((int)freeIds.size() + 1 > maxFree_) {        // more covisible keyframes than one solve takes: the strongest stay free, the others
+        auto w = kf->GetCovisibleKeyframeWeights();  // still constrain the points they observe, as fixed poses (edge loop below)
+        std::sort(freeIds.begin(), freeIds.end(), [&](size_t a, size_t b) { const int wa = w[a], wb = w[b]; return wa != wb ? wa > wb : a > b; });
+        freeIds.resize((size_t)maxFree_ - 1);
+        ++stats_.capped;
+    }
+    freeIds.push_back(kf->GetId());
     std::sort(freeIds.begin(), freeIds.end());
     for (size_t id : freeIds) {
         auto f = map.GetKeyframe(id);
@@ -148,6 +162,17 @@ void Backend::Build(Job& j, const Frame::Ptr& kf) {
     for (size_t p = 0; p < j.poseFrames.size(); ++p) j.poseFrames[p]->GetPose().to12(&j.poses[12 * p]);
     for (size_t k = 0; k < j.points.size(); ++k) { const Vector3d& x = j.points[k]->PositionUnlocked(); j.pts[3 * k] = x[0]; j.pts[3 * k + 1] = x[1]; j.pts[3 * k + 2] = x[2]; }
     j.posesOut.resize(12 * (size_t)std::max(j.nFree, 1)); j.ptsOut.resize(3 * std::max<size_t>(j.points.size(), 1)); j.flags.resize(std::max<size_t>(j.edgePose.size(), 1));
+}
+
+Backend::GraphView Backend::DescribeGraph(const Frame::Ptr& kf) {
+    Job j;
+    Build(j, kf);
+    GraphView g;
+    for (Frame* f : j.poseFrames) g.poseIds.push_back(f->GetId());
+    g.nFree = j.nFree;
+    for (Mappoint* mp : j.points) g.pointIds.push_back(mp->GetId());
+    g.edgePose = j.edgePose; g.edgePoint = j.edgePoint; g.edgeUv = j.edgeUv;
+    return g;
 }
 
 void Backend::Solve(Job& j, vo_ctx* ctx) {

@@ -4,10 +4,10 @@
 #include "myslam/mapmanager.h"
 
 namespace myslam {
-size_t Frame::nextId_ = 0;
+std::atomic<size_t> Frame::nextId_{0};         // shared by every VO system of the process: ids stay unique across threads
 
 Frame::Ptr Frame::CreateFrame(const double timestamp, const Camera::Ptr camera, const Mat color, const Mat depth) {
-    return Frame::Ptr(new Frame(++nextId_, timestamp, camera, color.clone(3), depth.clone(2)));
+    return Frame::Ptr(new Frame(nextId_.fetch_add(1) + 1, timestamp, camera, color.clone(3), depth.clone(2)));
 }
 
 Frame::Frame(const size_t id, const double timestamp, const Camera::Ptr camera, const Mat color, const Mat depth)

@@ -308,6 +308,18 @@ bool FrontEnd::IsKeyframe() {
     return rot > keyFrameMinRot_ || trans > keyFrameMinTrans_;                      // frontend.cpp:359
 }
 
+int FrontEnd::PolicyFlags(const SE3& T_ref_cw, const SE3& T_cur_cw, int numInliers) {
+    Frame::Ptr ref = Frame::CreateFrame(0, nullptr, Mat(), Mat()), cur = Frame::CreateFrame(0, nullptr, Mat(), Mat());
+    ref->SetPose(T_ref_cw); cur->SetPose(T_cur_cw);
+    std::swap(framePrev_, ref); std::swap(frameCurr_, cur);
+    const int keepInl = numInliers_, keepSince = framesSinceKf_; const double keepMotion = lastMotion_;
+    numInliers_ = numInliers;
+    const int flags = (IsGoodEstimation() ? 1 : 0) | (IsKeyframe() ? 2 : 0);
+    numInliers_ = keepInl; framesSinceKf_ = keepSince; lastMotion_ = keepMotion;
+    std::swap(framePrev_, ref); std::swap(frameCurr_, cur);
+    return flags;
+}
+
 void FrontEnd::AddCurrentKeyframeObservations() {
     // reference iterates an unordered_set (frontend.cpp:366-370); active-list (= id) order here, for determinism
     frameCurr_->BeginCovisibilityBatch();

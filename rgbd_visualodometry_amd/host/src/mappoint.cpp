@@ -4,10 +4,10 @@
 #include "myslam/mapmanager.h"
 
 namespace myslam {
-size_t Mappoint::nextId_ = 0;
+std::atomic<size_t> Mappoint::nextId_{0};      // shared by every VO system of the process: ids stay unique across threads
 
 Mappoint::Ptr Mappoint::CreateMappoint(const Vector3d position, const Descriptor& descriptor) {
-    return Mappoint::Ptr(new Mappoint(++nextId_, position, descriptor));
+    return Mappoint::Ptr(new Mappoint(nextId_.fetch_add(1) + 1, position, descriptor));
 }
 
 Mappoint::Mappoint(const size_t id, const Vector3d position, const Descriptor& descriptor)

@@ -123,6 +123,129 @@ int myslam_add_frame(myslam_system* s, double stamp, const void* bgr, const void
     });
 }
 
+int myslam_flush(myslam_system* s) {
+    if (!s) return -1;
+    return guarded(s, [&]() { if (s->backend) s->backend->Flush(); });
+}
+
+// ---- taps for parity tests (see include/myslam_c.h) ----------------------------------------------------------------
+int myslam_triangulate(int n, const double* T_cw, const double* pts, double out_xyz[3], int* ok) {
+    if (n < 1 || !T_cw || !pts || !out_xyz || !ok) return -1;
+    std::vector<SE3> poses; std::vector<Vec3> points;
+    for (int i = 0; i < n; ++i) { poses.push_back(SE3::from12(T_cw + 12 * i)); points.push_back(Vec3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2])); }
+    Vec3 p = Vec3::Zero();
+    *ok = Triangulation(poses, points, p) ? 1 : 0;
+    out_xyz[0] = p[0]; out_xyz[1] = p[1]; out_xyz[2] = p[2];
+    return 0;
+}
+int myslam_se3_log(const double T[12], double out6[6]) { if (!T || !out6) return -1; Vector6d d = SE3::from12(T).log(); for (int i = 0; i < 6; ++i) out6[i] = d[i]; return 0; }
+int myslam_se3_exp(const double d6[6], double T_out[12]) { if (!d6 || !T_out) return -1; Vector6d d; for (int i = 0; i < 6; ++i) d[i] = d6[i]; SE3::exp(d).to12(T_out); return 0; }
+
+int myslam_keyframe_policy(myslam_system* s, const double T_ref[12], const double T_cur[12], int num_inliers, int* flags) {
+    if (!s || !T_ref || !T_cur || !flags) return -1;
+    return guarded(s, [&]() { *flags = s->frontend->PolicyFlags(SE3::from12(T_ref), SE3::from12(T_cur), num_inliers); });
+}
+
+namespace {
+Frame::Ptr scn_keyframe(myslam_system* s, int64_t id) {
+    Frame::Ptr f = s->map.GetKeyframe((size_t)id);
+    if (!f) throw std::runtime_error("no such keyframe");
+    return f;
+}
+}  // namespace
+
+int myslam_scn_add_keyframe(myslam_system* s, const double T_cw[12], int64_t* id_out) {
+    if (!s || !T_cw || !id_out) return -1;
+    return guarded(s, [&]() {
+        Image c, d; c.rows = d.rows = s->opt.height; c.cols = d.cols = s->opt.width;
+        Frame::Ptr f = Frame::CreateFrame(0.0, s->camera, c, d);
+        f->SetPose(SE3::from12(T_cw));
+        s->map.InsertKeyframe(f);
+        *id_out = (int64_t)f->GetId();
+    });
+}
+int myslam_scn_add_mappoint(myslam_system* s, const double xyz[3], int64_t* id_out) {
+    if (!s || !xyz || !id_out) return -1;
+    return guarded(s, [&]() {
+        Descriptor d; d.fill(0);
+        Mappoint::Ptr mp = Mappoint::CreateMappoint(Vector3d(xyz[0], xyz[1], xyz[2]), d);
+        s->map.InsertMappoint(mp);
+        *id_out = (int64_t)mp->GetId();
+    });
+}
+int myslam_scn_observe(myslam_system* s, int64_t kf, int64_t mp, float u, float v) {
+    if (!s) return -1;
+    return guarded(s, [&]() { scn_keyframe(s, kf)->AddObservedMappoint((size_t)mp, Point2f(u, v)); });
+}
+int myslam_scn_unobserve(myslam_system* s, int64_t kf, int64_t mp) {
+    if (!s) return -1;
+    return guarded(s, [&]() { scn_keyframe(s, kf)->RemoveObservedMappoint((size_t)mp); });
+}
+int myslam_scn_covisibility(myslam_system* s, int64_t kf, int64_t* ids, int32_t* weights, uint8_t* active, int cap, int* n) {
+    if (!s || !n) return -1;
+    return guarded(s, [&]() {
+        Frame::Ptr f = scn_keyframe(s, kf);
+        auto w = f->GetCovisibleKeyframeWeights();
+        auto act = f->GetCovisibleKeyframes();
+        std::map<size_t, int> ordered(w.begin(), w.end());
+        int k = 0;
+        for (auto& e : ordered) { if (k < cap) { if (ids) ids[k] = (int64_t)e.first; if (weights) weights[k] = e.second; if (active) active[k] = act.count(e.first) ? 1 : 0; } ++k; }
+        for (size_t id : act) if (!w.count(id)) throw std::runtime_error("active covisible keyframe without a weight");
+        *n = k;
+    });
+}
+int myslam_scn_local_map(myslam_system* s, int64_t kf, int64_t* mp_ids, int cap, int* n) {
+    if (!s || !n) return -1;
+    return guarded(s, [&]() {
+        Frame::Ptr f = scn_keyframe(s, kf);
+        std::vector<Mappoint*> v = s->map.CollectMappointsAroundKeyframe(f);
+        auto dict = s->map.GetMappointsAroundKeyframe(f);              // the reference-shaped container must hold the same set
+        if (dict.size() != v.size()) throw std::runtime_error("local map: vector and dictionary forms differ");
+        for (Mappoint* mp : v) if (!dict.count(mp->GetId())) throw std::runtime_error("local map: vector and dictionary forms differ");
+        for (size_t i = 0; i < v.size() && (int)i < cap; ++i) if (mp_ids) mp_ids[i] = (int64_t)v[i]->GetId();
+        *n = (int)v.size();
+    });
+}
+int myslam_scn_ba_graph(myslam_system* s, int64_t kf, int64_t* pose_ids, int cap_poses, int* n_poses, int* n_free, int64_t* point_ids, int cap_points,
+                        int* n_points, int32_t* edge_pose, int32_t* edge_point, float* edge_uv, int cap_edges, int* n_edges) {
+    if (!s || !n_poses || !n_free || !n_points || !n_edges) return -1;
+    return guarded(s, [&]() {
+        if (!s->backend) throw std::runtime_error("local optimisation is disabled for this system");
+        Backend::GraphView g = s->backend->DescribeGraph(scn_keyframe(s, kf));
+        *n_poses = (int)g.poseIds.size(); *n_free = g.nFree; *n_points = (int)g.pointIds.size(); *n_edges = (int)g.edgePose.size();
+        for (size_t i = 0; i < g.poseIds.size() && (int)i < cap_poses; ++i) if (pose_ids) pose_ids[i] = (int64_t)g.poseIds[i];
+        for (size_t i = 0; i < g.pointIds.size() && (int)i < cap_points; ++i) if (point_ids) point_ids[i] = (int64_t)g.pointIds[i];
+        for (size_t e = 0; e < g.edgePose.size() && (int)e < cap_edges; ++e) {
+            if (edge_pose) edge_pose[e] = g.edgePose[e];
+            if (edge_point) edge_point[e] = g.edgePoint[e];
+            if (edge_uv) { edge_uv[2 * e] = g.edgeUv[2 * e]; edge_uv[2 * e + 1] = g.edgeUv[2 * e + 1]; }
+        }
+    });
+}
+int myslam_scn_mappoint(myslam_system* s, int64_t id, int* outlier, int* n_obs, double xyz[3], double normal[3]) {
+    if (!s) return -1;
+    return guarded(s, [&]() {
+        Mappoint::Ptr mp = s->map.GetMappoint((size_t)id);
+        if (!mp) throw std::runtime_error("no such map point");
+        if (outlier) *outlier = mp->outlier_ ? 1 : 0;
+        if (n_obs) *n_obs = (int)mp->GetObservedByKeyframesMap().size();
+        Vector3d p = mp->GetPosition(), nr = mp->GetNormDirection();
+        for (int a = 0; a < 3; ++a) { if (xyz) xyz[a] = p[a]; if (normal) normal[a] = nr[a]; }
+    });
+}
+int myslam_scn_run_ba(myslam_system* s, int64_t kf) {
+    if (!s) return -1;
+    return guarded(s, [&]() {
+        if (!s->backend) throw std::runtime_error("local optimisation is disabled for this system");
+        s->backend->OptimizeCovisibleGraphOfKeyframe(scn_keyframe(s, kf));
+        s->backend->Flush();
+    });
+}
+int myslam_scn_keyframe_pose(myslam_system* s, int64_t kf, double T_cw[12]) {
+    if (!s || !T_cw) return -1;
+    return guarded(s, [&]() { scn_keyframe(s, kf)->GetPose().to12(T_cw); });
+}
+
 void* myslam_get_context(myslam_system* s) { return s ? (void*)s->frontend->GetContext() : nullptr; }
 
 int myslam_get_stats(myslam_system* s, myslam_stats* st) {

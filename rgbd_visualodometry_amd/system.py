@@ -3,7 +3,7 @@
 ``VoSystem`` = one independent RGB-D stream: Camera + FrontEnd + Backend + map, i.e. what the
 reference's ``app/run_vo.cpp:73-117`` sets up and loops over.  The product library is
 ``rgbd_visualodometry_amd/host/libmyslam_amd.so`` (links the HIP C-ABI library); there is no CPU
-fallback.  Tests / the CPU baseline pass the oracle library path explicitly.
+fallback.  A different implementation of include/myslam_c.h is bound by passing its path.
 """
 from __future__ import annotations
 
@@ -16,7 +16,6 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 HOST_LIB = os.path.join(HERE, "host", "libmyslam_amd.so")
-ORACLE_LIB = os.path.join(ROOT, "oracle", "_build", "liboracle_vo.so")
 
 
 class Options(C.Structure):
@@ -42,7 +41,11 @@ class Stats(C.Structure):
 
 
 SYMBOLS = ["myslam_default_options", "myslam_system_create", "myslam_system_destroy", "myslam_prefetch",
-           "myslam_add_frame", "myslam_add_prefetched", "myslam_get_stats", "myslam_get_context", "myslam_last_error", "myslam_backend_name"]
+           "myslam_add_frame", "myslam_add_prefetched", "myslam_get_stats", "myslam_flush", "myslam_get_context", "myslam_last_error", "myslam_backend_name",
+           # taps for parity tests (include/myslam_c.h)
+           "myslam_triangulate", "myslam_se3_log", "myslam_se3_exp", "myslam_keyframe_policy", "myslam_scn_add_keyframe", "myslam_scn_add_mappoint",
+           "myslam_scn_observe", "myslam_scn_unobserve", "myslam_scn_covisibility", "myslam_scn_local_map", "myslam_scn_ba_graph", "myslam_scn_mappoint",
+           "myslam_scn_run_ba", "myslam_scn_keyframe_pose"]
 
 _libs = {}
 
@@ -63,10 +66,48 @@ def _load(path: str):
         lib.myslam_add_frame.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p]
         lib.myslam_add_prefetched.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
         lib.myslam_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        lib.myslam_flush.argtypes = [C.c_void_p]
+        lib.myslam_triangulate.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        lib.myslam_se3_log.argtypes = [C.c_void_p, C.c_void_p]
+        lib.myslam_se3_exp.argtypes = [C.c_void_p, C.c_void_p]
+        lib.myslam_keyframe_policy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        lib.myslam_scn_add_keyframe.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+        lib.myslam_scn_add_mappoint.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+        lib.myslam_scn_observe.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_float]
+        lib.myslam_scn_unobserve.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+        lib.myslam_scn_covisibility.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        lib.myslam_scn_local_map.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        lib.myslam_scn_ba_graph.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_int,
+                                            C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        lib.myslam_scn_mappoint.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
+        lib.myslam_scn_run_ba.argtypes = [C.c_void_p, C.c_int64]
+        lib.myslam_scn_keyframe_pose.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         lib.myslam_get_context.argtypes = [C.c_void_p]
         lib.myslam_get_context.restype = C.c_void_p
         _libs[path] = lib
     return _libs[path]
+
+
+def triangulate(lib_path: Optional[str], T_cw: np.ndarray, pts: np.ndarray):
+    """Triangulation tap (reference include/myslam/util.h:16-34) -> (xyz, ok)."""
+    lib = _load(lib_path or HOST_LIB)
+    T = np.ascontiguousarray(T_cw, dtype=np.float64).reshape(-1, 12); p = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
+    out = np.zeros(3); ok = C.c_int()
+    if lib.myslam_triangulate(len(T), T.ctypes.data, p.ctypes.data, out.ctypes.data, C.byref(ok)) != 0:
+        raise RuntimeError("myslam_triangulate failed")
+    return out, bool(ok.value)
+
+
+def se3_log(lib_path: Optional[str], T12) -> np.ndarray:
+    lib = _load(lib_path or HOST_LIB); T = np.ascontiguousarray(T12, dtype=np.float64).reshape(12); d = np.zeros(6)
+    lib.myslam_se3_log(T.ctypes.data, d.ctypes.data)
+    return d
+
+
+def se3_exp(lib_path: Optional[str], d6) -> np.ndarray:
+    lib = _load(lib_path or HOST_LIB); d = np.ascontiguousarray(d6, dtype=np.float64).reshape(6); T = np.zeros(12)
+    lib.myslam_se3_exp(d.ctypes.data, T.ctypes.data)
+    return T
 
 
 class VoSystem:
@@ -130,6 +171,63 @@ class VoSystem:
         T = np.zeros(12)
         self._check(self.lib.myslam_add_prefetched(self.h, C.byref(ok), T.ctypes.data), "myslam_add_prefetched")
         return bool(ok.value), T
+
+    def flush(self):
+        """Wait for a pending overlapped local BA and merge it (Backend::Flush)."""
+        self._check(self.lib.myslam_flush(self.h), "myslam_flush")
+
+    # ---- taps for parity tests (include/myslam_c.h): hand-built scenarios, not the product path --------------------
+    def scn_add_keyframe(self, T_cw) -> int:
+        T = np.ascontiguousarray(T_cw, dtype=np.float64).reshape(12); out = C.c_int64()
+        self._check(self.lib.myslam_scn_add_keyframe(self.h, T.ctypes.data, C.byref(out)), "myslam_scn_add_keyframe")
+        return out.value
+
+    def scn_add_mappoint(self, xyz) -> int:
+        p = np.ascontiguousarray(xyz, dtype=np.float64).reshape(3); out = C.c_int64()
+        self._check(self.lib.myslam_scn_add_mappoint(self.h, p.ctypes.data, C.byref(out)), "myslam_scn_add_mappoint")
+        return out.value
+
+    def scn_observe(self, kf: int, mp: int, u: float, v: float):
+        self._check(self.lib.myslam_scn_observe(self.h, kf, mp, u, v), "myslam_scn_observe")
+
+    def scn_unobserve(self, kf: int, mp: int):
+        self._check(self.lib.myslam_scn_unobserve(self.h, kf, mp), "myslam_scn_unobserve")
+
+    def scn_covisibility(self, kf: int, cap: int = 4096):
+        ids = np.zeros(cap, np.int64); w = np.zeros(cap, np.int32); a = np.zeros(cap, np.uint8); n = C.c_int()
+        self._check(self.lib.myslam_scn_covisibility(self.h, kf, ids.ctypes.data, w.ctypes.data, a.ctypes.data, cap, C.byref(n)), "myslam_scn_covisibility")
+        return {int(ids[i]): (int(w[i]), bool(a[i])) for i in range(n.value)}
+
+    def scn_local_map(self, kf: int, cap: int = 1 << 16):
+        ids = np.zeros(cap, np.int64); n = C.c_int()
+        self._check(self.lib.myslam_scn_local_map(self.h, kf, ids.ctypes.data, cap, C.byref(n)), "myslam_scn_local_map")
+        return [int(v) for v in ids[:n.value]]
+
+    def scn_ba_graph(self, kf: int, cap: int = 1 << 16):
+        pid = np.zeros(cap, np.int64); xid = np.zeros(cap, np.int64); ep = np.zeros(cap, np.int32); el = np.zeros(cap, np.int32)
+        uv = np.zeros((cap, 2), np.float32); npz, nf, nx, ne = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self._check(self.lib.myslam_scn_ba_graph(self.h, kf, pid.ctypes.data, cap, C.byref(npz), C.byref(nf), xid.ctypes.data, cap, C.byref(nx),
+                                                 ep.ctypes.data, el.ctypes.data, uv.ctypes.data, cap, C.byref(ne)), "myslam_scn_ba_graph")
+        return {"pose_ids": [int(v) for v in pid[:npz.value]], "n_free": nf.value, "point_ids": [int(v) for v in xid[:nx.value]],
+                "edge_pose": ep[:ne.value].copy(), "edge_point": el[:ne.value].copy(), "edge_uv": uv[:ne.value].copy()}
+
+    def scn_mappoint(self, mp: int):
+        o, n = C.c_int(), C.c_int(); p = np.zeros(3); nr = np.zeros(3)
+        self._check(self.lib.myslam_scn_mappoint(self.h, mp, C.byref(o), C.byref(n), p.ctypes.data, nr.ctypes.data), "myslam_scn_mappoint")
+        return {"outlier": bool(o.value), "n_obs": n.value, "xyz": p, "normal": nr}
+
+    def scn_run_ba(self, kf: int):
+        self._check(self.lib.myslam_scn_run_ba(self.h, kf), "myslam_scn_run_ba")
+
+    def scn_keyframe_pose(self, kf: int) -> np.ndarray:
+        T = np.zeros(12)
+        self._check(self.lib.myslam_scn_keyframe_pose(self.h, kf, T.ctypes.data), "myslam_scn_keyframe_pose")
+        return T
+
+    def keyframe_policy(self, T_ref_cw, T_cur_cw, num_inliers: int) -> int:
+        a = np.ascontiguousarray(T_ref_cw, dtype=np.float64).reshape(12); b = np.ascontiguousarray(T_cur_cw, dtype=np.float64).reshape(12); f = C.c_int()
+        self._check(self.lib.myslam_keyframe_policy(self.h, a.ctypes.data, b.ctypes.data, num_inliers, C.byref(f)), "myslam_keyframe_policy")
+        return f.value
 
     def context_handle(self) -> int:
         return self.lib.myslam_get_context(self.h)

@@ -5,6 +5,7 @@ import re
 
 import pytest
 
+from oracle import ORACLE_LIB
 from rgbd_visualodometry_amd import capi, system
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,7 +22,7 @@ def test_header_symbol_lists_are_complete():
     assert declared("myslam_c.h", "myslam_") == sorted(system.SYMBOLS)
 
 
-@pytest.mark.parametrize("path", [capi.HIP_LIB, capi.ORACLE_LIB])
+@pytest.mark.parametrize("path", [capi.HIP_LIB, ORACLE_LIB])
 def test_vo_abi_exports(path):
     L = capi.load(path)                     # raises if the library or any declared symbol is missing
     assert L.backend in ("hip-gfx950", "cpu-oracle")
@@ -31,7 +32,7 @@ def test_vo_abi_exports(path):
     assert t.n_hyp == 100 and abs(t.huber_delta ** 2 - 7.815) < 1e-12 and t.passes == 2
 
 
-@pytest.mark.parametrize("path", [system.HOST_LIB, system.ORACLE_LIB])
+@pytest.mark.parametrize("path", [system.HOST_LIB, ORACLE_LIB])
 def test_host_abi_exports(path):
     lib = system._load(path)
     assert lib.myslam_backend_name().decode() in ("hip-gfx950", "cpu-oracle")

@@ -4,6 +4,7 @@ reductions, f64 atomics: different summation order) agree to the tolerance writt
 import numpy as np
 import pytest
 
+from oracle import ORACLE_LIB
 from rgbd_visualodometry_amd import capi
 
 pytestmark = pytest.mark.gpu
@@ -27,7 +28,7 @@ def frames():
 
 @pytest.fixture(scope="module")
 def libs():
-    return capi.load(capi.HIP_LIB), capi.load(capi.ORACLE_LIB)
+    return capi.load(capi.HIP_LIB), capi.load(ORACLE_LIB)
 
 
 def make_ctx(L, **kw):
@@ -291,7 +292,7 @@ def test_vo_system_gpu_matches_oracle_trajectory(frames):
             i += k
         return np.array(poses), s.stats()
 
-    po, so = run(system.ORACLE_LIB)
+    po, so = run(ORACLE_LIB)
     ph, sh = run(system.HOST_LIB, max_frames_in_flight=5, track_batch=4)
     assert so["keyframes"] == sh["keyframes"] and so["map_points"] == sh["map_points"]
     np.testing.assert_allclose(ph, po, atol=1e-7)
@@ -324,7 +325,7 @@ def test_vo_system_config5_sizes_gpu_matches_oracle():
             i += k
         return np.array(poses), s.stats()
 
-    po, so = run(system.ORACLE_LIB)
+    po, so = run(ORACLE_LIB)
     ph, sh = run(system.HOST_LIB, max_frames_in_flight=5, track_batch=4)
     assert so["keyframes"] == sh["keyframes"] >= 2 and so["map_points"] == sh["map_points"] and so["lost"] == sh["lost"] == 0
     assert so["ba_runs"] == sh["ba_runs"] >= 1 and so["ba_edges"] == sh["ba_edges"]

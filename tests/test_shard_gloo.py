@@ -10,9 +10,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = r'''
 import json, os, sys
 sys.path.insert(0, %r)
+from oracle import ORACLE_LIB
 from rgbd_visualodometry_amd import shard, system
 g = shard.Group("gloo")
-res = shard.track_stream(system.ORACLE_LIB, shard.stream_seed(40, g.rank), 8, features=300, local_ba=False)
+res = shard.track_stream(ORACLE_LIB, shard.stream_seed(40, g.rank), 8, features=300, local_ba=False)
 g.barrier()
 mx = g.max_scalar(res["elapsed_s"])
 allr = g.gather_objects({"rank": g.rank, "seed": res["seed"], "frames": res["frames"], "elapsed": res["elapsed_s"],
