@@ -4,21 +4,26 @@
 One "step" = one frame through FrontEnd::AddFrame (ORB detect+describe, map match, P3P-RANSAC,
 pose LM, keyframe work incl. local BA) on the HIP path.  Workload at N=1 is BASELINE.json
 configs[1]: a single synthetic 640x480 stream, 2000 ORB features, default.yaml parameters
-otherwise.  For N>1 every rank tracks its own independent stream (configs[3]): weak scaling,
-no data-path collective (frames of one stream are sequentially dependent).
+otherwise, camera motion as SURVEY.md 8d prescribes (<= 2 cm and ~0.6 deg per frame: a keyframe
+every 3-4 frames; --speed 1 is round 1's slow-turn variant with a keyframe every ~10 frames).
+For N>1 every rank tracks its own independent stream (configs[3]): weak scaling, no data-path
+collective (frames of one stream are sequentially dependent).
 
 Inputs are rendered on the host before the timed region and are resident in HBM (torch tensors)
-when it starts.  ORB of up to --lookahead future frames of the stream runs as one batched launch
-chain (detection does not depend on earlier poses); matching/PnP/LM/BA run frame by frame.
+when it starts.  The timed region ends after the last frame's pending local BA has been solved
+and merged (Backend::Flush) and the device is idle.
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel, live HIP-event
-timing on the kernel's own stream) and `cpu_baseline` (the CPU oracle port, timed on rank 0 at
-N=1 on a bounded sample of the same frames).
+timing on the kernels' own streams), `cpu_baseline` (the CPU oracle port on the host cores, rank 0
+at N=1 only, bounded sample), `latency_mode` (causal single-frame figure: no look-ahead, no
+speculative batch, synchronous BA) and `multi_stream` (several streams on this GPU).
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -26,8 +31,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-F64_MFMA_PEAK_TFLOPS = 78.6 # MI355X FP64 matrix peak (AMD datasheet; the guide lists the f32 MFMA figure only)
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+F64_PEAK_TFLOPS = 78.6       # MI355X FP64 vector = FP64 matrix peak (AMD datasheet; the guide lists the f32 MFMA figure only)
 
 
 def level_sizes(W, H, L=8, sf=1.2):
@@ -38,27 +43,56 @@ def level_sizes(W, H, L=8, sf=1.2):
     return out
 
 
-def algorithmic_bytes(W, H, N, M, K, n_hyp, passes=2):
-    """Per-frame algorithmic bytes by kernel (SURVEY.md 8d decomposition)."""
+def algorithmic_bytes(W, H, N, A, M, K, I, n_hyp, passes=2):
+    """Per-frame algorithmic bytes by kernel (SURVEY.md 8d decomposition).  A active map points, M visible candidates,
+    K gated matches, I RANSAC inliers (averages over the tracked frames)."""
     lv = level_sizes(W, H)
     P = sum(w * h for w, h in lv)
     b = {
         "k_gray": 3 * W * H + W * H,                              # BGR in, level 0 out
+        "k_pyramid": sum(lv[l - 1][0] * lv[l - 1][1] + lv[l][0] * lv[l][1] for l in range(1, len(lv))),
         "k_resize": sum(lv[l - 1][0] * lv[l - 1][1] + lv[l][0] * lv[l][1] for l in range(1, len(lv))),
         "k_fast_nms": P,                                          # every pyramid pixel read once
         "k_select": 81 * 2 * N + 8 * 2 * N,                       # 9x9 Harris windows of the 2N survivors + list traffic
         "k_blur": 2 * P,                                          # level pyramid in, blurred pyramid out
         "k_describe": (709 + 512) * N + 32 * N + 64 * N,          # IC disc (709 px) + 512 BRIEF samples, kp in/out + descriptor
+        "k_frustum": passes * (53 * A + 4 * M),                   # position + normal + flag + index in, candidate list out
         "k_match": passes * (32 * M + 32 * N + 8 * M),
-        "k_match_gate": passes * (8 * M + 36 * K),
+        "k_match_gate": passes * (4 * A + 4 * K),
+        "k_match_emit": passes * (36 * K + 36 * K),
         "k_ransac_hyp": passes * (20 * 4 * n_hyp + 96 * n_hyp),
         "k_ransac_score": passes * (20 * K + 4 * n_hyp),
-        "k_ransac_select": passes * (20 * K + 4 * K),
-        "k_pose_lm": passes * (20 * K),
-        "depth": 2 * W * H * 0 + 2 * 5 * N,                       # depth samples at keypoints
+        "k_ransac_select": passes * (20 * K + 4 * I),
+        "k_pose_lm": passes * (20 * I),
     }
     total_survey = 5 * W * H + 4 * P + 2003 * N + 48 * N + (32 * M + 32 * N + 8 * M) + (20 * K + 4 * n_hyp)
     return b, total_survey, P
+
+
+def drive(sysm, stamps, bptr, dptr, i0, i1, lookahead, W, est=None):
+    i = i0
+    while i < i1:
+        n = min(lookahead, i1 - i)
+        sysm.prefetch(stamps[i:i + n], bptr[i:i + n], dptr[i:i + n], 3 * W, 2 * W, True)
+        for j in range(n):
+            ok, T = sysm.add_prefetched()
+            if est is not None:
+                est[stamps[i + j]] = T
+        i += n
+
+
+def accuracy(ev, capi, stamps, Twc, est, i0, i1):
+    gt = {stamps[i]: capi.pose12_to_tum(Twc[i]) for i in range(i0, i1)}
+    e = {stamps[i]: capi.pose12_to_tum(est[stamps[i]]) for i in range(i0, i1) if stamps[i] in est}
+    out = {"ate_rmse_m": round(ev.ate(gt, e)["rmse"], 5)}
+    try:                                                    # RPE as tools/run_rpe.sh runs it: fixed delta 1 s
+        tg = {k: ev.pose_matrix([k] + list(v)) for k, v in gt.items()}
+        te = {k: ev.pose_matrix([k] + list(v)) for k, v in e.items()}
+        r = ev.rpe_summary(ev.rpe(tg, te, fixed_delta=True, delta=1.0, delta_unit="s"))
+        out["rpe_trans_rmse_m"] = round(r["trans_rmse"], 5); out["rpe_rot_rmse_deg"] = round(r["rot_deg_rmse"], 4)
+    except ValueError:
+        out["rpe_trans_rmse_m"] = None; out["rpe_rot_rmse_deg"] = None
+    return out
 
 
 def main():
@@ -70,13 +104,17 @@ def main():
     ap.add_argument("--lookahead", type=int, default=32, help="frames per batched ORB launch chain")
     ap.add_argument("--track-batch", type=int, default=8, help="frames tracked speculatively per launch chain (share prior + map)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--speed", type=float, default=3.0, help="camera speed factor of the synthetic trajectory: 3 = SURVEY 8d cadence (2 cm / 0.75 deg per frame, keyframe every 3-4 frames); 1 = round-1 slow turn")
     ap.add_argument("--no-ba", action="store_true", help="disable local BA (enable_local_optimization: 0)")
-    ap.add_argument("--ba-lag", type=int, default=8, help="0: BA synchronous in AddFrame; L>0: overlapped, merged L frames later (deterministic)")
+    ap.add_argument("--ba-lag", type=int, default=8, help="0: BA synchronous in AddFrame; L>0: overlapped, merged L frames later or at the next keyframe (deterministic)")
     ap.add_argument("--hyps", type=int, default=100, help="PnP-RANSAC hypotheses per pass (default.yaml: 100; BASELINE config 3: 2048)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the driver's runs) | gloo (rehearsal of the multi-rank path)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses device 0 (needs --dist-backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=330, help="bounded CPU-baseline sample (frames; ~14 s of CPU work at the default)")
+    ap.add_argument("--cpu-frames", type=int, default=150, help="bounded single-thread CPU-baseline sample (frames; ~20 s of CPU work at the default)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU baseline (0: min(host cpus, 64))")
+    ap.add_argument("--no-latency-mode", action="store_true")
+    ap.add_argument("--multi-streams", default="8", help="comma list of stream counts for the several-streams-per-GPU figure ('' = skip)")
     args = ap.parse_args()
 
     import torch
@@ -93,7 +131,7 @@ def main():
     K, Wm = args.steps, args.warmup
     total = K + Wm
     syn = capi.Synth()
-    sp = syn.params(seed=shard.stream_seed(args.seed, rank))
+    sp = syn.params(seed=shard.stream_seed(args.seed, rank), speed=args.speed)
     threads = max(1, (os.cpu_count() or 8) // max(1, world))
     t0 = time.time()
     bgr, depth, Twc, stamps = syn.render(sp, 0, total, threads=min(32, threads))
@@ -107,86 +145,76 @@ def main():
 
     opts = dict(width=W, height=H, number_of_features=N, max_frames_in_flight=args.lookahead, device=local_rank,
                 enable_local_optimization=0 if args.no_ba else 1, backend_lag_frames=args.ba_lag, track_batch=args.track_batch, map_capacity=1 << 20, ransac_iterations=args.hyps)
+
+    # One-time costs (code-object load, pinned staging, scratch growth) are paid on a throw-away system before the
+    # warmup: the driver's short runs (--warmup 5) then time the same steady state as the long ones.
+    pre = system.VoSystem(system.HOST_LIB, **opts)
+    assert pre.backend == "hip-gfx950", pre.backend
+    drive(pre, stamps, bptr, dptr, 0, min(total, 16), args.lookahead, W)
+    pre.flush(); pre.close()
+
     sysm = system.VoSystem(system.HOST_LIB, **opts)
-    assert sysm.backend == "hip-gfx950", sysm.backend
-
     est = {}
-
-    def drive(i0, i1):
-        i = i0
-        while i < i1:
-            n = min(args.lookahead, i1 - i)
-            sysm.prefetch(stamps[i:i + n], bptr[i:i + n], dptr[i:i + n], 3 * W, 2 * W, True)
-            for j in range(n):
-                ok, T = sysm.add_prefetched()
-                est[stamps[i + j]] = T
-            i += n
-
-    drive(0, Wm)                                            # warmup (also initialises the map)
+    drive(sysm, stamps, bptr, dptr, 0, Wm, args.lookahead, W, est)     # warmup (also initialises the map)
+    sysm.flush()
     torch.cuda.synchronize()
     grp.barrier()
     torch.cuda.synchronize()
+    st_w = sysm.stats()
     t0 = time.perf_counter()
-    drive(Wm, total)
+    drive(sysm, stamps, bptr, dptr, Wm, total, args.lookahead, W, est)
+    sysm.flush()                                            # the last keyframe's local BA is solved and merged inside the timed region
     torch.cuda.synchronize()
     grp.barrier()
     torch.cuda.synchronize()
     elapsed = grp.max_scalar(time.perf_counter() - t0)
     st = sysm.stats()
-
-    # accuracy of the timed run (every rank checks its own stream; rank 0 reports)
-    gt = {stamps[i]: capi.pose12_to_tum(Twc[i]) for i in range(total)}
-    est_t = {k: capi.pose12_to_tum(v) for k, v in est.items()}
-    ate_gpu = ev.ate(gt, est_t)["rmse"]
+    acc = accuracy(ev, capi, stamps, Twc, est, 0, total)     # every rank checks its own stream; rank 0 reports
 
     out = None
     if rank == 0:
         fps = shard.aggregate_fps(K, world, elapsed)
+        L = capi.load(capi.HIP_LIB)
         # ---- roofline of the dominant kernel -------------------------------------------------------
         # Second pass over the SAME frames (warmup + steps) on a fresh system with per-kernel HIP-event timing
         # enabled on every context stream (tracker + overlapped back-end); not part of `value`.
         prof_sys = system.VoSystem(system.HOST_LIB, **opts)
-        L = capi.load(capi.HIP_LIB)
-        import ctypes as C
         h = C.c_void_p(prof_sys.context_handle())
         L.check(L.lib.vo_profile_enable(h, 1))
-        i = 0
-        while i < total:
-            n = min(args.lookahead, total - i)
-            prof_sys.prefetch(stamps[i:i + n], bptr[i:i + n], dptr[i:i + n], 3 * W, 2 * W, True)
-            for _ in range(n):
-                prof_sys.add_prefetched()
-            i += n
+        drive(prof_sys, stamps, bptr, dptr, 0, total, args.lookahead, W)
+        prof_sys.flush()
         pst = prof_sys.stats()
-        prof_sys.close()                                   # joins the back-end worker; its context is merged on destroy
-        sysm_ctx = C.c_void_p(sysm.context_handle())
-        names = (C.c_char * 48 * 64)()
-        ms = np.zeros(64)
-        calls = np.zeros(64, dtype=np.int64)
-        nn = C.c_int()
-        L.check(L.lib.vo_profile_read(sysm_ctx, C.cast(names, C.c_void_p), ms.ctypes.data, calls.ctypes.data, 64, C.byref(nn)))
-        L.check(L.lib.vo_profile_enable(sysm_ctx, 0))
+        names = (C.c_char * 48 * 96)()
+        ms = np.zeros(96); calls = np.zeros(96, dtype=np.int64); nn = C.c_int()
+        L.check(L.lib.vo_profile_read(h, C.cast(names, C.c_void_p), ms.ctypes.data, calls.ctypes.data, 96, C.byref(nn)))
+        L.check(L.lib.vo_profile_enable(h, 0))
+        prof_sys.close()
         kern = {names[j].value.decode(): (float(ms[j]), int(calls[j])) for j in range(nn.value)}
-        frames_prof = total
-        M = max(1, pst["last_candidates"]); Kc = max(1, pst["last_matches"])
-        per_frame, b_survey, P = algorithmic_bytes(W, H, N, M, Kc, args.hyps)
+        tf = max(1, pst["tracked_frames"])
+        A, M, Kc, I = (pst[k] / tf for k in ("sum_active", "sum_candidates", "sum_matches", "sum_ransac_inliers"))
+        per_frame, b_survey, P = algorithmic_bytes(W, H, N, A, M, Kc, I, args.hyps)
         table = {}
         for name, (tms, c) in kern.items():
             if c == 0:
                 continue
             row = {"total_ms": round(tms, 3), "launches": c, "avg_us": round(tms / c * 1e3, 2)}
             if name in per_frame:
-                bytes_total = per_frame[name] * frames_prof
+                frames_k = total if name in ("k_gray", "k_pyramid", "k_resize", "k_fast_nms", "k_select", "k_blur", "k_describe") else tf
+                bytes_total = per_frame[name] * frames_k
                 row["alg_bytes_per_launch"] = int(bytes_total / c)
                 row["GBps"] = round(bytes_total / (tms * 1e-3) / 1e9, 2)
             table[name] = row
-        # BA Cholesky: algorithmic flops = sum over BA runs of (D^3/3 + 2 D^2) multiply-adds x trials per run
+        if "k_pose_lm" in table:                            # ~120 f64 operations per edge and pass; passes = LM iterations + 2 initial + 2 cull sweeps per launch
+            fl = 120.0 * I * (pst["sum_lm_iters"] + 4.0 * 2 * tf)
+            table["k_pose_lm"]["f64_valu_frac"] = round(fl / (table["k_pose_lm"]["total_ms"] * 1e-3) / (F64_PEAK_TFLOPS * 1e12), 6)
+            table["k_pose_lm"]["limiter"] = "latency: one workgroup per frame runs ~20 dependent f64 passes (edge loop, 28-value reduction, 6x6 solve)"
         runs = max(1, pst["ba_runs"])
-        if "k_ba_chol" in table:
-            trials = table["k_ba_chol"]["launches"] / runs
-            flops = sum(2.0 * ((6.0 * (k + 2)) ** 3 / 3.0 + 2.0 * (6.0 * (k + 2)) ** 2) for k in range(runs)) * trials
+        if "k_ba_chol" in table:                            # (D^3/3 + 2 D^2) multiply-adds per factorisation + solve, D = 6 free poses
+            D = 6.0 * max(1, pst["ba_poses"])
+            flops = 2.0 * (D ** 3 / 3.0 + 2.0 * D ** 2) * table["k_ba_chol"]["launches"]
             table["k_ba_chol"]["alg_flops_per_launch"] = int(flops / table["k_ba_chol"]["launches"])
             table["k_ba_chol"]["TFLOPps"] = round(flops / (table["k_ba_chol"]["total_ms"] * 1e-3) / 1e12, 5)
+            table["k_ba_chol"]["limiter"] = "latency: one workgroup, panel-by-panel dependent chain (D = %d)" % int(D)
         roof = None
         if table:
             dom = max(table, key=lambda k: table[k]["total_ms"])
@@ -195,52 +223,139 @@ def main():
                 roof = {"bound": "hbm", "kernel": dom, "achieved": t["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(t["GBps"] / HBM_PEAK_GBS, 6), "traffic": None}
             elif "TFLOPps" in t:
-                roof = {"bound": "mfma", "kernel": dom, "achieved": t["TFLOPps"], "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(t["TFLOPps"] / F64_MFMA_PEAK_TFLOPS, 6), "traffic": None}
+                roof = {"bound": "mfma", "kernel": dom, "achieved": t["TFLOPps"], "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(t["TFLOPps"] / F64_PEAK_TFLOPS, 6), "traffic": None}
             else:
                 roof = {"bound": "hbm", "kernel": dom, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
-            # HBM traffic of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run inside
-            # this process); null when no measurement for this kernel is on file
+            # HBM traffic per launch from this round's PMC passes (rocprofv3 cannot run inside this process): only a file of
+            # the current round that covers this kernel is used, otherwise null
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")))
                 roof["traffic"] = pmc["kernels"][dom]["hbm_bytes_per_launch_corrected"]
-                roof["traffic_source"] = "profiles/r01_pmc_hbm_traffic.json (FETCH_SIZE, WRITE_SIZE: separate --pmc passes, (2*FETCH+WRITE)*1024)"
+                roof["traffic_source"] = "profiles/r02_pmc_hbm_traffic.json (FETCH_SIZE, WRITE_SIZE: separate --pmc passes of `%s`)" % pmc.get("command", "bench.py")
             except Exception:
                 pass
-            roof.update({"avg_launch_us": t["avg_us"], "launches": t["launches"],
-                         "note": "single 640x480 stream: the chain is latency bound (small dependent kernels); see `kernels` for the streaming ORB kernels",
+            roof.update({"avg_launch_us": t["avg_us"], "launches": t["launches"], "limiter": t.get("limiter", "HBM / L2 streaming"),
+                         "note": "a single 640x480 stream keeps ~1 % of the chip busy: its per-frame chain is a sequence of small dependent kernels; "
+                                 "the streaming ORB kernels and the several-streams figure (multi_stream) are the roofline-relevant ones",
                          "kernels": table})
-        # ---- CPU baseline: the oracle port on host cores, bounded sample ---------------------------
+
+        # ---- causal single-frame figure ---------------------------------------------------------------
+        lat = None
+        if not args.no_latency_mode and world == 1:
+            nl = min(total, 150)
+            lo = dict(opts, max_frames_in_flight=1, track_batch=1, backend_lag_frames=0)
+            s1 = system.VoSystem(system.HOST_LIB, **lo)
+            est_l = {}
+            per = []
+            for i in range(nl):
+                ta = time.perf_counter()
+                ok, T = s1.add_frame_device(stamps[i], bptr[i], dptr[i], 3 * W, 2 * W)
+                per.append(time.perf_counter() - ta)
+                est_l[stamps[i]] = T
+            s1.close()
+            body = np.array(per[min(10, nl // 2):])
+            lat = {"frames": int(len(body)), "frames_per_s": round(float(len(body) / body.sum()), 1), "ms_per_frame_mean": round(float(body.mean() * 1e3), 4),
+                   "ms_per_frame_median": round(float(np.median(body) * 1e3), 4), "ms_per_frame_p95": round(float(np.percentile(body, 95) * 1e3), 4),
+                   "config": "lookahead 1, track batch 1, local BA synchronous inside AddFrame (lag 0): every pose is final when AddFrame returns",
+                   **accuracy(ev, capi, stamps, Twc, est_l, 0, nl)}
+
+        # ---- several independent streams on this GPU (the roofline-relevant batched figure) ---------------
+        multi = None
+        if args.multi_streams and world == 1:
+            multi = []
+            for S in [int(v) for v in args.multi_streams.split(",") if v]:
+                nfr = min(total, 120)
+                syss = [system.VoSystem(system.HOST_LIB, **opts) for _ in range(S)]
+                bar = threading.Barrier(S + 1)
+
+                def run(s):
+                    drive(s, stamps, bptr, dptr, 0, 16, args.lookahead, W)
+                    bar.wait()
+                    drive(s, stamps, bptr, dptr, 16, nfr, args.lookahead, W)
+                    s.flush()
+                ths = [threading.Thread(target=run, args=(s,)) for s in syss]
+                for th in ths:
+                    th.start()
+                bar.wait()
+                tm = time.perf_counter()
+                for th in ths:
+                    th.join()
+                torch.cuda.synchronize()
+                tm = time.perf_counter() - tm
+                for s in syss:
+                    s.close()
+                f = S * (nfr - 16) / tm
+                multi.append({"streams_per_gpu": S, "frames_per_stream": nfr - 16, "frames_per_s": round(f, 1),
+                              "hbm_frac_whole_frame": round(b_survey * f / (HBM_PEAK_GBS * 1e9), 6)})
+
+        # ---- CPU baseline: the oracle port on host cores, bounded samples ----------------------------------
         cpu = None
         if not args.no_cpu_baseline and world == 1:
+            from oracle import ORACLE_LIB                   # the checker, timed as the CPU baseline (never on the product path)
+            copts = {**opts, "max_frames_in_flight": 1, "track_batch": 1, "backend_lag_frames": 0}
             nf = min(args.cpu_frames, total)
-            o = system.VoSystem(ORACLE_LIB, **{**opts, "max_frames_in_flight": 1, "track_batch": 1})
+            o = system.VoSystem(ORACLE_LIB, **copts)
             est_c = {}
             tc = time.perf_counter()
             for i in range(nf):
                 ok, T = o.add_frame(stamps[i], bgr[i], depth[i])
-                est_c[stamps[i]] = capi.pose12_to_tum(T)
+                est_c[stamps[i]] = T
             tc = time.perf_counter() - tc
-            gt_c = {stamps[i]: gt[stamps[i]] for i in range(nf)}
-            est_g = {stamps[i]: est_t[stamps[i]] for i in range(nf)}
-            cpu = {"value": round(nf / tc, 3), "unit": "frames/s", "cores": 1 if (args.ba_lag == 0 or args.no_ba) else 2, "kind": "port",
-                   "sample": "first %d frames of the same synthetic stream, single thread, oracle/_build/liboracle_vo.so" % nf,
-                   "ate_rmse_m": round(ev.ate(gt_c, est_c)["rmse"], 5), "gpu_ate_rmse_m_same_frames": round(ev.ate(gt_c, est_g)["rmse"], 5),
-                   "host_cpus": os.cpu_count()}
+            o.close()
+            acc_c = accuracy(ev, capi, stamps, Twc, est_c, 0, nf)
+            acc_g = accuracy(ev, capi, stamps, Twc, est, 0, nf) if nf <= total else {}
+            # all host cores: T independent streams, one per thread (the same frames), aggregate frames/s
+            T_all = args.cpu_threads or min(os.cpu_count() or 1, 64)
+            nfa = min(total, 24)
+            oo = [system.VoSystem(ORACLE_LIB, **copts) for _ in range(T_all)]
+
+            def crun(s):
+                for i in range(nfa):
+                    s.add_frame(stamps[i], bgr[i], depth[i])
+            ths = [threading.Thread(target=crun, args=(s,)) for s in oo]
+            ta = time.perf_counter()
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+            ta = time.perf_counter() - ta
+            for s in oo:
+                s.close()
+            cpu_model = ""
+            try:
+                cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+            except Exception:
+                pass
+            cpu = {"value": round(nf / tc, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+                   "sample": "first %d frames of the same synthetic stream, ONE thread (local BA synchronous), oracle/_build/liboracle_vo.so (-O3 -march=x86-64-v3)" % nf,
+                   "ate_rmse_m": acc_c["ate_rmse_m"], "gpu_ate_rmse_m_same_frames": acc_g.get("ate_rmse_m"),
+                   "rpe_trans_rmse_m": acc_c["rpe_trans_rmse_m"],
+                   "all_cores": {"value": round(T_all * nfa / ta, 2), "unit": "frames/s", "cores": T_all,
+                                 "sample": "%d independent streams (first %d frames each), one per thread" % (T_all, nfa)},
+                   "host_cpus": os.cpu_count(), "cpu_model": cpu_model}
+        kf_timed = st["keyframes"] - st_w["keyframes"]
         out = {
             "metric": "VO frames/sec (640x480 RGB-D)", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/f64", "data": "synthetic",
-            "config": {"workload": "synthetic 640x480 RGB-D stream per GPU, %d ORB features, default.yaml tracking parameters" % N,
-                       "streams_per_gpu": 1, "lookahead_frames": args.lookahead, "track_batch": args.track_batch, "local_ba": (False if args.no_ba else ("synchronous" if args.ba_lag == 0 else "overlapped, merged %d frames later" % args.ba_lag)), "ransac_hypotheses": args.hyps},
-            "ate_rmse_m": round(ate_gpu, 5), "keyframes": st["keyframes"], "lost": st["lost"], "map_points": st["map_points"],
+            "config": {"workload": "synthetic 640x480 RGB-D stream per GPU, %d ORB features, default.yaml tracking parameters, trajectory speed %.2g (keyframe every %.1f frames)"
+                                   % (N, args.speed, (K / kf_timed) if kf_timed else float("inf")),
+                       "streams_per_gpu": 1, "lookahead_frames": args.lookahead, "track_batch": args.track_batch,
+                       "local_ba": (False if args.no_ba else ("synchronous" if args.ba_lag == 0 else "overlapped, merged %d frames later or at the next keyframe" % args.ba_lag)),
+                       "ransac_hypotheses": args.hyps, "speed": args.speed},
+            **acc, "keyframes": st["keyframes"], "keyframes_timed": kf_timed, "ba_runs": st["ba_runs"], "ba_runs_timed": st["ba_runs"] - st_w["ba_runs"],
+            "lost": st["lost"], "map_points": st["map_points"],
             "alg_bytes_per_frame_survey": b_survey, "hbm_frac_whole_frame": round(b_survey * (fps / world) / (HBM_PEAK_GBS * 1e9), 6),
             "render_s": round(t_render, 2),
-            "host_stage_ms": {k: round(st[k], 2) for k in ("ms_extract", "ms_track", "ms_keyframe", "ms_backend")},
-            "ba": {k: st[k] for k in ("ba_runs", "ba_poses", "ba_fixed", "ba_points", "ba_edges", "ba_outliers")},
-            "roofline": roof, "cpu_baseline": cpu,
+            "host_stage_ms": {k: round(st[k] - st_w[k], 2) for k in ("ms_extract", "ms_track", "ms_keyframe", "ms_backend")},
+            "ba": {k: st[k] for k in ("ba_runs", "ba_poses", "ba_fixed", "ba_points", "ba_edges", "ba_outliers", "ba_failed", "ba_capped")},
+            "avg_per_tracked_frame": {"active_map_points": round(A, 1), "candidates": round(M, 1), "matches": round(Kc, 1), "ransac_inliers": round(I, 1),
+                                      "lm_iterations": round(pst["sum_lm_iters"] / tf, 2), "frames_per_launch_chain": round(tf / max(1, pst["track_launches"]), 2)},
+            "roofline": roof, "latency_mode": lat, "multi_stream": multi, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
+    sysm.close()
     grp.close()
 
 

@@ -41,6 +41,10 @@ typedef struct myslam_stats {
     int32_t ba_runs, ba_poses, ba_fixed, ba_points, ba_edges, ba_outliers;
     double ba_ms;
     double ms_extract, ms_track, ms_keyframe, ms_backend;   /* accumulated host wall time per stage */
+    /* sums over the frames that went through the tracking chain (the averages size the algorithmic bytes of a launch) */
+    int64_t tracked_frames, sum_active, sum_candidates, sum_matches, sum_ransac_inliers, sum_lm_inliers, sum_lm_iters;
+    int64_t track_launches;                                 /* vo_track_batch calls (launch chains) */
+    int32_t ba_failed, ba_capped;                           /* local BA runs skipped after a failed solve / solved with a capped free set */
 } myslam_stats;
 
 int myslam_default_options(myslam_options* o);

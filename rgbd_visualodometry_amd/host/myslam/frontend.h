@@ -34,7 +34,8 @@ public:
 
     vo_ctx* GetContext() const { return ctx_; }
     struct Stats { int frames = 0, keyframes = 0, lost = 0; int last_candidates = 0, last_matches = 0, last_ransac = 0, last_lm = 0, last_keypoints = 0;
-                   double ms_extract = 0, ms_track = 0, ms_keyframe = 0, ms_backend = 0, ms_refresh = 0, ms_flush = 0; };
+                   double ms_extract = 0, ms_track = 0, ms_keyframe = 0, ms_backend = 0, ms_refresh = 0, ms_flush = 0;
+                   long long tracked = 0, sum_active = 0, sum_cand = 0, sum_match = 0, sum_ransac = 0, sum_lm = 0, sum_lm_iters = 0, track_launches = 0; };
     const Stats& GetStats() const { return stats_; }
     bool verbose_ = false;
 

@@ -269,6 +269,7 @@ void FrontEnd::MatchAndEstimatePose() {
         std::vector<int> slots(nb); std::vector<uint64_t> seeds(nb); std::vector<vo_track_result> rs(nb);
         for (int j = 0; j < nb; ++j) { slots[j] = batch[j]->slot_; seeds[j] = 0x5eed5eedull + 2 * (uint64_t)(stats_.frames + j); }
         // match records are not copied back here: only keyframes (and the viewer) read them, through vo_track_fetch_matches
+        ++stats_.track_launches;
         { VO_SCOPE("fe.vo_track_batch"); vo_check(vo_track_batch(ctx_, nb, slots.data(), prior, &trackParams_, seeds.data(), rs.data(), nullptr, cap), "vo_track_batch"); }
         for (int j = 1; j < nb; ++j) {
             SpecResult sp; sp.frameId = batch[j]->GetId(); sp.epoch = epoch_; sp.res = rs[j]; sp.lane = j;
@@ -284,6 +285,8 @@ void FrontEnd::MatchAndEstimatePose() {
     frameCurr_->SetPose(SE3::from12(res.T_cw));                                     // frontend.cpp:312
     stats_.last_candidates = res.n_candidates; stats_.last_matches = res.n_matches;
     stats_.last_ransac = res.n_ransac_inliers; stats_.last_lm = res.n_lm_inliers;
+    ++stats_.tracked; stats_.sum_active += (long long)activeList_.size(); stats_.sum_cand += res.n_candidates; stats_.sum_match += res.n_matches;
+    stats_.sum_ransac += res.n_ransac_inliers; stats_.sum_lm += res.n_lm_inliers; stats_.sum_lm_iters += res.lm_iters;
     if (verbose_)
         std::cout << "  tracking map " << activeList_.size() << ", candidates " << res.n_candidates << ", matches " << res.n_matches
                   << ", PnP inliers " << res.n_ransac_inliers << ", LM inliers " << res.n_lm_inliers << std::endl;

@@ -256,10 +256,12 @@ int myslam_get_stats(myslam_system* s, myslam_stats* st) {
     st->last_keypoints = f.last_keypoints; st->last_candidates = f.last_candidates; st->last_matches = f.last_matches;
     st->ms_extract = f.ms_extract; st->ms_track = f.ms_track; st->ms_keyframe = f.ms_keyframe; st->ms_backend = f.ms_backend;
     if (getenv("VO_TRACE")) fprintf(stderr, "[vo_trace] frontend ms: extract %.1f track %.1f (refresh %.1f flush %.1f) keyframe %.1f backend %.1f\n", f.ms_extract, f.ms_track, f.ms_refresh, f.ms_flush, f.ms_keyframe, f.ms_backend);
+    st->tracked_frames = f.tracked; st->sum_active = f.sum_active; st->sum_candidates = f.sum_cand; st->sum_matches = f.sum_match; st->sum_ransac_inliers = f.sum_ransac;
+    st->sum_lm_inliers = f.sum_lm; st->sum_lm_iters = f.sum_lm_iters; st->track_launches = f.track_launches;
     st->last_ransac_inliers = f.last_ransac; st->last_lm_inliers = f.last_lm; st->map_points = (int)s->map.MappointCount();
     if (s->backend) {
         const auto& b = s->backend->GetStats();
-        st->ba_runs = b.runs; st->ba_poses = b.poses; st->ba_fixed = b.fixed; st->ba_points = b.points; st->ba_edges = b.edges; st->ba_outliers = b.outliers; st->ba_ms = b.ms;
+        st->ba_runs = b.runs; st->ba_poses = b.poses; st->ba_fixed = b.fixed; st->ba_points = b.points; st->ba_edges = b.edges; st->ba_outliers = b.outliers; st->ba_ms = b.ms; st->ba_failed = b.failed; st->ba_capped = b.capped;
         if (getenv("VO_TRACE")) fprintf(stderr, "[vo_trace] BA runs %d build %.2f ms solve %.2f ms wait %.2f ms\n", b.runs, b.ms_build, b.ms_solve, b.ms_wait);
     }
     if (myslam::TraceScope::on()) myslam::TraceScope::dump();

@@ -34,7 +34,10 @@ class Stats(C.Structure):
                 ("last_ransac_inliers", C.c_int32), ("last_lm_inliers", C.c_int32), ("map_points", C.c_int32),
                 ("ba_runs", C.c_int32), ("ba_poses", C.c_int32), ("ba_fixed", C.c_int32), ("ba_points", C.c_int32),
                 ("ba_edges", C.c_int32), ("ba_outliers", C.c_int32), ("ba_ms", C.c_double),
-                ("ms_extract", C.c_double), ("ms_track", C.c_double), ("ms_keyframe", C.c_double), ("ms_backend", C.c_double)]
+                ("ms_extract", C.c_double), ("ms_track", C.c_double), ("ms_keyframe", C.c_double), ("ms_backend", C.c_double),
+                ("tracked_frames", C.c_int64), ("sum_active", C.c_int64), ("sum_candidates", C.c_int64), ("sum_matches", C.c_int64),
+                ("sum_ransac_inliers", C.c_int64), ("sum_lm_inliers", C.c_int64), ("sum_lm_iters", C.c_int64), ("track_launches", C.c_int64),
+                ("ba_failed", C.c_int32), ("ba_capped", C.c_int32)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
