@@ -264,13 +264,19 @@ def main():
         multi = None
         if args.multi_streams and world == 1:
             multi = []
-            for S in [int(v) for v in args.multi_streams.split(",") if v]:
-                nfr = min(total, 120)
+            nfr = min(total, 136)
+
+            def run_streams(S, grouped):
+                grp_ = system.StreamGroup(system.HOST_LIB, local_rank, 128) if grouped else None
                 syss = [system.VoSystem(system.HOST_LIB, **opts) for _ in range(S)]
+                if grp_:
+                    for s in syss:
+                        grp_.join(s)
                 bar = threading.Barrier(S + 1)
 
                 def run(s):
                     drive(s, stamps, bptr, dptr, 0, 16, args.lookahead, W)
+                    s.flush()
                     bar.wait()
                     drive(s, stamps, bptr, dptr, 16, nfr, args.lookahead, W)
                     s.flush()
@@ -283,11 +289,22 @@ def main():
                     th.join()
                 torch.cuda.synchronize()
                 tm = time.perf_counter() - tm
+                gs = grp_.stats() if grp_ else None
                 for s in syss:
                     s.close()
-                f = S * (nfr - 16) / tm
-                multi.append({"streams_per_gpu": S, "frames_per_stream": nfr - 16, "frames_per_s": round(f, 1),
-                              "hbm_frac_whole_frame": round(b_survey * f / (HBM_PEAK_GBS * 1e9), 6)})
+                if grp_:
+                    grp_.close()
+                return S * (nfr - 16) / tm, gs
+
+            for S in [int(v) for v in args.multi_streams.split(",") if v]:
+                f_g, gs = run_streams(S, True)
+                f_s, _ = run_streams(S, False)
+                multi.append({"streams_per_gpu": S, "frames_per_stream": nfr - 16, "frames_per_s": round(f_g, 1),
+                              "hbm_frac_whole_frame": round(b_survey * f_g / (HBM_PEAK_GBS * 1e9), 6),
+                              "vs_single_stream": round(f_g / fps, 2), "lanes_per_launch_chain": round(gs["lanes"] / max(1, gs["chains"]), 2),
+                              "requests_per_launch_chain": round(gs["requests"] / max(1, gs["chains"]), 2),
+                              "frames_per_s_separate_contexts": round(f_s, 1),
+                              "mode": "one stream group: the members' tracking calls share launch chains (vo_group); ORB and local BA per stream on their own HIP streams"})
 
         # ---- CPU baseline: the oracle port on host cores, bounded samples ----------------------------------
         cpu = None

@@ -60,6 +60,13 @@ int myslam_add_frame(myslam_system* s, double stamp, const void* bgr, const void
                      int on_device, int* tracked, double T_wc[12]);
 int myslam_add_prefetched(myslam_system* s, int* tracked, double T_wc[12]);
 int myslam_get_stats(myslam_system* s, myslam_stats* st);
+/* Stream group: systems (independent streams) on the same GPU whose per-frame tracking shares launch chains (vo_group, include/vo_hip.h).
+ * Each member is still driven from its own host thread; trajectories are those of un-grouped systems. */
+typedef struct myslam_group myslam_group;
+int myslam_group_create(int device, int max_lanes, myslam_group** out);
+void myslam_group_destroy(myslam_group* g);                  /* after its members have been destroyed */
+int myslam_group_join(myslam_group* g, myslam_system* s);
+int myslam_group_stats(myslam_group* g, int64_t* chains, int64_t* lanes, int64_t* requests);
 /* Wait for a pending (overlapped) local BA and merge it now: end of a sequence, or of a timed region (Backend::Flush). */
 int myslam_flush(myslam_system* s);
 /* The vo_ctx (include/vo_hip.h) the system's FrontEnd owns, for profiling taps (vo_profile_*). */

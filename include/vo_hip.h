@@ -211,6 +211,22 @@ int vo_track_frame(vo_ctx* ctx, int slot, const double T_cw_prior[12], const vo_
 int vo_track_batch(vo_ctx* ctx, int n, const int* slots, const double T_cw_prior[12], const vo_track_params* tp,
                    const uint64_t* seeds, vo_track_result* res, vo_match* matches, int cap);
 
+/* ---- stream groups --------------------------------------------------------------------- */
+/* Several contexts = several independent RGB-D streams on ONE GPU.  Frames of different streams never depend on each
+ * other, so their tracking chains can share launches: after vo_group_join, a member's vo_track_batch (called from the
+ * member's own host thread, as before) is coalesced with the calls the other members have pending into ONE launch chain
+ * whose lanes carry their own map / frame / prior pointers.  Results are identical to un-grouped calls.  The reference
+ * has no counterpart (one process tracks one stream, app/run_vo.cpp:89-117); this is how BASELINE config 4's streams
+ * share a GPU when there are more streams than GPUs. */
+typedef struct vo_group vo_group;
+int vo_group_create(int device, int max_lanes, vo_group** out);        /* max_lanes: lanes of one fused chain (<= 128) */
+void vo_group_destroy(vo_group* g);                                    /* after every member has left or been destroyed */
+int vo_group_join(vo_group* g, vo_ctx* ctx);
+int vo_group_leave(vo_group* g, vo_ctx* ctx);
+/* A leader may wait up to timeout_us for min_requests pending requests before it launches (default: launch at once). */
+int vo_group_set_gather(vo_group* g, int min_requests, int timeout_us);
+int vo_group_stats(vo_group* g, int64_t* chains, int64_t* lanes, int64_t* requests);
+
 /* ---- local bundle adjustment --------------------------------------------------------- */
 int vo_local_ba(vo_ctx* ctx, const vo_ba_problem* in, vo_ba_result* out);
 

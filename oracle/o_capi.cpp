@@ -281,6 +281,16 @@ int vo_track_fetch_matches(vo_ctx* c, int lane, vo_match* matches, int cap, int*
     return VO_OK;
 }
 
+// Stream groups: on the CPU every call is computed on the spot; the group only counts (the fused launch chain is a property
+// of the HIP implementation, the results are defined to be those of un-grouped calls).
+struct vo_group { long long requests = 0; int members = 0; };
+int vo_group_create(int, int max_lanes, vo_group** out) { if (!out || max_lanes < 1 || max_lanes > 128) return VO_E_INVALID; *out = new (std::nothrow) vo_group(); return *out ? VO_OK : VO_E_NOMEM; }
+void vo_group_destroy(vo_group* g) { delete g; }
+int vo_group_join(vo_group* g, vo_ctx* c) { if (!g || !c) return VO_E_INVALID; ++g->members; return VO_OK; }
+int vo_group_leave(vo_group* g, vo_ctx* c) { if (!g || !c) return VO_E_INVALID; --g->members; return VO_OK; }
+int vo_group_set_gather(vo_group* g, int min_requests, int timeout_us) { return (!g || min_requests < 1 || timeout_us < 0) ? VO_E_INVALID : VO_OK; }
+int vo_group_stats(vo_group* g, int64_t* chains, int64_t* lanes, int64_t* requests) { if (!g) return VO_E_INVALID; if (chains) *chains = 0; if (lanes) *lanes = 0; if (requests) *requests = 0; return VO_OK; }
+
 int vo_local_ba(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     if (!c || !in || !out || !out->poses || !out->points || !out->edge_flags) return VO_E_INVALID;
     return local_ba(c->cam, *in, *out);

@@ -62,7 +62,8 @@ SYMBOLS = ["vo_ctx_create", "vo_ctx_destroy", "vo_strerror", "vo_backend_name", 
            "vo_default_track_params", "vo_frame_upload", "vo_frame_bind_device", "vo_orb_detect_describe",
            "vo_orb_fetch", "vo_orb_level_size", "vo_orb_fetch_level", "vo_orb_fetch_blur_level", "vo_map_upsert", "vo_map_set_active",
            "vo_match_active_map", "vo_matches_set", "vo_pnp_ransac", "vo_pose_refine_lm", "vo_track_frame", "vo_track_batch", "vo_track_fetch_matches",
-           "vo_local_ba", "vo_sync", "vo_profile_enable", "vo_profile_read"]
+           "vo_local_ba", "vo_sync", "vo_profile_enable", "vo_profile_read",
+           "vo_group_create", "vo_group_destroy", "vo_group_join", "vo_group_leave", "vo_group_set_gather", "vo_group_stats"]
 
 
 class VoError(RuntimeError):
@@ -88,7 +89,7 @@ class VoLib:
         L.vo_backend_name.restype = C.c_char_p
         L.vo_ctx_destroy.restype = None
         for name in SYMBOLS:
-            if name not in ("vo_strerror", "vo_backend_name", "vo_ctx_destroy"):
+            if name not in ("vo_strerror", "vo_backend_name", "vo_ctx_destroy", "vo_group_destroy"):
                 getattr(L, name).restype = C.c_int
         L.vo_ctx_create.argtypes = [C.POINTER(VoParams), C.c_int, C.POINTER(C.c_void_p)]
         L.vo_ctx_destroy.argtypes = [C.c_void_p]
@@ -114,6 +115,13 @@ class VoLib:
         L.vo_track_fetch_matches.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.vo_local_ba.argtypes = [C.c_void_p, C.POINTER(VoBaProblem), C.POINTER(VoBaResult)]
         L.vo_sync.argtypes = [C.c_void_p]
+        L.vo_group_destroy.restype = None
+        L.vo_group_create.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.vo_group_destroy.argtypes = [C.c_void_p]
+        L.vo_group_join.argtypes = [C.c_void_p, C.c_void_p]
+        L.vo_group_leave.argtypes = [C.c_void_p, C.c_void_p]
+        L.vo_group_set_gather.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.vo_group_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.vo_profile_enable.argtypes = [C.c_void_p, C.c_int]
         L.vo_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
 
@@ -141,6 +149,34 @@ class VoLib:
 
     def context(self, params: VoParams, device: int = 0) -> "VoContext":
         return VoContext(self, params, device)
+
+
+class VoGroup:
+    """Stream group (include/vo_hip.h): the vo_track_batch calls of its member contexts share launch chains."""
+
+    def __init__(self, lib: VoLib, device: int = 0, max_lanes: int = 64):
+        self.L = lib
+        self.h = C.c_void_p()
+        lib.check(lib.lib.vo_group_create(device, max_lanes, C.byref(self.h)), "vo_group_create")
+
+    def join(self, ctx: "VoContext"):
+        self.L.check(self.L.lib.vo_group_join(self.h, ctx.h), "vo_group_join")
+
+    def leave(self, ctx: "VoContext"):
+        self.L.check(self.L.lib.vo_group_leave(self.h, ctx.h), "vo_group_leave")
+
+    def set_gather(self, min_requests: int, timeout_us: int):
+        self.L.check(self.L.lib.vo_group_set_gather(self.h, min_requests, timeout_us), "vo_group_set_gather")
+
+    def stats(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self.L.check(self.L.lib.vo_group_stats(self.h, C.byref(a), C.byref(b), C.byref(c)), "vo_group_stats")
+        return {"chains": a.value, "lanes": b.value, "requests": c.value}
+
+    def close(self):
+        if self.h:
+            self.L.lib.vo_group_destroy(self.h)
+            self.h = C.c_void_p()
 
 
 class VoContext:

@@ -125,20 +125,21 @@ static std::vector<std::string> g_prof_names; static std::vector<double> g_prof_
 
 // Records are appended by the context's owning thread (under the context's prof_mu) and drained by whichever thread
 // reads the table; a record whose end event has not been recorded yet stays in the list.
-int vo_prof_begin(vo_ctx* c, const char* name) {
+int vo_prof_begin(vo_ctx* c, const char* name, hipStream_t st) {
     std::unique_lock<std::mutex> lk(c->prof_mu);
+    if (!st) st = c->stream;
     ProfRec r; r.name = name;
     auto get = [&]() { hipEvent_t e; if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
     r.a = get(); r.b = get();
-    (void)hipEventRecord(r.a, c->stream);
+    (void)hipEventRecord(r.a, st);
     c->prof.push_back(r);
-    c->prof_open = r;
+    c->prof_open = r; c->prof_open_stream = st;
     return (int)(++c->prof_ticket & 0x3FFFFFFF);
 }
 void vo_prof_end(vo_ctx* c, int ticket) {
     std::unique_lock<std::mutex> lk(c->prof_mu);
     if (ticket != (int)(c->prof_ticket & 0x3FFFFFFF)) return;      // not the innermost open record any more (cannot happen: scopes do not nest)
-    (void)hipEventRecord(c->prof_open.b, c->stream);
+    (void)hipEventRecord(c->prof_open.b, c->prof_open_stream);
     c->prof_closed = c->prof_ticket;
 }
 
@@ -170,6 +171,43 @@ static int dev_alloc(T** p, size_t count) {
     return VO_OK;
 }
 #define ALLOC(ptr, count) do { int rc_ = dev_alloc(&(ptr), (count)); if (rc_) { vo_ctx_destroy(c); return rc_; } } while (0)
+
+static void launchset_free(LaunchSet& ls) {
+    if (ls.d_lanes) (void)hipFree(ls.d_lanes);
+    if (ls.d_track) (void)hipFree(ls.d_track);
+    if (ls.h_lanes) (void)hipHostFree(ls.h_lanes);
+    if (ls.h_track) (void)hipHostFree(ls.h_track);
+    ls = LaunchSet();
+}
+static int launchset_alloc(LaunchSet& ls, int cap) {
+    ls = LaunchSet(); ls.cap = cap;
+    if (hipMalloc((void**)&ls.d_lanes, sizeof(LaneDesc) * cap) != hipSuccess || hipMalloc((void**)&ls.d_track, sizeof(TrackDev) * cap) != hipSuccess ||
+        hipHostMalloc((void**)&ls.h_lanes, sizeof(LaneDesc) * cap, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&ls.h_track, sizeof(TrackDev) * cap, hipHostMallocDefault) != hipSuccess) { launchset_free(ls); return VO_E_NOMEM; }
+    memset(ls.h_lanes, 0, sizeof(LaneDesc) * cap); memset(ls.h_track, 0, sizeof(TrackDev) * cap);
+    return VO_OK;
+}
+
+// ---- stream group: the tracking requests of several contexts (independent streams on one GPU) fused into one launch
+// chain.  Every member keeps its own host thread, map and buffers; a thread that calls vo_track_batch on a member context
+// queues its lanes, and whichever thread finds the group idle becomes the leader: it takes everything queued so far,
+// runs ONE chain for all of it on the group's stream, hands the results out and wakes the others.  Requests that arrive
+// while a chain is in flight pile up for the next one, so the batch size follows the load and nobody waits on a timer.
+#include <condition_variable>
+struct GroupReq {
+    vo_ctx* c; int n; const int* slots; const double* T0; const vo_track_params* tp; const uint64_t* seeds;
+    vo_track_result* res; vo_match* matches; int cap; int rc; bool done;
+};
+struct vo_group {
+    int device = 0, max_lanes = 0;
+    hipStream_t stream = nullptr;
+    LaunchSet ls;
+    std::mutex mu; std::condition_variable cv;
+    std::vector<GroupReq*> pending; bool busy = false;
+    int members = 0, gather_min = 1; long gather_timeout_us = 0;
+    int64_t n_chains = 0, n_lanes = 0, n_requests = 0;
+};
+static int chain_run(vo_ctx* prof, hipStream_t st, LaunchSet& ls, std::vector<GroupReq*>& batch);
 
 extern "C" {
 
@@ -209,9 +247,10 @@ void vo_ctx_destroy(vo_ctx* c) {
     for (auto p : c->own_depth) if (p) (void)hipFree(p);
     void* ptrs[] = {c->d_slots, c->d_pyr, c->d_blur, c->d_tab, c->d_tabs, c->d_cand, c->d_cand_cnt, c->d_sel, c->d_sel_key, c->d_sel_cnt, c->d_kps,
                     c->d_desc, c->d_nkp, c->d_status, c->d_map_pos, c->d_map_nrm, c->d_map_desc, c->d_map_flags, c->d_active, c->d_best, c->d_mcand,
-                    c->d_matches, c->d_corr_xyz, c->d_corr_uv, c->d_hyp_pose, c->d_hyp_cnt, c->d_inliers, c->d_lm_mask, c->d_track, c->d_ba};
+                    c->d_matches, c->d_corr_xyz, c->d_corr_uv, c->d_hyp_pose, c->d_hyp_cnt, c->d_inliers, c->d_lm_mask, c->d_ba};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    if (c->h_track) (void)hipHostFree(c->h_track);
+    launchset_free(c->ls);
+    if (c->group_ev) (void)hipEventDestroy(c->group_ev);
     if (c->h_matches) (void)hipHostFree(c->h_matches);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_slots_pinned) (void)hipHostFree(c->h_slots_pinned);
@@ -240,7 +279,7 @@ int vo_ctx_create(const vo_params* p, int device, vo_ctx** out) {
     c->d_map_pos = nullptr; c->d_map_nrm = nullptr; c->d_map_desc = nullptr; c->d_map_flags = nullptr; c->d_active = nullptr; c->n_active = 0; c->active_cap = 0;
     c->lanes = std::max(1, p->max_track_batch);
     c->d_best = nullptr; c->d_mcand = nullptr; c->d_matches = nullptr; c->d_corr_xyz = nullptr; c->d_corr_uv = nullptr; c->corr_cap = 0; c->d_hyp_pose = nullptr; c->d_hyp_cnt = nullptr;
-    c->d_inliers = nullptr; c->d_lm_mask = nullptr; c->d_track = nullptr; c->h_track = nullptr; c->h_matches = nullptr; c->h_matches_cap = 0;
+    c->d_inliers = nullptr; c->d_lm_mask = nullptr; c->d_track = nullptr; c->h_track = nullptr; c->h_matches = nullptr; c->h_matches_cap = 0; c->lane_stride = 0;
     c->h_stage = nullptr; c->h_stage_bytes = 0; c->d_ba = nullptr; c->d_ba_bytes = 0;
     c->h_orb_cache = nullptr; c->orb_cache_valid = false; c->orb_batch0 = 0; c->orb_batchn = 0;
     c->h_slots_pinned = nullptr; c->slots_ev = nullptr; c->slots_dirty = false; c->slots_pending = false;
@@ -281,12 +320,10 @@ int vo_ctx_create(const vo_params* p, int device, vo_ctx** out) {
     const size_t NL = (size_t)c->lanes;
     ALLOC(c->d_active, M); ALLOC(c->d_best, NL * M); ALLOC(c->d_mcand, NL * M); ALLOC(c->d_matches, NL * M); ALLOC(c->d_corr_xyz, NL * 3 * M); ALLOC(c->d_corr_uv, NL * 2 * M);
     ALLOC(c->d_hyp_pose, NL * 12 * p->max_hypotheses); ALLOC(c->d_hyp_cnt, NL * p->max_hypotheses);
-    ALLOC(c->d_inliers, NL * M); ALLOC(c->d_lm_mask, NL * M); ALLOC(c->d_track, NL);
-    if (hipHostMalloc((void**)&c->h_track, sizeof(TrackDev) * NL, hipHostMallocDefault) != hipSuccess) { vo_ctx_destroy(c); return VO_E_NOMEM; }
-    memset(&c->chain, 0, sizeof(c->chain));
-    c->chain.tr = c->d_track; c->chain.best = c->d_best; c->chain.mcand = c->d_mcand; c->chain.matches = c->d_matches; c->chain.cxyz = c->d_corr_xyz;
-    c->chain.cuv = c->d_corr_uv; c->chain.hyp_pose = c->d_hyp_pose; c->chain.hyp_cnt = c->d_hyp_cnt; c->chain.inliers = c->d_inliers; c->chain.lm_mask = c->d_lm_mask;
-    c->chain.stride = M; c->chain.max_hyp = p->max_hypotheses; c->chain.nfeat = P.nfeat; c->chain.desc = c->d_desc; c->chain.nkp = c->d_nkp; c->chain.kps = c->d_kps;
+    ALLOC(c->d_inliers, NL * M); ALLOC(c->d_lm_mask, NL * M);
+    if (launchset_alloc(c->ls, (int)NL) != VO_OK) { vo_ctx_destroy(c); return VO_E_NOMEM; }
+    c->d_track = c->ls.d_track; c->h_track = c->ls.h_track; c->lane_stride = M;
+    if (hipEventCreateWithFlags(&c->group_ev, hipEventDisableTiming) != hipSuccess) { vo_ctx_destroy(c); return VO_E_DEVICE; }
     hipStream_t st = c->stream;
     HIP_TRY(hipMemcpyAsync(c->d_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(c->d_tabs, tabs.data(), tabs.size() * sizeof(short), hipMemcpyHostToDevice, st));
@@ -463,6 +500,7 @@ int vo_map_set_active(vo_ctx* c, const int32_t* idx, int n) {
     return VO_OK;
 }
 
+// ---- the context's own launch set (lane 0 .. lanes-1) ---------------------------------------------------------------
 static int upload_pose(vo_ctx* c, int nl, const double T[12], bool reset) {
     // whole headers are rewritten: counters start from zero for a new frame
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -473,6 +511,13 @@ static int upload_pose(vo_ctx* c, int nl, const double T[12], bool reset) {
         memcpy(h->T_ransac, T, sizeof(double) * 12);
     }
     HIP_TRY(hipMemcpyAsync(c->d_track, c->h_track, sizeof(TrackDev) * nl, hipMemcpyHostToDevice, c->stream));
+    return VO_OK;
+}
+
+// lane descriptors of the context's own lanes (stream must be idle: the pinned mirror is rewritten)
+static int upload_lanes(vo_ctx* c, int nl, const int* slots, const uint64_t* seeds) {
+    for (int i = 0; i < nl; ++i) vo_lane_fill(c, i, slots ? slots[i] : 0, seeds ? seeds[i] : 0, c->d_track + i, c->ls.h_lanes + i);
+    HIP_TRY(hipMemcpyAsync(c->ls.d_lanes, c->ls.h_lanes, sizeof(LaneDesc) * nl, hipMemcpyHostToDevice, c->stream));
     return VO_OK;
 }
 
@@ -499,7 +544,9 @@ int vo_match_active_map(vo_ctx* c, int slot, const double T[12], float ratio, fl
     HIP_TRY(hipSetDevice(c->device));
     int rc = upload_pose(c, 1, T, true);
     if (rc) return rc;
-    rc = vo_track_match_launch(c, 1, &slot, ratio, floor_dist);
+    if ((rc = upload_lanes(c, 1, &slot, nullptr))) return rc;
+    c->corr_external = false;
+    rc = vo_track_match_launch(c, c->stream, c->ls.d_lanes, 1, ChainDims{c->n_active, c->p.n_features}, ratio, floor_dist);
     if (rc) return rc;
     const int take = std::min(cap, c->n_active);
     rc = ensure_match_stage(c, take);
@@ -531,7 +578,8 @@ int vo_pnp_ransac(vo_ctx* c, int n_hyp, float reproj_px, float conf, uint64_t se
     if (rc) return rc;
     memcpy(c->h_track->T, T, sizeof(double) * 12);
     HIP_TRY(hipMemcpyAsync(c->d_track, c->h_track, sizeof(TrackDev), hipMemcpyHostToDevice, c->stream));
-    rc = vo_track_ransac_launch(c, 1, n_hyp, reproj_px, conf, &seed);
+    if ((rc = upload_lanes(c, 1, nullptr, &seed))) return rc;
+    rc = vo_track_ransac_launch(c, c->stream, c->ls.d_lanes, 1, n_hyp, reproj_px, conf, 0);
     if (rc) return rc;
     rc = download_track(c);
     if (rc) return rc;
@@ -555,7 +603,8 @@ int vo_pose_refine_lm(vo_ctx* c, double T[12], double delta, double cut, int it_
     memcpy(c->h_track->T, T, sizeof(double) * 12);
     c->h_track->lm_iters = 0;
     HIP_TRY(hipMemcpyAsync(c->d_track, c->h_track, sizeof(TrackDev), hipMemcpyHostToDevice, c->stream));
-    rc = vo_track_lm_launch(c, 1, delta, cut, it_r, it_p, false);
+    if ((rc = upload_lanes(c, 1, nullptr, nullptr))) return rc;
+    rc = vo_track_lm_launch(c, c->stream, c->ls.d_lanes, 1, delta, cut, it_r, it_p, false);
     if (rc) return rc;
     rc = download_track(c);
     if (rc) return rc;
@@ -572,66 +621,135 @@ int vo_pose_refine_lm(vo_ctx* c, double T[12], double delta, double cut, int it_
     return VO_OK;
 }
 
-static double g_tt[6]; static long g_tn;
-static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-
 #define MATCH_COPY_FIRST 4096       // floor of the per-lane match copy that travels with the headers; a frame with more gets a second copy
+
+// ---- one launch chain over the lanes of a set of requests (one request = the lanes one context contributes) ----------
+// Used for a context's own vo_track_batch (one request, its own stream and launch set) and for the fused chain of a
+// stream group (its stream and launch set).  Returns after the chain has finished and every request's results are filled in.
+static int chain_run(vo_ctx* prof, hipStream_t st, LaunchSet& ls, std::vector<GroupReq*>& batch) {
+    const vo_track_params* tp = batch[0]->tp;
+    int nl = 0; ChainDims dims{0, 0};
+    HIP_TRY(hipStreamSynchronize(st));                      // the pinned mirrors are rewritten below
+    for (GroupReq* r : batch) {
+        vo_ctx* c = r->c;
+        c->corr_external = false;
+        for (int i = 0; i < r->n; ++i, ++nl) {
+            TrackDev* h = ls.h_track + nl;
+            memset(h, 0, sizeof(*h));
+            memcpy(h->T, r->T0, sizeof(double) * 12); memcpy(h->T_ransac, r->T0, sizeof(double) * 12);
+            vo_lane_fill(c, i, r->slots[i], 0, ls.d_track + nl, ls.h_lanes + nl);
+        }
+        dims.max_active = std::max(dims.max_active, c->n_active); dims.max_feat = std::max(dims.max_feat, c->p.n_features);
+        if (c->stream != st) {                              // a member's own stream carries its ORB results and map updates
+            HIP_TRY(hipEventRecord(c->group_ev, c->stream));
+            HIP_TRY(hipStreamWaitEvent(st, c->group_ev, 0));
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(ls.d_track, ls.h_track, sizeof(TrackDev) * nl, hipMemcpyHostToDevice, st));
+    int rc = VO_OK;
+    { int k = 0; for (GroupReq* r : batch) for (int i = 0; i < r->n; ++i, ++k) ls.h_lanes[k].seed = r->seeds ? r->seeds[i] : tp->seed; }
+    HIP_TRY(hipMemcpyAsync(ls.d_lanes, ls.h_lanes, sizeof(LaneDesc) * nl, hipMemcpyHostToDevice, st));
+    for (int pass = 0; pass < tp->passes; ++pass) {           // coarse, fine (frontend.cpp:100-108); the sampler's seed is lane seed + pass
+        if ((rc = vo_track_match_launch(prof, st, ls.d_lanes, nl, dims, tp->match_ratio, tp->match_floor))) return rc;
+        if ((rc = vo_track_ransac_launch(prof, st, ls.d_lanes, nl, tp->n_hyp, tp->reproj_px, tp->confidence, pass))) return rc;
+        if ((rc = vo_track_lm_launch(prof, st, ls.d_lanes, nl, tp->huber_delta, tp->chi2_cut, tp->it_robust, tp->it_plain, pass == tp->passes - 1))) return rc;
+    }
+    // match records that callers asked for travel with the headers; sized from the largest match count seen recently
+    // (+25 %): consecutive frames see the same map, and a synchronous second copy per lane costs more than the extra bytes
+    for (GroupReq* r : batch) {
+        if (!r->matches) continue;
+        vo_ctx* c = r->c;
+        const int first = std::min(std::min(r->cap, c->n_active), std::max(MATCH_COPY_FIRST, c->match_hint + c->match_hint / 4));
+        if ((rc = ensure_match_stage(c, std::max(first * r->n, std::min(r->cap, c->n_active))))) return rc;
+        if (first > 0)
+            HIP_TRY(hipMemcpy2DAsync(c->h_matches, sizeof(vo_match) * (size_t)first, c->d_matches, sizeof(vo_match) * c->lane_stride, sizeof(vo_match) * (size_t)first, r->n, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipMemcpyAsync(ls.h_track, ls.d_track, sizeof(TrackDev) * nl, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    int k0 = 0;
+    for (GroupReq* r : batch) {
+        vo_ctx* c = r->c;
+        int seen = 0;
+        for (int i = 0; i < r->n; ++i) { c->h_track[i] = ls.h_track[k0 + i]; seen = std::max(seen, c->h_track[i].n_match); }
+        c->last_track_lanes = r->n;
+        const int first = std::min(std::min(r->cap, c->n_active), std::max(MATCH_COPY_FIRST, c->match_hint + c->match_hint / 4));
+        c->match_hint = std::max(seen, c->match_hint - c->match_hint / 16);      // slow decay
+        for (int i = 0; i < r->n; ++i) {
+            const TrackDev& t = c->h_track[i];
+            vo_track_result& o = r->res[i];
+            memset(&o, 0, sizeof(o));
+            memcpy(o.T_cw, t.T, sizeof(double) * 12);
+            o.n_candidates = t.n_cand; o.n_matches = t.n_match; o.n_ransac_inliers = t.n_inl; o.n_lm_inliers = t.n_lm_inl;
+            o.min_distance = t.min_dist; o.ransac_iters = t.iters_used; o.best_hypothesis = t.best_hyp; o.lm_iters = t.lm_iters;
+            o.status = t.status;
+#ifdef VO_LM_STAMPS
+            for (int k = 0; k < 7; ++k) o.reserved[k] = (int32_t)(t.dbg[k == 6 ? 7 : k] >> ((k == 2 || k == 3) ? 0 : 4));
+            o.n_lm_inliers = (int32_t)(t.dbg[6] >> 4);
+#endif
+            if (t.n_match > r->cap && r->matches) o.status = VO_E_OVERFLOW;
+            if (r->matches) memcpy(r->matches + (size_t)i * r->cap, c->h_matches + (size_t)i * first, sizeof(vo_match) * std::min(first, t.n_match));
+        }
+        if (r->matches)
+            for (int i = 0; i < r->n; ++i) {                  // rare: more matches than the first copy carried
+                const int want = std::min(r->cap, c->h_track[i].n_match);
+                if (want > first) {
+                    HIP_TRY(hipMemcpy(c->h_matches, c->d_matches + (size_t)i * c->lane_stride, sizeof(vo_match) * (size_t)want, hipMemcpyDeviceToHost));
+                    memcpy(r->matches + (size_t)i * r->cap, c->h_matches, sizeof(vo_match) * (size_t)want);
+                }
+            }
+        k0 += r->n;
+    }
+    return VO_OK;
+}
+
+static bool same_track_params(const vo_track_params* a, const vo_track_params* b) {
+    return a->match_ratio == b->match_ratio && a->match_floor == b->match_floor && a->n_hyp == b->n_hyp && a->reproj_px == b->reproj_px &&
+           a->confidence == b->confidence && a->huber_delta == b->huber_delta && a->chi2_cut == b->chi2_cut && a->it_robust == b->it_robust &&
+           a->it_plain == b->it_plain && a->passes == b->passes;
+}
+
+// a member's request: queue it; lead a chain when the group is idle, otherwise sleep until some leader has served it
+static int group_submit(vo_group* g, GroupReq* req) {
+    std::unique_lock<std::mutex> lk(g->mu);
+    g->pending.push_back(req);
+    ++g->n_requests;
+    g->cv.notify_all();                                     // a leader gathering requests counts this one
+    while (!req->done) {
+        if (g->busy) { g->cv.wait(lk); continue; }
+        g->busy = true;
+        if (g->gather_min > 1 && g->gather_timeout_us > 0) {  // optional: wait a moment for the other members (tests, tuning)
+            const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(g->gather_timeout_us);
+            g->cv.wait_until(lk, until, [&] { return (int)g->pending.size() >= std::min(g->gather_min, g->members); });
+        }
+        std::vector<GroupReq*> batch;
+        int lanes = 0;
+        for (size_t i = 0; i < g->pending.size();) {          // oldest first; same solver parameters only
+            GroupReq* r = g->pending[i];
+            if ((batch.empty() || same_track_params(batch[0]->tp, r->tp)) && lanes + r->n <= g->max_lanes) { batch.push_back(r); lanes += r->n; g->pending.erase(g->pending.begin() + i); }
+            else ++i;
+        }
+        lk.unlock();
+        int rc = VO_OK;
+        if (hipSetDevice(g->device) != hipSuccess) rc = VO_E_DEVICE;
+        if (rc == VO_OK) rc = chain_run(req->c, g->stream, g->ls, batch);
+        lk.lock();
+        ++g->n_chains; g->n_lanes += lanes;
+        for (GroupReq* r : batch) { r->rc = rc; r->done = true; }
+        g->busy = false;
+        g->cv.notify_all();
+    }
+    return req->rc;
+}
 
 int vo_track_batch(vo_ctx* c, int n, const int* slots, const double T0[12], const vo_track_params* tp, const uint64_t* seeds,
                    vo_track_result* res, vo_match* matches, int cap) {
     if (!c || n < 1 || n > c->lanes || !slots || !T0 || !tp || !res || tp->passes < 1 || cap < 0 || tp->n_hyp < 1 || tp->n_hyp > c->p.max_hypotheses) return VO_E_INVALID;
     for (int i = 0; i < n; ++i) { if (slots[i] < 0 || slots[i] >= c->p.max_frames) return VO_E_INVALID; if (!c->slot_orb[slots[i]]) return VO_E_STATE; }
-    const bool trace = getenv("VO_TRACE") != nullptr;
-    const double t0 = trace ? now_us() : 0;
     HIP_TRY(hipSetDevice(c->device));
-    int rc = upload_pose(c, n, T0, true);
-    if (rc) return rc;
-    const double t1 = trace ? now_us() : 0;
-    uint64_t sd[VO_MAX_LANES];
-    for (int pass = 0; pass < tp->passes; ++pass) {           // coarse, fine (frontend.cpp:100-108)
-        for (int i = 0; i < n; ++i) sd[i] = (seeds ? seeds[i] : tp->seed) + (uint64_t)pass;
-        if ((rc = vo_track_match_launch(c, n, slots, tp->match_ratio, tp->match_floor))) return rc;
-        if ((rc = vo_track_ransac_launch(c, n, tp->n_hyp, tp->reproj_px, tp->confidence, sd))) return rc;
-        if ((rc = vo_track_lm_launch(c, n, tp->huber_delta, tp->chi2_cut, tp->it_robust, tp->it_plain, pass == tp->passes - 1))) return rc;
-    }
-    const double t2 = trace ? now_us() : 0;
-    // the copy is sized from the largest match count seen recently (+25 %): consecutive frames see the same map, and a
-    // synchronous second copy per lane costs more than the extra bytes
-    const int first = std::min(std::min(cap, c->n_active), std::max(MATCH_COPY_FIRST, c->match_hint + c->match_hint / 4));
-    if ((rc = ensure_match_stage(c, std::max(first * n, std::min(cap, c->n_active))))) return rc;
-    if (first > 0 && matches)
-        HIP_TRY(hipMemcpy2DAsync(c->h_matches, sizeof(vo_match) * (size_t)first, c->d_matches, sizeof(vo_match) * c->chain.stride, sizeof(vo_match) * (size_t)first, n, hipMemcpyDeviceToHost, c->stream));
-    if ((rc = download_track(c, n))) return rc;
-    c->last_track_lanes = n;
-    const double t2b = trace ? now_us() : 0;
-    int seen = 0;
-    for (int i = 0; i < n; ++i) seen = std::max(seen, c->h_track[i].n_match);
-    c->match_hint = std::max(seen, c->match_hint - c->match_hint / 16);      // slow decay
-    for (int i = 0; i < n; ++i) {
-        const TrackDev& t = c->h_track[i];
-        vo_track_result& r = res[i];
-        memset(&r, 0, sizeof(r));
-        memcpy(r.T_cw, t.T, sizeof(double) * 12);
-        r.n_candidates = t.n_cand; r.n_matches = t.n_match; r.n_ransac_inliers = t.n_inl; r.n_lm_inliers = t.n_lm_inl;
-        r.min_distance = t.min_dist; r.ransac_iters = t.iters_used; r.best_hypothesis = t.best_hyp; r.lm_iters = t.lm_iters;
-        r.status = t.status;
-#ifdef VO_LM_STAMPS
-        for (int k = 0; k < 7; ++k) r.reserved[k] = (int32_t)(t.dbg[k == 6 ? 7 : k] >> ((k == 2 || k == 3) ? 0 : 4));
-        r.n_lm_inliers = (int32_t)(t.dbg[6] >> 4);
-#endif
-        if (t.n_match > cap && matches) r.status = VO_E_OVERFLOW;
-        if (matches) memcpy(matches + (size_t)i * cap, c->h_matches + (size_t)i * first, sizeof(vo_match) * std::min(first, t.n_match));
-    }
-    if (matches)
-        for (int i = 0; i < n; ++i) {                          // rare: more matches than the first copy carried
-            const int want = std::min(cap, c->h_track[i].n_match);
-            if (want > first) {
-                HIP_TRY(hipMemcpy(c->h_matches, c->d_matches + (size_t)i * c->chain.stride, sizeof(vo_match) * (size_t)want, hipMemcpyDeviceToHost));
-                memcpy(matches + (size_t)i * cap, c->h_matches, sizeof(vo_match) * (size_t)want);
-            }
-        }
-    if (trace) { const double t3 = now_us(); g_tt[0] += t1 - t0; g_tt[1] += t2 - t1; g_tt[2] += t2b - t2; g_tt[4] += t3 - t2b; g_tt[3] += n; if (++g_tn % 50 == 0) fprintf(stderr, "[vo_trace] track_batch avg us: upload %.1f launch %.1f wait+d2h %.1f host copy-out %.1f, frames/batch %.2f\n", g_tt[0] / g_tn, g_tt[1] / g_tn, g_tt[2] / g_tn, g_tt[4] / g_tn, g_tt[3] / g_tn); }
-    return VO_OK;
+    GroupReq req{c, n, slots, T0, tp, seeds, res, matches, cap, VO_OK, false};
+    if (c->group) return group_submit(c->group, &req);
+    std::vector<GroupReq*> one{&req};
+    return chain_run(c, c->stream, c->ls, one);
 }
 
 int vo_track_fetch_matches(vo_ctx* c, int lane, vo_match* matches, int cap, int* n_out) {
@@ -641,7 +759,7 @@ int vo_track_fetch_matches(vo_ctx* c, int lane, vo_match* matches, int cap, int*
     int rc = ensure_match_stage(c, std::max(n, 1));
     if (rc) return rc;
     if (n > 0) {
-        HIP_TRY(hipMemcpyAsync(c->h_matches, c->d_matches + (size_t)lane * c->chain.stride, sizeof(vo_match) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->h_matches, c->d_matches + (size_t)lane * c->lane_stride, sizeof(vo_match) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         memcpy(matches, c->h_matches, sizeof(vo_match) * (size_t)n);
     }
@@ -653,6 +771,60 @@ int vo_track_frame(vo_ctx* c, int slot, const double T0[12], const vo_track_para
                    vo_match* matches, int cap) {
     if (!tp) return VO_E_INVALID;
     return vo_track_batch(c, 1, &slot, T0, tp, &tp->seed, res, matches, cap);
+}
+
+// ---- stream groups ----------------------------------------------------------------------------------------------------
+int vo_group_create(int device, int max_lanes, vo_group** out) {
+    if (!out || max_lanes < 1 || max_lanes > VO_GROUP_MAX_LANES) return VO_E_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return VO_E_DEVICE;
+    HIP_TRY(hipSetDevice(device));
+    vo_group* g = new (std::nothrow) vo_group();
+    if (!g) return VO_E_NOMEM;
+    g->device = device; g->max_lanes = max_lanes;
+    if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess) { delete g; return VO_E_DEVICE; }
+    if (launchset_alloc(g->ls, max_lanes) != VO_OK) { (void)hipStreamDestroy(g->stream); delete g; return VO_E_NOMEM; }
+    *out = g;
+    return VO_OK;
+}
+
+void vo_group_destroy(vo_group* g) {
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    if (g->stream) { (void)hipStreamSynchronize(g->stream); (void)hipStreamDestroy(g->stream); }
+    launchset_free(g->ls);
+    delete g;
+}
+
+int vo_group_join(vo_group* g, vo_ctx* c) {
+    if (!g || !c || c->group || c->device != g->device || c->lanes > g->max_lanes) return VO_E_INVALID;
+    std::unique_lock<std::mutex> lk(g->mu);
+    c->group = g; ++g->members;
+    return VO_OK;
+}
+
+int vo_group_leave(vo_group* g, vo_ctx* c) {
+    if (!g || !c || c->group != g) return VO_E_INVALID;
+    std::unique_lock<std::mutex> lk(g->mu);
+    c->group = nullptr; --g->members;
+    g->cv.notify_all();
+    return VO_OK;
+}
+
+int vo_group_set_gather(vo_group* g, int min_requests, int timeout_us) {
+    if (!g || min_requests < 1 || timeout_us < 0) return VO_E_INVALID;
+    std::unique_lock<std::mutex> lk(g->mu);
+    g->gather_min = min_requests; g->gather_timeout_us = timeout_us;
+    return VO_OK;
+}
+
+int vo_group_stats(vo_group* g, int64_t* chains, int64_t* lanes, int64_t* requests) {
+    if (!g) return VO_E_INVALID;
+    std::unique_lock<std::mutex> lk(g->mu);
+    if (chains) *chains = g->n_chains;
+    if (lanes) *lanes = g->n_lanes;
+    if (requests) *requests = g->n_requests;
+    return VO_OK;
 }
 
 int vo_local_ba(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {

@@ -49,16 +49,28 @@ struct TrackDev {
     long long dbg[8];           // diagnostic stamps (only written by -DVO_LM_STAMPS builds)
 };
 
-#define VO_MAX_LANES 16
-// Per-lane working set of the tracking chain.  A "lane" is one frame of a batch that is tracked
-// concurrently (blockIdx.z): frames between two keyframes share the prior pose and the map
-// (reference src/frontend.cpp:96 -- the prior is the last KEYFRAME's pose), so they are independent.
-struct ChainBuf {
-    TrackDev* tr; uint32_t* best; int32_t* mcand; vo_match* matches; float* cxyz; float* cuv;
-    double* hyp_pose; int* hyp_cnt; int32_t* inliers; uint8_t* lm_mask;
-    size_t stride; int max_hyp, nfeat;
-    const uint8_t* desc; const int* nkp; const vo_keypoint* kps;      // per frame slot: [slot][nfeat]
-    int slot[VO_MAX_LANES]; unsigned long long seed[VO_MAX_LANES];
+#define VO_MAX_LANES 16              // lanes one context contributes to a launch chain (vo_track_batch)
+#define VO_GROUP_MAX_LANES 128       // lanes of one fused chain of a stream group
+struct CamD { double fx, fy, cx, cy; int W, H; };
+// Per-lane working set of the tracking chain.  A "lane" is one frame tracked by a launch chain (blockIdx.z).  Frames
+// between two keyframes of a stream share the prior pose and the map (reference src/frontend.cpp:96 -- the prior is the
+// last KEYFRAME's pose), so they are independent lanes; frames of different streams (contexts of a stream group) are
+// independent anyway.  Every lane carries its own pointers: the chain's kernels never assume that two lanes share a map.
+struct LaneDesc {
+    TrackDev* tr; uint32_t* best; int32_t* cand; vo_match* matches; float* cxyz; float* cuv;
+    double* hyp_pose; int* hyp_cnt; int32_t* inliers; uint8_t* mask;
+    const uint32_t* fdesc; const int* nkp; const vo_keypoint* kps;                  // the lane's frame slot (ORB results)
+    const double* map_pos; const double* map_nrm; const uint8_t* map_flags; const uint32_t* map_desc; const int32_t* active;
+    int n_active, cap, max_hyp, gate_lds;
+    unsigned long long seed;
+    CamD cam;
+};
+// Buffers of one launch chain: lane descriptors + result headers, device copies and pinned mirrors.  A context owns
+// one (its own lanes); a stream group owns one for the fused chain of its members.
+struct LaunchSet {
+    int cap = 0;
+    LaneDesc* d_lanes = nullptr; LaneDesc* h_lanes = nullptr;      // h_lanes pinned
+    TrackDev* d_track = nullptr; TrackDev* h_track = nullptr;      // h_track pinned
 };
 
 struct vo_ctx {
@@ -89,8 +101,10 @@ struct vo_ctx {
     vo_match* d_matches; float* d_corr_xyz; float* d_corr_uv; int corr_cap;
     double* d_hyp_pose; int* d_hyp_cnt;             // [max_hyp][12], [max_hyp]
     int32_t* d_inliers; uint8_t* d_lm_mask;
+    LaunchSet ls;                                   // this context's own lanes (d_track / h_track alias ls.d_track / ls.h_track)
     TrackDev* d_track; TrackDev* h_track;           // [lanes]; h_track pinned
-    ChainBuf chain; int lanes;                      // base pointers of the per-lane chain buffers
+    size_t lane_stride; int lanes;                  // element stride of the per-lane chain buffers
+    struct vo_group* group = nullptr; hipEvent_t group_ev = nullptr;     // stream group membership (vo_group_join)
     vo_match* h_matches;                            // pinned staging
     int h_matches_cap;
     void* h_stage; size_t h_stage_bytes;            // pinned general staging
@@ -100,23 +114,28 @@ struct vo_ctx {
     void* d_ba; size_t d_ba_bytes;
     // profiling
     std::atomic<bool> prof_on; std::mutex prof_mu; std::vector<ProfRec> prof; std::vector<hipEvent_t> ev_pool;      // prof / ev_pool: under prof_mu
-    ProfRec prof_open; uint64_t prof_ticket = 0, prof_closed = 0;
+    ProfRec prof_open; hipStream_t prof_open_stream = nullptr; uint64_t prof_ticket = 0, prof_closed = 0;
 };
 
 // profiling helpers (vo_capi.hip)
-int vo_prof_begin(vo_ctx* c, const char* name);     // returns a ticket for vo_prof_end (-1: not recorded)
+int vo_prof_begin(vo_ctx* c, const char* name, hipStream_t st);     // returns a ticket for vo_prof_end (-1: not recorded)
 void vo_prof_end(vo_ctx* c, int ticket);
 // the flag is latched at construction: a toggle from another thread between begin and end cannot unbalance the records
-struct ProfScope { vo_ctx* c; int idx; ProfScope(vo_ctx* c_, const char* n) : c(c_), idx(c_->prof_on.load(std::memory_order_relaxed) ? vo_prof_begin(c_, n) : -1) {} ~ProfScope() { if (idx >= 0) vo_prof_end(c, idx); } };
+struct ProfScope { vo_ctx* c; int idx;
+    ProfScope(vo_ctx* c_, const char* n, hipStream_t st = nullptr) : c(c_), idx(c_->prof_on.load(std::memory_order_relaxed) ? vo_prof_begin(c_, n, st) : -1) {}      // st: the stream the kernel runs on (default: the context's)
+    ~ProfScope() { if (idx >= 0) vo_prof_end(c, idx); } };
 void* vo_stage(vo_ctx* c, size_t bytes);           // pinned host staging buffer of at least `bytes`
 int vo_scratch(vo_ctx* c, size_t bytes);           // grow the device scratch slab c->d_ba to at least `bytes`
 int vo_map_scatter_launch(vo_ctx* c, int n, const int32_t* d_idx, const double* d_xyz, const double* d_nrm, const uint32_t* d_desc, const uint8_t* d_flags);
 
 // stage launchers
 int vo_orb_launch(vo_ctx* c, int slot0, int nslots);                                        // vo_orb.hip
-int vo_track_match_launch(vo_ctx* c, int nl, const int* slots, float ratio, float floor_dist);       // vo_track.hip (nl lanes)
-int vo_track_ransac_launch(vo_ctx* c, int nl, int n_hyp, float reproj_px, float conf, const uint64_t* seeds);
-int vo_track_lm_launch(vo_ctx* c, int nl, double delta, double cut, int it_r, int it_p, bool write_flags);
+// vo_track.hip: the chain's stages over nl lanes described by d_lanes (device), on stream st; `prof` receives the timing records
+struct ChainDims { int max_active, max_feat; };
+int vo_track_match_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* d_lanes, int nl, ChainDims dims, float ratio, float floor_dist);
+int vo_track_ransac_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* d_lanes, int nl, int n_hyp, float reproj_px, float conf, int pass);
+int vo_track_lm_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* d_lanes, int nl, double delta, double cut, int it_r, int it_p, bool write_flags);
+void vo_lane_fill(vo_ctx* c, int lane, int slot, uint64_t seed, TrackDev* d_tr, LaneDesc* out);   // descriptor of lane `lane` of context c
 int vo_corr_from_host(vo_ctx* c, const float* xyz, const float* uv, int n);
 int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out);                       // vo_ba.hip
 

@@ -3,9 +3,10 @@
 //   k_match         frustum/view-angle filter (reference src/frame.cpp:70-91, loop src/frontend.cpp:171-184)
 //                   fused with an exact brute-force Hamming 1-NN of every active map point against the
 //                   frame's descriptors (replaces cv::FlannBasedMatcher+LSH, src/frontend.cpp:33,:187).
-//                   256 queries x 256 train descriptors per workgroup; the train tile sits in LDS and is
-//                   read as wave-wide broadcasts (2 x ds_read_b128 per descriptor); 8 x v_bcnt per pair;
-//                   cross-tile argmin by one 64-bit atomicMin((dist<<32)|index).
+//                   one wavefront = 64 candidates x one 64-descriptor tile of the frame; the train tile sits in LDS and
+//                   is read as wave-wide broadcasts; 8 chained v_bcnt per pair; the wave walks ALL keypoint tiles of
+//                   its candidates, so the cross-tile argmin stays in a register and every candidate's result is
+//                   written once: best[q] = (dist << 22) | keypoint, first minimum wins.
 //   k_match_gate    min distance, gate max(min*ratio, 30) (src/frontend.cpp:190-211), ORDER-PRESERVING
 //                   compaction (ballot + popcount prefix) and gather of the float32 3-D/2-D pairs (:225-230)
 //   k_ransac_hyp    one lane per hypothesis: counter-based 4-sample, Grunert P3P, 4th point disambiguates
@@ -18,6 +19,7 @@
 // The chain never returns to the host between stages: counts live in TrackDev, grids are sized
 // by capacity and trimmed on the device.  All double arithmetic mirrors oracle/o_track.cpp
 // operation by operation (file is compiled with -ffp-contract=off).
+#include <algorithm>
 #include <cfloat>
 #include <cstdio>
 #include <cstring>
@@ -30,25 +32,14 @@ __device__ long long g_dbg[8];
 __device__ long long g_dbg2[8];
 #endif
 
-struct CamD { double fx, fy, cx, cy; int W, H; };
-
-#define LANE_PTRS(cb) \
-    const int lane_ = blockIdx.z; \
-    TrackDev* tr = cb.tr + lane_; \
-    uint32_t* best = cb.best + (size_t)lane_ * cb.stride; \
-    int32_t* cand = cb.mcand + (size_t)lane_ * cb.stride; \
-    vo_match* matches = cb.matches + (size_t)lane_ * cb.stride; \
-    float* cxyz = cb.cxyz + 3 * (size_t)lane_ * cb.stride; \
-    float* cuv = cb.cuv + 2 * (size_t)lane_ * cb.stride; \
-    double* hyp_pose = cb.hyp_pose + (size_t)12 * lane_ * cb.max_hyp; \
-    int* hyp_cnt = cb.hyp_cnt + (size_t)lane_ * cb.max_hyp; \
-    int32_t* inliers = cb.inliers + (size_t)lane_ * cb.stride; \
-    uint8_t* mask = cb.lm_mask + (size_t)lane_ * cb.stride; \
-    const int slot_ = cb.slot[lane_]; \
-    const uint32_t* fdesc = (const uint32_t*)(cb.desc + (size_t)slot_ * cb.nfeat * 32); \
-    const int* nkp_p = cb.nkp + slot_; \
-    const vo_keypoint* kps = cb.kps + (size_t)slot_ * cb.nfeat; \
-    (void)tr; (void)best; (void)cand; (void)matches; (void)cxyz; (void)cuv; (void)hyp_pose; (void)hyp_cnt; (void)inliers; (void)mask; (void)fdesc; (void)nkp_p; (void)kps;
+// every kernel of the chain: blockIdx.z = lane; the lane's pointers come from its descriptor (uniform loads)
+#define LANE_PTRS(lanes) \
+    const LaneDesc& ld_ = lanes[blockIdx.z]; \
+    TrackDev* tr = ld_.tr; uint32_t* best = ld_.best; int32_t* cand = ld_.cand; vo_match* matches = ld_.matches; \
+    float* cxyz = ld_.cxyz; float* cuv = ld_.cuv; double* hyp_pose = ld_.hyp_pose; int* hyp_cnt = ld_.hyp_cnt; \
+    int32_t* inliers = ld_.inliers; uint8_t* mask = ld_.mask; const uint32_t* fdesc = ld_.fdesc; const int* nkp_p = ld_.nkp; \
+    const vo_keypoint* kps = ld_.kps; const CamD cam = ld_.cam; \
+    (void)tr; (void)best; (void)cand; (void)matches; (void)cxyz; (void)cuv; (void)hyp_pose; (void)hyp_cnt; (void)inliers; (void)mask; (void)fdesc; (void)nkp_p; (void)kps; (void)cam;
 
 // ------------------------------------------------------------------------------------------
 // small double-precision helpers (same operation order as oracle/o_math.h)
@@ -72,74 +63,106 @@ __device__ __forceinline__ double comp(D3 a, int i) { return i == 0 ? a.x : (i =
 #define MQ 64
 #define MT 64
 #define MATCH_NONE 0xFFFFFFFFu      // best[q] = (distance << 22) | keypoint index: one 32-bit atomicMin keeps the first minimum
-#define MATCH_GRID_X 512            // candidate tiles per grid row (32768 candidates); more are taken in a stride loop
+#define MATCH_GRID_X 512            // workgroups (candidate tiles) per lane; more candidates are taken in a stride loop
 // visibility filter: every active map point gets best[q] = ~0; visible ones are appended to the
 // (unordered) candidate list -- order is restored later because results are indexed by q.
-__global__ __launch_bounds__(256) void k_frustum(CamD cam, ChainBuf cb, const double* __restrict__ map_pos,
-                                                 const double* __restrict__ map_nrm, const uint8_t* __restrict__ map_flags,
-                                                 const int32_t* __restrict__ active, int n_active) {
-    LANE_PTRS(cb)
+__global__ __launch_bounds__(256) void k_frustum(const LaneDesc* __restrict__ lanes) {
+    LANE_PTRS(lanes)
+    const double* __restrict__ map_pos = ld_.map_pos; const double* __restrict__ map_nrm = ld_.map_nrm;
+    const uint8_t* __restrict__ map_flags = ld_.map_flags; const int32_t* __restrict__ active = ld_.active; const int n_active = ld_.n_active;
     const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= n_active) return;
-    best[q] = MATCH_NONE;
-    const int mi = active[q];
-    if (map_flags[mi] & VO_MAP_FLAG_OUTLIER) return;
-    double T[12];
+    bool vis = false;
+    if (q < n_active) {
+        best[q] = MATCH_NONE;
+        const int mi = active[q];
+        if (!(map_flags[mi] & VO_MAP_FLAG_OUTLIER)) {
+            double T[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) T[i] = tr->T[i];
-    const D3 pw = mk(map_pos[3 * (size_t)mi], map_pos[3 * (size_t)mi + 1], map_pos[3 * (size_t)mi + 2]);
-    const D3 pc = xform(T, pw);
-    if (!(pc.z > 0)) return;
-    const double u = cam.fx * pc.x / pc.z + cam.cx, v = cam.fy * pc.y / pc.z + cam.cy;
-    if (u < 0 || u >= cam.W || v < 0 || v >= cam.H) return;
-    // camera centre C = -R^T t
-    const D3 C = mk(-(T[0] * T[9] + T[3] * T[10] + T[6] * T[11]), -(T[1] * T[9] + T[4] * T[10] + T[7] * T[11]), -(T[2] * T[9] + T[5] * T[10] + T[8] * T[11]));
-    const D3 dir = nrm3(sub(pw, C));
-    const double dd = dir.x * map_nrm[3 * (size_t)mi] + dir.y * map_nrm[3 * (size_t)mi + 1] + dir.z * map_nrm[3 * (size_t)mi + 2];
-    if (dd < 0.8660254037844387) return;
-    cand[atomicAdd(&tr->pad0, 1)] = q;          // pad0 = live candidate counter (reset by k_match_gate)
+            for (int i = 0; i < 12; ++i) T[i] = tr->T[i];
+            const D3 pw = mk(map_pos[3 * (size_t)mi], map_pos[3 * (size_t)mi + 1], map_pos[3 * (size_t)mi + 2]);
+            const D3 pc = xform(T, pw);
+            if (pc.z > 0) {
+                const double u = cam.fx * pc.x / pc.z + cam.cx, v = cam.fy * pc.y / pc.z + cam.cy;
+                if (!(u < 0 || u >= cam.W || v < 0 || v >= cam.H)) {
+                    // camera centre C = -R^T t
+                    const D3 C = mk(-(T[0] * T[9] + T[3] * T[10] + T[6] * T[11]), -(T[1] * T[9] + T[4] * T[10] + T[7] * T[11]), -(T[2] * T[9] + T[5] * T[10] + T[8] * T[11]));
+                    const D3 dir = nrm3(sub(pw, C));
+                    const double dd = dir.x * map_nrm[3 * (size_t)mi] + dir.y * map_nrm[3 * (size_t)mi + 1] + dir.z * map_nrm[3 * (size_t)mi + 2];
+                    vis = !(dd < 0.8660254037844387);
+                }
+            }
+        }
+    }
+    // append: ONE atomic per wavefront on the lane's counter (pad0 = live candidate counter, reset by k_match_gate); a
+    // per-candidate atomic on that single address serialises in L2 (~10 k of them per frame)
+    const unsigned long long m = __ballot(vis);
+    if (m) {
+        const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&tr->pad0, __popcll(m));
+        base = __shfl(base, leader, 64);
+        if (vis) cand[base + __popcll(m & ((1ull << lane) - 1ull))] = q;
+    }
 }
 
-// 64 candidates x 64 frame descriptors per wavefront; the train tile sits in LDS and every lane reads
-// the same descriptor (broadcast), 8 x (v_xor, v_bcnt) per pair; cross-tile argmin by 64-bit atomicMin.
-__global__ __launch_bounds__(64) void k_match(ChainBuf cb, const uint32_t* __restrict__ map_desc, const int32_t* __restrict__ active) {
-    LANE_PTRS(cb)
-    __shared__ uint4 s_train[MT * 2];
+// One workgroup = 64 candidates x a slice of the lane's keypoints: 8 wavefronts, wave w takes keypoint tile w of every
+// round of 8 tiles (64 descriptors each, staged in LDS by the whole workgroup, read as wave-wide broadcasts) and keeps the
+// running argmin of its tiles in a register; the 8 partial results meet in LDS and the workgroup issues ONE atomicMin
+// per candidate.  gridDim.y workgroups share a candidate tile (keypoint rounds y, y + gridDim.y, ...): 4 atomics per
+// candidate instead of round 1's one per 64-keypoint tile (32 per candidate, 4.5 MB of L2 atomics per frame).
+#define MW 8                        // wavefronts per workgroup = keypoint tiles in flight
+__global__ __launch_bounds__(64 * MW) void k_match(const LaneDesc* __restrict__ lanes) {
+    LANE_PTRS(lanes)
+    const uint32_t* __restrict__ map_desc = ld_.map_desc; const int32_t* __restrict__ active = ld_.active;
+    __shared__ uint4 s_train[MW][MT * 2];
+    __shared__ uint32_t s_part[MW][MQ];
     const int nkp = *nkp_p, ncand = tr->pad0;
-    const int t0 = blockIdx.y * MT;
-    // the candidate count is only known on the device: the grid has a fixed number of candidate tiles per keypoint
-    // tile (instead of one per 64 ACTIVE points, most of which would exit at once) and strides over the rest
-    if (t0 >= nkp || (int)blockIdx.x * MQ >= ncand) return;
-    const int nt = min(MT, nkp - t0);
-    const uint4* src = (const uint4*)(fdesc + (size_t)t0 * 8);
-    for (int i = threadIdx.x; i < nt * 2; i += 64) s_train[i] = src[i];
-    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the candidate count is only known on the device: a fixed number of workgroups strides over the candidate tiles
     for (int c0 = blockIdx.x * MQ; c0 < ncand; c0 += gridDim.x * MQ) {
-        const int ci = c0 + threadIdx.x;
-        if (ci >= ncand) break;
+        const int ci = min(c0 + lane, ncand - 1);          // clamped: every lane computes, only valid ones store
         const int q = cand[ci];
         const uint4* qd = (const uint4*)(map_desc + (size_t)active[q] * 8);
         const uint4 qa = qd[0], qb = qd[1];
-        // distance and tile-local index travel as one key (dist << 6 | t): a single v_min keeps the first minimum;
-        // the eight popcounts are chained through v_bcnt's accumulate operand (two pairs in flight hide the chain)
-        uint32_t bk = 0xFFFFFFFFu;
+        uint32_t bk = MATCH_NONE;                          // (dist << 22) | keypoint
+        for (int r0 = blockIdx.y * MW * MT; r0 < nkp; r0 += gridDim.y * MW * MT) {
+            const int t0 = r0 + wave * MT;                  // this wave's tile of the round
+            const int nt = max(0, min(MT, nkp - t0));
+            if (nt > 0) {                                   // wave-uniform
+                const uint4* src = (const uint4*)(fdesc + (size_t)t0 * 8);
+                if (lane < nt) { s_train[wave][2 * lane] = src[2 * lane]; s_train[wave][2 * lane + 1] = src[2 * lane + 1]; }
+            }
+            __syncthreads();
+            // distance and tile-local index travel as one key (dist << 6 | t): a single v_min keeps the first minimum;
+            // the eight popcounts are chained through v_bcnt's accumulate operand (two pairs in flight hide the chain)
+            uint32_t tk = 0xFFFFFFFFu;
 #pragma unroll 2
-        for (int t = 0; t < nt; ++t) {
-            const uint4 a = s_train[2 * t], b = s_train[2 * t + 1];
-            uint32_t h;
-            asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(h) : "v"(qa.x ^ a.x), "v"((uint32_t)t));      // seeds the sum with t
-            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h) : "v"(qa.y ^ a.y));
-            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h) : "v"(qa.z ^ a.z));
-            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h) : "v"(qa.w ^ a.w));
-            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h) : "v"(qb.x ^ b.x));
-            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h) : "v"(qb.y ^ b.y));
-            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h) : "v"(qb.z ^ b.z));
-            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h) : "v"(qb.w ^ b.w));
-            // h = dist + t  ->  key = (dist << 6) | t = ((h - t) << 6) + t = (h << 6) - 63 t
-            bk = min(bk, (h << 6) - 63u * (uint32_t)t);
+            for (int t = 0; t < nt; ++t) {
+                const uint4 a = s_train[wave][2 * t], b = s_train[wave][2 * t + 1];
+                uint32_t h;
+                asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(h) : "v"(qa.x ^ a.x), "v"((uint32_t)t));      // seeds the sum with t
+                asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h) : "v"(qa.y ^ a.y));
+                asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h) : "v"(qa.z ^ a.z));
+                asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h) : "v"(qa.w ^ a.w));
+                asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h) : "v"(qb.x ^ b.x));
+                asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h) : "v"(qb.y ^ b.y));
+                asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h) : "v"(qb.z ^ b.z));
+                asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h) : "v"(qb.w ^ b.w));
+                // h = dist + t  ->  key = (dist << 6) | t = ((h - t) << 6) + t = (h << 6) - 63 t
+                tk = min(tk, (h << 6) - 63u * (uint32_t)t);
+            }
+            if (nt > 0) bk = min(bk, ((tk >> 6) << 22) | (uint32_t)(t0 + (int)(tk & 63u)));    // tiles ascend: first minimum wins
+            __syncthreads();
         }
-        const uint32_t bd = bk >> 6, bi = bk & 63u;
-        atomicMin(&best[q], (bd << 22) | (uint32_t)(t0 + (int)bi));
+        s_part[wave][lane] = bk;
+        __syncthreads();
+        if (wave == 0) {
+            uint32_t m = s_part[0][lane];
+#pragma unroll
+            for (int w = 1; w < MW; ++w) m = min(m, s_part[w][lane]);
+            if (c0 + lane < ncand && m != MATCH_NONE) atomicMin(&best[q], m);
+        }
+        __syncthreads();
     }
 }
 
@@ -161,9 +184,9 @@ __device__ __forceinline__ int block_excl_scan_flag(bool flag, int* s_w, int& to
 // staged in LDS with coalesced loads (packed to 32 bit); then every thread owns one contiguous
 // segment of the active list, so the output order is the list order with a single block scan.
 #define GATE_LDS_MAX 36864          // entries (144 KiB)
-__global__ __launch_bounds__(1024) void k_match_gate(ChainBuf cb, const int32_t* __restrict__ active, int n_active, const double* __restrict__ map_pos,
-                                                     float ratio, float floor_dist, int cap, int use_lds) {
-    LANE_PTRS(cb)
+__global__ __launch_bounds__(1024) void k_match_gate(const LaneDesc* __restrict__ lanes, float ratio, float floor_dist) {
+    LANE_PTRS(lanes)
+    const int n_active = ld_.n_active, cap = ld_.cap, use_lds = ld_.gate_lds;
     extern __shared__ uint32_t s_pk[];
     __shared__ int s_w[16];
     __shared__ int s_min;
@@ -242,8 +265,9 @@ __global__ __launch_bounds__(1024) void k_match_gate(ChainBuf cb, const int32_t*
 }
 
 // match records + float32 correspondence pairs of the kept queries (list written by k_match_gate), by output position
-__global__ __launch_bounds__(256) void k_match_emit(ChainBuf cb, const int32_t* __restrict__ active, const double* __restrict__ map_pos) {
-    LANE_PTRS(cb)
+__global__ __launch_bounds__(256) void k_match_emit(const LaneDesc* __restrict__ lanes) {
+    LANE_PTRS(lanes)
+    const int32_t* __restrict__ active = ld_.active; const double* __restrict__ map_pos = ld_.map_pos;
     const int nout = tr->n_match;
     for (int p = blockIdx.x * 256 + threadIdx.x; p < nout; p += gridDim.x * 256) {
         const int q = cand[p];
@@ -392,9 +416,9 @@ __device__ __forceinline__ bool reproj_ok_dev(const CamD& cam, const double* T, 
     return du * du + dv * dv <= thr2 * (pc.z * pc.z);
 }
 
-__global__ __launch_bounds__(64) void k_ransac_hyp(CamD cam, ChainBuf cb, int n_hyp) {
-    LANE_PTRS(cb)
-    const uint64_t seed = cb.seed[lane_];
+__global__ __launch_bounds__(64) void k_ransac_hyp(const LaneDesc* __restrict__ lanes, int n_hyp, int pass) {
+    LANE_PTRS(lanes)
+    const uint64_t seed = ld_.seed + (uint64_t)pass;
     const int h = blockIdx.x * 64 + threadIdx.x;
     if (h >= n_hyp) return;
     const int n = tr->n_match;
@@ -423,8 +447,8 @@ __global__ __launch_bounds__(64) void k_ransac_hyp(CamD cam, ChainBuf cb, int n_
     hyp_cnt[h] = 0;
 }
 
-__global__ __launch_bounds__(1024) void k_ransac_score(CamD cam, ChainBuf cb, int n_hyp, double thr2) {
-    LANE_PTRS(cb)
+__global__ __launch_bounds__(1024) void k_ransac_score(const LaneDesc* __restrict__ lanes, int n_hyp, double thr2) {
+    LANE_PTRS(lanes)
     __shared__ int s_cnt;
     const int h = blockIdx.x;
     if (hyp_cnt[h] < 0) return;
@@ -452,8 +476,8 @@ __device__ __forceinline__ int ransac_update_iters_dev(double conf, int n_pts, i
     return k;
 }
 
-__global__ __launch_bounds__(1024) void k_ransac_select(CamD cam, ChainBuf cb, int n_hyp, double thr2, double conf) {
-    LANE_PTRS(cb)
+__global__ __launch_bounds__(1024) void k_ransac_select(const LaneDesc* __restrict__ lanes, int n_hyp, double thr2, double conf) {
+    LANE_PTRS(lanes)
     __shared__ int s_w[16];
     __shared__ int s_best;
     const int n = tr->n_match;
@@ -737,8 +761,8 @@ __device__ __forceinline__ double edge_chi2_dev(const CamD& cam, const double* T
     return e0 * e0 + e1 * e1;
 }
 
-__global__ __launch_bounds__(LM_T) void k_pose_lm(CamD cam, ChainBuf cb, double delta, double cut, int it_r, int it_p, int write_flags) {
-    LANE_PTRS(cb)
+__global__ __launch_bounds__(LM_T) void k_pose_lm(const LaneDesc* __restrict__ lanes, double delta, double cut, int it_r, int it_p, int write_flags) {
+    LANE_PTRS(lanes)
     const int32_t* edges = inliers;
     if (!write_flags) matches = nullptr;
     const int32_t* edges_g = edges;
@@ -842,29 +866,32 @@ int vo_track_set_attrs() {
 
 static CamD cam_of(const vo_ctx* c) { CamD k; k.fx = c->p.fx; k.fy = c->p.fy; k.cx = c->p.cx; k.cy = c->p.cy; k.W = c->p.width; k.H = c->p.height; return k; }
 
-static ChainBuf chain_of(vo_ctx* c, int nl, const int* slots, const uint64_t* seeds) {
-    ChainBuf cb = c->chain;
-    for (int i = 0; i < nl; ++i) { cb.slot[i] = slots ? slots[i] : 0; cb.seed[i] = seeds ? seeds[i] : 0; }
-    return cb;
+// Descriptor of lane `lane` of context c, tracking the frame in slot `slot`; d_tr = where the lane's result header lives.
+void vo_lane_fill(vo_ctx* c, int lane, int slot, uint64_t seed, TrackDev* d_tr, LaneDesc* o) {
+    const size_t M = c->lane_stride, L = (size_t)lane;
+    o->tr = d_tr; o->best = c->d_best + L * M; o->cand = c->d_mcand + L * M; o->matches = c->d_matches + L * M;
+    o->cxyz = c->d_corr_xyz + 3 * L * M; o->cuv = c->d_corr_uv + 2 * L * M;
+    o->hyp_pose = c->d_hyp_pose + (size_t)12 * L * c->p.max_hypotheses; o->hyp_cnt = c->d_hyp_cnt + L * c->p.max_hypotheses;
+    o->inliers = c->d_inliers + L * M; o->mask = c->d_lm_mask + L * M;
+    o->fdesc = (const uint32_t*)(c->d_desc + (size_t)slot * c->plan.nfeat * 32); o->nkp = c->d_nkp + slot; o->kps = c->d_kps + (size_t)slot * c->plan.nfeat;
+    o->map_pos = c->d_map_pos; o->map_nrm = c->d_map_nrm; o->map_flags = c->d_map_flags; o->map_desc = c->d_map_desc; o->active = c->d_active;
+    o->n_active = c->n_active; o->cap = c->corr_cap; o->max_hyp = c->p.max_hypotheses; o->gate_lds = c->n_active <= GATE_LDS_MAX ? 1 : 0;
+    o->seed = seed; o->cam = cam_of(c);
 }
 
-int vo_track_match_launch(vo_ctx* c, int nl, const int* slots, float ratio, float floor_dist) {
-    hipStream_t st = c->stream;
-    const int na = c->n_active;
-    c->corr_external = false;
-    const ChainBuf cb = chain_of(c, nl, slots, nullptr);
+int vo_track_match_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* dl, int nl, ChainDims dims, float ratio, float floor_dist) {
+    const int na = dims.max_active;
     if (na > 0) {
-        { ProfScope ps(c, "k_frustum");
-          hipLaunchKernelGGL(k_frustum, dim3((na + 255) / 256, 1, nl), dim3(256), 0, st, cam_of(c), cb, c->d_map_pos, c->d_map_nrm, c->d_map_flags, c->d_active, na); }
-        ProfScope ps(c, "k_match");
-        dim3 g(std::min((na + MQ - 1) / MQ, MATCH_GRID_X), (c->p.n_features + MT - 1) / MT, nl);
-        hipLaunchKernelGGL(k_match, g, dim3(64), 0, st, cb, c->d_map_desc, c->d_active);
+        { ProfScope ps(prof, "k_frustum", st);
+          hipLaunchKernelGGL(k_frustum, dim3((na + 255) / 256, 1, nl), dim3(256), 0, st, dl); }
+        ProfScope ps(prof, "k_match", st);
+        const int ksplit = std::max(1, std::min(4, (dims.max_feat + MW * MT - 1) / (MW * MT)));      // keypoint rounds (8 tiles = 512 keypoints) spread over up to 4 workgroups
+        hipLaunchKernelGGL(k_match, dim3(std::min((na + MQ - 1) / MQ, MATCH_GRID_X), ksplit, nl), dim3(64 * MW), 0, st, dl);
     }
-    { ProfScope ps(c, "k_match_gate");
-      const int use_lds = na <= GATE_LDS_MAX ? 1 : 0;
-      hipLaunchKernelGGL(k_match_gate, dim3(1, 1, nl), dim3(1024), use_lds ? sizeof(uint32_t) * (((size_t)na + 3) & ~(size_t)3) : 0, st, cb, c->d_active, na, c->d_map_pos,
-                         ratio, floor_dist, c->corr_cap, use_lds);
-      if (na > 0) hipLaunchKernelGGL(k_match_emit, dim3(32, 1, nl), dim3(256), 0, st, cb, c->d_active, c->d_map_pos); }
+    { ProfScope ps(prof, "k_match_gate", st);
+      const size_t lds = sizeof(uint32_t) * (((size_t)std::min(na, GATE_LDS_MAX) + 3) & ~(size_t)3);
+      hipLaunchKernelGGL(k_match_gate, dim3(1, 1, nl), dim3(1024), lds, st, dl, ratio, floor_dist); }
+    if (na > 0) { ProfScope ps(prof, "k_match_emit", st); hipLaunchKernelGGL(k_match_emit, dim3(32, 1, nl), dim3(256), 0, st, dl); }
     HIP_TRY(hipGetLastError());
     return VO_OK;
 }
@@ -878,34 +905,30 @@ int vo_corr_from_host(vo_ctx* c, const float* xyz, const float* uv, int n) {
         HIP_TRY(hipStreamSynchronize(st));                  // the staging buffer may still feed an earlier vo_map_upsert
         memcpy(stage, xyz, sizeof(float) * 3 * (size_t)n);
         memcpy(stage + 3 * (size_t)n, uv, sizeof(float) * 2 * (size_t)n);
-        HIP_TRY(hipMemcpyAsync(c->chain.cxyz, stage, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(c->chain.cuv, stage + 3 * (size_t)n, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(c->d_corr_xyz, stage, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(c->d_corr_uv, stage + 3 * (size_t)n, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, st));
     }
-    hipLaunchKernelGGL(k_set_nmatch, dim3(1), dim3(1), 0, st, c->chain.tr, n);
+    hipLaunchKernelGGL(k_set_nmatch, dim3(1), dim3(1), 0, st, c->d_track, n);
     HIP_TRY(hipStreamSynchronize(st));      // staging buffer is reused by later calls
     c->corr_external = true;
     return VO_OK;
 }
 
-int vo_track_ransac_launch(vo_ctx* c, int nl, int n_hyp, float reproj_px, float conf, const uint64_t* seeds) {
-    hipStream_t st = c->stream;
-    const CamD cam = cam_of(c);
+int vo_track_ransac_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* dl, int nl, int n_hyp, float reproj_px, float conf, int pass) {
     const double thr2 = (double)reproj_px * (double)reproj_px;
-    const ChainBuf cb = chain_of(c, nl, nullptr, seeds);
-    { ProfScope ps(c, "k_ransac_hyp");
-      hipLaunchKernelGGL(k_ransac_hyp, dim3((n_hyp + 63) / 64, 1, nl), dim3(64), 0, st, cam, cb, n_hyp); }
-    { ProfScope ps(c, "k_ransac_score");
-      hipLaunchKernelGGL(k_ransac_score, dim3(n_hyp, 1, nl), dim3(1024), 0, st, cam, cb, n_hyp, thr2); }
-    { ProfScope ps(c, "k_ransac_select");
-      hipLaunchKernelGGL(k_ransac_select, dim3(1, 1, nl), dim3(1024), 0, st, cam, cb, n_hyp, thr2, (double)conf); }
+    { ProfScope ps(prof, "k_ransac_hyp", st);
+      hipLaunchKernelGGL(k_ransac_hyp, dim3((n_hyp + 63) / 64, 1, nl), dim3(64), 0, st, dl, n_hyp, pass); }
+    { ProfScope ps(prof, "k_ransac_score", st);
+      hipLaunchKernelGGL(k_ransac_score, dim3(n_hyp, 1, nl), dim3(1024), 0, st, dl, n_hyp, thr2); }
+    { ProfScope ps(prof, "k_ransac_select", st);
+      hipLaunchKernelGGL(k_ransac_select, dim3(1, 1, nl), dim3(1024), 0, st, dl, n_hyp, thr2, (double)conf); }
     HIP_TRY(hipGetLastError());
     return VO_OK;
 }
 
-int vo_track_lm_launch(vo_ctx* c, int nl, double delta, double cut, int it_r, int it_p, bool write_flags) {
-    ProfScope ps(c, "k_pose_lm");
-    const ChainBuf cb = chain_of(c, nl, nullptr, nullptr);
-    hipLaunchKernelGGL(k_pose_lm, dim3(1, 1, nl), dim3(LM_T), LM_LDS_MAX * 20, c->stream, cam_of(c), cb, delta, cut, it_r, it_p, write_flags ? 1 : 0);
+int vo_track_lm_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* dl, int nl, double delta, double cut, int it_r, int it_p, bool write_flags) {
+    ProfScope ps(prof, "k_pose_lm", st);
+    hipLaunchKernelGGL(k_pose_lm, dim3(1, 1, nl), dim3(LM_T), LM_LDS_MAX * 20, st, dl, delta, cut, it_r, it_p, write_flags ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return VO_OK;
 }

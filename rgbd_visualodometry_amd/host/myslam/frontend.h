@@ -33,6 +33,7 @@ public:
     int PrefetchFrames(const std::vector<Frame::Ptr>& frames);
 
     vo_ctx* GetContext() const { return ctx_; }
+    void JoinGroup(vo_group* g);         // this stream's tracking calls share launch chains with the group's other streams
     struct Stats { int frames = 0, keyframes = 0, lost = 0; int last_candidates = 0, last_matches = 0, last_ransac = 0, last_lm = 0, last_keypoints = 0;
                    double ms_extract = 0, ms_track = 0, ms_keyframe = 0, ms_backend = 0, ms_refresh = 0, ms_flush = 0;
                    long long tracked = 0, sum_active = 0, sum_cand = 0, sum_match = 0, sum_ransac = 0, sum_lm = 0, sum_lm_iters = 0, track_launches = 0; };
@@ -50,6 +51,7 @@ private:
     bool         trackingMapChanged_ = true;
 
     vo_ctx*                 ctx_ = nullptr;
+    vo_group*               group_ = nullptr;
     int                     device_ = 0;
     vo_params               params_;
     vo_track_params         trackParams_;

@@ -59,7 +59,9 @@ void FrontEnd::Init(int device, int width, int height, int max_frames) {
     if (backend_) backend_->SetContext(ctx_, device_);
 }
 
-FrontEnd::~FrontEnd() { if (ctx_) vo_ctx_destroy(ctx_); }
+FrontEnd::~FrontEnd() { if (ctx_) { if (group_) vo_group_leave(group_, ctx_); vo_ctx_destroy(ctx_); } }
+
+void FrontEnd::JoinGroup(vo_group* g) { vo_check(vo_group_join(g, ctx_), "vo_group_join"); group_ = g; }
 
 bool FrontEnd::AddFrame(const Frame::Ptr frame) {
     if (verbose_) std::cout << "Frontend status: " << (state_ == INITIALIZING ? "Initializing" : state_ == TRACKING ? "Tracking" : "Lost") << std::endl;

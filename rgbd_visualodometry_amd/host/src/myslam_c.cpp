@@ -123,6 +123,22 @@ int myslam_add_frame(myslam_system* s, double stamp, const void* bgr, const void
     });
 }
 
+struct myslam_group { vo_group* g = nullptr; };
+int myslam_group_create(int device, int max_lanes, myslam_group** out) {
+    if (!out) return -1;
+    myslam_group* g = new myslam_group();
+    int rc = vo_group_create(device, max_lanes, &g->g);
+    if (rc != VO_OK) { g_err = std::string("vo_group_create failed: ") + vo_strerror(rc); delete g; return -1; }
+    *out = g;
+    return 0;
+}
+void myslam_group_destroy(myslam_group* g) { if (g) { vo_group_destroy(g->g); delete g; } }
+int myslam_group_join(myslam_group* g, myslam_system* s) {
+    if (!g || !s) return -1;
+    return guarded(s, [&]() { s->frontend->JoinGroup(g->g); });
+}
+int myslam_group_stats(myslam_group* g, int64_t* chains, int64_t* lanes, int64_t* requests) { return g ? vo_group_stats(g->g, chains, lanes, requests) : -1; }
+
 int myslam_flush(myslam_system* s) {
     if (!s) return -1;
     return guarded(s, [&]() { if (s->backend) s->backend->Flush(); });

@@ -44,7 +44,8 @@ class Stats(C.Structure):
 
 
 SYMBOLS = ["myslam_default_options", "myslam_system_create", "myslam_system_destroy", "myslam_prefetch",
-           "myslam_add_frame", "myslam_add_prefetched", "myslam_get_stats", "myslam_flush", "myslam_get_context", "myslam_last_error", "myslam_backend_name",
+           "myslam_add_frame", "myslam_add_prefetched", "myslam_get_stats", "myslam_flush",
+           "myslam_group_create", "myslam_group_destroy", "myslam_group_join", "myslam_group_stats", "myslam_get_context", "myslam_last_error", "myslam_backend_name",
            # taps for parity tests (include/myslam_c.h)
            "myslam_triangulate", "myslam_se3_log", "myslam_se3_exp", "myslam_keyframe_policy", "myslam_scn_add_keyframe", "myslam_scn_add_mappoint",
            "myslam_scn_observe", "myslam_scn_unobserve", "myslam_scn_covisibility", "myslam_scn_local_map", "myslam_scn_ba_graph", "myslam_scn_mappoint",
@@ -70,6 +71,11 @@ def _load(path: str):
         lib.myslam_add_prefetched.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
         lib.myslam_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         lib.myslam_flush.argtypes = [C.c_void_p]
+        lib.myslam_group_create.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        lib.myslam_group_destroy.argtypes = [C.c_void_p]
+        lib.myslam_group_destroy.restype = None
+        lib.myslam_group_join.argtypes = [C.c_void_p, C.c_void_p]
+        lib.myslam_group_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.myslam_triangulate.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         lib.myslam_se3_log.argtypes = [C.c_void_p, C.c_void_p]
         lib.myslam_se3_exp.argtypes = [C.c_void_p, C.c_void_p]
@@ -111,6 +117,30 @@ def se3_exp(lib_path: Optional[str], d6) -> np.ndarray:
     lib = _load(lib_path or HOST_LIB); d = np.ascontiguousarray(d6, dtype=np.float64).reshape(6); T = np.zeros(12)
     lib.myslam_se3_exp(d.ctypes.data, T.ctypes.data)
     return T
+
+
+class StreamGroup:
+    """Several VoSystems (independent streams) on one GPU whose tracking shares launch chains; drive each member from its own thread."""
+
+    def __init__(self, lib_path: Optional[str] = None, device: int = 0, max_lanes: int = 64):
+        self.lib = _load(lib_path or HOST_LIB)
+        self.h = C.c_void_p()
+        if self.lib.myslam_group_create(device, max_lanes, C.byref(self.h)) != 0:
+            raise RuntimeError("myslam_group_create failed: %s" % self.lib.myslam_last_error().decode())
+
+    def join(self, system: "VoSystem"):
+        if self.lib.myslam_group_join(self.h, system.h) != 0:
+            raise RuntimeError("myslam_group_join failed: %s" % self.lib.myslam_last_error().decode())
+
+    def stats(self) -> dict:
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self.lib.myslam_group_stats(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return {"chains": a.value, "lanes": b.value, "requests": c.value}
+
+    def close(self):
+        if self.h:
+            self.lib.myslam_group_destroy(self.h)
+            self.h = C.c_void_p()
 
 
 class VoSystem:

@@ -73,4 +73,11 @@ def test_run_vo_on_gpu_matches_oracle_driver(tum_dir, tmp_path):
     np.testing.assert_allclose(pa, pb, atol=2e-5)           # text output has 6 significant digits
     (tmp_path / "l").mkdir()
     c, log = run_driver(HIP_BIN, root, str(tmp_path / "l"), number_of_features=800, lookahead_frames=8, decode_threads=4, track_batch=4)
-    assert "lookahead 8" in log and sorted(c) == sorted(a) and all(c[k] == a[k] for k in a)
+    assert "lookahead 8" in log and sorted(c) == sorted(a)
+    pc = np.array([[float(v) for v in c[k]] for k in sorted(c)])
+    # same trajectory up to the summation order of the local BA's f64 atomics (run-to-run differences of ~1e-9 on the GPU)
+    np.testing.assert_allclose(pc, pa, atol=1e-7)
+    (tmp_path / "n1").mkdir(); (tmp_path / "n2").mkdir()
+    d1, _ = run_driver(HIP_BIN, root, str(tmp_path / "n1"), number_of_features=800, enable_local_optimization=0)
+    d2, _ = run_driver(HIP_BIN, root, str(tmp_path / "n2"), number_of_features=800, enable_local_optimization=0, lookahead_frames=8, decode_threads=4, track_batch=4)
+    assert all(d1[k] == d2[k] for k in d1)                   # without the BA the tracking chain is bit-reproducible

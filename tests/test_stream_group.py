@@ -1,0 +1,146 @@
+"""Stream groups (include/vo_hip.h vo_group_*, include/myslam_c.h myslam_group_*): the tracking calls of several
+independent streams on one GPU fused into one launch chain must give exactly the results of un-grouped calls."""
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import ORACLE_LIB
+from rgbd_visualodometry_amd import capi, system
+
+LIBS = [pytest.param((ORACLE_LIB, ORACLE_LIB), id="cpu-oracle"),
+        pytest.param((capi.HIP_LIB, system.HOST_LIB), id="hip", marks=pytest.mark.gpu)]
+FIELDS = ("n_candidates", "n_matches", "n_ransac_inliers", "n_lm_inliers", "min_distance", "ransac_iters", "best_hypothesis", "lm_iters", "status")
+
+
+def inv12(T):
+    R = np.array(T[:9]).reshape(3, 3); t = np.array(T[9:12])
+    return np.concatenate([R.T.reshape(9), -R.T @ t])
+
+
+def seed_map(ctx, p, kps, desc, T_wc):
+    ok = kps["depth_raw"] > 0
+    z = kps["depth_raw"][ok].astype(np.float64) / p.depth_scale
+    pc = np.stack([(kps["x"][ok] - p.cx) * z / p.fx, (kps["y"][ok] - p.cy) * z / p.fy, z], 1)
+    R = np.array(T_wc[:9]).reshape(3, 3); t = np.array(T_wc[9:12])
+    pw = pc @ R.T + t
+    nrm = pw - t
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    idx = np.arange(len(pw), dtype=np.int32)
+    ctx.map_upsert(idx, pw, nrm, desc[ok], np.zeros(len(pw), np.uint8))
+    ctx.map_set_active(idx)
+
+
+@pytest.fixture(scope="module")
+def streams():
+    syn = capi.Synth()
+    return [syn.render(syn.params(seed=60 + k), 0, 9, threads=8) for k in range(3)]
+
+
+@pytest.mark.parametrize("libs", LIBS)
+def test_group_chain_equals_ungrouped_calls(libs, streams):
+    """Three contexts with different frames, maps, feature counts and batch sizes: one fused chain (the leader waits until
+    all three requests are pending) returns what the three un-grouped vo_track_batch calls return, bit for bit."""
+    L = capi.load(libs[0])
+    feats, lanes = (1000, 600, 800), (3, 1, 2)
+    ctxs, args = [], []
+    for k, (bgr, depth, Twc, _) in enumerate(streams):
+        p = L.default_params(n_features=feats[k], max_frames=4, map_capacity=8192, max_track_batch=4)
+        ctx = L.context(p)
+        for s in range(4):
+            ctx.upload(s, bgr[2 * s], depth[2 * s])
+        ctx.orb(0, 4)
+        k0, d0 = ctx.orb_fetch(0)
+        seed_map(ctx, p, k0, d0, Twc[0])
+        ctxs.append(ctx)
+        args.append((list(range(1, 1 + lanes[k])), inv12(Twc[0]), [7 * k + j + 1 for j in range(lanes[k])]))
+    tp = L.default_track_params()
+    want = [ctx.track_batch_deferred(a[0], a[1], tp, a[2], cap=4096) for ctx, a in zip(ctxs, args)]
+    grp = capi.VoGroup(L, 0, max_lanes=16)
+    for ctx in ctxs:
+        grp.join(ctx)
+    grp.set_gather(3, 5_000_000)
+    got = [None] * 3
+
+    def run(k):
+        got[k] = ctxs[k].track_batch_deferred(args[k][0], args[k][1], tp, args[k][2], cap=4096)
+    ths = [threading.Thread(target=run, args=(k,)) for k in range(3)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    st = grp.stats()
+    if libs[0] != ORACLE_LIB:
+        assert st == {"chains": 1, "lanes": 6, "requests": 3}
+    for k in range(3):
+        (rw, mw), (rg, mg) = want[k], got[k]
+        for j in range(lanes[k]):
+            for f in FIELDS:
+                assert getattr(rg[j], f) == getattr(rw[j], f), (k, j, f)
+            assert np.array_equal(np.array(rg[j].T_cw), np.array(rw[j].T_cw))
+            assert np.array_equal(mg[j], mw[j]) and len(mg[j]) > 50
+    # a second round without gathering: whatever the interleaving, results stay the same
+    grp.set_gather(1, 0)
+    ths = [threading.Thread(target=run, args=(k,)) for k in range(3)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for k in range(3):
+        for j in range(lanes[k]):
+            assert np.array_equal(np.array(got[k][0][j].T_cw), np.array(want[k][0][j].T_cw))
+    for ctx in ctxs:
+        grp.leave(ctx)
+    after = ctxs[0].track_batch_deferred(args[0][0], args[0][1], tp, args[0][2], cap=4096)     # un-grouped again
+    assert np.array_equal(np.array(after[0][0].T_cw), np.array(want[0][0][0].T_cw))
+    for ctx in ctxs:
+        ctx.close()
+    grp.close()
+
+
+@pytest.mark.parametrize("libs", LIBS)
+def test_grouped_systems_track_like_separate_systems(libs, streams):
+    """Through the libmyslam-style host layer: three streams driven from three threads in one group give the trajectories
+    of three separately driven systems (keyframes, local BA, look-ahead and speculative batches included)."""
+    host = libs[1]
+    opts = dict(number_of_features=600, max_frames_in_flight=3, track_batch=3, backend_lag_frames=2)
+
+    def drive(s, k, out):
+        bgr, depth, _, ts = streams[k]
+        n, i = len(ts), 0
+        while i < n:
+            m = min(3, n - i)
+            s.prefetch(ts[i:i + m], [bgr[j].ctypes.data for j in range(i, i + m)], [depth[j].ctypes.data for j in range(i, i + m)],
+                       bgr[0].strides[0], depth[0].strides[0], False)
+            for _ in range(m):
+                out.append(s.add_prefetched()[1])
+            i += m
+        s.flush()
+
+    want = []
+    for k in range(3):
+        s = system.VoSystem(host, **opts)
+        o = []
+        drive(s, k, o)
+        want.append((np.array(o), s.stats()))
+        s.close()
+    grp = system.StreamGroup(host, 0, 32)
+    syss = [system.VoSystem(host, **opts) for _ in range(3)]
+    for s in syss:
+        grp.join(s)
+    outs = [[] for _ in range(3)]
+    ths = [threading.Thread(target=drive, args=(syss[k], k, outs[k])) for k in range(3)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for k in range(3):
+        st = syss[k].stats()
+        assert st["keyframes"] == want[k][1]["keyframes"] and st["map_points"] == want[k][1]["map_points"] and st["ba_runs"] == want[k][1]["ba_runs"]
+        np.testing.assert_allclose(np.array(outs[k]), want[k][0], atol=1e-7)     # local BA: f64 atomics, ~1e-9 run to run
+    gs = grp.stats()
+    if host != ORACLE_LIB:
+        assert gs["requests"] >= 3 * 3 and gs["chains"] <= gs["requests"]
+    for s in syss:
+        s.close()
+    grp.close()
