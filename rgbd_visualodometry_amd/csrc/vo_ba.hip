@@ -38,10 +38,13 @@ struct BaBlock { int j1, j2, start, count; };      // one 6x6 block of the reduc
 struct BaCtl {
     double lambda, ni, cur;
     int it, qmax, max_it, need_lin, first, finished, buf, iters_done, steps, arrived;
+    int robust, pad;                 // Huber kernel on (round 1) / off (round 2): backend.cpp:138-160
 };
 
 struct BaDev {
     int n_poses, n_free, n_points, n_edges, D, n_blocks;
+    int gp;                                                  // point workgroups of the 4-lanes-per-point kernels (64 points each)
+    BaCam cam; double delta, chi2_th;
     BaCtl* ctl;
     double* posesA; double* ptsA; double* posesB; double* ptsB;      // double-buffered state, ctl->buf selects the current one
     const int32_t* e_pose; const int32_t* e_pt; const float* e_uv; uint8_t* active; uint8_t* flags;
@@ -54,6 +57,13 @@ struct BaDev {
     double* partU; double* partC; int nU;   // per-workgroup partial sums (no same-address atomics): update {gain term, max step} x nU, trial chi2 x grid of k_ba_chi_control
     double* scal;       // [0] chi cur  [1] chi trial  [2] scale  [3] ok  [4] maxdiag (as u64 bits) [5] chi report [6] chi final
 };
+
+// One launch serves every active problem of a batch (blockIdx.z): the local BAs of several streams step through the same
+// kernel sequence, each with its own state, control block and sizes; grids are sized for the largest problem and every
+// kernel trims to its own problem's extent.
+#define BA_SLOTS 16
+struct BaBatch { const BaDev* Bs; int n; int slot[BA_SLOTS]; };
+#define BA_PROBLEM(Q) const BaDev& B = Q.Bs[Q.slot[blockIdx.z]];
 
 #define BA_STATE(B) \
     const int buf_ = B.ctl->buf; \
@@ -203,15 +213,18 @@ __device__ __forceinline__ void ba_lin_poses_body(const BaCam& cam, const BaDev&
     }
 }
 
-__global__ __launch_bounds__(256) void k_ba_lin(BaCam cam, BaDev B, int robust, double delta, int gp) {
+__global__ __launch_bounds__(256) void k_ba_lin(BaBatch Q) {
+    BA_PROBLEM(Q)
     if (B.ctl->finished || !B.ctl->need_lin) return;
     BA_STATE(B)
     __shared__ double s_part[4 * 32];
-    if ((int)blockIdx.x < gp) ba_lin_points_body(cam, B, robust, delta, blockIdx.x, poses_c, pts_c, s_part);
-    else ba_lin_poses_body(cam, B, robust, delta, blockIdx.x - gp, poses_c, pts_c, s_part);
+    const int gp = B.gp, robust = B.ctl->robust;
+    if ((int)blockIdx.x < gp) ba_lin_points_body(B.cam, B, robust, B.delta, blockIdx.x, poses_c, pts_c, s_part);
+    else if ((int)blockIdx.x - gp < B.n_free * PSPLIT) ba_lin_poses_body(B.cam, B, robust, B.delta, blockIdx.x - gp, poses_c, pts_c, s_part);
 }
 
-__global__ void k_ba_maxdiag(BaDev B) {
+__global__ void k_ba_maxdiag(BaBatch Q) {
+    BA_PROBLEM(Q)
     if (B.ctl->finished || !B.ctl->need_lin || !B.ctl->first) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     double v = 0;
@@ -224,7 +237,8 @@ __global__ void k_ba_maxdiag(BaDev B) {
 }
 
 // S = blockdiag(H_pp) + lambda I, b_s = b_p, and (H_ll + lambda I)^-1 per point
-__global__ void k_ba_init_S(BaDev B) {
+__global__ void k_ba_init_S(BaBatch Q) {
+    BA_PROBLEM(Q)
     if (B.ctl->finished) return;
     // first step of a round: lambda = 1e-5 * max diag(H) (g2o computeLambdaInit); the control block is updated later in
     // this step by the Cholesky kernel's prologue, so every lane derives the same value here
@@ -257,11 +271,12 @@ __global__ void k_ba_init_S(BaDev B) {
 // Schur complement, one wavefront per 6x6 block (j1 <= j2) of the reduced system:
 //   S[j1][j2] -= sum over points seen by both poses of W_e1 (H_ll+lambda)^-1 W_e2^T       (no atomics)
 // Diagonal blocks also produce b_s[j] = b_p[j] - sum W_e (H_ll+lambda)^-1 b_l.
-__global__ __launch_bounds__(256) void k_ba_schur_blocks(BaDev B) {
+__global__ __launch_bounds__(256) void k_ba_schur_blocks(BaBatch Q) {
+    BA_PROBLEM(Q)
     if (B.ctl->finished) return;
     __shared__ double s_part[4 * 42];
     __shared__ double s_tot[42];
-    if (B.n_slices && (int)blockIdx.x >= *B.n_slices) return;
+    if ((int)blockIdx.x >= B.n_blocks || (B.n_slices && (int)blockIdx.x >= *B.n_slices)) return;
     const BaBlock blk = B.blocks[blockIdx.x];
     const bool diag = blk.j1 == blk.j2;
     double v[42];
@@ -541,8 +556,9 @@ __device__ __forceinline__ bool ch_factor_block(double (&a)[CH_NB], double* s_L,
     return ok;
 }
 
-__global__ __launch_bounds__(CH_THREADS) void k_ba_chol16(BaDev B) {
-    if (B.ctl->finished) return;
+__global__ __launch_bounds__(CH_THREADS) void k_ba_chol16(BaBatch Q) {
+    BA_PROBLEM(Q)
+    if (B.ctl->finished || B.D > 192) return;                   // larger systems: k_ba_chol16g
     extern __shared__ double s_mem[];
     const int D = B.D, DA = D + 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15;
     const double* const A = B.S;
@@ -797,8 +813,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_ba_chol16(BaDev B) {
 // augmented rhs row, y / x and the pivots.  (A volatile pointer would make every access system-coherent, i.e. miss
 // every cache: 5x slower.  Workgroup-scope coherence needs nothing beyond the barriers: one CU, one L1.)
 #define CHG_TB 8
-__global__ __launch_bounds__(CH_THREADS) void k_ba_chol16g(BaDev B) {
-    if (B.ctl->finished) return;
+__global__ __launch_bounds__(CH_THREADS) void k_ba_chol16g(BaBatch Q) {
+    BA_PROBLEM(Q)
+    if (B.ctl->finished || B.D <= 192) return;
     extern __shared__ double s_mem[];
     const int D = B.D, DA = D + 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15;
     double* const S = B.S;              // plain accesses: the waves of one workgroup share the CU's L1, barriers order them
@@ -1047,17 +1064,21 @@ __device__ __forceinline__ void ba_pose_body(const BaDev& B, double lambda, int 
 }
 
 // trial state: new points (blocks [0, gp)) and new poses (blocks [gp, ...)), gain-ratio terms, max |step|
-__global__ void k_ba_update(BaDev B, int gp) {
+__global__ void k_ba_update(BaBatch Q) {
+    BA_PROBLEM(Q)
     if (B.ctl->finished) return;
     const double lambda = B.ctl->lambda;
     BA_STATE(B)
+    const int gp = B.gp;
     if ((int)blockIdx.x < gp) ba_backsub_body(B, lambda, blockIdx.x, pts_c, pts_t);
-    else ba_pose_body(B, lambda, blockIdx.x - gp, poses_c, poses_t);
+    else if (((int)blockIdx.x - gp) * (int)blockDim.x < B.n_poses) ba_pose_body(B, lambda, blockIdx.x - gp, poses_c, poses_t);
 }
 
 // chi2 of the current (trial = 0 -> scal[5]) or trial (-> scal[1]) state
-__global__ void k_ba_chi(BaCam cam, BaDev B, int trial, int robust, double delta, int guard) {
+__global__ void k_ba_chi(BaBatch Q, int trial, int robust, int guard) {
+    BA_PROBLEM(Q)
     if (guard && B.ctl->finished) return;
+    const BaCam cam = B.cam; const double delta = B.delta;
     BA_STATE(B)
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     double v = 0;
@@ -1078,8 +1099,12 @@ __global__ void k_ba_chi(BaCam cam, BaDev B, int trial, int robust, double delta
 // (OptimizationAlgorithmLevenberg::solve) on the control block and, when the step is accepted, clears
 // H_pp / b_p for the next linearisation.  Partial sums reach L2 through f64 atomics; the arrival counter is
 // taken after a device-scope fence (threadfence reduction).
-__global__ __launch_bounds__(256) void k_ba_chi_control(BaCam cam, BaDev B, int robust, double delta) {
+__global__ __launch_bounds__(256) void k_ba_chi_control(BaBatch Q) {
+    BA_PROBLEM(Q)
     if (B.ctl->finished) return;
+    const int nblk_e = (B.n_edges + 255) / 256;                 // this problem's share of the grid
+    if ((int)blockIdx.x >= nblk_e) return;
+    const BaCam cam = B.cam; const double delta = B.delta; const int robust = B.ctl->robust;
     BA_STATE(B)
     __shared__ int s_last;
     const int e = blockIdx.x * 256 + threadIdx.x;
@@ -1097,7 +1122,7 @@ __global__ __launch_bounds__(256) void k_ba_chi_control(BaCam cam, BaDev B, int 
     if (threadIdx.x == 0) {
         B.partC[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);       // one partial per workgroup, no same-address atomics
         __threadfence();
-        s_last = atomicAdd(&B.ctl->arrived, 1) == (int)gridDim.x - 1;
+        s_last = atomicAdd(&B.ctl->arrived, 1) == nblk_e - 1;
     }
     __syncthreads();
     if (!s_last) return;
@@ -1106,7 +1131,7 @@ __global__ __launch_bounds__(256) void k_ba_chi_control(BaCam cam, BaDev B, int 
         __threadfence();
         const volatile double* pc = B.partC; const volatile double* pu = B.partU;
         double a = 0, b = 0, m = 0;
-        for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) a += pc[i];
+        for (int i = threadIdx.x; i < nblk_e; i += 256) a += pc[i];
         for (int i = threadIdx.x; i < B.nU; i += 256) { b += pu[2 * i]; m = fmax(m, pu[2 * i + 1]); }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); m = fmax(m, __shfl_xor(m, o, 64)); }
@@ -1151,7 +1176,9 @@ __global__ __launch_bounds__(256) void k_ba_chi_control(BaCam cam, BaDev B, int 
 }
 
 // stage 0: cull after the robust round (bit0, deactivate); stage 1: flag level-0 outliers (bit1)
-__global__ void k_ba_cull(BaCam cam, BaDev B, int stage, double th) {
+__global__ void k_ba_cull(BaBatch Q, int stage) {
+    BA_PROBLEM(Q)
+    const BaCam cam = B.cam; const double th = B.chi2_th;
     BA_STATE(B)
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= B.n_edges) return;
@@ -1169,8 +1196,235 @@ int vo_ba_set_attrs() {
     return VO_OK;
 }
 
+// ---- the BA engine: continuous batching of local BAs ------------------------------------------------------------------
+// One engine per GPU and process.  A caller (vo_local_ba on any context of that GPU: the back-end workers of several
+// streams) prepares its problem on its own stream, hands it to the engine and sleeps.  The engine thread keeps up to
+// BA_SLOTS problems "in flight": every LM step is ONE sequence of launches over all active slots (blockIdx.z = slot), a
+// problem that arrives while others are being solved joins at the next chunk of steps, one that finishes its robust
+// round is culled and restarted for the plain round, one that finishes leaves -- none waits for the others.  So eight
+// streams' BAs cost about the latency of one (their kernels are small: a 6K x 6K Cholesky is one workgroup), where eight
+// HIP streams with ~120 tiny dependent launches each mostly serialise in the command processor.
+#include <condition_variable>
+#include <deque>
+struct BaJob {
+    vo_ctx* c = nullptr; const vo_ba_problem* in = nullptr; vo_ba_result* out = nullptr;
+    BaDev B;
+    int grid_lin = 0, grid_initS = 0, grid_upd = 0, grid_e = 0, grid_maxdiag = 0; size_t lds = 0;
+    int round = 0, cur_buf = 0, iters = 0, steps = 0, need_first = 0;
+    double chi0 = 0, chi_final = 0;
+    int rc = VO_OK; bool done = false;
+};
+struct BaEngine {
+    int device = 0, refs = 0;
+    hipStream_t st = nullptr;
+    BaDev* d_Bs = nullptr; BaDev* h_Bs = nullptr;           // [BA_SLOTS] problem descriptors: device / pinned mirror
+    BaCtl* d_ctl = nullptr; BaCtl* h_ctl = nullptr;         // [BA_SLOTS] control blocks: device / pinned read-back
+    BaCtl* h_up = nullptr;                                  // [BA_SLOTS] pinned staging of control-block uploads
+    double* h_mail = nullptr;                               // [BA_SLOTS][16] pinned: initial chi2, final scal
+    BaJob* slot[BA_SLOTS] = {};
+    std::mutex mu; std::condition_variable cv;
+    std::deque<BaJob*> pending;
+    std::thread th; bool quit = false;
+    long long n_steps = 0, n_slot_steps = 0, n_jobs = 0;
+};
+static std::mutex g_eng_mu;
+static std::vector<BaEngine*> g_engines;
+
+static BaBatch ba_batch_of(BaEngine* E, const int* slots, int n) {
+    BaBatch Q; Q.Bs = E->d_Bs; Q.n = n;
+    for (int i = 0; i < BA_SLOTS; ++i) Q.slot[i] = i < n ? slots[i] : 0;
+    return Q;
+}
+
+// start a round of LM iterations for the problem in slot s (stream order: after everything enqueued so far)
+static int ba_start_round(BaEngine* E, int s, int robust) {
+    BaJob* j = E->slot[s];
+    const int max_it = robust ? j->in->it_robust : j->in->it_plain;
+    BaCtl* h = E->h_up + s;
+    memset(h, 0, sizeof(BaCtl));
+    h->max_it = max_it; h->need_lin = 1; h->first = 1; h->buf = j->cur_buf; h->ni = 2; h->robust = robust;
+    if (max_it <= 0) h->finished = 1;
+    HIP_TRY(hipMemcpyAsync(E->d_ctl + s, h, sizeof(BaCtl), hipMemcpyHostToDevice, E->st));
+    HIP_TRY(hipMemsetAsync(j->B.scal, 0, 64, E->st));
+    HIP_TRY(hipMemsetAsync(j->B.Hpp, 0, sizeof(double) * 36 * (size_t)j->B.n_free, E->st));
+    HIP_TRY(hipMemsetAsync(j->B.bp, 0, sizeof(double) * (size_t)j->B.D, E->st));
+    j->round = robust ? 0 : 1; j->steps = 0; j->need_first = 1;
+    return VO_OK;
+}
+
+static int ba_engine_pump(BaEngine* E) {                    // engine thread; returns after one chunk of steps (or when idle)
+    hipStream_t st = E->st;
+    // ---- admit queued problems into free slots
+    {
+        std::unique_lock<std::mutex> lk(E->mu);
+        for (int s = 0; s < BA_SLOTS && !E->pending.empty(); ++s) {
+            if (E->slot[s]) continue;
+            BaJob* j = E->pending.front(); E->pending.pop_front();
+            E->slot[s] = j; j->B.ctl = E->d_ctl + s; j->cur_buf = 0; j->iters = 0;
+            lk.unlock();
+            int rc = VO_OK;
+            E->h_Bs[s] = j->B;                              // the slot's mirror is free: its previous problem is gone
+            if (hipMemcpyAsync(E->d_Bs + s, E->h_Bs + s, sizeof(BaDev), hipMemcpyHostToDevice, st) != hipSuccess) rc = VO_E_DEVICE;
+            if (rc == VO_OK) rc = ba_start_round(E, s, 1);                                  // backend.cpp:140-141
+            if (rc == VO_OK) {                              // initial plain chi2 (reporting only)
+                const BaBatch Q = ba_batch_of(E, &s, 1);
+                hipLaunchKernelGGL(k_ba_chi, dim3(j->grid_e, 1, 1), dim3(256), 0, st, Q, 0, 0, 0);
+                if (hipMemcpyAsync(E->h_mail + 16 * s, j->B.scal + 5, sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) rc = VO_E_DEVICE;
+            }
+            lk.lock();
+            if (rc != VO_OK) { j->rc = rc; j->done = true; E->slot[s] = nullptr; E->cv.notify_all(); }
+            else ++E->n_jobs;
+        }
+    }
+    int act[BA_SLOTS], na = 0;
+    for (int s = 0; s < BA_SLOTS; ++s) if (E->slot[s]) act[na++] = s;
+    if (na == 0) return VO_OK;
+    // ---- one chunk of LM steps over every active slot
+    int chunk = 6, g_lin = 0, g_init = 0, g_blk = 0, g_upd = 0, g_e = 0, g_md = 0;
+    int s16[BA_SLOTS], n16 = 0, s16g[BA_SLOTS], n16g = 0, sfirst[BA_SLOTS], nfirst = 0; size_t lds16 = 0, lds16g = 0;
+    for (int i = 0; i < na; ++i) {
+        BaJob* j = E->slot[act[i]];
+        const BaCtl& h = E->h_ctl[act[i]];                  // last read-back (zeros right after a round started)
+        const int max_it = j->round == 0 ? j->in->it_robust : j->in->it_plain;
+        chunk = std::min(chunk, std::max(2, max_it - (j->steps ? h.it : 0)));
+        g_lin = std::max(g_lin, j->grid_lin); g_init = std::max(g_init, j->grid_initS); g_blk = std::max(g_blk, j->B.n_blocks);
+        g_upd = std::max(g_upd, j->grid_upd); g_e = std::max(g_e, j->grid_e);
+        if (j->B.D <= 192) { s16[n16++] = act[i]; lds16 = std::max(lds16, j->lds); } else { s16g[n16g++] = act[i]; lds16g = std::max(lds16g, j->lds); }
+        if (j->need_first) { sfirst[nfirst++] = act[i]; g_md = std::max(g_md, j->grid_maxdiag); }
+    }
+    vo_ctx* prof = E->slot[act[0]]->c;
+    const BaBatch Q = ba_batch_of(E, act, na);
+    const dim3 blk(256);
+    for (int sidx = 0; sidx < chunk; ++sidx) {
+        { ProfScope ps(prof, "k_ba_lin", st); hipLaunchKernelGGL(k_ba_lin, dim3(g_lin, 1, na), blk, 0, st, Q); }
+        if (sidx == 0 && nfirst) hipLaunchKernelGGL(k_ba_maxdiag, dim3(g_md, 1, nfirst), blk, 0, st, ba_batch_of(E, sfirst, nfirst));
+        { ProfScope ps(prof, "k_ba_init_S", st); hipLaunchKernelGGL(k_ba_init_S, dim3(g_init, 1, na), blk, 0, st, Q); }
+        if (g_blk) { ProfScope ps(prof, "k_ba_schur_blocks", st); hipLaunchKernelGGL(k_ba_schur_blocks, dim3(g_blk, 1, na), blk, 0, st, Q); }
+        { ProfScope ps(prof, "k_ba_chol", st);
+          if (n16) hipLaunchKernelGGL(k_ba_chol16, dim3(1, 1, n16), dim3(CH_THREADS), lds16, st, ba_batch_of(E, s16, n16));
+          if (n16g) hipLaunchKernelGGL(k_ba_chol16g, dim3(1, 1, n16g), dim3(CH_THREADS), lds16g, st, ba_batch_of(E, s16g, n16g)); }
+        { ProfScope ps(prof, "k_ba_update", st); hipLaunchKernelGGL(k_ba_update, dim3(g_upd, 1, na), blk, 0, st, Q); }
+        { ProfScope ps(prof, "k_ba_chi_control", st); hipLaunchKernelGGL(k_ba_chi_control, dim3(g_e, 1, na), blk, 0, st, Q); }
+    }
+    E->n_steps += chunk; E->n_slot_steps += (long long)chunk * na;
+    for (int i = 0; i < na; ++i) { BaJob* j = E->slot[act[i]]; j->steps += chunk; j->need_first = 0; }
+    HIP_TRY(hipMemcpyAsync(E->h_ctl, E->d_ctl, sizeof(BaCtl) * BA_SLOTS, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    // ---- round transitions and completions
+    int fin[BA_SLOTS], nfin = 0;
+    for (int i = 0; i < na; ++i) {
+        const int s = act[i];
+        BaJob* j = E->slot[s];
+        const BaCtl& h = E->h_ctl[s];
+        const int max_it = j->round == 0 ? j->in->it_robust : j->in->it_plain;
+        if (!h.finished) {
+            if (j->steps > max_it * 10 + 8) { j->rc = VO_E_DEVICE; fin[nfin++] = s; }      // the control block never reported the end of the round
+            continue;
+        }
+        j->iters += h.iters_done; j->cur_buf = h.buf;
+        const BaBatch Q1 = ba_batch_of(E, &s, 1);
+        if (j->round == 0) {
+            hipLaunchKernelGGL(k_ba_cull, dim3(j->grid_e, 1, 1), blk, 0, st, Q1, 0);       // backend.cpp:144-156
+            int rc = ba_start_round(E, s, 0);                                             // backend.cpp:158-159
+            if (rc != VO_OK) { j->rc = rc; fin[nfin++] = s; }
+            E->h_ctl[s].it = 0;
+        } else {
+            HIP_TRY(hipMemsetAsync(j->B.scal, 0, 64, st));
+            hipLaunchKernelGGL(k_ba_cull, dim3(j->grid_e, 1, 1), blk, 0, st, Q1, 1);       // backend.cpp:162-172
+            HIP_TRY(hipMemcpyAsync(E->h_mail + 16 * s + 8, j->B.scal, 64, hipMemcpyDeviceToHost, st));
+            fin[nfin++] = s;
+        }
+    }
+    if (nfin) {
+        HIP_TRY(hipStreamSynchronize(st));                  // final culls and their read-backs
+        HIP_TRY(hipGetLastError());
+        std::unique_lock<std::mutex> lk(E->mu);
+        for (int i = 0; i < nfin; ++i) {
+            BaJob* j = E->slot[fin[i]];
+            j->chi0 = E->h_mail[16 * fin[i]]; j->chi_final = E->h_mail[16 * fin[i] + 8 + 6];
+            j->done = true; E->slot[fin[i]] = nullptr;
+        }
+        E->cv.notify_all();
+    }
+    return VO_OK;
+}
+
+static void ba_engine_loop(BaEngine* E) {
+    (void)hipSetDevice(E->device);
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(E->mu);
+            E->cv.wait(lk, [&] { if (E->quit || !E->pending.empty()) return true; for (int s = 0; s < BA_SLOTS; ++s) if (E->slot[s]) return true; return false; });
+            if (E->quit) return;
+        }
+        const int rc = ba_engine_pump(E);
+        if (rc != VO_OK) {                                  // a HIP error: fail everything in flight, keep serving
+            std::unique_lock<std::mutex> lk(E->mu);
+            for (int s = 0; s < BA_SLOTS; ++s) if (E->slot[s]) { E->slot[s]->rc = rc; E->slot[s]->done = true; E->slot[s] = nullptr; }
+            E->cv.notify_all();
+        }
+    }
+}
+
+static int ba_engine_solve(BaEngine* E, BaJob* j) {
+    std::unique_lock<std::mutex> lk(E->mu);
+    E->pending.push_back(j);
+    E->cv.notify_all();
+    E->cv.wait(lk, [&] { return j->done; });
+    return j->rc;
+}
+
+// engines are shared by the contexts of a device: the first context creates the engine, the last one ends it
+BaEngine* vo_ba_engine_acquire(int device) {
+    std::unique_lock<std::mutex> lk(g_eng_mu);
+    for (BaEngine* E : g_engines) if (E->device == device) { ++E->refs; return E; }
+    BaEngine* E = new BaEngine();
+    E->device = device; E->refs = 1;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);         // BA is the latency-critical chain beside tracking
+    bool ok = hipStreamCreateWithPriority(&E->st, hipStreamNonBlocking, hi) == hipSuccess;
+    ok = ok && hipMalloc((void**)&E->d_Bs, sizeof(BaDev) * BA_SLOTS) == hipSuccess && hipMalloc((void**)&E->d_ctl, sizeof(BaCtl) * BA_SLOTS) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&E->h_Bs, sizeof(BaDev) * BA_SLOTS, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&E->h_ctl, sizeof(BaCtl) * BA_SLOTS, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&E->h_up, sizeof(BaCtl) * BA_SLOTS, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&E->h_mail, sizeof(double) * 16 * BA_SLOTS, hipHostMallocDefault) == hipSuccess;
+    if (ok) {
+        memset(E->h_ctl, 0, sizeof(BaCtl) * BA_SLOTS);
+        for (int s = 0; s < BA_SLOTS; ++s) E->h_ctl[s].finished = 1;
+        ok = hipMemcpy(E->d_ctl, E->h_ctl, sizeof(BaCtl) * BA_SLOTS, hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (!ok) { fprintf(stderr, "[vo_hip] BA engine: allocation failed on device %d\n", device); delete E; return nullptr; }
+    E->th = std::thread(ba_engine_loop, E);
+    g_engines.push_back(E);
+    return E;
+}
+
+void vo_ba_engine_release(BaEngine* E) {
+    if (!E) return;
+    {
+        std::unique_lock<std::mutex> lk(g_eng_mu);
+        if (--E->refs > 0) return;
+        for (size_t i = 0; i < g_engines.size(); ++i) if (g_engines[i] == E) { g_engines.erase(g_engines.begin() + i); break; }
+    }
+    { std::unique_lock<std::mutex> lk(E->mu); E->quit = true; }
+    E->cv.notify_all();
+    if (E->th.joinable()) E->th.join();
+    (void)hipSetDevice(E->device);
+    if (getenv("VO_TRACE")) fprintf(stderr, "[vo_trace] BA engine: %lld problems, %lld step launches, %.2f problems per step launch\n", E->n_jobs, E->n_steps, E->n_steps ? (double)E->n_slot_steps / E->n_steps : 0.0);
+    if (E->st) { (void)hipStreamSynchronize(E->st); (void)hipStreamDestroy(E->st); }
+    if (E->d_Bs) (void)hipFree(E->d_Bs);
+    if (E->d_ctl) (void)hipFree(E->d_ctl);
+    if (E->h_Bs) (void)hipHostFree(E->h_Bs);
+    if (E->h_ctl) (void)hipHostFree(E->h_ctl);
+    if (E->h_up) (void)hipHostFree(E->h_up);
+    if (E->h_mail) (void)hipHostFree(E->h_mail);
+    delete E;
+}
+
 int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     hipStream_t st = c->stream;
+    BaEngine* E = c->ba_engine;
+    if (!E) return VO_E_STATE;
     const int np = in->n_poses, nf = in->n_free, nx = in->n_points, ne = in->n_edges, D = 6 * nf;
     if ((CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D) * sizeof(double) > 158 * 1024) return VO_E_UNSUPPORTED;     // D > ~1060 (176 free poses)
     out->lm_iters = 0; out->chi2_initial = 0; out->chi2_final = 0;
@@ -1285,7 +1539,6 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     const size_t o_blk = carve(sizeof(BaBlock) * (size_t)std::max(nblk, 1)), o_pairs = carve(sizeof(int2) * (size_t)std::max(npairs, 1));
     const size_t o_pspt = carve(4 * ps_pt.size() + 4), o_pcnt = carve(4 * (size_t)std::max(nb_all, 1)), o_poff = carve(4 * (size_t)std::max(nb_all, 1)), o_pn = carve(16);
     const size_t o_Hpp = carve(288 * (size_t)nf), o_bp = carve(8 * (size_t)D), o_Hll = carve(72 * (size_t)nx), o_bl = carve(24 * (size_t)nx), o_scal = carve(64);
-    const size_t o_ctl = carve(sizeof(BaCtl));
     const size_t o_partU = carve(16 * ((size_t)(nx + 63) / 64 + 1)), o_partC = carve(8 * ((size_t)(ne + 255) / 256 + 1));
     const size_t o_W = carve(144 * (size_t)ne), o_S = carve(8 * (size_t)D * D), o_bs = carve(8 * (size_t)D), o_Hinv = carve(72 * (size_t)nx), o_dl = carve(24 * (size_t)nx);
     int rc = vo_scratch(c, off);
@@ -1296,13 +1549,14 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     B.n_slices = dev_pairs ? (const int*)(base + o_pn) : nullptr;
     B.ps_start = (const int32_t*)(base + o_qs); B.ps_edges = (const int32_t*)(base + o_qe); B.blocks = (const BaBlock*)(base + o_blk); B.pairs = (const int2*)(base + o_pairs);
     B.posesA = (double*)(base + o_poses); B.ptsA = (double*)(base + o_pts); B.posesB = (double*)(base + o_poses_n); B.ptsB = (double*)(base + o_pts_n);
-    B.ctl = (BaCtl*)(base + o_ctl);
+    B.ctl = nullptr;                                        // the engine assigns the control block of the problem's slot
     B.partU = (double*)(base + o_partU); B.partC = (double*)(base + o_partC); B.nU = (nx + 63) / 64;
     B.e_pose = (const int32_t*)(base + o_epose); B.e_pt = (const int32_t*)(base + o_ept); B.e_uv = (const float*)(base + o_euv);
     B.active = base + o_act; B.flags = base + o_flags; B.pt_start = (const int32_t*)(base + o_ps); B.pt_edges = (const int32_t*)(base + o_pe);
     B.Hpp = (double*)(base + o_Hpp); B.bp = (double*)(base + o_bp); B.Hll = (double*)(base + o_Hll); B.bl = (double*)(base + o_bl); B.scal = (double*)(base + o_scal);
     B.W = (double*)(base + o_W); B.S = (double*)(base + o_S); B.bs = (double*)(base + o_bs); B.Hinv = (double*)(base + o_Hinv); B.dl = (double*)(base + o_dl);
-    BaCam cam{(double)c->p.fx, (double)c->p.fy, (double)c->p.cx, (double)c->p.cy};
+    B.cam = BaCam{(double)c->p.fx, (double)c->p.fy, (double)c->p.cx, (double)c->p.cy};
+    B.delta = in->huber_delta; B.chi2_th = in->chi2_th; B.gp = (nx + 63) / 64;
 
     HIP_TRY(hipMemcpyAsync(base + o_poses, in->poses, 96 * (size_t)np, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(base + o_pts, in->points, 24 * (size_t)nx, hipMemcpyHostToDevice, st));
@@ -1341,80 +1595,24 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     if (dev_pairs && h_counts) { nblk_launch = std::min(nblk, h_counts[0]); npairs = h_counts[1]; }
 
     const double tt1 = tnow();
-    double* h_scal = (double*)vo_stage(c, 256);
-    if (!h_scal) return VO_E_NOMEM;
-    const dim3 blk(256), gE((ne + 255) / 256), gP((nx + 255) / 256), gP4((nx + 63) / 64), gJ((np + 255) / 256);
-    auto read_scal = [&]() -> int {
-        HIP_TRY(hipMemcpyAsync(h_scal, B.scal, 64, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        return VO_OK;
-    };
-    BaCtl* h_ctl = (BaCtl*)((uint8_t*)h_scal + 64);
-    int cur_buf = 0;
-    const int CHUNK = 6;                                    // LM steps enqueued between two host polls
-    auto optimize = [&](int robust, int max_it, int& iters) -> int {
-        if (max_it <= 0) return VO_OK;
-        // no synchronisation here: the stream was drained by the previous read-back of h_ctl (or by the upload), so the
-        // pinned control block is free to be rewritten
-        memset(h_ctl, 0, sizeof(BaCtl));
-        h_ctl->max_it = max_it; h_ctl->need_lin = 1; h_ctl->first = 1; h_ctl->buf = cur_buf; h_ctl->ni = 2;
-        HIP_TRY(hipMemcpyAsync(B.ctl, h_ctl, sizeof(BaCtl), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemsetAsync(B.scal, 0, 64, st));
-        HIP_TRY(hipMemsetAsync(B.Hpp, 0, sizeof(double) * 36 * (size_t)nf, st));
-        HIP_TRY(hipMemsetAsync(B.bp, 0, sizeof(double) * (size_t)D, st));
-        for (int guard_steps = 0, chunk = max_it; guard_steps < max_it * 10 + CHUNK; guard_steps += chunk, chunk = 2) {
-            for (int sidx = 0; sidx < chunk; ++sidx) {
-                { ProfScope ps(c, "k_ba_lin"); hipLaunchKernelGGL(k_ba_lin, dim3(gP4.x + nf * PSPLIT), blk, 0, st, cam, B, robust, in->huber_delta, (int)gP4.x); }
-                if (guard_steps == 0 && sidx == 0) hipLaunchKernelGGL(k_ba_maxdiag, dim3((D + 3 * nx + 255) / 256), blk, 0, st, B);
-                { ProfScope ps(c, "k_ba_init_S"); hipLaunchKernelGGL(k_ba_init_S, dim3((std::max(D * D, nx) + 255) / 256), blk, 0, st, B); }
-                if (nblk_launch) { ProfScope ps(c, "k_ba_schur_blocks"); hipLaunchKernelGGL(k_ba_schur_blocks, dim3(nblk_launch), blk, 0, st, B); }
-                { ProfScope ps(c, "k_ba_chol");
-                  if (D <= 192) hipLaunchKernelGGL(k_ba_chol16, dim3(1), dim3(CH_THREADS), sizeof(double) * (CH_NB * CH_NB + (size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D), st, B);
-                  else hipLaunchKernelGGL(k_ba_chol16g, dim3(1), dim3(CH_THREADS), sizeof(double) * (CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D), st, B); }
-                { ProfScope ps(c, "k_ba_update"); hipLaunchKernelGGL(k_ba_update, dim3(gP4.x + gJ.x), blk, 0, st, B, (int)gP4.x); }
-                { ProfScope ps(c, "k_ba_chi_control"); hipLaunchKernelGGL(k_ba_chi_control, gE, blk, 0, st, cam, B, robust, in->huber_delta); }
-            }
-            HIP_TRY(hipMemcpyAsync(h_ctl, B.ctl, sizeof(BaCtl), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            if (h_ctl->finished) break;
-        }
-        if (!h_ctl->finished) return VO_E_DEVICE;
-        iters += h_ctl->iters_done;
-        cur_buf = h_ctl->buf;
-        return VO_OK;
-    };
-    // kernels outside the LM loop read the current buffer index from the control block
-    auto set_ctl_idle = [&]() -> int {                     // called right after the upload synchronisation: stream idle
-        BaCtl* h_idle = (BaCtl*)((uint8_t*)h_scal + 128);   // its own pinned slot: h_ctl is rewritten before this copy has run
-        memset(h_idle, 0, sizeof(BaCtl));
-        h_idle->buf = cur_buf;
-        HIP_TRY(hipMemcpyAsync(B.ctl, h_idle, sizeof(BaCtl), hipMemcpyHostToDevice, st));
-        return VO_OK;
-    };
-
-    // initial plain chi2 (reporting only): its read-back rides on the next synchronisation
-    if ((rc = set_ctl_idle())) return rc;
-    HIP_TRY(hipMemsetAsync(B.scal, 0, 64, st));
-    hipLaunchKernelGGL(k_ba_chi, gE, blk, 0, st, cam, B, 0, 0, in->huber_delta, 0);
-    double* h_chi0 = h_scal + 24;                           // pinned mailbox, beyond scal (8 doubles) and ctl
-    HIP_TRY(hipMemcpyAsync(h_chi0, B.scal + 5, sizeof(double), hipMemcpyDeviceToHost, st));
-
-    int iters = 0;
-    if ((rc = optimize(1, in->it_robust, iters))) return rc;                       // backend.cpp:140-141
-    hipLaunchKernelGGL(k_ba_cull, gE, blk, 0, st, cam, B, 0, in->chi2_th);         // backend.cpp:144-156
-    if ((rc = optimize(0, in->it_plain, iters))) return rc;                        // backend.cpp:158-159
-    HIP_TRY(hipMemsetAsync(B.scal, 0, 64, st));
-    hipLaunchKernelGGL(k_ba_cull, gE, blk, 0, st, cam, B, 1, in->chi2_th);         // backend.cpp:162-172
-    out->lm_iters = iters;
+    // ---- solve: the engine steps this problem together with whatever other local BAs are in flight on this GPU ----------
+    BaJob job;
+    job.c = c; job.in = in; job.out = out; job.B = B; job.B.n_blocks = nblk_launch;
+    job.grid_lin = (nx + 63) / 64 + nf * PSPLIT; job.grid_initS = (std::max(D * D, nx) + 255) / 256; job.grid_upd = (nx + 63) / 64 + (np + 255) / 256;
+    job.grid_e = (ne + 255) / 256; job.grid_maxdiag = (D + 3 * nx + 255) / 256;
+    job.lds = D <= 192 ? sizeof(double) * (CH_NB * CH_NB + (size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D)
+                       : sizeof(double) * (CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D);
+    if ((rc = ba_engine_solve(E, &job))) return rc;
+    out->lm_iters = job.iters;
     const double tt2 = tnow();
-    HIP_TRY(hipMemcpyAsync(h_scal, B.scal, 64, hipMemcpyDeviceToHost, st));     // one synchronisation for chi2 and the results
+    const int cur_buf = job.cur_buf;
     HIP_TRY(hipMemcpyAsync(out->poses, cur_buf ? B.posesB : B.posesA, 96 * (size_t)nf, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(out->points, cur_buf ? B.ptsB : B.ptsA, 24 * (size_t)nx, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(out->edge_flags, B.flags, ne, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
-    out->chi2_final = h_scal[6];
-    out->chi2_initial = *h_chi0;
+    out->chi2_final = job.chi_final;
+    out->chi2_initial = job.chi0;
     if (trace) { static double a0 = 0, a1 = 0, a2 = 0; static int n = 0; a0 += tt1 - tt0; a1 += tt2 - tt1; a2 += tnow() - tt2; if (++n % 10 == 0) fprintf(stderr, "[vo_trace] vo_ba_run avg ms: prep+upload %.2f optimise %.2f download %.2f (D=%d edges=%d pairs=%d) | last prep: csr %.2f pairs %.2f enqueue %.2f sync %.2f\n", a0 / n, a1 / n, a2 / n, D, ne, npairs, tp1 - tt0, tp2 - tp1, tp3 - tp2, tt1 - tp3); }
     return VO_OK;
 }

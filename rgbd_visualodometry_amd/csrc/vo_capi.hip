@@ -243,6 +243,7 @@ void vo_ctx_destroy(vo_ctx* c) {
     { std::unique_lock<std::mutex> lk(g_prof_mu); prof_collect(c); for (size_t i = 0; i < g_ctxs.size(); ++i) if (g_ctxs[i] == c) { g_ctxs.erase(g_ctxs.begin() + i); break; } }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->ba_engine) { vo_ba_engine_release(c->ba_engine); c->ba_engine = nullptr; }
     for (auto p : c->own_bgr) if (p) (void)hipFree(p);
     for (auto p : c->own_depth) if (p) (void)hipFree(p);
     void* ptrs[] = {c->d_slots, c->d_pyr, c->d_blur, c->d_tab, c->d_tabs, c->d_cand, c->d_cand_cnt, c->d_sel, c->d_sel_key, c->d_sel_cnt, c->d_kps,
@@ -324,6 +325,7 @@ int vo_ctx_create(const vo_params* p, int device, vo_ctx** out) {
     if (launchset_alloc(c->ls, (int)NL) != VO_OK) { vo_ctx_destroy(c); return VO_E_NOMEM; }
     c->d_track = c->ls.d_track; c->h_track = c->ls.h_track; c->lane_stride = M;
     if (hipEventCreateWithFlags(&c->group_ev, hipEventDisableTiming) != hipSuccess) { vo_ctx_destroy(c); return VO_E_DEVICE; }
+    if (!(c->ba_engine = vo_ba_engine_acquire(device))) { vo_ctx_destroy(c); return VO_E_NOMEM; }
     hipStream_t st = c->stream;
     HIP_TRY(hipMemcpyAsync(c->d_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(c->d_tabs, tabs.data(), tabs.size() * sizeof(short), hipMemcpyHostToDevice, st));

@@ -110,8 +110,8 @@ struct vo_ctx {
     void* h_stage; size_t h_stage_bytes;            // pinned general staging
     uint8_t* h_orb_cache; bool orb_cache_valid; int orb_batch0, orb_batchn;   // pinned copy of the last ORB batch's results
     bool corr_external;
-    // BA scratch
-    void* d_ba; size_t d_ba_bytes;
+    // BA scratch; the device's BA engine (shared by the contexts of that device, vo_ba.hip)
+    void* d_ba; size_t d_ba_bytes; struct BaEngine* ba_engine = nullptr;
     // profiling
     std::atomic<bool> prof_on; std::mutex prof_mu; std::vector<ProfRec> prof; std::vector<hipEvent_t> ev_pool;      // prof / ev_pool: under prof_mu
     ProfRec prof_open; hipStream_t prof_open_stream = nullptr; uint64_t prof_ticket = 0, prof_closed = 0;
@@ -138,5 +138,7 @@ int vo_track_lm_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* d_lanes, in
 void vo_lane_fill(vo_ctx* c, int lane, int slot, uint64_t seed, TrackDev* d_tr, LaneDesc* out);   // descriptor of lane `lane` of context c
 int vo_corr_from_host(vo_ctx* c, const float* xyz, const float* uv, int n);
 int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out);                       // vo_ba.hip
+struct BaEngine* vo_ba_engine_acquire(int device);
+void vo_ba_engine_release(struct BaEngine* e);
 
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "[vo_hip] %s -> %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return VO_E_DEVICE; } } while (0)

@@ -76,7 +76,7 @@ private:
     std::vector<SpecResult> spec_;
     std::vector<Frame::Ptr> prefetched_;
     uint64_t epoch_ = 0;
-    int trackBatch_ = 1, framesSinceKf_ = 0; double lastMotion_ = 0;
+    int trackBatch_ = 1, framesSinceKf_ = 0, lastInterval_ = 0; double lastMotion_ = 0;     // lastInterval_: frames between the last two keyframes
     Stats stats_;
     std::vector<vo_keypoint> kpBuf_; std::vector<uint8_t> descBuf_; std::vector<vo_match> matchBuf_;
     // The per-frame containers above (keypointsCurr_, flann*/pnp* lists) are only read on keyframes and by the viewer:

@@ -102,7 +102,7 @@ bool FrontEnd::TrackingHandler() {
     accuLostFrameNums_ = 0;
     if (!IsKeyframe()) return true;
 
-    ++epoch_; framesSinceKf_ = 0;                                  // map + prior change: cached speculative results are void
+    ++epoch_; lastInterval_ = framesSinceKf_; framesSinceKf_ = 0;   // map + prior change: cached speculative results are void
     {
         StageTimer t(stats_.ms_keyframe);
         { VO_SCOPE("kf.lists"); EnsureMatchLists(); }
@@ -258,7 +258,9 @@ void FrontEnd::MatchAndEstimatePose() {
         size_t pos = 0;
         while (pos < prefetched_.size() && prefetched_[pos] != frameCurr_) ++pos;
         const size_t nextMerge = backend_ ? backend_->NextMergeFrame() : (size_t)-1;
-        int want = trackBatch_;
+        // how many frames are likely to see this map: right after a keyframe the previous keyframe interval is the
+        // estimate (lanes tracked beyond the next keyframe are thrown away), later the motion since the keyframe
+        int want = lastInterval_ > 0 ? std::min(trackBatch_, lastInterval_ + 1) : trackBatch_;
         if (framesSinceKf_ > 0 && lastMotion_ > 0) {
             const double left = (1.0 - lastMotion_) / (lastMotion_ / framesSinceKf_);      // frames until a threshold is reached
             want = std::max(1, std::min(trackBatch_, (int)left + 1));

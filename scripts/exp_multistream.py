@@ -13,6 +13,7 @@ def main():
     ap.add_argument("--lag", type=int, default=8)
     ap.add_argument("--same-seed", action="store_true")
     ap.add_argument("--modes", default="group,separate")
+    ap.add_argument("--profile", action="store_true", help="per-kernel HIP-event timing (all contexts and engines)")
     args = ap.parse_args()
     import torch
     from rgbd_visualodometry_amd import capi, system
@@ -35,6 +36,9 @@ def main():
                 for x in syss:
                     grp.join(x)
             bar = threading.Barrier(S + 1)
+            if args.profile:
+                import ctypes as C
+                L = capi.load(capi.HIP_LIB); h0 = C.c_void_p(syss[0].context_handle()); L.check(L.lib.vo_profile_enable(h0, 1))
 
             def drive(k, i0, i1):
                 db, dd, ts = data[k]
@@ -63,6 +67,13 @@ def main():
                               "kf": [x["keyframes"] for x in st], "ba_runs": [x["ba_runs"] for x in st], "lost": [x["lost"] for x in st],
                               "ms_track": [round(x["ms_track"]) for x in st], "ms_keyframe": [round(x["ms_keyframe"]) for x in st], "ms_backend": [round(x["ms_backend"]) for x in st],
                               "ms_extract": [round(x["ms_extract"]) for x in st]}), flush=True)
+            if args.profile:
+                names = (C.c_char * 48 * 96)(); ms = np.zeros(96); calls = np.zeros(96, dtype=np.int64); nn = C.c_int()
+                L.check(L.lib.vo_profile_read(h0, C.cast(names, C.c_void_p), ms.ctypes.data, calls.ctypes.data, 96, C.byref(nn)))
+                L.check(L.lib.vo_profile_enable(h0, 0))
+                rows = sorted(((names[j].value.decode(), float(ms[j]), int(calls[j])) for j in range(nn.value)), key=lambda r: -r[1])
+                for n_, t_, c_ in rows:
+                    print("    %-20s total %8.2f ms  launches %6d  avg %8.2f us" % (n_, t_, c_, 1e3 * t_ / max(1, c_)), flush=True)
             for x in syss: x.close()
             if grp: grp.close()
 
