@@ -227,6 +227,17 @@ int vo_group_leave(vo_group* g, vo_ctx* ctx);
 int vo_group_set_gather(vo_group* g, int min_requests, int timeout_us);
 int vo_group_stats(vo_group* g, int64_t* chains, int64_t* lanes, int64_t* requests);
 
+/* ---- RANSAC hypotheses sharded over ranks ------------------------------ */
+/* Several processes (one per GPU) track the SAME stream; each scores only its share of the PnP-RANSAC hypotheses
+ * (cv::solvePnPRansac, reference src/frontend.cpp:238-241): hypothesis h belongs to rank h % world.  Every rank generates
+ * all hypotheses (cheap, counter-based sampler: identical everywhere), scores its own, then `exchange` sums the per-
+ * hypothesis inlier counts element-wise over the ranks IN PLACE (counts of foreign hypotheses are sent as 0), after which
+ * every rank runs the same sequential adaptive-stop scan on the full count vector: results are identical to the un-sharded
+ * call on every rank.  One exchange per RANSAC pass and launch chain (lanes x n_hyp int32).  The caller supplies the
+ * collective (RCCL / gloo all-reduce through torch.distributed in this repo); world <= 1 switches sharding off. */
+typedef void (*vo_exchange_fn)(void* user, int32_t* counts, int n);
+int vo_set_hypothesis_shard(vo_ctx* ctx, int rank, int world, vo_exchange_fn exchange, void* user);
+
 /* ---- local bundle adjustment --------------------------------------------------------- */
 int vo_local_ba(vo_ctx* ctx, const vo_ba_problem* in, vo_ba_result* out);
 

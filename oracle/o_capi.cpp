@@ -31,6 +31,7 @@ struct vo_ctx {
     Corr corr; std::vector<vo_match> last_matches;
     std::vector<std::vector<vo_match>> lane_matches;           // per lane of the last vo_track_batch (vo_track_fetch_matches)
     std::vector<int32_t> ransac_inliers;
+    HypShard shard;
 };
 
 extern "C" {
@@ -202,7 +203,7 @@ int vo_pnp_ransac(vo_ctx* c, int n_hyp, float reproj_px, float conf, uint64_t se
                   int* n_inl, int32_t* hyp_counts, int* iters_used, int* best_hyp) {
     if (!c || !T || n_hyp < 1 || n_hyp > c->p.max_hypotheses) return VO_E_INVALID;
     RansacOut r;
-    pnp_ransac(c->cam, c->corr, n_hyp, reproj_px, conf, seed, SE3::from12(T), r);
+    pnp_ransac(c->cam, c->corr, n_hyp, reproj_px, conf, seed, SE3::from12(T), r, &c->shard);
     r.T.to12(T);
     c->ransac_inliers = r.inliers;
     if (inl) std::memcpy(inl, r.inliers.data(), 4 * std::min<size_t>(cap, r.inliers.size()));
@@ -278,6 +279,12 @@ int vo_track_fetch_matches(vo_ctx* c, int lane, vo_match* matches, int cap, int*
     const int n = (int)std::min<size_t>((size_t)cap, c->lane_matches[lane].size());
     std::memcpy(matches, c->lane_matches[lane].data(), sizeof(vo_match) * (size_t)n);
     *n_out = n;
+    return VO_OK;
+}
+
+int vo_set_hypothesis_shard(vo_ctx* c, int rank, int world, vo_exchange_fn fn, void* user) {
+    if (!c || world < 0 || (world > 1 && (rank < 0 || rank >= world || !fn))) return VO_E_INVALID;
+    c->shard.rank = rank; c->shard.world = world > 1 ? world : 1; c->shard.exchange = fn; c->shard.user = user;
     return VO_OK;
 }
 

@@ -203,7 +203,8 @@ static inline bool reproj_ok(const Cam& cam, const M3& R, V3 t, const float* X, 
 }
 
 void pnp_ransac(const Cam& cam, const Corr& c, int n_hyp, float reproj_px, float conf, uint64_t seed,
-                const SE3& prior, RansacOut& out) {
+                const SE3& prior, RansacOut& out, const HypShard* shard) {
+    const bool sharded = shard && shard->world > 1 && shard->exchange;
     out.T = prior; out.inliers.clear(); out.iters_used = 0; out.best = -1;
     out.hyp_counts.assign(n_hyp, 0); out.hyp_pose.assign((size_t)12 * n_hyp, 0.0);
     const int n = c.n;
@@ -227,12 +228,14 @@ void pnp_ransac(const Cam& cam, const Corr& c, int n_hyp, float reproj_px, float
             double e = du * du + dv * dv;
             if (e < be) { be = e; bi = s; }
         }
-        if (bi < 0) { out.hyp_counts[h] = -1; continue; }
+        if (bi < 0) { out.hyp_counts[h] = (!sharded || h % shard->world == shard->rank) ? -1 : 0; continue; }
         SE3(R[bi], t[bi]).to12(&out.hyp_pose[(size_t)12 * h]);
+        if (sharded && h % shard->world != shard->rank) continue;      // scored by its owner; 0 goes into the sum
         int cnt = 0;
         for (int k = 0; k < n; ++k) cnt += reproj_ok(cam, R[bi], t[bi], &c.xyz[3 * k], &c.uv[2 * k], thr2);
         out.hyp_counts[h] = cnt;
     }
+    if (sharded) shard->exchange(shard->user, out.hyp_counts.data(), n_hyp);      // element-wise sum over the ranks
     // sequential adaptive-stop scan (cv RANSAC loop semantics: frontend.cpp:240 iters=100, conf .99)
     int best_cnt = 3, niters = n_hyp, h = 0;
     for (; h < niters; ++h) {

@@ -40,8 +40,9 @@ struct RansacOut {
     std::vector<double> hyp_pose;   // 12 per hypothesis (valid flag in hyp_counts >= 0)
     int iters_used = 0, best = -1;
 };
+struct HypShard { int rank = 0, world = 1; void (*exchange)(void*, int32_t*, int) = nullptr; void* user = nullptr; };
 void pnp_ransac(const Cam& cam, const Corr& c, int n_hyp, float reproj_px, float conf, uint64_t seed,
-                const SE3& prior, RansacOut& out);
+                const SE3& prior, RansacOut& out, const HypShard* shard = nullptr);
 
 struct LmOut { SE3 T; std::vector<uint8_t> inlier_mask; int iters = 0; double chi2 = 0; };
 void pose_lm(const Cam& cam, const Corr& c, const std::vector<int32_t>& edges, const SE3& T0, double huber_delta,

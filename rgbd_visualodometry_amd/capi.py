@@ -63,7 +63,11 @@ SYMBOLS = ["vo_ctx_create", "vo_ctx_destroy", "vo_strerror", "vo_backend_name", 
            "vo_orb_fetch", "vo_orb_level_size", "vo_orb_fetch_level", "vo_orb_fetch_blur_level", "vo_map_upsert", "vo_map_set_active",
            "vo_match_active_map", "vo_matches_set", "vo_pnp_ransac", "vo_pose_refine_lm", "vo_track_frame", "vo_track_batch", "vo_track_fetch_matches",
            "vo_local_ba", "vo_sync", "vo_profile_enable", "vo_profile_read",
-           "vo_group_create", "vo_group_destroy", "vo_group_join", "vo_group_leave", "vo_group_set_gather", "vo_group_stats"]
+           "vo_group_create", "vo_group_destroy", "vo_group_join", "vo_group_leave", "vo_group_set_gather", "vo_group_stats",
+           "vo_set_hypothesis_shard"]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int32), C.c_int)     # vo_exchange_fn: in-place element-wise sum over the ranks
 
 
 class VoError(RuntimeError):
@@ -116,6 +120,7 @@ class VoLib:
         L.vo_local_ba.argtypes = [C.c_void_p, C.POINTER(VoBaProblem), C.POINTER(VoBaResult)]
         L.vo_sync.argtypes = [C.c_void_p]
         L.vo_group_destroy.restype = None
+        L.vo_set_hypothesis_shard.argtypes = [C.c_void_p, C.c_int, C.c_int, EXCHANGE_FN, C.c_void_p]
         L.vo_group_create.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.vo_group_destroy.argtypes = [C.c_void_p]
         L.vo_group_join.argtypes = [C.c_void_p, C.c_void_p]
@@ -326,6 +331,13 @@ class VoContext:
         res = VoBaResult(_ptr(po).value, _ptr(pt).value, _ptr(fl).value)
         self.L.check(self.L.lib.vo_local_ba(self.h, C.byref(prob), C.byref(res)), "vo_local_ba")
         return po[:n_free], pt[:len(points)], fl[:len(ep)], res
+
+    def set_hypothesis_shard(self, rank: int, world: int, all_reduce_sum):
+        """RANSAC hypotheses of this context's frames are scored h % world == rank; ``all_reduce_sum(np.int32 array)`` sums in place over the ranks."""
+        def _cb(user, ptr, n):
+            all_reduce_sum(np.ctypeslib.as_array(ptr, shape=(n,)))
+        self._keep["shard_cb"] = EXCHANGE_FN(_cb) if all_reduce_sum is not None else EXCHANGE_FN(0)
+        self.L.check(self.L.lib.vo_set_hypothesis_shard(self.h, rank, world, self._keep["shard_cb"], None), "vo_set_hypothesis_shard")
 
     def sync(self):
         self.L.check(self.L.lib.vo_sync(self.h), "vo_sync")

@@ -208,6 +208,7 @@ struct vo_group {
     int64_t n_chains = 0, n_lanes = 0, n_requests = 0;
 };
 static int chain_run(vo_ctx* prof, hipStream_t st, LaunchSet& ls, std::vector<GroupReq*>& batch);
+static int shard_exchange(vo_ctx* c, hipStream_t st, int nl, int n_hyp);
 
 extern "C" {
 
@@ -581,7 +582,11 @@ int vo_pnp_ransac(vo_ctx* c, int n_hyp, float reproj_px, float conf, uint64_t se
     memcpy(c->h_track->T, T, sizeof(double) * 12);
     HIP_TRY(hipMemcpyAsync(c->d_track, c->h_track, sizeof(TrackDev), hipMemcpyHostToDevice, c->stream));
     if ((rc = upload_lanes(c, 1, nullptr, &seed))) return rc;
-    rc = vo_track_ransac_launch(c, c->stream, c->ls.d_lanes, 1, n_hyp, reproj_px, conf, 0);
+    if (c->shard_world > 1) {
+        if ((rc = vo_track_ransac_launch(c, c->stream, c->ls.d_lanes, 1, n_hyp, reproj_px, conf, 0, 1, c->shard_rank, c->shard_world))) return rc;
+        if ((rc = shard_exchange(c, c->stream, 1, n_hyp))) return rc;
+        rc = vo_track_ransac_launch(c, c->stream, c->ls.d_lanes, 1, n_hyp, reproj_px, conf, 0, 2);
+    } else rc = vo_track_ransac_launch(c, c->stream, c->ls.d_lanes, 1, n_hyp, reproj_px, conf, 0);
     if (rc) return rc;
     rc = download_track(c);
     if (rc) return rc;
@@ -653,7 +658,12 @@ static int chain_run(vo_ctx* prof, hipStream_t st, LaunchSet& ls, std::vector<Gr
     HIP_TRY(hipMemcpyAsync(ls.d_lanes, ls.h_lanes, sizeof(LaneDesc) * nl, hipMemcpyHostToDevice, st));
     for (int pass = 0; pass < tp->passes; ++pass) {           // coarse, fine (frontend.cpp:100-108); the sampler's seed is lane seed + pass
         if ((rc = vo_track_match_launch(prof, st, ls.d_lanes, nl, dims, tp->match_ratio, tp->match_floor))) return rc;
-        if ((rc = vo_track_ransac_launch(prof, st, ls.d_lanes, nl, tp->n_hyp, tp->reproj_px, tp->confidence, pass))) return rc;
+        vo_ctx* sc = batch[0]->c;                           // hypothesis sharding applies to un-grouped contexts (one request per chain)
+        if (sc->shard_world > 1 && batch.size() == 1) {
+            if ((rc = vo_track_ransac_launch(prof, st, ls.d_lanes, nl, tp->n_hyp, tp->reproj_px, tp->confidence, pass, 1, sc->shard_rank, sc->shard_world))) return rc;
+            if ((rc = shard_exchange(sc, st, nl, tp->n_hyp))) return rc;
+            if ((rc = vo_track_ransac_launch(prof, st, ls.d_lanes, nl, tp->n_hyp, tp->reproj_px, tp->confidence, pass, 2))) return rc;
+        } else if ((rc = vo_track_ransac_launch(prof, st, ls.d_lanes, nl, tp->n_hyp, tp->reproj_px, tp->confidence, pass))) return rc;
         if ((rc = vo_track_lm_launch(prof, st, ls.d_lanes, nl, tp->huber_delta, tp->chi2_cut, tp->it_robust, tp->it_plain, pass == tp->passes - 1))) return rc;
     }
     // match records that callers asked for travel with the headers; sized from the largest match count seen recently
@@ -701,6 +711,18 @@ static int chain_run(vo_ctx* prof, hipStream_t st, LaunchSet& ls, std::vector<Gr
             }
         k0 += r->n;
     }
+    return VO_OK;
+}
+
+// the one exchange step of a hypothesis-sharded RANSAC pass: per-hypothesis inlier counts of every lane, summed over the ranks
+static int shard_exchange(vo_ctx* c, hipStream_t st, int nl, int n_hyp) {
+    const size_t n = (size_t)nl * n_hyp;
+    int32_t* h = (int32_t*)vo_stage(c, sizeof(int32_t) * n);
+    if (!h) return VO_E_NOMEM;
+    HIP_TRY(hipMemcpy2DAsync(h, sizeof(int32_t) * n_hyp, c->d_hyp_cnt, sizeof(int32_t) * c->p.max_hypotheses, sizeof(int32_t) * n_hyp, nl, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    c->shard_fn(c->shard_user, h, (int)n);
+    HIP_TRY(hipMemcpy2DAsync(c->d_hyp_cnt, sizeof(int32_t) * c->p.max_hypotheses, h, sizeof(int32_t) * n_hyp, sizeof(int32_t) * n_hyp, nl, hipMemcpyHostToDevice, st));
     return VO_OK;
 }
 
@@ -798,8 +820,15 @@ void vo_group_destroy(vo_group* g) {
     delete g;
 }
 
+int vo_set_hypothesis_shard(vo_ctx* c, int rank, int world, vo_exchange_fn fn, void* user) {
+    if (!c || world < 0 || (world > 1 && (rank < 0 || rank >= world || !fn))) return VO_E_INVALID;
+    if (world > 1 && c->group) return VO_E_UNSUPPORTED;      // a context either shares launch chains with other streams or shares a stream with other ranks
+    c->shard_rank = rank; c->shard_world = world > 1 ? world : 1; c->shard_fn = fn; c->shard_user = user;
+    return VO_OK;
+}
+
 int vo_group_join(vo_group* g, vo_ctx* c) {
-    if (!g || !c || c->group || c->device != g->device || c->lanes > g->max_lanes) return VO_E_INVALID;
+    if (!g || !c || c->group || c->shard_world > 1 || c->device != g->device || c->lanes > g->max_lanes) return VO_E_INVALID;
     std::unique_lock<std::mutex> lk(g->mu);
     c->group = g; ++g->members;
     return VO_OK;

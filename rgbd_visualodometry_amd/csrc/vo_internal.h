@@ -105,6 +105,7 @@ struct vo_ctx {
     TrackDev* d_track; TrackDev* h_track;           // [lanes]; h_track pinned
     size_t lane_stride; int lanes;                  // element stride of the per-lane chain buffers
     struct vo_group* group = nullptr; hipEvent_t group_ev = nullptr;     // stream group membership (vo_group_join)
+    int shard_rank = 0, shard_world = 1; vo_exchange_fn shard_fn = nullptr; void* shard_user = nullptr;     // RANSAC hypotheses sharded over ranks
     vo_match* h_matches;                            // pinned staging
     int h_matches_cap;
     void* h_stage; size_t h_stage_bytes;            // pinned general staging
@@ -133,7 +134,8 @@ int vo_orb_launch(vo_ctx* c, int slot0, int nslots);                            
 // vo_track.hip: the chain's stages over nl lanes described by d_lanes (device), on stream st; `prof` receives the timing records
 struct ChainDims { int max_active, max_feat; };
 int vo_track_match_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* d_lanes, int nl, ChainDims dims, float ratio, float floor_dist);
-int vo_track_ransac_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* d_lanes, int nl, int n_hyp, float reproj_px, float conf, int pass);
+// stage: 1 = hypotheses + scoring, 2 = adaptive-stop scan + inlier list, 3 = both; (rank, world): this process scores hypotheses h % world == rank
+int vo_track_ransac_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* d_lanes, int nl, int n_hyp, float reproj_px, float conf, int pass, int stage = 3, int rank = 0, int world = 1);
 int vo_track_lm_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* d_lanes, int nl, double delta, double cut, int it_r, int it_p, bool write_flags);
 void vo_lane_fill(vo_ctx* c, int lane, int slot, uint64_t seed, TrackDev* d_tr, LaneDesc* out);   // descriptor of lane `lane` of context c
 int vo_corr_from_host(vo_ctx* c, const float* xyz, const float* uv, int n);

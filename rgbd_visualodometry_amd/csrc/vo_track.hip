@@ -447,10 +447,11 @@ __global__ __launch_bounds__(64) void k_ransac_hyp(const LaneDesc* __restrict__ 
     hyp_cnt[h] = 0;
 }
 
-__global__ __launch_bounds__(1024) void k_ransac_score(const LaneDesc* __restrict__ lanes, int n_hyp, double thr2) {
+__global__ __launch_bounds__(1024) void k_ransac_score(const LaneDesc* __restrict__ lanes, int n_hyp, double thr2, int rank, int world) {
     LANE_PTRS(lanes)
     __shared__ int s_cnt;
     const int h = blockIdx.x;
+    if (world > 1 && h % world != rank) { if (threadIdx.x == 0) hyp_cnt[h] = 0; return; }      // another rank scores it: 0 goes into the sum
     if (hyp_cnt[h] < 0) return;
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
@@ -914,13 +915,15 @@ int vo_corr_from_host(vo_ctx* c, const float* xyz, const float* uv, int n) {
     return VO_OK;
 }
 
-int vo_track_ransac_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* dl, int nl, int n_hyp, float reproj_px, float conf, int pass) {
+int vo_track_ransac_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* dl, int nl, int n_hyp, float reproj_px, float conf, int pass, int stage, int rank, int world) {
     const double thr2 = (double)reproj_px * (double)reproj_px;
-    { ProfScope ps(prof, "k_ransac_hyp", st);
-      hipLaunchKernelGGL(k_ransac_hyp, dim3((n_hyp + 63) / 64, 1, nl), dim3(64), 0, st, dl, n_hyp, pass); }
-    { ProfScope ps(prof, "k_ransac_score", st);
-      hipLaunchKernelGGL(k_ransac_score, dim3(n_hyp, 1, nl), dim3(1024), 0, st, dl, n_hyp, thr2); }
-    { ProfScope ps(prof, "k_ransac_select", st);
+    if (stage & 1) {
+      { ProfScope ps(prof, "k_ransac_hyp", st);
+        hipLaunchKernelGGL(k_ransac_hyp, dim3((n_hyp + 63) / 64, 1, nl), dim3(64), 0, st, dl, n_hyp, pass); }
+      { ProfScope ps(prof, "k_ransac_score", st);
+        hipLaunchKernelGGL(k_ransac_score, dim3(n_hyp, 1, nl), dim3(1024), 0, st, dl, n_hyp, thr2, rank, world); }
+    }
+    if (stage & 2) { ProfScope ps(prof, "k_ransac_select", st);
       hipLaunchKernelGGL(k_ransac_select, dim3(1, 1, nl), dim3(1024), 0, st, dl, n_hyp, thr2, (double)conf); }
     HIP_TRY(hipGetLastError());
     return VO_OK;

@@ -50,6 +50,20 @@ class Group:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def all_reduce_sum_i32(self, arr) -> None:
+        """In-place element-wise sum of a host int32 array over the ranks: the exchange step of hypothesis-sharded RANSAC
+        (RCCL all-reduce over xGMI with backend nccl, gloo in the CPU tests)."""
+        if not self.dist:
+            return
+        import torch
+        t = torch.from_numpy(arr)
+        if self.device is not None:
+            d = t.to(self.device)
+            self.dist.all_reduce(d, op=self.dist.ReduceOp.SUM)
+            t.copy_(d.cpu())
+        else:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+
     def gather_objects(self, obj) -> List:
         if not self.dist:
             return [obj]

@@ -41,3 +41,57 @@ def test_two_rank_gloo_stream_sharding(tmp_path):
     assert abs(out["max"] - max(a["elapsed"], b["elapsed"])) < 1e-9  # MAX over ranks
     assert abs(out["fps"] - 16 / out["max"]) < 1e-9                  # whole-job aggregate, weak scaling
     assert a["ate"] < 0.05 and b["ate"] < 0.05
+
+
+WORKER_HYP = r'''
+import json, os, sys
+sys.path.insert(0, %r)
+import numpy as np
+from oracle import ORACLE_LIB
+from rgbd_visualodometry_amd import capi, shard
+g = shard.Group("gloo")
+L = capi.load(ORACLE_LIB)
+syn = capi.Synth()
+bgr, depth, Twc, _ = syn.render(syn.params(seed=77), 0, 4, threads=2)      # every rank sees the SAME stream
+p = L.default_params(n_features=600, max_frames=2, map_capacity=4096, max_hypotheses=512)
+ctx = L.context(p)
+ctx.upload(0, bgr[0], depth[0]); ctx.upload(1, bgr[3], depth[3]); ctx.orb(0, 2)
+k0, d0 = ctx.orb_fetch(0)
+ok = k0["depth_raw"] > 0
+z = k0["depth_raw"][ok] / 5000.0
+pw = np.stack([(k0["x"][ok] - p.cx) * z / p.fx, (k0["y"][ok] - p.cy) * z / p.fy, z], 1)
+idx = np.arange(len(pw), dtype=np.int32)
+ctx.map_upsert(idx, pw, pw / np.linalg.norm(pw, axis=1, keepdims=True), d0[ok], np.zeros(len(pw), np.uint8))
+ctx.map_set_active(idx)
+tp = L.default_track_params(n_hyp=256)
+ident = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], float)
+r0, m0 = ctx.track(1, ident, tp)                                            # un-sharded
+n_ex = [0]
+def ex(a):
+    n_ex[0] += 1
+    g.all_reduce_sum_i32(a)
+ctx.set_hypothesis_shard(g.rank, g.world, ex)
+r1, m1 = ctx.track(1, ident, tp)                                            # hypotheses h %% world == rank scored here
+same = (np.array_equal(np.array(r0.T_cw), np.array(r1.T_cw)) and r0.n_ransac_inliers == r1.n_ransac_inliers and r0.best_hypothesis == r1.best_hypothesis
+        and r0.ransac_iters == r1.ransac_iters and np.array_equal(m0, m1))
+allr = g.gather_objects({"rank": g.rank, "same": bool(same), "exchanges": n_ex[0], "inliers": int(r1.n_ransac_inliers), "pose": [float(v) for v in r1.T_cw]})
+if g.rank == 0:
+    print("RESULT " + json.dumps(allr))
+g.close()
+''' % ROOT
+
+
+def test_two_rank_gloo_hypothesis_shard(tmp_path):
+    """SURVEY.md 8e-2 over a real collective: two ranks track the same frame, each scores half of the RANSAC hypotheses, one
+    all-reduce (sum) of the count vector per pass; both ranks end with the un-sharded result."""
+    script = tmp_path / "worker_hyp.py"
+    script.write_text(WORKER_HYP)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29578", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29578", str(script)]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][0][len("RESULT "):])
+    assert len(out) == 2 and all(o["same"] for o in out)
+    assert out[0]["exchanges"] == out[1]["exchanges"] == 2          # coarse + fine pass
+    assert out[0]["pose"] == out[1]["pose"] and out[0]["inliers"] > 100

@@ -204,3 +204,48 @@ def test_concurrent_local_bas_equal_sequential_ones(libs):
             assert abs(rg.chi2_final - rw.chi2_final) <= 1e-6 * max(1.0, rw.chi2_final) and abs(rg.chi2_initial - rw.chi2_initial) <= 1e-9 * rw.chi2_initial
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.parametrize("libs", LIBS)
+def test_hypothesis_shard_equals_unsharded_ransac(libs, streams):
+    """the RANSAC hypotheses of a frame (batch) scored by `world` ranks, one exchange (element-wise sum of the
+    per-hypothesis inlier counts) per pass.  Simulated in one process: "rank 1" runs first and its partial counts are kept,
+    "rank 0" adds them in its exchange -- its result must be the un-sharded result, bit for bit."""
+    L = capi.load(libs[0])
+    bgr, depth, Twc, _ = streams[0]
+    p = L.default_params(n_features=800, max_frames=4, map_capacity=8192, max_track_batch=3, max_hypotheses=512)
+    ctx = L.context(p)
+    for s in range(4):
+        ctx.upload(s, bgr[2 * s], depth[2 * s])
+    ctx.orb(0, 4)
+    k0, d0 = ctx.orb_fetch(0)
+    seed_map(ctx, p, k0, d0, Twc[0])
+    tp = L.default_track_params(n_hyp=384)
+    slots, prior, seeds = [1, 2, 3], inv12(Twc[0]), [11, 12, 13]
+    want = ctx.track_batch_deferred(slots, prior, tp, seeds, cap=4096)
+    kept, calls = [], [0]
+
+    def rank1_exchange(a):                                  # keeps its partial counts (what the collective would send)
+        kept.append(a.copy())
+
+    def rank0_exchange(a):
+        other = kept[calls[0]]
+        calls[0] += 1
+        assert other.shape == a.shape
+        own = np.arange(len(a)) % 384 % 2 == 0              # hypothesis h of every lane belongs to rank h % 2
+        assert np.all(a[~own] == 0) and np.all(other[own] == 0) and np.any(a[own] > 0) and np.any(other[~own] > 0)
+        a += other
+    ctx.set_hypothesis_shard(1, 2, rank1_exchange)
+    ctx.track_batch_deferred(slots, prior, tp, seeds, cap=4096)
+    n_exchanges = len(kept)
+    ctx.set_hypothesis_shard(0, 2, rank0_exchange)
+    got = ctx.track_batch_deferred(slots, prior, tp, seeds, cap=4096)
+    assert calls[0] == n_exchanges and n_exchanges >= 2     # one per pass (HIP: all lanes at once; CPU restatement: per lane)
+    for j in range(3):
+        for f in FIELDS:
+            assert getattr(got[0][j], f) == getattr(want[0][j], f), (j, f)
+        assert np.array_equal(np.array(got[0][j].T_cw), np.array(want[0][j].T_cw)) and np.array_equal(got[1][j], want[1][j])
+    ctx.set_hypothesis_shard(0, 1, None)                    # off again
+    again = ctx.track_batch_deferred(slots, prior, tp, seeds, cap=4096)
+    assert np.array_equal(np.array(again[0][0].T_cw), np.array(want[0][0].T_cw))
+    ctx.close()
