@@ -32,6 +32,8 @@ typedef struct myslam_options {
     int32_t map_capacity;
     int32_t device;
     int32_t verbose;
+    int32_t triangulate_all;                /* 0: the reference's loop (stops after the first success, frontend.cpp:501); 1: every eligible point, batched */
+    int32_t reobserve_new_mappoints;        /* 1: run the reference's disabled re-observation pass (frontend.cpp:408-463) at every keyframe */
 } myslam_options;
 
 typedef struct myslam_stats {
@@ -45,6 +47,7 @@ typedef struct myslam_stats {
     int64_t tracked_frames, sum_active, sum_candidates, sum_matches, sum_ransac_inliers, sum_lm_inliers, sum_lm_iters;
     int64_t track_launches;                                 /* vo_track_batch calls (launch chains) */
     int32_t ba_failed, ba_capped;                           /* local BA runs skipped after a failed solve / solved with a capped free set */
+    int64_t triangulated, reobserved_matches;               /* points refined by triangulation; gated matches counted by the re-observation pass */
 } myslam_stats;
 
 int myslam_default_options(myslam_options* o);

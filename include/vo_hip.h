@@ -238,6 +238,15 @@ int vo_group_stats(vo_group* g, int64_t* chains, int64_t* lanes, int64_t* reques
 typedef void (*vo_exchange_fn)(void* user, int32_t* counts, int n);
 int vo_set_hypothesis_shard(vo_ctx* ctx, int rank, int world, vo_exchange_fn exchange, void* user);
 
+/* ---- batched triangulation -------------------------------------------------------------- */
+/* Linear N-view triangulation (reference include/myslam/util.h:16-34) of MANY map points in one launch, as applied by
+ * FrontEnd::TriangulateMappointsInTrackingMap (src/frontend.cpp:465-506) to the LM inliers of a keyframe: point i owns the
+ * views view_start[i] .. view_start[i+1]-1; per view the keyframe pose T_cw (12 doubles) and the observation on the
+ * normalised image plane (x, y; z = 1).  ok[i] = 1 iff sigma4 / sigma3 < 1e-2 (and the point has >= 2 views); xyz is written
+ * for every point with >= 2 views. */
+int vo_triangulate_batch(vo_ctx* ctx, int n_points, const int32_t* view_start, const double* T_cw, const double* xy,
+                         double* xyz_out, uint8_t* ok_out);
+
 /* ---- local bundle adjustment --------------------------------------------------------- */
 int vo_local_ba(vo_ctx* ctx, const vo_ba_problem* in, vo_ba_result* out);
 

@@ -288,6 +288,18 @@ int vo_set_hypothesis_shard(vo_ctx* c, int rank, int world, vo_exchange_fn fn, v
     return VO_OK;
 }
 
+int vo_triangulate_batch(vo_ctx* c, int n, const int32_t* vs, const double* T, const double* xy, double* xyz, uint8_t* ok) {
+    if (!c || n < 0 || (n && (!vs || !T || !xy || !xyz || !ok))) return VO_E_INVALID;
+    for (int i = 0; i < n; ++i) {
+        const int nv = vs[i + 1] - vs[i];
+        if (nv < 0) return VO_E_INVALID;
+        ok[i] = 0;
+        if (nv < 2) continue;
+        ok[i] = triangulate_point(nv, T + 12 * (size_t)vs[i], xy + 2 * (size_t)vs[i], xyz + 3 * (size_t)i) ? 1 : 0;
+    }
+    return VO_OK;
+}
+
 // Stream groups: on the CPU every call is computed on the spot; the group only counts (the fused launch chain is a property
 // of the HIP implementation, the results are defined to be those of un-grouped calls).
 struct vo_group { long long requests = 0; int members = 0; };

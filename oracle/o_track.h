@@ -50,4 +50,7 @@ void pose_lm(const Cam& cam, const Corr& c, const std::vector<int32_t>& edges, c
 
 int local_ba(const Cam& cam, const vo_ba_problem& in, vo_ba_result& out);
 
+// linear N-view triangulation of one point (reference include/myslam/util.h:16-34): smallest eigenvector of A^T A by cyclic Jacobi
+bool triangulate_point(int n_views, const double* T_cw, const double* xy, double xyz[3]);
+
 }  // namespace orc

@@ -64,7 +64,7 @@ SYMBOLS = ["vo_ctx_create", "vo_ctx_destroy", "vo_strerror", "vo_backend_name", 
            "vo_match_active_map", "vo_matches_set", "vo_pnp_ransac", "vo_pose_refine_lm", "vo_track_frame", "vo_track_batch", "vo_track_fetch_matches",
            "vo_local_ba", "vo_sync", "vo_profile_enable", "vo_profile_read",
            "vo_group_create", "vo_group_destroy", "vo_group_join", "vo_group_leave", "vo_group_set_gather", "vo_group_stats",
-           "vo_set_hypothesis_shard"]
+           "vo_set_hypothesis_shard", "vo_triangulate_batch"]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int32), C.c_int)     # vo_exchange_fn: in-place element-wise sum over the ranks
@@ -120,6 +120,7 @@ class VoLib:
         L.vo_local_ba.argtypes = [C.c_void_p, C.POINTER(VoBaProblem), C.POINTER(VoBaResult)]
         L.vo_sync.argtypes = [C.c_void_p]
         L.vo_group_destroy.restype = None
+        L.vo_triangulate_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vo_set_hypothesis_shard.argtypes = [C.c_void_p, C.c_int, C.c_int, EXCHANGE_FN, C.c_void_p]
         L.vo_group_create.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.vo_group_destroy.argtypes = [C.c_void_p]
@@ -338,6 +339,15 @@ class VoContext:
             all_reduce_sum(np.ctypeslib.as_array(ptr, shape=(n,)))
         self._keep["shard_cb"] = EXCHANGE_FN(_cb) if all_reduce_sum is not None else EXCHANGE_FN(0)
         self.L.check(self.L.lib.vo_set_hypothesis_shard(self.h, rank, world, self._keep["shard_cb"], None), "vo_set_hypothesis_shard")
+
+    def triangulate_batch(self, view_start, T_cw, xy):
+        """Batched N-view triangulation -> (xyz [n, 3], ok [n])."""
+        vs = np.ascontiguousarray(view_start, dtype=np.int32); T = np.ascontiguousarray(T_cw, dtype=np.float64).reshape(-1, 12)
+        z = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
+        n = len(vs) - 1
+        xyz = np.zeros((max(n, 1), 3)); ok = np.zeros(max(n, 1), dtype=np.uint8)
+        self.L.check(self.L.lib.vo_triangulate_batch(self.h, n, _ptr(vs), _ptr(T), _ptr(z), _ptr(xyz), _ptr(ok)), "vo_triangulate_batch")
+        return xyz[:n], ok[:n].astype(bool)
 
     def sync(self):
         self.L.check(self.L.lib.vo_sync(self.h), "vo_sync")

@@ -36,7 +36,7 @@ public:
     void JoinGroup(vo_group* g);         // this stream's tracking calls share launch chains with the group's other streams
     struct Stats { int frames = 0, keyframes = 0, lost = 0; int last_candidates = 0, last_matches = 0, last_ransac = 0, last_lm = 0, last_keypoints = 0;
                    double ms_extract = 0, ms_track = 0, ms_keyframe = 0, ms_backend = 0, ms_refresh = 0, ms_flush = 0;
-                   long long tracked = 0, sum_active = 0, sum_cand = 0, sum_match = 0, sum_ransac = 0, sum_lm = 0, sum_lm_iters = 0, track_launches = 0; };
+                   long long triangulated = 0, reobserved = 0, tracked = 0, sum_active = 0, sum_cand = 0, sum_match = 0, sum_ransac = 0, sum_lm = 0, sum_lm_iters = 0, track_launches = 0; };
     const Stats& GetStats() const { return stats_; }
     bool verbose_ = false;
 
@@ -69,6 +69,8 @@ private:
     int   numInliers_ = 0;
     float minDisRatio_; int maxLostFrames_, minInliers_; double keyFrameMinRot_, keyFrameMinTrans_;
     int   nextSlot_ = 0;
+    int   lookahead_ = 1, scratchSlot_ = -1;        // frame slots [0, lookahead_) serve PrefetchFrames; the scratch slot re-detects old keyframes
+    bool  triangulateAll_ = false, reobserveNew_ = false;
     // speculative batch tracking: frames between keyframes share prior + map (frontend.cpp:96), so the frames that
     // follow the current one in the prefetch queue are tracked in the same launch chain; results are cached and
     // dropped when a keyframe / BA merge changes the inputs (epoch).
@@ -100,6 +102,8 @@ private:
     void AddCurrentKeyframeObservations();
     void CreateNewMappoints();
     void TriangulateMappointsInTrackingMap();
+    void TriangulateAllBatched();                    // triangulate_all: 1 -- every eligible point, one vo_triangulate_batch call
+    void AddNewMappointsObservationsForOldKeyframes();   // reobserve_new_mappoints: 1 (reference src/frontend.cpp:408-463, disabled there at :130)
 };
 }  // namespace myslam
 #endif

@@ -43,7 +43,11 @@ void FrontEnd::Init(int device, int width, int height, int max_frames) {
     params_.n_features = cfg_or<int>("number_of_features", params_.n_features);            // frontend.cpp:35
     params_.scale_factor = (float)cfg_or<double>("scale_factor", params_.scale_factor);    // :36
     params_.n_levels = cfg_or<int>("level_pyramid", params_.n_levels);                     // :37
-    params_.max_frames = std::max(1, max_frames);
+    lookahead_ = std::max(1, max_frames);
+    triangulateAll_ = cfg_or<int>("triangulate_all", 0) != 0;
+    reobserveNew_ = cfg_or<int>("reobserve_new_mappoints", 0) != 0;
+    params_.max_frames = lookahead_ + (reobserveNew_ ? 1 : 0);
+    scratchSlot_ = reobserveNew_ ? lookahead_ : -1;
     params_.map_capacity = cfg_or<int>("map_capacity", 1 << 20);
     trackBatch_ = std::max(1, std::min(16, cfg_or<int>("track_batch", 1)));
     params_.max_track_batch = trackBatch_;
@@ -110,7 +114,8 @@ bool FrontEnd::TrackingHandler() {
         ++stats_.keyframes;
         { VO_SCOPE("kf.add_observations"); AddCurrentKeyframeObservations(); }
         { VO_SCOPE("kf.create_mappoints"); CreateNewMappoints(); }
-        { VO_SCOPE("kf.triangulate"); TriangulateMappointsInTrackingMap(); }
+        if (reobserveNew_) { VO_SCOPE("kf.reobserve"); AddNewMappointsObservationsForOldKeyframes(); }
+        { VO_SCOPE("kf.triangulate"); if (triangulateAll_) TriangulateAllBatched(); else TriangulateMappointsInTrackingMap(); }
     }
     if (backend_) { StageTimer t(stats_.ms_backend); backend_->OptimizeCovisibleGraphOfKeyframe(frameCurr_); }
     framePrev_ = frameCurr_;
@@ -121,7 +126,7 @@ bool FrontEnd::TrackingHandler() {
 void FrontEnd::LostHandler() { if (verbose_) std::cout << "Tracking is lost" << std::endl; }
 
 int FrontEnd::PrefetchFrames(const std::vector<Frame::Ptr>& frames) {
-    const int n = std::min<int>((int)frames.size(), params_.max_frames);
+    const int n = std::min<int>((int)frames.size(), lookahead_);
     if (n <= 0) return 0;
     for (int i = 0; i < n; ++i) {
         const Frame::Ptr& f = frames[i];
@@ -352,6 +357,65 @@ void FrontEnd::CreateNewMappoints() {
     if (verbose_) std::cout << "Created new mappoints: " << newMappoints_.size() << std::endl;
 }
 
+// Every eligible point of the keyframe in one batched launch (vo_triangulate_batch): the reference's loop stops after the
+// first success (src/frontend.cpp:501 -- kept as the default policy above); `triangulate_all: 1` applies them all.
+void FrontEnd::TriangulateAllBatched() {
+    std::vector<Mappoint*> pts; std::vector<int32_t> vs{0}; std::vector<double> T, xy;
+    for (Mappoint* mp : pnpMatchedMpt_) {
+        if (mp->outlier_ || mp->triangulated_ || mp->optimized_) continue;
+        const size_t before = xy.size();
+        for (const Mappoint::Observation& o : mp->ObservationList()) {
+            if (o.keyframe == nullptr) continue;
+            double p12[12];
+            o.keyframe->GetPose().to12(p12);
+            T.insert(T.end(), p12, p12 + 12);
+            const Vec3 pc = o.keyframe->camera_->Pixel2Camera(o.pixel);
+            xy.push_back(pc[0]); xy.push_back(pc[1]);
+        }
+        if ((xy.size() - before) / 2 < 2) { xy.resize(before); T.resize(before / 2 * 12); continue; }
+        pts.push_back(mp); vs.push_back((int32_t)(xy.size() / 2));
+    }
+    if (pts.empty()) return;
+    std::vector<double> xyz(3 * pts.size()); std::vector<uint8_t> ok(pts.size());
+    vo_check(vo_triangulate_batch(ctx_, (int)pts.size(), vs.data(), T.data(), xy.data(), xyz.data(), ok.data()), "vo_triangulate_batch");
+    int cnt = 0;
+    for (size_t i = 0; i < pts.size(); ++i)
+        if (ok[i] && xyz[3 * i + 2] > 0) { pts[i]->SetPosition(Vec3(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2])); pts[i]->triangulated_ = true; ++cnt; }
+    stats_.triangulated += cnt;
+    if (verbose_) std::cout << "  Triangulate active mappoints size: " << cnt << " (batched, " << pts.size() << " candidates)" << std::endl;
+}
+
+// The reference's disabled pass (src/frontend.cpp:408-463, call commented out at :130): every local keyframe is detected
+// again and the map points just created are matched against it; like the reference it only COUNTS the matches that pass the
+// distance gate (the lines that would add the observations are commented out there, :452-453).
+void FrontEnd::AddNewMappointsObservationsForOldKeyframes() {
+    if (newMappoints_.empty() || scratchSlot_ < 0) return;
+    auto local = keyframeRef_->GetCovisibleKeyframes();
+    local.insert(keyframeRef_->GetId());
+    std::vector<size_t> ids(local.begin(), local.end());
+    std::sort(ids.begin(), ids.end());
+    FlushDirtyMappoints();                                  // the new points' descriptors and positions reach the device map
+    std::vector<int32_t> slots(newMappoints_.size());
+    for (size_t i = 0; i < newMappoints_.size(); ++i) slots[i] = newMappoints_[i]->slot_;
+    vo_check(vo_map_set_active(ctx_, slots.data(), (int)slots.size()), "vo_map_set_active");
+    long long matched = 0;
+    for (size_t id : ids) {
+        Frame::Ptr kf = MapManager::GetInstance().GetKeyframe(id);
+        if (!kf || kf->color_.empty()) continue;
+        if (kf->color_.on_device) vo_check(vo_frame_bind_device(ctx_, scratchSlot_, kf->color_.data, kf->color_.stride, kf->depth_.data, kf->depth_.stride), "vo_frame_bind_device");
+        else vo_check(vo_frame_upload(ctx_, scratchSlot_, (const uint8_t*)kf->color_.data, kf->color_.stride, (const uint16_t*)kf->depth_.data, kf->depth_.stride), "vo_frame_upload");
+        vo_check(vo_orb_detect_describe(ctx_, scratchSlot_, 1), "vo_orb_detect_describe");     // orb_->detectAndCompute(keyframe->color_, ...)
+        double T[12];
+        kf->GetPose().to12(T);
+        int n = 0, ncand = 0, mind = 0;
+        vo_check(vo_match_active_map(ctx_, scratchSlot_, T, trackParams_.match_ratio, trackParams_.match_floor, nullptr, 0, &n, &ncand, &mind), "vo_match_active_map");
+        matched += n;
+        if (verbose_) std::cout << " for keyframe " << id << " add " << n << " new observations" << std::endl;
+    }
+    stats_.reobserved += matched;
+    keyframeForTrackingMap_ = nullptr;                      // the active list was borrowed: the next frame uploads the tracking map again
+}
+
 void FrontEnd::TriangulateMappointsInTrackingMap() {
     int triangulatedCnt = 0;
     for (Mappoint* mp : pnpMatchedMpt_) {                                           // trackingMap_ ∩ pnpMatchedMptSet_, id order
@@ -367,7 +431,7 @@ void FrontEnd::TriangulateMappointsInTrackingMap() {
             if (Triangulation(poses, points, pworld) && pworld[2] > 0) {
                 mp->SetPosition(pworld);
                 mp->triangulated_ = true;
-                triangulatedCnt++;
+                triangulatedCnt++; ++stats_.triangulated;
                 break;                                                              // frontend.cpp:501
             }
         }

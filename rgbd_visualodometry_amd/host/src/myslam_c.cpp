@@ -68,6 +68,7 @@ int myslam_system_create(const myslam_options* o, const char* yaml, myslam_syste
         Config::set("keyframe_rotation", S(o->keyframe_rotation)); Config::set("keyframe_translation", S(o->keyframe_translation));
         Config::set("enable_local_optimization", S(o->enable_local_optimization)); Config::set("chi2_th", S(o->chi2_th));
         Config::set("ransac_iterations", S(o->ransac_iterations)); Config::set("track_batch", S(o->track_batch)); Config::set("map_capacity", S(o->map_capacity));
+        Config::set("triangulate_all", S(o->triangulate_all)); Config::set("reobserve_new_mappoints", S(o->reobserve_new_mappoints));
         if (yaml) Config::setParameterFile(yaml);
         MapManager::BindToThread(&s->map);
         s->camera = Camera::Ptr(new Camera);
@@ -274,6 +275,7 @@ int myslam_get_stats(myslam_system* s, myslam_stats* st) {
     if (getenv("VO_TRACE")) fprintf(stderr, "[vo_trace] frontend ms: extract %.1f track %.1f (refresh %.1f flush %.1f) keyframe %.1f backend %.1f\n", f.ms_extract, f.ms_track, f.ms_refresh, f.ms_flush, f.ms_keyframe, f.ms_backend);
     st->tracked_frames = f.tracked; st->sum_active = f.sum_active; st->sum_candidates = f.sum_cand; st->sum_matches = f.sum_match; st->sum_ransac_inliers = f.sum_ransac;
     st->sum_lm_inliers = f.sum_lm; st->sum_lm_iters = f.sum_lm_iters; st->track_launches = f.track_launches;
+    st->triangulated = f.triangulated; st->reobserved_matches = f.reobserved;
     st->last_ransac_inliers = f.last_ransac; st->last_lm_inliers = f.last_lm; st->map_points = (int)s->map.MappointCount();
     if (s->backend) {
         const auto& b = s->backend->GetStats();

@@ -25,7 +25,7 @@ class Options(C.Structure):
                 ("max_num_lost", C.c_int32), ("min_inliers", C.c_int32), ("keyframe_rotation", C.c_double),
                 ("keyframe_translation", C.c_double), ("enable_local_optimization", C.c_int32), ("chi2_th", C.c_float),
                 ("ransac_iterations", C.c_int32), ("backend_lag_frames", C.c_int32), ("max_frames_in_flight", C.c_int32), ("track_batch", C.c_int32), ("map_capacity", C.c_int32),
-                ("device", C.c_int32), ("verbose", C.c_int32)]
+                ("device", C.c_int32), ("verbose", C.c_int32), ("triangulate_all", C.c_int32), ("reobserve_new_mappoints", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -37,7 +37,7 @@ class Stats(C.Structure):
                 ("ms_extract", C.c_double), ("ms_track", C.c_double), ("ms_keyframe", C.c_double), ("ms_backend", C.c_double),
                 ("tracked_frames", C.c_int64), ("sum_active", C.c_int64), ("sum_candidates", C.c_int64), ("sum_matches", C.c_int64),
                 ("sum_ransac_inliers", C.c_int64), ("sum_lm_inliers", C.c_int64), ("sum_lm_iters", C.c_int64), ("track_launches", C.c_int64),
-                ("ba_failed", C.c_int32), ("ba_capped", C.c_int32)]
+                ("ba_failed", C.c_int32), ("ba_capped", C.c_int32), ("triangulated", C.c_int64), ("reobserved_matches", C.c_int64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -332,6 +332,25 @@ def test_vo_system_config5_sizes_gpu_matches_oracle():
     np.testing.assert_allclose(ph, po, atol=1e-6)
 
 
+def test_triangulate_all_and_reobservation_pass_match_oracle(frames):
+    """SURVEY 8f-4 through the host layer: batched triangulation of every eligible point (vo_triangulate_batch) and the
+    reference's disabled re-observation pass (src/frontend.cpp:408-463: re-detect each local keyframe, match the new map points,
+    count the gated matches) give the same counters and the same trajectory on both implementations."""
+    from rgbd_visualodometry_amd import system
+    bgr, depth, Twc, ts = frames
+    out = []
+    for lib in (system.HOST_LIB, ORACLE_LIB):
+        s = system.VoSystem(lib, number_of_features=600, triangulate_all=1, reobserve_new_mappoints=1, keyframe_rotation=0.01, keyframe_translation=0.01)
+        poses = [s.add_frame(ts[i], bgr[i], depth[i])[1] for i in range(len(ts))]
+        out.append((np.array(poses), s.stats()))
+        s.close()
+    (ph, sh), (po, so) = out
+    assert sh["keyframes"] == so["keyframes"] >= 4
+    assert sh["reobserved_matches"] == so["reobserved_matches"] > 100
+    assert sh["triangulated"] == so["triangulated"]
+    np.testing.assert_allclose(ph, po, atol=1e-6)
+
+
 def test_degenerate_frames_behave_like_the_oracle(frames, libs):
     """Edge cases of the chain: a textureless frame (no FAST corner survives), an empty tracking map, a tracking map the
     frame cannot see -- same counts and status on both sides, no fault."""

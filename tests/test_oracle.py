@@ -268,3 +268,17 @@ def test_speculative_batch_and_lookahead_do_not_change_the_trajectory(frames):
     lag_a, sa = run_system(ORACLE_LIB, frames, n, number_of_features=400, backend_lag_frames=3)
     lag_b, sb = run_system(ORACLE_LIB, frames, n, number_of_features=400, backend_lag_frames=3, max_frames_in_flight=8, track_batch=4)
     assert np.array_equal(lag_a, lag_b) and sa["ba_runs"] == sb["ba_runs"] >= 1
+
+
+def test_triangulate_all_and_reobservation_options(frames):
+    """triangulate_all / reobserve_new_mappoints are off by default; switched on they run at every keyframe."""
+    bgr, depth, _, ts = frames
+    base = system.VoSystem(ORACLE_LIB, number_of_features=400, keyframe_rotation=0.01, keyframe_translation=0.01, enable_local_optimization=0)
+    opt = system.VoSystem(ORACLE_LIB, number_of_features=400, keyframe_rotation=0.01, keyframe_translation=0.01, enable_local_optimization=0, triangulate_all=1, reobserve_new_mappoints=1)
+    for i in range(10):
+        base.add_frame(ts[i], bgr[i], depth[i]); opt.add_frame(ts[i], bgr[i], depth[i])
+    sb, so = base.stats(), opt.stats()
+    assert sb["reobserved_matches"] == 0 and sb["triangulated"] <= sb["keyframes"]       # reference: at most one per keyframe (break after the first success)
+    assert so["keyframes"] >= 4 and so["reobserved_matches"] > 50
+    assert so["triangulated"] >= sb["triangulated"]
+    base.close(); opt.close()

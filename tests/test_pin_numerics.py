@@ -515,3 +515,36 @@ def test_local_ba_reaches_a_stationary_point_and_culls_by_chi2(lib):
     # Gauss-Newton decrement of the remaining gradient is tiny compared with the cost
     assert np.abs(g).max() < 2e-2 * max(1.0, c0), "gradient %.3g at cost %.3g" % (np.abs(g).max(), c0)
     ctx.close()
+
+
+@pytest.mark.parametrize("lib", LIBS)
+def test_batched_triangulation_against_svd(lib):
+    """vo_triangulate_batch (reference include/myslam/util.h:16-34 for many points): smallest right singular vector of the DLT
+    matrix, success iff sigma4 / sigma3 < 1e-2 -- against numpy's SVD."""
+    L = capi.load(lib)
+    rng = np.random.default_rng(12)
+    vs, Ts, xys, want, okw, ratios = [0], [], [], [], [], []
+    for i in range(400):
+        n = int(rng.integers(1, 7))                        # single-view points take part too: never a success
+        X = rng.uniform(-1, 1, 3) + [0, 0, 4]
+        noise = 0.0 if i % 4 == 0 else 10 ** rng.uniform(-5, -1.5)
+        Tl, pl = [], []
+        for _ in range(n):
+            T = rm.se3_exp(np.concatenate([rng.normal(0, 0.4, 3), rng.normal(0, 0.15, 3)]))
+            pc = T[:9].reshape(3, 3) @ X + T[9:]
+            Tl.append(T); pl.append([pc[0] / pc[2] + rng.normal(0, noise), pc[1] / pc[2] + rng.normal(0, noise), 1.0])
+        Ts += Tl; xys += [p[:2] for p in pl]; vs.append(vs[-1] + n)
+        if n >= 2:
+            x, ok, sv = rm.triangulate(Tl, pl)
+            want.append(x); okw.append(ok); ratios.append(sv[3] / sv[2])
+        else:
+            want.append(np.zeros(3)); okw.append(False); ratios.append(1.0)
+    ctx = L.context(L.default_params(n_features=64, map_capacity=64))
+    xyz, ok = ctx.triangulate_batch(vs, np.array(Ts), np.array(xys))
+    ctx.close()
+    ratios = np.array(ratios); okw = np.array(okw)
+    safe = np.abs(ratios - 1e-2) > 1e-6
+    assert np.array_equal(ok[safe], okw[safe]) and 100 < ok.sum() < 390
+    good = ratios < 0.5
+    err = np.abs(xyz[good] - np.array(want)[good]).max(axis=1) * (1 - ratios[good])
+    assert err.max() < 1e-6
