@@ -300,6 +300,7 @@ int vo_triangulate_batch(vo_ctx* c, int n, const int32_t* vs, const double* T, c
     return VO_OK;
 }
 
+// (the FAST candidate lists of the CPU restatement are unbounded vectors; the HIP capacity is sized so that it cannot overflow)
 // Stream groups: on the CPU every call is computed on the spot; the group only counts (the fused launch chain is a property
 // of the HIP implementation, the results are defined to be those of un-grouped calls).
 struct vo_group { long long requests = 0; int members = 0; };

@@ -45,7 +45,9 @@ static int build_plan(const vo_params& p, DevPlan& P, std::vector<int>& tab, std
     int maxq = 1;
     for (int l = 0; l < P.L; ++l) {
         P.qprefix[l + 1] = P.qprefix[l] + P.quota[l];
-        P.ccap[l] = std::max(4096, P.lw[l] * P.lh[l] / 8);
+        // strict 3x3 maxima never touch (8-neighbourhood): at most every other pixel in x and in y survives the NMS, so
+        // this capacity cannot overflow whatever the image (no arrival-order truncation, no error path)
+        P.ccap[l] = std::max(4096, ((P.lw[l] + 1) / 2) * ((P.lh[l] + 1) / 2));
         P.cprefix[l + 1] = P.cprefix[l] + P.ccap[l];
         P.tiles_x[l] = (P.lw[l] - 2 * P.edge + 63) / 64;
         const int tiles_y = (P.lh[l] - 2 * P.edge + 15) / 16;

@@ -9,8 +9,9 @@
 //                                                scores never leave LDS; survivors appended to a list
 //   k_select    retain-best by FAST then Harris  one workgroup per (level, slot): LDS histogram cut,
 //                                                exact integer Harris, LDS bitonic sort
-//   k_describe  IC angle + 7x7 blur + rBRIEF     one wavefront per keypoint: 43x43 patch staged in LDS,
-//                                                256 tests packed with 4 x __ballot (64 lanes)
+//   k_blur      7x7 sigma-2 Gaussian, 8-bit      streaming pass over the whole pyramid (LDS tile + halo)
+//   k_describe  IC angle + rBRIEF                one wavefront per keypoint: moments over the radius-15 disc, 256 steered
+//                                                tests on the blurred level packed with 4 x __ballot (64 lanes), depth sample
 //
 // Integer pipeline end to end: bit-exact against oracle/o_orb.cpp by construction.
 #include <cfloat>
@@ -265,8 +266,8 @@ __global__ __launch_bounds__(1024) void k_select(DevPlan P, const uint8_t* __res
     for (int i = tid; i < n; i += 1024) {
         const uint32_t c = cl[i];
         if ((int)(c >> 24) >= thr) {
-            const int pos = atomicAdd(&s_misc[0], 1);
-            if (pos < P.sel_cap) {
+            const int pos = atomicAdd(&s_misc[0], 1);      // at most 4 x quota <= sel_cap entries pass `thr` (see the cut above): the order of arrival only
+            if (pos < P.sel_cap) {                         // permutes the list that the sort below orders by (Harris key, pixel index)
                 const int x = c & 0xFFF, y = (c >> 12) & 0xFFF;
                 s_key[pos] = harris_key_dev(img, pitch, x, y);
                 s_idx[pos] = c & 0xFFFFFF;

@@ -126,8 +126,10 @@ bool FrontEnd::TrackingHandler() {
 void FrontEnd::LostHandler() { if (verbose_) std::cout << "Tracking is lost" << std::endl; }
 
 int FrontEnd::PrefetchFrames(const std::vector<Frame::Ptr>& frames) {
-    const int n = std::min<int>((int)frames.size(), lookahead_);
+    if ((int)frames.size() > lookahead_) throw std::runtime_error("PrefetchFrames: more frames than frame slots (max_frames_in_flight)");
+    const int n = (int)frames.size();
     if (n <= 0) return 0;
+    for (const Frame::Ptr& old : prefetched_) if (old) { old->orb_done_ = false; old->slot_ = -1; }      // their slots are rebound below
     for (int i = 0; i < n; ++i) {
         const Frame::Ptr& f = frames[i];
         if (f->color_.cols != params_.width || f->color_.rows != params_.height) throw std::runtime_error("frame size differs from the context's");

@@ -117,6 +117,7 @@ int myslam_add_prefetched(myslam_system* s, int* tracked, double T_wc[12]) {
 int myslam_add_frame(myslam_system* s, double stamp, const void* bgr, const void* depth, int bs, int ds, int on_device, int* tracked, double T_wc[12]) {
     if (!s || !bgr || !depth) return -1;
     return guarded(s, [&]() {
+        if (!s->queue.empty()) throw std::runtime_error("myslam_add_frame: prefetched frames are still queued (consume them with myslam_add_prefetched first)");
         Frame::Ptr f = make_frame(s, stamp, bgr, depth, bs, ds, on_device);
         bool ok = s->frontend->AddFrame(f);
         if (tracked) *tracked = ok ? 1 : 0;
