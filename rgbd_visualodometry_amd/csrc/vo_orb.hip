@@ -14,6 +14,13 @@
 //                                                tests on the blurred level packed with 4 x __ballot (64 lanes), depth sample
 //
 // Integer pipeline end to end: bit-exact against oracle/o_orb.cpp by construction.
+//
+// Frame-to-XCD affinity.  MI355X = 8 XCDs with a private 4 MiB L2 each; workgroups of a 1-D grid are dealt to the XCDs
+// round-robin (workgroup b runs on XCD b % 8).  With 8 or more frames in a batch every kernel of the chain sends ALL
+// workgroups of frame slot s to XCD s % 8 (vo_slot_block below): a frame's pyramid and its blurred copy (~1 MB each at
+// 640x480) are produced and consumed inside one L2 -- level l feeds level l+1, FAST, Harris, blur and the descriptor
+// gathers without a trip through HBM, and tile halos are never fetched by two L2s.  Batches of fewer than 8 frames
+// spread each frame over all XCDs instead (latency matters there, traffic does not).
 #include <cfloat>
 #include <climits>
 #include <cstdio>
@@ -25,6 +32,15 @@
 // rBRIEF test pattern: statically initialised, so every device of the process gets its copy with the code object
 // (a run-time upload guarded by a process-wide flag left the second GPU of a process with zeros)
 __constant__ int8_t c_pattern[256][4] = VO_BRIEF_PATTERN_INIT;
+
+// blockIdx.x -> (frame slot relative to the batch, block index inside the slot's share of the grid)
+__device__ __forceinline__ bool vo_slot_block(int per_slot, int n, int affinity, int& slot_rel, int& j) {
+    const int b = blockIdx.x;
+    if (affinity) { const int q = b >> 3; slot_rel = (b & 7) + 8 * (q / per_slot); j = q % per_slot; }
+    else { slot_rel = b / per_slot; j = b % per_slot; }
+    return slot_rel < n;
+}
+static inline int vo_slot_grid(int per_slot, int n, int affinity) { return affinity ? 8 * per_slot * ((n + 7) / 8) : per_slot * n; }
 
 // ------------------------------------------------------------------------------------------
 // 16 pixels per lane: 3 x 16-byte loads of BGR, one 16-byte store of gray (the row pitches are multiples of 16 for the
@@ -38,10 +54,12 @@ __device__ __forceinline__ uint32_t gray4(uint32_t w0, uint32_t w1, uint32_t w2)
     const uint32_t v2 = (b2 * 1868u + g2 * 9617u + r2 * 4899u + 8192u) >> 14, v3 = (b3 * 1868u + g3 * 9617u + r3 * 4899u + 8192u) >> 14;
     return v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
 }
-__global__ __launch_bounds__(256) void k_gray(DevPlan P, const SlotDesc* __restrict__ slots, uint8_t* __restrict__ pyr, int slot0) {
-    const int slot = slot0 + blockIdx.z;
+__global__ __launch_bounds__(256) void k_gray(DevPlan P, const SlotDesc* __restrict__ slots, uint8_t* __restrict__ pyr, int slot0, int n, int aff, int per_slot) {
+    int srel, jb;
+    if (!vo_slot_block(per_slot, n, aff, srel, jb)) return;
+    const int slot = slot0 + srel;
     const int gpr = (P.W + 15) >> 4;                   // 16-pixel groups per row
-    const int id = blockIdx.x * 256 + threadIdx.x;
+    const int id = jb * 256 + threadIdx.x;
     if (id >= gpr * P.H) return;
     const int y = id / gpr, x = (id - y * gpr) * 16;
     const SlotDesc sd = slots[slot];
@@ -61,9 +79,11 @@ __global__ __launch_bounds__(256) void k_gray(DevPlan P, const SlotDesc* __restr
 
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_resize(DevPlan P, int l, uint8_t* __restrict__ pyr, const int* __restrict__ tab,
-                                                const short* __restrict__ tabs, int slot0) {
-    const int slot = slot0 + blockIdx.z;
-    const int dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y * 4 + threadIdx.y;
+                                                const short* __restrict__ tabs, int slot0, int n, int aff, int gx, int gy) {
+    int srel, jb;
+    if (!vo_slot_block(gx * gy, n, aff, srel, jb)) return;
+    const int slot = slot0 + srel;
+    const int dx = (jb % gx) * 64 + threadIdx.x, dy = (jb / gx) * 4 + threadIdx.y;
     const int dw = P.lw[l], dh = P.lh[l], sw = P.lw[l - 1], sh = P.lh[l - 1];
     if (dx >= dw || dy >= dh) return;
     const uint8_t* src = pyr + (size_t)slot * P.pyr_stride + P.loff[l - 1];
@@ -115,11 +135,14 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t* g, int idx) {
 }
 
 __global__ __launch_bounds__(256) void k_fast_nms(DevPlan P, const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand,
-                                                  int* __restrict__ cand_cnt, int* __restrict__ status, int slot0) {
+                                                  int* __restrict__ cand_cnt, int* __restrict__ status, int slot0, int n, int aff, int per_slot) {
     __shared__ __align__(4) uint8_t s_gray[GP * (TH + 8)];
     __shared__ uint8_t s_score[SP * (TH + 2)];
-    const int slot = slot0 + blockIdx.z;
-    const int per_xcd = gridDim.x >> 3, tile = P.xcd_map ? (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;      // XCD-aware order, see k_blur
+    int srel, jb;
+    if (!vo_slot_block(per_slot, n, aff, srel, jb)) return;
+    const int slot = slot0 + srel;
+    // few frames: a frame's tiles are spread over the XCDs in 8 contiguous runs (neighbouring tiles share halo rows in one L2)
+    const int per_xcd = per_slot >> 3, tile = (!aff && P.xcd_map) ? (jb & 7) * per_xcd + (jb >> 3) : jb;
     if (tile >= P.tile_prefix[P.L]) return;
     int l = 0;
     while (l + 1 < P.L && tile >= P.tile_prefix[l + 1]) ++l;
@@ -234,13 +257,15 @@ __device__ __forceinline__ bool sel_before(long long ka, uint32_t ia, long long 
 // one workgroup per (level, slot)
 __global__ __launch_bounds__(1024) void k_select(DevPlan P, const uint8_t* __restrict__ pyr, const uint32_t* __restrict__ cand,
                                                  const int* __restrict__ cand_cnt, uint32_t* __restrict__ sel, long long* __restrict__ sel_key,
-                                                 int* __restrict__ sel_cnt, int slot0) {
+                                                 int* __restrict__ sel_cnt, int slot0, int nslots, int aff) {
     extern __shared__ __align__(16) unsigned char smem[];
     long long* s_key = (long long*)smem;                            // [sel_cap]
     uint32_t* s_idx = (uint32_t*)(smem + (size_t)P.sel_cap * 8);    // [sel_cap]  packed (y<<12|x) doubles as the tie-break index y*4096+x
     int* s_hist = (int*)(smem + (size_t)P.sel_cap * 12);            // [256] + misc
     int* s_misc = s_hist + 256;
-    const int l = blockIdx.x, slot = slot0 + blockIdx.y, tid = threadIdx.x;
+    int srel, l;
+    if (!vo_slot_block(P.L, nslots, aff, srel, l)) return;
+    const int slot = slot0 + srel, tid = threadIdx.x;
     const int n = min(cand_cnt[slot * VO_MAX_LEVELS + l], P.ccap[l]);
     const int quota = P.quota[l];
     const uint32_t* cl = cand + (size_t)slot * P.cprefix[P.L] + P.cprefix[l];
@@ -309,14 +334,16 @@ __global__ __launch_bounds__(1024) void k_select(DevPlan P, const uint8_t* __res
 #define BTW 128
 #define BTH 16
 #define BSTR (BTW + 16)                                 // s_in row stride in bytes: 4 halo bytes left, 4+ right, 16-byte multiple
-__global__ __launch_bounds__(256) void k_blur(DevPlan P, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, int slot0) {
+__global__ __launch_bounds__(256) void k_blur(DevPlan P, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, int slot0, int n, int aff, int per_slot) {
     // 4 pixels per lane in every phase: dword loads/stores to HBM and LDS (rows and level offsets are 64-byte aligned)
     __shared__ uint32_t s_in[(BTH + 6) * BSTR / 4];
     __shared__ uint32_t s_h[(BTH + 6) * BTW / 2];      // u16 row sums, two per dword
-    const int slot = slot0 + blockIdx.z;
-    // XCD-aware tile order: workgroups go round-robin over the 8 XCDs (each with its own L2), so workgroup b works on
-    // tile (b % 8) * (tiles / 8) + b / 8 -- neighbouring tiles, which share halo rows, meet in the same L2
-    const int per_xcd = gridDim.x >> 3, tile = P.xcd_map ? (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+    int srel, jb;
+    if (!vo_slot_block(per_slot, n, aff, srel, jb)) return;
+    const int slot = slot0 + srel;
+    // few frames: workgroups go round-robin over the 8 XCDs (each with its own L2), so block j of the frame works on
+    // tile (j % 8) * (tiles / 8) + j / 8 -- neighbouring tiles, which share halo rows, meet in the same L2
+    const int per_xcd = per_slot >> 3, tile = (!aff && P.xcd_map) ? (jb & 7) * per_xcd + (jb >> 3) : jb;
     if (tile >= P.btile_prefix[P.L]) return;
     int l = 0;
     while (l + 1 < P.L && tile >= P.btile_prefix[l + 1]) ++l;
@@ -407,13 +434,15 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 __global__ __launch_bounds__(256) void k_describe(DevPlan P, const SlotDesc* __restrict__ slots, const uint8_t* __restrict__ pyr,
                                                   const uint8_t* __restrict__ blurp, const uint32_t* __restrict__ sel,
                                                   const long long* __restrict__ sel_key, const int* __restrict__ sel_cnt,
-                                                  vo_keypoint* __restrict__ kps, uint8_t* __restrict__ desc, int* __restrict__ nkp, int slot0) {
-    const int slot = slot0 + blockIdx.y;
+                                                  vo_keypoint* __restrict__ kps, uint8_t* __restrict__ desc, int* __restrict__ nkp, int slot0, int n, int aff, int per_slot) {
+    int srel, jb;
+    if (!vo_slot_block(per_slot, n, aff, srel, jb)) return;
+    const int slot = slot0 + srel;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int g = blockIdx.x * 4 + wave;
+    const int g = jb * 4 + wave;
     int l = 0, base = 0, total = 0;
     for (int i = 0; i < P.L; ++i) total += sel_cnt[slot * VO_MAX_LEVELS + i];
-    if (blockIdx.x == 0 && threadIdx.x == 0) nkp[slot] = total;
+    if (jb == 0 && threadIdx.x == 0) nkp[slot] = total;
     if (g >= P.nfeat) return;
     while (l + 1 < P.L && g >= P.qprefix[l + 1]) { base += sel_cnt[slot * VO_MAX_LEVELS + l]; ++l; }
     if ((g - P.qprefix[l]) >= sel_cnt[slot * VO_MAX_LEVELS + l]) return;
@@ -483,27 +512,28 @@ int vo_orb_upload_constants() {
 int vo_orb_launch(vo_ctx* c, int slot0, int n) {
     const DevPlan& P = c->plan;
     hipStream_t st = c->stream;
+    const int aff = (n >= 8 && !getenv("VO_NO_XCD_AFFINITY")) ? 1 : 0;      // frame-to-XCD affinity (see the file header)
     HIP_TRY(hipMemsetAsync(c->d_cand_cnt + (size_t)slot0 * VO_MAX_LEVELS, 0, sizeof(int) * VO_MAX_LEVELS * n, st));
     { ProfScope ps(c, "k_gray");
-      dim3 g((((P.W + 15) / 16) * P.H + 255) / 256, 1, n);
-      hipLaunchKernelGGL(k_gray, g, dim3(256), 0, st, P, c->d_slots, c->d_pyr, slot0); }
+      const int per = (((P.W + 15) / 16) * P.H + 255) / 256;
+      hipLaunchKernelGGL(k_gray, dim3(vo_slot_grid(per, n, aff)), dim3(256), 0, st, P, c->d_slots, c->d_pyr, slot0, n, aff, per); }
     for (int l = 1; l < P.L; ++l) {
         ProfScope ps(c, "k_resize");
-        dim3 g((P.lw[l] + 63) / 64, (P.lh[l] + 3) / 4, n);
-        hipLaunchKernelGGL(k_resize, g, dim3(64, 4), 0, st, P, l, c->d_pyr, c->d_tab, c->d_tabs, slot0);
+        const int gx = (P.lw[l] + 63) / 64, gy = (P.lh[l] + 3) / 4;
+        hipLaunchKernelGGL(k_resize, dim3(vo_slot_grid(gx * gy, n, aff)), dim3(64, 4), 0, st, P, l, c->d_pyr, c->d_tab, c->d_tabs, slot0, n, aff, gx, gy);
     }
     { ProfScope ps(c, "k_fast_nms");
-      dim3 g(8 * ((P.tile_prefix[P.L] + 7) / 8), 1, n);
-      hipLaunchKernelGGL(k_fast_nms, g, dim3(64, 4), 0, st, P, c->d_pyr, c->d_cand, c->d_cand_cnt, c->d_status, slot0); }
+      const int per = 8 * ((P.tile_prefix[P.L] + 7) / 8);
+      hipLaunchKernelGGL(k_fast_nms, dim3(vo_slot_grid(per, n, aff)), dim3(64, 4), 0, st, P, c->d_pyr, c->d_cand, c->d_cand_cnt, c->d_status, slot0, n, aff, per); }
     { ProfScope ps(c, "k_select");
       size_t lds = (size_t)P.sel_cap * 12 + 4 * 260;
-      dim3 g(P.L, n);
-      hipLaunchKernelGGL(k_select, g, dim3(1024), lds, st, P, c->d_pyr, c->d_cand, c->d_cand_cnt, c->d_sel, c->d_sel_key, c->d_sel_cnt, slot0); }
+      hipLaunchKernelGGL(k_select, dim3(vo_slot_grid(P.L, n, aff)), dim3(1024), lds, st, P, c->d_pyr, c->d_cand, c->d_cand_cnt, c->d_sel, c->d_sel_key, c->d_sel_cnt, slot0, n, aff); }
     { ProfScope ps(c, "k_blur");
-      hipLaunchKernelGGL(k_blur, dim3(8 * ((P.btile_prefix[P.L] + 7) / 8), 1, n), dim3(32, 8), 0, st, P, c->d_pyr, c->d_blur, slot0); }
+      const int per = 8 * ((P.btile_prefix[P.L] + 7) / 8);
+      hipLaunchKernelGGL(k_blur, dim3(vo_slot_grid(per, n, aff)), dim3(32, 8), 0, st, P, c->d_pyr, c->d_blur, slot0, n, aff, per); }
     { ProfScope ps(c, "k_describe");
-      dim3 g((P.nfeat + 3) / 4, n);
-      hipLaunchKernelGGL(k_describe, g, dim3(256), 0, st, P, c->d_slots, c->d_pyr, c->d_blur, c->d_sel, c->d_sel_key, c->d_sel_cnt, c->d_kps, c->d_desc, c->d_nkp, slot0); }
+      const int per = (P.nfeat + 3) / 4;
+      hipLaunchKernelGGL(k_describe, dim3(vo_slot_grid(per, n, aff)), dim3(256), 0, st, P, c->d_slots, c->d_pyr, c->d_blur, c->d_sel, c->d_sel_key, c->d_sel_cnt, c->d_kps, c->d_desc, c->d_nkp, slot0, n, aff, per); }
     HIP_TRY(hipGetLastError());
     return VO_OK;
 }

@@ -75,6 +75,26 @@ def test_orb_bit_exact(frames, libs, nfeat):
         np.testing.assert_allclose(kh["response"], ko["response"], rtol=1e-5)
 
 
+def test_orb_batch_with_frame_to_xcd_affinity_is_bit_exact(frames, libs):
+    """Batches of >= 8 frame slots send every frame's workgroups to one XCD (vo_orb.hip header); same bits as frame-by-frame."""
+    bgr, depth, _, _ = frames
+    H, O = libs
+    ctx, _ = make_ctx(H, n_features=1200, max_frames=10)
+    octx, _ = make_ctx(O, n_features=1200, max_frames=1)
+    for s in range(10):
+        ctx.upload(s, bgr[s], depth[s])
+    ctx.orb(0, 10)
+    for s in (0, 3, 7, 8, 9):
+        octx.upload(0, bgr[s], depth[s]); octx.orb(0, 1)
+        kh, dh = ctx.orb_fetch(s)
+        ko, do = octx.orb_fetch(0)
+        assert len(kh) == len(ko) == 1200 and np.array_equal(dh, do)
+        for f in ("x", "y", "size", "angle", "response", "octave", "class_id", "depth_raw"):
+            assert np.array_equal(kh[f], ko[f]), (s, f)
+        for l in (0, 4, 7):
+            assert np.array_equal(ctx.fetch_level(s, l), octx.fetch_level(0, l)) and np.array_equal(ctx.fetch_blur_level(s, l), octx.fetch_blur_level(0, l))
+
+
 def test_match_bit_exact(frames, libs):
     bgr, depth, Twc, _ = frames
     out = []
