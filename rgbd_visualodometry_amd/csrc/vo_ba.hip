@@ -1198,8 +1198,10 @@ int vo_ba_set_attrs() {
 
 // ---- the BA engine: continuous batching of local BAs ------------------------------------------------------------------
 // One engine per GPU and process.  A caller (vo_local_ba on any context of that GPU: the back-end workers of several
-// streams) prepares its problem on its own stream, hands it to the engine and sleeps.  The engine thread keeps up to
-// BA_SLOTS problems "in flight": every LM step is ONE sequence of launches over all active slots (blockIdx.z = slot), a
+// streams) prepares its problem on its own stream and hands it to the engine.  Whichever caller finds the engine without
+// a driver drives it (enqueues the steps, polls the control blocks) until its own problem is done, then passes the wheel
+// to one of the callers still waiting -- no dedicated thread, no hand-off latency for a lone stream.  The engine keeps up
+// to BA_SLOTS problems "in flight": every LM step is ONE sequence of launches over all active slots (blockIdx.z = slot), a
 // problem that arrives while others are being solved joins at the next chunk of steps, one that finishes its robust
 // round is culled and restarted for the plain round, one that finishes leaves -- none waits for the others.  So eight
 // streams' BAs cost about the latency of one (their kernels are small: a 6K x 6K Cholesky is one workgroup), where eight
@@ -1224,8 +1226,9 @@ struct BaEngine {
     BaJob* slot[BA_SLOTS] = {};
     std::mutex mu; std::condition_variable cv;
     std::deque<BaJob*> pending;
-    std::thread th; bool quit = false;
+    bool driving = false;                                   // a caller is inside ba_engine_pump
     long long n_steps = 0, n_slot_steps = 0, n_jobs = 0;
+    int pending_hint = 0;                                   // queue length seen by the last admission (chunk size policy)
 };
 static std::mutex g_eng_mu;
 static std::vector<BaEngine*> g_engines;
@@ -1275,12 +1278,13 @@ static int ba_engine_pump(BaEngine* E) {                    // engine thread; re
             if (rc != VO_OK) { j->rc = rc; j->done = true; E->slot[s] = nullptr; E->cv.notify_all(); }
             else ++E->n_jobs;
         }
+        E->pending_hint = (int)E->pending.size();
     }
     int act[BA_SLOTS], na = 0;
     for (int s = 0; s < BA_SLOTS; ++s) if (E->slot[s]) act[na++] = s;
     if (na == 0) return VO_OK;
     // ---- one chunk of LM steps over every active slot
-    int chunk = 6, g_lin = 0, g_init = 0, g_blk = 0, g_upd = 0, g_e = 0, g_md = 0;
+    int chunk = (na == 1 && E->pending_hint == 0) ? 16 : 6, g_lin = 0, g_init = 0, g_blk = 0, g_upd = 0, g_e = 0, g_md = 0;
     int s16[BA_SLOTS], n16 = 0, s16g[BA_SLOTS], n16g = 0, sfirst[BA_SLOTS], nfirst = 0; size_t lds16 = 0, lds16g = 0;
     for (int i = 0; i < na; ++i) {
         BaJob* j = E->slot[act[i]];
@@ -1349,28 +1353,24 @@ static int ba_engine_pump(BaEngine* E) {                    // engine thread; re
     return VO_OK;
 }
 
-static void ba_engine_loop(BaEngine* E) {
-    (void)hipSetDevice(E->device);
-    for (;;) {
-        {
-            std::unique_lock<std::mutex> lk(E->mu);
-            E->cv.wait(lk, [&] { if (E->quit || !E->pending.empty()) return true; for (int s = 0; s < BA_SLOTS; ++s) if (E->slot[s]) return true; return false; });
-            if (E->quit) return;
-        }
-        const int rc = ba_engine_pump(E);
-        if (rc != VO_OK) {                                  // a HIP error: fail everything in flight, keep serving
-            std::unique_lock<std::mutex> lk(E->mu);
-            for (int s = 0; s < BA_SLOTS; ++s) if (E->slot[s]) { E->slot[s]->rc = rc; E->slot[s]->done = true; E->slot[s] = nullptr; }
-            E->cv.notify_all();
-        }
-    }
-}
-
 static int ba_engine_solve(BaEngine* E, BaJob* j) {
     std::unique_lock<std::mutex> lk(E->mu);
     E->pending.push_back(j);
-    E->cv.notify_all();
-    E->cv.wait(lk, [&] { return j->done; });
+    while (!j->done) {
+        if (E->driving) { E->cv.wait(lk); continue; }
+        E->driving = true;                                  // this caller drives the engine until its own problem is done
+        while (!j->done) {
+            lk.unlock();
+            const int rc = ba_engine_pump(E);
+            lk.lock();
+            if (rc != VO_OK) {                              // a HIP error: fail everything in flight
+                for (int s = 0; s < BA_SLOTS; ++s) if (E->slot[s]) { E->slot[s]->rc = rc; E->slot[s]->done = true; E->slot[s] = nullptr; }
+                while (!E->pending.empty()) { E->pending.front()->rc = rc; E->pending.front()->done = true; E->pending.pop_front(); }
+            }
+        }
+        E->driving = false;
+        E->cv.notify_all();                                 // a caller whose problem is still in flight takes over
+    }
     return j->rc;
 }
 
@@ -1394,7 +1394,6 @@ BaEngine* vo_ba_engine_acquire(int device) {
         ok = hipMemcpy(E->d_ctl, E->h_ctl, sizeof(BaCtl) * BA_SLOTS, hipMemcpyHostToDevice) == hipSuccess;
     }
     if (!ok) { fprintf(stderr, "[vo_hip] BA engine: allocation failed on device %d\n", device); delete E; return nullptr; }
-    E->th = std::thread(ba_engine_loop, E);
     g_engines.push_back(E);
     return E;
 }
@@ -1406,9 +1405,6 @@ void vo_ba_engine_release(BaEngine* E) {
         if (--E->refs > 0) return;
         for (size_t i = 0; i < g_engines.size(); ++i) if (g_engines[i] == E) { g_engines.erase(g_engines.begin() + i); break; }
     }
-    { std::unique_lock<std::mutex> lk(E->mu); E->quit = true; }
-    E->cv.notify_all();
-    if (E->th.joinable()) E->th.join();
     (void)hipSetDevice(E->device);
     if (getenv("VO_TRACE")) fprintf(stderr, "[vo_trace] BA engine: %lld problems, %lld step launches, %.2f problems per step launch\n", E->n_jobs, E->n_steps, E->n_steps ? (double)E->n_slot_steps / E->n_steps : 0.0);
     if (E->st) { (void)hipStreamSynchronize(E->st); (void)hipStreamDestroy(E->st); }

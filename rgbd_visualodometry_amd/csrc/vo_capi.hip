@@ -670,13 +670,18 @@ static int chain_run(vo_ctx* prof, hipStream_t st, LaunchSet& ls, std::vector<Gr
     }
     // match records that callers asked for travel with the headers; sized from the largest match count seen recently
     // (+25 %): consecutive frames see the same map, and a synchronous second copy per lane costs more than the extra bytes
+    const bool grouped = batch[0]->c->stream != st;         // a stream group's chain
     for (GroupReq* r : batch) {
-        if (!r->matches) continue;
         vo_ctx* c = r->c;
+        c->h_matches_lanes = 0;
+        // Members of a group get the records of every lane with the chain's own read-back: a later vo_track_fetch_matches
+        // is then a host memcpy.  (An on-demand copy on the member's stream queues behind the other streams' ORB / BA copies.)
+        if (!r->matches && !grouped) continue;
         const int first = std::min(std::min(r->cap, c->n_active), std::max(MATCH_COPY_FIRST, c->match_hint + c->match_hint / 4));
         if ((rc = ensure_match_stage(c, std::max(first * r->n, std::min(r->cap, c->n_active))))) return rc;
         if (first > 0)
             HIP_TRY(hipMemcpy2DAsync(c->h_matches, sizeof(vo_match) * (size_t)first, c->d_matches, sizeof(vo_match) * c->lane_stride, sizeof(vo_match) * (size_t)first, r->n, hipMemcpyDeviceToHost, st));
+        if (!r->matches) { c->h_matches_lanes = r->n; c->h_matches_first = first; }
     }
     HIP_TRY(hipMemcpyAsync(ls.h_track, ls.d_track, sizeof(TrackDev) * nl, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -782,6 +787,12 @@ int vo_track_fetch_matches(vo_ctx* c, int lane, vo_match* matches, int cap, int*
     if (!c || lane < 0 || lane >= c->last_track_lanes || !matches || cap < 0 || !n_out) return VO_E_INVALID;
     HIP_TRY(hipSetDevice(c->device));
     const int n = std::min(cap, c->h_track[lane].n_match);
+    if (lane < c->h_matches_lanes && n <= c->h_matches_first) {      // the chain's read-back already holds this lane's records
+        memcpy(matches, c->h_matches + (size_t)lane * c->h_matches_first, sizeof(vo_match) * (size_t)n);
+        *n_out = n;
+        return VO_OK;
+    }
+    c->h_matches_lanes = 0;                                 // the staging buffer is reused below
     int rc = ensure_match_stage(c, std::max(n, 1));
     if (rc) return rc;
     if (n > 0) {

@@ -108,6 +108,7 @@ struct vo_ctx {
     int shard_rank = 0, shard_world = 1; vo_exchange_fn shard_fn = nullptr; void* shard_user = nullptr;     // RANSAC hypotheses sharded over ranks
     vo_match* h_matches;                            // pinned staging
     int h_matches_cap;
+    int h_matches_lanes = 0, h_matches_first = 0;   // lanes whose first `h_matches_first` records the last chain left in h_matches (group mode)
     void* h_stage; size_t h_stage_bytes;            // pinned general staging
     uint8_t* h_orb_cache; bool orb_cache_valid; int orb_batch0, orb_batchn;   // pinned copy of the last ORB batch's results
     bool corr_external;
