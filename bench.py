@@ -209,9 +209,9 @@ def main():
             table["k_pose_lm"]["f64_valu_frac"] = round(fl / (table["k_pose_lm"]["total_ms"] * 1e-3) / (F64_PEAK_TFLOPS * 1e12), 6)
             table["k_pose_lm"]["limiter"] = "latency: one workgroup per frame runs ~20 dependent f64 passes (edge loop, 28-value reduction, 6x6 solve)"
         runs = max(1, pst["ba_runs"])
-        if "k_ba_chol" in table:                            # (D^3/3 + 2 D^2) multiply-adds per factorisation + solve, D = 6 free poses
-            D = 6.0 * max(1, pst["ba_poses"])
-            flops = 2.0 * (D ** 3 / 3.0 + 2.0 * D ** 2) * table["k_ba_chol"]["launches"]
+        if "k_ba_chol" in table:                            # (D^3/3 + 2 D^2) multiply-adds per factorisation + solve, D = 6 free poses, averaged over the BA runs
+            D = (pst["ba_sum_d3"] / runs) ** (1.0 / 3.0)
+            flops = 2.0 * (pst["ba_sum_d3"] / runs / 3.0 + 2.0 * pst["ba_sum_d2"] / runs) * table["k_ba_chol"]["launches"]
             table["k_ba_chol"]["alg_flops_per_launch"] = int(flops / table["k_ba_chol"]["launches"])
             table["k_ba_chol"]["TFLOPps"] = round(flops / (table["k_ba_chol"]["total_ms"] * 1e-3) / 1e12, 5)
             table["k_ba_chol"]["limiter"] = "latency: one workgroup, panel-by-panel dependent chain (D = %d)" % int(D)
@@ -231,7 +231,13 @@ def main():
             # the current round that covers this kernel is used, otherwise null
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")))
-                roof["traffic"] = pmc["kernels"][dom]["hbm_bytes_per_launch_corrected"]
+                pk = pmc["kernels"]
+                for name, row in table.items():             # measured fabric traffic per launch beside the algorithmic bytes, where a PMC row exists
+                    m = pk.get(name) or pk.get(name + "16")
+                    if m:
+                        row["pmc_hbm_bytes_per_launch"] = m["hbm_bytes_per_launch_corrected"]
+                        row["pmc_GBps"] = round(m["hbm_bytes_per_launch_corrected"] / (row["avg_us"] * 1e-6) / 1e9, 1)
+                roof["traffic"] = (pk.get(dom) or pk[dom + "16"])["hbm_bytes_per_launch_corrected"]
                 roof["traffic_source"] = "profiles/r02_pmc_hbm_traffic.json (FETCH_SIZE, WRITE_SIZE: separate --pmc passes of `%s`)" % pmc.get("command", "bench.py")
             except Exception:
                 pass

@@ -1102,18 +1102,21 @@ __global__ void k_ba_chi(BaBatch Q, int trial, int robust, int guard) {
 __global__ __launch_bounds__(256) void k_ba_chi_control(BaBatch Q) {
     BA_PROBLEM(Q)
     if (B.ctl->finished) return;
-    const int nblk_e = (B.n_edges + 255) / 256;                 // this problem's share of the grid
+    const int nblk_e = (B.n_edges + 1023) / 1024;               // this problem's share of the grid: 4 edges per lane (a quarter of the workgroups = a quarter of the arrival atomics)
     if ((int)blockIdx.x >= nblk_e) return;
     const BaCam cam = B.cam; const double delta = B.delta; const int robust = B.ctl->robust;
     BA_STATE(B)
     __shared__ int s_last;
-    const int e = blockIdx.x * 256 + threadIdx.x;
     double v = 0;
-    if (e < B.n_edges && B.active[e]) {
-        double r[2], pc[3];
-        ba_err(cam, poses_t + 12 * (size_t)B.e_pose[e], pts_t + 3 * (size_t)B.e_pt[e], B.e_uv + 2 * (size_t)e, r, pc);
-        const double e2 = r[0] * r[0] + r[1] * r[1];
-        v = (robust && e2 > delta * delta) ? 2.0 * sqrt(e2) * delta - delta * delta : e2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int e = blockIdx.x * 1024 + k * 256 + threadIdx.x;
+        if (e < B.n_edges && B.active[e]) {
+            double r[2], pc[3];
+            ba_err(cam, poses_t + 12 * (size_t)B.e_pose[e], pts_t + 3 * (size_t)B.e_pt[e], B.e_uv + 2 * (size_t)e, r, pc);
+            const double e2 = r[0] * r[0] + r[1] * r[1];
+            v += (robust && e2 > delta * delta) ? 2.0 * sqrt(e2) * delta - delta * delta : e2;
+        }
     }
     v = vo_wave_sum_f64(v);
     __shared__ double s_w[12];
@@ -1211,7 +1214,7 @@ int vo_ba_set_attrs() {
 struct BaJob {
     vo_ctx* c = nullptr; const vo_ba_problem* in = nullptr; vo_ba_result* out = nullptr;
     BaDev B;
-    int grid_lin = 0, grid_initS = 0, grid_upd = 0, grid_e = 0, grid_maxdiag = 0; size_t lds = 0;
+    int grid_lin = 0, grid_initS = 0, grid_upd = 0, grid_e = 0, grid_c = 0, grid_maxdiag = 0; size_t lds = 0;
     int round = 0, cur_buf = 0, iters = 0, steps = 0, need_first = 0;
     double chi0 = 0, chi_final = 0;
     int rc = VO_OK; bool done = false;
@@ -1284,7 +1287,7 @@ static int ba_engine_pump(BaEngine* E) {                    // engine thread; re
     for (int s = 0; s < BA_SLOTS; ++s) if (E->slot[s]) act[na++] = s;
     if (na == 0) return VO_OK;
     // ---- one chunk of LM steps over every active slot
-    int chunk = (na == 1 && E->pending_hint == 0) ? 16 : 6, g_lin = 0, g_init = 0, g_blk = 0, g_upd = 0, g_e = 0, g_md = 0;
+    int chunk = (na == 1 && E->pending_hint == 0) ? 16 : 6, g_lin = 0, g_init = 0, g_blk = 0, g_upd = 0, g_c = 0, g_md = 0;
     int s16[BA_SLOTS], n16 = 0, s16g[BA_SLOTS], n16g = 0, sfirst[BA_SLOTS], nfirst = 0; size_t lds16 = 0, lds16g = 0;
     for (int i = 0; i < na; ++i) {
         BaJob* j = E->slot[act[i]];
@@ -1292,7 +1295,7 @@ static int ba_engine_pump(BaEngine* E) {                    // engine thread; re
         const int max_it = j->round == 0 ? j->in->it_robust : j->in->it_plain;
         chunk = std::min(chunk, std::max(2, max_it - (j->steps ? h.it : 0)));
         g_lin = std::max(g_lin, j->grid_lin); g_init = std::max(g_init, j->grid_initS); g_blk = std::max(g_blk, j->B.n_blocks);
-        g_upd = std::max(g_upd, j->grid_upd); g_e = std::max(g_e, j->grid_e);
+        g_upd = std::max(g_upd, j->grid_upd); g_c = std::max(g_c, j->grid_c);
         if (j->B.D <= 192) { s16[n16++] = act[i]; lds16 = std::max(lds16, j->lds); } else { s16g[n16g++] = act[i]; lds16g = std::max(lds16g, j->lds); }
         if (j->need_first) { sfirst[nfirst++] = act[i]; g_md = std::max(g_md, j->grid_maxdiag); }
     }
@@ -1308,7 +1311,7 @@ static int ba_engine_pump(BaEngine* E) {                    // engine thread; re
           if (n16) hipLaunchKernelGGL(k_ba_chol16, dim3(1, 1, n16), dim3(CH_THREADS), lds16, st, ba_batch_of(E, s16, n16));
           if (n16g) hipLaunchKernelGGL(k_ba_chol16g, dim3(1, 1, n16g), dim3(CH_THREADS), lds16g, st, ba_batch_of(E, s16g, n16g)); }
         { ProfScope ps(prof, "k_ba_update", st); hipLaunchKernelGGL(k_ba_update, dim3(g_upd, 1, na), blk, 0, st, Q); }
-        { ProfScope ps(prof, "k_ba_chi_control", st); hipLaunchKernelGGL(k_ba_chi_control, dim3(g_e, 1, na), blk, 0, st, Q); }
+        { ProfScope ps(prof, "k_ba_chi_control", st); hipLaunchKernelGGL(k_ba_chi_control, dim3(g_c, 1, na), blk, 0, st, Q); }
     }
     E->n_steps += chunk; E->n_slot_steps += (long long)chunk * na;
     for (int i = 0; i < na; ++i) { BaJob* j = E->slot[act[i]]; j->steps += chunk; j->need_first = 0; }
@@ -1528,12 +1531,17 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     // carve the scratch slab
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t o_poses = carve(96 * (size_t)np), o_pts = carve(24 * (size_t)nx), o_poses_n = carve(96 * (size_t)np), o_pts_n = carve(24 * (size_t)nx);
-    const size_t o_epose = carve(4 * (size_t)ne), o_ept = carve(4 * (size_t)ne), o_euv = carve(8 * (size_t)ne), o_act = carve(ne), o_flags = carve(ne);
+    // the host inputs come first and contiguous: they are packed into one pinned mirror and travel in ONE H2D copy (ten
+    // pageable copies per problem used to queue behind each other -- and behind the other streams' -- on the copy engines)
+    const size_t o_poses = carve(96 * (size_t)np), o_pts = carve(24 * (size_t)nx);
+    const size_t o_epose = carve(4 * (size_t)ne), o_ept = carve(4 * (size_t)ne), o_euv = carve(8 * (size_t)ne);
     const size_t o_ps = carve(4 * (size_t)(nx + 1)), o_pe = carve(4 * (size_t)ne);
     const size_t o_qs = carve(4 * (size_t)(nf + 1)), o_qe = carve(4 * (size_t)std::max<size_t>(ps_edges.size(), 1));
+    const size_t o_pspt = carve(4 * ps_pt.size() + 4);
+    const size_t up_end = off;
+    const size_t o_poses_n = carve(96 * (size_t)np), o_pts_n = carve(24 * (size_t)nx), o_act = carve(ne), o_flags = carve(ne);
     const size_t o_blk = carve(sizeof(BaBlock) * (size_t)std::max(nblk, 1)), o_pairs = carve(sizeof(int2) * (size_t)std::max(npairs, 1));
-    const size_t o_pspt = carve(4 * ps_pt.size() + 4), o_pcnt = carve(4 * (size_t)std::max(nb_all, 1)), o_poff = carve(4 * (size_t)std::max(nb_all, 1)), o_pn = carve(16);
+    const size_t o_pcnt = carve(4 * (size_t)std::max(nb_all, 1)), o_poff = carve(4 * (size_t)std::max(nb_all, 1)), o_pn = carve(16);
     const size_t o_Hpp = carve(288 * (size_t)nf), o_bp = carve(8 * (size_t)D), o_Hll = carve(72 * (size_t)nx), o_bl = carve(24 * (size_t)nx), o_scal = carve(64);
     const size_t o_partU = carve(16 * ((size_t)(nx + 63) / 64 + 1)), o_partC = carve(8 * ((size_t)(ne + 255) / 256 + 1));
     const size_t o_W = carve(144 * (size_t)ne), o_S = carve(8 * (size_t)D * D), o_bs = carve(8 * (size_t)D), o_Hinv = carve(72 * (size_t)nx), o_dl = carve(24 * (size_t)nx);
@@ -1554,17 +1562,24 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     B.cam = BaCam{(double)c->p.fx, (double)c->p.fy, (double)c->p.cx, (double)c->p.cy};
     B.delta = in->huber_delta; B.chi2_th = in->chi2_th; B.gp = (nx + 63) / 64;
 
-    HIP_TRY(hipMemcpyAsync(base + o_poses, in->poses, 96 * (size_t)np, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(base + o_pts, in->points, 24 * (size_t)nx, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(base + o_epose, in->edge_pose, 4 * (size_t)ne, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(base + o_ept, in->edge_point, 4 * (size_t)ne, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(base + o_euv, in->edge_uv, 8 * (size_t)ne, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(base + o_ps, pt_start.data(), 4 * (size_t)(nx + 1), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(base + o_pe, pt_edges.data(), 4 * (size_t)ne, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(base + o_qs, ps_start.data(), 4 * (size_t)(nf + 1), hipMemcpyHostToDevice, st));
-    if (!ps_edges.empty()) HIP_TRY(hipMemcpyAsync(base + o_qe, ps_edges.data(), 4 * ps_edges.size(), hipMemcpyHostToDevice, st));
+    {
+        if (up_end > c->h_ba_up_bytes) {                    // pinned mirror of the upload region, grown geometrically
+            if (c->h_ba_up) (void)hipHostFree(c->h_ba_up);
+            c->h_ba_up = nullptr; c->h_ba_up_bytes = 0;
+            const size_t want = up_end + up_end / 2 + (1 << 20);
+            if (hipHostMalloc(&c->h_ba_up, want, hipHostMallocDefault) != hipSuccess) { c->h_ba_up = nullptr; return VO_E_NOMEM; }
+            c->h_ba_up_bytes = want;
+        }
+        uint8_t* m = (uint8_t*)c->h_ba_up;                  // free: the stream was drained at the top of this function
+        memcpy(m + o_poses, in->poses, 96 * (size_t)np); memcpy(m + o_pts, in->points, 24 * (size_t)nx);
+        memcpy(m + o_epose, in->edge_pose, 4 * (size_t)ne); memcpy(m + o_ept, in->edge_point, 4 * (size_t)ne); memcpy(m + o_euv, in->edge_uv, 8 * (size_t)ne);
+        memcpy(m + o_ps, pt_start.data(), 4 * (size_t)(nx + 1)); memcpy(m + o_pe, pt_edges.data(), 4 * (size_t)ne);
+        memcpy(m + o_qs, ps_start.data(), 4 * (size_t)(nf + 1));
+        if (!ps_edges.empty()) memcpy(m + o_qe, ps_edges.data(), 4 * ps_edges.size());
+        if (dev_pairs && !ps_edges.empty()) memcpy(m + o_pspt, ps_pt.data(), 4 * ps_edges.size());
+        HIP_TRY(hipMemcpyAsync(base, m, up_end, hipMemcpyHostToDevice, st));
+    }
     if (dev_pairs) {
-        if (!ps_edges.empty()) HIP_TRY(hipMemcpyAsync(base + o_pspt, ps_pt.data(), 4 * ps_edges.size(), hipMemcpyHostToDevice, st));
         BaPairPlan Q;
         Q.ps_start = B.ps_start; Q.ps_edges = B.ps_edges; Q.ps_pt = (const int32_t*)(base + o_pspt); Q.nf = nf;
         Q.cnt = (int*)(base + o_pcnt); Q.off = (int*)(base + o_poff); Q.n_slices = (int*)(base + o_pn); Q.n_pairs = (int*)(base + o_pn) + 1;
@@ -1595,7 +1610,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     BaJob job;
     job.c = c; job.in = in; job.out = out; job.B = B; job.B.n_blocks = nblk_launch;
     job.grid_lin = (nx + 63) / 64 + nf * PSPLIT; job.grid_initS = (std::max(D * D, nx) + 255) / 256; job.grid_upd = (nx + 63) / 64 + (np + 255) / 256;
-    job.grid_e = (ne + 255) / 256; job.grid_maxdiag = (D + 3 * nx + 255) / 256;
+    job.grid_e = (ne + 255) / 256; job.grid_c = (ne + 1023) / 1024; job.grid_maxdiag = (D + 3 * nx + 255) / 256;
     job.lds = D <= 192 ? sizeof(double) * (CH_NB * CH_NB + (size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D)
                        : sizeof(double) * (CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D);
     if ((rc = ba_engine_solve(E, &job))) return rc;

@@ -259,6 +259,7 @@ void vo_ctx_destroy(vo_ctx* c) {
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_slots_pinned) (void)hipHostFree(c->h_slots_pinned);
     if (c->h_orb_cache) (void)hipHostFree(c->h_orb_cache);
+    if (c->h_ba_up) (void)hipHostFree(c->h_ba_up);
     if (c->slots_ev) (void)hipEventDestroy(c->slots_ev);
     for (auto& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);

@@ -32,7 +32,8 @@ public:
     bool Poll(size_t frameIndex);
     // frame index at which the pending job will be merged (SIZE_MAX: none pending)
     size_t NextMergeFrame() const { return job_ ? job_->frameIndex + (size_t)lag_ : (size_t)-1; }
-    struct Stats { int runs = 0, poses = 0, fixed = 0, points = 0, edges = 0, outliers = 0, failed = 0, capped = 0; double ms = 0, ms_build = 0, ms_solve = 0, ms_wait = 0; };
+    struct Stats { int runs = 0, poses = 0, fixed = 0, points = 0, edges = 0, outliers = 0, failed = 0, capped = 0; double ms = 0, ms_build = 0, ms_solve = 0, ms_wait = 0;
+                   double sum_d3 = 0, sum_d2 = 0; long long sum_edges = 0; };
     const Stats& GetStats() const { return stats_; }
     // the flattened graph of a keyframe, for inspection (parity tests): what Solve would be handed
     struct GraphView { std::vector<size_t> poseIds; int nFree = 0; std::vector<size_t> pointIds; std::vector<int32_t> edgePose, edgePoint; std::vector<float> edgeUv; };

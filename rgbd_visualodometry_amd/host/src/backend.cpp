@@ -226,6 +226,7 @@ void Backend::Apply(Job& j) {
     }
     stats_.runs++; stats_.poses = j.nFree; stats_.fixed = (int)j.poseFrames.size() - j.nFree; stats_.points = (int)j.points.size();
     stats_.edges = (int)j.edgePose.size(); stats_.outliers = outlierCnt; stats_.ms_solve += j.solveMs;
+    { const double D = 6.0 * j.nFree; stats_.sum_d3 += D * D * D; stats_.sum_d2 += D * D; stats_.sum_edges += (long long)j.edgePose.size(); }
 }
 
 }  // namespace myslam
