@@ -198,7 +198,7 @@ def test_concurrent_local_bas_equal_sequential_ones(libs):
         for k, ((pw, xw, fw, rw), (pg, xg, fg, rg)) in enumerate(zip(want, got)):
             assert abs(rg.lm_iters - rw.lm_iters) <= (0 if probs[k][1] < 10 else 2), k
             assert np.array_equal(fg, fw), k
-            tol = 1e-9 if probs[k][1] < 10 else 1e-6       # f64 atomics: summation order differs run to run
+            tol = 1e-7 if probs[k][1] < 10 else 1e-6       # f64 atomics (LDS accumulators, partial sums): summation order differs run to run
             np.testing.assert_allclose(pg, pw, atol=tol)
             np.testing.assert_allclose(xg, xw, atol=10 * tol)
             assert abs(rg.chi2_final - rw.chi2_final) <= 1e-6 * max(1.0, rw.chi2_final) and abs(rg.chi2_initial - rw.chi2_initial) <= 1e-9 * rw.chi2_initial
