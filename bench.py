@@ -10,7 +10,8 @@ For N>1 every rank tracks its own independent stream (configs[3]): weak scaling,
 collective (frames of one stream are sequentially dependent).
 
 Inputs are rendered on the host before the timed region and are resident in HBM (torch tensors)
-when it starts.  The timed region ends after the last frame's pending local BA has been solved
+when it starts.  The stream is first advanced --prologue frames (untimed, like the warmup) so that short runs time the
+same steady state as long ones: a young map has a fifth of the active points and local BAs a tenth of the size.  The timed region ends after the last frame's pending local BA has been solved
 and merged (Backend::Flush) and the device is idle.
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel, live HIP-event
@@ -114,6 +115,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=150, help="bounded single-thread CPU-baseline sample (frames; ~20 s of CPU work at the default)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU baseline (0: min(host cpus, 64))")
     ap.add_argument("--no-latency-mode", action="store_true")
+    ap.add_argument("--prologue", type=int, default=150, help="frames tracked (untimed) before the warmup so that the timed steps see the steady-state map: covisible window, BA size and active-map size level off after ~100 frames; 0 = time a young map")
     ap.add_argument("--multi-streams", default="8", help="comma list of stream counts for the several-streams-per-GPU figure ('' = skip)")
     args = ap.parse_args()
 
@@ -128,7 +130,7 @@ def main():
     grp = shard.Group(args.dist_backend, device=torch.device("cuda", local_rank))     # RCCL; only barrier + MAX(time) cross ranks
 
     W, H, N = 640, 480, args.features
-    K, Wm = args.steps, args.warmup
+    K, Wm = args.steps, args.warmup + args.prologue          # everything before the timed steps is untimed: prologue + the caller's warmup
     total = K + Wm
     syn = capi.Synth()
     sp = syn.params(seed=shard.stream_seed(args.seed, rank), speed=args.speed)
@@ -249,7 +251,7 @@ def main():
         # ---- causal single-frame figure ---------------------------------------------------------------
         lat = None
         if not args.no_latency_mode and world == 1:
-            nl = min(total, 150)
+            nl = min(total, args.prologue + 150)
             lo = dict(opts, max_frames_in_flight=1, track_batch=1, backend_lag_frames=0)
             s1 = system.VoSystem(system.HOST_LIB, **lo)
             est_l = {}
@@ -260,7 +262,7 @@ def main():
                 per.append(time.perf_counter() - ta)
                 est_l[stamps[i]] = T
             s1.close()
-            body = np.array(per[min(10, nl // 2):])
+            body = np.array(per[min(max(10, args.prologue), nl // 2):])       # steady-state frames only
             lat = {"frames": int(len(body)), "frames_per_s": round(float(len(body) / body.sum()), 1), "ms_per_frame_mean": round(float(body.mean() * 1e3), 4),
                    "ms_per_frame_median": round(float(np.median(body) * 1e3), 4), "ms_per_frame_p95": round(float(np.percentile(body, 95) * 1e3), 4),
                    "config": "lookahead 1, track batch 1, local BA synchronous inside AddFrame (lag 0): every pose is final when AddFrame returns",
@@ -270,7 +272,7 @@ def main():
         multi = None
         if args.multi_streams and world == 1:
             multi = []
-            nfr = min(total, 136)
+            nfr, nwarm = min(total, args.prologue + 136), min(total, args.prologue + 136) - 120     # 120 timed frames per stream after the prologue
 
             def run_streams(S, grouped):
                 grp_ = system.StreamGroup(system.HOST_LIB, local_rank, 128) if grouped else None
@@ -281,10 +283,10 @@ def main():
                 bar = threading.Barrier(S + 1)
 
                 def run(s):
-                    drive(s, stamps, bptr, dptr, 0, 16, args.lookahead, W)
+                    drive(s, stamps, bptr, dptr, 0, nwarm, args.lookahead, W)
                     s.flush()
                     bar.wait()
-                    drive(s, stamps, bptr, dptr, 16, nfr, args.lookahead, W)
+                    drive(s, stamps, bptr, dptr, nwarm, nfr, args.lookahead, W)
                     s.flush()
                 ths = [threading.Thread(target=run, args=(s,)) for s in syss]
                 for th in ths:
@@ -300,12 +302,12 @@ def main():
                     s.close()
                 if grp_:
                     grp_.close()
-                return S * (nfr - 16) / tm, gs
+                return S * (nfr - nwarm) / tm, gs
 
             for S in [int(v) for v in args.multi_streams.split(",") if v]:
                 f_g, gs = run_streams(S, True)
                 f_s, _ = run_streams(S, False)
-                multi.append({"streams_per_gpu": S, "frames_per_stream": nfr - 16, "frames_per_s": round(f_g, 1),
+                multi.append({"streams_per_gpu": S, "frames_per_stream": nfr - nwarm, "frames_per_s": round(f_g, 1),
                               "hbm_frac_whole_frame": round(b_survey * f_g / (HBM_PEAK_GBS * 1e9), 6),
                               "vs_single_stream": round(f_g / fps, 2), "lanes_per_launch_chain": round(gs["lanes"] / max(1, gs["chains"]), 2),
                               "requests_per_launch_chain": round(gs["requests"] / max(1, gs["chains"]), 2),
@@ -351,7 +353,7 @@ def main():
             except Exception:
                 pass
             cpu = {"value": round(nf / tc, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-                   "sample": "first %d frames of the same synthetic stream, ONE thread (local BA synchronous), oracle/_build/liboracle_vo.so (-O3 -march=x86-64-v3)" % nf,
+                   "sample": "first %d frames of the same synthetic stream from a fresh map (younger, i.e. cheaper, than the GPU's timed steady state), ONE thread (local BA synchronous), oracle/_build/liboracle_vo.so (-O3 -march=x86-64-v3)" % nf,
                    "ate_rmse_m": acc_c["ate_rmse_m"], "gpu_ate_rmse_m_same_frames": acc_g.get("ate_rmse_m"),
                    "rpe_trans_rmse_m": acc_c["rpe_trans_rmse_m"],
                    "all_cores": {"value": round(T_all * nfa / ta, 2), "unit": "frames/s", "cores": T_all,
@@ -359,14 +361,15 @@ def main():
                    "host_cpus": os.cpu_count(), "cpu_model": cpu_model}
         kf_timed = st["keyframes"] - st_w["keyframes"]
         out = {
-            "metric": "VO frames/sec (640x480 RGB-D)", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "metric": "VO frames/sec (640x480 RGB-D)", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/f64", "data": "synthetic",
             "config": {"workload": "synthetic 640x480 RGB-D stream per GPU, %d ORB features, default.yaml tracking parameters, trajectory speed %.2g (keyframe every %.1f frames)"
                                    % (N, args.speed, (K / kf_timed) if kf_timed else float("inf")),
                        "streams_per_gpu": 1, "lookahead_frames": args.lookahead, "track_batch": args.track_batch,
                        "local_ba": (False if args.no_ba else ("synchronous" if args.ba_lag == 0 else "overlapped, merged %d frames later or at the next keyframe" % args.ba_lag)),
-                       "ransac_hypotheses": args.hyps, "speed": args.speed},
+                       "ransac_hypotheses": args.hyps, "speed": args.speed,
+                       "prologue_frames": args.prologue, "timed_frames": "frames %d..%d of the stream (steady state: the map and the local-BA window have levelled off)" % (Wm, total - 1)},
             **acc, "keyframes": st["keyframes"], "keyframes_timed": kf_timed, "ba_runs": st["ba_runs"], "ba_runs_timed": st["ba_runs"] - st_w["ba_runs"],
             "lost": st["lost"], "map_points": st["map_points"],
             "alg_bytes_per_frame_survey": b_survey, "hbm_frac_whole_frame": round(b_survey * (fps / world) / (HBM_PEAK_GBS * 1e9), 6),
