@@ -1437,21 +1437,22 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     HIP_TRY(hipStreamSynchronize(st));                      // the pinned staging buffer may still feed an earlier vo_map_upsert
     const double tt0 = tnow();
-    // CSR point -> edges
-    std::vector<int32_t> pt_start(nx + 1, 0), pt_edges(ne);
+    // CSR point -> edges and free pose -> edges: ONE counting pass here (the scratch vectors live in the context: no
+    // allocation, no zero-fill of edge-sized arrays per problem); the lists themselves are written straight into the pinned
+    // upload mirror further down
+    std::vector<int32_t>& pt_start = c->ba_pt_start; std::vector<int32_t>& ps_start = c->ba_ps_start;
+    pt_start.assign((size_t)nx + 1, 0); ps_start.assign((size_t)nf + 1, 0);
     bool sorted_by_point = true;
-    for (int e = 0; e < ne; ++e) { pt_start[in->edge_point[e] + 1]++; if (e && in->edge_point[e] < in->edge_point[e - 1]) sorted_by_point = false; }
+    for (int e = 0; e < ne; ++e) {
+        const int k = in->edge_point[e], j = in->edge_pose[e];
+        pt_start[k + 1]++;
+        if (e && k < in->edge_point[e - 1]) sorted_by_point = false;
+        if (j < nf) ps_start[j + 1]++;
+    }
     for (int k = 0; k < nx; ++k) pt_start[k + 1] += pt_start[k];
-    if (sorted_by_point) for (int e = 0; e < ne; ++e) pt_edges[e] = e;        // the graph cut of Backend::Build emits edges point by point
-    else { std::vector<int32_t> fill(pt_start.begin(), pt_start.end() - 1);
-           for (int e = 0; e < ne; ++e) pt_edges[fill[in->edge_point[e]]++] = e; }
-    // CSR free pose -> edges, and the (e1, e2) pair lists of every 6x6 block of the reduced system
-    std::vector<int32_t> ps_start(nf + 1, 0), ps_edges;
-    for (int e = 0; e < ne; ++e) if (in->edge_pose[e] < nf) ps_start[in->edge_pose[e] + 1]++;
     for (int j = 0; j < nf; ++j) ps_start[j + 1] += ps_start[j];
-    ps_edges.resize(ps_start[nf]);
-    { std::vector<int32_t> fill(ps_start.begin(), ps_start.end() - 1);
-      for (int e = 0; e < ne; ++e) if (in->edge_pose[e] < nf) ps_edges[fill[in->edge_pose[e]]++] = e; }
+    const size_t n_ps = (size_t)ps_start[nf];
+    std::vector<int32_t> pt_edges, ps_edges;                // only the host pair builder below needs them as vectors
     const double tp1 = tnow();
     // Device-built pair lists (k_ba_pairs) need the edges sorted by point (the per-pose lists are then sorted by point
     // and a block's list is a sorted intersection) and the longest per-pose list in LDS; otherwise the host builds them.
@@ -1463,18 +1464,20 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     std::vector<BaBlock> blocks;
     int npairs = 0;
     int2* pairs = nullptr;
-    std::vector<int32_t> ps_pt;
     int nb_all = 0, slices_ub = 0;
     int* h_counts = nullptr;
     if (dev_pairs) {
-        ps_pt.resize(std::max<size_t>(ps_edges.size(), 1));
-        for (size_t q = 0; q < ps_edges.size(); ++q) ps_pt[q] = in->edge_point[ps_edges[q]];
         nb_all = nf * (nf + 1) / 2;
         for (int j1 = 0; j1 < nf; ++j1) for (int j2 = j1; j2 < nf; ++j2) {
             const int m = std::min(ps_start[j1 + 1] - ps_start[j1], ps_start[j2 + 1] - ps_start[j2]);
             npairs += m; slices_ub += (m + 511) / 512;         // upper bounds: the device writes the real counts
         }
     } else {
+        pt_edges.resize(ne); ps_edges.resize(n_ps);
+        { std::vector<int32_t> fill(pt_start.begin(), pt_start.end() - 1);
+          for (int e = 0; e < ne; ++e) pt_edges[fill[in->edge_point[e]]++] = e; }
+        { std::vector<int32_t> fill(ps_start.begin(), ps_start.end() - 1);
+          for (int e = 0; e < ne; ++e) if (in->edge_pose[e] < nf) ps_edges[fill[in->edge_pose[e]]++] = e; }
         // Pair lists of the 6x6 blocks (j1 <= j2) of the reduced system, grouped by block with the points in ascending
         // order inside a block.  Host threads split the point range: count per (thread, block), prefix over blocks and
         // threads, then every thread writes its pairs straight into pinned memory -- same lists for any thread count.
@@ -1536,8 +1539,8 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     const size_t o_poses = carve(96 * (size_t)np), o_pts = carve(24 * (size_t)nx);
     const size_t o_epose = carve(4 * (size_t)ne), o_ept = carve(4 * (size_t)ne), o_euv = carve(8 * (size_t)ne);
     const size_t o_ps = carve(4 * (size_t)(nx + 1)), o_pe = carve(4 * (size_t)ne);
-    const size_t o_qs = carve(4 * (size_t)(nf + 1)), o_qe = carve(4 * (size_t)std::max<size_t>(ps_edges.size(), 1));
-    const size_t o_pspt = carve(4 * ps_pt.size() + 4);
+    const size_t o_qs = carve(4 * (size_t)(nf + 1)), o_qe = carve(4 * std::max<size_t>(n_ps, 1));
+    const size_t o_pspt = carve(4 * n_ps + 4);
     const size_t up_end = off;
     const size_t o_poses_n = carve(96 * (size_t)np), o_pts_n = carve(24 * (size_t)nx), o_act = carve(ne), o_flags = carve(ne);
     const size_t o_blk = carve(sizeof(BaBlock) * (size_t)std::max(nblk, 1)), o_pairs = carve(sizeof(int2) * (size_t)std::max(npairs, 1));
@@ -1573,10 +1576,22 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
         uint8_t* m = (uint8_t*)c->h_ba_up;                  // free: the stream was drained at the top of this function
         memcpy(m + o_poses, in->poses, 96 * (size_t)np); memcpy(m + o_pts, in->points, 24 * (size_t)nx);
         memcpy(m + o_epose, in->edge_pose, 4 * (size_t)ne); memcpy(m + o_ept, in->edge_point, 4 * (size_t)ne); memcpy(m + o_euv, in->edge_uv, 8 * (size_t)ne);
-        memcpy(m + o_ps, pt_start.data(), 4 * (size_t)(nx + 1)); memcpy(m + o_pe, pt_edges.data(), 4 * (size_t)ne);
-        memcpy(m + o_qs, ps_start.data(), 4 * (size_t)(nf + 1));
-        if (!ps_edges.empty()) memcpy(m + o_qe, ps_edges.data(), 4 * ps_edges.size());
-        if (dev_pairs && !ps_edges.empty()) memcpy(m + o_pspt, ps_pt.data(), 4 * ps_edges.size());
+        memcpy(m + o_ps, pt_start.data(), 4 * (size_t)(nx + 1)); memcpy(m + o_qs, ps_start.data(), 4 * (size_t)(nf + 1));
+        {   // the edge lists, written in place: point -> edges (identity when the caller's edges are grouped by point), free pose -> edges (+ their points)
+            int32_t* m_pe = (int32_t*)(m + o_pe); int32_t* m_qe = (int32_t*)(m + o_qe); int32_t* m_qp = (int32_t*)(m + o_pspt);
+            std::vector<int32_t>& cur = c->ba_cursor;
+            cur.assign(ps_start.begin(), ps_start.end());
+            if (sorted_by_point) {
+                for (int e = 0; e < ne; ++e) {
+                    m_pe[e] = e;
+                    const int j = in->edge_pose[e];
+                    if (j < nf) { const int pos = cur[j]++; m_qe[pos] = e; m_qp[pos] = in->edge_point[e]; }
+                }
+            } else {
+                memcpy(m_pe, pt_edges.data(), 4 * (size_t)ne);
+                for (int e = 0; e < ne; ++e) { const int j = in->edge_pose[e]; if (j < nf) { const int pos = cur[j]++; m_qe[pos] = e; m_qp[pos] = in->edge_point[e]; } }
+            }
+        }
         HIP_TRY(hipMemcpyAsync(base, m, up_end, hipMemcpyHostToDevice, st));
     }
     if (dev_pairs) {

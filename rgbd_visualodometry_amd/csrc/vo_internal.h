@@ -115,6 +115,7 @@ struct vo_ctx {
     // BA scratch; the device's BA engine (shared by the contexts of that device, vo_ba.hip)
     void* d_ba; size_t d_ba_bytes; struct BaEngine* ba_engine = nullptr;
     void* h_ba_up = nullptr; size_t h_ba_up_bytes = 0;      // pinned mirror of a BA problem's upload region
+    std::vector<int32_t> ba_pt_start, ba_ps_start, ba_cursor;      // host scratch of vo_ba_run (kept between problems)
     // profiling
     std::atomic<bool> prof_on; std::mutex prof_mu; std::vector<ProfRec> prof; std::vector<hipEvent_t> ev_pool;      // prof / ev_pool: under prof_mu
     ProfRec prof_open; hipStream_t prof_open_stream = nullptr; uint64_t prof_ticket = 0, prof_closed = 0;

@@ -11,10 +11,21 @@ public:
     typedef std::unordered_map<size_t, Point2f> ObservedByKeyframeIdtoPixelPos;
     struct Observation { size_t keyframeId; Point2f pixel; Frame* keyframe; };
 
-    Descriptor  descriptor_;        // 256-bit rBRIEF descriptor used for matching
+private:
+    // Hot fields first, in ONE cache line: the graph cut, the local-map query and the BA merge walk tens of thousands of
+    // map points per keyframe and touch exactly these (position, observation list, visit / index scratch, device slot).
+    Vector3d pos_;
+    std::vector<Observation> obsList_;
+public:
+    uint64_t baStamp_ = 0; int baIndex_ = -1;    // scratch of Backend::Build
+    int  slot_ = -1;                // device-map bookkeeping (slot in the vo_ctx map, set by MapManager::InsertMappoint)
+    uint64_t visitStamp_ = 0;       // scratch for de-duplicated traversals
+    bool        outlier_;           // no observation left / rejected
     bool        triangulated_;      // refined by the front-end's triangulation
     bool        optimized_;         // touched by the back-end
-    bool        outlier_;           // no observation left / rejected
+    bool dirty_ = false;            // host copy newer than the device copy (queued in MapManager's dirty list)
+
+    Descriptor  descriptor_;        // 256-bit rBRIEF descriptor used for matching
 
     static Mappoint::Ptr CreateMappoint(const Vector3d position, const Descriptor& descriptor);
 
@@ -39,11 +50,6 @@ public:
         return m;
     }
 
-    // device-map bookkeeping (slot in the vo_ctx map, set by MapManager::InsertMappoint)
-    int  slot_ = -1;
-    bool dirty_ = false;            // host copy newer than the device copy (queued in MapManager's dirty list)
-    uint64_t visitStamp_ = 0;       // scratch for de-duplicated traversals
-    uint64_t baStamp_ = 0; int baIndex_ = -1;    // scratch of Backend::Build
     void MarkDirty();
 
 private:
@@ -51,9 +57,7 @@ private:
     size_t id_;
     Vector3d norm_;
     std::mutex posLock_;
-    Vector3d pos_;
     std::mutex obsLock_;
-    std::vector<Observation> obsList_;
     Mappoint(const size_t id, const Vector3d position, const Descriptor& descriptor);
 };
 }  // namespace myslam

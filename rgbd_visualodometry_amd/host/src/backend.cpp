@@ -122,7 +122,10 @@ void Backend::Build(Job& j, const Frame::Ptr& kf) {
     { VO_SCOPE("ba.build.points");
     j.points.reserve(lastPoints_ + lastPoints_ / 4 + 1024);
     for (int p = 0; p < j.nFree; ++p) {
-        for (const Frame::ObservedEntry& e : j.poseFrames[p]->Observed()) {        // insertion order: deterministic without sorting
+        const std::vector<Frame::ObservedEntry>& ob = j.poseFrames[p]->Observed();
+        for (size_t q = 0; q < ob.size(); ++q) {                                    // insertion order: deterministic without sorting
+            if (q + 8 < ob.size()) __builtin_prefetch(ob[q + 8].mappoint);
+            const Frame::ObservedEntry& e = ob[q];
             Mappoint* mp = e.mappoint;
             if (!e.alive || mp->baStamp_ == stamp || mp->outlier_) continue;
             mp->baStamp_ = stamp; mp->baIndex_ = (int)j.points.size();
@@ -137,6 +140,9 @@ void Backend::Build(Job& j, const Frame::Ptr& kf) {
     int32_t* ep = j.edgePose.data(); int32_t* el = j.edgePoint.data(); float* uv = j.edgeUv.data();
     const size_t npts = j.points.size();
     for (size_t k = 0; k < npts; ++k) {
+        // the loop chases pointers (point -> its observation array -> keyframe): fetch the arrays of the points ahead
+        if (k + 12 < npts) __builtin_prefetch(j.points[k + 12]);
+        if (k + 6 < npts) __builtin_prefetch(j.points[k + 6]->ObservationList().data());
         const std::vector<Mappoint::Observation>& obs = j.points[k]->ObservationList();     // keyframe-id order
         if (ne + obs.size() > cap) {
             cap = 2 * (ne + obs.size());
@@ -160,7 +166,7 @@ void Backend::Build(Job& j, const Frame::Ptr& kf) {
     VO_SCOPE("ba.build.copy");
     j.poses.resize(12 * j.poseFrames.size()); j.pts.resize(3 * j.points.size());
     for (size_t p = 0; p < j.poseFrames.size(); ++p) j.poseFrames[p]->GetPose().to12(&j.poses[12 * p]);
-    for (size_t k = 0; k < j.points.size(); ++k) { const Vector3d& x = j.points[k]->PositionUnlocked(); j.pts[3 * k] = x[0]; j.pts[3 * k + 1] = x[1]; j.pts[3 * k + 2] = x[2]; }
+    for (size_t k = 0; k < j.points.size(); ++k) { if (k + 8 < j.points.size()) __builtin_prefetch(j.points[k + 8]); const Vector3d& x = j.points[k]->PositionUnlocked(); j.pts[3 * k] = x[0]; j.pts[3 * k + 1] = x[1]; j.pts[3 * k + 2] = x[2]; }
     j.posesOut.resize(12 * (size_t)std::max(j.nFree, 1)); j.ptsOut.resize(3 * std::max<size_t>(j.points.size(), 1)); j.flags.resize(std::max<size_t>(j.edgePose.size(), 1));
 }
 
@@ -212,6 +218,7 @@ void Backend::Apply(Job& j) {
     applySlots_.resize(np); applyXyz_.resize(3 * np);
     size_t m = 0;
     for (size_t k = 0; k < np; ++k) {
+        if (k + 8 < np) __builtin_prefetch(j.points[k + 8], 1);
         Mappoint& mp = *j.points[k];
         mp.optimized_ = true;                                                 // every point of the graph has at least one edge
         if (mp.outlier_) continue;

@@ -11,7 +11,7 @@ Mappoint::Ptr Mappoint::CreateMappoint(const Vector3d position, const Descriptor
 }
 
 Mappoint::Mappoint(const size_t id, const Vector3d position, const Descriptor& descriptor)
-    : descriptor_(descriptor), triangulated_(false), optimized_(false), outlier_(false), id_(id), norm_(Vector3d::Zero()), pos_(position) {}
+    : pos_(position), outlier_(false), triangulated_(false), optimized_(false), descriptor_(descriptor), id_(id), norm_(Vector3d::Zero()) {}
 
 void Mappoint::AddObservedByKeyframe(const size_t keyframeId, const Point2f posInPixel, const Vector3d cameraCenter, Frame* keyframe) {
     std::unique_lock<std::mutex> lock(obsLock_);
