@@ -250,6 +250,42 @@ int vo_triangulate_batch(vo_ctx* ctx, int n_points, const int32_t* view_start, c
 /* ---- local bundle adjustment --------------------------------------------------------- */
 int vo_local_ba(vo_ctx* ctx, const vo_ba_problem* in, vo_ba_result* out);
 
+/* ---- device-resident observation table and graph cut ------------------ */
+/* The keyframe bookkeeping the local BA's graph is cut from, kept on the device: one record per observation (keyframe k sees
+ * map point m at pixel uv: Frame::AddObservedMappoint, reference src/frame.cpp:93-120) and the current pose of every keyframe.
+ * The caller numbers its keyframes 0, 1, 2, ... in insertion order; observation ids are the append order (0, 1, 2, ...).
+ * vo_local_ba_resident cuts the covisibility graph of reference src/backend.cpp:36-135 on the device -- points = the non-outlier
+ * map points some free keyframe observes (ascending map slot), edges = every live observation of those points (per point in
+ * ascending keyframe order), fixed poses = their observers outside the free set (ascending keyframe number, after the free
+ * ones) -- solves it (same LM as vo_local_ba) and returns what the caller needs for its write-back (src/backend.cpp:144-194).
+ * `tables` is the context that owns the map and the observation table (the tracker's); `ctx` provides scratch and the stream,
+ * so a back-end thread can solve beside the tracker.  The device tables are NOT modified: the caller merges (vo_map_upsert,
+ * vo_kf_set_pose, vo_obs_kill) at the moment it chooses. */
+int vo_kf_set_pose(vo_ctx* ctx, const int32_t* kf, const double* T_cw, int n);
+int vo_obs_append(vo_ctx* ctx, const int32_t* kf, const int32_t* map_idx, const float* uv, int n, int64_t* first_id);
+int vo_obs_kill(vo_ctx* ctx, const int64_t* obs_ids, int n);
+typedef struct vo_ba_resident_result {
+    double* poses;              /* n_free x 12, optimised free poses (caller allocated)                                   */
+    int32_t* point_slots;       /* cap_points: device-map slots of the graph's points, graph order                        */
+    double* points;             /* cap_points x 3: optimised positions                                                     */
+    int64_t* culled_obs;        /* cap_culled: observations culled by the two chi2 tests (src/backend.cpp:144-172)         */
+    int32_t cap_points, cap_culled;
+    int32_t n_points, n_fixed, n_edges, n_culled;
+    double chi2_initial, chi2_final;
+    int32_t lm_iters, reserved;
+} vo_ba_resident_result;
+int vo_local_ba_resident(vo_ctx* ctx, vo_ctx* tables, const int32_t* free_kf, int n_free, double huber_delta, double chi2_th,
+                         int it_robust, int it_plain, vo_ba_resident_result* out);
+/* The same in two steps, for a back-end thread that solves beside the tracker: _cut returns as soon as the problem's arrays
+ * are complete (from then on `tables` may change: new keyframes, merges), _solve runs the optimisation on what _cut left in `ctx`. */
+int vo_local_ba_resident_cut(vo_ctx* ctx, vo_ctx* tables, const int32_t* free_kf, int n_free, double huber_delta, double chi2_th,
+                             int32_t* n_points, int32_t* n_fixed, int32_t* n_edges);
+int vo_local_ba_resident_solve(vo_ctx* ctx, int it_robust, int it_plain, vo_ba_resident_result* out);
+/* Parity tap: the graph vo_local_ba_resident would cut, in vo_ba_problem layout (edge_obs: observation id per edge). */
+int vo_ba_resident_graph(vo_ctx* ctx, vo_ctx* tables, const int32_t* free_kf, int n_free, int32_t* n_poses, int32_t* pose_kf, int cap_poses,
+                         int32_t* n_points, int32_t* point_slots, int cap_points, int32_t* n_edges, int32_t* edge_pose, int32_t* edge_point,
+                         float* edge_uv, int64_t* edge_obs, int cap_edges);
+
 /* ---- plumbing ------------------------------------------------------------------------- */
 int vo_sync(vo_ctx* ctx);
 /* Per-kernel accumulated device time measured with HIP events on the context's stream

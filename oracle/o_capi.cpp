@@ -32,6 +32,11 @@ struct vo_ctx {
     std::vector<std::vector<vo_match>> lane_matches;           // per lane of the last vo_track_batch (vo_track_fetch_matches)
     std::vector<int32_t> ransac_inliers;
     HypShard shard;
+    // observation table: keyframe number, map slot, pixel, alive; keyframe poses
+    std::vector<int32_t> obs_kf, obs_mp; std::vector<float> obs_uv; std::vector<uint8_t> obs_alive;
+    std::vector<double> kf_pose;
+    struct Pending { bool ready = false; std::vector<int32_t> pose_kf, point_slots, edge_pose, edge_point; std::vector<float> edge_uv; std::vector<int64_t> edge_obs;
+                     std::vector<double> poses, pts; int n_free = 0; double huber = 0, chi2 = 0; } pend;      // between vo_local_ba_resident_cut and _solve
 };
 
 extern "C" {
@@ -301,6 +306,126 @@ int vo_triangulate_batch(vo_ctx* c, int n, const int32_t* vs, const double* T, c
 }
 
 // (the FAST candidate lists of the CPU restatement are unbounded vectors; the HIP capacity is sized so that it cannot overflow)
+// ---- observation table and resident graph cut: plain loops restating reference src/backend.cpp:36-135 ----------
+int vo_kf_set_pose(vo_ctx* c, const int32_t* kf, const double* T, int n) {
+    if (!c || n < 0 || (n && (!kf || !T))) return VO_E_INVALID;
+    for (int i = 0; i < n; ++i) {
+        if (kf[i] < 0) return VO_E_INVALID;
+        if ((size_t)12 * (kf[i] + 1) > c->kf_pose.size()) c->kf_pose.resize((size_t)12 * (kf[i] + 1), 0.0);
+        std::memcpy(&c->kf_pose[12 * (size_t)kf[i]], T + 12 * (size_t)i, 96);
+    }
+    return VO_OK;
+}
+int vo_obs_append(vo_ctx* c, const int32_t* kf, const int32_t* mp, const float* uv, int n, int64_t* first) {
+    if (!c || n < 0 || (n && (!kf || !mp || !uv))) return VO_E_INVALID;
+    for (int i = 0; i < n; ++i) if (kf[i] < 0 || mp[i] < 0 || mp[i] >= c->p.map_capacity) return VO_E_INVALID;
+    if (first) *first = (int64_t)c->obs_kf.size();
+    for (int i = 0; i < n; ++i) { c->obs_kf.push_back(kf[i]); c->obs_mp.push_back(mp[i]); c->obs_uv.push_back(uv[2 * i]); c->obs_uv.push_back(uv[2 * i + 1]); c->obs_alive.push_back(1); }
+    return VO_OK;
+}
+int vo_obs_kill(vo_ctx* c, const int64_t* ids, int n) {
+    if (!c || n < 0 || (n && !ids)) return VO_E_INVALID;
+    for (int i = 0; i < n; ++i) { if (ids[i] < 0 || ids[i] >= (int64_t)c->obs_alive.size()) return VO_E_INVALID; c->obs_alive[ids[i]] = 0; }
+    return VO_OK;
+}
+namespace {
+struct ResidentGraph { std::vector<int32_t> pose_kf, point_slots, edge_pose, edge_point; std::vector<float> edge_uv; std::vector<int64_t> edge_obs; int n_free = 0; };
+int cut_graph(vo_ctx* t, const int32_t* free_kf, int n_free, ResidentGraph& g) {
+    const int nkf = (int)(t->kf_pose.size() / 12);
+    std::vector<int> kfi(nkf, -1);
+    for (int i = 0; i < n_free; ++i) { if (free_kf[i] < 0 || free_kf[i] >= nkf || kfi[free_kf[i]] >= 0) return VO_E_INVALID; kfi[free_kf[i]] = i; }
+    g.n_free = n_free; g.pose_kf.assign(free_kf, free_kf + n_free);
+    const size_t no = t->obs_kf.size();
+    std::vector<char> pflag(t->p.map_capacity, 0);
+    for (size_t o = 0; o < no; ++o)                         // points some free keyframe observes, outliers excluded (backend.cpp:62-81)
+        if (t->obs_alive[o] && t->obs_kf[o] < nkf && kfi[t->obs_kf[o]] >= 0 && !(t->map.flags[t->obs_mp[o]] & VO_MAP_FLAG_OUTLIER)) pflag[t->obs_mp[o]] = 1;
+    std::vector<int> pidx(t->p.map_capacity, -1);
+    for (int m = 0; m < t->p.map_capacity; ++m) if (pflag[m]) { pidx[m] = (int)g.point_slots.size(); g.point_slots.push_back(m); }
+    std::vector<char> fixed(nkf, 0);
+    std::vector<std::vector<int64_t>> per(g.point_slots.size());
+    for (size_t o = 0; o < no; ++o) {                       // every live observation of those points (backend.cpp:88-135)
+        if (!t->obs_alive[o] || pidx[t->obs_mp[o]] < 0 || t->obs_kf[o] >= nkf) continue;
+        per[pidx[t->obs_mp[o]]].push_back((int64_t)o);
+        if (kfi[t->obs_kf[o]] < 0) fixed[t->obs_kf[o]] = 1;
+    }
+    for (int k = 0; k < nkf; ++k) if (fixed[k]) { kfi[k] = (int)g.pose_kf.size(); g.pose_kf.push_back(k); }
+    for (size_t p = 0; p < per.size(); ++p) {
+        std::stable_sort(per[p].begin(), per[p].end(), [&](int64_t a, int64_t b) { return t->obs_kf[a] < t->obs_kf[b]; });
+        for (int64_t o : per[p]) {
+            g.edge_pose.push_back(kfi[t->obs_kf[o]]); g.edge_point.push_back((int32_t)p);
+            g.edge_uv.push_back(t->obs_uv[2 * o]); g.edge_uv.push_back(t->obs_uv[2 * o + 1]); g.edge_obs.push_back(o);
+        }
+    }
+    return VO_OK;
+}
+}  // namespace
+int vo_ba_resident_graph(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int n_free, int32_t* n_poses, int32_t* pose_kf, int cap_poses, int32_t* n_points,
+                         int32_t* point_slots, int cap_points, int32_t* n_edges, int32_t* edge_pose, int32_t* edge_point, float* edge_uv, int64_t* edge_obs, int cap_edges) {
+    if (!c || !t || n_free < 0 || (n_free && !free_kf) || !n_poses || !n_points || !n_edges) return VO_E_INVALID;
+    ResidentGraph g;
+    int rc = cut_graph(t, free_kf, n_free, g);
+    if (rc) return rc;
+    *n_poses = (int)g.pose_kf.size(); *n_points = (int)g.point_slots.size(); *n_edges = (int)g.edge_pose.size();
+    for (int i = 0; i < *n_poses && i < cap_poses; ++i) if (pose_kf) pose_kf[i] = g.pose_kf[i];
+    for (int i = 0; i < *n_points && i < cap_points; ++i) if (point_slots) point_slots[i] = g.point_slots[i];
+    for (int e = 0; e < *n_edges && e < cap_edges; ++e) {
+        if (edge_pose) edge_pose[e] = g.edge_pose[e];
+        if (edge_point) edge_point[e] = g.edge_point[e];
+        if (edge_uv) { edge_uv[2 * e] = g.edge_uv[2 * e]; edge_uv[2 * e + 1] = g.edge_uv[2 * e + 1]; }
+        if (edge_obs) edge_obs[e] = g.edge_obs[e];
+    }
+    return VO_OK;
+}
+int vo_local_ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int n_free, double huber_delta, double chi2_th, int32_t* n_points, int32_t* n_fixed, int32_t* n_edges) {
+    if (!c || !t || n_free < 0 || (n_free && !free_kf)) return VO_E_INVALID;
+    ResidentGraph g;
+    int rc = cut_graph(t, free_kf, n_free, g);
+    if (rc) return rc;
+    auto& P = c->pend;
+    P.pose_kf = g.pose_kf; P.point_slots = g.point_slots; P.edge_pose = g.edge_pose; P.edge_point = g.edge_point; P.edge_uv = g.edge_uv; P.edge_obs = g.edge_obs;
+    P.n_free = n_free; P.huber = huber_delta; P.chi2 = chi2_th;
+    P.poses.resize(12 * g.pose_kf.size()); P.pts.resize(3 * std::max<size_t>(g.point_slots.size(), 1));
+    for (size_t p = 0; p < g.pose_kf.size(); ++p) std::memcpy(&P.poses[12 * p], &t->kf_pose[12 * (size_t)g.pose_kf[p]], 96);      // values are taken NOW: the tables may change afterwards
+    for (size_t k = 0; k < g.point_slots.size(); ++k) std::memcpy(&P.pts[3 * k], &t->map.pos[3 * (size_t)g.point_slots[k]], 24);
+    P.ready = true;
+    if (n_points) *n_points = (int)g.point_slots.size();
+    if (n_fixed) *n_fixed = (int)g.pose_kf.size() - n_free;
+    if (n_edges) *n_edges = (int)g.edge_pose.size();
+    return VO_OK;
+}
+int vo_local_ba_resident_solve(vo_ctx* c, int it_robust, int it_plain, vo_ba_resident_result* out) {
+    if (!c || !out || !c->pend.ready || !out->poses || !out->point_slots || !out->points || !out->culled_obs) return VO_E_INVALID;
+    auto& P = c->pend;
+    P.ready = false;
+    const int n_free = P.n_free, np = (int)P.pose_kf.size(), nx = (int)P.point_slots.size(), ne = (int)P.edge_pose.size();
+    out->n_points = nx; out->n_fixed = np - n_free; out->n_edges = ne; out->n_culled = 0; out->chi2_initial = out->chi2_final = 0; out->lm_iters = 0;
+    if (nx > out->cap_points) return VO_E_OVERFLOW;
+    if (nx == 0 || ne == 0 || n_free == 0) return VO_OK;
+    std::vector<double> po(12 * (size_t)std::max(n_free, 1)), xo(3 * (size_t)std::max(nx, 1));
+    std::vector<uint8_t> fl(std::max(ne, 1));
+    for (int k = 0; k < nx; ++k) out->point_slots[k] = P.point_slots[k];
+    vo_ba_problem pr;
+    pr.n_poses = np; pr.n_free = n_free; pr.n_points = nx; pr.n_edges = ne; pr.poses = P.poses.data(); pr.points = P.pts.data();
+    pr.edge_pose = P.edge_pose.data(); pr.edge_point = P.edge_point.data(); pr.edge_uv = P.edge_uv.data();
+    pr.huber_delta = P.huber; pr.chi2_th = P.chi2; pr.it_robust = it_robust; pr.it_plain = it_plain;
+    vo_ba_result r;
+    std::memset(&r, 0, sizeof(r));
+    r.poses = po.data(); r.points = xo.data(); r.edge_flags = fl.data();
+    int rc = vo_local_ba(c, &pr, &r);
+    if (rc) return rc;
+    std::memcpy(out->poses, po.data(), 96 * (size_t)n_free);
+    std::memcpy(out->points, xo.data(), 24 * (size_t)nx);
+    for (int e = 0; e < ne; ++e) if (fl[e] & 3) { if (out->n_culled < out->cap_culled) out->culled_obs[out->n_culled] = P.edge_obs[e]; ++out->n_culled; }
+    std::sort(out->culled_obs, out->culled_obs + std::min(out->n_culled, out->cap_culled));
+    out->chi2_initial = r.chi2_initial; out->chi2_final = r.chi2_final; out->lm_iters = r.lm_iters;
+    return out->n_culled > out->cap_culled ? VO_E_OVERFLOW : VO_OK;
+}
+int vo_local_ba_resident(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int n_free, double huber_delta, double chi2_th, int it_robust, int it_plain,
+                         vo_ba_resident_result* out) {
+    int rc0 = vo_local_ba_resident_cut(c, t, free_kf, n_free, huber_delta, chi2_th, nullptr, nullptr, nullptr);
+    if (rc0) return rc0;
+    return vo_local_ba_resident_solve(c, it_robust, it_plain, out);
+}
 // Stream groups: on the CPU every call is computed on the spot; the group only counts (the fused launch chain is a property
 // of the HIP implementation, the results are defined to be those of un-grouped calls).
 struct vo_group { long long requests = 0; int members = 0; };

@@ -47,6 +47,12 @@ class VoBaProblem(C.Structure):
                 ("it_robust", C.c_int32), ("it_plain", C.c_int32)]
 
 
+class VoBaResidentResult(C.Structure):
+    _fields_ = [("poses", C.c_void_p), ("point_slots", C.c_void_p), ("points", C.c_void_p), ("culled_obs", C.c_void_p), ("cap_points", C.c_int32),
+                ("cap_culled", C.c_int32), ("n_points", C.c_int32), ("n_fixed", C.c_int32), ("n_edges", C.c_int32), ("n_culled", C.c_int32),
+                ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lm_iters", C.c_int32), ("reserved", C.c_int32)]
+
+
 class VoBaResult(C.Structure):
     _fields_ = [("poses", C.c_void_p), ("points", C.c_void_p), ("edge_flags", C.c_void_p),
                 ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lm_iters", C.c_int32),
@@ -64,7 +70,8 @@ SYMBOLS = ["vo_ctx_create", "vo_ctx_destroy", "vo_strerror", "vo_backend_name", 
            "vo_match_active_map", "vo_matches_set", "vo_pnp_ransac", "vo_pose_refine_lm", "vo_track_frame", "vo_track_batch", "vo_track_fetch_matches",
            "vo_local_ba", "vo_sync", "vo_profile_enable", "vo_profile_read",
            "vo_group_create", "vo_group_destroy", "vo_group_join", "vo_group_leave", "vo_group_set_gather", "vo_group_stats",
-           "vo_set_hypothesis_shard", "vo_triangulate_batch"]
+           "vo_set_hypothesis_shard", "vo_triangulate_batch", "vo_kf_set_pose", "vo_obs_append", "vo_obs_kill", "vo_local_ba_resident",
+           "vo_local_ba_resident_cut", "vo_local_ba_resident_solve", "vo_ba_resident_graph"]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int32), C.c_int)     # vo_exchange_fn: in-place element-wise sum over the ranks
@@ -120,6 +127,14 @@ class VoLib:
         L.vo_local_ba.argtypes = [C.c_void_p, C.POINTER(VoBaProblem), C.POINTER(VoBaResult)]
         L.vo_sync.argtypes = [C.c_void_p]
         L.vo_group_destroy.restype = None
+        L.vo_kf_set_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.vo_obs_append.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
+        L.vo_obs_kill.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.vo_local_ba_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(VoBaResidentResult)]
+        L.vo_local_ba_resident_cut.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.vo_local_ba_resident_solve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(VoBaResidentResult)]
+        L.vo_ba_resident_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_void_p, C.c_int,
+                                           C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.vo_triangulate_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vo_set_hypothesis_shard.argtypes = [C.c_void_p, C.c_int, C.c_int, EXCHANGE_FN, C.c_void_p]
         L.vo_group_create.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p)]
@@ -348,6 +363,38 @@ class VoContext:
         xyz = np.zeros((max(n, 1), 3)); ok = np.zeros(max(n, 1), dtype=np.uint8)
         self.L.check(self.L.lib.vo_triangulate_batch(self.h, n, _ptr(vs), _ptr(T), _ptr(z), _ptr(xyz), _ptr(ok)), "vo_triangulate_batch")
         return xyz[:n], ok[:n].astype(bool)
+
+    # device-resident keyframe bookkeeping -------------------------------------------------------
+    def kf_set_pose(self, kf, T_cw):
+        k = np.ascontiguousarray(kf, dtype=np.int32); T = np.ascontiguousarray(T_cw, dtype=np.float64).reshape(-1, 12)
+        self.L.check(self.L.lib.vo_kf_set_pose(self.h, _ptr(k), _ptr(T), len(k)), "vo_kf_set_pose")
+
+    def obs_append(self, kf, map_idx, uv) -> int:
+        k = np.ascontiguousarray(kf, dtype=np.int32); m = np.ascontiguousarray(map_idx, dtype=np.int32); z = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
+        first = C.c_int64()
+        self.L.check(self.L.lib.vo_obs_append(self.h, _ptr(k), _ptr(m), _ptr(z), len(k), C.byref(first)), "vo_obs_append")
+        return first.value
+
+    def obs_kill(self, ids):
+        a = np.ascontiguousarray(ids, dtype=np.int64)
+        self.L.check(self.L.lib.vo_obs_kill(self.h, _ptr(a), len(a)), "vo_obs_kill")
+
+    def resident_graph(self, tables: "VoContext", free_kf, cap=1 << 18):
+        f = np.ascontiguousarray(free_kf, dtype=np.int32)
+        npz, nx, ne = C.c_int32(), C.c_int32(), C.c_int32()
+        pk = np.zeros(4096, np.int32); ps = np.zeros(cap, np.int32); ep = np.zeros(cap, np.int32); el = np.zeros(cap, np.int32)
+        uv = np.zeros((cap, 2), np.float32); eo = np.zeros(cap, np.int64)
+        self.L.check(self.L.lib.vo_ba_resident_graph(self.h, tables.h, _ptr(f), len(f), C.byref(npz), _ptr(pk), 4096, C.byref(nx), _ptr(ps), cap, C.byref(ne),
+                                                     _ptr(ep), _ptr(el), _ptr(uv), _ptr(eo), cap), "vo_ba_resident_graph")
+        return {"pose_kf": pk[:npz.value].copy(), "point_slots": ps[:nx.value].copy(), "edge_pose": ep[:ne.value].copy(), "edge_point": el[:ne.value].copy(),
+                "edge_uv": uv[:ne.value].copy(), "edge_obs": eo[:ne.value].copy()}
+
+    def local_ba_resident(self, tables: "VoContext", free_kf, huber_delta=7.815 ** 0.5, chi2_th=1.0, it_robust=10, it_plain=10, cap_points=1 << 18, cap_culled=1 << 16):
+        f = np.ascontiguousarray(free_kf, dtype=np.int32)
+        po = np.zeros((max(len(f), 1), 12)); sl = np.zeros(cap_points, np.int32); pt = np.zeros((cap_points, 3)); cu = np.zeros(cap_culled, np.int64)
+        r = VoBaResidentResult(_ptr(po).value, _ptr(sl).value, _ptr(pt).value, _ptr(cu).value, cap_points, cap_culled)
+        self.L.check(self.L.lib.vo_local_ba_resident(self.h, tables.h, _ptr(f), len(f), huber_delta, chi2_th, it_robust, it_plain, C.byref(r)), "vo_local_ba_resident")
+        return po[:len(f)], sl[:r.n_points].copy(), pt[:r.n_points].copy(), cu[:r.n_culled].copy(), r
 
     def sync(self):
         self.L.check(self.L.lib.vo_sync(self.h), "vo_sync")

@@ -1642,3 +1642,366 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     if (trace) { static double a0 = 0, a1 = 0, a2 = 0; static int n = 0; a0 += tt1 - tt0; a1 += tt2 - tt1; a2 += tnow() - tt2; if (++n % 10 == 0) fprintf(stderr, "[vo_trace] vo_ba_run avg ms: prep+upload %.2f optimise %.2f download %.2f (D=%d edges=%d pairs=%d) | last prep: csr %.2f pairs %.2f enqueue %.2f sync %.2f\n", a0 / n, a1 / n, a2 / n, D, ne, npairs, tp1 - tt0, tp2 - tp1, tp3 - tp2, tt1 - tp3); }
     return VO_OK;
 }
+
+// =====================================================================================================================
+// Resident graph cut: the local BA's problem arrays are built ON THE DEVICE from the observation table
+// and the keyframe poses (reference src/backend.cpp:36-135, which walks hash maps of shared pointers), so a keyframe costs
+// the host neither the graph cut (0.45 ms of pointer chasing) nor the CSR build and 3 MB upload (0.4 ms).
+//
+//   k_cut_points   observation-parallel: flag the map points some FREE keyframe observes (outliers excluded)
+//   k_scan_*       exclusive scan of int32 arrays (flags -> dense point index, per-point edge counts -> pt_start, ...)
+//   k_cut_count    observation-parallel: edges per point (one atomic per observation, ~3 per address); flag the fixed keyframes
+//   k_cut_fill     observation-parallel: observation ids into their point's segment (arrival order)
+//   k_cut_emit     point-parallel: order each segment by keyframe number (what the host's graph cut emits: observation lists
+//                  are in keyframe order), then edge_pose / edge_point / edge_uv / pt_edges
+//   k_cut_gather   poses from the keyframe table, positions from the map
+//   k_ps_count / k_ps_fill   per free pose: its edges in ascending edge order (ordered ballot compaction)
+// Point order = ascending map slot, fixed poses = ascending keyframe number: deterministic, and the same as oracle/o_capi.cpp.
+// =====================================================================================================================
+struct CutTabs { const int32_t* obs_kf; const int32_t* obs_mp; const float* obs_uv; const uint8_t* alive; long long n_obs;
+                 const uint8_t* map_flags; const double* map_pos; const double* kf_pose; int n_kf, map_hi; };
+
+__global__ void k_cut_points(CutTabs T, const int* __restrict__ kf_idx, int* __restrict__ pt_flag) {
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= T.n_obs || !T.alive[o]) return;
+    const int k = T.obs_kf[o], m = T.obs_mp[o];
+    if (k < T.n_kf && m < T.map_hi && kf_idx[k] >= 0 && !(T.map_flags[m] & VO_MAP_FLAG_OUTLIER)) pt_flag[m] = 1;      // idempotent
+}
+// three-pass exclusive scan of n int32 (n <= 1024 * 1024): block sums, scan of the sums, per-block scan + offset; total -> *total_out
+__global__ __launch_bounds__(1024) void k_scan_blocksum(const int* __restrict__ in, int n, int* __restrict__ bsum) {
+    __shared__ int s_w[16];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    int v = i < n ? in[i] : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += s_w[w]; bsum[blockIdx.x] = t; }
+}
+__global__ __launch_bounds__(1024) void k_scan_sums(int* __restrict__ bsum, int nb, int* __restrict__ total_out) {
+    __shared__ int s[1024];
+    const int t = threadIdx.x;
+    s[t] = t < nb ? bsum[t] : 0;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) { const int v = t >= o ? s[t - o] : 0; __syncthreads(); s[t] += v; __syncthreads(); }
+    if (t == 0) *total_out = nb ? s[nb - 1] : 0;
+    __syncthreads();
+    if (t < nb) bsum[t] = t ? s[t - 1] : 0;
+}
+__global__ __launch_bounds__(1024) void k_scan_final(const int* __restrict__ in, int n, const int* __restrict__ bsum, int* __restrict__ out) {
+    __shared__ int s_w[16];
+    const int i = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int v = i < n ? in[i] : 0;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    int off = bsum[blockIdx.x];
+    for (int w = 0; w < wave; ++w) off += s_w[w];
+    if (i < n) out[i] = off + inc - v;
+}
+__global__ void k_cut_count(CutTabs T, const int* __restrict__ kf_idx, const int* __restrict__ pt_flag, const int* __restrict__ pidx,
+                            int* __restrict__ cnt, int* __restrict__ fixed_flag) {
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= T.n_obs || !T.alive[o]) return;
+    const int k = T.obs_kf[o], m = T.obs_mp[o];
+    if (k >= T.n_kf || m >= T.map_hi || !pt_flag[m]) return;
+    atomicAdd(&cnt[pidx[m]], 1);
+    if (kf_idx[k] < 0) fixed_flag[k] = 1;
+}
+__global__ void k_cut_fixed(int n_kf, int n_free, const int* __restrict__ fixed_flag, const int* __restrict__ fidx, int* __restrict__ kf_idx, int* __restrict__ pose_kf) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_kf || !fixed_flag[k]) return;
+    kf_idx[k] = n_free + fidx[k];                           // fixed poses follow the free ones, ascending keyframe number
+    pose_kf[n_free + fidx[k]] = k;
+}
+__global__ void k_cut_pointlist(int map_hi, const int* __restrict__ pt_flag, const int* __restrict__ pidx, int* __restrict__ point_slots) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < map_hi && pt_flag[m]) point_slots[pidx[m]] = m;
+}
+__global__ void k_cut_fill(CutTabs T, const int* __restrict__ pt_flag, const int* __restrict__ pidx, const int* __restrict__ pt_start,
+                           int* __restrict__ fill, long long* __restrict__ e_obs) {
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= T.n_obs || !T.alive[o]) return;
+    const int k = T.obs_kf[o], m = T.obs_mp[o];
+    if (k >= T.n_kf || m >= T.map_hi || !pt_flag[m]) return;
+    const int p = pidx[m];
+    e_obs[pt_start[p] + atomicAdd(&fill[p], 1)] = o;
+}
+__global__ void k_cut_emit(CutTabs T, int nx, const int* __restrict__ pt_start, const int* __restrict__ kf_idx, long long* __restrict__ e_obs,
+                           int32_t* __restrict__ e_pose, int32_t* __restrict__ e_pt, float* __restrict__ e_uv, int32_t* __restrict__ pt_edges) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nx) return;
+    const int a = pt_start[p], b = pt_start[p + 1];
+    for (int i = a + 1; i < b; ++i) {                       // insertion sort by keyframe number (a keyframe observes a point once: no ties)
+        const long long o = e_obs[i];
+        const int ko = T.obs_kf[o];
+        int j = i - 1;
+        while (j >= a && T.obs_kf[e_obs[j]] > ko) { e_obs[j + 1] = e_obs[j]; --j; }
+        e_obs[j + 1] = o;
+    }
+    for (int i = a; i < b; ++i) {
+        const long long o = e_obs[i];
+        e_pose[i] = kf_idx[T.obs_kf[o]]; e_pt[i] = p; e_uv[2 * i] = T.obs_uv[2 * o]; e_uv[2 * i + 1] = T.obs_uv[2 * o + 1]; pt_edges[i] = i;
+    }
+}
+__global__ void k_cut_gather(CutTabs T, int np, int nx, const int* __restrict__ pose_kf, const int* __restrict__ point_slots,
+                             double* __restrict__ posesA, double* __restrict__ posesB, double* __restrict__ ptsA) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < np * 12) { const double v = T.kf_pose[12 * (size_t)pose_kf[i / 12] + i % 12]; posesA[i] = v; posesB[i] = v; }
+    if (i < nx * 3) ptsA[i] = T.map_pos[3 * (size_t)point_slots[i / 3] + i % 3];
+}
+// one workgroup per free pose: count / ordered fill of its edges (ascending edge index = ascending point)
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_ps_lists(int ne, const int32_t* __restrict__ e_pose, const int32_t* __restrict__ e_pt, int* __restrict__ ps_cnt,
+                                                  const int* __restrict__ ps_start, int32_t* __restrict__ ps_edges, int32_t* __restrict__ ps_pt) {
+    __shared__ int s_w[4];
+    const int j = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int run = 0;
+    const int base = FILL ? ps_start[j] : 0;
+    for (int e0 = 0; e0 < ne; e0 += 256) {
+        const int e = e0 + threadIdx.x;
+        const bool hit = e < ne && e_pose[e] == j;
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) s_w[wave] = __popcll(m);
+        __syncthreads();
+        int before = __popcll(m & ((1ull << lane) - 1ull)), tot = 0;
+        for (int w = 0; w < 4; ++w) { if (w < wave) before += s_w[w]; tot += s_w[w]; }
+        if (FILL && hit) { ps_edges[base + run + before] = e; ps_pt[base + run + before] = e_pt[e]; }
+        run += tot;
+        __syncthreads();
+    }
+    if (!FILL && threadIdx.x == 0) ps_cnt[j] = run;
+}
+__global__ void k_ps_scan(int nf, const int* __restrict__ ps_cnt, int* __restrict__ ps_start) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { int a = 0; for (int j = 0; j < nf; ++j) { ps_start[j] = a; a += ps_cnt[j]; } ps_start[nf] = a; }
+}
+__global__ void k_culled_list(int ne, const uint8_t* __restrict__ flags, const long long* __restrict__ e_obs, int* __restrict__ n_out, long long* __restrict__ out, int cap) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < ne && (flags[e] & 3)) { const int pos = atomicAdd(n_out, 1); if (pos < cap) out[pos] = e_obs[e]; }
+}
+
+struct BaResident {
+    bool ready = false;
+    int np = 0, nf = 0, nx = 0, ne = 0, n_fixed = 0, nblk_launch = 0, npairs = 0;
+    BaDev B;
+    int32_t* d_point_slots = nullptr; int* d_pose_kf = nullptr; long long* d_e_obs = nullptr; int* d_ncull = nullptr; long long* d_cull = nullptr; int cull_cap = 0;
+};
+void vo_ba_resident_free(vo_ctx* c) { delete c->resident; c->resident = nullptr; }
+
+static int scan_i32(hipStream_t st, const int* in, int n, int* bsum, int* out, int* total) {        // n <= 1 Mi
+    const int nb = (n + 1023) / 1024;
+    if (nb > 1024) return VO_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_scan_blocksum, dim3(std::max(nb, 1)), dim3(1024), 0, st, in, n, bsum);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, bsum, nb, total);
+    hipLaunchKernelGGL(k_scan_final, dim3(std::max(nb, 1)), dim3(1024), 0, st, in, n, bsum, out);
+    return VO_OK;
+}
+
+// cut the graph of `free_kf` out of `t`'s tables into c's BA slab; returns when the arrays are complete (t may change afterwards)
+static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf, double huber_delta, double chi2_th) {
+    hipStream_t st = c->stream;
+    if (!t->d_obs_kf || t->n_kf <= 0) return VO_E_STATE;
+    if (!c->resident) c->resident = new BaResident();
+    BaResident& R = *c->resident;
+    R.ready = false;
+    const int nkf = t->n_kf, mh = std::max(t->map_hi, 1), D = 6 * nf;
+    const long long no = t->n_obs;
+    if (mh > 1024 * 1024 || nkf > 1024 * 1024) return VO_E_UNSUPPORTED;
+    if ((CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D) * sizeof(double) > 158 * 1024 || nf > 64) return VO_E_UNSUPPORTED;
+    for (int i = 0; i < nf; ++i) if (free_kf[i] < 0 || free_kf[i] >= nkf) return VO_E_INVALID;
+    // ---- cut scratch: [kf_idx nkf][fixed_flag nkf][fidx nkf][pt_flag mh][pidx mh][cnt mh][fill mh][pt_start mh + 1][bsum 1024][totals 8]
+    size_t co = 0;
+    auto cc = [&](size_t bytes) { size_t o = co; co += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_kfi = cc(4 * (size_t)nkf), o_ffl = cc(4 * (size_t)nkf), o_fid = cc(4 * (size_t)nkf), o_pfl = cc(4 * (size_t)mh), o_pid = cc(4 * (size_t)mh),
+                 o_cnt = cc(4 * (size_t)mh), o_fil = cc(4 * (size_t)mh), o_pst = cc(4 * (size_t)(mh + 1)), o_bs = cc(4096), o_tot = cc(64);
+    if (co > c->d_cut_bytes) {
+        if (c->d_cut) { (void)hipStreamSynchronize(st); (void)hipFree(c->d_cut); }
+        c->d_cut = nullptr; c->d_cut_bytes = 0;
+        if (hipMalloc(&c->d_cut, co + co / 2) != hipSuccess) return VO_E_NOMEM;
+        c->d_cut_bytes = co + co / 2;
+    }
+    uint8_t* cb = (uint8_t*)c->d_cut;
+    int* kf_idx = (int*)(cb + o_kfi); int* fixed_flag = (int*)(cb + o_ffl); int* fidx = (int*)(cb + o_fid); int* pt_flag = (int*)(cb + o_pfl); int* pidx = (int*)(cb + o_pid);
+    int* cnt = (int*)(cb + o_cnt); int* fill = (int*)(cb + o_fil); int* pt_start_w = (int*)(cb + o_pst); int* bsum = (int*)(cb + o_bs); int* tot = (int*)(cb + o_tot);
+    int* h = (int*)vo_stage(c, 4096);
+    if (!h) return VO_E_NOMEM;
+    HIP_TRY(hipStreamSynchronize(st));
+    CutTabs T{t->d_obs_kf, t->d_obs_mp, t->d_obs_uv, t->d_obs_alive, no, t->d_map_flags, t->d_map_pos, t->d_kf_pose, nkf, mh};
+    HIP_TRY(hipMemsetAsync(kf_idx, 0xFF, 4 * (size_t)nkf, st));                // -1: not in the graph
+    HIP_TRY(hipMemsetAsync(fixed_flag, 0, 4 * (size_t)nkf, st));
+    HIP_TRY(hipMemsetAsync(pt_flag, 0, 4 * (size_t)mh, st));
+    HIP_TRY(hipMemsetAsync(cnt, 0, 4 * (size_t)mh, st));
+    HIP_TRY(hipMemsetAsync(fill, 0, 4 * (size_t)mh, st));
+    {   // free keyframes -> pose index 0 .. nf-1 (tiny upload through the pinned mailbox)
+        for (int i = 0; i < nf; ++i) h[i] = free_kf[i];
+        // scatter on the device would need a kernel; nf <= 64 four-byte copies are cheaper than that
+        for (int i = 0; i < nf; ++i) { h[64 + i] = i; HIP_TRY(hipMemcpyAsync(kf_idx + free_kf[i], h + 64 + i, 4, hipMemcpyHostToDevice, st)); }
+    }
+    const int gO = (int)((no + 255) / 256);
+    if (gO) hipLaunchKernelGGL(k_cut_points, dim3(gO), dim3(256), 0, st, T, kf_idx, pt_flag);
+    int rc = scan_i32(st, pt_flag, mh, bsum, pidx, tot);                        // dense point index, nx
+    if (rc) return rc;
+    if (gO) hipLaunchKernelGGL(k_cut_count, dim3(gO), dim3(256), 0, st, T, kf_idx, pt_flag, pidx, cnt, fixed_flag);
+    if ((rc = scan_i32(st, cnt, mh, bsum, pt_start_w, tot + 1))) return rc;     // pt_start over the dense indices (cnt is zero beyond nx), ne
+    if ((rc = scan_i32(st, fixed_flag, nkf, bsum, fidx, tot + 2))) return rc;   // fixed pose numbering, n_fixed
+    HIP_TRY(hipMemcpyAsync(h + 128, tot, 12, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const int nx = h[128], ne = h[129], n_fixed = h[130], np = nf + n_fixed;
+    R.np = np; R.nf = nf; R.nx = nx; R.ne = ne; R.n_fixed = n_fixed;
+    if (nx == 0 || ne == 0 || nf == 0) { R.ready = true; return VO_OK; }         // nothing to optimise
+    // ---- BA slab (same layout as vo_ba_run's, filled by kernels instead of an upload)
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const int nb_all = nf * (nf + 1) / 2;
+    const size_t o_poses = carve(96 * (size_t)np), o_pts = carve(24 * (size_t)nx);
+    const size_t o_epose = carve(4 * (size_t)ne), o_ept = carve(4 * (size_t)ne), o_euv = carve(8 * (size_t)ne);
+    const size_t o_ps = carve(4 * (size_t)(nx + 1)), o_pe = carve(4 * (size_t)ne);
+    const size_t o_qs = carve(4 * (size_t)(nf + 1)), o_qe = carve(4 * (size_t)ne), o_pspt = carve(4 * (size_t)ne + 4), o_qc = carve(4 * (size_t)(nf + 1));
+    const size_t o_poses_n = carve(96 * (size_t)np), o_pts_n = carve(24 * (size_t)nx), o_act = carve(ne), o_flags = carve(ne);
+    const size_t o_eobs = carve(8 * (size_t)ne), o_pslots = carve(4 * (size_t)nx), o_posekf = carve(4 * (size_t)np), o_ncull = carve(64), o_cull = carve(8 * (size_t)ne);
+    const size_t o_pcnt = carve(4 * (size_t)std::max(nb_all, 1)), o_poff = carve(4 * (size_t)std::max(nb_all, 1)), o_pn = carve(16);
+    const size_t o_Hpp = carve(288 * (size_t)nf), o_bp = carve(8 * (size_t)D), o_Hll = carve(72 * (size_t)nx), o_bl = carve(24 * (size_t)nx), o_scal = carve(64);
+    const size_t o_partU = carve(16 * ((size_t)(nx + 63) / 64 + 1)), o_partC = carve(8 * ((size_t)(ne + 255) / 256 + 1));
+    const size_t o_W = carve(144 * (size_t)ne), o_S = carve(8 * (size_t)D * D), o_bs2 = carve(8 * (size_t)D), o_Hinv = carve(72 * (size_t)nx), o_dl = carve(24 * (size_t)nx);
+    // pair lists: a point seen by m free poses gives m (m + 1) / 2 <= m (nf + 1) / 2 pairs, so ne (nf + 1) / 2 bounds them before the
+    // per-pose lists exist; slices: one per 512 pairs plus a partial one per block
+    const size_t pairs_ub = (size_t)ne * (size_t)(nf + 1) / 2 + 1, slices_cap = pairs_ub / 512 + (size_t)nb_all + 1;
+    const size_t o_blk = carve(sizeof(BaBlock) * slices_cap), o_pairs = carve(sizeof(int2) * pairs_ub);
+    if ((rc = vo_scratch(c, off))) return rc;               // may reallocate: nothing of this problem lives in the slab yet
+    uint8_t* base = (uint8_t*)c->d_ba;
+    int32_t* e_pose = (int32_t*)(base + o_epose); int32_t* e_pt = (int32_t*)(base + o_ept); float* e_uv = (float*)(base + o_euv);
+    long long* e_obs = (long long*)(base + o_eobs); int* pose_kf = (int*)(base + o_posekf); int* point_slots = (int*)(base + o_pslots);
+    HIP_TRY(hipMemcpyAsync(base + o_ps, pt_start_w, 4 * (size_t)(nx + 1), hipMemcpyDeviceToDevice, st));
+    { for (int i = 0; i < nf; ++i) h[i] = free_kf[i]; HIP_TRY(hipMemcpyAsync(pose_kf, h, 4 * (size_t)nf, hipMemcpyHostToDevice, st)); }
+    hipLaunchKernelGGL(k_cut_fixed, dim3((nkf + 255) / 256), dim3(256), 0, st, nkf, nf, fixed_flag, fidx, kf_idx, pose_kf);
+    hipLaunchKernelGGL(k_cut_pointlist, dim3((mh + 255) / 256), dim3(256), 0, st, mh, pt_flag, pidx, point_slots);
+    hipLaunchKernelGGL(k_cut_fill, dim3(gO), dim3(256), 0, st, T, pt_flag, pidx, (const int*)(base + o_ps), fill, e_obs);
+    hipLaunchKernelGGL(k_cut_emit, dim3((nx + 255) / 256), dim3(256), 0, st, T, nx, (const int*)(base + o_ps), kf_idx, e_obs, e_pose, e_pt, e_uv, (int32_t*)(base + o_pe));
+    hipLaunchKernelGGL(k_cut_gather, dim3((std::max(np * 12, nx * 3) + 255) / 256), dim3(256), 0, st, T, np, nx, pose_kf, point_slots,
+                       (double*)(base + o_poses), (double*)(base + o_poses_n), (double*)(base + o_pts));
+    hipLaunchKernelGGL(k_ps_lists<false>, dim3(nf), dim3(256), 0, st, ne, e_pose, e_pt, (int*)(base + o_qc), nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL(k_ps_scan, dim3(1), dim3(64), 0, st, nf, (const int*)(base + o_qc), (int*)(base + o_qs));
+    hipLaunchKernelGGL(k_ps_lists<true>, dim3(nf), dim3(256), 0, st, ne, e_pose, e_pt, nullptr, (const int*)(base + o_qs), (int32_t*)(base + o_qe), (int32_t*)(base + o_pspt));
+    HIP_TRY(hipMemcpyAsync(h + 256, base + o_qs, 4 * (size_t)(nf + 1), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));                      // from here on `t` may change: every input has been gathered
+    const int* ps_start = h + 256;
+    int max_len = 0, npairs = 0, slices_ub = 0;
+    for (int j = 0; j < nf; ++j) max_len = std::max(max_len, ps_start[j + 1] - ps_start[j]);
+    if (max_len > PAIR_LDS_CAP) return VO_E_UNSUPPORTED;    // caller falls back to the host graph cut
+    for (int j1 = 0; j1 < nf; ++j1) for (int j2 = j1; j2 < nf; ++j2) {
+        const int m = std::min(ps_start[j1 + 1] - ps_start[j1], ps_start[j2 + 1] - ps_start[j2]);
+        npairs += m; slices_ub += (m + 511) / 512;
+    }
+    if ((size_t)npairs > pairs_ub || (size_t)slices_ub > slices_cap) return VO_E_OVERFLOW;
+    BaDev B;
+    B.n_poses = np; B.n_free = nf; B.n_points = nx; B.n_edges = ne; B.D = D; B.n_blocks = slices_ub;
+    B.n_slices = (const int*)(base + o_pn);
+    B.ps_start = (const int32_t*)(base + o_qs); B.ps_edges = (const int32_t*)(base + o_qe); B.blocks = (const BaBlock*)(base + o_blk); B.pairs = (const int2*)(base + o_pairs);
+    B.posesA = (double*)(base + o_poses); B.ptsA = (double*)(base + o_pts); B.posesB = (double*)(base + o_poses_n); B.ptsB = (double*)(base + o_pts_n);
+    B.ctl = nullptr;
+    B.partU = (double*)(base + o_partU); B.partC = (double*)(base + o_partC); B.nU = (nx + 63) / 64;
+    B.e_pose = e_pose; B.e_pt = e_pt; B.e_uv = e_uv;
+    B.active = base + o_act; B.flags = base + o_flags; B.pt_start = (const int32_t*)(base + o_ps); B.pt_edges = (const int32_t*)(base + o_pe);
+    B.Hpp = (double*)(base + o_Hpp); B.bp = (double*)(base + o_bp); B.Hll = (double*)(base + o_Hll); B.bl = (double*)(base + o_bl); B.scal = (double*)(base + o_scal);
+    B.W = (double*)(base + o_W); B.S = (double*)(base + o_S); B.bs = (double*)(base + o_bs2); B.Hinv = (double*)(base + o_Hinv); B.dl = (double*)(base + o_dl);
+    B.cam = BaCam{(double)c->p.fx, (double)c->p.fy, (double)c->p.cx, (double)c->p.cy};
+    B.delta = huber_delta; B.chi2_th = chi2_th; B.gp = (nx + 63) / 64;
+    BaPairPlan Q;
+    Q.ps_start = B.ps_start; Q.ps_edges = B.ps_edges; Q.ps_pt = (const int32_t*)(base + o_pspt); Q.nf = nf;
+    Q.cnt = (int*)(base + o_pcnt); Q.off = (int*)(base + o_poff); Q.n_slices = (int*)(base + o_pn); Q.n_pairs = (int*)(base + o_pn) + 1;
+    Q.blocks = (BaBlock*)(base + o_blk); Q.pairs = (int2*)(base + o_pairs);
+    hipLaunchKernelGGL(k_ba_pairs<false>, dim3(nb_all), dim3(256), 4 * (size_t)std::max(max_len, 1), st, Q);
+    hipLaunchKernelGGL(k_ba_pairs_scan, dim3(1), dim3(1024), 0, st, Q, nb_all);
+    hipLaunchKernelGGL(k_ba_pairs<true>, dim3(nb_all), dim3(256), 4 * (size_t)std::max(max_len, 1), st, Q);
+    h[0] = 0; h[1] = 0;
+    HIP_TRY(hipMemcpyAsync(h, base + o_pn, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemsetAsync(base + o_act, 1, ne, st));
+    HIP_TRY(hipMemsetAsync(base + o_flags, 0, ne, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    R.nblk_launch = std::min(slices_ub, h[0]); R.npairs = h[1];
+    R.B = B; R.B.n_blocks = R.nblk_launch;
+    R.d_point_slots = point_slots; R.d_pose_kf = pose_kf; R.d_e_obs = e_obs; R.d_ncull = (int*)(base + o_ncull); R.d_cull = (long long*)(base + o_cull); R.cull_cap = ne;
+    R.ready = true;
+    return VO_OK;
+}
+
+extern "C" int vo_local_ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int n_free, double huber_delta, double chi2_th,
+                                        int32_t* n_points, int32_t* n_fixed, int32_t* n_edges) {
+    if (!c || !t || n_free < 0 || (n_free && !free_kf) || c->device != t->device) return VO_E_INVALID;
+    HIP_TRY(hipSetDevice(c->device));
+    const int rc = ba_resident_cut(c, t, free_kf, n_free, huber_delta, chi2_th);
+    if (rc == VO_OK && c->resident) { if (n_points) *n_points = c->resident->nx; if (n_fixed) *n_fixed = c->resident->n_fixed; if (n_edges) *n_edges = c->resident->ne; }
+    return rc;
+}
+
+extern "C" int vo_local_ba_resident_solve(vo_ctx* c, int it_robust, int it_plain, vo_ba_resident_result* out) {
+    if (!c || !out || !c->resident || !c->resident->ready || !out->poses || !out->point_slots || !out->points || !out->culled_obs) return VO_E_INVALID;
+    HIP_TRY(hipSetDevice(c->device));
+    BaResident& R = *c->resident;
+    hipStream_t st = c->stream;
+    const int np = R.np, nf = R.nf, nx = R.nx, ne = R.ne, D = 6 * nf;
+    out->n_points = nx; out->n_fixed = R.n_fixed; out->n_edges = ne; out->n_culled = 0; out->chi2_initial = out->chi2_final = 0; out->lm_iters = 0;
+    R.ready = false;
+    if (nx == 0 || ne == 0 || nf == 0) return VO_OK;
+    if (nx > out->cap_points) return VO_E_OVERFLOW;
+    vo_ba_problem pr;
+    memset(&pr, 0, sizeof(pr));
+    pr.n_poses = np; pr.n_free = nf; pr.n_points = nx; pr.n_edges = ne; pr.huber_delta = R.B.delta; pr.chi2_th = R.B.chi2_th; pr.it_robust = it_robust; pr.it_plain = it_plain;
+    BaJob job;
+    job.c = c; job.in = &pr; job.out = nullptr; job.B = R.B;
+    job.grid_lin = (nx + 63) / 64 + nf * PSPLIT; job.grid_initS = (std::max(D * D, nx) + 255) / 256; job.grid_upd = (nx + 63) / 64 + (np + 255) / 256;
+    job.grid_e = (ne + 255) / 256; job.grid_c = (ne + 1023) / 1024; job.grid_maxdiag = (D + 3 * nx + 255) / 256;
+    job.lds = D <= 192 ? sizeof(double) * (CH_NB * CH_NB + (size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D)
+                       : sizeof(double) * (CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D);
+    int rc = ba_engine_solve(c->ba_engine, &job);
+    if (rc) return rc;
+    const BaDev& B = R.B;
+    int* h = (int*)vo_stage(c, 4096);
+    if (!h) return VO_E_NOMEM;
+    HIP_TRY(hipMemsetAsync(R.d_ncull, 0, 4, st));
+    hipLaunchKernelGGL(k_culled_list, dim3((ne + 255) / 256), dim3(256), 0, st, ne, (const uint8_t*)B.flags, (const long long*)R.d_e_obs, R.d_ncull, R.d_cull, R.cull_cap);
+    HIP_TRY(hipMemcpyAsync(h, R.d_ncull, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out->poses, job.cur_buf ? B.posesB : B.posesA, 96 * (size_t)nf, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out->points, job.cur_buf ? B.ptsB : B.ptsA, 24 * (size_t)nx, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out->point_slots, R.d_point_slots, 4 * (size_t)nx, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    out->n_culled = h[0];
+    const int take = std::min(out->n_culled, out->cap_culled);
+    if (take > 0) {
+        HIP_TRY(hipMemcpy(out->culled_obs, R.d_cull, 8 * (size_t)take, hipMemcpyDeviceToHost));
+        std::sort(out->culled_obs, out->culled_obs + take);                     // arrival order of an atomic append -> ascending observation id
+    }
+    out->chi2_initial = job.chi0; out->chi2_final = job.chi_final; out->lm_iters = job.iters;
+    HIP_TRY(hipGetLastError());
+    return out->n_culled > out->cap_culled ? VO_E_OVERFLOW : VO_OK;
+}
+
+extern "C" int vo_local_ba_resident(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int n_free, double huber_delta, double chi2_th, int it_robust, int it_plain,
+                                    vo_ba_resident_result* out) {
+    int rc = vo_local_ba_resident_cut(c, t, free_kf, n_free, huber_delta, chi2_th, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    return vo_local_ba_resident_solve(c, it_robust, it_plain, out);
+}
+
+extern "C" int vo_ba_resident_graph(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int n_free, int32_t* n_poses, int32_t* pose_kf, int cap_poses, int32_t* n_points,
+                                    int32_t* point_slots, int cap_points, int32_t* n_edges, int32_t* edge_pose, int32_t* edge_point, float* edge_uv, int64_t* edge_obs, int cap_edges) {
+    if (!c || !t || !n_poses || !n_points || !n_edges) return VO_E_INVALID;
+    int rc = vo_local_ba_resident_cut(c, t, free_kf, n_free, 1.0, 1.0, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    BaResident& R = *c->resident;
+    *n_poses = R.np; *n_points = R.nx; *n_edges = R.ne;
+    R.ready = false;
+    if (R.nx == 0 || R.ne == 0) return VO_OK;
+    const BaDev& B = R.B;
+    if (pose_kf) HIP_TRY(hipMemcpy(pose_kf, R.d_pose_kf, 4 * (size_t)std::min(R.np, cap_poses), hipMemcpyDeviceToHost));
+    if (point_slots) HIP_TRY(hipMemcpy(point_slots, R.d_point_slots, 4 * (size_t)std::min(R.nx, cap_points), hipMemcpyDeviceToHost));
+    const size_t k = (size_t)std::min(R.ne, cap_edges);
+    if (edge_pose) HIP_TRY(hipMemcpy(edge_pose, B.e_pose, 4 * k, hipMemcpyDeviceToHost));
+    if (edge_point) HIP_TRY(hipMemcpy(edge_point, B.e_pt, 4 * k, hipMemcpyDeviceToHost));
+    if (edge_uv) HIP_TRY(hipMemcpy(edge_uv, B.e_uv, 8 * k, hipMemcpyDeviceToHost));
+    if (edge_obs) HIP_TRY(hipMemcpy(edge_obs, R.d_e_obs, 8 * k, hipMemcpyDeviceToHost));
+    return VO_OK;
+}

@@ -260,6 +260,8 @@ void vo_ctx_destroy(vo_ctx* c) {
     if (c->h_slots_pinned) (void)hipHostFree(c->h_slots_pinned);
     if (c->h_orb_cache) (void)hipHostFree(c->h_orb_cache);
     if (c->h_ba_up) (void)hipHostFree(c->h_ba_up);
+    vo_ba_resident_free(c);
+    { void* tp[] = {c->d_obs_kf, c->d_obs_mp, c->d_obs_uv, c->d_obs_alive, c->d_kf_pose, c->d_cut}; for (void* q : tp) if (q) (void)hipFree(q); }
     if (c->slots_ev) (void)hipEventDestroy(c->slots_ev);
     for (auto& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -469,6 +471,7 @@ int vo_map_upsert(vo_ctx* c, const int32_t* idx, const double* xyz, const double
     if (!c || n < 0 || (n && !idx)) return VO_E_INVALID;
     for (int i = 0; i < n; ++i) if (idx[i] < 0 || idx[i] >= c->p.map_capacity) return VO_E_INVALID;
     if (n == 0) return VO_OK;
+    for (int i = 0; i < n; ++i) c->map_hi = std::max(c->map_hi, idx[i] + 1);
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     // pack -> one pinned staging buffer -> one H2D copy -> scatter kernel
@@ -809,6 +812,74 @@ int vo_track_frame(vo_ctx* c, int slot, const double T0[12], const vo_track_para
                    vo_match* matches, int cap) {
     if (!tp) return VO_E_INVALID;
     return vo_track_batch(c, 1, &slot, T0, tp, &tp->seed, res, matches, cap);
+}
+
+// ---- device-resident observation table -------------------------------------------------------------------------
+#define VO_OBS_CAP (4ll << 20)      // observations (17 B each); ~2000 per keyframe
+#define VO_KF_CAP 65536             // keyframes (96 B each)
+static int vo_obs_tables_ensure(vo_ctx* c) {     // allocates the observation / keyframe tables on first use
+    if (c->d_obs_kf) return VO_OK;
+    c->obs_cap = VO_OBS_CAP; c->kf_cap = VO_KF_CAP;
+    if (hipMalloc((void**)&c->d_obs_kf, 4 * (size_t)c->obs_cap) != hipSuccess || hipMalloc((void**)&c->d_obs_mp, 4 * (size_t)c->obs_cap) != hipSuccess ||
+        hipMalloc((void**)&c->d_obs_uv, 8 * (size_t)c->obs_cap) != hipSuccess || hipMalloc((void**)&c->d_obs_alive, (size_t)c->obs_cap) != hipSuccess ||
+        hipMalloc((void**)&c->d_kf_pose, 96 * (size_t)c->kf_cap) != hipSuccess) return VO_E_NOMEM;
+    return VO_OK;
+}
+
+int vo_kf_set_pose(vo_ctx* c, const int32_t* kf, const double* T, int n) {
+    if (!c || n < 0 || (n && (!kf || !T))) return VO_E_INVALID;
+    if (n == 0) return VO_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = vo_obs_tables_ensure(c);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) if (kf[i] < 0 || kf[i] >= c->kf_cap) return VO_E_INVALID;
+    double* h = (double*)vo_stage(c, 96 * (size_t)n);
+    if (!h) return VO_E_NOMEM;
+    HIP_TRY(hipStreamSynchronize(c->stream));               // the staging buffer may still feed an earlier copy
+    memcpy(h, T, 96 * (size_t)n);
+    int run0 = 0;                                           // consecutive keyframe numbers travel as one copy
+    for (int i = 1; i <= n; ++i)
+        if (i == n || kf[i] != kf[i - 1] + 1) {
+            HIP_TRY(hipMemcpyAsync(c->d_kf_pose + 12 * (size_t)kf[run0], h + 12 * (size_t)run0, 96 * (size_t)(i - run0), hipMemcpyHostToDevice, c->stream));
+            run0 = i;
+        }
+    for (int i = 0; i < n; ++i) c->n_kf = std::max(c->n_kf, kf[i] + 1);
+    HIP_TRY(hipStreamSynchronize(c->stream));               // a back-end thread may read the table from its own stream next
+    return VO_OK;
+}
+
+int vo_obs_append(vo_ctx* c, const int32_t* kf, const int32_t* mp, const float* uv, int n, int64_t* first) {
+    if (!c || n < 0 || (n && (!kf || !mp || !uv))) return VO_E_INVALID;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = vo_obs_tables_ensure(c);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) if (kf[i] < 0 || kf[i] >= c->kf_cap || mp[i] < 0 || mp[i] >= c->p.map_capacity) return VO_E_INVALID;
+    if (c->n_obs + n > c->obs_cap) return VO_E_OVERFLOW;
+    if (first) *first = (int64_t)c->n_obs;
+    if (n == 0) return VO_OK;
+    const size_t N = (size_t)n, o_mp = (4 * N + 255) & ~(size_t)255, o_uv = o_mp + ((4 * N + 255) & ~(size_t)255), total = o_uv + 8 * N;
+    uint8_t* h = (uint8_t*)vo_stage(c, total);
+    if (!h) return VO_E_NOMEM;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(h, kf, 4 * N); memcpy(h + o_mp, mp, 4 * N); memcpy(h + o_uv, uv, 8 * N);
+    const size_t at = (size_t)c->n_obs;
+    HIP_TRY(hipMemcpyAsync(c->d_obs_kf + at, h, 4 * N, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_obs_mp + at, h + o_mp, 4 * N, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_obs_uv + 2 * at, h + o_uv, 8 * N, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_obs_alive + at, 1, N, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->n_obs += n;
+    return VO_OK;
+}
+
+int vo_obs_kill(vo_ctx* c, const int64_t* ids, int n) {
+    if (!c || n < 0 || (n && !ids)) return VO_E_INVALID;
+    if (n == 0) return VO_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    for (int i = 0; i < n; ++i) if (ids[i] < 0 || ids[i] >= c->n_obs) return VO_E_INVALID;
+    for (int i = 0; i < n; ++i) HIP_TRY(hipMemsetAsync(c->d_obs_alive + (size_t)ids[i], 0, 1, c->stream));     // a handful per local BA
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return VO_OK;
 }
 
 // ---- stream groups ----------------------------------------------------------------------------------------------------

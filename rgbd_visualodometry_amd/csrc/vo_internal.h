@@ -116,6 +116,14 @@ struct vo_ctx {
     void* d_ba; size_t d_ba_bytes; struct BaEngine* ba_engine = nullptr;
     void* h_ba_up = nullptr; size_t h_ba_up_bytes = 0;      // pinned mirror of a BA problem's upload region
     std::vector<int32_t> ba_pt_start, ba_ps_start, ba_cursor;      // host scratch of vo_ba_run (kept between problems)
+    // device-resident keyframe bookkeeping: observation table and keyframe poses, fixed capacity (a back-end
+    // thread may be reading them while the tracker appends: no reallocation, appends only write beyond what a reader was given)
+    int32_t* d_obs_kf = nullptr; int32_t* d_obs_mp = nullptr; float* d_obs_uv = nullptr; uint8_t* d_obs_alive = nullptr;
+    long long n_obs = 0, obs_cap = 0;
+    double* d_kf_pose = nullptr; int n_kf = 0, kf_cap = 0;
+    int map_hi = 0;                                         // highest map slot ever upserted + 1
+    void* d_cut = nullptr; size_t d_cut_bytes = 0;          // scratch of the resident graph cut
+    struct BaResident* resident = nullptr;                  // state between vo_local_ba_resident_cut and _solve (vo_ba.hip)
     // profiling
     std::atomic<bool> prof_on; std::mutex prof_mu; std::vector<ProfRec> prof; std::vector<hipEvent_t> ev_pool;      // prof / ev_pool: under prof_mu
     ProfRec prof_open; hipStream_t prof_open_stream = nullptr; uint64_t prof_ticket = 0, prof_closed = 0;
@@ -143,6 +151,7 @@ int vo_track_lm_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* d_lanes, in
 void vo_lane_fill(vo_ctx* c, int lane, int slot, uint64_t seed, TrackDev* d_tr, LaneDesc* out);   // descriptor of lane `lane` of context c
 int vo_corr_from_host(vo_ctx* c, const float* xyz, const float* uv, int n);
 int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out);                       // vo_ba.hip
+void vo_ba_resident_free(vo_ctx* c);
 struct BaEngine* vo_ba_engine_acquire(int device);
 void vo_ba_engine_release(struct BaEngine* e);
 

@@ -249,3 +249,70 @@ def test_hypothesis_shard_equals_unsharded_ransac(libs, streams):
     again = ctx.track_batch_deferred(slots, prior, tp, seeds, cap=4096)
     assert np.array_equal(np.array(again[0][0].T_cw), np.array(want[0][0].T_cw))
     ctx.close()
+
+
+def _resident_scene(L, rng, n_kf=9, n_pts=400, n_free=4):
+    """Keyframes and map points with a sliding visibility pattern, loaded into the observation table and the map of a context."""
+    import ref_model as rm
+    p = L.default_params(n_features=64, map_capacity=4096)
+    t = L.context(p)
+    Ts = [rm.se3_exp(np.concatenate([rng.normal(0, 0.25, 3) + [0.12 * k, 0, 0], rng.normal(0, 0.05, 3)])) for k in range(n_kf)]
+    X = rng.uniform(-1.5, 1.5, (n_pts, 3)) + [0.5, 0, 5]
+    slots = rng.permutation(2000)[:n_pts].astype(np.int32)                 # map slots in arbitrary order, with holes
+    flags = (rng.random(n_pts) < 0.04).astype(np.uint8)                     # a few outliers
+    X0 = X + rng.normal(0, 0.01, X.shape)
+    t.map_upsert(slots, X0, np.tile([0, 0, 1.0], (n_pts, 1)), np.zeros((n_pts, 32), np.uint8), flags)
+    t._scene_positions, t._scene_slots = X0, slots
+    t.kf_set_pose(np.arange(n_kf), np.array(Ts))
+    obs = []
+    for k in range(n_kf):
+        seen = [i for i in range(n_pts) if (i * 7 + k * 31) % 100 < 45 + 5 * (k % 3)]
+        R, tt = Ts[k][:9].reshape(3, 3), Ts[k][9:]
+        uv = []
+        for i in seen:
+            pc = R @ X[i] + tt
+            uv.append([p.fx * pc[0] / pc[2] + p.cx + rng.normal(0, 0.3), p.fy * pc[1] / pc[2] + p.cy + rng.normal(0, 0.3)])
+        first = t.obs_append(np.full(len(seen), k), slots[seen], np.array(uv))
+        obs += [(first + j, k, int(slots[i]), uv[j]) for j, i in enumerate(seen)]
+    dead = [o[0] for o in obs if rng.random() < 0.03]
+    t.obs_kill(dead)
+    free = [n_kf - 1 - 2 * i for i in range(n_free)]                        # not sorted, not contiguous
+    return t, Ts, X, slots, flags, obs, set(dead), free
+
+
+@pytest.mark.parametrize("libs", LIBS)
+def test_resident_graph_cut_follows_backend_cpp(libs):
+    """the graph cut on the device-resident observation table (reference src/backend.cpp:36-135) against the
+    definition: points = non-outlier points a free keyframe observes, edges = all live observations of those points, fixed
+    poses = their other observers; ordering rules of include/vo_hip.h."""
+    L = capi.load(libs[0])
+    rng = np.random.default_rng(17)
+    t, Ts, X, slots, flags, obs, dead, free = _resident_scene(L, rng)
+    c = L.context(L.default_params(n_features=64, map_capacity=64))
+    g = c.resident_graph(t, free)
+    outl = {int(s) for s, f in zip(slots, flags) if f}
+    live = [o for o in obs if o[0] not in dead]
+    pts = sorted({o[2] for o in live if o[1] in free and o[2] not in outl})
+    assert list(g["point_slots"]) == pts and len(pts) > 100
+    edges = sorted([o for o in live if o[2] in set(pts)], key=lambda o: (pts.index(o[2]), o[1]))
+    fixed = sorted({o[1] for o in edges} - set(free))
+    assert list(g["pose_kf"]) == free + fixed and len(fixed) >= 2
+    pose_of = {k: i for i, k in enumerate(free + fixed)}
+    assert list(g["edge_obs"]) == [o[0] for o in edges]
+    assert list(g["edge_pose"]) == [pose_of[o[1]] for o in edges] and list(g["edge_point"]) == [pts.index(o[2]) for o in edges]
+    assert np.allclose(g["edge_uv"], np.array([o[3] for o in edges], np.float32))
+    # solving the cut = solving the same problem handed over explicitly (vo_local_ba)
+    poses = np.array([Ts[k] for k in g["pose_kf"]])
+    pos_now = {int(s): x for s, x in zip(slots, np.array(t_positions(L, t, slots)))}
+    po, sl, pt, cu, r = c.local_ba_resident(t, free)
+    P0 = np.array([pos_now[s] for s in sl])
+    pw, xw, fw, rw = c.local_ba(poses, len(free), P0, g["edge_pose"], g["edge_point"], g["edge_uv"])
+    assert np.array_equal(sl, g["point_slots"]) and r.n_fixed == len(fixed) and r.n_edges == len(edges)
+    np.testing.assert_allclose(po, pw, atol=1e-7); np.testing.assert_allclose(pt, xw, atol=1e-6)
+    assert sorted(cu) == sorted(int(g["edge_obs"][e]) for e in np.nonzero(fw & 3)[0]) and abs(r.chi2_final - rw.chi2_final) < 1e-6 * max(1.0, rw.chi2_final)
+    c.close(); t.close()
+
+
+def t_positions(L, t, slots):
+    """Positions the scene put into the map (the test keeps its own copy: the C-ABI has no map read-back)."""
+    return t._scene_positions[[list(t._scene_slots).index(s) for s in slots]] if hasattr(t, "_scene_positions") else None
