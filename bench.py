@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU baseline (0: min(host cpus, 64))")
     ap.add_argument("--no-latency-mode", action="store_true")
     ap.add_argument("--prologue", type=int, default=150, help="frames tracked (untimed) before the warmup so that the timed steps see the steady-state map: covisible window, BA size and active-map size level off after ~100 frames; 0 = time a young map")
+    ap.add_argument("--host-graph", action="store_true", help="cut the local BA's graph on the host (Backend::Build) instead of on the device from the resident observation table")
     ap.add_argument("--multi-streams", default="8", help="comma list of stream counts for the several-streams-per-GPU figure ('' = skip)")
     args = ap.parse_args()
 
@@ -146,7 +147,7 @@ def main():
     dptr = [d_depth.data_ptr() + i * fd for i in range(total)]
 
     opts = dict(width=W, height=H, number_of_features=N, max_frames_in_flight=args.lookahead, device=local_rank,
-                enable_local_optimization=0 if args.no_ba else 1, backend_lag_frames=args.ba_lag, track_batch=args.track_batch, map_capacity=1 << 20, ransac_iterations=args.hyps)
+                enable_local_optimization=0 if args.no_ba else 1, backend_lag_frames=args.ba_lag, track_batch=args.track_batch, map_capacity=1 << 20, ransac_iterations=args.hyps, ba_device_graph=0 if args.host_graph else 1)
 
     # One-time costs (code-object load, pinned staging, scratch growth) are paid on a throw-away system before the
     # warmup: the driver's short runs (--warmup 5) then time the same steady state as the long ones.
@@ -368,7 +369,7 @@ def main():
                                    % (N, args.speed, (K / kf_timed) if kf_timed else float("inf")),
                        "streams_per_gpu": 1, "lookahead_frames": args.lookahead, "track_batch": args.track_batch,
                        "local_ba": (False if args.no_ba else ("synchronous" if args.ba_lag == 0 else "overlapped, merged %d frames later or at the next keyframe" % args.ba_lag)),
-                       "ransac_hypotheses": args.hyps, "speed": args.speed,
+                       "ransac_hypotheses": args.hyps, "speed": args.speed, "ba_graph_cut": "host" if args.host_graph else "device (resident observation table)",
                        "prologue_frames": args.prologue, "timed_frames": "frames %d..%d of the stream (steady state: the map and the local-BA window have levelled off)" % (Wm, total - 1)},
             **acc, "keyframes": st["keyframes"], "keyframes_timed": kf_timed, "ba_runs": st["ba_runs"], "ba_runs_timed": st["ba_runs"] - st_w["ba_runs"],
             "lost": st["lost"], "map_points": st["map_points"],

@@ -26,7 +26,12 @@ public:
     void SetContext(vo_ctx* ctx, int device);        // tracker's context (used when lag == 0)
     void SetLag(int frames) { lag_ = frames < 0 ? 0 : frames; if (ctx_ && lag_ > 0) EnsureWorker(); }
     void Stop();                                     // finish the pending job, join the worker
-    void Flush() { if (job_) Finish(); }             // wait for the pending job and merge it now (end of a sequence / of a timed region)
+    void Flush() { if (job_) Finish(); }
+    // Device-resident graph: the back-end reads the tracker's device tables while it cuts the graph; the tracker calls this
+    // before a keyframe's bookkeeping changes them (the cut is the first ~0.2 ms of a BA, a keyframe is >= 1 ms away).
+    void WaitGraphCut();
+    void SetDeviceGraph(bool on) { deviceGraph_ = on; }
+    bool DeviceGraph() const { return deviceGraph_; }             // wait for the pending job and merge it now (end of a sequence / of a timed region)
     void OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr);
     // tracker thread, once per frame before tracking: merge a finished/overdue job; true if the map changed
     bool Poll(size_t frameIndex);
@@ -45,6 +50,8 @@ private:
         std::vector<int32_t> edgePose, edgePoint; std::vector<float> edgeUv;
         std::vector<double> poses, pts, posesOut, ptsOut; std::vector<uint8_t> flags;
         size_t frameIndex = 0; int rc = 0; double solveMs = 0; bool done = false;
+        // device-resident graph: only the free keyframes' numbers go down, the cut happens on the device
+        bool resident = false, cutDone = false; std::vector<int32_t> freeKf, pointSlots; std::vector<int64_t> culled; int nPoints = 0, nFixed = 0, nEdges = 0, nCulled = 0;
     };
     Camera::Ptr camera_;
     float chi2Threshold_;
@@ -64,6 +71,9 @@ private:
     void Finish();                  // wait for the pending job and merge it
     void WorkerLoop();
     void EnsureWorker();            // the worker's context, stream and thread exist before the first keyframe (no one-time setup inside a timed run)
+    bool deviceGraph_ = false;
+    void ApplyResident(Job& j);
+    void SolveResident(Job& j, vo_ctx* ctx);
     int maxFree_ = 160;             // free-pose cap of one solve: the Cholesky of the reduced system is LDS resident (vo_local_ba: D = 6 n_free <= ~1050)
 };
 }  // namespace myslam

@@ -52,6 +52,7 @@ public:
     CovisibleKeyframeIdToWeight GetCovisibleKeyframeWeights() { std::unique_lock<std::mutex> lck(obsLock_); return covis_.count; }     // allCovisibleKeyframeIdToWeight_ (frame.h:94)
 
     int slot_ = -1;                 // vo_ctx frame slot holding this frame's ORB results (-1: none)
+    int kfIndex_ = -1;              // dense keyframe number (insertion order) in the device-resident keyframe table; -1: not a keyframe there
     uint64_t baStamp_ = 0; int baIndex_ = -1;    // scratch of Backend::Build
     bool orb_done_ = false;
 

@@ -103,6 +103,7 @@ private:
     void CreateNewMappoints();
     void TriangulateMappointsInTrackingMap();
     void TriangulateAllBatched();                    // triangulate_all: 1 -- every eligible point, one vo_triangulate_batch call
+    void RegisterKeyframeOnDevice();                 // device-resident bookkeeping: the new keyframe's pose and observations
     void AddNewMappointsObservationsForOldKeyframes();   // reobserve_new_mappoints: 1 (reference src/frontend.cpp:408-463, disabled there at :130)
 };
 }  // namespace myslam

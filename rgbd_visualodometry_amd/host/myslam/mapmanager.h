@@ -43,6 +43,13 @@ private:
     std::vector<Mappoint*> dirty_;
     std::vector<Mappoint::Ptr> order_;
     uint64_t stamp_ = 0;
+public:
+    // Device-resident bookkeeping: keyframes by their dense number and the observation registry -- observation id
+    // (append order of vo_obs_append) -> (keyframe, map point), so that a device-side cull list can be applied to the host structures.
+    std::vector<Frame*> kfByIndex_;
+    struct ObsRef { Frame* keyframe; Mappoint* mappoint; };
+    std::vector<ObsRef> obsRegistry_;
+    Mappoint* MappointBySlot(int slot) const { return (slot >= 0 && (size_t)slot < order_.size()) ? order_[slot].get() : nullptr; }
 };
 }  // namespace myslam
 #endif

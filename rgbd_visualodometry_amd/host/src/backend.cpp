@@ -17,6 +17,7 @@ Backend::Backend(const Camera::Ptr camera) : camera_(camera) {
     chi2Threshold_ = Config::has("chi2_th") ? Config::get<float>("chi2_th") : 1.0f;       // backend.h:24
     if (Config::has("backend_lag_frames")) lag_ = std::max(0, Config::get<int>("backend_lag_frames"));
     if (Config::has("ba_max_free_keyframes")) maxFree_ = std::max(1, Config::get<int>("ba_max_free_keyframes"));
+    if (Config::has("ba_device_graph")) deviceGraph_ = Config::get<int>("ba_device_graph") != 0;
 }
 
 Backend::~Backend() { Stop(); if (ctxOwn_) vo_ctx_destroy(ctxOwn_); }
@@ -52,7 +53,13 @@ void Backend::WorkerLoop() {
         hasWork_ = false;
         Job* j = job_.get();
         lk.unlock();
-        Solve(*j, ctxOwn_);
+        if (j->resident) {                                   // cut on the device from the tracker's tables, then solve
+            auto t0 = std::chrono::steady_clock::now();
+            j->rc = vo_local_ba_resident_cut(ctxOwn_, ctx_, j->freeKf.data(), (int)j->freeKf.size(), std::sqrt(7.815), chi2Threshold_, &j->nPoints, &j->nFixed, &j->nEdges);
+            lk.lock(); j->cutDone = true; cv_.notify_all(); lk.unlock();
+            if (j->rc == VO_OK) SolveResident(*j, ctxOwn_);
+            j->solveMs = ms_since(t0);
+        } else Solve(*j, ctxOwn_);
         lk.lock();
         j->done = true;
         cv_.notify_all();
@@ -74,7 +81,7 @@ void Backend::Finish() {
         if (stats_.failed++ == 0) std::cerr << "[myslam] vo_local_ba failed (" << vo_strerror(j->rc) << "): this local BA is skipped, tracking continues" << std::endl;
         return;
     }
-    Apply(*j);
+    if (j->resident) ApplyResident(*j); else Apply(*j);
 }
 
 void Backend::OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr) {
@@ -83,6 +90,37 @@ void Backend::OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr) {
     if (job_) Finish();                              // the previous result is merged before a new graph is cut
     std::unique_ptr<Job> j(new Job);
     j->frameIndex = frameIndex_;
+    if (deviceGraph_ && keyframeCurr->kfIndex_ >= 0) {      // only the free keyframes' numbers go to the device; no host graph cut
+        auto covis = keyframeCurr->GetCovisibleKeyframes();
+        std::vector<size_t> ids(covis.begin(), covis.end());
+        if ((int)ids.size() + 1 > std::min(maxFree_, 64)) {  // the device pair-list builder takes <= 64 free poses
+            auto w = keyframeCurr->GetCovisibleKeyframeWeights();
+            std::sort(ids.begin(), ids.end(), [&](size_t a, size_t b) { const int wa = w[a], wb = w[b]; return wa != wb ? wa > wb : a > b; });
+            ids.resize((size_t)std::min(maxFree_, 64) - 1);
+            ++stats_.capped;
+        }
+        ids.push_back(keyframeCurr->GetId());
+        std::sort(ids.begin(), ids.end());
+        MapManager& map = MapManager::GetInstance();
+        for (size_t id : ids) { auto f = map.GetKeyframe(id); if (f && f->kfIndex_ >= 0) { j->freeKf.push_back(f->kfIndex_); j->poseFrames.push_back(f.get()); } }
+        j->nFree = (int)j->freeKf.size(); j->resident = true;
+        stats_.ms_build += ms_since(t0);
+        job_ = std::move(j);
+        if (lag_ == 0) {
+            auto t1 = std::chrono::steady_clock::now();
+            job_->rc = vo_local_ba_resident_cut(ctx_, ctx_, job_->freeKf.data(), job_->nFree, std::sqrt(7.815), chi2Threshold_, &job_->nPoints, &job_->nFixed, &job_->nEdges);
+            job_->cutDone = true;
+            if (job_->rc == VO_OK) SolveResident(*job_, ctx_);
+            job_->solveMs = ms_since(t1);
+            job_->done = true; Finish();
+        } else {
+            EnsureWorker();
+            { std::unique_lock<std::mutex> lk(mu_); hasWork_ = true; }
+            cv_.notify_all();
+        }
+        stats_.ms += ms_since(t0);
+        return;
+    }
     Build(*j, keyframeCurr);
     stats_.ms_build += ms_since(t0);
     if (j->edgePose.empty() || j->nFree == 0) return;
@@ -192,6 +230,55 @@ void Backend::Solve(Job& j, vo_ctx* ctx) {
     res.poses = j.posesOut.data(); res.points = j.ptsOut.data(); res.edge_flags = j.flags.data();
     j.rc = vo_local_ba(ctx, &prob, &res);
     j.solveMs = ms_since(t0);
+}
+
+void Backend::WaitGraphCut() {
+    if (!job_ || !job_->resident || lag_ == 0) return;
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_.wait(lk, [&] { return job_->cutDone; });
+}
+
+void Backend::SolveResident(Job& j, vo_ctx* ctx) {
+    if (j.nPoints == 0 || j.nEdges == 0) { j.nCulled = 0; return; }
+    j.posesOut.resize(12 * (size_t)std::max(j.nFree, 1)); j.pointSlots.resize((size_t)j.nPoints); j.ptsOut.resize(3 * (size_t)j.nPoints); j.culled.resize((size_t)j.nEdges);
+    vo_ba_resident_result r;
+    std::memset(&r, 0, sizeof(r));
+    r.poses = j.posesOut.data(); r.point_slots = j.pointSlots.data(); r.points = j.ptsOut.data(); r.culled_obs = j.culled.data();
+    r.cap_points = j.nPoints; r.cap_culled = j.nEdges;
+    j.rc = vo_local_ba_resident_solve(ctx, 10, 10, &r);                                  // backend.cpp:141,:159
+    j.nCulled = r.n_culled;
+}
+
+// Write-back of a device-cut BA (reference src/backend.cpp:144-194): culled observations by their registry entry, free poses by
+// keyframe number, points by map slot; then the device tables are brought up to date (the solve left them untouched).
+void Backend::ApplyResident(Job& j) {
+    VO_SCOPE("ba.apply");
+    MapManager& map = MapManager::GetInstance();
+    if (j.nPoints == 0 || j.nEdges == 0) return;
+    for (int i = 0; i < j.nCulled; ++i) {
+        const MapManager::ObsRef& o = map.obsRegistry_[(size_t)j.culled[i]];
+        if (o.keyframe->IsObservedMappoint(o.mappoint->GetId())) o.keyframe->RemoveObservedMappoint(o.mappoint->GetId());
+    }
+    for (int p = 0; p < j.nFree; ++p) j.poseFrames[p]->SetPose(SE3::from12(&j.posesOut[12 * (size_t)p]));
+    const size_t np = (size_t)j.nPoints;
+    applySlots_.resize(np); applyXyz_.resize(3 * np);
+    size_t m = 0;
+    for (size_t k = 0; k < np; ++k) {
+        Mappoint* mp = map.MappointBySlot(j.pointSlots[k]);
+        if (!mp) continue;
+        mp->optimized_ = true;
+        if (mp->outlier_) continue;
+        const double* x = &j.ptsOut[3 * k];
+        mp->SetPositionSyncedUnlocked(Vector3d(x[0], x[1], x[2]));
+        applySlots_[m] = mp->slot_; applyXyz_[3 * m] = x[0]; applyXyz_[3 * m + 1] = x[1]; applyXyz_[3 * m + 2] = x[2];
+        ++m;
+    }
+    auto check = [](int rc, const char* what) { if (rc != VO_OK) throw std::runtime_error(std::string(what) + " (BA merge) failed: " + vo_strerror(rc)); };
+    if (m) check(vo_map_upsert(ctx_, applySlots_.data(), applyXyz_.data(), nullptr, nullptr, nullptr, (int)m), "vo_map_upsert");
+    check(vo_kf_set_pose(ctx_, j.freeKf.data(), j.posesOut.data(), j.nFree), "vo_kf_set_pose");
+    if (j.nCulled) check(vo_obs_kill(ctx_, j.culled.data(), j.nCulled), "vo_obs_kill");
+    stats_.runs++; stats_.poses = j.nFree; stats_.fixed = j.nFixed; stats_.points = j.nPoints; stats_.edges = j.nEdges; stats_.outliers = j.nCulled; stats_.ms_solve += j.solveMs;
+    { const double D = 6.0 * j.nFree; stats_.sum_d3 += D * D * D; stats_.sum_d2 += D * D; stats_.sum_edges += j.nEdges; }
 }
 
 void Backend::Apply(Job& j) {

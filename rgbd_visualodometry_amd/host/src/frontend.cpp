@@ -87,6 +87,7 @@ void FrontEnd::InitializationHandler() {
     MapManager::GetInstance().InsertKeyframe(frameCurr_);       // the first frame is a keyframe
     ++stats_.keyframes;
     CreateNewMappoints();                                        // one frame suffices: depth is measured
+    if (backend_ && backend_->DeviceGraph()) RegisterKeyframeOnDevice();
     state_ = TRACKING;
     framePrev_ = frameCurr_;
     keyframeRef_ = frameCurr_;
@@ -107,6 +108,7 @@ bool FrontEnd::TrackingHandler() {
     if (!IsKeyframe()) return true;
 
     ++epoch_; lastInterval_ = framesSinceKf_; framesSinceKf_ = 0;   // map + prior change: cached speculative results are void
+    if (backend_) backend_->WaitGraphCut();                        // a device-side graph cut may still be reading the tables this keyframe changes
     {
         StageTimer t(stats_.ms_keyframe);
         { VO_SCOPE("kf.lists"); EnsureMatchLists(); }
@@ -117,6 +119,7 @@ bool FrontEnd::TrackingHandler() {
         if (reobserveNew_) { VO_SCOPE("kf.reobserve"); AddNewMappointsObservationsForOldKeyframes(); }
         { VO_SCOPE("kf.triangulate"); if (triangulateAll_) TriangulateAllBatched(); else TriangulateMappointsInTrackingMap(); }
     }
+    if (backend_ && backend_->DeviceGraph()) { StageTimer t(stats_.ms_keyframe); VO_SCOPE("kf.register"); RegisterKeyframeOnDevice(); }
     if (backend_) { StageTimer t(stats_.ms_backend); backend_->OptimizeCovisibleGraphOfKeyframe(frameCurr_); }
     framePrev_ = frameCurr_;
     keyframeRef_ = frameCurr_;
@@ -357,6 +360,31 @@ void FrontEnd::CreateNewMappoints() {
         newMappoints_.push_back(mpt);
     }
     if (verbose_) std::cout << "Created new mappoints: " << newMappoints_.size() << std::endl;
+}
+
+// The new keyframe enters the device-resident tables the local BA's graph is cut from: its map points (positions, flags --
+// the dirty list, flushed now instead of at the next frame), its pose, and one observation record per observed map point
+// (Frame::AddObservedMappoint, reference src/frame.cpp:93-120); the registry maps observation ids back to host objects.
+void FrontEnd::RegisterKeyframeOnDevice() {
+    MapManager& map = MapManager::GetInstance();
+    if (frameCurr_->kfIndex_ < 0) { frameCurr_->kfIndex_ = (int)map.kfByIndex_.size(); map.kfByIndex_.push_back(frameCurr_.get()); }
+    FlushDirtyMappoints();
+    const std::vector<Frame::ObservedEntry>& ob = frameCurr_->Observed();
+    std::vector<int32_t> kf(ob.size(), frameCurr_->kfIndex_), mp(ob.size()); std::vector<float> uv(2 * ob.size());
+    size_t n = 0;
+    for (const Frame::ObservedEntry& e : ob) {
+        if (!e.alive) continue;
+        const Mappoint::Observation& o = e.mappoint->ObservationList().back();          // this keyframe's observation was appended last
+        mp[n] = e.mappoint->slot_; uv[2 * n] = o.pixel.x; uv[2 * n + 1] = o.pixel.y;
+        map.obsRegistry_.push_back(MapManager::ObsRef{frameCurr_.get(), e.mappoint});
+        ++n;
+    }
+    int64_t first = 0;
+    vo_check(vo_obs_append(ctx_, kf.data(), mp.data(), uv.data(), (int)n, &first), "vo_obs_append");
+    if ((size_t)first + n != map.obsRegistry_.size()) throw std::runtime_error("observation registry out of step with the device table");
+    double T[12];
+    frameCurr_->GetPose().to12(T);
+    vo_check(vo_kf_set_pose(ctx_, &frameCurr_->kfIndex_, T, 1), "vo_kf_set_pose");
 }
 
 // Every eligible point of the keyframe in one batched launch (vo_triangulate_batch): the reference's loop stops after the

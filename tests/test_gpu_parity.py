@@ -371,6 +371,36 @@ def test_triangulate_all_and_reobservation_pass_match_oracle(frames):
     np.testing.assert_allclose(ph, po, atol=1e-6)
 
 
+def test_device_resident_graph_cut_system_matches_oracle(frames):
+    """SURVEY 8f-2 end to end: local BA graphs cut on the device from the resident observation table, overlapped back-end,
+    look-ahead and speculative batches -- HIP against the CPU restatement of the same path, and against the host graph cut."""
+    from rgbd_visualodometry_amd import system
+    bgr, depth, Twc, ts = frames
+    n = len(ts)
+
+    def run(lib, **opt):
+        s = system.VoSystem(lib, number_of_features=700, keyframe_rotation=0.02, keyframe_translation=0.02, backend_lag_frames=3, max_frames_in_flight=5, track_batch=4, **opt)
+        poses, i = [], 0
+        while i < n:
+            k = min(5, n - i)
+            s.prefetch(ts[i:i + k], [bgr[j].ctypes.data for j in range(i, i + k)], [depth[j].ctypes.data for j in range(i, i + k)], bgr[0].strides[0], depth[0].strides[0], False)
+            for _ in range(k):
+                poses.append(s.add_prefetched()[1])
+            i += k
+        s.flush()
+        st = s.stats()
+        s.close()
+        return np.array(poses), st
+    pd, sd = run(system.HOST_LIB, ba_device_graph=1)
+    po, so = run(ORACLE_LIB, ba_device_graph=1)
+    ph, sh = run(system.HOST_LIB)
+    for k in ("keyframes", "ba_runs", "map_points", "ba_points", "ba_edges", "ba_poses", "ba_fixed"):
+        assert sd[k] == so[k] == sh[k], k
+    assert sd["ba_runs"] >= 3
+    np.testing.assert_allclose(pd, po, atol=1e-6)
+    np.testing.assert_allclose(pd, ph, atol=1e-6)
+
+
 def test_degenerate_frames_behave_like_the_oracle(frames, libs):
     """Edge cases of the chain: a textureless frame (no FAST corner survives), an empty tracking map, a tracking map the
     frame cannot see -- same counts and status on both sides, no fault."""

@@ -282,3 +282,20 @@ def test_triangulate_all_and_reobservation_options(frames):
     assert so["keyframes"] >= 4 and so["reobserved_matches"] > 50
     assert so["triangulated"] >= sb["triangulated"]
     base.close(); opt.close()
+
+
+def test_device_resident_graph_cut_gives_the_host_graph_cut_trajectory(frames):
+    """with ba_device_graph the local BA's graph comes from the resident observation table (vo_local_ba_resident)
+    instead of Backend::Build's walk over the host objects; same graph up to the order of the points, so the same trajectory up
+    to summation order -- synchronous and overlapped (lag) back-end, with look-ahead and speculative batches."""
+    n = len(frames[3])
+    kw = dict(number_of_features=500, keyframe_rotation=0.02, keyframe_translation=0.02)
+    host, sh = run_system(ORACLE_LIB, frames, n, **kw)
+    dev, sd = run_system(ORACLE_LIB, frames, n, ba_device_graph=1, **kw)
+    assert sh["keyframes"] == sd["keyframes"] >= 5 and sh["ba_runs"] == sd["ba_runs"] >= 4 and sh["map_points"] == sd["map_points"]
+    assert sh["ba_points"] == sd["ba_points"] and sh["ba_edges"] == sd["ba_edges"] and sh["ba_poses"] == sd["ba_poses"] and sh["ba_fixed"] == sd["ba_fixed"]
+    np.testing.assert_allclose(dev, host, atol=1e-6)
+    lag_h, _ = run_system(ORACLE_LIB, frames, n, backend_lag_frames=3, max_frames_in_flight=8, track_batch=4, **kw)
+    lag_d, sl = run_system(ORACLE_LIB, frames, n, backend_lag_frames=3, max_frames_in_flight=8, track_batch=4, ba_device_graph=1, **kw)
+    assert sl["ba_runs"] >= 4
+    np.testing.assert_allclose(lag_d, lag_h, atol=1e-6)
