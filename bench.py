@@ -319,7 +319,7 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             from oracle import ORACLE_LIB                   # the checker, timed as the CPU baseline (never on the product path)
-            copts = {**opts, "max_frames_in_flight": 1, "track_batch": 1, "backend_lag_frames": 0}
+            copts = {**opts, "max_frames_in_flight": 1, "track_batch": 1, "backend_lag_frames": 0, "ba_device_graph": 0}
             nf = min(args.cpu_frames, total)
             o = system.VoSystem(ORACLE_LIB, **copts)
             est_c = {}

@@ -1808,14 +1808,14 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     R.ready = false;
     const int nkf = t->n_kf, mh = std::max(t->map_hi, 1), D = 6 * nf;
     const long long no = t->n_obs;
-    if (mh > 1024 * 1024 || nkf > 1024 * 1024) return VO_E_UNSUPPORTED;
+    if (mh >= 1024 * 1024 || nkf > 1024 * 1024) return VO_E_UNSUPPORTED;
     if ((CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D) * sizeof(double) > 158 * 1024 || nf > 64) return VO_E_UNSUPPORTED;
     for (int i = 0; i < nf; ++i) if (free_kf[i] < 0 || free_kf[i] >= nkf) return VO_E_INVALID;
     // ---- cut scratch: [kf_idx nkf][fixed_flag nkf][fidx nkf][pt_flag mh][pidx mh][cnt mh][fill mh][pt_start mh + 1][bsum 1024][totals 8]
     size_t co = 0;
     auto cc = [&](size_t bytes) { size_t o = co; co += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_kfi = cc(4 * (size_t)nkf), o_ffl = cc(4 * (size_t)nkf), o_fid = cc(4 * (size_t)nkf), o_pfl = cc(4 * (size_t)mh), o_pid = cc(4 * (size_t)mh),
-                 o_cnt = cc(4 * (size_t)mh), o_fil = cc(4 * (size_t)mh), o_pst = cc(4 * (size_t)(mh + 1)), o_bs = cc(4096), o_tot = cc(64);
+                 o_cnt = cc(4 * (size_t)(mh + 1)), o_fil = cc(4 * (size_t)mh), o_pst = cc(4 * (size_t)(mh + 1)), o_bs = cc(4096), o_tot = cc(64);
     if (co > c->d_cut_bytes) {
         if (c->d_cut) { (void)hipStreamSynchronize(st); (void)hipFree(c->d_cut); }
         c->d_cut = nullptr; c->d_cut_bytes = 0;
@@ -1832,7 +1832,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     HIP_TRY(hipMemsetAsync(kf_idx, 0xFF, 4 * (size_t)nkf, st));                // -1: not in the graph
     HIP_TRY(hipMemsetAsync(fixed_flag, 0, 4 * (size_t)nkf, st));
     HIP_TRY(hipMemsetAsync(pt_flag, 0, 4 * (size_t)mh, st));
-    HIP_TRY(hipMemsetAsync(cnt, 0, 4 * (size_t)mh, st));
+    HIP_TRY(hipMemsetAsync(cnt, 0, 4 * (size_t)(mh + 1), st));
     HIP_TRY(hipMemsetAsync(fill, 0, 4 * (size_t)mh, st));
     {   // free keyframes -> pose index 0 .. nf-1 (tiny upload through the pinned mailbox)
         for (int i = 0; i < nf; ++i) h[i] = free_kf[i];
@@ -1844,7 +1844,8 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     int rc = scan_i32(st, pt_flag, mh, bsum, pidx, tot);                        // dense point index, nx
     if (rc) return rc;
     if (gO) hipLaunchKernelGGL(k_cut_count, dim3(gO), dim3(256), 0, st, T, kf_idx, pt_flag, pidx, cnt, fixed_flag);
-    if ((rc = scan_i32(st, cnt, mh, bsum, pt_start_w, tot + 1))) return rc;     // pt_start over the dense indices (cnt is zero beyond nx), ne
+    if ((rc = scan_i32(st, cnt, mh + 1, bsum, pt_start_w, tot + 1))) return rc; // pt_start[0 .. nx] over the dense indices (cnt is zero from nx on; one spare entry so that
+                                                                                // pt_start[nx] exists when every slot of the map is in the graph), ne
     if ((rc = scan_i32(st, fixed_flag, nkf, bsum, fidx, tot + 2))) return rc;   // fixed pose numbering, n_fixed
     HIP_TRY(hipMemcpyAsync(h + 128, tot, 12, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

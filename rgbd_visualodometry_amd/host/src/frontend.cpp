@@ -232,6 +232,7 @@ void FrontEnd::RefreshTrackingMap() {
 void FrontEnd::FlushDirtyMappoints() {
     std::vector<Mappoint*> dirty = MapManager::GetInstance().TakeDirty();
     if (dirty.empty()) return;
+    if (backend_) backend_->WaitGraphCut();                 // the cut reads positions and outlier flags of the map as of its keyframe
     const size_t n = dirty.size();
     upIdx_.resize(n); upXyz_.resize(3 * n); upNrm_.resize(3 * n); upDesc_.resize(32 * n); upFlags_.resize(n);
     for (size_t i = 0; i < n; ++i) {

@@ -251,22 +251,22 @@ def test_hypothesis_shard_equals_unsharded_ransac(libs, streams):
     ctx.close()
 
 
-def _resident_scene(L, rng, n_kf=9, n_pts=400, n_free=4):
+def _resident_scene(L, rng, n_kf=9, n_pts=400, n_free=4, young=False):
     """Keyframes and map points with a sliding visibility pattern, loaded into the observation table and the map of a context."""
     import ref_model as rm
     p = L.default_params(n_features=64, map_capacity=4096)
     t = L.context(p)
     Ts = [rm.se3_exp(np.concatenate([rng.normal(0, 0.25, 3) + [0.12 * k, 0, 0], rng.normal(0, 0.05, 3)])) for k in range(n_kf)]
     X = rng.uniform(-1.5, 1.5, (n_pts, 3)) + [0.5, 0, 5]
-    slots = rng.permutation(2000)[:n_pts].astype(np.int32)                 # map slots in arbitrary order, with holes
-    flags = (rng.random(n_pts) < 0.04).astype(np.uint8)                     # a few outliers
+    slots = rng.permutation(n_pts if young else 2000)[:n_pts].astype(np.int32)   # map slots in arbitrary order, with holes unless young
+    flags = (rng.random(n_pts) < (0 if young else 0.04)).astype(np.uint8)        # a few outliers
     X0 = X + rng.normal(0, 0.01, X.shape)
     t.map_upsert(slots, X0, np.tile([0, 0, 1.0], (n_pts, 1)), np.zeros((n_pts, 32), np.uint8), flags)
     t._scene_positions, t._scene_slots = X0, slots
     t.kf_set_pose(np.arange(n_kf), np.array(Ts))
     obs = []
     for k in range(n_kf):
-        seen = [i for i in range(n_pts) if (i * 7 + k * 31) % 100 < 45 + 5 * (k % 3)]
+        seen = [i for i in range(n_pts) if young or (i * 7 + k * 31) % 100 < 45 + 5 * (k % 3)]
         R, tt = Ts[k][:9].reshape(3, 3), Ts[k][9:]
         uv = []
         for i in seen:
@@ -274,20 +274,22 @@ def _resident_scene(L, rng, n_kf=9, n_pts=400, n_free=4):
             uv.append([p.fx * pc[0] / pc[2] + p.cx + rng.normal(0, 0.3), p.fy * pc[1] / pc[2] + p.cy + rng.normal(0, 0.3)])
         first = t.obs_append(np.full(len(seen), k), slots[seen], np.array(uv))
         obs += [(first + j, k, int(slots[i]), uv[j]) for j, i in enumerate(seen)]
-    dead = [o[0] for o in obs if rng.random() < 0.03]
+    dead = [o[0] for o in obs if rng.random() < (0 if young else 0.03)]
     t.obs_kill(dead)
-    free = [n_kf - 1 - 2 * i for i in range(n_free)]                        # not sorted, not contiguous
+    free = [n_kf - 1 - (1 if young else 2) * i for i in range(n_free)]      # not sorted, not contiguous
     return t, Ts, X, slots, flags, obs, set(dead), free
 
 
 @pytest.mark.parametrize("libs", LIBS)
-def test_resident_graph_cut_follows_backend_cpp(libs):
+@pytest.mark.parametrize("young", [False, True])
+def test_resident_graph_cut_follows_backend_cpp(libs, young):
     """the graph cut on the device-resident observation table (reference src/backend.cpp:36-135) against the
     definition: points = non-outlier points a free keyframe observes, edges = all live observations of those points, fixed
     poses = their other observers; ordering rules of include/vo_hip.h."""
     L = capi.load(libs[0])
     rng = np.random.default_rng(17)
-    t, Ts, X, slots, flags, obs, dead, free = _resident_scene(L, rng)
+    # young: the first local BA of a run -- every slot of the map is in the graph, every keyframe is free (no fixed pose)
+    t, Ts, X, slots, flags, obs, dead, free = _resident_scene(L, rng, n_kf=2, n_pts=300, n_free=2, young=True) if young else _resident_scene(L, rng)
     c = L.context(L.default_params(n_features=64, map_capacity=64))
     g = c.resident_graph(t, free)
     outl = {int(s) for s, f in zip(slots, flags) if f}
@@ -296,7 +298,9 @@ def test_resident_graph_cut_follows_backend_cpp(libs):
     assert list(g["point_slots"]) == pts and len(pts) > 100
     edges = sorted([o for o in live if o[2] in set(pts)], key=lambda o: (pts.index(o[2]), o[1]))
     fixed = sorted({o[1] for o in edges} - set(free))
-    assert list(g["pose_kf"]) == free + fixed and len(fixed) >= 2
+    assert list(g["pose_kf"]) == free + fixed and len(fixed) >= (0 if young else 2)
+    if young:
+        assert len(pts) == 300 and max(pts) == 299 and not fixed
     pose_of = {k: i for i, k in enumerate(free + fixed)}
     assert list(g["edge_obs"]) == [o[0] for o in edges]
     assert list(g["edge_pose"]) == [pose_of[o[1]] for o in edges] and list(g["edge_point"]) == [pts.index(o[2]) for o in edges]
