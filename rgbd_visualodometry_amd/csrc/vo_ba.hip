@@ -1218,6 +1218,7 @@ struct BaJob {
     int round = 0, cur_buf = 0, iters = 0, steps = 0, need_first = 0;
     double chi0 = 0, chi_final = 0;
     int rc = VO_OK; bool done = false;
+    hipEvent_t wait_ev = nullptr;                           // the problem's arrays are complete once this event (recorded on the owner's stream) has passed
 };
 struct BaEngine {
     int device = 0, refs = 0;
@@ -1269,8 +1270,9 @@ static int ba_engine_pump(BaEngine* E) {                    // engine thread; re
             E->slot[s] = j; j->B.ctl = E->d_ctl + s; j->cur_buf = 0; j->iters = 0;
             lk.unlock();
             int rc = VO_OK;
+            if (j->wait_ev && hipStreamWaitEvent(st, j->wait_ev, 0) != hipSuccess) rc = VO_E_DEVICE;
             E->h_Bs[s] = j->B;                              // the slot's mirror is free: its previous problem is gone
-            if (hipMemcpyAsync(E->d_Bs + s, E->h_Bs + s, sizeof(BaDev), hipMemcpyHostToDevice, st) != hipSuccess) rc = VO_E_DEVICE;
+            if (rc == VO_OK && hipMemcpyAsync(E->d_Bs + s, E->h_Bs + s, sizeof(BaDev), hipMemcpyHostToDevice, st) != hipSuccess) rc = VO_E_DEVICE;
             if (rc == VO_OK) rc = ba_start_round(E, s, 1);                                  // backend.cpp:140-141
             if (rc == VO_OK) {                              // initial plain chi2 (reporting only)
                 const BaBatch Q = ba_batch_of(E, &s, 1);
@@ -1648,14 +1650,18 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
 // and the keyframe poses (reference src/backend.cpp:36-135, which walks hash maps of shared pointers), so a keyframe costs
 // the host neither the graph cut (0.45 ms of pointer chasing) nor the CSR build and 3 MB upload (0.4 ms).
 //
-//   k_cut_points   observation-parallel: flag the map points some FREE keyframe observes (outliers excluded)
-//   k_scan_*       exclusive scan of int32 arrays (flags -> dense point index, per-point edge counts -> pt_start, ...)
-//   k_cut_count    observation-parallel: edges per point (one atomic per observation, ~3 per address); flag the fixed keyframes
-//   k_cut_fill     observation-parallel: observation ids into their point's segment (arrival order)
-//   k_cut_emit     point-parallel: order each segment by keyframe number (what the host's graph cut emits: observation lists
-//                  are in keyframe order), then edge_pose / edge_point / edge_uv / pt_edges
-//   k_cut_gather   poses from the keyframe table, positions from the map
-//   k_ps_count / k_ps_fill   per free pose: its edges in ascending edge order (ordered ballot compaction)
+//   k_cut_init        keyframe -> pose index for the free keyframes (list passed by value)
+//   k_cut_points      observation-parallel: flag the map points some FREE keyframe observes (outliers excluded)
+//   k_scan_*          exclusive scan of int32 arrays (flags -> dense point index, per-point edge counts -> pt_start)
+//   k_cut_count       observation-parallel: edges per point (one atomic per observation, ~3 per address); flag the fixed keyframes
+//   k_cut_fixed_scan  one workgroup: numbers the fixed keyframes behind the free ones
+//   k_cut_fill        observation-parallel: observation ids into their point's segment (arrival order); map slot -> point list
+//   k_cut_emit        point-parallel: order each segment by keyframe number (what the host's graph cut emits: observation lists
+//                     are in keyframe order), then edge_pose / edge_point / edge_uv / pt_edges; the same launch gathers poses
+//                     from the keyframe table and positions from the map
+//   k_ps_lists        per free pose: its edges in ascending edge order (ordered ballot compaction)
+// 14 launches, one memset, two small read-backs (sizes; per-pose list lengths). The pair plan (k_ba_pairs*) is queued behind
+// them and an event hands the finished arrays to the engine's stream.
 // Point order = ascending map slot, fixed poses = ascending keyframe number: deterministic, and the same as oracle/o_capi.cpp.
 // =====================================================================================================================
 struct CutTabs { const int32_t* obs_kf; const int32_t* obs_mp; const float* obs_uv; const uint8_t* alive; long long n_obs;
@@ -1710,28 +1716,55 @@ __global__ void k_cut_count(CutTabs T, const int* __restrict__ kf_idx, const int
     atomicAdd(&cnt[pidx[m]], 1);
     if (kf_idx[k] < 0) fixed_flag[k] = 1;
 }
-__global__ void k_cut_fixed(int n_kf, int n_free, const int* __restrict__ fixed_flag, const int* __restrict__ fidx, int* __restrict__ kf_idx, int* __restrict__ pose_kf) {
+struct CutFree { int n; int kf[64]; };
+// keyframe -> pose index: the free keyframes take 0 .. n-1 in the caller's order, everything else -1 until k_cut_fixed_scan
+__global__ void k_cut_init(int n_kf, CutFree F, int* __restrict__ kf_idx, int* __restrict__ pose_kf) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_kf || !fixed_flag[k]) return;
-    kf_idx[k] = n_free + fidx[k];                           // fixed poses follow the free ones, ascending keyframe number
-    pose_kf[n_free + fidx[k]] = k;
+    if (k < F.n) pose_kf[k] = F.kf[k];
+    if (k >= n_kf) return;
+    int idx = -1;
+    for (int i = 0; i < F.n; ++i) if (F.kf[i] == k) idx = i;
+    kf_idx[k] = idx;
 }
-__global__ void k_cut_pointlist(int map_hi, const int* __restrict__ pt_flag, const int* __restrict__ pidx, int* __restrict__ point_slots) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m < map_hi && pt_flag[m]) point_slots[pidx[m]] = m;
+// one workgroup: fixed poses follow the free ones in ascending keyframe number (running scan over the keyframe table)
+__global__ __launch_bounds__(1024) void k_cut_fixed_scan(int n_kf, int n_free, const int* __restrict__ fixed_flag, int* __restrict__ kf_idx, int* __restrict__ pose_kf,
+                                                         int* __restrict__ n_fixed_out) {
+    __shared__ int s_w[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int run = 0;
+    for (int k0 = 0; k0 < n_kf; k0 += 1024) {
+        const int k = k0 + threadIdx.x;
+        const bool hit = k < n_kf && fixed_flag[k];
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) s_w[wave] = __popcll(m);
+        __syncthreads();
+        int before = __popcll(m & ((1ull << lane) - 1ull)), tot = 0;
+        for (int w = 0; w < 16; ++w) { if (w < wave) before += s_w[w]; tot += s_w[w]; }
+        if (hit) { kf_idx[k] = n_free + run + before; pose_kf[n_free + run + before] = k; }
+        run += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_fixed_out = run;
 }
+// observation -> its slot in its point's edge range (arrival order; k_cut_emit sorts), and map slot -> dense point list
 __global__ void k_cut_fill(CutTabs T, const int* __restrict__ pt_flag, const int* __restrict__ pidx, const int* __restrict__ pt_start,
-                           int* __restrict__ fill, long long* __restrict__ e_obs) {
+                           int* __restrict__ fill, long long* __restrict__ e_obs, int* __restrict__ point_slots) {
     const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o < T.map_hi && pt_flag[o]) point_slots[pidx[o]] = (int)o;
     if (o >= T.n_obs || !T.alive[o]) return;
     const int k = T.obs_kf[o], m = T.obs_mp[o];
     if (k >= T.n_kf || m >= T.map_hi || !pt_flag[m]) return;
     const int p = pidx[m];
     e_obs[pt_start[p] + atomicAdd(&fill[p], 1)] = o;
 }
-__global__ void k_cut_emit(CutTabs T, int nx, const int* __restrict__ pt_start, const int* __restrict__ kf_idx, long long* __restrict__ e_obs,
-                           int32_t* __restrict__ e_pose, int32_t* __restrict__ e_pt, float* __restrict__ e_uv, int32_t* __restrict__ pt_edges) {
+// per point: its observations in ascending keyframe number become the edges; the same launch gathers poses and positions
+__global__ void k_cut_emit(CutTabs T, int np, int nx, const int* __restrict__ pt_start, const int* __restrict__ kf_idx, const int* __restrict__ pose_kf,
+                           const int* __restrict__ point_slots, long long* __restrict__ e_obs, int32_t* __restrict__ e_pose, int32_t* __restrict__ e_pt,
+                           float* __restrict__ e_uv, int32_t* __restrict__ pt_edges, uint8_t* __restrict__ active, uint8_t* __restrict__ flags,
+                           double* __restrict__ posesA, double* __restrict__ posesB, double* __restrict__ ptsA) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < np * 12) { const double v = T.kf_pose[12 * (size_t)pose_kf[p / 12] + p % 12]; posesA[p] = v; posesB[p] = v; }
+    if (p < nx * 3) ptsA[p] = T.map_pos[3 * (size_t)point_slots[p / 3] + p % 3];
     if (p >= nx) return;
     const int a = pt_start[p], b = pt_start[p + 1];
     for (int i = a + 1; i < b; ++i) {                       // insertion sort by keyframe number (a keyframe observes a point once: no ties)
@@ -1744,22 +1777,25 @@ __global__ void k_cut_emit(CutTabs T, int nx, const int* __restrict__ pt_start, 
     for (int i = a; i < b; ++i) {
         const long long o = e_obs[i];
         e_pose[i] = kf_idx[T.obs_kf[o]]; e_pt[i] = p; e_uv[2 * i] = T.obs_uv[2 * o]; e_uv[2 * i + 1] = T.obs_uv[2 * o + 1]; pt_edges[i] = i;
+        active[i] = 1; flags[i] = 0;
     }
 }
-__global__ void k_cut_gather(CutTabs T, int np, int nx, const int* __restrict__ pose_kf, const int* __restrict__ point_slots,
-                             double* __restrict__ posesA, double* __restrict__ posesB, double* __restrict__ ptsA) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < np * 12) { const double v = T.kf_pose[12 * (size_t)pose_kf[i / 12] + i % 12]; posesA[i] = v; posesB[i] = v; }
-    if (i < nx * 3) ptsA[i] = T.map_pos[3 * (size_t)point_slots[i / 3] + i % 3];
-}
-// one workgroup per free pose: count / ordered fill of its edges (ascending edge index = ascending point)
-template <bool FILL>
-__global__ __launch_bounds__(256) void k_ps_lists(int ne, const int32_t* __restrict__ e_pose, const int32_t* __restrict__ e_pt, int* __restrict__ ps_cnt,
-                                                  const int* __restrict__ ps_start, int32_t* __restrict__ ps_edges, int32_t* __restrict__ ps_pt) {
-    __shared__ int s_w[4];
+// one workgroup per free pose j: a counting pass gives its list's start (edges of poses < j) and length, a second pass fills the list
+// in ascending edge index (= ascending point)
+__global__ __launch_bounds__(256) void k_ps_lists(int ne, int nf, const int32_t* __restrict__ e_pose, const int32_t* __restrict__ e_pt, int* __restrict__ ps_start,
+                                                  int32_t* __restrict__ ps_edges, int32_t* __restrict__ ps_pt) {
+    __shared__ int s_w[4], s_lo[4];
     const int j = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int lo = 0, mine = 0;
+    for (int e = threadIdx.x; e < ne; e += 256) { const int q = e_pose[e]; lo += q < j; mine += q == j; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo += __shfl_xor(lo, o, 64); mine += __shfl_xor(mine, o, 64); }
+    if (lane == 0) { s_lo[wave] = lo; s_w[wave] = mine; }
+    __syncthreads();
+    const int base = s_lo[0] + s_lo[1] + s_lo[2] + s_lo[3], len = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    __syncthreads();
+    if (threadIdx.x == 0) { ps_start[j] = base; if (j == nf - 1) ps_start[nf] = base + len; }
     int run = 0;
-    const int base = FILL ? ps_start[j] : 0;
     for (int e0 = 0; e0 < ne; e0 += 256) {
         const int e = e0 + threadIdx.x;
         const bool hit = e < ne && e_pose[e] == j;
@@ -1768,14 +1804,10 @@ __global__ __launch_bounds__(256) void k_ps_lists(int ne, const int32_t* __restr
         __syncthreads();
         int before = __popcll(m & ((1ull << lane) - 1ull)), tot = 0;
         for (int w = 0; w < 4; ++w) { if (w < wave) before += s_w[w]; tot += s_w[w]; }
-        if (FILL && hit) { ps_edges[base + run + before] = e; ps_pt[base + run + before] = e_pt[e]; }
+        if (hit) { ps_edges[base + run + before] = e; ps_pt[base + run + before] = e_pt[e]; }
         run += tot;
         __syncthreads();
     }
-    if (!FILL && threadIdx.x == 0) ps_cnt[j] = run;
-}
-__global__ void k_ps_scan(int nf, const int* __restrict__ ps_cnt, int* __restrict__ ps_start) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) { int a = 0; for (int j = 0; j < nf; ++j) { ps_start[j] = a; a += ps_cnt[j]; } ps_start[nf] = a; }
 }
 __global__ void k_culled_list(int ne, const uint8_t* __restrict__ flags, const long long* __restrict__ e_obs, int* __restrict__ n_out, long long* __restrict__ out, int cap) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1787,8 +1819,9 @@ struct BaResident {
     int np = 0, nf = 0, nx = 0, ne = 0, n_fixed = 0, nblk_launch = 0, npairs = 0;
     BaDev B;
     int32_t* d_point_slots = nullptr; int* d_pose_kf = nullptr; long long* d_e_obs = nullptr; int* d_ncull = nullptr; long long* d_cull = nullptr; int cull_cap = 0;
+    hipEvent_t ev = nullptr;                                // recorded behind the pair-plan kernels: the engine's stream waits for it
 };
-void vo_ba_resident_free(vo_ctx* c) { delete c->resident; c->resident = nullptr; }
+void vo_ba_resident_free(vo_ctx* c) { if (c->resident && c->resident->ev) (void)hipEventDestroy(c->resident->ev); delete c->resident; c->resident = nullptr; }
 
 static int scan_i32(hipStream_t st, const int* in, int n, int* bsum, int* out, int* total) {        // n <= 1 Mi
     const int nb = (n + 1023) / 1024;
@@ -1810,12 +1843,15 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     const long long no = t->n_obs;
     if (mh >= 1024 * 1024 || nkf > 1024 * 1024) return VO_E_UNSUPPORTED;
     if ((CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D) * sizeof(double) > 158 * 1024 || nf > 64) return VO_E_UNSUPPORTED;
-    for (int i = 0; i < nf; ++i) if (free_kf[i] < 0 || free_kf[i] >= nkf) return VO_E_INVALID;
-    // ---- cut scratch: [kf_idx nkf][fixed_flag nkf][fidx nkf][pt_flag mh][pidx mh][cnt mh][fill mh][pt_start mh + 1][bsum 1024][totals 8]
+    CutFree F; F.n = nf;
+    for (int i = 0; i < nf; ++i) { if (free_kf[i] < 0 || free_kf[i] >= nkf) return VO_E_INVALID; F.kf[i] = free_kf[i]; }
+    // ---- cut scratch (lives until c's next cut: the solve reads pt_start, pose_kf and point_slots from it)
+    //      zeroed per cut: [fixed_flag nkf][pt_flag mh][cnt mh + 1][fill mh]     written by kernels: [kf_idx][pose_kf][pidx][pt_start mh + 1][point_slots][bsum][totals]
     size_t co = 0;
     auto cc = [&](size_t bytes) { size_t o = co; co += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t o_kfi = cc(4 * (size_t)nkf), o_ffl = cc(4 * (size_t)nkf), o_fid = cc(4 * (size_t)nkf), o_pfl = cc(4 * (size_t)mh), o_pid = cc(4 * (size_t)mh),
-                 o_cnt = cc(4 * (size_t)(mh + 1)), o_fil = cc(4 * (size_t)mh), o_pst = cc(4 * (size_t)(mh + 1)), o_bs = cc(4096), o_tot = cc(64);
+    const size_t o_ffl = cc(4 * (size_t)nkf), o_pfl = cc(4 * (size_t)mh), o_cnt = cc(4 * (size_t)(mh + 1)), o_fil = cc(4 * (size_t)mh), zero_end = co;
+    const size_t o_kfi = cc(4 * (size_t)nkf), o_pkf = cc(4 * (size_t)(nkf + 64)), o_pid = cc(4 * (size_t)mh), o_pst = cc(4 * (size_t)(mh + 1)), o_psl = cc(4 * (size_t)mh),
+                 o_bs = cc(4096), o_tot = cc(64);
     if (co > c->d_cut_bytes) {
         if (c->d_cut) { (void)hipStreamSynchronize(st); (void)hipFree(c->d_cut); }
         c->d_cut = nullptr; c->d_cut_bytes = 0;
@@ -1823,30 +1859,24 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
         c->d_cut_bytes = co + co / 2;
     }
     uint8_t* cb = (uint8_t*)c->d_cut;
-    int* kf_idx = (int*)(cb + o_kfi); int* fixed_flag = (int*)(cb + o_ffl); int* fidx = (int*)(cb + o_fid); int* pt_flag = (int*)(cb + o_pfl); int* pidx = (int*)(cb + o_pid);
-    int* cnt = (int*)(cb + o_cnt); int* fill = (int*)(cb + o_fil); int* pt_start_w = (int*)(cb + o_pst); int* bsum = (int*)(cb + o_bs); int* tot = (int*)(cb + o_tot);
+    int* kf_idx = (int*)(cb + o_kfi); int* fixed_flag = (int*)(cb + o_ffl); int* pose_kf = (int*)(cb + o_pkf); int* pt_flag = (int*)(cb + o_pfl); int* pidx = (int*)(cb + o_pid);
+    int* cnt = (int*)(cb + o_cnt); int* fill = (int*)(cb + o_fil); int* pt_start = (int*)(cb + o_pst); int* point_slots = (int*)(cb + o_psl); int* bsum = (int*)(cb + o_bs);
+    int* tot = (int*)(cb + o_tot);
     int* h = (int*)vo_stage(c, 4096);
     if (!h) return VO_E_NOMEM;
     HIP_TRY(hipStreamSynchronize(st));
     CutTabs T{t->d_obs_kf, t->d_obs_mp, t->d_obs_uv, t->d_obs_alive, no, t->d_map_flags, t->d_map_pos, t->d_kf_pose, nkf, mh};
-    HIP_TRY(hipMemsetAsync(kf_idx, 0xFF, 4 * (size_t)nkf, st));                // -1: not in the graph
-    HIP_TRY(hipMemsetAsync(fixed_flag, 0, 4 * (size_t)nkf, st));
-    HIP_TRY(hipMemsetAsync(pt_flag, 0, 4 * (size_t)mh, st));
-    HIP_TRY(hipMemsetAsync(cnt, 0, 4 * (size_t)(mh + 1), st));
-    HIP_TRY(hipMemsetAsync(fill, 0, 4 * (size_t)mh, st));
-    {   // free keyframes -> pose index 0 .. nf-1 (tiny upload through the pinned mailbox)
-        for (int i = 0; i < nf; ++i) h[i] = free_kf[i];
-        // scatter on the device would need a kernel; nf <= 64 four-byte copies are cheaper than that
-        for (int i = 0; i < nf; ++i) { h[64 + i] = i; HIP_TRY(hipMemcpyAsync(kf_idx + free_kf[i], h + 64 + i, 4, hipMemcpyHostToDevice, st)); }
-    }
+    HIP_TRY(hipMemsetAsync(cb, 0, zero_end, st));
+    hipLaunchKernelGGL(k_cut_init, dim3((std::max(nkf, nf) + 255) / 256), dim3(256), 0, st, nkf, F, kf_idx, pose_kf);
     const int gO = (int)((no + 255) / 256);
     if (gO) hipLaunchKernelGGL(k_cut_points, dim3(gO), dim3(256), 0, st, T, kf_idx, pt_flag);
     int rc = scan_i32(st, pt_flag, mh, bsum, pidx, tot);                        // dense point index, nx
     if (rc) return rc;
     if (gO) hipLaunchKernelGGL(k_cut_count, dim3(gO), dim3(256), 0, st, T, kf_idx, pt_flag, pidx, cnt, fixed_flag);
-    if ((rc = scan_i32(st, cnt, mh + 1, bsum, pt_start_w, tot + 1))) return rc; // pt_start[0 .. nx] over the dense indices (cnt is zero from nx on; one spare entry so that
-                                                                                // pt_start[nx] exists when every slot of the map is in the graph), ne
-    if ((rc = scan_i32(st, fixed_flag, nkf, bsum, fidx, tot + 2))) return rc;   // fixed pose numbering, n_fixed
+    // pt_start[0 .. nx] over the dense indices (cnt is zero from nx on; one spare entry so that pt_start[nx] exists when every slot of
+    // the map is in the graph), ne
+    if ((rc = scan_i32(st, cnt, mh + 1, bsum, pt_start, tot + 1))) return rc;
+    hipLaunchKernelGGL(k_cut_fixed_scan, dim3(1), dim3(1024), 0, st, nkf, nf, fixed_flag, kf_idx, pose_kf, tot + 2);
     HIP_TRY(hipMemcpyAsync(h + 128, tot, 12, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const int nx = h[128], ne = h[129], n_fixed = h[130], np = nf + n_fixed;
@@ -1857,11 +1887,10 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     const int nb_all = nf * (nf + 1) / 2;
     const size_t o_poses = carve(96 * (size_t)np), o_pts = carve(24 * (size_t)nx);
-    const size_t o_epose = carve(4 * (size_t)ne), o_ept = carve(4 * (size_t)ne), o_euv = carve(8 * (size_t)ne);
-    const size_t o_ps = carve(4 * (size_t)(nx + 1)), o_pe = carve(4 * (size_t)ne);
-    const size_t o_qs = carve(4 * (size_t)(nf + 1)), o_qe = carve(4 * (size_t)ne), o_pspt = carve(4 * (size_t)ne + 4), o_qc = carve(4 * (size_t)(nf + 1));
+    const size_t o_epose = carve(4 * (size_t)ne), o_ept = carve(4 * (size_t)ne), o_euv = carve(8 * (size_t)ne), o_pe = carve(4 * (size_t)ne);
+    const size_t o_qs = carve(4 * (size_t)(nf + 1)), o_qe = carve(4 * (size_t)ne), o_pspt = carve(4 * (size_t)ne + 4);
     const size_t o_poses_n = carve(96 * (size_t)np), o_pts_n = carve(24 * (size_t)nx), o_act = carve(ne), o_flags = carve(ne);
-    const size_t o_eobs = carve(8 * (size_t)ne), o_pslots = carve(4 * (size_t)nx), o_posekf = carve(4 * (size_t)np), o_ncull = carve(64), o_cull = carve(8 * (size_t)ne);
+    const size_t o_eobs = carve(8 * (size_t)ne), o_ncull = carve(64), o_cull = carve(8 * (size_t)ne);
     const size_t o_pcnt = carve(4 * (size_t)std::max(nb_all, 1)), o_poff = carve(4 * (size_t)std::max(nb_all, 1)), o_pn = carve(16);
     const size_t o_Hpp = carve(288 * (size_t)nf), o_bp = carve(8 * (size_t)D), o_Hll = carve(72 * (size_t)nx), o_bl = carve(24 * (size_t)nx), o_scal = carve(64);
     const size_t o_partU = carve(16 * ((size_t)(nx + 63) / 64 + 1)), o_partC = carve(8 * ((size_t)(ne + 255) / 256 + 1));
@@ -1873,18 +1902,11 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     if ((rc = vo_scratch(c, off))) return rc;               // may reallocate: nothing of this problem lives in the slab yet
     uint8_t* base = (uint8_t*)c->d_ba;
     int32_t* e_pose = (int32_t*)(base + o_epose); int32_t* e_pt = (int32_t*)(base + o_ept); float* e_uv = (float*)(base + o_euv);
-    long long* e_obs = (long long*)(base + o_eobs); int* pose_kf = (int*)(base + o_posekf); int* point_slots = (int*)(base + o_pslots);
-    HIP_TRY(hipMemcpyAsync(base + o_ps, pt_start_w, 4 * (size_t)(nx + 1), hipMemcpyDeviceToDevice, st));
-    { for (int i = 0; i < nf; ++i) h[i] = free_kf[i]; HIP_TRY(hipMemcpyAsync(pose_kf, h, 4 * (size_t)nf, hipMemcpyHostToDevice, st)); }
-    hipLaunchKernelGGL(k_cut_fixed, dim3((nkf + 255) / 256), dim3(256), 0, st, nkf, nf, fixed_flag, fidx, kf_idx, pose_kf);
-    hipLaunchKernelGGL(k_cut_pointlist, dim3((mh + 255) / 256), dim3(256), 0, st, mh, pt_flag, pidx, point_slots);
-    hipLaunchKernelGGL(k_cut_fill, dim3(gO), dim3(256), 0, st, T, pt_flag, pidx, (const int*)(base + o_ps), fill, e_obs);
-    hipLaunchKernelGGL(k_cut_emit, dim3((nx + 255) / 256), dim3(256), 0, st, T, nx, (const int*)(base + o_ps), kf_idx, e_obs, e_pose, e_pt, e_uv, (int32_t*)(base + o_pe));
-    hipLaunchKernelGGL(k_cut_gather, dim3((std::max(np * 12, nx * 3) + 255) / 256), dim3(256), 0, st, T, np, nx, pose_kf, point_slots,
-                       (double*)(base + o_poses), (double*)(base + o_poses_n), (double*)(base + o_pts));
-    hipLaunchKernelGGL(k_ps_lists<false>, dim3(nf), dim3(256), 0, st, ne, e_pose, e_pt, (int*)(base + o_qc), nullptr, nullptr, nullptr);
-    hipLaunchKernelGGL(k_ps_scan, dim3(1), dim3(64), 0, st, nf, (const int*)(base + o_qc), (int*)(base + o_qs));
-    hipLaunchKernelGGL(k_ps_lists<true>, dim3(nf), dim3(256), 0, st, ne, e_pose, e_pt, nullptr, (const int*)(base + o_qs), (int32_t*)(base + o_qe), (int32_t*)(base + o_pspt));
+    long long* e_obs = (long long*)(base + o_eobs);
+    hipLaunchKernelGGL(k_cut_fill, dim3((int)((std::max<long long>(no, mh) + 255) / 256)), dim3(256), 0, st, T, pt_flag, pidx, pt_start, fill, e_obs, point_slots);
+    hipLaunchKernelGGL(k_cut_emit, dim3((std::max(np * 12, nx * 3) + 255) / 256), dim3(256), 0, st, T, np, nx, pt_start, kf_idx, pose_kf, point_slots, e_obs, e_pose, e_pt,
+                       e_uv, (int32_t*)(base + o_pe), base + o_act, base + o_flags, (double*)(base + o_poses), (double*)(base + o_poses_n), (double*)(base + o_pts));
+    hipLaunchKernelGGL(k_ps_lists, dim3(nf), dim3(256), 0, st, ne, nf, e_pose, e_pt, (int*)(base + o_qs), (int32_t*)(base + o_qe), (int32_t*)(base + o_pspt));
     HIP_TRY(hipMemcpyAsync(h + 256, base + o_qs, 4 * (size_t)(nf + 1), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));                      // from here on `t` may change: every input has been gathered
     const int* ps_start = h + 256;
@@ -1897,14 +1919,15 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     }
     if ((size_t)npairs > pairs_ub || (size_t)slices_ub > slices_cap) return VO_E_OVERFLOW;
     BaDev B;
-    B.n_poses = np; B.n_free = nf; B.n_points = nx; B.n_edges = ne; B.D = D; B.n_blocks = slices_ub;
+    B.n_poses = np; B.n_free = nf; B.n_points = nx; B.n_edges = ne; B.D = D;
+    B.n_blocks = slices_ub;                                 // launch bound; the Schur kernel stops at *n_slices, which the plan kernels below write
     B.n_slices = (const int*)(base + o_pn);
     B.ps_start = (const int32_t*)(base + o_qs); B.ps_edges = (const int32_t*)(base + o_qe); B.blocks = (const BaBlock*)(base + o_blk); B.pairs = (const int2*)(base + o_pairs);
     B.posesA = (double*)(base + o_poses); B.ptsA = (double*)(base + o_pts); B.posesB = (double*)(base + o_poses_n); B.ptsB = (double*)(base + o_pts_n);
     B.ctl = nullptr;
     B.partU = (double*)(base + o_partU); B.partC = (double*)(base + o_partC); B.nU = (nx + 63) / 64;
     B.e_pose = e_pose; B.e_pt = e_pt; B.e_uv = e_uv;
-    B.active = base + o_act; B.flags = base + o_flags; B.pt_start = (const int32_t*)(base + o_ps); B.pt_edges = (const int32_t*)(base + o_pe);
+    B.active = base + o_act; B.flags = base + o_flags; B.pt_start = (const int32_t*)pt_start; B.pt_edges = (const int32_t*)(base + o_pe);
     B.Hpp = (double*)(base + o_Hpp); B.bp = (double*)(base + o_bp); B.Hll = (double*)(base + o_Hll); B.bl = (double*)(base + o_bl); B.scal = (double*)(base + o_scal);
     B.W = (double*)(base + o_W); B.S = (double*)(base + o_S); B.bs = (double*)(base + o_bs2); B.Hinv = (double*)(base + o_Hinv); B.dl = (double*)(base + o_dl);
     B.cam = BaCam{(double)c->p.fx, (double)c->p.fy, (double)c->p.cx, (double)c->p.cy};
@@ -1915,15 +1938,12 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     Q.blocks = (BaBlock*)(base + o_blk); Q.pairs = (int2*)(base + o_pairs);
     hipLaunchKernelGGL(k_ba_pairs<false>, dim3(nb_all), dim3(256), 4 * (size_t)std::max(max_len, 1), st, Q);
     hipLaunchKernelGGL(k_ba_pairs_scan, dim3(1), dim3(1024), 0, st, Q, nb_all);
-    hipLaunchKernelGGL(k_ba_pairs<true>, dim3(nb_all), dim3(256), 4 * (size_t)std::max(max_len, 1), st, Q);
-    h[0] = 0; h[1] = 0;
-    HIP_TRY(hipMemcpyAsync(h, base + o_pn, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemsetAsync(base + o_act, 1, ne, st));
-    HIP_TRY(hipMemsetAsync(base + o_flags, 0, ne, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    hipLaunchKernelGGL(k_ba_pairs<true>, dim3(nb_all), dim3(256), 4 * (size_t)std::max(max_len, 1), st, Q);   // no wait: the solve follows on the same stream
+    if (!R.ev) HIP_TRY(hipEventCreateWithFlags(&R.ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(R.ev, st));
     HIP_TRY(hipGetLastError());
-    R.nblk_launch = std::min(slices_ub, h[0]); R.npairs = h[1];
-    R.B = B; R.B.n_blocks = R.nblk_launch;
+    R.nblk_launch = slices_ub; R.npairs = npairs;
+    R.B = B;
     R.d_point_slots = point_slots; R.d_pose_kf = pose_kf; R.d_e_obs = e_obs; R.d_ncull = (int*)(base + o_ncull); R.d_cull = (long long*)(base + o_cull); R.cull_cap = ne;
     R.ready = true;
     return VO_OK;
@@ -1952,7 +1972,7 @@ extern "C" int vo_local_ba_resident_solve(vo_ctx* c, int it_robust, int it_plain
     memset(&pr, 0, sizeof(pr));
     pr.n_poses = np; pr.n_free = nf; pr.n_points = nx; pr.n_edges = ne; pr.huber_delta = R.B.delta; pr.chi2_th = R.B.chi2_th; pr.it_robust = it_robust; pr.it_plain = it_plain;
     BaJob job;
-    job.c = c; job.in = &pr; job.out = nullptr; job.B = R.B;
+    job.c = c; job.in = &pr; job.out = nullptr; job.B = R.B; job.wait_ev = R.ev;
     job.grid_lin = (nx + 63) / 64 + nf * PSPLIT; job.grid_initS = (std::max(D * D, nx) + 255) / 256; job.grid_upd = (nx + 63) / 64 + (np + 255) / 256;
     job.grid_e = (ne + 255) / 256; job.grid_c = (ne + 1023) / 1024; job.grid_maxdiag = (D + 3 * nx + 255) / 256;
     job.lds = D <= 192 ? sizeof(double) * (CH_NB * CH_NB + (size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D)
@@ -1993,6 +2013,7 @@ extern "C" int vo_ba_resident_graph(vo_ctx* c, vo_ctx* t, const int32_t* free_kf
     int rc = vo_local_ba_resident_cut(c, t, free_kf, n_free, 1.0, 1.0, nullptr, nullptr, nullptr);
     if (rc) return rc;
     BaResident& R = *c->resident;
+    HIP_TRY(hipStreamSynchronize(c->stream));               // the cut leaves its last kernels in flight
     *n_poses = R.np; *n_points = R.nx; *n_edges = R.ne;
     R.ready = false;
     if (R.nx == 0 || R.ne == 0) return VO_OK;
