@@ -1211,6 +1211,7 @@ int vo_ba_set_attrs() {
 // HIP streams with ~120 tiny dependent launches each mostly serialise in the command processor.
 #include <condition_variable>
 #include <deque>
+static double tnow() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 struct BaJob {
     vo_ctx* c = nullptr; const vo_ba_problem* in = nullptr; vo_ba_result* out = nullptr;
     BaDev B;
@@ -1220,6 +1221,7 @@ struct BaJob {
     int rc = VO_OK; bool done = false;
     hipEvent_t wait_ev = nullptr;                           // the problem's arrays are complete once this event (recorded on the owner's stream) has passed
 };
+#define BA_MAX_ENGINES 4
 struct BaEngine {
     int device = 0, refs = 0;
     hipStream_t st = nullptr;
@@ -1233,7 +1235,9 @@ struct BaEngine {
     bool driving = false;                                   // a caller is inside ba_engine_pump
     long long n_steps = 0, n_slot_steps = 0, n_jobs = 0;
     int pending_hint = 0;                                   // queue length seen by the last admission (chunk size policy)
+    BaEngine* sib[BA_MAX_ENGINES] = {}; int n_sib = 1, rr = 0;   // engine 0 of a device: its engines (sib[0] = itself) and the rotation
 };
+static void ba_engine_free(BaEngine* E);
 static std::mutex g_eng_mu;
 static std::vector<BaEngine*> g_engines;
 
@@ -1380,9 +1384,7 @@ static int ba_engine_solve(BaEngine* E, BaJob* j) {
 }
 
 // engines are shared by the contexts of a device: the first context creates the engine, the last one ends it
-BaEngine* vo_ba_engine_acquire(int device) {
-    std::unique_lock<std::mutex> lk(g_eng_mu);
-    for (BaEngine* E : g_engines) if (E->device == device) { ++E->refs; return E; }
+static BaEngine* ba_engine_new(int device) {
     BaEngine* E = new BaEngine();
     E->device = device; E->refs = 1;
     int lo = 0, hi = 0;
@@ -1398,20 +1400,38 @@ BaEngine* vo_ba_engine_acquire(int device) {
         for (int s = 0; s < BA_SLOTS; ++s) E->h_ctl[s].finished = 1;
         ok = hipMemcpy(E->d_ctl, E->h_ctl, sizeof(BaCtl) * BA_SLOTS, hipMemcpyHostToDevice) == hipSuccess;
     }
-    if (!ok) { fprintf(stderr, "[vo_hip] BA engine: allocation failed on device %d\n", device); delete E; return nullptr; }
+    if (!ok) { fprintf(stderr, "[vo_hip] BA engine: allocation failed on device %d\n", device); ba_engine_free(E); return nullptr; }
+    return E;
+}
+
+// The engines of a device: the first context creates engine 0, the last one ends them all.  A device may run several engines
+// (VO_BA_ENGINES, default 2): while one engine's dense solves keep a handful of compute units busy, the other's Schur kernel
+// fills the rest of the chip.  A context is bound to one of them by its first solve (ba_engine_of), so contexts that never
+// run a local BA -- the trackers of an overlapped back-end -- do not take part in the rotation.
+BaEngine* vo_ba_engine_acquire(int device) {
+    std::unique_lock<std::mutex> lk(g_eng_mu);
+    for (BaEngine* E : g_engines) if (E->device == device) { ++E->refs; return E; }
+    BaEngine* E = ba_engine_new(device);
+    if (!E) return nullptr;
+    const char* env = getenv("VO_BA_ENGINES");
+    E->n_sib = std::max(1, std::min(BA_MAX_ENGINES, env ? atoi(env) : 2));
+    E->sib[0] = E;
     g_engines.push_back(E);
     return E;
 }
 
-void vo_ba_engine_release(BaEngine* E) {
-    if (!E) return;
-    {
-        std::unique_lock<std::mutex> lk(g_eng_mu);
-        if (--E->refs > 0) return;
-        for (size_t i = 0; i < g_engines.size(); ++i) if (g_engines[i] == E) { g_engines.erase(g_engines.begin() + i); break; }
-    }
-    (void)hipSetDevice(E->device);
-    if (getenv("VO_TRACE")) fprintf(stderr, "[vo_trace] BA engine: %lld problems, %lld step launches, %.2f problems per step launch\n", E->n_jobs, E->n_steps, E->n_steps ? (double)E->n_slot_steps / E->n_steps : 0.0);
+static BaEngine* ba_engine_of(vo_ctx* c) {
+    if (c->ba_engine_sel) return c->ba_engine_sel;
+    BaEngine* base = c->ba_engine;
+    if (!base) return nullptr;
+    std::unique_lock<std::mutex> lk(g_eng_mu);
+    const int k = base->rr++ % base->n_sib;
+    if (!base->sib[k] && !(base->sib[k] = ba_engine_new(base->device))) return nullptr;
+    return c->ba_engine_sel = base->sib[k];
+}
+
+static void ba_engine_free(BaEngine* E) {
+    if (getenv("VO_TRACE") && E->n_jobs) fprintf(stderr, "[vo_trace] BA engine: %lld problems, %lld step launches, %.2f problems per step launch\n", E->n_jobs, E->n_steps, E->n_steps ? (double)E->n_slot_steps / E->n_steps : 0.0);
     if (E->st) { (void)hipStreamSynchronize(E->st); (void)hipStreamDestroy(E->st); }
     if (E->d_Bs) (void)hipFree(E->d_Bs);
     if (E->d_ctl) (void)hipFree(E->d_ctl);
@@ -1422,9 +1442,20 @@ void vo_ba_engine_release(BaEngine* E) {
     delete E;
 }
 
+void vo_ba_engine_release(BaEngine* E) {
+    if (!E) return;
+    {
+        std::unique_lock<std::mutex> lk(g_eng_mu);
+        if (--E->refs > 0) return;
+        for (size_t i = 0; i < g_engines.size(); ++i) if (g_engines[i] == E) { g_engines.erase(g_engines.begin() + i); break; }
+    }
+    (void)hipSetDevice(E->device);
+    for (int k = E->n_sib - 1; k >= 0; --k) if (E->sib[k]) ba_engine_free(E->sib[k]);      // sib[0] is E itself
+}
+
 int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     hipStream_t st = c->stream;
-    BaEngine* E = c->ba_engine;
+    BaEngine* E = ba_engine_of(c);
     if (!E) return VO_E_STATE;
     const int np = in->n_poses, nf = in->n_free, nx = in->n_points, ne = in->n_edges, D = 6 * nf;
     if ((CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D) * sizeof(double) > 158 * 1024) return VO_E_UNSUPPORTED;     // D > ~1060 (176 free poses)
@@ -1436,7 +1467,6 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
         return VO_OK;
     }
     const bool trace = getenv("VO_TRACE") != nullptr;
-    auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     HIP_TRY(hipStreamSynchronize(st));                      // the pinned staging buffer may still feed an earlier vo_map_upsert
     const double tt0 = tnow();
     // CSR point -> edges and free pose -> edges: ONE counting pass here (the scratch vectors live in the context: no
@@ -1656,11 +1686,11 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
 //   k_cut_count       observation-parallel: edges per point (one atomic per observation, ~3 per address); flag the fixed keyframes
 //   k_cut_fixed_scan  one workgroup: numbers the fixed keyframes behind the free ones
 //   k_cut_fill        observation-parallel: observation ids into their point's segment (arrival order); map slot -> point list
-//   k_cut_emit        point-parallel: order each segment by keyframe number (what the host's graph cut emits: observation lists
-//                     are in keyframe order), then edge_pose / edge_point / edge_uv / pt_edges; the same launch gathers poses
-//                     from the keyframe table and positions from the map
-//   k_ps_lists        per free pose: its edges in ascending edge order (ordered ballot compaction)
-// 14 launches, one memset, two small read-backs (sizes; per-pose list lengths). The pair plan (k_ba_pairs*) is queued behind
+//   k_cut_emit        edge-parallel: an observation's place in its point's segment is its rank by keyframe number (what the host's
+//                     graph cut emits: observation lists are in keyframe order), then edge_pose / edge_point / edge_uv / pt_edges;
+//                     the same launch gathers poses from the keyframe table and positions from the map
+//   k_ps_hist / k_ps_offsets / k_ps_fill   per free pose: its edges in ascending edge order (stable counting sort by pose)
+// 16 launches, one memset, two small read-backs (sizes; per-pose list lengths). The pair plan (k_ba_pairs*) is queued behind
 // them and an event hands the finished arrays to the engine's stream.
 // Point order = ascending map slot, fixed poses = ascending keyframe number: deterministic, and the same as oracle/o_capi.cpp.
 // =====================================================================================================================
@@ -1757,57 +1787,89 @@ __global__ void k_cut_fill(CutTabs T, const int* __restrict__ pt_flag, const int
     const int p = pidx[m];
     e_obs[pt_start[p] + atomicAdd(&fill[p], 1)] = o;
 }
-// per point: its observations in ascending keyframe number become the edges; the same launch gathers poses and positions
-__global__ void k_cut_emit(CutTabs T, int np, int nx, const int* __restrict__ pt_start, const int* __restrict__ kf_idx, const int* __restrict__ pose_kf,
-                           const int* __restrict__ point_slots, long long* __restrict__ e_obs, int32_t* __restrict__ e_pose, int32_t* __restrict__ e_pt,
-                           float* __restrict__ e_uv, int32_t* __restrict__ pt_edges, uint8_t* __restrict__ active, uint8_t* __restrict__ flags,
-                           double* __restrict__ posesA, double* __restrict__ posesB, double* __restrict__ ptsA) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < np * 12) { const double v = T.kf_pose[12 * (size_t)pose_kf[p / 12] + p % 12]; posesA[p] = v; posesB[p] = v; }
-    if (p < nx * 3) ptsA[p] = T.map_pos[3 * (size_t)point_slots[p / 3] + p % 3];
-    if (p >= nx) return;
+// edge-parallel: slot i of its point's segment holds some observation (arrival order); its place among the point's edges is its
+// rank by keyframe number (a keyframe observes a point once: no ties).  The same launch gathers poses and positions.
+__global__ void k_cut_emit(CutTabs T, int np, int nx, int ne, const int* __restrict__ pidx, const int* __restrict__ pt_start, const int* __restrict__ kf_idx,
+                           const int* __restrict__ pose_kf, const int* __restrict__ point_slots, const long long* __restrict__ e_arr, long long* __restrict__ e_obs,
+                           int32_t* __restrict__ e_pose, int32_t* __restrict__ e_pt, float* __restrict__ e_uv, int32_t* __restrict__ pt_edges, uint8_t* __restrict__ active,
+                           uint8_t* __restrict__ flags, double* __restrict__ posesA, double* __restrict__ posesB, double* __restrict__ ptsA) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < np * 12) { const double v = T.kf_pose[12 * (size_t)pose_kf[i / 12] + i % 12]; posesA[i] = v; posesB[i] = v; }
+    if (i < nx * 3) ptsA[i] = T.map_pos[3 * (size_t)point_slots[i / 3] + i % 3];
+    if (i >= ne) return;
+    const long long o = e_arr[i];
+    const int ko = T.obs_kf[o], p = pidx[T.obs_mp[o]];
     const int a = pt_start[p], b = pt_start[p + 1];
-    for (int i = a + 1; i < b; ++i) {                       // insertion sort by keyframe number (a keyframe observes a point once: no ties)
-        const long long o = e_obs[i];
-        const int ko = T.obs_kf[o];
-        int j = i - 1;
-        while (j >= a && T.obs_kf[e_obs[j]] > ko) { e_obs[j + 1] = e_obs[j]; --j; }
-        e_obs[j + 1] = o;
-    }
-    for (int i = a; i < b; ++i) {
-        const long long o = e_obs[i];
-        e_pose[i] = kf_idx[T.obs_kf[o]]; e_pt[i] = p; e_uv[2 * i] = T.obs_uv[2 * o]; e_uv[2 * i + 1] = T.obs_uv[2 * o + 1]; pt_edges[i] = i;
-        active[i] = 1; flags[i] = 0;
-    }
+    int rank = 0;
+    for (int j = a; j < b; ++j) rank += T.obs_kf[e_arr[j]] < ko;
+    const int d = a + rank;
+    e_obs[d] = o; e_pose[d] = kf_idx[ko]; e_pt[d] = p; e_uv[2 * d] = T.obs_uv[2 * o]; e_uv[2 * d + 1] = T.obs_uv[2 * o + 1]; pt_edges[d] = d;
+    active[d] = 1; flags[d] = 0;
 }
-// one workgroup per free pose j: a counting pass gives its list's start (edges of poses < j) and length, a second pass fills the list
-// in ascending edge index (= ascending point)
-__global__ __launch_bounds__(256) void k_ps_lists(int ne, int nf, const int32_t* __restrict__ e_pose, const int32_t* __restrict__ e_pt, int* __restrict__ ps_start,
-                                                  int32_t* __restrict__ ps_edges, int32_t* __restrict__ ps_pt) {
-    __shared__ int s_w[4], s_lo[4];
+// per-pose edge lists (free poses only) in ascending edge index = ascending point: a stable counting sort by pose over chunks
+// of 1024 edges.  k_ps_hist: per-chunk counts; k_ps_offsets: one workgroup per pose scans its counts over the chunks;
+// k_ps_fill: recomputes the in-chunk ranks (ballot per pose) and writes the lists.
+#define PS_CHUNK 1024
+__device__ __forceinline__ int ps_wave_rank(int bin, int nf, int lane, int* __restrict__ wave_cnt /* [nf] of this wave, or nullptr */) {
+    int rank = 0;
+    for (int j = 0; j < nf; ++j) {
+        const unsigned long long m = __ballot(bin == j);
+        if (bin == j) rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (wave_cnt && lane == 0) wave_cnt[j] = __popcll(m);
+    }
+    return rank;
+}
+__global__ __launch_bounds__(PS_CHUNK) void k_ps_hist(int ne, int nf, const int32_t* __restrict__ e_pose, int* __restrict__ hist /* [chunks][nf] */) {
+    __shared__ int s_cnt[PS_CHUNK / 64][64];
+    const int e = blockIdx.x * PS_CHUNK + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = e < ne ? e_pose[e] : nf;
+    (void)ps_wave_rank(q < nf ? q : -1, nf, lane, s_cnt[wave]);
+    __syncthreads();
+    if ((int)threadIdx.x < nf) { int t = 0; for (int w = 0; w < PS_CHUNK / 64; ++w) t += s_cnt[w][threadIdx.x]; hist[blockIdx.x * nf + threadIdx.x] = t; }
+}
+__global__ __launch_bounds__(256) void k_ps_offsets(int chunks, int nf, const int* __restrict__ hist, int* __restrict__ offs /* [chunks][nf] */, int* __restrict__ total /* [nf] */) {
+    __shared__ int s_w[4];
     const int j = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int lo = 0, mine = 0;
-    for (int e = threadIdx.x; e < ne; e += 256) { const int q = e_pose[e]; lo += q < j; mine += q == j; }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { lo += __shfl_xor(lo, o, 64); mine += __shfl_xor(mine, o, 64); }
-    if (lane == 0) { s_lo[wave] = lo; s_w[wave] = mine; }
-    __syncthreads();
-    const int base = s_lo[0] + s_lo[1] + s_lo[2] + s_lo[3], len = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-    __syncthreads();
-    if (threadIdx.x == 0) { ps_start[j] = base; if (j == nf - 1) ps_start[nf] = base + len; }
     int run = 0;
-    for (int e0 = 0; e0 < ne; e0 += 256) {
-        const int e = e0 + threadIdx.x;
-        const bool hit = e < ne && e_pose[e] == j;
-        const unsigned long long m = __ballot(hit);
-        if (lane == 0) s_w[wave] = __popcll(m);
+    for (int g0 = 0; g0 < chunks; g0 += 256) {
+        const int g = g0 + threadIdx.x;
+        const int v = g < chunks ? hist[g * nf + j] : 0;
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if (lane == 63) s_w[wave] = inc;
         __syncthreads();
-        int before = __popcll(m & ((1ull << lane) - 1ull)), tot = 0;
+        int before = 0, tot = 0;
         for (int w = 0; w < 4; ++w) { if (w < wave) before += s_w[w]; tot += s_w[w]; }
-        if (hit) { ps_edges[base + run + before] = e; ps_pt[base + run + before] = e_pt[e]; }
+        if (g < chunks) offs[g * nf + j] = run + before + inc - v;
         run += tot;
         __syncthreads();
     }
+    if (threadIdx.x == 0) total[j] = run;
+}
+__global__ __launch_bounds__(PS_CHUNK) void k_ps_fill(int ne, int nf, const int32_t* __restrict__ e_pose, const int32_t* __restrict__ e_pt, const int* __restrict__ offs,
+                                                      const int* __restrict__ total, int* __restrict__ ps_start, int32_t* __restrict__ ps_edges, int32_t* __restrict__ ps_pt) {
+    __shared__ int s_cnt[PS_CHUNK / 64][64];
+    __shared__ int s_base[65];
+    const int e = blockIdx.x * PS_CHUNK + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 0) {                                        // start of each pose's list: exclusive scan of the totals (nf <= 64)
+        const int v = lane < nf ? total[lane] : 0;
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        s_base[lane] = inc - v;
+        if (lane == 63) s_base[64] = inc;
+    }
+    const int q = e < ne ? e_pose[e] : nf;
+    const int bin = q < nf ? q : -1;
+    const int rank = ps_wave_rank(bin, nf, lane, s_cnt[wave]);
+    __syncthreads();
+    if (blockIdx.x == 0 && (int)threadIdx.x <= nf) ps_start[threadIdx.x] = threadIdx.x < (unsigned)nf ? s_base[threadIdx.x] : s_base[64];
+    if (bin < 0) return;
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += s_cnt[w][bin];
+    const int pos = s_base[bin] + offs[blockIdx.x * nf + bin] + before + rank;
+    ps_edges[pos] = e; ps_pt[pos] = e_pt[e];
 }
 __global__ void k_culled_list(int ne, const uint8_t* __restrict__ flags, const long long* __restrict__ e_obs, int* __restrict__ n_out, long long* __restrict__ out, int cap) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1890,7 +1952,9 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     const size_t o_epose = carve(4 * (size_t)ne), o_ept = carve(4 * (size_t)ne), o_euv = carve(8 * (size_t)ne), o_pe = carve(4 * (size_t)ne);
     const size_t o_qs = carve(4 * (size_t)(nf + 1)), o_qe = carve(4 * (size_t)ne), o_pspt = carve(4 * (size_t)ne + 4);
     const size_t o_poses_n = carve(96 * (size_t)np), o_pts_n = carve(24 * (size_t)nx), o_act = carve(ne), o_flags = carve(ne);
-    const size_t o_eobs = carve(8 * (size_t)ne), o_ncull = carve(64), o_cull = carve(8 * (size_t)ne);
+    const int chunks = (ne + PS_CHUNK - 1) / PS_CHUNK;
+    const size_t o_eobs = carve(8 * (size_t)ne), o_earr = carve(8 * (size_t)ne), o_ncull = carve(64), o_cull = carve(8 * (size_t)ne);
+    const size_t o_hist = carve(4 * (size_t)chunks * nf), o_offs = carve(4 * (size_t)chunks * nf), o_ptot = carve(4 * 64);
     const size_t o_pcnt = carve(4 * (size_t)std::max(nb_all, 1)), o_poff = carve(4 * (size_t)std::max(nb_all, 1)), o_pn = carve(16);
     const size_t o_Hpp = carve(288 * (size_t)nf), o_bp = carve(8 * (size_t)D), o_Hll = carve(72 * (size_t)nx), o_bl = carve(24 * (size_t)nx), o_scal = carve(64);
     const size_t o_partU = carve(16 * ((size_t)(nx + 63) / 64 + 1)), o_partC = carve(8 * ((size_t)(ne + 255) / 256 + 1));
@@ -1903,10 +1967,15 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     uint8_t* base = (uint8_t*)c->d_ba;
     int32_t* e_pose = (int32_t*)(base + o_epose); int32_t* e_pt = (int32_t*)(base + o_ept); float* e_uv = (float*)(base + o_euv);
     long long* e_obs = (long long*)(base + o_eobs);
-    hipLaunchKernelGGL(k_cut_fill, dim3((int)((std::max<long long>(no, mh) + 255) / 256)), dim3(256), 0, st, T, pt_flag, pidx, pt_start, fill, e_obs, point_slots);
-    hipLaunchKernelGGL(k_cut_emit, dim3((std::max(np * 12, nx * 3) + 255) / 256), dim3(256), 0, st, T, np, nx, pt_start, kf_idx, pose_kf, point_slots, e_obs, e_pose, e_pt,
-                       e_uv, (int32_t*)(base + o_pe), base + o_act, base + o_flags, (double*)(base + o_poses), (double*)(base + o_poses_n), (double*)(base + o_pts));
-    hipLaunchKernelGGL(k_ps_lists, dim3(nf), dim3(256), 0, st, ne, nf, e_pose, e_pt, (int*)(base + o_qs), (int32_t*)(base + o_qe), (int32_t*)(base + o_pspt));
+    long long* e_arr = (long long*)(base + o_earr);
+    hipLaunchKernelGGL(k_cut_fill, dim3((int)((std::max<long long>(no, mh) + 255) / 256)), dim3(256), 0, st, T, pt_flag, pidx, pt_start, fill, e_arr, point_slots);
+    hipLaunchKernelGGL(k_cut_emit, dim3((std::max(ne, std::max(np * 12, nx * 3)) + 255) / 256), dim3(256), 0, st, T, np, nx, ne, pidx, pt_start, kf_idx, pose_kf, point_slots,
+                       (const long long*)e_arr, e_obs, e_pose, e_pt, e_uv, (int32_t*)(base + o_pe), base + o_act, base + o_flags, (double*)(base + o_poses),
+                       (double*)(base + o_poses_n), (double*)(base + o_pts));
+    hipLaunchKernelGGL(k_ps_hist, dim3(chunks), dim3(PS_CHUNK), 0, st, ne, nf, e_pose, (int*)(base + o_hist));
+    hipLaunchKernelGGL(k_ps_offsets, dim3(nf), dim3(256), 0, st, chunks, nf, (const int*)(base + o_hist), (int*)(base + o_offs), (int*)(base + o_ptot));
+    hipLaunchKernelGGL(k_ps_fill, dim3(chunks), dim3(PS_CHUNK), 0, st, ne, nf, e_pose, e_pt, (const int*)(base + o_offs), (const int*)(base + o_ptot), (int*)(base + o_qs),
+                       (int32_t*)(base + o_qe), (int32_t*)(base + o_pspt));
     HIP_TRY(hipMemcpyAsync(h + 256, base + o_qs, 4 * (size_t)(nf + 1), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));                      // from here on `t` may change: every input has been gathered
     const int* ps_start = h + 256;
@@ -1953,7 +2022,10 @@ extern "C" int vo_local_ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* fre
                                         int32_t* n_points, int32_t* n_fixed, int32_t* n_edges) {
     if (!c || !t || n_free < 0 || (n_free && !free_kf) || c->device != t->device) return VO_E_INVALID;
     HIP_TRY(hipSetDevice(c->device));
+    const bool trace = getenv("VO_TRACE") != nullptr;
+    const double t0 = trace ? tnow() : 0.0;
     const int rc = ba_resident_cut(c, t, free_kf, n_free, huber_delta, chi2_th);
+    if (trace) { static double a = 0; static int n = 0; a += tnow() - t0; if (++n % 10 == 0) fprintf(stderr, "[vo_trace] resident cut avg ms: %.3f\n", a / n); }
     if (rc == VO_OK && c->resident) { if (n_points) *n_points = c->resident->nx; if (n_fixed) *n_fixed = c->resident->n_fixed; if (n_edges) *n_edges = c->resident->ne; }
     return rc;
 }
@@ -1977,8 +2049,13 @@ extern "C" int vo_local_ba_resident_solve(vo_ctx* c, int it_robust, int it_plain
     job.grid_e = (ne + 255) / 256; job.grid_c = (ne + 1023) / 1024; job.grid_maxdiag = (D + 3 * nx + 255) / 256;
     job.lds = D <= 192 ? sizeof(double) * (CH_NB * CH_NB + (size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D)
                        : sizeof(double) * (CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D);
-    int rc = ba_engine_solve(c->ba_engine, &job);
+    const bool trace = getenv("VO_TRACE") != nullptr;
+    const double t0 = trace ? tnow() : 0.0;
+    BaEngine* E = ba_engine_of(c);
+    if (!E) return VO_E_STATE;
+    int rc = ba_engine_solve(E, &job);
     if (rc) return rc;
+    const double t1 = trace ? tnow() : 0.0;
     const BaDev& B = R.B;
     int* h = (int*)vo_stage(c, 4096);
     if (!h) return VO_E_NOMEM;
@@ -1997,6 +2074,7 @@ extern "C" int vo_local_ba_resident_solve(vo_ctx* c, int it_robust, int it_plain
     }
     out->chi2_initial = job.chi0; out->chi2_final = job.chi_final; out->lm_iters = job.iters;
     HIP_TRY(hipGetLastError());
+    if (trace) { static double a = 0, b = 0, st = 0; static int n = 0; a += t1 - t0; b += tnow() - t1; st += job.steps; if (++n % 10 == 0) fprintf(stderr, "[vo_trace] resident solve avg ms: optimise %.3f (%.1f step launches) result %.3f (D=%d edges=%d)\n", a / n, st / n, b / n, D, ne); }
     return out->n_culled > out->cap_culled ? VO_E_OVERFLOW : VO_OK;
 }
 

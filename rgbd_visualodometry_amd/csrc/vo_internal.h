@@ -113,7 +113,7 @@ struct vo_ctx {
     uint8_t* h_orb_cache; bool orb_cache_valid; int orb_batch0, orb_batchn;   // pinned copy of the last ORB batch's results
     bool corr_external;
     // BA scratch; the device's BA engine (shared by the contexts of that device, vo_ba.hip)
-    void* d_ba; size_t d_ba_bytes; struct BaEngine* ba_engine = nullptr;
+    void* d_ba; size_t d_ba_bytes; struct BaEngine* ba_engine = nullptr; struct BaEngine* ba_engine_sel = nullptr;
     void* h_ba_up = nullptr; size_t h_ba_up_bytes = 0;      // pinned mirror of a BA problem's upload region
     std::vector<int32_t> ba_pt_start, ba_ps_start, ba_cursor;      // host scratch of vo_ba_run (kept between problems)
     // device-resident keyframe bookkeeping: observation table and keyframe poses, fixed capacity (a back-end
