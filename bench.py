@@ -277,7 +277,8 @@ def main():
 
             def run_streams(S, grouped):
                 grp_ = system.StreamGroup(system.HOST_LIB, local_rank, 128) if grouped else None
-                syss = [system.VoSystem(system.HOST_LIB, **opts) for _ in range(S)]
+                # the GPU is the shared resource here and host cores are idle: the local BA's graph is cut on the host
+                syss = [system.VoSystem(system.HOST_LIB, **{**opts, "ba_device_graph": 0}) for _ in range(S)]
                 if grp_:
                     for s in syss:
                         grp_.join(s)
@@ -313,7 +314,7 @@ def main():
                               "vs_single_stream": round(f_g / fps, 2), "lanes_per_launch_chain": round(gs["lanes"] / max(1, gs["chains"]), 2),
                               "requests_per_launch_chain": round(gs["requests"] / max(1, gs["chains"]), 2),
                               "frames_per_s_separate_contexts": round(f_s, 1),
-                              "mode": "one stream group: the members' tracking calls share launch chains (vo_group); ORB and local BA per stream on their own HIP streams"})
+                              "mode": "one stream group: the members' tracking calls share launch chains (vo_group); ORB per stream on its own HIP stream; local BAs batched by the device's BA engines; graph cut on the host"})
 
         # ---- CPU baseline: the oracle port on host cores, bounded samples ----------------------------------
         cpu = None

@@ -268,9 +268,74 @@ __global__ void k_ba_init_S(BaBatch Q) {
     }
 }
 
-// Schur complement, one wavefront per 6x6 block (j1 <= j2) of the reduced system:
-//   S[j1][j2] -= sum over points seen by both poses of W_e1 (H_ll+lambda)^-1 W_e2^T       (no atomics)
-// Diagonal blocks also produce b_s[j] = b_p[j] - sum W_e (H_ll+lambda)^-1 b_l.
+// Schur complement, one workgroup per slice (<= 512 pairs) of a 6x6 block (j1 <= j2) of the reduced system:
+//   S[j1][j2] -= sum over points seen by both poses of W_e1 (H_ll+lambda)^-1 W_e2^T
+// Diagonal blocks also produce b_s[j] = b_p[j] - sum W_e (H_ll+lambda)^-1 b_l.  Half of all pairs are diagonal (every free edge pairs
+// with itself): there e1 == e2, so W is loaded once; off-diagonal slices carry 36 sums instead of 42 and never touch b_l.
+template <bool DIAG>
+__device__ __forceinline__ void ba_schur_slice(const BaDev& B, const BaBlock blk, double* s_part, double* s_tot) {
+    constexpr int NV = DIAG ? 42 : 36;
+    double v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = 0;
+    for (int q = blk.start + threadIdx.x; q < blk.start + blk.count; q += 256) {
+        const int2 pr = B.pairs[q];
+        if (!B.active[pr.x] || (!DIAG && !B.active[pr.y])) continue;
+        const int k = B.e_pt[pr.x];
+        const double* h = B.Hinv + 9 * (size_t)k;
+        const double* W2 = B.W + 18 * (size_t)pr.y;
+        double w2[18];
+#pragma unroll
+        for (int i = 0; i < 18; ++i) w2[i] = W2[i];
+        const double* W1 = B.W + 18 * (size_t)pr.x;
+        double b0 = 0, b1 = 0, b2 = 0;
+        if (DIAG) { b0 = B.bl[3 * (size_t)k]; b1 = B.bl[3 * (size_t)k + 1]; b2 = B.bl[3 * (size_t)k + 2]; }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const double a0 = DIAG ? w2[3 * r] : W1[3 * r], a1 = DIAG ? w2[3 * r + 1] : W1[3 * r + 1], a2 = DIAG ? w2[3 * r + 2] : W1[3 * r + 2];
+            const double y0 = a0 * h[0] + a1 * h[3] + a2 * h[6];
+            const double y1 = a0 * h[1] + a1 * h[4] + a2 * h[7];
+            const double y2 = a0 * h[2] + a1 * h[5] + a2 * h[8];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v[6 * r + c] += y0 * w2[3 * c] + y1 * w2[3 * c + 1] + y2 * w2[3 * c + 2];
+            if (DIAG) v[36 + r] += y0 * b0 + y1 * b1 + y2 * b2;
+        }
+    }
+    {   // NV sums: a transposed 32-value wave reduction for v[0..31], a second (padded) one for the rest; wave partials through LDS
+        double r0[8], r1[8];
+        {
+            double lo[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) lo[i] = v[i];
+            vo_wave_reduce32(lo, r0);
+        }
+        {
+            double hi[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) hi[i] = i < NV - 32 ? v[32 + i] : 0.0;
+            vo_wave_reduce32(hi, r1);
+        }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if ((lane & 15) == 0) {
+            const int slot = VO_R32_SLOT(lane >> 4);
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) s_part[wave * 42 + 4 * k8 + slot] = r0[k8];
+#pragma unroll
+            for (int k8 = 0; k8 < 3; ++k8) if (4 * k8 + slot < NV - 32) s_part[wave * 42 + 32 + 4 * k8 + slot] = r1[k8];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) s_tot[threadIdx.x] = s_part[threadIdx.x] + s_part[42 + threadIdx.x] + s_part[84 + threadIdx.x] + s_part[126 + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < 36) {
+        const int r = threadIdx.x / 6, c = threadIdx.x % 6;
+        const double val = s_tot[threadIdx.x];
+        atomicAdd(&B.S[(size_t)(6 * blk.j1 + r) * B.D + 6 * blk.j2 + c], -val);        // a block may be split over several workgroups
+        if (!DIAG) atomicAdd(&B.S[(size_t)(6 * blk.j2 + c) * B.D + 6 * blk.j1 + r], -val);
+    } else if (DIAG && threadIdx.x < 42) {
+        atomicAdd(&B.bs[6 * blk.j1 + threadIdx.x - 36], -s_tot[threadIdx.x]);
+    }
+}
 __global__ __launch_bounds__(256) void k_ba_schur_blocks(BaBatch Q) {
     BA_PROBLEM(Q)
     if (B.ctl->finished) return;
@@ -278,57 +343,8 @@ __global__ __launch_bounds__(256) void k_ba_schur_blocks(BaBatch Q) {
     __shared__ double s_tot[42];
     if ((int)blockIdx.x >= B.n_blocks || (B.n_slices && (int)blockIdx.x >= *B.n_slices)) return;
     const BaBlock blk = B.blocks[blockIdx.x];
-    const bool diag = blk.j1 == blk.j2;
-    double v[42];
-#pragma unroll
-    for (int i = 0; i < 42; ++i) v[i] = 0;
-    for (int q = blk.start + threadIdx.x; q < blk.start + blk.count; q += 256) {
-        const int2 pr = B.pairs[q];
-        if (!B.active[pr.x] || !B.active[pr.y]) continue;
-        const int k = B.e_pt[pr.x];
-        const double* h = B.Hinv + 9 * (size_t)k;
-        const double* W1 = B.W + 18 * (size_t)pr.x;
-        const double* W2 = B.W + 18 * (size_t)pr.y;
-        double w2[18];
-#pragma unroll
-        for (int i = 0; i < 18; ++i) w2[i] = W2[i];
-        const double b0 = B.bl[3 * (size_t)k], b1 = B.bl[3 * (size_t)k + 1], b2 = B.bl[3 * (size_t)k + 2];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            const double y0 = W1[3 * r] * h[0] + W1[3 * r + 1] * h[3] + W1[3 * r + 2] * h[6];
-            const double y1 = W1[3 * r] * h[1] + W1[3 * r + 1] * h[4] + W1[3 * r + 2] * h[7];
-            const double y2 = W1[3 * r] * h[2] + W1[3 * r + 1] * h[5] + W1[3 * r + 2] * h[8];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) v[6 * r + c] += y0 * w2[3 * c] + y1 * w2[3 * c + 1] + y2 * w2[3 * c + 2];
-            if (diag) v[36 + r] += y0 * b0 + y1 * b1 + y2 * b2;
-        }
-    }
-    {   // 42 sums: two transposed 32-value wave reductions (v[0..31], v[32..41] + padding), wave partials through LDS
-        double lo[32], hi[32], r0[8], r1[8];
-#pragma unroll
-        for (int i = 0; i < 32; ++i) { lo[i] = v[i]; hi[i] = i < 10 ? v[32 + i] : 0.0; }
-        vo_wave_reduce32(lo, r0);
-        vo_wave_reduce32(hi, r1);
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        if ((lane & 15) == 0) {
-            const int slot = VO_R32_SLOT(lane >> 4);
-#pragma unroll
-            for (int k8 = 0; k8 < 8; ++k8) s_part[wave * 42 + 4 * k8 + slot] = r0[k8];
-#pragma unroll
-            for (int k8 = 0; k8 < 3; ++k8) if (4 * k8 + slot < 10) s_part[wave * 42 + 32 + 4 * k8 + slot] = r1[k8];
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 42) s_tot[threadIdx.x] = s_part[threadIdx.x] + s_part[42 + threadIdx.x] + s_part[84 + threadIdx.x] + s_part[126 + threadIdx.x];
-    __syncthreads();
-    if (threadIdx.x < 36) {
-        const int r = threadIdx.x / 6, c = threadIdx.x % 6;
-        const double val = s_tot[threadIdx.x];
-        atomicAdd(&B.S[(size_t)(6 * blk.j1 + r) * B.D + 6 * blk.j2 + c], -val);        // a block may be split over several workgroups
-        if (!diag) atomicAdd(&B.S[(size_t)(6 * blk.j2 + c) * B.D + 6 * blk.j1 + r], -val);
-    } else if (diag && threadIdx.x < 42) {
-        atomicAdd(&B.bs[6 * blk.j1 + threadIdx.x - 36], -s_tot[threadIdx.x]);
-    }
+    if (blk.j1 == blk.j2) ba_schur_slice<true>(B, blk, s_part, s_tot);
+    else ba_schur_slice<false>(B, blk, s_part, s_tot);
 }
 
 // ---- pair lists of the reduced system, built on the device ---------------------------------------------------------
