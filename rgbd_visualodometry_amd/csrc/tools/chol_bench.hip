@@ -11,6 +11,8 @@ void vo_prof_begin(vo_ctx*, const char*) {}
 void vo_prof_end(vo_ctx*) {}
 void* vo_stage(vo_ctx*, size_t) { return nullptr; }
 int vo_scratch(vo_ctx*, size_t) { return VO_E_DEVICE; }
+int vo_prof_begin(vo_ctx*, const char*, hipStream_t) { return -1; }
+void vo_prof_end(vo_ctx*, int) {}
 
 static void host_solve(int D, std::vector<double> S, std::vector<double> b, std::vector<double>& x) {
     for (int j = 0; j < D; ++j) {
@@ -125,7 +127,7 @@ int main() {
     { double* d; hipMalloc(&d, 128 * 8); hipLaunchKernelGGL(k_dpp_probe, dim3(1), dim3(64), 0, 0, d); double h[128]; hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
       printf("bcast<3>: "); for (int i = 0; i < 64; i += 5) printf("[%d]=%.0f ", i, h[i]); printf("\nfnma<5>: "); for (int i = 0; i < 64; i += 5) printf("[%d]=%.0f ", i, h[64 + i]); printf("\n"); hipFree(d); }
 
-    const int sizes[] = {6, 24, 30, 60, 120, 168, 186, 192, 198, 216, 240, 300, 366};
+    const int sizes[] = {6, 24, 30, 60, 96, 120, 132, 144, 156, 168, 186, 192, 198, 216, 240, 300, 366};
     hipFuncSetAttribute((const void*)k_ba_chol16, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
     hipFuncSetAttribute((const void*)k_ba_chol16g, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
 
@@ -149,14 +151,16 @@ int main() {
         hipMalloc(&d_S0, sizeof(double) * D * D);
         hipMemcpy(d_S0, S.data(), sizeof(double) * D * D, hipMemcpyHostToDevice);
         hipMemcpy(d_b0, b.data(), sizeof(double) * D, hipMemcpyHostToDevice);
+        BaDev* d_B; hipMalloc(&d_B, sizeof(BaDev)); hipMemcpy(d_B, &B, sizeof(BaDev), hipMemcpyHostToDevice);
+        BaBatch Q; memset(&Q, 0, sizeof(Q)); Q.Bs = d_B; Q.n = 1;
         for (int variant = 1; variant < 2; ++variant) {
             float tot = 0; const int reps = 50;
             for (int it = 0; it < reps + 5; ++it) {
                 hipMemcpyAsync(B.bs, d_b0, sizeof(double) * D, hipMemcpyDeviceToDevice, st);
                 hipMemcpyAsync(B.S, d_S0, sizeof(double) * D * D, hipMemcpyDeviceToDevice, st);      // the global-resident kernels factor S in place
                 hipEventRecord(e0, st);
-                if (D <= 192) hipLaunchKernelGGL(k_ba_chol16, dim3(1), dim3(CH_THREADS), sizeof(double) * (CH_NB * CH_NB + (size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D), st, B);
-                else hipLaunchKernelGGL(k_ba_chol16g, dim3(1), dim3(CH_THREADS), sizeof(double) * (CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D), st, B);
+                if (D <= 192) hipLaunchKernelGGL(k_ba_chol16, dim3(1), dim3(CH_THREADS), sizeof(double) * (CH_NB * CH_NB + (size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D), st, Q);
+                else hipLaunchKernelGGL(k_ba_chol16g, dim3(1), dim3(CH_THREADS), sizeof(double) * (CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D), st, Q);
                 hipEventRecord(e1, st);
                 hipStreamSynchronize(st);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -176,7 +180,7 @@ int main() {
                        tt[0], tt[1], tt[5], tt[6], tt[7], tt[2], tt[4], tt[8], tt[9], tt[3], tt[10]); }
 #endif
         }
-        hipFree(d_S0); hipFree(B.S); hipFree(B.bs); hipFree(d_b0); hipFree(B.scal); hipFree(B.ctl);
+        hipFree(d_B); hipFree(d_S0); hipFree(B.S); hipFree(B.bs); hipFree(d_b0); hipFree(B.scal); hipFree(B.ctl);
     }
     hipError_t e = hipGetLastError();
     printf("last error: %s, mismatches: %d\n", hipGetErrorString(e), bad);
