@@ -1922,7 +1922,11 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     if (mh >= 1024 * 1024 || nkf > 1024 * 1024) return VO_E_UNSUPPORTED;
     if ((CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D) * sizeof(double) > 158 * 1024 || nf > 64) return VO_E_UNSUPPORTED;
     CutFree F; F.n = nf;
-    for (int i = 0; i < nf; ++i) { if (free_kf[i] < 0 || free_kf[i] >= nkf) return VO_E_INVALID; F.kf[i] = free_kf[i]; }
+    for (int i = 0; i < nf; ++i) {
+        if (free_kf[i] < 0 || free_kf[i] >= nkf) return VO_E_INVALID;
+        for (int k = 0; k < i; ++k) if (free_kf[k] == free_kf[i]) return VO_E_INVALID;       // a keyframe is free once
+        F.kf[i] = free_kf[i];
+    }
     // ---- cut scratch (lives until c's next cut: the solve reads pt_start, pose_kf and point_slots from it)
     //      zeroed per cut: [fixed_flag nkf][pt_flag mh][cnt mh + 1][fill mh]     written by kernels: [kf_idx][pose_kf][pidx][pt_start mh + 1][point_slots][bsum][totals]
     size_t co = 0;

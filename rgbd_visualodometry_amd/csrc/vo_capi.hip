@@ -819,7 +819,8 @@ int vo_track_frame(vo_ctx* c, int slot, const double T0[12], const vo_track_para
 #define VO_KF_CAP 65536             // keyframes (96 B each)
 static int vo_obs_tables_ensure(vo_ctx* c) {     // allocates the observation / keyframe tables on first use
     if (c->d_obs_kf) return VO_OK;
-    c->obs_cap = VO_OBS_CAP; c->kf_cap = VO_KF_CAP;
+    const char* env = getenv("VO_OBS_CAP");                // tests shrink the table to exercise the overflow path
+    c->obs_cap = env && atoll(env) > 0 ? std::min<long long>(atoll(env), VO_OBS_CAP) : VO_OBS_CAP; c->kf_cap = VO_KF_CAP;
     if (hipMalloc((void**)&c->d_obs_kf, 4 * (size_t)c->obs_cap) != hipSuccess || hipMalloc((void**)&c->d_obs_mp, 4 * (size_t)c->obs_cap) != hipSuccess ||
         hipMalloc((void**)&c->d_obs_uv, 8 * (size_t)c->obs_cap) != hipSuccess || hipMalloc((void**)&c->d_obs_alive, (size_t)c->obs_cap) != hipSuccess ||
         hipMalloc((void**)&c->d_kf_pose, 96 * (size_t)c->kf_cap) != hipSuccess) return VO_E_NOMEM;

@@ -381,11 +381,20 @@ void FrontEnd::RegisterKeyframeOnDevice() {
         ++n;
     }
     int64_t first = 0;
-    vo_check(vo_obs_append(ctx_, kf.data(), mp.data(), uv.data(), (int)n, &first), "vo_obs_append");
-    if ((size_t)first + n != map.obsRegistry_.size()) throw std::runtime_error("observation registry out of step with the device table");
     double T[12];
     frameCurr_->GetPose().to12(T);
-    vo_check(vo_kf_set_pose(ctx_, &frameCurr_->kfIndex_, T, 1), "vo_kf_set_pose");
+    int rc = vo_obs_append(ctx_, kf.data(), mp.data(), uv.data(), (int)n, &first);
+    if (rc == VO_OK) rc = vo_kf_set_pose(ctx_, &frameCurr_->kfIndex_, T, 1);
+    if (rc == VO_E_OVERFLOW || rc == VO_E_INVALID || rc == VO_E_NOMEM) {
+        // the tables are full (4 Mi observations / 64 Ki keyframes): from here on the back-end cuts its graphs on the host again;
+        // a job already cut from the tables still merges through them
+        std::cerr << "[myslam] device observation table full (" << vo_strerror(rc) << "): local BA graphs are cut on the host from keyframe " << frameCurr_->GetId() << " on" << std::endl;
+        map.obsRegistry_.resize(map.obsRegistry_.size() - n);
+        backend_->SetDeviceGraph(false);
+        return;
+    }
+    vo_check(rc, "vo_obs_append / vo_kf_set_pose");
+    if ((size_t)first + n != map.obsRegistry_.size()) throw std::runtime_error("observation registry out of step with the device table");
 }
 
 // Every eligible point of the keyframe in one batched launch (vo_triangulate_batch): the reference's loop stops after the

@@ -299,3 +299,16 @@ def test_device_resident_graph_cut_gives_the_host_graph_cut_trajectory(frames):
     lag_d, sl = run_system(ORACLE_LIB, frames, n, backend_lag_frames=3, max_frames_in_flight=8, track_batch=4, ba_device_graph=1, **kw)
     assert sl["ba_runs"] >= 4
     np.testing.assert_allclose(lag_d, lag_h, atol=1e-6)
+
+
+def test_full_observation_table_falls_back_to_the_host_graph_cut(frames, monkeypatch, capfd):
+    """The device tables have a fixed capacity; when a keyframe no longer fits, the back-end goes back to cutting its graphs on the
+    host (one line on stderr) and the stream goes on with the same trajectory."""
+    n = len(frames[3])
+    kw = dict(number_of_features=500, keyframe_rotation=0.02, keyframe_translation=0.02, backend_lag_frames=3, max_frames_in_flight=8, track_batch=4)
+    host, sh = run_system(ORACLE_LIB, frames, n, **kw)
+    monkeypatch.setenv("VO_OBS_CAP", "2000")                # the first keyframes fit (500 observations each), a later one does not
+    dev, sd = run_system(ORACLE_LIB, frames, n, ba_device_graph=1, **kw)
+    assert "device observation table full" in capfd.readouterr().err
+    assert sd["keyframes"] == sh["keyframes"] >= 5 and sd["ba_runs"] == sh["ba_runs"] and sd["lost"] == 0
+    np.testing.assert_allclose(dev, host, atol=1e-6)

@@ -251,29 +251,30 @@ def test_hypothesis_shard_equals_unsharded_ransac(libs, streams):
     ctx.close()
 
 
-def _resident_scene(L, rng, n_kf=9, n_pts=400, n_free=4, young=False):
+def _resident_scene(L, rng, n_kf=9, n_pts=400, n_free=4, young=False, seen_mod=100):
     """Keyframes and map points with a sliding visibility pattern, loaded into the observation table and the map of a context."""
     import ref_model as rm
     p = L.default_params(n_features=64, map_capacity=4096)
     t = L.context(p)
-    Ts = [rm.se3_exp(np.concatenate([rng.normal(0, 0.25, 3) + [0.12 * k, 0, 0], rng.normal(0, 0.05, 3)])) for k in range(n_kf)]
+    Ts = [rm.se3_exp(np.concatenate([rng.normal(0, 0.25, 3) + [0.12 * (k % 40), 0, 0], rng.normal(0, 0.05, 3)])) for k in range(n_kf)]
     X = rng.uniform(-1.5, 1.5, (n_pts, 3)) + [0.5, 0, 5]
-    slots = rng.permutation(n_pts if young else 2000)[:n_pts].astype(np.int32)   # map slots in arbitrary order, with holes unless young
+    slots = rng.permutation(n_pts if young else max(2000, n_pts + 500))[:n_pts].astype(np.int32)   # map slots in arbitrary order, with holes unless young
     flags = (rng.random(n_pts) < (0 if young else 0.04)).astype(np.uint8)        # a few outliers
     X0 = X + rng.normal(0, 0.01, X.shape)
     t.map_upsert(slots, X0, np.tile([0, 0, 1.0], (n_pts, 1)), np.zeros((n_pts, 32), np.uint8), flags)
     t._scene_positions, t._scene_slots = X0, slots
     t.kf_set_pose(np.arange(n_kf), np.array(Ts))
     obs = []
+    idx = np.arange(n_pts)
     for k in range(n_kf):
-        seen = [i for i in range(n_pts) if young or (i * 7 + k * 31) % 100 < 45 + 5 * (k % 3)]
+        seen = idx if young else idx[(idx * 7 + k * 31) % seen_mod < 45 + 5 * (k % 3)]
+        if len(seen) == 0:
+            continue
         R, tt = Ts[k][:9].reshape(3, 3), Ts[k][9:]
-        uv = []
-        for i in seen:
-            pc = R @ X[i] + tt
-            uv.append([p.fx * pc[0] / pc[2] + p.cx + rng.normal(0, 0.3), p.fy * pc[1] / pc[2] + p.cy + rng.normal(0, 0.3)])
-        first = t.obs_append(np.full(len(seen), k), slots[seen], np.array(uv))
-        obs += [(first + j, k, int(slots[i]), uv[j]) for j, i in enumerate(seen)]
+        pc = X[seen] @ R.T + tt
+        uv = np.stack([p.fx * pc[:, 0] / pc[:, 2] + p.cx, p.fy * pc[:, 1] / pc[:, 2] + p.cy], 1) + rng.normal(0, 0.3, (len(seen), 2))
+        first = t.obs_append(np.full(len(seen), k), slots[seen], uv)
+        obs += [(first + j, k, int(slots[i]), [float(uv[j, 0]), float(uv[j, 1])]) for j, i in enumerate(seen)]
     dead = [o[0] for o in obs if rng.random() < (0 if young else 0.03)]
     t.obs_kill(dead)
     free = [n_kf - 1 - (1 if young else 2) * i for i in range(n_free)]      # not sorted, not contiguous
@@ -281,29 +282,44 @@ def _resident_scene(L, rng, n_kf=9, n_pts=400, n_free=4, young=False):
 
 
 @pytest.mark.parametrize("libs", LIBS)
-@pytest.mark.parametrize("young", [False, True])
-def test_resident_graph_cut_follows_backend_cpp(libs, young):
+@pytest.mark.parametrize("shape", ["window", "young", "wide", "long"])
+def test_resident_graph_cut_follows_backend_cpp(libs, shape):
     """the graph cut on the device-resident observation table (reference src/backend.cpp:36-135) against the
     definition: points = non-outlier points a free keyframe observes, edges = all live observations of those points, fixed
     poses = their other observers; ordering rules of include/vo_hip.h."""
     L = capi.load(libs[0])
     rng = np.random.default_rng(17)
-    # young: the first local BA of a run -- every slot of the map is in the graph, every keyframe is free (no fixed pose)
-    t, Ts, X, slots, flags, obs, dead, free = _resident_scene(L, rng, n_kf=2, n_pts=300, n_free=2, young=True) if young else _resident_scene(L, rng)
+    young = shape == "young"
+    # young: the first local BA of a run -- every slot of the map is in the graph, every keyframe is free (no fixed pose);
+    # wide: the 64 free keyframes the cut allows, several 1024-edge chunks;  long: more keyframes than one scan block, most of them
+    # without a shared point (the table of a long run)
+    if young:
+        sc = _resident_scene(L, rng, n_kf=2, n_pts=300, n_free=2, young=True)
+    elif shape == "wide":
+        sc = _resident_scene(L, rng, n_kf=140, n_pts=900, n_free=64)
+    elif shape == "long":
+        sc = _resident_scene(L, rng, n_kf=1300, n_pts=600, n_free=5, seen_mod=700)
+    else:
+        sc = _resident_scene(L, rng)
+    t, Ts, X, slots, flags, obs, dead, free = sc
     c = L.context(L.default_params(n_features=64, map_capacity=64))
     g = c.resident_graph(t, free)
     outl = {int(s) for s, f in zip(slots, flags) if f}
     live = [o for o in obs if o[0] not in dead]
-    pts = sorted({o[2] for o in live if o[1] in free and o[2] not in outl})
-    assert list(g["point_slots"]) == pts and len(pts) > 100
-    edges = sorted([o for o in live if o[2] in set(pts)], key=lambda o: (pts.index(o[2]), o[1]))
-    fixed = sorted({o[1] for o in edges} - set(free))
+    fs = set(free)
+    pts = sorted({o[2] for o in live if o[1] in fs and o[2] not in outl})
+    pidx = {s: i for i, s in enumerate(pts)}
+    assert list(g["point_slots"]) == pts and len(pts) > (100 if shape != "long" else 40)
+    edges = sorted([o for o in live if o[2] in pidx], key=lambda o: (pidx[o[2]], o[1]))
+    fixed = sorted({o[1] for o in edges} - fs)
     assert list(g["pose_kf"]) == free + fixed and len(fixed) >= (0 if young else 2)
     if young:
         assert len(pts) == 300 and max(pts) == 299 and not fixed
+    if shape == "wide":
+        assert len(edges) > 4096
     pose_of = {k: i for i, k in enumerate(free + fixed)}
     assert list(g["edge_obs"]) == [o[0] for o in edges]
-    assert list(g["edge_pose"]) == [pose_of[o[1]] for o in edges] and list(g["edge_point"]) == [pts.index(o[2]) for o in edges]
+    assert list(g["edge_pose"]) == [pose_of[o[1]] for o in edges] and list(g["edge_point"]) == [pidx[o[2]] for o in edges]
     assert np.allclose(g["edge_uv"], np.array([o[3] for o in edges], np.float32))
     # solving the cut = solving the same problem handed over explicitly (vo_local_ba)
     poses = np.array([Ts[k] for k in g["pose_kf"]])
@@ -314,6 +330,9 @@ def test_resident_graph_cut_follows_backend_cpp(libs, young):
     assert np.array_equal(sl, g["point_slots"]) and r.n_fixed == len(fixed) and r.n_edges == len(edges)
     np.testing.assert_allclose(po, pw, atol=1e-7); np.testing.assert_allclose(pt, xw, atol=1e-6)
     assert sorted(cu) == sorted(int(g["edge_obs"][e]) for e in np.nonzero(fw & 3)[0]) and abs(r.chi2_final - rw.chi2_final) < 1e-6 * max(1.0, rw.chi2_final)
+    # a keyframe can be free only once
+    with pytest.raises(capi.VoError):
+        c.resident_graph(t, [free[0], free[0]])
     c.close(); t.close()
 
 
