@@ -146,6 +146,8 @@ int main() {
         B.D = D;
         double* d_b0; double* d_S0;
         hipMalloc(&B.S, sizeof(double) * D * D); hipMalloc(&B.bs, sizeof(double) * D); hipMalloc(&d_b0, sizeof(double) * D);
+        hipMalloc(&B.Hpp, sizeof(double) * 36 * (D / 6 + 1)); hipMemset(B.Hpp, 0, sizeof(double) * 36 * (D / 6 + 1));      // the kernel adds blockdiag(H_pp) + lambda I, b_p on load
+        hipMalloc(&B.bp, sizeof(double) * D); hipMemset(B.bp, 0, sizeof(double) * D);
         hipMalloc(&B.scal, 64); hipMalloc(&B.dl, 128); hipMemset(B.dl, 0, 128); hipMalloc(&B.ctl, sizeof(BaCtl));
         hipMemset(B.scal, 0, 64); hipMemset(B.ctl, 0, sizeof(BaCtl));
         hipMalloc(&d_S0, sizeof(double) * D * D);
@@ -180,7 +182,7 @@ int main() {
                        tt[0], tt[1], tt[5], tt[6], tt[7], tt[2], tt[4], tt[8], tt[9], tt[3], tt[10]); }
 #endif
         }
-        hipFree(d_B); hipFree(d_S0); hipFree(B.S); hipFree(B.bs); hipFree(d_b0); hipFree(B.scal); hipFree(B.ctl);
+        hipFree(B.Hpp); hipFree(B.bp); hipFree(d_B); hipFree(d_S0); hipFree(B.S); hipFree(B.bs); hipFree(d_b0); hipFree(B.scal); hipFree(B.ctl);
     }
     hipError_t e = hipGetLastError();
     printf("last error: %s, mismatches: %d\n", hipGetErrorString(e), bad);

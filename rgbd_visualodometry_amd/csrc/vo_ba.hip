@@ -5,8 +5,9 @@
 // Marquardt with g2o's lambda/rho policy, 10 robust iterations + chi2 cull + 10 plain ones.
 //
 //   k_ba_lin          4 lanes per point: r, J_pose (2x6), J_point (2x3) = J_pose[:,0:3] R, Huber weight, H_ll / b_l / W_e
-//                     (no atomics); 4 workgroups per free pose: H_pp / b_p
-//   k_ba_init_S       S = blockdiag(H_pp) + lambda I, b_s = b_p, (H_ll + lambda I)^-1 per point
+//                     (no atomics), (H_ll + lambda I)^-1, S = 0; 4 workgroups per free pose: H_pp / b_p
+//   k_ba_init_S       only for 6K > 192 (S = blockdiag(H_pp) + lambda I, b_s = b_p, the inverses) and on the first step of a
+//                     round (the inverses, once k_ba_maxdiag has produced lambda): otherwise folded into k_ba_lin / k_ba_chol16
 //   k_ba_schur_blocks one workgroup per <= 512-pair slice of a 6x6 block: S -= W_e1 Hinv W_e2^T, b_s -= W_e Hinv b_l
 //   k_ba_chol16       dense Cholesky + solve of the reduced 6K x 6K system in one workgroup (16-column DPP panels,
 //                     f64 MFMA trailing update); k_ba_chol16g (matrix in L2, panel in LDS) for 6K > 192
@@ -125,6 +126,31 @@ __device__ __forceinline__ double ba_quad_sum(double x) {
     x += vo_dpp_mov_f64<0x4E, 0xF>(x);      // quad_perm [2,3,0,1]
     return x;
 }
+__device__ __forceinline__ void ba_inv3_damped(const double* __restrict__ Hll, double lambda, double* __restrict__ h) {      // (H_ll + lambda I)^-1, zero if singular
+    double a[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) a[q] = Hll[q];
+    a[0] += lambda; a[4] += lambda; a[8] += lambda;
+    const double det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]);
+    if (!(fabs(det) > 0)) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) h[q] = 0;
+    } else {
+        const double id = 1.0 / det;
+        h[0] = (a[4] * a[8] - a[5] * a[7]) * id; h[1] = (a[2] * a[7] - a[1] * a[8]) * id; h[2] = (a[1] * a[5] - a[2] * a[4]) * id;
+        h[3] = (a[5] * a[6] - a[3] * a[8]) * id; h[4] = (a[0] * a[8] - a[2] * a[6]) * id; h[5] = (a[2] * a[3] - a[0] * a[5]) * id;
+        h[6] = (a[3] * a[7] - a[4] * a[6]) * id; h[7] = (a[1] * a[6] - a[0] * a[7]) * id; h[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+    }
+}
+// Systems that the LDS-resident Cholesky kernel solves (D <= BA_FOLD_D) have no separate "init S" launch: the linearisation
+// launch zeroes S / b_s and inverts the damped point blocks, the Schur kernel accumulates into the zeroed S, and the Cholesky
+// kernel adds blockdiag(H_pp) + lambda I and b_p while it loads the system.  Larger systems keep k_ba_init_S.
+#define BA_FOLD_D 192
+__device__ __forceinline__ void ba_fold_zero(const BaDev& B, int blk, int nblk) {            // S = 0, b_s = 0 (grid-stride over the point blocks)
+    const int n = B.D * B.D;
+    for (int i = blk * 256 + threadIdx.x; i < n; i += nblk * 256) B.S[i] = 0.0;
+    for (int i = blk * 256 + threadIdx.x; i < B.D; i += nblk * 256) B.bs[i] = 0.0;
+}
 __device__ __forceinline__ void ba_lin_points_body(const BaCam& cam, const BaDev& B, int robust, double delta, int blk,
                                                    const double* poses_c, const double* pts_c, double* s_part) {
     const int k = blk * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
@@ -160,7 +186,13 @@ __device__ __forceinline__ void ba_lin_points_body(const BaCam& cam, const BaDev
         double* Ho = B.Hll + 9 * (size_t)k;
         Ho[0] = H[0]; Ho[1] = H[1]; Ho[2] = H[2]; Ho[3] = H[1]; Ho[4] = H[3]; Ho[5] = H[4]; Ho[6] = H[2]; Ho[7] = H[4]; Ho[8] = H[5];
         B.bl[3 * (size_t)k] = b3[0]; B.bl[3 * (size_t)k + 1] = b3[1]; B.bl[3 * (size_t)k + 2] = b3[2];
+        // folded init: lambda of this step is known unless this is the first step of a round (then k_ba_init_S follows k_ba_maxdiag)
+        if (B.D <= BA_FOLD_D && !B.ctl->first) {
+            const double Hs[9] = {H[0], H[1], H[2], H[1], H[3], H[4], H[2], H[4], H[5]};
+            ba_inv3_damped(Hs, B.ctl->lambda, B.Hinv + 9 * (size_t)k);
+        }
     }
+    if (B.D <= BA_FOLD_D) ba_fold_zero(B, blk, B.gp);
     ba_block_reduce<1>(chi, s_part);
     if (threadIdx.x == 0 && chi[0] != 0.0) atomicAdd(&B.scal[0], chi[0]);
 }
@@ -215,7 +247,15 @@ __device__ __forceinline__ void ba_lin_poses_body(const BaCam& cam, const BaDev&
 
 __global__ __launch_bounds__(256) void k_ba_lin(BaBatch Q) {
     BA_PROBLEM(Q)
-    if (B.ctl->finished || !B.ctl->need_lin) return;
+    if (B.ctl->finished) return;
+    if (!B.ctl->need_lin) {                                 // a rejected step is solved again at the same linearisation with a larger lambda
+        if (B.D <= BA_FOLD_D && (int)blockIdx.x < B.gp) {
+            const int k = blockIdx.x * 64 + (threadIdx.x >> 2);
+            if (k < B.n_points && (threadIdx.x & 3) == 0) ba_inv3_damped(B.Hll + 9 * (size_t)k, B.ctl->lambda, B.Hinv + 9 * (size_t)k);
+            ba_fold_zero(B, blockIdx.x, B.gp);
+        }
+        return;
+    }
     BA_STATE(B)
     __shared__ double s_part[4 * 32];
     const int gp = B.gp, robust = B.ctl->robust;
@@ -236,36 +276,25 @@ __global__ void k_ba_maxdiag(BaBatch Q) {
     if ((threadIdx.x & 63) == 0) atomicMax((unsigned long long*)&B.scal[4], (unsigned long long)__double_as_longlong(v));   // v >= 0: bit order == value order
 }
 
-// S = blockdiag(H_pp) + lambda I, b_s = b_p, and (H_ll + lambda I)^-1 per point
+// D > BA_FOLD_D: S = blockdiag(H_pp) + lambda I, b_s = b_p, and (H_ll + lambda I)^-1 per point, every step.
+// D <= BA_FOLD_D: only the first step of a round, and only the inverses (lambda comes from k_ba_maxdiag just before).
 __global__ void k_ba_init_S(BaBatch Q) {
     BA_PROBLEM(Q)
     if (B.ctl->finished) return;
+    const bool fold = B.D <= BA_FOLD_D, first = B.ctl->need_lin && B.ctl->first;
+    if (fold && !first) return;
     // first step of a round: lambda = 1e-5 * max diag(H) (g2o computeLambdaInit); the control block is updated later in
-    // this step by the Cholesky kernel's prologue, so every lane derives the same value here
-    const double lambda = (B.ctl->need_lin && B.ctl->first) ? 1e-5 * B.scal[4] : B.ctl->lambda;
+    // this step by the Cholesky kernel, so every lane derives the same value here
+    const double lambda = first ? 1e-5 * B.scal[4] : B.ctl->lambda;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B.D * B.D) {
+    if (!fold && i < B.D * B.D) {
         const int r = i / B.D, c = i % B.D;
         double v = 0;
         if (r / 6 == c / 6) v = B.Hpp[36 * (size_t)(r / 6) + 6 * (r % 6) + (c % 6)];
         if (r == c) { v += lambda; B.bs[r] = B.bp[r]; }
         B.S[i] = v;
     }
-    if (i < B.n_points) {
-        const int k = i;
-        double a[9];
-        for (int q = 0; q < 9; ++q) a[q] = B.Hll[9 * (size_t)k + q];
-        a[0] += lambda; a[4] += lambda; a[8] += lambda;
-        const double det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]);
-        double* h = B.Hinv + 9 * (size_t)k;
-        if (!(fabs(det) > 0)) { for (int q = 0; q < 9; ++q) h[q] = 0; }
-        else {
-            const double id = 1.0 / det;
-            h[0] = (a[4] * a[8] - a[5] * a[7]) * id; h[1] = (a[2] * a[7] - a[1] * a[8]) * id; h[2] = (a[1] * a[5] - a[2] * a[4]) * id;
-            h[3] = (a[5] * a[6] - a[3] * a[8]) * id; h[4] = (a[0] * a[8] - a[2] * a[6]) * id; h[5] = (a[2] * a[3] - a[0] * a[5]) * id;
-            h[6] = (a[3] * a[7] - a[4] * a[6]) * id; h[7] = (a[1] * a[6] - a[0] * a[7]) * id; h[8] = (a[0] * a[4] - a[1] * a[3]) * id;
-        }
-    }
+    if (i < B.n_points) ba_inv3_damped(B.Hll + 9 * (size_t)i, lambda, B.Hinv + 9 * (size_t)i);
 }
 
 // Schur complement, one workgroup per slice (<= 512 pairs) of a 6x6 block (j1 <= j2) of the reduced system:
@@ -590,16 +619,16 @@ __global__ __launch_bounds__(CH_THREADS) void k_ba_chol16(BaBatch Q) {
 #else
 #define CH_STAMP(i)
 #endif
-    if (tid == 0) {
-        s_ok = 1;
-        BaCtl* c = B.ctl;                               // take over the fresh linearisation, clear the trial sums
-        if (c->need_lin) {
-            c->cur = B.scal[0];
-            if (c->first) { c->lambda = 1e-5 * B.scal[4]; c->ni = 2; c->first = 0; }
-            c->need_lin = 0;
-        }
-        B.scal[1] = 0; B.scal[2] = 0; B.scal[7] = 0;
-    }
+    if (tid == 0) s_ok = 1;
+    // the Schur kernel accumulated -sum W H^-1 W^T into a zeroed S: blockdiag(H_pp) + lambda I and b_p join while the system is
+    // loaded (no separate init launch).  Every lane derives this step's lambda the way k_ba_init_S does; the control block is
+    // taken over only after the barrier below, when nobody reads it any more.
+    const double lambda = (B.ctl->need_lin && B.ctl->first) ? 1e-5 * B.scal[4] : B.ctl->lambda;
+    const double* const Hpp = B.Hpp;
+    auto extra = [&](int r, int c) -> double {              // entry (r, c) of blockdiag(H_pp) + lambda I
+        const double h = Hpp[36 * (size_t)(r / 6) + 6 * (r % 6) + (c % 6)];     // always in range; used only inside the block
+        return (r / 6 == c / 6 ? h : 0.0) + (r == c ? lambda : 0.0);
+    };
     // ---- load.  Wave 0 takes the first diagonal block straight from global memory into registers and factors it
     // while the other waves bring the rest of the lower triangle (rows >= 16) and the rhs row into LDS.
     if (wave == 0) {
@@ -610,7 +639,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_ba_chol16(BaBatch Q) {
         const bool mine = r16 < nb;
         const double* row = A + (size_t)(mine ? r16 : 0) * D;
 #pragma unroll
-        for (int c = 0; c < CH_NB; ++c) a[c] = row[min(c, nb - 1)];
+        for (int c = 0; c < CH_NB; ++c) a[c] = row[min(c, nb - 1)] + extra(mine ? r16 : 0, min(c, nb - 1));
 #pragma unroll
         for (int c = 0; c < CH_NB; ++c) a[c] = (mine && c <= r16) ? a[c] : (c == r16 ? 1.0 : 0.0);
         if (!ch_factor_block(a, s_L, s_dg, s_inv, s_pinv, 0, nb, lane) && lane == 0) s_ok = 0;
@@ -627,10 +656,28 @@ __global__ __launch_bounds__(CH_THREADS) void k_ba_chol16(BaBatch Q) {
             if (c1 <= r) dst[c1] = v1.x;
             if (c1 + 1 <= r) dst[c1 + 1] = v1.y;
         }
-        for (int i = tid - 64; i < D; i += CH_THREADS - 64) s_L[TRI32(D, i)] = B.bs[i];
+        // the 6x6 diagonal block of row r (columns 6 (r / 6) .. r) joins in a second sweep over this wave's rows: 6 lanes per row,
+        // 10 rows at a time (LDS accesses of one wave are ordered, so no barrier is needed behind the loop above)
+        if (lane < 60)
+            for (int i = lane / 6; ; i += 10) {
+                const int r = CH_NB + wave - 1 + (CH_THREADS / 64 - 1) * i;
+                if (r >= D) break;
+                const int c = 6 * (r / 6) + lane % 6;
+                if (c <= r) s_L[TRI32(r, c)] += extra(r, c);
+            }
+        for (int i = tid - 64; i < D; i += CH_THREADS - 64) s_L[TRI32(D, i)] = B.bs[i] + B.bp[i];
         if (tid == 64) s_L[TRI32(D, D)] = 0.0;
     }
     __syncthreads();
+    if (tid == 0) {
+        BaCtl* c = B.ctl;                               // take over the fresh linearisation, clear the trial sums
+        if (c->need_lin) {
+            c->cur = B.scal[0];
+            if (c->first) { c->lambda = lambda; c->ni = 2; c->first = 0; }
+            c->need_lin = 0;
+        }
+        B.scal[1] = 0; B.scal[2] = 0; B.scal[7] = 0;
+    }
     CH_STAMP(0)
     // one 16x16 tile of the trailing update S22 -= L21 L21^T on the f64 matrix cores (K = 16: 4 MFMAs).  Lane l holds
     // A[l&15][l>>4], B[l>>4][l&15]; D: col = l&15, row = (l>>4) + 4 reg.  Rows past the end are clamped (their
@@ -1327,7 +1374,8 @@ static int ba_engine_pump(BaEngine* E) {                    // engine thread; re
     for (int sidx = 0; sidx < chunk; ++sidx) {
         { ProfScope ps(prof, "k_ba_lin", st); hipLaunchKernelGGL(k_ba_lin, dim3(g_lin, 1, na), blk, 0, st, Q); }
         if (sidx == 0 && nfirst) hipLaunchKernelGGL(k_ba_maxdiag, dim3(g_md, 1, nfirst), blk, 0, st, ba_batch_of(E, sfirst, nfirst));
-        { ProfScope ps(prof, "k_ba_init_S", st); hipLaunchKernelGGL(k_ba_init_S, dim3(g_init, 1, na), blk, 0, st, Q); }
+        // systems beyond the LDS-resident Cholesky need it every step, the others only behind k_ba_maxdiag (first step of a round)
+        if (n16g || (sidx == 0 && nfirst)) { ProfScope ps(prof, "k_ba_init_S", st); hipLaunchKernelGGL(k_ba_init_S, dim3(g_init, 1, na), blk, 0, st, Q); }
         if (g_blk) { ProfScope ps(prof, "k_ba_schur_blocks", st); hipLaunchKernelGGL(k_ba_schur_blocks, dim3(g_blk, 1, na), blk, 0, st, Q); }
         { ProfScope ps(prof, "k_ba_chol", st);
           if (n16) hipLaunchKernelGGL(k_ba_chol16, dim3(1, 1, n16), dim3(CH_THREADS), lds16, st, ba_batch_of(E, s16, n16));
