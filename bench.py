@@ -147,7 +147,7 @@ def main():
     dptr = [d_depth.data_ptr() + i * fd for i in range(total)]
 
     opts = dict(width=W, height=H, number_of_features=N, max_frames_in_flight=args.lookahead, device=local_rank,
-                enable_local_optimization=0 if args.no_ba else 1, backend_lag_frames=args.ba_lag, track_batch=args.track_batch, map_capacity=1 << 20, ransac_iterations=args.hyps, ba_device_graph=0 if args.host_graph else 1)
+                enable_local_optimization=0 if args.no_ba else 1, backend_lag_frames=args.ba_lag, track_batch=args.track_batch, map_capacity=1 << 20, ransac_iterations=args.hyps, ba_device_graph=0 if args.host_graph else 1, map_descriptors_on_device=1)
 
     # One-time costs (code-object load, pinned staging, scratch growth) are paid on a throw-away system before the
     # warmup: the driver's short runs (--warmup 5) then time the same steady state as the long ones.
@@ -320,7 +320,7 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             from oracle import ORACLE_LIB                   # the checker, timed as the CPU baseline (never on the product path)
-            copts = {**opts, "max_frames_in_flight": 1, "track_batch": 1, "backend_lag_frames": 0, "ba_device_graph": 0}
+            copts = {**opts, "max_frames_in_flight": 1, "track_batch": 1, "backend_lag_frames": 0, "ba_device_graph": 0, "map_descriptors_on_device": 0}
             nf = min(args.cpu_frames, total)
             o = system.VoSystem(ORACLE_LIB, **copts)
             est_c = {}

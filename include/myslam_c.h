@@ -35,6 +35,8 @@ typedef struct myslam_options {
     int32_t triangulate_all;                /* 0: the reference's loop (stops after the first success, frontend.cpp:501); 1: every eligible point, batched */
     int32_t ba_device_graph;                /* 1: the local BA's graph is cut on the device from the resident observation table */
     int32_t reobserve_new_mappoints;        /* 1: run the reference's disabled re-observation pass (frontend.cpp:408-463) at every keyframe */
+    int32_t map_descriptors_on_device;      /* 1: new map points take their descriptor from the frame's ORB results on the device (vo_map_upsert_from_frame);
+                                               descriptors are never fetched to the host */
 } myslam_options;
 
 typedef struct myslam_stats {

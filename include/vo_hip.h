@@ -166,7 +166,7 @@ int vo_frame_bind_device(vo_ctx* ctx, int slot, const void* d_bgr, int bgr_strid
 /* Detect + describe on slots [slot0, slot0+nslots) in one batched launch chain (asynchronous
  * on the context's stream; results stay on the device). */
 int vo_orb_detect_describe(vo_ctx* ctx, int slot0, int nslots);
-/* Download slot results: up to `cap` keypoints and cap x 32 descriptor bytes. */
+/* Download slot results: up to `cap` keypoints and cap x 32 descriptor bytes (either pointer may be NULL). */
 int vo_orb_fetch(vo_ctx* ctx, int slot, vo_keypoint* kps, uint8_t* desc, int cap, int* n_out);
 /* Debug/parity taps: pyramid level image (gray u8, tightly packed w*h) and its size. */
 int vo_orb_level_size(vo_ctx* ctx, int level, int* w, int* h, int* quota);
@@ -178,6 +178,12 @@ int vo_orb_fetch_blur_level(vo_ctx* ctx, int slot, int level, uint8_t* blur_out)
 /* Insert or overwrite map points at device-map slots idx[i] (0 <= idx < map_capacity). */
 int vo_map_upsert(vo_ctx* ctx, const int32_t* idx, const double* xyz, const double* normal,
                   const uint8_t* desc, const uint8_t* flags, int n);
+/* The same for points created from keypoints of the frame in `frame_slot` (reference src/frontend.cpp:372-406, where the new
+ * point copies its keypoint's descriptor row): the descriptors are copied on the device from that slot's ORB results, so they
+ * never travel to the host and back.  kp_index[i] = keypoint of point i; the slot must still hold the frame's ORB results.
+ * vo_orb_fetch with desc == NULL then leaves the descriptors of a batch on the device altogether. */
+int vo_map_upsert_from_frame(vo_ctx* ctx, int frame_slot, const int32_t* kp_index, const int32_t* idx, const double* xyz,
+                             const double* normal, const uint8_t* flags, int n);
 /* Define the tracking map: the ordered list of device-map slots matched against. */
 int vo_map_set_active(vo_ctx* ctx, const int32_t* idx, int n);
 

@@ -163,6 +163,21 @@ int vo_map_upsert(vo_ctx* c, const int32_t* idx, const double* xyz, const double
     return VO_OK;
 }
 
+int vo_map_upsert_from_frame(vo_ctx* c, int slot, const int32_t* kp, const int32_t* idx, const double* xyz, const double* nrm, const uint8_t* flags, int n) {
+    if (!c || n < 0 || (n && (!idx || !kp)) || slot < 0 || slot >= (int)c->slots.size()) return VO_E_INVALID;
+    auto& s = c->slots[slot];
+    if (!s.has_orb) return VO_E_STATE;
+    for (int i = 0; i < n; ++i) if (idx[i] < 0 || idx[i] >= c->p.map_capacity || kp[i] < 0 || kp[i] >= (int)s.kps.size()) return VO_E_INVALID;
+    for (int i = 0; i < n; ++i) {
+        size_t k = idx[i];
+        if (xyz) std::memcpy(&c->map.pos[3 * k], xyz + 3 * (size_t)i, 24);
+        if (nrm) std::memcpy(&c->map.nrm[3 * k], nrm + 3 * (size_t)i, 24);
+        std::memcpy(&c->map.desc[32 * k], &s.desc[(size_t)32 * kp[i]], 32);     // the keypoint's descriptor row (frontend.cpp:390)
+        if (flags) c->map.flags[k] = flags[i];
+    }
+    return VO_OK;
+}
+
 int vo_map_set_active(vo_ctx* c, const int32_t* idx, int n) {
     if (!c || n < 0 || (n && !idx)) return VO_E_INVALID;
     for (int i = 0; i < n; ++i) if (idx[i] < 0 || idx[i] >= c->p.map_capacity) return VO_E_INVALID;

@@ -66,7 +66,7 @@ MATCH_DTYPE = np.dtype([("map_index", "<i4"), ("kp_index", "<i4"), ("distance", 
 # every symbol include/vo_hip.h declares
 SYMBOLS = ["vo_ctx_create", "vo_ctx_destroy", "vo_strerror", "vo_backend_name", "vo_default_params",
            "vo_default_track_params", "vo_frame_upload", "vo_frame_bind_device", "vo_orb_detect_describe",
-           "vo_orb_fetch", "vo_orb_level_size", "vo_orb_fetch_level", "vo_orb_fetch_blur_level", "vo_map_upsert", "vo_map_set_active",
+           "vo_orb_fetch", "vo_orb_level_size", "vo_orb_fetch_level", "vo_orb_fetch_blur_level", "vo_map_upsert", "vo_map_upsert_from_frame", "vo_map_set_active",
            "vo_match_active_map", "vo_matches_set", "vo_pnp_ransac", "vo_pose_refine_lm", "vo_track_frame", "vo_track_batch", "vo_track_fetch_matches",
            "vo_local_ba", "vo_sync", "vo_profile_enable", "vo_profile_read",
            "vo_group_create", "vo_group_destroy", "vo_group_join", "vo_group_leave", "vo_group_set_gather", "vo_group_stats",
@@ -112,6 +112,7 @@ class VoLib:
         L.vo_orb_fetch_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.vo_orb_fetch_blur_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.vo_map_upsert.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int]
+        L.vo_map_upsert_from_frame.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int]
         L.vo_map_set_active.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.vo_match_active_map.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_int,
                                           C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -266,6 +267,14 @@ class VoContext:
         desc = None if desc is None else np.ascontiguousarray(desc, dtype=np.uint8)
         flags = None if flags is None else np.ascontiguousarray(flags, dtype=np.uint8)
         self.L.check(self.L.lib.vo_map_upsert(self.h, _ptr(idx), _ptr(xyz), _ptr(normal), _ptr(desc), _ptr(flags), len(idx)), "vo_map_upsert")
+
+    def map_upsert_from_frame(self, slot, kp_index, idx, xyz=None, normal=None, flags=None):
+        """Map points whose descriptor is keypoint kp_index[i] of the frame in `slot` (copied on the device)."""
+        idx = np.ascontiguousarray(idx, dtype=np.int32); kp = np.ascontiguousarray(kp_index, dtype=np.int32)
+        xyz = None if xyz is None else np.ascontiguousarray(xyz, dtype=np.float64)
+        normal = None if normal is None else np.ascontiguousarray(normal, dtype=np.float64)
+        flags = None if flags is None else np.ascontiguousarray(flags, dtype=np.uint8)
+        self.L.check(self.L.lib.vo_map_upsert_from_frame(self.h, slot, _ptr(kp), _ptr(idx), _ptr(xyz), _ptr(normal), _ptr(flags), len(idx)), "vo_map_upsert_from_frame")
 
     def map_set_active(self, idx):
         idx = np.ascontiguousarray(idx, dtype=np.int32)

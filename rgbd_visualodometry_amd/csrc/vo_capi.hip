@@ -425,9 +425,13 @@ int vo_orb_fetch(vo_ctx* c, int slot, vo_keypoint* kps, uint8_t* desc, int cap, 
         HIP_TRY(hipMemcpyAsync(h + o_n + 4 * (size_t)s0, c->d_nkp + s0, sizeof(int) * sn, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(h + o_st, c->d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(h + o_k + sizeof(vo_keypoint) * (size_t)s0 * N, c->d_kps + (size_t)s0 * N, sizeof(vo_keypoint) * (size_t)sn * N, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(h + o_d + (size_t)32 * s0 * N, c->d_desc + (size_t)s0 * N * 32, (size_t)32 * sn * N, hipMemcpyDeviceToHost, c->stream));
+        if (desc) HIP_TRY(hipMemcpyAsync(h + o_d + (size_t)32 * s0 * N, c->d_desc + (size_t)s0 * N * 32, (size_t)32 * sn * N, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (in_batch) c->orb_cache_valid = true;
+        if (in_batch) { c->orb_cache_valid = true; c->orb_cache_desc = desc != nullptr; }
+    } else if (desc && !c->orb_cache_desc) {                // the batch came down without its descriptors (callers that keep them on the device)
+        HIP_TRY(hipMemcpyAsync(c->h_orb_cache + o_d + (size_t)32 * c->orb_batch0 * N, c->d_desc + (size_t)c->orb_batch0 * N * 32, (size_t)32 * c->orb_batchn * N, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->orb_cache_desc = true;
     }
     const uint8_t* h = c->h_orb_cache;
     const int st = *(const int*)(h + o_st);
@@ -492,11 +496,39 @@ int vo_map_upsert(vo_ctx* c, const int32_t* idx, const double* xyz, const double
     uint8_t* d = (uint8_t*)c->d_ba;
     HIP_TRY(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, st));
     rc = vo_map_scatter_launch(c, n, (const int32_t*)(d + o_idx), xyz ? (const double*)(d + o_xyz) : nullptr, nrm ? (const double*)(d + o_nrm) : nullptr,
-                               desc ? (const uint32_t*)(d + o_desc) : nullptr, flags ? d + o_flags : nullptr);
+                               desc ? (const uint32_t*)(d + o_desc) : nullptr, nullptr, flags ? d + o_flags : nullptr);
     if (rc) return rc;
     // no wait here: the copy and the scatter are ordered before any later work on this stream, and the next user of the
     // staging buffer (this function, vo_ba_run, vo_corr_from_host) drains the stream before touching it
     return VO_OK;
+}
+
+int vo_map_upsert_from_frame(vo_ctx* c, int slot, const int32_t* kp, const int32_t* idx, const double* xyz, const double* nrm, const uint8_t* flags, int n) {
+    if (!c || n < 0 || (n && (!idx || !kp)) || slot < 0 || slot >= c->p.max_frames) return VO_E_INVALID;
+    if (!c->slot_orb[slot]) return VO_E_STATE;
+    for (int i = 0; i < n; ++i) if (idx[i] < 0 || idx[i] >= c->p.map_capacity || kp[i] < 0 || kp[i] >= c->p.n_features) return VO_E_INVALID;
+    if (n == 0) return VO_OK;
+    for (int i = 0; i < n; ++i) c->map_hi = std::max(c->map_hi, idx[i] + 1);
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const size_t N = (size_t)n;
+    const size_t o_idx = 0, o_kp = (4 * N + 255) & ~(size_t)255, o_xyz = o_kp + ((4 * N + 255) & ~(size_t)255), o_nrm = o_xyz + ((24 * N + 255) & ~(size_t)255),
+                 o_flags = o_nrm + ((24 * N + 255) & ~(size_t)255), total = o_flags + ((N + 255) & ~(size_t)255);
+    uint8_t* h = (uint8_t*)vo_stage(c, total);
+    if (!h) return VO_E_NOMEM;
+    int rc = vo_scratch(c, total);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(st));                      // staging buffer may still feed an earlier copy
+    memcpy(h + o_idx, idx, 4 * N); memcpy(h + o_kp, kp, 4 * N);
+    if (xyz) memcpy(h + o_xyz, xyz, 24 * N);
+    if (nrm) memcpy(h + o_nrm, nrm, 24 * N);
+    if (flags) memcpy(h + o_flags, flags, N);
+    uint8_t* d = (uint8_t*)c->d_ba;
+    HIP_TRY(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, st));
+    // the slot's descriptor rows (keypoint order) are the source: a keypoint index beyond the frame's count reads a stale row of
+    // the same table, never outside it
+    return vo_map_scatter_launch(c, n, (const int32_t*)(d + o_idx), xyz ? (const double*)(d + o_xyz) : nullptr, nrm ? (const double*)(d + o_nrm) : nullptr,
+                                 (const uint32_t*)(c->d_desc + (size_t)slot * c->p.n_features * 32), (const int32_t*)(d + o_kp), flags ? d + o_flags : nullptr);
 }
 
 int vo_map_set_active(vo_ctx* c, const int32_t* idx, int n) {

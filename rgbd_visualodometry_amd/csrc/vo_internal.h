@@ -110,7 +110,7 @@ struct vo_ctx {
     int h_matches_cap;
     int h_matches_lanes = 0, h_matches_first = 0;   // lanes whose first `h_matches_first` records the last chain left in h_matches (group mode)
     void* h_stage; size_t h_stage_bytes;            // pinned general staging
-    uint8_t* h_orb_cache; bool orb_cache_valid; int orb_batch0, orb_batchn;   // pinned copy of the last ORB batch's results
+    uint8_t* h_orb_cache; bool orb_cache_valid; bool orb_cache_desc = false; int orb_batch0, orb_batchn;   // pinned copy of the last ORB batch's results
     bool corr_external;
     // BA scratch; the device's BA engine (shared by the contexts of that device, vo_ba.hip)
     void* d_ba; size_t d_ba_bytes; struct BaEngine* ba_engine = nullptr; struct BaEngine* ba_engine_sel = nullptr;
@@ -138,7 +138,7 @@ struct ProfScope { vo_ctx* c; int idx;
     ~ProfScope() { if (idx >= 0) vo_prof_end(c, idx); } };
 void* vo_stage(vo_ctx* c, size_t bytes);           // pinned host staging buffer of at least `bytes`
 int vo_scratch(vo_ctx* c, size_t bytes);           // grow the device scratch slab c->d_ba to at least `bytes`
-int vo_map_scatter_launch(vo_ctx* c, int n, const int32_t* d_idx, const double* d_xyz, const double* d_nrm, const uint32_t* d_desc, const uint8_t* d_flags);
+int vo_map_scatter_launch(vo_ctx* c, int n, const int32_t* d_idx, const double* d_xyz, const double* d_nrm, const uint32_t* d_desc, const int32_t* d_kp, const uint8_t* d_flags);
 
 // stage launchers
 int vo_orb_launch(vo_ctx* c, int slot0, int nslots);                                        // vo_orb.hip

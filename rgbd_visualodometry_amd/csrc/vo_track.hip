@@ -844,12 +844,14 @@ __global__ __launch_bounds__(LM_T) void k_pose_lm(const LaneDesc* __restrict__ l
 __global__ void k_set_nmatch(TrackDev* tr, int n) { tr->n_match = n; tr->n_inl = 0; }
 
 // device-map update: scatter packed host records to their slots (vo_map_upsert)
+// desc: one row per point, or -- with kp != nullptr -- the descriptor table of a frame slot, row kp[i] (point created from that keypoint)
 __global__ void k_map_scatter(int n, const int32_t* __restrict__ idx, const double* __restrict__ xyz, const double* __restrict__ nrm,
-                              const uint32_t* __restrict__ desc, const uint8_t* __restrict__ flags, double* __restrict__ mpos,
+                              const uint32_t* __restrict__ desc, const int32_t* __restrict__ kp, const uint8_t* __restrict__ flags, double* __restrict__ mpos,
                               double* __restrict__ mnrm, uint32_t* __restrict__ mdesc, uint8_t* __restrict__ mflags) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const size_t k = (size_t)idx[i];
+    if (kp) { const uint32_t* src = desc + 8 * (size_t)kp[i]; for (int w = 0; w < 8; ++w) mdesc[8 * k + w] = src[w]; desc = nullptr; }
     if (xyz) { mpos[3 * k] = xyz[3 * (size_t)i]; mpos[3 * k + 1] = xyz[3 * (size_t)i + 1]; mpos[3 * k + 2] = xyz[3 * (size_t)i + 2]; }
     if (nrm) { mnrm[3 * k] = nrm[3 * (size_t)i]; mnrm[3 * k + 1] = nrm[3 * (size_t)i + 1]; mnrm[3 * k + 2] = nrm[3 * (size_t)i + 2]; }
     if (desc) for (int w = 0; w < 8; ++w) mdesc[8 * k + w] = desc[8 * (size_t)i + w];
@@ -936,8 +938,8 @@ int vo_track_lm_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* dl, int nl,
     return VO_OK;
 }
 
-int vo_map_scatter_launch(vo_ctx* c, int n, const int32_t* d_idx, const double* d_xyz, const double* d_nrm, const uint32_t* d_desc, const uint8_t* d_flags) {
-    hipLaunchKernelGGL(k_map_scatter, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, d_idx, d_xyz, d_nrm, d_desc, d_flags,
+int vo_map_scatter_launch(vo_ctx* c, int n, const int32_t* d_idx, const double* d_xyz, const double* d_nrm, const uint32_t* d_desc, const int32_t* d_kp, const uint8_t* d_flags) {
+    hipLaunchKernelGGL(k_map_scatter, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, d_idx, d_xyz, d_nrm, d_desc, d_kp, d_flags,
                        c->d_map_pos, c->d_map_nrm, c->d_map_desc, c->d_map_flags);
     HIP_TRY(hipGetLastError());
     return VO_OK;

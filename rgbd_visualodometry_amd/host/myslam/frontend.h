@@ -66,11 +66,12 @@ private:
     std::vector<int> pnpMatchedMptKp_;
     KeyPointSet pnpMatchedKptSet_;
     std::vector<Mappoint::Ptr> newMappoints_;
+    std::vector<int32_t> newMappointKp_;                    // keypoint each of them was created from (frontend.cpp:390)
     int   numInliers_ = 0;
     float minDisRatio_; int maxLostFrames_, minInliers_; double keyFrameMinRot_, keyFrameMinTrans_;
     int   nextSlot_ = 0;
     int   lookahead_ = 1, scratchSlot_ = -1;        // frame slots [0, lookahead_) serve PrefetchFrames; the scratch slot re-detects old keyframes
-    bool  triangulateAll_ = false, reobserveNew_ = false;
+    bool  triangulateAll_ = false, reobserveNew_ = false, deviceDescriptors_ = false;
     // speculative batch tracking: frames between keyframes share prior + map (frontend.cpp:96), so the frames that
     // follow the current one in the prefetch queue are tracked in the same launch chain; results are cached and
     // dropped when a keyframe / BA merge changes the inputs (epoch).

@@ -46,6 +46,7 @@ void FrontEnd::Init(int device, int width, int height, int max_frames) {
     lookahead_ = std::max(1, max_frames);
     triangulateAll_ = cfg_or<int>("triangulate_all", 0) != 0;
     reobserveNew_ = cfg_or<int>("reobserve_new_mappoints", 0) != 0;
+    deviceDescriptors_ = cfg_or<int>("map_descriptors_on_device", 0) != 0;
     params_.max_frames = lookahead_ + (reobserveNew_ ? 1 : 0);
     scratchSlot_ = reobserveNew_ ? lookahead_ : -1;
     params_.map_capacity = cfg_or<int>("map_capacity", 1 << 20);
@@ -168,7 +169,8 @@ void FrontEnd::EnsureKeypoints() {
     const int cap = 2 * params_.n_features + 64;
     kpBuf_.resize(cap); descBuf_.resize((size_t)32 * cap);
     int nf = 0;
-    vo_check(vo_orb_fetch(ctx_, frameCurr_->slot_, kpBuf_.data(), descBuf_.data(), cap, &nf), "vo_orb_fetch");
+    // with the descriptors kept on the device (map_descriptors_on_device) only the keypoint records come down
+    vo_check(vo_orb_fetch(ctx_, frameCurr_->slot_, kpBuf_.data(), deviceDescriptors_ ? nullptr : descBuf_.data(), cap, &nf), "vo_orb_fetch");
     const int n = nKeypointsCurr_;
     keypointsCurr_.resize(n); descriptorsCurr_.resize(n);
     for (int i = 0; i < n; ++i) {
@@ -176,7 +178,7 @@ void FrontEnd::EnsureKeypoints() {
         KeyPoint& o = keypointsCurr_[i];
         o.pt = Point2f(k.x, k.y); o.size = k.size; o.angle = k.angle; o.response = k.response; o.octave = k.octave; o.class_id = k.class_id;
         o.index = i; o.depth_raw = k.depth_raw;
-        std::memcpy(descriptorsCurr_[i].data(), &descBuf_[(size_t)32 * i], 32);
+        if (!deviceDescriptors_) std::memcpy(descriptorsCurr_[i].data(), &descBuf_[(size_t)32 * i], 32);
     }
     keypointsBuilt_ = true;
 }
@@ -244,7 +246,7 @@ void FrontEnd::FlushDirtyMappoints() {
         std::memcpy(&upDesc_[32 * i], mp->descriptor_.data(), 32);
         upFlags_[i] = mp->outlier_ ? VO_MAP_FLAG_OUTLIER : 0;
     }
-    vo_check(vo_map_upsert(ctx_, upIdx_.data(), upXyz_.data(), upNrm_.data(), upDesc_.data(), upFlags_.data(), (int)n), "vo_map_upsert");
+    vo_check(vo_map_upsert(ctx_, upIdx_.data(), upXyz_.data(), upNrm_.data(), deviceDescriptors_ ? nullptr : upDesc_.data(), upFlags_.data(), (int)n), "vo_map_upsert");
 }
 
 void FrontEnd::MatchAndEstimatePose() {
@@ -347,7 +349,7 @@ void FrontEnd::AddCurrentKeyframeObservations() {
 }
 
 void FrontEnd::CreateNewMappoints() {
-    newMappoints_.clear();
+    newMappoints_.clear(); newMappointKp_.clear();
     for (size_t idx = 0; idx < keypointsCurr_.size(); ++idx) {
         const KeyPoint& kp = keypointsCurr_[idx];
         if (pnpMatchedKptSet_.count(kp)) continue;                                  // already explained by the map
@@ -358,7 +360,15 @@ void FrontEnd::CreateNewMappoints() {
         MapManager::GetInstance().InsertMappoint(mpt);
         if (mpt->slot_ >= params_.map_capacity) throw std::runtime_error("device map capacity exceeded (raise map_capacity)");
         frameCurr_->AddObservedMappoint(mpt.get(), kp.pt);
-        newMappoints_.push_back(mpt);
+        newMappoints_.push_back(mpt); newMappointKp_.push_back((int32_t)idx);
+    }
+    if (deviceDescriptors_ && !newMappoints_.empty()) {
+        // the descriptor row of each new point is copied on the device from this frame's ORB results (its slot is still bound);
+        // position, normal and flags travel with the next flush of the dirty list as usual
+        const size_t n = newMappoints_.size();
+        std::vector<int32_t> kp(n), slots(n);
+        for (size_t i = 0; i < n; ++i) { kp[i] = newMappointKp_[i]; slots[i] = newMappoints_[i]->slot_; }
+        vo_check(vo_map_upsert_from_frame(ctx_, frameCurr_->slot_, kp.data(), slots.data(), nullptr, nullptr, nullptr, (int)n), "vo_map_upsert_from_frame");
     }
     if (verbose_) std::cout << "Created new mappoints: " << newMappoints_.size() << std::endl;
 }

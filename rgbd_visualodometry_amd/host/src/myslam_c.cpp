@@ -69,6 +69,7 @@ int myslam_system_create(const myslam_options* o, const char* yaml, myslam_syste
         Config::set("enable_local_optimization", S(o->enable_local_optimization)); Config::set("chi2_th", S(o->chi2_th));
         Config::set("ransac_iterations", S(o->ransac_iterations)); Config::set("track_batch", S(o->track_batch)); Config::set("map_capacity", S(o->map_capacity));
         Config::set("ba_device_graph", S(o->ba_device_graph)); Config::set("triangulate_all", S(o->triangulate_all)); Config::set("reobserve_new_mappoints", S(o->reobserve_new_mappoints));
+        Config::set("map_descriptors_on_device", S(o->map_descriptors_on_device));
         if (yaml) Config::setParameterFile(yaml);
         MapManager::BindToThread(&s->map);
         s->camera = Camera::Ptr(new Camera);

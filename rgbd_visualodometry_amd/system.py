@@ -25,7 +25,7 @@ class Options(C.Structure):
                 ("max_num_lost", C.c_int32), ("min_inliers", C.c_int32), ("keyframe_rotation", C.c_double),
                 ("keyframe_translation", C.c_double), ("enable_local_optimization", C.c_int32), ("chi2_th", C.c_float),
                 ("ransac_iterations", C.c_int32), ("backend_lag_frames", C.c_int32), ("max_frames_in_flight", C.c_int32), ("track_batch", C.c_int32), ("map_capacity", C.c_int32),
-                ("device", C.c_int32), ("verbose", C.c_int32), ("triangulate_all", C.c_int32), ("ba_device_graph", C.c_int32), ("reobserve_new_mappoints", C.c_int32)]
+                ("device", C.c_int32), ("verbose", C.c_int32), ("triangulate_all", C.c_int32), ("ba_device_graph", C.c_int32), ("reobserve_new_mappoints", C.c_int32), ("map_descriptors_on_device", C.c_int32)]
 
 
 class Stats(C.Structure):

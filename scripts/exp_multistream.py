@@ -28,7 +28,7 @@ def main():
     torch.cuda.synchronize()
     fb, fd = W * H * 3, W * H * 2
     opts = dict(width=W, height=H, number_of_features=2000, max_frames_in_flight=32, backend_lag_frames=args.lag, track_batch=8, map_capacity=1 << 19,
-                enable_local_optimization=0 if args.no_ba else 1, ba_device_graph=0 if args.host_graph else 1)
+                enable_local_optimization=0 if args.no_ba else 1, ba_device_graph=0 if args.host_graph else 1, map_descriptors_on_device=1)
     for S in [int(v) for v in args.streams.split(",")]:
         for mode in args.modes.split(","):
             grp = system.StreamGroup(system.HOST_LIB, 0, 128) if mode == "group" else None

@@ -391,14 +391,46 @@ def test_device_resident_graph_cut_system_matches_oracle(frames):
         st = s.stats()
         s.close()
         return np.array(poses), st
-    pd, sd = run(system.HOST_LIB, ba_device_graph=1)
-    po, so = run(ORACLE_LIB, ba_device_graph=1)
+    pd, sd = run(system.HOST_LIB, ba_device_graph=1, map_descriptors_on_device=1)      # both halves of SURVEY 8f-2 on
+    po, so = run(ORACLE_LIB, ba_device_graph=1, map_descriptors_on_device=1)
     ph, sh = run(system.HOST_LIB)
     for k in ("keyframes", "ba_runs", "map_points", "ba_points", "ba_edges", "ba_poses", "ba_fixed"):
         assert sd[k] == so[k] == sh[k], k
     assert sd["ba_runs"] >= 2
     np.testing.assert_allclose(pd, po, atol=1e-6)
     np.testing.assert_allclose(pd, ph, atol=1e-6)
+
+
+def test_map_points_created_from_frame_keypoints_on_the_device(frames, libs):
+    """vo_map_upsert_from_frame copies descriptor rows on the device: the map it builds matches like one built from fetched
+    descriptors (reference src/frontend.cpp:372-406 copies the keypoint's descriptor row into the new point)."""
+    bgr, depth, Twc, ts = frames
+    out = []
+    for L in libs:
+        for from_frame in (False, True):
+            ctx, p = make_ctx(L, n_features=700, max_frames=2, map_capacity=8192)
+            ctx.upload(0, bgr[0], depth[0]); ctx.orb(0, 1)
+            kps, desc = ctx.orb_fetch(0)
+            ok = np.nonzero(kps["depth_raw"] > 0)[0]
+            z = kps["depth_raw"][ok] / 5000.0
+            pc = np.stack([(kps["x"][ok] - p.cx) * z / p.fx, (kps["y"][ok] - p.cy) * z / p.fy, z], 1)
+            R, t = Twc[0][:9].reshape(3, 3), Twc[0][9:]
+            pw = pc @ R.T + t
+            nrm = pw - t; nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+            idx = np.arange(len(ok), dtype=np.int32)[::-1].copy()          # slots in reverse keypoint order
+            if from_frame:
+                ctx.map_upsert_from_frame(0, ok, idx, pw, nrm, np.zeros(len(ok), np.uint8))
+            else:
+                ctx.map_upsert(idx, pw, nrm, desc[ok], np.zeros(len(ok), np.uint8))
+            ctx.map_set_active(np.sort(idx))
+            ctx.upload(1, bgr[2], depth[2]); ctx.orb(1, 1)
+            m, ncand, mind = ctx.match(1, inv12(Twc[2]), 2.0, 30.0)
+            out.append((m["map_index"].copy(), m["kp_index"].copy(), m["distance"].copy(), ncand, mind))
+            ctx.close()
+    for o in out[1:]:
+        assert len(o[0]) > 200 and o[3] == out[0][3] and o[4] == out[0][4]
+        for a, b in zip(o[:3], out[0][:3]):
+            assert np.array_equal(a, b)
 
 
 def test_degenerate_frames_behave_like_the_oracle(frames, libs):

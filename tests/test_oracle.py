@@ -312,3 +312,17 @@ def test_full_observation_table_falls_back_to_the_host_graph_cut(frames, monkeyp
     assert "device observation table full" in capfd.readouterr().err
     assert sd["keyframes"] == sh["keyframes"] >= 5 and sd["ba_runs"] == sh["ba_runs"] and sd["lost"] == 0
     np.testing.assert_allclose(dev, host, atol=1e-6)
+
+
+def test_map_descriptors_kept_on_the_device_give_the_same_trajectory(frames):
+    """with map_descriptors_on_device a new map point's descriptor is copied from the frame's ORB results inside the
+    library (vo_map_upsert_from_frame) and the host never fetches descriptors; matching sees the same map, bit for bit."""
+    n = len(frames[3])
+    kw = dict(number_of_features=500, keyframe_rotation=0.02, keyframe_translation=0.02, backend_lag_frames=3, max_frames_in_flight=8, track_batch=4)
+    base, sb = run_system(ORACLE_LIB, frames, n, **kw)
+    dev, sd = run_system(ORACLE_LIB, frames, n, map_descriptors_on_device=1, **kw)
+    assert sd["keyframes"] == sb["keyframes"] >= 5 and sd["map_points"] == sb["map_points"] and sd["sum_matches"] == sb["sum_matches"]
+    assert np.array_equal(dev, base)
+    both, s2 = run_system(ORACLE_LIB, frames, n, map_descriptors_on_device=1, ba_device_graph=1, reobserve_new_mappoints=1, **kw)
+    ref2, s3 = run_system(ORACLE_LIB, frames, n, ba_device_graph=1, reobserve_new_mappoints=1, **kw)
+    assert s2["reobserved_matches"] == s3["reobserved_matches"] > 0 and np.array_equal(both, ref2)
