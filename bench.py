@@ -269,6 +269,30 @@ def main():
                    "config": "lookahead 1, track batch 1, local BA synchronous inside AddFrame (lag 0): every pose is final when AddFrame returns",
                    **accuracy(ev, capi, stamps, Twc, est_l, 0, nl)}
 
+        # ---- row a-1 alone: batched ORB detect + describe over a 32-frame look-ahead batch (the streaming, byte-moving part) ----
+        orb_only = None
+        if world == 1 and not args.no_latency_mode:
+            L = capi.load(capi.HIP_LIB)
+            F = 32
+            oc = L.context(L.default_params(width=W, height=H, n_features=N, max_frames=F))
+            for j in range(F):
+                oc.bind_device(j, bptr[j % total], 3 * W, dptr[j % total], 2 * W)
+            for _ in range(2):
+                oc.orb(0, F)
+            torch.cuda.synchronize()
+            reps = 8
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                oc.orb(0, F)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            oc.close()
+            b_orb = 5 * W * H + 4 * P + 2003 * N + 48 * N          # the ORB terms of B
+            f_orb = reps * F / dt
+            orb_only = {"frames_per_s": round(f_orb, 1), "batch_frames": F, "alg_bytes_per_frame": b_orb, "GBps_algorithmic": round(b_orb * f_orb / 1e9, 1),
+                        "hbm_frac": round(b_orb * f_orb / (HBM_PEAK_GBS * 1e9), 5),
+                        "note": "vo_orb_detect_describe on one context, frames resident in HBM, results left on the device; per-kernel figures in roofline.kernels"}
+
         # ---- several independent streams on this GPU (the roofline-relevant batched figure) ---------------
         multi = None
         if args.multi_streams and world == 1:
@@ -380,7 +404,7 @@ def main():
             "ba": {k: st[k] for k in ("ba_runs", "ba_poses", "ba_fixed", "ba_points", "ba_edges", "ba_outliers", "ba_failed", "ba_capped")},
             "avg_per_tracked_frame": {"active_map_points": round(A, 1), "candidates": round(M, 1), "matches": round(Kc, 1), "ransac_inliers": round(I, 1),
                                       "lm_iterations": round(pst["sum_lm_iters"] / tf, 2), "frames_per_launch_chain": round(tf / max(1, pst["track_launches"]), 2)},
-            "roofline": roof, "latency_mode": lat, "multi_stream": multi, "cpu_baseline": cpu,
+            "roofline": roof, "orb_only": orb_only, "latency_mode": lat, "multi_stream": multi, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     sysm.close()
