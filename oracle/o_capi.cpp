@@ -334,9 +334,9 @@ int vo_kf_set_pose(vo_ctx* c, const int32_t* kf, const double* T, int n) {
 int vo_obs_append(vo_ctx* c, const int32_t* kf, const int32_t* mp, const float* uv, int n, int64_t* first) {
     if (!c || n < 0 || (n && (!kf || !mp || !uv))) return VO_E_INVALID;
     for (int i = 0; i < n; ++i) if (kf[i] < 0 || mp[i] < 0 || mp[i] >= c->p.map_capacity) return VO_E_INVALID;
-    {   // same capacity rule as the HIP library (4 Mi observations; VO_OBS_CAP shrinks it for tests)
+    {   // same capacity rule as the HIP library (32 Mi observations; VO_OBS_CAP shrinks it for tests)
         const char* env = getenv("VO_OBS_CAP");
-        const long long cap = env && atoll(env) > 0 ? std::min<long long>(atoll(env), 4ll << 20) : (4ll << 20);
+        const long long cap = env && atoll(env) > 0 ? std::min<long long>(atoll(env), 32ll << 20) : (32ll << 20);
         if ((long long)c->obs_kf.size() + n > cap) return VO_E_OVERFLOW;
     }
     if (first) *first = (int64_t)c->obs_kf.size();

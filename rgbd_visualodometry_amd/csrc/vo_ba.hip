@@ -1767,11 +1767,16 @@ __global__ void k_cut_points(CutTabs T, const int* __restrict__ kf_idx, int* __r
     const int k = T.obs_kf[o], m = T.obs_mp[o];
     if (k < T.n_kf && m < T.map_hi && kf_idx[k] >= 0 && !(T.map_flags[m] & VO_MAP_FLAG_OUTLIER)) pt_flag[m] = 1;      // idempotent
 }
-// three-pass exclusive scan of n int32 (n <= 1024 * 1024): block sums, scan of the sums, per-block scan + offset; total -> *total_out
+// three-pass exclusive scan of n int32 (n <= 16 Mi): a workgroup covers SCAN_TILE = 1024 lanes x 16 consecutive elements; block sums,
+// scan of the (<= 1024) sums, per-block scan + offset; total -> *total_out
+#define SCAN_PER 16
+#define SCAN_TILE (1024 * SCAN_PER)
 __global__ __launch_bounds__(1024) void k_scan_blocksum(const int* __restrict__ in, int n, int* __restrict__ bsum) {
     __shared__ int s_w[16];
-    const int i = blockIdx.x * 1024 + threadIdx.x;
-    int v = i < n ? in[i] : 0;
+    const long long i0 = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_PER;
+    int v = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k) v += i0 + k < n ? in[i0 + k] : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
@@ -1790,16 +1795,20 @@ __global__ __launch_bounds__(1024) void k_scan_sums(int* __restrict__ bsum, int 
 }
 __global__ __launch_bounds__(1024) void k_scan_final(const int* __restrict__ in, int n, const int* __restrict__ bsum, int* __restrict__ out) {
     __shared__ int s_w[16];
-    const int i = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int v = i < n ? in[i] : 0;
+    const long long i0 = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_PER;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int e[SCAN_PER], v = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k) { e[k] = i0 + k < n ? in[i0 + k] : 0; v += e[k]; }
     int inc = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
     if (lane == 63) s_w[wave] = inc;
     __syncthreads();
-    int off = bsum[blockIdx.x];
+    int off = bsum[blockIdx.x] + inc - v;
     for (int w = 0; w < wave; ++w) off += s_w[w];
-    if (i < n) out[i] = off + inc - v;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k) { if (i0 + k < n) out[i0 + k] = off; off += e[k]; }
 }
 __global__ void k_cut_count(CutTabs T, const int* __restrict__ kf_idx, const int* __restrict__ pt_flag, const int* __restrict__ pidx,
                             int* __restrict__ cnt, int* __restrict__ fixed_flag) {
@@ -1949,8 +1958,8 @@ struct BaResident {
 };
 void vo_ba_resident_free(vo_ctx* c) { if (c->resident && c->resident->ev) (void)hipEventDestroy(c->resident->ev); delete c->resident; c->resident = nullptr; }
 
-static int scan_i32(hipStream_t st, const int* in, int n, int* bsum, int* out, int* total) {        // n <= 1 Mi
-    const int nb = (n + 1023) / 1024;
+static int scan_i32(hipStream_t st, const int* in, int n, int* bsum, int* out, int* total) {        // n <= 16 Mi
+    const int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (nb > 1024) return VO_E_UNSUPPORTED;
     hipLaunchKernelGGL(k_scan_blocksum, dim3(std::max(nb, 1)), dim3(1024), 0, st, in, n, bsum);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, bsum, nb, total);
@@ -1967,7 +1976,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     R.ready = false;
     const int nkf = t->n_kf, mh = std::max(t->map_hi, 1), D = 6 * nf;
     const long long no = t->n_obs;
-    if (mh >= 1024 * 1024 || nkf > 1024 * 1024) return VO_E_UNSUPPORTED;
+    if (mh >= 16 * 1024 * 1024 || nkf > 1024 * 1024) return VO_E_UNSUPPORTED;         // scan_i32's range
     if ((CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D) * sizeof(double) > 158 * 1024 || nf > 64) return VO_E_UNSUPPORTED;
     CutFree F; F.n = nf;
     for (int i = 0; i < nf; ++i) {

@@ -856,7 +856,7 @@ int vo_track_frame(vo_ctx* c, int slot, const double T0[12], const vo_track_para
 }
 
 // ---- device-resident observation table -------------------------------------------------------------------------
-#define VO_OBS_CAP (4ll << 20)      // observations (17 B each); ~2000 per keyframe
+#define VO_OBS_CAP (32ll << 20)     // observations (17 B each, 544 MB); ~2000 per keyframe: ~50 000 frames at a keyframe every 3 frames
 #define VO_KF_CAP 65536             // keyframes (96 B each)
 static int vo_obs_tables_ensure(vo_ctx* c) {     // allocates the observation / keyframe tables on first use
     if (c->d_obs_kf) return VO_OK;

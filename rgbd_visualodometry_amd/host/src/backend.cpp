@@ -78,6 +78,10 @@ void Backend::Finish() {
     stats_.ms_wait += ms_since(t0);
     std::unique_ptr<Job> j = std::move(job_);
     if (j->rc != VO_OK) {                            // a failed solve must not end the stream: the map keeps its un-optimised state
+        if (j->resident && deviceGraph_ && (j->rc == VO_E_UNSUPPORTED || j->rc == VO_E_OVERFLOW || j->rc == VO_E_NOMEM)) {
+            std::cerr << "[myslam] device graph cut unavailable (" << vo_strerror(j->rc) << "): local BA graphs are cut on the host from here on" << std::endl;
+            deviceGraph_ = false;
+        }
         if (stats_.failed++ == 0) std::cerr << "[myslam] vo_local_ba failed (" << vo_strerror(j->rc) << "): this local BA is skipped, tracking continues" << std::endl;
         return;
     }

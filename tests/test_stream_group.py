@@ -251,14 +251,14 @@ def test_hypothesis_shard_equals_unsharded_ransac(libs, streams):
     ctx.close()
 
 
-def _resident_scene(L, rng, n_kf=9, n_pts=400, n_free=4, young=False, seen_mod=100):
+def _resident_scene(L, rng, n_kf=9, n_pts=400, n_free=4, young=False, seen_mod=100, slot_range=None):
     """Keyframes and map points with a sliding visibility pattern, loaded into the observation table and the map of a context."""
     import ref_model as rm
-    p = L.default_params(n_features=64, map_capacity=4096)
+    p = L.default_params(n_features=64, map_capacity=max(4096, (slot_range or 0)))
     t = L.context(p)
     Ts = [rm.se3_exp(np.concatenate([rng.normal(0, 0.25, 3) + [0.12 * (k % 40), 0, 0], rng.normal(0, 0.05, 3)])) for k in range(n_kf)]
     X = rng.uniform(-1.5, 1.5, (n_pts, 3)) + [0.5, 0, 5]
-    slots = rng.permutation(n_pts if young else max(2000, n_pts + 500))[:n_pts].astype(np.int32)   # map slots in arbitrary order, with holes unless young
+    slots = rng.permutation(n_pts if young else (slot_range or max(2000, n_pts + 500)))[:n_pts].astype(np.int32)   # map slots in arbitrary order, with holes unless young
     flags = (rng.random(n_pts) < (0 if young else 0.04)).astype(np.uint8)        # a few outliers
     X0 = X + rng.normal(0, 0.01, X.shape)
     t.map_upsert(slots, X0, np.tile([0, 0, 1.0], (n_pts, 1)), np.zeros((n_pts, 32), np.uint8), flags)
@@ -298,7 +298,7 @@ def test_resident_graph_cut_follows_backend_cpp(libs, shape):
     elif shape == "wide":
         sc = _resident_scene(L, rng, n_kf=140, n_pts=900, n_free=64)
     elif shape == "long":
-        sc = _resident_scene(L, rng, n_kf=1300, n_pts=600, n_free=5, seen_mod=700)
+        sc = _resident_scene(L, rng, n_kf=1300, n_pts=600, n_free=5, seen_mod=700, slot_range=60000)     # map slots over several scan tiles
     else:
         sc = _resident_scene(L, rng)
     t, Ts, X, slots, flags, obs, dead, free = sc
