@@ -154,7 +154,7 @@ int main() {
         hipMemcpy(d_S0, S.data(), sizeof(double) * D * D, hipMemcpyHostToDevice);
         hipMemcpy(d_b0, b.data(), sizeof(double) * D, hipMemcpyHostToDevice);
         BaDev* d_B; hipMalloc(&d_B, sizeof(BaDev)); hipMemcpy(d_B, &B, sizeof(BaDev), hipMemcpyHostToDevice);
-        BaBatch Q; memset(&Q, 0, sizeof(Q)); Q.Bs = d_B; Q.n = 1;
+        BaBatch Q; memset(&Q, 0, sizeof(Q)); Q.Bs = d_B; Q.ctls = B.ctl; Q.n = 1;
         for (int variant = 1; variant < 2; ++variant) {
             float tot = 0; const int reps = 50;
             for (int it = 0; it < reps + 5; ++it) {

@@ -63,11 +63,13 @@ struct BaDev {
 // kernel sequence, each with its own state, control block and sizes; grids are sized for the largest problem and every
 // kernel trims to its own problem's extent.
 #define BA_SLOTS 16
-struct BaBatch { const BaDev* Bs; int n; int slot[BA_SLOTS]; };
-#define BA_PROBLEM(Q) const BaDev& B = Q.Bs[Q.slot[blockIdx.z]];
+// ctls: the engine's control blocks, indexed by slot like Bs -- a kernel reads its control block straight from the argument
+// (B.ctl holds the same address, but behind a dependent load of the descriptor: one memory latency more at every kernel start)
+struct BaBatch { const BaDev* Bs; BaCtl* ctls; int n; int slot[BA_SLOTS]; };
+#define BA_PROBLEM(Q) const BaDev& B = Q.Bs[Q.slot[blockIdx.z]]; BaCtl* const ctl_ = Q.ctls + Q.slot[blockIdx.z];
 
 #define BA_STATE(B) \
-    const int buf_ = B.ctl->buf; \
+    const int buf_ = ctl_->buf; \
     double* const poses_c = buf_ ? B.posesB : B.posesA; double* const pts_c = buf_ ? B.ptsB : B.ptsA; \
     double* const poses_t = buf_ ? B.posesA : B.posesB; double* const pts_t = buf_ ? B.ptsA : B.ptsB; \
     (void)poses_c; (void)pts_c; (void)poses_t; (void)pts_t;
@@ -151,7 +153,7 @@ __device__ __forceinline__ void ba_fold_zero(const BaDev& B, int blk, int nblk) 
     for (int i = blk * 256 + threadIdx.x; i < n; i += nblk * 256) B.S[i] = 0.0;
     for (int i = blk * 256 + threadIdx.x; i < B.D; i += nblk * 256) B.bs[i] = 0.0;
 }
-__device__ __forceinline__ void ba_lin_points_body(const BaCam& cam, const BaDev& B, int robust, double delta, int blk,
+__device__ __forceinline__ void ba_lin_points_body(const BaCam& cam, const BaDev& B, const BaCtl* ctl_, int robust, double delta, int blk,
                                                    const double* poses_c, const double* pts_c, double* s_part) {
     const int k = blk * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
     double chi[1] = {0.0};
@@ -187,9 +189,9 @@ __device__ __forceinline__ void ba_lin_points_body(const BaCam& cam, const BaDev
         Ho[0] = H[0]; Ho[1] = H[1]; Ho[2] = H[2]; Ho[3] = H[1]; Ho[4] = H[3]; Ho[5] = H[4]; Ho[6] = H[2]; Ho[7] = H[4]; Ho[8] = H[5];
         B.bl[3 * (size_t)k] = b3[0]; B.bl[3 * (size_t)k + 1] = b3[1]; B.bl[3 * (size_t)k + 2] = b3[2];
         // folded init: lambda of this step is known unless this is the first step of a round (then k_ba_init_S follows k_ba_maxdiag)
-        if (B.D <= BA_FOLD_D && !B.ctl->first) {
+        if (B.D <= BA_FOLD_D && !ctl_->first) {
             const double Hs[9] = {H[0], H[1], H[2], H[1], H[3], H[4], H[2], H[4], H[5]};
-            ba_inv3_damped(Hs, B.ctl->lambda, B.Hinv + 9 * (size_t)k);
+            ba_inv3_damped(Hs, ctl_->lambda, B.Hinv + 9 * (size_t)k);
         }
     }
     if (B.D <= BA_FOLD_D) ba_fold_zero(B, blk, B.gp);
@@ -247,25 +249,25 @@ __device__ __forceinline__ void ba_lin_poses_body(const BaCam& cam, const BaDev&
 
 __global__ __launch_bounds__(256) void k_ba_lin(BaBatch Q) {
     BA_PROBLEM(Q)
-    if (B.ctl->finished) return;
-    if (!B.ctl->need_lin) {                                 // a rejected step is solved again at the same linearisation with a larger lambda
+    if (ctl_->finished) return;
+    if (!ctl_->need_lin) {                                 // a rejected step is solved again at the same linearisation with a larger lambda
         if (B.D <= BA_FOLD_D && (int)blockIdx.x < B.gp) {
             const int k = blockIdx.x * 64 + (threadIdx.x >> 2);
-            if (k < B.n_points && (threadIdx.x & 3) == 0) ba_inv3_damped(B.Hll + 9 * (size_t)k, B.ctl->lambda, B.Hinv + 9 * (size_t)k);
+            if (k < B.n_points && (threadIdx.x & 3) == 0) ba_inv3_damped(B.Hll + 9 * (size_t)k, ctl_->lambda, B.Hinv + 9 * (size_t)k);
             ba_fold_zero(B, blockIdx.x, B.gp);
         }
         return;
     }
     BA_STATE(B)
     __shared__ double s_part[4 * 32];
-    const int gp = B.gp, robust = B.ctl->robust;
-    if ((int)blockIdx.x < gp) ba_lin_points_body(B.cam, B, robust, B.delta, blockIdx.x, poses_c, pts_c, s_part);
+    const int gp = B.gp, robust = ctl_->robust;
+    if ((int)blockIdx.x < gp) ba_lin_points_body(B.cam, B, ctl_, robust, B.delta, blockIdx.x, poses_c, pts_c, s_part);
     else if ((int)blockIdx.x - gp < B.n_free * PSPLIT) ba_lin_poses_body(B.cam, B, robust, B.delta, blockIdx.x - gp, poses_c, pts_c, s_part);
 }
 
 __global__ void k_ba_maxdiag(BaBatch Q) {
     BA_PROBLEM(Q)
-    if (B.ctl->finished || !B.ctl->need_lin || !B.ctl->first) return;
+    if (ctl_->finished || !ctl_->need_lin || !ctl_->first) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     double v = 0;
     if (i < B.D) v = fabs(B.Hpp[36 * (size_t)(i / 6) + 7 * (i % 6)]);
@@ -280,12 +282,12 @@ __global__ void k_ba_maxdiag(BaBatch Q) {
 // D <= BA_FOLD_D: only the first step of a round, and only the inverses (lambda comes from k_ba_maxdiag just before).
 __global__ void k_ba_init_S(BaBatch Q) {
     BA_PROBLEM(Q)
-    if (B.ctl->finished) return;
-    const bool fold = B.D <= BA_FOLD_D, first = B.ctl->need_lin && B.ctl->first;
+    if (ctl_->finished) return;
+    const bool fold = B.D <= BA_FOLD_D, first = ctl_->need_lin && ctl_->first;
     if (fold && !first) return;
     // first step of a round: lambda = 1e-5 * max diag(H) (g2o computeLambdaInit); the control block is updated later in
     // this step by the Cholesky kernel, so every lane derives the same value here
-    const double lambda = first ? 1e-5 * B.scal[4] : B.ctl->lambda;
+    const double lambda = first ? 1e-5 * B.scal[4] : ctl_->lambda;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (!fold && i < B.D * B.D) {
         const int r = i / B.D, c = i % B.D;
@@ -367,7 +369,7 @@ __device__ __forceinline__ void ba_schur_slice(const BaDev& B, const BaBlock blk
 }
 __global__ __launch_bounds__(256) void k_ba_schur_blocks(BaBatch Q) {
     BA_PROBLEM(Q)
-    if (B.ctl->finished) return;
+    if (ctl_->finished) return;
     __shared__ double s_part[4 * 42];
     __shared__ double s_tot[42];
     if ((int)blockIdx.x >= B.n_blocks || (B.n_slices && (int)blockIdx.x >= *B.n_slices)) return;
@@ -603,7 +605,7 @@ __device__ __forceinline__ bool ch_factor_block(double (&a)[CH_NB], double* s_L,
 
 __global__ __launch_bounds__(CH_THREADS) void k_ba_chol16(BaBatch Q) {
     BA_PROBLEM(Q)
-    if (B.ctl->finished || B.D > 192) return;                   // larger systems: k_ba_chol16g
+    if (ctl_->finished || B.D > 192) return;                   // larger systems: k_ba_chol16g
     extern __shared__ double s_mem[];
     const int D = B.D, DA = D + 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15;
     const double* const A = B.S;
@@ -623,7 +625,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_ba_chol16(BaBatch Q) {
     // the Schur kernel accumulated -sum W H^-1 W^T into a zeroed S: blockdiag(H_pp) + lambda I and b_p join while the system is
     // loaded (no separate init launch).  Every lane derives this step's lambda the way k_ba_init_S does; the control block is
     // taken over only after the barrier below, when nobody reads it any more.
-    const double lambda = (B.ctl->need_lin && B.ctl->first) ? 1e-5 * B.scal[4] : B.ctl->lambda;
+    const double lambda = (ctl_->need_lin && ctl_->first) ? 1e-5 * B.scal[4] : ctl_->lambda;
     const double* const Hpp = B.Hpp;
     auto extra = [&](int r, int c) -> double {              // entry (r, c) of blockdiag(H_pp) + lambda I
         const double h = Hpp[36 * (size_t)(r / 6) + 6 * (r % 6) + (c % 6)];     // always in range; used only inside the block
@@ -670,7 +672,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_ba_chol16(BaBatch Q) {
     }
     __syncthreads();
     if (tid == 0) {
-        BaCtl* c = B.ctl;                               // take over the fresh linearisation, clear the trial sums
+        BaCtl* c = ctl_;                               // take over the fresh linearisation, clear the trial sums
         if (c->need_lin) {
             c->cur = B.scal[0];
             if (c->first) { c->lambda = lambda; c->ni = 2; c->first = 0; }
@@ -878,7 +880,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_ba_chol16(BaBatch Q) {
 #define CHG_TB 8
 __global__ __launch_bounds__(CH_THREADS) void k_ba_chol16g(BaBatch Q) {
     BA_PROBLEM(Q)
-    if (B.ctl->finished || B.D <= 192) return;
+    if (ctl_->finished || B.D <= 192) return;
     extern __shared__ double s_mem[];
     const int D = B.D, DA = D + 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15;
     double* const S = B.S;              // plain accesses: the waves of one workgroup share the CU's L1, barriers order them
@@ -891,7 +893,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_ba_chol16g(BaBatch Q) {
     __shared__ double s_pinv[CH_NB];
     if (tid == 0) {
         s_ok = 1;
-        BaCtl* c = B.ctl;                               // take over the fresh linearisation, clear the trial sums
+        BaCtl* c = ctl_;                               // take over the fresh linearisation, clear the trial sums
         if (c->need_lin) {
             c->cur = B.scal[0];
             if (c->first) { c->lambda = 1e-5 * B.scal[4]; c->ni = 2; c->first = 0; }
@@ -1129,8 +1131,8 @@ __device__ __forceinline__ void ba_pose_body(const BaDev& B, double lambda, int 
 // trial state: new points (blocks [0, gp)) and new poses (blocks [gp, ...)), gain-ratio terms, max |step|
 __global__ void k_ba_update(BaBatch Q) {
     BA_PROBLEM(Q)
-    if (B.ctl->finished) return;
-    const double lambda = B.ctl->lambda;
+    if (ctl_->finished) return;
+    const double lambda = ctl_->lambda;
     BA_STATE(B)
     const int gp = B.gp;
     if ((int)blockIdx.x < gp) ba_backsub_body(B, lambda, blockIdx.x, pts_c, pts_t);
@@ -1140,7 +1142,7 @@ __global__ void k_ba_update(BaBatch Q) {
 // chi2 of the current (trial = 0 -> scal[5]) or trial (-> scal[1]) state
 __global__ void k_ba_chi(BaBatch Q, int trial, int robust, int guard) {
     BA_PROBLEM(Q)
-    if (guard && B.ctl->finished) return;
+    if (guard && ctl_->finished) return;
     const BaCam cam = B.cam; const double delta = B.delta;
     BA_STATE(B)
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1164,10 +1166,10 @@ __global__ void k_ba_chi(BaBatch Q, int trial, int robust, int guard) {
 // taken after a device-scope fence (threadfence reduction).
 __global__ __launch_bounds__(256) void k_ba_chi_control(BaBatch Q) {
     BA_PROBLEM(Q)
-    if (B.ctl->finished) return;
+    if (ctl_->finished) return;
     const int nblk_e = (B.n_edges + 1023) / 1024;               // this problem's share of the grid: 4 edges per lane (a quarter of the workgroups = a quarter of the arrival atomics)
     if ((int)blockIdx.x >= nblk_e) return;
-    const BaCam cam = B.cam; const double delta = B.delta; const int robust = B.ctl->robust;
+    const BaCam cam = B.cam; const double delta = B.delta; const int robust = ctl_->robust;
     BA_STATE(B)
     __shared__ int s_last;
     double v = 0;
@@ -1188,7 +1190,7 @@ __global__ __launch_bounds__(256) void k_ba_chi_control(BaBatch Q) {
     if (threadIdx.x == 0) {
         B.partC[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);       // one partial per workgroup, no same-address atomics
         __threadfence();
-        s_last = atomicAdd(&B.ctl->arrived, 1) == nblk_e - 1;
+        s_last = atomicAdd(&ctl_->arrived, 1) == nblk_e - 1;
     }
     __syncthreads();
     if (!s_last) return;
@@ -1206,7 +1208,7 @@ __global__ __launch_bounds__(256) void k_ba_chi_control(BaBatch Q) {
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        BaCtl* c = B.ctl;
+        BaCtl* c = ctl_;
         c->arrived = 0;
         const double s1 = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
         const double s2 = atomicAdd(&B.scal[2], 0.0) + ((s_w[4] + s_w[5]) + (s_w[6] + s_w[7])), s3 = atomicAdd(&B.scal[3], 0.0);
@@ -1305,7 +1307,7 @@ static std::mutex g_eng_mu;
 static std::vector<BaEngine*> g_engines;
 
 static BaBatch ba_batch_of(BaEngine* E, const int* slots, int n) {
-    BaBatch Q; Q.Bs = E->d_Bs; Q.n = n;
+    BaBatch Q; Q.Bs = E->d_Bs; Q.ctls = E->d_ctl; Q.n = n;
     for (int i = 0; i < BA_SLOTS; ++i) Q.slot[i] = i < n ? slots[i] : 0;
     return Q;
 }
