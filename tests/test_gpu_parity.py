@@ -126,12 +126,13 @@ def synth_corr(rng, n, outlier_frac, p, noise=0.3):
     return X.astype(np.float32), uv.astype(np.float32), np.concatenate([R.ravel(), t])
 
 
-@pytest.mark.parametrize("n,n_hyp,outl", [(300, 100, 0.3), (2000, 256, 0.5), (40, 64, 0.1), (5, 16, 0.0)])
+# the last case is BASELINE config 5 / 3 scale: 28 000 matches scored by 2048 hypotheses
+@pytest.mark.parametrize("n,n_hyp,outl", [(300, 100, 0.3), (2000, 256, 0.5), (40, 64, 0.1), (5, 16, 0.0), (28000, 2048, 0.4)])
 def test_ransac_counts_bit_exact_and_lm_close(libs, n, n_hyp, outl):
     rng = np.random.default_rng(n)
     out = []
     for L in libs:
-        ctx, p = make_ctx(L, map_capacity=4096)
+        ctx, p = make_ctx(L, map_capacity=max(4096, n + 64), max_hypotheses=max(2048, n_hyp))
         X, uv, Tgt = synth_corr(np.random.default_rng(n), n, outl, p)
         ctx.matches_set(X, uv)
         T, inl, counts, iters, best = ctx.pnp_ransac(IDENT, n_hyp=n_hyp, seed=77)
@@ -203,7 +204,7 @@ def test_config5_sizes_orb_and_tracking_match_oracle(libs):
 # D = 6 nfree: 24 (one 16-column panel + partial), 96 (full panels only), 180 (partial last panel), 192 (LDS-resident limit),
 # 216 (> limit: matrix in L2); 1300 points -> > 20000 edges (threaded pair-list build); shuffle: edges not sorted by point
 @pytest.mark.parametrize("nP,nX,nfree,shuffle", [(6, 400, 4, False), (18, 300, 16, False), (34, 500, 30, False), (34, 300, 32, True),
-                                                  (40, 500, 36, False), (34, 1300, 30, False)])
+                                                  (40, 500, 36, False), (34, 1300, 30, False), (26, 9000, 21, False)])      # last: config-5 scale, ~160 k edges
 def test_local_ba_matches_oracle(libs, nP, nX, nfree, shuffle):
     rng = np.random.default_rng(5)
 
@@ -241,6 +242,7 @@ def test_local_ba_matches_oracle(libs, nP, nX, nfree, shuffle):
     for L in (H, O):
         ctx, _ = make_ctx(L, map_capacity=1024)
         res.append(ctx.local_ba(poses0, nfree, X0, ep, el, np.array(uv, dtype=np.float32)))
+        ctx.close()
     (ph, xh, fh, rh), (po, xo, fo, ro) = res
     # the gain-ratio test near convergence is noise-limited: one LM iteration more or less is legitimate
     assert abs(rh.lm_iters - ro.lm_iters) <= (0 if nfree < 10 else 2)
