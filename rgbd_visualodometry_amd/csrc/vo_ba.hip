@@ -1211,8 +1211,12 @@ __global__ __launch_bounds__(256) void k_ba_chi_control(BaBatch Q) {
         BaCtl* c = ctl_;
         c->arrived = 0;
         const double s1 = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
-        const double s2 = atomicAdd(&B.scal[2], 0.0) + ((s_w[4] + s_w[5]) + (s_w[6] + s_w[7])), s3 = atomicAdd(&B.scal[3], 0.0);
-        const double m7 = fmax(__longlong_as_double((long long)atomicAdd((unsigned long long*)&B.scal[7], 0ull)), fmax(fmax(s_w[8], s_w[9]), fmax(s_w[10], s_w[11])));
+        // scal[2], [3], [7] were written by earlier kernels of this step (k_ba_update's pose part, the Cholesky kernel): plain loads,
+        // issued together -- three dependent atomic round trips here were a third of this kernel's time
+        const volatile double* sc = B.scal;
+        const double sc2 = sc[2], s3 = sc[3], sc7 = sc[7];
+        const double s2 = sc2 + ((s_w[4] + s_w[5]) + (s_w[6] + s_w[7]));
+        const double m7 = fmax(sc7, fmax(fmax(s_w[8], s_w[9]), fmax(s_w[10], s_w[11])));
         const unsigned long long s7 = (unsigned long long)__double_as_longlong(m7);
         const bool ok = s3 != 0.0;
         const double tmp = ok ? s1 : DBL_MAX;
