@@ -77,6 +77,15 @@ def test_run_vo_on_gpu_matches_oracle_driver(tum_dir, tmp_path):
     pc = np.array([[float(v) for v in c[k]] for k in sorted(c)])
     # same trajectory up to the summation order of the local BA's f64 atomics (run-to-run differences of ~1e-9 on the GPU)
     np.testing.assert_allclose(pc, pa, atol=1e-7)
+    # SURVEY 8f-2 through the driver: observation table, BA graph cut and map descriptors on the device, overlapped back-end
+    (tmp_path / "dv").mkdir(); (tmp_path / "do").mkdir()
+    dev = dict(number_of_features=800, lookahead_frames=8, decode_threads=4, track_batch=4, backend_lag_frames=3, ba_device_graph=1, map_descriptors_on_device=1)
+    e, _ = run_driver(HIP_BIN, root, str(tmp_path / "dv"), **dev)
+    f, _ = run_driver(ORACLE_BIN, root, str(tmp_path / "do"), **dev)
+    check(e, root)
+    pe = np.array([[float(v) for v in e[k]] for k in sorted(e)])
+    pf = np.array([[float(v) for v in f[k]] for k in sorted(f)])
+    np.testing.assert_allclose(pe, pf, atol=2e-5)
     (tmp_path / "n1").mkdir(); (tmp_path / "n2").mkdir()
     d1, _ = run_driver(HIP_BIN, root, str(tmp_path / "n1"), number_of_features=800, enable_local_optimization=0)
     d2, _ = run_driver(HIP_BIN, root, str(tmp_path / "n2"), number_of_features=800, enable_local_optimization=0, lookahead_frames=8, decode_threads=4, track_batch=4)
