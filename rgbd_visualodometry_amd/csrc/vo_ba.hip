@@ -45,6 +45,7 @@ struct BaCtl {
 struct BaDev {
     int n_poses, n_free, n_points, n_edges, D, n_blocks;
     int gp;                                                  // point workgroups of the 4-lanes-per-point kernels (64 points each)
+    int edges_by_point;                                      // 1: the edges are grouped by point, pt_edges is the identity
     BaCam cam; double delta, chi2_th;
     BaCtl* ctl;
     double* posesA; double* ptsA; double* posesB; double* ptsB;      // double-buffered state, ctl->buf selects the current one
@@ -603,12 +604,36 @@ __device__ __forceinline__ bool ch_factor_block(double (&a)[CH_NB], double* s_L,
     return ok;
 }
 
-__global__ __launch_bounds__(CH_THREADS) void k_ba_chol16(BaBatch Q) {
-    BA_PROBLEM(Q)
-    if (ctl_->finished || B.D > 192) return;                   // larger systems: k_ba_chol16g
-    extern __shared__ double s_mem[];
-    const int D = B.D, DA = D + 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15;
-    const double* const A = B.S;
+// 16-byte write-through (sc1) store: the line leaves this XCD's L2, so a later remote atomic / a later load after an acquire sees
+// memory, not a stale copy (persistent LM kernel: the solver workgroup clears S behind its own load)
+__device__ __forceinline__ void ba_st16_sc1(double* p, double a, double b) {
+    typedef double f64x2_ __attribute__((ext_vector_type(2)));
+    const f64x2_ v = {a, b};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+}
+// PB = false: the body of k_ba_chol16 (launch-per-phase path).  PB = true: the solver workgroup of the persistent LM kernel
+// (k_ba_persist): lambda comes from the caller, the control block is not touched, S / b_s are cleared behind the load (write-through:
+// they are the targets of the next step's Schur atomics) and the solution goes to x_out with write-through stores.
+template <bool PB>
+__device__ __forceinline__ bool ba_chol16_body(const BaDev& B, BaCtl* ctl_, double lambda_in, double* s_mem, double* x_out) {
+    int D_ = B.D;
+    // inside the persistent kernel's step loop everything derived from D and the LDS base is loop invariant; hoisted out of the loop it
+    // stays live across the whole kernel and spills: the values are laundered so that they are recomputed per call
+    int tid_ = threadIdx.x;
+    const double* A_ = B.S;
+    if (PB) {
+        // the LDS base is laundered as an address_space(3) pointer: through a generic pointer the compiler would lose the address
+        // space and fall back to flat_load / flat_store for every LDS access of the factorisation
+        typedef __attribute__((address_space(3))) double lds_f64;
+        typedef __attribute__((address_space(1))) const double glb_f64;
+        lds_f64* sm3 = (lds_f64*)s_mem;
+        glb_f64* a1 = (glb_f64*)A_;
+        asm volatile("" : "+s"(D_), "+s"(sm3), "+s"(a1));
+        asm volatile("" : "+v"(tid_));
+        s_mem = (double*)sm3; A_ = (const double*)a1;
+    }
+    const int D = D_, DA = D + 1, tid = tid_, lane = tid & 63, wave = tid >> 6, r16 = lane & 15;
+    const double* const A = A_;
     double* const s_dg = s_mem;                                 // [16][16] factored diagonal block, transposed, 1/L[k][k] on the diagonal
     double* const s_L = s_mem + CH_NB * CH_NB;                  // packed lower triangle of [S b; b^T 0]
     double* const s_b = s_L + TRI32(DA, 0);                       // y, then x
@@ -625,7 +650,8 @@ __global__ __launch_bounds__(CH_THREADS) void k_ba_chol16(BaBatch Q) {
     // the Schur kernel accumulated -sum W H^-1 W^T into a zeroed S: blockdiag(H_pp) + lambda I and b_p join while the system is
     // loaded (no separate init launch).  Every lane derives this step's lambda the way k_ba_init_S does; the control block is
     // taken over only after the barrier below, when nobody reads it any more.
-    const double lambda = (ctl_->need_lin && ctl_->first) ? 1e-5 * B.scal[4] : ctl_->lambda;
+    double lambda = lambda_in;
+    if (!PB) lambda = (ctl_->need_lin && ctl_->first) ? 1e-5 * B.scal[4] : ctl_->lambda;
     const double* const Hpp = B.Hpp;
     auto extra = [&](int r, int c) -> double {              // entry (r, c) of blockdiag(H_pp) + lambda I
         const double h = Hpp[36 * (size_t)(r / 6) + 6 * (r % 6) + (c % 6)];     // always in range; used only inside the block
@@ -658,6 +684,16 @@ __global__ __launch_bounds__(CH_THREADS) void k_ba_chol16(BaBatch Q) {
             if (c1 <= r) dst[c1] = v1.x;
             if (c1 + 1 <= r) dst[c1 + 1] = v1.y;
         }
+        if (PB) {
+            // clear the loaded part of every row for the next step's atomics: a sweep of its own (the asm stores are memory barriers
+            // to the compiler: inside the load loop they would keep the next rows' loads from being issued ahead)
+            for (int r = CH_NB + wave - 1; r < D; r += CH_THREADS / 64 - 1) {
+                double* gr = const_cast<double*>(A) + (size_t)r * D;
+                const int c0 = 2 * lane, c1 = 2 * lane + 128, last = (D >> 1) - 1;
+                if (c0 <= r) ba_st16_sc1(gr + c0, 0.0, 0.0);
+                if (c1 <= r && lane + 64 <= last) ba_st16_sc1(gr + c1, 0.0, 0.0);
+            }
+        }
         // the 6x6 diagonal block of row r (columns 6 (r / 6) .. r) joins in a second sweep over this wave's rows: 6 lanes per row,
         // 10 rows at a time (LDS accesses of one wave are ordered, so no barrier is needed behind the loop above)
         if (lane < 60)
@@ -667,11 +703,18 @@ __global__ __launch_bounds__(CH_THREADS) void k_ba_chol16(BaBatch Q) {
                 const int c = 6 * (r / 6) + lane % 6;
                 if (c <= r) s_L[TRI32(r, c)] += extra(r, c);
             }
-        for (int i = tid - 64; i < D; i += CH_THREADS - 64) s_L[TRI32(D, i)] = B.bs[i] + B.bp[i];
+        for (int i = tid - 64; i < D; i += CH_THREADS - 64) {
+            s_L[TRI32(D, i)] = B.bs[i] + B.bp[i];
+            if (PB) __hip_atomic_store(B.bs + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (tid == 64) s_L[TRI32(D, D)] = 0.0;
     }
     __syncthreads();
-    if (tid == 0) {
+    if (PB && wave == 0 && lane < 16) {                        // rows 0..15 were read by wave 0 (their factorisation is done by now)
+        const int nb0 = min(CH_NB, D);
+        if (lane < nb0) { double* gr = const_cast<double*>(A) + (size_t)lane * D; for (int c = 0; c <= lane; c += 2) ba_st16_sc1(gr + c, 0.0, 0.0); }
+    }
+    if (!PB && tid == 0) {
         BaCtl* c = ctl_;                               // take over the fresh linearisation, clear the trial sums
         if (c->need_lin) {
             c->cur = B.scal[0];
@@ -863,13 +906,22 @@ __global__ __launch_bounds__(CH_THREADS) void k_ba_chol16(BaBatch Q) {
             __syncthreads();
             CH_STAMP(9)
         }
-        for (int i = tid; i < D; i += CH_THREADS) B.bs[i] = s_b[i];
+        if (PB) { for (int i = tid; i < D; i += CH_THREADS) __hip_atomic_store(x_out + i, s_b[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        else { for (int i = tid; i < D; i += CH_THREADS) x_out[i] = s_b[i]; }
     }
-    if (tid == 0) B.scal[3] = s_ok ? 1.0 : 0.0;
+    if (!PB && tid == 0) B.scal[3] = s_ok ? 1.0 : 0.0;
 #ifdef CH_STAMPS
     CH_STAMP(10)
     if (tid == 0) for (int i = 0; i < 12; ++i) B.dl[i] = (double)t_[i];
 #endif
+    return s_ok != 0;
+}
+
+__global__ __launch_bounds__(CH_THREADS) void k_ba_chol16(BaBatch Q) {
+    BA_PROBLEM(Q)
+    if (ctl_->finished || B.D > 192) return;                   // larger systems: k_ba_chol16g
+    extern __shared__ double s_mem[];
+    (void)ba_chol16_body<false>(B, ctl_, 0.0, s_mem, B.bs);
 }
 
 // ---- k_ba_chol16g: the same 16-column scheme for D > 192, where the packed triangle no longer fits in LDS -----------
@@ -1261,10 +1313,13 @@ __global__ void k_ba_cull(BaBatch Q, int stage) {
     else if (B.active[e]) { if (c2 > th) B.flags[e] |= 2; else atomicAdd(&B.scal[6], c2); }
 }
 
+#include "vo_ba_persist.h"
+
 // per-device function attributes (vo_ctx_create calls this with the context's device current)
 int vo_ba_set_attrs() {
     HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol16, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol16g, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_ba_persist, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     return VO_OK;
 }
 
@@ -1523,6 +1578,106 @@ void vo_ba_engine_release(BaEngine* E) {
     for (int k = E->n_sib - 1; k >= 0; --k) if (E->sib[k]) ba_engine_free(E->sib[k]);      // sib[0] is E itself
 }
 
+// ---- persistent path: one launch per local BA (vo_ba_persist.h) -------------------------------------------------------------------
+// Every workgroup of a persistent launch spins on its peers, so all of them must be resident at once: a launch takes its
+// workgroups out of a per-device budget (VO_BA_WG_BUDGET, default 224 of the 256 compute units -- the dynamic LDS keeps it at
+// one workgroup per unit) and waits when the budget is spent.  Launches of different contexts run on their own streams and
+// advance independently: no lock-step over problems, no chunk of steps to wait for.
+#define PB_MAX_DEV 16
+#define PB_G_CAP 256
+static struct PbBudget { std::mutex mu; std::condition_variable cv; int free_wg[PB_MAX_DEV]; bool init = false; int total = 224, gmax = 128, on = 1; } g_pb;
+static void pb_budget_init() {
+    if (g_pb.init) return;
+    if (const char* e = getenv("VO_BA_WG_BUDGET")) g_pb.total = std::max(2, std::min(PB_G_CAP, atoi(e)));
+    if (const char* e = getenv("VO_BA_GROUP")) g_pb.gmax = std::max(2, std::min(PB_G_CAP, atoi(e)));
+    if (const char* e = getenv("VO_BA_PERSIST")) g_pb.on = atoi(e);
+    g_pb.gmax = std::min(g_pb.gmax, g_pb.total);
+    for (int d = 0; d < PB_MAX_DEV; ++d) g_pb.free_wg[d] = g_pb.total;
+    g_pb.init = true;
+}
+static size_t pb_lds_bytes(const BaDev& B) {
+    const size_t chol = sizeof(double) * (CH_NB * CH_NB + (size_t)(B.D + 1) * (B.D + 2) / 2 + 2 * (size_t)B.D);
+    const size_t work = sizeof(double) * (8 * 96 + 24 * (size_t)B.n_poses + (size_t)B.D + 2) + pb_tab_bytes();
+    return std::max(chol, work);
+}
+static bool ba_persist_ok(vo_ctx* c, const BaDev& B) {
+    std::unique_lock<std::mutex> lk(g_pb.mu);
+    pb_budget_init();
+    return g_pb.on && c->device < PB_MAX_DEV && B.D <= 192 && B.n_free <= 32 && B.edges_by_point && pb_lds_bytes(B) <= 158 * 1024 &&
+           (long long)B.n_edges / (g_pb.gmax - 1) + B.n_poses + 64 <= PB_ECAP;
+}
+void vo_ba_persist_free(vo_ctx* c) {
+    if (c->d_pb) (void)hipFree(c->d_pb);
+    if (c->h_pb) (void)hipHostFree(c->h_pb);
+    c->d_pb = nullptr; c->h_pb = nullptr;
+}
+static int ba_persist_solve(vo_ctx* c, BaJob* j) {
+    hipStream_t st = c->stream;
+    const BaDev& B = j->B;
+    // per-context block: [counters | part | hpart | rec | dp | mail]
+    const size_t o_sync = 0, o_part = 1024, o_hpart = o_part + sizeof(double) * PB_P_N * PB_G_CAP, o_rec = o_hpart + sizeof(double) * 32 * PB_PS * PB_HP,
+                 o_dp = o_rec + 64, o_mail = o_dp + sizeof(double) * 192, total = o_mail + 256;
+    if (!c->d_pb) {
+        if (hipMalloc(&c->d_pb, total) != hipSuccess) { c->d_pb = nullptr; return VO_E_NOMEM; }
+        if (hipHostMalloc((void**)&c->h_pb, 256, hipHostMallocDefault) != hipSuccess) { c->h_pb = nullptr; return VO_E_NOMEM; }
+    }
+    uint8_t* pb = (uint8_t*)c->d_pb;
+    // workgroups: about 256 edges per worker, at least 8, at most what the budget has left (never less than a quarter of the wish)
+    int want, G;
+    {
+        std::unique_lock<std::mutex> lk(g_pb.mu);
+        want = std::max(8, std::min(g_pb.gmax, B.n_edges / 256 + 2));
+        // a worker's edge table holds PB_ECAP edges: its share is n_edges / (G - 1) plus at most one point's edges (<= n_poses)
+        const int need = (int)((long long)B.n_edges / std::max(1, PB_ECAP - B.n_poses - 64)) + 2;
+        want = std::max(want, need);
+        const int least = std::max(std::max(4, want / 4), need);
+        while (g_pb.free_wg[c->device] < least) g_pb.cv.wait(lk);
+        G = std::min(want, g_pb.free_wg[c->device]);
+        g_pb.free_wg[c->device] -= G;
+    }
+    int rc = VO_OK;
+    do {
+        if (j->wait_ev && hipStreamWaitEvent(st, j->wait_ev, 0) != hipSuccess) { rc = VO_E_DEVICE; break; }
+        if (hipMemsetAsync(pb + o_sync, 0, 1024, st) != hipSuccess) { rc = VO_E_DEVICE; break; }
+        if (hipMemsetAsync(B.S, 0, sizeof(double) * (size_t)B.D * B.D, st) != hipSuccess) { rc = VO_E_DEVICE; break; }
+        if (hipMemsetAsync(B.bs, 0, sizeof(double) * (size_t)B.D, st) != hipSuccess) { rc = VO_E_DEVICE; break; }
+        PbArgs A;
+        A.B = B; A.sync = (unsigned*)(pb + o_sync); A.part = (double*)(pb + o_part); A.hpart = (double*)(pb + o_hpart); A.rec = (double*)(pb + o_rec);
+        A.dp = (double*)(pb + o_dp); A.mail = (double*)(pb + o_mail);
+        A.G = G; A.it_robust = j->in->it_robust; A.it_plain = j->in->it_plain;
+        A.ps = std::max(1, std::min(PB_PS, (G - 1) / std::max(1, B.n_free)));
+        A.dbg = getenv("VO_BA_DBG") ? atoi(getenv("VO_BA_DBG")) : 0;
+        A.spin_ticks = 100000000ull;                             // 1 s at 100 MHz
+        c->h_pb[5] = 1.0;
+        { ProfScope ps(c, "k_ba_persist", st); hipLaunchKernelGGL(k_ba_persist, dim3(G), dim3(PB_NT), pb_lds_bytes(B), st, A); }
+        if (hipMemcpyAsync(c->h_pb, pb + o_mail, 256, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = VO_E_DEVICE; break; }
+        if (hipStreamSynchronize(st) != hipSuccess) { rc = VO_E_DEVICE; break; }
+    } while (0);
+    {
+        std::unique_lock<std::mutex> lk(g_pb.mu);
+        g_pb.free_wg[c->device] += G;
+        g_pb.cv.notify_all();
+    }
+    if (rc) return rc;
+    if (c->h_pb[5] == 2.0) return VO_E_OVERFLOW;               // a worker's edge table was too small (nothing was modified): the caller takes the launch-per-phase path
+    if (c->h_pb[5] != 0.0) { fprintf(stderr, "[vo_hip] persistent BA launch aborted (a workgroup waited longer than 1 s for its peers: are other processes running persistent kernels on this GPU?)\n"); return VO_E_DEVICE; }
+    j->chi0 = c->h_pb[0]; j->chi_final = c->h_pb[1]; j->iters = (int)c->h_pb[2]; j->cur_buf = (int)c->h_pb[3]; j->steps = (int)c->h_pb[4];
+    j->done = true;
+    if (getenv("VO_TRACE")) {
+        static double acc[16]; static int n = 0; static long long steps = 0;
+        std::unique_lock<std::mutex> lk(g_pb.mu);
+        for (int i = 0; i < 16; ++i) acc[i] += c->h_pb[8 + i];
+        steps += j->steps;
+        if (++n % 10 == 0) {
+            const double k = 0.01 / (double)std::max(1LL, steps);      // 100 MHz ticks -> us per LM step
+            fprintf(stderr, "[vo_trace] persistent BA, us per LM step (G=%d, %d problems, %.1f steps each): solver: wait Schur %.1f | H_pp + lambda %.1f | Cholesky %.1f | trial poses + publish %.1f | wait chi2 %.1f | decide %.1f"
+                            "  worker 1: linearise %.1f | B1 %.1f | take %.1f | Schur %.1f | wait solver %.1f | update + chi2 %.1f | wait chi2 %.1f | decide %.1f\n",
+                    G, n, (double)steps / n, acc[0] * k, acc[1] * k, acc[2] * k, acc[3] * k, acc[4] * k, acc[5] * k, acc[8] * k, acc[9] * k, acc[10] * k, acc[11] * k, acc[12] * k, acc[13] * k, acc[14] * k, acc[15] * k);
+        }
+    }
+    return VO_OK;
+}
+
 int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     hipStream_t st = c->stream;
     BaEngine* E = ba_engine_of(c);
@@ -1665,7 +1820,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     B.Hpp = (double*)(base + o_Hpp); B.bp = (double*)(base + o_bp); B.Hll = (double*)(base + o_Hll); B.bl = (double*)(base + o_bl); B.scal = (double*)(base + o_scal);
     B.W = (double*)(base + o_W); B.S = (double*)(base + o_S); B.bs = (double*)(base + o_bs); B.Hinv = (double*)(base + o_Hinv); B.dl = (double*)(base + o_dl);
     B.cam = BaCam{(double)c->p.fx, (double)c->p.fy, (double)c->p.cx, (double)c->p.cy};
-    B.delta = in->huber_delta; B.chi2_th = in->chi2_th; B.gp = (nx + 63) / 64;
+    B.delta = in->huber_delta; B.chi2_th = in->chi2_th; B.gp = (nx + 63) / 64; B.edges_by_point = sorted_by_point ? 1 : 0;
 
     {
         if (up_end > c->h_ba_up_bytes) {                    // pinned mirror of the upload region, grown geometrically
@@ -1730,7 +1885,9 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     job.grid_e = (ne + 255) / 256; job.grid_c = (ne + 1023) / 1024; job.grid_maxdiag = (D + 3 * nx + 255) / 256;
     job.lds = D <= 192 ? sizeof(double) * (CH_NB * CH_NB + (size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D)
                        : sizeof(double) * (CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D);
-    if ((rc = ba_engine_solve(E, &job))) return rc;
+    rc = ba_persist_ok(c, job.B) ? ba_persist_solve(c, &job) : VO_E_OVERFLOW;
+    if (rc == VO_E_OVERFLOW) rc = ba_engine_solve(E, &job);
+    if (rc) return rc;
     out->lm_iters = job.iters;
     const double tt2 = tnow();
     const int cur_buf = job.cur_buf;
@@ -2083,7 +2240,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     B.Hpp = (double*)(base + o_Hpp); B.bp = (double*)(base + o_bp); B.Hll = (double*)(base + o_Hll); B.bl = (double*)(base + o_bl); B.scal = (double*)(base + o_scal);
     B.W = (double*)(base + o_W); B.S = (double*)(base + o_S); B.bs = (double*)(base + o_bs2); B.Hinv = (double*)(base + o_Hinv); B.dl = (double*)(base + o_dl);
     B.cam = BaCam{(double)c->p.fx, (double)c->p.fy, (double)c->p.cx, (double)c->p.cy};
-    B.delta = huber_delta; B.chi2_th = chi2_th; B.gp = (nx + 63) / 64;
+    B.delta = huber_delta; B.chi2_th = chi2_th; B.gp = (nx + 63) / 64; B.edges_by_point = 1;
     BaPairPlan Q;
     Q.ps_start = B.ps_start; Q.ps_edges = B.ps_edges; Q.ps_pt = (const int32_t*)(base + o_pspt); Q.nf = nf;
     Q.cnt = (int*)(base + o_pcnt); Q.off = (int*)(base + o_poff); Q.n_slices = (int*)(base + o_pn); Q.n_pairs = (int*)(base + o_pn) + 1;
@@ -2136,7 +2293,8 @@ extern "C" int vo_local_ba_resident_solve(vo_ctx* c, int it_robust, int it_plain
     const double t0 = trace ? tnow() : 0.0;
     BaEngine* E = ba_engine_of(c);
     if (!E) return VO_E_STATE;
-    int rc = ba_engine_solve(E, &job);
+    int rc = ba_persist_ok(c, job.B) ? ba_persist_solve(c, &job) : VO_E_OVERFLOW;
+    if (rc == VO_E_OVERFLOW) rc = ba_engine_solve(E, &job);
     if (rc) return rc;
     const double t1 = trace ? tnow() : 0.0;
     const BaDev& B = R.B;
