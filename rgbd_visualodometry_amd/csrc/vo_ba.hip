@@ -672,6 +672,16 @@ __device__ __forceinline__ bool ba_chol16_body(const BaDev& B, BaCtl* ctl_, doub
         for (int c = 0; c < CH_NB; ++c) a[c] = (mine && c <= r16) ? a[c] : (c == r16 ? 1.0 : 0.0);
         if (!ch_factor_block(a, s_L, s_dg, s_inv, s_pinv, 0, nb, lane) && lane == 0) s_ok = 0;
     } else {
+        // the small loads of the tail of this phase (the 6x6 diagonal-block terms of this lane's rows, its rhs entry) are issued first:
+        // vector-memory results return in order, so they are back with the first batch of rows instead of costing two more round trips
+        double exv[4];
+        const int ri = tid - 64, rix = min(ri, D - 1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = min(CH_NB + wave - 1 + (CH_THREADS / 64 - 1) * (lane / 6 + 10 * u), D - 1), c = min(6 * (r / 6) + lane % 6, r);
+            exv[u] = extra(r, c);
+        }
+        const double rhs_v = B.bs[rix] + B.bp[rix];
         // two columns per lane (rows are 16-byte aligned: D is even), 12 rows in flight per wave
 #pragma unroll 12
         for (int r = CH_NB + wave - 1; r < D; r += CH_THREADS / 64 - 1) {
@@ -696,16 +706,16 @@ __device__ __forceinline__ bool ba_chol16_body(const BaDev& B, BaCtl* ctl_, doub
         }
         // the 6x6 diagonal block of row r (columns 6 (r / 6) .. r) joins in a second sweep over this wave's rows: 6 lanes per row,
         // 10 rows at a time (LDS accesses of one wave are ordered, so no barrier is needed behind the loop above)
-        if (lane < 60)
-            for (int i = lane / 6; ; i += 10) {
-                const int r = CH_NB + wave - 1 + (CH_THREADS / 64 - 1) * i;
-                if (r >= D) break;
-                const int c = 6 * (r / 6) + lane % 6;
-                if (c <= r) s_L[TRI32(r, c)] += extra(r, c);
+        if (lane < 60) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {                       // rows per wave <= (192 - 16) / 7 + 1 = 26 < 40
+                const int r = CH_NB + wave - 1 + (CH_THREADS / 64 - 1) * (lane / 6 + 10 * u), c = 6 * (r / 6) + lane % 6;
+                if (r < D && c <= r) s_L[TRI32(r, c)] += exv[u];
             }
-        for (int i = tid - 64; i < D; i += CH_THREADS - 64) {
-            s_L[TRI32(D, i)] = B.bs[i] + B.bp[i];
-            if (PB) __hip_atomic_store(B.bs + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (ri < D) {                                           // D <= 192 < CH_THREADS - 64: one entry per thread
+            s_L[TRI32(D, ri)] = rhs_v;
+            if (PB) __hip_atomic_store(B.bs + ri, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (tid == 64) s_L[TRI32(D, D)] = 0.0;
     }
@@ -917,11 +927,20 @@ __device__ __forceinline__ bool ba_chol16_body(const BaDev& B, BaCtl* ctl_, doub
     return s_ok != 0;
 }
 
-__global__ __launch_bounds__(CH_THREADS) void k_ba_chol16(BaBatch Q) {
+__device__ __forceinline__ void ba_pose_body(const BaDev& B, double lambda, int blk, const double* poses_c, double* poses_t);
+// trial_poses = 1 (second-generation phases, vo_ba_phase2.h): the kernel also writes the trial poses exp(dp) T and the pose part of the
+// gain ratio, which is what k_ba_update's pose workgroups do in the first generation
+__global__ __launch_bounds__(CH_THREADS) void k_ba_chol16(BaBatch Q, int trial_poses) {
     BA_PROBLEM(Q)
     if (ctl_->finished || B.D > 192) return;                   // larger systems: k_ba_chol16g
     extern __shared__ double s_mem[];
     (void)ba_chol16_body<false>(B, ctl_, 0.0, s_mem, B.bs);
+    if (trial_poses) {
+        __syncthreads();                                       // dp, the ok flag and the control block are complete
+        BA_STATE(B)
+        const double lambda = ctl_->lambda;
+        for (int blk = 0; blk * CH_THREADS < B.n_poses; ++blk) ba_pose_body(B, lambda, blk, poses_c, poses_t);
+    }
 }
 
 // ---- k_ba_chol16g: the same 16-column scheme for D > 192, where the packed triangle no longer fits in LDS -----------
@@ -1314,12 +1333,14 @@ __global__ void k_ba_cull(BaBatch Q, int stage) {
 }
 
 #include "vo_ba_persist.h"
+#include "vo_ba_phase2.h"
 
 // per-device function attributes (vo_ctx_create calls this with the context's device current)
 int vo_ba_set_attrs() {
     HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol16, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol16g, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIP_TRY(hipFuncSetAttribute((const void*)k_ba_persist, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_ba_upchi2, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     return VO_OK;
 }
 
@@ -1416,33 +1437,54 @@ static int ba_engine_pump(BaEngine* E) {                    // engine thread; re
     int act[BA_SLOTS], na = 0;
     for (int s = 0; s < BA_SLOTS; ++s) if (E->slot[s]) act[na++] = s;
     if (na == 0) return VO_OK;
-    // ---- one chunk of LM steps over every active slot
-    int chunk = (na == 1 && E->pending_hint == 0) ? 16 : 6, g_lin = 0, g_init = 0, g_blk = 0, g_upd = 0, g_c = 0, g_md = 0;
-    int s16[BA_SLOTS], n16 = 0, s16g[BA_SLOTS], n16g = 0, sfirst[BA_SLOTS], nfirst = 0; size_t lds16 = 0, lds16g = 0;
+    // ---- one chunk of LM steps over every active slot.  Systems the LDS-resident Cholesky solves (D <= 192) take the second-generation
+    // phases (vo_ba_phase2.h: four launches per step), larger ones the first generation (VO_BA_PHASE2=0: everything does).
+    static const bool phase2 = !(getenv("VO_BA_PHASE2") && atoi(getenv("VO_BA_PHASE2")) == 0);
+    int chunk = (na == 1 && E->pending_hint == 0) ? 16 : 6;
+    int sA[BA_SLOTS], nA = 0, sB[BA_SLOTS], nB = 0, sB16[BA_SLOTS], nB16 = 0, sB16g[BA_SLOTS], nB16g = 0, fA[BA_SLOTS], nfA = 0, fB[BA_SLOTS], nfB = 0;
+    int gA_lin = 0, gA_blk = 0, gA_up = 0, gA_md = 0, gB_lin = 0, gB_init = 0, gB_blk = 0, gB_upd = 0, gB_c = 0, gB_md = 0;
+    size_t ldsA = 0, ldsA_up = 0, ldsB16 = 0, ldsB16g = 0;
     for (int i = 0; i < na; ++i) {
         BaJob* j = E->slot[act[i]];
         const BaCtl& h = E->h_ctl[act[i]];                  // last read-back (zeros right after a round started)
         const int max_it = j->round == 0 ? j->in->it_robust : j->in->it_plain;
         chunk = std::min(chunk, std::max(2, max_it - (j->steps ? h.it : 0)));
-        g_lin = std::max(g_lin, j->grid_lin); g_init = std::max(g_init, j->grid_initS); g_blk = std::max(g_blk, j->B.n_blocks);
-        g_upd = std::max(g_upd, j->grid_upd); g_c = std::max(g_c, j->grid_c);
-        if (j->B.D <= 192) { s16[n16++] = act[i]; lds16 = std::max(lds16, j->lds); } else { s16g[n16g++] = act[i]; lds16g = std::max(lds16g, j->lds); }
-        if (j->need_first) { sfirst[nfirst++] = act[i]; g_md = std::max(g_md, j->grid_maxdiag); }
+        if (phase2 && j->B.D <= BA_FOLD_D) {
+            sA[nA++] = act[i];
+            gA_lin = std::max(gA_lin, j->grid_lin); gA_blk = std::max(gA_blk, j->B.n_blocks); gA_up = std::max(gA_up, j->B.gp);
+            ldsA = std::max(ldsA, j->lds); ldsA_up = std::max(ldsA_up, sizeof(double) * (12 * (size_t)j->B.n_poses + (size_t)j->B.D));
+            if (j->need_first) { fA[nfA++] = act[i]; gA_md = std::max(gA_md, (j->B.D + j->B.n_points + 255) / 256); }
+        } else {
+            sB[nB++] = act[i];
+            gB_lin = std::max(gB_lin, j->grid_lin); gB_init = std::max(gB_init, j->grid_initS); gB_blk = std::max(gB_blk, j->B.n_blocks);
+            gB_upd = std::max(gB_upd, j->grid_upd); gB_c = std::max(gB_c, j->grid_c);
+            if (j->B.D <= 192) { sB16[nB16++] = act[i]; ldsB16 = std::max(ldsB16, j->lds); } else { sB16g[nB16g++] = act[i]; ldsB16g = std::max(ldsB16g, j->lds); }
+            if (j->need_first) { fB[nfB++] = act[i]; gB_md = std::max(gB_md, j->grid_maxdiag); }
+        }
     }
     vo_ctx* prof = E->slot[act[0]]->c;
-    const BaBatch Q = ba_batch_of(E, act, na);
+    const BaBatch QA = ba_batch_of(E, sA, nA), QB = ba_batch_of(E, sB, nB);
     const dim3 blk(256);
     for (int sidx = 0; sidx < chunk; ++sidx) {
-        { ProfScope ps(prof, "k_ba_lin", st); hipLaunchKernelGGL(k_ba_lin, dim3(g_lin, 1, na), blk, 0, st, Q); }
-        if (sidx == 0 && nfirst) hipLaunchKernelGGL(k_ba_maxdiag, dim3(g_md, 1, nfirst), blk, 0, st, ba_batch_of(E, sfirst, nfirst));
-        // systems beyond the LDS-resident Cholesky need it every step, the others only behind k_ba_maxdiag (first step of a round)
-        if (n16g || (sidx == 0 && nfirst)) { ProfScope ps(prof, "k_ba_init_S", st); hipLaunchKernelGGL(k_ba_init_S, dim3(g_init, 1, na), blk, 0, st, Q); }
-        if (g_blk) { ProfScope ps(prof, "k_ba_schur_blocks", st); hipLaunchKernelGGL(k_ba_schur_blocks, dim3(g_blk, 1, na), blk, 0, st, Q); }
-        { ProfScope ps(prof, "k_ba_chol", st);
-          if (n16) hipLaunchKernelGGL(k_ba_chol16, dim3(1, 1, n16), dim3(CH_THREADS), lds16, st, ba_batch_of(E, s16, n16));
-          if (n16g) hipLaunchKernelGGL(k_ba_chol16g, dim3(1, 1, n16g), dim3(CH_THREADS), lds16g, st, ba_batch_of(E, s16g, n16g)); }
-        { ProfScope ps(prof, "k_ba_update", st); hipLaunchKernelGGL(k_ba_update, dim3(g_upd, 1, na), blk, 0, st, Q); }
-        { ProfScope ps(prof, "k_ba_chi_control", st); hipLaunchKernelGGL(k_ba_chi_control, dim3(g_c, 1, na), blk, 0, st, Q); }
+        if (nA) {
+            { ProfScope ps(prof, "k_ba_lin", st); hipLaunchKernelGGL(k_ba_lin2, dim3(gA_lin, 1, nA), blk, 0, st, QA); }
+            if (sidx == 0 && nfA) hipLaunchKernelGGL(k_ba_maxdiag2, dim3(gA_md, 1, nfA), blk, 0, st, ba_batch_of(E, fA, nfA));
+            if (gA_blk) { ProfScope ps(prof, "k_ba_schur_blocks", st); hipLaunchKernelGGL(k_ba_schur2, dim3(gA_blk, 1, nA), blk, 0, st, QA); }
+            { ProfScope ps(prof, "k_ba_chol", st); hipLaunchKernelGGL(k_ba_chol16, dim3(1, 1, nA), dim3(CH_THREADS), ldsA, st, QA, 0); }
+            { ProfScope ps(prof, "k_ba_update", st); hipLaunchKernelGGL(k_ba_upchi2, dim3(gA_up, 1, nA), blk, ldsA_up, st, QA); }
+        }
+        if (nB) {
+            { ProfScope ps(prof, "k_ba_lin", st); hipLaunchKernelGGL(k_ba_lin, dim3(gB_lin, 1, nB), blk, 0, st, QB); }
+            if (sidx == 0 && nfB) hipLaunchKernelGGL(k_ba_maxdiag, dim3(gB_md, 1, nfB), blk, 0, st, ba_batch_of(E, fB, nfB));
+            // systems beyond the LDS-resident Cholesky need it every step, the others only behind k_ba_maxdiag (first step of a round)
+            if (nB16g || (sidx == 0 && nfB)) { ProfScope ps(prof, "k_ba_init_S", st); hipLaunchKernelGGL(k_ba_init_S, dim3(gB_init, 1, nB), blk, 0, st, QB); }
+            if (gB_blk) { ProfScope ps(prof, "k_ba_schur_blocks", st); hipLaunchKernelGGL(k_ba_schur_blocks, dim3(gB_blk, 1, nB), blk, 0, st, QB); }
+            { ProfScope ps(prof, "k_ba_chol", st);
+              if (nB16) hipLaunchKernelGGL(k_ba_chol16, dim3(1, 1, nB16), dim3(CH_THREADS), ldsB16, st, ba_batch_of(E, sB16, nB16), 0);
+              if (nB16g) hipLaunchKernelGGL(k_ba_chol16g, dim3(1, 1, nB16g), dim3(CH_THREADS), ldsB16g, st, ba_batch_of(E, sB16g, nB16g)); }
+            { ProfScope ps(prof, "k_ba_update", st); hipLaunchKernelGGL(k_ba_update, dim3(gB_upd, 1, nB), blk, 0, st, QB); }
+            { ProfScope ps(prof, "k_ba_chi_control", st); hipLaunchKernelGGL(k_ba_chi_control, dim3(gB_c, 1, nB), blk, 0, st, QB); }
+        }
     }
     E->n_steps += chunk; E->n_slot_steps += (long long)chunk * na;
     for (int i = 0; i < na; ++i) { BaJob* j = E->slot[act[i]]; j->steps += chunk; j->need_first = 0; }
@@ -1585,7 +1627,7 @@ void vo_ba_engine_release(BaEngine* E) {
 // advance independently: no lock-step over problems, no chunk of steps to wait for.
 #define PB_MAX_DEV 16
 #define PB_G_CAP 256
-static struct PbBudget { std::mutex mu; std::condition_variable cv; int free_wg[PB_MAX_DEV]; bool init = false; int total = 224, gmax = 128, on = 1; } g_pb;
+static struct PbBudget { std::mutex mu; std::condition_variable cv; int free_wg[PB_MAX_DEV]; bool init = false; int total = 224, gmax = 128, on = 0; } g_pb;      // on: VO_BA_PERSIST=1 (default off: the second-generation launch path is faster end to end)
 static void pb_budget_init() {
     if (g_pb.init) return;
     if (const char* e = getenv("VO_BA_WG_BUDGET")) g_pb.total = std::max(2, std::min(PB_G_CAP, atoi(e)));
@@ -1603,7 +1645,7 @@ static size_t pb_lds_bytes(const BaDev& B) {
 static bool ba_persist_ok(vo_ctx* c, const BaDev& B) {
     std::unique_lock<std::mutex> lk(g_pb.mu);
     pb_budget_init();
-    return g_pb.on && c->device < PB_MAX_DEV && B.D <= 192 && B.n_free <= 32 && B.edges_by_point && pb_lds_bytes(B) <= 158 * 1024 &&
+    return g_pb.on && c->device < PB_MAX_DEV && B.D <= 192 && B.n_free <= 32 && B.edges_by_point && pb_lds_bytes(B) <= 158 * 1024 && 96 * (long long)B.n_points + 8 * (long long)B.n_edges + 512 <= 144 * (long long)B.n_edges &&
            (long long)B.n_edges / (g_pb.gmax - 1) + B.n_poses + 64 <= PB_ECAP;
 }
 void vo_ba_persist_free(vo_ctx* c) {
@@ -1664,15 +1706,15 @@ static int ba_persist_solve(vo_ctx* c, BaJob* j) {
     j->chi0 = c->h_pb[0]; j->chi_final = c->h_pb[1]; j->iters = (int)c->h_pb[2]; j->cur_buf = (int)c->h_pb[3]; j->steps = (int)c->h_pb[4];
     j->done = true;
     if (getenv("VO_TRACE")) {
-        static double acc[16]; static int n = 0; static long long steps = 0;
+        static double acc[24]; static int n = 0; static long long steps = 0;
         std::unique_lock<std::mutex> lk(g_pb.mu);
-        for (int i = 0; i < 16; ++i) acc[i] += c->h_pb[8 + i];
+        for (int i = 0; i < 20; ++i) acc[i] += c->h_pb[8 + i];
         steps += j->steps;
         if (++n % 10 == 0) {
             const double k = 0.01 / (double)std::max(1LL, steps);      // 100 MHz ticks -> us per LM step
             fprintf(stderr, "[vo_trace] persistent BA, us per LM step (G=%d, %d problems, %.1f steps each): solver: wait Schur %.1f | H_pp + lambda %.1f | Cholesky %.1f | trial poses + publish %.1f | wait chi2 %.1f | decide %.1f"
-                            "  worker 1: linearise %.1f | B1 %.1f | take %.1f | Schur %.1f | wait solver %.1f | update + chi2 %.1f | wait chi2 %.1f | decide %.1f\n",
-                    G, n, (double)steps / n, acc[0] * k, acc[1] * k, acc[2] * k, acc[3] * k, acc[4] * k, acc[5] * k, acc[8] * k, acc[9] * k, acc[10] * k, acc[11] * k, acc[12] * k, acc[13] * k, acc[14] * k, acc[15] * k);
+                            "  worker 1: linearise %.1f | B1 %.1f | take %.1f | Schur %.1f | wait solver %.1f | update + chi2 %.1f | wait chi2 %.1f | decide %.1f  || Schur: loads %.1f | sums(dbg 4) %.1f | sums + reduce %.1f | commit %.1f\n",
+                    G, n, (double)steps / n, acc[0] * k, acc[1] * k, acc[2] * k, acc[3] * k, acc[4] * k, acc[5] * k, acc[8] * k, acc[9] * k, acc[10] * k, acc[11] * k, acc[12] * k, acc[13] * k, acc[14] * k, acc[15] * k, acc[16] * k, acc[17] * k, acc[18] * k, acc[19] * k);
         }
     }
     return VO_OK;
@@ -1803,7 +1845,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     const size_t o_blk = carve(sizeof(BaBlock) * (size_t)std::max(nblk, 1)), o_pairs = carve(sizeof(int2) * (size_t)std::max(npairs, 1));
     const size_t o_pcnt = carve(4 * (size_t)std::max(nb_all, 1)), o_poff = carve(4 * (size_t)std::max(nb_all, 1)), o_pn = carve(16);
     const size_t o_Hpp = carve(288 * (size_t)nf), o_bp = carve(8 * (size_t)D), o_Hll = carve(72 * (size_t)nx), o_bl = carve(24 * (size_t)nx), o_scal = carve(64);
-    const size_t o_partU = carve(16 * ((size_t)(nx + 63) / 64 + 1)), o_partC = carve(8 * ((size_t)(ne + 255) / 256 + 1));
+    const size_t o_partU = carve(24 * ((size_t)(nx + 63) / 64 + 1)), o_partC = carve(8 * ((size_t)(ne + 255) / 256 + 1));
     const size_t o_W = carve(144 * (size_t)ne), o_S = carve(8 * (size_t)D * D), o_bs = carve(8 * (size_t)D), o_Hinv = carve(72 * (size_t)nx), o_dl = carve(24 * (size_t)nx);
     int rc = vo_scratch(c, off);
     if (rc) return rc;
@@ -2197,7 +2239,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     const size_t o_hist = carve(4 * (size_t)chunks * nf), o_offs = carve(4 * (size_t)chunks * nf), o_ptot = carve(4 * 64);
     const size_t o_pcnt = carve(4 * (size_t)std::max(nb_all, 1)), o_poff = carve(4 * (size_t)std::max(nb_all, 1)), o_pn = carve(16);
     const size_t o_Hpp = carve(288 * (size_t)nf), o_bp = carve(8 * (size_t)D), o_Hll = carve(72 * (size_t)nx), o_bl = carve(24 * (size_t)nx), o_scal = carve(64);
-    const size_t o_partU = carve(16 * ((size_t)(nx + 63) / 64 + 1)), o_partC = carve(8 * ((size_t)(ne + 255) / 256 + 1));
+    const size_t o_partU = carve(24 * ((size_t)(nx + 63) / 64 + 1)), o_partC = carve(8 * ((size_t)(ne + 255) / 256 + 1));
     const size_t o_W = carve(144 * (size_t)ne), o_S = carve(8 * (size_t)D * D), o_bs2 = carve(8 * (size_t)D), o_Hinv = carve(72 * (size_t)nx), o_dl = carve(24 * (size_t)nx);
     // pair lists: a point seen by m free poses gives m (m + 1) / 2 <= m (nf + 1) / 2 pairs, so ne (nf + 1) / 2 bounds them before the
     // per-pose lists exist; slices: one per 512 pairs plus a partial one per block

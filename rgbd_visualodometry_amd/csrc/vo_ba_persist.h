@@ -42,6 +42,9 @@ struct PbArgs {
     unsigned long long spin_ticks;            // bound of every wait, in 100 MHz ticks
 };
 
+// in-kernel time stamps (100 MHz): `tk` accumulators and `tl` (last stamp) are locals of the function that uses the macro
+#define PB_TICK(i) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); tk[i] += n_ - tl; tl = n_; }
+
 struct PbLM { double lambda, ni, cur; int it, qmax, need_lin, first, finished, buf, iters_done, steps; };
 
 // A worker's static tables (LDS, filled once per BA): what the dependent index loads of every step would fetch again and again.
@@ -61,6 +64,23 @@ __device__ __forceinline__ double pb_ld(const double* p) { return __hip_atomic_l
 __device__ __forceinline__ void pb_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int pb_ldb(const uint8_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void pb_stb(uint8_t* p, uint8_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// 16-byte agent-scope (sc1: aux bit 4) loads / stores through a buffer descriptor: the per-point records are read by 64 lanes from 64
+// different cache lines, where the address unit pays per instruction and line -- half the instructions of 8-byte accesses
+typedef unsigned pb_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pb_rsrc(const void* p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000); }
+__device__ __forceinline__ void pb_ld16(__amdgpu_buffer_rsrc_t r, unsigned off, double& a, double& b) {
+    const pb_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16);
+    a = __hiloint2double((int)v[1], (int)v[0]); b = __hiloint2double((int)v[3], (int)v[2]);
+}
+__device__ __forceinline__ void pb_st16(__amdgpu_buffer_rsrc_t r, unsigned off, double a, double b) {
+    const pb_u32x4 v = {(unsigned)__double2loint(a), (unsigned)__double2hiint(a), (unsigned)__double2loint(b), (unsigned)__double2hiint(b)};
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 16);
+}
+// Per-point record of a linearisation (96 bytes, 32-byte aligned): H_ll (6 unique), b_l (3), the point (3).  It lives behind the
+// edge weights in the slab that the launch-per-phase path uses for W_e (144 bytes per edge).
+#define PB_REC 12
+__device__ __forceinline__ double* pb_rec_base(const BaDev& B) { return B.W + (((size_t)B.n_edges + 31) & ~(size_t)31); }
 
 // every wave's write-through stores and atomics have left, then one lane signals
 __device__ __forceinline__ void pb_arrive(unsigned* ctr) {
@@ -210,11 +230,13 @@ template <int LPP> __device__ __forceinline__ double pb_grp_sum(double x) {
 template <int LPP>
 __device__ __forceinline__ void pb_lin_points(const BaDev& B, const PbTab& W, int p_lo, int p_hi, int robust, const double* s_pc, const double* pts_c, double& chi_out, double& md_out) {
     double chi = 0, md = 0;
+    const __amdgpu_buffer_rsrc_t rec = pb_rsrc(pb_rec_base(B), (unsigned)B.n_points * (PB_REC * 8));
     for (int k0 = p_lo; k0 < p_hi; k0 += PB_NT / LPP) {
         const int k = k0 + (int)threadIdx.x / LPP, sub = threadIdx.x % LPP;
-        double H[6] = {0, 0, 0, 0, 0, 0}, b3[3] = {0, 0, 0};
+        double H[6] = {0, 0, 0, 0, 0, 0}, b3[3] = {0, 0, 0}, pk[3] = {0, 0, 0};
         if (k < p_hi) {
             const double p[3] = {pb_ld(pts_c + 3 * (size_t)k), pb_ld(pts_c + 3 * (size_t)k + 1), pb_ld(pts_c + 3 * (size_t)k + 2)};
+            pk[0] = p[0]; pk[1] = p[1]; pk[2] = p[2];
             const int q1 = B.pt_start[k + 1];
             for (int q = B.pt_start[k] + sub; q < q1; q += LPP) {
                 const int i = q - W.q_lo;
@@ -236,11 +258,9 @@ __device__ __forceinline__ void pb_lin_points(const BaDev& B, const PbTab& W, in
 #pragma unroll
         for (int i = 0; i < 3; ++i) b3[i] = pb_grp_sum<LPP>(b3[i]);
         if (k < p_hi && sub == 0) {
-            double* o = B.Hll + 9 * (size_t)k;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) pb_st(o + i, H[i]);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) pb_st(o + 6 + i, b3[i]);
+            const unsigned o = (unsigned)k * (PB_REC * 8);
+            pb_st16(rec, o, H[0], H[1]); pb_st16(rec, o + 16, H[2], H[3]); pb_st16(rec, o + 32, H[4], H[5]);
+            pb_st16(rec, o + 48, b3[0], b3[1]); pb_st16(rec, o + 64, b3[2], pk[0]); pb_st16(rec, o + 80, pk[1], pk[2]);
             md = fmax(md, fmax(fabs(H[0]), fmax(fabs(H[3]), fabs(H[5]))));
         }
     }
@@ -301,22 +321,18 @@ __device__ __forceinline__ void pb_lin_pose_part(const PbArgs& A, int vb, int ro
 struct PbPair { int on, diag; double p[3], h[9], bl[3], w1, w2; };
 // (e1, e2, k) of this thread's pair: from the worker's table (slot >= 0) or through the global lists; the dynamic part -- point, H_ll / b_l,
 // the two weights (0 for a culled edge) -- is ONE round of independent loads
-__device__ __forceinline__ void pb_pair_load(const BaDev& B, const PbTab& W, int slot, bool have, const BaBlock& blk, double lambda, const double* pts_c, PbPair& P) {
+__device__ __forceinline__ void pb_pair_load(const BaDev& B, const PbTab& W, __amdgpu_buffer_rsrc_t rec, int slot, bool have, const BaBlock& blk, double lambda, PbPair& P) {
     P.on = 0; P.diag = blk.j1 == blk.j2;
     int e1 = -1, e2 = -1, kk = -1;
     if (slot >= 0) { e1 = W.sl_e1[slot * PB_NT + threadIdx.x]; e2 = W.sl_e2[slot * PB_NT + threadIdx.x]; kk = W.sl_k[slot * PB_NT + threadIdx.x]; }
     else if (have && (int)threadIdx.x < blk.count) { const int2 pr = B.pairs[blk.start + threadIdx.x]; e1 = pr.x; e2 = pr.y; kk = B.e_pt[pr.x]; }
     if (kk < 0) return;
-    const size_t k = (size_t)kk;
     P.w2 = pb_ld(B.W + e2);
     P.w1 = P.diag ? P.w2 : pb_ld(B.W + e1);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) P.p[i] = pb_ld(pts_c + 3 * k + i);
+    const unsigned o = (unsigned)kk * (PB_REC * 8);
     double hb[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) hb[i] = pb_ld(B.Hll + 9 * k + i);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) P.bl[i] = pb_ld(B.Hll + 9 * k + 6 + i);
+    pb_ld16(rec, o, hb[0], hb[1]); pb_ld16(rec, o + 16, hb[2], hb[3]); pb_ld16(rec, o + 32, hb[4], hb[5]);
+    pb_ld16(rec, o + 48, P.bl[0], P.bl[1]); pb_ld16(rec, o + 64, P.bl[2], P.p[0]); pb_ld16(rec, o + 80, P.p[1], P.p[2]);
     if (P.w1 == 0.0 || P.w2 == 0.0) return;                    // a culled edge
     P.on = 1;
     const double Hs[9] = {hb[0], hb[1], hb[2], hb[1], hb[3], hb[4], hb[2], hb[4], hb[5]};
@@ -364,43 +380,59 @@ __device__ __forceinline__ void pb_pair_sums(const BaDev& B, const BaBlock& blk,
         }
     }
 }
-// the 42 sums of one slice over the wavefront -> s_red[wave][48]
-__device__ __forceinline__ void pb_slice_wave_reduce(double (&v)[42], double* s_red_w) {
-    double r0[8], r1[8];
-    {
-        double lo[32];
+// the sums of one slice over the wavefront -> s_red_w[0..41] (entry 6 r + c of the block, 36 + r of b_s).  A diagonal block is
+// symmetric: its 21 lower-triangle sums and the 6 of b_s fit ONE 32-value reduction; an off-diagonal block takes one plus 4 single sums.
+__device__ __forceinline__ void pb_slice_wave_reduce(bool diag, double (&v)[42], double* s_red_w) {
+    const int lane = threadIdx.x & 63;
+    double r0[8];
+    double lo[32];
+    if (diag) {
+        int n = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) lo[n++] = v[6 * r + c];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) lo[21 + r] = v[36 + r];
+#pragma unroll
+        for (int i = 27; i < 32; ++i) lo[i] = 0.0;
+    } else {
 #pragma unroll
         for (int i = 0; i < 32; ++i) lo[i] = v[i];
-        vo_wave_reduce32(lo, r0);
     }
-    {
-        double hi[32];
+    vo_wave_reduce32(lo, r0);
+    double x4[4] = {0, 0, 0, 0};
+    if (!diag) {
 #pragma unroll
-        for (int i = 0; i < 32; ++i) hi[i] = i < 10 ? v[32 + i] : 0.0;
-        vo_wave_reduce32(hi, r1);
+        for (int i = 0; i < 4; ++i) x4[i] = vo_wave_sum_f64(v[32 + i]);
     }
-    const int lane = threadIdx.x & 63;
     if ((lane & 15) == 0) {
         const int slot = VO_R32_SLOT(lane >> 4);
 #pragma unroll
         for (int k8 = 0; k8 < 8; ++k8) s_red_w[4 * k8 + slot] = r0[k8];
-#pragma unroll
-        for (int k8 = 0; k8 < 3; ++k8) if (4 * k8 + slot < 10) s_red_w[32 + 4 * k8 + slot] = r1[k8];
     }
+    if (lane < 4 && !diag) s_red_w[32 + lane] = lane == 0 ? x4[0] : lane == 1 ? x4[1] : lane == 2 ? x4[2] : x4[3];
 }
-__device__ __forceinline__ void pb_slice_commit(const BaDev& B, const BaBlock& blk, const double* s_red_u, int t) {     // t in [0, 42): entry of the slice's sums
+__device__ __forceinline__ void pb_slice_commit(const BaDev& B, const BaBlock& blk, const double* s_red_u, int t) {     // t in [0, 36): entry of the slice's sums
     double x = 0;
 #pragma unroll
     for (int wv = 0; wv < PB_NT / 64; ++wv) x += s_red_u[wv * 96 + t];
-    if (t < 36) {
+    if (blk.j1 == blk.j2) {                                    // packed: 21 lower-triangle entries (row-major), then 6 of b_s
+        if (t < 21) {
+            int r = 0, rem = t;
+            while (rem > r) { rem -= r + 1; ++r; }
+            atomicAdd(&B.S[(size_t)(6 * blk.j1 + r) * B.D + 6 * blk.j1 + rem], -x);
+        } else if (t < 27) atomicAdd(&B.bs[6 * blk.j1 + t - 21], -x);
+    } else {
         const int r = t / 6, c = t % 6;
-        if (blk.j1 == blk.j2) { if (c <= r) atomicAdd(&B.S[(size_t)(6 * blk.j1 + r) * B.D + 6 * blk.j1 + c], -x); }
-        else atomicAdd(&B.S[(size_t)(6 * blk.j2 + c) * B.D + 6 * blk.j1 + r], -x);          // j1 < j2: the block below the diagonal
-    } else if (blk.j1 == blk.j2) atomicAdd(&B.bs[6 * blk.j1 + t - 36], -x);
+        atomicAdd(&B.S[(size_t)(6 * blk.j2 + c) * B.D + 6 * blk.j1 + r], -x);              // j1 < j2: the block below the diagonal
+    }
 }
-__device__ __forceinline__ void pb_schur(const BaDev& B, const PbTab& W, int dbg, int wi, int NW, double lambda, const double* s_pc, const double* pts_c, double* s_red) {
+__device__ __forceinline__ void pb_schur(const BaDev& B, const PbTab& W, int dbg, int wi, int NW, double lambda, const double* s_pc, const double* pts_c, double* s_red, unsigned long long* tk) {
+    unsigned long long tl = __builtin_amdgcn_s_memrealtime();
     const int n_sl = B.n_slices ? min(*B.n_slices, B.n_blocks) : B.n_blocks;
     const int wave = threadIdx.x >> 6;
+    const __amdgpu_buffer_rsrc_t rec = pb_rsrc(pb_rec_base(B), (unsigned)B.n_points * (PB_REC * 8));
     int slot = 0;
     for (int sl0 = wi; sl0 < n_sl; sl0 += 2 * NW, slot += 2) {
         const int sl1 = sl0 + NW;
@@ -409,21 +441,26 @@ __device__ __forceinline__ void pb_schur(const BaDev& B, const PbTab& W, int dbg
         if (tab0) { blk0.j1 = W.sl_j[2 * slot]; blk0.j2 = W.sl_j[2 * slot + 1]; blk0.start = 0; blk0.count = 0; } else blk0 = B.blocks[sl0];
         if (tab1 && have1) { blk1.j1 = W.sl_j[2 * slot + 2]; blk1.j2 = W.sl_j[2 * slot + 3]; blk1.start = 0; blk1.count = 0; } else blk1 = B.blocks[have1 ? sl1 : sl0];
         PbPair P0, P1;
-        pb_pair_load(B, W, tab0 ? slot : -1, true, blk0, lambda, pts_c, P0);
-        pb_pair_load(B, W, (tab1 && have1) ? slot + 1 : -1, have1, blk1, lambda, pts_c, P1);
+        pb_pair_load(B, W, rec, tab0 ? slot : -1, true, blk0, lambda, P0);
+        pb_pair_load(B, W, rec, (tab1 && have1) ? slot + 1 : -1, have1, blk1, lambda, P1);
         double v[42];
+        if (dbg & 4) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         __syncthreads();                                       // s_red free (previous round's commits have read it)
+        PB_TICK(8)
         pb_pair_sums(B, blk0, s_pc, P0, v);
-        pb_slice_wave_reduce(v, s_red + wave * 96);
+        if (dbg & 4) { __syncthreads(); PB_TICK(9) }
+        pb_slice_wave_reduce(blk0.j1 == blk0.j2, v, s_red + wave * 96);
         if (have1) {
             pb_pair_sums(B, blk1, s_pc, P1, v);
-            pb_slice_wave_reduce(v, s_red + wave * 96 + 48);
+            pb_slice_wave_reduce(blk1.j1 == blk1.j2, v, s_red + wave * 96 + 48);
         }
         __syncthreads();
-        if (threadIdx.x < 42) pb_slice_commit(B, blk0, s_red, threadIdx.x);
-        else if (have1 && threadIdx.x >= 64 && threadIdx.x < 64 + 42) pb_slice_commit(B, blk1, s_red + 48, threadIdx.x - 64);
+        PB_TICK(10)
+        if (threadIdx.x < 36) pb_slice_commit(B, blk0, s_red, threadIdx.x);
+        else if (have1 && threadIdx.x >= 64 && threadIdx.x < 64 + 36) pb_slice_commit(B, blk1, s_red + 48, threadIdx.x - 64);
     }
     __syncthreads();
+    PB_TICK(11)
 }
 
 // back-substitution, trial point and trial chi2 of the worker's points (k_ba_update's point part + k_ba_chi_control's edge pass)
@@ -431,16 +468,16 @@ template <int LPP>
 __device__ __forceinline__ void pb_update_chi(const BaDev& B, const PbTab& W, int p_lo, int p_hi, int robust, double lambda, const double* s_pc, const double* s_pt, const double* s_dp,
                                               const double* pts_c, double* pts_t, double& chi_out, double& sc_out, double& mx_out) {
     double chi = 0, sc = 0, mx = 0;
+    const __amdgpu_buffer_rsrc_t rec = pb_rsrc(pb_rec_base(B), (unsigned)B.n_points * (PB_REC * 8));
     for (int k0 = p_lo; k0 < p_hi; k0 += PB_NT / LPP) {
         const int k = k0 + (int)threadIdx.x / LPP, sub = threadIdx.x % LPP;
         const bool live = k < p_hi;
         double p[3] = {0, 0, 0}, hb[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, rhs[3] = {0, 0, 0};
         int q0 = 0, q1 = 0;
         if (live) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) p[i] = pb_ld(pts_c + 3 * (size_t)k + i);
-#pragma unroll
-            for (int i = 0; i < 9; ++i) hb[i] = pb_ld(B.Hll + 9 * (size_t)k + i);
+            const unsigned o = (unsigned)k * (PB_REC * 8);
+            pb_ld16(rec, o, hb[0], hb[1]); pb_ld16(rec, o + 16, hb[2], hb[3]); pb_ld16(rec, o + 32, hb[4], hb[5]);
+            pb_ld16(rec, o + 48, hb[6], hb[7]); pb_ld16(rec, o + 64, hb[8], p[0]); pb_ld16(rec, o + 80, p[1], p[2]);
             if (sub == 0) { rhs[0] = hb[6]; rhs[1] = hb[7]; rhs[2] = hb[8]; }
             q0 = B.pt_start[k]; q1 = B.pt_start[k + 1];
             for (int q = q0 + sub; q < q1; q += LPP) {
@@ -606,7 +643,6 @@ __device__ __forceinline__ void pb_solver_main(const PbArgs& A, double* s_mem, i
     int iters_total = 0, steps_total = 0;
     bool alive = true;
     unsigned long long tk[6] = {0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memrealtime();      // where the solver's time goes (100 MHz ticks): mail[8..13]
-#define PB_TICK(i) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); tk[i] += n_ - tl; tl = n_; }
     for (int round = 0; round < 2 && alive; ++round) {
         const int max_it = round == 0 ? A.it_robust : A.it_plain;
         pb_round_init(lm, max_it);
@@ -715,7 +751,7 @@ __device__ __forceinline__ void pb_worker_main(const PbArgs& A, double* s_mem, i
     PbLM lm;
     lm.buf = 0; lm.lambda = 0; lm.ni = 2; lm.cur = 0;
     bool alive = true;
-    unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memrealtime();     // worker 1's time: mail[16..23]
+    unsigned long long tk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memrealtime();     // worker 1's time: mail[16..27]
     for (int round = 0; round < 2 && alive; ++round) {
         const int robust = round == 0, max_it = robust ? A.it_robust : A.it_plain;
         pb_round_init(lm, max_it);
@@ -740,7 +776,8 @@ __device__ __forceinline__ void pb_worker_main(const PbArgs& A, double* s_mem, i
                 pb_take_linearisation(A, lm, s_red);
                 PB_TICK(2)
             }
-            pb_schur(B, W, A.dbg, wi, NW, lm.lambda, s_pc, pts_c, s_red);
+            pb_schur(B, W, A.dbg, wi, NW, lm.lambda, s_pc, pts_c, s_red, tk);
+            tl = __builtin_amdgcn_s_memrealtime();
             PB_TICK(3)
             pb_arrive(C.fan);
             if (!pb_wait(C.solved, n_step, C.abort_w, A.spin_ticks, s_okw)) { alive = false; break; }
@@ -776,7 +813,7 @@ __device__ __forceinline__ void pb_worker_main(const PbArgs& A, double* s_mem, i
     double v[1] = {alive ? pb_edge_pass(B, W, 2, s_pc, lm.buf ? B.ptsB : B.ptsA) : 0.0};      // backend.cpp:162-172
     pb_wg_sum<1>(v, s_red);
     if (tid == 0) { pb_st(A.part + (size_t)w * PB_P_N + PB_P_CHI0, part_chi0); pb_st(A.part + (size_t)w * PB_P_N + PB_P_CHIF, v[0]); }
-    if (tid == 0 && w == 1) for (int i = 0; i < 8; ++i) A.mail[16 + i] = (double)tk[i];
+    if (tid == 0 && w == 1) for (int i = 0; i < 12; ++i) A.mail[16 + i] = (double)tk[i];
     pb_arrive(C.fin);
 }
 

@@ -1,0 +1,345 @@
+// vo_ba_phase2.h -- second generation of the launch-per-phase LM step for systems the LDS-resident Cholesky solves (D <= 192),
+// included by vo_ba.hip.  Four launches per step instead of five, and much less traffic:
+//   k_ba_lin2     4 lanes per point: H_ll / b_l and the point into ONE 96-byte record, the Huber weight of every edge (8 bytes) --
+//                 the 144-byte W_e blocks are no longer stored (15 MB per linearisation); 4 workgroups per free pose: H_pp / b_p
+//   k_ba_schur2   pair lists as before, but a pair's 6x6 contribution is rebuilt from the record and the two weights:
+//                 W_e1 Hinv W_e2^T = J_pose1^T M J_pose2 with the 2x2 matrix M = w1 w2 J_point1 Hinv J_point2^T (W_e has rank 2):
+//                 ~130 bytes and 72 FMAs per pair instead of ~370 bytes and 162; only the lower triangle of S is accumulated
+//   k_ba_chol16   unchanged (with trial_poses = 1 it would write the trial poses behind the solve: measured 5 us per step slower
+//                 than rebuilding them in every workgroup of the next kernel, where the exp maps overlap the loads)
+//   k_ba_upchi2   back-substitution, trial point AND the robust chi2 of the point's edges in one pass (every workgroup rebuilds the
+//                 ~50 trial poses in LDS), the last workgroup runs the LM accept / lambda policy
+// The arithmetic of the LM step is the one of vo_ba_persist.h (same helper functions), stores and loads are plain: between
+// launches the data stays in the XCDs' L2s.
+#pragma once
+
+__device__ __forceinline__ void p2_rec_store(double* rec, int k, const double (&H)[6], const double (&b3)[3], const double (&p)[3]) {
+    double2* o = reinterpret_cast<double2*>(rec + (size_t)PB_REC * k);
+    o[0] = make_double2(H[0], H[1]); o[1] = make_double2(H[2], H[3]); o[2] = make_double2(H[4], H[5]);
+    o[3] = make_double2(b3[0], b3[1]); o[4] = make_double2(b3[2], p[0]); o[5] = make_double2(p[1], p[2]);
+}
+__device__ __forceinline__ void p2_rec_load(const double* rec, int k, double (&H)[6], double (&b3)[3], double (&p)[3]) {
+    const double2* o = reinterpret_cast<const double2*>(rec + (size_t)PB_REC * k);
+    const double2 a = o[0], b = o[1], c = o[2], d = o[3], e = o[4], f = o[5];
+    H[0] = a.x; H[1] = a.y; H[2] = b.x; H[3] = b.y; H[4] = c.x; H[5] = c.y; b3[0] = d.x; b3[1] = d.y; b3[2] = e.x; p[0] = e.y; p[1] = f.x; p[2] = f.y;
+}
+
+__global__ __launch_bounds__(256) void k_ba_lin2(BaBatch Q) {
+    BA_PROBLEM(Q)
+    if (ctl_->finished || B.D > BA_FOLD_D) return;
+    const int gp = B.gp;
+    if (!ctl_->need_lin) {                                 // a rejected step is solved again at the same linearisation with a larger lambda: only S / b_s are cleared
+        if ((int)blockIdx.x < gp) ba_fold_zero(B, blockIdx.x, gp);
+        return;
+    }
+    BA_STATE(B)
+    __shared__ double s_part[4 * 32];
+    const int robust = ctl_->robust;
+    if ((int)blockIdx.x >= gp) {
+        if ((int)blockIdx.x - gp < B.n_free * PSPLIT) ba_lin_poses_body(B.cam, B, robust, B.delta, blockIdx.x - gp, poses_c, pts_c, s_part);
+        return;
+    }
+    double* const rec = pb_rec_base(B);
+    const int k = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+    double chi[1] = {0.0};
+    double H[6] = {0, 0, 0, 0, 0, 0}, b3[3] = {0, 0, 0}, p[3] = {0, 0, 0};
+    if (k < B.n_points) {
+        p[0] = pts_c[3 * (size_t)k]; p[1] = pts_c[3 * (size_t)k + 1]; p[2] = pts_c[3 * (size_t)k + 2];
+        const int q1 = B.pt_start[k + 1];
+        for (int q = B.pt_start[k] + sub; q < q1; q += 4) {
+            const int e = B.pt_edges[q];
+            if (!B.active[e]) continue;
+            double r[2], w, rho0, Jp[2][6], Jl[2][3];
+            ba_edge(B.cam, poses_c + 12 * (size_t)B.e_pose[e], p, B.e_uv + 2 * (size_t)e, robust, B.delta, r, w, rho0, Jp, Jl);
+            B.W[e] = w;
+            chi[0] += rho0;
+            b3[0] -= w * (Jl[0][0] * r[0] + Jl[1][0] * r[1]); b3[1] -= w * (Jl[0][1] * r[0] + Jl[1][1] * r[1]); b3[2] -= w * (Jl[0][2] * r[0] + Jl[1][2] * r[1]);
+            H[0] += w * (Jl[0][0] * Jl[0][0] + Jl[1][0] * Jl[1][0]); H[1] += w * (Jl[0][0] * Jl[0][1] + Jl[1][0] * Jl[1][1]); H[2] += w * (Jl[0][0] * Jl[0][2] + Jl[1][0] * Jl[1][2]);
+            H[3] += w * (Jl[0][1] * Jl[0][1] + Jl[1][1] * Jl[1][1]); H[4] += w * (Jl[0][1] * Jl[0][2] + Jl[1][1] * Jl[1][2]); H[5] += w * (Jl[0][2] * Jl[0][2] + Jl[1][2] * Jl[1][2]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) H[i] = ba_quad_sum(H[i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) b3[i] = ba_quad_sum(b3[i]);
+    if (k < B.n_points && sub == 0) p2_rec_store(rec, k, H, b3, p);
+    ba_fold_zero(B, blockIdx.x, gp);
+    ba_block_reduce<1>(chi, s_part);
+    if (threadIdx.x == 0 && chi[0] != 0.0) atomicAdd(&B.scal[0], chi[0]);
+}
+
+__global__ void k_ba_maxdiag2(BaBatch Q) {
+    BA_PROBLEM(Q)
+    if (ctl_->finished || !ctl_->need_lin || !ctl_->first || B.D > BA_FOLD_D) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double v = 0;
+    if (i < B.D) v = fabs(B.Hpp[36 * (size_t)(i / 6) + 7 * (i % 6)]);
+    else if (i < B.D + B.n_points) { const double* r = pb_rec_base(B) + (size_t)PB_REC * (i - B.D); v = fmax(fabs(r[0]), fmax(fabs(r[3]), fabs(r[5]))); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    if ((threadIdx.x & 63) == 0 && v > 0) atomicMax((unsigned long long*)&B.scal[4], (unsigned long long)__double_as_longlong(v));
+}
+
+template <bool DIAG>
+__device__ __forceinline__ void p2_schur_slice(const BaDev& B, const BaBlock blk, double lambda, const double* poses_c, double* s_part, double* s_tot) {
+    constexpr int NV = DIAG ? 42 : 36;
+    double v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = 0;
+    const double* const rec = pb_rec_base(B);
+    double T1[12], T2[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { T2[i] = poses_c[12 * (size_t)blk.j2 + i]; T1[i] = DIAG ? 0.0 : poses_c[12 * (size_t)blk.j1 + i]; }
+    for (int q = blk.start + threadIdx.x; q < blk.start + blk.count; q += 256) {
+        const int2 pr = B.pairs[q];
+        if (!B.active[pr.x] || (!DIAG && !B.active[pr.y])) continue;
+        double Hh[6], bl[3], p[3], h[9];
+        p2_rec_load(rec, B.e_pt[pr.x], Hh, bl, p);
+        const double w2 = B.W[pr.y], w1 = DIAG ? w2 : B.W[pr.x];
+        const double Hs[9] = {Hh[0], Hh[1], Hh[2], Hh[1], Hh[3], Hh[4], Hh[2], Hh[4], Hh[5]};
+        ba_inv3_damped(Hs, lambda, h);
+        double Jp2[2][6], Jl2[2][3], G2[2][3], M[2][2];
+        pb_jac(B.cam, T2, p, Jp2, Jl2);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) G2[a][c] = Jl2[a][0] * h[c] + Jl2[a][1] * h[3 + c] + Jl2[a][2] * h[6 + c];
+        if (DIAG) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) M[a][b] = w2 * w2 * (G2[a][0] * Jl2[b][0] + G2[a][1] * Jl2[b][1] + G2[a][2] * Jl2[b][2]);
+            const double g0 = w2 * (G2[0][0] * bl[0] + G2[0][1] * bl[1] + G2[0][2] * bl[2]), g1 = w2 * (G2[1][0] * bl[0] + G2[1][1] * bl[1] + G2[1][2] * bl[2]);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const double n0 = M[0][0] * Jp2[0][c] + M[0][1] * Jp2[1][c], n1 = M[1][0] * Jp2[0][c] + M[1][1] * Jp2[1][c];
+#pragma unroll
+                for (int r6 = 0; r6 < 6; ++r6) v[6 * r6 + c] += Jp2[0][r6] * n0 + Jp2[1][r6] * n1;
+            }
+#pragma unroll
+            for (int r6 = 0; r6 < 6; ++r6) v[36 + r6] += Jp2[0][r6] * g0 + Jp2[1][r6] * g1;
+        } else {
+            double Jp1[2][6], Jl1[2][3];
+            pb_jac(B.cam, T1, p, Jp1, Jl1);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) M[a][b] = w1 * w2 * (Jl1[a][0] * G2[b][0] + Jl1[a][1] * G2[b][1] + Jl1[a][2] * G2[b][2]);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const double n0 = M[0][0] * Jp2[0][c] + M[0][1] * Jp2[1][c], n1 = M[1][0] * Jp2[0][c] + M[1][1] * Jp2[1][c];
+#pragma unroll
+                for (int r6 = 0; r6 < 6; ++r6) v[6 * r6 + c] += Jp1[0][r6] * n0 + Jp1[1][r6] * n1;
+            }
+        }
+    }
+    {
+        double r0[8], r1[8];
+        {
+            double lo[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) lo[i] = v[i];
+            vo_wave_reduce32(lo, r0);
+        }
+        {
+            double hi[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) hi[i] = i < NV - 32 ? v[32 + i] : 0.0;
+            vo_wave_reduce32(hi, r1);
+        }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if ((lane & 15) == 0) {
+            const int slot = VO_R32_SLOT(lane >> 4);
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) s_part[wave * 42 + 4 * k8 + slot] = r0[k8];
+#pragma unroll
+            for (int k8 = 0; k8 < 3; ++k8) if (4 * k8 + slot < NV - 32) s_part[wave * 42 + 32 + 4 * k8 + slot] = r1[k8];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) s_tot[threadIdx.x] = s_part[threadIdx.x] + s_part[42 + threadIdx.x] + s_part[84 + threadIdx.x] + s_part[126 + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < 36) {
+        const int r = threadIdx.x / 6, c = threadIdx.x % 6;
+        const double val = s_tot[threadIdx.x];
+        if (DIAG) { if (c <= r) atomicAdd(&B.S[(size_t)(6 * blk.j1 + r) * B.D + 6 * blk.j1 + c], -val); }
+        else atomicAdd(&B.S[(size_t)(6 * blk.j2 + c) * B.D + 6 * blk.j1 + r], -val);          // j1 < j2: the block below the diagonal is the one the Cholesky reads
+    } else if (DIAG && threadIdx.x < 42) {
+        atomicAdd(&B.bs[6 * blk.j1 + threadIdx.x - 36], -s_tot[threadIdx.x]);
+    }
+}
+__global__ __launch_bounds__(256) void k_ba_schur2(BaBatch Q) {
+    BA_PROBLEM(Q)
+    if (ctl_->finished || B.D > BA_FOLD_D) return;
+    __shared__ double s_part[4 * 42];
+    __shared__ double s_tot[42];
+    if ((int)blockIdx.x >= B.n_blocks || (B.n_slices && (int)blockIdx.x >= *B.n_slices)) return;
+    BA_STATE(B)
+    const double lambda = (ctl_->need_lin && ctl_->first) ? 1e-5 * B.scal[4] : ctl_->lambda;      // as k_ba_chol16 derives it (the control block is updated there)
+    const BaBlock blk = B.blocks[blockIdx.x];
+    if (blk.j1 == blk.j2) p2_schur_slice<true>(B, blk, lambda, poses_c, s_part, s_tot);
+    else p2_schur_slice<false>(B, blk, lambda, poses_c, s_part, s_tot);
+}
+
+// trial state and its robust chi2, then (last workgroup) the LM decision of k_ba_chi_control
+__global__ __launch_bounds__(256) void k_ba_upchi2(BaBatch Q) {
+    BA_PROBLEM(Q)
+    if (ctl_->finished || B.D > BA_FOLD_D) return;
+    const int gp = B.gp;
+    if ((int)blockIdx.x >= gp) return;
+    extern __shared__ double s_dyn[];
+    double* const s_T = s_dyn;                             // trial poses [n_poses][12]
+    double* const s_dp = s_dyn + 12 * (size_t)B.n_poses;   // pose increments [D]
+    __shared__ double s_w[12];
+    __shared__ int s_last, s_accept;
+    const double lambda = ctl_->lambda;
+    const int robust = ctl_->robust;
+    const bool ok = B.scal[3] != 0.0;
+    BA_STATE(B)
+    for (int i = threadIdx.x; i < B.D; i += 256) s_dp[i] = B.bs[i];
+    for (int j = threadIdx.x; j < B.n_poses; j += 256) {   // exp(dp) * T for the free poses (ba_pose_body), copies for the fixed ones
+        const double* T = poses_c + 12 * (size_t)j;
+        double Tn[12];
+        if (j >= B.n_free || !ok) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) Tn[i] = T[i];
+        } else {
+            const double* d = B.bs + 6 * j;
+            const double w[3] = {d[3], d[4], d[5]};
+            const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = sqrt(th2);
+            double A, Bc, C;
+            if (th < 1e-8) { A = 1.0 - th2 / 6.0; Bc = 0.5 - th2 / 24.0; C = 1.0 / 6.0 - th2 / 120.0; }
+            else { A = sin(th) / th; Bc = (1.0 - cos(th)) / th2; C = (th - sin(th)) / (th2 * th); }
+            const double Wm[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+            double W2[9], R[9], V[9];
+            for (int i = 0; i < 3; ++i) for (int c = 0; c < 3; ++c) { double s = 0; for (int k = 0; k < 3; ++k) s += Wm[3 * i + k] * Wm[3 * k + c]; W2[3 * i + c] = s; }
+            for (int i = 0; i < 9; ++i) { const double I = (i % 4 == 0) ? 1.0 : 0.0; R[i] = I + A * Wm[i] + Bc * W2[i]; V[i] = I + Bc * Wm[i] + C * W2[i]; }
+            const double tx = V[0] * d[0] + V[1] * d[1] + V[2] * d[2], ty = V[3] * d[0] + V[4] * d[1] + V[5] * d[2], tz = V[6] * d[0] + V[7] * d[1] + V[8] * d[2];
+            for (int i = 0; i < 3; ++i) for (int c = 0; c < 3; ++c) { double s = 0; for (int k = 0; k < 3; ++k) s += R[3 * i + k] * T[3 * k + c]; Tn[3 * i + c] = s; }
+            Tn[9] = R[0] * T[9] + R[1] * T[10] + R[2] * T[11] + tx;
+            Tn[10] = R[3] * T[9] + R[4] * T[10] + R[5] * T[11] + ty;
+            Tn[11] = R[6] * T[9] + R[7] * T[10] + R[8] * T[11] + tz;
+            if (blockIdx.x == 0) {                         // the pose part of the gain ratio and of the step size, once
+                double sc = 0, mx = 0;
+                for (int a = 0; a < 6; ++a) { sc += d[a] * (lambda * d[a] + B.bp[6 * j + a]); mx = fmax(mx, fabs(d[a])); }
+                atomicAdd(&B.scal[2], sc);
+                atomicMax((unsigned long long*)&B.scal[7], (unsigned long long)__double_as_longlong(mx));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) s_T[12 * j + i] = Tn[i];
+        if (blockIdx.x == 0) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) poses_t[12 * (size_t)j + i] = Tn[i];
+        }
+    }
+    __syncthreads();
+    double chi = 0, sc = 0, mx = 0;
+    {
+        const double* const rec = pb_rec_base(B);
+        const int k = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+        const bool live = ok && k < B.n_points;
+        double H[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0}, p[3] = {0, 0, 0}, rhs[3] = {0, 0, 0};
+        int q0 = 0, q1 = 0;
+        if (live) {
+            p2_rec_load(rec, k, H, bl, p);
+            if (sub == 0) { rhs[0] = bl[0]; rhs[1] = bl[1]; rhs[2] = bl[2]; }
+            q0 = B.pt_start[k]; q1 = B.pt_start[k + 1];
+            for (int q = q0 + sub; q < q1; q += 4) {
+                const int e = B.pt_edges[q], j = B.e_pose[e];
+                if (!B.active[e] || j >= B.n_free) continue;
+                const double w = B.W[e];
+                double T[12], Jp[2][6], Jl[2][3];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) T[i] = poses_c[12 * (size_t)j + i];
+                pb_jac(B.cam, T, p, Jp, Jl);
+                const double* d6 = s_dp + 6 * j;
+                double t0 = 0, t1 = 0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) { t0 += Jp[0][a] * d6[a]; t1 += Jp[1][a] * d6[a]; }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) rhs[c] -= w * (Jl[0][c] * t0 + Jl[1][c] * t1);         // W_e^T dp_j
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rhs[c] = ba_quad_sum(rhs[c]);
+        if (live) {
+            const double Hs[9] = {H[0], H[1], H[2], H[1], H[3], H[4], H[2], H[4], H[5]};
+            double h[9], pn[3];
+            ba_inv3_damped(Hs, lambda, h);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double d = h[3 * a] * rhs[0] + h[3 * a + 1] * rhs[1] + h[3 * a + 2] * rhs[2];
+                pn[a] = p[a] + d;
+                if (sub == 0) { pts_t[3 * (size_t)k + a] = pn[a]; sc += d * (lambda * d + bl[a]); mx = fmax(mx, fabs(d)); }
+            }
+            for (int q = q0 + sub; q < q1; q += 4) {
+                const int e = B.pt_edges[q];
+                if (!B.active[e]) continue;
+                double r[2], pc[3];
+                ba_err(B.cam, s_T + 12 * B.e_pose[e], pn, B.e_uv + 2 * (size_t)e, r, pc);
+                const double e2 = r[0] * r[0] + r[1] * r[1];
+                chi += (robust && e2 > B.delta * B.delta) ? 2.0 * sqrt(e2) * B.delta - B.delta * B.delta : e2;
+            }
+        }
+    }
+    chi = vo_wave_sum_f64(chi); sc = vo_wave_sum_f64(sc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; s_w[w] = chi; s_w[4 + w] = sc; s_w[8 + w] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        B.partU[3 * (size_t)blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+        B.partU[3 * (size_t)blockIdx.x + 1] = (s_w[4] + s_w[5]) + (s_w[6] + s_w[7]);
+        B.partU[3 * (size_t)blockIdx.x + 2] = fmax(fmax(s_w[8], s_w[9]), fmax(s_w[10], s_w[11]));
+        __threadfence();
+        s_last = atomicAdd(&ctl_->arrived, 1) == gp - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    {   // the last workgroup: the partials of every workgroup, then g2o's gain-ratio test and lambda policy (as k_ba_chi_control)
+        __threadfence();
+        const volatile double* pu = B.partU;
+        double a = 0, b = 0, m = 0;
+        for (int i = threadIdx.x; i < gp; i += 256) { a += pu[3 * i]; b += pu[3 * i + 1]; m = fmax(m, pu[3 * i + 2]); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); m = fmax(m, __shfl_xor(m, o, 64)); }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; s_w[w] = a; s_w[4 + w] = b; s_w[8 + w] = m; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        BaCtl* c = ctl_;
+        c->arrived = 0;
+        const double s1 = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+        const volatile double* scv = B.scal;
+        const double sc2 = scv[2], sc7 = scv[7];
+        const double s2 = sc2 + ((s_w[4] + s_w[5]) + (s_w[6] + s_w[7]));
+        const double m7 = fmax(sc7, fmax(fmax(s_w[8], s_w[9]), fmax(s_w[10], s_w[11])));
+        const double tmp = ok ? s1 : DBL_MAX;
+        const double scale = (ok ? s2 : 0.0) + 1e-3;
+        const double rho = (c->cur - tmp) / scale;
+        bool converged = false;
+        int accept = 0;
+        if (rho > 0 && isfinite(tmp)) {
+            double a = 1.0 - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
+            a = fmin(a, 2.0 / 3.0);
+            c->lambda *= fmax(1.0 / 3.0, a); c->ni = 2; c->cur = tmp;
+            c->buf ^= 1; c->need_lin = 1; accept = 1;       // trial state becomes the current state
+            B.scal[0] = 0; B.scal[4] = 0;
+        } else { c->lambda *= c->ni; c->ni *= 2; }
+        if (ok) converged = m7 < 1e-10;
+        c->qmax += 1; c->steps += 1;
+        if (!(rho < 0 && c->qmax < 10 && !converged)) {     // this LM iteration is over
+            c->iters_done += 1;
+            if (c->qmax == 10 || rho == 0 || converged || c->it + 1 >= c->max_it) c->finished = 1;
+            c->it += 1; c->qmax = 0;
+        }
+        s_accept = accept;
+    }
+    __syncthreads();
+    if (s_accept) {
+        for (int i = threadIdx.x; i < 36 * B.n_free; i += 256) B.Hpp[i] = 0;
+        for (int i = threadIdx.x; i < B.D; i += 256) B.bp[i] = 0;
+    }
+}
