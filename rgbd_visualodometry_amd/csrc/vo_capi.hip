@@ -257,7 +257,7 @@ void vo_ctx_destroy(vo_ctx* c) {
     for (auto p : c->own_depth) if (p) (void)hipFree(p);
     void* ptrs[] = {c->d_slots, c->d_pyr, c->d_blur, c->d_tab, c->d_tabs, c->d_cand, c->d_cand_cnt, c->d_sel, c->d_sel_key, c->d_sel_cnt, c->d_kps,
                     c->d_desc, c->d_nkp, c->d_status, c->d_map_pos, c->d_map_nrm, c->d_map_desc, c->d_map_flags, c->d_active, c->d_best, c->d_mcand,
-                    c->d_matches, c->d_corr_xyz, c->d_corr_uv, c->d_hyp_pose, c->d_hyp_cnt, c->d_inliers, c->d_lm_mask, c->d_ba};
+                    c->d_matches, c->d_corr_xyz, c->d_corr_uv, c->d_hyp_pose, c->d_hyp_cnt, c->d_inliers, c->d_lm_mask, c->d_lm_x, c->d_ba};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     launchset_free(c->ls);
     if (c->group_ev) (void)hipEventDestroy(c->group_ev);
@@ -334,7 +334,7 @@ int vo_ctx_create(const vo_params* p, int device, vo_ctx** out) {
     const size_t NL = (size_t)c->lanes;
     ALLOC(c->d_active, M); ALLOC(c->d_best, NL * M); ALLOC(c->d_mcand, NL * M); ALLOC(c->d_matches, NL * M); ALLOC(c->d_corr_xyz, NL * 3 * M); ALLOC(c->d_corr_uv, NL * 2 * M);
     ALLOC(c->d_hyp_pose, NL * 12 * p->max_hypotheses); ALLOC(c->d_hyp_cnt, NL * p->max_hypotheses);
-    ALLOC(c->d_inliers, NL * M); ALLOC(c->d_lm_mask, NL * M);
+    ALLOC(c->d_inliers, NL * M); ALLOC(c->d_lm_mask, NL * M); ALLOC(c->d_lm_x, NL * VO_LM_X_DOUBLES);
     if (launchset_alloc(c->ls, (int)NL) != VO_OK) { vo_ctx_destroy(c); return VO_E_NOMEM; }
     c->d_track = c->ls.d_track; c->h_track = c->ls.h_track; c->lane_stride = M;
     if (hipEventCreateWithFlags(&c->group_ev, hipEventDisableTiming) != hipSuccess) { vo_ctx_destroy(c); return VO_E_DEVICE; }
@@ -343,6 +343,7 @@ int vo_ctx_create(const vo_params* p, int device, vo_ctx** out) {
     HIP_TRY(hipMemcpyAsync(c->d_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(c->d_tabs, tabs.data(), tabs.size() * sizeof(short), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(int), st));
+    HIP_TRY(hipMemsetAsync(c->d_lm_x, 0, sizeof(double) * NL * VO_LM_X_DOUBLES, st));      // hand-off counters start at 0; the last workgroup of a launch clears them again
     HIP_TRY(hipMemsetAsync(c->d_nkp, 0, sizeof(int) * F, st));
     HIP_TRY(hipMemsetAsync(c->d_sel_cnt, 0, sizeof(int) * F * VO_MAX_LEVELS, st));
     HIP_TRY(hipMemsetAsync(c->d_map_flags, 0, M, st));
@@ -656,7 +657,7 @@ int vo_pose_refine_lm(vo_ctx* c, double T[12], double delta, double cut, int it_
     c->h_track->lm_iters = 0;
     HIP_TRY(hipMemcpyAsync(c->d_track, c->h_track, sizeof(TrackDev), hipMemcpyHostToDevice, c->stream));
     if ((rc = upload_lanes(c, 1, nullptr, nullptr))) return rc;
-    rc = vo_track_lm_launch(c, c->stream, c->ls.d_lanes, 1, delta, cut, it_r, it_p, false);
+    rc = vo_track_lm_launch(c, c->stream, c->ls.d_lanes, 1, delta, cut, it_r, it_p, false, c->h_track->n_inl);
     if (rc) return rc;
     rc = download_track(c);
     if (rc) return rc;
@@ -701,6 +702,8 @@ static int chain_run(vo_ctx* prof, hipStream_t st, LaunchSet& ls, std::vector<Gr
     int rc = VO_OK;
     { int k = 0; for (GroupReq* r : batch) for (int i = 0; i < r->n; ++i, ++k) ls.h_lanes[k].seed = r->seeds ? r->seeds[i] : tp->seed; }
     HIP_TRY(hipMemcpyAsync(ls.d_lanes, ls.h_lanes, sizeof(LaneDesc) * nl, hipMemcpyHostToDevice, st));
+    int lm_hint = 0;                                        // the inlier sets are not known on the host yet: the largest recent match count bounds them
+    for (GroupReq* r : batch) lm_hint = std::max(lm_hint, r->c->match_hint);
     for (int pass = 0; pass < tp->passes; ++pass) {           // coarse, fine (frontend.cpp:100-108); the sampler's seed is lane seed + pass
         if ((rc = vo_track_match_launch(prof, st, ls.d_lanes, nl, dims, tp->match_ratio, tp->match_floor))) return rc;
         vo_ctx* sc = batch[0]->c;                           // hypothesis sharding applies to un-grouped contexts (one request per chain)
@@ -709,7 +712,7 @@ static int chain_run(vo_ctx* prof, hipStream_t st, LaunchSet& ls, std::vector<Gr
             if ((rc = shard_exchange(sc, st, nl, tp->n_hyp))) return rc;
             if ((rc = vo_track_ransac_launch(prof, st, ls.d_lanes, nl, tp->n_hyp, tp->reproj_px, tp->confidence, pass, 2))) return rc;
         } else if ((rc = vo_track_ransac_launch(prof, st, ls.d_lanes, nl, tp->n_hyp, tp->reproj_px, tp->confidence, pass))) return rc;
-        if ((rc = vo_track_lm_launch(prof, st, ls.d_lanes, nl, tp->huber_delta, tp->chi2_cut, tp->it_robust, tp->it_plain, pass == tp->passes - 1))) return rc;
+        if ((rc = vo_track_lm_launch(prof, st, ls.d_lanes, nl, tp->huber_delta, tp->chi2_cut, tp->it_robust, tp->it_plain, pass == tp->passes - 1, lm_hint))) return rc;
     }
     // match records that callers asked for travel with the headers; sized from the largest match count seen recently
     // (+25 %): consecutive frames see the same map, and a synchronous second copy per lane costs more than the extra bytes

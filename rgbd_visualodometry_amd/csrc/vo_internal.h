@@ -59,6 +59,7 @@ struct CamD { double fx, fy, cx, cy; int W, H; };
 struct LaneDesc {
     TrackDev* tr; uint32_t* best; int32_t* cand; vo_match* matches; float* cxyz; float* cuv;
     double* hyp_pose; int* hyp_cnt; int32_t* inliers; uint8_t* mask;
+    double* lm_x;                                   // hand-off area of a pose LM that runs in several workgroups (vo_track.hip, LM_X_DOUBLES)
     const uint32_t* fdesc; const int* nkp; const vo_keypoint* kps;                  // the lane's frame slot (ORB results)
     const double* map_pos; const double* map_nrm; const uint8_t* map_flags; const uint32_t* map_desc; const int32_t* active;
     int n_active, cap, max_hyp, gate_lds;
@@ -100,7 +101,7 @@ struct vo_ctx {
     int32_t* d_mcand;                               // visible candidates (indices into the active list), unordered
     vo_match* d_matches; float* d_corr_xyz; float* d_corr_uv; int corr_cap;
     double* d_hyp_pose; int* d_hyp_cnt;             // [max_hyp][12], [max_hyp]
-    int32_t* d_inliers; uint8_t* d_lm_mask;
+    int32_t* d_inliers; uint8_t* d_lm_mask; double* d_lm_x = nullptr;
     LaunchSet ls;                                   // this context's own lanes (d_track / h_track alias ls.d_track / ls.h_track)
     TrackDev* d_track; TrackDev* h_track;           // [lanes]; h_track pinned
     size_t lane_stride; int lanes;                  // element stride of the per-lane chain buffers
@@ -148,7 +149,8 @@ struct ChainDims { int max_active, max_feat; };
 int vo_track_match_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* d_lanes, int nl, ChainDims dims, float ratio, float floor_dist);
 // stage: 1 = hypotheses + scoring, 2 = adaptive-stop scan + inlier list, 3 = both; (rank, world): this process scores hypotheses h % world == rank
 int vo_track_ransac_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* d_lanes, int nl, int n_hyp, float reproj_px, float conf, int pass, int stage = 3, int rank = 0, int world = 1);
-int vo_track_lm_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* d_lanes, int nl, double delta, double cut, int it_r, int it_p, bool write_flags);
+int vo_track_lm_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* d_lanes, int nl, double delta, double cut, int it_r, int it_p, bool write_flags, int inlier_hint = 0);
+#define VO_LM_X_DOUBLES (32 + 2 * 8 * 32)               // = LM_X_DOUBLES of vo_track.hip
 void vo_lane_fill(vo_ctx* c, int lane, int slot, uint64_t seed, TrackDev* d_tr, LaneDesc* out);   // descriptor of lane `lane` of context c
 int vo_corr_from_host(vo_ctx* c, const float* xyz, const float* uv, int n);
 int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out);                       // vo_ba.hip

@@ -588,11 +588,51 @@ __device__ __forceinline__ bool chol6_dev(double* A, double* b) {
     return true;
 }
 
+// ---- several workgroups per lane (large inlier sets) ------------------------------------------------------------------------
+// Above a few thousand inliers one edge pass costs more than a hand-off between workgroups (config 5: 18 k inliers, 20 us per
+// pass in one workgroup), so the lane's inlier list is cut into `nwg` contiguous shares, one workgroup each.  After its own
+// reduction every workgroup publishes its 28 sums (write-through stores), arrives at the lane's counter and, once all have
+// arrived, adds up ALL partials in the same order: every workgroup then holds the same H, b, chi2 and takes the same LM
+// decisions -- the serial part is replicated, nothing is broadcast.  Hand-off recipe: cdna_hip_programming.md Guideline 16 (R1) with
+// agent-scope (sc1) loads on the consuming side.  The partials are double buffered by episode parity: a workgroup can be at
+// most one episode ahead of the slowest one.  Every spin is bounded (a timeout marks the lane's result and lets everybody go on).
+#define LM_KMAX 8
+#define LM_X_DOUBLES (32 + 2 * LM_KMAX * 32)       // per lane: [counter line | exit line] (256 B) + 2 x LM_KMAX x 32 partial sums
+struct LmX { unsigned* cnt; unsigned* exit_cnt; double* part; int nwg, wg; unsigned epi; int* status; int* s_flag; };
+__device__ __forceinline__ void lm_xchg(LmX& X, double* tot, int nv) {      // tot: LDS, [0, nv) valid in this workgroup -> sums over the lane's workgroups
+    const int par = X.epi & 1;
+    if ((int)threadIdx.x < nv) __hip_atomic_store(X.part + (size_t)(par * LM_KMAX + X.wg) * 32 + threadIdx.x, tot[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    ++X.epi;
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(X.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = (unsigned)X.nwg * X.epi;
+        unsigned spins = 0; unsigned long long t0 = 0; int ok = 1;
+        while (__hip_atomic_load(X.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 255u) == 0) {
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                if (!t0) t0 = now; else if (now - t0 > 20000000ull) { ok = 0; break; }       // 0.2 s: a peer workgroup never became resident
+            }
+        }
+        if (!ok) *X.status = VO_E_DEVICE;
+        *X.s_flag = ok;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nv) {
+        double sum = 0;
+        for (int w = 0; w < X.nwg; ++w) sum += __hip_atomic_load(X.part + (size_t)(par * LM_KMAX + w) * 32 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tot[threadIdx.x] = sum;
+    }
+    __syncthreads();
+}
+
 // One pass over the active edges at pose T: robust chi2, H (upper triangle) and b, reduced over the whole
 // workgroup into the LDS buffer `tot` ([0..20] H, [21..26] b, [27] chi) that every thread reads afterwards.
 __device__ void lm_pass_dev(const CamD& cam, const float* cxyz, const float* cuv, const int32_t* edges,
                             const uint8_t* mask, int n, int round, const double* T, double delta,
-                            double* s_part, double* tot, int& phase, const uint16_t* idx, int nidx) {
+                            double* s_part, double* tot, int& phase, const uint16_t* idx, int nidx, LmX* X) {
 #pragma clang fp contract(fast)
     const bool robust = round == 0;
 #ifdef VO_LM_STAMPS
@@ -674,6 +714,7 @@ __device__ void lm_pass_dev(const CamD& cam, const float* cxyz, const float* cuv
     }
     __syncthreads();                                   // tot[0..27] (LDS) is now valid for every thread
     phase ^= 1;
+    if (X) lm_xchg(*X, tot, LM_NV);                    // several workgroups per lane: sums over all of them
 #ifdef VO_LM_STAMPS
     if (threadIdx.x == 0) { g_dbg[4] += ts1 - ts0; g_dbg[5] += ts2 - ts1; g_dbg[6] += clock64() - ts2; }
 #endif
@@ -683,14 +724,14 @@ __device__ void lm_pass_dev(const CamD& cam, const float* cxyz, const float* cuv
 // linearises at the trial pose, so an accepted step needs no second pass (same numbers g2o recomputes).
 __device__ int lm_optimize_dev(const CamD& cam, const float* cxyz, const float* cuv, const int32_t* edges, const uint8_t* mask, int n,
                                int round, double* T, double delta, int max_it, double* s_part, double* s_tot, int& phase,
-                               const uint16_t* idx = nullptr, int nidx = 0) {
+                               LmX* X, const uint16_t* idx = nullptr, int nidx = 0) {
     // The current linearisation and the trial one live in two LDS buffers (s_tot + 32 cur, s_tot + 32 (cur ^ 1)): an
     // accepted step flips `cur`, nothing is copied and no thread keeps 2 x 28 doubles in registers across a pass.
     int cur = 0;
 #ifdef VO_LM_STAMPS
     long long t_pass = 0, t_serial = 0, n_pass = 1, t0 = clock64();
 #endif
-    lm_pass_dev(cam, cxyz, cuv, edges, mask, n, round, T, delta, s_part, s_tot, phase, idx, nidx);
+    lm_pass_dev(cam, cxyz, cuv, edges, mask, n, round, T, delta, s_part, s_tot, phase, idx, nidx, X);
 #ifdef VO_LM_STAMPS
     t_pass += clock64() - t0;
 #endif
@@ -724,7 +765,7 @@ __device__ int lm_optimize_dev(const CamD& cam, const float* cxyz, const float* 
 #endif
             // block-uniform control flow: every thread holds the same H, b, lambda
             const double* tv = s_tot + 32 * (cur ^ 1);
-            lm_pass_dev(cam, cxyz, cuv, edges, mask, n, round, Tn, delta, s_part, s_tot + 32 * (cur ^ 1), phase, idx, nidx);
+            lm_pass_dev(cam, cxyz, cuv, edges, mask, n, round, Tn, delta, s_part, s_tot + 32 * (cur ^ 1), phase, idx, nidx, X);
 #ifdef VO_LM_STAMPS
             t_pass += clock64() - t2; ++n_pass;
 #endif
@@ -764,18 +805,29 @@ __device__ __forceinline__ double edge_chi2_dev(const CamD& cam, const double* T
 
 __global__ __launch_bounds__(LM_T) void k_pose_lm(const LaneDesc* __restrict__ lanes, double delta, double cut, int it_r, int it_p, int write_flags) {
     LANE_PTRS(lanes)
-    const int32_t* edges = inliers;
     if (!write_flags) matches = nullptr;
-    const int32_t* edges_g = edges;
 #ifdef VO_LM_STAMPS
     const long long t_kernel0 = clock64();
 #endif
     extern __shared__ float s_corr[];                  // gathered inlier correspondences: n x 3 then n x 2 floats
     __shared__ double s_part[2 * LM_W * 32];
     __shared__ double s_out[2 * 32];
+    __shared__ double s_x[32];
     int phase = 0;
     __shared__ int s_cnt[2];
-    const int n = tr->n_inl;
+    __shared__ int s_xflag;
+    // this workgroup's share of the lane's inlier list: [lo, lo + n) of n_all (gridDim.x workgroups per lane)
+    const int n_all = tr->n_inl, nwg = gridDim.x, wg = blockIdx.x;
+    const int lo = (int)((long long)n_all * wg / nwg), n = (int)((long long)n_all * (wg + 1) / nwg) - lo;
+    LmX X_; LmX* X = nullptr;
+    if (nwg > 1) {
+        unsigned* cw = reinterpret_cast<unsigned*>(ld_.lm_x);
+        X_.cnt = cw; X_.exit_cnt = cw + 32; X_.part = ld_.lm_x + 32; X_.nwg = nwg; X_.wg = wg; X_.epi = 0; X_.status = &tr->status; X_.s_flag = &s_xflag;
+        X = &X_;
+    }
+    const int32_t* edges = inliers + lo;
+    const int32_t* edges_g = edges;
+    uint8_t* const mask_l = mask + lo;
     double T[12];
     for (int i = 0; i < 12; ++i) T[i] = tr->T[i];
     if (threadIdx.x == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
@@ -789,7 +841,7 @@ __global__ __launch_bounds__(LM_T) void k_pose_lm(const LaneDesc* __restrict__ l
     }
     __syncthreads();
     int iters = 0;
-    if (n > 0) iters += lm_optimize_dev(cam, cxyz, cuv, edges, mask, n, 0, T, delta, it_r, s_part, s_out, phase);
+    if (n_all > 0) iters += lm_optimize_dev(cam, cxyz, cuv, edges, mask_l, n, 0, T, delta, it_r, s_part, s_out, phase, X);
     // edges whose chi2 exceeds the cut leave the second round (frontend.cpp:294-306)
     int loc = 0;
     __shared__ uint16_t s_keep[LM_LDS_MAX];            // LDS path: ordered list of the surviving edges
@@ -802,7 +854,7 @@ __global__ __launch_bounds__(LM_T) void k_pose_lm(const LaneDesc* __restrict__ l
         if (i < n) {
             const int k = edges ? edges[i] : i;
             keep = !(edge_chi2_dev(cam, T, &cxyz[3 * k], &cuv[2 * k]) > cut);
-            mask[i] = keep ? 2 : 0;
+            mask_l[i] = keep ? 2 : 0;
             loc += keep ? 1 : 0;
         }
         if (lds_path) {                                // block-uniform
@@ -820,20 +872,39 @@ __global__ __launch_bounds__(LM_T) void k_pose_lm(const LaneDesc* __restrict__ l
     }
     if (loc) atomicAdd(&s_cnt[0], loc);
     __syncthreads();
-    if (s_cnt[0] > 0) iters += lm_optimize_dev(cam, cxyz, cuv, edges, mask, n, 1, T, delta, it_p, s_part, s_out, phase, lds_path ? s_keep : nullptr, run);
+    int kept_all = s_cnt[0];
+    if (X) {                                           // the lane's total (every workgroup takes the same branch below)
+        if (threadIdx.x == 0) s_x[0] = (double)s_cnt[0];
+        __syncthreads();
+        lm_xchg(*X, s_x, 1);
+        kept_all = (int)s_x[0];
+    }
+    if (kept_all > 0) iters += lm_optimize_dev(cam, cxyz, cuv, edges, mask_l, n, 1, T, delta, it_p, s_part, s_out, phase, X, lds_path ? s_keep : nullptr, run);
     loc = 0;
     for (int i = threadIdx.x; i < n; i += LM_T) {
         const int k = edges ? edges[i] : i;
         const bool in = !(edge_chi2_dev(cam, T, &cxyz[3 * k], &cuv[2 * k]) > cut);
-        mask[i] = (mask[i] & 2) | (in ? 1 : 0);
+        mask_l[i] = (mask_l[i] & 2) | (in ? 1 : 0);
         if (matches) matches[edges_g[i]].flags = VO_MATCH_RANSAC_INLIER | (in ? VO_MATCH_LM_INLIER : 0);     // frontend.cpp:242,:317-329
         loc += in ? 1 : 0;
     }
     if (loc) atomicAdd(&s_cnt[1], loc);
     __syncthreads();
-    if (threadIdx.x == 0) {
+    int inl_all = s_cnt[1];
+    if (X) {
+        if (threadIdx.x == 0) s_x[0] = (double)s_cnt[1];
+        __syncthreads();
+        lm_xchg(*X, s_x, 1);
+        inl_all = (int)s_x[0];
+        // the last workgroup out clears the counters for the next launch (nobody polls them any more)
+        if (threadIdx.x == 0 && __hip_atomic_fetch_add(X->exit_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nwg - 1) {
+            __hip_atomic_store(X->cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(X->exit_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (threadIdx.x == 0 && wg == 0) {
         for (int i = 0; i < 12; ++i) tr->T[i] = T[i];
-        tr->lm_iters += iters; tr->n_lm_inl = s_cnt[1];
+        tr->lm_iters += iters; tr->n_lm_inl = inl_all;
 #ifdef VO_LM_STAMPS
         for (int i = 0; i < 7; ++i) { tr->dbg[i] = g_dbg[i]; g_dbg[i] = 0; }
         tr->dbg[7] = clock64() - t_kernel0;
@@ -875,7 +946,7 @@ void vo_lane_fill(vo_ctx* c, int lane, int slot, uint64_t seed, TrackDev* d_tr, 
     o->tr = d_tr; o->best = c->d_best + L * M; o->cand = c->d_mcand + L * M; o->matches = c->d_matches + L * M;
     o->cxyz = c->d_corr_xyz + 3 * L * M; o->cuv = c->d_corr_uv + 2 * L * M;
     o->hyp_pose = c->d_hyp_pose + (size_t)12 * L * c->p.max_hypotheses; o->hyp_cnt = c->d_hyp_cnt + L * c->p.max_hypotheses;
-    o->inliers = c->d_inliers + L * M; o->mask = c->d_lm_mask + L * M;
+    o->inliers = c->d_inliers + L * M; o->mask = c->d_lm_mask + L * M; o->lm_x = c->d_lm_x + L * LM_X_DOUBLES;
     o->fdesc = (const uint32_t*)(c->d_desc + (size_t)slot * c->plan.nfeat * 32); o->nkp = c->d_nkp + slot; o->kps = c->d_kps + (size_t)slot * c->plan.nfeat;
     o->map_pos = c->d_map_pos; o->map_nrm = c->d_map_nrm; o->map_flags = c->d_map_flags; o->map_desc = c->d_map_desc; o->active = c->d_active;
     o->n_active = c->n_active; o->cap = c->corr_cap; o->max_hyp = c->p.max_hypotheses; o->gate_lds = c->n_active <= GATE_LDS_MAX ? 1 : 0;
@@ -931,9 +1002,14 @@ int vo_track_ransac_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* dl, int
     return VO_OK;
 }
 
-int vo_track_lm_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* dl, int nl, double delta, double cut, int it_r, int it_p, bool write_flags) {
+int vo_track_lm_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* dl, int nl, double delta, double cut, int it_r, int it_p, bool write_flags, int inlier_hint) {
     ProfScope ps(prof, "k_pose_lm", st);
-    hipLaunchKernelGGL(k_pose_lm, dim3(1, 1, nl), dim3(LM_T), LM_LDS_MAX * 20, st, dl, delta, cut, it_r, it_p, write_flags ? 1 : 0);
+    // workgroups per lane: one up to ~6 k inliers (a pass is then cheaper than a hand-off), one per 3 k beyond; all workgroups of the
+    // launch must be resident at once, so the split is only taken while the grid stays far below the chip (2 per compute unit fit)
+    static const int force = getenv("VO_LM_WGS") ? atoi(getenv("VO_LM_WGS")) : 0;
+    int nwg = force > 0 ? force : (inlier_hint > 6000 ? (inlier_hint + 2999) / 3000 : 1);
+    nwg = std::max(1, std::min(std::min(nwg, LM_KMAX), 128 / std::max(1, nl)));
+    hipLaunchKernelGGL(k_pose_lm, dim3(nwg, 1, nl), dim3(LM_T), LM_LDS_MAX * 20, st, dl, delta, cut, it_r, it_p, write_flags ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return VO_OK;
 }
