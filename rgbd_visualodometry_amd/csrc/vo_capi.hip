@@ -629,10 +629,10 @@ int vo_pnp_ransac(vo_ctx* c, int n_hyp, float reproj_px, float conf, uint64_t se
     HIP_TRY(hipMemcpyAsync(c->d_track, c->h_track, sizeof(TrackDev), hipMemcpyHostToDevice, c->stream));
     if ((rc = upload_lanes(c, 1, nullptr, &seed))) return rc;
     if (c->shard_world > 1) {
-        if ((rc = vo_track_ransac_launch(c, c->stream, c->ls.d_lanes, 1, n_hyp, reproj_px, conf, 0, 1, c->shard_rank, c->shard_world))) return rc;
+        if ((rc = vo_track_ransac_launch(c, c->stream, c->ls.d_lanes, 1, n_hyp, reproj_px, conf, 0, 1, c->shard_rank, c->shard_world, c->h_track->n_match))) return rc;
         if ((rc = shard_exchange(c, c->stream, 1, n_hyp))) return rc;
         rc = vo_track_ransac_launch(c, c->stream, c->ls.d_lanes, 1, n_hyp, reproj_px, conf, 0, 2);
-    } else rc = vo_track_ransac_launch(c, c->stream, c->ls.d_lanes, 1, n_hyp, reproj_px, conf, 0);
+    } else rc = vo_track_ransac_launch(c, c->stream, c->ls.d_lanes, 1, n_hyp, reproj_px, conf, 0, 3, 0, 1, c->h_track->n_match, hyp_counts != nullptr);
     if (rc) return rc;
     rc = download_track(c);
     if (rc) return rc;
@@ -708,10 +708,10 @@ static int chain_run(vo_ctx* prof, hipStream_t st, LaunchSet& ls, std::vector<Gr
         if ((rc = vo_track_match_launch(prof, st, ls.d_lanes, nl, dims, tp->match_ratio, tp->match_floor))) return rc;
         vo_ctx* sc = batch[0]->c;                           // hypothesis sharding applies to un-grouped contexts (one request per chain)
         if (sc->shard_world > 1 && batch.size() == 1) {
-            if ((rc = vo_track_ransac_launch(prof, st, ls.d_lanes, nl, tp->n_hyp, tp->reproj_px, tp->confidence, pass, 1, sc->shard_rank, sc->shard_world))) return rc;
+            if ((rc = vo_track_ransac_launch(prof, st, ls.d_lanes, nl, tp->n_hyp, tp->reproj_px, tp->confidence, pass, 1, sc->shard_rank, sc->shard_world, dims.max_active))) return rc;
             if ((rc = shard_exchange(sc, st, nl, tp->n_hyp))) return rc;
             if ((rc = vo_track_ransac_launch(prof, st, ls.d_lanes, nl, tp->n_hyp, tp->reproj_px, tp->confidence, pass, 2))) return rc;
-        } else if ((rc = vo_track_ransac_launch(prof, st, ls.d_lanes, nl, tp->n_hyp, tp->reproj_px, tp->confidence, pass))) return rc;
+        } else if ((rc = vo_track_ransac_launch(prof, st, ls.d_lanes, nl, tp->n_hyp, tp->reproj_px, tp->confidence, pass, 3, 0, 1, dims.max_active))) return rc;      // matches <= candidates <= active points
         if ((rc = vo_track_lm_launch(prof, st, ls.d_lanes, nl, tp->huber_delta, tp->chi2_cut, tp->it_robust, tp->it_plain, pass == tp->passes - 1, lm_hint))) return rc;
     }
     // match records that callers asked for travel with the headers; sized from the largest match count seen recently

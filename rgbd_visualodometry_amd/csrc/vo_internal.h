@@ -148,7 +148,8 @@ int vo_orb_launch(vo_ctx* c, int slot0, int nslots);                            
 struct ChainDims { int max_active, max_feat; };
 int vo_track_match_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* d_lanes, int nl, ChainDims dims, float ratio, float floor_dist);
 // stage: 1 = hypotheses + scoring, 2 = adaptive-stop scan + inlier list, 3 = both; (rank, world): this process scores hypotheses h % world == rank
-int vo_track_ransac_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* d_lanes, int nl, int n_hyp, float reproj_px, float conf, int pass, int stage = 3, int rank = 0, int world = 1);
+// corr_hint: upper bound of the lanes' match counts (sizes the scoring grid: the counts themselves are only known on the device)
+int vo_track_ransac_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* d_lanes, int nl, int n_hyp, float reproj_px, float conf, int pass, int stage = 3, int rank = 0, int world = 1, int corr_hint = 1 << 30, bool all_counts = false);
 int vo_track_lm_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* d_lanes, int nl, double delta, double cut, int it_r, int it_p, bool write_flags, int inlier_hint = 0);
 #define VO_LM_X_DOUBLES (32 + 2 * 8 * 32)               // = LM_X_DOUBLES of vo_track.hip
 void vo_lane_fill(vo_ctx* c, int lane, int slot, uint64_t seed, TrackDev* d_tr, LaneDesc* out);   // descriptor of lane `lane` of context c

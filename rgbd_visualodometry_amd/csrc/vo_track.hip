@@ -447,53 +447,140 @@ __global__ __launch_bounds__(64) void k_ransac_hyp(const LaneDesc* __restrict__ 
     hyp_cnt[h] = 0;
 }
 
-__global__ __launch_bounds__(1024) void k_ransac_score(const LaneDesc* __restrict__ lanes, int n_hyp, double thr2, int rank, int world) {
+// Scoring: a workgroup keeps up to RS_R x 1024 correspondences in REGISTERS (read once, coalesced) and streams a tile of `ht`
+// hypotheses past them: a hypothesis is 12 uniform doubles, i.e. scalar loads, so the vector side only does the reprojection test
+// and one ballot + popcount per wavefront.  blockIdx.x = hypothesis tile, blockIdx.y = chunk of RS_R x 1024 correspondences;
+// the chunks' counts meet in hyp_cnt[h] (integer atomics: exact in any order).  With one workgroup per hypothesis every one of
+// them re-read all K correspondences (round 2: 10x the algorithmic bytes; 800 MB of L2 reads per pass at 2048 x 19.6 k).
+#define RS_R 4
+__global__ __launch_bounds__(1024) void k_ransac_score(const LaneDesc* __restrict__ lanes, int h_first, int n_hyp, int ht, double thr2, int rank, int world) {
     LANE_PTRS(lanes)
-    __shared__ int s_cnt;
-    const int h = blockIdx.x;
-    if (world > 1 && h % world != rank) { if (threadIdx.x == 0) hyp_cnt[h] = 0; return; }      // another rank scores it: 0 goes into the sum
-    if (hyp_cnt[h] < 0) return;
-    if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
+    __shared__ int s_cnt[64];
     const int n = tr->n_match;
-    double T[12];
+    const int k0 = blockIdx.y * (RS_R * 1024);
+    if (k0 >= n) return;                                      // the grid is sized for the largest lane
+    const double* __restrict__ hp = ld_.hyp_pose;
+    const int h0 = h_first + blockIdx.x * ht;
+    // second stage (h_first > 0): the scan over the first h_first counts (k_ransac_peek) has bounded the number of hypotheses the
+    // sequential RANSAC loop would ever look at; the ones beyond it are not scored (their count stays 0: never a record)
+    if (h_first > 0 && h0 >= tr->pad1) return;
+    if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
+    float X[RS_R][3], Z[RS_R][2];
+    bool live[RS_R];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) T[i] = hyp_pose[(size_t)12 * h + i];
-    int cnt = 0;
-    for (int k = threadIdx.x; k < n; k += 1024) cnt += reproj_ok_dev(cam, T, &cxyz[3 * k], &cuv[2 * k], thr2) ? 1 : 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&s_cnt, cnt);
+    for (int r = 0; r < RS_R; ++r) {
+        const int k = k0 + r * 1024 + (int)threadIdx.x, kc = min(k, n - 1);
+        live[r] = k < n;
+        X[r][0] = cxyz[3 * kc]; X[r][1] = cxyz[3 * kc + 1]; X[r][2] = cxyz[3 * kc + 2]; Z[r][0] = cuv[2 * kc]; Z[r][1] = cuv[2 * kc + 1];
+    }
     __syncthreads();
-    if (threadIdx.x == 0) hyp_cnt[h] = s_cnt;
+    for (int hi = 0; hi < ht; ++hi) {
+        const int h = h0 + hi;
+        if (h >= n_hyp) break;
+        if (world > 1 && h % world != rank) { if (blockIdx.y == 0 && threadIdx.x == 0) hyp_cnt[h] = 0; continue; }      // another rank scores it: 0 goes into the sum
+        if (hyp_cnt[h] < 0) continue;                         // degenerate sample (k_ransac_hyp); counts only grow from 0, so the test is stable
+        double T[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T[i] = hp[(size_t)12 * h + i];
+        int c = 0;
+#pragma unroll
+        for (int r = 0; r < RS_R; ++r) c += __popcll(__ballot(live[r] && reproj_ok_dev(cam, T, X[r], Z[r], thr2)));
+        if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_cnt[hi], c);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < ht) {
+        const int h = h0 + threadIdx.x;
+        if (h < n_hyp && s_cnt[threadIdx.x]) atomicAdd(&hyp_cnt[h], s_cnt[threadIdx.x]);
+    }
 }
 
 __device__ __forceinline__ int ransac_update_iters_dev(double conf, int n_pts, int n_inl, int max_iters) {
     const double w = (double)n_inl / (double)n_pts;
     const double qf = 1.0 - w * w * w * w, target = 1.0 - conf;
     if (!(qf > 0.0)) return 0;
+    // The product loop below defines the result (the CPU restatement runs the same loop).  With a poor hypothesis qf is close to 1
+    // and the loop would run all max_iters dependent multiplications (13 us at 2048) only to return max_iters: a logarithm
+    // estimate with a 2 % margin -- far beyond the k * 2^-53 rounding drift of the product -- settles that case at once.
+    if (log(target) / log(qf) > 1.02 * (double)max_iters + 4.0) return max_iters;
     double acc = 1.0; int k = 0;
     while (acc > target && k < max_iters) { acc *= qf; ++k; }
     return k;
+}
+
+// The sequential scan of cv::RANSACPointSetRegistrator (best so far, adaptive iteration count) only acts at RECORDS: hypotheses
+// whose count exceeds every earlier one.  They are found in parallel (running maximum over the hypothesis order), compacted in
+// order, and one thread replays the scan over the handful of records instead of walking 100 .. 2048 counts in global memory.
+// Returns (thread 0 only): best hypothesis, its count, the final iteration bound, the index the sequential loop stops at.
+__device__ __forceinline__ void ransac_scan_dev(const int* hyp_cnt, int n_hyp, int n, double conf, int* s_w, int* s_pmax, int* s_rec_h, int* s_rec_c, int* s_nrec,
+                                                int& bh, int& best_cnt, int& niters, int& used) {
+    if (threadIdx.x == 0) *s_nrec = 0;
+    __syncthreads();
+    int run_max = 3;                                          // a model needs more than 3 inliers (best_cnt starts at 3)
+    for (int base = 0; base < n_hyp && n >= 4; base += 1024) {
+        const int h = base + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int cnt = h < n_hyp ? hyp_cnt[h] : -1;
+        int pm = cnt;                                         // inclusive prefix maximum inside the wavefront
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(pm, o, 64); if (lane >= o) pm = max(pm, t); }
+        if (lane == 63) s_pmax[wave] = pm;
+        __syncthreads();
+        int before = run_max;                                 // maximum of everything in front of this lane
+        for (int w = 0; w < wave; ++w) before = max(before, s_pmax[w]);
+        const int excl = __shfl_up(pm, 1, 64);
+        if (lane > 0) before = max(before, excl);
+        const bool rec = cnt > before;
+        int tot;
+        const int pos = block_excl_scan_flag(rec, s_w, tot);
+        const int nr0 = *s_nrec;
+        if (rec && nr0 + pos < 64) { s_rec_h[nr0 + pos] = h; s_rec_c[nr0 + pos] = cnt; }
+        int allmax = run_max;
+        for (int w = 0; w < 16; ++w) allmax = max(allmax, s_pmax[w]);
+        run_max = allmax;
+        __syncthreads();
+        if (threadIdx.x == 0) *s_nrec = min(64, nr0 + tot);   // counts grow at least by one per record: the replay below stops long before 64 records
+        __syncthreads();
+    }
+    bh = -1; best_cnt = 3; niters = n_hyp; used = 0;
+    if (threadIdx.x == 0 && n >= 4) {
+        for (int i = 0; i < *s_nrec; ++i) {
+            const int h = s_rec_h[i], cnt = s_rec_c[i];
+            if (h >= niters) break;                           // the sequential scan would have stopped before this hypothesis
+            best_cnt = cnt; bh = h; niters = min(niters, ransac_update_iters_dev(conf, n, cnt, niters));
+        }
+        used = max(niters, bh + 1);                           // the scan leaves its loop at the first index >= niters, and it has looked at index bh
+    }
+}
+
+// after the first stage of the scoring: how far the sequential scan can still get (tr->pad1), given the counts of hypotheses [0, h_first)
+__global__ __launch_bounds__(1024) void k_ransac_peek(const LaneDesc* __restrict__ lanes, int h_first, int n_hyp, double conf) {
+    LANE_PTRS(lanes)
+    __shared__ int s_w[16], s_pmax[16], s_rec_h[64], s_rec_c[64], s_nrec;
+    int bh, best_cnt, niters, used;
+    ransac_scan_dev(hyp_cnt, h_first, tr->n_match, conf, s_w, s_pmax, s_rec_h, s_rec_c, &s_nrec, bh, best_cnt, niters, used);
+    // the bound after h_first hypotheses, for a scan over n_hyp of them: update_iters(.., max = n_hyp) clipped by what the records gave
+    if (threadIdx.x == 0) {
+        int lim = n_hyp;
+        if (tr->n_match >= 4) for (int i = 0; i < s_nrec; ++i) { if (s_rec_h[i] >= lim) break; lim = min(lim, ransac_update_iters_dev(conf, tr->n_match, s_rec_c[i], lim)); }
+        tr->pad1 = lim;
+    }
 }
 
 __global__ __launch_bounds__(1024) void k_ransac_select(const LaneDesc* __restrict__ lanes, int n_hyp, double thr2, double conf) {
     LANE_PTRS(lanes)
     __shared__ int s_w[16];
     __shared__ int s_best;
+    __shared__ int s_pmax[16];
+    __shared__ int s_rec_h[64], s_rec_c[64], s_nrec;
     const int n = tr->n_match;
-    if (threadIdx.x == 0) {
-        int bh = -1, best_cnt = 3, niters = n_hyp, h = 0;
-        if (n >= 4) {
-            for (; h < niters; ++h) {
-                const int cnt = hyp_cnt[h];
-                if (cnt > best_cnt) { best_cnt = cnt; bh = h; niters = min(niters, ransac_update_iters_dev(conf, n, cnt, niters)); }
-            }
+    {
+        int bh, best_cnt, niters, used;
+        ransac_scan_dev(hyp_cnt, n_hyp, n, conf, s_w, s_pmax, s_rec_h, s_rec_c, &s_nrec, bh, best_cnt, niters, used);
+        if (threadIdx.x == 0) {
+            s_best = bh;
+            tr->best_hyp = bh; tr->iters_used = used; tr->best_cnt = bh >= 0 ? best_cnt : 0;
+            if (bh >= 0) for (int i = 0; i < 12; ++i) tr->T[i] = hyp_pose[(size_t)12 * bh + i];
+            for (int i = 0; i < 12; ++i) tr->T_ransac[i] = tr->T[i];
         }
-        s_best = bh;
-        tr->best_hyp = bh; tr->iters_used = h; tr->best_cnt = bh >= 0 ? best_cnt : 0;
-        if (bh >= 0) for (int i = 0; i < 12; ++i) tr->T[i] = hyp_pose[(size_t)12 * bh + i];
-        for (int i = 0; i < 12; ++i) tr->T_ransac[i] = tr->T[i];
     }
     __syncthreads();
     const int bsel = s_best;
@@ -988,13 +1075,25 @@ int vo_corr_from_host(vo_ctx* c, const float* xyz, const float* uv, int n) {
     return VO_OK;
 }
 
-int vo_track_ransac_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* dl, int nl, int n_hyp, float reproj_px, float conf, int pass, int stage, int rank, int world) {
+int vo_track_ransac_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* dl, int nl, int n_hyp, float reproj_px, float conf, int pass, int stage, int rank, int world, int corr_hint, bool all_counts) {
     const double thr2 = (double)reproj_px * (double)reproj_px;
     if (stage & 1) {
       { ProfScope ps(prof, "k_ransac_hyp", st);
         hipLaunchKernelGGL(k_ransac_hyp, dim3((n_hyp + 63) / 64, 1, nl), dim3(64), 0, st, dl, n_hyp, pass); }
       { ProfScope ps(prof, "k_ransac_score", st);
-        hipLaunchKernelGGL(k_ransac_score, dim3(n_hyp, 1, nl), dim3(1024), 0, st, dl, n_hyp, thr2, rank, world); }
+        // hypotheses per workgroup: 1 up to 128 hypotheses (latency matters there), up to 32 beyond; correspondence chunks from the host's hint
+        const int chunks = std::max(1, (corr_hint + RS_R * 1024 - 1) / (RS_R * 1024));
+        // Beyond 256 hypotheses (and unless the hypotheses are sharded over ranks: every rank must then produce all of its counts for the
+        // exchange) the scoring runs in two stages: the first 128, a peek at how far the adaptive stop lets the scan go, then the
+        // rest -- whose workgroups leave at once when their hypotheses lie beyond that bound.  The result is the full scan's.
+        const int h_split = (n_hyp > 256 && world == 1 && !all_counts) ? 128 : n_hyp;     // all_counts: the caller reads every hypothesis' count (vo_pnp_ransac)
+        const int ht1 = std::max(1, std::min(32, h_split / 64));
+        hipLaunchKernelGGL(k_ransac_score, dim3((h_split + ht1 - 1) / ht1, chunks, nl), dim3(1024), 0, st, dl, 0, h_split, ht1, thr2, rank, world);
+        if (h_split < n_hyp) {
+            hipLaunchKernelGGL(k_ransac_peek, dim3(1, 1, nl), dim3(1024), 0, st, dl, h_split, n_hyp, (double)conf);
+            const int ht2 = 32;
+            hipLaunchKernelGGL(k_ransac_score, dim3((n_hyp - h_split + ht2 - 1) / ht2, chunks, nl), dim3(1024), 0, st, dl, h_split, n_hyp, ht2, thr2, rank, world);
+        } }
     }
     if (stage & 2) { ProfScope ps(prof, "k_ransac_select", st);
       hipLaunchKernelGGL(k_ransac_select, dim3(1, 1, nl), dim3(1024), 0, st, dl, n_hyp, thr2, (double)conf); }
