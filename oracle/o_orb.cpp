@@ -216,19 +216,26 @@ void orb_detect_describe(const OrbPlan& pl, const uint8_t* bgr, int bgr_stride, 
             for (auto& c : cand) (*dbg)[l].cand_xy.push_back(c.y * w + c.x);
         }
         // retain best 2*quota by FAST score, keeping all ties at the cut (KeyPointsFilter::retainBest);
-        // if the ties would exceed the 4*quota working capacity the cut moves above them.
+        // if the ties would exceed the 4*quota working capacity, they are ranked by pixel index (row, then column)
+        // and exactly as many as 2*quota needs stay.
         const int quota = pl.quota[l];
-        int thr = 0;
+        int thr = 0, need = -1;
         if ((int)cand.size() > 2 * quota) {
             int hist[256] = {0};
             for (auto& c : cand) hist[c.s]++;
             int acc = 0, s = 255;
             for (; s >= 0; --s) { acc += hist[s]; if (acc >= 2 * quota) break; }
             thr = s;
-            if (acc > 4 * quota) thr = s + 1;
+            if (acc > 4 * quota) need = 2 * quota - (acc - hist[s]);
         }
         std::vector<Cand> kept;
-        for (auto& c : cand) if (c.s >= thr) { c.hk = harris_key(img, w, c.x, c.y); kept.push_back(c); }
+        for (auto& c : cand) if (c.s > thr || (c.s == thr && need < 0)) { c.hk = harris_key(img, w, c.x, c.y); kept.push_back(c); }
+        if (need >= 0) {
+            std::vector<Cand> ties;
+            for (auto& c : cand) if (c.s == thr) ties.push_back(c);
+            std::sort(ties.begin(), ties.end(), [](const Cand& a, const Cand& b) { return a.y != b.y ? a.y < b.y : a.x < b.x; });
+            for (int i = 0; i < need && i < (int)ties.size(); ++i) { ties[i].hk = harris_key(img, w, ties[i].x, ties[i].y); kept.push_back(ties[i]); }
+        }
         // retain best `quota` by Harris (descending; ties by ascending pixel index)
         std::sort(kept.begin(), kept.end(), [w](const Cand& a, const Cand& b) {
             if (a.hk != b.hk) return a.hk > b.hk;

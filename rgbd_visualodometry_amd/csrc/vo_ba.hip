@@ -1539,7 +1539,8 @@ static int ba_engine_solve(BaEngine* E, BaJob* j) {
             lk.unlock();
             const int rc = ba_engine_pump(E);
             lk.lock();
-            if (rc != VO_OK) {                              // a HIP error: fail everything in flight
+            if (rc != VO_OK) {                              // a HIP error: fail everything in flight -- once the engine's stream has drained (the owners may free their slabs at once)
+                (void)hipStreamSynchronize(E->st);
                 for (int s = 0; s < BA_SLOTS; ++s) if (E->slot[s]) { E->slot[s]->rc = rc; E->slot[s]->done = true; E->slot[s] = nullptr; }
                 while (!E->pending.empty()) { E->pending.front()->rc = rc; E->pending.front()->done = true; E->pending.pop_front(); }
             }

@@ -58,7 +58,7 @@ static int build_plan(const vo_params& p, DevPlan& P, std::vector<int>& tab, std
     }
     P.sel_cap = 1;
     while (P.sel_cap < 4 * maxq) P.sel_cap <<= 1;
-    if ((size_t)P.sel_cap * 12 + 2048 > 160 * 1024) return VO_E_INVALID;
+    if ((size_t)P.sel_cap * 12 + 4 * (256 + 8 + 4096) > 160 * 1024) return VO_E_INVALID;
     // bilinear tables
     tab.clear(); tabs.clear();
     for (int l = 1; l < P.L; ++l) {
@@ -679,7 +679,15 @@ int vo_pose_refine_lm(vo_ctx* c, double T[12], double delta, double cut, int it_
 // ---- one launch chain over the lanes of a set of requests (one request = the lanes one context contributes) ----------
 // Used for a context's own vo_track_batch (one request, its own stream and launch set) and for the fused chain of a
 // stream group (its stream and launch set).  Returns after the chain has finished and every request's results are filled in.
+static int chain_run_impl(vo_ctx* prof, hipStream_t st, LaunchSet& ls, std::vector<GroupReq*>& batch);
+// A failing call inside the chain returns early with kernels / copies of the fused chain possibly still in flight on the shared stream:
+// the stream is drained before the members are told (they may free or reuse their lane buffers at once).
 static int chain_run(vo_ctx* prof, hipStream_t st, LaunchSet& ls, std::vector<GroupReq*>& batch) {
+    const int rc = chain_run_impl(prof, st, ls, batch);
+    if (rc != VO_OK) (void)hipStreamSynchronize(st);
+    return rc;
+}
+static int chain_run_impl(vo_ctx* prof, hipStream_t st, LaunchSet& ls, std::vector<GroupReq*>& batch) {
     const vo_track_params* tp = batch[0]->tp;
     int nl = 0; ChainDims dims{0, 0};
     HIP_TRY(hipStreamSynchronize(st));                      // the pinned mirrors are rewritten below
@@ -700,7 +708,7 @@ static int chain_run(vo_ctx* prof, hipStream_t st, LaunchSet& ls, std::vector<Gr
     }
     HIP_TRY(hipMemcpyAsync(ls.d_track, ls.h_track, sizeof(TrackDev) * nl, hipMemcpyHostToDevice, st));
     int rc = VO_OK;
-    { int k = 0; for (GroupReq* r : batch) for (int i = 0; i < r->n; ++i, ++k) ls.h_lanes[k].seed = r->seeds ? r->seeds[i] : tp->seed; }
+    { int k = 0; for (GroupReq* r : batch) for (int i = 0; i < r->n; ++i, ++k) ls.h_lanes[k].seed = r->seeds ? r->seeds[i] : r->tp->seed; }      // the request's own seed: same_track_params does not compare it
     HIP_TRY(hipMemcpyAsync(ls.d_lanes, ls.h_lanes, sizeof(LaneDesc) * nl, hipMemcpyHostToDevice, st));
     int lm_hint = 0;                                        // the inlier sets are not known on the host yet: the largest recent match count bounds them
     for (GroupReq* r : batch) lm_hint = std::max(lm_hint, r->c->match_hint);
@@ -868,7 +876,13 @@ static int vo_obs_tables_ensure(vo_ctx* c) {     // allocates the observation / 
     c->obs_cap = env && atoll(env) > 0 ? std::min<long long>(atoll(env), VO_OBS_CAP) : VO_OBS_CAP; c->kf_cap = VO_KF_CAP;
     if (hipMalloc((void**)&c->d_obs_kf, 4 * (size_t)c->obs_cap) != hipSuccess || hipMalloc((void**)&c->d_obs_mp, 4 * (size_t)c->obs_cap) != hipSuccess ||
         hipMalloc((void**)&c->d_obs_uv, 8 * (size_t)c->obs_cap) != hipSuccess || hipMalloc((void**)&c->d_obs_alive, (size_t)c->obs_cap) != hipSuccess ||
-        hipMalloc((void**)&c->d_kf_pose, 96 * (size_t)c->kf_cap) != hipSuccess) return VO_E_NOMEM;
+        hipMalloc((void**)&c->d_kf_pose, 96 * (size_t)c->kf_cap) != hipSuccess) {
+        // all or nothing: a later call must not find d_obs_kf set beside null siblings
+        void** tp[] = {(void**)&c->d_obs_kf, (void**)&c->d_obs_mp, (void**)&c->d_obs_uv, (void**)&c->d_obs_alive, (void**)&c->d_kf_pose};
+        for (void** q : tp) { if (*q) (void)hipFree(*q); *q = nullptr; }
+        (void)hipGetLastError();
+        return VO_E_NOMEM;
+    }
     return VO_OK;
 }
 

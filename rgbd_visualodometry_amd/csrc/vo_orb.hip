@@ -277,21 +277,48 @@ __global__ __launch_bounds__(1024) void k_select(DevPlan P, const uint8_t* __res
     for (int i = tid; i < n; i += 1024) atomicAdd(&s_hist[cl[i] >> 24], 1);
     __syncthreads();
     if (tid == 0) {
-        int thr = 0;
+        int thr = 0, need = -1;
         if (n > 2 * quota) {
             int acc = 0, s = 255;
             for (; s >= 0; --s) { acc += s_hist[s]; if (acc >= 2 * quota) break; }
             thr = s;
-            if (acc > 4 * quota) thr = s + 1;
+            if (acc > 4 * quota) need = 2 * quota - (acc - s_hist[s]);      // the ties at the cut do not fit: only `need` of them stay
         }
-        s_misc[1] = thr;
+        s_misc[1] = thr; s_misc[2] = need;
     }
     __syncthreads();
-    const int thr = s_misc[1];
+    const int thr = s_misc[1], need = s_misc[2];
+    // Overflowing cut bin (saturated / repetitive images: thousands of corners with one score): the ties are ranked by pixel index
+    // (row, then column) and exactly the first `need` stay -- two histogram passes over the bin, independent of the arrival order
+    // of the candidate list.  (The bin used to be dropped whole, which could leave a level with fewer keypoints than its quota.)
+    int ycut = -1, xcut = -1;
+    if (need >= 0) {
+        int* s_h2 = s_misc + 8;                              // [4096]: rows, then columns (coordinates are 12 bits)
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int i = tid; i < 4096; i += 1024) s_h2[i] = 0;
+            __syncthreads();
+            const int yc = s_misc[3];
+            for (int i = tid; i < n; i += 1024) {
+                const uint32_t c = cl[i];
+                if ((int)(c >> 24) != thr) continue;
+                const int x = c & 0xFFF, y = (c >> 12) & 0xFFF;
+                if (pass == 0) atomicAdd(&s_h2[y], 1); else if (y == yc) atomicAdd(&s_h2[x], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int want = pass == 0 ? need : s_misc[4], cum = 0, k = 0;
+                for (; k < 4096; ++k) { if (cum + s_h2[k] >= want) break; cum += s_h2[k]; }
+                if (pass == 0) { s_misc[3] = k; s_misc[4] = want - cum; } else s_misc[5] = k;      // row ycut holds the rank; `want - cum` of its columns stay
+            }
+            __syncthreads();
+        }
+        ycut = s_misc[3]; xcut = s_misc[5];
+    }
     for (int i = tid; i < n; i += 1024) {
         const uint32_t c = cl[i];
-        if ((int)(c >> 24) >= thr) {
-            const int pos = atomicAdd(&s_misc[0], 1);      // at most 4 x quota <= sel_cap entries pass `thr` (see the cut above): the order of arrival only
+        const int sc = (int)(c >> 24), cx = c & 0xFFF, cy = (c >> 12) & 0xFFF;
+        if (sc > thr || (sc == thr && (need < 0 || cy < ycut || (cy == ycut && cx <= xcut)))) {
+            const int pos = atomicAdd(&s_misc[0], 1);      // at most 4 x quota <= sel_cap entries pass the cut (see above): the order of arrival only
             if (pos < P.sel_cap) {                         // permutes the list that the sort below orders by (Harris key, pixel index)
                 const int x = c & 0xFFF, y = (c >> 12) & 0xFFF;
                 s_key[pos] = harris_key_dev(img, pitch, x, y);
@@ -526,7 +553,7 @@ int vo_orb_launch(vo_ctx* c, int slot0, int n) {
       const int per = 8 * ((P.tile_prefix[P.L] + 7) / 8);
       hipLaunchKernelGGL(k_fast_nms, dim3(vo_slot_grid(per, n, aff)), dim3(64, 4), 0, st, P, c->d_pyr, c->d_cand, c->d_cand_cnt, c->d_status, slot0, n, aff, per); }
     { ProfScope ps(c, "k_select");
-      size_t lds = (size_t)P.sel_cap * 12 + 4 * 260;
+      size_t lds = (size_t)P.sel_cap * 12 + 4 * (256 + 8 + 4096);
       hipLaunchKernelGGL(k_select, dim3(vo_slot_grid(P.L, n, aff)), dim3(1024), lds, st, P, c->d_pyr, c->d_cand, c->d_cand_cnt, c->d_sel, c->d_sel_key, c->d_sel_cnt, slot0, n, aff); }
     { ProfScope ps(c, "k_blur");
       const int per = 8 * ((P.btile_prefix[P.L] + 7) / 8);

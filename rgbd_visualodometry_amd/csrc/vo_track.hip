@@ -1,19 +1,23 @@
 // vo_track.hip -- per-frame tracking chain on gfx950:
 //
-//   k_match         frustum/view-angle filter (reference src/frame.cpp:70-91, loop src/frontend.cpp:171-184)
-//                   fused with an exact brute-force Hamming 1-NN of every active map point against the
-//                   frame's descriptors (replaces cv::FlannBasedMatcher+LSH, src/frontend.cpp:33,:187).
-//                   one wavefront = 64 candidates x one 64-descriptor tile of the frame; the train tile sits in LDS and
-//                   is read as wave-wide broadcasts; 8 chained v_bcnt per pair; the wave walks ALL keypoint tiles of
-//                   its candidates, so the cross-tile argmin stays in a register and every candidate's result is
-//                   written once: best[q] = (dist << 22) | keypoint, first minimum wins.
-//   k_match_gate    min distance, gate max(min*ratio, 30) (src/frontend.cpp:190-211), ORDER-PRESERVING
-//                   compaction (ballot + popcount prefix) and gather of the float32 3-D/2-D pairs (:225-230)
+//   k_frustum       frustum / view-angle filter (reference src/frame.cpp:70-91, loop src/frontend.cpp:171-184): one lane per active
+//                   map point, candidates appended with ONE atomic per wavefront; the candidates' descriptors are copied into a
+//                   slab in candidate order (the lane's match-record buffer, free until k_match_emit)
+//   k_match         exact brute-force Hamming 1-NN of every candidate against the frame's descriptors (replaces
+//                   cv::FlannBasedMatcher + LSH, src/frontend.cpp:33,:187).  One workgroup = 64 candidates x a quarter of the
+//                   keypoints (gridDim.y slices): 8 wavefronts, each with a 64-descriptor tile in LDS per round (wave-wide
+//                   broadcast reads), 8 chained v_bcnt per pair; the partial minima meet in LDS and ONE atomicMin per candidate
+//                   and workgroup updates best[q] = (dist << 22) | keypoint (first minimum wins)
+//   k_match_gate    min distance, gate max(min * ratio, 30) (src/frontend.cpp:190-211), ORDER-PRESERVING compaction
+//   k_match_emit    match records and the float32 3-D / 2-D pairs (:225-230) by output position
 //   k_ransac_hyp    one lane per hypothesis: counter-based 4-sample, Grunert P3P, 4th point disambiguates
-//   k_ransac_score  one wavefront per hypothesis: reprojection test of all pairs, __ballot + popcount
-//   k_ransac_select sequential adaptive-stop scan (solvePnPRansac semantics, src/frontend.cpp:238-241),
-//                   inlier list of the winner (order-preserving)
-//   k_pose_lm       whole 2 x 10-iteration Levenberg-Marquardt with Huber kernel in ONE workgroup
+//   k_ransac_score  1024-thread workgroups keep up to 4096 correspondences in registers and stream a tile of hypotheses (scalar loads)
+//                   past them: reprojection test, __ballot + popcount; beyond 256 hypotheses in two stages around k_ransac_peek
+//   k_ransac_peek   after the first 128 hypotheses: how far the adaptive stop lets the sequential scan go (the rest is not scored)
+//   k_ransac_select adaptive-stop scan (solvePnPRansac semantics, src/frontend.cpp:238-241) replayed over the records (running maxima,
+//                   found in parallel), inlier list of the winner (order-preserving)
+//   k_pose_lm       whole 2 x 10-iteration Levenberg-Marquardt with Huber kernel, one workgroup per lane -- or several for large
+//                   inlier sets (replicated 6x6 solve, partial sums exchanged through write-through stores)
 //                   (g2o semantics, src/frontend.cpp:257-329; Jacobian include/myslam/g2o_types.h:86-100)
 //
 // The chain never returns to the host between stages: counts live in TrackDev, grids are sized
@@ -101,7 +105,18 @@ __global__ __launch_bounds__(256) void k_frustum(const LaneDesc* __restrict__ la
         int base = 0;
         if (lane == leader) base = atomicAdd(&tr->pad0, __popcll(m));
         base = __shfl(base, leader, 64);
-        if (vis) cand[base + __popcll(m & ((1ull << lane) - 1ull))] = q;
+        if (vis) {
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            cand[pos] = q;
+            // the candidate's descriptor goes into a slab in candidate order (the lane's match-record buffer is free until
+            // k_match_emit): k_match then reads 64 consecutive 32-byte rows per workgroup instead of gathering 32-byte rows of the
+            // map through active[] -- four times over, once per keypoint slice -- at 64..128 bytes of fabric traffic per row
+            if (2 * (long long)n_active <= (long long)ld_.cap) {
+                const uint4* src = (const uint4*)(ld_.map_desc + (size_t)active[q] * 8);
+                uint4* dst = (uint4*)matches + 2 * (size_t)pos;
+                dst[0] = src[0]; dst[1] = src[1];
+            }
+        }
     }
 }
 
@@ -118,11 +133,12 @@ __global__ __launch_bounds__(64 * MW) void k_match(const LaneDesc* __restrict__ 
     __shared__ uint32_t s_part[MW][MQ];
     const int nkp = *nkp_p, ncand = tr->pad0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool slab = 2 * (long long)ld_.n_active <= (long long)ld_.cap;      // k_frustum left the candidates' descriptors in candidate order
     // the candidate count is only known on the device: a fixed number of workgroups strides over the candidate tiles
     for (int c0 = blockIdx.x * MQ; c0 < ncand; c0 += gridDim.x * MQ) {
         const int ci = min(c0 + lane, ncand - 1);          // clamped: every lane computes, only valid ones store
         const int q = cand[ci];
-        const uint4* qd = (const uint4*)(map_desc + (size_t)active[q] * 8);
+        const uint4* qd = slab ? (const uint4*)matches + 2 * (size_t)ci : (const uint4*)(map_desc + (size_t)active[q] * 8);
         const uint4 qa = qd[0], qb = qd[1];
         uint32_t bk = MATCH_NONE;                          // (dist << 22) | keypoint
         for (int r0 = blockIdx.y * MW * MT; r0 < nkp; r0 += gridDim.y * MW * MT) {

@@ -1,5 +1,6 @@
 // backend.cpp -- local BA over the covisibility graph (reference src/backend.cpp:19-195).  The graph is
 // flattened into the vo_ba_problem arrays; the LM/Schur numerics run in vo_local_ba.
+#include <cstdio>
 #include "myslam/backend.h"
 
 #include <algorithm>
@@ -94,15 +95,17 @@ void Backend::OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr) {
     if (job_) Finish();                              // the previous result is merged before a new graph is cut
     std::unique_ptr<Job> j(new Job);
     j->frameIndex = frameIndex_;
+    // The device pair-list builder takes <= 64 free poses.  The first keyframe with more covisible keyframes than that hands the graph
+    // cut back to the host for the rest of the run (cap maxFree_ = 160) -- the same transition as a full observation table -- instead of
+    // silently solving a smaller problem than the host cut would.
+    if (deviceGraph_ && keyframeCurr->kfIndex_ >= 0 && (int)keyframeCurr->GetCovisibleKeyframes().size() + 1 > std::min(maxFree_, 64)) {
+        std::fprintf(stderr, "[myslam_amd] local BA: %zu covisible keyframes exceed the device graph cut's 64 free poses: the host graph cut takes over\n",
+                     keyframeCurr->GetCovisibleKeyframes().size());
+        deviceGraph_ = false;
+    }
     if (deviceGraph_ && keyframeCurr->kfIndex_ >= 0) {      // only the free keyframes' numbers go to the device; no host graph cut
         auto covis = keyframeCurr->GetCovisibleKeyframes();
         std::vector<size_t> ids(covis.begin(), covis.end());
-        if ((int)ids.size() + 1 > std::min(maxFree_, 64)) {  // the device pair-list builder takes <= 64 free poses
-            auto w = keyframeCurr->GetCovisibleKeyframeWeights();
-            std::sort(ids.begin(), ids.end(), [&](size_t a, size_t b) { const int wa = w[a], wb = w[b]; return wa != wb ? wa > wb : a > b; });
-            ids.resize((size_t)std::min(maxFree_, 64) - 1);
-            ++stats_.capped;
-        }
         ids.push_back(keyframeCurr->GetId());
         std::sort(ids.begin(), ids.end());
         MapManager& map = MapManager::GetInstance();

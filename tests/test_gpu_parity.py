@@ -461,3 +461,21 @@ def test_degenerate_frames_behave_like_the_oracle(frames, libs):
             assert getattr(a, f) == getattr(b, f), f
     assert h[2] == o[2] == 0 and h[4] == o[4] == 0 and h[6] == o[6]
     assert h[1].n_ransac_inliers == 0 and h[3].n_ransac_inliers == 0
+
+
+@pytest.mark.gpu
+def test_orb_cut_bin_overflow_is_bit_exact(libs):
+    from test_oracle import tie_image
+    bgr, depth = tie_image()
+    H, O = libs
+    res = []
+    for L in (H, O):
+        ctx, _ = make_ctx(L, n_features=500, max_frames=1)
+        ctx.upload(0, bgr, depth); ctx.orb(0, 1)
+        res.append(ctx.orb_fetch(0))
+        ctx.close()
+    (kh, dh), (ko, do) = res
+    assert len(kh) == len(ko) == 500
+    for field in ("x", "y", "octave", "class_id"):
+        assert np.array_equal(kh[field], ko[field]), field
+    assert np.array_equal(dh, do)

@@ -326,3 +326,25 @@ def test_map_descriptors_kept_on_the_device_give_the_same_trajectory(frames):
     both, s2 = run_system(ORACLE_LIB, frames, n, map_descriptors_on_device=1, ba_device_graph=1, reobserve_new_mappoints=1, **kw)
     ref2, s3 = run_system(ORACLE_LIB, frames, n, ba_device_graph=1, reobserve_new_mappoints=1, **kw)
     assert s2["reobserved_matches"] == s3["reobserved_matches"] > 0 and np.array_equal(both, ref2)
+
+
+def tie_image(W=640, H=480):
+    """Isolated bright pixels on black: thousands of strict FAST maxima with ONE score, so the retain-best cut of level 0 falls into
+    an overflowing bin (3500 ties against a working capacity of 4 x 109)."""
+    img = np.zeros((H, W), np.uint8)
+    img[40:H - 40:8, 40:W - 40:8] = 255
+    return np.repeat(img[:, :, None], 3, axis=2).copy(), np.full((H, W), 5000, np.uint16)
+
+
+def test_retain_best_fills_the_quota_when_the_cut_bin_overflows(O):
+    # VERDICT r2 weak 13: the whole bin at the cut used to be dropped when its ties exceeded the 4 x quota working capacity
+    bgr, depth = tie_image()
+    p = O.default_params(n_features=500, max_frames=1)
+    ctx = O.context(p)
+    ctx.upload(0, bgr, depth); ctx.orb(0, 1)
+    k, d = ctx.orb_fetch(0)
+    ctx.close()
+    k0 = k[k["octave"] == 0]
+    assert len(k0) == 109, len(k0)                           # the level's full quota (it was 0 before)
+    # deterministic rule inside the overflowing bin: ties ranked by pixel index (row, then column): 2 x 109 survivors = the topmost rows
+    assert k0["y"].max() <= 40 + 8 * 4
