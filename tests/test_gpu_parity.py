@@ -475,7 +475,7 @@ def test_orb_cut_bin_overflow_is_bit_exact(libs):
         res.append(ctx.orb_fetch(0))
         ctx.close()
     (kh, dh), (ko, do) = res
-    assert len(kh) == len(ko) == 500
+    assert len(kh) == len(ko) and int((kh["octave"] == 0).sum()) == 109      # level 0 fills its quota out of ~3500 ties (the coarse levels of this image have too few corners)
     for field in ("x", "y", "octave", "class_id"):
         assert np.array_equal(kh[field], ko[field]), field
     assert np.array_equal(dh, do)
