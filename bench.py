@@ -17,7 +17,9 @@ and merged (Backend::Flush) and the device is idle.
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel, live HIP-event
 timing on the kernels' own streams), `cpu_baseline` (the CPU oracle port on the host cores, rank 0
 at N=1 only, bounded sample), `latency_mode` (causal single-frame figure: no look-ahead, no
-speculative batch, synchronous BA) and `multi_stream` (several streams on this GPU).
+speculative batch, synchronous BA), `multi_stream` (several streams on this GPU), `upload_inclusive` (the same timed frames
+taken from pinned host memory through vo_frame_upload: the PCIe-inclusive rate, never `value`) and `distributed` (what the
+process group saw: world size, backend, every rank's device).
 """
 import argparse
 import ctypes as C
@@ -70,11 +72,11 @@ def algorithmic_bytes(W, H, N, A, M, K, I, n_hyp, passes=2):
     return b, total_survey, P
 
 
-def drive(sysm, stamps, bptr, dptr, i0, i1, lookahead, W, est=None):
+def drive(sysm, stamps, bptr, dptr, i0, i1, lookahead, W, est=None, on_device=True):
     i = i0
     while i < i1:
         n = min(lookahead, i1 - i)
-        sysm.prefetch(stamps[i:i + n], bptr[i:i + n], dptr[i:i + n], 3 * W, 2 * W, True)
+        sysm.prefetch(stamps[i:i + n], bptr[i:i + n], dptr[i:i + n], 3 * W, 2 * W, on_device)
         for j in range(n):
             ok, T = sysm.add_prefetched()
             if est is not None:
@@ -108,11 +110,13 @@ def main():
     ap.add_argument("--speed", type=float, default=3.0, help="camera speed factor of the synthetic trajectory: 3 = SURVEY 8d cadence (2 cm / 0.75 deg per frame, keyframe every 3-4 frames); 1 = round-1 slow turn")
     ap.add_argument("--no-ba", action="store_true", help="disable local BA (enable_local_optimization: 0)")
     ap.add_argument("--ba-lag", type=int, default=8, help="0: BA synchronous in AddFrame; L>0: overlapped, merged L frames later or at the next keyframe (deterministic)")
+    ap.add_argument("--chi2-th", type=float, default=1.0, help="chi2 cut of the local BA's outlier test (default.yaml: 1.0 = one pixel squared; experiments only)")
     ap.add_argument("--hyps", type=int, default=100, help="PnP-RANSAC hypotheses per pass (default.yaml: 100; BASELINE config 3: 2048)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the driver's runs) | gloo (rehearsal of the multi-rank path)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses device 0 (needs --dist-backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=150, help="bounded single-thread CPU-baseline sample (frames; ~20 s of CPU work at the default)")
+    ap.add_argument("--cpu-frames", type=int, default=100, help="fresh-map variant of the single-thread CPU baseline: the first N frames of the oracle run are timed (rounds 1-2's sample)")
+    ap.add_argument("--cpu-steady-frames", type=int, default=40, help="frames of the GPU's timed region that the single-thread CPU baseline is timed on (after an untimed oracle prologue)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU baseline (0: min(host cpus, 64))")
     ap.add_argument("--no-latency-mode", action="store_true")
     ap.add_argument("--prologue", type=int, default=150, help="frames tracked (untimed) before the warmup so that the timed steps see the steady-state map: covisible window, BA size and active-map size level off after ~100 frames; 0 = time a young map")
@@ -147,7 +151,7 @@ def main():
     dptr = [d_depth.data_ptr() + i * fd for i in range(total)]
 
     opts = dict(width=W, height=H, number_of_features=N, max_frames_in_flight=args.lookahead, device=local_rank,
-                enable_local_optimization=0 if args.no_ba else 1, backend_lag_frames=args.ba_lag, track_batch=args.track_batch, map_capacity=1 << 20, ransac_iterations=args.hyps, ba_device_graph=0 if args.host_graph else 1, map_descriptors_on_device=1)
+                enable_local_optimization=0 if args.no_ba else 1, backend_lag_frames=args.ba_lag, track_batch=args.track_batch, map_capacity=1 << 20, ransac_iterations=args.hyps, ba_device_graph=0 if args.host_graph else 1, map_descriptors_on_device=1, chi2_th=args.chi2_th)
 
     # One-time costs (code-object load, pinned staging, scratch growth) are paid on a throw-away system before the
     # warmup: the driver's short runs (--warmup 5) then time the same steady state as the long ones.
@@ -170,9 +174,20 @@ def main():
     torch.cuda.synchronize()
     grp.barrier()
     torch.cuda.synchronize()
-    elapsed = grp.max_scalar(time.perf_counter() - t0)
+    own_elapsed = time.perf_counter() - t0
+    elapsed = grp.max_scalar(own_elapsed)
     st = sysm.stats()
     acc = accuracy(ev, capi, stamps, Twc, est, 0, total)     # every rank checks its own stream; rank 0 reports
+    # what the process group saw (a SCALE run can prove that RCCL connected N ranks, each on its own GPU): a SUM all-reduce of ones
+    # through the same backend that carried the barrier, and every rank's device
+    props = torch.cuda.get_device_properties(local_rank)
+    ones = np.ones(1, dtype=np.int32)
+    grp.all_reduce_sum_i32(ones)
+    dist_info = {"world_size": world, "backend": (args.dist_backend if world > 1 else None), "allreduce_sum_of_ones": int(ones[0]),
+                 "ranks": grp.gather_objects({"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": props.name,
+                                              "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")),
+                                              "frames_per_s": round(K / own_elapsed, 1),
+                                              "keyframes": st["keyframes"], "lost": st["lost"], "ate_rmse_m": acc["ate_rmse_m"]})}
 
     out = None
     if rank == 0:
@@ -233,7 +248,8 @@ def main():
             # HBM traffic per launch from this round's PMC passes (rocprofv3 cannot run inside this process): only a file of
             # the current round that covers this kernel is used, otherwise null
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")))
+                pmc_file = next(f for f in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+                pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
                 pk = pmc["kernels"]
                 for name, row in table.items():             # measured fabric traffic per launch beside the algorithmic bytes, where a PMC row exists
                     m = pk.get(name) or pk.get(name + "16")
@@ -241,13 +257,41 @@ def main():
                         row["pmc_hbm_bytes_per_launch"] = m["hbm_bytes_per_launch_corrected"]
                         row["pmc_GBps"] = round(m["hbm_bytes_per_launch_corrected"] / (row["avg_us"] * 1e-6) / 1e9, 1)
                 roof["traffic"] = (pk.get(dom) or pk[dom + "16"])["hbm_bytes_per_launch_corrected"]
-                roof["traffic_source"] = "profiles/r02_pmc_hbm_traffic.json (FETCH_SIZE, WRITE_SIZE: separate --pmc passes of `%s`)" % pmc.get("command", "bench.py")
+                roof["traffic_source"] = "profiles/%s (FETCH_SIZE, WRITE_SIZE: separate --pmc passes of `%s`)" % (pmc_file, pmc.get("command", "bench.py"))
+                cmp_file = os.path.join(ROOT, "profiles", "r03_pmc_compute.json")      # SQ counters of the latency-bound kernels (separate --pmc passes)
+                if os.path.exists(cmp_file):
+                    cc = json.load(open(cmp_file)).get("kernels", {})
+                    for name, row in table.items():
+                        m = cc.get(name) or cc.get(name + "16")
+                        if m:
+                            row["pmc_compute"] = m
+                    if (cc.get(dom) or cc.get(dom + "16")):
+                        roof["compute_counters"] = cc.get(dom) or cc.get(dom + "16")
             except Exception:
                 pass
             roof.update({"avg_launch_us": t["avg_us"], "launches": t["launches"], "limiter": t.get("limiter", "HBM / L2 streaming"),
                          "note": "a single 640x480 stream keeps ~1 % of the chip busy: its per-frame chain is a sequence of small dependent kernels; "
                                  "the streaming ORB kernels and the several-streams figure (multi_stream) are the roofline-relevant ones",
                          "kernels": table})
+
+        # ---- PCIe-inclusive figure: the same frames from pinned host memory through vo_frame_upload (look-ahead batches) -------------
+        upl = None
+        if world == 1 and not args.no_latency_mode:
+            hb = torch.from_numpy(bgr).pin_memory(); hd = torch.from_numpy(depth.view(np.int16)).pin_memory()
+            hbp = [hb.data_ptr() + i * fb for i in range(total)]; hdp = [hd.data_ptr() + i * fd for i in range(total)]
+            su = system.VoSystem(system.HOST_LIB, **opts)
+            est_u = {}
+            drive(su, stamps, hbp, hdp, 0, Wm, args.lookahead, W, est_u, on_device=False)
+            su.flush(); torch.cuda.synchronize()
+            tu = time.perf_counter()
+            drive(su, stamps, hbp, hdp, Wm, total, args.lookahead, W, est_u, on_device=False)
+            su.flush(); torch.cuda.synchronize()
+            tu = time.perf_counter() - tu
+            su.close()
+            upl = {"frames_per_s": round(K / tu, 2), "ms_per_step": round(1e3 * tu / K, 4), "vs_resident": round((K / tu) / fps, 3),
+                   "bytes_per_frame_h2d": fb + fd, **accuracy(ev, capi, stamps, Twc, est_u, 0, total),
+                   "note": "frames in pinned host memory, uploaded per look-ahead batch by FrontEnd::PrefetchFrames (vo_frame_upload) inside the timed region"}
+            del hb, hd
 
         # ---- causal single-frame figure ---------------------------------------------------------------
         lat = None
@@ -345,7 +389,10 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             from oracle import ORACLE_LIB                   # the checker, timed as the CPU baseline (never on the product path)
             copts = {**opts, "max_frames_in_flight": 1, "track_batch": 1, "backend_lag_frames": 0, "ba_device_graph": 0, "map_descriptors_on_device": 0}
-            nf = min(args.cpu_frames, total)
+            # ONE oracle run gives both figures: the first `cpu_frames` frames from a fresh map (round 1/2's sample, kept as a variant)
+            # and -- after the rest of the GPU's untimed prologue -- the SAME steady-state frames the GPU was timed on (a bounded prefix)
+            nf = min(args.cpu_frames, Wm)
+            ns = min(args.cpu_steady_frames, K)
             o = system.VoSystem(ORACLE_LIB, **copts)
             est_c = {}
             tc = time.perf_counter()
@@ -353,9 +400,19 @@ def main():
                 ok, T = o.add_frame(stamps[i], bgr[i], depth[i])
                 est_c[stamps[i]] = T
             tc = time.perf_counter() - tc
+            for i in range(nf, Wm):                          # untimed: the remainder of the prologue + warmup
+                ok, T = o.add_frame(stamps[i], bgr[i], depth[i])
+                est_c[stamps[i]] = T
+            ts_ = time.perf_counter()
+            for i in range(Wm, Wm + ns):
+                ok, T = o.add_frame(stamps[i], bgr[i], depth[i])
+                est_c[stamps[i]] = T
+            ts_ = time.perf_counter() - ts_
             o.close()
             acc_c = accuracy(ev, capi, stamps, Twc, est_c, 0, nf)
             acc_g = accuracy(ev, capi, stamps, Twc, est, 0, nf) if nf <= total else {}
+            acc_cs = accuracy(ev, capi, stamps, Twc, est_c, 0, Wm + ns)
+            acc_gs = accuracy(ev, capi, stamps, Twc, est, 0, Wm + ns)
             # all host cores: T independent streams, one per thread (the same frames), aggregate frames/s
             T_all = args.cpu_threads or min(os.cpu_count() or 1, 64)
             nfa = min(total, 24)
@@ -378,10 +435,12 @@ def main():
                 cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
             except Exception:
                 pass
-            cpu = {"value": round(nf / tc, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-                   "sample": "first %d frames of the same synthetic stream from a fresh map (younger, i.e. cheaper, than the GPU's timed steady state), ONE thread (local BA synchronous), oracle/_build/liboracle_vo.so (-O3 -march=x86-64-v3)" % nf,
-                   "ate_rmse_m": acc_c["ate_rmse_m"], "gpu_ate_rmse_m_same_frames": acc_g.get("ate_rmse_m"),
-                   "rpe_trans_rmse_m": acc_c["rpe_trans_rmse_m"],
+            cpu = {"value": round(ns / ts_, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+                   "sample": "frames %d..%d of the same synthetic stream -- the first %d of the GPU's timed frames, behind the same %d-frame untimed prologue -- ONE thread (local BA synchronous), oracle/_build/liboracle_vo.so (-O3 -march=x86-64-v3)" % (Wm, Wm + ns - 1, ns, Wm),
+                   "ate_rmse_m": acc_cs["ate_rmse_m"], "gpu_ate_rmse_m_same_frames": acc_gs.get("ate_rmse_m"),
+                   "rpe_trans_rmse_m": acc_cs["rpe_trans_rmse_m"],
+                   "fresh_map": {"value": round(nf / tc, 3), "unit": "frames/s", "cores": 1, "sample": "first %d frames from a fresh map (younger, i.e. cheaper, than the timed steady state): rounds 1-2's sample" % nf,
+                                 "ate_rmse_m": acc_c["ate_rmse_m"], "gpu_ate_rmse_m_same_frames": acc_g.get("ate_rmse_m")},
                    "all_cores": {"value": round(T_all * nfa / ta, 2), "unit": "frames/s", "cores": T_all,
                                  "sample": "%d independent streams (first %d frames each), one per thread" % (T_all, nfa)},
                    "host_cpus": os.cpu_count(), "cpu_model": cpu_model}
@@ -404,7 +463,8 @@ def main():
             "ba": {k: st[k] for k in ("ba_runs", "ba_poses", "ba_fixed", "ba_points", "ba_edges", "ba_outliers", "ba_failed", "ba_capped")},
             "avg_per_tracked_frame": {"active_map_points": round(A, 1), "candidates": round(M, 1), "matches": round(Kc, 1), "ransac_inliers": round(I, 1),
                                       "lm_iterations": round(pst["sum_lm_iters"] / tf, 2), "frames_per_launch_chain": round(tf / max(1, pst["track_launches"]), 2)},
-            "roofline": roof, "orb_only": orb_only, "latency_mode": lat, "multi_stream": multi, "cpu_baseline": cpu,
+            "roofline": roof, "orb_only": orb_only, "latency_mode": lat, "multi_stream": multi, "upload_inclusive": upl, "cpu_baseline": cpu,
+            "distributed": dist_info,
         }
         print(json.dumps(out))
     sysm.close()

@@ -151,7 +151,12 @@ int main() {
         hipMalloc(&B.scal, 64); hipMalloc(&B.dl, 128); hipMemset(B.dl, 0, 128); hipMalloc(&B.ctl, sizeof(BaCtl));
         hipMemset(B.scal, 0, 64); hipMemset(B.ctl, 0, sizeof(BaCtl));
         hipMalloc(&d_S0, sizeof(double) * D * D);
-        hipMemcpy(d_S0, S.data(), sizeof(double) * D * D, hipMemcpyHostToDevice);
+        {   // k_ba_chol16 takes the packed lower triangle (ba_tri), k_ba_chol16g the full matrix
+            std::vector<double> Sp((size_t)D * D, 0.0);
+            if (D <= 192) { for (int r = 0; r < D; ++r) for (int c = 0; c <= r; ++c) Sp[(size_t)r * (r + 1) / 2 + c] = S[(size_t)r * D + c]; }
+            else Sp = S;
+            hipMemcpy(d_S0, Sp.data(), sizeof(double) * D * D, hipMemcpyHostToDevice);
+        }
         hipMemcpy(d_b0, b.data(), sizeof(double) * D, hipMemcpyHostToDevice);
         BaDev* d_B; hipMalloc(&d_B, sizeof(BaDev)); hipMemcpy(d_B, &B, sizeof(BaDev), hipMemcpyHostToDevice);
         BaBatch Q; memset(&Q, 0, sizeof(Q)); Q.Bs = d_B; Q.ctls = B.ctl; Q.n = 1;

@@ -149,8 +149,12 @@ __device__ __forceinline__ void ba_inv3_damped(const double* __restrict__ Hll, d
 // launch zeroes S / b_s and inverts the damped point blocks, the Schur kernel accumulates into the zeroed S, and the Cholesky
 // kernel adds blockdiag(H_pp) + lambda I and b_p while it loads the system.  Larger systems keep k_ba_init_S.
 #define BA_FOLD_D 192
+// Systems of the LDS-resident Cholesky (D <= BA_FOLD_D) keep S as a PACKED lower triangle, entry (r, c <= r) at r (r + 1) / 2 + c -- the
+// layout the factorisation uses in LDS, so that k_ba_chol16 brings it in with straight global -> LDS copies.  Larger systems (k_ba_chol16g)
+// keep the full row-major matrix.
+__device__ __forceinline__ size_t ba_tri(int r, int c) { return (size_t)r * (size_t)(r + 1) / 2 + (size_t)c; }
 __device__ __forceinline__ void ba_fold_zero(const BaDev& B, int blk, int nblk) {            // S = 0, b_s = 0 (grid-stride over the point blocks)
-    const int n = B.D * B.D;
+    const int n = B.D * (B.D + 1) / 2;
     for (int i = blk * 256 + threadIdx.x; i < n; i += nblk * 256) B.S[i] = 0.0;
     for (int i = blk * 256 + threadIdx.x; i < B.D; i += nblk * 256) B.bs[i] = 0.0;
 }
@@ -653,77 +657,46 @@ __device__ __forceinline__ bool ba_chol16_body(const BaDev& B, BaCtl* ctl_, doub
     double lambda = lambda_in;
     if (!PB) lambda = (ctl_->need_lin && ctl_->first) ? 1e-5 * B.scal[4] : ctl_->lambda;
     const double* const Hpp = B.Hpp;
-    auto extra = [&](int r, int c) -> double {              // entry (r, c) of blockdiag(H_pp) + lambda I
-        const double h = Hpp[36 * (size_t)(r / 6) + 6 * (r % 6) + (c % 6)];     // always in range; used only inside the block
-        return (r / 6 == c / 6 ? h : 0.0) + (r == c ? lambda : 0.0);
-    };
-    // ---- load.  Wave 0 takes the first diagonal block straight from global memory into registers and factors it
-    // while the other waves bring the rest of the lower triangle (rows >= 16) and the rhs row into LDS.
-    if (wave == 0) {
+    // ---- load.  S arrives as the packed lower triangle the factorisation works on (ba_tri), so it is copied global -> LDS by the DMA
+    // path (global_load_lds_dwordx4: 1 KiB per wave instruction, no registers, every piece in flight at once); blockdiag(H_pp) + lambda I
+    // and the right-hand side row b_s + b_p join in LDS.  (Row-by-row register loads of a full matrix: two dependent batches per wave, 10 us
+    // at D = 144.)
+    const int ntri = D * (D + 1) / 2;
+    {
+        typedef __attribute__((address_space(3))) void lds_void;
+        typedef __attribute__((address_space(1))) const void glb_void;
+        const int npiece = (ntri + 127) >> 7;                   // 128 doubles = 1 KiB per piece; the slab behind S is readable up to the next multiple (host: carve)
+        for (int pc = wave; pc < npiece; pc += CH_THREADS / 64)
+            if (pc * 128 + 2 * lane < ntri)                     // the last piece is cut at the end of the triangle (at most one double beyond it, inside both buffers)
+                __builtin_amdgcn_global_load_lds((glb_void*)(A + (size_t)pc * 128 + 2 * lane), (lds_void*)(s_L + (size_t)pc * 128), 16, 0, 0);
+    }
+    const double rhs_v = tid < D ? B.bs[tid] + B.bp[tid] : 0.0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int i = tid; i < 36 * (D / 6); i += CH_THREADS) {     // the 6x6 diagonal blocks of H_pp (lower halves) and lambda on the diagonal
+        const int j = i / 36, a = (i % 36) / 6, b = i % 6;
+        if (b <= a) s_L[TRI32(6 * j + a, 6 * j + b)] += Hpp[i] + (a == b ? lambda : 0.0);
+    }
+    if (tid < D) s_L[TRI32(D, tid)] = rhs_v;
+    if (tid == 0) s_L[TRI32(D, D)] = 0.0;
+    if (PB) {                                                   // clear S / b_s behind the copy for the next step's atomics (write-through: see ba_st16_sc1)
+        double* g = const_cast<double*>(A);
+        for (int i = 2 * tid; i < ntri; i += 2 * CH_THREADS) ba_st16_sc1(g + i, 0.0, 0.0);      // the slab is padded: a pair past the end is harmless
+        if (tid < D) __hip_atomic_store(B.bs + tid, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (wave == 0) {                                            // first diagonal block, in registers (the other waves wait at the barrier)
         const int nb = min(CH_NB, D);
         double a[CH_NB];
-        // loads are unconditional (clamped in range) and masked afterwards: a predicated load becomes a branch with
-        // its own wait, 16 of them in a row serialise the memory latency
         const bool mine = r16 < nb;
-        const double* row = A + (size_t)(mine ? r16 : 0) * D;
+        const double* row = s_L + TRI32(mine ? r16 : 0, 0);
 #pragma unroll
-        for (int c = 0; c < CH_NB; ++c) a[c] = row[min(c, nb - 1)] + extra(mine ? r16 : 0, min(c, nb - 1));
+        for (int c = 0; c < CH_NB; ++c) a[c] = row[min(c, mine ? r16 : 0)];
 #pragma unroll
         for (int c = 0; c < CH_NB; ++c) a[c] = (mine && c <= r16) ? a[c] : (c == r16 ? 1.0 : 0.0);
         if (!ch_factor_block(a, s_L, s_dg, s_inv, s_pinv, 0, nb, lane) && lane == 0) s_ok = 0;
-    } else {
-        // the small loads of the tail of this phase (the 6x6 diagonal-block terms of this lane's rows, its rhs entry) are issued first:
-        // vector-memory results return in order, so they are back with the first batch of rows instead of costing two more round trips
-        double exv[4];
-        const int ri = tid - 64, rix = min(ri, D - 1);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int r = min(CH_NB + wave - 1 + (CH_THREADS / 64 - 1) * (lane / 6 + 10 * u), D - 1), c = min(6 * (r / 6) + lane % 6, r);
-            exv[u] = extra(r, c);
-        }
-        const double rhs_v = B.bs[rix] + B.bp[rix];
-        // two columns per lane (rows are 16-byte aligned: D is even), 12 rows in flight per wave
-#pragma unroll 12
-        for (int r = CH_NB + wave - 1; r < D; r += CH_THREADS / 64 - 1) {
-            const double2* src = reinterpret_cast<const double2*>(A + (size_t)r * D);
-            double* dst = s_L + TRI32(r, 0);
-            const int c0 = 2 * lane, c1 = 2 * lane + 128, last = (D >> 1) - 1;
-            const double2 v0 = src[min(lane, last)], v1 = src[min(lane + 64, last)];        // unconditional, clamped to the row
-            if (c0 <= r) dst[c0] = v0.x;
-            if (c0 + 1 <= r) dst[c0 + 1] = v0.y;
-            if (c1 <= r) dst[c1] = v1.x;
-            if (c1 + 1 <= r) dst[c1 + 1] = v1.y;
-        }
-        if (PB) {
-            // clear the loaded part of every row for the next step's atomics: a sweep of its own (the asm stores are memory barriers
-            // to the compiler: inside the load loop they would keep the next rows' loads from being issued ahead)
-            for (int r = CH_NB + wave - 1; r < D; r += CH_THREADS / 64 - 1) {
-                double* gr = const_cast<double*>(A) + (size_t)r * D;
-                const int c0 = 2 * lane, c1 = 2 * lane + 128, last = (D >> 1) - 1;
-                if (c0 <= r) ba_st16_sc1(gr + c0, 0.0, 0.0);
-                if (c1 <= r && lane + 64 <= last) ba_st16_sc1(gr + c1, 0.0, 0.0);
-            }
-        }
-        // the 6x6 diagonal block of row r (columns 6 (r / 6) .. r) joins in a second sweep over this wave's rows: 6 lanes per row,
-        // 10 rows at a time (LDS accesses of one wave are ordered, so no barrier is needed behind the loop above)
-        if (lane < 60) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {                       // rows per wave <= (192 - 16) / 7 + 1 = 26 < 40
-                const int r = CH_NB + wave - 1 + (CH_THREADS / 64 - 1) * (lane / 6 + 10 * u), c = 6 * (r / 6) + lane % 6;
-                if (r < D && c <= r) s_L[TRI32(r, c)] += exv[u];
-            }
-        }
-        if (ri < D) {                                           // D <= 192 < CH_THREADS - 64: one entry per thread
-            s_L[TRI32(D, ri)] = rhs_v;
-            if (PB) __hip_atomic_store(B.bs + ri, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (tid == 64) s_L[TRI32(D, D)] = 0.0;
     }
     __syncthreads();
-    if (PB && wave == 0 && lane < 16) {                        // rows 0..15 were read by wave 0 (their factorisation is done by now)
-        const int nb0 = min(CH_NB, D);
-        if (lane < nb0) { double* gr = const_cast<double*>(A) + (size_t)lane * D; for (int c = 0; c <= lane; c += 2) ba_st16_sc1(gr + c, 0.0, 0.0); }
-    }
     if (!PB && tid == 0) {
         BaCtl* c = ctl_;                               // take over the fresh linearisation, clear the trial sums
         if (c->need_lin) {
@@ -1438,8 +1411,8 @@ static int ba_engine_pump(BaEngine* E) {                    // engine thread; re
     for (int s = 0; s < BA_SLOTS; ++s) if (E->slot[s]) act[na++] = s;
     if (na == 0) return VO_OK;
     // ---- one chunk of LM steps over every active slot.  Systems the LDS-resident Cholesky solves (D <= 192) take the second-generation
-    // phases (vo_ba_phase2.h: four launches per step), larger ones the first generation (VO_BA_PHASE2=0: everything does).
-    static const bool phase2 = !(getenv("VO_BA_PHASE2") && atoi(getenv("VO_BA_PHASE2")) == 0);
+    // phases (vo_ba_phase2.h: four launches per step), larger ones the first generation.
+    const bool phase2 = true;                               // (the first generation stays for D > 192 only: its Schur kernel writes the full matrix k_ba_chol16g reads)
     int chunk = (na == 1 && E->pending_hint == 0) ? 16 : 6;
     int sA[BA_SLOTS], nA = 0, sB[BA_SLOTS], nB = 0, sB16[BA_SLOTS], nB16 = 0, sB16g[BA_SLOTS], nB16g = 0, fA[BA_SLOTS], nfA = 0, fB[BA_SLOTS], nfB = 0;
     int gA_lin = 0, gA_blk = 0, gA_up = 0, gA_md = 0, gB_lin = 0, gB_init = 0, gB_blk = 0, gB_upd = 0, gB_c = 0, gB_md = 0;

@@ -421,11 +421,11 @@ __device__ __forceinline__ void pb_slice_commit(const BaDev& B, const BaBlock& b
         if (t < 21) {
             int r = 0, rem = t;
             while (rem > r) { rem -= r + 1; ++r; }
-            atomicAdd(&B.S[(size_t)(6 * blk.j1 + r) * B.D + 6 * blk.j1 + rem], -x);
+            atomicAdd(&B.S[ba_tri(6 * blk.j1 + r, 6 * blk.j1 + rem)], -x);
         } else if (t < 27) atomicAdd(&B.bs[6 * blk.j1 + t - 21], -x);
     } else {
         const int r = t / 6, c = t % 6;
-        atomicAdd(&B.S[(size_t)(6 * blk.j2 + c) * B.D + 6 * blk.j1 + r], -x);              // j1 < j2: the block below the diagonal
+        atomicAdd(&B.S[ba_tri(6 * blk.j2 + c, 6 * blk.j1 + r)], -x);              // j1 < j2: the block below the diagonal
     }
 }
 __device__ __forceinline__ void pb_schur(const BaDev& B, const PbTab& W, int dbg, int wi, int NW, double lambda, const double* s_pc, const double* pts_c, double* s_red, unsigned long long* tk) {

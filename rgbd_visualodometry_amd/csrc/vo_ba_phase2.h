@@ -162,8 +162,8 @@ __device__ __forceinline__ void p2_schur_slice(const BaDev& B, const BaBlock blk
     if (threadIdx.x < 36) {
         const int r = threadIdx.x / 6, c = threadIdx.x % 6;
         const double val = s_tot[threadIdx.x];
-        if (DIAG) { if (c <= r) atomicAdd(&B.S[(size_t)(6 * blk.j1 + r) * B.D + 6 * blk.j1 + c], -val); }
-        else atomicAdd(&B.S[(size_t)(6 * blk.j2 + c) * B.D + 6 * blk.j1 + r], -val);          // j1 < j2: the block below the diagonal is the one the Cholesky reads
+        if (DIAG) { if (c <= r) atomicAdd(&B.S[ba_tri(6 * blk.j1 + r, 6 * blk.j1 + c)], -val); }
+        else atomicAdd(&B.S[ba_tri(6 * blk.j2 + c, 6 * blk.j1 + r)], -val);          // j1 < j2: the block below the diagonal is the one the Cholesky reads
     } else if (DIAG && threadIdx.x < 42) {
         atomicAdd(&B.bs[6 * blk.j1 + threadIdx.x - 36], -s_tot[threadIdx.x]);
     }

@@ -72,6 +72,7 @@ private:
     void WorkerLoop();
     void EnsureWorker();            // the worker's context, stream and thread exist before the first keyframe (no one-time setup inside a timed run)
     bool deviceGraph_ = false;
+    bool fixOldest_ = false;        // ba_fix_oldest_free_keyframe: gauge-anchor experiment
     void ApplyResident(Job& j);
     void SolveResident(Job& j, vo_ctx* ctx);
     int maxFree_ = 160;             // free-pose cap of one solve: the Cholesky of the reduced system is LDS resident (vo_local_ba: D = 6 n_free <= ~1050)

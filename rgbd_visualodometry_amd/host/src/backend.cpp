@@ -1,6 +1,7 @@
 // backend.cpp -- local BA over the covisibility graph (reference src/backend.cpp:19-195).  The graph is
 // flattened into the vo_ba_problem arrays; the LM/Schur numerics run in vo_local_ba.
 #include <cstdio>
+#include <cstdlib>
 #include "myslam/backend.h"
 
 #include <algorithm>
@@ -19,6 +20,10 @@ Backend::Backend(const Camera::Ptr camera) : camera_(camera) {
     if (Config::has("backend_lag_frames")) lag_ = std::max(0, Config::get<int>("backend_lag_frames"));
     if (Config::has("ba_max_free_keyframes")) maxFree_ = std::max(1, Config::get<int>("ba_max_free_keyframes"));
     if (Config::has("ba_device_graph")) deviceGraph_ = Config::get<int>("ba_device_graph") != 0;
+    // experiment key (not a reference setting): the reference never fixes a vertex (backend.cpp:49-59: setFixed(id == 0), ids start at 1), so
+    // every local BA floats in its 6-dof gauge.  With this key the OLDEST keyframe of the free set is treated as fixed.
+    if (Config::has("ba_fix_oldest_free_keyframe")) fixOldest_ = Config::get<int>("ba_fix_oldest_free_keyframe") != 0;
+    if (const char* e = std::getenv("VO_BA_FIX_OLDEST")) fixOldest_ = std::atoi(e) != 0;      // the same switch for drivers without a config file (scripts/exp_gauge.sh)
 }
 
 Backend::~Backend() { Stop(); if (ctxOwn_) vo_ctx_destroy(ctxOwn_); }
@@ -108,6 +113,7 @@ void Backend::OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr) {
         std::vector<size_t> ids(covis.begin(), covis.end());
         ids.push_back(keyframeCurr->GetId());
         std::sort(ids.begin(), ids.end());
+        if (fixOldest_ && ids.size() > 1) ids.erase(ids.begin());      // its observations still constrain the points: it joins the fixed poses
         MapManager& map = MapManager::GetInstance();
         for (size_t id : ids) { auto f = map.GetKeyframe(id); if (f && f->kfIndex_ >= 0) { j->freeKf.push_back(f->kfIndex_); j->poseFrames.push_back(f.get()); } }
         j->nFree = (int)j->freeKf.size(); j->resident = true;
@@ -157,6 +163,7 @@ void Backend::Build(Job& j, const Frame::Ptr& kf) {
     }
     freeIds.push_back(kf->GetId());
     std::sort(freeIds.begin(), freeIds.end());
+    if (fixOldest_ && freeIds.size() > 1) freeIds.erase(freeIds.begin());      // gauge anchor (experiment key): it becomes one of the fixed observers below
     for (size_t id : freeIds) {
         auto f = map.GetKeyframe(id);
         if (f == nullptr) continue;
