@@ -29,6 +29,7 @@
 #ifndef VO_HIP_H
 #define VO_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -243,6 +244,14 @@ int vo_group_stats(vo_group* g, int64_t* chains, int64_t* lanes, int64_t* reques
  * collective (RCCL / gloo all-reduce through torch.distributed in this repo); world <= 1 switches sharding off. */
 typedef void (*vo_exchange_fn)(void* user, int32_t* counts, int n);
 int vo_set_hypothesis_shard(vo_ctx* ctx, int rank, int world, vo_exchange_fn exchange, void* user);
+/* On-stream form of the same exchange (north_star: "an RCCL all-reduce over xGMI ... where a frame batch is in flight"): `allreduce`
+ * is called on the caller's thread but must only ENQUEUE an in-place int32 SUM of `n` device-resident counts on `hip_stream` -- for
+ * RCCL: ncclAllReduce(buf, buf, n, ncclInt32, ncclSum, (ncclComm_t)comm, (hipStream_t)hip_stream) -- so the launch chain never
+ * returns to the host between scoring and the adaptive-stop scan.  The buffer is the context's count table (lanes x max_hypotheses:
+ * entries beyond n_hyp of a lane are summed too and never read).  Returns nonzero on failure (the chain fails with VO_E_DEVICE).
+ * The CPU restatement has no streams: VO_E_UNSUPPORTED there.  Setting one form clears the other. */
+typedef int (*vo_stream_allreduce_fn)(void* comm, int32_t* device_counts, size_t n, void* hip_stream);
+int vo_set_hypothesis_shard_stream(vo_ctx* ctx, int rank, int world, vo_stream_allreduce_fn allreduce, void* comm);
 
 /* ---- batched triangulation -------------------------------------------------------------- */
 /* Linear N-view triangulation (reference include/myslam/util.h:16-34) of MANY map points in one launch, as applied by

@@ -302,6 +302,7 @@ int vo_track_fetch_matches(vo_ctx* c, int lane, vo_match* matches, int cap, int*
     return VO_OK;
 }
 
+int vo_set_hypothesis_shard_stream(vo_ctx*, int, int, vo_stream_allreduce_fn, void*) { return VO_E_UNSUPPORTED; }      // no streams on the CPU
 int vo_set_hypothesis_shard(vo_ctx* c, int rank, int world, vo_exchange_fn fn, void* user) {
     if (!c || world < 0 || (world > 1 && (rank < 0 || rank >= world || !fn))) return VO_E_INVALID;
     c->shard.rank = rank; c->shard.world = world > 1 ? world : 1; c->shard.exchange = fn; c->shard.user = user;

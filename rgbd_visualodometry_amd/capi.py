@@ -70,11 +70,12 @@ SYMBOLS = ["vo_ctx_create", "vo_ctx_destroy", "vo_strerror", "vo_backend_name", 
            "vo_match_active_map", "vo_matches_set", "vo_pnp_ransac", "vo_pose_refine_lm", "vo_track_frame", "vo_track_batch", "vo_track_fetch_matches",
            "vo_local_ba", "vo_sync", "vo_profile_enable", "vo_profile_read",
            "vo_group_create", "vo_group_destroy", "vo_group_join", "vo_group_leave", "vo_group_set_gather", "vo_group_stats",
-           "vo_set_hypothesis_shard", "vo_triangulate_batch", "vo_kf_set_pose", "vo_obs_append", "vo_obs_kill", "vo_local_ba_resident",
+           "vo_set_hypothesis_shard", "vo_set_hypothesis_shard_stream", "vo_triangulate_batch", "vo_kf_set_pose", "vo_obs_append", "vo_obs_kill", "vo_local_ba_resident",
            "vo_local_ba_resident_cut", "vo_local_ba_resident_solve", "vo_ba_resident_graph"]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int32), C.c_int)     # vo_exchange_fn: in-place element-wise sum over the ranks
+STREAM_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.c_size_t, C.c_void_p)      # vo_stream_allreduce_fn: enqueue the sum on a HIP stream
 
 
 class VoError(RuntimeError):
@@ -138,6 +139,7 @@ class VoLib:
                                            C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.vo_triangulate_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vo_set_hypothesis_shard.argtypes = [C.c_void_p, C.c_int, C.c_int, EXCHANGE_FN, C.c_void_p]
+        L.vo_set_hypothesis_shard_stream.argtypes = [C.c_void_p, C.c_int, C.c_int, STREAM_ALLREDUCE_FN, C.c_void_p]
         L.vo_group_create.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.vo_group_destroy.argtypes = [C.c_void_p]
         L.vo_group_join.argtypes = [C.c_void_p, C.c_void_p]
@@ -363,6 +365,14 @@ class VoContext:
             all_reduce_sum(np.ctypeslib.as_array(ptr, shape=(n,)))
         self._keep["shard_cb"] = EXCHANGE_FN(_cb) if all_reduce_sum is not None else EXCHANGE_FN(0)
         self.L.check(self.L.lib.vo_set_hypothesis_shard(self.h, rank, world, self._keep["shard_cb"], None), "vo_set_hypothesis_shard")
+
+    def set_hypothesis_shard_stream(self, rank: int, world: int, enqueue_allreduce):
+        """On-stream form: ``enqueue_allreduce(device_ptr: int, n: int, hip_stream: int) -> int`` enqueues an in-place int32 SUM over the ranks
+        on the given HIP stream (RCCL: ncclAllReduce; through torch: shard.Group.stream_allreduce_i32) and returns 0."""
+        def _cb(comm, ptr, n, stream):
+            return int(enqueue_allreduce(C.cast(ptr, C.c_void_p).value, int(n), int(stream or 0)))
+        self._keep["shard_scb"] = STREAM_ALLREDUCE_FN(_cb) if enqueue_allreduce is not None else STREAM_ALLREDUCE_FN(0)
+        self.L.check(self.L.lib.vo_set_hypothesis_shard_stream(self.h, rank, world, self._keep["shard_scb"], None), "vo_set_hypothesis_shard_stream")
 
     def triangulate_batch(self, view_start, T_cw, xy):
         """Batched N-view triangulation -> (xyz [n, 3], ok [n])."""

@@ -166,7 +166,7 @@ int main() {
                 hipMemcpyAsync(B.bs, d_b0, sizeof(double) * D, hipMemcpyDeviceToDevice, st);
                 hipMemcpyAsync(B.S, d_S0, sizeof(double) * D * D, hipMemcpyDeviceToDevice, st);      // the global-resident kernels factor S in place
                 hipEventRecord(e0, st);
-                if (D <= 192) hipLaunchKernelGGL(k_ba_chol16, dim3(1), dim3(CH_THREADS), sizeof(double) * (CH_NB * CH_NB + (size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D), st, Q, 0);
+                if (D <= 192) hipLaunchKernelGGL(k_ba_chol16, dim3(1), dim3(CH_THREADS), sizeof(double) * (CH_NB * CH_NB + (size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D), st, Q, 0, 0);
                 else hipLaunchKernelGGL(k_ba_chol16g, dim3(1), dim3(CH_THREADS), sizeof(double) * (CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D), st, Q);
                 hipEventRecord(e1, st);
                 hipStreamSynchronize(st);

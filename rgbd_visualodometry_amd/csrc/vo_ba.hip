@@ -39,7 +39,7 @@ struct BaBlock { int j1, j2, start, count; };      // one 6x6 block of the reduc
 struct BaCtl {
     double lambda, ni, cur;
     int it, qmax, max_it, need_lin, first, finished, buf, iters_done, steps, arrived;
-    int robust, pad;                 // Huber kernel on (round 1) / off (round 2): backend.cpp:138-160
+    int robust, lbuf;                // Huber kernel on (round 1) / off (round 2): backend.cpp:138-160; lbuf: which record / weight buffer holds the current linearisation (vo_ba_phase2.h)
 };
 
 struct BaDev {
@@ -619,7 +619,7 @@ __device__ __forceinline__ void ba_st16_sc1(double* p, double a, double b) {
 // (k_ba_persist): lambda comes from the caller, the control block is not touched, S / b_s are cleared behind the load (write-through:
 // they are the targets of the next step's Schur atomics) and the solution goes to x_out with write-through stores.
 template <bool PB>
-__device__ __forceinline__ bool ba_chol16_body(const BaDev& B, BaCtl* ctl_, double lambda_in, double* s_mem, double* x_out) {
+__device__ __forceinline__ bool ba_chol16_body(const BaDev& B, BaCtl* ctl_, double lambda_in, double* s_mem, double* x_out, bool clear_after_load = false) {
     int D_ = B.D;
     // inside the persistent kernel's step loop everything derived from D and the LDS base is loop invariant; hoisted out of the loop it
     // stays live across the whole kernel and spills: the values are laundered so that they are recomputed per call
@@ -683,6 +683,10 @@ __device__ __forceinline__ bool ba_chol16_body(const BaDev& B, BaCtl* ctl_, doub
         double* g = const_cast<double*>(A);
         for (int i = 2 * tid; i < ntri; i += 2 * CH_THREADS) ba_st16_sc1(g + i, 0.0, 0.0);      // the slab is padded: a pair past the end is harmless
         if (tid < D) __hip_atomic_store(B.bs + tid, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (clear_after_load) {                              // launch path, second generation: plain stores (the kernel boundary publishes them)
+        double2* g = reinterpret_cast<double2*>(const_cast<double*>(A));
+        for (int i = tid; 2 * i < ntri; i += CH_THREADS) g[i] = make_double2(0.0, 0.0);
+        if (tid < D) B.bs[tid] = 0.0;
     }
     __syncthreads();
     if (wave == 0) {                                            // first diagonal block, in registers (the other waves wait at the barrier)
@@ -903,11 +907,13 @@ __device__ __forceinline__ bool ba_chol16_body(const BaDev& B, BaCtl* ctl_, doub
 __device__ __forceinline__ void ba_pose_body(const BaDev& B, double lambda, int blk, const double* poses_c, double* poses_t);
 // trial_poses = 1 (second-generation phases, vo_ba_phase2.h): the kernel also writes the trial poses exp(dp) T and the pose part of the
 // gain ratio, which is what k_ba_update's pose workgroups do in the first generation
-__global__ __launch_bounds__(CH_THREADS) void k_ba_chol16(BaBatch Q, int trial_poses) {
+// phase2 = 1 (vo_ba_phase2.h): S and b_s are cleared behind the load (the next step's Schur kernel accumulates into them: no separate zeroing
+// launch) and the solution goes to B.dl instead of overwriting b_s
+__global__ __launch_bounds__(CH_THREADS) void k_ba_chol16(BaBatch Q, int trial_poses, int phase2) {
     BA_PROBLEM(Q)
     if (ctl_->finished || B.D > 192) return;                   // larger systems: k_ba_chol16g
     extern __shared__ double s_mem[];
-    (void)ba_chol16_body<false>(B, ctl_, 0.0, s_mem, B.bs);
+    (void)ba_chol16_body<false>(B, ctl_, 0.0, s_mem, phase2 ? B.dl : B.bs, phase2 != 0);
     if (trial_poses) {
         __syncthreads();                                       // dp, the ok flag and the control block are complete
         BA_STATE(B)
@@ -1415,7 +1421,7 @@ static int ba_engine_pump(BaEngine* E) {                    // engine thread; re
     const bool phase2 = true;                               // (the first generation stays for D > 192 only: its Schur kernel writes the full matrix k_ba_chol16g reads)
     int chunk = (na == 1 && E->pending_hint == 0) ? 16 : 6;
     int sA[BA_SLOTS], nA = 0, sB[BA_SLOTS], nB = 0, sB16[BA_SLOTS], nB16 = 0, sB16g[BA_SLOTS], nB16g = 0, fA[BA_SLOTS], nfA = 0, fB[BA_SLOTS], nfB = 0;
-    int gA_lin = 0, gA_blk = 0, gA_up = 0, gA_md = 0, gB_lin = 0, gB_init = 0, gB_blk = 0, gB_upd = 0, gB_c = 0, gB_md = 0;
+    int gA_lin = 0, gA_blk = 0, gA_up = 0, gA_md = 0, gA_pose = 0, gB_lin = 0, gB_init = 0, gB_blk = 0, gB_upd = 0, gB_c = 0, gB_md = 0;
     size_t ldsA = 0, ldsA_up = 0, ldsB16 = 0, ldsB16g = 0;
     for (int i = 0; i < na; ++i) {
         BaJob* j = E->slot[act[i]];
@@ -1424,7 +1430,7 @@ static int ba_engine_pump(BaEngine* E) {                    // engine thread; re
         chunk = std::min(chunk, std::max(2, max_it - (j->steps ? h.it : 0)));
         if (phase2 && j->B.D <= BA_FOLD_D) {
             sA[nA++] = act[i];
-            gA_lin = std::max(gA_lin, j->grid_lin); gA_blk = std::max(gA_blk, j->B.n_blocks); gA_up = std::max(gA_up, j->B.gp);
+            gA_lin = std::max(gA_lin, j->grid_lin); gA_blk = std::max(gA_blk, j->B.n_blocks); gA_pose = std::max(gA_pose, j->B.n_free * PSPLIT); gA_up = std::max(gA_up, (j->B.n_points + UPC_T / 4 - 1) / (UPC_T / 4));
             ldsA = std::max(ldsA, j->lds); ldsA_up = std::max(ldsA_up, sizeof(double) * (12 * (size_t)j->B.n_poses + (size_t)j->B.D));
             if (j->need_first) { fA[nfA++] = act[i]; gA_md = std::max(gA_md, (j->B.D + j->B.n_points + 255) / 256); }
         } else {
@@ -1440,11 +1446,16 @@ static int ba_engine_pump(BaEngine* E) {                    // engine thread; re
     const dim3 blk(256);
     for (int sidx = 0; sidx < chunk; ++sidx) {
         if (nA) {
-            { ProfScope ps(prof, "k_ba_lin", st); hipLaunchKernelGGL(k_ba_lin2, dim3(gA_lin, 1, nA), blk, 0, st, QA); }
-            if (sidx == 0 && nfA) hipLaunchKernelGGL(k_ba_maxdiag2, dim3(gA_md, 1, nfA), blk, 0, st, ba_batch_of(E, fA, nfA));
-            if (gA_blk) { ProfScope ps(prof, "k_ba_schur_blocks", st); hipLaunchKernelGGL(k_ba_schur2, dim3(gA_blk, 1, nA), blk, 0, st, QA); }
-            { ProfScope ps(prof, "k_ba_chol", st); hipLaunchKernelGGL(k_ba_chol16, dim3(1, 1, nA), dim3(CH_THREADS), ldsA, st, QA, 0); }
-            { ProfScope ps(prof, "k_ba_update", st); hipLaunchKernelGGL(k_ba_upchi2, dim3(gA_up, 1, nA), blk, ldsA_up, st, QA); }
+            // the first step of a round linearises in a launch of its own (lambda needs the largest diagonal entry first); afterwards the
+            // linearisation at the accepted state is a by-product of k_ba_upchi2 and a step is THREE launches
+            if (sidx == 0 && nfA) {
+                const BaBatch QF = ba_batch_of(E, fA, nfA);
+                { ProfScope ps(prof, "k_ba_lin", st); hipLaunchKernelGGL(k_ba_lin2, dim3(gA_lin, 1, nfA), blk, 0, st, QF); }
+                hipLaunchKernelGGL(k_ba_maxdiag2, dim3(gA_md, 1, nfA), blk, 0, st, QF);
+            }
+            { ProfScope ps(prof, "k_ba_schur_blocks", st); hipLaunchKernelGGL(k_ba_schur2, dim3(gA_blk + gA_pose, 1, nA), blk, 0, st, QA); }
+            { ProfScope ps(prof, "k_ba_chol", st); hipLaunchKernelGGL(k_ba_chol16, dim3(1, 1, nA), dim3(CH_THREADS), ldsA, st, QA, 0, 1); }
+            { ProfScope ps(prof, "k_ba_update", st); hipLaunchKernelGGL(k_ba_upchi2, dim3(gA_up, 1, nA), dim3(UPC_T), ldsA_up, st, QA); }
         }
         if (nB) {
             { ProfScope ps(prof, "k_ba_lin", st); hipLaunchKernelGGL(k_ba_lin, dim3(gB_lin, 1, nB), blk, 0, st, QB); }
@@ -1453,7 +1464,7 @@ static int ba_engine_pump(BaEngine* E) {                    // engine thread; re
             if (nB16g || (sidx == 0 && nfB)) { ProfScope ps(prof, "k_ba_init_S", st); hipLaunchKernelGGL(k_ba_init_S, dim3(gB_init, 1, nB), blk, 0, st, QB); }
             if (gB_blk) { ProfScope ps(prof, "k_ba_schur_blocks", st); hipLaunchKernelGGL(k_ba_schur_blocks, dim3(gB_blk, 1, nB), blk, 0, st, QB); }
             { ProfScope ps(prof, "k_ba_chol", st);
-              if (nB16) hipLaunchKernelGGL(k_ba_chol16, dim3(1, 1, nB16), dim3(CH_THREADS), ldsB16, st, ba_batch_of(E, sB16, nB16), 0);
+              if (nB16) hipLaunchKernelGGL(k_ba_chol16, dim3(1, 1, nB16), dim3(CH_THREADS), ldsB16, st, ba_batch_of(E, sB16, nB16), 0, 0);
               if (nB16g) hipLaunchKernelGGL(k_ba_chol16g, dim3(1, 1, nB16g), dim3(CH_THREADS), ldsB16g, st, ba_batch_of(E, sB16g, nB16g)); }
             { ProfScope ps(prof, "k_ba_update", st); hipLaunchKernelGGL(k_ba_update, dim3(gB_upd, 1, nB), blk, 0, st, QB); }
             { ProfScope ps(prof, "k_ba_chi_control", st); hipLaunchKernelGGL(k_ba_chi_control, dim3(gB_c, 1, nB), blk, 0, st, QB); }
@@ -1820,7 +1831,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     const size_t o_pcnt = carve(4 * (size_t)std::max(nb_all, 1)), o_poff = carve(4 * (size_t)std::max(nb_all, 1)), o_pn = carve(16);
     const size_t o_Hpp = carve(288 * (size_t)nf), o_bp = carve(8 * (size_t)D), o_Hll = carve(72 * (size_t)nx), o_bl = carve(24 * (size_t)nx), o_scal = carve(64);
     const size_t o_partU = carve(24 * ((size_t)(nx + 63) / 64 + 1)), o_partC = carve(8 * ((size_t)(ne + 255) / 256 + 1));
-    const size_t o_W = carve(144 * (size_t)ne), o_S = carve(8 * (size_t)D * D), o_bs = carve(8 * (size_t)D), o_Hinv = carve(72 * (size_t)nx), o_dl = carve(24 * (size_t)nx);
+    const size_t o_W = carve(std::max<size_t>(144 * (size_t)ne, 16 * (size_t)ne + 192 * (size_t)nx + 2048)), o_S = carve(8 * (size_t)D * D), o_bs = carve(8 * (size_t)D), o_Hinv = carve(72 * (size_t)nx), o_dl = carve(std::max<size_t>(24 * (size_t)nx, 8 * (size_t)D));
     int rc = vo_scratch(c, off);
     if (rc) return rc;
     uint8_t* base = (uint8_t*)c->d_ba;
@@ -2214,7 +2225,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     const size_t o_pcnt = carve(4 * (size_t)std::max(nb_all, 1)), o_poff = carve(4 * (size_t)std::max(nb_all, 1)), o_pn = carve(16);
     const size_t o_Hpp = carve(288 * (size_t)nf), o_bp = carve(8 * (size_t)D), o_Hll = carve(72 * (size_t)nx), o_bl = carve(24 * (size_t)nx), o_scal = carve(64);
     const size_t o_partU = carve(24 * ((size_t)(nx + 63) / 64 + 1)), o_partC = carve(8 * ((size_t)(ne + 255) / 256 + 1));
-    const size_t o_W = carve(144 * (size_t)ne), o_S = carve(8 * (size_t)D * D), o_bs2 = carve(8 * (size_t)D), o_Hinv = carve(72 * (size_t)nx), o_dl = carve(24 * (size_t)nx);
+    const size_t o_W = carve(std::max<size_t>(144 * (size_t)ne, 16 * (size_t)ne + 192 * (size_t)nx + 2048)), o_S = carve(8 * (size_t)D * D), o_bs2 = carve(8 * (size_t)D), o_Hinv = carve(72 * (size_t)nx), o_dl = carve(std::max<size_t>(24 * (size_t)nx, 8 * (size_t)D));
     // pair lists: a point seen by m free poses gives m (m + 1) / 2 <= m (nf + 1) / 2 pairs, so ne (nf + 1) / 2 bounds them before the
     // per-pose lists exist; slices: one per 512 pairs plus a partial one per block
     const size_t pairs_ub = (size_t)ne * (size_t)(nf + 1) / 2 + 1, slices_cap = pairs_ub / 512 + (size_t)nb_all + 1;

@@ -1,18 +1,27 @@
 // vo_ba_phase2.h -- second generation of the launch-per-phase LM step for systems the LDS-resident Cholesky solves (D <= 192),
-// included by vo_ba.hip.  Four launches per step instead of five, and much less traffic:
-//   k_ba_lin2     4 lanes per point: H_ll / b_l and the point into ONE 96-byte record, the Huber weight of every edge (8 bytes) --
-//                 the 144-byte W_e blocks are no longer stored (15 MB per linearisation); 4 workgroups per free pose: H_pp / b_p
-//   k_ba_schur2   pair lists as before, but a pair's 6x6 contribution is rebuilt from the record and the two weights:
-//                 W_e1 Hinv W_e2^T = J_pose1^T M J_pose2 with the 2x2 matrix M = w1 w2 J_point1 Hinv J_point2^T (W_e has rank 2):
-//                 ~130 bytes and 72 FMAs per pair instead of ~370 bytes and 162; only the lower triangle of S is accumulated
-//   k_ba_chol16   unchanged (with trial_poses = 1 it would write the trial poses behind the solve: measured 5 us per step slower
-//                 than rebuilding them in every workgroup of the next kernel, where the exp maps overlap the loads)
-//   k_ba_upchi2   back-substitution, trial point AND the robust chi2 of the point's edges in one pass (every workgroup rebuilds the
-//                 ~50 trial poses in LDS), the last workgroup runs the LM accept / lambda policy
-// The arithmetic of the LM step is the one of vo_ba_persist.h (same helper functions), stores and loads are plain: between
-// launches the data stays in the XCDs' L2s.
+// included by vo_ba.hip.  THREE launches per step in the steady state instead of five, and much less traffic:
+//   k_ba_schur2   pair lists as before, but a pair's 6x6 contribution is rebuilt from a 96-byte per-point record (H_ll, b_l, the point) and
+//                 the two edges' Huber weights: W_e1 Hinv W_e2^T = J_pose1^T M J_pose2 with the 2x2 matrix M = w1 w2 J_point1 Hinv J_point2^T
+//                 (W_e has rank 2): ~130 bytes and 72 FMAs per pair instead of ~370 bytes and 162 (the 144-byte W_e blocks are never
+//                 stored: 15 MB per linearisation); lower triangle of S only, packed (ba_tri).  The same launch carries the 4 workgroups per
+//                 free pose that sum H_pp / b_p when the state has changed (the Cholesky needs them, the Schur slices do not).
+//   k_ba_chol16   as before; it clears S / b_s behind its load (no zeroing launch) and leaves the solution in B.dl
+//   k_ba_upchi2   back-substitution, trial point and the robust chi2 of the point's edges in one pass -- and, in that same pass over the
+//                 edges, the LINEARISATION AT THE TRIAL STATE (records and weights into the other buffer, `lbuf ^ 1`): when the last
+//                 workgroup's LM decision accepts the step (the usual case) the next step starts at the Schur launch; when it rejects,
+//                 the current buffers are still the linearisation at the unchanged state.  Every workgroup rebuilds the ~50 trial poses
+//                 in LDS (Taylor exp map); the last workgroup runs g2o's accept / lambda policy.
+//   k_ba_lin2 / k_ba_maxdiag2   only on the first step of a round: lambda_0 = 1e-5 max diag(H) needs a linearisation before anything else
+// Stores and loads are plain: between launches the data stays in the XCDs' L2s.  (A kernel boundary of this chain costs ~5.5 us while the
+// tracker's kernels run beside it -- 0.1 us alone, profiles/r03_ba_gaps.txt -- which is what taking launches out of the step buys.)
 #pragma once
 
+// The slab the first generation uses for W_e (>= 16 n_edges + 192 n_points + 2 KiB bytes) holds two weight arrays and two record arrays;
+// ctl->lbuf says which pair is the current linearisation.
+__device__ __forceinline__ double* p2_w(const BaDev& B, int which) { return B.W + (size_t)which * (((size_t)B.n_edges + 31) & ~(size_t)31); }
+__device__ __forceinline__ double* p2_rec(const BaDev& B, int which) {
+    return B.W + 2 * (((size_t)B.n_edges + 31) & ~(size_t)31) + (size_t)which * (((size_t)PB_REC * B.n_points + 31) & ~(size_t)31);
+}
 __device__ __forceinline__ void p2_rec_store(double* rec, int k, const double (&H)[6], const double (&b3)[3], const double (&p)[3]) {
     double2* o = reinterpret_cast<double2*>(rec + (size_t)PB_REC * k);
     o[0] = make_double2(H[0], H[1]); o[1] = make_double2(H[2], H[3]); o[2] = make_double2(H[4], H[5]);
@@ -39,7 +48,8 @@ __global__ __launch_bounds__(256) void k_ba_lin2(BaBatch Q) {
         if ((int)blockIdx.x - gp < B.n_free * PSPLIT) ba_lin_poses_body(B.cam, B, robust, B.delta, blockIdx.x - gp, poses_c, pts_c, s_part);
         return;
     }
-    double* const rec = pb_rec_base(B);
+    double* const rec = p2_rec(B, ctl_->lbuf);
+    double* const Wt = p2_w(B, ctl_->lbuf);
     const int k = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
     double chi[1] = {0.0};
     double H[6] = {0, 0, 0, 0, 0, 0}, b3[3] = {0, 0, 0}, p[3] = {0, 0, 0};
@@ -51,7 +61,7 @@ __global__ __launch_bounds__(256) void k_ba_lin2(BaBatch Q) {
             if (!B.active[e]) continue;
             double r[2], w, rho0, Jp[2][6], Jl[2][3];
             ba_edge(B.cam, poses_c + 12 * (size_t)B.e_pose[e], p, B.e_uv + 2 * (size_t)e, robust, B.delta, r, w, rho0, Jp, Jl);
-            B.W[e] = w;
+            Wt[e] = w;
             chi[0] += rho0;
             b3[0] -= w * (Jl[0][0] * r[0] + Jl[1][0] * r[1]); b3[1] -= w * (Jl[0][1] * r[0] + Jl[1][1] * r[1]); b3[2] -= w * (Jl[0][2] * r[0] + Jl[1][2] * r[1]);
             H[0] += w * (Jl[0][0] * Jl[0][0] + Jl[1][0] * Jl[1][0]); H[1] += w * (Jl[0][0] * Jl[0][1] + Jl[1][0] * Jl[1][1]); H[2] += w * (Jl[0][0] * Jl[0][2] + Jl[1][0] * Jl[1][2]);
@@ -74,19 +84,18 @@ __global__ void k_ba_maxdiag2(BaBatch Q) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     double v = 0;
     if (i < B.D) v = fabs(B.Hpp[36 * (size_t)(i / 6) + 7 * (i % 6)]);
-    else if (i < B.D + B.n_points) { const double* r = pb_rec_base(B) + (size_t)PB_REC * (i - B.D); v = fmax(fabs(r[0]), fmax(fabs(r[3]), fabs(r[5]))); }
+    else if (i < B.D + B.n_points) { const double* r = p2_rec(B, ctl_->lbuf) + (size_t)PB_REC * (i - B.D); v = fmax(fabs(r[0]), fmax(fabs(r[3]), fabs(r[5]))); }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
     if ((threadIdx.x & 63) == 0 && v > 0) atomicMax((unsigned long long*)&B.scal[4], (unsigned long long)__double_as_longlong(v));
 }
 
 template <bool DIAG>
-__device__ __forceinline__ void p2_schur_slice(const BaDev& B, const BaBlock blk, double lambda, const double* poses_c, double* s_part, double* s_tot) {
+__device__ __forceinline__ void p2_schur_slice(const BaDev& B, const BaBlock blk, double lambda, const double* poses_c, const double* rec, const double* Wt, double* s_part, double* s_tot) {
     constexpr int NV = DIAG ? 42 : 36;
     double v[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) v[i] = 0;
-    const double* const rec = pb_rec_base(B);
     double T1[12], T2[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) { T2[i] = poses_c[12 * (size_t)blk.j2 + i]; T1[i] = DIAG ? 0.0 : poses_c[12 * (size_t)blk.j1 + i]; }
@@ -95,7 +104,7 @@ __device__ __forceinline__ void p2_schur_slice(const BaDev& B, const BaBlock blk
         if (!B.active[pr.x] || (!DIAG && !B.active[pr.y])) continue;
         double Hh[6], bl[3], p[3], h[9];
         p2_rec_load(rec, B.e_pt[pr.x], Hh, bl, p);
-        const double w2 = B.W[pr.y], w1 = DIAG ? w2 : B.W[pr.x];
+        const double w2 = Wt[pr.y], w1 = DIAG ? w2 : Wt[pr.x];
         const double Hs[9] = {Hh[0], Hh[1], Hh[2], Hh[1], Hh[3], Hh[4], Hh[2], Hh[4], Hh[5]};
         ba_inv3_damped(Hs, lambda, h);
         double Jp2[2][6], Jl2[2][3], G2[2][3], M[2][2];
@@ -173,52 +182,81 @@ __global__ __launch_bounds__(256) void k_ba_schur2(BaBatch Q) {
     if (ctl_->finished || B.D > BA_FOLD_D) return;
     __shared__ double s_part[4 * 42];
     __shared__ double s_tot[42];
-    if ((int)blockIdx.x >= B.n_blocks || (B.n_slices && (int)blockIdx.x >= *B.n_slices)) return;
     BA_STATE(B)
+    const int n_pose_blk = B.n_free * PSPLIT;
+    if ((int)blockIdx.x < n_pose_blk) {
+        // H_pp / b_p of the accepted state (zeroed by the step that accepted it).  On the first step of a round k_ba_lin2 has done it (lambda_0
+        // needs the diagonal before this launch); after a rejected step the sums of the unchanged state are still there.
+        if (ctl_->need_lin && !ctl_->first) ba_lin_poses_body(B.cam, B, ctl_->robust, B.delta, blockIdx.x, poses_c, pts_c, s_part);
+        return;
+    }
+    const int sl = blockIdx.x - n_pose_blk;
+    if (sl >= B.n_blocks || (B.n_slices && sl >= *B.n_slices)) return;
     const double lambda = (ctl_->need_lin && ctl_->first) ? 1e-5 * B.scal[4] : ctl_->lambda;      // as k_ba_chol16 derives it (the control block is updated there)
-    const BaBlock blk = B.blocks[blockIdx.x];
-    if (blk.j1 == blk.j2) p2_schur_slice<true>(B, blk, lambda, poses_c, s_part, s_tot);
-    else p2_schur_slice<false>(B, blk, lambda, poses_c, s_part, s_tot);
+    const BaBlock blk = B.blocks[sl];
+    const double* const rec = p2_rec(B, ctl_->lbuf);
+    const double* const Wt = p2_w(B, ctl_->lbuf);
+    if (blk.j1 == blk.j2) p2_schur_slice<true>(B, blk, lambda, poses_c, rec, Wt, s_part, s_tot);
+    else p2_schur_slice<false>(B, blk, lambda, poses_c, rec, Wt, s_part, s_tot);
+}
+
+// exp(d) * T for a pose increment d = [translation, rotation] (g2o_types.h:56-60).  LM increments are small rotations: below 0.25 rad the
+// coefficients sin(th)/th, (1 - cos th)/th^2, (th - sin th)/th^3 come from their Taylor series to th^14 (error < 1e-19) instead of the
+// sin / cos call chains (~400 instructions, and every workgroup of k_ba_upchi2 rebuilds all trial poses)
+__device__ __forceinline__ void p2_exp_mul(const double* d, const double* T, double (&Tn)[12]) {
+#pragma clang fp contract(fast)
+    const double w[3] = {d[3], d[4], d[5]};
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    double A, Bc, C;
+    if (th2 < 0.0625) {
+        A = 1.0 - th2 * (1.0 / 6.0) * (1.0 - th2 * (1.0 / 20.0) * (1.0 - th2 * (1.0 / 42.0) * (1.0 - th2 * (1.0 / 72.0) * (1.0 - th2 * (1.0 / 110.0) * (1.0 - th2 * (1.0 / 156.0) * (1.0 - th2 * (1.0 / 210.0)))))));
+        Bc = 0.5 * (1.0 - th2 * (1.0 / 12.0) * (1.0 - th2 * (1.0 / 30.0) * (1.0 - th2 * (1.0 / 56.0) * (1.0 - th2 * (1.0 / 90.0) * (1.0 - th2 * (1.0 / 132.0) * (1.0 - th2 * (1.0 / 182.0) * (1.0 - th2 * (1.0 / 240.0))))))));
+        C = (1.0 / 6.0) * (1.0 - th2 * (1.0 / 20.0) * (1.0 - th2 * (1.0 / 42.0) * (1.0 - th2 * (1.0 / 72.0) * (1.0 - th2 * (1.0 / 110.0) * (1.0 - th2 * (1.0 / 156.0) * (1.0 - th2 * (1.0 / 210.0) * (1.0 - th2 * (1.0 / 272.0))))))));
+    } else { const double th = sqrt(th2); A = sin(th) / th; Bc = (1.0 - cos(th)) / th2; C = (th - sin(th)) / (th2 * th); }
+    const double Wm[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+    double W2[9], R[9], V[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) W2[3 * i + c] = Wm[3 * i] * Wm[c] + Wm[3 * i + 1] * Wm[3 + c] + Wm[3 * i + 2] * Wm[6 + c];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { const double I = (i % 4 == 0) ? 1.0 : 0.0; R[i] = I + A * Wm[i] + Bc * W2[i]; V[i] = I + Bc * Wm[i] + C * W2[i]; }
+    const double tx = V[0] * d[0] + V[1] * d[1] + V[2] * d[2], ty = V[3] * d[0] + V[4] * d[1] + V[5] * d[2], tz = V[6] * d[0] + V[7] * d[1] + V[8] * d[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Tn[3 * i + c] = R[3 * i] * T[c] + R[3 * i + 1] * T[3 + c] + R[3 * i + 2] * T[6 + c];
+    Tn[9] = R[0] * T[9] + R[1] * T[10] + R[2] * T[11] + tx;
+    Tn[10] = R[3] * T[9] + R[4] * T[10] + R[5] * T[11] + ty;
+    Tn[11] = R[6] * T[9] + R[7] * T[10] + R[8] * T[11] + tz;
 }
 
 // trial state and its robust chi2, then (last workgroup) the LM decision of k_ba_chi_control
-__global__ __launch_bounds__(256) void k_ba_upchi2(BaBatch Q) {
+#define UPC_T 512
+__global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q) {
     BA_PROBLEM(Q)
     if (ctl_->finished || B.D > BA_FOLD_D) return;
-    const int gp = B.gp;
+    const int gp = (B.n_points + UPC_T / 4 - 1) / (UPC_T / 4);     // 128 points per workgroup (4 lanes each)
     if ((int)blockIdx.x >= gp) return;
     extern __shared__ double s_dyn[];
     double* const s_T = s_dyn;                             // trial poses [n_poses][12]
     double* const s_dp = s_dyn + 12 * (size_t)B.n_poses;   // pose increments [D]
-    __shared__ double s_w[12];
+    __shared__ double s_w[3 * (UPC_T / 64)];
     __shared__ int s_last, s_accept;
     const double lambda = ctl_->lambda;
     const int robust = ctl_->robust;
     const bool ok = B.scal[3] != 0.0;
     BA_STATE(B)
-    for (int i = threadIdx.x; i < B.D; i += 256) s_dp[i] = B.bs[i];
-    for (int j = threadIdx.x; j < B.n_poses; j += 256) {   // exp(dp) * T for the free poses (ba_pose_body), copies for the fixed ones
+    for (int i = threadIdx.x; i < B.D; i += UPC_T) s_dp[i] = B.dl[i];           // the solution (k_ba_chol16, phase2 = 1)
+    for (int j = threadIdx.x; j < B.n_poses; j += UPC_T) {   // exp(dp) * T for the free poses (ba_pose_body), copies for the fixed ones
         const double* T = poses_c + 12 * (size_t)j;
         double Tn[12];
         if (j >= B.n_free || !ok) {
 #pragma unroll
             for (int i = 0; i < 12; ++i) Tn[i] = T[i];
         } else {
-            const double* d = B.bs + 6 * j;
-            const double w[3] = {d[3], d[4], d[5]};
-            const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = sqrt(th2);
-            double A, Bc, C;
-            if (th < 1e-8) { A = 1.0 - th2 / 6.0; Bc = 0.5 - th2 / 24.0; C = 1.0 / 6.0 - th2 / 120.0; }
-            else { A = sin(th) / th; Bc = (1.0 - cos(th)) / th2; C = (th - sin(th)) / (th2 * th); }
-            const double Wm[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
-            double W2[9], R[9], V[9];
-            for (int i = 0; i < 3; ++i) for (int c = 0; c < 3; ++c) { double s = 0; for (int k = 0; k < 3; ++k) s += Wm[3 * i + k] * Wm[3 * k + c]; W2[3 * i + c] = s; }
-            for (int i = 0; i < 9; ++i) { const double I = (i % 4 == 0) ? 1.0 : 0.0; R[i] = I + A * Wm[i] + Bc * W2[i]; V[i] = I + Bc * Wm[i] + C * W2[i]; }
-            const double tx = V[0] * d[0] + V[1] * d[1] + V[2] * d[2], ty = V[3] * d[0] + V[4] * d[1] + V[5] * d[2], tz = V[6] * d[0] + V[7] * d[1] + V[8] * d[2];
-            for (int i = 0; i < 3; ++i) for (int c = 0; c < 3; ++c) { double s = 0; for (int k = 0; k < 3; ++k) s += R[3 * i + k] * T[3 * k + c]; Tn[3 * i + c] = s; }
-            Tn[9] = R[0] * T[9] + R[1] * T[10] + R[2] * T[11] + tx;
-            Tn[10] = R[3] * T[9] + R[4] * T[10] + R[5] * T[11] + ty;
-            Tn[11] = R[6] * T[9] + R[7] * T[10] + R[8] * T[11] + tz;
+            const double* d = B.dl + 6 * j;
+            p2_exp_mul(d, T, Tn);
             if (blockIdx.x == 0) {                         // the pose part of the gain ratio and of the step size, once
                 double sc = 0, mx = 0;
                 for (int a = 0; a < 6; ++a) { sc += d[a] * (lambda * d[a] + B.bp[6 * j + a]); mx = fmax(mx, fabs(d[a])); }
@@ -236,8 +274,12 @@ __global__ __launch_bounds__(256) void k_ba_upchi2(BaBatch Q) {
     __syncthreads();
     double chi = 0, sc = 0, mx = 0;
     {
-        const double* const rec = pb_rec_base(B);
-        const int k = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+        const int lb = ctl_->lbuf;
+        const double* const rec = p2_rec(B, lb);
+        const double* const Wt = p2_w(B, lb);
+        double* const rec_n = p2_rec(B, lb ^ 1);
+        double* const Wn = p2_w(B, lb ^ 1);
+        const int k = blockIdx.x * (UPC_T / 4) + (threadIdx.x >> 2), sub = threadIdx.x & 3;
         const bool live = ok && k < B.n_points;
         double H[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0}, p[3] = {0, 0, 0}, rhs[3] = {0, 0, 0};
         int q0 = 0, q1 = 0;
@@ -248,7 +290,7 @@ __global__ __launch_bounds__(256) void k_ba_upchi2(BaBatch Q) {
             for (int q = q0 + sub; q < q1; q += 4) {
                 const int e = B.pt_edges[q], j = B.e_pose[e];
                 if (!B.active[e] || j >= B.n_free) continue;
-                const double w = B.W[e];
+                const double w = Wt[e];
                 double T[12], Jp[2][6], Jl[2][3];
 #pragma unroll
                 for (int i = 0; i < 12; ++i) T[i] = poses_c[12 * (size_t)j + i];
@@ -263,9 +305,10 @@ __global__ __launch_bounds__(256) void k_ba_upchi2(BaBatch Q) {
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) rhs[c] = ba_quad_sum(rhs[c]);
+        double Hn[6] = {0, 0, 0, 0, 0, 0}, bn[3] = {0, 0, 0}, pn[3] = {0, 0, 0};
         if (live) {
             const double Hs[9] = {H[0], H[1], H[2], H[1], H[3], H[4], H[2], H[4], H[5]};
-            double h[9], pn[3];
+            double h[9];
             ba_inv3_damped(Hs, lambda, h);
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
@@ -273,25 +316,38 @@ __global__ __launch_bounds__(256) void k_ba_upchi2(BaBatch Q) {
                 pn[a] = p[a] + d;
                 if (sub == 0) { pts_t[3 * (size_t)k + a] = pn[a]; sc += d * (lambda * d + bl[a]); mx = fmax(mx, fabs(d)); }
             }
+            // second pass over the point's edges at the TRIAL state: robust chi2 (the LM decision) and the whole linearisation (Huber weight,
+            // H_ll, b_l) that the next step needs if this one is accepted -- k_ba_lin2's point part at the price of a few dozen FMAs per edge
             for (int q = q0 + sub; q < q1; q += 4) {
                 const int e = B.pt_edges[q];
                 if (!B.active[e]) continue;
-                double r[2], pc[3];
-                ba_err(B.cam, s_T + 12 * B.e_pose[e], pn, B.e_uv + 2 * (size_t)e, r, pc);
-                const double e2 = r[0] * r[0] + r[1] * r[1];
-                chi += (robust && e2 > B.delta * B.delta) ? 2.0 * sqrt(e2) * B.delta - B.delta * B.delta : e2;
+                double r[2], w, rho0, Jp[2][6], Jl[2][3];
+                ba_edge(B.cam, s_T + 12 * B.e_pose[e], pn, B.e_uv + 2 * (size_t)e, robust, B.delta, r, w, rho0, Jp, Jl);
+                chi += rho0;
+                Wn[e] = w;
+                bn[0] -= w * (Jl[0][0] * r[0] + Jl[1][0] * r[1]); bn[1] -= w * (Jl[0][1] * r[0] + Jl[1][1] * r[1]); bn[2] -= w * (Jl[0][2] * r[0] + Jl[1][2] * r[1]);
+                Hn[0] += w * (Jl[0][0] * Jl[0][0] + Jl[1][0] * Jl[1][0]); Hn[1] += w * (Jl[0][0] * Jl[0][1] + Jl[1][0] * Jl[1][1]); Hn[2] += w * (Jl[0][0] * Jl[0][2] + Jl[1][0] * Jl[1][2]);
+                Hn[3] += w * (Jl[0][1] * Jl[0][1] + Jl[1][1] * Jl[1][1]); Hn[4] += w * (Jl[0][1] * Jl[0][2] + Jl[1][1] * Jl[1][2]); Hn[5] += w * (Jl[0][2] * Jl[0][2] + Jl[1][2] * Jl[1][2]);
             }
         }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Hn[i] = ba_quad_sum(Hn[i]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) bn[i] = ba_quad_sum(bn[i]);
+        if (live && sub == 0) p2_rec_store(rec_n, k, Hn, bn, pn);
     }
     chi = vo_wave_sum_f64(chi); sc = vo_wave_sum_f64(sc);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
-    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; s_w[w] = chi; s_w[4 + w] = sc; s_w[8 + w] = mx; }
+    constexpr int NWV = UPC_T / 64;
+    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; s_w[w] = chi; s_w[NWV + w] = sc; s_w[2 * NWV + w] = mx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        B.partU[3 * (size_t)blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
-        B.partU[3 * (size_t)blockIdx.x + 1] = (s_w[4] + s_w[5]) + (s_w[6] + s_w[7]);
-        B.partU[3 * (size_t)blockIdx.x + 2] = fmax(fmax(s_w[8], s_w[9]), fmax(s_w[10], s_w[11]));
+        double a_ = 0, b_ = 0, m_ = 0;
+        for (int w = 0; w < NWV; ++w) { a_ += s_w[w]; b_ += s_w[NWV + w]; m_ = fmax(m_, s_w[2 * NWV + w]); }
+        B.partU[3 * (size_t)blockIdx.x] = a_;
+        B.partU[3 * (size_t)blockIdx.x + 1] = b_;
+        B.partU[3 * (size_t)blockIdx.x + 2] = m_;
         __threadfence();
         s_last = atomicAdd(&ctl_->arrived, 1) == gp - 1;
     }
@@ -301,21 +357,22 @@ __global__ __launch_bounds__(256) void k_ba_upchi2(BaBatch Q) {
         __threadfence();
         const volatile double* pu = B.partU;
         double a = 0, b = 0, m = 0;
-        for (int i = threadIdx.x; i < gp; i += 256) { a += pu[3 * i]; b += pu[3 * i + 1]; m = fmax(m, pu[3 * i + 2]); }
+        for (int i = threadIdx.x; i < gp; i += UPC_T) { a += pu[3 * i]; b += pu[3 * i + 1]; m = fmax(m, pu[3 * i + 2]); }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); m = fmax(m, __shfl_xor(m, o, 64)); }
         __syncthreads();
-        if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; s_w[w] = a; s_w[4 + w] = b; s_w[8 + w] = m; }
+        if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; s_w[w] = a; s_w[NWV + w] = b; s_w[2 * NWV + w] = m; }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
         BaCtl* c = ctl_;
         c->arrived = 0;
-        const double s1 = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+        double s1 = 0, sB = 0, mB = 0;
+        for (int w = 0; w < NWV; ++w) { s1 += s_w[w]; sB += s_w[NWV + w]; mB = fmax(mB, s_w[2 * NWV + w]); }
         const volatile double* scv = B.scal;
         const double sc2 = scv[2], sc7 = scv[7];
-        const double s2 = sc2 + ((s_w[4] + s_w[5]) + (s_w[6] + s_w[7]));
-        const double m7 = fmax(sc7, fmax(fmax(s_w[8], s_w[9]), fmax(s_w[10], s_w[11])));
+        const double s2 = sc2 + sB;
+        const double m7 = fmax(sc7, mB);
         const double tmp = ok ? s1 : DBL_MAX;
         const double scale = (ok ? s2 : 0.0) + 1e-3;
         const double rho = (c->cur - tmp) / scale;
@@ -325,8 +382,9 @@ __global__ __launch_bounds__(256) void k_ba_upchi2(BaBatch Q) {
             double a = 1.0 - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
             a = fmin(a, 2.0 / 3.0);
             c->lambda *= fmax(1.0 / 3.0, a); c->ni = 2; c->cur = tmp;
-            c->buf ^= 1; c->need_lin = 1; accept = 1;       // trial state becomes the current state
-            B.scal[0] = 0; B.scal[4] = 0;
+            c->buf ^= 1; c->need_lin = 1; accept = 1;       // trial state becomes the current state,
+            c->lbuf ^= 1;                                   // the linearisation this launch wrote at it becomes the current one,
+            B.scal[0] = tmp; B.scal[4] = 0;                 // and its chi2 is the trial chi2 (k_ba_chol16 takes it over as `cur`)
         } else { c->lambda *= c->ni; c->ni *= 2; }
         if (ok) converged = m7 < 1e-10;
         c->qmax += 1; c->steps += 1;
@@ -339,7 +397,7 @@ __global__ __launch_bounds__(256) void k_ba_upchi2(BaBatch Q) {
     }
     __syncthreads();
     if (s_accept) {
-        for (int i = threadIdx.x; i < 36 * B.n_free; i += 256) B.Hpp[i] = 0;
-        for (int i = threadIdx.x; i < B.D; i += 256) B.bp[i] = 0;
+        for (int i = threadIdx.x; i < 36 * B.n_free; i += UPC_T) B.Hpp[i] = 0;
+        for (int i = threadIdx.x; i < B.D; i += UPC_T) B.bp[i] = 0;
     }
 }

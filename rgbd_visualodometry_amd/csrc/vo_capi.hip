@@ -777,6 +777,8 @@ static int chain_run_impl(vo_ctx* prof, hipStream_t st, LaunchSet& ls, std::vect
 
 // the one exchange step of a hypothesis-sharded RANSAC pass: per-hypothesis inlier counts of every lane, summed over the ranks
 static int shard_exchange(vo_ctx* c, hipStream_t st, int nl, int n_hyp) {
+    if (c->shard_stream_fn)                                 // enqueued on the chain's stream, in place on the count table: no host round trip
+        return c->shard_stream_fn(c->shard_user, c->d_hyp_cnt, (size_t)nl * c->p.max_hypotheses, (void*)st) == 0 ? VO_OK : VO_E_DEVICE;
     const size_t n = (size_t)nl * n_hyp;
     int32_t* h = (int32_t*)vo_stage(c, sizeof(int32_t) * n);
     if (!h) return VO_E_NOMEM;
@@ -974,7 +976,14 @@ void vo_group_destroy(vo_group* g) {
 int vo_set_hypothesis_shard(vo_ctx* c, int rank, int world, vo_exchange_fn fn, void* user) {
     if (!c || world < 0 || (world > 1 && (rank < 0 || rank >= world || !fn))) return VO_E_INVALID;
     if (world > 1 && c->group) return VO_E_UNSUPPORTED;      // a context either shares launch chains with other streams or shares a stream with other ranks
-    c->shard_rank = rank; c->shard_world = world > 1 ? world : 1; c->shard_fn = fn; c->shard_user = user;
+    c->shard_rank = rank; c->shard_world = world > 1 ? world : 1; c->shard_fn = fn; c->shard_user = user; c->shard_stream_fn = nullptr;
+    return VO_OK;
+}
+
+int vo_set_hypothesis_shard_stream(vo_ctx* c, int rank, int world, vo_stream_allreduce_fn fn, void* comm) {
+    if (!c || world < 0 || (world > 1 && (rank < 0 || rank >= world || !fn))) return VO_E_INVALID;
+    if (world > 1 && c->group) return VO_E_UNSUPPORTED;
+    c->shard_rank = rank; c->shard_world = world > 1 ? world : 1; c->shard_fn = nullptr; c->shard_user = comm; c->shard_stream_fn = world > 1 ? fn : nullptr;
     return VO_OK;
 }
 

@@ -107,6 +107,7 @@ struct vo_ctx {
     size_t lane_stride; int lanes;                  // element stride of the per-lane chain buffers
     struct vo_group* group = nullptr; hipEvent_t group_ev = nullptr;     // stream group membership (vo_group_join)
     int shard_rank = 0, shard_world = 1; vo_exchange_fn shard_fn = nullptr; void* shard_user = nullptr;     // RANSAC hypotheses sharded over ranks
+    vo_stream_allreduce_fn shard_stream_fn = nullptr;     // on-stream form of the exchange (shard_user = communicator)
     vo_match* h_matches;                            // pinned staging
     int h_matches_cap;
     int h_matches_lanes = 0, h_matches_first = 0;   // lanes whose first `h_matches_first` records the last chain left in h_matches (group mode)

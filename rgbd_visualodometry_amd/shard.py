@@ -64,6 +64,23 @@ class Group:
         else:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
 
+    def stream_allreduce_i32(self, device_ptr: int, n: int, hip_stream: int) -> int:
+        """vo_stream_allreduce_fn through torch.distributed: an in-place int32 SUM of `n` device-resident values, ENQUEUED behind the work of
+        `hip_stream` (the launch chain's stream) -- with backend nccl this is an RCCL all-reduce over xGMI and the host never waits for it.
+        Returns 0.  (gloo cannot reduce device memory: the CPU tests use the host callback form, all_reduce_sum_i32.)"""
+        if not self.dist:
+            return 0
+        import torch
+
+        class _Dev:                                          # a view of the caller's device buffer (no copy, no ownership)
+            __cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i4", "data": (int(device_ptr), False), "version": 2}
+        t = torch.as_tensor(_Dev(), device=self.device)
+        ext = torch.cuda.ExternalStream(int(hip_stream), device=self.device) if hip_stream else torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(ext):
+            work = self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, async_op=True)
+            work.wait()                                      # stream-level dependency for what follows on `ext`; the host does not block
+        return 0
+
     def gather_objects(self, obj) -> List:
         if not self.dist:
             return [obj]

@@ -339,3 +339,55 @@ def test_resident_graph_cut_follows_backend_cpp(libs, shape):
 def t_positions(L, t, slots):
     """Positions the scene put into the map (the test keeps its own copy: the C-ABI has no map read-back)."""
     return t._scene_positions[[list(t._scene_slots).index(s) for s in slots]] if hasattr(t, "_scene_positions") else None
+
+
+@pytest.mark.parametrize("libs", LIBS[1:])                 # device memory and a HIP stream: the CPU restatement answers VO_E_UNSUPPORTED
+def test_hypothesis_shard_on_stream_exchange_equals_unsharded_ransac(libs, streams):
+    """The on-stream form of the 8e-2 exchange (vo_set_hypothesis_shard_stream): the callback gets the DEVICE count table and the chain's
+    HIP stream.  The stand-in for ncclAllReduce below works on that stream through the HIP runtime (a real RCCL run needs >= 2 GPUs);
+    the plumbing -- device pointer, element count, stream, ordering inside the chain -- is what is under test."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    L = capi.load(libs[0])
+    bgr, depth, Twc, _ = streams[0]
+    p = L.default_params(n_features=800, max_frames=4, map_capacity=8192, max_track_batch=3, max_hypotheses=512)
+    ctx = L.context(p)
+    for s in range(4):
+        ctx.upload(s, bgr[2 * s], depth[2 * s])
+    ctx.orb(0, 4)
+    k0, d0 = ctx.orb_fetch(0)
+    seed_map(ctx, p, k0, d0, Twc[0])
+    tp = L.default_track_params(n_hyp=384)
+    slots, prior, seeds = [1, 2, 3], inv12(Twc[0]), [11, 12, 13]
+    want = ctx.track_batch_deferred(slots, prior, tp, seeds, cap=4096)
+    kept, calls = [], [0]
+
+    def fetch(ptr, n, stream):
+        assert hip.hipStreamSynchronize(C.c_void_p(stream)) == 0          # the stand-in is synchronous; ncclAllReduce would be enqueued
+        a = np.zeros(n, np.int32)
+        assert hip.hipMemcpy(a.ctypes.data, C.c_void_p(ptr), 4 * n, 2) == 0
+        return a
+
+    def rank1(ptr, n, stream):
+        assert n == 3 * 512 and stream != 0                  # lanes x max_hypotheses, on the context's own stream
+        kept.append(fetch(ptr, n, stream))
+        return 0
+
+    def rank0(ptr, n, stream):
+        a = fetch(ptr, n, stream) + kept[calls[0]]
+        calls[0] += 1
+        assert hip.hipMemcpy(C.c_void_p(ptr), a.ctypes.data, 4 * n, 1) == 0
+        return 0
+    ctx.set_hypothesis_shard_stream(1, 2, rank1)
+    ctx.track_batch_deferred(slots, prior, tp, seeds, cap=4096)
+    ctx.set_hypothesis_shard_stream(0, 2, rank0)
+    got = ctx.track_batch_deferred(slots, prior, tp, seeds, cap=4096)
+    assert calls[0] == len(kept) >= 2
+    for j in range(3):
+        for f in FIELDS:
+            assert getattr(got[0][j], f) == getattr(want[0][j], f), (j, f)
+        assert np.array_equal(np.array(got[0][j].T_cw), np.array(want[0][j].T_cw)) and np.array_equal(got[1][j], want[1][j])
+    ctx.set_hypothesis_shard_stream(0, 1, None)
+    ctx.close()
