@@ -300,6 +300,15 @@ int vo_local_ba_resident(vo_ctx* ctx, vo_ctx* tables, const int32_t* free_kf, in
 int vo_local_ba_resident_cut(vo_ctx* ctx, vo_ctx* tables, const int32_t* free_kf, int n_free, double huber_delta, double chi2_th,
                              int32_t* n_points, int32_t* n_fixed, int32_t* n_edges);
 int vo_local_ba_resident_solve(vo_ctx* ctx, int it_robust, int it_plain, vo_ba_resident_result* out);
+/* Merge on the device, for a caller whose next graph cut should not wait for the result's trip to the host and back
+ * (host/src/backend.cpp): vo_local_ba_resident_solve called with poses = point_slots = points = NULL leaves the optimised state in
+ * `ctx` and returns only the counts and the culled observations (the caller's covisibility ledger needs them before it picks the next
+ * free keyframes); _merge then writes that state into `tables` -- the positions of the graph's points whose map flag is not
+ * VO_MAP_FLAG_OUTLIER (vo_map_upsert), the free keyframes' poses (vo_kf_set_pose), the culled observations (vo_obs_kill) -- on
+ * the tables' stream, and the next _cut of `ctx` is ordered behind it; _fetch brings poses / point_slots / points to the host
+ * afterwards (any time before the next _merge of `ctx`).  Replaces the write-back of reference src/backend.cpp:144-194 on the device side. */
+int vo_local_ba_resident_merge(vo_ctx* ctx, vo_ctx* tables);
+int vo_local_ba_resident_fetch(vo_ctx* ctx, vo_ba_resident_result* out);
 /* Parity tap: the graph vo_local_ba_resident would cut, in vo_ba_problem layout (edge_obs: observation id per edge). */
 int vo_ba_resident_graph(vo_ctx* ctx, vo_ctx* tables, const int32_t* free_kf, int n_free, int32_t* n_poses, int32_t* pose_kf, int cap_poses,
                          int32_t* n_points, int32_t* point_slots, int cap_points, int32_t* n_edges, int32_t* edge_pose, int32_t* edge_point,

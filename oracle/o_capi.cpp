@@ -37,6 +37,8 @@ struct vo_ctx {
     std::vector<double> kf_pose;
     struct Pending { bool ready = false; std::vector<int32_t> pose_kf, point_slots, edge_pose, edge_point; std::vector<float> edge_uv; std::vector<int64_t> edge_obs;
                      std::vector<double> poses, pts; int n_free = 0; double huber = 0, chi2 = 0; } pend;      // between vo_local_ba_resident_cut and _solve
+    struct Solved { bool ready = false, merged = false; std::vector<double> poses, pts; std::vector<int32_t> pose_kf, slots; std::vector<int64_t> culled;
+                    int n_fixed = 0, n_edges = 0, n_culled = 0, lm_iters = 0; double chi0 = 0, chi1 = 0; } solved, staged;      // solved: between _solve and _merge; staged: _merge's copy for _fetch (a back-end thread may be in the next _cut / _solve meanwhile)
 };
 
 extern "C" {
@@ -415,16 +417,20 @@ int vo_local_ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int n
     return VO_OK;
 }
 int vo_local_ba_resident_solve(vo_ctx* c, int it_robust, int it_plain, vo_ba_resident_result* out) {
-    if (!c || !out || !c->pend.ready || !out->poses || !out->point_slots || !out->points || !out->culled_obs) return VO_E_INVALID;
+    if (!c || !out || !c->pend.ready || !out->culled_obs) return VO_E_INVALID;
+    const bool deferred = !out->poses && !out->points && !out->point_slots;       // vo_local_ba_resident_merge / _fetch follow
+    if (!deferred && (!out->poses || !out->points || !out->point_slots)) return VO_E_INVALID;
     auto& P = c->pend;
-    P.ready = false;
+    P.ready = false; c->solved.ready = false;
     const int n_free = P.n_free, np = (int)P.pose_kf.size(), nx = (int)P.point_slots.size(), ne = (int)P.edge_pose.size();
     out->n_points = nx; out->n_fixed = np - n_free; out->n_edges = ne; out->n_culled = 0; out->chi2_initial = out->chi2_final = 0; out->lm_iters = 0;
-    if (nx > out->cap_points) return VO_E_OVERFLOW;
-    if (nx == 0 || ne == 0 || n_free == 0) return VO_OK;
+    if (!deferred && nx > out->cap_points) return VO_E_OVERFLOW;
+    auto& S = c->solved;
+    S.merged = false; S.poses.clear(); S.pts.clear(); S.slots.clear(); S.pose_kf.clear(); S.culled.clear(); S.n_fixed = np - n_free; S.n_edges = ne; S.n_culled = 0; S.lm_iters = 0; S.chi0 = S.chi1 = 0;
+    if (nx == 0 || ne == 0 || n_free == 0) { S.ready = true; return VO_OK; }
     std::vector<double> po(12 * (size_t)std::max(n_free, 1)), xo(3 * (size_t)std::max(nx, 1));
     std::vector<uint8_t> fl(std::max(ne, 1));
-    for (int k = 0; k < nx; ++k) out->point_slots[k] = P.point_slots[k];
+    if (!deferred) for (int k = 0; k < nx; ++k) out->point_slots[k] = P.point_slots[k];
     vo_ba_problem pr;
     pr.n_poses = np; pr.n_free = n_free; pr.n_points = nx; pr.n_edges = ne; pr.poses = P.poses.data(); pr.points = P.pts.data();
     pr.edge_pose = P.edge_pose.data(); pr.edge_point = P.edge_point.data(); pr.edge_uv = P.edge_uv.data();
@@ -434,12 +440,39 @@ int vo_local_ba_resident_solve(vo_ctx* c, int it_robust, int it_plain, vo_ba_res
     r.poses = po.data(); r.points = xo.data(); r.edge_flags = fl.data();
     int rc = vo_local_ba(c, &pr, &r);
     if (rc) return rc;
-    std::memcpy(out->poses, po.data(), 96 * (size_t)n_free);
-    std::memcpy(out->points, xo.data(), 24 * (size_t)nx);
-    for (int e = 0; e < ne; ++e) if (fl[e] & 3) { if (out->n_culled < out->cap_culled) out->culled_obs[out->n_culled] = P.edge_obs[e]; ++out->n_culled; }
+    if (!deferred) { std::memcpy(out->poses, po.data(), 96 * (size_t)n_free); std::memcpy(out->points, xo.data(), 24 * (size_t)nx); }
+    for (int e = 0; e < ne; ++e) if (fl[e] & 3) { if (out->n_culled < out->cap_culled) out->culled_obs[out->n_culled] = P.edge_obs[e]; ++out->n_culled; S.culled.push_back(P.edge_obs[e]); }
     std::sort(out->culled_obs, out->culled_obs + std::min(out->n_culled, out->cap_culled));
     out->chi2_initial = r.chi2_initial; out->chi2_final = r.chi2_final; out->lm_iters = r.lm_iters;
+    po.resize(12 * (size_t)n_free); xo.resize(3 * (size_t)nx);
+    S.poses = po; S.pts = xo; S.slots = P.point_slots; S.pose_kf.assign(P.pose_kf.begin(), P.pose_kf.begin() + n_free);
+    S.n_culled = out->n_culled; S.lm_iters = r.lm_iters; S.chi0 = r.chi2_initial; S.chi1 = r.chi2_final; S.ready = true;
     return out->n_culled > out->cap_culled ? VO_E_OVERFLOW : VO_OK;
+}
+// the write-back of reference src/backend.cpp:183-194 on the tables' side: positions of the non-outlier points, free poses, culled observations
+int vo_local_ba_resident_merge(vo_ctx* c, vo_ctx* t) {
+    if (!c || !t || !c->solved.ready || c->solved.merged) return VO_E_STATE;
+    auto& S = c->solved;
+    for (size_t k = 0; k < S.slots.size(); ++k) {
+        const size_t slot = (size_t)S.slots[k];
+        if (t->map.flags[slot] & VO_MAP_FLAG_OUTLIER) continue;
+        std::memcpy(&t->map.pos[3 * slot], &S.pts[3 * k], 24);
+    }
+    for (size_t p = 0; p < S.pose_kf.size(); ++p) std::memcpy(&t->kf_pose[12 * (size_t)S.pose_kf[p]], &S.poses[12 * p], 96);
+    for (int64_t id : S.culled) t->obs_alive[(size_t)id] = 0;
+    S.merged = true;
+    c->staged = S;
+    return VO_OK;
+}
+int vo_local_ba_resident_fetch(vo_ctx* c, vo_ba_resident_result* out) {
+    if (!c || !out || !c->staged.merged || !out->poses || !out->points || !out->point_slots) return VO_E_STATE;
+    auto& S = c->staged;
+    const int nx = (int)S.slots.size();
+    out->n_points = nx; out->n_fixed = S.n_fixed; out->n_edges = S.n_edges; out->n_culled = S.n_culled; out->chi2_initial = S.chi0; out->chi2_final = S.chi1; out->lm_iters = S.lm_iters;
+    if (nx > out->cap_points) return VO_E_OVERFLOW;
+    if (!S.poses.empty()) std::memcpy(out->poses, S.poses.data(), 8 * S.poses.size());
+    if (nx) { std::memcpy(out->points, S.pts.data(), 24 * (size_t)nx); std::memcpy(out->point_slots, S.slots.data(), 4 * (size_t)nx); }
+    return VO_OK;
 }
 int vo_local_ba_resident(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int n_free, double huber_delta, double chi2_th, int it_robust, int it_plain,
                          vo_ba_resident_result* out) {

@@ -71,7 +71,7 @@ SYMBOLS = ["vo_ctx_create", "vo_ctx_destroy", "vo_strerror", "vo_backend_name", 
            "vo_local_ba", "vo_sync", "vo_profile_enable", "vo_profile_read",
            "vo_group_create", "vo_group_destroy", "vo_group_join", "vo_group_leave", "vo_group_set_gather", "vo_group_stats",
            "vo_set_hypothesis_shard", "vo_set_hypothesis_shard_stream", "vo_triangulate_batch", "vo_kf_set_pose", "vo_obs_append", "vo_obs_kill", "vo_local_ba_resident",
-           "vo_local_ba_resident_cut", "vo_local_ba_resident_solve", "vo_ba_resident_graph"]
+           "vo_local_ba_resident_cut", "vo_local_ba_resident_solve", "vo_local_ba_resident_merge", "vo_local_ba_resident_fetch", "vo_ba_resident_graph"]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int32), C.c_int)     # vo_exchange_fn: in-place element-wise sum over the ranks
@@ -135,6 +135,8 @@ class VoLib:
         L.vo_local_ba_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(VoBaResidentResult)]
         L.vo_local_ba_resident_cut.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.vo_local_ba_resident_solve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(VoBaResidentResult)]
+        L.vo_local_ba_resident_merge.argtypes = [C.c_void_p, C.c_void_p]
+        L.vo_local_ba_resident_fetch.argtypes = [C.c_void_p, C.POINTER(VoBaResidentResult)]
         L.vo_ba_resident_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_void_p, C.c_int,
                                            C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.vo_triangulate_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -414,6 +416,21 @@ class VoContext:
         r = VoBaResidentResult(_ptr(po).value, _ptr(sl).value, _ptr(pt).value, _ptr(cu).value, cap_points, cap_culled)
         self.L.check(self.L.lib.vo_local_ba_resident(self.h, tables.h, _ptr(f), len(f), huber_delta, chi2_th, it_robust, it_plain, C.byref(r)), "vo_local_ba_resident")
         return po[:len(f)], sl[:r.n_points].copy(), pt[:r.n_points].copy(), cu[:r.n_culled].copy(), r
+
+    def local_ba_resident_merged(self, tables: "VoContext", free_kf, huber_delta=7.815 ** 0.5, chi2_th=1.0, it_robust=10, it_plain=10, cap_points=1 << 18, cap_culled=1 << 16):
+        """The back-end's sequence: cut, solve with the result left on the device, merge into `tables` on the device, fetch the host's copy."""
+        f = np.ascontiguousarray(free_kf, dtype=np.int32)
+        nx, nfx, ne = C.c_int32(), C.c_int32(), C.c_int32()
+        self.L.check(self.L.lib.vo_local_ba_resident_cut(self.h, tables.h, _ptr(f), len(f), huber_delta, chi2_th, C.byref(nx), C.byref(nfx), C.byref(ne)), "vo_local_ba_resident_cut")
+        cu = np.zeros(cap_culled, np.int64)
+        r = VoBaResidentResult(None, None, None, _ptr(cu).value, 0, cap_culled)
+        self.L.check(self.L.lib.vo_local_ba_resident_solve(self.h, it_robust, it_plain, C.byref(r)), "vo_local_ba_resident_solve")
+        n_culled = r.n_culled
+        self.L.check(self.L.lib.vo_local_ba_resident_merge(self.h, tables.h), "vo_local_ba_resident_merge")
+        po = np.zeros((max(len(f), 1), 12)); sl = np.zeros(cap_points, np.int32); pt = np.zeros((cap_points, 3))
+        r2 = VoBaResidentResult(_ptr(po).value, _ptr(sl).value, _ptr(pt).value, _ptr(cu).value, cap_points, cap_culled)
+        self.L.check(self.L.lib.vo_local_ba_resident_fetch(self.h, C.byref(r2)), "vo_local_ba_resident_fetch")
+        return po[:len(f)], sl[:r2.n_points].copy(), pt[:r2.n_points].copy(), cu[:n_culled].copy(), r2
 
     def sync(self):
         self.L.check(self.L.lib.vo_sync(self.h), "vo_sync")

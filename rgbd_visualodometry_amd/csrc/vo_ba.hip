@@ -40,13 +40,22 @@ struct BaCtl {
     double lambda, ni, cur;
     int it, qmax, max_it, need_lin, first, finished, buf, iters_done, steps, arrived;
     int robust, lbuf;                // Huber kernel on (round 1) / off (round 2): backend.cpp:138-160; lbuf: which record / weight buffer holds the current linearisation (vo_ba_phase2.h)
+    // the rounds of one local BA (k_ba_admit / k_ba_round): the device moves from the robust round to the plain one and on to "done" by itself
+    int stage;                       // 0: robust round, 1: plain round, 2: done (final cull made, BaStat written)
+    int max_it_next;                 // iterations of the plain round
+    int iters_total, ticket, gen, pad_;
+    double chi0;                     // plain chi2 of the initial state (reporting)
 };
+
+// What the host needs to know about a slot, written by k_ba_round straight into pinned host memory (no read-back copy per chunk of steps)
+struct BaStat { int gen, stage, finished, it, buf, iters_total, steps, pad_; double chi0, chi_final; };
 
 struct BaDev {
     int n_poses, n_free, n_points, n_edges, D, n_blocks;
     int gp;                                                  // point workgroups of the 4-lanes-per-point kernels (64 points each)
     int edges_by_point;                                      // 1: the edges are grouped by point, pt_edges is the identity
     BaCam cam; double delta, chi2_th;
+    int it_robust, it_plain, gen, pad_;                      // iterations of the two rounds (backend.cpp:141,159); gen: the engine's admission counter (stale status records are told apart by it)
     BaCtl* ctl;
     double* posesA; double* ptsA; double* posesB; double* ptsB;      // double-buffered state, ctl->buf selects the current one
     const int32_t* e_pose; const int32_t* e_pt; const float* e_uv; uint8_t* active; uint8_t* flags;
@@ -66,7 +75,7 @@ struct BaDev {
 #define BA_SLOTS 16
 // ctls: the engine's control blocks, indexed by slot like Bs -- a kernel reads its control block straight from the argument
 // (B.ctl holds the same address, but behind a dependent load of the descriptor: one memory latency more at every kernel start)
-struct BaBatch { const BaDev* Bs; BaCtl* ctls; int n; int slot[BA_SLOTS]; };
+struct BaBatch { const BaDev* Bs; BaCtl* ctls; BaStat* stat; int n; int slot[BA_SLOTS]; };
 #define BA_PROBLEM(Q) const BaDev& B = Q.Bs[Q.slot[blockIdx.z]]; BaCtl* const ctl_ = Q.ctls + Q.slot[blockIdx.z];
 
 #define BA_STATE(B) \
@@ -1298,17 +1307,82 @@ __global__ __launch_bounds__(256) void k_ba_chi_control(BaBatch Q) {
 }
 
 // stage 0: cull after the robust round (bit0, deactivate); stage 1: flag level-0 outliers (bit1)
-__global__ void k_ba_cull(BaBatch Q, int stage) {
-    BA_PROBLEM(Q)
-    const BaCam cam = B.cam; const double th = B.chi2_th;
-    BA_STATE(B)
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= B.n_edges) return;
+__device__ __forceinline__ void ba_cull_edge(const BaDev& B, const double* poses_c, const double* pts_c, int e, int stage) {
     double r[2], pc[3];
-    ba_err(cam, poses_c + 12 * (size_t)B.e_pose[e], pts_c + 3 * (size_t)B.e_pt[e], B.e_uv + 2 * (size_t)e, r, pc);
-    const double c2 = r[0] * r[0] + r[1] * r[1];
+    ba_err(B.cam, poses_c + 12 * (size_t)B.e_pose[e], pts_c + 3 * (size_t)B.e_pt[e], B.e_uv + 2 * (size_t)e, r, pc);
+    const double c2 = r[0] * r[0] + r[1] * r[1], th = B.chi2_th;
     if (stage == 0) { if (c2 > th) { B.flags[e] = 1; B.active[e] = 0; } else B.flags[e] = 0; }
     else if (B.active[e]) { if (c2 > th) B.flags[e] |= 2; else atomicAdd(&B.scal[6], c2); }
+}
+__global__ void k_ba_cull(BaBatch Q, int stage) {           // (the persistent path's host side)
+    BA_PROBLEM(Q)
+    BA_STATE(B)
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < B.n_edges) ba_cull_edge(B, poses_c, pts_c, e, stage);
+}
+
+// A problem enters its slot: control block of the robust round, zeroed accumulators (one workgroup; the plain chi2 of the
+// initial state follows in k_ba_chi).  The descriptor (BaDev) is the only thing the host uploads.
+__global__ __launch_bounds__(256) void k_ba_admit(BaBatch Q) {
+    BA_PROBLEM(Q)
+    if (threadIdx.x == 0) {
+        BaCtl c;
+        memset(&c, 0, sizeof(c));
+        c.max_it = B.it_robust; c.max_it_next = B.it_plain; c.need_lin = 1; c.first = 1; c.ni = 2; c.robust = 1; c.finished = B.it_robust <= 0 ? 1 : 0; c.gen = B.gen;
+        *ctl_ = c;
+    }
+    if (threadIdx.x < 8) B.scal[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < 36 * B.n_free; i += 256) B.Hpp[i] = 0;
+    for (int i = threadIdx.x; i < B.D; i += 256) B.bp[i] = 0;
+}
+
+// End of a chunk of LM steps: a slot whose round has ended is culled (backend.cpp:144-156 after the robust round, :162-172 after
+// the plain one) and moved on -- to the plain round (control block reset, accumulators zeroed: the next launches linearise it
+// afresh) or to "done" -- by the last of its workgroups; every slot's state goes to the host's status record.  The host
+// neither waits for a round to end nor enqueues anything in between: it reads the records when the chunk's event has passed.
+__global__ __launch_bounds__(256) void k_ba_round(BaBatch Q) {
+    BA_PROBLEM(Q)
+    BaStat* const st = Q.stat + Q.slot[blockIdx.z];
+    const int stage = ctl_->stage;
+    if (stage >= 2) return;
+    if (!ctl_->finished) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { st->stage = stage; st->finished = 0; st->it = ctl_->it; st->steps = ctl_->steps; st->gen = ctl_->gen; }
+        return;
+    }
+    const int nblk = (B.n_edges + 255) / 256;
+    if ((int)blockIdx.x >= nblk) return;
+    BA_STATE(B)
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < B.n_edges) ba_cull_edge(B, poses_c, pts_c, e, stage);
+    __shared__ int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) { __threadfence(); s_last = atomicAdd(&ctl_->ticket, 1) == nblk - 1; }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (stage == 0) {
+        if (threadIdx.x < 8 && threadIdx.x != 5) B.scal[threadIdx.x] = 0;       // [5]: the initial chi2 (k_ba_chi at admission)
+        for (int i = threadIdx.x; i < 36 * B.n_free; i += 256) B.Hpp[i] = 0;
+        for (int i = threadIdx.x; i < B.D; i += 256) B.bp[i] = 0;
+    }
+    if (threadIdx.x == 0) {
+        BaCtl* c = ctl_;
+        c->ticket = 0;
+        c->iters_total += c->iters_done;
+        if (stage == 0) {
+            c->chi0 = ((const volatile double*)B.scal)[5];
+            c->lambda = 0; c->ni = 2; c->cur = 0; c->it = 0; c->qmax = 0; c->max_it = c->max_it_next; c->need_lin = 1; c->first = 1; c->iters_done = 0; c->steps = 0;
+            c->arrived = 0; c->robust = 0; c->lbuf = 0; c->finished = c->max_it_next <= 0 ? 1 : 0;
+            c->stage = 1;
+            st->stage = 1; st->finished = c->finished; st->it = 0; st->steps = 0; st->gen = c->gen;
+        } else {
+            c->stage = 2;
+            st->chi0 = c->chi0; st->chi_final = __hip_atomic_load(&B.scal[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            st->buf = c->buf; st->iters_total = c->iters_total; st->finished = 1; st->it = c->it; st->steps = c->steps; st->gen = c->gen;
+            __threadfence_system();
+            st->stage = 2;
+        }
+    }
 }
 
 #include "vo_ba_persist.h"
@@ -1340,20 +1414,24 @@ struct BaJob {
     vo_ctx* c = nullptr; const vo_ba_problem* in = nullptr; vo_ba_result* out = nullptr;
     BaDev B;
     int grid_lin = 0, grid_initS = 0, grid_upd = 0, grid_e = 0, grid_c = 0, grid_maxdiag = 0; size_t lds = 0;
-    int round = 0, cur_buf = 0, iters = 0, steps = 0, need_first = 0;
+    int cur_buf = 0, iters = 0, steps = 0;
+    int est_stage = 0, est_left = 0;                        // the host's estimate of where the device is (chunk sizes only: the device moves on by itself)
     double chi0 = 0, chi_final = 0;
     int rc = VO_OK; bool done = false;
     hipEvent_t wait_ev = nullptr;                           // the problem's arrays are complete once this event (recorded on the owner's stream) has passed
 };
+// one enqueued chunk of LM steps: the slots it covers (with their admission numbers) and two events -- before its last step and behind it
+struct BaChunk { hipEvent_t ev_near = nullptr, ev_end = nullptr; int n = 0, steps = 0; int sl[BA_SLOTS]; int gen[BA_SLOTS]; };
 #define BA_MAX_ENGINES 4
 struct BaEngine {
     int device = 0, refs = 0;
     hipStream_t st = nullptr;
     BaDev* d_Bs = nullptr; BaDev* h_Bs = nullptr;           // [BA_SLOTS] problem descriptors: device / pinned mirror
-    BaCtl* d_ctl = nullptr; BaCtl* h_ctl = nullptr;         // [BA_SLOTS] control blocks: device / pinned read-back
-    BaCtl* h_up = nullptr;                                  // [BA_SLOTS] pinned staging of control-block uploads
-    double* h_mail = nullptr;                               // [BA_SLOTS][16] pinned: initial chi2, final scal
+    BaCtl* d_ctl = nullptr;                                 // [BA_SLOTS] control blocks (device only: k_ba_admit / k_ba_round write them)
+    BaStat* h_stat = nullptr;                               // [BA_SLOTS] pinned status records, written by k_ba_round
     BaJob* slot[BA_SLOTS] = {};
+    int slot_gen[BA_SLOTS] = {}; int gen_ctr = 0;
+    BaChunk ring[2]; int r_head = 0, r_n = 0;               // chunks in flight (oldest first)
     std::mutex mu; std::condition_variable cv;
     std::deque<BaJob*> pending;
     bool driving = false;                                   // a caller is inside ba_engine_pump
@@ -1366,92 +1444,94 @@ static std::mutex g_eng_mu;
 static std::vector<BaEngine*> g_engines;
 
 static BaBatch ba_batch_of(BaEngine* E, const int* slots, int n) {
-    BaBatch Q; Q.Bs = E->d_Bs; Q.ctls = E->d_ctl; Q.n = n;
+    BaBatch Q; Q.Bs = E->d_Bs; Q.ctls = E->d_ctl; Q.stat = E->h_stat; Q.n = n;
     for (int i = 0; i < BA_SLOTS; ++i) Q.slot[i] = i < n ? slots[i] : 0;
     return Q;
 }
 
-// start a round of LM iterations for the problem in slot s (stream order: after everything enqueued so far)
-static int ba_start_round(BaEngine* E, int s, int robust) {
-    BaJob* j = E->slot[s];
-    const int max_it = robust ? j->in->it_robust : j->in->it_plain;
-    BaCtl* h = E->h_up + s;
-    memset(h, 0, sizeof(BaCtl));
-    h->max_it = max_it; h->need_lin = 1; h->first = 1; h->buf = j->cur_buf; h->ni = 2; h->robust = robust;
-    if (max_it <= 0) h->finished = 1;
-    HIP_TRY(hipMemcpyAsync(E->d_ctl + s, h, sizeof(BaCtl), hipMemcpyHostToDevice, E->st));
-    HIP_TRY(hipMemsetAsync(j->B.scal, 0, 64, E->st));
-    HIP_TRY(hipMemsetAsync(j->B.Hpp, 0, sizeof(double) * 36 * (size_t)j->B.n_free, E->st));
-    HIP_TRY(hipMemsetAsync(j->B.bp, 0, sizeof(double) * (size_t)j->B.D, E->st));
-    j->round = robust ? 0 : 1; j->steps = 0; j->need_first = 1;
+// admit queued problems into free slots (stream order: behind everything enqueued so far).  The descriptor is the only upload:
+// k_ba_admit writes the control block of the robust round (backend.cpp:140-141) and clears the accumulators, k_ba_chi leaves the
+// plain chi2 of the initial state in scal[5] (reporting only)
+static int ba_engine_admit(BaEngine* E) {
+    hipStream_t st = E->st;
+    std::unique_lock<std::mutex> lk(E->mu);
+    for (int s = 0; s < BA_SLOTS && !E->pending.empty(); ++s) {
+        if (E->slot[s]) continue;
+        BaJob* j = E->pending.front(); E->pending.pop_front();
+        E->slot[s] = j; j->B.ctl = E->d_ctl + s; j->cur_buf = 0; j->iters = 0; j->steps = 0;
+        j->B.it_robust = j->in->it_robust; j->B.it_plain = j->in->it_plain; j->B.gen = E->slot_gen[s] = ++E->gen_ctr;
+        j->est_stage = 0; j->est_left = std::max(1, j->in->it_robust);
+        lk.unlock();
+        int rc = VO_OK;
+        if (j->wait_ev && hipStreamWaitEvent(st, j->wait_ev, 0) != hipSuccess) rc = VO_E_DEVICE;
+        E->h_Bs[s] = j->B;                                  // the slot's mirror is free: its previous problem is gone
+        if (rc == VO_OK && hipMemcpyAsync(E->d_Bs + s, E->h_Bs + s, sizeof(BaDev), hipMemcpyHostToDevice, st) != hipSuccess) rc = VO_E_DEVICE;
+        if (rc == VO_OK) {
+            const BaBatch Q = ba_batch_of(E, &s, 1);
+            hipLaunchKernelGGL(k_ba_admit, dim3(1, 1, 1), dim3(256), 0, st, Q);
+            hipLaunchKernelGGL(k_ba_chi, dim3(j->grid_e, 1, 1), dim3(256), 0, st, Q, 0, 0, 0);
+        }
+        lk.lock();
+        if (rc != VO_OK) { j->rc = rc; j->done = true; E->slot[s] = nullptr; E->cv.notify_all(); }
+        else ++E->n_jobs;
+    }
+    E->pending_hint = (int)E->pending.size();
     return VO_OK;
 }
 
-static int ba_engine_pump(BaEngine* E) {                    // engine thread; returns after one chunk of steps (or when idle)
+static bool ba_engine_wants_steps(const BaEngine* E) {
+    for (int s = 0; s < BA_SLOTS; ++s) if (E->slot[s] && E->slot[s]->est_stage < 2) return true;
+    return false;
+}
+
+// One chunk of LM steps over every active slot, enqueued without waiting for anything: [first linearisation of a round, for the
+// slots that are at one] K x [Schur, Cholesky, update + chi2 + control] [k_ba_round: round transitions, status records].  Systems the
+// LDS-resident Cholesky solves (D <= 192) take the second-generation phases (vo_ba_phase2.h: three launches per step), larger
+// ones the first generation (its Schur kernel writes the full matrix k_ba_chol16g reads).
+static int ba_engine_enqueue(BaEngine* E) {
     hipStream_t st = E->st;
-    // ---- admit queued problems into free slots
-    {
-        std::unique_lock<std::mutex> lk(E->mu);
-        for (int s = 0; s < BA_SLOTS && !E->pending.empty(); ++s) {
-            if (E->slot[s]) continue;
-            BaJob* j = E->pending.front(); E->pending.pop_front();
-            E->slot[s] = j; j->B.ctl = E->d_ctl + s; j->cur_buf = 0; j->iters = 0;
-            lk.unlock();
-            int rc = VO_OK;
-            if (j->wait_ev && hipStreamWaitEvent(st, j->wait_ev, 0) != hipSuccess) rc = VO_E_DEVICE;
-            E->h_Bs[s] = j->B;                              // the slot's mirror is free: its previous problem is gone
-            if (rc == VO_OK && hipMemcpyAsync(E->d_Bs + s, E->h_Bs + s, sizeof(BaDev), hipMemcpyHostToDevice, st) != hipSuccess) rc = VO_E_DEVICE;
-            if (rc == VO_OK) rc = ba_start_round(E, s, 1);                                  // backend.cpp:140-141
-            if (rc == VO_OK) {                              // initial plain chi2 (reporting only)
-                const BaBatch Q = ba_batch_of(E, &s, 1);
-                hipLaunchKernelGGL(k_ba_chi, dim3(j->grid_e, 1, 1), dim3(256), 0, st, Q, 0, 0, 0);
-                if (hipMemcpyAsync(E->h_mail + 16 * s, j->B.scal + 5, sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) rc = VO_E_DEVICE;
-            }
-            lk.lock();
-            if (rc != VO_OK) { j->rc = rc; j->done = true; E->slot[s] = nullptr; E->cv.notify_all(); }
-            else ++E->n_jobs;
-        }
-        E->pending_hint = (int)E->pending.size();
-    }
     int act[BA_SLOTS], na = 0;
     for (int s = 0; s < BA_SLOTS; ++s) if (E->slot[s]) act[na++] = s;
-    if (na == 0) return VO_OK;
-    // ---- one chunk of LM steps over every active slot.  Systems the LDS-resident Cholesky solves (D <= 192) take the second-generation
-    // phases (vo_ba_phase2.h: four launches per step), larger ones the first generation.
-    const bool phase2 = true;                               // (the first generation stays for D > 192 only: its Schur kernel writes the full matrix k_ba_chol16g reads)
-    int chunk = (na == 1 && E->pending_hint == 0) ? 16 : 6;
-    int sA[BA_SLOTS], nA = 0, sB[BA_SLOTS], nB = 0, sB16[BA_SLOTS], nB16 = 0, sB16g[BA_SLOTS], nB16g = 0, fA[BA_SLOTS], nfA = 0, fB[BA_SLOTS], nfB = 0;
-    int gA_lin = 0, gA_blk = 0, gA_up = 0, gA_md = 0, gA_pose = 0, gB_lin = 0, gB_init = 0, gB_blk = 0, gB_upd = 0, gB_c = 0, gB_md = 0;
-    size_t ldsA = 0, ldsA_up = 0, ldsB16 = 0, ldsB16g = 0;
+    if (na == 0 || E->r_n >= 2) return VO_OK;
+    // chunk length: to the end of the nearest round (a slot that ends its round idles through the rest of the chunk), short while
+    // other problems may want to join
+    int chunk = (na == 1 && E->pending_hint == 0) ? 16 : 4;
+    int sA[BA_SLOTS], nA = 0, sB[BA_SLOTS], nB = 0;
+    int gA_lin = 0, gA_blk = 0, gA_up = 0, gA_md = 0, gA_pose = 0, gB_lin = 0, gB_init = 0, gB_blk = 0, gB_upd = 0, gB_c = 0, gB_md = 0, g_e = 0;
+    size_t ldsA = 0, ldsA_up = 0, ldsB = 0;
     for (int i = 0; i < na; ++i) {
         BaJob* j = E->slot[act[i]];
-        const BaCtl& h = E->h_ctl[act[i]];                  // last read-back (zeros right after a round started)
-        const int max_it = j->round == 0 ? j->in->it_robust : j->in->it_plain;
-        chunk = std::min(chunk, std::max(2, max_it - (j->steps ? h.it : 0)));
-        if (phase2 && j->B.D <= BA_FOLD_D) {
+        if (j->est_stage < 2) chunk = std::min(chunk, std::max(1, j->est_left));
+        g_e = std::max(g_e, j->grid_e);
+        if (j->B.D <= BA_FOLD_D) {
             sA[nA++] = act[i];
             gA_lin = std::max(gA_lin, j->grid_lin); gA_blk = std::max(gA_blk, j->B.n_blocks); gA_pose = std::max(gA_pose, j->B.n_free * PSPLIT); gA_up = std::max(gA_up, (j->B.n_points + UPC_T / 4 - 1) / (UPC_T / 4));
             ldsA = std::max(ldsA, j->lds); ldsA_up = std::max(ldsA_up, sizeof(double) * (12 * (size_t)j->B.n_poses + (size_t)j->B.D));
-            if (j->need_first) { fA[nfA++] = act[i]; gA_md = std::max(gA_md, (j->B.D + j->B.n_points + 255) / 256); }
+            gA_md = std::max(gA_md, (j->B.D + j->B.n_points + 255) / 256);
         } else {
             sB[nB++] = act[i];
             gB_lin = std::max(gB_lin, j->grid_lin); gB_init = std::max(gB_init, j->grid_initS); gB_blk = std::max(gB_blk, j->B.n_blocks);
-            gB_upd = std::max(gB_upd, j->grid_upd); gB_c = std::max(gB_c, j->grid_c);
-            if (j->B.D <= 192) { sB16[nB16++] = act[i]; ldsB16 = std::max(ldsB16, j->lds); } else { sB16g[nB16g++] = act[i]; ldsB16g = std::max(ldsB16g, j->lds); }
-            if (j->need_first) { fB[nfB++] = act[i]; gB_md = std::max(gB_md, j->grid_maxdiag); }
+            gB_upd = std::max(gB_upd, j->grid_upd); gB_c = std::max(gB_c, j->grid_c); gB_md = std::max(gB_md, j->grid_maxdiag);
+            ldsB = std::max(ldsB, j->lds);
         }
     }
+    BaChunk& C = E->ring[(E->r_head + E->r_n) % 2];
+    if (!C.ev_end) { HIP_TRY(hipEventCreateWithFlags(&C.ev_near, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&C.ev_end, hipEventDisableTiming)); }
+    C.n = na; C.steps = chunk;
+    for (int i = 0; i < na; ++i) { C.sl[i] = act[i]; C.gen[i] = E->slot_gen[act[i]]; }
     vo_ctx* prof = E->slot[act[0]]->c;
-    const BaBatch QA = ba_batch_of(E, sA, nA), QB = ba_batch_of(E, sB, nB);
+    const BaBatch QA = ba_batch_of(E, sA, nA), QB = ba_batch_of(E, sB, nB), QE = ba_batch_of(E, act, na);
     const dim3 blk(256);
+    if (chunk < 2) HIP_TRY(hipEventRecord(C.ev_near, st));
     for (int sidx = 0; sidx < chunk; ++sidx) {
+        if (chunk >= 2 && sidx == chunk - 1) HIP_TRY(hipEventRecord(C.ev_near, st));
         if (nA) {
-            // the first step of a round linearises in a launch of its own (lambda needs the largest diagonal entry first); afterwards the
-            // linearisation at the accepted state is a by-product of k_ba_upchi2 and a step is THREE launches
-            if (sidx == 0 && nfA) {
-                const BaBatch QF = ba_batch_of(E, fA, nfA);
-                { ProfScope ps(prof, "k_ba_lin", st); hipLaunchKernelGGL(k_ba_lin2, dim3(gA_lin, 1, nfA), blk, 0, st, QF); }
-                hipLaunchKernelGGL(k_ba_maxdiag2, dim3(gA_md, 1, nfA), blk, 0, st, QF);
+            // the first step of a round linearises in a launch of its own (lambda_0 needs the largest diagonal entry first; both kernels
+            // leave at once for a slot that is not at the start of a round); afterwards the linearisation at the accepted state is a
+            // by-product of k_ba_upchi2 and a step is THREE launches
+            if (sidx == 0) {
+                { ProfScope ps(prof, "k_ba_lin", st); hipLaunchKernelGGL(k_ba_lin2, dim3(gA_lin, 1, nA), blk, 0, st, QA); }
+                hipLaunchKernelGGL(k_ba_maxdiag2, dim3(gA_md, 1, nA), blk, 0, st, QA);
             }
             { ProfScope ps(prof, "k_ba_schur_blocks", st); hipLaunchKernelGGL(k_ba_schur2, dim3(gA_blk + gA_pose, 1, nA), blk, 0, st, QA); }
             { ProfScope ps(prof, "k_ba_chol", st); hipLaunchKernelGGL(k_ba_chol16, dim3(1, 1, nA), dim3(CH_THREADS), ldsA, st, QA, 0, 1); }
@@ -1459,58 +1539,86 @@ static int ba_engine_pump(BaEngine* E) {                    // engine thread; re
         }
         if (nB) {
             { ProfScope ps(prof, "k_ba_lin", st); hipLaunchKernelGGL(k_ba_lin, dim3(gB_lin, 1, nB), blk, 0, st, QB); }
-            if (sidx == 0 && nfB) hipLaunchKernelGGL(k_ba_maxdiag, dim3(gB_md, 1, nfB), blk, 0, st, ba_batch_of(E, fB, nfB));
-            // systems beyond the LDS-resident Cholesky need it every step, the others only behind k_ba_maxdiag (first step of a round)
-            if (nB16g || (sidx == 0 && nfB)) { ProfScope ps(prof, "k_ba_init_S", st); hipLaunchKernelGGL(k_ba_init_S, dim3(gB_init, 1, nB), blk, 0, st, QB); }
+            if (sidx == 0) hipLaunchKernelGGL(k_ba_maxdiag, dim3(gB_md, 1, nB), blk, 0, st, QB);
+            { ProfScope ps(prof, "k_ba_init_S", st); hipLaunchKernelGGL(k_ba_init_S, dim3(gB_init, 1, nB), blk, 0, st, QB); }
             if (gB_blk) { ProfScope ps(prof, "k_ba_schur_blocks", st); hipLaunchKernelGGL(k_ba_schur_blocks, dim3(gB_blk, 1, nB), blk, 0, st, QB); }
-            { ProfScope ps(prof, "k_ba_chol", st);
-              if (nB16) hipLaunchKernelGGL(k_ba_chol16, dim3(1, 1, nB16), dim3(CH_THREADS), ldsB16, st, ba_batch_of(E, sB16, nB16), 0, 0);
-              if (nB16g) hipLaunchKernelGGL(k_ba_chol16g, dim3(1, 1, nB16g), dim3(CH_THREADS), ldsB16g, st, ba_batch_of(E, sB16g, nB16g)); }
+            { ProfScope ps(prof, "k_ba_chol", st); hipLaunchKernelGGL(k_ba_chol16g, dim3(1, 1, nB), dim3(CH_THREADS), ldsB, st, QB); }
             { ProfScope ps(prof, "k_ba_update", st); hipLaunchKernelGGL(k_ba_update, dim3(gB_upd, 1, nB), blk, 0, st, QB); }
             { ProfScope ps(prof, "k_ba_chi_control", st); hipLaunchKernelGGL(k_ba_chi_control, dim3(gB_c, 1, nB), blk, 0, st, QB); }
         }
     }
+    { ProfScope ps(prof, "k_ba_round", st); hipLaunchKernelGGL(k_ba_round, dim3(g_e, 1, na), blk, 0, st, QE); }
+    HIP_TRY(hipEventRecord(C.ev_end, st));
+    HIP_TRY(hipGetLastError());
+    ++E->r_n;
     E->n_steps += chunk; E->n_slot_steps += (long long)chunk * na;
-    for (int i = 0; i < na; ++i) { BaJob* j = E->slot[act[i]]; j->steps += chunk; j->need_first = 0; }
-    HIP_TRY(hipMemcpyAsync(E->h_ctl, E->d_ctl, sizeof(BaCtl) * BA_SLOTS, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    // ---- round transitions and completions
-    int fin[BA_SLOTS], nfin = 0;
-    for (int i = 0; i < na; ++i) {
-        const int s = act[i];
-        BaJob* j = E->slot[s];
-        const BaCtl& h = E->h_ctl[s];
-        const int max_it = j->round == 0 ? j->in->it_robust : j->in->it_plain;
-        if (!h.finished) {
-            if (j->steps > max_it * 10 + 8) { j->rc = VO_E_DEVICE; fin[nfin++] = s; }      // the control block never reported the end of the round
-            continue;
-        }
-        j->iters += h.iters_done; j->cur_buf = h.buf;
-        const BaBatch Q1 = ba_batch_of(E, &s, 1);
-        if (j->round == 0) {
-            hipLaunchKernelGGL(k_ba_cull, dim3(j->grid_e, 1, 1), blk, 0, st, Q1, 0);       // backend.cpp:144-156
-            int rc = ba_start_round(E, s, 0);                                             // backend.cpp:158-159
-            if (rc != VO_OK) { j->rc = rc; fin[nfin++] = s; }
-            E->h_ctl[s].it = 0;
-        } else {
-            HIP_TRY(hipMemsetAsync(j->B.scal, 0, 64, st));
-            hipLaunchKernelGGL(k_ba_cull, dim3(j->grid_e, 1, 1), blk, 0, st, Q1, 1);       // backend.cpp:162-172
-            HIP_TRY(hipMemcpyAsync(E->h_mail + 16 * s + 8, j->B.scal, 64, hipMemcpyDeviceToHost, st));
-            fin[nfin++] = s;
+    for (int i = 0; i < na; ++i) {                          // where the device will be behind this chunk if every step is accepted
+        BaJob* j = E->slot[act[i]];
+        j->steps += chunk;
+        if (j->est_stage >= 2) continue;
+        j->est_left -= chunk;
+        if (j->est_left <= 0) {
+            j->est_stage += 1; j->est_left = std::max(1, j->in->it_plain);
+            if (j->est_stage == 1 && j->in->it_plain <= 0) j->est_left = 1;      // the plain round ends at once; its transition comes with the next chunk
         }
     }
-    if (nfin) {
-        HIP_TRY(hipStreamSynchronize(st));                  // final culls and their read-backs
-        HIP_TRY(hipGetLastError());
-        std::unique_lock<std::mutex> lk(E->mu);
-        for (int i = 0; i < nfin; ++i) {
-            BaJob* j = E->slot[fin[i]];
-            j->chi0 = E->h_mail[16 * fin[i]]; j->chi_final = E->h_mail[16 * fin[i] + 8 + 6];
-            j->done = true; E->slot[fin[i]] = nullptr;
+    return VO_OK;
+}
+
+// the oldest chunk has passed: completions, and -- when nothing newer is in flight -- the estimates are set from the device's state
+static int ba_engine_retire(BaEngine* E) {
+    BaChunk& C = E->ring[E->r_head];
+    HIP_TRY(hipEventSynchronize(C.ev_end));
+    E->r_head = (E->r_head + 1) % 2; --E->r_n;
+    int fin[BA_SLOTS], nfin = 0, stuck = 0;
+    for (int i = 0; i < C.n; ++i) {
+        const int s = C.sl[i];
+        BaJob* j = E->slot[s];
+        if (!j || E->slot_gen[s] != C.gen[i]) continue;     // the slot has changed hands since
+        const volatile BaStat* t = E->h_stat + s;
+        if (t->gen != C.gen[i]) continue;
+        if (t->stage == 2) {
+            j->iters = t->iters_total; j->cur_buf = t->buf; j->chi0 = t->chi0; j->chi_final = t->chi_final;
+            fin[nfin++] = s;
+            continue;
         }
+        if (E->r_n == 0) {
+            const int max_it = t->stage == 0 ? j->in->it_robust : j->in->it_plain;
+            j->est_stage = t->stage; j->est_left = t->finished ? 1 : std::max(1, max_it - t->it);
+        }
+        if (j->steps > (j->in->it_robust + j->in->it_plain) * 10 + 64) { j->rc = VO_E_DEVICE; fin[nfin++] = s; stuck = 1; }      // the control block never reported the end
+    }
+    if (nfin) {
+        if (stuck) (void)hipStreamSynchronize(E->st);      // nothing enqueued may touch a slab its owner is about to reuse
+        std::unique_lock<std::mutex> lk(E->mu);
+        for (int i = 0; i < nfin; ++i) { E->slot[fin[i]]->done = true; E->slot[fin[i]] = nullptr; }
         E->cv.notify_all();
     }
     return VO_OK;
+}
+
+// engine thread (whichever caller drives): one turn = keep a chunk enqueued ahead of the one in flight, retire the oldest
+static int ba_engine_pump(BaEngine* E) {
+    int rc = ba_engine_admit(E);
+    if (rc) return rc;
+    if (E->r_n == 0) {
+        int na = 0;
+        for (int s = 0; s < BA_SLOTS; ++s) if (E->slot[s]) { ++na; if (E->slot[s]->est_stage >= 2) { E->slot[s]->est_stage = 1; E->slot[s]->est_left = 1; } }   // not done after all: keep stepping
+        if (na == 0) return VO_OK;
+        return ba_engine_enqueue(E);
+    }
+    if (E->r_n == 1 && ba_engine_wants_steps(E)) {
+        // With several problems in flight the next chunk is put together as late as possible -- when the one in flight starts its last
+        // step -- so that a problem that arrives meanwhile joins after at most one chunk; a lone problem is enqueued ahead at once.
+        int na = 0;
+        for (int s = 0; s < BA_SLOTS; ++s) if (E->slot[s]) ++na;
+        if (na > 1 || E->pending_hint > 0) {
+            HIP_TRY(hipEventSynchronize(E->ring[E->r_head].ev_near));
+            if ((rc = ba_engine_admit(E))) return rc;
+        }
+        if ((rc = ba_engine_enqueue(E))) return rc;
+    }
+    return ba_engine_retire(E);
 }
 
 static int ba_engine_solve(BaEngine* E, BaJob* j) {
@@ -1525,6 +1633,7 @@ static int ba_engine_solve(BaEngine* E, BaJob* j) {
             lk.lock();
             if (rc != VO_OK) {                              // a HIP error: fail everything in flight -- once the engine's stream has drained (the owners may free their slabs at once)
                 (void)hipStreamSynchronize(E->st);
+                E->r_n = 0; E->r_head = 0;
                 for (int s = 0; s < BA_SLOTS; ++s) if (E->slot[s]) { E->slot[s]->rc = rc; E->slot[s]->done = true; E->slot[s] = nullptr; }
                 while (!E->pending.empty()) { E->pending.front()->rc = rc; E->pending.front()->done = true; E->pending.pop_front(); }
             }
@@ -1544,13 +1653,13 @@ static BaEngine* ba_engine_new(int device) {
     bool ok = hipStreamCreateWithPriority(&E->st, hipStreamNonBlocking, hi) == hipSuccess;
     ok = ok && hipMalloc((void**)&E->d_Bs, sizeof(BaDev) * BA_SLOTS) == hipSuccess && hipMalloc((void**)&E->d_ctl, sizeof(BaCtl) * BA_SLOTS) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&E->h_Bs, sizeof(BaDev) * BA_SLOTS, hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc((void**)&E->h_ctl, sizeof(BaCtl) * BA_SLOTS, hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc((void**)&E->h_up, sizeof(BaCtl) * BA_SLOTS, hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc((void**)&E->h_mail, sizeof(double) * 16 * BA_SLOTS, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&E->h_stat, sizeof(BaStat) * BA_SLOTS, hipHostMallocDefault) == hipSuccess;
     if (ok) {
-        memset(E->h_ctl, 0, sizeof(BaCtl) * BA_SLOTS);
-        for (int s = 0; s < BA_SLOTS; ++s) E->h_ctl[s].finished = 1;
-        ok = hipMemcpy(E->d_ctl, E->h_ctl, sizeof(BaCtl) * BA_SLOTS, hipMemcpyHostToDevice) == hipSuccess;
+        memset(E->h_stat, 0, sizeof(BaStat) * BA_SLOTS);
+        std::vector<BaCtl> z(BA_SLOTS);
+        memset(z.data(), 0, sizeof(BaCtl) * BA_SLOTS);
+        for (int s = 0; s < BA_SLOTS; ++s) { z[s].finished = 1; z[s].stage = 2; }
+        ok = hipMemcpy(E->d_ctl, z.data(), sizeof(BaCtl) * BA_SLOTS, hipMemcpyHostToDevice) == hipSuccess;
     }
     if (!ok) { fprintf(stderr, "[vo_hip] BA engine: allocation failed on device %d\n", device); ba_engine_free(E); return nullptr; }
     return E;
@@ -1588,9 +1697,8 @@ static void ba_engine_free(BaEngine* E) {
     if (E->d_Bs) (void)hipFree(E->d_Bs);
     if (E->d_ctl) (void)hipFree(E->d_ctl);
     if (E->h_Bs) (void)hipHostFree(E->h_Bs);
-    if (E->h_ctl) (void)hipHostFree(E->h_ctl);
-    if (E->h_up) (void)hipHostFree(E->h_up);
-    if (E->h_mail) (void)hipHostFree(E->h_mail);
+    if (E->h_stat) (void)hipHostFree(E->h_stat);
+    for (BaChunk& C : E->ring) { if (C.ev_near) (void)hipEventDestroy(C.ev_near); if (C.ev_end) (void)hipEventDestroy(C.ev_end); }
     delete E;
 }
 
@@ -2145,8 +2253,38 @@ struct BaResident {
     BaDev B;
     int32_t* d_point_slots = nullptr; int* d_pose_kf = nullptr; long long* d_e_obs = nullptr; int* d_ncull = nullptr; long long* d_cull = nullptr; int cull_cap = 0;
     hipEvent_t ev = nullptr;                                // recorded behind the pair-plan kernels: the engine's stream waits for it
+    // the last solve, until the next cut: where its result lies (vo_local_ba_resident_merge / _fetch)
+    // (a back-end thread writes the first line in _cut / _solve; the caller's thread runs _merge while that thread idles and _fetch
+    // beside its next _cut: _fetch reads only what _merge copied into the st_* fields)
+    bool solved = false; int solve_seq = 0, cur_buf = 0, n_culled = 0; double chi0 = 0, chi_final = 0; int lm_iters = 0;
+    void* d_stage = nullptr; size_t stage_bytes = 0;        // merged result, out of the slab the next cut reuses: [poses nf x 12][points nx x 3][slots nx]
+    bool has_stage = false; int merged_seq = 0, st_nf = 0, st_nx = 0, st_ne = 0, st_fixed = 0, st_culled = 0, st_iters = 0; double st_chi0 = 0, st_chi1 = 0;
+    hipStream_t merge_stream = nullptr; hipEvent_t ev_merge = nullptr;
 };
-void vo_ba_resident_free(vo_ctx* c) { if (c->resident && c->resident->ev) (void)hipEventDestroy(c->resident->ev); delete c->resident; c->resident = nullptr; }
+void vo_ba_resident_free(vo_ctx* c) {
+    if (c->resident) {
+        if (c->resident->ev) (void)hipEventDestroy(c->resident->ev);
+        if (c->resident->ev_merge) (void)hipEventDestroy(c->resident->ev_merge);
+        if (c->resident->d_stage) (void)hipFree(c->resident->d_stage);
+    }
+    delete c->resident; c->resident = nullptr;
+}
+
+// merge of a solved graph into the tracker's tables (vo_local_ba_resident_merge): what vo_map_upsert (positions only), vo_kf_set_pose and
+// vo_obs_kill do from host arrays, straight from the solve's buffers; the same values also go to a staging buffer for the host's copy
+__global__ void k_ba_merge(int nf, int nx, const double* __restrict__ poses, const double* __restrict__ pts, const int* __restrict__ pose_kf, const int32_t* __restrict__ point_slots,
+                           const int* __restrict__ n_cull, const long long* __restrict__ cull, int cull_cap, double* __restrict__ map_pos, const uint8_t* __restrict__ map_flags,
+                           double* __restrict__ kf_pose, uint8_t* __restrict__ obs_alive, double* __restrict__ st_poses, double* __restrict__ st_pts, int32_t* __restrict__ st_slots) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nx) {
+        const int slot = point_slots[i];
+        const double x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
+        st_pts[3 * (size_t)i] = x; st_pts[3 * (size_t)i + 1] = y; st_pts[3 * (size_t)i + 2] = z; st_slots[i] = slot;
+        if (!(map_flags[slot] & VO_MAP_FLAG_OUTLIER)) { map_pos[3 * (size_t)slot] = x; map_pos[3 * (size_t)slot + 1] = y; map_pos[3 * (size_t)slot + 2] = z; }
+    }
+    if (i < 12 * nf) { const double v = poses[i]; st_poses[i] = v; kf_pose[12 * (size_t)pose_kf[i / 12] + i % 12] = v; }
+    if (i < min(*n_cull, cull_cap)) obs_alive[cull[i]] = 0;
+}
 
 static int scan_i32(hipStream_t st, const int* in, int n, int* bsum, int* out, int* total) {        // n <= 16 Mi
     const int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
@@ -2163,7 +2301,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     if (!t->d_obs_kf || t->n_kf <= 0) return VO_E_STATE;
     if (!c->resident) c->resident = new BaResident();
     BaResident& R = *c->resident;
-    R.ready = false;
+    R.ready = false; R.solved = false;
     const int nkf = t->n_kf, mh = std::max(t->map_hi, 1), D = 6 * nf;
     const long long no = t->n_obs;
     if (mh >= 16 * 1024 * 1024 || nkf > 1024 * 1024) return VO_E_UNSUPPORTED;         // scan_i32's range
@@ -2298,7 +2436,9 @@ extern "C" int vo_local_ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* fre
 }
 
 extern "C" int vo_local_ba_resident_solve(vo_ctx* c, int it_robust, int it_plain, vo_ba_resident_result* out) {
-    if (!c || !out || !c->resident || !c->resident->ready || !out->poses || !out->point_slots || !out->points || !out->culled_obs) return VO_E_INVALID;
+    if (!c || !out || !c->resident || !c->resident->ready || !out->culled_obs) return VO_E_INVALID;
+    const bool deferred = !out->poses && !out->points && !out->point_slots;       // the result stays on the device: vo_local_ba_resident_merge / _fetch
+    if (!deferred && (!out->poses || !out->points || !out->point_slots)) return VO_E_INVALID;
     HIP_TRY(hipSetDevice(c->device));
     BaResident& R = *c->resident;
     hipStream_t st = c->stream;
@@ -2306,7 +2446,7 @@ extern "C" int vo_local_ba_resident_solve(vo_ctx* c, int it_robust, int it_plain
     out->n_points = nx; out->n_fixed = R.n_fixed; out->n_edges = ne; out->n_culled = 0; out->chi2_initial = out->chi2_final = 0; out->lm_iters = 0;
     R.ready = false;
     if (nx == 0 || ne == 0 || nf == 0) return VO_OK;
-    if (nx > out->cap_points) return VO_E_OVERFLOW;
+    if (!deferred && nx > out->cap_points) return VO_E_OVERFLOW;
     vo_ba_problem pr;
     memset(&pr, 0, sizeof(pr));
     pr.n_poses = np; pr.n_free = nf; pr.n_points = nx; pr.n_edges = ne; pr.huber_delta = R.B.delta; pr.chi2_th = R.B.chi2_th; pr.it_robust = it_robust; pr.it_plain = it_plain;
@@ -2330,9 +2470,11 @@ extern "C" int vo_local_ba_resident_solve(vo_ctx* c, int it_robust, int it_plain
     HIP_TRY(hipMemsetAsync(R.d_ncull, 0, 4, st));
     hipLaunchKernelGGL(k_culled_list, dim3((ne + 255) / 256), dim3(256), 0, st, ne, (const uint8_t*)B.flags, (const long long*)R.d_e_obs, R.d_ncull, R.d_cull, R.cull_cap);
     HIP_TRY(hipMemcpyAsync(h, R.d_ncull, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(out->poses, job.cur_buf ? B.posesB : B.posesA, 96 * (size_t)nf, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(out->points, job.cur_buf ? B.ptsB : B.ptsA, 24 * (size_t)nx, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(out->point_slots, R.d_point_slots, 4 * (size_t)nx, hipMemcpyDeviceToHost, st));
+    if (!deferred) {
+        HIP_TRY(hipMemcpyAsync(out->poses, job.cur_buf ? B.posesB : B.posesA, 96 * (size_t)nf, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(out->points, job.cur_buf ? B.ptsB : B.ptsA, 24 * (size_t)nx, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(out->point_slots, R.d_point_slots, 4 * (size_t)nx, hipMemcpyDeviceToHost, st));
+    }
     HIP_TRY(hipStreamSynchronize(st));
     out->n_culled = h[0];
     const int take = std::min(out->n_culled, out->cap_culled);
@@ -2342,8 +2484,58 @@ extern "C" int vo_local_ba_resident_solve(vo_ctx* c, int it_robust, int it_plain
     }
     out->chi2_initial = job.chi0; out->chi2_final = job.chi_final; out->lm_iters = job.iters;
     HIP_TRY(hipGetLastError());
+    R.solved = true; ++R.solve_seq; R.cur_buf = job.cur_buf; R.n_culled = out->n_culled; R.chi0 = job.chi0; R.chi_final = job.chi_final; R.lm_iters = job.iters;
     if (trace) { static double a = 0, b = 0, st = 0; static int n = 0; a += t1 - t0; b += tnow() - t1; st += job.steps; if (++n % 10 == 0) fprintf(stderr, "[vo_trace] resident solve avg ms: optimise %.3f (%.1f step launches) result %.3f (D=%d edges=%d)\n", a / n, st / n, b / n, D, ne); }
     return out->n_culled > out->cap_culled ? VO_E_OVERFLOW : VO_OK;
+}
+
+// The result of the last solve goes into t's tables on the device (t's stream: the tracker's own work is ordered around it; c's
+// stream waits for it, so the next cut of `c` reads merged tables and may reuse the slab) and into c's staging buffer.
+extern "C" int vo_local_ba_resident_merge(vo_ctx* c, vo_ctx* t) {
+    if (!c || !t || c->device != t->device || !c->resident || !c->resident->solved || c->resident->merged_seq == c->resident->solve_seq) return VO_E_STATE;
+    HIP_TRY(hipSetDevice(c->device));
+    BaResident& R = *c->resident;
+    const int nf = R.nf, nx = R.nx;
+    R.st_nf = nf; R.st_nx = nx; R.st_ne = R.ne; R.st_fixed = R.n_fixed; R.st_culled = R.n_culled; R.st_iters = R.lm_iters; R.st_chi0 = R.chi0; R.st_chi1 = R.chi_final;
+    R.merge_stream = t->stream; R.merged_seq = R.solve_seq; R.has_stage = true;
+    if (nx == 0 || R.ne == 0 || nf == 0) return VO_OK;
+    if (!t->d_obs_alive || !t->d_kf_pose || R.n_culled > R.cull_cap) return VO_E_STATE;
+    const size_t o_pts = (96 * (size_t)nf + 255) & ~(size_t)255, o_sl = o_pts + ((24 * (size_t)nx + 255) & ~(size_t)255), total = o_sl + 4 * (size_t)nx;
+    if (total > R.stage_bytes) {
+        if (R.d_stage) { (void)hipStreamSynchronize(t->stream); (void)hipFree(R.d_stage); }
+        R.d_stage = nullptr; R.stage_bytes = 0;
+        if (hipMalloc(&R.d_stage, total + total / 2) != hipSuccess) return VO_E_NOMEM;
+        R.stage_bytes = total + total / 2;
+    }
+    uint8_t* sb = (uint8_t*)R.d_stage;
+    const BaDev& B = R.B;
+    const int n = std::max(std::max(nx, 12 * nf), R.n_culled);
+    hipLaunchKernelGGL(k_ba_merge, dim3((n + 255) / 256), dim3(256), 0, t->stream, nf, nx, (const double*)(R.cur_buf ? B.posesB : B.posesA), (const double*)(R.cur_buf ? B.ptsB : B.ptsA),
+                       (const int*)R.d_pose_kf, (const int32_t*)R.d_point_slots, (const int*)R.d_ncull, (const long long*)R.d_cull, R.cull_cap, t->d_map_pos, (const uint8_t*)t->d_map_flags,
+                       t->d_kf_pose, t->d_obs_alive, (double*)sb, (double*)(sb + o_pts), (int32_t*)(sb + o_sl));
+    if (!R.ev_merge) HIP_TRY(hipEventCreateWithFlags(&R.ev_merge, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(R.ev_merge, t->stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, R.ev_merge, 0));
+    HIP_TRY(hipGetLastError());
+    return VO_OK;
+}
+
+// the host's copy of a merged result (poses, point slots, positions; the culled observations came back with the solve)
+extern "C" int vo_local_ba_resident_fetch(vo_ctx* c, vo_ba_resident_result* out) {
+    if (!c || !out || !c->resident || !c->resident->has_stage || !out->poses || !out->points || !out->point_slots) return VO_E_STATE;
+    HIP_TRY(hipSetDevice(c->device));
+    BaResident& R = *c->resident;
+    const int nf = R.st_nf, nx = R.st_nx;
+    out->n_points = nx; out->n_fixed = R.st_fixed; out->n_edges = R.st_ne; out->n_culled = R.st_culled; out->chi2_initial = R.st_chi0; out->chi2_final = R.st_chi1; out->lm_iters = R.st_iters;
+    if (nx == 0 || R.st_ne == 0 || nf == 0) return VO_OK;
+    if (nx > out->cap_points) return VO_E_OVERFLOW;
+    const size_t o_pts = (96 * (size_t)nf + 255) & ~(size_t)255, o_sl = o_pts + ((24 * (size_t)nx + 255) & ~(size_t)255);
+    const uint8_t* sb = (const uint8_t*)R.d_stage;
+    HIP_TRY(hipMemcpyAsync(out->poses, sb, 96 * (size_t)nf, hipMemcpyDeviceToHost, R.merge_stream));
+    HIP_TRY(hipMemcpyAsync(out->points, sb + o_pts, 24 * (size_t)nx, hipMemcpyDeviceToHost, R.merge_stream));
+    HIP_TRY(hipMemcpyAsync(out->point_slots, sb + o_sl, 4 * (size_t)nx, hipMemcpyDeviceToHost, R.merge_stream));
+    HIP_TRY(hipStreamSynchronize(R.merge_stream));
+    return VO_OK;
 }
 
 extern "C" int vo_local_ba_resident(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int n_free, double huber_delta, double chi2_th, int it_robust, int it_plain,

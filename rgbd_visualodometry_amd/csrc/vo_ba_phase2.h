@@ -36,11 +36,8 @@ __device__ __forceinline__ void p2_rec_load(const double* rec, int k, double (&H
 __global__ __launch_bounds__(256) void k_ba_lin2(BaBatch Q) {
     BA_PROBLEM(Q)
     if (ctl_->finished || B.D > BA_FOLD_D) return;
+    if (!(ctl_->need_lin && ctl_->first)) return;          // only the first step of a round: later linearisations come out of k_ba_upchi2
     const int gp = B.gp;
-    if (!ctl_->need_lin) {                                 // a rejected step is solved again at the same linearisation with a larger lambda: only S / b_s are cleared
-        if ((int)blockIdx.x < gp) ba_fold_zero(B, blockIdx.x, gp);
-        return;
-    }
     BA_STATE(B)
     __shared__ double s_part[4 * 32];
     const int robust = ctl_->robust;

@@ -26,7 +26,7 @@ public:
     void SetContext(vo_ctx* ctx, int device);        // tracker's context (used when lag == 0)
     void SetLag(int frames) { lag_ = frames < 0 ? 0 : frames; if (ctx_ && lag_ > 0) EnsureWorker(); }
     void Stop();                                     // finish the pending job, join the worker
-    void Flush() { if (job_) Finish(); }
+    void Flush() { if (job_) Finish(); FinishTail(); }
     // Device-resident graph: the back-end reads the tracker's device tables while it cuts the graph; the tracker calls this
     // before a keyframe's bookkeeping changes them (the cut is the first ~0.2 ms of a BA, a keyframe is >= 1 ms away).
     void WaitGraphCut();
@@ -68,12 +68,13 @@ private:
     void Build(Job& j, const Frame::Ptr& kf);
     void Solve(Job& j, vo_ctx* ctx);
     void Apply(Job& j);
-    void Finish();                  // wait for the pending job and merge it
+    void Finish(bool deferTail = false);   // wait for the pending job and merge it (deferTail: the host-side copy of a device-merged result is left for FinishTail)
+    void FinishTail();              // positions and poses of a device-merged local BA reach the host objects (after the next graph cut has been started)
+    std::unique_ptr<Job> tail_; vo_ctx* tailCtx_ = nullptr;
     void WorkerLoop();
     void EnsureWorker();            // the worker's context, stream and thread exist before the first keyframe (no one-time setup inside a timed run)
     bool deviceGraph_ = false;
     bool fixOldest_ = false;        // ba_fix_oldest_free_keyframe: gauge-anchor experiment
-    void ApplyResident(Job& j);
     void SolveResident(Job& j, vo_ctx* ctx);
     int maxFree_ = 160;             // free-pose cap of one solve: the Cholesky of the reduced system is LDS resident (vo_local_ba: D = 6 n_free <= ~1050)
 };

@@ -78,7 +78,7 @@ bool Backend::Poll(size_t frameIndex) {
     return false;
 }
 
-void Backend::Finish() {
+void Backend::Finish(bool deferTail) {
     auto t0 = std::chrono::steady_clock::now();
     if (lag_ > 0) { std::unique_lock<std::mutex> lk(mu_); cv_.wait(lk, [&] { return job_->done; }); }
     stats_.ms_wait += ms_since(t0);
@@ -91,13 +91,57 @@ void Backend::Finish() {
         if (stats_.failed++ == 0) std::cerr << "[myslam] vo_local_ba failed (" << vo_strerror(j->rc) << "): this local BA is skipped, tracking continues" << std::endl;
         return;
     }
-    if (j->resident) ApplyResident(*j); else Apply(*j);
+    if (!j->resident) { Apply(*j); return; }
+    // Device-cut BA (reference src/backend.cpp:144-194 in two halves).  Now: the culled observations leave the host ledger (the next
+    // free-keyframe set depends on the covisibility counts they change) and the result is merged into the device tables ON the device
+    // (vo_local_ba_resident_merge: no trip to the host and back before the next graph cut may start).  Later (FinishTail): the host
+    // objects receive their copy.
+    FinishTail();                                    // an earlier tail, if its owner never came back for it
+    MapManager& map = MapManager::GetInstance();
+    if (j->nPoints == 0 || j->nEdges == 0) return;
+    for (int i = 0; i < j->nCulled; ++i) {
+        const MapManager::ObsRef& o = map.obsRegistry_[(size_t)j->culled[i]];
+        if (o.keyframe->IsObservedMappoint(o.mappoint->GetId())) o.keyframe->RemoveObservedMappoint(o.mappoint->GetId());
+    }
+    vo_ctx* solver = lag_ > 0 ? ctxOwn_ : ctx_;
+    int rc = vo_local_ba_resident_merge(solver, ctx_);
+    if (rc != VO_OK) throw std::runtime_error(std::string("vo_local_ba_resident_merge failed: ") + vo_strerror(rc));
+    tail_ = std::move(j); tailCtx_ = solver;
+    if (!deferTail) FinishTail();
+}
+
+void Backend::FinishTail() {
+    if (!tail_) return;
+    VO_SCOPE("ba.apply");
+    std::unique_ptr<Job> jp = std::move(tail_);
+    Job& j = *jp;
+    j.posesOut.resize(12 * (size_t)std::max(j.nFree, 1)); j.pointSlots.resize((size_t)j.nPoints); j.ptsOut.resize(3 * (size_t)j.nPoints);
+    vo_ba_resident_result r;
+    std::memset(&r, 0, sizeof(r));
+    r.poses = j.posesOut.data(); r.point_slots = j.pointSlots.data(); r.points = j.ptsOut.data(); r.culled_obs = j.culled.data();
+    r.cap_points = j.nPoints; r.cap_culled = (int)j.culled.size();
+    int rc = vo_local_ba_resident_fetch(tailCtx_, &r);
+    if (rc != VO_OK) throw std::runtime_error(std::string("vo_local_ba_resident_fetch failed: ") + vo_strerror(rc));
+    MapManager& map = MapManager::GetInstance();
+    for (int p = 0; p < j.nFree; ++p) j.poseFrames[p]->SetPose(SE3::from12(&j.posesOut[12 * (size_t)p]));
+    const size_t np = (size_t)j.nPoints;
+    for (size_t k = 0; k < np; ++k) {
+        if (k + 8 < np) __builtin_prefetch(map.MappointBySlot(j.pointSlots[k + 8]), 1);
+        Mappoint* mp = map.MappointBySlot(j.pointSlots[k]);
+        if (!mp) continue;
+        mp->optimized_ = true;
+        if (mp->outlier_) continue;                  // (a point that lost its last observation to this BA's culls: its flag travels with the next dirty-list flush)
+        const double* x = &j.ptsOut[3 * k];
+        mp->SetPositionSyncedUnlocked(Vector3d(x[0], x[1], x[2]));
+    }
+    stats_.runs++; stats_.poses = j.nFree; stats_.fixed = j.nFixed; stats_.points = j.nPoints; stats_.edges = j.nEdges; stats_.outliers = j.nCulled; stats_.ms_solve += j.solveMs;
+    { const double D = 6.0 * j.nFree; stats_.sum_d3 += D * D * D; stats_.sum_d2 += D * D; stats_.sum_edges += j.nEdges; }
 }
 
 void Backend::OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr) {
     if (!ctx_) throw std::runtime_error("Backend has no compute context (FrontEnd::SetBackend binds it)");
     auto t0 = std::chrono::steady_clock::now();
-    if (job_) Finish();                              // the previous result is merged before a new graph is cut
+    if (job_) Finish(true);                          // the previous result is merged before a new graph is cut (its host-side copy follows below, beside the new solve)
     std::unique_ptr<Job> j(new Job);
     j->frameIndex = frameIndex_;
     // The device pair-list builder takes <= 64 free poses.  The first keyframe with more covisible keyframes than that hands the graph
@@ -131,9 +175,11 @@ void Backend::OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr) {
             { std::unique_lock<std::mutex> lk(mu_); hasWork_ = true; }
             cv_.notify_all();
         }
+        FinishTail();
         stats_.ms += ms_since(t0);
         return;
     }
+    FinishTail();
     Build(*j, keyframeCurr);
     stats_.ms_build += ms_since(t0);
     if (j->edgePose.empty() || j->nFree == 0) return;
@@ -254,45 +300,12 @@ void Backend::WaitGraphCut() {
 
 void Backend::SolveResident(Job& j, vo_ctx* ctx) {
     if (j.nPoints == 0 || j.nEdges == 0) { j.nCulled = 0; return; }
-    j.posesOut.resize(12 * (size_t)std::max(j.nFree, 1)); j.pointSlots.resize((size_t)j.nPoints); j.ptsOut.resize(3 * (size_t)j.nPoints); j.culled.resize((size_t)j.nEdges);
+    j.culled.resize((size_t)j.nEdges);
     vo_ba_resident_result r;
-    std::memset(&r, 0, sizeof(r));
-    r.poses = j.posesOut.data(); r.point_slots = j.pointSlots.data(); r.points = j.ptsOut.data(); r.culled_obs = j.culled.data();
-    r.cap_points = j.nPoints; r.cap_culled = j.nEdges;
+    std::memset(&r, 0, sizeof(r));                   // poses / point_slots / points stay NULL: the result is merged on the device (Finish) and fetched later (FinishTail)
+    r.culled_obs = j.culled.data(); r.cap_culled = j.nEdges;
     j.rc = vo_local_ba_resident_solve(ctx, 10, 10, &r);                                  // backend.cpp:141,:159
     j.nCulled = r.n_culled;
-}
-
-// Write-back of a device-cut BA (reference src/backend.cpp:144-194): culled observations by their registry entry, free poses by
-// keyframe number, points by map slot; then the device tables are brought up to date (the solve left them untouched).
-void Backend::ApplyResident(Job& j) {
-    VO_SCOPE("ba.apply");
-    MapManager& map = MapManager::GetInstance();
-    if (j.nPoints == 0 || j.nEdges == 0) return;
-    for (int i = 0; i < j.nCulled; ++i) {
-        const MapManager::ObsRef& o = map.obsRegistry_[(size_t)j.culled[i]];
-        if (o.keyframe->IsObservedMappoint(o.mappoint->GetId())) o.keyframe->RemoveObservedMappoint(o.mappoint->GetId());
-    }
-    for (int p = 0; p < j.nFree; ++p) j.poseFrames[p]->SetPose(SE3::from12(&j.posesOut[12 * (size_t)p]));
-    const size_t np = (size_t)j.nPoints;
-    applySlots_.resize(np); applyXyz_.resize(3 * np);
-    size_t m = 0;
-    for (size_t k = 0; k < np; ++k) {
-        Mappoint* mp = map.MappointBySlot(j.pointSlots[k]);
-        if (!mp) continue;
-        mp->optimized_ = true;
-        if (mp->outlier_) continue;
-        const double* x = &j.ptsOut[3 * k];
-        mp->SetPositionSyncedUnlocked(Vector3d(x[0], x[1], x[2]));
-        applySlots_[m] = mp->slot_; applyXyz_[3 * m] = x[0]; applyXyz_[3 * m + 1] = x[1]; applyXyz_[3 * m + 2] = x[2];
-        ++m;
-    }
-    auto check = [](int rc, const char* what) { if (rc != VO_OK) throw std::runtime_error(std::string(what) + " (BA merge) failed: " + vo_strerror(rc)); };
-    if (m) check(vo_map_upsert(ctx_, applySlots_.data(), applyXyz_.data(), nullptr, nullptr, nullptr, (int)m), "vo_map_upsert");
-    check(vo_kf_set_pose(ctx_, j.freeKf.data(), j.posesOut.data(), j.nFree), "vo_kf_set_pose");
-    if (j.nCulled) check(vo_obs_kill(ctx_, j.culled.data(), j.nCulled), "vo_obs_kill");
-    stats_.runs++; stats_.poses = j.nFree; stats_.fixed = j.nFixed; stats_.points = j.nPoints; stats_.edges = j.nEdges; stats_.outliers = j.nCulled; stats_.ms_solve += j.solveMs;
-    { const double D = 6.0 * j.nFree; stats_.sum_d3 += D * D * D; stats_.sum_d2 += D * D; stats_.sum_edges += j.nEdges; }
 }
 
 void Backend::Apply(Job& j) {

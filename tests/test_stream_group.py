@@ -391,3 +391,31 @@ def test_hypothesis_shard_on_stream_exchange_equals_unsharded_ransac(libs, strea
         assert np.array_equal(np.array(got[0][j].T_cw), np.array(want[0][j].T_cw)) and np.array_equal(got[1][j], want[1][j])
     ctx.set_hypothesis_shard_stream(0, 1, None)
     ctx.close()
+
+
+@pytest.mark.parametrize("libs", LIBS)
+def test_resident_merge_on_the_device_equals_the_host_write_back(libs):
+    """vo_local_ba_resident_merge / _fetch (the back-end's path: reference src/backend.cpp:144-194 done on the device) against the same
+    local BA whose result travels to the host and is written back with vo_map_upsert / vo_kf_set_pose / vo_obs_kill: same result, and the
+    tables hold the same values afterwards (read through a zero-iteration BA over the same keyframes, which returns the tables' state)."""
+    L = capi.load(libs[0])
+    outs = []
+    for merged in (False, True):
+        rng = np.random.default_rng(23)
+        t, Ts, X, slots, flags, obs, dead, free = _resident_scene(L, rng, n_kf=12, n_pts=500, n_free=5)
+        c = L.context(L.default_params(n_features=64, map_capacity=64))
+        if merged:
+            po, sl, pt, cu, r = c.local_ba_resident_merged(t, free)
+        else:
+            po, sl, pt, cu, r = c.local_ba_resident(t, free)
+            keep = (flags[[list(slots).index(s) for s in sl]] & 1) == 0          # VO_MAP_FLAG_OUTLIER points are not in the graph anyway
+            t.map_upsert(sl[keep], pt[keep], None, None, None)
+            t.kf_set_pose(np.array(free), po)
+            t.obs_kill(cu)
+        state = c.local_ba_resident(t, free, it_robust=0, it_plain=0)        # the tables as the next graph cut sees them
+        outs.append((po, sl, pt, np.sort(cu), r.n_edges, r.n_fixed, r.lm_iters, state[0], state[1], state[2], state[4].n_edges))
+        c.close(); t.close()
+    a, b = outs
+    assert a[4] > 1000 and a[6] == 20 and len(a[3]) > 0
+    for x, y in zip(a, b):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
