@@ -520,15 +520,26 @@ template <int K> __device__ __forceinline__ double ch_mul_bcast(double bsrc, dou
 template <int K> __device__ __forceinline__ void ch_fnma_bcast(double& acc, double bsrc, double m) {   // acc -= bsrc[lane K] * m
     asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(m), "n"(K));
 }
+// the same, pinned in program order against the other volatile statements: the rank-1 updates of the block factorisation must stay
+// right-looking (left to itself the scheduler sinks them next to the pivot that consumes them -- a chain of J dependent
+// accumulations in front of pivot J instead of one)
+template <int K> __device__ __forceinline__ void ch_fnma_bcast_v(double& acc, double bsrc, double m) {
+    asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(m), "n"(K));
+}
+template <int K> __device__ __forceinline__ double ch_bcast_v(double v) {
+    double r;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=&v"(r) : "v"(v), "n"(K));
+    return r;
+}
 template <int J, int K> struct ChRank1 {
-    static __device__ __forceinline__ void run(double (&a)[CH_NB], double l) { ch_fnma_bcast<K>(a[K], l, l); ChRank1<J, K + 1>::run(a, l); }
+    static __device__ __forceinline__ void run(double (&a)[CH_NB], double l) { ch_fnma_bcast_v<K>(a[K], l, l); ChRank1<J, K + 1>::run(a, l); }
 };
 template <int J> struct ChRank1<J, CH_NB> { static __device__ __forceinline__ void run(double (&)[CH_NB], double) {} };
 template <int J> struct ChCol {                                 // column J of the in-register block factorisation
     // No divergent branch may sit between the DPP ops (an EXEC write needs 5 wait states before the next DPP and the
     // broadcast source lanes must be active): selects only, and the pivot inverse goes to LDS from every lane alike.
     static __device__ __forceinline__ void run(double (&a)[CH_NB], double* s_pinv, bool& ok, int r) {
-        const double d = ch_bcast<J>(a[J]);
+        const double d = ch_bcast_v<J>(a[J]);
         ok = ok && (d > 0.0);
         double y, q;
         ba_rsqrt_parts(d, y, q);
@@ -791,15 +802,42 @@ __device__ __forceinline__ bool ba_chol16_body(const BaDev& B, BaCtl* ctl_, doub
         // while the other waves update the rest of the trailing matrix.
         const int T = (m + 15) >> 4, ntile = T * (T + 1) / 2;
         if (wave == 0) {
-            tile(0, 0, base, j0, m);
-            CH_STAMP(5)
+            // the tile holding the next diagonal block: updated on the matrix cores like the others, but handed to the factorisation's
+            // row-per-lane layout through the (now idle) 16x16 scratch s_dg instead of the packed triangle -- the block's pre-factor values
+            // are never needed there.  Entry (row, col) sits at row * 16 + (col ^ row): conflict-free both for the MFMA layout's
+            // writes (a row per 16 lanes) and for the row reads (a column per instruction).
             const int nb2 = min(CH_NB, D - base);
             double a[CH_NB];
-            const bool mine = r16 < nb2;
-            const int rl = mine ? r16 : 0;
-            const double* row = s_L + TRI32(base + rl, base);
+            {
+                const int kq = lane >> 4, ra = min(r16, m - 1);
+                const double* pa = s_L + TRI32(base + ra, j0) + kq;
+                const double a0 = pa[0], a1 = pa[4], a2 = pa[8], a3 = pa[12];
+                double cv[4];
 #pragma unroll
-            for (int c = 0; c < CH_NB; ++c) a[c] = row[min(c, rl)];
+                for (int q = 0; q < 4; ++q) {                  // old values, by symmetry from the packed lower triangle (clamped past the end)
+                    const int rw = kq + 4 * q, hi = min(max(rw, r16), m - 1), lo = min(min(rw, r16), hi);
+                    cv[q] = s_L[TRI32(base + hi, base + lo)];
+                }
+                f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, a2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, a3, acc, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int rw = kq + 4 * q;
+                    const double val = cv[q] - acc[q];
+                    s_dg[rw * CH_NB + (r16 ^ rw)] = val;
+                    if (rw >= nb2 && rw < m && r16 <= rw) s_L[TRI32(base + rw, base + r16)] = val;      // a partial last block: the rhs row below it stays in the triangle
+                }
+            }
+            CH_STAMP(5)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const bool mine = r16 < nb2;
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) a[c] = s_dg[r16 * CH_NB + (c ^ r16)];
 #pragma unroll
             for (int c = 0; c < CH_NB; ++c) a[c] = (mine && c <= r16) ? a[c] : (c == r16 ? 1.0 : 0.0);
             CH_STAMP(6)
@@ -1506,7 +1544,7 @@ static int ba_engine_enqueue(BaEngine* E) {
         if (j->B.D <= BA_FOLD_D) {
             sA[nA++] = act[i];
             gA_lin = std::max(gA_lin, j->grid_lin); gA_blk = std::max(gA_blk, j->B.n_blocks); gA_pose = std::max(gA_pose, j->B.n_free * PSPLIT); gA_up = std::max(gA_up, (j->B.n_points + UPC_T / 4 - 1) / (UPC_T / 4));
-            ldsA = std::max(ldsA, j->lds); ldsA_up = std::max(ldsA_up, sizeof(double) * (12 * (size_t)j->B.n_poses + (size_t)j->B.D));
+            ldsA = std::max(ldsA, j->lds); ldsA_up = std::max(ldsA_up, sizeof(double) * (24 * (size_t)j->B.n_poses + (size_t)j->B.D));
             gA_md = std::max(gA_md, (j->B.D + j->B.n_points + 255) / 256);
         } else {
             sB[nB++] = act[i];

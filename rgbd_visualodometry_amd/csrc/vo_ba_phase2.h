@@ -243,11 +243,41 @@ __global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q) {
     const double lambda = ctl_->lambda;
     const int robust = ctl_->robust;
     const bool ok = B.scal[3] != 0.0;
+#ifdef P2_STAMPS
+    long long tq_[8]; int nq_ = 0; const bool stamp_ = (blockIdx.x == 7 || blockIdx.x == gp - 1) && threadIdx.x == 0 && ctl_->it == 4 && blockIdx.z == 0;
+#define P2_STAMP() { if (nq_ < 8) tq_[nq_++] = wall_clock64(); }
+#else
+#define P2_STAMP()
+#endif
+    P2_STAMP()
     BA_STATE(B)
+    // everything the point passes read from global memory that does not depend on the trial poses is requested BEFORE the poses are
+    // built: the ~2 us of exponential maps below hide the two dependent load levels (pt_start -> edge data) of the first round of edges
+    const int lb = ctl_->lbuf;
+    const double* const rec = p2_rec(B, lb);
+    const double* const Wt = p2_w(B, lb);
+    double* const rec_n = p2_rec(B, lb ^ 1);
+    double* const Wn = p2_w(B, lb ^ 1);
+    const int k = blockIdx.x * (UPC_T / 4) + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+    const bool live = ok && k < B.n_points;
+    double H[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0}, p[3] = {0, 0, 0}, rhs[3] = {0, 0, 0};
+    int q0 = 0, q1 = 0;
+    int e0 = -1, j0 = 0; uint8_t act0 = 0; double w0 = 0; float2 uv0 = make_float2(0.f, 0.f);       // first edge of this lane (most points have <= 4 edges: one round)
+    if (live) {
+        q0 = B.pt_start[k]; q1 = B.pt_start[k + 1];
+        p2_rec_load(rec, k, H, bl, p);
+        if (q0 + sub < q1) {                               // (no branch on a loaded value here: the loads stay in flight across the pose block below)
+            const int e = B.edges_by_point ? q0 + sub : B.pt_edges[q0 + sub];
+            act0 = B.active[e]; e0 = e; j0 = B.e_pose[e]; w0 = Wt[e]; uv0 = reinterpret_cast<const float2*>(B.e_uv)[e];
+        }
+    }
+    double* const s_Tc = s_dp + B.D;                        // current poses [n_poses][12] (pass 1 reads them per edge)
     for (int i = threadIdx.x; i < B.D; i += UPC_T) s_dp[i] = B.dl[i];           // the solution (k_ba_chol16, phase2 = 1)
     for (int j = threadIdx.x; j < B.n_poses; j += UPC_T) {   // exp(dp) * T for the free poses (ba_pose_body), copies for the fixed ones
-        const double* T = poses_c + 12 * (size_t)j;
-        double Tn[12];
+        const double* Tg = poses_c + 12 * (size_t)j;
+        double T[12], Tn[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T[i] = Tg[i];
         if (j >= B.n_free || !ok) {
 #pragma unroll
             for (int i = 0; i < 12; ++i) Tn[i] = T[i];
@@ -262,47 +292,53 @@ __global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < 12; ++i) s_T[12 * j + i] = Tn[i];
+        for (int i = 0; i < 12; ++i) { s_T[12 * j + i] = Tn[i]; s_Tc[12 * j + i] = T[i]; }
         if (blockIdx.x == 0) {
 #pragma unroll
             for (int i = 0; i < 12; ++i) poses_t[12 * (size_t)j + i] = Tn[i];
         }
     }
     __syncthreads();
+    P2_STAMP()
+    if (!act0) e0 = -1;
     double chi = 0, sc = 0, mx = 0;
     {
-        const int lb = ctl_->lbuf;
-        const double* const rec = p2_rec(B, lb);
-        const double* const Wt = p2_w(B, lb);
-        double* const rec_n = p2_rec(B, lb ^ 1);
-        double* const Wn = p2_w(B, lb ^ 1);
-        const int k = blockIdx.x * (UPC_T / 4) + (threadIdx.x >> 2), sub = threadIdx.x & 3;
-        const bool live = ok && k < B.n_points;
-        double H[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0}, p[3] = {0, 0, 0}, rhs[3] = {0, 0, 0};
-        int q0 = 0, q1 = 0;
+        auto pass1 = [&](int j, double w) {                 // rhs -= W_e^T dp_j
+            double T[12], Jp[2][6], Jl[2][3];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) T[i] = s_Tc[12 * j + i];
+            pb_jac(B.cam, T, p, Jp, Jl);
+            const double* d6 = s_dp + 6 * j;
+            double t0 = 0, t1 = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) { t0 += Jp[0][a] * d6[a]; t1 += Jp[1][a] * d6[a]; }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rhs[c] -= w * (Jl[0][c] * t0 + Jl[1][c] * t1);
+        };
         if (live) {
-            p2_rec_load(rec, k, H, bl, p);
             if (sub == 0) { rhs[0] = bl[0]; rhs[1] = bl[1]; rhs[2] = bl[2]; }
-            q0 = B.pt_start[k]; q1 = B.pt_start[k + 1];
-            for (int q = q0 + sub; q < q1; q += 4) {
-                const int e = B.pt_edges[q], j = B.e_pose[e];
+            if (e0 >= 0 && j0 < B.n_free) pass1(j0, w0);
+            for (int q = q0 + sub + 4; q < q1; q += 4) {
+                const int e = B.edges_by_point ? q : B.pt_edges[q], j = B.e_pose[e];
                 if (!B.active[e] || j >= B.n_free) continue;
-                const double w = Wt[e];
-                double T[12], Jp[2][6], Jl[2][3];
-#pragma unroll
-                for (int i = 0; i < 12; ++i) T[i] = poses_c[12 * (size_t)j + i];
-                pb_jac(B.cam, T, p, Jp, Jl);
-                const double* d6 = s_dp + 6 * j;
-                double t0 = 0, t1 = 0;
-#pragma unroll
-                for (int a = 0; a < 6; ++a) { t0 += Jp[0][a] * d6[a]; t1 += Jp[1][a] * d6[a]; }
-#pragma unroll
-                for (int c = 0; c < 3; ++c) rhs[c] -= w * (Jl[0][c] * t0 + Jl[1][c] * t1);         // W_e^T dp_j
+                pass1(j, Wt[e]);
             }
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) rhs[c] = ba_quad_sum(rhs[c]);
+        P2_STAMP()
         double Hn[6] = {0, 0, 0, 0, 0, 0}, bn[3] = {0, 0, 0}, pn[3] = {0, 0, 0};
+        // second pass over the point's edges at the TRIAL state: robust chi2 (the LM decision) and the whole linearisation (Huber weight,
+        // H_ll, b_l) that the next step needs if this one is accepted -- k_ba_lin2's point part at the price of a few dozen FMAs per edge
+        auto pass2 = [&](int e, int j, const float* uv) {
+            double r[2], w, rho0, Jp[2][6], Jl[2][3];
+            ba_edge(B.cam, s_T + 12 * j, pn, uv, robust, B.delta, r, w, rho0, Jp, Jl);
+            chi += rho0;
+            Wn[e] = w;
+            bn[0] -= w * (Jl[0][0] * r[0] + Jl[1][0] * r[1]); bn[1] -= w * (Jl[0][1] * r[0] + Jl[1][1] * r[1]); bn[2] -= w * (Jl[0][2] * r[0] + Jl[1][2] * r[1]);
+            Hn[0] += w * (Jl[0][0] * Jl[0][0] + Jl[1][0] * Jl[1][0]); Hn[1] += w * (Jl[0][0] * Jl[0][1] + Jl[1][0] * Jl[1][1]); Hn[2] += w * (Jl[0][0] * Jl[0][2] + Jl[1][0] * Jl[1][2]);
+            Hn[3] += w * (Jl[0][1] * Jl[0][1] + Jl[1][1] * Jl[1][1]); Hn[4] += w * (Jl[0][1] * Jl[0][2] + Jl[1][1] * Jl[1][2]); Hn[5] += w * (Jl[0][2] * Jl[0][2] + Jl[1][2] * Jl[1][2]);
+        };
         if (live) {
             const double Hs[9] = {H[0], H[1], H[2], H[1], H[3], H[4], H[2], H[4], H[5]};
             double h[9];
@@ -313,18 +349,11 @@ __global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q) {
                 pn[a] = p[a] + d;
                 if (sub == 0) { pts_t[3 * (size_t)k + a] = pn[a]; sc += d * (lambda * d + bl[a]); mx = fmax(mx, fabs(d)); }
             }
-            // second pass over the point's edges at the TRIAL state: robust chi2 (the LM decision) and the whole linearisation (Huber weight,
-            // H_ll, b_l) that the next step needs if this one is accepted -- k_ba_lin2's point part at the price of a few dozen FMAs per edge
-            for (int q = q0 + sub; q < q1; q += 4) {
-                const int e = B.pt_edges[q];
+            if (e0 >= 0) { const float uvv[2] = {uv0.x, uv0.y}; pass2(e0, j0, uvv); }
+            for (int q = q0 + sub + 4; q < q1; q += 4) {
+                const int e = B.edges_by_point ? q : B.pt_edges[q];
                 if (!B.active[e]) continue;
-                double r[2], w, rho0, Jp[2][6], Jl[2][3];
-                ba_edge(B.cam, s_T + 12 * B.e_pose[e], pn, B.e_uv + 2 * (size_t)e, robust, B.delta, r, w, rho0, Jp, Jl);
-                chi += rho0;
-                Wn[e] = w;
-                bn[0] -= w * (Jl[0][0] * r[0] + Jl[1][0] * r[1]); bn[1] -= w * (Jl[0][1] * r[0] + Jl[1][1] * r[1]); bn[2] -= w * (Jl[0][2] * r[0] + Jl[1][2] * r[1]);
-                Hn[0] += w * (Jl[0][0] * Jl[0][0] + Jl[1][0] * Jl[1][0]); Hn[1] += w * (Jl[0][0] * Jl[0][1] + Jl[1][0] * Jl[1][1]); Hn[2] += w * (Jl[0][0] * Jl[0][2] + Jl[1][0] * Jl[1][2]);
-                Hn[3] += w * (Jl[0][1] * Jl[0][1] + Jl[1][1] * Jl[1][1]); Hn[4] += w * (Jl[0][1] * Jl[0][2] + Jl[1][1] * Jl[1][2]); Hn[5] += w * (Jl[0][2] * Jl[0][2] + Jl[1][2] * Jl[1][2]);
+                pass2(e, B.e_pose[e], B.e_uv + 2 * (size_t)e);
             }
         }
 #pragma unroll
@@ -333,6 +362,7 @@ __global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q) {
         for (int i = 0; i < 3; ++i) bn[i] = ba_quad_sum(bn[i]);
         if (live && sub == 0) p2_rec_store(rec_n, k, Hn, bn, pn);
     }
+    P2_STAMP()
     chi = vo_wave_sum_f64(chi); sc = vo_wave_sum_f64(sc);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
@@ -349,6 +379,10 @@ __global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q) {
         s_last = atomicAdd(&ctl_->arrived, 1) == gp - 1;
     }
     __syncthreads();
+    P2_STAMP()
+#ifdef P2_STAMPS
+    if (stamp_ && !s_last) printf("[upchi2 wg %d of %d] wall clocks (100 MHz): prelude %lld pass1 %lld pass2 %lld reduce+ticket %lld\n", (int)blockIdx.x, gp, tq_[1] - tq_[0], tq_[2] - tq_[1], tq_[3] - tq_[2], tq_[4] - tq_[3]);
+#endif
     if (!s_last) return;
     {   // the last workgroup: the partials of every workgroup, then g2o's gain-ratio test and lambda policy (as k_ba_chi_control)
         __threadfence();
@@ -397,4 +431,8 @@ __global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q) {
         for (int i = threadIdx.x; i < 36 * B.n_free; i += UPC_T) B.Hpp[i] = 0;
         for (int i = threadIdx.x; i < B.D; i += UPC_T) B.bp[i] = 0;
     }
+    P2_STAMP()
+#ifdef P2_STAMPS
+    if (threadIdx.x == 0 && blockIdx.z == 0 && ctl_->it == 5) printf("[upchi2 last wg %d of %d] prelude %lld pass1 %lld pass2 %lld reduce+ticket %lld control %lld\n", (int)blockIdx.x, gp, tq_[1] - tq_[0], tq_[2] - tq_[1], tq_[3] - tq_[2], tq_[4] - tq_[3], tq_[5] - tq_[4]);
+#endif
 }

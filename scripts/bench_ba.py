@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--its", default="10,10", help="LM iterations of the robust and the plain round")
     args = ap.parse_args()
     from rgbd_visualodometry_amd import capi
-    H = capi.load(capi.HIP_LIB)
+    H = capi.load(os.environ.get("VO_HIP_LIB", capi.HIP_LIB))          # e.g. csrc/build/libvo_hip_stamps.so
     p = H.default_params(map_capacity=1024)
     shapes = {"bench": [(50, 24, 9000, 16), (30, 17, 6000, 14), (60, 30, 9000, 20)], "small": [(18, 16, 300, 18), (6, 4, 400, 6)],
               "config5": [(26, 21, 9000, 26)]}[args.shapes]
