@@ -73,6 +73,12 @@ __global__ void k_lat_probe(double* out, double seed) {
 #pragma unroll
     for (int i = 0; i < 128; ++i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(reinterpret_cast<int&>(y)) : "v"(i));
     long long t5 = clock64();
+    double b0 = x, b1 = x + 1, b2 = x + 2, b3 = x + 3;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) asm volatile("v_fmac_f64_dpp %0, -%4, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, -%4, %5 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, -%4, %5 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, -%4, %5 row_newbcast:6 row_mask:0xf bank_mask:0xf" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3) : "v"(y), "v"(z));
+    long long t6 = clock64();
+    if (threadIdx.x == 0) out[5] = (t6 - t5) / 256.0;
+    a0 += b0 + b1 + b2 + b3;
     if (threadIdx.x == 0) { out[0] = (t1 - t0) / 256.0; out[1] = (t2 - t1) / 128.0; out[2] = (t3 - t2) / 64.0; out[3] = (t4 - t3) / 256.0; out[4] = (t5 - t4) / 128.0; }
     out[8 + threadIdx.x] = x + a0 + a1 + a2 + a3 + y;
 }
@@ -114,7 +120,7 @@ int main() {
       }
       printf("reduce32 probe: %d mismatches\n", bad); hipFree(d); }
     { double* d; hipMalloc(&d, 128 * 8); hipLaunchKernelGGL(k_lat_probe, dim3(1), dim3(64), 0, 0, d, 1.0); double h[8]; hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
-      printf("latency probe (clocks): dependent v_fma_f64 %.1f | mul+nop+fmac_dpp pair %.1f | dependent v_rsq_f64 %.1f | independent v_fma_f64 %.1f | dependent v_cndmask_b32 %.1f\n", h[0], h[1], h[2], h[3], h[4]); hipFree(d); }
+      printf("latency probe (clocks): dependent v_fma_f64 %.1f | mul+nop+fmac_dpp pair %.1f | dependent v_rsq_f64 %.1f | independent v_fma_f64 %.1f | dependent v_cndmask_b32 %.1f | independent v_fmac_f64_dpp %.1f\n", h[0], h[1], h[2], h[3], h[4], h[5]); hipFree(d); }
     { const int n = 1 << 16; std::vector<double> hx(n), hy(4 * n); std::mt19937_64 rg(7); std::uniform_real_distribution<double> ud(-30.0, 30.0);
       for (auto& v : hx) v = std::exp2(ud(rg));
       double *dx, *dy; hipMalloc(&dx, n * 8); hipMalloc(&dy, 4 * n * 8); hipMemcpy(dx, hx.data(), n * 8, hipMemcpyHostToDevice);

@@ -537,21 +537,26 @@ template <int J, int K> struct ChRank1 {
 template <int J> struct ChRank1<J, CH_NB> { static __device__ __forceinline__ void run(double (&)[CH_NB], double) {} };
 template <int J> struct ChCol {                                 // column J of the in-register block factorisation
     // No divergent branch may sit between the DPP ops (an EXEC write needs 5 wait states before the next DPP and the
-    // broadcast source lanes must be active): selects only, and the pivot inverse goes to LDS from every lane alike.
-    static __device__ __forceinline__ void run(double (&a)[CH_NB], double* s_pinv, bool& ok, int r) {
+    // broadcast source lanes must be active), and this wave is issue-bound (~28 VALU instructions per column at ~8 clocks each, the
+    // dependent chain of ~110 clocks hides underneath): nothing per column that is not arithmetic.  Lanes above the diagonal (r < J)
+    // carry the symmetric counterpart in a[J] and are NOT masked: what they compute lands in entries of their row right of the diagonal,
+    // which nobody reads.  A non-positive pivot is not tested here either: rsq turns it into NaN / inf, which reaches every later pivot
+    // inverse of the block (ch_pivots_ok looks at them once).
+    static __device__ __forceinline__ void run(double (&a)[CH_NB], double* s_pinv) {
         const double d = ch_bcast_v<J>(a[J]);
-        ok = ok && (d > 0.0);
         double y, q;
         ba_rsqrt_parts(d, y, q);
-        const double l0 = (r >= J ? a[J] : 0.0) * y;            // off the dependent chain (parallel to e, q)
+        const double l0 = a[J] * y;                             // off the dependent chain (parallel to e, q)
         const double l = ch_fma_for_dpp(l0, q, l0);             // a * rsqrt(d); lane J: d * rsqrt(d) = sqrt(d)
         s_pinv[J] = fma(y, q, y);
         a[J] = l;
         ChRank1<J, J + 1>::run(a, l);
-        ChCol<J + 1>::run(a, s_pinv, ok, r);
+        ChCol<J + 1>::run(a, s_pinv);
     }
 };
-template <> struct ChCol<CH_NB> { static __device__ __forceinline__ void run(double (&)[CH_NB], double*, bool&, int) {} };
+template <> struct ChCol<CH_NB> { static __device__ __forceinline__ void run(double (&)[CH_NB], double*) {} };
+// every pivot of the block was positive: its inverse square root is finite and positive in every lane (NaN compares false)
+__device__ __forceinline__ bool ch_pivots_ok(double myinv) { return __ballot(!(myinv > 0.0 && myinv < 1e300)) == 0ull; }
 __device__ __forceinline__ void ch_exec_settle(double& v) { asm("s_nop 4" : "+v"(v)); }   // EXEC write -> DPP: 5 wait states
 template <int K> struct ChBack {                                // step K of the in-register back substitution
     static __device__ __forceinline__ void run(const double (&col)[CH_NB], double& y, double inv, double& xf, int r) {
@@ -611,10 +616,10 @@ template <> struct ChSolve<CH_NB> { static __device__ __forceinline__ void run(d
 // non-positive pivot.  `a` arrives loaded (row r16 of the block in every 16-lane DPP row, identity padding).
 __device__ __forceinline__ bool ch_factor_block(double (&a)[CH_NB], double* s_L, double* s_dg, double* s_inv, double* s_pinv, int j0, int nb, int lane) {
     const int r16 = lane & 15;
-    bool ok = true;
     ch_exec_settle(a[0]);
-    ChCol<0>::run(a, s_pinv, ok, r16);
+    ChCol<0>::run(a, s_pinv);
     const double myinv = s_pinv[r16];
+    const bool ok = ch_pivots_ok(myinv);
     if (lane < CH_NB) {                                         // transposed copy: column k of the block is contiguous
 #pragma unroll
         for (int c = 0; c < CH_NB; ++c) s_dg[c * CH_NB + lane] = c < lane ? a[c] : (c == lane ? myinv : 0.0);
@@ -756,6 +761,35 @@ __device__ __forceinline__ bool ba_chol16_body(const BaDev& B, BaCtl* ctl_, doub
 #pragma unroll
         for (int q = 0; q < 4; ++q) if (st[q]) *pc[q] = cv[q] - acc[q];
     };
+    auto tile2 = [&](int trA, int tcA, int trB, int tcB, int base, int j0, int m) {      // two independent tiles, interleaved
+        const int kq = lane >> 4;
+        const int raA = min(16 * trA + r16, m - 1), rbA = min(16 * tcA + r16, m - 1), raB = min(16 * trB + r16, m - 1), rbB = min(16 * tcB + r16, m - 1);
+        const double* paA = s_L + TRI32(base + raA, j0) + kq; const double* pbA = s_L + TRI32(base + rbA, j0) + kq;
+        const double* paB = s_L + TRI32(base + raB, j0) + kq; const double* pbB = s_L + TRI32(base + rbB, j0) + kq;
+        const double a0 = paA[0], a1 = paA[4], a2 = paA[8], a3 = paA[12], b0 = pbA[0], b1 = pbA[4], b2 = pbA[8], b3 = pbA[12];
+        const double c0 = paB[0], c1 = paB[4], c2 = paB[8], c3 = paB[12], d0 = pbB[0], d1 = pbB[4], d2 = pbB[8], d3 = pbB[12];
+        double* pcA[4]; double* pcB[4]; double cvA[4], cvB[4]; bool stA[4], stB[4];
+        const int colA = 16 * tcA + r16, colB = 16 * tcB + r16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rwA = 16 * trA + kq + 4 * q, rwB = 16 * trB + kq + 4 * q;
+            stA[q] = rwA < m && colA <= rwA; stB[q] = rwB < m && colB <= rwB;
+            pcA[q] = s_L + TRI32(base + min(rwA, m - 1), base + min(colA, min(rwA, m - 1)));
+            pcB[q] = s_L + TRI32(base + min(rwB, m - 1), base + min(colB, min(rwB, m - 1)));
+            cvA[q] = *pcA[q]; cvB[q] = *pcB[q];
+        }
+        f64x4 accA = {0.0, 0.0, 0.0, 0.0}, accB = {0.0, 0.0, 0.0, 0.0};
+        accA = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f64_16x16x4f64(c0, d0, accB, 0, 0, 0);
+        accA = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f64_16x16x4f64(c1, d1, accB, 0, 0, 0);
+        accA = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f64_16x16x4f64(c2, d2, accB, 0, 0, 0);
+        accA = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f64_16x16x4f64(c3, d3, accB, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { if (stA[q]) *pcA[q] = cvA[q] - accA[q]; if (stB[q]) *pcB[q] = cvB[q] - accB[q]; }
+    };
     for (int j0 = 0; j0 < D; j0 += CH_NB) {
         const int nb = min(CH_NB, D - j0);
         if (!s_ok) break;
@@ -844,11 +878,18 @@ __device__ __forceinline__ bool ba_chol16_body(const BaDev& B, BaCtl* ctl_, doub
             if (!ch_factor_block(a, s_L, s_dg, s_inv, s_pinv, base, nb2, lane) && lane == 0) s_ok = 0;
             CH_STAMP(7)
         } else {
-            int tr = 0, tc = wave;                              // tiles 1.. in (tr, tc <= tr) order, 7 waves
+            // tiles 1.. in (tr, tc <= tr) order over 7 waves, two tiles in flight per wave: a tile is a dependent chain (operand loads ->
+            // 4 MFMAs on one accumulator -> read-modify-write of the target), ~1400 clocks of mostly latency; with D >= 130 the first panels'
+            // 45 / 36 tiles are more than wave 0's chain hides
+            constexpr int NW = CH_THREADS / 64 - 1;
+            int tr = 0, tc = wave;
             while (tc > tr) { tc -= tr + 1; ++tr; }
-            for (int t = wave; t < ntile; t += CH_THREADS / 64 - 1) {
-                tile(tr, tc, base, j0, m);
-                tc += CH_THREADS / 64 - 1;
+            for (int t = wave; t < ntile; t += 2 * NW) {
+                int tr2 = tr, tc2 = tc + NW;
+                while (tc2 > tr2) { tc2 -= tr2 + 1; ++tr2; }
+                if (t + NW < ntile) tile2(tr, tc, tr2, tc2, base, j0, m);
+                else tile(tr, tc, base, j0, m);
+                tr = tr2; tc = tc2 + NW;
                 while (tc > tr) { tc -= tr + 1; ++tr; }
             }
         }
@@ -1020,10 +1061,10 @@ __global__ __launch_bounds__(CH_THREADS) void k_ba_chol16g(BaBatch Q) {
             for (int c = 0; c < CH_NB; ++c) a[c] = row[min(c, nb - 1)];
 #pragma unroll
             for (int c = 0; c < CH_NB; ++c) a[c] = (mine && c <= r16) ? a[c] : (c == r16 ? 1.0 : 0.0);
-            bool ok = true;
             ch_exec_settle(a[0]);
-            ChCol<0>::run(a, s_pinv, ok, r16);
+            ChCol<0>::run(a, s_pinv);
             const double myinv = s_pinv[r16];
+            const bool ok = ch_pivots_ok(myinv);
             if (lane < CH_NB) {
 #pragma unroll
                 for (int c = 0; c < CH_NB; ++c) s_dg[c * CH_NB + lane] = c < lane ? a[c] : (c == lane ? myinv : 0.0);
@@ -1568,19 +1609,19 @@ static int ba_engine_enqueue(BaEngine* E) {
             // leave at once for a slot that is not at the start of a round); afterwards the linearisation at the accepted state is a
             // by-product of k_ba_upchi2 and a step is THREE launches
             if (sidx == 0) {
-                { ProfScope ps(prof, "k_ba_lin", st); hipLaunchKernelGGL(k_ba_lin2, dim3(gA_lin, 1, nA), blk, 0, st, QA); }
+                { ProfScope ps(prof, "k_ba_lin2", st); hipLaunchKernelGGL(k_ba_lin2, dim3(gA_lin, 1, nA), blk, 0, st, QA); }
                 hipLaunchKernelGGL(k_ba_maxdiag2, dim3(gA_md, 1, nA), blk, 0, st, QA);
             }
-            { ProfScope ps(prof, "k_ba_schur_blocks", st); hipLaunchKernelGGL(k_ba_schur2, dim3(gA_blk + gA_pose, 1, nA), blk, 0, st, QA); }
-            { ProfScope ps(prof, "k_ba_chol", st); hipLaunchKernelGGL(k_ba_chol16, dim3(1, 1, nA), dim3(CH_THREADS), ldsA, st, QA, 0, 1); }
-            { ProfScope ps(prof, "k_ba_update", st); hipLaunchKernelGGL(k_ba_upchi2, dim3(gA_up, 1, nA), dim3(UPC_T), ldsA_up, st, QA); }
+            { ProfScope ps(prof, "k_ba_schur2", st); hipLaunchKernelGGL(k_ba_schur2, dim3(gA_blk + gA_pose, 1, nA), blk, 0, st, QA); }
+            { ProfScope ps(prof, "k_ba_chol16", st); hipLaunchKernelGGL(k_ba_chol16, dim3(1, 1, nA), dim3(CH_THREADS), ldsA, st, QA, 0, 1); }
+            { ProfScope ps(prof, "k_ba_upchi2", st); hipLaunchKernelGGL(k_ba_upchi2, dim3(gA_up, 1, nA), dim3(UPC_T), ldsA_up, st, QA); }
         }
         if (nB) {
             { ProfScope ps(prof, "k_ba_lin", st); hipLaunchKernelGGL(k_ba_lin, dim3(gB_lin, 1, nB), blk, 0, st, QB); }
             if (sidx == 0) hipLaunchKernelGGL(k_ba_maxdiag, dim3(gB_md, 1, nB), blk, 0, st, QB);
             { ProfScope ps(prof, "k_ba_init_S", st); hipLaunchKernelGGL(k_ba_init_S, dim3(gB_init, 1, nB), blk, 0, st, QB); }
             if (gB_blk) { ProfScope ps(prof, "k_ba_schur_blocks", st); hipLaunchKernelGGL(k_ba_schur_blocks, dim3(gB_blk, 1, nB), blk, 0, st, QB); }
-            { ProfScope ps(prof, "k_ba_chol", st); hipLaunchKernelGGL(k_ba_chol16g, dim3(1, 1, nB), dim3(CH_THREADS), ldsB, st, QB); }
+            { ProfScope ps(prof, "k_ba_chol16g", st); hipLaunchKernelGGL(k_ba_chol16g, dim3(1, 1, nB), dim3(CH_THREADS), ldsB, st, QB); }
             { ProfScope ps(prof, "k_ba_update", st); hipLaunchKernelGGL(k_ba_update, dim3(gB_upd, 1, nB), blk, 0, st, QB); }
             { ProfScope ps(prof, "k_ba_chi_control", st); hipLaunchKernelGGL(k_ba_chi_control, dim3(gB_c, 1, nB), blk, 0, st, QB); }
         }

@@ -469,18 +469,16 @@ __global__ __launch_bounds__(64) void k_ransac_hyp(const LaneDesc* __restrict__ 
 // the chunks' counts meet in hyp_cnt[h] (integer atomics: exact in any order).  With one workgroup per hypothesis every one of
 // them re-read all K correspondences (round 2: 10x the algorithmic bytes; 800 MB of L2 reads per pass at 2048 x 19.6 k).
 #define RS_R 4
-__global__ __launch_bounds__(1024) void k_ransac_score(const LaneDesc* __restrict__ lanes, int h_first, int n_hyp, int ht, double thr2, int rank, int world, int xcd_aff) {
+__global__ __launch_bounds__(1024) void k_ransac_score(const LaneDesc* __restrict__ lanes, int h_first, int n_hyp, int ht, double thr2, int rank, int world) {
     LANE_PTRS(lanes)
     __shared__ int s_cnt[64];
     const int n = tr->n_match;
     const int k0 = blockIdx.y * (RS_R * 1024);
     if (k0 >= n) return;                                      // the grid is sized for the largest lane
     const double* __restrict__ hp = ld_.hyp_pose;
-    // xcd_aff: the grid is 8x oversized and only the workgroups that the dispatcher places on XCD (lane % 8) work (workgroup b runs on
-    // XCD b % 8, MI355X_MICROARCH.md: speed only): a lane's correspondences then cross the fabric once instead of once per XCD
-    int bx = blockIdx.x;
-    if (xcd_aff) { if ((bx & 7) != (int)(blockIdx.z & 7)) return; bx >>= 3; }
-    const int h0 = h_first + bx * ht;
+    // (Keeping a lane's workgroups on one XCD -- an 8x oversized grid whose other workgroups leave at once -- did not lower the fabric
+    // traffic of this kernel (8.7x its algorithmic bytes, 4 MB per launch) and cost 4 us of empty waves: measured, removed.)
+    const int h0 = h_first + blockIdx.x * ht;
     // second stage (h_first > 0): the scan over the first h_first counts (k_ransac_peek) has bounded the number of hypotheses the
     // sequential RANSAC loop would ever look at; the ones beyond it are not scored (their count stays 0: never a record)
     if (h_first > 0 && h0 >= tr->pad1) return;
@@ -1104,21 +1102,18 @@ int vo_track_ransac_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* dl, int
       { ProfScope ps(prof, "k_ransac_hyp", st);
         hipLaunchKernelGGL(k_ransac_hyp, dim3((n_hyp + 63) / 64, 1, nl), dim3(64), 0, st, dl, n_hyp, pass); }
       { ProfScope ps(prof, "k_ransac_score", st);
-        // hypotheses per workgroup: 1 up to 128 hypotheses (latency matters there), up to 32 beyond; correspondence chunks from the host's hint
+        // hypotheses per workgroup: ~1/24 of the set, up to 32; correspondence chunks from the host's hint
         const int chunks = std::max(1, (corr_hint + RS_R * 1024 - 1) / (RS_R * 1024));
         // Beyond 256 hypotheses (and unless the hypotheses are sharded over ranks: every rank must then produce all of its counts for the
         // exchange) the scoring runs in two stages: the first 128, a peek at how far the adaptive stop lets the scan go, then the
         // rest -- whose workgroups leave at once when their hypotheses lie beyond that bound.  The result is the full scan's.
         const int h_split = (n_hyp > 256 && world == 1 && !all_counts) ? 128 : n_hyp;     // all_counts: the caller reads every hypothesis' count (vo_pnp_ransac)
-        const int ht1 = std::max(1, std::min(32, h_split / 64));
-        // few hypotheses and correspondences (default.yaml: 100 x ~2000): the work is tiny, the traffic is the lane's correspondence list once
-        // per XCD -- the lane's workgroups are kept on one XCD
-        const int aff = (h_split <= 256 && chunks <= 4) ? 1 : 0;
-        hipLaunchKernelGGL(k_ransac_score, dim3(((h_split + ht1 - 1) / ht1) * (aff ? 8 : 1), chunks, nl), dim3(1024), 0, st, dl, 0, h_split, ht1, thr2, rank, world, aff);
+        const int ht1 = std::max(1, std::min(32, (h_split + 15) / 24));      // default.yaml's 100 hypotheses: 4 per workgroup -- 19 us and a quarter of the re-read traffic, against 25 us with one each
+        hipLaunchKernelGGL(k_ransac_score, dim3((h_split + ht1 - 1) / ht1, chunks, nl), dim3(1024), 0, st, dl, 0, h_split, ht1, thr2, rank, world);
         if (h_split < n_hyp) {
             hipLaunchKernelGGL(k_ransac_peek, dim3(1, 1, nl), dim3(1024), 0, st, dl, h_split, n_hyp, (double)conf);
             const int ht2 = 32;
-            hipLaunchKernelGGL(k_ransac_score, dim3((n_hyp - h_split + ht2 - 1) / ht2, chunks, nl), dim3(1024), 0, st, dl, h_split, n_hyp, ht2, thr2, rank, world, 0);
+            hipLaunchKernelGGL(k_ransac_score, dim3((n_hyp - h_split + ht2 - 1) / ht2, chunks, nl), dim3(1024), 0, st, dl, h_split, n_hyp, ht2, thr2, rank, world);
         } }
     }
     if (stage & 2) { ProfScope ps(prof, "k_ransac_select", st);
