@@ -2148,44 +2148,61 @@ __global__ void k_cut_points(CutTabs T, const int* __restrict__ kf_idx, int* __r
 // scan of the (<= 1024) sums, per-block scan + offset; total -> *total_out
 #define SCAN_PER 16
 #define SCAN_TILE (1024 * SCAN_PER)
+// Exclusive scan of an int32 array in two launches.  A workgroup owns a tile of 16 Ki elements = 4 sub-tiles of 4 Ki; a thread takes one
+// int4 per sub-tile (consecutive lanes, consecutive 16 bytes: the arrays are 256-byte aligned and padded).  k_scan_blocksum leaves the tile
+// totals; k_scan_final adds up the totals in front of its tile itself (<= 1024 of them) instead of waiting for a third launch.
+__device__ __forceinline__ int4 scan_load4(const int* __restrict__ in, long long i, int n) {
+    int4 v = make_int4(0, 0, 0, 0);
+    if (i + 3 < n) v = *reinterpret_cast<const int4*>(in + i);
+    else { if (i < n) v.x = in[i]; if (i + 1 < n) v.y = in[i + 1]; if (i + 2 < n) v.z = in[i + 2]; }
+    return v;
+}
 __global__ __launch_bounds__(1024) void k_scan_blocksum(const int* __restrict__ in, int n, int* __restrict__ bsum) {
     __shared__ int s_w[16];
-    const long long i0 = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_PER;
     int v = 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_PER; ++k) v += i0 + k < n ? in[i0 + k] : 0;
+    for (int q = 0; q < SCAN_PER / 4; ++q) {
+        const int4 e = scan_load4(in, (long long)blockIdx.x * SCAN_TILE + ((long long)q * 1024 + threadIdx.x) * 4, n);
+        v += (e.x + e.y) + (e.z + e.w);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += s_w[w]; bsum[blockIdx.x] = t; }
 }
-__global__ __launch_bounds__(1024) void k_scan_sums(int* __restrict__ bsum, int nb, int* __restrict__ total_out) {
-    __shared__ int s[1024];
-    const int t = threadIdx.x;
-    s[t] = t < nb ? bsum[t] : 0;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) { const int v = t >= o ? s[t - o] : 0; __syncthreads(); s[t] += v; __syncthreads(); }
-    if (t == 0) *total_out = nb ? s[nb - 1] : 0;
-    __syncthreads();
-    if (t < nb) bsum[t] = t ? s[t - 1] : 0;
-}
-__global__ __launch_bounds__(1024) void k_scan_final(const int* __restrict__ in, int n, const int* __restrict__ bsum, int* __restrict__ out) {
-    __shared__ int s_w[16];
-    const long long i0 = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_PER;
+__global__ __launch_bounds__(1024) void k_scan_final(const int* __restrict__ in, int n, const int* __restrict__ bsum, int nb, int* __restrict__ out, int* __restrict__ total_out) {
+    __shared__ int s_w[16], s_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int e[SCAN_PER], v = 0;
+    {   // totals of the tiles in front of this one
+        int p = 0;
+        for (int i = threadIdx.x; i < (int)blockIdx.x; i += 1024) p += bsum[i];
 #pragma unroll
-    for (int k = 0; k < SCAN_PER; ++k) { e[k] = i0 + k < n ? in[i0 + k] : 0; v += e[k]; }
-    int inc = v;
+        for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
+        if (lane == 0) s_w[wave] = p;
+        __syncthreads();
+        if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += s_w[w]; s_base = t; if ((int)blockIdx.x == nb - 1) *total_out = t + bsum[blockIdx.x]; }
+        __syncthreads();
+    }
+    int run = s_base;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
-    if (lane == 63) s_w[wave] = inc;
-    __syncthreads();
-    int off = bsum[blockIdx.x] + inc - v;
-    for (int w = 0; w < wave; ++w) off += s_w[w];
+    for (int q = 0; q < SCAN_PER / 4; ++q) {
+        const long long i = (long long)blockIdx.x * SCAN_TILE + ((long long)q * 1024 + threadIdx.x) * 4;
+        const int4 e = scan_load4(in, i, n);
+        const int v = (e.x + e.y) + (e.z + e.w);
+        int inc = v;
 #pragma unroll
-    for (int k = 0; k < SCAN_PER; ++k) { if (i0 + k < n) out[i0 + k] = off; off += e[k]; }
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        __syncthreads();                                    // s_w of the previous round has been read
+        if (lane == 63) s_w[wave] = inc;
+        __syncthreads();
+        int off = run + inc - v, tot = 0;
+        for (int w = 0; w < 16; ++w) { const int sw = s_w[w]; if (w < wave) off += sw; tot += sw; }
+        const int4 o4 = make_int4(off, off + e.x, off + e.x + e.y, off + e.x + e.y + e.z);
+        if (i + 3 < n) *reinterpret_cast<int4*>(out + i) = o4;
+        else { if (i < n) out[i] = o4.x; if (i + 1 < n) out[i + 1] = o4.y; if (i + 2 < n) out[i + 2] = o4.z; }
+        run += tot;
+    }
 }
 __global__ void k_cut_count(CutTabs T, const int* __restrict__ kf_idx, const int* __restrict__ pt_flag, const int* __restrict__ pidx,
                             int* __restrict__ cnt, int* __restrict__ fixed_flag) {
@@ -2369,8 +2386,7 @@ static int scan_i32(hipStream_t st, const int* in, int n, int* bsum, int* out, i
     const int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (nb > 1024) return VO_E_UNSUPPORTED;
     hipLaunchKernelGGL(k_scan_blocksum, dim3(std::max(nb, 1)), dim3(1024), 0, st, in, n, bsum);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, bsum, nb, total);
-    hipLaunchKernelGGL(k_scan_final, dim3(std::max(nb, 1)), dim3(1024), 0, st, in, n, bsum, out);
+    hipLaunchKernelGGL(k_scan_final, dim3(std::max(nb, 1)), dim3(1024), 0, st, in, n, (const int*)bsum, std::max(nb, 1), out, total);
     return VO_OK;
 }
 
