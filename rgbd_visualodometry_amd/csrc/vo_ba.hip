@@ -1584,7 +1584,7 @@ static int ba_engine_enqueue(BaEngine* E) {
         g_e = std::max(g_e, j->grid_e);
         if (j->B.D <= BA_FOLD_D) {
             sA[nA++] = act[i];
-            gA_lin = std::max(gA_lin, j->grid_lin); gA_blk = std::max(gA_blk, j->B.n_blocks); gA_pose = std::max(gA_pose, j->B.n_free * PSPLIT); gA_up = std::max(gA_up, (j->B.n_points + UPC_T / 4 - 1) / (UPC_T / 4));
+            gA_lin = std::max(gA_lin, j->grid_lin); gA_blk = std::max(gA_blk, j->B.n_blocks); gA_pose = std::max(gA_pose, j->B.n_free * PSPLIT); gA_up = std::max(gA_up, j->B.n_points);
             ldsA = std::max(ldsA, j->lds); ldsA_up = std::max(ldsA_up, sizeof(double) * (24 * (size_t)j->B.n_poses + (size_t)j->B.D));
             gA_md = std::max(gA_md, (j->B.D + j->B.n_points + 255) / 256);
         } else {
@@ -1594,6 +1594,7 @@ static int ba_engine_enqueue(BaEngine* E) {
             ldsB = std::max(ldsB, j->lds);
         }
     }
+    const int up_rep = nA >= 2 ? 2 : 1;                     // points per workgroup of k_ba_upchi2: 128 x up_rep (vo_ba_phase2.h; 8 problems per launch: 45.7 / 40.7 / 41.0 / 88 us for 1 / 2 / 4 / 8)
     BaChunk& C = E->ring[(E->r_head + E->r_n) % 2];
     if (!C.ev_end) { HIP_TRY(hipEventCreateWithFlags(&C.ev_near, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&C.ev_end, hipEventDisableTiming)); }
     C.n = na; C.steps = chunk;
@@ -1614,7 +1615,7 @@ static int ba_engine_enqueue(BaEngine* E) {
             }
             { ProfScope ps(prof, "k_ba_schur2", st); hipLaunchKernelGGL(k_ba_schur2, dim3(gA_blk + gA_pose, 1, nA), blk, 0, st, QA); }
             { ProfScope ps(prof, "k_ba_chol16", st); hipLaunchKernelGGL(k_ba_chol16, dim3(1, 1, nA), dim3(CH_THREADS), ldsA, st, QA, 0, 1); }
-            { ProfScope ps(prof, "k_ba_upchi2", st); hipLaunchKernelGGL(k_ba_upchi2, dim3(gA_up, 1, nA), dim3(UPC_T), ldsA_up, st, QA); }
+            { ProfScope ps(prof, "k_ba_upchi2", st); hipLaunchKernelGGL(k_ba_upchi2, dim3((gA_up + up_rep * (UPC_T / 4) - 1) / (up_rep * (UPC_T / 4)), 1, nA), dim3(UPC_T), ldsA_up, st, QA, up_rep); }
         }
         if (nB) {
             { ProfScope ps(prof, "k_ba_lin", st); hipLaunchKernelGGL(k_ba_lin, dim3(gB_lin, 1, nB), blk, 0, st, QB); }

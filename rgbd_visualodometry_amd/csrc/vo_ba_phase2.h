@@ -230,10 +230,12 @@ __device__ __forceinline__ void p2_exp_mul(const double* d, const double* T, dou
 
 // trial state and its robust chi2, then (last workgroup) the LM decision of k_ba_chi_control
 #define UPC_T 512
-__global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q) {
+__global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q, int rep) {
     BA_PROBLEM(Q)
     if (ctl_->finished || B.D > BA_FOLD_D) return;
-    const int gp = (B.n_points + UPC_T / 4 - 1) / (UPC_T / 4);     // 128 points per workgroup (4 lanes each)
+    // 128 points per workgroup and round (4 lanes each), `rep` rounds: with several problems per launch every workgroup's fixed costs (the trial
+    // poses, the partial sums and the ticket) are spread over more points -- a lone problem keeps rep = 1 and the most workgroups
+    const int gp = (B.n_points + rep * (UPC_T / 4) - 1) / (rep * (UPC_T / 4));
     if ((int)blockIdx.x >= gp) return;
     extern __shared__ double s_dyn[];
     double* const s_T = s_dyn;                             // trial poses [n_poses][12]
@@ -258,19 +260,25 @@ __global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q) {
     const double* const Wt = p2_w(B, lb);
     double* const rec_n = p2_rec(B, lb ^ 1);
     double* const Wn = p2_w(B, lb ^ 1);
-    const int k = blockIdx.x * (UPC_T / 4) + (threadIdx.x >> 2), sub = threadIdx.x & 3;
-    const bool live = ok && k < B.n_points;
+    int k = blockIdx.x * rep * (UPC_T / 4) + (threadIdx.x >> 2);
+    const int sub = threadIdx.x & 3;
+    bool live = false;
     double H[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0}, p[3] = {0, 0, 0}, rhs[3] = {0, 0, 0};
     int q0 = 0, q1 = 0;
     int e0 = -1, j0 = 0; uint8_t act0 = 0; double w0 = 0; float2 uv0 = make_float2(0.f, 0.f);       // first edge of this lane (most points have <= 4 edges: one round)
-    if (live) {
-        q0 = B.pt_start[k]; q1 = B.pt_start[k + 1];
-        p2_rec_load(rec, k, H, bl, p);
-        if (q0 + sub < q1) {                               // (no branch on a loaded value here: the loads stay in flight across the pose block below)
-            const int e = B.edges_by_point ? q0 + sub : B.pt_edges[q0 + sub];
-            act0 = B.active[e]; e0 = e; j0 = B.e_pose[e]; w0 = Wt[e]; uv0 = reinterpret_cast<const float2*>(B.e_uv)[e];
+    auto fetch = [&]() {
+        live = ok && k < B.n_points;
+        e0 = -1; act0 = 0; q0 = q1 = 0;
+        if (live) {
+            q0 = B.pt_start[k]; q1 = B.pt_start[k + 1];
+            p2_rec_load(rec, k, H, bl, p);
+            if (q0 + sub < q1) {                           // (no branch on a loaded value here: the loads stay in flight across the pose block below)
+                const int e = B.edges_by_point ? q0 + sub : B.pt_edges[q0 + sub];
+                act0 = B.active[e]; e0 = e; j0 = B.e_pose[e]; w0 = Wt[e]; uv0 = reinterpret_cast<const float2*>(B.e_uv)[e];
+            }
         }
-    }
+    };
+    fetch();
     double* const s_Tc = s_dp + B.D;                        // current poses [n_poses][12] (pass 1 reads them per edge)
     for (int i = threadIdx.x; i < B.D; i += UPC_T) s_dp[i] = B.dl[i];           // the solution (k_ba_chol16, phase2 = 1)
     for (int j = threadIdx.x; j < B.n_poses; j += UPC_T) {   // exp(dp) * T for the free poses (ba_pose_body), copies for the fixed ones
@@ -300,9 +308,10 @@ __global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q) {
     }
     __syncthreads();
     P2_STAMP()
-    if (!act0) e0 = -1;
     double chi = 0, sc = 0, mx = 0;
-    {
+    for (int r = 0; r < rep; ++r, k += UPC_T / 4) {
+        if (r) { fetch(); rhs[0] = rhs[1] = rhs[2] = 0; }
+        if (!act0) e0 = -1;
         auto pass1 = [&](int j, double w) {                 // rhs -= W_e^T dp_j
             double T[12], Jp[2][6], Jl[2][3];
 #pragma unroll
