@@ -381,11 +381,14 @@ __global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q, int rep) {
     if (threadIdx.x == 0) {
         double a_ = 0, b_ = 0, m_ = 0;
         for (int w = 0; w < NWV; ++w) { a_ += s_w[w]; b_ += s_w[NWV + w]; m_ = fmax(m_, s_w[2 * NWV + w]); }
-        B.partU[3 * (size_t)blockIdx.x] = a_;
-        B.partU[3 * (size_t)blockIdx.x + 1] = b_;
-        B.partU[3 * (size_t)blockIdx.x + 2] = m_;
-        __threadfence();
-        s_last = atomicAdd(&ctl_->arrived, 1) == gp - 1;
+        // The partials leave as write-through (sc1) stores and the ticket follows once they have been performed: no release fence -- on this
+        // part a device-scope fence writes the XCD's dirty L2 lines back (this kernel has just produced megabytes of them), 1.5-5 us per
+        // workgroup in the clock stamps.  The last workgroup reads the partials past its own L2 (pb_ld).
+        pb_st(B.partU + 3 * (size_t)blockIdx.x, a_);
+        pb_st(B.partU + 3 * (size_t)blockIdx.x + 1, b_);
+        pb_st(B.partU + 3 * (size_t)blockIdx.x + 2, m_);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = __hip_atomic_fetch_add(&ctl_->arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gp - 1;
     }
     __syncthreads();
     P2_STAMP()
@@ -394,10 +397,9 @@ __global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q, int rep) {
 #endif
     if (!s_last) return;
     {   // the last workgroup: the partials of every workgroup, then g2o's gain-ratio test and lambda policy (as k_ba_chi_control)
-        __threadfence();
-        const volatile double* pu = B.partU;
+        const double* pu = B.partU;
         double a = 0, b = 0, m = 0;
-        for (int i = threadIdx.x; i < gp; i += UPC_T) { a += pu[3 * i]; b += pu[3 * i + 1]; m = fmax(m, pu[3 * i + 2]); }
+        for (int i = threadIdx.x; i < gp; i += UPC_T) { a += pb_ld(pu + 3 * i); b += pb_ld(pu + 3 * i + 1); m = fmax(m, pb_ld(pu + 3 * i + 2)); }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); m = fmax(m, __shfl_xor(m, o, 64)); }
         __syncthreads();
