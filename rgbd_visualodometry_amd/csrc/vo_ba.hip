@@ -1435,10 +1435,11 @@ __global__ __launch_bounds__(256) void k_ba_round(BaBatch Q) {
     if (e < B.n_edges) ba_cull_edge(B, poses_c, pts_c, e, stage);
     __shared__ int s_last;
     __syncthreads();
-    if (threadIdx.x == 0) { __threadfence(); s_last = atomicAdd(&ctl_->ticket, 1) == nblk - 1; }
+    // (no fences around the ticket: the last workgroup reads nothing the others wrote except scal[6], whose atomic adds are performed at the
+    // memory side before the barrier above lets thread 0 take the ticket; a device-scope fence here would write this XCD's L2 back)
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&ctl_->ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1;
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     if (stage == 0) {
         if (threadIdx.x < 8 && threadIdx.x != 5) B.scal[threadIdx.x] = 0;       // [5]: the initial chi2 (k_ba_chi at admission)
         for (int i = threadIdx.x; i < 36 * B.n_free; i += 256) B.Hpp[i] = 0;
@@ -1529,8 +1530,8 @@ static BaBatch ba_batch_of(BaEngine* E, const int* slots, int n) {
 }
 
 // admit queued problems into free slots (stream order: behind everything enqueued so far).  The descriptor is the only upload:
-// k_ba_admit writes the control block of the robust round (backend.cpp:140-141) and clears the accumulators, k_ba_chi leaves the
-// plain chi2 of the initial state in scal[5] (reporting only)
+// k_ba_admit writes the control block of the robust round (backend.cpp:140-141) and clears the accumulators; the plain chi2 of the
+// initial state (scal[5], reporting only) comes out of the first linearisation (k_ba_lin2; k_ba_chi for the larger systems)
 static int ba_engine_admit(BaEngine* E) {
     hipStream_t st = E->st;
     std::unique_lock<std::mutex> lk(E->mu);
@@ -1548,7 +1549,7 @@ static int ba_engine_admit(BaEngine* E) {
         if (rc == VO_OK) {
             const BaBatch Q = ba_batch_of(E, &s, 1);
             hipLaunchKernelGGL(k_ba_admit, dim3(1, 1, 1), dim3(256), 0, st, Q);
-            hipLaunchKernelGGL(k_ba_chi, dim3(j->grid_e, 1, 1), dim3(256), 0, st, Q, 0, 0, 0);
+            if (j->B.D > BA_FOLD_D) hipLaunchKernelGGL(k_ba_chi, dim3(j->grid_e, 1, 1), dim3(256), 0, st, Q, 0, 0, 0);      // (D <= 192: k_ba_lin2 sums it in passing)
         }
         lk.lock();
         if (rc != VO_OK) { j->rc = rc; j->done = true; E->slot[s] = nullptr; E->cv.notify_all(); }

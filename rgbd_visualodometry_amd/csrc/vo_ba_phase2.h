@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_ba_lin2(BaBatch Q) {
     double* const rec = p2_rec(B, ctl_->lbuf);
     double* const Wt = p2_w(B, ctl_->lbuf);
     const int k = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
-    double chi[1] = {0.0};
+    double chi[2] = {0.0, 0.0};                            // robust chi2 of the linearisation; plain chi2 (the initial state's, reported as chi2_initial)
     double H[6] = {0, 0, 0, 0, 0, 0}, b3[3] = {0, 0, 0}, p[3] = {0, 0, 0};
     if (k < B.n_points) {
         p[0] = pts_c[3 * (size_t)k]; p[1] = pts_c[3 * (size_t)k + 1]; p[2] = pts_c[3 * (size_t)k + 2];
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void k_ba_lin2(BaBatch Q) {
             double r[2], w, rho0, Jp[2][6], Jl[2][3];
             ba_edge(B.cam, poses_c + 12 * (size_t)B.e_pose[e], p, B.e_uv + 2 * (size_t)e, robust, B.delta, r, w, rho0, Jp, Jl);
             Wt[e] = w;
-            chi[0] += rho0;
+            chi[0] += rho0; chi[1] += r[0] * r[0] + r[1] * r[1];
             b3[0] -= w * (Jl[0][0] * r[0] + Jl[1][0] * r[1]); b3[1] -= w * (Jl[0][1] * r[0] + Jl[1][1] * r[1]); b3[2] -= w * (Jl[0][2] * r[0] + Jl[1][2] * r[1]);
             H[0] += w * (Jl[0][0] * Jl[0][0] + Jl[1][0] * Jl[1][0]); H[1] += w * (Jl[0][0] * Jl[0][1] + Jl[1][0] * Jl[1][1]); H[2] += w * (Jl[0][0] * Jl[0][2] + Jl[1][0] * Jl[1][2]);
             H[3] += w * (Jl[0][1] * Jl[0][1] + Jl[1][1] * Jl[1][1]); H[4] += w * (Jl[0][1] * Jl[0][2] + Jl[1][1] * Jl[1][2]); H[5] += w * (Jl[0][2] * Jl[0][2] + Jl[1][2] * Jl[1][2]);
@@ -71,8 +71,9 @@ __global__ __launch_bounds__(256) void k_ba_lin2(BaBatch Q) {
     for (int i = 0; i < 3; ++i) b3[i] = ba_quad_sum(b3[i]);
     if (k < B.n_points && sub == 0) p2_rec_store(rec, k, H, b3, p);
     ba_fold_zero(B, blockIdx.x, gp);
-    ba_block_reduce<1>(chi, s_part);
+    ba_block_reduce<2>(chi, s_part);
     if (threadIdx.x == 0 && chi[0] != 0.0) atomicAdd(&B.scal[0], chi[0]);
+    if (threadIdx.x == 0 && chi[1] != 0.0 && ctl_->stage == 0) atomicAdd(&B.scal[5], chi[1]);      // (the first-generation path has k_ba_chi for this)
 }
 
 __global__ void k_ba_maxdiag2(BaBatch Q) {
@@ -411,8 +412,9 @@ __global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q, int rep) {
         c->arrived = 0;
         double s1 = 0, sB = 0, mB = 0;
         for (int w = 0; w < NWV; ++w) { s1 += s_w[w]; sB += s_w[NWV + w]; mB = fmax(mB, s_w[2 * NWV + w]); }
-        const volatile double* scv = B.scal;
-        const double sc2 = scv[2], sc7 = scv[7];
+        // block 0's atomics on scal[2] / scal[7] were performed at the memory side; this workgroup's XCD may still hold the line it read
+        // scal[3] from at the start: agent-scope loads go past that L2 (there is no acquire fence in this kernel any more)
+        const double sc2 = pb_ld(B.scal + 2), sc7 = pb_ld(B.scal + 7);
         const double s2 = sc2 + sB;
         const double m7 = fmax(sc7, mB);
         const double tmp = ok ? s1 : DBL_MAX;
@@ -429,6 +431,9 @@ __global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q, int rep) {
             B.scal[0] = tmp; B.scal[4] = 0;                 // and its chi2 is the trial chi2 (k_ba_chol16 takes it over as `cur`)
         } else { c->lambda *= c->ni; c->ni *= 2; }
         if (ok) converged = m7 < 1e-10;
+#ifdef P2_STAMPS
+        if (B.n_points < 1000) printf("[upchi2 ctl] stage %d it %d qmax %d ok %d cur %.12e trial %.12e rho %.3e scale %.3e m7 %.3e (pose part %.3e) lambda %.3e\n", c->stage, c->it, c->qmax, (int)ok, c->cur, tmp, rho, scale, m7, sc7, c->lambda);
+#endif
         c->qmax += 1; c->steps += 1;
         if (!(rho < 0 && c->qmax < 10 && !converged)) {     // this LM iteration is over
             c->iters_done += 1;

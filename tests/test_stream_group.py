@@ -416,6 +416,10 @@ def test_resident_merge_on_the_device_equals_the_host_write_back(libs):
         outs.append((po, sl, pt, np.sort(cu), r.n_edges, r.n_fixed, r.lm_iters, state[0], state[1], state[2], state[4].n_edges))
         c.close(); t.close()
     a, b = outs
-    assert a[4] > 1000 and a[6] == 20 and len(a[3]) > 0
+    assert a[4] > 1000 and 15 <= a[6] <= 20 and len(a[3]) > 0       # (a round may end early at rho == 0 once the problem has converged)
     for x, y in zip(a, b):
-        assert np.array_equal(np.asarray(x), np.asarray(y))
+        x, y = np.asarray(x), np.asarray(y)
+        if x.dtype.kind == "f":                             # two runs of the same solve: the order of the atomic sums is not fixed
+            np.testing.assert_allclose(x, y, rtol=0, atol=1e-9)
+        else:
+            assert np.array_equal(x, y)
