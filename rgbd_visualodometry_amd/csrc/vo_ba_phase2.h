@@ -94,6 +94,9 @@ __device__ __forceinline__ void p2_schur_slice(const BaDev& B, const BaBlock blk
     double v[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) v[i] = 0;
+#ifdef P2_STAMPS
+    long long ts_[5]; ts_[0] = wall_clock64();
+#endif
     double T1[12], T2[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) { T2[i] = poses_c[12 * (size_t)blk.j2 + i]; T1[i] = DIAG ? 0.0 : poses_c[12 * (size_t)blk.j1 + i]; }
@@ -140,6 +143,9 @@ __device__ __forceinline__ void p2_schur_slice(const BaDev& B, const BaBlock blk
             }
         }
     }
+#ifdef P2_STAMPS
+    ts_[1] = wall_clock64();
+#endif
     {
         double r0[8], r1[8];
         {
@@ -174,6 +180,10 @@ __device__ __forceinline__ void p2_schur_slice(const BaDev& B, const BaBlock blk
     } else if (DIAG && threadIdx.x < 42) {
         atomicAdd(&B.bs[6 * blk.j1 + threadIdx.x - 36], -s_tot[threadIdx.x]);
     }
+#ifdef P2_STAMPS
+    ts_[2] = wall_clock64();
+    if (threadIdx.x == 0 && blockIdx.z == 0 && (blockIdx.x % 97) == 5 && B.n_points > 1000) printf("[schur2 wg %d, %d pairs, diag %d] 10 ns ticks: loads + compute %lld | reduce + atomics issued %lld\n", (int)blockIdx.x, blk.count, (int)DIAG, ts_[1] - ts_[0], ts_[2] - ts_[1]);
+#endif
 }
 __global__ __launch_bounds__(256) void k_ba_schur2(BaBatch Q) {
     BA_PROBLEM(Q)
