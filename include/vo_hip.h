@@ -155,7 +155,9 @@ int vo_default_params(vo_params* p);        /* fills default.yaml + TUM fr1 valu
 int vo_default_track_params(vo_track_params* tp);
 
 /* ---- frames ------------------------------------------------------------------------ */
-/* Copy a BGR8 + depth16 frame from host memory into frame slot `slot` (strides in bytes). */
+/* Copy a BGR8 + depth16 frame from host memory into frame slot `slot` (strides in bytes).  Pageable sources: the call returns when
+ * the copies are done.  Page-locked sources (hipHostMalloc / hipHostRegister / torch pin_memory): the copies are enqueued and the call
+ * returns at once -- the buffers must stay untouched until the next call that waits for the context (vo_orb_detect_describe, vo_sync). */
 int vo_frame_upload(vo_ctx* ctx, int slot, const uint8_t* bgr, int bgr_stride,
                     const uint16_t* depth, int depth_stride);
 /* Use frames already resident in device memory (no copy; pointers must stay valid until the

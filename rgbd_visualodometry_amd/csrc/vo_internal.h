@@ -81,6 +81,7 @@ struct vo_ctx {
     hipStream_t stream;
     // frames
     std::vector<uint8_t*> own_bgr, own_depth;       // per slot (allocated lazily on upload)
+    std::vector<size_t> own_bgr_bytes, own_depth_bytes;
     SlotDesc* d_slots; std::vector<SlotDesc> h_slots;
     SlotDesc* h_slots_pinned; hipEvent_t slots_ev; bool slots_dirty, slots_pending;
     std::vector<char> slot_bound, slot_orb;

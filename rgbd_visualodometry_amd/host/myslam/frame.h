@@ -18,6 +18,10 @@ public:
 
     // Host images are deep-copied (frame.cpp:28-29); device-resident images are referenced.
     static Frame::Ptr CreateFrame(const double timestamp, const Camera::Ptr camera, const Mat color, const Mat depth);
+    // The same without the deep copy, for callers that keep their buffers alive until the frame has been consumed (the C wrapper's
+    // contract, include/myslam_c.h): the frame's pixels are read exactly once, by the upload into its frame slot (the depth samples
+    // the reference takes from Frame::depth_ later, src/frame.cpp:43-67, are taken on the device beside the keypoints).
+    static Frame::Ptr CreateFrameView(const double timestamp, const Camera::Ptr camera, const Mat color, const Mat depth);
 
     size_t GetId() const { return id_; }
     SE3 GetPose() { std::unique_lock<std::mutex> lck(poseLock_); return pose_cw_; }

@@ -10,6 +10,10 @@ Frame::Ptr Frame::CreateFrame(const double timestamp, const Camera::Ptr camera, 
     return Frame::Ptr(new Frame(nextId_.fetch_add(1) + 1, timestamp, camera, color.clone(3), depth.clone(2)));
 }
 
+Frame::Ptr Frame::CreateFrameView(const double timestamp, const Camera::Ptr camera, const Mat color, const Mat depth) {
+    return Frame::Ptr(new Frame(nextId_.fetch_add(1) + 1, timestamp, camera, color, depth));
+}
+
 Frame::Frame(const size_t id, const double timestamp, const Camera::Ptr camera, const Mat color, const Mat depth)
     : timestamp_(timestamp), camera_(camera), color_(color), depth_(depth), id_(id), pose_cw_(SE3()) {}
 

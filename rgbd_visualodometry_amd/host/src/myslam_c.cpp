@@ -34,7 +34,7 @@ Frame::Ptr make_frame(myslam_system* s, double stamp, const void* bgr, const voi
     Image c, d;
     c.data = bgr; c.rows = s->opt.height; c.cols = s->opt.width; c.stride = bs; c.on_device = on_device != 0;
     d.data = depth; d.rows = s->opt.height; d.cols = s->opt.width; d.stride = ds; d.on_device = on_device != 0;
-    return Frame::CreateFrame(stamp, s->camera, c, d);
+    return Frame::CreateFrameView(stamp, s->camera, c, d);      // the caller's buffers stay valid until the frame has been consumed (myslam_c.h)
 }
 void out_pose(const Frame::Ptr& f, double T_wc[12]) { if (T_wc) f->GetPose().inverse().to12(T_wc); }
 }  // namespace
