@@ -1434,6 +1434,7 @@ __global__ __launch_bounds__(256) void k_ba_round(BaBatch Q) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e < B.n_edges) ba_cull_edge(B, poses_c, pts_c, e, stage);
     __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every wave's atomic adds on scal[6] have been performed before the barrier (a workgroup-scope barrier alone need not wait for them)
     __syncthreads();
     // (no fences around the ticket: the last workgroup reads nothing the others wrote except scal[6], whose atomic adds are performed at the
     // memory side before the barrier above lets thread 0 take the ticket; a device-scope fence here would write this XCD's L2 back)
