@@ -479,3 +479,24 @@ def test_orb_cut_bin_overflow_is_bit_exact(libs):
     for field in ("x", "y", "octave", "class_id"):
         assert np.array_equal(kh[field], ko[field]), field
     assert np.array_equal(dh, do)
+
+
+def test_frame_upload_keeps_the_callers_strides(frames, libs):
+    """vo_frame_upload takes any row stride >= the tight one (the slot keeps it: one contiguous copy per image) and a slot may be
+    re-uploaded with a different stride; the ORB result does not depend on it."""
+    import ctypes as C
+    bgr, depth, _, _ = frames
+    H, _ = libs
+    c, _ = make_ctx(H, n_features=500, max_frames=2)
+    c.upload(0, bgr[3], depth[3])                                        # tight: 1920 / 1280 bytes per row
+    pb = np.zeros((480, 2048), np.uint8); pb[:, :1920] = bgr[3].reshape(480, 1920)
+    pd = np.zeros((480, 704), np.uint16); pd[:, :640] = depth[3]
+    c.upload(1, bgr[5], depth[5])                                        # slot 1: tight first, then padded rows (a larger image buffer)
+    H.check(H.lib.vo_frame_upload(c.h, 1, C.c_void_p(pb.ctypes.data), 2048, C.c_void_p(pd.ctypes.data), 1408), "vo_frame_upload")
+    c.orb(0, 2)
+    k0, d0 = c.orb_fetch(0)
+    k1, d1 = c.orb_fetch(1)
+    for field in ("x", "y", "octave", "depth_raw"):
+        assert np.array_equal(k0[field], k1[field]), field
+    assert np.array_equal(d0, d1) and len(k0) == 500
+    c.close()
