@@ -4,18 +4,25 @@
 // residual/Jacobians (include/myslam/g2o_types.h:143-167), Huber delta sqrt(7.815), Levenberg-
 // Marquardt with g2o's lambda/rho policy, 10 robust iterations + chi2 cull + 10 plain ones.
 //
+// Systems the LDS-resident Cholesky solves (6K <= 192, i.e. up to 32 free poses) take the three-launch LM step of vo_ba_phase2.h:
+//   k_ba_schur2       pair lists -> packed lower triangle of S from per-point records (rank-2 form) + H_pp / b_p sums
+//   k_ba_chol16       dense Cholesky + solve of [S b; b^T 0] in one workgroup (packed triangle by LDS-DMA, 16-column DPP panels,
+//                     f64 MFMA trailing update); clears S behind its load
+//   k_ba_upchi2       back-substitution, trial state, robust chi2, LM decision, and the linearisation at the trial state
+//   k_ba_lin2 / k_ba_maxdiag2   first step of a round only
+// Larger systems keep the first-generation step:
 //   k_ba_lin          4 lanes per point: r, J_pose (2x6), J_point (2x3) = J_pose[:,0:3] R, Huber weight, H_ll / b_l / W_e
-//                     (no atomics), (H_ll + lambda I)^-1, S = 0; 4 workgroups per free pose: H_pp / b_p
-//   k_ba_init_S       only for 6K > 192 (S = blockdiag(H_pp) + lambda I, b_s = b_p, the inverses) and on the first step of a
-//                     round (the inverses, once k_ba_maxdiag has produced lambda): otherwise folded into k_ba_lin / k_ba_chol16
+//                     (no atomics); 4 workgroups per free pose: H_pp / b_p
+//   k_ba_init_S       S = blockdiag(H_pp) + lambda I, b_s = b_p, (H_ll + lambda I)^-1
 //   k_ba_schur_blocks one workgroup per <= 512-pair slice of a 6x6 block: S -= W_e1 Hinv W_e2^T, b_s -= W_e Hinv b_l
-//   k_ba_chol16       dense Cholesky + solve of the reduced 6K x 6K system in one workgroup (16-column DPP panels,
-//                     f64 MFMA trailing update); k_ba_chol16g (matrix in L2, panel in LDS) for 6K > 192
+//   k_ba_chol16g      the same Cholesky with the matrix in global memory (L2), panel in LDS
 //   k_ba_update       trial points (back-substitution) and trial poses exp(dp) * T, gain-ratio terms
 //   k_ba_chi_control  robust chi2 of the trial state; the last workgroup runs the LM accept / lambda policy
-// The LM state (lambda, current chi2, iteration counters, which of the two state buffers is current) lives in a
-// device-resident control block, so a whole round of LM steps is enqueued back to back and the host polls
-// `finished` once per chunk.
+// The LM state (lambda, current chi2, iteration counters, round, which of the two state / linearisation buffers is current) lives in
+// a device-resident control block: k_ba_admit starts a problem, k_ba_round moves it from the robust round through the cull to the
+// plain round and on to "done" and reports to pinned host memory -- the BA engine (further down) enqueues chunks of steps over all
+// problems in flight without waiting for any of that.  vo_ba_persist.h holds the opt-in one-launch-per-BA variant; the second half
+// of this file is the device-resident graph cut and merge.
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
