@@ -8,6 +8,8 @@
 //                   keypoints (gridDim.y slices): 8 wavefronts, each with a 64-descriptor tile in LDS per round (wave-wide
 //                   broadcast reads), 8 chained v_bcnt per pair; the partial minima meet in LDS and ONE atomicMin per candidate
 //                   and workgroup updates best[q] = (dist << 22) | keypoint (first minimum wins)
+//   k_match_mfma    the same search on the matrix cores for larger frames (>= 8 Mi map-point x feature pairs): descriptor bits as +-1 bytes,
+//                   v_mfma_i32_16x16x64_i8 leaves 2 x Hamming distance; same packed key, bit-identical results
 //   k_match_gate    min distance, gate max(min * ratio, 30) (src/frontend.cpp:190-211), ORDER-PRESERVING compaction
 //   k_match_emit    match records and the float32 3-D / 2-D pairs (:225-230) by output position
 //   k_ransac_hyp    one lane per hypothesis: counter-based 4-sample, Grunert P3P, 4th point disambiguates
@@ -28,6 +30,7 @@
 #include <cstdio>
 #include <cstring>
 
+#include <type_traits>
 #include "vo_internal.h"
 #include "vo_reduce.h"
 
@@ -179,6 +182,120 @@ __global__ __launch_bounds__(64 * MW) void k_match(const LaneDesc* __restrict__ 
             if (c0 + lane < ncand && m != MATCH_NONE) atomicMin(&best[q], m);
         }
         __syncthreads();
+    }
+}
+
+// ---- the same search on the matrix cores ------------------------------------------------------------------------------------------
+// Hamming distance as a dot product: with every descriptor bit written as a byte (+1 / -1 for a keypoint, -1 / +1 for a candidate) the
+// int8 dot product over the 256 bits is  -(256 - 2 h) ; with the accumulator started at 256 the MFMA leaves D = 2 h.  One
+// v_mfma_i32_16x16x64_i8 covers 16 candidates x 16 keypoints x 64 bits: four of them per 16 x 16 tile -- 256 pairs per 128 cycles of one
+// wave's matrix pipe against 64 pairs per ~90 cycles of its vector ALU in k_match.  The result is the same packed key
+// (distance << 22 | keypoint index, unsigned minimum = first minimum), so both kernels are interchangeable bit for bit; this one pays
+// off once the expansion of a 64-keypoint tile into bytes (every workgroup redoes it for the tiles it visits) is shared by enough
+// candidates: it is used above MMF_MIN_PAIRS candidate-keypoint pairs (host launcher).
+// A workgroup = 4 waves x 32 candidates (two 16-row A operand sets per wave, built once) x a slice of the keypoints; keypoint tiles of 64
+// are expanded into LDS rows of 272 bytes (256 + 16: the 16-byte operand reads of 16 consecutive rows then fall into different banks).
+// Operand maps (checked with exact integer data by the parity tests: tests/test_gpu_parity.py): lane l supplies, for k-step s,
+// bits 64 s + 16 (l >> 4) .. + 15 of row / column (l & 15); D: column = l & 15, rows 4 (l >> 4) + 0..3.
+#define MMF_NA 4                    // 16-candidate operand sets per wave
+#define MMF_CAND (64 * MMF_NA)
+#define MMF_MIN_PAIRS (8ll << 20)             // active map points x features per frame from which the launcher takes this kernel: 4.6 k x 500 -> k_match (14.8 vs 20.1 us), 21 k x 2000 -> here (50.6 vs 73.1 us), 41 k x 8000 -> here (235 vs 520 us)
+#define MMF_ROW 272
+typedef int mmf_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t mmf_expand4(uint32_t x, uint32_t flip) {       // 4 bits -> 4 bytes: bit set -> +1 (flip = 0xFFFFFFFF) / -1 (flip = 0x01010101)
+    const uint32_t y = (x * 0x00204081u) & 0x01010101u;      // bit i -> byte i (no two partial products share a bit position)
+    return (y * 0xFEu) ^ flip;                                 // byte 0 -> flip byte, byte 1 -> 0xFE ^ flip byte
+}
+__device__ __forceinline__ mmf_v4i mmf_expand16(uint32_t bits, uint32_t flip) {
+    mmf_v4i v;
+    v[0] = (int)mmf_expand4(bits & 15u, flip); v[1] = (int)mmf_expand4((bits >> 4) & 15u, flip);
+    v[2] = (int)mmf_expand4((bits >> 8) & 15u, flip); v[3] = (int)mmf_expand4((bits >> 12) & 15u, flip);
+    return v;
+}
+__global__ __launch_bounds__(256) void k_match_mfma(const LaneDesc* __restrict__ lanes) {
+    LANE_PTRS(lanes)
+    const uint32_t* __restrict__ map_desc = ld_.map_desc; const int32_t* __restrict__ active = ld_.active;
+    __shared__ __attribute__((aligned(16))) uint8_t s_kp[MT * MMF_ROW];
+    const int nkp = *nkp_p, ncand = tr->pad0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
+    const bool slab = 2 * (long long)ld_.n_active <= (long long)ld_.cap;
+    for (int c0 = blockIdx.x * MMF_CAND; c0 < ncand; c0 += gridDim.x * MMF_CAND) {
+        // ---- A operands: candidates c0 + 16 MMF_NA wave + 16 a + r16; per k-step s one 16-byte operand (bits 64 s + 16 g .. + 15)
+        mmf_v4i A[MMF_NA][4];
+#pragma unroll
+        for (int a = 0; a < MMF_NA; ++a) {
+            const int ci = min(c0 + 16 * MMF_NA * wave + 16 * a + r16, ncand - 1);      // clamped: every lane computes, only valid ones store
+            const uint32_t* qd = slab ? (const uint32_t*)((const uint4*)matches + 2 * (size_t)ci) : map_desc + (size_t)active[cand[ci]] * 8;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const uint32_t w = qd[2 * s4 + (g >> 1)];
+                A[a][s4] = mmf_expand16((w >> (16 * (g & 1))) & 0xFFFFu, 0x01010101u);         // candidate side carries the minus sign
+            }
+        }
+        uint32_t best_k[MMF_NA][4];
+#pragma unroll
+        for (int a = 0; a < MMF_NA; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) best_k[a][q] = MATCH_NONE;
+        for (int t0 = blockIdx.y * MT; t0 < nkp; t0 += gridDim.y * MT) {
+            __syncthreads();                                // the previous tile has been consumed
+            {   // expand keypoints t0 .. t0 + 63: thread -> (keypoint, quarter of its descriptor = 2 words = 64 bytes)
+                const int kp = threadIdx.x >> 2, qtr = threadIdx.x & 3;
+                const int src = min(t0 + kp, nkp - 1);
+                const uint2 w2 = *reinterpret_cast<const uint2*>(fdesc + (size_t)src * 8 + 2 * qtr);
+                mmf_v4i* dst = reinterpret_cast<mmf_v4i*>(s_kp + kp * MMF_ROW + 64 * qtr);
+                dst[0] = mmf_expand16(w2.x & 0xFFFFu, 0xFFFFFFFFu); dst[1] = mmf_expand16(w2.x >> 16, 0xFFFFFFFFu);
+                dst[2] = mmf_expand16(w2.y & 0xFFFFu, 0xFFFFFFFFu); dst[3] = mmf_expand16(w2.y >> 16, 0xFFFFFFFFu);
+            }
+            __syncthreads();
+            // (the test for columns past the end sits in a workgroup-uniform branch: only the last tile of a lane's keypoints pays for it,
+            // and no MFMA runs under a divergent EXEC mask)
+            auto tile = [&](auto partial_c) {
+                constexpr bool PARTIAL = decltype(partial_c)::value;
+#pragma unroll
+                for (int sub = 0; sub < MT / 16; ++sub) {
+                    const uint8_t* row = s_kp + (16 * sub + r16) * MMF_ROW + 16 * g;
+                    const mmf_v4i b0 = *reinterpret_cast<const mmf_v4i*>(row), b1 = *reinterpret_cast<const mmf_v4i*>(row + 64),
+                                  b2 = *reinterpret_cast<const mmf_v4i*>(row + 128), b3 = *reinterpret_cast<const mmf_v4i*>(row + 192);
+                    const uint32_t kpi = (uint32_t)(t0 + 16 * sub + r16);
+                    const bool kvalid = !PARTIAL || (int)kpi < nkp;
+#pragma unroll
+                    for (int a = 0; a < MMF_NA; ++a) {
+                        mmf_v4i acc = {256, 256, 256, 256};
+                        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[a][0], b0, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[a][1], b1, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[a][2], b2, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[a][3], b3, acc, 0, 0, 0);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {       // acc = 2 h: key = (h << 22) | kp = (acc << 21) + kp (one v_lshl_add_u32)
+                            const uint32_t key = (((uint32_t)acc[q]) << 21) + kpi;
+                            best_k[a][q] = min(best_k[a][q], PARTIAL ? (kvalid ? key : MATCH_NONE) : key);
+                        }
+                    }
+                }
+            };
+            if (t0 + MT > nkp) tile(std::true_type{}); else tile(std::false_type{});
+        }
+        // ---- register q of lane (g, r16) holds candidate 4 g + q of set a, minimum over the keypoint columns r16 + 16 k it has seen:
+        // the 16 lanes of a DPP row finish the minimum, lane r16 == 0 publishes
+#pragma unroll
+        for (int a = 0; a < MMF_NA; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t v = best_k[a][q];
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o, 64));
+                best_k[a][q] = v;
+            }
+        if (r16 == 0) {
+#pragma unroll
+            for (int a = 0; a < MMF_NA; ++a)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ci = c0 + 16 * MMF_NA * wave + 16 * a + 4 * g + q;
+                    if (ci < ncand && best_k[a][q] != MATCH_NONE) atomicMin(&best[cand[ci]], best_k[a][q]);
+                }
+        }
     }
 }
 
@@ -1066,9 +1183,19 @@ int vo_track_match_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* dl, int 
         ProfScope ps(prof, "k_match", st);
         // keypoint rounds (8 tiles = 512 keypoints) are spread over up to 4 workgroups only while the launch stays within ~4 workgroups per compute
         // unit: every extra slice re-reads the candidate tile (usually through another XCD's L2) and adds an atomicMin per candidate
+        const char* mmf_s = getenv("VO_MATCH_MFMA");        // tests / experiments: 0 = never, 1 = always (read per launch)
+        const int mmf_env = mmf_s ? atoi(mmf_s) : -1;
+        const bool use_mfma = mmf_env >= 0 ? mmf_env != 0 : (long long)na * dims.max_feat >= MMF_MIN_PAIRS;
+        if (use_mfma) {
+            // candidate tiles of 128; the keypoint tiles of a lane are spread over as many workgroups as keep the grid within ~4 per compute unit
+            const int ct = std::min((na + MMF_CAND - 1) / MMF_CAND, MATCH_GRID_X), kt = (dims.max_feat + MT - 1) / MT;
+            const int ksplit = std::max(1, std::min(kt, 1024 / std::max(1, ct * std::max(1, nl))));
+            hipLaunchKernelGGL(k_match_mfma, dim3(ct, ksplit, nl), dim3(256), 0, st, dl);
+        } else {
         const int tiles = std::min((na + MQ - 1) / MQ, MATCH_GRID_X) * std::max(1, nl);
         const int ksplit = std::max(1, std::min(std::min(4, (dims.max_feat + MW * MT - 1) / (MW * MT)), 1024 / std::max(1, tiles)));
         hipLaunchKernelGGL(k_match, dim3(std::min((na + MQ - 1) / MQ, MATCH_GRID_X), ksplit, nl), dim3(64 * MW), 0, st, dl);
+        }
     }
     { ProfScope ps(prof, "k_match_gate", st);
       const size_t lds = sizeof(uint32_t) * (((size_t)std::min(na, GATE_LDS_MAX) + 3) & ~(size_t)3);

@@ -500,3 +500,24 @@ def test_frame_upload_keeps_the_callers_strides(frames, libs):
         assert np.array_equal(k0[field], k1[field]), field
     assert np.array_equal(d0, d1) and len(k0) == 500
     c.close()
+
+
+@pytest.mark.parametrize("mfma", ["0", "1"])
+def test_both_matching_kernels_give_the_oracles_matches(frames, libs, mfma, monkeypatch):
+    """k_match (vector ALU) and k_match_mfma (int8 matrix cores) are interchangeable bit for bit: the launcher picks by problem size; here
+    each is forced in turn (VO_MATCH_MFMA, read per launch) on a frame with a partial last keypoint tile."""
+    monkeypatch.setenv("VO_MATCH_MFMA", mfma)
+    bgr, depth, Twc, _ = frames
+    H, O = libs
+    out = {}
+    for name, L in (("hip", H), ("oracle", O)):
+        c, p = make_ctx(L, n_features=777, max_frames=2, map_capacity=4096)          # 777 keypoints: 12 full tiles of 64 + 9
+        c.upload(0, bgr[0], depth[0]); c.upload(1, bgr[4], depth[4])
+        c.orb(0, 2)
+        k0, d0 = c.orb_fetch(0)
+        n = seed_map(c, p, k0, d0, Twc[0])
+        r, m = c.track(1, inv12(Twc[0]), L.default_track_params())
+        out[name] = (n, r.n_candidates, r.n_matches, m)
+        c.close()
+    assert out["hip"][:3] == out["oracle"][:3] and out["hip"][1] > 300
+    assert np.array_equal(out["hip"][3], out["oracle"][3])
