@@ -61,6 +61,7 @@ def algorithmic_bytes(W, H, N, A, M, K, I, n_hyp, passes=2):
         "k_describe": (709 + 512) * N + 32 * N + 64 * N,          # IC disc (709 px) + 512 BRIEF samples, kp in/out + descriptor
         "k_frustum": passes * (53 * A + 4 * M),                   # position + normal + flag + index in, candidate list out
         "k_match": passes * (32 * M + 32 * N + 8 * M),
+        "k_match_mfma": passes * (32 * M + 32 * N + 8 * M),       # the same search on the int8 matrix cores (larger frames)
         "k_match_gate": passes * (4 * A + 4 * K),
         "k_match_emit": passes * (36 * K + 36 * K),
         "k_ransac_hyp": passes * (20 * 4 * n_hyp + 96 * n_hyp),

@@ -1180,14 +1180,14 @@ int vo_track_match_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* dl, int 
     if (na > 0) {
         { ProfScope ps(prof, "k_frustum", st);
           hipLaunchKernelGGL(k_frustum, dim3((na + 255) / 256, 1, nl), dim3(256), 0, st, dl); }
-        ProfScope ps(prof, "k_match", st);
-        // keypoint rounds (8 tiles = 512 keypoints) are spread over up to 4 workgroups only while the launch stays within ~4 workgroups per compute
-        // unit: every extra slice re-reads the candidate tile (usually through another XCD's L2) and adds an atomicMin per candidate
         const char* mmf_s = getenv("VO_MATCH_MFMA");        // tests / experiments: 0 = never, 1 = always (read per launch)
         const int mmf_env = mmf_s ? atoi(mmf_s) : -1;
         const bool use_mfma = mmf_env >= 0 ? mmf_env != 0 : (long long)na * dims.max_feat >= MMF_MIN_PAIRS;
+        ProfScope ps(prof, use_mfma ? "k_match_mfma" : "k_match", st);
+        // keypoint rounds (8 tiles = 512 keypoints) are spread over up to 4 workgroups only while the launch stays within ~4 workgroups per compute
+        // unit: every extra slice re-reads the candidate tile (usually through another XCD's L2) and adds an atomicMin per candidate
         if (use_mfma) {
-            // candidate tiles of 128; the keypoint tiles of a lane are spread over as many workgroups as keep the grid within ~4 per compute unit
+            // candidate tiles of MMF_CAND; the keypoint tiles of a lane are spread over as many workgroups as keep the grid within ~4 per compute unit
             const int ct = std::min((na + MMF_CAND - 1) / MMF_CAND, MATCH_GRID_X), kt = (dims.max_feat + MT - 1) / MT;
             const int ksplit = std::max(1, std::min(kt, 1024 / std::max(1, ct * std::max(1, nl))));
             hipLaunchKernelGGL(k_match_mfma, dim3(ct, ksplit, nl), dim3(256), 0, st, dl);
