@@ -55,7 +55,7 @@ struct BaCtl {
 };
 
 // What the host needs to know about a slot, written by k_ba_round straight into pinned host memory (no read-back copy per chunk of steps)
-struct BaStat { int gen, stage, finished, it, buf, iters_total, steps, pad_; double chi0, chi_final; };
+struct BaStat { int gen, stage, finished, it, buf, iters_total, steps, n_culled; double chi0, chi_final; };
 
 struct BaDev {
     int n_poses, n_free, n_points, n_edges, D, n_blocks;
@@ -63,6 +63,9 @@ struct BaDev {
     int edges_by_point;                                      // 1: the edges are grouped by point, pt_edges is the identity
     BaCam cam; double delta, chi2_th;
     int it_robust, it_plain, gen, pad_;                      // iterations of the two rounds (backend.cpp:141,159); gen: the engine's admission counter (stale status records are told apart by it)
+    // resident graphs only (nullptr otherwise): observation id per edge; the ids of the culled edges are collected by k_ba_round's final
+    // stage (device list for the merge kernel, first cull_host_cap of them also in pinned host memory: no list kernel, no read-back copy)
+    const long long* e_obs; long long* cull; int* ncull; int cull_cap; long long* cull_host; int cull_host_cap;
     BaCtl* ctl;
     double* posesA; double* ptsA; double* posesB; double* ptsB;      // double-buffered state, ctl->buf selects the current one
     const int32_t* e_pose; const int32_t* e_pt; const float* e_uv; uint8_t* active; uint8_t* flags;
@@ -1418,6 +1421,7 @@ __global__ __launch_bounds__(256) void k_ba_admit(BaBatch Q) {
         *ctl_ = c;
     }
     if (threadIdx.x < 8) B.scal[threadIdx.x] = 0;
+    if (threadIdx.x == 8 && B.ncull) *B.ncull = 0;
     for (int i = threadIdx.x; i < 36 * B.n_free; i += 256) B.Hpp[i] = 0;
     for (int i = threadIdx.x; i < B.D; i += 256) B.bp[i] = 0;
 }
@@ -1439,7 +1443,13 @@ __global__ __launch_bounds__(256) void k_ba_round(BaBatch Q) {
     if ((int)blockIdx.x >= nblk) return;
     BA_STATE(B)
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e < B.n_edges) ba_cull_edge(B, poses_c, pts_c, e, stage);
+    if (e < B.n_edges) {
+        ba_cull_edge(B, poses_c, pts_c, e, stage);
+        if (stage == 1 && B.e_obs && (B.flags[e] & 3)) {    // culled by either test: its observation id joins the list (agent-scope store: read by another workgroup / the merge kernel)
+            const int pos = __hip_atomic_fetch_add(B.ncull, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (pos < B.cull_cap) __hip_atomic_store(B.cull + pos, B.e_obs[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     __shared__ int s_last;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every wave's atomic adds on scal[6] have been performed before the barrier (a workgroup-scope barrier alone need not wait for them)
     __syncthreads();
@@ -1453,6 +1463,12 @@ __global__ __launch_bounds__(256) void k_ba_round(BaBatch Q) {
         for (int i = threadIdx.x; i < 36 * B.n_free; i += 256) B.Hpp[i] = 0;
         for (int i = threadIdx.x; i < B.D; i += 256) B.bp[i] = 0;
     }
+    if (stage == 1 && B.ncull && B.cull_host) {
+        const int n = min(min(__hip_atomic_load(B.ncull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), B.cull_cap), B.cull_host_cap);
+        for (int i = threadIdx.x; i < n; i += 256) B.cull_host[i] = __hip_atomic_load(B.cull + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence_system();
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
         BaCtl* c = ctl_;
         c->ticket = 0;
@@ -1465,6 +1481,7 @@ __global__ __launch_bounds__(256) void k_ba_round(BaBatch Q) {
             st->stage = 1; st->finished = c->finished; st->it = 0; st->steps = 0; st->gen = c->gen;
         } else {
             c->stage = 2;
+            st->n_culled = B.ncull ? __hip_atomic_load(B.ncull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
             st->chi0 = c->chi0; st->chi_final = __hip_atomic_load(&B.scal[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             st->buf = c->buf; st->iters_total = c->iters_total; st->finished = 1; st->it = c->it; st->steps = c->steps; st->gen = c->gen;
             __threadfence_system();
@@ -1505,18 +1522,21 @@ struct BaJob {
     int cur_buf = 0, iters = 0, steps = 0;
     int est_stage = 0, est_left = 0;                        // the host's estimate of where the device is (chunk sizes only: the device moves on by itself)
     double chi0 = 0, chi_final = 0;
+    int n_culled = -1; std::vector<long long> culled;       // resident graphs: from k_ba_round's pinned list (-1: not collected)
     int rc = VO_OK; bool done = false;
     hipEvent_t wait_ev = nullptr;                           // the problem's arrays are complete once this event (recorded on the owner's stream) has passed
 };
 // one enqueued chunk of LM steps: the slots it covers (with their admission numbers) and two events -- before its last step and behind it
 struct BaChunk { hipEvent_t ev_near = nullptr, ev_end = nullptr; int n = 0, steps = 0; int sl[BA_SLOTS]; int gen[BA_SLOTS]; };
 #define BA_MAX_ENGINES 4
+#define BA_CULL_HOST 4096
 struct BaEngine {
     int device = 0, refs = 0;
     hipStream_t st = nullptr;
     BaDev* d_Bs = nullptr; BaDev* h_Bs = nullptr;           // [BA_SLOTS] problem descriptors: device / pinned mirror
     BaCtl* d_ctl = nullptr;                                 // [BA_SLOTS] control blocks (device only: k_ba_admit / k_ba_round write them)
     BaStat* h_stat = nullptr;                               // [BA_SLOTS] pinned status records, written by k_ba_round
+    long long* h_cull = nullptr;                            // [BA_SLOTS][BA_CULL_HOST] pinned: culled observation ids of a resident graph
     BaJob* slot[BA_SLOTS] = {};
     int slot_gen[BA_SLOTS] = {}; int gen_ctr = 0;
     BaChunk ring[2]; int r_head = 0, r_n = 0;               // chunks in flight (oldest first)
@@ -1548,6 +1568,7 @@ static int ba_engine_admit(BaEngine* E) {
         BaJob* j = E->pending.front(); E->pending.pop_front();
         E->slot[s] = j; j->B.ctl = E->d_ctl + s; j->cur_buf = 0; j->iters = 0; j->steps = 0;
         j->B.it_robust = j->in->it_robust; j->B.it_plain = j->in->it_plain; j->B.gen = E->slot_gen[s] = ++E->gen_ctr;
+        j->B.cull_host = j->B.e_obs ? E->h_cull + (size_t)s * BA_CULL_HOST : nullptr; j->B.cull_host_cap = BA_CULL_HOST; j->n_culled = -1;
         j->est_stage = 0; j->est_left = std::max(1, j->in->it_robust);
         lk.unlock();
         int rc = VO_OK;
@@ -1668,6 +1689,7 @@ static int ba_engine_retire(BaEngine* E) {
         if (t->gen != C.gen[i]) continue;
         if (t->stage == 2) {
             j->iters = t->iters_total; j->cur_buf = t->buf; j->chi0 = t->chi0; j->chi_final = t->chi_final;
+            if (j->B.cull_host) { j->n_culled = t->n_culled; const int take = std::max(0, std::min(j->n_culled, BA_CULL_HOST)); j->culled.assign(E->h_cull + (size_t)s * BA_CULL_HOST, E->h_cull + (size_t)s * BA_CULL_HOST + take); }
             fin[nfin++] = s;
             continue;
         }
@@ -1743,6 +1765,7 @@ static BaEngine* ba_engine_new(int device) {
     ok = ok && hipMalloc((void**)&E->d_Bs, sizeof(BaDev) * BA_SLOTS) == hipSuccess && hipMalloc((void**)&E->d_ctl, sizeof(BaCtl) * BA_SLOTS) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&E->h_Bs, sizeof(BaDev) * BA_SLOTS, hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&E->h_stat, sizeof(BaStat) * BA_SLOTS, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&E->h_cull, sizeof(long long) * BA_SLOTS * BA_CULL_HOST, hipHostMallocDefault) == hipSuccess;
     if (ok) {
         memset(E->h_stat, 0, sizeof(BaStat) * BA_SLOTS);
         std::vector<BaCtl> z(BA_SLOTS);
@@ -1787,6 +1810,7 @@ static void ba_engine_free(BaEngine* E) {
     if (E->d_ctl) (void)hipFree(E->d_ctl);
     if (E->h_Bs) (void)hipHostFree(E->h_Bs);
     if (E->h_stat) (void)hipHostFree(E->h_stat);
+    if (E->h_cull) (void)hipHostFree(E->h_cull);
     for (BaChunk& C : E->ring) { if (C.ev_near) (void)hipEventDestroy(C.ev_near); if (C.ev_end) (void)hipEventDestroy(C.ev_end); }
     delete E;
 }
@@ -2045,6 +2069,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     B.W = (double*)(base + o_W); B.S = (double*)(base + o_S); B.bs = (double*)(base + o_bs); B.Hinv = (double*)(base + o_Hinv); B.dl = (double*)(base + o_dl);
     B.cam = BaCam{(double)c->p.fx, (double)c->p.fy, (double)c->p.cx, (double)c->p.cy};
     B.delta = in->huber_delta; B.chi2_th = in->chi2_th; B.gp = (nx + 63) / 64; B.edges_by_point = sorted_by_point ? 1 : 0;
+    B.e_obs = nullptr; B.cull = nullptr; B.ncull = nullptr; B.cull_cap = 0; B.cull_host = nullptr; B.cull_host_cap = 0;
 
     {
         if (up_end > c->h_ba_up_bytes) {                    // pinned mirror of the upload region, grown geometrically
@@ -2511,6 +2536,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     B.W = (double*)(base + o_W); B.S = (double*)(base + o_S); B.bs = (double*)(base + o_bs2); B.Hinv = (double*)(base + o_Hinv); B.dl = (double*)(base + o_dl);
     B.cam = BaCam{(double)c->p.fx, (double)c->p.fy, (double)c->p.cx, (double)c->p.cy};
     B.delta = huber_delta; B.chi2_th = chi2_th; B.gp = (nx + 63) / 64; B.edges_by_point = 1;
+    B.e_obs = e_obs; B.cull = (long long*)(base + o_cull); B.ncull = (int*)(base + o_ncull); B.cull_cap = ne; B.cull_host = nullptr; B.cull_host_cap = 0;      // (the engine points cull_host at its slot's pinned list)
     BaPairPlan Q;
     Q.ps_start = B.ps_start; Q.ps_edges = B.ps_edges; Q.ps_pt = (const int32_t*)(base + o_pspt); Q.nf = nf;
     Q.cnt = (int*)(base + o_pcnt); Q.off = (int*)(base + o_poff); Q.n_slices = (int*)(base + o_pn); Q.n_pairs = (int*)(base + o_pn) + 1;
@@ -2572,20 +2598,34 @@ extern "C" int vo_local_ba_resident_solve(vo_ctx* c, int it_robust, int it_plain
     const BaDev& B = R.B;
     int* h = (int*)vo_stage(c, 4096);
     if (!h) return VO_E_NOMEM;
-    HIP_TRY(hipMemsetAsync(R.d_ncull, 0, 4, st));
-    hipLaunchKernelGGL(k_culled_list, dim3((ne + 255) / 256), dim3(256), 0, st, ne, (const uint8_t*)B.flags, (const long long*)R.d_e_obs, R.d_ncull, R.d_cull, R.cull_cap);
-    HIP_TRY(hipMemcpyAsync(h, R.d_ncull, 4, hipMemcpyDeviceToHost, st));
-    if (!deferred) {
-        HIP_TRY(hipMemcpyAsync(out->poses, job.cur_buf ? B.posesB : B.posesA, 96 * (size_t)nf, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(out->points, job.cur_buf ? B.ptsB : B.ptsA, 24 * (size_t)nx, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(out->point_slots, R.d_point_slots, 4 * (size_t)nx, hipMemcpyDeviceToHost, st));
-    }
-    HIP_TRY(hipStreamSynchronize(st));
-    out->n_culled = h[0];
-    const int take = std::min(out->n_culled, out->cap_culled);
-    if (take > 0) {
-        HIP_TRY(hipMemcpy(out->culled_obs, R.d_cull, 8 * (size_t)take, hipMemcpyDeviceToHost));
-        std::sort(out->culled_obs, out->culled_obs + take);                     // arrival order of an atomic append -> ascending observation id
+    if (job.n_culled >= 0 && job.n_culled <= BA_CULL_HOST) {
+        // the engine's final k_ba_round left the culled observations' ids in the device list (for the merge kernel) and in pinned host memory
+        out->n_culled = job.n_culled;
+        const int take = std::min(out->n_culled, out->cap_culled);
+        if (take > 0) { memcpy(out->culled_obs, job.culled.data(), 8 * (size_t)take); std::sort(out->culled_obs, out->culled_obs + take); }
+        if (!deferred) {
+            HIP_TRY(hipMemcpyAsync(out->poses, job.cur_buf ? B.posesB : B.posesA, 96 * (size_t)nf, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(out->points, job.cur_buf ? B.ptsB : B.ptsA, 24 * (size_t)nx, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(out->point_slots, R.d_point_slots, 4 * (size_t)nx, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+    } else {
+        // (the persistent path, or more culled observations than the pinned list holds: list kernel + read-back)
+        HIP_TRY(hipMemsetAsync(R.d_ncull, 0, 4, st));
+        hipLaunchKernelGGL(k_culled_list, dim3((ne + 255) / 256), dim3(256), 0, st, ne, (const uint8_t*)B.flags, (const long long*)R.d_e_obs, R.d_ncull, R.d_cull, R.cull_cap);
+        HIP_TRY(hipMemcpyAsync(h, R.d_ncull, 4, hipMemcpyDeviceToHost, st));
+        if (!deferred) {
+            HIP_TRY(hipMemcpyAsync(out->poses, job.cur_buf ? B.posesB : B.posesA, 96 * (size_t)nf, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(out->points, job.cur_buf ? B.ptsB : B.ptsA, 24 * (size_t)nx, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(out->point_slots, R.d_point_slots, 4 * (size_t)nx, hipMemcpyDeviceToHost, st));
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+        out->n_culled = h[0];
+        const int take = std::min(out->n_culled, out->cap_culled);
+        if (take > 0) {
+            HIP_TRY(hipMemcpy(out->culled_obs, R.d_cull, 8 * (size_t)take, hipMemcpyDeviceToHost));
+            std::sort(out->culled_obs, out->culled_obs + take);                     // arrival order of an atomic append -> ascending observation id
+        }
     }
     out->chi2_initial = job.chi0; out->chi2_final = job.chi_final; out->lm_iters = job.iters;
     HIP_TRY(hipGetLastError());
