@@ -1525,6 +1525,7 @@ struct BaJob {
     int n_culled = -1; std::vector<long long> culled;       // resident graphs: from k_ba_round's pinned list (-1: not collected)
     int rc = VO_OK; bool done = false;
     hipEvent_t wait_ev = nullptr;                           // the problem's arrays are complete once this event (recorded on the owner's stream) has passed
+    hipEvent_t wait_pairs = nullptr;                        // optional: the pair lists are complete once this one has passed (waited for in front of the first Schur launch only)
 };
 // one enqueued chunk of LM steps: the slots it covers (with their admission numbers) and two events -- before its last step and behind it
 struct BaChunk { hipEvent_t ev_near = nullptr, ev_end = nullptr; int n = 0, steps = 0; int sl[BA_SLOTS]; int gen[BA_SLOTS]; };
@@ -1642,12 +1643,17 @@ static int ba_engine_enqueue(BaEngine* E) {
             if (sidx == 0) {
                 { ProfScope ps(prof, "k_ba_lin2", st); hipLaunchKernelGGL(k_ba_lin2, dim3(gA_lin, 1, nA), blk, 0, st, QA); }
                 hipLaunchKernelGGL(k_ba_maxdiag2, dim3(gA_md, 1, nA), blk, 0, st, QA);
+                for (int i = 0; i < na; ++i) {              // a problem's pair plan may still be running on its owner's stream: the linearisation above did not need it
+                    BaJob* j = E->slot[act[i]];
+                    if (j->wait_pairs) { HIP_TRY(hipStreamWaitEvent(st, j->wait_pairs, 0)); j->wait_pairs = nullptr; }
+                }
             }
             { ProfScope ps(prof, "k_ba_schur2", st); hipLaunchKernelGGL(k_ba_schur2, dim3(gA_blk + gA_pose, 1, nA), blk, 0, st, QA); }
             { ProfScope ps(prof, "k_ba_chol16", st); hipLaunchKernelGGL(k_ba_chol16, dim3(1, 1, nA), dim3(CH_THREADS), ldsA, st, QA, 0, 1); }
             { ProfScope ps(prof, "k_ba_upchi2", st); hipLaunchKernelGGL(k_ba_upchi2, dim3((gA_up + up_rep * (UPC_T / 4) - 1) / (up_rep * (UPC_T / 4)), 1, nA), dim3(UPC_T), ldsA_up, st, QA, up_rep); }
         }
         if (nB) {
+            if (sidx == 0) for (int i = 0; i < nB; ++i) { BaJob* j = E->slot[sB[i]]; if (j->wait_pairs) { HIP_TRY(hipStreamWaitEvent(st, j->wait_pairs, 0)); j->wait_pairs = nullptr; } }
             { ProfScope ps(prof, "k_ba_lin", st); hipLaunchKernelGGL(k_ba_lin, dim3(gB_lin, 1, nB), blk, 0, st, QB); }
             if (sidx == 0) hipLaunchKernelGGL(k_ba_maxdiag, dim3(gB_md, 1, nB), blk, 0, st, QB);
             { ProfScope ps(prof, "k_ba_init_S", st); hipLaunchKernelGGL(k_ba_init_S, dim3(gB_init, 1, nB), blk, 0, st, QB); }
@@ -1886,6 +1892,7 @@ static int ba_persist_solve(vo_ctx* c, BaJob* j) {
     int rc = VO_OK;
     do {
         if (j->wait_ev && hipStreamWaitEvent(st, j->wait_ev, 0) != hipSuccess) { rc = VO_E_DEVICE; break; }
+        if (j->wait_pairs && hipStreamWaitEvent(st, j->wait_pairs, 0) != hipSuccess) { rc = VO_E_DEVICE; break; }
         if (hipMemsetAsync(pb + o_sync, 0, 1024, st) != hipSuccess) { rc = VO_E_DEVICE; break; }
         if (hipMemsetAsync(B.S, 0, sizeof(double) * (size_t)B.D * B.D, st) != hipSuccess) { rc = VO_E_DEVICE; break; }
         if (hipMemsetAsync(B.bs, 0, sizeof(double) * (size_t)B.D, st) != hipSuccess) { rc = VO_E_DEVICE; break; }
@@ -2383,7 +2390,7 @@ struct BaResident {
     int np = 0, nf = 0, nx = 0, ne = 0, n_fixed = 0, nblk_launch = 0, npairs = 0;
     BaDev B;
     int32_t* d_point_slots = nullptr; int* d_pose_kf = nullptr; long long* d_e_obs = nullptr; int* d_ncull = nullptr; long long* d_cull = nullptr; int cull_cap = 0;
-    hipEvent_t ev = nullptr;                                // recorded behind the pair-plan kernels: the engine's stream waits for it
+    hipEvent_t ev = nullptr, ev_arrays = nullptr;           // ev_arrays: recorded in FRONT of the pair-plan kernels (the first linearisation needs no pairs); ev: behind them (the first Schur launch waits for it)
     // the last solve, until the next cut: where its result lies (vo_local_ba_resident_merge / _fetch)
     // (a back-end thread writes the first line in _cut / _solve; the caller's thread runs _merge while that thread idles and _fetch
     // beside its next _cut: _fetch reads only what _merge copied into the st_* fields)
@@ -2395,6 +2402,7 @@ struct BaResident {
 void vo_ba_resident_free(vo_ctx* c) {
     if (c->resident) {
         if (c->resident->ev) (void)hipEventDestroy(c->resident->ev);
+        if (c->resident->ev_arrays) (void)hipEventDestroy(c->resident->ev_arrays);
         if (c->resident->ev_merge) (void)hipEventDestroy(c->resident->ev_merge);
         if (c->resident->d_stage) (void)hipFree(c->resident->d_stage);
     }
@@ -2541,9 +2549,11 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     Q.ps_start = B.ps_start; Q.ps_edges = B.ps_edges; Q.ps_pt = (const int32_t*)(base + o_pspt); Q.nf = nf;
     Q.cnt = (int*)(base + o_pcnt); Q.off = (int*)(base + o_poff); Q.n_slices = (int*)(base + o_pn); Q.n_pairs = (int*)(base + o_pn) + 1;
     Q.blocks = (BaBlock*)(base + o_blk); Q.pairs = (int2*)(base + o_pairs);
+    if (!R.ev_arrays) HIP_TRY(hipEventCreateWithFlags(&R.ev_arrays, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(R.ev_arrays, st));
     hipLaunchKernelGGL(k_ba_pairs<false>, dim3(nb_all), dim3(256), 4 * (size_t)std::max(max_len, 1), st, Q);
     hipLaunchKernelGGL(k_ba_pairs_scan, dim3(1), dim3(1024), 0, st, Q, nb_all);
-    hipLaunchKernelGGL(k_ba_pairs<true>, dim3(nb_all), dim3(256), 4 * (size_t)std::max(max_len, 1), st, Q);   // no wait: the solve follows on the same stream
+    hipLaunchKernelGGL(k_ba_pairs<true>, dim3(nb_all), dim3(256), 4 * (size_t)std::max(max_len, 1), st, Q);   // no wait: the solve follows on the engine's stream
     if (!R.ev) HIP_TRY(hipEventCreateWithFlags(&R.ev, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(R.ev, st));
     HIP_TRY(hipGetLastError());
@@ -2582,7 +2592,7 @@ extern "C" int vo_local_ba_resident_solve(vo_ctx* c, int it_robust, int it_plain
     memset(&pr, 0, sizeof(pr));
     pr.n_poses = np; pr.n_free = nf; pr.n_points = nx; pr.n_edges = ne; pr.huber_delta = R.B.delta; pr.chi2_th = R.B.chi2_th; pr.it_robust = it_robust; pr.it_plain = it_plain;
     BaJob job;
-    job.c = c; job.in = &pr; job.out = nullptr; job.B = R.B; job.wait_ev = R.ev;
+    job.c = c; job.in = &pr; job.out = nullptr; job.B = R.B; job.wait_ev = R.ev_arrays; job.wait_pairs = R.ev;
     job.grid_lin = (nx + 63) / 64 + nf * PSPLIT; job.grid_initS = (std::max(D * D, nx) + 255) / 256; job.grid_upd = (nx + 63) / 64 + (np + 255) / 256;
     job.grid_e = (ne + 255) / 256; job.grid_c = (ne + 1023) / 1024; job.grid_maxdiag = (D + 3 * nx + 255) / 256;
     job.lds = D <= 192 ? sizeof(double) * (CH_NB * CH_NB + (size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D)
