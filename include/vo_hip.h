@@ -219,6 +219,13 @@ int vo_track_frame(vo_ctx* ctx, int slot, const double T_cw_prior[12], const vo_
  * frame; seeds[i] replaces tp->seed for frame i.  n <= max_track_batch. */
 int vo_track_batch(vo_ctx* ctx, int n, const int* slots, const double T_cw_prior[12], const vo_track_params* tp,
                    const uint64_t* seeds, vo_track_result* res, vo_match* matches, int cap);
+/* vo_track_batch in two halves, for a caller with host work to do while the launch chain runs: _begin enqueues the chain and returns
+ * (its arrays are copied), _end waits and fills results[n]; match records stay on the device (vo_track_fetch_matches).  Between the two
+ * the context must not be given other tracking or map-changing calls.  A member of a stream group gets VO_E_UNSUPPORTED (its chain is
+ * shared); _end without a chain in flight returns VO_E_STATE.  Results equal vo_track_batch's. */
+int vo_track_batch_begin(vo_ctx* ctx, int n, const int* slots, const double T_cw_prior[12], const vo_track_params* tp,
+                         const uint64_t* seeds, int match_cap);
+int vo_track_batch_end(vo_ctx* ctx, vo_track_result* results);
 
 /* ---- stream groups --------------------------------------------------------------------- */
 /* Several contexts = several independent RGB-D streams on ONE GPU.  Frames of different streams never depend on each

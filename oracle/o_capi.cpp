@@ -30,6 +30,7 @@ struct vo_ctx {
     MapStore map;
     Corr corr; std::vector<vo_match> last_matches;
     std::vector<std::vector<vo_match>> lane_matches;           // per lane of the last vo_track_batch (vo_track_fetch_matches)
+    bool async_pending = false; std::vector<vo_track_result> async_res;      // vo_track_batch_begin / _end
     std::vector<int32_t> ransac_inliers;
     HypShard shard;
     // observation table: keyframe number, map slot, pixel, alive; keyframe poses
@@ -296,6 +297,23 @@ int vo_track_batch(vo_ctx* c, int n, const int* slots, const double T0[12], cons
     return VO_OK;
 }
 
+// vo_track_batch in two halves: the CPU restatement computes at _begin and hands the results out at _end
+int vo_track_batch_begin(vo_ctx* c, int n, const int* slots, const double T0[12], const vo_track_params* tp, const uint64_t* seeds, int cap) {
+    if (!c || n < 1 || !slots || !T0 || !tp) return VO_E_INVALID;
+    if (c->async_pending) return VO_E_STATE;
+    c->async_res.assign((size_t)n, vo_track_result());
+    const int rc = vo_track_batch(c, n, slots, T0, tp, seeds, c->async_res.data(), nullptr, cap);
+    if (rc != VO_OK) return rc;
+    c->async_pending = true;
+    return VO_OK;
+}
+int vo_track_batch_end(vo_ctx* c, vo_track_result* res) {
+    if (!c || !res) return VO_E_INVALID;
+    if (!c->async_pending) return VO_E_STATE;
+    c->async_pending = false;
+    for (size_t i = 0; i < c->async_res.size(); ++i) res[i] = c->async_res[i];
+    return VO_OK;
+}
 int vo_track_fetch_matches(vo_ctx* c, int lane, vo_match* matches, int cap, int* n_out) {
     if (!c || lane < 0 || lane >= (int)c->lane_matches.size() || !matches || cap < 0 || !n_out) return VO_E_INVALID;
     const int n = (int)std::min<size_t>((size_t)cap, c->lane_matches[lane].size());

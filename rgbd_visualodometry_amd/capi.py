@@ -67,7 +67,7 @@ MATCH_DTYPE = np.dtype([("map_index", "<i4"), ("kp_index", "<i4"), ("distance", 
 SYMBOLS = ["vo_ctx_create", "vo_ctx_destroy", "vo_strerror", "vo_backend_name", "vo_default_params",
            "vo_default_track_params", "vo_frame_upload", "vo_frame_bind_device", "vo_orb_detect_describe",
            "vo_orb_fetch", "vo_orb_level_size", "vo_orb_fetch_level", "vo_orb_fetch_blur_level", "vo_map_upsert", "vo_map_upsert_from_frame", "vo_map_set_active",
-           "vo_match_active_map", "vo_matches_set", "vo_pnp_ransac", "vo_pose_refine_lm", "vo_track_frame", "vo_track_batch", "vo_track_fetch_matches",
+           "vo_match_active_map", "vo_matches_set", "vo_pnp_ransac", "vo_pose_refine_lm", "vo_track_frame", "vo_track_batch", "vo_track_batch_begin", "vo_track_batch_end", "vo_track_fetch_matches",
            "vo_local_ba", "vo_sync", "vo_profile_enable", "vo_profile_read",
            "vo_group_create", "vo_group_destroy", "vo_group_join", "vo_group_leave", "vo_group_set_gather", "vo_group_stats",
            "vo_set_hypothesis_shard", "vo_set_hypothesis_shard_stream", "vo_triangulate_batch", "vo_kf_set_pose", "vo_obs_append", "vo_obs_kill", "vo_local_ba_resident",

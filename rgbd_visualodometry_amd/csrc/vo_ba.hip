@@ -2397,7 +2397,7 @@ struct BaResident {
     bool solved = false; int solve_seq = 0, cur_buf = 0, n_culled = 0; double chi0 = 0, chi_final = 0; int lm_iters = 0;
     void* d_stage = nullptr; size_t stage_bytes = 0;        // merged result, out of the slab the next cut reuses: [poses nf x 12][points nx x 3][slots nx]
     bool has_stage = false; int merged_seq = 0, st_nf = 0, st_nx = 0, st_ne = 0, st_fixed = 0, st_culled = 0, st_iters = 0; double st_chi0 = 0, st_chi1 = 0;
-    hipStream_t merge_stream = nullptr; hipEvent_t ev_merge = nullptr;
+    hipStream_t fetch_stream = nullptr; hipEvent_t ev_merge = nullptr;      // _fetch copies on a stream of its own (behind ev_merge): the tables' stream may be running the tracker's next launch chain, the context's own stream the next cut
 };
 void vo_ba_resident_free(vo_ctx* c) {
     if (c->resident) {
@@ -2405,6 +2405,7 @@ void vo_ba_resident_free(vo_ctx* c) {
         if (c->resident->ev_arrays) (void)hipEventDestroy(c->resident->ev_arrays);
         if (c->resident->ev_merge) (void)hipEventDestroy(c->resident->ev_merge);
         if (c->resident->d_stage) (void)hipFree(c->resident->d_stage);
+        if (c->resident->fetch_stream) (void)hipStreamDestroy(c->resident->fetch_stream);
     }
     delete c->resident; c->resident = nullptr;
 }
@@ -2652,12 +2653,12 @@ extern "C" int vo_local_ba_resident_merge(vo_ctx* c, vo_ctx* t) {
     BaResident& R = *c->resident;
     const int nf = R.nf, nx = R.nx;
     R.st_nf = nf; R.st_nx = nx; R.st_ne = R.ne; R.st_fixed = R.n_fixed; R.st_culled = R.n_culled; R.st_iters = R.lm_iters; R.st_chi0 = R.chi0; R.st_chi1 = R.chi_final;
-    R.merge_stream = t->stream; R.merged_seq = R.solve_seq; R.has_stage = true;
+    R.merged_seq = R.solve_seq; R.has_stage = true;
     if (nx == 0 || R.ne == 0 || nf == 0) return VO_OK;
     if (!t->d_obs_alive || !t->d_kf_pose || R.n_culled > R.cull_cap) return VO_E_STATE;
     const size_t o_pts = (96 * (size_t)nf + 255) & ~(size_t)255, o_sl = o_pts + ((24 * (size_t)nx + 255) & ~(size_t)255), total = o_sl + 4 * (size_t)nx;
     if (total > R.stage_bytes) {
-        if (R.d_stage) { (void)hipStreamSynchronize(t->stream); (void)hipFree(R.d_stage); }
+        if (R.d_stage) { (void)hipStreamSynchronize(t->stream); if (R.fetch_stream) (void)hipStreamSynchronize(R.fetch_stream); (void)hipFree(R.d_stage); }
         R.d_stage = nullptr; R.stage_bytes = 0;
         if (hipMalloc(&R.d_stage, total + total / 2) != hipSuccess) return VO_E_NOMEM;
         R.stage_bytes = total + total / 2;
@@ -2669,8 +2670,10 @@ extern "C" int vo_local_ba_resident_merge(vo_ctx* c, vo_ctx* t) {
                        (const int*)R.d_pose_kf, (const int32_t*)R.d_point_slots, (const int*)R.d_ncull, (const long long*)R.d_cull, R.cull_cap, t->d_map_pos, (const uint8_t*)t->d_map_flags,
                        t->d_kf_pose, t->d_obs_alive, (double*)sb, (double*)(sb + o_pts), (int32_t*)(sb + o_sl));
     if (!R.ev_merge) HIP_TRY(hipEventCreateWithFlags(&R.ev_merge, hipEventDisableTiming));
+    if (!R.fetch_stream) HIP_TRY(hipStreamCreateWithFlags(&R.fetch_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventRecord(R.ev_merge, t->stream));
     HIP_TRY(hipStreamWaitEvent(c->stream, R.ev_merge, 0));
+    HIP_TRY(hipStreamWaitEvent(R.fetch_stream, R.ev_merge, 0));
     HIP_TRY(hipGetLastError());
     return VO_OK;
 }
@@ -2686,10 +2689,10 @@ extern "C" int vo_local_ba_resident_fetch(vo_ctx* c, vo_ba_resident_result* out)
     if (nx > out->cap_points) return VO_E_OVERFLOW;
     const size_t o_pts = (96 * (size_t)nf + 255) & ~(size_t)255, o_sl = o_pts + ((24 * (size_t)nx + 255) & ~(size_t)255);
     const uint8_t* sb = (const uint8_t*)R.d_stage;
-    HIP_TRY(hipMemcpyAsync(out->poses, sb, 96 * (size_t)nf, hipMemcpyDeviceToHost, R.merge_stream));
-    HIP_TRY(hipMemcpyAsync(out->points, sb + o_pts, 24 * (size_t)nx, hipMemcpyDeviceToHost, R.merge_stream));
-    HIP_TRY(hipMemcpyAsync(out->point_slots, sb + o_sl, 4 * (size_t)nx, hipMemcpyDeviceToHost, R.merge_stream));
-    HIP_TRY(hipStreamSynchronize(R.merge_stream));
+    HIP_TRY(hipMemcpyAsync(out->poses, sb, 96 * (size_t)nf, hipMemcpyDeviceToHost, R.fetch_stream));
+    HIP_TRY(hipMemcpyAsync(out->points, sb + o_pts, 24 * (size_t)nx, hipMemcpyDeviceToHost, R.fetch_stream));
+    HIP_TRY(hipMemcpyAsync(out->point_slots, sb + o_sl, 4 * (size_t)nx, hipMemcpyDeviceToHost, R.fetch_stream));
+    HIP_TRY(hipStreamSynchronize(R.fetch_stream));
     return VO_OK;
 }
 

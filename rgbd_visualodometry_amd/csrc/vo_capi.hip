@@ -694,7 +694,12 @@ int vo_pose_refine_lm(vo_ctx* c, double T[12], double delta, double cut, int it_
 // ---- one launch chain over the lanes of a set of requests (one request = the lanes one context contributes) ----------
 // Used for a context's own vo_track_batch (one request, its own stream and launch set) and for the fused chain of a
 // stream group (its stream and launch set).  Returns after the chain has finished and every request's results are filled in.
-static int chain_run_impl(vo_ctx* prof, hipStream_t st, LaunchSet& ls, std::vector<GroupReq*>& batch);
+static int chain_enqueue(vo_ctx* prof, hipStream_t st, LaunchSet& ls, std::vector<GroupReq*>& batch);
+static int chain_collect(hipStream_t st, LaunchSet& ls, std::vector<GroupReq*>& batch);
+static int chain_run_impl(vo_ctx* prof, hipStream_t st, LaunchSet& ls, std::vector<GroupReq*>& batch) {
+    const int rc = chain_enqueue(prof, st, ls, batch);
+    return rc ? rc : chain_collect(st, ls, batch);
+}
 // A failing call inside the chain returns early with kernels / copies of the fused chain possibly still in flight on the shared stream:
 // the stream is drained before the members are told (they may free or reuse their lane buffers at once).
 static int chain_run(vo_ctx* prof, hipStream_t st, LaunchSet& ls, std::vector<GroupReq*>& batch) {
@@ -702,7 +707,8 @@ static int chain_run(vo_ctx* prof, hipStream_t st, LaunchSet& ls, std::vector<Gr
     if (rc != VO_OK) (void)hipStreamSynchronize(st);
     return rc;
 }
-static int chain_run_impl(vo_ctx* prof, hipStream_t st, LaunchSet& ls, std::vector<GroupReq*>& batch) {
+// everything up to the read-back copies is enqueued; nothing waits (vo_track_batch_begin returns here)
+static int chain_enqueue(vo_ctx* prof, hipStream_t st, LaunchSet& ls, std::vector<GroupReq*>& batch) {
     const vo_track_params* tp = batch[0]->tp;
     int nl = 0; ChainDims dims{0, 0};
     HIP_TRY(hipStreamSynchronize(st));                      // the pinned mirrors are rewritten below
@@ -753,6 +759,10 @@ static int chain_run_impl(vo_ctx* prof, hipStream_t st, LaunchSet& ls, std::vect
         if (!r->matches) { c->h_matches_lanes = r->n; c->h_matches_first = first; }
     }
     HIP_TRY(hipMemcpyAsync(ls.h_track, ls.d_track, sizeof(TrackDev) * nl, hipMemcpyDeviceToHost, st));
+    return VO_OK;
+}
+// wait for the chain and hand the results out
+static int chain_collect(hipStream_t st, LaunchSet& ls, std::vector<GroupReq*>& batch) {
     HIP_TRY(hipStreamSynchronize(st));
     int k0 = 0;
     for (GroupReq* r : batch) {
@@ -855,6 +865,33 @@ int vo_track_batch(vo_ctx* c, int n, const int* slots, const double T0[12], cons
     if (c->group) return group_submit(c->group, &req);
     std::vector<GroupReq*> one{&req};
     return chain_run(c, c->stream, c->ls, one);
+}
+
+// The same call in two halves for a caller that has host work to do while the chain runs (host/src/frontend.cpp: at a keyframe the next
+// frames' chain is started before the BA write-back).  Un-grouped contexts only: a group's chain is led by whichever member finds it idle.
+int vo_track_batch_begin(vo_ctx* c, int n, const int* slots, const double T0[12], const vo_track_params* tp, const uint64_t* seeds, int cap) {
+    if (!c || n < 1 || n > c->lanes || !slots || !T0 || !tp || tp->passes < 1 || cap < 0 || tp->n_hyp < 1 || tp->n_hyp > c->p.max_hypotheses) return VO_E_INVALID;
+    if (c->group) return VO_E_UNSUPPORTED;
+    if (c->async_pending) return VO_E_STATE;
+    for (int i = 0; i < n; ++i) { if (slots[i] < 0 || slots[i] >= c->p.max_frames) return VO_E_INVALID; if (!c->slot_orb[slots[i]]) return VO_E_STATE; }
+    HIP_TRY(hipSetDevice(c->device));
+    c->async_slots.assign(slots, slots + n); c->async_seeds.clear(); if (seeds) c->async_seeds.assign(seeds, seeds + n);
+    memcpy(c->async_T0, T0, sizeof(double) * 12); c->async_tp = *tp; c->async_n = n; c->async_cap = cap;
+    GroupReq req{c, n, c->async_slots.data(), c->async_T0, &c->async_tp, seeds ? c->async_seeds.data() : nullptr, nullptr, nullptr, cap, VO_OK, false};
+    std::vector<GroupReq*> one{&req};
+    const int rc = chain_enqueue(c, c->stream, c->ls, one);
+    if (rc != VO_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
+    c->async_pending = true;
+    return VO_OK;
+}
+int vo_track_batch_end(vo_ctx* c, vo_track_result* res) {
+    if (!c || !res) return VO_E_INVALID;
+    if (!c->async_pending) return VO_E_STATE;
+    HIP_TRY(hipSetDevice(c->device));
+    c->async_pending = false;
+    GroupReq req{c, c->async_n, c->async_slots.data(), c->async_T0, &c->async_tp, c->async_seeds.empty() ? nullptr : c->async_seeds.data(), res, nullptr, c->async_cap, VO_OK, false};
+    std::vector<GroupReq*> one{&req};
+    return chain_collect(c->stream, c->ls, one);
 }
 
 int vo_track_fetch_matches(vo_ctx* c, int lane, vo_match* matches, int cap, int* n_out) {

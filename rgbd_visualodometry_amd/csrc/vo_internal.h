@@ -128,6 +128,8 @@ struct vo_ctx {
     int map_hi = 0;                                         // highest map slot ever upserted + 1
     void* d_cut = nullptr; size_t d_cut_bytes = 0;          // scratch of the resident graph cut
     struct BaResident* resident = nullptr;                  // state between vo_local_ba_resident_cut and _solve (vo_ba.hip)
+    // vo_track_batch_begin / _end: the request of the chain in flight (copies: the caller's arrays need not outlive _begin)
+    bool async_pending = false; int async_n = 0, async_cap = 0; std::vector<int> async_slots; std::vector<uint64_t> async_seeds; double async_T0[12]; vo_track_params async_tp;
     // profiling
     std::atomic<bool> prof_on; std::mutex prof_mu; std::vector<ProfRec> prof; std::vector<hipEvent_t> ev_pool;      // prof / ev_pool: under prof_mu
     ProfRec prof_open; hipStream_t prof_open_stream = nullptr; uint64_t prof_ticket = 0, prof_closed = 0;

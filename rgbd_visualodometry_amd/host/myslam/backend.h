@@ -32,10 +32,15 @@ public:
     void WaitGraphCut();
     void SetDeviceGraph(bool on) { deviceGraph_ = on; }
     bool DeviceGraph() const { return deviceGraph_; }             // wait for the pending job and merge it now (end of a sequence / of a timed region)
-    void OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr);
+    void OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr, bool deferTail = false);
+    // The three parts a caller may interleave with its own work (FrontEnd::TrackingHandler at a keyframe): the pending local BA is waited for and merged
+    // (host ledger + device tables); the next one is started (OptimizeCovisibleGraphOfKeyframe with deferTail); the merged result reaches the host objects.
+    void MergePending() { if (job_) Finish(true); }
+    void FinishTailNow() { FinishTail(); }
     // tracker thread, once per frame before tracking: merge a finished/overdue job; true if the map changed
     bool Poll(size_t frameIndex);
     // frame index at which the pending job will be merged (SIZE_MAX: none pending)
+    int Lag() const { return lag_; }
     size_t NextMergeFrame() const { return job_ ? job_->frameIndex + (size_t)lag_ : (size_t)-1; }
     struct Stats { int runs = 0, poses = 0, fixed = 0, points = 0, edges = 0, outliers = 0, failed = 0, capped = 0; double ms = 0, ms_build = 0, ms_solve = 0, ms_wait = 0;
                    double sum_d3 = 0, sum_d2 = 0; long long sum_edges = 0; };

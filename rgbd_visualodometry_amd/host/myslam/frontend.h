@@ -77,6 +77,11 @@ private:
     // dropped when a keyframe / BA merge changes the inputs (epoch).
     struct SpecResult { size_t frameId; uint64_t epoch; vo_track_result res; int lane; };    // matches stay on the device (lane buffers)
     std::vector<SpecResult> spec_;
+    // A launch chain started ahead of the frames it tracks (at a keyframe, before the BA write-back): the frames, the state it was started in
+    struct Ahead { bool pending = false; uint64_t epoch = 0; std::vector<size_t> ids; std::vector<vo_track_result> res; } ahead_;
+    bool trackAhead_ = true;
+    void LaunchTrackAhead();        // start the next frames' chain now (vo_track_batch_begin)
+    void DrainAhead();              // wait for a chain in flight and drop its results
     std::vector<Frame::Ptr> prefetched_;
     uint64_t epoch_ = 0;
     int trackBatch_ = 1, framesSinceKf_ = 0, lastInterval_ = 0; double lastMotion_ = 0;     // lastInterval_: frames between the last two keyframes

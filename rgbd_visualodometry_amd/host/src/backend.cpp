@@ -138,7 +138,7 @@ void Backend::FinishTail() {
     { const double D = 6.0 * j.nFree; stats_.sum_d3 += D * D * D; stats_.sum_d2 += D * D; stats_.sum_edges += j.nEdges; }
 }
 
-void Backend::OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr) {
+void Backend::OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr, bool deferTail) {
     if (!ctx_) throw std::runtime_error("Backend has no compute context (FrontEnd::SetBackend binds it)");
     auto t0 = std::chrono::steady_clock::now();
     if (job_) Finish(true);                          // the previous result is merged before a new graph is cut (its host-side copy follows below, beside the new solve)
@@ -175,7 +175,7 @@ void Backend::OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr) {
             { std::unique_lock<std::mutex> lk(mu_); hasWork_ = true; }
             cv_.notify_all();
         }
-        FinishTail();
+        if (!deferTail) FinishTail();
         stats_.ms += ms_since(t0);
         return;
     }

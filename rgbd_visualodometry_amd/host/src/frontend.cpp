@@ -51,6 +51,8 @@ void FrontEnd::Init(int device, int width, int height, int max_frames) {
     scratchSlot_ = reobserveNew_ ? lookahead_ : -1;
     params_.map_capacity = cfg_or<int>("map_capacity", 1 << 20);
     trackBatch_ = std::max(1, std::min(16, cfg_or<int>("track_batch", 1)));
+    trackAhead_ = cfg_or<int>("track_ahead", 1) != 0;
+    if (const char* e = std::getenv("VO_TRACK_AHEAD")) trackAhead_ = std::atoi(e) != 0;      // experiments
     params_.max_track_batch = trackBatch_;
     vo_default_track_params(&trackParams_);
     trackParams_.match_ratio = minDisRatio_ = cfg_or<float>("match_ratio", 2.0f);          // :38
@@ -64,7 +66,7 @@ void FrontEnd::Init(int device, int width, int height, int max_frames) {
     if (backend_) backend_->SetContext(ctx_, device_);
 }
 
-FrontEnd::~FrontEnd() { if (ctx_) { if (group_) vo_group_leave(group_, ctx_); vo_ctx_destroy(ctx_); } }
+FrontEnd::~FrontEnd() { if (ctx_) { try { DrainAhead(); } catch (...) {} if (group_) vo_group_leave(group_, ctx_); vo_ctx_destroy(ctx_); } }
 
 void FrontEnd::JoinGroup(vo_group* g) { vo_check(vo_group_join(g, ctx_), "vo_group_join"); group_ = g; }
 
@@ -121,9 +123,23 @@ bool FrontEnd::TrackingHandler() {
         { VO_SCOPE("kf.triangulate"); if (triangulateAll_) TriangulateAllBatched(); else TriangulateMappointsInTrackingMap(); }
     }
     if (backend_ && backend_->DeviceGraph()) { StageTimer t(stats_.ms_keyframe); VO_SCOPE("kf.register"); RegisterKeyframeOnDevice(); }
-    if (backend_) { StageTimer t(stats_.ms_backend); backend_->OptimizeCovisibleGraphOfKeyframe(frameCurr_); }
+    const bool ahead = backend_ && backend_->DeviceGraph() && backend_->Lag() > 0 && trackAhead_ && !group_;
+    if (!ahead) {
+        if (backend_) { StageTimer t(stats_.ms_backend); backend_->OptimizeCovisibleGraphOfKeyframe(frameCurr_); }
+        framePrev_ = frameCurr_;
+        keyframeRef_ = frameCurr_;
+        return true;
+    }
+    // Overlapped back-end with the graph on the device: the previous local BA is merged (host ledger + device tables), the map points that lost their
+    // last observation to it are flushed before the next cut reads the tables, the next BA starts, the NEXT FRAMES' tracking chain is launched -- and
+    // only then the merged result is copied into the host objects, while the GPU tracks.
+    { StageTimer t(stats_.ms_backend); backend_->MergePending(); }
+    { StageTimer t(stats_.ms_flush); FlushDirtyMappoints(); }
+    { StageTimer t(stats_.ms_backend); backend_->OptimizeCovisibleGraphOfKeyframe(frameCurr_, true); }
     framePrev_ = frameCurr_;
     keyframeRef_ = frameCurr_;
+    { StageTimer t(stats_.ms_track); LaunchTrackAhead(); }
+    { StageTimer t(stats_.ms_backend); backend_->FinishTailNow(); }
     return true;
 }
 
@@ -133,6 +149,7 @@ int FrontEnd::PrefetchFrames(const std::vector<Frame::Ptr>& frames) {
     if ((int)frames.size() > lookahead_) throw std::runtime_error("PrefetchFrames: more frames than frame slots (max_frames_in_flight)");
     const int n = (int)frames.size();
     if (n <= 0) return 0;
+    DrainAhead();                                                // a chain in flight reads the slots that are rebound below
     for (const Frame::Ptr& old : prefetched_) if (old) { old->orb_done_ = false; old->slot_ = -1; }      // their slots are rebound below
     for (int i = 0; i < n; ++i) {
         const Frame::Ptr& f = frames[i];
@@ -249,10 +266,56 @@ void FrontEnd::FlushDirtyMappoints() {
     vo_check(vo_map_upsert(ctx_, upIdx_.data(), upXyz_.data(), upNrm_.data(), deviceDescriptors_ ? nullptr : upDesc_.data(), upFlags_.data(), (int)n), "vo_map_upsert");
 }
 
+void FrontEnd::DrainAhead() {
+    if (!ahead_.pending) return;
+    ahead_.pending = false;
+    ahead_.res.resize(ahead_.ids.size());
+    vo_check(vo_track_batch_end(ctx_, ahead_.res.data()), "vo_track_batch_end");
+}
+
+// The frames after the current one (a keyframe: the prior and the map they will be tracked against are final) get their launch chain now; the batch is
+// put together exactly as MatchAndEstimatePose would at the next AddFrame (same frames, same seeds), which then only collects the results.
+void FrontEnd::LaunchTrackAhead() {
+    if (ahead_.pending || group_) return;
+    size_t pos = 0;
+    while (pos < prefetched_.size() && prefetched_[pos] != frameCurr_) ++pos;
+    if (pos + 1 >= prefetched_.size() || !prefetched_[pos + 1]->orb_done_) return;
+    { StageTimer t(stats_.ms_refresh); RefreshTrackingMap(); }
+    FlushDirtyMappoints();
+    double prior[12];
+    framePrev_->GetPose().to12(prior);                           // = what TrackingHandler gives the next frame as its prior (frontend.cpp:96)
+    const size_t nextFrames = (size_t)stats_.frames + 1;         // AddFrame's counter when the first of these frames arrives
+    const size_t nextMerge = backend_ ? backend_->NextMergeFrame() : (size_t)-1;
+    int want = lastInterval_ > 0 ? std::min(trackBatch_, lastInterval_ + 1) : trackBatch_;      // framesSinceKf_ == 0 here
+    std::vector<Frame::Ptr> batch{prefetched_[pos + 1]};
+    for (size_t j = pos + 2; j < prefetched_.size() && (int)batch.size() < want; ++j) {
+        if (!prefetched_[j]->orb_done_ || nextFrames + batch.size() >= nextMerge) break;
+        batch.push_back(prefetched_[j]);
+    }
+    const int nb = (int)batch.size(), cap = (int)activeList_.size() + 1;
+    std::vector<int> slots(nb); std::vector<uint64_t> seeds(nb);
+    ahead_.ids.resize(nb);
+    for (int j = 0; j < nb; ++j) { slots[j] = batch[j]->slot_; seeds[j] = 0x5eed5eedull + 2 * (uint64_t)(nextFrames + j); ahead_.ids[j] = batch[j]->GetId(); }
+    const int rc = vo_track_batch_begin(ctx_, nb, slots.data(), prior, &trackParams_, seeds.data(), cap);
+    if (rc == VO_E_UNSUPPORTED) { trackAhead_ = false; return; }
+    vo_check(rc, "vo_track_batch_begin");
+    ahead_.pending = true; ahead_.epoch = epoch_;
+}
+
 void FrontEnd::MatchAndEstimatePose() {
     vo_track_result res;
     bool have = false;
-    for (auto& sp : spec_)
+    if (ahead_.pending) {                                        // the chain launched at the last keyframe
+        const uint64_t ep = ahead_.epoch;
+        DrainAhead();
+        if (!ahead_.ids.empty() && ahead_.ids[0] == frameCurr_->GetId() && ep == epoch_) {
+            spec_.clear();
+            for (size_t j = 1; j < ahead_.ids.size(); ++j) { SpecResult sp; sp.frameId = ahead_.ids[j]; sp.epoch = epoch_; sp.res = ahead_.res[j]; sp.lane = (int)j; spec_.push_back(sp); }
+            res = ahead_.res[0]; curLane_ = 0; have = true;
+            ++stats_.track_launches;
+        }
+    }
+    if (!have) for (auto& sp : spec_)
         if (sp.frameId == frameCurr_->GetId() && sp.epoch == epoch_) {            // tracked ahead of time with identical inputs
             res = sp.res;
             curLane_ = sp.lane;                                                   // lane buffers live until the next batch call
