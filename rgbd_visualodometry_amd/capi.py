@@ -125,6 +125,8 @@ class VoLib:
         L.vo_track_frame.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(VoTrackParams), C.POINTER(VoTrackResult),
                                      C.c_void_p, C.c_int]
         L.vo_track_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(VoTrackParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.vo_track_batch_begin.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(VoTrackParams), C.c_void_p, C.c_int]
+        L.vo_track_batch_end.argtypes = [C.c_void_p, C.c_void_p]
         L.vo_track_fetch_matches.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.vo_local_ba.argtypes = [C.c_void_p, C.POINTER(VoBaProblem), C.POINTER(VoBaResult)]
         L.vo_sync.argtypes = [C.c_void_p]
@@ -339,6 +341,26 @@ class VoContext:
         T = np.ascontiguousarray(T_prior, dtype=np.float64).reshape(12)
         res = (VoTrackResult * n)()
         self.L.check(self.L.lib.vo_track_batch(self.h, n, _ptr(sl), _ptr(T), C.byref(tp), _ptr(sd), C.cast(res, C.c_void_p), None, cap), "vo_track_batch")
+        out = []
+        for lane in range(n):
+            m = np.zeros(cap, dtype=MATCH_DTYPE)
+            got = C.c_int()
+            self.L.check(self.L.lib.vo_track_fetch_matches(self.h, lane, _ptr(m), cap, C.byref(got)), "vo_track_fetch_matches")
+            out.append(m[:got.value].copy())
+        return [res[i] for i in range(n)], out
+
+    def track_batch_begin(self, slots, T_prior, tp: VoTrackParams, seeds, cap=4096):
+        """vo_track_batch_begin: enqueue the launch chain and return; the arrays may be dropped right away (the library copies them)."""
+        sl = np.ascontiguousarray(slots, dtype=np.int32)
+        sd = np.ascontiguousarray(seeds, dtype=np.uint64)
+        T = np.ascontiguousarray(T_prior, dtype=np.float64).reshape(12)
+        self.L.check(self.L.lib.vo_track_batch_begin(self.h, len(sl), _ptr(sl), _ptr(T), C.byref(tp), _ptr(sd), cap), "vo_track_batch_begin")
+        return len(sl)
+
+    def track_batch_end(self, n, cap=4096):
+        """vo_track_batch_end + one vo_track_fetch_matches per lane."""
+        res = (VoTrackResult * n)()
+        self.L.check(self.L.lib.vo_track_batch_end(self.h, C.cast(res, C.c_void_p)), "vo_track_batch_end")
         out = []
         for lane in range(n):
             m = np.zeros(cap, dtype=MATCH_DTYPE)

@@ -14,7 +14,7 @@
 //   k_ba_lin          4 lanes per point: r, J_pose (2x6), J_point (2x3) = J_pose[:,0:3] R, Huber weight, H_ll / b_l / W_e
 //                     (no atomics); 4 workgroups per free pose: H_pp / b_p
 //   k_ba_init_S       S = blockdiag(H_pp) + lambda I, b_s = b_p, (H_ll + lambda I)^-1
-//   k_ba_schur_blocks one workgroup per <= 512-pair slice of a 6x6 block: S -= W_e1 Hinv W_e2^T, b_s -= W_e Hinv b_l
+//   k_ba_schur_blocks one workgroup per <= BA_SLICE-pair slice of a 6x6 block: S -= W_e1 Hinv W_e2^T, b_s -= W_e Hinv b_l
 //   k_ba_chol16g      the same Cholesky with the matrix in global memory (L2), panel in LDS
 //   k_ba_update       trial points (back-substitution) and trial poses exp(dp) * T, gain-ratio terms
 //   k_ba_chi_control  robust chi2 of the trial state; the last workgroup runs the LM accept / lambda policy
@@ -141,6 +141,7 @@ __device__ __forceinline__ void ba_wave_reduce(double* v) {      // 64 threads; 
 // blocks [gp, gp + PSPLIT n_free) reduce slices of a free pose's edges into H_pp / b_p (27 f64 atomics per block;
 // H_pp / b_p are zeroed by the step that accepted the state, see k_ba_chi_control).
 #define PSPLIT 4
+#define BA_SLICE 256                                         // pairs per Schur workgroup: one per lane (k_ba_schur2 keeps nothing across pairs)
 // Four lanes share a point (a quad): each takes every fourth edge, the quad sums H_ll / b_l with two DPP quad
 // permutes.  A point seen by all ~30 keyframes of the window no longer makes one lane walk 30 edges in a row.
 __device__ __forceinline__ double ba_quad_sum(double x) {
@@ -323,7 +324,7 @@ __global__ void k_ba_init_S(BaBatch Q) {
     if (i < B.n_points) ba_inv3_damped(B.Hll + 9 * (size_t)i, lambda, B.Hinv + 9 * (size_t)i);
 }
 
-// Schur complement, one workgroup per slice (<= 512 pairs) of a 6x6 block (j1 <= j2) of the reduced system:
+// Schur complement, one workgroup per slice (<= BA_SLICE pairs) of a 6x6 block (j1 <= j2) of the reduced system:
 //   S[j1][j2] -= sum over points seen by both poses of W_e1 (H_ll+lambda)^-1 W_e2^T
 // Diagonal blocks also produce b_s[j] = b_p[j] - sum W_e (H_ll+lambda)^-1 b_l.  Half of all pairs are diagonal (every free edge pairs
 // with itself): there e1 == e2, so W is loaded once; off-diagonal slices carry 36 sums instead of 42 and never touch b_l.
@@ -456,11 +457,11 @@ __global__ __launch_bounds__(256) void k_ba_pairs(BaPairPlan Q) {
     if (!FILL && threadIdx.x == 0) Q.cnt[blockIdx.x] = run;
 }
 
-// one workgroup: offsets of the blocks' lists, the table of <= 512-pair slices, totals
+// one workgroup: offsets of the blocks' lists, the table of <= BA_SLICE-pair slices, totals
 __global__ __launch_bounds__(1024) void k_ba_pairs_scan(BaPairPlan Q, int nb) {
     __shared__ int s_c[2112], s_s[2112];
     const int tid = threadIdx.x;
-    for (int i = tid; i < nb; i += 1024) { const int c = Q.cnt[i]; s_c[i] = c; s_s[i] = (c + 511) >> 9; }
+    for (int i = tid; i < nb; i += 1024) { const int c = Q.cnt[i]; s_c[i] = c; s_s[i] = (c + BA_SLICE - 1) / BA_SLICE; }
     __syncthreads();
     if (tid == 0) {                                  // nb <= 2080 entries: a serial scan is a few microseconds
         int a = 0, b = 0;
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(1024) void k_ba_pairs_scan(BaPairPlan Q, int nb) {
         Q.off[i] = o;
         int j1, j2;
         ba_block_of(i, Q.nf, j1, j2);
-        for (int k = 0, sl = s_s[i]; k < c; k += 512, ++sl) Q.blocks[sl] = BaBlock{j1, j2, o + k, min(512, c - k)};
+        for (int k = 0, sl = s_s[i]; k < c; k += BA_SLICE, ++sl) Q.blocks[sl] = BaBlock{j1, j2, o + k, min(BA_SLICE, c - k)};
     }
 }
 
@@ -1982,7 +1983,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
         nb_all = nf * (nf + 1) / 2;
         for (int j1 = 0; j1 < nf; ++j1) for (int j2 = j1; j2 < nf; ++j2) {
             const int m = std::min(ps_start[j1 + 1] - ps_start[j1], ps_start[j2 + 1] - ps_start[j2]);
-            npairs += m; slices_ub += (m + 511) / 512;         // upper bounds: the device writes the real counts
+            npairs += m; slices_ub += (m + BA_SLICE - 1) / BA_SLICE;         // upper bounds: the device writes the real counts
         }
     } else {
         pt_edges.resize(ne); ps_edges.resize(n_ps);
@@ -2031,7 +2032,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
             int cnt = 0;
             for (int t = 0; t < NT; ++t) { off_t[t][bid] = npairs + cnt; cnt += cnt_t[t][bid]; }
             if (!cnt) continue;
-            for (int o = 0; o < cnt; o += 512) blocks.push_back(BaBlock{j1, j2, npairs + o, std::min(512, cnt - o)});   // <= 2 pairs per lane
+            for (int o = 0; o < cnt; o += BA_SLICE) blocks.push_back(BaBlock{j1, j2, npairs + o, std::min(BA_SLICE, cnt - o)});
             npairs += cnt;
         }
         // pairs are written straight into pinned memory (after the 512-byte mailbox used for scal / ctl read-backs)
@@ -2504,8 +2505,8 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     const size_t o_partU = carve(24 * ((size_t)(nx + 63) / 64 + 1)), o_partC = carve(8 * ((size_t)(ne + 255) / 256 + 1));
     const size_t o_W = carve(std::max<size_t>(144 * (size_t)ne, 16 * (size_t)ne + 192 * (size_t)nx + 2048)), o_S = carve(8 * (size_t)D * D), o_bs2 = carve(8 * (size_t)D), o_Hinv = carve(72 * (size_t)nx), o_dl = carve(std::max<size_t>(24 * (size_t)nx, 8 * (size_t)D));
     // pair lists: a point seen by m free poses gives m (m + 1) / 2 <= m (nf + 1) / 2 pairs, so ne (nf + 1) / 2 bounds them before the
-    // per-pose lists exist; slices: one per 512 pairs plus a partial one per block
-    const size_t pairs_ub = (size_t)ne * (size_t)(nf + 1) / 2 + 1, slices_cap = pairs_ub / 512 + (size_t)nb_all + 1;
+    // per-pose lists exist; slices: one per BA_SLICE pairs plus a partial one per block
+    const size_t pairs_ub = (size_t)ne * (size_t)(nf + 1) / 2 + 1, slices_cap = pairs_ub / BA_SLICE + (size_t)nb_all + 1;
     const size_t o_blk = carve(sizeof(BaBlock) * slices_cap), o_pairs = carve(sizeof(int2) * pairs_ub);
     if ((rc = vo_scratch(c, off))) return rc;               // may reallocate: nothing of this problem lives in the slab yet
     uint8_t* base = (uint8_t*)c->d_ba;
@@ -2528,7 +2529,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     if (max_len > PAIR_LDS_CAP) return VO_E_UNSUPPORTED;    // caller falls back to the host graph cut
     for (int j1 = 0; j1 < nf; ++j1) for (int j2 = j1; j2 < nf; ++j2) {
         const int m = std::min(ps_start[j1 + 1] - ps_start[j1], ps_start[j2 + 1] - ps_start[j2]);
-        npairs += m; slices_ub += (m + 511) / 512;
+        npairs += m; slices_ub += (m + BA_SLICE - 1) / BA_SLICE;
     }
     if ((size_t)npairs > pairs_ub || (size_t)slices_ub > slices_cap) return VO_E_OVERFLOW;
     BaDev B;

@@ -88,97 +88,102 @@ __global__ void k_ba_maxdiag2(BaBatch Q) {
     if ((threadIdx.x & 63) == 0 && v > 0) atomicMax((unsigned long long*)&B.scal[4], (unsigned long long)__double_as_longlong(v));
 }
 
+// A workgroup-uniform f64 in a scalar register pair (the two poses of a block: 24 values that would otherwise sit in 48 vector registers)
+__device__ __forceinline__ double p2_uniform(double x) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+// One slice (<= BA_SLICE pairs) of a 6x6 block.  A thread holds ONE pair at a time and nothing across pairs: the pair's 36 (+ 6) products leave in three
+// 16-value wavefront reductions (two columns of the block each, + two entries of b_s on a diagonal block) whose results the row leaders add up in
+// LDS.  Register need is the two pose Jacobians + one 16-value reduction (round 3 first kept 42 f64 accumulators per thread: 226 VGPRs, two
+// waves per SIMD, and a launch over several problems ran its workgroups in as many rounds as it had problems).
 template <bool DIAG>
 __device__ __forceinline__ void p2_schur_slice(const BaDev& B, const BaBlock blk, double lambda, const double* poses_c, const double* rec, const double* Wt, double* s_part, double* s_tot) {
-    constexpr int NV = DIAG ? 42 : 36;
-    double v[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = 0;
 #ifdef P2_STAMPS
     long long ts_[5]; ts_[0] = wall_clock64();
 #endif
     double T1[12], T2[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) { T2[i] = poses_c[12 * (size_t)blk.j2 + i]; T1[i] = DIAG ? 0.0 : poses_c[12 * (size_t)blk.j1 + i]; }
-    for (int q = blk.start + threadIdx.x; q < blk.start + blk.count; q += 256) {
-        const int2 pr = B.pairs[q];
-        if (!B.active[pr.x] || (!DIAG && !B.active[pr.y])) continue;
-        double Hh[6], bl[3], p[3], h[9];
-        p2_rec_load(rec, B.e_pt[pr.x], Hh, bl, p);
-        const double w2 = Wt[pr.y], w1 = DIAG ? w2 : Wt[pr.x];
-        const double Hs[9] = {Hh[0], Hh[1], Hh[2], Hh[1], Hh[3], Hh[4], Hh[2], Hh[4], Hh[5]};
-        ba_inv3_damped(Hs, lambda, h);
-        double Jp2[2][6], Jl2[2][3], G2[2][3], M[2][2];
-        pb_jac(B.cam, T2, p, Jp2, Jl2);
+    for (int i = 0; i < 12; ++i) { T2[i] = p2_uniform(poses_c[12 * (size_t)blk.j2 + i]); T1[i] = DIAG ? 0.0 : p2_uniform(poses_c[12 * (size_t)blk.j1 + i]); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < blk.count; base += 256) {                   // workgroup-uniform trip count: every lane takes part in the reductions
+        bool on = base + (int)threadIdx.x < blk.count;
+        int2 pr = make_int2(0, 0);
+        if (on) { pr = B.pairs[blk.start + base + threadIdx.x]; on = B.active[pr.x] && (DIAG || B.active[pr.y]); }
+        double Jp1[2][6], Jp2[2][6], M[2][2] = {{0, 0}, {0, 0}}, g[2] = {0, 0};
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) G2[a][c] = Jl2[a][0] * h[c] + Jl2[a][1] * h[3 + c] + Jl2[a][2] * h[6 + c];
-        if (DIAG) {
+            for (int c = 0; c < 6; ++c) Jp1[a][c] = Jp2[a][c] = 0;
+        if (on) {
+            double Hh[6], bl[3], p[3], h[9];
+            p2_rec_load(rec, B.e_pt[pr.x], Hh, bl, p);
+            const double w2 = Wt[pr.y], w1 = DIAG ? w2 : Wt[pr.x];
+            const double Hs[9] = {Hh[0], Hh[1], Hh[2], Hh[1], Hh[3], Hh[4], Hh[2], Hh[4], Hh[5]};
+            ba_inv3_damped(Hs, lambda, h);
+            double Jl2[2][3], G2[2][3];
+            pb_jac(B.cam, T2, p, Jp2, Jl2);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) M[a][b] = w2 * w2 * (G2[a][0] * Jl2[b][0] + G2[a][1] * Jl2[b][1] + G2[a][2] * Jl2[b][2]);
-            const double g0 = w2 * (G2[0][0] * bl[0] + G2[0][1] * bl[1] + G2[0][2] * bl[2]), g1 = w2 * (G2[1][0] * bl[0] + G2[1][1] * bl[1] + G2[1][2] * bl[2]);
+                for (int c = 0; c < 3; ++c) G2[a][c] = Jl2[a][0] * h[c] + Jl2[a][1] * h[3 + c] + Jl2[a][2] * h[6 + c];
+            if (DIAG) {
 #pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                const double n0 = M[0][0] * Jp2[0][c] + M[0][1] * Jp2[1][c], n1 = M[1][0] * Jp2[0][c] + M[1][1] * Jp2[1][c];
+                for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int r6 = 0; r6 < 6; ++r6) v[6 * r6 + c] += Jp2[0][r6] * n0 + Jp2[1][r6] * n1;
+                    for (int b = 0; b < 2; ++b) M[a][b] = w2 * w2 * (G2[a][0] * Jl2[b][0] + G2[a][1] * Jl2[b][1] + G2[a][2] * Jl2[b][2]);
+                g[0] = w2 * (G2[0][0] * bl[0] + G2[0][1] * bl[1] + G2[0][2] * bl[2]); g[1] = w2 * (G2[1][0] * bl[0] + G2[1][1] * bl[1] + G2[1][2] * bl[2]);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) Jp1[a][c] = Jp2[a][c];
+            } else {
+                double Jl1[2][3];
+                pb_jac(B.cam, T1, p, Jp1, Jl1);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) M[a][b] = w1 * w2 * (Jl1[a][0] * G2[b][0] + Jl1[a][1] * G2[b][1] + Jl1[a][2] * G2[b][2]);
             }
+        }
 #pragma unroll
-            for (int r6 = 0; r6 < 6; ++r6) v[36 + r6] += Jp2[0][r6] * g0 + Jp2[1][r6] * g1;
-        } else {
-            double Jp1[2][6], Jl1[2][3];
-            pb_jac(B.cam, T1, p, Jp1, Jl1);
+        for (int cp = 0; cp < 3; ++cp) {                                   // columns 2 cp, 2 cp + 1 of the block: x[6 cc + r]; x[12 + cc]: entry 2 cp + cc of b_s
+            double x[16], o4[4];
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) M[a][b] = w1 * w2 * (Jl1[a][0] * G2[b][0] + Jl1[a][1] * G2[b][1] + Jl1[a][2] * G2[b][2]);
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
+            for (int cc = 0; cc < 2; ++cc) {
+                const int c = 2 * cp + cc;
                 const double n0 = M[0][0] * Jp2[0][c] + M[0][1] * Jp2[1][c], n1 = M[1][0] * Jp2[0][c] + M[1][1] * Jp2[1][c];
 #pragma unroll
-                for (int r6 = 0; r6 < 6; ++r6) v[6 * r6 + c] += Jp1[0][r6] * n0 + Jp1[1][r6] * n1;
+                for (int r6 = 0; r6 < 6; ++r6) x[6 * cc + r6] = Jp1[0][r6] * n0 + Jp1[1][r6] * n1;
+                x[12 + cc] = DIAG ? Jp2[0][c] * g[0] + Jp2[1][c] * g[1] : 0.0;
+            }
+            x[14] = x[15] = 0.0;
+            vo_wave_reduce16(x, o4);
+            if ((lane & 15) == 0) {
+                const int slot = VO_R32_SLOT(lane >> 4);
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    double* d = s_part + wave * 48 + 16 * cp + 4 * k4 + slot;
+                    *d = base ? *d + o4[k4] : o4[k4];
+                }
             }
         }
     }
 #ifdef P2_STAMPS
     ts_[1] = wall_clock64();
 #endif
-    {
-        double r0[8], r1[8];
-        {
-            double lo[32];
-#pragma unroll
-            for (int i = 0; i < 32; ++i) lo[i] = v[i];
-            vo_wave_reduce32(lo, r0);
-        }
-        {
-            double hi[32];
-#pragma unroll
-            for (int i = 0; i < 32; ++i) hi[i] = i < NV - 32 ? v[32 + i] : 0.0;
-            vo_wave_reduce32(hi, r1);
-        }
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        if ((lane & 15) == 0) {
-            const int slot = VO_R32_SLOT(lane >> 4);
-#pragma unroll
-            for (int k8 = 0; k8 < 8; ++k8) s_part[wave * 42 + 4 * k8 + slot] = r0[k8];
-#pragma unroll
-            for (int k8 = 0; k8 < 3; ++k8) if (4 * k8 + slot < NV - 32) s_part[wave * 42 + 32 + 4 * k8 + slot] = r1[k8];
-        }
-    }
     __syncthreads();
-    if (threadIdx.x < NV) s_tot[threadIdx.x] = s_part[threadIdx.x] + s_part[42 + threadIdx.x] + s_part[84 + threadIdx.x] + s_part[126 + threadIdx.x];
+    if (threadIdx.x < 48) s_tot[threadIdx.x] = s_part[threadIdx.x] + s_part[48 + threadIdx.x] + s_part[96 + threadIdx.x] + s_part[144 + threadIdx.x];
     __syncthreads();
-    if (threadIdx.x < 36) {
-        const int r = threadIdx.x / 6, c = threadIdx.x % 6;
+    if (threadIdx.x < 48) {
+        const int cp = threadIdx.x >> 4, idx = threadIdx.x & 15;
         const double val = s_tot[threadIdx.x];
-        if (DIAG) { if (c <= r) atomicAdd(&B.S[ba_tri(6 * blk.j1 + r, 6 * blk.j1 + c)], -val); }
-        else atomicAdd(&B.S[ba_tri(6 * blk.j2 + c, 6 * blk.j1 + r)], -val);          // j1 < j2: the block below the diagonal is the one the Cholesky reads
-    } else if (DIAG && threadIdx.x < 42) {
-        atomicAdd(&B.bs[6 * blk.j1 + threadIdx.x - 36], -s_tot[threadIdx.x]);
+        if (idx < 12) {
+            const int r = idx % 6, c = 2 * cp + idx / 6;
+            if (DIAG) { if (c <= r) atomicAdd(&B.S[ba_tri(6 * blk.j1 + r, 6 * blk.j1 + c)], -val); }
+            else atomicAdd(&B.S[ba_tri(6 * blk.j2 + c, 6 * blk.j1 + r)], -val);          // j1 < j2: the block below the diagonal is the one the Cholesky reads
+        } else if (DIAG && idx < 14) {
+            atomicAdd(&B.bs[6 * blk.j1 + 2 * cp + idx - 12], -val);
+        }
     }
 #ifdef P2_STAMPS
     ts_[2] = wall_clock64();
@@ -188,8 +193,8 @@ __device__ __forceinline__ void p2_schur_slice(const BaDev& B, const BaBlock blk
 __global__ __launch_bounds__(256) void k_ba_schur2(BaBatch Q) {
     BA_PROBLEM(Q)
     if (ctl_->finished || B.D > BA_FOLD_D) return;
-    __shared__ double s_part[4 * 42];
-    __shared__ double s_tot[42];
+    __shared__ double s_part[4 * 48];
+    __shared__ double s_tot[48];
     BA_STATE(B)
     const int n_pose_blk = B.n_free * PSPLIT;
     if ((int)blockIdx.x < n_pose_blk) {

@@ -60,6 +60,23 @@ __device__ __forceinline__ void vo_wave_reduce32(double (&v)[32], double (&out)[
         out[k] = x;
     }
 }
+// 16 values: v[0..15] per-lane partials; out[k], k = 0..3: every lane of row r holds the wavefront sum of v[4 k + VO_R32_SLOT(r)] (28 adds)
+__device__ __forceinline__ void vo_wave_reduce16(double (&v)[16], double (&out)[4]) {
+    double p[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { double a = v[2 * i], b = v[2 * i + 1]; vo_swap_halves_f64(a, b); p[i] = a + b; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { double a = p[2 * k], b = p[2 * k + 1]; vo_swap_rows_f64(a, b); out[k] = a + b; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double x = out[k];
+        x += vo_dpp_mov_f64<0x128, 0xF>(x);
+        x += vo_dpp_mov_f64<0x124, 0xF>(x);
+        x += vo_dpp_mov_f64<0x122, 0xF>(x);
+        x += vo_dpp_mov_f64<0x121, 0xF>(x);
+        out[k] = x;
+    }
+}
 
 // 1 / sqrt(d): v_rsq_f64 (2^-24) + one cubic correction e (1/2 + 3/8 e), e = 1 - d y^2 -> 2^-52.7 relative error,
 // 6 dependent operations instead of the ~25 of an IEEE sqrt followed by an IEEE divide.

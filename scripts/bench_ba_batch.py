@@ -15,7 +15,7 @@ def main():
     ap.add_argument("--reps", type=int, default=30)
     args = ap.parse_args()
     from rgbd_visualodometry_amd import capi
-    H = capi.load(capi.HIP_LIB)
+    H = capi.load(os.environ.get("VO_HIP_LIB", capi.HIP_LIB))
     p = H.default_params(map_capacity=1024)
     for T in [int(v) for v in args.threads.split(",")]:
         probs = [make_problem(p, 50, 24, 9000, 16, 11 + k) for k in range(T)]

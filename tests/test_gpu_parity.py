@@ -293,6 +293,15 @@ def test_track_batch_equals_sequential_calls(frames, libs):
     res2, ms2 = ctx.track_batch_deferred([1, 2, 3, 4], inv12(Twc[0]), tp, seeds, cap=4096)
     for j in range(4):
         assert np.array_equal(np.array(res2[j].T_cw), np.array(res[j].T_cw)) and np.array_equal(ms2[j], ms[j])
+    # the two-halves form (what the front-end's track-ahead uses): _end without a chain is a state error, then same records
+    with pytest.raises(capi.VoError):
+        ctx.track_batch_end(4)
+    n = ctx.track_batch_begin([1, 2, 3, 4], inv12(Twc[0]), tp, seeds, cap=4096)
+    res3, ms3 = ctx.track_batch_end(n, cap=4096)
+    for j in range(4):
+        for f in ("n_candidates", "n_matches", "n_ransac_inliers", "n_lm_inliers", "min_distance", "ransac_iters", "best_hypothesis", "lm_iters"):
+            assert getattr(res3[j], f) == getattr(res[j], f), (j, f)
+        assert np.array_equal(np.array(res3[j].T_cw), np.array(res[j].T_cw)) and np.array_equal(ms3[j], ms[j])
 
 
 def test_vo_system_gpu_matches_oracle_trajectory(frames):
