@@ -63,8 +63,10 @@ typedef struct vo_params {
     int32_t map_capacity;           /* device map capacity in points                        */
     int32_t max_hypotheses;         /* RANSAC hypothesis capacity (>= n_hyp ever passed)    */
     int32_t max_track_batch;        /* frames tracked concurrently by vo_track_batch (0/1 = one) */
-    int32_t stream_priority;        /* 0 = default; 1 = the context's HIP stream is created with the highest priority (the
-                                       back-end's context: local BA is the latency-critical chain beside tracking) */
+    int32_t stream_priority;        /* class of the context's HIP stream: 0 = default, > 0 = highest, < 0 = lowest.  The runtime keeps a pool of
+                                       hardware queues per class and streams of one class share its queues: the library's own pace-setting
+                                       streams (BA engines, group chains) are in the highest class; a back-end's private context, which only
+                                       prepares problems, takes the lowest so that its queues are not the trackers'  */
     int32_t reserved[6];
 } vo_params;
 

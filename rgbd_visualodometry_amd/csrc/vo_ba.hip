@@ -1766,9 +1766,7 @@ static int ba_engine_solve(BaEngine* E, BaJob* j) {
 static BaEngine* ba_engine_new(int device) {
     BaEngine* E = new BaEngine();
     E->device = device; E->refs = 1;
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);         // BA is the latency-critical chain beside tracking
-    bool ok = hipStreamCreateWithPriority(&E->st, hipStreamNonBlocking, hi) == hipSuccess;
+    bool ok = vo_stream_create(&E->st, 1, nullptr) == hipSuccess;      // BA is the latency-critical chain beside tracking
     ok = ok && hipMalloc((void**)&E->d_Bs, sizeof(BaDev) * BA_SLOTS) == hipSuccess && hipMalloc((void**)&E->d_ctl, sizeof(BaCtl) * BA_SLOTS) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&E->h_Bs, sizeof(BaDev) * BA_SLOTS, hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&E->h_stat, sizeof(BaStat) * BA_SLOTS, hipHostMallocDefault) == hipSuccess;
@@ -1785,16 +1783,18 @@ static BaEngine* ba_engine_new(int device) {
 }
 
 // The engines of a device: the first context creates engine 0, the last one ends them all.  A device may run several engines
-// (VO_BA_ENGINES, default 2): while one engine's dense solves keep a handful of compute units busy, the other's Schur kernel
-// fills the rest of the chip.  A context is bound to one of them by its first solve (ba_engine_of), so contexts that never
-// run a local BA -- the trackers of an overlapped back-end -- do not take part in the rotation.
+// (VO_BA_ENGINES, default 1).  Two were the default while a step was five launches with host round trips between chunks: the second
+// engine's kernels filled the first one's gaps.  With the three-launch step and the device-side round transitions the gaps are gone and
+// two engines' step kernels only slow each other down (isolated, 16 problems: one engine 2400 BA/s, two 1260; 32 streams: 5556 against
+// 4721 frames/s).  A context is bound to an engine by its first solve (ba_engine_of), so contexts that never run a local BA -- the
+// trackers of an overlapped back-end -- do not take part in the rotation.
 BaEngine* vo_ba_engine_acquire(int device) {
     std::unique_lock<std::mutex> lk(g_eng_mu);
     for (BaEngine* E : g_engines) if (E->device == device) { ++E->refs; return E; }
     BaEngine* E = ba_engine_new(device);
     if (!E) return nullptr;
     const char* env = getenv("VO_BA_ENGINES");
-    E->n_sib = std::max(1, std::min(BA_MAX_ENGINES, env ? atoi(env) : 2));
+    E->n_sib = std::max(1, std::min(BA_MAX_ENGINES, env ? atoi(env) : 1));
     E->sib[0] = E;
     g_engines.push_back(E);
     return E;
@@ -2671,7 +2671,7 @@ extern "C" int vo_local_ba_resident_merge(vo_ctx* c, vo_ctx* t) {
                        (const int*)R.d_pose_kf, (const int32_t*)R.d_point_slots, (const int*)R.d_ncull, (const long long*)R.d_cull, R.cull_cap, t->d_map_pos, (const uint8_t*)t->d_map_flags,
                        t->d_kf_pose, t->d_obs_alive, (double*)sb, (double*)(sb + o_pts), (int32_t*)(sb + o_sl));
     if (!R.ev_merge) HIP_TRY(hipEventCreateWithFlags(&R.ev_merge, hipEventDisableTiming));
-    if (!R.fetch_stream) HIP_TRY(hipStreamCreateWithFlags(&R.fetch_stream, hipStreamNonBlocking));
+    if (!R.fetch_stream) HIP_TRY(vo_stream_create(&R.fetch_stream, -1, "VO_FETCH_PRIO"));      // lowest class: three small copies behind an event wait must not sit in a queue a chain uses
     HIP_TRY(hipEventRecord(R.ev_merge, t->stream));
     HIP_TRY(hipStreamWaitEvent(c->stream, R.ev_merge, 0));
     HIP_TRY(hipStreamWaitEvent(R.fetch_stream, R.ev_merge, 0));

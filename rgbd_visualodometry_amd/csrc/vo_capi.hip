@@ -218,6 +218,14 @@ struct vo_group {
 static int chain_run(vo_ctx* prof, hipStream_t st, LaunchSet& ls, std::vector<GroupReq*>& batch);
 static int shard_exchange(vo_ctx* c, hipStream_t st, int nl, int n_hyp);
 
+hipError_t vo_stream_create(hipStream_t* st, int cls, const char* env) {
+    if (env) { if (const char* e = getenv(env)) cls = atoi(e); }
+    if (cls == 0) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // numerically lower = higher priority: `hi` is the highest, `lo` the lowest
+    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, cls > 0 ? hi : lo);
+}
+
 extern "C" {
 
 const char* vo_backend_name(void) { return "hip-gfx950"; }
@@ -300,13 +308,7 @@ int vo_ctx_create(const vo_params* p, int device, vo_ctx** out) {
     std::vector<int> tab; std::vector<short> tabs;
     int rc = build_plan(*p, c->plan, tab, tabs);
     if (rc) { delete c; return rc; }
-    {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // numerically lower = higher priority
-        const hipError_t se = p->stream_priority > 0 ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi)
-                                                     : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-        if (se != hipSuccess) { delete c; return VO_E_DEVICE; }
-    }
+    if (vo_stream_create(&c->stream, p->stream_priority, nullptr) != hipSuccess) { delete c; return VO_E_DEVICE; }
     rc = vo_orb_upload_constants();
     if (rc) { vo_ctx_destroy(c); return rc; }
     rc = vo_track_set_attrs();
@@ -1008,7 +1010,7 @@ int vo_group_create(int device, int max_lanes, vo_group** out) {
     const char* env = getenv("VO_GROUP_CHAINS");
     g->n_slots = std::max(1, std::min(VO_GROUP_MAX_CHAINS, env ? atoi(env) : 1));
     for (int i = 0; i < g->n_slots; ++i) {
-        if (hipStreamCreateWithFlags(&g->slot[i].stream, hipStreamNonBlocking) != hipSuccess) { vo_group_destroy(g); return VO_E_DEVICE; }
+        if (vo_stream_create(&g->slot[i].stream, 1, "VO_GROUP_PRIO") != hipSuccess) { vo_group_destroy(g); return VO_E_DEVICE; }      // the members' pace: a queue of the highest class
         if (launchset_alloc(g->slot[i].ls, max_lanes) != VO_OK) { vo_group_destroy(g); return VO_E_NOMEM; }
     }
     *out = g;

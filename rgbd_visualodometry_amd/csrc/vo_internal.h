@@ -142,6 +142,11 @@ void vo_prof_end(vo_ctx* c, int ticket);
 struct ProfScope { vo_ctx* c; int idx;
     ProfScope(vo_ctx* c_, const char* n, hipStream_t st = nullptr) : c(c_), idx(c_->prof_on.load(std::memory_order_relaxed) ? vo_prof_begin(c_, n, st) : -1) {}      // st: the stream the kernel runs on (default: the context's)
     ~ProfScope() { if (idx >= 0) vo_prof_end(c, idx); } };
+// A non-blocking stream of one of the runtime's three priority classes (cls < 0: lowest, 0: default, > 0: highest).  The runtime keeps a pool of
+// hardware queues per class (GPU_MAX_HW_QUEUES each; streams beyond that share queues of their class), so the class also says WHOSE queues a
+// stream may share: the chains that set a stream's pace (a group's tracking chain, the BA engines' step launches) live in the highest class, where
+// nothing with cross-stream waits or long batches is created beside them.  `env` names an override for experiments.
+hipError_t vo_stream_create(hipStream_t* st, int cls, const char* env);
 void* vo_stage(vo_ctx* c, size_t bytes);           // pinned host staging buffer of at least `bytes`
 int vo_scratch(vo_ctx* c, size_t bytes);           // grow the device scratch slab c->d_ba to at least `bytes`
 int vo_map_scatter_launch(vo_ctx* c, int n, const int32_t* d_idx, const double* d_xyz, const double* d_nrm, const uint32_t* d_desc, const int32_t* d_kp, const uint8_t* d_flags);

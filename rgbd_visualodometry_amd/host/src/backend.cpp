@@ -35,7 +35,9 @@ void Backend::EnsureWorker() {
         vo_params p; vo_default_params(&p);
         p.fx = camera_->GetFx(); p.fy = camera_->GetFy(); p.cx = camera_->GetCx(); p.cy = camera_->GetCy();
         p.n_features = 64; p.max_frames = 1; p.map_capacity = 64; p.max_hypotheses = 1;
-        p.stream_priority = 1;                          // BA is the latency-critical chain beside tracking
+        p.stream_priority = -1;                         // problem preparation (graph cut, uploads, pair lists) in the lowest class: a pool of hardware queues of its own, away from
+                                                        // the trackers' streams (default class) and from the pace-setting chains (highest class: BA engines, group chains)
+        if (const char* e = std::getenv("VO_BACKEND_PRIO")) p.stream_priority = std::atoi(e);      // experiments
         int rc = vo_ctx_create(&p, device_, &ctxOwn_);
         if (rc != VO_OK) throw std::runtime_error(std::string("vo_ctx_create (backend) failed: ") + vo_strerror(rc));
     }

@@ -23,3 +23,4 @@ python scripts/trace_busy.py $O/trace8 --tail-frac 0.5 --out $O/r03_multistream8
 python scripts/trace_gaps.py $O/trace1 > $O/r03_ba_gaps.txt 2>&1 || true
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
 ls -la $O | head -40
+(cd rgbd_visualodometry_amd/csrc && timeout -k 10 120 ./build/queue_map > $O/r03_queue_map.txt 2>&1) || true
