@@ -218,14 +218,6 @@ struct vo_group {
 static int chain_run(vo_ctx* prof, hipStream_t st, LaunchSet& ls, std::vector<GroupReq*>& batch);
 static int shard_exchange(vo_ctx* c, hipStream_t st, int nl, int n_hyp);
 
-hipError_t vo_stream_create(hipStream_t* st, int cls, const char* env) {
-    if (env) { if (const char* e = getenv(env)) cls = atoi(e); }
-    if (cls == 0) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // numerically lower = higher priority: `hi` is the highest, `lo` the lowest
-    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, cls > 0 ? hi : lo);
-}
-
 extern "C" {
 
 const char* vo_backend_name(void) { return "hip-gfx950"; }

@@ -1,6 +1,7 @@
 // vo_internal.h -- internal declarations of the HIP implementation of include/vo_hip.h.
 // Target: gfx950 (MI355X, CDNA4) only: 64-wide wavefronts, 160 KiB LDS per CU, 256 CUs.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -146,7 +147,13 @@ struct ProfScope { vo_ctx* c; int idx;
 // hardware queues per class (GPU_MAX_HW_QUEUES each; streams beyond that share queues of their class), so the class also says WHOSE queues a
 // stream may share: the chains that set a stream's pace (a group's tracking chain, the BA engines' step launches) live in the highest class, where
 // nothing with cross-stream waits or long batches is created beside them.  `env` names an override for experiments.
-hipError_t vo_stream_create(hipStream_t* st, int cls, const char* env);
+inline hipError_t vo_stream_create(hipStream_t* st, int cls, const char* env) {
+    if (env) { if (const char* e = getenv(env)) cls = atoi(e); }
+    if (cls == 0) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // numerically lower = higher priority: `hi` is the highest, `lo` the lowest
+    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, cls > 0 ? hi : lo);
+}
 void* vo_stage(vo_ctx* c, size_t bytes);           // pinned host staging buffer of at least `bytes`
 int vo_scratch(vo_ctx* c, size_t bytes);           // grow the device scratch slab c->d_ba to at least `bytes`
 int vo_map_scatter_launch(vo_ctx* c, int n, const int32_t* d_idx, const double* d_xyz, const double* d_nrm, const uint32_t* d_desc, const int32_t* d_kp, const uint8_t* d_flags);
