@@ -87,9 +87,13 @@ struct BaDev {
 // (B.ctl holds the same address, but behind a dependent load of the descriptor: one memory latency more at every kernel start)
 struct BaBatch { const BaDev* Bs; BaCtl* ctls; BaStat* stat; int n; int slot[BA_SLOTS]; };
 #define BA_PROBLEM(Q) const BaDev& B = Q.Bs[Q.slot[blockIdx.z]]; BaCtl* const ctl_ = Q.ctls + Q.slot[blockIdx.z];
+// The same with the descriptor copied at kernel entry: there every field is a scalar load (nothing has been stored yet, so the compiler may treat
+// the descriptor as unclobbered); a field read through the reference AFTER the kernel's first store comes back through a vector load into vector
+// registers -- per use, and for good where it is a base pointer of a loop.
+#define BA_PROBLEM_COPY(Q) const BaDev B_copy_ = Q.Bs[Q.slot[blockIdx.z]]; const BaDev& B = B_copy_; BaCtl* const ctl_ = Q.ctls + Q.slot[blockIdx.z];
 
 #define BA_STATE(B) \
-    const int buf_ = ctl_->buf; \
+    const int buf_ = __builtin_amdgcn_readfirstlane(ctl_->buf); \
     double* const poses_c = buf_ ? B.posesB : B.posesA; double* const pts_c = buf_ ? B.ptsB : B.ptsA; \
     double* const poses_t = buf_ ? B.posesA : B.posesB; double* const pts_t = buf_ ? B.ptsA : B.ptsB; \
     (void)poses_c; (void)pts_c; (void)poses_t; (void)pts_t;

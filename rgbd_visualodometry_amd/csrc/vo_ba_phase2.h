@@ -33,6 +33,73 @@ __device__ __forceinline__ void p2_rec_load(const double* rec, int k, double (&H
     H[0] = a.x; H[1] = a.y; H[2] = b.x; H[3] = b.y; H[4] = c.x; H[5] = c.y; b3[0] = d.x; b3[1] = d.y; b3[2] = e.x; p[0] = e.y; p[1] = f.x; p[2] = f.y;
 }
 
+// A workgroup-uniform f64 in a scalar register pair (the two poses of a block: 24 values that would otherwise sit in 48 vector registers)
+__device__ __forceinline__ double p2_uniform(double x) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+// One slice (<= BA_SLICE pairs) of a 6x6 block.  A thread holds ONE pair at a time and nothing across pairs: the pair's 36 (+ 6) products leave in three
+// 16-value wavefront reductions (two columns of the block each, + two entries of b_s on a diagonal block) whose results the row leaders add up in
+// LDS.  Register need is the two pose Jacobians + one 16-value reduction (round 3 first kept 42 f64 accumulators per thread: 226 VGPRs, two
+// waves per SIMD, and a launch over several problems ran its workgroups in as many rounds as it had problems).
+// ba_lin_poses_body without per-lane accumulators (27 f64 = 54 registers across the edge loop made this the register peak of k_ba_schur2): every
+// round of 256 edges leaves its 21 + 6 products in two 16-value wavefront reductions whose row leaders add them up in LDS (s_part: 4 waves x 32).
+__device__ __forceinline__ void p2_lin_poses_body(const BaCam& cam, const BaDev& B, int robust, double delta, int blk, const double* poses_c, const double* pts_c, double* s_part) {
+    const int j = blk / PSPLIT, part = blk % PSPLIT;
+    const int q_lo = __builtin_amdgcn_readfirstlane(B.ps_start[j]) + part * 256, q_hi = __builtin_amdgcn_readfirstlane(B.ps_start[j + 1]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = p2_uniform(poses_c[12 * (size_t)j + i]);
+    if (threadIdx.x < 128) s_part[threadIdx.x] = 0.0;
+    __syncthreads();
+    for (int q0 = q_lo; q0 < q_hi; q0 += 256 * PSPLIT) {                  // workgroup-uniform trip count
+        const int q = q0 + threadIdx.x;
+        double r[2] = {0, 0}, w = 0, rho0, Jp[2][6], Jl[2][3];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) Jp[a][c] = 0;
+        if (q < q_hi) {
+            const int e = B.ps_edges[q];
+            if (B.active[e]) ba_edge(cam, T, pts_c + 3 * (size_t)B.e_pt[e], B.e_uv + 2 * (size_t)e, robust, delta, r, w, rho0, Jp, Jl);
+            else w = 0;
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {                            // upper-triangle entries 0..15, then 16..20 and the 6 of b_p (21..26)
+            double x[16], o4[4];
+            int c = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = a; b < 6; ++b, ++c) if (c / 16 == half) x[c % 16] = w * (Jp[0][a] * Jp[0][b] + Jp[1][a] * Jp[1][b]);
+            if (half) {
+#pragma unroll
+                for (int a = 0; a < 6; ++a) x[5 + a] = -(w * (Jp[0][a] * r[0] + Jp[1][a] * r[1]));
+#pragma unroll
+                for (int i = 11; i < 16; ++i) x[i] = 0.0;
+            }
+            vo_wave_reduce16(x, o4);
+            if ((lane & 15) == 0) {
+                const int slot = VO_R32_SLOT(lane >> 4);
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) s_part[wave * 32 + 16 * half + 4 * k4 + slot] += o4[k4];
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 27) {
+        const int i = threadIdx.x;
+        const double t = s_part[i] + s_part[32 + i] + s_part[64 + i] + s_part[96 + i];
+        if (i < 21) {
+            int a = 0, rem = i;
+            while (rem >= 6 - a) { rem -= 6 - a; ++a; }        // upper-triangle index -> (a, b)
+            const int b = a + rem;
+            atomicAdd(&B.Hpp[36 * (size_t)j + 6 * a + b], t);
+            if (a != b) atomicAdd(&B.Hpp[36 * (size_t)j + 6 * b + a], t);
+        } else atomicAdd(&B.bp[6 * j + (i - 21)], t);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_ba_lin2(BaBatch Q) {
     BA_PROBLEM(Q)
     if (ctl_->finished || B.D > BA_FOLD_D) return;
@@ -42,7 +109,7 @@ __global__ __launch_bounds__(256) void k_ba_lin2(BaBatch Q) {
     __shared__ double s_part[4 * 32];
     const int robust = ctl_->robust;
     if ((int)blockIdx.x >= gp) {
-        if ((int)blockIdx.x - gp < B.n_free * PSPLIT) ba_lin_poses_body(B.cam, B, robust, B.delta, blockIdx.x - gp, poses_c, pts_c, s_part);
+        if ((int)blockIdx.x - gp < B.n_free * PSPLIT) p2_lin_poses_body(B.cam, B, robust, B.delta, blockIdx.x - gp, poses_c, pts_c, s_part);
         return;
     }
     double* const rec = p2_rec(B, ctl_->lbuf);
@@ -88,14 +155,31 @@ __global__ void k_ba_maxdiag2(BaBatch Q) {
     if ((threadIdx.x & 63) == 0 && v > 0) atomicMax((unsigned long long*)&B.scal[4], (unsigned long long)__double_as_longlong(v));
 }
 
-// A workgroup-uniform f64 in a scalar register pair (the two poses of a block: 24 values that would otherwise sit in 48 vector registers)
-__device__ __forceinline__ double p2_uniform(double x) {
-    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+// pb_jac in two halves: the camera-frame point (X, Y, 1 / Z), and the pose Jacobian rebuilt from it (the same expressions: the values are pb_jac's)
+__device__ __forceinline__ void p2_cam_point(const double (&T)[12], const double (&p)[3], double& X, double& Y, double& Zi) {
+#pragma clang fp contract(fast)
+    X = T[0] * p[0] + T[1] * p[1] + T[2] * p[2] + T[9]; Y = T[3] * p[0] + T[4] * p[1] + T[5] * p[2] + T[10];
+    const double Z = T[6] * p[0] + T[7] * p[1] + T[8] * p[2] + T[11];
+    Zi = 1.0 / (Z + 1e-18);
+}
+__device__ __forceinline__ void p2_jp(const BaCam& cam, double X, double Y, double Zi, double (&Jp)[2][6]) {
+#pragma clang fp contract(fast)
+    const double Zi2 = Zi * Zi, fx = cam.fx, fy = cam.fy;
+    Jp[0][0] = -fx * Zi; Jp[0][1] = 0; Jp[0][2] = fx * X * Zi2; Jp[0][3] = fx * X * Y * Zi2; Jp[0][4] = -fx - fx * X * X * Zi2; Jp[0][5] = fx * Y * Zi;
+    Jp[1][0] = 0; Jp[1][1] = -fy * Zi; Jp[1][2] = fy * Y * Zi2; Jp[1][3] = fy + fy * Y * Y * Zi2; Jp[1][4] = -fy * X * Y * Zi2; Jp[1][5] = -fy * X * Zi;
+}
+__device__ __forceinline__ void p2_jl(const double (&Jp)[2][6], const double (&T)[12], double (&Jl)[2][3]) {
+#pragma clang fp contract(fast)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Jl[a][c] = Jp[a][0] * T[c] + Jp[a][1] * T[3 + c] + Jp[a][2] * T[6 + c];
 }
 // One slice (<= BA_SLICE pairs) of a 6x6 block.  A thread holds ONE pair at a time and nothing across pairs: the pair's 36 (+ 6) products leave in three
 // 16-value wavefront reductions (two columns of the block each, + two entries of b_s on a diagonal block) whose results the row leaders add up in
-// LDS.  Register need is the two pose Jacobians + one 16-value reduction (round 3 first kept 42 f64 accumulators per thread: 226 VGPRs, two
-// waves per SIMD, and a launch over several problems ran its workgroups in as many rounds as it had problems).
+// LDS.  Between the passes a lane keeps only the two camera-frame points, the 2x2 middle factor M and g: the 2x6 pose Jacobians are rebuilt from
+// the camera-frame points in every pass (a dozen multiplications) instead of occupying 40 registers.  (Round 3 first kept 42 f64 accumulators
+// per thread: 226 VGPRs, two waves per SIMD, and a launch over several problems ran its workgroups in as many rounds as it had problems.)
 template <bool DIAG>
 __device__ __forceinline__ void p2_schur_slice(const BaDev& B, const BaBlock blk, double lambda, const double* poses_c, const double* rec, const double* Wt, double* s_part, double* s_tot) {
 #ifdef P2_STAMPS
@@ -109,19 +193,17 @@ __device__ __forceinline__ void p2_schur_slice(const BaDev& B, const BaBlock blk
         bool on = base + (int)threadIdx.x < blk.count;
         int2 pr = make_int2(0, 0);
         if (on) { pr = B.pairs[blk.start + base + threadIdx.x]; on = B.active[pr.x] && (DIAG || B.active[pr.y]); }
-        double Jp1[2][6], Jp2[2][6], M[2][2] = {{0, 0}, {0, 0}}, g[2] = {0, 0};
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int c = 0; c < 6; ++c) Jp1[a][c] = Jp2[a][c] = 0;
+        double X1 = 0, Y1 = 0, Zi1 = 0, X2 = 0, Y2 = 0, Zi2 = 0, M[2][2] = {{0, 0}, {0, 0}}, g[2] = {0, 0};      // an idle lane: M = g = 0, every product is 0
         if (on) {
             double Hh[6], bl[3], p[3], h[9];
             p2_rec_load(rec, B.e_pt[pr.x], Hh, bl, p);
             const double w2 = Wt[pr.y], w1 = DIAG ? w2 : Wt[pr.x];
             const double Hs[9] = {Hh[0], Hh[1], Hh[2], Hh[1], Hh[3], Hh[4], Hh[2], Hh[4], Hh[5]};
             ba_inv3_damped(Hs, lambda, h);
-            double Jl2[2][3], G2[2][3];
-            pb_jac(B.cam, T2, p, Jp2, Jl2);
+            double Jp2[2][6], Jl2[2][3], G2[2][3];
+            p2_cam_point(T2, p, X2, Y2, Zi2);
+            p2_jp(B.cam, X2, Y2, Zi2, Jp2);
+            p2_jl(Jp2, T2, Jl2);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -132,13 +214,11 @@ __device__ __forceinline__ void p2_schur_slice(const BaDev& B, const BaBlock blk
 #pragma unroll
                     for (int b = 0; b < 2; ++b) M[a][b] = w2 * w2 * (G2[a][0] * Jl2[b][0] + G2[a][1] * Jl2[b][1] + G2[a][2] * Jl2[b][2]);
                 g[0] = w2 * (G2[0][0] * bl[0] + G2[0][1] * bl[1] + G2[0][2] * bl[2]); g[1] = w2 * (G2[1][0] * bl[0] + G2[1][1] * bl[1] + G2[1][2] * bl[2]);
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) Jp1[a][c] = Jp2[a][c];
             } else {
-                double Jl1[2][3];
-                pb_jac(B.cam, T1, p, Jp1, Jl1);
+                double Jp1[2][6], Jl1[2][3];
+                p2_cam_point(T1, p, X1, Y1, Zi1);
+                p2_jp(B.cam, X1, Y1, Zi1, Jp1);
+                p2_jl(Jp1, T1, Jl1);
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -147,6 +227,17 @@ __device__ __forceinline__ void p2_schur_slice(const BaDev& B, const BaBlock blk
         }
 #pragma unroll
         for (int cp = 0; cp < 3; ++cp) {                                   // columns 2 cp, 2 cp + 1 of the block: x[6 cc + r]; x[12 + cc]: entry 2 cp + cc of b_s
+            // (the empty asm makes the camera-frame points new values to the compiler in every pass: it must not keep the Jacobians of one pass for the next)
+            asm volatile("" : "+v"(X2), "+v"(Y2), "+v"(Zi2));
+            if (!DIAG) asm volatile("" : "+v"(X1), "+v"(Y1), "+v"(Zi1));
+            double Jp1[2][6], Jp2[2][6];
+            p2_jp(B.cam, X2, Y2, Zi2, Jp2);
+            if (DIAG) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) Jp1[a][c] = Jp2[a][c];
+            } else p2_jp(B.cam, X1, Y1, Zi1, Jp1);
             double x[16], o4[4];
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
@@ -191,7 +282,7 @@ __device__ __forceinline__ void p2_schur_slice(const BaDev& B, const BaBlock blk
 #endif
 }
 __global__ __launch_bounds__(256) void k_ba_schur2(BaBatch Q) {
-    BA_PROBLEM(Q)
+    BA_PROBLEM_COPY(Q)
     if (ctl_->finished || B.D > BA_FOLD_D) return;
     __shared__ double s_part[4 * 48];
     __shared__ double s_tot[48];
@@ -200,15 +291,18 @@ __global__ __launch_bounds__(256) void k_ba_schur2(BaBatch Q) {
     if ((int)blockIdx.x < n_pose_blk) {
         // H_pp / b_p of the accepted state (zeroed by the step that accepted it).  On the first step of a round k_ba_lin2 has done it (lambda_0
         // needs the diagonal before this launch); after a rejected step the sums of the unchanged state are still there.
-        if (ctl_->need_lin && !ctl_->first) ba_lin_poses_body(B.cam, B, ctl_->robust, B.delta, blockIdx.x, poses_c, pts_c, s_part);
+        if (ctl_->need_lin && !ctl_->first) p2_lin_poses_body(B.cam, B, __builtin_amdgcn_readfirstlane(ctl_->robust), B.delta, blockIdx.x, poses_c, pts_c, s_part);
         return;
     }
     const int sl = blockIdx.x - n_pose_blk;
     if (sl >= B.n_blocks || (B.n_slices && sl >= *B.n_slices)) return;
-    const double lambda = (ctl_->need_lin && ctl_->first) ? 1e-5 * B.scal[4] : ctl_->lambda;      // as k_ba_chol16 derives it (the control block is updated there)
-    const BaBlock blk = B.blocks[sl];
-    const double* const rec = p2_rec(B, ctl_->lbuf);
-    const double* const Wt = p2_w(B, ctl_->lbuf);
+    const double lambda = p2_uniform((ctl_->need_lin && ctl_->first) ? 1e-5 * B.scal[4] : ctl_->lambda);      // as k_ba_chol16 derives it (the control block is updated there)
+    BaBlock blk = B.blocks[sl];
+    blk.j1 = __builtin_amdgcn_readfirstlane(blk.j1); blk.j2 = __builtin_amdgcn_readfirstlane(blk.j2);
+    blk.start = __builtin_amdgcn_readfirstlane(blk.start); blk.count = __builtin_amdgcn_readfirstlane(blk.count);
+    const int lb = __builtin_amdgcn_readfirstlane(ctl_->lbuf);
+    const double* const rec = p2_rec(B, lb);
+    const double* const Wt = p2_w(B, lb);
     if (blk.j1 == blk.j2) p2_schur_slice<true>(B, blk, lambda, poses_c, rec, Wt, s_part, s_tot);
     else p2_schur_slice<false>(B, blk, lambda, poses_c, rec, Wt, s_part, s_tot);
 }
@@ -244,10 +338,38 @@ __device__ __forceinline__ void p2_exp_mul(const double* d, const double* T, dou
     Tn[11] = R[6] * T[9] + R[7] * T[10] + R[8] * T[11] + tz;
 }
 
+// Row r (0..2) of exp(d) * T: the three rotation entries and translation entry r -- the same expressions as p2_exp_mul, evaluated by three lanes per
+// pose instead of one lane per pose (k_ba_upchi2: the pose prelude was its register peak and ran on one wave in eight)
+__device__ __forceinline__ void p2_exp_mul_row(const double* d, const double* T, int r, double (&row)[3], double& tr) {
+#pragma clang fp contract(fast)
+    const double w[3] = {d[3], d[4], d[5]};
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    double A, Bc, C;
+    if (th2 < 0.0625) {
+        A = 1.0 - th2 * (1.0 / 6.0) * (1.0 - th2 * (1.0 / 20.0) * (1.0 - th2 * (1.0 / 42.0) * (1.0 - th2 * (1.0 / 72.0) * (1.0 - th2 * (1.0 / 110.0) * (1.0 - th2 * (1.0 / 156.0) * (1.0 - th2 * (1.0 / 210.0)))))));
+        Bc = 0.5 * (1.0 - th2 * (1.0 / 12.0) * (1.0 - th2 * (1.0 / 30.0) * (1.0 - th2 * (1.0 / 56.0) * (1.0 - th2 * (1.0 / 90.0) * (1.0 - th2 * (1.0 / 132.0) * (1.0 - th2 * (1.0 / 182.0) * (1.0 - th2 * (1.0 / 240.0))))))));
+        C = (1.0 / 6.0) * (1.0 - th2 * (1.0 / 20.0) * (1.0 - th2 * (1.0 / 42.0) * (1.0 - th2 * (1.0 / 72.0) * (1.0 - th2 * (1.0 / 110.0) * (1.0 - th2 * (1.0 / 156.0) * (1.0 - th2 * (1.0 / 210.0) * (1.0 - th2 * (1.0 / 272.0))))))));
+    } else { const double th = sqrt(th2); A = sin(th) / th; Bc = (1.0 - cos(th)) / th2; C = (th - sin(th)) / (th2 * th); }
+    const double Wm[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+    const double m0 = r == 0 ? Wm[0] : (r == 1 ? Wm[3] : Wm[6]), m1 = r == 0 ? Wm[1] : (r == 1 ? Wm[4] : Wm[7]), m2 = r == 0 ? Wm[2] : (r == 1 ? Wm[5] : Wm[8]);
+    const double mr[3] = {m0, m1, m2};
+    double Rr[3], Vr[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double w2 = m0 * Wm[c] + m1 * Wm[3 + c] + m2 * Wm[6 + c];
+        const double I = (c == r) ? 1.0 : 0.0;
+        Rr[c] = I + A * mr[c] + Bc * w2; Vr[c] = I + Bc * mr[c] + C * w2;
+    }
+    const double tt = Vr[0] * d[0] + Vr[1] * d[1] + Vr[2] * d[2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) row[c] = Rr[0] * T[c] + Rr[1] * T[3 + c] + Rr[2] * T[6 + c];
+    tr = Rr[0] * T[9] + Rr[1] * T[10] + Rr[2] * T[11] + tt;
+}
+
 // trial state and its robust chi2, then (last workgroup) the LM decision of k_ba_chi_control
 #define UPC_T 512
 __global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q, int rep) {
-    BA_PROBLEM(Q)
+    BA_PROBLEM_COPY(Q)
     if (ctl_->finished || B.D > BA_FOLD_D) return;
     // 128 points per workgroup and round (4 lanes each), `rep` rounds: with several problems per launch every workgroup's fixed costs (the trial
     // poses, the partial sums and the ticket) are spread over more points -- a lone problem keeps rep = 1 and the most workgroups
@@ -257,10 +379,14 @@ __global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q, int rep) {
     double* const s_T = s_dyn;                             // trial poses [n_poses][12]
     double* const s_dp = s_dyn + 12 * (size_t)B.n_poses;   // pose increments [D]
     __shared__ double s_w[3 * (UPC_T / 64)];
+    __shared__ double s_hb[9 * (UPC_T / 4)];               // H_ll (6) and b_l (3) of the round's 128 points, parked during pass 1
     __shared__ int s_last, s_accept;
-    const double lambda = ctl_->lambda;
-    const int robust = ctl_->robust;
-    const bool ok = B.scal[3] != 0.0;
+    // workgroup-uniform values that arrive through vector loads (the control block is written by this kernel's last workgroup, so the compiler
+    // may not use scalar loads): moved to scalar registers by hand, or they and everything derived from them (four record / weight base pointers)
+    // occupy vector registers for the whole kernel
+    const double lambda = p2_uniform(ctl_->lambda);
+    const int robust = __builtin_amdgcn_readfirstlane(ctl_->robust);
+    const bool ok = __builtin_amdgcn_readfirstlane((int)(B.scal[3] != 0.0)) != 0;
 #ifdef P2_STAMPS
     long long tq_[8]; int nq_ = 0; const bool stamp_ = (blockIdx.x == 7 || blockIdx.x == gp - 1) && threadIdx.x == 0 && ctl_->it == 4 && blockIdx.z == 0;
 #define P2_STAMP() { if (nq_ < 8) tq_[nq_++] = wall_clock64(); }
@@ -271,7 +397,7 @@ __global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q, int rep) {
     BA_STATE(B)
     // everything the point passes read from global memory that does not depend on the trial poses is requested BEFORE the poses are
     // built: the ~2 us of exponential maps below hide the two dependent load levels (pt_start -> edge data) of the first round of edges
-    const int lb = ctl_->lbuf;
+    const int lb = __builtin_amdgcn_readfirstlane(ctl_->lbuf);
     const double* const rec = p2_rec(B, lb);
     const double* const Wt = p2_w(B, lb);
     double* const rec_n = p2_rec(B, lb ^ 1);
@@ -297,30 +423,28 @@ __global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q, int rep) {
     fetch();
     double* const s_Tc = s_dp + B.D;                        // current poses [n_poses][12] (pass 1 reads them per edge)
     for (int i = threadIdx.x; i < B.D; i += UPC_T) s_dp[i] = B.dl[i];           // the solution (k_ba_chol16, phase2 = 1)
-    for (int j = threadIdx.x; j < B.n_poses; j += UPC_T) {   // exp(dp) * T for the free poses (ba_pose_body), copies for the fixed ones
-        const double* Tg = poses_c + 12 * (size_t)j;
-        double T[12], Tn[12];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) T[i] = Tg[i];
-        if (j >= B.n_free || !ok) {
-#pragma unroll
-            for (int i = 0; i < 12; ++i) Tn[i] = T[i];
-        } else {
-            const double* d = B.dl + 6 * j;
-            p2_exp_mul(d, T, Tn);
-            if (blockIdx.x == 0) {                         // the pose part of the gain ratio and of the step size, once
-                double sc = 0, mx = 0;
-                for (int a = 0; a < 6; ++a) { sc += d[a] * (lambda * d[a] + B.bp[6 * j + a]); mx = fmax(mx, fabs(d[a])); }
-                atomicAdd(&B.scal[2], sc);
-                atomicMax((unsigned long long*)&B.scal[7], (unsigned long long)__double_as_longlong(mx));
-            }
+    // current poses -> s_Tc; trial poses -> s_T: copies for the fixed ones (and for all of them after a failed factorisation), exp(dp) * T for the free
+    // ones with three lanes per pose, a row each (one lane per pose made this prelude the kernel's register peak, on one wave in eight)
+    const int n_exp = ok ? B.n_free : 0;
+    for (int i = threadIdx.x; i < 12 * B.n_poses; i += UPC_T) {
+        const double v = poses_c[i];
+        s_Tc[i] = v;
+        if (i >= 12 * n_exp) { s_T[i] = v; if (blockIdx.x == 0) poses_t[i] = v; }
+    }
+    for (int t = threadIdx.x; t < 3 * n_exp; t += UPC_T) {
+        const int j = t / 3, r = t - 3 * j;
+        const double* d = B.dl + 6 * j;
+        double row[3], tr;
+        p2_exp_mul_row(d, poses_c + 12 * (size_t)j, r, row, tr);
+        if (blockIdx.x == 0 && r == 0) {                   // the pose part of the gain ratio and of the step size, once
+            double sc = 0, mx = 0;
+            for (int a = 0; a < 6; ++a) { sc += d[a] * (lambda * d[a] + B.bp[6 * j + a]); mx = fmax(mx, fabs(d[a])); }
+            atomicAdd(&B.scal[2], sc);
+            atomicMax((unsigned long long*)&B.scal[7], (unsigned long long)__double_as_longlong(mx));
         }
-#pragma unroll
-        for (int i = 0; i < 12; ++i) { s_T[12 * j + i] = Tn[i]; s_Tc[12 * j + i] = T[i]; }
-        if (blockIdx.x == 0) {
-#pragma unroll
-            for (int i = 0; i < 12; ++i) poses_t[12 * (size_t)j + i] = Tn[i];
-        }
+        double* o = s_T + 12 * j;
+        o[3 * r] = row[0]; o[3 * r + 1] = row[1]; o[3 * r + 2] = row[2]; o[9 + r] = tr;
+        if (blockIdx.x == 0) { double* g = poses_t + 12 * (size_t)j; g[3 * r] = row[0]; g[3 * r + 1] = row[1]; g[3 * r + 2] = row[2]; g[9 + r] = tr; }
     }
     __syncthreads();
     P2_STAMP()
@@ -340,9 +464,19 @@ __global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q, int rep) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) rhs[c] -= w * (Jl[0][c] * t0 + Jl[1][c] * t1);
         };
+        // H_ll and b_l are not needed while pass 1 runs (the kernel's register peak): lane 0 of the point parks them in LDS, all four lanes take them
+        // back afterwards (same wavefront: program order is enough)
+        double* const park = s_hb + (threadIdx.x >> 2);
+        if (live && sub == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) park[i * (UPC_T / 4)] = H[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) park[(6 + i) * (UPC_T / 4)] = bl[i];
+        }
         if (live) {
             if (sub == 0) { rhs[0] = bl[0]; rhs[1] = bl[1]; rhs[2] = bl[2]; }
             if (e0 >= 0 && j0 < B.n_free) pass1(j0, w0);
+#pragma nounroll
             for (int q = q0 + sub + 4; q < q1; q += 4) {
                 const int e = B.edges_by_point ? q : B.pt_edges[q], j = B.e_pose[e];
                 if (!B.active[e] || j >= B.n_free) continue;
@@ -365,16 +499,25 @@ __global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q, int rep) {
             Hn[3] += w * (Jl[0][1] * Jl[0][1] + Jl[1][1] * Jl[1][1]); Hn[4] += w * (Jl[0][1] * Jl[0][2] + Jl[1][1] * Jl[1][2]); Hn[5] += w * (Jl[0][2] * Jl[0][2] + Jl[1][2] * Jl[1][2]);
         };
         if (live) {
-            const double Hs[9] = {H[0], H[1], H[2], H[1], H[3], H[4], H[2], H[4], H[5]};
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double Hq[6], bq[3];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) Hq[i] = park[i * (UPC_T / 4)];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) bq[i] = park[(6 + i) * (UPC_T / 4)];
+            const double Hs[9] = {Hq[0], Hq[1], Hq[2], Hq[1], Hq[3], Hq[4], Hq[2], Hq[4], Hq[5]};
             double h[9];
             ba_inv3_damped(Hs, lambda, h);
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 const double d = h[3 * a] * rhs[0] + h[3 * a + 1] * rhs[1] + h[3 * a + 2] * rhs[2];
                 pn[a] = p[a] + d;
-                if (sub == 0) { pts_t[3 * (size_t)k + a] = pn[a]; sc += d * (lambda * d + bl[a]); mx = fmax(mx, fabs(d)); }
+                if (sub == 0) { pts_t[3 * (size_t)k + a] = pn[a]; sc += d * (lambda * d + bq[a]); mx = fmax(mx, fabs(d)); }
             }
             if (e0 >= 0) { const float uvv[2] = {uv0.x, uv0.y}; pass2(e0, j0, uvv); }
+#pragma nounroll
             for (int q = q0 + sub + 4; q < q1; q += 4) {
                 const int e = B.edges_by_point ? q : B.pt_edges[q];
                 if (!B.active[e]) continue;
