@@ -531,9 +531,13 @@ void FrontEnd::AddNewMappointsObservationsForOldKeyframes() {
 
 void FrontEnd::TriangulateMappointsInTrackingMap() {
     int triangulatedCnt = 0;
-    for (Mappoint* mp : pnpMatchedMpt_) {                                           // trackingMap_ ∩ pnpMatchedMptSet_, id order
+    std::vector<SE3> poses; std::vector<Vec3> points;
+    const size_t nm = pnpMatchedMpt_.size();
+    for (size_t i = 0; i < nm; ++i) {                                               // trackingMap_ ∩ pnpMatchedMptSet_, id order
+        if (i + 8 < nm) __builtin_prefetch(pnpMatchedMpt_[i + 8]);                  // ~8000 objects, almost all skipped on their flags: the walk is cache misses
+        Mappoint* mp = pnpMatchedMpt_[i];
         if (mp->outlier_ || mp->triangulated_ || mp->optimized_) continue;
-        std::vector<SE3> poses; std::vector<Vec3> points;
+        poses.clear(); points.clear();
         for (const Mappoint::Observation& o : mp->ObservationList()) {              // keyframe-id order
             if (o.keyframe == nullptr) continue;
             poses.push_back(o.keyframe->GetPose());
