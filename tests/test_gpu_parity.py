@@ -410,6 +410,16 @@ def test_device_resident_graph_cut_system_matches_oracle(frames):
     assert sd["ba_runs"] >= 2
     np.testing.assert_allclose(pd, po, atol=1e-6)
     np.testing.assert_allclose(pd, ph, atol=1e-6)
+    # track-ahead (the default of this configuration: the next frames' chain is launched at the keyframe by vo_track_batch_begin and collected by
+    # the next AddFrame) only moves work in time: without it the frames are tracked by the same lanes with the same seeds
+    import os
+    os.environ["VO_TRACK_AHEAD"] = "0"
+    try:
+        pn, sn = run(system.HOST_LIB, ba_device_graph=1, map_descriptors_on_device=1)
+    finally:
+        del os.environ["VO_TRACK_AHEAD"]
+    assert sn["keyframes"] == sd["keyframes"] and sn["ba_runs"] == sd["ba_runs"]
+    np.testing.assert_allclose(pn, pd, atol=1e-9)      # (the local BA's atomic sums are not ordered: the two runs agree to rounding, not to the bit)
 
 
 def test_map_points_created_from_frame_keypoints_on_the_device(frames, libs):
