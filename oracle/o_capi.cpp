@@ -285,6 +285,7 @@ int vo_track_batch(vo_ctx* c, int n, const int* slots, const double T0[12], cons
                    vo_track_result* res, vo_match* matches, int cap) {
     if (!c || n < 1 || !slots || !T0 || !tp || !res || cap < 0) return VO_E_INVALID;
     if (n > std::max(1, c->p.max_track_batch)) return VO_E_INVALID;
+    if (c->async_pending) return VO_E_STATE;          // as the HIP library: a chain begun by vo_track_batch_begin is in flight
     std::vector<std::vector<vo_match>> lanes(n);
     for (int i = 0; i < n; ++i) {                  // frames sharing prior + map are independent: a plain loop on the CPU
         vo_track_params t = *tp;

@@ -853,6 +853,7 @@ static int group_submit(vo_group* g, GroupReq* req) {
 int vo_track_batch(vo_ctx* c, int n, const int* slots, const double T0[12], const vo_track_params* tp, const uint64_t* seeds,
                    vo_track_result* res, vo_match* matches, int cap) {
     if (!c || n < 1 || n > c->lanes || !slots || !T0 || !tp || !res || tp->passes < 1 || cap < 0 || tp->n_hyp < 1 || tp->n_hyp > c->p.max_hypotheses) return VO_E_INVALID;
+    if (c->async_pending) return VO_E_STATE;                  // a chain started by vo_track_batch_begin owns the lane buffers until vo_track_batch_end
     for (int i = 0; i < n; ++i) { if (slots[i] < 0 || slots[i] >= c->p.max_frames) return VO_E_INVALID; if (!c->slot_orb[slots[i]]) return VO_E_STATE; }
     HIP_TRY(hipSetDevice(c->device));
     GroupReq req{c, n, slots, T0, tp, seeds, res, matches, cap, VO_OK, false};

@@ -297,6 +297,8 @@ def test_track_batch_equals_sequential_calls(frames, libs):
     with pytest.raises(capi.VoError):
         ctx.track_batch_end(4)
     n = ctx.track_batch_begin([1, 2, 3, 4], inv12(Twc[0]), tp, seeds, cap=4096)
+    with pytest.raises(capi.VoError):
+        ctx.track_batch([1, 2], inv12(Twc[0]), tp, seeds[:2], cap=4096)      # the chain in flight owns the lane buffers
     res3, ms3 = ctx.track_batch_end(n, cap=4096)
     for j in range(4):
         for f in ("n_candidates", "n_matches", "n_ransac_inliers", "n_lm_inliers", "min_distance", "ransac_iters", "best_hypothesis", "lm_iters"):
