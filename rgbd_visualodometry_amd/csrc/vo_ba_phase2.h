@@ -555,6 +555,11 @@ __global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q, int rep) {
     if (stamp_ && !s_last) printf("[upchi2 wg %d of %d] wall clocks (100 MHz): prelude %lld pass1 %lld pass2 %lld reduce+ticket %lld\n", (int)blockIdx.x, gp, tq_[1] - tq_[0], tq_[2] - tq_[1], tq_[3] - tq_[2], tq_[4] - tq_[3]);
 #endif
     if (!s_last) return;
+    // block 0's atomics on scal[2] / scal[7] were performed at the memory side (and before block 0 took its ticket); this workgroup's XCD may still hold
+    // the line it read scal[3] from at the start: agent-scope loads go past that L2 (there is no acquire fence in this kernel any more).  Requested
+    // here, ahead of the partial sums, so that the two round trips overlap
+    double sc2 = 0, sc7 = 0;
+    if (threadIdx.x == 0) { sc2 = pb_ld(B.scal + 2); sc7 = pb_ld(B.scal + 7); }
     {   // the last workgroup: the partials of every workgroup, then g2o's gain-ratio test and lambda policy (as k_ba_chi_control)
         const double* pu = B.partU;
         double a = 0, b = 0, m = 0;
@@ -570,9 +575,6 @@ __global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q, int rep) {
         c->arrived = 0;
         double s1 = 0, sB = 0, mB = 0;
         for (int w = 0; w < NWV; ++w) { s1 += s_w[w]; sB += s_w[NWV + w]; mB = fmax(mB, s_w[2 * NWV + w]); }
-        // block 0's atomics on scal[2] / scal[7] were performed at the memory side; this workgroup's XCD may still hold the line it read
-        // scal[3] from at the start: agent-scope loads go past that L2 (there is no acquire fence in this kernel any more)
-        const double sc2 = pb_ld(B.scal + 2), sc7 = pb_ld(B.scal + 7);
         const double s2 = sc2 + sB;
         const double m7 = fmax(sc7, mB);
         const double tmp = ok ? s1 : DBL_MAX;
