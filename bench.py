@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--prologue", type=int, default=150, help="frames tracked (untimed) before the warmup so that the timed steps see the steady-state map: covisible window, BA size and active-map size level off after ~100 frames; 0 = time a young map")
     ap.add_argument("--host-graph", action="store_true", help="cut the local BA's graph on the host (Backend::Build) instead of on the device from the resident observation table")
     ap.add_argument("--multi-streams", default="8", help="comma list of stream counts for the several-streams-per-GPU figure ('' = skip)")
+    ap.add_argument("--multi-device-graph", type=int, default=0, help="several-streams figure: 1 = the local BA's graph is cut on the device (as the single stream does), 0 = on the host")
     args = ap.parse_args()
 
     import torch
@@ -348,7 +349,7 @@ def main():
             def run_streams(S, grouped):
                 grp_ = system.StreamGroup(system.HOST_LIB, local_rank, 128) if grouped else None
                 # the GPU is the shared resource here and host cores are idle: the local BA's graph is cut on the host
-                syss = [system.VoSystem(system.HOST_LIB, **{**opts, "ba_device_graph": 0}) for _ in range(S)]
+                syss = [system.VoSystem(system.HOST_LIB, **{**opts, "ba_device_graph": 1 if args.multi_device_graph else 0}) for _ in range(S)]
                 if grp_:
                     for s in syss:
                         grp_.join(s)
@@ -384,7 +385,7 @@ def main():
                               "vs_single_stream": round(f_g / fps, 2), "lanes_per_launch_chain": round(gs["lanes"] / max(1, gs["chains"]), 2),
                               "requests_per_launch_chain": round(gs["requests"] / max(1, gs["chains"]), 2),
                               "frames_per_s_separate_contexts": round(f_s, 1),
-                              "mode": "one stream group: the members' tracking calls share launch chains (vo_group); ORB per stream on its own HIP stream; local BAs batched by the device's BA engines; graph cut on the host"})
+                              "mode": "one stream group: the members' tracking calls share launch chains (vo_group); ORB per stream on its own HIP stream; local BAs batched by the device's BA engine; graph cut on the " + ("device" if args.multi_device_graph else "host")})
 
         # ---- CPU baseline: the oracle port on host cores, bounded samples ----------------------------------
         cpu = None
