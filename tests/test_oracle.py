@@ -123,6 +123,40 @@ def test_match_gate_rule(O, frames):
     assert np.all(np.diff(m["map_index"]) > 0)                                # active-list order is kept
 
 
+def test_track_batch_in_two_halves_equals_the_one_call(O, frames):
+    """vo_track_batch_begin / _end (include/vo_hip.h: the front-end's track-ahead) on the CPU restatement: the same records as vo_track_batch,
+    state errors for _end without _begin and for a second tracking call in between."""
+    bgr, depth, Twc, _ = frames
+    p = O.default_params(n_features=600, max_frames=4, map_capacity=4096, max_track_batch=3)
+    ctx = O.context(p)
+    for s in range(4):
+        ctx.upload(s, bgr[2 * s], depth[2 * s])
+    ctx.orb(0, 4)
+    k0, d0 = ctx.orb_fetch(0)
+    ok = k0["depth_raw"] > 0
+    z = k0["depth_raw"][ok] / 5000.0
+    pc = np.stack([(k0["x"][ok] - p.cx) * z / p.fx, (k0["y"][ok] - p.cy) * z / p.fy, z], 1)
+    R, t = Twc[0][:9].reshape(3, 3), Twc[0][9:]
+    pw = pc @ R.T + t
+    nrm = pw - t; nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    idx = np.arange(len(pw), dtype=np.int32)
+    ctx.map_upsert(idx, pw, nrm, d0[ok], np.zeros(len(pw), np.uint8)); ctx.map_set_active(idx)
+    prior = np.concatenate([R.T.ravel(), -R.T @ t])
+    tp = O.default_track_params()
+    seeds = [11, 22, 33]
+    res, ms = ctx.track_batch_deferred([1, 2, 3], prior, tp, seeds, cap=4096)
+    with pytest.raises(capi.VoError):
+        ctx.track_batch_end(3)
+    n = ctx.track_batch_begin([1, 2, 3], prior, tp, seeds, cap=4096)
+    with pytest.raises(capi.VoError):
+        ctx.track_batch([1], prior, tp, seeds[:1], cap=4096)
+    res2, ms2 = ctx.track_batch_end(n, cap=4096)
+    for j in range(3):
+        assert res[j].n_matches == res2[j].n_matches > 50 and res[j].n_lm_inliers == res2[j].n_lm_inliers
+        assert np.array_equal(np.array(res[j].T_cw), np.array(res2[j].T_cw)) and np.array_equal(ms[j], ms2[j])
+    ctx.close()
+
+
 def corr(rng, n, p, noise=0.0, outl=0.0):
     X = rng.uniform(-2, 2, size=(n, 3)) + np.array([0, 0, 5.0])
     R = expso3(rng.normal(size=3) * 0.1)
