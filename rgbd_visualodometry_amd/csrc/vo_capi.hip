@@ -218,6 +218,14 @@ struct vo_group {
 static int chain_run(vo_ctx* prof, hipStream_t st, LaunchSet& ls, std::vector<GroupReq*>& batch);
 static int shard_exchange(vo_ctx* c, hipStream_t st, int nl, int n_hyp);
 
+// vo_obs_append: the packed upload -> the observation table's columns
+__global__ void k_obs_append(int n, const int32_t* __restrict__ kf, const int32_t* __restrict__ mp, const float2* __restrict__ uv,
+                             int32_t* __restrict__ o_kf, int32_t* __restrict__ o_mp, float2* __restrict__ o_uv, uint8_t* __restrict__ o_alive) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    o_kf[i] = kf[i]; o_mp[i] = mp[i]; o_uv[i] = uv[i]; o_alive[i] = 1;
+}
+
 extern "C" {
 
 const char* vo_backend_name(void) { return "hip-gfx950"; }
@@ -966,17 +974,22 @@ int vo_obs_append(vo_ctx* c, const int32_t* kf, const int32_t* mp, const float* 
     if (c->n_obs + n > c->obs_cap) return VO_E_OVERFLOW;
     if (first) *first = (int64_t)c->n_obs;
     if (n == 0) return VO_OK;
+    // pack -> one pinned staging buffer -> one H2D copy into the scratch slab -> one kernel writes the four table columns (three copies and a
+    // fill were four blit kernels with their gaps: DESIGN 4a)
     const size_t N = (size_t)n, o_mp = (4 * N + 255) & ~(size_t)255, o_uv = o_mp + ((4 * N + 255) & ~(size_t)255), total = o_uv + 8 * N;
     uint8_t* h = (uint8_t*)vo_stage(c, total);
     if (!h) return VO_E_NOMEM;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    rc = vo_scratch(c, total);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));               // the staging buffer / the scratch slab may still feed an earlier copy or scatter
     memcpy(h, kf, 4 * N); memcpy(h + o_mp, mp, 4 * N); memcpy(h + o_uv, uv, 8 * N);
     const size_t at = (size_t)c->n_obs;
-    HIP_TRY(hipMemcpyAsync(c->d_obs_kf + at, h, 4 * N, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->d_obs_mp + at, h + o_mp, 4 * N, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->d_obs_uv + 2 * at, h + o_uv, 8 * N, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_obs_alive + at, 1, N, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    uint8_t* d = (uint8_t*)c->d_ba;
+    HIP_TRY(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_obs_append, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, (const int32_t*)d, (const int32_t*)(d + o_mp), (const float2*)(d + o_uv),
+                       c->d_obs_kf + at, c->d_obs_mp + at, reinterpret_cast<float2*>(c->d_obs_uv + 2 * at), c->d_obs_alive + at);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));               // a back-end thread may read the table from its own stream next
     c->n_obs += n;
     return VO_OK;
 }
