@@ -14,7 +14,8 @@ when it starts.  The stream is first advanced --prologue frames (untimed, like t
 same steady state as long ones: a young map has a fifth of the active points and local BAs a tenth of the size.  The timed region ends after the last frame's pending local BA has been solved
 and merged (Backend::Flush) and the device is idle.
 
-Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel, live HIP-event
+Prints ONE JSON line (rank 0) of < 4 KB (compact_line: the driver keeps an ~8 KB tail of stdout) and writes the full record --
+per-kernel table, counters, notes -- to bench_detail.json (also under gpurun_out/ when that exists).  Objects of the full record: `roofline` (dominant kernel, live HIP-event
 timing on the kernels' own streams), `cpu_baseline` (the CPU oracle port on the host cores, rank 0
 at N=1 only, bounded sample), `latency_mode` (causal single-frame figure: no look-ahead, no
 speculative batch, synchronous BA), `multi_stream` (several streams on this GPU), `upload_inclusive` (the same timed frames
@@ -71,6 +72,87 @@ def algorithmic_bytes(W, H, N, A, M, K, I, n_hyp, passes=2):
     }
     total_survey = 5 * W * H + 4 * P + 2003 * N + 48 * N + (32 * M + 32 * N + 8 * M) + (20 * K + 4 * n_hyp)
     return b, total_survey, P
+
+
+LINE_LIMIT = 4096          # the driver keeps an ~8 KB tail of stdout: the ONE JSON line must stay well inside it
+
+
+def _short(s, n=120):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 3] + "..."
+
+
+def compact_line(full):
+    """The ONE JSON line the driver parses, built from the full record (which goes to bench_detail.json): the contract's
+    keys, `roofline` without per-kernel tables or counter blocks, `cpu_baseline` with a short sample text, and one-number
+    summaries of the side figures.  Always shorter than LINE_LIMIT."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+    out = {k: full.get(k) for k in keep}
+    cfg = full.get("config") or {}
+    out["config"] = {"workload": _short(cfg.get("workload", ""), 200)}
+    for k in ("streams_per_gpu", "ransac_hypotheses", "lookahead_frames", "local_ba", "ba_graph_cut", "prologue_frames"):
+        if k in cfg:
+            out["config"][k] = _short(cfg[k], 60) if isinstance(cfg[k], str) else cfg[k]
+    r = full.get("roofline")
+    if r:
+        out["roofline"] = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "launches")}
+        out["roofline"]["limiter"] = _short(r.get("limiter", ""), 100)
+    else:
+        out["roofline"] = None
+    c = full.get("cpu_baseline")
+    if c:
+        out["cpu_baseline"] = {"value": c.get("value"), "unit": c.get("unit"), "cores": c.get("cores"), "kind": c.get("kind"),
+                               "sample": _short(c.get("sample", ""), 120),
+                               "all_cores": {k: (c.get("all_cores") or {}).get(k) for k in ("value", "cores")},
+                               "cpu_model": _short(c.get("cpu_model", ""), 48)}
+    else:
+        out["cpu_baseline"] = None
+    for k in ("ate_rmse_m", "rpe_trans_rmse_m", "rpe_rot_rmse_deg", "keyframes_timed", "ba_runs_timed", "lost", "hbm_frac_whole_frame",
+              "alg_bytes_per_frame_survey"):
+        if k in full:
+            out[k] = full[k]
+    u = full.get("upload_inclusive")
+    if u:
+        out["upload_inclusive"] = {"frames_per_s": u.get("frames_per_s"), "vs_resident": u.get("vs_resident")}
+    lat = full.get("latency_mode")
+    if lat:
+        out["latency_mode"] = {"frames_per_s": lat.get("frames_per_s"), "ms_per_frame_median": lat.get("ms_per_frame_median")}
+    o = full.get("orb_only")
+    if o:
+        out["orb_only"] = {"frames_per_s": o.get("frames_per_s"), "hbm_frac": o.get("hbm_frac")}
+    m = full.get("multi_stream")
+    if m:
+        out["multi_stream"] = [{"streams_per_gpu": e.get("streams_per_gpu"), "frames_per_s": e.get("frames_per_s"),
+                                "vs_single_stream": e.get("vs_single_stream"), "hbm_frac_whole_frame": e.get("hbm_frac_whole_frame")} for e in m[:4]]
+    d = full.get("distributed")
+    if d:
+        ranks = d.get("ranks") or []
+        out["distributed"] = {"world_size": d.get("world_size"), "backend": d.get("backend"), "allreduce_sum_of_ones": d.get("allreduce_sum_of_ones"),
+                              "ranks": [{"rank": x.get("rank"), "device": x.get("device"), "pci_bus_id": x.get("pci_bus_id"),
+                                         "frames_per_s": x.get("frames_per_s")} for x in ranks[:8]]}
+    out["detail"] = "bench_detail.json"
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) >= LINE_LIMIT:                              # never expected; drop the optional summaries rather than overflow
+        for k in ("distributed", "multi_stream", "orb_only", "latency_mode", "upload_inclusive"):
+            out.pop(k, None)
+            line = json.dumps(out, separators=(",", ":"))
+            if len(line) < LINE_LIMIT:
+                break
+    assert len(line) < LINE_LIMIT, len(line)
+    return line
+
+
+def write_detail(full):
+    """The full record (per-kernel table, counters, notes) beside the script and, when present, under gpurun_out/."""
+    txt = json.dumps(full, indent=1)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    f.write(txt)
+            except OSError:
+                pass
 
 
 def drive(sysm, stamps, bptr, dptr, i0, i1, lookahead, W, est=None, on_device=True):
@@ -439,7 +521,8 @@ def main():
             except Exception:
                 pass
             cpu = {"value": round(ns / ts_, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-                   "sample": "frames %d..%d of the same synthetic stream -- the first %d of the GPU's timed frames, behind the same %d-frame untimed prologue -- ONE thread (local BA synchronous), oracle/_build/liboracle_vo.so (-O3 -march=x86-64-v3)" % (Wm, Wm + ns - 1, ns, Wm),
+                   "sample": "frames %d..%d = first %d of the GPU's timed frames, same %d-frame prologue; 1 thread, sync BA, oracle port -O3" % (Wm, Wm + ns - 1, ns, Wm),
+                   "sample_detail": "the same synthetic stream, oracle/_build/liboracle_vo.so (-O3 -march=x86-64-v3), local BA synchronous inside AddFrame",
                    "ate_rmse_m": acc_cs["ate_rmse_m"], "gpu_ate_rmse_m_same_frames": acc_gs.get("ate_rmse_m"),
                    "rpe_trans_rmse_m": acc_cs["rpe_trans_rmse_m"],
                    "fresh_map": {"value": round(nf / tc, 3), "unit": "frames/s", "cores": 1, "sample": "first %d frames from a fresh map (younger, i.e. cheaper, than the timed steady state): rounds 1-2's sample" % nf,
@@ -469,7 +552,9 @@ def main():
             "roofline": roof, "orb_only": orb_only, "latency_mode": lat, "multi_stream": multi, "upload_inclusive": upl, "cpu_baseline": cpu,
             "distributed": dist_info,
         }
-        print(json.dumps(out))
+        write_detail(out)
+        sys.stdout.flush()
+        print(compact_line(out), flush=True)
     sysm.close()
     grp.close()
 
