@@ -60,7 +60,9 @@ int myslam_system_create(const myslam_options* o, const char* yaml_path, myslam_
 void myslam_system_destroy(myslam_system* s);
 /* Register the next n frames (host or device memory) and run batched ORB on them (look-ahead).  The image buffers are NOT copied
  * on the host: they must stay valid and unchanged until the frame has been consumed (myslam_add_prefetched returned for it) -- from
- * page-locked host memory the upload is asynchronous.  (The C++ surface, Frame::CreateFrame, deep-copies like the reference.) */
+ * page-locked host memory the upload is asynchronous.  (The C++ surface, Frame::CreateFrame, deep-copies like the reference.)
+ * Exception: with reobserve_new_mappoints = 1 keyframes are detected again at later keyframes; host frames are then deep-copied
+ * by this call, and frames in DEVICE memory must stay valid for as long as the frame can be a covisible keyframe (the whole run). */
 int myslam_prefetch(myslam_system* s, int n, const double* stamps, const void* const* bgr, const void* const* depth,
                     int bgr_stride, int depth_stride, int on_device);
 /* AddFrame on the next prefetched frame, or on an explicit host/device frame if none is queued.

@@ -21,7 +21,7 @@
 // The LM state (lambda, current chi2, iteration counters, round, which of the two state / linearisation buffers is current) lives in
 // a device-resident control block: k_ba_admit starts a problem, k_ba_round moves it from the robust round through the cull to the
 // plain round and on to "done" and reports to pinned host memory -- the BA engine (further down) enqueues chunks of steps over all
-// problems in flight without waiting for any of that.  vo_ba_persist.h holds the opt-in one-launch-per-BA variant; the second half
+// problems in flight without waiting for any of that.  The second half
 // of this file is the device-resident graph cut and merge.
 #include <cfloat>
 #include <cmath>
@@ -1408,13 +1408,6 @@ __device__ __forceinline__ void ba_cull_edge(const BaDev& B, const double* poses
     if (stage == 0) { if (c2 > th) { B.flags[e] = 1; B.active[e] = 0; } else B.flags[e] = 0; }
     else if (B.active[e]) { if (c2 > th) B.flags[e] |= 2; else atomicAdd(&B.scal[6], c2); }
 }
-__global__ void k_ba_cull(BaBatch Q, int stage) {           // (the persistent path's host side)
-    BA_PROBLEM(Q)
-    BA_STATE(B)
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < B.n_edges) ba_cull_edge(B, poses_c, pts_c, e, stage);
-}
-
 // A problem enters its slot: control block of the robust round, zeroed accumulators (one workgroup; the plain chi2 of the
 // initial state follows in k_ba_chi).  The descriptor (BaDev) is the only thing the host uploads.
 __global__ __launch_bounds__(256) void k_ba_admit(BaBatch Q) {
@@ -1495,14 +1488,12 @@ __global__ __launch_bounds__(256) void k_ba_round(BaBatch Q) {
     }
 }
 
-#include "vo_ba_persist.h"
 #include "vo_ba_phase2.h"
 
 // per-device function attributes (vo_ctx_create calls this with the context's device current)
 int vo_ba_set_attrs() {
     HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol16, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol16g, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-    HIP_TRY(hipFuncSetAttribute((const void*)k_ba_persist, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIP_TRY(hipFuncSetAttribute((const void*)k_ba_upchi2, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     return VO_OK;
 }
@@ -1837,107 +1828,6 @@ void vo_ba_engine_release(BaEngine* E) {
     for (int k = E->n_sib - 1; k >= 0; --k) if (E->sib[k]) ba_engine_free(E->sib[k]);      // sib[0] is E itself
 }
 
-// ---- persistent path: one launch per local BA (vo_ba_persist.h) -------------------------------------------------------------------
-// Every workgroup of a persistent launch spins on its peers, so all of them must be resident at once: a launch takes its
-// workgroups out of a per-device budget (VO_BA_WG_BUDGET, default 224 of the 256 compute units -- the dynamic LDS keeps it at
-// one workgroup per unit) and waits when the budget is spent.  Launches of different contexts run on their own streams and
-// advance independently: no lock-step over problems, no chunk of steps to wait for.
-#define PB_MAX_DEV 16
-#define PB_G_CAP 256
-static struct PbBudget { std::mutex mu; std::condition_variable cv; int free_wg[PB_MAX_DEV]; bool init = false; int total = 224, gmax = 128, on = 0; } g_pb;      // on: VO_BA_PERSIST=1 (default off: the second-generation launch path is faster end to end)
-static void pb_budget_init() {
-    if (g_pb.init) return;
-    if (const char* e = getenv("VO_BA_WG_BUDGET")) g_pb.total = std::max(2, std::min(PB_G_CAP, atoi(e)));
-    if (const char* e = getenv("VO_BA_GROUP")) g_pb.gmax = std::max(2, std::min(PB_G_CAP, atoi(e)));
-    if (const char* e = getenv("VO_BA_PERSIST")) g_pb.on = atoi(e);
-    g_pb.gmax = std::min(g_pb.gmax, g_pb.total);
-    for (int d = 0; d < PB_MAX_DEV; ++d) g_pb.free_wg[d] = g_pb.total;
-    g_pb.init = true;
-}
-static size_t pb_lds_bytes(const BaDev& B) {
-    const size_t chol = sizeof(double) * (CH_NB * CH_NB + (size_t)(B.D + 1) * (B.D + 2) / 2 + 2 * (size_t)B.D);
-    const size_t work = sizeof(double) * (8 * 96 + 24 * (size_t)B.n_poses + (size_t)B.D + 2) + pb_tab_bytes();
-    return std::max(chol, work);
-}
-static bool ba_persist_ok(vo_ctx* c, const BaDev& B) {
-    std::unique_lock<std::mutex> lk(g_pb.mu);
-    pb_budget_init();
-    return g_pb.on && c->device < PB_MAX_DEV && B.D <= 192 && B.n_free <= 32 && B.edges_by_point && pb_lds_bytes(B) <= 158 * 1024 && 96 * (long long)B.n_points + 8 * (long long)B.n_edges + 512 <= 144 * (long long)B.n_edges &&
-           (long long)B.n_edges / (g_pb.gmax - 1) + B.n_poses + 64 <= PB_ECAP;
-}
-void vo_ba_persist_free(vo_ctx* c) {
-    if (c->d_pb) (void)hipFree(c->d_pb);
-    if (c->h_pb) (void)hipHostFree(c->h_pb);
-    c->d_pb = nullptr; c->h_pb = nullptr;
-}
-static int ba_persist_solve(vo_ctx* c, BaJob* j) {
-    hipStream_t st = c->stream;
-    const BaDev& B = j->B;
-    // per-context block: [counters | part | hpart | rec | dp | mail]
-    const size_t o_sync = 0, o_part = 1024, o_hpart = o_part + sizeof(double) * PB_P_N * PB_G_CAP, o_rec = o_hpart + sizeof(double) * 32 * PB_PS * PB_HP,
-                 o_dp = o_rec + 64, o_mail = o_dp + sizeof(double) * 192, total = o_mail + 256;
-    if (!c->d_pb) {
-        if (hipMalloc(&c->d_pb, total) != hipSuccess) { c->d_pb = nullptr; return VO_E_NOMEM; }
-        if (hipHostMalloc((void**)&c->h_pb, 256, hipHostMallocDefault) != hipSuccess) { c->h_pb = nullptr; return VO_E_NOMEM; }
-    }
-    uint8_t* pb = (uint8_t*)c->d_pb;
-    // workgroups: about 256 edges per worker, at least 8, at most what the budget has left (never less than a quarter of the wish)
-    int want, G;
-    {
-        std::unique_lock<std::mutex> lk(g_pb.mu);
-        want = std::max(8, std::min(g_pb.gmax, B.n_edges / 256 + 2));
-        // a worker's edge table holds PB_ECAP edges: its share is n_edges / (G - 1) plus at most one point's edges (<= n_poses)
-        const int need = (int)((long long)B.n_edges / std::max(1, PB_ECAP - B.n_poses - 64)) + 2;
-        want = std::max(want, need);
-        const int least = std::max(std::max(4, want / 4), need);
-        while (g_pb.free_wg[c->device] < least) g_pb.cv.wait(lk);
-        G = std::min(want, g_pb.free_wg[c->device]);
-        g_pb.free_wg[c->device] -= G;
-    }
-    int rc = VO_OK;
-    do {
-        if (j->wait_ev && hipStreamWaitEvent(st, j->wait_ev, 0) != hipSuccess) { rc = VO_E_DEVICE; break; }
-        if (j->wait_pairs && hipStreamWaitEvent(st, j->wait_pairs, 0) != hipSuccess) { rc = VO_E_DEVICE; break; }
-        if (hipMemsetAsync(pb + o_sync, 0, 1024, st) != hipSuccess) { rc = VO_E_DEVICE; break; }
-        if (hipMemsetAsync(B.S, 0, sizeof(double) * (size_t)B.D * B.D, st) != hipSuccess) { rc = VO_E_DEVICE; break; }
-        if (hipMemsetAsync(B.bs, 0, sizeof(double) * (size_t)B.D, st) != hipSuccess) { rc = VO_E_DEVICE; break; }
-        PbArgs A;
-        A.B = B; A.sync = (unsigned*)(pb + o_sync); A.part = (double*)(pb + o_part); A.hpart = (double*)(pb + o_hpart); A.rec = (double*)(pb + o_rec);
-        A.dp = (double*)(pb + o_dp); A.mail = (double*)(pb + o_mail);
-        A.G = G; A.it_robust = j->in->it_robust; A.it_plain = j->in->it_plain;
-        A.ps = std::max(1, std::min(PB_PS, (G - 1) / std::max(1, B.n_free)));
-        A.dbg = getenv("VO_BA_DBG") ? atoi(getenv("VO_BA_DBG")) : 0;
-        A.spin_ticks = 100000000ull;                             // 1 s at 100 MHz
-        c->h_pb[5] = 1.0;
-        { ProfScope ps(c, "k_ba_persist", st); hipLaunchKernelGGL(k_ba_persist, dim3(G), dim3(PB_NT), pb_lds_bytes(B), st, A); }
-        if (hipMemcpyAsync(c->h_pb, pb + o_mail, 256, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = VO_E_DEVICE; break; }
-        if (hipStreamSynchronize(st) != hipSuccess) { rc = VO_E_DEVICE; break; }
-    } while (0);
-    {
-        std::unique_lock<std::mutex> lk(g_pb.mu);
-        g_pb.free_wg[c->device] += G;
-        g_pb.cv.notify_all();
-    }
-    if (rc) return rc;
-    if (c->h_pb[5] == 2.0) return VO_E_OVERFLOW;               // a worker's edge table was too small (nothing was modified): the caller takes the launch-per-phase path
-    if (c->h_pb[5] != 0.0) { fprintf(stderr, "[vo_hip] persistent BA launch aborted (a workgroup waited longer than 1 s for its peers: are other processes running persistent kernels on this GPU?)\n"); return VO_E_DEVICE; }
-    j->chi0 = c->h_pb[0]; j->chi_final = c->h_pb[1]; j->iters = (int)c->h_pb[2]; j->cur_buf = (int)c->h_pb[3]; j->steps = (int)c->h_pb[4];
-    j->done = true;
-    if (getenv("VO_TRACE")) {
-        static double acc[24]; static int n = 0; static long long steps = 0;
-        std::unique_lock<std::mutex> lk(g_pb.mu);
-        for (int i = 0; i < 20; ++i) acc[i] += c->h_pb[8 + i];
-        steps += j->steps;
-        if (++n % 10 == 0) {
-            const double k = 0.01 / (double)std::max(1LL, steps);      // 100 MHz ticks -> us per LM step
-            fprintf(stderr, "[vo_trace] persistent BA, us per LM step (G=%d, %d problems, %.1f steps each): solver: wait Schur %.1f | H_pp + lambda %.1f | Cholesky %.1f | trial poses + publish %.1f | wait chi2 %.1f | decide %.1f"
-                            "  worker 1: linearise %.1f | B1 %.1f | take %.1f | Schur %.1f | wait solver %.1f | update + chi2 %.1f | wait chi2 %.1f | decide %.1f  || Schur: loads %.1f | sums(dbg 4) %.1f | sums + reduce %.1f | commit %.1f\n",
-                    G, n, (double)steps / n, acc[0] * k, acc[1] * k, acc[2] * k, acc[3] * k, acc[4] * k, acc[5] * k, acc[8] * k, acc[9] * k, acc[10] * k, acc[11] * k, acc[12] * k, acc[13] * k, acc[14] * k, acc[15] * k, acc[16] * k, acc[17] * k, acc[18] * k, acc[19] * k);
-        }
-    }
-    return VO_OK;
-}
-
 int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     hipStream_t st = c->stream;
     BaEngine* E = ba_engine_of(c);
@@ -2146,8 +2036,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     job.grid_e = (ne + 255) / 256; job.grid_c = (ne + 1023) / 1024; job.grid_maxdiag = (D + 3 * nx + 255) / 256;
     job.lds = D <= 192 ? sizeof(double) * (CH_NB * CH_NB + (size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D)
                        : sizeof(double) * (CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D);
-    rc = ba_persist_ok(c, job.B) ? ba_persist_solve(c, &job) : VO_E_OVERFLOW;
-    if (rc == VO_E_OVERFLOW) rc = ba_engine_solve(E, &job);
+    rc = ba_engine_solve(E, &job);
     if (rc) return rc;
     out->lm_iters = job.iters;
     const double tt2 = tnow();
@@ -2607,8 +2496,7 @@ extern "C" int vo_local_ba_resident_solve(vo_ctx* c, int it_robust, int it_plain
     const double t0 = trace ? tnow() : 0.0;
     BaEngine* E = ba_engine_of(c);
     if (!E) return VO_E_STATE;
-    int rc = ba_persist_ok(c, job.B) ? ba_persist_solve(c, &job) : VO_E_OVERFLOW;
-    if (rc == VO_E_OVERFLOW) rc = ba_engine_solve(E, &job);
+    int rc = ba_engine_solve(E, &job);
     if (rc) return rc;
     const double t1 = trace ? tnow() : 0.0;
     const BaDev& B = R.B;
@@ -2626,7 +2514,7 @@ extern "C" int vo_local_ba_resident_solve(vo_ctx* c, int it_robust, int it_plain
             HIP_TRY(hipStreamSynchronize(st));
         }
     } else {
-        // (the persistent path, or more culled observations than the pinned list holds: list kernel + read-back)
+        // (more culled observations than the pinned list holds: list kernel + read-back)
         HIP_TRY(hipMemsetAsync(R.d_ncull, 0, 4, st));
         hipLaunchKernelGGL(k_culled_list, dim3((ne + 255) / 256), dim3(256), 0, st, ne, (const uint8_t*)B.flags, (const long long*)R.d_e_obs, R.d_ncull, R.d_cull, R.cull_cap);
         HIP_TRY(hipMemcpyAsync(h, R.d_ncull, 4, hipMemcpyDeviceToHost, st));

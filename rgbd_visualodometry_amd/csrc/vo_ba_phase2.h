@@ -16,6 +16,26 @@
 // tracker's kernels run beside it -- 0.1 us alone, profiles/r03_ba_gaps.txt -- which is what taking launches out of the step buys.)
 #pragma once
 
+// agent-scope relaxed accesses: they go past this XCD's L2 (the eight L2s are not coherent with each other), which is what the
+// fence-free "last workgroup" tickets of k_ba_upchi2 / k_ba_round read their peers' partial sums with
+__device__ __forceinline__ double pb_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void pb_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Per-point record of a linearisation (96 bytes, 32-byte aligned): H_ll (6 unique), b_l (3), the point (3).  It lives behind the
+// edge weights in the slab that the five-launch path uses for W_e (144 bytes per edge).
+#define PB_REC 12
+// Jacobians of one edge without the residual (one division): J_pose (2x6), J_point = J_pose[:, 0:3] R (g2o_types.h:143-167)
+__device__ __forceinline__ void pb_jac(const BaCam& cam, const double (&T)[12], const double (&p)[3], double (&Jp)[2][6], double (&Jl)[2][3]) {
+#pragma clang fp contract(fast)
+    const double X = T[0] * p[0] + T[1] * p[1] + T[2] * p[2] + T[9], Y = T[3] * p[0] + T[4] * p[1] + T[5] * p[2] + T[10], Z = T[6] * p[0] + T[7] * p[1] + T[8] * p[2] + T[11];
+    const double Zi = 1.0 / (Z + 1e-18), Zi2 = Zi * Zi, fx = cam.fx, fy = cam.fy;
+    Jp[0][0] = -fx * Zi; Jp[0][1] = 0; Jp[0][2] = fx * X * Zi2; Jp[0][3] = fx * X * Y * Zi2; Jp[0][4] = -fx - fx * X * X * Zi2; Jp[0][5] = fx * Y * Zi;
+    Jp[1][0] = 0; Jp[1][1] = -fy * Zi; Jp[1][2] = fy * Y * Zi2; Jp[1][3] = fy + fy * Y * Y * Zi2; Jp[1][4] = -fy * X * Y * Zi2; Jp[1][5] = -fy * X * Zi;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Jl[a][c] = Jp[a][0] * T[c] + Jp[a][1] * T[3 + c] + Jp[a][2] * T[6 + c];
+}
+
 // The slab the first generation uses for W_e (>= 16 n_edges + 192 n_points + 2 KiB bytes) holds two weight arrays and two record arrays;
 // ctl->lbuf says which pair is the current linearisation.
 __device__ __forceinline__ double* p2_w(const BaDev& B, int which) { return B.W + (size_t)which * (((size_t)B.n_edges + 31) & ~(size_t)31); }
@@ -446,6 +466,10 @@ __global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q, int rep) {
         o[3 * r] = row[0]; o[3 * r + 1] = row[1]; o[3 * r + 2] = row[2]; o[9 + r] = tr;
         if (blockIdx.x == 0) { double* g = poses_t + 12 * (size_t)j; g[3 * r] = row[0]; g[3 * r + 1] = row[1]; g[3 * r + 2] = row[2]; g[9 + r] = tr; }
     }
+    // block 0's atomics on scal[2] / scal[7] above come from lanes of several waves; the fence-free ticket at the end of this kernel has only
+    // thread 0's wave drain vmcnt before it takes its ticket, and a workgroup-scope barrier does not drain it: every wave of block 0
+    // drains here, so the atomics are performed before block 0 can take a ticket (k_ba_round got the same fix in ac73ae7)
+    if (blockIdx.x == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     P2_STAMP()
     double chi = 0, sc = 0, mx = 0;

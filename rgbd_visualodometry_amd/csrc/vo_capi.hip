@@ -275,7 +275,6 @@ void vo_ctx_destroy(vo_ctx* c) {
     if (c->h_orb_cache) (void)hipHostFree(c->h_orb_cache);
     if (c->h_ba_up) (void)hipHostFree(c->h_ba_up);
     vo_ba_resident_free(c);
-    vo_ba_persist_free(c);
     { void* tp[] = {c->d_obs_kf, c->d_obs_mp, c->d_obs_uv, c->d_obs_alive, c->d_kf_pose, c->d_cut}; for (void* q : tp) if (q) (void)hipFree(q); }
     if (c->slots_ev) (void)hipEventDestroy(c->slots_ev);
     for (auto& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -390,8 +389,11 @@ int vo_frame_upload(vo_ctx* c, int slot, const uint8_t* bgr, int bs, const uint1
         if (hipMalloc((void**)&c->own_depth[slot], nd) != hipSuccess) return VO_E_NOMEM;
         c->own_depth_bytes[slot] = nd;
     }
-    HIP_TRY(hipMemcpyAsync(c->own_bgr[slot], bgr, nb, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->own_depth[slot], depth, nd, hipMemcpyHostToDevice, c->stream));
+    // only (H - 1) strides + one row of pixels are the caller's to read: the padding behind the LAST row need not exist (a column
+    // slice of a wider image, a cv::Mat ROI); the slot itself is stride * H so that every row has its pitch
+    const size_t cb = (size_t)bs * (H - 1) + 3 * (size_t)c->p.width, cd = (size_t)ds * (H - 1) + 2 * (size_t)c->p.width;
+    HIP_TRY(hipMemcpyAsync(c->own_bgr[slot], bgr, cb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->own_depth[slot], depth, cd, hipMemcpyHostToDevice, c->stream));
     c->h_slots[slot] = SlotDesc{c->own_bgr[slot], c->own_depth[slot], bs, ds};
     c->slot_bound[slot] = 1; c->slot_orb[slot] = 0;
     hipPointerAttribute_t at;

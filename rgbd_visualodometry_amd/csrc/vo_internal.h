@@ -119,7 +119,6 @@ struct vo_ctx {
     // BA scratch; the device's BA engine (shared by the contexts of that device, vo_ba.hip)
     void* d_ba; size_t d_ba_bytes; struct BaEngine* ba_engine = nullptr; struct BaEngine* ba_engine_sel = nullptr;
     void* h_ba_up = nullptr; size_t h_ba_up_bytes = 0;      // pinned mirror of a BA problem's upload region
-    void* d_pb = nullptr; double* h_pb = nullptr;           // persistent LM kernel: counters / partials / records (device), result mail (pinned)
     std::vector<int32_t> ba_pt_start, ba_ps_start, ba_cursor;      // host scratch of vo_ba_run (kept between problems)
     // device-resident keyframe bookkeeping: observation table and keyframe poses, fixed capacity (a back-end
     // thread may be reading them while the tracker appends: no reallocation, appends only write beyond what a reader was given)
@@ -172,7 +171,6 @@ void vo_lane_fill(vo_ctx* c, int lane, int slot, uint64_t seed, TrackDev* d_tr, 
 int vo_corr_from_host(vo_ctx* c, const float* xyz, const float* uv, int n);
 int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out);                       // vo_ba.hip
 void vo_ba_resident_free(vo_ctx* c);
-void vo_ba_persist_free(vo_ctx* c);
 struct BaEngine* vo_ba_engine_acquire(int device);
 void vo_ba_engine_release(struct BaEngine* e);
 

@@ -34,6 +34,10 @@ Frame::Ptr make_frame(myslam_system* s, double stamp, const void* bgr, const voi
     Image c, d;
     c.data = bgr; c.rows = s->opt.height; c.cols = s->opt.width; c.stride = bs; c.on_device = on_device != 0;
     d.data = depth; d.rows = s->opt.height; d.cols = s->opt.width; d.stride = ds; d.on_device = on_device != 0;
+    // With the re-observation pass on, keyframes are detected again at later keyframes (frontend.cpp:408-463): a host frame is then
+    // deep-copied like Frame::CreateFrame does, because the caller's buffer is only promised until the frame has been consumed
+    // (myslam_c.h).  Device frames are never copied: the caller keeps them alive for the run in that mode (documented there).
+    if (s->opt.reobserve_new_mappoints && !on_device) return Frame::CreateFrame(stamp, s->camera, c, d);
     return Frame::CreateFrameView(stamp, s->camera, c, d);      // the caller's buffers stay valid until the frame has been consumed (myslam_c.h)
 }
 void out_pose(const Frame::Ptr& f, double T_wc[12]) { if (T_wc) f->GetPose().inverse().to12(T_wc); }

@@ -523,6 +523,45 @@ def test_frame_upload_keeps_the_callers_strides(frames, libs):
     c.close()
 
 
+def test_frame_upload_reads_no_byte_behind_the_last_row(frames, libs):
+    """A column slice of a wider image (a cv::Mat ROI): rows are padded, but the padding behind the LAST row is not the caller's.
+    The images are placed so that their last pixel row ends exactly at a PROT_NONE guard page: an upload that copies stride * H
+    bytes faults, one that copies (H - 1) * stride + row bytes does not."""
+    import ctypes as C
+    import mmap
+    bgr, depth, _, _ = frames
+    H, _ = libs
+    libc = C.CDLL(None, use_errno=True)
+    libc.mprotect.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    page = mmap.PAGESIZE
+
+    def guarded_view(img2d, stride):                                       # img2d: (rows, row_bytes) uint8
+        rows, rb = img2d.shape
+        need = (rows - 1) * stride + rb
+        npages = (need + page - 1) // page
+        mm = mmap.mmap(-1, (npages + 1) * page)
+        base = C.addressof(C.c_char.from_buffer(mm))
+        assert libc.mprotect(base + npages * page, page, 0) == 0            # PROT_NONE behind the image
+        start = npages * page - need
+        buf = np.frombuffer(mm, dtype=np.uint8, count=npages * page)
+        for r in range(rows):
+            buf[start + r * stride: start + r * stride + rb] = img2d[r]
+        return mm, base + start
+
+    c, _ = make_ctx(H, n_features=500, max_frames=2)
+    c.upload(0, bgr[3], depth[3])
+    mb, pb = guarded_view(bgr[3].reshape(480, 1920), 2048)
+    md, pd = guarded_view(depth[3].view(np.uint8).reshape(480, 1280), 1408)
+    H.check(H.lib.vo_frame_upload(c.h, 1, C.c_void_p(pb), 2048, C.c_void_p(pd), 1408), "vo_frame_upload")
+    c.orb(0, 2)
+    k0, d0 = c.orb_fetch(0)
+    k1, d1 = c.orb_fetch(1)
+    for field in ("x", "y", "octave", "depth_raw"):
+        assert np.array_equal(k0[field], k1[field]), field
+    assert np.array_equal(d0, d1) and len(k0) == 500
+    c.close()
+
+
 @pytest.mark.parametrize("mfma", ["0", "1"])
 def test_both_matching_kernels_give_the_oracles_matches(frames, libs, mfma, monkeypatch):
     """k_match (vector ALU) and k_match_mfma (int8 matrix cores) are interchangeable bit for bit: the launcher picks by problem size; here
