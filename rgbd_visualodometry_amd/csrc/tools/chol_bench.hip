@@ -133,9 +133,10 @@ int main() {
     { double* d; hipMalloc(&d, 128 * 8); hipLaunchKernelGGL(k_dpp_probe, dim3(1), dim3(64), 0, 0, d); double h[128]; hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
       printf("bcast<3>: "); for (int i = 0; i < 64; i += 5) printf("[%d]=%.0f ", i, h[i]); printf("\nfnma<5>: "); for (int i = 0; i < 64; i += 5) printf("[%d]=%.0f ", i, h[64 + i]); printf("\n"); hipFree(d); }
 
-    const int sizes[] = {6, 24, 30, 60, 96, 120, 132, 144, 156, 168, 186, 192, 198, 216, 240, 300, 366};
+    const int sizes[] = {6, 12, 18, 24, 30, 48, 60, 96, 120, 126, 132, 138, 144, 156, 168, 186, 192, 198, 216};
     hipFuncSetAttribute((const void*)k_ba_chol16, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
     hipFuncSetAttribute((const void*)k_ba_chol16g, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+    hipFuncSetAttribute((const void*)k_ba_chol16v2, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
 
     hipStream_t st; hipStreamCreate(&st);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -154,25 +155,39 @@ int main() {
         hipMalloc(&B.S, sizeof(double) * D * D); hipMalloc(&B.bs, sizeof(double) * D); hipMalloc(&d_b0, sizeof(double) * D);
         hipMalloc(&B.Hpp, sizeof(double) * 36 * (D / 6 + 1)); hipMemset(B.Hpp, 0, sizeof(double) * 36 * (D / 6 + 1));      // the kernel adds blockdiag(H_pp) + lambda I, b_p on load
         hipMalloc(&B.bp, sizeof(double) * D); hipMemset(B.bp, 0, sizeof(double) * D);
-        hipMalloc(&B.scal, 64); hipMalloc(&B.dl, 128); hipMemset(B.dl, 0, 128); hipMalloc(&B.ctl, sizeof(BaCtl));
+        hipMalloc(&B.scal, 64); hipMalloc(&B.dl, 8 * (D + 16)); hipMemset(B.dl, 0, 8 * (D + 16)); hipMalloc(&B.ctl, sizeof(BaCtl));
         hipMemset(B.scal, 0, 64); hipMemset(B.ctl, 0, sizeof(BaCtl));
         hipMalloc(&d_S0, sizeof(double) * D * D);
+#if defined(CH2_DEBUG) || defined(CH2_STAMPS)
+        hipMalloc(&B.W, sizeof(double) * ((D + 2) * (D + 2) + 8192)); hipMemset(B.W, 0, sizeof(double) * ((D + 2) * (D + 2) + 8192));
+#endif
         {   // k_ba_chol16 takes the packed lower triangle (ba_tri), k_ba_chol16g the full matrix
             std::vector<double> Sp((size_t)D * D, 0.0);
             if (D <= 192) { for (int r = 0; r < D; ++r) for (int c = 0; c <= r; ++c) Sp[(size_t)r * (r + 1) / 2 + c] = S[(size_t)r * D + c]; }
             else Sp = S;
             hipMemcpy(d_S0, Sp.data(), sizeof(double) * D * D, hipMemcpyHostToDevice);
         }
+        double* d_S0t = nullptr; const size_t nt_dbl = ba_tile_doubles(D) + 128;      // the same lower triangle as 16x16 tiles (vo_ba_chol2.h)
+        {
+            std::vector<double> St(nt_dbl, 0.0);
+            for (int r = 0; r < D; ++r) for (int c = 0; c <= r; ++c) St[ba_tile_idx(r, c)] = S[(size_t)r * D + c];
+            hipMalloc(&d_S0t, sizeof(double) * nt_dbl); hipMemcpy(d_S0t, St.data(), sizeof(double) * nt_dbl, hipMemcpyHostToDevice);
+        }
+        double* S_packed = B.S; double* S_tiles; hipMalloc(&S_tiles, sizeof(double) * nt_dbl);
         hipMemcpy(d_b0, b.data(), sizeof(double) * D, hipMemcpyHostToDevice);
         BaDev* d_B; hipMalloc(&d_B, sizeof(BaDev)); hipMemcpy(d_B, &B, sizeof(BaDev), hipMemcpyHostToDevice);
         BaBatch Q; memset(&Q, 0, sizeof(Q)); Q.Bs = d_B; Q.ctls = B.ctl; Q.n = 1;
-        for (int variant = 1; variant < 2; ++variant) {
+        for (int variant = 1; variant < (D <= CH2_MAXD ? 3 : 2); ++variant) {          // 1: first generation (barrier phases, packed rows), 2: second generation (roles + LDS words, tiles: vo_ba_chol2.h)
+            B.s_tiles = variant == 2; B.S = variant == 2 ? S_tiles : S_packed;
+            hipMemcpy(d_B, &B, sizeof(BaDev), hipMemcpyHostToDevice);
             float tot = 0; const int reps = 50;
             for (int it = 0; it < reps + 5; ++it) {
                 hipMemcpyAsync(B.bs, d_b0, sizeof(double) * D, hipMemcpyDeviceToDevice, st);
-                hipMemcpyAsync(B.S, d_S0, sizeof(double) * D * D, hipMemcpyDeviceToDevice, st);      // the global-resident kernels factor S in place
+                if (variant == 2) hipMemcpyAsync(B.S, d_S0t, sizeof(double) * nt_dbl, hipMemcpyDeviceToDevice, st);
+                else hipMemcpyAsync(B.S, d_S0, sizeof(double) * D * D, hipMemcpyDeviceToDevice, st);      // the global-resident kernels factor S in place
                 hipEventRecord(e0, st);
-                if (D <= 192) hipLaunchKernelGGL(k_ba_chol16, dim3(1), dim3(CH_THREADS), sizeof(double) * (CH_NB * CH_NB + (size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D), st, Q, 0, 0);
+                if (variant == 2) hipLaunchKernelGGL(k_ba_chol16v2, dim3(1), dim3(CH2_T), ch2_lds_bytes(D), st, Q);
+                else if (D <= 192) hipLaunchKernelGGL(k_ba_chol16, dim3(1), dim3(CH_THREADS), sizeof(double) * (CH_NB * CH_NB + (size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D), st, Q, 0, 0);
                 else hipLaunchKernelGGL(k_ba_chol16g, dim3(1), dim3(CH_THREADS), sizeof(double) * (CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D), st, Q);
                 hipEventRecord(e1, st);
                 hipStreamSynchronize(st);
@@ -180,20 +195,59 @@ int main() {
                 if (it >= 5) tot += ms;
             }
             std::vector<double> got(D); double ok;
-            hipMemcpy(got.data(), B.bs, sizeof(double) * D, hipMemcpyDeviceToHost);
+            hipMemcpy(got.data(), variant == 2 ? B.dl : B.bs, sizeof(double) * D, hipMemcpyDeviceToHost);
             hipMemcpy(&ok, B.scal + 3, 8, hipMemcpyDeviceToHost);
             double err = 0, ref = 0;
             for (int i = 0; i < D; ++i) { err = std::max(err, std::fabs(got[i] - x[i])); ref = std::max(ref, std::fabs(x[i])); }
-            printf("D %3d  %-13s  %8.2f us  ok %.0f  max|dx|/max|x| %.3e%s\n", D, variant ? (D <= 192 ? "k_ba_chol16" : "k_ba_chol16g") : "k_ba_chol_t", 1e3 * tot / reps, ok, err / ref,
+            printf("D %3d  %-13s  %8.2f us  ok %.0f  max|dx|/max|x| %.3e%s\n", D, variant == 2 ? "k_ba_chol16v2" : (D <= 192 ? "k_ba_chol16" : "k_ba_chol16g"), 1e3 * tot / reps, ok, err / ref,
                    (ok == 1.0 && err / ref < 1e-10) ? "" : "   <-- MISMATCH");
             if (!(ok == 1.0 && err / ref < 1e-10)) ++bad;
+#ifdef CH2_DEBUG
+            if (variant == 2) {                                  // the augmented factor [L 0; y^T .] against the host's
+                const int DA = D + 1;
+                const int Tt = (DA + 15) / 16;
+                std::vector<double> Lh((size_t)DA * DA, 0.0), Ld((size_t)Tt * (Tt + 1) / 2 * CH2_TS);
+                for (int i = 0; i < D; ++i) for (int j = 0; j <= i; ++j) Lh[(size_t)i * DA + j] = S[(size_t)i * D + j];
+                for (int j = 0; j < D; ++j) Lh[(size_t)D * DA + j] = b[j];
+                for (int j = 0; j < D; ++j) {
+                    double d = Lh[(size_t)j * DA + j]; for (int k = 0; k < j; ++k) d -= Lh[(size_t)j * DA + k] * Lh[(size_t)j * DA + k];
+                    d = std::sqrt(d); Lh[(size_t)j * DA + j] = d;
+                    for (int i = j + 1; i < DA; ++i) { double s = Lh[(size_t)i * DA + j]; for (int k = 0; k < j; ++k) s -= Lh[(size_t)i * DA + k] * Lh[(size_t)j * DA + k]; Lh[(size_t)i * DA + j] = s / d; }
+                }
+                hipMemcpy(Ld.data(), B.W, sizeof(double) * Ld.size(), hipMemcpyDeviceToHost);
+                int nbad = 0; int tb[16][16]; memset(tb, 0, sizeof(tb));
+                for (int i = 0; i < DA; ++i) for (int j = 0; j <= i && j < D; ++j) {
+                    if (i / 16 == j / 16 && i < D) continue;   // the diagonal tiles hold W_k = L_kk^-T at the end, not L_kk (the solution check covers them)
+                    const double g = Ld[ch2_sidx(i, j)], h = Lh[(size_t)i * DA + j];
+                    if (!(std::fabs(g - h) <= 1e-9 * (1.0 + std::fabs(h)))) { if (nbad < 6) printf("        L[%d][%d] = %.6e, host %.6e (tile %d,%d)\n", i, j, g, h, i / 16, j / 16); ++nbad; tb[i / 16][j / 16]++; }
+                }
+                if (nbad) { printf("        %d factor entries differ; per tile (row block: counts per column block):\n", nbad);
+                    for (int i = 0; i * 16 < DA; ++i) { printf("          %2d:", i); for (int j = 0; j <= i; ++j) printf(" %3d", tb[i][j]); printf("\n"); } }
+            }
+#endif
+#ifdef CH2_STAMPS
+            if (variant == 2 && (D == 144 || D == 48)) {
+                std::vector<long long> ts(8 * 128);
+                hipMemcpy(ts.data(), B.W, sizeof(long long) * ts.size(), hipMemcpyDeviceToHost);
+                const long long t0 = ts[127];
+                auto T = [&](int w, int s) { return (double)(ts[w * 128 + s] - t0); };
+                const int nblk = (D + 15) / 16;
+                printf("        v2 timeline (clocks since the first barrier), D = %d\n", D);
+                printf("        wave 0: "); for (int k = 0; k < nblk; ++k) printf("[k%d potrf %.0f..%.0f rdy-wait from %.0f] ", k, T(0, 3 * k + 1), T(0, 3 * k + 2), T(0, 3 * k + 3)); printf("| bwd wait %.0f..%.0f end %.0f\n", T(0, 60), T(0, 61), T(0, 62));
+                printf("        wave 0 rdy seen:      "); for (int k = 0; k < 8; ++k) printf("k%d %.0f  ", k, T(0, 80 + k)); printf("\n");
+                printf("        wave 1 W_k published: "); for (int k = 0; k < 9; ++k) printf("k%d %.0f  ", k, T(1, k)); printf("\n");
+                printf("        wave 0 inv seen:      "); for (int k = 0; k < 8; ++k) printf("k%d %.0f  ", k, T(0, 90 + k)); printf("\n");
+                for (int w : {1, 2, 3}) printf("        wave %d col_update(1, 0): enter %.0f | waited %.0f | 3 tiles %.0f | done %.0f\n", w, T(w, 100), T(w, 101), T(w, 102), T(w, 103));
+                for (int w : {2, 3, 6, 7}) { printf("        wave %d: init %.0f ", w, T(w, 126)); for (int k = 0; k < nblk; ++k) printf("[k%d %.0f A ..%.0f D,W ..%.0f C ..%.0f] ", k, T(w, 6 * k), T(w, 6 * k + 1), T(w, 6 * k + 2), T(w, 6 * k + 3)); printf("\n"); }
+            }
+#endif
 #ifdef CH_STAMPS
-            if (variant == 1) { double tt[12]; hipMemcpy(tt, B.dl, 96, hipMemcpyDeviceToHost);
+            if (variant == 1 && D <= 192) { double tt[12]; hipMemcpy(tt, B.dl, 96, hipMemcpyDeviceToHost);
                 printf("        clocks: load+block0 %.0f | solve+barrier %.0f | wave0: tile00 %.0f, load rows %.0f, factor %.0f, barrier wait %.0f | bwd: loads %.0f, push+chain %.0f, barrier %.0f, head/tail %.0f+%.0f\n",
                        tt[0], tt[1], tt[5], tt[6], tt[7], tt[2], tt[4], tt[8], tt[9], tt[3], tt[10]); }
 #endif
         }
-        hipFree(B.Hpp); hipFree(B.bp); hipFree(d_B); hipFree(d_S0); hipFree(B.S); hipFree(B.bs); hipFree(d_b0); hipFree(B.scal); hipFree(B.ctl);
+        hipFree(B.Hpp); hipFree(B.bp); hipFree(d_B); hipFree(d_S0); hipFree(d_S0t); hipFree(S_tiles); hipFree(S_packed); hipFree(B.bs); hipFree(d_b0); hipFree(B.scal); hipFree(B.ctl);
     }
     hipError_t e = hipGetLastError();
     printf("last error: %s, mismatches: %d\n", hipGetErrorString(e), bad);

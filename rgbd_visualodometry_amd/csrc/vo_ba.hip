@@ -62,7 +62,7 @@ struct BaDev {
     int gp;                                                  // point workgroups of the 4-lanes-per-point kernels (64 points each)
     int edges_by_point;                                      // 1: the edges are grouped by point, pt_edges is the identity
     BaCam cam; double delta, chi2_th;
-    int it_robust, it_plain, gen, pad_;                      // iterations of the two rounds (backend.cpp:141,159); gen: the engine's admission counter (stale status records are told apart by it)
+    int it_robust, it_plain, gen, s_tiles;                   // iterations of the two rounds (backend.cpp:141,159); gen: the engine's admission counter (stale status records are told apart by it); s_tiles: S is kept as 16x16 tiles (vo_ba_chol2.h: D <= CH2_MAXD) instead of packed rows
     // resident graphs only (nullptr otherwise): observation id per edge; the ids of the culled edges are collected by k_ba_round's final
     // stage (device list for the merge kernel, first cull_host_cap of them also in pinned host memory: no list kernel, no read-back copy)
     const long long* e_obs; long long* cull; int* ncull; int cull_cap; long long* cull_host; int cull_host_cap;
@@ -177,8 +177,14 @@ __device__ __forceinline__ void ba_inv3_damped(const double* __restrict__ Hll, d
 // layout the factorisation uses in LDS, so that k_ba_chol16 brings it in with straight global -> LDS copies.  Larger systems (k_ba_chol16g)
 // keep the full row-major matrix.
 __device__ __forceinline__ size_t ba_tri(int r, int c) { return (size_t)r * (size_t)(r + 1) / 2 + (size_t)c; }
+// ... or, for the second-generation Cholesky (vo_ba_chol2.h, D <= CH2_MAXD), as 16x16 tiles of row stride 17 in tile order
+#define BA_TILE_RS 17
+#define BA_TILE_TS 272
+__host__ __device__ inline size_t ba_tile_idx(int r, int c) { const int i = r >> 4, j = c >> 4; return (size_t)(i * (i + 1) / 2 + j) * BA_TILE_TS + (size_t)((r & 15) * BA_TILE_RS + (c & 15)); }
+__host__ __device__ inline size_t ba_tile_doubles(int D) { const int T = (D + 15) >> 4; return (size_t)T * (T + 1) / 2 * BA_TILE_TS; }
+__device__ __forceinline__ size_t ba_sidx(const BaDev& B, int r, int c) { return B.s_tiles ? ba_tile_idx(r, c) : ba_tri(r, c); }
 __device__ __forceinline__ void ba_fold_zero(const BaDev& B, int blk, int nblk) {            // S = 0, b_s = 0 (grid-stride over the point blocks)
-    const int n = B.D * (B.D + 1) / 2;
+    const int n = B.s_tiles ? (int)ba_tile_doubles(B.D) : B.D * (B.D + 1) / 2;
     for (int i = blk * 256 + threadIdx.x; i < n; i += nblk * 256) B.S[i] = 0.0;
     for (int i = blk * 256 + threadIdx.x; i < B.D; i += nblk * 256) B.bs[i] = 0.0;
 }
@@ -1014,7 +1020,7 @@ __device__ __forceinline__ void ba_pose_body(const BaDev& B, double lambda, int 
 // launch) and the solution goes to B.dl instead of overwriting b_s
 __global__ __launch_bounds__(CH_THREADS) void k_ba_chol16(BaBatch Q, int trial_poses, int phase2) {
     BA_PROBLEM(Q)
-    if (ctl_->finished || B.D > 192) return;                   // larger systems: k_ba_chol16g
+    if (ctl_->finished || B.D > 192 || B.s_tiles) return;      // larger systems: k_ba_chol16g; tile-major ones: k_ba_chol16v2
     extern __shared__ double s_mem[];
     (void)ba_chol16_body<false>(B, ctl_, 0.0, s_mem, phase2 ? B.dl : B.bs, phase2 != 0);
     if (trial_poses) {
@@ -1023,6 +1029,15 @@ __global__ __launch_bounds__(CH_THREADS) void k_ba_chol16(BaBatch Q, int trial_p
         const double lambda = ctl_->lambda;
         for (int blk = 0; blk * CH_THREADS < B.n_poses; ++blk) ba_pose_body(B, lambda, blk, poses_c, poses_t);
     }
+}
+
+#include "vo_ba_chol2.h"
+// second generation of the same solve (vo_ba_chol2.h): the waves have roles and hand work over through words in LDS
+__global__ __launch_bounds__(CH2_T) void k_ba_chol16v2(BaBatch Q) {
+    BA_PROBLEM(Q)
+    if (ctl_->finished || !B.s_tiles) return;
+    extern __shared__ double s_mem[];
+    ba_chol16v2_body(B, ctl_, s_mem, B.dl, true);
 }
 
 // ---- k_ba_chol16g: the same 16-column scheme for D > 192, where the packed triangle no longer fits in LDS -----------
@@ -1494,6 +1509,7 @@ __global__ __launch_bounds__(256) void k_ba_round(BaBatch Q) {
 int vo_ba_set_attrs() {
     HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol16, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol16g, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol16v2, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIP_TRY(hipFuncSetAttribute((const void*)k_ba_upchi2, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     return VO_OK;
 }
@@ -1510,6 +1526,8 @@ int vo_ba_set_attrs() {
 // HIP streams with ~120 tiny dependent launches each mostly serialise in the command processor.
 #include <condition_variable>
 #include <deque>
+// which layout S has (and which Cholesky kernel a problem takes): tiles + the second generation up to CH2_MAXD, packed rows + the first above; VO_CHOL_V1 forces the first
+static int ba_use_tiles(int D) { static const bool v1 = getenv("VO_CHOL_V1") != nullptr; return (!v1 && D <= CH2_MAXD) ? 1 : 0; }
 static double tnow() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 struct BaJob {
     vo_ctx* c = nullptr; const vo_ba_problem* in = nullptr; vo_ba_result* out = nullptr;
@@ -1602,7 +1620,7 @@ static int ba_engine_enqueue(BaEngine* E) {
     // chunk length: to the end of the nearest round (a slot that ends its round idles through the rest of the chunk), short while
     // other problems may want to join
     int chunk = (na == 1 && E->pending_hint == 0) ? 16 : 4;
-    int sA[BA_SLOTS], nA = 0, sB[BA_SLOTS], nB = 0;
+    int sA[BA_SLOTS], nA = 0, sB[BA_SLOTS], nB = 0, nA_tiles = 0;
     int gA_lin = 0, gA_blk = 0, gA_up = 0, gA_md = 0, gA_pose = 0, gB_lin = 0, gB_init = 0, gB_blk = 0, gB_upd = 0, gB_c = 0, gB_md = 0, g_e = 0;
     size_t ldsA = 0, ldsA_up = 0, ldsB = 0;
     for (int i = 0; i < na; ++i) {
@@ -1610,7 +1628,7 @@ static int ba_engine_enqueue(BaEngine* E) {
         if (j->est_stage < 2) chunk = std::min(chunk, std::max(1, j->est_left));
         g_e = std::max(g_e, j->grid_e);
         if (j->B.D <= BA_FOLD_D) {
-            sA[nA++] = act[i];
+            sA[nA++] = act[i]; nA_tiles += j->B.s_tiles;
             gA_lin = std::max(gA_lin, j->grid_lin); gA_blk = std::max(gA_blk, j->B.n_blocks); gA_pose = std::max(gA_pose, j->B.n_free * PSPLIT); gA_up = std::max(gA_up, j->B.n_points);
             ldsA = std::max(ldsA, j->lds); ldsA_up = std::max(ldsA_up, sizeof(double) * (24 * (size_t)j->B.n_poses + (size_t)j->B.D));
             gA_md = std::max(gA_md, (j->B.D + j->B.n_points + 255) / 256);
@@ -1645,7 +1663,9 @@ static int ba_engine_enqueue(BaEngine* E) {
                 }
             }
             { ProfScope ps(prof, "k_ba_schur2", st); hipLaunchKernelGGL(k_ba_schur2, dim3(gA_blk + gA_pose, 1, nA), blk, 0, st, QA); }
-            { ProfScope ps(prof, "k_ba_chol16", st); hipLaunchKernelGGL(k_ba_chol16, dim3(1, 1, nA), dim3(CH_THREADS), ldsA, st, QA, 0, 1); }
+            // both generations in one step: every problem leaves the kernel that is not its own at once (s_tiles says which one is)
+            if (nA_tiles) { ProfScope ps(prof, "k_ba_chol16", st); hipLaunchKernelGGL(k_ba_chol16v2, dim3(1, 1, nA), dim3(CH2_T), ldsA, st, QA); }
+            if (nA_tiles < nA) { ProfScope ps(prof, "k_ba_chol16_packed", st); hipLaunchKernelGGL(k_ba_chol16, dim3(1, 1, nA), dim3(CH_THREADS), ldsA, st, QA, 0, 1); }
             { ProfScope ps(prof, "k_ba_upchi2", st); hipLaunchKernelGGL(k_ba_upchi2, dim3((gA_up + up_rep * (UPC_T / 4) - 1) / (up_rep * (UPC_T / 4)), 1, nA), dim3(UPC_T), ldsA_up, st, QA, up_rep); }
         }
         if (nB) {
@@ -1954,12 +1974,12 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     const size_t o_pcnt = carve(4 * (size_t)std::max(nb_all, 1)), o_poff = carve(4 * (size_t)std::max(nb_all, 1)), o_pn = carve(16);
     const size_t o_Hpp = carve(288 * (size_t)nf), o_bp = carve(8 * (size_t)D), o_Hll = carve(72 * (size_t)nx), o_bl = carve(24 * (size_t)nx), o_scal = carve(64);
     const size_t o_partU = carve(24 * ((size_t)(nx + 63) / 64 + 1)), o_partC = carve(8 * ((size_t)(ne + 255) / 256 + 1));
-    const size_t o_W = carve(std::max<size_t>(144 * (size_t)ne, 16 * (size_t)ne + 192 * (size_t)nx + 2048)), o_S = carve(8 * (size_t)D * D), o_bs = carve(8 * (size_t)D), o_Hinv = carve(72 * (size_t)nx), o_dl = carve(std::max<size_t>(24 * (size_t)nx, 8 * (size_t)D));
+    const size_t o_W = carve(std::max<size_t>(144 * (size_t)ne, 16 * (size_t)ne + 192 * (size_t)nx + 2048)), o_S = carve(std::max<size_t>(8 * (size_t)D * D, 8 * ba_tile_doubles(D)) + 1024), o_bs = carve(8 * (size_t)D), o_Hinv = carve(72 * (size_t)nx), o_dl = carve(std::max<size_t>(24 * (size_t)nx, 8 * (size_t)D));
     int rc = vo_scratch(c, off);
     if (rc) return rc;
     uint8_t* base = (uint8_t*)c->d_ba;
     BaDev B;
-    B.n_poses = np; B.n_free = nf; B.n_points = nx; B.n_edges = ne; B.D = D; B.n_blocks = nblk;
+    B.n_poses = np; B.n_free = nf; B.n_points = nx; B.n_edges = ne; B.D = D; B.n_blocks = nblk; B.s_tiles = ba_use_tiles(D);
     B.n_slices = dev_pairs ? (const int*)(base + o_pn) : nullptr;
     B.ps_start = (const int32_t*)(base + o_qs); B.ps_edges = (const int32_t*)(base + o_qe); B.blocks = (const BaBlock*)(base + o_blk); B.pairs = (const int2*)(base + o_pairs);
     B.posesA = (double*)(base + o_poses); B.ptsA = (double*)(base + o_pts); B.posesB = (double*)(base + o_poses_n); B.ptsB = (double*)(base + o_pts_n);
@@ -2034,7 +2054,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     job.c = c; job.in = in; job.out = out; job.B = B; job.B.n_blocks = nblk_launch;
     job.grid_lin = (nx + 63) / 64 + nf * PSPLIT; job.grid_initS = (std::max(D * D, nx) + 255) / 256; job.grid_upd = (nx + 63) / 64 + (np + 255) / 256;
     job.grid_e = (ne + 255) / 256; job.grid_c = (ne + 1023) / 1024; job.grid_maxdiag = (D + 3 * nx + 255) / 256;
-    job.lds = D <= 192 ? sizeof(double) * (CH_NB * CH_NB + (size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D)
+    job.lds = job.B.s_tiles ? ch2_lds_bytes(D) : D <= 192 ? sizeof(double) * (CH_NB * CH_NB + (size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D)
                        : sizeof(double) * (CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D);
     rc = ba_engine_solve(E, &job);
     if (rc) return rc;
@@ -2396,7 +2416,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     const size_t o_pcnt = carve(4 * (size_t)std::max(nb_all, 1)), o_poff = carve(4 * (size_t)std::max(nb_all, 1)), o_pn = carve(16);
     const size_t o_Hpp = carve(288 * (size_t)nf), o_bp = carve(8 * (size_t)D), o_Hll = carve(72 * (size_t)nx), o_bl = carve(24 * (size_t)nx), o_scal = carve(64);
     const size_t o_partU = carve(24 * ((size_t)(nx + 63) / 64 + 1)), o_partC = carve(8 * ((size_t)(ne + 255) / 256 + 1));
-    const size_t o_W = carve(std::max<size_t>(144 * (size_t)ne, 16 * (size_t)ne + 192 * (size_t)nx + 2048)), o_S = carve(8 * (size_t)D * D), o_bs2 = carve(8 * (size_t)D), o_Hinv = carve(72 * (size_t)nx), o_dl = carve(std::max<size_t>(24 * (size_t)nx, 8 * (size_t)D));
+    const size_t o_W = carve(std::max<size_t>(144 * (size_t)ne, 16 * (size_t)ne + 192 * (size_t)nx + 2048)), o_S = carve(std::max<size_t>(8 * (size_t)D * D, 8 * ba_tile_doubles(D)) + 1024), o_bs2 = carve(8 * (size_t)D), o_Hinv = carve(72 * (size_t)nx), o_dl = carve(std::max<size_t>(24 * (size_t)nx, 8 * (size_t)D));
     // pair lists: a point seen by m free poses gives m (m + 1) / 2 <= m (nf + 1) / 2 pairs, so ne (nf + 1) / 2 bounds them before the
     // per-pose lists exist; slices: one per BA_SLICE pairs plus a partial one per block
     const size_t pairs_ub = (size_t)ne * (size_t)(nf + 1) / 2 + 1, slices_cap = pairs_ub / BA_SLICE + (size_t)nb_all + 1;
@@ -2426,7 +2446,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     }
     if ((size_t)npairs > pairs_ub || (size_t)slices_ub > slices_cap) return VO_E_OVERFLOW;
     BaDev B;
-    B.n_poses = np; B.n_free = nf; B.n_points = nx; B.n_edges = ne; B.D = D;
+    B.n_poses = np; B.n_free = nf; B.n_points = nx; B.n_edges = ne; B.D = D; B.s_tiles = ba_use_tiles(D);
     B.n_blocks = slices_ub;                                 // launch bound; the Schur kernel stops at *n_slices, which the plan kernels below write
     B.n_slices = (const int*)(base + o_pn);
     B.ps_start = (const int32_t*)(base + o_qs); B.ps_edges = (const int32_t*)(base + o_qe); B.blocks = (const BaBlock*)(base + o_blk); B.pairs = (const int2*)(base + o_pairs);
@@ -2490,7 +2510,7 @@ extern "C" int vo_local_ba_resident_solve(vo_ctx* c, int it_robust, int it_plain
     job.c = c; job.in = &pr; job.out = nullptr; job.B = R.B; job.wait_ev = R.ev_arrays; job.wait_pairs = R.ev;
     job.grid_lin = (nx + 63) / 64 + nf * PSPLIT; job.grid_initS = (std::max(D * D, nx) + 255) / 256; job.grid_upd = (nx + 63) / 64 + (np + 255) / 256;
     job.grid_e = (ne + 255) / 256; job.grid_c = (ne + 1023) / 1024; job.grid_maxdiag = (D + 3 * nx + 255) / 256;
-    job.lds = D <= 192 ? sizeof(double) * (CH_NB * CH_NB + (size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D)
+    job.lds = job.B.s_tiles ? ch2_lds_bytes(D) : D <= 192 ? sizeof(double) * (CH_NB * CH_NB + (size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D)
                        : sizeof(double) * (CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D);
     const bool trace = getenv("VO_TRACE") != nullptr;
     const double t0 = trace ? tnow() : 0.0;

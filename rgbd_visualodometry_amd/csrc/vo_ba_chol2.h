@@ -1,0 +1,644 @@
+// vo_ba_chol2.h -- the reduced system's Cholesky + solve for D <= CH2_MAXD, second generation: the arithmetic of k_ba_chol16 (16-column
+// panels, in-register block factor, DPP panel solves, f64-MFMA trailing tiles) run as a DATAFLOW inside one workgroup instead of as
+// barrier-separated phases, on a TILE-MAJOR matrix.  Included by vo_ba.hip behind the first generation's DPP helpers.
+//
+// Layout.  The lower triangle of the augmented matrix [S b; b^T 0] is kept as 16x16 tiles, tile (i, j <= i) at (i (i + 1) / 2 + j) * 272
+// doubles, entry (r, c) of a tile at 17 r + c (ch2_sidx).  The row stride of 17 makes every access pattern of the solve free of bank
+// conflicts (16 lanes reading one column of 16 rows: banks 34 r + 2 c mod 64, all different; 16 lanes reading one row: contiguous), and
+// the tile order makes every address "tile base (a scalar) + a per-lane constant + an immediate": a trailing-tile update is ~30
+// instructions, where the packed-row layout of the first generation spent ~150 on index arithmetic.  The Schur kernel writes S in the
+// same layout in global memory (BaDev::s_tiles), so the matrix still arrives by straight global -> LDS DMA.
+//
+// Dataflow.  The factorisation is a chain of 16x16 block factorisations (POTRF) that nothing can shorten: block k+1 needs block k's panel
+// solve (TRSM) of its own 16 rows and that tile's product with itself (SYRK).  The first generation put two workgroup barriers into every
+// link of that chain and wave 0 -- the only wave on the chain -- waited at both.  Here the waves have ROLES and hand work to each other
+// through words in LDS; after the first few hundred clocks nobody executes s_barrier:
+//   wave 0  (P)  factors the diagonal blocks, one after the other, in registers; every finished COLUMN of a block is published at once
+//                (16 values + the pivot's inverse into a column buffer, then a progress word);
+//   waves 1-3 (solvers, one per remaining SIMD) own the ROW BLOCKS below the first, round robin (row block i belongs to solver (i - 1) mod 3).
+//                A solver does everything that writes its rows.  The one that owns row block k+1 first turns the published block into
+//                W_k = L_kk^-T (the first generation's DPP panel solve applied to the identity: ONE such pass per stage); every panel
+//                solve is then a product X = A W_k on the matrix cores -- 4 MFMAs per 16 rows, where the row-per-lane solve is 136
+//                double-precision DPP or broadcast-fed instructions per 64 rows and three waves at it saturate a pipe that the whole compute
+//                unit shares (tools/chol_bench: v_fmac_f64_dpp 5.8 clocks with one wave, 45.8 with eight; an independent
+//                v_mfma_f64_16x16x4 issues every 16).  That solver then updates tile (k+1, k+1) and tells wave 0: POTRF -> W_k -> 8
+//                MFMAs -> POTRF is the whole critical loop, and the solver on it changes every stage.
+//                Trailing updates are LEFT-LOOKING: a solver's tiles of block column j are touched once, right before stage j solves
+//                against them, with all j panels in one read-modify-write (two accumulators per tile, the next panel's operands in flight
+//                behind the MFMAs).  A right-looking first stage floods the matrix cores with 45 tiles while the chain waits.
+//   waves 4-7    help to load (f64 MFMA, f64 DPP and f64 FMA share a SIMD's double-precision units: a second wave per SIMD adds no
+//                throughput, and beside wave 0 it would only slow the chain down); wave 4 clears S in global memory.
+// The only cross-wave inputs are: the published columns (prog), W_k (inv), L(j, k) of another solver's row block j for a trailing tile
+// (rowdone[j] = stages solved for row block j) and the finished diagonal tile (diag).  Words are monotone and never reset.  Producers store data, then
+// the word, in program order (LDS executes a wave's instructions in order; the asm memory clobbers keep the compiler from reordering);
+// consumers poll the word, then load.  Every wait is bounded: after CH2_SPIN_LIMIT polls a wave raises `abort`, stops waiting and the
+// solve is reported as failed -- a logic error can produce a wrong (flagged) result, not a hung GPU.
+// The backward substitution runs on three waves (rows 0-63, 64-127, 128-191: a row per lane), without any barrier: the 16x16 triangles by a
+// DPP chain on the wave that owns the block's rows, x_p through LDS into the rows above.
+#pragma once
+#include <type_traits>
+
+#define CH2_T 512
+#define CH2_NW (CH2_T / 64)
+#define CH2_NC (CH2_NW - 1)                 // waves that load the matrix: everyone but wave 0
+#define CH2_NS 4                            // solvers: waves 2, 3, 6, 7 (two per SIMD); wave 1 inverts the blocks with SIMD 1 to itself; wave 4 clears S
+#define CH2_SPIN_LIMIT (1 << 21)
+#define CH2_RS 17                           // row stride of a tile (doubles)
+#define CH2_TS 272                          // tile stride (16 rows x 17)
+#define CH2_MAXD 174                        // 11 row blocks of the augmented matrix: 66 tiles = 140 KiB of LDS
+
+#ifdef CH2_STAMPS
+#define CH2_STAMP(slot) { if (lane == 0) { const int s_ = (slot); if (s_ < 128) ((long long*)B.W)[wave * 128 + s_] = clock64(); } }
+#else
+#define CH2_STAMP(slot)
+#endif
+struct Ch2Flags { int prog, diag, dma, init, ok, abort_, xflag, inv; int rowdone[16], rdy[16]; };
+
+__host__ __device__ inline int ch2_tix(int i, int j) { return i * (i + 1) / 2 + j; }
+__host__ __device__ inline size_t ch2_sidx(int r, int c) { return (size_t)ch2_tix(r >> 4, c >> 4) * CH2_TS + (size_t)((r & 15) * CH2_RS + (c & 15)); }
+__host__ __device__ inline size_t ch2_s_doubles(int D) { const int T = (D + 15) >> 4; return (size_t)T * (T + 1) / 2 * CH2_TS; }      // S in global memory: the row blocks of rows < D
+__host__ __device__ inline size_t ch2_lds_bytes(int D) { const int T = (D + 16) >> 4; return sizeof(double) * (512 + (size_t)T * (T + 1) / 2 * CH2_TS); }
+
+// the words and the published columns are read and written through explicit LDS pointers: a volatile access through a generic pointer stays a
+// flat_load / flat_store (the address-space inference leaves volatile accesses alone)
+typedef __attribute__((address_space(3))) int ch2_lds_int;
+typedef __attribute__((address_space(3))) double ch2_lds_f64;
+__device__ __forceinline__ int ch2_peek(const int* p) { return __builtin_amdgcn_readfirstlane(*(const volatile ch2_lds_int*)p); }
+__device__ __forceinline__ void ch2_wait_ge(int* p, int target, int* abort_) {
+    if (ch2_peek(p) < target) {
+        int i = 0;
+        for (; i < CH2_SPIN_LIMIT; ++i) {
+#ifndef CH2_NOSLEEP
+            __builtin_amdgcn_s_sleep(1);
+#endif
+            if (ch2_peek(p) >= target) break;
+            if ((i & 1023) == 1023 && ch2_peek(abort_)) break;
+        }
+        if (i >= CH2_SPIN_LIMIT) *(volatile ch2_lds_int*)abort_ = 1;
+    }
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void ch2_set(int* p, int v) { asm volatile("" ::: "memory"); *(volatile ch2_lds_int*)p = v; }
+__device__ __forceinline__ void ch2_inc(int* p) { asm volatile("" ::: "memory"); (void)__hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// column J of the in-register block factorisation (ChCol of the first generation) + publication: lane c of the column buffer's row J
+// gets L[c][J] (c > J) or 1 / L[J][J] (c == J); lanes c < J hold leftovers nobody reads
+template <int J> struct Ch2Col {
+    static __device__ __forceinline__ void run(double (&a)[CH_NB], double* s_colp, int* s_prog, int progbase, int r16) {
+        const double d = ch_bcast_v<J>(a[J]);
+        double y, q;
+        ba_rsqrt_parts(d, y, q);
+        const double l0 = a[J] * y;
+        const double l = ch_fma_for_dpp(l0, q, l0);
+        const double pinv = fma(y, q, y);
+        a[J] = l;
+        ChRank1<J, J + 1>::run(a, l);
+        s_colp[J * CH_NB + r16] = r16 == J ? pinv : l;
+        ch2_set(s_prog, progbase + J + 1);
+        Ch2Col<J + 1>::run(a, s_colp, s_prog, progbase, r16);
+    }
+};
+template <> struct Ch2Col<CH_NB> { static __device__ __forceinline__ void run(double (&)[CH_NB], double*, int*, int, int) {} };
+
+template <int KK, int C> struct Ch2StreamRow {
+    static __device__ __forceinline__ void run(double (&x)[CH_NB], double Lk) { ch_fnma_bcast<C>(x[C], Lk, x[KK]); Ch2StreamRow<KK, C + 1>::run(x, Lk); }
+};
+template <int KK> struct Ch2StreamRow<KK, CH_NB> { static __device__ __forceinline__ void run(double (&)[CH_NB], double) {} };
+// one column step of the streamed panel solve: x[K] *= 1 / L[K][K], x[C] -= L[C][K] x[K] (C > K).  `avail` = columns known to be published:
+// a step that finds its column missing polls, then fetches its column -- or, when the whole block has been published by then, all remaining
+// columns in one batch of loads: a wave that is behind the factorisation (the usual case at the start of a stage) pays one LDS round trip
+// for the block, one that keeps up pays one per column
+template <int K, int C> struct Ch2Fetch {                     // columns C .. 15, no branch between the loads (one wait for all of them)
+    static __device__ __forceinline__ void run(double (&Lk)[CH_NB], const double* s_colp, int r16) {
+        Lk[C] = *(const volatile ch2_lds_f64*)(s_colp + C * CH_NB + r16);
+        Ch2Fetch<K, C + 1>::run(Lk, s_colp, r16);
+    }
+};
+template <int K> struct Ch2Fetch<K, CH_NB> { static __device__ __forceinline__ void run(double (&)[CH_NB], const double*, int) {} };
+template <int K> struct Ch2Stream {
+    // `f` / Lk[K]: the word and column K as read one step ago (speculatively: valid iff f says so).  Column K+1 is requested before column
+    // K is used, so that a wave that is behind the factorisation pays no LDS round trip per step and catches up.
+    static __device__ __forceinline__ void run(double (&x)[CH_NB], double (&Lk)[CH_NB], int f, const double* s_colp, int* s_prog, int progbase, int r16, int* abort_) {
+        int fn = 0;
+        if (K + 1 < CH_NB) {
+            fn = __builtin_amdgcn_readfirstlane(*(const volatile ch2_lds_int*)s_prog);
+            Lk[K + 1 < CH_NB ? K + 1 : K] = *(const volatile ch2_lds_f64*)(s_colp + (K + 1 < CH_NB ? K + 1 : K) * CH_NB + r16);
+        }
+        if (f < progbase + K + 1) {                             // column K was not out yet when it was read: wait, read again
+            ch2_wait_ge(s_prog, progbase + K + 1, abort_);
+            Lk[K] = *(const volatile ch2_lds_f64*)(s_colp + K * CH_NB + r16);
+        }
+        double l = Lk[K];
+        ch_exec_settle(l);
+        x[K] = ch_mul_bcast<K>(l, x[K]);
+        Ch2StreamRow<K, K + 1>::run(x, l);
+        Ch2Stream<K + 1>::run(x, Lk, fn, s_colp, s_prog, progbase, r16, abort_);
+    }
+};
+template <> struct Ch2Stream<CH_NB> { static __device__ __forceinline__ void run(double (&)[CH_NB], double (&)[CH_NB], int, const double*, int*, int, int, int*) {} };
+
+// wait until arr[i] >= need for every i of the 16-bit set `mask`: ONE load per poll, lane i reads word i (an LDS round trip costs ~130
+// clocks whether it fetches one word or sixteen)
+__device__ __forceinline__ void ch2_wait_set(int* arr, unsigned mask, int need, int* abort_) {
+    const int li = threadIdx.x & 15;
+    const bool want = (mask >> li) & 1u;
+    for (int i = 0; i < CH2_SPIN_LIMIT; ++i) {
+        const int v = *(const volatile ch2_lds_int*)(arr + li);
+        if (__ballot(want && v < need) == 0ull) break;
+        if ((i & 1023) == 1023 && ch2_peek(abort_)) break;
+        if (i == CH2_SPIN_LIMIT - 1) *(volatile ch2_lds_int*)abort_ = 1;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+}
+
+// The panel solve WITHOUT cross-lane operations: a row per lane, L[C][K] (the same for every lane) arrives as an LDS broadcast read of the
+// published column and meets x[K] in a plain v_fma_f64.  The DPP form of the first generation (L in a register, v_fmac_f64_dpp row
+// broadcasts) is one instruction per term as well, but double-precision DPP instructions of ALL waves of a compute unit go through one
+// shared pipe (tools/chol_bench: 5.8 clocks per v_fmac_f64_dpp with one wave, 45.8 with eight; plain v_fma_f64: 5.0 and 6.5): three waves
+// solving at once each ran three times slower, and slowed the block factorisation beside them.  Same operations, same roundings.
+template <int K> struct Ch2LoadCol {                            // entries K .. 15 of published column K (the same address in every lane)
+    static __device__ __forceinline__ void run(double (&l)[CH_NB], const double* s_colp) {
+#pragma unroll
+        for (int c = K; c < CH_NB; ++c) l[c] = s_colp[K * CH_NB + c];
+    }
+};
+template <> struct Ch2LoadCol<CH_NB> { static __device__ __forceinline__ void run(double (&)[CH_NB], const double*) {} };
+template <> struct Ch2LoadCol<CH_NB + 1> { static __device__ __forceinline__ void run(double (&)[CH_NB], const double*) {} };
+// column K is in `l`, column K+1 in `l1` (requested one step ago); column K+2 is requested before column K is used: an LDS round trip
+// is ~130 clocks, a column step 30 to 80
+template <int K> struct Ch2SolveB {
+    static __device__ __forceinline__ void run(double (&x)[CH_NB], double (&l)[CH_NB], double (&l1)[CH_NB], const double* s_colp) {
+        double l2[CH_NB];
+        Ch2LoadCol<K + 2>::run(l2, s_colp);
+        x[K] = fma(l[K], x[K], 0.0);
+#pragma unroll
+        for (int c = K + 1; c < CH_NB; ++c) x[c] = fma(-l[c], x[K], x[c]);
+        Ch2SolveB<K + 1>::run(x, l1, l2, s_colp);
+    }
+};
+template <> struct Ch2SolveB<CH_NB> { static __device__ __forceinline__ void run(double (&)[CH_NB], double (&)[CH_NB], double (&)[CH_NB], const double*) {} };
+// the same, streamed: one column step per published column
+template <int K> struct Ch2StreamB {
+    static __device__ __forceinline__ void run(double (&x)[CH_NB], const double* s_colp, int* s_prog, int progbase, int* abort_) {
+        ch2_wait_ge(s_prog, progbase + K + 1, abort_);
+        double l[CH_NB];
+#pragma unroll
+        for (int c = K; c < CH_NB; ++c) l[c] = *(const volatile ch2_lds_f64*)(s_colp + K * CH_NB + c);
+        x[K] = fma(l[K], x[K], 0.0);
+#pragma unroll
+        for (int c = K + 1; c < CH_NB; ++c) x[c] = fma(-l[c], x[K], x[c]);
+        Ch2StreamB<K + 1>::run(x, s_colp, s_prog, progbase, abort_);
+    }
+};
+template <> struct Ch2StreamB<CH_NB> { static __device__ __forceinline__ void run(double (&)[CH_NB], const double*, int*, int, int*) {} };
+
+// N trailing tiles at once: tile (ti, tj) -= L(ti, k) L(tj, k)^T, 4 MFMAs each, interleaved (a tile alone is a dependent chain of
+// operand loads -> 4 MFMAs on one accumulator -> read-modify-write).  Lane l holds A[l & 15][l >> 4 + 4 q], B likewise, C: row (l >> 4) + 4 q, column l & 15.
+template <int N>
+__device__ __forceinline__ void ch2_tiles(double* s_L, const int (&ti)[3], const int (&tj)[3], int k, int o_op, int o_c) {
+    double a[N][4], b[N][4], c[N][4];
+    double* pc[N];
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+        const double* pa = s_L + ch2_tix(ti[t], k) * CH2_TS + o_op;
+        const double* pb = s_L + ch2_tix(tj[t], k) * CH2_TS + o_op;
+        pc[t] = s_L + ch2_tix(ti[t], tj[t]) * CH2_TS + o_c;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a[t][q] = pa[4 * q]; b[t][q] = pb[4 * q]; c[t][q] = pc[t][4 * CH2_RS * q]; }
+    }
+    f64x4 acc[N];
+#pragma unroll
+    for (int t = 0; t < N; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int t = 0; t < N; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t][q], b[t][q], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < N; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pc[t][4 * CH2_RS * q] = c[t][q] - acc[t][q];
+}
+
+// the same for panels k0 .. k1 in one go (a worker that applies its pending panels to a tile just before the tile is needed -- or early,
+// while it has nothing more urgent to do): 4 (k1 - k0 + 1) MFMAs per tile on one accumulator, ONE read-modify-write of the tile
+template <int N>
+__device__ __forceinline__ void ch2_tiles_mp(double* s_L, const int (&ti)[3], const int (&tj)[3], int k0, int k1, int o_op, int o_c) {
+    // two accumulators per tile (an MFMA on an accumulator of its own issues every 16 clocks, a dependent one every 64) and the next
+    // panel's operands requested before this panel's MFMAs (an LDS round trip is 130+ clocks: as long as a panel's 4 N MFMAs)
+    double c[N][4];
+    double* pc[N];
+    const double* pa[N]; const double* pb[N];
+    f64x4 acc0[N], acc1[N];
+    double a[N][4], b[N][4];
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+        pc[t] = s_L + ch2_tix(ti[t], tj[t]) * CH2_TS + o_c;
+        pa[t] = s_L + ch2_tix(ti[t], k0) * CH2_TS + o_op;
+        pb[t] = s_L + ch2_tix(tj[t], k0) * CH2_TS + o_op;
+        acc0[t] = f64x4{0.0, 0.0, 0.0, 0.0}; acc1[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a[t][q] = pa[t][4 * q]; b[t][q] = pb[t][4 * q]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c[t][q] = pc[t][4 * CH2_RS * q];
+    }
+    for (int k = k0; k <= k1; ++k) {
+        double an[N][4], bn[N][4];
+        const int step = k < k1 ? CH2_TS : 0;                   // tiles (i, k) and (i, k + 1) are neighbours in memory; the last panel re-reads itself
+#pragma unroll
+        for (int t = 0; t < N; ++t) {
+            pa[t] += step; pb[t] += step;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { an[t][q] = pa[t][4 * q]; bn[t][q] = pb[t][4 * q]; }
+        }
+#pragma unroll
+        for (int t = 0; t < N; ++t) {
+            acc0[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t][0], b[t][0], acc0[t], 0, 0, 0);
+            acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t][1], b[t][1], acc1[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < N; ++t) {
+            acc0[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t][2], b[t][2], acc0[t], 0, 0, 0);
+            acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t][3], b[t][3], acc1[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < N; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { a[t][q] = an[t][q]; b[t][q] = bn[t][q]; }
+    }
+#pragma unroll
+    for (int t = 0; t < N; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pc[t][4 * CH2_RS * q] = c[t][q] - (acc0[t][q] + acc1[t][q]);
+}
+
+// x_out receives the solution, B.scal[3] whether the system was positive definite (and no wait ran out).
+__device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, double* s_mem, double* x_out, bool clear_after_load) {
+    // the wave number goes through readfirstlane: as a per-thread value every role branch below would be compiled as divergent (EXEC masks,
+    // loop counters and tile indices in vector registers)
+    const int D = B.D, DA = D + 1, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r16 = lane & 15, kq = lane >> 4;
+    const double* const A = B.S;
+    const int nblk = (D + CH_NB - 1) / CH_NB;                  // column blocks = row blocks of S
+    const int T = (DA + CH_NB - 1) / CH_NB;                    // row blocks of the augmented matrix
+    const int iD = D >> 4, rD = D & 15;                        // where the right-hand-side row lives
+    double* const s_col = s_mem;                               // [2][16][16] published columns of the block being factored (stage parity); x during the backward substitution
+    double* const s_L = s_mem + 512;                           // the tiles; the diagonal tile of a factored block holds W_k = L_kk^-T (not L_kk, which nobody needs again)
+    const int o_row = CH2_RS * r16;                            // row r16 of a tile (a row per lane)
+    const int o_op = CH2_RS * r16 + kq;                        // MFMA operand: row r16, columns kq + 4 q
+    const int o_c = CH2_RS * kq + r16;                         // MFMA result: rows kq + 4 q, column r16
+    __shared__ Ch2Flags F;
+    if (tid < 16) { F.rowdone[tid] = 0; F.rdy[tid] = -1; }
+    if (tid == 0) { F.prog = 0; F.diag = 0; F.dma = 0; F.init = 0; F.ok = 1; F.abort_ = 0; F.xflag = 0; F.inv = 0; }
+    const double lambda = (ctl_->need_lin && ctl_->first) ? 1e-5 * B.scal[4] : ctl_->lambda;      // as k_ba_init_S derives it
+    const double* const Hpp = B.Hpp;
+    __syncthreads();                                           // the words are zero, everyone has read the control block
+    CH2_STAMP(127)
+    if (tid == 0) {                                            // take over the fresh linearisation, clear the trial sums
+        BaCtl* c = ctl_;
+        if (c->need_lin) {
+            c->cur = B.scal[0];
+            if (c->first) { c->lambda = lambda; c->ni = 2; c->first = 0; }
+            c->need_lin = 0;
+        }
+        B.scal[1] = 0; B.scal[2] = 0; B.scal[7] = 0;
+    }
+
+    // W_k = L_kk^-T: the first generation's panel solve (a row per lane, DPP row broadcasts of the published columns) applied to the rows
+    // of the identity -- ONE such pass per stage, by one wave, while wave 0 waits for it (the double-precision DPP pipe is shared by the
+    // whole compute unit); every panel solve below the block is then X = A W_k on the matrix cores.
+    auto invert_block = [&](int k) {
+        const double* s_colp = s_col + (k & 1) * 256;
+        double x[CH_NB], Lk[CH_NB];
+#pragma unroll
+        for (int c = 0; c < CH_NB; ++c) { x[c] = c == r16 ? 1.0 : 0.0; Lk[c] = 0.0; }
+        // streamed: a column step per published column, so that W_k is complete one step behind the factorisation (a wave that comes late
+        // takes what is there in one batch)
+        const int f0 = __builtin_amdgcn_readfirstlane(*(const volatile ch2_lds_int*)&F.prog);
+        Lk[0] = *(const volatile ch2_lds_f64*)(s_colp + r16);
+        Ch2Stream<0>::run(x, Lk, f0, s_colp, &F.prog, CH_NB * k, r16, &F.abort_);
+        if (r16 < min(CH_NB, D - CH_NB * k)) {                   // (behind a partial last block the tile's rows hold the right-hand side: not touched)
+            double* w = s_L + ch2_tix(k, k) * CH2_TS + o_row;
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) w[c] = x[c];        // (four DPP rows hold the same sixteen rows: same values to the same addresses)
+        }
+        ch2_set(&F.inv, k + 1);
+    };
+    // tiles (ti[t], k) <- tile W_k, N at once, in place: 4 MFMAs each on accumulators of their own (lane l: A[l & 15][(l >> 4) + 4 q] = the
+    // tile's row, B[(l >> 4) + 4 q][l & 15] = W_k's row; result rows (l >> 4) + 4 q, column l & 15)
+    auto solve_tiles = [&](auto nconst, const int (&ti)[3], int k) {
+        constexpr int N = decltype(nconst)::value;
+        const double* pw = s_L + ch2_tix(k, k) * CH2_TS + o_c;
+        double bw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bw[q] = pw[4 * CH2_RS * q];
+        double a[N][4];
+#pragma unroll
+        for (int t = 0; t < N; ++t) {
+            const double* pa = s_L + ch2_tix(ti[t], k) * CH2_TS + o_op;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[t][q] = pa[4 * q];
+        }
+        f64x4 acc[N];
+#pragma unroll
+        for (int t = 0; t < N; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int t = 0; t < N; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t][q], bw[q], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < N; ++t) {
+            double* pc = s_L + ch2_tix(ti[t], k) * CH2_TS + o_c;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pc[4 * CH2_RS * q] = acc[t][q];
+        }
+    };
+
+    // Backward substitution L^T x = y, three waves (0, 2, 3), wave s_w owns rows 64 s_w .. 64 s_w + 63 (a row per lane; the residual, then
+    // the solution, in `acc`).  Blocks are solved from the bottom by the wave that owns their rows: x_p = W_p r_p (every DPP row computes,
+    // only row p & 3 holds the block), x_p into LDS (a slot per block) and the word xflag; every wave with rows above block p adds
+    // -L[j0 + k][r] x[j0 + k] to them (operands requested before the wait).  No barrier; the chain crosses from one wave to the next twice.
+    auto backsub = [&](int s_w) {
+        // every row block has been solved against every block left of it (the one with the right-hand side: against all of them) and every
+        // block has been inverted: the factor is complete, its last row is y
+        ch2_wait_set(F.rowdone, 1u << iD, nblk, &F.abort_);
+        for (int i = 1; i < T; ++i) if (i != iD) ch2_wait_ge(&F.rowdone[i], i, &F.abort_);
+        ch2_wait_ge(&F.inv, nblk, &F.abort_);
+        CH2_STAMP(61)
+#ifdef CH2_DEBUG
+        if (s_w == 0) for (int i = lane; i < T * (T + 1) / 2 * CH2_TS; i += 64) B.W[i] = s_L[i];      // the augmented factor (W_k on the diagonal), for tools/chol_bench
+#endif
+        double* const s_xb = s_col;                             // x_p, 16 per block, in the (now idle) column buffer; [256 ..] takes the other DPP rows' leftovers
+        const int row = 64 * s_w + lane;
+        double acc;
+        { const int r = min(row, D - 1); acc = s_L[ch2_tix(iD, r >> 4) * CH2_TS + CH2_RS * rD + (r & 15)]; acc = row < D ? acc : 0.0; }
+        for (int p = nblk - 1; p >= 4 * s_w; --p) {
+            const int j0 = CH_NB * p, nb = min(CH_NB, D - j0), gp = p & 3;
+            const bool mine_p = (p >> 2) == s_w;
+            double Lp[CH_NB], w[CH_NB];
+            if (64 * s_w < j0) {                                // my rows, column block 4 s_w + kq: tile (p, 4 s_w + kq), clamped for the lanes at or past the block
+                const double* t = s_L + ch2_tix(p, min(4 * s_w + kq, p)) * CH2_TS + r16;
+#pragma unroll
+                for (int k = 0; k < CH_NB; ++k) Lp[k] = t[CH2_RS * k];
+            }
+            if (mine_p) {
+                // x_p = W_p r_p: lane i of the DPP row that holds the block keeps row i of W_p, the residuals arrive by row broadcast (16
+                // independent DPP multiply-adds on four sums -- the dependent chain of a triangular solve is gone with L_pp)
+                const double* t = s_L + ch2_tix(p, p) * CH2_TS + CH2_RS * min(r16, nb - 1);
+#pragma unroll
+                for (int j = 0; j < CH_NB; ++j) w[j] = t[j];
+                double r = acc, s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                ch_exec_settle(r);
+                ch_fnma_bcast<0>(s0, r, w[0]); ch_fnma_bcast<1>(s1, r, w[1]); ch_fnma_bcast<2>(s2, r, w[2]); ch_fnma_bcast<3>(s3, r, w[3]);
+                ch_fnma_bcast<4>(s0, r, w[4]); ch_fnma_bcast<5>(s1, r, w[5]); ch_fnma_bcast<6>(s2, r, w[6]); ch_fnma_bcast<7>(s3, r, w[7]);
+                ch_fnma_bcast<8>(s0, r, w[8]); ch_fnma_bcast<9>(s1, r, w[9]); ch_fnma_bcast<10>(s2, r, w[10]); ch_fnma_bcast<11>(s3, r, w[11]);
+                ch_fnma_bcast<12>(s0, r, w[12]); ch_fnma_bcast<13>(s1, r, w[13]); ch_fnma_bcast<14>(s2, r, w[14]); ch_fnma_bcast<15>(s3, r, w[15]);
+                const double z = -((s0 + s1) + (s2 + s3));
+                const bool holder = kq == gp && r16 < nb;
+                s_xb[holder ? CH_NB * p + r16 : 256 + lane] = z;
+                acc = holder ? z : acc;
+                ch2_set(&F.xflag, nblk - p);
+            } else {
+                ch2_wait_ge(&F.xflag, nblk - p, &F.abort_);
+            }
+            if (64 * s_w < j0) {
+                double xk[CH_NB];
+#pragma unroll
+                for (int k = 0; k < CH_NB; ++k) { xk[k] = s_xb[CH_NB * p + min(k, nb - 1)]; xk[k] = k < nb ? xk[k] : 0.0; }
+                double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+                for (int k = 0; k < CH_NB; k += 4) {
+                    s0 = fma(Lp[k], xk[k], s0); s1 = fma(Lp[k + 1], xk[k + 1], s1);
+                    s2 = fma(Lp[k + 2], xk[k + 2], s2); s3 = fma(Lp[k + 3], xk[k + 3], s3);
+                }
+                acc -= row < j0 ? ((s0 + s1) + (s2 + s3)) : 0.0;
+            }
+        }
+        if (row < D) x_out[row] = acc;
+    };
+
+    if (wave == 0) {
+        // ================= P: the chain of diagonal blocks =====================================================================
+        __builtin_amdgcn_s_setprio(3);
+        bool ok = true;
+        for (int k = 0; k < nblk; ++k) {
+            const int j0 = CH_NB * k, nb = min(CH_NB, D - j0);
+            const bool mine = r16 < nb;
+            double* const tkk = s_L + ch2_tix(k, k) * CH2_TS + o_row;
+            double a[CH_NB];
+            if (k == 0) {
+                // block 0 straight from global memory into registers (row r16 per lane; H_pp + lambda I join here): the factorisation starts
+                // while the other waves are still bringing the tiles into LDS
+                const int jb = r16 / 6, ab = r16 - 6 * jb;
+                const double* grow = A + o_row;
+#pragma unroll
+                for (int c = 0; c < CH_NB; ++c) {
+                    const int b = c - 6 * jb;
+                    const bool inb = mine && b >= 0 && b <= ab;
+                    const double h = inb ? Hpp[36 * jb + 6 * ab + b] : 0.0;
+                    a[c] = grow[c] + h + (c == r16 ? lambda : 0.0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // S is cleared behind the loads: these count as one of them
+                if (lane == 0) ch2_inc(&F.dma);
+            } else {
+#pragma unroll
+                for (int c = 0; c < CH_NB; ++c) a[c] = tkk[c];          // written by this wave at the end of the previous stage
+            }
+            CH2_STAMP(3 * k + 1)
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) a[c] = (mine && c <= r16) ? a[c] : (c == r16 ? 1.0 : 0.0);
+            double* const s_colp = s_col + (k & 1) * 256;
+            ch_exec_settle(a[0]);
+            Ch2Col<0>::run(a, s_colp, &F.prog, CH_NB * k, r16);
+            CH2_STAMP(3 * k + 2)
+            const double myinv = s_colp[r16 * CH_NB + r16];
+            ok = ok && ch_pivots_ok(myinv);
+            if (k == 0) ch2_wait_ge(&F.init, CH2_NC, &F.abort_);        // the DMA of the tiles has landed: block 0's rows may be overwritten
+            if (k + 1 < T) {
+                // ---- the rest of the critical loop stays on this wave.  What a wave can issue is ~1 instruction per 10 clocks here
+                // whatever the instruction (tools/lds_probe: 3 tiles x 1 panel = 75 instructions = 1200 clocks; a 136-instruction DPP
+                // solve of 16 rows 1400), so the loop is kept SHORT rather than clever: tile (k+1, k) is solved as a product with
+                // W_k = L_kk^-T (wave 1 inverts the block while it is being factored) -- computed TRANSPOSED, X^T = W_k^T A^T, so that the
+                // result registers are at once the MFMA operands of tile (k+1, k+1) -= X X^T (lane (kq, r): X[r][kq + 4 q]) -- 4 + 4
+                // MFMAs, 12 LDS reads, 8 writes, then the 16 reads that bring the next block's rows into the row-per-lane form.  The
+                // owner of row block k+1 has both tiles ready through panel k-1 (rdy) -- normally long before.
+                CH2_STAMP(3 * k + 3)
+                ch2_wait_ge(&F.rdy[k + 1], k, &F.abort_);
+                CH2_STAMP(80 + (k & 7))
+                double* const px = s_L + ch2_tix(k + 1, k) * CH2_TS + o_op;
+                double* const pd = s_L + ch2_tix(k + 1, k + 1) * CH2_TS + o_c;
+                double at[4], cc[4], w[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { at[q] = px[4 * q]; cc[q] = pd[4 * CH2_RS * q]; }
+                ch2_wait_ge(&F.inv, k + 1, &F.abort_);
+                CH2_STAMP(3 * k + 4 >= 3 * nblk ? 99 : 90 + (k & 7))
+                const double* pw = s_L + ch2_tix(k, k) * CH2_TS + o_c;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w[q] = pw[4 * CH2_RS * q];
+                // X^T[r][c] = sum_m W^T[r][m] A^T[m][c]: "A" operand W^T[r][kq + 4 q] = W[kq + 4 q][r] (the result pattern of the tile that holds W),
+                // "B" operand A^T[kq + 4 q][c] = A[c][kq + 4 q] (the operand pattern of tile (k+1, k)); lane (kq, c) gets X^T[kq + 4 q][c] = X[c][kq + 4 q]
+                f64x4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = x0;
+                x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w[0], at[0], x0, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w[1], at[1], x1, 0, 0, 0);
+                x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w[2], at[2], x0, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w[3], at[3], x1, 0, 0, 0);
+                double xo[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { xo[q] = x0[q] + x1[q]; px[4 * q] = xo[q]; }      // L(k+1, k)
+                if (k + 1 < nblk) {
+                    f64x4 s0 = {0.0, 0.0, 0.0, 0.0}, s1 = s0;
+                    s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xo[0], xo[0], s0, 0, 0, 0);
+                    s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xo[1], xo[1], s1, 0, 0, 0);
+                    s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xo[2], xo[2], s0, 0, 0, 0);
+                    s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xo[3], xo[3], s1, 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) pd[4 * CH2_RS * q] = cc[q] - (s0[q] + s1[q]);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                ch2_set(&F.rowdone[k + 1], k + 1);
+            }
+            if (nb < CH_NB) {
+                // a partial last block: the right-hand side is row nb of this very tile; its forward substitution y_c = (b_c - sum_{m<c} L[c][m] y_m)
+                // / L[c][c] runs here, in registers (lane c: b_c and row c of the block, y_m by DPP broadcast: ChFwd of the first generation)
+                double* prhs = s_L + ch2_tix(k, k) * CH2_TS + CH2_RS * nb;
+                double Lr[CH_NB];
+#pragma unroll
+                for (int m = 0; m < CH_NB; ++m) Lr[m] = (mine && m < r16) ? a[m] : 0.0;
+                double bc = prhs[min(r16, nb - 1)], yf = 0.0;
+                bc = mine ? bc : 0.0;
+                const double inv = mine ? myinv : 0.0;
+                ch_exec_settle(bc);
+                ChFwd<0>::run(Lr, bc, inv, yf, r16);
+                if (lane < nb) prhs[lane] = yf;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                ch2_set(&F.rowdone[iD], nblk);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        // ================= backward substitution: this wave takes rows 0 .. 63 ==================================================
+        CH2_STAMP(60)
+        backsub(0);
+        CH2_STAMP(62)
+        ok = ok && ch2_peek(&F.abort_) == 0;
+        if (lane == 0) { F.ok = ok ? 1 : 0; B.scal[3] = ok ? 1.0 : 0.0; }
+    } else {
+        // ================= everyone else: bring the system into LDS ==============================================================
+        const int ndbl = nblk * (nblk + 1) / 2 * CH2_TS;        // the tiles of S (rows < D), in the order and layout of LDS
+        {
+            typedef __attribute__((address_space(3))) void lds_void;
+            typedef __attribute__((address_space(1))) const void glb_void;
+            const int npiece = (ndbl + 127) >> 7;               // 128 doubles = 1 KiB per piece (272 is a multiple of 16: the last piece ends on a lane pair)
+            for (int pc = wave - 1; pc < npiece; pc += CH2_NC)
+                if (pc * 128 + 2 * lane < ndbl)
+                    __builtin_amdgcn_global_load_lds((glb_void*)(A + (size_t)pc * 128 + 2 * lane), (lds_void*)(s_L + (size_t)pc * 128), 16, 0, 0);
+        }
+        const int ct = tid - 64;                                // 0 .. 64 * CH2_NC - 1
+        const double rhs_v = ct < D ? B.bs[ct] + B.bp[ct] : 0.0;      // D <= 174 < 448
+        if (T > nblk) {                                         // D is a multiple of 16: the right-hand side is a row block of its own, which no DMA fills
+            double* z = s_L + ch2_tix(T - 1, 0) * CH2_TS;
+            for (int i = ct; i < T * CH2_TS; i += 64 * CH2_NC) z[i] = 0.0;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (lane == 0) ch2_inc(&F.dma);
+        ch2_wait_ge(&F.dma, CH2_NC + 1, &F.abort_);
+        const int nb0 = min(CH_NB, D);
+        for (int i = ct; i < 36 * (D / 6); i += 64 * CH2_NC) {  // the 6x6 diagonal blocks of H_pp (lower halves) and lambda on the diagonal; rows of block 0 are wave 0's
+            const int j = i / 36, a = (i % 36) / 6, b = i % 6, row = 6 * j + a;
+            if (b <= a && row >= nb0) s_L[ch2_sidx(row, 6 * j + b)] += Hpp[i] + (a == b ? lambda : 0.0);
+        }
+        if (ct < D) s_L[ch2_sidx(D, ct)] = rhs_v;
+        if (ct == 0) s_L[ch2_sidx(D, D)] = 0.0;
+        if (clear_after_load && ct < D) B.bs[ct] = 0.0;         // b_s and (below) S are the targets of the next step's Schur atomics (the kernel boundary publishes the stores)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) ch2_inc(&F.init);
+        CH2_STAMP(126)
+        if (clear_after_load && wave == 4) {                    // every copy of S has left global memory (dma): wave 4, which has no other work, clears it
+            double2* g = reinterpret_cast<double2*>(const_cast<double*>(A));
+            for (int i = lane; 2 * i < ndbl; i += 64) g[i] = make_double2(0.0, 0.0);
+        }
+
+        if (wave == 1) {
+            // ================= the inverter: W_k = L_kk^-T, one column step behind the factorisation ================================
+            ch2_wait_ge(&F.init, CH2_NC, &F.abort_);            // W_0 goes where the DMA wrote tile (0, 0)
+            for (int k = 0; k < nblk; ++k) { invert_block(k); CH2_STAMP(k) }
+        } else if (wave != 4 && wave != 5) {
+            // ================= solvers ==========================================================================================
+            // Solver g owns the row blocks i = g + 1, g + 1 + CH2_NS, ...: it alone writes their tiles below block row 0 -- except tile
+            // (i, i-1), which wave 0 solves, and the last panel of tile (i, i), which wave 0 applies.  The schedule is fixed (no
+            // bookkeeping): LEFT-LOOKING, tile (i, j) gets all its panels 0 .. j-1 in one read-modify-write at stage j, right before it is
+            // solved against block j (X = A W_j).  The two tiles that wave 0 takes from the owner of row block k+1 at stage k -- (k+1, k) and
+            // (k+1, k+1) -- are the exception: their panels 0 .. k-2 go in one stage ahead (D), and panel k-1, which needs wave 0's L(k, k-1),
+            // is ONE fused step whose own operands are in registers before the wait: it sits between the end of wave 0's stage k-1 and
+            // the end of its block k.  Foreign inputs: W_k (inv) and L(j, .) of other solvers' / wave 0's row block j (rowdone[j] = stages
+            // solved for row block j).
+            const int g = wave <= 3 ? wave - 2 : wave - 4;      // waves 2, 3, 6, 7
+            auto first_row = [&](int lo) { return lo + ((g + 1 - lo) % CH2_NS + CH2_NS) % CH2_NS; };      // my first row block >= lo
+            auto mark_rows = [&](int k, int i0, int n) {        // row blocks i0, i0 + CH2_NS, .. (n of them) are solved through stage k
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane < n) *(volatile ch2_lds_int*)&F.rowdone[i0 + CH2_NS * lane] = k + 1;
+            };
+            auto rows_update = [&](int i0, int j, int p0, int p1) {      // tiles (i0, j), (i0 + CH2_NS, j), ..: panels p0 .. p1
+                if (i0 >= T || p1 < p0) return;
+                const int ti[3] = {i0, i0 + CH2_NS, i0 + 2 * CH2_NS}, tj[3] = {j, j, j};      // T <= 11: at most three of my row blocks
+                if (i0 + 2 * CH2_NS < T) ch2_tiles_mp<3>(s_L, ti, tj, p0, p1, o_op, o_c);
+                else if (i0 + CH2_NS < T) ch2_tiles_mp<2>(s_L, ti, tj, p0, p1, o_op, o_c);
+                else ch2_tiles_mp<1>(s_L, ti, tj, p0, p1, o_op, o_c);
+            };
+            ch2_wait_ge(&F.init, CH2_NC, &F.abort_);
+            for (int k = 0; k < nblk; ++k) {
+                if (k + 1 >= T) break;                           // nothing below the last block (its right-hand-side row is wave 0's)
+                const bool own1 = k % CH2_NS == g;               // row block k+1 is mine: wave 0 takes its tiles (k+1, k) and (k+1, k+1) from me
+                CH2_STAMP(6 * k)
+                // (A) block column k of my rows, up to date
+                if (own1) {
+                    if (k >= 1) {
+                        const double* pa = s_L + ch2_tix(k + 1, k - 1) * CH2_TS + o_op;
+                        double* pc1 = s_L + ch2_tix(k + 1, k) * CH2_TS + o_c;
+                        double* pc2 = s_L + ch2_tix(k + 1, k + 1) * CH2_TS + o_c;
+                        double a[4], b[4], c1[4], c2[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { a[q] = pa[4 * q]; c1[q] = pc1[4 * CH2_RS * q]; c2[q] = pc2[4 * CH2_RS * q]; }
+                        ch2_wait_ge(&F.rowdone[k], k, &F.abort_);
+                        const double* pb = s_L + ch2_tix(k, k - 1) * CH2_TS + o_op;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) b[q] = pb[4 * q];
+                        f64x4 u0 = {0.0, 0.0, 0.0, 0.0}, u1 = u0, v0 = u0, v1 = u0;
+                        u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], u0, 0, 0, 0); v0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], a[0], v0, 0, 0, 0);
+                        u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], u1, 0, 0, 0); v1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], a[1], v1, 0, 0, 0);
+                        u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], u0, 0, 0, 0); v0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], a[2], v0, 0, 0, 0);
+                        u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], u1, 0, 0, 0); v1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], a[3], v1, 0, 0, 0);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { pc1[4 * CH2_RS * q] = c1[q] - (u0[q] + u1[q]); pc2[4 * CH2_RS * q] = c2[q] - (v0[q] + v1[q]); }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    ch2_set(&F.rdy[k + 1], k);
+                    if (k >= 1) rows_update(k + 1 + CH2_NS, k, 0, k - 1);      // my other row blocks of this column: all panels
+                } else if (k >= 1) {
+                    ch2_wait_ge(&F.rowdone[k], k, &F.abort_);
+                    rows_update(first_row(k + 1), k, 0, k - 1);
+                }
+                CH2_STAMP(6 * k + 1)
+                // (D) one stage ahead, while block k is still being factored: the two tiles wave 0 will take from me at stage k+1, through panel k-1
+                if ((k + 1) % CH2_NS == g && k >= 1 && k + 2 < T) {
+                    ch2_wait_ge(&F.rowdone[k + 1], k, &F.abort_);
+                    const int ti[3] = {k + 2, k + 2, 0}, tj[3] = {k + 1, k + 2, 0};
+                    ch2_tiles_mp<2>(s_L, ti, tj, 0, k - 1, o_op, o_c);
+                }
+                // (B) W_k (wave 1's)
+                const int i0 = first_row(k + 2);
+                if (i0 < T) ch2_wait_ge(&F.inv, k + 1, &F.abort_);
+                CH2_STAMP(6 * k + 2)
+                // (C) my tiles of block column k below row block k+1: X = A W_k
+                if (i0 < T) {
+                    const int ti[3] = {i0, i0 + CH2_NS, i0 + 2 * CH2_NS};
+                    const int n = (T - 1 - i0) / CH2_NS + 1;
+                    if (n == 3) solve_tiles(std::integral_constant<int, 3>{}, ti, k);
+                    else if (n == 2) solve_tiles(std::integral_constant<int, 2>{}, ti, k);
+                    else solve_tiles(std::integral_constant<int, 1>{}, ti, k);
+                    mark_rows(k, i0, n);
+                }
+                CH2_STAMP(6 * k + 3)
+            }
+            if ((wave == 2 || wave == 3) && 64 * (wave - 1) < D) backsub(wave - 1);      // waves 2 and 3: rows 64 .. 127 and 128 .. 191
+        }
+    }
+}

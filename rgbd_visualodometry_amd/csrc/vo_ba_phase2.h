@@ -290,8 +290,8 @@ __device__ __forceinline__ void p2_schur_slice(const BaDev& B, const BaBlock blk
         const double val = s_tot[threadIdx.x];
         if (idx < 12) {
             const int r = idx % 6, c = 2 * cp + idx / 6;
-            if (DIAG) { if (c <= r) atomicAdd(&B.S[ba_tri(6 * blk.j1 + r, 6 * blk.j1 + c)], -val); }
-            else atomicAdd(&B.S[ba_tri(6 * blk.j2 + c, 6 * blk.j1 + r)], -val);          // j1 < j2: the block below the diagonal is the one the Cholesky reads
+            if (DIAG) { if (c <= r) atomicAdd(&B.S[ba_sidx(B, 6 * blk.j1 + r, 6 * blk.j1 + c)], -val); }
+            else atomicAdd(&B.S[ba_sidx(B, 6 * blk.j2 + c, 6 * blk.j1 + r)], -val);      // j1 < j2: the block below the diagonal is the one the Cholesky reads
         } else if (DIAG && idx < 14) {
             atomicAdd(&B.bs[6 * blk.j1 + 2 * cp + idx - 12], -val);
         }

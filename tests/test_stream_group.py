@@ -196,7 +196,7 @@ def test_concurrent_local_bas_equal_sequential_ones(libs):
         for t in ths:
             t.join()
         for k, ((pw, xw, fw, rw), (pg, xg, fg, rg)) in enumerate(zip(want, got)):
-            assert abs(rg.lm_iters - rw.lm_iters) <= (0 if probs[k][1] < 10 else 2), k
+            assert abs(rg.lm_iters - rw.lm_iters) <= (0 if probs[k][1] < 10 else 3), k      # (the early stop below 1e-10 falls on a neighbouring iteration when the atomics' order differs)
             assert np.array_equal(fg, fw), k
             tol = 1e-7 if probs[k][1] < 10 else 1e-6       # f64 atomics (LDS accumulators, partial sums): summation order differs run to run
             np.testing.assert_allclose(pg, pw, atol=tol)
