@@ -160,6 +160,15 @@ def drive(sysm, stamps, bptr, dptr, i0, i1, lookahead, W, est=None, on_device=Tr
     while i < i1:
         n = min(lookahead, i1 - i)
         sysm.prefetch(stamps[i:i + n], bptr[i:i + n], dptr[i:i + n], 3 * W, 2 * W, on_device)
+        if not on_device:
+            # host frames: the NEXT batch's uploads run on the copy stream beside this batch's tracking, as a reader thread ahead of AddFrame
+            # does.  The stream is continuous across drive() calls (the warmup's last batch starts the first timed batch's copies), and
+            # a call issues as many frame copies as it consumes: behind the last frame the copies wrap around to the first frames.
+            nt = len(bptr)
+            nxt = [(i + n + j) % nt for j in range(min(lookahead, nt))]
+            if i + n >= i1 and i1 < nt:
+                nxt = nxt[:min(lookahead, nt - i1)]         # (the following drive() call starts at i1 with a batch of this size)
+            sysm.preload([bptr[q] for q in nxt], [dptr[q] for q in nxt], 3 * W, 2 * W)
         for j in range(n):
             ok, T = sysm.add_prefetched()
             if est is not None:
@@ -375,7 +384,8 @@ def main():
             su.close()
             upl = {"frames_per_s": round(K / tu, 2), "ms_per_step": round(1e3 * tu / K, 4), "vs_resident": round((K / tu) / fps, 3),
                    "bytes_per_frame_h2d": fb + fd, **accuracy(ev, capi, stamps, Twc, est_u, 0, total),
-                   "note": "frames in pinned host memory, uploaded per look-ahead batch by FrontEnd::PrefetchFrames (vo_frame_upload) inside the timed region"}
+                   "note": "frames in pinned host memory; every look-ahead batch's upload is issued one batch ahead on the context's copy stream (FrontEnd::PreloadFrames / "
+                           "vo_frames_preload) and overlaps the previous batch's tracking, as a reader thread ahead of AddFrame would; the timed region issues as many frame copies as it consumes"}
             del hb, hd
 
         # ---- causal single-frame figure ---------------------------------------------------------------

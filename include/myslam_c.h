@@ -65,6 +65,10 @@ void myslam_system_destroy(myslam_system* s);
  * by this call, and frames in DEVICE memory must stay valid for as long as the frame can be a covisible keyframe (the whole run). */
 int myslam_prefetch(myslam_system* s, int n, const double* stamps, const void* const* bgr, const void* const* depth,
                     int bgr_stride, int depth_stride, int on_device);
+/* Start the uploads of the frames of the NEXT myslam_prefetch call (the same buffers, in the same order) now, on a copy stream, beside
+ * the tracking of the frames already queued: what a reader thread ahead of FrontEnd::AddFrame does in run_vo.  Page-locked host memory
+ * only (a no-op otherwise); the buffers must stay untouched until those frames have been consumed. */
+int myslam_preload(myslam_system* s, int n, const void* const* bgr, const void* const* depth, int bgr_stride, int depth_stride);
 /* AddFrame on the next prefetched frame, or on an explicit host/device frame if none is queued.
  * tracked = return value of FrontEnd::AddFrame; T_wc = GetPose().inverse() as written by run_vo.cpp:116. */
 int myslam_add_frame(myslam_system* s, double stamp, const void* bgr, const void* depth, int bgr_stride, int depth_stride,

@@ -162,6 +162,15 @@ int vo_default_track_params(vo_track_params* tp);
  * returns at once -- the buffers must stay untouched until the next call that waits for the context (vo_orb_detect_describe, vo_sync). */
 int vo_frame_upload(vo_ctx* ctx, int slot, const uint8_t* bgr, int bgr_stride,
                     const uint16_t* depth, int depth_stride);
+/* The uploads of the NEXT look-ahead batch ahead of time (page-locked sources only; a no-op otherwise): frames slot0 .. slot0 + n - 1
+ * are enqueued on a copy stream of the context's own into one of two device slabs, beside whatever the context is doing with the slots'
+ * current frames; evenly spaced host frames (one array) travel as one 2-D copy per image kind.  A later vo_frame_upload of a slot from
+ * the same buffers and strides takes the frame from there (no copy, no host wait).  The host buffers must stay untouched from this
+ * call until the frames' ORB results have been fetched; a slot that took a preloaded frame must be rebound before the second next
+ * preload (its slab is reused then; such a slot is unbound rather than left showing new bytes).  Mirrors what a reader thread ahead of
+ * FrontEnd::AddFrame does for run_vo (app/run_vo.cpp:91-109). */
+int vo_frames_preload(vo_ctx* ctx, int slot0, int n, const uint8_t* const* bgr, int bgr_stride,
+                      const uint16_t* const* depth, int depth_stride);
 /* Use frames already resident in device memory (no copy; pointers must stay valid until the
  * slot is rebound).  For the CPU oracle these are ordinary host pointers. */
 int vo_frame_bind_device(vo_ctx* ctx, int slot, const void* d_bgr, int bgr_stride,

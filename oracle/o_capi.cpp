@@ -100,6 +100,11 @@ int vo_frame_upload(vo_ctx* c, int slot, const uint8_t* bgr, int bs, const uint1
     return VO_OK;
 }
 
+int vo_frames_preload(vo_ctx* c, int slot0, int n, const uint8_t* const* bgr, int bs, const uint16_t* const* depth, int ds) {      // (the CPU has nothing to overlap a copy with)
+    if (!c || slot0 < 0 || n < 1 || slot0 + n > (int)c->slots.size() || !bgr || !depth || bs < 3 * c->p.width || ds < 2 * c->p.width) return VO_E_INVALID;
+    return VO_OK;
+}
+
 int vo_frame_bind_device(vo_ctx* c, int slot, const void* b, int bs, const void* d, int ds) {
     if (!c || slot < 0 || slot >= (int)c->slots.size() || !b || !d || bs < 3 * c->p.width || ds < 2 * c->p.width) return VO_E_INVALID;
     auto& s = c->slots[slot];

@@ -65,7 +65,7 @@ MATCH_DTYPE = np.dtype([("map_index", "<i4"), ("kp_index", "<i4"), ("distance", 
 
 # every symbol include/vo_hip.h declares
 SYMBOLS = ["vo_ctx_create", "vo_ctx_destroy", "vo_strerror", "vo_backend_name", "vo_default_params",
-           "vo_default_track_params", "vo_frame_upload", "vo_frame_bind_device", "vo_orb_detect_describe",
+           "vo_default_track_params", "vo_frame_upload", "vo_frames_preload", "vo_frame_bind_device", "vo_orb_detect_describe",
            "vo_orb_fetch", "vo_orb_level_size", "vo_orb_fetch_level", "vo_orb_fetch_blur_level", "vo_map_upsert", "vo_map_upsert_from_frame", "vo_map_set_active",
            "vo_match_active_map", "vo_matches_set", "vo_pnp_ransac", "vo_pose_refine_lm", "vo_track_frame", "vo_track_batch", "vo_track_batch_begin", "vo_track_batch_end", "vo_track_fetch_matches",
            "vo_local_ba", "vo_sync", "vo_profile_enable", "vo_profile_read",
@@ -106,6 +106,7 @@ class VoLib:
         L.vo_ctx_create.argtypes = [C.POINTER(VoParams), C.c_int, C.POINTER(C.c_void_p)]
         L.vo_ctx_destroy.argtypes = [C.c_void_p]
         L.vo_frame_upload.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.vo_frames_preload.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.vo_frame_bind_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.vo_orb_detect_describe.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.vo_orb_fetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
@@ -231,6 +232,14 @@ class VoContext:
         bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
         depth = np.ascontiguousarray(depth, dtype=np.uint16)
         self.L.check(self.L.lib.vo_frame_upload(self.h, slot, _ptr(bgr), bgr.strides[0], _ptr(depth), depth.strides[0]), "vo_frame_upload")
+
+    def preload_ptrs(self, slot0: int, bgr_ptrs, bgr_stride: int, depth_ptrs, depth_stride: int):
+        n = len(bgr_ptrs)
+        b = (C.c_void_p * n)(*bgr_ptrs); d = (C.c_void_p * n)(*depth_ptrs)
+        self.L.check(self.L.lib.vo_frames_preload(self.h, slot0, n, C.cast(b, C.c_void_p), bgr_stride, C.cast(d, C.c_void_p), depth_stride), "vo_frames_preload")
+
+    def upload_ptr(self, slot: int, bgr_ptr: int, bgr_stride: int, depth_ptr: int, depth_stride: int):
+        self.L.check(self.L.lib.vo_frame_upload(self.h, slot, C.c_void_p(bgr_ptr), bgr_stride, C.c_void_p(depth_ptr), depth_stride), "vo_frame_upload")
 
     def bind_device(self, slot: int, bgr_ptr: int, bgr_stride: int, depth_ptr: int, depth_stride: int):
         self.L.check(self.L.lib.vo_frame_bind_device(self.h, slot, C.c_void_p(bgr_ptr), bgr_stride, C.c_void_p(depth_ptr), depth_stride), "vo_frame_bind_device")

@@ -263,6 +263,10 @@ void vo_ctx_destroy(vo_ctx* c) {
     if (c->ba_engine) { vo_ba_engine_release(c->ba_engine); c->ba_engine = nullptr; }
     for (auto p : c->own_bgr) if (p) (void)hipFree(p);
     for (auto p : c->own_depth) if (p) (void)hipFree(p);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    for (auto& sl : c->pre) { if (sl.bgr) (void)hipFree(sl.bgr); if (sl.depth) (void)hipFree(sl.depth); if (sl.ev) (void)hipEventDestroy(sl.ev); }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->orb_ev) (void)hipEventDestroy(c->orb_ev);
     void* ptrs[] = {c->d_slots, c->d_pyr, c->d_blur, c->d_tab, c->d_tabs, c->d_cand, c->d_cand_cnt, c->d_sel, c->d_sel_key, c->d_sel_cnt, c->d_kps,
                     c->d_desc, c->d_nkp, c->d_status, c->d_map_pos, c->d_map_nrm, c->d_map_desc, c->d_map_flags, c->d_active, c->d_best, c->d_mcand,
                     c->d_matches, c->d_corr_xyz, c->d_corr_uv, c->d_hyp_pose, c->d_hyp_cnt, c->d_inliers, c->d_lm_mask, c->d_lm_x, c->d_ba};
@@ -370,10 +374,77 @@ static int push_slots(vo_ctx* c) {
     return VO_OK;
 }
 
+// The uploads of a whole look-ahead batch ahead of time, on the context's copy stream, into one of two slabs: the slots' current frames
+// (and everything enqueued on the context's stream) go on undisturbed.  Evenly spaced host frames (one array of frames) travel as ONE
+// two-dimensional copy per image kind -- per-frame API calls, not bytes, were what the per-slot upload cost the caller's thread (64 copies
+// and 64 pointer queries per batch of 32: ~2 ms of host time per 21 ms of frames).  A later vo_frame_upload of a slot from the same host
+// buffers finds the frame on the device: it points the slot into the slab and makes the context's stream wait for the copy's event once.
+int vo_frames_preload(vo_ctx* c, int slot0, int n, const uint8_t* const* bgr, int bs, const uint16_t* const* depth, int ds) {
+    if (!c || slot0 < 0 || n < 1 || slot0 + n > c->p.max_frames || !bgr || !depth || bs < 3 * c->p.width || ds < 2 * c->p.width) return VO_E_INVALID;
+    for (int i = 0; i < n; ++i) if (!bgr[i] || !depth[i]) return VO_E_INVALID;
+    HIP_TRY(hipSetDevice(c->device));
+    hipPointerAttribute_t at;
+    const bool pinned = hipPointerGetAttributes(&at, bgr[0]) == hipSuccess && at.type == hipMemoryTypeHost && hipPointerGetAttributes(&at, depth[0]) == hipSuccess && at.type == hipMemoryTypeHost;
+    (void)hipGetLastError();
+    if (!pinned) return VO_OK;                              // pageable memory copies synchronously: nothing to gain, vo_frame_upload does it
+    if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!c->orb_ev) HIP_TRY(hipEventCreateWithFlags(&c->orb_ev, hipEventDisableTiming));
+    const int F = c->p.max_frames, H = c->p.height;
+    if ((int)c->pre_slot.size() != F) { c->pre_slot.assign(F, vo_ctx::PreSlot{}); c->slot_gen.assign(F, -1); }
+    const int g = c->pre_next;
+    vo_ctx::PreSlab& sl = c->pre[g];
+    const size_t nb = (size_t)bs * H, nd = (size_t)ds * H;
+    if (sl.nb != nb || sl.nd != nd || !sl.bgr) {            // (first use, or the strides changed: nobody may still be reading the slab)
+        HIP_TRY(hipStreamSynchronize(c->copy_stream)); HIP_TRY(hipStreamSynchronize(c->stream));
+        if (sl.bgr) (void)hipFree(sl.bgr); if (sl.depth) (void)hipFree(sl.depth);
+        sl.bgr = sl.depth = nullptr; sl.nb = sl.nd = 0;
+        if (hipMalloc((void**)&sl.bgr, nb * F) != hipSuccess || hipMalloc((void**)&sl.depth, nd * F) != hipSuccess) return VO_E_NOMEM;
+        sl.nb = nb; sl.nd = nd;
+    }
+    if (!sl.ev) HIP_TRY(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    // a slot that still shows a frame of this slab (not rebound for two batches) loses it: its next ORB launch fails instead of reading the new bytes
+    for (int i = 0; i < F; ++i) if (c->slot_gen[i] == g) { c->slot_gen[i] = -1; c->slot_bound[i] = 0; }
+    // the slab's previous frames were read by ORB chains enqueued before the last recorded orb_ev
+    if (c->orb_ev_set) HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->orb_ev, 0));
+    const size_t cb = (size_t)bs * (H - 1) + 3 * (size_t)c->p.width, cd = (size_t)ds * (H - 1) + 2 * (size_t)c->p.width;
+    bool even = n >= 2;
+    const ptrdiff_t db = n >= 2 ? (const uint8_t*)bgr[1] - (const uint8_t*)bgr[0] : 0, dd = n >= 2 ? (const uint8_t*)depth[1] - (const uint8_t*)depth[0] : 0;
+    for (int i = 1; i + 1 < n && even; ++i) even = ((const uint8_t*)bgr[i + 1] - (const uint8_t*)bgr[i]) == db && ((const uint8_t*)depth[i + 1] - (const uint8_t*)depth[i]) == dd;
+    even = even && db >= (ptrdiff_t)cb && dd >= (ptrdiff_t)cd;
+    if (even) {
+        HIP_TRY(hipMemcpy2DAsync(sl.bgr + nb * slot0, nb, bgr[0], (size_t)db, cb, n, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(hipMemcpy2DAsync(sl.depth + nd * slot0, nd, depth[0], (size_t)dd, cd, n, hipMemcpyHostToDevice, c->copy_stream));
+    } else {
+        for (int i = 0; i < n; ++i) {
+            HIP_TRY(hipMemcpyAsync(sl.bgr + nb * (slot0 + i), bgr[i], cb, hipMemcpyHostToDevice, c->copy_stream));
+            HIP_TRY(hipMemcpyAsync(sl.depth + nd * (slot0 + i), depth[i], cd, hipMemcpyHostToDevice, c->copy_stream));
+        }
+    }
+    HIP_TRY(hipEventRecord(sl.ev, c->copy_stream));
+    sl.waited = false;
+    for (int i = 0; i < n; ++i) c->pre_slot[slot0 + i] = vo_ctx::PreSlot{bgr[i], depth[i], bs, ds, g, true};
+    c->pre_next = g ^ 1;
+    return VO_OK;
+}
+
 int vo_frame_upload(vo_ctx* c, int slot, const uint8_t* bgr, int bs, const uint16_t* depth, int ds) {
     if (!c || slot < 0 || slot >= c->p.max_frames || !bgr || !depth || bs < 3 * c->p.width || ds < 2 * c->p.width) return VO_E_INVALID;
     HIP_TRY(hipSetDevice(c->device));
     const int H = c->p.height;
+    if (slot < (int)c->pre_slot.size()) {
+        vo_ctx::PreSlot& ps = c->pre_slot[slot];
+        c->slot_gen[slot] = -1;
+        if (ps.valid) {
+            ps.valid = false;
+            if (ps.src_bgr == bgr && ps.src_depth == depth && ps.bs == bs && ps.ds == ds) {      // preloaded: the slot shows the slab's frame; the copy is waited for on the device
+                vo_ctx::PreSlab& sl = c->pre[ps.gen];
+                if (!sl.waited) { HIP_TRY(hipStreamWaitEvent(c->stream, sl.ev, 0)); sl.waited = true; }
+                c->h_slots[slot] = SlotDesc{sl.bgr + sl.nb * slot, sl.depth + sl.nd * slot, bs, ds};
+                c->slot_bound[slot] = 1; c->slot_orb[slot] = 0; c->slot_gen[slot] = (signed char)ps.gen;
+                return mark_slot(c, slot);
+            }
+        }
+    }
     // The slot keeps the caller's strides (the kernels take any pitch, as for vo_frame_bind_device): each image travels as ONE
     // contiguous copy -- a pitch-converting 2-D copy of 480 rows cost 0.14 ms per image.  From page-locked memory the copies are
     // asynchronous and the call does not wait (include/vo_hip.h); pageable sources are staged by the runtime, the wait is then free.
@@ -407,6 +478,7 @@ int vo_frame_bind_device(vo_ctx* c, int slot, const void* b, int bs, const void*
     if (!c || slot < 0 || slot >= c->p.max_frames || !b || !d || bs < 3 * c->p.width || ds < 2 * c->p.width) return VO_E_INVALID;
     HIP_TRY(hipSetDevice(c->device));
     c->h_slots[slot] = SlotDesc{(const uint8_t*)b, (const uint8_t*)d, bs, ds};
+    if (slot < (int)c->slot_gen.size()) c->slot_gen[slot] = -1;
     c->slot_bound[slot] = 1; c->slot_orb[slot] = 0;
     return mark_slot(c, slot);
 }
@@ -419,6 +491,7 @@ int vo_orb_detect_describe(vo_ctx* c, int slot0, int n) {
     if (rc) return rc;
     rc = vo_orb_launch(c, slot0, n);
     if (rc) return rc;
+    if (c->orb_ev) { HIP_TRY(hipEventRecord(c->orb_ev, c->stream)); c->orb_ev_set = true; }      // (vo_frame_preload: the frames of these slots have been read once this has passed)
     for (int i = slot0; i < slot0 + n; ++i) c->slot_orb[i] = 1;
     c->orb_cache_valid = false; c->orb_batch0 = slot0; c->orb_batchn = n;
     return VO_OK;

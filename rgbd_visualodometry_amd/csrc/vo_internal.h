@@ -83,6 +83,13 @@ struct vo_ctx {
     // frames
     std::vector<uint8_t*> own_bgr, own_depth;       // per slot (allocated lazily on upload)
     std::vector<size_t> own_bgr_bytes, own_depth_bytes;
+    // vo_frames_preload: two slabs of max_frames frames each, filled in turn on a copy stream of the context's own while the slots' current
+    // frames are still in use; a slot that takes a preloaded frame points into the slab until it is rebound
+    struct PreSlab { uint8_t* bgr = nullptr; uint8_t* depth = nullptr; size_t nb = 0, nd = 0; hipEvent_t ev = nullptr; bool waited = true; };
+    PreSlab pre[2]; int pre_next = 0;
+    struct PreSlot { const void* src_bgr = nullptr; const void* src_depth = nullptr; int bs = 0, ds = 0, gen = -1; bool valid = false; };
+    std::vector<PreSlot> pre_slot; std::vector<signed char> slot_gen;      // slot_gen[i]: the slab slot i's frame lives in (-1: not a preloaded one)
+    hipStream_t copy_stream = nullptr; hipEvent_t orb_ev = nullptr; bool orb_ev_set = false;
     SlotDesc* d_slots; std::vector<SlotDesc> h_slots;
     SlotDesc* h_slots_pinned; hipEvent_t slots_ev; bool slots_dirty, slots_pending;
     std::vector<char> slot_bound, slot_orb;

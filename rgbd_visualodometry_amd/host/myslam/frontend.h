@@ -31,6 +31,9 @@ public:
     // Frames of one stream depend on each other only from matching onwards, so detection and
     // description of up to max_frames future frames run as one batched launch chain.
     int PrefetchFrames(const std::vector<Frame::Ptr>& frames);
+    // Start the host -> device copies of the frames of the NEXT PrefetchFrames call (same order, same buffers) beside the tracking of the
+    // current ones: (pointer, stride) pairs of frames in page-locked host memory; no-op for anything else (vo_frames_preload)
+    void PreloadFrames(const std::vector<const void*>& bgr, const std::vector<const void*>& depth, int bgr_stride, int depth_stride);
 
     vo_ctx* GetContext() const { return ctx_; }
     void JoinGroup(vo_group* g);         // this stream's tracking calls share launch chains with the group's other streams

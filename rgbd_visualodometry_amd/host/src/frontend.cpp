@@ -166,6 +166,12 @@ int FrontEnd::PrefetchFrames(const std::vector<Frame::Ptr>& frames) {
     return n;
 }
 
+void FrontEnd::PreloadFrames(const std::vector<const void*>& bgr, const std::vector<const void*>& depth, int bgr_stride, int depth_stride) {
+    const int n = std::min<int>((int)std::min(bgr.size(), depth.size()), lookahead_);
+    if (n < 1) return;
+    vo_check(vo_frames_preload(ctx_, 0, n, (const uint8_t* const*)bgr.data(), bgr_stride, (const uint16_t* const*)depth.data(), depth_stride), "vo_frames_preload");
+}
+
 void FrontEnd::ExtractKeyPointsAndComputeDescriptors() {
     VO_SCOPE("fe.fetch_keypoints");
     Frame::Ptr f = frameCurr_;

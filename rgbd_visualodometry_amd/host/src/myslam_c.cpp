@@ -107,6 +107,14 @@ int myslam_prefetch(myslam_system* s, int n, const double* stamps, const void* c
     });
 }
 
+int myslam_preload(myslam_system* s, int n, const void* const* bgr, const void* const* depth, int bs, int ds) {
+    if (!s || n < 1 || !bgr || !depth) return -1;
+    return guarded(s, [&]() {
+        std::vector<const void*> b(bgr, bgr + n), d(depth, depth + n);
+        s->frontend->PreloadFrames(b, d, bs, ds);
+    });
+}
+
 int myslam_add_prefetched(myslam_system* s, int* tracked, double T_wc[12]) {
     if (!s) return -1;
     VO_SCOPE("c.add_prefetched");

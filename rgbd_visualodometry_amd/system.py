@@ -44,7 +44,7 @@ class Stats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
-SYMBOLS = ["myslam_default_options", "myslam_system_create", "myslam_system_destroy", "myslam_prefetch",
+SYMBOLS = ["myslam_default_options", "myslam_system_create", "myslam_system_destroy", "myslam_prefetch", "myslam_preload",
            "myslam_add_frame", "myslam_add_prefetched", "myslam_get_stats", "myslam_flush",
            "myslam_group_create", "myslam_group_destroy", "myslam_group_join", "myslam_group_stats", "myslam_get_context", "myslam_last_error", "myslam_backend_name",
            # taps for parity tests (include/myslam_c.h)
@@ -68,6 +68,7 @@ def _load(path: str):
         lib.myslam_system_create.argtypes = [C.POINTER(Options), C.c_char_p, C.POINTER(C.c_void_p)]
         lib.myslam_system_destroy.argtypes = [C.c_void_p]
         lib.myslam_prefetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        lib.myslam_preload.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         lib.myslam_add_frame.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p]
         lib.myslam_add_prefetched.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
         lib.myslam_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
@@ -199,6 +200,15 @@ class VoSystem:
         d = (C.c_void_p * n)(*depth_ptrs)
         self._check(self.lib.myslam_prefetch(self.h, n, st.ctypes.data, C.cast(b, C.c_void_p), C.cast(d, C.c_void_p), bgr_stride,
                                              depth_stride, int(on_device)), "myslam_prefetch")
+
+    def preload(self, bgr_ptrs: Sequence[int], depth_ptrs: Sequence[int], bgr_stride: int, depth_stride: int):
+        """Start the uploads of the NEXT prefetch() call's frames (pinned host memory) beside the tracking of the queued ones."""
+        n = len(bgr_ptrs)
+        if n == 0:
+            return
+        b = (C.c_void_p * n)(*bgr_ptrs)
+        d = (C.c_void_p * n)(*depth_ptrs)
+        self._check(self.lib.myslam_preload(self.h, n, C.cast(b, C.c_void_p), C.cast(d, C.c_void_p), bgr_stride, depth_stride), "myslam_preload")
 
     def add_prefetched(self):
         ok = C.c_int()

@@ -523,6 +523,49 @@ def test_frame_upload_keeps_the_callers_strides(frames, libs):
     c.close()
 
 
+def test_preloaded_frames_equal_uploaded_ones(frames, libs):
+    """vo_frames_preload copies a look-ahead batch ahead of time on the context's copy stream into one of two slabs (one 2-D copy per image
+    kind when the host frames are evenly spaced); the vo_frame_upload calls that follow from the same page-locked buffers take the frames
+    from there.  Three rounds through the same slots (the slabs take turns), unevenly spaced frames (per-frame copies), a slot that is
+    preloaded from one buffer and uploaded from another (falls back to the copy), and pageable memory (preload is a no-op): the ORB
+    results are those of plain uploads."""
+    import ctypes as C
+    bgr, depth, _, _ = frames
+    H, _ = libs
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipHostMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+    hip.hipHostFree.argtypes = [C.c_void_p]
+    fb, fd, nfr = 640 * 480 * 3, 640 * 480 * 2, 6
+    pb, pd = C.c_void_p(), C.c_void_p()
+    assert hip.hipHostMalloc(C.byref(pb), fb * nfr, 0) == 0 and hip.hipHostMalloc(C.byref(pd), fd * nfr, 0) == 0
+    C.memmove(pb, np.ascontiguousarray(bgr[:nfr]).ctypes.data, fb * nfr)
+    C.memmove(pd, np.ascontiguousarray(depth[:nfr]).ctypes.data, fd * nfr)
+    bp = lambda i: pb.value + i * fb
+    dp = lambda i: pd.value + i * fd
+    c, _ = make_ctx(H, n_features=500, max_frames=4)
+    r, _ = make_ctx(H, n_features=500, max_frames=4)
+    rounds = [([0, 1, 2, 3], [0, 1, 2, 3]),                 # evenly spaced: one 2-D copy per image kind
+              ([4, 5, 0, 2], [4, 5, 1, 2]),                 # uneven spacing: per-frame copies; slot 2 is preloaded with frame 0 but uploaded from frame 1's buffers
+              ([2, 3, 4, 5], [2, 3, 4, 5])]                 # the first slab again
+    for rnd, (pre, ids) in enumerate(rounds):
+        c.preload_ptrs(0, [bp(i) for i in pre], 1920, [dp(i) for i in pre], 1280)
+        for s, i in enumerate(ids):
+            c.upload_ptr(s, bp(i), 1920, dp(i), 1280)
+            r.upload(s, bgr[i], depth[i])
+        c.orb(0, 4); r.orb(0, 4)
+        for s in range(4):
+            kc, dc = c.orb_fetch(s); kr, dr = r.orb_fetch(s)
+            for field in ("x", "y", "octave", "depth_raw"):
+                assert np.array_equal(kc[field], kr[field]), (rnd, s, field)
+            assert np.array_equal(dc, dr), (rnd, s)
+    c.preload_ptrs(0, [bgr[3].ctypes.data], 1920, [depth[3].ctypes.data], 1280)      # pageable: nothing happens
+    c.upload(0, bgr[3], depth[3]); r.upload(0, bgr[3], depth[3])
+    c.orb(0, 1); r.orb(0, 1)
+    assert np.array_equal(c.orb_fetch(0)[1], r.orb_fetch(0)[1])
+    c.close(); r.close()
+    hip.hipHostFree(pb); hip.hipHostFree(pd)
+
+
 def test_frame_upload_reads_no_byte_behind_the_last_row(frames, libs):
     """A column slice of a wider image (a cv::Mat ROI): rows are padded, but the padding behind the LAST row is not the caller's.
     The images are placed so that their last pixel row ends exactly at a PROT_NONE guard page: an upload that copies stride * H
