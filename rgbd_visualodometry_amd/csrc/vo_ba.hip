@@ -50,7 +50,7 @@ struct BaCtl {
     // the rounds of one local BA (k_ba_admit / k_ba_round): the device moves from the robust round to the plain one and on to "done" by itself
     int stage;                       // 0: robust round, 1: plain round, 2: done (final cull made, BaStat written)
     int max_it_next;                 // iterations of the plain round
-    int iters_total, ticket, gen, pad_;
+    int iters_total, ticket, gen, chol_seq;      // chol_seq: steps + 1, written by the Cholesky behind its results (k_ba_cholup: the update workgroups of the same launch wait for it)
     double chi0;                     // plain chi2 of the initial state (reporting)
 };
 
@@ -1037,7 +1037,7 @@ __global__ __launch_bounds__(CH2_T) void k_ba_chol16v2(BaBatch Q) {
     BA_PROBLEM(Q)
     if (ctl_->finished || !B.s_tiles) return;
     extern __shared__ double s_mem[];
-    ba_chol16v2_body(B, ctl_, s_mem, B.dl, true);
+    ba_chol16v2_body<false>(B, ctl_, s_mem, B.dl, true);
 }
 
 // ---- k_ba_chol16g: the same 16-column scheme for D > 192, where the packed triangle no longer fits in LDS -----------
@@ -1505,11 +1505,27 @@ __global__ __launch_bounds__(256) void k_ba_round(BaBatch Q) {
 
 #include "vo_ba_phase2.h"
 
+// The Cholesky and the update in ONE launch (a lone problem with a tile-major system): workgroup 0 is the solver, workgroups 1 .. are
+// k_ba_upchi2's, which request everything that does not depend on the solution and then wait for the solver's word (ctl->chol_seq).
+// Workgroup 0 is dispatched first, so the wait cannot starve it; it is bounded all the same.  A step is then TWO launches.
+__global__ __launch_bounds__(CH2_T) void k_ba_cholup(BaBatch Q) {
+    static_assert(CH2_T == UPC_T, "one block size for both roles");
+    BA_PROBLEM_COPY(Q)
+    if (ctl_->finished) return;
+    if (blockIdx.x == 0) {
+        extern __shared__ double s_mem[];
+        ba_chol16v2_body<true>(B, ctl_, s_mem, B.dl, true);
+    } else {
+        ba_upchi2_body<true>(B, ctl_, 1, (int)blockIdx.x - 1, 0);
+    }
+}
+
 // per-device function attributes (vo_ctx_create calls this with the context's device current)
 int vo_ba_set_attrs() {
     HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol16, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol16g, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol16v2, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_ba_cholup, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     HIP_TRY(hipFuncSetAttribute((const void*)k_ba_upchi2, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     return VO_OK;
 }
@@ -1640,6 +1656,8 @@ static int ba_engine_enqueue(BaEngine* E) {
         }
     }
     const int up_rep = nA >= 2 ? 2 : 1;                     // points per workgroup of k_ba_upchi2: 128 x up_rep (vo_ba_phase2.h; 8 problems per launch: 45.7 / 40.7 / 41.0 / 88 us for 1 / 2 / 4 / 8)
+    static const bool no_fuse = getenv("VO_BA_NO_FUSE") != nullptr;
+    const bool fuse_up = nA == 1 && nA_tiles == 1 && !no_fuse && std::max(ldsA, ldsA_up) <= 150 * 1024;
     BaChunk& C = E->ring[(E->r_head + E->r_n) % 2];
     if (!C.ev_end) { HIP_TRY(hipEventCreateWithFlags(&C.ev_near, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&C.ev_end, hipEventDisableTiming)); }
     C.n = na; C.steps = chunk;
@@ -1664,9 +1682,15 @@ static int ba_engine_enqueue(BaEngine* E) {
             }
             { ProfScope ps(prof, "k_ba_schur2", st); hipLaunchKernelGGL(k_ba_schur2, dim3(gA_blk + gA_pose, 1, nA), blk, 0, st, QA); }
             // both generations in one step: every problem leaves the kernel that is not its own at once (s_tiles says which one is)
+            // a lone tile-major problem: solver and update in one launch (vo_ba_phase2.h, FUSED)
+            if (fuse_up) {
+                ProfScope ps(prof, "k_ba_cholup", st);
+                hipLaunchKernelGGL(k_ba_cholup, dim3(1 + (gA_up + UPC_T / 4 - 1) / (UPC_T / 4)), dim3(CH2_T), std::max(ldsA, ldsA_up), st, QA);
+            } else {
             if (nA_tiles) { ProfScope ps(prof, "k_ba_chol16", st); hipLaunchKernelGGL(k_ba_chol16v2, dim3(1, 1, nA), dim3(CH2_T), ldsA, st, QA); }
             if (nA_tiles < nA) { ProfScope ps(prof, "k_ba_chol16_packed", st); hipLaunchKernelGGL(k_ba_chol16, dim3(1, 1, nA), dim3(CH_THREADS), ldsA, st, QA, 0, 1); }
             { ProfScope ps(prof, "k_ba_upchi2", st); hipLaunchKernelGGL(k_ba_upchi2, dim3((gA_up + up_rep * (UPC_T / 4) - 1) / (up_rep * (UPC_T / 4)), 1, nA), dim3(UPC_T), ldsA_up, st, QA, up_rep); }
+            }
         }
         if (nB) {
             if (sidx == 0) for (int i = 0; i < nB; ++i) { BaJob* j = E->slot[sB[i]]; if (j->wait_pairs) { HIP_TRY(hipStreamWaitEvent(st, j->wait_pairs, 0)); j->wait_pairs = nullptr; } }

@@ -273,6 +273,12 @@ __device__ __forceinline__ void ch2_tiles_mp(double* s_L, const int (&ti)[3], co
 }
 
 // x_out receives the solution, B.scal[3] whether the system was positive definite (and no wait ran out).
+// PUB (k_ba_cholup: the update workgroups of the SAME launch read the results): everything this workgroup hands on -- the control block's
+// fields, the cleared sums, the solution, scal[3] -- leaves as write-through stores, and ctl->chol_seq = steps + 1 follows once all of
+// them have been performed (the same fence-free publication as k_ba_upchi2's ticket).
+__device__ __forceinline__ void ch2_pub_i(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ch2_pub_d(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool PUB>
 __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, double* s_mem, double* x_out, bool clear_after_load) {
     // the wave number goes through readfirstlane: as a per-thread value every role branch below would be compiled as divergent (EXEC masks,
     // loop counters and tile indices in vector registers)
@@ -295,13 +301,23 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
     CH2_STAMP(127)
     if (tid == 0) {                                            // take over the fresh linearisation, clear the trial sums
         BaCtl* c = ctl_;
-        if (c->need_lin) {
-            c->cur = B.scal[0];
-            if (c->first) { c->lambda = lambda; c->ni = 2; c->first = 0; }
-            c->need_lin = 0;
+        if (PUB) {
+            if (c->need_lin) {
+                ch2_pub_d(&c->cur, B.scal[0]);
+                if (c->first) { ch2_pub_d(&c->lambda, lambda); ch2_pub_d(&c->ni, 2.0); ch2_pub_i(&c->first, 0); }
+                ch2_pub_i(&c->need_lin, 0);
+            }
+            ch2_pub_d(B.scal + 1, 0.0); ch2_pub_d(B.scal + 2, 0.0); ch2_pub_d(B.scal + 7, 0.0);
+        } else {
+            if (c->need_lin) {
+                c->cur = B.scal[0];
+                if (c->first) { c->lambda = lambda; c->ni = 2; c->first = 0; }
+                c->need_lin = 0;
+            }
+            B.scal[1] = 0; B.scal[2] = 0; B.scal[7] = 0;
         }
-        B.scal[1] = 0; B.scal[2] = 0; B.scal[7] = 0;
     }
+    const int seq = PUB ? ctl_->steps + 1 : 0;
 
     // W_k = L_kk^-T: the first generation's panel solve (a row per lane, DPP row broadcasts of the published columns) applied to the rows
     // of the identity -- ONE such pass per stage, by one wave, while wave 0 waits for it (the double-precision DPP pipe is shared by the
@@ -413,7 +429,10 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
                 acc -= row < j0 ? ((s0 + s1) + (s2 + s3)) : 0.0;
             }
         }
-        if (row < D) x_out[row] = acc;
+        if (PUB) {
+            if (row < D) ch2_pub_d(x_out + row, acc);
+            if (s_w) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) ch2_inc(&F.diag); }      // (wave 0 counts the others in)
+        } else if (row < D) x_out[row] = acc;
     };
 
     if (wave == 0) {
@@ -519,7 +538,15 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
         backsub(0);
         CH2_STAMP(62)
         ok = ok && ch2_peek(&F.abort_) == 0;
-        if (lane == 0) { F.ok = ok ? 1 : 0; B.scal[3] = ok ? 1.0 : 0.0; }
+        if (PUB) {
+            if (lane == 0) { F.ok = ok ? 1 : 0; ch2_pub_d(B.scal + 3, ok ? 1.0 : 0.0); }
+            // the other waves of the backward substitution have counted themselves in behind their stores (or an abort has ended them:
+            // then the step has failed and the count may stay short -- the wait is bounded like every other)
+            const int others = (64 < D ? 1 : 0) + (128 < D ? 1 : 0);
+            if (ok) ch2_wait_ge(&F.diag, others, &F.abort_);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) ch2_pub_i(&ctl_->chol_seq, seq);
+        } else if (lane == 0) { F.ok = ok ? 1 : 0; B.scal[3] = ok ? 1.0 : 0.0; }
     } else {
         // ================= everyone else: bring the system into LDS ==============================================================
         const int ndbl = nblk * (nblk + 1) / 2 * CH2_TS;        // the tiles of S (rows < D), in the order and layout of LDS

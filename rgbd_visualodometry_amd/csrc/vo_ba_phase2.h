@@ -388,13 +388,15 @@ __device__ __forceinline__ void p2_exp_mul_row(const double* d, const double* T,
 
 // trial state and its robust chi2, then (last workgroup) the LM decision of k_ba_chi_control
 #define UPC_T 512
-__global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q, int rep) {
-    BA_PROBLEM_COPY(Q)
-    if (ctl_->finished || B.D > BA_FOLD_D) return;
+// FUSED: the workgroup runs in the same launch as the Cholesky (k_ba_cholup): everything that does not depend on the solution -- the
+// point records, the first round of edges, the current poses -- is requested first, then the workgroup waits for the word the solver
+// workgroup sets behind its results (which it has written through to memory), and reads them past its own caches.
+template <bool FUSED>
+__device__ __forceinline__ void ba_upchi2_body(const BaDev& B, BaCtl* ctl_, int rep, const int bx, const int bz) {
     // 128 points per workgroup and round (4 lanes each), `rep` rounds: with several problems per launch every workgroup's fixed costs (the trial
     // poses, the partial sums and the ticket) are spread over more points -- a lone problem keeps rep = 1 and the most workgroups
     const int gp = (B.n_points + rep * (UPC_T / 4) - 1) / (rep * (UPC_T / 4));
-    if ((int)blockIdx.x >= gp) return;
+    if (bx >= gp) return;
     extern __shared__ double s_dyn[];
     double* const s_T = s_dyn;                             // trial poses [n_poses][12]
     double* const s_dp = s_dyn + 12 * (size_t)B.n_poses;   // pose increments [D]
@@ -404,11 +406,11 @@ __global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q, int rep) {
     // workgroup-uniform values that arrive through vector loads (the control block is written by this kernel's last workgroup, so the compiler
     // may not use scalar loads): moved to scalar registers by hand, or they and everything derived from them (four record / weight base pointers)
     // occupy vector registers for the whole kernel
-    const double lambda = p2_uniform(ctl_->lambda);
+    double lambda = FUSED ? 0.0 : p2_uniform(ctl_->lambda);
     const int robust = __builtin_amdgcn_readfirstlane(ctl_->robust);
-    const bool ok = __builtin_amdgcn_readfirstlane((int)(B.scal[3] != 0.0)) != 0;
+    bool ok = FUSED ? true : __builtin_amdgcn_readfirstlane((int)(B.scal[3] != 0.0)) != 0;
 #ifdef P2_STAMPS
-    long long tq_[8]; int nq_ = 0; const bool stamp_ = (blockIdx.x == 7 || blockIdx.x == gp - 1) && threadIdx.x == 0 && ctl_->it == 4 && blockIdx.z == 0;
+    long long tq_[8]; int nq_ = 0; const bool stamp_ = (bx == 7 || bx == gp - 1) && threadIdx.x == 0 && ctl_->it == 4 && bz == 0;
 #define P2_STAMP() { if (nq_ < 8) tq_[nq_++] = wall_clock64(); }
 #else
 #define P2_STAMP()
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q, int rep) {
     const double* const Wt = p2_w(B, lb);
     double* const rec_n = p2_rec(B, lb ^ 1);
     double* const Wn = p2_w(B, lb ^ 1);
-    int k = blockIdx.x * rep * (UPC_T / 4) + (threadIdx.x >> 2);
+    int k = bx * rep * (UPC_T / 4) + (threadIdx.x >> 2);
     const int sub = threadIdx.x & 3;
     bool live = false;
     double H[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0}, p[3] = {0, 0, 0}, rhs[3] = {0, 0, 0};
@@ -442,21 +444,39 @@ __global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q, int rep) {
     };
     fetch();
     double* const s_Tc = s_dp + B.D;                        // current poses [n_poses][12] (pass 1 reads them per edge)
-    for (int i = threadIdx.x; i < B.D; i += UPC_T) s_dp[i] = B.dl[i];           // the solution (k_ba_chol16, phase2 = 1)
+    if (FUSED) {
+        // the solver workgroup of this launch: its results (dl, scal[3], the control block's lambda) have been written through before the word
+        __shared__ int s_seen;
+        if (threadIdx.x == 0) {
+            const int want = ctl_->steps + 1;              // (steps: the last workgroup of the previous step's launch wrote it)
+            int seen = 0;
+            for (int i = 0; i < (1 << 21) && !seen; ++i) { seen = __hip_atomic_load(&ctl_->chol_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want; if (!seen) __builtin_amdgcn_s_sleep(2); }
+            s_seen = seen;
+        }
+        __syncthreads();
+        lambda = p2_uniform(pb_ld(&ctl_->lambda));
+        ok = s_seen != 0 && __builtin_amdgcn_readfirstlane((int)(pb_ld(B.scal + 3) != 0.0)) != 0;      // (a wait that ran out: the step counts as failed)
+        live = live && ok;
+        if (!ok) { e0 = -1; act0 = 0; q0 = q1 = 0; }
+        for (int i = threadIdx.x; i < B.D; i += UPC_T) s_dp[i] = pb_ld(B.dl + i);
+        __syncthreads();
+    } else {
+        for (int i = threadIdx.x; i < B.D; i += UPC_T) s_dp[i] = B.dl[i];       // the solution (k_ba_chol16, phase2 = 1)
+    }
     // current poses -> s_Tc; trial poses -> s_T: copies for the fixed ones (and for all of them after a failed factorisation), exp(dp) * T for the free
     // ones with three lanes per pose, a row each (one lane per pose made this prelude the kernel's register peak, on one wave in eight)
     const int n_exp = ok ? B.n_free : 0;
     for (int i = threadIdx.x; i < 12 * B.n_poses; i += UPC_T) {
         const double v = poses_c[i];
         s_Tc[i] = v;
-        if (i >= 12 * n_exp) { s_T[i] = v; if (blockIdx.x == 0) poses_t[i] = v; }
+        if (i >= 12 * n_exp) { s_T[i] = v; if (bx == 0) poses_t[i] = v; }
     }
     for (int t = threadIdx.x; t < 3 * n_exp; t += UPC_T) {
         const int j = t / 3, r = t - 3 * j;
-        const double* d = B.dl + 6 * j;
+        const double* d = FUSED ? s_dp + 6 * j : B.dl + 6 * j;
         double row[3], tr;
         p2_exp_mul_row(d, poses_c + 12 * (size_t)j, r, row, tr);
-        if (blockIdx.x == 0 && r == 0) {                   // the pose part of the gain ratio and of the step size, once
+        if (bx == 0 && r == 0) {                   // the pose part of the gain ratio and of the step size, once
             double sc = 0, mx = 0;
             for (int a = 0; a < 6; ++a) { sc += d[a] * (lambda * d[a] + B.bp[6 * j + a]); mx = fmax(mx, fabs(d[a])); }
             atomicAdd(&B.scal[2], sc);
@@ -464,12 +484,12 @@ __global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q, int rep) {
         }
         double* o = s_T + 12 * j;
         o[3 * r] = row[0]; o[3 * r + 1] = row[1]; o[3 * r + 2] = row[2]; o[9 + r] = tr;
-        if (blockIdx.x == 0) { double* g = poses_t + 12 * (size_t)j; g[3 * r] = row[0]; g[3 * r + 1] = row[1]; g[3 * r + 2] = row[2]; g[9 + r] = tr; }
+        if (bx == 0) { double* g = poses_t + 12 * (size_t)j; g[3 * r] = row[0]; g[3 * r + 1] = row[1]; g[3 * r + 2] = row[2]; g[9 + r] = tr; }
     }
     // block 0's atomics on scal[2] / scal[7] above come from lanes of several waves; the fence-free ticket at the end of this kernel has only
     // thread 0's wave drain vmcnt before it takes its ticket, and a workgroup-scope barrier does not drain it: every wave of block 0
     // drains here, so the atomics are performed before block 0 can take a ticket (k_ba_round got the same fix in ac73ae7)
-    if (blockIdx.x == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (bx == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     P2_STAMP()
     double chi = 0, sc = 0, mx = 0;
@@ -567,16 +587,16 @@ __global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q, int rep) {
         // The partials leave as write-through (sc1) stores and the ticket follows once they have been performed: no release fence -- on this
         // part a device-scope fence writes the XCD's dirty L2 lines back (this kernel has just produced megabytes of them), 1.5-5 us per
         // workgroup in the clock stamps.  The last workgroup reads the partials past its own L2 (pb_ld).
-        pb_st(B.partU + 3 * (size_t)blockIdx.x, a_);
-        pb_st(B.partU + 3 * (size_t)blockIdx.x + 1, b_);
-        pb_st(B.partU + 3 * (size_t)blockIdx.x + 2, m_);
+        pb_st(B.partU + 3 * (size_t)bx, a_);
+        pb_st(B.partU + 3 * (size_t)bx + 1, b_);
+        pb_st(B.partU + 3 * (size_t)bx + 2, m_);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         s_last = __hip_atomic_fetch_add(&ctl_->arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gp - 1;
     }
     __syncthreads();
     P2_STAMP()
 #ifdef P2_STAMPS
-    if (stamp_ && !s_last) printf("[upchi2 wg %d of %d] wall clocks (100 MHz): prelude %lld pass1 %lld pass2 %lld reduce+ticket %lld\n", (int)blockIdx.x, gp, tq_[1] - tq_[0], tq_[2] - tq_[1], tq_[3] - tq_[2], tq_[4] - tq_[3]);
+    if (stamp_ && !s_last) printf("[upchi2 wg %d of %d] wall clocks (100 MHz): prelude %lld pass1 %lld pass2 %lld reduce+ticket %lld\n", bx, gp, tq_[1] - tq_[0], tq_[2] - tq_[1], tq_[3] - tq_[2], tq_[4] - tq_[3]);
 #endif
     if (!s_last) return;
     // block 0's atomics on scal[2] / scal[7] were performed at the memory side (and before block 0 took its ticket); this workgroup's XCD may still hold
@@ -603,20 +623,22 @@ __global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q, int rep) {
         const double m7 = fmax(sc7, mB);
         const double tmp = ok ? s1 : DBL_MAX;
         const double scale = (ok ? s2 : 0.0) + 1e-3;
-        const double rho = (c->cur - tmp) / scale;
+        // (FUSED: the solver workgroup of this launch may have written cur, lambda and ni -- past this XCD's L2, which may hold the line from before)
+        const double cur = FUSED ? pb_ld(&c->cur) : c->cur, lam = FUSED ? pb_ld(&c->lambda) : c->lambda, ni = FUSED ? pb_ld(&c->ni) : c->ni;
+        const double rho = (cur - tmp) / scale;
         bool converged = false;
         int accept = 0;
         if (rho > 0 && isfinite(tmp)) {
             double a = 1.0 - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
             a = fmin(a, 2.0 / 3.0);
-            c->lambda *= fmax(1.0 / 3.0, a); c->ni = 2; c->cur = tmp;
+            c->lambda = lam * fmax(1.0 / 3.0, a); c->ni = 2; c->cur = tmp;
             c->buf ^= 1; c->need_lin = 1; accept = 1;       // trial state becomes the current state,
             c->lbuf ^= 1;                                   // the linearisation this launch wrote at it becomes the current one,
             B.scal[0] = tmp; B.scal[4] = 0;                 // and its chi2 is the trial chi2 (k_ba_chol16 takes it over as `cur`)
-        } else { c->lambda *= c->ni; c->ni *= 2; }
+        } else { c->lambda = lam * ni; c->ni = 2 * ni; }
         if (ok) converged = m7 < 1e-10;
 #ifdef P2_STAMPS
-        if (B.n_points < 1000) printf("[upchi2 ctl] stage %d it %d qmax %d ok %d cur %.12e trial %.12e rho %.3e scale %.3e m7 %.3e (pose part %.3e) lambda %.3e\n", c->stage, c->it, c->qmax, (int)ok, c->cur, tmp, rho, scale, m7, sc7, c->lambda);
+        if (B.n_points < 1000) printf("[upchi2 ctl] stage %d it %d qmax %d ok %d cur %.12e trial %.12e rho %.3e scale %.3e m7 %.3e (pose part %.3e) lambda %.3e\n", c->stage, c->it, c->qmax, (int)ok, cur, tmp, rho, scale, m7, sc7, c->lambda);
 #endif
         c->qmax += 1; c->steps += 1;
         if (!(rho < 0 && c->qmax < 10 && !converged)) {     // this LM iteration is over
@@ -633,6 +655,12 @@ __global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q, int rep) {
     }
     P2_STAMP()
 #ifdef P2_STAMPS
-    if (threadIdx.x == 0 && blockIdx.z == 0 && ctl_->it == 5) printf("[upchi2 last wg %d of %d] prelude %lld pass1 %lld pass2 %lld reduce+ticket %lld control %lld\n", (int)blockIdx.x, gp, tq_[1] - tq_[0], tq_[2] - tq_[1], tq_[3] - tq_[2], tq_[4] - tq_[3], tq_[5] - tq_[4]);
+    if (threadIdx.x == 0 && bz == 0 && ctl_->it == 5) printf("[upchi2 last wg %d of %d] prelude %lld pass1 %lld pass2 %lld reduce+ticket %lld control %lld\n", bx, gp, tq_[1] - tq_[0], tq_[2] - tq_[1], tq_[3] - tq_[2], tq_[4] - tq_[3], tq_[5] - tq_[4]);
 #endif
+}
+
+__global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q, int rep) {
+    BA_PROBLEM_COPY(Q)
+    if (ctl_->finished || B.D > BA_FOLD_D) return;
+    ba_upchi2_body<false>(B, ctl_, rep, (int)blockIdx.x, (int)blockIdx.z);
 }
