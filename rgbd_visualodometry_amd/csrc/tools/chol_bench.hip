@@ -237,7 +237,7 @@ int main() {
                 printf("        wave 0 rdy seen:      "); for (int k = 0; k < 8; ++k) printf("k%d %.0f  ", k, T(0, 80 + k)); printf("\n");
                 printf("        wave 1 W_k published: "); for (int k = 0; k < 9; ++k) printf("k%d %.0f  ", k, T(1, k)); printf("\n");
                 printf("        wave 0 inv seen:      "); for (int k = 0; k < 8; ++k) printf("k%d %.0f  ", k, T(0, 90 + k)); printf("\n");
-                for (int w : {1, 2, 3}) printf("        wave %d col_update(1, 0): enter %.0f | waited %.0f | 3 tiles %.0f | done %.0f\n", w, T(w, 100), T(w, 101), T(w, 102), T(w, 103));
+                for (int w : {4, 5}) { printf("        feeder %d: ", w); for (int k = w - 4; k < nblk; k += 2) printf("[k%d %.0f pre ..%.0f inputs ..%.0f rdy %.0f] ", k, T(w, 4 * k), T(w, 4 * k + 1), T(w, 4 * k + 2), T(w, 4 * k + 3)); printf("\n"); }
                 for (int w : {2, 3, 6, 7}) { printf("        wave %d: init %.0f ", w, T(w, 126)); for (int k = 0; k < nblk; ++k) printf("[k%d %.0f A ..%.0f D,W ..%.0f C ..%.0f] ", k, T(w, 6 * k), T(w, 6 * k + 1), T(w, 6 * k + 2), T(w, 6 * k + 3)); printf("\n"); }
             }
 #endif

@@ -1505,18 +1505,20 @@ __global__ __launch_bounds__(256) void k_ba_round(BaBatch Q) {
 
 #include "vo_ba_phase2.h"
 
-// The Cholesky and the update in ONE launch (a lone problem with a tile-major system): workgroup 0 is the solver, workgroups 1 .. are
-// k_ba_upchi2's, which request everything that does not depend on the solution and then wait for the solver's word (ctl->chol_seq).
-// Workgroup 0 is dispatched first, so the wait cannot starve it; it is bounded all the same.  A step is then TWO launches.
-__global__ __launch_bounds__(CH2_T) void k_ba_cholup(BaBatch Q) {
+// The Cholesky and the update in ONE launch (tile-major systems): workgroups 0 .. n-1 are the solvers of the launch's n problems,
+// the rest are k_ba_upchi2's (gpmax per problem, problem-major), which request everything that does not depend on the solution
+// and then wait for their solver's word (ctl->chol_seq).  Workgroups are dispatched in order and every wait is for a workgroup
+// with a lower number, so the wait cannot starve what it waits for; it is bounded all the same.  A step is then TWO launches.
+__global__ __launch_bounds__(CH2_T) void k_ba_cholup(BaBatch Q, int n, int gpmax, int rep) {
     static_assert(CH2_T == UPC_T, "one block size for both roles");
-    BA_PROBLEM_COPY(Q)
+    const int b = blockIdx.x, z = b < n ? b : (b - n) / gpmax;
+    const BaDev B_copy_ = Q.Bs[Q.slot[z]]; const BaDev& B = B_copy_; BaCtl* const ctl_ = Q.ctls + Q.slot[z];
     if (ctl_->finished) return;
-    if (blockIdx.x == 0) {
+    if (b < n) {
         extern __shared__ double s_mem[];
         ba_chol16v2_body<true>(B, ctl_, s_mem, B.dl, true);
     } else {
-        ba_upchi2_body<true>(B, ctl_, 1, (int)blockIdx.x - 1, 0);
+        ba_upchi2_body<true>(B, ctl_, rep, (b - n) % gpmax, z);
     }
 }
 
@@ -1656,8 +1658,8 @@ static int ba_engine_enqueue(BaEngine* E) {
         }
     }
     const int up_rep = nA >= 2 ? 2 : 1;                     // points per workgroup of k_ba_upchi2: 128 x up_rep (vo_ba_phase2.h; 8 problems per launch: 45.7 / 40.7 / 41.0 / 88 us for 1 / 2 / 4 / 8)
-    static const bool no_fuse = getenv("VO_BA_NO_FUSE") != nullptr;
-    const bool fuse_up = nA == 1 && nA_tiles == 1 && !no_fuse && std::max(ldsA, ldsA_up) <= 150 * 1024;
+    static const int fuse_max = getenv("VO_BA_FUSE_MAX") ? atoi(getenv("VO_BA_FUSE_MAX")) : 1;      // problems per fused launch at most (0: never -- the three-launch step). Default 1: with several problems the waiting update workgroups hold compute units other streams want (8 / 16 streams: 3540 / 4530 frames/s fused, 3740 / 4760 not)
+    const bool fuse_up = nA >= 1 && nA <= fuse_max && nA_tiles == nA && std::max(ldsA, ldsA_up) <= 150 * 1024;
     BaChunk& C = E->ring[(E->r_head + E->r_n) % 2];
     if (!C.ev_end) { HIP_TRY(hipEventCreateWithFlags(&C.ev_near, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&C.ev_end, hipEventDisableTiming)); }
     C.n = na; C.steps = chunk;
@@ -1682,10 +1684,11 @@ static int ba_engine_enqueue(BaEngine* E) {
             }
             { ProfScope ps(prof, "k_ba_schur2", st); hipLaunchKernelGGL(k_ba_schur2, dim3(gA_blk + gA_pose, 1, nA), blk, 0, st, QA); }
             // both generations in one step: every problem leaves the kernel that is not its own at once (s_tiles says which one is)
-            // a lone tile-major problem: solver and update in one launch (vo_ba_phase2.h, FUSED)
+            // tile-major problems only: solvers and updates in one launch (vo_ba_phase2.h, FUSED)
             if (fuse_up) {
                 ProfScope ps(prof, "k_ba_cholup", st);
-                hipLaunchKernelGGL(k_ba_cholup, dim3(1 + (gA_up + UPC_T / 4 - 1) / (UPC_T / 4)), dim3(CH2_T), std::max(ldsA, ldsA_up), st, QA);
+                const int gpmax = (gA_up + up_rep * (UPC_T / 4) - 1) / (up_rep * (UPC_T / 4));
+                hipLaunchKernelGGL(k_ba_cholup, dim3(nA * (1 + gpmax)), dim3(CH2_T), std::max(ldsA, ldsA_up), st, QA, nA, gpmax, up_rep);
             } else {
             if (nA_tiles) { ProfScope ps(prof, "k_ba_chol16", st); hipLaunchKernelGGL(k_ba_chol16v2, dim3(1, 1, nA), dim3(CH2_T), ldsA, st, QA); }
             if (nA_tiles < nA) { ProfScope ps(prof, "k_ba_chol16_packed", st); hipLaunchKernelGGL(k_ba_chol16, dim3(1, 1, nA), dim3(CH_THREADS), ldsA, st, QA, 0, 1); }

@@ -37,6 +37,9 @@
 // DPP chain on the wave that owns the block's rows, x_p through LDS into the rows above.
 #pragma once
 #include <type_traits>
+#ifndef CH2_EXP
+#define CH2_EXP 0                           // tools/chol_bench: timing experiments that leave work out (results are wrong); 0 in the library
+#endif
 
 #define CH2_T 512
 #define CH2_NW (CH2_T / 64)
@@ -45,6 +48,7 @@
 #define CH2_SPIN_LIMIT (1 << 21)
 #define CH2_RS 17                           // row stride of a tile (doubles)
 #define CH2_TS 272                          // tile stride (16 rows x 17)
+#define CH2_HEAD 528                        // doubles in front of the tiles: the published columns [2][16][16], 16 that take stores nobody reads
 #define CH2_MAXD 174                        // 11 row blocks of the augmented matrix: 66 tiles = 140 KiB of LDS
 
 #ifdef CH2_STAMPS
@@ -57,7 +61,7 @@ struct Ch2Flags { int prog, diag, dma, init, ok, abort_, xflag, inv; int rowdone
 __host__ __device__ inline int ch2_tix(int i, int j) { return i * (i + 1) / 2 + j; }
 __host__ __device__ inline size_t ch2_sidx(int r, int c) { return (size_t)ch2_tix(r >> 4, c >> 4) * CH2_TS + (size_t)((r & 15) * CH2_RS + (c & 15)); }
 __host__ __device__ inline size_t ch2_s_doubles(int D) { const int T = (D + 15) >> 4; return (size_t)T * (T + 1) / 2 * CH2_TS; }      // S in global memory: the row blocks of rows < D
-__host__ __device__ inline size_t ch2_lds_bytes(int D) { const int T = (D + 16) >> 4; return sizeof(double) * (512 + (size_t)T * (T + 1) / 2 * CH2_TS); }
+__host__ __device__ inline size_t ch2_lds_bytes(int D) { const int T = (D + 16) >> 4; return sizeof(double) * (CH2_HEAD + (size_t)T * (T + 1) / 2 * CH2_TS); }
 
 // the words and the published columns are read and written through explicit LDS pointers: a volatile access through a generic pointer stays a
 // flat_load / flat_store (the address-space inference leaves volatile accesses alone)
@@ -85,12 +89,15 @@ __device__ __forceinline__ void ch2_inc(int* p) { asm volatile("" ::: "memory");
 // gets L[c][J] (c > J) or 1 / L[J][J] (c == J); lanes c < J hold leftovers nobody reads
 template <int J> struct Ch2Col {
     static __device__ __forceinline__ void run(double (&a)[CH_NB], double* s_colp, int* s_prog, int progbase, int r16) {
+        // 1 / sqrt(d) = y (1 + e u), y = rsq(d), e = 1 - d y^2, u = 1/2 + 3/8 e (ba_rsqrt_parts); the column is a[J] y (1 + e u) = l0 + (l0 e) u with
+        // l0 e beside u: the dependent chain from pivot to column is bcast, rsq, d y, e, u | l0 e, l -- one operation shorter than q = e u first
         const double d = ch_bcast_v<J>(a[J]);
-        double y, q;
-        ba_rsqrt_parts(d, y, q);
+        const double y = __builtin_amdgcn_rsq(d);
         const double l0 = a[J] * y;
-        const double l = ch_fma_for_dpp(l0, q, l0);
-        const double pinv = fma(y, q, y);
+        const double e = fma(-(d * y), y, 1.0);
+        const double u = fma(e, 0.375, 0.5), l0e = l0 * e, ye = y * e;
+        const double l = ch_fma_for_dpp(l0e, u, l0);
+        const double pinv = fma(ye, u, y);
         a[J] = l;
         ChRank1<J, J + 1>::run(a, l);
         s_colp[J * CH_NB + r16] = r16 == J ? pinv : l;
@@ -118,7 +125,9 @@ template <int K> struct Ch2Fetch<K, CH_NB> { static __device__ __forceinline__ v
 template <int K> struct Ch2Stream {
     // `f` / Lk[K]: the word and column K as read one step ago (speculatively: valid iff f says so).  Column K+1 is requested before column
     // K is used, so that a wave that is behind the factorisation pays no LDS round trip per step and catches up.
-    static __device__ __forceinline__ void run(double (&x)[CH_NB], double (&Lk)[CH_NB], int f, const double* s_colp, int* s_prog, int progbase, int r16, int* abort_) {
+    // `w`: row r16 of the result's home; x[K] is final after step K and leaves at once, so that behind the
+    // last column one store remains
+    static __device__ __forceinline__ void run(double (&x)[CH_NB], double (&Lk)[CH_NB], int f, const double* s_colp, int* s_prog, int progbase, int r16, int* abort_, double* w) {
         int fn = 0;
         if (K + 1 < CH_NB) {
             fn = __builtin_amdgcn_readfirstlane(*(const volatile ch2_lds_int*)s_prog);
@@ -131,11 +140,12 @@ template <int K> struct Ch2Stream {
         double l = Lk[K];
         ch_exec_settle(l);
         x[K] = ch_mul_bcast<K>(l, x[K]);
+        w[K] = x[K];
         Ch2StreamRow<K, K + 1>::run(x, l);
-        Ch2Stream<K + 1>::run(x, Lk, fn, s_colp, s_prog, progbase, r16, abort_);
+        Ch2Stream<K + 1>::run(x, Lk, fn, s_colp, s_prog, progbase, r16, abort_, w);
     }
 };
-template <> struct Ch2Stream<CH_NB> { static __device__ __forceinline__ void run(double (&)[CH_NB], double (&)[CH_NB], int, const double*, int*, int, int, int*) {} };
+template <> struct Ch2Stream<CH_NB> { static __device__ __forceinline__ void run(double (&)[CH_NB], double (&)[CH_NB], int, const double*, int*, int, int, int*, double*) {} };
 
 // wait until arr[i] >= need for every i of the 16-bit set `mask`: ONE load per poll, lane i reads word i (an LDS round trip costs ~130
 // clocks whether it fetches one word or sixteen)
@@ -288,7 +298,7 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
     const int T = (DA + CH_NB - 1) / CH_NB;                    // row blocks of the augmented matrix
     const int iD = D >> 4, rD = D & 15;                        // where the right-hand-side row lives
     double* const s_col = s_mem;                               // [2][16][16] published columns of the block being factored (stage parity); x during the backward substitution
-    double* const s_L = s_mem + 512;                           // the tiles; the diagonal tile of a factored block holds W_k = L_kk^-T (not L_kk, which nobody needs again)
+    double* const s_L = s_mem + CH2_HEAD;                           // the tiles; the diagonal tile of a factored block holds W_k = L_kk^-T (not L_kk, which nobody needs again)
     const int o_row = CH2_RS * r16;                            // row r16 of a tile (a row per lane)
     const int o_op = CH2_RS * r16 + kq;                        // MFMA operand: row r16, columns kq + 4 q
     const int o_c = CH2_RS * kq + r16;                         // MFMA result: rows kq + 4 q, column r16
@@ -331,12 +341,12 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
         // takes what is there in one batch)
         const int f0 = __builtin_amdgcn_readfirstlane(*(const volatile ch2_lds_int*)&F.prog);
         Lk[0] = *(const volatile ch2_lds_f64*)(s_colp + r16);
-        Ch2Stream<0>::run(x, Lk, f0, s_colp, &F.prog, CH_NB * k, r16, &F.abort_);
-        if (r16 < min(CH_NB, D - CH_NB * k)) {                   // (behind a partial last block the tile's rows hold the right-hand side: not touched)
-            double* w = s_L + ch2_tix(k, k) * CH2_TS + o_row;
-#pragma unroll
-            for (int c = 0; c < CH_NB; ++c) w[c] = x[c];        // (four DPP rows hold the same sixteen rows: same values to the same addresses)
-        }
+        // Lane r16 writes row r16 of tile (k, k), whose rows wave 0 took into registers before it published the block's first column.  (Four DPP
+        // rows hold the same sixteen rows: same values to the same addresses.)  Behind a partial last block row D - 16 k of the tile is the
+        // right-hand side: that lane's stores go to the 16 doubles nobody reads; the rows below it are nobody's.
+        // (no branch: an EXEC write between the DPP operations of the chain needs wait states the compiler does not see)
+        double* const w = r16 != D - CH_NB * k ? s_L + ch2_tix(k, k) * CH2_TS + o_row : s_mem + 512;
+        Ch2Stream<0>::run(x, Lk, f0, s_colp, &F.prog, CH_NB * k, r16, &F.abort_, w);
         ch2_set(&F.inv, k + 1);
     };
     // tiles (ti[t], k) <- tile W_k, N at once, in place: 4 MFMAs each on accumulators of their own (lane l: A[l & 15][(l >> 4) + 4 q] = the
@@ -369,70 +379,81 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
         }
     };
 
-    // Backward substitution L^T x = y, three waves (0, 2, 3), wave s_w owns rows 64 s_w .. 64 s_w + 63 (a row per lane; the residual, then
-    // the solution, in `acc`).  Blocks are solved from the bottom by the wave that owns their rows: x_p = W_p r_p (every DPP row computes,
-    // only row p & 3 holds the block), x_p into LDS (a slot per block) and the word xflag; every wave with rows above block p adds
-    // -L[j0 + k][r] x[j0 + k] to them (operands requested before the wait).  No barrier; the chain crosses from one wave to the next twice.
-    auto backsub = [&](int s_w) {
-        // every row block has been solved against every block left of it (the one with the right-hand side: against all of them) and every
-        // block has been inverted: the factor is complete, its last row is y
+    // Backward substitution L^T x = y on ONE wave (wave 0), everything between two blocks in registers: no word, no hand-off.
+    // Lane (c = r16, g = kq): the residual of block p lives in DPP row p & 3 (register rr[p >> 2], lane c = entry c); x_q, once known,
+    // is copied into all four DPP rows.  Step q (from the bottom): x_q = W_q r_q (16 DPP multiply-adds, four sums; row c of W_q per
+    // lane; valid in DPP row q & 3) -> all rows (one ds_bpermute pair) -> r_p -= L(q, p)^T x_q for the blocks p < q, four at a time (DPP
+    // row g takes block 4 j + g: column c of its tile per lane, x_q by row broadcast), the four that contain block q-1 first.  Rows of a
+    // tile beyond the matrix (the right-hand-side row, what lies below it) meet x entries that are forced to zero.
+    // Measured at D = 144 (tools/chol_bench, whole kernel): three waves with a row per lane, x_p through LDS and a word per block 36.2 us;
+    // this 34.2 us; the same on the matrix cores (vectors in the MFMA's k layout, 4 loads + 4 MFMAs per tile, no lane-to-lane movement
+    // at all) 38.1 us -- a v_mfma_f64_16x16x4 holds the SIMD's double-precision pipe for 64 clocks whether or not its accumulator is
+    // free, 216 of them are 14 k clocks; without any backward substitution 29.6 us.
+    auto backsub1 = [&]() {
         ch2_wait_set(F.rowdone, 1u << iD, nblk, &F.abort_);
         for (int i = 1; i < T; ++i) if (i != iD) ch2_wait_ge(&F.rowdone[i], i, &F.abort_);
         ch2_wait_ge(&F.inv, nblk, &F.abort_);
         CH2_STAMP(61)
 #ifdef CH2_DEBUG
-        if (s_w == 0) for (int i = lane; i < T * (T + 1) / 2 * CH2_TS; i += 64) B.W[i] = s_L[i];      // the augmented factor (W_k on the diagonal), for tools/chol_bench
+        for (int i = lane; i < T * (T + 1) / 2 * CH2_TS; i += 64) B.W[i] = s_L[i];      // the augmented factor (W_k on the diagonal), for tools/chol_bench
 #endif
-        double* const s_xb = s_col;                             // x_p, 16 per block, in the (now idle) column buffer; [256 ..] takes the other DPP rows' leftovers
-        const int row = 64 * s_w + lane;
-        double acc;
-        { const int r = min(row, D - 1); acc = s_L[ch2_tix(iD, r >> 4) * CH2_TS + CH2_RS * rD + (r & 15)]; acc = row < D ? acc : 0.0; }
-        for (int p = nblk - 1; p >= 4 * s_w; --p) {
-            const int j0 = CH_NB * p, nb = min(CH_NB, D - j0), gp = p & 3;
-            const bool mine_p = (p >> 2) == s_w;
-            double Lp[CH_NB], w[CH_NB];
-            if (64 * s_w < j0) {                                // my rows, column block 4 s_w + kq: tile (p, 4 s_w + kq), clamped for the lanes at or past the block
-                const double* t = s_L + ch2_tix(p, min(4 * s_w + kq, p)) * CH2_TS + r16;
+        double* const s_xb = s_col;                             // x, for the coalesced store at the end
+        const int g = kq, c = r16;
+        double rr[3];
 #pragma unroll
-                for (int k = 0; k < CH_NB; ++k) Lp[k] = t[CH2_RS * k];
-            }
-            if (mine_p) {
-                // x_p = W_p r_p: lane i of the DPP row that holds the block keeps row i of W_p, the residuals arrive by row broadcast (16
-                // independent DPP multiply-adds on four sums -- the dependent chain of a triangular solve is gone with L_pp)
-                const double* t = s_L + ch2_tix(p, p) * CH2_TS + CH2_RS * min(r16, nb - 1);
-#pragma unroll
-                for (int j = 0; j < CH_NB; ++j) w[j] = t[j];
-                double r = acc, s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-                ch_exec_settle(r);
-                ch_fnma_bcast<0>(s0, r, w[0]); ch_fnma_bcast<1>(s1, r, w[1]); ch_fnma_bcast<2>(s2, r, w[2]); ch_fnma_bcast<3>(s3, r, w[3]);
-                ch_fnma_bcast<4>(s0, r, w[4]); ch_fnma_bcast<5>(s1, r, w[5]); ch_fnma_bcast<6>(s2, r, w[6]); ch_fnma_bcast<7>(s3, r, w[7]);
-                ch_fnma_bcast<8>(s0, r, w[8]); ch_fnma_bcast<9>(s1, r, w[9]); ch_fnma_bcast<10>(s2, r, w[10]); ch_fnma_bcast<11>(s3, r, w[11]);
-                ch_fnma_bcast<12>(s0, r, w[12]); ch_fnma_bcast<13>(s1, r, w[13]); ch_fnma_bcast<14>(s2, r, w[14]); ch_fnma_bcast<15>(s3, r, w[15]);
-                const double z = -((s0 + s1) + (s2 + s3));
-                const bool holder = kq == gp && r16 < nb;
-                s_xb[holder ? CH_NB * p + r16 : 256 + lane] = z;
-                acc = holder ? z : acc;
-                ch2_set(&F.xflag, nblk - p);
-            } else {
-                ch2_wait_ge(&F.xflag, nblk - p, &F.abort_);
-            }
-            if (64 * s_w < j0) {
-                double xk[CH_NB];
-#pragma unroll
-                for (int k = 0; k < CH_NB; ++k) { xk[k] = s_xb[CH_NB * p + min(k, nb - 1)]; xk[k] = k < nb ? xk[k] : 0.0; }
-                double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-#pragma unroll
-                for (int k = 0; k < CH_NB; k += 4) {
-                    s0 = fma(Lp[k], xk[k], s0); s1 = fma(Lp[k + 1], xk[k + 1], s1);
-                    s2 = fma(Lp[k + 2], xk[k + 2], s2); s3 = fma(Lp[k + 3], xk[k + 3], s3);
-                }
-                acc -= row < j0 ? ((s0 + s1) + (s2 + s3)) : 0.0;
-            }
+        for (int j = 0; j < 3; ++j) {                           // y: row D of the augmented factor
+            const int col = 16 * (4 * j + g) + c, cc = min(col, D - 1);
+            const double v = s_L[ch2_tix(iD, cc >> 4) * CH2_TS + CH2_RS * rD + (cc & 15)];
+            rr[j] = col < D ? v : 0.0;
         }
-        if (PUB) {
-            if (row < D) ch2_pub_d(x_out + row, acc);
-            if (s_w) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) ch2_inc(&F.diag); }      // (wave 0 counts the others in)
-        } else if (row < D) x_out[row] = acc;
+        auto load_w = [&](int q, double (&w)[CH_NB]) {          // row c of W_q (the last block may be partial: its row nb is the right-hand side, the lane's result is dropped)
+            const double* t = s_L + ch2_tix(q, q) * CH2_TS + CH2_RS * c;
+#pragma unroll
+            for (int j = 0; j < CH_NB; ++j) w[j] = t[j];
+        };
+        auto load_t = [&](int q, int j, double (&t)[CH_NB]) {   // column c of tile (q, 4 j + g), clamped to the tiles left of the diagonal (the result of a clamped lane lands in a residual nobody reads again)
+            const double* pt = s_L + ch2_tix(q, min(4 * j + g, max(q - 1, 0))) * CH2_TS + c;
+#pragma unroll
+            for (int m = 0; m < CH_NB; ++m) t[m] = pt[CH2_RS * m];
+        };
+        auto dot_bcast = [&](const double (&v)[CH_NB], double src) -> double {      // sum_m v[m] * src[lane m of the DPP row]
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            ch_exec_settle(src);
+            ch_fnma_bcast<0>(s0, src, v[0]); ch_fnma_bcast<1>(s1, src, v[1]); ch_fnma_bcast<2>(s2, src, v[2]); ch_fnma_bcast<3>(s3, src, v[3]);
+            ch_fnma_bcast<4>(s0, src, v[4]); ch_fnma_bcast<5>(s1, src, v[5]); ch_fnma_bcast<6>(s2, src, v[6]); ch_fnma_bcast<7>(s3, src, v[7]);
+            ch_fnma_bcast<8>(s0, src, v[8]); ch_fnma_bcast<9>(s1, src, v[9]); ch_fnma_bcast<10>(s2, src, v[10]); ch_fnma_bcast<11>(s3, src, v[11]);
+            ch_fnma_bcast<12>(s0, src, v[12]); ch_fnma_bcast<13>(s1, src, v[13]); ch_fnma_bcast<14>(s2, src, v[14]); ch_fnma_bcast<15>(s3, src, v[15]);
+            return -((s0 + s1) + (s2 + s3));
+        };
+        double w[CH_NB], t[CH_NB];
+        load_w(nblk - 1, w);
+        if (nblk >= 2) load_t(nblk - 1, (nblk - 2) >> 2, t);
+        auto step = [&](int q, double& rq) {
+            const int nb = min(CH_NB, D - CH_NB * q);
+            double xs = dot_bcast(w, rq);                       // valid in DPP row q & 3
+            xs = c < nb ? xs : 0.0;
+            const double xq = __shfl(xs, 16 * (q & 3) + c, 64);
+            s_xb[CH_NB * q + c] = xq;                           // (four lanes, one value)
+            if (q == 0) return;
+            const int jc = (q - 1) >> 2;
+            // the round with block q-1: its operands were requested a step ago
+            const double d = dot_bcast(t, xq);
+            if (jc == 2) rr[2] -= d; else if (jc == 1) rr[1] -= d; else rr[0] -= d;
+            // the next step's operands, then the other rounds of this one
+            load_w(q - 1, w);
+            double t2[CH_NB];
+            for (int j = jc - 1; j >= 0; --j) {
+                load_t(q, j, t2);
+                const double d2 = dot_bcast(t2, xq);
+                if (j == 1) rr[1] -= d2; else rr[0] -= d2;
+            }
+            if (q >= 2) load_t(q - 1, (q - 2) >> 2, t);
+        };
+        for (int q = nblk - 1; q >= 8; --q) step(q, rr[2]);
+        for (int q = min(nblk - 1, 7); q >= 4; --q) step(q, rr[1]);
+        for (int q = min(nblk - 1, 3); q >= 0; --q) step(q, rr[0]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int i = lane; i < D; i += 64) { const double v = s_xb[i]; if (PUB) ch2_pub_d(x_out + i, v); else x_out[i] = v; }
     };
 
     if (wave == 0) {
@@ -467,7 +488,12 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
             for (int c = 0; c < CH_NB; ++c) a[c] = (mine && c <= r16) ? a[c] : (c == r16 ? 1.0 : 0.0);
             double* const s_colp = s_col + (k & 1) * 256;
             ch_exec_settle(a[0]);
+#if CH2_EXP & 8
+            for (int c = 0; c < CH_NB; ++c) s_colp[c * CH_NB + r16] = 1.0;
+            ch2_set(&F.prog, CH_NB * k + CH_NB);
+#else
             Ch2Col<0>::run(a, s_colp, &F.prog, CH_NB * k, r16);
+#endif
             CH2_STAMP(3 * k + 2)
             const double myinv = s_colp[r16 * CH_NB + r16];
             ok = ok && ch_pivots_ok(myinv);
@@ -481,14 +507,18 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
                 // MFMAs, 12 LDS reads, 8 writes, then the 16 reads that bring the next block's rows into the row-per-lane form.  The
                 // owner of row block k+1 has both tiles ready through panel k-1 (rdy) -- normally long before.
                 CH2_STAMP(3 * k + 3)
+#if !(CH2_EXP & 4)
                 ch2_wait_ge(&F.rdy[k + 1], k, &F.abort_);
+#endif
                 CH2_STAMP(80 + (k & 7))
                 double* const px = s_L + ch2_tix(k + 1, k) * CH2_TS + o_op;
                 double* const pd = s_L + ch2_tix(k + 1, k + 1) * CH2_TS + o_c;
                 double at[4], cc[4], w[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { at[q] = px[4 * q]; cc[q] = pd[4 * CH2_RS * q]; }
+#if !(CH2_EXP & 2)
                 ch2_wait_ge(&F.inv, k + 1, &F.abort_);
+#endif
                 CH2_STAMP(3 * k + 4 >= 3 * nblk ? 99 : 90 + (k & 7))
                 const double* pw = s_L + ch2_tix(k, k) * CH2_TS + o_c;
 #pragma unroll
@@ -535,15 +565,13 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
         __builtin_amdgcn_s_setprio(0);
         // ================= backward substitution: this wave takes rows 0 .. 63 ==================================================
         CH2_STAMP(60)
-        backsub(0);
+#if !(CH2_EXP & 1)
+        backsub1();
+#endif
         CH2_STAMP(62)
         ok = ok && ch2_peek(&F.abort_) == 0;
         if (PUB) {
             if (lane == 0) { F.ok = ok ? 1 : 0; ch2_pub_d(B.scal + 3, ok ? 1.0 : 0.0); }
-            // the other waves of the backward substitution have counted themselves in behind their stores (or an abort has ended them:
-            // then the step has failed and the count may stay short -- the wait is bounded like every other)
-            const int others = (64 < D ? 1 : 0) + (128 < D ? 1 : 0);
-            if (ok) ch2_wait_ge(&F.diag, others, &F.abort_);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) ch2_pub_i(&ctl_->chol_seq, seq);
         } else if (lane == 0) { F.ok = ok ? 1 : 0; B.scal[3] = ok ? 1.0 : 0.0; }
@@ -611,61 +639,80 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
                 else ch2_tiles_mp<1>(s_L, ti, tj, p0, p1, o_op, o_c);
             };
             ch2_wait_ge(&F.init, CH2_NC, &F.abort_);
+            if (g == 0) ch2_set(&F.rdy[1], 0);                  // tiles (1, 0) and (1, 1) have no panel to wait for
             for (int k = 0; k < nblk; ++k) {
                 if (k + 1 >= T) break;                           // nothing below the last block (its right-hand-side row is wave 0's)
-                const bool own1 = k % CH2_NS == g;               // row block k+1 is mine: wave 0 takes its tiles (k+1, k) and (k+1, k+1) from me
+                const bool own1 = k % CH2_NS == g;               // row block k+1 is mine: its tiles (k+1, k) and (k+1, k+1) are finished (end of my stage k-1) and wave 0's
                 CH2_STAMP(6 * k)
                 // (A) block column k of my rows, up to date
-                if (own1) {
-                    if (k >= 1) {
-                        const double* pa = s_L + ch2_tix(k + 1, k - 1) * CH2_TS + o_op;
-                        double* pc1 = s_L + ch2_tix(k + 1, k) * CH2_TS + o_c;
-                        double* pc2 = s_L + ch2_tix(k + 1, k + 1) * CH2_TS + o_c;
-                        double a[4], b[4], c1[4], c2[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { a[q] = pa[4 * q]; c1[q] = pc1[4 * CH2_RS * q]; c2[q] = pc2[4 * CH2_RS * q]; }
-                        ch2_wait_ge(&F.rowdone[k], k, &F.abort_);
-                        const double* pb = s_L + ch2_tix(k, k - 1) * CH2_TS + o_op;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) b[q] = pb[4 * q];
-                        f64x4 u0 = {0.0, 0.0, 0.0, 0.0}, u1 = u0, v0 = u0, v1 = u0;
-                        u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], u0, 0, 0, 0); v0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], a[0], v0, 0, 0, 0);
-                        u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], u1, 0, 0, 0); v1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], a[1], v1, 0, 0, 0);
-                        u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], u0, 0, 0, 0); v0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], a[2], v0, 0, 0, 0);
-                        u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], u1, 0, 0, 0); v1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], a[3], v1, 0, 0, 0);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { pc1[4 * CH2_RS * q] = c1[q] - (u0[q] + u1[q]); pc2[4 * CH2_RS * q] = c2[q] - (v0[q] + v1[q]); }
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    ch2_set(&F.rdy[k + 1], k);
-                    if (k >= 1) rows_update(k + 1 + CH2_NS, k, 0, k - 1);      // my other row blocks of this column: all panels
-                } else if (k >= 1) {
+                if (k >= 1) {
                     ch2_wait_ge(&F.rowdone[k], k, &F.abort_);
-                    rows_update(first_row(k + 1), k, 0, k - 1);
+                    rows_update(own1 ? k + 1 + CH2_NS : first_row(k + 1), k, 0, k - 1);
                 }
                 CH2_STAMP(6 * k + 1)
                 // (D) one stage ahead, while block k is still being factored: the two tiles wave 0 will take from me at stage k+1, through panel k-1
-                if ((k + 1) % CH2_NS == g && k >= 1 && k + 2 < T) {
+                const int i0 = first_row(k + 2);
+                const bool crit = i0 == k + 2 && i0 < T;        // row block k+2 is mine: the chain wave 0 -> W_k -> L(k+2, k) -> tiles (k+2, k+1), (k+2, k+2) -> wave 0 runs through me
+                if (crit && k >= 1) {
                     ch2_wait_ge(&F.rowdone[k + 1], k, &F.abort_);
                     const int ti[3] = {k + 2, k + 2, 0}, tj[3] = {k + 1, k + 2, 0};
                     ch2_tiles_mp<2>(s_L, ti, tj, 0, k - 1, o_op, o_c);
                 }
-                // (B) W_k (wave 1's)
-                const int i0 = first_row(k + 2);
-                if (i0 < T) ch2_wait_ge(&F.inv, k + 1, &F.abort_);
-                CH2_STAMP(6 * k + 2)
-                // (C) my tiles of block column k below row block k+1: X = A W_k
-                if (i0 < T) {
-                    const int ti[3] = {i0, i0 + CH2_NS, i0 + 2 * CH2_NS};
-                    const int n = (T - 1 - i0) / CH2_NS + 1;
+                if (i0 >= T) continue;
+                int i1 = i0;                                     // first row block of the ordinary solve below
+                if (crit) {
+                    // The critical tile first and alone, as the TRANSPOSED product X^T = W_k^T A^T: the result registers are then the operand
+                    // registers of the update that follows (row r16, columns kq + 4 q) -- no trip through LDS between the two.  Then panel k
+                    // of the two tiles wave 0 is waiting for (everything of mine is in registers before the waits), then the rest.
+                    double* const px = s_L + ch2_tix(k + 2, k) * CH2_TS + o_op;
+                    double* const pc1 = s_L + ch2_tix(k + 2, k + 1) * CH2_TS + o_c;
+                    double* const pc2 = s_L + ch2_tix(k + 2, k + 2) * CH2_TS + o_c;
+                    double at[4], w[4], b[4], c1[4], c2[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { at[q] = px[4 * q]; c1[q] = pc1[4 * CH2_RS * q]; c2[q] = pc2[4 * CH2_RS * q]; }
+                    ch2_wait_ge(&F.inv, k + 1, &F.abort_);
+                    CH2_STAMP(6 * k + 2)
+                    __builtin_amdgcn_s_setprio(2);
+                    const double* pw = s_L + ch2_tix(k, k) * CH2_TS + o_c;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) w[q] = pw[4 * CH2_RS * q];
+                    f64x4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = x0;
+                    x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w[0], at[0], x0, 0, 0, 0); x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w[1], at[1], x1, 0, 0, 0);
+                    x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w[2], at[2], x0, 0, 0, 0); x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w[3], at[3], x1, 0, 0, 0);
+                    double x[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { x[q] = x0[q] + x1[q]; px[4 * q] = x[q]; }
+                    ch2_wait_ge(&F.rowdone[k + 1], k + 1, &F.abort_);      // L(k+1, k): wave 0, right behind W_k
+                    const double* pb = s_L + ch2_tix(k + 1, k) * CH2_TS + o_op;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) b[q] = pb[4 * q];
+                    f64x4 u0 = {0.0, 0.0, 0.0, 0.0}, u1 = u0, v0 = u0, v1 = u0;
+                    u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[0], b[0], u0, 0, 0, 0); v0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[0], x[0], v0, 0, 0, 0);
+                    u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[1], b[1], u1, 0, 0, 0); v1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[1], x[1], v1, 0, 0, 0);
+                    u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[2], b[2], u0, 0, 0, 0); v0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[2], x[2], v0, 0, 0, 0);
+                    u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[3], b[3], u1, 0, 0, 0); v1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[3], x[3], v1, 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { pc1[4 * CH2_RS * q] = c1[q] - (u0[q] + u1[q]); pc2[4 * CH2_RS * q] = c2[q] - (v0[q] + v1[q]); }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane == 0) { *(volatile ch2_lds_int*)&F.rdy[k + 2] = k + 1; *(volatile ch2_lds_int*)&F.rowdone[k + 2] = k + 1; }
+                    __builtin_amdgcn_s_setprio(0);
+                    i1 = i0 + CH2_NS;
+                } else {
+                    // (B) W_k (wave 1's)
+                    ch2_wait_ge(&F.inv, k + 1, &F.abort_);
+                    CH2_STAMP(6 * k + 2)
+                }
+                // (C) my other tiles of block column k: X = A W_k
+                if (i1 < T) {
+                    const int ti[3] = {i1, i1 + CH2_NS, i1 + 2 * CH2_NS};
+                    const int n = (T - 1 - i1) / CH2_NS + 1;
                     if (n == 3) solve_tiles(std::integral_constant<int, 3>{}, ti, k);
                     else if (n == 2) solve_tiles(std::integral_constant<int, 2>{}, ti, k);
                     else solve_tiles(std::integral_constant<int, 1>{}, ti, k);
-                    mark_rows(k, i0, n);
+                    mark_rows(k, i1, n);
                 }
                 CH2_STAMP(6 * k + 3)
             }
-            if ((wave == 2 || wave == 3) && 64 * (wave - 1) < D) backsub(wave - 1);      // waves 2 and 3: rows 64 .. 127 and 128 .. 191
         }
     }
 }
