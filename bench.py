@@ -289,6 +289,10 @@ def main():
         # ---- roofline of the dominant kernel -------------------------------------------------------
         # Second pass over the SAME frames (warmup + steps) on a fresh system with per-kernel HIP-event timing
         # enabled on every context stream (tracker + overlapped back-end); not part of `value`.
+        # (the local BA's solver and update share a launch in the timed run; here they are launched apart -- VO_BA_FUSE_MAX=0, read per
+        # chunk of steps -- so that HIP events bracket the solver alone: k_ba_chol16 is the same code either way)
+        fuse_env = os.environ.get("VO_BA_FUSE_MAX")
+        os.environ["VO_BA_FUSE_MAX"] = "0"
         prof_sys = system.VoSystem(system.HOST_LIB, **opts)
         h = C.c_void_p(prof_sys.context_handle())
         L.check(L.lib.vo_profile_enable(h, 1))
@@ -300,6 +304,10 @@ def main():
         L.check(L.lib.vo_profile_read(h, C.cast(names, C.c_void_p), ms.ctypes.data, calls.ctypes.data, 96, C.byref(nn)))
         L.check(L.lib.vo_profile_enable(h, 0))
         prof_sys.close()
+        if fuse_env is None:
+            os.environ.pop("VO_BA_FUSE_MAX", None)
+        else:
+            os.environ["VO_BA_FUSE_MAX"] = fuse_env
         kern = {names[j].value.decode(): (float(ms[j]), int(calls[j])) for j in range(nn.value)}
         tf = max(1, pst["tracked_frames"])
         A, M, Kc, I = (pst[k] / tf for k in ("sum_active", "sum_candidates", "sum_matches", "sum_ransac_inliers"))
@@ -320,16 +328,17 @@ def main():
             table["k_pose_lm"]["f64_valu_frac"] = round(fl / (table["k_pose_lm"]["total_ms"] * 1e-3) / (F64_PEAK_TFLOPS * 1e12), 6)
             table["k_pose_lm"]["limiter"] = "latency: one workgroup per frame runs ~20 dependent f64 passes (edge loop, 28-value reduction, 6x6 solve)"
         runs = max(1, pst["ba_runs"])
-        ck = next((k for k in ("k_ba_chol16", "k_ba_chol16g", "k_ba_chol") if k in table), None)
+        ck = next((k for k in ("k_ba_chol16v2", "k_ba_chol16", "k_ba_chol16g", "k_ba_chol") if k in table), None)      # v2: tile-major systems (D <= 174), the bench's case
         if ck:                                              # (D^3/3 + 2 D^2) multiply-adds per factorisation + solve, D = 6 free poses, averaged over the BA runs
             D = (pst["ba_sum_d3"] / runs) ** (1.0 / 3.0)
             flops = 2.0 * (pst["ba_sum_d3"] / runs / 3.0 + 2.0 * pst["ba_sum_d2"] / runs) * table[ck]["launches"]
             table[ck]["alg_flops_per_launch"] = int(flops / table[ck]["launches"])
             table[ck]["TFLOPps"] = round(flops / (table[ck]["total_ms"] * 1e-3) / 1e12, 5)
-            table[ck]["limiter"] = "latency: one workgroup, panel-by-panel dependent chain (D = %d)" % int(D)
+            table[ck]["limiter"] = ("latency: one workgroup; the chain block factorisation -> its inverse -> panel solve -> trailing update runs through four waves, "
+                                    "every f64 MFMA holds its SIMD's double-precision pipe for 64 clocks (D = %d)" % int(D))
         roof = None
         if table:
-            dom = max(table, key=lambda k: table[k]["total_ms"])
+            dom = ck or max(table, key=lambda k: table[k]["total_ms"])      # the kernel VERDICT.md names (it is also the one with the largest total)
             t = table[dom]
             if "GBps" in t:
                 roof = {"bound": "hbm", "kernel": dom, "achieved": t["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -342,7 +351,7 @@ def main():
             # HBM traffic per launch from this round's PMC passes (rocprofv3 cannot run inside this process): only a file of
             # the current round that covers this kernel is used, otherwise null
             try:
-                pmc_file = next(f for f in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+                pmc_file = next(f for f in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
                 pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
                 pk = pmc["kernels"]
                 for name, row in table.items():             # measured fabric traffic per launch beside the algorithmic bytes, where a PMC row exists
@@ -352,7 +361,7 @@ def main():
                         row["pmc_GBps"] = round(m["hbm_bytes_per_launch_corrected"] / (row["avg_us"] * 1e-6) / 1e9, 1)
                 roof["traffic"] = pk[dom]["hbm_bytes_per_launch_corrected"]
                 roof["traffic_source"] = "profiles/%s (FETCH_SIZE, WRITE_SIZE: separate --pmc passes of `%s`)" % (pmc_file, pmc.get("command", "bench.py"))
-                cmp_file = os.path.join(ROOT, "profiles", "r03_pmc_compute.json")      # SQ counters of the latency-bound kernels (separate --pmc passes)
+                cmp_file = next((os.path.join(ROOT, "profiles", f) for f in ("r04_pmc_compute.json", "r03_pmc_compute.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "")      # SQ counters of the latency-bound kernels (separate --pmc passes)
                 if os.path.exists(cmp_file):
                     cc = json.load(open(cmp_file)).get("kernels", {})
                     for name, row in table.items():

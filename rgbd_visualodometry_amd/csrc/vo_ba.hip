@@ -1658,7 +1658,11 @@ static int ba_engine_enqueue(BaEngine* E) {
         }
     }
     const int up_rep = nA >= 2 ? 2 : 1;                     // points per workgroup of k_ba_upchi2: 128 x up_rep (vo_ba_phase2.h; 8 problems per launch: 45.7 / 40.7 / 41.0 / 88 us for 1 / 2 / 4 / 8)
-    static const int fuse_max = getenv("VO_BA_FUSE_MAX") ? atoi(getenv("VO_BA_FUSE_MAX")) : 1;      // problems per fused launch at most (0: never -- the three-launch step). Default 1: with several problems the waiting update workgroups hold compute units other streams want (8 / 16 streams: 3540 / 4530 frames/s fused, 3740 / 4760 not)
+    // problems per fused launch at most (VO_BA_FUSE_MAX; 0: never -- the three-launch step; read per chunk, so that bench.py's per-kernel
+    // timing pass can take the solver's launch apart).  Default 1: with several problems the waiting update workgroups hold compute
+    // units other streams want (8 / 16 streams: 3540 / 4530 frames/s fused, 3740 / 4760 not)
+    const char* const fm_env = getenv("VO_BA_FUSE_MAX");
+    const int fuse_max = fm_env ? atoi(fm_env) : 1;
     const bool fuse_up = nA >= 1 && nA <= fuse_max && nA_tiles == nA && std::max(ldsA, ldsA_up) <= 150 * 1024;
     BaChunk& C = E->ring[(E->r_head + E->r_n) % 2];
     if (!C.ev_end) { HIP_TRY(hipEventCreateWithFlags(&C.ev_near, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&C.ev_end, hipEventDisableTiming)); }
@@ -1690,8 +1694,8 @@ static int ba_engine_enqueue(BaEngine* E) {
                 const int gpmax = (gA_up + up_rep * (UPC_T / 4) - 1) / (up_rep * (UPC_T / 4));
                 hipLaunchKernelGGL(k_ba_cholup, dim3(nA * (1 + gpmax)), dim3(CH2_T), std::max(ldsA, ldsA_up), st, QA, nA, gpmax, up_rep);
             } else {
-            if (nA_tiles) { ProfScope ps(prof, "k_ba_chol16", st); hipLaunchKernelGGL(k_ba_chol16v2, dim3(1, 1, nA), dim3(CH2_T), ldsA, st, QA); }
-            if (nA_tiles < nA) { ProfScope ps(prof, "k_ba_chol16_packed", st); hipLaunchKernelGGL(k_ba_chol16, dim3(1, 1, nA), dim3(CH_THREADS), ldsA, st, QA, 0, 1); }
+            if (nA_tiles) { ProfScope ps(prof, "k_ba_chol16v2", st); hipLaunchKernelGGL(k_ba_chol16v2, dim3(1, 1, nA), dim3(CH2_T), ldsA, st, QA); }
+            if (nA_tiles < nA) { ProfScope ps(prof, "k_ba_chol16", st); hipLaunchKernelGGL(k_ba_chol16, dim3(1, 1, nA), dim3(CH_THREADS), ldsA, st, QA, 0, 1); }
             { ProfScope ps(prof, "k_ba_upchi2", st); hipLaunchKernelGGL(k_ba_upchi2, dim3((gA_up + up_rep * (UPC_T / 4) - 1) / (up_rep * (UPC_T / 4)), 1, nA), dim3(UPC_T), ldsA_up, st, QA, up_rep); }
             }
         }

@@ -681,6 +681,7 @@ static int ensure_match_stage(vo_ctx* c, int n) {
 int vo_match_active_map(vo_ctx* c, int slot, const double T[12], float ratio, float floor_dist, vo_match* out, int cap,
                         int* n_out, int* n_cand, int* min_distance) {
     if (!c || slot < 0 || slot >= c->p.max_frames || !T || cap < 0) return VO_E_INVALID;
+    if (c->async_pending) return VO_E_STATE;                  // a chain started by vo_track_batch_begin owns the lane buffers and the pinned mirrors until vo_track_batch_end
     if (!c->slot_orb[slot]) return VO_E_STATE;
     HIP_TRY(hipSetDevice(c->device));
     int rc = upload_pose(c, 1, T, true);
@@ -705,6 +706,7 @@ int vo_match_active_map(vo_ctx* c, int slot, const double T[12], float ratio, fl
 
 int vo_matches_set(vo_ctx* c, const float* xyz, const float* uv, int n) {
     if (!c || n < 0 || (n && (!xyz || !uv))) return VO_E_INVALID;
+    if (c->async_pending) return VO_E_STATE;                  // a chain started by vo_track_batch_begin owns the lane buffers and the pinned mirrors until vo_track_batch_end
     HIP_TRY(hipSetDevice(c->device));
     return vo_corr_from_host(c, xyz, uv, n);
 }
@@ -712,6 +714,7 @@ int vo_matches_set(vo_ctx* c, const float* xyz, const float* uv, int n) {
 int vo_pnp_ransac(vo_ctx* c, int n_hyp, float reproj_px, float conf, uint64_t seed, double T[12], int32_t* inl, int cap,
                   int* n_inl, int32_t* hyp_counts, int* iters_used, int* best_hyp) {
     if (!c || !T || n_hyp < 1 || n_hyp > c->p.max_hypotheses || cap < 0) return VO_E_INVALID;
+    if (c->async_pending) return VO_E_STATE;                  // a chain started by vo_track_batch_begin owns the lane buffers and the pinned mirrors until vo_track_batch_end
     HIP_TRY(hipSetDevice(c->device));
     // keep n_match of the current correspondence set; only the pose is replaced
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -742,6 +745,7 @@ int vo_pnp_ransac(vo_ctx* c, int n_hyp, float reproj_px, float conf, uint64_t se
 int vo_pose_refine_lm(vo_ctx* c, double T[12], double delta, double cut, int it_r, int it_p, uint8_t* mask, int cap,
                       int* n_edges, int* lm_iters) {
     if (!c || !T || cap < 0) return VO_E_INVALID;
+    if (c->async_pending) return VO_E_STATE;                  // a chain started by vo_track_batch_begin owns the lane buffers and the pinned mirrors until vo_track_batch_end
     HIP_TRY(hipSetDevice(c->device));
     int rc = download_track(c);
     if (rc) return rc;
@@ -861,6 +865,8 @@ static int chain_collect(hipStream_t st, LaunchSet& ls, std::vector<GroupReq*>& 
             for (int k = 0; k < 7; ++k) o.reserved[k] = (int32_t)(t.dbg[k == 6 ? 7 : k] >> ((k == 2 || k == 3) ? 0 : 4));
             o.n_lm_inliers = (int32_t)(t.dbg[6] >> 4);
 #endif
+            // a pose-LM hand-off that ran out (k_pose_lm, lm_xchg) leaves this lane's counters behind: cleared before the next chain reads them
+            if (t.status == VO_E_DEVICE && c->d_lm_x) HIP_TRY(hipMemsetAsync(c->d_lm_x + (size_t)i * VO_LM_X_DOUBLES, 0, sizeof(double) * VO_LM_X_DOUBLES, st));
             if (t.n_match > r->cap && r->matches) o.status = VO_E_OVERFLOW;
             if (r->matches) memcpy(r->matches + (size_t)i * r->cap, c->h_matches + (size_t)i * first, sizeof(vo_match) * std::min(first, t.n_match));
         }
@@ -1124,6 +1130,7 @@ int vo_set_hypothesis_shard_stream(vo_ctx* c, int rank, int world, vo_stream_all
 
 int vo_group_join(vo_group* g, vo_ctx* c) {
     if (!g || !c || c->group || c->shard_world > 1 || c->device != g->device || c->lanes > g->max_lanes) return VO_E_INVALID;
+    if (c->async_pending) return VO_E_STATE;                  // its own chain is still in flight (vo_track_batch_begin)
     std::unique_lock<std::mutex> lk(g->mu);
     c->group = g; ++g->members;
     return VO_OK;

@@ -820,9 +820,10 @@ __device__ __forceinline__ bool chol6_dev(double* A, double* b) {
 // most one episode ahead of the slowest one.  Every spin is bounded (a timeout marks the lane's result and lets everybody go on).
 #define LM_KMAX 8
 #define LM_X_DOUBLES (32 + 2 * LM_KMAX * 32)       // per lane: [counter line | exit line] (256 B) + 2 x LM_KMAX x 32 partial sums
-struct LmX { unsigned* cnt; unsigned* exit_cnt; double* part; int nwg, wg; unsigned epi; int* status; int* s_flag; };
+struct LmX { unsigned* cnt; unsigned* exit_cnt; double* part; int nwg, wg; unsigned epi; int* status; int* s_flag; bool dead; };      // dead: a hand-off has run out (sticky: the launch's remaining ones are skipped, its result carries VO_E_DEVICE)
 __device__ __forceinline__ void lm_xchg(LmX& X, double* tot, int nv) {      // tot: LDS, [0, nv) valid in this workgroup -> sums over the lane's workgroups
     const int par = X.epi & 1;
+    if (X.dead) { ++X.epi; return; }                  // (workgroup-uniform: every thread read the same s_flag)
     if ((int)threadIdx.x < nv) __hip_atomic_store(X.part + (size_t)(par * LM_KMAX + X.wg) * 32 + threadIdx.x, tot[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -842,6 +843,7 @@ __device__ __forceinline__ void lm_xchg(LmX& X, double* tot, int nv) {      // t
         *X.s_flag = ok;
     }
     __syncthreads();
+    if (!*X.s_flag) { X.dead = true; return; }        // the sums stay this workgroup's own; no further hand-off waits 0.2 s again
     if ((int)threadIdx.x < nv) {
         double sum = 0;
         for (int w = 0; w < X.nwg; ++w) sum += __hip_atomic_load(X.part + (size_t)(par * LM_KMAX + w) * 32 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1044,7 +1046,7 @@ __global__ __launch_bounds__(LM_T) void k_pose_lm(const LaneDesc* __restrict__ l
     LmX X_; LmX* X = nullptr;
     if (nwg > 1) {
         unsigned* cw = reinterpret_cast<unsigned*>(ld_.lm_x);
-        X_.cnt = cw; X_.exit_cnt = cw + 32; X_.part = ld_.lm_x + 32; X_.nwg = nwg; X_.wg = wg; X_.epi = 0; X_.status = &tr->status; X_.s_flag = &s_xflag;
+        X_.cnt = cw; X_.exit_cnt = cw + 32; X_.part = ld_.lm_x + 32; X_.nwg = nwg; X_.wg = wg; X_.epi = 0; X_.status = &tr->status; X_.s_flag = &s_xflag; X_.dead = false;
         X = &X_;
     }
     const int32_t* edges = inliers + lo;

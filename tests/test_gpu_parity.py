@@ -205,7 +205,9 @@ def test_config5_sizes_orb_and_tracking_match_oracle(libs):
 # 216 (> limit: matrix in L2); 1300 points -> > 20000 edges (threaded pair-list build); shuffle: edges not sorted by point
 @pytest.mark.parametrize("nP,nX,nfree,shuffle", [(6, 400, 4, False), (18, 300, 16, False), (34, 500, 30, False), (34, 300, 32, True),
                                                   (40, 500, 36, False), (34, 1300, 30, False), (26, 9000, 21, False)])      # last: config-5 scale, ~160 k edges
-def test_local_ba_matches_oracle(libs, nP, nX, nfree, shuffle):
+@pytest.mark.parametrize("fuse", ["1", "0"])                 # 1: Cholesky + update in one launch (k_ba_cholup, the default), 0: launched apart (k_ba_chol16v2, k_ba_upchi2)
+def test_local_ba_matches_oracle(libs, nP, nX, nfree, shuffle, fuse, monkeypatch):
+    monkeypatch.setenv("VO_BA_FUSE_MAX", fuse)             # (read per chunk of steps: csrc/vo_ba.hip, ba_engine_enqueue)
     rng = np.random.default_rng(5)
 
     def expso3(w):
