@@ -334,6 +334,11 @@ int vo_ba_resident_graph(vo_ctx* ctx, vo_ctx* tables, const int32_t* free_kf, in
                          int32_t* n_points, int32_t* point_slots, int cap_points, int32_t* n_edges, int32_t* edge_pose, int32_t* edge_point,
                          float* edge_uv, int64_t* edge_obs, int cap_edges);
 
+/* Diagnostic: how much of the tables the last vo_local_ba_resident_cut / vo_ba_resident_graph of `ctx` visited -- observations from
+ * the first one of the oldest point a free keyframe observes, map slots from that point's slot.  Both depend on the cut's window, not on
+ * how long the run has been (the reference's Backend walks only the covisible keyframes' observation maps: src/backend.cpp:36-120). */
+int vo_ba_resident_window(vo_ctx* ctx, int64_t* observations_visited, int64_t* map_slots_visited);
+
 /* ---- plumbing ------------------------------------------------------------------------- */
 int vo_sync(vo_ctx* ctx);
 /* Per-kernel accumulated device time measured with HIP events on the context's stream

@@ -19,6 +19,7 @@ using namespace orc;
 
 struct vo_ctx {
     vo_params p;
+    long long win_obs = -1, win_slots = -1;                 // vo_ba_resident_window: this restatement walks the whole tables
     OrbPlan plan;
     Cam cam;
     struct Slot {
@@ -406,11 +407,18 @@ int cut_graph(vo_ctx* t, const int32_t* free_kf, int n_free, ResidentGraph& g) {
     return VO_OK;
 }
 }  // namespace
+int vo_ba_resident_window(vo_ctx* c, int64_t* observations_visited, int64_t* map_slots_visited) {
+    if (!c || !observations_visited || !map_slots_visited) return VO_E_INVALID;
+    if (c->win_obs < 0) return VO_E_STATE;
+    *observations_visited = c->win_obs; *map_slots_visited = c->win_slots;
+    return VO_OK;
+}
 int vo_ba_resident_graph(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int n_free, int32_t* n_poses, int32_t* pose_kf, int cap_poses, int32_t* n_points,
                          int32_t* point_slots, int cap_points, int32_t* n_edges, int32_t* edge_pose, int32_t* edge_point, float* edge_uv, int64_t* edge_obs, int cap_edges) {
     if (!c || !t || n_free < 0 || (n_free && !free_kf) || !n_poses || !n_points || !n_edges) return VO_E_INVALID;
     ResidentGraph g;
     int rc = cut_graph(t, free_kf, n_free, g);
+    if (rc == VO_OK) { c->win_obs = (long long)t->obs_kf.size(); c->win_slots = t->p.map_capacity; }
     if (rc) return rc;
     *n_poses = (int)g.pose_kf.size(); *n_points = (int)g.point_slots.size(); *n_edges = (int)g.edge_pose.size();
     for (int i = 0; i < *n_poses && i < cap_poses; ++i) if (pose_kf) pose_kf[i] = g.pose_kf[i];
@@ -427,6 +435,7 @@ int vo_local_ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int n
     if (!c || !t || n_free < 0 || (n_free && !free_kf)) return VO_E_INVALID;
     ResidentGraph g;
     int rc = cut_graph(t, free_kf, n_free, g);
+    if (rc == VO_OK) { c->win_obs = (long long)t->obs_kf.size(); c->win_slots = t->p.map_capacity; }
     if (rc) return rc;
     auto& P = c->pend;
     P.pose_kf = g.pose_kf; P.point_slots = g.point_slots; P.edge_pose = g.edge_pose; P.edge_point = g.edge_point; P.edge_uv = g.edge_uv; P.edge_obs = g.edge_obs;

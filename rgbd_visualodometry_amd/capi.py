@@ -71,7 +71,7 @@ SYMBOLS = ["vo_ctx_create", "vo_ctx_destroy", "vo_strerror", "vo_backend_name", 
            "vo_local_ba", "vo_sync", "vo_profile_enable", "vo_profile_read",
            "vo_group_create", "vo_group_destroy", "vo_group_join", "vo_group_leave", "vo_group_set_gather", "vo_group_stats",
            "vo_set_hypothesis_shard", "vo_set_hypothesis_shard_stream", "vo_triangulate_batch", "vo_kf_set_pose", "vo_obs_append", "vo_obs_kill", "vo_local_ba_resident",
-           "vo_local_ba_resident_cut", "vo_local_ba_resident_solve", "vo_local_ba_resident_merge", "vo_local_ba_resident_fetch", "vo_ba_resident_graph"]
+           "vo_local_ba_resident_cut", "vo_local_ba_resident_solve", "vo_local_ba_resident_merge", "vo_local_ba_resident_fetch", "vo_ba_resident_graph", "vo_ba_resident_window"]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int32), C.c_int)     # vo_exchange_fn: in-place element-wise sum over the ranks
@@ -430,6 +430,12 @@ class VoContext:
     def obs_kill(self, ids):
         a = np.ascontiguousarray(ids, dtype=np.int64)
         self.L.check(self.L.lib.vo_obs_kill(self.h, _ptr(a), len(a)), "vo_obs_kill")
+
+    def resident_window(self):
+        """(observations, map slots) the last resident graph cut of this context visited."""
+        a, b = C.c_int64(), C.c_int64()
+        self.L.check(self.L.lib.vo_ba_resident_window(self.h, C.byref(a), C.byref(b)), "vo_ba_resident_window")
+        return a.value, b.value
 
     def resident_graph(self, tables: "VoContext", free_kf, cap=1 << 18):
         f = np.ascontiguousarray(free_kf, dtype=np.int32)

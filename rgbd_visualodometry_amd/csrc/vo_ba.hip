@@ -2122,14 +2122,19 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
 // them and an event hands the finished arrays to the engine's stream.
 // Point order = ascending map slot, fixed poses = ascending keyframe number: deterministic, and the same as oracle/o_capi.cpp.
 // =====================================================================================================================
+// obs_lo / map_lo: where the tables are entered.  Both tables only grow (observations are appended, map slots are handed out in ascending
+// order), so everything a cut can touch lies behind two bounds the host keeps per keyframe (vo_obs_append, vo_ctx::kf_reach): the first
+// observation of the oldest point a free keyframe observes -- every observation of every point in the graph sits behind it -- and that
+// point's slot.  The slot-indexed scratch arrays (pt_flag, pidx) are indexed by slot - map_lo.  A cut costs what its window holds, not
+// what the run has accumulated.
 struct CutTabs { const int32_t* obs_kf; const int32_t* obs_mp; const float* obs_uv; const uint8_t* alive; long long n_obs;
-                 const uint8_t* map_flags; const double* map_pos; const double* kf_pose; int n_kf, map_hi; };
+                 const uint8_t* map_flags; const double* map_pos; const double* kf_pose; int n_kf, map_hi; long long obs_lo; int map_lo; };
 
 __global__ void k_cut_points(CutTabs T, const int* __restrict__ kf_idx, int* __restrict__ pt_flag) {
-    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long o = T.obs_lo + (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= T.n_obs || !T.alive[o]) return;
     const int k = T.obs_kf[o], m = T.obs_mp[o];
-    if (k < T.n_kf && m < T.map_hi && kf_idx[k] >= 0 && !(T.map_flags[m] & VO_MAP_FLAG_OUTLIER)) pt_flag[m] = 1;      // idempotent
+    if (k < T.n_kf && m >= T.map_lo && m < T.map_hi && kf_idx[k] >= 0 && !(T.map_flags[m] & VO_MAP_FLAG_OUTLIER)) pt_flag[m - T.map_lo] = 1;      // idempotent
 }
 // three-pass exclusive scan of n int32 (n <= 16 Mi): a workgroup covers SCAN_TILE = 1024 lanes x 16 consecutive elements; block sums,
 // scan of the (<= 1024) sums, per-block scan + offset; total -> *total_out
@@ -2193,11 +2198,11 @@ __global__ __launch_bounds__(1024) void k_scan_final(const int* __restrict__ in,
 }
 __global__ void k_cut_count(CutTabs T, const int* __restrict__ kf_idx, const int* __restrict__ pt_flag, const int* __restrict__ pidx,
                             int* __restrict__ cnt, int* __restrict__ fixed_flag) {
-    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long o = T.obs_lo + (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= T.n_obs || !T.alive[o]) return;
     const int k = T.obs_kf[o], m = T.obs_mp[o];
-    if (k >= T.n_kf || m >= T.map_hi || !pt_flag[m]) return;
-    atomicAdd(&cnt[pidx[m]], 1);
+    if (k >= T.n_kf || m < T.map_lo || m >= T.map_hi || !pt_flag[m - T.map_lo]) return;
+    atomicAdd(&cnt[pidx[m - T.map_lo]], 1);
     if (kf_idx[k] < 0) fixed_flag[k] = 1;
 }
 struct CutFree { int n; int kf[64]; };
@@ -2233,12 +2238,12 @@ __global__ __launch_bounds__(1024) void k_cut_fixed_scan(int n_kf, int n_free, c
 // observation -> its slot in its point's edge range (arrival order; k_cut_emit sorts), and map slot -> dense point list
 __global__ void k_cut_fill(CutTabs T, const int* __restrict__ pt_flag, const int* __restrict__ pidx, const int* __restrict__ pt_start,
                            int* __restrict__ fill, long long* __restrict__ e_obs, int* __restrict__ point_slots) {
-    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (o < T.map_hi && pt_flag[o]) point_slots[pidx[o]] = (int)o;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, o = T.obs_lo + i;
+    if (i < T.map_hi - T.map_lo && pt_flag[i]) point_slots[pidx[i]] = T.map_lo + (int)i;
     if (o >= T.n_obs || !T.alive[o]) return;
     const int k = T.obs_kf[o], m = T.obs_mp[o];
-    if (k >= T.n_kf || m >= T.map_hi || !pt_flag[m]) return;
-    const int p = pidx[m];
+    if (k >= T.n_kf || m < T.map_lo || m >= T.map_hi || !pt_flag[m - T.map_lo]) return;
+    const int p = pidx[m - T.map_lo];
     e_obs[pt_start[p] + atomicAdd(&fill[p], 1)] = o;
 }
 // edge-parallel: slot i of its point's segment holds some observation (arrival order); its place among the point's edges is its
@@ -2252,7 +2257,7 @@ __global__ void k_cut_emit(CutTabs T, int np, int nx, int ne, const int* __restr
     if (i < nx * 3) ptsA[i] = T.map_pos[3 * (size_t)point_slots[i / 3] + i % 3];
     if (i >= ne) return;
     const long long o = e_arr[i];
-    const int ko = T.obs_kf[o], p = pidx[T.obs_mp[o]];
+    const int ko = T.obs_kf[o], p = pidx[T.obs_mp[o] - T.map_lo];
     const int a = pt_start[p], b = pt_start[p + 1];
     int rank = 0;
     for (int j = a; j < b; ++j) rank += T.obs_kf[e_arr[j]] < ko;
@@ -2332,6 +2337,7 @@ __global__ void k_culled_list(int ne, const uint8_t* __restrict__ flags, const l
 
 struct BaResident {
     bool ready = false;
+    long long win_obs = -1, win_slots = -1;                 // what the last cut visited (vo_ba_resident_window)
     int np = 0, nf = 0, nx = 0, ne = 0, n_fixed = 0, nblk_launch = 0, npairs = 0;
     BaDev B;
     int32_t* d_point_slots = nullptr; int* d_pose_kf = nullptr; long long* d_e_obs = nullptr; int* d_ncull = nullptr; long long* d_cull = nullptr; int cull_cap = 0;
@@ -2386,8 +2392,16 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     if (!c->resident) c->resident = new BaResident();
     BaResident& R = *c->resident;
     R.ready = false; R.solved = false;
-    const int nkf = t->n_kf, mh = std::max(t->map_hi, 1), D = 6 * nf;
+    const int nkf = t->n_kf, D = 6 * nf;
     const long long no = t->n_obs;
+    // the window of this cut (see CutTabs): entered behind the oldest point any free keyframe observes
+    long long obs_lo = no; int map_lo = std::max(t->map_hi, 1) - 1;
+    for (int i = 0; i < nf; ++i)
+        if (free_kf[i] >= 0 && free_kf[i] < (int)t->kf_reach.size() && t->kf_reach[free_kf[i]].obs_lo >= 0) {
+            obs_lo = std::min(obs_lo, (long long)t->kf_reach[free_kf[i]].obs_lo); map_lo = std::min(map_lo, (int)t->kf_reach[free_kf[i]].slot_lo);
+        }
+    obs_lo &= ~63ll; map_lo = std::max(0, map_lo) & ~63;      // (aligned: the scans read int4s)
+    const int mh = std::max(t->map_hi, 1) - map_lo;          // slots the cut can see
     if (mh >= 16 * 1024 * 1024 || nkf > 1024 * 1024) return VO_E_UNSUPPORTED;         // scan_i32's range
     if ((CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D) * sizeof(double) > 158 * 1024 || nf > 64) return VO_E_UNSUPPORTED;
     CutFree F; F.n = nf;
@@ -2416,10 +2430,11 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     int* h = (int*)vo_stage(c, 4096);
     if (!h) return VO_E_NOMEM;
     HIP_TRY(hipStreamSynchronize(st));
-    CutTabs T{t->d_obs_kf, t->d_obs_mp, t->d_obs_uv, t->d_obs_alive, no, t->d_map_flags, t->d_map_pos, t->d_kf_pose, nkf, mh};
+    CutTabs T{t->d_obs_kf, t->d_obs_mp, t->d_obs_uv, t->d_obs_alive, no, t->d_map_flags, t->d_map_pos, t->d_kf_pose, nkf, map_lo + mh, obs_lo, map_lo};
+    R.win_obs = no - obs_lo; R.win_slots = mh;
     HIP_TRY(hipMemsetAsync(cb, 0, zero_end, st));
     hipLaunchKernelGGL(k_cut_init, dim3((std::max(nkf, nf) + 255) / 256), dim3(256), 0, st, nkf, F, kf_idx, pose_kf);
-    const int gO = (int)((no + 255) / 256);
+    const int gO = (int)((no - obs_lo + 255) / 256);
     if (gO) hipLaunchKernelGGL(k_cut_points, dim3(gO), dim3(256), 0, st, T, kf_idx, pt_flag);
     int rc = scan_i32(st, pt_flag, mh, bsum, pidx, tot);                        // dense point index, nx
     if (rc) return rc;
@@ -2457,7 +2472,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     int32_t* e_pose = (int32_t*)(base + o_epose); int32_t* e_pt = (int32_t*)(base + o_ept); float* e_uv = (float*)(base + o_euv);
     long long* e_obs = (long long*)(base + o_eobs);
     long long* e_arr = (long long*)(base + o_earr);
-    hipLaunchKernelGGL(k_cut_fill, dim3((int)((std::max<long long>(no, mh) + 255) / 256)), dim3(256), 0, st, T, pt_flag, pidx, pt_start, fill, e_arr, point_slots);
+    hipLaunchKernelGGL(k_cut_fill, dim3((int)((std::max<long long>(no - obs_lo, mh) + 255) / 256)), dim3(256), 0, st, T, pt_flag, pidx, pt_start, fill, e_arr, point_slots);
     hipLaunchKernelGGL(k_cut_emit, dim3((std::max(ne, std::max(np * 12, nx * 3)) + 255) / 256), dim3(256), 0, st, T, np, nx, ne, pidx, pt_start, kf_idx, pose_kf, point_slots,
                        (const long long*)e_arr, e_obs, e_pose, e_pt, e_uv, (int32_t*)(base + o_pe), base + o_act, base + o_flags, (double*)(base + o_poses),
                        (double*)(base + o_poses_n), (double*)(base + o_pts));
@@ -2645,6 +2660,13 @@ extern "C" int vo_local_ba_resident(vo_ctx* c, vo_ctx* t, const int32_t* free_kf
     int rc = vo_local_ba_resident_cut(c, t, free_kf, n_free, huber_delta, chi2_th, nullptr, nullptr, nullptr);
     if (rc) return rc;
     return vo_local_ba_resident_solve(c, it_robust, it_plain, out);
+}
+
+extern "C" int vo_ba_resident_window(vo_ctx* c, int64_t* observations_visited, int64_t* map_slots_visited) {
+    if (!c || !observations_visited || !map_slots_visited) return VO_E_INVALID;
+    if (!c->resident || c->resident->win_obs < 0) return VO_E_STATE;
+    *observations_visited = c->resident->win_obs; *map_slots_visited = c->resident->win_slots;
+    return VO_OK;
 }
 
 extern "C" int vo_ba_resident_graph(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int n_free, int32_t* n_poses, int32_t* pose_kf, int cap_poses, int32_t* n_points,

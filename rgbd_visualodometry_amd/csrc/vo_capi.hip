@@ -1071,6 +1071,16 @@ int vo_obs_append(vo_ctx* c, const int32_t* kf, const int32_t* mp, const float* 
                        c->d_obs_kf + at, c->d_obs_mp + at, reinterpret_cast<float2*>(c->d_obs_uv + 2 * at), c->d_obs_alive + at);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));               // a back-end thread may read the table from its own stream next
+    // where this keyframe's points begin in the tables (the resident graph cut starts there: vo_ba.hip, CutTabs)
+    if (c->pt_first.size() < (size_t)c->p.map_capacity) c->pt_first.resize((size_t)c->p.map_capacity, -1);
+    if (c->kf_reach.size() < (size_t)c->kf_cap) c->kf_reach.resize((size_t)c->kf_cap);
+    for (int i = 0; i < n; ++i) {
+        long long& pf = c->pt_first[mp[i]];
+        if (pf < 0) pf = (long long)at + i;
+        vo_ctx::KfReach& r = c->kf_reach[kf[i]];
+        if (r.obs_lo < 0) { r.obs_lo = pf; r.slot_lo = mp[i]; }
+        else { r.obs_lo = std::min(r.obs_lo, pf); r.slot_lo = std::min(r.slot_lo, mp[i]); }
+    }
     c->n_obs += n;
     return VO_OK;
 }

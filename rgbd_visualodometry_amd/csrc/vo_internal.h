@@ -131,6 +131,10 @@ struct vo_ctx {
     // thread may be reading them while the tracker appends: no reallocation, appends only write beyond what a reader was given)
     int32_t* d_obs_kf = nullptr; int32_t* d_obs_mp = nullptr; float* d_obs_uv = nullptr; uint8_t* d_obs_alive = nullptr;
     long long n_obs = 0, obs_cap = 0;
+    // what a keyframe's points reach back to (host bookkeeping of vo_obs_append; the resident graph cut enters the tables there): pt_first[slot] = table position of the
+    // point's first observation (-1: none yet); kf_reach[kf] = minimum of that, and of the slot, over the points the keyframe observes
+    struct KfReach { long long obs_lo = -1; int slot_lo = 0; };
+    std::vector<long long> pt_first; std::vector<KfReach> kf_reach;
     double* d_kf_pose = nullptr; int n_kf = 0, kf_cap = 0;
     int map_hi = 0;                                         // highest map slot ever upserted + 1
     void* d_cut = nullptr; size_t d_cut_bytes = 0;          // scratch of the resident graph cut

@@ -336,6 +336,65 @@ def test_resident_graph_cut_follows_backend_cpp(libs, shape):
     c.close(); t.close()
 
 
+@pytest.mark.parametrize("libs", LIBS)
+def test_resident_graph_cut_enters_the_tables_at_its_window(libs):
+    """A long run behind the window: 600 old keyframes with 150 k observations of 40 k old points that no recent keyframe sees, then the
+    scene of the other tests on top (keyframe numbers and map slots continue).  The graph is the window's own -- and the cut visits the
+    window, not the run (vo_ba_resident_window; the CPU restatement walks everything and says so)."""
+    L = capi.load(libs[0])
+    rng = np.random.default_rng(23)
+    n_old_kf, n_old_pts, per_kf = 600, 40000, 250
+    p = L.default_params(n_features=64, map_capacity=65536)
+    t = L.context(p)
+    import ref_model as rm
+    # the old part of the run
+    old_slots = np.arange(n_old_pts, dtype=np.int32)
+    t.map_upsert(old_slots, rng.uniform(-1, 1, (n_old_pts, 3)) + [0, 0, 5], np.tile([0, 0, 1.0], (n_old_pts, 1)), np.zeros((n_old_pts, 32), np.uint8), np.zeros(n_old_pts, np.uint8))
+    n_kf, n_pts, n_free = 12, 500, 4
+    Ts = [rm.se3_exp(np.concatenate([rng.normal(0, 0.25, 3), rng.normal(0, 0.05, 3)])) for _ in range(n_old_kf + n_kf)]
+    t.kf_set_pose(np.arange(n_old_kf + n_kf), np.array(Ts))
+    n_old_obs = 0
+    for k in range(n_old_kf):
+        seen = (np.arange(per_kf) * 37 + k * 61) % n_old_pts
+        t.obs_append(np.full(per_kf, k), old_slots[seen], rng.uniform(0, 600, (per_kf, 2)))
+        n_old_obs += per_kf
+    # the window: new points in the slots behind the old ones, seen by the last n_kf keyframes only
+    X = rng.uniform(-1.5, 1.5, (n_pts, 3)) + [0.5, 0, 5]
+    slots = (n_old_pts + rng.permutation(2000)[:n_pts]).astype(np.int32)
+    flags = (rng.random(n_pts) < 0.04).astype(np.uint8)
+    t.map_upsert(slots, X, np.tile([0, 0, 1.0], (n_pts, 1)), np.zeros((n_pts, 32), np.uint8), flags)
+    obs, idx = [], np.arange(n_pts)
+    for k in range(n_old_kf, n_old_kf + n_kf):
+        seen = idx[(idx * 7 + k * 31) % 100 < 45 + 5 * (k % 3)]
+        R, tt = Ts[k][:9].reshape(3, 3), Ts[k][9:]
+        pc = X[seen] @ R.T + tt
+        uv = np.stack([p.fx * pc[:, 0] / pc[:, 2] + p.cx, p.fy * pc[:, 1] / pc[:, 2] + p.cy], 1)
+        first = t.obs_append(np.full(len(seen), k), slots[seen], uv)
+        obs += [(first + j, k, int(slots[i])) for j, i in enumerate(seen)]
+    free = [n_old_kf + n_kf - 1 - 2 * i for i in range(n_free)]
+    c = L.context(L.default_params(n_features=64, map_capacity=64))
+    g = c.resident_graph(t, free)
+    outl = {int(s) for s, f in zip(slots, flags) if f}
+    fs = set(free)
+    pts = sorted({o[2] for o in obs if o[1] in fs and o[2] not in outl})
+    pidx = {s: i for i, s in enumerate(pts)}
+    edges = sorted([o for o in obs if o[2] in pidx], key=lambda o: (pidx[o[2]], o[1]))
+    fixed = sorted({o[1] for o in edges} - fs)
+    assert list(g["point_slots"]) == pts and len(pts) > 100 and list(g["pose_kf"]) == free + fixed and len(fixed) >= 2
+    assert list(g["edge_obs"]) == [o[0] for o in edges]
+    w_obs, w_slots = c.resident_window()
+    if libs[0] == capi.HIP_LIB:
+        assert w_obs <= len(obs) + 64 and w_slots <= 2000 + 64, (w_obs, w_slots, n_old_obs)      # the window, rounded to the scans' alignment
+    else:
+        assert w_obs == n_old_obs + len(obs)
+    # an old keyframe set free reaches back into the old part: the same rule, a larger window
+    g2 = c.resident_graph(t, [5, free[0]])
+    assert 5 in list(g2["pose_kf"]) and min(g2["point_slots"]) < n_old_pts
+    if libs[0] == capi.HIP_LIB:
+        assert c.resident_window()[0] > n_old_obs // 2
+    c.close(); t.close()
+
+
 def t_positions(L, t, slots):
     """Positions the scene put into the map (the test keeps its own copy: the C-ABI has no map read-back)."""
     return t._scene_positions[[list(t._scene_slots).index(s) for s in slots]] if hasattr(t, "_scene_positions") else None
