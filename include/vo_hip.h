@@ -297,7 +297,7 @@ int vo_local_ba(vo_ctx* ctx, const vo_ba_problem* in, vo_ba_result* out);
  * so a back-end thread can solve beside the tracker.  The device tables are NOT modified: the caller merges (vo_map_upsert,
  * vo_kf_set_pose, vo_obs_kill) at the moment it chooses.
  * Limits and threading: the tables hold 32 Mi observations and 64 Ki keyframes, the map may use slots below 16 Mi (VO_E_OVERFLOW / VO_E_INVALID beyond: the caller goes
- * back to vo_local_ba with a graph of its own); a cut takes at most 64 free keyframes, each listed once.  The tables belong to the
+ * back to vo_local_ba with a graph of its own); a cut takes at most VO_BA_RESIDENT_MAX_FREE free keyframes (the host back-end's own cap), each listed once.  The tables belong to the
  * tracker's thread; a back-end thread may run _cut on them from its own context as long as the tracker appends nothing, changes no
  * flag or position of the map and kills no observation between the call and its return (host/src/backend.cpp: WaitGraphCut). */
 int vo_kf_set_pose(vo_ctx* ctx, const int32_t* kf, const double* T_cw, int n);
@@ -313,6 +313,7 @@ typedef struct vo_ba_resident_result {
     double chi2_initial, chi2_final;
     int32_t lm_iters, reserved;
 } vo_ba_resident_result;
+#define VO_BA_RESIDENT_MAX_FREE 160
 int vo_local_ba_resident(vo_ctx* ctx, vo_ctx* tables, const int32_t* free_kf, int n_free, double huber_delta, double chi2_th,
                          int it_robust, int it_plain, vo_ba_resident_result* out);
 /* The same in two steps, for a back-end thread that solves beside the tracker: _cut returns as soon as the problem's arrays

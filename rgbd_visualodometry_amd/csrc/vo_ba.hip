@@ -467,24 +467,29 @@ __global__ __launch_bounds__(256) void k_ba_pairs(BaPairPlan Q) {
     if (!FILL && threadIdx.x == 0) Q.cnt[blockIdx.x] = run;
 }
 
-// one workgroup: offsets of the blocks' lists, the table of <= BA_SLICE-pair slices, totals
+// one workgroup: offsets of the blocks' lists, the table of <= BA_SLICE-pair slices, totals.  A thread takes a run of consecutive blocks
+// (nb = nf (nf + 1) / 2 <= 12880 for the 160 free poses a cut may have: 13 per thread), the runs' sums are scanned over the workgroup.
 __global__ __launch_bounds__(1024) void k_ba_pairs_scan(BaPairPlan Q, int nb) {
-    __shared__ int s_c[2112], s_s[2112];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < nb; i += 1024) { const int c = Q.cnt[i]; s_c[i] = c; s_s[i] = (c + BA_SLICE - 1) / BA_SLICE; }
+    __shared__ int s_wa[16], s_wb[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (nb + 1023) / 1024, i0 = min(nb, tid * per), i1 = min(nb, i0 + per);
+    int a = 0, b = 0;
+    for (int i = i0; i < i1; ++i) { const int c = Q.cnt[i]; a += c; b += (c + BA_SLICE - 1) / BA_SLICE; }
+    int ia = a, ib = b;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int ta = __shfl_up(ia, o, 64), tb = __shfl_up(ib, o, 64); if (lane >= o) { ia += ta; ib += tb; } }
+    if (lane == 63) { s_wa[wave] = ia; s_wb[wave] = ib; }
     __syncthreads();
-    if (tid == 0) {                                  // nb <= 2080 entries: a serial scan is a few microseconds
-        int a = 0, b = 0;
-        for (int i = 0; i < nb; ++i) { const int c = s_c[i], sl = s_s[i]; s_c[i] = a; s_s[i] = b; a += c; b += sl; }
-        *Q.n_pairs = a; *Q.n_slices = b;
-    }
-    __syncthreads();
-    for (int i = tid; i < nb; i += 1024) {
-        const int c = Q.cnt[i], o = s_c[i];
-        Q.off[i] = o;
+    int oa = ia - a, ob = ib - b, ta = 0, tb = 0;
+    for (int w = 0; w < 16; ++w) { if (w < wave) { oa += s_wa[w]; ob += s_wb[w]; } ta += s_wa[w]; tb += s_wb[w]; }
+    if (tid == 0) { *Q.n_pairs = ta; *Q.n_slices = tb; }
+    for (int i = i0; i < i1; ++i) {
+        const int c = Q.cnt[i];
+        Q.off[i] = oa;
         int j1, j2;
         ba_block_of(i, Q.nf, j1, j2);
-        for (int k = 0, sl = s_s[i]; k < c; k += BA_SLICE, ++sl) Q.blocks[sl] = BaBlock{j1, j2, o + k, min(BA_SLICE, c - k)};
+        for (int k = 0, sl = ob; k < c; k += BA_SLICE, ++sl) Q.blocks[sl] = BaBlock{j1, j2, oa + k, min(BA_SLICE, c - k)};
+        oa += c; ob += (c + BA_SLICE - 1) / BA_SLICE;
     }
 }
 
@@ -1914,7 +1919,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     const double tp1 = tnow();
     // Device-built pair lists (k_ba_pairs) need the edges sorted by point (the per-pose lists are then sorted by point
     // and a block's list is a sorted intersection) and the longest per-pose list in LDS; otherwise the host builds them.
-    bool dev_pairs = nf <= 64 && sorted_by_point;
+    bool dev_pairs = nf <= 64 && sorted_by_point;                 // (beyond: the host builds the pair lists -- the resident cut builds them on the device up to its 160)
     int max_len = 0;
     for (int j = 0; j < nf; ++j) max_len = std::max(max_len, ps_start[j + 1] - ps_start[j]);
     if (max_len > PAIR_LDS_CAP) dev_pairs = false;
@@ -2205,7 +2210,7 @@ __global__ void k_cut_count(CutTabs T, const int* __restrict__ kf_idx, const int
     atomicAdd(&cnt[pidx[m - T.map_lo]], 1);
     if (kf_idx[k] < 0) fixed_flag[k] = 1;
 }
-struct CutFree { int n; int kf[64]; };
+struct CutFree { int n; int kf[VO_BA_RESIDENT_MAX_FREE]; };       // by value: 644 bytes of kernel arguments
 // keyframe -> pose index: the free keyframes take 0 .. n-1 in the caller's order, everything else -1 until k_cut_fixed_scan
 __global__ void k_cut_init(int n_kf, CutFree F, int* __restrict__ kf_idx, int* __restrict__ pose_kf) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2279,7 +2284,7 @@ __device__ __forceinline__ int ps_wave_rank(int bin, int nf, int lane, int* __re
     return rank;
 }
 __global__ __launch_bounds__(PS_CHUNK) void k_ps_hist(int ne, int nf, const int32_t* __restrict__ e_pose, int* __restrict__ hist /* [chunks][nf] */) {
-    __shared__ int s_cnt[PS_CHUNK / 64][64];
+    __shared__ int s_cnt[PS_CHUNK / 64][VO_BA_RESIDENT_MAX_FREE];
     const int e = blockIdx.x * PS_CHUNK + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = e < ne ? e_pose[e] : nf;
     (void)ps_wave_rank(q < nf ? q : -1, nf, lane, s_cnt[wave]);
@@ -2308,22 +2313,26 @@ __global__ __launch_bounds__(256) void k_ps_offsets(int chunks, int nf, const in
 }
 __global__ __launch_bounds__(PS_CHUNK) void k_ps_fill(int ne, int nf, const int32_t* __restrict__ e_pose, const int32_t* __restrict__ e_pt, const int* __restrict__ offs,
                                                       const int* __restrict__ total, int* __restrict__ ps_start, int32_t* __restrict__ ps_edges, int32_t* __restrict__ ps_pt) {
-    __shared__ int s_cnt[PS_CHUNK / 64][64];
-    __shared__ int s_base[65];
+    __shared__ int s_cnt[PS_CHUNK / 64][VO_BA_RESIDENT_MAX_FREE];
+    __shared__ int s_base[VO_BA_RESIDENT_MAX_FREE + 1];
     const int e = blockIdx.x * PS_CHUNK + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (wave == 0) {                                        // start of each pose's list: exclusive scan of the totals (nf <= 64)
-        const int v = lane < nf ? total[lane] : 0;
-        int inc = v;
+    if (wave == 0) {                                        // start of each pose's list: exclusive scan of the totals, 64 at a time
+        int run = 0;
+        for (int j0 = 0; j0 < nf; j0 += 64) {
+            const int v = j0 + lane < nf ? total[j0 + lane] : 0;
+            int inc = v;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
-        s_base[lane] = inc - v;
-        if (lane == 63) s_base[64] = inc;
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+            if (j0 + lane < nf) s_base[j0 + lane] = run + inc - v;
+            run += __shfl(inc, 63, 64);
+        }
+        if (lane == 0) s_base[nf] = run;
     }
     const int q = e < ne ? e_pose[e] : nf;
     const int bin = q < nf ? q : -1;
     const int rank = ps_wave_rank(bin, nf, lane, s_cnt[wave]);
     __syncthreads();
-    if (blockIdx.x == 0 && (int)threadIdx.x <= nf) ps_start[threadIdx.x] = threadIdx.x < (unsigned)nf ? s_base[threadIdx.x] : s_base[64];
+    if (blockIdx.x == 0 && (int)threadIdx.x <= nf) ps_start[threadIdx.x] = s_base[threadIdx.x];
     if (bin < 0) return;
     int before = 0;
     for (int w = 0; w < wave; ++w) before += s_cnt[w][bin];
@@ -2403,7 +2412,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     obs_lo &= ~63ll; map_lo = std::max(0, map_lo) & ~63;      // (aligned: the scans read int4s)
     const int mh = std::max(t->map_hi, 1) - map_lo;          // slots the cut can see
     if (mh >= 16 * 1024 * 1024 || nkf > 1024 * 1024) return VO_E_UNSUPPORTED;         // scan_i32's range
-    if ((CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D) * sizeof(double) > 158 * 1024 || nf > 64) return VO_E_UNSUPPORTED;
+    if ((CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D) * sizeof(double) > 158 * 1024 || nf > VO_BA_RESIDENT_MAX_FREE) return VO_E_UNSUPPORTED;
     CutFree F; F.n = nf;
     for (int i = 0; i < nf; ++i) {
         if (free_kf[i] < 0 || free_kf[i] >= nkf) return VO_E_INVALID;
@@ -2415,7 +2424,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     size_t co = 0;
     auto cc = [&](size_t bytes) { size_t o = co; co += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_ffl = cc(4 * (size_t)nkf), o_pfl = cc(4 * (size_t)mh), o_cnt = cc(4 * (size_t)(mh + 1)), o_fil = cc(4 * (size_t)mh), zero_end = co;
-    const size_t o_kfi = cc(4 * (size_t)nkf), o_pkf = cc(4 * (size_t)(nkf + 64)), o_pid = cc(4 * (size_t)mh), o_pst = cc(4 * (size_t)(mh + 1)), o_psl = cc(4 * (size_t)mh),
+    const size_t o_kfi = cc(4 * (size_t)nkf), o_pkf = cc(4 * (size_t)(nkf + VO_BA_RESIDENT_MAX_FREE)), o_pid = cc(4 * (size_t)mh), o_pst = cc(4 * (size_t)(mh + 1)), o_psl = cc(4 * (size_t)mh),
                  o_bs = cc(4096), o_tot = cc(64);
     if (co > c->d_cut_bytes) {
         if (c->d_cut) { (void)hipStreamSynchronize(st); (void)hipFree(c->d_cut); }
@@ -2458,7 +2467,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     const size_t o_poses_n = carve(96 * (size_t)np), o_pts_n = carve(24 * (size_t)nx), o_act = carve(ne), o_flags = carve(ne);
     const int chunks = (ne + PS_CHUNK - 1) / PS_CHUNK;
     const size_t o_eobs = carve(8 * (size_t)ne), o_earr = carve(8 * (size_t)ne), o_ncull = carve(64), o_cull = carve(8 * (size_t)ne);
-    const size_t o_hist = carve(4 * (size_t)chunks * nf), o_offs = carve(4 * (size_t)chunks * nf), o_ptot = carve(4 * 64);
+    const size_t o_hist = carve(4 * (size_t)chunks * nf), o_offs = carve(4 * (size_t)chunks * nf), o_ptot = carve(4 * VO_BA_RESIDENT_MAX_FREE);
     const size_t o_pcnt = carve(4 * (size_t)std::max(nb_all, 1)), o_poff = carve(4 * (size_t)std::max(nb_all, 1)), o_pn = carve(16);
     const size_t o_Hpp = carve(288 * (size_t)nf), o_bp = carve(8 * (size_t)D), o_Hll = carve(72 * (size_t)nx), o_bl = carve(24 * (size_t)nx), o_scal = carve(64);
     const size_t o_partU = carve(24 * ((size_t)(nx + 63) / 64 + 1)), o_partC = carve(8 * ((size_t)(ne + 255) / 256 + 1));

@@ -146,12 +146,12 @@ void Backend::OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr, bo
     if (job_) Finish(true);                          // the previous result is merged before a new graph is cut (its host-side copy follows below, beside the new solve)
     std::unique_ptr<Job> j(new Job);
     j->frameIndex = frameIndex_;
-    // The device pair-list builder takes <= 64 free poses.  The first keyframe with more covisible keyframes than that hands the graph
-    // cut back to the host for the rest of the run (cap maxFree_ = 160) -- the same transition as a full observation table -- instead of
-    // silently solving a smaller problem than the host cut would.
-    if (deviceGraph_ && keyframeCurr->kfIndex_ >= 0 && (int)keyframeCurr->GetCovisibleKeyframes().size() + 1 > std::min(maxFree_, 64)) {
-        std::fprintf(stderr, "[myslam_amd] local BA: %zu covisible keyframes exceed the device graph cut's 64 free poses: the host graph cut takes over\n",
-                     keyframeCurr->GetCovisibleKeyframes().size());
+    // The device graph cut takes VO_BA_RESIDENT_MAX_FREE free poses (include/vo_hip.h; the same number as maxFree_'s default).  A keyframe with
+    // more covisible keyframes than that hands the graph cut back to the host for the rest of the run -- the same transition as a full
+    // observation table -- instead of silently solving a smaller problem than the host cut would.
+    if (deviceGraph_ && keyframeCurr->kfIndex_ >= 0 && (int)keyframeCurr->GetCovisibleKeyframes().size() + 1 > std::min(maxFree_, VO_BA_RESIDENT_MAX_FREE)) {
+        std::fprintf(stderr, "[myslam_amd] local BA: %zu covisible keyframes exceed the device graph cut's %d free poses: the host graph cut takes over\n",
+                     keyframeCurr->GetCovisibleKeyframes().size(), VO_BA_RESIDENT_MAX_FREE);
         deviceGraph_ = false;
     }
     if (deviceGraph_ && keyframeCurr->kfIndex_ >= 0) {      // only the free keyframes' numbers go to the device; no host graph cut

@@ -282,7 +282,7 @@ def _resident_scene(L, rng, n_kf=9, n_pts=400, n_free=4, young=False, seen_mod=1
 
 
 @pytest.mark.parametrize("libs", LIBS)
-@pytest.mark.parametrize("shape", ["window", "young", "wide", "long"])
+@pytest.mark.parametrize("shape", ["window", "young", "wide", "wider", "long"])
 def test_resident_graph_cut_follows_backend_cpp(libs, shape):
     """the graph cut on the device-resident observation table (reference src/backend.cpp:36-135) against the
     definition: points = non-outlier points a free keyframe observes, edges = all live observations of those points, fixed
@@ -291,12 +291,14 @@ def test_resident_graph_cut_follows_backend_cpp(libs, shape):
     rng = np.random.default_rng(17)
     young = shape == "young"
     # young: the first local BA of a run -- every slot of the map is in the graph, every keyframe is free (no fixed pose);
-    # wide: the 64 free keyframes the cut allows, several 1024-edge chunks;  long: more keyframes than one scan block, most of them
+    # wide / wider: 64 and 150 free keyframes (the cut takes VO_BA_RESIDENT_MAX_FREE = 160), several 1024-edge chunks;  long: more keyframes than one scan block, most of them
     # without a shared point (the table of a long run)
     if young:
         sc = _resident_scene(L, rng, n_kf=2, n_pts=300, n_free=2, young=True)
     elif shape == "wide":
         sc = _resident_scene(L, rng, n_kf=140, n_pts=900, n_free=64)
+    elif shape == "wider":                                  # 150 free keyframes: beyond one wave's scan of the per-pose lists, D = 900 (the host back-end's cap is 160)
+        sc = _resident_scene(L, rng, n_kf=320, n_pts=700, n_free=150)
     elif shape == "long":
         sc = _resident_scene(L, rng, n_kf=1300, n_pts=600, n_free=5, seen_mod=700, slot_range=60000)     # map slots over several scan tiles
     else:
@@ -315,7 +317,7 @@ def test_resident_graph_cut_follows_backend_cpp(libs, shape):
     assert list(g["pose_kf"]) == free + fixed and len(fixed) >= (0 if young else 2)
     if young:
         assert len(pts) == 300 and max(pts) == 299 and not fixed
-    if shape == "wide":
+    if shape in ("wide", "wider"):
         assert len(edges) > 4096
     pose_of = {k: i for i, k in enumerate(free + fixed)}
     assert list(g["edge_obs"]) == [o[0] for o in edges]
@@ -324,7 +326,7 @@ def test_resident_graph_cut_follows_backend_cpp(libs, shape):
     # solving the cut = solving the same problem handed over explicitly (vo_local_ba)
     poses = np.array([Ts[k] for k in g["pose_kf"]])
     pos_now = {int(s): x for s, x in zip(slots, np.array(t_positions(L, t, slots)))}
-    po, sl, pt, cu, r = c.local_ba_resident(t, free)
+    po, sl, pt, cu, r = c.local_ba_resident(t, free, cap_culled=1 << 18)
     P0 = np.array([pos_now[s] for s in sl])
     pw, xw, fw, rw = c.local_ba(poses, len(free), P0, g["edge_pose"], g["edge_point"], g["edge_uv"])
     assert np.array_equal(sl, g["point_slots"]) and r.n_fixed == len(fixed) and r.n_edges == len(edges)
