@@ -168,6 +168,8 @@ def drive(sysm, stamps, bptr, dptr, i0, i1, lookahead, W, est=None, on_device=Tr
             nxt = [(i + n + j) % nt for j in range(min(lookahead, nt))]
             if i + n >= i1 and i1 < nt:
                 nxt = nxt[:min(lookahead, nt - i1)]         # (the following drive() call starts at i1 with a batch of this size)
+            elif i + n >= nt:
+                nxt = nxt[:n]                               # behind the last frame: as many copies as this batch consumed
             sysm.preload([bptr[q] for q in nxt], [dptr[q] for q in nxt], 3 * W, 2 * W)
         for j in range(n):
             ok, T = sysm.add_prefetched()
@@ -234,14 +236,16 @@ def main():
     sp = syn.params(seed=shard.stream_seed(args.seed, rank), speed=args.speed)
     threads = max(1, (os.cpu_count() or 8) // max(1, world))
     t0 = time.time()
-    bgr, depth, Twc, stamps = syn.render(sp, 0, total, threads=min(32, threads))
+    # the several-streams figure always runs frames prologue+16 .. prologue+135 (steady-state maps), whatever --steps says: a short run renders those too
+    n_render = max(total, args.prologue + 136) if (args.multi_streams and world == 1) else total
+    bgr, depth, Twc, stamps = syn.render(sp, 0, n_render, threads=min(32, threads))
     t_render = time.time() - t0
     d_bgr = torch.from_numpy(bgr).cuda(local_rank)          # inputs resident in HBM
     d_depth = torch.from_numpy(depth.view(np.int16)).cuda(local_rank)
     torch.cuda.synchronize()
     fb, fd = W * H * 3, W * H * 2
-    bptr = [d_bgr.data_ptr() + i * fb for i in range(total)]
-    dptr = [d_depth.data_ptr() + i * fd for i in range(total)]
+    bptr = [d_bgr.data_ptr() + i * fb for i in range(n_render)]
+    dptr = [d_depth.data_ptr() + i * fd for i in range(n_render)]
 
     opts = dict(width=W, height=H, number_of_features=N, max_frames_in_flight=args.lookahead, device=local_rank,
                 enable_local_optimization=0 if args.no_ba else 1, backend_lag_frames=args.ba_lag, track_batch=args.track_batch, map_capacity=1 << 20, ransac_iterations=args.hyps, ba_device_graph=0 if args.host_graph else 1, map_descriptors_on_device=1, chi2_th=args.chi2_th)
@@ -445,7 +449,7 @@ def main():
         multi = None
         if args.multi_streams and world == 1:
             multi = []
-            nfr, nwarm = min(total, args.prologue + 136), min(total, args.prologue + 136) - 120     # 120 timed frames per stream after the prologue
+            nfr, nwarm = min(n_render, args.prologue + 136), min(n_render, args.prologue + 136) - 120     # 120 timed frames per stream after the prologue
 
             def run_streams(S, grouped):
                 grp_ = system.StreamGroup(system.HOST_LIB, local_rank, 128) if grouped else None
