@@ -259,19 +259,25 @@ __global__ __launch_bounds__(256) void k_match_mfma(const LaneDesc* __restrict__
                                   b2 = *reinterpret_cast<const mmf_v4i*>(row + 128), b3 = *reinterpret_cast<const mmf_v4i*>(row + 192);
                     const uint32_t kpi = (uint32_t)(t0 + 16 * sub + r16);
                     const bool kvalid = !PARTIAL || (int)kpi < nkp;
+                    // the four operand sets' accumulators advance side by side: a dependent MFMA waits for the whole pass of its predecessor
+                    mmf_v4i acc[MMF_NA];
 #pragma unroll
-                    for (int a = 0; a < MMF_NA; ++a) {
-                        mmf_v4i acc = {256, 256, 256, 256};
-                        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[a][0], b0, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[a][1], b1, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[a][2], b2, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[a][3], b3, acc, 0, 0, 0);
+                    for (int a = 0; a < MMF_NA; ++a) acc[a] = mmf_v4i{256, 256, 256, 256};
+#pragma unroll
+                    for (int a = 0; a < MMF_NA; ++a) acc[a] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[a][0], b0, acc[a], 0, 0, 0);
+#pragma unroll
+                    for (int a = 0; a < MMF_NA; ++a) acc[a] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[a][1], b1, acc[a], 0, 0, 0);
+#pragma unroll
+                    for (int a = 0; a < MMF_NA; ++a) acc[a] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[a][2], b2, acc[a], 0, 0, 0);
+#pragma unroll
+                    for (int a = 0; a < MMF_NA; ++a) acc[a] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[a][3], b3, acc[a], 0, 0, 0);
+#pragma unroll
+                    for (int a = 0; a < MMF_NA; ++a)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {       // acc = 2 h: key = (h << 22) | kp = (acc << 21) + kp (one v_lshl_add_u32)
-                            const uint32_t key = (((uint32_t)acc[q]) << 21) + kpi;
+                            const uint32_t key = (((uint32_t)acc[a][q]) << 21) + kpi;
                             best_k[a][q] = min(best_k[a][q], PARTIAL ? (kvalid ? key : MATCH_NONE) : key);
                         }
-                    }
                 }
             };
             if (t0 + MT > nkp) tile(std::true_type{}); else tile(std::false_type{});

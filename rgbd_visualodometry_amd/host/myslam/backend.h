@@ -42,7 +42,7 @@ public:
     // frame index at which the pending job will be merged (SIZE_MAX: none pending)
     int Lag() const { return lag_; }
     size_t NextMergeFrame() const { return job_ ? job_->frameIndex + (size_t)lag_ : (size_t)-1; }
-    struct Stats { int runs = 0, poses = 0, fixed = 0, points = 0, edges = 0, outliers = 0, failed = 0, capped = 0; double ms = 0, ms_build = 0, ms_solve = 0, ms_wait = 0;
+    struct Stats { int runs = 0, poses = 0, fixed = 0, points = 0, edges = 0, outliers = 0, failed = 0, capped = 0; double ms = 0, ms_build = 0, ms_solve = 0, ms_wait = 0, ms_wake = 0, ms_to_merge = 0; int waited = 0;
                    double sum_d3 = 0, sum_d2 = 0; long long sum_edges = 0; };
     const Stats& GetStats() const { return stats_; }
     // the flattened graph of a keyframe, for inspection (parity tests): what Solve would be handed
@@ -54,7 +54,7 @@ private:
         std::vector<Mappoint*> points;                          // plain pointers stay valid for the job's lifetime
         std::vector<int32_t> edgePose, edgePoint; std::vector<float> edgeUv;
         std::vector<double> poses, pts, posesOut, ptsOut; std::vector<uint8_t> flags;
-        size_t frameIndex = 0; int rc = 0; double solveMs = 0; bool done = false;
+        size_t frameIndex = 0; int rc = 0; double solveMs = 0; bool done = false; std::chrono::steady_clock::time_point tDone;
         // device-resident graph: only the free keyframes' numbers go down, the cut happens on the device
         bool resident = false, cutDone = false; std::vector<int32_t> freeKf, pointSlots; std::vector<int64_t> culled; int nPoints = 0, nFixed = 0, nEdges = 0, nCulled = 0;
     };

@@ -68,6 +68,7 @@ void Backend::WorkerLoop() {
             if (j->rc == VO_OK) SolveResident(*j, ctxOwn_);
             j->solveMs = ms_since(t0);
         } else Solve(*j, ctxOwn_);
+        j->tDone = std::chrono::steady_clock::now();
         lk.lock();
         j->done = true;
         cv_.notify_all();
@@ -82,8 +83,11 @@ bool Backend::Poll(size_t frameIndex) {
 
 void Backend::Finish(bool deferTail) {
     auto t0 = std::chrono::steady_clock::now();
-    if (lag_ > 0) { std::unique_lock<std::mutex> lk(mu_); cv_.wait(lk, [&] { return job_->done; }); }
+    bool waited = false;
+    if (lag_ > 0) { std::unique_lock<std::mutex> lk(mu_); waited = !job_->done; cv_.wait(lk, [&] { return job_->done; }); }
     stats_.ms_wait += ms_since(t0);
+    const auto tWake = std::chrono::steady_clock::now();
+    if (waited) { stats_.ms_wake += std::chrono::duration<double, std::milli>(tWake - job_->tDone).count(); ++stats_.waited; }
     std::unique_ptr<Job> j = std::move(job_);
     if (j->rc != VO_OK) {                            // a failed solve must not end the stream: the map keeps its un-optimised state
         if (j->resident && deviceGraph_ && (j->rc == VO_E_UNSUPPORTED || j->rc == VO_E_OVERFLOW || j->rc == VO_E_NOMEM)) {
@@ -101,13 +105,16 @@ void Backend::Finish(bool deferTail) {
     FinishTail();                                    // an earlier tail, if its owner never came back for it
     MapManager& map = MapManager::GetInstance();
     if (j->nPoints == 0 || j->nEdges == 0) return;
+    { VO_SCOPE("ba.culled");
     for (int i = 0; i < j->nCulled; ++i) {
         const MapManager::ObsRef& o = map.obsRegistry_[(size_t)j->culled[i]];
         if (o.keyframe->IsObservedMappoint(o.mappoint->GetId())) o.keyframe->RemoveObservedMappoint(o.mappoint->GetId());
-    }
+    } }
     vo_ctx* solver = lag_ > 0 ? ctxOwn_ : ctx_;
-    int rc = vo_local_ba_resident_merge(solver, ctx_);
+    int rc;
+    { VO_SCOPE("ba.merge_call"); rc = vo_local_ba_resident_merge(solver, ctx_); }
     if (rc != VO_OK) throw std::runtime_error(std::string("vo_local_ba_resident_merge failed: ") + vo_strerror(rc));
+    if (waited) stats_.ms_to_merge += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tWake).count();
     tail_ = std::move(j); tailCtx_ = solver;
     if (!deferTail) FinishTail();
 }

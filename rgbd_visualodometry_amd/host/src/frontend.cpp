@@ -192,6 +192,7 @@ void FrontEnd::EnsureKeypoints() {
     const int cap = 2 * params_.n_features + 64;
     kpBuf_.resize(cap); descBuf_.resize((size_t)32 * cap);
     int nf = 0;
+    VO_SCOPE("fe.keypoints");
     // with the descriptors kept on the device (map_descriptors_on_device) only the keypoint records come down
     vo_check(vo_orb_fetch(ctx_, frameCurr_->slot_, kpBuf_.data(), deviceDescriptors_ ? nullptr : descBuf_.data(), cap, &nf), "vo_orb_fetch");
     const int n = nKeypointsCurr_;
@@ -213,6 +214,7 @@ void FrontEnd::EnsureMatchLists() {
     if (!matchesFetched_ && curLane_ >= 0 && nCurMatches_ > 0) {        // the records of this frame are still in its lane's device buffer
         if ((int)matchBuf_.size() < nCurMatches_) matchBuf_.resize(nCurMatches_);
         int got = 0;
+        VO_SCOPE("fe.fetch_matches");
         vo_check(vo_track_fetch_matches(ctx_, curLane_, matchBuf_.data(), nCurMatches_, &got), "vo_track_fetch_matches");
         nCurMatches_ = got;
     }
