@@ -266,7 +266,6 @@ void vo_ctx_destroy(vo_ctx* c) {
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     for (auto& sl : c->pre) { if (sl.bgr) (void)hipFree(sl.bgr); if (sl.depth) (void)hipFree(sl.depth); if (sl.ev) (void)hipEventDestroy(sl.ev); }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-    if (c->fetch_stream) { (void)hipStreamSynchronize(c->fetch_stream); (void)hipStreamDestroy(c->fetch_stream); }
     if (c->orb_ev) (void)hipEventDestroy(c->orb_ev);
     void* ptrs[] = {c->d_slots, c->d_pyr, c->d_blur, c->d_tab, c->d_tabs, c->d_cand, c->d_cand_cnt, c->d_sel, c->d_sel_key, c->d_sel_cnt, c->d_kps,
                     c->d_desc, c->d_nkp, c->d_status, c->d_map_pos, c->d_map_nrm, c->d_map_desc, c->d_map_flags, c->d_active, c->d_best, c->d_mcand,
@@ -992,12 +991,11 @@ int vo_track_fetch_matches(vo_ctx* c, int lane, vo_match* matches, int cap, int*
     int rc = ensure_match_stage(c, std::max(n, 1));
     if (rc) return rc;
     if (n > 0) {
-        // The chain that wrote these records has been collected (its stream was synchronised then), so the copy needs no ordering -- and on the
-        // context's own stream it would queue behind whatever has been enqueued since (the next look-ahead batch's ORB launches: 77 us per
-        // keyframe in the bench's VO_TRACE scopes): a stream of its own.
-        if (!c->fetch_stream) HIP_TRY(hipStreamCreateWithFlags(&c->fetch_stream, hipStreamNonBlocking));
-        HIP_TRY(hipMemcpyAsync(c->h_matches, c->d_matches + (size_t)lane * c->lane_stride, sizeof(vo_match) * (size_t)n, hipMemcpyDeviceToHost, c->fetch_stream));
-        HIP_TRY(hipStreamSynchronize(c->fetch_stream));
+        // (On the context's own stream the copy queues behind whatever has been enqueued since -- 77 us per keyframe in the bench's VO_TRACE
+        // scopes.  A stream of its own was tried and lost: one more stream, even in the lowest priority class, changed which streams share
+        // a hardware queue -- every step kernel of the local BA a third slower by HIP events, upload_inclusive 0.97 -> 0.75, -3 % frames/s.)
+        HIP_TRY(hipMemcpyAsync(c->h_matches, c->d_matches + (size_t)lane * c->lane_stride, sizeof(vo_match) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
         memcpy(matches, c->h_matches, sizeof(vo_match) * (size_t)n);
     }
     *n_out = n;

@@ -119,7 +119,6 @@ struct vo_ctx {
     vo_stream_allreduce_fn shard_stream_fn = nullptr;     // on-stream form of the exchange (shard_user = communicator)
     vo_match* h_matches;                            // pinned staging
     int h_matches_cap;
-    hipStream_t fetch_stream = nullptr;             // vo_track_fetch_matches' on-demand copy (not behind the context stream's backlog)
     int h_matches_lanes = 0, h_matches_first = 0;   // lanes whose first `h_matches_first` records the last chain left in h_matches (group mode)
     void* h_stage; size_t h_stage_bytes;            // pinned general staging
     uint8_t* h_orb_cache; bool orb_cache_valid; bool orb_cache_desc = false; int orb_batch0, orb_batchn;   // pinned copy of the last ORB batch's results
