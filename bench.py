@@ -484,7 +484,7 @@ def main():
 
             for S in [int(v) for v in args.multi_streams.split(",") if v]:
                 f_g, gs = run_streams(S, True)
-                f_s, _ = run_streams(S, False)
+                f_s, _ = (0.0, None) if os.environ.get("VO_BENCH_NO_SEPARATE") else run_streams(S, False)      # (experiments: a kernel trace that ends with the grouped run)
                 multi.append({"streams_per_gpu": S, "frames_per_stream": nfr - nwarm, "frames_per_s": round(f_g, 1),
                               "hbm_frac_whole_frame": round(b_survey * f_g / (HBM_PEAK_GBS * 1e9), 6),
                               "vs_single_stream": round(f_g / fps, 2), "lanes_per_launch_chain": round(gs["lanes"] / max(1, gs["chains"]), 2),
