@@ -1,40 +1,42 @@
-// vo_ba_chol2.h -- the reduced system's Cholesky + solve for D <= CH2_MAXD, second generation: the arithmetic of k_ba_chol16 (16-column
-// panels, in-register block factor, DPP panel solves, f64-MFMA trailing tiles) run as a DATAFLOW inside one workgroup instead of as
-// barrier-separated phases, on a TILE-MAJOR matrix.  Included by vo_ba.hip behind the first generation's DPP helpers.
+// vo_ba_chol2.h -- the reduced system's Cholesky + solve for D <= CH2_MAXD, second generation (k_ba_chol16v2, and workgroup 0 of k_ba_cholup):
+// the arithmetic of k_ba_chol16 (16-column panels, in-register block factor, f64-MFMA tiles) run as a DATAFLOW inside one workgroup instead
+// of as barrier-separated phases, on a TILE-MAJOR matrix, with every panel solve turned into a product with the block's inverse.
+// Included by vo_ba.hip behind the first generation's DPP helpers.  Reference: the linear solver of src/backend.cpp:23-27 (g2o's dense
+// Cholesky on the Schur complement), one call per LM iteration of :140-159.
 //
 // Layout.  The lower triangle of the augmented matrix [S b; b^T 0] is kept as 16x16 tiles, tile (i, j <= i) at (i (i + 1) / 2 + j) * 272
 // doubles, entry (r, c) of a tile at 17 r + c (ch2_sidx).  The row stride of 17 makes every access pattern of the solve free of bank
 // conflicts (16 lanes reading one column of 16 rows: banks 34 r + 2 c mod 64, all different; 16 lanes reading one row: contiguous), and
 // the tile order makes every address "tile base (a scalar) + a per-lane constant + an immediate": a trailing-tile update is ~30
 // instructions, where the packed-row layout of the first generation spent ~150 on index arithmetic.  The Schur kernel writes S in the
-// same layout in global memory (BaDev::s_tiles), so the matrix still arrives by straight global -> LDS DMA.
+// same layout in global memory (BaDev::s_tiles), so the matrix still arrives by straight global -> LDS DMA; the waves that fetched it
+// clear it behind the load.  The right-hand side rides along as row D, so the forward substitution falls out of the factorisation.
 //
 // Dataflow.  The factorisation is a chain of 16x16 block factorisations (POTRF) that nothing can shorten: block k+1 needs block k's panel
 // solve (TRSM) of its own 16 rows and that tile's product with itself (SYRK).  The first generation put two workgroup barriers into every
-// link of that chain and wave 0 -- the only wave on the chain -- waited at both.  Here the waves have ROLES and hand work to each other
-// through words in LDS; after the first few hundred clocks nobody executes s_barrier:
-//   wave 0  (P)  factors the diagonal blocks, one after the other, in registers; every finished COLUMN of a block is published at once
-//                (16 values + the pivot's inverse into a column buffer, then a progress word);
-//   waves 1-3 (solvers, one per remaining SIMD) own the ROW BLOCKS below the first, round robin (row block i belongs to solver (i - 1) mod 3).
-//                A solver does everything that writes its rows.  The one that owns row block k+1 first turns the published block into
-//                W_k = L_kk^-T (the first generation's DPP panel solve applied to the identity: ONE such pass per stage); every panel
-//                solve is then a product X = A W_k on the matrix cores -- 4 MFMAs per 16 rows, where the row-per-lane solve is 136
-//                double-precision DPP or broadcast-fed instructions per 64 rows and three waves at it saturate a pipe that the whole compute
-//                unit shares (tools/chol_bench: v_fmac_f64_dpp 5.8 clocks with one wave, 45.8 with eight; an independent
-//                v_mfma_f64_16x16x4 issues every 16).  That solver then updates tile (k+1, k+1) and tells wave 0: POTRF -> W_k -> 8
-//                MFMAs -> POTRF is the whole critical loop, and the solver on it changes every stage.
-//                Trailing updates are LEFT-LOOKING: a solver's tiles of block column j are touched once, right before stage j solves
-//                against them, with all j panels in one read-modify-write (two accumulators per tile, the next panel's operands in flight
-//                behind the MFMAs).  A right-looking first stage floods the matrix cores with 45 tiles while the chain waits.
-//   waves 4-7    help to load (f64 MFMA, f64 DPP and f64 FMA share a SIMD's double-precision units: a second wave per SIMD adds no
-//                throughput, and beside wave 0 it would only slow the chain down); wave 4 clears S in global memory.
-// The only cross-wave inputs are: the published columns (prog), W_k (inv), L(j, k) of another solver's row block j for a trailing tile
-// (rowdone[j] = stages solved for row block j) and the finished diagonal tile (diag).  Words are monotone and never reset.  Producers store data, then
-// the word, in program order (LDS executes a wave's instructions in order; the asm memory clobbers keep the compiler from reordering);
-// consumers poll the word, then load.  Every wait is bounded: after CH2_SPIN_LIMIT polls a wave raises `abort`, stops waiting and the
-// solve is reported as failed -- a logic error can produce a wrong (flagged) result, not a hung GPU.
-// The backward substitution runs on three waves (rows 0-63, 64-127, 128-191: a row per lane), without any barrier: the 16x16 triangles by a
-// DPP chain on the wave that owns the block's rows, x_p through LDS into the rows above.
+// link of that chain.  Here the waves have ROLES and hand work to each other through words in LDS; after the load nobody executes s_barrier:
+//   wave 0       the chain: factors diagonal block k in registers (a row per lane, DPP row broadcasts), publishing every finished COLUMN at
+//                once (16 values + the pivot's inverse into a column buffer, then the word `prog`); then takes tiles (k+1, k) and (k+1, k+1)
+//                from the solver that owns row block k+1 (`rdy`), solves the first as a transposed MFMA product with W_k -- the result
+//                registers are the SYRK's operands -- and applies it to the second.  At the end it runs the backward substitution.
+//   wave 1       the inverter, alone on its SIMD: W_k = L_kk^-T, the first generation's DPP panel solve applied to the identity, streamed one
+//                column behind the factorisation and stored column by column into the diagonal tile (which nobody needs as L_kk again);
+//                the word `inv`.  With W_k every panel solve below the block is X = A W_k on the matrix cores (4 MFMAs per tile) and
+//                the backward substitution needs no triangular solve either.
+//   waves 2,3,6,7  solvers, two per remaining SIMD; row block i belongs to solver (i - 1) mod 4, which alone writes its tiles (except what wave 0
+//                takes).  LEFT-LOOKING with a fixed schedule: at stage k a solver brings its tiles of block column k up to date with
+//                all k panels in ONE read-modify-write (two accumulators per tile, the next panel's operands in flight behind the MFMAs)
+//                while block k is being factored, waits for W_k, solves them.  The solver that owns row block k+2 is on the chain
+//                wave 0 -> W_k -> L(k+2, k) -> tiles (k+2, k+1), (k+2, k+2) -> wave 0: it has given those two tiles their panels 0 .. k-1 one
+//                stage ahead, solves the critical tile first and alone (as a transposed product, so that the result registers are the
+//                operands of what follows), adds panel k to the two tiles and raises `rdy`; `rowdone[i]` = stages solved for row block i.
+//   waves 4, 5   help to load; wave 4 clears S in global memory.  (An MFMA, a DPP operation and a plain FMA in double precision all draw on
+//                the same 16 lanes per clock of their SIMD -- a v_mfma_f64_16x16x4 holds them for ~64 clocks -- so work placed beside
+//                wave 0 or beside the inverter slows the chain by more than it relieves the solvers: measured)
+// Words are monotone and never reset.  Producers store data, then the word, in program order (LDS executes a wave's instructions in order;
+// the asm memory clobbers keep the compiler from reordering); consumers poll the word, then load.  Every wait is bounded: after
+// CH2_SPIN_LIMIT polls a wave raises `abort`, stops waiting and the solve is reported as failed -- a logic error can produce a wrong
+// (flagged) result, not a hung GPU.
 #pragma once
 #include <type_traits>
 #ifndef CH2_EXP
@@ -56,7 +58,7 @@
 #else
 #define CH2_STAMP(slot)
 #endif
-struct Ch2Flags { int prog, diag, dma, init, ok, abort_, xflag, inv; int rowdone[16], rdy[16]; };
+struct Ch2Flags { int prog, dma, init, ok, abort_, inv; int rowdone[16], rdy[16]; };
 
 __host__ __device__ inline int ch2_tix(int i, int j) { return i * (i + 1) / 2 + j; }
 __host__ __device__ inline size_t ch2_sidx(int r, int c) { return (size_t)ch2_tix(r >> 4, c >> 4) * CH2_TS + (size_t)((r & 15) * CH2_RS + (c & 15)); }
@@ -111,17 +113,7 @@ template <int KK, int C> struct Ch2StreamRow {
     static __device__ __forceinline__ void run(double (&x)[CH_NB], double Lk) { ch_fnma_bcast<C>(x[C], Lk, x[KK]); Ch2StreamRow<KK, C + 1>::run(x, Lk); }
 };
 template <int KK> struct Ch2StreamRow<KK, CH_NB> { static __device__ __forceinline__ void run(double (&)[CH_NB], double) {} };
-// one column step of the streamed panel solve: x[K] *= 1 / L[K][K], x[C] -= L[C][K] x[K] (C > K).  `avail` = columns known to be published:
-// a step that finds its column missing polls, then fetches its column -- or, when the whole block has been published by then, all remaining
-// columns in one batch of loads: a wave that is behind the factorisation (the usual case at the start of a stage) pays one LDS round trip
-// for the block, one that keeps up pays one per column
-template <int K, int C> struct Ch2Fetch {                     // columns C .. 15, no branch between the loads (one wait for all of them)
-    static __device__ __forceinline__ void run(double (&Lk)[CH_NB], const double* s_colp, int r16) {
-        Lk[C] = *(const volatile ch2_lds_f64*)(s_colp + C * CH_NB + r16);
-        Ch2Fetch<K, C + 1>::run(Lk, s_colp, r16);
-    }
-};
-template <int K> struct Ch2Fetch<K, CH_NB> { static __device__ __forceinline__ void run(double (&)[CH_NB], const double*, int) {} };
+// one column step of the streamed solve: x[K] *= 1 / L[K][K], x[C] -= L[C][K] x[K] (C > K)
 template <int K> struct Ch2Stream {
     // `f` / Lk[K]: the word and column K as read one step ago (speculatively: valid iff f says so).  Column K+1 is requested before column
     // K is used, so that a wave that is behind the factorisation pays no LDS round trip per step and catches up.
@@ -162,80 +154,12 @@ __device__ __forceinline__ void ch2_wait_set(int* arr, unsigned mask, int need, 
     asm volatile("" ::: "memory");
 }
 
-// The panel solve WITHOUT cross-lane operations: a row per lane, L[C][K] (the same for every lane) arrives as an LDS broadcast read of the
-// published column and meets x[K] in a plain v_fma_f64.  The DPP form of the first generation (L in a register, v_fmac_f64_dpp row
-// broadcasts) is one instruction per term as well, but double-precision DPP instructions of ALL waves of a compute unit go through one
-// shared pipe (tools/chol_bench: 5.8 clocks per v_fmac_f64_dpp with one wave, 45.8 with eight; plain v_fma_f64: 5.0 and 6.5): three waves
-// solving at once each ran three times slower, and slowed the block factorisation beside them.  Same operations, same roundings.
-template <int K> struct Ch2LoadCol {                            // entries K .. 15 of published column K (the same address in every lane)
-    static __device__ __forceinline__ void run(double (&l)[CH_NB], const double* s_colp) {
-#pragma unroll
-        for (int c = K; c < CH_NB; ++c) l[c] = s_colp[K * CH_NB + c];
-    }
-};
-template <> struct Ch2LoadCol<CH_NB> { static __device__ __forceinline__ void run(double (&)[CH_NB], const double*) {} };
-template <> struct Ch2LoadCol<CH_NB + 1> { static __device__ __forceinline__ void run(double (&)[CH_NB], const double*) {} };
-// column K is in `l`, column K+1 in `l1` (requested one step ago); column K+2 is requested before column K is used: an LDS round trip
-// is ~130 clocks, a column step 30 to 80
-template <int K> struct Ch2SolveB {
-    static __device__ __forceinline__ void run(double (&x)[CH_NB], double (&l)[CH_NB], double (&l1)[CH_NB], const double* s_colp) {
-        double l2[CH_NB];
-        Ch2LoadCol<K + 2>::run(l2, s_colp);
-        x[K] = fma(l[K], x[K], 0.0);
-#pragma unroll
-        for (int c = K + 1; c < CH_NB; ++c) x[c] = fma(-l[c], x[K], x[c]);
-        Ch2SolveB<K + 1>::run(x, l1, l2, s_colp);
-    }
-};
-template <> struct Ch2SolveB<CH_NB> { static __device__ __forceinline__ void run(double (&)[CH_NB], double (&)[CH_NB], double (&)[CH_NB], const double*) {} };
-// the same, streamed: one column step per published column
-template <int K> struct Ch2StreamB {
-    static __device__ __forceinline__ void run(double (&x)[CH_NB], const double* s_colp, int* s_prog, int progbase, int* abort_) {
-        ch2_wait_ge(s_prog, progbase + K + 1, abort_);
-        double l[CH_NB];
-#pragma unroll
-        for (int c = K; c < CH_NB; ++c) l[c] = *(const volatile ch2_lds_f64*)(s_colp + K * CH_NB + c);
-        x[K] = fma(l[K], x[K], 0.0);
-#pragma unroll
-        for (int c = K + 1; c < CH_NB; ++c) x[c] = fma(-l[c], x[K], x[c]);
-        Ch2StreamB<K + 1>::run(x, s_colp, s_prog, progbase, abort_);
-    }
-};
-template <> struct Ch2StreamB<CH_NB> { static __device__ __forceinline__ void run(double (&)[CH_NB], const double*, int*, int, int*) {} };
 
-// N trailing tiles at once: tile (ti, tj) -= L(ti, k) L(tj, k)^T, 4 MFMAs each, interleaved (a tile alone is a dependent chain of
-// operand loads -> 4 MFMAs on one accumulator -> read-modify-write).  Lane l holds A[l & 15][l >> 4 + 4 q], B likewise, C: row (l >> 4) + 4 q, column l & 15.
-template <int N>
-__device__ __forceinline__ void ch2_tiles(double* s_L, const int (&ti)[3], const int (&tj)[3], int k, int o_op, int o_c) {
-    double a[N][4], b[N][4], c[N][4];
-    double* pc[N];
-#pragma unroll
-    for (int t = 0; t < N; ++t) {
-        const double* pa = s_L + ch2_tix(ti[t], k) * CH2_TS + o_op;
-        const double* pb = s_L + ch2_tix(tj[t], k) * CH2_TS + o_op;
-        pc[t] = s_L + ch2_tix(ti[t], tj[t]) * CH2_TS + o_c;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { a[t][q] = pa[4 * q]; b[t][q] = pb[4 * q]; c[t][q] = pc[t][4 * CH2_RS * q]; }
-    }
-    f64x4 acc[N];
-#pragma unroll
-    for (int t = 0; t < N; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int t = 0; t < N; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t][q], b[t][q], acc[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < N; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) pc[t][4 * CH2_RS * q] = c[t][q] - acc[t][q];
-}
-
-// the same for panels k0 .. k1 in one go (a worker that applies its pending panels to a tile just before the tile is needed -- or early,
-// while it has nothing more urgent to do): 4 (k1 - k0 + 1) MFMAs per tile on one accumulator, ONE read-modify-write of the tile
+// N trailing tiles at once: tile (ti, tj) -= sum over panels k0 .. k1 of L(ti, k) L(tj, k)^T, 4 MFMAs per tile and panel, interleaved over the tiles.
+// Lane l holds A[l & 15][l >> 4 + 4 q], B likewise, C: row (l >> 4) + 4 q, column l & 15.  ONE read-modify-write of the tile for all its panels.
 template <int N>
 __device__ __forceinline__ void ch2_tiles_mp(double* s_L, const int (&ti)[3], const int (&tj)[3], int k0, int k1, int o_op, int o_c) {
-    // two accumulators per tile (an MFMA on an accumulator of its own issues every 16 clocks, a dependent one every 64) and the next
-    // panel's operands requested before this panel's MFMAs (an LDS round trip is 130+ clocks: as long as a panel's 4 N MFMAs)
+    // two accumulators per tile and the next panel's operands requested before this panel's MFMAs (an LDS round trip is 130+ clocks)
     double c[N][4];
     double* pc[N];
     const double* pa[N]; const double* pb[N];
@@ -304,7 +228,7 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
     const int o_c = CH2_RS * kq + r16;                         // MFMA result: rows kq + 4 q, column r16
     __shared__ Ch2Flags F;
     if (tid < 16) { F.rowdone[tid] = 0; F.rdy[tid] = -1; }
-    if (tid == 0) { F.prog = 0; F.diag = 0; F.dma = 0; F.init = 0; F.ok = 1; F.abort_ = 0; F.xflag = 0; F.inv = 0; }
+    if (tid == 0) { F.prog = 0; F.dma = 0; F.init = 0; F.ok = 1; F.abort_ = 0; F.inv = 0; }
     const double lambda = (ctl_->need_lin && ctl_->first) ? 1e-5 * B.scal[4] : ctl_->lambda;      // as k_ba_init_S derives it
     const double* const Hpp = B.Hpp;
     __syncthreads();                                           // the words are zero, everyone has read the control block
