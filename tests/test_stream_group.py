@@ -174,10 +174,12 @@ def _ba_problem(rng, nP, nX, nfree, p):
 
 
 @pytest.mark.parametrize("libs", LIBS)
-def test_concurrent_local_bas_equal_sequential_ones(libs):
+@pytest.mark.parametrize("fuse", ["1", "8"])                 # 8: the solvers and updates of up to 8 problems share a launch (k_ba_cholup; the library's default fuses a lone problem only)
+def test_concurrent_local_bas_equal_sequential_ones(libs, fuse, monkeypatch):
     """Local BAs of several contexts submitted at the same time (the back-end workers of several streams) are stepped together
     by the device's BA engine (continuous batching, blockIdx.z = problem): sizes differ (one reduced system > 192 takes the
     other Cholesky kernel), rounds start and end at different steps; every result equals the one a lone call returns."""
+    monkeypatch.setenv("VO_BA_FUSE_MAX", fuse)
     L = capi.load(libs[0])
     rng = np.random.default_rng(8)
     p = L.default_params()
