@@ -296,7 +296,7 @@ int vo_local_ba(vo_ctx* ctx, const vo_ba_problem* in, vo_ba_result* out);
  * `tables` is the context that owns the map and the observation table (the tracker's); `ctx` provides scratch and the stream,
  * so a back-end thread can solve beside the tracker.  The device tables are NOT modified: the caller merges (vo_map_upsert,
  * vo_kf_set_pose, vo_obs_kill) at the moment it chooses.
- * Limits and threading: the tables hold 32 Mi observations and 64 Ki keyframes, the map may use slots below 16 Mi (VO_E_OVERFLOW / VO_E_INVALID beyond: the caller goes
+ * Limits and threading: the observation table grows on demand up to 256 Mi entries (it starts at 4 Mi: 68 MB), the keyframe table holds 64 Ki keyframes, the map may use slots below 16 Mi (VO_E_OVERFLOW / VO_E_INVALID beyond: the caller goes
  * back to vo_local_ba with a graph of its own); a cut takes at most VO_BA_RESIDENT_MAX_FREE free keyframes (the host back-end's own cap), each listed once.  The tables belong to the
  * tracker's thread; a back-end thread may run _cut on them from its own context as long as the tracker appends nothing, changes no
  * flag or position of the map and kills no observation between the call and its return (host/src/backend.cpp: WaitGraphCut). */

@@ -1009,21 +1009,50 @@ int vo_track_frame(vo_ctx* c, int slot, const double T0[12], const vo_track_para
 }
 
 // ---- device-resident observation table -------------------------------------------------------------------------
-#define VO_OBS_CAP (32ll << 20)     // observations (17 B each, 544 MB); ~2000 per keyframe: ~50 000 frames at a keyframe every 3 frames
+#define VO_OBS_CAP (256ll << 20)    // observations the table may grow to (17 B each: 4.4 GB); ~5000 per keyframe at the bench workload: ~170 000 frames
 #define VO_KF_CAP 65536             // keyframes (96 B each)
-static int vo_obs_tables_ensure(vo_ctx* c) {     // allocates the observation / keyframe tables on first use
-    if (c->d_obs_kf) return VO_OK;
-    const char* env = getenv("VO_OBS_CAP");                // tests shrink the table to exercise the overflow path
-    c->obs_cap = env && atoll(env) > 0 ? std::min<long long>(atoll(env), VO_OBS_CAP) : VO_OBS_CAP; c->kf_cap = VO_KF_CAP;
-    if (hipMalloc((void**)&c->d_obs_kf, 4 * (size_t)c->obs_cap) != hipSuccess || hipMalloc((void**)&c->d_obs_mp, 4 * (size_t)c->obs_cap) != hipSuccess ||
-        hipMalloc((void**)&c->d_obs_uv, 8 * (size_t)c->obs_cap) != hipSuccess || hipMalloc((void**)&c->d_obs_alive, (size_t)c->obs_cap) != hipSuccess ||
-        hipMalloc((void**)&c->d_kf_pose, 96 * (size_t)c->kf_cap) != hipSuccess) {
-        // all or nothing: a later call must not find d_obs_kf set beside null siblings
-        void** tp[] = {(void**)&c->d_obs_kf, (void**)&c->d_obs_mp, (void**)&c->d_obs_uv, (void**)&c->d_obs_alive, (void**)&c->d_kf_pose};
-        for (void** q : tp) { if (*q) (void)hipFree(*q); *q = nullptr; }
+// The observation table starts at VO_OBS_CAP0 entries and doubles when a keyframe does not fit, up to VO_OBS_CAP (env VO_OBS_CAP lowers
+// that bound: tests exercise the overflow path with it).  Growing copies the live prefix on the context's stream and waits for it: nothing
+// may be reading the table then -- the front-end appends only behind Backend::WaitGraphCut, and merges are ordered on this stream.
+#define VO_OBS_CAP0 (4ll << 20)     // 68 MB; ~800 keyframes of the bench workload
+static int vo_obs_tables_alloc(long long cap, int32_t** kf, int32_t** mp, float** uv, uint8_t** alive) {
+    *kf = nullptr; *mp = nullptr; *uv = nullptr; *alive = nullptr;
+    if (hipMalloc((void**)kf, 4 * (size_t)cap) != hipSuccess || hipMalloc((void**)mp, 4 * (size_t)cap) != hipSuccess ||
+        hipMalloc((void**)uv, 8 * (size_t)cap) != hipSuccess || hipMalloc((void**)alive, (size_t)cap) != hipSuccess) {
+        // all or nothing: a later call must not find one array set beside null siblings
+        void* q[] = {*kf, *mp, *uv, *alive};
+        for (void* x : q) if (x) (void)hipFree(x);
+        *kf = nullptr; *mp = nullptr; *uv = nullptr; *alive = nullptr;
         (void)hipGetLastError();
         return VO_E_NOMEM;
     }
+    return VO_OK;
+}
+static int vo_obs_tables_ensure(vo_ctx* c) {     // allocates the observation / keyframe tables on first use
+    if (c->d_obs_kf) return VO_OK;
+    const char* env = getenv("VO_OBS_CAP");
+    c->obs_cap_max = env && atoll(env) > 0 ? std::min<long long>(atoll(env), VO_OBS_CAP) : VO_OBS_CAP; c->kf_cap = VO_KF_CAP;
+    const char* env0 = getenv("VO_OBS_CAP0");             // tests start small to exercise the growth
+    const long long cap = std::min<long long>(env0 && atoll(env0) > 0 ? atoll(env0) : VO_OBS_CAP0, c->obs_cap_max);
+    if (hipMalloc((void**)&c->d_kf_pose, 96 * (size_t)c->kf_cap) != hipSuccess) { c->d_kf_pose = nullptr; (void)hipGetLastError(); return VO_E_NOMEM; }
+    if (vo_obs_tables_alloc(cap, &c->d_obs_kf, &c->d_obs_mp, &c->d_obs_uv, &c->d_obs_alive) != VO_OK) { (void)hipFree(c->d_kf_pose); c->d_kf_pose = nullptr; return VO_E_NOMEM; }
+    c->obs_cap = cap;
+    return VO_OK;
+}
+static int vo_obs_tables_grow(vo_ctx* c, long long need) {
+    long long cap = c->obs_cap;
+    while (cap < need) cap = std::min(2 * cap, c->obs_cap_max);
+    int32_t* kf; int32_t* mp; float* uv; uint8_t* alive;
+    int rc = vo_obs_tables_alloc(cap, &kf, &mp, &uv, &alive);
+    if (rc) return rc;
+    const size_t n = (size_t)c->n_obs;
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(kf, c->d_obs_kf, 4 * n, hipMemcpyDeviceToDevice, c->stream)); HIP_TRY(hipMemcpyAsync(mp, c->d_obs_mp, 4 * n, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(uv, c->d_obs_uv, 8 * n, hipMemcpyDeviceToDevice, c->stream)); HIP_TRY(hipMemcpyAsync(alive, c->d_obs_alive, n, hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->d_obs_kf); (void)hipFree(c->d_obs_mp); (void)hipFree(c->d_obs_uv); (void)hipFree(c->d_obs_alive);
+    c->d_obs_kf = kf; c->d_obs_mp = mp; c->d_obs_uv = uv; c->d_obs_alive = alive; c->obs_cap = cap;
     return VO_OK;
 }
 
@@ -1055,7 +1084,8 @@ int vo_obs_append(vo_ctx* c, const int32_t* kf, const int32_t* mp, const float* 
     int rc = vo_obs_tables_ensure(c);
     if (rc) return rc;
     for (int i = 0; i < n; ++i) if (kf[i] < 0 || kf[i] >= c->kf_cap || mp[i] < 0 || mp[i] >= c->p.map_capacity) return VO_E_INVALID;
-    if (c->n_obs + n > c->obs_cap) return VO_E_OVERFLOW;
+    if (c->n_obs + n > c->obs_cap_max) return VO_E_OVERFLOW;
+    if (c->n_obs + n > c->obs_cap && (rc = vo_obs_tables_grow(c, c->n_obs + n))) return rc;
     if (first) *first = (int64_t)c->n_obs;
     if (n == 0) return VO_OK;
     // pack -> one pinned staging buffer -> one H2D copy into the scratch slab -> one kernel writes the four table columns (three copies and a

@@ -130,7 +130,7 @@ struct vo_ctx {
     // device-resident keyframe bookkeeping: observation table and keyframe poses, fixed capacity (a back-end
     // thread may be reading them while the tracker appends: no reallocation, appends only write beyond what a reader was given)
     int32_t* d_obs_kf = nullptr; int32_t* d_obs_mp = nullptr; float* d_obs_uv = nullptr; uint8_t* d_obs_alive = nullptr;
-    long long n_obs = 0, obs_cap = 0;
+    long long n_obs = 0, obs_cap = 0, obs_cap_max = 0;     // entries used / allocated / the bound the table may grow to
     // what a keyframe's points reach back to (host bookkeeping of vo_obs_append; the resident graph cut enters the tables there): pt_first[slot] = table position of the
     // point's first observation (-1: none yet); kf_reach[kf] = minimum of that, and of the slot, over the points the keyframe observes
     struct KfReach { long long obs_lo = -1; int slot_lo = 0; };

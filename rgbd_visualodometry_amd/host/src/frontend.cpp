@@ -467,7 +467,7 @@ void FrontEnd::RegisterKeyframeOnDevice() {
     int rc = vo_obs_append(ctx_, kf.data(), mp.data(), uv.data(), (int)n, &first);
     if (rc == VO_OK) rc = vo_kf_set_pose(ctx_, &frameCurr_->kfIndex_, T, 1);
     if (rc == VO_E_OVERFLOW || rc == VO_E_INVALID || rc == VO_E_NOMEM) {
-        // the tables are full (32 Mi observations / 64 Ki keyframes): from here on the back-end cuts its graphs on the host again;
+        // the tables are full (256 Mi observations / 64 Ki keyframes) or could not grow: from here on the back-end cuts its graphs on the host again;
         // a job already cut from the tables still merges through them
         std::cerr << "[myslam] device observation table full (" << vo_strerror(rc) << "): local BA graphs are cut on the host from keyframe " << frameCurr_->GetId() << " on" << std::endl;
         map.obsRegistry_.resize(map.obsRegistry_.size() - n);

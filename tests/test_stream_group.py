@@ -341,10 +341,11 @@ def test_resident_graph_cut_follows_backend_cpp(libs, shape):
 
 
 @pytest.mark.parametrize("libs", LIBS)
-def test_resident_graph_cut_enters_the_tables_at_its_window(libs):
+def test_resident_graph_cut_enters_the_tables_at_its_window(libs, monkeypatch):
     """A long run behind the window: 600 old keyframes with 150 k observations of 40 k old points that no recent keyframe sees, then the
     scene of the other tests on top (keyframe numbers and map slots continue).  The graph is the window's own -- and the cut visits the
     window, not the run (vo_ba_resident_window; the CPU restatement walks everything and says so)."""
+    monkeypatch.setenv("VO_OBS_CAP0", "4096")               # the HIP library's observation table starts here and doubles six times under this test
     L = capi.load(libs[0])
     rng = np.random.default_rng(23)
     n_old_kf, n_old_pts, per_kf = 600, 40000, 250
