@@ -98,12 +98,9 @@ __device__ __forceinline__ void p2_lin_poses_body(const BaCam& cam, const BaDev&
 #pragma unroll
                 for (int i = 11; i < 16; ++i) x[i] = 0.0;
             }
-            vo_wave_reduce16(x, o4);
-            if ((lane & 15) == 0) {
-                const int slot = VO_R32_SLOT(lane >> 4);
-#pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) s_part[wave * 32 + 16 * half + 4 * k4 + slot] += o4[k4];
-            }
+            (void)o4;
+            const double tsum = vo_wave_reduce16t(x);
+            if ((lane & 15) < 4) s_part[wave * 32 + 16 * half + 4 * VO_R16T_K(lane) + VO_R32_SLOT(lane >> 4)] += tsum;
         }
     }
     __syncthreads();
@@ -268,14 +265,11 @@ __device__ __forceinline__ void p2_schur_slice(const BaDev& B, const BaBlock blk
                 x[12 + cc] = DIAG ? Jp2[0][c] * g[0] + Jp2[1][c] * g[1] : 0.0;
             }
             x[14] = x[15] = 0.0;
-            vo_wave_reduce16(x, o4);
-            if ((lane & 15) == 0) {
-                const int slot = VO_R32_SLOT(lane >> 4);
-#pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) {
-                    double* d = s_part + wave * 48 + 16 * cp + 4 * k4 + slot;
-                    *d = base ? *d + o4[k4] : o4[k4];
-                }
+            (void)o4;
+            const double tsum = vo_wave_reduce16t(x);
+            if ((lane & 15) < 4) {
+                double* d = s_part + wave * 48 + 16 * cp + 4 * VO_R16T_K(lane) + VO_R32_SLOT(lane >> 4);
+                *d = base ? *d + tsum : tsum;
             }
         }
     }

@@ -78,6 +78,48 @@ __device__ __forceinline__ void vo_wave_reduce16(double (&v)[16], double (&out)[
     }
 }
 
+// The same first two stages, then the rows are finished TRANSPOSED: instead of four butterflies of four steps (16 move + add pairs), the four
+// values fold onto each other -- lane pairs (l, l ^ 1) split them two and two, lane pairs (l, l ^ 2) one and one, two rotations finish -- 5
+// adds, 5 moves and 6 selects.  Result: ONE value per lane; lane l of row r holds the wavefront sum of v[4 VO_R16T_K(l) + VO_R32_SLOT(r)].
+#define VO_R16T_K(lane) ((((lane) & 1) << 1) | (((lane) >> 1) & 1))
+__device__ __forceinline__ double vo_wave_reduce16t(double (&v)[16]) {
+    double p[8], o[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { double a = v[2 * i], b = v[2 * i + 1]; vo_swap_halves_f64(a, b); p[i] = a + b; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { double a = p[2 * k], b = p[2 * k + 1]; vo_swap_rows_f64(a, b); o[k] = a + b; }
+    const int lane = threadIdx.x & 63;
+    const bool odd = lane & 1, hi = lane & 2;
+    // even lanes keep o[0], o[1] and receive them from their odd neighbour, odd lanes o[2], o[3]
+    const double r0 = (odd ? o[2] : o[0]) + vo_dpp_mov_f64<0xB1, 0xF>(odd ? o[0] : o[2]);      // quad_perm [1,0,3,2]
+    const double r1 = (odd ? o[3] : o[1]) + vo_dpp_mov_f64<0xB1, 0xF>(odd ? o[1] : o[3]);
+    // lanes 0, 1 of a quad keep r0 (o[0] / o[2]), lanes 2, 3 keep r1 (o[1] / o[3])
+    double t = (hi ? r1 : r0) + vo_dpp_mov_f64<0x4E, 0xF>(hi ? r0 : r1);                        // quad_perm [2,3,0,1]
+    t += vo_dpp_mov_f64<0x124, 0xF>(t);     // row_ror:4  (lane & 3 is preserved: the four quads of the row)
+    t += vo_dpp_mov_f64<0x128, 0xF>(t);     // row_ror:8
+    return t;
+}
+
+// 32 values, transposed finish (see vo_wave_reduce16t): 8 adds, 8 moves and 14 selects instead of 32 move + add pairs behind the two swap stages.
+// ONE value per lane; lane l of row r holds the wavefront sum of v[4 VO_R32T_K(l) + VO_R32_SLOT(r)].
+#define VO_R32T_K(lane) ((((lane) & 1) << 2) | ((lane) & 2) | (((lane) >> 2) & 1))
+__device__ __forceinline__ double vo_wave_reduce32t(double (&v)[32]) {
+    double p[16], o[8], r[4], q[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { double a = v[2 * i], b = v[2 * i + 1]; vo_swap_halves_f64(a, b); p[i] = a + b; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { double a = p[2 * k], b = p[2 * k + 1]; vo_swap_rows_f64(a, b); o[k] = a + b; }
+    const int lane = threadIdx.x & 63;
+    const bool odd = lane & 1, hi = lane & 2, b2 = lane & 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (odd ? o[4 + i] : o[i]) + vo_dpp_mov_f64<0xB1, 0xF>(odd ? o[i] : o[4 + i]);      // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) q[i] = (hi ? r[2 + i] : r[i]) + vo_dpp_mov_f64<0x4E, 0xF>(hi ? r[i] : r[2 + i]);        // quad_perm [2,3,0,1]
+    double t = (b2 ? q[1] : q[0]) + vo_dpp_mov_f64<0x124, 0xF>(b2 ? q[0] : q[1]);      // row_ror:4: lane l takes from lane l + 4, whose bit 2 is the other one
+    t += vo_dpp_mov_f64<0x128, 0xF>(t);     // row_ror:8
+    return t;
+}
+
 // 1 / sqrt(d): v_rsq_f64 (2^-24) + one cubic correction e (1/2 + 3/8 e), e = 1 - d y^2 -> 2^-52.7 relative error,
 // 6 dependent operations instead of the ~25 of an IEEE sqrt followed by an IEEE divide.
 __device__ __forceinline__ double vo_rsqrt_f64(double d) {

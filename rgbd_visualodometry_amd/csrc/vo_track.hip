@@ -922,19 +922,14 @@ __device__ void lm_pass_dev(const CamD& cam, const float* cxyz, const float* cuv
 #ifdef VO_LM_STAMPS
     const long long ts1 = clock64();
 #endif
-    double r8[8];
-    vo_wave_reduce32(a32, r8);                         // row r of r8[k]: wavefront sum of a32[4 k + VO_R32_SLOT(r)]
+    const double rsum = vo_wave_reduce32t(a32);        // lane l of row r: wavefront sum of a32[4 VO_R32T_K(l) + VO_R32_SLOT(r)]
 #ifdef VO_LM_STAMPS
     const long long ts2 = clock64();
 #endif
     // cross-wave: partials and totals are double buffered by `phase`, so two barriers per pass are enough (a buffer
     // is rewritten two passes later, after every reader has crossed two barriers)
     double* part = s_part + phase * (LM_W * 32);
-    if ((lane & 15) == 0) {
-        const int slot = VO_R32_SLOT(lane >> 4);
-#pragma unroll
-        for (int k = 0; k < 7; ++k) part[wave * 32 + 4 * k + slot] = r8[k];
-    }
+    if ((lane & 15) < 8) part[wave * 32 + 4 * VO_R32T_K(lane) + VO_R32_SLOT(lane >> 4)] = rsum;
     __syncthreads();
     if (threadIdx.x < LM_NV) {
         double sum = 0;
