@@ -2490,7 +2490,17 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     hipLaunchKernelGGL(k_ps_fill, dim3(chunks), dim3(PS_CHUNK), 0, st, ne, nf, e_pose, e_pt, (const int*)(base + o_offs), (const int*)(base + o_ptot), (int*)(base + o_qs),
                        (int32_t*)(base + o_qe), (int32_t*)(base + o_pspt));
     HIP_TRY(hipMemcpyAsync(h + 256, base + o_qs, 4 * (size_t)(nf + 1), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));                      // from here on `t` may change: every input has been gathered
+    // the counting pass and the scan of the pair plan go out BEFORE the host looks at the list lengths (with the largest LDS a list may
+    // need): the stream works through them while the host wakes up, checks the lengths and fills in the descriptor (~25 us per cut)
+    BaPairPlan Q;
+    Q.ps_start = (const int32_t*)(base + o_qs); Q.ps_edges = (const int32_t*)(base + o_qe); Q.ps_pt = (const int32_t*)(base + o_pspt); Q.nf = nf;
+    Q.cnt = (int*)(base + o_pcnt); Q.off = (int*)(base + o_poff); Q.n_slices = (int*)(base + o_pn); Q.n_pairs = (int*)(base + o_pn) + 1;
+    Q.blocks = (BaBlock*)(base + o_blk); Q.pairs = (int2*)(base + o_pairs);
+    if (!R.ev_arrays) HIP_TRY(hipEventCreateWithFlags(&R.ev_arrays, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(R.ev_arrays, st));               // (the first linearisation needs no pairs: it may start here)
+    hipLaunchKernelGGL(k_ba_pairs<false>, dim3(nb_all), dim3(256), 4 * (size_t)PAIR_LDS_CAP, st, Q);      // (a list beyond the cap: its stores past the allocation are dropped, the cut is refused below)
+    hipLaunchKernelGGL(k_ba_pairs_scan, dim3(1), dim3(1024), 0, st, Q, nb_all);
+    HIP_TRY(hipEventSynchronize(R.ev_arrays));              // from here on `t` may change: every input has been gathered (and the list lengths are in h)
     const int* ps_start = h + 256;
     int max_len = 0, npairs = 0, slices_ub = 0;
     for (int j = 0; j < nf; ++j) max_len = std::max(max_len, ps_start[j + 1] - ps_start[j]);
@@ -2515,14 +2525,6 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     B.cam = BaCam{(double)c->p.fx, (double)c->p.fy, (double)c->p.cx, (double)c->p.cy};
     B.delta = huber_delta; B.chi2_th = chi2_th; B.gp = (nx + 63) / 64; B.edges_by_point = 1;
     B.e_obs = e_obs; B.cull = (long long*)(base + o_cull); B.ncull = (int*)(base + o_ncull); B.cull_cap = ne; B.cull_host = nullptr; B.cull_host_cap = 0;      // (the engine points cull_host at its slot's pinned list)
-    BaPairPlan Q;
-    Q.ps_start = B.ps_start; Q.ps_edges = B.ps_edges; Q.ps_pt = (const int32_t*)(base + o_pspt); Q.nf = nf;
-    Q.cnt = (int*)(base + o_pcnt); Q.off = (int*)(base + o_poff); Q.n_slices = (int*)(base + o_pn); Q.n_pairs = (int*)(base + o_pn) + 1;
-    Q.blocks = (BaBlock*)(base + o_blk); Q.pairs = (int2*)(base + o_pairs);
-    if (!R.ev_arrays) HIP_TRY(hipEventCreateWithFlags(&R.ev_arrays, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(R.ev_arrays, st));
-    hipLaunchKernelGGL(k_ba_pairs<false>, dim3(nb_all), dim3(256), 4 * (size_t)std::max(max_len, 1), st, Q);
-    hipLaunchKernelGGL(k_ba_pairs_scan, dim3(1), dim3(1024), 0, st, Q, nb_all);
     hipLaunchKernelGGL(k_ba_pairs<true>, dim3(nb_all), dim3(256), 4 * (size_t)std::max(max_len, 1), st, Q);   // no wait: the solve follows on the engine's stream
     if (!R.ev) HIP_TRY(hipEventCreateWithFlags(&R.ev, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(R.ev, st));
