@@ -257,6 +257,7 @@ int vo_default_track_params(vo_track_params* t) {
 
 void vo_ctx_destroy(vo_ctx* c) {
     if (!c) return;
+    if (getenv("VO_TRACE") && c->n_pre_calls) fprintf(stderr, "[vo_trace] uploads: %lld preload calls (%lld refused: not page-locked), %lld frames preloaded, %lld of them taken by vo_frame_upload, %lld frames copied by vo_frame_upload itself\n", c->n_pre_calls, c->n_pre_unpinned, c->n_pre_frames, c->n_up_hit, c->n_up_copy);
     { std::unique_lock<std::mutex> lk(g_prof_mu); prof_collect(c); for (size_t i = 0; i < g_ctxs.size(); ++i) if (g_ctxs[i] == c) { g_ctxs.erase(g_ctxs.begin() + i); break; } }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -386,7 +387,9 @@ int vo_frames_preload(vo_ctx* c, int slot0, int n, const uint8_t* const* bgr, in
     hipPointerAttribute_t at;
     const bool pinned = hipPointerGetAttributes(&at, bgr[0]) == hipSuccess && at.type == hipMemoryTypeHost && hipPointerGetAttributes(&at, depth[0]) == hipSuccess && at.type == hipMemoryTypeHost;
     (void)hipGetLastError();
-    if (!pinned) return VO_OK;                              // pageable memory copies synchronously: nothing to gain, vo_frame_upload does it
+    ++c->n_pre_calls;
+    if (!pinned) { ++c->n_pre_unpinned; return VO_OK; }      // pageable memory copies synchronously: nothing to gain, vo_frame_upload does it
+    c->n_pre_frames += n;
     if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     if (!c->orb_ev) HIP_TRY(hipEventCreateWithFlags(&c->orb_ev, hipEventDisableTiming));
     const int F = c->p.max_frames, H = c->p.height;
@@ -439,6 +442,7 @@ int vo_frame_upload(vo_ctx* c, int slot, const uint8_t* bgr, int bs, const uint1
             if (ps.src_bgr == bgr && ps.src_depth == depth && ps.bs == bs && ps.ds == ds) {      // preloaded: the slot shows the slab's frame; the copy is waited for on the device
                 vo_ctx::PreSlab& sl = c->pre[ps.gen];
                 if (!sl.waited) { HIP_TRY(hipStreamWaitEvent(c->stream, sl.ev, 0)); sl.waited = true; }
+                ++c->n_up_hit;
                 c->h_slots[slot] = SlotDesc{sl.bgr + sl.nb * slot, sl.depth + sl.nd * slot, bs, ds};
                 c->slot_bound[slot] = 1; c->slot_orb[slot] = 0; c->slot_gen[slot] = (signed char)ps.gen;
                 return mark_slot(c, slot);
@@ -463,6 +467,7 @@ int vo_frame_upload(vo_ctx* c, int slot, const uint8_t* bgr, int bs, const uint1
     // only (H - 1) strides + one row of pixels are the caller's to read: the padding behind the LAST row need not exist (a column
     // slice of a wider image, a cv::Mat ROI); the slot itself is stride * H so that every row has its pitch
     const size_t cb = (size_t)bs * (H - 1) + 3 * (size_t)c->p.width, cd = (size_t)ds * (H - 1) + 2 * (size_t)c->p.width;
+    ++c->n_up_copy;
     HIP_TRY(hipMemcpyAsync(c->own_bgr[slot], bgr, cb, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->own_depth[slot], depth, cd, hipMemcpyHostToDevice, c->stream));
     c->h_slots[slot] = SlotDesc{c->own_bgr[slot], c->own_depth[slot], bs, ds};

@@ -130,6 +130,7 @@ struct vo_ctx {
     // device-resident keyframe bookkeeping: observation table and keyframe poses, fixed capacity (a back-end
     // thread may be reading them while the tracker appends: no reallocation, appends only write beyond what a reader was given)
     int32_t* d_obs_kf = nullptr; int32_t* d_obs_mp = nullptr; float* d_obs_uv = nullptr; uint8_t* d_obs_alive = nullptr;
+    long long n_pre_calls = 0, n_pre_unpinned = 0, n_pre_frames = 0, n_up_hit = 0, n_up_copy = 0;      // VO_TRACE: how the frames reached the device (vo_frames_preload / vo_frame_upload)
     long long n_obs = 0, obs_cap = 0, obs_cap_max = 0;     // entries used / allocated / the bound the table may grow to
     // what a keyframe's points reach back to (host bookkeeping of vo_obs_append; the resident graph cut enters the tables there): pt_first[slot] = table position of the
     // point's first observation (-1: none yet); kf_reach[kf] = minimum of that, and of the slot, over the points the keyframe observes
