@@ -192,6 +192,63 @@ def accuracy(ev, capi, stamps, Twc, est, i0, i1):
     return out
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run as a CHILD process (this process has not
+    imported torch nor made a HIP call), pass the child's output through, print rank 0's JSON line last, return the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for l in p.stdout:
+        if l.startswith("{") and '"metric"' in l:
+            line = l.rstrip("\n")
+        else:
+            sys.stderr.write(l)
+    rc = p.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks ended without a result line\n")
+        rc = 1
+    return rc
+
+
+def dry_run(args, shard, rank, local_rank, world):
+    """--dry-run: everything between the launcher and the line except the GPU -- process group, barrier, MAX over ranks, the SUM of ones,
+    the gather of every rank's record -- so that `bench.py --gpus 2 --dist-backend gloo --dry-run` can be tested where there is no GPU."""
+    if args.dist_backend == "nccl":
+        sys.stderr.write("bench.py: --dry-run makes no GPU call; use --dist-backend gloo\n")
+        return 2
+    grp = shard.Group(args.dist_backend)
+    grp.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))                           # stand-in for the timed region: rank r 'works' 10 (r + 1) ms
+    own = time.perf_counter() - t0
+    grp.barrier()
+    elapsed = grp.max_scalar(own)
+    ones = np.ones(1, dtype=np.int32)
+    grp.all_reduce_sum_i32(ones)
+    ranks = grp.gather_objects({"rank": rank, "local_rank": local_rank, "device": None, "pci_bus_id": None, "stream_seed": shard.stream_seed(args.seed, rank),
+                                "frames_per_s": None, "own_elapsed_s": round(own, 4)})
+    if rank == 0:
+        out = {"metric": "VO frames/sec (640x480 RGB-D)", "value": None, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f64", "data": "none (dry run)",
+               "dry_run": True, "config": {"workload": "DRY RUN: launcher and process-group rehearsal, nothing tracked"},
+               "roofline": None, "cpu_baseline": None, "max_elapsed_s": round(elapsed, 4),
+               "distributed": {"world_size": world, "backend": (args.dist_backend if world > 1 else None), "allreduce_sum_of_ones": int(ones[0]), "ranks": ranks}}
+        print(json.dumps(out, separators=(",", ":")), flush=True)
+    grp.close()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -217,15 +274,34 @@ def main():
     ap.add_argument("--host-graph", action="store_true", help="cut the local BA's graph on the host (Backend::Build) instead of on the device from the resident observation table")
     ap.add_argument("--multi-streams", default="8,16", help="comma list of stream counts for the several-streams-per-GPU figure ('' = skip)")
     ap.add_argument("--multi-device-graph", type=int, default=1, help="several-streams figure: 1 = the local BA's graph is cut on the device (as the single stream does), 0 = on the host")
+    ap.add_argument("--dry-run", action="store_true", help="rehearsal of the launch + process-group plumbing only: no GPU call, no tracking, `value` null and `dry_run` true in the line (CPU test of --gpus N)")
     args = ap.parse_args()
 
-    import torch
-    from rgbd_visualodometry_amd import capi, system, shard, evaluate as ev
+    # --gpus N means N ranks, one per GPU.  Under torchrun (the driver's N > 1 form) RANK / WORLD_SIZE are set and this process IS a rank;
+    # called directly with N > 1 the ranks are started here, as children, BEFORE this process imports torch or touches HIP (a process that
+    # has initialised the GPU must never be replaced or forked into ranks), and rank 0's line is relayed.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+
+    from rgbd_visualodometry_amd import shard
     rank, local_rank, world = shard.env_rank_world()
+    if world != args.gpus:                                  # never print an N-GPU line from a different number of ranks
+        sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks\n" % (args.gpus, world))
+        raise SystemExit(2)
+    if args.dry_run:
+        raise SystemExit(dry_run(args, shard, rank, local_rank, world))
+
+    import torch
+    from rgbd_visualodometry_amd import capi, system, evaluate as ev
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
     if args.same_device:
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        sys.stderr.write("bench.py: --gpus %d but only %d device(s) are visible (one rank per GPU; --same-device is the one-GPU rehearsal)\n" % (world, torch.cuda.device_count()))
+        raise SystemExit(2)
     torch.cuda.set_device(local_rank)
     grp = shard.Group(args.dist_backend, device=torch.device("cuda", local_rank))     # RCCL; only barrier + MAX(time) cross ranks
 
