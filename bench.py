@@ -125,6 +125,9 @@ def compact_line(full):
     if m:
         out["multi_stream"] = [{"streams_per_gpu": e.get("streams_per_gpu"), "frames_per_s": e.get("frames_per_s"),
                                 "vs_single_stream": e.get("vs_single_stream"), "hbm_frac_whole_frame": e.get("hbm_frac_whole_frame")} for e in m[:4]]
+    n5 = full.get("default_yaml")
+    if n5:
+        out["n500"] = {k: n5.get(k) for k in ("gpu", "cpu1", "ratio", "ate_gpu", "ate_cpu")}
     d = full.get("distributed")
     if d:
         ranks = d.get("ranks") or []
@@ -134,7 +137,7 @@ def compact_line(full):
     out["detail"] = "bench_detail.json"
     line = json.dumps(out, separators=(",", ":"))
     if len(line) >= LINE_LIMIT:                              # never expected; drop the optional summaries rather than overflow
-        for k in ("distributed", "multi_stream", "orb_only", "latency_mode", "upload_inclusive"):
+        for k in ("distributed", "multi_stream", "orb_only", "latency_mode", "upload_inclusive", "n500"):
             out.pop(k, None)
             line = json.dumps(out, separators=(",", ":"))
             if len(line) < LINE_LIMIT:
@@ -272,6 +275,7 @@ def main():
     ap.add_argument("--no-latency-mode", action="store_true")
     ap.add_argument("--prologue", type=int, default=150, help="frames tracked (untimed) before the warmup so that the timed steps see the steady-state map: covisible window, BA size and active-map size level off after ~100 frames; 0 = time a young map")
     ap.add_argument("--host-graph", action="store_true", help="cut the local BA's graph on the host (Backend::Build) instead of on the device from the resident observation table")
+    ap.add_argument("--host-keyframes", action="store_true", help="keep the keyframe bookkeeping in host objects (round 4's path) instead of on the device tables (device_keyframes)")
     ap.add_argument("--multi-streams", default="8,16", help="comma list of stream counts for the several-streams-per-GPU figure ('' = skip)")
     ap.add_argument("--multi-device-graph", type=int, default=1, help="several-streams figure: 1 = the local BA's graph is cut on the device (as the single stream does), 0 = on the host")
     ap.add_argument("--dry-run", action="store_true", help="rehearsal of the launch + process-group plumbing only: no GPU call, no tracking, `value` null and `dry_run` true in the line (CPU test of --gpus N)")
@@ -324,7 +328,8 @@ def main():
     dptr = [d_depth.data_ptr() + i * fd for i in range(n_render)]
 
     opts = dict(width=W, height=H, number_of_features=N, max_frames_in_flight=args.lookahead, device=local_rank,
-                enable_local_optimization=0 if args.no_ba else 1, backend_lag_frames=args.ba_lag, track_batch=args.track_batch, map_capacity=1 << 20, ransac_iterations=args.hyps, ba_device_graph=0 if args.host_graph else 1, map_descriptors_on_device=1, chi2_th=args.chi2_th)
+                enable_local_optimization=0 if args.no_ba else 1, backend_lag_frames=args.ba_lag, track_batch=args.track_batch, map_capacity=1 << 20, ransac_iterations=args.hyps, ba_device_graph=0 if args.host_graph else 1, map_descriptors_on_device=1, chi2_th=args.chi2_th,
+                device_keyframes=0 if (args.host_graph or args.host_keyframes) else 1)
 
     # One-time costs (code-object load, pinned staging, scratch growth) are paid on a throw-away system before the
     # warmup: the driver's short runs (--warmup 5) then time the same steady state as the long ones.
@@ -530,7 +535,7 @@ def main():
             def run_streams(S, grouped):
                 grp_ = system.StreamGroup(system.HOST_LIB, local_rank, 128) if grouped else None
                 # the GPU is the shared resource here and host cores are idle: the local BA's graph is cut on the host
-                syss = [system.VoSystem(system.HOST_LIB, **{**opts, "ba_device_graph": 1 if args.multi_device_graph else 0}) for _ in range(S)]
+                syss = [system.VoSystem(system.HOST_LIB, **{**opts, "ba_device_graph": 1 if args.multi_device_graph else 0, "device_keyframes": opts["device_keyframes"] if args.multi_device_graph else 0}) for _ in range(S)]
                 if grp_:
                     for s in syss:
                         grp_.join(s)
@@ -572,7 +577,7 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             from oracle import ORACLE_LIB                   # the checker, timed as the CPU baseline (never on the product path)
-            copts = {**opts, "max_frames_in_flight": 1, "track_batch": 1, "backend_lag_frames": 0, "ba_device_graph": 0, "map_descriptors_on_device": 0}
+            copts = {**opts, "max_frames_in_flight": 1, "track_batch": 1, "backend_lag_frames": 0, "ba_device_graph": 0, "map_descriptors_on_device": 0, "device_keyframes": 0}
             # ONE oracle run gives both figures: the first `cpu_frames` frames from a fresh map (round 1/2's sample, kept as a variant)
             # and -- after the rest of the GPU's untimed prologue -- the SAME steady-state frames the GPU was timed on (a bounded prefix)
             nf = min(args.cpu_frames, Wm)
@@ -629,6 +634,39 @@ def main():
                    "all_cores": {"value": round(T_all * nfa / ta, 2), "unit": "frames/s", "cores": T_all,
                                  "sample": "%d independent streams (first %d frames each), one per thread" % (T_all, nfa)},
                    "host_cpus": os.cpu_count(), "cpu_model": cpu_model}
+        # ---- the target's own configuration (north_star: ">= 30x the reference CPU on TUM fr1_xyz, default.yaml"): default.yaml's 500 features
+        # (config/default.yaml:18) on the same synthetic stream, GPU and single-thread CPU restatement on the SAME timed frames, ATE of both
+        n500 = None
+        if world == 1 and not args.no_cpu_baseline and N != 500:
+            o5 = dict(opts, number_of_features=500)
+            p5 = system.VoSystem(system.HOST_LIB, **o5)
+            drive(p5, stamps, bptr, dptr, 0, min(total, 64), args.lookahead, W); p5.flush(); p5.close()      # scratch of this size class is grown before the timed pass
+            s5 = system.VoSystem(system.HOST_LIB, **o5)
+            est5 = {}
+            drive(s5, stamps, bptr, dptr, 0, Wm, args.lookahead, W, est5); s5.flush(); torch.cuda.synchronize()
+            st5w = s5.stats()
+            t5 = time.perf_counter()
+            drive(s5, stamps, bptr, dptr, Wm, total, args.lookahead, W, est5); s5.flush(); torch.cuda.synchronize()
+            t5 = time.perf_counter() - t5
+            st5 = s5.stats(); s5.close()
+            from oracle import ORACLE_LIB                   # the checker, timed as the CPU baseline (never on the product path)
+            c5 = system.VoSystem(ORACLE_LIB, **{**o5, "max_frames_in_flight": 1, "track_batch": 1, "backend_lag_frames": 0, "ba_device_graph": 0, "map_descriptors_on_device": 0, "device_keyframes": 0})
+            estc5 = {}
+            for i in range(Wm):
+                ok, T = c5.add_frame(stamps[i], bgr[i], depth[i]); estc5[stamps[i]] = T
+            ns5 = min(2 * args.cpu_steady_frames, K)
+            tc5 = time.perf_counter()
+            for i in range(Wm, Wm + ns5):
+                ok, T = c5.add_frame(stamps[i], bgr[i], depth[i]); estc5[stamps[i]] = T
+            tc5 = time.perf_counter() - tc5
+            c5.close()
+            g5, k5 = K / t5, ns5 / tc5
+            n500 = {"features": 500, "gpu": round(g5, 1), "cpu1": round(k5, 2), "ratio": round(g5 / k5, 1),
+                    "ate_gpu": accuracy(ev, capi, stamps, Twc, est5, 0, Wm + ns5)["ate_rmse_m"], "ate_cpu": accuracy(ev, capi, stamps, Twc, estc5, 0, Wm + ns5)["ate_rmse_m"],
+                    "ate_gpu_all_frames": accuracy(ev, capi, stamps, Twc, est5, 0, total)["ate_rmse_m"],
+                    "gpu_timed_frames": K, "cpu_timed_frames": ns5, "keyframes_timed": st5["keyframes"] - st5w["keyframes"], "lost": st5["lost"],
+                    "note": "default.yaml's number_of_features (500), everything else as the headline workload; cpu1 = oracle port, 1 thread, synchronous BA, "
+                            "timed on the first %d of the GPU's timed frames after the same %d-frame prologue; ATE over frames 0..%d for both" % (ns5, Wm, Wm + ns5 - 1)}
         kf_timed = st["keyframes"] - st_w["keyframes"]
         out = {
             "metric": "VO frames/sec (640x480 RGB-D)", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -639,6 +677,7 @@ def main():
                        "streams_per_gpu": 1, "lookahead_frames": args.lookahead, "track_batch": args.track_batch,
                        "local_ba": (False if args.no_ba else ("synchronous" if args.ba_lag == 0 else "overlapped, merged %d frames later or at the next keyframe" % args.ba_lag)),
                        "ransac_hypotheses": args.hyps, "speed": args.speed, "ba_graph_cut": "host" if args.host_graph else "device (resident observation table)",
+                       "keyframe_bookkeeping": "host objects" if (args.host_graph or args.host_keyframes) else "device tables (vo_keyframe_commit)",
                        "prologue_frames": args.prologue, "timed_frames": "frames %d..%d of the stream (steady state: the map and the local-BA window have levelled off)" % (Wm, total - 1)},
             **acc, "keyframes": st["keyframes"], "keyframes_timed": kf_timed, "ba_runs": st["ba_runs"], "ba_runs_timed": st["ba_runs"] - st_w["ba_runs"],
             "lost": st["lost"], "map_points": st["map_points"],
@@ -649,7 +688,7 @@ def main():
             "avg_per_tracked_frame": {"active_map_points": round(A, 1), "candidates": round(M, 1), "matches": round(Kc, 1), "ransac_inliers": round(I, 1),
                                       "lm_iterations": round(pst["sum_lm_iters"] / tf, 2), "frames_per_launch_chain": round(tf / max(1, pst["track_launches"]), 2)},
             "roofline": roof, "orb_only": orb_only, "latency_mode": lat, "multi_stream": multi, "upload_inclusive": upl, "cpu_baseline": cpu,
-            "distributed": dist_info,
+            "distributed": dist_info, "default_yaml": n500,
         }
         write_detail(out)
         sys.stdout.flush()

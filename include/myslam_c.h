@@ -37,6 +37,10 @@ typedef struct myslam_options {
     int32_t reobserve_new_mappoints;        /* 1: run the reference's disabled re-observation pass (frontend.cpp:408-463) at every keyframe */
     int32_t map_descriptors_on_device;      /* 1: new map points take their descriptor from the frame's ORB results on the device (vo_map_upsert_from_frame);
                                                descriptors are never fetched to the host */
+    int32_t device_keyframes;               /* 1 (needs ba_device_graph and map_descriptors_on_device): the keyframe bookkeeping -- observations, covisibility weights,
+                                               new map points, the triangulation loop, the local-map query, the BA write-back -- runs on the device tables
+                                               (vo_keyframe_commit, vo_map_set_active_covisible, vo_local_ba_resident_merge_ledger); the host keeps keyframe poses and
+                                               covisibility ledgers and builds Mappoint objects only on request (myslam_materialize).  SURVEY 8f-2 */
 } myslam_options;
 
 typedef struct myslam_stats {
@@ -115,6 +119,12 @@ int myslam_scn_mappoint(myslam_system* s, int64_t mappoint_id, int* outlier, int
 /* Run the local BA of a keyframe synchronously and merge it (Backend::Optimize incl. write-back, src/backend.cpp:19-195). */
 int myslam_scn_run_ba(myslam_system* s, int64_t keyframe_id);
 int myslam_scn_keyframe_pose(myslam_system* s, int64_t keyframe_id, double T_cw[12]);
+/* device_keyframes: rebuild the host map objects (Mappoint, observation lists, Frame observation sets) from the device tables as of now, so
+ * that the taps above and MapManager's containers show the run's map; keyframe ids in insertion order -> ids[cap], *n = their number.
+ * 1 in *on_device iff the system keeps its keyframes on the device. */
+int myslam_materialize(myslam_system* s, int64_t* keyframe_ids, int cap, int* n, int* on_device);
+/* map point ids in device-slot order (after myslam_materialize for a device_keyframes system) */
+int myslam_mappoint_ids(myslam_system* s, int64_t* ids, int cap, int* n);
 const char* myslam_backend_name(void);
 #ifdef __cplusplus
 }

@@ -340,6 +340,57 @@ int vo_ba_resident_graph(vo_ctx* ctx, vo_ctx* tables, const int32_t* free_kf, in
  * how long the run has been (the reference's Backend walks only the covisible keyframes' observation maps: src/backend.cpp:36-120). */
 int vo_ba_resident_window(vo_ctx* ctx, int64_t* observations_visited, int64_t* map_slots_visited);
 
+/* ---- keyframe bookkeeping on the device (the rest of the row) ------------- */
+/* What FrontEnd::TrackingHandler does to host objects when a frame becomes a keyframe (reference src/frontend.cpp:119-131), done on the
+ * tables above without a trip through the host: the tracking chain's match records, the frame's keypoints, depth samples and descriptors
+ * and the map are all resident already.  One call =
+ *   AddCurrentKeyframeObservations   src/frontend.cpp:366-370   one observation per LM-inlier match (match order); Frame::AddObservedMappoint
+ *                                    src/frame.cpp:93-120: the map point's mean viewing direction (src/mappoint.cpp:30-38) and the
+ *                                    covisibility weight of every keyframe that already sees the point (+1 per shared point);
+ *   CreateNewMappoints               src/frontend.cpp:372-406   every keypoint that is no LM inlier and has depth becomes a map point at
+ *                                    Camera::Pixel2World (src/camera.cpp:41-86) with its descriptor row; slots first_new_slot, +1, ... in
+ *                                    keypoint order; one observation each, behind the matched ones;
+ *   TriangulateMappointsInTrackingMap src/frontend.cpp:465-506  the LM-inlier points that are neither outliers nor triangulated nor optimised
+ *                                    are triangulated from all their live observations (include/myslam/util.h:16-34) in match order; the FIRST
+ *                                    that succeeds with z > 0 is moved and flagged (the reference's loop breaks there, :501);
+ *   the keyframe's pose and observations in the tables (what vo_kf_set_pose / vo_obs_append do from host arrays).
+ * lane: lane of the context's last tracking call that holds this frame's match records (-1: no matches -- the first keyframe).
+ * covis_kf / covis_weight receive the keyframes (ascending number) that share >= 1 live observation's point with the new one and the
+ * counts: allCovisibleKeyframeIdToWeight_ of the new keyframe (include/myslam/frame.h:94); the caller keeps the ledger.  More than
+ * cap_covis partners: VO_E_OVERFLOW (nothing is lost on the device; the weights can be read again with vo_kf_covisibility).
+ * The map flags carry Mappoint::triangulated_ / optimized_ beside outlier_ (VO_MAP_FLAG_*). */
+#define VO_MAP_FLAG_TRIANGULATED 2   /* Mappoint::triangulated_ (src/frontend.cpp:498) */
+#define VO_MAP_FLAG_OPTIMIZED    4   /* Mappoint::optimized_    (src/backend.cpp:190)  */
+typedef struct vo_kf_commit_result {
+    int32_t n_matched;          /* observations added for LM-inlier matches                                        */
+    int32_t n_new;              /* map points created: slots first_new_slot .. first_new_slot + n_new - 1          */
+    int64_t first_obs;          /* observation id of the first record appended (matched ones first, then the new)  */
+    int32_t n_covisible;        /* entries written to covis_kf / covis_weight                                      */
+    int32_t n_tri_candidates;   /* points the triangulation loop looked at                                         */
+    int32_t triangulated_slot;  /* map slot moved by the first successful triangulation, -1: none                  */
+    int32_t reserved;
+} vo_kf_commit_result;
+int vo_keyframe_commit(vo_ctx* ctx, int lane, int frame_slot, int32_t kf, const double T_cw[12], int32_t first_new_slot,
+                       int32_t* covis_kf, int32_t* covis_weight, int cap_covis, vo_kf_commit_result* out);
+/* Covisibility weights of keyframe `kf` recounted from the tables (live observations only): the parity tap of the ledger. */
+int vo_kf_covisibility(vo_ctx* ctx, int32_t kf, int32_t* covis_kf, int32_t* covis_weight, int cap, int32_t* n);
+/* MapManager::GetMappointsAroundKeyframe (reference src/mapmanager.cpp:14-38) + the tracking-map rule of src/frontend.cpp:159-166 on the
+ * device: the active list becomes the non-outlier map points the listed keyframes observe (live observations), ordered by the first
+ * listed keyframe that sees them and by observation order inside it; fewer than min_points of them: every slot below n_map_points
+ * (the reference falls back to GetAllMappoints).  Replaces vo_map_set_active for a caller that keeps no host map. */
+int vo_map_set_active_covisible(vo_ctx* ctx, const int32_t* kf, int n, int min_points, int32_t n_map_points, int32_t* n_active);
+/* vo_local_ba_resident_merge for a caller that keeps no host map objects: besides positions, free poses and culled observations, every
+ * point of the graph is flagged VO_MAP_FLAG_OPTIMIZED (src/backend.cpp:190), a point that lost its last live observation becomes an
+ * outlier (Mappoint::RemoveObservedByKeyframe, src/mappoint.cpp:40-45), and the covisibility ledger's decrements come back as keyframe
+ * pairs: culling the observation (K, P) costs K and every other keyframe that still sees P one shared point (Frame::RemoveObservedMappoint,
+ * src/frame.cpp:122-152).  poses receives the n_free optimised poses (what _fetch would bring).  Waits for the tables' stream. */
+int vo_local_ba_resident_merge_ledger(vo_ctx* ctx, vo_ctx* tables, int32_t* pair_a, int32_t* pair_b, int cap_pairs, int32_t* n_pairs,
+                                      double* poses, int cap_poses);
+/* Parity / inspection tap: the tables as they stand.  Any pointer may be NULL; n_obs / n_map receive the totals. */
+int vo_tables_fetch(vo_ctx* ctx, int64_t obs0, int64_t obs_cap, int32_t* obs_kf, int32_t* obs_mp, float* obs_uv, uint8_t* obs_alive, int64_t* n_obs,
+                    int32_t map0, int32_t map_cap, double* map_xyz, double* map_normal, uint8_t* map_desc, uint8_t* map_flags,
+                    int32_t* active, int active_cap, int32_t* n_active);
+
 /* ---- plumbing ------------------------------------------------------------------------- */
 int vo_sync(vo_ctx* ctx);
 /* Per-kernel accumulated device time measured with HIP events on the context's stream

@@ -513,6 +513,197 @@ int vo_local_ba_resident(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int n_fre
     if (rc0) return rc0;
     return vo_local_ba_resident_solve(c, it_robust, it_plain, out);
 }
+// ---- keyframe bookkeeping on the tables: plain loops over the whole observation table, restating reference
+// src/frontend.cpp:366-406 (observations of the LM inliers, new map points), src/frame.cpp:93-152 (covisibility weights),
+// src/mappoint.cpp:30-45 (mean viewing direction, outlier when the last observation goes), src/frontend.cpp:465-506 (first-success
+// triangulation) and src/mapmanager.cpp:14-38 (local map).  The HIP library walks per-point chains instead; same results.
+namespace {
+struct KV3 { double v[3]; };
+inline KV3 kv3_norm(const KV3& a) { const double n = std::sqrt(a.v[0] * a.v[0] + a.v[1] * a.v[1] + a.v[2] * a.v[2]); return KV3{{a.v[0] / n, a.v[1] / n, a.v[2] / n}}; }
+// camera centre = translation of T^-1 = (R^T t) * -1 (SE3::inverse of the host layer, operation for operation)
+inline KV3 cam_center(const double T[12]) {
+    KV3 c;
+    for (int i = 0; i < 3; ++i) c.v[i] = (T[i] * T[9] + T[3 + i] * T[10] + T[6 + i] * T[11]) * -1.0;
+    return c;
+}
+// live observations of a map slot in table order (= ascending keyframe number)
+void observers_of(const vo_ctx* c, int slot, std::vector<int64_t>& out) {
+    out.clear();
+    for (size_t o = 0; o < c->obs_mp.size(); ++o) if (c->obs_alive[o] && c->obs_mp[o] == slot) out.push_back((int64_t)o);
+}
+}  // namespace
+
+int vo_keyframe_commit(vo_ctx* c, int lane, int frame_slot, int32_t kf, const double T[12], int32_t first_new_slot,
+                       int32_t* covis_kf, int32_t* covis_weight, int cap_covis, vo_kf_commit_result* out) {
+    if (!c || !T || !out || kf < 0 || frame_slot < 0 || frame_slot >= (int)c->slots.size() || first_new_slot < 0 || cap_covis < 0 || (cap_covis && (!covis_kf || !covis_weight))) return VO_E_INVALID;
+    if (lane >= (int)c->lane_matches.size()) return VO_E_INVALID;
+    auto& s = c->slots[frame_slot];
+    if (!s.has_orb) return VO_E_STATE;
+    static const std::vector<vo_match> none;
+    const std::vector<vo_match>& ms = lane >= 0 ? c->lane_matches[lane] : none;
+    const int nkp = (int)s.kps.size();
+    const KV3 C = cam_center(T);
+    std::memset(out, 0, sizeof(*out));
+    out->first_obs = (int64_t)c->obs_kf.size(); out->triangulated_slot = -1;
+    std::vector<char> matched(nkp, 0);
+    std::vector<int32_t> inl;                                // map slots of the LM inliers, match order
+    for (const vo_match& m : ms) if (m.flags & VO_MATCH_LM_INLIER) { if (m.kp_index < 0 || m.kp_index >= nkp || m.map_index < 0 || m.map_index >= c->p.map_capacity) return VO_E_INVALID; inl.push_back(m.map_index); }
+    // covisibility (src/frame.cpp:104-119): every keyframe that already sees an inlier point gains one shared point with the new keyframe
+    std::vector<int32_t> w;
+    {
+        std::vector<char> is_inl(c->p.map_capacity, 0);
+        for (int32_t sl : inl) is_inl[sl] = 1;
+        for (size_t o = 0; o < c->obs_mp.size(); ++o)
+            if (c->obs_alive[o] && is_inl[c->obs_mp[o]] && c->obs_kf[o] != kf) { if ((size_t)c->obs_kf[o] >= w.size()) w.resize((size_t)c->obs_kf[o] + 1, 0); ++w[c->obs_kf[o]]; }
+    }
+    // AddCurrentKeyframeObservations (src/frontend.cpp:366-370)
+    for (const vo_match& m : ms) {
+        if (!(m.flags & VO_MATCH_LM_INLIER)) continue;
+        const size_t sl = (size_t)m.map_index;
+        matched[m.kp_index] = 1;
+        c->obs_kf.push_back(kf); c->obs_mp.push_back(m.map_index); c->obs_uv.push_back(s.kps[m.kp_index].x); c->obs_uv.push_back(s.kps[m.kp_index].y); c->obs_alive.push_back(1);
+        const KV3 d = kv3_norm(KV3{{c->map.pos[3 * sl] - C.v[0], c->map.pos[3 * sl + 1] - C.v[1], c->map.pos[3 * sl + 2] - C.v[2]}});      // src/mappoint.cpp:30-38
+        const KV3 n = kv3_norm(KV3{{c->map.nrm[3 * sl] + d.v[0], c->map.nrm[3 * sl + 1] + d.v[1], c->map.nrm[3 * sl + 2] + d.v[2]}});
+        for (int a = 0; a < 3; ++a) c->map.nrm[3 * sl + a] = n.v[a];
+        ++out->n_matched;
+    }
+    // CreateNewMappoints (src/frontend.cpp:372-406): Pixel2World = T^-1 * ((u - cx) d / fx, (v - cy) d / fy, d)
+    const double fx = c->p.fx, fy = c->p.fy, cx = c->p.cx, cy = c->p.cy;
+    const KV3 tinv = C;
+    for (int i = 0; i < nkp; ++i) {
+        if (matched[i] || s.kps[i].depth_raw == 0) continue;
+        const int32_t sl = first_new_slot + out->n_new;
+        if (sl >= c->p.map_capacity) return VO_E_OVERFLOW;
+        const double depth = double(s.kps[i].depth_raw) / c->p.depth_scale;
+        const double pc[3] = {((double)s.kps[i].x - cx) * depth / fx, ((double)s.kps[i].y - cy) * depth / fy, depth};
+        KV3 pw;
+        for (int a = 0; a < 3; ++a) pw.v[a] = (T[a] * pc[0] + T[3 + a] * pc[1] + T[6 + a] * pc[2]) + tinv.v[a];       // R^T p + t'
+        const KV3 n = kv3_norm(kv3_norm(KV3{{pw.v[0] - C.v[0], pw.v[1] - C.v[1], pw.v[2] - C.v[2]}}));                    // (0 + d).normalized(), d normalised
+        for (int a = 0; a < 3; ++a) { c->map.pos[3 * (size_t)sl + a] = pw.v[a]; c->map.nrm[3 * (size_t)sl + a] = n.v[a]; }
+        std::memcpy(&c->map.desc[32 * (size_t)sl], &s.desc[(size_t)32 * i], 32);
+        c->map.flags[sl] = 0;
+        c->obs_kf.push_back(kf); c->obs_mp.push_back(sl); c->obs_uv.push_back(s.kps[i].x); c->obs_uv.push_back(s.kps[i].y); c->obs_alive.push_back(1);
+        ++out->n_new;
+    }
+    // the keyframe's pose
+    if ((size_t)12 * (kf + 1) > c->kf_pose.size()) c->kf_pose.resize((size_t)12 * (kf + 1), 0.0);
+    std::memcpy(&c->kf_pose[12 * (size_t)kf], T, 96);
+    // TriangulateMappointsInTrackingMap (src/frontend.cpp:465-506): match order, first success wins
+    std::vector<int64_t> ob; std::vector<double> Ts, xy;
+    for (int32_t sl : inl) {
+        if (c->map.flags[sl] & (VO_MAP_FLAG_OUTLIER | VO_MAP_FLAG_TRIANGULATED | VO_MAP_FLAG_OPTIMIZED)) continue;
+        ++out->n_tri_candidates;
+        observers_of(c, sl, ob);
+        if (ob.size() < 2) continue;
+        Ts.clear(); xy.clear();
+        for (int64_t o : ob) {
+            const double* P = &c->kf_pose[12 * (size_t)c->obs_kf[o]];
+            Ts.insert(Ts.end(), P, P + 12);
+            xy.push_back(((double)c->obs_uv[2 * o] - cx) * 1.0 / fx); xy.push_back(((double)c->obs_uv[2 * o + 1] - cy) * 1.0 / fy);      // Camera::Pixel2Camera, depth 1
+        }
+        double x[3];
+        if (triangulate_point((int)ob.size(), Ts.data(), xy.data(), x) && x[2] > 0) {
+            for (int a = 0; a < 3; ++a) c->map.pos[3 * (size_t)sl + a] = x[a];
+            c->map.flags[sl] |= VO_MAP_FLAG_TRIANGULATED;
+            out->triangulated_slot = sl;
+            break;                                           // src/frontend.cpp:501
+        }
+    }
+    int k = 0;
+    for (size_t q = 0; q < w.size(); ++q) if (w[q] > 0) { if (k < cap_covis) { covis_kf[k] = (int32_t)q; covis_weight[k] = w[q]; } ++k; }
+    out->n_covisible = std::min(k, cap_covis);
+    return k > cap_covis ? VO_E_OVERFLOW : VO_OK;
+}
+
+int vo_kf_covisibility(vo_ctx* c, int32_t kf, int32_t* covis_kf, int32_t* covis_weight, int cap, int32_t* n) {
+    if (!c || kf < 0 || !n || cap < 0 || (cap && (!covis_kf || !covis_weight))) return VO_E_INVALID;
+    std::vector<char> seen(c->p.map_capacity, 0);
+    for (size_t o = 0; o < c->obs_mp.size(); ++o) if (c->obs_alive[o] && c->obs_kf[o] == kf) seen[c->obs_mp[o]] = 1;
+    std::vector<int32_t> w;
+    for (size_t o = 0; o < c->obs_mp.size(); ++o)
+        if (c->obs_alive[o] && c->obs_kf[o] != kf && seen[c->obs_mp[o]]) { if ((size_t)c->obs_kf[o] >= w.size()) w.resize((size_t)c->obs_kf[o] + 1, 0); ++w[c->obs_kf[o]]; }
+    int k = 0;
+    for (size_t q = 0; q < w.size(); ++q) if (w[q] > 0) { if (k < cap) { covis_kf[k] = (int32_t)q; covis_weight[k] = w[q]; } ++k; }
+    *n = k;
+    return k > cap ? VO_E_OVERFLOW : VO_OK;
+}
+
+int vo_map_set_active_covisible(vo_ctx* c, const int32_t* kf, int n, int min_points, int32_t n_map_points, int32_t* n_active) {
+    if (!c || n < 0 || (n && !kf) || n_map_points < 0 || n_map_points > c->p.map_capacity) return VO_E_INVALID;
+    std::vector<int32_t> ks(kf, kf + n);
+    std::sort(ks.begin(), ks.end());
+    std::vector<char> seen(c->p.map_capacity, 0);
+    c->map.active.clear();
+    for (int32_t k : ks)                                     // keyframes in ascending order, each one's observations in table order (src/mapmanager.cpp:14-38)
+        for (size_t o = 0; o < c->obs_mp.size(); ++o) {
+            if (!c->obs_alive[o] || c->obs_kf[o] != k) continue;
+            const int32_t sl = c->obs_mp[o];
+            if (seen[sl] || (c->map.flags[sl] & VO_MAP_FLAG_OUTLIER)) continue;
+            seen[sl] = 1; c->map.active.push_back(sl);
+        }
+    if ((int)c->map.active.size() < min_points) {            // src/frontend.cpp:163-166: the whole map
+        c->map.active.resize((size_t)n_map_points);
+        for (int32_t i = 0; i < n_map_points; ++i) c->map.active[i] = i;
+    }
+    if (n_active) *n_active = (int32_t)c->map.active.size();
+    return VO_OK;
+}
+
+int vo_local_ba_resident_merge_ledger(vo_ctx* c, vo_ctx* t, int32_t* pair_a, int32_t* pair_b, int cap_pairs, int32_t* n_pairs, double* poses, int cap_poses) {
+    if (!c || !t || !n_pairs || cap_pairs < 0 || (cap_pairs && (!pair_a || !pair_b)) || cap_poses < 0 || (cap_poses && !poses)) return VO_E_INVALID;
+    if (!c->solved.ready || c->solved.merged) return VO_E_STATE;
+    auto& S = c->solved;
+    // Frame::RemoveObservedMappoint (src/frame.cpp:122-152), one culled observation after the other in ascending id order: the keyframes that
+    // STILL see the point lose one shared point with the culled observation's keyframe; a point without observations becomes an outlier
+    std::vector<int64_t> cu(S.culled.begin(), S.culled.end());
+    std::sort(cu.begin(), cu.end());
+    int np = 0;
+    std::vector<int64_t> ob;
+    for (int64_t id : cu) {
+        if (id < 0 || id >= (int64_t)t->obs_alive.size() || !t->obs_alive[(size_t)id]) continue;
+        t->obs_alive[(size_t)id] = 0;
+        observers_of(t, t->obs_mp[(size_t)id], ob);
+        for (int64_t o : ob) { if (np < cap_pairs) { pair_a[np] = t->obs_kf[(size_t)id]; pair_b[np] = t->obs_kf[(size_t)o]; } ++np; }
+        if (ob.empty()) t->map.flags[t->obs_mp[(size_t)id]] |= VO_MAP_FLAG_OUTLIER;       // src/mappoint.cpp:40-45
+    }
+    for (size_t k = 0; k < S.slots.size(); ++k) {            // src/backend.cpp:188-194
+        const size_t slot = (size_t)S.slots[k];
+        t->map.flags[slot] |= VO_MAP_FLAG_OPTIMIZED;
+        if (t->map.flags[slot] & VO_MAP_FLAG_OUTLIER) continue;
+        std::memcpy(&t->map.pos[3 * slot], &S.pts[3 * k], 24);
+    }
+    for (size_t p = 0; p < S.pose_kf.size(); ++p) std::memcpy(&t->kf_pose[12 * (size_t)S.pose_kf[p]], &S.poses[12 * p], 96);      // src/backend.cpp:183-187
+    if (poses) std::memcpy(poses, S.poses.data(), 8 * std::min(S.poses.size(), (size_t)12 * cap_poses));
+    S.merged = true;
+    c->staged = S;
+    *n_pairs = std::min(np, cap_pairs);
+    return np > cap_pairs ? VO_E_OVERFLOW : VO_OK;
+}
+
+int vo_tables_fetch(vo_ctx* c, int64_t obs0, int64_t obs_cap, int32_t* obs_kf, int32_t* obs_mp, float* obs_uv, uint8_t* obs_alive, int64_t* n_obs,
+                    int32_t map0, int32_t map_cap, double* map_xyz, double* map_normal, uint8_t* map_desc, uint8_t* map_flags,
+                    int32_t* active, int active_cap, int32_t* n_active) {
+    if (!c || obs0 < 0 || obs_cap < 0 || map0 < 0 || map_cap < 0 || map0 + (int64_t)map_cap > c->p.map_capacity || active_cap < 0) return VO_E_INVALID;
+    const int64_t no = (int64_t)c->obs_kf.size();
+    if (n_obs) *n_obs = no;
+    const int64_t take = std::max<int64_t>(0, std::min(obs_cap, no - obs0));
+    if (take > 0) {
+        if (obs_kf) std::memcpy(obs_kf, &c->obs_kf[(size_t)obs0], 4 * (size_t)take);
+        if (obs_mp) std::memcpy(obs_mp, &c->obs_mp[(size_t)obs0], 4 * (size_t)take);
+        if (obs_uv) std::memcpy(obs_uv, &c->obs_uv[2 * (size_t)obs0], 8 * (size_t)take);
+        if (obs_alive) std::memcpy(obs_alive, &c->obs_alive[(size_t)obs0], (size_t)take);
+    }
+    if (map_cap > 0) {
+        if (map_xyz) std::memcpy(map_xyz, &c->map.pos[3 * (size_t)map0], 24 * (size_t)map_cap);
+        if (map_normal) std::memcpy(map_normal, &c->map.nrm[3 * (size_t)map0], 24 * (size_t)map_cap);
+        if (map_desc) std::memcpy(map_desc, &c->map.desc[32 * (size_t)map0], 32 * (size_t)map_cap);
+        if (map_flags) std::memcpy(map_flags, &c->map.flags[(size_t)map0], (size_t)map_cap);
+    }
+    if (n_active) *n_active = (int32_t)c->map.active.size();
+    if (active) std::memcpy(active, c->map.active.data(), 4 * (size_t)std::min<size_t>(active_cap, c->map.active.size()));
+    return VO_OK;
+}
+
 // Stream groups: on the CPU every call is computed on the spot; the group only counts (the fused launch chain is a property
 // of the HIP implementation, the results are defined to be those of un-grouped calls).
 struct vo_group { long long requests = 0; int members = 0; };

@@ -53,6 +53,11 @@ class VoBaResidentResult(C.Structure):
                 ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lm_iters", C.c_int32), ("reserved", C.c_int32)]
 
 
+class VoKfCommitResult(C.Structure):
+    _fields_ = [("n_matched", C.c_int32), ("n_new", C.c_int32), ("first_obs", C.c_int64), ("n_covisible", C.c_int32), ("n_tri_candidates", C.c_int32),
+                ("triangulated_slot", C.c_int32), ("reserved", C.c_int32)]
+
+
 class VoBaResult(C.Structure):
     _fields_ = [("poses", C.c_void_p), ("points", C.c_void_p), ("edge_flags", C.c_void_p),
                 ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lm_iters", C.c_int32),
@@ -71,7 +76,8 @@ SYMBOLS = ["vo_ctx_create", "vo_ctx_destroy", "vo_strerror", "vo_backend_name", 
            "vo_local_ba", "vo_sync", "vo_profile_enable", "vo_profile_read",
            "vo_group_create", "vo_group_destroy", "vo_group_join", "vo_group_leave", "vo_group_set_gather", "vo_group_stats",
            "vo_set_hypothesis_shard", "vo_set_hypothesis_shard_stream", "vo_triangulate_batch", "vo_kf_set_pose", "vo_obs_append", "vo_obs_kill", "vo_local_ba_resident",
-           "vo_local_ba_resident_cut", "vo_local_ba_resident_solve", "vo_local_ba_resident_merge", "vo_local_ba_resident_fetch", "vo_ba_resident_graph", "vo_ba_resident_window"]
+           "vo_local_ba_resident_cut", "vo_local_ba_resident_solve", "vo_local_ba_resident_merge", "vo_local_ba_resident_fetch", "vo_ba_resident_graph", "vo_ba_resident_window",
+           "vo_keyframe_commit", "vo_kf_covisibility", "vo_map_set_active_covisible", "vo_local_ba_resident_merge_ledger", "vo_tables_fetch"]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int32), C.c_int)     # vo_exchange_fn: in-place element-wise sum over the ranks
@@ -142,6 +148,12 @@ class VoLib:
         L.vo_local_ba_resident_fetch.argtypes = [C.c_void_p, C.POINTER(VoBaResidentResult)]
         L.vo_ba_resident_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_void_p, C.c_int,
                                            C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.vo_keyframe_commit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(VoKfCommitResult)]
+        L.vo_kf_covisibility.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32)]
+        L.vo_map_set_active_covisible.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int32, C.POINTER(C.c_int32)]
+        L.vo_local_ba_resident_merge_ledger.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_void_p, C.c_int]
+        L.vo_tables_fetch.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32)]
         L.vo_triangulate_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vo_set_hypothesis_shard.argtypes = [C.c_void_p, C.c_int, C.c_int, EXCHANGE_FN, C.c_void_p]
         L.vo_set_hypothesis_shard_stream.argtypes = [C.c_void_p, C.c_int, C.c_int, STREAM_ALLREDUCE_FN, C.c_void_p]
@@ -468,6 +480,41 @@ class VoContext:
         r2 = VoBaResidentResult(_ptr(po).value, _ptr(sl).value, _ptr(pt).value, _ptr(cu).value, cap_points, cap_culled)
         self.L.check(self.L.lib.vo_local_ba_resident_fetch(self.h, C.byref(r2)), "vo_local_ba_resident_fetch")
         return po[:len(f)], sl[:r2.n_points].copy(), pt[:r2.n_points].copy(), cu[:n_culled].copy(), r2
+
+    # keyframe bookkeeping on the device tables (second half) -------------------------------------------
+    def keyframe_commit(self, lane: int, frame_slot: int, kf: int, T_cw, first_new_slot: int, cap_covis: int = 4096):
+        """-> (VoKfCommitResult, {partner keyframe: weight})"""
+        T = np.ascontiguousarray(T_cw, dtype=np.float64).reshape(12)
+        ck = np.zeros(cap_covis, np.int32); cw = np.zeros(cap_covis, np.int32); r = VoKfCommitResult()
+        self.L.check(self.L.lib.vo_keyframe_commit(self.h, lane, frame_slot, kf, _ptr(T), first_new_slot, _ptr(ck), _ptr(cw), cap_covis, C.byref(r)), "vo_keyframe_commit")
+        return r, {int(ck[i]): int(cw[i]) for i in range(r.n_covisible)}
+
+    def kf_covisibility(self, kf: int, cap: int = 4096):
+        ck = np.zeros(cap, np.int32); cw = np.zeros(cap, np.int32); n = C.c_int32()
+        self.L.check(self.L.lib.vo_kf_covisibility(self.h, kf, _ptr(ck), _ptr(cw), cap, C.byref(n)), "vo_kf_covisibility")
+        return {int(ck[i]): int(cw[i]) for i in range(n.value)}
+
+    def map_set_active_covisible(self, kfs, n_map_points: int, min_points: int = 100) -> int:
+        k = np.ascontiguousarray(kfs, dtype=np.int32); n = C.c_int32()
+        self.L.check(self.L.lib.vo_map_set_active_covisible(self.h, _ptr(k), len(k), min_points, n_map_points, C.byref(n)), "vo_map_set_active_covisible")
+        return n.value
+
+    def merge_ledger(self, tables: "VoContext", n_free: int, cap_pairs: int = 1 << 16):
+        """vo_local_ba_resident_merge_ledger -> (sorted list of (kf_a, kf_b) decrements, free poses)"""
+        pa = np.zeros(cap_pairs, np.int32); pb = np.zeros(cap_pairs, np.int32); n = C.c_int32(); po = np.zeros((max(n_free, 1), 12))
+        self.L.check(self.L.lib.vo_local_ba_resident_merge_ledger(self.h, tables.h, _ptr(pa), _ptr(pb), cap_pairs, C.byref(n), _ptr(po), n_free), "vo_local_ba_resident_merge_ledger")
+        return sorted((int(pa[i]), int(pb[i])) for i in range(n.value)), po[:n_free]
+
+    def tables(self, n_map: int):
+        """The device tables as numpy arrays (vo_tables_fetch): observations, map columns for slots [0, n_map), active list."""
+        no = C.c_int64(); na = C.c_int32()
+        self.L.check(self.L.lib.vo_tables_fetch(self.h, 0, 0, None, None, None, None, C.byref(no), 0, 0, None, None, None, None, None, 0, C.byref(na)), "vo_tables_fetch")
+        n = no.value
+        kf = np.zeros(n, np.int32); mp = np.zeros(n, np.int32); uv = np.zeros((n, 2), np.float32); al = np.zeros(n, np.uint8)
+        xyz = np.zeros((n_map, 3)); nr = np.zeros((n_map, 3)); de = np.zeros((n_map, 32), np.uint8); fl = np.zeros(n_map, np.uint8); ac = np.zeros(max(na.value, 1), np.int32)
+        self.L.check(self.L.lib.vo_tables_fetch(self.h, 0, n, _ptr(kf), _ptr(mp), _ptr(uv), _ptr(al), C.byref(no), 0, n_map, _ptr(xyz), _ptr(nr), _ptr(de), _ptr(fl),
+                                                _ptr(ac), na.value, C.byref(na)), "vo_tables_fetch")
+        return {"obs_kf": kf, "obs_mp": mp, "obs_uv": uv, "obs_alive": al, "xyz": xyz, "normal": nr, "desc": de, "flags": fl, "active": ac[:na.value].copy()}
 
     def sync(self):
         self.L.check(self.L.lib.vo_sync(self.h), "vo_sync")

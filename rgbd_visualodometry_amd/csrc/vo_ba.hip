@@ -2372,21 +2372,56 @@ void vo_ba_resident_free(vo_ctx* c) {
 
 // merge of a solved graph into the tracker's tables (vo_local_ba_resident_merge): what vo_map_upsert (positions only), vo_kf_set_pose and
 // vo_obs_kill do from host arrays, straight from the solve's buffers; the same values also go to a staging buffer for the host's copy
+// ledger = 1 (vo_local_ba_resident_merge_ledger: the caller keeps no host map objects): every point of the graph is flagged optimised
+// (src/backend.cpp:190), the free poses also go to pinned host memory, and the culled observations are left to k_merge_ledger
 __global__ void k_ba_merge(int nf, int nx, const double* __restrict__ poses, const double* __restrict__ pts, const int* __restrict__ pose_kf, const int32_t* __restrict__ point_slots,
-                           const int* __restrict__ n_cull, const long long* __restrict__ cull, int cull_cap, double* __restrict__ map_pos, const uint8_t* __restrict__ map_flags,
-                           double* __restrict__ kf_pose, uint8_t* __restrict__ obs_alive, double* __restrict__ st_poses, double* __restrict__ st_pts, int32_t* __restrict__ st_slots) {
+                           const int* __restrict__ n_cull, const long long* __restrict__ cull, int cull_cap, double* __restrict__ map_pos, uint8_t* __restrict__ map_flags,
+                           double* __restrict__ kf_pose, uint8_t* __restrict__ obs_alive, double* __restrict__ st_poses, double* __restrict__ st_pts, int32_t* __restrict__ st_slots,
+                           int ledger, double* __restrict__ host_poses) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nx) {
         const int slot = point_slots[i];
         const double x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
         st_pts[3 * (size_t)i] = x; st_pts[3 * (size_t)i + 1] = y; st_pts[3 * (size_t)i + 2] = z; st_slots[i] = slot;
-        if (!(map_flags[slot] & VO_MAP_FLAG_OUTLIER)) { map_pos[3 * (size_t)slot] = x; map_pos[3 * (size_t)slot + 1] = y; map_pos[3 * (size_t)slot + 2] = z; }
+        const uint8_t fl = map_flags[slot];
+        if (ledger) map_flags[slot] = fl | VO_MAP_FLAG_OPTIMIZED;
+        if (!(fl & VO_MAP_FLAG_OUTLIER)) { map_pos[3 * (size_t)slot] = x; map_pos[3 * (size_t)slot + 1] = y; map_pos[3 * (size_t)slot + 2] = z; }
     }
-    if (i < 12 * nf) { const double v = poses[i]; st_poses[i] = v; kf_pose[12 * (size_t)pose_kf[i / 12] + i % 12] = v; }
-    if (i < min(*n_cull, cull_cap)) obs_alive[cull[i]] = 0;
+    if (i < 12 * nf) { const double v = poses[i]; st_poses[i] = v; kf_pose[12 * (size_t)pose_kf[i / 12] + i % 12] = v; if (host_poses) host_poses[i] = v; }
+    if (!ledger && i < min(*n_cull, cull_cap)) obs_alive[cull[i]] = 0;
+}
+// The covisibility ledger's side of a merge (Frame::RemoveObservedMappoint, reference src/frame.cpp:122-152; Mappoint::RemoveObservedByKeyframe,
+// src/mappoint.cpp:40-45), one workgroup: culling observation (K, P) costs K and every keyframe that still sees P one shared point -- the pairs go to
+// pinned host memory, the caller's ledger applies them -- and a point nobody sees any more becomes an outlier.  The reference removes the
+// observations one after the other; with c < c' both culled from one point, the pair (K, K') is therefore reported once, from c.  Phases: mark the
+// culled observations (alive = 2), walk each one's point chain, clear them.
+__global__ __launch_bounds__(256) void k_merge_ledger(const int* __restrict__ n_cull, const long long* __restrict__ cull, int cull_cap, const int32_t* __restrict__ obs_kf,
+                                                      const int32_t* __restrict__ obs_mp, uint8_t* __restrict__ obs_alive, const int32_t* __restrict__ obs_prev, const int32_t* __restrict__ pt_last,
+                                                      uint8_t* __restrict__ map_flags, int* __restrict__ pair_a, int* __restrict__ pair_b, int pair_cap, int* __restrict__ n_pairs_total) {
+    __shared__ int s_n;
+    const int n = min(*n_cull, cull_cap);
+    if (threadIdx.x == 0) s_n = 0;
+    for (int i = threadIdx.x; i < n; i += 256) { const long long c = cull[i]; if (obs_alive[c]) obs_alive[c] = 2; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int c = (int)cull[i];
+        if (obs_alive[c] != 2) continue;
+        const int K = obs_kf[c], P = obs_mp[c];
+        int survivors = 0;
+        for (int q = pt_last[P]; q >= 0; q = obs_prev[q]) {
+            const int a = obs_alive[q];
+            if (q == c || !a) continue;
+            if (a == 1) ++survivors;
+            if (a == 1 || q > c) { const int pos = atomicAdd(&s_n, 1); if (pos < pair_cap) { pair_a[pos] = K; pair_b[pos] = obs_kf[q]; } }
+        }
+        if (survivors == 0) map_flags[P] |= VO_MAP_FLAG_OUTLIER;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) { const long long c = cull[i]; if (obs_alive[c] == 2) obs_alive[c] = 0; }
+    if (threadIdx.x == 0) *n_pairs_total = s_n;
 }
 
-static int scan_i32(hipStream_t st, const int* in, int n, int* bsum, int* out, int* total) {        // n <= 16 Mi
+int vo_scan_i32(hipStream_t st, const int* in, int n, int* bsum, int* out, int* total) {        // n <= 16 Mi
     const int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (nb > 1024) return VO_E_UNSUPPORTED;
     hipLaunchKernelGGL(k_scan_blocksum, dim3(std::max(nb, 1)), dim3(1024), 0, st, in, n, bsum);
@@ -2445,12 +2480,12 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     hipLaunchKernelGGL(k_cut_init, dim3((std::max(nkf, nf) + 255) / 256), dim3(256), 0, st, nkf, F, kf_idx, pose_kf);
     const int gO = (int)((no - obs_lo + 255) / 256);
     if (gO) hipLaunchKernelGGL(k_cut_points, dim3(gO), dim3(256), 0, st, T, kf_idx, pt_flag);
-    int rc = scan_i32(st, pt_flag, mh, bsum, pidx, tot);                        // dense point index, nx
+    int rc = vo_scan_i32(st, pt_flag, mh, bsum, pidx, tot);                        // dense point index, nx
     if (rc) return rc;
     if (gO) hipLaunchKernelGGL(k_cut_count, dim3(gO), dim3(256), 0, st, T, kf_idx, pt_flag, pidx, cnt, fixed_flag);
     // pt_start[0 .. nx] over the dense indices (cnt is zero from nx on; one spare entry so that pt_start[nx] exists when every slot of
     // the map is in the graph), ne
-    if ((rc = scan_i32(st, cnt, mh + 1, bsum, pt_start, tot + 1))) return rc;
+    if ((rc = vo_scan_i32(st, cnt, mh + 1, bsum, pt_start, tot + 1))) return rc;
     hipLaunchKernelGGL(k_cut_fixed_scan, dim3(1), dim3(1024), 0, st, nkf, nf, fixed_flag, kf_idx, pose_kf, tot + 2);
     HIP_TRY(hipMemcpyAsync(h + 128, tot, 12, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -2617,10 +2652,24 @@ extern "C" int vo_local_ba_resident_solve(vo_ctx* c, int it_robust, int it_plain
 
 // The result of the last solve goes into t's tables on the device (t's stream: the tracker's own work is ordered around it; c's
 // stream waits for it, so the next cut of `c` reads merged tables and may reuse the slab) and into c's staging buffer.
-extern "C" int vo_local_ba_resident_merge(vo_ctx* c, vo_ctx* t) {
+static int ba_resident_merge(vo_ctx* c, vo_ctx* t, bool ledger, int32_t* pair_a, int32_t* pair_b, int cap_pairs, int32_t* n_pairs, double* poses, int cap_poses);
+extern "C" int vo_local_ba_resident_merge(vo_ctx* c, vo_ctx* t) { return ba_resident_merge(c, t, false, nullptr, nullptr, 0, nullptr, nullptr, 0); }
+extern "C" int vo_local_ba_resident_merge_ledger(vo_ctx* c, vo_ctx* t, int32_t* pair_a, int32_t* pair_b, int cap_pairs, int32_t* n_pairs, double* poses, int cap_poses) {
+    if (!n_pairs || cap_pairs < 0 || (cap_pairs && (!pair_a || !pair_b)) || cap_poses < 0 || (cap_poses && !poses)) return VO_E_INVALID;
+    *n_pairs = 0;
+    return ba_resident_merge(c, t, true, pair_a, pair_b, cap_pairs, n_pairs, poses, cap_poses);
+}
+static int ba_resident_merge(vo_ctx* c, vo_ctx* t, bool ledger, int32_t* pair_a, int32_t* pair_b, int cap_pairs, int32_t* n_pairs, double* poses, int cap_poses) {
     if (!c || !t || c->device != t->device || !c->resident || !c->resident->solved || c->resident->merged_seq == c->resident->solve_seq) return VO_E_STATE;
     HIP_TRY(hipSetDevice(c->device));
     BaResident& R = *c->resident;
+    int* h_pa = nullptr; int* h_pb = nullptr; int* h_np = nullptr; double* h_poses = nullptr; int h_cap = 0;
+    if (ledger) {
+        if (!t->d_obs_prev || !t->d_pt_last) return VO_E_STATE;
+        int rc = vo_kf_host_pairs(t, &h_pa, &h_pb, &h_cap, &h_np, &h_poses);
+        if (rc) return rc;
+        *h_np = 0;
+    }
     const int nf = R.nf, nx = R.nx;
     R.st_nf = nf; R.st_nx = nx; R.st_ne = R.ne; R.st_fixed = R.n_fixed; R.st_culled = R.n_culled; R.st_iters = R.lm_iters; R.st_chi0 = R.chi0; R.st_chi1 = R.chi_final;
     R.merged_seq = R.solve_seq; R.has_stage = true;
@@ -2636,15 +2685,26 @@ extern "C" int vo_local_ba_resident_merge(vo_ctx* c, vo_ctx* t) {
     uint8_t* sb = (uint8_t*)R.d_stage;
     const BaDev& B = R.B;
     const int n = std::max(std::max(nx, 12 * nf), R.n_culled);
+    if (ledger)       // first: a point that loses its last observation here keeps its position (src/backend.cpp:191: outliers are skipped)
+        hipLaunchKernelGGL(k_merge_ledger, dim3(1), dim3(256), 0, t->stream, (const int*)R.d_ncull, (const long long*)R.d_cull, R.cull_cap, (const int32_t*)t->d_obs_kf, (const int32_t*)t->d_obs_mp,
+                           t->d_obs_alive, (const int32_t*)t->d_obs_prev, (const int32_t*)t->d_pt_last, t->d_map_flags, h_pa, h_pb, h_cap, h_np);
     hipLaunchKernelGGL(k_ba_merge, dim3((n + 255) / 256), dim3(256), 0, t->stream, nf, nx, (const double*)(R.cur_buf ? B.posesB : B.posesA), (const double*)(R.cur_buf ? B.ptsB : B.ptsA),
-                       (const int*)R.d_pose_kf, (const int32_t*)R.d_point_slots, (const int*)R.d_ncull, (const long long*)R.d_cull, R.cull_cap, t->d_map_pos, (const uint8_t*)t->d_map_flags,
-                       t->d_kf_pose, t->d_obs_alive, (double*)sb, (double*)(sb + o_pts), (int32_t*)(sb + o_sl));
+                       (const int*)R.d_pose_kf, (const int32_t*)R.d_point_slots, (const int*)R.d_ncull, (const long long*)R.d_cull, R.cull_cap, t->d_map_pos, t->d_map_flags,
+                       t->d_kf_pose, t->d_obs_alive, (double*)sb, (double*)(sb + o_pts), (int32_t*)(sb + o_sl), ledger ? 1 : 0, ledger ? h_poses : (double*)nullptr);
     if (!R.ev_merge) HIP_TRY(hipEventCreateWithFlags(&R.ev_merge, hipEventDisableTiming));
     if (!R.fetch_stream) HIP_TRY(vo_stream_create(&R.fetch_stream, -1, "VO_FETCH_PRIO"));      // lowest class: three small copies behind an event wait must not sit in a queue a chain uses
     HIP_TRY(hipEventRecord(R.ev_merge, t->stream));
     HIP_TRY(hipStreamWaitEvent(c->stream, R.ev_merge, 0));
     HIP_TRY(hipStreamWaitEvent(R.fetch_stream, R.ev_merge, 0));
     HIP_TRY(hipGetLastError());
+    if (ledger) {                                           // the caller's ledger needs the pairs before it picks the next free keyframes
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        const int np = std::min(*h_np, h_cap), take = std::min(np, cap_pairs);
+        if (take > 0) { memcpy(pair_a, h_pa, 4 * (size_t)take); memcpy(pair_b, h_pb, 4 * (size_t)take); }
+        *n_pairs = take;
+        if (poses) memcpy(poses, h_poses, 96 * (size_t)std::min(nf, cap_poses));
+        if (*h_np > take) return VO_E_OVERFLOW;
+    }
     return VO_OK;
 }
 

@@ -218,14 +218,6 @@ struct vo_group {
 static int chain_run(vo_ctx* prof, hipStream_t st, LaunchSet& ls, std::vector<GroupReq*>& batch);
 static int shard_exchange(vo_ctx* c, hipStream_t st, int nl, int n_hyp);
 
-// vo_obs_append: the packed upload -> the observation table's columns
-__global__ void k_obs_append(int n, const int32_t* __restrict__ kf, const int32_t* __restrict__ mp, const float2* __restrict__ uv,
-                             int32_t* __restrict__ o_kf, int32_t* __restrict__ o_mp, float2* __restrict__ o_uv, uint8_t* __restrict__ o_alive) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    o_kf[i] = kf[i]; o_mp[i] = mp[i]; o_uv[i] = uv[i]; o_alive[i] = 1;
-}
-
 extern "C" {
 
 const char* vo_backend_name(void) { return "hip-gfx950"; }
@@ -280,7 +272,8 @@ void vo_ctx_destroy(vo_ctx* c) {
     if (c->h_orb_cache) (void)hipHostFree(c->h_orb_cache);
     if (c->h_ba_up) (void)hipHostFree(c->h_ba_up);
     vo_ba_resident_free(c);
-    { void* tp[] = {c->d_obs_kf, c->d_obs_mp, c->d_obs_uv, c->d_obs_alive, c->d_kf_pose, c->d_cut}; for (void* q : tp) if (q) (void)hipFree(q); }
+    { void* tp[] = {c->d_obs_kf, c->d_obs_mp, c->d_obs_uv, c->d_obs_alive, c->d_obs_prev, c->d_kf_pose, c->d_cut}; for (void* q : tp) if (q) (void)hipFree(q); }
+    vo_kf_free(c);
     if (c->slots_ev) (void)hipEventDestroy(c->slots_ev);
     for (auto& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -1011,126 +1004,6 @@ int vo_track_frame(vo_ctx* c, int slot, const double T0[12], const vo_track_para
                    vo_match* matches, int cap) {
     if (!tp) return VO_E_INVALID;
     return vo_track_batch(c, 1, &slot, T0, tp, &tp->seed, res, matches, cap);
-}
-
-// ---- device-resident observation table -------------------------------------------------------------------------
-#define VO_OBS_CAP (256ll << 20)    // observations the table may grow to (17 B each: 4.4 GB); ~5000 per keyframe at the bench workload: ~170 000 frames
-#define VO_KF_CAP 65536             // keyframes (96 B each)
-// The observation table starts at VO_OBS_CAP0 entries and doubles when a keyframe does not fit, up to VO_OBS_CAP (env VO_OBS_CAP lowers
-// that bound: tests exercise the overflow path with it).  Growing copies the live prefix on the context's stream and waits for it: nothing
-// may be reading the table then -- the front-end appends only behind Backend::WaitGraphCut, and merges are ordered on this stream.
-#define VO_OBS_CAP0 (4ll << 20)     // 68 MB; ~800 keyframes of the bench workload
-static int vo_obs_tables_alloc(long long cap, int32_t** kf, int32_t** mp, float** uv, uint8_t** alive) {
-    *kf = nullptr; *mp = nullptr; *uv = nullptr; *alive = nullptr;
-    if (hipMalloc((void**)kf, 4 * (size_t)cap) != hipSuccess || hipMalloc((void**)mp, 4 * (size_t)cap) != hipSuccess ||
-        hipMalloc((void**)uv, 8 * (size_t)cap) != hipSuccess || hipMalloc((void**)alive, (size_t)cap) != hipSuccess) {
-        // all or nothing: a later call must not find one array set beside null siblings
-        void* q[] = {*kf, *mp, *uv, *alive};
-        for (void* x : q) if (x) (void)hipFree(x);
-        *kf = nullptr; *mp = nullptr; *uv = nullptr; *alive = nullptr;
-        (void)hipGetLastError();
-        return VO_E_NOMEM;
-    }
-    return VO_OK;
-}
-static int vo_obs_tables_ensure(vo_ctx* c) {     // allocates the observation / keyframe tables on first use
-    if (c->d_obs_kf) return VO_OK;
-    const char* env = getenv("VO_OBS_CAP");
-    c->obs_cap_max = env && atoll(env) > 0 ? std::min<long long>(atoll(env), VO_OBS_CAP) : VO_OBS_CAP; c->kf_cap = VO_KF_CAP;
-    const char* env0 = getenv("VO_OBS_CAP0");             // tests start small to exercise the growth
-    const long long cap = std::min<long long>(env0 && atoll(env0) > 0 ? atoll(env0) : VO_OBS_CAP0, c->obs_cap_max);
-    if (hipMalloc((void**)&c->d_kf_pose, 96 * (size_t)c->kf_cap) != hipSuccess) { c->d_kf_pose = nullptr; (void)hipGetLastError(); return VO_E_NOMEM; }
-    if (vo_obs_tables_alloc(cap, &c->d_obs_kf, &c->d_obs_mp, &c->d_obs_uv, &c->d_obs_alive) != VO_OK) { (void)hipFree(c->d_kf_pose); c->d_kf_pose = nullptr; return VO_E_NOMEM; }
-    c->obs_cap = cap;
-    return VO_OK;
-}
-static int vo_obs_tables_grow(vo_ctx* c, long long need) {
-    long long cap = c->obs_cap;
-    while (cap < need) cap = std::min(2 * cap, c->obs_cap_max);
-    int32_t* kf; int32_t* mp; float* uv; uint8_t* alive;
-    int rc = vo_obs_tables_alloc(cap, &kf, &mp, &uv, &alive);
-    if (rc) return rc;
-    const size_t n = (size_t)c->n_obs;
-    if (n) {
-        HIP_TRY(hipMemcpyAsync(kf, c->d_obs_kf, 4 * n, hipMemcpyDeviceToDevice, c->stream)); HIP_TRY(hipMemcpyAsync(mp, c->d_obs_mp, 4 * n, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(uv, c->d_obs_uv, 8 * n, hipMemcpyDeviceToDevice, c->stream)); HIP_TRY(hipMemcpyAsync(alive, c->d_obs_alive, n, hipMemcpyDeviceToDevice, c->stream));
-    }
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    (void)hipFree(c->d_obs_kf); (void)hipFree(c->d_obs_mp); (void)hipFree(c->d_obs_uv); (void)hipFree(c->d_obs_alive);
-    c->d_obs_kf = kf; c->d_obs_mp = mp; c->d_obs_uv = uv; c->d_obs_alive = alive; c->obs_cap = cap;
-    return VO_OK;
-}
-
-int vo_kf_set_pose(vo_ctx* c, const int32_t* kf, const double* T, int n) {
-    if (!c || n < 0 || (n && (!kf || !T))) return VO_E_INVALID;
-    if (n == 0) return VO_OK;
-    HIP_TRY(hipSetDevice(c->device));
-    int rc = vo_obs_tables_ensure(c);
-    if (rc) return rc;
-    for (int i = 0; i < n; ++i) if (kf[i] < 0 || kf[i] >= c->kf_cap) return VO_E_INVALID;
-    double* h = (double*)vo_stage(c, 96 * (size_t)n);
-    if (!h) return VO_E_NOMEM;
-    HIP_TRY(hipStreamSynchronize(c->stream));               // the staging buffer may still feed an earlier copy
-    memcpy(h, T, 96 * (size_t)n);
-    int run0 = 0;                                           // consecutive keyframe numbers travel as one copy
-    for (int i = 1; i <= n; ++i)
-        if (i == n || kf[i] != kf[i - 1] + 1) {
-            HIP_TRY(hipMemcpyAsync(c->d_kf_pose + 12 * (size_t)kf[run0], h + 12 * (size_t)run0, 96 * (size_t)(i - run0), hipMemcpyHostToDevice, c->stream));
-            run0 = i;
-        }
-    for (int i = 0; i < n; ++i) c->n_kf = std::max(c->n_kf, kf[i] + 1);
-    HIP_TRY(hipStreamSynchronize(c->stream));               // a back-end thread may read the table from its own stream next
-    return VO_OK;
-}
-
-int vo_obs_append(vo_ctx* c, const int32_t* kf, const int32_t* mp, const float* uv, int n, int64_t* first) {
-    if (!c || n < 0 || (n && (!kf || !mp || !uv))) return VO_E_INVALID;
-    HIP_TRY(hipSetDevice(c->device));
-    int rc = vo_obs_tables_ensure(c);
-    if (rc) return rc;
-    for (int i = 0; i < n; ++i) if (kf[i] < 0 || kf[i] >= c->kf_cap || mp[i] < 0 || mp[i] >= c->p.map_capacity) return VO_E_INVALID;
-    if (c->n_obs + n > c->obs_cap_max) return VO_E_OVERFLOW;
-    if (c->n_obs + n > c->obs_cap && (rc = vo_obs_tables_grow(c, c->n_obs + n))) return rc;
-    if (first) *first = (int64_t)c->n_obs;
-    if (n == 0) return VO_OK;
-    // pack -> one pinned staging buffer -> one H2D copy into the scratch slab -> one kernel writes the four table columns (three copies and a
-    // fill were four blit kernels with their gaps: DESIGN 4a)
-    const size_t N = (size_t)n, o_mp = (4 * N + 255) & ~(size_t)255, o_uv = o_mp + ((4 * N + 255) & ~(size_t)255), total = o_uv + 8 * N;
-    uint8_t* h = (uint8_t*)vo_stage(c, total);
-    if (!h) return VO_E_NOMEM;
-    rc = vo_scratch(c, total);
-    if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(c->stream));               // the staging buffer / the scratch slab may still feed an earlier copy or scatter
-    memcpy(h, kf, 4 * N); memcpy(h + o_mp, mp, 4 * N); memcpy(h + o_uv, uv, 8 * N);
-    const size_t at = (size_t)c->n_obs;
-    uint8_t* d = (uint8_t*)c->d_ba;
-    HIP_TRY(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_obs_append, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, (const int32_t*)d, (const int32_t*)(d + o_mp), (const float2*)(d + o_uv),
-                       c->d_obs_kf + at, c->d_obs_mp + at, reinterpret_cast<float2*>(c->d_obs_uv + 2 * at), c->d_obs_alive + at);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(c->stream));               // a back-end thread may read the table from its own stream next
-    // where this keyframe's points begin in the tables (the resident graph cut starts there: vo_ba.hip, CutTabs)
-    if (c->pt_first.size() < (size_t)c->p.map_capacity) c->pt_first.resize((size_t)c->p.map_capacity, -1);
-    if (c->kf_reach.size() < (size_t)c->kf_cap) c->kf_reach.resize((size_t)c->kf_cap);
-    for (int i = 0; i < n; ++i) {
-        long long& pf = c->pt_first[mp[i]];
-        if (pf < 0) pf = (long long)at + i;
-        vo_ctx::KfReach& r = c->kf_reach[kf[i]];
-        if (r.obs_lo < 0) { r.obs_lo = pf; r.slot_lo = mp[i]; }
-        else { r.obs_lo = std::min(r.obs_lo, pf); r.slot_lo = std::min(r.slot_lo, mp[i]); }
-    }
-    c->n_obs += n;
-    return VO_OK;
-}
-
-int vo_obs_kill(vo_ctx* c, const int64_t* ids, int n) {
-    if (!c || n < 0 || (n && !ids)) return VO_E_INVALID;
-    if (n == 0) return VO_OK;
-    HIP_TRY(hipSetDevice(c->device));
-    for (int i = 0; i < n; ++i) if (ids[i] < 0 || ids[i] >= c->n_obs) return VO_E_INVALID;
-    for (int i = 0; i < n; ++i) HIP_TRY(hipMemsetAsync(c->d_obs_alive + (size_t)ids[i], 0, 1, c->stream));     // a handful per local BA
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return VO_OK;
 }
 
 // ---- stream groups ----------------------------------------------------------------------------------------------------

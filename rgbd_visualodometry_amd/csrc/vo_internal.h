@@ -130,12 +130,17 @@ struct vo_ctx {
     // device-resident keyframe bookkeeping: observation table and keyframe poses, fixed capacity (a back-end
     // thread may be reading them while the tracker appends: no reallocation, appends only write beyond what a reader was given)
     int32_t* d_obs_kf = nullptr; int32_t* d_obs_mp = nullptr; float* d_obs_uv = nullptr; uint8_t* d_obs_alive = nullptr;
+    // per-point chains through the observation table (vo_kf.hip): obs_prev[o] = the previous (older) observation of o's map point (-1: none),
+    // pt_last[slot] / pt_first[slot] = a point's newest / oldest observation (-1: none); d_kf_reach[kf] = (obs_lo, slot_lo) as int2
+    int32_t* d_obs_prev = nullptr; int32_t* d_pt_last = nullptr; int32_t* d_pt_first = nullptr; int* d_kf_reach = nullptr;
+    struct KfState* kf = nullptr;                           // buffers of vo_keyframe_commit / vo_map_set_active_covisible (vo_kf.hip)
+    std::vector<long long> kf_first_obs;                    // host: where a keyframe's own observations begin in the table (-1: none yet)
     long long n_pre_calls = 0, n_pre_unpinned = 0, n_pre_frames = 0, n_up_hit = 0, n_up_copy = 0;      // VO_TRACE: how the frames reached the device (vo_frames_preload / vo_frame_upload)
     long long n_obs = 0, obs_cap = 0, obs_cap_max = 0;     // entries used / allocated / the bound the table may grow to
-    // what a keyframe's points reach back to (host bookkeeping of vo_obs_append; the resident graph cut enters the tables there): pt_first[slot] = table position of the
-    // point's first observation (-1: none yet); kf_reach[kf] = minimum of that, and of the slot, over the points the keyframe observes
+    // what a keyframe's points reach back to (the resident graph cut enters the tables there): kf_reach[kf] = minimum, over the points the keyframe
+    // observes, of the table position of the point's first observation, and of the slot (host mirror of d_kf_reach, read back per keyframe)
     struct KfReach { long long obs_lo = -1; int slot_lo = 0; };
-    std::vector<long long> pt_first; std::vector<KfReach> kf_reach;
+    std::vector<KfReach> kf_reach;
     double* d_kf_pose = nullptr; int n_kf = 0, kf_cap = 0;
     int map_hi = 0;                                         // highest map slot ever upserted + 1
     void* d_cut = nullptr; size_t d_cut_bytes = 0;          // scratch of the resident graph cut
@@ -182,6 +187,11 @@ int vo_track_lm_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* d_lanes, in
 void vo_lane_fill(vo_ctx* c, int lane, int slot, uint64_t seed, TrackDev* d_tr, LaneDesc* out);   // descriptor of lane `lane` of context c
 int vo_corr_from_host(vo_ctx* c, const float* xyz, const float* uv, int n);
 int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out);                       // vo_ba.hip
+int vo_scan_i32(hipStream_t st, const int* in, int n, int* bsum /* >= 1024 ints */, int* out, int* total);      // vo_ba.hip: exclusive scan, n <= 16 Mi
+// vo_kf.hip
+int vo_obs_tables_ensure(vo_ctx* c);
+void vo_kf_free(vo_ctx* c);
+int vo_kf_host_pairs(vo_ctx* c, int** pair_a, int** pair_b, int* cap, int** n_total, double** poses);      // pinned block a BA merge reports into (vo_local_ba_resident_merge_ledger)
 void vo_ba_resident_free(vo_ctx* c);
 struct BaEngine* vo_ba_engine_acquire(int device);
 void vo_ba_engine_release(struct BaEngine* e);

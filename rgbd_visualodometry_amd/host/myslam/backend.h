@@ -31,6 +31,9 @@ public:
     // before a keyframe's bookkeeping changes them (the cut is the first ~0.2 ms of a BA, a keyframe is >= 1 ms away).
     void WaitGraphCut();
     void SetDeviceGraph(bool on) { deviceGraph_ = on; }
+    // The front-end keeps keyframes and map points on the device (FrontEnd with device_keyframes): a merge then also reports the covisibility
+    // ledger's decrements and flags the graph's points on the device (vo_local_ba_resident_merge_ledger); no host map object is touched.
+    void SetDeviceKeyframes(bool on) { deviceKeyframes_ = on; }
     bool DeviceGraph() const { return deviceGraph_; }             // wait for the pending job and merge it now (end of a sequence / of a timed region)
     void OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr, bool deferTail = false);
     // The three parts a caller may interleave with its own work (FrontEnd::TrackingHandler at a keyframe): the pending local BA is waited for and merged
@@ -78,7 +81,9 @@ private:
     std::unique_ptr<Job> tail_; vo_ctx* tailCtx_ = nullptr;
     void WorkerLoop();
     void EnsureWorker();            // the worker's context, stream and thread exist before the first keyframe (no one-time setup inside a timed run)
-    bool deviceGraph_ = false;
+    bool deviceGraph_ = false, deviceKeyframes_ = false;
+    std::vector<int32_t> pairA_, pairB_;            // ledger decrements of a merge (device keyframes)
+    void FinishOnDevice(Job& j, vo_ctx* solver);
     bool fixOldest_ = false;        // ba_fix_oldest_free_keyframe: gauge-anchor experiment
     void SolveResident(Job& j, vo_ctx* ctx);
     int maxFree_ = 160;             // free-pose cap of one solve: the Cholesky of the reduced system is LDS resident (vo_local_ba: D = 6 n_free <= ~1050)

@@ -52,6 +52,13 @@ public:
     // and written once (same final weights and active sets as one update per observation).
     void BeginCovisibilityBatch() { covisBatch_ = true; }
     void EndCovisibilityBatch();
+    // Device-resident bookkeeping (FrontEnd with device_keyframes): the weights come counted from the device tables; both sides of the ledger are
+    // written here (the two halves of src/frame.cpp:104-119 / :133-150 for one partner)
+    void SetCovisibleWeightBoth(Frame* partner, int weight) { covis_.set(partner->id_, weight); partner->covis_.set(id_, weight); }
+    void AddCovisibleWeightBoth(Frame* partner, int delta) { partner->covis_.set(id_, covis_.add(partner->id_, delta)); }
+    // the observation set rebuilt from the device tables (MapManager::MaterializeFromTables)
+    void RestoreObservedClear() { observed_.clear(); }
+    void RestoreObserved(Mappoint* mp) { observed_.push_back(ObservedEntry{mp->GetId(), mp, true}); }
     std::unordered_set<size_t> GetCovisibleKeyframes() { std::unique_lock<std::mutex> lck(obsLock_); return covis_.strong; }
     CovisibleKeyframeIdToWeight GetCovisibleKeyframeWeights() { std::unique_lock<std::mutex> lck(obsLock_); return covis_.count; }     // allCovisibleKeyframeIdToWeight_ (frame.h:94)
 

@@ -114,6 +114,20 @@ private:
     void TriangulateAllBatched();                    // triangulate_all: 1 -- every eligible point, one vo_triangulate_batch call
     void RegisterKeyframeOnDevice();                 // device-resident bookkeeping: the new keyframe's pose and observations
     void AddNewMappointsObservationsForOldKeyframes();   // reobserve_new_mappoints: 1 (reference src/frontend.cpp:408-463, disabled there at :130)
+    // device_keyframes: 1 -- the keyframe bookkeeping above (observations, covisibility, new map points, triangulation, local map) runs on the device
+    // tables (vo_keyframe_commit, vo_map_set_active_covisible); the host keeps the keyframes' poses and covisibility ledgers, and no Mappoint objects
+    // until somebody asks for them (MaterializeMap).  SURVEY 8f-2.
+    bool deviceKeyframes_ = false, kfModeDecided_ = false, kfOnDevice_ = false;
+    int nActive_ = 0;                                // size of the device's active list in that mode
+    std::vector<int32_t> covisKf_, covisW_;
+    bool UseDeviceKeyframes();
+    void CommitKeyframeOnDevice();
+    int ActiveCount() const { return kfOnDevice_ ? nActive_ : (int)activeList_.size(); }
+public:
+    // Mappoint objects, observation lists and Frame observation sets as of now, rebuilt from the device tables (device_keyframes; a no-op otherwise)
+    void MaterializeMap();
+    bool KeyframesOnDevice() const { return kfOnDevice_; }
+private:
 };
 }  // namespace myslam
 #endif

@@ -4,6 +4,7 @@
 // process-wide singleton of the reference.
 #ifndef MYSLAM_MAPMANAGER_H
 #define MYSLAM_MAPMANAGER_H
+#include <algorithm>
 #include "myslam/common_include.h"
 #include "myslam/frame.h"
 #include "myslam/mappoint.h"
@@ -27,7 +28,13 @@ public:
     MappointIdToPtr GetMappointsAroundKeyframe(const Frame::Ptr& keyframe);
 
     Mappoint* FindMappoint(const size_t id) { auto it = pointsById_.find(id); return it == pointsById_.end() ? nullptr : it->second.get(); }   // no lock, no copy
-    size_t MappointCount() { std::unique_lock<std::mutex> lck(tableLock_); return pointsById_.size(); }
+    size_t MappointCount() { std::unique_lock<std::mutex> lck(tableLock_); return std::max(pointsById_.size(), (size_t)nextSlot_); }
+    // Device-resident map (FrontEnd with device_keyframes): map points are created ON the device (vo_keyframe_commit); the host only hands out their slots.
+    int NextSlot() const { return nextSlot_; }
+    void ReserveSlots(int n) { std::unique_lock<std::mutex> lck(tableLock_); nextSlot_ += n; }
+    // Mappoint objects, observation lists and observation sets rebuilt from the device tables (inspection, viewers, tests): everything the
+    // reference's containers hold (include/myslam/mapmanager.h:23-58), as of now.  Objects of slots that already exist are updated in place.
+    void MaterializeFromTables(vo_ctx* ctx);
     // map points whose host state is newer than the device copy (drained by the front-end once per frame)
     void NoteDirty(Mappoint* mp) { dirty_.push_back(mp); }
     std::vector<Mappoint*> TakeDirty() { std::vector<Mappoint*> d; d.swap(dirty_); return d; }

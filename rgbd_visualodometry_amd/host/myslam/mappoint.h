@@ -51,6 +51,10 @@ public:
     }
 
     void MarkDirty();
+    // state taken over from the device tables (MapManager::MaterializeFromTables): no dirty marking, no recomputation
+    void RestoreState(const Vector3d& pos, const Vector3d& norm, bool outlier, bool triangulated, bool optimized) { pos_ = pos; norm_ = norm; outlier_ = outlier; triangulated_ = triangulated; optimized_ = optimized; }
+    void RestoreObservationsClear() { obsList_.clear(); }
+    void RestoreObservation(const size_t keyframeId, const Point2f pixel, Frame* keyframe) { obsList_.push_back(Observation{keyframeId, pixel, keyframe}); }
 
 private:
     static std::atomic<size_t> nextId_;

@@ -90,7 +90,7 @@ void Backend::Finish(bool deferTail) {
     if (waited) { stats_.ms_wake += std::chrono::duration<double, std::milli>(tWake - job_->tDone).count(); ++stats_.waited; }
     std::unique_ptr<Job> j = std::move(job_);
     if (j->rc != VO_OK) {                            // a failed solve must not end the stream: the map keeps its un-optimised state
-        if (j->resident && deviceGraph_ && (j->rc == VO_E_UNSUPPORTED || j->rc == VO_E_OVERFLOW || j->rc == VO_E_NOMEM)) {
+        if (j->resident && deviceGraph_ && !deviceKeyframes_ && (j->rc == VO_E_UNSUPPORTED || j->rc == VO_E_OVERFLOW || j->rc == VO_E_NOMEM)) {      // (with device keyframes there is no host graph to cut: the BA is skipped, the next one tries again)
             std::cerr << "[myslam] device graph cut unavailable (" << vo_strerror(j->rc) << "): local BA graphs are cut on the host from here on" << std::endl;
             deviceGraph_ = false;
         }
@@ -105,6 +105,7 @@ void Backend::Finish(bool deferTail) {
     FinishTail();                                    // an earlier tail, if its owner never came back for it
     MapManager& map = MapManager::GetInstance();
     if (j->nPoints == 0 || j->nEdges == 0) return;
+    if (deviceKeyframes_) { FinishOnDevice(*j, lag_ > 0 ? ctxOwn_ : ctx_); if (waited) stats_.ms_to_merge += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tWake).count(); return; }
     { VO_SCOPE("ba.culled");
     for (int i = 0; i < j->nCulled; ++i) {
         const MapManager::ObsRef& o = map.obsRegistry_[(size_t)j->culled[i]];
@@ -117,6 +118,26 @@ void Backend::Finish(bool deferTail) {
     if (waited) stats_.ms_to_merge += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tWake).count();
     tail_ = std::move(j); tailCtx_ = solver;
     if (!deferTail) FinishTail();
+}
+
+// The write-back of reference src/backend.cpp:144-194 when the map lives on the device: positions, flags, poses and culled observations are merged there
+// (vo_local_ba_resident_merge_ledger); the host applies the covisibility decrements to its ledger (src/frame.cpp:133-150) and takes the free poses.
+void Backend::FinishOnDevice(Job& j, vo_ctx* solver) {
+    VO_SCOPE("ba.merge_ledger");
+    MapManager& map = MapManager::GetInstance();
+    if (pairA_.size() < 16384) { pairA_.resize(16384); pairB_.resize(16384); }
+    j.posesOut.resize(12 * (size_t)std::max(j.nFree, 1));
+    int32_t np = 0;
+    const int rc = vo_local_ba_resident_merge_ledger(solver, ctx_, pairA_.data(), pairB_.data(), (int)pairA_.size(), &np, j.posesOut.data(), j.nFree);
+    if (rc != VO_OK) throw std::runtime_error(std::string("vo_local_ba_resident_merge_ledger failed: ") + vo_strerror(rc));
+    for (int i = 0; i < np; ++i) {
+        Frame* a = (size_t)pairA_[i] < map.kfByIndex_.size() ? map.kfByIndex_[pairA_[i]] : nullptr;
+        Frame* b = (size_t)pairB_[i] < map.kfByIndex_.size() ? map.kfByIndex_[pairB_[i]] : nullptr;
+        if (a && b && a != b) a->AddCovisibleWeightBoth(b, -1);
+    }
+    for (int p = 0; p < j.nFree; ++p) j.poseFrames[p]->SetPose(SE3::from12(&j.posesOut[12 * (size_t)p]));
+    stats_.runs++; stats_.poses = j.nFree; stats_.fixed = j.nFixed; stats_.points = j.nPoints; stats_.edges = j.nEdges; stats_.outliers = j.nCulled; stats_.ms_solve += j.solveMs;
+    { const double D = 6.0 * j.nFree; stats_.sum_d3 += D * D * D; stats_.sum_d2 += D * D; stats_.sum_edges += j.nEdges; }
 }
 
 void Backend::FinishTail() {
@@ -156,7 +177,7 @@ void Backend::OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr, bo
     // The device graph cut takes VO_BA_RESIDENT_MAX_FREE free poses (include/vo_hip.h; the same number as maxFree_'s default).  A keyframe with
     // more covisible keyframes than that hands the graph cut back to the host for the rest of the run -- the same transition as a full
     // observation table -- instead of silently solving a smaller problem than the host cut would.
-    if (deviceGraph_ && keyframeCurr->kfIndex_ >= 0 && (int)keyframeCurr->GetCovisibleKeyframes().size() + 1 > std::min(maxFree_, VO_BA_RESIDENT_MAX_FREE)) {
+    if (deviceGraph_ && !deviceKeyframes_ && keyframeCurr->kfIndex_ >= 0 && (int)keyframeCurr->GetCovisibleKeyframes().size() + 1 > std::min(maxFree_, VO_BA_RESIDENT_MAX_FREE)) {
         std::fprintf(stderr, "[myslam_amd] local BA: %zu covisible keyframes exceed the device graph cut's %d free poses: the host graph cut takes over\n",
                      keyframeCurr->GetCovisibleKeyframes().size(), VO_BA_RESIDENT_MAX_FREE);
         deviceGraph_ = false;
@@ -164,6 +185,13 @@ void Backend::OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr, bo
     if (deviceGraph_ && keyframeCurr->kfIndex_ >= 0) {      // only the free keyframes' numbers go to the device; no host graph cut
         auto covis = keyframeCurr->GetCovisibleKeyframes();
         std::vector<size_t> ids(covis.begin(), covis.end());
+        const int cap = std::min(maxFree_, VO_BA_RESIDENT_MAX_FREE);
+        if ((int)ids.size() + 1 > cap) {             // (device keyframes only: there is no host graph to fall back to) the strongest stay free, as in Build
+            auto w = keyframeCurr->GetCovisibleKeyframeWeights();
+            std::sort(ids.begin(), ids.end(), [&](size_t a, size_t b) { const int wa = w[a], wb = w[b]; return wa != wb ? wa > wb : a > b; });
+            ids.resize((size_t)cap - 1);
+            ++stats_.capped;
+        }
         ids.push_back(keyframeCurr->GetId());
         std::sort(ids.begin(), ids.end());
         if (fixOldest_ && ids.size() > 1) ids.erase(ids.begin());      // its observations still constrain the points: it joins the fixed poses

@@ -47,6 +47,8 @@ void FrontEnd::Init(int device, int width, int height, int max_frames) {
     triangulateAll_ = cfg_or<int>("triangulate_all", 0) != 0;
     reobserveNew_ = cfg_or<int>("reobserve_new_mappoints", 0) != 0;
     deviceDescriptors_ = cfg_or<int>("map_descriptors_on_device", 0) != 0;
+    deviceKeyframes_ = cfg_or<int>("device_keyframes", 0) != 0;
+    if (const char* e = std::getenv("VO_DEVICE_KEYFRAMES")) deviceKeyframes_ = std::atoi(e) != 0;      // experiments / A-B runs
     params_.max_frames = lookahead_ + (reobserveNew_ ? 1 : 0);
     scratchSlot_ = reobserveNew_ ? lookahead_ : -1;
     params_.map_capacity = cfg_or<int>("map_capacity", 1 << 20);
@@ -84,8 +86,29 @@ bool FrontEnd::AddFrame(const Frame::Ptr frame) {
     return true;
 }
 
+// The mode is fixed at the first keyframe: everything it needs must be there (device graph cut, descriptors on the device, the reference's
+// default triangulation policy, nobody who reads host map objects per frame).
+bool FrontEnd::UseDeviceKeyframes() {
+    if (!kfModeDecided_) {
+        kfOnDevice_ = deviceKeyframes_ && deviceDescriptors_ && backend_ && backend_->DeviceGraph() && !reobserveNew_ && !triangulateAll_ && !viewer_;
+        kfModeDecided_ = true;
+        if (backend_) backend_->SetDeviceKeyframes(kfOnDevice_);
+    }
+    return kfOnDevice_;
+}
+
 void FrontEnd::InitializationHandler() {
     ExtractKeyPointsAndComputeDescriptors();
+    if (UseDeviceKeyframes()) {
+        MapManager::GetInstance().InsertKeyframe(frameCurr_);
+        ++stats_.keyframes;
+        curLane_ = -1;                                           // no matches yet
+        CommitKeyframeOnDevice();
+        state_ = TRACKING;
+        framePrev_ = frameCurr_;
+        keyframeRef_ = frameCurr_;
+        return;
+    }
     EnsureMatchLists();                                          // no matches yet: empty lists sized for this frame
     MapManager::GetInstance().InsertKeyframe(frameCurr_);       // the first frame is a keyframe
     ++stats_.keyframes;
@@ -112,7 +135,12 @@ bool FrontEnd::TrackingHandler() {
 
     ++epoch_; lastInterval_ = framesSinceKf_; framesSinceKf_ = 0;   // map + prior change: cached speculative results are void
     if (backend_) backend_->WaitGraphCut();                        // a device-side graph cut may still be reading the tables this keyframe changes
-    {
+    if (kfOnDevice_) {
+        StageTimer t(stats_.ms_keyframe);
+        MapManager::GetInstance().InsertKeyframe(frameCurr_);
+        ++stats_.keyframes;
+        { VO_SCOPE("kf.commit"); CommitKeyframeOnDevice(); }
+    } else {
         StageTimer t(stats_.ms_keyframe);
         { VO_SCOPE("kf.lists"); EnsureMatchLists(); }
         { VO_SCOPE("kf.insert"); MapManager::GetInstance().InsertKeyframe(frameCurr_); }
@@ -122,7 +150,7 @@ bool FrontEnd::TrackingHandler() {
         if (reobserveNew_) { VO_SCOPE("kf.reobserve"); AddNewMappointsObservationsForOldKeyframes(); }
         { VO_SCOPE("kf.triangulate"); if (triangulateAll_) TriangulateAllBatched(); else TriangulateMappointsInTrackingMap(); }
     }
-    if (backend_ && backend_->DeviceGraph()) { StageTimer t(stats_.ms_keyframe); VO_SCOPE("kf.register"); RegisterKeyframeOnDevice(); }
+    if (!kfOnDevice_ && backend_ && backend_->DeviceGraph()) { StageTimer t(stats_.ms_keyframe); VO_SCOPE("kf.register"); RegisterKeyframeOnDevice(); }
     const bool ahead = backend_ && backend_->DeviceGraph() && backend_->Lag() > 0 && trackAhead_ && !group_;
     if (!ahead) {
         if (backend_) { StageTimer t(stats_.ms_backend); backend_->OptimizeCovisibleGraphOfKeyframe(frameCurr_); }
@@ -235,6 +263,20 @@ void FrontEnd::EnsureMatchLists() {
 }
 
 void FrontEnd::RefreshTrackingMap() {
+    if (kfOnDevice_) {                                                              // the local-map query runs on the device tables (src/mapmanager.cpp:14-38, src/frontend.cpp:159-166)
+        if (keyframeForTrackingMap_ == keyframeRef_) return;
+        keyframeForTrackingMap_ = keyframeRef_;
+        MapManager& map = MapManager::GetInstance();
+        std::vector<int32_t> kfs{keyframeRef_->kfIndex_};
+        for (size_t id : keyframeRef_->GetCovisibleKeyframes()) { Frame::Ptr f = map.GetKeyframe(id); if (f && f->kfIndex_ >= 0) kfs.push_back(f->kfIndex_); }
+        std::sort(kfs.begin(), kfs.end());
+        if (backend_) backend_->WaitGraphCut();
+        int32_t n = 0;
+        VO_SCOPE("fe.active_covisible");
+        vo_check(vo_map_set_active_covisible(ctx_, kfs.data(), (int)kfs.size(), 100, map.NextSlot(), &n), "vo_map_set_active_covisible");
+        nActive_ = n;
+        return;
+    }
     bool changed = false;
     if (keyframeForTrackingMap_ != keyframeRef_) {                                  // frontend.cpp:159-162
         keyframeForTrackingMap_ = keyframeRef_;
@@ -300,7 +342,7 @@ void FrontEnd::LaunchTrackAhead() {
         if (!prefetched_[j]->orb_done_ || nextFrames + batch.size() >= nextMerge) break;
         batch.push_back(prefetched_[j]);
     }
-    const int nb = (int)batch.size(), cap = (int)activeList_.size() + 1;
+    const int nb = (int)batch.size(), cap = ActiveCount() + 1;
     std::vector<int> slots(nb); std::vector<uint64_t> seeds(nb);
     ahead_.ids.resize(nb);
     for (int j = 0; j < nb; ++j) { slots[j] = batch[j]->slot_; seeds[j] = 0x5eed5eedull + 2 * (uint64_t)(nextFrames + j); ahead_.ids[j] = batch[j]->GetId(); }
@@ -353,7 +395,7 @@ void FrontEnd::MatchAndEstimatePose() {
             if (!prefetched_[j]->orb_done_ || (size_t)stats_.frames + batch.size() >= nextMerge) break;
             batch.push_back(prefetched_[j]);
         }
-        const int nb = (int)batch.size(), cap = (int)activeList_.size() + 1;
+        const int nb = (int)batch.size(), cap = ActiveCount() + 1;
         std::vector<int> slots(nb); std::vector<uint64_t> seeds(nb); std::vector<vo_track_result> rs(nb);
         for (int j = 0; j < nb; ++j) { slots[j] = batch[j]->slot_; seeds[j] = 0x5eed5eedull + 2 * (uint64_t)(stats_.frames + j); }
         // match records are not copied back here: only keyframes (and the viewer) read them, through vo_track_fetch_matches
@@ -368,15 +410,15 @@ void FrontEnd::MatchAndEstimatePose() {
     }
     if (res.status != VO_OK) throw std::runtime_error(std::string("device pipeline: ") + vo_strerror(res.status));
     matchListsBuilt_ = false; matchesFetched_ = false;
-    nCurMatches_ = std::min(res.n_matches, (int)activeList_.size() + 1);
+    nCurMatches_ = std::min(res.n_matches, ActiveCount() + 1);
     numInliers_ = res.n_ransac_inliers;                                             // frontend.cpp:242
     frameCurr_->SetPose(SE3::from12(res.T_cw));                                     // frontend.cpp:312
     stats_.last_candidates = res.n_candidates; stats_.last_matches = res.n_matches;
     stats_.last_ransac = res.n_ransac_inliers; stats_.last_lm = res.n_lm_inliers;
-    ++stats_.tracked; stats_.sum_active += (long long)activeList_.size(); stats_.sum_cand += res.n_candidates; stats_.sum_match += res.n_matches;
+    ++stats_.tracked; stats_.sum_active += (long long)ActiveCount(); stats_.sum_cand += res.n_candidates; stats_.sum_match += res.n_matches;
     stats_.sum_ransac += res.n_ransac_inliers; stats_.sum_lm += res.n_lm_inliers; stats_.sum_lm_iters += res.lm_iters;
     if (verbose_)
-        std::cout << "  tracking map " << activeList_.size() << ", candidates " << res.n_candidates << ", matches " << res.n_matches
+        std::cout << "  tracking map " << ActiveCount() << ", candidates " << res.n_candidates << ", matches " << res.n_matches
                   << ", PnP inliers " << res.n_ransac_inliers << ", LM inliers " << res.n_lm_inliers << std::endl;
 }
 
@@ -417,6 +459,36 @@ void FrontEnd::AddCurrentKeyframeObservations() {
     for (size_t i = 0; i < pnpMatchedMpt_.size(); ++i)
         frameCurr_->AddObservedMappoint(pnpMatchedMpt_[i], keypointsCurr_[pnpMatchedMptKp_[i]].pt);
     frameCurr_->EndCovisibilityBatch();
+}
+
+// A frame becomes a keyframe with its bookkeeping done where the data already is (vo_keyframe_commit): observations of the LM inliers, their viewing
+// directions, the covisibility weights (the ledger below receives them counted), the new map points from the unmatched keypoints with depth, the
+// reference's first-success triangulation, pose and observations into the device tables.  Reference src/frontend.cpp:119-131.
+void FrontEnd::CommitKeyframeOnDevice() {
+    MapManager& map = MapManager::GetInstance();
+    if (frameCurr_->kfIndex_ < 0) { frameCurr_->kfIndex_ = (int)map.kfByIndex_.size(); map.kfByIndex_.push_back(frameCurr_.get()); }
+    FlushDirtyMappoints();                                   // (scenario-built points only: tracking creates none on the host in this mode)
+    if (covisKf_.size() < 4096) { covisKf_.resize(4096); covisW_.resize(4096); }
+    double T[12];
+    frameCurr_->GetPose().to12(T);
+    vo_kf_commit_result r;
+    const int rc = vo_keyframe_commit(ctx_, curLane_, frameCurr_->slot_, frameCurr_->kfIndex_, T, map.NextSlot(), covisKf_.data(), covisW_.data(), (int)covisKf_.size(), &r);
+    if (rc == VO_E_OVERFLOW) throw std::runtime_error("device map / observation tables full (raise map_capacity; device_keyframes keeps no host map to fall back to)");
+    vo_check(rc, "vo_keyframe_commit");
+    map.ReserveSlots(r.n_new);
+    for (int i = 0; i < r.n_covisible; ++i) {                // allCovisibleKeyframeIdToWeight_ / activeCovisibleKeyframes_ of both sides (src/frame.cpp:104-119, :157-171)
+        Frame* partner = (size_t)covisKf_[i] < map.kfByIndex_.size() ? map.kfByIndex_[covisKf_[i]] : nullptr;
+        if (partner && partner != frameCurr_.get()) frameCurr_->SetCovisibleWeightBoth(partner, covisW_[i]);
+    }
+    if (r.triangulated_slot >= 0) ++stats_.triangulated;
+    if (verbose_) std::cout << "Created new mappoints: " << r.n_new << "\n  Triangulate active mappoints size: " << (r.triangulated_slot >= 0 ? 1 : 0) << std::endl;
+}
+
+void FrontEnd::MaterializeMap() {
+    if (!kfOnDevice_) return;
+    if (backend_) backend_->WaitGraphCut();
+    DrainAhead();
+    MapManager::GetInstance().MaterializeFromTables(ctx_);
 }
 
 void FrontEnd::CreateNewMappoints() {

@@ -73,7 +73,7 @@ int myslam_system_create(const myslam_options* o, const char* yaml, myslam_syste
         Config::set("enable_local_optimization", S(o->enable_local_optimization)); Config::set("chi2_th", S(o->chi2_th));
         Config::set("ransac_iterations", S(o->ransac_iterations)); Config::set("track_batch", S(o->track_batch)); Config::set("map_capacity", S(o->map_capacity));
         Config::set("ba_device_graph", S(o->ba_device_graph)); Config::set("triangulate_all", S(o->triangulate_all)); Config::set("reobserve_new_mappoints", S(o->reobserve_new_mappoints));
-        Config::set("map_descriptors_on_device", S(o->map_descriptors_on_device));
+        Config::set("map_descriptors_on_device", S(o->map_descriptors_on_device)); Config::set("device_keyframes", S(o->device_keyframes));
         if (yaml) Config::setParameterFile(yaml);
         MapManager::BindToThread(&s->map);
         s->camera = Camera::Ptr(new Camera);
@@ -275,6 +275,27 @@ int myslam_scn_run_ba(myslam_system* s, int64_t kf) {
 int myslam_scn_keyframe_pose(myslam_system* s, int64_t kf, double T_cw[12]) {
     if (!s || !T_cw) return -1;
     return guarded(s, [&]() { scn_keyframe(s, kf)->GetPose().to12(T_cw); });
+}
+
+int myslam_materialize(myslam_system* s, int64_t* keyframe_ids, int cap, int* n, int* on_device) {
+    if (!s || !n) return -1;
+    return guarded(s, [&]() {
+        s->frontend->MaterializeMap();
+        if (on_device) *on_device = s->frontend->KeyframesOnDevice() ? 1 : 0;
+        std::map<size_t, Frame::Ptr> ordered;
+        for (auto& e : s->map.GetAllKeyframes()) ordered[e.first] = e.second;
+        int k = 0;
+        for (auto& e : ordered) { if (k < cap && keyframe_ids) keyframe_ids[k] = (int64_t)e.first; ++k; }
+        *n = k;
+    });
+}
+int myslam_mappoint_ids(myslam_system* s, int64_t* ids, int cap, int* n) {
+    if (!s || !n) return -1;
+    return guarded(s, [&]() {
+        const auto& all = s->map.AllMappointsOrdered();
+        for (size_t i = 0; i < all.size() && (int)i < cap; ++i) if (ids) ids[i] = (int64_t)all[i]->GetId();
+        *n = (int)all.size();
+    });
 }
 
 void* myslam_get_context(myslam_system* s) { return s ? (void*)s->frontend->GetContext() : nullptr; }

@@ -25,7 +25,7 @@ class Options(C.Structure):
                 ("max_num_lost", C.c_int32), ("min_inliers", C.c_int32), ("keyframe_rotation", C.c_double),
                 ("keyframe_translation", C.c_double), ("enable_local_optimization", C.c_int32), ("chi2_th", C.c_float),
                 ("ransac_iterations", C.c_int32), ("backend_lag_frames", C.c_int32), ("max_frames_in_flight", C.c_int32), ("track_batch", C.c_int32), ("map_capacity", C.c_int32),
-                ("device", C.c_int32), ("verbose", C.c_int32), ("triangulate_all", C.c_int32), ("ba_device_graph", C.c_int32), ("reobserve_new_mappoints", C.c_int32), ("map_descriptors_on_device", C.c_int32)]
+                ("device", C.c_int32), ("verbose", C.c_int32), ("triangulate_all", C.c_int32), ("ba_device_graph", C.c_int32), ("reobserve_new_mappoints", C.c_int32), ("map_descriptors_on_device", C.c_int32), ("device_keyframes", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -50,7 +50,7 @@ SYMBOLS = ["myslam_default_options", "myslam_system_create", "myslam_system_dest
            # taps for parity tests (include/myslam_c.h)
            "myslam_triangulate", "myslam_se3_log", "myslam_se3_exp", "myslam_keyframe_policy", "myslam_scn_add_keyframe", "myslam_scn_add_mappoint",
            "myslam_scn_observe", "myslam_scn_unobserve", "myslam_scn_covisibility", "myslam_scn_local_map", "myslam_scn_ba_graph", "myslam_scn_mappoint",
-           "myslam_scn_run_ba", "myslam_scn_keyframe_pose"]
+           "myslam_scn_run_ba", "myslam_scn_keyframe_pose", "myslam_materialize", "myslam_mappoint_ids"]
 
 _libs = {}
 
@@ -93,6 +93,8 @@ def _load(path: str):
         lib.myslam_scn_mappoint.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
         lib.myslam_scn_run_ba.argtypes = [C.c_void_p, C.c_int64]
         lib.myslam_scn_keyframe_pose.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        lib.myslam_materialize.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.myslam_mappoint_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         lib.myslam_get_context.argtypes = [C.c_void_p]
         lib.myslam_get_context.restype = C.c_void_p
         _libs[path] = lib
@@ -272,6 +274,17 @@ class VoSystem:
         a = np.ascontiguousarray(T_ref_cw, dtype=np.float64).reshape(12); b = np.ascontiguousarray(T_cur_cw, dtype=np.float64).reshape(12); f = C.c_int()
         self._check(self.lib.myslam_keyframe_policy(self.h, a.ctypes.data, b.ctypes.data, num_inliers, C.byref(f)), "myslam_keyframe_policy")
         return f.value
+
+    def materialize(self):
+        """device_keyframes: rebuild the host map objects from the device tables -> (keyframe ids in insertion order, on_device)."""
+        ids = np.zeros(1 << 16, np.int64); n, on = C.c_int(), C.c_int()
+        self._check(self.lib.myslam_materialize(self.h, ids.ctypes.data, len(ids), C.byref(n), C.byref(on)), "myslam_materialize")
+        return [int(v) for v in ids[:n.value]], bool(on.value)
+
+    def mappoint_ids(self, cap: int = 1 << 21):
+        ids = np.zeros(cap, np.int64); n = C.c_int()
+        self._check(self.lib.myslam_mappoint_ids(self.h, ids.ctypes.data, cap, C.byref(n)), "myslam_mappoint_ids")
+        return [int(v) for v in ids[:min(n.value, cap)]]
 
     def context_handle(self) -> int:
         return self.lib.myslam_get_context(self.h)

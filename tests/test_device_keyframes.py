@@ -1,0 +1,316 @@
+"""SURVEY 8f-2, second half: the keyframe bookkeeping on the device tables (vo_keyframe_commit, vo_map_set_active_covisible,
+vo_local_ba_resident_merge_ledger) against (a) the reference-shaped host objects of the same host layer -- Frame / Mappoint / MapManager,
+which tests/test_host_model.py pins to an independent Python model of src/frame.cpp:93-171, src/mapmanager.cpp:14-38 -- and (b) definitions
+written out in numpy below.  CPU: the restatement (oracle) in both modes.  GPU: the HIP kernels against the restatement and against the
+host objects."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ORACLE_LIB  # noqa: E402
+from rgbd_visualodometry_amd import capi, system  # noqa: E402
+
+I12 = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], float)
+
+
+@pytest.fixture(scope="module")
+def stream():
+    syn = capi.Synth()
+    return syn.render(syn.params(seed=11, speed=3.0), 0, 64, threads=8)
+
+
+def run_system(lib, stream, n, lag, dk, feats=500, lookahead=1, batch=1, **kw):
+    bgr, depth, Twc, ts = stream
+    s = system.VoSystem(lib, number_of_features=feats, ba_device_graph=1, map_descriptors_on_device=1, device_keyframes=dk, backend_lag_frames=lag,
+                        map_capacity=1 << 17, max_frames_in_flight=lookahead, track_batch=batch, **kw)
+    traj, i = [], 0
+    while i < n:
+        k = min(lookahead, n - i)
+        if lookahead > 1:
+            s.prefetch(ts[i:i + k], [bgr[j].ctypes.data for j in range(i, i + k)], [depth[j].ctypes.data for j in range(i, i + k)], bgr[0].strides[0], depth[0].strides[0], False)
+            for _ in range(k):
+                traj.append(s.add_prefetched()[1])
+        else:
+            traj.append(s.add_frame(ts[i], bgr[i], depth[i])[1])
+        i += k
+    s.flush()
+    st = s.stats()
+    kfs, on = s.materialize()
+    assert on == bool(dk)
+    order = {k: i for i, k in enumerate(kfs)}
+    cov = [{order[p]: v for p, v in s.scn_covisibility(k).items()} for k in kfs]
+    ids = s.mappoint_ids()
+    slot = {m: i for i, m in enumerate(ids)}
+    pts = [s.scn_mappoint(m) for m in ids]
+    local = [[slot[m] for m in s.scn_local_map(k)] for k in kfs[-3:]]
+    s.close()
+    return {"traj": np.array(traj), "stats": st, "covis": cov, "points": pts, "local": local, "n_kf": len(kfs)}
+
+
+def compare_runs(a, b, tol):
+    for k in ("keyframes", "map_points", "ba_runs", "triangulated", "lost", "ba_points", "ba_edges", "ba_poses", "ba_fixed", "ba_outliers"):
+        assert a["stats"][k] == b["stats"][k], k
+    np.testing.assert_allclose(a["traj"], b["traj"], atol=tol, rtol=0)
+    assert a["covis"] == b["covis"]                            # weights and the >= 15 active sets of every keyframe, both ways
+    assert len(a["points"]) == len(b["points"])
+    for p, q in zip(a["points"], b["points"]):
+        assert p["outlier"] == q["outlier"] and p["n_obs"] == q["n_obs"]
+        np.testing.assert_allclose(p["xyz"], q["xyz"], atol=tol, rtol=0)
+        np.testing.assert_allclose(p["normal"], q["normal"], atol=tol, rtol=0)
+    assert a["local"] == b["local"]                            # the local-map query, in matching order
+
+
+@pytest.mark.parametrize("lag", [0, 6])
+def test_device_keyframes_equal_the_host_objects_on_the_restatement(stream, lag):
+    """Same host layer, same C-ABI implementation, two bookkeepings: shared_ptr objects walked per keyframe against tables + one commit call.
+    -ffp-contract=off on both sides: equality to the bit, culls and triangulations included."""
+    a = run_system(ORACLE_LIB, stream, 48, lag, 0)
+    b = run_system(ORACLE_LIB, stream, 48, lag, 1)
+    assert a["stats"]["keyframes"] >= 10 and a["stats"]["ba_runs"] >= 8 and a["stats"]["triangulated"] >= (1 if lag == 0 else 5)
+    compare_runs(a, b, 0.0)
+
+
+def _two_frame_scene(L, stream, nfeat=600):
+    """Frame 0 becomes keyframe 0 through a commit without matches, frame 4 is tracked against it and committed as keyframe 1."""
+    bgr, depth, Twc, ts = stream
+    p = L.default_params(n_features=nfeat, max_frames=2, map_capacity=1 << 14)
+    ctx = L.context(p)
+    ctx.upload(0, bgr[0], depth[0]); ctx.upload(1, bgr[4], depth[4])
+    ctx.orb(0, 2)
+    k0, d0 = ctx.orb_fetch(0)
+    k1, d1 = ctx.orb_fetch(1)
+    r0, c0 = ctx.keyframe_commit(-1, 0, 0, I12, 0)
+    n0 = r0.n_new
+    na = ctx.map_set_active_covisible([0], n0, 100)
+    res, m = ctx.track(1, I12, L.default_track_params())
+    T1 = np.array(res.T_cw)
+    r1, c1 = ctx.keyframe_commit(0, 1, 1, T1, n0)
+    return ctx, p, (k0, d0, k1, d1), (r0, c0, n0, na), (res, m, T1), (r1, c1)
+
+
+def _check_commit_against_definitions(L, stream):
+    ctx, p, (k0, d0, k1, d1), (r0, c0, n0, na), (res, m, T1), (r1, c1) = _two_frame_scene(L, stream)
+    # keyframe 0: every keypoint with depth is a map point at Pixel2World (src/frontend.cpp:372-406, src/camera.cpp:41-86), identity pose
+    has = k0["depth_raw"] > 0
+    assert r0.n_matched == 0 and n0 == int(has.sum()) and c0 == {} and r0.first_obs == 0 and r0.triangulated_slot == -1
+    assert na == n0
+    t = ctx.tables(n0 + r1.n_new)
+    z = k0["depth_raw"][has].astype(np.float64) / float(np.float32(p.depth_scale))
+    fx, fy, cx, cy = (float(np.float32(v)) for v in (p.fx, p.fy, p.cx, p.cy))
+    want = np.stack([(k0["x"][has].astype(np.float64) - cx) * z / fx, (k0["y"][has].astype(np.float64) - cy) * z / fy, z], 1)
+    n_inl = int(((m["flags"] & 2) != 0).sum())
+    # (inlier points had their viewing direction updated by keyframe 1 and one of them may have been triangulated: compare the untouched ones)
+    inl_slots = m["map_index"][(m["flags"] & 2) != 0]
+    untouched = np.setdiff1d(np.arange(n0), inl_slots)
+    np.testing.assert_allclose(t["xyz"][untouched], want[untouched], atol=1e-12, rtol=0)
+    nr = want / np.linalg.norm(want, axis=1, keepdims=True)
+    np.testing.assert_allclose(t["normal"][untouched], nr[untouched], atol=1e-12, rtol=0)
+    assert np.array_equal(t["desc"][:n0], d0[has])               # the descriptor row of the keypoint (src/frontend.cpp:390)
+    # keyframe 1: one observation per LM inlier, in match order, at the matched keypoint's pixel (src/frontend.cpp:366-370)
+    assert r1.n_matched == n_inl == res.n_lm_inliers and r1.first_obs == n0
+    o = slice(n0, n0 + n_inl)
+    assert np.array_equal(t["obs_kf"][o], np.ones(n_inl, np.int32)) and np.array_equal(t["obs_mp"][o], inl_slots)
+    kp_inl = m["kp_index"][(m["flags"] & 2) != 0]
+    assert np.array_equal(t["obs_uv"][o], np.stack([k1["x"][kp_inl], k1["y"][kp_inl]], 1))
+    # the new points of keyframe 1: keypoints that are no LM inlier's and have depth, keypoint order, slots n0, n0 + 1, ...
+    free = np.ones(len(k1), bool); free[kp_inl] = False
+    new_kp = np.nonzero(free & (k1["depth_raw"] > 0))[0]
+    assert r1.n_new == len(new_kp)
+    o2 = slice(n0 + n_inl, n0 + n_inl + r1.n_new)
+    assert np.array_equal(t["obs_mp"][o2], np.arange(n0, n0 + r1.n_new)) and np.array_equal(t["obs_uv"][o2], np.stack([k1["x"][new_kp], k1["y"][new_kp]], 1))
+    assert np.array_equal(t["desc"][n0:n0 + r1.n_new], d1[new_kp])
+    R = T1[:9].reshape(3, 3); tt = T1[9:]
+    z1 = k1["depth_raw"][new_kp].astype(np.float64) / float(np.float32(p.depth_scale))
+    pc = np.stack([(k1["x"][new_kp].astype(np.float64) - cx) * z1 / fx, (k1["y"][new_kp].astype(np.float64) - cy) * z1 / fy, z1], 1)
+    np.testing.assert_allclose(t["xyz"][n0:n0 + r1.n_new], (pc - tt) @ R, atol=1e-9, rtol=0)      # R^T (p - t)
+    # viewing direction of an inlier point: mean of the two unit rays (src/mappoint.cpp:30-38)
+    C1 = -R.T @ tt
+    s = inl_slots[inl_slots != r1.triangulated_slot][:50]
+    d = want[s] - C1; d /= np.linalg.norm(d, axis=1, keepdims=True)
+    e = nr[s] + d; e /= np.linalg.norm(e, axis=1, keepdims=True)
+    np.testing.assert_allclose(t["normal"][s], e, atol=1e-12, rtol=0)
+    # covisibility: keyframe 0 shares every inlier point with keyframe 1 (src/frame.cpp:104-119); the recount from the tables agrees
+    assert c1 == {0: n_inl} and ctx.kf_covisibility(1) == {0: n_inl} and ctx.kf_covisibility(0) == {1: n_inl}
+    # the triangulation loop looked at the inliers in match order until one succeeded with z > 0 (src/frontend.cpp:465-506): none of keyframe 0's
+    # points has been optimised or triangulated before, so every inlier is a candidate
+    assert r1.n_tri_candidates >= 1
+    if r1.triangulated_slot >= 0:
+        assert r1.triangulated_slot == inl_slots[r1.n_tri_candidates - 1] and t["flags"][r1.triangulated_slot] == capi_flag("TRIANGULATED")
+        assert t["xyz"][r1.triangulated_slot][2] > 0
+        assert int((t["flags"] != 0).sum()) == 1
+    else:
+        assert r1.n_tri_candidates == n_inl and int((t["flags"] != 0).sum()) == 0
+    # local map of {0, 1}: keyframe 0's points in observation order, then keyframe 1's new ones (src/mapmanager.cpp:14-38)
+    n_all = n0 + r1.n_new
+    assert ctx.map_set_active_covisible([1, 0], n_all, 100) == n_all
+    assert np.array_equal(ctx.tables(n_all)["active"], np.arange(n_all))
+    assert ctx.map_set_active_covisible([1], n_all, 100) == n_inl + r1.n_new
+    assert np.array_equal(ctx.tables(n_all)["active"], np.concatenate([inl_slots, np.arange(n0, n_all)]))
+    assert ctx.map_set_active_covisible([1], n_all, 10 ** 6) == n_all       # fewer than min_points: the whole map (src/frontend.cpp:163-166)
+    ctx.close()
+
+
+def capi_flag(name):
+    return {"OUTLIER": 1, "TRIANGULATED": 2, "OPTIMIZED": 4}[name]
+
+
+def test_keyframe_commit_follows_the_definitions_on_the_restatement(stream):
+    _check_commit_against_definitions(capi.load(ORACLE_LIB), stream)
+
+
+def _ledger_scene(L):
+    """Three keyframes see twelve points; a resident BA with gross outliers culls observations; the merge reports the ledger's decrements."""
+    rng = np.random.default_rng(3)
+    p = L.default_params(map_capacity=256)
+    t = L.context(p); c = L.context(L.default_params(map_capacity=64))
+    nX, nK = 40, 4
+    X = rng.uniform(-1.0, 1.0, (nX, 3)) + [0, 0, 4.0]
+    poses = np.tile(I12, (nK, 1)); poses[:, 9] = -0.15 * np.arange(nK)
+    t.map_upsert(np.arange(nX, dtype=np.int32), X + rng.normal(size=X.shape) * 0.01, np.tile([0, 0, 1.0], (nX, 1)), np.zeros((nX, 32), np.uint8), np.zeros(nX, np.uint8))
+    t.kf_set_pose(np.arange(nK), poses)
+    obs = []
+    for k in range(nK):
+        for x in range(nX):
+            if (x + k) % 5 == 0:
+                continue
+            pc = X[x] + poses[k][9:]
+            uv = [p.fx * pc[0] / pc[2] + p.cx + rng.normal() * 0.2, p.fy * pc[1] / pc[2] + p.cy + rng.normal() * 0.2]
+            if x < 6 and k == x % nK:
+                uv[0] += 40.0                                    # a gross outlier: culled by the chi2 tests (src/backend.cpp:144-172)
+            if x >= 36:                                          # every observation of these points is wrong, each in its own way: some lose them all and become outliers
+                uv[0] += [60.0, -70.0, 35.0, -50.0][k] + 3 * x; uv[1] += [-45.0, 30.0, 80.0, -60.0][k]
+            obs.append((k, x, uv))
+    for k in range(nK):
+        rows = [o for o in obs if o[0] == k]
+        t.obs_append([k] * len(rows), [o[1] for o in rows], [o[2] for o in rows])
+    return t, c, nX, nK
+
+
+def _merge_ledger_against_definition(L):
+    t, c, nX, nK = _ledger_scene(L)
+    before = t.tables(nX)
+    w_before = {k: t.kf_covisibility(k) for k in range(nK)}
+    nx, nfx, ne = (capi.C.c_int32() for _ in range(3))
+    f = np.arange(nK, dtype=np.int32)
+    L.check(L.lib.vo_local_ba_resident_cut(c.h, t.h, f.ctypes.data, nK, 7.815 ** 0.5, 1.0, capi.C.byref(nx), capi.C.byref(nfx), capi.C.byref(ne)), "cut")
+    cu = np.zeros(4096, np.int64)
+    r = capi.VoBaResidentResult(None, None, None, cu.ctypes.data, 0, 4096)
+    L.check(L.lib.vo_local_ba_resident_solve(c.h, 10, 10, capi.C.byref(r)), "solve")
+    culled = sorted(int(v) for v in cu[:r.n_culled])
+    assert len(culled) >= 6
+    pairs, poses = c.merge_ledger(t, nK)
+    after = t.tables(nX)
+    # definition (src/frame.cpp:122-152, one removal after the other): the keyframes that still see the point lose one shared point with the culled one's keyframe
+    alive = before["obs_alive"].copy(); want = []
+    for o in culled:
+        alive[o] = 0
+        for q in np.nonzero((before["obs_mp"] == before["obs_mp"][o]) & (alive == 1))[0]:
+            want.append((int(before["obs_kf"][o]), int(before["obs_kf"][q])))
+    assert pairs == sorted(want)
+    assert np.array_equal(after["obs_alive"], alive)
+    # ledger after the decrements == recount from the tables
+    for k in range(nK):
+        w = dict(w_before[k])
+        for a, b in pairs:
+            if a == k:
+                w[b] -= 1
+            if b == k:
+                w[a] -= 1
+        assert {q: v for q, v in w.items() if v > 0} == t.kf_covisibility(k)
+    # flags: every point of the graph is optimised; a point without observations is an outlier (src/mappoint.cpp:40-45) and keeps its position
+    left = np.array([int(alive[before["obs_mp"] == x].sum()) for x in range(nX)])
+    assert np.array_equal((after["flags"] & 1) != 0, left == 0) and (left == 0).any()
+    assert np.all((after["flags"] & 4) != 0)
+    gone = left == 0
+    assert np.array_equal(after["xyz"][gone], before["xyz"][gone]) and not np.array_equal(after["xyz"][~gone], before["xyz"][~gone])
+    assert np.abs(poses - np.tile(I12, (nK, 1))).max() < 1.0 and not np.array_equal(poses[:, 9], -0.15 * np.arange(nK))
+    out = {"pairs": pairs, "poses": poses, "xyz": after["xyz"], "flags": after["flags"], "alive": after["obs_alive"], "culled": culled}
+    t.close(); c.close()
+    return out
+
+
+def test_merge_ledger_follows_the_definition_on_the_restatement():
+    _merge_ledger_against_definition(capi.load(ORACLE_LIB))
+
+
+# ---- the HIP path ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_keyframe_commit_hip_follows_the_definitions_and_the_restatement(stream):
+    H, O = capi.load(capi.HIP_LIB), capi.load(ORACLE_LIB)
+    _check_commit_against_definitions(H, stream)
+    outs = []
+    for L in (H, O):
+        ctx, p, kd, (r0, c0, n0, na), (res, m, T1), (r1, c1) = _two_frame_scene(L, stream)
+        t = ctx.tables(n0 + r1.n_new)
+        outs.append((r0, c0, n0, na, res, m, T1, r1, c1, t))
+        ctx.close()
+    a, b = outs
+    assert (a[2], a[3], a[1]) == (b[2], b[3], b[1]) and np.array_equal(a[5], b[5])                      # same matches -> same bookkeeping input
+    for f in ("n_matched", "n_new", "first_obs", "n_covisible", "n_tri_candidates", "triangulated_slot"):
+        assert getattr(a[7], f) == getattr(b[7], f), f
+    assert a[8] == b[8]
+    for k in ("obs_kf", "obs_mp", "obs_uv", "obs_alive", "desc", "flags", "active"):
+        assert np.array_equal(a[9][k], b[9][k]), k
+    np.testing.assert_allclose(a[9]["xyz"], b[9]["xyz"], atol=1e-9, rtol=0)      # (the tracked pose of keyframe 1 agrees to 1e-9, the points with it)
+    np.testing.assert_allclose(a[9]["normal"], b[9]["normal"], atol=1e-9, rtol=0)
+
+
+@pytest.mark.gpu
+def test_merge_ledger_hip_follows_the_definition_and_the_restatement():
+    a = _merge_ledger_against_definition(capi.load(capi.HIP_LIB))
+    b = _merge_ledger_against_definition(capi.load(ORACLE_LIB))
+    assert a["pairs"] == b["pairs"] and a["culled"] == b["culled"] and np.array_equal(a["flags"], b["flags"]) and np.array_equal(a["alive"], b["alive"])
+    np.testing.assert_allclose(a["poses"], b["poses"], atol=1e-6, rtol=0)      # (a free-gauge toy BA with gross outliers: the tolerance of the BA parity tests)
+    np.testing.assert_allclose(a["xyz"], b["xyz"], atol=1e-5, rtol=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lag,lookahead,batch", [(0, 1, 1), (6, 8, 4)])
+def test_device_keyframes_hip_equal_the_host_objects_and_the_restatement(stream, lag, lookahead, batch):
+    """The HIP kernels in both bookkeepings, and the restatement in the device bookkeeping: same keyframes, map, covisibility ledger,
+    local maps; trajectories to the tolerance of the local BA's unordered sums."""
+    h0 = run_system(system.HOST_LIB, stream, 48, lag, 0, lookahead=lookahead, batch=batch)
+    h1 = run_system(system.HOST_LIB, stream, 48, lag, 1, lookahead=lookahead, batch=batch)
+    o1 = run_system(ORACLE_LIB, stream, 48, lag, 1, lookahead=lookahead, batch=batch)
+    assert h1["stats"]["keyframes"] >= 10 and h1["stats"]["ba_runs"] >= 8
+    compare_runs(h0, h1, 1e-6)
+    compare_runs(o1, h1, 1e-6)
+
+
+@pytest.mark.gpu
+def test_device_keyframes_in_a_stream_group(stream):
+    """Members of a stream group keep their keyframes on the device too (their tracking chain is shared, the commit runs on the member's stream)."""
+    import threading
+    bgr, depth, Twc, ts = stream
+    ref = run_system(system.HOST_LIB, stream, 32, 4, 1, lookahead=4, batch=2)
+    grp = system.StreamGroup(system.HOST_LIB, 0, 32)
+    syss = [system.VoSystem(system.HOST_LIB, number_of_features=500, ba_device_graph=1, map_descriptors_on_device=1, device_keyframes=1, backend_lag_frames=4,
+                            map_capacity=1 << 17, max_frames_in_flight=4, track_batch=2) for _ in range(3)]
+    for s in syss:
+        grp.join(s)
+    out = [None] * 3
+
+    def drive(k):
+        s, traj, i = syss[k], [], 0
+        while i < 32:
+            s.prefetch(ts[i:i + 4], [bgr[j].ctypes.data for j in range(i, i + 4)], [depth[j].ctypes.data for j in range(i, i + 4)], bgr[0].strides[0], depth[0].strides[0], False)
+            for _ in range(4):
+                traj.append(s.add_prefetched()[1])
+            i += 4
+        s.flush()
+        out[k] = (np.array(traj), s.stats())
+    th = [threading.Thread(target=drive, args=(k,)) for k in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for s in syss:
+        s.close()
+    grp.close()
+    for traj, st in out:
+        assert st["keyframes"] == ref["stats"]["keyframes"] and st["map_points"] == ref["stats"]["map_points"]
+        np.testing.assert_allclose(traj, ref["traj"], atol=1e-6, rtol=0)
