@@ -275,6 +275,7 @@ def main():
     ap.add_argument("--no-latency-mode", action="store_true")
     ap.add_argument("--prologue", type=int, default=150, help="frames tracked (untimed) before the warmup so that the timed steps see the steady-state map: covisible window, BA size and active-map size level off after ~100 frames; 0 = time a young map")
     ap.add_argument("--host-graph", action="store_true", help="cut the local BA's graph on the host (Backend::Build) instead of on the device from the resident observation table")
+    ap.add_argument("--no-roofline-pass", action="store_true", help="skip the per-kernel timing pass (kernel traces of the timed pass alone; the line then carries no roofline)")
     ap.add_argument("--host-keyframes", action="store_true", help="keep the keyframe bookkeeping in host objects (round 4's path) instead of on the device tables (device_keyframes)")
     ap.add_argument("--multi-streams", default="8,16", help="comma list of stream counts for the several-streams-per-GPU figure ('' = skip)")
     ap.add_argument("--multi-device-graph", type=int, default=1, help="several-streams figure: 1 = the local BA's graph is cut on the device (as the single stream does), 0 = on the host")
@@ -378,10 +379,10 @@ def main():
         # chunk of steps -- so that HIP events bracket the solver alone: k_ba_chol16 is the same code either way)
         fuse_env = os.environ.get("VO_BA_FUSE_MAX")
         os.environ["VO_BA_FUSE_MAX"] = "0"
-        prof_sys = system.VoSystem(system.HOST_LIB, **opts)
+        prof_sys = system.VoSystem(system.HOST_LIB, **(opts if not args.no_roofline_pass else dict(opts, enable_local_optimization=0)))
         h = C.c_void_p(prof_sys.context_handle())
         L.check(L.lib.vo_profile_enable(h, 1))
-        drive(prof_sys, stamps, bptr, dptr, 0, total, args.lookahead, W)
+        drive(prof_sys, stamps, bptr, dptr, 0, total if not args.no_roofline_pass else min(total, 8), args.lookahead, W)
         prof_sys.flush()
         pst = prof_sys.stats()
         names = (C.c_char * 48 * 96)()

@@ -1430,6 +1430,12 @@ __device__ __forceinline__ void ba_cull_edge(const BaDev& B, const double* poses
 }
 // A problem enters its slot: control block of the robust round, zeroed accumulators (one workgroup; the plain chi2 of the
 // initial state follows in k_ba_chi).  The descriptor (BaDev) is the only thing the host uploads.
+// the descriptor travels as a kernel argument (a copy would be a blit kernel with its own launch gap)
+__global__ void k_ba_put_desc(BaDev v, BaDev* __restrict__ dst) {
+    const int n = (int)(sizeof(BaDev) / 4);
+    const int* src = reinterpret_cast<const int*>(&v); int* d = reinterpret_cast<int*>(dst);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) d[i] = src[i];
+}
 __global__ __launch_bounds__(256) void k_ba_admit(BaBatch Q) {
     BA_PROBLEM(Q)
     if (threadIdx.x == 0) {
@@ -1551,6 +1557,31 @@ int vo_ba_set_attrs() {
 #include <deque>
 // which layout S has (and which Cholesky kernel a problem takes): tiles + the second generation up to CH2_MAXD, packed rows + the first above; VO_CHOL_V1 forces the first
 static int ba_use_tiles(int D) { static const bool v1 = getenv("VO_CHOL_V1") != nullptr; return (!v1 && D <= CH2_MAXD) ? 1 : 0; }
+// Host waits on this latency chain poll instead of sleeping: a blocking wait costs the wake-up of a sleeping thread (10-40 us) per hand-off, and a
+// local BA has six of them.  vo_spin_event: hipEventSynchronize by polling (bounded: falls back to the blocking call after ~2 ms);
+// vo_spin_word: a word in pinned host memory that a kernel stores behind its results (system-scope fence in the kernel).
+static inline void vo_cpu_relax() { __builtin_ia32_pause(); }
+static hipError_t vo_spin_event(hipEvent_t ev) {
+    static const bool spin = !(getenv("VO_NO_SPIN") && atoi(getenv("VO_NO_SPIN")));
+    if (spin) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0;; ++i) {
+            const hipError_t e = hipEventQuery(ev);
+            if (e != hipErrorNotReady) return e;
+            for (int k = 0; k < 8; ++k) vo_cpu_relax();
+            if ((i & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        }
+    }
+    return hipEventSynchronize(ev);
+}
+static bool vo_spin_word(const volatile int* w, int want, int timeout_ms) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0;; ++i) {
+        if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == want) return true;
+        for (int k = 0; k < 4; ++k) vo_cpu_relax();
+        if ((i & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms)) return false;
+    }
+}
 static double tnow() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 struct BaJob {
     vo_ctx* c = nullptr; const vo_ba_problem* in = nullptr; vo_ba_result* out = nullptr;
@@ -1612,8 +1643,9 @@ static int ba_engine_admit(BaEngine* E) {
         int rc = VO_OK;
         if (j->wait_ev && hipStreamWaitEvent(st, j->wait_ev, 0) != hipSuccess) rc = VO_E_DEVICE;
         E->h_Bs[s] = j->B;                                  // the slot's mirror is free: its previous problem is gone
-        if (rc == VO_OK && hipMemcpyAsync(E->d_Bs + s, E->h_Bs + s, sizeof(BaDev), hipMemcpyHostToDevice, st) != hipSuccess) rc = VO_E_DEVICE;
+        static_assert(sizeof(BaDev) % 4 == 0 && sizeof(BaDev) <= 2048, "BaDev travels as a kernel argument");
         if (rc == VO_OK) {
+            hipLaunchKernelGGL(k_ba_put_desc, dim3(1), dim3(128), 0, st, j->B, E->d_Bs + s);
             const BaBatch Q = ba_batch_of(E, &s, 1);
             hipLaunchKernelGGL(k_ba_admit, dim3(1, 1, 1), dim3(256), 0, st, Q);
             if (j->B.D > BA_FOLD_D) hipLaunchKernelGGL(k_ba_chi, dim3(j->grid_e, 1, 1), dim3(256), 0, st, Q, 0, 0, 0);      // (D <= 192: k_ba_lin2 sums it in passing)
@@ -1736,7 +1768,27 @@ static int ba_engine_enqueue(BaEngine* E) {
 // the oldest chunk has passed: completions, and -- when nothing newer is in flight -- the estimates are set from the device's state
 static int ba_engine_retire(BaEngine* E) {
     BaChunk& C = E->ring[E->r_head];
-    HIP_TRY(hipEventSynchronize(C.ev_end));
+    {   // The chunk is over when its event has passed -- or, sooner, when every problem in it has reported "done": k_ba_round stores a slot's final
+        // status record in pinned memory behind a system-scope fence, and for such a slot the rest of the chunk is empty launches.  (The event becomes
+        // visible to the host tens of microseconds after the kernel has ended; the record within a few.)
+        static const bool poll = !(getenv("VO_NO_STAT_POLL") && atoi(getenv("VO_NO_STAT_POLL")));
+        bool fin = false;
+        if (poll && C.n > 0) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0;; ++i) {
+                fin = true;
+                for (int k = 0; k < C.n && fin; ++k) {
+                    const volatile BaStat* t = E->h_stat + C.sl[k];
+                    fin = __atomic_load_n(&t->stage, __ATOMIC_ACQUIRE) == 2 && t->gen == C.gen[k];
+                }
+                if (fin) break;
+                if ((i & 7) == 7) { const hipError_t e = hipEventQuery(C.ev_end); if (e == hipSuccess) break; if (e != hipErrorNotReady) HIP_TRY(e); }
+                for (int k = 0; k < 8; ++k) vo_cpu_relax();
+                if ((i & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(4)) break;
+            }
+        }
+        if (!fin) HIP_TRY(vo_spin_event(C.ev_end));
+    }
     E->r_head = (E->r_head + 1) % 2; --E->r_n;
     int fin[BA_SLOTS], nfin = 0, stuck = 0;
     for (int i = 0; i < C.n; ++i) {
@@ -1782,7 +1834,7 @@ static int ba_engine_pump(BaEngine* E) {
         int na = 0;
         for (int s = 0; s < BA_SLOTS; ++s) if (E->slot[s]) ++na;
         if (na > 1 || E->pending_hint > 0) {
-            HIP_TRY(hipEventSynchronize(E->ring[E->r_head].ev_near));
+            HIP_TRY(vo_spin_event(E->ring[E->r_head].ev_near));
             if ((rc = ba_engine_admit(E))) return rc;
         }
         if ((rc = ba_engine_enqueue(E))) return rc;
@@ -2212,13 +2264,22 @@ __global__ void k_cut_count(CutTabs T, const int* __restrict__ kf_idx, const int
 }
 struct CutFree { int n; int kf[VO_BA_RESIDENT_MAX_FREE]; };       // by value: 644 bytes of kernel arguments
 // keyframe -> pose index: the free keyframes take 0 .. n-1 in the caller's order, everything else -1 until k_cut_fixed_scan
-__global__ void k_cut_init(int n_kf, CutFree F, int* __restrict__ kf_idx, int* __restrict__ pose_kf) {
+// (the same launch zeroes the cut's flag / count / cursor arrays: a memset is a blit kernel with a launch gap of its own)
+__global__ void k_cut_init(int n_kf, CutFree F, int* __restrict__ kf_idx, int* __restrict__ pose_kf, int4* __restrict__ zero, int n_zero16) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = k; i < n_zero16; i += gridDim.x * blockDim.x) zero[i] = make_int4(0, 0, 0, 0);
     if (k < F.n) pose_kf[k] = F.kf[k];
     if (k >= n_kf) return;
     int idx = -1;
     for (int i = 0; i < F.n; ++i) if (F.kf[i] == k) idx = i;
     kf_idx[k] = idx;
+}
+// a kernel's results for the host, in pinned memory: values first, a system-scope fence, then the word the host polls (vo_spin_word)
+__global__ void k_cut_report(const int* __restrict__ src, int n, int* __restrict__ host, int* __restrict__ word, int seq) {
+    if ((int)threadIdx.x < n) host[threadIdx.x] = src[threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) { __hip_atomic_store(word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 }
 // one workgroup: fixed poses follow the free ones in ascending keyframe number (running scan over the keyframe table)
 __global__ __launch_bounds__(1024) void k_cut_fixed_scan(int n_kf, int n_free, const int* __restrict__ fixed_flag, int* __restrict__ kf_idx, int* __restrict__ pose_kf,
@@ -2476,8 +2537,10 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     HIP_TRY(hipStreamSynchronize(st));
     CutTabs T{t->d_obs_kf, t->d_obs_mp, t->d_obs_uv, t->d_obs_alive, no, t->d_map_flags, t->d_map_pos, t->d_kf_pose, nkf, map_lo + mh, obs_lo, map_lo};
     R.win_obs = no - obs_lo; R.win_slots = mh;
-    HIP_TRY(hipMemsetAsync(cb, 0, zero_end, st));
-    hipLaunchKernelGGL(k_cut_init, dim3((std::max(nkf, nf) + 255) / 256), dim3(256), 0, st, nkf, F, kf_idx, pose_kf);
+    const int n_zero16 = (int)(zero_end / 16);              // (every carve is a multiple of 256 bytes)
+    hipLaunchKernelGGL(k_cut_init, dim3(std::max((std::max(nkf, nf) + 255) / 256, std::min(64, (n_zero16 + 255) / 256))), dim3(256), 0, st, nkf, F, kf_idx, pose_kf, (int4*)cb, n_zero16);
+    const int seq = ++c->cut_seq;
+    h[132] = 0; h[133] = 0;
     const int gO = (int)((no - obs_lo + 255) / 256);
     if (gO) hipLaunchKernelGGL(k_cut_points, dim3(gO), dim3(256), 0, st, T, kf_idx, pt_flag);
     int rc = vo_scan_i32(st, pt_flag, mh, bsum, pidx, tot);                        // dense point index, nx
@@ -2487,8 +2550,9 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     // the map is in the graph), ne
     if ((rc = vo_scan_i32(st, cnt, mh + 1, bsum, pt_start, tot + 1))) return rc;
     hipLaunchKernelGGL(k_cut_fixed_scan, dim3(1), dim3(1024), 0, st, nkf, nf, fixed_flag, kf_idx, pose_kf, tot + 2);
-    HIP_TRY(hipMemcpyAsync(h + 128, tot, 12, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    hipLaunchKernelGGL(k_cut_report, dim3(1), dim3(64), 0, st, (const int*)tot, 3, h + 128, h + 132, seq);      // sizes to the host without a copy or a blocking wait
+    HIP_TRY(hipGetLastError());
+    if (!vo_spin_word(h + 132, seq, 2000)) HIP_TRY(hipStreamSynchronize(st));
     const int nx = h[128], ne = h[129], n_fixed = h[130], np = nf + n_fixed;
     R.np = np; R.nf = nf; R.nx = nx; R.ne = ne; R.n_fixed = n_fixed;
     if (nx == 0 || ne == 0 || nf == 0) { R.ready = true; return VO_OK; }         // nothing to optimise
@@ -2524,7 +2588,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     hipLaunchKernelGGL(k_ps_offsets, dim3(nf), dim3(256), 0, st, chunks, nf, (const int*)(base + o_hist), (int*)(base + o_offs), (int*)(base + o_ptot));
     hipLaunchKernelGGL(k_ps_fill, dim3(chunks), dim3(PS_CHUNK), 0, st, ne, nf, e_pose, e_pt, (const int*)(base + o_offs), (const int*)(base + o_ptot), (int*)(base + o_qs),
                        (int32_t*)(base + o_qe), (int32_t*)(base + o_pspt));
-    HIP_TRY(hipMemcpyAsync(h + 256, base + o_qs, 4 * (size_t)(nf + 1), hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(k_cut_report, dim3(1), dim3(256), 0, st, (const int*)(base + o_qs), nf + 1, h + 256, h + 133, seq);      // the list lengths; behind it every input of `t` has been gathered
     // the counting pass and the scan of the pair plan go out BEFORE the host looks at the list lengths (with the largest LDS a list may
     // need): the stream works through them while the host wakes up, checks the lengths and fills in the descriptor (~25 us per cut)
     BaPairPlan Q;
@@ -2535,7 +2599,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     HIP_TRY(hipEventRecord(R.ev_arrays, st));               // (the first linearisation needs no pairs: it may start here)
     hipLaunchKernelGGL(k_ba_pairs<false>, dim3(nb_all), dim3(256), 4 * (size_t)PAIR_LDS_CAP, st, Q);      // (a list beyond the cap: its stores past the allocation are dropped, the cut is refused below)
     hipLaunchKernelGGL(k_ba_pairs_scan, dim3(1), dim3(1024), 0, st, Q, nb_all);
-    HIP_TRY(hipEventSynchronize(R.ev_arrays));              // from here on `t` may change: every input has been gathered (and the list lengths are in h)
+    if (!vo_spin_word(h + 133, seq, 2000)) HIP_TRY(hipEventSynchronize(R.ev_arrays));      // from here on `t` may change: every input has been gathered (and the list lengths are in h)
     const int* ps_start = h + 256;
     int max_len = 0, npairs = 0, slices_ub = 0;
     for (int j = 0; j < nf; ++j) max_len = std::max(max_len, ps_start[j + 1] - ps_start[j]);
@@ -2691,14 +2755,17 @@ static int ba_resident_merge(vo_ctx* c, vo_ctx* t, bool ledger, int32_t* pair_a,
     hipLaunchKernelGGL(k_ba_merge, dim3((n + 255) / 256), dim3(256), 0, t->stream, nf, nx, (const double*)(R.cur_buf ? B.posesB : B.posesA), (const double*)(R.cur_buf ? B.ptsB : B.ptsA),
                        (const int*)R.d_pose_kf, (const int32_t*)R.d_point_slots, (const int*)R.d_ncull, (const long long*)R.d_cull, R.cull_cap, t->d_map_pos, t->d_map_flags,
                        t->d_kf_pose, t->d_obs_alive, (double*)sb, (double*)(sb + o_pts), (int32_t*)(sb + o_sl), ledger ? 1 : 0, ledger ? h_poses : (double*)nullptr);
-    if (!R.ev_merge) HIP_TRY(hipEventCreateWithFlags(&R.ev_merge, hipEventDisableTiming));
-    if (!R.fetch_stream) HIP_TRY(vo_stream_create(&R.fetch_stream, -1, "VO_FETCH_PRIO"));      // lowest class: three small copies behind an event wait must not sit in a queue a chain uses
-    HIP_TRY(hipEventRecord(R.ev_merge, t->stream));
-    HIP_TRY(hipStreamWaitEvent(c->stream, R.ev_merge, 0));
-    HIP_TRY(hipStreamWaitEvent(R.fetch_stream, R.ev_merge, 0));
+    if (!ledger) {                                          // (with the ledger the call waits for the tables' stream below: the next cut and a fetch are behind it anyway)
+        if (!R.ev_merge) HIP_TRY(hipEventCreateWithFlags(&R.ev_merge, hipEventDisableTiming));
+        if (!R.fetch_stream) HIP_TRY(vo_stream_create(&R.fetch_stream, -1, "VO_FETCH_PRIO"));      // lowest class: three small copies behind an event wait must not sit in a queue a chain uses
+        HIP_TRY(hipEventRecord(R.ev_merge, t->stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream, R.ev_merge, 0));
+        HIP_TRY(hipStreamWaitEvent(R.fetch_stream, R.ev_merge, 0));
+    }
     HIP_TRY(hipGetLastError());
     if (ledger) {                                           // the caller's ledger needs the pairs before it picks the next free keyframes
         HIP_TRY(hipStreamSynchronize(t->stream));
+        if (!R.fetch_stream) HIP_TRY(vo_stream_create(&R.fetch_stream, -1, "VO_FETCH_PRIO"));      // (a later _fetch of this result finds its stream; idle, it needs no event)
         const int np = std::min(*h_np, h_cap), take = std::min(np, cap_pairs);
         if (take > 0) { memcpy(pair_a, h_pa, 4 * (size_t)take); memcpy(pair_b, h_pb, 4 * (size_t)take); }
         *n_pairs = take;

@@ -144,6 +144,7 @@ struct vo_ctx {
     double* d_kf_pose = nullptr; int n_kf = 0, kf_cap = 0;
     int map_hi = 0;                                         // highest map slot ever upserted + 1
     void* d_cut = nullptr; size_t d_cut_bytes = 0;          // scratch of the resident graph cut
+    int cut_seq = 0;                                        // sequence number of the cut's pinned report words
     struct BaResident* resident = nullptr;                  // state between vo_local_ba_resident_cut and _solve (vo_ba.hip)
     // vo_track_batch_begin / _end: the request of the chain in flight (copies: the caller's arrays need not outlive _begin)
     bool async_pending = false; int async_n = 0, async_cap = 0; std::vector<int> async_slots; std::vector<uint64_t> async_seeds; double async_T0[12]; vo_track_params async_tp;

@@ -9,6 +9,8 @@
 // lag = 0 (default) solves and merges synchronously inside OptimizeCovisibleGraphOfKeyframe.
 #ifndef MYSLAM_BACKEND_H
 #define MYSLAM_BACKEND_H
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <thread>
 
@@ -72,6 +74,11 @@ private:
     std::vector<int32_t> applySlots_; std::vector<double> applyXyz_;      // merge scratch
     std::unique_ptr<Job> job_;
     std::thread worker_; std::mutex mu_; std::condition_variable cv_; bool quit_ = false, hasWork_ = false;
+    // The two hand-offs of an overlapped BA (tracker -> worker: a job; worker -> tracker: done / graph cut done) are on the latency chain that bounds a
+    // single stream: both sides poll these counters for a few hundred microseconds before they sleep on the condition variable.
+    std::atomic<int> workSeq_{0}, doneSeq_{0}, cutSeq_{0};
+    bool spin_ = true;
+    template <typename Pred> void SpinThenWait(std::unique_lock<std::mutex>& lk, std::atomic<int>& seq, int seen, Pred pred);
     Stats stats_;
     void Build(Job& j, const Frame::Ptr& kf);
     void Solve(Job& j, vo_ctx* ctx);
@@ -83,6 +90,7 @@ private:
     void EnsureWorker();            // the worker's context, stream and thread exist before the first keyframe (no one-time setup inside a timed run)
     bool deviceGraph_ = false, deviceKeyframes_ = false;
     std::vector<int32_t> pairA_, pairB_;            // ledger decrements of a merge (device keyframes)
+    std::vector<int64_t> culledSpare_;              // the culled-observation list's buffer, handed from job to job
     void FinishOnDevice(Job& j, vo_ctx* solver);
     bool fixOldest_ = false;        // ba_fix_oldest_free_keyframe: gauge-anchor experiment
     void SolveResident(Job& j, vo_ctx* ctx);

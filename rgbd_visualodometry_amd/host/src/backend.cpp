@@ -23,6 +23,7 @@ Backend::Backend(const Camera::Ptr camera) : camera_(camera) {
     // experiment key (not a reference setting): the reference never fixes a vertex (backend.cpp:49-59: setFixed(id == 0), ids start at 1), so
     // every local BA floats in its 6-dof gauge.  With this key the OLDEST keyframe of the free set is treated as fixed.
     if (Config::has("ba_fix_oldest_free_keyframe")) fixOldest_ = Config::get<int>("ba_fix_oldest_free_keyframe") != 0;
+    if (const char* e = std::getenv("VO_NO_SPIN")) spin_ = std::atoi(e) == 0;                    // A/B runs
     if (const char* e = std::getenv("VO_BA_FIX_OLDEST")) fixOldest_ = std::atoi(e) != 0;      // the same switch for drivers without a config file (scripts/exp_gauge.sh)
 }
 
@@ -47,30 +48,48 @@ void Backend::EnsureWorker() {
 void Backend::Stop() {
     if (job_) Finish();
     if (worker_.joinable()) {
-        { std::unique_lock<std::mutex> lk(mu_); quit_ = true; }
+        { std::unique_lock<std::mutex> lk(mu_); quit_ = true; workSeq_.fetch_add(1, std::memory_order_release); }
         cv_.notify_all();
         worker_.join();
     }
 }
 
+// poll `seq` (it changes when the other side has something for us) for up to ~300 us with the lock released, then wait on the condition variable
+template <typename Pred> void Backend::SpinThenWait(std::unique_lock<std::mutex>& lk, std::atomic<int>& seq, int seen, Pred pred) {
+    if (spin_ && !pred()) {
+        lk.unlock();
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; seq.load(std::memory_order_acquire) == seen; ++i) {
+            __builtin_ia32_pause();
+            if ((i & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) break;
+        }
+        lk.lock();
+    }
+    cv_.wait(lk, pred);
+}
+
 void Backend::WorkerLoop() {
+    int seenWork = 0;
     for (;;) {
         std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] { return quit_ || hasWork_; });
+        SpinThenWait(lk, workSeq_, seenWork, [&] { return quit_ || hasWork_; });
+        seenWork = workSeq_.load(std::memory_order_acquire);
         if (quit_) return;
         hasWork_ = false;
         Job* j = job_.get();
         lk.unlock();
         if (j->resident) {                                   // cut on the device from the tracker's tables, then solve
             auto t0 = std::chrono::steady_clock::now();
-            j->rc = vo_local_ba_resident_cut(ctxOwn_, ctx_, j->freeKf.data(), (int)j->freeKf.size(), std::sqrt(7.815), chi2Threshold_, &j->nPoints, &j->nFixed, &j->nEdges);
-            lk.lock(); j->cutDone = true; cv_.notify_all(); lk.unlock();
-            if (j->rc == VO_OK) SolveResident(*j, ctxOwn_);
+            { VO_SCOPE("bw.cut");
+            j->rc = vo_local_ba_resident_cut(ctxOwn_, ctx_, j->freeKf.data(), (int)j->freeKf.size(), std::sqrt(7.815), chi2Threshold_, &j->nPoints, &j->nFixed, &j->nEdges); }
+            lk.lock(); j->cutDone = true; cutSeq_.fetch_add(1, std::memory_order_release); cv_.notify_all(); lk.unlock();
+            if (j->rc == VO_OK) { VO_SCOPE("bw.solve"); SolveResident(*j, ctxOwn_); }
             j->solveMs = ms_since(t0);
         } else Solve(*j, ctxOwn_);
         j->tDone = std::chrono::steady_clock::now();
         lk.lock();
         j->done = true;
+        doneSeq_.fetch_add(1, std::memory_order_release);
         cv_.notify_all();
     }
 }
@@ -84,7 +103,7 @@ bool Backend::Poll(size_t frameIndex) {
 void Backend::Finish(bool deferTail) {
     auto t0 = std::chrono::steady_clock::now();
     bool waited = false;
-    if (lag_ > 0) { std::unique_lock<std::mutex> lk(mu_); waited = !job_->done; cv_.wait(lk, [&] { return job_->done; }); }
+    if (lag_ > 0) { VO_SCOPE("ba.wait_done"); const int seen = doneSeq_.load(std::memory_order_acquire); std::unique_lock<std::mutex> lk(mu_); waited = !job_->done; SpinThenWait(lk, doneSeq_, seen, [&] { return job_->done; }); }
     stats_.ms_wait += ms_since(t0);
     const auto tWake = std::chrono::steady_clock::now();
     if (waited) { stats_.ms_wake += std::chrono::duration<double, std::milli>(tWake - job_->tDone).count(); ++stats_.waited; }
@@ -138,6 +157,7 @@ void Backend::FinishOnDevice(Job& j, vo_ctx* solver) {
     for (int p = 0; p < j.nFree; ++p) j.poseFrames[p]->SetPose(SE3::from12(&j.posesOut[12 * (size_t)p]));
     stats_.runs++; stats_.poses = j.nFree; stats_.fixed = j.nFixed; stats_.points = j.nPoints; stats_.edges = j.nEdges; stats_.outliers = j.nCulled; stats_.ms_solve += j.solveMs;
     { const double D = 6.0 * j.nFree; stats_.sum_d3 += D * D * D; stats_.sum_d2 += D * D; stats_.sum_edges += j.nEdges; }
+    if (j.culled.capacity() > culledSpare_.capacity()) culledSpare_.swap(j.culled);      // the list's buffer goes on to the next job
 }
 
 void Backend::FinishTail() {
@@ -166,6 +186,7 @@ void Backend::FinishTail() {
     }
     stats_.runs++; stats_.poses = j.nFree; stats_.fixed = j.nFixed; stats_.points = j.nPoints; stats_.edges = j.nEdges; stats_.outliers = j.nCulled; stats_.ms_solve += j.solveMs;
     { const double D = 6.0 * j.nFree; stats_.sum_d3 += D * D * D; stats_.sum_d2 += D * D; stats_.sum_edges += j.nEdges; }
+    if (j.culled.capacity() > culledSpare_.capacity()) culledSpare_.swap(j.culled);
 }
 
 void Backend::OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr, bool deferTail) {
@@ -173,6 +194,7 @@ void Backend::OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr, bo
     auto t0 = std::chrono::steady_clock::now();
     if (job_) Finish(true);                          // the previous result is merged before a new graph is cut (its host-side copy follows below, beside the new solve)
     std::unique_ptr<Job> j(new Job);
+    j->culled.swap(culledSpare_);                    // (the previous job's list buffer, see SolveResident)
     j->frameIndex = frameIndex_;
     // The device graph cut takes VO_BA_RESIDENT_MAX_FREE free poses (include/vo_hip.h; the same number as maxFree_'s default).  A keyframe with
     // more covisible keyframes than that hands the graph cut back to the host for the rest of the run -- the same transition as a full
@@ -209,7 +231,7 @@ void Backend::OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr, bo
             job_->done = true; Finish();
         } else {
             EnsureWorker();
-            { std::unique_lock<std::mutex> lk(mu_); hasWork_ = true; }
+            { std::unique_lock<std::mutex> lk(mu_); hasWork_ = true; workSeq_.fetch_add(1, std::memory_order_release); }
             cv_.notify_all();
         }
         if (!deferTail) FinishTail();
@@ -224,7 +246,7 @@ void Backend::OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr, bo
     if (lag_ == 0) { Solve(*job_, ctx_); job_->done = true; Finish(); }
     else {
         EnsureWorker();
-        { std::unique_lock<std::mutex> lk(mu_); hasWork_ = true; }
+        { std::unique_lock<std::mutex> lk(mu_); hasWork_ = true; workSeq_.fetch_add(1, std::memory_order_release); }
         cv_.notify_all();
     }
     stats_.ms += ms_since(t0);
@@ -331,16 +353,20 @@ void Backend::Solve(Job& j, vo_ctx* ctx) {
 
 void Backend::WaitGraphCut() {
     if (!job_ || !job_->resident || lag_ == 0) return;
+    const int seen = cutSeq_.load(std::memory_order_acquire);
     std::unique_lock<std::mutex> lk(mu_);
-    cv_.wait(lk, [&] { return job_->cutDone; });
+    SpinThenWait(lk, cutSeq_, seen, [&] { return job_->cutDone; });
 }
 
 void Backend::SolveResident(Job& j, vo_ctx* ctx) {
     if (j.nPoints == 0 || j.nEdges == 0) { j.nCulled = 0; return; }
-    j.culled.resize((size_t)j.nEdges);
+    // (sized once and kept: an edge-sized vector per BA is 800 KB of page faults and an munmap on the latency chain; more culled observations
+    // than this come back as VO_E_OVERFLOW and the BA is skipped)
+    const size_t cullCap = std::min<size_t>((size_t)j.nEdges, 1 << 16);
+    if (j.culled.size() < cullCap) j.culled.resize(cullCap);
     vo_ba_resident_result r;
     std::memset(&r, 0, sizeof(r));                   // poses / point_slots / points stay NULL: the result is merged on the device (Finish) and fetched later (FinishTail)
-    r.culled_obs = j.culled.data(); r.cap_culled = j.nEdges;
+    r.culled_obs = j.culled.data(); r.cap_culled = (int)cullCap;
     j.rc = vo_local_ba_resident_solve(ctx, 10, 10, &r);                                  // backend.cpp:141,:159
     j.nCulled = r.n_culled;
 }

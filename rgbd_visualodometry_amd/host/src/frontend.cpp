@@ -161,12 +161,12 @@ bool FrontEnd::TrackingHandler() {
     // Overlapped back-end with the graph on the device: the previous local BA is merged (host ledger + device tables), the map points that lost their
     // last observation to it are flushed before the next cut reads the tables, the next BA starts, the NEXT FRAMES' tracking chain is launched -- and
     // only then the merged result is copied into the host objects, while the GPU tracks.
-    { StageTimer t(stats_.ms_backend); backend_->MergePending(); }
+    { StageTimer t(stats_.ms_backend); VO_SCOPE("kf.merge_pending"); backend_->MergePending(); }
     { StageTimer t(stats_.ms_flush); FlushDirtyMappoints(); }
-    { StageTimer t(stats_.ms_backend); backend_->OptimizeCovisibleGraphOfKeyframe(frameCurr_, true); }
+    { StageTimer t(stats_.ms_backend); VO_SCOPE("kf.start_ba"); backend_->OptimizeCovisibleGraphOfKeyframe(frameCurr_, true); }
     framePrev_ = frameCurr_;
     keyframeRef_ = frameCurr_;
-    { StageTimer t(stats_.ms_track); LaunchTrackAhead(); }
+    { StageTimer t(stats_.ms_track); VO_SCOPE("kf.track_ahead"); LaunchTrackAhead(); }
     { StageTimer t(stats_.ms_backend); backend_->FinishTailNow(); }
     return true;
 }
