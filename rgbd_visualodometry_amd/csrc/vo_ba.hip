@@ -2457,7 +2457,7 @@ __global__ void k_ba_merge(int nf, int nx, const double* __restrict__ poses, con
 // observations one after the other; with c < c' both culled from one point, the pair (K, K') is therefore reported once, from c.  Phases: mark the
 // culled observations (alive = 2), walk each one's point chain, clear them.
 __global__ __launch_bounds__(256) void k_merge_ledger(const int* __restrict__ n_cull, const long long* __restrict__ cull, int cull_cap, const int32_t* __restrict__ obs_kf,
-                                                      const int32_t* __restrict__ obs_mp, uint8_t* __restrict__ obs_alive, const int32_t* __restrict__ obs_prev, const int32_t* __restrict__ pt_last,
+                                                      const int32_t* __restrict__ obs_mp, uint8_t* __restrict__ obs_alive, const int2* __restrict__ obs_link, const int32_t* __restrict__ pt_last,
                                                       uint8_t* __restrict__ map_flags, int* __restrict__ pair_a, int* __restrict__ pair_b, int pair_cap, int* __restrict__ n_pairs_total) {
     __shared__ int s_n;
     const int n = min(*n_cull, cull_cap);
@@ -2469,11 +2469,14 @@ __global__ __launch_bounds__(256) void k_merge_ledger(const int* __restrict__ n_
         if (obs_alive[c] != 2) continue;
         const int K = obs_kf[c], P = obs_mp[c];
         int survivors = 0;
-        for (int q = pt_last[P]; q >= 0; q = obs_prev[q]) {
+        for (int q = pt_last[P]; q >= 0;) {
+            const int2 l = obs_link[q];
             const int a = obs_alive[q];
-            if (q == c || !a) continue;
-            if (a == 1) ++survivors;
-            if (a == 1 || q > c) { const int pos = atomicAdd(&s_n, 1); if (pos < pair_cap) { pair_a[pos] = K; pair_b[pos] = obs_kf[q]; } }
+            if (q != c && a) {
+                if (a == 1) ++survivors;
+                if (a == 1 || q > c) { const int pos = atomicAdd(&s_n, 1); if (pos < pair_cap) { pair_a[pos] = K; pair_b[pos] = l.y; } }
+            }
+            q = l.x;
         }
         if (survivors == 0) map_flags[P] |= VO_MAP_FLAG_OUTLIER;
     }
@@ -2729,7 +2732,7 @@ static int ba_resident_merge(vo_ctx* c, vo_ctx* t, bool ledger, int32_t* pair_a,
     BaResident& R = *c->resident;
     int* h_pa = nullptr; int* h_pb = nullptr; int* h_np = nullptr; double* h_poses = nullptr; int h_cap = 0;
     if (ledger) {
-        if (!t->d_obs_prev || !t->d_pt_last) return VO_E_STATE;
+        if (!t->d_obs_link || !t->d_pt_last) return VO_E_STATE;
         int rc = vo_kf_host_pairs(t, &h_pa, &h_pb, &h_cap, &h_np, &h_poses);
         if (rc) return rc;
         *h_np = 0;
@@ -2751,7 +2754,7 @@ static int ba_resident_merge(vo_ctx* c, vo_ctx* t, bool ledger, int32_t* pair_a,
     const int n = std::max(std::max(nx, 12 * nf), R.n_culled);
     if (ledger)       // first: a point that loses its last observation here keeps its position (src/backend.cpp:191: outliers are skipped)
         hipLaunchKernelGGL(k_merge_ledger, dim3(1), dim3(256), 0, t->stream, (const int*)R.d_ncull, (const long long*)R.d_cull, R.cull_cap, (const int32_t*)t->d_obs_kf, (const int32_t*)t->d_obs_mp,
-                           t->d_obs_alive, (const int32_t*)t->d_obs_prev, (const int32_t*)t->d_pt_last, t->d_map_flags, h_pa, h_pb, h_cap, h_np);
+                           t->d_obs_alive, (const int2*)t->d_obs_link, (const int32_t*)t->d_pt_last, t->d_map_flags, h_pa, h_pb, h_cap, h_np);
     hipLaunchKernelGGL(k_ba_merge, dim3((n + 255) / 256), dim3(256), 0, t->stream, nf, nx, (const double*)(R.cur_buf ? B.posesB : B.posesA), (const double*)(R.cur_buf ? B.ptsB : B.ptsA),
                        (const int*)R.d_pose_kf, (const int32_t*)R.d_point_slots, (const int*)R.d_ncull, (const long long*)R.d_cull, R.cull_cap, t->d_map_pos, t->d_map_flags,
                        t->d_kf_pose, t->d_obs_alive, (double*)sb, (double*)(sb + o_pts), (int32_t*)(sb + o_sl), ledger ? 1 : 0, ledger ? h_poses : (double*)nullptr);

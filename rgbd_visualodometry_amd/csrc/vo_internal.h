@@ -130,9 +130,9 @@ struct vo_ctx {
     // device-resident keyframe bookkeeping: observation table and keyframe poses, fixed capacity (a back-end
     // thread may be reading them while the tracker appends: no reallocation, appends only write beyond what a reader was given)
     int32_t* d_obs_kf = nullptr; int32_t* d_obs_mp = nullptr; float* d_obs_uv = nullptr; uint8_t* d_obs_alive = nullptr;
-    // per-point chains through the observation table (vo_kf.hip): obs_prev[o] = the previous (older) observation of o's map point (-1: none),
+    // per-point chains through the observation table (vo_kf.hip): obs_link[o] = int2(the previous, older observation of o's map point or -1, o's keyframe),
     // pt_last[slot] / pt_first[slot] = a point's newest / oldest observation (-1: none); d_kf_reach[kf] = (obs_lo, slot_lo) as int2
-    int32_t* d_obs_prev = nullptr; int32_t* d_pt_last = nullptr; int32_t* d_pt_first = nullptr; int* d_kf_reach = nullptr;
+    int* d_obs_link = nullptr; int32_t* d_pt_last = nullptr; int32_t* d_pt_first = nullptr; int* d_kf_reach = nullptr;
     struct KfState* kf = nullptr;                           // buffers of vo_keyframe_commit / vo_map_set_active_covisible (vo_kf.hip)
     std::vector<long long> kf_first_obs;                    // host: where a keyframe's own observations begin in the table (-1: none yet)
     long long n_pre_calls = 0, n_pre_unpinned = 0, n_pre_frames = 0, n_up_hit = 0, n_up_copy = 0;      // VO_TRACE: how the frames reached the device (vo_frames_preload / vo_frame_upload)

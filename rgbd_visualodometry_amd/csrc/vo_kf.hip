@@ -4,7 +4,7 @@
 // src/mappoint.cpp:17-49, src/mapmanager.cpp:14-38) and walks them at every keyframe.  Here the same state is four flat tables in HBM:
 //
 //   observation table   (keyframe number, map slot, pixel, alive) per observation, append-only; an observation's index is its id
-//   per-point chains    obs_prev[o] = the previous (older) observation of the same map point, pt_last[slot] = its newest one,
+//   per-point chains    obs_link[o] = (the previous, older observation of the same map point; its keyframe), pt_last[slot] = its newest one,
 //                       pt_first[slot] = its oldest one: "who else sees this point" is a walk of 2 .. ~20 links instead of a table scan
 //   map SoA             position, mean viewing direction, descriptor, flags (outlier / triangulated / optimised) per slot
 //   keyframe poses      T_cw per keyframe number
@@ -13,8 +13,8 @@
 //   k_kf_commit   one workgroup: LM-inlier matches -> observations + viewing directions (src/frontend.cpp:366-370, src/frame.cpp:93-120,
 //                 src/mappoint.cpp:30-38); unmatched keypoints with depth -> new map points (src/frontend.cpp:372-406,
 //                 src/camera.cpp:41-86); ordered by block-wide ballot scans, so slots and observation ids are those of the host loop
-//   k_kf_covis    one lane per new observation: walks the point's chain, +1 for every keyframe that already sees it (src/frame.cpp:104-119)
-//   k_kf_tri      one lane per candidate of the reference's triangulation loop (src/frontend.cpp:465-506): views gathered along the chain
+//   k_kf_covis_tri  two independent jobs side by side: one lane per new observation walks the point's chain, +1 for every keyframe that already sees it
+//                 (src/frame.cpp:104-119); one lane per candidate of the reference's triangulation loop (src/frontend.cpp:465-506), views gathered along the chain
 //   k_kf_finish   one workgroup: the covisibility weights as an ascending (keyframe, weight) list and the FIRST successful triangulation
 //                 (the reference's loop breaks there) go straight into pinned host memory with the counts
 // The local-map query (src/mapmanager.cpp:14-38) is vo_map_set_active_covisible, the ledger side of a BA merge (src/frame.cpp:122-152)
@@ -29,12 +29,12 @@
 #include "vo_tri_dev.h"
 
 // ---- table management -------------------------------------------------------------------------------------------------------------
-#define VO_OBS_CAP (256ll << 20)    // observations the table may grow to (21 B each: 5.4 GB); ~5000 per keyframe at the bench workload: ~170 000 frames
+#define VO_OBS_CAP (256ll << 20)    // observations the table may grow to (25 B each: 6.4 GB); ~5000 per keyframe at the bench workload: ~170 000 frames
 #define VO_KF_CAP 65536             // keyframes (96 B each)
 // The observation table starts at VO_OBS_CAP0 entries and doubles when a keyframe does not fit, up to VO_OBS_CAP (env VO_OBS_CAP lowers
 // that bound: tests exercise the overflow path with it).  Growing copies the live prefix on the context's stream and waits for it: nothing
 // may be reading the table then -- the front-end appends only behind Backend::WaitGraphCut, and merges are ordered on this stream.
-#define VO_OBS_CAP0 (4ll << 20)     // 84 MB; ~800 keyframes of the bench workload
+#define VO_OBS_CAP0 (4ll << 20)     // 100 MB; ~800 keyframes of the bench workload
 #define KF_COVIS_CAP 4096           // partners of one keyframe that fit the pinned result block
 #define KF_PAIR_CAP 16384           // ledger decrements of one BA merge
 #define KF_LIST_CAP 4096            // keyframes of one local-map query
@@ -60,10 +60,10 @@ struct KfState {
     uint32_t epoch = 0;
 };
 
-static int obs_tables_alloc(long long cap, int32_t** kf, int32_t** mp, float** uv, uint8_t** alive, int32_t** prev) {
+static int obs_tables_alloc(long long cap, int32_t** kf, int32_t** mp, float** uv, uint8_t** alive, int** prev) {
     *kf = nullptr; *mp = nullptr; *uv = nullptr; *alive = nullptr; *prev = nullptr;
     if (hipMalloc((void**)kf, 4 * (size_t)cap) != hipSuccess || hipMalloc((void**)mp, 4 * (size_t)cap) != hipSuccess ||
-        hipMalloc((void**)uv, 8 * (size_t)cap) != hipSuccess || hipMalloc((void**)alive, (size_t)cap) != hipSuccess || hipMalloc((void**)prev, 4 * (size_t)cap) != hipSuccess) {
+        hipMalloc((void**)uv, 8 * (size_t)cap) != hipSuccess || hipMalloc((void**)alive, (size_t)cap) != hipSuccess || hipMalloc((void**)prev, 8 * (size_t)cap) != hipSuccess) {
         // all or nothing: a later call must not find one array set beside null siblings
         void* q[] = {*kf, *mp, *uv, *alive, *prev};
         for (void* x : q) if (x) (void)hipFree(x);
@@ -94,7 +94,7 @@ int vo_obs_tables_ensure(vo_ctx* c) {     // allocates the observation / keyfram
     const size_t M = (size_t)c->p.map_capacity;
     bool ok = hipMalloc((void**)&c->d_kf_pose, 96 * (size_t)c->kf_cap) == hipSuccess && hipMalloc((void**)&c->d_pt_last, 4 * M) == hipSuccess &&
               hipMalloc((void**)&c->d_pt_first, 4 * M) == hipSuccess && hipMalloc((void**)&c->d_kf_reach, 8 * (size_t)c->kf_cap) == hipSuccess;
-    ok = ok && obs_tables_alloc(cap, &c->d_obs_kf, &c->d_obs_mp, &c->d_obs_uv, &c->d_obs_alive, &c->d_obs_prev) == VO_OK;
+    ok = ok && obs_tables_alloc(cap, &c->d_obs_kf, &c->d_obs_mp, &c->d_obs_uv, &c->d_obs_alive, &c->d_obs_link) == VO_OK;
     if (!ok) {
         void* q[] = {c->d_kf_pose, c->d_pt_last, c->d_pt_first, c->d_kf_reach};
         for (void* x : q) if (x) (void)hipFree(x);
@@ -110,18 +110,18 @@ int vo_obs_tables_ensure(vo_ctx* c) {     // allocates the observation / keyfram
 static int obs_tables_grow(vo_ctx* c, long long need) {
     long long cap = c->obs_cap;
     while (cap < need) cap = std::min(2 * cap, c->obs_cap_max);
-    int32_t* kf; int32_t* mp; float* uv; uint8_t* alive; int32_t* prev;
+    int32_t* kf; int32_t* mp; float* uv; uint8_t* alive; int* prev;
     int rc = obs_tables_alloc(cap, &kf, &mp, &uv, &alive, &prev);
     if (rc) return rc;
     const size_t n = (size_t)c->n_obs;
     if (n) {
         HIP_TRY(hipMemcpyAsync(kf, c->d_obs_kf, 4 * n, hipMemcpyDeviceToDevice, c->stream)); HIP_TRY(hipMemcpyAsync(mp, c->d_obs_mp, 4 * n, hipMemcpyDeviceToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(uv, c->d_obs_uv, 8 * n, hipMemcpyDeviceToDevice, c->stream)); HIP_TRY(hipMemcpyAsync(alive, c->d_obs_alive, n, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(prev, c->d_obs_prev, 4 * n, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(prev, c->d_obs_link, 8 * n, hipMemcpyDeviceToDevice, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    (void)hipFree(c->d_obs_kf); (void)hipFree(c->d_obs_mp); (void)hipFree(c->d_obs_uv); (void)hipFree(c->d_obs_alive); (void)hipFree(c->d_obs_prev);
-    c->d_obs_kf = kf; c->d_obs_mp = mp; c->d_obs_uv = uv; c->d_obs_alive = alive; c->d_obs_prev = prev; c->obs_cap = cap;
+    (void)hipFree(c->d_obs_kf); (void)hipFree(c->d_obs_mp); (void)hipFree(c->d_obs_uv); (void)hipFree(c->d_obs_alive); (void)hipFree(c->d_obs_link);
+    c->d_obs_kf = kf; c->d_obs_mp = mp; c->d_obs_uv = uv; c->d_obs_alive = alive; c->d_obs_link = prev; c->obs_cap = cap;
     return VO_OK;
 }
 static int obs_room(vo_ctx* c, long long n) {               // make room for n more observations
@@ -163,13 +163,13 @@ int vo_kf_host_pairs(vo_ctx* c, int** pair_a, int** pair_b, int* cap, int** n_to
 // vo_obs_append: the packed upload -> the observation table's columns, the points' chains and the keyframes' reach.  One launch per run of
 // equal keyframe numbers: inside a run every map slot occurs once (a keyframe observes a point once), so the chain updates do not collide.
 __global__ void k_obs_append(int n, int at, const int32_t* __restrict__ kf, const int32_t* __restrict__ mp, const float2* __restrict__ uv,
-                             int32_t* __restrict__ o_kf, int32_t* __restrict__ o_mp, float2* __restrict__ o_uv, uint8_t* __restrict__ o_alive, int32_t* __restrict__ o_prev,
+                             int32_t* __restrict__ o_kf, int32_t* __restrict__ o_mp, float2* __restrict__ o_uv, uint8_t* __restrict__ o_alive, int2* __restrict__ o_link,
                              int32_t* __restrict__ pt_last, int32_t* __restrict__ pt_first, int2* __restrict__ kf_reach) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int o = at + i, slot = mp[i], k = kf[i];
     o_kf[o] = k; o_mp[o] = slot; o_uv[o] = uv[i]; o_alive[o] = 1;
-    o_prev[o] = pt_last[slot]; pt_last[slot] = o;
+    o_link[o] = make_int2(pt_last[slot], k); pt_last[slot] = o;
     int pf = pt_first[slot];
     if (pf < 0) { pf = o; pt_first[slot] = o; }
     atomicMin(&kf_reach[k].x, pf); atomicMin(&kf_reach[k].y, slot);
@@ -222,7 +222,7 @@ extern "C" int vo_obs_append(vo_ctx* c, const int32_t* kf, const int32_t* mp, co
         int r1 = r0 + 1;
         while (r1 < n && kf[r1] == kf[r0]) ++r1;
         hipLaunchKernelGGL(k_obs_append, dim3((r1 - r0 + 255) / 256), dim3(256), 0, c->stream, r1 - r0, at + r0, (const int32_t*)d + r0, (const int32_t*)(d + o_mp) + r0,
-                           (const float2*)(d + o_uv) + r0, c->d_obs_kf, c->d_obs_mp, reinterpret_cast<float2*>(c->d_obs_uv), c->d_obs_alive, c->d_obs_prev, c->d_pt_last, c->d_pt_first,
+                           (const float2*)(d + o_uv) + r0, c->d_obs_kf, c->d_obs_mp, reinterpret_cast<float2*>(c->d_obs_uv), c->d_obs_alive, reinterpret_cast<int2*>(c->d_obs_link), c->d_pt_last, c->d_pt_first,
                            reinterpret_cast<int2*>(c->d_kf_reach));
         if (std::find(kfs.begin(), kfs.end(), kf[r0]) == kfs.end()) kfs.push_back(kf[r0]);
         note_kf_first(c, kf[r0], (long long)at + r0);
@@ -251,15 +251,30 @@ extern "C" int vo_obs_kill(vo_ctx* c, const int64_t* ids, int n) {
 }
 
 // ---- keyframe commit ---------------------------------------------------------------------------------------------------------------
-struct KfTabs { int32_t* obs_kf; int32_t* obs_mp; float2* obs_uv; uint8_t* obs_alive; int32_t* obs_prev; int32_t* pt_last; int32_t* pt_first;
+struct KfTabs { int32_t* obs_kf; int32_t* obs_mp; float2* obs_uv; uint8_t* obs_alive; int2* obs_link; int32_t* pt_last; int32_t* pt_first;
                 double* map_pos; double* map_nrm; uint32_t* map_desc; uint8_t* map_flags; double* kf_pose; };
 struct Pose12 { double v[12]; };
 
 static KfTabs tabs_of(vo_ctx* c) {
-    return KfTabs{c->d_obs_kf, c->d_obs_mp, reinterpret_cast<float2*>(c->d_obs_uv), c->d_obs_alive, c->d_obs_prev, c->d_pt_last, c->d_pt_first,
+    return KfTabs{c->d_obs_kf, c->d_obs_mp, reinterpret_cast<float2*>(c->d_obs_uv), c->d_obs_alive, reinterpret_cast<int2*>(c->d_obs_link), c->d_pt_last, c->d_pt_first,
                   c->d_map_pos, c->d_map_nrm, c->d_map_desc, c->d_map_flags, c->d_kf_pose};
 }
 
+// exclusive prefix of one value per lane over the workgroup's lanes (lane order, NW waves), and the total
+template <int NW> __device__ __forceinline__ int block_excl(int v, int& total, int* s_w) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    int before = inc - v, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { const int x = s_w[w]; if (w < wave) before += x; tot += x; }
+    __syncthreads();                                        // s_w is rewritten by the next call
+    total = tot;
+    return before;
+}
 // position of a set flag among the set flags of the workgroup's 1024 lanes (lane order), and their number
 __device__ __forceinline__ int block_rank(bool f, int& total, int* s_w) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -274,13 +289,18 @@ __device__ __forceinline__ int block_rank(bool f, int& total, int* s_w) {
     return before;
 }
 
-__global__ __launch_bounds__(1024) void k_kf_commit(KfTabs T, const vo_match* __restrict__ matches, int n_match, const vo_keypoint* __restrict__ kps, const int* __restrict__ nkp_p,
+// One workgroup.  A lane owns KF_IPT CONSECUTIVE records of a list, so that one prefix sum over the lanes' counts orders a whole pass of
+// 8 Ki records (the match lists of the bench workload fit one pass) and a lane's dependent gathers (match -> keypoint, map point, chain head)
+// are in flight together.
+#define KF_IPT 8
+#define KF_CT 512                   // lanes of k_kf_commit (256 VGPRs each: the 8 records a lane holds must not spill -- scratch makes concurrent queues wait for each other)
+__global__ __launch_bounds__(KF_CT) void k_kf_commit(KfTabs T, const vo_match* __restrict__ matches, int n_match, const vo_keypoint* __restrict__ kps, const int* __restrict__ nkp_p,
                                                     int nfeat, const uint32_t* __restrict__ fdesc, int kf, int n_obs0, int first_new, Pose12 P, CamD cam, double depth_scale,
                                                     int32_t* __restrict__ cand, KfDev* __restrict__ hdr) {
     extern __shared__ unsigned s_bits[];                    // [(nfeat + 31) / 32] keypoints explained by an LM inlier (pnpMatchedKptSet_)
-    __shared__ int s_w[16], s_min[2];
+    __shared__ int s_w[KF_CT / 64], s_min[2];
     const int tid = threadIdx.x;
-    for (int i = tid; i < (nfeat + 31) / 32; i += 1024) s_bits[i] = 0u;
+    for (int i = tid; i < (nfeat + 31) / 32; i += KF_CT) s_bits[i] = 0u;
     if (tid < 2) s_min[tid] = INT_MAX;
     if (tid < 12) T.kf_pose[12 * (size_t)kf + tid] = P.v[tid];
     const double* R = P.v; const double* t = P.v + 9;
@@ -290,94 +310,129 @@ __global__ __launch_bounds__(1024) void k_kf_commit(KfTabs T, const vo_match* __
     for (int a = 0; a < 3; ++a) C[a] = (R[a] * t[0] + R[3 + a] * t[1] + R[6 + a] * t[2]) * -1.0;
     __syncthreads();
     int base = 0, cbase = 0;
-    for (int i0 = 0; i0 < n_match; i0 += 1024) {            // AddCurrentKeyframeObservations (src/frontend.cpp:366-370), match order
-        const int i = i0 + tid;
-        vo_match m; m.flags = 0; m.map_index = 0; m.kp_index = 0;
-        if (i < n_match) m = matches[i];
-        const bool f = i < n_match && (m.flags & VO_MATCH_LM_INLIER);
-        int tot;
-        const int r = block_rank(f, tot, s_w);
-        bool isc = false;
-        if (f) {
-            const int o = n_obs0 + base + r, slot = m.map_index;
-            atomicOr(&s_bits[m.kp_index >> 5], 1u << (m.kp_index & 31));
-            const vo_keypoint k = kps[m.kp_index];
-            T.obs_kf[o] = kf; T.obs_mp[o] = slot; T.obs_uv[o] = make_float2(k.x, k.y); T.obs_alive[o] = 1;
-            T.obs_prev[o] = T.pt_last[slot]; T.pt_last[slot] = o;
-            int pf = T.pt_first[slot];
-            if (pf < 0) { pf = o; T.pt_first[slot] = o; }
-            atomicMin(&s_min[0], pf); atomicMin(&s_min[1], slot);
-            // Mappoint::AddObservedByKeyframe (src/mappoint.cpp:30-38): norm = (norm + (pos - centre).normalized()).normalized()
-            const double* p = T.map_pos + 3 * (size_t)slot; double* nr = T.map_nrm + 3 * (size_t)slot;
-            double d0 = p[0] - C[0], d1 = p[1] - C[1], d2 = p[2] - C[2];
-            double n = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
-            d0 = d0 / n; d1 = d1 / n; d2 = d2 / n;
-            double e0 = nr[0] + d0, e1 = nr[1] + d1, e2 = nr[2] + d2;
-            n = sqrt(e0 * e0 + e1 * e1 + e2 * e2);
-            nr[0] = e0 / n; nr[1] = e1 / n; nr[2] = e2 / n;
-            isc = !(T.map_flags[slot] & (VO_MAP_FLAG_OUTLIER | VO_MAP_FLAG_TRIANGULATED | VO_MAP_FLAG_OPTIMIZED));
+    for (int i0 = 0; i0 < n_match; i0 += KF_CT * KF_IPT) {   // AddCurrentKeyframeObservations (src/frontend.cpp:366-370), match order
+        const int first = i0 + tid * KF_IPT;
+        int slot[KF_IPT], kp[KF_IPT]; unsigned inl = 0, cnd = 0;
+        float2 uv[KF_IPT]; int last[KF_IPT], pf[KF_IPT];
+#pragma unroll
+        for (int k = 0; k < KF_IPT; ++k) {
+            slot[k] = 0; kp[k] = 0;
+            if (first + k < n_match) {
+                const int4 m = *reinterpret_cast<const int4*>(matches + first + k);      // map_index, kp_index, distance, flags
+                slot[k] = m.x; kp[k] = m.y;
+                if (m.w & VO_MATCH_LM_INLIER) inl |= 1u << k;
+            }
         }
-        int tot2;
-        const int r2 = block_rank(isc, tot2, s_w);           // candidates of the triangulation loop, match order
-        if (isc) cand[cbase + r2] = m.map_index;
+#pragma unroll
+        for (int k = 0; k < KF_IPT; ++k)
+            if (inl >> k & 1u) {
+                const float2 xy = *reinterpret_cast<const float2*>(kps + kp[k]);      // x, y lead the record
+                uv[k] = xy; last[k] = T.pt_last[slot[k]]; pf[k] = T.pt_first[slot[k]];
+                if (!(T.map_flags[slot[k]] & (VO_MAP_FLAG_OUTLIER | VO_MAP_FLAG_TRIANGULATED | VO_MAP_FLAG_OPTIMIZED))) cnd |= 1u << k;
+            }
+        int tot, tot2;
+        int r = block_excl<KF_CT / 64>(__popc(inl), tot, s_w);
+        int r2 = block_excl<KF_CT / 64>(__popc(cnd), tot2, s_w);           // candidates of the triangulation loop, match order
+        int lo_obs = INT_MAX, lo_slot = INT_MAX;
+#pragma unroll
+        for (int k = 0; k < KF_IPT; ++k)
+            if (inl >> k & 1u) {
+                const int o = n_obs0 + base + r++, sl = slot[k];
+                atomicOr(&s_bits[kp[k] >> 5], 1u << (kp[k] & 31));
+                T.obs_kf[o] = kf; T.obs_mp[o] = sl; T.obs_uv[o] = uv[k]; T.obs_alive[o] = 1;
+                T.obs_link[o] = make_int2(last[k], kf); T.pt_last[sl] = o;
+                int f = pf[k];
+                if (f < 0) { f = o; T.pt_first[sl] = o; }
+                lo_obs = min(lo_obs, f); lo_slot = min(lo_slot, sl);
+                // Mappoint::AddObservedByKeyframe (src/mappoint.cpp:30-38): norm = (norm + (pos - centre).normalized()).normalized()
+                const double* p = T.map_pos + 3 * (size_t)sl; double* nr = T.map_nrm + 3 * (size_t)sl;
+                double d0 = p[0] - C[0], d1 = p[1] - C[1], d2 = p[2] - C[2];
+                double n = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+                d0 = d0 / n; d1 = d1 / n; d2 = d2 / n;
+                double e0 = nr[0] + d0, e1 = nr[1] + d1, e2 = nr[2] + d2;
+                n = sqrt(e0 * e0 + e1 * e1 + e2 * e2);
+                nr[0] = e0 / n; nr[1] = e1 / n; nr[2] = e2 / n;
+                if (cnd >> k & 1u) cand[cbase + r2++] = sl;
+            }
+        if (lo_obs != INT_MAX) { atomicMin(&s_min[0], lo_obs); atomicMin(&s_min[1], lo_slot); }
         base += tot; cbase += tot2;
     }
     __syncthreads();                                        // s_bits complete
     const int nkp = min(*nkp_p, nfeat);
     int nnew = 0;
-    for (int i0 = 0; i0 < nkp; i0 += 1024) {                // CreateNewMappoints (src/frontend.cpp:372-406), keypoint order
-        const int i = i0 + tid;
-        vo_keypoint k; k.depth_raw = 0; k.x = 0; k.y = 0;
-        if (i < nkp) k = kps[i];
-        const bool f = i < nkp && !((s_bits[i >> 5] >> (i & 31)) & 1u) && k.depth_raw != 0;
-        int tot;
-        const int r = block_rank(f, tot, s_w);
-        if (f) {
-            const int slot = first_new + nnew + r, o = n_obs0 + base + nnew + r;
-            const double depth = double(k.depth_raw) / depth_scale;                       // Frame::GetDepth (src/frame.cpp:43-67)
-            const double pc0 = ((double)k.x - cam.cx) * depth / cam.fx, pc1 = ((double)k.y - cam.cy) * depth / cam.fy, pc2 = depth;      // Camera::Pixel2Camera
-            double pw[3];
+    for (int i0 = 0; i0 < nkp; i0 += KF_CT * 4) {            // CreateNewMappoints (src/frontend.cpp:372-406), keypoint order; four keypoints per lane
+        const int first = i0 + tid * 4;
+        vo_keypoint k2[4]; unsigned fl = 0;
 #pragma unroll
-            for (int a = 0; a < 3; ++a) pw[a] = (R[a] * pc0 + R[3 + a] * pc1 + R[6 + a] * pc2) + C[a];      // T^-1 * p_c = R^T p_c + t'
-            double d0 = pw[0] - C[0], d1 = pw[1] - C[1], d2 = pw[2] - C[2];
-            double n = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
-            d0 = d0 / n; d1 = d1 / n; d2 = d2 / n;
-            n = sqrt(d0 * d0 + d1 * d1 + d2 * d2);            // (0 + d).normalized() of the first observation
-            double* mp = T.map_pos + 3 * (size_t)slot; double* nr = T.map_nrm + 3 * (size_t)slot;
-            mp[0] = pw[0]; mp[1] = pw[1]; mp[2] = pw[2]; nr[0] = d0 / n; nr[1] = d1 / n; nr[2] = d2 / n;
-            const uint4* src = reinterpret_cast<const uint4*>(fdesc + 8 * (size_t)i); uint4* dst = reinterpret_cast<uint4*>(T.map_desc + 8 * (size_t)slot);
-            dst[0] = src[0]; dst[1] = src[1];
-            T.map_flags[slot] = 0;
-            T.obs_kf[o] = kf; T.obs_mp[o] = slot; T.obs_uv[o] = make_float2(k.x, k.y); T.obs_alive[o] = 1; T.obs_prev[o] = -1;
-            T.pt_last[slot] = o; T.pt_first[slot] = o;
+        for (int k = 0; k < 4; ++k) {
+            const int i = first + k;
+            if (i < nkp) { k2[k] = kps[i]; if (!((s_bits[i >> 5] >> (i & 31)) & 1u) && k2[k].depth_raw != 0) fl |= 1u << k; }
         }
+        int tot;
+        int r = block_excl<KF_CT / 64>(__popc(fl), tot, s_w);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (fl >> k & 1u) {
+                const int i = first + k, slot = first_new + nnew + r, o = n_obs0 + base + nnew + r;
+                ++r;
+                const double depth = double(k2[k].depth_raw) / depth_scale;                       // Frame::GetDepth (src/frame.cpp:43-67)
+                const double pc0 = ((double)k2[k].x - cam.cx) * depth / cam.fx, pc1 = ((double)k2[k].y - cam.cy) * depth / cam.fy, pc2 = depth;      // Camera::Pixel2Camera
+                double pw[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) pw[a] = (R[a] * pc0 + R[3 + a] * pc1 + R[6 + a] * pc2) + C[a];      // T^-1 * p_c = R^T p_c + t'
+                double d0 = pw[0] - C[0], d1 = pw[1] - C[1], d2 = pw[2] - C[2];
+                double n = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+                d0 = d0 / n; d1 = d1 / n; d2 = d2 / n;
+                n = sqrt(d0 * d0 + d1 * d1 + d2 * d2);            // (0 + d).normalized() of the first observation
+                double* mp = T.map_pos + 3 * (size_t)slot; double* nr = T.map_nrm + 3 * (size_t)slot;
+                mp[0] = pw[0]; mp[1] = pw[1]; mp[2] = pw[2]; nr[0] = d0 / n; nr[1] = d1 / n; nr[2] = d2 / n;
+                const uint4* src = reinterpret_cast<const uint4*>(fdesc + 8 * (size_t)i); uint4* dst = reinterpret_cast<uint4*>(T.map_desc + 8 * (size_t)slot);
+                dst[0] = src[0]; dst[1] = src[1];
+                T.map_flags[slot] = 0;
+                T.obs_kf[o] = kf; T.obs_mp[o] = slot; T.obs_uv[o] = make_float2(k2[k].x, k2[k].y); T.obs_alive[o] = 1; T.obs_link[o] = make_int2(-1, kf);
+                T.pt_last[slot] = o; T.pt_first[slot] = o;
+            }
         nnew += tot;
     }
+    __syncthreads();
     if (tid == 0) {
         hdr->n_matched = base; hdr->n_new = nnew; hdr->n_tri = cbase;
         hdr->reach_obs = min(s_min[0], nnew > 0 ? n_obs0 + base : INT_MAX); hdr->reach_slot = min(s_min[1], nnew > 0 ? first_new : INT_MAX);
     }
 }
 
-// src/frame.cpp:104-119: every keyframe that already sees a point the new keyframe observes gains one shared point with it
-__global__ void k_kf_covis(KfTabs T, const KfDev* __restrict__ hdr, int n_obs0, int32_t* __restrict__ w) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= hdr->n_matched) return;
-    int q = T.obs_prev[n_obs0 + j];
-    while (q >= 0) {
-        if (T.obs_alive[q]) atomicAdd(&w[T.obs_kf[q]], 1);
-        q = T.obs_prev[q];
+// Two jobs in one launch (they are independent; side by side they cost the longer one).
+// Blocks [0, nb_covis): src/frame.cpp:104-119 -- every keyframe that already sees a point the new keyframe observes gains one shared point with it:
+//   one lane per new observation walks the point's chain; the counts are gathered in an LDS table over the newest KF_WLDS keyframe numbers
+//   (thousands of global atomics on a few dozen addresses serialise: DESIGN 4a) and leave with one atomic per keyframe and workgroup.
+// Blocks [nb_covis, ..): src/frontend.cpp:465-506, one lane per candidate: the live observations along the point's chain (newest first) are taken
+//   oldest first -- the order of Mappoint's observation list -- by walking the chain once per view (2-3 views: no BA has touched these points yet).
+#define KF_WLDS 2048
+__global__ __launch_bounds__(256) void k_kf_covis_tri(KfTabs T, const KfDev* __restrict__ hdr, int n_obs0, int n_kf, int32_t* __restrict__ w, int nb_covis,
+                                                      const int32_t* __restrict__ cand, CamD cam, uint8_t* __restrict__ tri_ok, double* __restrict__ tri_xyz) {
+    __shared__ int s_cnt[KF_WLDS];
+    if ((int)blockIdx.x < nb_covis) {
+        const int j = blockIdx.x * 256 + threadIdx.x, k_lo = max(0, n_kf - KF_WLDS);
+        if (blockIdx.x * 256 >= hdr->n_matched) return;
+        for (int i = threadIdx.x; i < KF_WLDS; i += 256) s_cnt[i] = 0;
+        __syncthreads();
+        if (j < hdr->n_matched) {
+            int q = T.obs_link[n_obs0 + j].x;
+            while (q >= 0) {
+                const int2 l = T.obs_link[q];
+                if (T.obs_alive[q]) { if (l.y >= k_lo) atomicAdd(&s_cnt[l.y - k_lo], 1); else atomicAdd(&w[l.y], 1); }
+                q = l.x;
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < KF_WLDS; i += 256) { const int v = s_cnt[i]; if (v) atomicAdd(&w[k_lo + i], v); }
+        return;
     }
-}
-
-// src/frontend.cpp:465-506, one lane per candidate: the live observations along the point's chain (newest first) are taken oldest first
-// -- the order of Mappoint's observation list -- by walking the chain once per view (2-3 views: the candidates are points no BA has touched yet)
-__global__ void k_kf_tri(KfTabs T, const KfDev* __restrict__ hdr, const int32_t* __restrict__ cand, CamD cam, uint8_t* __restrict__ tri_ok, double* __restrict__ tri_xyz) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = (blockIdx.x - nb_covis) * 256 + threadIdx.x;
     if (r >= hdr->n_tri) return;
     const int slot = cand[r];
     int n = 0;
-    for (int q = T.pt_last[slot]; q >= 0; q = T.obs_prev[q]) n += T.obs_alive[q] ? 1 : 0;
+    for (int q = T.pt_last[slot]; q >= 0; q = T.obs_link[q].x) n += T.obs_alive[q] ? 1 : 0;
     uint8_t good = 0;
     if (n >= 2) {
         double a[16];
@@ -385,8 +440,8 @@ __global__ void k_kf_tri(KfTabs T, const KfDev* __restrict__ hdr, const int32_t*
         for (int k = 0; k < 16; ++k) a[k] = 0.0;
         for (int v = 0; v < n; ++v) {                        // view v in ascending order = live link number n - 1 - v from the head
             int skip = n - 1 - v, q = T.pt_last[slot];
-            for (;;) { if (T.obs_alive[q]) { if (skip == 0) break; --skip; } q = T.obs_prev[q]; }
-            const double* Pq = T.kf_pose + 12 * (size_t)T.obs_kf[q];
+            for (;;) { if (T.obs_alive[q]) { if (skip == 0) break; --skip; } q = T.obs_link[q].x; }
+            const double* Pq = T.kf_pose + 12 * (size_t)T.obs_link[q].y;
             double p[12];
 #pragma unroll
             for (int k = 0; k < 12; ++k) p[k] = Pq[k];
@@ -460,14 +515,13 @@ extern "C" int vo_keyframe_commit(vo_ctx* c, int lane, int frame_slot, int32_t k
     const int n_obs0 = (int)c->n_obs, n_kf = std::max(c->n_kf, kf + 1);
     const vo_match* dm = c->d_matches + (size_t)std::max(lane, 0) * c->lane_stride;
     { ProfScope ps(c, "k_kf_commit");
-      hipLaunchKernelGGL(k_kf_commit, dim3(1), dim3(1024), 4 * (size_t)((nfeat + 31) / 32), st, T, dm, n_match, (const vo_keypoint*)(c->d_kps + (size_t)frame_slot * nfeat),
+      hipLaunchKernelGGL(k_kf_commit, dim3(1), dim3(KF_CT), 4 * (size_t)((nfeat + 31) / 32), st, T, dm, n_match, (const vo_keypoint*)(c->d_kps + (size_t)frame_slot * nfeat),
                          (const int*)(c->d_nkp + frame_slot), nfeat, (const uint32_t*)(c->d_desc + (size_t)frame_slot * nfeat * 32), (int)kf, n_obs0, (int)first_new_slot, P, cam,
                          (double)c->p.depth_scale, K.d_cand, K.d_hdr); }
     if (n_match > 0) {
-        { ProfScope ps(c, "k_kf_covis");
-          hipLaunchKernelGGL(k_kf_covis, dim3((n_match + 255) / 256), dim3(256), 0, st, T, (const KfDev*)K.d_hdr, n_obs0, K.d_w); }
-        { ProfScope ps(c, "k_kf_tri");
-          hipLaunchKernelGGL(k_kf_tri, dim3((n_match + 63) / 64), dim3(64), 0, st, T, (const KfDev*)K.d_hdr, (const int32_t*)K.d_cand, cam, K.d_tri_ok, K.d_tri_xyz); }
+        ProfScope ps(c, "k_kf_covis_tri");
+        const int nb = (n_match + 255) / 256;
+        hipLaunchKernelGGL(k_kf_covis_tri, dim3(2 * nb), dim3(256), 0, st, T, (const KfDev*)K.d_hdr, n_obs0, n_kf, K.d_w, nb, (const int32_t*)K.d_cand, cam, K.d_tri_ok, K.d_tri_xyz);
     }
     { ProfScope ps(c, "k_kf_finish");
       hipLaunchKernelGGL(k_kf_finish, dim3(1), dim3(1024), 0, st, T, (const KfDev*)K.d_hdr, n_kf, (int)kf, n_obs0, K.d_w, (const int32_t*)K.d_cand, (const uint8_t*)K.d_tri_ok,
@@ -491,7 +545,7 @@ extern "C" int vo_keyframe_commit(vo_ctx* c, int lane, int frame_slot, int32_t k
 __global__ void k_kf_recount(KfTabs T, int n_obs, int kf, int32_t* __restrict__ w) {
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= n_obs || !T.obs_alive[o] || T.obs_kf[o] != kf) return;
-    for (int q = T.pt_last[T.obs_mp[o]]; q >= 0; q = T.obs_prev[q]) if (q != o && T.obs_alive[q]) atomicAdd(&w[T.obs_kf[q]], 1);
+    for (int q = T.pt_last[T.obs_mp[o]]; q >= 0; q = T.obs_link[q].x) if (q != o && T.obs_alive[q]) atomicAdd(&w[T.obs_link[q].y], 1);
 }
 extern "C" int vo_kf_covisibility(vo_ctx* c, int32_t kf, int32_t* covis_kf, int32_t* covis_weight, int cap, int32_t* n) {
     if (!c || kf < 0 || !n || cap < 0 || (cap && (!covis_kf || !covis_weight))) return VO_E_INVALID;
