@@ -275,12 +275,15 @@ def main():
     ap.add_argument("--no-latency-mode", action="store_true")
     ap.add_argument("--prologue", type=int, default=150, help="frames tracked (untimed) before the warmup so that the timed steps see the steady-state map: covisible window, BA size and active-map size level off after ~100 frames; 0 = time a young map")
     ap.add_argument("--host-graph", action="store_true", help="cut the local BA's graph on the host (Backend::Build) instead of on the device from the resident observation table")
+    ap.add_argument("--upload-only", action="store_true", help="the resident figure and the PCIe-inclusive one, nothing else (repeated runs: profiles/r05_upload_runs.jsonl)")
     ap.add_argument("--no-roofline-pass", action="store_true", help="skip the per-kernel timing pass (kernel traces of the timed pass alone; the line then carries no roofline)")
     ap.add_argument("--host-keyframes", action="store_true", help="keep the keyframe bookkeeping in host objects (round 4's path) instead of on the device tables (device_keyframes)")
     ap.add_argument("--multi-streams", default="8,16", help="comma list of stream counts for the several-streams-per-GPU figure ('' = skip)")
     ap.add_argument("--multi-device-graph", type=int, default=1, help="several-streams figure: 1 = the local BA's graph is cut on the device (as the single stream does), 0 = on the host")
     ap.add_argument("--dry-run", action="store_true", help="rehearsal of the launch + process-group plumbing only: no GPU call, no tracking, `value` null and `dry_run` true in the line (CPU test of --gpus N)")
     args = ap.parse_args()
+    if args.upload_only:
+        args.no_roofline_pass = True; args.no_cpu_baseline = True; args.multi_streams = ""
 
     # --gpus N means N ranks, one per GPU.  Under torchrun (the driver's N > 1 form) RANK / WORLD_SIZE are set and this process IS a rank;
     # called directly with N > 1 the ranks are started here, as children, BEFORE this process imports torch or touches HIP (a process that
@@ -485,7 +488,7 @@ def main():
 
         # ---- causal single-frame figure ---------------------------------------------------------------
         lat = None
-        if not args.no_latency_mode and world == 1:
+        if not args.no_latency_mode and world == 1 and not args.upload_only:
             nl = min(total, args.prologue + 150)
             lo = dict(opts, max_frames_in_flight=1, track_batch=1, backend_lag_frames=0)
             s1 = system.VoSystem(system.HOST_LIB, **lo)
@@ -505,7 +508,7 @@ def main():
 
         # ---- row a-1 alone: batched ORB detect + describe over a 32-frame look-ahead batch (the streaming, byte-moving part) ----
         orb_only = None
-        if world == 1 and not args.no_latency_mode:
+        if world == 1 and not args.no_latency_mode and not args.upload_only:
             L = capi.load(capi.HIP_LIB)
             F = 32
             oc = L.context(L.default_params(width=W, height=H, n_features=N, max_frames=F))

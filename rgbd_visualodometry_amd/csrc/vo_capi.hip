@@ -262,7 +262,7 @@ void vo_ctx_destroy(vo_ctx* c) {
     if (c->orb_ev) (void)hipEventDestroy(c->orb_ev);
     void* ptrs[] = {c->d_slots, c->d_pyr, c->d_blur, c->d_tab, c->d_tabs, c->d_cand, c->d_cand_cnt, c->d_sel, c->d_sel_key, c->d_sel_cnt, c->d_kps,
                     c->d_desc, c->d_nkp, c->d_status, c->d_map_pos, c->d_map_nrm, c->d_map_desc, c->d_map_flags, c->d_active, c->d_best, c->d_mcand,
-                    c->d_matches, c->d_corr_xyz, c->d_corr_uv, c->d_hyp_pose, c->d_hyp_cnt, c->d_inliers, c->d_lm_mask, c->d_lm_x, c->d_ba};
+                    c->d_matches, c->d_corr_xyz, c->d_corr_uv, c->d_hyp_pose, c->d_hyp_cnt, c->d_inliers, c->d_lm_mask, c->d_lm_x, c->d_ba, c->d_pyr_rng};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     launchset_free(c->ls);
     if (c->group_ev) (void)hipEventDestroy(c->group_ev);
@@ -307,6 +307,8 @@ int vo_ctx_create(const vo_params* p, int device, vo_ctx** out) {
     if (rc) { delete c; return rc; }
     if (vo_stream_create(&c->stream, p->stream_priority, nullptr) != hipSuccess) { delete c; return VO_E_DEVICE; }
     rc = vo_orb_upload_constants();
+    if (rc) { vo_ctx_destroy(c); return rc; }
+    rc = vo_orb_pyramid_plan(c, tab);
     if (rc) { vo_ctx_destroy(c); return rc; }
     rc = vo_track_set_attrs();
     if (rc) { vo_ctx_destroy(c); return rc; }

@@ -96,6 +96,7 @@ struct vo_ctx {
     // pyramid + ORB work buffers
     uint8_t* d_pyr; uint8_t* d_blur;                // gray pyramid and its 7x7 sigma-2 blurred copy, same layout
     int* d_tab; short* d_tabs;                      // resize tables: int offsets, short weights
+    void* d_pyr_rng = nullptr; int pyr_gx = 0, pyr_gy = 0;      // k_pyramid: tiles per level and what each tile needs of each level (0 x 0: level-by-level k_resize)
     uint32_t* d_cand; int* d_cand_cnt;              // [slot][cprefix[L]] packed candidates, [slot][L] counts
     uint32_t* d_sel; long long* d_sel_key; int* d_sel_cnt;   // [slot][nfeat] selected (x|y<<12), keys, [slot][L] counts
     vo_keypoint* d_kps; uint8_t* d_desc; int* d_nkp;         // [slot][nfeat], [slot][nfeat*32], [slot]
@@ -177,6 +178,7 @@ int vo_map_scatter_launch(vo_ctx* c, int n, const int32_t* d_idx, const double* 
 
 // stage launchers
 int vo_orb_launch(vo_ctx* c, int slot0, int nslots);                                        // vo_orb.hip
+int vo_orb_pyramid_plan(vo_ctx* c, const std::vector<int>& tab);
 // vo_track.hip: the chain's stages over nl lanes described by d_lanes (device), on stream st; `prof` receives the timing records
 struct ChainDims { int max_active, max_feat; };
 int vo_track_match_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* d_lanes, int nl, ChainDims dims, float ratio, float floor_dist);

@@ -21,9 +21,11 @@
 // 640x480) are produced and consumed inside one L2 -- level l feeds level l+1, FAST, Harris, blur and the descriptor
 // gathers without a trip through HBM, and tile halos are never fetched by two L2s.  Batches of fewer than 8 frames
 // spread each frame over all XCDs instead (latency matters there, traffic does not).
+#include <algorithm>
 #include <cfloat>
 #include <climits>
 #include <cstdio>
+#include <vector>
 
 #include "vo_brief_pattern.h"
 #include "vo_internal.h"
@@ -100,6 +102,132 @@ __global__ __launch_bounds__(256) void k_resize(DevPlan P, int l, uint8_t* __res
     const int h1 = S1[sx] * a0 + S1[sx1] * a1;
     int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
     dst[(size_t)dy * P.pitch[l] + dx] = (uint8_t)min(255, max(0, v));
+}
+
+// ------------------------------------------------------------------------------------------
+// The whole pyramid below level 0 in ONE launch.  Level l is a bilinear resize of level l - 1 (cv::ORB resizes level by level), which made
+// seven dependent launches of 16-18 us each.  Here a workgroup owns the same fraction (tile tx, ty of gx x gy) of EVERY level and carries it
+// down the pyramid in LDS: it loads its part of level 0 plus the halo the seven levels need (vo_ctx::d_pyr_rng: the ranges are the same
+// for every frame and are computed once on the host from the resize tables), resizes level after level from one LDS buffer into the
+// other and stores the pixels of each level that fall into dwords touching its own tile.  Halo pixels are computed by two neighbours --
+// with the same integer formula from the same inputs, so the duplicated dword stores carry identical bytes.  No workgroup waits for
+// another one.  Arithmetic = k_resize's, bit for bit.
+#define PYR_BUF_A 14592              // bytes: levels 0, 2, 4, 6 of a tile + halo (640 x 480, 5 x 8 tiles: 14504; five workgroups per CU with these sizes)
+#define PYR_BUF_B 9984               // levels 1, 3, 5, 7 (9760)
+#define PYR_TAB 200                  // table entries per level and axis (196)
+struct PyrRng { short x0, x1, y0, y1; };                    // the part of a level a tile needs (half-open; x0 is a multiple of 4)
+__global__ __launch_bounds__(256) void k_pyramid(DevPlan P, uint8_t* __restrict__ pyr, const int* __restrict__ tab, const short* __restrict__ tabs,
+                                                 const PyrRng* __restrict__ rng, int slot0, int n, int aff, int gx, int gy) {
+    __shared__ __align__(16) uint8_t s_a[PYR_BUF_A];
+    __shared__ __align__(16) uint8_t s_b[PYR_BUF_B];
+    __shared__ int2 s_tx[PYR_TAB], s_ty[PYR_TAB];           // x: (local sx | local sx1 << 16, a0 | a1 << 16); y: (local r0 | local r1 << 16, b0 | b1 << 16)
+    int srel, jb;
+    if (!vo_slot_block(gx * gy, n, aff, srel, jb)) return;
+    const int slot = slot0 + srel, tx = jb % gx, ty = jb / gx, tid = threadIdx.x;
+    const PyrRng* R = rng + (size_t)jb * VO_MAX_LEVELS;
+    uint8_t* base = pyr + (size_t)slot * P.pyr_stride;
+    {   // this tile's part of level 0 (written by k_gray) -> LDS, one dword per lane and step
+        const PyrRng r = R[0];
+        const int wq = (r.x1 - r.x0 + 3) >> 2, h = r.y1 - r.y0;
+        const uint8_t* src = base + P.loff[0];
+        for (int i = tid; i < wq * h; i += 256) {
+            const int j = i / wq, q = i - j * wq;
+            reinterpret_cast<uint32_t*>(s_a)[i] = *reinterpret_cast<const uint32_t*>(src + (size_t)(r.y0 + j) * P.pitch[0] + r.x0 + 4 * q);      // (rows are padded to 64 bytes: the last dword of a row stays inside it)
+        }
+    }
+    for (int l = 1; l < P.L; ++l) {
+        const PyrRng r = R[l], rp = R[l - 1];
+        const int w = r.x1 - r.x0, h = r.y1 - r.y0, wq = (w + 3) >> 2, pp = ((rp.x1 - rp.x0 + 3) >> 2) << 2;      // pp: pitch of the previous level's buffer
+        const int sw = P.lw[l - 1], sh = P.lh[l - 1];
+        if (tid < w) {
+            const int dx = r.x0 + tid, sx = tab[P.tabx[l] + dx], sx1 = min(sx + 1, sw - 1);
+            s_tx[tid] = make_int2((sx - rp.x0) | ((sx1 - rp.x0) << 16), (int)(unsigned short)tabs[2 * (P.tabx[l] + dx)] | ((int)tabs[2 * (P.tabx[l] + dx) + 1] << 16));
+        }
+        if (tid >= 256 - h) {                                // (the y table from the other end of the workgroup: w + h may exceed 256)
+            const int j = 255 - tid, dy = r.y0 + j, sy = tab[P.taby[l] + dy];
+            const int r0 = min(max(sy, 0), sh - 1), r1 = min(max(sy + 1, 0), sh - 1);
+            s_ty[j] = make_int2((r0 - rp.y0) | ((r1 - rp.y0) << 16), (int)(unsigned short)tabs[2 * (P.taby[l] + dy)] | ((int)tabs[2 * (P.taby[l] + dy) + 1] << 16));
+        }
+        __syncthreads();                                     // tables + the previous level's buffer are complete
+        const uint8_t* prev = (l & 1) ? s_a : s_b;
+        uint8_t* cur = (l & 1) ? s_b : s_a;
+        // the tile's own pixels of this level: the same fraction of every level
+        const int ox0 = tx * P.lw[l] / gx, ox1 = (tx + 1) * P.lw[l] / gx, oy0 = ty * P.lh[l] / gy, oy1 = (ty + 1) * P.lh[l] / gy;
+        uint8_t* dst = base + P.loff[l];
+        const int pitch = P.pitch[l];
+        for (int i = tid; i < wq * h; i += 256) {
+            const int j = i / wq, q = i - j * wq;
+            const int2 ty2 = s_ty[j];
+            const uint8_t* S0 = prev + (ty2.x & 0xFFFF) * pp;
+            const uint8_t* S1 = prev + ((unsigned)ty2.x >> 16) * pp;
+            const int b0 = (short)(ty2.y & 0xFFFF), b1 = ty2.y >> 16;
+            uint32_t o = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int x = 4 * q + k;
+                if (x < w) {
+                    const int2 tx2 = s_tx[x];
+                    const int lx = tx2.x & 0xFFFF, lx1 = (unsigned)tx2.x >> 16, a0 = (short)(tx2.y & 0xFFFF), a1 = tx2.y >> 16;
+                    const int h0 = S0[lx] * a0 + S0[lx1] * a1;
+                    const int h1 = S1[lx] * a0 + S1[lx1] * a1;
+                    const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                    o |= (uint32_t)min(255, max(0, v)) << (8 * k);
+                }
+            }
+            reinterpret_cast<uint32_t*>(cur)[i] = o;
+            const int gy_ = r.y0 + j, gx_ = r.x0 + 4 * q;
+            if (gy_ >= oy0 && gy_ < oy1 && gx_ < ox1 && gx_ + 4 > ox0) *reinterpret_cast<uint32_t*>(dst + (size_t)gy_ * pitch + gx_) = o;
+        }
+        __syncthreads();                                     // this level is complete before its tables are overwritten
+    }
+}
+// the ranges of k_pyramid for every tile and level, from the resize tables (host, once per context); false: some tile does not fit the LDS buffers
+static bool pyr_ranges(const DevPlan& P, const std::vector<int>& tab, int gx, int gy, std::vector<PyrRng>& out) {
+    out.assign((size_t)gx * gy * VO_MAX_LEVELS, PyrRng{0, 0, 0, 0});
+    for (int ty = 0; ty < gy; ++ty)
+        for (int tx = 0; tx < gx; ++tx) {
+            PyrRng* R = &out[(size_t)(ty * gx + tx) * VO_MAX_LEVELS];
+            int nx0 = 0, nx1 = 0, ny0 = 0, ny1 = 0;           // what level l + 1 needs of level l
+            for (int l = P.L - 1; l >= 0; --l) {
+                int x0 = tx * P.lw[l] / gx, x1 = (tx + 1) * P.lw[l] / gx, y0 = ty * P.lh[l] / gy, y1 = (ty + 1) * P.lh[l] / gy;
+                if (l == 0) { x0 = nx0; x1 = nx1; y0 = ny0; y1 = ny1; }       // level 0 is only read
+                else if (l < P.L - 1) { x0 = std::min(x0, nx0); x1 = std::max(x1, nx1); y0 = std::min(y0, ny0); y1 = std::max(y1, ny1); }
+                x0 &= ~3;
+                x1 = std::min(P.lw[l], x0 + ((x1 - x0 + 3) & ~3));      // whole dwords: every byte a tile stores has been computed (or lies in the row padding)
+                if (x1 <= x0 || y1 <= y0) return false;
+                R[l] = PyrRng{(short)x0, (short)x1, (short)y0, (short)y1};
+                const size_t bytes = (size_t)(((x1 - x0 + 3) >> 2) << 2) * (y1 - y0);
+                if (bytes > ((l & 1) ? PYR_BUF_B : PYR_BUF_A) || x1 - x0 > PYR_TAB || y1 - y0 > PYR_TAB || x1 - x0 > 256 || y1 - y0 > 256) return false;
+                if (l == 0) break;
+                const int sw = P.lw[l - 1], sh = P.lh[l - 1];
+                const int* txb = &tab[P.tabx[l]]; const int* tyb = &tab[P.taby[l]];
+                nx0 = txb[x0]; nx1 = std::min(txb[x1 - 1] + 1, sw - 1) + 1;
+                ny0 = std::min(std::max(tyb[y0], 0), sh - 1); ny1 = std::min(std::max(tyb[y1 - 1] + 1, 0), sh - 1) + 1;
+            }
+        }
+    return true;
+}
+int vo_orb_pyramid_plan(vo_ctx* c, const std::vector<int>& tab) {
+    const DevPlan& P = c->plan;
+    c->pyr_gx = 0; c->pyr_gy = 0;
+    if (P.L < 2 || getenv("VO_NO_PYRAMID_KERNEL")) return VO_OK;
+    std::vector<PyrRng> rng;
+    for (int shrink = 0; shrink < 4; ++shrink) {               // 128 x 60 pixel tiles of level 0 at 640 x 480; smaller ones if the halo of a deep pyramid does not fit
+        const int gx = std::max(1, (P.W + 127) / 128) + shrink, gy = std::max(1, (P.H + 59) / 60) + 2 * shrink;
+        if (gx > P.lw[P.L - 1] || gy > P.lh[P.L - 1]) break;
+        if (!pyr_ranges(P, tab, gx, gy, rng)) continue;
+        if (hipMalloc((void**)&c->d_pyr_rng, rng.size() * sizeof(PyrRng)) != hipSuccess) { c->d_pyr_rng = nullptr; return VO_E_NOMEM; }
+        HIP_TRY(hipMemcpy(c->d_pyr_rng, rng.data(), rng.size() * sizeof(PyrRng), hipMemcpyHostToDevice));
+        c->pyr_gx = gx; c->pyr_gy = gy;
+        if (getenv("VO_TRACE")) {
+            size_t ma = 0, mb = 0;
+            for (int t = 0; t < gx * gy; ++t) for (int l = 0; l < P.L; ++l) { const PyrRng& r = rng[(size_t)t * VO_MAX_LEVELS + l]; const size_t b = (size_t)((r.x1 - r.x0 + 3) & ~3) * (r.y1 - r.y0); if (l & 1) mb = std::max(mb, b); else ma = std::max(ma, b); }
+            fprintf(stderr, "[vo_trace] k_pyramid: largest tile parts %zu / %zu bytes (buffers %d / %d)\n", ma, mb, PYR_BUF_A, PYR_BUF_B);
+        }
+        if (getenv("VO_TRACE")) { const PyrRng& a = rng[0]; const PyrRng& b = rng[1]; fprintf(stderr, "[vo_trace] k_pyramid: %d x %d tiles per level; tile 0 needs %d x %d of level 0, %d x %d of level 1\n", gx, gy, a.x1 - a.x0, a.y1 - a.y0, b.x1 - b.x0, b.y1 - b.y0); }
+        return VO_OK;
+    }
+    return VO_OK;                                            // no plan: vo_orb_launch keeps the level-by-level kernels
 }
 
 // ------------------------------------------------------------------------------------------
@@ -544,7 +672,10 @@ int vo_orb_launch(vo_ctx* c, int slot0, int n) {
     { ProfScope ps(c, "k_gray");
       const int per = (((P.W + 15) / 16) * P.H + 255) / 256;
       hipLaunchKernelGGL(k_gray, dim3(vo_slot_grid(per, n, aff)), dim3(256), 0, st, P, c->d_slots, c->d_pyr, slot0, n, aff, per); }
-    for (int l = 1; l < P.L; ++l) {
+    if (c->pyr_gx > 0) {
+        ProfScope ps(c, "k_pyramid");
+        hipLaunchKernelGGL(k_pyramid, dim3(vo_slot_grid(c->pyr_gx * c->pyr_gy, n, aff)), dim3(256), 0, st, P, c->d_pyr, c->d_tab, c->d_tabs, (const PyrRng*)c->d_pyr_rng, slot0, n, aff, c->pyr_gx, c->pyr_gy);
+    } else for (int l = 1; l < P.L; ++l) {
         ProfScope ps(c, "k_resize");
         const int gx = (P.lw[l] + 63) / 64, gy = (P.lh[l] + 3) / 4;
         hipLaunchKernelGGL(k_resize, dim3(vo_slot_grid(gx * gy, n, aff)), dim3(64, 4), 0, st, P, l, c->d_pyr, c->d_tab, c->d_tabs, slot0, n, aff, gx, gy);

@@ -14,6 +14,7 @@ def main():
     ap.add_argument("--same-seed", action="store_true")
     ap.add_argument("--modes", default="group,separate")
     ap.add_argument("--host-graph", action="store_true")
+    ap.add_argument("--host-keyframes", action="store_true")
     ap.add_argument("--profile", action="store_true", help="per-kernel HIP-event timing (all contexts and engines)")
     args = ap.parse_args()
     import torch
@@ -28,7 +29,7 @@ def main():
     torch.cuda.synchronize()
     fb, fd = W * H * 3, W * H * 2
     opts = dict(width=W, height=H, number_of_features=2000, max_frames_in_flight=32, backend_lag_frames=args.lag, track_batch=8, map_capacity=1 << 19,
-                enable_local_optimization=0 if args.no_ba else 1, ba_device_graph=0 if args.host_graph else 1, map_descriptors_on_device=1)
+                enable_local_optimization=0 if args.no_ba else 1, ba_device_graph=0 if args.host_graph else 1, map_descriptors_on_device=1, device_keyframes=0 if (args.host_graph or args.host_keyframes) else 1)
     for S in [int(v) for v in args.streams.split(",")]:
         for mode in args.modes.split(","):
             grp = system.StreamGroup(system.HOST_LIB, 0, 128) if mode == "group" else None
