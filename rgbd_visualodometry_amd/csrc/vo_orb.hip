@@ -583,9 +583,12 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
     return v;
 }
 
-// One wavefront per keypoint, 4 per workgroup, no LDS: intensity-centroid moments over the radius-15 disc straight
-// from the level image (two 31-pixel rows per wave instruction), then the 256 steered tests read the blurred level
-// (8 samples per lane) and are packed with 4 x __ballot.
+// One wavefront per keypoint at a time, DK keypoints per wavefront in flight: the chain of a keypoint (position -> 31 rows of the level image ->
+// angle -> 512 samples of the blurred level -> bits) is four dependent trips to L2, and a wave that walks it for one keypoint waits most of the
+// time; with DK keypoints interleaved phase by phase the trips overlap.  No LDS: intensity-centroid moments over the radius-15 disc straight
+// from the level image (two 31-pixel rows per wave instruction), then the 256 steered tests read the blurred level (8 samples per lane)
+// and are packed with 4 x __ballot.
+#define DK 1                        // (measured: 2000 features, 32 frames: DK 1 120 us, DK 4 132 us -- the kernel is bound by the scattered byte gathers of the 512 samples, not by the latency of its chain)
 __global__ __launch_bounds__(256) void k_describe(DevPlan P, const SlotDesc* __restrict__ slots, const uint8_t* __restrict__ pyr,
                                                   const uint8_t* __restrict__ blurp, const uint32_t* __restrict__ sel,
                                                   const long long* __restrict__ sel_key, const int* __restrict__ sel_cnt,
@@ -594,54 +597,74 @@ __global__ __launch_bounds__(256) void k_describe(DevPlan P, const SlotDesc* __r
     if (!vo_slot_block(per_slot, n, aff, srel, jb)) return;
     const int slot = slot0 + srel;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int g = jb * 4 + wave;
-    int l = 0, base = 0, total = 0;
-    for (int i = 0; i < P.L; ++i) total += sel_cnt[slot * VO_MAX_LEVELS + i];
+    int cnt[VO_MAX_LEVELS], total = 0;
+    for (int i = 0; i < P.L; ++i) { cnt[i] = sel_cnt[slot * VO_MAX_LEVELS + i]; total += cnt[i]; }
     if (jb == 0 && threadIdx.x == 0) nkp[slot] = total;
-    if (g >= P.nfeat) return;
-    while (l + 1 < P.L && g >= P.qprefix[l + 1]) { base += sel_cnt[slot * VO_MAX_LEVELS + l]; ++l; }
-    if ((g - P.qprefix[l]) >= sel_cnt[slot * VO_MAX_LEVELS + l]) return;
-    const int pitch = P.pitch[l];
-    const uint8_t* img = pyr + (size_t)slot * P.pyr_stride + P.loff[l];
-    const uint8_t* blur = blurp + (size_t)slot * P.pyr_stride + P.loff[l];
-    const uint32_t c = sel[(size_t)slot * P.nfeat + g];
-    const int x = c & 0xFFF, y = (c >> 12) & 0xFFF;
+    // keypoints g0 .. g0 + DK - 1 of the quota-ordered list (level-major)
+    const int g0 = (jb * 4 + wave) * DK;
+    int lv[DK], outi[DK], x[DK], y[DK]; bool on[DK];
+#pragma unroll
+    for (int k = 0; k < DK; ++k) {
+        const int g = g0 + k;
+        int l = 0, base = 0;
+        on[k] = g < P.nfeat;
+        while (l + 1 < P.L && g >= P.qprefix[l + 1]) { base += cnt[l]; ++l; }
+        if (on[k] && (g - P.qprefix[l]) >= cnt[l]) on[k] = false;
+        lv[k] = l; outi[k] = base + (g - P.qprefix[l]);
+        const uint32_t c = on[k] ? sel[(size_t)slot * P.nfeat + g] : 0u;
+        x[k] = c & 0xFFF; y[k] = (c >> 12) & 0xFFF;
+    }
     // intensity centroid: lanes 0..30 take row v, lanes 32..62 row v+1
-    int m10 = 0, m01 = 0;
+    int m10[DK], m01[DK];
     const int u = (lane & 31) - 15, half = lane >> 5;
-    for (int v0 = -15; v0 <= 15; v0 += 2) {
-        const int v = v0 + half;
-        if ((lane & 31) < 31 && v <= 15 && abs(u) <= P.umax[abs(v)]) {
-            const int I = img[(size_t)(y + v) * pitch + x + u];
-            m10 += u * I; m01 += v * I;
+#pragma unroll
+    for (int k = 0; k < DK; ++k) {
+        m10[k] = 0; m01[k] = 0;
+        if (!on[k]) continue;
+        const uint8_t* img = pyr + (size_t)slot * P.pyr_stride + P.loff[lv[k]];
+        const int pitch = P.pitch[lv[k]];
+        for (int v0 = -15; v0 <= 15; v0 += 2) {
+            const int v = v0 + half;
+            if ((lane & 31) < 31 && v <= 15 && abs(u) <= P.umax[abs(v)]) {
+                const int I = img[(size_t)(y[k] + v) * pitch + x[k] + u];
+                m10[k] += u * I; m01[k] += v * I;
+            }
         }
     }
-    m10 = wave_sum_i32(m10); m01 = wave_sum_i32(m01);
-    double cs = 1.0, sn = 0.0;
-    if (m10 != 0 || m01 != 0) {
-        const double nrm = sqrt((double)m10 * (double)m10 + (double)m01 * (double)m01);
-        cs = (double)m10 / nrm; sn = (double)m01 / nrm;
-    }
-    const int out = base + (g - P.qprefix[l]);
-    const uint8_t* ctr = blur + (size_t)y * pitch + x;
-    uint64_t bits[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int8_t* q = c_pattern[r * 64 + lane];
-        const int x1 = __double2int_rn((double)q[0] * cs - (double)q[1] * sn), y1 = __double2int_rn((double)q[0] * sn + (double)q[1] * cs);
-        const int x2 = __double2int_rn((double)q[2] * cs - (double)q[3] * sn), y2 = __double2int_rn((double)q[2] * sn + (double)q[3] * cs);
-        const bool b = ctr[y1 * pitch + x1] < ctr[y2 * pitch + x2];
-        bits[r] = __ballot(b);
+    for (int k = 0; k < DK; ++k) { m10[k] = wave_sum_i32(m10[k]); m01[k] = wave_sum_i32(m01[k]); }
+    uint64_t bits[DK][4];
+#pragma unroll
+    for (int k = 0; k < DK; ++k) {
+        double cs = 1.0, sn = 0.0;
+        if (m10[k] != 0 || m01[k] != 0) {
+            const double nrm = sqrt((double)m10[k] * (double)m10[k] + (double)m01[k] * (double)m01[k]);
+            cs = (double)m10[k] / nrm; sn = (double)m01[k] / nrm;
+        }
+        const int pitch = P.pitch[lv[k]];
+        const uint8_t* ctr = blurp + (size_t)slot * P.pyr_stride + P.loff[lv[k]] + (size_t)y[k] * pitch + x[k];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int8_t* q = c_pattern[r * 64 + lane];
+            const int x1 = __double2int_rn((double)q[0] * cs - (double)q[1] * sn), y1 = __double2int_rn((double)q[0] * sn + (double)q[1] * cs);
+            const int x2 = __double2int_rn((double)q[2] * cs - (double)q[3] * sn), y2 = __double2int_rn((double)q[2] * sn + (double)q[3] * cs);
+            const bool b = on[k] && ctr[y1 * pitch + x1] < ctr[y2 * pitch + x2];
+            bits[k][r] = __ballot(b);
+        }
     }
-    if (lane == 0) {
-        uint64_t* d = (uint64_t*)(desc + ((size_t)slot * P.nfeat + out) * 32);
-        d[0] = bits[0]; d[1] = bits[1]; d[2] = bits[2]; d[3] = bits[3];
+    if (lane < DK && on[lane < DK ? lane : 0]) {
+        // lane k writes keypoint k (the per-keypoint values live in registers indexed at compile time: select them without dynamic indexing)
+        int l = 0, o = 0, xx = 0, yy = 0, a10 = 0, a01 = 0, gg = 0; uint64_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+#pragma unroll
+        for (int k = 0; k < DK; ++k) if (lane == k) { l = lv[k]; o = outi[k]; xx = x[k]; yy = y[k]; a10 = m10[k]; a01 = m01[k]; gg = g0 + k; b0 = bits[k][0]; b1 = bits[k][1]; b2 = bits[k][2]; b3 = bits[k][3]; }
+        uint64_t* d = (uint64_t*)(desc + ((size_t)slot * P.nfeat + o) * 32);
+        d[0] = b0; d[1] = b1; d[2] = b2; d[3] = b3;
         vo_keypoint kp;
-        kp.x = (float)x * P.scale[l];
-        kp.y = (float)y * P.scale[l];
+        kp.x = (float)xx * P.scale[l];
+        kp.y = (float)yy * P.scale[l];
         kp.size = 31.f * P.scale[l];
-        kp.angle = fast_atan2_deg_dev((float)m01, (float)m10);
-        kp.response = (float)((double)sel_key[(size_t)slot * P.nfeat + g] * (1.0 / (25.0 * 7140.0 * 7140.0 * 7140.0 * 7140.0)));
+        kp.angle = fast_atan2_deg_dev((float)a01, (float)a10);
+        kp.response = (float)((double)sel_key[(size_t)slot * P.nfeat + gg] * (1.0 / (25.0 * 7140.0 * 7140.0 * 7140.0 * 7140.0)));
         kp.octave = l; kp.class_id = -1;
         // Frame::GetDepth (reference src/frame.cpp:43-67), bounds-checked
         const SlotDesc sd = slots[slot];
@@ -649,11 +672,11 @@ __global__ __launch_bounds__(256) void k_describe(DevPlan P, const SlotDesc* __r
         const int nx[5] = {0, -1, 0, 1, 0}, ny[5] = {0, 0, -1, 0, 1};
         int dr = 0;
         for (int i = 0; i < 5 && dr == 0; ++i) {
-            const int xx = px + nx[i], yy = py + ny[i];
-            if (xx >= 0 && yy >= 0 && xx < P.W && yy < P.H) dr = *(const uint16_t*)(sd.depth + (size_t)yy * sd.depth_stride + 2 * (size_t)xx);
+            const int x2 = px + nx[i], y2 = py + ny[i];
+            if (x2 >= 0 && y2 >= 0 && x2 < P.W && y2 < P.H) dr = *(const uint16_t*)(sd.depth + (size_t)y2 * sd.depth_stride + 2 * (size_t)x2);
         }
         kp.depth_raw = dr;
-        kps[(size_t)slot * P.nfeat + out] = kp;
+        kps[(size_t)slot * P.nfeat + o] = kp;
     }
 }
 
@@ -690,7 +713,7 @@ int vo_orb_launch(vo_ctx* c, int slot0, int n) {
       const int per = 8 * ((P.btile_prefix[P.L] + 7) / 8);
       hipLaunchKernelGGL(k_blur, dim3(vo_slot_grid(per, n, aff)), dim3(32, 8), 0, st, P, c->d_pyr, c->d_blur, slot0, n, aff, per); }
     { ProfScope ps(c, "k_describe");
-      const int per = (P.nfeat + 3) / 4;
+      const int per = (P.nfeat + 4 * DK - 1) / (4 * DK);
       hipLaunchKernelGGL(k_describe, dim3(vo_slot_grid(per, n, aff)), dim3(256), 0, st, P, c->d_slots, c->d_pyr, c->d_blur, c->d_sel, c->d_sel_key, c->d_sel_cnt, c->d_kps, c->d_desc, c->d_nkp, slot0, n, aff, per); }
     HIP_TRY(hipGetLastError());
     return VO_OK;

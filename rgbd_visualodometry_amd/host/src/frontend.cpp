@@ -82,7 +82,7 @@ bool FrontEnd::AddFrame(const Frame::Ptr frame) {
         case TRACKING: if (!TrackingHandler()) return false; break;
         case LOST: LostHandler(); return false;
     }
-    if (viewer_) { EnsureMatchLists(); viewer_->setCurrentFrame(frameCurr_, flannMatchedKptSet_); viewer_->updateDrawingObjects(); }
+    if (viewer_ && !kfOnDevice_) { EnsureMatchLists(); viewer_->setCurrentFrame(frameCurr_, flannMatchedKptSet_); viewer_->updateDrawingObjects(); }      // (a viewer set after the first keyframe of a device_keyframes run gets no per-frame match sets: the mode is fixed there)
     return true;
 }
 
