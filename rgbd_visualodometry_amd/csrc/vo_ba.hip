@@ -2283,7 +2283,7 @@ __global__ void k_cut_report(const int* __restrict__ src, int n, int* __restrict
 }
 // one workgroup: fixed poses follow the free ones in ascending keyframe number (running scan over the keyframe table)
 __global__ __launch_bounds__(1024) void k_cut_fixed_scan(int n_kf, int n_free, const int* __restrict__ fixed_flag, int* __restrict__ kf_idx, int* __restrict__ pose_kf,
-                                                         int* __restrict__ n_fixed_out) {
+                                                         int* __restrict__ n_fixed_out, const int* __restrict__ tot, int* __restrict__ host, int* __restrict__ word, int seq) {
     __shared__ int s_w[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int run = 0;
@@ -2299,7 +2299,13 @@ __global__ __launch_bounds__(1024) void k_cut_fixed_scan(int n_kf, int n_free, c
         run += tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *n_fixed_out = run;
+    if (threadIdx.x == 0) {
+        *n_fixed_out = run;
+        // the sizes go to the host at once (pinned memory, then the word it polls: k_cut_report's protocol without a launch of its own)
+        host[0] = tot[0]; host[1] = tot[1]; host[2] = run;
+        __threadfence_system();
+        __hip_atomic_store(word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 // observation -> its slot in its point's edge range (arrival order; k_cut_emit sorts), and map slot -> dense point list
 __global__ void k_cut_fill(CutTabs T, const int* __restrict__ pt_flag, const int* __restrict__ pidx, const int* __restrict__ pt_start,
@@ -2485,6 +2491,8 @@ __global__ __launch_bounds__(256) void k_merge_ledger(const int* __restrict__ n_
     if (threadIdx.x == 0) *n_pairs_total = s_n;
 }
 
+// (A one-launch variant for windows of up to 64 Ki elements -- one workgroup, a contiguous run per lane -- was measured and lost 3 % of a single
+// stream's frames/s: the lanes' 256-byte runs do not coalesce, and two small launches cost less than one slow one.)
 int vo_scan_i32(hipStream_t st, const int* in, int n, int* bsum, int* out, int* total) {        // n <= 16 Mi
     const int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (nb > 1024) return VO_E_UNSUPPORTED;
@@ -2552,8 +2560,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     // pt_start[0 .. nx] over the dense indices (cnt is zero from nx on; one spare entry so that pt_start[nx] exists when every slot of
     // the map is in the graph), ne
     if ((rc = vo_scan_i32(st, cnt, mh + 1, bsum, pt_start, tot + 1))) return rc;
-    hipLaunchKernelGGL(k_cut_fixed_scan, dim3(1), dim3(1024), 0, st, nkf, nf, fixed_flag, kf_idx, pose_kf, tot + 2);
-    hipLaunchKernelGGL(k_cut_report, dim3(1), dim3(64), 0, st, (const int*)tot, 3, h + 128, h + 132, seq);      // sizes to the host without a copy or a blocking wait
+    hipLaunchKernelGGL(k_cut_fixed_scan, dim3(1), dim3(1024), 0, st, nkf, nf, fixed_flag, kf_idx, pose_kf, tot + 2, (const int*)tot, h + 128, h + 132, seq);      // (sizes to the host without a copy or a blocking wait)
     HIP_TRY(hipGetLastError());
     if (!vo_spin_word(h + 132, seq, 2000)) HIP_TRY(hipStreamSynchronize(st));
     const int nx = h[128], ne = h[129], n_fixed = h[130], np = nf + n_fixed;
