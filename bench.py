@@ -54,7 +54,7 @@ def algorithmic_bytes(W, H, N, A, M, K, I, n_hyp, passes=2):
     P = sum(w * h for w, h in lv)
     b = {
         "k_gray": 3 * W * H + W * H,                              # BGR in, level 0 out
-        "k_pyramid": sum(lv[l - 1][0] * lv[l - 1][1] + lv[l][0] * lv[l][1] for l in range(1, len(lv))),
+        "k_pyramid": lv[0][0] * lv[0][1] + sum(w * h for w, h in lv[1:]),      # level 0 read once, levels 1.. written once (the levels in between live in LDS)
         "k_resize": sum(lv[l - 1][0] * lv[l - 1][1] + lv[l][0] * lv[l][1] for l in range(1, len(lv))),
         "k_fast_nms": P,                                          # every pyramid pixel read once
         "k_select": 81 * 2 * N + 8 * 2 * N,                       # 9x9 Harris windows of the 2N survivors + list traffic
@@ -440,7 +440,7 @@ def main():
             # HBM traffic per launch from this round's PMC passes (rocprofv3 cannot run inside this process): only a file of
             # the current round that covers this kernel is used, otherwise null
             try:
-                pmc_file = next(f for f in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+                pmc_file = next(f for f in ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
                 pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
                 pk = pmc["kernels"]
                 for name, row in table.items():             # measured fabric traffic per launch beside the algorithmic bytes, where a PMC row exists
@@ -450,7 +450,7 @@ def main():
                         row["pmc_GBps"] = round(m["hbm_bytes_per_launch_corrected"] / (row["avg_us"] * 1e-6) / 1e9, 1)
                 roof["traffic"] = pk[dom]["hbm_bytes_per_launch_corrected"]
                 roof["traffic_source"] = "profiles/%s (FETCH_SIZE, WRITE_SIZE: separate --pmc passes of `%s`)" % (pmc_file, pmc.get("command", "bench.py"))
-                cmp_file = next((os.path.join(ROOT, "profiles", f) for f in ("r04_pmc_compute.json", "r03_pmc_compute.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "")      # SQ counters of the latency-bound kernels (separate --pmc passes)
+                cmp_file = next((os.path.join(ROOT, "profiles", f) for f in ("r05_pmc_compute.json", "r04_pmc_compute.json", "r03_pmc_compute.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "")      # SQ counters of the latency-bound kernels (separate --pmc passes)
                 if os.path.exists(cmp_file):
                     cc = json.load(open(cmp_file)).get("kernels", {})
                     for name, row in table.items():

@@ -3,6 +3,7 @@
 void vo_prof_begin(vo_ctx*, const char*) {}
 void vo_prof_end(vo_ctx*) {}
 void* vo_stage(vo_ctx*, size_t) { return nullptr; }
+int vo_kf_host_pairs(vo_ctx*, int**, int**, int*, int**, double**) { return VO_E_DEVICE; }
 int vo_scratch(vo_ctx*, size_t) { return VO_E_DEVICE; }
 int vo_prof_begin(vo_ctx*, const char*, hipStream_t) { return -1; }
 void vo_prof_end(vo_ctx*, int) {}

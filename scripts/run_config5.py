@@ -11,6 +11,7 @@ def main():
     ap.add_argument("--speed", type=float, default=3.0)
     ap.add_argument("--features", type=int, default=8000)
     ap.add_argument("--hyps", type=int, default=2048)
+    ap.add_argument("--device", action="store_true", help="ba_device_graph + map_descriptors_on_device + device_keyframes")
     args = ap.parse_args()
     import torch
     import bench
@@ -25,6 +26,8 @@ def main():
     bptr = [db.data_ptr() + i * fb for i in range(n)]; dptr = [dd.data_ptr() + i * fd for i in range(n)]
     opts = dict(width=W, height=H, fx=2 * 517.3, fy=2 * 516.5, cx=2 * 318.6, cy=2 * 255.3, number_of_features=args.features, max_frames_in_flight=8,
                 backend_lag_frames=8, track_batch=4, map_capacity=1 << 20, ransac_iterations=args.hyps)
+    if args.device:                                          # graph cut and keyframe bookkeeping on the device tables, as the single 640x480 stream runs
+        opts.update(ba_device_graph=1, map_descriptors_on_device=1, device_keyframes=1)
 
     def drive(s, i0, i1, est=None):
         i = i0
