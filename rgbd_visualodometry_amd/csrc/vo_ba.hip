@@ -1431,10 +1431,10 @@ __device__ __forceinline__ void ba_cull_edge(const BaDev& B, const double* poses
 // A problem enters its slot: control block of the robust round, zeroed accumulators (one workgroup; the plain chi2 of the
 // initial state follows in k_ba_chi).  The descriptor (BaDev) is the only thing the host uploads.
 // the descriptor travels as a kernel argument (a copy would be a blit kernel with its own launch gap)
+// (one lane, a plain struct assignment: the argument is then read with scalar loads through the constant cache -- per-lane vector loads
+// from the kernel-argument segment took 14 us for these 500 bytes)
 __global__ void k_ba_put_desc(BaDev v, BaDev* __restrict__ dst) {
-    const int n = (int)(sizeof(BaDev) / 4);
-    const int* src = reinterpret_cast<const int*>(&v); int* d = reinterpret_cast<int*>(dst);
-    for (int i = threadIdx.x; i < n; i += blockDim.x) d[i] = src[i];
+    if (threadIdx.x == 0) *dst = v;
 }
 __global__ __launch_bounds__(256) void k_ba_admit(BaBatch Q) {
     BA_PROBLEM(Q)
@@ -1645,7 +1645,7 @@ static int ba_engine_admit(BaEngine* E) {
         E->h_Bs[s] = j->B;                                  // the slot's mirror is free: its previous problem is gone
         static_assert(sizeof(BaDev) % 4 == 0 && sizeof(BaDev) <= 2048, "BaDev travels as a kernel argument");
         if (rc == VO_OK) {
-            hipLaunchKernelGGL(k_ba_put_desc, dim3(1), dim3(128), 0, st, j->B, E->d_Bs + s);
+            hipLaunchKernelGGL(k_ba_put_desc, dim3(1), dim3(64), 0, st, j->B, E->d_Bs + s);
             const BaBatch Q = ba_batch_of(E, &s, 1);
             hipLaunchKernelGGL(k_ba_admit, dim3(1, 1, 1), dim3(256), 0, st, Q);
             if (j->B.D > BA_FOLD_D) hipLaunchKernelGGL(k_ba_chi, dim3(j->grid_e, 1, 1), dim3(256), 0, st, Q, 0, 0, 0);      // (D <= 192: k_ba_lin2 sums it in passing)

@@ -10,9 +10,9 @@
 //   keyframe poses      T_cw per keyframe number
 //
 // and a keyframe is ONE launch sequence on the tracker's stream (vo_keyframe_commit):
-//   k_kf_commit   one workgroup: LM-inlier matches -> observations + viewing directions (src/frontend.cpp:366-370, src/frame.cpp:93-120,
-//                 src/mappoint.cpp:30-38); unmatched keypoints with depth -> new map points (src/frontend.cpp:372-406,
-//                 src/camera.cpp:41-86); ordered by block-wide ballot scans, so slots and observation ids are those of the host loop
+//   k_kf_count, k_kf_place   a lane per record: LM-inlier matches -> observations + viewing directions (src/frontend.cpp:366-370, src/frame.cpp:93-120,
+//                 src/mappoint.cpp:30-38); unmatched keypoints with depth -> new map points (src/frontend.cpp:372-406, src/camera.cpp:41-86);
+//                 ordered by per-block counts + ballot ranks, so slots and observation ids are those of the host loop
 //   k_kf_covis_tri  two independent jobs side by side: one lane per new observation walks the point's chain, +1 for every keyframe that already sees it
 //                 (src/frame.cpp:104-119); one lane per candidate of the reference's triangulation loop (src/frontend.cpp:465-506), views gathered along the chain
 //   k_kf_finish   one workgroup: the covisibility weights as an ascending (keyframe, weight) list and the FIRST successful triangulation
@@ -56,6 +56,7 @@ struct KfState {
     int32_t* d_w = nullptr; int32_t* d_mark = nullptr;              // [kf_cap] covisibility counters (zero between calls), epoch marks
     unsigned long long* d_key = nullptr;                            // [map_capacity] leader keys of the local-map query
     int32_t* d_cand = nullptr; uint8_t* d_tri_ok = nullptr; double* d_tri_xyz = nullptr; int cand_cap = 0;
+    int2* d_cnt = nullptr; unsigned* d_kp_bits = nullptr;           // per 256 matches: (LM inliers, triangulation candidates); keypoints explained by an inlier (zero between commits)
     void* d_act = nullptr; size_t act_bytes = 0;                    // flag / position scratch of the local-map query
     uint32_t epoch = 0;
 };
@@ -81,7 +82,7 @@ void vo_kf_free(vo_ctx* c) {
     KfState* k = c->kf;
     if (!k) return;
     if (k->h) (void)hipHostFree(k->h);
-    void* q[] = {k->d_hdr, k->d_w, k->d_mark, k->d_key, k->d_cand, k->d_tri_ok, k->d_tri_xyz, k->d_act};
+    void* q[] = {k->d_hdr, k->d_w, k->d_mark, k->d_key, k->d_cand, k->d_tri_ok, k->d_tri_xyz, k->d_act, k->d_cnt, k->d_kp_bits};
     for (void* x : q) if (x) (void)hipFree(x);
     delete k; c->kf = nullptr;
 }
@@ -141,11 +142,13 @@ static int kf_state(vo_ctx* c) {
     bool ok = hipHostMalloc((void**)&k->h, sizeof(KfHost), hipHostMallocDefault) == hipSuccess && hipMalloc((void**)&k->d_hdr, sizeof(KfDev)) == hipSuccess &&
               hipMalloc((void**)&k->d_w, 4 * (size_t)c->kf_cap) == hipSuccess && hipMalloc((void**)&k->d_mark, 4 * (size_t)c->kf_cap) == hipSuccess &&
               hipMalloc((void**)&k->d_key, 8 * M) == hipSuccess && hipMalloc((void**)&k->d_cand, 4 * (size_t)k->cand_cap) == hipSuccess &&
-              hipMalloc((void**)&k->d_tri_ok, (size_t)k->cand_cap) == hipSuccess && hipMalloc((void**)&k->d_tri_xyz, 24 * (size_t)k->cand_cap) == hipSuccess;
+              hipMalloc((void**)&k->d_tri_ok, (size_t)k->cand_cap) == hipSuccess && hipMalloc((void**)&k->d_tri_xyz, 24 * (size_t)k->cand_cap) == hipSuccess &&
+              hipMalloc((void**)&k->d_cnt, 8 * ((size_t)k->cand_cap / 256 + 2)) == hipSuccess && hipMalloc((void**)&k->d_kp_bits, 4 * ((size_t)c->p.n_features / 32 + 2)) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); vo_kf_free(c); return VO_E_NOMEM; }
     memset(k->h, 0, sizeof(KfHost));
     HIP_TRY(hipMemsetAsync(k->d_w, 0, 4 * (size_t)c->kf_cap, c->stream)); HIP_TRY(hipMemsetAsync(k->d_mark, 0, 4 * (size_t)c->kf_cap, c->stream));
     HIP_TRY(hipMemsetAsync(k->d_key, 0, 8 * M, c->stream)); HIP_TRY(hipMemsetAsync(k->d_hdr, 0, sizeof(KfDev), c->stream));
+    HIP_TRY(hipMemsetAsync(k->d_kp_bits, 0, 4 * ((size_t)c->p.n_features / 32 + 2), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return VO_OK;
 }
@@ -289,115 +292,133 @@ __device__ __forceinline__ int block_rank(bool f, int& total, int* s_w) {
     return before;
 }
 
-// One workgroup.  A lane owns KF_IPT CONSECUTIVE records of a list, so that one prefix sum over the lanes' counts orders a whole pass of
-// 8 Ki records (the match lists of the bench workload fit one pass) and a lane's dependent gathers (match -> keypoint, map point, chain head)
-// are in flight together.
-#define KF_IPT 8
-#define KF_CT 512                   // lanes of k_kf_commit (256 VGPRs each: the 8 records a lane holds must not spill -- scratch makes concurrent queues wait for each other)
-__global__ __launch_bounds__(KF_CT) void k_kf_commit(KfTabs T, const vo_match* __restrict__ matches, int n_match, const vo_keypoint* __restrict__ kps, const int* __restrict__ nkp_p,
-                                                    int nfeat, const uint32_t* __restrict__ fdesc, int kf, int n_obs0, int first_new, Pose12 P, CamD cam, double depth_scale,
-                                                    int32_t* __restrict__ cand, KfDev* __restrict__ hdr) {
-    extern __shared__ unsigned s_bits[];                    // [(nfeat + 31) / 32] keypoints explained by an LM inlier (pnpMatchedKptSet_)
-    __shared__ int s_w[KF_CT / 64], s_min[2];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < (nfeat + 31) / 32; i += KF_CT) s_bits[i] = 0u;
-    if (tid < 2) s_min[tid] = INT_MAX;
-    if (tid < 12) T.kf_pose[12 * (size_t)kf + tid] = P.v[tid];
+// The commit proper, in two launches over as many workgroups as the lists need (a single workgroup walked the 3 000 matches and 2 000 keypoints
+// of the bench workload in 55-85 us; a lane per record takes one trip through the dependent gathers):
+//   k_kf_count   per 256 matches: how many are LM inliers / candidates of the triangulation loop; the keypoints the inliers explain are marked in a
+//                bitmap in global memory (pnpMatchedKptSet_)
+//   k_kf_place   match blocks: a record's place in the observation table = inliers in the blocks in front (sum of their counts) + rank inside the
+//                block (ballot): the order of the host loop (src/frontend.cpp:366-370); keypoint blocks: the same for the new map points
+//                (src/frontend.cpp:372-406) -- a block recounts the keypoints in front of it from the bitmap and the depth samples (<= 31 per lane)
+__device__ __forceinline__ int kf_block_sum(int v, int* s_w) {      // sum over a 256-lane workgroup, returned to every lane
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) s_w[wave] = v;
+    __syncthreads();
+    const int t = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    __syncthreads();
+    return t;
+}
+__global__ __launch_bounds__(256) void k_kf_count(KfTabs T, const vo_match* __restrict__ matches, int n_match, int2* __restrict__ cnt, unsigned* __restrict__ kp_bits, KfDev* __restrict__ hdr) {
+    __shared__ int s_w[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    bool inl = false, cnd = false;
+    if (i < n_match) {
+        const int4 m = *reinterpret_cast<const int4*>(matches + i);      // map_index, kp_index, distance, flags
+        inl = (m.w & VO_MATCH_LM_INLIER) != 0;
+        if (inl) {
+            atomicOr(&kp_bits[m.y >> 5], 1u << (m.y & 31));
+            cnd = !(T.map_flags[m.x] & (VO_MAP_FLAG_OUTLIER | VO_MAP_FLAG_TRIANGULATED | VO_MAP_FLAG_OPTIMIZED));
+        }
+    }
+    const int a = kf_block_sum(inl ? 1 : 0, s_w), c = kf_block_sum(cnd ? 1 : 0, s_w);
+    if (threadIdx.x == 0) {
+        cnt[blockIdx.x] = make_int2(a, c);
+        if (blockIdx.x == 0) { hdr->reach_obs = INT_MAX; hdr->reach_slot = INT_MAX; }
+    }
+}
+__global__ __launch_bounds__(256) void k_kf_place(KfTabs T, const vo_match* __restrict__ matches, int n_match, int nb, const int2* __restrict__ cnt, const unsigned* __restrict__ kp_bits,
+                                                  const vo_keypoint* __restrict__ kps, const int* __restrict__ nkp_p, int nfeat, const uint32_t* __restrict__ fdesc, int kf, int n_obs0,
+                                                  int first_new, Pose12 P, CamD cam, double depth_scale, int32_t* __restrict__ cand, KfDev* __restrict__ hdr) {
+    __shared__ int s_w[4], s_min[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
     const double* R = P.v; const double* t = P.v + 9;
     // camera centre = translation of T^-1 = (R^T t) * -1 (SE3::inverse of the host layer, operation for operation)
     double C[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) C[a] = (R[a] * t[0] + R[3 + a] * t[1] + R[6 + a] * t[2]) * -1.0;
-    __syncthreads();
-    int base = 0, cbase = 0;
-    for (int i0 = 0; i0 < n_match; i0 += KF_CT * KF_IPT) {   // AddCurrentKeyframeObservations (src/frontend.cpp:366-370), match order
-        const int first = i0 + tid * KF_IPT;
-        int slot[KF_IPT], kp[KF_IPT]; unsigned inl = 0, cnd = 0;
-        float2 uv[KF_IPT]; int last[KF_IPT], pf[KF_IPT];
-#pragma unroll
-        for (int k = 0; k < KF_IPT; ++k) {
-            slot[k] = 0; kp[k] = 0;
-            if (first + k < n_match) {
-                const int4 m = *reinterpret_cast<const int4*>(matches + first + k);      // map_index, kp_index, distance, flags
-                slot[k] = m.x; kp[k] = m.y;
-                if (m.w & VO_MATCH_LM_INLIER) inl |= 1u << k;
-            }
+    // inliers / candidates in the match blocks in front of this one (every block: the keypoint blocks need the totals)
+    int fi = 0, fc = 0, ti = 0, tc = 0;
+    for (int j = tid; j < nb; j += 256) { const int2 v = cnt[j]; ti += v.x; tc += v.y; if (j < b) { fi += v.x; fc += v.y; } }
+    fi = kf_block_sum(fi, s_w); fc = kf_block_sum(fc, s_w); ti = kf_block_sum(ti, s_w); tc = kf_block_sum(tc, s_w);
+    if (b < nb) {                                            // AddCurrentKeyframeObservations (src/frontend.cpp:366-370), match order
+        if (tid < 2) s_min[tid] = INT_MAX;
+        const int i = b * 256 + tid;
+        int4 m = make_int4(0, 0, 0, 0);
+        if (i < n_match) m = *reinterpret_cast<const int4*>(matches + i);
+        const bool inl = i < n_match && (m.w & VO_MATCH_LM_INLIER);
+        const bool cnd = inl && !(T.map_flags[m.x] & (VO_MAP_FLAG_OUTLIER | VO_MAP_FLAG_TRIANGULATED | VO_MAP_FLAG_OPTIMIZED));
+        const unsigned long long mi = __ballot(inl), mc = __ballot(cnd);
+        if (lane == 0) { s_w[wave] = __popcll(mi); }
+        __syncthreads();
+        int ri = fi + __popcll(mi & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; ++w) ri += s_w[w];
+        __syncthreads();
+        if (lane == 0) { s_w[wave] = __popcll(mc); }
+        __syncthreads();
+        int rc = fc + __popcll(mc & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; ++w) rc += s_w[w];
+        if (inl) {
+            const int o = n_obs0 + ri, sl = m.x;
+            const float2 xy = *reinterpret_cast<const float2*>(kps + m.y);      // x, y lead the record
+            T.obs_kf[o] = kf; T.obs_mp[o] = sl; T.obs_uv[o] = xy; T.obs_alive[o] = 1;
+            T.obs_link[o] = make_int2(T.pt_last[sl], kf); T.pt_last[sl] = o;
+            int f = T.pt_first[sl];
+            if (f < 0) { f = o; T.pt_first[sl] = o; }
+            atomicMin(&s_min[0], f); atomicMin(&s_min[1], sl);
+            // Mappoint::AddObservedByKeyframe (src/mappoint.cpp:30-38): norm = (norm + (pos - centre).normalized()).normalized()
+            const double* p = T.map_pos + 3 * (size_t)sl; double* nr = T.map_nrm + 3 * (size_t)sl;
+            double d0 = p[0] - C[0], d1 = p[1] - C[1], d2 = p[2] - C[2];
+            double n = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+            d0 = d0 / n; d1 = d1 / n; d2 = d2 / n;
+            double e0 = nr[0] + d0, e1 = nr[1] + d1, e2 = nr[2] + d2;
+            n = sqrt(e0 * e0 + e1 * e1 + e2 * e2);
+            nr[0] = e0 / n; nr[1] = e1 / n; nr[2] = e2 / n;
+            if (cnd) cand[rc] = sl;
         }
-#pragma unroll
-        for (int k = 0; k < KF_IPT; ++k)
-            if (inl >> k & 1u) {
-                const float2 xy = *reinterpret_cast<const float2*>(kps + kp[k]);      // x, y lead the record
-                uv[k] = xy; last[k] = T.pt_last[slot[k]]; pf[k] = T.pt_first[slot[k]];
-                if (!(T.map_flags[slot[k]] & (VO_MAP_FLAG_OUTLIER | VO_MAP_FLAG_TRIANGULATED | VO_MAP_FLAG_OPTIMIZED))) cnd |= 1u << k;
-            }
-        int tot, tot2;
-        int r = block_excl<KF_CT / 64>(__popc(inl), tot, s_w);
-        int r2 = block_excl<KF_CT / 64>(__popc(cnd), tot2, s_w);           // candidates of the triangulation loop, match order
-        int lo_obs = INT_MAX, lo_slot = INT_MAX;
-#pragma unroll
-        for (int k = 0; k < KF_IPT; ++k)
-            if (inl >> k & 1u) {
-                const int o = n_obs0 + base + r++, sl = slot[k];
-                atomicOr(&s_bits[kp[k] >> 5], 1u << (kp[k] & 31));
-                T.obs_kf[o] = kf; T.obs_mp[o] = sl; T.obs_uv[o] = uv[k]; T.obs_alive[o] = 1;
-                T.obs_link[o] = make_int2(last[k], kf); T.pt_last[sl] = o;
-                int f = pf[k];
-                if (f < 0) { f = o; T.pt_first[sl] = o; }
-                lo_obs = min(lo_obs, f); lo_slot = min(lo_slot, sl);
-                // Mappoint::AddObservedByKeyframe (src/mappoint.cpp:30-38): norm = (norm + (pos - centre).normalized()).normalized()
-                const double* p = T.map_pos + 3 * (size_t)sl; double* nr = T.map_nrm + 3 * (size_t)sl;
-                double d0 = p[0] - C[0], d1 = p[1] - C[1], d2 = p[2] - C[2];
-                double n = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
-                d0 = d0 / n; d1 = d1 / n; d2 = d2 / n;
-                double e0 = nr[0] + d0, e1 = nr[1] + d1, e2 = nr[2] + d2;
-                n = sqrt(e0 * e0 + e1 * e1 + e2 * e2);
-                nr[0] = e0 / n; nr[1] = e1 / n; nr[2] = e2 / n;
-                if (cnd >> k & 1u) cand[cbase + r2++] = sl;
-            }
-        if (lo_obs != INT_MAX) { atomicMin(&s_min[0], lo_obs); atomicMin(&s_min[1], lo_slot); }
-        base += tot; cbase += tot2;
+        __syncthreads();
+        if (tid == 0 && s_min[0] != INT_MAX) { atomicMin(&hdr->reach_obs, s_min[0]); atomicMin(&hdr->reach_slot, s_min[1]); }
+        return;
     }
-    __syncthreads();                                        // s_bits complete
-    const int nkp = min(*nkp_p, nfeat);
-    int nnew = 0;
-    for (int i0 = 0; i0 < nkp; i0 += KF_CT * 4) {            // CreateNewMappoints (src/frontend.cpp:372-406), keypoint order; four keypoints per lane
-        const int first = i0 + tid * 4;
-        vo_keypoint k2[4]; unsigned fl = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = first + k;
-            if (i < nkp) { k2[k] = kps[i]; if (!((s_bits[i >> 5] >> (i & 31)) & 1u) && k2[k].depth_raw != 0) fl |= 1u << k; }
-        }
-        int tot;
-        int r = block_excl<KF_CT / 64>(__popc(fl), tot, s_w);
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (fl >> k & 1u) {
-                const int i = first + k, slot = first_new + nnew + r, o = n_obs0 + base + nnew + r;
-                ++r;
-                const double depth = double(k2[k].depth_raw) / depth_scale;                       // Frame::GetDepth (src/frame.cpp:43-67)
-                const double pc0 = ((double)k2[k].x - cam.cx) * depth / cam.fx, pc1 = ((double)k2[k].y - cam.cy) * depth / cam.fy, pc2 = depth;      // Camera::Pixel2Camera
-                double pw[3];
-#pragma unroll
-                for (int a = 0; a < 3; ++a) pw[a] = (R[a] * pc0 + R[3 + a] * pc1 + R[6 + a] * pc2) + C[a];      // T^-1 * p_c = R^T p_c + t'
-                double d0 = pw[0] - C[0], d1 = pw[1] - C[1], d2 = pw[2] - C[2];
-                double n = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
-                d0 = d0 / n; d1 = d1 / n; d2 = d2 / n;
-                n = sqrt(d0 * d0 + d1 * d1 + d2 * d2);            // (0 + d).normalized() of the first observation
-                double* mp = T.map_pos + 3 * (size_t)slot; double* nr = T.map_nrm + 3 * (size_t)slot;
-                mp[0] = pw[0]; mp[1] = pw[1]; mp[2] = pw[2]; nr[0] = d0 / n; nr[1] = d1 / n; nr[2] = d2 / n;
-                const uint4* src = reinterpret_cast<const uint4*>(fdesc + 8 * (size_t)i); uint4* dst = reinterpret_cast<uint4*>(T.map_desc + 8 * (size_t)slot);
-                dst[0] = src[0]; dst[1] = src[1];
-                T.map_flags[slot] = 0;
-                T.obs_kf[o] = kf; T.obs_mp[o] = slot; T.obs_uv[o] = make_float2(k2[k].x, k2[k].y); T.obs_alive[o] = 1; T.obs_link[o] = make_int2(-1, kf);
-                T.pt_last[slot] = o; T.pt_first[slot] = o;
-            }
-        nnew += tot;
-    }
+    // CreateNewMappoints (src/frontend.cpp:372-406), keypoint order
+    const int jb = b - nb, nkp = min(*nkp_p, nfeat), i = jb * 256 + tid;
+    if (jb == 0 && tid < 12) T.kf_pose[12 * (size_t)kf + tid] = P.v[tid];      // the keyframe's pose (vo_kf_set_pose)
+    int front = 0;                                           // new points among the keypoints in front of this block
+    for (int q = tid; q < jb * 256; q += 256) front += (q < nkp && !((kp_bits[q >> 5] >> (q & 31)) & 1u) && kps[q].depth_raw != 0) ? 1 : 0;
+    front = kf_block_sum(front, s_w);
+    vo_keypoint k; k.depth_raw = 0; k.x = 0; k.y = 0;
+    if (i < nkp) k = kps[i];
+    const bool f = i < nkp && !((kp_bits[i >> 5] >> (i & 31)) & 1u) && k.depth_raw != 0;
+    const unsigned long long mf = __ballot(f);
+    if (lane == 0) s_w[wave] = __popcll(mf);
     __syncthreads();
+    int r = front + __popcll(mf & ((1ull << lane) - 1ull)), own = 0;
+    for (int w = 0; w < 4; ++w) { if (w < wave) r += s_w[w]; own += s_w[w]; }
+    if (f) {
+        const int slot = first_new + r, o = n_obs0 + ti + r;
+        const double depth = double(k.depth_raw) / depth_scale;                       // Frame::GetDepth (src/frame.cpp:43-67)
+        const double pc0 = ((double)k.x - cam.cx) * depth / cam.fx, pc1 = ((double)k.y - cam.cy) * depth / cam.fy, pc2 = depth;      // Camera::Pixel2Camera
+        double pw[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) pw[a] = (R[a] * pc0 + R[3 + a] * pc1 + R[6 + a] * pc2) + C[a];      // T^-1 * p_c = R^T p_c + t'
+        double d0 = pw[0] - C[0], d1 = pw[1] - C[1], d2 = pw[2] - C[2];
+        double n = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+        d0 = d0 / n; d1 = d1 / n; d2 = d2 / n;
+        n = sqrt(d0 * d0 + d1 * d1 + d2 * d2);            // (0 + d).normalized() of the first observation
+        double* mp = T.map_pos + 3 * (size_t)slot; double* nr = T.map_nrm + 3 * (size_t)slot;
+        mp[0] = pw[0]; mp[1] = pw[1]; mp[2] = pw[2]; nr[0] = d0 / n; nr[1] = d1 / n; nr[2] = d2 / n;
+        const uint4* src = reinterpret_cast<const uint4*>(fdesc + 8 * (size_t)i); uint4* dst = reinterpret_cast<uint4*>(T.map_desc + 8 * (size_t)slot);
+        dst[0] = src[0]; dst[1] = src[1];
+        T.map_flags[slot] = 0;
+        T.obs_kf[o] = kf; T.obs_mp[o] = slot; T.obs_uv[o] = make_float2(k.x, k.y); T.obs_alive[o] = 1; T.obs_link[o] = make_int2(-1, kf);
+        T.pt_last[slot] = o; T.pt_first[slot] = o;
+    }
     if (tid == 0) {
-        hdr->n_matched = base; hdr->n_new = nnew; hdr->n_tri = cbase;
-        hdr->reach_obs = min(s_min[0], nnew > 0 ? n_obs0 + base : INT_MAX); hdr->reach_slot = min(s_min[1], nnew > 0 ? first_new : INT_MAX);
+        if (jb == 0) { hdr->n_matched = ti; hdr->n_tri = tc; }
+        if (b == (int)gridDim.x - 1) {                       // the last keypoint block knows the number of new points
+            hdr->n_new = front + own;
+            if (front + own > 0) { atomicMin(&hdr->reach_obs, n_obs0 + ti); atomicMin(&hdr->reach_slot, first_new); }
+        }
     }
 }
 
@@ -457,10 +478,12 @@ __global__ __launch_bounds__(256) void k_kf_covis_tri(KfTabs T, const KfDev* __r
 // one workgroup: weights -> ascending (keyframe, weight) list in pinned memory (the counters are left at zero for the next keyframe); the first
 // successful triangulation moves its point (src/frontend.cpp:496-501); counts and reach to the host
 __global__ __launch_bounds__(1024) void k_kf_finish(KfTabs T, const KfDev* __restrict__ hdr, int n_kf, int kf, int n_obs0, int32_t* __restrict__ w, const int32_t* __restrict__ cand,
-                                                    const uint8_t* __restrict__ tri_ok, const double* __restrict__ tri_xyz, int2* __restrict__ kf_reach, KfHost* __restrict__ h) {
+                                                    const uint8_t* __restrict__ tri_ok, const double* __restrict__ tri_xyz, int2* __restrict__ kf_reach, KfHost* __restrict__ h,
+                                                    unsigned* __restrict__ kp_bits, int nfeat) {
     __shared__ int s_w[16], s_pick;
     const int tid = threadIdx.x;
     if (tid == 0) s_pick = INT_MAX;
+    for (int i = tid; i < (nfeat + 31) / 32; i += 1024) kp_bits[i] = 0u;      // the keypoint bitmap is left empty for the next keyframe
     int base = 0;
     for (int k0 = 0; k0 < n_kf; k0 += 1024) {
         const int k = k0 + tid;
@@ -514,8 +537,11 @@ extern "C" int vo_keyframe_commit(vo_ctx* c, int lane, int frame_slot, int32_t k
     const CamD cam{(double)c->p.fx, (double)c->p.fy, (double)c->p.cx, (double)c->p.cy, c->p.width, c->p.height};
     const int n_obs0 = (int)c->n_obs, n_kf = std::max(c->n_kf, kf + 1);
     const vo_match* dm = c->d_matches + (size_t)std::max(lane, 0) * c->lane_stride;
-    { ProfScope ps(c, "k_kf_commit");
-      hipLaunchKernelGGL(k_kf_commit, dim3(1), dim3(KF_CT), 4 * (size_t)((nfeat + 31) / 32), st, T, dm, n_match, (const vo_keypoint*)(c->d_kps + (size_t)frame_slot * nfeat),
+    const int nbm = (n_match + 255) / 256, nbk = (nfeat + 255) / 256;
+    { ProfScope ps(c, "k_kf_commit");                       // (two launches under one name: count, then place)
+      if (nbm > 0) hipLaunchKernelGGL(k_kf_count, dim3(nbm), dim3(256), 0, st, T, dm, n_match, K.d_cnt, K.d_kp_bits, K.d_hdr);
+      else HIP_TRY(hipMemsetAsync(K.d_hdr, 0x7F, sizeof(KfDev), st));      // no matches (the first keyframe): nothing counts, the reach starts at "none"
+      hipLaunchKernelGGL(k_kf_place, dim3(nbm + nbk), dim3(256), 0, st, T, dm, n_match, nbm, (const int2*)K.d_cnt, (const unsigned*)K.d_kp_bits, (const vo_keypoint*)(c->d_kps + (size_t)frame_slot * nfeat),
                          (const int*)(c->d_nkp + frame_slot), nfeat, (const uint32_t*)(c->d_desc + (size_t)frame_slot * nfeat * 32), (int)kf, n_obs0, (int)first_new_slot, P, cam,
                          (double)c->p.depth_scale, K.d_cand, K.d_hdr); }
     if (n_match > 0) {
@@ -525,7 +551,7 @@ extern "C" int vo_keyframe_commit(vo_ctx* c, int lane, int frame_slot, int32_t k
     }
     { ProfScope ps(c, "k_kf_finish");
       hipLaunchKernelGGL(k_kf_finish, dim3(1), dim3(1024), 0, st, T, (const KfDev*)K.d_hdr, n_kf, (int)kf, n_obs0, K.d_w, (const int32_t*)K.d_cand, (const uint8_t*)K.d_tri_ok,
-                         (const double*)K.d_tri_xyz, reinterpret_cast<int2*>(c->d_kf_reach), K.h); }
+                         (const double*)K.d_tri_xyz, reinterpret_cast<int2*>(c->d_kf_reach), K.h, K.d_kp_bits, nfeat); }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));                      // the pinned block is complete; a back-end thread may read the tables from its own stream next
     const KfHost& H = *K.h;
