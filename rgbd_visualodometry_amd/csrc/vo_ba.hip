@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_blocks(BaBatch Q) {
 // launches (count, scan + slice table, ordered fill) replace a host enumeration of ~4 pairs per edge and the upload
 // of the lists; the order inside a block (ascending point) is the host builder's, so the sums are the same.
 #define PAIR_LDS_CAP 8192
-struct BaPairPlan { const int32_t* ps_start; const int32_t* ps_edges; const int32_t* ps_pt; int nf; int* cnt; int* off; int* n_slices; int* n_pairs; BaBlock* blocks; int2* pairs; };
+struct BaPairPlan { const int32_t* ps_start; const int32_t* ps_edges; const int32_t* ps_pt; int nf; int* cnt; int* off; int* n_slices; int* n_pairs; BaBlock* blocks; int2* pairs; int lds_cap; };      // lds_cap: entries of the launch's dynamic LDS (a longer list is searched in global memory)
 
 __device__ __forceinline__ void ba_block_of(int b, int nf, int& j1, int& j2) {     // b-th (j1 <= j2) pair in row-major order
     j1 = 0;
@@ -447,12 +447,15 @@ __global__ __launch_bounds__(256) void k_ba_pairs(BaPairPlan Q) {
         for (int q = threadIdx.x; q < n1; q += 256) { const int e = Q.ps_edges[a0 + q]; Q.pairs[base + q] = make_int2(e, e); }
         return;
     }
-    for (int i = threadIdx.x; i < n2; i += 256) s_pts[i] = Q.ps_pt[b0 + i];
+    // pose j2's sorted point list: in LDS when it fits this launch's allocation, searched in global memory otherwise (config 5: 11 k edges per pose)
+    const int* pts = s_pts;
+    if (n2 <= Q.lds_cap) { for (int i = threadIdx.x; i < n2; i += 256) s_pts[i] = Q.ps_pt[b0 + i]; }
+    else pts = Q.ps_pt + b0;
     __syncthreads();
     int run = 0;
     for (int c0 = 0; c0 < n1; c0 += 256) {
         const int q = c0 + threadIdx.x;
-        const int hit = q < n1 ? ba_find_sorted(s_pts, n2, Q.ps_pt[a0 + q]) : -1;
+        const int hit = q < n1 ? ba_find_sorted(pts, n2, Q.ps_pt[a0 + q]) : -1;
         // order-preserving position of the hits inside this chunk of 256
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const unsigned long long m = __ballot(hit >= 0);
@@ -2114,7 +2117,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
         BaPairPlan Q;
         Q.ps_start = B.ps_start; Q.ps_edges = B.ps_edges; Q.ps_pt = (const int32_t*)(base + o_pspt); Q.nf = nf;
         Q.cnt = (int*)(base + o_pcnt); Q.off = (int*)(base + o_poff); Q.n_slices = (int*)(base + o_pn); Q.n_pairs = (int*)(base + o_pn) + 1;
-        Q.blocks = (BaBlock*)(base + o_blk); Q.pairs = (int2*)(base + o_pairs);
+        Q.blocks = (BaBlock*)(base + o_blk); Q.pairs = (int2*)(base + o_pairs); Q.lds_cap = std::max(max_len, 1);
         if (nb_all) {
             hipLaunchKernelGGL(k_ba_pairs<false>, dim3(nb_all), dim3(256), 4 * (size_t)std::max(max_len, 1), st, Q);
             hipLaunchKernelGGL(k_ba_pairs_scan, dim3(1), dim3(1024), 0, st, Q, nb_all);
@@ -2607,13 +2610,14 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     Q.blocks = (BaBlock*)(base + o_blk); Q.pairs = (int2*)(base + o_pairs);
     if (!R.ev_arrays) HIP_TRY(hipEventCreateWithFlags(&R.ev_arrays, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(R.ev_arrays, st));               // (the first linearisation needs no pairs: it may start here)
-    hipLaunchKernelGGL(k_ba_pairs<false>, dim3(nb_all), dim3(256), 4 * (size_t)PAIR_LDS_CAP, st, Q);      // (a list beyond the cap: its stores past the allocation are dropped, the cut is refused below)
+    Q.lds_cap = PAIR_LDS_CAP;
+    hipLaunchKernelGGL(k_ba_pairs<false>, dim3(nb_all), dim3(256), 4 * (size_t)PAIR_LDS_CAP, st, Q);      // (a list beyond the cap is searched in global memory)
     hipLaunchKernelGGL(k_ba_pairs_scan, dim3(1), dim3(1024), 0, st, Q, nb_all);
     if (!vo_spin_word(h + 133, seq, 2000)) HIP_TRY(hipEventSynchronize(R.ev_arrays));      // from here on `t` may change: every input has been gathered (and the list lengths are in h)
     const int* ps_start = h + 256;
     int max_len = 0, npairs = 0, slices_ub = 0;
     for (int j = 0; j < nf; ++j) max_len = std::max(max_len, ps_start[j + 1] - ps_start[j]);
-    if (max_len > PAIR_LDS_CAP) return VO_E_UNSUPPORTED;    // caller falls back to the host graph cut
+    // (a list longer than PAIR_LDS_CAP -- config 5's 11 k edges per pose -- stays in global memory for the binary searches: slower per pair, same lists)
     for (int j1 = 0; j1 < nf; ++j1) for (int j2 = j1; j2 < nf; ++j2) {
         const int m = std::min(ps_start[j1 + 1] - ps_start[j1], ps_start[j2 + 1] - ps_start[j2]);
         npairs += m; slices_ub += (m + BA_SLICE - 1) / BA_SLICE;
@@ -2634,7 +2638,8 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     B.cam = BaCam{(double)c->p.fx, (double)c->p.fy, (double)c->p.cx, (double)c->p.cy};
     B.delta = huber_delta; B.chi2_th = chi2_th; B.gp = (nx + 63) / 64; B.edges_by_point = 1;
     B.e_obs = e_obs; B.cull = (long long*)(base + o_cull); B.ncull = (int*)(base + o_ncull); B.cull_cap = ne; B.cull_host = nullptr; B.cull_host_cap = 0;      // (the engine points cull_host at its slot's pinned list)
-    hipLaunchKernelGGL(k_ba_pairs<true>, dim3(nb_all), dim3(256), 4 * (size_t)std::max(max_len, 1), st, Q);   // no wait: the solve follows on the engine's stream
+    Q.lds_cap = std::min(std::max(max_len, 1), PAIR_LDS_CAP);
+    hipLaunchKernelGGL(k_ba_pairs<true>, dim3(nb_all), dim3(256), 4 * (size_t)Q.lds_cap, st, Q);   // no wait: the solve follows on the engine's stream
     if (!R.ev) HIP_TRY(hipEventCreateWithFlags(&R.ev, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(R.ev, st));
     HIP_TRY(hipGetLastError());

@@ -12,6 +12,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <functional>
 #include <thread>
 
 #include "myslam/camera.h"
@@ -36,6 +37,9 @@ public:
     // The front-end keeps keyframes and map points on the device (FrontEnd with device_keyframes): a merge then also reports the covisibility
     // ledger's decrements and flags the graph's points on the device (vo_local_ba_resident_merge_ledger); no host map object is touched.
     void SetDeviceKeyframes(bool on) { deviceKeyframes_ = on; }
+    // What to do when a device graph cut cannot take a keyframe's graph (VO_E_UNSUPPORTED / _OVERFLOW / _NOMEM) while the map lives on the device:
+    // the front-end rebuilds its host objects from the tables and both go back to host bookkeeping and the host graph cut (FrontEnd::FallBackToHostObjects)
+    void SetFallbackHook(std::function<void()> f) { onDeviceFallback_ = std::move(f); }
     bool DeviceGraph() const { return deviceGraph_; }             // wait for the pending job and merge it now (end of a sequence / of a timed region)
     void OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr, bool deferTail = false);
     // The three parts a caller may interleave with its own work (FrontEnd::TrackingHandler at a keyframe): the pending local BA is waited for and merged
@@ -89,6 +93,8 @@ private:
     void WorkerLoop();
     void EnsureWorker();            // the worker's context, stream and thread exist before the first keyframe (no one-time setup inside a timed run)
     bool deviceGraph_ = false, deviceKeyframes_ = false;
+    std::function<void()> onDeviceFallback_;
+    int testFailAt_ = 0, nCuts_ = 0;                // VO_TEST_FAIL_CUT_AT=k: the k-th device graph cut reports VO_E_UNSUPPORTED (tests of the fall-back paths)
     std::vector<int32_t> pairA_, pairB_;            // ledger decrements of a merge (device keyframes)
     std::vector<int64_t> culledSpare_;              // the culled-observation list's buffer, handed from job to job
     void FinishOnDevice(Job& j, vo_ctx* solver);

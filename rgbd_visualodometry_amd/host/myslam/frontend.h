@@ -22,7 +22,7 @@ public:
 
     bool AddFrame(const Frame::Ptr frame);
     void SetViewer(const Viewer::Ptr viewer) { viewer_ = viewer; }
-    void SetBackend(const Backend::Ptr backend) { backend_ = backend; if (backend_) backend_->SetContext(ctx_, device_); }
+    void SetBackend(const Backend::Ptr backend) { backend_ = backend; if (backend_) { backend_->SetContext(ctx_, device_); backend_->SetFallbackHook([this]() { FallBackToHostObjects(); }); } }
     VOState GetState() const { return state_; }
     // the two per-frame decisions on explicit inputs (parity tests): bit0 IsGoodEstimation, bit1 IsKeyframe
     int PolicyFlags(const SE3& T_ref_cw, const SE3& T_cur_cw, int numInliers);
@@ -127,6 +127,9 @@ public:
     // Mappoint objects, observation lists and Frame observation sets as of now, rebuilt from the device tables (device_keyframes; a no-op otherwise)
     void MaterializeMap();
     bool KeyframesOnDevice() const { return kfOnDevice_; }
+    // device_keyframes given up for the rest of the run (a graph the device cut cannot take): host objects rebuilt from the tables, bookkeeping and
+    // graph cut back on the host from the next keyframe on
+    void FallBackToHostObjects();
 private:
 };
 }  // namespace myslam

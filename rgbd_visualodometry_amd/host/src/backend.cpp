@@ -24,6 +24,7 @@ Backend::Backend(const Camera::Ptr camera) : camera_(camera) {
     // every local BA floats in its 6-dof gauge.  With this key the OLDEST keyframe of the free set is treated as fixed.
     if (Config::has("ba_fix_oldest_free_keyframe")) fixOldest_ = Config::get<int>("ba_fix_oldest_free_keyframe") != 0;
     if (const char* e = std::getenv("VO_NO_SPIN")) spin_ = std::atoi(e) == 0;                    // A/B runs
+    if (const char* e = std::getenv("VO_TEST_FAIL_CUT_AT")) testFailAt_ = std::atoi(e);
     if (const char* e = std::getenv("VO_BA_FIX_OLDEST")) fixOldest_ = std::atoi(e) != 0;      // the same switch for drivers without a config file (scripts/exp_gauge.sh)
 }
 
@@ -82,6 +83,7 @@ void Backend::WorkerLoop() {
             auto t0 = std::chrono::steady_clock::now();
             { VO_SCOPE("bw.cut");
             j->rc = vo_local_ba_resident_cut(ctxOwn_, ctx_, j->freeKf.data(), (int)j->freeKf.size(), std::sqrt(7.815), chi2Threshold_, &j->nPoints, &j->nFixed, &j->nEdges); }
+            if (testFailAt_ > 0 && ++nCuts_ == testFailAt_ && j->rc == VO_OK) j->rc = VO_E_UNSUPPORTED;
             lk.lock(); j->cutDone = true; cutSeq_.fetch_add(1, std::memory_order_release); cv_.notify_all(); lk.unlock();
             if (j->rc == VO_OK) { VO_SCOPE("bw.solve"); SolveResident(*j, ctxOwn_); }
             j->solveMs = ms_since(t0);
@@ -109,9 +111,10 @@ void Backend::Finish(bool deferTail) {
     if (waited) { stats_.ms_wake += std::chrono::duration<double, std::milli>(tWake - job_->tDone).count(); ++stats_.waited; }
     std::unique_ptr<Job> j = std::move(job_);
     if (j->rc != VO_OK) {                            // a failed solve must not end the stream: the map keeps its un-optimised state
-        if (j->resident && deviceGraph_ && !deviceKeyframes_ && (j->rc == VO_E_UNSUPPORTED || j->rc == VO_E_OVERFLOW || j->rc == VO_E_NOMEM)) {      // (with device keyframes there is no host graph to cut: the BA is skipped, the next one tries again)
+        if (j->resident && deviceGraph_ && (j->rc == VO_E_UNSUPPORTED || j->rc == VO_E_OVERFLOW || j->rc == VO_E_NOMEM)) {
             std::cerr << "[myslam] device graph cut unavailable (" << vo_strerror(j->rc) << "): local BA graphs are cut on the host from here on" << std::endl;
-            deviceGraph_ = false;
+            if (deviceKeyframes_ && onDeviceFallback_) onDeviceFallback_();      // the host objects the host cut walks are rebuilt from the device tables first
+            deviceGraph_ = false; deviceKeyframes_ = false;
         }
         if (stats_.failed++ == 0) std::cerr << "[myslam] vo_local_ba failed (" << vo_strerror(j->rc) << "): this local BA is skipped, tracking continues" << std::endl;
         return;
@@ -226,6 +229,7 @@ void Backend::OptimizeCovisibleGraphOfKeyframe(const Frame::Ptr keyframeCurr, bo
             auto t1 = std::chrono::steady_clock::now();
             job_->rc = vo_local_ba_resident_cut(ctx_, ctx_, job_->freeKf.data(), job_->nFree, std::sqrt(7.815), chi2Threshold_, &job_->nPoints, &job_->nFixed, &job_->nEdges);
             job_->cutDone = true;
+            if (testFailAt_ > 0 && ++nCuts_ == testFailAt_ && job_->rc == VO_OK) job_->rc = VO_E_UNSUPPORTED;
             if (job_->rc == VO_OK) SolveResident(*job_, ctx_);
             job_->solveMs = ms_since(t1);
             job_->done = true; Finish();

@@ -491,6 +491,17 @@ void FrontEnd::MaterializeMap() {
     MapManager::GetInstance().MaterializeFromTables(ctx_);
 }
 
+void FrontEnd::FallBackToHostObjects() {
+    if (!kfOnDevice_) return;
+    std::cerr << "[myslam] device_keyframes: going back to host map objects (rebuilt from the device tables)" << std::endl;
+    DrainAhead();
+    MapManager::GetInstance().MaterializeFromTables(ctx_);
+    kfOnDevice_ = false;
+    keyframeForTrackingMap_ = nullptr;                       // the active list is built from the host objects again (and uploaded) at the next frame
+    activeList_.clear(); activeIndexOfSlot_.clear();
+    spec_.clear(); ++epoch_;
+}
+
 void FrontEnd::CreateNewMappoints() {
     newMappoints_.clear(); newMappointKp_.clear();
     for (size_t idx = 0; idx < keypointsCurr_.size(); ++idx) {

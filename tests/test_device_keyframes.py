@@ -23,7 +23,7 @@ def stream():
     return syn.render(syn.params(seed=11, speed=3.0), 0, 64, threads=8)
 
 
-def run_system(lib, stream, n, lag, dk, feats=500, lookahead=1, batch=1, **kw):
+def run_system(lib, stream, n, lag, dk, feats=500, lookahead=1, batch=1, expect_on_device=None, **kw):
     bgr, depth, Twc, ts = stream
     s = system.VoSystem(lib, number_of_features=feats, ba_device_graph=1, map_descriptors_on_device=1, device_keyframes=dk, backend_lag_frames=lag,
                         map_capacity=1 << 17, max_frames_in_flight=lookahead, track_batch=batch, **kw)
@@ -40,7 +40,7 @@ def run_system(lib, stream, n, lag, dk, feats=500, lookahead=1, batch=1, **kw):
     s.flush()
     st = s.stats()
     kfs, on = s.materialize()
-    assert on == bool(dk)
+    assert on == (bool(dk) if expect_on_device is None else expect_on_device)
     order = {k: i for i, k in enumerate(kfs)}
     cov = [{order[p]: v for p, v in s.scn_covisibility(k).items()} for k in kfs]
     ids = s.mappoint_ids()
@@ -52,7 +52,7 @@ def run_system(lib, stream, n, lag, dk, feats=500, lookahead=1, batch=1, **kw):
 
 
 def compare_runs(a, b, tol):
-    for k in ("keyframes", "map_points", "ba_runs", "triangulated", "lost", "ba_points", "ba_edges", "ba_poses", "ba_fixed", "ba_outliers"):
+    for k in ("keyframes", "map_points", "ba_runs", "ba_failed", "triangulated", "lost", "ba_points", "ba_edges", "ba_poses", "ba_fixed", "ba_outliers"):
         assert a["stats"][k] == b["stats"][k], k
     np.testing.assert_allclose(a["traj"], b["traj"], atol=tol, rtol=0)
     assert a["covis"] == b["covis"]                            # weights and the >= 15 active sets of every keyframe, both ways
@@ -71,6 +71,17 @@ def test_device_keyframes_equal_the_host_objects_on_the_restatement(stream, lag)
     a = run_system(ORACLE_LIB, stream, 48, lag, 0)
     b = run_system(ORACLE_LIB, stream, 48, lag, 1)
     assert a["stats"]["keyframes"] >= 10 and a["stats"]["ba_runs"] >= 8 and a["stats"]["triangulated"] >= (1 if lag == 0 else 5)
+    compare_runs(a, b, 0.0)
+
+
+def test_a_graph_the_device_cut_refuses_sends_both_bookkeepings_back_to_host_objects(stream, monkeypatch):
+    """VO_TEST_FAIL_CUT_AT makes the third device graph cut report VO_E_UNSUPPORTED.  With host objects the back-end then cuts on the host for the rest
+    of the run; with device keyframes the front-end first rebuilds its host objects from the tables (FrontEnd::FallBackToHostObjects).  From there
+    on both runs are the same program in the same state: equal to the bit on the restatement."""
+    monkeypatch.setenv("VO_TEST_FAIL_CUT_AT", "3")
+    a = run_system(ORACLE_LIB, stream, 40, 0, 0, expect_on_device=False)
+    b = run_system(ORACLE_LIB, stream, 40, 0, 1, expect_on_device=False)
+    assert a["stats"]["ba_failed"] == b["stats"]["ba_failed"] == 1 and b["stats"]["ba_runs"] >= 6
     compare_runs(a, b, 0.0)
 
 
@@ -279,6 +290,15 @@ def test_device_keyframes_hip_equal_the_host_objects_and_the_restatement(stream,
     assert h1["stats"]["keyframes"] >= 10 and h1["stats"]["ba_runs"] >= 8
     compare_runs(h0, h1, 1e-6)
     compare_runs(o1, h1, 1e-6)
+
+
+@pytest.mark.gpu
+def test_fall_back_to_host_objects_on_the_hip_path(stream, monkeypatch):
+    monkeypatch.setenv("VO_TEST_FAIL_CUT_AT", "3")
+    a = run_system(system.HOST_LIB, stream, 40, 4, 0, lookahead=4, batch=2, expect_on_device=False)
+    b = run_system(system.HOST_LIB, stream, 40, 4, 1, lookahead=4, batch=2, expect_on_device=False)
+    assert a["stats"]["ba_failed"] == b["stats"]["ba_failed"] == 1 and b["stats"]["ba_runs"] >= 6
+    compare_runs(a, b, 1e-6)
 
 
 @pytest.mark.gpu
