@@ -263,21 +263,6 @@ static KfTabs tabs_of(vo_ctx* c) {
                   c->d_map_pos, c->d_map_nrm, c->d_map_desc, c->d_map_flags, c->d_kf_pose};
 }
 
-// exclusive prefix of one value per lane over the workgroup's lanes (lane order, NW waves), and the total
-template <int NW> __device__ __forceinline__ int block_excl(int v, int& total, int* s_w) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
-    if (lane == 63) s_w[wave] = inc;
-    __syncthreads();
-    int before = inc - v, tot = 0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) { const int x = s_w[w]; if (w < wave) before += x; tot += x; }
-    __syncthreads();                                        // s_w is rewritten by the next call
-    total = tot;
-    return before;
-}
 // position of a set flag among the set flags of the workgroup's 1024 lanes (lane order), and their number
 __device__ __forceinline__ int block_rank(bool f, int& total, int* s_w) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
