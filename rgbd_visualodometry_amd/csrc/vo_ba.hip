@@ -144,7 +144,9 @@ __device__ __forceinline__ void ba_wave_reduce(double* v) {      // 64 threads; 
 // Linearisation, one launch: blocks [0, gp) own 64 points each, 4 lanes per point (H_ll, b_l, W_e, chi2: no atomics, no zeroing),
 // blocks [gp, gp + PSPLIT n_free) reduce slices of a free pose's edges into H_pp / b_p (27 f64 atomics per block;
 // H_pp / b_p are zeroed by the step that accepted the state, see k_ba_chi_control).
+#ifndef PSPLIT
 #define PSPLIT 4
+#endif
 #define BA_SLICE 256                                         // pairs per Schur workgroup: one per lane (k_ba_schur2 keeps nothing across pairs)
 // Four lanes share a point (a quad): each takes every fourth edge, the quad sums H_ll / b_l with two DPP quad
 // permutes.  A point seen by all ~30 keyframes of the window no longer makes one lane walk 30 edges in a row.

@@ -6,6 +6,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
@@ -58,3 +60,18 @@ def test_single_rank_dry_run_needs_no_launcher_and_no_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 1 and d["distributed"]["world_size"] == 1 and d["distributed"]["allreduce_sum_of_ones"] == 1
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_tracks_two_streams_on_a_one_gpu_box():
+    """The real N > 1 path with GPU work, as far as a one-GPU box allows: two self-started ranks share device 0 (--same-device), gloo carries the
+    barrier / MAX / SUM / gather; each rank tracks its own stream and the line reports the whole job."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dist-backend", "gloo", "--same-device", "--steps", "12", "--warmup", "4", "--prologue", "40"],
+                       env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["steps"] == 12 and d["scaling"] == "weak" and d["value"] > 0 and d.get("dry_run") is None
+    dist = d["distributed"]
+    assert dist["world_size"] == 2 and dist["allreduce_sum_of_ones"] == 2 and len(dist["ranks"]) == 2
+    assert all(x["device"] == 0 and x["frames_per_s"] > 0 for x in dist["ranks"])
+    assert abs(d["value"] - 2 * 12 / (d["ms_per_step"] * 12e-3)) / d["value"] < 0.01      # whole job: both ranks' frames over the slowest rank's time
