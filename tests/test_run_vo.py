@@ -118,7 +118,8 @@ def test_run_vo_300_frames_with_default_yaml_and_with_2048_hypotheses(tmp_path):
     res = {}
     trajs = {}
     for tag, over in (("default_yaml", {}), ("hyp2048", {"ransac_iterations": 2048, "lookahead_frames": 16, "decode_threads": 8, "track_batch": 4, "backend_lag_frames": 8}),
-                      ("default_yaml_device_tables", {"ba_device_graph": 1, "map_descriptors_on_device": 1})):
+                      ("default_yaml_device_tables", {"ba_device_graph": 1, "map_descriptors_on_device": 1}),
+                      ("default_yaml_device_keyframes", {"ba_device_graph": 1, "map_descriptors_on_device": 1, "device_keyframes": 1})):
         d = tmp_path / tag
         d.mkdir()
         traj, log = run_driver(HIP_BIN, root, str(d), **over)
@@ -132,6 +133,8 @@ def test_run_vo_300_frames_with_default_yaml_and_with_2048_hypotheses(tmp_path):
         assert a["rmse"] < 0.15 and r["trans_rmse"] < 0.12 and r["rot_deg_rmse"] < 1.5, (tag, res[tag])    # free-gauge local BA drifts (DESIGN.md accuracy notes)
     # ~90 local BAs cut on the device from the resident observation table: the same trajectory as with the host's graph cut
     np.testing.assert_allclose(trajs["default_yaml_device_tables"], trajs["default_yaml"], atol=5e-5)
+    # ... and with the keyframe bookkeeping on the device tables as well (no host map objects): the C++ driver, default.yaml otherwise
+    np.testing.assert_allclose(trajs["default_yaml_device_keyframes"], trajs["default_yaml"], atol=5e-5)
     print("ATE / RPE:", res)
 
 
