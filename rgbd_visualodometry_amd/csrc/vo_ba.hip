@@ -2727,7 +2727,8 @@ extern "C" int vo_local_ba_resident_solve(vo_ctx* c, int it_robust, int it_plain
     out->chi2_initial = job.chi0; out->chi2_final = job.chi_final; out->lm_iters = job.iters;
     HIP_TRY(hipGetLastError());
     R.solved = true; ++R.solve_seq; R.cur_buf = job.cur_buf; R.n_culled = out->n_culled; R.chi0 = job.chi0; R.chi_final = job.chi_final; R.lm_iters = job.iters;
-    if (trace) { static double a = 0, b = 0, st = 0; static int n = 0; a += t1 - t0; b += tnow() - t1; st += job.steps; if (++n % 10 == 0) fprintf(stderr, "[vo_trace] resident solve avg ms: optimise %.3f (%.1f step launches) result %.3f (D=%d edges=%d)\n", a / n, st / n, b / n, D, ne); }
+    if (trace) { static double a = 0, b = 0, st = 0; static int n = 0; a += t1 - t0; b += tnow() - t1; st += job.steps; if (++n % 10 == 0) fprintf(stderr, "[vo_trace] resident solve avg ms: optimise %.3f (%.1f step launches) result %.3f (D=%d edges=%d)\n", a / n, st / n, b / n, D, ne);
+                 static const bool each = atoi(getenv("VO_TRACE")) >= 2; if (each) fprintf(stderr, "[vo_trace] BA %d: D=%d points=%d edges=%d optimise %.3f ms\n", n, D, nx, ne, t1 - t0); }
     return out->n_culled > out->cap_culled ? VO_E_OVERFLOW : VO_OK;
 }
 
