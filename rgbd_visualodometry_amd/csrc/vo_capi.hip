@@ -25,6 +25,7 @@ static int build_plan(const vo_params& p, DevPlan& P, std::vector<int>& tab, std
     P.W = p.width; P.H = p.height; P.L = p.n_levels; P.nfeat = p.n_features; P.fast_thr = p.fast_threshold; P.edge = p.edge_threshold;
     P.fx = p.fx; P.fy = p.fy; P.cx = p.cx; P.cy = p.cy;
     const double sf = (double)p.scale_factor;
+    if (P.edge < 20) return VO_E_INVALID;       // k_describe copies rows y-19..y+19, columns x-19..x+20 of the blurred level around every keypoint
     unsigned off = 0;
     for (int l = 0; l < P.L; ++l) {
         P.scale[l] = (float)std::pow(sf, (double)l);
@@ -50,7 +51,7 @@ static int build_plan(const vo_params& p, DevPlan& P, std::vector<int>& tab, std
         P.ccap[l] = std::max(4096, ((P.lw[l] + 1) / 2) * ((P.lh[l] + 1) / 2));
         P.cprefix[l + 1] = P.cprefix[l] + P.ccap[l];
         P.tiles_x[l] = (P.lw[l] - 2 * P.edge + 63) / 64;
-        const int tiles_y = (P.lh[l] - 2 * P.edge + 15) / 16;
+        const int tiles_y = (P.lh[l] - 2 * P.edge + VO_FAST_TH - 1) / VO_FAST_TH;
         P.tile_prefix[l + 1] = P.tile_prefix[l] + P.tiles_x[l] * tiles_y;
         P.btiles_x[l] = (P.lw[l] + 127) / 128;
         P.btile_prefix[l + 1] = P.btile_prefix[l] + P.btiles_x[l] * ((P.lh[l] + 15) / 16);
@@ -91,6 +92,8 @@ static int build_plan(const vo_params& p, DevPlan& P, std::vector<int>& tab, std
         P.umax[v] = v0;
         ++v0;
     }
+    P.umax_pk = 0;
+    for (int v = 0; v <= hp; ++v) P.umax_pk |= (unsigned long long)P.umax[v] << (4 * v);
     double g[7], gs = 0;
     for (int i = 0; i < 7; ++i) { double x = i - 3; g[i] = (double)(float)std::exp(-0.5 / 4.0 * x * x); gs += g[i]; }
     for (int i = 0; i < 7; ++i) P.gk[i] = (int)lrintf((float)(g[i] / gs) * 256.f);

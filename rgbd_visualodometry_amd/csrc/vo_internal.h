@@ -16,6 +16,9 @@
 #define VO_WAVE 64
 
 // Everything a kernel needs to know about the pyramid / detector geometry; passed by value.
+#ifndef VO_FAST_TH
+#define VO_FAST_TH 32                // rows per k_fast_nms tile (64 columns)
+#endif
 struct DevPlan {
     int W, H, L, nfeat, fast_thr, edge;
     int lw[VO_MAX_LEVELS], lh[VO_MAX_LEVELS], pitch[VO_MAX_LEVELS];
@@ -23,11 +26,12 @@ struct DevPlan {
     int ccap[VO_MAX_LEVELS], cprefix[VO_MAX_LEVELS + 1];        // FAST candidate capacity per level and prefix
     unsigned loff[VO_MAX_LEVELS];                               // byte offset of each level inside a slot's pyramid slab
     float scale[VO_MAX_LEVELS];
-    int tiles_x[VO_MAX_LEVELS], tile_prefix[VO_MAX_LEVELS + 1]; // FAST tiling (64x16 tiles), blockIdx.x -> (level, tile)
+    int tiles_x[VO_MAX_LEVELS], tile_prefix[VO_MAX_LEVELS + 1]; // FAST tiling (64 x VO_FAST_TH tiles), blockIdx.x -> (level, tile)
     int xcd_map;                                                // 1: XCD-aware tile order in the tiled ORB kernels (VO_NO_XCD_MAP=1 turns it off for A/B runs)
     int btiles_x[VO_MAX_LEVELS], btile_prefix[VO_MAX_LEVELS + 1]; // blur tiling (128x16 tiles over the whole level)
     int tabx[VO_MAX_LEVELS], taby[VO_MAX_LEVELS];               // offsets into the resize tables
     int umax[16];
+    unsigned long long umax_pk;     // umax[] as sixteen 4-bit fields (the radius-15 disc is symmetric: |u| <= umax[|v|]  <=>  |v| <= umax[|u|])
     int gk[7];
     int sel_cap;                                                // power-of-two sort capacity of the select kernel
     unsigned pyr_stride;                                        // bytes per slot in the pyramid slab

@@ -44,6 +44,8 @@ __device__ __forceinline__ bool vo_slot_block(int per_slot, int n, int affinity,
 }
 static inline int vo_slot_grid(int per_slot, int n, int affinity) { return affinity ? 8 * per_slot * ((n + 7) / 8) : per_slot * n; }
 
+struct __attribute__((packed)) U32u { uint32_t v; };    // a dword at any byte address (gfx950 global loads take any alignment)
+
 // ------------------------------------------------------------------------------------------
 // 16 pixels per lane: 3 x 16-byte loads of BGR, one 16-byte store of gray (the row pitches are multiples of 16 for the
 // common widths; otherwise the byte path below).  The image is flattened over (row, 16-pixel group), so every
@@ -234,38 +236,52 @@ int vo_orb_pyramid_plan(vo_ctx* c, const std::vector<int>& tab) {
 // FAST-9/16 corner score: the largest threshold for which the pixel is still a corner =
 // max over the 16 arcs of 9 contiguous ring pixels of min(+diff) or min(-diff), minus 1.
 #define TW 64
-#define TH 16
+#define TH VO_FAST_TH
 #define GP (TW + 8)          // gray tile pitch (halo 4)
 #define SP (TW + 2)          // score tile pitch (halo 1)
+
+// The differences fit 16 bits, so two arcs are walked per instruction: register i holds (d[i], d[i + 8]) and "index i + 8" of any
+// intermediate is the same register with its halves swapped (v_pk_min_i16 / v_pk_max_i16; ~125 instructions where the scalar form took ~190).
+typedef short v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2s pk_swap(v2s a) { return __builtin_shufflevector(a, a, 1, 0); }
+__device__ __forceinline__ v2s pk_min(v2s a, v2s b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ v2s pk_max(v2s a, v2s b) { return __builtin_elementwise_max(a, b); }
 
 __device__ __forceinline__ int fast_score_lds(const uint8_t* g, int idx) {
     // ring offsets in a GP-pitch tile, same order as the oracle's RING table
     const int off[16] = {3 * GP, 3 * GP + 1, 2 * GP + 2, GP + 3, 3, -GP + 3, -2 * GP + 2, -3 * GP + 1,
                          -3 * GP, -3 * GP - 1, -2 * GP - 2, -GP - 3, -3, GP - 3, 2 * GP - 2, 3 * GP - 1};
-    const int p = g[idx];
-    int d[16];
+    const short p = g[idx];
+    const v2s pp = {p, p};
+    v2s A[8], As[8];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) d[i] = (int)g[idx + off[i]] - p;
-    int mn2[16], mx2[16], mn4[16], mx4[16], mn8[16], mx8[16];
+    for (int i = 0; i < 8; ++i) { const v2s r = {(short)g[idx + off[i]], (short)g[idx + off[i + 8]]}; A[i] = r - pp; As[i] = pk_swap(A[i]); }
+    v2s n2[10], x2[10], n4[12], x4[12], n8[8], x8[8];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { mn2[i] = min(d[i], d[(i + 1) & 15]); mx2[i] = max(d[i], d[(i + 1) & 15]); }
+    for (int i = 0; i < 8; ++i) { const v2s nx = i < 7 ? A[i + 1] : As[0]; n2[i] = pk_min(A[i], nx); x2[i] = pk_max(A[i], nx); }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { mn4[i] = min(mn2[i], mn2[(i + 2) & 15]); mx4[i] = max(mx2[i], mx2[(i + 2) & 15]); }
+    for (int i = 0; i < 2; ++i) { n2[8 + i] = pk_swap(n2[i]); x2[8 + i] = pk_swap(x2[i]); }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { mn8[i] = min(mn4[i], mn4[(i + 4) & 15]); mx8[i] = max(mx4[i], mx4[(i + 4) & 15]); }
-    int best = -256;
+    for (int i = 0; i < 8; ++i) { n4[i] = pk_min(n2[i], n2[i + 2]); x4[i] = pk_max(x2[i], x2[i + 2]); }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        int mn9 = min(mn8[i], d[(i + 8) & 15]), mx9 = max(mx8[i], d[(i + 8) & 15]);
-        best = max(best, max(mn9, -mx9));
+    for (int i = 0; i < 4; ++i) { n4[8 + i] = pk_swap(n4[i]); x4[8 + i] = pk_swap(x4[i]); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { n8[i] = pk_min(n4[i], n4[i + 4]); x8[i] = pk_max(x4[i], x4[i + 4]); }
+    const v2s zero = {0, 0};
+    v2s best = {-256, -256};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const v2s mn9 = pk_min(n8[i], As[i]), mx9 = pk_max(x8[i], As[i]);      // arcs starting at i (low half) and at i + 8 (high half)
+        best = pk_max(best, pk_max(mn9, zero - mx9));
     }
-    return best - 1;
+    return max((int)best.x, (int)best.y) - 1;
 }
 
 __global__ __launch_bounds__(256) void k_fast_nms(DevPlan P, const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand,
                                                   int* __restrict__ cand_cnt, int* __restrict__ status, int slot0, int n, int aff, int per_slot) {
     __shared__ __align__(4) uint8_t s_gray[GP * (TH + 8)];
-    __shared__ uint8_t s_score[SP * (TH + 2)];
+    __shared__ __align__(4) uint8_t s_score[SP * (TH + 2)];
+    static_assert(SP * (TH + 2) % 4 == 0 && TH % 4 == 0, "score tile is cleared by dwords");
     int srel, jb;
     if (!vo_slot_block(per_slot, n, aff, srel, jb)) return;
     const int slot = slot0 + srel;
@@ -281,7 +297,6 @@ __global__ __launch_bounds__(256) void k_fast_nms(DevPlan P, const uint8_t* __re
     const int tid = threadIdx.y * 64 + threadIdx.x;
     // gray tile with halo 4 (coordinates clamped; clamped positions never produce a score): one dword per lane and
     // step; tile columns start at edge + 64 k - 4, i.e. not dword aligned -- gfx950 global loads take any alignment
-    struct __attribute__((packed)) U32u { uint32_t v; };
     for (int i = tid; i < (GP / 4) * (TH + 8); i += 256) {
         const int d = i % (GP / 4), r = i / (GP / 4);
         const int gx0 = x0 - 4 + 4 * d;
@@ -301,21 +316,55 @@ __global__ __launch_bounds__(256) void k_fast_nms(DevPlan P, const uint8_t* __re
     // (A) every position: cheap reject (a 9-arc always contains one pixel of each opposite pair) -> LDS work list,
     // (B) lanes walk the list and evaluate the full corner score.  Without the split, one candidate per
     //     wavefront makes all 64 lanes wait for the ~250-instruction score at every position.
-    __shared__ uint16_t s_list[SP * (TH + 2)];
+    __shared__ __align__(4) uint16_t s_list[SP * (TH + 2)];       // the work list of (B); the survivors of the suppression reuse it
     __shared__ int s_nlist;
     if (tid == 0) s_nlist = 0;
     __syncthreads();
     const int thr = P.fast_thr;
-    for (int i = tid; i < SP * (TH + 2); i += 256) {
-        const int sx = i % SP, sy = i / SP;
-        const int x = x0 - 1 + sx, y = y0 - 1 + sy;
-        s_score[i] = 0;
-        if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) {
-            const int gi = (sy + 3) * GP + sx + 3;
-            const int p = s_gray[gi];
-            const bool c0 = abs((int)s_gray[gi + 3 * GP] - p) > thr || abs((int)s_gray[gi - 3 * GP] - p) > thr;
-            const bool c1 = abs((int)s_gray[gi + 3] - p) > thr || abs((int)s_gray[gi - 3] - p) > thr;
-            if (c0 && c1) s_list[atomicAdd(&s_nlist, 1)] = (uint16_t)i;
+    // (A) four positions per lane: the lane takes one dword of a gray row (pixels c .. c+3 of the tile), the dwords 3 rows above and below
+    // and its two neighbours (v_alignbyte gives the pixels 3 to the left and right), and tests the four with packed 16-bit arithmetic
+    // (even bytes in one register, odd bytes in another).  Survivors are appended with one LDS atomic per wavefront.
+    for (int i = tid; i < SP * (TH + 2) / 4; i += 256) reinterpret_cast<uint32_t*>(s_score)[i] = 0;
+    {
+        const uint32_t* g32 = reinterpret_cast<const uint32_t*>(s_gray);
+        const int xlo = max(3, x0 - 1), xhi = min(w - 3, x0 + TW + 1), ylo = max(3, y0 - 1), yhi = min(h - 3, y0 + TH + 1);   // where a score is wanted
+        const short ts = (short)thr; const v2s thr2 = {ts, ts};
+        const unsigned long long lt = (1ull << threadIdx.x) - 1;
+        constexpr int GD = GP / 4, NA = GD * (TH + 2);
+        for (int i0 = 0; i0 < NA; i0 += 256) {
+            const int i = min(i0 + tid, NA - 1);
+            const int r = i / GD, dq = i - r * GD;              // score row r = gray row r + 3; gray dword dq = tile columns 4 dq .. 4 dq + 3
+            const uint32_t* row = g32 + (r + 3) * GD + dq;
+            const uint32_t C = row[0], U = row[-3 * GD], D = row[3 * GD], Cp = row[dq > 0 ? -1 : 0], Cn = row[dq < GD - 1 ? 1 : 0];
+            const uint32_t Lf = __builtin_amdgcn_alignbyte(C, Cp, 1), Rt = __builtin_amdgcn_alignbyte(Cn, C, 3);
+            uint32_t sgn[2];
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                const uint32_t sel = hb ? 0x0c030c01u : 0x0c020c00u;        // bytes (1, 3) or (0, 2), zero-extended to 16 bits
+                const v2s pc = __builtin_bit_cast(v2s, __builtin_amdgcn_perm(0u, C, sel));
+                const v2s du = __builtin_bit_cast(v2s, __builtin_amdgcn_perm(0u, U, sel)) - pc, dd = __builtin_bit_cast(v2s, __builtin_amdgcn_perm(0u, D, sel)) - pc;
+                const v2s dl = __builtin_bit_cast(v2s, __builtin_amdgcn_perm(0u, Lf, sel)) - pc, dr = __builtin_bit_cast(v2s, __builtin_amdgcn_perm(0u, Rt, sel)) - pc;
+                const v2s zero = {0, 0};
+                const v2s v = thr2 - pk_max(pk_max(du, zero - du), pk_max(dd, zero - dd));     // negative <=> one of the vertical pair differs by more than thr
+                const v2s hh = thr2 - pk_max(pk_max(dl, zero - dl), pk_max(dr, zero - dr));
+                sgn[hb] = __builtin_bit_cast(uint32_t, v) & __builtin_bit_cast(uint32_t, hh);
+            }
+            uint32_t km = ((sgn[0] >> 15) & 1u) | ((sgn[1] >> 14) & 2u) | ((sgn[0] >> 29) & 4u) | ((sgn[1] >> 28) & 8u);
+            const int xb = x0 - 4 + 4 * dq, gy = y0 - 1 + r;       // image column of byte 0, image row
+            const int jmin = min(max(xlo - xb, 0), 4), jmax = min(max(xhi - xb, 0), 4);
+            const uint32_t vm = (jmax > jmin && gy >= ylo && gy < yhi && i0 + tid < NA) ? ((1u << jmax) - (1u << jmin)) : 0u;
+            km &= vm;
+            const unsigned long long m0 = __ballot(km & 1u), m1 = __ballot(km & 2u), m2 = __ballot(km & 4u), m3 = __ballot(km & 8u);
+            const int c0 = __popcll(m0), c1 = __popcll(m1), c2 = __popcll(m2), c3 = __popcll(m3);
+            if (c0 + c1 + c2 + c3 == 0) continue;                 // wave-uniform
+            int wbase = 0;
+            if (threadIdx.x == 0) wbase = atomicAdd(&s_nlist, c0 + c1 + c2 + c3);
+            wbase = __shfl(wbase, 0, 64);
+            const int si = r * SP + 4 * dq - 3;                    // score-tile index of byte 0 (column sx = 4 dq - 3)
+            if (km & 1u) s_list[wbase + __popcll(m0 & lt)] = (uint16_t)si;
+            if (km & 2u) s_list[wbase + c0 + __popcll(m1 & lt)] = (uint16_t)(si + 1);
+            if (km & 4u) s_list[wbase + c0 + c1 + __popcll(m2 & lt)] = (uint16_t)(si + 2);
+            if (km & 8u) s_list[wbase + c0 + c1 + c2 + __popcll(m3 & lt)] = (uint16_t)(si + 3);
         }
     }
     __syncthreads();
@@ -330,18 +379,20 @@ __global__ __launch_bounds__(256) void k_fast_nms(DevPlan P, const uint8_t* __re
     // 3x3 non-max suppression (strict), border filter; survivors are gathered in LDS and appended with ONE
     // global atomic per workgroup (a per-survivor atomic on the shared (slot, level) counter serialises at L2:
     // it was 80 % of this kernel's time)
-    __shared__ uint32_t s_surv[TW * TH / 2];
+    uint32_t* s_surv = reinterpret_cast<uint32_t*>(s_list);       // [TW * TH / 2]
+    static_assert(sizeof(uint16_t) * SP * (TH + 2) >= sizeof(uint32_t) * TW * TH / 2, "survivors fit the work list");
     __shared__ int s_nsurv, s_base;
     if (tid == 0) s_nsurv = 0;
     __syncthreads();
+#pragma unroll
     for (int k = 0; k < TH / 4; ++k) {
         const int ty = threadIdx.y + 4 * k, tx = threadIdx.x;
         const int x = x0 + tx, y = y0 + ty;
-        if (x >= w - P.edge || y >= h - P.edge) continue;
         const uint8_t* q = &s_score[(ty + 1) * SP + tx + 1];
-        const int sc = q[0];
-        if (sc == 0) continue;
-        if (sc > q[-1] && sc > q[1] && sc > q[-SP - 1] && sc > q[-SP] && sc > q[-SP + 1] && sc > q[SP - 1] && sc > q[SP] && sc > q[SP + 1]) {
+        const int sc = (x < w - P.edge && y < h - P.edge) ? q[0] : 0;
+        if (sc == 0) continue;                          // most wavefronts of most tiles leave here
+        const int nb = max(max(max((int)q[-1], (int)q[1]), max((int)q[-SP - 1], (int)q[-SP])), max(max((int)q[-SP + 1], (int)q[SP - 1]), max((int)q[SP], (int)q[SP + 1])));
+        if (sc > nb) {
             const int pos = atomicAdd(&s_nsurv, 1);      // strict 3x3 maxima: at most every other pixel -> fits TW*TH/2
             s_surv[pos] = ((uint32_t)sc << 24) | ((uint32_t)y << 12) | (uint32_t)x;
         }
@@ -583,16 +634,21 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
     return v;
 }
 
-// One wavefront per keypoint at a time, DK keypoints per wavefront in flight: the chain of a keypoint (position -> 31 rows of the level image ->
-// angle -> 512 samples of the blurred level -> bits) is four dependent trips to L2, and a wave that walks it for one keypoint waits most of the
-// time; with DK keypoints interleaved phase by phase the trips overlap.  No LDS: intensity-centroid moments over the radius-15 disc straight
-// from the level image (two 31-pixel rows per wave instruction), then the 256 steered tests read the blurred level (8 samples per lane)
-// and are packed with 4 x __ballot.
-#define DK 1                        // (measured: 2000 features, 32 frames: DK 1 120 us, DK 4 132 us -- the kernel is bound by the scattered byte gathers of the 512 samples, not by the latency of its chain)
+// One wavefront per keypoint.  The chain of a keypoint is position -> 31 rows of the level image (intensity-centroid moments over the
+// radius-15 disc, two 31-pixel rows per wave instruction) -> angle -> 512 steered samples of the blurred level -> 256 bits (4 x __ballot).
+// The samples are where the time goes: 8 byte gathers per lane whose 64 addresses of one instruction spread over ~35 cache lines.  The
+// pattern stays inside radius 13*sqrt(2) < 19 whatever the angle, so the wave first copies the 39 x 40-byte window of the blurred level
+// around the keypoint into LDS with 7 row-contiguous dword loads (issued before the moments so both trips to L2 overlap) and gathers from
+// there.  (Tried and dropped: several keypoints per wave in flight -- 2000 features x 32 frames, 1: 120 us, 4: 132 us.)
+#define DP_R 19                     // window radius (rows/columns either side of the keypoint)
+#define DP_ROWS (2 * DP_R + 1)
+#define DP_DW 10                    // dwords per window row: columns x-19 .. x+20
+#define DP_LOADS ((DP_ROWS * DP_DW + 63) / 64)
 __global__ __launch_bounds__(256) void k_describe(DevPlan P, const SlotDesc* __restrict__ slots, const uint8_t* __restrict__ pyr,
                                                   const uint8_t* __restrict__ blurp, const uint32_t* __restrict__ sel,
                                                   const long long* __restrict__ sel_key, const int* __restrict__ sel_cnt,
                                                   vo_keypoint* __restrict__ kps, uint8_t* __restrict__ desc, int* __restrict__ nkp, int slot0, int n, int aff, int per_slot) {
+    __shared__ uint32_t s_win[4][DP_LOADS * 64];
     int srel, jb;
     if (!vo_slot_block(per_slot, n, aff, srel, jb)) return;
     const int slot = slot0 + srel;
@@ -600,71 +656,68 @@ __global__ __launch_bounds__(256) void k_describe(DevPlan P, const SlotDesc* __r
     int cnt[VO_MAX_LEVELS], total = 0;
     for (int i = 0; i < P.L; ++i) { cnt[i] = sel_cnt[slot * VO_MAX_LEVELS + i]; total += cnt[i]; }
     if (jb == 0 && threadIdx.x == 0) nkp[slot] = total;
-    // keypoints g0 .. g0 + DK - 1 of the quota-ordered list (level-major)
-    const int g0 = (jb * 4 + wave) * DK;
-    int lv[DK], outi[DK], x[DK], y[DK]; bool on[DK];
+    // keypoint g of the quota-ordered list (level-major)
+    const int g = jb * 4 + wave;
+    int l = 0, base = 0;
+    while (l + 1 < P.L && g >= P.qprefix[l + 1]) { base += cnt[l]; ++l; }
+    if (g >= P.nfeat || (g - P.qprefix[l]) >= cnt[l]) return;          // wave-uniform; no workgroup barrier below
+    const int outi = base + (g - P.qprefix[l]);
+    const uint32_t c = sel[(size_t)slot * P.nfeat + g];
+    const int x = c & 0xFFF, y = (c >> 12) & 0xFFF;
+    const int pitch = P.pitch[l];
+    const uint8_t* ctr = blurp + (size_t)slot * P.pyr_stride + P.loff[l] + (size_t)y * pitch + x;
+    // the window of the blurred level, row-contiguous (keypoints keep >= 19 rows and 20 columns from the border: ORB's edge threshold is 31)
+    uint32_t wreg[DP_LOADS];
 #pragma unroll
-    for (int k = 0; k < DK; ++k) {
-        const int g = g0 + k;
-        int l = 0, base = 0;
-        on[k] = g < P.nfeat;
-        while (l + 1 < P.L && g >= P.qprefix[l + 1]) { base += cnt[l]; ++l; }
-        if (on[k] && (g - P.qprefix[l]) >= cnt[l]) on[k] = false;
-        lv[k] = l; outi[k] = base + (g - P.qprefix[l]);
-        const uint32_t c = on[k] ? sel[(size_t)slot * P.nfeat + g] : 0u;
-        x[k] = c & 0xFFF; y[k] = (c >> 12) & 0xFFF;
+    for (int i = 0; i < DP_LOADS; ++i) {
+        const int e = min(i * 64 + lane, DP_ROWS * DP_DW - 1), r = e / DP_DW, q = e - r * DP_DW;      // (the last load's spare lanes repeat the last dword)
+        wreg[i] = ((const U32u*)(ctr + (r - DP_R) * pitch - DP_R + 4 * q))->v;
     }
-    // intensity centroid: lanes 0..30 take row v, lanes 32..62 row v+1
-    int m10[DK], m01[DK];
-    const int u = (lane & 31) - 15, half = lane >> 5;
+    // intensity centroid: lanes 0..30 take row v, lanes 32..62 row v+1; lane u is inside the disc on the rows |v| <= umax[|u|].  Every lane
+    // loads on every row (lanes outside read the centre pixel and drop it) so the sixteen loads go out back to back, no branch between them
+    int m10 = 0, m01 = 0;
+    {
+        const uint8_t* img = pyr + (size_t)slot * P.pyr_stride + P.loff[l] + (size_t)y * pitch + x;
+        const int u = (lane & 31) - 15, half = lane >> 5;
+        const int vlim = (lane & 31) < 31 ? (int)((P.umax_pk >> (4 * abs(u))) & 15) : -1;
 #pragma unroll
-    for (int k = 0; k < DK; ++k) {
-        m10[k] = 0; m01[k] = 0;
-        if (!on[k]) continue;
-        const uint8_t* img = pyr + (size_t)slot * P.pyr_stride + P.loff[lv[k]];
-        const int pitch = P.pitch[lv[k]];
         for (int v0 = -15; v0 <= 15; v0 += 2) {
             const int v = v0 + half;
-            if ((lane & 31) < 31 && v <= 15 && abs(u) <= P.umax[abs(v)]) {
-                const int I = img[(size_t)(y[k] + v) * pitch + x[k] + u];
-                m10[k] += u * I; m01[k] += v * I;
-            }
+            const bool in = abs(v) <= vlim;
+            const int I = img[in ? v * pitch + u : 0];
+            m10 += in ? u * I : 0; m01 += in ? v * I : 0;
         }
     }
+    uint8_t* win = (uint8_t*)s_win[wave];
 #pragma unroll
-    for (int k = 0; k < DK; ++k) { m10[k] = wave_sum_i32(m10[k]); m01[k] = wave_sum_i32(m01[k]); }
-    uint64_t bits[DK][4];
-#pragma unroll
-    for (int k = 0; k < DK; ++k) {
-        double cs = 1.0, sn = 0.0;
-        if (m10[k] != 0 || m01[k] != 0) {
-            const double nrm = sqrt((double)m10[k] * (double)m10[k] + (double)m01[k] * (double)m01[k]);
-            cs = (double)m10[k] / nrm; sn = (double)m01[k] / nrm;
-        }
-        const int pitch = P.pitch[lv[k]];
-        const uint8_t* ctr = blurp + (size_t)slot * P.pyr_stride + P.loff[lv[k]] + (size_t)y[k] * pitch + x[k];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int8_t* q = c_pattern[r * 64 + lane];
-            const int x1 = __double2int_rn((double)q[0] * cs - (double)q[1] * sn), y1 = __double2int_rn((double)q[0] * sn + (double)q[1] * cs);
-            const int x2 = __double2int_rn((double)q[2] * cs - (double)q[3] * sn), y2 = __double2int_rn((double)q[2] * sn + (double)q[3] * cs);
-            const bool b = on[k] && ctr[y1 * pitch + x1] < ctr[y2 * pitch + x2];
-            bits[k][r] = __ballot(b);
-        }
+    for (int i = 0; i < DP_LOADS; ++i) s_win[wave][i * 64 + lane] = wreg[i];
+    m10 = wave_sum_i32(m10); m01 = wave_sum_i32(m01);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double cs = 1.0, sn = 0.0;
+    if (m10 != 0 || m01 != 0) {
+        const double nrm = sqrt((double)m10 * (double)m10 + (double)m01 * (double)m01);
+        cs = (double)m10 / nrm; sn = (double)m01 / nrm;
     }
-    if (lane < DK && on[lane < DK ? lane : 0]) {
-        // lane k writes keypoint k (the per-keypoint values live in registers indexed at compile time: select them without dynamic indexing)
-        int l = 0, o = 0, xx = 0, yy = 0, a10 = 0, a01 = 0, gg = 0; uint64_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+    uint64_t bits[4];
+    const uint8_t* wc = win + DP_R * (DP_DW * 4) + DP_R;                // the keypoint's own pixel inside the window
 #pragma unroll
-        for (int k = 0; k < DK; ++k) if (lane == k) { l = lv[k]; o = outi[k]; xx = x[k]; yy = y[k]; a10 = m10[k]; a01 = m01[k]; gg = g0 + k; b0 = bits[k][0]; b1 = bits[k][1]; b2 = bits[k][2]; b3 = bits[k][3]; }
-        uint64_t* d = (uint64_t*)(desc + ((size_t)slot * P.nfeat + o) * 32);
-        d[0] = b0; d[1] = b1; d[2] = b2; d[3] = b3;
+    for (int r = 0; r < 4; ++r) {
+        const int8_t* q = c_pattern[r * 64 + lane];
+        const int x1 = __double2int_rn((double)q[0] * cs - (double)q[1] * sn), y1 = __double2int_rn((double)q[0] * sn + (double)q[1] * cs);
+        const int x2 = __double2int_rn((double)q[2] * cs - (double)q[3] * sn), y2 = __double2int_rn((double)q[2] * sn + (double)q[3] * cs);
+        bits[r] = __ballot(wc[y1 * (DP_DW * 4) + x1] < wc[y2 * (DP_DW * 4) + x2]);
+    }
+    if (lane == 0) {
+        uint64_t* d = (uint64_t*)(desc + ((size_t)slot * P.nfeat + outi) * 32);
+        d[0] = bits[0]; d[1] = bits[1]; d[2] = bits[2]; d[3] = bits[3];
         vo_keypoint kp;
-        kp.x = (float)xx * P.scale[l];
-        kp.y = (float)yy * P.scale[l];
+        kp.x = (float)x * P.scale[l];
+        kp.y = (float)y * P.scale[l];
         kp.size = 31.f * P.scale[l];
-        kp.angle = fast_atan2_deg_dev((float)a01, (float)a10);
-        kp.response = (float)((double)sel_key[(size_t)slot * P.nfeat + gg] * (1.0 / (25.0 * 7140.0 * 7140.0 * 7140.0 * 7140.0)));
+        kp.angle = fast_atan2_deg_dev((float)m01, (float)m10);
+        kp.response = (float)((double)sel_key[(size_t)slot * P.nfeat + g] * (1.0 / (25.0 * 7140.0 * 7140.0 * 7140.0 * 7140.0)));
         kp.octave = l; kp.class_id = -1;
         // Frame::GetDepth (reference src/frame.cpp:43-67), bounds-checked
         const SlotDesc sd = slots[slot];
@@ -676,7 +729,7 @@ __global__ __launch_bounds__(256) void k_describe(DevPlan P, const SlotDesc* __r
             if (x2 >= 0 && y2 >= 0 && x2 < P.W && y2 < P.H) dr = *(const uint16_t*)(sd.depth + (size_t)y2 * sd.depth_stride + 2 * (size_t)x2);
         }
         kp.depth_raw = dr;
-        kps[(size_t)slot * P.nfeat + o] = kp;
+        kps[(size_t)slot * P.nfeat + outi] = kp;
     }
 }
 
@@ -713,7 +766,7 @@ int vo_orb_launch(vo_ctx* c, int slot0, int n) {
       const int per = 8 * ((P.btile_prefix[P.L] + 7) / 8);
       hipLaunchKernelGGL(k_blur, dim3(vo_slot_grid(per, n, aff)), dim3(32, 8), 0, st, P, c->d_pyr, c->d_blur, slot0, n, aff, per); }
     { ProfScope ps(c, "k_describe");
-      const int per = (P.nfeat + 4 * DK - 1) / (4 * DK);
+      const int per = (P.nfeat + 3) / 4;
       hipLaunchKernelGGL(k_describe, dim3(vo_slot_grid(per, n, aff)), dim3(256), 0, st, P, c->d_slots, c->d_pyr, c->d_blur, c->d_sel, c->d_sel_key, c->d_sel_cnt, c->d_kps, c->d_desc, c->d_nkp, slot0, n, aff, per); }
     HIP_TRY(hipGetLastError());
     return VO_OK;

@@ -3,7 +3,7 @@ import sys, os, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from rgbd_visualodometry_amd import capi
-W, H, N, F = 640, 480, int(sys.argv[1]) if len(sys.argv) > 1 else 2000, 32
+W, H, N, F = 640, 480, int(sys.argv[1]) if len(sys.argv) > 1 else 2000, int(sys.argv[2]) if len(sys.argv) > 2 else 32
 syn = capi.Synth(); bgr, depth, Twc, ts = syn.render(syn.params(seed=0, speed=3.0), 0, F, threads=16)
 d_b = torch.from_numpy(bgr).cuda(); d_d = torch.from_numpy(depth.view(np.int16)).cuda()
 L = capi.load(capi.HIP_LIB)
@@ -14,7 +14,7 @@ torch.cuda.synchronize()
 reps = 20; t0 = time.perf_counter()
 for _ in range(reps): oc.orb(0, F)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print("orb_only frames/s %.0f  (%.1f us per 32-frame batch)" % (reps * F / dt, dt / reps * 1e6))
+print("orb_only frames/s %.0f  (%.1f us per %d-frame batch, %d features)" % (reps * F / dt, dt / reps * 1e6, F, N))
 oc.profile_enable(True)
 for _ in range(10): oc.orb(0, F)
 torch.cuda.synchronize()
