@@ -35,6 +35,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# Two hardware queues for this process (the HIP runtime reads the variable when it starts; its default is 4).  Measured on one box, alternating
+# (profiles/r05_hw_queues_ab.txt): a single stream does not care (2150-2185 frames/s with 2, 3, 4 or 8), eight / sixteen streams per GPU run
+# 5200 / 6070 frames/s on 2 queues against 4850 / 5680 on 4, 4650 / 5470 on 8, 3670 / 4790 on 1 -- and 1900 / 800 on 16.  The local-BA engine's
+# chain and the tracking chains are two queues' worth of work; every further queue only lets kernels of one-workgroup chains share CUs.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 F64_PEAK_TFLOPS = 78.6       # MI355X FP64 vector = FP64 matrix peak (AMD datasheet; the guide lists the f32 MFMA figure only)
 
@@ -91,7 +97,7 @@ def compact_line(full):
     out = {k: full.get(k) for k in keep}
     cfg = full.get("config") or {}
     out["config"] = {"workload": _short(cfg.get("workload", ""), 200)}
-    for k in ("streams_per_gpu", "ransac_hypotheses", "lookahead_frames", "local_ba", "ba_graph_cut", "prologue_frames"):
+    for k in ("streams_per_gpu", "ransac_hypotheses", "lookahead_frames", "local_ba", "ba_graph_cut", "prologue_frames", "hip_hw_queues"):
         if k in cfg:
             out["config"][k] = _short(cfg[k], 60) if isinstance(cfg[k], str) else cfg[k]
     r = full.get("roofline")
@@ -682,6 +688,7 @@ def main():
                        "local_ba": (False if args.no_ba else ("synchronous" if args.ba_lag == 0 else "overlapped, merged %d frames later or at the next keyframe" % args.ba_lag)),
                        "ransac_hypotheses": args.hyps, "speed": args.speed, "ba_graph_cut": "host" if args.host_graph else "device (resident observation table)",
                        "keyframe_bookkeeping": "host objects" if (args.host_graph or args.host_keyframes) else "device tables (vo_keyframe_commit)",
+                       "hip_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "prologue_frames": args.prologue, "timed_frames": "frames %d..%d of the stream (steady state: the map and the local-BA window have levelled off)" % (Wm, total - 1)},
             **acc, "keyframes": st["keyframes"], "keyframes_timed": kf_timed, "ba_runs": st["ba_runs"], "ba_runs_timed": st["ba_runs"] - st_w["ba_runs"],
             "lost": st["lost"], "map_points": st["map_points"],
