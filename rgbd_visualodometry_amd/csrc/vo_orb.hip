@@ -543,7 +543,7 @@ __global__ __launch_bounds__(1024) void k_select(DevPlan P, const uint8_t* __res
 __global__ __launch_bounds__(256) void k_blur(DevPlan P, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, int slot0, int n, int aff, int per_slot) {
     // 4 pixels per lane in every phase: dword loads/stores to HBM and LDS (rows and level offsets are 64-byte aligned)
     __shared__ uint32_t s_in[(BTH + 6) * BSTR / 4];
-    __shared__ uint32_t s_h[(BTH + 6) * BTW / 2];      // u16 row sums, two per dword
+    __shared__ uint32_t s_h[(BTH + 6) / 2 * BTW];      // u16 row sums: rows 2 k and 2 k + 1 of a column in one dword
     int srel, jb;
     if (!vo_slot_block(per_slot, n, aff, srel, jb)) return;
     const int slot = slot0 + srel;
@@ -560,57 +560,72 @@ __global__ __launch_bounds__(256) void k_blur(DevPlan P, const uint8_t* __restri
     uint8_t* out = blur + (size_t)slot * P.pyr_stride + P.loff[l];
     const int tx = threadIdx.x, ty = threadIdx.y;      // 32 x 8
     // halo tile: image columns x0-4 .. x0+BTW+3 as (BTW+8)/4 dwords per row, reflect-101 at the image border
-    for (int r = ty; r < BTH + 6; r += 8) {
-        int gy = y0 - 3 + r;
-        gy = gy < 0 ? -gy : (gy >= h ? 2 * h - 2 - gy : gy);
-        gy = min(max(gy, 0), h - 1);
-        const uint8_t* rowp = img + (size_t)gy * pitch;
-        for (int d = tx; d < (BTW + 8) / 4; d += 32) {
+    {
+        constexpr int HD = (BTW + 8) / 4;                   // dwords per halo row
+        const int tid = ty * 32 + tx;
+        for (int i = tid; i < HD * (BTH + 6); i += 256) {   // (flat: a row is 34 dwords, a lane row of 32 would idle through a second trip)
+            const int r = i / HD, d = i - r * HD;
+            int gy = y0 - 3 + r;
+            gy = gy < 0 ? -gy : (gy >= h ? 2 * h - 2 - gy : gy);
+            gy = min(max(gy, 0), h - 1);
+            const uint8_t* rowp = img + (size_t)gy * pitch;
             const int gx0 = x0 - 4 + 4 * d;
             uint32_t v;
             if (gx0 >= 0 && gx0 + 3 < w) v = *(const uint32_t*)(rowp + gx0);
             else {
                 v = 0;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    int gx = gx0 + i;
+                for (int k = 0; k < 4; ++k) {
+                    int gx = gx0 + k;
                     gx = gx < 0 ? -gx : (gx >= w ? 2 * w - 2 - gx : gx);
                     gx = min(max(gx, 0), w - 1);
-                    v |= (uint32_t)rowp[gx] << (8 * i);
+                    v |= (uint32_t)rowp[gx] << (8 * k);
                 }
             }
             s_in[r * (BSTR / 4) + d] = v;
         }
     }
     __syncthreads();
-    const int g0 = P.gk[0], g1 = P.gk[1], g2 = P.gk[2], g3 = P.gk[3];      // symmetric 7-tap kernel
-    for (int r = ty; r < BTH + 6; r += 8) {
-        const uint32_t* q = &s_in[r * (BSTR / 4) + tx];
-        const uint32_t a = q[0], b = q[1], c = q[2];   // bytes x-4 .. x+7 of this lane's 4 outputs x .. x+3
-        int px[12];
+    const uint32_t g0 = P.gk[0], g1 = P.gk[1], g2 = P.gk[2], g3 = P.gk[3];      // symmetric 7-tap kernel, round(k * 256): every tap fits a byte
+    // Row pass on bytes: output i of a lane's four needs bytes i+1 .. i+7 of its 12-byte window [a | b | c]: two v_dot4_u32_u8 on windows cut out with
+    // v_alignbyte (weights (g0 g1 g2 g3) and (g2 g1 g0 0)).  A lane takes TWO rows (2 rp, 2 rp + 1) and stores the sums of a column as one dword
+    // (even row low, odd row high): the column pass then reads row PAIRS and is four v_dot2_u32_u16 per output.  Columns are stored permuted
+    // (column 4 tx + i at i * 32 + tx) so that both passes touch consecutive dwords in consecutive lanes.
+    const uint32_t G1 = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24), G2 = g2 | (g1 << 8) | (g0 << 16);
+    for (int rp = ty; rp < (BTH + 6) / 2; rp += 8) {
+        uint32_t hs[2][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { px[i] = (a >> (8 * i)) & 255; px[4 + i] = (b >> (8 * i)) & 255; px[8 + i] = (c >> (8 * i)) & 255; }
-        int sum[4];
+        for (int e = 0; e < 2; ++e) {
+            const uint32_t* q = &s_in[(2 * rp + e) * (BSTR / 4) + tx];
+            const uint32_t a = q[0], b = q[1], c = q[2];   // bytes x-4 .. x+7 of this lane's 4 outputs x .. x+3
+            hs[e][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b, a, 1), G1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, b, 1), G2, 0u, false), false);
+            hs[e][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b, a, 2), G1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, b, 2), G2, 0u, false), false);
+            hs[e][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b, a, 3), G1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, b, 3), G2, 0u, false), false);
+            hs[e][3] = __builtin_amdgcn_udot4(b, G1, __builtin_amdgcn_udot4(c, G2, 0u, false), false);
+        }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            sum[i] = g3 * px[i + 4] + g2 * (px[i + 3] + px[i + 5]) + g1 * (px[i + 2] + px[i + 6]) + g0 * (px[i + 1] + px[i + 7]);
-        s_h[r * (BTW / 2) + 2 * tx] = (uint32_t)sum[0] | ((uint32_t)sum[1] << 16);
-        s_h[r * (BTW / 2) + 2 * tx + 1] = (uint32_t)sum[2] | ((uint32_t)sum[3] << 16);
+        for (int i = 0; i < 4; ++i) s_h[rp * BTW + i * 32 + tx] = hs[0][i] | (hs[1][i] << 16);      // (a row sum is at most 255 * 256)
     }
     __syncthreads();
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    // output row y needs the row sums y .. y+6: for even y three whole pairs and the low half of a fourth, for odd y the high half of a
+    // pair and three whole ones -- four dot products either way, with the weights chosen by the parity of the lane's rows (ty: BTH and 8 are even)
+    const bool odd = ty & 1;
+    const us2 W0 = __builtin_bit_cast(us2, odd ? (g0 << 16) : (g0 | (g1 << 16))), W1 = __builtin_bit_cast(us2, odd ? (g1 | (g2 << 16)) : (g2 | (g3 << 16)));
+    const us2 W2 = __builtin_bit_cast(us2, odd ? (g3 | (g2 << 16)) : (g2 | (g1 << 16))), W3 = __builtin_bit_cast(us2, odd ? (g1 | (g0 << 16)) : g0);
     for (int r = ty; r < BTH; r += 8) {
         const int x = x0 + 4 * tx, y = y0 + r;
         if (x >= w || y >= h) continue;
-        int acc[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            const uint32_t lo = s_h[(r + k) * (BTW / 2) + 2 * tx], hi = s_h[(r + k) * (BTW / 2) + 2 * tx + 1];
-            const int gk = P.gk[k];
-            acc[0] += gk * (int)(lo & 0xFFFF); acc[1] += gk * (int)(lo >> 16); acc[2] += gk * (int)(hi & 0xFFFF); acc[3] += gk * (int)(hi >> 16);
-        }
+        const uint32_t* hp = &s_h[(r >> 1) * BTW + tx];
         uint32_t o = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o |= (uint32_t)min(255, (acc[i] + (1 << 15)) >> 16) << (8 * i);
+        for (int i = 0; i < 4; ++i) {
+            uint32_t acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, hp[i * 32]), W0, 1u << 15, false);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, hp[BTW + i * 32]), W1, acc, false);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, hp[2 * BTW + i * 32]), W2, acc, false);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, hp[3 * BTW + i * 32]), W3, acc, false);
+            o |= min(255u, acc >> 16) << (8 * i);
+        }
         uint8_t* op = out + (size_t)y * pitch + x;
         if (x + 3 < w) *(uint32_t*)op = o;
         else for (int i = 0; x + i < w; ++i) op[i] = (uint8_t)(o >> (8 * i));
