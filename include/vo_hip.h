@@ -58,7 +58,7 @@ typedef struct vo_params {
     float scale_factor;             /* 1.2                                                 */
     int32_t n_levels;               /* 8                                                   */
     int32_t fast_threshold;         /* 20                                                  */
-    int32_t edge_threshold;         /* 31                                                  */
+    int32_t edge_threshold;         /* 31 (>= 20: the steered BRIEF pattern reaches 19 pixels) */
     int32_t max_frames;             /* frame slots (frames in flight for batched ORB), >=1 */
     int32_t map_capacity;           /* device map capacity in points                        */
     int32_t max_hypotheses;         /* RANSAC hypothesis capacity (>= n_hyp ever passed)    */

@@ -74,7 +74,7 @@ int vo_default_track_params(vo_track_params* t) {
 
 int vo_ctx_create(const vo_params* p, int, vo_ctx** out) {
     if (!p || !out || p->width < 64 || p->height < 64 || p->n_levels < 1 || p->n_levels > 16 || p->max_frames < 1 ||
-        p->n_features < 1 || !(p->scale_factor > 1.0f) || p->map_capacity < 1) return VO_E_INVALID;
+        p->n_features < 1 || !(p->scale_factor > 1.0f) || p->map_capacity < 1 || p->edge_threshold < 20) return VO_E_INVALID;      // (edge: the steered pattern reaches 19 pixels from the keypoint)
     vo_ctx* c = new (std::nothrow) vo_ctx();
     if (!c) return VO_E_NOMEM;
     c->p = *p;

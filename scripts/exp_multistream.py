@@ -1,5 +1,6 @@
 """Experiment: S independent streams on one MI355X, grouped (shared launch chains) or not; prints where the host threads spend time."""
 import argparse, json, os, sys, threading, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")            # as bench.py (profiles/r05_hw_queues_ab.txt); read by the HIP runtime when it starts
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 

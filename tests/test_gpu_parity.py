@@ -261,6 +261,8 @@ def test_hip_rejects_bad_arguments(libs):
     p = H.default_params(width=32)
     with pytest.raises(capi.VoError):
         H.context(p)
+    with pytest.raises(capi.VoError):       # k_describe copies the 39 x 40 window around a keypoint: keypoints must keep 20 pixels from the border
+        H.context(H.default_params(edge_threshold=19))
     ctx, _ = make_ctx(H)
     with pytest.raises(capi.VoError):
         ctx.orb(0, 1)                       # no frame bound yet -> VO_E_STATE
