@@ -39,7 +39,9 @@ sys.path.insert(0, ROOT)
 # (profiles/r05_hw_queues_ab.txt): a single stream does not care (2150-2185 frames/s with 2, 3, 4 or 8), eight / sixteen streams per GPU run
 # 5200 / 6070 frames/s on 2 queues against 4850 / 5680 on 4, 4650 / 5470 on 8, 3670 / 4790 on 1 -- and 1900 / 800 on 16.  The local-BA engine's
 # chain and the tracking chains are two queues' worth of work; every further queue only lets kernels of one-workgroup chains share CUs.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+# Only without a launcher: the several-streams leg runs at N = 1 only, and a rank of an N > 1 job shares its GPU's queues with RCCL's own streams.
+if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 F64_PEAK_TFLOPS = 78.6       # MI355X FP64 vector = FP64 matrix peak (AMD datasheet; the guide lists the f32 MFMA figure only)
