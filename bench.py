@@ -40,8 +40,9 @@ sys.path.insert(0, ROOT)
 # 5200 / 6070 frames/s on 2 queues against 4850 / 5680 on 4, 4650 / 5470 on 8, 3670 / 4790 on 1 -- and 1900 / 800 on 16.  The local-BA engine's
 # chain and the tracking chains are two queues' worth of work; every further queue only lets kernels of one-workgroup chains share CUs.
 # Only without a launcher: the several-streams leg runs at N = 1 only, and a rank of an N > 1 job shares its GPU's queues with RCCL's own streams.
-if int(os.environ.get("WORLD_SIZE", "1")) == 1:
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+_HWQ_DEFAULTED = int(os.environ.get("WORLD_SIZE", "1")) == 1 and "GPU_MAX_HW_QUEUES" not in os.environ
+if _HWQ_DEFAULTED:
+    os.environ["GPU_MAX_HW_QUEUES"] = "2"
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 F64_PEAK_TFLOPS = 78.6       # MI355X FP64 vector = FP64 matrix peak (AMD datasheet; the guide lists the f32 MFMA figure only)
@@ -212,6 +213,8 @@ def spawn_ranks(n, argv):
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if _HWQ_DEFAULTED:
+        env.pop("GPU_MAX_HW_QUEUES", None)                   # (this process's own default, not the ranks': see the top of the file)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
