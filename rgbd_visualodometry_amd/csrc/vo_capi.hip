@@ -57,7 +57,7 @@ static int build_plan(const vo_params& p, DevPlan& P, std::vector<int>& tab, std
         P.btile_prefix[l + 1] = P.btile_prefix[l] + P.btiles_x[l] * ((P.lh[l] + 15) / 16);
         maxq = std::max(maxq, P.quota[l]);
     }
-    P.sel_cap = 1;
+    P.sel_cap = 64;                                         // (k_select sorts whole blocks of 64)
     while (P.sel_cap < 4 * maxq) P.sel_cap <<= 1;
     if ((size_t)P.sel_cap * 12 + 4 * (256 + 8 + 4096) > 160 * 1024) return VO_E_INVALID;
     // bilinear tables

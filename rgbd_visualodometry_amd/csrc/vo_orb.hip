@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void k_pyramid(DevPlan P, uint8_t* __restrict_
                                                  const PyrRng* __restrict__ rng, int slot0, int n, int aff, int gx, int gy) {
     __shared__ __align__(16) uint8_t s_a[PYR_BUF_A];
     __shared__ __align__(16) uint8_t s_b[PYR_BUF_B];
-    __shared__ int2 s_tx[PYR_TAB], s_ty[PYR_TAB];           // x: (local sx | local sx1 << 16, a0 | a1 << 16); y: (local r0 | local r1 << 16, b0 | b1 << 16)
+    __shared__ int2 s_tx[256], s_ty[PYR_TAB];               // x: (local sx | local sx1 << 16, a0 | a1 << 16), column x at (x & 3) * 64 + (x >> 2): a lane reads columns 4 q + k, so lanes of one k read consecutive entries (a plain table: 32-byte stride, four lanes per bank); y: (local r0 | local r1 << 16, b0 | b1 << 16)
     int srel, jb;
     if (!vo_slot_block(gx * gy, n, aff, srel, jb)) return;
     const int slot = slot0 + srel, tx = jb % gx, ty = jb / gx, tid = threadIdx.x;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void k_pyramid(DevPlan P, uint8_t* __restrict_
         const int sw = P.lw[l - 1], sh = P.lh[l - 1];
         if (tid < w) {
             const int dx = r.x0 + tid, sx = tab[P.tabx[l] + dx], sx1 = min(sx + 1, sw - 1);
-            s_tx[tid] = make_int2((sx - rp.x0) | ((sx1 - rp.x0) << 16), (int)(unsigned short)tabs[2 * (P.tabx[l] + dx)] | ((int)tabs[2 * (P.tabx[l] + dx) + 1] << 16));
+            s_tx[(tid & 3) * 64 + (tid >> 2)] = make_int2((sx - rp.x0) | ((sx1 - rp.x0) << 16), (int)(unsigned short)tabs[2 * (P.tabx[l] + dx)] | ((int)tabs[2 * (P.tabx[l] + dx) + 1] << 16));
         }
         if (tid >= 256 - h) {                                // (the y table from the other end of the workgroup: w + h may exceed 256)
             const int j = 255 - tid, dy = r.y0 + j, sy = tab[P.taby[l] + dy];
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void k_pyramid(DevPlan P, uint8_t* __restrict_
             for (int k = 0; k < 4; ++k) {
                 const int x = 4 * q + k;
                 if (x < w) {
-                    const int2 tx2 = s_tx[x];
+                    const int2 tx2 = s_tx[k * 64 + q];
                     const int lx = tx2.x & 0xFFFF, lx1 = (unsigned)tx2.x >> 16, a0 = (short)(tx2.y & 0xFFFF), a1 = tx2.y >> 16;
                     const int h0 = S0[lx] * a0 + S0[lx1] * a1;
                     const int h1 = S1[lx] * a0 + S1[lx1] * a1;
@@ -413,20 +413,33 @@ __global__ __launch_bounds__(256) void k_fast_nms(DevPlan P, const uint8_t* __re
 }
 
 // ------------------------------------------------------------------------------------------
+// Harris response of the 7x7 block around (x, y) on Sobel gradients, as an integer key (25 (ab - c^2) - (a + b)^2: k = 0.04 without a division).
+// Separable: per row of the 9x9 window the horizontal difference d and the horizontal [1 2 1] sum s of its seven interior columns, then
+// ix = d(above) + 2 d + d(below), iy = s(below) - s(above); three rows of d / s roll through registers.  |ix|, |iy| <= 1020 and 49 terms: the
+// sums fit 32 bits (5.1e7), only the key needs 64.  (The direct form -- twelve pixels fetched per position -- took twice the instructions.)
 __device__ __forceinline__ long long harris_key_dev(const uint8_t* img, int pitch, int x, int y) {
-    long long a = 0, b = 0, c = 0;
-    for (int dy = -3; dy <= 3; ++dy) {
-        const uint8_t* r0 = img + (size_t)(y + dy - 1) * pitch + x;
-        const uint8_t* r1 = r0 + pitch;
-        const uint8_t* r2 = r1 + pitch;
+    int a = 0, b = 0, c = 0;
+    int d[3][7], s[3][7];
+    const uint8_t* q = img + (size_t)(y - 4) * pitch + x - 4;
 #pragma unroll
-        for (int dx = -3; dx <= 3; ++dx) {
-            const int ix = ((int)r1[dx + 1] - (int)r1[dx - 1]) * 2 + ((int)r0[dx + 1] - (int)r0[dx - 1]) + ((int)r2[dx + 1] - (int)r2[dx - 1]);
-            const int iy = ((int)r2[dx] - (int)r0[dx]) * 2 + ((int)r2[dx - 1] - (int)r0[dx - 1]) + ((int)r2[dx + 1] - (int)r0[dx + 1]);
-            a += ix * ix; b += iy * iy; c += ix * iy;
+    for (int r = 0; r < 9; ++r, q += pitch) {
+        const uint32_t w0 = reinterpret_cast<const U32u*>(q)->v, w1 = reinterpret_cast<const U32u*>(q + 4)->v;
+        const int p[9] = {(int)(w0 & 255), (int)((w0 >> 8) & 255), (int)((w0 >> 16) & 255), (int)(w0 >> 24),
+                          (int)(w1 & 255), (int)((w1 >> 8) & 255), (int)((w1 >> 16) & 255), (int)(w1 >> 24), (int)q[8]};
+        int (&dn)[7] = d[r % 3]; int (&sn)[7] = s[r % 3];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) { dn[k] = p[k + 2] - p[k]; sn[k] = p[k] + 2 * p[k + 1] + p[k + 2]; }
+        if (r >= 2) {
+            const int (&du)[7] = d[(r + 1) % 3]; const int (&dm)[7] = d[(r + 2) % 3]; const int (&su)[7] = s[(r + 1) % 3];      // rows r - 2 and r - 1
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                const int ix = du[k] + 2 * dm[k] + dn[k], iy = sn[k] - su[k];
+                a += ix * ix; b += iy * iy; c += ix * iy;
+            }
         }
     }
-    return 25 * (a * b - c * c) - (a + b) * (a + b);
+    const long long A = a, B = b, C = c;
+    return 25 * (A * B - C * C) - (A + B) * (A + B);
 }
 
 __device__ __forceinline__ bool sel_before(long long ka, uint32_t ia, long long kb, uint32_t ib) {
@@ -507,12 +520,34 @@ __global__ __launch_bounds__(1024) void k_select(DevPlan P, const uint8_t* __res
     }
     __syncthreads();
     const int kept = min(s_misc[0], P.sel_cap);
-    int m = 1;
+    int m = 64;
     while (m < kept) m <<= 1;
     for (int i = kept + tid; i < m; i += 1024) { s_key[i] = LLONG_MIN; s_idx[i] = 0xFFFFFFFFu; }
     __syncthreads();
-    for (int k = 2; k <= m; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
+    // Bitonic sort into "before" order.  Compare-exchange steps whose partners are less than 64 apart stay inside an aligned block of 64
+    // elements: a wavefront takes the block into registers and runs all of them (for one k, or for every k up to 64 at the start) with
+    // lane exchanges -- 21 workgroup barriers for 2048 elements instead of 66.  Only the steps with partners >= 64 apart go through LDS.
+    const int lane = tid & 63, wv = tid >> 6;
+    auto reg_pass = [&](int k_lo, int k_hi) {                // the steps j = min(k / 2, 32) .. 1 of every k in [k_lo, k_hi] on blocks of 64
+        for (int blk = wv; blk < (m >> 6); blk += 16) {
+            const int i = (blk << 6) + lane;
+            long long key = s_key[i]; uint32_t idx = s_idx[i];
+            for (int k = k_lo; k <= k_hi; k <<= 1) {
+                const bool up = (i & k) == 0;
+                for (int j = min(k >> 1, 32); j > 0; j >>= 1) {
+                    const long long pk = __shfl_xor(key, j, 64); const uint32_t pi = (uint32_t)__shfl_xor((int)idx, j, 64);
+                    const bool want_before = ((lane & j) == 0) == up;       // the lower position of an ascending pair (or the upper of a descending one) keeps the element that comes first
+                    const bool take = want_before ? sel_before(pk, pi, key, idx) : sel_before(key, idx, pk, pi);
+                    if (take) { key = pk; idx = pi; }
+                }
+            }
+            s_key[i] = key; s_idx[i] = idx;
+        }
+    };
+    reg_pass(2, 64);
+    __syncthreads();
+    for (int k = 128; k <= m; k <<= 1) {
+        for (int j = k >> 1; j >= 64; j >>= 1) {
             for (int i = tid; i < m; i += 1024) {
                 const int p = i ^ j;
                 if (p > i) {
@@ -525,6 +560,9 @@ __global__ __launch_bounds__(1024) void k_select(DevPlan P, const uint8_t* __res
             }
             __syncthreads();
         }
+        reg_pass(k, k);
+        __syncthreads();
+    }
     const int out_n = min(kept, quota);
     for (int i = tid; i < out_n; i += 1024) {
         sel[(size_t)slot * P.nfeat + P.qprefix[l] + i] = s_idx[i];
