@@ -498,6 +498,88 @@ __global__ __launch_bounds__(1024) void k_ba_pairs_scan(BaPairPlan Q, int nb) {
     }
 }
 
+// The pair plan in ONE launch (the resident cut; the three launches above remain for vo_local_ba's own slab).  A block's list cannot be longer than the
+// shorter of its two per-pose lists, so the lists are laid out at offsets of those bounds -- known from ps_start alone, no counting pass -- and
+// the pair array has gaps (a slice names its range; nothing walks the array end to end).  Every workgroup stores its block's count, takes a ticket,
+// and the last one builds the slice table from the counts (agent-scope loads: the counts come from workgroups on other XCDs).
+// Q.off[0] is the ticket (zero at launch: k_cut_report clears it), Q.off[1 ..] unused.  Same pairs, same order inside a block as k_ba_pairs<true>.
+__global__ __launch_bounds__(256) void k_ba_pairs_one(BaPairPlan Q, int nb) {
+    extern __shared__ int s_pts[];
+    __shared__ int s_w[16];
+    __shared__ int s_row[VO_BA_RESIDENT_MAX_FREE];       // row r: sum over j2 >= r of min(len r, len j2)
+    __shared__ int s_len[VO_BA_RESIDENT_MAX_FREE];
+    __shared__ int s_last;
+    const int nf = Q.nf;
+    int j1, j2;
+    ba_block_of(blockIdx.x, nf, j1, j2);
+    for (int j = threadIdx.x; j < nf; j += 256) s_len[j] = Q.ps_start[j + 1] - Q.ps_start[j];
+    __syncthreads();
+    for (int r = threadIdx.x; r < nf; r += 256) { const int lr = s_len[r]; int a = 0; for (int c = r; c < nf; ++c) a += min(lr, s_len[c]); s_row[r] = a; }
+    __syncthreads();
+    int base = 0;
+    for (int r = 0; r < j1; ++r) base += s_row[r];
+    for (int c = j1; c < j2; ++c) base += min(s_len[j1], s_len[c]);
+    const int a0 = Q.ps_start[j1], n1 = s_len[j1], b0 = Q.ps_start[j2], n2 = s_len[j2];
+    int run = 0;
+    if (j1 == j2) {
+        for (int q = threadIdx.x; q < n1; q += 256) { const int e = Q.ps_edges[a0 + q]; Q.pairs[base + q] = make_int2(e, e); }
+        run = n1;
+    } else {
+        // pose j2's sorted point list: in LDS when it fits this launch's allocation, searched in global memory otherwise (config 5: 11 k edges per pose)
+        const int* pts = s_pts;
+        if (n2 <= Q.lds_cap) { for (int i = threadIdx.x; i < n2; i += 256) s_pts[i] = Q.ps_pt[b0 + i]; }
+        else pts = Q.ps_pt + b0;
+        __syncthreads();
+        for (int c0 = 0; c0 < n1; c0 += 256) {
+            const int q = c0 + threadIdx.x;
+            const int hit = q < n1 ? ba_find_sorted(pts, n2, Q.ps_pt[a0 + q]) : -1;
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;      // order-preserving position of the hits inside this chunk of 256
+            const unsigned long long m = __ballot(hit >= 0);
+            if (lane == 0) s_w[wave] = __popcll(m);
+            __syncthreads();
+            int before = __popcll(m & ((1ull << lane) - 1ull)), tot = 0;
+            for (int w = 0; w < 4; ++w) { if (w < wave) before += s_w[w]; tot += s_w[w]; }
+            if (hit >= 0) Q.pairs[base + run + before] = make_int2(Q.ps_edges[a0 + q], Q.ps_edges[b0 + hit]);
+            run += tot;
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&Q.cnt[blockIdx.x], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the count has been performed before the ticket is taken
+        s_last = __hip_atomic_fetch_add(&Q.off[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nb - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // the last workgroup: the table of <= BA_SLICE-pair slices over all blocks, in block order.  A thread takes a run of consecutive blocks.
+    __shared__ int s_wa[4], s_wb[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (nb + 255) / 256, i0 = min(nb, tid * per), i1 = min(nb, i0 + per);
+    int a = 0, b = 0, ub0 = 0;
+    {   // offset of block i0 (bound-based), then this run's pair and slice counts
+        int r1, r2;
+        if (i0 < nb) { ba_block_of(i0, nf, r1, r2); for (int r = 0; r < r1; ++r) ub0 += s_row[r]; for (int c = r1; c < r2; ++c) ub0 += min(s_len[r1], s_len[c]); }
+    }
+    for (int i = i0; i < i1; ++i) { const int c = __hip_atomic_load(&Q.cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); a += c; b += (c + BA_SLICE - 1) / BA_SLICE; }
+    int ia = a, ib = b;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int ta = __shfl_up(ia, o, 64), tb = __shfl_up(ib, o, 64); if (lane >= o) { ia += ta; ib += tb; } }
+    if (lane == 63) { s_wa[wave] = ia; s_wb[wave] = ib; }
+    __syncthreads();
+    int ob = ib - b, ta = 0, tb = 0;
+    for (int w = 0; w < 4; ++w) { if (w < wave) ob += s_wb[w]; ta += s_wa[w]; tb += s_wb[w]; }
+    if (tid == 0) { *Q.n_pairs = ta; *Q.n_slices = tb; Q.off[0] = 0; }
+    int r1 = 0, r2 = 0, oa = ub0;
+    if (i0 < nb) ba_block_of(i0, nf, r1, r2);
+    for (int i = i0; i < i1; ++i) {
+        const int c = __hip_atomic_load(&Q.cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0, sl = ob; k < c; k += BA_SLICE, ++sl) Q.blocks[sl] = BaBlock{r1, r2, oa + k, min(BA_SLICE, c - k)};
+        ob += (c + BA_SLICE - 1) / BA_SLICE;
+        oa += min(s_len[r1], s_len[r2]);                  // the next block's offset: this block's bound
+        if (++r2 == nf) { ++r1; r2 = r1; }
+    }
+}
+
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 // ---- k_ba_chol16: the D <= 192 Cholesky + solve, 16-column panels ---------------------------------------------
@@ -2280,8 +2362,9 @@ __global__ void k_cut_init(int n_kf, CutFree F, int* __restrict__ kf_idx, int* _
     kf_idx[k] = idx;
 }
 // a kernel's results for the host, in pinned memory: values first, a system-scope fence, then the word the host polls (vo_spin_word)
-__global__ void k_cut_report(const int* __restrict__ src, int n, int* __restrict__ host, int* __restrict__ word, int seq) {
+__global__ void k_cut_report(const int* __restrict__ src, int n, int* __restrict__ host, int* __restrict__ word, int seq, int* __restrict__ clear) {
     if ((int)threadIdx.x < n) host[threadIdx.x] = src[threadIdx.x];
+    if (threadIdx.x == 0 && clear) *clear = 0;              // (k_ba_pairs_one's ticket)
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) { __hip_atomic_store(word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -2603,9 +2686,9 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     hipLaunchKernelGGL(k_ps_offsets, dim3(nf), dim3(256), 0, st, chunks, nf, (const int*)(base + o_hist), (int*)(base + o_offs), (int*)(base + o_ptot));
     hipLaunchKernelGGL(k_ps_fill, dim3(chunks), dim3(PS_CHUNK), 0, st, ne, nf, e_pose, e_pt, (const int*)(base + o_offs), (const int*)(base + o_ptot), (int*)(base + o_qs),
                        (int32_t*)(base + o_qe), (int32_t*)(base + o_pspt));
-    hipLaunchKernelGGL(k_cut_report, dim3(1), dim3(256), 0, st, (const int*)(base + o_qs), nf + 1, h + 256, h + 133, seq);      // the list lengths; behind it every input of `t` has been gathered
-    // the counting pass and the scan of the pair plan go out BEFORE the host looks at the list lengths (with the largest LDS a list may
-    // need): the stream works through them while the host wakes up, checks the lengths and fills in the descriptor (~25 us per cut)
+    hipLaunchKernelGGL(k_cut_report, dim3(1), dim3(256), 0, st, (const int*)(base + o_qs), nf + 1, h + 256, h + 133, seq, (int*)(base + o_poff));      // the list lengths; behind it every input of `t` has been gathered
+    // the pair plan goes out BEFORE the host looks at the list lengths (with the largest LDS a list may need): the stream works through it
+    // while the host wakes up, checks the lengths and fills in the descriptor (~25 us per cut)
     BaPairPlan Q;
     Q.ps_start = (const int32_t*)(base + o_qs); Q.ps_edges = (const int32_t*)(base + o_qe); Q.ps_pt = (const int32_t*)(base + o_pspt); Q.nf = nf;
     Q.cnt = (int*)(base + o_pcnt); Q.off = (int*)(base + o_poff); Q.n_slices = (int*)(base + o_pn); Q.n_pairs = (int*)(base + o_pn) + 1;
@@ -2613,8 +2696,14 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     if (!R.ev_arrays) HIP_TRY(hipEventCreateWithFlags(&R.ev_arrays, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(R.ev_arrays, st));               // (the first linearisation needs no pairs: it may start here)
     Q.lds_cap = PAIR_LDS_CAP;
-    hipLaunchKernelGGL(k_ba_pairs<false>, dim3(nb_all), dim3(256), 4 * (size_t)PAIR_LDS_CAP, st, Q);      // (a list beyond the cap is searched in global memory)
-    hipLaunchKernelGGL(k_ba_pairs_scan, dim3(1), dim3(1024), 0, st, Q, nb_all);
+    static const bool three_launches = getenv("VO_PAIRS_3") != nullptr;      // A/B: count, scan, fill as three launches
+    if (three_launches) {
+        hipLaunchKernelGGL(k_ba_pairs<false>, dim3(nb_all), dim3(256), 4 * (size_t)PAIR_LDS_CAP, st, Q);
+        hipLaunchKernelGGL(k_ba_pairs_scan, dim3(1), dim3(1024), 0, st, Q, nb_all);
+        hipLaunchKernelGGL(k_ba_pairs<true>, dim3(nb_all), dim3(256), 4 * (size_t)PAIR_LDS_CAP, st, Q);
+    } else hipLaunchKernelGGL(k_ba_pairs_one, dim3(nb_all), dim3(256), 4 * (size_t)PAIR_LDS_CAP, st, Q, nb_all);      // (a list beyond the cap is searched in global memory)
+    if (!R.ev) HIP_TRY(hipEventCreateWithFlags(&R.ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(R.ev, st));
     if (!vo_spin_word(h + 133, seq, 2000)) HIP_TRY(hipEventSynchronize(R.ev_arrays));      // from here on `t` may change: every input has been gathered (and the list lengths are in h)
     const int* ps_start = h + 256;
     int max_len = 0, npairs = 0, slices_ub = 0;
@@ -2640,10 +2729,6 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     B.cam = BaCam{(double)c->p.fx, (double)c->p.fy, (double)c->p.cx, (double)c->p.cy};
     B.delta = huber_delta; B.chi2_th = chi2_th; B.gp = (nx + 63) / 64; B.edges_by_point = 1;
     B.e_obs = e_obs; B.cull = (long long*)(base + o_cull); B.ncull = (int*)(base + o_ncull); B.cull_cap = ne; B.cull_host = nullptr; B.cull_host_cap = 0;      // (the engine points cull_host at its slot's pinned list)
-    Q.lds_cap = std::min(std::max(max_len, 1), PAIR_LDS_CAP);
-    hipLaunchKernelGGL(k_ba_pairs<true>, dim3(nb_all), dim3(256), 4 * (size_t)Q.lds_cap, st, Q);   // no wait: the solve follows on the engine's stream
-    if (!R.ev) HIP_TRY(hipEventCreateWithFlags(&R.ev, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(R.ev, st));
     HIP_TRY(hipGetLastError());
     R.nblk_launch = slices_ub; R.npairs = npairs;
     R.B = B;
