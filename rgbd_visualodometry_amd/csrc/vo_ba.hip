@@ -23,6 +23,7 @@
 // plain round and on to "done" and reports to pinned host memory -- the BA engine (further down) enqueues chunks of steps over all
 // problems in flight without waiting for any of that.  The second half
 // of this file is the device-resident graph cut and merge.
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -2579,11 +2580,74 @@ __global__ __launch_bounds__(256) void k_merge_ledger(const int* __restrict__ n_
     if (threadIdx.x == 0) *n_pairs_total = s_n;
 }
 
-// (A one-launch variant for windows of up to 64 Ki elements -- one workgroup, a contiguous run per lane -- was measured and lost 3 % of a single
-// stream's frames/s: the lanes' 256-byte runs do not coalesce, and two small launches cost less than one slow one.)
-int vo_scan_i32(hipStream_t st, const int* in, int n, int* bsum, int* out, int* total) {        // n <= 16 Mi
+// The same scan in ONE launch for up to 512 tiles (8 Mi elements): a workgroup publishes its tile's total -- (call number << 32 | total) in one
+// 64-bit agent-scope store, so a stale entry of an earlier scan through the same buffer can never be taken for this call's -- BEFORE it waits for
+// anything, then adds up the totals of the tiles in front of it (lane i polls tile i: a workgroup waits only for workgroups with a lower index,
+// which the dispatcher started first and which never wait before they publish), scans its tile from the registers it loaded for the total and
+// writes the result.  The spins are bounded; a tile that never shows up makes the last tile report -1 as the total.
+// (Another one-launch variant -- one workgroup, a contiguous run per lane -- was measured and lost 3 % of a single stream's frames/s: the lanes'
+// 256-byte runs do not coalesce.)  `agg` must not hold (call number << 32) of a FUTURE call: the buffers are zeroed when they are allocated.
+__global__ __launch_bounds__(1024) void k_scan_one(const int* __restrict__ in, int n, unsigned long long* __restrict__ agg, int nb, int* __restrict__ out, int* __restrict__ total_out, unsigned seq) {
+    __shared__ int s_w[16], s_base, s_bad;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.x;
+    int4 e[SCAN_PER / 4]; int v[SCAN_PER / 4];
+    int t = 0;
+#pragma unroll
+    for (int q = 0; q < SCAN_PER / 4; ++q) {
+        e[q] = scan_load4(in, (long long)b * SCAN_TILE + ((long long)q * 1024 + threadIdx.x) * 4, n);
+        v[q] = (e[q].x + e[q].y) + (e[q].z + e[q].w); t += v[q];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    if (lane == 0) s_w[wave] = t;
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    int mine = 0;
+    if (threadIdx.x == 0) {
+        for (int w = 0; w < 16; ++w) mine += s_w[w];
+        __hip_atomic_store(&agg[b], ((unsigned long long)seq << 32) | (unsigned)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();                                        // (s_w is reused below)
+    int p = 0;
+    for (int i = threadIdx.x; i < b; i += 1024) {
+        unsigned long long a = 0;
+        int spins = 0;
+        for (; spins < (1 << 22); ++spins) { a = __hip_atomic_load(&agg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if ((unsigned)(a >> 32) == seq) break; __builtin_amdgcn_s_sleep(1); }
+        if ((unsigned)(a >> 32) != seq) s_bad = 1; else p += (int)(unsigned)a;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
+    if (lane == 0) s_w[wave] = p;
+    __syncthreads();
+    if (threadIdx.x == 0) { int s = 0; for (int w = 0; w < 16; ++w) s += s_w[w]; s_base = s; if (b == nb - 1) *total_out = s_bad ? -1 : s + mine; }
+    __syncthreads();
+    int run = s_base;
+#pragma unroll
+    for (int q = 0; q < SCAN_PER / 4; ++q) {
+        const long long i = (long long)b * SCAN_TILE + ((long long)q * 1024 + threadIdx.x) * 4;
+        int inc = v[q];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+        __syncthreads();                                    // s_w of the previous round has been read
+        if (lane == 63) s_w[wave] = inc;
+        __syncthreads();
+        int off = run + inc - v[q], tot = 0;
+        for (int w = 0; w < 16; ++w) { const int sw = s_w[w]; if (w < wave) off += sw; tot += sw; }
+        const int4 o4 = make_int4(off, off + e[q].x, off + e[q].x + e[q].y, off + e[q].x + e[q].y + e[q].z);
+        if (i + 3 < n) *reinterpret_cast<int4*>(out + i) = o4;
+        else { if (i < n) out[i] = o4.x; if (i + 1 < n) out[i + 1] = o4.y; if (i + 2 < n) out[i + 2] = o4.z; }
+        run += tot;
+    }
+}
+static std::atomic<unsigned> g_scan_seq{0};
+int vo_scan_i32(hipStream_t st, const int* in, int n, int* bsum, int* out, int* total) {        // n <= 16 Mi; bsum: 4096 bytes, 256-byte aligned, zeroed when allocated
     const int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (nb > 1024) return VO_E_UNSUPPORTED;
+    static const bool two = getenv("VO_SCAN_2") != nullptr;             // A/B: block sums and the scan as two launches
+    if (!two && nb <= 512) {
+        hipLaunchKernelGGL(k_scan_one, dim3(std::max(nb, 1)), dim3(1024), 0, st, in, n, (unsigned long long*)bsum, std::max(nb, 1), out, total, ++g_scan_seq);
+        return VO_OK;
+    }
     hipLaunchKernelGGL(k_scan_blocksum, dim3(std::max(nb, 1)), dim3(1024), 0, st, in, n, bsum);
     hipLaunchKernelGGL(k_scan_final, dim3(std::max(nb, 1)), dim3(1024), 0, st, in, n, (const int*)bsum, std::max(nb, 1), out, total);
     return VO_OK;
@@ -2626,6 +2690,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
         c->d_cut = nullptr; c->d_cut_bytes = 0;
         if (hipMalloc(&c->d_cut, co + co / 2) != hipSuccess) return VO_E_NOMEM;
         c->d_cut_bytes = co + co / 2;
+        HIP_TRY(hipMemsetAsync(c->d_cut, 0, c->d_cut_bytes, st));      // (k_scan_one's published totals: see there)
     }
     uint8_t* cb = (uint8_t*)c->d_cut;
     int* kf_idx = (int*)(cb + o_kfi); int* fixed_flag = (int*)(cb + o_ffl); int* pose_kf = (int*)(cb + o_pkf); int* pt_flag = (int*)(cb + o_pfl); int* pidx = (int*)(cb + o_pid);
@@ -2652,6 +2717,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     HIP_TRY(hipGetLastError());
     if (!vo_spin_word(h + 132, seq, 2000)) HIP_TRY(hipStreamSynchronize(st));
     const int nx = h[128], ne = h[129], n_fixed = h[130], np = nf + n_fixed;
+    if (nx < 0 || ne < 0) return VO_E_DEVICE;               // (a scan gave up waiting for one of its tiles)
     R.np = np; R.nf = nf; R.nx = nx; R.ne = ne; R.n_fixed = n_fixed;
     if (nx == 0 || ne == 0 || nf == 0) { R.ready = true; return VO_OK; }         // nothing to optimise
     // ---- BA slab (same layout as vo_ba_run's, filled by kernels instead of an upload)

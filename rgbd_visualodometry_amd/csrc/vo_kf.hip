@@ -639,6 +639,7 @@ extern "C" int vo_map_set_active_covisible(vo_ctx* c, const int32_t* kf, int n, 
             K.d_act = nullptr; K.act_bytes = 0;
             if (hipMalloc(&K.d_act, total + total / 2) != hipSuccess) { (void)hipGetLastError(); return VO_E_NOMEM; }
             K.act_bytes = total + total / 2;
+            HIP_TRY(hipMemsetAsync(K.d_act, 0, K.act_bytes, st));      // (vo_scan_i32's published totals must not look like a later call's)
         }
         int* flag = (int*)K.d_act; int* pos = (int*)((uint8_t*)K.d_act + o_pos); int* bsum = (int*)((uint8_t*)K.d_act + o_bs); int* tot = bsum + 1024;
         const int epoch = (int)(++K.epoch & 0x7FFFFFFF);
