@@ -251,7 +251,7 @@ def dry_run(args, shard, rank, local_rank, world):
     ones = np.ones(1, dtype=np.int32)
     grp.all_reduce_sum_i32(ones)
     ranks = grp.gather_objects({"rank": rank, "local_rank": local_rank, "device": None, "pci_bus_id": None, "stream_seed": shard.stream_seed(args.seed, rank),
-                                "frames_per_s": None, "own_elapsed_s": round(own, 4)})
+                                "frames_per_s": None, "own_elapsed_s": round(own, 4), "hip_hw_queues_env": os.environ.get("GPU_MAX_HW_QUEUES")})
     if rank == 0:
         out = {"metric": "VO frames/sec (640x480 RGB-D)", "value": None, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f64", "data": "none (dry run)",

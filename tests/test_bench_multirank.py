@@ -13,7 +13,7 @@ BENCH = os.path.join(ROOT, "bench.py")
 
 
 def _env(**kw):
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GPU_MAX_HW_QUEUES")}
     env.update(OMP_NUM_THREADS="1", **kw)
     return env
 
@@ -34,6 +34,8 @@ def test_bench_gpus_2_without_a_launcher_starts_two_ranks():
     assert ranks[0]["stream_seed"] + 1 == ranks[1]["stream_seed"]          # one independent stream per rank
     assert d["max_elapsed_s"] >= max(x["own_elapsed_s"] for x in ranks) - 1e-3   # MAX over ranks (rank 1 'works' twice as long)
     assert ranks[1]["own_elapsed_s"] > ranks[0]["own_elapsed_s"]
+    # the two-hardware-queue default is the single-rank run's (its several-streams leg); ranks of an N > 1 job keep the runtime's own
+    assert all(x["hip_hw_queues_env"] is None for x in ranks)
 
 
 def test_bench_under_a_launcher_refuses_a_world_size_that_is_not_gpus():
@@ -60,6 +62,7 @@ def test_single_rank_dry_run_needs_no_launcher_and_no_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 1 and d["distributed"]["world_size"] == 1 and d["distributed"]["allreduce_sum_of_ones"] == 1
+    assert d["distributed"]["ranks"][0]["hip_hw_queues_env"] == "2"
 
 
 @pytest.mark.gpu
