@@ -241,12 +241,18 @@ __global__ __launch_bounds__(256) void k_match_mfma(const LaneDesc* __restrict__
         for (int a = 0; a < MMF_NA; ++a)
 #pragma unroll
             for (int q = 0; q < 4; ++q) best_k[a][q] = MATCH_NONE;
+        // the descriptor words of a tile are requested one tile ahead: the trip to L2 (~1.5 us, eight tiles per workgroup at the bench workload) runs
+        // behind the previous tile's MFMAs instead of between two barriers
+        const int kp_l = threadIdx.x & 63, qtr_l = threadIdx.x >> 6;
+        uint2 w2n = make_uint2(0u, 0u);
+        if ((int)(blockIdx.y * MT) < nkp) w2n = *reinterpret_cast<const uint2*>(fdesc + (size_t)min((int)(blockIdx.y * MT) + kp_l, nkp - 1) * 8 + 2 * qtr_l);
         for (int t0 = blockIdx.y * MT; t0 < nkp; t0 += gridDim.y * MT) {
             __syncthreads();                                // the previous tile has been consumed
             {   // expand keypoints t0 .. t0 + 63: lane -> keypoint, wave -> quarter of the descriptor (2 words = 64 bytes = chunks 4 qtr .. 4 qtr + 3)
-                const int kp = threadIdx.x & 63, qtr = threadIdx.x >> 6;
-                const int src = min(t0 + kp, nkp - 1);
-                const uint2 w2 = *reinterpret_cast<const uint2*>(fdesc + (size_t)src * 8 + 2 * qtr);
+                const int kp = kp_l, qtr = qtr_l;
+                const uint2 w2 = w2n;
+                const int tn = t0 + gridDim.y * MT;
+                if (tn < nkp) w2n = *reinterpret_cast<const uint2*>(fdesc + (size_t)min(tn + kp, nkp - 1) * 8 + 2 * qtr);
                 uint8_t* dst = s_kp + (size_t)(4 * qtr) * MMF_PLANE + kp * 16;
                 *reinterpret_cast<mmf_v4i*>(dst) = mmf_expand16(w2.x & 0xFFFFu, 0xFFFFFFFFu); *reinterpret_cast<mmf_v4i*>(dst + MMF_PLANE) = mmf_expand16(w2.x >> 16, 0xFFFFFFFFu);
                 *reinterpret_cast<mmf_v4i*>(dst + 2 * MMF_PLANE) = mmf_expand16(w2.y & 0xFFFFu, 0xFFFFFFFFu); *reinterpret_cast<mmf_v4i*>(dst + 3 * MMF_PLANE) = mmf_expand16(w2.y >> 16, 0xFFFFFFFFu);
