@@ -2409,11 +2409,12 @@ __global__ void k_cut_fill(CutTabs T, const int* __restrict__ pt_flag, const int
 }
 // edge-parallel: slot i of its point's segment holds some observation (arrival order); its place among the point's edges is its
 // rank by keyframe number (a keyframe observes a point once: no ties).  The same launch gathers poses and positions.
-__global__ void k_cut_emit(CutTabs T, int np, int nx, int ne, const int* __restrict__ pidx, const int* __restrict__ pt_start, const int* __restrict__ kf_idx,
+__global__ void k_cut_emit(CutTabs T, int nf, const int* __restrict__ tot /* nx, ne, n_fixed: k_scan_*, k_cut_fixed_scan */, const int* __restrict__ pidx, const int* __restrict__ pt_start, const int* __restrict__ kf_idx,
                            const int* __restrict__ pose_kf, const int* __restrict__ point_slots, const long long* __restrict__ e_arr, long long* __restrict__ e_obs,
                            int32_t* __restrict__ e_pose, int32_t* __restrict__ e_pt, float* __restrict__ e_uv, int32_t* __restrict__ pt_edges, uint8_t* __restrict__ active,
                            uint8_t* __restrict__ flags, double* __restrict__ posesA, double* __restrict__ posesB, double* __restrict__ ptsA) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nx = tot[0], ne = tot[1], np = nf + tot[2];      // (the launch covers the host's upper bounds: the sizes themselves never leave the device before the chain's end)
     if (i < np * 12) { const double v = T.kf_pose[12 * (size_t)pose_kf[i / 12] + i % 12]; posesA[i] = v; posesB[i] = v; }
     if (i < nx * 3) ptsA[i] = T.map_pos[3 * (size_t)point_slots[i / 3] + i % 3];
     if (i >= ne) return;
@@ -2439,8 +2440,9 @@ __device__ __forceinline__ int ps_wave_rank(int bin, int nf, int lane, int* __re
     }
     return rank;
 }
-__global__ __launch_bounds__(PS_CHUNK) void k_ps_hist(int ne, int nf, const int32_t* __restrict__ e_pose, int* __restrict__ hist /* [chunks][nf] */) {
+__global__ __launch_bounds__(PS_CHUNK) void k_ps_hist(const int* __restrict__ ne_p, int nf, const int32_t* __restrict__ e_pose, int* __restrict__ hist /* [chunks][nf] */) {
     __shared__ int s_cnt[PS_CHUNK / 64][VO_BA_RESIDENT_MAX_FREE];
+    const int ne = *ne_p;                                   // (a chunk behind the last edge counts nothing: its row of hist is zero)
     const int e = blockIdx.x * PS_CHUNK + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = e < ne ? e_pose[e] : nf;
     (void)ps_wave_rank(q < nf ? q : -1, nf, lane, s_cnt[wave]);
@@ -2467,10 +2469,11 @@ __global__ __launch_bounds__(256) void k_ps_offsets(int chunks, int nf, const in
     }
     if (threadIdx.x == 0) total[j] = run;
 }
-__global__ __launch_bounds__(PS_CHUNK) void k_ps_fill(int ne, int nf, const int32_t* __restrict__ e_pose, const int32_t* __restrict__ e_pt, const int* __restrict__ offs,
+__global__ __launch_bounds__(PS_CHUNK) void k_ps_fill(const int* __restrict__ ne_p, int nf, const int32_t* __restrict__ e_pose, const int32_t* __restrict__ e_pt, const int* __restrict__ offs,
                                                       const int* __restrict__ total, int* __restrict__ ps_start, int32_t* __restrict__ ps_edges, int32_t* __restrict__ ps_pt) {
     __shared__ int s_cnt[PS_CHUNK / 64][VO_BA_RESIDENT_MAX_FREE];
     __shared__ int s_base[VO_BA_RESIDENT_MAX_FREE + 1];
+    const int ne = *ne_p;
     const int e = blockIdx.x * PS_CHUNK + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (wave == 0) {                                        // start of each pose's list: exclusive scan of the totals, 64 at a time
         int run = 0;
@@ -2715,42 +2718,58 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     if ((rc = vo_scan_i32(st, cnt, mh + 1, bsum, pt_start, tot + 1))) return rc;
     hipLaunchKernelGGL(k_cut_fixed_scan, dim3(1), dim3(1024), 0, st, nkf, nf, fixed_flag, kf_idx, pose_kf, tot + 2, (const int*)tot, h + 128, h + 132, seq);      // (sizes to the host without a copy or a blocking wait)
     HIP_TRY(hipGetLastError());
-    if (!vo_spin_word(h + 132, seq, 2000)) HIP_TRY(hipStreamSynchronize(st));
-    const int nx = h[128], ne = h[129], n_fixed = h[130], np = nf + n_fixed;
-    if (nx < 0 || ne < 0) return VO_E_DEVICE;               // (a scan gave up waiting for one of its tiles)
-    R.np = np; R.nf = nf; R.nx = nx; R.ne = ne; R.n_fixed = n_fixed;
-    if (nx == 0 || ne == 0 || nf == 0) { R.ready = true; return VO_OK; }         // nothing to optimise
+    // The slab is carved for UPPER BOUNDS of the three sizes -- every slot of the window a point, every observation of the window an edge, every
+    // keyframe a pose (the graph is typically half of its window) -- so that the host does not wait for the sizes in the middle of the chain:
+    // the kernels below take nx, ne and n_fixed from `tot` on the device, their grids cover the bounds (workgroups behind the real sizes leave
+    // at once), and the host reads everything -- sizes and list lengths -- behind the last kernel.  VO_CUT_SIZES_FIRST=1: the earlier order
+    // (wait for the sizes, carve and launch exactly).
+    static const bool sizes_first = getenv("VO_CUT_SIZES_FIRST") != nullptr;
+    int nx = 0, ne = 0, n_fixed = 0, np = nf;
+    int nx_c = mh, np_c = std::max(nkf, nf);
+    long long ne_cl = std::max<long long>(no - obs_lo, 1);
+    if (sizes_first) {
+        if (!vo_spin_word(h + 132, seq, 2000)) HIP_TRY(hipStreamSynchronize(st));
+        nx = h[128]; ne = h[129]; n_fixed = h[130]; np = nf + n_fixed;
+        if (nx < 0 || ne < 0) return VO_E_DEVICE;               // (a scan gave up waiting for one of its tiles)
+        R.np = np; R.nf = nf; R.nx = nx; R.ne = ne; R.n_fixed = n_fixed;
+        if (nx == 0 || ne == 0 || nf == 0) { R.ready = true; return VO_OK; }         // nothing to optimise
+        nx_c = nx; ne_cl = ne; np_c = np;
+    }
+    if (ne_cl > (1ll << 30)) return VO_E_UNSUPPORTED;
+    const int ne_c = (int)ne_cl;
     // ---- BA slab (same layout as vo_ba_run's, filled by kernels instead of an upload)
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     const int nb_all = nf * (nf + 1) / 2;
-    const size_t o_poses = carve(96 * (size_t)np), o_pts = carve(24 * (size_t)nx);
-    const size_t o_epose = carve(4 * (size_t)ne), o_ept = carve(4 * (size_t)ne), o_euv = carve(8 * (size_t)ne), o_pe = carve(4 * (size_t)ne);
-    const size_t o_qs = carve(4 * (size_t)(nf + 1)), o_qe = carve(4 * (size_t)ne), o_pspt = carve(4 * (size_t)ne + 4);
-    const size_t o_poses_n = carve(96 * (size_t)np), o_pts_n = carve(24 * (size_t)nx), o_act = carve(ne), o_flags = carve(ne);
-    const int chunks = (ne + PS_CHUNK - 1) / PS_CHUNK;
-    const size_t o_eobs = carve(8 * (size_t)ne), o_earr = carve(8 * (size_t)ne), o_ncull = carve(64), o_cull = carve(8 * (size_t)ne);
+    const size_t o_poses = carve(96 * (size_t)np_c), o_pts = carve(24 * (size_t)nx_c);
+    const size_t o_epose = carve(4 * (size_t)ne_c), o_ept = carve(4 * (size_t)ne_c), o_euv = carve(8 * (size_t)ne_c), o_pe = carve(4 * (size_t)ne_c);
+    const size_t o_qs = carve(4 * (size_t)(nf + 1)), o_qe = carve(4 * (size_t)ne_c), o_pspt = carve(4 * (size_t)ne_c + 4);
+    const size_t o_poses_n = carve(96 * (size_t)np_c), o_pts_n = carve(24 * (size_t)nx_c), o_act = carve(ne_c), o_flags = carve(ne_c);
+    const int chunks = (ne_c + PS_CHUNK - 1) / PS_CHUNK;
+    const size_t o_eobs = carve(8 * (size_t)ne_c), o_earr = carve(8 * (size_t)ne_c), o_ncull = carve(64), o_cull = carve(8 * (size_t)ne_c);
     const size_t o_hist = carve(4 * (size_t)chunks * nf), o_offs = carve(4 * (size_t)chunks * nf), o_ptot = carve(4 * VO_BA_RESIDENT_MAX_FREE);
     const size_t o_pcnt = carve(4 * (size_t)std::max(nb_all, 1)), o_poff = carve(4 * (size_t)std::max(nb_all, 1)), o_pn = carve(16);
-    const size_t o_Hpp = carve(288 * (size_t)nf), o_bp = carve(8 * (size_t)D), o_Hll = carve(72 * (size_t)nx), o_bl = carve(24 * (size_t)nx), o_scal = carve(64);
-    const size_t o_partU = carve(24 * ((size_t)(nx + 63) / 64 + 1)), o_partC = carve(8 * ((size_t)(ne + 255) / 256 + 1));
-    const size_t o_W = carve(std::max<size_t>(144 * (size_t)ne, 16 * (size_t)ne + 192 * (size_t)nx + 2048)), o_S = carve(std::max<size_t>(8 * (size_t)D * D, 8 * ba_tile_doubles(D)) + 1024), o_bs2 = carve(8 * (size_t)D), o_Hinv = carve(72 * (size_t)nx), o_dl = carve(std::max<size_t>(24 * (size_t)nx, 8 * (size_t)D));
+    const size_t o_Hpp = carve(288 * (size_t)nf), o_bp = carve(8 * (size_t)D), o_Hll = carve(72 * (size_t)nx_c), o_bl = carve(24 * (size_t)nx_c), o_scal = carve(64);
+    const size_t o_partU = carve(24 * ((size_t)(nx_c + 63) / 64 + 1)), o_partC = carve(8 * ((size_t)(ne_c + 255) / 256 + 1));
+    const size_t o_W = carve(std::max<size_t>(144 * (size_t)ne_c, 16 * (size_t)ne_c + 192 * (size_t)nx_c + 2048)), o_S = carve(std::max<size_t>(8 * (size_t)D * D, 8 * ba_tile_doubles(D)) + 1024), o_bs2 = carve(8 * (size_t)D), o_Hinv = carve(72 * (size_t)nx_c), o_dl = carve(std::max<size_t>(24 * (size_t)nx_c, 8 * (size_t)D));
     // pair lists: a point seen by m free poses gives m (m + 1) / 2 <= m (nf + 1) / 2 pairs, so ne (nf + 1) / 2 bounds them before the
     // per-pose lists exist; slices: one per BA_SLICE pairs plus a partial one per block
-    const size_t pairs_ub = (size_t)ne * (size_t)(nf + 1) / 2 + 1, slices_cap = pairs_ub / BA_SLICE + (size_t)nb_all + 1;
+    const size_t pairs_ub = (size_t)ne_c * (size_t)(nf + 1) / 2 + 1, slices_cap = pairs_ub / BA_SLICE + (size_t)nb_all + 1;
     const size_t o_blk = carve(sizeof(BaBlock) * slices_cap), o_pairs = carve(sizeof(int2) * pairs_ub);
-    if ((rc = vo_scratch(c, off))) return rc;               // may reallocate: nothing of this problem lives in the slab yet
+    // (may reallocate: nothing of this problem lives in the slab yet.  The bounds follow the window, which keeps growing for the first ~200 frames of a
+    // stream: a slab that has to grow takes twice what is asked for, or the short runs meet a hipFree + hipMalloc in every other cut)
+    if ((rc = vo_scratch(c, (!sizes_first && off > c->d_ba_bytes) ? 2 * off : off))) return rc;
     uint8_t* base = (uint8_t*)c->d_ba;
     int32_t* e_pose = (int32_t*)(base + o_epose); int32_t* e_pt = (int32_t*)(base + o_ept); float* e_uv = (float*)(base + o_euv);
     long long* e_obs = (long long*)(base + o_eobs);
     long long* e_arr = (long long*)(base + o_earr);
     hipLaunchKernelGGL(k_cut_fill, dim3((int)((std::max<long long>(no - obs_lo, mh) + 255) / 256)), dim3(256), 0, st, T, pt_flag, pidx, pt_start, fill, e_arr, point_slots);
-    hipLaunchKernelGGL(k_cut_emit, dim3((std::max(ne, std::max(np * 12, nx * 3)) + 255) / 256), dim3(256), 0, st, T, np, nx, ne, pidx, pt_start, kf_idx, pose_kf, point_slots,
+    hipLaunchKernelGGL(k_cut_emit, dim3((std::max(ne_c, std::max(np_c * 12, nx_c * 3)) + 255) / 256), dim3(256), 0, st, T, nf, (const int*)tot, pidx, pt_start, kf_idx, pose_kf, point_slots,
                        (const long long*)e_arr, e_obs, e_pose, e_pt, e_uv, (int32_t*)(base + o_pe), base + o_act, base + o_flags, (double*)(base + o_poses),
                        (double*)(base + o_poses_n), (double*)(base + o_pts));
-    hipLaunchKernelGGL(k_ps_hist, dim3(chunks), dim3(PS_CHUNK), 0, st, ne, nf, e_pose, (int*)(base + o_hist));
+    hipLaunchKernelGGL(k_ps_hist, dim3(chunks), dim3(PS_CHUNK), 0, st, (const int*)(tot + 1), nf, e_pose, (int*)(base + o_hist));
     hipLaunchKernelGGL(k_ps_offsets, dim3(nf), dim3(256), 0, st, chunks, nf, (const int*)(base + o_hist), (int*)(base + o_offs), (int*)(base + o_ptot));
-    hipLaunchKernelGGL(k_ps_fill, dim3(chunks), dim3(PS_CHUNK), 0, st, ne, nf, e_pose, e_pt, (const int*)(base + o_offs), (const int*)(base + o_ptot), (int*)(base + o_qs),
+    hipLaunchKernelGGL(k_ps_fill, dim3(chunks), dim3(PS_CHUNK), 0, st, (const int*)(tot + 1), nf, e_pose, e_pt, (const int*)(base + o_offs), (const int*)(base + o_ptot), (int*)(base + o_qs),
                        (int32_t*)(base + o_qe), (int32_t*)(base + o_pspt));
     hipLaunchKernelGGL(k_cut_report, dim3(1), dim3(256), 0, st, (const int*)(base + o_qs), nf + 1, h + 256, h + 133, seq, (int*)(base + o_poff));      // the list lengths; behind it every input of `t` has been gathered
     // the pair plan goes out BEFORE the host looks at the list lengths (with the largest LDS a list may need): the stream works through it
@@ -2771,6 +2790,12 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     if (!R.ev) HIP_TRY(hipEventCreateWithFlags(&R.ev, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(R.ev, st));
     if (!vo_spin_word(h + 133, seq, 2000)) HIP_TRY(hipEventSynchronize(R.ev_arrays));      // from here on `t` may change: every input has been gathered (and the list lengths are in h)
+    if (!sizes_first) {                                     // (k_cut_fixed_scan's words were performed before k_cut_report started)
+        nx = h[128]; ne = h[129]; n_fixed = h[130]; np = nf + n_fixed;
+        if (nx < 0 || ne < 0 || nx > nx_c || ne > ne_c || np > np_c) return VO_E_DEVICE;
+        R.np = np; R.nf = nf; R.nx = nx; R.ne = ne; R.n_fixed = n_fixed;
+        if (nx == 0 || ne == 0 || nf == 0) { R.ready = true; return VO_OK; }         // nothing to optimise (the kernels above found nothing to do)
+    }
     const int* ps_start = h + 256;
     int max_len = 0, npairs = 0, slices_ub = 0;
     for (int j = 0; j < nf; ++j) max_len = std::max(max_len, ps_start[j + 1] - ps_start[j]);
@@ -2810,7 +2835,7 @@ extern "C" int vo_local_ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* fre
     const bool trace = getenv("VO_TRACE") != nullptr;
     const double t0 = trace ? tnow() : 0.0;
     const int rc = ba_resident_cut(c, t, free_kf, n_free, huber_delta, chi2_th);
-    if (trace) { static double a = 0; static int n = 0; a += tnow() - t0; if (++n % 10 == 0) fprintf(stderr, "[vo_trace] resident cut avg ms: %.3f\n", a / n); }
+    if (trace) { static double a = 0; static int n = 0; a += tnow() - t0; if (++n % 10 == 0 && c->resident) fprintf(stderr, "[vo_trace] resident cut avg ms: %.3f (this one: window %lld observations / %d slots -> %d points, %d edges, %d free + %d fixed poses)\n", a / n, c->resident->win_obs, c->resident->win_slots, c->resident->nx, c->resident->ne, c->resident->nf, c->resident->n_fixed); }
     if (rc == VO_OK && c->resident) { if (n_points) *n_points = c->resident->nx; if (n_fixed) *n_fixed = c->resident->n_fixed; if (n_edges) *n_edges = c->resident->ne; }
     return rc;
 }
