@@ -1524,8 +1524,9 @@ __device__ __forceinline__ void ba_cull_edge(const BaDev& B, const double* poses
 __global__ void k_ba_put_desc(BaDev v, BaDev* __restrict__ dst) {
     if (threadIdx.x == 0) *dst = v;
 }
-__global__ __launch_bounds__(256) void k_ba_admit(BaBatch Q) {
-    BA_PROBLEM(Q)
+// (one launch: the descriptor arrives as a kernel argument, thread 0 stores it where the step kernels read it, everybody works from the argument)
+__global__ __launch_bounds__(256) void k_ba_admit(BaDev B, BaDev* __restrict__ dst, BaCtl* ctl_) {
+    if (threadIdx.x == 0) *dst = B;
     if (threadIdx.x == 0) {
         BaCtl c;
         memset(&c, 0, sizeof(c));
@@ -1733,9 +1734,8 @@ static int ba_engine_admit(BaEngine* E) {
         E->h_Bs[s] = j->B;                                  // the slot's mirror is free: its previous problem is gone
         static_assert(sizeof(BaDev) % 4 == 0 && sizeof(BaDev) <= 2048, "BaDev travels as a kernel argument");
         if (rc == VO_OK) {
-            hipLaunchKernelGGL(k_ba_put_desc, dim3(1), dim3(64), 0, st, j->B, E->d_Bs + s);
             const BaBatch Q = ba_batch_of(E, &s, 1);
-            hipLaunchKernelGGL(k_ba_admit, dim3(1, 1, 1), dim3(256), 0, st, Q);
+            hipLaunchKernelGGL(k_ba_admit, dim3(1, 1, 1), dim3(256), 0, st, j->B, E->d_Bs + s, E->d_ctl + s);
             if (j->B.D > BA_FOLD_D) hipLaunchKernelGGL(k_ba_chi, dim3(j->grid_e, 1, 1), dim3(256), 0, st, Q, 0, 0, 0);      // (D <= 192: k_ba_lin2 sums it in passing)
         }
         lk.lock();
