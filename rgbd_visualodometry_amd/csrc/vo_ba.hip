@@ -9,7 +9,7 @@
 //   k_ba_chol16       dense Cholesky + solve of [S b; b^T 0] in one workgroup (packed triangle by LDS-DMA, 16-column DPP panels,
 //                     f64 MFMA trailing update); clears S behind its load
 //   k_ba_upchi2       back-substitution, trial state, robust chi2, LM decision, and the linearisation at the trial state
-//   k_ba_lin2 / k_ba_maxdiag2   first step of a round only
+//   k_ba_lin2                   first step of a round only (linearisation + the largest diagonal entry for lambda_0)
 // Larger systems keep the first-generation step:
 //   k_ba_lin          4 lanes per point: r, J_pose (2x6), J_point (2x3) = J_pose[:,0:3] R, Huber weight, H_ll / b_l / W_e
 //                     (no atomics); 4 workgroups per free pose: H_pp / b_p
@@ -51,6 +51,7 @@ struct BaCtl {
     // the rounds of one local BA (k_ba_admit / k_ba_round): the device moves from the robust round to the plain one and on to "done" by itself
     int stage;                       // 0: robust round, 1: plain round, 2: done (final cull made, BaStat written)
     int max_it_next;                 // iterations of the plain round
+    int lin_ticket;                  // k_ba_lin2: workgroups that have added their sums (the last one takes the largest diagonal entry; back to 0 behind it)
     int iters_total, ticket, gen, chol_seq;      // chol_seq: steps + 1, written by the Cholesky behind its results (k_ba_cholup: the update workgroups of the same launch wait for it)
     double chi0;                     // plain chi2 of the initial state (reporting)
 };
@@ -1804,8 +1805,7 @@ static int ba_engine_enqueue(BaEngine* E) {
             // leave at once for a slot that is not at the start of a round); afterwards the linearisation at the accepted state is a
             // by-product of k_ba_upchi2 and a step is THREE launches
             if (sidx == 0) {
-                { ProfScope ps(prof, "k_ba_lin2", st); hipLaunchKernelGGL(k_ba_lin2, dim3(gA_lin, 1, nA), blk, 0, st, QA); }
-                hipLaunchKernelGGL(k_ba_maxdiag2, dim3(gA_md, 1, nA), blk, 0, st, QA);
+                { ProfScope ps(prof, "k_ba_lin2", st); hipLaunchKernelGGL(k_ba_lin2, dim3(gA_lin, 1, nA), blk, 0, st, QA); }      // (+ the largest diagonal entry: its last workgroup)
                 for (int i = 0; i < na; ++i) {              // a problem's pair plan may still be running on its owner's stream: the linearisation above did not need it
                     BaJob* j = E->slot[act[i]];
                     if (j->wait_pairs) { HIP_TRY(hipStreamWaitEvent(st, j->wait_pairs, 0)); j->wait_pairs = nullptr; }

@@ -117,6 +117,28 @@ __device__ __forceinline__ void p2_lin_poses_body(const BaCam& cam, const BaDev&
     }
 }
 
+// lambda_0 = 1e-5 x the largest diagonal entry of the linearised system (g2o's computeLambdaInit; scal[4]).  The point blocks' entries are at hand in
+// the workgroup that sums them; H_pp's are complete only when every pose workgroup has added its share, so every workgroup of the launch takes a
+// ticket behind its atomics (each wave drains its own first: ADVICE r3) and the last one reads H_pp's diagonal past its caches.  (Round 4 had a
+// launch of its own for this, k_ba_maxdiag2: 6 us + a boundary, twice per BA.)
+__device__ __forceinline__ void p2_lin_finish(const BaDev& B, BaCtl* ctl_, double vmax, int expected) {
+    __shared__ int s_lin_last;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmax(vmax, __shfl_xor(vmax, o, 64));
+    if ((threadIdx.x & 63) == 0 && vmax > 0) atomicMax((unsigned long long*)&B.scal[4], (unsigned long long)__double_as_longlong(vmax));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_lin_last = __hip_atomic_fetch_add(&ctl_->lin_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expected - 1;
+    __syncthreads();
+    if (!s_lin_last) return;
+    double v = 0;
+    for (int i = threadIdx.x; i < B.D; i += 256) v = fmax(v, fabs(pb_ld(&B.Hpp[36 * (size_t)(i / 6) + 7 * (i % 6)])));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    if ((threadIdx.x & 63) == 0 && v > 0) atomicMax((unsigned long long*)&B.scal[4], (unsigned long long)__double_as_longlong(v));
+    if (threadIdx.x == 0) ctl_->lin_ticket = 0;
+}
+
 __global__ __launch_bounds__(256) void k_ba_lin2(BaBatch Q) {
     BA_PROBLEM(Q)
     if (ctl_->finished || B.D > BA_FOLD_D) return;
@@ -125,8 +147,12 @@ __global__ __launch_bounds__(256) void k_ba_lin2(BaBatch Q) {
     BA_STATE(B)
     __shared__ double s_part[4 * 32];
     const int robust = ctl_->robust;
+    const int expected = gp + B.n_free * PSPLIT;           // the workgroups of this problem that do anything (a launch over several problems may be wider)
     if ((int)blockIdx.x >= gp) {
-        if ((int)blockIdx.x - gp < B.n_free * PSPLIT) p2_lin_poses_body(B.cam, B, robust, B.delta, blockIdx.x - gp, poses_c, pts_c, s_part);
+        if ((int)blockIdx.x - gp < B.n_free * PSPLIT) {
+            p2_lin_poses_body(B.cam, B, robust, B.delta, blockIdx.x - gp, poses_c, pts_c, s_part);
+            p2_lin_finish(B, ctl_, 0.0, expected);
+        }
         return;
     }
     double* const rec = p2_rec(B, ctl_->lbuf);
@@ -154,22 +180,12 @@ __global__ __launch_bounds__(256) void k_ba_lin2(BaBatch Q) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) b3[i] = ba_quad_sum(b3[i]);
     if (k < B.n_points && sub == 0) p2_rec_store(rec, k, H, b3, p);
+    const double vdiag = k < B.n_points ? fmax(fabs(H[0]), fmax(fabs(H[3]), fabs(H[5]))) : 0.0;      // the point block's diagonal (what the record holds)
     ba_fold_zero(B, blockIdx.x, gp);
     ba_block_reduce<2>(chi, s_part);
     if (threadIdx.x == 0 && chi[0] != 0.0) atomicAdd(&B.scal[0], chi[0]);
     if (threadIdx.x == 0 && chi[1] != 0.0 && ctl_->stage == 0) atomicAdd(&B.scal[5], chi[1]);      // (the first-generation path has k_ba_chi for this)
-}
-
-__global__ void k_ba_maxdiag2(BaBatch Q) {
-    BA_PROBLEM(Q)
-    if (ctl_->finished || !ctl_->need_lin || !ctl_->first || B.D > BA_FOLD_D) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    double v = 0;
-    if (i < B.D) v = fabs(B.Hpp[36 * (size_t)(i / 6) + 7 * (i % 6)]);
-    else if (i < B.D + B.n_points) { const double* r = p2_rec(B, ctl_->lbuf) + (size_t)PB_REC * (i - B.D); v = fmax(fabs(r[0]), fmax(fabs(r[3]), fabs(r[5]))); }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    if ((threadIdx.x & 63) == 0 && v > 0) atomicMax((unsigned long long*)&B.scal[4], (unsigned long long)__double_as_longlong(v));
+    p2_lin_finish(B, ctl_, vdiag, expected);
 }
 
 // pb_jac in two halves: the camera-frame point (X, Y, 1 / Z), and the pose Jacobian rebuilt from it (the same expressions: the values are pb_jac's)
