@@ -2648,7 +2648,9 @@ int vo_scan_i32(hipStream_t st, const int* in, int n, int* bsum, int* out, int* 
     if (nb > 1024) return VO_E_UNSUPPORTED;
     static const bool two = getenv("VO_SCAN_2") != nullptr;             // A/B: block sums and the scan as two launches
     if (!two && nb <= 512) {
-        hipLaunchKernelGGL(k_scan_one, dim3(std::max(nb, 1)), dim3(1024), 0, st, in, n, (unsigned long long*)bsum, std::max(nb, 1), out, total, ++g_scan_seq);
+        unsigned seq = ++g_scan_seq;
+        if (seq == 0) seq = ++g_scan_seq;                       // (0 is what a fresh buffer holds)
+        hipLaunchKernelGGL(k_scan_one, dim3(std::max(nb, 1)), dim3(1024), 0, st, in, n, (unsigned long long*)bsum, std::max(nb, 1), out, total, seq);
         return VO_OK;
     }
     hipLaunchKernelGGL(k_scan_blocksum, dim3(std::max(nb, 1)), dim3(1024), 0, st, in, n, bsum);
@@ -2663,6 +2665,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     if (!c->resident) c->resident = new BaResident();
     BaResident& R = *c->resident;
     R.ready = false; R.solved = false;
+    if (nf == 0) { R.np = 0; R.nf = 0; R.nx = 0; R.ne = 0; R.n_fixed = 0; R.ready = true; return VO_OK; }      // nothing to optimise (and no launch with an empty grid)
     const int nkf = t->n_kf, D = 6 * nf;
     const long long no = t->n_obs;
     // the window of this cut (see CutTabs): entered behind the oldest point any free keyframe observes

@@ -248,6 +248,25 @@ def test_merge_ledger_follows_the_definition_on_the_restatement():
     _merge_ledger_against_definition(capi.load(ORACLE_LIB))
 
 
+def _empty_cuts(L):
+    """A cut with no free keyframe, and one whose free keyframe observes nothing: VO_OK and three zeros, no launch with an empty grid."""
+    t, c, nX, nK = _ledger_scene(L)
+    nx, nfx, ne = (capi.C.c_int32(-1) for _ in range(3))
+    f = np.zeros(1, dtype=np.int32)
+    L.check(L.lib.vo_local_ba_resident_cut(c.h, t.h, f.ctypes.data, 0, 7.815 ** 0.5, 1.0, capi.C.byref(nx), capi.C.byref(nfx), capi.C.byref(ne)), "cut without free keyframes")
+    assert (nx.value, ne.value) == (0, 0)
+    # a fresh keyframe without observations
+    t.kf_set_pose(np.array([nK]), np.array([I12]))
+    f[0] = nK
+    L.check(L.lib.vo_local_ba_resident_cut(c.h, t.h, f.ctypes.data, 1, 7.815 ** 0.5, 1.0, capi.C.byref(nx), capi.C.byref(nfx), capi.C.byref(ne)), "cut of a keyframe that observes nothing")
+    assert (nx.value, ne.value) == (0, 0)
+    t.close(); c.close()
+
+
+def test_empty_graph_cuts_on_the_restatement():
+    _empty_cuts(capi.load(ORACLE_LIB))
+
+
 # ---- the HIP path ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 def test_keyframe_commit_hip_follows_the_definitions_and_the_restatement(stream):
@@ -334,3 +353,8 @@ def test_device_keyframes_in_a_stream_group(stream):
     for traj, st in out:
         assert st["keyframes"] == ref["stats"]["keyframes"] and st["map_points"] == ref["stats"]["map_points"]
         np.testing.assert_allclose(traj, ref["traj"], atol=1e-6, rtol=0)
+
+
+@pytest.mark.gpu
+def test_empty_graph_cuts_hip():
+    _empty_cuts(capi.load(capi.HIP_LIB))
