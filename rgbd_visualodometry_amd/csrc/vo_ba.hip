@@ -74,6 +74,7 @@ struct BaDev {
     const int32_t* pt_start; const int32_t* pt_edges;       // CSR point -> edges
     const int32_t* ps_start; const int32_t* ps_edges;       // CSR free pose -> edges
     const BaBlock* blocks; const int2* pairs;               // (e1, e2) pairs sharing a point, grouped by (pose(e1) <= pose(e2))
+    const int32_t* pair_pt;                                 // optional: the pairs' points (same positions as `pairs`), so that the Schur slices read the point record one load level earlier; nullptr: e_pt[e1]
     const int* n_slices;                                     // device-built pair lists: number of valid entries of `blocks` (nullptr: n_blocks)
     double* Hpp; double* bp; double* Hll; double* bl; double* W;
     double* S; double* bs; double* Hinv; double* dl;
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_blocks(BaBatch Q) {
 // launches (count, scan + slice table, ordered fill) replace a host enumeration of ~4 pairs per edge and the upload
 // of the lists; the order inside a block (ascending point) is the host builder's, so the sums are the same.
 #define PAIR_LDS_CAP 8192
-struct BaPairPlan { const int32_t* ps_start; const int32_t* ps_edges; const int32_t* ps_pt; int nf; int* cnt; int* off; int* n_slices; int* n_pairs; BaBlock* blocks; int2* pairs; int lds_cap; };      // lds_cap: entries of the launch's dynamic LDS (a longer list is searched in global memory)
+struct BaPairPlan { const int32_t* ps_start; const int32_t* ps_edges; const int32_t* ps_pt; int nf; int* cnt; int* off; int* n_slices; int* n_pairs; BaBlock* blocks; int2* pairs; int32_t* pair_pt; int lds_cap; };      // lds_cap: entries of the launch's dynamic LDS (a longer list is searched in global memory)
 
 __device__ __forceinline__ void ba_block_of(int b, int nf, int& j1, int& j2) {     // b-th (j1 <= j2) pair in row-major order
     j1 = 0;
@@ -524,7 +525,7 @@ __global__ __launch_bounds__(256) void k_ba_pairs_one(BaPairPlan Q, int nb) {
     const int a0 = Q.ps_start[j1], n1 = s_len[j1], b0 = Q.ps_start[j2], n2 = s_len[j2];
     int run = 0;
     if (j1 == j2) {
-        for (int q = threadIdx.x; q < n1; q += 256) { const int e = Q.ps_edges[a0 + q]; Q.pairs[base + q] = make_int2(e, e); }
+        for (int q = threadIdx.x; q < n1; q += 256) { const int e = Q.ps_edges[a0 + q]; Q.pairs[base + q] = make_int2(e, e); Q.pair_pt[base + q] = Q.ps_pt[a0 + q]; }
         run = n1;
     } else {
         // pose j2's sorted point list: in LDS when it fits this launch's allocation, searched in global memory otherwise (config 5: 11 k edges per pose)
@@ -534,14 +535,15 @@ __global__ __launch_bounds__(256) void k_ba_pairs_one(BaPairPlan Q, int nb) {
         __syncthreads();
         for (int c0 = 0; c0 < n1; c0 += 256) {
             const int q = c0 + threadIdx.x;
-            const int hit = q < n1 ? ba_find_sorted(pts, n2, Q.ps_pt[a0 + q]) : -1;
+            const int ptq = q < n1 ? Q.ps_pt[a0 + q] : -1;
+            const int hit = q < n1 ? ba_find_sorted(pts, n2, ptq) : -1;
             const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;      // order-preserving position of the hits inside this chunk of 256
             const unsigned long long m = __ballot(hit >= 0);
             if (lane == 0) s_w[wave] = __popcll(m);
             __syncthreads();
             int before = __popcll(m & ((1ull << lane) - 1ull)), tot = 0;
             for (int w = 0; w < 4; ++w) { if (w < wave) before += s_w[w]; tot += s_w[w]; }
-            if (hit >= 0) Q.pairs[base + run + before] = make_int2(Q.ps_edges[a0 + q], Q.ps_edges[b0 + hit]);
+            if (hit >= 0) { Q.pairs[base + run + before] = make_int2(Q.ps_edges[a0 + q], Q.ps_edges[b0 + hit]); Q.pair_pt[base + run + before] = ptq; }
             run += tot;
             __syncthreads();
         }
@@ -2157,7 +2159,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     BaDev B;
     B.n_poses = np; B.n_free = nf; B.n_points = nx; B.n_edges = ne; B.D = D; B.n_blocks = nblk; B.s_tiles = ba_use_tiles(D);
     B.n_slices = dev_pairs ? (const int*)(base + o_pn) : nullptr;
-    B.ps_start = (const int32_t*)(base + o_qs); B.ps_edges = (const int32_t*)(base + o_qe); B.blocks = (const BaBlock*)(base + o_blk); B.pairs = (const int2*)(base + o_pairs);
+    B.ps_start = (const int32_t*)(base + o_qs); B.ps_edges = (const int32_t*)(base + o_qe); B.blocks = (const BaBlock*)(base + o_blk); B.pairs = (const int2*)(base + o_pairs); B.pair_pt = nullptr;
     B.posesA = (double*)(base + o_poses); B.ptsA = (double*)(base + o_pts); B.posesB = (double*)(base + o_poses_n); B.ptsB = (double*)(base + o_pts_n);
     B.ctl = nullptr;                                        // the engine assigns the control block of the problem's slot
     B.partU = (double*)(base + o_partU); B.partC = (double*)(base + o_partC); B.nU = (nx + 63) / 64;
@@ -2758,7 +2760,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     // pair lists: a point seen by m free poses gives m (m + 1) / 2 <= m (nf + 1) / 2 pairs, so ne (nf + 1) / 2 bounds them before the
     // per-pose lists exist; slices: one per BA_SLICE pairs plus a partial one per block
     const size_t pairs_ub = (size_t)ne_c * (size_t)(nf + 1) / 2 + 1, slices_cap = pairs_ub / BA_SLICE + (size_t)nb_all + 1;
-    const size_t o_blk = carve(sizeof(BaBlock) * slices_cap), o_pairs = carve(sizeof(int2) * pairs_ub);
+    const size_t o_blk = carve(sizeof(BaBlock) * slices_cap), o_pairs = carve(sizeof(int2) * pairs_ub), o_ppt = carve(sizeof(int32_t) * pairs_ub);
     // (may reallocate: nothing of this problem lives in the slab yet.  The bounds follow the window, which keeps growing for the first ~200 frames of a
     // stream: a slab that has to grow takes twice what is asked for, or the short runs meet a hipFree + hipMalloc in every other cut)
     if ((rc = vo_scratch(c, (!sizes_first && off > c->d_ba_bytes) ? 2 * off : off))) return rc;
@@ -2780,7 +2782,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     BaPairPlan Q;
     Q.ps_start = (const int32_t*)(base + o_qs); Q.ps_edges = (const int32_t*)(base + o_qe); Q.ps_pt = (const int32_t*)(base + o_pspt); Q.nf = nf;
     Q.cnt = (int*)(base + o_pcnt); Q.off = (int*)(base + o_poff); Q.n_slices = (int*)(base + o_pn); Q.n_pairs = (int*)(base + o_pn) + 1;
-    Q.blocks = (BaBlock*)(base + o_blk); Q.pairs = (int2*)(base + o_pairs);
+    Q.blocks = (BaBlock*)(base + o_blk); Q.pairs = (int2*)(base + o_pairs); Q.pair_pt = (int32_t*)(base + o_ppt);
     if (!R.ev_arrays) HIP_TRY(hipEventCreateWithFlags(&R.ev_arrays, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(R.ev_arrays, st));               // (the first linearisation needs no pairs: it may start here)
     Q.lds_cap = PAIR_LDS_CAP;
@@ -2812,7 +2814,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     B.n_poses = np; B.n_free = nf; B.n_points = nx; B.n_edges = ne; B.D = D; B.s_tiles = ba_use_tiles(D);
     B.n_blocks = slices_ub;                                 // launch bound; the Schur kernel stops at *n_slices, which the plan kernels below write
     B.n_slices = (const int*)(base + o_pn);
-    B.ps_start = (const int32_t*)(base + o_qs); B.ps_edges = (const int32_t*)(base + o_qe); B.blocks = (const BaBlock*)(base + o_blk); B.pairs = (const int2*)(base + o_pairs);
+    B.ps_start = (const int32_t*)(base + o_qs); B.ps_edges = (const int32_t*)(base + o_qe); B.blocks = (const BaBlock*)(base + o_blk); B.pairs = (const int2*)(base + o_pairs); B.pair_pt = getenv("VO_PAIRS_3") ? nullptr : (const int32_t*)(base + o_ppt);      // (the three-launch plan does not write it)
     B.posesA = (double*)(base + o_poses); B.ptsA = (double*)(base + o_pts); B.posesB = (double*)(base + o_poses_n); B.ptsB = (double*)(base + o_pts_n);
     B.ctl = nullptr;
     B.partU = (double*)(base + o_partU); B.partC = (double*)(base + o_partC); B.nU = (nx + 63) / 64;

@@ -225,11 +225,12 @@ __device__ __forceinline__ void p2_schur_slice(const BaDev& B, const BaBlock blk
     for (int base = 0; base < blk.count; base += 256) {                   // workgroup-uniform trip count: every lane takes part in the reductions
         bool on = base + (int)threadIdx.x < blk.count;
         int2 pr = make_int2(0, 0);
-        if (on) { pr = B.pairs[blk.start + base + threadIdx.x]; on = B.active[pr.x] && (DIAG || B.active[pr.y]); }
+        int pt_l = 0;
+        if (on) { pr = B.pairs[blk.start + base + threadIdx.x]; if (B.pair_pt) pt_l = B.pair_pt[blk.start + base + threadIdx.x]; on = B.active[pr.x] && (DIAG || B.active[pr.y]); }
         double X1 = 0, Y1 = 0, Zi1 = 0, X2 = 0, Y2 = 0, Zi2 = 0, M[2][2] = {{0, 0}, {0, 0}}, g[2] = {0, 0};      // an idle lane: M = g = 0, every product is 0
         if (on) {
             double Hh[6], bl[3], p[3], h[9];
-            p2_rec_load(rec, B.e_pt[pr.x], Hh, bl, p);
+            p2_rec_load(rec, B.pair_pt ? pt_l : B.e_pt[pr.x], Hh, bl, p);      // (the pair's point arrives with the pair where the plan wrote it: one load level less)
             const double w2 = Wt[pr.y], w1 = DIAG ? w2 : Wt[pr.x];
             const double Hs[9] = {Hh[0], Hh[1], Hh[2], Hh[1], Hh[3], Hh[4], Hh[2], Hh[4], Hh[5]};
             ba_inv3_damped(Hs, lambda, h);
