@@ -1625,12 +1625,24 @@ __global__ __launch_bounds__(CH2_T) void k_ba_cholup(BaBatch Q, int n, int gpmax
     }
 }
 
+// the same for a lone problem, its descriptor in the kernel's arguments (see k_ba_schur2_one)
+__global__ __launch_bounds__(CH2_T) void k_ba_cholup_one(BaDev B, BaCtl* ctl_, int gpmax, int rep) {
+    if (ctl_->finished) return;
+    if (blockIdx.x == 0) {
+        extern __shared__ double s_mem[];
+        ba_chol16v2_body<true>(B, ctl_, s_mem, B.dl, true);
+    } else {
+        ba_upchi2_body<true>(B, ctl_, rep, ((int)blockIdx.x - 1) % gpmax, 0);
+    }
+}
+
 // per-device function attributes (vo_ctx_create calls this with the context's device current)
 int vo_ba_set_attrs() {
     HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol16, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol16g, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIP_TRY(hipFuncSetAttribute((const void*)k_ba_chol16v2, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIP_TRY(hipFuncSetAttribute((const void*)k_ba_cholup, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_ba_cholup_one, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     HIP_TRY(hipFuncSetAttribute((const void*)k_ba_upchi2, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     return VO_OK;
 }
@@ -1813,13 +1825,17 @@ static int ba_engine_enqueue(BaEngine* E) {
                     if (j->wait_pairs) { HIP_TRY(hipStreamWaitEvent(st, j->wait_pairs, 0)); j->wait_pairs = nullptr; }
                 }
             }
-            { ProfScope ps(prof, "k_ba_schur2", st); hipLaunchKernelGGL(k_ba_schur2, dim3(gA_blk + gA_pose, 1, nA), blk, 0, st, QA); }
+            static const bool direct_ok = getenv("VO_BA_DESC_TABLE") == nullptr;      // (A/B: always through the descriptor table)
+            const bool direct = direct_ok && nA == 1;                  // a lone problem: descriptor by value
+            if (direct) { ProfScope ps(prof, "k_ba_schur2", st); hipLaunchKernelGGL(k_ba_schur2_one, dim3(gA_blk + gA_pose), blk, 0, st, E->h_Bs[sA[0]], E->d_ctl + sA[0]); }
+            else { ProfScope ps(prof, "k_ba_schur2", st); hipLaunchKernelGGL(k_ba_schur2, dim3(gA_blk + gA_pose, 1, nA), blk, 0, st, QA); }
             // both generations in one step: every problem leaves the kernel that is not its own at once (s_tiles says which one is)
             // tile-major problems only: solvers and updates in one launch (vo_ba_phase2.h, FUSED)
             if (fuse_up) {
                 ProfScope ps(prof, "k_ba_cholup", st);
                 const int gpmax = (gA_up + up_rep * (UPC_T / 4) - 1) / (up_rep * (UPC_T / 4));
-                hipLaunchKernelGGL(k_ba_cholup, dim3(nA * (1 + gpmax)), dim3(CH2_T), std::max(ldsA, ldsA_up), st, QA, nA, gpmax, up_rep);
+                if (direct) hipLaunchKernelGGL(k_ba_cholup_one, dim3(1 + gpmax), dim3(CH2_T), std::max(ldsA, ldsA_up), st, E->h_Bs[sA[0]], E->d_ctl + sA[0], gpmax, up_rep);
+                else hipLaunchKernelGGL(k_ba_cholup, dim3(nA * (1 + gpmax)), dim3(CH2_T), std::max(ldsA, ldsA_up), st, QA, nA, gpmax, up_rep);
             } else {
             if (nA_tiles) { ProfScope ps(prof, "k_ba_chol16v2", st); hipLaunchKernelGGL(k_ba_chol16v2, dim3(1, 1, nA), dim3(CH2_T), ldsA, st, QA); }
             if (nA_tiles < nA) { ProfScope ps(prof, "k_ba_chol16", st); hipLaunchKernelGGL(k_ba_chol16, dim3(1, 1, nA), dim3(CH_THREADS), ldsA, st, QA, 0, 1); }
