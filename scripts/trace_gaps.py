@@ -7,7 +7,7 @@ rows = []
 for f in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True):
     with open(f, newline="") as fh:
         for r in csv.DictReader(fh):
-            rows.append((r.get("Queue_Id", "0"), int(r["Start_Timestamp"]), int(r["End_Timestamp"]), re.sub(r"\(.*$", "", r["Kernel_Name"]).replace("void ", "").strip()))
+            rows.append((r.get("Queue_Id", "0"), int(r["Start_Timestamp"]), int(r["End_Timestamp"]), re.sub(r"_one$", "", re.sub(r"\(.*$", "", r["Kernel_Name"]).replace("void ", "").strip())))
 byq = defaultdict(list)
 for q, s, e, n in rows:
     byq[q].append((s, e, n))
