@@ -75,6 +75,32 @@ def test_orb_bit_exact(frames, libs, nfeat):
         np.testing.assert_allclose(kh["response"], ko["response"], rtol=1e-5)
 
 
+@pytest.mark.parametrize("w,h,nfeat", [(517, 391, 600), (322, 250, 300), (639, 477, 1500)])
+def test_orb_bit_exact_at_odd_sizes(frames, libs, w, h, nfeat):
+    """Image sizes that are multiples of nothing: partial tiles of every ORB kernel (FAST 64 x 32, blur 128 x 16, the pyramid's 5 x 8 split or its
+    level-by-level fallback), level widths that end inside a dword, keypoints next to the 31-pixel border."""
+    bgr, depth, _, _ = frames
+    H, O = libs
+    kw = dict(width=w, height=h, n_features=nfeat, max_frames=2, cx=w / 2.0, cy=h / 2.0)
+    ch, _ = make_ctx(H, **kw)
+    co, _ = make_ctx(O, **kw)
+    for s, f in enumerate((1, 7)):
+        oy, ox = (bgr[f].shape[0] - h) // 2, (bgr[f].shape[1] - w) // 2
+        b = np.ascontiguousarray(bgr[f][oy:oy + h, ox:ox + w]); d = np.ascontiguousarray(depth[f][oy:oy + h, ox:ox + w])
+        ch.upload(s, b, d); co.upload(s, b, d)
+    ch.orb(0, 2); co.orb(0, 2)
+    for s in range(2):
+        for l in range(8):
+            assert np.array_equal(ch.fetch_level(s, l), co.fetch_level(s, l)), "pyramid level %d of slot %d differs" % (l, s)
+            assert np.array_equal(ch.fetch_blur_level(s, l), co.fetch_blur_level(s, l)), "blurred level %d of slot %d differs" % (l, s)
+        kh, dh = ch.orb_fetch(s)
+        ko, do = co.orb_fetch(s)
+        assert len(kh) == len(ko) and len(kh) > nfeat // 2
+        for field in ("x", "y", "size", "octave", "class_id", "depth_raw"):
+            assert np.array_equal(kh[field], ko[field]), "keypoint field %s differs (slot %d)" % (field, s)
+        assert np.array_equal(dh, do), "descriptors differ (slot %d): %d rows" % (s, int((dh != do).any(axis=1).sum()))
+
+
 def test_orb_batch_with_frame_to_xcd_affinity_is_bit_exact(frames, libs):
     """Batches of >= 8 frame slots send every frame's workgroups to one XCD (vo_orb.hip header); same bits as frame-by-frame."""
     bgr, depth, _, _ = frames
