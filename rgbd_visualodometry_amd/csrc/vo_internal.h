@@ -194,7 +194,7 @@ int vo_track_lm_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* d_lanes, in
 void vo_lane_fill(vo_ctx* c, int lane, int slot, uint64_t seed, TrackDev* d_tr, LaneDesc* out);   // descriptor of lane `lane` of context c
 int vo_corr_from_host(vo_ctx* c, const float* xyz, const float* uv, int n);
 int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out);                       // vo_ba.hip
-int vo_scan_i32(hipStream_t st, const int* in, int n, int* bsum /* >= 1024 ints */, int* out, int* total);      // vo_ba.hip: exclusive scan, n <= 16 Mi
+int vo_scan_i32(hipStream_t st, const int* in, int n, int* bsum /* >= 1024 ints, 256-byte aligned, zeroed once when allocated (k_scan_one's published totals) */, int* out, int* total);      // vo_ba.hip: exclusive scan, n <= 16 Mi; *total = -1 if a tile of the one-launch form never showed up
 // vo_kf.hip
 int vo_obs_tables_ensure(vo_ctx* c);
 void vo_kf_free(vo_ctx* c);
