@@ -54,7 +54,7 @@ int myslam_default_options(myslam_options* o) {
     o->width = 640; o->height = 480; o->fx = 517.3f; o->fy = 516.5f; o->cx = 318.6f; o->cy = 255.3f; o->depth_scale = 5000.f;
     o->number_of_features = 500; o->scale_factor = 1.2f; o->level_pyramid = 8; o->match_ratio = 2.0f; o->max_num_lost = 10;
     o->min_inliers = 10; o->keyframe_rotation = 0.05; o->keyframe_translation = 0.05; o->enable_local_optimization = 1; o->chi2_th = 1.f;
-    o->ransac_iterations = 100; o->backend_lag_frames = 0; o->max_frames_in_flight = 1; o->track_batch = 1; o->map_capacity = 1 << 20; o->device = 0; o->verbose = 0;
+    o->ransac_iterations = 100; o->backend_lag_frames = 0; o->max_frames_in_flight = 1; o->track_batch = 1; o->map_capacity = 1 << 22; o->device = 0; o->verbose = 0;
     return 0;
 }
 
