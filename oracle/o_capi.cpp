@@ -573,7 +573,13 @@ int vo_keyframe_commit(vo_ctx* c, int lane, int frame_slot, int32_t kf, const do
     for (int i = 0; i < nkp; ++i) {
         if (matched[i] || s.kps[i].depth_raw == 0) continue;
         const int32_t sl = first_new_slot + out->n_new;
-        if (sl >= c->p.map_capacity) return VO_E_OVERFLOW;
+        if (sl >= c->p.map_capacity) {                      // the map grows (as the product's vo_map_grow: doubling; the reference's container has no size)
+            long long cap = c->p.map_capacity;
+            while (cap <= sl) cap *= 2;
+            if (cap > (1ll << 28)) return VO_E_OVERFLOW;
+            c->map.pos.resize((size_t)3 * cap, 0.0); c->map.nrm.resize((size_t)3 * cap, 0.0); c->map.desc.resize((size_t)32 * cap, 0); c->map.flags.resize((size_t)cap, 0);
+            c->p.map_capacity = (int32_t)cap;
+        }
         const double depth = double(s.kps[i].depth_raw) / c->p.depth_scale;
         const double pc[3] = {((double)s.kps[i].x - cx) * depth / fx, ((double)s.kps[i].y - cy) * depth / fy, depth};
         KV3 pw;

@@ -152,6 +152,34 @@ static int kf_state(vo_ctx* c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     return VO_OK;
 }
+// the map's arrays have grown (vo_map_grow): chain heads keep their contents and get empty tails, the leader keys restart (epochs), the candidate buffers are scratch
+int vo_kf_map_grown(vo_ctx* c, size_t m_old, size_t m_new) {
+    hipStream_t st = c->stream;
+    if (c->d_pt_last) {
+        int32_t* a = nullptr; int32_t* b = nullptr;
+        if (hipMalloc((void**)&a, 4 * m_new) != hipSuccess || hipMalloc((void**)&b, 4 * m_new) != hipSuccess) { if (a) (void)hipFree(a); (void)hipGetLastError(); return VO_E_NOMEM; }
+        HIP_TRY(hipMemcpyAsync(a, c->d_pt_last, 4 * m_old, hipMemcpyDeviceToDevice, st)); HIP_TRY(hipMemcpyAsync(b, c->d_pt_first, 4 * m_old, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemsetAsync(a + m_old, 0xFF, 4 * (m_new - m_old), st)); HIP_TRY(hipMemsetAsync(b + m_old, 0xFF, 4 * (m_new - m_old), st));
+        HIP_TRY(hipStreamSynchronize(st));
+        (void)hipFree(c->d_pt_last); (void)hipFree(c->d_pt_first);
+        c->d_pt_last = a; c->d_pt_first = b;
+    }
+    if (c->kf) {
+        KfState& K = *c->kf;
+        const int cand_new = (int)std::min<size_t>(c->lane_stride, m_new);
+        unsigned long long* key = nullptr; int* cand = nullptr; uint8_t* tok = nullptr; double* txyz = nullptr; int* cnt = nullptr;
+        const bool ok = hipMalloc((void**)&key, 8 * m_new) == hipSuccess && hipMalloc((void**)&cand, 4 * (size_t)cand_new) == hipSuccess && hipMalloc((void**)&tok, (size_t)cand_new) == hipSuccess &&
+                        hipMalloc((void**)&txyz, 24 * (size_t)cand_new) == hipSuccess && hipMalloc((void**)&cnt, 8 * ((size_t)cand_new / 256 + 2)) == hipSuccess;
+        if (!ok) { void* q[] = {key, cand, tok, txyz, cnt}; for (void* x : q) if (x) (void)hipFree(x); (void)hipGetLastError(); return VO_E_NOMEM; }
+        HIP_TRY(hipMemcpyAsync(key, K.d_key, 8 * m_old, hipMemcpyDeviceToDevice, st));      // (leader keys carry their epoch: old entries stay comparable, new ones start at 0)
+        HIP_TRY(hipMemsetAsync(key + m_old, 0, 8 * (m_new - m_old), st));
+        HIP_TRY(hipStreamSynchronize(st));
+        void* old[] = {K.d_key, K.d_cand, K.d_tri_ok, K.d_tri_xyz, K.d_cnt};
+        for (void* x : old) if (x) (void)hipFree(x);
+        K.d_key = key; K.d_cand = (decltype(K.d_cand))cand; K.d_tri_ok = (decltype(K.d_tri_ok))tok; K.d_tri_xyz = (decltype(K.d_tri_xyz))txyz; K.d_cnt = (decltype(K.d_cnt))cnt; K.cand_cap = cand_new;
+    }
+    return VO_OK;
+}
 static void note_kf_first(vo_ctx* c, int kf, long long at) {
     if (c->kf_first_obs.size() <= (size_t)kf) c->kf_first_obs.resize((size_t)kf + 1, -1);
     if (c->kf_first_obs[kf] < 0) c->kf_first_obs[kf] = at;
@@ -511,7 +539,10 @@ extern "C" int vo_keyframe_commit(vo_ctx* c, int lane, int frame_slot, int32_t k
     if (kf < 0 || kf >= c->kf_cap) return VO_E_INVALID;
     const int n_match = lane >= 0 ? std::min(c->h_track[lane].n_match, (int)c->lane_stride) : 0;
     const int nfeat = c->p.n_features;
-    if ((long long)first_new_slot + nfeat > c->p.map_capacity) return VO_E_OVERFLOW;      // every keypoint may become a map point
+    if ((long long)first_new_slot + nfeat > c->p.map_capacity) {      // every keypoint may become a map point: the map grows (vo_map_grow; VO_E_OVERFLOW beyond its ceiling)
+        const int grc = vo_map_grow(c, (long long)first_new_slot + nfeat);
+        if (grc) return grc;
+    }
     if (n_match > c->kf->cand_cap) return VO_E_OVERFLOW;
     if ((rc = obs_room(c, (long long)n_match + nfeat))) return rc;
     if (c->n_obs + n_match + nfeat >= INT_MAX) return VO_E_OVERFLOW;

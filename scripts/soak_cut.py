@@ -9,6 +9,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=6000)
     ap.add_argument("--every", type=int, default=1000)
+    ap.add_argument("--map-capacity", type=int, default=1 << 22, help="initial device map slots (the map doubles when a keyframe may not fit)")
     args = ap.parse_args()
     import torch
     from rgbd_visualodometry_amd import capi, system
@@ -17,7 +18,7 @@ def main():
     chunk = 1000                                            # rendered and uploaded in pieces: 1.5 MB per frame
     sp = syn.params(seed=0, speed=3.0)
     s = system.VoSystem(system.HOST_LIB, width=W, height=H, number_of_features=2000, max_frames_in_flight=32, enable_local_optimization=1, backend_lag_frames=8,
-                        track_batch=8, map_capacity=1 << 22, ransac_iterations=100, ba_device_graph=1, map_descriptors_on_device=1, device_keyframes=0 if os.environ.get("VO_SOAK_HOST_KEYFRAMES") else 1)
+                        track_batch=8, map_capacity=args.map_capacity, ransac_iterations=100, ba_device_graph=1, map_descriptors_on_device=1, device_keyframes=0 if os.environ.get("VO_SOAK_HOST_KEYFRAMES") else 1)
     fb, fd = W * H * 3, W * H * 2
     done, t_last, n_last = 0, time.perf_counter(), 0
     while done < args.frames:
