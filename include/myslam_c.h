@@ -29,7 +29,7 @@ typedef struct myslam_options {
                                                merged deterministically L frames later (or at the next keyframe) */
     int32_t max_frames_in_flight;           /* look-ahead ORB batch (1 = none) */
     int32_t track_batch;                    /* frames tracked speculatively in one launch chain (1 = none, <= 16) */
-    int32_t map_capacity;                   /* device map slots, allocated once (4 Mi; the map arrays do not grow: AddFrame fails with a message naming this field when they are full) */
+    int32_t map_capacity;                   /* device map slots to start with (4 Mi); with device_keyframes the map doubles when a keyframe's points may not fit */
     int32_t device;
     int32_t verbose;
     int32_t triangulate_all;                /* 0: the reference's loop (stops after the first success, frontend.cpp:501); 1: every eligible point, batched */

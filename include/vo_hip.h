@@ -358,7 +358,10 @@ int vo_ba_resident_window(vo_ctx* ctx, int64_t* observations_visited, int64_t* m
  * covis_kf / covis_weight receive the keyframes (ascending number) that share >= 1 live observation's point with the new one and the
  * counts: allCovisibleKeyframeIdToWeight_ of the new keyframe (include/myslam/frame.h:94); the caller keeps the ledger.  More than
  * cap_covis partners: VO_E_OVERFLOW (nothing is lost on the device; the weights can be read again with vo_kf_covisibility).
- * The map flags carry Mappoint::triangulated_ / optimized_ beside outlier_ (VO_MAP_FLAG_*). */
+ * The map flags carry Mappoint::triangulated_ / optimized_ beside outlier_ (VO_MAP_FLAG_*).
+ * The map has no fixed size on this path (the reference's is a host container): when first_new_slot + n_features exceeds the context's map capacity the map
+ * arrays and the tracking chain's per-lane buffers are reallocated at twice the size, contents kept, before anything is written (no tracking chain of this
+ * context may be in flight, which holds at this point of AddFrame anyway; VO_E_NOMEM / VO_E_OVERFLOW if that fails or passes 2^28 points). */
 #define VO_MAP_FLAG_TRIANGULATED 2   /* Mappoint::triangulated_ (src/frontend.cpp:498) */
 #define VO_MAP_FLAG_OPTIMIZED    4   /* Mappoint::optimized_    (src/backend.cpp:190)  */
 typedef struct vo_kf_commit_result {

@@ -51,7 +51,7 @@ void FrontEnd::Init(int device, int width, int height, int max_frames) {
     if (const char* e = std::getenv("VO_DEVICE_KEYFRAMES")) deviceKeyframes_ = std::atoi(e) != 0;      // experiments / A-B runs
     params_.max_frames = lookahead_ + (reobserveNew_ ? 1 : 0);
     scratchSlot_ = reobserveNew_ ? lookahead_ : -1;
-    params_.map_capacity = cfg_or<int>("map_capacity", 1 << 22);      // 4 Mi map points (~100 bytes each + 49 per tracking lane): ~15 k frames of the bench workload; the arrays do not grow
+    params_.map_capacity = cfg_or<int>("map_capacity", 1 << 22);      // 4 Mi map points to start with (~100 bytes each + 49 per tracking lane); vo_keyframe_commit doubles the arrays when a keyframe may not fit
     trackBatch_ = std::max(1, std::min(16, cfg_or<int>("track_batch", 1)));
     trackAhead_ = cfg_or<int>("track_ahead", 1) != 0;
     if (const char* e = std::getenv("VO_TRACK_AHEAD")) trackAhead_ = std::atoi(e) != 0;      // experiments
