@@ -157,28 +157,37 @@ __global__ __launch_bounds__(256) void k_pyramid(DevPlan P, uint8_t* __restrict_
         const int ox0 = tx * P.lw[l] / gx, ox1 = (tx + 1) * P.lw[l] / gx, oy0 = ty * P.lh[l] / gy, oy1 = (ty + 1) * P.lh[l] / gy;
         uint8_t* dst = base + P.loff[l];
         const int pitch = P.pitch[l];
-        for (int i = tid; i < wq * h; i += 256) {
-            const int j = i / wq, q = i - j * wq;
-            const int2 ty2 = s_ty[j];
-            const uint8_t* S0 = prev + (ty2.x & 0xFFFF) * pp;
-            const uint8_t* S1 = prev + ((unsigned)ty2.x >> 16) * pp;
-            const int b0 = (short)(ty2.y & 0xFFFF), b1 = ty2.y >> 16;
-            uint32_t o = 0;
+        // a lane keeps ONE dword column (four pixels) of the tile and walks down its rows: the four x-table entries are read and unpacked once per level
+        // instead of once per pixel (half of the kernel's vector instructions were that)
+        const int rpp = max(1, 256 / wq), q = tid % wq, rg = tid / wq;      // rows per pass; this lane's column group and first row
+        if (rg < rpp) {
+            int lx[4], lx1[4], a0[4], a1[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int x = 4 * q + k;
-                if (x < w) {
-                    const int2 tx2 = s_tx[k * 64 + q];
-                    const int lx = tx2.x & 0xFFFF, lx1 = (unsigned)tx2.x >> 16, a0 = (short)(tx2.y & 0xFFFF), a1 = tx2.y >> 16;
-                    const int h0 = S0[lx] * a0 + S0[lx1] * a1;
-                    const int h1 = S1[lx] * a0 + S1[lx1] * a1;
-                    const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-                    o |= (uint32_t)min(255, max(0, v)) << (8 * k);
-                }
+                const int2 tx2 = s_tx[k * 64 + q];
+                lx[k] = x < w ? (tx2.x & 0xFFFF) : 0; lx1[k] = x < w ? (int)((unsigned)tx2.x >> 16) : 0;
+                a0[k] = x < w ? (int)(short)(tx2.y & 0xFFFF) : 0; a1[k] = x < w ? (tx2.y >> 16) : 0;      // (columns past the level: weight 0 -> pixel 0, as before)
             }
-            reinterpret_cast<uint32_t*>(cur)[i] = o;
-            const int gy_ = r.y0 + j, gx_ = r.x0 + 4 * q;
-            if (gy_ >= oy0 && gy_ < oy1 && gx_ < ox1 && gx_ + 4 > ox0) *reinterpret_cast<uint32_t*>(dst + (size_t)gy_ * pitch + gx_) = o;
+            const int gx_ = r.x0 + 4 * q;
+            const bool colmine = gx_ < ox1 && gx_ + 4 > ox0;
+            for (int j = rg; j < h; j += rpp) {
+                const int2 ty2 = s_ty[j];
+                const uint8_t* S0 = prev + (ty2.x & 0xFFFF) * pp;
+                const uint8_t* S1 = prev + ((unsigned)ty2.x >> 16) * pp;
+                const int b0 = (short)(ty2.y & 0xFFFF), b1 = ty2.y >> 16;
+                uint32_t o = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int h0 = S0[lx[k]] * a0[k] + S0[lx1[k]] * a1[k];
+                    const int h1 = S1[lx[k]] * a0[k] + S1[lx1[k]] * a1[k];
+                    const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                    o |= (4 * q + k < w ? (uint32_t)min(255, max(0, v)) : 0u) << (8 * k);
+                }
+                reinterpret_cast<uint32_t*>(cur)[j * wq + q] = o;
+                const int gy_ = r.y0 + j;
+                if (colmine && gy_ >= oy0 && gy_ < oy1) *reinterpret_cast<uint32_t*>(dst + (size_t)gy_ * pitch + gx_) = o;
+            }
         }
         __syncthreads();                                     // this level is complete before its tables are overwritten
     }
