@@ -477,13 +477,32 @@ __global__ __launch_bounds__(1024) void k_select(DevPlan P, const uint8_t* __res
     __syncthreads();
     for (int i = tid; i < n; i += 1024) atomicAdd(&s_hist[cl[i] >> 24], 1);
     __syncthreads();
+    // the cut: the largest score s whose suffix sum hist[s] + .. + hist[255] reaches 2 x quota.  Four wavefronts scan the 256 bins (one lane walking them
+    // was 256 dependent LDS reads: 7 us of the level-0 workgroup's 43, and that workgroup is the launch's duration)
+    int* const s_scr = s_misc + 8;                              // (the two 4096-bin passes below clear what they use of this area)
+    const int lane_c = tid & 63, wave_c = tid >> 6;
+    int suf = 0;
+    if (tid < 256) {
+        suf = s_hist[tid];                                      // inclusive suffix sum inside the wavefront
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_down(suf, o, 64); if (lane_c + o < 64) suf += t; }
+        if (lane_c == 0) s_scr[wave_c] = suf;
+    }
+    __syncthreads();
+    if (tid < 256) {
+        for (int w = wave_c + 1; w < 4; ++w) suf += s_scr[w];
+        const bool reach = n > 2 * quota && suf >= 2 * quota;   // true for every bin up to the cut (suffix sums do not grow with s)
+        const unsigned long long m = __ballot(reach);
+        if (lane_c == 0) s_scr[4 + wave_c] = __popcll(m);
+        s_scr[16 + tid] = suf;
+    }
+    __syncthreads();
     if (tid == 0) {
         int thr = 0, need = -1;
         if (n > 2 * quota) {
-            int acc = 0, s = 255;
-            for (; s >= 0; --s) { acc += s_hist[s]; if (acc >= 2 * quota) break; }
-            thr = s;
-            if (acc > 4 * quota) need = 2 * quota - (acc - s_hist[s]);      // the ties at the cut do not fit: only `need` of them stay
+            thr = s_scr[4] + s_scr[5] + s_scr[6] + s_scr[7] - 1;
+            const int acc = s_scr[16 + thr];
+            if (acc > 4 * quota) need = 2 * quota - (acc - s_hist[thr]);      // the ties at the cut do not fit: only `need` of them stay
         }
         s_misc[1] = thr; s_misc[2] = need;
     }
@@ -515,20 +534,24 @@ __global__ __launch_bounds__(1024) void k_select(DevPlan P, const uint8_t* __res
         }
         ycut = s_misc[3]; xcut = s_misc[5];
     }
-    for (int i = tid; i < n; i += 1024) {
-        const uint32_t c = cl[i];
+    // two steps: first the survivors of the cut are gathered (one LDS atomic per wavefront), then every lane takes ONE of them to its Harris key.  (Computed
+    // inside the gathering loop, the ~600-instruction key ran in each of its trips with the quarter of the lanes that had a survivor there.)
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + tid;
+        const uint32_t c = i < n ? cl[i] : 0u;
         const int sc = (int)(c >> 24), cx = c & 0xFFF, cy = (c >> 12) & 0xFFF;
-        if (sc > thr || (sc == thr && (need < 0 || cy < ycut || (cy == ycut && cx <= xcut)))) {
-            const int pos = atomicAdd(&s_misc[0], 1);      // at most 4 x quota <= sel_cap entries pass the cut (see above): the order of arrival only
-            if (pos < P.sel_cap) {                         // permutes the list that the sort below orders by (Harris key, pixel index)
-                const int x = c & 0xFFF, y = (c >> 12) & 0xFFF;
-                s_key[pos] = harris_key_dev(img, pitch, x, y);
-                s_idx[pos] = c & 0xFFFFFF;
-            }
-        }
+        const bool pass = i < n && (sc > thr || (sc == thr && (need < 0 || cy < ycut || (cy == ycut && cx <= xcut))));
+        const unsigned long long m = __ballot(pass);
+        int wbase = 0;
+        if (lane_c == 0 && m) wbase = atomicAdd(&s_misc[0], __popcll(m));      // at most 4 x quota <= sel_cap entries pass the cut (see above): the order of arrival only
+        wbase = __shfl(wbase, 0, 64);                                         // permutes the list that the sort below orders by (Harris key, pixel index)
+        const int pos = wbase + __popcll(m & ((1ull << lane_c) - 1ull));
+        if (pass && pos < P.sel_cap) s_idx[pos] = c & 0xFFFFFF;
     }
     __syncthreads();
     const int kept = min(s_misc[0], P.sel_cap);
+    for (int p = tid; p < kept; p += 1024) { const uint32_t c = s_idx[p]; s_key[p] = harris_key_dev(img, pitch, c & 0xFFF, (c >> 12) & 0xFFF); }
+    __syncthreads();
     int m = 64;
     while (m < kept) m <<= 1;
     for (int i = kept + tid; i < m; i += 1024) { s_key[i] = LLONG_MIN; s_idx[i] = 0xFFFFFFFFu; }
