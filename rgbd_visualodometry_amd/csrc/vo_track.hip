@@ -237,10 +237,15 @@ __global__ __launch_bounds__(256) void k_match_mfma(const LaneDesc* __restrict__
             }
         }
         uint32_t best_k[MMF_NA][4];
+        int32_t out_q[MMF_NA][4];                          // where the sixteen results of lane (g, 0) go: requested now, used behind the tiles (the load used to sit between the minimum and its atomic: clock stamps, 6 of a workgroup's 14 us)
 #pragma unroll
         for (int a = 0; a < MMF_NA; ++a)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) best_k[a][q] = MATCH_NONE;
+            for (int q = 0; q < 4; ++q) {
+                best_k[a][q] = MATCH_NONE;
+                const int ci = c0 + 16 * MMF_NA * wave + 16 * a + 4 * g + q;
+                out_q[a][q] = (r16 == 0 && ci < ncand) ? cand[ci] : -1;
+            }
         // the descriptor words of a tile are requested one tile ahead: the trip to L2 (~1.5 us, eight tiles per workgroup at the bench workload) runs
         // behind the previous tile's MFMAs instead of between two barriers
         const int kp_l = threadIdx.x & 63, qtr_l = threadIdx.x >> 6;
@@ -308,8 +313,7 @@ __global__ __launch_bounds__(256) void k_match_mfma(const LaneDesc* __restrict__
             for (int a = 0; a < MMF_NA; ++a)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int ci = c0 + 16 * MMF_NA * wave + 16 * a + 4 * g + q;
-                    if (ci < ncand && best_k[a][q] != MATCH_NONE) atomicMin(&best[cand[ci]], best_k[a][q]);
+                    if (out_q[a][q] >= 0 && best_k[a][q] != MATCH_NONE) atomicMin(&best[out_q[a][q]], best_k[a][q]);
                 }
         }
     }
