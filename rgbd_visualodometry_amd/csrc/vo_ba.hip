@@ -1512,12 +1512,15 @@ __global__ __launch_bounds__(256) void k_ba_chi_control(BaBatch Q) {
 }
 
 // stage 0: cull after the robust round (bit0, deactivate); stage 1: flag level-0 outliers (bit1)
-__device__ __forceinline__ void ba_cull_edge(const BaDev& B, const double* poses_c, const double* pts_c, int e, int stage) {
+// returns the edge's share of the final chi2 (stage 1, edges that stay): the caller sums a wavefront's shares before it touches scal[6] -- one atomic per
+// EDGE on that one address was what the BA's last launch waited for (60-90 k same-address atomics: 25 us)
+__device__ __forceinline__ double ba_cull_edge(const BaDev& B, const double* poses_c, const double* pts_c, int e, int stage) {
     double r[2], pc[3];
     ba_err(B.cam, poses_c + 12 * (size_t)B.e_pose[e], pts_c + 3 * (size_t)B.e_pt[e], B.e_uv + 2 * (size_t)e, r, pc);
     const double c2 = r[0] * r[0] + r[1] * r[1], th = B.chi2_th;
     if (stage == 0) { if (c2 > th) { B.flags[e] = 1; B.active[e] = 0; } else B.flags[e] = 0; }
-    else if (B.active[e]) { if (c2 > th) B.flags[e] |= 2; else atomicAdd(&B.scal[6], c2); }
+    else if (B.active[e]) { if (c2 > th) B.flags[e] |= 2; else return c2; }
+    return 0.0;
 }
 // A problem enters its slot: control block of the robust round, zeroed accumulators (one workgroup; the plain chi2 of the
 // initial state follows in k_ba_chi).  The descriptor (BaDev) is the only thing the host uploads.
@@ -1559,12 +1562,17 @@ __global__ __launch_bounds__(256) void k_ba_round(BaBatch Q) {
     if ((int)blockIdx.x >= nblk) return;
     BA_STATE(B)
     const int e = blockIdx.x * 256 + threadIdx.x;
+    double chi_keep = 0.0;
     if (e < B.n_edges) {
-        ba_cull_edge(B, poses_c, pts_c, e, stage);
+        chi_keep = ba_cull_edge(B, poses_c, pts_c, e, stage);
         if (stage == 1 && B.e_obs && (B.flags[e] & 3)) {    // culled by either test: its observation id joins the list (agent-scope store: read by another workgroup / the merge kernel)
             const int pos = __hip_atomic_fetch_add(B.ncull, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (pos < B.cull_cap) __hip_atomic_store(B.cull + pos, B.e_obs[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+    if (stage == 1) {                                        // (workgroup-uniform)
+        chi_keep = vo_wave_sum_f64(chi_keep);
+        if ((threadIdx.x & 63) == 0 && chi_keep != 0.0) atomicAdd(&B.scal[6], chi_keep);
     }
     __shared__ int s_last;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every wave's atomic adds on scal[6] have been performed before the barrier (a workgroup-scope barrier alone need not wait for them)
