@@ -123,41 +123,43 @@ int vo_scratch(vo_ctx* c, size_t bytes) {
 // ---- the map grows.  The reference's map is a host container without a size; here the map arrays (and the per-lane chain buffers, whose worst case is the
 // whole map as the local map: src/frontend.cpp:163-166) are device allocations for `map_capacity` points.  vo_keyframe_commit -- the one place where map points
 // are created on the device path -- calls this when a keyframe's new points may not fit: every array is reallocated at twice the size and its contents copied
-// (device to device: 2 GB in well under a millisecond of copy time; the hipMalloc / hipFree pairs dominate, ~1 ms per array, once per doubling).  The caller
-// guarantees that no chain that reads these buffers is in flight (the host layer commits a keyframe behind the frame's own chain and behind the graph cut).
-template <typename T>
-static int map_regrow(T*& p, size_t per, size_t nl, size_t m0, size_t m1, bool keep, int fill_tail, hipStream_t st) {
-    T* q = nullptr;
-    if (hipMalloc((void**)&q, sizeof(T) * nl * per * m1) != hipSuccess) { (void)hipGetLastError(); return VO_E_NOMEM; }
-    for (size_t l = 0; l < nl; ++l) {
-        if (keep && p) HIP_TRY(hipMemcpyAsync(q + l * per * m1, p + l * per * m0, sizeof(T) * per * m0, hipMemcpyDeviceToDevice, st));
-        if (fill_tail >= 0) HIP_TRY(hipMemsetAsync(q + l * per * m1 + per * m0, fill_tail, sizeof(T) * per * (m1 - m0), st));
-    }
-    HIP_TRY(hipStreamSynchronize(st));
-    if (p) (void)hipFree(p);
-    p = q;
-    return VO_OK;
-}
+// (device to device: 2 GB in well under a millisecond of copy time; the hipMalloc / hipFree pairs dominate, ~1 ms per array, once per doubling).  Every new array
+// is allocated before anything is copied or freed, so a failed allocation (VO_E_NOMEM) leaves the context as it was.  The caller guarantees that no chain
+// that reads these buffers is in flight (the host layer commits a keyframe behind the frame's own chain and behind the graph cut).
 int vo_map_grow(vo_ctx* c, long long need) {
     static const long long cap_max = getenv("VO_MAP_CAP_MAX") && atoll(getenv("VO_MAP_CAP_MAX")) > 0 ? atoll(getenv("VO_MAP_CAP_MAX")) : (1ll << 28);
     long long cap = c->p.map_capacity;
     if (need <= cap) return VO_OK;
     if (need > cap_max || need > (1ll << 30)) return VO_E_OVERFLOW;
     while (cap < need) cap = std::min(2 * cap, std::max(cap_max, need));
-    const size_t m0 = c->lane_stride, m1 = ((size_t)cap + 3) & ~(size_t)3, nl = (size_t)c->lanes;
+    const size_t m_old = (size_t)c->p.map_capacity, m0 = c->lane_stride, m1 = ((size_t)cap + 3) & ~(size_t)3, nl = (size_t)c->lanes;
     hipStream_t st = c->stream;
+    std::vector<MapRegrow> v;
+    auto rec = [&](auto*& p, size_t per, size_t lanes, int fill) {
+        typedef typename std::remove_reference<decltype(*p)>::type T;
+        v.push_back(MapRegrow{(void**)&p, sizeof(T) * per * m0, sizeof(T) * per * m1, sizeof(T) * per * m0, lanes, fill, nullptr});
+    };
+    rec(c->d_map_pos, 3, 1, -1); rec(c->d_map_nrm, 3, 1, -1); rec(c->d_map_desc, 8, 1, -1); rec(c->d_map_flags, 1, 1, 0); rec(c->d_active, 1, 1, -1);
+    rec(c->d_best, 1, nl, -1); rec(c->d_mcand, 1, nl, -1); rec(c->d_matches, 1, nl, -1); rec(c->d_corr_xyz, 3, nl, -1); rec(c->d_corr_uv, 2, nl, -1);
+    rec(c->d_inliers, 1, nl, -1); rec(c->d_lm_mask, 1, nl, -1);
+    vo_kf_map_regrow_records(c, m_old, (size_t)cap, m1, v);
+    for (MapRegrow& r : v)
+        if (hipMalloc(&r.fresh, r.new_b * r.nl) != hipSuccess) {      // nothing has been touched yet: the context stays as it was
+            (void)hipGetLastError();
+            for (MapRegrow& q : v) if (q.fresh) (void)hipFree(q.fresh);
+            return VO_E_NOMEM;
+        }
     HIP_TRY(hipStreamSynchronize(st));
-    int rc;
-    if ((rc = map_regrow(c->d_map_pos, 3, 1, m0, m1, true, -1, st)) || (rc = map_regrow(c->d_map_nrm, 3, 1, m0, m1, true, -1, st)) ||
-        (rc = map_regrow(c->d_map_desc, 8, 1, m0, m1, true, -1, st)) || (rc = map_regrow(c->d_map_flags, 1, 1, m0, m1, true, 0, st)) ||
-        (rc = map_regrow(c->d_active, 1, 1, m0, m1, true, -1, st)) ||
-        (rc = map_regrow(c->d_best, 1, nl, m0, m1, true, -1, st)) || (rc = map_regrow(c->d_mcand, 1, nl, m0, m1, true, -1, st)) ||
-        (rc = map_regrow(c->d_matches, 1, nl, m0, m1, true, -1, st)) || (rc = map_regrow(c->d_corr_xyz, 3, nl, m0, m1, true, -1, st)) ||
-        (rc = map_regrow(c->d_corr_uv, 2, nl, m0, m1, true, -1, st)) || (rc = map_regrow(c->d_inliers, 1, nl, m0, m1, true, -1, st)) ||
-        (rc = map_regrow(c->d_lm_mask, 1, nl, m0, m1, true, -1, st))) return rc;      // (a failure leaves the arrays grown so far at the new stride: the context is unusable, the caller gets VO_E_NOMEM)
-    const size_t m_old_kf = (size_t)c->p.map_capacity;
+    for (MapRegrow& r : v)
+        for (size_t l = 0; l < r.nl; ++l) {
+            uint8_t* dst = (uint8_t*)r.fresh + l * r.new_b;
+            if (r.keep_b && *r.slot) HIP_TRY(hipMemcpyAsync(dst, (const uint8_t*)*r.slot + l * r.old_b, r.keep_b, hipMemcpyDeviceToDevice, st));
+            if (r.fill >= 0 && r.new_b > r.keep_b) HIP_TRY(hipMemsetAsync(dst + r.keep_b, r.fill, r.new_b - r.keep_b, st));
+        }
+    HIP_TRY(hipStreamSynchronize(st));
+    for (MapRegrow& r : v) { if (*r.slot) (void)hipFree(*r.slot); *r.slot = r.fresh; }
     c->lane_stride = m1; c->p.map_capacity = (int32_t)cap; c->active_cap = (int)cap; c->corr_cap = (int)cap;
-    if ((rc = vo_kf_map_grown(c, m_old_kf, (size_t)cap))) return rc;
+    vo_kf_map_regrown(c, (size_t)cap, m1);
     if (getenv("VO_TRACE")) fprintf(stderr, "[vo_trace] the device map grew to %lld points (%zu lanes)\n", cap, nl);
     return VO_OK;
 }
@@ -165,6 +167,7 @@ int vo_map_grow(vo_ctx* c, long long need) {
 // Profiling is process-wide: a VO system owns several contexts (tracker + overlapped back-end), and the
 // per-kernel table has to cover all of them.  Contexts register themselves; reads merge every context.
 #include <mutex>
+#include <type_traits>
 static std::mutex g_prof_mu;
 static std::vector<vo_ctx*> g_ctxs;
 static bool g_prof_on = false;

@@ -194,8 +194,13 @@ int vo_track_lm_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* d_lanes, in
 void vo_lane_fill(vo_ctx* c, int lane, int slot, uint64_t seed, TrackDev* d_tr, LaneDesc* out);   // descriptor of lane `lane` of context c
 int vo_corr_from_host(vo_ctx* c, const float* xyz, const float* uv, int n);
 int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out);                       // vo_ba.hip
+// One array that follows the map's capacity (vo_map_grow): `nl` lanes of `old_b` bytes become `nl` lanes of `new_b`; the first `keep_b` bytes of every lane are
+// copied, the rest is filled with `fill` (< 0: left as allocated).  All fresh arrays are allocated before anything is copied or freed: a failed allocation leaves
+// the context as it was.
+struct MapRegrow { void** slot; size_t old_b, new_b, keep_b, nl; int fill; void* fresh; };
 int vo_map_grow(vo_ctx* c, long long need_slots);          // vo_capi.hip: the map arrays and the per-lane chain buffers for at least `need_slots` map points (doubling; VO_E_OVERFLOW beyond VO_MAP_CAP_MAX); the caller has no chain in flight
-int vo_kf_map_grown(vo_ctx* c, size_t m_old, size_t m_new);   // vo_kf.hip: the chain heads / leader keys / candidate buffers follow
+void vo_kf_map_regrow_records(vo_ctx* c, size_t m_old, size_t m_new, size_t stride_new, std::vector<MapRegrow>& v);   // vo_kf.hip: chain heads, leader keys, candidate buffers
+void vo_kf_map_regrown(vo_ctx* c, size_t m_new, size_t stride_new);      // ... and their bookkeeping once the new arrays are in place
 int vo_scan_i32(hipStream_t st, const int* in, int n, int* bsum /* >= 1024 ints, 256-byte aligned, zeroed once when allocated (k_scan_one's published totals) */, int* out, int* total);      // vo_ba.hip: exclusive scan, n <= 16 Mi; *total = -1 if a tile of the one-launch form never showed up
 // vo_kf.hip
 int vo_obs_tables_ensure(vo_ctx* c);

@@ -152,33 +152,25 @@ static int kf_state(vo_ctx* c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     return VO_OK;
 }
-// the map's arrays have grown (vo_map_grow): chain heads keep their contents and get empty tails, the leader keys restart (epochs), the candidate buffers are scratch
-int vo_kf_map_grown(vo_ctx* c, size_t m_old, size_t m_new) {
-    hipStream_t st = c->stream;
+// the map's arrays grow (vo_map_grow): chain heads keep their contents and get empty tails, the leader keys keep theirs (they carry their epoch) and get
+// zeroes, the candidate buffers are scratch
+void vo_kf_map_regrow_records(vo_ctx* c, size_t m_old, size_t m_new, size_t stride_new, std::vector<MapRegrow>& v) {
     if (c->d_pt_last) {
-        int32_t* a = nullptr; int32_t* b = nullptr;
-        if (hipMalloc((void**)&a, 4 * m_new) != hipSuccess || hipMalloc((void**)&b, 4 * m_new) != hipSuccess) { if (a) (void)hipFree(a); (void)hipGetLastError(); return VO_E_NOMEM; }
-        HIP_TRY(hipMemcpyAsync(a, c->d_pt_last, 4 * m_old, hipMemcpyDeviceToDevice, st)); HIP_TRY(hipMemcpyAsync(b, c->d_pt_first, 4 * m_old, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemsetAsync(a + m_old, 0xFF, 4 * (m_new - m_old), st)); HIP_TRY(hipMemsetAsync(b + m_old, 0xFF, 4 * (m_new - m_old), st));
-        HIP_TRY(hipStreamSynchronize(st));
-        (void)hipFree(c->d_pt_last); (void)hipFree(c->d_pt_first);
-        c->d_pt_last = a; c->d_pt_first = b;
+        v.push_back(MapRegrow{(void**)&c->d_pt_last, 4 * m_old, 4 * m_new, 4 * m_old, 1, 0xFF, nullptr});
+        v.push_back(MapRegrow{(void**)&c->d_pt_first, 4 * m_old, 4 * m_new, 4 * m_old, 1, 0xFF, nullptr});
     }
     if (c->kf) {
         KfState& K = *c->kf;
-        const int cand_new = (int)std::min<size_t>(c->lane_stride, m_new);
-        unsigned long long* key = nullptr; int* cand = nullptr; uint8_t* tok = nullptr; double* txyz = nullptr; int* cnt = nullptr;
-        const bool ok = hipMalloc((void**)&key, 8 * m_new) == hipSuccess && hipMalloc((void**)&cand, 4 * (size_t)cand_new) == hipSuccess && hipMalloc((void**)&tok, (size_t)cand_new) == hipSuccess &&
-                        hipMalloc((void**)&txyz, 24 * (size_t)cand_new) == hipSuccess && hipMalloc((void**)&cnt, 8 * ((size_t)cand_new / 256 + 2)) == hipSuccess;
-        if (!ok) { void* q[] = {key, cand, tok, txyz, cnt}; for (void* x : q) if (x) (void)hipFree(x); (void)hipGetLastError(); return VO_E_NOMEM; }
-        HIP_TRY(hipMemcpyAsync(key, K.d_key, 8 * m_old, hipMemcpyDeviceToDevice, st));      // (leader keys carry their epoch: old entries stay comparable, new ones start at 0)
-        HIP_TRY(hipMemsetAsync(key + m_old, 0, 8 * (m_new - m_old), st));
-        HIP_TRY(hipStreamSynchronize(st));
-        void* old[] = {K.d_key, K.d_cand, K.d_tri_ok, K.d_tri_xyz, K.d_cnt};
-        for (void* x : old) if (x) (void)hipFree(x);
-        K.d_key = key; K.d_cand = (decltype(K.d_cand))cand; K.d_tri_ok = (decltype(K.d_tri_ok))tok; K.d_tri_xyz = (decltype(K.d_tri_xyz))txyz; K.d_cnt = (decltype(K.d_cnt))cnt; K.cand_cap = cand_new;
+        const size_t cand_old = (size_t)K.cand_cap, cand_new = std::min(stride_new, m_new);
+        v.push_back(MapRegrow{(void**)&K.d_key, 8 * m_old, 8 * m_new, 8 * m_old, 1, 0, nullptr});
+        v.push_back(MapRegrow{(void**)&K.d_cand, 4 * cand_old, 4 * cand_new, 0, 1, -1, nullptr});
+        v.push_back(MapRegrow{(void**)&K.d_tri_ok, cand_old, cand_new, 0, 1, -1, nullptr});
+        v.push_back(MapRegrow{(void**)&K.d_tri_xyz, 24 * cand_old, 24 * cand_new, 0, 1, -1, nullptr});
+        v.push_back(MapRegrow{(void**)&K.d_cnt, 8 * (cand_old / 256 + 2), 8 * (cand_new / 256 + 2), 0, 1, -1, nullptr});
     }
-    return VO_OK;
+}
+void vo_kf_map_regrown(vo_ctx* c, size_t m_new, size_t stride_new) {
+    if (c->kf) c->kf->cand_cap = (int)std::min(stride_new, m_new);
 }
 static void note_kf_first(vo_ctx* c, int kf, long long at) {
     if (c->kf_first_obs.size() <= (size_t)kf) c->kf_first_obs.resize((size_t)kf + 1, -1);
