@@ -153,6 +153,7 @@ int vo_ctx_create(const vo_params* p, int device, vo_ctx** out);
 void vo_ctx_destroy(vo_ctx* ctx);
 const char* vo_strerror(int status);
 const char* vo_backend_name(void);          /* "hip-gfx950" or "cpu-oracle" */
+int vo_trace_level(void);                   /* the environment's VO_TRACE (0: unset), read once: the library and the host layer print their [vo_trace] lines to stderr when it is > 0 */
 int vo_default_params(vo_params* p);        /* fills default.yaml + TUM fr1 values */
 int vo_default_track_params(vo_track_params* tp);
 
@@ -339,6 +340,10 @@ int vo_ba_resident_graph(vo_ctx* ctx, vo_ctx* tables, const int32_t* free_kf, in
  * the first one of the oldest point a free keyframe observes, map slots from that point's slot.  Both depend on the cut's window, not on
  * how long the run has been (the reference's Backend walks only the covisible keyframes' observation maps: src/backend.cpp:36-120). */
 int vo_ba_resident_window(vo_ctx* ctx, int64_t* observations_visited, int64_t* map_slots_visited);
+/* The resident cut carves its scratch slab for UPPER BOUNDS of the graph's sizes (every observation of the window an edge, ...) so that the host
+ * need not wait for the sizes in the middle of the launch chain.  When those bounds ask for more than `bytes` (default 1 GiB: a revisit whose window
+ * spans most of the tables with ~100 free keyframes) the cut waits for the sizes and carves exactly.  0 < bytes; the results do not depend on it. */
+int vo_ba_resident_set_slab_budget(vo_ctx* ctx, int64_t bytes);
 
 /* ---- keyframe bookkeeping on the device (the rest of the row) ------------- */
 /* What FrontEnd::TrackingHandler does to host objects when a frame becomes a keyframe (reference src/frontend.cpp:119-131), done on the
@@ -357,7 +362,8 @@ int vo_ba_resident_window(vo_ctx* ctx, int64_t* observations_visited, int64_t* m
  * lane: lane of the context's last tracking call that holds this frame's match records (-1: no matches -- the first keyframe).
  * covis_kf / covis_weight receive the keyframes (ascending number) that share >= 1 live observation's point with the new one and the
  * counts: allCovisibleKeyframeIdToWeight_ of the new keyframe (include/myslam/frame.h:94); the caller keeps the ledger.  More than
- * cap_covis partners: VO_E_OVERFLOW (nothing is lost on the device; the weights can be read again with vo_kf_covisibility).
+ * cap_covis (or 4096) partners: the list is cut, out->n_covisible_total says how many there are and vo_kf_covisibility reads them all
+ * (nothing is lost on the device).  VO_E_OVERFLOW means what it says elsewhere: the observation / keyframe tables are full, nothing was written.
  * The map flags carry Mappoint::triangulated_ / optimized_ beside outlier_ (VO_MAP_FLAG_*).
  * The map has no fixed size on this path (the reference's is a host container): when first_new_slot + n_features exceeds the context's map capacity the map
  * arrays and the tracking chain's per-lane buffers are reallocated at twice the size, contents kept, before anything is written (no tracking chain of this
@@ -371,7 +377,7 @@ typedef struct vo_kf_commit_result {
     int32_t n_covisible;        /* entries written to covis_kf / covis_weight                                      */
     int32_t n_tri_candidates;   /* points the triangulation loop looked at                                         */
     int32_t triangulated_slot;  /* map slot moved by the first successful triangulation, -1: none                  */
-    int32_t reserved;
+    int32_t n_covisible_total;  /* partners the new keyframe has; > n_covisible: the list was cut -- vo_kf_covisibility has all */
 } vo_kf_commit_result;
 int vo_keyframe_commit(vo_ctx* ctx, int lane, int frame_slot, int32_t kf, const double T_cw[12], int32_t first_new_slot,
                        int32_t* covis_kf, int32_t* covis_weight, int cap_covis, vo_kf_commit_result* out);
@@ -386,7 +392,11 @@ int vo_map_set_active_covisible(vo_ctx* ctx, const int32_t* kf, int n, int min_p
  * point of the graph is flagged VO_MAP_FLAG_OPTIMIZED (src/backend.cpp:190), a point that lost its last live observation becomes an
  * outlier (Mappoint::RemoveObservedByKeyframe, src/mappoint.cpp:40-45), and the covisibility ledger's decrements come back as keyframe
  * pairs: culling the observation (K, P) costs K and every other keyframe that still sees P one shared point (Frame::RemoveObservedMappoint,
- * src/frame.cpp:122-152).  poses receives the n_free optimised poses (what _fetch would bring).  Waits for the tables' stream. */
+ * src/frame.cpp:122-152).  poses receives the n_free optimised poses (what _fetch would bring).  Waits for the tables' stream.
+ * The number of pairs has no bound the caller could know (culled observations x the other observers of their points: the reference's chi2
+ * threshold of 1 culls a large share of a real sequence's edges).  More than cap_pairs of them: VO_E_OVERFLOW, *n_pairs = the number the call
+ * needs, and the merge is INCOMPLETE (the culled observations are still marked in the tables) until the call has been repeated with arrays of
+ * that size: same pairs and same tables then as from one call with large arrays.  Nothing else may use `tables` between the two calls. */
 int vo_local_ba_resident_merge_ledger(vo_ctx* ctx, vo_ctx* tables, int32_t* pair_a, int32_t* pair_b, int cap_pairs, int32_t* n_pairs,
                                       double* poses, int cap_poses);
 /* Parity / inspection tap: the tables as they stand.  Any pointer may be NULL; n_obs / n_map receive the totals. */

@@ -46,6 +46,7 @@ struct vo_ctx {
 extern "C" {
 
 const char* vo_backend_name(void) { return "cpu-oracle"; }
+int vo_trace_level(void) { static const int v = [] { const char* e = std::getenv("VO_TRACE"); return e ? std::max(1, std::atoi(e)) : 0; }(); return v; }
 
 const char* vo_strerror(int s) {
     switch (s) {
@@ -407,6 +408,7 @@ int cut_graph(vo_ctx* t, const int32_t* free_kf, int n_free, ResidentGraph& g) {
     return VO_OK;
 }
 }  // namespace
+int vo_ba_resident_set_slab_budget(vo_ctx* c, int64_t bytes) { return (c && bytes > 0) ? VO_OK : VO_E_INVALID; }      // (this restatement has no slab)
 int vo_ba_resident_window(vo_ctx* c, int64_t* observations_visited, int64_t* map_slots_visited) {
     if (!c || !observations_visited || !map_slots_visited) return VO_E_INVALID;
     if (c->win_obs < 0) return VO_E_STATE;
@@ -618,7 +620,8 @@ int vo_keyframe_commit(vo_ctx* c, int lane, int frame_slot, int32_t kf, const do
     int k = 0;
     for (size_t q = 0; q < w.size(); ++q) if (w[q] > 0) { if (k < cap_covis) { covis_kf[k] = (int32_t)q; covis_weight[k] = w[q]; } ++k; }
     out->n_covisible = std::min(k, cap_covis);
-    return k > cap_covis ? VO_E_OVERFLOW : VO_OK;
+    out->n_covisible_total = k;                              // (a cut list: vo_kf_covisibility reads them all)
+    return VO_OK;
 }
 
 int vo_kf_covisibility(vo_ctx* c, int32_t kf, int32_t* covis_kf, int32_t* covis_weight, int cap, int32_t* n) {
@@ -664,13 +667,19 @@ int vo_local_ba_resident_merge_ledger(vo_ctx* c, vo_ctx* t, int32_t* pair_a, int
     std::vector<int64_t> cu(S.culled.begin(), S.culled.end());
     std::sort(cu.begin(), cu.end());
     int np = 0;
-    std::vector<int64_t> ob;
+    std::vector<int64_t> ob, undo_alive; std::vector<size_t> undo_flag;
     for (int64_t id : cu) {
         if (id < 0 || id >= (int64_t)t->obs_alive.size() || !t->obs_alive[(size_t)id]) continue;
-        t->obs_alive[(size_t)id] = 0;
+        t->obs_alive[(size_t)id] = 0; undo_alive.push_back(id);
         observers_of(t, t->obs_mp[(size_t)id], ob);
         for (int64_t o : ob) { if (np < cap_pairs) { pair_a[np] = t->obs_kf[(size_t)id]; pair_b[np] = t->obs_kf[(size_t)o]; } ++np; }
-        if (ob.empty()) t->map.flags[t->obs_mp[(size_t)id]] |= VO_MAP_FLAG_OUTLIER;       // src/mappoint.cpp:40-45
+        if (ob.empty() && !(t->map.flags[t->obs_mp[(size_t)id]] & VO_MAP_FLAG_OUTLIER)) { t->map.flags[t->obs_mp[(size_t)id]] |= VO_MAP_FLAG_OUTLIER; undo_flag.push_back((size_t)t->obs_mp[(size_t)id]); }       // src/mappoint.cpp:40-45
+    }
+    if (np > cap_pairs) {                                    // the caller's arrays are too short: nothing is merged, *n_pairs says what the call needs (include/vo_hip.h)
+        for (int64_t id : undo_alive) t->obs_alive[(size_t)id] = 1;
+        for (size_t s : undo_flag) t->map.flags[s] &= (uint8_t)~VO_MAP_FLAG_OUTLIER;
+        *n_pairs = np;
+        return VO_E_OVERFLOW;
     }
     for (size_t k = 0; k < S.slots.size(); ++k) {            // src/backend.cpp:188-194
         const size_t slot = (size_t)S.slots[k];
@@ -682,8 +691,8 @@ int vo_local_ba_resident_merge_ledger(vo_ctx* c, vo_ctx* t, int32_t* pair_a, int
     if (poses) std::memcpy(poses, S.poses.data(), 8 * std::min(S.poses.size(), (size_t)12 * cap_poses));
     S.merged = true;
     c->staged = S;
-    *n_pairs = std::min(np, cap_pairs);
-    return np > cap_pairs ? VO_E_OVERFLOW : VO_OK;
+    *n_pairs = np;
+    return VO_OK;
 }
 
 int vo_tables_fetch(vo_ctx* c, int64_t obs0, int64_t obs_cap, int32_t* obs_kf, int32_t* obs_mp, float* obs_uv, uint8_t* obs_alive, int64_t* n_obs,

@@ -55,7 +55,7 @@ class VoBaResidentResult(C.Structure):
 
 class VoKfCommitResult(C.Structure):
     _fields_ = [("n_matched", C.c_int32), ("n_new", C.c_int32), ("first_obs", C.c_int64), ("n_covisible", C.c_int32), ("n_tri_candidates", C.c_int32),
-                ("triangulated_slot", C.c_int32), ("reserved", C.c_int32)]
+                ("triangulated_slot", C.c_int32), ("n_covisible_total", C.c_int32)]
 
 
 class VoBaResult(C.Structure):
@@ -76,9 +76,11 @@ SYMBOLS = ["vo_ctx_create", "vo_ctx_destroy", "vo_strerror", "vo_backend_name", 
            "vo_local_ba", "vo_sync", "vo_profile_enable", "vo_profile_read",
            "vo_group_create", "vo_group_destroy", "vo_group_join", "vo_group_leave", "vo_group_set_gather", "vo_group_stats",
            "vo_set_hypothesis_shard", "vo_set_hypothesis_shard_stream", "vo_triangulate_batch", "vo_kf_set_pose", "vo_obs_append", "vo_obs_kill", "vo_local_ba_resident",
-           "vo_local_ba_resident_cut", "vo_local_ba_resident_solve", "vo_local_ba_resident_merge", "vo_local_ba_resident_fetch", "vo_ba_resident_graph", "vo_ba_resident_window",
+           "vo_local_ba_resident_cut", "vo_local_ba_resident_solve", "vo_local_ba_resident_merge", "vo_local_ba_resident_fetch", "vo_ba_resident_graph", "vo_ba_resident_window", "vo_ba_resident_set_slab_budget", "vo_trace_level",
            "vo_keyframe_commit", "vo_kf_covisibility", "vo_map_set_active_covisible", "vo_local_ba_resident_merge_ledger", "vo_tables_fetch"]
 
+
+VO_E_OVERFLOW = -4        # include/vo_hip.h: vo_status
 
 EXCHANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int32), C.c_int)     # vo_exchange_fn: in-place element-wise sum over the ranks
 STREAM_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.c_size_t, C.c_void_p)      # vo_stream_allreduce_fn: enqueue the sum on a HIP stream
@@ -443,6 +445,10 @@ class VoContext:
         a = np.ascontiguousarray(ids, dtype=np.int64)
         self.L.check(self.L.lib.vo_obs_kill(self.h, _ptr(a), len(a)), "vo_obs_kill")
 
+    def resident_set_slab_budget(self, nbytes):
+        """Scratch budget of the bound-sized resident cut; a cut that would exceed it waits for the graph's sizes and carves exactly."""
+        self.L.check(self.L.lib.vo_ba_resident_set_slab_budget(self.h, C.c_int64(int(nbytes))), "vo_ba_resident_set_slab_budget")
+
     def resident_window(self):
         """(observations, map slots) the last resident graph cut of this context visited."""
         a, b = C.c_int64(), C.c_int64()
@@ -501,8 +507,13 @@ class VoContext:
 
     def merge_ledger(self, tables: "VoContext", n_free: int, cap_pairs: int = 1 << 16):
         """vo_local_ba_resident_merge_ledger -> (sorted list of (kf_a, kf_b) decrements, free poses)"""
-        pa = np.zeros(cap_pairs, np.int32); pb = np.zeros(cap_pairs, np.int32); n = C.c_int32(); po = np.zeros((max(n_free, 1), 12))
-        self.L.check(self.L.lib.vo_local_ba_resident_merge_ledger(self.h, tables.h, _ptr(pa), _ptr(pb), cap_pairs, C.byref(n), _ptr(po), n_free), "vo_local_ba_resident_merge_ledger")
+        pa = np.zeros(max(cap_pairs, 1), np.int32); pb = np.zeros(max(cap_pairs, 1), np.int32); n = C.c_int32(); po = np.zeros((max(n_free, 1), 12))
+        rc = self.L.lib.vo_local_ba_resident_merge_ledger(self.h, tables.h, _ptr(pa), _ptr(pb), cap_pairs, C.byref(n), _ptr(po), n_free)
+        if rc == VO_E_OVERFLOW and n.value > cap_pairs:        # the call says how many pairs it needs; the repeated call completes the merge (include/vo_hip.h)
+            cap_pairs = n.value
+            pa = np.zeros(cap_pairs, np.int32); pb = np.zeros(cap_pairs, np.int32)
+            rc = self.L.lib.vo_local_ba_resident_merge_ledger(self.h, tables.h, _ptr(pa), _ptr(pb), cap_pairs, C.byref(n), _ptr(po), n_free)
+        self.L.check(rc, "vo_local_ba_resident_merge_ledger")
         return sorted((int(pa[i]), int(pb[i])) for i in range(n.value)), po[:n_free]
 
     def tables(self, n_map: int):

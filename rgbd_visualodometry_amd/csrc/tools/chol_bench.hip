@@ -7,6 +7,7 @@
 #include <random>
 
 // context helpers of vo_capi.hip that vo_ba_run references; the tool never calls vo_ba_run
+int vo_trace_level(void) { return 0; }
 void vo_prof_begin(vo_ctx*, const char*) {}
 void vo_prof_end(vo_ctx*) {}
 void* vo_stage(vo_ctx*, size_t) { return nullptr; }
@@ -96,7 +97,7 @@ __global__ void k_rsq_probe(const double* x, double* y, int n) {
     y[i] = y0; y[n + i] = y1; y[2 * n + i] = yc; { double yy, qq; ba_rsqrt_parts(d, yy, qq); y[3 * n + i] = yy + yy * qq; }
 }
 
-int main() {
+int main(int argc, char** argv) {
     {   // do small kernels on different streams overlap?  N streams x 20 spin kernels of ~50 us (1 workgroup of 256 threads each)
         int* sink; hipMalloc(&sink, 4);
         for (int ns : {1, 2, 4, 8, 16}) {
@@ -134,7 +135,8 @@ int main() {
     { double* d; hipMalloc(&d, 128 * 8); hipLaunchKernelGGL(k_dpp_probe, dim3(1), dim3(64), 0, 0, d); double h[128]; hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
       printf("bcast<3>: "); for (int i = 0; i < 64; i += 5) printf("[%d]=%.0f ", i, h[i]); printf("\nfnma<5>: "); for (int i = 0; i < 64; i += 5) printf("[%d]=%.0f ", i, h[64 + i]); printf("\n"); hipFree(d); }
 
-    const int sizes[] = {6, 12, 18, 24, 30, 48, 60, 96, 120, 126, 132, 138, 144, 156, 168, 186, 192, 198, 216};
+    std::vector<int> sizes = {6, 12, 18, 24, 30, 48, 60, 96, 120, 126, 132, 138, 144, 156, 168, 186, 192, 198, 216};
+    if (argc > 1 && !strcmp(argv[1], "big")) sizes = {216, 366, 480, 510, 516, 540, 600, 720, 900, 960};      // k_ba_chol16g up to the 160 free keyframes the ABI admits
     hipFuncSetAttribute((const void*)k_ba_chol16, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
     hipFuncSetAttribute((const void*)k_ba_chol16g, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
     hipFuncSetAttribute((const void*)k_ba_chol16v2, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);

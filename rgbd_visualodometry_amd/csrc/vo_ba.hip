@@ -1205,18 +1205,26 @@ __global__ __launch_bounds__(CH_THREADS) void k_ba_chol16g(BaBatch Q) {
         }
         __syncthreads();
         if (!s_ok) break;
-        if (nb == CH_NB) {                                      // ---- panel solve, one lane per row
-            if (solver) {
+        if (nb == CH_NB) {                                      // ---- panel solve, one lane per row, CH_THREADS rows per pass
+            // (round 6: the rows beyond the first CH_THREADS were never solved -- systems above D = 527, i.e. 88 free keyframes, were factored
+            // wrongly; the parity tests stopped at D = 360 against the restatement and compared HIP with HIP above)
+            for (int row0 = 0; row0 < m; row0 += CH_THREADS) {
+                if (wave * 64 + row0 >= m) break;               // (wave-uniform)
+                if (row0) {
+                    const int rl = min(row0 + tid, m - 1), r = base + rl;
+#pragma unroll
+                    for (int c = 0; c < CH_NB; ++c) x[c] = r < D ? S[(size_t)r * D + j0 + c] : s_aug[j0 + c];
+                }
                 double Lk[CH_NB];
 #pragma unroll
                 for (int k = 0; k < CH_NB; ++k) Lk[k] = s_dg[k * CH_NB + r16];
                 ch_exec_settle(x[0]);
                 ChSolve<0>::run(x, Lk);
-                if (tid < m) {
-                    const int r = base + tid;
+                if (row0 + tid < m) {
+                    const int r = base + row0 + tid;
 #pragma unroll
                     for (int c = 0; c < CH_NB; ++c) {
-                        s_P[tid * CH_NB + c] = x[c];
+                        s_P[(row0 + tid) * CH_NB + c] = x[c];
                         if (r < D) S[(size_t)r * D + j0 + c] = x[c]; else s_aug[j0 + c] = x[c];
                     }
                 }
@@ -1667,15 +1675,14 @@ int vo_ba_set_attrs() {
 // HIP streams with ~120 tiny dependent launches each mostly serialise in the command processor.
 #include <condition_variable>
 #include <deque>
-// which layout S has (and which Cholesky kernel a problem takes): tiles + the second generation up to CH2_MAXD, packed rows + the first above; VO_CHOL_V1 forces the first
-static int ba_use_tiles(int D) { static const bool v1 = getenv("VO_CHOL_V1") != nullptr; return (!v1 && D <= CH2_MAXD) ? 1 : 0; }
+// which layout S has (and which Cholesky kernel a problem takes): tiles + the second generation up to CH2_MAXD, packed rows + the first above
+static int ba_use_tiles(int D) { return D <= CH2_MAXD ? 1 : 0; }
 // Host waits on this latency chain poll instead of sleeping: a blocking wait costs the wake-up of a sleeping thread (10-40 us) per hand-off, and a
 // local BA has six of them.  vo_spin_event: hipEventSynchronize by polling (bounded: falls back to the blocking call after ~2 ms);
 // vo_spin_word: a word in pinned host memory that a kernel stores behind its results (system-scope fence in the kernel).
 static inline void vo_cpu_relax() { __builtin_ia32_pause(); }
 static hipError_t vo_spin_event(hipEvent_t ev) {
-    static const bool spin = !(getenv("VO_NO_SPIN") && atoi(getenv("VO_NO_SPIN")));
-    if (spin) {
+    {
         const auto t0 = std::chrono::steady_clock::now();
         for (int i = 0;; ++i) {
             const hipError_t e = hipEventQuery(ev);
@@ -1833,8 +1840,7 @@ static int ba_engine_enqueue(BaEngine* E) {
                     if (j->wait_pairs) { HIP_TRY(hipStreamWaitEvent(st, j->wait_pairs, 0)); j->wait_pairs = nullptr; }
                 }
             }
-            static const bool direct_ok = getenv("VO_BA_DESC_TABLE") == nullptr;      // (A/B: always through the descriptor table)
-            const bool direct = direct_ok && nA == 1;                  // a lone problem: descriptor by value
+            const bool direct = nA == 1;                               // a lone problem: descriptor by value
             if (direct) { ProfScope ps(prof, "k_ba_schur2", st); hipLaunchKernelGGL(k_ba_schur2_one, dim3(gA_blk + gA_pose), blk, 0, st, E->h_Bs[sA[0]], E->d_ctl + sA[0]); }
             else { ProfScope ps(prof, "k_ba_schur2", st); hipLaunchKernelGGL(k_ba_schur2, dim3(gA_blk + gA_pose, 1, nA), blk, 0, st, QA); }
             // both generations in one step: every problem leaves the kernel that is not its own at once (s_tiles says which one is)
@@ -1885,9 +1891,8 @@ static int ba_engine_retire(BaEngine* E) {
     {   // The chunk is over when its event has passed -- or, sooner, when every problem in it has reported "done": k_ba_round stores a slot's final
         // status record in pinned memory behind a system-scope fence, and for such a slot the rest of the chunk is empty launches.  (The event becomes
         // visible to the host tens of microseconds after the kernel has ended; the record within a few.)
-        static const bool poll = !(getenv("VO_NO_STAT_POLL") && atoi(getenv("VO_NO_STAT_POLL")));
         bool fin = false;
-        if (poll && C.n > 0) {
+        if (C.n > 0) {
             const auto t0 = std::chrono::steady_clock::now();
             for (int i = 0;; ++i) {
                 fin = true;
@@ -1983,7 +1988,7 @@ static int ba_engine_solve(BaEngine* E, BaJob* j) {
 static BaEngine* ba_engine_new(int device) {
     BaEngine* E = new BaEngine();
     E->device = device; E->refs = 1;
-    bool ok = vo_stream_create(&E->st, 1, nullptr) == hipSuccess;      // BA is the latency-critical chain beside tracking
+    bool ok = vo_stream_create(&E->st, 1) == hipSuccess;      // BA is the latency-critical chain beside tracking
     ok = ok && hipMalloc((void**)&E->d_Bs, sizeof(BaDev) * BA_SLOTS) == hipSuccess && hipMalloc((void**)&E->d_ctl, sizeof(BaCtl) * BA_SLOTS) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&E->h_Bs, sizeof(BaDev) * BA_SLOTS, hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&E->h_stat, sizeof(BaStat) * BA_SLOTS, hipHostMallocDefault) == hipSuccess;
@@ -2028,7 +2033,7 @@ static BaEngine* ba_engine_of(vo_ctx* c) {
 }
 
 static void ba_engine_free(BaEngine* E) {
-    if (getenv("VO_TRACE") && E->n_jobs) fprintf(stderr, "[vo_trace] BA engine: %lld problems, %lld step launches, %.2f problems per step launch\n", E->n_jobs, E->n_steps, E->n_steps ? (double)E->n_slot_steps / E->n_steps : 0.0);
+    if (vo_trace_level() && E->n_jobs) fprintf(stderr, "[vo_trace] BA engine: %lld problems, %lld step launches, %.2f problems per step launch\n", E->n_jobs, E->n_steps, E->n_steps ? (double)E->n_slot_steps / E->n_steps : 0.0);
     if (E->st) { (void)hipStreamSynchronize(E->st); (void)hipStreamDestroy(E->st); }
     if (E->d_Bs) (void)hipFree(E->d_Bs);
     if (E->d_ctl) (void)hipFree(E->d_ctl);
@@ -2063,7 +2068,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
         memset(out->edge_flags, 0, ne);
         return VO_OK;
     }
-    const bool trace = getenv("VO_TRACE") != nullptr;
+    const bool trace = vo_trace_level() != 0;
     HIP_TRY(hipStreamSynchronize(st));                      // the pinned staging buffer may still feed an earlier vo_map_upsert
     const double tt0 = tnow();
     // CSR point -> edges and free pose -> edges: ONE counting pass here (the scratch vectors live in the context: no
@@ -2089,7 +2094,6 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     int max_len = 0;
     for (int j = 0; j < nf; ++j) max_len = std::max(max_len, ps_start[j + 1] - ps_start[j]);
     if (max_len > PAIR_LDS_CAP) dev_pairs = false;
-    if (getenv("VO_BA_HOST_PAIRS")) dev_pairs = false;
     std::vector<BaBlock> blocks;
     int npairs = 0;
     int2* pairs = nullptr;
@@ -2542,6 +2546,7 @@ struct BaResident {
     bool solved = false; int solve_seq = 0, cur_buf = 0, n_culled = 0; double chi0 = 0, chi_final = 0; int lm_iters = 0;
     void* d_stage = nullptr; size_t stage_bytes = 0;        // merged result, out of the slab the next cut reuses: [poses nf x 12][points nx x 3][slots nx]
     bool has_stage = false; int merged_seq = 0, st_nf = 0, st_nx = 0, st_ne = 0, st_fixed = 0, st_culled = 0, st_iters = 0; double st_chi0 = 0, st_chi1 = 0;
+    bool ledger_pending = false; int ledger_total = 0;      // vo_local_ba_resident_merge_ledger answered VO_E_OVERFLOW: the culled observations are still marked, the next call pages the pairs out
     hipStream_t fetch_stream = nullptr; hipEvent_t ev_merge = nullptr;      // _fetch copies on a stream of its own (behind ev_merge): the tables' stream may be running the tracker's next launch chain, the context's own stream the next cut
 };
 void vo_ba_resident_free(vo_ctx* c) {
@@ -2580,15 +2585,20 @@ __global__ void k_ba_merge(int nf, int nx, const double* __restrict__ poses, con
 // pinned host memory, the caller's ledger applies them -- and a point nobody sees any more becomes an outlier.  The reference removes the
 // observations one after the other; with c < c' both culled from one point, the pair (K, K') is therefore reported once, from c.  Phases: mark the
 // culled observations (alive = 2), walk each one's point chain, clear them.
+// mode 0: the three phases in one launch -- unless the walk finds more than pair_cap pairs: then the marks STAY (nothing is lost: the host pages the pairs
+// out with mode 1 launches over ranges [i0, i1) of the culled list, the marks being what makes every walk see the same survivors, and ends with mode 2,
+// the clearing phase alone).  The outlier flags a walk sets are the same ones whichever launch sets them.
 __global__ __launch_bounds__(256) void k_merge_ledger(const int* __restrict__ n_cull, const long long* __restrict__ cull, int cull_cap, const int32_t* __restrict__ obs_kf,
                                                       const int32_t* __restrict__ obs_mp, uint8_t* __restrict__ obs_alive, const int2* __restrict__ obs_link, const int32_t* __restrict__ pt_last,
-                                                      uint8_t* __restrict__ map_flags, int* __restrict__ pair_a, int* __restrict__ pair_b, int pair_cap, int* __restrict__ n_pairs_total) {
+                                                      uint8_t* __restrict__ map_flags, int* __restrict__ pair_a, int* __restrict__ pair_b, int pair_cap, int* __restrict__ n_pairs_total,
+                                                      int mode, int i0, int i1) {
     __shared__ int s_n;
     const int n = min(*n_cull, cull_cap);
     if (threadIdx.x == 0) s_n = 0;
-    for (int i = threadIdx.x; i < n; i += 256) { const long long c = cull[i]; if (obs_alive[c]) obs_alive[c] = 2; }
+    if (mode == 0) for (int i = threadIdx.x; i < n; i += 256) { const long long c = cull[i]; if (obs_alive[c]) obs_alive[c] = 2; }
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 256) {
+    if (mode != 2)
+    for (int i = (mode == 1 ? i0 : 0) + threadIdx.x; i < (mode == 1 ? min(i1, n) : n); i += 256) {
         const int c = (int)cull[i];
         if (obs_alive[c] != 2) continue;
         const int K = obs_kf[c], P = obs_mp[c];
@@ -2605,8 +2615,8 @@ __global__ __launch_bounds__(256) void k_merge_ledger(const int* __restrict__ n_
         if (survivors == 0) map_flags[P] |= VO_MAP_FLAG_OUTLIER;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 256) { const long long c = cull[i]; if (obs_alive[c] == 2) obs_alive[c] = 0; }
-    if (threadIdx.x == 0) *n_pairs_total = s_n;
+    if (mode == 2 || (mode == 0 && s_n <= pair_cap)) for (int i = threadIdx.x; i < n; i += 256) { const long long c = cull[i]; if (obs_alive[c] == 2) obs_alive[c] = 0; }
+    if (threadIdx.x == 0 && mode != 2) *n_pairs_total = s_n;
 }
 
 // The same scan in ONE launch for up to 512 tiles (8 Mi elements): a workgroup publishes its tile's total -- (call number << 32 | total) in one
@@ -2672,8 +2682,7 @@ static std::atomic<unsigned> g_scan_seq{0};
 int vo_scan_i32(hipStream_t st, const int* in, int n, int* bsum, int* out, int* total) {        // n <= 16 Mi; bsum: 4096 bytes, 256-byte aligned, zeroed when allocated
     const int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (nb > 1024) return VO_E_UNSUPPORTED;
-    static const bool two = getenv("VO_SCAN_2") != nullptr;             // A/B: block sums and the scan as two launches
-    if (!two && nb <= 512) {
+    if (nb <= 512) {
         unsigned seq = ++g_scan_seq;
         if (seq == 0) seq = ++g_scan_seq;                       // (0 is what a fresh buffer holds)
         hipLaunchKernelGGL(k_scan_one, dim3(std::max(nb, 1)), dim3(1024), 0, st, in, n, (unsigned long long*)bsum, std::max(nb, 1), out, total, seq);
@@ -2681,6 +2690,9 @@ int vo_scan_i32(hipStream_t st, const int* in, int n, int* bsum, int* out, int* 
     }
     hipLaunchKernelGGL(k_scan_blocksum, dim3(std::max(nb, 1)), dim3(1024), 0, st, in, n, bsum);
     hipLaunchKernelGGL(k_scan_final, dim3(std::max(nb, 1)), dim3(1024), 0, st, in, n, (const int*)bsum, std::max(nb, 1), out, total);
+    // (windows beyond 8 Mi elements only.)  The raw tile sums must not stay: a later one-launch scan reads a word of this buffer as
+    // (call number << 32 | tile total) and would take a stale sum whose upper half happens to equal its call number for a published total
+    HIP_TRY(hipMemsetAsync(bsum, 0, 4096, st));
     return VO_OK;
 }
 
@@ -2750,41 +2762,50 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     // The slab is carved for UPPER BOUNDS of the three sizes -- every slot of the window a point, every observation of the window an edge, every
     // keyframe a pose (the graph is typically half of its window) -- so that the host does not wait for the sizes in the middle of the chain:
     // the kernels below take nx, ne and n_fixed from `tot` on the device, their grids cover the bounds (workgroups behind the real sizes leave
-    // at once), and the host reads everything -- sizes and list lengths -- behind the last kernel.  VO_CUT_SIZES_FIRST=1: the earlier order
-    // (wait for the sizes, carve and launch exactly).
-    static const bool sizes_first = getenv("VO_CUT_SIZES_FIRST") != nullptr;
+    // at once), and the host reads everything -- sizes and list lengths -- behind the last kernel.  When the bounds ask for more than the
+    // context's slab budget (vo_ba_resident_set_slab_budget; a revisit whose window spans most of the tables, with ~100 free keyframes: GBs of
+    // pair scratch for a graph a fraction of that size), the cut waits for the sizes instead and carves exactly.
+    bool sizes_first = false;
     int nx = 0, ne = 0, n_fixed = 0, np = nf;
     int nx_c = mh, np_c = std::max(nkf, nf);
     long long ne_cl = std::max<long long>(no - obs_lo, 1);
-    if (sizes_first) {
+    const int nb_all = nf * (nf + 1) / 2;
+    int ne_c = 0, chunks = 0;
+    size_t off = 0, pairs_ub = 0, slices_cap = 0;
+    size_t o_poses = 0, o_pts = 0, o_epose = 0, o_ept = 0, o_euv = 0, o_pe = 0, o_qs = 0, o_qe = 0, o_pspt = 0, o_poses_n = 0, o_pts_n = 0, o_act = 0, o_flags = 0, o_eobs = 0, o_earr = 0, o_ncull = 0, o_cull = 0, o_hist = 0, o_offs = 0, o_ptot = 0, o_pcnt = 0, o_poff = 0, o_pn = 0, o_Hpp = 0, o_bp = 0, o_Hll = 0, o_bl = 0, o_scal = 0, o_partU = 0, o_partC = 0, o_W = 0, o_S = 0, o_bs2 = 0, o_Hinv = 0, o_dl = 0, o_blk = 0, o_pairs = 0, o_ppt = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    auto layout = [&]() {
+        off = 0;
+        ne_c = (int)std::min<long long>(ne_cl, 1ll << 30);
+        // ---- BA slab (same layout as vo_ba_run's, filled by kernels instead of an upload)
+        o_poses = carve(96 * (size_t)np_c), o_pts = carve(24 * (size_t)nx_c);
+        o_epose = carve(4 * (size_t)ne_c), o_ept = carve(4 * (size_t)ne_c), o_euv = carve(8 * (size_t)ne_c), o_pe = carve(4 * (size_t)ne_c);
+        o_qs = carve(4 * (size_t)(nf + 1)), o_qe = carve(4 * (size_t)ne_c), o_pspt = carve(4 * (size_t)ne_c + 4);
+        o_poses_n = carve(96 * (size_t)np_c), o_pts_n = carve(24 * (size_t)nx_c), o_act = carve(ne_c), o_flags = carve(ne_c);
+        chunks = (ne_c + PS_CHUNK - 1) / PS_CHUNK;
+        o_eobs = carve(8 * (size_t)ne_c), o_earr = carve(8 * (size_t)ne_c), o_ncull = carve(64), o_cull = carve(8 * (size_t)ne_c);
+        o_hist = carve(4 * (size_t)chunks * nf), o_offs = carve(4 * (size_t)chunks * nf), o_ptot = carve(4 * VO_BA_RESIDENT_MAX_FREE);
+        o_pcnt = carve(4 * (size_t)std::max(nb_all, 1)), o_poff = carve(4 * (size_t)std::max(nb_all, 1)), o_pn = carve(16);
+        o_Hpp = carve(288 * (size_t)nf), o_bp = carve(8 * (size_t)D), o_Hll = carve(72 * (size_t)nx_c), o_bl = carve(24 * (size_t)nx_c), o_scal = carve(64);
+        o_partU = carve(24 * ((size_t)(nx_c + 63) / 64 + 1)), o_partC = carve(8 * ((size_t)(ne_c + 255) / 256 + 1));
+        o_W = carve(std::max<size_t>(144 * (size_t)ne_c, 16 * (size_t)ne_c + 192 * (size_t)nx_c + 2048)), o_S = carve(std::max<size_t>(8 * (size_t)D * D, 8 * ba_tile_doubles(D)) + 1024), o_bs2 = carve(8 * (size_t)D), o_Hinv = carve(72 * (size_t)nx_c), o_dl = carve(std::max<size_t>(24 * (size_t)nx_c, 8 * (size_t)D));
+        // pair lists: a point seen by m free poses gives m (m + 1) / 2 <= m (nf + 1) / 2 pairs, so ne (nf + 1) / 2 bounds them before the
+        // per-pose lists exist; slices: one per BA_SLICE pairs plus a partial one per block
+        pairs_ub = (size_t)ne_c * (size_t)(nf + 1) / 2 + 1; slices_cap = pairs_ub / BA_SLICE + (size_t)nb_all + 1;
+        o_blk = carve(sizeof(BaBlock) * slices_cap), o_pairs = carve(sizeof(int2) * pairs_ub), o_ppt = carve(sizeof(int32_t) * pairs_ub);
+    };
+    if (ne_cl > (1ll << 30)) return VO_E_UNSUPPORTED;
+    layout();
+    if (off > (size_t)c->cut_slab_budget) {
+        sizes_first = true;
         if (!vo_spin_word(h + 132, seq, 2000)) HIP_TRY(hipStreamSynchronize(st));
         nx = h[128]; ne = h[129]; n_fixed = h[130]; np = nf + n_fixed;
         if (nx < 0 || ne < 0) return VO_E_DEVICE;               // (a scan gave up waiting for one of its tiles)
         R.np = np; R.nf = nf; R.nx = nx; R.ne = ne; R.n_fixed = n_fixed;
         if (nx == 0 || ne == 0 || nf == 0) { R.ready = true; return VO_OK; }         // nothing to optimise
         nx_c = nx; ne_cl = ne; np_c = np;
+        layout();
     }
-    if (ne_cl > (1ll << 30)) return VO_E_UNSUPPORTED;
-    const int ne_c = (int)ne_cl;
-    // ---- BA slab (same layout as vo_ba_run's, filled by kernels instead of an upload)
-    size_t off = 0;
-    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    const int nb_all = nf * (nf + 1) / 2;
-    const size_t o_poses = carve(96 * (size_t)np_c), o_pts = carve(24 * (size_t)nx_c);
-    const size_t o_epose = carve(4 * (size_t)ne_c), o_ept = carve(4 * (size_t)ne_c), o_euv = carve(8 * (size_t)ne_c), o_pe = carve(4 * (size_t)ne_c);
-    const size_t o_qs = carve(4 * (size_t)(nf + 1)), o_qe = carve(4 * (size_t)ne_c), o_pspt = carve(4 * (size_t)ne_c + 4);
-    const size_t o_poses_n = carve(96 * (size_t)np_c), o_pts_n = carve(24 * (size_t)nx_c), o_act = carve(ne_c), o_flags = carve(ne_c);
-    const int chunks = (ne_c + PS_CHUNK - 1) / PS_CHUNK;
-    const size_t o_eobs = carve(8 * (size_t)ne_c), o_earr = carve(8 * (size_t)ne_c), o_ncull = carve(64), o_cull = carve(8 * (size_t)ne_c);
-    const size_t o_hist = carve(4 * (size_t)chunks * nf), o_offs = carve(4 * (size_t)chunks * nf), o_ptot = carve(4 * VO_BA_RESIDENT_MAX_FREE);
-    const size_t o_pcnt = carve(4 * (size_t)std::max(nb_all, 1)), o_poff = carve(4 * (size_t)std::max(nb_all, 1)), o_pn = carve(16);
-    const size_t o_Hpp = carve(288 * (size_t)nf), o_bp = carve(8 * (size_t)D), o_Hll = carve(72 * (size_t)nx_c), o_bl = carve(24 * (size_t)nx_c), o_scal = carve(64);
-    const size_t o_partU = carve(24 * ((size_t)(nx_c + 63) / 64 + 1)), o_partC = carve(8 * ((size_t)(ne_c + 255) / 256 + 1));
-    const size_t o_W = carve(std::max<size_t>(144 * (size_t)ne_c, 16 * (size_t)ne_c + 192 * (size_t)nx_c + 2048)), o_S = carve(std::max<size_t>(8 * (size_t)D * D, 8 * ba_tile_doubles(D)) + 1024), o_bs2 = carve(8 * (size_t)D), o_Hinv = carve(72 * (size_t)nx_c), o_dl = carve(std::max<size_t>(24 * (size_t)nx_c, 8 * (size_t)D));
-    // pair lists: a point seen by m free poses gives m (m + 1) / 2 <= m (nf + 1) / 2 pairs, so ne (nf + 1) / 2 bounds them before the
-    // per-pose lists exist; slices: one per BA_SLICE pairs plus a partial one per block
-    const size_t pairs_ub = (size_t)ne_c * (size_t)(nf + 1) / 2 + 1, slices_cap = pairs_ub / BA_SLICE + (size_t)nb_all + 1;
-    const size_t o_blk = carve(sizeof(BaBlock) * slices_cap), o_pairs = carve(sizeof(int2) * pairs_ub), o_ppt = carve(sizeof(int32_t) * pairs_ub);
     // (may reallocate: nothing of this problem lives in the slab yet.  The bounds follow the window, which keeps growing for the first ~200 frames of a
     // stream: a slab that has to grow takes twice what is asked for, or the short runs meet a hipFree + hipMalloc in every other cut)
     if ((rc = vo_scratch(c, (!sizes_first && off > c->d_ba_bytes) ? 2 * off : off))) return rc;
@@ -2810,12 +2831,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     if (!R.ev_arrays) HIP_TRY(hipEventCreateWithFlags(&R.ev_arrays, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(R.ev_arrays, st));               // (the first linearisation needs no pairs: it may start here)
     Q.lds_cap = PAIR_LDS_CAP;
-    static const bool three_launches = getenv("VO_PAIRS_3") != nullptr;      // A/B: count, scan, fill as three launches
-    if (three_launches) {
-        hipLaunchKernelGGL(k_ba_pairs<false>, dim3(nb_all), dim3(256), 4 * (size_t)PAIR_LDS_CAP, st, Q);
-        hipLaunchKernelGGL(k_ba_pairs_scan, dim3(1), dim3(1024), 0, st, Q, nb_all);
-        hipLaunchKernelGGL(k_ba_pairs<true>, dim3(nb_all), dim3(256), 4 * (size_t)PAIR_LDS_CAP, st, Q);
-    } else hipLaunchKernelGGL(k_ba_pairs_one, dim3(nb_all), dim3(256), 4 * (size_t)PAIR_LDS_CAP, st, Q, nb_all);      // (a list beyond the cap is searched in global memory)
+    hipLaunchKernelGGL(k_ba_pairs_one, dim3(nb_all), dim3(256), 4 * (size_t)PAIR_LDS_CAP, st, Q, nb_all);      // (a list beyond the cap is searched in global memory)
     if (!R.ev) HIP_TRY(hipEventCreateWithFlags(&R.ev, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(R.ev, st));
     if (!vo_spin_word(h + 133, seq, 2000)) HIP_TRY(hipEventSynchronize(R.ev_arrays));      // from here on `t` may change: every input has been gathered (and the list lengths are in h)
@@ -2838,7 +2854,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     B.n_poses = np; B.n_free = nf; B.n_points = nx; B.n_edges = ne; B.D = D; B.s_tiles = ba_use_tiles(D);
     B.n_blocks = slices_ub;                                 // launch bound; the Schur kernel stops at *n_slices, which the plan kernels below write
     B.n_slices = (const int*)(base + o_pn);
-    B.ps_start = (const int32_t*)(base + o_qs); B.ps_edges = (const int32_t*)(base + o_qe); B.blocks = (const BaBlock*)(base + o_blk); B.pairs = (const int2*)(base + o_pairs); B.pair_pt = getenv("VO_PAIRS_3") ? nullptr : (const int32_t*)(base + o_ppt);      // (the three-launch plan does not write it)
+    B.ps_start = (const int32_t*)(base + o_qs); B.ps_edges = (const int32_t*)(base + o_qe); B.blocks = (const BaBlock*)(base + o_blk); B.pairs = (const int2*)(base + o_pairs); B.pair_pt = (const int32_t*)(base + o_ppt);
     B.posesA = (double*)(base + o_poses); B.ptsA = (double*)(base + o_pts); B.posesB = (double*)(base + o_poses_n); B.ptsB = (double*)(base + o_pts_n);
     B.ctl = nullptr;
     B.partU = (double*)(base + o_partU); B.partC = (double*)(base + o_partC); B.nU = (nx + 63) / 64;
@@ -2861,7 +2877,7 @@ extern "C" int vo_local_ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* fre
                                         int32_t* n_points, int32_t* n_fixed, int32_t* n_edges) {
     if (!c || !t || n_free < 0 || (n_free && !free_kf) || c->device != t->device) return VO_E_INVALID;
     HIP_TRY(hipSetDevice(c->device));
-    const bool trace = getenv("VO_TRACE") != nullptr;
+    const bool trace = vo_trace_level() != 0;
     const double t0 = trace ? tnow() : 0.0;
     const int rc = ba_resident_cut(c, t, free_kf, n_free, huber_delta, chi2_th);
     if (trace) { static double a = 0; static int n = 0; a += tnow() - t0; if (++n % 10 == 0 && c->resident) fprintf(stderr, "[vo_trace] resident cut avg ms: %.3f (this one: window %lld observations / %d slots -> %d points, %d edges, %d free + %d fixed poses)\n", a / n, c->resident->win_obs, c->resident->win_slots, c->resident->nx, c->resident->ne, c->resident->nf, c->resident->n_fixed); }
@@ -2890,7 +2906,7 @@ extern "C" int vo_local_ba_resident_solve(vo_ctx* c, int it_robust, int it_plain
     job.grid_e = (ne + 255) / 256; job.grid_c = (ne + 1023) / 1024; job.grid_maxdiag = (D + 3 * nx + 255) / 256;
     job.lds = job.B.s_tiles ? ch2_lds_bytes(D) : D <= 192 ? sizeof(double) * (CH_NB * CH_NB + (size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D)
                        : sizeof(double) * (CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D);
-    const bool trace = getenv("VO_TRACE") != nullptr;
+    const bool trace = vo_trace_level() != 0;
     const double t0 = trace ? tnow() : 0.0;
     BaEngine* E = ba_engine_of(c);
     if (!E) return VO_E_STATE;
@@ -2933,7 +2949,7 @@ extern "C" int vo_local_ba_resident_solve(vo_ctx* c, int it_robust, int it_plain
     HIP_TRY(hipGetLastError());
     R.solved = true; ++R.solve_seq; R.cur_buf = job.cur_buf; R.n_culled = out->n_culled; R.chi0 = job.chi0; R.chi_final = job.chi_final; R.lm_iters = job.iters;
     if (trace) { static double a = 0, b = 0, st = 0; static int n = 0; a += t1 - t0; b += tnow() - t1; st += job.steps; if (++n % 10 == 0) fprintf(stderr, "[vo_trace] resident solve avg ms: optimise %.3f (%.1f step launches) result %.3f (D=%d edges=%d)\n", a / n, st / n, b / n, D, ne);
-                 static const bool each = atoi(getenv("VO_TRACE")) >= 2; if (each) fprintf(stderr, "[vo_trace] BA %d: D=%d points=%d edges=%d optimise %.3f ms\n", n, D, nx, ne, t1 - t0); }
+                 static const bool each = vo_trace_level() >= 2; if (each) fprintf(stderr, "[vo_trace] BA %d: D=%d points=%d edges=%d optimise %.3f ms\n", n, D, nx, ne, t1 - t0); }
     return out->n_culled > out->cap_culled ? VO_E_OVERFLOW : VO_OK;
 }
 
@@ -2947,7 +2963,9 @@ extern "C" int vo_local_ba_resident_merge_ledger(vo_ctx* c, vo_ctx* t, int32_t* 
     return ba_resident_merge(c, t, true, pair_a, pair_b, cap_pairs, n_pairs, poses, cap_poses);
 }
 static int ba_resident_merge(vo_ctx* c, vo_ctx* t, bool ledger, int32_t* pair_a, int32_t* pair_b, int cap_pairs, int32_t* n_pairs, double* poses, int cap_poses) {
-    if (!c || !t || c->device != t->device || !c->resident || !c->resident->solved || c->resident->merged_seq == c->resident->solve_seq) return VO_E_STATE;
+    if (!c || !t || c->device != t->device || !c->resident || !c->resident->solved) return VO_E_STATE;
+    const bool resume = ledger && c->resident->ledger_pending;      // the call that follows a VO_E_OVERFLOW
+    if (c->resident->merged_seq == c->resident->solve_seq && !resume) return VO_E_STATE;
     HIP_TRY(hipSetDevice(c->device));
     BaResident& R = *c->resident;
     int* h_pa = nullptr; int* h_pb = nullptr; int* h_np = nullptr; double* h_poses = nullptr; int h_cap = 0;
@@ -2955,15 +2973,16 @@ static int ba_resident_merge(vo_ctx* c, vo_ctx* t, bool ledger, int32_t* pair_a,
         if (!t->d_obs_link || !t->d_pt_last) return VO_E_STATE;
         int rc = vo_kf_host_pairs(t, &h_pa, &h_pb, &h_cap, &h_np, &h_poses);
         if (rc) return rc;
-        *h_np = 0;
+        if (!resume) *h_np = 0;
     }
+    const int commit_cap = ledger ? std::min(h_cap, cap_pairs) : 0;      // mode 0 of k_merge_ledger clears its marks only if this many pairs suffice
     const int nf = R.nf, nx = R.nx;
     R.st_nf = nf; R.st_nx = nx; R.st_ne = R.ne; R.st_fixed = R.n_fixed; R.st_culled = R.n_culled; R.st_iters = R.lm_iters; R.st_chi0 = R.chi0; R.st_chi1 = R.chi_final;
     R.merged_seq = R.solve_seq; R.has_stage = true;
     if (nx == 0 || R.ne == 0 || nf == 0) return VO_OK;
     if (!t->d_obs_alive || !t->d_kf_pose || R.n_culled > R.cull_cap) return VO_E_STATE;
     const size_t o_pts = (96 * (size_t)nf + 255) & ~(size_t)255, o_sl = o_pts + ((24 * (size_t)nx + 255) & ~(size_t)255), total = o_sl + 4 * (size_t)nx;
-    if (total > R.stage_bytes) {
+    if (!resume && total > R.stage_bytes) {
         if (R.d_stage) { (void)hipStreamSynchronize(t->stream); if (R.fetch_stream) (void)hipStreamSynchronize(R.fetch_stream); (void)hipFree(R.d_stage); }
         R.d_stage = nullptr; R.stage_bytes = 0;
         if (hipMalloc(&R.d_stage, total + total / 2) != hipSuccess) return VO_E_NOMEM;
@@ -2972,15 +2991,17 @@ static int ba_resident_merge(vo_ctx* c, vo_ctx* t, bool ledger, int32_t* pair_a,
     uint8_t* sb = (uint8_t*)R.d_stage;
     const BaDev& B = R.B;
     const int n = std::max(std::max(nx, 12 * nf), R.n_culled);
-    if (ledger)       // first: a point that loses its last observation here keeps its position (src/backend.cpp:191: outliers are skipped)
+    auto ledger_launch = [&](int mode, int cap, int i0, int i1) {
         hipLaunchKernelGGL(k_merge_ledger, dim3(1), dim3(256), 0, t->stream, (const int*)R.d_ncull, (const long long*)R.d_cull, R.cull_cap, (const int32_t*)t->d_obs_kf, (const int32_t*)t->d_obs_mp,
-                           t->d_obs_alive, (const int2*)t->d_obs_link, (const int32_t*)t->d_pt_last, t->d_map_flags, h_pa, h_pb, h_cap, h_np);
-    hipLaunchKernelGGL(k_ba_merge, dim3((n + 255) / 256), dim3(256), 0, t->stream, nf, nx, (const double*)(R.cur_buf ? B.posesB : B.posesA), (const double*)(R.cur_buf ? B.ptsB : B.ptsA),
+                           t->d_obs_alive, (const int2*)t->d_obs_link, (const int32_t*)t->d_pt_last, t->d_map_flags, h_pa, h_pb, cap, h_np, mode, i0, i1);
+    };
+    if (ledger && !resume) ledger_launch(0, commit_cap, 0, 0);      // first: a point that loses its last observation here keeps its position (src/backend.cpp:191: outliers are skipped)
+    if (!resume) hipLaunchKernelGGL(k_ba_merge, dim3((n + 255) / 256), dim3(256), 0, t->stream, nf, nx, (const double*)(R.cur_buf ? B.posesB : B.posesA), (const double*)(R.cur_buf ? B.ptsB : B.ptsA),
                        (const int*)R.d_pose_kf, (const int32_t*)R.d_point_slots, (const int*)R.d_ncull, (const long long*)R.d_cull, R.cull_cap, t->d_map_pos, t->d_map_flags,
                        t->d_kf_pose, t->d_obs_alive, (double*)sb, (double*)(sb + o_pts), (int32_t*)(sb + o_sl), ledger ? 1 : 0, ledger ? h_poses : (double*)nullptr);
     if (!ledger) {                                          // (with the ledger the call waits for the tables' stream below: the next cut and a fetch are behind it anyway)
         if (!R.ev_merge) HIP_TRY(hipEventCreateWithFlags(&R.ev_merge, hipEventDisableTiming));
-        if (!R.fetch_stream) HIP_TRY(vo_stream_create(&R.fetch_stream, -1, "VO_FETCH_PRIO"));      // lowest class: three small copies behind an event wait must not sit in a queue a chain uses
+        if (!R.fetch_stream) HIP_TRY(vo_stream_create(&R.fetch_stream, -1));      // lowest class: three small copies behind an event wait must not sit in a queue a chain uses
         HIP_TRY(hipEventRecord(R.ev_merge, t->stream));
         HIP_TRY(hipStreamWaitEvent(c->stream, R.ev_merge, 0));
         HIP_TRY(hipStreamWaitEvent(R.fetch_stream, R.ev_merge, 0));
@@ -2988,12 +3009,37 @@ static int ba_resident_merge(vo_ctx* c, vo_ctx* t, bool ledger, int32_t* pair_a,
     HIP_TRY(hipGetLastError());
     if (ledger) {                                           // the caller's ledger needs the pairs before it picks the next free keyframes
         HIP_TRY(hipStreamSynchronize(t->stream));
-        if (!R.fetch_stream) HIP_TRY(vo_stream_create(&R.fetch_stream, -1, "VO_FETCH_PRIO"));      // (a later _fetch of this result finds its stream; idle, it needs no event)
-        const int np = std::min(*h_np, h_cap), take = std::min(np, cap_pairs);
-        if (take > 0) { memcpy(pair_a, h_pa, 4 * (size_t)take); memcpy(pair_b, h_pb, 4 * (size_t)take); }
-        *n_pairs = take;
+        if (!R.fetch_stream) HIP_TRY(vo_stream_create(&R.fetch_stream, -1));      // (a later _fetch of this result finds its stream; idle, it needs no event)
+        const int total_pairs = resume ? R.ledger_total : *h_np;
         if (poses) memcpy(poses, h_poses, 96 * (size_t)std::min(nf, cap_poses));
-        if (*h_np > take) return VO_E_OVERFLOW;
+        if (!resume && total_pairs <= commit_cap) {           // the usual case: one launch, the marks are gone
+            if (total_pairs > 0) { memcpy(pair_a, h_pa, 4 * (size_t)total_pairs); memcpy(pair_b, h_pb, 4 * (size_t)total_pairs); }
+            *n_pairs = total_pairs;
+            return VO_OK;
+        }
+        // More pairs than the pinned block (or the caller's arrays) hold: the culled observations are still marked.  Too many for the caller: say how
+        // many and wait for the repeated call; otherwise page them out -- walks over ranges of the culled list sized from the average pairs per entry,
+        // halved when a range overflows the block -- and clear the marks at the end (this overflow used to end the run).
+        R.ledger_pending = true; R.ledger_total = total_pairs;
+        if (total_pairs > cap_pairs) { *n_pairs = total_pairs; return VO_E_OVERFLOW; }
+        const int n_c = std::min(R.n_culled, R.cull_cap);
+        int got = 0, range = (int)std::max<long long>(1, (long long)n_c * h_cap / (2 * (long long)std::max(total_pairs, 1)));
+        for (int i0 = 0; i0 < n_c;) {
+            const int i1 = std::min(n_c, i0 + range);
+            ledger_launch(1, h_cap, i0, i1);
+            HIP_TRY(hipStreamSynchronize(t->stream));
+            const int cnt = *h_np;
+            if (cnt > h_cap) { if (range == 1) return VO_E_UNSUPPORTED; range = std::max(1, range / 2); continue; }      // (one observation with more co-observers than the block holds pairs: 16 Ki keyframes on one point)
+            if (got + cnt > cap_pairs) return VO_E_DEVICE;
+            if (cnt > 0) { memcpy(pair_a + got, h_pa, 4 * (size_t)cnt); memcpy(pair_b + got, h_pb, 4 * (size_t)cnt); }
+            got += cnt; i0 = i1;
+            if (cnt < h_cap / 4) range *= 2;
+        }
+        ledger_launch(2, 0, 0, 0);
+        HIP_TRY(hipGetLastError());
+        R.ledger_pending = false;
+        *n_pairs = got;
+        if (got != total_pairs) return VO_E_DEVICE;
     }
     return VO_OK;
 }
@@ -3021,6 +3067,12 @@ extern "C" int vo_local_ba_resident(vo_ctx* c, vo_ctx* t, const int32_t* free_kf
     int rc = vo_local_ba_resident_cut(c, t, free_kf, n_free, huber_delta, chi2_th, nullptr, nullptr, nullptr);
     if (rc) return rc;
     return vo_local_ba_resident_solve(c, it_robust, it_plain, out);
+}
+
+extern "C" int vo_ba_resident_set_slab_budget(vo_ctx* c, int64_t bytes) {
+    if (!c || bytes <= 0) return VO_E_INVALID;
+    c->cut_slab_budget = bytes;
+    return VO_OK;
 }
 
 extern "C" int vo_ba_resident_window(vo_ctx* c, int64_t* observations_visited, int64_t* map_slots_visited) {

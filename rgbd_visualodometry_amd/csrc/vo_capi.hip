@@ -21,7 +21,7 @@ static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 // see SURVEY.md 8a-1).  Computed once per context; the kernels only read it.
 static int build_plan(const vo_params& p, DevPlan& P, std::vector<int>& tab, std::vector<short>& tabs) {
     memset(&P, 0, sizeof(P));
-    P.xcd_map = getenv("VO_NO_XCD_MAP") ? 0 : 1;
+    P.xcd_map = 1;
     P.W = p.width; P.H = p.height; P.L = p.n_levels; P.nfeat = p.n_features; P.fast_thr = p.fast_threshold; P.edge = p.edge_threshold;
     P.fx = p.fx; P.fy = p.fy; P.cx = p.cx; P.cy = p.cy;
     const double sf = (double)p.scale_factor;
@@ -127,7 +127,7 @@ int vo_scratch(vo_ctx* c, size_t bytes) {
 // is allocated before anything is copied or freed, so a failed allocation (VO_E_NOMEM) leaves the context as it was.  The caller guarantees that no chain
 // that reads these buffers is in flight (the host layer commits a keyframe behind the frame's own chain and behind the graph cut).
 int vo_map_grow(vo_ctx* c, long long need) {
-    static const long long cap_max = getenv("VO_MAP_CAP_MAX") && atoll(getenv("VO_MAP_CAP_MAX")) > 0 ? atoll(getenv("VO_MAP_CAP_MAX")) : (1ll << 28);
+    const long long cap_max = 1ll << 28;                   // VO_MAP_CAP_MAX of the docs: 2^28 map points
     long long cap = c->p.map_capacity;
     if (need <= cap) return VO_OK;
     if (need > cap_max || need > (1ll << 30)) return VO_E_OVERFLOW;
@@ -160,7 +160,7 @@ int vo_map_grow(vo_ctx* c, long long need) {
     for (MapRegrow& r : v) { if (*r.slot) (void)hipFree(*r.slot); *r.slot = r.fresh; }
     c->lane_stride = m1; c->p.map_capacity = (int32_t)cap; c->active_cap = (int)cap; c->corr_cap = (int)cap;
     vo_kf_map_regrown(c, (size_t)cap, m1);
-    if (getenv("VO_TRACE")) fprintf(stderr, "[vo_trace] the device map grew to %lld points (%zu lanes)\n", cap, nl);
+    if (vo_trace_level()) fprintf(stderr, "[vo_trace] the device map grew to %lld points (%zu lanes)\n", cap, nl);
     return VO_OK;
 }
 
@@ -252,10 +252,9 @@ struct GroupReq {
 #define VO_GROUP_MAX_CHAINS 4
 struct vo_group {
     int device = 0, max_lanes = 0;
-    // chain slots: a launch chain in flight owns one (stream + launch set).  With more than one slot (VO_GROUP_CHAINS, default 1) the
-    // requests that arrive while a chain is running start a second chain beside it instead of piling up for the next one.  Measured
-    // with 8 / 16 streams and local BA: 3202 / 3689 frames/s with one slot, 2725 / 2864 with two -- more, smaller chains on a GPU that
-    // is already the bottleneck -- so one slot is the default.
+    // chain slots: a launch chain in flight owns one (stream + launch set).  ONE slot: requests that arrive while a chain is running pile up
+    // for the next one.  (Two chains side by side were measured in rounds 2 and 3 and lost: 8 / 16 streams 3202 / 3689 frames/s with one slot,
+    // 2725 / 2864 with two -- more, smaller chains on a GPU that is already the bottleneck.)
     struct Slot { hipStream_t stream = nullptr; LaunchSet ls; bool busy = false; };
     Slot slot[VO_GROUP_MAX_CHAINS]; int n_slots = 1;
     std::mutex mu; std::condition_variable cv;
@@ -269,6 +268,8 @@ static int shard_exchange(vo_ctx* c, hipStream_t st, int nl, int n_hyp);
 extern "C" {
 
 const char* vo_backend_name(void) { return "hip-gfx950"; }
+
+int vo_trace_level(void) { static const int v = [] { const char* e = getenv("VO_TRACE"); return e ? std::max(1, atoi(e)) : 0; }(); return v; }
 
 const char* vo_strerror(int s) {
     switch (s) {
@@ -297,7 +298,7 @@ int vo_default_track_params(vo_track_params* t) {
 
 void vo_ctx_destroy(vo_ctx* c) {
     if (!c) return;
-    if (getenv("VO_TRACE") && c->n_pre_calls) fprintf(stderr, "[vo_trace] uploads: %lld preload calls (%lld refused: not page-locked), %lld frames preloaded, %lld of them taken by vo_frame_upload, %lld frames copied by vo_frame_upload itself\n", c->n_pre_calls, c->n_pre_unpinned, c->n_pre_frames, c->n_up_hit, c->n_up_copy);
+    if (vo_trace_level() && c->n_pre_calls) fprintf(stderr, "[vo_trace] uploads: %lld preload calls (%lld refused: not page-locked), %lld frames preloaded, %lld of them taken by vo_frame_upload, %lld frames copied by vo_frame_upload itself\n", c->n_pre_calls, c->n_pre_unpinned, c->n_pre_frames, c->n_up_hit, c->n_up_copy);
     { std::unique_lock<std::mutex> lk(g_prof_mu); prof_collect(c); for (size_t i = 0; i < g_ctxs.size(); ++i) if (g_ctxs[i] == c) { g_ctxs.erase(g_ctxs.begin() + i); break; } }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -353,7 +354,7 @@ int vo_ctx_create(const vo_params* p, int device, vo_ctx** out) {
     std::vector<int> tab; std::vector<short> tabs;
     int rc = build_plan(*p, c->plan, tab, tabs);
     if (rc) { delete c; return rc; }
-    if (vo_stream_create(&c->stream, p->stream_priority, nullptr) != hipSuccess) { delete c; return VO_E_DEVICE; }
+    if (vo_stream_create(&c->stream, p->stream_priority) != hipSuccess) { delete c; return VO_E_DEVICE; }
     rc = vo_orb_upload_constants();
     if (rc) { vo_ctx_destroy(c); return rc; }
     rc = vo_orb_pyramid_plan(c, tab);
@@ -1065,10 +1066,9 @@ int vo_group_create(int device, int max_lanes, vo_group** out) {
     vo_group* g = new (std::nothrow) vo_group();
     if (!g) return VO_E_NOMEM;
     g->device = device; g->max_lanes = max_lanes;
-    const char* env = getenv("VO_GROUP_CHAINS");
-    g->n_slots = std::max(1, std::min(VO_GROUP_MAX_CHAINS, env ? atoi(env) : 1));
+    g->n_slots = 1;
     for (int i = 0; i < g->n_slots; ++i) {
-        if (vo_stream_create(&g->slot[i].stream, 1, "VO_GROUP_PRIO") != hipSuccess) { vo_group_destroy(g); return VO_E_DEVICE; }      // the members' pace: a queue of the highest class
+        if (vo_stream_create(&g->slot[i].stream, 1) != hipSuccess) { vo_group_destroy(g); return VO_E_DEVICE; }      // the members' pace: a queue of the highest class
         if (launchset_alloc(g->slot[i].ls, max_lanes) != VO_OK) { vo_group_destroy(g); return VO_E_NOMEM; }
     }
     *out = g;

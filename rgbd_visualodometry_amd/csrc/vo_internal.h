@@ -27,7 +27,7 @@ struct DevPlan {
     unsigned loff[VO_MAX_LEVELS];                               // byte offset of each level inside a slot's pyramid slab
     float scale[VO_MAX_LEVELS];
     int tiles_x[VO_MAX_LEVELS], tile_prefix[VO_MAX_LEVELS + 1]; // FAST tiling (64 x VO_FAST_TH tiles), blockIdx.x -> (level, tile)
-    int xcd_map;                                                // 1: XCD-aware tile order in the tiled ORB kernels (VO_NO_XCD_MAP=1 turns it off for A/B runs)
+    int xcd_map;                                                // 1: XCD-aware tile order in the tiled ORB kernels (always on; kept in the plan for the kernels that read it)
     int btiles_x[VO_MAX_LEVELS], btile_prefix[VO_MAX_LEVELS + 1]; // blur tiling (128x16 tiles over the whole level)
     int tabx[VO_MAX_LEVELS], taby[VO_MAX_LEVELS];               // offsets into the resize tables
     int umax[16];
@@ -150,6 +150,7 @@ struct vo_ctx {
     int map_hi = 0;                                         // highest map slot ever upserted + 1
     void* d_cut = nullptr; size_t d_cut_bytes = 0;          // scratch of the resident graph cut
     int cut_seq = 0;                                        // sequence number of the cut's pinned report words
+    long long cut_slab_budget = 1ll << 30;                  // vo_ba_resident_set_slab_budget: a cut whose bound-sized slab would exceed it waits for the graph's sizes and carves exactly
     struct BaResident* resident = nullptr;                  // state between vo_local_ba_resident_cut and _solve (vo_ba.hip)
     // vo_track_batch_begin / _end: the request of the chain in flight (copies: the caller's arrays need not outlive _begin)
     bool async_pending = false; int async_n = 0, async_cap = 0; std::vector<int> async_slots; std::vector<uint64_t> async_seeds; double async_T0[12]; vo_track_params async_tp;
@@ -168,9 +169,8 @@ struct ProfScope { vo_ctx* c; int idx;
 // A non-blocking stream of one of the runtime's three priority classes (cls < 0: lowest, 0: default, > 0: highest).  The runtime keeps a pool of
 // hardware queues per class (GPU_MAX_HW_QUEUES each; streams beyond that share queues of their class), so the class also says WHOSE queues a
 // stream may share: the chains that set a stream's pace (a group's tracking chain, the BA engines' step launches) live in the highest class, where
-// nothing with cross-stream waits or long batches is created beside them.  `env` names an override for experiments.
-inline hipError_t vo_stream_create(hipStream_t* st, int cls, const char* env) {
-    if (env) { if (const char* e = getenv(env)) cls = atoi(e); }
+// nothing with cross-stream waits or long batches is created beside them.
+inline hipError_t vo_stream_create(hipStream_t* st, int cls) {
     if (cls == 0) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // numerically lower = higher priority: `hi` is the highest, `lo` the lowest

@@ -74,17 +74,21 @@ static int obs_tables_alloc(long long cap, int32_t** kf, int32_t** mp, float** u
     }
     return VO_OK;
 }
-void vo_kf_free(vo_ctx* c) {
-    if (c->d_pt_last) (void)hipFree(c->d_pt_last);
-    if (c->d_pt_first) (void)hipFree(c->d_pt_first);
-    if (c->d_kf_reach) (void)hipFree(c->d_kf_reach);
-    c->d_pt_last = nullptr; c->d_pt_first = nullptr; c->d_kf_reach = nullptr;
+// the keyframe-commit state alone (kf_state's failure path: the chain heads and the keyframes' reach belong to the observation tables, which stay)
+static void kf_state_free(vo_ctx* c) {
     KfState* k = c->kf;
     if (!k) return;
     if (k->h) (void)hipHostFree(k->h);
     void* q[] = {k->d_hdr, k->d_w, k->d_mark, k->d_key, k->d_cand, k->d_tri_ok, k->d_tri_xyz, k->d_act, k->d_cnt, k->d_kp_bits};
     for (void* x : q) if (x) (void)hipFree(x);
     delete k; c->kf = nullptr;
+}
+void vo_kf_free(vo_ctx* c) {                 // vo_ctx_destroy: the tables' chain heads / reach, then the commit state
+    if (c->d_pt_last) (void)hipFree(c->d_pt_last);
+    if (c->d_pt_first) (void)hipFree(c->d_pt_first);
+    if (c->d_kf_reach) (void)hipFree(c->d_kf_reach);
+    c->d_pt_last = nullptr; c->d_pt_first = nullptr; c->d_kf_reach = nullptr;
+    kf_state_free(c);
 }
 int vo_obs_tables_ensure(vo_ctx* c) {     // allocates the observation / keyframe tables on first use
     if (c->d_obs_kf) return VO_OK;
@@ -115,12 +119,19 @@ static int obs_tables_grow(vo_ctx* c, long long need) {
     int rc = obs_tables_alloc(cap, &kf, &mp, &uv, &alive, &prev);
     if (rc) return rc;
     const size_t n = (size_t)c->n_obs;
+    bool ok = true;
     if (n) {
-        HIP_TRY(hipMemcpyAsync(kf, c->d_obs_kf, 4 * n, hipMemcpyDeviceToDevice, c->stream)); HIP_TRY(hipMemcpyAsync(mp, c->d_obs_mp, 4 * n, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(uv, c->d_obs_uv, 8 * n, hipMemcpyDeviceToDevice, c->stream)); HIP_TRY(hipMemcpyAsync(alive, c->d_obs_alive, n, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(prev, c->d_obs_link, 8 * n, hipMemcpyDeviceToDevice, c->stream));
+        ok = hipMemcpyAsync(kf, c->d_obs_kf, 4 * n, hipMemcpyDeviceToDevice, c->stream) == hipSuccess && hipMemcpyAsync(mp, c->d_obs_mp, 4 * n, hipMemcpyDeviceToDevice, c->stream) == hipSuccess &&
+             hipMemcpyAsync(uv, c->d_obs_uv, 8 * n, hipMemcpyDeviceToDevice, c->stream) == hipSuccess && hipMemcpyAsync(alive, c->d_obs_alive, n, hipMemcpyDeviceToDevice, c->stream) == hipSuccess &&
+             hipMemcpyAsync(prev, c->d_obs_link, 8 * n, hipMemcpyDeviceToDevice, c->stream) == hipSuccess;
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    ok = hipStreamSynchronize(c->stream) == hipSuccess && ok;
+    if (!ok) {                                              // the fresh arrays go back; the tables stay as they were
+        void* q[] = {kf, mp, uv, alive, prev};
+        for (void* x : q) (void)hipFree(x);
+        (void)hipGetLastError();
+        return VO_E_DEVICE;
+    }
     (void)hipFree(c->d_obs_kf); (void)hipFree(c->d_obs_mp); (void)hipFree(c->d_obs_uv); (void)hipFree(c->d_obs_alive); (void)hipFree(c->d_obs_link);
     c->d_obs_kf = kf; c->d_obs_mp = mp; c->d_obs_uv = uv; c->d_obs_alive = alive; c->d_obs_link = prev; c->obs_cap = cap;
     return VO_OK;
@@ -144,7 +155,7 @@ static int kf_state(vo_ctx* c) {
               hipMalloc((void**)&k->d_key, 8 * M) == hipSuccess && hipMalloc((void**)&k->d_cand, 4 * (size_t)k->cand_cap) == hipSuccess &&
               hipMalloc((void**)&k->d_tri_ok, (size_t)k->cand_cap) == hipSuccess && hipMalloc((void**)&k->d_tri_xyz, 24 * (size_t)k->cand_cap) == hipSuccess &&
               hipMalloc((void**)&k->d_cnt, 8 * ((size_t)k->cand_cap / 256 + 2)) == hipSuccess && hipMalloc((void**)&k->d_kp_bits, 4 * ((size_t)c->p.n_features / 32 + 2)) == hipSuccess;
-    if (!ok) { (void)hipGetLastError(); vo_kf_free(c); return VO_E_NOMEM; }
+    if (!ok) { (void)hipGetLastError(); kf_state_free(c); return VO_E_NOMEM; }
     memset(k->h, 0, sizeof(KfHost));
     HIP_TRY(hipMemsetAsync(k->d_w, 0, 4 * (size_t)c->kf_cap, c->stream)); HIP_TRY(hipMemsetAsync(k->d_mark, 0, 4 * (size_t)c->kf_cap, c->stream));
     HIP_TRY(hipMemsetAsync(k->d_key, 0, 8 * M, c->stream)); HIP_TRY(hipMemsetAsync(k->d_hdr, 0, sizeof(KfDev), c->stream));
@@ -514,7 +525,7 @@ __global__ __launch_bounds__(1024) void k_kf_finish(KfTabs T, const KfDev* __res
         kf_reach[kf] = make_int2(hdr->reach_obs, hdr->reach_slot);
         h->r.n_matched = hdr->n_matched; h->r.n_new = hdr->n_new; h->r.first_obs = n_obs0; h->r.n_covisible = min(base, KF_COVIS_CAP);
         // the reference's loop stops looking at the first success: candidates behind it are not counted
-        h->r.n_tri_candidates = s_pick != INT_MAX ? s_pick + 1 : nt; h->r.triangulated_slot = slot; h->r.reserved = 0;
+        h->r.n_tri_candidates = s_pick != INT_MAX ? s_pick + 1 : nt; h->r.triangulated_slot = slot; h->r.n_covisible_total = base;
         h->reach_obs = hdr->reach_obs; h->reach_slot = hdr->reach_slot; h->n_covis_total = base;
     }
 }
@@ -572,7 +583,8 @@ extern "C" int vo_keyframe_commit(vo_ctx* c, int lane, int frame_slot, int32_t k
     const int take = std::min(H.r.n_covisible, cap_covis);
     if (take > 0) { memcpy(covis_kf, H.covis_kf, 4 * (size_t)take); memcpy(covis_weight, H.covis_w, 4 * (size_t)take); }
     out->n_covisible = take;
-    return H.n_covis_total > take ? VO_E_OVERFLOW : VO_OK;
+    out->n_covisible_total = H.n_covis_total;              // more than the caller (or the pinned block) holds: vo_kf_covisibility reads them all (nothing is lost on the device)
+    return VO_OK;
 }
 
 // parity tap: the weights of one keyframe recounted from the tables (a scan of the whole table: not on the product path)

@@ -221,7 +221,7 @@ static bool pyr_ranges(const DevPlan& P, const std::vector<int>& tab, int gx, in
 int vo_orb_pyramid_plan(vo_ctx* c, const std::vector<int>& tab) {
     const DevPlan& P = c->plan;
     c->pyr_gx = 0; c->pyr_gy = 0;
-    if (P.L < 2 || getenv("VO_NO_PYRAMID_KERNEL")) return VO_OK;
+    if (P.L < 2) return VO_OK;
     std::vector<PyrRng> rng;
     for (int shrink = 0; shrink < 4; ++shrink) {               // 128 x 60 pixel tiles of level 0 at 640 x 480; smaller ones if the halo of a deep pyramid does not fit
         const int gx = std::max(1, (P.W + 127) / 128) + shrink, gy = std::max(1, (P.H + 59) / 60) + 2 * shrink;
@@ -230,12 +230,12 @@ int vo_orb_pyramid_plan(vo_ctx* c, const std::vector<int>& tab) {
         if (hipMalloc((void**)&c->d_pyr_rng, rng.size() * sizeof(PyrRng)) != hipSuccess) { c->d_pyr_rng = nullptr; return VO_E_NOMEM; }
         HIP_TRY(hipMemcpy(c->d_pyr_rng, rng.data(), rng.size() * sizeof(PyrRng), hipMemcpyHostToDevice));
         c->pyr_gx = gx; c->pyr_gy = gy;
-        if (getenv("VO_TRACE")) {
+        if (vo_trace_level()) {
             size_t ma = 0, mb = 0;
             for (int t = 0; t < gx * gy; ++t) for (int l = 0; l < P.L; ++l) { const PyrRng& r = rng[(size_t)t * VO_MAX_LEVELS + l]; const size_t b = (size_t)((r.x1 - r.x0 + 3) & ~3) * (r.y1 - r.y0); if (l & 1) mb = std::max(mb, b); else ma = std::max(ma, b); }
             fprintf(stderr, "[vo_trace] k_pyramid: largest tile parts %zu / %zu bytes (buffers %d / %d)\n", ma, mb, PYR_BUF_A, PYR_BUF_B);
         }
-        if (getenv("VO_TRACE")) { const PyrRng& a = rng[0]; const PyrRng& b = rng[1]; fprintf(stderr, "[vo_trace] k_pyramid: %d x %d tiles per level; tile 0 needs %d x %d of level 0, %d x %d of level 1\n", gx, gy, a.x1 - a.x0, a.y1 - a.y0, b.x1 - b.x0, b.y1 - b.y0); }
+        if (vo_trace_level()) { const PyrRng& a = rng[0]; const PyrRng& b = rng[1]; fprintf(stderr, "[vo_trace] k_pyramid: %d x %d tiles per level; tile 0 needs %d x %d of level 0, %d x %d of level 1\n", gx, gy, a.x1 - a.x0, a.y1 - a.y0, b.x1 - b.x0, b.y1 - b.y0); }
         return VO_OK;
     }
     return VO_OK;                                            // no plan: vo_orb_launch keeps the level-by-level kernels
@@ -828,7 +828,7 @@ int vo_orb_upload_constants() {
 int vo_orb_launch(vo_ctx* c, int slot0, int n) {
     const DevPlan& P = c->plan;
     hipStream_t st = c->stream;
-    const int aff = (n >= 8 && !getenv("VO_NO_XCD_AFFINITY")) ? 1 : 0;      // frame-to-XCD affinity (see the file header)
+    const int aff = n >= 8 ? 1 : 0;      // frame-to-XCD affinity (see the file header)
     HIP_TRY(hipMemsetAsync(c->d_cand_cnt + (size_t)slot0 * VO_MAX_LEVELS, 0, sizeof(int) * VO_MAX_LEVELS * n, st));
     { ProfScope ps(c, "k_gray");
       const int per = (((P.W + 15) / 16) * P.H + 255) / 256;

@@ -1270,7 +1270,8 @@ int vo_track_lm_launch(vo_ctx* prof, hipStream_t st, const LaneDesc* dl, int nl,
     ProfScope ps(prof, "k_pose_lm", st);
     // workgroups per lane: one up to ~6 k inliers (a pass is then cheaper than a hand-off), one per 3 k beyond; all workgroups of the
     // launch must be resident at once, so the split is only taken while the grid stays far below the chip (2 per compute unit fit)
-    static const int force = getenv("VO_LM_WGS") ? atoi(getenv("VO_LM_WGS")) : 0;
+    const char* const force_s = getenv("VO_LM_WGS");       // tests: force the workgroups per lane (read per launch; tests/test_gpu_parity.py runs the hand-off form at small sizes)
+    const int force = force_s ? atoi(force_s) : 0;
     int nwg = force > 0 ? force : (inlier_hint > 6000 ? (inlier_hint + 2999) / 3000 : 1);
     nwg = std::max(1, std::min(std::min(nwg, LM_KMAX), 128 / std::max(1, nl)));
     hipLaunchKernelGGL(k_pose_lm, dim3(nwg, 1, nl), dim3(LM_T), LM_LDS_MAX * 20, st, dl, delta, cut, it_r, it_p, write_flags ? 1 : 0);

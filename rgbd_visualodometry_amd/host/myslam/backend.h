@@ -81,7 +81,6 @@ private:
     // The two hand-offs of an overlapped BA (tracker -> worker: a job; worker -> tracker: done / graph cut done) are on the latency chain that bounds a
     // single stream: both sides poll these counters for a few hundred microseconds before they sleep on the condition variable.
     std::atomic<int> workSeq_{0}, doneSeq_{0}, cutSeq_{0};
-    bool spin_ = true;
     template <typename Pred> void SpinThenWait(std::unique_lock<std::mutex>& lk, std::atomic<int>& seq, int seen, Pred pred);
     Stats stats_;
     void Build(Job& j, const Frame::Ptr& kf);

@@ -23,9 +23,7 @@ Backend::Backend(const Camera::Ptr camera) : camera_(camera) {
     // experiment key (not a reference setting): the reference never fixes a vertex (backend.cpp:49-59: setFixed(id == 0), ids start at 1), so
     // every local BA floats in its 6-dof gauge.  With this key the OLDEST keyframe of the free set is treated as fixed.
     if (Config::has("ba_fix_oldest_free_keyframe")) fixOldest_ = Config::get<int>("ba_fix_oldest_free_keyframe") != 0;
-    if (const char* e = std::getenv("VO_NO_SPIN")) spin_ = std::atoi(e) == 0;                    // A/B runs
     if (const char* e = std::getenv("VO_TEST_FAIL_CUT_AT")) testFailAt_ = std::atoi(e);
-    if (const char* e = std::getenv("VO_BA_FIX_OLDEST")) fixOldest_ = std::atoi(e) != 0;      // the same switch for drivers without a config file (scripts/exp_gauge.sh)
 }
 
 Backend::~Backend() { Stop(); if (ctxOwn_) vo_ctx_destroy(ctxOwn_); }
@@ -39,7 +37,6 @@ void Backend::EnsureWorker() {
         p.n_features = 64; p.max_frames = 1; p.map_capacity = 64; p.max_hypotheses = 1;
         p.stream_priority = -1;                         // problem preparation (graph cut, uploads, pair lists) in the lowest class: a pool of hardware queues of its own, away from
                                                         // the trackers' streams (default class) and from the pace-setting chains (highest class: BA engines, group chains)
-        if (const char* e = std::getenv("VO_BACKEND_PRIO")) p.stream_priority = std::atoi(e);      // experiments
         int rc = vo_ctx_create(&p, device_, &ctxOwn_);
         if (rc != VO_OK) throw std::runtime_error(std::string("vo_ctx_create (backend) failed: ") + vo_strerror(rc));
     }
@@ -57,7 +54,7 @@ void Backend::Stop() {
 
 // poll `seq` (it changes when the other side has something for us) for up to ~300 us with the lock released, then wait on the condition variable
 template <typename Pred> void Backend::SpinThenWait(std::unique_lock<std::mutex>& lk, std::atomic<int>& seq, int seen, Pred pred) {
-    if (spin_ && !pred()) {
+    if (!pred()) {
         lk.unlock();
         const auto t0 = std::chrono::steady_clock::now();
         for (int i = 0; seq.load(std::memory_order_acquire) == seen; ++i) {
@@ -150,7 +147,11 @@ void Backend::FinishOnDevice(Job& j, vo_ctx* solver) {
     if (pairA_.size() < 16384) { pairA_.resize(16384); pairB_.resize(16384); }
     j.posesOut.resize(12 * (size_t)std::max(j.nFree, 1));
     int32_t np = 0;
-    const int rc = vo_local_ba_resident_merge_ledger(solver, ctx_, pairA_.data(), pairB_.data(), (int)pairA_.size(), &np, j.posesOut.data(), j.nFree);
+    int rc = vo_local_ba_resident_merge_ledger(solver, ctx_, pairA_.data(), pairB_.data(), (int)pairA_.size(), &np, j.posesOut.data(), j.nFree);
+    if (rc == VO_E_OVERFLOW && np > (int)pairA_.size()) {       // more decrements than the arrays hold (a noisy graph: culled observations x co-observers): the call says how many, the repeated call delivers them
+        pairA_.resize((size_t)np + 1024); pairB_.resize((size_t)np + 1024);
+        rc = vo_local_ba_resident_merge_ledger(solver, ctx_, pairA_.data(), pairB_.data(), (int)pairA_.size(), &np, j.posesOut.data(), j.nFree);
+    }
     if (rc != VO_OK) throw std::runtime_error(std::string("vo_local_ba_resident_merge_ledger failed: ") + vo_strerror(rc));
     for (int i = 0; i < np; ++i) {
         Frame* a = (size_t)pairA_[i] < map.kfByIndex_.size() ? map.kfByIndex_[pairA_[i]] : nullptr;

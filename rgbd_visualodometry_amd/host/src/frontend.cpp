@@ -48,7 +48,6 @@ void FrontEnd::Init(int device, int width, int height, int max_frames) {
     reobserveNew_ = cfg_or<int>("reobserve_new_mappoints", 0) != 0;
     deviceDescriptors_ = cfg_or<int>("map_descriptors_on_device", 0) != 0;
     deviceKeyframes_ = cfg_or<int>("device_keyframes", 0) != 0;
-    if (const char* e = std::getenv("VO_DEVICE_KEYFRAMES")) deviceKeyframes_ = std::atoi(e) != 0;      // experiments / A-B runs
     params_.max_frames = lookahead_ + (reobserveNew_ ? 1 : 0);
     scratchSlot_ = reobserveNew_ ? lookahead_ : -1;
     params_.map_capacity = cfg_or<int>("map_capacity", 1 << 22);      // 4 Mi map points to start with (~100 bytes each + 49 per tracking lane); vo_keyframe_commit doubles the arrays when a keyframe may not fit
@@ -475,6 +474,12 @@ void FrontEnd::CommitKeyframeOnDevice() {
     const int rc = vo_keyframe_commit(ctx_, curLane_, frameCurr_->slot_, frameCurr_->kfIndex_, T, map.NextSlot(), covisKf_.data(), covisW_.data(), (int)covisKf_.size(), &r);
     if (rc == VO_E_OVERFLOW) throw std::runtime_error("device map / observation tables full (raise map_capacity; device_keyframes keeps no host map to fall back to)");
     vo_check(rc, "vo_keyframe_commit");
+    if (r.n_covisible_total > r.n_covisible) {               // more partners than the arrays (or the library's pinned block) hold: recount this keyframe's row from the tables
+        covisKf_.resize((size_t)r.n_covisible_total + 64); covisW_.resize(covisKf_.size());
+        int32_t n = 0;
+        vo_check(vo_kf_covisibility(ctx_, frameCurr_->kfIndex_, covisKf_.data(), covisW_.data(), (int)covisKf_.size(), &n), "vo_kf_covisibility");
+        r.n_covisible = n;
+    }
     map.ReserveSlots(r.n_new);
     for (int i = 0; i < r.n_covisible; ++i) {                // allCovisibleKeyframeIdToWeight_ / activeCovisibleKeyframes_ of both sides (src/frame.cpp:104-119, :157-171)
         Frame* partner = (size_t)covisKf_[i] < map.kfByIndex_.size() ? map.kfByIndex_[covisKf_[i]] : nullptr;

@@ -307,7 +307,7 @@ int myslam_get_stats(myslam_system* s, myslam_stats* st) {
     st->frames = f.frames; st->keyframes = f.keyframes; st->lost = f.lost; st->state = (int)s->frontend->GetState();
     st->last_keypoints = f.last_keypoints; st->last_candidates = f.last_candidates; st->last_matches = f.last_matches;
     st->ms_extract = f.ms_extract; st->ms_track = f.ms_track; st->ms_keyframe = f.ms_keyframe; st->ms_backend = f.ms_backend;
-    if (getenv("VO_TRACE")) fprintf(stderr, "[vo_trace] frontend ms: extract %.1f track %.1f (refresh %.1f flush %.1f) keyframe %.1f backend %.1f\n", f.ms_extract, f.ms_track, f.ms_refresh, f.ms_flush, f.ms_keyframe, f.ms_backend);
+    if (myslam::TraceScope::on()) fprintf(stderr, "[vo_trace] frontend ms: extract %.1f track %.1f (refresh %.1f flush %.1f) keyframe %.1f backend %.1f\n", f.ms_extract, f.ms_track, f.ms_refresh, f.ms_flush, f.ms_keyframe, f.ms_backend);
     st->tracked_frames = f.tracked; st->sum_active = f.sum_active; st->sum_candidates = f.sum_cand; st->sum_matches = f.sum_match; st->sum_ransac_inliers = f.sum_ransac;
     st->sum_lm_inliers = f.sum_lm; st->sum_lm_iters = f.sum_lm_iters; st->track_launches = f.track_launches;
     st->triangulated = f.triangulated; st->reobserved_matches = f.reobserved;
@@ -316,7 +316,7 @@ int myslam_get_stats(myslam_system* s, myslam_stats* st) {
         const auto& b = s->backend->GetStats();
         st->ba_runs = b.runs; st->ba_poses = b.poses; st->ba_fixed = b.fixed; st->ba_points = b.points; st->ba_edges = b.edges; st->ba_outliers = b.outliers; st->ba_ms = b.ms; st->ba_failed = b.failed; st->ba_capped = b.capped;
         st->ba_sum_d3 = b.sum_d3; st->ba_sum_d2 = b.sum_d2; st->ba_sum_edges = b.sum_edges;
-        if (getenv("VO_TRACE")) fprintf(stderr, "[vo_trace] BA runs %d build %.2f ms solve %.2f ms wait %.2f ms (%d waits: solve done -> tracker awake %.1f us, awake -> merge launched %.1f us per wait)\n", b.runs, b.ms_build, b.ms_solve, b.ms_wait, b.waited, b.waited ? 1e3 * b.ms_wake / b.waited : 0.0, b.waited ? 1e3 * b.ms_to_merge / b.waited : 0.0);
+        if (myslam::TraceScope::on()) fprintf(stderr, "[vo_trace] BA runs %d build %.2f ms solve %.2f ms wait %.2f ms (%d waits: solve done -> tracker awake %.1f us, awake -> merge launched %.1f us per wait)\n", b.runs, b.ms_build, b.ms_solve, b.ms_wait, b.waited, b.waited ? 1e3 * b.ms_wake / b.waited : 0.0, b.waited ? 1e3 * b.ms_to_merge / b.waited : 0.0);
     }
     if (myslam::TraceScope::on()) myslam::TraceScope::dump();
     return 0;

@@ -60,7 +60,7 @@ std::mutex g_trace_mu;
 std::vector<TraceRow> g_trace_rows;
 }  // namespace
 
-bool TraceScope::on() { static const bool v = getenv("VO_TRACE") != nullptr; return v; }
+bool TraceScope::on() { return vo_trace_level() != 0; }
 void TraceScope::add(const char* name, double ms) {
     std::lock_guard<std::mutex> lk(g_trace_mu);
     for (auto& r : g_trace_rows) if (r.name == name || !strcmp(r.name, name)) { r.ms += ms; ++r.calls; return; }

@@ -201,7 +201,7 @@ def _ledger_scene(L):
     return t, c, nX, nK
 
 
-def _merge_ledger_against_definition(L):
+def _merge_ledger_against_definition(L, cap_pairs=1 << 16):
     t, c, nX, nK = _ledger_scene(L)
     before = t.tables(nX)
     w_before = {k: t.kf_covisibility(k) for k in range(nK)}
@@ -213,7 +213,7 @@ def _merge_ledger_against_definition(L):
     L.check(L.lib.vo_local_ba_resident_solve(c.h, 10, 10, capi.C.byref(r)), "solve")
     culled = sorted(int(v) for v in cu[:r.n_culled])
     assert len(culled) >= 6
-    pairs, poses = c.merge_ledger(t, nK)
+    pairs, poses = c.merge_ledger(t, nK, cap_pairs=cap_pairs)
     after = t.tables(nX)
     # definition (src/frame.cpp:122-152, one removal after the other): the keyframes that still see the point lose one shared point with the culled one's keyframe
     alive = before["obs_alive"].copy(); want = []
@@ -245,7 +245,47 @@ def _merge_ledger_against_definition(L):
 
 
 def test_merge_ledger_follows_the_definition_on_the_restatement():
-    _merge_ledger_against_definition(capi.load(ORACLE_LIB))
+    a = _merge_ledger_against_definition(capi.load(ORACLE_LIB))
+    b = _merge_ledger_against_definition(capi.load(ORACLE_LIB), cap_pairs=3)      # too short: VO_E_OVERFLOW + the number needed, the repeated call delivers (include/vo_hip.h)
+    assert a["pairs"] == b["pairs"] and len(a["pairs"]) > 3 and np.array_equal(a["alive"], b["alive"]) and np.array_equal(a["flags"], b["flags"])
+
+
+def _noisy_merge(L, cap_pairs):
+    """A graph whose culls cost the ledger more decrements than the library's pinned block holds (16 Ki): 30 keyframes see 600 points, every seventh
+    observation is grossly wrong.  ADVICE r5: with the reference's chi2 threshold of 1 a real sequence culls a large share of its edges."""
+    rng = np.random.default_rng(29)
+    nK, nX = 30, 600
+    p = L.default_params(map_capacity=1024)
+    t = L.context(p); c = L.context(L.default_params(map_capacity=64))
+    X = rng.uniform(-2.0, 2.0, (nX, 3)) * [1.0, 0.6, 1.0] + [0, 0, 6.0]
+    poses = np.tile(I12, (nK, 1)); poses[:, 9] = 0.03 * (np.arange(nK) - nK / 2)
+    t.map_upsert(np.arange(nX, dtype=np.int32), X + rng.normal(size=X.shape) * 0.01, np.tile([0, 0, 1.0], (nX, 1)), np.zeros((nX, 32), np.uint8), np.zeros(nX, np.uint8))
+    t.kf_set_pose(np.arange(nK), poses)
+    for k in range(nK):
+        uv = []
+        for x in range(nX):
+            pc = X[x] + poses[k][9:]
+            bad = (x * 31 + k * 17) % 7 == 0
+            uv.append([p.fx * pc[0] / pc[2] + p.cx + rng.normal() * 0.2 + (25.0 + (x % 13) if bad else 0.0), p.fy * pc[1] / pc[2] + p.cy + rng.normal() * 0.2 - (18.0 if bad else 0.0)])
+        t.obs_append([k] * nX, list(range(nX)), uv)
+    nx, nfx, ne = (capi.C.c_int32() for _ in range(3))
+    f = np.arange(nK, dtype=np.int32)
+    L.check(L.lib.vo_local_ba_resident_cut(c.h, t.h, f.ctypes.data, nK, 7.815 ** 0.5, 1.0, capi.C.byref(nx), capi.C.byref(nfx), capi.C.byref(ne)), "cut")
+    cu = np.zeros(1 << 16, np.int64)
+    r = capi.VoBaResidentResult(None, None, None, cu.ctypes.data, 0, 1 << 16)
+    L.check(L.lib.vo_local_ba_resident_solve(c.h, 10, 10, capi.C.byref(r)), "solve")
+    pairs, kfposes = c.merge_ledger(t, nK, cap_pairs=cap_pairs)
+    after = t.tables(nX)
+    w = {k: t.kf_covisibility(k) for k in range(nK)}
+    t.close(); c.close()
+    return {"n_culled": r.n_culled, "culled": sorted(int(v) for v in cu[:r.n_culled]), "pairs": pairs, "alive": after["obs_alive"], "flags": after["flags"], "covis": w}
+
+
+def test_a_merge_with_more_ledger_decrements_than_the_arrays_hold_on_the_restatement():
+    a = _noisy_merge(capi.load(ORACLE_LIB), 1 << 20)
+    b = _noisy_merge(capi.load(ORACLE_LIB), 100)
+    assert a["n_culled"] > 1500 and len(a["pairs"]) > 20000
+    assert a["pairs"] == b["pairs"] and np.array_equal(a["alive"], b["alive"]) and np.array_equal(a["flags"], b["flags"]) and a["covis"] == b["covis"]
 
 
 def test_the_device_map_grows_on_the_restatement(stream):
@@ -298,8 +338,21 @@ def test_keyframe_commit_hip_follows_the_definitions_and_the_restatement(stream)
 
 
 @pytest.mark.gpu
+def test_a_merge_with_more_ledger_decrements_than_the_pinned_block_holds_hip():
+    """more than 16 Ki covisibility decrements in one BA merge used to end the run.  Now the pairs are paged out over ranges of the
+    culled list (the marks stay until the last page) -- in one call when the caller's arrays are long enough, in a repeated call when they are not."""
+    o = _noisy_merge(capi.load(ORACLE_LIB), 1 << 20)
+    assert len(o["pairs"]) > 20000                              # > KF_PAIR_CAP (csrc/vo_kf.hip)
+    for cap in (1 << 20, 100):
+        h = _noisy_merge(capi.load(capi.HIP_LIB), cap)
+        assert h["culled"] == o["culled"] and h["pairs"] == o["pairs"]
+        assert np.array_equal(h["alive"], o["alive"]) and np.array_equal(h["flags"], o["flags"]) and h["covis"] == o["covis"]
+
+
+@pytest.mark.gpu
 def test_merge_ledger_hip_follows_the_definition_and_the_restatement():
     a = _merge_ledger_against_definition(capi.load(capi.HIP_LIB))
+    assert _merge_ledger_against_definition(capi.load(capi.HIP_LIB), cap_pairs=3)["pairs"] == a["pairs"]      # VO_E_OVERFLOW + the repeated call
     b = _merge_ledger_against_definition(capi.load(ORACLE_LIB))
     assert a["pairs"] == b["pairs"] and a["culled"] == b["culled"] and np.array_equal(a["flags"], b["flags"]) and np.array_equal(a["alive"], b["alive"])
     np.testing.assert_allclose(a["poses"], b["poses"], atol=1e-6, rtol=0)      # (a free-gauge toy BA with gross outliers: the tolerance of the BA parity tests)
@@ -367,7 +420,7 @@ def test_device_keyframes_in_a_stream_group(stream):
 def test_empty_graph_cuts_hip():
     _empty_cuts(capi.load(capi.HIP_LIB))
 
-def _wide_cut(L, nK, nX, n_free):
+def _wide_cut(L, nK, nX, n_free, slab_budget=None):
     """A resident cut + solve + merge with many keyframes: nK keyframes on a line see nX points (each point from a window of keyframes), the first
     n_free are free, the others that see a point of the graph are fixed.  Returns what the merge left in the tables."""
     rng = np.random.default_rng(17)
@@ -386,6 +439,8 @@ def _wide_cut(L, nK, nX, n_free):
         t.obs_append([k] * len(xs), xs, uv)
     nx, nfx, ne = (capi.C.c_int32() for _ in range(3))
     f = np.arange(n_free, dtype=np.int32)
+    if slab_budget is not None:
+        c.resident_set_slab_budget(slab_budget)
     L.check(L.lib.vo_local_ba_resident_cut(c.h, t.h, f.ctypes.data, n_free, 7.815 ** 0.5, 1.0, capi.C.byref(nx), capi.C.byref(nfx), capi.C.byref(ne)), "cut")
     cu = np.zeros(65536, np.int64)
     r = capi.VoBaResidentResult(None, None, None, cu.ctypes.data, 0, 65536)
@@ -398,9 +453,10 @@ def _wide_cut(L, nK, nX, n_free):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nK,nX,n_free", [(12, 300, 1), (44, 900, 36), (70, 1500, 60)])
+@pytest.mark.parametrize("nK,nX,n_free", [(12, 300, 1), (44, 900, 36), (70, 1500, 60), (115, 2000, 100), (170, 2400, 150)])
 def test_wide_resident_cuts_match_the_restatement(nK, nX, n_free):
-    """D = 6, 216 and 360 unknowns: a single free pose, and the reduced systems beyond the LDS-resident Cholesky (the pair plan with gaps feeds the first-generation Schur kernel there)."""
+    """D = 6, 216, 360, 600 and 900 unknowns against the CPU restatement: a single free pose, and the reduced systems beyond the LDS-resident Cholesky (the pair plan
+    with gaps feeds the first-generation Schur kernel and k_ba_chol16g there; reference src/backend.cpp:36-59 has no cap on the free set, the ABI admits 160)."""
     h = _wide_cut(capi.load(capi.HIP_LIB), nK, nX, n_free)
     o = _wide_cut(capi.load(ORACLE_LIB), nK, nX, n_free)
     assert h["sizes"] == o["sizes"] and h["sizes"][0] > 0 and h["sizes"][2] > 0
@@ -408,6 +464,25 @@ def test_wide_resident_cuts_match_the_restatement(nK, nX, n_free):
     assert np.array_equal(h["flags"], o["flags"])
     assert abs(h["chi"][0] - o["chi"][0]) <= 1e-9 * max(1.0, abs(o["chi"][0])) and abs(h["chi"][1] - o["chi"][1]) <= 1e-6 * max(1.0, abs(o["chi"][1]))
     assert np.abs(h["poses"] - o["poses"]).max() < 1e-6 and np.abs(h["xyz"] - o["xyz"]).max() < 1e-5
+
+
+@pytest.mark.gpu
+def test_a_cut_over_its_slab_budget_waits_for_the_sizes_and_gives_the_same_graph():
+    """vo_ba_resident_set_slab_budget: the cut carves its slab for upper bounds of the graph's sizes unless those exceed the budget; then it waits
+    for the sizes and carves exactly.  A budget of one byte forces that order: same sizes, same culls, same result as the bound-sized cut and as the restatement."""
+    L = capi.load(capi.HIP_LIB)
+    a = _wide_cut(L, 44, 900, 20)
+    b = _wide_cut(L, 44, 900, 20, slab_budget=1)
+    o = _wide_cut(capi.load(ORACLE_LIB), 44, 900, 20, slab_budget=1)
+    for x in (a, b):
+        assert x["sizes"] == o["sizes"] and x["n_culled"] == o["n_culled"] and np.array_equal(x["flags"], o["flags"])
+        assert np.abs(x["poses"] - o["poses"]).max() < 1e-6 and np.abs(x["xyz"] - o["xyz"]).max() < 1e-5
+    with pytest.raises(capi.VoError):
+        c = L.context(L.default_params(map_capacity=64))
+        try:
+            c.resident_set_slab_budget(0)
+        finally:
+            c.close()
 
 
 @pytest.mark.gpu

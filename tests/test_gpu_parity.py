@@ -228,9 +228,11 @@ def test_config5_sizes_orb_and_tracking_match_oracle(libs):
 
 
 # D = 6 nfree: 24 (one 16-column panel + partial), 96 (full panels only), 180 (partial last panel), 192 (LDS-resident limit),
-# 216 (> limit: matrix in L2); 1300 points -> > 20000 edges (threaded pair-list build); shuffle: edges not sorted by point
+# 216 (> limit: matrix in L2), 600 and 900 (k_ba_chol16g on the sizes between the tests of round 5 and the 960 the ABI admits; host-built pair lists);
+# 1300 points -> > 20000 edges (threaded pair-list build); shuffle: edges not sorted by point
 @pytest.mark.parametrize("nP,nX,nfree,shuffle", [(6, 400, 4, False), (18, 300, 16, False), (34, 500, 30, False), (34, 300, 32, True),
-                                                  (40, 500, 36, False), (34, 1300, 30, False), (26, 9000, 21, False)])      # last: config-5 scale, ~160 k edges
+                                                  (40, 500, 36, False), (34, 1300, 30, False), (26, 9000, 21, False),      # config-5 scale, ~160 k edges
+                                                  (108, 400, 100, False), (158, 300, 150, False)])
 @pytest.mark.parametrize("fuse", ["1", "0"])                 # 1: Cholesky + update in one launch (k_ba_cholup, the default), 0: launched apart (k_ba_chol16v2, k_ba_upchi2)
 def test_local_ba_matches_oracle(libs, nP, nX, nfree, shuffle, fuse, monkeypatch):
     monkeypatch.setenv("VO_BA_FUSE_MAX", fuse)             # (read per chunk of steps: csrc/vo_ba.hip, ba_engine_enqueue)
