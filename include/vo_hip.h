@@ -274,6 +274,26 @@ int vo_set_hypothesis_shard(vo_ctx* ctx, int rank, int world, vo_exchange_fn exc
 typedef int (*vo_stream_allreduce_fn)(void* comm, int32_t* device_counts, size_t n, void* hip_stream);
 int vo_set_hypothesis_shard_stream(vo_ctx* ctx, int rank, int world, vo_stream_allreduce_fn allreduce, void* comm);
 
+/* ---- local BA sharded over ranks (last sentence; BASELINE config 5) -------- */
+/* Several processes (one per GPU) hold the SAME local-BA problem (Backend::Optimize, reference src/backend.cpp:19-195) and call vo_local_ba
+ * with identical arguments; each linearises only the edges of ITS map points (point k belongs to rank k % world: a point's 3x3 block, its
+ * edges and its pairs of the Schur complement are one rank's), and per LM step the ranks exchange
+ *   1. the pose blocks H_pp, b_p, the robust chi2 of the linearisation (+ per-rank maxima for lambda_0)      36 n_free + D + 2 + world doubles
+ *   2. the reduced system: S (D x D, row-major) and b_s -- the all-reduce SURVEY 8e names (115 KB at D = 120)   D^2 + D doubles
+ *   3. the trial state's chi2, the gain ratio's denominator and the per-rank largest step                      2 + world doubles
+ * as element-wise SUMs in place; every rank then factors the same S, takes the same LM decision and moves the free poses identically, so the
+ * ranks stay in lockstep without a broadcast.  Points and edge flags are one rank's each; a last exchange (3 n_points + n_edges + 2 doubles) hands
+ * every rank the whole result: poses, points, edge_flags and the chi2 values of the un-sharded call up to the summation order (tests: 1e-6 on
+ * poses, identical flags).  The exchanges are latency-bound (20 LM steps x 3): the mode is opt-in, for problems whose linearisation dominates
+ * (config 5: 160 k edges).  Every system takes the launch-per-phase step with S in global memory here (k_ba_chol16g), whatever its size.
+ * `exchange` works on a HOST buffer (gloo / MPI); the _stream form must only ENQUEUE an in-place f64 SUM of n device-resident doubles on hip_stream --
+ * for RCCL: ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, (ncclComm_t)comm, (hipStream_t)hip_stream).  world <= 1 switches sharding off; setting one
+ * form clears the other.  vo_local_ba_resident (the device graph cut) is not sharded: VO_E_UNSUPPORTED while a BA shard is set. */
+typedef void (*vo_exchange_f64_fn)(void* user, double* data, int n);
+int vo_set_ba_shard(vo_ctx* ctx, int rank, int world, vo_exchange_f64_fn exchange, void* user);
+typedef int (*vo_stream_allreduce_f64_fn)(void* comm, double* device_data, size_t n, void* hip_stream);
+int vo_set_ba_shard_stream(vo_ctx* ctx, int rank, int world, vo_stream_allreduce_f64_fn allreduce, void* comm);
+
 /* ---- batched triangulation -------------------------------------------------------------- */
 /* Linear N-view triangulation (reference include/myslam/util.h:16-34) of MANY map points in one launch, as applied by
  * FrontEnd::TriangulateMappointsInTrackingMap (src/frontend.cpp:465-506) to the LM inliers of a keyframe: point i owns the

@@ -19,7 +19,10 @@ struct BA {
     std::vector<SE3> pose; std::vector<V3> pt;
     std::vector<uint8_t> active;                    // per edge (level 0)
     std::vector<int> pt_start, pt_edges;            // CSR point -> edges
+    const BaShard* sh = nullptr;                    // e-3: this rank's share (its points' edges are the active ones); the three exchanges per LM step make the shares one system
     BA(const Cam& c, const vo_ba_problem& p) : cam(c), in(p) {}
+    bool mine(int k) const { return !sh || k % sh->world == sh->rank; }
+    void xsum(std::vector<double>& v) const { if (sh) sh->exchange(sh->user, v.data(), (int)v.size()); }
 
     void err(int e, const SE3& T, V3 p, double r[2], V3& pc) const {
         pc = T * p;
@@ -42,7 +45,7 @@ struct BA {
         const int nf = in.n_free, np = in.n_points, ne = in.n_edges, D = 6 * nf;
         int nact = 0;
         for (int e = 0; e < ne; ++e) nact += active[e];
-        if (!nact || nf == 0) return 0;
+        if ((!nact && !sh) || nf == 0) return 0;          // (a sharded rank without active edges of its own still takes part in the exchanges)
         double lambda = 0, ni = 2;
         std::vector<double> Hpp((size_t)D * D), bp(D), Hll((size_t)9 * np), bl((size_t)3 * np), W((size_t)18 * ne);
         int it = 0;
@@ -76,10 +79,22 @@ struct BA {
                     }
                 }
             }
+            double md_ll = 0;
+            if (it == 0) for (int k = 0; k < np; ++k) for (int a = 0; a < 3; ++a) md_ll = std::max(md_ll, std::fabs(Hll[9 * (size_t)k + 4 * a]));
+            if (sh) {                                       // exchange 1: the pose blocks, b_p, the chi2 of the linearisation, every rank's largest point-block entry
+                std::vector<double> x((size_t)36 * nf + D + 1 + sh->world, 0.0);
+                for (int j = 0; j < nf; ++j) for (int a = 0; a < 6; ++a) for (int c_ = 0; c_ < 6; ++c_) x[36 * (size_t)j + 6 * a + c_] = Hpp[(size_t)(6 * j + a) * D + 6 * j + c_];
+                for (int i = 0; i < D; ++i) x[36 * (size_t)nf + i] = bp[i];
+                x[36 * (size_t)nf + D] = cur; x[36 * (size_t)nf + D + 1 + sh->rank] = md_ll;
+                xsum(x);
+                for (int j = 0; j < nf; ++j) for (int a = 0; a < 6; ++a) for (int c_ = 0; c_ < 6; ++c_) Hpp[(size_t)(6 * j + a) * D + 6 * j + c_] = x[36 * (size_t)j + 6 * a + c_];
+                for (int i = 0; i < D; ++i) bp[i] = x[36 * (size_t)nf + i];
+                cur = x[36 * (size_t)nf + D];
+                for (int r = 0; r < sh->world; ++r) md_ll = std::max(md_ll, x[36 * (size_t)nf + D + 1 + r]);
+            }
             if (it == 0) {
-                double md = 0;
+                double md = md_ll;
                 for (int i = 0; i < D; ++i) md = std::max(md, std::fabs(Hpp[(size_t)i * D + i]));
-                for (int k = 0; k < np; ++k) for (int a = 0; a < 3; ++a) md = std::max(md, std::fabs(Hll[9 * (size_t)k + 4 * a]));
                 lambda = 1e-5 * md; ni = 2;
             }
             double rho = 0; int qmax = 0; bool converged = false;
@@ -87,6 +102,7 @@ struct BA {
                 // Schur complement on the points
                 std::vector<double> S = Hpp, bs = bp, Hinv((size_t)9 * np), dl((size_t)3 * np);
                 for (int i = 0; i < D; ++i) S[(size_t)i * D + i] += lambda;
+                if (sh && sh->rank > 0) { std::fill(S.begin(), S.end(), 0.0); std::fill(bs.begin(), bs.end(), 0.0); }      // (H_pp, b_p and lambda enter the summed system once, through rank 0)
                 bool ok = true;
                 for (int k = 0; k < np; ++k) {
                     double a[9];
@@ -118,10 +134,15 @@ struct BA {
                         }
                     }
                 }
+                if (sh) {                                   // exchange 2: the reduced system
+                    std::vector<double> x(S); x.insert(x.end(), bs.begin(), bs.end());
+                    xsum(x);
+                    std::copy(x.begin(), x.begin() + (size_t)D * D, S.begin()); std::copy(x.begin() + (size_t)D * D, x.end(), bs.begin());
+                }
                 std::vector<double> dp = bs;
                 ok = chol_solve(D, S.data(), dp.data());
                 std::vector<SE3> Pn = pose; std::vector<V3> Xn = pt;
-                double tmp = DBL_MAX, scale = 1e-3;
+                double tmp = DBL_MAX, scale = 1e-3, tmp_pts_scale = 0;
                 if (ok) {
                     for (int k = 0; k < np; ++k) {
                         double rhs[3] = {bl[3 * k], bl[3 * k + 1], bl[3 * k + 2]};
@@ -138,7 +159,19 @@ struct BA {
                     for (int k = 0; k < np; ++k) Xn[k] = pt[k] + V3(dl[3 * k], dl[3 * k + 1], dl[3 * k + 2]);  // :121-125
                     tmp = chi(robust, Pn, Xn);
                     for (int i = 0; i < D; ++i) scale += dp[i] * (lambda * dp[i] + bp[i]);
-                    for (int i = 0; i < 3 * np; ++i) scale += dl[i] * (lambda * dl[i] + bl[i]);
+                    double sc_pts = 0;
+                    for (int i = 0; i < 3 * np; ++i) sc_pts += dl[i] * (lambda * dl[i] + bl[i]);
+                    if (!sh) scale += sc_pts;
+                    else tmp_pts_scale = sc_pts;
+                }
+                double mx_pts = 0;
+                if (ok) for (int i = 0; i < 3 * np; ++i) mx_pts = std::max(mx_pts, std::fabs(dl[i]));
+                if (sh) {                                   // exchange 3: the trial state's chi2, the points' part of the gain ratio's denominator, every rank's largest point step
+                    std::vector<double> x(2 + (size_t)sh->world, 0.0);
+                    x[0] = ok ? tmp : 0.0; x[1] = ok ? tmp_pts_scale : 0.0; x[2 + sh->rank] = mx_pts;
+                    xsum(x);
+                    if (ok) { tmp = x[0]; scale += x[1]; }
+                    for (int r = 0; r < sh->world; ++r) mx_pts = std::max(mx_pts, x[2 + r]);
                 }
                 rho = (cur - tmp) / scale;
                 if (rho > 0 && std::isfinite(tmp)) {
@@ -147,9 +180,8 @@ struct BA {
                     lambda *= std::max(1.0 / 3.0, a); ni = 2; cur = tmp; pose.swap(Pn); pt.swap(Xn);
                 } else { lambda *= ni; ni *= 2; }
                 if (ok) {
-                    double mx = 0;
+                    double mx = mx_pts;
                     for (int i = 0; i < D; ++i) mx = std::max(mx, std::fabs(dp[i]));
-                    for (int i = 0; i < 3 * np; ++i) mx = std::max(mx, std::fabs(dl[i]));
                     converged = mx < 1e-10;
                 }
                 ++qmax;
@@ -162,7 +194,7 @@ struct BA {
 
 }  // namespace
 
-int local_ba(const Cam& cam, const vo_ba_problem& in, vo_ba_result& out) {
+int local_ba(const Cam& cam, const vo_ba_problem& in, vo_ba_result& out, const BaShard* shard) {
     if (in.n_free < 0 || in.n_free > in.n_poses || in.n_points < 0 || in.n_edges < 0) return VO_E_INVALID;
     BA ba(cam, in);
     ba.pose.resize(in.n_poses); ba.pt.resize(in.n_points);
@@ -171,6 +203,7 @@ int local_ba(const Cam& cam, const vo_ba_problem& in, vo_ba_result& out) {
     for (int e = 0; e < in.n_edges; ++e)
         if (in.edge_pose[e] < 0 || in.edge_pose[e] >= in.n_poses || in.edge_point[e] < 0 || in.edge_point[e] >= in.n_points) return VO_E_INVALID;
     ba.active.assign(in.n_edges, 1);
+    if (shard && shard->world > 1) { ba.sh = shard; for (int e = 0; e < in.n_edges; ++e) ba.active[e] = ba.mine(in.edge_point[e]) ? 1 : 0; }
     ba.pt_start.assign(in.n_points + 1, 0);
     for (int e = 0; e < in.n_edges; ++e) ba.pt_start[in.edge_point[e] + 1]++;
     for (int k = 0; k < in.n_points; ++k) ba.pt_start[k + 1] += ba.pt_start[k];
@@ -184,6 +217,7 @@ int local_ba(const Cam& cam, const vo_ba_problem& in, vo_ba_result& out) {
         double r[2]; V3 pc;
         ba.err(e, ba.pose[in.edge_pose[e]], ba.pt[in.edge_point[e]], r, pc);
         out.edge_flags[e] = 0;
+        if (!ba.mine(in.edge_point[e])) continue;
         if (r[0] * r[0] + r[1] * r[1] > in.chi2_th) { out.edge_flags[e] |= 1; ba.active[e] = 0; }
     }
     out.lm_iters += ba.optimize(false, in.it_plain);                       // backend.cpp:158-159
@@ -196,6 +230,17 @@ int local_ba(const Cam& cam, const vo_ba_problem& in, vo_ba_result& out) {
     }
     for (int j = 0; j < in.n_free; ++j) ba.pose[j].to12(out.poses + 12 * (size_t)j);
     for (int k = 0; k < in.n_points; ++k) { out.points[3 * k] = ba.pt[k].x; out.points[3 * k + 1] = ba.pt[k].y; out.points[3 * k + 2] = ba.pt[k].z; }
+    if (ba.sh) {                                            // the last exchange: every rank gets the whole result (its own points / flags, zeros elsewhere, summed)
+        const size_t nx = (size_t)in.n_points, ne = (size_t)in.n_edges;
+        std::vector<double> x(3 * nx + ne + 2, 0.0);
+        for (size_t k = 0; k < nx; ++k) if (ba.mine((int)k)) for (int a = 0; a < 3; ++a) x[3 * k + a] = out.points[3 * k + a];
+        for (size_t e = 0; e < ne; ++e) if (ba.mine(in.edge_point[e])) x[3 * nx + e] = out.edge_flags[e];
+        x[3 * nx + ne] = out.chi2_initial; x[3 * nx + ne + 1] = out.chi2_final;
+        ba.xsum(x);
+        for (size_t i = 0; i < 3 * nx; ++i) out.points[i] = x[i];
+        for (size_t e = 0; e < ne; ++e) out.edge_flags[e] = (uint8_t)std::lrint(x[3 * nx + e]);
+        out.chi2_initial = x[3 * nx + ne]; out.chi2_final = x[3 * nx + ne + 1];
+    }
     return VO_OK;
 }
 

@@ -34,6 +34,7 @@ struct vo_ctx {
     bool async_pending = false; std::vector<vo_track_result> async_res;      // vo_track_batch_begin / _end
     std::vector<int32_t> ransac_inliers;
     HypShard shard;
+    BaShard ba_shard;
     // observation table: keyframe number, map slot, pixel, alive; keyframe poses
     std::vector<int32_t> obs_kf, obs_mp; std::vector<float> obs_uv; std::vector<uint8_t> obs_alive;
     std::vector<double> kf_pose;
@@ -731,8 +732,14 @@ int vo_group_stats(vo_group* g, int64_t* chains, int64_t* lanes, int64_t* reques
 
 int vo_local_ba(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     if (!c || !in || !out || !out->poses || !out->points || !out->edge_flags) return VO_E_INVALID;
-    return local_ba(c->cam, *in, *out);
+    return local_ba(c->cam, *in, *out, c->ba_shard.world > 1 ? &c->ba_shard : nullptr);
 }
+int vo_set_ba_shard(vo_ctx* c, int rank, int world, vo_exchange_f64_fn fn, void* user) {
+    if (!c || world < 0 || world > 64 || (world > 1 && (rank < 0 || rank >= world || !fn))) return VO_E_INVALID;
+    c->ba_shard.rank = world > 1 ? rank : 0; c->ba_shard.world = world > 1 ? world : 1; c->ba_shard.exchange = world > 1 ? fn : nullptr; c->ba_shard.user = user;
+    return VO_OK;
+}
+int vo_set_ba_shard_stream(vo_ctx*, int, int, vo_stream_allreduce_f64_fn, void*) { return VO_E_UNSUPPORTED; }      // no streams on the CPU
 
 int vo_sync(vo_ctx*) { return VO_OK; }
 int vo_profile_enable(vo_ctx*, int) { return VO_OK; }

@@ -48,7 +48,9 @@ struct LmOut { SE3 T; std::vector<uint8_t> inlier_mask; int iters = 0; double ch
 void pose_lm(const Cam& cam, const Corr& c, const std::vector<int32_t>& edges, const SE3& T0, double huber_delta,
              double chi2_cut, int it_robust, int it_plain, LmOut& out);
 
-int local_ba(const Cam& cam, const vo_ba_problem& in, vo_ba_result& out);
+// e-3 (include/vo_hip.h: vo_set_ba_shard): this rank linearises the edges of the points k % world == rank; `exchange` sums n doubles over the ranks in place
+struct BaShard { int rank = 0, world = 1; void (*exchange)(void*, double*, int) = nullptr; void* user = nullptr; };
+int local_ba(const Cam& cam, const vo_ba_problem& in, vo_ba_result& out, const BaShard* shard = nullptr);
 
 // linear N-view triangulation of one point (reference include/myslam/util.h:16-34): smallest eigenvector of A^T A by cyclic Jacobi
 bool triangulate_point(int n_views, const double* T_cw, const double* xy, double xyz[3]);

@@ -76,7 +76,7 @@ SYMBOLS = ["vo_ctx_create", "vo_ctx_destroy", "vo_strerror", "vo_backend_name", 
            "vo_local_ba", "vo_sync", "vo_profile_enable", "vo_profile_read",
            "vo_group_create", "vo_group_destroy", "vo_group_join", "vo_group_leave", "vo_group_set_gather", "vo_group_stats",
            "vo_set_hypothesis_shard", "vo_set_hypothesis_shard_stream", "vo_triangulate_batch", "vo_kf_set_pose", "vo_obs_append", "vo_obs_kill", "vo_local_ba_resident",
-           "vo_local_ba_resident_cut", "vo_local_ba_resident_solve", "vo_local_ba_resident_merge", "vo_local_ba_resident_fetch", "vo_ba_resident_graph", "vo_ba_resident_window", "vo_ba_resident_set_slab_budget", "vo_trace_level",
+           "vo_local_ba_resident_cut", "vo_local_ba_resident_solve", "vo_local_ba_resident_merge", "vo_local_ba_resident_fetch", "vo_ba_resident_graph", "vo_ba_resident_window", "vo_ba_resident_set_slab_budget", "vo_trace_level", "vo_set_ba_shard", "vo_set_ba_shard_stream",
            "vo_keyframe_commit", "vo_kf_covisibility", "vo_map_set_active_covisible", "vo_local_ba_resident_merge_ledger", "vo_tables_fetch"]
 
 
@@ -84,6 +84,8 @@ VO_E_OVERFLOW = -4        # include/vo_hip.h: vo_status
 
 EXCHANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int32), C.c_int)     # vo_exchange_fn: in-place element-wise sum over the ranks
 STREAM_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.c_size_t, C.c_void_p)      # vo_stream_allreduce_fn: enqueue the sum on a HIP stream
+EXCHANGE_F64_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int)     # vo_exchange_f64_fn: in-place element-wise sum of doubles over the ranks (e-3)
+STREAM_ALLREDUCE_F64_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.c_void_p)      # vo_stream_allreduce_f64_fn
 
 
 class VoError(RuntimeError):
@@ -420,6 +422,22 @@ class VoContext:
             return int(enqueue_allreduce(C.cast(ptr, C.c_void_p).value, int(n), int(stream or 0)))
         self._keep["shard_scb"] = STREAM_ALLREDUCE_FN(_cb) if enqueue_allreduce is not None else STREAM_ALLREDUCE_FN(0)
         self.L.check(self.L.lib.vo_set_hypothesis_shard_stream(self.h, rank, world, self._keep["shard_scb"], None), "vo_set_hypothesis_shard_stream")
+
+    def set_ba_shard(self, rank: int, world: int, all_reduce_sum):
+        """e-3: vo_local_ba of this context works on the edges of the points k % world == rank; ``all_reduce_sum(np.float64 array)`` sums in place over
+        the ranks (three calls per LM step + one for the result).  world <= 1: off."""
+        def _cb(user, ptr, n):
+            all_reduce_sum(np.ctypeslib.as_array(ptr, shape=(n,)))
+        self._keep["ba_shard_cb"] = EXCHANGE_F64_FN(_cb) if all_reduce_sum is not None else EXCHANGE_F64_FN(0)
+        self.L.check(self.L.lib.vo_set_ba_shard(self.h, rank, world, self._keep["ba_shard_cb"], None), "vo_set_ba_shard")
+
+    def set_ba_shard_stream(self, rank: int, world: int, enqueue_allreduce):
+        """On-stream form: ``enqueue_allreduce(device_ptr: int, n: int, hip_stream: int) -> int`` enqueues an in-place f64 SUM over the ranks on the given HIP
+        stream (RCCL: ncclAllReduce with ncclDouble; through torch: shard.Group.stream_allreduce_f64) and returns 0."""
+        def _cb(comm, ptr, n, stream):
+            return int(enqueue_allreduce(C.cast(ptr, C.c_void_p).value, int(n), int(stream or 0)))
+        self._keep["ba_shard_scb"] = STREAM_ALLREDUCE_F64_FN(_cb) if enqueue_allreduce is not None else STREAM_ALLREDUCE_F64_FN(0)
+        self.L.check(self.L.lib.vo_set_ba_shard_stream(self.h, rank, world, self._keep["ba_shard_scb"], None), "vo_set_ba_shard_stream")
 
     def triangulate_batch(self, view_start, T_cw, xy):
         """Batched N-view triangulation -> (xyz [n, 3], ok [n])."""

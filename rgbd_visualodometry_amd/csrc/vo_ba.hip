@@ -80,7 +80,15 @@ struct BaDev {
     double* S; double* bs; double* Hinv; double* dl;
     double* partU; double* partC; int nU;   // per-workgroup partial sums (no same-address atomics): update {gain term, max step} x nU, trial chi2 x grid of k_ba_chi_control
     double* scal;       // [0] chi cur  [1] chi trial  [2] scale  [3] ok  [4] maxdiag (as u64 bits) [5] chi report [6] chi final
+    // e-3 (ba_shard_solve): the problem is one rank's share of a BA sharded by point.  gen1: the launch-per-phase step with S in global memory whatever D is;
+    // xbuf: the exchange regions behind S / b_s (which live in it: [S D*D][b_s D][x1: H_pp 36 nf, b_p D, chi, maxima per rank][x3: chi trial, scale, max step per rank])
+    int gen1, shard_rank, shard_world, pad_; double* xbuf;
 };
+#define BA_FOLD(B) ((B).D <= BA_FOLD_D && !(B).gen1)
+__host__ __device__ inline size_t ba_x1_off(int D) { return (size_t)D * D + D; }
+__host__ __device__ inline size_t ba_x1_len(int nf, int world) { return 36 * (size_t)nf + 6 * (size_t)nf + 1 + world; }
+__host__ __device__ inline size_t ba_x3_off(int D, int nf, int world) { return ba_x1_off(D) + ba_x1_len(nf, world); }
+__host__ __device__ inline size_t ba_x3_len(int world) { return 2 + (size_t)world; }
 
 // One launch serves every active problem of a batch (blockIdx.z): the local BAs of several streams step through the same
 // kernel sequence, each with its own state, control block and sizes; grids are sized for the largest problem and every
@@ -229,12 +237,12 @@ __device__ __forceinline__ void ba_lin_points_body(const BaCam& cam, const BaDev
         Ho[0] = H[0]; Ho[1] = H[1]; Ho[2] = H[2]; Ho[3] = H[1]; Ho[4] = H[3]; Ho[5] = H[4]; Ho[6] = H[2]; Ho[7] = H[4]; Ho[8] = H[5];
         B.bl[3 * (size_t)k] = b3[0]; B.bl[3 * (size_t)k + 1] = b3[1]; B.bl[3 * (size_t)k + 2] = b3[2];
         // folded init: lambda of this step is known unless this is the first step of a round (then k_ba_init_S follows k_ba_maxdiag)
-        if (B.D <= BA_FOLD_D && !ctl_->first) {
+        if (BA_FOLD(B) && !ctl_->first) {
             const double Hs[9] = {H[0], H[1], H[2], H[1], H[3], H[4], H[2], H[4], H[5]};
             ba_inv3_damped(Hs, ctl_->lambda, B.Hinv + 9 * (size_t)k);
         }
     }
-    if (B.D <= BA_FOLD_D) ba_fold_zero(B, blk, B.gp);
+    if (BA_FOLD(B)) ba_fold_zero(B, blk, B.gp);
     ba_block_reduce<1>(chi, s_part);
     if (threadIdx.x == 0 && chi[0] != 0.0) atomicAdd(&B.scal[0], chi[0]);
 }
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(256) void k_ba_lin(BaBatch Q) {
     BA_PROBLEM(Q)
     if (ctl_->finished) return;
     if (!ctl_->need_lin) {                                 // a rejected step is solved again at the same linearisation with a larger lambda
-        if (B.D <= BA_FOLD_D && (int)blockIdx.x < B.gp) {
+        if (BA_FOLD(B) && (int)blockIdx.x < B.gp) {
             const int k = blockIdx.x * 64 + (threadIdx.x >> 2);
             if (k < B.n_points && (threadIdx.x & 3) == 0) ba_inv3_damped(B.Hll + 9 * (size_t)k, ctl_->lambda, B.Hinv + 9 * (size_t)k);
             ba_fold_zero(B, blockIdx.x, B.gp);
@@ -323,7 +331,7 @@ __global__ void k_ba_maxdiag(BaBatch Q) {
 __global__ void k_ba_init_S(BaBatch Q) {
     BA_PROBLEM(Q)
     if (ctl_->finished) return;
-    const bool fold = B.D <= BA_FOLD_D, first = ctl_->need_lin && ctl_->first;
+    const bool fold = BA_FOLD(B), first = ctl_->need_lin && ctl_->first;
     if (fold && !first) return;
     // first step of a round: lambda = 1e-5 * max diag(H) (g2o computeLambdaInit); the control block is updated later in
     // this step by the Cholesky kernel, so every lane derives the same value here
@@ -332,8 +340,9 @@ __global__ void k_ba_init_S(BaBatch Q) {
     if (!fold && i < B.D * B.D) {
         const int r = i / B.D, c = i % B.D;
         double v = 0;
-        if (r / 6 == c / 6) v = B.Hpp[36 * (size_t)(r / 6) + 6 * (r % 6) + (c % 6)];
-        if (r == c) { v += lambda; B.bs[r] = B.bp[r]; }
+        const bool root = B.shard_rank == 0;                // (a sharded BA: H_pp and b_p are the exchanged sums; they and lambda enter the summed S once, through rank 0)
+        if (root && r / 6 == c / 6) v = B.Hpp[36 * (size_t)(r / 6) + 6 * (r % 6) + (c % 6)];
+        if (r == c) { if (root) v += lambda; B.bs[r] = root ? B.bp[r] : 0.0; }
         B.S[i] = v;
     }
     if (i < B.n_points) ba_inv3_damped(B.Hll + 9 * (size_t)i, lambda, B.Hinv + 9 * (size_t)i);
@@ -1144,7 +1153,7 @@ __global__ __launch_bounds__(CH2_T) void k_ba_chol16v2(BaBatch Q) {
 #define CHG_TB 8
 __global__ __launch_bounds__(CH_THREADS) void k_ba_chol16g(BaBatch Q) {
     BA_PROBLEM(Q)
-    if (ctl_->finished || B.D <= 192) return;
+    if (ctl_->finished || (B.D <= 192 && !B.gen1)) return;
     extern __shared__ double s_mem[];
     const int D = B.D, DA = D + 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15;
     double* const S = B.S;              // plain accesses: the waves of one workgroup share the CU's L1, barriers order them
@@ -1432,6 +1441,31 @@ __global__ void k_ba_chi(BaBatch Q, int trial, int robust, int guard) {
     if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(&B.scal[trial ? 1 : 5], v);
 }
 
+// g2o's gain-ratio test and lambda policy (OptimizationAlgorithmLevenberg::solve) on the control block: s1 = robust chi2 of the trial state, s2 = the
+// gain ratio's denominator without its 1e-3, m7 = the largest step entry.  Returns whether the step is accepted (the caller clears H_pp / b_p then).
+__device__ __forceinline__ int ba_lm_decide(const BaDev& B, BaCtl* c, double s1, double s2, double m7, bool ok) {
+    const double tmp = ok ? s1 : DBL_MAX;
+    const double scale = (ok ? s2 : 0.0) + 1e-3;
+    const double rho = (c->cur - tmp) / scale;
+    bool converged = false;
+    int accept = 0;
+    if (rho > 0 && isfinite(tmp)) {
+        double a = 1.0 - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
+        a = fmin(a, 2.0 / 3.0);
+        c->lambda *= fmax(1.0 / 3.0, a); c->ni = 2; c->cur = tmp;
+        c->buf ^= 1; c->need_lin = 1; accept = 1;       // trial state becomes the current state
+        B.scal[0] = 0; B.scal[4] = 0;
+    } else { c->lambda *= c->ni; c->ni *= 2; }
+    if (ok) converged = m7 < 1e-10;
+    c->qmax += 1; c->steps += 1;
+    if (!(rho < 0 && c->qmax < 10 && !converged)) {     // this LM iteration is over
+        c->iters_done += 1;
+        if (c->qmax == 10 || rho == 0 || converged || c->it + 1 >= c->max_it) c->finished = 1;
+        c->it += 1; c->qmax = 0;
+    }
+    return accept;
+}
+
 // Robust chi2 of the trial state; the LAST workgroup to finish runs g2o's gain-ratio test and lambda policy
 // (OptimizationAlgorithmLevenberg::solve) on the control block and, when the step is accepted, clears
 // H_pp / b_p for the next linearisation.  Partial sums reach L2 through f64 atomics; the arrival counter is
@@ -1489,34 +1523,94 @@ __global__ __launch_bounds__(256) void k_ba_chi_control(BaBatch Q) {
         const double sc2 = sc[2], s3 = sc[3], sc7 = sc[7];
         const double s2 = sc2 + ((s_w[4] + s_w[5]) + (s_w[6] + s_w[7]));
         const double m7 = fmax(sc7, fmax(fmax(s_w[8], s_w[9]), fmax(s_w[10], s_w[11])));
-        const unsigned long long s7 = (unsigned long long)__double_as_longlong(m7);
-        const bool ok = s3 != 0.0;
-        const double tmp = ok ? s1 : DBL_MAX;
-        const double scale = (ok ? s2 : 0.0) + 1e-3;
-        const double rho = (c->cur - tmp) / scale;
-        bool converged = false;
-        int accept = 0;
-        if (rho > 0 && isfinite(tmp)) {
-            double a = 1.0 - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
-            a = fmin(a, 2.0 / 3.0);
-            c->lambda *= fmax(1.0 / 3.0, a); c->ni = 2; c->cur = tmp;
-            c->buf ^= 1; c->need_lin = 1; accept = 1;       // trial state becomes the current state
-            B.scal[0] = 0; B.scal[4] = 0;
-        } else { c->lambda *= c->ni; c->ni *= 2; }
-        if (ok) converged = __longlong_as_double((long long)s7) < 1e-10;
-        c->qmax += 1; c->steps += 1;
-        if (!(rho < 0 && c->qmax < 10 && !converged)) {     // this LM iteration is over
-            c->iters_done += 1;
-            if (c->qmax == 10 || rho == 0 || converged || c->it + 1 >= c->max_it) c->finished = 1;
-            c->it += 1; c->qmax = 0;
-        }
-        s_accept = accept;
+        if (B.shard_world > 1) {
+            // a sharded BA (e-3): these are ONE rank's sums.  They go to the exchange region -- the pose part of the gain ratio's denominator, which every rank
+            // computes identically, through rank 0 only; the largest step in this rank's slot -- and k_ba_shard_decide takes the decision behind the exchange
+            double* x3 = B.xbuf + ba_x3_off(B.D, B.n_free, B.shard_world);
+            x3[0] = s1; x3[1] = s2 - (B.shard_rank == 0 ? 0.0 : sc2);
+            for (int r = 0; r < B.shard_world; ++r) x3[2 + r] = r == B.shard_rank ? m7 : 0.0;
+            s_accept = 0;
+        } else s_accept = ba_lm_decide(B, c, s1, s2, m7, s3 != 0.0);
     }
     __syncthreads();
     if (s_accept) {
         for (int i = threadIdx.x; i < 36 * B.n_free; i += 256) B.Hpp[i] = 0;
         for (int i = threadIdx.x; i < B.D; i += 256) B.bp[i] = 0;
     }
+}
+
+// ---- e-3: the local BA sharded over ranks by point (include/vo_hip.h, vo_set_ba_shard) -- the kernels at its three exchanges -------------------------
+// after k_ba_lin: this rank's H_pp, b_p, robust chi2 and (first step of a round) largest diagonal entry -> region x1; a step that does not linearise
+// (a rejected one: the sums in place are already the exchanged ones) sends zeros and keeps what it has
+__global__ __launch_bounds__(256) void k_ba_shard_pack1(BaBatch Q) {
+    BA_PROBLEM(Q)
+    double* x1 = B.xbuf + ba_x1_off(B.D);
+    const int n = (int)ba_x1_len(B.n_free, B.shard_world), nh = 36 * B.n_free, live = !ctl_->finished && ctl_->need_lin;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        double v = 0.0;
+        if (live) {
+            if (i < nh) v = B.Hpp[i];
+            else if (i < nh + B.D) v = B.bp[i - nh];
+            else if (i == nh + B.D) v = B.scal[0];
+            else if (i - (nh + B.D + 1) == B.shard_rank) v = ctl_->first ? B.scal[4] : 0.0;      // (k_ba_maxdiag ran on this rank's sums: its H_pp part is a lower bound of the full one's, see unpack1)
+        }
+        x1[i] = v;
+    }
+}
+__global__ __launch_bounds__(256) void k_ba_shard_unpack1(BaBatch Q) {
+    BA_PROBLEM(Q)
+    if (ctl_->finished || !ctl_->need_lin) return;
+    const double* x1 = B.xbuf + ba_x1_off(B.D);
+    const int nh = 36 * B.n_free;
+    for (int i = threadIdx.x; i < nh; i += 256) B.Hpp[i] = x1[i];
+    for (int i = threadIdx.x; i < B.D; i += 256) B.bp[i] = x1[nh + i];
+    __shared__ double s_m[4];
+    double m = 0.0;
+    if (ctl_->first) {                                       // lambda_0 = 1e-5 max diag(H): the summed H_pp's diagonal and every rank's point blocks
+        for (int i = threadIdx.x; i < B.D; i += 256) m = fmax(m, fabs(x1[36 * (i / 6) + 7 * (i % 6)]));
+        for (int r = threadIdx.x; r < B.shard_world; r += 256) m = fmax(m, x1[nh + B.D + 1 + r]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        B.scal[0] = x1[nh + B.D];
+        if (ctl_->first) B.scal[4] = fmax(fmax(s_m[0], s_m[1]), fmax(s_m[2], s_m[3]));
+    }
+}
+// behind the third exchange: the decision k_ba_chi_control's last workgroup takes in an un-sharded solve, from the summed values -- on every rank the same
+__global__ __launch_bounds__(256) void k_ba_shard_decide(BaBatch Q) {
+    BA_PROBLEM(Q)
+    if (ctl_->finished) return;
+    __shared__ int s_accept;
+    if (threadIdx.x == 0) {
+        const double* x3 = B.xbuf + ba_x3_off(B.D, B.n_free, B.shard_world);
+        double m7 = 0.0;
+        for (int r = 0; r < B.shard_world; ++r) m7 = fmax(m7, x3[2 + r]);
+        s_accept = ba_lm_decide(B, ctl_, x3[0], x3[1], m7, B.scal[3] != 0.0);
+    }
+    __syncthreads();
+    if (s_accept) {
+        for (int i = threadIdx.x; i < 36 * B.n_free; i += 256) B.Hpp[i] = 0;
+        for (int i = threadIdx.x; i < B.D; i += 256) B.bp[i] = 0;
+    }
+}
+// a rank's edges: those of its points (point k belongs to rank k % world); the others are inactive from the start
+__global__ void k_ba_shard_mask(BaBatch Q) {
+    BA_PROBLEM(Q)
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < B.n_edges) B.active[e] = (B.e_pt[e] % B.shard_world) == B.shard_rank ? 1 : 0;
+}
+// the last exchange's buffer: positions of this rank's points, flags of its edges (others zero: the sum is the whole result), its shares of the two chi2 reports
+__global__ void k_ba_shard_pack_final(BaBatch Q, double* __restrict__ xf) {
+    BA_PROBLEM(Q)
+    BA_STATE(B)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, nx = B.n_points, ne = B.n_edges;
+    if (i < 3 * nx) xf[i] = ((i / 3) % B.shard_world) == B.shard_rank ? pts_c[i] : 0.0;
+    else if (i < 3 * nx + ne) { const int e = i - 3 * nx; xf[i] = (B.e_pt[e] % B.shard_world) == B.shard_rank ? (double)B.flags[e] : 0.0; }
+    else if (i == 3 * nx + ne) xf[i] = B.scal[5];
+    else if (i == 3 * nx + ne + 1) xf[i] = B.scal[6];
 }
 
 // stage 0: cull after the robust round (bit0, deactivate); stage 1: flag level-0 outliers (bit1)
@@ -2055,6 +2149,86 @@ void vo_ba_engine_release(BaEngine* E) {
     for (int k = E->n_sib - 1; k >= 0; --k) if (E->sib[k]) ba_engine_free(E->sib[k]);      // sib[0] is E itself
 }
 
+// ---- e-3: one rank's share of a local BA sharded over ranks by point (include/vo_hip.h: vo_set_ba_shard*) --------------------------
+// The problem arrays are the whole problem's (every rank uploads the same); k_ba_shard_mask leaves only the edges of this rank's points active, so every
+// kernel of the launch-per-phase step works on this rank's share, and three in-place SUM exchanges per LM step make the shares one system (see the ABI
+// header).  The engine is not involved: the exchanges must appear in the same order on every rank, so the steps are enqueued here, on the context's
+// stream, a chunk at a time; the device-side control block decides as in the un-sharded solve (identically on every rank: same sums, same arithmetic).
+static int ba_shard_solve(vo_ctx* c, BaJob* j, const vo_ba_problem* in, vo_ba_result* out) {
+    hipStream_t st = c->stream;
+    const int W = c->ba_shard_world, R = c->ba_shard_rank;
+    BaDev B = j->B;
+    const int D = B.D, nf = B.n_free, nx = B.n_points, ne = B.n_edges;
+    const size_t n_x = ba_x3_off(D, nf, W) + ba_x3_len(W), n_fin = 3 * (size_t)nx + (size_t)ne + 2, n_dbl = std::max(n_x, n_fin) + 64;
+    const size_t hdr = 4096, need = hdr + 8 * n_dbl;
+    static_assert(sizeof(BaDev) <= 3072 && sizeof(BaCtl) <= 512 && sizeof(BaStat) <= 512, "header layout of the shard buffers");
+    if (need > c->ba_shard_bytes) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (c->d_ba_shard) (void)hipFree(c->d_ba_shard);
+        if (c->h_ba_shard) (void)hipHostFree(c->h_ba_shard);
+        c->d_ba_shard = nullptr; c->h_ba_shard = nullptr; c->ba_shard_bytes = 0;
+        const size_t want = need + need / 2;
+        if (hipMalloc(&c->d_ba_shard, want) != hipSuccess) { c->d_ba_shard = nullptr; return VO_E_NOMEM; }
+        if (hipHostMalloc(&c->h_ba_shard, want, hipHostMallocDefault) != hipSuccess) { (void)hipFree(c->d_ba_shard); c->d_ba_shard = nullptr; c->h_ba_shard = nullptr; return VO_E_NOMEM; }
+        c->ba_shard_bytes = want;
+    }
+    uint8_t* db = (uint8_t*)c->d_ba_shard; uint8_t* hb = (uint8_t*)c->h_ba_shard;
+    BaDev* d_B = (BaDev*)db; BaCtl* d_ctl = (BaCtl*)(db + 3072); BaStat* h_stat = (BaStat*)hb; double* h_x = (double*)(hb + hdr);
+    B.gen1 = 1; B.shard_rank = R; B.shard_world = W; B.xbuf = (double*)(db + hdr); B.S = B.xbuf; B.bs = B.xbuf + (size_t)D * D; B.s_tiles = 0;
+    B.ctl = d_ctl; B.it_robust = in->it_robust; B.it_plain = in->it_plain; B.gen = 1;
+    memset(h_stat, 0, sizeof(BaStat));
+    BaBatch Q; Q.Bs = d_B; Q.ctls = d_ctl; Q.stat = h_stat; Q.n = 1;
+    for (int i = 0; i < BA_SLOTS; ++i) Q.slot[i] = 0;
+    auto xchg = [&](double* dev, size_t n) -> int {        // in-place SUM over the ranks of n doubles in device memory
+        if (c->ba_shard_stream_fn) return c->ba_shard_stream_fn(c->ba_shard_user, dev, n, (void*)st) == 0 ? VO_OK : VO_E_DEVICE;
+        HIP_TRY(hipMemcpyAsync(h_x, dev, 8 * n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        c->ba_shard_fn(c->ba_shard_user, h_x, (int)n);
+        HIP_TRY(hipMemcpyAsync(dev, h_x, 8 * n, hipMemcpyHostToDevice, st));
+        return VO_OK;
+    };
+    const dim3 blk(256);
+    hipLaunchKernelGGL(k_ba_admit, dim3(1), blk, 0, st, B, d_B, d_ctl);
+    hipLaunchKernelGGL(k_ba_shard_mask, dim3(j->grid_e), blk, 0, st, Q);
+    hipLaunchKernelGGL(k_ba_chi, dim3(j->grid_e), blk, 0, st, Q, 0, 0, 0);      // this rank's share of the initial state's plain chi2 (reporting)
+    const size_t lds = sizeof(double) * (CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D);
+    double* const x1 = B.xbuf + ba_x1_off(D); double* const x3 = B.xbuf + ba_x3_off(D, nf, W);
+    int rc = VO_OK;
+    for (int chunk = 0;; ++chunk) {
+        if (chunk > 64) return VO_E_DEVICE;                  // (20 LM iterations of at most 10 trials each; a control block that never reports the end)
+        for (int s = 0; s < 5; ++s) {
+            { ProfScope ps(c, "k_ba_lin", st); hipLaunchKernelGGL(k_ba_lin, dim3(j->grid_lin), blk, 0, st, Q); }
+            hipLaunchKernelGGL(k_ba_maxdiag, dim3(j->grid_maxdiag), blk, 0, st, Q);
+            hipLaunchKernelGGL(k_ba_shard_pack1, dim3(1), blk, 0, st, Q);
+            if ((rc = xchg(x1, ba_x1_len(nf, W)))) return rc;
+            hipLaunchKernelGGL(k_ba_shard_unpack1, dim3(1), blk, 0, st, Q);
+            { ProfScope ps(c, "k_ba_init_S", st); hipLaunchKernelGGL(k_ba_init_S, dim3(j->grid_initS), blk, 0, st, Q); }
+            if (B.n_blocks) { ProfScope ps(c, "k_ba_schur_blocks", st); hipLaunchKernelGGL(k_ba_schur_blocks, dim3(B.n_blocks), blk, 0, st, Q); }
+            if ((rc = xchg(B.xbuf, (size_t)D * D + D))) return rc;      // the reduced system: S and b_s, one all-reduce (115 KB at D = 120)
+            { ProfScope ps(c, "k_ba_chol16g", st); hipLaunchKernelGGL(k_ba_chol16g, dim3(1), dim3(CH_THREADS), lds, st, Q); }
+            { ProfScope ps(c, "k_ba_update", st); hipLaunchKernelGGL(k_ba_update, dim3(j->grid_upd), blk, 0, st, Q); }
+            { ProfScope ps(c, "k_ba_chi_control", st); hipLaunchKernelGGL(k_ba_chi_control, dim3(j->grid_c), blk, 0, st, Q); }
+            if ((rc = xchg(x3, ba_x3_len(W)))) return rc;
+            hipLaunchKernelGGL(k_ba_shard_decide, dim3(1), blk, 0, st, Q);
+        }
+        hipLaunchKernelGGL(k_ba_round, dim3(j->grid_e), blk, 0, st, Q);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(st));
+        if (__atomic_load_n(&h_stat->stage, __ATOMIC_ACQUIRE) == 2) break;
+    }
+    // the whole result on every rank: this rank's points and edge flags, zeros elsewhere, summed
+    hipLaunchKernelGGL(k_ba_shard_pack_final, dim3((int)((n_fin + 255) / 256)), blk, 0, st, Q, B.xbuf);
+    if ((rc = xchg(B.xbuf, n_fin))) return rc;
+    HIP_TRY(hipMemcpyAsync(h_x, B.xbuf, 8 * n_fin, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out->poses, h_stat->buf ? B.posesB : B.posesA, 96 * (size_t)nf, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    memcpy(out->points, h_x, 24 * (size_t)nx);
+    for (int e = 0; e < ne; ++e) out->edge_flags[e] = (uint8_t)lrint(h_x[3 * (size_t)nx + e]);
+    out->chi2_initial = h_x[3 * (size_t)nx + ne]; out->chi2_final = h_x[3 * (size_t)nx + ne + 1];
+    out->lm_iters = h_stat->iters_total;
+    return VO_OK;
+}
+
 int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     hipStream_t st = c->stream;
     BaEngine* E = ba_engine_of(c);
@@ -2198,6 +2372,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     B.cam = BaCam{(double)c->p.fx, (double)c->p.fy, (double)c->p.cx, (double)c->p.cy};
     B.delta = in->huber_delta; B.chi2_th = in->chi2_th; B.gp = (nx + 63) / 64; B.edges_by_point = sorted_by_point ? 1 : 0;
     B.e_obs = nullptr; B.cull = nullptr; B.ncull = nullptr; B.cull_cap = 0; B.cull_host = nullptr; B.cull_host_cap = 0;
+    B.gen1 = 0; B.shard_rank = 0; B.shard_world = 1; B.pad_ = 0; B.xbuf = nullptr;
 
     {
         if (up_end > c->h_ba_up_bytes) {                    // pinned mirror of the upload region, grown geometrically
@@ -2262,6 +2437,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     job.grid_e = (ne + 255) / 256; job.grid_c = (ne + 1023) / 1024; job.grid_maxdiag = (D + 3 * nx + 255) / 256;
     job.lds = job.B.s_tiles ? ch2_lds_bytes(D) : D <= 192 ? sizeof(double) * (CH_NB * CH_NB + (size_t)(D + 1) * (D + 2) / 2 + 2 * (size_t)D)
                        : sizeof(double) * (CH_NB * CH_NB + (size_t)(CH_NB + 1) * (D + 1) + 2 * (size_t)D);
+    if (c->ba_shard_world > 1) return ba_shard_solve(c, &job, in, out);      // e-3: this rank's share, in lockstep with the other ranks (no engine: the exchanges order the launches)
     rc = ba_engine_solve(E, &job);
     if (rc) return rc;
     out->lm_iters = job.iters;
@@ -2865,6 +3041,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     B.cam = BaCam{(double)c->p.fx, (double)c->p.fy, (double)c->p.cx, (double)c->p.cy};
     B.delta = huber_delta; B.chi2_th = chi2_th; B.gp = (nx + 63) / 64; B.edges_by_point = 1;
     B.e_obs = e_obs; B.cull = (long long*)(base + o_cull); B.ncull = (int*)(base + o_ncull); B.cull_cap = ne; B.cull_host = nullptr; B.cull_host_cap = 0;      // (the engine points cull_host at its slot's pinned list)
+    B.gen1 = 0; B.shard_rank = 0; B.shard_world = 1; B.pad_ = 0; B.xbuf = nullptr;
     HIP_TRY(hipGetLastError());
     R.nblk_launch = slices_ub; R.npairs = npairs;
     R.B = B;
@@ -2875,6 +3052,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
 
 extern "C" int vo_local_ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int n_free, double huber_delta, double chi2_th,
                                         int32_t* n_points, int32_t* n_fixed, int32_t* n_edges) {
+    if (c && c->ba_shard_world > 1) return VO_E_UNSUPPORTED;      // (e-3 shards vo_local_ba's explicit problems; the device graph cut is one rank's)
     if (!c || !t || n_free < 0 || (n_free && !free_kf) || c->device != t->device) return VO_E_INVALID;
     HIP_TRY(hipSetDevice(c->device));
     const bool trace = vo_trace_level() != 0;

@@ -320,6 +320,8 @@ void vo_ctx_destroy(vo_ctx* c) {
     if (c->h_slots_pinned) (void)hipHostFree(c->h_slots_pinned);
     if (c->h_orb_cache) (void)hipHostFree(c->h_orb_cache);
     if (c->h_ba_up) (void)hipHostFree(c->h_ba_up);
+    if (c->d_ba_shard) (void)hipFree(c->d_ba_shard);
+    if (c->h_ba_shard) (void)hipHostFree(c->h_ba_shard);
     vo_ba_resident_free(c);
     { void* tp[] = {c->d_obs_kf, c->d_obs_mp, c->d_obs_uv, c->d_obs_alive, c->d_obs_link, c->d_kf_pose, c->d_cut}; for (void* q : tp) if (q) (void)hipFree(q); }
     vo_kf_free(c);
@@ -1089,6 +1091,18 @@ int vo_set_hypothesis_shard(vo_ctx* c, int rank, int world, vo_exchange_fn fn, v
     if (!c || world < 0 || (world > 1 && (rank < 0 || rank >= world || !fn))) return VO_E_INVALID;
     if (world > 1 && c->group) return VO_E_UNSUPPORTED;      // a context either shares launch chains with other streams or shares a stream with other ranks
     c->shard_rank = rank; c->shard_world = world > 1 ? world : 1; c->shard_fn = fn; c->shard_user = user; c->shard_stream_fn = nullptr;
+    return VO_OK;
+}
+
+// e-3: the local BA sharded over ranks by point (vo_ba.hip: ba_shard_solve)
+int vo_set_ba_shard(vo_ctx* c, int rank, int world, vo_exchange_f64_fn fn, void* user) {
+    if (!c || world < 0 || world > 64 || (world > 1 && (rank < 0 || rank >= world || !fn))) return VO_E_INVALID;
+    c->ba_shard_rank = world > 1 ? rank : 0; c->ba_shard_world = world > 1 ? world : 1; c->ba_shard_fn = world > 1 ? fn : nullptr; c->ba_shard_stream_fn = nullptr; c->ba_shard_user = user;
+    return VO_OK;
+}
+int vo_set_ba_shard_stream(vo_ctx* c, int rank, int world, vo_stream_allreduce_f64_fn fn, void* comm) {
+    if (!c || world < 0 || world > 64 || (world > 1 && (rank < 0 || rank >= world || !fn))) return VO_E_INVALID;
+    c->ba_shard_rank = world > 1 ? rank : 0; c->ba_shard_world = world > 1 ? world : 1; c->ba_shard_fn = nullptr; c->ba_shard_stream_fn = world > 1 ? fn : nullptr; c->ba_shard_user = comm;
     return VO_OK;
 }
 

@@ -122,6 +122,8 @@ struct vo_ctx {
     struct vo_group* group = nullptr; hipEvent_t group_ev = nullptr;     // stream group membership (vo_group_join)
     int shard_rank = 0, shard_world = 1; vo_exchange_fn shard_fn = nullptr; void* shard_user = nullptr;     // RANSAC hypotheses sharded over ranks
     vo_stream_allreduce_fn shard_stream_fn = nullptr;     // on-stream form of the exchange (shard_user = communicator)
+    int ba_shard_rank = 0, ba_shard_world = 1; vo_exchange_f64_fn ba_shard_fn = nullptr; vo_stream_allreduce_f64_fn ba_shard_stream_fn = nullptr; void* ba_shard_user = nullptr;      // local BA sharded over ranks by point (vo_set_ba_shard*)
+    void* d_ba_shard = nullptr; size_t ba_shard_bytes = 0; void* h_ba_shard = nullptr;      // its exchange buffers + descriptor / control block (device), status record (pinned)
     vo_match* h_matches;                            // pinned staging
     int h_matches_cap;
     int h_matches_lanes = 0, h_matches_first = 0;   // lanes whose first `h_matches_first` records the last chain left in h_matches (group mode)

@@ -81,6 +81,35 @@ class Group:
             work.wait()                                      # stream-level dependency for what follows on `ext`; the host does not block
         return 0
 
+    def all_reduce_sum_f64(self, arr) -> None:
+        """In-place element-wise sum of a host float64 array over the ranks: the exchanges of the sharded local BA (vo_set_ba_shard)."""
+        if not self.dist:
+            return
+        import torch
+        t = torch.from_numpy(arr)
+        if self.device is not None:
+            d = t.to(self.device)
+            self.dist.all_reduce(d, op=self.dist.ReduceOp.SUM)
+            t.copy_(d.cpu())
+        else:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+
+    def stream_allreduce_f64(self, device_ptr: int, n: int, hip_stream: int) -> int:
+        """vo_stream_allreduce_f64_fn through torch.distributed: an in-place float64 SUM of `n` device-resident values enqueued behind the work of
+        `hip_stream` (backend nccl: an RCCL all-reduce over xGMI of the reduced system S, b_s -- 115 KB at D = 120 -- that the host never waits for)."""
+        if not self.dist:
+            return 0
+        import torch
+
+        class _Dev:
+            __cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(device_ptr), False), "version": 2}
+        t = torch.as_tensor(_Dev(), device=self.device)
+        ext = torch.cuda.ExternalStream(int(hip_stream), device=self.device) if hip_stream else torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(ext):
+            work = self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, async_op=True)
+            work.wait()
+        return 0
+
     def gather_objects(self, obj) -> List:
         if not self.dist:
             return [obj]

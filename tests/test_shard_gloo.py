@@ -95,3 +95,49 @@ def test_two_rank_gloo_hypothesis_shard(tmp_path):
     assert len(out) == 2 and all(o["same"] for o in out)
     assert out[0]["exchanges"] == out[1]["exchanges"] == 2          # coarse + fine pass
     assert out[0]["pose"] == out[1]["pose"] and out[0]["inliers"] > 100
+
+
+WORKER_BA = r'''
+import json, os, sys
+sys.path.insert(0, %r)
+import numpy as np
+from oracle import ORACLE_LIB
+from rgbd_visualodometry_amd import capi, shard
+sys.path.insert(0, os.path.join(%r, "tests"))
+from test_ba_shard import ba_problem
+g = shard.Group("gloo")
+L = capi.load(ORACLE_LIB)
+pr = ba_problem(np.random.default_rng(11), 9, 400, 6, L.default_params())        # every rank holds the SAME problem
+ctx = L.context(L.default_params(map_capacity=1024))
+p0, x0, f0, r0 = ctx.local_ba(pr[0], 6, *pr[1:])                                  # un-sharded
+n_ex = [0]
+def ex(a):
+    n_ex[0] += 1
+    g.all_reduce_sum_f64(a)
+ctx.set_ba_shard(g.rank, g.world, ex)
+p1, x1, f1, r1 = ctx.local_ba(pr[0], 6, *pr[1:])                                  # this rank linearises the points k %% world == rank
+allr = g.gather_objects({"rank": g.rank, "exchanges": n_ex[0], "flags_same": bool(np.array_equal(f0, f1)), "dpose": float(np.abs(p0 - p1).max()), "dpts": float(np.abs(x0 - x1).max()),
+                         "iters": [int(r0.lm_iters), int(r1.lm_iters)], "chi": [float(r0.chi2_final), float(r1.chi2_final)], "pose": [float(v) for v in p1.ravel()], "culled": int((f1 != 0).sum())})
+if g.rank == 0:
+    print("RESULT " + json.dumps(allr))
+g.close()
+''' % (ROOT, ROOT)
+
+
+def test_two_rank_gloo_ba_edge_shard(tmp_path):
+    """SURVEY.md 8e item 2 (e-3) over a real collective: two ranks hold the same local BA, each linearises the edges of its points, three all-reduces
+    (sum) per LM step -- the second one is the reduced system S, b_s -- and one for the result; both ranks end with the un-sharded result."""
+    script = tmp_path / "worker_ba.py"
+    script.write_text(WORKER_BA)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29579", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29579", str(script)]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][0][len("RESULT "):])
+    assert len(out) == 2
+    for o in out:
+        assert o["flags_same"] and o["dpose"] < 1e-6 and o["dpts"] < 1e-5 and o["culled"] > 0
+        assert abs(o["iters"][0] - o["iters"][1]) <= 2 and abs(o["chi"][0] - o["chi"][1]) <= 1e-6 * max(1.0, o["chi"][0])
+    assert out[0]["exchanges"] == out[1]["exchanges"] and out[0]["exchanges"] >= 3 * 12 + 1 and (out[0]["exchanges"] - 1) % 3 == 0
+    assert out[0]["pose"] == out[1]["pose"]                        # the ranks stayed in lockstep: bit-identical poses
