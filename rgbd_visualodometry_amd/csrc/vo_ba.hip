@@ -2354,7 +2354,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     const size_t o_pcnt = carve(4 * (size_t)std::max(nb_all, 1)), o_poff = carve(4 * (size_t)std::max(nb_all, 1)), o_pn = carve(16);
     const size_t o_Hpp = carve(288 * (size_t)nf), o_bp = carve(8 * (size_t)D), o_Hll = carve(72 * (size_t)nx), o_bl = carve(24 * (size_t)nx), o_scal = carve(64);
     const size_t o_partU = carve(24 * ((size_t)(nx + 63) / 64 + 1)), o_partC = carve(8 * ((size_t)(ne + 255) / 256 + 1));
-    const size_t o_W = carve(std::max<size_t>(144 * (size_t)ne, 16 * (size_t)ne + 192 * (size_t)nx + 2048)), o_S = carve(std::max<size_t>(8 * (size_t)D * D, 8 * ba_tile_doubles(D)) + 1024), o_bs = carve(8 * (size_t)D), o_Hinv = carve(72 * (size_t)nx), o_dl = carve(std::max<size_t>(24 * (size_t)nx, 8 * (size_t)D));
+    const size_t o_W = carve(std::max<size_t>(144 * (size_t)ne, 16 * (size_t)ne + 192 * (size_t)nx + 2048)), o_S = carve(std::max<size_t>(8 * (size_t)D * D, 8 * ba_tile_doubles(D)) + 1024), o_bs = carve(8 * (size_t)D), o_Hinv = carve(72 * (size_t)nx), o_dl = carve(std::max<size_t>(24 * (size_t)nx, 8 * (size_t)(D + 8)));      // (dl: the solution and, behind it, lambda / ok / cur / ni for the update workgroups of a fused launch)
     int rc = vo_scratch(c, off);
     if (rc) return rc;
     uint8_t* base = (uint8_t*)c->d_ba;
@@ -2964,7 +2964,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
         o_pcnt = carve(4 * (size_t)std::max(nb_all, 1)), o_poff = carve(4 * (size_t)std::max(nb_all, 1)), o_pn = carve(16);
         o_Hpp = carve(288 * (size_t)nf), o_bp = carve(8 * (size_t)D), o_Hll = carve(72 * (size_t)nx_c), o_bl = carve(24 * (size_t)nx_c), o_scal = carve(64);
         o_partU = carve(24 * ((size_t)(nx_c + 63) / 64 + 1)), o_partC = carve(8 * ((size_t)(ne_c + 255) / 256 + 1));
-        o_W = carve(std::max<size_t>(144 * (size_t)ne_c, 16 * (size_t)ne_c + 192 * (size_t)nx_c + 2048)), o_S = carve(std::max<size_t>(8 * (size_t)D * D, 8 * ba_tile_doubles(D)) + 1024), o_bs2 = carve(8 * (size_t)D), o_Hinv = carve(72 * (size_t)nx_c), o_dl = carve(std::max<size_t>(24 * (size_t)nx_c, 8 * (size_t)D));
+        o_W = carve(std::max<size_t>(144 * (size_t)ne_c, 16 * (size_t)ne_c + 192 * (size_t)nx_c + 2048)), o_S = carve(std::max<size_t>(8 * (size_t)D * D, 8 * ba_tile_doubles(D)) + 1024), o_bs2 = carve(8 * (size_t)D), o_Hinv = carve(72 * (size_t)nx_c), o_dl = carve(std::max<size_t>(24 * (size_t)nx_c, 8 * (size_t)(D + 8)));      // (dl: the solution and, behind it, lambda / ok / cur / ni for the update workgroups of a fused launch)
         // pair lists: a point seen by m free poses gives m (m + 1) / 2 <= m (nf + 1) / 2 pairs, so ne (nf + 1) / 2 bounds them before the
         // per-pose lists exist; slices: one per BA_SLICE pairs plus a partial one per block
         pairs_ub = (size_t)ne_c * (size_t)(nf + 1) / 2 + 1; slices_cap = pairs_ub / BA_SLICE + (size_t)nb_all + 1;

@@ -236,8 +236,12 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
     if (tid == 0) {                                            // take over the fresh linearisation, clear the trial sums
         BaCtl* c = ctl_;
         if (PUB) {
+            // what the update workgroups need of the control block goes out beside the solution (dl[D]: lambda, [D + 1]: ok, [D + 2]: cur, [D + 3]: ni): they fetch
+            // all of it in ONE batch of loads behind the word (three dependent trips before round 6)
+            const double cur_v = c->need_lin ? B.scal[0] : c->cur, ni_v = (c->need_lin && c->first) ? 2.0 : c->ni;
+            ch2_pub_d(B.dl + D, lambda); ch2_pub_d(B.dl + D + 2, cur_v); ch2_pub_d(B.dl + D + 3, ni_v);
             if (c->need_lin) {
-                ch2_pub_d(&c->cur, B.scal[0]);
+                ch2_pub_d(&c->cur, cur_v);
                 if (c->first) { ch2_pub_d(&c->lambda, lambda); ch2_pub_d(&c->ni, 2.0); ch2_pub_i(&c->first, 0); }
                 ch2_pub_i(&c->need_lin, 0);
             }
@@ -380,6 +384,9 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
         for (int i = lane; i < D; i += 64) { const double v = s_xb[i]; if (PUB) ch2_pub_d(x_out + i, v); else x_out[i] = v; }
     };
 
+#ifdef P2_STAMPS
+    const long long ts0_ = wall_clock64(); long long ts1_ = 0;
+#endif
     if (wave == 0) {
         // ================= P: the chain of diagonal blocks =====================================================================
         __builtin_amdgcn_s_setprio(3);
@@ -487,6 +494,9 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
             }
         }
         __builtin_amdgcn_s_setprio(0);
+#ifdef P2_STAMPS
+        ts1_ = wall_clock64();
+#endif
         // ================= backward substitution: this wave takes rows 0 .. 63 ==================================================
         CH2_STAMP(60)
 #if !(CH2_EXP & 1)
@@ -495,9 +505,12 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
         CH2_STAMP(62)
         ok = ok && ch2_peek(&F.abort_) == 0;
         if (PUB) {
-            if (lane == 0) { F.ok = ok ? 1 : 0; ch2_pub_d(B.scal + 3, ok ? 1.0 : 0.0); }
+            if (lane == 0) { F.ok = ok ? 1 : 0; ch2_pub_d(B.scal + 3, ok ? 1.0 : 0.0); ch2_pub_d(B.dl + D + 1, ok ? 1.0 : 0.0); }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) ch2_pub_i(&ctl_->chol_seq, seq);
+#ifdef P2_STAMPS
+            if (lane == 0 && ctl_->it == 4) printf("[solver D %d] abs: start %lld factor done %lld published %lld\n", D, ts0_ % 1000000000ll, ts1_ % 1000000000ll, (long long)wall_clock64() % 1000000000ll);
+#endif
         } else if (lane == 0) { F.ok = ok ? 1 : 0; B.scal[3] = ok ? 1.0 : 0.0; }
     } else {
         // ================= everyone else: bring the system into LDS ==============================================================

@@ -432,7 +432,7 @@ __device__ __forceinline__ void ba_upchi2_body(const BaDev& B, BaCtl* ctl_, int 
     const int robust = __builtin_amdgcn_readfirstlane(ctl_->robust);
     bool ok = FUSED ? true : __builtin_amdgcn_readfirstlane((int)(B.scal[3] != 0.0)) != 0;
 #ifdef P2_STAMPS
-    long long tq_[8]; int nq_ = 0; const bool stamp_ = (bx == 7 || bx == gp - 1) && threadIdx.x == 0 && ctl_->it == 4 && bz == 0;
+    long long tq_[8], tw_ = 0; int nq_ = 0; const bool stamp_ = (bx == 7 || bx == gp - 1) && threadIdx.x == 0 && ctl_->it == 4 && bz == 0;
 #define P2_STAMP() { if (nq_ < 8) tq_[nq_++] = wall_clock64(); }
 #else
 #define P2_STAMP()
@@ -466,22 +466,44 @@ __device__ __forceinline__ void ba_upchi2_body(const BaDev& B, BaCtl* ctl_, int 
     };
     fetch();
     double* const s_Tc = s_dp + B.D;                        // current poses [n_poses][12] (pass 1 reads them per edge)
+    __shared__ double s_ctl[4];                             // FUSED: lambda, ok, cur, ni as the solver workgroup published them
+    double Jp0[2][6], Jl0[2][3];                            // FUSED: the first edge's Jacobians at the CURRENT state, built while the solver works
+    bool pre0 = false;
     if (FUSED) {
-        // the solver workgroup of this launch: its results (dl, scal[3], the control block's lambda) have been written through before the word
-        __shared__ int s_seen;
+        // Round 6: nothing that can be done without the solution is left behind the wait.  The current poses go to LDS now; the lane's first edge (pass 1:
+        // rhs -= W_e^T dp_j needs only the Jacobians at the current state and dp) is linearised now; and behind the solver's word the solution, lambda,
+        // ok, cur and ni arrive in ONE batch of loads (the solver stores them side by side: dl[0 .. D + 3]).  (Measured and dropped: every value as
+        // two tagged 64-bit words that the lanes poll themselves -- no word, no drain in the solver -- was 1.7 % SLOWER end to end: twice the bytes from
+        // 171 workgroups at the same instant, on one memory channel.)
+        for (int i = threadIdx.x; i < 12 * B.n_poses; i += UPC_T) s_Tc[i] = poses_c[i];
+        if (live && e0 >= 0 && act0 && j0 < B.n_free) {
+            double T0[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) T0[i] = poses_c[12 * (size_t)j0 + i];
+            pb_jac(B.cam, T0, p, Jp0, Jl0);
+            pre0 = true;
+        }
+        __shared__ int s_flag;
         if (threadIdx.x == 0) {
-            const int want = ctl_->steps + 1;              // (steps: the last workgroup of the previous step's launch wrote it)
-            int seen = 0;
-            for (int i = 0; i < (1 << 21) && !seen; ++i) { seen = __hip_atomic_load(&ctl_->chol_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want; if (!seen) __builtin_amdgcn_s_sleep(2); }
-            s_seen = seen;
+            const int wseq = ctl_->steps + 1;              // (steps: the last workgroup of the previous step's launch wrote it)
+            int f = 0;
+            for (int it = 0; it < (1 << 21) && !f; ++it) { f = __hip_atomic_load(&ctl_->chol_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == wseq; if (!f) __builtin_amdgcn_s_sleep(2); }
+            s_flag = f;
         }
         __syncthreads();
-        lambda = p2_uniform(pb_ld(&ctl_->lambda));
-        ok = s_seen != 0 && __builtin_amdgcn_readfirstlane((int)(pb_ld(B.scal + 3) != 0.0)) != 0;      // (a wait that ran out: the step counts as failed)
+#ifdef P2_STAMPS
+        tw_ = wall_clock64();
+#endif
+        const bool got = s_flag != 0;
+        if (got && (int)threadIdx.x < B.D + 4) {
+            const double v = pb_ld(B.dl + threadIdx.x);
+            if ((int)threadIdx.x < B.D) s_dp[threadIdx.x] = v; else s_ctl[threadIdx.x - B.D] = v;
+        }
+        const int seen = __syncthreads_and(got ? 1 : 0);    // (also publishes s_Tc, s_dp and s_ctl to the workgroup)
+        lambda = p2_uniform(s_ctl[0]);
+        ok = seen != 0 && __builtin_amdgcn_readfirstlane((int)(s_ctl[1] != 0.0)) != 0;      // (a wait that ran out: the step counts as failed)
         live = live && ok;
-        if (!ok) { e0 = -1; act0 = 0; q0 = q1 = 0; }
-        for (int i = threadIdx.x; i < B.D; i += UPC_T) s_dp[i] = pb_ld(B.dl + i);
-        __syncthreads();
+        if (!ok) { e0 = -1; act0 = 0; q0 = q1 = 0; pre0 = false; }
     } else {
         for (int i = threadIdx.x; i < B.D; i += UPC_T) s_dp[i] = B.dl[i];       // the solution (k_ba_chol16, phase2 = 1)
     }
@@ -489,15 +511,15 @@ __device__ __forceinline__ void ba_upchi2_body(const BaDev& B, BaCtl* ctl_, int 
     // ones with three lanes per pose, a row each (one lane per pose made this prelude the kernel's register peak, on one wave in eight)
     const int n_exp = ok ? B.n_free : 0;
     for (int i = threadIdx.x; i < 12 * B.n_poses; i += UPC_T) {
-        const double v = poses_c[i];
-        s_Tc[i] = v;
+        const double v = FUSED ? s_Tc[i] : poses_c[i];      // (FUSED: this lane's own entries of a moment ago)
+        if (!FUSED) s_Tc[i] = v;
         if (i >= 12 * n_exp) { s_T[i] = v; if (bx == 0) poses_t[i] = v; }
     }
     for (int t = threadIdx.x; t < 3 * n_exp; t += UPC_T) {
         const int j = t / 3, r = t - 3 * j;
         const double* d = FUSED ? s_dp + 6 * j : B.dl + 6 * j;
         double row[3], tr;
-        p2_exp_mul_row(d, poses_c + 12 * (size_t)j, r, row, tr);
+        p2_exp_mul_row(d, FUSED ? s_Tc + 12 * j : poses_c + 12 * (size_t)j, r, row, tr);
         if (bx == 0 && r == 0) {                   // the pose part of the gain ratio and of the step size, once
             double sc = 0, mx = 0;
             for (int a = 0; a < 6; ++a) { sc += d[a] * (lambda * d[a] + B.bp[6 * j + a]); mx = fmax(mx, fabs(d[a])); }
@@ -541,7 +563,14 @@ __device__ __forceinline__ void ba_upchi2_body(const BaDev& B, BaCtl* ctl_, int 
         }
         if (live) {
             if (sub == 0) { rhs[0] = bl[0]; rhs[1] = bl[1]; rhs[2] = bl[2]; }
-            if (e0 >= 0 && j0 < B.n_free) pass1(j0, w0);
+            if (FUSED && pre0 && r == 0) {                  // the Jacobians were built before the wait
+                const double* d6 = s_dp + 6 * j0;
+                double t0 = 0, t1 = 0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) { t0 += Jp0[0][a] * d6[a]; t1 += Jp0[1][a] * d6[a]; }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) rhs[c] -= w0 * (Jl0[0][c] * t0 + Jl0[1][c] * t1);
+            } else if (e0 >= 0 && j0 < B.n_free) pass1(j0, w0);
 #pragma nounroll
             for (int q = q0 + sub + 4; q < q1; q += 4) {
                 const int e = B.edges_by_point ? q : B.pt_edges[q], j = B.e_pose[e];
@@ -618,7 +647,11 @@ __device__ __forceinline__ void ba_upchi2_body(const BaDev& B, BaCtl* ctl_, int 
     __syncthreads();
     P2_STAMP()
 #ifdef P2_STAMPS
-    if (stamp_ && !s_last) printf("[upchi2 wg %d of %d] wall clocks (100 MHz): prelude %lld pass1 %lld pass2 %lld reduce+ticket %lld\n", bx, gp, tq_[1] - tq_[0], tq_[2] - tq_[1], tq_[3] - tq_[2], tq_[4] - tq_[3]);
+    if (stamp_ && !s_last) { long long tw2_ = 0;
+#ifdef P2_STAMPS
+        if (FUSED) tw2_ = tw_ % 1000000000ll;
+#endif
+        printf("[upchi2 wg %d of %d] abs flag seen %lld | prelude %lld pass1 %lld pass2 %lld reduce+ticket %lld  (abs ticks: poses done %lld, end %lld)\n", bx, gp, tw2_, tq_[1] - tq_[0], tq_[2] - tq_[1], tq_[3] - tq_[2], tq_[4] - tq_[3], tq_[1] % 1000000000ll, tq_[4] % 1000000000ll); }
 #endif
     if (!s_last) return;
     // block 0's atomics on scal[2] / scal[7] were performed at the memory side (and before block 0 took its ticket); this workgroup's XCD may still hold
@@ -646,7 +679,7 @@ __device__ __forceinline__ void ba_upchi2_body(const BaDev& B, BaCtl* ctl_, int 
         const double tmp = ok ? s1 : DBL_MAX;
         const double scale = (ok ? s2 : 0.0) + 1e-3;
         // (FUSED: the solver workgroup of this launch may have written cur, lambda and ni -- past this XCD's L2, which may hold the line from before)
-        const double cur = FUSED ? pb_ld(&c->cur) : c->cur, lam = FUSED ? pb_ld(&c->lambda) : c->lambda, ni = FUSED ? pb_ld(&c->ni) : c->ni;
+        const double cur = FUSED ? s_ctl[2] : c->cur, lam = FUSED ? s_ctl[0] : c->lambda, ni = FUSED ? s_ctl[3] : c->ni;      // (FUSED: the values the solver workgroup of this launch published)
         const double rho = (cur - tmp) / scale;
         bool converged = false;
         int accept = 0;
@@ -677,6 +710,7 @@ __device__ __forceinline__ void ba_upchi2_body(const BaDev& B, BaCtl* ctl_, int 
     }
     P2_STAMP()
 #ifdef P2_STAMPS
+    if (threadIdx.x == 0 && bz == 0 && (ctl_->it == 5 || ctl_->it == 4)) printf("[upchi2 last wg abs end %lld] ", tq_[5] % 1000000000ll);
     if (threadIdx.x == 0 && bz == 0 && ctl_->it == 5) printf("[upchi2 last wg %d of %d] prelude %lld pass1 %lld pass2 %lld reduce+ticket %lld control %lld\n", bx, gp, tq_[1] - tq_[0], tq_[2] - tq_[1], tq_[3] - tq_[2], tq_[4] - tq_[3], tq_[5] - tq_[4]);
 #endif
 }
