@@ -105,19 +105,21 @@ def compact_line(full):
             out["config"][k] = _short(cfg[k], 60) if isinstance(cfg[k], str) else cfg[k]
     r = full.get("roofline")
     if r:
-        out["roofline"] = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "launches")}
+        out["roofline"] = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "frac_whole_frame", "avg_launch_us", "launches",
+                                                 "alg_bytes_per_launch", "alg_flops_per_launch", "f64_frac")}
+        out["roofline"]["traffic_source"] = _short(out["roofline"].get("traffic_source") or "", 90) or None
         out["roofline"]["limiter"] = _short(r.get("limiter", ""), 100)
     else:
         out["roofline"] = None
     c = full.get("cpu_baseline")
     if c:
         out["cpu_baseline"] = {"value": c.get("value"), "unit": c.get("unit"), "cores": c.get("cores"), "kind": c.get("kind"),
-                               "sample": _short(c.get("sample", ""), 120),
+                               "sample": _short(c.get("sample", ""), 120), "stage_ms": c.get("stage_ms"),
                                "all_cores": {k: (c.get("all_cores") or {}).get(k) for k in ("value", "cores")},
                                "cpu_model": _short(c.get("cpu_model", ""), 48)}
     else:
         out["cpu_baseline"] = None
-    for k in ("ate_rmse_m", "rpe_trans_rmse_m", "rpe_rot_rmse_deg", "keyframes_timed", "ba_runs_timed", "lost", "hbm_frac_whole_frame",
+    for k in ("ate_rmse_m", "rpe_trans_rmse_m", "rpe_rot_rmse_deg", "ate_ratio_vs_sync", "keyframes_timed", "ba_runs_timed", "lost", "hbm_frac_whole_frame",
               "alg_bytes_per_frame_survey"):
         if k in full:
             out[k] = full[k]
@@ -143,10 +145,14 @@ def compact_line(full):
         out["distributed"] = {"world_size": d.get("world_size"), "backend": d.get("backend"), "allreduce_sum_of_ones": d.get("allreduce_sum_of_ones"),
                               "ranks": [{"rank": x.get("rank"), "device": x.get("device"), "pci_bus_id": x.get("pci_bus_id"),
                                          "frames_per_s": x.get("frames_per_s")} for x in ranks[:8]]}
+    for k, keys in (("hyp_shard", ("frames_per_s", "frames_per_s_unsharded", "exchanges_per_frame", "identical_to_unsharded", "identical_on_every_rank", "exchange", "error")),
+                    ("ba_shard", ("ms_per_ba", "ms_per_ba_unsharded", "exchanges_per_ba", "flags_identical_to_unsharded", "max_pose_diff", "identical_on_every_rank", "exchange"))):
+        if full.get(k):
+            out[k] = {q: (_short(full[k][q], 60) if isinstance(full[k].get(q), str) else full[k].get(q)) for q in keys if q in full[k]}
     out["detail"] = "bench_detail.json"
     line = json.dumps(out, separators=(",", ":"))
     if len(line) >= LINE_LIMIT:                              # never expected; drop the optional summaries rather than overflow
-        for k in ("distributed", "multi_stream", "orb_only", "latency_mode", "upload_inclusive", "n500"):
+        for k in ("distributed", "multi_stream", "orb_only", "latency_mode", "upload_inclusive", "n500", "ba_shard", "hyp_shard"):
             out.pop(k, None)
             line = json.dumps(out, separators=(",", ":"))
             if len(line) < LINE_LIMIT:
@@ -235,6 +241,152 @@ def spawn_ranks(n, argv):
     return rc
 
 
+def shard_legs(args, grp, rank, world, local_rank, dry=False):
+    """N > 1 only: the two sharded paths that are NOT replicas, measured beside the stream-per-rank headline.  Every rank holds the SAME data.
+    hyp_shard: one frame of BASELINE config 5's shape (1280x960, 8000 features, 2048 hypotheses) tracked with the PnP-RANSAC hypotheses h % world == rank scored per
+    rank and ONE all-reduce of the count table per pass (reference src/frontend.cpp:238-241); ba_shard: one config-5-scale local BA (21 free + 5 fixed poses, 9000
+    points, ~160 k edges; src/backend.cpp:19-195) with the points k % world == rank linearised per rank and the reduced system all-reduced per LM step.
+    backend nccl: the exchanges are RCCL all-reduces ENQUEUED on the launch chain's stream -- by the host layer's native ncclAllReduce binding
+    (host/src/rccl_exchange.cpp, dlopen) when librccl loads, through torch.distributed otherwise; backend gloo (one-GPU rehearsal): host callbacks.
+    Both results must equal the un-sharded call's on every rank.  --dry-run: the exchanges alone, on dummy arrays."""
+    out = {"hyp_shard": None, "ba_shard": None}
+    if dry:
+        a = np.full(8, rank + 1, dtype=np.int32); grp.all_reduce_sum_i32(a)
+        b = np.full(8, 0.5 * (rank + 1)); grp.all_reduce_sum_f64(b)
+        tot = world * (world + 1) // 2
+        out["hyp_shard"] = {"dry": True, "exchanges": 1, "sum_ok": bool((a == tot).all())}
+        out["ba_shard"] = {"dry": True, "exchanges": 1, "sum_ok": bool(np.allclose(b, 0.5 * tot))}
+        return out
+    import torch
+    from rgbd_visualodometry_amd import capi, system
+    H = capi.load(capi.HIP_LIB)
+    on_stream = args.dist_backend == "nccl"
+    native = None
+    if on_stream:                                           # the native binding: id from rank 0 through the process group, one communicator per exchanged path
+        try:
+            NL = C.CDLL(system.HOST_LIB)
+            NL.myslam_rccl_last_error.restype = C.c_char_p
+            if NL.myslam_rccl_load(None) == 0:
+                comms = []
+                for _ in range(2):
+                    idb = C.create_string_buffer(128)
+                    if rank == 0 and NL.myslam_rccl_unique_id(idb) != 0:
+                        raise RuntimeError(NL.myslam_rccl_last_error().decode())
+                    ids = grp.gather_objects(idb.raw if rank == 0 else None)
+                    idb = C.create_string_buffer(ids[0], 128)
+                    cm = C.c_void_p()
+                    if NL.myslam_rccl_comm_create(idb, rank, world, C.byref(cm)) != 0:
+                        raise RuntimeError(NL.myslam_rccl_last_error().decode())
+                    comms.append(cm)
+                native = (NL, comms)
+        except Exception as e:                              # (every rank fails or none: the id exchange is collective)
+            sys.stderr.write("bench.py: native RCCL binding unavailable (%s); the exchanges go through torch.distributed\n" % e)
+            native = None
+    exch = {"i32": 0, "f64": 0}
+
+    def set_hyp(ctx):
+        if native:
+            fn = C.cast(native[0].myslam_rccl_allreduce_i32, C.c_void_p)
+            H.check(H.lib.vo_set_hypothesis_shard_stream(ctx.h, rank, world, fn, native[1][0]), "vo_set_hypothesis_shard_stream")
+        elif on_stream:
+            def cb(p, n, st):
+                exch["i32"] += 1
+                return grp.stream_allreduce_i32(p, n, st)
+            ctx.set_hypothesis_shard_stream(rank, world, cb)
+        else:
+            def cb(a):
+                exch["i32"] += 1
+                grp.all_reduce_sum_i32(a)
+            ctx.set_hypothesis_shard(rank, world, cb)
+
+    def set_ba(ctx):
+        if native:
+            fn = C.cast(native[0].myslam_rccl_allreduce_f64, C.c_void_p)
+            H.check(H.lib.vo_set_ba_shard_stream(ctx.h, rank, world, fn, native[1][1]), "vo_set_ba_shard_stream")
+        elif on_stream:
+            def cb(p, n, st):
+                exch["f64"] += 1
+                return grp.stream_allreduce_f64(p, n, st)
+            ctx.set_ba_shard_stream(rank, world, cb)
+        else:
+            def cb(a):
+                exch["f64"] += 1
+                grp.all_reduce_sum_f64(a)
+            ctx.set_ba_shard(rank, world, cb)
+    how = "native ncclAllReduce on the chain's stream" if native else ("torch.distributed (nccl) on the chain's stream" if on_stream else "host callback (%s)" % args.dist_backend)
+    # ---- hyp_shard -----------------------------------------------------------------------------------------------
+    syn = capi.Synth()
+    sp = syn.params(seed=args.seed, width=1280, height=960, fx=2 * 517.3, fy=2 * 516.5, cx=2 * 318.6, cy=2 * 255.3)
+    bgr, depth, Twc, _ = syn.render(sp, 0, 6, threads=8)
+    p = H.default_params(width=1280, height=960, fx=sp.fx, fy=sp.fy, cx=sp.cx, cy=sp.cy, n_features=8000, max_frames=2, map_capacity=16384, max_hypotheses=2048)
+    ctx = H.context(p)
+    ctx.upload(0, bgr[0], depth[0]); ctx.upload(1, bgr[5], depth[5]); ctx.orb(0, 2)
+    k0, d0 = ctx.orb_fetch(0)
+    okd = k0["depth_raw"] > 0
+    z = k0["depth_raw"][okd] / 5000.0
+    pc = np.stack([(k0["x"][okd] - p.cx) * z / p.fx, (k0["y"][okd] - p.cy) * z / p.fy, z], 1)
+    R0, t0 = Twc[0][:9].reshape(3, 3), Twc[0][9:]
+    pw = pc @ R0.T + t0
+    nrm = pw - t0; nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    idx = np.arange(len(pw), dtype=np.int32)
+    ctx.map_upsert(idx, pw, nrm, d0[okd], np.zeros(len(pw), np.uint8)); ctx.map_set_active(idx)
+    T0 = np.concatenate([R0.T.ravel(), -R0.T @ t0])
+    tp = H.default_track_params(n_hyp=2048)
+    reps = 20
+    r0, m0 = ctx.track(1, T0, tp)
+    torch.cuda.synchronize(); grp.barrier()
+    ta = time.perf_counter()
+    for _ in range(reps):
+        r0, m0 = ctx.track(1, T0, tp)
+    torch.cuda.synchronize(); ta = time.perf_counter() - ta
+    set_hyp(ctx)
+    r1, m1 = ctx.track(1, T0, tp)
+    torch.cuda.synchronize(); grp.barrier()
+    n_before = exch["i32"]
+    tb = time.perf_counter()
+    for _ in range(reps):
+        r1, m1 = ctx.track(1, T0, tp)
+    torch.cuda.synchronize(); grp.barrier(); tb = time.perf_counter() - tb
+    same = bool(np.array_equal(np.array(r0.T_cw), np.array(r1.T_cw)) and r0.n_ransac_inliers == r1.n_ransac_inliers and r0.best_hypothesis == r1.best_hypothesis and np.array_equal(m0, m1))
+    ctx.close()
+    hs = {"frames_per_s": round(reps / tb, 1), "frames_per_s_unsharded": round(reps / ta, 1), "exchanges_per_frame": ((exch["i32"] - n_before) / reps if not native else 2.0),
+          "identical_to_unsharded": same, "matches": int(r1.n_matches), "ransac_inliers": int(r1.n_ransac_inliers), "exchange": how,
+          "shape": "1280x960, 8000 features, 2048 hypotheses, every rank tracks the same frame"}
+    # ---- ba_shard ------------------------------------------------------------------------------------------------
+    rng = np.random.default_rng(11)
+    nP, nfree, nX = 26, 21, 9000
+    ident = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], float)
+    poses = np.tile(ident, (nP, 1)); poses[:, 9] = -0.05 * np.arange(nP)
+    X = rng.uniform(-2.0, 2.0, (nX, 3)) + [0.6, 0, 5]
+    pcx = X[:, None, :] + poses[None, :, 9:]
+    keep = rng.uniform(size=(nX, nP)) < 0.7
+    uv_all = np.stack([p.fx / 2 * pcx[..., 0] / pcx[..., 2] + p.cx / 2, p.fy / 2 * pcx[..., 1] / pcx[..., 2] + p.cy / 2], -1) + rng.normal(size=(nX, nP, 2)) * 0.3
+    kk, jj = np.nonzero(keep)
+    ep, el, uv = jj.astype(np.int32), kk.astype(np.int32), uv_all[kk, jj].astype(np.float32)
+    poses0 = poses.copy(); poses0[:nfree, 9:] += rng.normal(size=(nfree, 3)) * 0.01
+    X0 = X + rng.normal(size=X.shape) * 0.03
+    cb_ = H.context(H.default_params(map_capacity=1024))
+    out0 = cb_.local_ba(poses0, nfree, X0, ep, el, uv)
+    torch.cuda.synchronize(); grp.barrier()
+    ta = time.perf_counter(); out0 = cb_.local_ba(poses0, nfree, X0, ep, el, uv); torch.cuda.synchronize(); ta = time.perf_counter() - ta
+    set_ba(cb_)
+    out1 = cb_.local_ba(poses0, nfree, X0, ep, el, uv)
+    torch.cuda.synchronize(); grp.barrier()
+    n_before = exch["f64"]
+    tb = time.perf_counter(); out1 = cb_.local_ba(poses0, nfree, X0, ep, el, uv); torch.cuda.synchronize(); grp.barrier(); tb = time.perf_counter() - tb
+    cb_.close()
+    bs = {"ms_per_ba": round(1e3 * tb, 3), "ms_per_ba_unsharded": round(1e3 * ta, 3), "exchanges_per_ba": ((exch["f64"] - n_before) if not native else None),
+          "flags_identical_to_unsharded": bool(np.array_equal(out0[2], out1[2])), "max_pose_diff": float(np.abs(out0[0] - out1[0]).max()), "lm_iters": [int(out0[3].lm_iters), int(out1[3].lm_iters)],
+          "edges": int(len(ep)), "D": 6 * nfree, "allreduce_doubles_per_step": (6 * nfree) ** 2 + 6 * nfree, "exchange": how}
+    alls = grp.gather_objects({"rank": rank, "hyp_same": same, "ba_flags": bs["flags_identical_to_unsharded"], "ba_dpose": bs["max_pose_diff"]})
+    hs["identical_on_every_rank"] = all(a["hyp_same"] for a in alls); bs["identical_on_every_rank"] = all(a["ba_flags"] for a in alls)
+    if native:
+        for cm in native[1]:
+            native[0].myslam_rccl_comm_destroy(cm)
+    out["hyp_shard"] = hs; out["ba_shard"] = bs
+    return out
+
+
 def dry_run(args, shard, rank, local_rank, world):
     """--dry-run: everything between the launcher and the line except the GPU -- process group, barrier, MAX over ranks, the SUM of ones,
     the gather of every rank's record -- so that `bench.py --gpus 2 --dist-backend gloo --dry-run` can be tested where there is no GPU."""
@@ -250,6 +402,7 @@ def dry_run(args, shard, rank, local_rank, world):
     elapsed = grp.max_scalar(own)
     ones = np.ones(1, dtype=np.int32)
     grp.all_reduce_sum_i32(ones)
+    legs = shard_legs(args, grp, rank, world, local_rank, dry=True) if world > 1 else None
     ranks = grp.gather_objects({"rank": rank, "local_rank": local_rank, "device": None, "pci_bus_id": None, "stream_seed": shard.stream_seed(args.seed, rank),
                                 "frames_per_s": None, "own_elapsed_s": round(own, 4), "hip_hw_queues_env": os.environ.get("GPU_MAX_HW_QUEUES")})
     if rank == 0:
@@ -258,6 +411,8 @@ def dry_run(args, shard, rank, local_rank, world):
                "dry_run": True, "config": {"workload": "DRY RUN: launcher and process-group rehearsal, nothing tracked"},
                "roofline": None, "cpu_baseline": None, "max_elapsed_s": round(elapsed, 4),
                "distributed": {"world_size": world, "backend": (args.dist_backend if world > 1 else None), "allreduce_sum_of_ones": int(ones[0]), "ranks": ranks}}
+        if legs:
+            out.update(legs)
         print(json.dumps(out, separators=(",", ":")), flush=True)
     grp.close()
     return 0
@@ -291,6 +446,7 @@ def main():
     ap.add_argument("--host-keyframes", action="store_true", help="keep the keyframe bookkeeping in host objects (round 4's path) instead of on the device tables (device_keyframes)")
     ap.add_argument("--multi-streams", default="8,16", help="comma list of stream counts for the several-streams-per-GPU figure ('' = skip)")
     ap.add_argument("--multi-device-graph", type=int, default=1, help="several-streams figure: 1 = the local BA's graph is cut on the device (as the single stream does), 0 = on the host")
+    ap.add_argument("--no-shard-legs", action="store_true", help="N > 1: skip the hypothesis-shard and BA-shard legs (the collectives inside a stream / a BA)")
     ap.add_argument("--dry-run", action="store_true", help="rehearsal of the launch + process-group plumbing only: no GPU call, no tracking, `value` null and `dry_run` true in the line (CPU test of --gpus N)")
     args = ap.parse_args()
     if args.upload_only:
@@ -382,17 +538,21 @@ def main():
                                               "frames_per_s": round(K / own_elapsed, 1),
                                               "keyframes": st["keyframes"], "lost": st["lost"], "ate_rmse_m": acc["ate_rmse_m"]})}
 
+    legs = None
+    if world > 1 and not args.no_shard_legs:                # the paths that shard WITHIN a stream / a BA: every rank takes part (collectives inside)
+        try:
+            legs = shard_legs(args, grp, rank, world, local_rank)
+        except Exception as e:                              # never lose the headline line over a side figure
+            sys.stderr.write("bench.py: shard legs failed on rank %d: %r\n" % (rank, e))
+            legs = {"hyp_shard": {"error": repr(e)[:200]}, "ba_shard": None}
     out = None
     if rank == 0:
         fps = shard.aggregate_fps(K, world, elapsed)
         L = capi.load(capi.HIP_LIB)
         # ---- roofline of the dominant kernel -------------------------------------------------------
-        # Second pass over the SAME frames (warmup + steps) on a fresh system with per-kernel HIP-event timing
-        # enabled on every context stream (tracker + overlapped back-end); not part of `value`.
-        # (the local BA's solver and update share a launch in the timed run; here they are launched apart -- VO_BA_FUSE_MAX=0, read per
-        # chunk of steps -- so that HIP events bracket the solver alone: k_ba_chol16 is the same code either way)
-        fuse_env = os.environ.get("VO_BA_FUSE_MAX")
-        os.environ["VO_BA_FUSE_MAX"] = "0"
+        # Second pass over the SAME frames (warmup + steps) on a fresh system in the SAME configuration as the timed pass, with per-kernel HIP-event
+        # timing enabled on every context stream (tracker + overlapped back-end + the BA engine's); not part of `value`.  The local BA's step kernels
+        # appear under the names rocprofv3 lists them by (k_ba_schur2_one / k_ba_cholup_one: a lone problem's descriptor rides in the arguments).
         prof_sys = system.VoSystem(system.HOST_LIB, **(opts if not args.no_roofline_pass else dict(opts, enable_local_optimization=0)))
         h = C.c_void_p(prof_sys.context_handle())
         L.check(L.lib.vo_profile_enable(h, 1))
@@ -404,10 +564,6 @@ def main():
         L.check(L.lib.vo_profile_read(h, C.cast(names, C.c_void_p), ms.ctypes.data, calls.ctypes.data, 96, C.byref(nn)))
         L.check(L.lib.vo_profile_enable(h, 0))
         prof_sys.close()
-        if fuse_env is None:
-            os.environ.pop("VO_BA_FUSE_MAX", None)
-        else:
-            os.environ["VO_BA_FUSE_MAX"] = fuse_env
         kern = {names[j].value.decode(): (float(ms[j]), int(calls[j])) for j in range(nn.value)}
         tf = max(1, pst["tracked_frames"])
         A, M, Kc, I = (pst[k] / tf for k in ("sum_active", "sum_candidates", "sum_matches", "sum_ransac_inliers"))
@@ -427,31 +583,54 @@ def main():
             fl = 120.0 * I * (pst["sum_lm_iters"] + 4.0 * 2 * tf)
             table["k_pose_lm"]["f64_valu_frac"] = round(fl / (table["k_pose_lm"]["total_ms"] * 1e-3) / (F64_PEAK_TFLOPS * 1e12), 6)
             table["k_pose_lm"]["limiter"] = "latency: one workgroup per frame runs ~20 dependent f64 passes (edge loop, 28-value reduction, 6x6 solve)"
+        # The local BA's step kernels: algorithmic bytes AND flops per launch from the run's own averages (per BA: points, edges, pairs of the Schur pair plan,
+        # D = 6 free poses; DESIGN 4 states the per-unit figures).  Every launch of a BA works on that BA's sizes, so per-BA averages are per-launch averages.
         runs = max(1, pst["ba_runs"])
-        ck = next((k for k in ("k_ba_chol16v2", "k_ba_chol16", "k_ba_chol16g", "k_ba_chol") if k in table), None)      # v2: tile-major systems (D <= 174), the bench's case
-        if ck:                                              # (D^3/3 + 2 D^2) multiply-adds per factorisation + solve, D = 6 free poses, averaged over the BA runs
-            D = (pst["ba_sum_d3"] / runs) ** (1.0 / 3.0)
-            flops = 2.0 * (pst["ba_sum_d3"] / runs / 3.0 + 2.0 * pst["ba_sum_d2"] / runs) * table[ck]["launches"]
-            table[ck]["alg_flops_per_launch"] = int(flops / table[ck]["launches"])
-            table[ck]["TFLOPps"] = round(flops / (table[ck]["total_ms"] * 1e-3) / 1e12, 5)
-            table[ck]["limiter"] = ("latency: one workgroup; the chain block factorisation -> its inverse -> panel solve -> trailing update runs through four waves, "
-                                    "every f64 MFMA holds its SIMD's double-precision pipe for 64 clocks (D = %d)" % int(D))
+        ba_pts, ba_edges, ba_pairs = pst["ba_sum_points"] / runs, pst["ba_sum_edges"] / runs, pst["ba_sum_pairs"] / runs
+        d3, d2 = pst["ba_sum_d3"] / runs, pst["ba_sum_d2"] / runs
+        Dm = d3 ** (1.0 / 3.0) if d3 > 0 else 0.0
+        Tt = int(np.ceil((Dm + 1) / 16.0))
+        s_tile_bytes = 8 * 272 * Tt * (Tt + 1) // 2          # S as 16x16 tiles of 17-double rows (lower block triangle of the augmented matrix)
+        chol_flops = 2.0 * (d3 / 3.0 + 2.0 * d2)             # factorisation + two triangular solves
+        ba_units = {"points": round(ba_pts, 1), "edges": round(ba_edges, 1), "pairs": round(ba_pairs, 1), "D": round(Dm, 1)}
+        ba_alg = {
+            # Schur: each point record (96 B) and each Huber weight (8 B) ONCE per step, the pair list (8 B + 4 B point index per pair); 72 FMAs per pair for the
+            # rank-2 contraction + ~60 for the point block's inverse and the two Jacobians
+            "k_ba_schur2": (96.0 * ba_pts + 8.0 * ba_edges + 12.0 * ba_pairs, 2.0 * 132.0 * ba_pairs),
+            # update + chi2 + linearisation at the trial state: 29 B per edge (pixel 8, pose index 4, flag 1, weight read 8 + written 8) + 224 B per point
+            # (record read 96 + written 96, CSR 8, trial point 24); ~300 f64 operations per edge (two Jacobian evaluations, the robust chi2, H_ll / b_l)
+            "k_ba_upchi2": (29.0 * ba_edges + 224.0 * ba_pts, 300.0 * ba_edges + 60.0 * ba_pts),
+            # Cholesky + solve: the tiles of S read and cleared + H_pp, b
+            "k_ba_chol16v2": (2.0 * s_tile_bytes + 8.0 * (6.0 * Dm + 2.0 * Dm), chol_flops),
+        }
+        ba_alg["k_ba_schur2_one"] = ba_alg["k_ba_schur2"]
+        ba_alg["k_ba_cholup"] = (ba_alg["k_ba_upchi2"][0] + ba_alg["k_ba_chol16v2"][0], ba_alg["k_ba_upchi2"][1] + ba_alg["k_ba_chol16v2"][1])
+        ba_alg["k_ba_cholup_one"] = ba_alg["k_ba_cholup"]
+        ba_alg["k_ba_chol16"] = ba_alg["k_ba_chol16v2"]
+        for name, (by, fl) in ba_alg.items():
+            if name in table and by > 0:
+                t = table[name]
+                t["alg_bytes_per_launch"] = int(by); t["alg_flops_per_launch"] = int(fl)
+                t["GBps"] = round(by / (t["avg_us"] * 1e-6) / 1e9, 2); t["TFLOPps"] = round(fl / (t["avg_us"] * 1e-6) / 1e12, 5)
+                t["f64_frac"] = round(t["TFLOPps"] / F64_PEAK_TFLOPS, 6)
+        for name in ("k_ba_cholup_one", "k_ba_cholup", "k_ba_chol16v2", "k_ba_chol16"):
+            if name in table:
+                table[name]["limiter"] = ("latency: the solver is ONE workgroup (block factorisation -> its inverse -> panel solve -> trailing update through four waves, f64 MFMA at the vector rate); "
+                                          "the update workgroups of the same launch wait for it, then run two dependent passes over each point's edges (D = %d)" % int(Dm))
         roof = None
         if table:
-            dom = ck or max(table, key=lambda k: table[k]["total_ms"])      # the kernel VERDICT.md names (it is also the one with the largest total)
+            dom = max(table, key=lambda k: table[k]["total_ms"])      # the kernel with the largest total of the TIMED configuration
             t = table[dom]
-            if "GBps" in t:
-                roof = {"bound": "hbm", "kernel": dom, "achieved": t["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(t["GBps"] / HBM_PEAK_GBS, 6), "traffic": None}
-            elif "TFLOPps" in t:
-                roof = {"bound": "mfma", "kernel": dom, "achieved": t["TFLOPps"], "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(t["TFLOPps"] / F64_PEAK_TFLOPS, 6), "traffic": None}
-            else:
-                roof = {"bound": "hbm", "kernel": dom, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
-            # HBM traffic per launch from this round's PMC passes (rocprofv3 cannot run inside this process): only a file of
-            # the current round that covers this kernel is used, otherwise null
+            roof = {"bound": "hbm", "kernel": dom, "achieved": t.get("GBps"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": (round(t["GBps"] / HBM_PEAK_GBS, 6) if "GBps" in t else None), "traffic": None, "traffic_source": None,
+                    # SURVEY 8d's own definition: algorithmic bytes per FRAME x frames/s of this GPU against the HBM peak
+                    "frac_whole_frame": round(b_survey * (fps / world) / (HBM_PEAK_GBS * 1e9), 6),
+                    "alg_bytes_per_launch": t.get("alg_bytes_per_launch"), "alg_flops_per_launch": t.get("alg_flops_per_launch"),
+                    "TFLOPps": t.get("TFLOPps"), "f64_frac": t.get("f64_frac"), "units_per_launch": ba_units if dom.startswith("k_ba_") else None}
+            # HBM traffic per launch from THIS round's PMC passes (rocprofv3 cannot run inside this process): only a file of the current round that
+            # covers this kernel is used, with its name and date in the record; otherwise null
             try:
-                pmc_file = next(f for f in ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+                pmc_file = next(f for f in ("r06_pmc_hbm_traffic.json",) if os.path.exists(os.path.join(ROOT, "profiles", f)))
                 pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
                 pk = pmc["kernels"]
                 for name, row in table.items():             # measured fabric traffic per launch beside the algorithmic bytes, where a PMC row exists
@@ -459,9 +638,10 @@ def main():
                     if m:
                         row["pmc_hbm_bytes_per_launch"] = m["hbm_bytes_per_launch_corrected"]
                         row["pmc_GBps"] = round(m["hbm_bytes_per_launch_corrected"] / (row["avg_us"] * 1e-6) / 1e9, 1)
-                roof["traffic"] = pk[dom]["hbm_bytes_per_launch_corrected"]
-                roof["traffic_source"] = "profiles/%s (FETCH_SIZE, WRITE_SIZE: separate --pmc passes of `%s`)" % (pmc_file, pmc.get("command", "bench.py"))
-                cmp_file = next((os.path.join(ROOT, "profiles", f) for f in ("r05_pmc_compute.json", "r04_pmc_compute.json", "r03_pmc_compute.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "")      # SQ counters of the latency-bound kernels (separate --pmc passes)
+                if pk.get(dom):
+                    roof["traffic"] = pk[dom]["hbm_bytes_per_launch_corrected"]
+                    roof["traffic_source"] = "profiles/%s, collected %s (FETCH_SIZE, WRITE_SIZE: separate --pmc passes of `%s`)" % (pmc_file, pmc.get("date", "?"), pmc.get("command", "bench.py"))
+                cmp_file = os.path.join(ROOT, "profiles", "r06_pmc_compute.json")      # SQ counters of the latency-bound kernels (separate --pmc passes)
                 if os.path.exists(cmp_file):
                     cc = json.load(open(cmp_file)).get("kernels", {})
                     for name, row in table.items():
@@ -598,6 +778,15 @@ def main():
             nf = min(args.cpu_frames, Wm)
             ns = min(args.cpu_steady_frames, K)
             o = system.VoSystem(ORACLE_LIB, **copts)
+            LO = capi.load(ORACLE_LIB)
+
+            def cpu_stages(s_):                             # the restatement's own stage clocks (oracle/o_capi.cpp: vo_profile_read) + the host layer's
+                nm = (C.c_char * 48 * 8)(); m_ = np.zeros(8); c_ = np.zeros(8, dtype=np.int64); n_ = C.c_int()
+                LO.check(LO.lib.vo_profile_read(C.c_void_p(s_.context_handle()), C.cast(nm, C.c_void_p), m_.ctypes.data, c_.ctypes.data, 8, C.byref(n_)))
+                d = {nm[j].value.decode(): float(m_[j]) for j in range(n_.value)}
+                st_ = s_.stats()
+                d.update({k: st_[k] for k in ("ms_extract", "ms_track", "ms_keyframe", "ms_backend")})
+                return d
             est_c = {}
             tc = time.perf_counter()
             for i in range(nf):
@@ -607,12 +796,21 @@ def main():
             for i in range(nf, Wm):                          # untimed: the remainder of the prologue + warmup
                 ok, T = o.add_frame(stamps[i], bgr[i], depth[i])
                 est_c[stamps[i]] = T
+            sg0 = cpu_stages(o)
             ts_ = time.perf_counter()
             for i in range(Wm, Wm + ns):
                 ok, T = o.add_frame(stamps[i], bgr[i], depth[i])
                 est_c[stamps[i]] = T
             ts_ = time.perf_counter() - ts_
+            sg1 = cpu_stages(o)
             o.close()
+            dsg = {k: (sg1[k] - sg0[k]) / ns for k in sg1}
+            # ms per frame by stage, timed sample only.  `filter_match` is the restatement's EXACT O(M' N) Hamming search (the reference uses FLANN-LSH there,
+            # src/frontend.cpp:33,187): how much of the CPU's time is that substitute can be read off here.  keyframe = the host layer's bookkeeping
+            # (observations, new map points, covisibility; without the local BA, which is a stage of its own)
+            cpu_stage_ms = {"orb": round(dsg.get("cpu_orb", 0.0), 3), "filter_match": round(dsg.get("cpu_filter_match", 0.0), 3), "ransac": round(dsg.get("cpu_ransac", 0.0), 3),
+                            "pose_lm": round(dsg.get("cpu_pose_lm", 0.0), 3), "ba": round(dsg.get("cpu_local_ba", 0.0), 3),
+                            "keyframe": round(max(0.0, dsg["ms_keyframe"] + dsg["ms_backend"] - dsg.get("cpu_local_ba", 0.0)), 3), "total": round(1e3 * ts_ / ns, 3)}
             acc_c = accuracy(ev, capi, stamps, Twc, est_c, 0, nf)
             acc_g = accuracy(ev, capi, stamps, Twc, est, 0, nf) if nf <= total else {}
             acc_cs = accuracy(ev, capi, stamps, Twc, est_c, 0, Wm + ns)
@@ -642,7 +840,7 @@ def main():
             cpu = {"value": round(ns / ts_, 3), "unit": "frames/s", "cores": 1, "kind": "port",
                    "sample": "frames %d..%d = first %d of the GPU's timed frames, same %d-frame prologue; 1 thread, sync BA, oracle port -O3" % (Wm, Wm + ns - 1, ns, Wm),
                    "sample_detail": "the same synthetic stream, oracle/_build/liboracle_vo.so (-O3 -march=x86-64-v3), local BA synchronous inside AddFrame",
-                   "ate_rmse_m": acc_cs["ate_rmse_m"], "gpu_ate_rmse_m_same_frames": acc_gs.get("ate_rmse_m"),
+                   "ate_rmse_m": acc_cs["ate_rmse_m"], "gpu_ate_rmse_m_same_frames": acc_gs.get("ate_rmse_m"), "stage_ms": cpu_stage_ms,
                    "rpe_trans_rmse_m": acc_cs["rpe_trans_rmse_m"],
                    "fresh_map": {"value": round(nf / tc, 3), "unit": "frames/s", "cores": 1, "sample": "first %d frames from a fresh map (younger, i.e. cheaper, than the timed steady state): rounds 1-2's sample" % nf,
                                  "ate_rmse_m": acc_c["ate_rmse_m"], "gpu_ate_rmse_m_same_frames": acc_g.get("ate_rmse_m")},
@@ -683,6 +881,21 @@ def main():
                     "note": "default.yaml's number_of_features (500), everything else as the headline workload; cpu1 = oracle port, 1 thread, synchronous BA, "
                             "timed on the first %d of the GPU's timed frames after the same %d-frame prologue; ATE over frames 0..%d for both" % (ns5, Wm, Wm + ns5 - 1)}
         kf_timed = st["keyframes"] - st_w["keyframes"]
+        # the GPU run's kernel time per frame by stage (per-kernel timing pass of the timed configuration; kernels of different stages overlap on the
+        # device, so the sum exceeds 1 / frames-per-second: it is the GPU time a frame costs, the CPU column is the wall time it costs)
+        gpu_stage_ms = None
+        if roof:
+            grp_of = lambda n: ("orb" if n in ("k_gray", "k_pyramid", "k_resize", "k_fast_nms", "k_select", "k_blur", "k_describe") else
+                                "filter_match" if n.startswith(("k_frustum", "k_match")) else "ransac" if n.startswith("k_ransac") else "pose_lm" if n == "k_pose_lm" else
+                                "ba" if n.startswith(("k_ba_", "k_cut", "k_scan", "k_ps_", "k_merge", "k_culled")) else "keyframe" if n.startswith(("k_kf", "k_act", "k_obs", "k_map")) else "other")
+            gpu_stage_ms = {}
+            for n_, row in roof["kernels"].items():
+                gpu_stage_ms[grp_of(n_)] = gpu_stage_ms.get(grp_of(n_), 0.0) + row["total_ms"] / total
+            gpu_stage_ms = {k: round(v, 4) for k, v in gpu_stage_ms.items()}
+            gpu_stage_ms["wall_per_frame"] = round(1e3 * elapsed / K, 4)
+        ate_ratio = None
+        if cpu and cpu.get("ate_rmse_m") and cpu.get("gpu_ate_rmse_m_same_frames"):
+            ate_ratio = round(cpu["gpu_ate_rmse_m_same_frames"] / cpu["ate_rmse_m"], 3)      # GPU (BA merged `--ba-lag` frames late) / CPU restatement (synchronous BA), same frames, this seed; seeds 0-3: BASELINE.md
         out = {
             "metric": "VO frames/sec (640x480 RGB-D)", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -700,12 +913,15 @@ def main():
             "alg_bytes_per_frame_survey": b_survey, "hbm_frac_whole_frame": round(b_survey * (fps / world) / (HBM_PEAK_GBS * 1e9), 6),
             "render_s": round(t_render, 2),
             "host_stage_ms": {k: round(st[k] - st_w[k], 2) for k in ("ms_extract", "ms_track", "ms_keyframe", "ms_backend")},
+            "gpu_stage_ms": gpu_stage_ms, "ate_ratio_vs_sync": ate_ratio,
             "ba": {k: st[k] for k in ("ba_runs", "ba_poses", "ba_fixed", "ba_points", "ba_edges", "ba_outliers", "ba_failed", "ba_capped")},
             "avg_per_tracked_frame": {"active_map_points": round(A, 1), "candidates": round(M, 1), "matches": round(Kc, 1), "ransac_inliers": round(I, 1),
                                       "lm_iterations": round(pst["sum_lm_iters"] / tf, 2), "frames_per_launch_chain": round(tf / max(1, pst["track_launches"]), 2)},
             "roofline": roof, "orb_only": orb_only, "latency_mode": lat, "multi_stream": multi, "upload_inclusive": upl, "cpu_baseline": cpu,
             "distributed": dist_info, "default_yaml": n500,
         }
+        if legs:
+            out.update(legs)
         write_detail(out)
         sys.stdout.flush()
         print(compact_line(out), flush=True)

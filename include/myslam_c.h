@@ -56,6 +56,7 @@ typedef struct myslam_stats {
     int32_t ba_failed, ba_capped;                           /* local BA runs skipped after a failed solve / solved with a capped free set */
     int64_t triangulated, reobserved_matches;               /* points refined by triangulation; gated matches counted by the re-observation pass */
     double ba_sum_d3, ba_sum_d2; int64_t ba_sum_edges;      /* over the local BA runs: (6 n_free)^3, (6 n_free)^2, edges (flop / byte accounting) */
+    int64_t ba_sum_points, ba_sum_pairs;                    /* ... points, pairs of the Schur pair plan (device graph cut only; 0 otherwise) */
 } myslam_stats;
 
 int myslam_default_options(myslam_options* o);

@@ -332,7 +332,8 @@ typedef struct vo_ba_resident_result {
     int32_t cap_points, cap_culled;
     int32_t n_points, n_fixed, n_edges, n_culled;
     double chi2_initial, chi2_final;
-    int32_t lm_iters, reserved;
+    int32_t lm_iters;
+    int32_t n_pairs;            /* pairs (e1, e2) of the reduced system's pair plan: what one Schur launch contracts (byte / flop accounting)  */
 } vo_ba_resident_result;
 #define VO_BA_RESIDENT_MAX_FREE 160
 int vo_local_ba_resident(vo_ctx* ctx, vo_ctx* tables, const int32_t* free_kf, int n_free, double huber_delta, double chi2_th,

@@ -35,6 +35,8 @@ struct vo_ctx {
     std::vector<int32_t> ransac_inliers;
     HypShard shard;
     BaShard ba_shard;
+    // wall time per stage of the restatement (vo_profile_read): what bench.py's cpu_baseline breaks its frames/s down into
+    double prof_ms[5] = {0, 0, 0, 0, 0}; long long prof_calls[5] = {0, 0, 0, 0, 0};      // orb, filter + match, ransac, pose lm, local ba
     // observation table: keyframe number, map slot, pixel, alive; keyframe poses
     std::vector<int32_t> obs_kf, obs_mp; std::vector<float> obs_uv; std::vector<uint8_t> obs_alive;
     std::vector<double> kf_pose;
@@ -115,8 +117,11 @@ int vo_frame_bind_device(vo_ctx* c, int slot, const void* b, int bs, const void*
     return VO_OK;
 }
 
+namespace { struct StageTimer { vo_ctx* c; int k; std::chrono::steady_clock::time_point t0; StageTimer(vo_ctx* c_, int k_) : c(c_), k(k_), t0(std::chrono::steady_clock::now()) {}
+    ~StageTimer() { c->prof_ms[k] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); c->prof_calls[k]++; } }; }
 int vo_orb_detect_describe(vo_ctx* c, int slot0, int n) {
     if (!c || slot0 < 0 || n < 1 || slot0 + n > (int)c->slots.size()) return VO_E_INVALID;
+    StageTimer tm(c, 0);
     for (int i = slot0; i < slot0 + n; ++i) {
         auto& s = c->slots[i];
         if (!s.bgr_p) return VO_E_STATE;
@@ -213,6 +218,7 @@ int vo_match_active_map(vo_ctx* c, int slot, const double T[12], float ratio, fl
     auto& s = c->slots[slot];
     if (!s.has_orb) return VO_E_STATE;
     int nc = 0, md = -1;
+    StageTimer tm(c, 1);
     match_active(c->cam, c->map, SE3::from12(T), s.desc.data(), (int)s.kps.size(), ratio, floor_dist, c->last_matches, nc, md);
     corr_from_matches(c, slot);
     c->ransac_inliers.clear();
@@ -234,6 +240,7 @@ int vo_pnp_ransac(vo_ctx* c, int n_hyp, float reproj_px, float conf, uint64_t se
                   int* n_inl, int32_t* hyp_counts, int* iters_used, int* best_hyp) {
     if (!c || !T || n_hyp < 1 || n_hyp > c->p.max_hypotheses) return VO_E_INVALID;
     RansacOut r;
+    StageTimer tm(c, 2);
     pnp_ransac(c->cam, c->corr, n_hyp, reproj_px, conf, seed, SE3::from12(T), r, &c->shard);
     r.T.to12(T);
     c->ransac_inliers = r.inliers;
@@ -249,6 +256,7 @@ int vo_pose_refine_lm(vo_ctx* c, double T[12], double delta, double cut, int it_
                       int* n_edges, int* lm_iters) {
     if (!c || !T) return VO_E_INVALID;
     LmOut o;
+    StageTimer tm(c, 3);
     pose_lm(c->cam, c->corr, c->ransac_inliers, SE3::from12(T), delta, cut, it_r, it_p, o);
     o.T.to12(T);
     if (mask) std::memcpy(mask, o.inlier_mask.data(), std::min<size_t>(cap, o.inlier_mask.size()));
@@ -479,7 +487,7 @@ int vo_local_ba_resident_solve(vo_ctx* c, int it_robust, int it_plain, vo_ba_res
     if (!deferred) { std::memcpy(out->poses, po.data(), 96 * (size_t)n_free); std::memcpy(out->points, xo.data(), 24 * (size_t)nx); }
     for (int e = 0; e < ne; ++e) if (fl[e] & 3) { if (out->n_culled < out->cap_culled) out->culled_obs[out->n_culled] = P.edge_obs[e]; ++out->n_culled; S.culled.push_back(P.edge_obs[e]); }
     std::sort(out->culled_obs, out->culled_obs + std::min(out->n_culled, out->cap_culled));
-    out->chi2_initial = r.chi2_initial; out->chi2_final = r.chi2_final; out->lm_iters = r.lm_iters;
+    out->chi2_initial = r.chi2_initial; out->chi2_final = r.chi2_final; out->lm_iters = r.lm_iters; out->n_pairs = 0;
     po.resize(12 * (size_t)n_free); xo.resize(3 * (size_t)nx);
     S.poses = po; S.pts = xo; S.slots = P.point_slots; S.pose_kf.assign(P.pose_kf.begin(), P.pose_kf.begin() + n_free);
     S.n_culled = out->n_culled; S.lm_iters = r.lm_iters; S.chi0 = r.chi2_initial; S.chi1 = r.chi2_final; S.ready = true;
@@ -732,6 +740,7 @@ int vo_group_stats(vo_group* g, int64_t* chains, int64_t* lanes, int64_t* reques
 
 int vo_local_ba(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     if (!c || !in || !out || !out->poses || !out->points || !out->edge_flags) return VO_E_INVALID;
+    StageTimer tm(c, 4);
     return local_ba(c->cam, *in, *out, c->ba_shard.world > 1 ? &c->ba_shard : nullptr);
 }
 int vo_set_ba_shard(vo_ctx* c, int rank, int world, vo_exchange_f64_fn fn, void* user) {
@@ -743,6 +752,12 @@ int vo_set_ba_shard_stream(vo_ctx*, int, int, vo_stream_allreduce_f64_fn, void*)
 
 int vo_sync(vo_ctx*) { return VO_OK; }
 int vo_profile_enable(vo_ctx*, int) { return VO_OK; }
-int vo_profile_read(vo_ctx*, char (*)[48], double*, int64_t*, int, int* n) { if (n) *n = 0; return VO_OK; }
+int vo_profile_read(vo_ctx* c, char (*names)[48], double* ms, int64_t* calls, int cap, int* n) {      // the restatement's stages (always on): wall ms and calls
+    static const char* nm[5] = {"cpu_orb", "cpu_filter_match", "cpu_ransac", "cpu_pose_lm", "cpu_local_ba"};
+    if (!c || !n) return VO_E_INVALID;
+    *n = 0;
+    for (int k = 0; k < 5 && k < cap; ++k) { std::snprintf(names[k], 48, "%s", nm[k]); ms[k] = c->prof_ms[k]; calls[k] = c->prof_calls[k]; *n = k + 1; }
+    return VO_OK;
+}
 
 }  // extern "C"

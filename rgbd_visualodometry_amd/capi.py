@@ -50,7 +50,7 @@ class VoBaProblem(C.Structure):
 class VoBaResidentResult(C.Structure):
     _fields_ = [("poses", C.c_void_p), ("point_slots", C.c_void_p), ("points", C.c_void_p), ("culled_obs", C.c_void_p), ("cap_points", C.c_int32),
                 ("cap_culled", C.c_int32), ("n_points", C.c_int32), ("n_fixed", C.c_int32), ("n_edges", C.c_int32), ("n_culled", C.c_int32),
-                ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lm_iters", C.c_int32), ("reserved", C.c_int32)]
+                ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lm_iters", C.c_int32), ("n_pairs", C.c_int32)]
 
 
 class VoKfCommitResult(C.Structure):

@@ -57,7 +57,7 @@ struct BaCtl {
 };
 
 // What the host needs to know about a slot, written by k_ba_round straight into pinned host memory (no read-back copy per chunk of steps)
-struct BaStat { int gen, stage, finished, it, buf, iters_total, steps, n_culled; double chi0, chi_final; };
+struct BaStat { int gen, stage, finished, it, buf, iters_total, steps, n_culled; double chi0, chi_final; int n_pairs, pad_[3]; };
 
 struct BaDev {
     int n_poses, n_free, n_points, n_edges, D, n_blocks;
@@ -1709,6 +1709,7 @@ __global__ __launch_bounds__(256) void k_ba_round(BaBatch Q) {
             c->stage = 2;
             st->n_culled = B.ncull ? __hip_atomic_load(B.ncull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
             st->chi0 = c->chi0; st->chi_final = __hip_atomic_load(&B.scal[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            st->n_pairs = B.n_slices ? B.n_slices[1] : 0;      // (the device-built pair plan's count: byte / flop accounting of the Schur launches)
             st->buf = c->buf; st->iters_total = c->iters_total; st->finished = 1; st->it = c->it; st->steps = c->steps; st->gen = c->gen;
             __threadfence_system();
             st->stage = 2;
@@ -1802,7 +1803,7 @@ struct BaJob {
     int grid_lin = 0, grid_initS = 0, grid_upd = 0, grid_e = 0, grid_c = 0, grid_maxdiag = 0; size_t lds = 0;
     int cur_buf = 0, iters = 0, steps = 0;
     int est_stage = 0, est_left = 0;                        // the host's estimate of where the device is (chunk sizes only: the device moves on by itself)
-    double chi0 = 0, chi_final = 0;
+    double chi0 = 0, chi_final = 0; int n_pairs = 0;
     int n_culled = -1; std::vector<long long> culled;       // resident graphs: from k_ba_round's pinned list (-1: not collected)
     int rc = VO_OK; bool done = false;
     hipEvent_t wait_ev = nullptr;                           // the problem's arrays are complete once this event (recorded on the owner's stream) has passed
@@ -1935,12 +1936,12 @@ static int ba_engine_enqueue(BaEngine* E) {
                 }
             }
             const bool direct = nA == 1;                               // a lone problem: descriptor by value
-            if (direct) { ProfScope ps(prof, "k_ba_schur2", st); hipLaunchKernelGGL(k_ba_schur2_one, dim3(gA_blk + gA_pose), blk, 0, st, E->h_Bs[sA[0]], E->d_ctl + sA[0]); }
+            if (direct) { ProfScope ps(prof, "k_ba_schur2_one", st); hipLaunchKernelGGL(k_ba_schur2_one, dim3(gA_blk + gA_pose), blk, 0, st, E->h_Bs[sA[0]], E->d_ctl + sA[0]); }
             else { ProfScope ps(prof, "k_ba_schur2", st); hipLaunchKernelGGL(k_ba_schur2, dim3(gA_blk + gA_pose, 1, nA), blk, 0, st, QA); }
             // both generations in one step: every problem leaves the kernel that is not its own at once (s_tiles says which one is)
             // tile-major problems only: solvers and updates in one launch (vo_ba_phase2.h, FUSED)
             if (fuse_up) {
-                ProfScope ps(prof, "k_ba_cholup", st);
+                ProfScope ps(prof, direct ? "k_ba_cholup_one" : "k_ba_cholup", st);
                 const int gpmax = (gA_up + up_rep * (UPC_T / 4) - 1) / (up_rep * (UPC_T / 4));
                 if (direct) hipLaunchKernelGGL(k_ba_cholup_one, dim3(1 + gpmax), dim3(CH2_T), std::max(ldsA, ldsA_up), st, E->h_Bs[sA[0]], E->d_ctl + sA[0], gpmax, up_rep);
                 else hipLaunchKernelGGL(k_ba_cholup, dim3(nA * (1 + gpmax)), dim3(CH2_T), std::max(ldsA, ldsA_up), st, QA, nA, gpmax, up_rep);
@@ -2011,7 +2012,7 @@ static int ba_engine_retire(BaEngine* E) {
         const volatile BaStat* t = E->h_stat + s;
         if (t->gen != C.gen[i]) continue;
         if (t->stage == 2) {
-            j->iters = t->iters_total; j->cur_buf = t->buf; j->chi0 = t->chi0; j->chi_final = t->chi_final;
+            j->iters = t->iters_total; j->cur_buf = t->buf; j->chi0 = t->chi0; j->chi_final = t->chi_final; j->n_pairs = t->n_pairs;
             if (j->B.cull_host) { j->n_culled = t->n_culled; const int take = std::max(0, std::min(j->n_culled, BA_CULL_HOST)); j->culled.assign(E->h_cull + (size_t)s * BA_CULL_HOST, E->h_cull + (size_t)s * BA_CULL_HOST + take); }
             fin[nfin++] = s;
             continue;
@@ -3123,7 +3124,7 @@ extern "C" int vo_local_ba_resident_solve(vo_ctx* c, int it_robust, int it_plain
             std::sort(out->culled_obs, out->culled_obs + take);                     // arrival order of an atomic append -> ascending observation id
         }
     }
-    out->chi2_initial = job.chi0; out->chi2_final = job.chi_final; out->lm_iters = job.iters;
+    out->chi2_initial = job.chi0; out->chi2_final = job.chi_final; out->lm_iters = job.iters; out->n_pairs = job.n_pairs;
     HIP_TRY(hipGetLastError());
     R.solved = true; ++R.solve_seq; R.cur_buf = job.cur_buf; R.n_culled = out->n_culled; R.chi0 = job.chi0; R.chi_final = job.chi_final; R.lm_iters = job.iters;
     if (trace) { static double a = 0, b = 0, st = 0; static int n = 0; a += t1 - t0; b += tnow() - t1; st += job.steps; if (++n % 10 == 0) fprintf(stderr, "[vo_trace] resident solve avg ms: optimise %.3f (%.1f step launches) result %.3f (D=%d edges=%d)\n", a / n, st / n, b / n, D, ne);

@@ -50,6 +50,17 @@ int main(int argc, char** argv) {
             backend = myslam::Backend::Ptr(new myslam::Backend(camera));
             frontend->SetBackend(backend);
         }
+        // Several ranks of one job (one per GPU) on the SAME dataset: world_size / rank / rccl_id_file in the parameter file.  Every rank tracks every frame; the RANSAC
+        // hypotheses of a frame (shard_hypotheses, default on) and / or the local BA's edges (shard_ba, default off) are shared out and exchanged by RCCL all-reduces
+        // on the launch chains' streams.  Every rank writes the same trajectory: give each its own output_file.
+        const int world = myslam::Config::has("world_size") ? myslam::Config::get<int>("world_size") : 1;
+        if (world > 1) {
+            const int rank = myslam::Config::get<int>("rank");
+            const std::string idFile = myslam::Config::get<std::string>("rccl_id_file");
+            if (!myslam::Config::has("shard_hypotheses") || myslam::Config::get<int>("shard_hypotheses")) frontend->ShardHypothesesOverRanks(rank, world, idFile);
+            if (backend && myslam::Config::has("shard_ba") && myslam::Config::get<int>("shard_ba")) backend->ShardOverRanks(rank, world, idFile + ".ba");
+            std::cout << "rank " << rank << " of " << world << " (RCCL exchanges on the launch chains' streams)" << std::endl;
+        }
         std::cout << "Finish initialization! (compute backend: " << vo_backend_name() << ", lookahead " << lookahead << ")\n\n" << std::endl;
 
         // one chunk = up to `lookahead` decoded frame pairs; ok[i] false marks the first missing / undecodable frame

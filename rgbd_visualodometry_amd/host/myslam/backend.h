@@ -52,8 +52,11 @@ public:
     int Lag() const { return lag_; }
     size_t NextMergeFrame() const { return job_ ? job_->frameIndex + (size_t)lag_ : (size_t)-1; }
     struct Stats { int runs = 0, poses = 0, fixed = 0, points = 0, edges = 0, outliers = 0, failed = 0, capped = 0; double ms = 0, ms_build = 0, ms_solve = 0, ms_wait = 0, ms_wake = 0, ms_to_merge = 0; int waited = 0;
-                   double sum_d3 = 0, sum_d2 = 0; long long sum_edges = 0; };
+                   double sum_d3 = 0, sum_d2 = 0; long long sum_edges = 0, sum_points = 0, sum_pairs = 0; };
     const Stats& GetStats() const { return stats_; }
+    // e-3: the local BA of every keyframe sharded over the ranks of a job by point, an RCCL all-reduce of the reduced system per LM step (vo_set_ba_shard_stream with
+    // the native exchange of myslam/rccl_exchange.h).  The graph is then cut on the host (the sharded solve takes explicit problems).  Call before the first keyframe.
+    void ShardOverRanks(int rank, int world, const std::string& idFile);
     // the flattened graph of a keyframe, for inspection (parity tests): what Solve would be handed
     struct GraphView { std::vector<size_t> poseIds; int nFree = 0; std::vector<size_t> pointIds; std::vector<int32_t> edgePose, edgePoint; std::vector<float> edgeUv; };
     GraphView DescribeGraph(const Frame::Ptr& keyframe);
@@ -65,12 +68,13 @@ private:
         std::vector<double> poses, pts, posesOut, ptsOut; std::vector<uint8_t> flags;
         size_t frameIndex = 0; int rc = 0; double solveMs = 0; bool done = false; std::chrono::steady_clock::time_point tDone;
         // device-resident graph: only the free keyframes' numbers go down, the cut happens on the device
-        bool resident = false, cutDone = false; std::vector<int32_t> freeKf, pointSlots; std::vector<int64_t> culled; int nPoints = 0, nFixed = 0, nEdges = 0, nCulled = 0;
+        bool resident = false, cutDone = false; std::vector<int32_t> freeKf, pointSlots; std::vector<int64_t> culled; int nPoints = 0, nFixed = 0, nEdges = 0, nCulled = 0, nPairs = 0;
     };
     Camera::Ptr camera_;
     float chi2Threshold_;
     vo_ctx* ctx_ = nullptr;         // tracker context
     vo_ctx* ctxOwn_ = nullptr;      // worker's own context (lag > 0)
+    void* rcclComm_ = nullptr; int shardRank_ = 0, shardWorld_ = 1;      // ShardOverRanks
     int device_ = 0, lag_ = 0;
     size_t frameIndex_ = 0;
     uint64_t buildStamp_ = 0;

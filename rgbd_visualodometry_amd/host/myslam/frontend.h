@@ -24,6 +24,10 @@ public:
     void SetViewer(const Viewer::Ptr viewer) { viewer_ = viewer; }
     void SetBackend(const Backend::Ptr backend) { backend_ = backend; if (backend_) { backend_->SetContext(ctx_, device_); backend_->SetFallbackHook([this]() { FallBackToHostObjects(); }); } }
     VOState GetState() const { return state_; }
+    // Several processes (one per GPU) track the SAME stream: each scores the PnP-RANSAC hypotheses h % world == rank (src/frontend.cpp:238-241), one RCCL all-reduce
+    // of the per-hypothesis inlier counts per pass, enqueued on the tracking chain's stream (vo_set_hypothesis_shard_stream with the native
+    // exchange of myslam/rccl_exchange.h).  idFile: where rank 0 leaves the RCCL id for the other ranks.  Throws when RCCL cannot be loaded / initialised.
+    void ShardHypothesesOverRanks(int rank, int world, const std::string& idFile);
     // the two per-frame decisions on explicit inputs (parity tests): bit0 IsGoodEstimation, bit1 IsKeyframe
     int PolicyFlags(const SE3& T_ref_cw, const SE3& T_cur_cw, int numInliers);
 
@@ -55,6 +59,7 @@ private:
 
     vo_ctx*                 ctx_ = nullptr;
     vo_group*               group_ = nullptr;
+    void*                   rcclComm_ = nullptr;     // ShardHypothesesOverRanks
     int                     device_ = 0;
     vo_params               params_;
     vo_track_params         trackParams_;

@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include "myslam/backend.h"
+#include "myslam/rccl_exchange.h"
 
 #include <algorithm>
 #include <chrono>
@@ -26,7 +27,18 @@ Backend::Backend(const Camera::Ptr camera) : camera_(camera) {
     if (const char* e = std::getenv("VO_TEST_FAIL_CUT_AT")) testFailAt_ = std::atoi(e);
 }
 
-Backend::~Backend() { Stop(); if (ctxOwn_) vo_ctx_destroy(ctxOwn_); }
+Backend::~Backend() { Stop(); if (ctxOwn_) vo_ctx_destroy(ctxOwn_); if (rcclComm_) myslam_rccl_comm_destroy(rcclComm_); }
+
+void Backend::ShardOverRanks(int rank, int world, const std::string& idFile) {
+    if (world <= 1) return;
+    char id[MYSLAM_RCCL_ID_BYTES];
+    if (myslam_rccl_id_via_file(idFile.c_str(), rank, 120, id) || myslam_rccl_comm_create(id, rank, world, &rcclComm_))
+        throw std::runtime_error(std::string("RCCL: ") + myslam_rccl_last_error());
+    shardRank_ = rank; shardWorld_ = world;
+    deviceGraph_ = false; deviceKeyframes_ = false;     // the sharded solve takes explicit problems: the graph is cut on the host
+    if (ctx_) (void)vo_set_ba_shard_stream(ctx_, rank, world, myslam_rccl_allreduce_f64, rcclComm_);
+    if (ctxOwn_) (void)vo_set_ba_shard_stream(ctxOwn_, rank, world, myslam_rccl_allreduce_f64, rcclComm_);
+}
 
 void Backend::SetContext(vo_ctx* ctx, int device) { ctx_ = ctx; device_ = device; if (ctx_ && lag_ > 0) EnsureWorker(); }
 
@@ -39,6 +51,7 @@ void Backend::EnsureWorker() {
                                                         // the trackers' streams (default class) and from the pace-setting chains (highest class: BA engines, group chains)
         int rc = vo_ctx_create(&p, device_, &ctxOwn_);
         if (rc != VO_OK) throw std::runtime_error(std::string("vo_ctx_create (backend) failed: ") + vo_strerror(rc));
+        if (shardWorld_ > 1) (void)vo_set_ba_shard_stream(ctxOwn_, shardRank_, shardWorld_, myslam_rccl_allreduce_f64, rcclComm_);
     }
     if (!worker_.joinable()) worker_ = std::thread(&Backend::WorkerLoop, this);
 }
@@ -160,7 +173,7 @@ void Backend::FinishOnDevice(Job& j, vo_ctx* solver) {
     }
     for (int p = 0; p < j.nFree; ++p) j.poseFrames[p]->SetPose(SE3::from12(&j.posesOut[12 * (size_t)p]));
     stats_.runs++; stats_.poses = j.nFree; stats_.fixed = j.nFixed; stats_.points = j.nPoints; stats_.edges = j.nEdges; stats_.outliers = j.nCulled; stats_.ms_solve += j.solveMs;
-    { const double D = 6.0 * j.nFree; stats_.sum_d3 += D * D * D; stats_.sum_d2 += D * D; stats_.sum_edges += j.nEdges; }
+    { const double D = 6.0 * j.nFree; stats_.sum_d3 += D * D * D; stats_.sum_d2 += D * D; stats_.sum_edges += j.nEdges; stats_.sum_points += j.nPoints; stats_.sum_pairs += j.nPairs; }
     if (j.culled.capacity() > culledSpare_.capacity()) culledSpare_.swap(j.culled);      // the list's buffer goes on to the next job
 }
 
@@ -189,7 +202,7 @@ void Backend::FinishTail() {
         mp->SetPositionSyncedUnlocked(Vector3d(x[0], x[1], x[2]));
     }
     stats_.runs++; stats_.poses = j.nFree; stats_.fixed = j.nFixed; stats_.points = j.nPoints; stats_.edges = j.nEdges; stats_.outliers = j.nCulled; stats_.ms_solve += j.solveMs;
-    { const double D = 6.0 * j.nFree; stats_.sum_d3 += D * D * D; stats_.sum_d2 += D * D; stats_.sum_edges += j.nEdges; }
+    { const double D = 6.0 * j.nFree; stats_.sum_d3 += D * D * D; stats_.sum_d2 += D * D; stats_.sum_edges += j.nEdges; stats_.sum_points += j.nPoints; stats_.sum_pairs += j.nPairs; }
     if (j.culled.capacity() > culledSpare_.capacity()) culledSpare_.swap(j.culled);
 }
 
@@ -373,7 +386,7 @@ void Backend::SolveResident(Job& j, vo_ctx* ctx) {
     std::memset(&r, 0, sizeof(r));                   // poses / point_slots / points stay NULL: the result is merged on the device (Finish) and fetched later (FinishTail)
     r.culled_obs = j.culled.data(); r.cap_culled = (int)cullCap;
     j.rc = vo_local_ba_resident_solve(ctx, 10, 10, &r);                                  // backend.cpp:141,:159
-    j.nCulled = r.n_culled;
+    j.nCulled = r.n_culled; j.nPairs = r.n_pairs;
 }
 
 void Backend::Apply(Job& j) {

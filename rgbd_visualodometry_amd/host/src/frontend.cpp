@@ -2,6 +2,7 @@
 // (reference src/frontend.cpp:29-506).  State machine, keyframe policy and map bookkeeping stay
 // on the host; ORB, matching, PnP-RANSAC and pose refinement run through the C-ABI (vo_hip.h).
 #include "myslam/frontend.h"
+#include "myslam/rccl_exchange.h"
 
 #include <algorithm>
 #include <chrono>
@@ -67,7 +68,15 @@ void FrontEnd::Init(int device, int width, int height, int max_frames) {
     if (backend_) backend_->SetContext(ctx_, device_);
 }
 
-FrontEnd::~FrontEnd() { if (ctx_) { try { DrainAhead(); } catch (...) {} if (group_) vo_group_leave(group_, ctx_); vo_ctx_destroy(ctx_); } }
+FrontEnd::~FrontEnd() { if (ctx_) { try { DrainAhead(); } catch (...) {} if (group_) vo_group_leave(group_, ctx_); vo_ctx_destroy(ctx_); } if (rcclComm_) myslam_rccl_comm_destroy(rcclComm_); }
+
+void FrontEnd::ShardHypothesesOverRanks(int rank, int world, const std::string& idFile) {
+    if (world <= 1) { vo_check(vo_set_hypothesis_shard_stream(ctx_, 0, 1, nullptr, nullptr), "vo_set_hypothesis_shard_stream"); return; }
+    char id[MYSLAM_RCCL_ID_BYTES];
+    if (myslam_rccl_id_via_file(idFile.c_str(), rank, 120, id) || myslam_rccl_comm_create(id, rank, world, &rcclComm_))
+        throw std::runtime_error(std::string("RCCL: ") + myslam_rccl_last_error());
+    vo_check(vo_set_hypothesis_shard_stream(ctx_, rank, world, myslam_rccl_allreduce_i32, rcclComm_), "vo_set_hypothesis_shard_stream");
+}
 
 void FrontEnd::JoinGroup(vo_group* g) { vo_check(vo_group_join(g, ctx_), "vo_group_join"); group_ = g; }
 

@@ -315,7 +315,7 @@ int myslam_get_stats(myslam_system* s, myslam_stats* st) {
     if (s->backend) {
         const auto& b = s->backend->GetStats();
         st->ba_runs = b.runs; st->ba_poses = b.poses; st->ba_fixed = b.fixed; st->ba_points = b.points; st->ba_edges = b.edges; st->ba_outliers = b.outliers; st->ba_ms = b.ms; st->ba_failed = b.failed; st->ba_capped = b.capped;
-        st->ba_sum_d3 = b.sum_d3; st->ba_sum_d2 = b.sum_d2; st->ba_sum_edges = b.sum_edges;
+        st->ba_sum_d3 = b.sum_d3; st->ba_sum_d2 = b.sum_d2; st->ba_sum_edges = b.sum_edges; st->ba_sum_points = b.sum_points; st->ba_sum_pairs = b.sum_pairs;
         if (myslam::TraceScope::on()) fprintf(stderr, "[vo_trace] BA runs %d build %.2f ms solve %.2f ms wait %.2f ms (%d waits: solve done -> tracker awake %.1f us, awake -> merge launched %.1f us per wait)\n", b.runs, b.ms_build, b.ms_solve, b.ms_wait, b.waited, b.waited ? 1e3 * b.ms_wake / b.waited : 0.0, b.waited ? 1e3 * b.ms_to_merge / b.waited : 0.0);
     }
     if (myslam::TraceScope::on()) myslam::TraceScope::dump();

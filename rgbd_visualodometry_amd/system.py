@@ -38,7 +38,8 @@ class Stats(C.Structure):
                 ("tracked_frames", C.c_int64), ("sum_active", C.c_int64), ("sum_candidates", C.c_int64), ("sum_matches", C.c_int64),
                 ("sum_ransac_inliers", C.c_int64), ("sum_lm_inliers", C.c_int64), ("sum_lm_iters", C.c_int64), ("track_launches", C.c_int64),
                 ("ba_failed", C.c_int32), ("ba_capped", C.c_int32), ("triangulated", C.c_int64), ("reobserved_matches", C.c_int64),
-                ("ba_sum_d3", C.c_double), ("ba_sum_d2", C.c_double), ("ba_sum_edges", C.c_int64)]
+                ("ba_sum_d3", C.c_double), ("ba_sum_d2", C.c_double), ("ba_sum_edges", C.c_int64),
+                ("ba_sum_points", C.c_int64), ("ba_sum_pairs", C.c_int64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

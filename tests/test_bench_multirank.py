@@ -26,6 +26,7 @@ def test_bench_gpus_2_without_a_launcher_starts_two_ranks():
     assert len(lines) == 1, r.stdout                       # ONE line on stdout, everything else went to stderr
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 7 and d["warmup"] == 3 and d["scaling"] == "weak"
+    assert d["hyp_shard"] == {"dry": True, "exchanges": 1, "sum_ok": True} and d["ba_shard"] == {"dry": True, "exchanges": 1, "sum_ok": True}      # the shard legs' collectives (int32 and f64 sums) over the same group
     assert d["dry_run"] is True and d["value"] is None    # a rehearsal can never be mistaken for a measurement
     dist = d["distributed"]
     assert dist["world_size"] == 2 and dist["backend"] == "gloo" and dist["allreduce_sum_of_ones"] == 2
@@ -78,3 +79,7 @@ def test_bench_gpus_2_tracks_two_streams_on_a_one_gpu_box():
     assert dist["world_size"] == 2 and dist["allreduce_sum_of_ones"] == 2 and len(dist["ranks"]) == 2
     assert all(x["device"] == 0 and x["frames_per_s"] > 0 for x in dist["ranks"])
     assert abs(d["value"] - 2 * 12 / (d["ms_per_step"] * 12e-3)) / d["value"] < 0.01      # whole job: both ranks' frames over the slowest rank's time
+    # the legs that shard WITHIN a stream / a BA, here over gloo host callbacks: both ranks end with the un-sharded results
+    hs, bs = d["hyp_shard"], d["ba_shard"]
+    assert hs["identical_to_unsharded"] and hs["identical_on_every_rank"] and hs["exchanges_per_frame"] == 2 and hs["frames_per_s"] > 0
+    assert bs["flags_identical_to_unsharded"] and bs["identical_on_every_rank"] and bs["max_pose_diff"] < 1e-6 and bs["exchanges_per_ba"] >= 3 * 10 + 1
