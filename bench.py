@@ -126,6 +126,8 @@ def compact_line(full):
     u = full.get("upload_inclusive")
     if u:
         out["upload_inclusive"] = {"frames_per_s": u.get("frames_per_s"), "vs_resident": u.get("vs_resident")}
+    if full.get("sync_ba"):
+        out["sync_ba"] = {k: full["sync_ba"].get(k) for k in ("frames_per_s", "ate_rmse_m", "ate_overlapped_over_sync")}
     lat = full.get("latency_mode")
     if lat:
         out["latency_mode"] = {"frames_per_s": lat.get("frames_per_s"), "ms_per_frame_median": lat.get("ms_per_frame_median")}
@@ -152,7 +154,7 @@ def compact_line(full):
     out["detail"] = "bench_detail.json"
     line = json.dumps(out, separators=(",", ":"))
     if len(line) >= LINE_LIMIT:                              # never expected; drop the optional summaries rather than overflow
-        for k in ("distributed", "multi_stream", "orb_only", "latency_mode", "upload_inclusive", "n500", "ba_shard", "hyp_shard"):
+        for k in ("distributed", "multi_stream", "orb_only", "latency_mode", "upload_inclusive", "n500", "ba_shard", "hyp_shard", "sync_ba"):
             out.pop(k, None)
             line = json.dumps(out, separators=(",", ":"))
             if len(line) < LINE_LIMIT:
@@ -677,6 +679,22 @@ def main():
                            "vo_frames_preload) and overlaps the previous batch's tracking, as a reader thread ahead of AddFrame would; the timed region issues as many frame copies as it consumes"}
             del hb, hd
 
+        # ---- the same stream with the local BA SYNCHRONOUS inside AddFrame (lag 0), look-ahead and speculative batches kept: the schedule whose trajectory equals the CPU
+        # restatement's to 1e-7 (tests) and whose ATE is the reference point of `ate_ratio_vs_sync`; what the overlapped schedule buys in frames/s and costs in ATE
+        # (seeds 0-3: scripts/ate_seeds.py)
+        sync_ba = None
+        if world == 1 and not args.no_latency_mode and not args.upload_only and not args.no_ba and args.ba_lag != 0:
+            s0 = system.VoSystem(system.HOST_LIB, **dict(opts, backend_lag_frames=0))
+            est_s = {}
+            drive(s0, stamps, bptr, dptr, 0, Wm, args.lookahead, W, est_s); s0.flush(); torch.cuda.synchronize()
+            t_s = time.perf_counter()
+            drive(s0, stamps, bptr, dptr, Wm, total, args.lookahead, W, est_s); s0.flush(); torch.cuda.synchronize()
+            t_s = time.perf_counter() - t_s
+            s0.close()
+            a_s = accuracy(ev, capi, stamps, Twc, est_s, 0, total)
+            sync_ba = {"frames_per_s": round(K / t_s, 1), "vs_overlapped": round((K / t_s) / fps, 3), "ate_rmse_m": a_s["ate_rmse_m"], "rpe_trans_rmse_m": a_s["rpe_trans_rmse_m"],
+                       "ate_overlapped_over_sync": round(acc["ate_rmse_m"] / a_s["ate_rmse_m"], 3) if a_s["ate_rmse_m"] else None}
+
         # ---- causal single-frame figure ---------------------------------------------------------------
         lat = None
         if not args.no_latency_mode and world == 1 and not args.upload_only:
@@ -917,7 +935,7 @@ def main():
             "ba": {k: st[k] for k in ("ba_runs", "ba_poses", "ba_fixed", "ba_points", "ba_edges", "ba_outliers", "ba_failed", "ba_capped")},
             "avg_per_tracked_frame": {"active_map_points": round(A, 1), "candidates": round(M, 1), "matches": round(Kc, 1), "ransac_inliers": round(I, 1),
                                       "lm_iterations": round(pst["sum_lm_iters"] / tf, 2), "frames_per_launch_chain": round(tf / max(1, pst["track_launches"]), 2)},
-            "roofline": roof, "orb_only": orb_only, "latency_mode": lat, "multi_stream": multi, "upload_inclusive": upl, "cpu_baseline": cpu,
+            "roofline": roof, "orb_only": orb_only, "sync_ba": sync_ba, "latency_mode": lat, "multi_stream": multi, "upload_inclusive": upl, "cpu_baseline": cpu,
             "distributed": dist_info, "default_yaml": n500,
         }
         if legs:
