@@ -82,7 +82,7 @@ struct BaDev {
     double* scal;       // [0] chi cur  [1] chi trial  [2] scale  [3] ok  [4] maxdiag (as u64 bits) [5] chi report [6] chi final
     // e-3 (ba_shard_solve): the problem is one rank's share of a BA sharded by point.  gen1: the launch-per-phase step with S in global memory whatever D is;
     // xbuf: the exchange regions behind S / b_s (which live in it: [S D*D][b_s D][x1: H_pp 36 nf, b_p D, chi, maxima per rank][x3: chi trial, scale, max step per rank])
-    int gen1, shard_rank, shard_world, pad_; double* xbuf;
+    int gen1, shard_rank, shard_world, upc_ovf; double* xbuf;      // upc_ovf: the update workgroups' LDS holds the overflow list + cells beside the poses (vo_ba_phase2.h; 0: too many poses)
 };
 #define BA_FOLD(B) ((B).D <= BA_FOLD_D && !(B).gen1)
 __host__ __device__ inline size_t ba_x1_off(int D) { return (size_t)D * D + D; }
@@ -1890,7 +1890,7 @@ static int ba_engine_enqueue(BaEngine* E) {
     int chunk = (na == 1 && E->pending_hint == 0) ? 16 : 4;
     int sA[BA_SLOTS], nA = 0, sB[BA_SLOTS], nB = 0, nA_tiles = 0;
     int gA_lin = 0, gA_blk = 0, gA_up = 0, gA_md = 0, gA_pose = 0, gB_lin = 0, gB_init = 0, gB_blk = 0, gB_upd = 0, gB_c = 0, gB_md = 0, g_e = 0;
-    size_t ldsA = 0, ldsA_up = 0, ldsB = 0;
+    size_t ldsA = 0, ldsA_up = 0, ldsA_up_plain = 0, ldsB = 0;
     for (int i = 0; i < na; ++i) {
         BaJob* j = E->slot[act[i]];
         if (j->est_stage < 2) chunk = std::min(chunk, std::max(1, j->est_left));
@@ -1898,7 +1898,8 @@ static int ba_engine_enqueue(BaEngine* E) {
         if (j->B.D <= BA_FOLD_D) {
             sA[nA++] = act[i]; nA_tiles += j->B.s_tiles;
             gA_lin = std::max(gA_lin, j->grid_lin); gA_blk = std::max(gA_blk, j->B.n_blocks); gA_pose = std::max(gA_pose, j->B.n_free * PSPLIT); gA_up = std::max(gA_up, j->B.n_points);
-            ldsA = std::max(ldsA, j->lds); ldsA_up = std::max(ldsA_up, sizeof(double) * (24 * (size_t)j->B.n_poses + (size_t)j->B.D));
+            ldsA = std::max(ldsA, j->lds); ldsA_up = std::max(ldsA_up, sizeof(double) * (24 * (size_t)j->B.n_poses + (size_t)j->B.D + (j->B.upc_ovf ? UPC_LDS_EXTRA : 0)));      // (the overflow region: used by the fused launch only)
+            ldsA_up_plain = std::max(ldsA_up_plain, sizeof(double) * (24 * (size_t)j->B.n_poses + (size_t)j->B.D));
             gA_md = std::max(gA_md, (j->B.D + j->B.n_points + 255) / 256);
         } else {
             sB[nB++] = act[i];
@@ -1942,13 +1943,13 @@ static int ba_engine_enqueue(BaEngine* E) {
             // tile-major problems only: solvers and updates in one launch (vo_ba_phase2.h, FUSED)
             if (fuse_up) {
                 ProfScope ps(prof, direct ? "k_ba_cholup_one" : "k_ba_cholup", st);
-                const int gpmax = (gA_up + up_rep * (UPC_T / 4) - 1) / (up_rep * (UPC_T / 4));
+                const int gpmax = (gA_up + up_rep * (UPC_T / 4) - 1) / (up_rep * (UPC_T / 4)) + 1;      // (+ 1: the pose workgroup behind a problem's point workgroups)
                 if (direct) hipLaunchKernelGGL(k_ba_cholup_one, dim3(1 + gpmax), dim3(CH2_T), std::max(ldsA, ldsA_up), st, E->h_Bs[sA[0]], E->d_ctl + sA[0], gpmax, up_rep);
                 else hipLaunchKernelGGL(k_ba_cholup, dim3(nA * (1 + gpmax)), dim3(CH2_T), std::max(ldsA, ldsA_up), st, QA, nA, gpmax, up_rep);
             } else {
             if (nA_tiles) { ProfScope ps(prof, "k_ba_chol16v2", st); hipLaunchKernelGGL(k_ba_chol16v2, dim3(1, 1, nA), dim3(CH2_T), ldsA, st, QA); }
             if (nA_tiles < nA) { ProfScope ps(prof, "k_ba_chol16", st); hipLaunchKernelGGL(k_ba_chol16, dim3(1, 1, nA), dim3(CH_THREADS), ldsA, st, QA, 0, 1); }
-            { ProfScope ps(prof, "k_ba_upchi2", st); hipLaunchKernelGGL(k_ba_upchi2, dim3((gA_up + up_rep * (UPC_T / 4) - 1) / (up_rep * (UPC_T / 4)), 1, nA), dim3(UPC_T), ldsA_up, st, QA, up_rep); }
+            { ProfScope ps(prof, "k_ba_upchi2", st); hipLaunchKernelGGL(k_ba_upchi2, dim3((gA_up + up_rep * (UPC_T / 4) - 1) / (up_rep * (UPC_T / 4)) + 1, 1, nA), dim3(UPC_T), ldsA_up_plain, st, QA, up_rep); }
             }
         }
         if (nB) {
@@ -2373,7 +2374,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     B.cam = BaCam{(double)c->p.fx, (double)c->p.fy, (double)c->p.cx, (double)c->p.cy};
     B.delta = in->huber_delta; B.chi2_th = in->chi2_th; B.gp = (nx + 63) / 64; B.edges_by_point = sorted_by_point ? 1 : 0;
     B.e_obs = nullptr; B.cull = nullptr; B.ncull = nullptr; B.cull_cap = 0; B.cull_host = nullptr; B.cull_host_cap = 0;
-    B.gen1 = 0; B.shard_rank = 0; B.shard_world = 1; B.pad_ = 0; B.xbuf = nullptr;
+    B.gen1 = 0; B.shard_rank = 0; B.shard_world = 1; B.upc_ovf = sizeof(double) * (24 * (size_t)np + (size_t)D + UPC_LDS_EXTRA) <= 150 * 1024 ? 1 : 0; B.xbuf = nullptr;
 
     {
         if (up_end > c->h_ba_up_bytes) {                    // pinned mirror of the upload region, grown geometrically
@@ -3042,7 +3043,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     B.cam = BaCam{(double)c->p.fx, (double)c->p.fy, (double)c->p.cx, (double)c->p.cy};
     B.delta = huber_delta; B.chi2_th = chi2_th; B.gp = (nx + 63) / 64; B.edges_by_point = 1;
     B.e_obs = e_obs; B.cull = (long long*)(base + o_cull); B.ncull = (int*)(base + o_ncull); B.cull_cap = ne; B.cull_host = nullptr; B.cull_host_cap = 0;      // (the engine points cull_host at its slot's pinned list)
-    B.gen1 = 0; B.shard_rank = 0; B.shard_world = 1; B.pad_ = 0; B.xbuf = nullptr;
+    B.gen1 = 0; B.shard_rank = 0; B.shard_world = 1; B.upc_ovf = sizeof(double) * (24 * (size_t)np + (size_t)D + UPC_LDS_EXTRA) <= 150 * 1024 ? 1 : 0; B.xbuf = nullptr;
     HIP_TRY(hipGetLastError());
     R.nblk_launch = slices_ub; R.npairs = npairs;
     R.B = B;

@@ -413,18 +413,33 @@ __device__ __forceinline__ void p2_exp_mul_row(const double* d, const double* T,
 // FUSED: the workgroup runs in the same launch as the Cholesky (k_ba_cholup): everything that does not depend on the solution -- the
 // point records, the first round of edges, the current poses -- is requested first, then the workgroup waits for the word the solver
 // workgroup sets behind its results (which it has written through to memory), and reads them past its own caches.
+// LDS of an update workgroup behind the poses and the solution (doubles): the round's points for the overflow lanes, their pass-1 / pass-2 accumulators, the overflow list
+#define UPC_OVF_CAP 1024                                     // overflow list entries (a workgroup's edges beyond the first four of each point: 60-130 in the bench's windows)
+#define UPC_OVF_MINE 4                                       // list entries a lane can own (its point's edges 5 .. 20 spread over the point's four lanes; beyond: the lane walks them itself)
+#define UPC_LDS_EXTRA (3 * (UPC_T / 4) + 9 * UPC_OVF_CAP + UPC_OVF_CAP / 2)
 template <bool FUSED>
 __device__ __forceinline__ void ba_upchi2_body(const BaDev& B, BaCtl* ctl_, int rep, const int bx, const int bz) {
     // 128 points per workgroup and round (4 lanes each), `rep` rounds: with several problems per launch every workgroup's fixed costs (the trial
-    // poses, the partial sums and the ticket) are spread over more points -- a lone problem keeps rep = 1 and the most workgroups
+    // poses, the partial sums and the ticket) are spread over more points -- a lone problem keeps rep = 1 and the most workgroups.
+    // Round 6: (a) workgroup gp owns NO points: it does what workgroup 0 did beside its points -- the trial poses to global memory, the pose part of the gain
+    // ratio (atomics + a drain of every wave) -- so that the workgroup that takes the last ticket is no longer the one with the most work;
+    // (b) a point's edges beyond its first four are not walked by its four lanes in rounds of four (the bench's windows: largest degree per workgroup
+    // 10 on average, 21 at most: 3-6 dependent rounds per pass where most lanes had one) but put on a workgroup-wide list and taken ONE PER LANE,
+    // their contributions written to the entry's own LDS cell and added up by the lane that listed them, in the order it listed them (no atomics: two runs of
+    // one solve add in the same order): two rounds per pass whatever the degrees are (scripts/ba_degree_stats.py).
     const int gp = (B.n_points + rep * (UPC_T / 4) - 1) / (rep * (UPC_T / 4));
-    if (bx >= gp) return;
+    if (bx > gp) return;
+    const bool pose_wg = bx == gp;
     extern __shared__ double s_dyn[];
     double* const s_T = s_dyn;                             // trial poses [n_poses][12]
     double* const s_dp = s_dyn + 12 * (size_t)B.n_poses;   // pose increments [D]
+    double* const s_Tc = s_dp + B.D;                       // current poses [n_poses][12] (pass 1 reads them per edge)
+    double* const s_pp = s_Tc + 12 * (size_t)B.n_poses;    // [128][3] the round's points: current, then trial (what an overflow lane knows of a point that is not its own)
+    double* const s_c = s_pp + 3 * (UPC_T / 4);            // [UPC_OVF_CAP][9] an overflow entry's contribution: pass 1 rhs (3), pass 2 H_ll (6) + b_l (3)
+    int* const s_list = reinterpret_cast<int*>(s_c + 9 * UPC_OVF_CAP);      // [UPC_OVF_CAP] (local point << 24 | edge position)
     __shared__ double s_w[3 * (UPC_T / 64)];
     __shared__ double s_hb[9 * (UPC_T / 4)];               // H_ll (6) and b_l (3) of the round's 128 points, parked during pass 1
-    __shared__ int s_last, s_accept;
+    __shared__ int s_last, s_accept, s_nov;
     // workgroup-uniform values that arrive through vector loads (the control block is written by this kernel's last workgroup, so the compiler
     // may not use scalar loads): moved to scalar registers by hand, or they and everything derived from them (four record / weight base pointers)
     // occupy vector registers for the whole kernel
@@ -439,50 +454,93 @@ __device__ __forceinline__ void ba_upchi2_body(const BaDev& B, BaCtl* ctl_, int 
 #endif
     P2_STAMP()
     BA_STATE(B)
-    // everything the point passes read from global memory that does not depend on the trial poses is requested BEFORE the poses are
-    // built: the ~2 us of exponential maps below hide the two dependent load levels (pt_start -> edge data) of the first round of edges
     const int lb = __builtin_amdgcn_readfirstlane(ctl_->lbuf);
     const double* const rec = p2_rec(B, lb);
     const double* const Wt = p2_w(B, lb);
     double* const rec_n = p2_rec(B, lb ^ 1);
     double* const Wn = p2_w(B, lb ^ 1);
     int k = bx * rep * (UPC_T / 4) + (threadIdx.x >> 2);
-    const int sub = threadIdx.x & 3;
+    const int sub = threadIdx.x & 3, pl = threadIdx.x >> 2;
+    // (the list packs an edge position into 24 bits; and a graph with so many poses that the list and the cells do not fit LDS beside them -- upc_ovf = 0, the
+    // launch then carries no such region -- walks its edges in rounds of four as before)
+    // Only in the FUSED form (a lone problem, one workgroup per CU because of the solver's LDS: registers and LDS are free there): with several problems per launch the
+    // list's state costs the kernel its second workgroup per CU (149 against 128 VGPRs: 8 / 16 streams 6015 / 7088 against 6184 / 7382 frames/s, measured).
+    const bool ovf_ok = FUSED && B.upc_ovf != 0 && B.n_edges < (1 << 24);
     bool live = false;
     double H[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0}, p[3] = {0, 0, 0}, rhs[3] = {0, 0, 0};
     int q0 = 0, q1 = 0;
-    int e0 = -1, j0 = 0; uint8_t act0 = 0; double w0 = 0; float2 uv0 = make_float2(0.f, 0.f);       // first edge of this lane (most points have <= 4 edges: one round)
-    auto fetch = [&]() {
-        live = ok && k < B.n_points;
-        e0 = -1; act0 = 0; q0 = q1 = 0;
+    // edge A: the lane's own (its point's sub-th edge); edge B: the lane's first item of the overflow list.  Everything of both that does not depend on the
+    // solution is requested -- and, FUSED, linearised at the current state -- before the solution is waited for.
+    int eA = -1, jA = 0; uint8_t actA = 0; double wA = 0; float2 uvA = make_float2(0.f, 0.f);
+    int eB = -1, jB = 0, plB = 0; uint8_t actB = 0; double wB = 0; float2 uvB = make_float2(0.f, 0.f);
+    double JpA[2][6], JlA[2][3], JpB[2][6], JlB[2][3];
+    bool preA = false, preB = false, serial = false;
+    int nov = 0, mine[UPC_OVF_MINE], n_mine = 0, q_ser = 0;      // mine: the list entries this lane made; q_ser: its point's edges from here on it walks itself
+    auto prep = [&](bool pre_jac) {
+        live = ok && !pose_wg && k < B.n_points;
+        eA = -1; actA = 0; q0 = q1 = 0; eB = -1; actB = 0; preA = preB = false;
+        if (FUSED && threadIdx.x == 0) s_nov = 0;
         if (live) {
             q0 = B.pt_start[k]; q1 = B.pt_start[k + 1];
             p2_rec_load(rec, k, H, bl, p);
-            if (q0 + sub < q1) {                           // (no branch on a loaded value here: the loads stay in flight across the pose block below)
+            if (q0 + sub < q1) {
                 const int e = B.edges_by_point ? q0 + sub : B.pt_edges[q0 + sub];
-                act0 = B.active[e]; e0 = e; j0 = B.e_pose[e]; w0 = Wt[e]; uv0 = reinterpret_cast<const float2*>(B.e_uv)[e];
+                actA = B.active[e]; eA = e; jA = B.e_pose[e]; wA = Wt[e]; uvA = reinterpret_cast<const float2*>(B.e_uv)[e];
+            }
+        }
+        n_mine = 0; q_ser = q0 + sub + 4;
+        if (!FUSED) { serial = true; nov = 0; return; }     // (several problems per launch: no overflow list, see ovf_ok)
+        __syncthreads();                                    // s_nov is zero; the previous round's readers of s_pp / s_c / s_list are done
+        if (live) {
+            if (sub == 0 && ovf_ok) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) s_pp[3 * pl + c] = p[c];
+            }
+        }
+        if (live && ovf_ok) {
+#pragma unroll
+            for (int m = 0; m < UPC_OVF_MINE; ++m) {
+                mine[m] = 0;
+                if (q_ser < q1) { const int pos = atomicAdd(&s_nov, 1); mine[m] = pos; if (pos < UPC_OVF_CAP) s_list[pos] = (pl << 24) | q_ser; q_ser += 4; n_mine = m + 1; }
+            }
+        }
+        __syncthreads();
+        nov = __builtin_amdgcn_readfirstlane(s_nov);
+        serial = !ovf_ok || nov > UPC_OVF_CAP;              // (a workgroup whose points have more than 1024 further edges: rounds of four as before)
+        if (serial) { nov = 0; n_mine = 0; q_ser = q0 + sub + 4; }
+        if ((int)threadIdx.x < nov) {
+            const int it = s_list[threadIdx.x], q = it & 0xFFFFFF;
+            plB = it >> 24;
+            const int e = B.edges_by_point ? q : B.pt_edges[q];
+            actB = B.active[e]; eB = e; jB = B.e_pose[e]; wB = Wt[e]; uvB = reinterpret_cast<const float2*>(B.e_uv)[e];
+        }
+        if (pre_jac) {
+            if (live && eA >= 0 && actA && jA < B.n_free) {
+                double T0[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) T0[i] = poses_c[12 * (size_t)jA + i];
+                pb_jac(B.cam, T0, p, JpA, JlA);
+                preA = true;
+            }
+            if (eB >= 0 && actB && jB < B.n_free) {
+                double T0[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) T0[i] = poses_c[12 * (size_t)jB + i];
+                const double pb[3] = {s_pp[3 * plB], s_pp[3 * plB + 1], s_pp[3 * plB + 2]};
+                pb_jac(B.cam, T0, pb, JpB, JlB);
+                preB = true;
             }
         }
     };
-    fetch();
-    double* const s_Tc = s_dp + B.D;                        // current poses [n_poses][12] (pass 1 reads them per edge)
+    prep(FUSED);
     __shared__ double s_ctl[4];                             // FUSED: lambda, ok, cur, ni as the solver workgroup published them
-    double Jp0[2][6], Jl0[2][3];                            // FUSED: the first edge's Jacobians at the CURRENT state, built while the solver works
-    bool pre0 = false;
     if (FUSED) {
-        // Round 6: nothing that can be done without the solution is left behind the wait.  The current poses go to LDS now; the lane's first edge (pass 1:
-        // rhs -= W_e^T dp_j needs only the Jacobians at the current state and dp) is linearised now; and behind the solver's word the solution, lambda,
-        // ok, cur and ni arrive in ONE batch of loads (the solver stores them side by side: dl[0 .. D + 3]).  (Measured and dropped: every value as
-        // two tagged 64-bit words that the lanes poll themselves -- no word, no drain in the solver -- was 1.7 % SLOWER end to end: twice the bytes from
-        // 171 workgroups at the same instant, on one memory channel.)
+        // Nothing that can be done without the solution is left behind the wait: the current poses go to LDS, both of the lane's edges are linearised at the
+        // current state (pass 1: rhs -= W_e^T dp_j needs only those Jacobians and dp), and behind the solver's word the solution, lambda, ok, cur and
+        // ni arrive in ONE batch of loads (the solver stores them side by side: dl[0 .. D + 3]).  (Measured and dropped: every value as two tagged
+        // 64-bit words that the lanes poll themselves -- no word, no drain in the solver -- was 1.7 % SLOWER end to end: twice the bytes from 171
+        // workgroups at the same instant, on one memory channel.)
         for (int i = threadIdx.x; i < 12 * B.n_poses; i += UPC_T) s_Tc[i] = poses_c[i];
-        if (live && e0 >= 0 && act0 && j0 < B.n_free) {
-            double T0[12];
-#pragma unroll
-            for (int i = 0; i < 12; ++i) T0[i] = poses_c[12 * (size_t)j0 + i];
-            pb_jac(B.cam, T0, p, Jp0, Jl0);
-            pre0 = true;
-        }
         __shared__ int s_flag;
         if (threadIdx.x == 0) {
             const int wseq = ctl_->steps + 1;              // (steps: the last workgroup of the previous step's launch wrote it)
@@ -503,7 +561,7 @@ __device__ __forceinline__ void ba_upchi2_body(const BaDev& B, BaCtl* ctl_, int 
         lambda = p2_uniform(s_ctl[0]);
         ok = seen != 0 && __builtin_amdgcn_readfirstlane((int)(s_ctl[1] != 0.0)) != 0;      // (a wait that ran out: the step counts as failed)
         live = live && ok;
-        if (!ok) { e0 = -1; act0 = 0; q0 = q1 = 0; pre0 = false; }
+        if (!ok) { eA = -1; actA = 0; q0 = q1 = 0; preA = preB = false; eB = -1; actB = 0; nov = 0; }
     } else {
         for (int i = threadIdx.x; i < B.D; i += UPC_T) s_dp[i] = B.dl[i];       // the solution (k_ba_chol16, phase2 = 1)
     }
@@ -513,14 +571,14 @@ __device__ __forceinline__ void ba_upchi2_body(const BaDev& B, BaCtl* ctl_, int 
     for (int i = threadIdx.x; i < 12 * B.n_poses; i += UPC_T) {
         const double v = FUSED ? s_Tc[i] : poses_c[i];      // (FUSED: this lane's own entries of a moment ago)
         if (!FUSED) s_Tc[i] = v;
-        if (i >= 12 * n_exp) { s_T[i] = v; if (bx == 0) poses_t[i] = v; }
+        if (i >= 12 * n_exp) { s_T[i] = v; if (pose_wg) poses_t[i] = v; }
     }
     for (int t = threadIdx.x; t < 3 * n_exp; t += UPC_T) {
         const int j = t / 3, r = t - 3 * j;
         const double* d = FUSED ? s_dp + 6 * j : B.dl + 6 * j;
         double row[3], tr;
         p2_exp_mul_row(d, FUSED ? s_Tc + 12 * j : poses_c + 12 * (size_t)j, r, row, tr);
-        if (bx == 0 && r == 0) {                   // the pose part of the gain ratio and of the step size, once
+        if (pose_wg && r == 0) {                   // the pose part of the gain ratio and of the step size, once
             double sc = 0, mx = 0;
             for (int a = 0; a < 6; ++a) { sc += d[a] * (lambda * d[a] + B.bp[6 * j + a]); mx = fmax(mx, fabs(d[a])); }
             atomicAdd(&B.scal[2], sc);
@@ -528,29 +586,39 @@ __device__ __forceinline__ void ba_upchi2_body(const BaDev& B, BaCtl* ctl_, int 
         }
         double* o = s_T + 12 * j;
         o[3 * r] = row[0]; o[3 * r + 1] = row[1]; o[3 * r + 2] = row[2]; o[9 + r] = tr;
-        if (bx == 0) { double* g = poses_t + 12 * (size_t)j; g[3 * r] = row[0]; g[3 * r + 1] = row[1]; g[3 * r + 2] = row[2]; g[9 + r] = tr; }
+        if (pose_wg) { double* g = poses_t + 12 * (size_t)j; g[3 * r] = row[0]; g[3 * r + 1] = row[1]; g[3 * r + 2] = row[2]; g[9 + r] = tr; }
     }
-    // block 0's atomics on scal[2] / scal[7] above come from lanes of several waves; the fence-free ticket at the end of this kernel has only
-    // thread 0's wave drain vmcnt before it takes its ticket, and a workgroup-scope barrier does not drain it: every wave of block 0
-    // drains here, so the atomics are performed before block 0 can take a ticket (k_ba_round got the same fix in ac73ae7)
-    if (bx == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the pose workgroup's atomics on scal[2] / scal[7] above come from lanes of several waves; the fence-free ticket at the end of this kernel has only
+    // thread 0's wave drain vmcnt before it takes its ticket, and a workgroup-scope barrier does not drain it: every wave of that workgroup
+    // drains here, so the atomics are performed before it can take a ticket (k_ba_round got the same fix in ac73ae7)
+    if (pose_wg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     P2_STAMP()
     double chi = 0, sc = 0, mx = 0;
     for (int r = 0; r < rep; ++r, k += UPC_T / 4) {
-        if (r) { fetch(); rhs[0] = rhs[1] = rhs[2] = 0; }
-        if (!act0) e0 = -1;
-        auto pass1 = [&](int j, double w) {                 // rhs -= W_e^T dp_j
+        if (r) { prep(false); rhs[0] = rhs[1] = rhs[2] = 0; }
+        if (!actA) eA = -1;
+        if (!actB) eB = -1;
+        // rhs -= W_e^T dp_j for one edge of point `pt` to free pose j: into acc (the lane's own point) or, for an overflow edge, into the point's LDS cell
+        auto pass1 = [&](int j, double w, const double (&pt)[3], double (&acc)[3]) {
             double T[12], Jp[2][6], Jl[2][3];
 #pragma unroll
             for (int i = 0; i < 12; ++i) T[i] = s_Tc[12 * j + i];
-            pb_jac(B.cam, T, p, Jp, Jl);
+            pb_jac(B.cam, T, pt, Jp, Jl);
             const double* d6 = s_dp + 6 * j;
             double t0 = 0, t1 = 0;
 #pragma unroll
             for (int a = 0; a < 6; ++a) { t0 += Jp[0][a] * d6[a]; t1 += Jp[1][a] * d6[a]; }
 #pragma unroll
-            for (int c = 0; c < 3; ++c) rhs[c] -= w * (Jl[0][c] * t0 + Jl[1][c] * t1);
+            for (int c = 0; c < 3; ++c) acc[c] -= w * (Jl[0][c] * t0 + Jl[1][c] * t1);
+        };
+        auto pass1_pre = [&](int j, double w, const double (&Jp)[2][6], const double (&Jl)[2][3], double (&acc)[3]) {      // the same from Jacobians built before the wait
+            const double* d6 = s_dp + 6 * j;
+            double t0 = 0, t1 = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) { t0 += Jp[0][a] * d6[a]; t1 += Jp[1][a] * d6[a]; }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c] -= w * (Jl[0][c] * t0 + Jl[1][c] * t1);
         };
         // H_ll and b_l are not needed while pass 1 runs (the kernel's register peak): lane 0 of the point parks them in LDS, all four lanes take them
         // back afterwards (same wavefront: program order is enough)
@@ -563,35 +631,53 @@ __device__ __forceinline__ void ba_upchi2_body(const BaDev& B, BaCtl* ctl_, int 
         }
         if (live) {
             if (sub == 0) { rhs[0] = bl[0]; rhs[1] = bl[1]; rhs[2] = bl[2]; }
-            if (FUSED && pre0 && r == 0) {                  // the Jacobians were built before the wait
-                const double* d6 = s_dp + 6 * j0;
-                double t0 = 0, t1 = 0;
-#pragma unroll
-                for (int a = 0; a < 6; ++a) { t0 += Jp0[0][a] * d6[a]; t1 += Jp0[1][a] * d6[a]; }
-#pragma unroll
-                for (int c = 0; c < 3; ++c) rhs[c] -= w0 * (Jl0[0][c] * t0 + Jl0[1][c] * t1);
-            } else if (e0 >= 0 && j0 < B.n_free) pass1(j0, w0);
+            if (preA && r == 0) pass1_pre(jA, wA, JpA, JlA, rhs);
+            else if (eA >= 0 && jA < B.n_free) pass1(jA, wA, p, rhs);
 #pragma nounroll
-            for (int q = q0 + sub + 4; q < q1; q += 4) {
+            for (int q = q_ser; q < q1; q += 4) {         // (nothing, usually: the edges the list did not take)
                 const int e = B.edges_by_point ? q : B.pt_edges[q], j = B.e_pose[e];
                 if (!B.active[e] || j >= B.n_free) continue;
-                pass1(j, Wt[e]);
+                pass1(j, Wt[e], p, rhs);
             }
         }
+        // overflow edges, one per lane (the first one was fetched, and FUSED linearised, in prep)
+        for (int i = threadIdx.x; i < nov; i += UPC_T) {
+            int e = eB, j = jB, plq = plB; double w = wB; bool pre = preB && r == 0;
+            if (i >= UPC_T) {
+                const int it = s_list[i], q = it & 0xFFFFFF;
+                plq = it >> 24; e = B.edges_by_point ? q : B.pt_edges[q];
+                if (!B.active[e]) e = -1; else { j = B.e_pose[e]; w = Wt[e]; }
+                pre = false;
+            }
+            double acc[3] = {0, 0, 0};
+            if (e >= 0 && j < B.n_free) {
+                if (pre) pass1_pre(j, w, JpB, JlB, acc);
+                else { const double pt[3] = {s_pp[3 * plq], s_pp[3 * plq + 1], s_pp[3 * plq + 2]}; pass1(j, w, pt, acc); }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) s_c[9 * i + c] = acc[c];
+        }
+        __syncthreads();                                    // the entries' shares of rhs are in their cells (and nobody reads s_pp's CURRENT points any more)
+#pragma unroll
+        for (int m = 0; m < UPC_OVF_MINE; ++m)
+            if (m < n_mine) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) rhs[c] += s_c[9 * mine[m] + c];
+            }
 #pragma unroll
         for (int c = 0; c < 3; ++c) rhs[c] = ba_quad_sum(rhs[c]);
         P2_STAMP()
         double Hn[6] = {0, 0, 0, 0, 0, 0}, bn[3] = {0, 0, 0}, pn[3] = {0, 0, 0};
         // second pass over the point's edges at the TRIAL state: robust chi2 (the LM decision) and the whole linearisation (Huber weight,
         // H_ll, b_l) that the next step needs if this one is accepted -- k_ba_lin2's point part at the price of a few dozen FMAs per edge
-        auto pass2 = [&](int e, int j, const float* uv) {
-            double r[2], w, rho0, Jp[2][6], Jl[2][3];
-            ba_edge(B.cam, s_T + 12 * j, pn, uv, robust, B.delta, r, w, rho0, Jp, Jl);
+        auto pass2 = [&](int e, int j, const float* uv, const double (&pt)[3], double (&Ha)[6], double (&ba)[3]) {
+            double rr[2], w, rho0, Jp[2][6], Jl[2][3];
+            ba_edge(B.cam, s_T + 12 * j, pt, uv, robust, B.delta, rr, w, rho0, Jp, Jl);
             chi += rho0;
             Wn[e] = w;
-            bn[0] -= w * (Jl[0][0] * r[0] + Jl[1][0] * r[1]); bn[1] -= w * (Jl[0][1] * r[0] + Jl[1][1] * r[1]); bn[2] -= w * (Jl[0][2] * r[0] + Jl[1][2] * r[1]);
-            Hn[0] += w * (Jl[0][0] * Jl[0][0] + Jl[1][0] * Jl[1][0]); Hn[1] += w * (Jl[0][0] * Jl[0][1] + Jl[1][0] * Jl[1][1]); Hn[2] += w * (Jl[0][0] * Jl[0][2] + Jl[1][0] * Jl[1][2]);
-            Hn[3] += w * (Jl[0][1] * Jl[0][1] + Jl[1][1] * Jl[1][1]); Hn[4] += w * (Jl[0][1] * Jl[0][2] + Jl[1][1] * Jl[1][2]); Hn[5] += w * (Jl[0][2] * Jl[0][2] + Jl[1][2] * Jl[1][2]);
+            ba[0] -= w * (Jl[0][0] * rr[0] + Jl[1][0] * rr[1]); ba[1] -= w * (Jl[0][1] * rr[0] + Jl[1][1] * rr[1]); ba[2] -= w * (Jl[0][2] * rr[0] + Jl[1][2] * rr[1]);
+            Ha[0] += w * (Jl[0][0] * Jl[0][0] + Jl[1][0] * Jl[1][0]); Ha[1] += w * (Jl[0][0] * Jl[0][1] + Jl[1][0] * Jl[1][1]); Ha[2] += w * (Jl[0][0] * Jl[0][2] + Jl[1][0] * Jl[1][2]);
+            Ha[3] += w * (Jl[0][1] * Jl[0][1] + Jl[1][1] * Jl[1][1]); Ha[4] += w * (Jl[0][1] * Jl[0][2] + Jl[1][1] * Jl[1][2]); Ha[5] += w * (Jl[0][2] * Jl[0][2] + Jl[1][2] * Jl[1][2]);
         };
         if (live) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -609,16 +695,46 @@ __device__ __forceinline__ void ba_upchi2_body(const BaDev& B, BaCtl* ctl_, int 
             for (int a = 0; a < 3; ++a) {
                 const double d = h[3 * a] * rhs[0] + h[3 * a + 1] * rhs[1] + h[3 * a + 2] * rhs[2];
                 pn[a] = p[a] + d;
-                if (sub == 0) { pts_t[3 * (size_t)k + a] = pn[a]; sc += d * (lambda * d + bq[a]); mx = fmax(mx, fabs(d)); }
-            }
-            if (e0 >= 0) { const float uvv[2] = {uv0.x, uv0.y}; pass2(e0, j0, uvv); }
-#pragma nounroll
-            for (int q = q0 + sub + 4; q < q1; q += 4) {
-                const int e = B.edges_by_point ? q : B.pt_edges[q];
-                if (!B.active[e]) continue;
-                pass2(e, B.e_pose[e], B.e_uv + 2 * (size_t)e);
+                if (sub == 0) { pts_t[3 * (size_t)k + a] = pn[a]; if (ovf_ok) s_pp[3 * pl + a] = pn[a]; sc += d * (lambda * d + bq[a]); mx = fmax(mx, fabs(d)); }
             }
         }
+        __syncthreads();                                    // s_pp holds the TRIAL points
+        if (live) {
+            if (eA >= 0) { const float uvv[2] = {uvA.x, uvA.y}; pass2(eA, jA, uvv, pn, Hn, bn); }
+#pragma nounroll
+            for (int q = q_ser; q < q1; q += 4) {
+                const int e = B.edges_by_point ? q : B.pt_edges[q];
+                if (!B.active[e]) continue;
+                pass2(e, B.e_pose[e], B.e_uv + 2 * (size_t)e, pn, Hn, bn);
+            }
+        }
+        for (int i = threadIdx.x; i < nov; i += UPC_T) {
+            int e = eB, j = jB, plq = plB; float2 uv = uvB;
+            if (i >= UPC_T) {
+                const int it = s_list[i], q = it & 0xFFFFFF;
+                plq = it >> 24; e = B.edges_by_point ? q : B.pt_edges[q];
+                if (!B.active[e]) e = -1; else { j = B.e_pose[e]; uv = reinterpret_cast<const float2*>(B.e_uv)[e]; }
+            }
+            double Ha[6] = {0, 0, 0, 0, 0, 0}, ba[3] = {0, 0, 0};
+            if (e >= 0) {
+                const double pt[3] = {s_pp[3 * plq], s_pp[3 * plq + 1], s_pp[3 * plq + 2]};
+                const float uvv[2] = {uv.x, uv.y};
+                pass2(e, j, uvv, pt, Ha, ba);
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) s_c[9 * i + c] = Ha[c];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) s_c[9 * i + 6 + c] = ba[c];
+        }
+        __syncthreads();                                    // the entries' shares of H_ll / b_l are in their cells
+#pragma unroll
+        for (int m = 0; m < UPC_OVF_MINE; ++m)
+            if (m < n_mine) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) Hn[c] += s_c[9 * mine[m] + c];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) bn[c] += s_c[9 * mine[m] + 6 + c];
+            }
 #pragma unroll
         for (int i = 0; i < 6; ++i) Hn[i] = ba_quad_sum(Hn[i]);
 #pragma unroll
@@ -642,7 +758,7 @@ __device__ __forceinline__ void ba_upchi2_body(const BaDev& B, BaCtl* ctl_, int 
         pb_st(B.partU + 3 * (size_t)bx + 1, b_);
         pb_st(B.partU + 3 * (size_t)bx + 2, m_);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_last = __hip_atomic_fetch_add(&ctl_->arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gp - 1;
+        s_last = __hip_atomic_fetch_add(&ctl_->arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gp;      // (gp point workgroups + the pose workgroup)
     }
     __syncthreads();
     P2_STAMP()
@@ -662,7 +778,7 @@ __device__ __forceinline__ void ba_upchi2_body(const BaDev& B, BaCtl* ctl_, int 
     {   // the last workgroup: the partials of every workgroup, then g2o's gain-ratio test and lambda policy (as k_ba_chi_control)
         const double* pu = B.partU;
         double a = 0, b = 0, m = 0;
-        for (int i = threadIdx.x; i < gp; i += UPC_T) { a += pb_ld(pu + 3 * i); b += pb_ld(pu + 3 * i + 1); m = fmax(m, pb_ld(pu + 3 * i + 2)); }
+        for (int i = threadIdx.x; i <= gp; i += UPC_T) { a += pb_ld(pu + 3 * i); b += pb_ld(pu + 3 * i + 1); m = fmax(m, pb_ld(pu + 3 * i + 2)); }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); m = fmax(m, __shfl_xor(m, o, 64)); }
         __syncthreads();
@@ -715,7 +831,7 @@ __device__ __forceinline__ void ba_upchi2_body(const BaDev& B, BaCtl* ctl_, int 
 #endif
 }
 
-__global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q, int rep) {
+__global__ __launch_bounds__(UPC_T) void k_ba_upchi2(BaBatch Q, int rep) {      // (two workgroups per CU: 128 VGPRs -- at 129 the kernel ran one)
     BA_PROBLEM_COPY(Q)
     if (ctl_->finished || B.D > BA_FOLD_D) return;
     ba_upchi2_body<false>(B, ctl_, rep, (int)blockIdx.x, (int)blockIdx.z);
