@@ -73,6 +73,7 @@ struct BaDev {
     const int32_t* e_pose; const int32_t* e_pt; const float* e_uv; uint8_t* active; uint8_t* flags;
     const int32_t* pt_start; const int32_t* pt_edges;       // CSR point -> edges
     const int32_t* ps_start; const int32_t* ps_edges;       // CSR free pose -> edges
+    const int32_t* ps_pt;                                   // optional: the points of the per-pose lists' edges (same positions as ps_edges): one load level less in the pose workgroups of the Schur launch; nullptr: e_pt[e]
     const BaBlock* blocks; const int2* pairs;               // (e1, e2) pairs sharing a point, grouped by (pose(e1) <= pose(e2))
     const int32_t* pair_pt;                                 // optional: the pairs' points (same positions as `pairs`), so that the Schur slices read the point record one load level earlier; nullptr: e_pt[e1]
     const int* n_slices;                                     // device-built pair lists: number of valid entries of `blocks` (nullptr: n_blocks)
@@ -1738,11 +1739,11 @@ __global__ __launch_bounds__(CH2_T) void k_ba_cholup(BaBatch Q, int n, int gpmax
 
 // the same for a lone problem, its descriptor in the kernel's arguments (see k_ba_schur2_one)
 __global__ __launch_bounds__(CH2_T) void k_ba_cholup_one(BaDev B, BaCtl* ctl_, int gpmax, int rep) {
-    if (ctl_->finished) return;
     if (blockIdx.x == 0) {
         extern __shared__ double s_mem[];
-        ba_chol16v2_body<true>(B, ctl_, s_mem, B.dl, true);
+        ba_chol16v2_body<true>(B, ctl_, s_mem, B.dl, true, true);      // (ctl->finished comes with the solver's head load)
     } else {
+        if (ctl_->finished) return;
         ba_upchi2_body<true>(B, ctl_, rep, ((int)blockIdx.x - 1) % gpmax, 0);
     }
 }
@@ -2363,7 +2364,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     BaDev B;
     B.n_poses = np; B.n_free = nf; B.n_points = nx; B.n_edges = ne; B.D = D; B.n_blocks = nblk; B.s_tiles = ba_use_tiles(D);
     B.n_slices = dev_pairs ? (const int*)(base + o_pn) : nullptr;
-    B.ps_start = (const int32_t*)(base + o_qs); B.ps_edges = (const int32_t*)(base + o_qe); B.blocks = (const BaBlock*)(base + o_blk); B.pairs = (const int2*)(base + o_pairs); B.pair_pt = nullptr;
+    B.ps_start = (const int32_t*)(base + o_qs); B.ps_edges = (const int32_t*)(base + o_qe); B.blocks = (const BaBlock*)(base + o_blk); B.pairs = (const int2*)(base + o_pairs); B.pair_pt = nullptr; B.ps_pt = (const int32_t*)(base + o_pspt);
     B.posesA = (double*)(base + o_poses); B.ptsA = (double*)(base + o_pts); B.posesB = (double*)(base + o_poses_n); B.ptsB = (double*)(base + o_pts_n);
     B.ctl = nullptr;                                        // the engine assigns the control block of the problem's slot
     B.partU = (double*)(base + o_partU); B.partC = (double*)(base + o_partC); B.nU = (nx + 63) / 64;
@@ -3032,7 +3033,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     B.n_poses = np; B.n_free = nf; B.n_points = nx; B.n_edges = ne; B.D = D; B.s_tiles = ba_use_tiles(D);
     B.n_blocks = slices_ub;                                 // launch bound; the Schur kernel stops at *n_slices, which the plan kernels below write
     B.n_slices = (const int*)(base + o_pn);
-    B.ps_start = (const int32_t*)(base + o_qs); B.ps_edges = (const int32_t*)(base + o_qe); B.blocks = (const BaBlock*)(base + o_blk); B.pairs = (const int2*)(base + o_pairs); B.pair_pt = (const int32_t*)(base + o_ppt);
+    B.ps_start = (const int32_t*)(base + o_qs); B.ps_edges = (const int32_t*)(base + o_qe); B.blocks = (const BaBlock*)(base + o_blk); B.pairs = (const int2*)(base + o_pairs); B.pair_pt = (const int32_t*)(base + o_ppt); B.ps_pt = (const int32_t*)(base + o_pspt);
     B.posesA = (double*)(base + o_poses); B.ptsA = (double*)(base + o_pts); B.posesB = (double*)(base + o_poses_n); B.ptsB = (double*)(base + o_pts_n);
     B.ctl = nullptr;
     B.partU = (double*)(base + o_partU); B.partC = (double*)(base + o_partC); B.nU = (nx + 63) / 64;
@@ -3060,7 +3061,7 @@ extern "C" int vo_local_ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* fre
     const bool trace = vo_trace_level() != 0;
     const double t0 = trace ? tnow() : 0.0;
     const int rc = ba_resident_cut(c, t, free_kf, n_free, huber_delta, chi2_th);
-    if (trace) { static double a = 0; static int n = 0; a += tnow() - t0; if (++n % 10 == 0 && c->resident) fprintf(stderr, "[vo_trace] resident cut avg ms: %.3f (this one: window %lld observations / %d slots -> %d points, %d edges, %d free + %d fixed poses)\n", a / n, c->resident->win_obs, c->resident->win_slots, c->resident->nx, c->resident->ne, c->resident->nf, c->resident->n_fixed); }
+    if (trace) { static double a = 0; static int n = 0; a += tnow() - t0; if (++n % 10 == 0 && c->resident) fprintf(stderr, "[vo_trace] resident cut avg ms: %.3f (this one: window %lld observations / %lld slots -> %d points, %d edges, %d free + %d fixed poses)\n", a / n, c->resident->win_obs, c->resident->win_slots, c->resident->nx, c->resident->ne, c->resident->nf, c->resident->n_fixed); }
     if (rc == VO_OK && c->resident) { if (n_points) *n_points = c->resident->nx; if (n_fixed) *n_fixed = c->resident->n_fixed; if (n_edges) *n_edges = c->resident->ne; }
     return rc;
 }

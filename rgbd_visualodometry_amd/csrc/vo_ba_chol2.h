@@ -213,7 +213,7 @@ __device__ __forceinline__ void ch2_tiles_mp(double* s_L, const int (&ti)[3], co
 __device__ __forceinline__ void ch2_pub_i(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ch2_pub_d(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <bool PUB>
-__device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, double* s_mem, double* x_out, bool clear_after_load) {
+__device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, double* s_mem, double* x_out, bool clear_after_load, const bool check_finished = false) {
     // the wave number goes through readfirstlane: as a per-thread value every role branch below would be compiled as divergent (EXEC masks,
     // loop counters and tile indices in vector registers)
     const int D = B.D, DA = D + 1, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r16 = lane & 15, kq = lane >> 4;
@@ -226,36 +226,49 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
     const int o_row = CH2_RS * r16;                            // row r16 of a tile (a row per lane)
     const int o_op = CH2_RS * r16 + kq;                        // MFMA operand: row r16, columns kq + 4 q
     const int o_c = CH2_RS * kq + r16;                         // MFMA result: rows kq + 4 q, column r16
+    // The head: ONE trip to L2 for everything this workgroup needs of the control block and of scal[] -- lane i < 28 takes word i of the control block, lanes
+    // 32 .. 47 the words of scal[0 .. 7]; the fields come out by readlane.  (Up to round 6 a field at a time behind a branch each: need_lin, first, lambda or
+    // scal[4] -- and then thread 0's take-over of the fresh linearisation, another three dependent trips in front of block 0's factorisation.  A vector load, not
+    // scalar ones: the barrier below waits for LDS and scalar memory together, a vector load stays in flight across it, so the tiles' DMA goes out while the head
+    // is still on its way.)
+    static_assert(sizeof(BaCtl) <= 112 && sizeof(BaCtl) % 4 == 0, "the head load takes the control block as sizeof / 4 <= 28 words");
+    const int hw_ = *(lane < 32 ? reinterpret_cast<const int*>(ctl_) + min(lane, (int)sizeof(BaCtl) / 4 - 1) : reinterpret_cast<const int*>(B.scal) + ((lane - 32) & 15));
+    auto h_i = [&](size_t byte_off) { return __builtin_amdgcn_readlane(hw_, (int)(byte_off / 4)); };
+    auto h_d = [&](size_t byte_off) { return __hiloint2double(__builtin_amdgcn_readlane(hw_, (int)(byte_off / 4) + 1), __builtin_amdgcn_readlane(hw_, (int)(byte_off / 4))); };
+    auto h_scal = [&](int i) { return __hiloint2double(__builtin_amdgcn_readlane(hw_, 32 + 2 * i + 1), __builtin_amdgcn_readlane(hw_, 32 + 2 * i)); };
     __shared__ Ch2Flags F;
     if (tid < 16) { F.rowdone[tid] = 0; F.rdy[tid] = -1; }
     if (tid == 0) { F.prog = 0; F.dma = 0; F.init = 0; F.ok = 1; F.abort_ = 0; F.inv = 0; }
-    const double lambda = (ctl_->need_lin && ctl_->first) ? 1e-5 * B.scal[4] : ctl_->lambda;      // as k_ba_init_S derives it
     const double* const Hpp = B.Hpp;
-    __syncthreads();                                           // the words are zero, everyone has read the control block
+    __syncthreads();                                           // the words are zero
     CH2_STAMP(127)
-    if (tid == 0) {                                            // take over the fresh linearisation, clear the trial sums
+    // (values of the head: evaluated where they are first needed -- behind the DMA's issue for the loading waves, behind block 0's row loads for wave 0)
+#define CH2_LAMBDA() ((h_i(offsetof(BaCtl, need_lin)) && h_i(offsetof(BaCtl, first))) ? 1e-5 * h_scal(4) : h_d(offsetof(BaCtl, lambda)))      /* as k_ba_init_S derives it */
+    // The fresh linearisation is taken over and the trial sums are cleared at the END (take_over, wave 0 lane 0, in front of the solution's publication): nothing in this
+    // workgroup reads those fields again, and the update workgroups look at them only behind the solver's word.
+    auto take_over = [&](double lambda) {
         BaCtl* c = ctl_;
+        const int need_lin0 = h_i(offsetof(BaCtl, need_lin)), first0 = h_i(offsetof(BaCtl, first));
+        const double cur_v = need_lin0 ? h_scal(0) : h_d(offsetof(BaCtl, cur)), ni_v = (need_lin0 && first0) ? 2.0 : h_d(offsetof(BaCtl, ni));
         if (PUB) {
             // what the update workgroups need of the control block goes out beside the solution (dl[D]: lambda, [D + 1]: ok, [D + 2]: cur, [D + 3]: ni): they fetch
             // all of it in ONE batch of loads behind the word (three dependent trips before round 6)
-            const double cur_v = c->need_lin ? B.scal[0] : c->cur, ni_v = (c->need_lin && c->first) ? 2.0 : c->ni;
             ch2_pub_d(B.dl + D, lambda); ch2_pub_d(B.dl + D + 2, cur_v); ch2_pub_d(B.dl + D + 3, ni_v);
-            if (c->need_lin) {
+            if (need_lin0) {
                 ch2_pub_d(&c->cur, cur_v);
-                if (c->first) { ch2_pub_d(&c->lambda, lambda); ch2_pub_d(&c->ni, 2.0); ch2_pub_i(&c->first, 0); }
+                if (first0) { ch2_pub_d(&c->lambda, lambda); ch2_pub_d(&c->ni, 2.0); ch2_pub_i(&c->first, 0); }
                 ch2_pub_i(&c->need_lin, 0);
             }
             ch2_pub_d(B.scal + 1, 0.0); ch2_pub_d(B.scal + 2, 0.0); ch2_pub_d(B.scal + 7, 0.0);
         } else {
-            if (c->need_lin) {
-                c->cur = B.scal[0];
-                if (c->first) { c->lambda = lambda; c->ni = 2; c->first = 0; }
+            if (need_lin0) {
+                c->cur = cur_v;
+                if (first0) { c->lambda = lambda; c->ni = 2; c->first = 0; }
                 c->need_lin = 0;
             }
             B.scal[1] = 0; B.scal[2] = 0; B.scal[7] = 0;
         }
-    }
-    const int seq = PUB ? ctl_->steps + 1 : 0;
+    };
 
     // W_k = L_kk^-T: the first generation's panel solve (a row per lane, DPP row broadcasts of the published columns) applied to the rows
     // of the identity -- ONE such pass per stage, by one wave, while wave 0 waits for it (the double-precision DPP pipe is shared by the
@@ -389,8 +402,12 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
 #endif
     if (wave == 0) {
         // ================= P: the chain of diagonal blocks =====================================================================
+        // (check_finished: the caller has NOT looked at ctl->finished -- that would be a trip to L2 in front of everything; the flag comes with the head, and a
+        // finished problem's workgroup leaves here, before it has stored anything, while the other waves leave behind their loads)
+        if (check_finished && h_i(offsetof(BaCtl, finished))) return;
         __builtin_amdgcn_s_setprio(3);
         bool ok = true;
+        double lambda = 0.0;
         for (int k = 0; k < nblk; ++k) {
             const int j0 = CH_NB * k, nb = min(CH_NB, D - j0);
             const bool mine = r16 < nb;
@@ -406,8 +423,10 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
                     const int b = c - 6 * jb;
                     const bool inb = mine && b >= 0 && b <= ab;
                     const double h = inb ? Hpp[36 * jb + 6 * ab + b] : 0.0;
-                    a[c] = grow[c] + h + (c == r16 ? lambda : 0.0);
+                    a[c] = grow[c] + h;
                 }
+                lambda = CH2_LAMBDA();                           // (the head's first use on this wave: behind the row's loads in program order)
+                a[r16] += lambda;                                // (r16 is a lane value: the compiler selects per register)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // S is cleared behind the loads: these count as one of them
                 if (lane == 0) ch2_inc(&F.dma);
             } else {
@@ -505,13 +524,13 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
         CH2_STAMP(62)
         ok = ok && ch2_peek(&F.abort_) == 0;
         if (PUB) {
-            if (lane == 0) { F.ok = ok ? 1 : 0; ch2_pub_d(B.scal + 3, ok ? 1.0 : 0.0); ch2_pub_d(B.dl + D + 1, ok ? 1.0 : 0.0); }
+            if (lane == 0) { F.ok = ok ? 1 : 0; take_over(lambda); ch2_pub_d(B.scal + 3, ok ? 1.0 : 0.0); ch2_pub_d(B.dl + D + 1, ok ? 1.0 : 0.0); }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) ch2_pub_i(&ctl_->chol_seq, seq);
+            if (lane == 0) ch2_pub_i(&ctl_->chol_seq, h_i(offsetof(BaCtl, steps)) + 1);
 #ifdef P2_STAMPS
             if (lane == 0 && ctl_->it == 4) printf("[solver D %d] abs: start %lld factor done %lld published %lld\n", D, ts0_ % 1000000000ll, ts1_ % 1000000000ll, (long long)wall_clock64() % 1000000000ll);
 #endif
-        } else if (lane == 0) { F.ok = ok ? 1 : 0; B.scal[3] = ok ? 1.0 : 0.0; }
+        } else if (lane == 0) { F.ok = ok ? 1 : 0; take_over(lambda); B.scal[3] = ok ? 1.0 : 0.0; }
     } else {
         // ================= everyone else: bring the system into LDS ==============================================================
         const int ndbl = nblk * (nblk + 1) / 2 * CH2_TS;        // the tiles of S (rows < D), in the order and layout of LDS
@@ -530,9 +549,11 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
             for (int i = ct; i < T * CH2_TS; i += 64 * CH2_NC) z[i] = 0.0;
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (check_finished && h_i(offsetof(BaCtl, finished))) return;
         if (lane == 0) ch2_inc(&F.dma);
         ch2_wait_ge(&F.dma, CH2_NC + 1, &F.abort_);
         const int nb0 = min(CH_NB, D);
+        const double lambda = CH2_LAMBDA();
         for (int i = ct; i < 36 * (D / 6); i += 64 * CH2_NC) {  // the 6x6 diagonal blocks of H_pp (lower halves) and lambda on the diagonal; rows of block 0 are wave 0's
             const int j = i / 36, a = (i % 36) / 6, b = i % 6, row = 6 * j + a;
             if (b <= a && row >= nb0) s_L[ch2_sidx(row, 6 * j + b)] += Hpp[i] + (a == b ? lambda : 0.0);

@@ -63,9 +63,12 @@ __device__ __forceinline__ double p2_uniform(double x) {
 // waves per SIMD, and a launch over several problems ran its workgroups in as many rounds as it had problems).
 // ba_lin_poses_body without per-lane accumulators (27 f64 = 54 registers across the edge loop made this the register peak of k_ba_schur2): every
 // round of 256 edges leaves its 21 + 6 products in two 16-value wavefront reductions whose row leaders add them up in LDS (s_part: 4 waves x 32).
-__device__ __forceinline__ void p2_lin_poses_body(const BaCam& cam, const BaDev& B, int robust, double delta, int blk, const double* poses_c, const double* pts_c, double* s_part) {
+// (ps_lo / ps_hi: ps_start[j], ps_start[j + 1] where the caller has them already -- the Schur launch's head load -- or -1: read here)
+__device__ __forceinline__ void p2_lin_poses_body(const BaCam& cam, const BaDev& B, int robust, double delta, int blk, const double* poses_c, const double* pts_c, double* s_part,
+                                                  int ps_lo = -1, int ps_hi = -1) {
     const int j = blk / PSPLIT, part = blk % PSPLIT;
-    const int q_lo = __builtin_amdgcn_readfirstlane(B.ps_start[j]) + part * 256, q_hi = __builtin_amdgcn_readfirstlane(B.ps_start[j + 1]);
+    if (ps_lo < 0) { ps_lo = __builtin_amdgcn_readfirstlane(B.ps_start[j]); ps_hi = __builtin_amdgcn_readfirstlane(B.ps_start[j + 1]); }
+    const int q_lo = ps_lo + part * 256, q_hi = ps_hi;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double T[12];
 #pragma unroll
@@ -80,8 +83,17 @@ __device__ __forceinline__ void p2_lin_poses_body(const BaCam& cam, const BaDev&
 #pragma unroll
             for (int c = 0; c < 6; ++c) Jp[a][c] = 0;
         if (q < q_hi) {
-            const int e = B.ps_edges[q];
-            if (B.active[e]) ba_edge(cam, T, pts_c + 3 * (size_t)B.e_pt[e], B.e_uv + 2 * (size_t)e, robust, delta, r, w, rho0, Jp, Jl);
+            // two load levels: the list's edge and point together, then the activity byte, the observation and the position together (asked for before any of
+            // them is looked at: without the pins the compiler moves each load behind the test of the one before it)
+            int e = B.ps_edges[q], k = B.ps_pt ? B.ps_pt[q] : 0;
+            asm volatile("" : "+v"(e), "+v"(k));
+            if (!B.ps_pt) k = B.e_pt[e];
+            int act = B.active[e];
+            const float2 uvf = *reinterpret_cast<const float2*>(B.e_uv + 2 * (size_t)e);
+            float uv[2] = {uvf.x, uvf.y};
+            double pk[3] = {pts_c[3 * (size_t)k], pts_c[3 * (size_t)k + 1], pts_c[3 * (size_t)k + 2]};
+            asm volatile("" : "+v"(act), "+v"(uv[0]), "+v"(uv[1]), "+v"(pk[0]), "+v"(pk[1]), "+v"(pk[2]));
+            if (act) ba_edge(cam, T, pk, uv, robust, delta, r, w, rho0, Jp, Jl);
             else w = 0;
         }
 #pragma unroll
@@ -224,14 +236,22 @@ __device__ __forceinline__ void p2_schur_slice(const BaDev& B, const BaBlock blk
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int base = 0; base < blk.count; base += 256) {                   // workgroup-uniform trip count: every lane takes part in the reductions
         bool on = base + (int)threadIdx.x < blk.count;
-        int2 pr = make_int2(0, 0);
-        int pt_l = 0;
-        if (on) { pr = B.pairs[blk.start + base + threadIdx.x]; if (B.pair_pt) pt_l = B.pair_pt[blk.start + base + threadIdx.x]; on = B.active[pr.x] && (DIAG || B.active[pr.y]); }
+        const int pi = blk.start + (on ? base + (int)threadIdx.x : 0);      // (an idle lane reads the slice's first pair: a valid address, nothing of it is used)
+        int2 pr = B.pairs[pi];
+        int pt_l = B.pair_pt ? B.pair_pt[pi] : 0;                           // (the pair's point arrives with the pair where the plan wrote it: one load level less)
+        asm volatile("" : "+v"(pr.x), "+v"(pr.y), "+v"(pt_l));              // (both asked for before either is waited for)
+        if (!B.pair_pt) pt_l = B.e_pt[pr.x];
+        // one batch behind the pair: both activity bytes, the point's record, the two weights (an inactive pair's are read and dropped)
+        const int a1 = B.active[pr.x], a2 = B.active[pr.y];
+        double Hh[6], bl[3], p[3];
+        p2_rec_load(rec, pt_l, Hh, bl, p);
+        double w2 = Wt[pr.y], w1 = DIAG ? w2 : Wt[pr.x];
+        // (all of the batch is asked for before anything of it is looked at: without the pins the compiler moves each load behind the test of the one before it)
+        { int a12 = a1 | (a2 << 8); asm volatile("" : "+v"(a12), "+v"(w1), "+v"(w2), "+v"(Hh[0]), "+v"(Hh[2]), "+v"(Hh[4]), "+v"(bl[0]), "+v"(bl[2]), "+v"(p[1]));
+          on = on && (a12 & 0xff) && (DIAG || (a12 >> 8)); }
         double X1 = 0, Y1 = 0, Zi1 = 0, X2 = 0, Y2 = 0, Zi2 = 0, M[2][2] = {{0, 0}, {0, 0}}, g[2] = {0, 0};      // an idle lane: M = g = 0, every product is 0
         if (on) {
-            double Hh[6], bl[3], p[3], h[9];
-            p2_rec_load(rec, B.pair_pt ? pt_l : B.e_pt[pr.x], Hh, bl, p);      // (the pair's point arrives with the pair where the plan wrote it: one load level less)
-            const double w2 = Wt[pr.y], w1 = DIAG ? w2 : Wt[pr.x];
+            double h[9];
             const double Hs[9] = {Hh[0], Hh[1], Hh[2], Hh[1], Hh[3], Hh[4], Hh[2], Hh[4], Hh[5]};
             ba_inv3_damped(Hs, lambda, h);
             double Jp2[2][6], Jl2[2][3], G2[2][3];
@@ -312,23 +332,41 @@ __device__ __forceinline__ void p2_schur_slice(const BaDev& B, const BaBlock blk
     if (threadIdx.x == 0 && blockIdx.z == 0 && (blockIdx.x % 97) == 5 && B.n_points > 1000) printf("[schur2 wg %d, %d pairs, diag %d] 10 ns ticks: loads + compute %lld | reduce + atomics issued %lld\n", (int)blockIdx.x, blk.count, (int)DIAG, ts_[1] - ts_[0], ts_[2] - ts_[1]);
 #endif
 }
+// Everything a workgroup needs before its first pair comes in ONE vector load: lane i < 28 takes word i of the control block, lanes 32 .. 47 the words of
+// scal[0 .. 7], lane 48 the slice count, lanes 52 .. 55 the slice's descriptor (its index clamped: a workgroup behind the last slice reads the last one's and
+// leaves); the fields come out by readlane.  Written field by field -- as up to round 5, and again when the fields were merely read at the top of the function:
+// the compiler moves every load to its first use, behind the branches -- a slice workgroup made nine dependent trips to L2 (~0.5 us each, forty launches per BA)
+// before it asked for its pairs.
 __device__ __forceinline__ void ba_schur2_body(const BaDev& B, BaCtl* ctl_, double* s_part, double* s_tot) {
-    if (ctl_->finished || B.D > BA_FOLD_D) return;
-    BA_STATE(B)
+    static_assert(sizeof(BaCtl) <= 112 && sizeof(BaCtl) % 4 == 0 && sizeof(BaBlock) == 16, "the head load's lane map");
     const int n_pose_blk = B.n_free * PSPLIT;
+    const int sl = (int)blockIdx.x - n_pose_blk;
+    const int lane_ = threadIdx.x & 63;
+    const int* hp_ = reinterpret_cast<const int*>(ctl_) + min(lane_, (int)sizeof(BaCtl) / 4 - 1);
+    if (lane_ >= 32 && lane_ < 48) hp_ = reinterpret_cast<const int*>(B.scal) + (lane_ - 32);
+    if (lane_ == 48 && B.n_slices) hp_ = B.n_slices;
+    if (lane_ >= 52 && lane_ < 56 && B.blocks) hp_ = reinterpret_cast<const int*>(B.blocks + min(max(sl, 0), max(B.n_blocks - 1, 0))) + (lane_ - 52);
+    if (lane_ >= 56 && lane_ < 58 && sl < 0) hp_ = B.ps_start + (int)blockIdx.x / PSPLIT + (lane_ - 56);      // (a pose workgroup: its list's bounds)
+    const int hw_ = *hp_;
+    auto h_i = [&](size_t byte_off) { return __builtin_amdgcn_readlane(hw_, (int)(byte_off / 4)); };
+    const int finished = h_i(offsetof(BaCtl, finished)), buf_ = h_i(offsetof(BaCtl, buf)), need_lin = h_i(offsetof(BaCtl, need_lin)), first = h_i(offsetof(BaCtl, first)),
+              robust = h_i(offsetof(BaCtl, robust)), lbuf = h_i(offsetof(BaCtl, lbuf));
+    const double lambda_c = __hiloint2double(h_i(offsetof(BaCtl, lambda) + 4), h_i(offsetof(BaCtl, lambda)));
+    const double scal4 = __hiloint2double(__builtin_amdgcn_readlane(hw_, 32 + 9), __builtin_amdgcn_readlane(hw_, 32 + 8));
+    const int nsl_v = __builtin_amdgcn_readlane(hw_, 48);
+    BaBlock blk;
+    blk.j1 = __builtin_amdgcn_readlane(hw_, 52); blk.j2 = __builtin_amdgcn_readlane(hw_, 53); blk.start = __builtin_amdgcn_readlane(hw_, 54); blk.count = __builtin_amdgcn_readlane(hw_, 55);
+    if (finished || B.D > BA_FOLD_D) return;
+    double* const poses_c = buf_ ? B.posesB : B.posesA; double* const pts_c = buf_ ? B.ptsB : B.ptsA;
     if ((int)blockIdx.x < n_pose_blk) {
         // H_pp / b_p of the accepted state (zeroed by the step that accepted it).  On the first step of a round k_ba_lin2 has done it (lambda_0
         // needs the diagonal before this launch); after a rejected step the sums of the unchanged state are still there.
-        if (ctl_->need_lin && !ctl_->first) p2_lin_poses_body(B.cam, B, __builtin_amdgcn_readfirstlane(ctl_->robust), B.delta, blockIdx.x, poses_c, pts_c, s_part);
+        if (need_lin && !first) p2_lin_poses_body(B.cam, B, robust, B.delta, blockIdx.x, poses_c, pts_c, s_part, __builtin_amdgcn_readlane(hw_, 56), __builtin_amdgcn_readlane(hw_, 57));
         return;
     }
-    const int sl = blockIdx.x - n_pose_blk;
-    if (sl >= B.n_blocks || (B.n_slices && sl >= *B.n_slices)) return;
-    const double lambda = p2_uniform((ctl_->need_lin && ctl_->first) ? 1e-5 * B.scal[4] : ctl_->lambda);      // as k_ba_chol16 derives it (the control block is updated there)
-    BaBlock blk = B.blocks[sl];
-    blk.j1 = __builtin_amdgcn_readfirstlane(blk.j1); blk.j2 = __builtin_amdgcn_readfirstlane(blk.j2);
-    blk.start = __builtin_amdgcn_readfirstlane(blk.start); blk.count = __builtin_amdgcn_readfirstlane(blk.count);
-    const int lb = __builtin_amdgcn_readfirstlane(ctl_->lbuf);
+    if (sl >= B.n_blocks || (B.n_slices && sl >= nsl_v)) return;
+    const double lambda = p2_uniform((need_lin && first) ? 1e-5 * scal4 : lambda_c);      // as k_ba_chol16 derives it (the control block is updated there)
+    const int lb = lbuf;
     const double* const rec = p2_rec(B, lb);
     const double* const Wt = p2_w(B, lb);
     if (blk.j1 == blk.j2) p2_schur_slice<true>(B, blk, lambda, poses_c, rec, Wt, s_part, s_tot);
