@@ -1890,7 +1890,7 @@ static int ba_engine_enqueue(BaEngine* E) {
     // other problems may want to join
     int chunk = (na == 1 && E->pending_hint == 0) ? 16 : 4;
     int sA[BA_SLOTS], nA = 0, sB[BA_SLOTS], nB = 0, nA_tiles = 0;
-    int gA_lin = 0, gA_blk = 0, gA_up = 0, gA_md = 0, gA_pose = 0, gB_lin = 0, gB_init = 0, gB_blk = 0, gB_upd = 0, gB_c = 0, gB_md = 0, g_e = 0;
+    int gA_lin = 0, gA_blk = 0, gA_up = 0, gA_md = 0, gA_pose = 0, gA_np = 0, gB_lin = 0, gB_init = 0, gB_blk = 0, gB_upd = 0, gB_c = 0, gB_md = 0, g_e = 0;
     size_t ldsA = 0, ldsA_up = 0, ldsA_up_plain = 0, ldsB = 0;
     for (int i = 0; i < na; ++i) {
         BaJob* j = E->slot[act[i]];
@@ -1899,6 +1899,7 @@ static int ba_engine_enqueue(BaEngine* E) {
         if (j->B.D <= BA_FOLD_D) {
             sA[nA++] = act[i]; nA_tiles += j->B.s_tiles;
             gA_lin = std::max(gA_lin, j->grid_lin); gA_blk = std::max(gA_blk, j->B.n_blocks); gA_pose = std::max(gA_pose, j->B.n_free * PSPLIT); gA_up = std::max(gA_up, j->B.n_points);
+            gA_np = std::max(gA_np, std::min(j->B.n_poses, 512));      // k_ba_lin2 stages up to 512 poses (48 KB) in LDS
             ldsA = std::max(ldsA, j->lds); ldsA_up = std::max(ldsA_up, sizeof(double) * (24 * (size_t)j->B.n_poses + (size_t)j->B.D + (j->B.upc_ovf ? UPC_LDS_EXTRA : 0)));      // (the overflow region: used by the fused launch only)
             ldsA_up_plain = std::max(ldsA_up_plain, sizeof(double) * (24 * (size_t)j->B.n_poses + (size_t)j->B.D));
             gA_md = std::max(gA_md, (j->B.D + j->B.n_points + 255) / 256);
@@ -1931,7 +1932,7 @@ static int ba_engine_enqueue(BaEngine* E) {
             // leave at once for a slot that is not at the start of a round); afterwards the linearisation at the accepted state is a
             // by-product of k_ba_upchi2 and a step is THREE launches
             if (sidx == 0) {
-                { ProfScope ps(prof, "k_ba_lin2", st); hipLaunchKernelGGL(k_ba_lin2, dim3(gA_lin, 1, nA), blk, 0, st, QA); }      // (+ the largest diagonal entry: its last workgroup)
+                { ProfScope ps(prof, "k_ba_lin2", st); hipLaunchKernelGGL(k_ba_lin2, dim3(gA_lin, 1, nA), blk, 96 * (size_t)gA_np, st, QA, gA_np); }      // (+ the largest diagonal entry: its last workgroup)
                 for (int i = 0; i < na; ++i) {              // a problem's pair plan may still be running on its owner's stream: the linearisation above did not need it
                     BaJob* j = E->slot[act[i]];
                     if (j->wait_pairs) { HIP_TRY(hipStreamWaitEvent(st, j->wait_pairs, 0)); j->wait_pairs = nullptr; }

@@ -75,44 +75,62 @@ __device__ __forceinline__ void p2_lin_poses_body(const BaCam& cam, const BaDev&
     for (int i = 0; i < 12; ++i) T[i] = p2_uniform(poses_c[12 * (size_t)j + i]);
     if (threadIdx.x < 128) s_part[threadIdx.x] = 0.0;
     __syncthreads();
-    for (int q0 = q_lo; q0 < q_hi; q0 += 256 * PSPLIT) {                  // workgroup-uniform trip count
-        const int q = q0 + threadIdx.x;
-        double r[2] = {0, 0}, w = 0, rho0, Jp[2][6], Jl[2][3];
+    // Four rounds' loads at a time (a list of ~3600 edges over PSPLIT workgroups of 256 lanes is four rounds): the lists' edges and points in one batch, then the
+    // activity bytes, observations and positions in one batch -- two dependent trips for the whole list instead of two to three per round (this workgroup is the
+    // longest of an accepted step's Schur launch).  The rounds' sums are formed and added in the same order as before.
+    constexpr int NU = 4;
+    for (int q0 = q_lo; q0 < q_hi; q0 += 256 * PSPLIT * NU) {             // workgroup-uniform trip count
+        int e[NU], k[NU], act[NU]; float uv[NU][2]; double pk[NU][3]; bool on[NU];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int c = 0; c < 6; ++c) Jp[a][c] = 0;
-        if (q < q_hi) {
-            // two load levels: the list's edge and point together, then the activity byte, the observation and the position together (asked for before any of
-            // them is looked at: without the pins the compiler moves each load behind the test of the one before it)
-            int e = B.ps_edges[q], k = B.ps_pt ? B.ps_pt[q] : 0;
-            asm volatile("" : "+v"(e), "+v"(k));
-            if (!B.ps_pt) k = B.e_pt[e];
-            int act = B.active[e];
-            const float2 uvf = *reinterpret_cast<const float2*>(B.e_uv + 2 * (size_t)e);
-            float uv[2] = {uvf.x, uvf.y};
-            double pk[3] = {pts_c[3 * (size_t)k], pts_c[3 * (size_t)k + 1], pts_c[3 * (size_t)k + 2]};
-            asm volatile("" : "+v"(act), "+v"(uv[0]), "+v"(uv[1]), "+v"(pk[0]), "+v"(pk[1]), "+v"(pk[2]));
-            if (act) ba_edge(cam, T, pk, uv, robust, delta, r, w, rho0, Jp, Jl);
-            else w = 0;
+        for (int u = 0; u < NU; ++u) {
+            const int q = q0 + u * 256 * PSPLIT + (int)threadIdx.x;
+            on[u] = q < q_hi;
+            const int qc = on[u] ? q : q_lo;                                // (an idle lane reads the list's first entry: a valid address, nothing of it is used)
+            e[u] = B.ps_edges[qc]; k[u] = B.ps_pt ? B.ps_pt[qc] : 0;
         }
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {                            // upper-triangle entries 0..15, then 16..20 and the 6 of b_p (21..26)
-            double x[16], o4[4];
-            int c = 0;
+        for (int u = 0; u < NU; ++u) asm volatile("" : "+v"(e[u]), "+v"(k[u]));
+        if (!B.ps_pt) {
 #pragma unroll
-            for (int a = 0; a < 6; ++a)
+            for (int u = 0; u < NU; ++u) k[u] = B.e_pt[e[u]];
+        }
 #pragma unroll
-                for (int b = a; b < 6; ++b, ++c) if (c / 16 == half) x[c % 16] = w * (Jp[0][a] * Jp[0][b] + Jp[1][a] * Jp[1][b]);
-            if (half) {
+        for (int u = 0; u < NU; ++u) {
+            act[u] = B.active[e[u]];
+            const float2 uvf = *reinterpret_cast<const float2*>(B.e_uv + 2 * (size_t)e[u]);
+            uv[u][0] = uvf.x; uv[u][1] = uvf.y;
+            pk[u][0] = pts_c[3 * (size_t)k[u]]; pk[u][1] = pts_c[3 * (size_t)k[u] + 1]; pk[u][2] = pts_c[3 * (size_t)k[u] + 2];
+        }
 #pragma unroll
-                for (int a = 0; a < 6; ++a) x[5 + a] = -(w * (Jp[0][a] * r[0] + Jp[1][a] * r[1]));
+        for (int u = 0; u < NU; ++u) asm volatile("" : "+v"(act[u]), "+v"(uv[u][0]), "+v"(uv[u][1]), "+v"(pk[u][0]), "+v"(pk[u][1]), "+v"(pk[u][2]));
 #pragma unroll
-                for (int i = 11; i < 16; ++i) x[i] = 0.0;
+        for (int u = 0; u < NU; ++u) {
+            if (q0 + u * 256 * PSPLIT >= q_hi) break;                       // (workgroup-uniform: the list ended in an earlier round)
+            double r[2] = {0, 0}, w = 0, rho0, Jp[2][6], Jl[2][3];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 6; ++c) Jp[a][c] = 0;
+            if (on[u] && act[u]) ba_edge(cam, T, pk[u], uv[u], robust, delta, r, w, rho0, Jp, Jl);
+            else w = 0;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {                            // upper-triangle entries 0..15, then 16..20 and the 6 of b_p (21..26)
+                double x[16], o4[4];
+                int c = 0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+#pragma unroll
+                    for (int b = a; b < 6; ++b, ++c) if (c / 16 == half) x[c % 16] = w * (Jp[0][a] * Jp[0][b] + Jp[1][a] * Jp[1][b]);
+                if (half) {
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) x[5 + a] = -(w * (Jp[0][a] * r[0] + Jp[1][a] * r[1]));
+#pragma unroll
+                    for (int i = 11; i < 16; ++i) x[i] = 0.0;
+                }
+                (void)o4;
+                const double tsum = vo_wave_reduce16t(x);
+                if ((lane & 15) < 4) s_part[wave * 32 + 16 * half + 4 * VO_R16T_K(lane) + VO_R32_SLOT(lane >> 4)] += tsum;
             }
-            (void)o4;
-            const double tsum = vo_wave_reduce16t(x);
-            if ((lane & 15) < 4) s_part[wave * 32 + 16 * half + 4 * VO_R16T_K(lane) + VO_R32_SLOT(lane >> 4)] += tsum;
         }
     }
     __syncthreads();
@@ -151,14 +169,22 @@ __device__ __forceinline__ void p2_lin_finish(const BaDev& B, BaCtl* ctl_, doubl
     if (threadIdx.x == 0) ctl_->lin_ticket = 0;
 }
 
-__global__ __launch_bounds__(256) void k_ba_lin2(BaBatch Q) {
-    BA_PROBLEM(Q)
-    if (ctl_->finished || B.D > BA_FOLD_D) return;
-    if (!(ctl_->need_lin && ctl_->first)) return;          // only the first step of a round: later linearisations come out of k_ba_upchi2
+// Round 6: (a) the control block comes in one vector load (fields by readlane) and the descriptor as a copy (one batch of scalar loads) instead of a field per
+// dependent trip; (b) the poses are staged in LDS (pose_cap of them fit the launch's dynamic LDS; more: read where they lie), so an edge's pose is not a trip of
+// its own; (c) a lane asks for everything two of its edges need -- activity byte, pose number, observation -- in one batch instead of one edge and one field at a
+// time: a point with 21 edges was 6 rounds x 4 dependent trips, now 3 x 1.  The sums are taken in the same order: same values.
+__global__ __launch_bounds__(256) void k_ba_lin2(BaBatch Q, int pose_cap) {
+    BA_PROBLEM_COPY(Q)
+    static_assert(sizeof(BaCtl) <= 112 && sizeof(BaCtl) % 4 == 0, "the head load takes the control block as sizeof / 4 <= 28 words");
+    const int hw_ = reinterpret_cast<const int*>(ctl_)[min((int)(threadIdx.x & 63), (int)sizeof(BaCtl) / 4 - 1)];
+    auto h_i = [&](size_t byte_off) { return __builtin_amdgcn_readlane(hw_, (int)(byte_off / 4)); };
+    if (h_i(offsetof(BaCtl, finished)) || B.D > BA_FOLD_D) return;
+    if (!(h_i(offsetof(BaCtl, need_lin)) && h_i(offsetof(BaCtl, first)))) return;      // only the first step of a round: later linearisations come out of k_ba_upchi2
     const int gp = B.gp;
-    BA_STATE(B)
+    const int buf_ = h_i(offsetof(BaCtl, buf)), robust = h_i(offsetof(BaCtl, robust)), lbuf = h_i(offsetof(BaCtl, lbuf)), stage = h_i(offsetof(BaCtl, stage));
+    const double* const poses_c = buf_ ? B.posesB : B.posesA; const double* const pts_c = buf_ ? B.ptsB : B.ptsA;
     __shared__ double s_part[4 * 32];
-    const int robust = ctl_->robust;
+    extern __shared__ double s_T[];                          // [12 pose_cap]
     const int expected = gp + B.n_free * PSPLIT;           // the workgroups of this problem that do anything (a launch over several problems may be wider)
     if ((int)blockIdx.x >= gp) {
         if ((int)blockIdx.x - gp < B.n_free * PSPLIT) {
@@ -167,25 +193,40 @@ __global__ __launch_bounds__(256) void k_ba_lin2(BaBatch Q) {
         }
         return;
     }
-    double* const rec = p2_rec(B, ctl_->lbuf);
-    double* const Wt = p2_w(B, ctl_->lbuf);
+    double* const rec = p2_rec(B, lbuf);
+    double* const Wt = p2_w(B, lbuf);
     const int k = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+    const bool in_lds = B.n_poses <= pose_cap;
+    if (in_lds) for (int i = threadIdx.x; i < 12 * B.n_poses; i += 256) s_T[i] = poses_c[i];
     double chi[2] = {0.0, 0.0};                            // robust chi2 of the linearisation; plain chi2 (the initial state's, reported as chi2_initial)
     double H[6] = {0, 0, 0, 0, 0, 0}, b3[3] = {0, 0, 0}, p[3] = {0, 0, 0};
+    int q0 = 0, q1 = 0;
     if (k < B.n_points) {
         p[0] = pts_c[3 * (size_t)k]; p[1] = pts_c[3 * (size_t)k + 1]; p[2] = pts_c[3 * (size_t)k + 2];
-        const int q1 = B.pt_start[k + 1];
-        for (int q = B.pt_start[k] + sub; q < q1; q += 4) {
-            const int e = B.pt_edges[q];
-            if (!B.active[e]) continue;
-            double r[2], w, rho0, Jp[2][6], Jl[2][3];
-            ba_edge(B.cam, poses_c + 12 * (size_t)B.e_pose[e], p, B.e_uv + 2 * (size_t)e, robust, B.delta, r, w, rho0, Jp, Jl);
-            Wt[e] = w;
-            chi[0] += rho0; chi[1] += r[0] * r[0] + r[1] * r[1];
-            b3[0] -= w * (Jl[0][0] * r[0] + Jl[1][0] * r[1]); b3[1] -= w * (Jl[0][1] * r[0] + Jl[1][1] * r[1]); b3[2] -= w * (Jl[0][2] * r[0] + Jl[1][2] * r[1]);
-            H[0] += w * (Jl[0][0] * Jl[0][0] + Jl[1][0] * Jl[1][0]); H[1] += w * (Jl[0][0] * Jl[0][1] + Jl[1][0] * Jl[1][1]); H[2] += w * (Jl[0][0] * Jl[0][2] + Jl[1][0] * Jl[1][2]);
-            H[3] += w * (Jl[0][1] * Jl[0][1] + Jl[1][1] * Jl[1][1]); H[4] += w * (Jl[0][1] * Jl[0][2] + Jl[1][1] * Jl[1][2]); H[5] += w * (Jl[0][2] * Jl[0][2] + Jl[1][2] * Jl[1][2]);
-        }
+        q0 = B.pt_start[k]; q1 = B.pt_start[k + 1];
+    }
+    __syncthreads();                                        // the poses are in LDS
+    const double* const Tb = in_lds ? s_T : poses_c;
+    auto one = [&](int e, int act, int jp, const float (&uv)[2]) {
+        if (!act) return;
+        double r[2], w, rho0, Jp[2][6], Jl[2][3];
+        ba_edge(B.cam, Tb + 12 * (size_t)jp, p, uv, robust, B.delta, r, w, rho0, Jp, Jl);
+        Wt[e] = w;
+        chi[0] += rho0; chi[1] += r[0] * r[0] + r[1] * r[1];
+        b3[0] -= w * (Jl[0][0] * r[0] + Jl[1][0] * r[1]); b3[1] -= w * (Jl[0][1] * r[0] + Jl[1][1] * r[1]); b3[2] -= w * (Jl[0][2] * r[0] + Jl[1][2] * r[1]);
+        H[0] += w * (Jl[0][0] * Jl[0][0] + Jl[1][0] * Jl[1][0]); H[1] += w * (Jl[0][0] * Jl[0][1] + Jl[1][0] * Jl[1][1]); H[2] += w * (Jl[0][0] * Jl[0][2] + Jl[1][0] * Jl[1][2]);
+        H[3] += w * (Jl[0][1] * Jl[0][1] + Jl[1][1] * Jl[1][1]); H[4] += w * (Jl[0][1] * Jl[0][2] + Jl[1][1] * Jl[1][2]); H[5] += w * (Jl[0][2] * Jl[0][2] + Jl[1][2] * Jl[1][2]);
+    };
+    for (int q = q0 + sub; q < q1; q += 8) {
+        const bool two = q + 4 < q1;
+        int ea = B.edges_by_point ? q : B.pt_edges[q], eb = two ? (B.edges_by_point ? q + 4 : B.pt_edges[q + 4]) : ea;
+        if (!B.edges_by_point) asm volatile("" : "+v"(ea), "+v"(eb));
+        int aa = B.active[ea], ab = B.active[eb], ja = B.e_pose[ea], jb = B.e_pose[eb];
+        const float2 ua = *reinterpret_cast<const float2*>(B.e_uv + 2 * (size_t)ea), ub = *reinterpret_cast<const float2*>(B.e_uv + 2 * (size_t)eb);
+        float uva[2] = {ua.x, ua.y}, uvb[2] = {ub.x, ub.y};
+        asm volatile("" : "+v"(aa), "+v"(ab), "+v"(ja), "+v"(jb), "+v"(uva[0]), "+v"(uva[1]), "+v"(uvb[0]), "+v"(uvb[1]));      // (one batch)
+        one(ea, aa, ja, uva);
+        if (two) one(eb, ab, jb, uvb);
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) H[i] = ba_quad_sum(H[i]);
@@ -196,7 +237,7 @@ __global__ __launch_bounds__(256) void k_ba_lin2(BaBatch Q) {
     ba_fold_zero(B, blockIdx.x, gp);
     ba_block_reduce<2>(chi, s_part);
     if (threadIdx.x == 0 && chi[0] != 0.0) atomicAdd(&B.scal[0], chi[0]);
-    if (threadIdx.x == 0 && chi[1] != 0.0 && ctl_->stage == 0) atomicAdd(&B.scal[5], chi[1]);      // (the first-generation path has k_ba_chi for this)
+    if (threadIdx.x == 0 && chi[1] != 0.0 && stage == 0) atomicAdd(&B.scal[5], chi[1]);      // (the first-generation path has k_ba_chi for this)
     p2_lin_finish(B, ctl_, vdiag, expected);
 }
 
