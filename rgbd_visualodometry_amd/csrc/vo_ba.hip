@@ -1673,18 +1673,32 @@ __global__ __launch_bounds__(256) void k_ba_round(BaBatch Q) {
             if (pos < B.cull_cap) __hip_atomic_store(B.cull + pos, B.e_obs[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    if (stage == 1) {                                        // (workgroup-uniform)
-        chi_keep = vo_wave_sum_f64(chi_keep);
-        if ((threadIdx.x & 63) == 0 && chi_keep != 0.0) atomicAdd(&B.scal[6], chi_keep);
-    }
     __shared__ int s_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every wave's atomic adds on scal[6] have been performed before the barrier (a workgroup-scope barrier alone need not wait for them)
+    __shared__ double s_keep[4];
+    if (stage == 1) {                                        // (workgroup-uniform)
+        // the kept edges' chi2: one partial per workgroup (B.partC), added up by the last one -- as ~1200 same-address atomics (one per wave) the sum was ~10 of
+        // the final round's 23 us, and its value depended on the order the atomics arrived in
+        chi_keep = vo_wave_sum_f64(chi_keep);
+        if ((threadIdx.x & 63) == 0) s_keep[threadIdx.x >> 6] = chi_keep;
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(B.partC + blockIdx.x, (s_keep[0] + s_keep[1]) + (s_keep[2] + s_keep[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's stores (the partial, the culled list's entries) have been performed before the barrier (a workgroup-scope barrier alone need not wait for them)
     __syncthreads();
-    // (no fences around the ticket: the last workgroup reads nothing the others wrote except scal[6], whose atomic adds are performed at the
-    // memory side before the barrier above lets thread 0 take the ticket; a device-scope fence here would write this XCD's L2 back)
+    // (no fences around the ticket: the last workgroup reads nothing the others wrote except the partials and the culled list, which leave as agent-scope
+    // stores performed before the barrier above lets thread 0 take the ticket; a device-scope fence here would write this XCD's L2 back)
     if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&ctl_->ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1;
     __syncthreads();
     if (!s_last) return;
+    if (stage == 1) {
+        double t = 0.0;
+        for (int i = threadIdx.x; i < nblk; i += 256) t += __hip_atomic_load(B.partC + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = vo_wave_sum_f64(t);
+        __syncthreads();                                    // (s_keep's first use has been read)
+        if ((threadIdx.x & 63) == 0) s_keep[threadIdx.x >> 6] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(&B.scal[6], (s_keep[0] + s_keep[1]) + (s_keep[2] + s_keep[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (stage == 0) {
         if (threadIdx.x < 8 && threadIdx.x != 5) B.scal[threadIdx.x] = 0;       // [5]: the initial chi2 (k_ba_chi at admission)
         for (int i = threadIdx.x; i < 36 * B.n_free; i += 256) B.Hpp[i] = 0;

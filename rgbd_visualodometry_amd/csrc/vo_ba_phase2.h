@@ -151,22 +151,31 @@ __device__ __forceinline__ void p2_lin_poses_body(const BaCam& cam, const BaDev&
 // the workgroup that sums them; H_pp's are complete only when every pose workgroup has added its share, so every workgroup of the launch takes a
 // ticket behind its atomics (each wave drains its own first: ADVICE r3) and the last one reads H_pp's diagonal past its caches.  (Round 4 had a
 // launch of its own for this, k_ba_maxdiag2: 6 us + a boundary, twice per BA.)
-__device__ __forceinline__ void p2_lin_finish(const BaDev& B, BaCtl* ctl_, double vmax, int expected) {
+// (Round 6: the point workgroups' sums -- the two chi2 and the largest point-block diagonal entry -- go to per-workgroup partials, B.partU, and the last
+// workgroup adds them up: they were ~2000 same-address atomics per launch, which the memory side performs one after the other: ~15 of the launch's 26 us.)
+__device__ __forceinline__ void p2_lin_finish(const BaDev& B, BaCtl* ctl_, int expected, int stage) {
     __shared__ int s_lin_last;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) vmax = fmax(vmax, __shfl_xor(vmax, o, 64));
-    if ((threadIdx.x & 63) == 0 && vmax > 0) atomicMax((unsigned long long*)&B.scal[4], (unsigned long long)__double_as_longlong(vmax));
+    __shared__ double s_fin[3 * 4];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) s_lin_last = __hip_atomic_fetch_add(&ctl_->lin_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expected - 1;
     __syncthreads();
     if (!s_lin_last) return;
-    double v = 0;
+    double a = 0, b = 0, v = 0;
+    for (int i = threadIdx.x; i < B.gp; i += 256) { a += pb_ld(B.partU + 3 * (size_t)i); b += pb_ld(B.partU + 3 * (size_t)i + 1); v = fmax(v, pb_ld(B.partU + 3 * (size_t)i + 2)); }
     for (int i = threadIdx.x; i < B.D; i += 256) v = fmax(v, fabs(pb_ld(&B.Hpp[36 * (size_t)(i / 6) + 7 * (i % 6)])));
+    a = vo_wave_sum_f64(a); b = vo_wave_sum_f64(b);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    if ((threadIdx.x & 63) == 0 && v > 0) atomicMax((unsigned long long*)&B.scal[4], (unsigned long long)__double_as_longlong(v));
-    if (threadIdx.x == 0) ctl_->lin_ticket = 0;
+    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; s_fin[w] = a; s_fin[4 + w] = b; s_fin[8 + w] = v; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = (s_fin[0] + s_fin[1]) + (s_fin[2] + s_fin[3]); b = (s_fin[4] + s_fin[5]) + (s_fin[6] + s_fin[7]); v = fmax(fmax(s_fin[8], s_fin[9]), fmax(s_fin[10], s_fin[11]));
+        if (a != 0.0) atomicAdd(&B.scal[0], a);
+        if (b != 0.0 && stage == 0) atomicAdd(&B.scal[5], b);      // (the first-generation path has k_ba_chi for this)
+        if (v > 0) atomicMax((unsigned long long*)&B.scal[4], (unsigned long long)__double_as_longlong(v));
+        ctl_->lin_ticket = 0;
+    }
 }
 
 // Round 6: (a) the control block comes in one vector load (fields by readlane) and the descriptor as a copy (one batch of scalar loads) instead of a field per
@@ -189,7 +198,7 @@ __global__ __launch_bounds__(256) void k_ba_lin2(BaBatch Q, int pose_cap) {
     if ((int)blockIdx.x >= gp) {
         if ((int)blockIdx.x - gp < B.n_free * PSPLIT) {
             p2_lin_poses_body(B.cam, B, robust, B.delta, blockIdx.x - gp, poses_c, pts_c, s_part);
-            p2_lin_finish(B, ctl_, 0.0, expected);
+            p2_lin_finish(B, ctl_, expected, stage);
         }
         return;
     }
@@ -235,10 +244,18 @@ __global__ __launch_bounds__(256) void k_ba_lin2(BaBatch Q, int pose_cap) {
     if (k < B.n_points && sub == 0) p2_rec_store(rec, k, H, b3, p);
     const double vdiag = k < B.n_points ? fmax(fabs(H[0]), fmax(fabs(H[3]), fabs(H[5]))) : 0.0;      // the point block's diagonal (what the record holds)
     ba_fold_zero(B, blockIdx.x, gp);
-    ba_block_reduce<2>(chi, s_part);
-    if (threadIdx.x == 0 && chi[0] != 0.0) atomicAdd(&B.scal[0], chi[0]);
-    if (threadIdx.x == 0 && chi[1] != 0.0 && stage == 0) atomicAdd(&B.scal[5], chi[1]);      // (the first-generation path has k_ba_chi for this)
-    p2_lin_finish(B, ctl_, vdiag, expected);
+    double red[3] = {chi[0], chi[1], 0.0};
+    {   // (the workgroup's largest diagonal entry: a wave maximum each, joined behind the block reduction's barriers)
+        double vm = vdiag;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vm = fmax(vm, __shfl_xor(vm, o, 64));
+        __shared__ double s_vm[4];
+        if ((threadIdx.x & 63) == 0) s_vm[threadIdx.x >> 6] = vm;
+        ba_block_reduce<2>(red, s_part);                    // (its barriers also publish s_vm)
+        if (threadIdx.x == 0) red[2] = fmax(fmax(s_vm[0], s_vm[1]), fmax(s_vm[2], s_vm[3]));
+    }
+    if (threadIdx.x == 0) { pb_st(B.partU + 3 * (size_t)blockIdx.x, red[0]); pb_st(B.partU + 3 * (size_t)blockIdx.x + 1, red[1]); pb_st(B.partU + 3 * (size_t)blockIdx.x + 2, red[2]); }
+    p2_lin_finish(B, ctl_, expected, stage);
 }
 
 // pb_jac in two halves: the camera-frame point (X, Y, 1 / Z), and the pose Jacobian rebuilt from it (the same expressions: the values are pb_jac's)
