@@ -157,7 +157,7 @@ __device__ __forceinline__ void ba_wave_reduce(double* v) {      // 64 threads; 
 // blocks [gp, gp + PSPLIT n_free) reduce slices of a free pose's edges into H_pp / b_p (27 f64 atomics per block;
 // H_pp / b_p are zeroed by the step that accepted the state, see k_ba_chi_control).
 #ifndef PSPLIT
-#define PSPLIT 4
+#define PSPLIT 16
 #endif
 #define BA_SLICE 256                                         // pairs per Schur workgroup: one per lane (k_ba_schur2 keeps nothing across pairs)
 // Four lanes share a point (a quad): each takes every fourth edge, the quad sums H_ll / b_l with two DPP quad
