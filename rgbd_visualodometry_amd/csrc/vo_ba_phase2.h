@@ -78,7 +78,7 @@ __device__ __forceinline__ void p2_lin_poses_body(const BaCam& cam, const BaDev&
     // Four rounds' loads at a time (a list of ~3600 edges over PSPLIT workgroups of 256 lanes is four rounds): the lists' edges and points in one batch, then the
     // activity bytes, observations and positions in one batch -- two dependent trips for the whole list instead of two to three per round (this workgroup is the
     // longest of an accepted step's Schur launch).  The rounds' sums are formed and added in the same order as before.
-    constexpr int NU = PSPLIT >= 16 ? 1 : PSPLIT >= 8 ? 2 : 4;      // (rounds in flight: a list of ~3600 edges is one round of PSPLIT = 16 workgroups)
+    constexpr int NU = PSPLIT >= 8 ? 2 : 4;                 // (rounds in flight: a list of ~3600 edges is one round of PSPLIT = 16 workgroups, config 5's 11 k are three)
     for (int q0 = q_lo; q0 < q_hi; q0 += 256 * PSPLIT * NU) {             // workgroup-uniform trip count
         int e[NU], k[NU], act[NU]; float uv[NU][2]; double pk[NU][3]; bool on[NU];
 #pragma unroll
