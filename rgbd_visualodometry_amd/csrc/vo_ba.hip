@@ -2917,12 +2917,12 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
         F.kf[i] = free_kf[i];
     }
     // ---- cut scratch (lives until c's next cut: the solve reads pt_start, pose_kf and point_slots from it)
-    //      zeroed per cut: [fixed_flag nkf][pt_flag mh][cnt mh + 1][fill mh]     written by kernels: [kf_idx][pose_kf][pidx][pt_start mh + 1][point_slots][bsum][totals]
+    //      zeroed per cut: [fixed_flag nkf][pt_flag mh][cnt mh + 1][fill mh]     written by kernels: [kf_idx][pose_kf][pidx][pt_start mh + 1][point_slots][totals]
     size_t co = 0;
     auto cc = [&](size_t bytes) { size_t o = co; co += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_ffl = cc(4 * (size_t)nkf), o_pfl = cc(4 * (size_t)mh), o_cnt = cc(4 * (size_t)(mh + 1)), o_fil = cc(4 * (size_t)mh), zero_end = co;
     const size_t o_kfi = cc(4 * (size_t)nkf), o_pkf = cc(4 * (size_t)(nkf + VO_BA_RESIDENT_MAX_FREE)), o_pid = cc(4 * (size_t)mh), o_pst = cc(4 * (size_t)(mh + 1)), o_psl = cc(4 * (size_t)mh),
-                 o_bs = cc(4096), o_tot = cc(64);
+                 o_tot = cc(64);
     if (co > c->d_cut_bytes) {
         if (c->d_cut) { (void)hipStreamSynchronize(st); (void)hipFree(c->d_cut); }
         c->d_cut = nullptr; c->d_cut_bytes = 0;
@@ -2930,9 +2930,13 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
         c->d_cut_bytes = co + co / 2;
         HIP_TRY(hipMemsetAsync(c->d_cut, 0, c->d_cut_bytes, st));      // (k_scan_one's published totals: see there)
     }
+    if (!c->d_cut_sync) {                                   // (see vo_internal.h)
+        if (hipMalloc(&c->d_cut_sync, 4096) != hipSuccess) { c->d_cut_sync = nullptr; return VO_E_NOMEM; }
+        HIP_TRY(hipMemsetAsync(c->d_cut_sync, 0, 4096, st));
+    }
     uint8_t* cb = (uint8_t*)c->d_cut;
     int* kf_idx = (int*)(cb + o_kfi); int* fixed_flag = (int*)(cb + o_ffl); int* pose_kf = (int*)(cb + o_pkf); int* pt_flag = (int*)(cb + o_pfl); int* pidx = (int*)(cb + o_pid);
-    int* cnt = (int*)(cb + o_cnt); int* fill = (int*)(cb + o_fil); int* pt_start = (int*)(cb + o_pst); int* point_slots = (int*)(cb + o_psl); int* bsum = (int*)(cb + o_bs);
+    int* cnt = (int*)(cb + o_cnt); int* fill = (int*)(cb + o_fil); int* pt_start = (int*)(cb + o_pst); int* point_slots = (int*)(cb + o_psl); int* bsum = (int*)c->d_cut_sync;
     int* tot = (int*)(cb + o_tot);
     int* h = (int*)vo_stage(c, 4096);
     if (!h) return VO_E_NOMEM;

@@ -323,7 +323,7 @@ void vo_ctx_destroy(vo_ctx* c) {
     if (c->d_ba_shard) (void)hipFree(c->d_ba_shard);
     if (c->h_ba_shard) (void)hipHostFree(c->h_ba_shard);
     vo_ba_resident_free(c);
-    { void* tp[] = {c->d_obs_kf, c->d_obs_mp, c->d_obs_uv, c->d_obs_alive, c->d_obs_link, c->d_kf_pose, c->d_cut}; for (void* q : tp) if (q) (void)hipFree(q); }
+    { void* tp[] = {c->d_obs_kf, c->d_obs_mp, c->d_obs_uv, c->d_obs_alive, c->d_obs_link, c->d_kf_pose, c->d_cut, c->d_cut_sync}; for (void* q : tp) if (q) (void)hipFree(q); }
     vo_kf_free(c);
     if (c->slots_ev) (void)hipEventDestroy(c->slots_ev);
     for (auto& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }

@@ -152,6 +152,7 @@ struct vo_ctx {
     int map_hi = 0;                                         // highest map slot ever upserted + 1
     void* d_cut = nullptr; size_t d_cut_bytes = 0;          // scratch of the resident graph cut
     int cut_seq = 0;                                        // sequence number of the cut's pinned report words
+    void* d_cut_sync = nullptr;                             // k_scan_one's published tile totals (call number << 32 | total): a block of its own, 4 KiB, zeroed once -- d_cut's carves move with the keyframe count and the window, and a word that held another array's data could be taken for a published total
     long long cut_slab_budget = 1ll << 30;                  // vo_ba_resident_set_slab_budget: a cut whose bound-sized slab would exceed it waits for the graph's sizes and carves exactly
     struct BaResident* resident = nullptr;                  // state between vo_local_ba_resident_cut and _solve (vo_ba.hip)
     // vo_track_batch_begin / _end: the request of the chain in flight (copies: the caller's arrays need not outlive _begin)

@@ -483,7 +483,7 @@ def test_resident_merge_on_the_device_equals_the_host_write_back(libs):
     assert a[4] > 1000 and 15 <= a[6] <= 20 and len(a[3]) > 0       # (a round may end early at rho == 0 once the problem has converged)
     for x, y in zip(a, b):
         x, y = np.asarray(x), np.asarray(y)
-        if x.dtype.kind == "f":                             # two runs of the same solve: the order of the atomic sums is not fixed
-            np.testing.assert_allclose(x, y, rtol=0, atol=1e-9)
+        if x.dtype.kind == "f":                             # two runs of the same solve: the order of the atomic sums is not fixed, and a weakly constrained point (two views,
+            np.testing.assert_allclose(x, y, rtol=0, atol=1e-7)      # short baseline) turns a last-bit difference of S into 1e-8 of its position (seen: 3 of 1440 coordinates; the parity bar against the restatement is 1e-6)
         else:
             assert np.array_equal(x, y)
