@@ -157,8 +157,9 @@ __device__ __forceinline__ void ba_wave_reduce(double* v) {      // 64 threads; 
 // blocks [gp, gp + PSPLIT n_free) reduce slices of a free pose's edges into H_pp / b_p (27 f64 atomics per block;
 // H_pp / b_p are zeroed by the step that accepted the state, see k_ba_chi_control).
 #ifndef PSPLIT
-#define PSPLIT 16
+#define PSPLIT 4
 #endif
+#define PSPLIT_LONE 16                                       // a lone problem's step / linearisation launches (round 6): a pose's list is one round of sixteen workgroups; launches over several problems keep PSPLIT (their grids are wide already: 8 / 16 streams lost 6-7 % with sixteen)
 #define BA_SLICE 256                                         // pairs per Schur workgroup: one per lane (k_ba_schur2 keeps nothing across pairs)
 // Four lanes share a point (a quad): each takes every fourth edge, the quad sums H_ll / b_l with two DPP quad
 // permutes.  A point seen by all ~30 keyframes of the window no longer makes one lane walk 30 edges in a row.
@@ -1904,7 +1905,7 @@ static int ba_engine_enqueue(BaEngine* E) {
     // other problems may want to join
     int chunk = (na == 1 && E->pending_hint == 0) ? 16 : 4;
     int sA[BA_SLOTS], nA = 0, sB[BA_SLOTS], nB = 0, nA_tiles = 0;
-    int gA_lin = 0, gA_blk = 0, gA_up = 0, gA_md = 0, gA_pose = 0, gA_np = 0, gB_lin = 0, gB_init = 0, gB_blk = 0, gB_upd = 0, gB_c = 0, gB_md = 0, g_e = 0;
+    int gA_lin = 0, gA_blk = 0, gA_up = 0, gA_md = 0, gA_pose = 0, gA_np = 0, gA_pts = 0, gB_lin = 0, gB_init = 0, gB_blk = 0, gB_upd = 0, gB_c = 0, gB_md = 0, g_e = 0;
     size_t ldsA = 0, ldsA_up = 0, ldsA_up_plain = 0, ldsB = 0;
     for (int i = 0; i < na; ++i) {
         BaJob* j = E->slot[act[i]];
@@ -1912,7 +1913,7 @@ static int ba_engine_enqueue(BaEngine* E) {
         g_e = std::max(g_e, j->grid_e);
         if (j->B.D <= BA_FOLD_D) {
             sA[nA++] = act[i]; nA_tiles += j->B.s_tiles;
-            gA_lin = std::max(gA_lin, j->grid_lin); gA_blk = std::max(gA_blk, j->B.n_blocks); gA_pose = std::max(gA_pose, j->B.n_free * PSPLIT); gA_up = std::max(gA_up, j->B.n_points);
+            gA_lin = std::max(gA_lin, j->grid_lin); gA_blk = std::max(gA_blk, j->B.n_blocks); gA_pose = std::max(gA_pose, j->B.n_free); gA_pts = std::max(gA_pts, (j->B.n_points + 63) / 64); gA_up = std::max(gA_up, j->B.n_points);
             gA_np = std::max(gA_np, std::min(j->B.n_poses, 512));      // k_ba_lin2 stages up to 512 poses (48 KB) in LDS
             ldsA = std::max(ldsA, j->lds); ldsA_up = std::max(ldsA_up, sizeof(double) * (24 * (size_t)j->B.n_poses + (size_t)j->B.D + (j->B.upc_ovf ? UPC_LDS_EXTRA : 0)));      // (the overflow region: used by the fused launch only)
             ldsA_up_plain = std::max(ldsA_up_plain, sizeof(double) * (24 * (size_t)j->B.n_poses + (size_t)j->B.D));
@@ -1924,6 +1925,8 @@ static int ba_engine_enqueue(BaEngine* E) {
             ldsB = std::max(ldsB, j->lds);
         }
     }
+    const int ps_A = nA == 1 ? PSPLIT_LONE : PSPLIT;         // workgroups per free pose's list (see PSPLIT_LONE)
+    gA_pose *= ps_A; gA_lin = gA_pts + gA_pose;
     const int up_rep = nA >= 2 ? 2 : 1;                     // points per workgroup of k_ba_upchi2: 128 x up_rep (vo_ba_phase2.h; 8 problems per launch: 45.7 / 40.7 / 41.0 / 88 us for 1 / 2 / 4 / 8)
     // problems per fused launch at most (VO_BA_FUSE_MAX; 0: never -- the three-launch step; read per chunk, so that bench.py's per-kernel
     // timing pass can take the solver's launch apart).  Default 1: with several problems the waiting update workgroups hold compute
@@ -1946,7 +1949,7 @@ static int ba_engine_enqueue(BaEngine* E) {
             // leave at once for a slot that is not at the start of a round); afterwards the linearisation at the accepted state is a
             // by-product of k_ba_upchi2 and a step is THREE launches
             if (sidx == 0) {
-                { ProfScope ps(prof, "k_ba_lin2", st); hipLaunchKernelGGL(k_ba_lin2, dim3(gA_lin, 1, nA), blk, 96 * (size_t)gA_np, st, QA, gA_np); }      // (+ the largest diagonal entry: its last workgroup)
+                { ProfScope ps(prof, "k_ba_lin2", st); hipLaunchKernelGGL(k_ba_lin2, dim3(gA_lin, 1, nA), blk, 96 * (size_t)gA_np, st, QA, gA_np, ps_A); }      // (+ the largest diagonal entry: its last workgroup)
                 for (int i = 0; i < na; ++i) {              // a problem's pair plan may still be running on its owner's stream: the linearisation above did not need it
                     BaJob* j = E->slot[act[i]];
                     if (j->wait_pairs) { HIP_TRY(hipStreamWaitEvent(st, j->wait_pairs, 0)); j->wait_pairs = nullptr; }

@@ -64,9 +64,10 @@ __device__ __forceinline__ double p2_uniform(double x) {
 // ba_lin_poses_body without per-lane accumulators (27 f64 = 54 registers across the edge loop made this the register peak of k_ba_schur2): every
 // round of 256 edges leaves its 21 + 6 products in two 16-value wavefront reductions whose row leaders add them up in LDS (s_part: 4 waves x 32).
 // (ps_lo / ps_hi: ps_start[j], ps_start[j + 1] where the caller has them already -- the Schur launch's head load -- or -1: read here)
+template <int PS>                                           // PS workgroups per list: PSPLIT (launches over several problems) or PSPLIT_LONE (a lone problem's)
 __device__ __forceinline__ void p2_lin_poses_body(const BaCam& cam, const BaDev& B, int robust, double delta, int blk, const double* poses_c, const double* pts_c, double* s_part,
                                                   int ps_lo = -1, int ps_hi = -1) {
-    const int j = blk / PSPLIT, part = blk % PSPLIT;
+    const int j = blk / PS, part = blk % PS;
     if (ps_lo < 0) { ps_lo = __builtin_amdgcn_readfirstlane(B.ps_start[j]); ps_hi = __builtin_amdgcn_readfirstlane(B.ps_start[j + 1]); }
     const int q_lo = ps_lo + part * 256, q_hi = ps_hi;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -75,15 +76,15 @@ __device__ __forceinline__ void p2_lin_poses_body(const BaCam& cam, const BaDev&
     for (int i = 0; i < 12; ++i) T[i] = p2_uniform(poses_c[12 * (size_t)j + i]);
     if (threadIdx.x < 128) s_part[threadIdx.x] = 0.0;
     __syncthreads();
-    // Four rounds' loads at a time (a list of ~3600 edges over PSPLIT workgroups of 256 lanes is four rounds): the lists' edges and points in one batch, then the
+    // Four rounds' loads at a time (a list of ~3600 edges over four workgroups of 256 lanes is four rounds): the lists' edges and points in one batch, then the
     // activity bytes, observations and positions in one batch -- two dependent trips for the whole list instead of two to three per round (this workgroup is the
     // longest of an accepted step's Schur launch).  The rounds' sums are formed and added in the same order as before.
-    constexpr int NU = PSPLIT >= 8 ? 2 : 4;                 // (rounds in flight: a list of ~3600 edges is one round of PSPLIT = 16 workgroups, config 5's 11 k are three)
-    for (int q0 = q_lo; q0 < q_hi; q0 += 256 * PSPLIT * NU) {             // workgroup-uniform trip count
+    constexpr int NU = 2;                                    // (rounds in flight: a list of ~3600 edges is one round of sixteen workgroups, config 5's 11 k are three)
+    for (int q0 = q_lo; q0 < q_hi; q0 += 256 * PS * NU) {             // workgroup-uniform trip count
         int e[NU], k[NU], act[NU]; float uv[NU][2]; double pk[NU][3]; bool on[NU];
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            const int q = q0 + u * 256 * PSPLIT + (int)threadIdx.x;
+            const int q = q0 + u * 256 * PS + (int)threadIdx.x;
             on[u] = q < q_hi;
             const int qc = on[u] ? q : q_lo;                                // (an idle lane reads the list's first entry: a valid address, nothing of it is used)
             e[u] = B.ps_edges[qc]; k[u] = B.ps_pt ? B.ps_pt[qc] : 0;
@@ -105,7 +106,7 @@ __device__ __forceinline__ void p2_lin_poses_body(const BaCam& cam, const BaDev&
         for (int u = 0; u < NU; ++u) asm volatile("" : "+v"(act[u]), "+v"(uv[u][0]), "+v"(uv[u][1]), "+v"(pk[u][0]), "+v"(pk[u][1]), "+v"(pk[u][2]));
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            if (q0 + u * 256 * PSPLIT >= q_hi) break;                       // (workgroup-uniform: the list ended in an earlier round)
+            if (q0 + u * 256 * PS >= q_hi) break;                       // (workgroup-uniform: the list ended in an earlier round)
             double r[2] = {0, 0}, w = 0, rho0, Jp[2][6], Jl[2][3];
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -182,7 +183,7 @@ __device__ __forceinline__ void p2_lin_finish(const BaDev& B, BaCtl* ctl_, int e
 // dependent trip; (b) the poses are staged in LDS (pose_cap of them fit the launch's dynamic LDS; more: read where they lie), so an edge's pose is not a trip of
 // its own; (c) a lane asks for everything two of its edges need -- activity byte, pose number, observation -- in one batch instead of one edge and one field at a
 // time: a point with 21 edges was 6 rounds x 4 dependent trips, now 3 x 1.  The sums are taken in the same order: same values.
-__global__ __launch_bounds__(256) void k_ba_lin2(BaBatch Q, int pose_cap) {
+__global__ __launch_bounds__(256) void k_ba_lin2(BaBatch Q, int pose_cap, int ps) {
     BA_PROBLEM_COPY(Q)
     static_assert(sizeof(BaCtl) <= 112 && sizeof(BaCtl) % 4 == 0, "the head load takes the control block as sizeof / 4 <= 28 words");
     const int hw_ = reinterpret_cast<const int*>(ctl_)[min((int)(threadIdx.x & 63), (int)sizeof(BaCtl) / 4 - 1)];
@@ -194,10 +195,11 @@ __global__ __launch_bounds__(256) void k_ba_lin2(BaBatch Q, int pose_cap) {
     const double* const poses_c = buf_ ? B.posesB : B.posesA; const double* const pts_c = buf_ ? B.ptsB : B.ptsA;
     __shared__ double s_part[4 * 32];
     extern __shared__ double s_T[];                          // [12 pose_cap]
-    const int expected = gp + B.n_free * PSPLIT;           // the workgroups of this problem that do anything (a launch over several problems may be wider)
+    const int expected = gp + B.n_free * ps;               // the workgroups of this problem that do anything (a launch over several problems may be wider)
     if ((int)blockIdx.x >= gp) {
-        if ((int)blockIdx.x - gp < B.n_free * PSPLIT) {
-            p2_lin_poses_body(B.cam, B, robust, B.delta, blockIdx.x - gp, poses_c, pts_c, s_part);
+        if ((int)blockIdx.x - gp < B.n_free * ps) {
+            if (ps == PSPLIT_LONE) p2_lin_poses_body<PSPLIT_LONE>(B.cam, B, robust, B.delta, blockIdx.x - gp, poses_c, pts_c, s_part);
+            else p2_lin_poses_body<PSPLIT>(B.cam, B, robust, B.delta, blockIdx.x - gp, poses_c, pts_c, s_part);
             p2_lin_finish(B, ctl_, expected, stage);
         }
         return;
@@ -294,19 +296,24 @@ __device__ __forceinline__ void p2_schur_slice(const BaDev& B, const BaBlock blk
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int base = 0; base < blk.count; base += 256) {                   // workgroup-uniform trip count: every lane takes part in the reductions
         bool on = base + (int)threadIdx.x < blk.count;
-        const int pi = blk.start + (on ? base + (int)threadIdx.x : 0);      // (an idle lane reads the slice's first pair: a valid address, nothing of it is used)
-        int2 pr = B.pairs[pi];
-        int pt_l = B.pair_pt ? B.pair_pt[pi] : 0;                           // (the pair's point arrives with the pair where the plan wrote it: one load level less)
-        asm volatile("" : "+v"(pr.x), "+v"(pr.y), "+v"(pt_l));              // (both asked for before either is waited for)
-        if (!B.pair_pt) pt_l = B.e_pt[pr.x];
-        // one batch behind the pair: both activity bytes, the point's record, the two weights (an inactive pair's are read and dropped)
-        const int a1 = B.active[pr.x], a2 = B.active[pr.y];
-        double Hh[6], bl[3], p[3];
-        p2_rec_load(rec, pt_l, Hh, bl, p);
-        double w2 = Wt[pr.y], w1 = DIAG ? w2 : Wt[pr.x];
-        // (all of the batch is asked for before anything of it is looked at: without the pins the compiler moves each load behind the test of the one before it)
-        { int a12 = a1 | (a2 << 8); asm volatile("" : "+v"(a12), "+v"(w1), "+v"(w2), "+v"(Hh[0]), "+v"(Hh[2]), "+v"(Hh[4]), "+v"(bl[0]), "+v"(bl[2]), "+v"(p[1]));
-          on = on && (a12 & 0xff) && (DIAG || (a12 >> 8)); }
+        const int pi = blk.start + base + (int)threadIdx.x;
+        // two batches of loads, each asked for before anything of it is looked at (without the pins the compiler moves every load behind the test of the one
+        // before it); an idle lane of a partial slice asks for nothing (a third of the slices are partial: read-and-drop cost 8 / 16 streams 2 %)
+        int2 pr = make_int2(0, 0);
+        int pt_l = 0;
+        if (on) { pr = B.pairs[pi]; if (B.pair_pt) pt_l = B.pair_pt[pi]; }      // (the pair's point arrives with the pair where the plan wrote it: one load level less)
+        asm volatile("" : "+v"(pr.x), "+v"(pr.y), "+v"(pt_l));
+        if (on && !B.pair_pt) pt_l = B.e_pt[pr.x];
+        int a12 = 0;
+        double Hh[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0}, p[3] = {0, 0, 0}, w1 = 0, w2 = 0;
+        if (on) {                                           // both activity bytes, the point's record, the two weights (an inactive pair's are read and dropped)
+            const int a1 = B.active[pr.x], a2 = B.active[pr.y];
+            w2 = Wt[pr.y]; w1 = DIAG ? w2 : Wt[pr.x];
+            p2_rec_load(rec, pt_l, Hh, bl, p);
+            a12 = a1 | (a2 << 8);
+        }
+        asm volatile("" : "+v"(a12), "+v"(w1), "+v"(w2), "+v"(Hh[0]), "+v"(Hh[2]), "+v"(Hh[4]), "+v"(bl[0]), "+v"(bl[2]), "+v"(p[1]));
+        on = on && (a12 & 0xff) && (DIAG || (a12 >> 8));
         double X1 = 0, Y1 = 0, Zi1 = 0, X2 = 0, Y2 = 0, Zi2 = 0, M[2][2] = {{0, 0}, {0, 0}}, g[2] = {0, 0};      // an idle lane: M = g = 0, every product is 0
         if (on) {
             double h[9];
@@ -395,16 +402,17 @@ __device__ __forceinline__ void p2_schur_slice(const BaDev& B, const BaBlock blk
 // leaves); the fields come out by readlane.  Written field by field -- as up to round 5, and again when the fields were merely read at the top of the function:
 // the compiler moves every load to its first use, behind the branches -- a slice workgroup made nine dependent trips to L2 (~0.5 us each, forty launches per BA)
 // before it asked for its pairs.
+template <int PS>
 __device__ __forceinline__ void ba_schur2_body(const BaDev& B, BaCtl* ctl_, double* s_part, double* s_tot) {
     static_assert(sizeof(BaCtl) <= 112 && sizeof(BaCtl) % 4 == 0 && sizeof(BaBlock) == 16, "the head load's lane map");
-    const int n_pose_blk = B.n_free * PSPLIT;
+    const int n_pose_blk = B.n_free * PS;
     const int sl = (int)blockIdx.x - n_pose_blk;
     const int lane_ = threadIdx.x & 63;
     const int* hp_ = reinterpret_cast<const int*>(ctl_) + min(lane_, (int)sizeof(BaCtl) / 4 - 1);
     if (lane_ >= 32 && lane_ < 48) hp_ = reinterpret_cast<const int*>(B.scal) + (lane_ - 32);
     if (lane_ == 48 && B.n_slices) hp_ = B.n_slices;
     if (lane_ >= 52 && lane_ < 56 && B.blocks) hp_ = reinterpret_cast<const int*>(B.blocks + min(max(sl, 0), max(B.n_blocks - 1, 0))) + (lane_ - 52);
-    if (lane_ >= 56 && lane_ < 58 && sl < 0) hp_ = B.ps_start + (int)blockIdx.x / PSPLIT + (lane_ - 56);      // (a pose workgroup: its list's bounds)
+    if (lane_ >= 56 && lane_ < 58 && sl < 0) hp_ = B.ps_start + (int)blockIdx.x / PS + (lane_ - 56);      // (a pose workgroup: its list's bounds)
     const int hw_ = *hp_;
     auto h_i = [&](size_t byte_off) { return __builtin_amdgcn_readlane(hw_, (int)(byte_off / 4)); };
     const int finished = h_i(offsetof(BaCtl, finished)), buf_ = h_i(offsetof(BaCtl, buf)), need_lin = h_i(offsetof(BaCtl, need_lin)), first = h_i(offsetof(BaCtl, first)),
@@ -419,7 +427,7 @@ __device__ __forceinline__ void ba_schur2_body(const BaDev& B, BaCtl* ctl_, doub
     if ((int)blockIdx.x < n_pose_blk) {
         // H_pp / b_p of the accepted state (zeroed by the step that accepted it).  On the first step of a round k_ba_lin2 has done it (lambda_0
         // needs the diagonal before this launch); after a rejected step the sums of the unchanged state are still there.
-        if (need_lin && !first) p2_lin_poses_body(B.cam, B, robust, B.delta, blockIdx.x, poses_c, pts_c, s_part, __builtin_amdgcn_readlane(hw_, 56), __builtin_amdgcn_readlane(hw_, 57));
+        if (need_lin && !first) p2_lin_poses_body<PS>(B.cam, B, robust, B.delta, blockIdx.x, poses_c, pts_c, s_part, __builtin_amdgcn_readlane(hw_, 56), __builtin_amdgcn_readlane(hw_, 57));
         return;
     }
     if (sl >= B.n_blocks || (B.n_slices && sl >= nsl_v)) return;
@@ -434,7 +442,7 @@ __global__ __launch_bounds__(256) void k_ba_schur2(BaBatch Q) {
     BA_PROBLEM_COPY(Q)
     __shared__ double s_part[4 * 48];
     __shared__ double s_tot[48];
-    ba_schur2_body(B, ctl_, s_part, s_tot);
+    ba_schur2_body<PSPLIT>(B, ctl_, s_part, s_tot);
 }
 // A lone problem (the engine's usual case with one stream): the descriptor rides in the kernel's arguments -- scalar loads from the argument
 // segment, which is there when the wave starts -- instead of being fetched from the descriptor table first: one dependent trip to L2 less at the
@@ -442,7 +450,7 @@ __global__ __launch_bounds__(256) void k_ba_schur2(BaBatch Q) {
 __global__ __launch_bounds__(256) void k_ba_schur2_one(BaDev B, BaCtl* ctl_) {
     __shared__ double s_part[4 * 48];
     __shared__ double s_tot[48];
-    ba_schur2_body(B, ctl_, s_part, s_tot);
+    ba_schur2_body<PSPLIT_LONE>(B, ctl_, s_part, s_tot);
 }
 
 // exp(d) * T for a pose increment d = [translation, rotation] (g2o_types.h:56-60).  LM increments are small rotations: below 0.25 rad the

@@ -10,7 +10,6 @@ def read_dir(d):
         with open(f, newline="") as fh:
             for row in csv.DictReader(fh):
                 k = re.sub(r"\(.*$", "", row["Kernel_Name"]).replace("void ", "").strip()
-                k = {"k_ba_schur2_one": "k_ba_schur2", "k_ba_cholup_one": "k_ba_cholup"}.get(k, k)      # a lone problem's step kernels (descriptor by value): the same bodies
                 a = agg.setdefault(k, {}).setdefault(row["Counter_Name"], [0.0, 0])
                 a[0] += float(row["Counter_Value"]); a[1] += 1
     return agg
