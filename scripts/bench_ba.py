@@ -1,7 +1,7 @@
 """Local-BA micro-benchmark (developer tool): times vo_local_ba on synthetic covisibility-window problems of the bench workload's
 shape (about 24 free + 26 fixed keyframes, 9000 points, 70-90 k observations) and checks the result against the CPU restatement.
 
-    python scripts/bench_ba.py [--reps 20] [--oracle]          # VO_BA_PERSIST=0 selects the launch-per-phase path
+    python scripts/bench_ba.py [--reps 20] [--oracle]
 
 Prints one JSON line per problem shape: wall ms per BA, LM iterations, chi2, max |pose - oracle|."""
 import argparse, json, os, sys, time
@@ -68,7 +68,7 @@ def main():
             out = ctx.local_ba(prob[0], nfree, prob[1], prob[2], prob[3], prob[4], it_robust=itr, it_plain=itp)
         ms = (time.perf_counter() - t0) * 1e3 / args.reps
         ph, xh, fh, rh = out
-        rec = {"mode": "launch" if os.environ.get("VO_BA_PERSIST") == "0" else "persist", "group": os.environ.get("VO_BA_GROUP", "default"), "poses": nP, "free": nfree,
+        rec = {"poses": nP, "free": nfree,
                "its": args.its, "points": nX, "edges": int(len(prob[2])), "ms_per_ba": round(ms, 3), "lm_iters": rh.lm_iters, "chi2_initial": rh.chi2_initial, "chi2_final": rh.chi2_final,
                "culled": int((fh != 0).sum())}
         ctx.close()
