@@ -135,7 +135,7 @@ int main(int argc, char** argv) {
     { double* d; hipMalloc(&d, 128 * 8); hipLaunchKernelGGL(k_dpp_probe, dim3(1), dim3(64), 0, 0, d); double h[128]; hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
       printf("bcast<3>: "); for (int i = 0; i < 64; i += 5) printf("[%d]=%.0f ", i, h[i]); printf("\nfnma<5>: "); for (int i = 0; i < 64; i += 5) printf("[%d]=%.0f ", i, h[64 + i]); printf("\n"); hipFree(d); }
 
-    std::vector<int> sizes = {6, 12, 18, 24, 30, 48, 60, 96, 120, 126, 132, 138, 144, 156, 168, 186, 192, 198, 216};
+    std::vector<int> sizes = {6, 12, 18, 24, 30, 48, 60, 96, 120, 126, 132, 138, 144, 156, 168, 174, 180, 186, 192, 198, 216};
     if (argc > 1 && !strcmp(argv[1], "big")) sizes = {216, 366, 480, 510, 516, 540, 600, 720, 900, 960};      // k_ba_chol16g up to the 160 free keyframes the ABI admits
     hipFuncSetAttribute((const void*)k_ba_chol16, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
     hipFuncSetAttribute((const void*)k_ba_chol16g, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
@@ -180,7 +180,7 @@ int main(int argc, char** argv) {
         hipMemcpy(d_b0, b.data(), sizeof(double) * D, hipMemcpyHostToDevice);
         BaDev* d_B; hipMalloc(&d_B, sizeof(BaDev)); hipMemcpy(d_B, &B, sizeof(BaDev), hipMemcpyHostToDevice);
         BaBatch Q; memset(&Q, 0, sizeof(Q)); Q.Bs = d_B; Q.ctls = B.ctl; Q.n = 1;
-        for (int variant = 1; variant < (D <= CH2_MAXD ? 3 : 2); ++variant) {          // 1: first generation (barrier phases, packed rows), 2: second generation (roles + LDS words, tiles: vo_ba_chol2.h)
+        for (int variant = 1; variant < (ch2_fits(D) ? 3 : 2); ++variant) {          // 1: first generation (barrier phases, packed rows), 2: second generation (roles + LDS words, tiles: vo_ba_chol2.h)
             B.s_tiles = variant == 2; B.S = variant == 2 ? S_tiles : S_packed;
             hipMemcpy(d_B, &B, sizeof(BaDev), hipMemcpyHostToDevice);
             float tot = 0; const int reps = 50;

@@ -1786,8 +1786,8 @@ int vo_ba_set_attrs() {
 // HIP streams with ~120 tiny dependent launches each mostly serialise in the command processor.
 #include <condition_variable>
 #include <deque>
-// which layout S has (and which Cholesky kernel a problem takes): tiles + the second generation up to CH2_MAXD, packed rows + the first above
-static int ba_use_tiles(int D) { return D <= CH2_MAXD ? 1 : 0; }
+// which layout S has (and which Cholesky kernel a problem takes): tiles + the second generation where ch2_fits says so (D <= 174, 177 .. 191), packed rows + the first otherwise
+static int ba_use_tiles(int D) { return ch2_fits(D) ? 1 : 0; }      // (D <= 174 whole in LDS; 177 .. 191 with the last row block in global memory: vo_ba_chol2.h)
 // Host waits on this latency chain poll instead of sleeping: a blocking wait costs the wake-up of a sleeping thread (10-40 us) per hand-off, and a
 // local BA has six of them.  vo_spin_event: hipEventSynchronize by polling (bounded: falls back to the blocking call after ~2 ms);
 // vo_spin_word: a word in pinned host memory that a kernel stores behind its results (system-scope fence in the kernel).

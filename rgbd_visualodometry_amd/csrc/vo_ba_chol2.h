@@ -52,18 +52,24 @@
 #define CH2_TS 272                          // tile stride (16 rows x 17)
 #define CH2_HEAD 528                        // doubles in front of the tiles: the published columns [2][16][16], 16 that take stores nobody reads
 #define CH2_MAXD 174                        // 11 row blocks of the augmented matrix: 66 tiles = 140 KiB of LDS
+#define CH2_SPILL_T 12                      // D = 177 .. 191 (12 row blocks, the right-hand side inside the last): row block 11 stays in GLOBAL memory (round 6, see "spill" in the body)
 
 #ifdef CH2_STAMPS
 #define CH2_STAMP(slot) { if (lane == 0) { const int s_ = (slot); if (s_ < 128) ((long long*)B.W)[wave * 128 + s_] = clock64(); } }
 #else
 #define CH2_STAMP(slot)
 #endif
-struct Ch2Flags { int prog, dma, init, ok, abort_, inv; int rowdone[16], rdy[16]; };
+struct Ch2Flags { int prog, dma, init, ok, abort_, inv, bsdone; int rowdone[16], rdy[16]; };      // bsdone: the backward substitution has read the spilled row block (spill only)
 
 __host__ __device__ inline int ch2_tix(int i, int j) { return i * (i + 1) / 2 + j; }
 __host__ __device__ inline size_t ch2_sidx(int r, int c) { return (size_t)ch2_tix(r >> 4, c >> 4) * CH2_TS + (size_t)((r & 15) * CH2_RS + (c & 15)); }
 __host__ __device__ inline size_t ch2_s_doubles(int D) { const int T = (D + 15) >> 4; return (size_t)T * (T + 1) / 2 * CH2_TS; }      // S in global memory: the row blocks of rows < D
-__host__ __device__ inline size_t ch2_lds_bytes(int D) { const int T = (D + 16) >> 4; return sizeof(double) * (CH2_HEAD + (size_t)T * (T + 1) / 2 * CH2_TS); }
+__host__ __device__ inline bool ch2_fits(int D) { return D <= CH2_MAXD || (((D + 15) >> 4) == CH2_SPILL_T && ((D + 16) >> 4) == CH2_SPILL_T); }      // sizes the second generation takes
+__host__ __device__ inline size_t ch2_lds_bytes(int D) {
+    const int T = (D + 16) >> 4;
+    const size_t tiles = D > CH2_MAXD ? (size_t)(T - 1) * T / 2 + 2 : (size_t)T * (T + 1) / 2;      // spill: row blocks 0 .. T-2 and the last row block's two right-most tiles
+    return sizeof(double) * (CH2_HEAD + tiles * CH2_TS);
+}
 
 // the words and the published columns are read and written through explicit LDS pointers: a volatile access through a generic pointer stays a
 // flat_load / flat_store (the address-space inference leaves volatile accesses alone)
@@ -226,6 +232,18 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
     const int o_row = CH2_RS * r16;                            // row r16 of a tile (a row per lane)
     const int o_op = CH2_RS * r16 + kq;                        // MFMA operand: row r16, columns kq + 4 q
     const int o_c = CH2_RS * kq + r16;                         // MFMA result: rows kq + 4 q, column r16
+    // SPILL (D = 177 .. 191: 78 tiles, 66 + 2 fit beside the update role's static LDS).  The last row block R = nblk - 1 -- up to 15 rows of S and the
+    // right-hand side -- stays in global memory, where the Schur launch left it, except its two right-most tiles (R, R-1) and (R, R), which wave 0 takes
+    // over at stage R-1 like any row block's and which live in two LDS slots behind row block R-1.  Wave 5 (idle otherwise) owns the row: it holds the
+    // tiles L(R, p) in REGISTERS, in the MFMA operand layout, from the moment they are final -- every product it forms is the transposed one (result
+    // registers = operand registers, as in the solvers' critical step), so nothing is ever re-laid out -- and writes each to global memory once, for
+    // the backward substitution.  The solver waves see Ts = T - 1 row blocks.
+    const bool spill = D > CH2_MAXD;
+    const int Rs = spill ? nblk - 1 : -1, Ts = spill ? T - 1 : T;
+    double* const Ag = const_cast<double*>(A);
+    auto tix = [&](int i, int j) { return i == Rs ? Rs * (Rs + 1) / 2 + (j - (Rs - 1)) : ch2_tix(i, j); };      // where tile (i, j) lies in LDS (row block Rs: j >= Rs - 1 only)
+    auto sidx = [&](int r, int c) { return (size_t)tix(r >> 4, c >> 4) * CH2_TS + (size_t)((r & 15) * CH2_RS + (c & 15)); };
+    auto g_ld = [&](const double* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };      // (past this compute unit's vector cache: another wave wrote it)
     // The head: ONE trip to L2 for everything this workgroup needs of the control block and of scal[] -- lane i < 28 takes word i of the control block, lanes
     // 32 .. 47 the words of scal[0 .. 7]; the fields come out by readlane.  (Up to round 6 a field at a time behind a branch each: need_lin, first, lambda or
     // scal[4] -- and then thread 0's take-over of the fresh linearisation, another three dependent trips in front of block 0's factorisation.  A vector load, not
@@ -238,7 +256,7 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
     auto h_scal = [&](int i) { return __hiloint2double(__builtin_amdgcn_readlane(hw_, 32 + 2 * i + 1), __builtin_amdgcn_readlane(hw_, 32 + 2 * i)); };
     __shared__ Ch2Flags F;
     if (tid < 16) { F.rowdone[tid] = 0; F.rdy[tid] = -1; }
-    if (tid == 0) { F.prog = 0; F.dma = 0; F.init = 0; F.ok = 1; F.abort_ = 0; F.inv = 0; }
+    if (tid == 0) { F.prog = 0; F.dma = 0; F.init = 0; F.ok = 1; F.abort_ = 0; F.inv = 0; F.bsdone = 0; }
     const double* const Hpp = B.Hpp;
     __syncthreads();                                           // the words are zero
     CH2_STAMP(127)
@@ -286,7 +304,7 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
         // rows hold the same sixteen rows: same values to the same addresses.)  Behind a partial last block row D - 16 k of the tile is the
         // right-hand side: that lane's stores go to the 16 doubles nobody reads; the rows below it are nobody's.
         // (no branch: an EXEC write between the DPP operations of the chain needs wait states the compiler does not see)
-        double* const w = r16 != D - CH_NB * k ? s_L + ch2_tix(k, k) * CH2_TS + o_row : s_mem + 512;
+        double* const w = r16 != D - CH_NB * k ? s_L + tix(k, k) * CH2_TS + o_row : s_mem + 512;
         Ch2Stream<0>::run(x, Lk, f0, s_colp, &F.prog, CH_NB * k, r16, &F.abort_, w);
         ch2_set(&F.inv, k + 1);
     };
@@ -344,16 +362,28 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
 #pragma unroll
         for (int j = 0; j < 3; ++j) {                           // y: row D of the augmented factor
             const int col = 16 * (4 * j + g) + c, cc = min(col, D - 1);
-            const double v = s_L[ch2_tix(iD, cc >> 4) * CH2_TS + CH2_RS * rD + (cc & 15)];
+            const bool in_g = spill && (cc >> 4) <= Rs - 2;      // (spill: iD == Rs; the tiles left of (Rs, Rs-1) are in global memory)
+            const double vl = s_L[tix(iD, in_g ? Rs - 1 : cc >> 4) * CH2_TS + CH2_RS * rD + (cc & 15)];
+            const double vg = in_g ? g_ld(Ag + (size_t)ch2_tix(iD, cc >> 4) * CH2_TS + CH2_RS * rD + (cc & 15)) : 0.0;
+            const double v = in_g ? vg : vl;
             rr[j] = col < D ? v : 0.0;
         }
         auto load_w = [&](int q, double (&w)[CH_NB]) {          // row c of W_q (the last block may be partial: its row nb is the right-hand side, the lane's result is dropped)
-            const double* t = s_L + ch2_tix(q, q) * CH2_TS + CH2_RS * c;
+            const double* t = s_L + tix(q, q) * CH2_TS + CH2_RS * c;
 #pragma unroll
             for (int j = 0; j < CH_NB; ++j) w[j] = t[j];
         };
         auto load_t = [&](int q, int j, double (&t)[CH_NB]) {   // column c of tile (q, 4 j + g), clamped to the tiles left of the diagonal (the result of a clamped lane lands in a residual nobody reads again)
-            const double* pt = s_L + ch2_tix(q, min(4 * j + g, max(q - 1, 0))) * CH2_TS + c;
+            const int jj = min(4 * j + g, max(q - 1, 0));
+            if (q == Rs) {                                      // spill: tiles (Rs, jj <= Rs - 2) are wave 5's, in global memory (a lane group per tile: both sources are read, one is taken)
+                const bool in_g = jj <= Rs - 2;
+                const double* pl = s_L + tix(q, Rs - 1) * CH2_TS + c;
+                const double* pg = Ag + (size_t)ch2_tix(q, in_g ? jj : 0) * CH2_TS + c;
+#pragma unroll
+                for (int m = 0; m < CH_NB; ++m) { const double vl = pl[CH2_RS * m], vg = g_ld(pg + CH2_RS * m); t[m] = in_g ? vg : vl; }
+                return;
+            }
+            const double* pt = s_L + ch2_tix(q, jj) * CH2_TS + c;
 #pragma unroll
             for (int m = 0; m < CH_NB; ++m) t[m] = pt[CH2_RS * m];
         };
@@ -395,6 +425,7 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
         for (int q = min(nblk - 1, 3); q >= 0; --q) step(q, rr[0]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         for (int i = lane; i < D; i += 64) { const double v = s_xb[i]; if (PUB) ch2_pub_d(x_out + i, v); else x_out[i] = v; }
+        if (spill) ch2_set(&F.bsdone, 1);                       // (the spilled row block has been read: wave 5 clears it for the next step's atomics)
     };
 
 #ifdef P2_STAMPS
@@ -411,7 +442,7 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
         for (int k = 0; k < nblk; ++k) {
             const int j0 = CH_NB * k, nb = min(CH_NB, D - j0);
             const bool mine = r16 < nb;
-            double* const tkk = s_L + ch2_tix(k, k) * CH2_TS + o_row;
+            double* const tkk = s_L + tix(k, k) * CH2_TS + o_row;
             double a[CH_NB];
             if (k == 0) {
                 // block 0 straight from global memory into registers (row r16 per lane; H_pp + lambda I join here): the factorisation starts
@@ -461,8 +492,8 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
                 ch2_wait_ge(&F.rdy[k + 1], k, &F.abort_);
 #endif
                 CH2_STAMP(80 + (k & 7))
-                double* const px = s_L + ch2_tix(k + 1, k) * CH2_TS + o_op;
-                double* const pd = s_L + ch2_tix(k + 1, k + 1) * CH2_TS + o_c;
+                double* const px = s_L + tix(k + 1, k) * CH2_TS + o_op;
+                double* const pd = s_L + tix(k + 1, k + 1) * CH2_TS + o_c;
                 double at[4], cc[4], w[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { at[q] = px[4 * q]; cc[q] = pd[4 * CH2_RS * q]; }
@@ -470,7 +501,7 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
                 ch2_wait_ge(&F.inv, k + 1, &F.abort_);
 #endif
                 CH2_STAMP(3 * k + 4 >= 3 * nblk ? 99 : 90 + (k & 7))
-                const double* pw = s_L + ch2_tix(k, k) * CH2_TS + o_c;
+                const double* pw = s_L + tix(k, k) * CH2_TS + o_c;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) w[q] = pw[4 * CH2_RS * q];
                 // X^T[r][c] = sum_m W^T[r][m] A^T[m][c]: "A" operand W^T[r][kq + 4 q] = W[kq + 4 q][r] (the result pattern of the tile that holds W),
@@ -498,7 +529,7 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
             if (nb < CH_NB) {
                 // a partial last block: the right-hand side is row nb of this very tile; its forward substitution y_c = (b_c - sum_{m<c} L[c][m] y_m)
                 // / L[c][c] runs here, in registers (lane c: b_c and row c of the block, y_m by DPP broadcast: ChFwd of the first generation)
-                double* prhs = s_L + ch2_tix(k, k) * CH2_TS + CH2_RS * nb;
+                double* prhs = s_L + tix(k, k) * CH2_TS + CH2_RS * nb;
                 double Lr[CH_NB];
 #pragma unroll
                 for (int m = 0; m < CH_NB; ++m) Lr[m] = (mine && m < r16) ? a[m] : 0.0;
@@ -533,7 +564,9 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
         } else if (lane == 0) { F.ok = ok ? 1 : 0; take_over(lambda); B.scal[3] = ok ? 1.0 : 0.0; }
     } else {
         // ================= everyone else: bring the system into LDS ==============================================================
-        const int ndbl = nblk * (nblk + 1) / 2 * CH2_TS;        // the tiles of S (rows < D), in the order and layout of LDS
+        const int nrb = spill ? nblk - 1 : nblk;                // row blocks that come into LDS whole
+        const int ndbl = nrb * (nrb + 1) / 2 * CH2_TS;          // the tiles of S (rows < D), in the order and layout of LDS
+        const int nsl = spill ? 2 * CH2_TS : 0;                 // spill: tiles (Rs, Rs-1) and (Rs, Rs) -- neighbours in global memory -- go into the two slots behind them
         {
             typedef __attribute__((address_space(3))) void lds_void;
             typedef __attribute__((address_space(1))) const void glb_void;
@@ -541,6 +574,10 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
             for (int pc = wave - 1; pc < npiece; pc += CH2_NC)
                 if (pc * 128 + 2 * lane < ndbl)
                     __builtin_amdgcn_global_load_lds((glb_void*)(A + (size_t)pc * 128 + 2 * lane), (lds_void*)(s_L + (size_t)pc * 128), 16, 0, 0);
+            const double* const Asl = A + (size_t)ch2_tix(nblk - 1, nblk - 2) * CH2_TS;
+            for (int pc = wave - 1; pc * 128 < nsl; pc += CH2_NC)
+                if (pc * 128 + 2 * lane < nsl)
+                    __builtin_amdgcn_global_load_lds((glb_void*)(Asl + (size_t)pc * 128 + 2 * lane), (lds_void*)(s_L + (size_t)ndbl + (size_t)pc * 128), 16, 0, 0);
         }
         const int ct = tid - 64;                                // 0 .. 64 * CH2_NC - 1
         const double rhs_v = ct < D ? B.bs[ct] + B.bp[ct] : 0.0;      // D <= 174 < 448
@@ -556,17 +593,98 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
         const double lambda = CH2_LAMBDA();
         for (int i = ct; i < 36 * (D / 6); i += 64 * CH2_NC) {  // the 6x6 diagonal blocks of H_pp (lower halves) and lambda on the diagonal; rows of block 0 are wave 0's
             const int j = i / 36, a = (i % 36) / 6, b = i % 6, row = 6 * j + a;
-            if (b <= a && row >= nb0) s_L[ch2_sidx(row, 6 * j + b)] += Hpp[i] + (a == b ? lambda : 0.0);
+            if (b <= a && row >= nb0) s_L[sidx(row, 6 * j + b)] += Hpp[i] + (a == b ? lambda : 0.0);      // (spill: a pose's 6x6 block in row block Rs lies in tile column >= Rs - 1: the slots)
         }
-        if (ct < D) s_L[ch2_sidx(D, ct)] = rhs_v;
-        if (ct == 0) s_L[ch2_sidx(D, D)] = 0.0;
+        if (ct < D) {
+            if (spill && (ct >> 4) <= Rs - 2) Ag[(size_t)ch2_tix(Rs, ct >> 4) * CH2_TS + CH2_RS * rD + (ct & 15)] = rhs_v;      // (the right-hand side's entries under the spilled tiles: wave 5 reads them past the cache, behind `init`)
+            else s_L[sidx(D, ct)] = rhs_v;
+        }
+        if (ct == 0) s_L[sidx(D, D)] = 0.0;
         if (clear_after_load && ct < D) B.bs[ct] = 0.0;         // b_s and (below) S are the targets of the next step's Schur atomics (the kernel boundary publishes the stores)
+        if (spill) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) ch2_inc(&F.init);
         CH2_STAMP(126)
         if (clear_after_load && wave == 4) {                    // every copy of S has left global memory (dma): wave 4, which has no other work, clears it
             double2* g = reinterpret_cast<double2*>(const_cast<double*>(A));
             for (int i = lane; 2 * i < ndbl; i += 64) g[i] = make_double2(0.0, 0.0);
+            if (spill) { double2* gs = reinterpret_cast<double2*>(Ag + (size_t)ch2_tix(Rs, Rs - 1) * CH2_TS); for (int i = lane; 2 * i < nsl; i += 64) gs[i] = make_double2(0.0, 0.0); }
+        }
+        if (spill && wave == 5) {
+            // ================= the spilled row block (see "SPILL" above): R = 11, tiles (R, 0 .. 9) in registers, (R, 10) and (R, 11) in the slots =====================
+            constexpr int R = CH2_SPILL_T - 1, NK = R - 1;      // NK tiles are kept in registers
+            ch2_wait_ge(&F.init, CH2_NC, &F.abort_);
+            double xr[NK][4];                                   // L(R, k) in the operand layout (row r16, columns kq + 4 q) once stage k is through; before: the tile as it came
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const double* t = Ag + (size_t)ch2_tix(R, k) * CH2_TS + o_op;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xr[k][q] = g_ld(t + 4 * q);
+            }
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                // tile (R, k) -= sum_{p < k} L(R, p) L(k, p)^T, formed as the TRANSPOSED product (A operand: L(k, p), B operand: L(R, p)): the result registers hold
+                // [kq + 4 q][r16] of the transpose = [r16][kq + 4 q] of the tile: the operand layout again
+                if (k >= 1) {
+                    ch2_wait_ge(&F.rowdone[k], k, &F.abort_);   // L(k, 0 .. k-1) are final
+                    f64x4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = a0;
+#pragma unroll
+                    for (int p = 0; p < k; ++p) {
+                        const double* pb = s_L + ch2_tix(k, p) * CH2_TS + o_op;
+                        double b[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) b[q] = pb[4 * q];
+                        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(b[0], xr[p][0], a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(b[1], xr[p][1], a1, 0, 0, 0);
+                        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(b[2], xr[p][2], a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(b[3], xr[p][3], a1, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xr[k][q] -= a0[q] + a1[q];
+                }
+                // X = A W_k as X^T = W_k^T A^T (wave 0's form): result = the operand layout of X
+                ch2_wait_ge(&F.inv, k + 1, &F.abort_);
+                const double* pw = s_L + ch2_tix(k, k) * CH2_TS + o_c;
+                double w[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w[q] = pw[4 * CH2_RS * q];
+                f64x4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = x0;
+                x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w[0], xr[k][0], x0, 0, 0, 0); x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w[1], xr[k][1], x1, 0, 0, 0);
+                x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w[2], xr[k][2], x0, 0, 0, 0); x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w[3], xr[k][3], x1, 0, 0, 0);
+                double* const tg = Ag + (size_t)ch2_tix(R, k) * CH2_TS + o_op;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { xr[k][q] = x0[q] + x1[q]; tg[4 * q] = xr[k][q]; }      // (to global memory for the backward substitution)
+            }
+            // the two tiles wave 0 takes at stage R-1, through panel R-2: (R, R-1) -= L(R, p) L(R-1, p)^T (transposed form, read and written in the operand
+            // layout), (R, R) -= L(R, p) L(R, p)^T (both operands in registers; result layout)
+            ch2_wait_ge(&F.rowdone[R - 1], R - 1, &F.abort_);
+            {
+                double* const p1 = s_L + tix(R, R - 1) * CH2_TS + o_op;
+                double* const p2 = s_L + tix(R, R) * CH2_TS + o_c;
+                double c1[4], c2[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { c1[q] = p1[4 * q]; c2[q] = p2[4 * CH2_RS * q]; }
+                f64x4 u0 = {0.0, 0.0, 0.0, 0.0}, u1 = u0, v0 = u0, v1 = u0;
+#pragma unroll
+                for (int p = 0; p < NK; ++p) {
+                    const double* pb = s_L + ch2_tix(R - 1, p) * CH2_TS + o_op;
+                    double b[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) b[q] = pb[4 * q];
+                    u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(b[0], xr[p][0], u0, 0, 0, 0); v0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[p][0], xr[p][0], v0, 0, 0, 0);
+                    u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(b[1], xr[p][1], u1, 0, 0, 0); v1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[p][1], xr[p][1], v1, 0, 0, 0);
+                    u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(b[2], xr[p][2], u0, 0, 0, 0); v0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[p][2], xr[p][2], v0, 0, 0, 0);
+                    u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(b[3], xr[p][3], u1, 0, 0, 0); v1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[p][3], xr[p][3], v1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { p1[4 * q] = c1[q] - (u0[q] + u1[q]); p2[4 * CH2_RS * q] = c2[q] - (v0[q] + v1[q]); }
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (the tiles in global memory too: the backward substitution reads them behind rowdone[R])
+            if (lane == 0) *(volatile ch2_lds_int*)&F.rdy[R] = R - 1;
+            // ... and once the backward substitution has read the row block, its tiles in global memory are cleared for the next step's atomics
+            if (clear_after_load) {
+                ch2_wait_ge(&F.bsdone, 1, &F.abort_);
+                double2* gs = reinterpret_cast<double2*>(Ag + (size_t)ch2_tix(R, 0) * CH2_TS);
+                for (int i = lane; 2 * i < NK * CH2_TS; i += 64) gs[i] = make_double2(0.0, 0.0);
+            }
         }
 
         if (wave == 1) {
@@ -590,16 +708,16 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
                 if (lane < n) *(volatile ch2_lds_int*)&F.rowdone[i0 + CH2_NS * lane] = k + 1;
             };
             auto rows_update = [&](int i0, int j, int p0, int p1) {      // tiles (i0, j), (i0 + CH2_NS, j), ..: panels p0 .. p1
-                if (i0 >= T || p1 < p0) return;
+                if (i0 >= Ts || p1 < p0) return;
                 const int ti[3] = {i0, i0 + CH2_NS, i0 + 2 * CH2_NS}, tj[3] = {j, j, j};      // T <= 11: at most three of my row blocks
-                if (i0 + 2 * CH2_NS < T) ch2_tiles_mp<3>(s_L, ti, tj, p0, p1, o_op, o_c);
-                else if (i0 + CH2_NS < T) ch2_tiles_mp<2>(s_L, ti, tj, p0, p1, o_op, o_c);
+                if (i0 + 2 * CH2_NS < Ts) ch2_tiles_mp<3>(s_L, ti, tj, p0, p1, o_op, o_c);
+                else if (i0 + CH2_NS < Ts) ch2_tiles_mp<2>(s_L, ti, tj, p0, p1, o_op, o_c);
                 else ch2_tiles_mp<1>(s_L, ti, tj, p0, p1, o_op, o_c);
             };
             ch2_wait_ge(&F.init, CH2_NC, &F.abort_);
             if (g == 0) ch2_set(&F.rdy[1], 0);                  // tiles (1, 0) and (1, 1) have no panel to wait for
             for (int k = 0; k < nblk; ++k) {
-                if (k + 1 >= T) break;                           // nothing below the last block (its right-hand-side row is wave 0's)
+                if (k + 1 >= Ts) break;                          // nothing below the last block (its right-hand-side row is wave 0's)
                 const bool own1 = k % CH2_NS == g;               // row block k+1 is mine: its tiles (k+1, k) and (k+1, k+1) are finished (end of my stage k-1) and wave 0's
                 CH2_STAMP(6 * k)
                 // (A) block column k of my rows, up to date
@@ -610,13 +728,13 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
                 CH2_STAMP(6 * k + 1)
                 // (D) one stage ahead, while block k is still being factored: the two tiles wave 0 will take from me at stage k+1, through panel k-1
                 const int i0 = first_row(k + 2);
-                const bool crit = i0 == k + 2 && i0 < T;        // row block k+2 is mine: the chain wave 0 -> W_k -> L(k+2, k) -> tiles (k+2, k+1), (k+2, k+2) -> wave 0 runs through me
+                const bool crit = i0 == k + 2 && i0 < Ts;        // row block k+2 is mine: the chain wave 0 -> W_k -> L(k+2, k) -> tiles (k+2, k+1), (k+2, k+2) -> wave 0 runs through me
                 if (crit && k >= 1) {
                     ch2_wait_ge(&F.rowdone[k + 1], k, &F.abort_);
                     const int ti[3] = {k + 2, k + 2, 0}, tj[3] = {k + 1, k + 2, 0};
                     ch2_tiles_mp<2>(s_L, ti, tj, 0, k - 1, o_op, o_c);
                 }
-                if (i0 >= T) continue;
+                if (i0 >= Ts) continue;
                 int i1 = i0;                                     // first row block of the ordinary solve below
                 if (crit) {
                     // The critical tile first and alone, as the TRANSPOSED product X^T = W_k^T A^T: the result registers are then the operand
@@ -661,9 +779,9 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
                     CH2_STAMP(6 * k + 2)
                 }
                 // (C) my other tiles of block column k: X = A W_k
-                if (i1 < T) {
+                if (i1 < Ts) {
                     const int ti[3] = {i1, i1 + CH2_NS, i1 + 2 * CH2_NS};
-                    const int n = (T - 1 - i1) / CH2_NS + 1;
+                    const int n = (Ts - 1 - i1) / CH2_NS + 1;
                     if (n == 3) solve_tiles(std::integral_constant<int, 3>{}, ti, k);
                     else if (n == 2) solve_tiles(std::integral_constant<int, 2>{}, ti, k);
                     else solve_tiles(std::integral_constant<int, 1>{}, ti, k);

@@ -227,10 +227,10 @@ def test_config5_sizes_orb_and_tracking_match_oracle(libs):
     np.testing.assert_allclose(np.array(rh.T_cw), np.array(ro.T_cw), atol=1e-9)
 
 
-# D = 6 nfree: 24 (one 16-column panel + partial), 96 (full panels only), 180 (partial last panel), 192 (LDS-resident limit),
+# D = 6 nfree: 24 (one 16-column panel + partial), 96 (full panels only), 180 and 186 (the second-generation solver with its last row block in global memory), 192 (first generation's LDS-resident limit),
 # 216 (> limit: matrix in L2), 600 and 900 (k_ba_chol16g on the sizes between the tests of round 5 and the 960 the ABI admits; host-built pair lists);
 # 1300 points -> > 20000 edges (threaded pair-list build); shuffle: edges not sorted by point
-@pytest.mark.parametrize("nP,nX,nfree,shuffle", [(6, 400, 4, False), (18, 300, 16, False), (34, 500, 30, False), (34, 300, 32, True),
+@pytest.mark.parametrize("nP,nX,nfree,shuffle", [(6, 400, 4, False), (18, 300, 16, False), (34, 500, 30, False), (35, 400, 31, False), (34, 300, 32, True),
                                                   (40, 500, 36, False), (34, 1300, 30, False), (26, 9000, 21, False),      # config-5 scale, ~160 k edges
                                                   (108, 400, 100, False), (158, 300, 150, False)])
 @pytest.mark.parametrize("fuse", ["1", "0"])                 # 1: Cholesky + update in one launch (k_ba_cholup, the default), 0: launched apart (k_ba_chol16v2, k_ba_upchi2)
