@@ -638,6 +638,7 @@ __device__ __forceinline__ void ba_upchi2_body(const BaDev& B, BaCtl* ctl_, int 
     };
     prep(FUSED);
     __shared__ double s_ctl[4];                             // FUSED: lambda, ok, cur, ni as the solver workgroup published them
+    int c_steps = 0, c_qmax = 0, c_it = 0, c_max_it = 0, c_iters_done = 0;      // (thread 0, FUSED)
     if (FUSED) {
         // Nothing that can be done without the solution is left behind the wait: the current poses go to LDS, both of the lane's edges are linearised at the
         // current state (pass 1: rhs -= W_e^T dp_j needs only those Jacobians and dp), and behind the solver's word the solution, lambda, ok, cur and
@@ -647,7 +648,10 @@ __device__ __forceinline__ void ba_upchi2_body(const BaDev& B, BaCtl* ctl_, int 
         for (int i = threadIdx.x; i < 12 * B.n_poses; i += UPC_T) s_Tc[i] = poses_c[i];
         __shared__ int s_flag;
         if (threadIdx.x == 0) {
-            const int wseq = ctl_->steps + 1;              // (steps: the last workgroup of the previous step's launch wrote it)
+            // (the bookkeeping fields the LM decision will update: read here, while the solver works -- the decision, if this workgroup takes the last ticket, then
+            // stores new values without a trip for the old ones; none of them is written by anybody else during this launch)
+            c_steps = ctl_->steps; c_qmax = ctl_->qmax; c_it = ctl_->it; c_max_it = ctl_->max_it; c_iters_done = ctl_->iters_done;
+            const int wseq = c_steps + 1;                  // (steps: the last workgroup of the previous step's launch wrote it)
             int f = 0;
             for (int it = 0; it < (1 << 21) && !f; ++it) { f = __hip_atomic_load(&ctl_->chol_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == wseq; if (!f) __builtin_amdgcn_s_sleep(2); }
             s_flag = f;
@@ -907,20 +911,22 @@ __device__ __forceinline__ void ba_upchi2_body(const BaDev& B, BaCtl* ctl_, int 
             double a = 1.0 - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
             a = fmin(a, 2.0 / 3.0);
             c->lambda = lam * fmax(1.0 / 3.0, a); c->ni = 2; c->cur = tmp;
-            c->buf ^= 1; c->need_lin = 1; accept = 1;       // trial state becomes the current state,
-            c->lbuf ^= 1;                                   // the linearisation this launch wrote at it becomes the current one,
+            c->buf = buf_ ^ 1; c->need_lin = 1; accept = 1; // trial state becomes the current state,
+            c->lbuf = lb ^ 1;                               // the linearisation this launch wrote at it becomes the current one,
             B.scal[0] = tmp; B.scal[4] = 0;                 // and its chi2 is the trial chi2 (k_ba_chol16 takes it over as `cur`)
         } else { c->lambda = lam * ni; c->ni = 2 * ni; }
         if (ok) converged = m7 < 1e-10;
 #ifdef P2_STAMPS
         if (B.n_points < 1000) printf("[upchi2 ctl] stage %d it %d qmax %d ok %d cur %.12e trial %.12e rho %.3e scale %.3e m7 %.3e (pose part %.3e) lambda %.3e\n", c->stage, c->it, c->qmax, (int)ok, cur, tmp, rho, scale, m7, sc7, c->lambda);
 #endif
-        c->qmax += 1; c->steps += 1;
-        if (!(rho < 0 && c->qmax < 10 && !converged)) {     // this LM iteration is over
-            c->iters_done += 1;
-            if (c->qmax == 10 || rho == 0 || converged || c->it + 1 >= c->max_it) c->finished = 1;
-            c->it += 1; c->qmax = 0;
+        if (!FUSED) { c_steps = c->steps; c_qmax = c->qmax; c_it = c->it; c_max_it = c->max_it; c_iters_done = c->iters_done; }
+        c_qmax += 1; c->steps = c_steps + 1;
+        if (!(rho < 0 && c_qmax < 10 && !converged)) {      // this LM iteration is over
+            c->iters_done = c_iters_done + 1;
+            if (c_qmax == 10 || rho == 0 || converged || c_it + 1 >= c_max_it) c->finished = 1;
+            c->it = c_it + 1; c_qmax = 0;
         }
+        c->qmax = c_qmax;
         s_accept = accept;
     }
     __syncthreads();
