@@ -83,7 +83,8 @@ struct BaDev {
     double* scal;       // [0] chi cur  [1] chi trial  [2] scale  [3] ok  [4] maxdiag (as u64 bits) [5] chi report [6] chi final
     // e-3 (ba_shard_solve): the problem is one rank's share of a BA sharded by point.  gen1: the launch-per-phase step with S in global memory whatever D is;
     // xbuf: the exchange regions behind S / b_s (which live in it: [S D*D][b_s D][x1: H_pp 36 nf, b_p D, chi, maxima per rank][x3: chi trial, scale, max step per rank])
-    int gen1, shard_rank, shard_world, upc_ovf; double* xbuf;      // upc_ovf: the update workgroups' LDS holds the overflow list + cells beside the poses (vo_ba_phase2.h; 0: too many poses)
+    int gen1, shard_rank, shard_world, upc_ovf; double* xbuf;
+    int upc_ppw;                                             // points per update workgroup of a lone problem's fused launch (vo_ba_phase2.h; 0: 128)      // upc_ovf: the update workgroups' LDS holds the overflow list + cells beside the poses (vo_ba_phase2.h; 0: too many poses)
 };
 #define BA_FOLD(B) ((B).D <= BA_FOLD_D && !(B).gen1)
 __host__ __device__ inline size_t ba_x1_off(int D) { return (size_t)D * D + D; }
@@ -1787,6 +1788,9 @@ int vo_ba_set_attrs() {
 #include <condition_variable>
 #include <deque>
 // which layout S has (and which Cholesky kernel a problem takes): tiles + the second generation where ch2_fits says so (D <= 174, 177 .. 191), packed rows + the first otherwise
+// points per update workgroup of the fused launch: as few as keeps the launch (solver + point workgroups + pose workgroup) within the chip's 256 compute units,
+// whole wavefronts (16 points), at least 64 (the partial-sum arrays are sized for 64-point workgroups)
+static int ba_upc_ppw(int nx) { const int p = ((nx + 249) / 250 + 15) / 16 * 16; return std::min(UPC_T / 4, std::max(64, p)); }
 static int ba_use_tiles(int D) { return ch2_fits(D) ? 1 : 0; }      // (D <= 174 whole in LDS; 177 .. 191 with the last row block in global memory: vo_ba_chol2.h)
 // Host waits on this latency chain poll instead of sleeping: a blocking wait costs the wake-up of a sleeping thread (10-40 us) per hand-off, and a
 // local BA has six of them.  vo_spin_event: hipEventSynchronize by polling (bounded: falls back to the blocking call after ~2 ms);
@@ -1962,7 +1966,8 @@ static int ba_engine_enqueue(BaEngine* E) {
             // tile-major problems only: solvers and updates in one launch (vo_ba_phase2.h, FUSED)
             if (fuse_up) {
                 ProfScope ps(prof, direct ? "k_ba_cholup_one" : "k_ba_cholup", st);
-                const int gpmax = (gA_up + up_rep * (UPC_T / 4) - 1) / (up_rep * (UPC_T / 4)) + 1;      // (+ 1: the pose workgroup behind a problem's point workgroups)
+                const int ppw = (direct && E->h_Bs[sA[0]].upc_ppw > 0) ? E->h_Bs[sA[0]].upc_ppw : UPC_T / 4;
+                const int gpmax = (gA_up + up_rep * ppw - 1) / (up_rep * ppw) + 1;      // (+ 1: the pose workgroup behind a problem's point workgroups)
                 if (direct) hipLaunchKernelGGL(k_ba_cholup_one, dim3(1 + gpmax), dim3(CH2_T), std::max(ldsA, ldsA_up), st, E->h_Bs[sA[0]], E->d_ctl + sA[0], gpmax, up_rep);
                 else hipLaunchKernelGGL(k_ba_cholup, dim3(nA * (1 + gpmax)), dim3(CH2_T), std::max(ldsA, ldsA_up), st, QA, nA, gpmax, up_rep);
             } else {
@@ -2393,7 +2398,7 @@ int vo_ba_run(vo_ctx* c, const vo_ba_problem* in, vo_ba_result* out) {
     B.cam = BaCam{(double)c->p.fx, (double)c->p.fy, (double)c->p.cx, (double)c->p.cy};
     B.delta = in->huber_delta; B.chi2_th = in->chi2_th; B.gp = (nx + 63) / 64; B.edges_by_point = sorted_by_point ? 1 : 0;
     B.e_obs = nullptr; B.cull = nullptr; B.ncull = nullptr; B.cull_cap = 0; B.cull_host = nullptr; B.cull_host_cap = 0;
-    B.gen1 = 0; B.shard_rank = 0; B.shard_world = 1; B.upc_ovf = sizeof(double) * (24 * (size_t)np + (size_t)D + UPC_LDS_EXTRA) <= 150 * 1024 ? 1 : 0; B.xbuf = nullptr;
+    B.gen1 = 0; B.shard_rank = 0; B.shard_world = 1; B.upc_ovf = sizeof(double) * (24 * (size_t)np + (size_t)D + UPC_LDS_EXTRA) <= 150 * 1024 ? 1 : 0; B.upc_ppw = ba_upc_ppw(nx); B.xbuf = nullptr;
 
     {
         if (up_end > c->h_ba_up_bytes) {                    // pinned mirror of the upload region, grown geometrically
@@ -3066,7 +3071,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     B.cam = BaCam{(double)c->p.fx, (double)c->p.fy, (double)c->p.cx, (double)c->p.cy};
     B.delta = huber_delta; B.chi2_th = chi2_th; B.gp = (nx + 63) / 64; B.edges_by_point = 1;
     B.e_obs = e_obs; B.cull = (long long*)(base + o_cull); B.ncull = (int*)(base + o_ncull); B.cull_cap = ne; B.cull_host = nullptr; B.cull_host_cap = 0;      // (the engine points cull_host at its slot's pinned list)
-    B.gen1 = 0; B.shard_rank = 0; B.shard_world = 1; B.upc_ovf = sizeof(double) * (24 * (size_t)np + (size_t)D + UPC_LDS_EXTRA) <= 150 * 1024 ? 1 : 0; B.xbuf = nullptr;
+    B.gen1 = 0; B.shard_rank = 0; B.shard_world = 1; B.upc_ovf = sizeof(double) * (24 * (size_t)np + (size_t)D + UPC_LDS_EXTRA) <= 150 * 1024 ? 1 : 0; B.upc_ppw = ba_upc_ppw(nx); B.xbuf = nullptr;
     HIP_TRY(hipGetLastError());
     R.nblk_launch = slices_ub; R.npairs = npairs;
     R.B = B;

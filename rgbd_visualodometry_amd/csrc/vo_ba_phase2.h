@@ -531,7 +531,11 @@ __device__ __forceinline__ void ba_upchi2_body(const BaDev& B, BaCtl* ctl_, int 
     // 10 on average, 21 at most: 3-6 dependent rounds per pass where most lanes had one) but put on a workgroup-wide list and taken ONE PER LANE,
     // their contributions written to the entry's own LDS cell and added up by the lane that listed them, in the order it listed them (no atomics: two runs of
     // one solve add in the same order): two rounds per pass whatever the degrees are (scripts/ba_degree_stats.py).
-    const int gp = (B.n_points + rep * (UPC_T / 4) - 1) / (rep * (UPC_T / 4));
+    // points per workgroup and round: 128 (four lanes each) -- or fewer for a lone problem's fused launch (BaDev::upc_ppw, a multiple of 16 = whole wavefronts), where
+    // every workgroup has a compute unit to itself anyway (the solver's LDS size) and the chip has more compute units than 128-point workgroups: pass 1 and pass 2 are
+    // bound by the double-precision issue of the two wavefronts a SIMD holds, and 96 points leave two of the eight wavefronts without work
+    const int P = (FUSED && rep == 1 && B.upc_ppw > 0) ? B.upc_ppw : UPC_T / 4;
+    const int gp = (B.n_points + rep * P - 1) / (rep * P);
     if (bx > gp) return;
     const bool pose_wg = bx == gp;
     extern __shared__ double s_dyn[];
@@ -563,7 +567,7 @@ __device__ __forceinline__ void ba_upchi2_body(const BaDev& B, BaCtl* ctl_, int 
     const double* const Wt = p2_w(B, lb);
     double* const rec_n = p2_rec(B, lb ^ 1);
     double* const Wn = p2_w(B, lb ^ 1);
-    int k = bx * rep * (UPC_T / 4) + (threadIdx.x >> 2);
+    int k = bx * rep * P + (threadIdx.x >> 2);
     const int sub = threadIdx.x & 3, pl = threadIdx.x >> 2;
     // (the list packs an edge position into 24 bits; and a graph with so many poses that the list and the cells do not fit LDS beside them -- upc_ovf = 0, the
     // launch then carries no such region -- walks its edges in rounds of four as before)
@@ -581,7 +585,7 @@ __device__ __forceinline__ void ba_upchi2_body(const BaDev& B, BaCtl* ctl_, int 
     bool preA = false, preB = false, serial = false;
     int nov = 0, mine[UPC_OVF_MINE], n_mine = 0, q_ser = 0;      // mine: the list entries this lane made; q_ser: its point's edges from here on it walks itself
     auto prep = [&](bool pre_jac) {
-        live = ok && !pose_wg && k < B.n_points;
+        live = ok && !pose_wg && k < B.n_points && (int)(threadIdx.x >> 2) < P;
         eA = -1; actA = 0; q0 = q1 = 0; eB = -1; actB = 0; preA = preB = false;
         if (FUSED && threadIdx.x == 0) s_nov = 0;
         if (live) {
@@ -703,7 +707,7 @@ __device__ __forceinline__ void ba_upchi2_body(const BaDev& B, BaCtl* ctl_, int 
     __syncthreads();
     P2_STAMP()
     double chi = 0, sc = 0, mx = 0;
-    for (int r = 0; r < rep; ++r, k += UPC_T / 4) {
+    for (int r = 0; r < rep; ++r, k += P) {
         if (r) { prep(false); rhs[0] = rhs[1] = rhs[2] = 0; }
         if (!actA) eA = -1;
         if (!actB) eB = -1;
