@@ -64,7 +64,7 @@ struct BaDev {
     int gp;                                                  // point workgroups of the 4-lanes-per-point kernels (64 points each)
     int edges_by_point;                                      // 1: the edges are grouped by point, pt_edges is the identity
     BaCam cam; double delta, chi2_th;
-    int it_robust, it_plain, gen, s_tiles;                   // iterations of the two rounds (backend.cpp:141,159); gen: the engine's admission counter (stale status records are told apart by it); s_tiles: S is kept as 16x16 tiles (vo_ba_chol2.h: D <= CH2_MAXD) instead of packed rows
+    int it_robust, it_plain, gen, s_tiles;                   // iterations of the two rounds (backend.cpp:141,159); gen: the engine's admission counter (stale status records are told apart by it); s_tiles: S is kept as 16x16 tiles (vo_ba_chol2.h: ch2_fits(D)) instead of packed rows
     // resident graphs only (nullptr otherwise): observation id per edge; the ids of the culled edges are collected by k_ba_round's final
     // stage (device list for the merge kernel, first cull_host_cap of them also in pinned host memory: no list kernel, no read-back copy)
     const long long* e_obs; long long* cull; int* ncull; int cull_cap; long long* cull_host; int cull_host_cap;
@@ -193,7 +193,7 @@ __device__ __forceinline__ void ba_inv3_damped(const double* __restrict__ Hll, d
 // layout the factorisation uses in LDS, so that k_ba_chol16 brings it in with straight global -> LDS copies.  Larger systems (k_ba_chol16g)
 // keep the full row-major matrix.
 __device__ __forceinline__ size_t ba_tri(int r, int c) { return (size_t)r * (size_t)(r + 1) / 2 + (size_t)c; }
-// ... or, for the second-generation Cholesky (vo_ba_chol2.h, D <= CH2_MAXD), as 16x16 tiles of row stride 17 in tile order
+// ... or, for the second-generation Cholesky (vo_ba_chol2.h, ch2_fits(D)), as 16x16 tiles of row stride 17 in tile order
 #define BA_TILE_RS 17
 #define BA_TILE_TS 272
 __host__ __device__ inline size_t ba_tile_idx(int r, int c) { const int i = r >> 4, j = c >> 4; return (size_t)(i * (i + 1) / 2 + j) * BA_TILE_TS + (size_t)((r & 15) * BA_TILE_RS + (c & 15)); }

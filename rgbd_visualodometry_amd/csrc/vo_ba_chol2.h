@@ -1,4 +1,4 @@
-// vo_ba_chol2.h -- the reduced system's Cholesky + solve for D <= CH2_MAXD, second generation (k_ba_chol16v2, and workgroup 0 of k_ba_cholup):
+// vo_ba_chol2.h -- the reduced system's Cholesky + solve for D <= CH2_MAXD (and, with the last row block outside LDS, D = 177 .. 191: "SPILL" in the body), second generation (k_ba_chol16v2, and workgroup 0 of k_ba_cholup):
 // the arithmetic of k_ba_chol16 (16-column panels, in-register block factor, f64-MFMA tiles) run as a DATAFLOW inside one workgroup instead
 // of as barrier-separated phases, on a TILE-MAJOR matrix, with every panel solve turned into a product with the block's inverse.
 // Included by vo_ba.hip behind the first generation's DPP helpers.  Reference: the linear solver of src/backend.cpp:23-27 (g2o's dense
@@ -30,7 +30,7 @@
 //                wave 0 -> W_k -> L(k+2, k) -> tiles (k+2, k+1), (k+2, k+2) -> wave 0: it has given those two tiles their panels 0 .. k-1 one
 //                stage ahead, solves the critical tile first and alone (as a transposed product, so that the result registers are the
 //                operands of what follows), adds panel k to the two tiles and raises `rdy`; `rowdone[i]` = stages solved for row block i.
-//   waves 4, 5   help to load; wave 4 clears S in global memory.  (An MFMA, a DPP operation and a plain FMA in double precision all draw on
+//   waves 4, 5   help to load; wave 4 clears S in global memory; wave 5 owns the last row block of a system that does not fit (SPILL: the row's tiles in its registers).  (An MFMA, a DPP operation and a plain FMA in double precision all draw on
 //                the same 16 lanes per clock of their SIMD -- a v_mfma_f64_16x16x4 holds them for ~64 clocks -- so work placed beside
 //                wave 0 or beside the inverter slows the chain by more than it relieves the solvers: measured)
 // Words are monotone and never reset.  Producers store data, then the word, in program order (LDS executes a wave's instructions in order;
