@@ -2142,6 +2142,11 @@ BaEngine* vo_ba_engine_acquire(int device) {
     return E;
 }
 
+void vo_ba_engine_drain(vo_ctx* c) {                        // (see vo_internal.h)
+    BaEngine* E = c ? c->ba_engine_sel : nullptr;
+    if (E && E->st) (void)hipStreamSynchronize(E->st);
+}
+
 static BaEngine* ba_engine_of(vo_ctx* c) {
     if (c->ba_engine_sel) return c->ba_engine_sel;
     BaEngine* base = c->ba_engine;
@@ -2932,7 +2937,7 @@ static int ba_resident_cut(vo_ctx* c, vo_ctx* t, const int32_t* free_kf, int nf,
     const size_t o_kfi = cc(4 * (size_t)nkf), o_pkf = cc(4 * (size_t)(nkf + VO_BA_RESIDENT_MAX_FREE)), o_pid = cc(4 * (size_t)mh), o_pst = cc(4 * (size_t)(mh + 1)), o_psl = cc(4 * (size_t)mh),
                  o_tot = cc(64);
     if (co > c->d_cut_bytes) {
-        if (c->d_cut) { (void)hipStreamSynchronize(st); (void)hipFree(c->d_cut); }
+        if (c->d_cut) { (void)hipStreamSynchronize(st); vo_ba_engine_drain(c); (void)hipFree(c->d_cut); }
         c->d_cut = nullptr; c->d_cut_bytes = 0;
         if (hipMalloc(&c->d_cut, co + co / 2) != hipSuccess) return VO_E_NOMEM;
         c->d_cut_bytes = co + co / 2;

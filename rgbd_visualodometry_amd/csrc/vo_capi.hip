@@ -112,7 +112,7 @@ void* vo_stage(vo_ctx* c, size_t bytes) {
 
 int vo_scratch(vo_ctx* c, size_t bytes) {
     if (bytes <= c->d_ba_bytes) return VO_OK;
-    if (c->d_ba) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->d_ba); }
+    if (c->d_ba) { (void)hipStreamSynchronize(c->stream); vo_ba_engine_drain(c); (void)hipFree(c->d_ba); }
     c->d_ba = nullptr; c->d_ba_bytes = 0;
     const size_t want = bytes + bytes / 2 + (1 << 20);
     if (hipMalloc(&c->d_ba, want) != hipSuccess) return VO_E_NOMEM;

@@ -181,6 +181,9 @@ inline hipError_t vo_stream_create(hipStream_t* st, int cls) {
 }
 void* vo_stage(vo_ctx* c, size_t bytes);           // pinned host staging buffer of at least `bytes`
 int vo_scratch(vo_ctx* c, size_t bytes);           // grow the device scratch slab c->d_ba to at least `bytes`
+// nothing the context's BA engine has enqueued may still run when a buffer its step kernels read is freed: since round 6 a step kernel reads words of the slab
+// BEFORE it knows that its problem has finished (one-trip heads), and a chunk's last launches may still be queued when the host has long moved on (vo_ba.hip)
+void vo_ba_engine_drain(vo_ctx* c);
 int vo_map_scatter_launch(vo_ctx* c, int n, const int32_t* d_idx, const double* d_xyz, const double* d_nrm, const uint32_t* d_desc, const int32_t* d_kp, const uint8_t* d_flags);
 
 // stage launchers
