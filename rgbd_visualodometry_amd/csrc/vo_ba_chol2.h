@@ -362,7 +362,7 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
 #pragma unroll
         for (int j = 0; j < 3; ++j) {                           // y: row D of the augmented factor
             const int col = 16 * (4 * j + g) + c, cc = min(col, D - 1);
-            const bool in_g = spill && (cc >> 4) <= Rs - 2;      // (spill: iD == Rs; the tiles left of (Rs, Rs-1) are in global memory)
+            const bool in_g = !(CH2_EXP & 16) && spill && (cc >> 4) <= Rs - 2;      // (spill: iD == Rs; the tiles left of (Rs, Rs-1) are in global memory)
             const double vl = s_L[tix(iD, in_g ? Rs - 1 : cc >> 4) * CH2_TS + CH2_RS * rD + (cc & 15)];
             const double vg = in_g ? g_ld(Ag + (size_t)ch2_tix(iD, cc >> 4) * CH2_TS + CH2_RS * rD + (cc & 15)) : 0.0;
             const double v = in_g ? vg : vl;
@@ -375,7 +375,7 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
         };
         auto load_t = [&](int q, int j, double (&t)[CH_NB]) {   // column c of tile (q, 4 j + g), clamped to the tiles left of the diagonal (the result of a clamped lane lands in a residual nobody reads again)
             const int jj = min(4 * j + g, max(q - 1, 0));
-            if (q == Rs) {                                      // spill: tiles (Rs, jj <= Rs - 2) are wave 5's, in global memory (a lane group per tile: both sources are read, one is taken)
+            if (q == Rs && !(CH2_EXP & 16)) {                   // spill: tiles (Rs, jj <= Rs - 2) are wave 5's, in global memory (a lane group per tile: both sources are read, one is taken)
                 const bool in_g = jj <= Rs - 2;
                 const double* pl = s_L + tix(q, Rs - 1) * CH2_TS + c;
                 const double* pg = Ag + (size_t)ch2_tix(q, in_g ? jj : 0) * CH2_TS + c;
