@@ -701,7 +701,11 @@ __device__ __forceinline__ void ba_chol16v2_body(const BaDev& B, BaCtl* ctl_, do
             // is ONE fused step whose own operands are in registers before the wait: it sits between the end of wave 0's stage k-1 and
             // the end of its block k.  Foreign inputs: W_k (inv) and L(j, .) of other solvers' / wave 0's row block j (rowdone[j] = stages
             // solved for row block j).
-            const int g = wave <= 3 ? wave - 2 : wave - 4;      // waves 2, 3, 6, 7
+            // waves 2, 3, 6, 7 -- or 2, 3, 7, 6 in the twelve-row-block (spilled) form: the owners' work grows with the square of the row block's number (solver 1 of 4 has row
+            // blocks 2, 6, 10), and with 6 and 7 swapped the two SIMDs the solvers live on issue 107 : 113 of the tile products instead of 95 : 125.  At that size the
+            // matrix pipe of the busier SIMD is what the last stages wait for (tools/chol_bench: D = 168 ... 186 -1.0 ... -1.4 us; below, where it is not, consecutive
+            // row blocks on different SIMDs are worth more: D = 132 ... 156 +0.4 ... +0.6 us with the swap -- and with eleven row blocks the bench lost 1 % at 300 steps)
+            const int g = wave <= 3 ? wave - 2 : (spill ? 9 - wave : wave - 4);
             auto first_row = [&](int lo) { return lo + ((g + 1 - lo) % CH2_NS + CH2_NS) % CH2_NS; };      // my first row block >= lo
             auto mark_rows = [&](int k, int i0, int n) {        // row blocks i0, i0 + CH2_NS, .. (n of them) are solved through stage k
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
