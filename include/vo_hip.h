@@ -425,6 +425,12 @@ int vo_tables_fetch(vo_ctx* ctx, int64_t obs0, int64_t obs_cap, int32_t* obs_kf,
                     int32_t map0, int32_t map_cap, double* map_xyz, double* map_normal, uint8_t* map_desc, uint8_t* map_flags,
                     int32_t* active, int active_cap, int32_t* n_active);
 
+/* Test tap: the process-wide call number of the one-launch prefix sums (the graph cut's two and the local-map query's one per keyframe; a scan's
+ * workgroups publish (call number << 32 | tile total) words).  set_to >= 0 sets it first -- a test then walks the number through the range of values
+ * the scratch arrays hold (tests/test_device_keyframes.py: the words once lived at a place that follows the window).  Returns the number (the CPU
+ * restatement has no such scan: 0). */
+long long vo_scan_call_number(long long set_to);
+
 /* ---- plumbing ------------------------------------------------------------------------- */
 int vo_sync(vo_ctx* ctx);
 /* Per-kernel accumulated device time measured with HIP events on the context's stream

@@ -704,6 +704,8 @@ int vo_local_ba_resident_merge_ledger(vo_ctx* c, vo_ctx* t, int32_t* pair_a, int
     return VO_OK;
 }
 
+long long vo_scan_call_number(long long) { return 0; }      // (the restatement's prefix sums are loops: nothing is published)
+
 int vo_tables_fetch(vo_ctx* c, int64_t obs0, int64_t obs_cap, int32_t* obs_kf, int32_t* obs_mp, float* obs_uv, uint8_t* obs_alive, int64_t* n_obs,
                     int32_t map0, int32_t map_cap, double* map_xyz, double* map_normal, uint8_t* map_desc, uint8_t* map_flags,
                     int32_t* active, int active_cap, int32_t* n_active) {

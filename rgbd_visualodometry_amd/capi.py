@@ -77,7 +77,7 @@ SYMBOLS = ["vo_ctx_create", "vo_ctx_destroy", "vo_strerror", "vo_backend_name", 
            "vo_group_create", "vo_group_destroy", "vo_group_join", "vo_group_leave", "vo_group_set_gather", "vo_group_stats",
            "vo_set_hypothesis_shard", "vo_set_hypothesis_shard_stream", "vo_triangulate_batch", "vo_kf_set_pose", "vo_obs_append", "vo_obs_kill", "vo_local_ba_resident",
            "vo_local_ba_resident_cut", "vo_local_ba_resident_solve", "vo_local_ba_resident_merge", "vo_local_ba_resident_fetch", "vo_ba_resident_graph", "vo_ba_resident_window", "vo_ba_resident_set_slab_budget", "vo_trace_level", "vo_set_ba_shard", "vo_set_ba_shard_stream",
-           "vo_keyframe_commit", "vo_kf_covisibility", "vo_map_set_active_covisible", "vo_local_ba_resident_merge_ledger", "vo_tables_fetch"]
+           "vo_keyframe_commit", "vo_kf_covisibility", "vo_map_set_active_covisible", "vo_local_ba_resident_merge_ledger", "vo_tables_fetch", "vo_scan_call_number"]
 
 
 VO_E_OVERFLOW = -4        # include/vo_hip.h: vo_status
@@ -158,6 +158,7 @@ class VoLib:
         L.vo_local_ba_resident_merge_ledger.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_void_p, C.c_int]
         L.vo_tables_fetch.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32)]
+        L.vo_scan_call_number.argtypes = [C.c_longlong]; L.vo_scan_call_number.restype = C.c_longlong
         L.vo_triangulate_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vo_set_hypothesis_shard.argtypes = [C.c_void_p, C.c_int, C.c_int, EXCHANGE_FN, C.c_void_p]
         L.vo_set_hypothesis_shard_stream.argtypes = [C.c_void_p, C.c_int, C.c_int, STREAM_ALLREDUCE_FN, C.c_void_p]

@@ -2886,6 +2886,7 @@ __global__ __launch_bounds__(1024) void k_scan_one(const int* __restrict__ in, i
     }
 }
 static std::atomic<unsigned> g_scan_seq{0};
+extern "C" long long vo_scan_call_number(long long set_to) { if (set_to >= 0) g_scan_seq = (unsigned)set_to; return (long long)g_scan_seq.load(); }      // (test tap: include/vo_hip.h)
 int vo_scan_i32(hipStream_t st, const int* in, int n, int* bsum, int* out, int* total) {        // n <= 16 Mi; bsum: 4096 bytes, 256-byte aligned, zeroed when allocated
     const int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (nb > 1024) return VO_E_UNSUPPORTED;

@@ -58,6 +58,12 @@ struct KfState {
     int32_t* d_cand = nullptr; uint8_t* d_tri_ok = nullptr; double* d_tri_xyz = nullptr; int cand_cap = 0;
     int2* d_cnt = nullptr; unsigned* d_kp_bits = nullptr;           // per 256 matches: (LM inliers, triangulation candidates); keypoints explained by an inlier (zero between commits)
     void* d_act = nullptr; size_t act_bytes = 0;                    // flag / position scratch of the local-map query
+    // vo_scan_i32's published tile totals (call number << 32 | total) and the scan's total: a block of its OWN, allocated once and zeroed.  Up to round 6 it was
+    // carved out of d_act behind the position array, i.e. at an offset that follows the window: the words then held an earlier, larger window's prefix sums -- values
+    // up to the local map's size, ~18 000 -- and once the process-wide call number had counted up to that range (three scans per keyframe: keyframe ~6000, frame
+    // ~20 000) a tile's stale word could pass for this call's published total: wrong places, a wrong n_active, and the chain indexing the map with whatever
+    // d_active held behind the written entries: the GPU memory fault of two 30 000-frame soaks in sixteen (profiles/r06_soak_30k_fault.txt).
+    void* d_scan = nullptr;                                         // [4096 B tile totals | 256 B total]
     uint32_t epoch = 0;
 };
 
@@ -79,7 +85,7 @@ static void kf_state_free(vo_ctx* c) {
     KfState* k = c->kf;
     if (!k) return;
     if (k->h) (void)hipHostFree(k->h);
-    void* q[] = {k->d_hdr, k->d_w, k->d_mark, k->d_key, k->d_cand, k->d_tri_ok, k->d_tri_xyz, k->d_act, k->d_cnt, k->d_kp_bits};
+    void* q[] = {k->d_hdr, k->d_w, k->d_mark, k->d_key, k->d_cand, k->d_tri_ok, k->d_tri_xyz, k->d_act, k->d_cnt, k->d_kp_bits, k->d_scan};
     for (void* x : q) if (x) (void)hipFree(x);
     delete k; c->kf = nullptr;
 }
@@ -668,15 +674,18 @@ extern "C" int vo_map_set_active_covisible(vo_ctx* c, const int32_t* kf, int n, 
     const int n_win = (int)(c->n_obs - lo);
     if (n > 0 && n_win > 0) {
         const int n_pad = (n_win + 3) & ~3;
-        const size_t o_pos = ((size_t)4 * n_pad + 255) & ~(size_t)255, o_bs = 2 * o_pos, total = o_bs + 4096 + 256;
+        const size_t o_pos = ((size_t)4 * n_pad + 255) & ~(size_t)255, total = 2 * o_pos;
+        if (!K.d_scan) {
+            if (hipMalloc(&K.d_scan, 4096 + 256) != hipSuccess) { (void)hipGetLastError(); K.d_scan = nullptr; return VO_E_NOMEM; }
+            HIP_TRY(hipMemsetAsync(K.d_scan, 0, 4096 + 256, st));
+        }
         if (total > K.act_bytes) {
             if (K.d_act) { HIP_TRY(hipStreamSynchronize(st)); (void)hipFree(K.d_act); }
             K.d_act = nullptr; K.act_bytes = 0;
             if (hipMalloc(&K.d_act, total + total / 2) != hipSuccess) { (void)hipGetLastError(); return VO_E_NOMEM; }
             K.act_bytes = total + total / 2;
-            HIP_TRY(hipMemsetAsync(K.d_act, 0, K.act_bytes, st));      // (vo_scan_i32's published totals must not look like a later call's)
         }
-        int* flag = (int*)K.d_act; int* pos = (int*)((uint8_t*)K.d_act + o_pos); int* bsum = (int*)((uint8_t*)K.d_act + o_bs); int* tot = bsum + 1024;
+        int* flag = (int*)K.d_act; int* pos = (int*)((uint8_t*)K.d_act + o_pos); int* bsum = (int*)K.d_scan; int* tot = bsum + 1024;
         const int epoch = (int)(++K.epoch & 0x7FFFFFFF);
         memcpy(K.h->kf_list, kf, 4 * (size_t)n);            // (the previous call's kernels have been waited for)
         const KfTabs T = tabs_of(c);

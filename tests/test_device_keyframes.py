@@ -500,3 +500,52 @@ def test_the_device_map_grows_hip(stream):
     np.testing.assert_allclose(np.array([p["xyz"] for p in a["points"]]), np.array([p["xyz"] for p in b["points"]]), atol=1e-4, rtol=0)
     na, nb = sum(p["n_obs"] for p in a["points"]), sum(p["n_obs"] for p in b["points"])
     assert na > 0 and abs(na - nb) <= 8
+
+
+@pytest.mark.gpu
+def test_the_local_map_scan_does_not_take_stale_scratch_for_a_published_total(stream):
+    """vo_map_set_active_covisible's prefix sum is a one-launch scan whose workgroups publish (call number << 32 | tile total) words.  Up to round 6 those words
+    lived behind the query's position array, at an offset that follows the window: after a query over a LARGER window the words held that query's prefix sums --
+    (n_active << 32 | n_active) where the sums had levelled off -- and a query whose process-wide call number equals that value took a tile's stale word for
+    its published total whenever a later tile's workgroup looked before the earlier one had stored: wrong places, n_active up to the list's capacity, and the
+    tracking chain reading map slots d_active never received (the GPU memory fault of two 30 000-frame soaks, where the local map's ~18 000 points meet the
+    call number around keyframe 6000).  Here: forty keyframes that each see the same 3000 points, queries alternating between a window of forty and of thirty
+    keyframes' observations (eight and six tiles), the call number walked through 3000 with both parities of the alternation, while a second context's ORB
+    keeps the chip busy (an idle chip starts the tiles' workgroups together and the earlier one always wins).  The library of round 6's start returned 4096
+    for the query with call number 3000 in nine of ten such walks (scripts/scan_stale_probe.py)."""
+    import threading
+    L = capi.load(capi.HIP_LIB)
+    bgr, depth, Twc, ts = stream
+    busy = L.context(L.default_params(n_features=2000, max_frames=8, map_capacity=1 << 12))
+    for i in range(8):
+        busy.upload(i, bgr[i], depth[i])
+    stop = threading.Event()
+    def load():
+        while not stop.is_set():
+            busy.orb(0, 8)
+    nX, nK = 3000, 40
+    t = L.context(L.default_params(map_capacity=4096))
+    rng = np.random.default_rng(5)
+    X = rng.uniform(-1.0, 1.0, (nX, 3)) + [0, 0, 4.0]
+    t.map_upsert(np.arange(nX, dtype=np.int32), X, np.tile([0, 0, 1.0], (nX, 1)), np.zeros((nX, 32), np.uint8), np.zeros(nX, np.uint8))
+    t.kf_set_pose(np.arange(nK), np.tile(I12, (nK, 1)))
+    uv = np.tile([320.0, 240.0], (nX, 1))
+    for k in range(nK):
+        t.obs_append([k] * nX, np.arange(nX), uv)
+    wide, narrow = list(range(nK)), list(range(10, nK))
+    want = np.arange(nX)
+    th = threading.Thread(target=load); th.start()
+    try:
+        for rep in range(4):
+            for parity in (0, 1):
+                L.lib.vo_scan_call_number(nX - 30 - parity)
+                for i in range(60):
+                    assert t.map_set_active_covisible(wide, nX, 100) == nX
+                    n = t.map_set_active_covisible(narrow, nX, 100)
+                    assert n == nX, (rep, parity, i, n, L.lib.vo_scan_call_number(-1))
+                    if i % 10 == 0:
+                        assert np.array_equal(t.tables(nX)["active"], want)
+                assert L.lib.vo_scan_call_number(-1) > nX
+    finally:
+        stop.set(); th.join()
+    t.close(); busy.close()
