@@ -15,6 +15,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--ba-lag", type=int, default=8)
+    ap.add_argument("--speed", type=float, default=0.0, help="camera speed factor of the synthetic trajectories (0: the renderer's default; 3 = the bench line's keyframe cadence)")
+    ap.add_argument("--device-keyframes", type=int, default=-1, help="1: the keyframe bookkeeping on the device tables, graph cut on the device (the bench line's path); -1: the host layer's defaults")
     args = ap.parse_args()
     import torch
     from rgbd_visualodometry_amd import capi, system, evaluate as ev
@@ -22,13 +24,14 @@ def main():
     syn = capi.Synth()
     data = []
     for s in range(S):
-        bgr, depth, Twc, ts = syn.render(syn.params(seed=s), 0, total, threads=min(32, os.cpu_count() or 8))
+        bgr, depth, Twc, ts = syn.render(syn.params(seed=s, speed=args.speed) if args.speed > 0 else syn.params(seed=s), 0, total, threads=min(32, os.cpu_count() or 8))
         db = torch.from_numpy(bgr).cuda(); dd = torch.from_numpy(depth.view(np.int16)).cuda()
         data.append((db, dd, Twc, ts))
     torch.cuda.synchronize()
     fb, fd = W * H * 3, W * H * 2
     systems = [system.VoSystem(system.HOST_LIB, width=W, height=H, number_of_features=args.features, max_frames_in_flight=32,
-                               backend_lag_frames=args.ba_lag, track_batch=8, map_capacity=1 << 18) for _ in range(S)]
+                               backend_lag_frames=args.ba_lag, track_batch=8, map_capacity=1 << 18,
+                               **({} if args.device_keyframes < 0 else dict(ba_device_graph=1, map_descriptors_on_device=1, device_keyframes=args.device_keyframes, enable_local_optimization=1, ransac_iterations=100))) for _ in range(S)]
     est = [dict() for _ in range(S)]
 
     def drive(s, i0, i1):
