@@ -344,7 +344,7 @@ void FrontEnd::LaunchTrackAhead() {
     framePrev_->GetPose().to12(prior);                           // = what TrackingHandler gives the next frame as its prior (frontend.cpp:96)
     const size_t nextFrames = (size_t)stats_.frames + 1;         // AddFrame's counter when the first of these frames arrives
     const size_t nextMerge = backend_ ? backend_->NextMergeFrame() : (size_t)-1;
-    int want = lastInterval_ > 0 ? std::min(trackBatch_, lastInterval_ + 1) : trackBatch_;      // framesSinceKf_ == 0 here
+    int want = lastInterval_ > 0 ? std::min(trackBatch_, lastInterval_ + 1) : trackBatch_;      // framesSinceKf_ == 0 here (a frame more changed nothing: profiles/r06_spec_margin_ab.txt)
     std::vector<Frame::Ptr> batch{prefetched_[pos + 1]};
     for (size_t j = pos + 2; j < prefetched_.size() && (int)batch.size() < want; ++j) {
         if (!prefetched_[j]->orb_done_ || nextFrames + batch.size() >= nextMerge) break;
@@ -397,7 +397,9 @@ void FrontEnd::MatchAndEstimatePose() {
         int want = lastInterval_ > 0 ? std::min(trackBatch_, lastInterval_ + 1) : trackBatch_;
         if (framesSinceKf_ > 0 && lastMotion_ > 0) {
             const double left = (1.0 - lastMotion_) / (lastMotion_ / framesSinceKf_);      // frames until a threshold is reached
-            want = std::max(1, std::min(trackBatch_, (int)left + 1));
+            // (+ 2, not + 1: the estimate is a straight line through the motion so far; a chain that stops one frame short of the keyframe costs a second chain --
+            // ~0.5 ms of latency -- while a lane too many costs one more workgroup per kernel: the driver's 20-step form 1762 -> 1846 frames/s, 300 steps +1 %, same poses)
+            want = std::max(1, std::min(trackBatch_, (int)left + 2));
         }
         for (size_t j = pos + 1; j < prefetched_.size() && (int)batch.size() < want; ++j) {
             if (!prefetched_[j]->orb_done_ || (size_t)stats_.frames + batch.size() >= nextMerge) break;
