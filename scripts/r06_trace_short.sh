@@ -7,4 +7,4 @@ rocprofv3 --kernel-trace --output-format csv -d $O/tr -- python3 $R/bench.py --s
 cd $R
 python scripts/trace_short_form.py $O/tr > gpurun_out/r06_short_timeline.txt 2>&1
 rm -rf $O/tr
-tail -c 300 $O/bench_traced.json; tail -8 gpurun_out/r06_short_timeline.txt
+tail -c 300 $O/bench_traced.json; head -24 gpurun_out/r06_short_timeline.txt
